@@ -1,0 +1,21 @@
+"""Loader for the package directory `ais-catcher_amd/` (hyphenated, so not importable by name).
+
+Registers it as the module `ais_catcher_amd`; `import _pkg; pkg = _pkg.load()`.
+"""
+import importlib.util
+import os
+import sys
+
+_NAME = "ais_catcher_amd"
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ais-catcher_amd")
+
+
+def load():
+    if _NAME in sys.modules:
+        return sys.modules[_NAME]
+    spec = importlib.util.spec_from_file_location(
+        _NAME, os.path.join(_DIR, "__init__.py"), submodule_search_locations=[_DIR])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[_NAME] = mod
+    spec.loader.exec_module(mod)
+    return mod

@@ -1,0 +1,50 @@
+/*
+ * oracle/ais_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C, sequential, float32 restatement of the reference hot path
+ * (AIS::ModelDefault / ModelChallenger of jvde-github/AIS-catcher v0.70): the checker the HIP
+ * path is compared against.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this; the product (ais-catcher_amd/) never does.
+ *
+ * Parity status: PINNED -- every stage is checked bit-for-bit against the compiled reference
+ * itself (oracle/_ref/libaisref_strict.so, built from /root/reference by oracle/Makefile) in
+ * tests/test_oracle_vs_ref.py, and against the committed golden fixtures in tests/golden/
+ * (generated from that same compiled reference by tests/golden/make_golden.py).  The reference
+ * ships no DSP golden vectors of its own.
+ */
+#ifndef AIS_ORACLE_H
+#define AIS_ORACLE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ao_chain ao_chain;
+
+/* model: 2 = ModelDefault, 4 = ModelChallenger.  fmt: 0 = CU8, 1 = CF32.  taps: record taps. */
+ao_chain* ao_create(int model, int sample_rate, int fmt, int taps);
+void ao_destroy(ao_chain*);
+/* one call == one reference Receive() block (call boundaries are part of the numerical contract:
+ * Rotate renormalises once per call, Source/DSP/DSP.cpp:315) */
+int ao_feed(ao_chain*, const void* data, int nbytes);
+int ao_msg_count(ao_chain*);
+int ao_nmea(ao_chain*, char* dst, int cap);
+int ao_msg_meta(ao_chain*, float* level, float* ppm, int cap);
+/* taps: 0/1 = 48 kHz front-end output A/B, 2/3 = CGF out, 4/5 = FIR-17 out (complex, interleaved) */
+long long ao_tap(ao_chain*, int which, float* dst, long long cap);
+long long ao_tap_ppm(ao_chain*, int which, float* dst, long long cap);
+long long ao_bits(ao_chain*, int ch, int j, int fm, float* bits, float* lvl, long long* idx, long long cap);
+void ao_reset_seq(void);
+
+/* stand-alone stage functions (used by unit tests and to check individual HIP kernels) */
+void ao_cic5_decimate(const float* x, int n, float* state10, float* y);          /* n even, y: n/2 */
+void ao_cic5_filter(const float* x, int n, float* state10, float* y);
+void ao_fdc(const float* x, int n, float alpha, float* state4, float* y);
+void ao_rotate(const float* x, int n, float* rot2, const float* mult2, float* up, float* down);
+void ao_rotate_mult(float* mult2);
+void ao_fir_complex(const float* x, int n, const float* taps, int nt, float* hist, float* y);
+float ao_hypotf(float a, float b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

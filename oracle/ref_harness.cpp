@@ -1,0 +1,212 @@
+/*
+ * oracle/ref_harness.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * A thin C-ABI shim around the *unmodified* reference sources, compiled where they
+ * lie under /root/reference by oracle/Makefile into oracle/_ref/libaisref_{strict,fast}.so.
+ * It instantiates the reference's own AIS::ModelDefault / AIS::ModelChallenger
+ * (Source/DSP/Model.cpp:520-577, :601-678) on a stub Device::Device (Device.h:58-77),
+ * pushes fixed-size RAW blocks through device.out.Send() exactly like
+ * Device/FileRAW.cpp:135 does, and records
+ *   - the NMEA sentences per channel (Marine/Message.cpp:569-631),
+ *   - float taps after every stage of the hot path (recorder sinks Connect()ed to the
+ *     reference's own Connection<> objects; no reference arithmetic is re-implemented here).
+ *
+ * This TU is compiled with -fno-access-control so the recorders can reach the private
+ * block members of ModelFrontend/ModelDefault (Model.h:138-213).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load the result.
+ */
+#include <atomic>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <chrono>
+
+#include "Model.h"
+#include "Device.h"
+
+// normally provided by Application/Main.cpp:38-49 (which we do not link)
+std::atomic<bool> stop;
+std::atomic<bool> stop_process;
+void StopRequest() { stop = true; }
+
+namespace {
+
+template <typename T>
+struct Rec : public StreamIn<T> {
+	std::vector<T> buf;
+	std::vector<float> ppm;   // tag.ppm seen at each call
+	bool on = false;
+	void Receive(const T* d, int len, TAG& tag) {
+		if (!on) return;
+		buf.insert(buf.end(), d, d + len);
+		ppm.push_back(tag.ppm);
+	}
+};
+
+struct BitRec : public StreamIn<FLOAT32> {
+	std::vector<float> bits;
+	std::vector<float> lvl;
+	std::vector<long long> idx;
+	bool on = false;
+	void Receive(const FLOAT32* d, int len, TAG& tag) {
+		if (!on) return;
+		for (int i = 0; i < len; i++) {
+			bits.push_back(d[i]);
+			lvl.push_back(tag.sample_lvl);
+			idx.push_back(tag.sample_idx);
+		}
+	}
+};
+
+struct MsgSink : public StreamIn<AIS::Message> {
+	std::string text;       // "<nmea>\n" per sentence, in emission order
+	std::vector<float> level, ppm;
+	int count = 0;
+	void Receive(const AIS::Message* m, int len, TAG& tag) {
+		for (int i = 0; i < len; i++) {
+			for (const auto& s : m[i].sentences()) { text += s; text += '\n'; }
+			level.push_back(tag.level);
+			ppm.push_back(tag.ppm);
+			count++;
+		}
+	}
+};
+
+struct Harness {
+	Device::Device dev;
+	AIS::ModelDefault* md = nullptr;
+	AIS::ModelChallenger* mc = nullptr;
+	AIS::Model* model = nullptr;
+	TAG tag;
+	Format fmt;
+	MsgSink sink;
+	// taps: 0/1 = 48k front-end output A/B (FCIC5_a/b.out), 2/3 = CGF out, 4/5 = FIR-17 out
+	Rec<CFLOAT32> tap[6];
+	BitRec bits[2][5];   // after PhaseSearchEMA, per channel/phase
+	BitRec fmbits[2][5]; // challenger FM branch (input of DEC_af/bf)
+	double seconds = 0;
+
+	Harness(Format f, int rate) : dev(f, rate, Type::RAWFILE, "stub"), fmt(f) {}
+};
+
+} // namespace
+
+extern "C" {
+
+// kind: 2 = ModelDefault, 4 = ModelChallenger.  fmt: 0 = CU8, 1 = CF32.  taps: record float taps
+void* ref_create(int kind, int sample_rate, int fmt, int taps) {
+	try {
+		Format f = fmt == 0 ? Format::CU8 : Format::CF32;
+		Harness* h = new Harness(f, sample_rate);
+		if (kind == 4) { h->mc = new AIS::ModelChallenger(); h->model = h->mc; }
+		else { h->md = new AIS::ModelDefault(); h->model = h->md; }
+		h->model->buildModel('A', 'B', sample_rate, false, &h->dev);
+		h->model->Output() >> h->sink;
+		h->dev.setTag(h->tag);
+		if (taps) {
+			AIS::ModelFrontend* fe = static_cast<AIS::ModelFrontend*>(h->model);
+			for (auto& t : h->tap) t.on = true;
+			*fe->C_a >> h->tap[0];
+			*fe->C_b >> h->tap[1];
+			if (h->md) {
+				h->md->CGF_a.out >> h->tap[2]; h->md->CGF_b.out >> h->tap[3];
+				h->md->FC_a.out >> h->tap[4];  h->md->FC_b.out >> h->tap[5];
+				for (int j = 0; j < 5; j++) {
+					h->bits[0][j].on = h->bits[1][j].on = true;
+					h->md->CD_EMA_a[j].out >> h->bits[0][j];
+					h->md->CD_EMA_b[j].out >> h->bits[1][j];
+				}
+			} else {
+				h->mc->CGF_a.out >> h->tap[2]; h->mc->CGF_b.out >> h->tap[3];
+				h->mc->FC_a.out >> h->tap[4];  h->mc->FC_b.out >> h->tap[5];
+				for (int j = 0; j < 5; j++) {
+					h->bits[0][j].on = h->bits[1][j].on = true;
+					h->fmbits[0][j].on = h->fmbits[1][j].on = true;
+					h->mc->CD_EMA_a[j].out >> h->bits[0][j];
+					h->mc->CD_EMA_b[j].out >> h->bits[1][j];
+					h->mc->S_af.out[j] >> h->fmbits[0][j];
+					h->mc->S_bf.out[j] >> h->fmbits[1][j];
+				}
+			}
+		}
+		return h;
+	} catch (const std::exception& e) {
+		fprintf(stderr, "ref_create: %s\n", e.what());
+		return nullptr;
+	}
+}
+
+// one Receive() call == one device block (Device/FileRAW.cpp:129-136)
+int ref_feed(void* hv, const void* data, int nbytes) {
+	Harness* h = (Harness*)hv;
+	RAW r = { h->fmt, (void*)data, nbytes };
+	auto t0 = std::chrono::high_resolution_clock::now();
+	h->dev.out.Send(&r, 1, h->tag);
+	auto t1 = std::chrono::high_resolution_clock::now();
+	h->seconds += std::chrono::duration<double>(t1 - t0).count();
+	return 0;
+}
+
+double ref_seconds(void* hv) { return ((Harness*)hv)->seconds; }
+int ref_msg_count(void* hv) { return ((Harness*)hv)->sink.count; }
+
+// copies the accumulated NMEA text; returns the required size
+int ref_nmea(void* hv, char* dst, int cap) {
+	Harness* h = (Harness*)hv;
+	int n = (int)h->sink.text.size();
+	if (dst && cap > 0) {
+		int c = n < cap - 1 ? n : cap - 1;
+		memcpy(dst, h->sink.text.data(), c);
+		dst[c] = 0;
+	}
+	return n + 1;
+}
+
+int ref_msg_meta(void* hv, float* level, float* ppm, int cap) {
+	Harness* h = (Harness*)hv;
+	int n = (int)h->sink.level.size();
+	for (int i = 0; i < n && i < cap; i++) { level[i] = h->sink.level[i]; ppm[i] = h->sink.ppm[i]; }
+	return n;
+}
+
+// complex taps: returns number of complex samples, copies up to cap
+long long ref_tap(void* hv, int which, float* dst, long long cap) {
+	Harness* h = (Harness*)hv;
+	auto& b = h->tap[which].buf;
+	long long n = (long long)b.size();
+	if (dst) memcpy(dst, b.data(), sizeof(CFLOAT32) * (size_t)(n < cap ? n : cap));
+	return n;
+}
+
+// tag.ppm observed at each Send() into tap `which` (one per 512-window for taps 2..5)
+long long ref_tap_ppm(void* hv, int which, float* dst, long long cap) {
+	Harness* h = (Harness*)hv;
+	auto& b = h->tap[which].ppm;
+	long long n = (long long)b.size();
+	if (dst) memcpy(dst, b.data(), sizeof(float) * (size_t)(n < cap ? n : cap));
+	return n;
+}
+
+// hard bits of channel ch (0/1), phase j (0..4); fm=1 selects the Challenger FM branch
+long long ref_bits(void* hv, int ch, int j, int fm, float* bits, float* lvl, long long* idx, long long cap) {
+	Harness* h = (Harness*)hv;
+	BitRec& r = fm ? h->fmbits[ch][j] : h->bits[ch][j];
+	long long n = (long long)r.bits.size();
+	long long c = n < cap ? n : cap;
+	if (bits) memcpy(bits, r.bits.data(), sizeof(float) * (size_t)c);
+	if (lvl) memcpy(lvl, r.lvl.data(), sizeof(float) * (size_t)c);
+	if (idx) memcpy(idx, r.idx.data(), sizeof(long long) * (size_t)c);
+	return n;
+}
+
+// Message::ID is the process-global multi-sentence sequence counter (Marine/Message.cpp:28-39)
+void ref_reset_seq(void) { AIS::Message::ID.store(0); }
+
+void ref_destroy(void* hv) {
+	Harness* h = (Harness*)hv;
+	delete h->md; delete h->mc;
+	delete h;
+}
+
+} // extern "C"

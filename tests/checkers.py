@@ -1,0 +1,144 @@
+"""ctypes front ends for the two CHECKERS (test infrastructure, never the product):
+
+  Oracle  -- oracle/libaisoracle.so, our plain-C restatement (prefix ao_)
+  Ref     -- oracle/_ref/libaisref_{strict,fast}.so, the reference's own sources compiled in
+             place with a C shim (prefix ref_); built only where /root/reference exists, the
+             prebuilt .so travels to the GPU box.
+
+Both expose the same surface, so every test can run against either.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libaisoracle.so"])
+
+
+def build_ref():
+    if os.path.isdir("/root/reference/Source"):
+        subprocess.check_call(["make", "-s", "-j8", "-C", ORACLE_DIR, "ref"])
+
+
+def have_ref(kind="strict"):
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libaisref_%s.so" % kind))
+
+
+class _Chain:
+    """One receiver instance behind either checker library."""
+
+    def __init__(self, lib, prefix, model, rate, fmt, taps):
+        self.lib, self.p = lib, prefix
+        f = lambda name: getattr(lib, prefix + name)
+        f("create").restype = ctypes.c_void_p
+        f("create").argtypes = [ctypes.c_int] * 4
+        f("feed").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        f("nmea").argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+        f("msg_count").argtypes = [ctypes.c_void_p]
+        f("msg_meta").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        f("tap").restype = ctypes.c_longlong
+        f("tap").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong]
+        f("tap_ppm").restype = ctypes.c_longlong
+        f("tap_ppm").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong]
+        f("bits").restype = ctypes.c_longlong
+        f("bits").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong]
+        f("destroy").argtypes = [ctypes.c_void_p]
+        self._f = f
+        self.fmt = fmt
+        self.h = f("create")(model, rate, 0 if fmt == "cu8" else 1, 1 if taps else 0)
+        if not self.h:
+            raise RuntimeError("checker create failed")
+
+    def feed(self, block):
+        block = np.ascontiguousarray(block)
+        self._f("feed")(self.h, block.ctypes.data, block.nbytes)
+
+    def feed_blocks(self, x, block_len):
+        """Feed whole blocks of block_len IQ samples (the tail that does not fill a block is dropped)."""
+        per = 2 if self.fmt == "cu8" else 1
+        n = (len(x) // per) // block_len
+        for b in range(n):
+            self.feed(x[b * block_len * per:(b + 1) * block_len * per])
+        return n
+
+    def nmea(self):
+        n = self._f("nmea")(self.h, None, 0)
+        buf = ctypes.create_string_buffer(n)
+        self._f("nmea")(self.h, buf, n)
+        return buf.value.decode().splitlines()
+
+    def msg_meta(self):
+        n = self._f("msg_count")(self.h)
+        lvl = np.zeros(max(n, 1), np.float32)
+        ppm = np.zeros(max(n, 1), np.float32)
+        self._f("msg_meta")(self.h, lvl.ctypes.data, ppm.ctypes.data, n)
+        return lvl[:n], ppm[:n]
+
+    def tap(self, which):
+        n = self._f("tap")(self.h, which, None, 0)
+        out = np.zeros(n, np.complex64)
+        self._f("tap")(self.h, which, out.ctypes.data, n)
+        return out
+
+    def tap_ppm(self, which):
+        n = self._f("tap_ppm")(self.h, which, None, 0)
+        out = np.zeros(n, np.float32)
+        self._f("tap_ppm")(self.h, which, out.ctypes.data, n)
+        return out
+
+    def bits(self, ch, j, fm=0):
+        n = self._f("bits")(self.h, ch, j, fm, None, None, None, 0)
+        b = np.zeros(n, np.float32)
+        l = np.zeros(n, np.float32)
+        i = np.zeros(n, np.int64)
+        self._f("bits")(self.h, ch, j, fm, b.ctypes.data, l.ctypes.data, i.ctypes.data, n)
+        return b, l, i
+
+    def close(self):
+        if self.h:
+            self._f("destroy")(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_libs = {}
+
+
+def _lib(path):
+    if path not in _libs:
+        _libs[path] = ctypes.CDLL(path)
+    return _libs[path]
+
+
+def Oracle(model=2, rate=1536000, fmt="cf32", taps=False):
+    path = os.path.join(ORACLE_DIR, "libaisoracle.so")
+    if not os.path.exists(path):
+        build_oracle()
+    lib = _lib(path)
+    lib.ao_reset_seq()
+    return _Chain(lib, "ao_", model, rate, fmt, taps)
+
+
+def Ref(model=2, rate=1536000, fmt="cf32", taps=False, kind="strict"):
+    lib = _lib(os.path.join(ORACLE_DIR, "_ref", "libaisref_%s.so" % kind))
+    lib.ref_reset_seq()
+    return _Chain(lib, "ref_", model, rate, fmt, taps)
+
+
+def oracle_lib():
+    path = os.path.join(ORACLE_DIR, "libaisoracle.so")
+    if not os.path.exists(path):
+        build_oracle()
+    return _lib(path)
