@@ -1,0 +1,62 @@
+// ais-catcher_amd/csrc/kernels.h -- parameter blocks and launchers shared by kernels.hip and aisgpu.cpp
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aisk {
+
+constexpr int CGF_HIST = 32;   // 48 kHz samples of CGF output carried in front of each block (FIR-17 needs 16 + 4)
+constexpr int ROT_HIST = 256;  // 96 kHz rotator phasors carried in front of each block's table (one tile)
+constexpr int FZ_MIN = -205, FZ_COUNT = 414; // CGF peak index range
+
+struct K1Params {
+	const void* in;          // [n_rx][in_stride] input samples (float2 or uchar2)
+	long long in_stride;     // samples
+	const void* hist;        // [n_rx][tile] last tile of the previous block
+	const float2* rot;       // [ROT_HIST + block_len >> K] Rotate phasor per 96 kHz sample (host generated)
+	float2* c48;             // [n_rx][2][c48_stride] 48 kHz front-end output (FCIC5_a/b.out)
+	long long c48_stride;
+	int tiles_per_block, tiles_per_span;
+	float alpha, beta;       // FilterComplex3Tap
+	int has_fdc;
+};
+
+struct K2Params {
+	const float2* c48; long long c48_stride;
+	float2* cgf; long long cgf_stride;   // [n_chan][CGF_HIST + L]
+	const float2* omega;      // [512] FFT twiddles
+	const float2* step_table; // [FZ_COUNT] rot_step per fz
+	const float* ppm_table;   // [FZ_COUNT]
+	int* fz;                  // [n_chan][n_windows]
+	float* ppm;               // [n_chan][n_windows]
+	float2* rot_state;        // [n_chan]
+	int n_windows, wide;
+};
+
+struct K3Params {
+	const float2* cgf; long long cgf_stride;
+	float2* sym; long long sym_stride;   // [n_chan][5][sym_stride]
+	float* lvl;                           // [n_chan][sym_stride]
+	float2* fir_tap; long long fir_tap_stride; // optional [n_chan][4 + L]
+	float taps[17];
+	long long first_group, first_sample48;
+	int n_groups;
+};
+
+struct EmaState { float ma[16]; unsigned bits[16]; int max_idx, rot; int pad[2]; };
+
+struct K4Params {
+	const float2* sym; long long sym_stride; // chain c row = c * sym_stride
+	uint32_t* bits; long long bits_stride;   // words per chain
+	EmaState* state;
+	int n_chains, n_groups;
+};
+
+hipError_t launch_k1(const K1Params& p, int K, bool cu8, int spans, int n_rx, hipStream_t s);
+hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long block_bytes, void* hist, int tail_bytes,
+                          int n_rx, hipStream_t s);
+hipError_t launch_k2(const K2Params& p, int n_chan, hipStream_t s);
+hipError_t launch_k3(const K3Params& p, int n_chan, hipStream_t s);
+hipError_t launch_k4(const K4Params& p, hipStream_t s);
+
+} // namespace aisk

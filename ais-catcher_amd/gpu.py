@@ -1,0 +1,178 @@
+"""ctypes binding of libaisgpu.so (include/aisgpu.h) -- the C-ABI boundary of the MI355X chain.
+
+No torch types cross this boundary: device buffers are passed as raw pointers (e.g. tensor.data_ptr()).
+The library is built in-tree by `make -C ais-catcher_amd/csrc` (see __graft_entry__.build()).
+There is NO CPU fallback: if the library or a GPU is missing, construction raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaisgpu.so")
+
+FMT_CU8, FMT_CF32 = 0, 1
+MODEL_DEFAULT = 2
+FLAG_TAPS = 1
+
+EXPORTS = (
+    "aisgpu_default_cfg", "aisgpu_create", "aisgpu_destroy", "aisgpu_submit", "aisgpu_submit_device",
+    "aisgpu_run", "aisgpu_sync_outputs", "aisgpu_sync", "aisgpu_fetch", "aisgpu_tap", "aisgpu_stream",
+    "aisgpu_frontend_ms", "aisgpu_timing", "aisgpu_strerror", "aisgpu_last_error", "aisgpu_device_count",
+)
+
+
+class Cfg(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "sample_rate", "n_receivers", "block_len", "model", "input_format", "afc_wide", "droop",
+        "device_id", "flags", "tiles_per_span")]
+
+
+class Out(ctypes.Structure):
+    _fields_ = [
+        ("n_groups", ctypes.c_int),
+        ("first_group", ctypes.c_longlong),
+        ("bits", ctypes.POINTER(ctypes.c_uint32) * 5),
+        ("lvl", ctypes.POINTER(ctypes.c_float)),
+        ("n_windows", ctypes.c_int),
+        ("ppm", ctypes.POINTER(ctypes.c_float)),
+        ("group_window", ctypes.POINTER(ctypes.c_int)),
+        ("first_sample48", ctypes.c_longlong),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libaisgpu.so and declare the prototypes of every symbol include/aisgpu.h exports."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libaisgpu.so is not built (%s); run __graft_entry__.build()" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci, cll = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
+    lib.aisgpu_default_cfg.argtypes = [ctypes.POINTER(Cfg)]
+    lib.aisgpu_default_cfg.restype = None
+    lib.aisgpu_create.argtypes = [ctypes.POINTER(Cfg), ctypes.POINTER(vp)]
+    lib.aisgpu_destroy.argtypes = [vp]
+    lib.aisgpu_destroy.restype = None
+    lib.aisgpu_submit.argtypes = [vp, ci, vp, ci]
+    lib.aisgpu_submit_device.argtypes = [vp, vp, cll]
+    lib.aisgpu_run.argtypes = [vp]
+    lib.aisgpu_sync_outputs.argtypes = [vp]
+    lib.aisgpu_sync.argtypes = [vp]
+    lib.aisgpu_fetch.argtypes = [vp, ci, ci, ctypes.POINTER(Out)]
+    lib.aisgpu_tap.argtypes = [vp, ci, ci, vp, cll]
+    lib.aisgpu_tap.restype = cll
+    lib.aisgpu_stream.argtypes = [vp]
+    lib.aisgpu_stream.restype = vp
+    lib.aisgpu_frontend_ms.argtypes = [vp, ctypes.POINTER(ci)]
+    lib.aisgpu_frontend_ms.restype = ctypes.c_float
+    lib.aisgpu_timing.argtypes = [vp, ci]
+    lib.aisgpu_timing.restype = None
+    lib.aisgpu_strerror.argtypes = [ci]
+    lib.aisgpu_strerror.restype = ctypes.c_char_p
+    lib.aisgpu_last_error.argtypes = [vp]
+    lib.aisgpu_last_error.restype = ctypes.c_char_p
+    lib.aisgpu_device_count.restype = ci
+    _lib = lib
+    return lib
+
+
+class AisGpuError(RuntimeError):
+    pass
+
+
+class AisGpu:
+    """One context = n_receivers batched dual-channel receivers on one GPU."""
+
+    def __init__(self, sample_rate=1536000, n_receivers=1, block_len=786432, input_format=FMT_CF32,
+                 afc_wide=True, droop=True, device_id=0, taps=False, tiles_per_span=0):
+        self.lib = load()
+        cfg = Cfg()
+        self.lib.aisgpu_default_cfg(ctypes.byref(cfg))
+        cfg.sample_rate, cfg.n_receivers, cfg.block_len = sample_rate, n_receivers, block_len
+        cfg.input_format, cfg.afc_wide, cfg.droop = input_format, int(afc_wide), int(droop)
+        cfg.device_id, cfg.flags, cfg.tiles_per_span = device_id, (FLAG_TAPS if taps else 0), tiles_per_span
+        self.cfg = cfg
+        self.h = ctypes.c_void_p()
+        rc = self.lib.aisgpu_create(ctypes.byref(cfg), ctypes.byref(self.h))
+        if rc != 0:
+            msg = self.lib.aisgpu_strerror(rc).decode()
+            if self.h:
+                msg += ": " + self.lib.aisgpu_last_error(self.h).decode()
+                self.lib.aisgpu_destroy(self.h)
+                self.h = ctypes.c_void_p()
+            raise AisGpuError("aisgpu_create failed (%d): %s" % (rc, msg))
+        self.n_receivers, self.block_len = n_receivers, block_len
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise AisGpuError("%s failed (%d): %s: %s" % (
+                what, rc, self.lib.aisgpu_strerror(rc).decode(), self.lib.aisgpu_last_error(self.h).decode()))
+
+    def submit(self, rx, block):
+        block = np.ascontiguousarray(block)
+        per = 2 if self.cfg.input_format == FMT_CU8 else 1
+        self._chk(self.lib.aisgpu_submit(self.h, rx, block.ctypes.data, block.size // per), "aisgpu_submit")
+
+    def submit_device(self, ptr, rx_stride_samples):
+        self._chk(self.lib.aisgpu_submit_device(self.h, ctypes.c_void_p(ptr), rx_stride_samples), "aisgpu_submit_device")
+
+    def run(self):
+        self._chk(self.lib.aisgpu_run(self.h), "aisgpu_run")
+
+    def sync(self):
+        self._chk(self.lib.aisgpu_sync(self.h), "aisgpu_sync")
+
+    def sync_outputs(self):
+        self._chk(self.lib.aisgpu_sync_outputs(self.h), "aisgpu_sync_outputs")
+
+    def fetch(self, rx, ch):
+        """-> dict(bits[5][n_groups] of +-1.0f, lvl[n_groups], ppm[n_windows], first_group, first_sample48)."""
+        o = Out()
+        self._chk(self.lib.aisgpu_fetch(self.h, rx, ch, ctypes.byref(o)), "aisgpu_fetch")
+        n = o.n_groups
+        words = (n + 31) // 32
+        bits = np.zeros((5, n), np.float32)
+        for j in range(5):
+            w = np.ctypeslib.as_array(o.bits[j], shape=(max(words, 1),))[:words]
+            b = ((w[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).reshape(-1)[:n]
+            bits[j] = np.where(b != 0, 1.0, -1.0)
+        lvl = np.ctypeslib.as_array(o.lvl, shape=(max(n, 1),))[:n].copy()
+        ppm = np.ctypeslib.as_array(o.ppm, shape=(max(o.n_windows, 1),))[:o.n_windows].copy()
+        return dict(bits=bits, lvl=lvl, ppm=ppm, first_group=o.first_group, first_sample48=o.first_sample48,
+                    n_groups=n, n_windows=o.n_windows)
+
+    def tap(self, which, rx=0):
+        n = self.lib.aisgpu_tap(self.h, which, rx, None, 0)
+        if n < 0:
+            raise AisGpuError("aisgpu_tap failed (%d)" % n)
+        out = np.zeros(n, np.complex64)
+        self.lib.aisgpu_tap(self.h, which, rx, out.ctypes.data, n)
+        return out
+
+    def timing(self, enable=True):
+        self.lib.aisgpu_timing(self.h, int(enable))
+
+    def frontend_ms(self):
+        n = ctypes.c_int()
+        ms = self.lib.aisgpu_frontend_ms(self.h, ctypes.byref(n))
+        return float(ms), n.value
+
+    def stream(self):
+        return self.lib.aisgpu_stream(self.h)
+
+    def close(self):
+        if self.h:
+            self.lib.aisgpu_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- IQ Msamples/s through the ModelDefault demodulation chain on MI355X.
+
+Workload (BASELINE.json configs[3] / configs[4]): 256 batched dual-channel receivers per GPU,
+1536 kSPS CFLOAT32, one reference Receive() block (786,432 IQ samples) per receiver per step,
+synthetic GMSK bursts + AWGN, inputs resident in HBM before the timed region.  One process per GPU;
+receivers are independent, so N GPUs run N x 256 receivers with no collective (weak scaling).
+
+Prints ONE JSON line (rank 0): metric/value/unit..., plus
+  roofline     -- front-end kernel (the HBM-bound kernel): algorithmic bytes per launch
+                  (8.30 B/IQ sample) / its average launch time measured with HIP events
+                  on the library's own stream
+  cpu_baseline -- the reference's own sources compiled with its shipped flags (oracle/_ref), timed on
+                  this host's cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+ALGO_BYTES_PER_SAMPLE = 8.30   # 8 B read + 0.25 B hard bits + 0.05 B level
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+RATE = 1536000
+BLOCK = 786432
+
+
+def make_resident_input(torch, n_rx, n_blocks, seed, unique=8):
+    """[n_blocks][n_rx][BLOCK] complex64 on the GPU: `unique` CPU-synthesised burst streams, shared by
+    receiver groups with a per-receiver slot shift, plus independent AWGN per receiver (torch RNG)."""
+    import _pkg
+    _pkg.load()
+    from ais_catcher_amd import synth
+    slot = 40960
+    base = []
+    for u in range(unique):
+        x = synth.receiver_stream(BLOCK * n_blocks, receiver_id=seed * 1000 + u, noise_sigma=0.0)
+        base.append(torch.from_numpy(x.view(np.float32).reshape(n_blocks, BLOCK, 2)))
+    base = torch.stack(base).cuda()                      # [unique][n_blocks][BLOCK][2]
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(12345 + seed)
+    out = torch.empty((n_blocks, n_rx, BLOCK, 2), dtype=torch.float32, device="cuda")
+    for r in range(n_rx):
+        b = torch.roll(base[r % unique], shifts=(r // unique) * slot, dims=1)
+        out[:, r] = b
+    out.add_(torch.randn(out.shape, generator=gen, device="cuda", dtype=torch.float32), alpha=0.01)
+    torch.cuda.synchronize()
+    return out
+
+
+def cpu_baseline(seconds=12.0):
+    """Reference chain (shipped flags -O3 -ffast-math) on the host cores, one ModelDefault per thread."""
+    import checkers
+    import _pkg
+    _pkg.load()
+    from ais_catcher_amd import synth
+    if checkers.have_ref("fast"):
+        kind, mk = "reference", (lambda: checkers.Ref(model=2, rate=RATE, fmt="cf32", kind="fast"))
+    else:
+        kind, mk = "port", (lambda: checkers.Oracle(model=2, rate=RATE, fmt="cf32"))
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    nblk = 4
+    x = synth.receiver_stream(BLOCK * nblk, receiver_id=4242)
+    blocks = [np.ascontiguousarray(x[i * BLOCK:(i + 1) * BLOCK]) for i in range(nblk)]
+    chains = [mk() for _ in range(cores)]
+    counts = [0] * cores
+    t_end = time.perf_counter() + seconds
+
+    def work(i):
+        c = chains[i]
+        k = 0
+        while time.perf_counter() < t_end:
+            c.feed(blocks[k % nblk])
+            k += 1
+        counts[i] = k
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    total = sum(counts) * BLOCK
+    return {"value": round(total / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": kind,
+            "sample": "%d blocks of %d CF32 IQ samples over %d threads in %.1f s (4 distinct blocks cycled, "
+                      "one ModelDefault instance per thread, in-memory)" % (sum(counts), BLOCK, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--receivers", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import _pkg
+    _pkg.load()
+    from ais_catcher_amd import gpu
+
+    R = args.receivers
+    nb = 2  # distinct resident blocks cycled (2 x 1.6 GB)
+    data = make_resident_input(torch, R, nb, seed=rank)
+    g = gpu.AisGpu(sample_rate=RATE, n_receivers=R, block_len=BLOCK, device_id=local)
+
+    def step(i):
+        g.submit_device(data[i % nb].data_ptr(), BLOCK)
+        g.run()
+
+    for i in range(args.warmup):
+        step(i)
+    g.sync()
+    g.timing(True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    g.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    k1_ms, k1_n = g.frontend_ms()
+    g.close()
+    samples_per_step = R * BLOCK
+    value = samples_per_step * world * args.steps / dt / 1e6
+    achieved = samples_per_step * ALGO_BYTES_PER_SAMPLE / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+    res = {
+        "metric": "IQ Msamples/s (CFLOAT32) through ModelDefault chain", "value": round(value, 1),
+        "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3]: %d batched dual-channel receivers per GPU, 1536 kSPS CF32, "
+                               "%d IQ samples per receiver per step, resident in HBM, chain up to hard bits/levels/ppm"
+                               % (R, BLOCK),
+                   "receivers_per_gpu": R, "block_len": BLOCK, "sample_rate": RATE, "parallelism": "receivers sharded, no collective"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "k1_frontend", "avg_launch_ms": round(k1_ms, 4), "launches": k1_n},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

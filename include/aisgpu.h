@@ -1,0 +1,122 @@
+/*
+ * include/aisgpu.h -- C ABI of libaisgpu.so: the MI355X (gfx950) AIS GMSK demodulation chain.
+ *
+ * This is the drop-in boundary for the hot path behind the reference's AIS::ModelDefault
+ * (jvde-github/AIS-catcher v0.70).  Every entry point is plain C (pointers + sizes, int status,
+ * never throws) so the reference can bind it from its own C++ or any FFI.
+ * File:line citations are relative to the reference's Source/ directory.
+ *
+ * What one context replaces, per receiver (the blocks between Util::ConvertRAW and the
+ * AIS::Decoder objects in DSP/Model.cpp:27-356 + :520-577):
+ *   ConvertRAW (CU8 -> CFLOAT32)          Utilities/StreamHelpers.cpp:51-133, Utilities/Convert.cpp:255-264
+ *   4x Downsample2CIC5 (1536k -> 96k)     DSP/DSP.cpp:93-117
+ *   FilterComplex3Tap (droop comp.)       DSP/DSP.cpp:283-293
+ *   Rotate (+-25 kHz channel split)       DSP/DSP.cpp:296-316
+ *   Downsample2CIC5 + FilterCIC5 (x2)     DSP/DSP.cpp:93-157
+ *   SquareFreqOffsetCorrection (FFT-512)  DSP/DSP.cpp:417-489, DSP/FFT.h:36-131
+ *   FilterComplex (Filters::Coherent)     DSP/DSP.cpp:215-246
+ *   ScatterPLL (/5, signal level)         DSP/DSP.h:76-117
+ *   5x PhaseSearchEMA per channel         DSP/Demod.cpp:39-101
+ * and, optionally on the device as well (AISGPU_FLAG_DECODE), the consumer
+ *   5x AIS::Decoder per channel + NMEA    Marine/AIS.h:82-181, Marine/AIS.cpp:33-142, Marine/Message.cpp:569-631
+ *
+ * A context batches n_receivers independent dual-channel receivers; one aisgpu_run() consumes
+ * exactly one reference Receive() block (block_len IQ samples) of every receiver.  Block
+ * boundaries are part of the numerical contract (Rotate renormalises once per call,
+ * DSP/DSP.cpp:315), so results equal the reference driven with the same block size.
+ */
+#ifndef AISGPU_H
+#define AISGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AISGPU_OK 0
+#define AISGPU_ERR_ARG 1      /* invalid argument / unsupported configuration */
+#define AISGPU_ERR_NODEV 2    /* no usable HIP device */
+#define AISGPU_ERR_HIP 3      /* a HIP runtime call failed (see aisgpu_last_error) */
+#define AISGPU_ERR_STATE 4    /* call sequence error (e.g. fetch before run) */
+#define AISGPU_ERR_OVERFLOW 5 /* an output buffer supplied by the caller is too small */
+
+/* input formats: the RAW formats the reference's file/RTL devices deliver (Library/Common.h:88-99) */
+#define AISGPU_FMT_CU8 0
+#define AISGPU_FMT_CF32 1
+
+/* models (DSP/Model.h:61-72) */
+#define AISGPU_MODEL_DEFAULT 2
+
+#define AISGPU_FLAG_TAPS 1    /* keep intermediate float taps readable via aisgpu_tap() (tests) */
+
+typedef struct aisgpu aisgpu_t;
+
+typedef struct aisgpu_cfg {
+	int sample_rate;   /* 1536000, 768000, 384000, 192000, 3072000 (pure 2^k CIC5 ladders, Model.cpp:157-338) */
+	int n_receivers;   /* independent dual-channel receiver instances batched on this GPU */
+	int block_len;     /* IQ samples per receiver per Receive() block; multiple of 512 * sample_rate/48000 */
+	int model;         /* AISGPU_MODEL_DEFAULT */
+	int input_format;  /* AISGPU_FMT_* */
+	int afc_wide;      /* KEY_SETTING_AFC_WIDE (default on, Model.cpp:536-540) */
+	int droop;         /* KEY_SETTING_DROOP    (default on, Model.cpp:223-229) */
+	int device_id;     /* HIP device ordinal */
+	int flags;         /* AISGPU_FLAG_* */
+	int tiles_per_span;/* front-end time tiling (0 = auto) */
+} aisgpu_cfg;
+
+/* per (receiver, channel) result of one block: what ScatterPLL/PhaseSearchEMA hand to the
+ * five AIS::Decoder objects (DSP/DSP.h:95-117, Demod.cpp:96-99), in host memory owned by the
+ * context and valid until the next aisgpu_run(). */
+typedef struct aisgpu_out {
+	int n_groups;            /* complete 5-sample groups emitted in this block */
+	long long first_group;   /* stream index of the first group; tag.sample_idx of phase j = 5*(first_group+g)+j */
+	const uint32_t* bits[5]; /* phase j: bit g of word g/32 -> PhaseSearchEMA output (+1.0f if set, else -1.0f) */
+	const float* lvl;        /* [n_groups] tag.sample_lvl */
+	int n_windows;           /* CGF windows (512 samples @48k) completed in this block */
+	const float* ppm;        /* [n_windows] tag.ppm */
+	const int* group_window; /* reserved (NULL): window of group g is (5*(first_group+g)+4 - first_sample48)/512 */
+	long long first_sample48;/* stream index (48 kHz) of the first sample of this block */
+} aisgpu_out;
+
+void aisgpu_default_cfg(aisgpu_cfg* cfg);
+int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out);
+void aisgpu_destroy(aisgpu_t* h);
+
+/* Copy one receiver's block from host memory (borrowed for the call only, like the reference's
+ * Receive(const T*, int, TAG&), Library/Stream.h:36-45) into the staging buffer.  n_iq must equal
+ * block_len.  Data is CU8 pairs or CFLOAT32 per cfg.input_format. */
+int aisgpu_submit(aisgpu_t* h, int rx, const void* iq, int n_iq);
+
+/* Zero-copy alternative: the whole batch is already resident in device memory as
+ * [n_receivers][rx_stride_samples] samples of the configured format (rx_stride_samples >= block_len). */
+int aisgpu_submit_device(aisgpu_t* h, const void* iq_dev, long long rx_stride_samples);
+
+/* Enqueue the whole chain for the submitted block on the context's stream (asynchronous). */
+int aisgpu_run(aisgpu_t* h);
+/* Enqueue the device->host copy of the block's outputs and wait for the stream. */
+int aisgpu_sync_outputs(aisgpu_t* h);
+/* Wait for the stream without copying outputs (throughput runs). */
+int aisgpu_sync(aisgpu_t* h);
+int aisgpu_fetch(aisgpu_t* h, int rx, int ch, aisgpu_out* out);
+
+/* Float taps of the last block (tests only; needs AISGPU_FLAG_TAPS):
+ *   which 0/1: 48 kHz front-end output A/B (== FCIC5_a/b.out), 2/3: CGF output, 4/5: FIR-17 output.
+ * Copies up to cap complex samples (interleaved re,im) to dst; returns the number available or <0. */
+long long aisgpu_tap(aisgpu_t* h, int which, int rx, float* dst, long long cap);
+
+/* raw HIP stream / timing hooks for the benchmark */
+void* aisgpu_stream(aisgpu_t* h);
+/* average device time (ms) of the front-end kernel over the launches since the last reset,
+ * measured with HIP events on the context's stream; *launches receives the count */
+float aisgpu_frontend_ms(aisgpu_t* h, int* launches);
+void aisgpu_timing(aisgpu_t* h, int enable);
+
+const char* aisgpu_strerror(int code);
+const char* aisgpu_last_error(aisgpu_t* h);
+int aisgpu_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AISGPU_H */

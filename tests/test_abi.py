@@ -1,0 +1,44 @@
+"""CPU: the C-ABI library loads and exports every symbol include/aisgpu.h declares; no compute calls."""
+import ctypes
+import os
+import re
+
+from ais_catcher_amd import gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "aisgpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(aisgpu_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert _declared() == sorted(gpu.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = gpu.load()
+    for name in _declared():
+        assert hasattr(lib, name), name
+
+
+def test_structs_match_header_layout():
+    assert ctypes.sizeof(gpu.Cfg) == 10 * 4
+    cfg = gpu.Cfg()
+    gpu.load().aisgpu_default_cfg(ctypes.byref(cfg))
+    assert (cfg.sample_rate, cfg.block_len, cfg.model, cfg.input_format) == (1536000, 786432, 2, 1)
+
+
+def test_create_rejects_bad_config_without_gpu_work():
+    lib = gpu.load()
+    cfg = gpu.Cfg()
+    lib.aisgpu_default_cfg(ctypes.byref(cfg))
+    h = ctypes.c_void_p()
+    cfg.sample_rate = 1000000
+    assert lib.aisgpu_create(ctypes.byref(cfg), ctypes.byref(h)) == 1 and not h
+    cfg.sample_rate = 1536000
+    cfg.block_len = 1000
+    assert lib.aisgpu_create(ctypes.byref(cfg), ctypes.byref(h)) == 1 and not h
+    assert lib.aisgpu_strerror(2).decode().startswith("no usable")

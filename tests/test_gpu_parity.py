@@ -1,0 +1,169 @@
+"""GPU (-m gpu): the HIP chain, called through the C ABI (libaisgpu.so), against the oracle and the
+golden fixtures recorded from the compiled reference.  Everything is compared BIT-EXACT: the float
+taps are required to be identical binary32 values (north_star tolerance 1e-5 rel is therefore met
+with margin 0), hard bits / levels / ppm identical.
+"""
+import numpy as np
+import pytest
+
+import checkers
+from ais_catcher_amd import gpu, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _feq(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.float32), b.view(np.float32))
+
+
+def _run_gpu_vs_oracle(streams, rate, fmt, block, nblocks, **kw):
+    """streams: list of per-receiver arrays.  Compares every block's taps and outputs per receiver."""
+    R = len(streams)
+    g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block,
+                   input_format=gpu.FMT_CU8 if fmt == "cu8" else gpu.FMT_CF32, taps=True, **kw)
+    per = 2 if fmt == "cu8" else 1
+    oracles = [checkers.Oracle(model=2, rate=rate, fmt=fmt, taps=True) for _ in range(R)]
+    for o, x in zip(oracles, streams):
+        o.feed_blocks(x, block)
+    otaps = [[o.tap(w) for w in range(6)] for o in oracles]
+    oppm = [[o.tap_ppm(2), o.tap_ppm(3)] for o in oracles]
+    obits = [[[o.bits(ch, j) for j in range(5)] for ch in range(2)] for o in oracles]
+    L = block // (rate // 48000)
+    W = L // 512
+    gdone = [[0, 0] for _ in range(R)]
+    for b in range(nblocks):
+        for r in range(R):
+            g.submit(r, streams[r][b * block * per:(b + 1) * block * per])
+        g.run()
+        g.sync_outputs()
+        for r in range(R):
+            for w in (0, 1, 2, 3):
+                assert _feq(g.tap(w, r), otaps[r][w][b * L:(b + 1) * L]), "block %d rx %d tap %d" % (b, r, w)
+            for ch in range(2):
+                out = g.fetch(r, ch)
+                assert out["first_sample48"] == b * L
+                assert out["first_group"] == gdone[r][ch]
+                n = out["n_groups"]
+                assert n == ((b + 1) * L) // 5 - (b * L) // 5
+                g0 = gdone[r][ch]
+                fir = g.tap(4 + ch, r)
+                assert _feq(fir, otaps[r][4 + ch][5 * g0:5 * (g0 + n)]), "block %d rx %d FIR ch %d" % (b, r, ch)
+                for j in range(5):
+                    ob, ol, oi = obits[r][ch][j]
+                    assert np.array_equal(out["bits"][j], ob[g0:g0 + n]), "bits b%d r%d c%d j%d" % (b, r, ch, j)
+                    assert np.array_equal(oi[g0:g0 + n], 5 * (g0 + np.arange(n)) + j)
+                    assert _feq(out["lvl"], ol[g0:g0 + n]), "lvl b%d r%d c%d" % (b, r, ch)
+                assert _feq(out["ppm"], oppm[r][ch][b * W:(b + 1) * W]), "ppm b%d r%d c%d" % (b, r, ch)
+                gdone[r][ch] += n
+    g.close()
+
+
+def test_golden_cu8(golden):
+    """3 RTL-size CU8 blocks: GPU taps/bits/levels/ppm == recorded outputs of the compiled reference."""
+    cu8, block = golden["cu8"], int(golden["block_len"])
+    L = block // 32
+    g = gpu.AisGpu(n_receivers=1, block_len=block, input_format=gpu.FMT_CU8, taps=True)
+    gd = [0, 0]
+    for b in range(3):
+        g.submit(0, cu8[b * block * 2:(b + 1) * block * 2])
+        g.run()
+        g.sync_outputs()
+        for w in range(4):
+            assert _feq(g.tap(w), golden["tap%d" % w][b * L:(b + 1) * L]), "tap %d block %d" % (w, b)
+        for ch in range(2):
+            out = g.fetch(0, ch)
+            n, g0 = out["n_groups"], gd[ch]
+            assert _feq(g.tap(4 + ch), golden["tap%d" % (4 + ch)][5 * g0:5 * (g0 + n)])
+            for j in range(5):
+                assert np.array_equal(out["bits"][j].astype(np.int8), golden["bits_%d_%d" % (ch, j)][g0:g0 + n])
+            assert _feq(out["lvl"], golden["lvl_%d_0" % ch][g0:g0 + n])
+            assert _feq(out["ppm"], golden["ppm_" + "ab"[ch]][b * 8:(b + 1) * 8])
+            gd[ch] += n
+    g.close()
+
+
+def test_cf32_reference_block_two_receivers():
+    xs = [synth.receiver_stream(786432 * 3, receiver_id=r, type5_every=5) for r in (0, 1)]
+    _run_gpu_vs_oracle(xs, 1536000, "cf32", 786432, 3)
+
+
+def test_cu8_equals_cf32_path():
+    x = synth.receiver_stream(131072 * 4, receiver_id=3, gap_slots=(1, 2))
+    _run_gpu_vs_oracle([synth.to_cu8(x)], 1536000, "cu8", 131072, 4)
+
+
+@pytest.mark.parametrize("tps", [1, 5, 24])
+def test_span_tiling_is_invisible(tps):
+    """Time tiling (spans + warm-up tile) must not change a single bit."""
+    x = synth.receiver_stream(98304 * 3, receiver_id=4, gap_slots=(1, 1))
+    _run_gpu_vs_oracle([x], 1536000, "cf32", 98304, 3, tiles_per_span=tps)
+
+
+@pytest.mark.parametrize("rate", [768000, 384000, 192000])
+def test_other_ladders(rate):
+    block = 512 * (rate // 48000) * 6
+    x = synth.receiver_stream(block * 3, sample_rate=rate, receiver_id=5, gap_slots=(1, 2))
+    _run_gpu_vs_oracle([x], rate, "cf32", block, 3)
+    _run_gpu_vs_oracle([synth.to_cu8(x)], rate, "cu8", block, 3)
+
+
+def test_edge_inputs():
+    """All-zero, DC, full-scale alternating and a huge-dynamic-range burst: still bit-exact."""
+    n = 16384 * 4
+    rng = np.random.default_rng(1)
+    zero = np.zeros(n, np.complex64)
+    dc = np.full(n, 0.25 - 0.5j, np.complex64)
+    alt = (np.where(np.arange(n) % 2 == 0, 1.0, -1.0) * (1 + 1j)).astype(np.complex64)
+    wild = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    wild[:n // 2] *= np.float32(1e-18)
+    wild[n // 2:] *= np.float32(3e4)
+    _run_gpu_vs_oracle([zero, dc, alt, wild], 1536000, "cf32", 16384, 4)
+    cu = np.zeros(2 * n, np.uint8)
+    cu[0::4] = 255
+    _run_gpu_vs_oracle([cu], 1536000, "cu8", 16384, 4)
+
+
+def test_noise_only_long():
+    rng = np.random.default_rng(2)
+    x = (0.05 * (rng.standard_normal(786432 * 2) + 1j * rng.standard_normal(786432 * 2))).astype(np.complex64)
+    _run_gpu_vs_oracle([x], 1536000, "cf32", 786432, 2)
+
+
+def test_full_batch_256_resident_matches_single():
+    """BASELINE config 4 geometry (256 receivers x 786,432 samples, resident in HBM): every receiver of
+    a batch fed the same stream must produce identical outputs, equal to the oracle's (size-independent
+    property: batch invariance + checksum)."""
+    import torch
+    R, block = 256, 786432
+    x = synth.receiver_stream(block * 2, receiver_id=9)
+    o = checkers.Oracle(taps=True)
+    o.feed_blocks(x, block)
+    g = gpu.AisGpu(n_receivers=R, block_len=block, taps=True)
+    gd = 0
+    for b in range(2):
+        one = torch.from_numpy(x[b * block:(b + 1) * block].view(np.float32).copy()).cuda()
+        batch = one.unsqueeze(0).expand(R, -1).contiguous()
+        torch.cuda.synchronize()
+        g.submit_device(batch.data_ptr(), block)
+        g.run()
+        g.sync_outputs()
+        L = block // 32
+        ref = [g.fetch(0, ch) for ch in range(2)]
+        for ch in range(2):
+            n = ref[ch]["n_groups"]
+            for j in range(5):
+                assert np.array_equal(ref[ch]["bits"][j], o.bits(ch, j)[0][gd:gd + n])
+            assert _feq(ref[ch]["lvl"], o.bits(ch, 0)[1][gd:gd + n])
+        assert _feq(g.tap(0, 0), o.tap(0)[b * L:(b + 1) * L])
+        for r in (1, 17, 128, 255):
+            assert _feq(g.tap(0, r), g.tap(0, 0)) and _feq(g.tap(3, r), g.tap(3, 0))
+        for r in range(1, R):
+            for ch in range(2):
+                out = g.fetch(r, ch)
+                assert np.array_equal(out["bits"], ref[ch]["bits"]) and _feq(out["lvl"], ref[ch]["lvl"])
+                assert _feq(out["ppm"], ref[ch]["ppm"])
+        gd += ref[0]["n_groups"]
+        del batch, one
+    g.close()

@@ -1,0 +1,75 @@
+"""CPU: oracle/ais_oracle.c against the compiled reference (oracle/_ref/libaisref_strict.so) on seeded
+synthetic streams -- every tap, every hard bit, every level/ppm and the NMEA text, bit-exact.
+Skipped where the compiled reference is absent (it is built from /root/reference by oracle/Makefile)."""
+import numpy as np
+import pytest
+
+import checkers
+from ais_catcher_amd import synth
+
+pytestmark = pytest.mark.skipif(not checkers.have_ref("strict"), reason="oracle/_ref not built")
+
+
+def _compare(model, rate, fmt, block, nblocks, rid, fm=False, **kw):
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=rid, **kw)
+    data = synth.to_cu8(x) if fmt == "cu8" else x
+    o = checkers.Oracle(model=model, rate=rate, fmt=fmt, taps=True)
+    r = checkers.Ref(model=model, rate=rate, fmt=fmt, taps=True)
+    o.feed_blocks(data, block)
+    r.feed_blocks(data, block)
+    for w in range(6):
+        a, b = o.tap(w), r.tap(w)
+        assert len(a) == len(b) and len(a) > 0
+        assert np.array_equal(a.view(np.float32), b.view(np.float32)), "tap %d" % w
+    for w in (2, 3):
+        assert np.array_equal(o.tap_ppm(w), r.tap_ppm(w))
+    for ch in range(2):
+        for j in range(5):
+            for f in ((0, 1) if fm else (0,)):
+                ob, rb = o.bits(ch, j, f), r.bits(ch, j, f)
+                assert len(ob[0]) == len(rb[0]) > 0
+                for p, q in zip(ob, rb):
+                    assert np.array_equal(p, q)
+    assert o.nmea() == r.nmea()
+    ol, rl = o.msg_meta(), r.msg_meta()
+    assert np.array_equal(ol[0], rl[0]) and np.array_equal(ol[1], rl[1])
+    return r.nmea()
+
+
+def test_default_cf32_reference_block():
+    lines = _compare(2, 1536000, "cf32", 786432, 3, rid=0, type5_every=4)
+    assert len(lines) >= 10
+
+
+def test_default_cu8_rtl_block():
+    assert len(_compare(2, 1536000, "cu8", 131072, 8, rid=1)) >= 3
+
+
+def test_default_small_blocks():
+    _compare(2, 1536000, "cf32", 16384, 24, rid=2, gap_slots=(1, 1))
+
+
+@pytest.mark.parametrize("rate", [768000, 384000, 192000, 3072000])
+def test_default_other_ladders(rate):
+    _compare(2, rate, "cf32", 512 * (rate // 48000) * 8, 3, rid=3, gap_slots=(1, 2))
+
+
+def test_challenger_cf32():
+    _compare(4, 1536000, "cf32", 131072, 8, rid=4, fm=True)
+
+
+def test_default_6msps_upsampled():
+    # 6,000,000 S/s -> 6.144M bucket with Upsample 125/128 (Model.cpp:183-189)
+    lines = _compare(2, 6000000, "cf32", 786432, 4, rid=5)
+    assert len(lines) >= 1
+
+
+def test_strict_and_shipped_builds_decode_the_same():
+    if not checkers.have_ref("fast"):
+        pytest.skip("fast build missing")
+    x = synth.receiver_stream(786432 * 3, receiver_id=11)
+    a = checkers.Ref(kind="strict")
+    b = checkers.Ref(kind="fast")
+    a.feed_blocks(x, 786432)
+    b.feed_blocks(x, 786432)
+    assert sorted(a.nmea()) == sorted(b.nmea()) and len(a.nmea()) > 5
