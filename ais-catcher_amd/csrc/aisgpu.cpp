@@ -233,6 +233,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	}
 	const size_t R = cfg->n_receivers, C = h->n_chan;
 	HIPCHK(dalloc((unsigned char**)&h->d_hist, R * h->tile_in * h->in_bytes));
+	// zero signal before the stream starts: CU8 zero is the byte 128 (Utilities/Convert.cpp:255-264)
+	if (cfg->input_format == AISGPU_FMT_CU8) HIPCHK(hipMemset(h->d_hist, 0x80, R * h->tile_in * h->in_bytes));
 	for (int i = 0; i < 2; i++) {
 		HIPCHK(dalloc(&h->d_rot[i], (size_t)ROT_HIST + h->n96));
 		HIPCHK(hipHostMalloc((void**)&h->h_rot[i], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipHostMallocDefault));

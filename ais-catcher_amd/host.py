@@ -1,0 +1,119 @@
+"""ctypes binding of libaishost.so: the C++ host side (GpuChain / ModelDefaultGPU / frame decoder).
+
+ModelDefaultGPU mirrors the reference's AIS::Model contract (DSP/Model.h:76-126): one instance per
+receiver, fed one RAW block per call like the reference's device thread does, NMEA out.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import gpu as _gpu
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaishost.so")
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    _gpu.load()
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libaishost.so is not built; run __graft_entry__.build()")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci, cll = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
+    lib.aishost_batch_create.restype = vp
+    lib.aishost_batch_create.argtypes = [ctypes.POINTER(_gpu.Cfg), ctypes.c_char_p, ci]
+    lib.aishost_batch_destroy.argtypes = [vp]
+    lib.aishost_model_create.restype = vp
+    lib.aishost_model_create.argtypes = [vp, ci, ci, ci, ci, ctypes.c_char, ctypes.c_char, ci, ctypes.c_char_p, ci]
+    lib.aishost_model_destroy.argtypes = [vp]
+    lib.aishost_model_receive.argtypes = [vp, vp, ci]
+    lib.aishost_model_replay.argtypes = [vp, ci, cll, cll, ci, ctypes.POINTER(vp), vp, ci, vp]
+    lib.aishost_model_msg_count.argtypes = [vp]
+    lib.aishost_model_nmea.argtypes = [vp, ctypes.c_char_p, ci]
+    lib.aishost_model_msg_meta.argtypes = [vp, vp, vp, ci]
+    _lib = lib
+    return lib
+
+
+class Batch:
+    """Shared GPU context for n_receivers ModelDefaultGPU instances (one per receiver thread)."""
+
+    def __init__(self, sample_rate=1536000, n_receivers=1, block_len=786432, input_format=_gpu.FMT_CF32, device_id=0):
+        lib = load()
+        cfg = _gpu.Cfg()
+        _gpu.load().aisgpu_default_cfg(ctypes.byref(cfg))
+        cfg.sample_rate, cfg.n_receivers, cfg.block_len = sample_rate, n_receivers, block_len
+        cfg.input_format, cfg.device_id = input_format, device_id
+        err = ctypes.create_string_buffer(512)
+        self.h = lib.aishost_batch_create(ctypes.byref(cfg), err, 512)
+        if not self.h:
+            raise RuntimeError(err.value.decode())
+        self.cfg = cfg
+
+    def close(self):
+        if self.h:
+            load().aishost_batch_destroy(self.h)
+            self.h = None
+
+
+class ModelDefaultGPU:
+    def __init__(self, sample_rate=1536000, block_len=786432, input_format=_gpu.FMT_CF32, ch1="A", ch2="B",
+                 batch=None, rx=0, detached=False):
+        self.lib = load()
+        err = ctypes.create_string_buffer(512)
+        self.fmt = input_format
+        self.h = self.lib.aishost_model_create(batch.h if batch else None, rx, sample_rate, block_len, input_format,
+                                               ch1.encode(), ch2.encode(), 1 if detached else 0, err, 512)
+        if not self.h:
+            raise RuntimeError(err.value.decode())
+
+    def receive(self, block):
+        block = np.ascontiguousarray(block)
+        self.lib.aishost_model_receive(self.h, block.ctypes.data, block.nbytes)
+
+    def replay(self, ch, first_group, first_sample48, bits5, lvl, ppm):
+        """bits5: [5][n_groups] array of +-1 (or 0/1) decisions; packed here like the GPU packs them."""
+        n = bits5.shape[1]
+        words = (n + 31) // 32
+        packed = []
+        for j in range(5):
+            b = np.zeros(words * 32, np.uint32)
+            b[:n] = (np.asarray(bits5[j]) > 0)
+            w = (b.reshape(words, 32) << np.arange(32, dtype=np.uint32)[None, :]).sum(axis=1, dtype=np.uint64).astype(np.uint32)
+            packed.append(np.ascontiguousarray(w))
+        ptrs = (ctypes.c_void_p * 5)(*[p.ctypes.data for p in packed])
+        lvl = np.ascontiguousarray(lvl, np.float32)
+        ppm = np.ascontiguousarray(ppm, np.float32)
+        self.lib.aishost_model_replay(self.h, ch, first_group, first_sample48, n, ptrs, lvl.ctypes.data, len(ppm), ppm.ctypes.data)
+
+    def nmea(self):
+        n = self.lib.aishost_model_nmea(self.h, None, 0)
+        buf = ctypes.create_string_buffer(n)
+        self.lib.aishost_model_nmea(self.h, buf, n)
+        return buf.value.decode().splitlines()
+
+    def msg_meta(self):
+        n = self.lib.aishost_model_msg_count(self.h)
+        lvl = np.zeros(max(n, 1), np.float32)
+        ppm = np.zeros(max(n, 1), np.float32)
+        self.lib.aishost_model_msg_meta(self.h, lvl.ctypes.data, ppm.ctypes.data, n)
+        return lvl[:n], ppm[:n]
+
+    def close(self):
+        if self.h:
+            self.lib.aishost_model_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def reset_sequence():
+    load().aishost_reset_sequence()

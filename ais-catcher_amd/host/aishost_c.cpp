@@ -1,0 +1,103 @@
+// ais-catcher_amd/host/aishost_c.cpp -- small C surface over the C++ host classes so the Python tests
+// (and any FFI) can drive ModelDefaultGPU exactly like the reference's device thread drives a Model.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gpu_model.h"
+
+using namespace aisamd;
+
+namespace {
+struct Sink : public StreamIn<AIS::Message> {
+	std::string text;
+	std::vector<float> level, ppm;
+	int count = 0;
+	void Receive(const AIS::Message* m, int len, TAG& tag) override {
+		for (int i = 0; i < len; i++) {
+			for (const auto& s : m[i].sentences()) { text += s; text += '\n'; }
+			level.push_back(tag.level);
+			ppm.push_back(tag.ppm);
+			count++;
+		}
+	}
+};
+struct Model {
+	ModelDefaultGPU m;
+	Sink sink;
+	TAG tag;
+	Format fmt = Format::CF32;
+	std::string err;
+};
+} // namespace
+
+extern "C" {
+
+void* aishost_batch_create(const aisgpu_cfg* cfg, char* errbuf, int errcap) {
+	try {
+		return new GpuBatch(*cfg);
+	} catch (const std::exception& e) {
+		if (errbuf && errcap > 0) { strncpy(errbuf, e.what(), errcap - 1); errbuf[errcap - 1] = 0; }
+		return nullptr;
+	}
+}
+void aishost_batch_destroy(void* b) { delete (GpuBatch*)b; }
+
+// batch == NULL and detached == 0: stand-alone single receiver with its own context
+// detached != 0: no GPU at all, only aishost_model_replay() may be used (host-logic tests)
+void* aishost_model_create(void* batch, int rx, int sample_rate, int block_len, int input_format, char ch1, char ch2,
+                           int detached, char* errbuf, int errcap) {
+	Model* m = new Model();
+	try {
+		m->fmt = input_format == AISGPU_FMT_CU8 ? Format::CU8 : Format::CF32;
+		m->m.setFormat(m->fmt);
+		m->m.setBlockLength(block_len);
+		if (batch) m->m.useBatch((GpuBatch*)batch, rx);
+		if (!detached) m->m.buildModel(ch1, ch2, sample_rate, false, nullptr);
+		else m->m.wireDecoders(ch1, ch2); // no GPU context
+		m->m.Output() >> m->sink;
+		return m;
+	} catch (const std::exception& e) {
+		if (errbuf && errcap > 0) { strncpy(errbuf, e.what(), errcap - 1); errbuf[errcap - 1] = 0; }
+		delete m;
+		return nullptr;
+	}
+}
+void aishost_model_destroy(void* mv) { delete (Model*)mv; }
+
+// One device block, exactly what the reference's run thread sends (RAW{format,data,size}, Device/FileRAW.cpp:135)
+int aishost_model_receive(void* mv, const void* data, int nbytes) {
+	Model* m = (Model*)mv;
+	RAW r = { m->fmt, (void*)data, nbytes };
+	m->m.Receive(&r, m->tag);
+	return 0;
+}
+
+int aishost_model_replay(void* mv, int ch, long long first_group, long long first_sample48, int n_groups,
+                         const uint32_t* const* bits5, const float* lvl, int n_windows, const float* ppm) {
+	Model* m = (Model*)mv;
+	aisgpu_out o;
+	memset(&o, 0, sizeof o);
+	o.n_groups = n_groups; o.first_group = first_group; o.first_sample48 = first_sample48;
+	for (int j = 0; j < 5; j++) o.bits[j] = bits5[j];
+	o.lvl = lvl; o.n_windows = n_windows; o.ppm = ppm;
+	m->m.replay(ch, o, m->tag);
+	return 0;
+}
+
+int aishost_model_msg_count(void* mv) { return ((Model*)mv)->sink.count; }
+int aishost_model_nmea(void* mv, char* dst, int cap) {
+	Model* m = (Model*)mv;
+	int n = (int)m->sink.text.size();
+	if (dst && cap > 0) { int c = n < cap - 1 ? n : cap - 1; memcpy(dst, m->sink.text.data(), c); dst[c] = 0; }
+	return n + 1;
+}
+int aishost_model_msg_meta(void* mv, float* level, float* ppm, int cap) {
+	Model* m = (Model*)mv;
+	int n = (int)m->sink.level.size();
+	for (int i = 0; i < n && i < cap; i++) { level[i] = m->sink.level[i]; ppm[i] = m->sink.ppm[i]; }
+	return n;
+}
+void aishost_reset_sequence(void) { AIS::Message::resetSequence(); }
+
+} // extern "C"

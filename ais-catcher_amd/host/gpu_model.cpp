@@ -1,0 +1,111 @@
+// ais-catcher_amd/host/gpu_model.cpp -- see gpu_model.h
+#include "gpu_model.h"
+
+namespace aisamd {
+
+GpuBatch::GpuBatch(const aisgpu_cfg& c) : cfg(c) {
+	int rc = aisgpu_create(&cfg, &ctx);
+	if (rc != AISGPU_OK) {
+		std::string msg = std::string("GpuBatch: ") + aisgpu_strerror(rc);
+		if (ctx) { msg += std::string(": ") + aisgpu_last_error(ctx); aisgpu_destroy(ctx); ctx = nullptr; }
+		throw std::runtime_error(msg);
+	}
+}
+
+GpuBatch::~GpuBatch() { aisgpu_destroy(ctx); }
+
+int GpuBatch::submitAndWait(int rx, const void* iq, int n_iq) {
+	std::unique_lock<std::mutex> lock(mtx);
+	int rc = aisgpu_submit(ctx, rx, iq, n_iq);
+	if (rc != AISGPU_OK) { status = rc; }
+	const long long my_gen = generation;
+	if (++arrived == cfg.n_receivers) {
+		// last receiver of this block: run the whole batch, copy the outputs back, release everyone
+		if (status == AISGPU_OK) status = aisgpu_run(ctx);
+		if (status == AISGPU_OK) status = aisgpu_sync_outputs(ctx);
+		arrived = 0;
+		generation++;
+		cv.notify_all();
+	} else {
+		cv.wait(lock, [&] { return generation != my_gen; });
+	}
+	return status;
+}
+
+void GpuChain::replay(Connection<FLOAT32>* out, const aisgpu_out& o, TAG& tag) {
+	for (int g = 0; g < o.n_groups; g++) {
+		const long long n_last = 5 * (o.first_group + g) + 4; // the sample that completes the group
+		const int w = (int)((n_last - o.first_sample48) / 512);
+		if (o.ppm && w >= 0 && w < o.n_windows) tag.ppm = o.ppm[w];
+		if (tag.mode & 1) tag.sample_lvl = o.lvl[g];
+		for (int j = 0; j < N_SAMPLES_PER_SYMBOL; j++) {
+			tag.sample_idx = 5 * (o.first_group + g) + j;
+			const FLOAT32 b = ((o.bits[j][g >> 5] >> (g & 31)) & 1u) ? 1.0f : -1.0f;
+			out[j].Send(&b, 1, tag);
+		}
+	}
+}
+
+void GpuChain::process(const void* data, int len, TAG& tag) {
+	if (failed || !batch) return;
+	int rc = batch->submitAndWait(rx, data, len);
+	if (rc != AISGPU_OK) {
+		failed = true;
+		if (on_error) on_error(std::string("GpuChain: ") + aisgpu_strerror(rc) + ": " + batch->lastError());
+		return;
+	}
+	// Rotate hands the whole block to channel A before channel B (reference DSP/DSP.cpp:312-313)
+	for (int ch = 0; ch < 2; ch++) {
+		aisgpu_out o;
+		if (batch->fetch(rx, ch, &o) != AISGPU_OK) { failed = true; return; }
+		replay(ch == 0 ? outA : outB, o, tag);
+	}
+}
+
+ModelDefaultGPU::~ModelDefaultGPU() {
+	if (own_batch) delete batch;
+}
+
+void ModelDefaultGPU::buildModel(char CH1, char CH2, int sample_rate, bool /*timerOn*/, void* /*device*/) {
+	if (!batch) { // stand-alone receiver: a batch of one
+		aisgpu_cfg c;
+		aisgpu_default_cfg(&c);
+		c.sample_rate = sample_rate;
+		c.n_receivers = 1;
+		c.block_len = block_len;
+		c.input_format = format == Format::CU8 ? AISGPU_FMT_CU8 : AISGPU_FMT_CF32;
+		c.afc_wide = CGF_wide;
+		c.droop = droop_compensation;
+		batch = new GpuBatch(c); // throws std::runtime_error on unsupported rate / missing GPU
+		own_batch = true;
+		chain.attach(batch, 0);
+	} else if (batch->config().sample_rate != sample_rate) {
+		throw std::runtime_error("ModelDefaultGPU: batch was created for a different sample rate");
+	}
+	wireDecoders(CH1, CH2);
+}
+
+void ModelDefaultGPU::wireDecoders(char CH1, char CH2) {
+	fan.o = &output;
+	for (int i = 0; i < N_SAMPLES_PER_SYMBOL; i++) {
+		DEC_a[i].setOrigin(CH1, station, own_mmsi);
+		DEC_b[i].setOrigin(CH2, station, own_mmsi);
+		chain.outA[i] >> DEC_a[i];
+		chain.outB[i] >> DEC_b[i];
+		DEC_a[i].out.Connect(&fan);
+		DEC_b[i].out.Connect(&fan);
+		for (int j = 0; j < N_SAMPLES_PER_SYMBOL; j++) {
+			if (i != j) { // a decoder that finds a message resets its four siblings (Model.cpp:566-573)
+				DEC_a[i].DecoderMessage.Connect(DEC_a[j]);
+				DEC_b[i].DecoderMessage.Connect(DEC_b[j]);
+			}
+		}
+	}
+}
+
+void ModelDefaultGPU::Receive(const RAW* raw, TAG& tag) {
+	if (raw->format == Format::CU8) chain.Receive((const CU8*)raw->data, raw->size / 2, tag);
+	else if (raw->format == Format::CF32) chain.Receive((const CFLOAT32*)raw->data, raw->size / (int)sizeof(CFLOAT32), tag);
+}
+
+} // namespace aisamd

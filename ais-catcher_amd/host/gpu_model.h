@@ -1,0 +1,111 @@
+// ais-catcher_amd/host/gpu_model.h -- the GPU chain behind the reference's block API.
+//
+//   GpuBatch        owns one aisgpu_t (include/aisgpu.h) for R batched receivers on one GPU; receiver
+//                   threads hand in their Receive() blocks, the last one to arrive launches the chain,
+//                   every thread then replays ITS receiver's symbol decisions into its decoders.
+//   GpuChain        : StreamIn<CFLOAT32>, StreamIn<CU8> -- the drop-in for everything between
+//                   Util::ConvertRAW and the AIS::Decoder objects of AIS::ModelDefault
+//                   (reference DSP/Model.cpp:27-356 + :520-577).  Exposes Connection<FLOAT32> outA[5],
+//                   outB[5], fed in exactly the reference's order: channel A's whole block
+//                   first, then channel B; per 5-sample group the phases j = 0..4 with
+//                   tag.sample_idx = 5g+j, tag.sample_lvl = level[g], tag.ppm = ppm[window of g].
+//   ModelDefaultGPU same contract as AIS::Model (reference DSP/Model.h:76-126): buildModel(CH1, CH2,
+//                   sample_rate, timerOn, device) wires GpuChain -> 2 x 5 AIS::Decoder with the Reset mesh
+//                   of Model.cpp:566-573 -> Output().
+// Errors: set-up problems throw std::runtime_error like the reference's models (Model.cpp:109-110);
+// run-time failures inside Receive() are reported through the error callback and stop the chain
+// (the reference logs and calls StopRequest(), Device/FileRAW.cpp:111-115).
+#pragma once
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/aisgpu.h"
+#include "ais_frame.h"
+#include "stream.h"
+
+namespace aisamd {
+
+constexpr int N_SAMPLES_PER_SYMBOL = 5; // reference DSP/Model.h:37
+
+class GpuBatch {
+	aisgpu_t* ctx = nullptr;
+	aisgpu_cfg cfg;
+	std::mutex mtx;
+	std::condition_variable cv;
+	int arrived = 0;
+	long long generation = 0;
+	int status = AISGPU_OK;
+
+public:
+	explicit GpuBatch(const aisgpu_cfg& c);
+	~GpuBatch();
+	GpuBatch(const GpuBatch&) = delete;
+	const aisgpu_cfg& config() const { return cfg; }
+	// Copies the receiver's block in; returns once the whole batch has been processed for this block.
+	int submitAndWait(int rx, const void* iq, int n_iq);
+	int fetch(int rx, int ch, aisgpu_out* out) { return aisgpu_fetch(ctx, rx, ch, out); }
+	const char* lastError() { return aisgpu_last_error(ctx); }
+};
+
+class GpuChain : public StreamIn<CFLOAT32>, public StreamIn<CU8> {
+	GpuBatch* batch = nullptr;
+	int rx = 0;
+	std::function<void(const std::string&)> on_error;
+	bool failed = false;
+
+	void process(const void* data, int len, TAG& tag);
+
+public:
+	Connection<FLOAT32> outA[N_SAMPLES_PER_SYMBOL], outB[N_SAMPLES_PER_SYMBOL];
+
+	void attach(GpuBatch* b, int receiver) { batch = b; rx = receiver; }
+	void setErrorHandler(std::function<void(const std::string&)> f) { on_error = f; }
+	void Receive(const CFLOAT32* data, int len, TAG& tag) override { process(data, len, tag); }
+	void Receive(const CU8* data, int len, TAG& tag) override { process(data, len, tag); }
+	// Replay one channel's symbol decisions of a block into the five phase outputs (host logic,
+	// also used stand-alone by the CPU tests).
+	static void replay(Connection<FLOAT32>* out, const aisgpu_out& o, TAG& tag);
+};
+
+class ModelDefaultGPU {
+	GpuBatch* batch = nullptr;
+	bool own_batch = false;
+	GpuChain chain;
+	AIS::Decoder DEC_a[N_SAMPLES_PER_SYMBOL], DEC_b[N_SAMPLES_PER_SYMBOL];
+	StreamOut<AIS::Message> output;
+	int own_mmsi = -1, station = 0;
+	int block_len = 786432;
+	Format format = Format::CF32;
+	bool CGF_wide = true, droop_compensation = true;
+
+	struct Fan : public StreamIn<AIS::Message> { // PassThrough<Message> of the reference (Model.h:88)
+		StreamOut<AIS::Message>* o = nullptr;
+		void Receive(const AIS::Message* d, int len, TAG& tag) override { o->Send(d, len, tag); }
+	} fan;
+
+public:
+	ModelDefaultGPU() {}
+	~ModelDefaultGPU();
+	// share one GPU context between several receivers (receiver index rx inside the batch)
+	void useBatch(GpuBatch* b, int rx) { batch = b; chain.attach(b, rx); }
+	void setBlockLength(int n) { block_len = n; }
+	void setFormat(Format f) { format = f; }
+	void setOwnMMSI(int m) { own_mmsi = m; }
+	void setAFCWide(bool b) { CGF_wide = b; }
+	void setDroop(bool b) { droop_compensation = b; }
+	// same signature as AIS::Model::buildModel (the Device* of the reference is only used for wiring there)
+	void buildModel(char CH1, char CH2, int sample_rate, bool timerOn, void* device);
+	// decoder wiring only, no GPU context (CPU tests of the replay/decoder host logic)
+	void wireDecoders(char CH1, char CH2);
+	StreamOut<AIS::Message>& Output() { return output; }
+	GpuChain& Chain() { return chain; }
+	// entry used by the C API: the RAW block as the device thread delivers it (Device/FileRAW.cpp:135)
+	void Receive(const RAW* raw, TAG& tag);
+	// CPU-only replay entry (host-logic tests): decisions produced elsewhere
+	void replay(int ch, const aisgpu_out& o, TAG& tag) { GpuChain::replay(ch == 0 ? chain.outA : chain.outB, o, tag); }
+};
+
+} // namespace aisamd
