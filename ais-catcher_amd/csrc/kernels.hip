@@ -421,9 +421,11 @@ __global__ __launch_bounds__(64) void k2_cgf_analyse(K2Params p) {
 // K2b: CGF derotation (DSP/DSP.cpp:457-466).  rot *= rot_step; output[i] *= rot per sample, rot
 // renormalised per window and carried across windows -> a strictly sequential float recurrence per
 // (receiver, channel).  One wave per chain: all 64 lanes run the recurrence redundantly (no
-// divergence, no LDS), lane l latches rot_k for k == l (mod 64) and applies it to its own sample,
-// so global traffic stays fully coalesced (8 B / lane).
+// divergence, no LDS), a DPP wave shift hands the phasor of step k to lane 63-k, which applies it to
+// its own sample, so global traffic stays fully coalesced (8 B / lane).
 // ------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 __global__ __launch_bounds__(64) void k2_cgf_derotate(K2Params p) {
 	const int lane = threadIdx.x;
 	const int chan = blockIdx.x;
@@ -436,25 +438,44 @@ __global__ __launch_bounds__(64) void k2_cgf_derotate(K2Params p) {
 		float2 tv = y[L + lane];
 		y[lane] = tv;
 	}
-	float2 rot = p.rot_state[chan];
+	const float2 r0 = p.rot_state[chan];
+	// `cur` is at the same time the recurrence variable (lane 0) and a 64-deep history (lane l holds the
+	// phasor of l steps ago): each step computes rot*rot_step in every lane -- only lane 0's result is
+	// meaningful -- and a DPP wave_shr:1 move then refills lanes 1..63 from the previous register while
+	// lane 0 (no source lane) keeps the new phasor.  5 VALU ops per sample, no LDS, no select.
+	// The product is 3 packed ops: P = (rx*sx, rx*sy), Q = (ry*-sy, ry*sx), rot' = P + Q; x*-y == -(x*y)
+	// exactly, so this is the reference's (ac - bd, ad + bc) bit for bit (DSP/DSP.cpp:460-463).
+	v2f cur = { r0.x, r0.y };
+	const int rl = 63 - lane; // after 64 steps lane l holds the phasor of step 63-l of the chunk
+	float2 xv = x[rl];        // sample of the first 64-chunk, prefetched
 	for (int w = 0; w < p.n_windows; w++) {
 		const int fz = p.fz[(size_t)chan * p.n_windows + w];
-		const float2 step = p.step_table[fz + 205];
+		const float2 stp = p.step_table[fz + 205];
+		const v2f st = { stp.x, stp.y }, st_sw = { -stp.y, stp.x };
 #pragma unroll 1
 		for (int c = 0; c < 8; c++) {
-			float2 xv = x[w * 512 + c * 64 + lane];
-			float2 mine = rot;
+			const int base = w * 512 + c * 64;
+			float2 xn = xv;
+			if (base + 64 < L) xn = x[base + 64 + rl]; // next chunk in flight during the 64 serial steps
 #pragma unroll
 			for (int k = 0; k < 64; k++) {
-				rot = cmul(rot, step);
-				if (lane == k) mine = rot;
+				const v2f P = cur.xx * st;
+				const v2f Q = cur.yy * st_sw;
+				v2f nw = P + Q;
+				nw.x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(nw.x), __float_as_int(cur.x), 0x138, 0xF, 0xF, false));
+				nw.y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(nw.y), __float_as_int(cur.y), 0x138, 0xF, 0xF, false));
+				cur = nw;
 			}
-			y[CGF_HIST + w * 512 + c * 64 + lane] = cmul(xv, mine);
+			y[CGF_HIST + base + rl] = cmul(xv, make_float2(cur.x, cur.y)); // output[i] *= rot
+			xv = xn;
 		}
-		float a = hypot_ref(rot.x, rot.y);
-		rot = make_float2(__fdiv_rn(rot.x, a), __fdiv_rn(rot.y, a)); // rot /= std::abs(rot)
+		// rot /= std::abs(rot) once per window (DSP.cpp:465); only lane 0 carries the chain
+		const float a = hypot_ref(cur.x, cur.y);
+		const float nx = __fdiv_rn(cur.x, a), ny = __fdiv_rn(cur.y, a);
+		cur.x = lane == 0 ? nx : cur.x;
+		cur.y = lane == 0 ? ny : cur.y;
 	}
-	if (lane == 0) p.rot_state[chan] = rot;
+	if (lane == 0) p.rot_state[chan] = make_float2(cur.x, cur.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -501,6 +522,100 @@ __constant__ float2 c_ps_phase[8] = { // DSP/Demod.h:29-31
 	{ 6.3439326515712957e-01f, 7.7301046896098113e-01f }, { 4.7139671032286945e-01f, 8.8192127851457169e-01f },
 	{ 2.9028464326824349e-01f, 9.5694034604181499e-01f }, { 9.8017099547459546e-02f, 9.9518473068888236e-01f } };
 
+// neighbour exchange inside a 16-lane row: DPP row rotate (a VALU modifier, no LDS round trip).
+// The rotate direction is probed once per wave (mode 0: row_ror:1 delivers lane k-1; mode 1: lane k+1;
+// mode 2: unexpected -> fall back to ds_bpermute), so correctness never rests on the ISA manual's wording.
+__device__ __forceinline__ float dpp_ror1(float v) {
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_ror15(float v) {
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x12F, 0xF, 0xF, false));
+}
+
+struct PsLane { // per-lane PhaseSearchEMA state: hypothesis k of one chain
+	float ma;
+	unsigned bits;
+};
+
+// One symbol for all 16 hypotheses of a row (DSP/Demod.cpp:39-101).  Returns the emitted bit (0/1).
+template <int MODE>
+__device__ __forceinline__ unsigned ps_step(float2 v, int rot, float pc, float psn, PsLane& s, int& idx, int k, int rowbase) {
+	const float w = 0.85f;
+	const float w1 = 1 - w; // (1 - weight) evaluated in float (Demod.cpp:71)
+	// multiply by (1j)^rot via swaps/negations (Demod.cpp:44-61); branch-free because rot differs per row
+	const bool sw = (rot & 1) != 0;
+	float re = sw ? v.y : v.x, im = sw ? v.x : v.y;
+	re = (rot == 1 || rot == 2) ? -re : re;
+	im = (rot >= 2) ? -im : im;
+	const float a = re * pc, b = im * psn;
+	const float tt = a + b;
+	s.bits = ((s.bits << 1) | (tt > 0 ? 1u : 0u)) & 0xFFu; // uint8_t shift register
+	s.ma = w * s.ma + w1 * fabsf(tt);
+	float left, right;
+	if (MODE == 2) {
+		left = __shfl(s.ma, (k + 15) & 15, 16);
+		right = __shfl(s.ma, (k + 1) & 15, 16);
+	} else {
+		const float r1 = dpp_ror1(s.ma), r15 = dpp_ror15(s.ma);
+		left = MODE == 0 ? r1 : r15;
+		right = MODE == 0 ? r15 : r1;
+	}
+	const bool p0 = s.ma > left;         // centre beats idx-1
+	const float bestc = p0 ? s.ma : left;
+	const bool p1 = right > bestc;       // idx+1 beats the better of the two
+	// nDelay = 3 (Model.cpp:560-561): bit(nDelay) XOR bit(nDelay + 1) of the winning hypothesis
+	const bool xb = (((s.bits >> 4) ^ (s.bits >> 3)) & 1u) != 0;
+	const unsigned long long B0 = __ballot(p0), B1 = __ballot(p1), BX = __ballot(xb);
+	const unsigned m0 = (unsigned)(B0 >> rowbase), m1 = (unsigned)(B1 >> rowbase), mx = (unsigned)(BX >> rowbase);
+	const int q0 = (int)((m0 >> idx) & 1u), q1 = (int)((m1 >> idx) & 1u);
+	idx = (idx + (q1 ? 1 : q0 - 1)) & 15; // prev-1, prev, prev+1 with first-maximum preference
+	return (mx >> idx) & 1u;
+}
+
+constexpr int PS_BATCH = 16; // symbols whose samples are fetched together (multiple of 4: rot phase is preserved)
+
+template <int MODE>
+__device__ __forceinline__ void ps_chain(const float2* __restrict__ x, uint32_t* __restrict__ out, int n, bool writer, float pc,
+                                         float psn, PsLane& s, int& idx, int& rot, int k, int rowbase) {
+	const int nb = n - (n % PS_BATCH);
+	uint32_t word = 0;
+	float2 cur[PS_BATCH];
+	if (nb > 0) {
+#pragma unroll
+		for (int e = 0; e < PS_BATCH; e++) cur[e] = x[e];
+	}
+#pragma unroll 1
+	for (int g0 = 0; g0 < nb; g0 += PS_BATCH) {
+		float2 nxt[PS_BATCH];
+		const bool more = g0 + PS_BATCH < nb;
+		if (more) { // next batch in flight while this one is processed
+#pragma unroll
+			for (int e = 0; e < PS_BATCH; e++) nxt[e] = x[g0 + PS_BATCH + e];
+		}
+		uint32_t part = 0;
+#pragma unroll
+		for (int e = 0; e < PS_BATCH; e++) part |= ps_step<MODE>(cur[e], (rot + e) & 3, pc, psn, s, idx, k, rowbase) << e;
+		word |= part << (g0 & 31);
+		if (((g0 + PS_BATCH) & 31) == 0) {
+			if (writer) out[g0 >> 5] = word;
+			word = 0;
+		}
+		if (more) {
+#pragma unroll
+			for (int e = 0; e < PS_BATCH; e++) cur[e] = nxt[e];
+		}
+	}
+	for (int g = nb; g < n; g++) {
+		word |= ps_step<MODE>(x[g], rot, pc, psn, s, idx, k, rowbase) << (g & 31);
+		rot = (rot + 1) & 3;
+		if ((g & 31) == 31) {
+			if (writer) out[g >> 5] = word;
+			word = 0;
+		}
+	}
+	if ((n & 31) != 0 && writer) out[n >> 5] = word;
+}
+
 __global__ __launch_bounds__(64) void k4_phase_search(K4Params p) {
 	const int lane = threadIdx.x;
 	const int k = lane & 15, row = lane >> 4;
@@ -509,56 +624,28 @@ __global__ __launch_bounds__(64) void k4_phase_search(K4Params p) {
 	const int cidx = live ? chain : p.n_chains - 1;
 	const int rowbase = row * 16;
 
+	const int src = __builtin_amdgcn_update_dpp(0, k, 0x121, 0xF, 0xF, false);
+	const bool all_left = __all(src == ((k + 15) & 15)), all_right = __all(src == ((k + 1) & 15));
+
 	const int jj = k < 8 ? k : 15 - k;
 	const float pc = c_ps_phase[jj].x;
 	const float psn = k < 8 ? c_ps_phase[jj].y : -c_ps_phase[jj].y; // a - b == a + (im * -s) exactly
 
 	EmaState* st = p.state + cidx;
-	float ma = st->ma[k];
-	unsigned bits = st->bits[k];
+	PsLane s;
+	s.ma = st->ma[k];
+	s.bits = st->bits[k];
 	int idx = st->max_idx, rot = st->rot;
 
 	const float2* x = p.sym + (size_t)cidx * p.sym_stride;
 	uint32_t* out = p.bits + (size_t)cidx * p.bits_stride;
-	const float w = 0.85f;
-	const float w1 = 1 - w; // (1 - weight) evaluated in float (Demod.cpp:71)
-	uint32_t word = 0;
-
-	for (int g = 0; g < p.n_groups; g++) {
-		float2 v = x[g];
-		// multiply by (1j)^rot via swaps/negations (Demod.cpp:44-61); branch-free because rot differs per row
-		const bool sw = (rot & 1) != 0;
-		float re = sw ? v.y : v.x, im = sw ? v.x : v.y;
-		re = (rot == 1 || rot == 2) ? -re : re;
-		im = (rot >= 2) ? -im : im;
-		rot = (rot + 1) & 3;
-		float a = re * pc, b = im * psn;
-		float tt = a + b;
-		bits = ((bits << 1) | (tt > 0 ? 1u : 0u)) & 0xFFu; // uint8_t shift register
-		ma = w * ma + w1 * fabsf(tt);
-		float left = __shfl(ma, (k + 15) & 15, 16);
-		float right = __shfl(ma, (k + 1) & 15, 16);
-		bool p0 = ma > left;             // centre beats idx-1
-		float bestc = p0 ? ma : left;
-		bool p1 = right > bestc;         // idx+1 beats the better of the two
-		unsigned long long B0 = __ballot(p0), B1 = __ballot(p1);
-		int sh = rowbase + idx;
-		int q1 = (int)((B1 >> sh) & 1ull), q0 = (int)((B0 >> sh) & 1ull);
-		idx = (idx + (q1 ? 1 : (q0 ? 0 : -1))) & 15;
-		// nDelay = 3 (Model.cpp:560-561): bit(nDelay) XOR bit(nDelay + 1) of the winning hypothesis
-		unsigned xb = ((bits >> 4) ^ (bits >> 3)) & 1u;
-		unsigned long long BX = __ballot(xb != 0);
-		uint32_t ob = (uint32_t)((BX >> (rowbase + idx)) & 1ull);
-		word |= ob << (g & 31);
-		if ((g & 31) == 31) {
-			if (live && k == 0) out[g >> 5] = word;
-			word = 0;
-		}
-	}
-	if ((p.n_groups & 31) != 0 && live && k == 0) out[p.n_groups >> 5] = word;
+	const bool writer = live && k == 0;
+	if (all_left) ps_chain<0>(x, out, p.n_groups, writer, pc, psn, s, idx, rot, k, rowbase);
+	else if (all_right) ps_chain<1>(x, out, p.n_groups, writer, pc, psn, s, idx, rot, k, rowbase);
+	else ps_chain<2>(x, out, p.n_groups, writer, pc, psn, s, idx, rot, k, rowbase);
 	if (live) {
-		st->ma[k] = ma;
-		st->bits[k] = bits;
+		st->ma[k] = s.ma;
+		st->bits[k] = s.bits;
 		if (k == 0) { st->max_idx = idx; st->rot = rot; }
 	}
 }
