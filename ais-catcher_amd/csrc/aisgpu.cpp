@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -35,7 +36,9 @@ struct EvPair { hipEvent_t a, b; };
 struct aisgpu {
 	aisgpu_cfg cfg;
 	int K = 0;            // CIC5 stages in front of the 96 kHz point
-	int tile_in = 0;      // input samples per front-end tile (256 << K)
+	int tile96 = 256;     // 96 kHz samples per front-end tile
+	int depth = 2;        // tiles prefetched ahead by the front end
+	int tile_in = 0;      // input samples per front-end tile (tile96 << K)
 	int in_bytes = 0;     // bytes per input sample
 	int n96 = 0, L = 0, W = 0; // per block: 96 kHz samples, 48 kHz samples per channel, CGF windows
 	int Gcap = 0, words = 0;   // group capacity per block, bit words per chain
@@ -43,15 +46,31 @@ struct aisgpu {
 	int tiles_per_block = 0, tiles_per_span = 0, spans = 0;
 	float alpha = 0, beta = 1; int has_fdc = 0;
 
-	hipStream_t stream = nullptr;
+	// Three streams software-pipeline consecutive blocks:
+	//   s0 (stream): Rotate table upload -> K1 -> K1-tail -> K2a   (bandwidth-bound front end)
+	//   s3: K2b                                         (sequential CGF phasor recurrence, 8 waves, latency bound)
+	//   s1 (= s2): K2c -> K3 -> K4 (+ D2H of the outputs) (apply phasors, FIR/ScatterPLL, PhaseSearchEMA)
+	// so block b+1's front end overlaps block b's phasor recurrence and back end.  Buffers that cross a
+	// stream boundary are double buffered by block parity.
+	hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, s3 = nullptr; // s3: the CGF phasor recurrence alone
+	hipEvent_t ev_phasor[2] = { nullptr, nullptr }; // s3: phasor(b) done -> s1 may apply it
+	bool serial = false;
+	hipEvent_t ev_front[2] = { nullptr, nullptr }; // s0: K2a(b) done           -> s1 may start K2b(b)
+	hipEvent_t ev_c48free[2] = { nullptr, nullptr }; // s1: K2b(b) done (c48/fz[p] consumed) -> s0 may run K1(b+2)
+	hipEvent_t ev_mid[2] = { nullptr, nullptr };   // s1: K3(b) done            -> s2 may start K4(b)
+	hipEvent_t ev_ema[2] = { nullptr, nullptr };   // s2: K4(b) done (sym/lvl[p] consumed) -> s1 may run K3(b+2)
 	// device buffers
 	void* d_in = nullptr; void* d_hist = nullptr;
 	float2* d_rot[2] = { nullptr, nullptr };
-	float2 *d_c48 = nullptr, *d_cgf = nullptr, *d_sym = nullptr, *d_omega = nullptr, *d_step = nullptr, *d_rotstate = nullptr, *d_firtap = nullptr;
-	float *d_ppmtab = nullptr, *d_ppm = nullptr, *d_lvl = nullptr;
-	int* d_fz = nullptr;
-	uint32_t* d_bits = nullptr;
-	EmaState* d_ema = nullptr;
+	float2 *d_c48[2] = { nullptr, nullptr }, *d_sym[2] = { nullptr, nullptr };
+	float2 *d_rotT[2] = { nullptr, nullptr };
+	float2 *d_cgf = nullptr, *d_omega = nullptr, *d_step = nullptr, *d_rotstate = nullptr, *d_firtap = nullptr;
+	float *d_ppmtab = nullptr, *d_ppm[2] = { nullptr, nullptr }, *d_lvl[2] = { nullptr, nullptr };
+	int* d_fz[2] = { nullptr, nullptr };
+	uint32_t* d_bits[2] = { nullptr, nullptr };
+	EmaState* d_ema[2] = { nullptr, nullptr }; // state before / after the current block (swapped per block)
+	uint32_t* d_pswords = nullptr; float *d_psma0 = nullptr, *d_psma1 = nullptr; unsigned* d_psfin = nullptr; int* d_psflag = nullptr;
+	int ps_chunks = 1, ps_warm = 256; bool ps_parallel = true;
 	// host (pinned)
 	void* h_in = nullptr;
 	float2* h_rot[2] = { nullptr, nullptr };
@@ -179,7 +198,17 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	if (!h) return AISGPU_ERR_ARG;
 	h->cfg = *cfg;
 	h->K = K;
-	h->tile_in = 256 << K;
+	h->tile96 = 256;
+	if (const char* e = getenv("AISGPU_TILE96")) { // tuning knob (256, 128 or 64)
+		int v = atoi(e);
+		if (v == 256 || v == 128 || v == 64) h->tile96 = v;
+	}
+	h->depth = h->tile96 == 256 ? 2 : (h->tile96 == 128 ? 3 : 4);
+	if (const char* e = getenv("AISGPU_DEPTH")) {
+		int v = atoi(e);
+		if ((h->tile96 == 256 && v >= 1 && v <= 3) || (h->tile96 == 128 && v >= 2 && v <= 4)) h->depth = v;
+	}
+	h->tile_in = h->tile96 << K;
 	h->in_bytes = cfg->input_format == AISGPU_FMT_CU8 ? 2 : 8;
 	h->n96 = cfg->block_len >> K;
 	h->L = h->n96 / 2;
@@ -196,7 +225,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	int tps = cfg->tiles_per_span;
 	if (tps <= 0) {
 		tps = h->tiles_per_block;
-		while (tps > 8 && (long long)cfg->n_receivers * ((h->tiles_per_block + tps - 1) / tps) < 1024) tps = (tps + 1) / 2;
+		const long long want = h->tile96 >= 256 ? 1024 : 2048; // workgroups: a few per CU per residency slot
+		while (tps > 8 && (long long)cfg->n_receivers * ((h->tiles_per_block + tps - 1) / tps) < want) tps = (tps + 1) / 2;
 	}
 	if (tps > h->tiles_per_block) tps = h->tiles_per_block;
 	h->tiles_per_span = tps;
@@ -205,6 +235,23 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 
 	HIPCHK(hipSetDevice(cfg->device_id));
 	HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+	if (getenv("AISGPU_SERIAL")) { // profiling aid: no cross-block overlap, every kernel runs alone
+		h->s1 = h->s2 = h->s3 = h->stream;
+		h->serial = true;
+	} else {
+		// HIP maps streams onto a small number of hardware queues (4 by default, one is the application's
+		// null stream): two of our streams sharing a queue would serialise.  So: three streams.
+		HIPCHK(hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking));
+		HIPCHK(hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking));
+		h->s2 = h->s1; // apply + FIR + PhaseSearchEMA of a block run back to back on one stream
+	}
+	for (int i = 0; i < 2; i++) {
+		HIPCHK(hipEventCreateWithFlags(&h->ev_front[i], hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&h->ev_phasor[i], hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&h->ev_c48free[i], hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&h->ev_mid[i], hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&h->ev_ema[i], hipEventDisableTiming));
+	}
 
 	// ---- constant tables (host libm, like the reference on this machine)
 	{
@@ -240,19 +287,31 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(hipHostMalloc((void**)&h->h_rot[i], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipHostMallocDefault));
 		HIPCHK(hipEventCreateWithFlags(&h->rot_ev[i], hipEventDisableTiming));
 	}
-	HIPCHK(dalloc(&h->d_c48, C * h->L));
+	for (int i = 0; i < 2; i++) {
+		HIPCHK(dalloc(&h->d_c48[i], C * h->L));
+		HIPCHK(dalloc(&h->d_fz[i], C * h->W));
+		HIPCHK(dalloc(&h->d_ppm[i], C * h->W));
+		HIPCHK(dalloc(&h->d_sym[i], C * 5 * h->Gcap));
+		HIPCHK(dalloc(&h->d_lvl[i], C * h->Gcap));
+		HIPCHK(dalloc(&h->d_bits[i], C * 5 * h->words));
+	}
 	HIPCHK(dalloc(&h->d_cgf, C * (CGF_HIST + h->L)));
-	HIPCHK(dalloc(&h->d_fz, C * h->W));
-	HIPCHK(dalloc(&h->d_ppm, C * h->W));
+	for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_rotT[i], (size_t)h->L * ((C + 63) / 64 * 64)));
 	HIPCHK(dalloc(&h->d_rotstate, C));
 	{
 		std::vector<float2> ones(C, make_float2(1.0f, 0.0f)); // SquareFreqOffsetCorrection::rot = 1.0f (DSP.h:379)
 		HIPCHK(hipMemcpy(h->d_rotstate, ones.data(), C * sizeof(float2), hipMemcpyHostToDevice));
 	}
-	HIPCHK(dalloc(&h->d_sym, C * 5 * h->Gcap));
-	HIPCHK(dalloc(&h->d_lvl, C * h->Gcap));
-	HIPCHK(dalloc(&h->d_bits, C * 5 * h->words));
-	HIPCHK(dalloc(&h->d_ema, C * 5));
+	HIPCHK(dalloc(&h->d_ema[0], C * 5));
+	HIPCHK(dalloc(&h->d_ema[1], C * 5));
+	h->ps_chunks = (h->Gcap + PS_CHUNK - 1) / PS_CHUNK;
+	if (const char* e = getenv("AISGPU_PS_WARM")) { int v = atoi(e); if (v >= 1 && v <= PS_CHUNK) h->ps_warm = (v + 15) / 16 * 16; } // test hook: small values force the exact fallback
+	if (getenv("AISGPU_PS_SEQUENTIAL")) h->ps_parallel = false;
+	HIPCHK(dalloc(&h->d_pswords, C * 5 * h->ps_chunks * (PS_CHUNK / 32) * 16));
+	HIPCHK(dalloc(&h->d_psma0, C * 5 * h->ps_chunks * 16));
+	HIPCHK(dalloc(&h->d_psma1, C * 5 * h->ps_chunks * 16));
+	HIPCHK(dalloc(&h->d_psfin, C * 5 * h->ps_chunks * 16));
+	HIPCHK(dalloc(&h->d_psflag, 4));
 	if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_firtap, C * (8 + h->L)));
 	HIPCHK(hipHostMalloc((void**)&h->h_bits, C * 5 * h->words * sizeof(uint32_t), hipHostMallocDefault));
 	HIPCHK(hipHostMalloc((void**)&h->h_lvl, C * h->Gcap * sizeof(float), hipHostMallocDefault));
@@ -264,18 +323,32 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 void aisgpu_destroy(aisgpu_t* h) {
 	if (!h) return;
 	if (h->stream) hipStreamSynchronize(h->stream);
+	if (h->s1) hipStreamSynchronize(h->s1);
+	if (h->s2) hipStreamSynchronize(h->s2);
+	if (h->s3) hipStreamSynchronize(h->s3);
 	drain_events(h);
+	for (int i = 0; i < 2; i++) {
+		if (h->ev_front[i]) hipEventDestroy(h->ev_front[i]);
+		if (h->ev_phasor[i]) hipEventDestroy(h->ev_phasor[i]);
+		hipFree(h->d_rotT[i]);
+		if (h->ev_c48free[i]) hipEventDestroy(h->ev_c48free[i]);
+		if (h->ev_mid[i]) hipEventDestroy(h->ev_mid[i]);
+		if (h->ev_ema[i]) hipEventDestroy(h->ev_ema[i]);
+		hipFree(h->d_c48[i]); hipFree(h->d_fz[i]); hipFree(h->d_ppm[i]); hipFree(h->d_sym[i]); hipFree(h->d_lvl[i]); hipFree(h->d_bits[i]);
+	}
 	for (auto& p : h->ev_free) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
 	hipFree(h->d_in); hipFree(h->d_hist);
 	for (int i = 0; i < 2; i++) { hipFree(h->d_rot[i]); if (h->h_rot[i]) hipHostFree(h->h_rot[i]); if (h->rot_ev[i]) hipEventDestroy(h->rot_ev[i]); }
-	hipFree(h->d_c48); hipFree(h->d_cgf); hipFree(h->d_sym); hipFree(h->d_omega); hipFree(h->d_step);
-	hipFree(h->d_rotstate); hipFree(h->d_firtap); hipFree(h->d_ppmtab); hipFree(h->d_ppm); hipFree(h->d_lvl);
-	hipFree(h->d_fz); hipFree(h->d_bits); hipFree(h->d_ema);
+	hipFree(h->d_cgf); hipFree(h->d_omega); hipFree(h->d_step);
+	hipFree(h->d_rotstate); hipFree(h->d_firtap); hipFree(h->d_ppmtab); hipFree(h->d_ema[0]); hipFree(h->d_ema[1]);
+	hipFree(h->d_pswords); hipFree(h->d_psma0); hipFree(h->d_psma1); hipFree(h->d_psfin); hipFree(h->d_psflag);
 	if (h->h_in) hipHostFree(h->h_in);
 	if (h->h_bits) hipHostFree(h->h_bits);
 	if (h->h_lvl) hipHostFree(h->h_lvl);
 	if (h->h_ppm) hipHostFree(h->h_ppm);
 	if (h->stream) hipStreamDestroy(h->stream);
+	if (h->s1 && !h->serial) hipStreamDestroy(h->s1);
+	if (h->s3 && !h->serial) hipStreamDestroy(h->s3);
 	delete h;
 }
 
@@ -319,9 +392,11 @@ int aisgpu_run(aisgpu_t* h) {
 	HIPCHK(hipMemcpyAsync(h->d_rot[pb], h->h_rot[pb], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
 	HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
 
+	// c48/fz/ppm[pb] were last read by K2b of block b-2 (stream s1)
+	HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[pb], 0));
 	K1Params k1;
 	k1.in = h->cur_in; k1.in_stride = h->cur_in_stride; k1.hist = h->d_hist; k1.rot = h->d_rot[pb];
-	k1.c48 = h->d_c48; k1.c48_stride = h->L;
+	k1.c48 = h->d_c48[pb]; k1.c48_stride = h->L;
 	k1.tiles_per_block = h->tiles_per_block; k1.tiles_per_span = h->tiles_per_span;
 	k1.alpha = h->alpha; k1.beta = h->beta; k1.has_fdc = h->has_fdc;
 	EvPair ev{};
@@ -330,30 +405,50 @@ int aisgpu_run(aisgpu_t* h) {
 		else { ev = h->ev_free.back(); h->ev_free.pop_back(); }
 		HIPCHK(hipEventRecord(ev.a, h->stream));
 	}
-	HIPCHK(launch_k1(k1, h->K, h->cfg.input_format == AISGPU_FMT_CU8, h->spans, h->cfg.n_receivers, h->stream));
+	HIPCHK(launch_k1(k1, h->K, h->cfg.input_format == AISGPU_FMT_CU8, h->tile96, h->depth, h->spans, h->cfg.n_receivers, h->stream));
 	if (h->timing) { HIPCHK(hipEventRecord(ev.b, h->stream)); h->ev_busy.push_back(ev); }
 	HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist,
 	                      h->tile_in * h->in_bytes, h->cfg.n_receivers, h->stream));
 
 	K2Params k2;
-	k2.c48 = h->d_c48; k2.c48_stride = h->L; k2.cgf = h->d_cgf; k2.cgf_stride = CGF_HIST + h->L;
-	k2.omega = h->d_omega; k2.step_table = h->d_step; k2.ppm_table = h->d_ppmtab; k2.fz = h->d_fz; k2.ppm = h->d_ppm;
+	k2.c48 = h->d_c48[pb]; k2.c48_stride = h->L; k2.cgf = h->d_cgf; k2.cgf_stride = CGF_HIST + h->L;
+	k2.omega = h->d_omega; k2.step_table = h->d_step; k2.ppm_table = h->d_ppmtab; k2.fz = h->d_fz[pb]; k2.ppm = h->d_ppm[pb];
 	k2.rot_state = h->d_rotstate; k2.n_windows = h->W; k2.wide = h->cfg.afc_wide ? 1 : 0;
-	HIPCHK(launch_k2(k2, h->n_chan, h->stream));
+	k2.rotT = h->d_rotT[pb]; k2.rotT_stride = (h->n_chan + 63) / 64 * 64; k2.n_chan = h->n_chan;
+	HIPCHK(launch_k2a(k2, h->n_chan, h->stream));
+	HIPCHK(hipEventRecord(h->ev_front[pb], h->stream));
 
+	// ---- s3: sequential CGF phasor recurrence (needs fz of this block; rotT[pb] was last read by apply(b-2))
+	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_front[pb], 0));
+	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_c48free[pb], 0));
+	HIPCHK(launch_k2b(k2, h->n_chan, h->s3));
+	HIPCHK(hipEventRecord(h->ev_phasor[pb], h->s3));
+	// ---- s1: apply the phasors, then FIR-17 + ScatterPLL
+	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_phasor[pb], 0));
+	HIPCHK(launch_k2c(k2, h->n_chan, h->s1));
+	HIPCHK(hipEventRecord(h->ev_c48free[pb], h->s1));
 	// ScatterPLL groups completed inside this block (DSP/DSP.h:95-117): group g completes with sample 5g+4
 	const long long g0 = h->n48 / 5, g1 = (h->n48 + h->L) / 5;
 	K3Params k3;
-	k3.cgf = h->d_cgf; k3.cgf_stride = CGF_HIST + h->L; k3.sym = h->d_sym; k3.sym_stride = h->Gcap; k3.lvl = h->d_lvl;
+	k3.cgf = h->d_cgf; k3.cgf_stride = CGF_HIST + h->L; k3.sym = h->d_sym[pb]; k3.sym_stride = h->Gcap; k3.lvl = h->d_lvl[pb];
 	k3.fir_tap = h->d_firtap; k3.fir_tap_stride = 8 + h->L;
 	memcpy(k3.taps, TAPS_COHERENT, sizeof k3.taps);
 	k3.first_group = g0; k3.first_sample48 = h->n48; k3.n_groups = (int)(g1 - g0);
-	HIPCHK(launch_k3(k3, h->n_chan, h->stream));
+	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_ema[pb], 0)); // sym/lvl[pb] were last read by K4 of block b-2
+	HIPCHK(launch_k3(k3, h->n_chan, h->s1));
+	HIPCHK(hipEventRecord(h->ev_mid[pb], h->s1));
 
+	// ---- s2: sequential PhaseSearchEMA chains
 	K4Params k4;
-	k4.sym = h->d_sym; k4.sym_stride = h->Gcap; k4.bits = h->d_bits; k4.bits_stride = h->words; k4.state = h->d_ema;
+	k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[pb]; k4.bits_stride = h->words;
+	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
+	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag;
 	k4.n_chains = h->n_chains; k4.n_groups = (int)(g1 - g0);
-	HIPCHK(launch_k4(k4, h->stream));
+	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
+	HIPCHK(hipStreamWaitEvent(h->s2, h->ev_mid[pb], 0));
+	if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, h->s2));
+	else HIPCHK(launch_k4_sequential(k4, h->s2));
+	HIPCHK(hipEventRecord(h->ev_ema[pb], h->s2));
 
 	h->out_groups = (int)(g1 - g0); h->out_first_group = g0; h->out_first48 = h->n48;
 	h->n48 += h->L;
@@ -363,22 +458,31 @@ int aisgpu_run(aisgpu_t* h) {
 	return AISGPU_OK;
 }
 
-int aisgpu_sync(aisgpu_t* h) {
-	if (!h) return AISGPU_ERR_ARG;
+static int sync_all(aisgpu_t* h) {
 	HIPCHK(hipStreamSynchronize(h->stream));
+	HIPCHK(hipStreamSynchronize(h->s1));
+	HIPCHK(hipStreamSynchronize(h->s2));
+	HIPCHK(hipStreamSynchronize(h->s3));
 	drain_events(h);
 	return AISGPU_OK;
+}
+
+int aisgpu_sync(aisgpu_t* h) {
+	if (!h) return AISGPU_ERR_ARG;
+	return sync_all(h);
 }
 
 int aisgpu_sync_outputs(aisgpu_t* h) {
 	if (!h) return AISGPU_ERR_ARG;
 	if (h->block_idx == 0) return AISGPU_ERR_STATE;
 	const size_t C = h->n_chan;
-	HIPCHK(hipMemcpyAsync(h->h_bits, h->d_bits, C * 5 * h->words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-	HIPCHK(hipMemcpyAsync(h->h_lvl, h->d_lvl, C * h->Gcap * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-	HIPCHK(hipMemcpyAsync(h->h_ppm, h->d_ppm, C * h->W * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-	HIPCHK(hipStreamSynchronize(h->stream));
-	drain_events(h);
+	const int pb = (int)((h->block_idx - 1) & 1); // buffers of the last block run
+	// s2 is ordered after K4 of that block, which is ordered after everything that produced lvl/ppm
+	HIPCHK(hipMemcpyAsync(h->h_bits, h->d_bits[pb], C * 5 * h->words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s2));
+	HIPCHK(hipMemcpyAsync(h->h_lvl, h->d_lvl[pb], C * h->Gcap * sizeof(float), hipMemcpyDeviceToHost, h->s2));
+	HIPCHK(hipMemcpyAsync(h->h_ppm, h->d_ppm[pb], C * h->W * sizeof(float), hipMemcpyDeviceToHost, h->s2));
+	int rc = sync_all(h);
+	if (rc != AISGPU_OK) return rc;
 	h->have_out = true;
 	return AISGPU_OK;
 }
@@ -404,7 +508,9 @@ long long aisgpu_tap(aisgpu_t* h, int which, int rx, float* dst, long long cap) 
 	const size_t chan = (size_t)rx * 2 + (which & 1);
 	const float2* src;
 	long long n = h->L;
-	if (which < 2) src = h->d_c48 + chan * h->L;
+	const int pb = (int)((h->block_idx - 1) & 1);
+	if (h->block_idx == 0) return -AISGPU_ERR_STATE;
+	if (which < 2) src = h->d_c48[pb] + chan * h->L;
 	else if (which < 4) src = h->d_cgf + chan * (CGF_HIST + h->L) + CGF_HIST;
 	else {
 		// FIR outputs exist for every sample that belongs to a group completed in this block:
@@ -413,7 +519,7 @@ long long aisgpu_tap(aisgpu_t* h, int which, int rx, float* dst, long long cap) 
 		src = h->d_firtap + chan * (8 + h->L) + 4 - carry;
 		n = 5LL * h->out_groups;
 	}
-	if (hipStreamSynchronize(h->stream) != hipSuccess) return -AISGPU_ERR_HIP;
+	if (sync_all(h) != AISGPU_OK) return -AISGPU_ERR_HIP;
 	if (dst) {
 		long long c = n < cap ? n : cap;
 		if (hipMemcpy(dst, src, (size_t)c * sizeof(float2), hipMemcpyDeviceToHost) != hipSuccess) return -AISGPU_ERR_HIP;
@@ -425,8 +531,7 @@ void* aisgpu_stream(aisgpu_t* h) { return h ? (void*)h->stream : nullptr; }
 
 void aisgpu_timing(aisgpu_t* h, int enable) {
 	if (!h) return;
-	hipStreamSynchronize(h->stream);
-	drain_events(h);
+	sync_all(h);
 	h->timing = enable != 0;
 	h->k1_ms = 0;
 	h->k1_launches = 0;
@@ -434,8 +539,7 @@ void aisgpu_timing(aisgpu_t* h, int enable) {
 
 float aisgpu_frontend_ms(aisgpu_t* h, int* launches) {
 	if (!h) return 0;
-	hipStreamSynchronize(h->stream);
-	drain_events(h);
+	sync_all(h);
 	if (launches) *launches = h->k1_launches;
 	return h->k1_launches ? (float)(h->k1_ms / h->k1_launches) : 0.0f;
 }

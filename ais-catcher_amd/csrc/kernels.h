@@ -30,7 +30,8 @@ struct K2Params {
 	int* fz;                  // [n_chan][n_windows]
 	float* ppm;               // [n_chan][n_windows]
 	float2* rot_state;        // [n_chan]
-	int n_windows, wide;
+	float2* rotT; long long rotT_stride; // [L][rotT_stride] derotation phasor per sample, time-major
+	int n_windows, wide, n_chan;
 };
 
 struct K3Params {
@@ -45,18 +46,31 @@ struct K3Params {
 
 struct EmaState { float ma[16]; unsigned bits[16]; int max_idx, rot; int pad[2]; };
 
+constexpr int PS_CHUNK = 1024;   // symbols per time chunk of the chunk-parallel PhaseSearchEMA (multiple of 32)
+constexpr int PS_MAXCHUNKS = 16;
+
 struct K4Params {
 	const float2* sym; long long sym_stride; // chain c row = c * sym_stride
 	uint32_t* bits; long long bits_stride;   // words per chain
-	EmaState* state;
-	int n_chains, n_groups;
+	const EmaState* state_in;                // state before this block
+	EmaState* state_out;                     // state after this block
+	// chunk-parallel scratch, all indexed [chain][chunk][...]
+	uint32_t* words;   // [PS_CHUNK/32][16] output words per possible start index
+	float* ma_start;   // [16] EMA after the warm-up (speculative), chunk > 0
+	float* ma_fin;     // [16] EMA at the end of the chunk
+	unsigned* fin;     // [16] low 4 bits: final max_idx per start index; bits 4..7: last four decisions of hypothesis k
+	int* flag;         // != 0: a speculative warm-up did not reproduce the sequential EMA -> exact fallback runs
+	int n_chains, n_groups, n_chunks, warm;
 };
 
-hipError_t launch_k1(const K1Params& p, int K, bool cu8, int spans, int n_rx, hipStream_t s);
+hipError_t launch_k1(const K1Params& p, int K, bool cu8, int tile96, int depth, int spans, int n_rx, hipStream_t s);
 hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long block_bytes, void* hist, int tail_bytes,
                           int n_rx, hipStream_t s);
-hipError_t launch_k2(const K2Params& p, int n_chan, hipStream_t s);
+hipError_t launch_k2a(const K2Params& p, int n_chan, hipStream_t s);
+hipError_t launch_k2b(const K2Params& p, int n_chan, hipStream_t s); // phasor recurrence
+hipError_t launch_k2c(const K2Params& p, int n_chan, hipStream_t s); // history carry + apply
 hipError_t launch_k3(const K3Params& p, int n_chan, hipStream_t s);
-hipError_t launch_k4(const K4Params& p, hipStream_t s);
+hipError_t launch_k4(const K4Params& p, hipStream_t s);          // chunk-parallel + assemble + (conditional) exact fallback
+hipError_t launch_k4_sequential(const K4Params& p, hipStream_t s); // the plain sequential kernel only
 
 } // namespace aisk

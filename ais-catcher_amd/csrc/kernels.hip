@@ -48,90 +48,158 @@ __device__ __forceinline__ void cic5_dec_chunk(float2 (&v)[2 * NOUT + 4], float2
 // ------------------------------------------------------------------------------------------
 // K1: front end.  RAW -> [CU8 convert] -> K x Downsample2CIC5 -> FDC -> Rotate -> 2 x (DS2 + FilterCIC5)
 //
-// One workgroup (256 threads) streams a span of consecutive tiles of one receiver.  A tile is 256
-// samples at 96 kHz (= 256 << K input samples); every stage keeps the few samples of history it
+// One workgroup (256 threads) streams a span of consecutive tiles of one receiver.  A tile is P
+// samples at 96 kHz (= P << K input samples); every stage keeps the few samples of history it
 // needs in LDS between tiles, so nothing is recomputed inside a span.  A span starts with one
 // warm-up tile whose outputs are discarded: every stage is feed-forward with a dependency cone of
-// < 348 input samples, so after one tile all carried histories are exact.
-// Global loads are fully coalesced float4 (16 B / lane) and are issued one tile ahead into registers
+// < 348 input samples plus 8 samples of carried history per stage (< 1024 inputs in
+// total), so after one tile all carried histories are exact.
+// Global loads are fully coalesced 16 B / lane and are issued one tile ahead into registers
 // (async-stage split), so HBM latency overlaps the LDS ladder of the current tile.
 //
-// LDS chunk layouts: a thread owns C consecutive samples of a stage input; rows of C samples are
-// padded by one 16-byte slot so that the per-thread ds_read_b128 of a 16-lane group covers all 64
-// banks (row stride 144/80/48 B -> conflict free).
+// LDS "levels": level s holds the n_s = TILE_IN >> s samples that enter CIC stage s+1.
+//   * chunked levels (n_s / 256 = C in {16, 8, 4} samples per thread): thread t owns row t of C samples;
+//     rows are padded by one 16-byte slot (row strides 144 / 80 / 48 B) so the per-thread 16-byte LDS
+//     reads of a lane group cover all banks; the last 8 samples of the previous tile live in a
+//     separate 8-entry history array (row -1).
+//   * small levels (n_s <= 512): contiguous, 8 leading history slots, thread t produces output t.
 // ------------------------------------------------------------------------------------------
 constexpr int K1_THREADS = 256;
-constexpr int R0 = 18, R1 = 10, R2 = 6; // padded row lengths (float2) for chunk sizes 16, 8, 4
+constexpr int R16 = 18, R8 = 10, R4 = 6; // padded row lengths (float2) for chunk sizes 16, 8, 4
 
-struct __align__(16) K1Smem {
-	float2 x0[256 * R0]; // stage-1 input (body). x2 aliases the front of it once stage 1 is done.
-	float2 x1[256 * R1]; // stage-2 input
-	float2 x3[8 + 512];  // stage-4 input, 8 leading history samples
-	float2 x4[8 + 256];  // 96 kHz (FDC input)
-	float2 x5[2][8 + 256]; // rotated up/down (DS2_a/b input)
-	float2 x6[2][8 + 128]; // FilterCIC5 input
-	float2 h0[8], h1[8], h2[8]; // last 8 samples of x0 / x1 / x2 of the previous tile
+template <int K, int P>
+struct K1Cfg {
+	static constexpr int TILE_IN = P << K;
+	static constexpr int CE = TILE_IN / K1_THREADS; // samples per thread of the entry level
+	static_assert(TILE_IN % K1_THREADS == 0 || TILE_IN < K1_THREADS, "tile");
+	static constexpr bool has16 = CE >= 16, has8 = CE >= 8, has4 = CE >= 4;
+	static_assert(CE <= 16, "tile too large for the LDS layout");
+	static constexpr int nbig = (has16 ? 1 : 0) + (has8 ? 1 : 0) + (has4 ? 1 : 0);
+	static constexpr int first_small = nbig; // first level stored contiguously
+	static constexpr int n(int s) { return TILE_IN >> s; }
+	// offsets in float2 units
+	static constexpr int off16 = 0;
+	static constexpr int size16 = has16 ? K1_THREADS * R16 : 0;
+	static constexpr int off8 = off16 + size16;
+	static constexpr int size8 = has8 ? K1_THREADS * R8 : 0;
+	static constexpr int size4 = (has4 && !has16) ? K1_THREADS * R4 : 0; // aliases the dead 16-level otherwise
+	static constexpr int off4 = has16 ? off16 : off8 + size8;
+	static constexpr int off_small0 = off8 + size8 + size4;
+	static constexpr int small_off(int s) { // levels first_small .. K (level K = 96 kHz)
+		int o = off_small0;
+		for (int q = first_small; q < s; q++) o += 8 + n(q);
+		return o;
+	}
+	static constexpr int off_x5 = small_off(K + 1);           // 2 x (8 + P): rotated up / down
+	static constexpr int off_x6 = off_x5 + 2 * (8 + P);       // 2 x (8 + P/2): FilterCIC5 input
+	static constexpr int off_h = off_x6 + 2 * (8 + P / 2);    // 3 x 8: histories of the chunked levels
+	static constexpr int total = off_h + 24;
+	static constexpr int bytes = total * 8;
 };
 
-template <int K, bool CU8>
+// LDS is addressed in 16-byte units (float4 = two complex samples) wherever a thread moves more than one
+// sample, so that every such access is a single ds_read_b128 / ds_write_b128 (the padded row strides are
+// only conflict free for the 128-bit lane grouping).
+// 16-byte LDS load whose four components are all kept live, so the compiler cannot narrow it and re-pair
+// the halves into ds_read2_b64 (whose 16-lane grouping conflicts on the padded rows: measured 30 % of the
+// LDS cycles as bank conflicts before this)
+__device__ __forceinline__ float4 lds4(const float4* p) {
+	float4 v = *p;
+	asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+	return v;
+}
+__device__ __forceinline__ float2 lo(float4 v) { return make_float2(v.x, v.y); }
+__device__ __forceinline__ float2 hi(float4 v) { return make_float2(v.z, v.w); }
+__device__ __forceinline__ float4 pack(float2 a, float2 b) { return make_float4(a.x, a.y, b.x, b.y); }
+
+// one decimating CIC5 output from in[2t-5 .. 2t] of a contiguous level with 8 leading history slots
+// (lvl4 = level base in float4 units: sample i lives at float2 index 8 + i)
+__device__ __forceinline__ float2 cic5_small(const float4* lvl4, int t) {
+	float2 v[6];
+	const float4 c0 = lds4(lvl4 + t + 1), c1 = lds4(lvl4 + t + 2), c2 = lds4(lvl4 + t + 3), c3 = lds4(lvl4 + t + 4); // samples 2t-6 .. 2t+1
+	v[0] = hi(c0);
+	v[1] = lo(c1); v[2] = hi(c1);
+	v[3] = lo(c2); v[4] = hi(c2);
+	v[5] = lo(c3);
+	float2 o[1];
+	cic5_dec_chunk<1>(v, o);
+	return o[0];
+}
+
+// D = prefetch depth in tiles: D * TILE bytes per workgroup are in flight, which is what covers the HBM
+// latency (measured: with one tile in flight the kernel is latency bound at ~50 % of peak).
+template <int K, int P, int D, bool CU8>
 __global__ __launch_bounds__(K1_THREADS) void k1_frontend(K1Params p) {
+	using C = K1Cfg<K, P>;
 	static_assert(K >= 1 && K <= 4, "ladder depth");
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	K1Smem& sm = *reinterpret_cast<K1Smem*>(smem_raw);
-	float2* x2 = sm.x0; // alias: x0 is dead after stage 1 (its tail lives in h0)
+	// Other kernels of the pipeline run concurrently on other streams; the bandwidth-bound front end gets a
+	// higher issue priority than the throughput kernels behind it (only the tiny phasor kernel is higher).
+	__builtin_amdgcn_s_setprio(2);
+	extern __shared__ __attribute__((aligned(16))) float4 smem4[];
+	float2* const sm = reinterpret_cast<float2*>(smem4);
+	float4* const l16 = smem4 + C::off16 / 2; // rows of R16/2 = 9 float4
+	float4* const l8 = smem4 + C::off8 / 2;   // rows of R8/2 = 5 float4
+	float4* const l4 = smem4 + C::off4 / 2;   // rows of R4/2 = 3 float4
+	float4* const h16 = smem4 + C::off_h / 2; // 4 float4 = last 8 samples
+	float4* const h8 = h16 + 4;
+	float4* const h4 = h16 + 8;
+	constexpr int W16 = R16 / 2, W8 = R8 / 2, W4 = R4 / 2;
 
 	const int t = threadIdx.x;
 	const int rx = blockIdx.y;
 	const int span = blockIdx.x;
-	constexpr int TILE_IN = 256 << K; // input samples per tile
+	constexpr int TILE_IN = C::TILE_IN;
 
-	// zero all carried histories (true zero state at stream start; warm-up overwrites them otherwise)
+	// zero all carried histories (true zero state at stream start; the warm-up tile overwrites them otherwise)
 	if (t < 8) {
-		sm.h0[t] = sm.h1[t] = sm.h2[t] = make_float2(0.f, 0.f);
-		sm.x3[t] = sm.x4[t] = make_float2(0.f, 0.f);
-		sm.x5[0][t] = sm.x5[1][t] = sm.x6[0][t] = sm.x6[1][t] = make_float2(0.f, 0.f);
+		sm[C::off_h + t] = sm[C::off_h + 8 + t] = sm[C::off_h + 16 + t] = make_float2(0.f, 0.f);
+#pragma unroll
+		for (int s = C::first_small; s <= K; s++) sm[C::small_off(s) + t] = make_float2(0.f, 0.f);
+		sm[C::off_x5 + t] = sm[C::off_x5 + 8 + P + t] = make_float2(0.f, 0.f);
+		sm[C::off_x6 + t] = sm[C::off_x6 + 8 + P / 2 + t] = make_float2(0.f, 0.f);
 	}
 
 	const int tile_first = span * p.tiles_per_span - 1; // warm-up tile
 	int tile_last = tile_first + p.tiles_per_span;        // inclusive
 	if (tile_last >= p.tiles_per_block) tile_last = p.tiles_per_block - 1;
 
-	// ---- register prefetch of one tile: NV float4 (CF32) or uint4 (CU8) per thread, coalesced
-	constexpr int NV = CU8 ? ((TILE_IN * 2) / (256 * 16) > 0 ? (TILE_IN * 2) / (256 * 16) : 1) : (TILE_IN * 8) / (256 * 16);
-	uint4 pre[NV];
-	auto prefetch = [&](int tile) {
+	// ---- register prefetch: 16 bytes per thread per slot, coalesced; D tiles deep
+	constexpr int TILE_BYTES = TILE_IN * (CU8 ? 2 : 8);
+	constexpr int NV = TILE_BYTES >= K1_THREADS * 16 ? TILE_BYTES / (K1_THREADS * 16) : 1;
+	constexpr bool PARTIAL = TILE_BYTES < K1_THREADS * 16; // not every thread has a 16-byte piece
+	uint4 pre[D][NV];
+	auto prefetch = [&](uint4 (&r)[NV], int tile) {
 		// tile -1 lives in the history buffer (last TILE_IN samples of the previous block)
 		const unsigned char* base;
-		if (tile < 0) base = (const unsigned char*)p.hist + (size_t)rx * TILE_IN * (CU8 ? 2 : 8);
+		if (tile < 0) base = (const unsigned char*)p.hist + (size_t)rx * TILE_BYTES;
 		else base = (const unsigned char*)p.in + ((size_t)rx * p.in_stride + (size_t)tile * TILE_IN) * (CU8 ? 2 : 8);
 		const uint4* src = (const uint4*)base;
 #pragma unroll
 		for (int e = 0; e < NV; e++) {
-			if (CU8 && (TILE_IN * 2) < 256 * 16) { // tiny CU8 tiles (K small): not every thread loads
-				pre[e] = (t * 16 < TILE_IN * 2) ? src[t] : make_uint4(0, 0, 0, 0);
-			} else pre[e] = src[e * 256 + t];
+			if (PARTIAL) r[e] = (t * 16 < TILE_BYTES) ? src[t] : make_uint4(0, 0, 0, 0);
+			else r[e] = src[e * K1_THREADS + t];
 		}
 	};
-	// first-stage buffer the tile enters at (K = 4: x0, 3: x1, 2: x2, 1: x3)
-	auto store_sample_pair = [&](int s, float4 v) { // s even sample index inside the tile
-		if (K == 4) *reinterpret_cast<float4*>(&sm.x0[(s >> 4) * R0 + (s & 15)]) = v;
-		else if (K == 3) *reinterpret_cast<float4*>(&sm.x1[(s >> 3) * R1 + (s & 7)]) = v;
-		else if (K == 2) *reinterpret_cast<float4*>(&x2[(s >> 2) * R2 + (s & 3)]) = v;
-		else *reinterpret_cast<float4*>(&sm.x3[8 + s]) = v;
+	auto store_sample_pair = [&](int s, float4 v) { // s: even sample index inside the tile -> entry level
+		if (C::CE == 16) l16[(s >> 4) * W16 + ((s & 15) >> 1)] = v;
+		else if (C::CE == 8) l8[(s >> 3) * W8 + ((s & 7) >> 1)] = v;
+		else if (C::CE == 4) l4[(s >> 2) * W4 + ((s & 3) >> 1)] = v;
+		else smem4[C::small_off(0) / 2 + 4 + (s >> 1)] = v;
 	};
-	auto stage_in = [&]() {
+	auto stage_in = [&](uint4 (&r)[NV]) {
 		if (!CU8) {
 #pragma unroll
 			for (int e = 0; e < NV; e++) {
-				int s = (e * 256 + t) * 2;
-				store_sample_pair(s, *reinterpret_cast<float4*>(&pre[e]));
+				const int s = (e * K1_THREADS + t) * 2;
+				if (PARTIAL && s >= TILE_IN) continue;
+				store_sample_pair(s, make_float4(__uint_as_float(r[e].x), __uint_as_float(r[e].y), __uint_as_float(r[e].z), __uint_as_float(r[e].w)));
 			}
 		} else {
 #pragma unroll
 			for (int e = 0; e < NV; e++) {
-				int s = (e * 256 + t) * 8; // 16 bytes = 8 CU8 samples
-				if ((TILE_IN * 2) < 256 * 16 && s >= TILE_IN) continue;
-				const unsigned w[4] = { pre[e].x, pre[e].y, pre[e].z, pre[e].w };
+				const int s = (e * K1_THREADS + t) * 8; // 16 bytes = 8 CU8 samples
+				if (PARTIAL && s >= TILE_IN) continue;
+				const unsigned w[4] = { r[e].x, r[e].y, r[e].z, r[e].w };
 #pragma unroll
 				for (int q = 0; q < 4; q++) { // Utilities/Convert.cpp:255-264: ((int)u - 128) / 128.0f (exact)
 					float4 v;
@@ -145,163 +213,163 @@ __global__ __launch_bounds__(K1_THREADS) void k1_frontend(K1Params p) {
 		}
 	};
 
-	prefetch(tile_first);
-
-	for (int tile = tile_first; tile <= tile_last; tile++) {
-		__syncthreads(); // previous tile fully consumed (x0/x2 alias, x6 reads, tail copies)
-		stage_in();
+	auto process_tile = [&](int tile, uint4 (&regs)[NV]) {
+		__syncthreads(); // previous tile fully consumed (aliased level, x6 reads, tail copies)
+		stage_in(regs);
 		__syncthreads();
-		if (tile < tile_last) prefetch(tile + 1); // in flight during the whole ladder
+		// The Rotate phasor of this tile is fetched BEFORE the prefetch is issued: vector-memory loads retire
+		// in order, so a load issued after the prefetch would force `s_waitcnt vmcnt(0)` at its use in the
+		// middle of the ladder and drain the prefetch there (that was 65 % of the kernel's wave time).
+		// (unconditional for the same reason: no control flow between the loads and their waits)
+		const float2 rotv = p.rot[(size_t)ROT_HIST + (long long)tile * P + (t & (P - 1))]; // ROT_HIST leading entries: previous block's tail
+		// unconditional (clamped past the end of the span) so that the number of loads in flight is static and
+		// the compiler can wait for the phasor alone (`vmcnt(NV)`) instead of draining everything
+		prefetch(regs, tile + D <= tile_last ? tile + D : tile_last);
 
-		// ---- stage 1: x0 (4096) -> x1 (2048); thread owns x0[16t..16t+15], needs x0[16t-5..16t+14]
-		if (K >= 4) {
+		// ---- chunk 16 -> 8: thread owns x[16t..16t+15], needs x[16t-5..16t+14], makes 8 outputs
+		if (C::has16) {
 			float2 v[20];
-			const float4* own = reinterpret_cast<const float4*>(&sm.x0[t * R0]);
-			const float4* halo = (t == 0) ? reinterpret_cast<const float4*>(&sm.h0[2])
-			                              : reinterpret_cast<const float4*>(&sm.x0[(t - 1) * R0 + 10]);
+			const float4* own = l16 + t * W16;
+			const float4* halo = (t == 0) ? h16 + 1 : l16 + (t - 1) * W16 + 5; // samples 16t-6 .. 16t-1
 			float4 hv[3], ov[8];
 #pragma unroll
-			for (int e = 0; e < 3; e++) hv[e] = halo[e];
+			for (int e = 0; e < 3; e++) hv[e] = lds4(halo + e);
 #pragma unroll
-			for (int e = 0; e < 8; e++) ov[e] = own[e];
-			// v[i] = x0[16t-5+i]
-			v[0] = make_float2(hv[0].z, hv[0].w);
-			v[1] = make_float2(hv[1].x, hv[1].y); v[2] = make_float2(hv[1].z, hv[1].w);
-			v[3] = make_float2(hv[2].x, hv[2].y); v[4] = make_float2(hv[2].z, hv[2].w);
+			for (int e = 0; e < 8; e++) ov[e] = lds4(own + e);
+			v[0] = hi(hv[0]);
+			v[1] = lo(hv[1]); v[2] = hi(hv[1]);
+			v[3] = lo(hv[2]); v[4] = hi(hv[2]);
 #pragma unroll
-			for (int e = 0; e < 7; e++) { v[5 + 2 * e] = make_float2(ov[e].x, ov[e].y); v[6 + 2 * e] = make_float2(ov[e].z, ov[e].w); }
-			v[19] = make_float2(ov[7].x, ov[7].y);
+			for (int e = 0; e < 7; e++) { v[5 + 2 * e] = lo(ov[e]); v[6 + 2 * e] = hi(ov[e]); }
+			v[19] = lo(ov[7]);
 			float2 o[8];
 			cic5_dec_chunk<8>(v, o);
-			float4* dst = reinterpret_cast<float4*>(&sm.x1[t * R1]);
+			float4* dst = l8 + t * W8;
 #pragma unroll
-			for (int e = 0; e < 4; e++) dst[e] = make_float4(o[2 * e].x, o[2 * e].y, o[2 * e + 1].x, o[2 * e + 1].y);
+			for (int e = 0; e < 4; e++) dst[e] = pack(o[2 * e], o[2 * e + 1]);
 			__syncthreads();
-			if (t == 255) { // tail of x0 for the next tile (x0 body is dead from here on)
+			if (t == K1_THREADS - 1) { // tail for the next tile (this level's body is dead from here on)
 #pragma unroll
-				for (int e = 0; e < 4; e++) reinterpret_cast<float4*>(sm.h0)[e] = ov[4 + e];
+				for (int e = 0; e < 4; e++) h16[e] = ov[4 + e];
 			}
 		}
-		// ---- stage 2: x1 (2048) -> x2 (1024); thread owns x1[8t..8t+7], needs x1[8t-5..8t+6]
-		if (K >= 3) {
+		// ---- chunk 8 -> 4: thread owns x[8t..8t+7], needs x[8t-5..8t+6], makes 4 outputs
+		if (C::has8) {
 			float2 v[12];
-			const float4* own = reinterpret_cast<const float4*>(&sm.x1[t * R1]);
-			const float4* halo = (t == 0) ? reinterpret_cast<const float4*>(&sm.h1[2])
-			                              : reinterpret_cast<const float4*>(&sm.x1[(t - 1) * R1 + 2]);
+			const float4* own = l8 + t * W8;
+			const float4* halo = (t == 0) ? h8 + 1 : l8 + (t - 1) * W8 + 1; // samples 8t-6 .. 8t-1
 			float4 hv[3], ov[4];
 #pragma unroll
-			for (int e = 0; e < 3; e++) hv[e] = halo[e];
+			for (int e = 0; e < 3; e++) hv[e] = lds4(halo + e);
 #pragma unroll
-			for (int e = 0; e < 4; e++) ov[e] = own[e];
-			v[0] = make_float2(hv[0].z, hv[0].w);
-			v[1] = make_float2(hv[1].x, hv[1].y); v[2] = make_float2(hv[1].z, hv[1].w);
-			v[3] = make_float2(hv[2].x, hv[2].y); v[4] = make_float2(hv[2].z, hv[2].w);
+			for (int e = 0; e < 4; e++) ov[e] = lds4(own + e);
+			v[0] = hi(hv[0]);
+			v[1] = lo(hv[1]); v[2] = hi(hv[1]);
+			v[3] = lo(hv[2]); v[4] = hi(hv[2]);
 #pragma unroll
-			for (int e = 0; e < 3; e++) { v[5 + 2 * e] = make_float2(ov[e].x, ov[e].y); v[6 + 2 * e] = make_float2(ov[e].z, ov[e].w); }
-			v[11] = make_float2(ov[3].x, ov[3].y);
+			for (int e = 0; e < 3; e++) { v[5 + 2 * e] = lo(ov[e]); v[6 + 2 * e] = hi(ov[e]); }
+			v[11] = lo(ov[3]);
 			float2 o[4];
 			cic5_dec_chunk<4>(v, o);
-			float4* dst = reinterpret_cast<float4*>(&x2[t * R2]);
-			dst[0] = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
-			dst[1] = make_float4(o[2].x, o[2].y, o[3].x, o[3].y);
+			float4* dst = l4 + t * W4;
+			dst[0] = pack(o[0], o[1]);
+			dst[1] = pack(o[2], o[3]);
 			__syncthreads();
-			if (t == 255) {
+			if (t == K1_THREADS - 1) {
 #pragma unroll
-				for (int e = 0; e < 4; e++) reinterpret_cast<float4*>(sm.h1)[e] = ov[e];
+				for (int e = 0; e < 4; e++) h8[e] = ov[e];
 			}
 		}
-		// ---- stage 3: x2 (1024) -> x3 (512); thread owns x2[4t..4t+3], needs x2[4t-5..4t+2]
-		if (K >= 2) {
+		// ---- chunk 4 -> contiguous: thread owns x[4t..4t+3], needs x[4t-5..4t+2], makes 2 outputs
+		if (C::has4) {
 			float2 v[8];
-			// x2[4t-6..4t-5], x2[4t-4..4t-1], own x2[4t..4t+3]
-			const float4* a = (t >= 2) ? reinterpret_cast<const float4*>(&x2[(t - 2) * R2 + 2])
-			                           : reinterpret_cast<const float4*>(&sm.h2[2 + 4 * t]);
-			const float4* b = (t >= 1) ? reinterpret_cast<const float4*>(&x2[(t - 1) * R2])
-			                           : reinterpret_cast<const float4*>(&sm.h2[4]);
-			const float4* own = reinterpret_cast<const float4*>(&x2[t * R2]);
-			float4 av = a[0], b0 = b[0], b1 = b[1], o0 = own[0], o1 = own[1];
-			v[0] = make_float2(av.z, av.w);
-			v[1] = make_float2(b0.x, b0.y); v[2] = make_float2(b0.z, b0.w);
-			v[3] = make_float2(b1.x, b1.y); v[4] = make_float2(b1.z, b1.w);
-			v[5] = make_float2(o0.x, o0.y); v[6] = make_float2(o0.z, o0.w);
-			v[7] = make_float2(o1.x, o1.y);
+			const float4* a = (t >= 2) ? l4 + (t - 2) * W4 + 1 : h4 + 1 + 2 * t; // samples 4t-6, 4t-5
+			const float4* b = (t >= 1) ? l4 + (t - 1) * W4 : h4 + 2;             // samples 4t-4 .. 4t-1
+			const float4* own = l4 + t * W4;
+			const float4 av = lds4(a), b0 = lds4(b), b1 = lds4(b + 1), o0 = lds4(own), o1 = lds4(own + 1);
+			v[0] = hi(av);
+			v[1] = lo(b0); v[2] = hi(b0);
+			v[3] = lo(b1); v[4] = hi(b1);
+			v[5] = lo(o0); v[6] = hi(o0);
+			v[7] = lo(o1);
 			float2 o[2];
 			cic5_dec_chunk<2>(v, o);
-			*reinterpret_cast<float4*>(&sm.x3[8 + 2 * t]) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+			smem4[C::small_off(C::first_small) / 2 + 4 + t] = pack(o[0], o[1]);
 			__syncthreads();
-			if (t == 255) { // x2[1016..1023]
-				reinterpret_cast<float4*>(sm.h2)[0] = b0; reinterpret_cast<float4*>(sm.h2)[1] = b1;
-				reinterpret_cast<float4*>(sm.h2)[2] = o0; reinterpret_cast<float4*>(sm.h2)[3] = o1;
-			}
+			if (t == K1_THREADS - 1) { h4[0] = b0; h4[1] = b1; h4[2] = o0; h4[3] = o1; } // last 8 samples of this level
 		}
-		// ---- stage 4: x3 (512) -> x4 (256 @ 96 kHz); thread t: x3[2t-5..2t]
-		{
-			float2 v[6];
-			const float4* src = reinterpret_cast<const float4*>(&sm.x3[8 + 2 * t - 6]);
-			float4 c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];
-			v[0] = make_float2(c0.z, c0.w);
-			v[1] = make_float2(c1.x, c1.y); v[2] = make_float2(c1.z, c1.w);
-			v[3] = make_float2(c2.x, c2.y); v[4] = make_float2(c2.z, c2.w);
-			v[5] = make_float2(c3.x, c3.y);
-			float2 o[1];
-			cic5_dec_chunk<1>(v, o);
-			sm.x4[8 + t] = o[0];
+		// ---- remaining stages on contiguous levels: thread t < n/2 makes output t from in[2t-5..2t]
+#pragma unroll
+		for (int s = C::first_small; s < K; s++) {
+			if (t < C::n(s + 1)) sm[C::small_off(s + 1) + 8 + t] = cic5_small(smem4 + C::small_off(s) / 2, t);
+			__syncthreads();
 		}
-		__syncthreads();
+		float2* const x4 = sm + C::small_off(K);
+		float2* const x5 = sm + C::off_x5;
+		float2* const x6 = sm + C::off_x6;
 		// ---- FDC (DSP.cpp:283-293) + Rotate (DSP.cpp:296-316) at 96 kHz
-		{
-			float2 xm2 = sm.x4[8 + t - 2], xm1 = sm.x4[8 + t - 1], x = sm.x4[8 + t];
+		if (t < P) {
+			const float2 xm2 = x4[8 + t - 2], xm1 = x4[8 + t - 1], x = x4[8 + t];
 			float2 y = x;
 			if (p.has_fdc) {
 				// alpha * (h1 + x) + h2 * beta, evaluated componentwise: add, mul, mul, add
-				float2 s = cadd(xm2, x);
-				y = make_float2(p.alpha * s.x + xm1.x * p.beta, p.alpha * s.y + xm1.y * p.beta);
+				const float2 s2 = cadd(xm2, x);
+				y = make_float2(p.alpha * s2.x + xm1.x * p.beta, p.alpha * s2.y + xm1.y * p.beta);
 			}
-			float2 rot = p.rot[(size_t)(tile + 1) * 256 + t]; // table has 256 leading entries (previous block's tail)
-			float RR = y.x * rot.x, II = y.y * rot.y, RI = y.x * rot.y, IR = y.y * rot.x;
-			sm.x5[0][8 + t] = make_float2(RR - II, IR + RI); // up   -> channel A
-			sm.x5[1][8 + t] = make_float2(RR + II, IR - RI); // down -> channel B
+			const float2 rot = rotv;
+			const float RR = y.x * rot.x, II = y.y * rot.y, RI = y.x * rot.y, IR = y.y * rot.x;
+			x5[8 + t] = make_float2(RR - II, IR + RI);         // up   -> channel A
+			x5[8 + P + 8 + t] = make_float2(RR + II, IR - RI); // down -> channel B
 		}
 		__syncthreads();
-		// ---- DS2_a / DS2_b (96k -> 48k), waves 0-1: channel A, waves 2-3: channel B
-		{
-			const int ch = t >> 7, j = t & 127;
-			float2 v[6];
-			const float4* src = reinterpret_cast<const float4*>(&sm.x5[ch][8 + 2 * j - 6]);
-			float4 c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];
-			v[0] = make_float2(c0.z, c0.w);
-			v[1] = make_float2(c1.x, c1.y); v[2] = make_float2(c1.z, c1.w);
-			v[3] = make_float2(c2.x, c2.y); v[4] = make_float2(c2.z, c2.w);
-			v[5] = make_float2(c3.x, c3.y);
-			float2 o[1];
-			cic5_dec_chunk<1>(v, o);
-			sm.x6[ch][8 + j] = o[0];
+		// ---- DS2_a / DS2_b (96k -> 48k): first half of the active threads channel A, second half channel B
+		if (t < P) {
+			const int ch = t / (P / 2), j = t % (P / 2);
+			x6[ch * (8 + P / 2) + 8 + j] = cic5_small(smem4 + (C::off_x5 + ch * (8 + P)) / 2, j);
 		}
 		__syncthreads();
 		// ---- FilterCIC5 (DSP.cpp:132-157): same binomial filter, no decimation -> 48 kHz output
-		{
-			const int ch = t >> 7, j = t & 127;
+		if (t < P) {
+			const int ch = t / (P / 2), j = t % (P / 2);
+			const float2* src = x6 + ch * (8 + P / 2) + 8 + j - 5;
 			float2 v[6];
 #pragma unroll
-			for (int e = 0; e < 6; e++) v[e] = sm.x6[ch][8 + j - 5 + e];
+			for (int e = 0; e < 6; e++) v[e] = src[e];
 #pragma unroll
 			for (int lvl = 0; lvl < 5; lvl++) {
 #pragma unroll
 				for (int i = 0; i < 5 - lvl; i++) v[i] = cadd(v[i + 1], v[i]);
 			}
-			if (tile >= 0 && tile > tile_first) {
-				float2* dst = p.c48 + ((size_t)rx * 2 + ch) * p.c48_stride + (size_t)tile * 128 + j;
+			if (tile > tile_first) {
+				float2* dst = p.c48 + ((size_t)rx * 2 + ch) * p.c48_stride + (size_t)tile * (P / 2) + j;
 				*dst = make_float2(v[0].x * 0.03125f, v[0].y * 0.03125f);
 			}
 		}
 		__syncthreads();
-		// ---- carry the tails of the small in-buffer-history stages to their leading slots
-		if (t < 8) sm.x3[t] = sm.x3[512 + t];
-		else if (t < 16) sm.x4[t - 8] = sm.x4[256 + t - 8];
-		else if (t < 24) sm.x5[0][t - 16] = sm.x5[0][256 + t - 16];
-		else if (t < 32) sm.x5[1][t - 24] = sm.x5[1][256 + t - 24];
-		else if (t < 40) sm.x6[0][t - 32] = sm.x6[0][128 + t - 32];
-		else if (t < 48) sm.x6[1][t - 40] = sm.x6[1][128 + t - 40];
+		// ---- carry the tails of the contiguous levels to their leading history slots
+		{
+			constexpr int NSMALL = K - C::first_small + 1;
+			const int grp = t >> 3, e = t & 7;
+			if (grp < NSMALL) {
+				const int s = C::first_small + grp;
+				int off = C::off_small0;
+				for (int q = C::first_small; q < s; q++) off += 8 + (C::TILE_IN >> q);
+				const int cnt = C::TILE_IN >> s;
+				sm[off + e] = sm[off + cnt + e];
+			} else if (grp == NSMALL) x5[e] = x5[P + e];
+			else if (grp == NSMALL + 1) x5[8 + P + e] = x5[8 + P + P + e];
+			else if (grp == NSMALL + 2) x6[e] = x6[P / 2 + e];
+			else if (grp == NSMALL + 3) x6[8 + P / 2 + e] = x6[8 + P / 2 + P / 2 + e];
+		}
+	};
+
+#pragma unroll
+	for (int d = 0; d < D; d++)
+		if (tile_first + d <= tile_last) prefetch(pre[d], tile_first + d);
+	for (int tile = tile_first; tile <= tile_last; tile += D) {
+#pragma unroll
+		for (int d = 0; d < D; d++)
+			if (tile + d <= tile_last) process_tile(tile + d, pre[d]);
 	}
 }
 
@@ -337,6 +405,7 @@ __global__ __launch_bounds__(64) void k2_cgf_analyse(K2Params p) {
 	__shared__ __attribute__((aligned(16))) float mag[520]; // mag[q] = |X[(q + 256) % 512]|, q in [0, 512]
 	__shared__ __attribute__((aligned(16))) float cs[512];
 
+	__builtin_amdgcn_s_setprio(1);
 	const int lane = threadIdx.x;
 	const int w = blockIdx.x, chan = blockIdx.y; // chan = rx * 2 + ch
 	const float2* x = p.c48 + (size_t)chan * p.c48_stride + (size_t)w * 512;
@@ -418,64 +487,84 @@ __global__ __launch_bounds__(64) void k2_cgf_analyse(K2Params p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K2b: CGF derotation (DSP/DSP.cpp:457-466).  rot *= rot_step; output[i] *= rot per sample, rot
-// renormalised per window and carried across windows -> a strictly sequential float recurrence per
-// (receiver, channel).  One wave per chain: all 64 lanes run the recurrence redundantly (no
-// divergence, no LDS), a DPP wave shift hands the phasor of step k to lane 63-k, which applies it to
-// its own sample, so global traffic stays fully coalesced (8 B / lane).
+// K2b: CGF derotation phasors (DSP/DSP.cpp:457-466).  rot *= rot_step per sample, renormalised per
+// window and carried across windows and blocks: a strictly sequential float recurrence of 24,576 steps
+// per (receiver, channel) and block -- no re-association is allowed, so time cannot be parallelised.
+// What CAN be done is to make the recurrence cost almost no issue slots: one LANE per chain (64
+// chains per wave), 3 packed VALU ops per step (P = (rx*sx, rx*sy), Q = (ry*-sy, ry*sx), rot' = P + Q;
+// x*-y == -(x*y) exactly, so this is the reference's (ac - bd, ad + bc) bit for bit), and the phasor of
+// every step is stored time-major (rotT[n][chain]) so the 64 lanes write 512 contiguous bytes.
+// The kernel is latency bound (~20 cycles per step) but occupies only n_chan/64 waves, so it hides
+// behind the bandwidth-bound kernels of the next block; K2c applies the phasors in parallel.
 // ------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(64) void k2_cgf_derotate(K2Params p) {
+__global__ __launch_bounds__(64) void k2_cgf_phasor(K2Params p) {
 	const int lane = threadIdx.x;
-	const int chan = blockIdx.x;
-	const float2* x = p.c48 + (size_t)chan * p.c48_stride;
-	float2* y = p.cgf + (size_t)chan * p.cgf_stride; // row has CGF_HIST leading history samples
+	const int chan_raw = blockIdx.x * 64 + lane;
+	const bool live = chan_raw < p.n_chan;
+	const int chan = live ? chan_raw : p.n_chan - 1;
 	const int L = p.n_windows * 512;
 
-	// carry the tail of the previous block (FIR-17 history + partial ScatterPLL group) to the front
-	if (lane < CGF_HIST) {
-		float2 tv = y[L + lane];
-		y[lane] = tv;
-	}
+	// this handful of waves is the longest dependency chain of the whole pipeline: always issue first
+	__builtin_amdgcn_s_setprio(3);
+	(void)L;
 	const float2 r0 = p.rot_state[chan];
-	// `cur` is at the same time the recurrence variable (lane 0) and a 64-deep history (lane l holds the
-	// phasor of l steps ago): each step computes rot*rot_step in every lane -- only lane 0's result is
-	// meaningful -- and a DPP wave_shr:1 move then refills lanes 1..63 from the previous register while
-	// lane 0 (no source lane) keeps the new phasor.  5 VALU ops per sample, no LDS, no select.
-	// The product is 3 packed ops: P = (rx*sx, rx*sy), Q = (ry*-sy, ry*sx), rot' = P + Q; x*-y == -(x*y)
-	// exactly, so this is the reference's (ac - bd, ad + bc) bit for bit (DSP/DSP.cpp:460-463).
 	v2f cur = { r0.x, r0.y };
-	const int rl = 63 - lane; // after 64 steps lane l holds the phasor of step 63-l of the chunk
-	float2 xv = x[rl];        // sample of the first 64-chunk, prefetched
+	// wave-uniform row base + lane: the store addresses are SGPR base + constant lane offset
+	float2* const out = p.rotT + (size_t)blockIdx.x * 64; // padded columns exist for dead lanes
+	const size_t stride = p.rotT_stride;
 	for (int w = 0; w < p.n_windows; w++) {
 		const int fz = p.fz[(size_t)chan * p.n_windows + w];
 		const float2 stp = p.step_table[fz + 205];
 		const v2f st = { stp.x, stp.y }, st_sw = { -stp.y, stp.x };
-#pragma unroll 1
-		for (int c = 0; c < 8; c++) {
-			const int base = w * 512 + c * 64;
-			float2 xn = xv;
-			if (base + 64 < L) xn = x[base + 64 + rl]; // next chunk in flight during the 64 serial steps
-#pragma unroll
-			for (int k = 0; k < 64; k++) {
-				const v2f P = cur.xx * st;
-				const v2f Q = cur.yy * st_sw;
-				v2f nw = P + Q;
-				nw.x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(nw.x), __float_as_int(cur.x), 0x138, 0xF, 0xF, false));
-				nw.y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(nw.y), __float_as_int(cur.y), 0x138, 0xF, 0xF, false));
-				cur = nw;
-			}
-			y[CGF_HIST + base + rl] = cmul(xv, make_float2(cur.x, cur.y)); // output[i] *= rot
-			xv = xn;
+		float2* o = out + (size_t)w * 512 * stride;
+#pragma unroll 8
+		for (int k = 0; k < 512; k++) {
+			cur = cur.xx * st + cur.yy * st_sw; // rot *= rot_step
+			o[lane] = make_float2(cur.x, cur.y);
+			o += stride;
 		}
-		// rot /= std::abs(rot) once per window (DSP.cpp:465); only lane 0 carries the chain
-		const float a = hypot_ref(cur.x, cur.y);
-		const float nx = __fdiv_rn(cur.x, a), ny = __fdiv_rn(cur.y, a);
-		cur.x = lane == 0 ? nx : cur.x;
-		cur.y = lane == 0 ? ny : cur.y;
+		const float a = hypot_ref(cur.x, cur.y); // rot /= std::abs(rot), once per window (DSP.cpp:465)
+		cur.x = __fdiv_rn(cur.x, a);
+		cur.y = __fdiv_rn(cur.y, a);
 	}
-	if (lane == 0) p.rot_state[chan] = make_float2(cur.x, cur.y);
+	if (live) p.rot_state[chan] = make_float2(cur.x, cur.y);
+}
+
+// carry the tail of the previous block's derotated samples (FIR-17 history + partial ScatterPLL group) to the
+// front of each row, before K2c overwrites the row (same stream: K3 of the previous block has finished)
+__global__ __launch_bounds__(64) void k2_cgf_carry(K2Params p) {
+	const int lane = threadIdx.x;
+	const int L = p.n_windows * 512;
+	float2* y = p.cgf + (size_t)blockIdx.x * p.cgf_stride;
+	if (lane < CGF_HIST) y[lane] = y[L + lane];
+}
+
+// K2c: output[i] *= rot (DSP.cpp:463), fully parallel: a 64-sample x 64-chain tile of phasors is read
+// time-major (coalesced along chains), transposed through LDS, multiplied into the chain-major 48 kHz
+// samples (coalesced along time) and written to the CGF output rows.
+__global__ __launch_bounds__(256) void k2_cgf_apply(K2Params p) {
+	__shared__ float2 tile[64][65];
+	const int t = threadIdx.x;
+	const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+	{
+		const int cc = t & 63, nn = t >> 6; // 4 time rows per pass
+#pragma unroll
+		for (int q = 0; q < 16; q++) tile[nn + 4 * q][cc] = p.rotT[(size_t)(n0 + nn + 4 * q) * p.rotT_stride + c0 + cc];
+	}
+	__syncthreads();
+	{
+		const int nn = t & 63, cq = t >> 6; // 4 chain rows per pass
+#pragma unroll
+		for (int q = 0; q < 16; q++) {
+			const int c = c0 + cq + 4 * q;
+			if (c < p.n_chan) {
+				const float2 xv = p.c48[(size_t)c * p.c48_stride + n0 + nn];
+				p.cgf[(size_t)c * p.cgf_stride + CGF_HIST + n0 + nn] = cmul(xv, tile[nn][cq + 4 * q]);
+			}
+		}
+	}
 }
 
 // ------------------------------------------------------------------------------------------
@@ -504,7 +593,13 @@ __global__ __launch_bounds__(256) void k3_fir_scatter(K3Params p) {
 			acc = make_float2(acc.x + tp * win[j + i].x, acc.y + tp * win[j + i].y);
 		}
 		level = level + (acc.x * acc.x + acc.y * acc.y); // std::norm
-		p.sym[((size_t)chan * 5 + j) * p.sym_stride + g] = acc;
+		// PhaseSearchEMA multiplies symbol n of a chain by (1j)^(n & 3) with swaps/negations (Demod.cpp:44-61);
+		// every chain has consumed exactly first_group + g symbols, so that exact rotation is applied here
+		const int rot = (int)((p.first_group + g) & 3);
+		float2 sv = (rot & 1) ? make_float2(acc.y, acc.x) : acc; // rot 1: (-y, x)   rot 3: (y, -x)
+		if (rot == 1 || rot == 2) sv.x = -sv.x;
+		if (rot >= 2) sv.y = -sv.y;
+		p.sym[((size_t)chan * 5 + j) * p.sym_stride + g] = sv;
 		if (p.fir_tap) p.fir_tap[(size_t)chan * p.fir_tap_stride + (n_rel + j + 4)] = acc;
 	}
 	p.lvl[(size_t)chan * p.sym_stride + g] = __fdiv_rn(level, 5.0f);
@@ -532,51 +627,50 @@ __device__ __forceinline__ float dpp_ror15(float v) {
 	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x12F, 0xF, 0xF, false));
 }
 
-struct PsLane { // per-lane PhaseSearchEMA state: hypothesis k of one chain
-	float ma;
-	unsigned bits;
+// Per-lane state is just ma[k]; the 8-bit decision shift registers bits[k] of the reference live in
+// wave ballots: D[j] = ballot(decision of j+1 symbols ago), so "bit(nDelay) XOR bit(nDelay+1)" of any
+// hypothesis is a scalar XOR of two ballot words and costs no vector instruction.
+struct PsWave {
+	unsigned long long h1, h2, h3, h4; // decisions of 1..4 symbols ago, one bit per lane
 };
 
-// One symbol for all 16 hypotheses of a row (DSP/Demod.cpp:39-101).  Returns the emitted bit (0/1).
+// One symbol for all 16 hypotheses of a row (DSP/Demod.cpp:39-101); v is already multiplied by (1j)^n (K3).
+// Returns the emitted bit (0/1).
 template <int MODE>
-__device__ __forceinline__ unsigned ps_step(float2 v, int rot, float pc, float psn, PsLane& s, int& idx, int k, int rowbase) {
+__device__ __forceinline__ unsigned ps_step(float2 v, float pc, float psn, float& ma, PsWave& hs, int& idx, int k, int rowbase) {
 	const float w = 0.85f;
 	const float w1 = 1 - w; // (1 - weight) evaluated in float (Demod.cpp:71)
-	// multiply by (1j)^rot via swaps/negations (Demod.cpp:44-61); branch-free because rot differs per row
-	const bool sw = (rot & 1) != 0;
-	float re = sw ? v.y : v.x, im = sw ? v.x : v.y;
-	re = (rot == 1 || rot == 2) ? -re : re;
-	im = (rot >= 2) ? -im : im;
-	const float a = re * pc, b = im * psn;
+	const float a = v.x * pc, b = v.y * psn;
 	const float tt = a + b;
-	s.bits = ((s.bits << 1) | (tt > 0 ? 1u : 0u)) & 0xFFu; // uint8_t shift register
-	s.ma = w * s.ma + w1 * fabsf(tt);
+	const unsigned long long dn = __ballot(tt > 0); // bits[k] = (bits[k] << 1) | (t > 0)
+	ma = w * ma + w1 * fabsf(tt);
 	float left, right;
 	if (MODE == 2) {
-		left = __shfl(s.ma, (k + 15) & 15, 16);
-		right = __shfl(s.ma, (k + 1) & 15, 16);
+		left = __shfl(ma, (k + 15) & 15, 16);
+		right = __shfl(ma, (k + 1) & 15, 16);
 	} else {
-		const float r1 = dpp_ror1(s.ma), r15 = dpp_ror15(s.ma);
+		const float r1 = dpp_ror1(ma), r15 = dpp_ror15(ma);
 		left = MODE == 0 ? r1 : r15;
 		right = MODE == 0 ? r15 : r1;
 	}
-	const bool p0 = s.ma > left;         // centre beats idx-1
-	const float bestc = p0 ? s.ma : left;
-	const bool p1 = right > bestc;       // idx+1 beats the better of the two
-	// nDelay = 3 (Model.cpp:560-561): bit(nDelay) XOR bit(nDelay + 1) of the winning hypothesis
-	const bool xb = (((s.bits >> 4) ^ (s.bits >> 3)) & 1u) != 0;
-	const unsigned long long B0 = __ballot(p0), B1 = __ballot(p1), BX = __ballot(xb);
-	const unsigned m0 = (unsigned)(B0 >> rowbase), m1 = (unsigned)(B1 >> rowbase), mx = (unsigned)(BX >> rowbase);
-	const int q0 = (int)((m0 >> idx) & 1u), q1 = (int)((m1 >> idx) & 1u);
+	const bool p0 = ma > left;         // centre beats idx-1
+	const float bestc = p0 ? ma : left;
+	const bool p1 = right > bestc;     // idx+1 beats the better of the two
+	const unsigned long long B0 = __ballot(p0), B1 = __ballot(p1);
+	const int sh = rowbase + idx;
+	const int q0 = (int)((unsigned)(B0 >> sh) & 1u), q1 = (int)((unsigned)(B1 >> sh) & 1u);
 	idx = (idx + (q1 ? 1 : q0 - 1)) & 15; // prev-1, prev, prev+1 with first-maximum preference
-	return (mx >> idx) & 1u;
+	// nDelay = 3 (Model.cpp:560-561): after the shift-in, bit 3 = decision of 3 symbols ago, bit 4 = 4 symbols ago
+	const unsigned long long X = hs.h3 ^ hs.h4;
+	hs.h4 = hs.h3; hs.h3 = hs.h2; hs.h2 = hs.h1; hs.h1 = dn;
+	return (unsigned)(X >> (rowbase + idx)) & 1u;
 }
 
-constexpr int PS_BATCH = 16; // symbols whose samples are fetched together (multiple of 4: rot phase is preserved)
+constexpr int PS_BATCH = 16; // symbols whose samples are fetched together
 
 template <int MODE>
 __device__ __forceinline__ void ps_chain(const float2* __restrict__ x, uint32_t* __restrict__ out, int n, bool writer, float pc,
-                                         float psn, PsLane& s, int& idx, int& rot, int k, int rowbase) {
+                                         float psn, float& ma, PsWave& hs, int& idx, int k, int rowbase) {
 	const int nb = n - (n % PS_BATCH);
 	uint32_t word = 0;
 	float2 cur[PS_BATCH];
@@ -587,27 +681,22 @@ __device__ __forceinline__ void ps_chain(const float2* __restrict__ x, uint32_t*
 #pragma unroll 1
 	for (int g0 = 0; g0 < nb; g0 += PS_BATCH) {
 		float2 nxt[PS_BATCH];
-		const bool more = g0 + PS_BATCH < nb;
-		if (more) { // next batch in flight while this one is processed
+		const int gn = g0 + PS_BATCH < nb ? g0 + PS_BATCH : g0; // next batch in flight while this one is processed
 #pragma unroll
-			for (int e = 0; e < PS_BATCH; e++) nxt[e] = x[g0 + PS_BATCH + e];
-		}
+		for (int e = 0; e < PS_BATCH; e++) nxt[e] = x[gn + e];
 		uint32_t part = 0;
 #pragma unroll
-		for (int e = 0; e < PS_BATCH; e++) part |= ps_step<MODE>(cur[e], (rot + e) & 3, pc, psn, s, idx, k, rowbase) << e;
+		for (int e = 0; e < PS_BATCH; e++) part |= ps_step<MODE>(cur[e], pc, psn, ma, hs, idx, k, rowbase) << e;
 		word |= part << (g0 & 31);
 		if (((g0 + PS_BATCH) & 31) == 0) {
 			if (writer) out[g0 >> 5] = word;
 			word = 0;
 		}
-		if (more) {
 #pragma unroll
-			for (int e = 0; e < PS_BATCH; e++) cur[e] = nxt[e];
-		}
+		for (int e = 0; e < PS_BATCH; e++) cur[e] = nxt[e];
 	}
 	for (int g = nb; g < n; g++) {
-		word |= ps_step<MODE>(x[g], rot, pc, psn, s, idx, k, rowbase) << (g & 31);
-		rot = (rot + 1) & 3;
+		word |= ps_step<MODE>(x[g], pc, psn, ma, hs, idx, k, rowbase) << (g & 31);
 		if ((g & 31) == 31) {
 			if (writer) out[g >> 5] = word;
 			word = 0;
@@ -616,7 +705,10 @@ __device__ __forceinline__ void ps_chain(const float2* __restrict__ x, uint32_t*
 	if ((n & 31) != 0 && writer) out[n >> 5] = word;
 }
 
-__global__ __launch_bounds__(64) void k4_phase_search(K4Params p) {
+// Sequential reference kernel: one pass over the whole block per chain.  Used as the exact fallback of the
+// chunk-parallel path (runs only when p.flag is set) and on its own for small batches.
+__global__ __launch_bounds__(64) void k4_phase_search(K4Params p, int conditional) {
+	if (conditional && *p.flag == 0) return;
 	const int lane = threadIdx.x;
 	const int k = lane & 15, row = lane >> 4;
 	const int chain = blockIdx.x * 4 + row; // (rx*2 + ch) * 5 + j
@@ -631,50 +723,219 @@ __global__ __launch_bounds__(64) void k4_phase_search(K4Params p) {
 	const float pc = c_ps_phase[jj].x;
 	const float psn = k < 8 ? c_ps_phase[jj].y : -c_ps_phase[jj].y; // a - b == a + (im * -s) exactly
 
-	EmaState* st = p.state + cidx;
-	PsLane s;
-	s.ma = st->ma[k];
-	s.bits = st->bits[k];
-	int idx = st->max_idx, rot = st->rot;
+	const EmaState* st = p.state_in + cidx;
+	EmaState* sto = p.state_out + cidx;
+	float ma = st->ma[k];
+	const unsigned bits = st->bits[k]; // bit j = decision of j+1 symbols ago
+	PsWave hs;
+	hs.h1 = __ballot((bits & 1u) != 0);
+	hs.h2 = __ballot((bits & 2u) != 0);
+	hs.h3 = __ballot((bits & 4u) != 0);
+	hs.h4 = __ballot((bits & 8u) != 0);
+	int idx = st->max_idx;
 
 	const float2* x = p.sym + (size_t)cidx * p.sym_stride;
 	uint32_t* out = p.bits + (size_t)cidx * p.bits_stride;
 	const bool writer = live && k == 0;
-	if (all_left) ps_chain<0>(x, out, p.n_groups, writer, pc, psn, s, idx, rot, k, rowbase);
-	else if (all_right) ps_chain<1>(x, out, p.n_groups, writer, pc, psn, s, idx, rot, k, rowbase);
-	else ps_chain<2>(x, out, p.n_groups, writer, pc, psn, s, idx, rot, k, rowbase);
+	if (all_left) ps_chain<0>(x, out, p.n_groups, writer, pc, psn, ma, hs, idx, k, rowbase);
+	else if (all_right) ps_chain<1>(x, out, p.n_groups, writer, pc, psn, ma, hs, idx, k, rowbase);
+	else ps_chain<2>(x, out, p.n_groups, writer, pc, psn, ma, hs, idx, k, rowbase);
 	if (live) {
-		st->ma[k] = s.ma;
-		st->bits[k] = s.bits;
-		if (k == 0) { st->max_idx = idx; st->rot = rot; }
+		sto->ma[k] = ma;
+		// only the last four decisions can ever be read again (bits 3 and 4 after the next shift-in)
+		sto->bits[k] = (unsigned)((hs.h1 >> lane) & 1ull) | ((unsigned)((hs.h2 >> lane) & 1ull) << 1) |
+		               ((unsigned)((hs.h3 >> lane) & 1ull) << 2) | ((unsigned)((hs.h4 >> lane) & 1ull) << 3);
+		if (k == 0) { sto->max_idx = idx; sto->rot = (st->rot + p.n_groups) & 3; }
 	}
+}
+
+// ------------------------------------------------------------------------------------------
+// K4 chunk-parallel: the block's symbols are cut into chunks of PS_CHUNK; one 16-lane row per (chain, chunk).
+//  * ma[k] is a contraction (x0.85 per symbol), so a chunk starts from ma = 0 and first replays the `warm`
+//    symbols in front of it; after that the float state is (with overwhelming probability) bit-identical to
+//    the sequential one.  That is VERIFIED: k4_assemble compares the post-warm-up values with the previous
+//    chunk's final values bit for bit and raises p.flag on any difference, in which case the sequential
+//    kernel above recomputes the block exactly.  Results are therefore always bit-exact.
+//  * the decisions (t > 0) do not depend on state at all.
+//  * max_idx is not contractive, so it is not guessed: lane k of the row tracks the trajectory that STARTS at
+//    max_idx = k (same instructions as one trajectory, the row's 16 lanes just stop being redundant);
+//    k4_assemble then walks the chunks sequentially, picking for each the trajectory of the true start.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ void ps_warm_step(float2 v, float pc, float psn, float& ma, PsWave& hs) {
+	const float w = 0.85f;
+	const float w1 = 1 - w;
+	const float tt = v.x * pc + v.y * psn;
+	const unsigned long long dn = __ballot(tt > 0);
+	ma = w * ma + w1 * fabsf(tt);
+	hs.h4 = hs.h3; hs.h3 = hs.h2; hs.h2 = hs.h1; hs.h1 = dn;
+}
+
+template <int MODE>
+__device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int chunk, bool live, int k, int rowbase, int lane) {
+	const int jj = k < 8 ? k : 15 - k;
+	const float pc = c_ps_phase[jj].x;
+	const float psn = k < 8 ? c_ps_phase[jj].y : -c_ps_phase[jj].y;
+	const float2* x = p.sym + (size_t)chain * p.sym_stride;
+	const int g0 = chunk * PS_CHUNK;
+	const int g1 = g0 + PS_CHUNK < p.n_groups ? g0 + PS_CHUNK : p.n_groups;
+	const size_t slot = (size_t)chain * p.n_chunks + chunk;
+
+	float ma;
+	PsWave hs;
+	int idx;
+	if (chunk == 0) { // the true state
+		const EmaState* st = p.state_in + chain;
+		ma = st->ma[k];
+		const unsigned bits = st->bits[k];
+		hs.h1 = __ballot((bits & 1u) != 0); hs.h2 = __ballot((bits & 2u) != 0);
+		hs.h3 = __ballot((bits & 4u) != 0); hs.h4 = __ballot((bits & 8u) != 0);
+	} else {
+		ma = 0.0f;
+		hs.h1 = hs.h2 = hs.h3 = hs.h4 = 0;
+		const int ws = g0 - p.warm; // >= 0: warm is a multiple of PS_BATCH and <= PS_CHUNK
+#pragma unroll 1
+		for (int g = ws; g < g0; g += PS_BATCH) {
+			float2 wv[PS_BATCH];
+#pragma unroll
+			for (int e = 0; e < PS_BATCH; e++) wv[e] = x[g + e];
+#pragma unroll
+			for (int e = 0; e < PS_BATCH; e++) ps_warm_step<MODE>(wv[e], pc, psn, ma, hs);
+		}
+		if (live) p.ma_start[slot * 16 + k] = ma;
+	}
+	idx = k; // trajectory that starts at max_idx == k
+
+	uint32_t* wout = p.words + slot * (PS_CHUNK / 32) * 16 + k;
+	uint32_t word = 0;
+	const int n = g1 - g0;
+	const int nb = n - (n % PS_BATCH);
+	float2 cur[PS_BATCH];
+	if (nb > 0) {
+#pragma unroll
+		for (int e = 0; e < PS_BATCH; e++) cur[e] = x[g0 + e];
+	}
+#pragma unroll 1
+	for (int q = 0; q < nb; q += PS_BATCH) {
+		float2 nxt[PS_BATCH];
+		const int qn = q + PS_BATCH < nb ? q + PS_BATCH : q;
+#pragma unroll
+		for (int e = 0; e < PS_BATCH; e++) nxt[e] = x[g0 + qn + e];
+		uint32_t part = 0;
+#pragma unroll
+		for (int e = 0; e < PS_BATCH; e++) part |= ps_step<MODE>(cur[e], pc, psn, ma, hs, idx, k, rowbase) << e;
+		word |= part << (q & 31);
+		if (((q + PS_BATCH) & 31) == 0) {
+			if (live) wout[(q >> 5) * 16] = word;
+			word = 0;
+		}
+#pragma unroll
+		for (int e = 0; e < PS_BATCH; e++) cur[e] = nxt[e];
+	}
+	for (int q = nb; q < n; q++) {
+		word |= ps_step<MODE>(x[g0 + q], pc, psn, ma, hs, idx, k, rowbase) << (q & 31);
+		if ((q & 31) == 31) {
+			if (live) wout[(q >> 5) * 16] = word;
+			word = 0;
+		}
+	}
+	if ((n & 31) != 0 && live) wout[(n >> 5) * 16] = word;
+	if (live) {
+		p.ma_fin[slot * 16 + k] = ma;
+		const unsigned dec = (unsigned)((hs.h1 >> lane) & 1ull) | ((unsigned)((hs.h2 >> lane) & 1ull) << 1) |
+		                     ((unsigned)((hs.h3 >> lane) & 1ull) << 2) | ((unsigned)((hs.h4 >> lane) & 1ull) << 3);
+		p.fin[slot * 16 + k] = (unsigned)idx | (dec << 4);
+	}
+}
+
+__global__ __launch_bounds__(64) void k4_phase_chunks(K4Params p) {
+	const int lane = threadIdx.x;
+	const int k = lane & 15, row = lane >> 4;
+	const int chunk = blockIdx.y;
+	const int chain_raw = blockIdx.x * 4 + row; // the four rows of a wave work on the same chunk: equal trip counts
+	const bool live = chain_raw < p.n_chains;
+	const int chain = live ? chain_raw : p.n_chains - 1;
+	const int rowbase = row * 16;
+	const int src = __builtin_amdgcn_update_dpp(0, k, 0x121, 0xF, 0xF, false);
+	const bool all_left = __all(src == ((k + 15) & 15)), all_right = __all(src == ((k + 1) & 15));
+	if (all_left) ps_chunk_body<0>(p, chain, chunk, live, k, rowbase, lane);
+	else if (all_right) ps_chunk_body<1>(p, chain, chunk, live, k, rowbase, lane);
+	else ps_chunk_body<2>(p, chain, chunk, live, k, rowbase, lane);
+}
+
+// sequential over the (few) chunks of a chain, 16 lanes per chain: verify the speculative warm-ups, select the
+// trajectory of the true start index per chunk, emit the packed decisions and the new state
+__global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
+	const int lane = threadIdx.x;
+	const int k = lane & 15, row = lane >> 4;
+	const int chain = blockIdx.x * 4 + row;
+	if (chain >= p.n_chains) return;
+	const EmaState* st = p.state_in + chain;
+	EmaState* sto = p.state_out + chain;
+	int start = st->max_idx;
+	uint32_t* out = p.bits + (size_t)chain * p.bits_stride;
+	bool bad = false;
+	for (int c = 0; c < p.n_chunks; c++) {
+		const size_t slot = (size_t)chain * p.n_chunks + c;
+		if (c > 0) {
+			const unsigned a = __float_as_uint(p.ma_start[slot * 16 + k]), b = __float_as_uint(p.ma_fin[(slot - 1) * 16 + k]);
+			bad = bad || (a != b);
+		}
+		const int g0 = c * PS_CHUNK;
+		const int n = (g0 + PS_CHUNK < p.n_groups ? PS_CHUNK : p.n_groups - g0);
+		const int nw = (n + 31) >> 5;
+		const uint32_t* w = p.words + slot * (PS_CHUNK / 32) * 16 + start;
+		for (int i = k; i < nw; i += 16) out[(g0 >> 5) + i] = w[i * 16];
+		start = (int)(p.fin[slot * 16 + start] & 15u);
+	}
+	if (bad) atomicOr(p.flag, 1);
+	const size_t last = (size_t)chain * p.n_chunks + (p.n_chunks - 1);
+	sto->ma[k] = p.ma_fin[last * 16 + k];
+	sto->bits[k] = p.fin[last * 16 + k] >> 4;
+	if (k == 0) { sto->max_idx = start; sto->rot = (st->rot + p.n_groups) & 3; }
 }
 
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-template <int K, bool CU8>
+template <int K, int P, int D, bool CU8>
 static hipError_t launch_k1_t(const K1Params& p, int spans, int n_rx, hipStream_t s) {
 	static bool attr_set = false;
+	constexpr int bytes = K1Cfg<K, P>::bytes;
 	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute((const void*)k1_frontend<K, CU8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K1Smem));
+		hipError_t e = hipFuncSetAttribute((const void*)k1_frontend<K, P, D, CU8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
-	hipLaunchKernelGGL((k1_frontend<K, CU8>), dim3(spans, n_rx), dim3(K1_THREADS), sizeof(K1Smem), s, p);
+	hipLaunchKernelGGL((k1_frontend<K, P, D, CU8>), dim3(spans, n_rx), dim3(K1_THREADS), bytes, s, p);
 	return hipGetLastError();
 }
 
-hipError_t launch_k1(const K1Params& p, int K, bool cu8, int spans, int n_rx, hipStream_t s) {
+template <int P, int D>
+static hipError_t launch_k1_p(const K1Params& p, int K, bool cu8, int spans, int n_rx, hipStream_t s) {
 	switch (K * 2 + (cu8 ? 1 : 0)) {
-	case 8: return launch_k1_t<4, false>(p, spans, n_rx, s);
-	case 9: return launch_k1_t<4, true>(p, spans, n_rx, s);
-	case 6: return launch_k1_t<3, false>(p, spans, n_rx, s);
-	case 7: return launch_k1_t<3, true>(p, spans, n_rx, s);
-	case 4: return launch_k1_t<2, false>(p, spans, n_rx, s);
-	case 5: return launch_k1_t<2, true>(p, spans, n_rx, s);
-	case 2: return launch_k1_t<1, false>(p, spans, n_rx, s);
-	case 3: return launch_k1_t<1, true>(p, spans, n_rx, s);
+	case 8: return launch_k1_t<4, P, D, false>(p, spans, n_rx, s);
+	case 9: return launch_k1_t<4, P, D, true>(p, spans, n_rx, s);
+	case 6: return launch_k1_t<3, P, D, false>(p, spans, n_rx, s);
+	case 7: return launch_k1_t<3, P, D, true>(p, spans, n_rx, s);
+	case 4: return launch_k1_t<2, P, D, false>(p, spans, n_rx, s);
+	case 5: return launch_k1_t<2, P, D, true>(p, spans, n_rx, s);
+	case 2: return launch_k1_t<1, P, D, false>(p, spans, n_rx, s);
+	case 3: return launch_k1_t<1, P, D, true>(p, spans, n_rx, s);
+	}
+	return hipErrorInvalidValue;
+}
+
+// tile96: samples at 96 kHz per tile (256, 128 or 64); depth: tiles prefetched ahead (1..4)
+hipError_t launch_k1(const K1Params& p, int K, bool cu8, int tile96, int depth, int spans, int n_rx, hipStream_t s) {
+	switch (tile96 * 10 + depth) {
+	case 2561: return launch_k1_p<256, 1>(p, K, cu8, spans, n_rx, s);
+	case 2562: return launch_k1_p<256, 2>(p, K, cu8, spans, n_rx, s);
+	case 2563: return launch_k1_p<256, 3>(p, K, cu8, spans, n_rx, s);
+	case 1282: return launch_k1_p<128, 2>(p, K, cu8, spans, n_rx, s);
+	case 1283: return launch_k1_p<128, 3>(p, K, cu8, spans, n_rx, s);
+	case 1284: return launch_k1_p<128, 4>(p, K, cu8, spans, n_rx, s);
+	case 644: return launch_k1_p<64, 4>(p, K, cu8, spans, n_rx, s);
 	}
 	return hipErrorInvalidValue;
 }
@@ -688,11 +949,19 @@ hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long b
 	return hipGetLastError();
 }
 
-hipError_t launch_k2(const K2Params& p, int n_chan, hipStream_t s) {
+hipError_t launch_k2a(const K2Params& p, int n_chan, hipStream_t s) {
 	hipLaunchKernelGGL(k2_cgf_analyse, dim3(p.n_windows, n_chan), dim3(64), 0, s, p);
-	hipError_t e = hipGetLastError();
-	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(k2_cgf_derotate, dim3(n_chan), dim3(64), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_k2b(const K2Params& p, int n_chan, hipStream_t s) {
+	hipLaunchKernelGGL(k2_cgf_phasor, dim3((n_chan + 63) / 64), dim3(64), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_k2c(const K2Params& p, int n_chan, hipStream_t s) {
+	hipLaunchKernelGGL(k2_cgf_carry, dim3(n_chan), dim3(64), 0, s, p);
+	hipLaunchKernelGGL(k2_cgf_apply, dim3(p.n_windows * 8, (n_chan + 63) / 64), dim3(256), 0, s, p);
 	return hipGetLastError();
 }
 
@@ -702,9 +971,19 @@ hipError_t launch_k3(const K3Params& p, int n_chan, hipStream_t s) {
 	return hipGetLastError();
 }
 
+hipError_t launch_k4_sequential(const K4Params& p, hipStream_t s) {
+	if (p.n_groups <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k4_phase_search, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p, 0);
+	return hipGetLastError();
+}
+
 hipError_t launch_k4(const K4Params& p, hipStream_t s) {
 	if (p.n_groups <= 0) return hipSuccess;
-	hipLaunchKernelGGL(k4_phase_search, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p);
+	hipError_t e = hipMemsetAsync(p.flag, 0, sizeof(int), s);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k4_phase_chunks, dim3((p.n_chains + 3) / 4, p.n_chunks), dim3(64), 0, s, p);
+	hipLaunchKernelGGL(k4_assemble, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p);
+	hipLaunchKernelGGL(k4_phase_search, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p, 1); // exits at once unless flagged
 	return hipGetLastError();
 }
 

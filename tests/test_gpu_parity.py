@@ -236,3 +236,14 @@ def test_nmea_batched_receivers_on_threads():
         assert models[r].nmea() == want[r] and len(want[r]) >= 2
         models[r].close()
     batch.close()
+
+
+@pytest.mark.parametrize("env", [{"AISGPU_PS_WARM": "16"}, {"AISGPU_PS_SEQUENTIAL": "1"}, {"AISGPU_SERIAL": "1"}])
+def test_phase_search_fallback_and_variants(env, monkeypatch):
+    """The chunk-parallel PhaseSearchEMA verifies its speculative warm-ups; with a 16-symbol warm-up the check
+    must fail and the sequential fallback must still deliver bit-exact decisions.  Also: the plain sequential
+    kernel and the single-stream (non-overlapped) schedule."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    xs = [synth.receiver_stream(786432 * 2, receiver_id=40 + r) for r in range(2)]
+    _run_gpu_vs_oracle(xs, 1536000, "cf32", 786432, 2)

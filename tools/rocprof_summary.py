@@ -18,12 +18,12 @@ def main(path):
             r[0][:64], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / total,
             r[6], r[7], r[8], r[9], r[10], r[11]))
     try:
-        pmc = c.execute("select name, counter_name, sum(value), count(*) from counters_collection "
-                        "group by name, counter_name order by name").fetchall()
+        pmc = c.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection "
+                        "group by kernel_name, counter_name order by kernel_name, counter_name").fetchall()
         if pmc:
-            print("\ncounters (sum over dispatches, dispatch count):")
+            print("\ncounters (value summed over all instances, per dispatch average):")
             for r in pmc:
-                print("%-64s %-24s %20.1f %6d" % (r[0][:64], r[1], r[2], r[3]))
+                print("%-64s %-24s %20.1f" % (r[0][:64], r[1], r[2] / max(r[3], 1)))
     except sqlite3.Error:
         pass
 
