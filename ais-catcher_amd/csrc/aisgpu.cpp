@@ -235,7 +235,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 
 	HIPCHK(hipSetDevice(cfg->device_id));
 	HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-	if (getenv("AISGPU_SERIAL")) { // profiling aid: no cross-block overlap, every kernel runs alone
+	if ((cfg->flags & AISGPU_FLAG_SERIAL) || getenv("AISGPU_SERIAL")) { // profiling aid: no cross-block overlap, every kernel runs alone
 		h->s1 = h->s2 = h->s3 = h->stream;
 		h->serial = true;
 	} else {

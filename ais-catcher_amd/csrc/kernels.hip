@@ -400,89 +400,104 @@ __device__ __forceinline__ void wave_argmax_first(float& v, int& i) {
 	}
 }
 
+// One wave handles NW consecutive windows of one channel: the FFTs run one after the other on all 64 lanes
+// (twiddles stay in registers), then the order-sensitive part -- the float prefix sum and the first search,
+// which the reference evaluates strictly left to right -- runs for the NW windows at once, one LANE per window,
+// so its ~4,000 dependent instructions are paid once per NW windows instead of once per window.
+template <int NW>
 __global__ __launch_bounds__(64) void k2_cgf_analyse(K2Params p) {
+	constexpr int MS = 516; // row stride of mag (floats): 512 + wrap slot, stride 4 (mod 32) banks between windows
 	__shared__ __attribute__((aligned(16))) float2 X[512];
-	__shared__ __attribute__((aligned(16))) float mag[520]; // mag[q] = |X[(q + 256) % 512]|, q in [0, 512]
-	__shared__ __attribute__((aligned(16))) float cs[512];
+	__shared__ __attribute__((aligned(16))) float mag[NW * MS]; // mag[w][q] = |X_w[(q + 256) % 512]|, q in [0, 512]
 
 	__builtin_amdgcn_s_setprio(1);
 	const int lane = threadIdx.x;
-	const int w = blockIdx.x, chan = blockIdx.y; // chan = rx * 2 + ch
-	const float2* x = p.c48 + (size_t)chan * p.c48_stride + (size_t)w * 512;
+	const int w0 = blockIdx.x * NW, chan = blockIdx.y; // chan = rx * 2 + ch
 
+	// twiddles of the 4 butterflies this lane does in each of the 9 stages (FFT.h:104-129: Omega[j * (N >> (s+1))])
+	float2 tw[9][4];
 #pragma unroll
-	for (int q = 0; q < 8; q++) {
-		int n = lane + 64 * q;
-		float2 v = x[n];
-		// data[i] * data[i]: (a*a - b*b, a*b + b*a)
-		X[__brev((unsigned)n) >> 23] = make_float2(v.x * v.x - v.y * v.y, v.x * v.y + v.y * v.x);
-	}
-	__syncthreads();
-#pragma unroll 1
 	for (int s = 0; s < 9; s++) {
-		const int m2 = 1 << s;
 #pragma unroll
 		for (int q = 0; q < 4; q++) {
-			int b = lane + 64 * q;
-			int j = b & (m2 - 1);
-			int i0 = ((b >> s) << (s + 1)) + j, i1 = i0 + m2;
-			float2 o = p.omega[j << (8 - s)];
-			float2 a = X[i0], c = X[i1];
-			float2 tt = cmul(o, c);
-			X[i1] = csub(a, tt);
-			X[i0] = cadd(a, tt);
+			const int bfly = lane + 64 * q;
+			tw[s][q] = p.omega[(bfly & ((1 << s) - 1)) << (8 - s)];
+		}
+	}
+
+	for (int wi_ = 0; wi_ < NW; wi_++) {
+		const float2* x = p.c48 + (size_t)chan * p.c48_stride + (size_t)(w0 + wi_) * 512;
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			const int n = lane + 64 * q;
+			const float2 v = x[n];
+			// data[i] * data[i]: (a*a - b*b, a*b + b*a), stored bit-reversed (DSP.cpp:480)
+			X[__brev((unsigned)n) >> 23] = make_float2(v.x * v.x - v.y * v.y, v.x * v.y + v.y * v.x);
+		}
+		__syncthreads();
+#pragma unroll
+		for (int s = 0; s < 9; s++) {
+			const int m2 = 1 << s;
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const int bfly = lane + 64 * q;
+				const int j = bfly & (m2 - 1);
+				const int i0 = ((bfly >> s) << (s + 1)) + j, i1 = i0 + m2;
+				const float2 a = X[i0], c = X[i1];
+				const float2 tt = cmul(tw[s][q], c);
+				X[i1] = csub(a, tt);
+				X[i0] = cadd(a, tt);
+			}
+			__syncthreads();
+		}
+		float* mg = mag + wi_ * MS;
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			const int k = lane + 64 * q;
+			const float2 v = X[k];
+			const float m = hypot_ref(v.x, v.y);
+			mg[(k + 256) & 511] = m;
+			if (k == 256) mg[512] = m; // wrap slot: shifted index 512 == 0
 		}
 		__syncthreads();
 	}
-#pragma unroll
-	for (int q = 0; q < 8; q++) {
-		int k = lane + 64 * q;
-		float2 v = X[k];
-		float m = hypot_ref(v.x, v.y);
-		mag[(k + 256) & 511] = m;
-		if (k == 256) mag[512] = m; // wrap slot: shifted index 512 == 0
-	}
-	__syncthreads();
 
+	// ---- wide search (DSP.cpp:426-447), one lane per window, strictly sequential like the reference:
+	// cumsum[i] = cumsum[i-1] + mag[i];  v(i) = cumsum[i+M] - cumsum[i] + 0.6f * (mag[i+ofs] + mag[i+ofs+delta]);
+	// two running sums 133 apart reproduce cumsum[i+M] and cumsum[i] with the same additions in the same order.
 	int wi = 0;
 	if (p.wide) {
-		if (lane == 0) { // cumsum[0] = 0; cumsum[i] = cumsum[i-1] + mag[i]  (DSP.cpp:431-436)
-			float acc = 0.0f;
-			cs[0] = 0.0f;
-			for (int i = 1; i < 512; i += 1) {
-				acc = acc + mag[i];
-				cs[i] = acc;
-			}
-		}
-		__syncthreads();
-		// M = 133, ofs = 15, delta = 102: v = cs[i+M] - cs[i] + 0.6f * (mag[i+ofs] + mag[i+ofs+delta]), i < 379
-		float best = -1.0f;
+		const float* mg = mag + (lane < NW ? lane : 0) * MS;
+		float hi = 0.0f; // cumsum[0] = 0
+		for (int i = 1; i <= 133; i++) hi = hi + mg[i];
+		float lo_ = 0.0f, best = -1.0f;
 		int bi = 0;
-#pragma unroll
-		for (int q = 0; q < 6; q++) {
-			int i = lane + 64 * q;
-			if (i < 512 - 133) {
-				float v = cs[i + 133] - cs[i] + 0.6f * (mag[i + 15] + mag[i + 117]);
-				if (v > best) { best = v; bi = i; }
-			}
+		for (int i = 0; i < 512 - 133; i++) {
+			const float v = hi - lo_ + 0.6f * (mg[i + 15] + mg[i + 117]);
+			if (v > best) { best = v; bi = i; }
+			hi = hi + mg[i + 134 < 512 ? i + 134 : 511]; // cumsum[i+1+M] (the value after the last i is never used)
+			lo_ = lo_ + mg[i + 1];                         // cumsum[i+1]
 		}
-		wave_argmax_first(best, bi);
 		wi = bi + 66 - 256; // wi + M/2 - N/2
 	}
-	// i in [wi+187, wi+223): h = mag[i] + mag[i+102] (shifted indices, wrap at 512); first strict max > 0
-	float h = 0.0f;
-	int hi = 0x7fffffff;
-	if (lane < 36) {
-		int i = wi + 187 + lane;
-		float v = mag[(i + 512) & 511] + mag[(i + 102 + 512) & 511];
-		if (v > 0.0f) { h = v; hi = i; }
-	}
-	wave_argmax_first(h, hi);
-	if (lane == 0) {
-		// fz = N/2 - (i + delta/2) = 205 - i (integer valued); default -1
-		int fz = (h > 0.0f) ? (205 - hi) : -1;
-		p.fz[(size_t)chan * p.n_windows + w] = fz;
-		p.ppm[(size_t)chan * p.n_windows + w] = p.ppm_table[fz + 205];
+	// ---- second search per window with the whole wave (36 candidates): i in [wi+187, wi+223)
+	for (int wi_ = 0; wi_ < NW; wi_++) {
+		const float* mg = mag + wi_ * MS;
+		const int wiw = __shfl(wi, wi_);
+		float h = 0.0f;
+		int hidx = 0x7fffffff;
+		if (lane < 36) {
+			const int i = wiw + 187 + lane;
+			const float v = mg[(i + 512) & 511] + mg[(i + 102 + 512) & 511];
+			if (v > 0.0f) { h = v; hidx = i; }
+		}
+		wave_argmax_first(h, hidx);
+		if (lane == 0) {
+			// fz = N/2 - (i + delta/2) = 205 - i (integer valued); default -1
+			const int fz = (h > 0.0f) ? (205 - hidx) : -1;
+			p.fz[(size_t)chan * p.n_windows + w0 + wi_] = fz;
+			p.ppm[(size_t)chan * p.n_windows + w0 + wi_] = p.ppm_table[fz + 205];
+		}
 	}
 }
 
@@ -950,7 +965,10 @@ hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long b
 }
 
 hipError_t launch_k2a(const K2Params& p, int n_chan, hipStream_t s) {
-	hipLaunchKernelGGL(k2_cgf_analyse, dim3(p.n_windows, n_chan), dim3(64), 0, s, p);
+	if (p.n_windows % 8 == 0) hipLaunchKernelGGL(k2_cgf_analyse<8>, dim3(p.n_windows / 8, n_chan), dim3(64), 0, s, p);
+	else if (p.n_windows % 4 == 0) hipLaunchKernelGGL(k2_cgf_analyse<4>, dim3(p.n_windows / 4, n_chan), dim3(64), 0, s, p);
+	else if (p.n_windows % 2 == 0) hipLaunchKernelGGL(k2_cgf_analyse<2>, dim3(p.n_windows / 2, n_chan), dim3(64), 0, s, p);
+	else hipLaunchKernelGGL(k2_cgf_analyse<1>, dim3(p.n_windows, n_chan), dim3(64), 0, s, p);
 	return hipGetLastError();
 }
 

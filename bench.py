@@ -116,11 +116,12 @@ def main():
 
     import _pkg
     _pkg.load()
-    from ais_catcher_amd import gpu
+    from ais_catcher_amd import gpu, shard
 
     R = args.receivers
     nb = 2  # distinct resident blocks cycled (2 x 1.6 GB)
-    data = make_resident_input(torch, R, nb, seed=rank)
+    rx_ids = shard.receiver_range(rank, world, R)  # this rank's receivers; no other rank touches them
+    data = make_resident_input(torch, R, nb, seed=rx_ids[0] // R)
     g = gpu.AisGpu(sample_rate=RATE, n_receivers=R, block_len=BLOCK, device_id=local)
 
     def step(i):
@@ -145,15 +146,24 @@ def main():
     g.sync()
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = shard.max_over_ranks(dt, dist, device="cuda")
 
     k1_ms, k1_n = g.frontend_ms()
     g.close()
+    # the same kernel measured without the other streams' kernels competing for the chip (untimed extra steps)
+    gs = gpu.AisGpu(sample_rate=RATE, n_receivers=R, block_len=BLOCK, device_id=local, serial=True)
+    for i in range(2):
+        gs.submit_device(data[i % nb].data_ptr(), BLOCK)
+        gs.run()
+    gs.sync()
+    gs.timing(True)
+    for i in range(4):
+        gs.submit_device(data[i % nb].data_ptr(), BLOCK)
+        gs.run()
+    iso_ms, _ = gs.frontend_ms()
+    gs.close()
     samples_per_step = R * BLOCK
-    value = samples_per_step * world * args.steps / dt / 1e6
+    value = shard.aggregate_msamples(samples_per_step, world, args.steps, dt)
     achieved = samples_per_step * ALGO_BYTES_PER_SAMPLE / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
     res = {
         "metric": "IQ Msamples/s (CFLOAT32) through ModelDefault chain", "value": round(value, 1),
@@ -166,7 +176,9 @@ def main():
                    "receivers_per_gpu": R, "block_len": BLOCK, "sample_rate": RATE, "parallelism": "receivers sharded, no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel": "k1_frontend", "avg_launch_ms": round(k1_ms, 4), "launches": k1_n},
+                     "kernel": "k1_frontend", "avg_launch_ms": round(k1_ms, 4), "launches": k1_n,
+                     "isolated_launch_ms": round(iso_ms, 4),
+                     "isolated_frac": round(samples_per_step * ALGO_BYTES_PER_SAMPLE / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if iso_ms > 0 else None},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -49,6 +49,7 @@ extern "C" {
 #define AISGPU_MODEL_DEFAULT 2
 
 #define AISGPU_FLAG_TAPS 1    /* keep intermediate float taps readable via aisgpu_tap() (tests) */
+#define AISGPU_FLAG_SERIAL 2  /* profiling aid: one stream, no overlap between the kernels of consecutive blocks */
 
 typedef struct aisgpu aisgpu_t;
 
