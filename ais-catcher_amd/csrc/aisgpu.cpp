@@ -30,14 +30,16 @@ const float TAPS_COHERENT[17] = { // DSP/Filters.h:35-41
 	1.30411453e-02f, 2.52892989e-03f, 3.40605309e-04f, 3.18610148e-05f, 2.06995719e-06f };
 
 struct EvPair { hipEvent_t a, b; };
+constexpr int NBUF = 3; // ring depth of the buffers that cross from the front-end stream to the others
 
 } // namespace
 
 struct aisgpu {
 	aisgpu_cfg cfg;
 	int K = 0;            // CIC5 stages in front of the 96 kHz point
-	int tile96 = 256;     // 96 kHz samples per front-end tile
-	int depth = 2;        // tiles prefetched ahead by the front end
+	int tile96 = 64;      // 96 kHz samples per front-end tile
+	int depth = 1;        // tiles prefetched ahead by the front end
+	int k1_threads = 64;  // front-end workgroup size (64: one autonomous wave per workgroup)
 	int tile_in = 0;      // input samples per front-end tile (tile96 << K)
 	int in_bytes = 0;     // bytes per input sample
 	int n96 = 0, L = 0, W = 0; // per block: 96 kHz samples, 48 kHz samples per channel, CGF windows
@@ -53,20 +55,20 @@ struct aisgpu {
 	// so block b+1's front end overlaps block b's phasor recurrence and back end.  Buffers that cross a
 	// stream boundary are double buffered by block parity.
 	hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, s3 = nullptr; // s3: the CGF phasor recurrence alone
-	hipEvent_t ev_phasor[2] = { nullptr, nullptr }; // s3: phasor(b) done -> s1 may apply it
+	hipEvent_t ev_phasor[NBUF] = {}; // s3: phasor(b) done -> s1 may apply it
 	bool serial = false;
-	hipEvent_t ev_front[2] = { nullptr, nullptr }; // s0: K2a(b) done           -> s1 may start K2b(b)
-	hipEvent_t ev_c48free[2] = { nullptr, nullptr }; // s1: K2b(b) done (c48/fz[p] consumed) -> s0 may run K1(b+2)
+	hipEvent_t ev_front[NBUF] = {}; // s0: K2a(b) done           -> s3 may start K2b(b)
+	hipEvent_t ev_c48free[NBUF] = {}; // s1: K2c(b) done (c48/fz/rotT[q] consumed) -> s0 may run K1(b+NBUF)
 	hipEvent_t ev_mid[2] = { nullptr, nullptr };   // s1: K3(b) done            -> s2 may start K4(b)
 	hipEvent_t ev_ema[2] = { nullptr, nullptr };   // s2: K4(b) done (sym/lvl[p] consumed) -> s1 may run K3(b+2)
 	// device buffers
 	void* d_in = nullptr; void* d_hist = nullptr;
 	float2* d_rot[2] = { nullptr, nullptr };
-	float2 *d_c48[2] = { nullptr, nullptr }, *d_sym[2] = { nullptr, nullptr };
-	float2 *d_rotT[2] = { nullptr, nullptr };
+	float2 *d_c48[NBUF] = {}, *d_sym[2] = { nullptr, nullptr };
+	float2 *d_rotT[NBUF] = {};
 	float2 *d_cgf = nullptr, *d_omega = nullptr, *d_step = nullptr, *d_rotstate = nullptr, *d_firtap = nullptr;
-	float *d_ppmtab = nullptr, *d_ppm[2] = { nullptr, nullptr }, *d_lvl[2] = { nullptr, nullptr };
-	int* d_fz[2] = { nullptr, nullptr };
+	float *d_ppmtab = nullptr, *d_ppm[NBUF] = {}, *d_lvl[2] = { nullptr, nullptr };
+	int* d_fz[NBUF] = {};
 	uint32_t* d_bits[2] = { nullptr, nullptr };
 	EmaState* d_ema[2] = { nullptr, nullptr }; // state before / after the current block (swapped per block)
 	uint32_t* d_pswords = nullptr; float *d_psma0 = nullptr, *d_psma1 = nullptr; unsigned* d_psfin = nullptr; int* d_psflag = nullptr;
@@ -198,15 +200,16 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	if (!h) return AISGPU_ERR_ARG;
 	h->cfg = *cfg;
 	h->K = K;
-	h->tile96 = 256;
-	if (const char* e = getenv("AISGPU_TILE96")) { // tuning knob (256, 128 or 64)
-		int v = atoi(e);
-		if (v == 256 || v == 128 || v == 64) h->tile96 = v;
-	}
-	h->depth = h->tile96 == 256 ? 2 : (h->tile96 == 128 ? 3 : 4);
-	if (const char* e = getenv("AISGPU_DEPTH")) {
-		int v = atoi(e);
-		if ((h->tile96 == 256 && v >= 1 && v <= 3) || (h->tile96 == 128 && v >= 2 && v <= 4)) h->depth = v;
+	// front-end geometry (tuning knobs; the defaults are the measured best): workgroup size, 96 kHz samples per
+	// tile, prefetch depth.  Valid combinations: 256 threads x {256,128}; 64 threads x {64,32}.
+	h->k1_threads = 64; h->tile96 = 64; h->depth = 1; // measured best: autonomous waves (profiles/r01_k1_geometry_sweep.txt)
+	if (const char* e = getenv("AISGPU_K1")) { // "threads,tile96,depth"
+		int a = 0, b = 0, d = 0;
+		if (sscanf(e, "%d,%d,%d", &a, &b, &d) == 3) {
+			const bool ok = (a == 256 && (b == 256 || b == 128) && (d == 1 || d == 2 || (b == 128 && d == 3)) && !(b == 128 && d == 1)) ||
+			                (a == 64 && (b == 64 || b == 32) && (d == 1 || d == 2));
+			if (ok) { h->k1_threads = a; h->tile96 = b; h->depth = d; }
+		}
 	}
 	h->tile_in = h->tile96 << K;
 	h->in_bytes = cfg->input_format == AISGPU_FMT_CU8 ? 2 : 8;
@@ -225,7 +228,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	int tps = cfg->tiles_per_span;
 	if (tps <= 0) {
 		tps = h->tiles_per_block;
-		const long long want = h->tile96 >= 256 ? 1024 : 2048; // workgroups: a few per CU per residency slot
+		const long long want = h->k1_threads == 64 ? 8192 : (h->tile96 >= 256 ? 1024 : 2048); // workgroups: a few per CU per residency slot
 		while (tps > 8 && (long long)cfg->n_receivers * ((h->tiles_per_block + tps - 1) / tps) < want) tps = (tps + 1) / 2;
 	}
 	if (tps > h->tiles_per_block) tps = h->tiles_per_block;
@@ -245,10 +248,12 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking));
 		h->s2 = h->s1; // apply + FIR + PhaseSearchEMA of a block run back to back on one stream
 	}
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < NBUF; i++) {
 		HIPCHK(hipEventCreateWithFlags(&h->ev_front[i], hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&h->ev_phasor[i], hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&h->ev_c48free[i], hipEventDisableTiming));
+	}
+	for (int i = 0; i < 2; i++) {
 		HIPCHK(hipEventCreateWithFlags(&h->ev_mid[i], hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&h->ev_ema[i], hipEventDisableTiming));
 	}
@@ -287,16 +292,18 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(hipHostMalloc((void**)&h->h_rot[i], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipHostMallocDefault));
 		HIPCHK(hipEventCreateWithFlags(&h->rot_ev[i], hipEventDisableTiming));
 	}
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < NBUF; i++) {
 		HIPCHK(dalloc(&h->d_c48[i], C * h->L));
 		HIPCHK(dalloc(&h->d_fz[i], C * h->W));
 		HIPCHK(dalloc(&h->d_ppm[i], C * h->W));
+		HIPCHK(dalloc(&h->d_rotT[i], (size_t)h->L * ((C + 63) / 64 * 64)));
+	}
+	for (int i = 0; i < 2; i++) {
 		HIPCHK(dalloc(&h->d_sym[i], C * 5 * h->Gcap));
 		HIPCHK(dalloc(&h->d_lvl[i], C * h->Gcap));
 		HIPCHK(dalloc(&h->d_bits[i], C * 5 * h->words));
 	}
 	HIPCHK(dalloc(&h->d_cgf, C * (CGF_HIST + h->L)));
-	for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_rotT[i], (size_t)h->L * ((C + 63) / 64 * 64)));
 	HIPCHK(dalloc(&h->d_rotstate, C));
 	{
 		std::vector<float2> ones(C, make_float2(1.0f, 0.0f)); // SquareFreqOffsetCorrection::rot = 1.0f (DSP.h:379)
@@ -327,14 +334,16 @@ void aisgpu_destroy(aisgpu_t* h) {
 	if (h->s2) hipStreamSynchronize(h->s2);
 	if (h->s3) hipStreamSynchronize(h->s3);
 	drain_events(h);
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < NBUF; i++) {
 		if (h->ev_front[i]) hipEventDestroy(h->ev_front[i]);
 		if (h->ev_phasor[i]) hipEventDestroy(h->ev_phasor[i]);
-		hipFree(h->d_rotT[i]);
 		if (h->ev_c48free[i]) hipEventDestroy(h->ev_c48free[i]);
+		hipFree(h->d_rotT[i]); hipFree(h->d_c48[i]); hipFree(h->d_fz[i]); hipFree(h->d_ppm[i]);
+	}
+	for (int i = 0; i < 2; i++) {
 		if (h->ev_mid[i]) hipEventDestroy(h->ev_mid[i]);
 		if (h->ev_ema[i]) hipEventDestroy(h->ev_ema[i]);
-		hipFree(h->d_c48[i]); hipFree(h->d_fz[i]); hipFree(h->d_ppm[i]); hipFree(h->d_sym[i]); hipFree(h->d_lvl[i]); hipFree(h->d_bits[i]);
+		hipFree(h->d_sym[i]); hipFree(h->d_lvl[i]); hipFree(h->d_bits[i]);
 	}
 	for (auto& p : h->ev_free) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
 	hipFree(h->d_in); hipFree(h->d_hist);
@@ -385,6 +394,7 @@ int aisgpu_run(aisgpu_t* h) {
 	if (!h->submitted) return AISGPU_ERR_STATE;
 	HIPCHK(hipSetDevice(h->cfg.device_id));
 	const int pb = (int)(h->block_idx & 1);
+	const int q = (int)(h->block_idx % NBUF); // ring slot of c48 / fz / ppm / rotT
 	// the pinned phasor buffer `pb` was last used two blocks ago; wait until that upload has been consumed
 	// (only blocks when the host runs more than one block ahead of the device)
 	if (h->block_idx >= 2) HIPCHK(hipEventSynchronize(h->rot_ev[pb]));
@@ -392,11 +402,11 @@ int aisgpu_run(aisgpu_t* h) {
 	HIPCHK(hipMemcpyAsync(h->d_rot[pb], h->h_rot[pb], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
 	HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
 
-	// c48/fz/ppm[pb] were last read by K2b of block b-2 (stream s1)
-	HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[pb], 0));
+	// c48/fz/ppm[q] were last read by K2b/K2c of block b-NBUF
+	HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[q], 0));
 	K1Params k1;
 	k1.in = h->cur_in; k1.in_stride = h->cur_in_stride; k1.hist = h->d_hist; k1.rot = h->d_rot[pb];
-	k1.c48 = h->d_c48[pb]; k1.c48_stride = h->L;
+	k1.c48 = h->d_c48[q]; k1.c48_stride = h->L;
 	k1.tiles_per_block = h->tiles_per_block; k1.tiles_per_span = h->tiles_per_span;
 	k1.alpha = h->alpha; k1.beta = h->beta; k1.has_fdc = h->has_fdc;
 	EvPair ev{};
@@ -405,28 +415,28 @@ int aisgpu_run(aisgpu_t* h) {
 		else { ev = h->ev_free.back(); h->ev_free.pop_back(); }
 		HIPCHK(hipEventRecord(ev.a, h->stream));
 	}
-	HIPCHK(launch_k1(k1, h->K, h->cfg.input_format == AISGPU_FMT_CU8, h->tile96, h->depth, h->spans, h->cfg.n_receivers, h->stream));
+	HIPCHK(launch_k1(k1, h->K, h->cfg.input_format == AISGPU_FMT_CU8, h->tile96, h->depth, h->k1_threads, h->spans, h->cfg.n_receivers, h->stream));
 	if (h->timing) { HIPCHK(hipEventRecord(ev.b, h->stream)); h->ev_busy.push_back(ev); }
 	HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist,
 	                      h->tile_in * h->in_bytes, h->cfg.n_receivers, h->stream));
 
 	K2Params k2;
-	k2.c48 = h->d_c48[pb]; k2.c48_stride = h->L; k2.cgf = h->d_cgf; k2.cgf_stride = CGF_HIST + h->L;
-	k2.omega = h->d_omega; k2.step_table = h->d_step; k2.ppm_table = h->d_ppmtab; k2.fz = h->d_fz[pb]; k2.ppm = h->d_ppm[pb];
+	k2.c48 = h->d_c48[q]; k2.c48_stride = h->L; k2.cgf = h->d_cgf; k2.cgf_stride = CGF_HIST + h->L;
+	k2.omega = h->d_omega; k2.step_table = h->d_step; k2.ppm_table = h->d_ppmtab; k2.fz = h->d_fz[q]; k2.ppm = h->d_ppm[q];
 	k2.rot_state = h->d_rotstate; k2.n_windows = h->W; k2.wide = h->cfg.afc_wide ? 1 : 0;
-	k2.rotT = h->d_rotT[pb]; k2.rotT_stride = (h->n_chan + 63) / 64 * 64; k2.n_chan = h->n_chan;
+	k2.rotT = h->d_rotT[q]; k2.rotT_stride = (h->n_chan + 63) / 64 * 64; k2.n_chan = h->n_chan;
 	HIPCHK(launch_k2a(k2, h->n_chan, h->stream));
-	HIPCHK(hipEventRecord(h->ev_front[pb], h->stream));
+	HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
 
-	// ---- s3: sequential CGF phasor recurrence (needs fz of this block; rotT[pb] was last read by apply(b-2))
-	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_front[pb], 0));
-	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_c48free[pb], 0));
+	// ---- s3: sequential CGF phasor recurrence (needs fz of this block; rotT[q] was last read by apply(b-NBUF))
+	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_front[q], 0));
+	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_c48free[q], 0));
 	HIPCHK(launch_k2b(k2, h->n_chan, h->s3));
-	HIPCHK(hipEventRecord(h->ev_phasor[pb], h->s3));
+	HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
 	// ---- s1: apply the phasors, then FIR-17 + ScatterPLL
-	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_phasor[pb], 0));
+	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_phasor[q], 0));
 	HIPCHK(launch_k2c(k2, h->n_chan, h->s1));
-	HIPCHK(hipEventRecord(h->ev_c48free[pb], h->s1));
+	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s1));
 	// ScatterPLL groups completed inside this block (DSP/DSP.h:95-117): group g completes with sample 5g+4
 	const long long g0 = h->n48 / 5, g1 = (h->n48 + h->L) / 5;
 	K3Params k3;
@@ -477,10 +487,11 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 	if (h->block_idx == 0) return AISGPU_ERR_STATE;
 	const size_t C = h->n_chan;
 	const int pb = (int)((h->block_idx - 1) & 1); // buffers of the last block run
+	const int q = (int)((h->block_idx - 1) % NBUF);
 	// s2 is ordered after K4 of that block, which is ordered after everything that produced lvl/ppm
 	HIPCHK(hipMemcpyAsync(h->h_bits, h->d_bits[pb], C * 5 * h->words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s2));
 	HIPCHK(hipMemcpyAsync(h->h_lvl, h->d_lvl[pb], C * h->Gcap * sizeof(float), hipMemcpyDeviceToHost, h->s2));
-	HIPCHK(hipMemcpyAsync(h->h_ppm, h->d_ppm[pb], C * h->W * sizeof(float), hipMemcpyDeviceToHost, h->s2));
+	HIPCHK(hipMemcpyAsync(h->h_ppm, h->d_ppm[q], C * h->W * sizeof(float), hipMemcpyDeviceToHost, h->s2));
 	int rc = sync_all(h);
 	if (rc != AISGPU_OK) return rc;
 	h->have_out = true;
@@ -508,9 +519,9 @@ long long aisgpu_tap(aisgpu_t* h, int which, int rx, float* dst, long long cap) 
 	const size_t chan = (size_t)rx * 2 + (which & 1);
 	const float2* src;
 	long long n = h->L;
-	const int pb = (int)((h->block_idx - 1) & 1);
 	if (h->block_idx == 0) return -AISGPU_ERR_STATE;
-	if (which < 2) src = h->d_c48[pb] + chan * h->L;
+	const int q = (int)((h->block_idx - 1) % NBUF);
+	if (which < 2) src = h->d_c48[q] + chan * h->L;
 	else if (which < 4) src = h->d_cgf + chan * (CGF_HIST + h->L) + CGF_HIST;
 	else {
 		// FIR outputs exist for every sample that belongs to a group completed in this block:

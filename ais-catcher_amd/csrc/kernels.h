@@ -63,7 +63,7 @@ struct K4Params {
 	int n_chains, n_groups, n_chunks, warm;
 };
 
-hipError_t launch_k1(const K1Params& p, int K, bool cu8, int tile96, int depth, int spans, int n_rx, hipStream_t s);
+hipError_t launch_k1(const K1Params& p, int K, bool cu8, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s);
 hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long block_bytes, void* hist, int tail_bytes,
                           int n_rx, hipStream_t s);
 hipError_t launch_k2a(const K2Params& p, int n_chan, hipStream_t s);

@@ -64,14 +64,16 @@ __device__ __forceinline__ void cic5_dec_chunk(float2 (&v)[2 * NOUT + 4], float2
 //     separate 8-entry history array (row -1).
 //   * small levels (n_s <= 512): contiguous, 8 leading history slots, thread t produces output t.
 // ------------------------------------------------------------------------------------------
-constexpr int K1_THREADS = 256;
 constexpr int R16 = 18, R8 = 10, R4 = 6; // padded row lengths (float2) for chunk sizes 16, 8, 4
 
-template <int K, int P>
+// NT = threads per workgroup.  NT = 64 makes every WAVE an autonomous stream processor: all levels are
+// wave-private, __syncthreads() degenerates to a wait for the wave's own LDS operations, and nothing ever
+// waits for another wave.
+template <int K, int P, int NT>
 struct K1Cfg {
 	static constexpr int TILE_IN = P << K;
-	static constexpr int CE = TILE_IN / K1_THREADS; // samples per thread of the entry level
-	static_assert(TILE_IN % K1_THREADS == 0 || TILE_IN < K1_THREADS, "tile");
+	static constexpr int CE = TILE_IN / NT; // samples per thread of the entry level
+	static_assert(TILE_IN % NT == 0 || TILE_IN < NT, "tile");
 	static constexpr bool has16 = CE >= 16, has8 = CE >= 8, has4 = CE >= 4;
 	static_assert(CE <= 16, "tile too large for the LDS layout");
 	static constexpr int nbig = (has16 ? 1 : 0) + (has8 ? 1 : 0) + (has4 ? 1 : 0);
@@ -79,10 +81,10 @@ struct K1Cfg {
 	static constexpr int n(int s) { return TILE_IN >> s; }
 	// offsets in float2 units
 	static constexpr int off16 = 0;
-	static constexpr int size16 = has16 ? K1_THREADS * R16 : 0;
+	static constexpr int size16 = has16 ? NT * R16 : 0;
 	static constexpr int off8 = off16 + size16;
-	static constexpr int size8 = has8 ? K1_THREADS * R8 : 0;
-	static constexpr int size4 = (has4 && !has16) ? K1_THREADS * R4 : 0; // aliases the dead 16-level otherwise
+	static constexpr int size8 = has8 ? NT * R8 : 0;
+	static constexpr int size4 = (has4 && !has16) ? NT * R4 : 0; // aliases the dead 16-level otherwise
 	static constexpr int off4 = has16 ? off16 : off8 + size8;
 	static constexpr int off_small0 = off8 + size8 + size4;
 	static constexpr int small_off(int s) { // levels first_small .. K (level K = 96 kHz)
@@ -128,9 +130,9 @@ __device__ __forceinline__ float2 cic5_small(const float4* lvl4, int t) {
 
 // D = prefetch depth in tiles: D * TILE bytes per workgroup are in flight, which is what covers the HBM
 // latency (measured: with one tile in flight the kernel is latency bound at ~50 % of peak).
-template <int K, int P, int D, bool CU8>
-__global__ __launch_bounds__(K1_THREADS) void k1_frontend(K1Params p) {
-	using C = K1Cfg<K, P>;
+template <int K, int P, int D, int NT, bool CU8>
+__global__ __launch_bounds__(NT) void k1_frontend(K1Params p) {
+	using C = K1Cfg<K, P, NT>;
 	static_assert(K >= 1 && K <= 4, "ladder depth");
 	// Other kernels of the pipeline run concurrently on other streams; the bandwidth-bound front end gets a
 	// higher issue priority than the throughput kernels behind it (only the tiny phasor kernel is higher).
@@ -165,8 +167,8 @@ __global__ __launch_bounds__(K1_THREADS) void k1_frontend(K1Params p) {
 
 	// ---- register prefetch: 16 bytes per thread per slot, coalesced; D tiles deep
 	constexpr int TILE_BYTES = TILE_IN * (CU8 ? 2 : 8);
-	constexpr int NV = TILE_BYTES >= K1_THREADS * 16 ? TILE_BYTES / (K1_THREADS * 16) : 1;
-	constexpr bool PARTIAL = TILE_BYTES < K1_THREADS * 16; // not every thread has a 16-byte piece
+	constexpr int NV = TILE_BYTES >= NT * 16 ? TILE_BYTES / (NT * 16) : 1;
+	constexpr bool PARTIAL = TILE_BYTES < NT * 16; // not every thread has a 16-byte piece
 	uint4 pre[D][NV];
 	auto prefetch = [&](uint4 (&r)[NV], int tile) {
 		// tile -1 lives in the history buffer (last TILE_IN samples of the previous block)
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_frontend(K1Params p) {
 #pragma unroll
 		for (int e = 0; e < NV; e++) {
 			if (PARTIAL) r[e] = (t * 16 < TILE_BYTES) ? src[t] : make_uint4(0, 0, 0, 0);
-			else r[e] = src[e * K1_THREADS + t];
+			else r[e] = src[e * NT + t];
 		}
 	};
 	auto store_sample_pair = [&](int s, float4 v) { // s: even sample index inside the tile -> entry level
@@ -190,14 +192,14 @@ __global__ __launch_bounds__(K1_THREADS) void k1_frontend(K1Params p) {
 		if (!CU8) {
 #pragma unroll
 			for (int e = 0; e < NV; e++) {
-				const int s = (e * K1_THREADS + t) * 2;
+				const int s = (e * NT + t) * 2;
 				if (PARTIAL && s >= TILE_IN) continue;
 				store_sample_pair(s, make_float4(__uint_as_float(r[e].x), __uint_as_float(r[e].y), __uint_as_float(r[e].z), __uint_as_float(r[e].w)));
 			}
 		} else {
 #pragma unroll
 			for (int e = 0; e < NV; e++) {
-				const int s = (e * K1_THREADS + t) * 8; // 16 bytes = 8 CU8 samples
+				const int s = (e * NT + t) * 8; // 16 bytes = 8 CU8 samples
 				if (PARTIAL && s >= TILE_IN) continue;
 				const unsigned w[4] = { r[e].x, r[e].y, r[e].z, r[e].w };
 #pragma unroll
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_frontend(K1Params p) {
 #pragma unroll
 			for (int e = 0; e < 4; e++) dst[e] = pack(o[2 * e], o[2 * e + 1]);
 			__syncthreads();
-			if (t == K1_THREADS - 1) { // tail for the next tile (this level's body is dead from here on)
+			if (t == NT - 1) { // tail for the next tile (this level's body is dead from here on)
 #pragma unroll
 				for (int e = 0; e < 4; e++) h16[e] = ov[4 + e];
 			}
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_frontend(K1Params p) {
 			dst[0] = pack(o[0], o[1]);
 			dst[1] = pack(o[2], o[3]);
 			__syncthreads();
-			if (t == K1_THREADS - 1) {
+			if (t == NT - 1) {
 #pragma unroll
 				for (int e = 0; e < 4; e++) h8[e] = ov[e];
 			}
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_frontend(K1Params p) {
 			cic5_dec_chunk<2>(v, o);
 			smem4[C::small_off(C::first_small) / 2 + 4 + t] = pack(o[0], o[1]);
 			__syncthreads();
-			if (t == K1_THREADS - 1) { h4[0] = b0; h4[1] = b1; h4[2] = o0; h4[3] = o1; } // last 8 samples of this level
+			if (t == NT - 1) { h4[0] = b0; h4[1] = b1; h4[2] = o0; h4[3] = o1; } // last 8 samples of this level
 		}
 		// ---- remaining stages on contiguous levels: thread t < n/2 makes output t from in[2t-5..2t]
 #pragma unroll
@@ -913,44 +915,46 @@ __global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-template <int K, int P, int D, bool CU8>
+template <int K, int P, int D, int NT, bool CU8>
 static hipError_t launch_k1_t(const K1Params& p, int spans, int n_rx, hipStream_t s) {
 	static bool attr_set = false;
-	constexpr int bytes = K1Cfg<K, P>::bytes;
+	constexpr int bytes = K1Cfg<K, P, NT>::bytes;
 	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute((const void*)k1_frontend<K, P, D, CU8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+		hipError_t e = hipFuncSetAttribute((const void*)k1_frontend<K, P, D, NT, CU8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
-	hipLaunchKernelGGL((k1_frontend<K, P, D, CU8>), dim3(spans, n_rx), dim3(K1_THREADS), bytes, s, p);
+	hipLaunchKernelGGL((k1_frontend<K, P, D, NT, CU8>), dim3(spans, n_rx), dim3(NT), bytes, s, p);
 	return hipGetLastError();
 }
 
-template <int P, int D>
+template <int P, int D, int NT>
 static hipError_t launch_k1_p(const K1Params& p, int K, bool cu8, int spans, int n_rx, hipStream_t s) {
 	switch (K * 2 + (cu8 ? 1 : 0)) {
-	case 8: return launch_k1_t<4, P, D, false>(p, spans, n_rx, s);
-	case 9: return launch_k1_t<4, P, D, true>(p, spans, n_rx, s);
-	case 6: return launch_k1_t<3, P, D, false>(p, spans, n_rx, s);
-	case 7: return launch_k1_t<3, P, D, true>(p, spans, n_rx, s);
-	case 4: return launch_k1_t<2, P, D, false>(p, spans, n_rx, s);
-	case 5: return launch_k1_t<2, P, D, true>(p, spans, n_rx, s);
-	case 2: return launch_k1_t<1, P, D, false>(p, spans, n_rx, s);
-	case 3: return launch_k1_t<1, P, D, true>(p, spans, n_rx, s);
+	case 8: return launch_k1_t<4, P, D, NT, false>(p, spans, n_rx, s);
+	case 9: return launch_k1_t<4, P, D, NT, true>(p, spans, n_rx, s);
+	case 6: return launch_k1_t<3, P, D, NT, false>(p, spans, n_rx, s);
+	case 7: return launch_k1_t<3, P, D, NT, true>(p, spans, n_rx, s);
+	case 4: return launch_k1_t<2, P, D, NT, false>(p, spans, n_rx, s);
+	case 5: return launch_k1_t<2, P, D, NT, true>(p, spans, n_rx, s);
+	case 2: return launch_k1_t<1, P, D, NT, false>(p, spans, n_rx, s);
+	case 3: return launch_k1_t<1, P, D, NT, true>(p, spans, n_rx, s);
 	}
 	return hipErrorInvalidValue;
 }
 
-// tile96: samples at 96 kHz per tile (256, 128 or 64); depth: tiles prefetched ahead (1..4)
-hipError_t launch_k1(const K1Params& p, int K, bool cu8, int tile96, int depth, int spans, int n_rx, hipStream_t s) {
-	switch (tile96 * 10 + depth) {
-	case 2561: return launch_k1_p<256, 1>(p, K, cu8, spans, n_rx, s);
-	case 2562: return launch_k1_p<256, 2>(p, K, cu8, spans, n_rx, s);
-	case 2563: return launch_k1_p<256, 3>(p, K, cu8, spans, n_rx, s);
-	case 1282: return launch_k1_p<128, 2>(p, K, cu8, spans, n_rx, s);
-	case 1283: return launch_k1_p<128, 3>(p, K, cu8, spans, n_rx, s);
-	case 1284: return launch_k1_p<128, 4>(p, K, cu8, spans, n_rx, s);
-	case 644: return launch_k1_p<64, 4>(p, K, cu8, spans, n_rx, s);
+// tile96: samples at 96 kHz per tile; depth: tiles prefetched ahead; threads: workgroup size (256, or 64 = one
+// autonomous wave per workgroup)
+hipError_t launch_k1(const K1Params& p, int K, bool cu8, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s) {
+	switch (threads * 10000 + tile96 * 10 + depth) {
+	case 2562561: return launch_k1_p<256, 1, 256>(p, K, cu8, spans, n_rx, s);
+	case 2562562: return launch_k1_p<256, 2, 256>(p, K, cu8, spans, n_rx, s);
+	case 2561282: return launch_k1_p<128, 2, 256>(p, K, cu8, spans, n_rx, s);
+	case 2561283: return launch_k1_p<128, 3, 256>(p, K, cu8, spans, n_rx, s);
+	case 640641: return launch_k1_p<64, 1, 64>(p, K, cu8, spans, n_rx, s);
+	case 640642: return launch_k1_p<64, 2, 64>(p, K, cu8, spans, n_rx, s);
+	case 640321: return launch_k1_p<32, 1, 64>(p, K, cu8, spans, n_rx, s);
+	case 640322: return launch_k1_p<32, 2, 64>(p, K, cu8, spans, n_rx, s);
 	}
 	return hipErrorInvalidValue;
 }

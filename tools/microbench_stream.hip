@@ -1,0 +1,83 @@
+// tools/microbench_stream.hip -- read-bandwidth ceilings on MI355X for the access patterns of the front end.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/microbench_stream.hip -o tools/microbench_stream
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+// (a) classic grid-stride streaming read, 16 B per lane
+__global__ __launch_bounds__(256) void gridstride(const float4* __restrict__ in, float* out, size_t n4) {
+	float acc = 0;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+		float4 v = in[i];
+		acc += v.x + v.y + v.z + v.w;
+	}
+	if (acc == 12345.678f) out[0] = acc;
+}
+// (b) span walk: each workgroup streams a contiguous span tile by tile (NV float4 per thread per tile), prefetch 1 tile
+template <int NT, int NV, int LDSB>
+__global__ __launch_bounds__(NT) void spanwalk(const float4* __restrict__ in, float* out, int tiles_per_span, size_t span_stride4) {
+	extern __shared__ float4 lds[];
+	const float4* src = in + (size_t)blockIdx.x * span_stride4;
+	float4 pre[NV];
+#pragma unroll
+	for (int e = 0; e < NV; e++) pre[e] = src[e * NT + threadIdx.x];
+	float acc = 0;
+	for (int t = 0; t < tiles_per_span; t++) {
+		float4 cur[NV];
+#pragma unroll
+		for (int e = 0; e < NV; e++) cur[e] = pre[e];
+		const int tn = t + 1 < tiles_per_span ? t + 1 : t;
+#pragma unroll
+		for (int e = 0; e < NV; e++) pre[e] = src[(size_t)tn * NT * NV + e * NT + threadIdx.x];
+#pragma unroll
+		for (int e = 0; e < NV; e++) acc += cur[e].x + cur[e].y + cur[e].z + cur[e].w;
+		if (LDSB && threadIdx.x == 0 && acc == 1.2345f) lds[0] = cur[0];
+	}
+	if (acc == 12345.678f) out[0] = acc;
+}
+
+template <typename F>
+static void timeit(const char* name, F launch, double bytes) {
+	hipEvent_t a, b;
+	hipEventCreate(&a); hipEventCreate(&b);
+	launch();
+	hipDeviceSynchronize();
+	hipEventRecord(a);
+	for (int i = 0; i < 5; i++) launch();
+	hipEventRecord(b);
+	hipEventSynchronize(b);
+	float ms = 0;
+	hipEventElapsedTime(&ms, a, b);
+	ms /= 5;
+	printf("%-44s %8.3f ms  %8.1f GB/s\n", name, ms, bytes / ms / 1e6);
+}
+
+int main() {
+	const size_t bytes = (size_t)256 * 786432 * 8; // 1.61 GB, the bench block
+	float4* d; float* o;
+	hipMalloc(&d, bytes + (1 << 20)); hipMalloc(&o, 64);
+	hipMemset(d, 1, bytes);
+	const size_t n4 = bytes / 16;
+	for (int g : { 2048, 8192, 32768 })
+		timeit(("gridstride grid=" + std::to_string(g)).c_str(), [&] { hipLaunchKernelGGL(gridstride, dim3(g), dim3(256), 0, 0, d, o, n4); }, (double)bytes);
+	// K1-like: 1024 workgroups of 256 threads, 32 KB tiles, 70 KB LDS (2 per CU)
+	{
+		auto k = spanwalk<256, 8, 1>;
+		hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 70208);
+		timeit("spanwalk 1024 WG x256, 32KB tile, 70KB LDS", [&] { hipLaunchKernelGGL(k, dim3(1024), dim3(256), 70208, 0, d, o, 48, (size_t)48 * 2048); }, (double)bytes);
+		timeit("spanwalk 2048 WG x256, 32KB tile, 70KB LDS", [&] { hipLaunchKernelGGL(k, dim3(2048), dim3(256), 70208, 0, d, o, 24, (size_t)24 * 2048); }, (double)bytes);
+	}
+	{
+		auto k = spanwalk<256, 8, 0>;
+		timeit("spanwalk 1024 WG x256, 32KB tile, no LDS", [&] { hipLaunchKernelGGL(k, dim3(1024), dim3(256), 0, 0, d, o, 48, (size_t)48 * 2048); }, (double)bytes);
+		timeit("spanwalk 4096 WG x256, 32KB tile, no LDS", [&] { hipLaunchKernelGGL(k, dim3(4096), dim3(256), 0, 0, d, o, 12, (size_t)12 * 2048); }, (double)bytes);
+	}
+	{
+		auto k = spanwalk<64, 8, 1>;
+		hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 18432);
+		timeit("spanwalk 8192 WG x64, 8KB tile, 18KB LDS", [&] { hipLaunchKernelGGL(k, dim3(8192), dim3(64), 18432, 0, d, o, 24, (size_t)24 * 512); }, (double)bytes);
+		auto k2 = spanwalk<64, 8, 0>;
+		timeit("spanwalk 8192 WG x64, 8KB tile, no LDS", [&] { hipLaunchKernelGGL(k2, dim3(8192), dim3(64), 0, 0, d, o, 24, (size_t)24 * 512); }, (double)bytes);
+		timeit("spanwalk 32768 WG x64, 8KB tile, no LDS", [&] { hipLaunchKernelGGL(k2, dim3(32768), dim3(64), 0, 0, d, o, 6, (size_t)6 * 512); }, (double)bytes);
+	}
+	return 0;
+}

@@ -1,16 +1,10 @@
 #!/bin/bash
-# K1 tile-size / prefetch-depth sweep on the GPU box: serial (non-overlapped) kernel times from the library's HIP events
+# K1 geometry sweep on the GPU box ("threads,tile96,depth"): serial (isolated) K1 time + overlapped step time
 cd "$(dirname "$0")/.."
-for cfg in "256 1" "256 2" "256 3" "128 2" "128 3" "128 4" "64 4"; do
-  set -- $cfg
-  AISGPU_SERIAL=1 AISGPU_TILE96=$1 AISGPU_DEPTH=$2 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+for cfg in "256,256,2" "64,64,1" "64,64,2" "64,32,1" "64,32,2"; do
+  AISGPU_K1=$cfg python bench.py --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print('P=$1 D=$2 serial : ms_per_step', d['ms_per_step'], 'k1_ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'])"
-  AISGPU_TILE96=$1 AISGPU_DEPTH=$2 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
-import sys, json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d = json.loads(l); print('P=$1 D=$2 overlap: ms_per_step', d['ms_per_step'], 'k1_ms', d['roofline']['avg_launch_ms'], 'value', d['value'])"
+        d = json.loads(l); r = d['roofline']; print('K1=$cfg : ms_per_step', d['ms_per_step'], 'value', d['value'], 'k1 overlapped ms', r['avg_launch_ms'], 'isolated ms', r['isolated_launch_ms'], 'isolated frac', r['isolated_frac'])"
 done
