@@ -165,6 +165,13 @@ def main():
     samples_per_step = R * BLOCK
     value = shard.aggregate_msamples(samples_per_step, world, args.steps, dt)
     achieved = samples_per_step * ALGO_BYTES_PER_SAMPLE / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+    # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (FETCH_SIZE/WRITE_SIZE, collected separately
+    # by tools/pmc_traffic.sh on this workload and committed under profiles/); expressed like `achieved` (GB/s)
+    traffic = traffic_bytes = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_k1.json")
+    if os.path.exists(tpath) and R == 256 and k1_ms > 0:
+        traffic_bytes = json.load(open(tpath))["hbm_bytes_per_launch"]
+        traffic = round(traffic_bytes / (k1_ms * 1e-3) / 1e9, 1)
     res = {
         "metric": "IQ Msamples/s (CFLOAT32) through ModelDefault chain", "value": round(value, 1),
         "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -175,7 +182,9 @@ def main():
                                % (R, BLOCK),
                    "receivers_per_gpu": R, "block_len": BLOCK, "sample_rate": RATE, "parallelism": "receivers sharded, no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_bytes_per_launch": traffic_bytes,
+                     "algorithmic_bytes_per_launch": samples_per_step * ALGO_BYTES_PER_SAMPLE,
                      "kernel": "k1_frontend", "avg_launch_ms": round(k1_ms, 4), "launches": k1_n,
                      "isolated_launch_ms": round(iso_ms, 4),
                      "isolated_frac": round(samples_per_step * ALGO_BYTES_PER_SAMPLE / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if iso_ms > 0 else None},

@@ -17,8 +17,8 @@
  *   FilterComplex (Filters::Coherent)     DSP/DSP.cpp:215-246
  *   ScatterPLL (/5, signal level)         DSP/DSP.h:76-117
  *   5x PhaseSearchEMA per channel         DSP/Demod.cpp:39-101
- * and, optionally on the device as well (AISGPU_FLAG_DECODE), the consumer
- *   5x AIS::Decoder per channel + NMEA    Marine/AIS.h:82-181, Marine/AIS.cpp:33-142, Marine/Message.cpp:569-631
+ * The consumer -- 5x AIS::Decoder per channel + NMEA (Marine/AIS.h:82-181, Marine/AIS.cpp:33-142,
+ * Marine/Message.cpp:569-631) -- stays on the host, unchanged, fed from aisgpu_fetch() (ais-catcher_amd/host/).
  *
  * A context batches n_receivers independent dual-channel receivers; one aisgpu_run() consumes
  * exactly one reference Receive() block (block_len IQ samples) of every receiver.  Block
@@ -54,7 +54,7 @@ extern "C" {
 typedef struct aisgpu aisgpu_t;
 
 typedef struct aisgpu_cfg {
-	int sample_rate;   /* 1536000, 768000, 384000, 192000, 3072000 (pure 2^k CIC5 ladders, Model.cpp:157-338) */
+	int sample_rate;   /* 1536000, 768000, 384000 or 192000 (pure 2^k CIC5 ladders, Model.cpp:157-338) */
 	int n_receivers;   /* independent dual-channel receiver instances batched on this GPU */
 	int block_len;     /* IQ samples per receiver per Receive() block; multiple of 512 * sample_rate/48000 */
 	int model;         /* AISGPU_MODEL_DEFAULT */
