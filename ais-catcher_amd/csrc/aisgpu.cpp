@@ -3,8 +3,9 @@
 // Everything data-independent that the reference computes with libm or as a sequential float
 // recurrence is produced HERE on the host, with the host's own libm, exactly as the reference
 // would on the same machine: FFT twiddles (DSP/FFT.h:83), the Rotate phasor
-// sequence incl. its once-per-Receive renormalisation (DSP/DSP.cpp:309,315), and the finite set
-// of CGF rot_step phasors (DSP/DSP.cpp:457-458).  The device never calls sin/cos.
+// sequence incl. its once-per-Receive renormalisation (DSP/DSP.cpp:309,315), the finite set
+// of CGF rot_step phasors (DSP/DSP.cpp:457-458) and the fractional resampler's (index, alpha)
+// sequence (DSP/DSP.cpp:192-212).  The device never calls sin/cos.
 // Compiled with -ffp-contract=off (host and device).
 #include <hip/hip_runtime.h>
 
@@ -30,64 +31,87 @@ const float TAPS_COHERENT[17] = { // DSP/Filters.h:35-41
 	1.30411453e-02f, 2.52892989e-03f, 3.40605309e-04f, 3.18610148e-05f, 2.06995719e-06f };
 
 struct EvPair { hipEvent_t a, b; };
-constexpr int NBUF = 3; // ring depth of the buffers that cross from the front-end stream to the others
+constexpr int NBUF = 3;    // ring depth of the buffers that cross from the front-end stream to the others
+constexpr int MAXSUB = 4;  // downstream blocks ("flushes" of the resampler) that one input block can complete
+constexpr int XPAD = 128;  // extra history of the pre-decimated stream in front of one full block (resampler halo)
+
+// How the samples get from the input rate to the two 48 kHz channels (ModelFrontend::buildModel, Model.cpp:129-346)
+enum Mode {
+	MODE_DIRECT,    // rate == 96k * 2^k, k <= 4: one fused front-end kernel
+	MODE_PRE,       // rate == 96k * 2^k, k = 5..7: (k-4) CIC5 stages in a pre-decimation pass, then the fused kernel
+	MODE_RESAMPLE,  // rate between two buckets: (k-2) CIC5 stages, Upsample to the bucket, DS2_2, DS2_1, ...
+};
+
+struct SubOut { int pb, q, groups; long long first_group, first48; };
 
 } // namespace
 
 struct aisgpu {
 	aisgpu_cfg cfg;
-	int K = 0;            // CIC5 stages in front of the 96 kHz point
-	int tile96 = 64;      // 96 kHz samples per front-end tile
+	Mode mode = MODE_DIRECT;
+	int K = 0;            // CIC5 stages executed by the fused front-end kernel (MODE_DIRECT / MODE_PRE)
+	int KP = 0;           // CIC5 stages of the pre-decimation pass
+	int tile96 = 64;      // output samples per front-end tile
 	int depth = 1;        // tiles prefetched ahead by the front end
 	int k1_threads = 64;  // front-end workgroup size (64: one autonomous wave per workgroup)
-	int tile_in = 0;      // input samples per front-end tile (tile96 << K)
 	int in_bytes = 0;     // bytes per input sample
-	int n96 = 0, L = 0, W = 0; // per block: 96 kHz samples, 48 kHz samples per channel, CGF windows
+	int n_pre = 0;        // samples per receiver per input block after the pre-decimation pass
+	int n96 = 0, L = 0, W = 0; // per downstream block: 96 kHz samples, 48 kHz samples per channel, CGF windows
 	int Gcap = 0, words = 0;   // group capacity per block, bit words per chain
 	int n_chan = 0, n_chains = 0;
-	int tiles_per_block = 0, tiles_per_span = 0, spans = 0;
 	float alpha = 0, beta = 1; int has_fdc = 0;
+	float us_increment = 1.0f;
 
-	// Three streams software-pipeline consecutive blocks:
-	//   s0 (stream): Rotate table upload -> K1 -> K1-tail -> K2a   (bandwidth-bound front end)
+	// Streams software-pipeline consecutive blocks:
+	//   s0 (stream): table uploads -> [pre-decimation] -> K1 -> tails -> K2a   (bandwidth-bound front end)
 	//   s3: K2b                                         (sequential CGF phasor recurrence, 8 waves, latency bound)
 	//   s1 (= s2): K2c -> K3 -> K4 (+ D2H of the outputs) (apply phasors, FIR/ScatterPLL, PhaseSearchEMA)
-	// so block b+1's front end overlaps block b's phasor recurrence and back end.  Buffers that cross a
-	// stream boundary are double buffered by block parity.
-	hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, s3 = nullptr; // s3: the CGF phasor recurrence alone
-	hipEvent_t ev_phasor[NBUF] = {}; // s3: phasor(b) done -> s1 may apply it
+	// Buffers that cross a stream boundary are ring buffered by downstream-block index.
+	hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, s3 = nullptr;
+	hipEvent_t ev_phasor[NBUF] = {};  // s3: phasor(f) done -> s1 may apply it
 	bool serial = false;
-	hipEvent_t ev_front[NBUF] = {}; // s0: K2a(b) done           -> s3 may start K2b(b)
-	hipEvent_t ev_c48free[NBUF] = {}; // s1: K2c(b) done (c48/fz/rotT[q] consumed) -> s0 may run K1(b+NBUF)
-	hipEvent_t ev_mid[2] = { nullptr, nullptr };   // s1: K3(b) done            -> s2 may start K4(b)
-	hipEvent_t ev_ema[2] = { nullptr, nullptr };   // s2: K4(b) done (sym/lvl[p] consumed) -> s1 may run K3(b+2)
+	hipEvent_t ev_front[NBUF] = {};   // s0: K2a(f) done -> s3 may start K2b(f)
+	hipEvent_t ev_c48free[NBUF] = {}; // s1: K2c(f) done (c48/fz/rotT[q] consumed) -> s0 may run the front end of f+NBUF
+	hipEvent_t ev_ema[2] = {};        // s2: K4(f) done (sym/lvl[p] consumed)
 	// device buffers
-	void* d_in = nullptr; void* d_hist = nullptr;
-	float2* d_rot[2] = { nullptr, nullptr };
-	float2 *d_c48[NBUF] = {}, *d_sym[2] = { nullptr, nullptr };
+	void* d_in = nullptr; void* d_hist = nullptr; void* d_hist2 = nullptr;
+	float2* d_xpre[2] = {};           // pre-decimated stream: [R][xh + n_pre], ping-pong by input block (MODE_PRE uses [0] only)
+	float2* d_rot[2] = {};
+	int* d_usidx[2] = {}; float* d_usalpha[2] = {};
+	float2 *d_c48[NBUF] = {}, *d_sym[2] = {};
 	float2 *d_rotT[NBUF] = {};
 	float2 *d_cgf = nullptr, *d_omega = nullptr, *d_step = nullptr, *d_rotstate = nullptr, *d_firtap = nullptr;
-	float *d_ppmtab = nullptr, *d_ppm[NBUF] = {}, *d_lvl[2] = { nullptr, nullptr };
+	float *d_ppmtab = nullptr, *d_ppm[NBUF] = {}, *d_lvl[2] = {};
 	int* d_fz[NBUF] = {};
-	uint32_t* d_bits[2] = { nullptr, nullptr };
-	EmaState* d_ema[2] = { nullptr, nullptr }; // state before / after the current block (swapped per block)
+	uint32_t* d_bits[2] = {};
+	EmaState* d_ema[2] = {}; // state before / after the current downstream block (swapped per block)
 	uint32_t* d_pswords = nullptr; float *d_psma0 = nullptr, *d_psma1 = nullptr; unsigned* d_psfin = nullptr; int* d_psflag = nullptr;
-	int ps_chunks = 1, ps_warm = 256; bool ps_parallel = true;
+	int ps_warm = 256; bool ps_parallel = true;
 	// host (pinned)
 	void* h_in = nullptr;
-	float2* h_rot[2] = { nullptr, nullptr };
-	hipEvent_t rot_ev[2] = { nullptr, nullptr };
-	uint32_t* h_bits = nullptr; float* h_lvl = nullptr; float* h_ppm = nullptr;
+	float2* h_rot[2] = {};
+	int* h_usidx[2] = {}; float* h_usalpha[2] = {};
+	hipEvent_t rot_ev[2] = {};
+	uint32_t* h_bits = nullptr; float* h_lvl = nullptr; float* h_ppm = nullptr; // MAXSUB slots each
 	// stream state
-	long long block_idx = 0;     // blocks run so far
-	long long n48 = 0;           // 48 kHz samples consumed before the current block
-	float2 rot = { 1.0f, 0.0f }; // Rotate::rot carried across blocks
+	long long in_blocks = 0;     // input blocks run so far
+	long long block_idx = 0;     // downstream blocks run so far
+	long long n48 = 0;           // 48 kHz samples consumed before the current downstream block
+	float2 rot = { 1.0f, 0.0f }; // Rotate::rot carried across Receive() calls
 	float2 mult = { 1.0f, 0.0f };
-	std::vector<float2> rot_tail; // last ROT_HIST phasors of the previous block
+	std::vector<float2> rot_tail; // last ROT_HIST phasors of the previous downstream block
+	// resampler replay (DSP.cpp:192-212): alpha carried, outputs waiting for a full flush
+	float us_alpha = 0.0f;
+	long long us_in = 0;          // inputs consumed so far (pre-decimated samples)
+	std::vector<long long> us_pend_idx; std::vector<float> us_pend_alpha;
+	std::vector<long long> us_tail_idx; std::vector<float> us_tail_alpha; // last US_HIST entries of the previous flush
 	const void* cur_in = nullptr; long long cur_in_stride = 0;
 	bool submitted = false, have_out = false;
-	// last block's output geometry
-	int out_groups = 0; long long out_first_group = 0, out_first48 = 0;
+	SubOut sub[MAXSUB]; int n_sub = 0;
+	// per-kernel geometry
+	int tile_in = 0, tiles_per_block = 0, tiles_per_span = 0, spans = 0;         // fused front end (its own input)
+	int ptile_in = 0, ptiles_per_block = 0, ptiles_per_span = 0, pspans = 0;     // pre-decimation pass
+	int xh = 0;                                                                  // history samples in front of d_xpre rows
 	// timing
 	bool timing = false;
 	std::vector<EvPair> ev_busy, ev_free;
@@ -142,6 +166,74 @@ void drain_events(aisgpu_t* h) {
 	h->ev_busy.clear();
 }
 
+int span_tiles(int tiles_per_block, int n_rx, int threads, int tile96, int requested) {
+	int tps = requested;
+	if (tps <= 0) {
+		tps = tiles_per_block;
+		const long long want = threads == 64 ? 8192 : (tile96 >= 256 ? 1024 : 2048); // workgroups: a few per CU per residency slot
+		while (tps > 8 && (long long)n_rx * ((tiles_per_block + tps - 1) / tps) < want) tps = (tps + 1) / 2;
+	}
+	if (tps > tiles_per_block) tps = tiles_per_block;
+	return tps;
+}
+
+// everything behind the 48 kHz front-end output of one downstream block, ring slot q, parity pb
+int enqueue_downstream(aisgpu_t* h, int q, int pb) {
+	K2Params k2;
+	k2.c48 = h->d_c48[q]; k2.c48_stride = h->L; k2.cgf = h->d_cgf; k2.cgf_stride = CGF_HIST + h->L;
+	k2.omega = h->d_omega; k2.step_table = h->d_step; k2.ppm_table = h->d_ppmtab; k2.fz = h->d_fz[q]; k2.ppm = h->d_ppm[q];
+	k2.rot_state = h->d_rotstate; k2.n_windows = h->W; k2.wide = h->cfg.afc_wide ? 1 : 0;
+	k2.rotT = h->d_rotT[q]; k2.rotT_stride = (h->n_chan + 63) / 64 * 64; k2.n_chan = h->n_chan;
+	HIPCHK(launch_k2a(k2, h->n_chan, h->stream));
+	HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
+
+	// ---- s3: sequential CGF phasor recurrence (needs fz of this block; rotT[q] was last read by apply(f-NBUF))
+	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_front[q], 0));
+	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_c48free[q], 0));
+	HIPCHK(launch_k2b(k2, h->n_chan, h->s3));
+	HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
+	// ---- s1: apply the phasors, then FIR-17 + ScatterPLL
+	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_phasor[q], 0));
+	HIPCHK(launch_k2c(k2, h->n_chan, h->s1));
+	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s1));
+	// ScatterPLL groups completed inside this block (DSP/DSP.h:95-117): group g completes with sample 5g+4
+	const long long g0 = h->n48 / 5, g1 = (h->n48 + h->L) / 5;
+	K3Params k3;
+	k3.cgf = h->d_cgf; k3.cgf_stride = CGF_HIST + h->L; k3.sym = h->d_sym[pb]; k3.sym_stride = h->Gcap; k3.lvl = h->d_lvl[pb];
+	k3.fir_tap = h->d_firtap; k3.fir_tap_stride = 8 + h->L;
+	memcpy(k3.taps, TAPS_COHERENT, sizeof k3.taps);
+	k3.first_group = g0; k3.first_sample48 = h->n48; k3.n_groups = (int)(g1 - g0);
+	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_ema[pb], 0)); // sym/lvl[pb] were last read by K4 of block f-2
+	HIPCHK(launch_k3(k3, h->n_chan, h->s1));
+
+	// ---- PhaseSearchEMA chains (same stream)
+	K4Params k4;
+	k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[pb]; k4.bits_stride = h->words;
+	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
+	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag;
+	k4.n_chains = h->n_chains; k4.n_groups = (int)(g1 - g0);
+	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
+	if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, h->s2));
+	else HIPCHK(launch_k4_sequential(k4, h->s2));
+	HIPCHK(hipEventRecord(h->ev_ema[pb], h->s2));
+
+	if (h->n_sub < MAXSUB) {
+		SubOut& s = h->sub[h->n_sub++];
+		s.pb = pb; s.q = q; s.groups = (int)(g1 - g0); s.first_group = g0; s.first48 = h->n48;
+	}
+	h->n48 += h->L;
+	h->block_idx++;
+	return AISGPU_OK;
+}
+
+int sync_all(aisgpu_t* h) {
+	HIPCHK(hipStreamSynchronize(h->stream));
+	HIPCHK(hipStreamSynchronize(h->s1));
+	HIPCHK(hipStreamSynchronize(h->s3));
+	drain_events(h);
+	return AISGPU_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -179,61 +271,72 @@ void aisgpu_default_cfg(aisgpu_cfg* c) {
 int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	if (!cfg || !out) return AISGPU_ERR_ARG;
 	*out = nullptr;
-	int K = -1;
-	float alpha = 0;
-	// pure 2^k ladders of ModelFrontend::buildModel (DSP/Model.cpp:157-338) that fit the LDS tile
-	switch (cfg->sample_rate) {
-	case 192000: K = 1; alpha = -0.8f; break;
-	case 384000: K = 2; alpha = -1.1f; break;
-	case 768000: K = 3; alpha = -1.2f; break;
-	case 1536000: K = 4; alpha = -1.2f; break;
-	default: return AISGPU_ERR_ARG;
+	// ---- ladder selection, ModelFrontend::buildModel (DSP/Model.cpp:129-338): smallest bucket >= rate
+	static const int buckets[8] = { 96000, 192000, 384000, 768000, 1536000, 3072000, 6144000, 12288000 };
+	static const float alphas[8] = { 0.0f, -0.8f, -1.1f, -1.2f, -1.2f, -1.5f, -2.0f, -2.0f };
+	int k = -1;
+	for (int i = 0; i < 8; i++) if (buckets[i] >= cfg->sample_rate) { k = i; break; }
+	if (k < 1 || cfg->sample_rate < 96000) return AISGPU_ERR_ARG;
+	const bool interpolated = buckets[k] != cfg->sample_rate;
+	Mode mode; int K, KP;
+	if (!interpolated) {
+		if (k <= 4) { mode = MODE_DIRECT; K = k; KP = 0; }
+		else { mode = MODE_PRE; K = 4; KP = k - 4; }
+	} else {
+		if (k < 3 || k > 6) return AISGPU_ERR_ARG; // the resampler sits two CIC5 stages in front of 96 kHz
+		mode = MODE_RESAMPLE; K = 0; KP = k - 2;
 	}
-	const int dec = 2 << K; // input samples per 48 kHz sample
 	if (cfg->model != AISGPU_MODEL_DEFAULT) return AISGPU_ERR_ARG;
 	if (cfg->input_format != AISGPU_FMT_CU8 && cfg->input_format != AISGPU_FMT_CF32) return AISGPU_ERR_ARG;
 	if (cfg->n_receivers < 1 || cfg->n_receivers > 65535) return AISGPU_ERR_ARG;
-	if (cfg->block_len < 512 * dec || cfg->block_len % (512 * dec) != 0) return AISGPU_ERR_ARG;
+	// a downstream block must be a whole number of 512-sample CGF windows
+	const int dec48 = 2 << k; // input samples per 48 kHz sample (bucket rate)
+	if (cfg->block_len < 512 * dec48 || cfg->block_len % (512 * dec48) != 0) return AISGPU_ERR_ARG;
 	if (aisgpu_device_count() <= cfg->device_id || cfg->device_id < 0) return AISGPU_ERR_NODEV;
 
 	aisgpu_t* h = new (std::nothrow) aisgpu();
 	if (!h) return AISGPU_ERR_ARG;
 	h->cfg = *cfg;
-	h->K = K;
-	// front-end geometry (tuning knobs; the defaults are the measured best): workgroup size, 96 kHz samples per
-	// tile, prefetch depth.  Valid combinations: 256 threads x {256,128}; 64 threads x {64,32}.
-	h->k1_threads = 64; h->tile96 = 64; h->depth = 1; // measured best: autonomous waves (profiles/r01_k1_geometry_sweep.txt)
+	h->mode = mode; h->K = K; h->KP = KP;
+	// front-end geometry (tuning knobs; the defaults are the measured best): workgroup size, output samples per
+	// tile, prefetch depth.  Compiled combinations: "256,256,2", "64,64,1", "64,64,2".
+	h->k1_threads = 64; h->tile96 = 64; h->depth = 1; // autonomous waves (profiles/r01_k1_geometry_sweep.txt)
 	if (const char* e = getenv("AISGPU_K1")) { // "threads,tile96,depth"
 		int a = 0, b = 0, d = 0;
 		if (sscanf(e, "%d,%d,%d", &a, &b, &d) == 3) {
-			const bool ok = (a == 256 && (b == 256 || b == 128) && (d == 1 || d == 2 || (b == 128 && d == 3)) && !(b == 128 && d == 1)) ||
-			                (a == 64 && (b == 64 || b == 32) && (d == 1 || d == 2));
+			const bool ok = (a == 256 && b == 256 && d == 2) || (a == 64 && b == 64 && (d == 1 || d == 2));
 			if (ok) { h->k1_threads = a; h->tile96 = b; h->depth = d; }
 		}
 	}
-	h->tile_in = h->tile96 << K;
 	h->in_bytes = cfg->input_format == AISGPU_FMT_CU8 ? 2 : 8;
-	h->n96 = cfg->block_len >> K;
+	h->n_pre = cfg->block_len >> KP;
+	if (mode == MODE_RESAMPLE) h->n96 = h->n_pre / 4; // one flush of n_pre samples at the bucket rate >> KP (= 384 kHz)
+	else h->n96 = h->n_pre >> K;
 	h->L = h->n96 / 2;
 	h->W = h->L / 512;
 	h->Gcap = ((h->L + 4) / 5 + 1 + 31) / 32 * 32;
 	h->words = h->Gcap / 32;
 	h->n_chan = cfg->n_receivers * 2;
 	h->n_chains = h->n_chan * 5;
-	h->tiles_per_block = cfg->block_len / h->tile_in;
 	h->has_fdc = cfg->droop ? 1 : 0;
-	h->alpha = alpha;
-	h->beta = 1 - 2 * alpha; // DSP/DSP.h:296, evaluated in float
-	// span length: enough workgroups to fill 256 CUs twice over, at most 1/8 warm-up overhead
-	int tps = cfg->tiles_per_span;
-	if (tps <= 0) {
-		tps = h->tiles_per_block;
-		const long long want = h->k1_threads == 64 ? 8192 : (h->tile96 >= 256 ? 1024 : 2048); // workgroups: a few per CU per residency slot
-		while (tps > 8 && (long long)cfg->n_receivers * ((h->tiles_per_block + tps - 1) / tps) < want) tps = (tps + 1) / 2;
+	h->alpha = alphas[k];
+	h->beta = 1 - 2 * h->alpha; // DSP/DSP.h:296, evaluated in float
+	h->us_increment = (float)cfg->sample_rate / (float)buckets[k]; // DSP/DSP.h:172-176
+	if (K > 0) {
+		h->tile_in = h->tile96 << K;
+		if (h->n_pre % h->tile_in) { delete h; return AISGPU_ERR_ARG; }
+		h->tiles_per_block = h->n_pre / h->tile_in;
+		h->tiles_per_span = span_tiles(h->tiles_per_block, cfg->n_receivers, h->k1_threads, h->tile96, cfg->tiles_per_span);
+		h->spans = (h->tiles_per_block + h->tiles_per_span - 1) / h->tiles_per_span;
 	}
-	if (tps > h->tiles_per_block) tps = h->tiles_per_block;
-	h->tiles_per_span = tps;
-	h->spans = (h->tiles_per_block + tps - 1) / tps;
+	if (KP > 0) {
+		h->ptile_in = h->tile96 << KP;
+		if (cfg->block_len % h->ptile_in) { delete h; return AISGPU_ERR_ARG; }
+		h->ptiles_per_block = cfg->block_len / h->ptile_in;
+		h->ptiles_per_span = span_tiles(h->ptiles_per_block, cfg->n_receivers, h->k1_threads, h->tile96, cfg->tiles_per_span);
+		h->pspans = (h->ptiles_per_block + h->ptiles_per_span - 1) / h->ptiles_per_span;
+		h->xh = mode == MODE_RESAMPLE ? h->n_pre + XPAD : 0;
+	}
 	*out = h; // from here on the caller destroys it on failure
 
 	HIPCHK(hipSetDevice(cfg->device_id));
@@ -253,16 +356,14 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(hipEventCreateWithFlags(&h->ev_phasor[i], hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&h->ev_c48free[i], hipEventDisableTiming));
 	}
-	for (int i = 0; i < 2; i++) {
-		HIPCHK(hipEventCreateWithFlags(&h->ev_mid[i], hipEventDisableTiming));
-		HIPCHK(hipEventCreateWithFlags(&h->ev_ema[i], hipEventDisableTiming));
-	}
+	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_ema[i], hipEventDisableTiming));
 
 	// ---- constant tables (host libm, like the reference on this machine)
 	{
 		float angle = (float)((double)PI_F * 25000.0 / 48000.0); // Model.cpp:31
 		h->mult = make_float2(cosf(angle), sinf(angle));         // std::polar(1.0f, angle), DSP.h:311
 		h->rot_tail.assign(ROT_HIST, make_float2(1.0f, 0.0f));
+		h->us_tail_idx.assign(US_HIST, -1); h->us_tail_alpha.assign(US_HIST, 0.0f); // zero signal before the stream starts
 		std::vector<float2> omega(512), step(FZ_COUNT);
 		std::vector<float> ppm(FZ_COUNT);
 		for (int s = 0; s < 512; s++) { // FFT.h:83
@@ -284,13 +385,28 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(hipMemcpy(h->d_ppmtab, ppm.data(), FZ_COUNT * sizeof(float), hipMemcpyHostToDevice));
 	}
 	const size_t R = cfg->n_receivers, C = h->n_chan;
-	HIPCHK(dalloc((unsigned char**)&h->d_hist, R * h->tile_in * h->in_bytes));
-	// zero signal before the stream starts: CU8 zero is the byte 128 (Utilities/Convert.cpp:255-264)
-	if (cfg->input_format == AISGPU_FMT_CU8) HIPCHK(hipMemset(h->d_hist, 0x80, R * h->tile_in * h->in_bytes));
+	// history of the raw input: the last tile of the previous block (for the first kernel that touches the input)
+	{
+		const size_t first_tile = KP > 0 ? h->ptile_in : h->tile_in;
+		HIPCHK(dalloc((unsigned char**)&h->d_hist, R * first_tile * h->in_bytes));
+		// zero signal before the stream starts: CU8 zero is the byte 128 (Utilities/Convert.cpp:255-264)
+		if (cfg->input_format == AISGPU_FMT_CU8) HIPCHK(hipMemset(h->d_hist, 0x80, R * first_tile * h->in_bytes));
+	}
+	if (KP > 0) {
+		const int nx = mode == MODE_RESAMPLE ? 2 : 1;
+		for (int i = 0; i < nx; i++) HIPCHK(dalloc(&h->d_xpre[i], R * ((size_t)h->xh + h->n_pre)));
+		if (mode == MODE_PRE) HIPCHK(dalloc((unsigned char**)&h->d_hist2, R * h->tile_in * 8));
+	}
 	for (int i = 0; i < 2; i++) {
 		HIPCHK(dalloc(&h->d_rot[i], (size_t)ROT_HIST + h->n96));
 		HIPCHK(hipHostMalloc((void**)&h->h_rot[i], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipHostMallocDefault));
 		HIPCHK(hipEventCreateWithFlags(&h->rot_ev[i], hipEventDisableTiming));
+		if (mode == MODE_RESAMPLE) {
+			HIPCHK(dalloc(&h->d_usidx[i], (size_t)US_HIST + h->n_pre));
+			HIPCHK(dalloc(&h->d_usalpha[i], (size_t)US_HIST + h->n_pre));
+			HIPCHK(hipHostMalloc((void**)&h->h_usidx[i], ((size_t)US_HIST + h->n_pre) * sizeof(int), hipHostMallocDefault));
+			HIPCHK(hipHostMalloc((void**)&h->h_usalpha[i], ((size_t)US_HIST + h->n_pre) * sizeof(float), hipHostMallocDefault));
+		}
 	}
 	for (int i = 0; i < NBUF; i++) {
 		HIPCHK(dalloc(&h->d_c48[i], C * h->L));
@@ -302,6 +418,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(dalloc(&h->d_sym[i], C * 5 * h->Gcap));
 		HIPCHK(dalloc(&h->d_lvl[i], C * h->Gcap));
 		HIPCHK(dalloc(&h->d_bits[i], C * 5 * h->words));
+		HIPCHK(dalloc(&h->d_ema[i], C * 5));
 	}
 	HIPCHK(dalloc(&h->d_cgf, C * (CGF_HIST + h->L)));
 	HIPCHK(dalloc(&h->d_rotstate, C));
@@ -309,20 +426,18 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		std::vector<float2> ones(C, make_float2(1.0f, 0.0f)); // SquareFreqOffsetCorrection::rot = 1.0f (DSP.h:379)
 		HIPCHK(hipMemcpy(h->d_rotstate, ones.data(), C * sizeof(float2), hipMemcpyHostToDevice));
 	}
-	HIPCHK(dalloc(&h->d_ema[0], C * 5));
-	HIPCHK(dalloc(&h->d_ema[1], C * 5));
-	h->ps_chunks = (h->Gcap + PS_CHUNK - 1) / PS_CHUNK;
+	const int ps_chunks = (h->Gcap + PS_CHUNK - 1) / PS_CHUNK;
 	if (const char* e = getenv("AISGPU_PS_WARM")) { int v = atoi(e); if (v >= 1 && v <= PS_CHUNK) h->ps_warm = (v + 15) / 16 * 16; } // test hook: small values force the exact fallback
 	if (getenv("AISGPU_PS_SEQUENTIAL")) h->ps_parallel = false;
-	HIPCHK(dalloc(&h->d_pswords, C * 5 * h->ps_chunks * (PS_CHUNK / 32) * 16));
-	HIPCHK(dalloc(&h->d_psma0, C * 5 * h->ps_chunks * 16));
-	HIPCHK(dalloc(&h->d_psma1, C * 5 * h->ps_chunks * 16));
-	HIPCHK(dalloc(&h->d_psfin, C * 5 * h->ps_chunks * 16));
+	HIPCHK(dalloc(&h->d_pswords, C * 5 * ps_chunks * (PS_CHUNK / 32) * 16));
+	HIPCHK(dalloc(&h->d_psma0, C * 5 * ps_chunks * 16));
+	HIPCHK(dalloc(&h->d_psma1, C * 5 * ps_chunks * 16));
+	HIPCHK(dalloc(&h->d_psfin, C * 5 * ps_chunks * 16));
 	HIPCHK(dalloc(&h->d_psflag, 4));
 	if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_firtap, C * (8 + h->L)));
-	HIPCHK(hipHostMalloc((void**)&h->h_bits, C * 5 * h->words * sizeof(uint32_t), hipHostMallocDefault));
-	HIPCHK(hipHostMalloc((void**)&h->h_lvl, C * h->Gcap * sizeof(float), hipHostMallocDefault));
-	HIPCHK(hipHostMalloc((void**)&h->h_ppm, C * h->W * sizeof(float), hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void**)&h->h_bits, MAXSUB * C * 5 * h->words * sizeof(uint32_t), hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void**)&h->h_lvl, MAXSUB * C * h->Gcap * sizeof(float), hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void**)&h->h_ppm, MAXSUB * C * h->W * sizeof(float), hipHostMallocDefault));
 	HIPCHK(hipDeviceSynchronize());
 	return AISGPU_OK;
 }
@@ -331,7 +446,6 @@ void aisgpu_destroy(aisgpu_t* h) {
 	if (!h) return;
 	if (h->stream) hipStreamSynchronize(h->stream);
 	if (h->s1) hipStreamSynchronize(h->s1);
-	if (h->s2) hipStreamSynchronize(h->s2);
 	if (h->s3) hipStreamSynchronize(h->s3);
 	drain_events(h);
 	for (int i = 0; i < NBUF; i++) {
@@ -341,15 +455,17 @@ void aisgpu_destroy(aisgpu_t* h) {
 		hipFree(h->d_rotT[i]); hipFree(h->d_c48[i]); hipFree(h->d_fz[i]); hipFree(h->d_ppm[i]);
 	}
 	for (int i = 0; i < 2; i++) {
-		if (h->ev_mid[i]) hipEventDestroy(h->ev_mid[i]);
 		if (h->ev_ema[i]) hipEventDestroy(h->ev_ema[i]);
-		hipFree(h->d_sym[i]); hipFree(h->d_lvl[i]); hipFree(h->d_bits[i]);
+		hipFree(h->d_sym[i]); hipFree(h->d_lvl[i]); hipFree(h->d_bits[i]); hipFree(h->d_ema[i]);
+		hipFree(h->d_rot[i]); if (h->h_rot[i]) hipHostFree(h->h_rot[i]); if (h->rot_ev[i]) hipEventDestroy(h->rot_ev[i]);
+		hipFree(h->d_usidx[i]); hipFree(h->d_usalpha[i]); hipFree(h->d_xpre[i]);
+		if (h->h_usidx[i]) hipHostFree(h->h_usidx[i]);
+		if (h->h_usalpha[i]) hipHostFree(h->h_usalpha[i]);
 	}
 	for (auto& p : h->ev_free) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-	hipFree(h->d_in); hipFree(h->d_hist);
-	for (int i = 0; i < 2; i++) { hipFree(h->d_rot[i]); if (h->h_rot[i]) hipHostFree(h->h_rot[i]); if (h->rot_ev[i]) hipEventDestroy(h->rot_ev[i]); }
+	hipFree(h->d_in); hipFree(h->d_hist); hipFree(h->d_hist2);
 	hipFree(h->d_cgf); hipFree(h->d_omega); hipFree(h->d_step);
-	hipFree(h->d_rotstate); hipFree(h->d_firtap); hipFree(h->d_ppmtab); hipFree(h->d_ema[0]); hipFree(h->d_ema[1]);
+	hipFree(h->d_rotstate); hipFree(h->d_firtap); hipFree(h->d_ppmtab);
 	hipFree(h->d_pswords); hipFree(h->d_psma0); hipFree(h->d_psma1); hipFree(h->d_psfin); hipFree(h->d_psflag);
 	if (h->h_in) hipHostFree(h->h_in);
 	if (h->h_bits) hipHostFree(h->h_bits);
@@ -368,10 +484,9 @@ int aisgpu_submit(aisgpu_t* h, int rx, const void* iq, int n_iq) {
 		HIPCHK(hipMalloc(&h->d_in, row * h->cfg.n_receivers));
 		HIPCHK(hipHostMalloc(&h->h_in, row * h->cfg.n_receivers, hipHostMallocDefault));
 	}
-	// the caller's buffer is only borrowed for this call (Device/FileRAW.cpp:131-136): copy to pinned staging
-	// (the previous block's H2D copies are complete: run() orders them before its kernels on the same stream,
-	//  and a new block is only staged after the previous run() was enqueued; we wait for it here)
-	if (!h->submitted && h->block_idx > 0) HIPCHK(hipStreamSynchronize(h->stream));
+	// the caller's buffer is only borrowed for this call (Device/FileRAW.cpp:131-136): copy to pinned staging.
+	// The staging buffer of the previous block has been consumed once the front-end stream is idle.
+	if (!h->submitted && h->in_blocks > 0) HIPCHK(hipStreamSynchronize(h->stream));
 	memcpy((char*)h->h_in + row * rx, iq, row);
 	HIPCHK(hipMemcpyAsync((char*)h->d_in + row * rx, (char*)h->h_in + row * rx, row, hipMemcpyHostToDevice, h->stream));
 	h->cur_in = h->d_in;
@@ -393,87 +508,123 @@ int aisgpu_run(aisgpu_t* h) {
 	if (!h) return AISGPU_ERR_ARG;
 	if (!h->submitted) return AISGPU_ERR_STATE;
 	HIPCHK(hipSetDevice(h->cfg.device_id));
-	const int pb = (int)(h->block_idx & 1);
-	const int q = (int)(h->block_idx % NBUF); // ring slot of c48 / fz / ppm / rotT
-	// the pinned phasor buffer `pb` was last used two blocks ago; wait until that upload has been consumed
-	// (only blocks when the host runs more than one block ahead of the device)
-	if (h->block_idx >= 2) HIPCHK(hipEventSynchronize(h->rot_ev[pb]));
-	gen_rot_table(h, h->h_rot[pb]);
-	HIPCHK(hipMemcpyAsync(h->d_rot[pb], h->h_rot[pb], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
-	HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
+	const bool cu8 = h->cfg.input_format == AISGPU_FMT_CU8;
+	const int R = h->cfg.n_receivers;
+	h->n_sub = 0;
 
-	// c48/fz/ppm[q] were last read by K2b/K2c of block b-NBUF
-	HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[q], 0));
-	K1Params k1;
-	k1.in = h->cur_in; k1.in_stride = h->cur_in_stride; k1.hist = h->d_hist; k1.rot = h->d_rot[pb];
-	k1.c48 = h->d_c48[q]; k1.c48_stride = h->L;
-	k1.tiles_per_block = h->tiles_per_block; k1.tiles_per_span = h->tiles_per_span;
-	k1.alpha = h->alpha; k1.beta = h->beta; k1.has_fdc = h->has_fdc;
 	EvPair ev{};
-	if (h->timing) {
+	auto time_begin = [&]() -> int {
+		if (!h->timing) return AISGPU_OK;
 		if (h->ev_free.empty()) { HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b)); }
 		else { ev = h->ev_free.back(); h->ev_free.pop_back(); }
 		HIPCHK(hipEventRecord(ev.a, h->stream));
+		return AISGPU_OK;
+	};
+	auto time_end = [&]() -> int {
+		if (!h->timing) return AISGPU_OK;
+		HIPCHK(hipEventRecord(ev.b, h->stream));
+		h->ev_busy.push_back(ev);
+		return AISGPU_OK;
+	};
+
+	// ---- pre-decimation pass (MODE_PRE / MODE_RESAMPLE): KP CIC5 stages at the input rate -> d_xpre
+	float2* xcur = nullptr;
+	long long xstride = 0;
+	if (h->KP > 0) {
+		const int xb = h->mode == MODE_RESAMPLE ? (int)(h->in_blocks & 1) : 0;
+		xcur = h->d_xpre[xb];
+		xstride = (long long)h->xh + h->n_pre;
+		if (h->mode == MODE_RESAMPLE && h->in_blocks > 0) // history = the last xh samples before this block
+			HIPCHK(launch_copy_rows(h->d_xpre[xb ^ 1] + h->n_pre, xstride, xcur, xstride, h->xh, R, h->stream));
+		K1Params kp{};
+		kp.in = h->cur_in; kp.in_stride = h->cur_in_stride; kp.hist = h->d_hist; kp.rot = nullptr;
+		kp.c48 = nullptr; kp.c48_stride = 0;
+		kp.tiles_per_block = h->ptiles_per_block; kp.tiles_per_span = h->ptiles_per_span;
+		kp.alpha = 0; kp.beta = 1; kp.has_fdc = 0;
+		kp.pre_out = xcur + h->xh; kp.pre_stride = xstride;
+		int rc = time_begin(); if (rc) return rc;
+		HIPCHK(launch_k1(kp, h->KP, cu8, h->tile96, h->depth, h->k1_threads, h->pspans, R, h->stream));
+		rc = time_end(); if (rc) return rc;
+		HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist,
+		                      h->ptile_in * h->in_bytes, R, h->stream));
 	}
-	HIPCHK(launch_k1(k1, h->K, h->cfg.input_format == AISGPU_FMT_CU8, h->tile96, h->depth, h->k1_threads, h->spans, h->cfg.n_receivers, h->stream));
-	if (h->timing) { HIPCHK(hipEventRecord(ev.b, h->stream)); h->ev_busy.push_back(ev); }
-	HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist,
-	                      h->tile_in * h->in_bytes, h->cfg.n_receivers, h->stream));
 
-	K2Params k2;
-	k2.c48 = h->d_c48[q]; k2.c48_stride = h->L; k2.cgf = h->d_cgf; k2.cgf_stride = CGF_HIST + h->L;
-	k2.omega = h->d_omega; k2.step_table = h->d_step; k2.ppm_table = h->d_ppmtab; k2.fz = h->d_fz[q]; k2.ppm = h->d_ppm[q];
-	k2.rot_state = h->d_rotstate; k2.n_windows = h->W; k2.wide = h->cfg.afc_wide ? 1 : 0;
-	k2.rotT = h->d_rotT[q]; k2.rotT_stride = (h->n_chan + 63) / 64 * 64; k2.n_chan = h->n_chan;
-	HIPCHK(launch_k2a(k2, h->n_chan, h->stream));
-	HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
-
-	// ---- s3: sequential CGF phasor recurrence (needs fz of this block; rotT[q] was last read by apply(b-NBUF))
-	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_front[q], 0));
-	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_c48free[q], 0));
-	HIPCHK(launch_k2b(k2, h->n_chan, h->s3));
-	HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
-	// ---- s1: apply the phasors, then FIR-17 + ScatterPLL
-	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_phasor[q], 0));
-	HIPCHK(launch_k2c(k2, h->n_chan, h->s1));
-	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s1));
-	// ScatterPLL groups completed inside this block (DSP/DSP.h:95-117): group g completes with sample 5g+4
-	const long long g0 = h->n48 / 5, g1 = (h->n48 + h->L) / 5;
-	K3Params k3;
-	k3.cgf = h->d_cgf; k3.cgf_stride = CGF_HIST + h->L; k3.sym = h->d_sym[pb]; k3.sym_stride = h->Gcap; k3.lvl = h->d_lvl[pb];
-	k3.fir_tap = h->d_firtap; k3.fir_tap_stride = 8 + h->L;
-	memcpy(k3.taps, TAPS_COHERENT, sizeof k3.taps);
-	k3.first_group = g0; k3.first_sample48 = h->n48; k3.n_groups = (int)(g1 - g0);
-	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_ema[pb], 0)); // sym/lvl[pb] were last read by K4 of block b-2
-	HIPCHK(launch_k3(k3, h->n_chan, h->s1));
-	HIPCHK(hipEventRecord(h->ev_mid[pb], h->s1));
-
-	// ---- s2: sequential PhaseSearchEMA chains
-	K4Params k4;
-	k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[pb]; k4.bits_stride = h->words;
-	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
-	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag;
-	k4.n_chains = h->n_chains; k4.n_groups = (int)(g1 - g0);
-	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
-	HIPCHK(hipStreamWaitEvent(h->s2, h->ev_mid[pb], 0));
-	if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, h->s2));
-	else HIPCHK(launch_k4_sequential(k4, h->s2));
-	HIPCHK(hipEventRecord(h->ev_ema[pb], h->s2));
-
-	h->out_groups = (int)(g1 - g0); h->out_first_group = g0; h->out_first48 = h->n48;
-	h->n48 += h->L;
-	h->block_idx++;
+	if (h->mode != MODE_RESAMPLE) {
+		// ---- one downstream block per input block
+		const int pb = (int)(h->block_idx & 1);
+		const int q = (int)(h->block_idx % NBUF); // ring slot of c48 / fz / ppm / rotT
+		// the pinned phasor buffer `pb` was last used two blocks ago; wait until that upload has been consumed
+		// (only blocks when the host runs more than one block ahead of the device)
+		if (h->block_idx >= 2) HIPCHK(hipEventSynchronize(h->rot_ev[pb]));
+		gen_rot_table(h, h->h_rot[pb]);
+		HIPCHK(hipMemcpyAsync(h->d_rot[pb], h->h_rot[pb], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
+		// c48/fz/ppm[q] were last read by K2b/K2c of block f-NBUF
+		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[q], 0));
+		K1Params k1{};
+		const bool from_pre = h->mode == MODE_PRE;
+		k1.in = from_pre ? (const void*)xcur : h->cur_in;
+		k1.in_stride = from_pre ? xstride : h->cur_in_stride;
+		k1.hist = from_pre ? h->d_hist2 : h->d_hist;
+		k1.rot = h->d_rot[pb];
+		k1.c48 = h->d_c48[q]; k1.c48_stride = h->L;
+		k1.tiles_per_block = h->tiles_per_block; k1.tiles_per_span = h->tiles_per_span;
+		k1.alpha = h->alpha; k1.beta = h->beta; k1.has_fdc = h->has_fdc;
+		k1.pre_out = nullptr; k1.pre_stride = 0;
+		if (!from_pre) { int rc = time_begin(); if (rc) return rc; }
+		HIPCHK(launch_k1(k1, h->K, from_pre ? false : cu8, h->tile96, h->depth, h->k1_threads, h->spans, R, h->stream));
+		if (!from_pre) { int rc = time_end(); if (rc) return rc; }
+		if (from_pre) HIPCHK(launch_k1_tail(xcur, xstride * 8, (long long)h->n_pre * 8, h->d_hist2, h->tile_in * 8, R, h->stream));
+		else HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist,
+		                           h->tile_in * h->in_bytes, R, h->stream));
+		int rc = enqueue_downstream(h, q, pb);
+		if (rc) return rc;
+	} else {
+		// ---- replay Upsample::Receive over this block's n_pre inputs (DSP.cpp:192-212); every time `len` outputs
+		// are complete the reference flushes them downstream as one Receive() call -> one downstream block here
+		const long long in0 = h->us_in;
+		const int len = h->n_pre;
+		for (int i = 0; i < len; i++) {
+			do {
+				h->us_pend_idx.push_back(in0 + i);
+				h->us_pend_alpha.push_back(h->us_alpha);
+				h->us_alpha += h->us_increment;
+				if ((int)h->us_pend_idx.size() == len) {
+					const int pb = (int)(h->block_idx & 1);
+					const int q = (int)(h->block_idx % NBUF);
+					if (h->block_idx >= 2) HIPCHK(hipEventSynchronize(h->rot_ev[pb]));
+					gen_rot_table(h, h->h_rot[pb]);
+					int* ti = h->h_usidx[pb]; float* ta = h->h_usalpha[pb];
+					for (int e = 0; e < US_HIST; e++) { // halo: the tail of the previous flush, re-based to this block
+						const long long a = h->us_tail_idx[e];
+						ti[e] = a < 0 ? -1 : (int)(a - in0);
+						ta[e] = h->us_tail_alpha[e];
+					}
+					for (int e = 0; e < len; e++) { ti[US_HIST + e] = (int)(h->us_pend_idx[e] - in0); ta[US_HIST + e] = h->us_pend_alpha[e]; }
+					for (int e = 0; e < US_HIST; e++) { h->us_tail_idx[e] = h->us_pend_idx[len - US_HIST + e]; h->us_tail_alpha[e] = h->us_pend_alpha[len - US_HIST + e]; }
+					h->us_pend_idx.clear(); h->us_pend_alpha.clear();
+					HIPCHK(hipMemcpyAsync(h->d_rot[pb], h->h_rot[pb], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+					HIPCHK(hipMemcpyAsync(h->d_usidx[pb], ti, ((size_t)US_HIST + len) * sizeof(int), hipMemcpyHostToDevice, h->stream));
+					HIPCHK(hipMemcpyAsync(h->d_usalpha[pb], ta, ((size_t)US_HIST + len) * sizeof(float), hipMemcpyHostToDevice, h->stream));
+					HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
+					HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[q], 0));
+					K1uParams ku;
+					ku.xin = xcur; ku.xin_stride = xstride; ku.xin_off = h->xh;
+					ku.us_idx = h->d_usidx[pb]; ku.us_alpha = h->d_usalpha[pb]; ku.rot = h->d_rot[pb];
+					ku.c48 = h->d_c48[q]; ku.c48_stride = h->L;
+					ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->has_fdc; ku.L = h->L;
+					HIPCHK(launch_k1u(ku, R, h->stream));
+					int rc = enqueue_downstream(h, q, pb);
+					if (rc) return rc;
+				}
+			} while (h->us_alpha < 1.0f);
+			h->us_alpha -= 1.0f;
+		}
+		h->us_in += len;
+	}
+	h->in_blocks++;
 	h->submitted = false;
 	h->have_out = false;
-	return AISGPU_OK;
-}
-
-static int sync_all(aisgpu_t* h) {
-	HIPCHK(hipStreamSynchronize(h->stream));
-	HIPCHK(hipStreamSynchronize(h->s1));
-	HIPCHK(hipStreamSynchronize(h->s2));
-	HIPCHK(hipStreamSynchronize(h->s3));
-	drain_events(h);
 	return AISGPU_OK;
 }
 
@@ -484,51 +635,59 @@ int aisgpu_sync(aisgpu_t* h) {
 
 int aisgpu_sync_outputs(aisgpu_t* h) {
 	if (!h) return AISGPU_ERR_ARG;
-	if (h->block_idx == 0) return AISGPU_ERR_STATE;
+	if (h->in_blocks == 0) return AISGPU_ERR_STATE;
 	const size_t C = h->n_chan;
-	const int pb = (int)((h->block_idx - 1) & 1); // buffers of the last block run
-	const int q = (int)((h->block_idx - 1) % NBUF);
-	// s2 is ordered after K4 of that block, which is ordered after everything that produced lvl/ppm
-	HIPCHK(hipMemcpyAsync(h->h_bits, h->d_bits[pb], C * 5 * h->words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s2));
-	HIPCHK(hipMemcpyAsync(h->h_lvl, h->d_lvl[pb], C * h->Gcap * sizeof(float), hipMemcpyDeviceToHost, h->s2));
-	HIPCHK(hipMemcpyAsync(h->h_ppm, h->d_ppm[q], C * h->W * sizeof(float), hipMemcpyDeviceToHost, h->s2));
+	for (int s = 0; s < h->n_sub; s++) {
+		const SubOut& so = h->sub[s];
+		// s2 is ordered after K4 of that block, which is ordered after everything that produced lvl/ppm
+		HIPCHK(hipMemcpyAsync(h->h_bits + (size_t)s * C * 5 * h->words, h->d_bits[so.pb], C * 5 * h->words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s2));
+		HIPCHK(hipMemcpyAsync(h->h_lvl + (size_t)s * C * h->Gcap, h->d_lvl[so.pb], C * h->Gcap * sizeof(float), hipMemcpyDeviceToHost, h->s2));
+		HIPCHK(hipMemcpyAsync(h->h_ppm + (size_t)s * C * h->W, h->d_ppm[so.q], C * h->W * sizeof(float), hipMemcpyDeviceToHost, h->s2));
+	}
 	int rc = sync_all(h);
 	if (rc != AISGPU_OK) return rc;
 	h->have_out = true;
 	return AISGPU_OK;
 }
 
-int aisgpu_fetch(aisgpu_t* h, int rx, int ch, aisgpu_out* o) {
+int aisgpu_out_count(aisgpu_t* h) { return h ? h->n_sub : 0; }
+
+int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* o) {
 	if (!h || !o || rx < 0 || rx >= h->cfg.n_receivers || ch < 0 || ch > 1) return AISGPU_ERR_ARG;
 	if (!h->have_out) return AISGPU_ERR_STATE;
+	if (sub < 0 || sub >= h->n_sub) return AISGPU_ERR_ARG;
+	const size_t C = h->n_chan;
 	const size_t chan = (size_t)rx * 2 + ch;
-	o->n_groups = h->out_groups;
-	o->first_group = h->out_first_group;
-	for (int j = 0; j < 5; j++) o->bits[j] = h->h_bits + (chan * 5 + j) * h->words;
-	o->lvl = h->h_lvl + chan * h->Gcap;
+	const SubOut& so = h->sub[sub];
+	o->n_groups = so.groups;
+	o->first_group = so.first_group;
+	for (int j = 0; j < 5; j++) o->bits[j] = h->h_bits + (size_t)sub * C * 5 * h->words + (chan * 5 + j) * h->words;
+	o->lvl = h->h_lvl + (size_t)sub * C * h->Gcap + chan * h->Gcap;
 	o->n_windows = h->W;
-	o->ppm = h->h_ppm + chan * h->W;
+	o->ppm = h->h_ppm + (size_t)sub * C * h->W + chan * h->W;
 	o->group_window = nullptr;
-	o->first_sample48 = h->out_first48;
+	o->first_sample48 = so.first48;
 	return AISGPU_OK;
 }
+
+int aisgpu_fetch(aisgpu_t* h, int rx, int ch, aisgpu_out* o) { return aisgpu_fetch_sub(h, 0, rx, ch, o); }
 
 long long aisgpu_tap(aisgpu_t* h, int which, int rx, float* dst, long long cap) {
 	if (!h || which < 0 || which > 5 || rx < 0 || rx >= h->cfg.n_receivers) return -AISGPU_ERR_ARG;
 	if (!(h->cfg.flags & AISGPU_FLAG_TAPS)) return -AISGPU_ERR_STATE;
+	if (h->block_idx == 0 || h->n_sub == 0) return -AISGPU_ERR_STATE;
 	const size_t chan = (size_t)rx * 2 + (which & 1);
+	const SubOut& so = h->sub[h->n_sub - 1]; // taps show the last downstream block
 	const float2* src;
 	long long n = h->L;
-	if (h->block_idx == 0) return -AISGPU_ERR_STATE;
-	const int q = (int)((h->block_idx - 1) % NBUF);
-	if (which < 2) src = h->d_c48[q] + chan * h->L;
+	if (which < 2) src = h->d_c48[so.q] + chan * h->L;
 	else if (which < 4) src = h->d_cgf + chan * (CGF_HIST + h->L) + CGF_HIST;
 	else {
 		// FIR outputs exist for every sample that belongs to a group completed in this block:
 		// block-relative indices [-carry, 5*n_groups - carry)
-		const long long carry = h->out_first48 - h->out_first_group * 5;
+		const long long carry = so.first48 - so.first_group * 5;
 		src = h->d_firtap + chan * (8 + h->L) + 4 - carry;
-		n = 5LL * h->out_groups;
+		n = 5LL * so.groups;
 	}
 	if (sync_all(h) != AISGPU_OK) return -AISGPU_ERR_HIP;
 	if (dst) {

@@ -19,6 +19,19 @@ struct K1Params {
 	int tiles_per_block, tiles_per_span;
 	float alpha, beta;       // FilterComplex3Tap
 	int has_fdc;
+	float2* pre_out;         // != nullptr: pre-decimation pass, write the level after K stages here ([n_rx][pre_stride])
+	long long pre_stride;
+};
+
+constexpr int US_HIST = 96;  // resampler table entries carried in front of each flush block (halo of K1u: 84)
+
+struct K1uParams {
+	const float2* xin; long long xin_stride; long long xin_off; // xin[rx * stride + off + i]: pre-decimated sample i of the current block (i < 0: history)
+	const int* us_idx; const float* us_alpha; // [US_HIST + len]: Upsample output n -> (input index b, alpha); out = (1 - alpha) * x[b - 1] + alpha * x[b]
+	const float2* rot;      // [ROT_HIST + len / 4]
+	float2* c48; long long c48_stride;
+	float alpha, beta; int has_fdc;
+	int L;                  // 48 kHz samples per channel per flush block (len / 8)
 };
 
 struct K2Params {
@@ -64,6 +77,8 @@ struct K4Params {
 };
 
 hipError_t launch_k1(const K1Params& p, int K, bool cu8, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s);
+hipError_t launch_k1u(const K1uParams& p, int n_rx, hipStream_t s);
+hipError_t launch_copy_rows(const float2* src, long long src_stride, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
 hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long block_bytes, void* hist, int tail_bytes,
                           int n_rx, hipStream_t s);
 hipError_t launch_k2a(const K2Params& p, int n_chan, hipStream_t s);

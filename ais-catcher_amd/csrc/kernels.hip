@@ -130,7 +130,9 @@ __device__ __forceinline__ float2 cic5_small(const float4* lvl4, int t) {
 
 // D = prefetch depth in tiles: D * TILE bytes per workgroup are in flight, which is what covers the HBM
 // latency (measured: with one tile in flight the kernel is latency bound at ~50 % of peak).
-template <int K, int P, int D, int NT, bool CU8>
+// PRE = true: stop after the K CIC5 stages and write that level to p.pre_out (the pre-decimation pass of the
+// ladders that are deeper than four stages or contain the fractional resampler, Model.cpp:157-221).
+template <int K, int P, int D, int NT, bool CU8, bool PRE>
 __global__ __launch_bounds__(NT) void k1_frontend(K1Params p) {
 	using C = K1Cfg<K, P, NT>;
 	static_assert(K >= 1 && K <= 4, "ladder depth");
@@ -223,7 +225,8 @@ __global__ __launch_bounds__(NT) void k1_frontend(K1Params p) {
 		// in order, so a load issued after the prefetch would force `s_waitcnt vmcnt(0)` at its use in the
 		// middle of the ladder and drain the prefetch there (that was 65 % of the kernel's wave time).
 		// (unconditional for the same reason: no control flow between the loads and their waits)
-		const float2 rotv = p.rot[(size_t)ROT_HIST + (long long)tile * P + (t & (P - 1))]; // ROT_HIST leading entries: previous block's tail
+		float2 rotv = make_float2(1.0f, 0.0f);
+		if (!PRE) rotv = p.rot[(size_t)ROT_HIST + (long long)tile * P + (t & (P - 1))]; // ROT_HIST leading entries: previous block's tail
 		// unconditional (clamped past the end of the span) so that the number of loads in flight is static and
 		// the compiler can wait for the phasor alone (`vmcnt(NV)`) instead of draining everything
 		prefetch(regs, tile + D <= tile_last ? tile + D : tile_last);
@@ -309,8 +312,12 @@ __global__ __launch_bounds__(NT) void k1_frontend(K1Params p) {
 		float2* const x4 = sm + C::small_off(K);
 		float2* const x5 = sm + C::off_x5;
 		float2* const x6 = sm + C::off_x6;
+		if (PRE) {
+			if (t < P && tile > tile_first) p.pre_out[(size_t)rx * p.pre_stride + (size_t)tile * P + t] = x4[8 + t];
+			__syncthreads();
+		}
 		// ---- FDC (DSP.cpp:283-293) + Rotate (DSP.cpp:296-316) at 96 kHz
-		if (t < P) {
+		if (!PRE && t < P) {
 			const float2 xm2 = x4[8 + t - 2], xm1 = x4[8 + t - 1], x = x4[8 + t];
 			float2 y = x;
 			if (p.has_fdc) {
@@ -325,13 +332,13 @@ __global__ __launch_bounds__(NT) void k1_frontend(K1Params p) {
 		}
 		__syncthreads();
 		// ---- DS2_a / DS2_b (96k -> 48k): first half of the active threads channel A, second half channel B
-		if (t < P) {
+		if (!PRE && t < P) {
 			const int ch = t / (P / 2), j = t % (P / 2);
 			x6[ch * (8 + P / 2) + 8 + j] = cic5_small(smem4 + (C::off_x5 + ch * (8 + P)) / 2, j);
 		}
 		__syncthreads();
 		// ---- FilterCIC5 (DSP.cpp:132-157): same binomial filter, no decimation -> 48 kHz output
-		if (t < P) {
+		if (!PRE && t < P) {
 			const int ch = t / (P / 2), j = t % (P / 2);
 			const float2* src = x6 + ch * (8 + P / 2) + 8 + j - 5;
 			float2 v[6];
@@ -373,6 +380,100 @@ __global__ __launch_bounds__(NT) void k1_frontend(K1Params p) {
 		for (int d = 0; d < D; d++)
 			if (tile + d <= tile_last) process_tile(tile + d, pre[d]);
 	}
+}
+
+// ------------------------------------------------------------------------------------------
+// K1u: the tail of an interpolated ladder (sample rates between two 2^k buckets, Model.cpp:163-189, e.g. 6 MSPS):
+// Upsample (linear fractional resampler, DSP/DSP.cpp:192-212) -> DS2_2 -> DS2_1 -> FDC -> Rotate -> DS2_a/b ->
+// FilterCIC5, on the pre-decimated stream written by the PRE pass.  The resampler's (input index, alpha) sequence
+// is data independent and comes as a host-generated table (the float accumulation `alpha += increment` is
+// replayed exactly there), so every output is a pure function of nearby inputs: a workgroup computes a tile of
+// 32 output samples per channel and recomputes the short halos of every stage (no carried state).  This stream
+// carries 1/16 of the input rate, so the kernel is a footnote in the time budget.
+// ------------------------------------------------------------------------------------------
+constexpr int K1U_M = 32;  // 48 kHz outputs per channel per workgroup
+
+__device__ __forceinline__ float2 cic5_at(const float2* a, int pos2j) { // decimating CIC5 output from a[pos2j-5 .. pos2j]
+	float2 v[6];
+#pragma unroll
+	for (int e = 0; e < 6; e++) v[e] = a[pos2j - 5 + e];
+	float2 o[1];
+	cic5_dec_chunk<1>(v, o);
+	return o[0];
+}
+
+__global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
+	__shared__ float2 U[8 * K1U_M + 88];   // u(n),  n  in [8 m0 - 83, 8 m0 + 8 M)
+	__shared__ float2 S1[4 * K1U_M + 40];  // 192 kHz-equivalent level, j in [4 m0 - 39, 4 m0 + 4 M)
+	__shared__ float2 S2[2 * K1U_M + 18];  // 96 kHz level,           i in [2 m0 - 17, 2 m0 + 2 M)
+	__shared__ float2 RU[2][2 * K1U_M + 16]; // rotated up/down,        i in [2 m0 - 15, 2 m0 + 2 M)
+	__shared__ float2 DD[2][K1U_M + 6];    // DS2_a/b output,         j in [m0 - 5, m0 + M)
+	const int t = threadIdx.x;
+	const int rx = blockIdx.y;
+	const int m0 = blockIdx.x * K1U_M;
+	const float2* x = p.xin + (size_t)rx * p.xin_stride + p.xin_off; // x[i]: i relative to the current block start
+	{
+		const int n_lo = 8 * m0 - 83;
+		for (int q = t; q < 8 * K1U_M + 83; q += 256) {
+			const int n = n_lo + q;
+			const int i = p.us_idx[US_HIST + n];
+			const float al = p.us_alpha[US_HIST + n];
+			const float2 a = x[i - 1], b = x[i];
+			const float w0 = 1 - al; // (1 - alpha) * a + alpha * b, products rounded separately (DSP.cpp:199)
+			U[q] = make_float2(w0 * a.x + al * b.x, w0 * a.y + al * b.y);
+		}
+	}
+	__syncthreads();
+	for (int q = t; q < 4 * K1U_M + 39; q += 256) { // j = 4 m0 - 39 + q needs u(2j-5..2j): U index 2j - n_lo
+		const int j = 4 * m0 - 39 + q;
+		S1[q] = cic5_at(U, 2 * j - (8 * m0 - 83));
+	}
+	__syncthreads();
+	for (int q = t; q < 2 * K1U_M + 17; q += 256) { // i = 2 m0 - 17 + q needs s1(2i-5..2i)
+		const int i = 2 * m0 - 17 + q;
+		S2[q] = cic5_at(S1, 2 * i - (4 * m0 - 39));
+	}
+	__syncthreads();
+	for (int q = t; q < 2 * K1U_M + 15; q += 256) { // i = 2 m0 - 15 + q: FDC (DSP.cpp:283-293) + Rotate (DSP.cpp:296-316)
+		const int i = 2 * m0 - 15 + q;
+		const int si = i - (2 * m0 - 17);
+		const float2 xm2 = S2[si - 2], xm1 = S2[si - 1], xv = S2[si];
+		float2 y = xv;
+		if (p.has_fdc) {
+			const float2 s2 = cadd(xm2, xv);
+			y = make_float2(p.alpha * s2.x + xm1.x * p.beta, p.alpha * s2.y + xm1.y * p.beta);
+		}
+		const float2 rot = p.rot[ROT_HIST + i];
+		const float RR = y.x * rot.x, II = y.y * rot.y, RI = y.x * rot.y, IR = y.y * rot.x;
+		RU[0][q] = make_float2(RR - II, IR + RI);
+		RU[1][q] = make_float2(RR + II, IR - RI);
+	}
+	__syncthreads();
+	for (int q = t; q < 2 * (K1U_M + 5); q += 256) { // DS2_a / DS2_b: j = m0 - 5 + jj needs up(2j-5..2j)
+		const int ch = q / (K1U_M + 5), jj = q % (K1U_M + 5);
+		const int j = m0 - 5 + jj;
+		DD[ch][jj] = cic5_at(RU[ch], 2 * j - (2 * m0 - 15));
+	}
+	__syncthreads();
+	if (t < 2 * K1U_M) { // FilterCIC5 (DSP.cpp:132-157)
+		const int ch = t / K1U_M, mm = t % K1U_M;
+		float2 v[6];
+#pragma unroll
+		for (int e = 0; e < 6; e++) v[e] = DD[ch][mm + e]; // d(m-5 .. m)
+#pragma unroll
+		for (int lvl = 0; lvl < 5; lvl++) {
+#pragma unroll
+			for (int i = 0; i < 5 - lvl; i++) v[i] = cadd(v[i + 1], v[i]);
+		}
+		p.c48[((size_t)rx * 2 + ch) * p.c48_stride + m0 + mm] = make_float2(v[0].x * 0.03125f, v[0].y * 0.03125f);
+	}
+}
+
+// copy rows of float2 (history carry of the pre-decimated stream)
+__global__ void k_copy_rows(const float2* src, long long src_stride, float2* dst, long long dst_stride, int n) {
+	const int rx = blockIdx.y;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+		dst[(size_t)rx * dst_stride + i] = src[(size_t)rx * src_stride + i];
 }
 
 // K1b: keep the last tile of the block as history for the next block's warm-up tile
@@ -915,48 +1016,64 @@ __global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-template <int K, int P, int D, int NT, bool CU8>
+template <int K, int P, int D, int NT, bool CU8, bool PRE>
 static hipError_t launch_k1_t(const K1Params& p, int spans, int n_rx, hipStream_t s) {
 	static bool attr_set = false;
 	constexpr int bytes = K1Cfg<K, P, NT>::bytes;
 	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute((const void*)k1_frontend<K, P, D, NT, CU8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+		hipError_t e = hipFuncSetAttribute((const void*)k1_frontend<K, P, D, NT, CU8, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
-	hipLaunchKernelGGL((k1_frontend<K, P, D, NT, CU8>), dim3(spans, n_rx), dim3(NT), bytes, s, p);
+	hipLaunchKernelGGL((k1_frontend<K, P, D, NT, CU8, PRE>), dim3(spans, n_rx), dim3(NT), bytes, s, p);
 	return hipGetLastError();
 }
 
 template <int P, int D, int NT>
 static hipError_t launch_k1_p(const K1Params& p, int K, bool cu8, int spans, int n_rx, hipStream_t s) {
-	switch (K * 2 + (cu8 ? 1 : 0)) {
-	case 8: return launch_k1_t<4, P, D, NT, false>(p, spans, n_rx, s);
-	case 9: return launch_k1_t<4, P, D, NT, true>(p, spans, n_rx, s);
-	case 6: return launch_k1_t<3, P, D, NT, false>(p, spans, n_rx, s);
-	case 7: return launch_k1_t<3, P, D, NT, true>(p, spans, n_rx, s);
-	case 4: return launch_k1_t<2, P, D, NT, false>(p, spans, n_rx, s);
-	case 5: return launch_k1_t<2, P, D, NT, true>(p, spans, n_rx, s);
-	case 2: return launch_k1_t<1, P, D, NT, false>(p, spans, n_rx, s);
-	case 3: return launch_k1_t<1, P, D, NT, true>(p, spans, n_rx, s);
+	const bool pre = p.pre_out != nullptr;
+	switch (K * 4 + (cu8 ? 2 : 0) + (pre ? 1 : 0)) {
+	case 16: return launch_k1_t<4, P, D, NT, false, false>(p, spans, n_rx, s);
+	case 17: return launch_k1_t<4, P, D, NT, false, true>(p, spans, n_rx, s);
+	case 18: return launch_k1_t<4, P, D, NT, true, false>(p, spans, n_rx, s);
+	case 19: return launch_k1_t<4, P, D, NT, true, true>(p, spans, n_rx, s);
+	case 12: return launch_k1_t<3, P, D, NT, false, false>(p, spans, n_rx, s);
+	case 13: return launch_k1_t<3, P, D, NT, false, true>(p, spans, n_rx, s);
+	case 14: return launch_k1_t<3, P, D, NT, true, false>(p, spans, n_rx, s);
+	case 15: return launch_k1_t<3, P, D, NT, true, true>(p, spans, n_rx, s);
+	case 8: return launch_k1_t<2, P, D, NT, false, false>(p, spans, n_rx, s);
+	case 9: return launch_k1_t<2, P, D, NT, false, true>(p, spans, n_rx, s);
+	case 10: return launch_k1_t<2, P, D, NT, true, false>(p, spans, n_rx, s);
+	case 11: return launch_k1_t<2, P, D, NT, true, true>(p, spans, n_rx, s);
+	case 4: return launch_k1_t<1, P, D, NT, false, false>(p, spans, n_rx, s);
+	case 5: return launch_k1_t<1, P, D, NT, false, true>(p, spans, n_rx, s);
+	case 6: return launch_k1_t<1, P, D, NT, true, false>(p, spans, n_rx, s);
+	case 7: return launch_k1_t<1, P, D, NT, true, true>(p, spans, n_rx, s);
 	}
 	return hipErrorInvalidValue;
 }
 
-// tile96: samples at 96 kHz per tile; depth: tiles prefetched ahead; threads: workgroup size (256, or 64 = one
-// autonomous wave per workgroup)
+// tile96: samples at the kernel's output rate per tile; depth: tiles prefetched ahead; threads: workgroup size
+// (256, or 64 = one autonomous wave per workgroup)
 hipError_t launch_k1(const K1Params& p, int K, bool cu8, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s) {
 	switch (threads * 10000 + tile96 * 10 + depth) {
-	case 2562561: return launch_k1_p<256, 1, 256>(p, K, cu8, spans, n_rx, s);
 	case 2562562: return launch_k1_p<256, 2, 256>(p, K, cu8, spans, n_rx, s);
-	case 2561282: return launch_k1_p<128, 2, 256>(p, K, cu8, spans, n_rx, s);
-	case 2561283: return launch_k1_p<128, 3, 256>(p, K, cu8, spans, n_rx, s);
 	case 640641: return launch_k1_p<64, 1, 64>(p, K, cu8, spans, n_rx, s);
 	case 640642: return launch_k1_p<64, 2, 64>(p, K, cu8, spans, n_rx, s);
-	case 640321: return launch_k1_p<32, 1, 64>(p, K, cu8, spans, n_rx, s);
-	case 640322: return launch_k1_p<32, 2, 64>(p, K, cu8, spans, n_rx, s);
 	}
 	return hipErrorInvalidValue;
+}
+
+hipError_t launch_k1u(const K1uParams& p, int n_rx, hipStream_t s) {
+	hipLaunchKernelGGL(k1u_resample_frontend, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_copy_rows(const float2* src, long long src_stride, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s) {
+	int blocks = (n + 255) / 256;
+	if (blocks > 64) blocks = 64;
+	hipLaunchKernelGGL(k_copy_rows, dim3(blocks, n_rx), dim3(256), 0, s, src, src_stride, dst, dst_stride, n);
+	return hipGetLastError();
 }
 
 hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long block_bytes, void* hist, int tail_bytes,

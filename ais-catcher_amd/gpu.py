@@ -21,6 +21,7 @@ EXPORTS = (
     "aisgpu_default_cfg", "aisgpu_create", "aisgpu_destroy", "aisgpu_submit", "aisgpu_submit_device",
     "aisgpu_run", "aisgpu_sync_outputs", "aisgpu_sync", "aisgpu_fetch", "aisgpu_tap", "aisgpu_stream",
     "aisgpu_frontend_ms", "aisgpu_timing", "aisgpu_strerror", "aisgpu_last_error", "aisgpu_device_count",
+    "aisgpu_out_count", "aisgpu_fetch_sub",
 )
 
 
@@ -66,6 +67,8 @@ def load():
     lib.aisgpu_sync_outputs.argtypes = [vp]
     lib.aisgpu_sync.argtypes = [vp]
     lib.aisgpu_fetch.argtypes = [vp, ci, ci, ctypes.POINTER(Out)]
+    lib.aisgpu_out_count.argtypes = [vp]
+    lib.aisgpu_fetch_sub.argtypes = [vp, ci, ci, ci, ctypes.POINTER(Out)]
     lib.aisgpu_tap.argtypes = [vp, ci, ci, vp, cll]
     lib.aisgpu_tap.restype = cll
     lib.aisgpu_stream.argtypes = [vp]
@@ -133,10 +136,13 @@ class AisGpu:
     def sync_outputs(self):
         self._chk(self.lib.aisgpu_sync_outputs(self.h), "aisgpu_sync_outputs")
 
-    def fetch(self, rx, ch):
+    def out_count(self):
+        return self.lib.aisgpu_out_count(self.h)
+
+    def fetch(self, rx, ch, sub=0):
         """-> dict(bits[5][n_groups] of +-1.0f, lvl[n_groups], ppm[n_windows], first_group, first_sample48)."""
         o = Out()
-        self._chk(self.lib.aisgpu_fetch(self.h, rx, ch, ctypes.byref(o)), "aisgpu_fetch")
+        self._chk(self.lib.aisgpu_fetch_sub(self.h, sub, rx, ch, ctypes.byref(o)), "aisgpu_fetch_sub")
         n = o.n_groups
         words = (n + 31) // 32
         bits = np.zeros((5, n), np.float32)

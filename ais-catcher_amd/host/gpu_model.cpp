@@ -54,11 +54,15 @@ void GpuChain::process(const void* data, int len, TAG& tag) {
 		if (on_error) on_error(std::string("GpuChain: ") + aisgpu_strerror(rc) + ": " + batch->lastError());
 		return;
 	}
-	// Rotate hands the whole block to channel A before channel B (reference DSP/DSP.cpp:312-313)
-	for (int ch = 0; ch < 2; ch++) {
-		aisgpu_out o;
-		if (batch->fetch(rx, ch, &o) != AISGPU_OK) { failed = true; return; }
-		replay(ch == 0 ? outA : outB, o, tag);
+	// One downstream block per Receive() call of the chain behind the (optional) resampler; within it Rotate hands
+	// the whole block to channel A before channel B (reference DSP/DSP.cpp:312-313)
+	const int nsub = batch->outCount();
+	for (int s = 0; s < nsub; s++) {
+		for (int ch = 0; ch < 2; ch++) {
+			aisgpu_out o;
+			if (batch->fetch(s, rx, ch, &o) != AISGPU_OK) { failed = true; return; }
+			replay(ch == 0 ? outA : outB, o, tag);
+		}
 	}
 }
 

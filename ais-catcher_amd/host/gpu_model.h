@@ -46,7 +46,8 @@ public:
 	const aisgpu_cfg& config() const { return cfg; }
 	// Copies the receiver's block in; returns once the whole batch has been processed for this block.
 	int submitAndWait(int rx, const void* iq, int n_iq);
-	int fetch(int rx, int ch, aisgpu_out* out) { return aisgpu_fetch(ctx, rx, ch, out); }
+	int outCount() { return aisgpu_out_count(ctx); }
+	int fetch(int sub, int rx, int ch, aisgpu_out* out) { return aisgpu_fetch_sub(ctx, sub, rx, ch, out); }
 	const char* lastError() { return aisgpu_last_error(ctx); }
 };
 

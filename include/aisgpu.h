@@ -54,9 +54,10 @@ extern "C" {
 typedef struct aisgpu aisgpu_t;
 
 typedef struct aisgpu_cfg {
-	int sample_rate;   /* 1536000, 768000, 384000 or 192000 (pure 2^k CIC5 ladders, Model.cpp:157-338) */
+	int sample_rate;   /* 96000*2^k for k = 1..7 (192k .. 12288k), or any rate in (384k, 6144k) that the reference
+	                    * resamples up to the next bucket, e.g. 6000000 (Model.cpp:129-338) */
 	int n_receivers;   /* independent dual-channel receiver instances batched on this GPU */
-	int block_len;     /* IQ samples per receiver per Receive() block; multiple of 512 * sample_rate/48000 */
+	int block_len;     /* IQ samples per receiver per Receive() block; multiple of 512 * bucket_rate/48000 */
 	int model;         /* AISGPU_MODEL_DEFAULT */
 	int input_format;  /* AISGPU_FMT_* */
 	int afc_wide;      /* KEY_SETTING_AFC_WIDE (default on, Model.cpp:536-540) */
@@ -99,7 +100,13 @@ int aisgpu_run(aisgpu_t* h);
 int aisgpu_sync_outputs(aisgpu_t* h);
 /* Wait for the stream without copying outputs (throughput runs). */
 int aisgpu_sync(aisgpu_t* h);
-int aisgpu_fetch(aisgpu_t* h, int rx, int ch, aisgpu_out* out);
+int aisgpu_fetch(aisgpu_t* h, int rx, int ch, aisgpu_out* out); /* == aisgpu_fetch_sub(h, 0, ...) */
+/* Sample rates between two 2^k buckets go through the reference's fractional resampler (DSP/DSP.cpp:192-212), which
+ * hands fixed-size blocks downstream whenever one is full: one input block then completes 1 or 2 downstream blocks
+ * (each is one Receive() call of everything behind the resampler in the reference).  aisgpu_out_count() tells how
+ * many the last aisgpu_run() completed (always 1 for the 2^k rates); fetch them in order with aisgpu_fetch_sub(). */
+int aisgpu_out_count(aisgpu_t* h);
+int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* out);
 
 /* Float taps of the last block (tests only; needs AISGPU_FLAG_TAPS):
  *   which 0/1: 48 kHz front-end output A/B (== FCIC5_a/b.out), 2/3: CGF output, 4/5: FIR-17 output.

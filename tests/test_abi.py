@@ -36,8 +36,9 @@ def test_create_rejects_bad_config_without_gpu_work():
     cfg = gpu.Cfg()
     lib.aisgpu_default_cfg(ctypes.byref(cfg))
     h = ctypes.c_void_p()
-    cfg.sample_rate = 1000000
-    assert lib.aisgpu_create(ctypes.byref(cfg), ctypes.byref(h)) == 1 and not h
+    for bad_rate in (50000, 250000, 13000000):  # below 96k; resampled ladder without two CIC5 stages behind it; above 12288k
+        cfg.sample_rate = bad_rate
+        assert lib.aisgpu_create(ctypes.byref(cfg), ctypes.byref(h)) == 1 and not h
     cfg.sample_rate = 1536000
     cfg.block_len = 1000
     assert lib.aisgpu_create(ctypes.byref(cfg), ctypes.byref(h)) == 1 and not h

@@ -247,3 +247,69 @@ def test_phase_search_fallback_and_variants(env, monkeypatch):
         monkeypatch.setenv(k, v)
     xs = [synth.receiver_stream(786432 * 2, receiver_id=40 + r) for r in range(2)]
     _run_gpu_vs_oracle(xs, 1536000, "cf32", 786432, 2)
+
+
+def _run_multi_sub(x, rate, block, nblocks, fmt="cf32"):
+    """Rates whose ladder contains the resampler or a pre-decimation pass: compare every completed downstream
+    block (there can be 1 or 2 per input block) with the oracle's stream."""
+    g = gpu.AisGpu(sample_rate=rate, n_receivers=1, block_len=block,
+                   input_format=gpu.FMT_CU8 if fmt == "cu8" else gpu.FMT_CF32, taps=True)
+    per = 2 if fmt == "cu8" else 1
+    o = checkers.Oracle(model=2, rate=rate, fmt=fmt, taps=True)
+    o.feed_blocks(x, block)
+    otap = [o.tap(w) for w in range(6)]
+    oppm = [o.tap_ppm(2), o.tap_ppm(3)]
+    obits = [[o.bits(ch, j) for j in range(5)] for ch in range(2)]
+    n48 = 0
+    gd = 0
+    subs = []
+    for b in range(nblocks):
+        g.submit(0, x[b * block * per:(b + 1) * block * per])
+        g.run()
+        g.sync_outputs()
+        ns = g.out_count()
+        subs.append(ns)
+        for s in range(ns):
+            outs = [g.fetch(0, ch, s) for ch in range(2)]
+            L = outs[0]["n_windows"] * 512
+            assert outs[0]["first_sample48"] == n48
+            n = outs[0]["n_groups"]
+            for ch in range(2):
+                for j in range(5):
+                    assert np.array_equal(outs[ch]["bits"][j], obits[ch][j][0][gd:gd + n]), "bits blk %d sub %d ch %d j %d" % (b, s, ch, j)
+                assert _feq(outs[ch]["lvl"], obits[ch][0][1][gd:gd + n])
+                assert _feq(outs[ch]["ppm"], oppm[ch][n48 // 512:(n48 + L) // 512])
+            if s == ns - 1:  # float taps are readable for the last downstream block of a run
+                for w in range(4):
+                    assert _feq(g.tap(w), otap[w][n48:n48 + L]), "tap %d blk %d" % (w, b)
+            n48 += L
+            gd += n
+    assert n48 > 0 and len(otap[0]) >= n48
+    g.close()
+    return subs
+
+
+def test_6msps_resampled_ladder():
+    """BASELINE config 3 front end: 6,000,000 S/s -> 4 x CIC5 -> Upsample 125/128 -> DS2_2 -> DS2_1 -> FDC(-2.0) -> ...
+    (Model.cpp:183-189).  One input block completes 1 or 2 downstream blocks."""
+    block = 786432
+    x = synth.receiver_stream(block * 5, sample_rate=6000000, receiver_id=50)
+    subs = _run_multi_sub(x, 6000000, block, 5)
+    assert set(subs) <= {1, 2} and sum(subs) == (5 * 49152 * 128 // 125) // 49152
+
+
+@pytest.mark.parametrize("rate", [3072000, 6144000, 12288000])
+def test_deep_pure_ladders(rate):
+    block = 512 * (rate // 48000) * 4
+    x = synth.receiver_stream(block * 3, sample_rate=rate, receiver_id=51, gap_slots=(1, 1))
+    _run_multi_sub(x, rate, block, 3)
+    _run_multi_sub(synth.to_cu8(x), rate, block, 3, fmt="cu8")
+
+
+@pytest.mark.parametrize("rate", [2000000, 1000000, 2400000])
+def test_other_resampled_rates(rate):
+    """Rates whose resampler increment is NOT exactly representable: the host replays the float accumulation."""
+    bucket = 3072000 if rate > 1536000 else 1536000
+    block = 512 * (bucket // 48000) * 8
+    x = synth.receiver_stream(block * 4, sample_rate=rate, receiver_id=52, gap_slots=(1, 2))
+    _run_multi_sub(x, rate, block, 4)
