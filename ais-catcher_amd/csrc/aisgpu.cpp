@@ -25,6 +25,12 @@ using namespace aisk;
 namespace {
 
 const float PI_F = 3.14159265358979323846f; // Library/Common.h:318: PI is a float constant
+const float TAPS_RECEIVER[37] = { // DSP/Filters.h:24-33
+	0.00119025f, -0.00148464f, -0.00282428f, -0.00200561f, -0.00068852f, 0.00343044f, 0.00902093f, 0.01367867f,
+	0.01147965f, 0.0027259f, -0.01766614f, -0.04244429f, -0.0577468f, -0.05245161f, -0.01072754f, 0.0732564f,
+	0.17643278f, 0.25582214f, 0.28200453f, 0.25582214f, 0.17643278f, 0.0732564f, -0.01072754f, -0.05245161f,
+	-0.0577468f, -0.04244429f, -0.01766614f, 0.0027259f, 0.01147965f, 0.01367867f, 0.00902093f, 0.00343044f,
+	-0.00068852f, -0.00200561f, -0.00282428f, -0.00148464f, 0.00119025f };
 const float TAPS_COHERENT[17] = { // DSP/Filters.h:35-41
 	2.06995719e-06f, 3.18610148e-05f, 3.40605309e-04f, 2.52892989e-03f, 1.30411453e-02f, 4.67076746e-02f,
 	1.16186141e-01f, 2.00730781e-01f, 2.40861391e-01f, 2.00730781e-01f, 1.16186141e-01f, 4.67076746e-02f,
@@ -84,6 +90,8 @@ struct aisgpu {
 	float *d_ppmtab = nullptr, *d_ppm[NBUF] = {}, *d_lvl[2] = {};
 	int* d_fz[NBUF] = {};
 	uint32_t* d_bits[2] = {};
+	bool challenger = false;
+	float* d_fm = nullptr; uint32_t* d_fmbits[2] = {}; uint32_t* h_fmbits = nullptr; // ModelChallenger FM branch
 	EmaState* d_ema[2] = {}; // state before / after the current downstream block (swapped per block)
 	uint32_t* d_pswords = nullptr; float *d_psma0 = nullptr, *d_psma1 = nullptr; unsigned* d_psfin = nullptr; int* d_psflag = nullptr;
 	int ps_warm = 256; bool ps_parallel = true;
@@ -205,6 +213,13 @@ int enqueue_downstream(aisgpu_t* h, int q, int pb) {
 	k3.first_group = g0; k3.first_sample48 = h->n48; k3.n_groups = (int)(g1 - g0);
 	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_ema[pb], 0)); // sym/lvl[pb] were last read by K4 of block f-2
 	HIPCHK(launch_k3(k3, h->n_chan, h->s1));
+	if (h->challenger) { // FM branch on the same derotated samples (Model.cpp:638-639)
+		K5Params k5;
+		k5.cgf = h->d_cgf; k5.cgf_stride = CGF_HIST + h->L; k5.fm = h->d_fm; k5.fm_stride = FM_HIST + h->L;
+		k5.fmbits = h->d_fmbits[pb]; k5.fmbits_stride = h->L / 32; k5.L = h->L;
+		memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
+		HIPCHK(launch_k5(k5, h->n_chan, h->s1));
+	}
 
 	// ---- PhaseSearchEMA chains (same stream)
 	K4Params k4;
@@ -286,7 +301,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		if (k < 3 || k > 6) return AISGPU_ERR_ARG; // the resampler sits two CIC5 stages in front of 96 kHz
 		mode = MODE_RESAMPLE; K = 0; KP = k - 2;
 	}
-	if (cfg->model != AISGPU_MODEL_DEFAULT) return AISGPU_ERR_ARG;
+	if (cfg->model != AISGPU_MODEL_DEFAULT && cfg->model != AISGPU_MODEL_CHALLENGER) return AISGPU_ERR_ARG;
 	if (cfg->input_format != AISGPU_FMT_CU8 && cfg->input_format != AISGPU_FMT_CF32) return AISGPU_ERR_ARG;
 	if (cfg->n_receivers < 1 || cfg->n_receivers > 65535) return AISGPU_ERR_ARG;
 	// a downstream block must be a whole number of 512-sample CGF windows
@@ -298,6 +313,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	if (!h) return AISGPU_ERR_ARG;
 	h->cfg = *cfg;
 	h->mode = mode; h->K = K; h->KP = KP;
+	h->challenger = cfg->model == AISGPU_MODEL_CHALLENGER;
 	// front-end geometry (tuning knobs; the defaults are the measured best): workgroup size, output samples per
 	// tile, prefetch depth.  Compiled combinations: "256,256,2", "64,64,1", "64,64,2".
 	h->k1_threads = 64; h->tile96 = 64; h->depth = 1; // autonomous waves (profiles/r01_k1_geometry_sweep.txt)
@@ -421,6 +437,11 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(dalloc(&h->d_ema[i], C * 5));
 	}
 	HIPCHK(dalloc(&h->d_cgf, C * (CGF_HIST + h->L)));
+	if (h->challenger) {
+		HIPCHK(dalloc(&h->d_fm, C * (FM_HIST + h->L)));
+		for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmbits[i], C * (h->L / 32)));
+		HIPCHK(hipHostMalloc((void**)&h->h_fmbits, MAXSUB * C * (h->L / 32) * sizeof(uint32_t), hipHostMallocDefault));
+	}
 	HIPCHK(dalloc(&h->d_rotstate, C));
 	{
 		std::vector<float2> ones(C, make_float2(1.0f, 0.0f)); // SquareFreqOffsetCorrection::rot = 1.0f (DSP.h:379)
@@ -464,6 +485,8 @@ void aisgpu_destroy(aisgpu_t* h) {
 	}
 	for (auto& p : h->ev_free) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
 	hipFree(h->d_in); hipFree(h->d_hist); hipFree(h->d_hist2);
+	hipFree(h->d_fm); hipFree(h->d_fmbits[0]); hipFree(h->d_fmbits[1]);
+	if (h->h_fmbits) hipHostFree(h->h_fmbits);
 	hipFree(h->d_cgf); hipFree(h->d_omega); hipFree(h->d_step);
 	hipFree(h->d_rotstate); hipFree(h->d_firtap); hipFree(h->d_ppmtab);
 	hipFree(h->d_pswords); hipFree(h->d_psma0); hipFree(h->d_psma1); hipFree(h->d_psfin); hipFree(h->d_psflag);
@@ -643,6 +666,8 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 		HIPCHK(hipMemcpyAsync(h->h_bits + (size_t)s * C * 5 * h->words, h->d_bits[so.pb], C * 5 * h->words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s2));
 		HIPCHK(hipMemcpyAsync(h->h_lvl + (size_t)s * C * h->Gcap, h->d_lvl[so.pb], C * h->Gcap * sizeof(float), hipMemcpyDeviceToHost, h->s2));
 		HIPCHK(hipMemcpyAsync(h->h_ppm + (size_t)s * C * h->W, h->d_ppm[so.q], C * h->W * sizeof(float), hipMemcpyDeviceToHost, h->s2));
+		if (h->challenger)
+			HIPCHK(hipMemcpyAsync(h->h_fmbits + (size_t)s * C * (h->L / 32), h->d_fmbits[so.pb], C * (h->L / 32) * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s2));
 	}
 	int rc = sync_all(h);
 	if (rc != AISGPU_OK) return rc;
@@ -667,6 +692,7 @@ int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* o) {
 	o->ppm = h->h_ppm + (size_t)sub * C * h->W + chan * h->W;
 	o->group_window = nullptr;
 	o->first_sample48 = so.first48;
+	o->fm_bits = h->challenger ? h->h_fmbits + (size_t)sub * C * (h->L / 32) + chan * (h->L / 32) : nullptr;
 	return AISGPU_OK;
 }
 

@@ -5,7 +5,7 @@
 
 namespace aisk {
 
-constexpr int CGF_HIST = 32;   // 48 kHz samples of CGF output carried in front of each block (FIR-17 needs 16 + 4)
+constexpr int CGF_HIST = 64;   // 48 kHz samples of CGF output carried in front of each block (FIR-17: 16 + 4; FM branch: 37 + 1)
 constexpr int ROT_HIST = 256;  // 96 kHz rotator phasors carried in front of each block's table (one tile)
 constexpr int FZ_MIN = -205, FZ_COUNT = 414; // CGF peak index range
 
@@ -85,6 +85,16 @@ hipError_t launch_k2a(const K2Params& p, int n_chan, hipStream_t s);
 hipError_t launch_k2b(const K2Params& p, int n_chan, hipStream_t s); // phasor recurrence
 hipError_t launch_k2c(const K2Params& p, int n_chan, hipStream_t s); // history carry + apply
 hipError_t launch_k3(const K3Params& p, int n_chan, hipStream_t s);
+struct K5Params { // ModelChallenger FM branch (Model.cpp:638-639): Demod::FM -> Filter(Receiver, 37 taps) -> sign
+	const float2* cgf; long long cgf_stride; // [n_chan][CGF_HIST + L]
+	float* fm; long long fm_stride;          // [n_chan][FM_HIST + L] discriminator output, FM_HIST leading history
+	uint32_t* fmbits; long long fmbits_stride; // [n_chan][L/32] bit n: filtered discriminator > 0
+	float taps[37];
+	int L;
+};
+constexpr int FM_HIST = 36;
+
+hipError_t launch_k5(const K5Params& p, int n_chan, hipStream_t s);
 hipError_t launch_k4(const K4Params& p, hipStream_t s);          // chunk-parallel + assemble + (conditional) exact fallback
 hipError_t launch_k4_sequential(const K4Params& p, hipStream_t s); // the plain sequential kernel only
 

@@ -1014,6 +1014,125 @@ __global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K5: ModelChallenger's non-coherent branch (DSP/Model.cpp:638-639): Demod::FM (DSP/Demod.cpp:27-37) ->
+// DSP::Filter with Filters::Receiver (37 taps, DSP/DSP.cpp:249-280) -> Deinterleave(5) -> AIS::Decoder.
+// The decoders only look at the sign, so the device hands back one bit per 48 kHz sample.
+// atan2f is glibc's (fdlibm e_atan2f.c / s_atanf.c) restated operation by operation; the CPU test
+// tests/test_atan2f.py checks the same restatement against the host libm on 10^7 inputs, and the GPU parity
+// tests compare every decision with the reference chain.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float atanf_ref(float x) {
+	const float atanhi[4] = { 4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f };
+	const float atanlo[4] = { 5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f };
+	const float aT[11] = { 3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f, 9.0908870101e-02f,
+	                       -7.6918758452e-02f, 6.6610731184e-02f, -5.8335702866e-02f, 4.9768779427e-02f, -3.6531571299e-02f,
+	                       1.6285819933e-02f };
+	const int hx = __float_as_int(x);
+	const int ix = hx & 0x7fffffff;
+	int id;
+	if (ix >= 0x4c000000) { // |x| >= 2^25
+		if (ix > 0x7f800000) return x + x;
+		return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+	}
+	if (ix < 0x3ee00000) { // |x| < 0.4375
+		if (ix < 0x31000000) return x; // |x| < 2^-29 (the reference raises inexact here; the value is x)
+		id = -1;
+	} else {
+		x = fabsf(x);
+		if (ix < 0x3f980000) { // |x| < 1.1875
+			if (ix < 0x3f300000) { id = 0; x = __fdiv_rn(2.0f * x - 1.0f, 2.0f + x); }
+			else { id = 1; x = __fdiv_rn(x - 1.0f, x + 1.0f); }
+		} else {
+			if (ix < 0x401c0000) { id = 2; x = __fdiv_rn(x - 1.5f, 1.0f + 1.5f * x); }
+			else { id = 3; x = __fdiv_rn(-1.0f, x); }
+		}
+	}
+	const float z = x * x;
+	const float w = z * z;
+	const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+	const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+	if (id < 0) return x - x * (s1 + s2);
+	const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+	return hx < 0 ? -r : r;
+}
+
+__device__ __forceinline__ float atan2f_ref(float y, float x) {
+	const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+	const int hx = __float_as_int(x), hy = __float_as_int(y);
+	const int ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+	if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+	if (hx == 0x3f800000) return atanf_ref(y);
+	const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+	if (iy == 0) {
+		if (m < 2) return y;
+		return m == 2 ? pi + tiny : -pi - tiny;
+	}
+	if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+	if (ix == 0x7f800000) {
+		if (iy == 0x7f800000) {
+			switch (m) {
+			case 0: return pi_o_4 + tiny;
+			case 1: return -pi_o_4 - tiny;
+			case 2: return 3.0f * pi_o_4 + tiny;
+			default: return -3.0f * pi_o_4 - tiny;
+			}
+		}
+		switch (m) {
+		case 0: return 0.0f;
+		case 1: return -0.0f;
+		case 2: return pi + tiny;
+		default: return -pi - tiny;
+		}
+	}
+	if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+	const int k = (iy - ix) >> 23;
+	float z;
+	if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+	else if (hx < 0 && k < -60) z = 0.0f;
+	else z = atanf_ref(fabsf(__fdiv_rn(y, x)));
+	switch (m) {
+	case 0: return z;
+	case 1: return __int_as_float(__float_as_int(z) ^ 0x80000000);
+	case 2: return pi - (z - pi_lo);
+	default: return (z - pi_lo) - pi;
+	}
+}
+
+// history carry of the discriminator output (same stream, before k5_fm overwrites the row)
+__global__ __launch_bounds__(64) void k5_carry(K5Params p) {
+	float* f = p.fm + (size_t)blockIdx.x * p.fm_stride;
+	if (threadIdx.x < FM_HIST) f[threadIdx.x] = f[p.L + threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k5_fm(K5Params p) {
+	const int chan = blockIdx.y;
+	const int n = blockIdx.x * 256 + threadIdx.x;
+	if (n >= p.L) return;
+	const float2* y = p.cgf + (size_t)chan * p.cgf_stride + CGF_HIST + n;
+	const float2 d = y[0], pv = y[-1];
+	// data[i] * std::conj(prev): (xr*pr - xi*(-pi), xr*(-pi) + xi*pr)
+	const float npi = -pv.y;
+	const float re = d.x * pv.x - d.y * npi;
+	const float im = d.x * npi + d.y * pv.x;
+	p.fm[(size_t)chan * p.fm_stride + FM_HIST + n] = __fdiv_rn(atan2f_ref(im, re), 3.14159265358979323846f);
+}
+
+__global__ __launch_bounds__(256) void k5_filter(K5Params p) {
+	const int chan = blockIdx.y;
+	const int n = blockIdx.x * 256 + threadIdx.x; // L is a multiple of 512
+	const float* f = p.fm + (size_t)chan * p.fm_stride + n; // f[i] = fm[n - 36 + i]
+	float acc = 0.0f;
+#pragma unroll
+	for (int i = 0; i < 37; i++) acc += p.taps[i] * f[i]; // x += taps[i] * *data++ (DSP.h:257-263)
+	const unsigned long long b = __ballot(acc > 0);
+	if ((threadIdx.x & 63) == 0) {
+		uint32_t* o = p.fmbits + (size_t)chan * p.fmbits_stride + (n >> 5);
+		o[0] = (uint32_t)b;
+		o[1] = (uint32_t)(b >> 32);
+	}
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 template <int K, int P, int D, int NT, bool CU8, bool PRE>
@@ -1107,6 +1226,13 @@ hipError_t launch_k2c(const K2Params& p, int n_chan, hipStream_t s) {
 hipError_t launch_k3(const K3Params& p, int n_chan, hipStream_t s) {
 	if (p.n_groups <= 0) return hipSuccess;
 	hipLaunchKernelGGL(k3_fir_scatter, dim3((p.n_groups + 255) / 256, n_chan), dim3(256), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_k5(const K5Params& p, int n_chan, hipStream_t s) {
+	hipLaunchKernelGGL(k5_carry, dim3(n_chan), dim3(64), 0, s, p);
+	hipLaunchKernelGGL(k5_fm, dim3(p.L / 256, n_chan), dim3(256), 0, s, p);
+	hipLaunchKernelGGL(k5_filter, dim3(p.L / 256, n_chan), dim3(256), 0, s, p);
 	return hipGetLastError();
 }
 

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libaisgpu.so")
 
 FMT_CU8, FMT_CF32 = 0, 1
 MODEL_DEFAULT = 2
+MODEL_CHALLENGER = 4
 FLAG_TAPS = 1
 FLAG_SERIAL = 2
 
@@ -41,6 +42,7 @@ class Out(ctypes.Structure):
         ("ppm", ctypes.POINTER(ctypes.c_float)),
         ("group_window", ctypes.POINTER(ctypes.c_int)),
         ("first_sample48", ctypes.c_longlong),
+        ("fm_bits", ctypes.POINTER(ctypes.c_uint32)),
     ]
 
 
@@ -94,11 +96,12 @@ class AisGpu:
     """One context = n_receivers batched dual-channel receivers on one GPU."""
 
     def __init__(self, sample_rate=1536000, n_receivers=1, block_len=786432, input_format=FMT_CF32,
-                 afc_wide=True, droop=True, device_id=0, taps=False, tiles_per_span=0, serial=False):
+                 afc_wide=True, droop=True, device_id=0, taps=False, tiles_per_span=0, serial=False, model=MODEL_DEFAULT):
         self.lib = load()
         cfg = Cfg()
         self.lib.aisgpu_default_cfg(ctypes.byref(cfg))
         cfg.sample_rate, cfg.n_receivers, cfg.block_len = sample_rate, n_receivers, block_len
+        cfg.model = model
         cfg.input_format, cfg.afc_wide, cfg.droop = input_format, int(afc_wide), int(droop)
         cfg.device_id, cfg.tiles_per_span = device_id, tiles_per_span
         cfg.flags = (FLAG_TAPS if taps else 0) | (FLAG_SERIAL if serial else 0)
@@ -152,8 +155,13 @@ class AisGpu:
             bits[j] = np.where(b != 0, 1.0, -1.0)
         lvl = np.ctypeslib.as_array(o.lvl, shape=(max(n, 1),))[:n].copy()
         ppm = np.ctypeslib.as_array(o.ppm, shape=(max(o.n_windows, 1),))[:o.n_windows].copy()
+        fm = None
+        if o.fm_bits:
+            L = o.n_windows * 512
+            w = np.ctypeslib.as_array(o.fm_bits, shape=(L // 32,))
+            fm = ((w[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).reshape(-1).astype(np.uint8)
         return dict(bits=bits, lvl=lvl, ppm=ppm, first_group=o.first_group, first_sample48=o.first_sample48,
-                    n_groups=n, n_windows=o.n_windows)
+                    n_groups=n, n_windows=o.n_windows, fm_bits=fm)
 
     def tap(self, which, rx=0):
         n = self.lib.aisgpu_tap(self.h, which, rx, None, 0)

@@ -28,10 +28,10 @@ def load():
     lib.aishost_batch_create.argtypes = [ctypes.POINTER(_gpu.Cfg), ctypes.c_char_p, ci]
     lib.aishost_batch_destroy.argtypes = [vp]
     lib.aishost_model_create.restype = vp
-    lib.aishost_model_create.argtypes = [vp, ci, ci, ci, ci, ctypes.c_char, ctypes.c_char, ci, ctypes.c_char_p, ci]
+    lib.aishost_model_create.argtypes = [vp, ci, ci, ci, ci, ctypes.c_char, ctypes.c_char, ci, ci, ctypes.c_char_p, ci]
     lib.aishost_model_destroy.argtypes = [vp]
     lib.aishost_model_receive.argtypes = [vp, vp, ci]
-    lib.aishost_model_replay.argtypes = [vp, ci, cll, cll, ci, ctypes.POINTER(vp), vp, ci, vp]
+    lib.aishost_model_replay.argtypes = [vp, ci, cll, cll, ci, ctypes.POINTER(vp), vp, ci, vp, vp]
     lib.aishost_model_msg_count.argtypes = [vp]
     lib.aishost_model_nmea.argtypes = [vp, ctypes.c_char_p, ci]
     lib.aishost_model_msg_meta.argtypes = [vp, vp, vp, ci]
@@ -42,12 +42,13 @@ def load():
 class Batch:
     """Shared GPU context for n_receivers ModelDefaultGPU instances (one per receiver thread)."""
 
-    def __init__(self, sample_rate=1536000, n_receivers=1, block_len=786432, input_format=_gpu.FMT_CF32, device_id=0):
+    def __init__(self, sample_rate=1536000, n_receivers=1, block_len=786432, input_format=_gpu.FMT_CF32, device_id=0,
+                 model=_gpu.MODEL_DEFAULT):
         lib = load()
         cfg = _gpu.Cfg()
         _gpu.load().aisgpu_default_cfg(ctypes.byref(cfg))
         cfg.sample_rate, cfg.n_receivers, cfg.block_len = sample_rate, n_receivers, block_len
-        cfg.input_format, cfg.device_id = input_format, device_id
+        cfg.input_format, cfg.device_id, cfg.model = input_format, device_id, model
         err = ctypes.create_string_buffer(512)
         self.h = lib.aishost_batch_create(ctypes.byref(cfg), err, 512)
         if not self.h:
@@ -62,12 +63,12 @@ class Batch:
 
 class ModelDefaultGPU:
     def __init__(self, sample_rate=1536000, block_len=786432, input_format=_gpu.FMT_CF32, ch1="A", ch2="B",
-                 batch=None, rx=0, detached=False):
+                 batch=None, rx=0, detached=False, model=_gpu.MODEL_DEFAULT):
         self.lib = load()
         err = ctypes.create_string_buffer(512)
         self.fmt = input_format
         self.h = self.lib.aishost_model_create(batch.h if batch else None, rx, sample_rate, block_len, input_format,
-                                               ch1.encode(), ch2.encode(), 1 if detached else 0, err, 512)
+                                               ch1.encode(), ch2.encode(), 1 if detached else 0, model, err, 512)
         if not self.h:
             raise RuntimeError(err.value.decode())
 
@@ -75,8 +76,9 @@ class ModelDefaultGPU:
         block = np.ascontiguousarray(block)
         self.lib.aishost_model_receive(self.h, block.ctypes.data, block.nbytes)
 
-    def replay(self, ch, first_group, first_sample48, bits5, lvl, ppm):
-        """bits5: [5][n_groups] array of +-1 (or 0/1) decisions; packed here like the GPU packs them."""
+    def replay(self, ch, first_group, first_sample48, bits5, lvl, ppm, fm=None):
+        """bits5: [5][n_groups] array of +-1 (or 0/1) decisions; packed here like the GPU packs them.
+        fm: ModelChallenger only, [512 * len(ppm)] FM-branch decisions (> 0) of the block's 48 kHz samples."""
         n = bits5.shape[1]
         words = (n + 31) // 32
         packed = []
@@ -88,7 +90,12 @@ class ModelDefaultGPU:
         ptrs = (ctypes.c_void_p * 5)(*[p.ctypes.data for p in packed])
         lvl = np.ascontiguousarray(lvl, np.float32)
         ppm = np.ascontiguousarray(ppm, np.float32)
-        self.lib.aishost_model_replay(self.h, ch, first_group, first_sample48, n, ptrs, lvl.ctypes.data, len(ppm), ppm.ctypes.data)
+        fmw = None
+        if fm is not None:
+            fb = (np.asarray(fm) > 0).astype(np.uint32).reshape(-1, 32)
+            fmw = np.ascontiguousarray((fb << np.arange(32, dtype=np.uint32)[None, :]).sum(axis=1, dtype=np.uint64).astype(np.uint32))
+        self.lib.aishost_model_replay(self.h, ch, first_group, first_sample48, n, ptrs, lvl.ctypes.data, len(ppm), ppm.ctypes.data,
+                                      fmw.ctypes.data if fmw is not None else None)
 
     def nmea(self):
         n = self.lib.aishost_model_nmea(self.h, None, 0)
@@ -113,6 +120,12 @@ class ModelDefaultGPU:
             self.close()
         except Exception:
             pass
+
+
+class ModelChallengerGPU(ModelDefaultGPU):
+    def __init__(self, **kw):
+        kw["model"] = _gpu.MODEL_CHALLENGER
+        super().__init__(**kw)
 
 
 def reset_sequence():

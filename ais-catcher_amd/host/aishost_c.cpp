@@ -46,12 +46,13 @@ void aishost_batch_destroy(void* b) { delete (GpuBatch*)b; }
 // batch == NULL and detached == 0: stand-alone single receiver with its own context
 // detached != 0: no GPU at all, only aishost_model_replay() may be used (host-logic tests)
 void* aishost_model_create(void* batch, int rx, int sample_rate, int block_len, int input_format, char ch1, char ch2,
-                           int detached, char* errbuf, int errcap) {
+                           int detached, int model, char* errbuf, int errcap) {
 	Model* m = new Model();
 	try {
 		m->fmt = input_format == AISGPU_FMT_CU8 ? Format::CU8 : Format::CF32;
 		m->m.setFormat(m->fmt);
 		m->m.setBlockLength(block_len);
+		m->m.setChallenger(model == AISGPU_MODEL_CHALLENGER);
 		if (batch) m->m.useBatch((GpuBatch*)batch, rx);
 		if (!detached) m->m.buildModel(ch1, ch2, sample_rate, false, nullptr);
 		else m->m.wireDecoders(ch1, ch2); // no GPU context
@@ -74,13 +75,13 @@ int aishost_model_receive(void* mv, const void* data, int nbytes) {
 }
 
 int aishost_model_replay(void* mv, int ch, long long first_group, long long first_sample48, int n_groups,
-                         const uint32_t* const* bits5, const float* lvl, int n_windows, const float* ppm) {
+                         const uint32_t* const* bits5, const float* lvl, int n_windows, const float* ppm, const uint32_t* fm_bits) {
 	Model* m = (Model*)mv;
 	aisgpu_out o;
 	memset(&o, 0, sizeof o);
 	o.n_groups = n_groups; o.first_group = first_group; o.first_sample48 = first_sample48;
 	for (int j = 0; j < 5; j++) o.bits[j] = bits5[j];
-	o.lvl = lvl; o.n_windows = n_windows; o.ppm = ppm;
+	o.lvl = lvl; o.n_windows = n_windows; o.ppm = ppm; o.fm_bits = fm_bits;
 	m->m.replay(ch, o, m->tag);
 	return 0;
 }

@@ -46,6 +46,27 @@ void GpuChain::replay(Connection<FLOAT32>* out, const aisgpu_out& o, TAG& tag) {
 	}
 }
 
+void GpuChain::replayChallenger(Connection<FLOAT32>* coh, Connection<FLOAT32>* fm, const aisgpu_out& o, TAG& tag) {
+	const int L = o.n_windows * 512;
+	for (int n = 0; n < L; n++) {
+		const long long N = o.first_sample48 + n;
+		if (o.ppm) tag.ppm = o.ppm[n >> 9]; // set by the CGF before it hands the window to the throttle (DSP.cpp:484)
+		if (N % 5 == 4) { // ScatterPLL has its five samples (DSP.h:101-113)
+			const long long g = N / 5;
+			const int gi = (int)(g - o.first_group);
+			if (tag.mode & 1) tag.sample_lvl = o.lvl[gi];
+			for (int j = 0; j < N_SAMPLES_PER_SYMBOL; j++) {
+				tag.sample_idx = 5 * g + j;
+				const FLOAT32 b = ((o.bits[j][gi >> 5] >> (gi & 31)) & 1u) ? 1.0f : -1.0f;
+				coh[j].Send(&b, 1, tag);
+			}
+		}
+		tag.sample_idx = N; // Deinterleave<FLOAT32> S_af counts every sample (DSP.h:65-71)
+		const FLOAT32 f = ((o.fm_bits[n >> 5] >> (n & 31)) & 1u) ? 1.0f : -1.0f;
+		fm[(int)(N % 5)].Send(&f, 1, tag);
+	}
+}
+
 void GpuChain::process(const void* data, int len, TAG& tag) {
 	if (failed || !batch) return;
 	int rc = batch->submitAndWait(rx, data, len);
@@ -61,7 +82,8 @@ void GpuChain::process(const void* data, int len, TAG& tag) {
 		for (int ch = 0; ch < 2; ch++) {
 			aisgpu_out o;
 			if (batch->fetch(s, rx, ch, &o) != AISGPU_OK) { failed = true; return; }
-			replay(ch == 0 ? outA : outB, o, tag);
+			if (o.fm_bits) replayChallenger(ch == 0 ? outA : outB, ch == 0 ? outAf : outBf, o, tag);
+			else replay(ch == 0 ? outA : outB, o, tag);
 		}
 	}
 }
@@ -80,6 +102,7 @@ void ModelDefaultGPU::buildModel(char CH1, char CH2, int sample_rate, bool /*tim
 		c.input_format = format == Format::CU8 ? AISGPU_FMT_CU8 : AISGPU_FMT_CF32;
 		c.afc_wide = CGF_wide;
 		c.droop = droop_compensation;
+		c.model = challenger ? AISGPU_MODEL_CHALLENGER : AISGPU_MODEL_DEFAULT;
 		batch = new GpuBatch(c); // throws std::runtime_error on unsupported rate / missing GPU
 		own_batch = true;
 		chain.attach(batch, 0);
@@ -98,10 +121,28 @@ void ModelDefaultGPU::wireDecoders(char CH1, char CH2) {
 		chain.outB[i] >> DEC_b[i];
 		DEC_a[i].out.Connect(&fan);
 		DEC_b[i].out.Connect(&fan);
+		if (challenger) {
+			DEC_af[i].setOrigin(CH1, station, own_mmsi);
+			DEC_bf[i].setOrigin(CH2, station, own_mmsi);
+			chain.outAf[i] >> DEC_af[i];
+			chain.outBf[i] >> DEC_bf[i];
+			DEC_af[i].out.Connect(&fan);
+			DEC_bf[i].out.Connect(&fan);
+		}
 		for (int j = 0; j < N_SAMPLES_PER_SYMBOL; j++) {
+			if (challenger) { // coherent and FM decoders of a channel reset each other too (Model.cpp:658-674)
+				DEC_af[i].DecoderMessage.Connect(DEC_a[j]);
+				DEC_a[i].DecoderMessage.Connect(DEC_af[j]);
+				DEC_bf[i].DecoderMessage.Connect(DEC_b[j]);
+				DEC_b[i].DecoderMessage.Connect(DEC_bf[j]);
+			}
 			if (i != j) { // a decoder that finds a message resets its four siblings (Model.cpp:566-573)
 				DEC_a[i].DecoderMessage.Connect(DEC_a[j]);
 				DEC_b[i].DecoderMessage.Connect(DEC_b[j]);
+				if (challenger) {
+					DEC_af[i].DecoderMessage.Connect(DEC_af[j]);
+					DEC_bf[i].DecoderMessage.Connect(DEC_bf[j]);
+				}
 			}
 		}
 	}

@@ -61,6 +61,8 @@ class GpuChain : public StreamIn<CFLOAT32>, public StreamIn<CU8> {
 
 public:
 	Connection<FLOAT32> outA[N_SAMPLES_PER_SYMBOL], outB[N_SAMPLES_PER_SYMBOL];
+	// ModelChallenger's FM branch (reference S_af / S_bf, DSP/Model.cpp:638-639); unconnected for ModelDefault
+	Connection<FLOAT32> outAf[N_SAMPLES_PER_SYMBOL], outBf[N_SAMPLES_PER_SYMBOL];
 
 	void attach(GpuBatch* b, int receiver) { batch = b; rx = receiver; }
 	void setErrorHandler(std::function<void(const std::string&)> f) { on_error = f; }
@@ -69,6 +71,10 @@ public:
 	// Replay one channel's symbol decisions of a block into the five phase outputs (host logic,
 	// also used stand-alone by the CPU tests).
 	static void replay(Connection<FLOAT32>* out, const aisgpu_out& o, TAG& tag);
+	// ModelChallenger: the reference throttles the CGF output one sample at a time into both branches
+	// (Deinterleave n=1, Model.cpp:630-639), so per 48 kHz sample N: first the coherent branch (which fires its five
+	// decoders when N completes a group), then FM decoder N % 5.
+	static void replayChallenger(Connection<FLOAT32>* coh, Connection<FLOAT32>* fm, const aisgpu_out& o, TAG& tag);
 };
 
 class ModelDefaultGPU {
@@ -76,6 +82,8 @@ class ModelDefaultGPU {
 	bool own_batch = false;
 	GpuChain chain;
 	AIS::Decoder DEC_a[N_SAMPLES_PER_SYMBOL], DEC_b[N_SAMPLES_PER_SYMBOL];
+	AIS::Decoder DEC_af[N_SAMPLES_PER_SYMBOL], DEC_bf[N_SAMPLES_PER_SYMBOL]; // ModelChallenger only
+	bool challenger = false;
 	StreamOut<AIS::Message> output;
 	int own_mmsi = -1, station = 0;
 	int block_len = 786432;
@@ -97,6 +105,7 @@ public:
 	void setOwnMMSI(int m) { own_mmsi = m; }
 	void setAFCWide(bool b) { CGF_wide = b; }
 	void setDroop(bool b) { droop_compensation = b; }
+	void setChallenger(bool b) { challenger = b; } // AIS::ModelChallenger wiring (Model.cpp:601-678) instead of ModelDefault
 	// same signature as AIS::Model::buildModel (the Device* of the reference is only used for wiring there)
 	void buildModel(char CH1, char CH2, int sample_rate, bool timerOn, void* device);
 	// decoder wiring only, no GPU context (CPU tests of the replay/decoder host logic)
@@ -106,7 +115,16 @@ public:
 	// entry used by the C API: the RAW block as the device thread delivers it (Device/FileRAW.cpp:135)
 	void Receive(const RAW* raw, TAG& tag);
 	// CPU-only replay entry (host-logic tests): decisions produced elsewhere
-	void replay(int ch, const aisgpu_out& o, TAG& tag) { GpuChain::replay(ch == 0 ? chain.outA : chain.outB, o, tag); }
+	void replay(int ch, const aisgpu_out& o, TAG& tag) {
+		if (challenger) GpuChain::replayChallenger(ch == 0 ? chain.outA : chain.outB, ch == 0 ? chain.outAf : chain.outBf, o, tag);
+		else GpuChain::replay(ch == 0 ? chain.outA : chain.outB, o, tag);
+	}
+};
+
+// same contract, AIS::ModelChallenger wiring ("-m 4")
+class ModelChallengerGPU : public ModelDefaultGPU {
+public:
+	ModelChallengerGPU() { setChallenger(true); }
 };
 
 } // namespace aisamd

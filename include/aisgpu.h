@@ -17,6 +17,8 @@
  *   FilterComplex (Filters::Coherent)     DSP/DSP.cpp:215-246
  *   ScatterPLL (/5, signal level)         DSP/DSP.h:76-117
  *   5x PhaseSearchEMA per channel         DSP/Demod.cpp:39-101
+ * and for AIS::ModelChallenger additionally (DSP/Model.cpp:630-639)
+ *   Demod::FM + Filter(Receiver, 37 taps) DSP/Demod.cpp:27-37, DSP/DSP.cpp:249-280
  * The consumer -- 5x AIS::Decoder per channel + NMEA (Marine/AIS.h:82-181, Marine/AIS.cpp:33-142,
  * Marine/Message.cpp:569-631) -- stays on the host, unchanged, fed from aisgpu_fetch() (ais-catcher_amd/host/).
  *
@@ -46,7 +48,8 @@ extern "C" {
 #define AISGPU_FMT_CF32 1
 
 /* models (DSP/Model.h:61-72) */
-#define AISGPU_MODEL_DEFAULT 2
+#define AISGPU_MODEL_DEFAULT 2     /* AIS::ModelDefault    (-m 2), DSP/Model.cpp:520-577 */
+#define AISGPU_MODEL_CHALLENGER 4  /* AIS::ModelChallenger (-m 4), DSP/Model.cpp:601-678: ModelDefault + the FM branch */
 
 #define AISGPU_FLAG_TAPS 1    /* keep intermediate float taps readable via aisgpu_tap() (tests) */
 #define AISGPU_FLAG_SERIAL 2  /* profiling aid: one stream, no overlap between the kernels of consecutive blocks */
@@ -58,7 +61,7 @@ typedef struct aisgpu_cfg {
 	                    * resamples up to the next bucket, e.g. 6000000 (Model.cpp:129-338) */
 	int n_receivers;   /* independent dual-channel receiver instances batched on this GPU */
 	int block_len;     /* IQ samples per receiver per Receive() block; multiple of 512 * bucket_rate/48000 */
-	int model;         /* AISGPU_MODEL_DEFAULT */
+	int model;         /* AISGPU_MODEL_DEFAULT or AISGPU_MODEL_CHALLENGER */
 	int input_format;  /* AISGPU_FMT_* */
 	int afc_wide;      /* KEY_SETTING_AFC_WIDE (default on, Model.cpp:536-540) */
 	int droop;         /* KEY_SETTING_DROOP    (default on, Model.cpp:223-229) */
@@ -79,6 +82,8 @@ typedef struct aisgpu_out {
 	const float* ppm;        /* [n_windows] tag.ppm */
 	const int* group_window; /* reserved (NULL): window of group g is (5*(first_group+g)+4 - first_sample48)/512 */
 	long long first_sample48;/* stream index (48 kHz) of the first sample of this block */
+	const uint32_t* fm_bits; /* AISGPU_MODEL_CHALLENGER only (else NULL): bit n of word n/32 set <=> the filtered FM discriminator
+	                          * sample first_sample48 + n is > 0 (what Deinterleave S_af hands to DEC_af[n % 5], Model.cpp:638-639) */
 } aisgpu_out;
 
 void aisgpu_default_cfg(aisgpu_cfg* cfg);

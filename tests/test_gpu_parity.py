@@ -313,3 +313,51 @@ def test_other_resampled_rates(rate):
     block = 512 * (bucket // 48000) * 8
     x = synth.receiver_stream(block * 4, sample_rate=rate, receiver_id=52, gap_slots=(1, 2))
     _run_multi_sub(x, rate, block, 4)
+
+
+def test_challenger_fm_branch_bits_and_nmea():
+    """AIS::ModelChallenger at 1536 kSPS: FM-branch decisions (atan2f discriminator -> 37-tap FIR -> sign) and the
+    end-to-end NMEA of the 20-decoder wiring == the checker (Model.cpp:601-678)."""
+    from ais_catcher_amd import host
+    block, nblocks = 131072, 8
+    x = synth.receiver_stream(block * nblocks, receiver_id=60, gap_slots=(1, 2), type5_every=4)
+    chk = checkers.Ref(model=4, taps=True) if checkers.have_ref() else checkers.Oracle(model=4, taps=True)
+    chk.feed_blocks(x, block)
+    L = block // 32
+    g = gpu.AisGpu(n_receivers=1, block_len=block, model=gpu.MODEL_CHALLENGER)
+    for b in range(nblocks):
+        g.submit(0, x[b * block:(b + 1) * block])
+        g.run()
+        g.sync_outputs()
+        for ch in range(2):
+            out = g.fetch(0, ch)
+            for j in range(5):
+                f = chk.bits(ch, j, 1)[0]  # FM decoder j saw samples N = j (mod 5)
+                N = np.arange(b * L, (b + 1) * L)
+                sel = N[N % 5 == j]
+                assert np.array_equal(out["fm_bits"][sel - b * L], (f[sel // 5] > 0).astype(np.uint8)), "fm blk %d ch %d j %d" % (b, ch, j)
+    g.close()
+    host.reset_sequence()
+    m = host.ModelChallengerGPU(block_len=block)
+    for b in range(nblocks):
+        m.receive(x[b * block:(b + 1) * block])
+    assert m.nmea() == chk.nmea() and len(chk.nmea()) >= 4
+    m.close()
+
+
+def test_config3_6msps_challenger_nmea():
+    """BASELINE configs[2]: 6 MSPS input, deeper CIC5 ladder + resampler, ModelChallenger -- NMEA identical to the checker."""
+    from ais_catcher_amd import host
+    block, nblocks = 786432, 6
+    x = synth.receiver_stream(block * nblocks, sample_rate=6000000, receiver_id=61, type5_every=5)
+    chk = checkers.Ref(model=4, rate=6000000) if checkers.have_ref() else checkers.Oracle(model=4, rate=6000000)
+    chk.feed_blocks(x, block)
+    host.reset_sequence()
+    m = host.ModelChallengerGPU(sample_rate=6000000, block_len=block)
+    for b in range(nblocks):
+        m.receive(x[b * block:(b + 1) * block])
+    assert len(chk.nmea()) >= 5
+    assert m.nmea() == chk.nmea()
+    a, c = m.msg_meta(), chk.msg_meta()
+    assert np.array_equal(a[1], c[1])
+    m.close()

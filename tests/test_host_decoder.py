@@ -58,3 +58,34 @@ def test_random_bits_never_crash_and_match_oracle_decoder():
     m = host.ModelDefaultGPU(detached=True)
     _replay_blocks(m, chk, 4096, 6)
     assert m.nmea() == chk.nmea()
+
+
+def test_challenger_replay_matches_checker():
+    """ModelChallenger wiring (20 decoders, throttled interleave of the coherent and the FM branch) fed with the
+    checker's decisions == the checker's NMEA."""
+    block, nblocks = 131072, 10
+    x = synth.receiver_stream(block * nblocks, receiver_id=7, gap_slots=(1, 2), type5_every=4)
+    chk = checkers.Ref(model=4, taps=True) if checkers.have_ref() else checkers.Oracle(model=4, taps=True)
+    chk.feed_blocks(x, block)
+    host.reset_sequence()
+    m = host.ModelChallengerGPU(detached=True)
+    L = block // 32
+    W = L // 512
+    bits = [[chk.bits(ch, j) for j in range(5)] for ch in range(2)]
+    ppm = [chk.tap_ppm(2), chk.tap_ppm(3)]
+    fm = []
+    for ch in range(2):  # FM decoder j saw the samples N = j (mod 5): interleave them back into one stream
+        per = [chk.bits(ch, j, 1)[0] for j in range(5)]
+        n = min(len(p) for p in per) * 5
+        f = np.zeros(n, np.float32)
+        for j in range(5):
+            f[j::5] = per[j][:n // 5]
+        fm.append(f)
+    for b in range(nblocks):
+        g0, g1 = (b * L) // 5, ((b + 1) * L) // 5
+        for ch in range(2):
+            b5 = np.stack([bits[ch][j][0][g0:g1] for j in range(5)])
+            m.replay(ch, g0, b * L, b5, bits[ch][0][1][g0:g1], ppm[ch][b * W:(b + 1) * W], fm=fm[ch][b * L:(b + 1) * L])
+    assert m.nmea() == chk.nmea() and len(chk.nmea()) >= 5
+    a, c = m.msg_meta(), chk.msg_meta()
+    assert np.array_equal(a[1], c[1])
