@@ -316,11 +316,11 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->challenger = cfg->model == AISGPU_MODEL_CHALLENGER;
 	// front-end geometry (tuning knobs; the defaults are the measured best): workgroup size, output samples per
 	// tile, prefetch depth.  Compiled combinations: "256,256,2", "64,64,1", "64,64,2".
-	h->k1_threads = 64; h->tile96 = 64; h->depth = 1; // autonomous waves (profiles/r01_k1_geometry_sweep.txt)
+	h->k1_threads = 64; h->tile96 = 64; h->depth = 0; // autonomous waves, register/DPP ladder (profiles/r01_k1_geometry_sweep.txt)
 	if (const char* e = getenv("AISGPU_K1")) { // "threads,tile96,depth"
 		int a = 0, b = 0, d = 0;
 		if (sscanf(e, "%d,%d,%d", &a, &b, &d) == 3) {
-			const bool ok = (a == 256 && b == 256 && d == 2) || (a == 64 && b == 64 && (d == 1 || d == 2));
+			const bool ok = (a == 256 && b == 256 && d == 2) || (a == 64 && b == 64 && (d == 0 || d == 1 || d == 2)); // d == 0: register (DPP) ladder
 			if (ok) { h->k1_threads = a; h->tile96 = b; h->depth = d; }
 		}
 	}

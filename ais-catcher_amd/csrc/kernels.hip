@@ -383,6 +383,217 @@ __global__ __launch_bounds__(NT) void k1_frontend(K1Params p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K1 (register variant): the same ladder with the CIC5 stages, the droop filter and the rotator entirely in
+// registers.  One wave = one autonomous stream processor; lane l owns 2^K consecutive input samples of the
+// wave-tile (64 * 2^K samples) and ends up with exactly one 96 kHz sample.  The five samples of history every
+// stage needs come from the neighbouring lane through DPP wave shifts (lane 0 receives lane 63's value of the
+// PREVIOUS tile, kept in a shadow register), so between the coalesced-load transposition and the 96 kHz point
+// there is no LDS traffic and no synchronisation at all; only the two channel filters behind the rotator use a
+// small wave-private LDS ring.  Arithmetic and pairing are identical to the LDS variant (cic5_dec_chunk).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_wave_shr1(float old_lane0, float src) { // lane l <- src[l-1]; lane 0 keeps old_lane0
+	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old_lane0), __float_as_int(src), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_wave_ror1(float src) { // lane l <- src[(l + 63) % 64]
+	// every lane has a source lane, so the `old` operand is never used: tie it to src (dead afterwards) to save a move
+	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(src), __float_as_int(src), 0x13C, 0xF, 0xF, false));
+}
+// value of the previous lane; for lane 0 the value lane 63 held in `prev` (the same quantity one tile earlier).
+// `prev` is then refreshed with the current value.
+__device__ __forceinline__ float2 from_prev_lane(float2 cur, float2& prev) {
+	float2 r;
+	r.x = dpp_wave_shr1(dpp_wave_ror1(prev.x), cur.x);
+	r.y = dpp_wave_shr1(dpp_wave_ror1(prev.y), cur.y);
+	prev = cur;
+	return r;
+}
+
+template <int C> struct HaloState;           // shadow registers of one stage (all zero = silence before the stream)
+template <> struct HaloState<16> { float2 p[5]; };
+template <> struct HaloState<8> { float2 p[5]; };
+template <> struct HaloState<4> { float2 p[4], q; };
+template <> struct HaloState<2> { float2 p1[2], p2[2], p3; };
+
+// h[i] = sample (chunk_start - 5 + i) of the stage's input stream
+template <int C>
+__device__ __forceinline__ void get_halo(const float2 (&x)[C], HaloState<C>& hs, float2 (&h)[5]) {
+	if constexpr (C >= 5) {
+#pragma unroll
+		for (int i = 0; i < 5; i++) h[i] = from_prev_lane(x[C - 5 + i], hs.p[i]);
+	} else if constexpr (C == 4) {
+		float2 t[4];
+#pragma unroll
+		for (int j = 0; j < 4; j++) { t[j] = from_prev_lane(x[j], hs.p[j]); h[1 + j] = t[j]; }
+		h[0] = from_prev_lane(t[3], hs.q); // two lanes back
+	} else { // C == 2
+		float2 t1[2], t2[2];
+#pragma unroll
+		for (int j = 0; j < 2; j++) { t1[j] = from_prev_lane(x[j], hs.p1[j]); h[3 + j] = t1[j]; }
+#pragma unroll
+		for (int j = 0; j < 2; j++) { t2[j] = from_prev_lane(t1[j], hs.p2[j]); h[1 + j] = t2[j]; }
+		h[0] = from_prev_lane(t2[1], hs.p3); // three lanes back
+	}
+}
+
+template <int C>
+__device__ __forceinline__ void reg_stage(const float2 (&x)[C], HaloState<C>& hs, float2 (&out)[C / 2]) {
+	float2 h[5];
+	get_halo<C>(x, hs, h);
+	float2 v[C + 4];
+#pragma unroll
+	for (int i = 0; i < 5; i++) v[i] = h[i];
+#pragma unroll
+	for (int i = 0; i < C - 1; i++) v[5 + i] = x[i];
+	cic5_dec_chunk<C / 2>(v, out);
+}
+
+template <int K> struct RegLadder;
+template <> struct RegLadder<4> { HaloState<16> s16; HaloState<8> s8; HaloState<4> s4; HaloState<2> s2; };
+template <> struct RegLadder<3> { HaloState<8> s8; HaloState<4> s4; HaloState<2> s2; };
+template <> struct RegLadder<2> { HaloState<4> s4; HaloState<2> s2; };
+template <> struct RegLadder<1> { HaloState<2> s2; };
+
+template <int K>
+__device__ __forceinline__ float2 run_ladder(const float2 (&x)[1 << K], RegLadder<K>& st) {
+	if constexpr (K == 4) {
+		float2 a[8], b[4], c[2], d[1];
+		reg_stage<16>(x, st.s16, a); reg_stage<8>(a, st.s8, b); reg_stage<4>(b, st.s4, c); reg_stage<2>(c, st.s2, d);
+		return d[0];
+	} else if constexpr (K == 3) {
+		float2 b[4], c[2], d[1];
+		reg_stage<8>(x, st.s8, b); reg_stage<4>(b, st.s4, c); reg_stage<2>(c, st.s2, d);
+		return d[0];
+	} else if constexpr (K == 2) {
+		float2 c[2], d[1];
+		reg_stage<4>(x, st.s4, c); reg_stage<2>(c, st.s2, d);
+		return d[0];
+	} else {
+		float2 d[1];
+		reg_stage<2>(x, st.s2, d);
+		return d[0];
+	}
+}
+
+template <int K, bool CU8, bool PRE>
+__global__ __launch_bounds__(64) void k1_dpp(K1Params p) {
+	constexpr int C0 = 1 << K;        // input samples per lane per tile
+	constexpr int TILE_IN = 64 * C0;  // input samples per wave-tile
+	constexpr int W4 = C0 / 2 + 1;    // padded row (float4) of the transposition buffer
+	__shared__ __attribute__((aligned(16))) float4 xt[C0 >= 4 && !CU8 ? 64 * W4 : 1]; // coalesced -> per-lane layout
+	__shared__ __attribute__((aligned(16))) float2 x5[2][8 + 64];  // rotated up/down with 8 samples of history
+	__shared__ __attribute__((aligned(16))) float2 x6[2][8 + 32];  // DS2_a/b output
+	const int lane = threadIdx.x;
+	const int rx = blockIdx.y;
+	const int span = blockIdx.x;
+	__builtin_amdgcn_s_setprio(2);
+
+	if (lane < 8) { x5[0][lane] = x5[1][lane] = x6[0][lane] = x6[1][lane] = make_float2(0.f, 0.f); }
+	RegLadder<K> st = {};
+	float2 fdc_p1 = make_float2(0.f, 0.f), fdc_p2 = make_float2(0.f, 0.f);
+
+	const int tile_first = span * p.tiles_per_span - 1; // warm-up tile
+	int tile_last = tile_first + p.tiles_per_span;
+	if (tile_last >= p.tiles_per_block) tile_last = p.tiles_per_block - 1;
+
+	constexpr int TILE_BYTES = TILE_IN * (CU8 ? 2 : 8);
+	constexpr int LANE_BYTES = TILE_BYTES / 64;                    // 2^K * (2 or 8)
+	constexpr int NV = LANE_BYTES >= 16 ? LANE_BYTES / 16 : 1;      // 16-byte pieces per lane
+	uint4 pre[NV];
+	auto prefetch = [&](int tile) {
+		const unsigned char* base;
+		if (tile < 0) base = (const unsigned char*)p.hist + (size_t)rx * TILE_BYTES;
+		else base = (const unsigned char*)p.in + ((size_t)rx * p.in_stride + (size_t)tile * TILE_IN) * (CU8 ? 2 : 8);
+		if constexpr (LANE_BYTES >= 16) {
+			const uint4* src = (const uint4*)base;
+#pragma unroll
+			for (int e = 0; e < NV; e++) {
+				if (CU8 || C0 < 4) pre[e] = src[lane * NV + e]; // the lane's own contiguous bytes
+				else pre[e] = src[e * 64 + lane];               // coalesced; transposed through LDS below
+			}
+		} else if constexpr (LANE_BYTES == 8) {
+			const uint2 v = ((const uint2*)base)[lane];
+			pre[0] = make_uint4(v.x, v.y, 0, 0);
+		} else {
+			pre[0] = make_uint4(((const unsigned*)base)[lane], 0, 0, 0);
+		}
+	};
+	prefetch(tile_first);
+
+	for (int tile = tile_first; tile <= tile_last; tile++) {
+		float2 x[C0];
+		if constexpr (CU8) { // Utilities/Convert.cpp:255-264: ((int)u - 128) / 128.0f (exact)
+			const unsigned* w = reinterpret_cast<const unsigned*>(pre);
+#pragma unroll
+			for (int i = 0; i < C0; i++) {
+				const unsigned v = w[i >> 1] >> ((i & 1) * 16);
+				x[i] = make_float2((float)((int)(v & 255u) - 128) * 0.0078125f, (float)((int)((v >> 8) & 255u) - 128) * 0.0078125f);
+			}
+		} else if constexpr (C0 < 4) {
+			x[0] = make_float2(__uint_as_float(pre[0].x), __uint_as_float(pre[0].y));
+			x[1] = make_float2(__uint_as_float(pre[0].z), __uint_as_float(pre[0].w));
+		} else {
+			__syncthreads(); // single wave: orders the previous tile's reads against these writes
+#pragma unroll
+			for (int e = 0; e < NV; e++) {
+				const int s2 = e * 64 + lane; // float4 index inside the tile
+				xt[(s2 / (C0 / 2)) * W4 + (s2 % (C0 / 2))] = make_float4(__uint_as_float(pre[e].x), __uint_as_float(pre[e].y), __uint_as_float(pre[e].z), __uint_as_float(pre[e].w));
+			}
+			__syncthreads();
+#pragma unroll
+			for (int e = 0; e < C0 / 2; e++) {
+				const float4 v = lds4(xt + lane * W4 + e);
+				x[2 * e] = lo(v); x[2 * e + 1] = hi(v);
+			}
+		}
+		float2 rotv = make_float2(1.0f, 0.0f);
+		if (!PRE) rotv = p.rot[(size_t)ROT_HIST + (long long)tile * 64 + lane];
+		prefetch(tile + 1 <= tile_last ? tile + 1 : tile_last);
+
+		const float2 x96 = run_ladder<K>(x, st);
+		if constexpr (PRE) {
+			if (tile > tile_first) p.pre_out[(size_t)rx * p.pre_stride + (size_t)tile * 64 + lane] = x96;
+		} else {
+			// ---- FDC (DSP.cpp:283-293) + Rotate (DSP.cpp:296-316)
+			const float2 xm1 = from_prev_lane(x96, fdc_p1);
+			const float2 xm2 = from_prev_lane(xm1, fdc_p2);
+			float2 y = x96;
+			if (p.has_fdc) {
+				const float2 s2 = cadd(xm2, x96);
+				y = make_float2(p.alpha * s2.x + xm1.x * p.beta, p.alpha * s2.y + xm1.y * p.beta);
+			}
+			const float RR = y.x * rotv.x, II = y.y * rotv.y, RI = y.x * rotv.y, IR = y.y * rotv.x;
+			__syncthreads(); // previous tile's x5/x6 reads are complete
+			x5[0][8 + lane] = make_float2(RR - II, IR + RI); // up   -> channel A
+			x5[1][8 + lane] = make_float2(RR + II, IR - RI); // down -> channel B
+			__syncthreads();
+			// ---- DS2_a / DS2_b: lanes 0..31 channel A, lanes 32..63 channel B
+			const int ch = lane >> 5, j = lane & 31;
+			x6[ch][8 + j] = cic5_small(reinterpret_cast<const float4*>(&x5[ch][0]), j);
+			__syncthreads();
+			// ---- FilterCIC5 (DSP.cpp:132-157)
+			{
+				const float2* src = &x6[ch][8 + j - 5];
+				float2 v[6];
+#pragma unroll
+				for (int e = 0; e < 6; e++) v[e] = src[e];
+#pragma unroll
+				for (int lvl = 0; lvl < 5; lvl++) {
+#pragma unroll
+					for (int i = 0; i < 5 - lvl; i++) v[i] = cadd(v[i + 1], v[i]);
+				}
+				if (tile > tile_first) {
+					float2* dst = p.c48 + ((size_t)rx * 2 + ch) * p.c48_stride + (size_t)tile * 32 + j;
+					*dst = make_float2(v[0].x * 0.03125f, v[0].y * 0.03125f);
+				}
+			}
+			__syncthreads();
+			if (lane < 8) { x5[0][lane] = x5[0][64 + lane]; x5[1][lane] = x5[1][64 + lane]; }
+			else if (lane < 16) { x6[0][lane - 8] = x6[0][32 + lane - 8]; x6[1][lane - 8] = x6[1][32 + lane - 8]; }
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------
 // K1u: the tail of an interpolated ladder (sample rates between two 2^k buckets, Model.cpp:163-189, e.g. 6 MSPS):
 // Upsample (linear fractional resampler, DSP/DSP.cpp:192-212) -> DS2_2 -> DS2_1 -> FDC -> Rotate -> DS2_a/b ->
 // FilterCIC5, on the pre-decimated stream written by the PRE pass.  The resampler's (input index, alpha) sequence
@@ -1172,9 +1383,33 @@ static hipError_t launch_k1_p(const K1Params& p, int K, bool cu8, int spans, int
 	return hipErrorInvalidValue;
 }
 
+template <int K>
+static hipError_t launch_k1_dpp_k(const K1Params& p, bool cu8, int spans, int n_rx, hipStream_t s) {
+	const bool pre = p.pre_out != nullptr;
+	if (cu8) {
+		if (pre) hipLaunchKernelGGL((k1_dpp<K, true, true>), dim3(spans, n_rx), dim3(64), 0, s, p);
+		else hipLaunchKernelGGL((k1_dpp<K, true, false>), dim3(spans, n_rx), dim3(64), 0, s, p);
+	} else {
+		if (pre) hipLaunchKernelGGL((k1_dpp<K, false, true>), dim3(spans, n_rx), dim3(64), 0, s, p);
+		else hipLaunchKernelGGL((k1_dpp<K, false, false>), dim3(spans, n_rx), dim3(64), 0, s, p);
+	}
+	return hipGetLastError();
+}
+
+static hipError_t launch_k1_dpp(const K1Params& p, int K, bool cu8, int spans, int n_rx, hipStream_t s) {
+	switch (K) {
+	case 4: return launch_k1_dpp_k<4>(p, cu8, spans, n_rx, s);
+	case 3: return launch_k1_dpp_k<3>(p, cu8, spans, n_rx, s);
+	case 2: return launch_k1_dpp_k<2>(p, cu8, spans, n_rx, s);
+	case 1: return launch_k1_dpp_k<1>(p, cu8, spans, n_rx, s);
+	}
+	return hipErrorInvalidValue;
+}
+
 // tile96: samples at the kernel's output rate per tile; depth: tiles prefetched ahead; threads: workgroup size
 // (256, or 64 = one autonomous wave per workgroup)
 hipError_t launch_k1(const K1Params& p, int K, bool cu8, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s) {
+	if (depth == 0) return launch_k1_dpp(p, K, cu8, spans, n_rx, s); // register (DPP) variant: 64 threads, tile96 = 64
 	switch (threads * 10000 + tile96 * 10 + depth) {
 	case 2562562: return launch_k1_p<256, 2, 256>(p, K, cu8, spans, n_rx, s);
 	case 640641: return launch_k1_p<64, 1, 64>(p, K, cu8, spans, n_rx, s);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # K1 geometry sweep on the GPU box ("threads,tile96,depth"): serial (isolated) K1 time + overlapped step time
 cd "$(dirname "$0")/.."
-for cfg in "256,256,2" "64,64,1" "64,64,2"; do
+for cfg in "64,64,1" "64,64,0"; do
   AISGPU_K1=$cfg python bench.py --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
