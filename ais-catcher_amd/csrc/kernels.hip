@@ -110,6 +110,15 @@ __device__ __forceinline__ float4 lds4(const float4* p) {
 	asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
 	return v;
 }
+// the same for a batch: all loads are issued first, the keep-alive statements follow (an asm right behind each load
+// would force a wait per load and serialise the LDS round trips)
+template <int N>
+__device__ __forceinline__ void lds4_batch(const float4* p, float4 (&v)[N]) {
+#pragma unroll
+	for (int e = 0; e < N; e++) v[e] = p[e];
+#pragma unroll
+	for (int e = 0; e < N; e++) asm volatile("" : "+v"(v[e].x), "+v"(v[e].y), "+v"(v[e].z), "+v"(v[e].w));
+}
 __device__ __forceinline__ float2 lo(float4 v) { return make_float2(v.x, v.y); }
 __device__ __forceinline__ float2 hi(float4 v) { return make_float2(v.z, v.w); }
 __device__ __forceinline__ float4 pack(float2 a, float2 b) { return make_float4(a.x, a.y, b.x, b.y); }
@@ -118,11 +127,12 @@ __device__ __forceinline__ float4 pack(float2 a, float2 b) { return make_float4(
 // (lvl4 = level base in float4 units: sample i lives at float2 index 8 + i)
 __device__ __forceinline__ float2 cic5_small(const float4* lvl4, int t) {
 	float2 v[6];
-	const float4 c0 = lds4(lvl4 + t + 1), c1 = lds4(lvl4 + t + 2), c2 = lds4(lvl4 + t + 3), c3 = lds4(lvl4 + t + 4); // samples 2t-6 .. 2t+1
-	v[0] = hi(c0);
-	v[1] = lo(c1); v[2] = hi(c1);
-	v[3] = lo(c2); v[4] = hi(c2);
-	v[5] = lo(c3);
+	float4 c[4];
+	lds4_batch<4>(lvl4 + t + 1, c); // samples 2t-6 .. 2t+1
+	v[0] = hi(c[0]);
+	v[1] = lo(c[1]); v[2] = hi(c[1]);
+	v[3] = lo(c[2]); v[4] = hi(c[2]);
+	v[5] = lo(c[3]);
 	float2 o[1];
 	cic5_dec_chunk<1>(v, o);
 	return o[0];
@@ -237,10 +247,8 @@ __global__ __launch_bounds__(NT) void k1_frontend(K1Params p) {
 			const float4* own = l16 + t * W16;
 			const float4* halo = (t == 0) ? h16 + 1 : l16 + (t - 1) * W16 + 5; // samples 16t-6 .. 16t-1
 			float4 hv[3], ov[8];
-#pragma unroll
-			for (int e = 0; e < 3; e++) hv[e] = lds4(halo + e);
-#pragma unroll
-			for (int e = 0; e < 8; e++) ov[e] = lds4(own + e);
+			lds4_batch<3>(halo, hv);
+			lds4_batch<8>(own, ov);
 			v[0] = hi(hv[0]);
 			v[1] = lo(hv[1]); v[2] = hi(hv[1]);
 			v[3] = lo(hv[2]); v[4] = hi(hv[2]);
@@ -264,10 +272,8 @@ __global__ __launch_bounds__(NT) void k1_frontend(K1Params p) {
 			const float4* own = l8 + t * W8;
 			const float4* halo = (t == 0) ? h8 + 1 : l8 + (t - 1) * W8 + 1; // samples 8t-6 .. 8t-1
 			float4 hv[3], ov[4];
-#pragma unroll
-			for (int e = 0; e < 3; e++) hv[e] = lds4(halo + e);
-#pragma unroll
-			for (int e = 0; e < 4; e++) ov[e] = lds4(own + e);
+			lds4_batch<3>(halo, hv);
+			lds4_batch<4>(own, ov);
 			v[0] = hi(hv[0]);
 			v[1] = lo(hv[1]); v[2] = hi(hv[1]);
 			v[3] = lo(hv[2]); v[4] = hi(hv[2]);
@@ -391,42 +397,60 @@ __global__ __launch_bounds__(NT) void k1_frontend(K1Params p) {
 // there is no LDS traffic and no synchronisation at all; only the two channel filters behind the rotator use a
 // small wave-private LDS ring.  Arithmetic and pairing are identical to the LDS variant (cic5_dec_chunk).
 // ------------------------------------------------------------------------------------------
+// complex samples as native 2-vectors: an add is one v_pk_add_f32 on an aligned register pair and (re, im) stay
+// together (with the float2 struct the SLP vectoriser re-pairs components of different samples and pays for it in moves)
+typedef float c2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float dpp_wave_shr1(float old_lane0, float src) { // lane l <- src[l-1]; lane 0 keeps old_lane0
 	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old_lane0), __float_as_int(src), 0x138, 0xF, 0xF, false));
 }
 __device__ __forceinline__ float dpp_wave_ror1(float src) { // lane l <- src[(l + 63) % 64]
-	// every lane has a source lane, so the `old` operand is never used: tie it to src (dead afterwards) to save a move
-	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(src), __float_as_int(src), 0x13C, 0xF, 0xF, false));
+	// every lane has a source lane, so no `old` value is needed (mov_dpp: old = undef, no extra move)
+	return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(src), 0x13C, 0xF, 0xF, false));
 }
-// value of the previous lane; for lane 0 the value lane 63 held in `prev` (the same quantity one tile earlier).
-// `prev` is then refreshed with the current value.
-__device__ __forceinline__ float2 from_prev_lane(float2 cur, float2& prev) {
-	float2 r;
-	r.x = dpp_wave_shr1(dpp_wave_ror1(prev.x), cur.x);
-	r.y = dpp_wave_shr1(dpp_wave_ror1(prev.y), cur.y);
-	prev = cur;
+// value of the previous lane; for lane 0 the value lane 63 held one tile earlier.  The shadow register `prev`
+// holds that quantity ALREADY ROTATED by one lane (lane 0 = last tile's lane 63), so a tile costs exactly two DPP
+// moves per dword: the shift, and the rotation that prepares the next tile's shadow.
+__device__ __forceinline__ c2 from_prev_lane(c2 cur, c2& prev) {
+	c2 r;
+	r.x = dpp_wave_shr1(prev.x, cur.x);
+	r.y = dpp_wave_shr1(prev.y, cur.y);
+	prev.x = dpp_wave_ror1(cur.x);
+	prev.y = dpp_wave_ror1(cur.y);
 	return r;
 }
 
+// cic5_dec_chunk on native vectors (same pairing, same rounding)
+template <int NOUT>
+__device__ __forceinline__ void cic5_dec_chunk_v(c2 (&v)[2 * NOUT + 4], c2 (&out)[NOUT]) {
+#pragma unroll
+	for (int lvl = 0; lvl < 4; lvl++) {
+#pragma unroll
+		for (int i = 0; i < 2 * NOUT + 3 - lvl; i++) v[i] = v[i + 1] + v[i];
+	}
+#pragma unroll
+	for (int q = 0; q < NOUT; q++) out[q] = (v[2 * q + 1] + v[2 * q]) * 0.03125f;
+}
+
 template <int C> struct HaloState;           // shadow registers of one stage (all zero = silence before the stream)
-template <> struct HaloState<16> { float2 p[5]; };
-template <> struct HaloState<8> { float2 p[5]; };
-template <> struct HaloState<4> { float2 p[4], q; };
-template <> struct HaloState<2> { float2 p1[2], p2[2], p3; };
+template <> struct HaloState<16> { c2 p[5]; };
+template <> struct HaloState<8> { c2 p[5]; };
+template <> struct HaloState<4> { c2 p[4], q; };
+template <> struct HaloState<2> { c2 p1[2], p2[2], p3; };
 
 // h[i] = sample (chunk_start - 5 + i) of the stage's input stream
 template <int C>
-__device__ __forceinline__ void get_halo(const float2 (&x)[C], HaloState<C>& hs, float2 (&h)[5]) {
+__device__ __forceinline__ void get_halo(const c2 (&x)[C], HaloState<C>& hs, c2 (&h)[5]) {
 	if constexpr (C >= 5) {
 #pragma unroll
 		for (int i = 0; i < 5; i++) h[i] = from_prev_lane(x[C - 5 + i], hs.p[i]);
 	} else if constexpr (C == 4) {
-		float2 t[4];
+		c2 t[4];
 #pragma unroll
 		for (int j = 0; j < 4; j++) { t[j] = from_prev_lane(x[j], hs.p[j]); h[1 + j] = t[j]; }
 		h[0] = from_prev_lane(t[3], hs.q); // two lanes back
 	} else { // C == 2
-		float2 t1[2], t2[2];
+		c2 t1[2], t2[2];
 #pragma unroll
 		for (int j = 0; j < 2; j++) { t1[j] = from_prev_lane(x[j], hs.p1[j]); h[3 + j] = t1[j]; }
 #pragma unroll
@@ -436,15 +460,15 @@ __device__ __forceinline__ void get_halo(const float2 (&x)[C], HaloState<C>& hs,
 }
 
 template <int C>
-__device__ __forceinline__ void reg_stage(const float2 (&x)[C], HaloState<C>& hs, float2 (&out)[C / 2]) {
-	float2 h[5];
+__device__ __forceinline__ void reg_stage(const c2 (&x)[C], HaloState<C>& hs, c2 (&out)[C / 2]) {
+	c2 h[5];
 	get_halo<C>(x, hs, h);
-	float2 v[C + 4];
+	c2 v[C + 4];
 #pragma unroll
 	for (int i = 0; i < 5; i++) v[i] = h[i];
 #pragma unroll
 	for (int i = 0; i < C - 1; i++) v[5 + i] = x[i];
-	cic5_dec_chunk<C / 2>(v, out);
+	cic5_dec_chunk_v<C / 2>(v, out);
 }
 
 template <int K> struct RegLadder;
@@ -454,21 +478,21 @@ template <> struct RegLadder<2> { HaloState<4> s4; HaloState<2> s2; };
 template <> struct RegLadder<1> { HaloState<2> s2; };
 
 template <int K>
-__device__ __forceinline__ float2 run_ladder(const float2 (&x)[1 << K], RegLadder<K>& st) {
+__device__ __forceinline__ c2 run_ladder(const c2 (&x)[1 << K], RegLadder<K>& st) {
 	if constexpr (K == 4) {
-		float2 a[8], b[4], c[2], d[1];
+		c2 a[8], b[4], c[2], d[1];
 		reg_stage<16>(x, st.s16, a); reg_stage<8>(a, st.s8, b); reg_stage<4>(b, st.s4, c); reg_stage<2>(c, st.s2, d);
 		return d[0];
 	} else if constexpr (K == 3) {
-		float2 b[4], c[2], d[1];
+		c2 b[4], c[2], d[1];
 		reg_stage<8>(x, st.s8, b); reg_stage<4>(b, st.s4, c); reg_stage<2>(c, st.s2, d);
 		return d[0];
 	} else if constexpr (K == 2) {
-		float2 c[2], d[1];
+		c2 c[2], d[1];
 		reg_stage<4>(x, st.s4, c); reg_stage<2>(c, st.s2, d);
 		return d[0];
 	} else {
-		float2 d[1];
+		c2 d[1];
 		reg_stage<2>(x, st.s2, d);
 		return d[0];
 	}
@@ -489,7 +513,7 @@ __global__ __launch_bounds__(64) void k1_dpp(K1Params p) {
 
 	if (lane < 8) { x5[0][lane] = x5[1][lane] = x6[0][lane] = x6[1][lane] = make_float2(0.f, 0.f); }
 	RegLadder<K> st = {};
-	float2 fdc_p1 = make_float2(0.f, 0.f), fdc_p2 = make_float2(0.f, 0.f);
+	c2 fdc_p1 = { 0.f, 0.f }, fdc_p2 = { 0.f, 0.f };
 
 	const int tile_first = span * p.tiles_per_span - 1; // warm-up tile
 	int tile_last = tile_first + p.tiles_per_span;
@@ -520,17 +544,17 @@ __global__ __launch_bounds__(64) void k1_dpp(K1Params p) {
 	prefetch(tile_first);
 
 	for (int tile = tile_first; tile <= tile_last; tile++) {
-		float2 x[C0];
+		c2 x[C0];
 		if constexpr (CU8) { // Utilities/Convert.cpp:255-264: ((int)u - 128) / 128.0f (exact)
 			const unsigned* w = reinterpret_cast<const unsigned*>(pre);
 #pragma unroll
 			for (int i = 0; i < C0; i++) {
 				const unsigned v = w[i >> 1] >> ((i & 1) * 16);
-				x[i] = make_float2((float)((int)(v & 255u) - 128) * 0.0078125f, (float)((int)((v >> 8) & 255u) - 128) * 0.0078125f);
+				x[i] = c2{ (float)((int)(v & 255u) - 128) * 0.0078125f, (float)((int)((v >> 8) & 255u) - 128) * 0.0078125f };
 			}
 		} else if constexpr (C0 < 4) {
-			x[0] = make_float2(__uint_as_float(pre[0].x), __uint_as_float(pre[0].y));
-			x[1] = make_float2(__uint_as_float(pre[0].z), __uint_as_float(pre[0].w));
+			x[0] = c2{ __uint_as_float(pre[0].x), __uint_as_float(pre[0].y) };
+			x[1] = c2{ __uint_as_float(pre[0].z), __uint_as_float(pre[0].w) };
 		} else {
 			__syncthreads(); // single wave: orders the previous tile's reads against these writes
 #pragma unroll
@@ -540,26 +564,26 @@ __global__ __launch_bounds__(64) void k1_dpp(K1Params p) {
 			}
 			__syncthreads();
 #pragma unroll
-			for (int e = 0; e < C0 / 2; e++) {
-				const float4 v = lds4(xt + lane * W4 + e);
-				x[2 * e] = lo(v); x[2 * e + 1] = hi(v);
+			for (int e = 0; e < C0 / 2; e++) { // every component is used, so these stay 128-bit loads
+				const float4 v = xt[lane * W4 + e];
+				x[2 * e] = c2{ v.x, v.y }; x[2 * e + 1] = c2{ v.z, v.w };
 			}
 		}
 		float2 rotv = make_float2(1.0f, 0.0f);
 		if (!PRE) rotv = p.rot[(size_t)ROT_HIST + (long long)tile * 64 + lane];
 		prefetch(tile + 1 <= tile_last ? tile + 1 : tile_last);
 
-		const float2 x96 = run_ladder<K>(x, st);
+		const c2 x96 = run_ladder<K>(x, st);
 		if constexpr (PRE) {
-			if (tile > tile_first) p.pre_out[(size_t)rx * p.pre_stride + (size_t)tile * 64 + lane] = x96;
+			if (tile > tile_first) p.pre_out[(size_t)rx * p.pre_stride + (size_t)tile * 64 + lane] = make_float2(x96.x, x96.y);
 		} else {
 			// ---- FDC (DSP.cpp:283-293) + Rotate (DSP.cpp:296-316)
-			const float2 xm1 = from_prev_lane(x96, fdc_p1);
-			const float2 xm2 = from_prev_lane(xm1, fdc_p2);
-			float2 y = x96;
-			if (p.has_fdc) {
-				const float2 s2 = cadd(xm2, x96);
-				y = make_float2(p.alpha * s2.x + xm1.x * p.beta, p.alpha * s2.y + xm1.y * p.beta);
+			const c2 xm1 = from_prev_lane(x96, fdc_p1);
+			const c2 xm2 = from_prev_lane(xm1, fdc_p2);
+			c2 y = x96;
+			if (p.has_fdc) { // alpha * (h1 + x) + h2 * beta: add, mul, mul, add (componentwise)
+				const c2 s2 = xm2 + x96;
+				y = s2 * p.alpha + xm1 * p.beta;
 			}
 			const float RR = y.x * rotv.x, II = y.y * rotv.y, RI = y.x * rotv.y, IR = y.y * rotv.x;
 			__syncthreads(); // previous tile's x5/x6 reads are complete
