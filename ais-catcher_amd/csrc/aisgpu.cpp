@@ -73,12 +73,14 @@ struct aisgpu {
 	//   s3: K2b                                         (sequential CGF phasor recurrence, 8 waves, latency bound)
 	//   s1 (= s2): K2c -> K3 -> K4 (+ D2H of the outputs) (apply phasors, FIR/ScatterPLL, PhaseSearchEMA)
 	// Buffers that cross a stream boundary are ring buffered by downstream-block index.
-	hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, s3 = nullptr;
+	hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, s3 = nullptr, s4 = nullptr;
 	hipEvent_t ev_phasor[NBUF] = {};  // s3: phasor(f) done -> s1 may apply it
+	hipEvent_t ev_search[NBUF] = {};  // s4: fz(f) known -> s3 may run the phasor recurrence
 	bool serial = false;
 	hipEvent_t ev_front[NBUF] = {};   // s0: K2a(f) done -> s3 may start K2b(f)
 	hipEvent_t ev_c48free[NBUF] = {}; // s1: K2c(f) done (c48/fz/rotT[q] consumed) -> s0 may run the front end of f+NBUF
 	hipEvent_t ev_ema[2] = {};        // s2: K4(f) done (sym/lvl[p] consumed)
+	hipEvent_t ev_k3[2] = {};         // front stream: sym/lvl[p] of block f written -> s2 may run K4(f)
 	// device buffers
 	void* d_in = nullptr; void* d_hist = nullptr; void* d_hist2 = nullptr;
 	float2* d_xpre[2] = {};           // pre-decimated stream: [R][xh + n_pre], ping-pong by input block (MODE_PRE uses [0] only)
@@ -89,6 +91,7 @@ struct aisgpu {
 	float2 *d_cgf = nullptr, *d_omega = nullptr, *d_step = nullptr, *d_rotstate = nullptr, *d_firtap = nullptr;
 	float *d_ppmtab = nullptr, *d_ppm[NBUF] = {}, *d_lvl[2] = {};
 	int* d_fz[NBUF] = {};
+	float* d_magT[NBUF] = {}; // shifted FFT magnitudes (written by the FFT on the front stream, read by the searches on s3)
 	uint32_t* d_bits[2] = {};
 	bool challenger = false;
 	float* d_fm = nullptr; uint32_t* d_fmbits[2] = {}; uint32_t* h_fmbits = nullptr; // ModelChallenger FM branch
@@ -116,6 +119,8 @@ struct aisgpu {
 	const void* cur_in = nullptr; long long cur_in_stride = 0;
 	bool submitted = false, have_out = false;
 	SubOut sub[MAXSUB]; int n_sub = 0;
+	struct { bool valid = false; int q = 0, pb = 0; long long g0 = 0, g1 = 0, first48 = 0; } pend; // deferred second half
+	bool defer = true;
 	// per-kernel geometry
 	int tile_in = 0, tiles_per_block = 0, tiles_per_span = 0, spans = 0;         // fused front end (its own input)
 	int ptile_in = 0, ptiles_per_block = 0, ptiles_per_span = 0, pspans = 0;     // pre-decimation pass
@@ -185,66 +190,99 @@ int span_tiles(int tiles_per_block, int n_rx, int threads, int tile96, int reque
 	return tps;
 }
 
-// everything behind the 48 kHz front-end output of one downstream block, ring slot q, parity pb
-int enqueue_downstream(aisgpu_t* h, int q, int pb) {
+K2Params make_k2(aisgpu_t* h, int q) {
 	K2Params k2;
 	k2.c48 = h->d_c48[q]; k2.c48_stride = h->L; k2.cgf = h->d_cgf; k2.cgf_stride = CGF_HIST + h->L;
-	k2.omega = h->d_omega; k2.step_table = h->d_step; k2.ppm_table = h->d_ppmtab; k2.fz = h->d_fz[q]; k2.ppm = h->d_ppm[q];
+	k2.omega = h->d_omega; k2.step_table = h->d_step; k2.ppm_table = h->d_ppmtab; k2.magT = h->d_magT[q]; k2.fz = h->d_fz[q]; k2.ppm = h->d_ppm[q];
 	k2.rot_state = h->d_rotstate; k2.n_windows = h->W; k2.wide = h->cfg.afc_wide ? 1 : 0;
 	k2.rotT = h->d_rotT[q]; k2.rotT_stride = (h->n_chan + 63) / 64 * 64; k2.n_chan = h->n_chan;
-	HIPCHK(launch_k2a(k2, h->n_chan, h->stream));
-	HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
+	return k2;
+}
 
-	// ---- s3: sequential CGF phasor recurrence (needs fz of this block; rotT[q] was last read by apply(f-NBUF))
-	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_front[q], 0));
-	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_c48free[q], 0));
-	HIPCHK(launch_k2b(k2, h->n_chan, h->s3));
-	HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
-	// ---- s1: apply the phasors, then FIR-17 + ScatterPLL
-	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_phasor[q], 0));
-	HIPCHK(launch_k2c(k2, h->n_chan, h->s1));
-	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s1));
-	// ScatterPLL groups completed inside this block (DSP/DSP.h:95-117): group g completes with sample 5g+4
-	const long long g0 = h->n48 / 5, g1 = (h->n48 + h->L) / 5;
+// Second half of a downstream block (deferred, see enqueue_downstream): apply the phasors, FIR-17 + ScatterPLL
+// (+ the Challenger FM branch) on the front stream, PhaseSearchEMA on s1.
+int enqueue_back(aisgpu_t* h) {
+	if (!h->pend.valid) return AISGPU_OK;
+	h->pend.valid = false;
+	const int q = h->pend.q, pb = h->pend.pb;
+	const long long g0 = h->pend.g0, g1 = h->pend.g1;
+	const K2Params k2 = make_k2(h, q);
+	HIPCHK(hipStreamWaitEvent(h->stream, h->ev_phasor[q], 0));
+	HIPCHK(launch_k2c(k2, h->n_chan, h->stream));
+	HIPCHK(hipEventRecord(h->ev_c48free[q], h->stream));
 	K3Params k3;
 	k3.cgf = h->d_cgf; k3.cgf_stride = CGF_HIST + h->L; k3.sym = h->d_sym[pb]; k3.sym_stride = h->Gcap; k3.lvl = h->d_lvl[pb];
 	k3.fir_tap = h->d_firtap; k3.fir_tap_stride = 8 + h->L;
 	memcpy(k3.taps, TAPS_COHERENT, sizeof k3.taps);
-	k3.first_group = g0; k3.first_sample48 = h->n48; k3.n_groups = (int)(g1 - g0);
-	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_ema[pb], 0)); // sym/lvl[pb] were last read by K4 of block f-2
-	HIPCHK(launch_k3(k3, h->n_chan, h->s1));
+	k3.first_group = g0; k3.first_sample48 = h->pend.first48; k3.n_groups = (int)(g1 - g0);
+	HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ema[pb], 0)); // sym/lvl[pb] were last read by K4 of block f-2
+	HIPCHK(launch_k3(k3, h->n_chan, h->stream));
 	if (h->challenger) { // FM branch on the same derotated samples (Model.cpp:638-639)
 		K5Params k5;
 		k5.cgf = h->d_cgf; k5.cgf_stride = CGF_HIST + h->L; k5.fm = h->d_fm; k5.fm_stride = FM_HIST + h->L;
 		k5.fmbits = h->d_fmbits[pb]; k5.fmbits_stride = h->L / 32; k5.L = h->L;
 		memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
-		HIPCHK(launch_k5(k5, h->n_chan, h->s1));
+		HIPCHK(launch_k5(k5, h->n_chan, h->stream));
 	}
+	HIPCHK(hipEventRecord(h->ev_k3[pb], h->stream));
 
-	// ---- PhaseSearchEMA chains (same stream)
+	// ---- PhaseSearchEMA chains on s1: VALU-bound, overlaps the HBM-bound front end of the next block
 	K4Params k4;
 	k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[pb]; k4.bits_stride = h->words;
 	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
 	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag;
 	k4.n_chains = h->n_chains; k4.n_groups = (int)(g1 - g0);
 	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
+	HIPCHK(hipStreamWaitEvent(h->s2, h->ev_k3[pb], 0));
 	if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, h->s2));
 	else HIPCHK(launch_k4_sequential(k4, h->s2));
 	HIPCHK(hipEventRecord(h->ev_ema[pb], h->s2));
+	return AISGPU_OK;
+}
 
+// Everything behind the 48 kHz front-end output of one downstream block, ring slot q, parity pb.
+//
+// Stream plan.  The HBM-bound kernels (front end, FFT, phasor apply, FIR/ScatterPLL) run one after the other on
+// the front stream: run side by side they only take bandwidth from each other.  What overlaps them are the
+// kernels that want something else: PhaseSearchEMA (VALU-bound, s1), the spectral searches (latency-bound, s4)
+// and the phasor recurrence (latency-bound, s3, on CUs of its own).  The recurrence of block f is hidden behind
+// the next block's front end by DEFERRING the second half of block f (apply ... PhaseSearchEMA) until the first
+// half of block f+1 has been enqueued -- or until the caller asks for results (sync_all / aisgpu_sync_outputs).
+int enqueue_downstream(aisgpu_t* h, int q, int pb) {
+	const K2Params k2 = make_k2(h, q);
+	HIPCHK(launch_k2a_fft(k2, h->n_chan, h->stream));
+	HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
+	// ---- s4: the sequential spectral searches, then on s3 the sequential CGF phasor recurrence (needs fz of this
+	// block; rotT[q] was last read by apply(f-NBUF))
+	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_front[q], 0));
+	HIPCHK(launch_k2a_search(k2, h->n_chan, h->s4));
+	HIPCHK(hipEventRecord(h->ev_search[q], h->s4));
+	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_search[q], 0));
+	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_c48free[q], 0));
+	HIPCHK(launch_k2b(k2, h->n_chan, h->s3));
+	HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
+
+	int rc = enqueue_back(h); // the previous block's second half
+	if (rc) return rc;
+	// ScatterPLL groups completed inside this block (DSP/DSP.h:95-117): group g completes with sample 5g+4
+	const long long g0 = h->n48 / 5, g1 = (h->n48 + h->L) / 5;
+	h->pend.valid = true; h->pend.q = q; h->pend.pb = pb; h->pend.g0 = g0; h->pend.g1 = g1; h->pend.first48 = h->n48;
 	if (h->n_sub < MAXSUB) {
 		SubOut& s = h->sub[h->n_sub++];
 		s.pb = pb; s.q = q; s.groups = (int)(g1 - g0); s.first_group = g0; s.first48 = h->n48;
 	}
 	h->n48 += h->L;
 	h->block_idx++;
+	if (h->serial || !h->defer) return enqueue_back(h);
 	return AISGPU_OK;
 }
 
 int sync_all(aisgpu_t* h) {
+	{ int rc = enqueue_back(h); if (rc) return rc; }
 	HIPCHK(hipStreamSynchronize(h->stream));
 	HIPCHK(hipStreamSynchronize(h->s1));
 	HIPCHK(hipStreamSynchronize(h->s3));
+	HIPCHK(hipStreamSynchronize(h->s4));
 	drain_events(h);
 	return AISGPU_OK;
 }
@@ -270,6 +308,22 @@ int aisgpu_device_count(void) {
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
 	return n;
+}
+
+long long aisgpu_selftest(int device_id, int which, const void* in, long long n) {
+	if (which != 0 || !in || n <= 0 || n > (1ll << 30)) return -AISGPU_ERR_ARG;
+	if (hipSetDevice(device_id) != hipSuccess) return -AISGPU_ERR_NODEV;
+	float2* d_in = nullptr;
+	unsigned* d_cnt = nullptr;
+	unsigned cnt = 0;
+	hipError_t e = hipMalloc((void**)&d_in, (size_t)n * sizeof(float2));
+	if (e == hipSuccess) e = hipMalloc((void**)&d_cnt, sizeof(unsigned));
+	if (e == hipSuccess) e = hipMemcpy(d_in, in, (size_t)n * sizeof(float2), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemset(d_cnt, 0, sizeof(unsigned));
+	if (e == hipSuccess) e = launch_selftest_hypot(d_in, (int)n, d_cnt, 0);
+	if (e == hipSuccess) e = hipMemcpy(&cnt, d_cnt, sizeof(unsigned), hipMemcpyDeviceToHost);
+	hipFree(d_in); hipFree(d_cnt);
+	return e == hipSuccess ? (long long)cnt : -AISGPU_ERR_HIP;
 }
 
 void aisgpu_default_cfg(aisgpu_cfg* c) {
@@ -356,23 +410,47 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	*out = h; // from here on the caller destroys it on failure
 
 	HIPCHK(hipSetDevice(cfg->device_id));
-	HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 	if ((cfg->flags & AISGPU_FLAG_SERIAL) || getenv("AISGPU_SERIAL")) { // profiling aid: no cross-block overlap, every kernel runs alone
-		h->s1 = h->s2 = h->s3 = h->stream;
+		HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+		h->s1 = h->s2 = h->s3 = h->s4 = h->stream;
 		h->serial = true;
 	} else {
 		// HIP maps streams onto a small number of hardware queues (4 by default, one is the application's
 		// null stream): two of our streams sharing a queue would serialise.  So: three streams.
-		HIPCHK(hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking));
-		HIPCHK(hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking));
+		//
+		// The CGF phasor recurrence (s3) is a handful of latency-bound waves and the longest dependency chain of the
+		// pipeline; sharing a SIMD with throughput kernels more than doubles its run time (every foreign VALU
+		// instruction delays its next dependent one).  It therefore gets CUs of its own: CU-mask bits 0..7 are one
+		// CU in each of the 8 XCDs (tools/microbench_cumask.hip), 3% of the chip; the other streams use the rest.
+		int n_cu = 0;
+		HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device_id));
+		const char* e = getenv("AISGPU_CUMASK");
+		const int reserve = e ? atoi(e) : 8;
+		if (reserve > 0 && reserve < n_cu && n_cu >= 64) {
+			const int words = (n_cu + 31) / 32;
+			std::vector<uint32_t> lat(words, 0u), rest(words, 0u);
+			for (int i = 0; i < n_cu; i++) (i < reserve ? lat : rest)[i / 32] |= 1u << (i % 32);
+			HIPCHK(hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)words, rest.data()));
+			HIPCHK(hipExtStreamCreateWithCUMask(&h->s1, (uint32_t)words, rest.data()));
+			HIPCHK(hipExtStreamCreateWithCUMask(&h->s3, (uint32_t)words, lat.data()));
+			HIPCHK(hipExtStreamCreateWithCUMask(&h->s4, (uint32_t)words, rest.data()));
+		} else {
+			HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+			HIPCHK(hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking));
+			HIPCHK(hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking));
+			HIPCHK(hipStreamCreateWithFlags(&h->s4, hipStreamNonBlocking));
+		}
 		h->s2 = h->s1; // apply + FIR + PhaseSearchEMA of a block run back to back on one stream
 	}
 	for (int i = 0; i < NBUF; i++) {
 		HIPCHK(hipEventCreateWithFlags(&h->ev_front[i], hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&h->ev_phasor[i], hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&h->ev_search[i], hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&h->ev_c48free[i], hipEventDisableTiming));
 	}
 	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_ema[i], hipEventDisableTiming));
+	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_k3[i], hipEventDisableTiming));
+	if (const char* e = getenv("AISGPU_DEFER")) h->defer = atoi(e) != 0;
 
 	// ---- constant tables (host libm, like the reference on this machine)
 	{
@@ -425,6 +503,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		}
 	}
 	for (int i = 0; i < NBUF; i++) {
+		HIPCHK(dalloc(&h->d_magT[i], (C * h->W + 63) / 64 * (size_t)(512 * 64)));
 		HIPCHK(dalloc(&h->d_c48[i], C * h->L));
 		HIPCHK(dalloc(&h->d_fz[i], C * h->W));
 		HIPCHK(dalloc(&h->d_ppm[i], C * h->W));
@@ -465,18 +544,22 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 
 void aisgpu_destroy(aisgpu_t* h) {
 	if (!h) return;
+	h->pend.valid = false;
 	if (h->stream) hipStreamSynchronize(h->stream);
 	if (h->s1) hipStreamSynchronize(h->s1);
 	if (h->s3) hipStreamSynchronize(h->s3);
+	if (h->s4) hipStreamSynchronize(h->s4);
 	drain_events(h);
 	for (int i = 0; i < NBUF; i++) {
 		if (h->ev_front[i]) hipEventDestroy(h->ev_front[i]);
 		if (h->ev_phasor[i]) hipEventDestroy(h->ev_phasor[i]);
+		if (h->ev_search[i]) hipEventDestroy(h->ev_search[i]);
 		if (h->ev_c48free[i]) hipEventDestroy(h->ev_c48free[i]);
 		hipFree(h->d_rotT[i]); hipFree(h->d_c48[i]); hipFree(h->d_fz[i]); hipFree(h->d_ppm[i]);
 	}
 	for (int i = 0; i < 2; i++) {
 		if (h->ev_ema[i]) hipEventDestroy(h->ev_ema[i]);
+		if (h->ev_k3[i]) hipEventDestroy(h->ev_k3[i]);
 		hipFree(h->d_sym[i]); hipFree(h->d_lvl[i]); hipFree(h->d_bits[i]); hipFree(h->d_ema[i]);
 		hipFree(h->d_rot[i]); if (h->h_rot[i]) hipHostFree(h->h_rot[i]); if (h->rot_ev[i]) hipEventDestroy(h->rot_ev[i]);
 		hipFree(h->d_usidx[i]); hipFree(h->d_usalpha[i]); hipFree(h->d_xpre[i]);
@@ -487,6 +570,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_in); hipFree(h->d_hist); hipFree(h->d_hist2);
 	hipFree(h->d_fm); hipFree(h->d_fmbits[0]); hipFree(h->d_fmbits[1]);
 	if (h->h_fmbits) hipHostFree(h->h_fmbits);
+	for (int i = 0; i < NBUF; i++) hipFree(h->d_magT[i]);
 	hipFree(h->d_cgf); hipFree(h->d_omega); hipFree(h->d_step);
 	hipFree(h->d_rotstate); hipFree(h->d_firtap); hipFree(h->d_ppmtab);
 	hipFree(h->d_pswords); hipFree(h->d_psma0); hipFree(h->d_psma1); hipFree(h->d_psfin); hipFree(h->d_psflag);
@@ -497,6 +581,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	if (h->stream) hipStreamDestroy(h->stream);
 	if (h->s1 && !h->serial) hipStreamDestroy(h->s1);
 	if (h->s3 && !h->serial) hipStreamDestroy(h->s3);
+	if (h->s4 && !h->serial) hipStreamDestroy(h->s4);
 	delete h;
 }
 
@@ -660,6 +745,7 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 	if (!h) return AISGPU_ERR_ARG;
 	if (h->in_blocks == 0) return AISGPU_ERR_STATE;
 	const size_t C = h->n_chan;
+	{ int rc = enqueue_back(h); if (rc) return rc; }
 	for (int s = 0; s < h->n_sub; s++) {
 		const SubOut& so = h->sub[s];
 		// s2 is ordered after K4 of that block, which is ordered after everything that produced lvl/ppm

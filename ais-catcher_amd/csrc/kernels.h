@@ -40,6 +40,7 @@ struct K2Params {
 	const float2* omega;      // [512] FFT twiddles
 	const float2* step_table; // [FZ_COUNT] rot_step per fz
 	const float* ppm_table;   // [FZ_COUNT]
+	float* magT;              // [ceil(n_chan * n_windows / 64)][512][64] shifted FFT magnitudes, window-minor
 	int* fz;                  // [n_chan][n_windows]
 	float* ppm;               // [n_chan][n_windows]
 	float2* rot_state;        // [n_chan]
@@ -81,7 +82,9 @@ hipError_t launch_k1u(const K1uParams& p, int n_rx, hipStream_t s);
 hipError_t launch_copy_rows(const float2* src, long long src_stride, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
 hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long block_bytes, void* hist, int tail_bytes,
                           int n_rx, hipStream_t s);
-hipError_t launch_k2a(const K2Params& p, int n_chan, hipStream_t s);
+hipError_t launch_k2a_fft(const K2Params& p, int n_chan, hipStream_t s);
+hipError_t launch_k2a_search(const K2Params& p, int n_chan, hipStream_t s);
+hipError_t launch_selftest_hypot(const float2* in, int n, unsigned* mismatches, hipStream_t s);
 hipError_t launch_k2b(const K2Params& p, int n_chan, hipStream_t s); // phasor recurrence
 hipError_t launch_k2c(const K2Params& p, int n_chan, hipStream_t s); // history carry + apply
 hipError_t launch_k3(const K3Params& p, int n_chan, hipStream_t s);

@@ -15,6 +15,8 @@ namespace aisk {
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
+typedef float c2 __attribute__((ext_vector_type(2))); // complex sample as a native 2-vector (one VGPR pair)
+
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 // std::complex<float> product as the strict-FP reference evaluates it: (ac-bd, ad+bc), 4 mul + 2 add
@@ -399,7 +401,6 @@ __global__ __launch_bounds__(NT) void k1_frontend(K1Params p) {
 // ------------------------------------------------------------------------------------------
 // complex samples as native 2-vectors: an add is one v_pk_add_f32 on an aligned register pair and (re, im) stay
 // together (with the float2 struct the SLP vectoriser re-pairs components of different samples and pays for it in moves)
-typedef float c2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float dpp_wave_shr1(float old_lane0, float src) { // lane l <- src[l-1]; lane 0 keeps old_lane0
 	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old_lane0), __float_as_int(src), 0x138, 0xF, 0xF, false));
@@ -738,105 +739,185 @@ __device__ __forceinline__ void wave_argmax_first(float& v, int& i) {
 	}
 }
 
-// One wave handles NW consecutive windows of one channel: the FFTs run one after the other on all 64 lanes
-// (twiddles stay in registers), then the order-sensitive part -- the float prefix sum and the first search,
-// which the reference evaluates strictly left to right -- runs for the NW windows at once, one LANE per window,
-// so its ~4,000 dependent instructions are paid once per NW windows instead of once per window.
-template <int NW>
-__global__ __launch_bounds__(64) void k2_cgf_analyse(K2Params p) {
-	constexpr int MS = 516; // row stride of mag (floats): 512 + wrap slot, stride 4 (mod 32) banks between windows
-	__shared__ __attribute__((aligned(16))) float2 X[512];
-	__shared__ __attribute__((aligned(16))) float mag[NW * MS]; // mag[w][q] = |X_w[(q + 256) % 512]|, q in [0, 512]
+// K2a is two kernels.
+//
+// k2_fft_mag: one wave per FFT_NW consecutive windows.  The reference's radix-2 DIT butterflies (FFT.h:104-129:
+// t = Omega[j * (N >> (s+1))] * x[hi]; x[hi] = x[lo] - t; x[lo] += t) are evaluated unchanged, but three stages
+// at a time in registers: a lane owns the 8 points whose indices differ in bits {0,1,2}, then {3,4,5}, then
+// {6,7,8}; between the three passes the points change lanes through a padded (conflict-free) LDS buffer.  The
+// 14 lane-dependent twiddles stay in registers for all windows of the wave.  |X| goes through the
+// glibc-equivalent hypot, is staged in LDS for the wave's windows and leaves transposed: magT[W / 64][q][W % 64]
+// with q = (bin + 256) % 512, so that the search kernel's lanes (one per window) read consecutive floats.
+//
+// k2_cgf_search: the order-sensitive part -- the float prefix sum and the two first-maximum searches, which the
+// reference evaluates strictly left to right -- one LANE per window, 64 windows per wave, branch-free.
+constexpr int FFT_NW = 8;
+constexpr int MAG_STRIDE = 520; // floats; 8 (mod 64) banks between the windows of a wave
+
+// twiddle o with its rotated copy (-o.y, o.x): o * c = c.xx * o + c.yy * (-o.y, o.x) = (o.x c.x - o.y c.y, o.x c.y + o.y c.x),
+// the same two products and one addition per component as std::complex's operator* (x - y == x + (-y) exactly)
+struct Tw { c2 o, r; };
+__device__ __forceinline__ c2 cmul_tw(const Tw& w, c2 c) { return c.xx * w.o + c.yy * w.r; }
+
+// three radix-2 stages on the 8 points of a lane; tw0: twiddle of the first stage (all 4 butterflies), tw1[b]:
+// second stage for local index bit 0 = b, tw2[c]: third stage for local index bits (1,0) = c
+__device__ __forceinline__ void fft_pass(c2 (&v)[8], const Tw& tw0, const Tw (&tw1)[2], const Tw (&tw2)[4]) {
+#pragma unroll
+	for (int r = 0; r < 8; r += 2) {
+		const c2 t = cmul_tw(tw0, v[r + 1]);
+		v[r + 1] = v[r] - t;
+		v[r] = v[r] + t;
+	}
+#pragma unroll
+	for (int r = 0; r < 8; r++) {
+		if (r & 2) continue;
+		const c2 t = cmul_tw(tw1[r & 1], v[r + 2]);
+		v[r + 2] = v[r] - t;
+		v[r] = v[r] + t;
+	}
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const c2 t = cmul_tw(tw2[r], v[r + 4]);
+		v[r + 4] = v[r] - t;
+		v[r] = v[r] + t;
+	}
+}
+
+// hypot_ref for the FFT bins: the same correctly rounded double sqrt (rsq seed + the Goldschmidt/Newton fma chain the
+// compiler emits for sqrt(double)), minus its denormal-range rescaling, which x*x + y*y of two floats can never need:
+// a non-zero sum is >= 2^-298.  A zero sum is lifted to 2^-600, whose root still converts to 0.0f.
+__device__ __forceinline__ float hypot_bins(float x, float y) {
+	const double dx = (double)x, dy = (double)y;
+	double s = __builtin_fma(dy, dy, dx * dx); // dx * dx is exact, so this is the one rounding of dx*dx + dy*dy
+	s = __builtin_fmax(s, 0x1p-600);
+	const double y0 = __builtin_amdgcn_rsq(s);
+	const double g0 = s * y0, h0 = y0 * 0.5;
+	const double r0 = __builtin_fma(-h0, g0, 0.5);
+	const double g1 = __builtin_fma(g0, r0, g0), h1 = __builtin_fma(h0, r0, h0);
+	const double d0 = __builtin_fma(-g1, g1, s);
+	const double g2 = __builtin_fma(d0, h1, g1);
+	const double d1 = __builtin_fma(-g2, g2, s);
+	return (float)__builtin_fma(d1, h1, g2);
+}
+
+// debug/self-test: count inputs on which hypot_bins differs from hypot_ref (tests only)
+__global__ void k_selftest_hypot(const float2* in, int n, unsigned* mismatches) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float a = hypot_ref(in[i].x, in[i].y), b = hypot_bins(in[i].x, in[i].y);
+	if (__float_as_uint(a) != __float_as_uint(b)) atomicAdd(mismatches, 1u);
+}
+
+__global__ __launch_bounds__(64) void k2_fft_mag(K2Params p) {
+	__shared__ __attribute__((aligned(16))) float2 X[584];
+	__shared__ __attribute__((aligned(16))) float mag[FFT_NW * MAG_STRIDE];
 
 	__builtin_amdgcn_s_setprio(1);
+	const int lane = threadIdx.x, l7 = lane & 7, l8 = lane >> 3;
+	const int W0 = blockIdx.x * FFT_NW, n_win_total = p.n_chan * p.n_windows;
+	const auto tw = [&](int idx) { const float2 o = p.omega[idx]; return Tw{ c2{ o.x, o.y }, c2{ -o.y, o.x } }; };
+
+	// pass 1 twiddles are the same for every lane (scalar loads); passes 2 and 3 depend on the lane
+	const Tw a0 = tw(0), a1[2] = { tw(0), tw(128) }, a2[4] = { tw(0), tw(64), tw(128), tw(192) };
+	const Tw b0 = tw(l7 << 5), b1[2] = { tw(l7 << 4), tw((l7 + 8) << 4) };
+	const Tw b2[4] = { tw(l7 << 3), tw((l7 + 8) << 3), tw((l7 + 16) << 3), tw((l7 + 24) << 3) };
+	const Tw c0 = tw(lane << 2), c1[2] = { tw(lane << 1), tw((lane + 64) << 1) };
+	const Tw c2_[4] = { tw(lane), tw(lane + 64), tw(lane + 128), tw(lane + 192) };
+	const int src = (int)(__brev((unsigned)lane) >> 26); // bit-reversed storage (DSP.cpp:480): position 8*lane + r <- sample brev6(lane) + 64*brev3(r)
+
+	for (int wi = 0; wi < FFT_NW; wi++) {
+		const int W = W0 + wi;
+		if (W >= n_win_total) break;
+		const int chan = W / p.n_windows, w = W - chan * p.n_windows;
+		const float2* x = p.c48 + (size_t)chan * p.c48_stride + (size_t)w * 512 + src;
+		c2 v[8];
+#pragma unroll
+		for (int r = 0; r < 8; r++) {
+			const float2 d = x[64 * (((r & 1) << 2) | (r & 2) | (r >> 2))];
+			v[r] = c2{ d.x * d.x - d.y * d.y, d.x * d.y + d.y * d.x }; // data[i] * data[i]
+		}
+		fft_pass(v, a0, a1, a2); // stages 0-2: position 8*lane + r
+#pragma unroll
+		for (int r = 0; r < 8; r++) X[9 * lane + r] = make_float2(v[r].x, v[r].y); // index P + (P >> 3)
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < 8; r++) { const float2 d = X[l7 + 9 * r + 72 * l8]; v[r] = c2{ d.x, d.y }; }
+		__syncthreads();
+		fft_pass(v, b0, b1, b2); // stages 3-5: position l7 + 8*r + 64*l8
+#pragma unroll
+		for (int r = 0; r < 8; r++) X[l7 + 8 * r + 72 * l8] = make_float2(v[r].x, v[r].y); // index P + 8 * (P >> 6)
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < 8; r++) { const float2 d = X[lane + 72 * r]; v[r] = c2{ d.x, d.y }; }
+		__syncthreads();
+		fft_pass(v, c0, c1, c2_); // stages 6-8: bin lane + 64*r
+		float* mg = mag + wi * MAG_STRIDE;
+#pragma unroll
+		for (int r = 0; r < 8; r++) mg[(lane + 64 * r + 256) & 511] = hypot_bins(v[r].x, v[r].y);
+	}
+	__syncthreads();
+	// transposed store: 8 bins x 8 windows per instruction, 32 contiguous bytes per bin
+	const int W = W0 + l7;
+	if (W < n_win_total) {
+		float* dst = p.magT + (size_t)(W >> 6) * (512 * 64) + (W & 63);
+		const float* mg = mag + l7 * MAG_STRIDE;
+#pragma unroll 8
+		for (int it = 0; it < 64; it++) {
+			const int q = it * 8 + l8;
+			dst[(size_t)q * 64] = mg[q];
+		}
+	}
+}
+
+__global__ __launch_bounds__(64) void k2_cgf_search(K2Params p) {
 	const int lane = threadIdx.x;
-	const int w0 = blockIdx.x * NW, chan = blockIdx.y; // chan = rx * 2 + ch
-
-	// twiddles of the 4 butterflies this lane does in each of the 9 stages (FFT.h:104-129: Omega[j * (N >> (s+1))])
-	float2 tw[9][4];
-#pragma unroll
-	for (int s = 0; s < 9; s++) {
-#pragma unroll
-		for (int q = 0; q < 4; q++) {
-			const int bfly = lane + 64 * q;
-			tw[s][q] = p.omega[(bfly & ((1 << s) - 1)) << (8 - s)];
-		}
-	}
-
-	for (int wi_ = 0; wi_ < NW; wi_++) {
-		const float2* x = p.c48 + (size_t)chan * p.c48_stride + (size_t)(w0 + wi_) * 512;
-#pragma unroll
-		for (int q = 0; q < 8; q++) {
-			const int n = lane + 64 * q;
-			const float2 v = x[n];
-			// data[i] * data[i]: (a*a - b*b, a*b + b*a), stored bit-reversed (DSP.cpp:480)
-			X[__brev((unsigned)n) >> 23] = make_float2(v.x * v.x - v.y * v.y, v.x * v.y + v.y * v.x);
-		}
-		__syncthreads();
-#pragma unroll
-		for (int s = 0; s < 9; s++) {
-			const int m2 = 1 << s;
-#pragma unroll
-			for (int q = 0; q < 4; q++) {
-				const int bfly = lane + 64 * q;
-				const int j = bfly & (m2 - 1);
-				const int i0 = ((bfly >> s) << (s + 1)) + j, i1 = i0 + m2;
-				const float2 a = X[i0], c = X[i1];
-				const float2 tt = cmul(tw[s][q], c);
-				X[i1] = csub(a, tt);
-				X[i0] = cadd(a, tt);
-			}
-			__syncthreads();
-		}
-		float* mg = mag + wi_ * MS;
-#pragma unroll
-		for (int q = 0; q < 8; q++) {
-			const int k = lane + 64 * q;
-			const float2 v = X[k];
-			const float m = hypot_ref(v.x, v.y);
-			mg[(k + 256) & 511] = m;
-			if (k == 256) mg[512] = m; // wrap slot: shifted index 512 == 0
-		}
-		__syncthreads();
-	}
-
-	// ---- wide search (DSP.cpp:426-447), one lane per window, strictly sequential like the reference:
+	const int W = blockIdx.x * 64 + lane, n_win_total = p.n_chan * p.n_windows;
+	const float* mrow = p.magT + (size_t)blockIdx.x * (512 * 64); // wave-uniform: mrow[64 * q + lane] = |X[(q + 256) % 512]| of this lane's window
+#define MG(q) mrow[64 * (q) + lane]
+	__builtin_amdgcn_s_setprio(2);
+	// ---- wide search (DSP.cpp:426-447), strictly sequential like the reference:
 	// cumsum[i] = cumsum[i-1] + mag[i];  v(i) = cumsum[i+M] - cumsum[i] + 0.6f * (mag[i+ofs] + mag[i+ofs+delta]);
 	// two running sums 133 apart reproduce cumsum[i+M] and cumsum[i] with the same additions in the same order.
 	int wi = 0;
 	if (p.wide) {
-		const float* mg = mag + (lane < NW ? lane : 0) * MS;
 		float hi = 0.0f; // cumsum[0] = 0
-		for (int i = 1; i <= 133; i++) hi = hi + mg[i];
+#pragma unroll 7
+		for (int i = 1; i <= 133; i++) hi = hi + MG(i);
 		float lo_ = 0.0f, best = -1.0f;
 		int bi = 0;
-		for (int i = 0; i < 512 - 133; i++) {
-			const float v = hi - lo_ + 0.6f * (mg[i + 15] + mg[i + 117]);
-			if (v > best) { best = v; bi = i; }
-			hi = hi + mg[i + 134 < 512 ? i + 134 : 511]; // cumsum[i+1+M] (the value after the last i is never used)
-			lo_ = lo_ + mg[i + 1];                         // cumsum[i+1]
+#pragma unroll 9
+		for (int i = 0; i < 512 - 134; i++) { // 378 = 9 * 42 iterations, then the last candidate without the sum updates
+			const float v = hi - lo_ + 0.6f * (MG(i + 15) + MG(i + 117));
+			const bool gt = v > best;
+			best = gt ? v : best;
+			bi = gt ? i : bi;
+			hi = hi + MG(i + 134); // cumsum[i+1+M]
+			lo_ = lo_ + MG(i + 1); // cumsum[i+1]
+		}
+		{
+			const int i = 512 - 134;
+			const float v = hi - lo_ + 0.6f * (MG(i + 15) + MG(i + 117));
+			bi = v > best ? i : bi;
 		}
 		wi = bi + 66 - 256; // wi + M/2 - N/2
 	}
-	// ---- second search per window with the whole wave (36 candidates): i in [wi+187, wi+223)
-	for (int wi_ = 0; wi_ < NW; wi_++) {
-		const float* mg = mag + wi_ * MS;
-		const int wiw = __shfl(wi, wi_);
-		float h = 0.0f;
-		int hidx = 0x7fffffff;
-		if (lane < 36) {
-			const int i = wiw + 187 + lane;
-			const float v = mg[(i + 512) & 511] + mg[(i + 102 + 512) & 511];
-			if (v > 0.0f) { h = v; hidx = i; }
-		}
-		wave_argmax_first(h, hidx);
-		if (lane == 0) {
-			// fz = N/2 - (i + delta/2) = 205 - i (integer valued); default -1
-			const int fz = (h > 0.0f) ? (205 - hidx) : -1;
-			p.fz[(size_t)chan * p.n_windows + w0 + wi_] = fz;
-			p.ppm[(size_t)chan * p.n_windows + w0 + wi_] = p.ppm_table[fz + 205];
-		}
+	// ---- second search (DSP.cpp:449-456): i in [wi+187, wi+223), first maximum above 0
+	float h = 0.0f;
+	int hidx = 0;
+#pragma unroll 6
+	for (int c = 0; c < 36; c++) {
+		const int i = wi + 187 + c;
+		const float v = MG((i + 512) & 511) + MG((i + 102 + 512) & 511);
+		const bool gt = v > h;
+		h = gt ? v : h;
+		hidx = gt ? i : hidx;
 	}
+	if (W < n_win_total) {
+		const int fz = (h > 0.0f) ? (205 - hidx) : -1; // fz = N/2 - (i + delta/2) = 205 - i (integer valued); default -1
+		p.fz[W] = fz;
+		p.ppm[W] = p.ppm_table[fz + 205];
+	}
+#undef MG
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1463,11 +1544,20 @@ hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long b
 	return hipGetLastError();
 }
 
-hipError_t launch_k2a(const K2Params& p, int n_chan, hipStream_t s) {
-	if (p.n_windows % 8 == 0) hipLaunchKernelGGL(k2_cgf_analyse<8>, dim3(p.n_windows / 8, n_chan), dim3(64), 0, s, p);
-	else if (p.n_windows % 4 == 0) hipLaunchKernelGGL(k2_cgf_analyse<4>, dim3(p.n_windows / 4, n_chan), dim3(64), 0, s, p);
-	else if (p.n_windows % 2 == 0) hipLaunchKernelGGL(k2_cgf_analyse<2>, dim3(p.n_windows / 2, n_chan), dim3(64), 0, s, p);
-	else hipLaunchKernelGGL(k2_cgf_analyse<1>, dim3(p.n_windows, n_chan), dim3(64), 0, s, p);
+hipError_t launch_selftest_hypot(const float2* in, int n, unsigned* mismatches, hipStream_t s) {
+	hipLaunchKernelGGL(k_selftest_hypot, dim3((n + 255) / 256), dim3(256), 0, s, in, n, mismatches);
+	return hipGetLastError();
+}
+
+hipError_t launch_k2a_fft(const K2Params& p, int n_chan, hipStream_t s) {
+	const int n = n_chan * p.n_windows;
+	hipLaunchKernelGGL(k2_fft_mag, dim3((n + FFT_NW - 1) / FFT_NW), dim3(64), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_k2a_search(const K2Params& p, int n_chan, hipStream_t s) {
+	const int n = n_chan * p.n_windows;
+	hipLaunchKernelGGL(k2_cgf_search, dim3((n + 63) / 64), dim3(64), 0, s, p);
 	return hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ EXPORTS = (
     "aisgpu_default_cfg", "aisgpu_create", "aisgpu_destroy", "aisgpu_submit", "aisgpu_submit_device",
     "aisgpu_run", "aisgpu_sync_outputs", "aisgpu_sync", "aisgpu_fetch", "aisgpu_tap", "aisgpu_stream",
     "aisgpu_frontend_ms", "aisgpu_timing", "aisgpu_strerror", "aisgpu_last_error", "aisgpu_device_count",
-    "aisgpu_out_count", "aisgpu_fetch_sub",
+    "aisgpu_out_count", "aisgpu_fetch_sub", "aisgpu_selftest",
 )
 
 
@@ -84,6 +84,9 @@ def load():
     lib.aisgpu_last_error.argtypes = [vp]
     lib.aisgpu_last_error.restype = ctypes.c_char_p
     lib.aisgpu_device_count.restype = ci
+    if hasattr(lib, "aisgpu_selftest"):  # absent from older builds used in A/B runs (AISGPU_LIB)
+        lib.aisgpu_selftest.argtypes = [ci, ci, vp, cll]
+        lib.aisgpu_selftest.restype = cll
     _lib = lib
     return lib
 

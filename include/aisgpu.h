@@ -129,6 +129,11 @@ const char* aisgpu_strerror(int code);
 const char* aisgpu_last_error(aisgpu_t* h);
 int aisgpu_device_count(void);
 
+/* Device self-tests of arithmetic identities the kernels rely on (no reference counterpart; used by tests/).
+ * which = 0: n pairs of floats (x, y) in `in`; returns the number of pairs on which the FFT-bin magnitude routine
+ * differs from the glibc-equivalent hypotf restatement, or a negative AISGPU_ERR_* code. */
+long long aisgpu_selftest(int device_id, int which, const void* in, long long n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -361,3 +361,32 @@ def test_config3_6msps_challenger_nmea():
     a, c = m.msg_meta(), chk.msg_meta()
     assert np.array_equal(a[1], c[1])
     m.close()
+
+
+def test_fft_bin_magnitude_matches_hypot_restatement():
+    """The FFT-bin magnitude routine (double sqrt without the denormal rescaling) against the glibc-equivalent
+    hypotf restatement on 16M inputs: random bit patterns over the exponent range IQ data can reach, IQ-like
+    values, zeros and denormals."""
+    import ctypes
+    lib = gpu.load()
+    rng = np.random.default_rng(99)
+    n = 1 << 22
+    parts = []
+    # uniform random mantissas, exponents -60..+20, both signs
+    e = rng.integers(-60, 21, size=(n, 2))
+    m = rng.random((n, 2), dtype=np.float32) + 1.0
+    sgn = rng.choice(np.float32([-1, 1]), size=(n, 2))
+    parts.append((np.ldexp(m, e).astype(np.float32) * sgn))
+    parts.append(rng.standard_normal((n, 2), dtype=np.float32))
+    parts.append((rng.integers(-128, 128, size=(n, 2)).astype(np.float32) / 128.0) ** 2)
+    sp = rng.standard_normal((n, 2), dtype=np.float32) * np.float32(1e-3)
+    sp[::7, 0] = 0.0
+    sp[::11, 1] = 0.0
+    sp[::13] = 0.0
+    sp[1::13] = np.float32(1e-42)  # denormal
+    sp[2::13, 0] = np.float32(3e-39)
+    parts.append(sp)
+    for x in parts:
+        x = np.ascontiguousarray(x, np.float32)
+        bad = lib.aisgpu_selftest(0, 0, x.ctypes.data_as(ctypes.c_void_p), x.shape[0])
+        assert bad == 0
