@@ -181,6 +181,7 @@ void drain_events(aisgpu_t* h) {
 
 int span_tiles(int tiles_per_block, int n_rx, int threads, int tile96, int requested) {
 	int tps = requested;
+	if (const char* e = getenv("AISGPU_TPS")) tps = atoi(e); // tuning knob
 	if (tps <= 0) {
 		tps = tiles_per_block;
 		const long long want = threads == 64 ? 8192 : (tile96 >= 256 ? 1024 : 2048); // workgroups: a few per CU per residency slot

@@ -405,20 +405,25 @@ __global__ __launch_bounds__(NT) void k1_frontend(K1Params p) {
 __device__ __forceinline__ float dpp_wave_shr1(float old_lane0, float src) { // lane l <- src[l-1]; lane 0 keeps old_lane0
 	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old_lane0), __float_as_int(src), 0x138, 0xF, 0xF, false));
 }
-__device__ __forceinline__ float dpp_wave_ror1(float src) { // lane l <- src[(l + 63) % 64]
-	// every lane has a source lane, so no `old` value is needed (mov_dpp: old = undef, no extra move)
-	return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(src), 0x13C, 0xF, 0xF, false));
+// lanes 0..3 <- src[(l + 63) % 64], the other lanes keep `keep` (row_mask 0x1, bank_mask 0x1): only lane 0 matters
+__device__ __forceinline__ float dpp_carry_lane63(float keep, float src) {
+	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(src), 0x13C, 0x1, 0x1, false));
 }
-// value of the previous lane; for lane 0 the value lane 63 held one tile earlier.  The shadow register `prev`
-// holds that quantity ALREADY ROTATED by one lane (lane 0 = last tile's lane 63), so a tile costs exactly two DPP
-// moves per dword: the shift, and the rotation that prepares the next tile's shadow.
-__device__ __forceinline__ c2 from_prev_lane(c2 cur, c2& prev) {
+// value of the previous lane; for lane 0 the value lane 63 held one tile earlier.  `prev` is a shadow register whose
+// lane 0 holds that carried value.  Both DPP moves work IN PLACE on the shadow register (the shift's `old` operand
+// and, after the caller's last use of the result, the carry for the next tile), so the loop-carried shadow never
+// needs a copy: call from_prev_lane(), use the result, then call carry_to_next_tile() with the same registers.
+__device__ __forceinline__ c2 from_prev_lane(c2 cur, c2 prev) {
 	c2 r;
 	r.x = dpp_wave_shr1(prev.x, cur.x);
 	r.y = dpp_wave_shr1(prev.y, cur.y);
-	prev.x = dpp_wave_ror1(cur.x);
-	prev.y = dpp_wave_ror1(cur.y);
 	return r;
+}
+__device__ __forceinline__ c2 carry_to_next_tile(c2 halo, c2 cur) {
+	c2 p;
+	p.x = dpp_carry_lane63(halo.x, cur.x);
+	p.y = dpp_carry_lane63(halo.y, cur.y);
+	return p;
 }
 
 // cic5_dec_chunk on native vectors (same pairing, same rounding)
@@ -441,22 +446,38 @@ template <> struct HaloState<2> { c2 p1[2], p2[2], p3; };
 
 // h[i] = sample (chunk_start - 5 + i) of the stage's input stream
 template <int C>
-__device__ __forceinline__ void get_halo(const c2 (&x)[C], HaloState<C>& hs, c2 (&h)[5]) {
+__device__ __forceinline__ void get_halo(const c2 (&x)[C], const HaloState<C>& hs, c2 (&h)[5]) {
 	if constexpr (C >= 5) {
 #pragma unroll
 		for (int i = 0; i < 5; i++) h[i] = from_prev_lane(x[C - 5 + i], hs.p[i]);
 	} else if constexpr (C == 4) {
-		c2 t[4];
 #pragma unroll
-		for (int j = 0; j < 4; j++) { t[j] = from_prev_lane(x[j], hs.p[j]); h[1 + j] = t[j]; }
-		h[0] = from_prev_lane(t[3], hs.q); // two lanes back
+		for (int j = 0; j < 4; j++) h[1 + j] = from_prev_lane(x[j], hs.p[j]);
+		h[0] = from_prev_lane(h[4], hs.q); // two lanes back
 	} else { // C == 2
-		c2 t1[2], t2[2];
 #pragma unroll
-		for (int j = 0; j < 2; j++) { t1[j] = from_prev_lane(x[j], hs.p1[j]); h[3 + j] = t1[j]; }
+		for (int j = 0; j < 2; j++) h[3 + j] = from_prev_lane(x[j], hs.p1[j]);
 #pragma unroll
-		for (int j = 0; j < 2; j++) { t2[j] = from_prev_lane(t1[j], hs.p2[j]); h[1 + j] = t2[j]; }
-		h[0] = from_prev_lane(t2[1], hs.p3); // three lanes back
+		for (int j = 0; j < 2; j++) h[1 + j] = from_prev_lane(h[3 + j], hs.p2[j]);
+		h[0] = from_prev_lane(h[2], hs.p3); // three lanes back
+	}
+}
+// after the halo values have been consumed: their registers become the shadows of the next tile
+template <int C>
+__device__ __forceinline__ void put_halo(const c2 (&x)[C], HaloState<C>& hs, const c2 (&h)[5]) {
+	if constexpr (C >= 5) {
+#pragma unroll
+		for (int i = 0; i < 5; i++) hs.p[i] = carry_to_next_tile(h[i], x[C - 5 + i]);
+	} else if constexpr (C == 4) {
+		hs.q = carry_to_next_tile(h[0], h[4]);
+#pragma unroll
+		for (int j = 0; j < 4; j++) hs.p[j] = carry_to_next_tile(h[1 + j], x[j]);
+	} else {
+		hs.p3 = carry_to_next_tile(h[0], h[2]);
+#pragma unroll
+		for (int j = 0; j < 2; j++) hs.p2[j] = carry_to_next_tile(h[1 + j], h[3 + j]);
+#pragma unroll
+		for (int j = 0; j < 2; j++) hs.p1[j] = carry_to_next_tile(h[3 + j], x[j]);
 	}
 }
 
@@ -470,6 +491,7 @@ __device__ __forceinline__ void reg_stage(const c2 (&x)[C], HaloState<C>& hs, c2
 #pragma unroll
 	for (int i = 0; i < C - 1; i++) v[5 + i] = x[i];
 	cic5_dec_chunk_v<C / 2>(v, out);
+	put_halo<C>(x, hs, h);
 }
 
 template <int K> struct RegLadder;
@@ -581,11 +603,13 @@ __global__ __launch_bounds__(64) void k1_dpp(K1Params p) {
 			// ---- FDC (DSP.cpp:283-293) + Rotate (DSP.cpp:296-316)
 			const c2 xm1 = from_prev_lane(x96, fdc_p1);
 			const c2 xm2 = from_prev_lane(xm1, fdc_p2);
+			const auto fdc_carry = [&]() { fdc_p2 = carry_to_next_tile(xm2, xm1); fdc_p1 = carry_to_next_tile(xm1, x96); };
 			c2 y = x96;
 			if (p.has_fdc) { // alpha * (h1 + x) + h2 * beta: add, mul, mul, add (componentwise)
 				const c2 s2 = xm2 + x96;
 				y = s2 * p.alpha + xm1 * p.beta;
 			}
+			fdc_carry();
 			const float RR = y.x * rotv.x, II = y.y * rotv.y, RI = y.x * rotv.y, IR = y.y * rotv.x;
 			__syncthreads(); // previous tile's x5/x6 reads are complete
 			x5[0][8 + lane] = make_float2(RR - II, IR + RI); // up   -> channel A
