@@ -37,6 +37,7 @@ const float TAPS_COHERENT[17] = { // DSP/Filters.h:35-41
 	1.30411453e-02f, 2.52892989e-03f, 3.40605309e-04f, 3.18610148e-05f, 2.06995719e-06f };
 
 struct EvPair { hipEvent_t a, b; };
+struct TraceRec { const char* name; long long block; hipEvent_t a, b; }; // AISGPU_TRACE=1: kernel timeline from HIP events
 constexpr int NBUF = 3;    // ring depth of the buffers that cross from the front-end stream to the others
 constexpr int MAXSUB = 4;  // downstream blocks ("flushes" of the resampler) that one input block can complete
 constexpr int XPAD = 128;  // extra history of the pre-decimated stream in front of one full block (resampler halo)
@@ -64,6 +65,8 @@ struct aisgpu {
 	int n_pre = 0;        // samples per receiver per input block after the pre-decimation pass
 	int n96 = 0, L = 0, W = 0; // per downstream block: 96 kHz samples, 48 kHz samples per channel, CGF windows
 	int Gcap = 0, words = 0;   // group capacity per block, bit words per chain
+	long long c48s = 0;        // row stride of the 48 kHz arrays: L + 32 so that the rows of consecutive chains start in different
+	                           // HBM channels (the fused FIR kernel walks 64 rows in lock step, one per lane)
 	int n_chan = 0, n_chains = 0;
 	float alpha = 0, beta = 1; int has_fdc = 0;
 	float us_increment = 1.0f;
@@ -73,7 +76,7 @@ struct aisgpu {
 	//   s3: K2b                                         (sequential CGF phasor recurrence, 8 waves, latency bound)
 	//   s1 (= s2): K2c -> K3 -> K4 (+ D2H of the outputs) (apply phasors, FIR/ScatterPLL, PhaseSearchEMA)
 	// Buffers that cross a stream boundary are ring buffered by downstream-block index.
-	hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, s3 = nullptr, s4 = nullptr;
+	hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, s3 = nullptr, s4 = nullptr, s5 = nullptr;
 	hipEvent_t ev_phasor[NBUF] = {};  // s3: phasor(f) done -> s1 may apply it
 	hipEvent_t ev_search[NBUF] = {};  // s4: fz(f) known -> s3 may run the phasor recurrence
 	bool serial = false;
@@ -121,6 +124,10 @@ struct aisgpu {
 	SubOut sub[MAXSUB]; int n_sub = 0;
 	struct { bool valid = false; int q = 0, pb = 0; long long g0 = 0, g1 = 0, first48 = 0; } pend; // deferred second half
 	bool defer = true;
+	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
+	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
+	bool fused = false; int GL = 40;
+	float2 *d_ck[NBUF] = {}, *d_ckw[NBUF] = {}, *d_dfhist[2] = {};
 	// per-kernel geometry
 	int tile_in = 0, tiles_per_block = 0, tiles_per_span = 0, spans = 0;         // fused front end (its own input)
 	int ptile_in = 0, ptiles_per_block = 0, ptiles_per_span = 0, pspans = 0;     // pre-decimation pass
@@ -179,6 +186,34 @@ void drain_events(aisgpu_t* h) {
 	h->ev_busy.clear();
 }
 
+// AISGPU_TRACE=1: bracket a launch with events on its stream; dumped (relative to the first record) by trace_dump()
+struct TraceScope {
+	aisgpu_t* h; hipStream_t s; TraceRec r{};
+	TraceScope(aisgpu_t* h_, const char* name, hipStream_t s_) : h(h_), s(s_) {
+		if (!h->trace) return;
+		if (!h->trace_origin) { hipEventCreate(&h->trace_origin); hipEventRecord(h->trace_origin, s); }
+		r.name = name; r.block = h->block_idx;
+		hipEventCreate(&r.a); hipEventCreate(&r.b);
+		hipEventRecord(r.a, s);
+	}
+	~TraceScope() {
+		if (!h->trace) return;
+		hipEventRecord(r.b, s);
+		h->trace_recs.push_back(r);
+	}
+};
+void trace_dump(aisgpu_t* h) {
+	if (!h->trace || h->trace_recs.empty()) return;
+	for (auto& r : h->trace_recs) {
+		float a = 0, b = 0;
+		hipEventElapsedTime(&a, h->trace_origin, r.a);
+		hipEventElapsedTime(&b, h->trace_origin, r.b);
+		fprintf(stderr, "TRACE %-8s block %3lld  %10.1f -> %10.1f  (%7.1f us)\n", r.name, r.block, a * 1e3, b * 1e3, (b - a) * 1e3);
+		hipEventDestroy(r.a); hipEventDestroy(r.b);
+	}
+	h->trace_recs.clear();
+}
+
 int span_tiles(int tiles_per_block, int n_rx, int threads, int tile96, int requested) {
 	int tps = requested;
 	if (const char* e = getenv("AISGPU_TPS")) tps = atoi(e); // tuning knob
@@ -191,9 +226,11 @@ int span_tiles(int tiles_per_block, int n_rx, int threads, int tile96, int reque
 	return tps;
 }
 
+int enqueue_downstream_fused(aisgpu_t* h, int q, int pb);
+
 K2Params make_k2(aisgpu_t* h, int q) {
 	K2Params k2;
-	k2.c48 = h->d_c48[q]; k2.c48_stride = h->L; k2.cgf = h->d_cgf; k2.cgf_stride = CGF_HIST + h->L;
+	k2.c48 = h->d_c48[q]; k2.c48_stride = h->c48s; k2.cgf = h->d_cgf; k2.cgf_stride = CGF_HIST + h->L;
 	k2.omega = h->d_omega; k2.step_table = h->d_step; k2.ppm_table = h->d_ppmtab; k2.magT = h->d_magT[q]; k2.fz = h->d_fz[q]; k2.ppm = h->d_ppm[q];
 	k2.rot_state = h->d_rotstate; k2.n_windows = h->W; k2.wide = h->cfg.afc_wide ? 1 : 0;
 	k2.rotT = h->d_rotT[q]; k2.rotT_stride = (h->n_chan + 63) / 64 * 64; k2.n_chan = h->n_chan;
@@ -241,7 +278,69 @@ int enqueue_back(aisgpu_t* h) {
 	return AISGPU_OK;
 }
 
-// Everything behind the 48 kHz front-end output of one downstream block, ring slot q, parity pb.
+// Default path: the phasor recurrence keeps checkpoints only, and one fused kernel derotates, filters and scatters.
+// Nothing behind the FFT touches the front stream, so nothing needs to be deferred:
+//   front stream: front end, FFT            (HBM-bound)
+//   s4: spectral searches                   (latency-bound)
+//   s3: phasor recurrence, own CUs          (latency-bound)
+//   s5: derotation + FIR + ScatterPLL       (VALU/latency-bound)
+//   s1: PhaseSearchEMA                      (VALU-bound; both overlap the next block's front end)
+int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
+	K2Params k2 = make_k2(h, q);
+	const long long g0 = h->n48 / 5, g1 = (h->n48 + h->L) / 5; // groups completed inside this block (DSP/DSP.h:95-117)
+	const int n_groups = (int)(g1 - g0), n_rel0 = (int)(g0 * 5 - h->n48);
+	const int S = (n_groups + h->GL - 1) / h->GL;
+	k2.ck = h->d_ck[q]; k2.ckw = h->d_ckw[q]; k2.ck_stride = k2.rotT_stride;
+	k2.ck_first = n_rel0 - 20; k2.ck_period = 5 * h->GL; k2.n_ck = S;
+	{ TraceScope t(h, "fft", h->stream); HIPCHK(launch_k2a_fft(k2, h->n_chan, h->stream)); }
+	HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
+	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_front[q], 0));
+	{ TraceScope t(h, "search", h->s4); HIPCHK(launch_k2a_search(k2, h->n_chan, h->s4)); }
+	HIPCHK(hipEventRecord(h->ev_search[q], h->s4));
+	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_search[q], 0));
+	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_c48free[q], 0)); // ck[q] was last read by K6 of block f-NBUF
+	{ TraceScope t(h, "phasor", h->s3); HIPCHK(launch_k2b_ck(k2, h->n_chan, h->s3)); }
+	HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
+
+	K6Params k6;
+	k6.c48 = h->d_c48[q]; k6.c48_stride = h->c48s; k6.ck = h->d_ck[q]; k6.ckw = h->d_ckw[q]; k6.ck_stride = k2.ck_stride;
+	k6.step_table = h->d_step; k6.fz = h->d_fz[q];
+	k6.hist_in = h->d_dfhist[pb ^ 1]; k6.hist_out = h->d_dfhist[pb];
+	k6.sym = h->d_sym[pb]; k6.sym_stride = h->Gcap; k6.lvl = h->d_lvl[pb];
+	memcpy(k6.taps, TAPS_COHERENT, sizeof k6.taps);
+	k6.first_group = g0; k6.n_rel0 = n_rel0; k6.n_groups = n_groups; k6.L = h->L; k6.n_windows = h->W; k6.n_chan = h->n_chan;
+	k6.GL = h->GL; k6.S = S;
+	HIPCHK(hipStreamWaitEvent(h->s5, h->ev_phasor[q], 0));
+	HIPCHK(hipStreamWaitEvent(h->s5, h->ev_ema[pb], 0)); // sym/lvl[pb] were last read by K4 of block f-2
+	{ TraceScope t(h, "derotfir", h->s5); HIPCHK(launch_k6(k6, h->s5)); }
+	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s5));
+	HIPCHK(hipEventRecord(h->ev_k3[pb], h->s5));
+	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_k3[pb], 0));
+
+	K4Params k4;
+	k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[pb]; k4.bits_stride = h->words;
+	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
+	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag;
+	k4.n_chains = h->n_chains; k4.n_groups = n_groups;
+	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
+	{
+		TraceScope t(h, "psearch", h->s1);
+		if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, h->s1));
+		else HIPCHK(launch_k4_sequential(k4, h->s1));
+	}
+	HIPCHK(hipEventRecord(h->ev_ema[pb], h->s1));
+
+	if (h->n_sub < MAXSUB) {
+		SubOut& so = h->sub[h->n_sub++];
+		so.pb = pb; so.q = q; so.groups = n_groups; so.first_group = g0; so.first48 = h->n48;
+	}
+	h->n48 += h->L;
+	h->block_idx++;
+	return AISGPU_OK;
+}
+
+// Path with the phasor and derotated-sample arrays materialised (taps, Challenger FM branch): everything behind the
+// 48 kHz front-end output of one downstream block, ring slot q, parity pb.
 //
 // Stream plan.  The HBM-bound kernels (front end, FFT, phasor apply, FIR/ScatterPLL) run one after the other on
 // the front stream: run side by side they only take bandwidth from each other.  What overlaps them are the
@@ -250,6 +349,7 @@ int enqueue_back(aisgpu_t* h) {
 // the next block's front end by DEFERRING the second half of block f (apply ... PhaseSearchEMA) until the first
 // half of block f+1 has been enqueued -- or until the caller asks for results (sync_all / aisgpu_sync_outputs).
 int enqueue_downstream(aisgpu_t* h, int q, int pb) {
+	if (h->fused) return enqueue_downstream_fused(h, q, pb);
 	const K2Params k2 = make_k2(h, q);
 	HIPCHK(launch_k2a_fft(k2, h->n_chan, h->stream));
 	HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
@@ -284,7 +384,9 @@ int sync_all(aisgpu_t* h) {
 	HIPCHK(hipStreamSynchronize(h->s1));
 	HIPCHK(hipStreamSynchronize(h->s3));
 	HIPCHK(hipStreamSynchronize(h->s4));
+	HIPCHK(hipStreamSynchronize(h->s5));
 	drain_events(h);
+	trace_dump(h);
 	return AISGPU_OK;
 }
 
@@ -386,6 +488,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->L = h->n96 / 2;
 	h->W = h->L / 512;
 	h->Gcap = ((h->L + 4) / 5 + 1 + 31) / 32 * 32;
+	h->c48s = (long long)h->L + 32;
 	h->words = h->Gcap / 32;
 	h->n_chan = cfg->n_receivers * 2;
 	h->n_chains = h->n_chan * 5;
@@ -413,7 +516,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	HIPCHK(hipSetDevice(cfg->device_id));
 	if ((cfg->flags & AISGPU_FLAG_SERIAL) || getenv("AISGPU_SERIAL")) { // profiling aid: no cross-block overlap, every kernel runs alone
 		HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-		h->s1 = h->s2 = h->s3 = h->s4 = h->stream;
+		h->s1 = h->s2 = h->s3 = h->s4 = h->s5 = h->stream;
 		h->serial = true;
 	} else {
 		// HIP maps streams onto a small number of hardware queues (4 by default, one is the application's
@@ -435,11 +538,15 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			HIPCHK(hipExtStreamCreateWithCUMask(&h->s1, (uint32_t)words, rest.data()));
 			HIPCHK(hipExtStreamCreateWithCUMask(&h->s3, (uint32_t)words, lat.data()));
 			HIPCHK(hipExtStreamCreateWithCUMask(&h->s4, (uint32_t)words, rest.data()));
+			if (getenv("AISGPU_S5") && atoi(getenv("AISGPU_S5")) == 4) h->s5 = h->s4;       // experiment: share the search stream
+			else if (getenv("AISGPU_S5") && atoi(getenv("AISGPU_S5")) == 1) h->s5 = h->s1;  // experiment: share the PhaseSearchEMA stream
+			else HIPCHK(hipExtStreamCreateWithCUMask(&h->s5, (uint32_t)words, rest.data()));
 		} else {
 			HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 			HIPCHK(hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking));
 			HIPCHK(hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking));
 			HIPCHK(hipStreamCreateWithFlags(&h->s4, hipStreamNonBlocking));
+			HIPCHK(hipStreamCreateWithFlags(&h->s5, hipStreamNonBlocking));
 		}
 		h->s2 = h->s1; // apply + FIR + PhaseSearchEMA of a block run back to back on one stream
 	}
@@ -452,6 +559,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_ema[i], hipEventDisableTiming));
 	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_k3[i], hipEventDisableTiming));
 	if (const char* e = getenv("AISGPU_DEFER")) h->defer = atoi(e) != 0;
+	if (const char* e = getenv("AISGPU_TRACE")) h->trace = atoi(e) != 0;
 
 	// ---- constant tables (host libm, like the reference on this machine)
 	{
@@ -503,9 +611,20 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			HIPCHK(hipHostMalloc((void**)&h->h_usalpha[i], ((size_t)US_HIST + h->n_pre) * sizeof(float), hipHostMallocDefault));
 		}
 	}
+	h->fused = !(cfg->flags & AISGPU_FLAG_TAPS) && !h->challenger;
+	if (const char* e = getenv("AISGPU_FUSED")) h->fused = h->fused && atoi(e) != 0;
+	if (const char* e = getenv("AISGPU_GL")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0) h->GL = v; }
+	if (h->fused) {
+		const size_t cs = (C + 63) / 64 * 64;
+		for (int i = 0; i < NBUF; i++) {
+			HIPCHK(dalloc(&h->d_ck[i], (size_t)(h->Gcap / h->GL + 2) * cs));
+			HIPCHK(dalloc(&h->d_ckw[i], (size_t)h->W * cs));
+		}
+		for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_dfhist[i], C * DF_HIST)); // zero = silence before the stream
+	}
 	for (int i = 0; i < NBUF; i++) {
 		HIPCHK(dalloc(&h->d_magT[i], (C * h->W + 63) / 64 * (size_t)(512 * 64)));
-		HIPCHK(dalloc(&h->d_c48[i], C * h->L));
+		HIPCHK(dalloc(&h->d_c48[i], C * h->c48s + 64)); // + over-read slack of the fused FIR kernel's last segment
 		HIPCHK(dalloc(&h->d_fz[i], C * h->W));
 		HIPCHK(dalloc(&h->d_ppm[i], C * h->W));
 		HIPCHK(dalloc(&h->d_rotT[i], (size_t)h->L * ((C + 63) / 64 * 64)));
@@ -550,6 +669,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	if (h->s1) hipStreamSynchronize(h->s1);
 	if (h->s3) hipStreamSynchronize(h->s3);
 	if (h->s4) hipStreamSynchronize(h->s4);
+	if (h->s5) hipStreamSynchronize(h->s5);
 	drain_events(h);
 	for (int i = 0; i < NBUF; i++) {
 		if (h->ev_front[i]) hipEventDestroy(h->ev_front[i]);
@@ -571,7 +691,8 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_in); hipFree(h->d_hist); hipFree(h->d_hist2);
 	hipFree(h->d_fm); hipFree(h->d_fmbits[0]); hipFree(h->d_fmbits[1]);
 	if (h->h_fmbits) hipHostFree(h->h_fmbits);
-	for (int i = 0; i < NBUF; i++) hipFree(h->d_magT[i]);
+	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); hipFree(h->d_ckw[i]); }
+	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
 	hipFree(h->d_cgf); hipFree(h->d_omega); hipFree(h->d_step);
 	hipFree(h->d_rotstate); hipFree(h->d_firtap); hipFree(h->d_ppmtab);
 	hipFree(h->d_pswords); hipFree(h->d_psma0); hipFree(h->d_psma1); hipFree(h->d_psfin); hipFree(h->d_psflag);
@@ -583,6 +704,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	if (h->s1 && !h->serial) hipStreamDestroy(h->s1);
 	if (h->s3 && !h->serial) hipStreamDestroy(h->s3);
 	if (h->s4 && !h->serial) hipStreamDestroy(h->s4);
+	if (h->s5 && !h->serial && h->s5 != h->s4 && h->s5 != h->s1) hipStreamDestroy(h->s5);
 	delete h;
 }
 
@@ -676,12 +798,12 @@ int aisgpu_run(aisgpu_t* h) {
 		k1.in_stride = from_pre ? xstride : h->cur_in_stride;
 		k1.hist = from_pre ? h->d_hist2 : h->d_hist;
 		k1.rot = h->d_rot[pb];
-		k1.c48 = h->d_c48[q]; k1.c48_stride = h->L;
+		k1.c48 = h->d_c48[q]; k1.c48_stride = h->c48s;
 		k1.tiles_per_block = h->tiles_per_block; k1.tiles_per_span = h->tiles_per_span;
 		k1.alpha = h->alpha; k1.beta = h->beta; k1.has_fdc = h->has_fdc;
 		k1.pre_out = nullptr; k1.pre_stride = 0;
 		if (!from_pre) { int rc = time_begin(); if (rc) return rc; }
-		HIPCHK(launch_k1(k1, h->K, from_pre ? false : cu8, h->tile96, h->depth, h->k1_threads, h->spans, R, h->stream));
+		{ TraceScope t(h, "front", h->stream); HIPCHK(launch_k1(k1, h->K, from_pre ? false : cu8, h->tile96, h->depth, h->k1_threads, h->spans, R, h->stream)); }
 		if (!from_pre) { int rc = time_end(); if (rc) return rc; }
 		if (from_pre) HIPCHK(launch_k1_tail(xcur, xstride * 8, (long long)h->n_pre * 8, h->d_hist2, h->tile_in * 8, R, h->stream));
 		else HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist,
@@ -720,7 +842,7 @@ int aisgpu_run(aisgpu_t* h) {
 					K1uParams ku;
 					ku.xin = xcur; ku.xin_stride = xstride; ku.xin_off = h->xh;
 					ku.us_idx = h->d_usidx[pb]; ku.us_alpha = h->d_usalpha[pb]; ku.rot = h->d_rot[pb];
-					ku.c48 = h->d_c48[q]; ku.c48_stride = h->L;
+					ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
 					ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->has_fdc; ku.L = h->L;
 					HIPCHK(launch_k1u(ku, R, h->stream));
 					int rc = enqueue_downstream(h, q, pb);
@@ -793,7 +915,7 @@ long long aisgpu_tap(aisgpu_t* h, int which, int rx, float* dst, long long cap) 
 	const SubOut& so = h->sub[h->n_sub - 1]; // taps show the last downstream block
 	const float2* src;
 	long long n = h->L;
-	if (which < 2) src = h->d_c48[so.q] + chan * h->L;
+	if (which < 2) src = h->d_c48[so.q] + chan * h->c48s;
 	else if (which < 4) src = h->d_cgf + chan * (CGF_HIST + h->L) + CGF_HIST;
 	else {
 		// FIR outputs exist for every sample that belongs to a group completed in this block:

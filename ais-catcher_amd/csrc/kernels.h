@@ -46,6 +46,26 @@ struct K2Params {
 	float2* rot_state;        // [n_chan]
 	float2* rotT; long long rotT_stride; // [L][rotT_stride] derotation phasor per sample, time-major
 	int n_windows, wide, n_chan;
+	// checkpointed recurrence (k2_cgf_phasor_ck): state BEFORE sample ck_first + s * ck_period for s = 1..n_ck-1, block start for s = 0
+	float2* ck; long long ck_stride; // [n_ck][ck_stride]
+	float2* ckw;                     // [n_windows][ck_stride] state at every window start
+	int ck_first, ck_period, n_ck;
+};
+
+// Fused derotation + FilterComplex(Coherent) + ScatterPLL (k3_derot_fir): one wave = 64 chains x one time segment
+constexpr int DF_HIST = 24; // derotated samples carried from block to block (17-tap history + a partial group)
+struct K6Params {
+	const float2* c48; long long c48_stride;
+	const float2* ck; long long ck_stride;       // phasor checkpoints, segment-major
+	const float2* ckw;                           // ... and at every window start (renormalised)
+	const float2* step_table; const int* fz;     // fz[chain][n_windows]
+	const float2* hist_in; float2* hist_out;     // [n_chan][DF_HIST]
+	float2* sym; long long sym_stride;           // [n_chan][5][sym_stride]
+	float* lvl;                                   // [n_chan][sym_stride]
+	float taps[17];
+	long long first_group;
+	int n_rel0;                                   // first_group * 5 - first_sample48, in [-4, 0]
+	int n_groups, L, n_windows, n_chan, GL, S;    // GL groups per segment (multiple of 8), S segments
 };
 
 struct K3Params {
@@ -88,6 +108,8 @@ hipError_t launch_selftest_hypot(const float2* in, int n, unsigned* mismatches, 
 hipError_t launch_k2b(const K2Params& p, int n_chan, hipStream_t s); // phasor recurrence
 hipError_t launch_k2c(const K2Params& p, int n_chan, hipStream_t s); // history carry + apply
 hipError_t launch_k3(const K3Params& p, int n_chan, hipStream_t s);
+hipError_t launch_k2b_ck(const K2Params& p, int n_chan, hipStream_t s); // phasor recurrence, checkpoints only
+hipError_t launch_k6(const K6Params& p, hipStream_t s);
 struct K5Params { // ModelChallenger FM branch (Model.cpp:638-639): Demod::FM -> Filter(Receiver, 37 taps) -> sign
 	const float2* cgf; long long cgf_stride; // [n_chan][CGF_HIST + L]
 	float* fm; long long fm_stride;          // [n_chan][FM_HIST + L] discriminator output, FM_HIST leading history

@@ -521,8 +521,13 @@ __device__ __forceinline__ c2 run_ladder(const c2 (&x)[1 << K], RegLadder<K>& st
 	}
 }
 
+// Register budget: three front-end waves per SIMD must leave room for one PhaseSearchEMA wave (96 VGPRs) in the
+// 512-entry file, or the two kernels evict each other instead of overlapping (HBM-bound next to VALU-bound).
+#ifndef K1_WAVES
+#define K1_WAVES 3
+#endif
 template <int K, bool CU8, bool PRE>
-__global__ __launch_bounds__(64) void k1_dpp(K1Params p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1_WAVES))) void k1_dpp(K1Params p) {
 	constexpr int C0 = 1 << K;        // input samples per lane per tile
 	constexpr int TILE_IN = 64 * C0;  // input samples per wave-tile
 	constexpr int W4 = C0 / 2 + 1;    // padded row (float4) of the transposition buffer
@@ -988,6 +993,184 @@ __global__ __launch_bounds__(64) void k2_cgf_phasor(K2Params p) {
 		cur.y = __fdiv_rn(cur.y, a);
 	}
 	if (live) p.rot_state[chan] = make_float2(cur.x, cur.y);
+}
+
+// The same recurrence without the per-sample stores: only its state at the start of every time segment of the
+// fused derotation/FIR kernel is kept (K6 recomputes the 200-odd steps of a segment, 64 chains per wave, all
+// segments in parallel).  3 packed VALU ops per step and nothing else.
+__global__ __launch_bounds__(64) void k2_cgf_phasor_ck(K2Params p) {
+	const int lane = threadIdx.x;
+	const int chan_raw = blockIdx.x * 64 + lane;
+	const bool live = chan_raw < p.n_chan;
+	const int chan = live ? chan_raw : p.n_chan - 1;
+	__builtin_amdgcn_s_setprio(3);
+	const float2 r0 = p.rot_state[chan];
+	v2f cur = { r0.x, r0.y };
+	float2* const ck = p.ck + (size_t)blockIdx.x * 64 + lane; // padded columns exist for dead lanes
+	ck[0] = r0;
+	int s = 1, next_ck = p.ck_first + p.ck_period, n = 0;
+	float2* const ckw = p.ckw + (size_t)blockIdx.x * 64 + lane;
+	for (int w = 0; w < p.n_windows; w++) {
+		const int fz = p.fz[(size_t)chan * p.n_windows + w];
+		const float2 stp = p.step_table[fz + 205];
+		const v2f st = { stp.x, stp.y }, st_sw = { -stp.y, stp.x };
+		const int wend = (w + 1) * 512;
+		ckw[(size_t)w * p.ck_stride] = make_float2(cur.x, cur.y); // state at the window start (after the renormalisation)
+		while (n < wend) {
+			if (s < p.n_ck && next_ck == n) { // wave-uniform
+				ck[(size_t)s * p.ck_stride] = make_float2(cur.x, cur.y);
+				s++;
+				next_ck += p.ck_period;
+			}
+			const int stop = (s < p.n_ck && next_ck < wend) ? next_ck : wend;
+			const int run = stop - n;
+#pragma unroll 8
+			for (int k = 0; k < run; k++) cur = cur.xx * st + cur.yy * st_sw; // rot *= rot_step
+			n = stop;
+		}
+		const float a = hypot_ref(cur.x, cur.y); // rot /= std::abs(rot), once per window (DSP.cpp:465)
+		cur.x = __fdiv_rn(cur.x, a);
+		cur.y = __fdiv_rn(cur.y, a);
+	}
+	if (live) p.rot_state[chan] = make_float2(cur.x, cur.y);
+}
+
+// ------------------------------------------------------------------------------------------
+// K6: output[i] *= rot (DSP.cpp:457-466) + FilterComplex(Filters::Coherent) + ScatterPLL (DSP.cpp:215-246,
+// DSP.h:95-117) in one pass, without the phasor array and without the derotated-sample array in HBM.
+// One wave = 64 chains (one per lane) x one time segment of GL ScatterPLL groups: it restarts the recurrence
+// from the segment's checkpoint, 20 samples early (FIR history), and walks the segment sample by sample --
+// everything that depends on time (window boundaries, renormalisation, group phase, the (1j)^n pre-rotation of
+// PhaseSearchEMA) is wave-uniform.  Each lane reads its own chain's row sequentially (whole cache lines per
+// lane) and keeps the last 20 derotated samples in registers; the outputs of 4 groups are written together
+// (32 contiguous bytes per lane and symbol phase).  Arithmetic per sample is exactly K2b/K2c/K3's.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ c2 pk_sub_add(c2 a, c2 b) { // (a.x - b.x, a.y + b.y) in one packed add (x - y == x + (-y) exactly)
+	c2 r;
+	asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+
+// R0 = first_group & 3: the (1j)^n pre-rotation pattern of the 4 groups of a body is the same for the whole launch
+// (segments and bodies start at multiples of 4 groups)
+template <int R0>
+__global__ __launch_bounds__(64) void k3_derot_fir(K6Params p) {
+	const int lane = threadIdx.x, s = blockIdx.x;
+	const int chain_raw = blockIdx.y * 64 + lane;
+	const bool live = chain_raw < p.n_chan;
+	const int chain = live ? chain_raw : p.n_chan - 1;
+	const int ga = s * p.GL;
+	const int gb = ga + p.GL < p.n_groups ? ga + p.GL : p.n_groups;
+	const bool last = s == p.S - 1;
+	const int a = p.n_rel0 + 5 * ga;                 // first sample that has a FIR output here
+	const int e = last ? p.L : p.n_rel0 + 5 * gb;    // one past the last sample to derotate
+	// wave-uniform base pointers + a 32-bit per-lane element offset (SGPR base / VGPR offset addressing)
+	const unsigned xoff = (unsigned)chain * (unsigned)p.c48_stride, hoff = (unsigned)chain * DF_HIST;
+	const unsigned ckoff = (unsigned)(blockIdx.y * 64 + lane);
+	const float2* hin = p.hist_in + DF_HIST;              // hin[n][hoff], n in [-DF_HIST, 0)
+	float2* hout = p.hist_out - (p.L - DF_HIST);          // hout[n][hoff], n in [L - DF_HIST, L)
+	const int* fzrow = p.fz + (size_t)chain * p.n_windows;
+	const float2 r0 = (p.ck + (size_t)s * p.ck_stride)[ckoff];
+	c2 rot = { r0.x, r0.y }, st = { 0.f, 0.f }, st_sw = { 0.f, 0.f };
+	const auto load_step = [&](int w) {
+		const float2 stp = p.step_table[fzrow[w] + 205];
+		st = c2{ stp.x, stp.y }; st_sw = c2{ -stp.y, stp.x };
+	};
+	int n = a - 20;
+	load_step((n > 0 ? n : 0) >> 9);
+	// derotated sample n (wave-uniform n); advances the recurrence.  The once-per-window renormalisation
+	// rot /= |rot| is not redone here: the recurrence kernel left the renormalised state of every window start.
+	// PLAIN: the caller guarantees 0 <= n, no window start and no block-tail store (straight-line code, so the
+	// loads of a whole body can be issued together)
+	const auto derotate = [&](float2 d) -> c2 {
+		rot = rot.xx * st + rot.yy * st_sw; // rot *= rot_step
+		return pk_sub_add(rot * d.x, rot.yx * d.y); // data * rot = (d.x r.x - d.y r.y, d.x r.y + d.y r.x)
+	};
+	const auto next_sample = [&](int nn) -> c2 {
+		if (nn < 0) { const float2 d = (hin + nn)[hoff]; return c2{ d.x, d.y }; } // the previous block's tail
+		if ((nn & 511) == 0 && nn < p.L) {
+			load_step(nn >> 9);
+			const float2 r = (p.ckw + (size_t)(nn >> 9) * p.ck_stride)[ckoff];
+			rot = c2{ r.x, r.y };
+		}
+		const c2 y = derotate((p.c48 + nn)[xoff]);
+		if (last && nn >= p.L - DF_HIST && nn < p.L && live) (hout + nn)[hoff] = make_float2(y.x, y.y);
+		return y;
+	};
+	c2 y[20];
+#pragma unroll
+	for (int m = 0; m < 20; m++) y[m] = next_sample(n + m);
+	n += 20;
+	for (int g = ga; n < e; g += 4, n += 20) {
+		c2 out[5][4];
+		float lv[4];
+		// FIR + ScatterPLL of the 4 groups whose 20 derotated samples are produced by `sample(m)`
+		const auto body = [&](auto sample) {
+#pragma unroll
+			for (int gi = 0; gi < 4; gi++) {
+				c2 yn[5]; // the group's own samples; y[] keeps the 20 before them until the group is done
+#pragma unroll
+				for (int j = 0; j < 5; j++) yn[j] = sample(gi * 5 + j);
+				// the five 17-tap sums of the group advance together, tap by tap (each one left to right from 0, DSP.h:224-230)
+				c2 acc[5];
+#pragma unroll
+				for (int j = 0; j < 5; j++) acc[j] = c2{ 0.0f, 0.0f };
+#pragma unroll
+				for (int i = 0; i < 17; i++) {
+#pragma unroll
+					for (int j = 0; j < 5; j++) {
+						const int k = j - 16 + i; // sample index relative to the group's first sample
+						acc[j] = acc[j] + (k >= 0 ? yn[k < 5 ? k : 0] : y[(gi * 5 + k + 20) % 20]) * p.taps[i];
+					}
+				}
+#pragma unroll
+				for (int j = 0; j < 5; j++) y[gi * 5 + j] = yn[j];
+				float level = 0.0f;
+				// PhaseSearchEMA multiplies symbol n of a chain by (1j)^(n & 3) with swaps/negations (Demod.cpp:44-61);
+				// every chain has consumed exactly first_group + g symbols, so that exact rotation is applied here
+				const int rsel = (R0 + gi) & 3; // compile-time after unrolling
+#pragma unroll
+				for (int j = 0; j < 5; j++) {
+					level = level + (acc[j].x * acc[j].x + acc[j].y * acc[j].y); // std::norm
+					c2 sv = (rsel & 1) ? acc[j].yx : acc[j]; // rot 1: (-y, x)   rot 3: (y, -x)
+					if (rsel == 1 || rsel == 2) sv.x = -sv.x;
+					if (rsel >= 2) sv.y = -sv.y;
+					out[j][gi] = sv;
+				}
+				lv[gi] = __fdiv_rn(level, 5.0f);
+			}
+		};
+		const bool plain = n >= 0 && (n & 511) != 0 && (n & 511) + 20 <= 512 && !(last && n + 20 > p.L - DF_HIST);
+		if (plain) {
+			float2 d[20];
+			const float2* xb = p.c48 + n;
+#pragma unroll
+			for (int m = 0; m < 20; m++) d[m] = (xb + m)[xoff];
+			body([&](int m) { return derotate(d[m]); });
+		} else {
+			body([&](int m) { return next_sample(n + m); });
+		}
+		if (live) {
+			if (g + 4 <= gb) {
+#pragma unroll
+				for (int j = 0; j < 5; j++) {
+					float4* dst = reinterpret_cast<float4*>(p.sym + ((size_t)chain * 5 + j) * p.sym_stride + g);
+#pragma unroll
+					for (int q = 0; q < 2; q++) dst[q] = make_float4(out[j][2 * q].x, out[j][2 * q].y, out[j][2 * q + 1].x, out[j][2 * q + 1].y);
+				}
+				*reinterpret_cast<float4*>(p.lvl + (size_t)chain * p.sym_stride + g) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+			} else {
+#pragma unroll
+				for (int gi = 0; gi < 4; gi++) {
+					if (g + gi < gb) {
+#pragma unroll
+						for (int j = 0; j < 5; j++) p.sym[((size_t)chain * 5 + j) * p.sym_stride + g + gi] = make_float2(out[j][gi].x, out[j][gi].y);
+						p.lvl[(size_t)chain * p.sym_stride + g + gi] = lv[gi];
+					}
+				}
+			}
+		}
+	}
 }
 
 // carry the tail of the previous block's derotated samples (FIR-17 history + partial ScatterPLL group) to the
@@ -1587,6 +1770,22 @@ hipError_t launch_k2a_search(const K2Params& p, int n_chan, hipStream_t s) {
 
 hipError_t launch_k2b(const K2Params& p, int n_chan, hipStream_t s) {
 	hipLaunchKernelGGL(k2_cgf_phasor, dim3((n_chan + 63) / 64), dim3(64), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_k2b_ck(const K2Params& p, int n_chan, hipStream_t s) {
+	hipLaunchKernelGGL(k2_cgf_phasor_ck, dim3((n_chan + 63) / 64), dim3(64), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_k6(const K6Params& p, hipStream_t s) {
+	const dim3 grid(p.S, (p.n_chan + 63) / 64);
+	switch ((int)(p.first_group & 3)) {
+	case 0: hipLaunchKernelGGL(k3_derot_fir<0>, grid, dim3(64), 0, s, p); break;
+	case 1: hipLaunchKernelGGL(k3_derot_fir<1>, grid, dim3(64), 0, s, p); break;
+	case 2: hipLaunchKernelGGL(k3_derot_fir<2>, grid, dim3(64), 0, s, p); break;
+	default: hipLaunchKernelGGL(k3_derot_fir<3>, grid, dim3(64), 0, s, p); break;
+	}
 	return hipGetLastError();
 }
 

@@ -143,6 +143,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    t_enq = time.perf_counter() - t0   # host time to enqueue all steps (no device sync inside)
     g.sync()
     barrier()
     dt = time.perf_counter() - t0
@@ -175,7 +176,8 @@ def main():
     res = {
         "metric": "IQ Msamples/s (CFLOAT32) through ModelDefault chain", "value": round(value, 1),
         "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[3]: %d batched dual-channel receivers per GPU, 1536 kSPS CF32, "
                                "%d IQ samples per receiver per step, resident in HBM, chain up to hard bits/levels/ppm"

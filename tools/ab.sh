@@ -8,6 +8,6 @@ for i in $(seq $N); do
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); r = d['roofline']; print('$L', 'ms/step', d['ms_per_step'], 'k1 ovl', r['avg_launch_ms'], 'k1 iso', r['isolated_launch_ms'])"
+        d = json.loads(l); r = d['roofline']; print('$L', 'ms/step', d['ms_per_step'], 'k1 ovl', r['avg_launch_ms'], 'k1 iso', r['isolated_launch_ms'], 'host enq', d.get('host_enqueue_ms_per_step'))"
   done
 done

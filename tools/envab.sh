@@ -7,6 +7,6 @@ for i in 1 2; do
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); r = d['roofline']; print('$E', 'ms/step', d['ms_per_step'], 'k1 ovl', r['avg_launch_ms'], 'k1 iso', r['isolated_launch_ms'])"
+        d = json.loads(l); r = d['roofline']; print('$E', 'ms/step', d['ms_per_step'], 'k1 ovl', r['avg_launch_ms'], 'k1 iso', r['isolated_launch_ms'], 'host enq', d.get('host_enqueue_ms_per_step'))"
   done
 done
