@@ -611,8 +611,9 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			HIPCHK(hipHostMalloc((void**)&h->h_usalpha[i], ((size_t)US_HIST + h->n_pre) * sizeof(float), hipHostMallocDefault));
 		}
 	}
-	h->fused = !(cfg->flags & AISGPU_FLAG_TAPS) && !h->challenger;
-	if (const char* e = getenv("AISGPU_FUSED")) h->fused = h->fused && atoi(e) != 0;
+	// experimental (AISGPU_FUSED=1): bit-exact, but slower end to end than the materialised path so far
+	h->fused = false;
+	if (const char* e = getenv("AISGPU_FUSED")) h->fused = atoi(e) != 0 && !(cfg->flags & AISGPU_FLAG_TAPS) && !h->challenger;
 	if (const char* e = getenv("AISGPU_GL")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0) h->GL = v; }
 	if (h->fused) {
 		const size_t cs = (C + 63) / 64 * 64;

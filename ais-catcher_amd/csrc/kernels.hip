@@ -521,17 +521,26 @@ __device__ __forceinline__ c2 run_ladder(const c2 (&x)[1 << K], RegLadder<K>& st
 	}
 }
 
+// A workgroup of ONE wave needs no s_barrier and, above all, no "s_waitcnt vmcnt(0)" (which __syncthreads() implies
+// and which would drain the next tile's prefetch in the middle of this tile's arithmetic): the LDS unit executes a
+// wave's DS instructions in order, so a wavefront-scope fence (compiler ordering only) is all that is needed.
+__device__ __forceinline__ void wave_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
 // Register budget: three front-end waves per SIMD must leave room for one PhaseSearchEMA wave (96 VGPRs) in the
 // 512-entry file, or the two kernels evict each other instead of overlapping (HBM-bound next to VALU-bound).
 #ifndef K1_WAVES
 #define K1_WAVES 3
 #endif
 template <int K, bool CU8, bool PRE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1_WAVES))) void k1_dpp(K1Params p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4))) void k1_dpp(K1Params p) {
 	constexpr int C0 = 1 << K;        // input samples per lane per tile
 	constexpr int TILE_IN = 64 * C0;  // input samples per wave-tile
-	constexpr int W4 = C0 / 2 + 1;    // padded row (float4) of the transposition buffer
-	__shared__ __attribute__((aligned(16))) float4 xt[C0 >= 4 && !CU8 ? 64 * W4 : 1]; // coalesced -> per-lane layout
+	constexpr bool DMA = C0 >= 4 && !CU8; // tiles come straight from HBM into LDS (global_load_lds), no staging registers
+	constexpr int W4 = C0 / 2;            // 16-byte pieces per lane
+	__shared__ __attribute__((aligned(16))) float4 xt[DMA ? 64 * W4 : 1]; // the tile, linear, XOR-swizzled in units of 16 B
 	__shared__ __attribute__((aligned(16))) float2 x5[2][8 + 64];  // rotated up/down with 8 samples of history
 	__shared__ __attribute__((aligned(16))) float2 x6[2][8 + 32];  // DS2_a/b output
 	const int lane = threadIdx.x;
@@ -550,18 +559,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1
 	constexpr int TILE_BYTES = TILE_IN * (CU8 ? 2 : 8);
 	constexpr int LANE_BYTES = TILE_BYTES / 64;                    // 2^K * (2 or 8)
 	constexpr int NV = LANE_BYTES >= 16 ? LANE_BYTES / 16 : 1;      // 16-byte pieces per lane
-	uint4 pre[NV];
+	uint4 pre[DMA ? 1 : NV];
+	// DMA path.  Piece q (16 B) of lane r's row lives in LDS slot r*W4 + (q ^ (r % W4)): with the XOR the 8 lanes a
+	// ds_read_b128 serves per clock hit 8 different bank groups.  global_load_lds writes lane l of instruction e to slot
+	// 64*e + l, so that lane FETCHES the piece that belongs there (the swizzle is applied to the global address).
+	const int dma_r = lane / W4, dma_q = (lane % W4) ^ ((lane / W4) % W4); // slot 64*e + lane -> row 64/W4*e + dma_r, piece dma_q
 	auto prefetch = [&](int tile) {
 		const unsigned char* base;
 		if (tile < 0) base = (const unsigned char*)p.hist + (size_t)rx * TILE_BYTES;
 		else base = (const unsigned char*)p.in + ((size_t)rx * p.in_stride + (size_t)tile * TILE_IN) * (CU8 ? 2 : 8);
-		if constexpr (LANE_BYTES >= 16) {
+		if constexpr (DMA) {
+			const uint4* src = (const uint4*)base + dma_r * W4 + dma_q;
+#pragma unroll
+			for (int e = 0; e < NV; e++)
+				__builtin_amdgcn_global_load_lds((const void*)(src + e * 64), (__attribute__((address_space(3))) void*)(xt + e * 64), 16, 0, 0);
+		} else if constexpr (LANE_BYTES >= 16) {
 			const uint4* src = (const uint4*)base;
 #pragma unroll
-			for (int e = 0; e < NV; e++) {
-				if (CU8 || C0 < 4) pre[e] = src[lane * NV + e]; // the lane's own contiguous bytes
-				else pre[e] = src[e * 64 + lane];               // coalesced; transposed through LDS below
-			}
+			for (int e = 0; e < NV; e++) pre[e] = src[lane * NV + e]; // the lane's own contiguous bytes
 		} else if constexpr (LANE_BYTES == 8) {
 			const uint2 v = ((const uint2*)base)[lane];
 			pre[0] = make_uint4(v.x, v.y, 0, 0);
@@ -570,6 +585,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1
 		}
 	};
 	prefetch(tile_first);
+	float2 rot_next = make_float2(1.0f, 0.0f);
+	if (!PRE) rot_next = p.rot[(size_t)ROT_HIST + (long long)tile_first * 64 + lane];
 
 	for (int tile = tile_first; tile <= tile_last; tile++) {
 		c2 x[C0];
@@ -584,22 +601,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1
 			x[0] = c2{ __uint_as_float(pre[0].x), __uint_as_float(pre[0].y) };
 			x[1] = c2{ __uint_as_float(pre[0].z), __uint_as_float(pre[0].w) };
 		} else {
-			__syncthreads(); // single wave: orders the previous tile's reads against these writes
 #pragma unroll
-			for (int e = 0; e < NV; e++) {
-				const int s2 = e * 64 + lane; // float4 index inside the tile
-				xt[(s2 / (C0 / 2)) * W4 + (s2 % (C0 / 2))] = make_float4(__uint_as_float(pre[e].x), __uint_as_float(pre[e].y), __uint_as_float(pre[e].z), __uint_as_float(pre[e].w));
-			}
-			__syncthreads();
-#pragma unroll
-			for (int e = 0; e < C0 / 2; e++) { // every component is used, so these stay 128-bit loads
-				const float4 v = xt[lane * W4 + e];
+			for (int e = 0; e < W4; e++) { // every component is used, so these stay 128-bit loads
+				const float4 v = xt[lane * W4 + (e ^ (lane % W4))];
 				x[2 * e] = c2{ v.x, v.y }; x[2 * e + 1] = c2{ v.z, v.w };
 			}
+			wave_sync(); // the tile is in registers: the next one may land in xt
 		}
-		float2 rotv = make_float2(1.0f, 0.0f);
-		if (!PRE) rotv = p.rot[(size_t)ROT_HIST + (long long)tile * 64 + lane];
-		prefetch(tile + 1 <= tile_last ? tile + 1 : tile_last);
+		// the Rotate phasor travels one tile ahead like the samples: with a global_load_lds in flight the compiler
+		// waits for ALL vector memory operations at the first use of an ordinary load, so the only such use sits
+		// at the top of the loop, where the tile itself is awaited anyway
+		const float2 rotv = rot_next;
+		const int tile_n = tile + 1 <= tile_last ? tile + 1 : tile_last;
+		prefetch(tile_n);
+		if (!PRE) rot_next = p.rot[(size_t)ROT_HIST + (long long)tile_n * 64 + lane];
 
 		const c2 x96 = run_ladder<K>(x, st);
 		if constexpr (PRE) {
@@ -616,14 +631,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1
 			}
 			fdc_carry();
 			const float RR = y.x * rotv.x, II = y.y * rotv.y, RI = y.x * rotv.y, IR = y.y * rotv.x;
-			__syncthreads(); // previous tile's x5/x6 reads are complete
+			wave_sync(); // previous tile's x5/x6 reads are complete
 			x5[0][8 + lane] = make_float2(RR - II, IR + RI); // up   -> channel A
 			x5[1][8 + lane] = make_float2(RR + II, IR - RI); // down -> channel B
-			__syncthreads();
+			wave_sync();
 			// ---- DS2_a / DS2_b: lanes 0..31 channel A, lanes 32..63 channel B
 			const int ch = lane >> 5, j = lane & 31;
 			x6[ch][8 + j] = cic5_small(reinterpret_cast<const float4*>(&x5[ch][0]), j);
-			__syncthreads();
+			wave_sync();
 			// ---- FilterCIC5 (DSP.cpp:132-157)
 			{
 				const float2* src = &x6[ch][8 + j - 5];
@@ -640,7 +655,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1
 					*dst = make_float2(v[0].x * 0.03125f, v[0].y * 0.03125f);
 				}
 			}
-			__syncthreads();
+			wave_sync();
 			if (lane < 8) { x5[0][lane] = x5[0][64 + lane]; x5[1][lane] = x5[1][64 + lane]; }
 			else if (lane < 16) { x6[0][lane - 8] = x6[0][32 + lane - 8]; x6[1][lane - 8] = x6[1][32 + lane - 8]; }
 		}
