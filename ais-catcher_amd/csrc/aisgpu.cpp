@@ -36,6 +36,12 @@ const float TAPS_COHERENT[17] = { // DSP/Filters.h:35-41
 	1.16186141e-01f, 2.00730781e-01f, 2.40861391e-01f, 2.00730781e-01f, 1.16186141e-01f, 4.67076746e-02f,
 	1.30411453e-02f, 2.52892989e-03f, 3.40605309e-04f, 3.18610148e-05f, 2.06995719e-06f };
 
+const float TAPS_BH_28_3[26] = { // DSP/Filters.h:45-53 (Filters::BlackmanHarris_28_3)
+	6.32542387e-05f, -2.90015252e-04f, -1.54206250e-03f, -1.64972455e-03f, 3.12793899e-03f, 1.09494413e-02f, 9.04975801e-03f,
+	-1.43685846e-02f, -4.45615933e-02f, -3.44883647e-02f, 5.53474269e-02f, 2.01827915e-01f, 3.16534610e-01f, 3.16534610e-01f,
+	2.01827915e-01f, 5.53474269e-02f, -3.44883647e-02f, -4.45615933e-02f, -1.43685846e-02f, 9.04975801e-03f, 1.09494413e-02f,
+	3.12793899e-03f, -1.64972455e-03f, -1.54206250e-03f, -2.90015252e-04f, 6.32542387e-05f };
+
 struct EvPair { hipEvent_t a, b; };
 struct TraceRec { const char* name; long long block; hipEvent_t a, b; }; // AISGPU_TRACE=1: kernel timeline from HIP events
 constexpr int NBUF = 3;    // ring depth of the buffers that cross from the front-end stream to the others
@@ -47,6 +53,7 @@ enum Mode {
 	MODE_DIRECT,    // rate == 96k * 2^k, k <= 4: one fused front-end kernel
 	MODE_PRE,       // rate == 96k * 2^k, k = 5..7: (k-4) CIC5 stages in a pre-decimation pass, then the fused kernel
 	MODE_RESAMPLE,  // rate between two buckets: (k-2) CIC5 stages, Upsample to the bucket, DS2_2, DS2_1, ...
+	MODE_DSK,       // rate == 288k * 2^k: k CIC5 stages (or a plain conversion), DownsampleKFilter (/3), Rotate, ...
 };
 
 struct SubOut { int pb, q, groups; long long first_group, first48; };
@@ -109,6 +116,7 @@ struct aisgpu {
 	uint32_t* h_bits = nullptr; float* h_lvl = nullptr; float* h_ppm = nullptr; // MAXSUB slots each
 	// stream state
 	long long in_blocks = 0;     // input blocks run so far
+	int rot_period = 0;          // Rotate renormalisation period in 96 kHz samples (0: once per block)
 	long long block_idx = 0;     // downstream blocks run so far
 	long long n48 = 0;           // 48 kHz samples consumed before the current downstream block
 	float2 rot = { 1.0f, 0.0f }; // Rotate::rot carried across Receive() calls
@@ -165,14 +173,17 @@ void gen_rot_table(aisgpu_t* h, float2* tab) {
 	float2 r = h->rot;
 	const float2 m = h->mult;
 	float2* t = tab + ROT_HIST;
+	const int period = h->rot_period > 0 ? h->rot_period : h->n96; // samples per Rotate::Receive call
 	for (int i = 0; i < h->n96; i++) {
 		t[i] = r;
 		float re = r.x * m.x - r.y * m.y;
 		float im = r.x * m.y + r.y * m.x;
 		r.x = re; r.y = im;
+		if ((i + 1) % period == 0) { // rot /= std::abs(rot) at the end of every call (DSP.cpp:315)
+			float a = hypotf(r.x, r.y);
+			r.x /= a; r.y /= a;
+		}
 	}
-	float a = hypotf(r.x, r.y);
-	r.x /= a; r.y /= a;
 	h->rot = r;
 	for (int i = 0; i < ROT_HIST; i++) h->rot_tail[i] = t[h->n96 - ROT_HIST + i];
 }
@@ -446,24 +457,36 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	// ---- ladder selection, ModelFrontend::buildModel (DSP/Model.cpp:129-338): smallest bucket >= rate
 	static const int buckets[8] = { 96000, 192000, 384000, 768000, 1536000, 3072000, 6144000, 12288000 };
 	static const float alphas[8] = { 0.0f, -0.8f, -1.1f, -1.2f, -1.2f, -1.5f, -2.0f, -2.0f };
-	int k = -1;
+	// the reference's bucket lists also hold 288k and, with `-go DSK on`, 576k / 1152k / 2304k (Model.cpp:129-130)
+	static const int buckets3[4] = { 288000, 576000, 1152000, 2304000 };
+	const int n3 = (cfg->flags & AISGPU_FLAG_DSK) ? 4 : 1;
+	int k = -1, k3 = -1;
 	for (int i = 0; i < 8; i++) if (buckets[i] >= cfg->sample_rate) { k = i; break; }
-	if (k < 1 || cfg->sample_rate < 96000) return AISGPU_ERR_ARG;
-	const bool interpolated = buckets[k] != cfg->sample_rate;
+	for (int i = 0; i < n3; i++) if (buckets3[i] >= cfg->sample_rate && (k < 0 || buckets3[i] < buckets[k])) { k3 = i; break; }
+	if (cfg->sample_rate < 96000 || (k < 1 && k3 < 0)) return AISGPU_ERR_ARG;
 	Mode mode; int K, KP;
-	if (!interpolated) {
-		if (k <= 4) { mode = MODE_DIRECT; K = k; KP = 0; }
-		else { mode = MODE_PRE; K = 4; KP = k - 4; }
+	if (k3 >= 0) { // a decimate-by-3 bucket is the smallest one >= rate
+		if (buckets3[k3] != cfg->sample_rate) return AISGPU_ERR_ARG; // Upsample in front of DownsampleKFilter: not built
+		mode = MODE_DSK; K = 0; KP = k3; k = 0;
 	} else {
-		if (k < 3 || k > 6) return AISGPU_ERR_ARG; // the resampler sits two CIC5 stages in front of 96 kHz
-		mode = MODE_RESAMPLE; K = 0; KP = k - 2;
+		const bool interpolated = buckets[k] != cfg->sample_rate;
+		if (!interpolated) {
+			if (k <= 4) { mode = MODE_DIRECT; K = k; KP = 0; }
+			else { mode = MODE_PRE; K = 4; KP = k - 4; }
+		} else {
+			if (k < 3 || k > 6) return AISGPU_ERR_ARG; // the resampler sits two CIC5 stages in front of 96 kHz
+			mode = MODE_RESAMPLE; K = 0; KP = k - 2;
+		}
 	}
 	if (cfg->model != AISGPU_MODEL_DEFAULT && cfg->model != AISGPU_MODEL_CHALLENGER) return AISGPU_ERR_ARG;
 	if (cfg->input_format != AISGPU_FMT_CU8 && cfg->input_format != AISGPU_FMT_CF32) return AISGPU_ERR_ARG;
 	if (cfg->n_receivers < 1 || cfg->n_receivers > 65535) return AISGPU_ERR_ARG;
 	// a downstream block must be a whole number of 512-sample CGF windows
-	const int dec48 = 2 << k; // input samples per 48 kHz sample (bucket rate)
+	const int dec48 = mode == MODE_DSK ? 6 << KP : 2 << k; // input samples per 48 kHz sample (bucket rate)
 	if (cfg->block_len < 512 * dec48 || cfg->block_len % (512 * dec48) != 0) return AISGPU_ERR_ARG;
+	// DownsampleKFilter hands its output on in blocks of 8192 samples (DSP.h:193), whatever the input block was: only
+	// input blocks that are a whole number of them reproduce the reference's call pattern (its file block does)
+	if (mode == MODE_DSK && cfg->block_len % ((3 * 8192) << KP) != 0) return AISGPU_ERR_ARG;
 	if (aisgpu_device_count() <= cfg->device_id || cfg->device_id < 0) return AISGPU_ERR_NODEV;
 
 	aisgpu_t* h = new (std::nothrow) aisgpu();
@@ -484,6 +507,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->in_bytes = cfg->input_format == AISGPU_FMT_CU8 ? 2 : 8;
 	h->n_pre = cfg->block_len >> KP;
 	if (mode == MODE_RESAMPLE) h->n96 = h->n_pre / 4; // one flush of n_pre samples at the bucket rate >> KP (= 384 kHz)
+	else if (mode == MODE_DSK) h->n96 = h->n_pre / 3;
 	else h->n96 = h->n_pre >> K;
 	h->L = h->n96 / 2;
 	h->W = h->L / 512;
@@ -492,10 +516,11 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->words = h->Gcap / 32;
 	h->n_chan = cfg->n_receivers * 2;
 	h->n_chains = h->n_chan * 5;
-	h->has_fdc = cfg->droop ? 1 : 0;
+	h->has_fdc = cfg->droop && mode != MODE_DSK ? 1 : 0; // no droop filter on the decimate-by-3 ladders (Model.cpp:207-219)
 	h->alpha = alphas[k];
 	h->beta = 1 - 2 * h->alpha; // DSP/DSP.h:296, evaluated in float
 	h->us_increment = (float)cfg->sample_rate / (float)buckets[k]; // DSP/DSP.h:172-176
+	h->rot_period = mode == MODE_DSK ? 8192 : 0; // Rotate is called once per DownsampleKFilter output block
 	if (K > 0) {
 		h->tile_in = h->tile96 << K;
 		if (h->n_pre % h->tile_in) { delete h; return AISGPU_ERR_ARG; }
@@ -511,6 +536,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		h->pspans = (h->ptiles_per_block + h->ptiles_per_span - 1) / h->ptiles_per_span;
 		h->xh = mode == MODE_RESAMPLE ? h->n_pre + XPAD : 0;
 	}
+	if (mode == MODE_DSK) h->xh = DSK_HIST;
 	*out = h; // from here on the caller destroys it on failure
 
 	HIPCHK(hipSetDevice(cfg->device_id));
@@ -590,13 +616,13 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	const size_t R = cfg->n_receivers, C = h->n_chan;
 	// history of the raw input: the last tile of the previous block (for the first kernel that touches the input)
 	{
-		const size_t first_tile = KP > 0 ? h->ptile_in : h->tile_in;
+		const size_t first_tile = KP > 0 ? h->ptile_in : (h->tile_in > 0 ? h->tile_in : 64);
 		HIPCHK(dalloc((unsigned char**)&h->d_hist, R * first_tile * h->in_bytes));
 		// zero signal before the stream starts: CU8 zero is the byte 128 (Utilities/Convert.cpp:255-264)
 		if (cfg->input_format == AISGPU_FMT_CU8) HIPCHK(hipMemset(h->d_hist, 0x80, R * first_tile * h->in_bytes));
 	}
-	if (KP > 0) {
-		const int nx = mode == MODE_RESAMPLE ? 2 : 1;
+	if (KP > 0 || mode == MODE_DSK) {
+		const int nx = mode == MODE_RESAMPLE || mode == MODE_DSK ? 2 : 1;
 		for (int i = 0; i < nx; i++) HIPCHK(dalloc(&h->d_xpre[i], R * ((size_t)h->xh + h->n_pre)));
 		if (mode == MODE_PRE) HIPCHK(dalloc((unsigned char**)&h->d_hist2, R * h->tile_in * 8));
 	}
@@ -762,11 +788,19 @@ int aisgpu_run(aisgpu_t* h) {
 	// ---- pre-decimation pass (MODE_PRE / MODE_RESAMPLE): KP CIC5 stages at the input rate -> d_xpre
 	float2* xcur = nullptr;
 	long long xstride = 0;
-	if (h->KP > 0) {
-		const int xb = h->mode == MODE_RESAMPLE ? (int)(h->in_blocks & 1) : 0;
+	if (h->KP == 0 && h->mode == MODE_DSK) { // 288 kHz input: no CIC5 stage in front of DownsampleKFilter, only the conversion
+		const int xb = (int)(h->in_blocks & 1);
 		xcur = h->d_xpre[xb];
 		xstride = (long long)h->xh + h->n_pre;
-		if (h->mode == MODE_RESAMPLE && h->in_blocks > 0) // history = the last xh samples before this block
+		if (h->in_blocks > 0) HIPCHK(launch_copy_rows(h->d_xpre[xb ^ 1] + h->n_pre, xstride, xcur, xstride, h->xh, R, h->stream));
+		HIPCHK(launch_convert_rows(h->cur_in, h->cur_in_stride, cu8 ? 1 : 0, xcur + h->xh, xstride, h->n_pre, R, h->stream));
+	}
+	if (h->KP > 0) {
+		const bool two = h->mode == MODE_RESAMPLE || h->mode == MODE_DSK;
+		const int xb = two ? (int)(h->in_blocks & 1) : 0;
+		xcur = h->d_xpre[xb];
+		xstride = (long long)h->xh + h->n_pre;
+		if (two && h->in_blocks > 0) // history = the last xh samples before this block
 			HIPCHK(launch_copy_rows(h->d_xpre[xb ^ 1] + h->n_pre, xstride, xcur, xstride, h->xh, R, h->stream));
 		K1Params kp{};
 		kp.in = h->cur_in; kp.in_stride = h->cur_in_stride; kp.hist = h->d_hist; kp.rot = nullptr;
@@ -781,7 +815,24 @@ int aisgpu_run(aisgpu_t* h) {
 		                      h->ptile_in * h->in_bytes, R, h->stream));
 	}
 
-	if (h->mode != MODE_RESAMPLE) {
+	if (h->mode == MODE_DSK) {
+		// ---- decimate-by-3 ladder: one downstream block per input block (block_len is a whole number of the
+		// filter's 8192-sample output blocks, so the reference hands everything on within the same call)
+		const int pb = (int)(h->block_idx & 1);
+		const int q = (int)(h->block_idx % NBUF);
+		if (h->block_idx >= 2) HIPCHK(hipEventSynchronize(h->rot_ev[pb]));
+		gen_rot_table(h, h->h_rot[pb]);
+		HIPCHK(hipMemcpyAsync(h->d_rot[pb], h->h_rot[pb], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
+		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[q], 0));
+		K1kParams kk;
+		kk.xin = xcur; kk.xin_stride = xstride; kk.xin_off = h->xh;
+		kk.rot = h->d_rot[pb]; kk.c48 = h->d_c48[q]; kk.c48_stride = h->c48s; kk.L = h->L;
+		memcpy(kk.taps, TAPS_BH_28_3, sizeof kk.taps);
+		HIPCHK(launch_k1k(kk, R, h->stream));
+		int rc = enqueue_downstream(h, q, pb);
+		if (rc) return rc;
+	} else if (h->mode != MODE_RESAMPLE) {
 		// ---- one downstream block per input block
 		const int pb = (int)(h->block_idx & 1);
 		const int q = (int)(h->block_idx % NBUF); // ring slot of c48 / fz / ppm / rotT

@@ -34,6 +34,15 @@ struct K1uParams {
 	int L;                  // 48 kHz samples per channel per flush block (len / 8)
 };
 
+struct K1kParams { // decimate-by-3 front end (DownsampleKFilter ladders: 288k * 2^k)
+	const float2* xin; long long xin_stride; long long xin_off; // 288 kHz stream of the current block (i < 0: history, >= 70 samples)
+	const float2* rot;      // [ROT_HIST + n96]
+	float2* c48; long long c48_stride;
+	float taps[26];         // Filters::BlackmanHarris_28_3
+	int L;                  // 48 kHz samples per channel per block
+};
+constexpr int DSK_HIST = 128; // samples of the 288 kHz stream kept in front of a block
+
 struct K2Params {
 	const float2* c48; long long c48_stride;
 	float2* cgf; long long cgf_stride;   // [n_chan][CGF_HIST + L]
@@ -102,6 +111,8 @@ hipError_t launch_k1u(const K1uParams& p, int n_rx, hipStream_t s);
 hipError_t launch_copy_rows(const float2* src, long long src_stride, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
 hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long block_bytes, void* hist, int tail_bytes,
                           int n_rx, hipStream_t s);
+hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s);
+hipError_t launch_convert_rows(const void* in, long long in_stride, int cu8, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
 hipError_t launch_k2a_fft(const K2Params& p, int n_chan, hipStream_t s);
 hipError_t launch_k2a_search(const K2Params& p, int n_chan, hipStream_t s);
 hipError_t launch_selftest_hypot(const float2* in, int n, unsigned* mismatches, hipStream_t s);

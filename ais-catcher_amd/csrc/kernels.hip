@@ -749,6 +749,71 @@ __global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
 	}
 }
 
+// ------------------------------------------------------------------------------------------
+// K1k: the tail of a decimate-by-3 ladder (rates 288k * 2^k, Model.cpp:207-219,248-259,278-289,308-313):
+// DownsampleKFilter (26-tap Blackman-Harris FIR, keep every 3rd output, DSP.cpp:160-189, DSP.h:195-201) ->
+// Rotate -> DS2_a/b -> FilterCIC5 (no droop filter on these ladders).  With block lengths that are a multiple
+// of 3 the filter's input phase is 0 at every block start, so 96 kHz sample i of a block is
+// sum_t taps[t] * x[3 i + t - 25] (accumulated left to right from 0).  Same tile scheme as K1u: a workgroup
+// produces 32 outputs per channel and recomputes the short halos of every stage.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k1k_dsk_frontend(K1kParams p) {
+	constexpr int M = K1U_M;
+	__shared__ float2 X[6 * M + 72];       // x(n), n in [6 m0 - 70, 6 m0 + 6 M)
+	__shared__ float2 RU[2][2 * M + 16];   // rotated up/down, i in [2 m0 - 15, 2 m0 + 2 M)
+	__shared__ float2 DD[2][M + 6];        // DS2_a/b output,  j in [m0 - 5, m0 + M)
+	const int t = threadIdx.x;
+	const int rx = blockIdx.y;
+	const int m0 = blockIdx.x * M;
+	const float2* x = p.xin + (size_t)rx * p.xin_stride + p.xin_off;
+	const int n_lo = 6 * m0 - 70;
+	for (int q = t; q < 6 * M + 70; q += 256) X[q] = x[n_lo + q];
+	__syncthreads();
+	for (int q = t; q < 2 * M + 15; q += 256) { // i = 2 m0 - 15 + q
+		const int i = 2 * m0 - 15 + q;
+		const float2* d = X + (3 * i - 25 - n_lo);
+		float2 acc = make_float2(0.0f, 0.0f);
+#pragma unroll
+		for (int k = 0; k < 26; k++) acc = make_float2(acc.x + p.taps[k] * d[k].x, acc.y + p.taps[k] * d[k].y);
+		const float2 rot = p.rot[ROT_HIST + i];
+		const float RR = acc.x * rot.x, II = acc.y * rot.y, RI = acc.x * rot.y, IR = acc.y * rot.x; // DSP.cpp:296-316
+		RU[0][q] = make_float2(RR - II, IR + RI);
+		RU[1][q] = make_float2(RR + II, IR - RI);
+	}
+	__syncthreads();
+	for (int q = t; q < 2 * (M + 5); q += 256) { // DS2_a / DS2_b: j = m0 - 5 + jj needs up(2j-5..2j)
+		const int ch = q / (M + 5), jj = q % (M + 5);
+		const int j = m0 - 5 + jj;
+		DD[ch][jj] = cic5_at(RU[ch], 2 * j - (2 * m0 - 15));
+	}
+	__syncthreads();
+	if (t < 2 * M) { // FilterCIC5 (DSP.cpp:132-157)
+		const int ch = t / M, mm = t % M;
+		float2 v[6];
+#pragma unroll
+		for (int e = 0; e < 6; e++) v[e] = DD[ch][mm + e]; // d(m-5 .. m)
+#pragma unroll
+		for (int lvl = 0; lvl < 5; lvl++) {
+#pragma unroll
+			for (int i = 0; i < 5 - lvl; i++) v[i] = cadd(v[i + 1], v[i]);
+		}
+		p.c48[((size_t)rx * 2 + ch) * p.c48_stride + m0 + mm] = make_float2(v[0].x * 0.03125f, v[0].y * 0.03125f);
+	}
+}
+
+// raw input rows -> complex float rows (Utilities/Convert.cpp:255-264 for CU8), for ladders without a CIC5 pre-pass
+__global__ void k_convert_rows(const unsigned char* in, long long in_stride_bytes, int cu8, float2* dst, long long dst_stride, int n) {
+	const int rx = blockIdx.y;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		float2 v;
+		if (cu8) {
+			const unsigned char* u = in + (size_t)rx * in_stride_bytes + 2 * (size_t)i;
+			v = make_float2((float)((int)u[0] - 128) * 0.0078125f, (float)((int)u[1] - 128) * 0.0078125f);
+		} else v = reinterpret_cast<const float2*>(in + (size_t)rx * in_stride_bytes)[i];
+		dst[(size_t)rx * dst_stride + i] = v;
+	}
+}
+
 // copy rows of float2 (history carry of the pre-decimated stream)
 __global__ void k_copy_rows(const float2* src, long long src_stride, float2* dst, long long dst_stride, int n) {
 	const int rx = blockIdx.y;
@@ -1747,6 +1812,18 @@ hipError_t launch_k1(const K1Params& p, int K, bool cu8, int tile96, int depth, 
 
 hipError_t launch_k1u(const K1uParams& p, int n_rx, hipStream_t s) {
 	hipLaunchKernelGGL(k1u_resample_frontend, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s) {
+	hipLaunchKernelGGL(k1k_dsk_frontend, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_convert_rows(const void* in, long long in_stride, int cu8, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s) {
+	int blocks = (n + 255) / 256;
+	if (blocks > 256) blocks = 256;
+	hipLaunchKernelGGL(k_convert_rows, dim3(blocks, n_rx), dim3(256), 0, s, (const unsigned char*)in, in_stride * (cu8 ? 2 : 8), cu8, dst, dst_stride, n);
 	return hipGetLastError();
 }
 

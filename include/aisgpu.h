@@ -53,12 +53,14 @@ extern "C" {
 
 #define AISGPU_FLAG_TAPS 1    /* keep intermediate float taps readable via aisgpu_tap() (tests) */
 #define AISGPU_FLAG_SERIAL 2  /* profiling aid: one stream, no overlap between the kernels of consecutive blocks */
+#define AISGPU_FLAG_DSK 4     /* KEY_SETTING_DSK (`-go DSK on`): 576k / 1152k / 2304k use the decimate-by-3 ladder (Model.cpp:130) */
 
 typedef struct aisgpu aisgpu_t;
 
 typedef struct aisgpu_cfg {
-	int sample_rate;   /* 96000*2^k for k = 1..7 (192k .. 12288k), or any rate in (384k, 6144k) that the reference
-	                    * resamples up to the next bucket, e.g. 6000000 (Model.cpp:129-338) */
+	int sample_rate;   /* 96000*2^k for k = 1..7 (192k .. 12288k); any rate in (384k, 6144k) that the reference resamples up
+	                    * to the next 2^k bucket, e.g. 6000000; 288000, and with AISGPU_FLAG_DSK 576000 / 1152000 / 2304000
+	                    * (DownsampleKFilter ladders; block_len must then be a multiple of 24576 * rate/288000) (Model.cpp:129-338) */
 	int n_receivers;   /* independent dual-channel receiver instances batched on this GPU */
 	int block_len;     /* IQ samples per receiver per Receive() block; multiple of 512 * bucket_rate/48000 */
 	int model;         /* AISGPU_MODEL_DEFAULT or AISGPU_MODEL_CHALLENGER */

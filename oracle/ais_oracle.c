@@ -274,6 +274,42 @@ static float psema_step(psema_t* p, cf x, int nDelay) {
 	return (b1 ^ b2) ? 1.0f : -1.0f;
 }
 
+/* a9': Demod::PhaseSearch (Demod.cpp:103-170), the boxcar variant used with `-go PS_EMA off`: |t| of the last nHistory
+ * symbols in a ring, summed in SLOT order (not time order), first maximum over prev-2 .. prev+2 starting from max_val = 0 */
+typedef struct { float memory[16][14]; uint8_t bits[16]; int max_idx, rot, last; } psbox_t;
+
+static float psbox_step(psbox_t* p, cf x, int nHistory, int nDelay) {
+	float re = 0, im = 0;
+	switch (p->rot) {
+	case 0: re = x.re; im = x.im; break;
+	case 1: im = x.re; re = -x.im; break;
+	case 2: re = -x.re; im = -x.im; break;
+	case 3: im = -x.re; re = x.im; break;
+	}
+	p->rot = (p->rot + 1) & 3;
+	for (int j = 0; j < 8; j++) {
+		float t, a = re * PS_PHASE[j].re, b = im * PS_PHASE[j].im;
+		t = a + b;
+		p->bits[j] = (uint8_t)((p->bits[j] << 1) | (t > 0));
+		p->memory[j][p->last] = fabsf(t);
+		t = a - b;
+		p->bits[15 - j] = (uint8_t)((p->bits[15 - j] << 1) | (t > 0));
+		p->memory[15 - j][p->last] = fabsf(t);
+	}
+	p->last = (p->last + 1) % nHistory;
+	float max_val = 0;
+	int prev_max = p->max_idx;
+	for (int q = 16 + prev_max - 2; q <= 16 + prev_max + 2; q++) { /* nSearch = 2 */
+		int j = q % 16;
+		float avg = p->memory[j][0];
+		for (int l = 1; l < nHistory; l++) avg += p->memory[j][l];
+		if (avg > max_val) { max_val = avg; p->max_idx = j; }
+	}
+	int b2 = (p->bits[p->max_idx] >> (nDelay + 1)) & 1;
+	int b1 = (p->bits[p->max_idx] >> nDelay) & 1;
+	return (b1 ^ b2) ? 1.0f : -1.0f;
+}
+
 /* ---------------------------------------------------------------- a10: AIS::Decoder + NMEA (Marine/AIS.h:82-181, AIS.cpp:33-142,
  *                                                                   Marine/Message.h:36-41,171-183,264-281, Message.cpp:398-413,569-686) */
 #define MAX_AIS_LENGTH 1064
@@ -464,6 +500,7 @@ typedef struct {
 	/* ScatterPLL (DSP.h:76-117) */
 	cf sample[5]; int lastSymbol; float level; long long sample_idx;
 	psema_t ps[5];
+	psbox_t pb[5];
 	ao_dec dec[5];
 	/* Challenger FM branch: Demod::FM (Demod.cpp:27-37), Filter (Receiver taps), Deinterleave(5) (DSP.h:51-74) */
 	cf fm_prev; float fr_hist[36]; int fm_last; long long fm_idx;
@@ -474,7 +511,9 @@ typedef struct {
 
 struct ao_chain {
 	int model, fmt, rate, taps;
-	int npre, npost, has_us, has_fdc;
+	int npre, npost, has_us, has_fdc, has_dsk, ps_ema;
+	/* DownsampleKFilter (DSP.cpp:160-189, DSP.h:181-211): BlackmanHarris_28_3, K = 3, output blocks of 8192 */
+	cf* dsk_buf; long long dsk_cap; cf dsk_out[8192]; int dsk_in, dsk_idx_out;
 	float fdc_alpha;
 	cic5_t pre[8], post[2];
 	ups_t us;
@@ -499,7 +538,7 @@ static void coherent_branch(ao_chain* c, chan_t* ch, const cf* x, int n) {
 			if (c->tag.mode & 1) c->tag.sample_lvl = ch->level / 5;
 			for (int j = 0; j < 5; j++) {
 				c->tag.sample_idx = ch->sample_idx++;
-				float b = psema_step(&ch->ps[j], ch->sample[j], 3);
+				float b = c->ps_ema ? psema_step(&ch->ps[j], ch->sample[j], 3) : psbox_step(&ch->pb[j], ch->sample[j], 12, 3); /* Model.h:218-219 */
 				dec_run(&ch->dec[j], b, &c->tag, &c->sink);
 				if (c->taps) { fv_push(&ch->br[j].bits, &b, 1); fv_push(&ch->br[j].lvl, &c->tag.sample_lvl, 1); lv_push1(&ch->br[j].idx, c->tag.sample_idx); }
 			}
@@ -577,6 +616,34 @@ static void post_us(ao_chain* c, const cf* x, int n) { /* DS2_2 -> DS2_1 (or few
 	if (bufs[1]) free(bufs[1]);
 }
 
+static const float TAPS_BH_28_3[26] = { /* DSP/Filters.h:45-53 */
+	6.32542387e-05f, -2.90015252e-04f, -1.54206250e-03f, -1.64972455e-03f, 3.12793899e-03f, 1.09494413e-02f, 9.04975801e-03f,
+	-1.43685846e-02f, -4.45615933e-02f, -3.44883647e-02f, 5.53474269e-02f, 2.01827915e-01f, 3.16534610e-01f, 3.16534610e-01f,
+	2.01827915e-01f, 5.53474269e-02f, -3.44883647e-02f, -4.45615933e-02f, -1.43685846e-02f, 9.04975801e-03f, 1.09494413e-02f,
+	3.12793899e-03f, -1.64972455e-03f, -1.54206250e-03f, -2.90015252e-04f, 6.32542387e-05f };
+
+static void dsk_run(ao_chain* c, const cf* data, int len) { /* DSP.cpp:160-189 */
+	const int nt = 26, K = 3;
+	if (len < nt - 1) return;
+	if (c->dsk_cap < len + nt) {
+		cf* nb = (cf*)calloc((size_t)len + nt, sizeof(cf));
+		if (c->dsk_buf) { memcpy(nb, c->dsk_buf, sizeof(cf) * (nt - 1)); free(c->dsk_buf); }
+		c->dsk_buf = nb; c->dsk_cap = len + nt;
+	}
+	cf* buffer = c->dsk_buf;
+	for (int i = 0, j = nt - 1; i < len; i++, j++) buffer[j] = data[i];
+	while (c->dsk_in < len) {
+		cf x = { 0.0f, 0.0f };
+		const cf* d = &buffer[c->dsk_in];
+		for (int i = 0; i < nt; i++) { x.re += TAPS_BH_28_3[i] * d[i].re; x.im += TAPS_BH_28_3[i] * d[i].im; } /* DSP.h:195-201 */
+		c->dsk_out[c->dsk_idx_out] = x;
+		if (++c->dsk_idx_out == 8192) { frontend_96k(c, c->dsk_out, 8192); c->dsk_idx_out = 0; }
+		c->dsk_in += K;
+	}
+	c->dsk_in -= len;
+	for (int j = 0, i = len - nt + 1; j < nt - 1; i++, j++) buffer[j] = data[i];
+}
+
 static void upsample_run(ao_chain* c, const cf* x, int len) { /* DSP.cpp:192-212 */
 	ups_t* u = &c->us;
 	if (u->cap < len) { u->out = (cf*)realloc(u->out, sizeof(cf) * (size_t)len); u->cap = len; }
@@ -614,27 +681,40 @@ int ao_feed(ao_chain* c, const void* data, int nbytes) {
 		in = o; m /= 2;
 		o = (o == c->b1) ? c->b0 : c->b1;
 	}
-	if (c->has_us) upsample_run(c, in, m);
+	if (c->has_dsk) dsk_run(c, in, m);
+	else if (c->has_us) upsample_run(c, in, m);
 	else post_us(c, in, m);
 	return 0;
 }
 
-ao_chain* ao_create(int model, int sample_rate, int fmt, int taps) {
-	static const unsigned buckets[] = { 96000, 192000, 384000, 768000, 1536000, 3072000, 6144000, 12288000 };
-	static const float alphas[] = { 0.0f, -0.8f, -1.1f, -1.2f, -1.2f, -1.5f, -2.0f, -2.0f }; /* Model.cpp:157-338 */
+ao_chain* ao_create(int model, int sample_rate, int fmt, int flags) {
+	/* flags: bit 0 record taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off` */
+	static const unsigned buckets_nodsk[] = { 96000, 192000, 288000, 384000, 768000, 1536000, 3072000, 6144000, 12288000 }; /* Model.cpp:129-130 */
+	static const unsigned buckets_dsk[] = { 96000, 192000, 288000, 384000, 576000, 768000, 1152000, 1536000, 2304000, 3072000, 6144000, 12288000 };
+	const int taps = flags & 1, dsk = (flags >> 1) & 1;
+	const unsigned* buckets = dsk ? buckets_dsk : buckets_nodsk;
+	const int nb = dsk ? 12 : 9;
 	tables_init();
-	int k = -1;
-	for (int i = 0; i < 8; i++) if (buckets[i] >= (unsigned)sample_rate) { k = i; break; }
-	if (k < 0 || sample_rate < 96000) return NULL;
-	/* the decimate-by-3 rates (288k, and 576k/1152k/2304k with DSK) are outside this oracle */
+	int bi = -1;
+	for (int i = 0; i < nb; i++) if (buckets[i] >= (unsigned)sample_rate) { bi = i; break; }
+	if (bi < 0 || sample_rate < 96000) return NULL;
+	const unsigned bucket = buckets[bi];
+	int k = 0, is3 = 0; /* bucket = 96000 * 2^k or 288000 * 2^k */
+	if (bucket % 288000 == 0) { is3 = 1; while ((288000u << k) != bucket) k++; }
+	else while ((96000u << k) != bucket) k++;
+	/* interpolation into a decimate-by-3 bucket (US >> DSK) is outside this oracle */
+	if (is3 && bucket != (unsigned)sample_rate) return NULL;
+	static const float alphas[] = { 0.0f, -0.8f, -1.1f, -1.2f, -1.2f, -1.5f, -2.0f, -2.0f }; /* Model.cpp:157-338 */
 	ao_chain* c = (ao_chain*)calloc(1, sizeof(ao_chain));
 	c->model = model; c->fmt = fmt; c->rate = sample_rate; c->taps = taps;
-	c->has_us = buckets[k] != (unsigned)sample_rate;
-	c->has_fdc = k > 0;
-	c->fdc_alpha = alphas[k];
+	c->ps_ema = !((flags >> 2) & 1);
+	c->has_dsk = is3;
+	c->has_us = !is3 && bucket != (unsigned)sample_rate;
+	c->has_fdc = !is3 && k > 0; /* the decimate-by-3 ladders have no droop compensation (Model.cpp:207-219 etc.) */
+	c->fdc_alpha = is3 ? 0.0f : alphas[k];
 	if (c->has_us) { c->npost = k >= 2 ? 2 : k; c->npre = k - c->npost; }
 	else { c->npre = k; c->npost = 0; }
-	c->us.increment = (float)sample_rate / (float)buckets[k];
+	c->us.increment = (float)sample_rate / (float)bucket;
 	c->rot.re = 1.0f; c->rot.im = 0.0f;
 	ao_rotate_mult((float*)&c->mult);
 	c->tag.mode = 3; /* Common.h:242 */
@@ -663,6 +743,7 @@ ao_chain* ao_create(int model, int sample_rate, int fmt, int taps) {
 static void fv_free(fvec* v) { free(v->p); }
 void ao_destroy(ao_chain* c) {
 	if (!c) return;
+	free(c->dsk_buf);
 	for (int q = 0; q < 2; q++) {
 		chan_t* ch = &c->ch[q];
 		fv_free(&ch->tap48); fv_free(&ch->tapcgf); fv_free(&ch->tapfir); fv_free(&ch->ppm_cgf); fv_free(&ch->ppm_fir);

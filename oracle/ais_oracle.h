@@ -20,8 +20,10 @@ extern "C" {
 
 typedef struct ao_chain ao_chain;
 
-/* model: 2 = ModelDefault, 4 = ModelChallenger.  fmt: 0 = CU8, 1 = CF32.  taps: record taps. */
-ao_chain* ao_create(int model, int sample_rate, int fmt, int taps);
+/* model: 2 = ModelDefault, 4 = ModelChallenger.  fmt: 0 = CU8, 1 = CF32.
+ * flags: bit 0 record taps, bit 1 `-go DSK on` (decimate-by-3 ladders for 576k/1152k/2304k), bit 2 `-go PS_EMA off`
+ * (PhaseSearch with a boxcar history instead of PhaseSearchEMA). */
+ao_chain* ao_create(int model, int sample_rate, int fmt, int flags);
 void ao_destroy(ao_chain*);
 /* one call == one reference Receive() block (call boundaries are part of the numerical contract:
  * Rotate renormalises once per call, Source/DSP/DSP.cpp:315) */

@@ -94,13 +94,17 @@ struct Harness {
 
 extern "C" {
 
-// kind: 2 = ModelDefault, 4 = ModelChallenger.  fmt: 0 = CU8, 1 = CF32.  taps: record float taps
-void* ref_create(int kind, int sample_rate, int fmt, int taps) {
+// kind: 2 = ModelDefault, 4 = ModelChallenger.  fmt: 0 = CU8, 1 = CF32.
+// flags: bit 0 record float taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`
+void* ref_create(int kind, int sample_rate, int fmt, int flags) {
+	const int taps = flags & 1;
 	try {
 		Format f = fmt == 0 ? Format::CU8 : Format::CF32;
 		Harness* h = new Harness(f, sample_rate);
 		if (kind == 4) { h->mc = new AIS::ModelChallenger(); h->model = h->mc; }
 		else { h->md = new AIS::ModelDefault(); h->model = h->md; }
+		if (flags & 2) h->model->SetKey(AIS::KEY_SETTING_DSK, "ON");
+		if (flags & 4) h->model->SetKey(AIS::KEY_SETTING_PS_EMA, "OFF");
 		h->model->buildModel('A', 'B', sample_rate, false, &h->dev);
 		h->model->Output() >> h->sink;
 		h->dev.setTag(h->tag);
@@ -114,8 +118,8 @@ void* ref_create(int kind, int sample_rate, int fmt, int taps) {
 				h->md->FC_a.out >> h->tap[4];  h->md->FC_b.out >> h->tap[5];
 				for (int j = 0; j < 5; j++) {
 					h->bits[0][j].on = h->bits[1][j].on = true;
-					h->md->CD_EMA_a[j].out >> h->bits[0][j];
-					h->md->CD_EMA_b[j].out >> h->bits[1][j];
+					if (flags & 4) { h->md->CD_a[j].out >> h->bits[0][j]; h->md->CD_b[j].out >> h->bits[1][j]; }
+					else { h->md->CD_EMA_a[j].out >> h->bits[0][j]; h->md->CD_EMA_b[j].out >> h->bits[1][j]; }
 				}
 			} else {
 				h->mc->CGF_a.out >> h->tap[2]; h->mc->CGF_b.out >> h->tap[3];

@@ -43,3 +43,26 @@ def test_create_rejects_bad_config_without_gpu_work():
     cfg.block_len = 1000
     assert lib.aisgpu_create(ctypes.byref(cfg), ctypes.byref(h)) == 1 and not h
     assert lib.aisgpu_strerror(2).decode().startswith("no usable")
+
+
+def test_create_ladder_selection_for_decimate_by_3_rates():
+    """Argument validation runs before any device is touched: unsupported -> 1 (ARG); supported -> 0 or 2 (no device here)."""
+    lib = gpu.load()
+    cfg = gpu.Cfg()
+    h = ctypes.c_void_p()
+
+    def rc(rate, block, flags=0):
+        lib.aisgpu_default_cfg(ctypes.byref(cfg))
+        cfg.sample_rate, cfg.block_len, cfg.flags = rate, block, flags
+        r = lib.aisgpu_create(ctypes.byref(cfg), ctypes.byref(h))
+        if h:
+            lib.aisgpu_destroy(h)
+            h.value = None
+        return r
+
+    assert rc(288000, 24576 * 4) in (0, 2)                   # DownsampleKFilter ladder, no option needed (Model.cpp:129)
+    assert rc(288000, 3072 * 5) == 1                          # not a whole number of the filter's 8192-sample output blocks
+    assert rc(2304000, 24576 * 8 * 2, gpu.FLAG_DSK) in (0, 2)
+    assert rc(2304000, 512 * 64 * 6) in (0, 2)                # without the option 2304k is resampled up to 3072k
+    assert rc(500000, 786432, gpu.FLAG_DSK) == 1              # would need Upsample in front of DownsampleKFilter
+    assert rc(500000, 786432) in (0, 2)                       # resampled up to 768k

@@ -28,10 +28,11 @@ def _feq(a, b):
 def _run_gpu_vs_oracle(streams, rate, fmt, block, nblocks, **kw):
     """streams: list of per-receiver arrays.  Compares every block's taps and outputs per receiver."""
     R = len(streams)
+    okw = dict(dsk=kw.get("dsk", False))
     g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block,
                    input_format=gpu.FMT_CU8 if fmt == "cu8" else gpu.FMT_CF32, taps=True, **kw)
     per = 2 if fmt == "cu8" else 1
-    oracles = [checkers.Oracle(model=2, rate=rate, fmt=fmt, taps=True) for _ in range(R)]
+    oracles = [checkers.Oracle(model=2, rate=rate, fmt=fmt, taps=True, **okw) for _ in range(R)]
     for o, x in zip(oracles, streams):
         o.feed_blocks(x, block)
     otaps = [[o.tap(w) for w in range(6)] for o in oracles]
@@ -390,3 +391,12 @@ def test_fft_bin_magnitude_matches_hypot_restatement():
         x = np.ascontiguousarray(x, np.float32)
         bad = lib.aisgpu_selftest(0, 0, x.ctypes.data_as(ctypes.c_void_p), x.shape[0])
         assert bad == 0
+
+
+@pytest.mark.parametrize("rate,dsk", [(288000, False), (576000, True), (1152000, True), (2304000, True)])
+def test_decimate_by_3_ladders(rate, dsk):
+    """DownsampleKFilter ladders (a15): 288k needs no option, the others `-go DSK on`; CF32 and CU8."""
+    block = 24576 * (rate // 288000) * 2
+    x = synth.receiver_stream(block * 3, sample_rate=rate, receiver_id=31, gap_slots=(1, 2))
+    _run_gpu_vs_oracle([x], rate, "cf32", block, 3, dsk=dsk)
+    _run_gpu_vs_oracle([synth.to_cu8(x)], rate, "cu8", block, 3, dsk=dsk)

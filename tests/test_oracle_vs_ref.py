@@ -10,11 +10,11 @@ from ais_catcher_amd import synth
 pytestmark = pytest.mark.skipif(not checkers.have_ref("strict"), reason="oracle/_ref not built")
 
 
-def _compare(model, rate, fmt, block, nblocks, rid, fm=False, **kw):
+def _compare(model, rate, fmt, block, nblocks, rid, fm=False, dsk=False, ps_ema=True, **kw):
     x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=rid, **kw)
     data = synth.to_cu8(x) if fmt == "cu8" else x
-    o = checkers.Oracle(model=model, rate=rate, fmt=fmt, taps=True)
-    r = checkers.Ref(model=model, rate=rate, fmt=fmt, taps=True)
+    o = checkers.Oracle(model=model, rate=rate, fmt=fmt, taps=True, dsk=dsk, ps_ema=ps_ema)
+    r = checkers.Ref(model=model, rate=rate, fmt=fmt, taps=True, dsk=dsk, ps_ema=ps_ema)
     o.feed_blocks(data, block)
     r.feed_blocks(data, block)
     for w in range(6):
@@ -73,3 +73,25 @@ def test_strict_and_shipped_builds_decode_the_same():
     a.feed_blocks(x, 786432)
     b.feed_blocks(x, 786432)
     assert sorted(a.nmea()) == sorted(b.nmea()) and len(a.nmea()) > 5
+
+
+def test_decimate_by_3_ladder_288k():
+    """DownsampleKFilter (DSP.cpp:160-189): the 288 kHz bucket needs no option; Rotate then runs on its 8192-sample blocks."""
+    lines = _compare(2, 288000, "cf32", 24576 * 4, 6, rid=21, gap_slots=(1, 2))
+    assert len(lines) >= 3
+
+
+@pytest.mark.parametrize("rate", [576000, 1152000, 2304000])
+def test_decimate_by_3_ladders_with_dsk(rate):
+    _compare(2, rate, "cf32", 24576 * (rate // 288000) * 2, 6, rid=22, dsk=True, gap_slots=(1, 2))
+
+
+def test_dsk_input_blocks_not_aligned_to_its_output_blocks():
+    """input blocks that are not a multiple of 3 * 8192 samples: the phase carry (idx_in) and the partial output block"""
+    _compare(2, 288000, "cf32", 40000, 12, rid=23, gap_slots=(1, 1))
+
+
+def test_phase_search_boxcar():
+    """`-go PS_EMA off`: Demod::PhaseSearch (Demod.cpp:103-170) instead of PhaseSearchEMA"""
+    lines = _compare(2, 1536000, "cf32", 131072, 8, rid=24, ps_ema=False)
+    assert len(lines) >= 3
