@@ -132,6 +132,7 @@ struct aisgpu {
 	SubOut sub[MAXSUB]; int n_sub = 0;
 	struct { bool valid = false; int q = 0, pb = 0; long long g0 = 0, g1 = 0, first48 = 0; } pend; // deferred second half
 	bool defer = true;
+	bool ps_box = false; PsBoxState* d_box[2] = {}; // Demod::PhaseSearch (boxcar) instead of PhaseSearchEMA
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
 	bool fused = false; int GL = 40;
@@ -283,7 +284,9 @@ int enqueue_back(aisgpu_t* h) {
 	k4.n_chains = h->n_chains; k4.n_groups = (int)(g1 - g0);
 	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
 	HIPCHK(hipStreamWaitEvent(h->s2, h->ev_k3[pb], 0));
-	if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, h->s2));
+	k4.box_in = h->d_box[pb]; k4.box_out = h->d_box[pb ^ 1]; k4.first_group = g0;
+	if (h->ps_box) HIPCHK(launch_k4_box(k4, h->s2));
+	else if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, h->s2));
 	else HIPCHK(launch_k4_sequential(k4, h->s2));
 	HIPCHK(hipEventRecord(h->ev_ema[pb], h->s2));
 	return AISGPU_OK;
@@ -336,7 +339,9 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
 	{
 		TraceScope t(h, "psearch", h->s1);
-		if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, h->s1));
+		k4.box_in = h->d_box[pb]; k4.box_out = h->d_box[pb ^ 1]; k4.first_group = g0;
+		if (h->ps_box) HIPCHK(launch_k4_box(k4, h->s1));
+		else if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, h->s1));
 		else HIPCHK(launch_k4_sequential(k4, h->s1));
 	}
 	HIPCHK(hipEventRecord(h->ev_ema[pb], h->s1));
@@ -637,6 +642,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			HIPCHK(hipHostMalloc((void**)&h->h_usalpha[i], ((size_t)US_HIST + h->n_pre) * sizeof(float), hipHostMallocDefault));
 		}
 	}
+	h->ps_box = (cfg->flags & AISGPU_FLAG_PS_BOXCAR) != 0;
+	if (h->ps_box) for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_box[i], (size_t)h->n_chains));
 	// experimental (AISGPU_FUSED=1): bit-exact, but slower end to end than the materialised path so far
 	h->fused = false;
 	if (const char* e = getenv("AISGPU_FUSED")) h->fused = atoi(e) != 0 && !(cfg->flags & AISGPU_FLAG_TAPS) && !h->challenger;
@@ -720,6 +727,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	if (h->h_fmbits) hipHostFree(h->h_fmbits);
 	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); hipFree(h->d_ckw[i]); }
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
+	hipFree(h->d_box[0]); hipFree(h->d_box[1]);
 	hipFree(h->d_cgf); hipFree(h->d_omega); hipFree(h->d_step);
 	hipFree(h->d_rotstate); hipFree(h->d_firtap); hipFree(h->d_ppmtab);
 	hipFree(h->d_pswords); hipFree(h->d_psma0); hipFree(h->d_psma1); hipFree(h->d_psfin); hipFree(h->d_psflag);

@@ -89,6 +89,10 @@ struct K3Params {
 
 struct EmaState { float ma[16]; unsigned bits[16]; int max_idx, rot; int pad[2]; };
 
+// Demod::PhaseSearch (boxcar, `-go PS_EMA off`): per chain the |t| ring of the 16 hypotheses (slot-major), the decision
+// shift registers and max_idx
+struct PsBoxState { float mem[12][16]; unsigned bits[16]; int max_idx; int pad[3]; };
+
 constexpr int PS_CHUNK = 1024;   // symbols per time chunk of the chunk-parallel PhaseSearchEMA (multiple of 32)
 constexpr int PS_MAXCHUNKS = 16;
 
@@ -104,6 +108,8 @@ struct K4Params {
 	unsigned* fin;     // [16] low 4 bits: final max_idx per start index; bits 4..7: last four decisions of hypothesis k
 	int* flag;         // != 0: a speculative warm-up did not reproduce the sequential EMA -> exact fallback runs
 	int n_chains, n_groups, n_chunks, warm;
+	// boxcar variant (k4_phase_search_box)
+	const PsBoxState* box_in; PsBoxState* box_out; long long first_group;
 };
 
 hipError_t launch_k1(const K1Params& p, int K, bool cu8, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s);
@@ -133,5 +139,6 @@ constexpr int FM_HIST = 36;
 hipError_t launch_k5(const K5Params& p, int n_chan, hipStream_t s);
 hipError_t launch_k4(const K4Params& p, hipStream_t s);          // chunk-parallel + assemble + (conditional) exact fallback
 hipError_t launch_k4_sequential(const K4Params& p, hipStream_t s); // the plain sequential kernel only
+hipError_t launch_k4_box(const K4Params& p, hipStream_t s);        // Demod::PhaseSearch (boxcar history), sequential
 
 } // namespace aisk

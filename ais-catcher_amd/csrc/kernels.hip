@@ -1471,6 +1471,70 @@ __global__ __launch_bounds__(64) void k4_phase_search(K4Params p, int conditiona
 }
 
 // ------------------------------------------------------------------------------------------
+// K4': Demod::PhaseSearch (Demod.cpp:103-170), the boxcar variant behind `-go PS_EMA off` (nHistory = 12, nDelay = 3,
+// nSearch = 2; Model.h:218-219).  Same row layout (lane k = hypothesis k, 4 chains per wave), sequential over the
+// block.  memory[k][slot] lives in LDS; the average is the sum of the 12 slots in SLOT order (not time order),
+// exactly like the reference's inner loop; lane k evaluates the 5-candidate first-maximum search for "previous
+// maximum = k", and the row then takes the answer of the lane its previous maximum points at.
+// An optional, unoptimised mode: one dependent LDS/bpermute round trip per symbol.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k4_phase_search_box(K4Params p) {
+	__shared__ float mem[64][13]; // [lane][slot], padded
+	const int lane = threadIdx.x;
+	const int k = lane & 15, row = lane >> 4;
+	const int chain = blockIdx.x * 4 + row;
+	const bool live = chain < p.n_chains;
+	const int cidx = live ? chain : p.n_chains - 1;
+	const int rowbase = row * 16;
+	const int jj = k < 8 ? k : 15 - k;
+	const float pc = c_ps_phase[jj].x;
+	const float psn = k < 8 ? c_ps_phase[jj].y : -c_ps_phase[jj].y; // a - b == a + (im * -s) exactly
+	const PsBoxState* st = p.box_in + cidx;
+	PsBoxState* sto = p.box_out + cidx;
+#pragma unroll
+	for (int l = 0; l < 12; l++) mem[lane][l] = st->mem[l][k];
+	unsigned bits = st->bits[k];
+	int idx = st->max_idx;
+	int last = (int)(p.first_group % 12); // every chain has consumed first_group symbols
+	const float2* x = p.sym + (size_t)cidx * p.sym_stride;
+	uint32_t* out = p.bits + (size_t)cidx * p.bits_stride;
+	uint32_t word = 0;
+	for (int g = 0; g < p.n_groups; g++) {
+		const float2 v = x[g]; // already multiplied by (1j)^n (K3)
+		const float tt = v.x * pc + v.y * psn;
+		bits = (bits << 1) | (tt > 0 ? 1u : 0u);
+		mem[lane][last] = fabsf(tt);
+		last = last == 11 ? 0 : last + 1;
+		float avg = mem[lane][0];
+#pragma unroll
+		for (int l = 1; l < 12; l++) avg += mem[lane][l];
+		// candidates prev-2 .. prev+2 in that order, strict '>' against a running maximum that starts at 0
+		float max_val = 0.0f;
+		int res = k;
+#pragma unroll
+		for (int d = -2; d <= 2; d++) {
+			const float a = __shfl(avg, (k + d + 16) & 15, 16);
+			if (a > max_val) { max_val = a; res = (k + d + 16) & 15; }
+		}
+		idx = __shfl(res, idx, 16);
+		const unsigned b = (unsigned)__shfl((int)bits, idx, 16);
+		word |= (((b >> 4) ^ (b >> 3)) & 1u) << (g & 31); // bit(nDelay + 1) XOR bit(nDelay)
+		if ((g & 31) == 31) {
+			if (live && k == 0) out[g >> 5] = word;
+			word = 0;
+		}
+	}
+	if ((p.n_groups & 31) != 0 && live && k == 0) out[p.n_groups >> 5] = word;
+	if (live) {
+#pragma unroll
+		for (int l = 0; l < 12; l++) sto->mem[l][k] = mem[lane][l];
+		sto->bits[k] = bits & 0xffu;
+		if (k == 0) sto->max_idx = idx;
+	}
+	(void)rowbase;
+}
+
+// ------------------------------------------------------------------------------------------
 // K4 chunk-parallel: the block's symbols are cut into chunks of PS_CHUNK; one 16-lane row per (chain, chunk).
 //  * ma[k] is a contraction (x0.85 per symbol), so a chunk starts from ma = 0 and first replays the `warm`
 //    symbols in front of it; after that the float state is (with overwhelming probability) bit-identical to
@@ -1897,6 +1961,11 @@ hipError_t launch_k5(const K5Params& p, int n_chan, hipStream_t s) {
 	hipLaunchKernelGGL(k5_carry, dim3(n_chan), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(k5_fm, dim3(p.L / 256, n_chan), dim3(256), 0, s, p);
 	hipLaunchKernelGGL(k5_filter, dim3(p.L / 256, n_chan), dim3(256), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_k4_box(const K4Params& p, hipStream_t s) {
+	hipLaunchKernelGGL(k4_phase_search_box, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p);
 	return hipGetLastError();
 }
 

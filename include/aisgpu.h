@@ -53,6 +53,7 @@ extern "C" {
 
 #define AISGPU_FLAG_TAPS 1    /* keep intermediate float taps readable via aisgpu_tap() (tests) */
 #define AISGPU_FLAG_SERIAL 2  /* profiling aid: one stream, no overlap between the kernels of consecutive blocks */
+#define AISGPU_FLAG_PS_BOXCAR 8 /* KEY_SETTING_PS_EMA off: Demod::PhaseSearch (boxcar history) instead of PhaseSearchEMA (Model.cpp:550-555) */
 #define AISGPU_FLAG_DSK 4     /* KEY_SETTING_DSK (`-go DSK on`): 576k / 1152k / 2304k use the decimate-by-3 ladder (Model.cpp:130) */
 
 typedef struct aisgpu aisgpu_t;

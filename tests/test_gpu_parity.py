@@ -28,7 +28,7 @@ def _feq(a, b):
 def _run_gpu_vs_oracle(streams, rate, fmt, block, nblocks, **kw):
     """streams: list of per-receiver arrays.  Compares every block's taps and outputs per receiver."""
     R = len(streams)
-    okw = dict(dsk=kw.get("dsk", False))
+    okw = dict(dsk=kw.get("dsk", False), ps_ema=kw.get("ps_ema", True))
     g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block,
                    input_format=gpu.FMT_CU8 if fmt == "cu8" else gpu.FMT_CF32, taps=True, **kw)
     per = 2 if fmt == "cu8" else 1
@@ -400,3 +400,11 @@ def test_decimate_by_3_ladders(rate, dsk):
     x = synth.receiver_stream(block * 3, sample_rate=rate, receiver_id=31, gap_slots=(1, 2))
     _run_gpu_vs_oracle([x], rate, "cf32", block, 3, dsk=dsk)
     _run_gpu_vs_oracle([synth.to_cu8(x)], rate, "cu8", block, 3, dsk=dsk)
+
+
+def test_phase_search_boxcar():
+    """`-go PS_EMA off` (a9'): Demod::PhaseSearch with its 12-symbol boxcar instead of PhaseSearchEMA; three block sizes so
+    that the ring slot and the decision history cross block boundaries at different phases."""
+    for block, nb, rid in ((131072, 6, 41), (16384, 20, 42), (786432, 2, 43)):
+        x = synth.receiver_stream(block * nb, receiver_id=rid, gap_slots=(1, 2))
+        _run_gpu_vs_oracle([x, x[::-1].copy()], 1536000, "cf32", block, nb, ps_ema=False)
