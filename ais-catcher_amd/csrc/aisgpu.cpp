@@ -104,6 +104,7 @@ struct aisgpu {
 	float* d_magT[NBUF] = {}; // shifted FFT magnitudes (written by the FFT on the front stream, read by the searches on s3)
 	uint32_t* d_bits[2] = {};
 	bool challenger = false;
+	bool base = false; float2* d_fmprev[2] = {}; // ModelBase: FM receiver on the 48 kHz channels, no coherent chain
 	float* d_fm = nullptr; uint32_t* d_fmbits[2] = {}; uint32_t* h_fmbits = nullptr; // ModelChallenger FM branch
 	EmaState* d_ema[2] = {}; // state before / after the current downstream block (swapped per block)
 	uint32_t* d_pswords = nullptr; float *d_psma0 = nullptr, *d_psma1 = nullptr; unsigned* d_psfin = nullptr; int* d_psflag = nullptr;
@@ -269,7 +270,7 @@ int enqueue_back(aisgpu_t* h) {
 	HIPCHK(launch_k3(k3, h->n_chan, h->stream));
 	if (h->challenger) { // FM branch on the same derotated samples (Model.cpp:638-639)
 		K5Params k5;
-		k5.cgf = h->d_cgf; k5.cgf_stride = CGF_HIST + h->L; k5.fm = h->d_fm; k5.fm_stride = FM_HIST + h->L;
+		k5.x = h->d_cgf; k5.x_stride = CGF_HIST + h->L; k5.x_off = CGF_HIST; k5.prev_in = nullptr; k5.prev_out = nullptr; k5.fm = h->d_fm; k5.fm_stride = FM_HIST + h->L;
 		k5.fmbits = h->d_fmbits[pb]; k5.fmbits_stride = h->L / 32; k5.L = h->L;
 		memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
 		HIPCHK(launch_k5(k5, h->n_chan, h->stream));
@@ -364,7 +365,29 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 // and the phasor recurrence (latency-bound, s3, on CUs of its own).  The recurrence of block f is hidden behind
 // the next block's front end by DEFERRING the second half of block f (apply ... PhaseSearchEMA) until the first
 // half of block f+1 has been enqueued -- or until the caller asks for results (sync_all / aisgpu_sync_outputs).
+// ModelBase (Model.cpp:419-438): the two 48 kHz channels go straight into Demod::FM -> Filter(Receiver); the sign of
+// every filtered sample is all that SimplePLL and the decoder look at (DSP.cpp:30, AIS.h:96)
+int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
+	K5Params k5;
+	k5.x = h->d_c48[q]; k5.x_stride = h->c48s; k5.x_off = 0; k5.prev_in = h->d_fmprev[pb]; k5.prev_out = h->d_fmprev[pb ^ 1];
+	k5.fm = h->d_fm; k5.fm_stride = FM_HIST + h->L;
+	k5.fmbits = h->d_fmbits[pb]; k5.fmbits_stride = h->L / 32; k5.L = h->L;
+	memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
+	HIPCHK(launch_k5(k5, h->n_chan, h->stream));
+	HIPCHK(hipEventRecord(h->ev_c48free[q], h->stream));
+	HIPCHK(hipEventRecord(h->ev_k3[pb], h->stream));
+	HIPCHK(hipStreamWaitEvent(h->s2, h->ev_k3[pb], 0)); // aisgpu_sync_outputs copies on s2
+	if (h->n_sub < MAXSUB) {
+		SubOut& so = h->sub[h->n_sub++];
+		so.pb = pb; so.q = q; so.groups = 0; so.first_group = h->n48 / 5; so.first48 = h->n48;
+	}
+	h->n48 += h->L;
+	h->block_idx++;
+	return AISGPU_OK;
+}
+
 int enqueue_downstream(aisgpu_t* h, int q, int pb) {
+	if (h->base) return enqueue_downstream_base(h, q, pb);
 	if (h->fused) return enqueue_downstream_fused(h, q, pb);
 	const K2Params k2 = make_k2(h, q);
 	HIPCHK(launch_k2a_fft(k2, h->n_chan, h->stream));
@@ -483,7 +506,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			mode = MODE_RESAMPLE; K = 0; KP = k - 2;
 		}
 	}
-	if (cfg->model != AISGPU_MODEL_DEFAULT && cfg->model != AISGPU_MODEL_CHALLENGER) return AISGPU_ERR_ARG;
+	if (cfg->model != AISGPU_MODEL_DEFAULT && cfg->model != AISGPU_MODEL_CHALLENGER && cfg->model != AISGPU_MODEL_BASE) return AISGPU_ERR_ARG;
 	if (cfg->input_format != AISGPU_FMT_CU8 && cfg->input_format != AISGPU_FMT_CF32) return AISGPU_ERR_ARG;
 	if (cfg->n_receivers < 1 || cfg->n_receivers > 65535) return AISGPU_ERR_ARG;
 	// a downstream block must be a whole number of 512-sample CGF windows
@@ -499,6 +522,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->cfg = *cfg;
 	h->mode = mode; h->K = K; h->KP = KP;
 	h->challenger = cfg->model == AISGPU_MODEL_CHALLENGER;
+	h->base = cfg->model == AISGPU_MODEL_BASE;
 	// front-end geometry (tuning knobs; the defaults are the measured best): workgroup size, output samples per
 	// tile, prefetch depth.  Compiled combinations: "256,256,2", "64,64,1", "64,64,2".
 	h->k1_threads = 64; h->tile96 = 64; h->depth = 0; // autonomous waves, register/DPP ladder (profiles/r01_k1_geometry_sweep.txt)
@@ -670,7 +694,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(dalloc(&h->d_ema[i], C * 5));
 	}
 	HIPCHK(dalloc(&h->d_cgf, C * (CGF_HIST + h->L)));
-	if (h->challenger) {
+	if (h->base) for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmprev[i], C)); // Demod::FM::prev = 0 (Demod.h)
+	if (h->challenger || h->base) {
 		HIPCHK(dalloc(&h->d_fm, C * (FM_HIST + h->L)));
 		for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmbits[i], C * (h->L / 32)));
 		HIPCHK(hipHostMalloc((void**)&h->h_fmbits, MAXSUB * C * (h->L / 32) * sizeof(uint32_t), hipHostMallocDefault));
@@ -728,6 +753,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); hipFree(h->d_ckw[i]); }
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
 	hipFree(h->d_box[0]); hipFree(h->d_box[1]);
+	hipFree(h->d_fmprev[0]); hipFree(h->d_fmprev[1]);
 	hipFree(h->d_cgf); hipFree(h->d_omega); hipFree(h->d_step);
 	hipFree(h->d_rotstate); hipFree(h->d_firtap); hipFree(h->d_ppmtab);
 	hipFree(h->d_pswords); hipFree(h->d_psma0); hipFree(h->d_psma1); hipFree(h->d_psfin); hipFree(h->d_psflag);
@@ -932,10 +958,12 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 	for (int s = 0; s < h->n_sub; s++) {
 		const SubOut& so = h->sub[s];
 		// s2 is ordered after K4 of that block, which is ordered after everything that produced lvl/ppm
+		if (!h->base) {
 		HIPCHK(hipMemcpyAsync(h->h_bits + (size_t)s * C * 5 * h->words, h->d_bits[so.pb], C * 5 * h->words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s2));
 		HIPCHK(hipMemcpyAsync(h->h_lvl + (size_t)s * C * h->Gcap, h->d_lvl[so.pb], C * h->Gcap * sizeof(float), hipMemcpyDeviceToHost, h->s2));
 		HIPCHK(hipMemcpyAsync(h->h_ppm + (size_t)s * C * h->W, h->d_ppm[so.q], C * h->W * sizeof(float), hipMemcpyDeviceToHost, h->s2));
-		if (h->challenger)
+		}
+		if (h->challenger || h->base)
 			HIPCHK(hipMemcpyAsync(h->h_fmbits + (size_t)s * C * (h->L / 32), h->d_fmbits[so.pb], C * (h->L / 32) * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s2));
 	}
 	int rc = sync_all(h);
@@ -961,7 +989,7 @@ int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* o) {
 	o->ppm = h->h_ppm + (size_t)sub * C * h->W + chan * h->W;
 	o->group_window = nullptr;
 	o->first_sample48 = so.first48;
-	o->fm_bits = h->challenger ? h->h_fmbits + (size_t)sub * C * (h->L / 32) + chan * (h->L / 32) : nullptr;
+	o->fm_bits = (h->challenger || h->base) ? h->h_fmbits + (size_t)sub * C * (h->L / 32) + chan * (h->L / 32) : nullptr;
 	return AISGPU_OK;
 }
 

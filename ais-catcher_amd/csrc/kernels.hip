@@ -1775,8 +1775,10 @@ __global__ __launch_bounds__(256) void k5_fm(K5Params p) {
 	const int chan = blockIdx.y;
 	const int n = blockIdx.x * 256 + threadIdx.x;
 	if (n >= p.L) return;
-	const float2* y = p.cgf + (size_t)chan * p.cgf_stride + CGF_HIST + n;
-	const float2 d = y[0], pv = y[-1];
+	const float2* y = p.x + (size_t)chan * p.x_stride + p.x_off + n;
+	const float2 d = y[0];
+	const float2 pv = (n == 0 && p.prev_in) ? p.prev_in[chan] : y[-1];
+	if (n == p.L - 1 && p.prev_out) p.prev_out[chan] = d;
 	// data[i] * std::conj(prev): (xr*pr - xi*(-pi), xr*(-pi) + xi*pr)
 	const float npi = -pv.y;
 	const float re = d.x * pv.x - d.y * npi;

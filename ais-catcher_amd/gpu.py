@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AISGPU_LIB") or os.path.join(_HERE, "libaisgpu.so")  # AISGPU_LIB: A/B a kernel build
 
 FMT_CU8, FMT_CF32 = 0, 1
+MODEL_BASE = 1
 MODEL_DEFAULT = 2
 MODEL_CHALLENGER = 4
 FLAG_TAPS = 1

@@ -128,5 +128,13 @@ class ModelChallengerGPU(ModelDefaultGPU):
         super().__init__(**kw)
 
 
+class ModelBaseGPU(ModelDefaultGPU):
+    """AIS::ModelBase (-m 1): GPU front end + FM discriminator + filter; SimplePLL and its decoder feedback on the host."""
+
+    def __init__(self, **kw):
+        kw["model"] = _gpu.MODEL_BASE
+        super().__init__(**kw)
+
+
 def reset_sequence():
     load().aishost_reset_sequence()

@@ -53,6 +53,7 @@ void* aishost_model_create(void* batch, int rx, int sample_rate, int block_len, 
 		m->m.setFormat(m->fmt);
 		m->m.setBlockLength(block_len);
 		m->m.setChallenger(model == AISGPU_MODEL_CHALLENGER);
+		m->m.setBase(model == AISGPU_MODEL_BASE);
 		if (batch) m->m.useBatch((GpuBatch*)batch, rx);
 		if (!detached) m->m.buildModel(ch1, ch2, sample_rate, false, nullptr);
 		else m->m.wireDecoders(ch1, ch2); // no GPU context

@@ -67,6 +67,14 @@ void GpuChain::replayChallenger(Connection<FLOAT32>* coh, Connection<FLOAT32>* f
 	}
 }
 
+void GpuChain::replayBase(Connection<FLOAT32>& fm, const aisgpu_out& o, TAG& tag) {
+	const int L = o.n_windows * 512;
+	for (int n = 0; n < L; n++) { // FM, Filter and SimplePLL leave the tag alone (Demod.cpp:27-37, DSP.cpp:249-280, 28-44)
+		const FLOAT32 f = ((o.fm_bits[n >> 5] >> (n & 31)) & 1u) ? 1.0f : -1.0f;
+		fm.Send(&f, 1, tag);
+	}
+}
+
 void GpuChain::process(const void* data, int len, TAG& tag) {
 	if (failed || !batch) return;
 	int rc = batch->submitAndWait(rx, data, len);
@@ -82,7 +90,8 @@ void GpuChain::process(const void* data, int len, TAG& tag) {
 		for (int ch = 0; ch < 2; ch++) {
 			aisgpu_out o;
 			if (batch->fetch(s, rx, ch, &o) != AISGPU_OK) { failed = true; return; }
-			if (o.fm_bits) replayChallenger(ch == 0 ? outA : outB, ch == 0 ? outAf : outBf, o, tag);
+			if (o.fm_bits && o.n_groups == 0) replayBase(ch == 0 ? outFMa : outFMb, o, tag);
+			else if (o.fm_bits) replayChallenger(ch == 0 ? outA : outB, ch == 0 ? outAf : outBf, o, tag);
 			else replay(ch == 0 ? outA : outB, o, tag);
 		}
 	}
@@ -102,7 +111,7 @@ void ModelDefaultGPU::buildModel(char CH1, char CH2, int sample_rate, bool /*tim
 		c.input_format = format == Format::CU8 ? AISGPU_FMT_CU8 : AISGPU_FMT_CF32;
 		c.afc_wide = CGF_wide;
 		c.droop = droop_compensation;
-		c.model = challenger ? AISGPU_MODEL_CHALLENGER : AISGPU_MODEL_DEFAULT;
+		c.model = base ? AISGPU_MODEL_BASE : challenger ? AISGPU_MODEL_CHALLENGER : AISGPU_MODEL_DEFAULT;
 		batch = new GpuBatch(c); // throws std::runtime_error on unsupported rate / missing GPU
 		own_batch = true;
 		chain.attach(batch, 0);
@@ -114,6 +123,17 @@ void ModelDefaultGPU::buildModel(char CH1, char CH2, int sample_rate, bool /*tim
 
 void ModelDefaultGPU::wireDecoders(char CH1, char CH2) {
 	fan.o = &output;
+	if (base) { // Model.cpp:428-435
+		DEC_base_a.setOrigin(CH1, station, own_mmsi);
+		DEC_base_b.setOrigin(CH2, station, own_mmsi);
+		chain.outFMa >> sampler_a; sampler_a.out >> DEC_base_a;
+		chain.outFMb >> sampler_b; sampler_b.out >> DEC_base_b;
+		DEC_base_a.out.Connect(&fan);
+		DEC_base_b.out.Connect(&fan);
+		DEC_base_a.DecoderMessage.Connect(sampler_a);
+		DEC_base_b.DecoderMessage.Connect(sampler_b);
+		return;
+	}
 	for (int i = 0; i < N_SAMPLES_PER_SYMBOL; i++) {
 		DEC_a[i].setOrigin(CH1, station, own_mmsi);
 		DEC_b[i].setOrigin(CH2, station, own_mmsi);

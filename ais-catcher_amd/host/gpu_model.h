@@ -30,6 +30,32 @@ namespace aisamd {
 
 constexpr int N_SAMPLES_PER_SYMBOL = 5; // reference DSP/Model.h:37
 
+// DSP::SimplePLL of the reference (DSP/DSP.h:35-50, DSP/DSP.cpp:28-57): the symbol sampler of ModelBase.  Sequential, one
+// float of state, and switched between a fast and a slow loop by the decoder behind it -- host logic by nature.
+class SimplePLL : public SimpleStreamInOut<FLOAT32, FLOAT32>, public SignalIn<DecoderSignals> {
+	bool prev = false;
+	float PLL = 0.0f;
+	bool FastPLL = true;
+
+public:
+	void Receive(const FLOAT32* data, int len, TAG& tag) override {
+		for (int i = 0; i < len; i++) {
+			const bool bit = data[i] > 0;
+			if (bit != prev) PLL += (0.5f - PLL) * (FastPLL ? 0.6f : 0.05f);
+			PLL += 0.2f;
+			if (PLL >= 1.0f) {
+				Send(&data[i], 1, tag);
+				PLL -= (int)PLL;
+			}
+			prev = bit;
+		}
+	}
+	void Signal(const DecoderSignals& in) override {
+		if (in == DecoderSignals::StartTraining) FastPLL = true;
+		else if (in == DecoderSignals::StopTraining) FastPLL = false;
+	}
+};
+
 class GpuBatch {
 	aisgpu_t* ctx = nullptr;
 	aisgpu_cfg cfg;
@@ -63,6 +89,9 @@ public:
 	Connection<FLOAT32> outA[N_SAMPLES_PER_SYMBOL], outB[N_SAMPLES_PER_SYMBOL];
 	// ModelChallenger's FM branch (reference S_af / S_bf, DSP/Model.cpp:638-639); unconnected for ModelDefault
 	Connection<FLOAT32> outAf[N_SAMPLES_PER_SYMBOL], outBf[N_SAMPLES_PER_SYMBOL];
+	// ModelBase: the filtered FM discriminator of each channel (FR_a / FR_b, DSP/Model.cpp:431-432); only its sign is known
+	// here, and only its sign is looked at downstream (DSP.cpp:30, Marine/AIS.h:96)
+	Connection<FLOAT32> outFMa, outFMb;
 
 	void attach(GpuBatch* b, int receiver) { batch = b; rx = receiver; }
 	void setErrorHandler(std::function<void(const std::string&)> f) { on_error = f; }
@@ -75,6 +104,8 @@ public:
 	// (Deinterleave n=1, Model.cpp:630-639), so per 48 kHz sample N: first the coherent branch (which fires its five
 	// decoders when N completes a group), then FM decoder N % 5.
 	static void replayChallenger(Connection<FLOAT32>* coh, Connection<FLOAT32>* fm, const aisgpu_out& o, TAG& tag);
+	// ModelBase: every 48 kHz sample of the block, in order, into the sampler
+	static void replayBase(Connection<FLOAT32>& fm, const aisgpu_out& o, TAG& tag);
 };
 
 class ModelDefaultGPU {
@@ -84,6 +115,9 @@ class ModelDefaultGPU {
 	AIS::Decoder DEC_a[N_SAMPLES_PER_SYMBOL], DEC_b[N_SAMPLES_PER_SYMBOL];
 	AIS::Decoder DEC_af[N_SAMPLES_PER_SYMBOL], DEC_bf[N_SAMPLES_PER_SYMBOL]; // ModelChallenger only
 	bool challenger = false;
+	bool base = false; // AIS::ModelBase wiring: outFM -> SimplePLL -> one decoder per channel, decoder -> sampler feedback
+	SimplePLL sampler_a, sampler_b;
+	AIS::Decoder DEC_base_a, DEC_base_b;
 	StreamOut<AIS::Message> output;
 	int own_mmsi = -1, station = 0;
 	int block_len = 786432;
@@ -106,6 +140,7 @@ public:
 	void setAFCWide(bool b) { CGF_wide = b; }
 	void setDroop(bool b) { droop_compensation = b; }
 	void setChallenger(bool b) { challenger = b; } // AIS::ModelChallenger wiring (Model.cpp:601-678) instead of ModelDefault
+	void setBase(bool b) { base = b; }             // AIS::ModelBase wiring (Model.cpp:419-438)
 	// same signature as AIS::Model::buildModel (the Device* of the reference is only used for wiring there)
 	void buildModel(char CH1, char CH2, int sample_rate, bool timerOn, void* device);
 	// decoder wiring only, no GPU context (CPU tests of the replay/decoder host logic)
@@ -116,7 +151,8 @@ public:
 	void Receive(const RAW* raw, TAG& tag);
 	// CPU-only replay entry (host-logic tests): decisions produced elsewhere
 	void replay(int ch, const aisgpu_out& o, TAG& tag) {
-		if (challenger) GpuChain::replayChallenger(ch == 0 ? chain.outA : chain.outB, ch == 0 ? chain.outAf : chain.outBf, o, tag);
+		if (base) GpuChain::replayBase(ch == 0 ? chain.outFMa : chain.outFMb, o, tag);
+		else if (challenger) GpuChain::replayChallenger(ch == 0 ? chain.outA : chain.outB, ch == 0 ? chain.outAf : chain.outBf, o, tag);
 		else GpuChain::replay(ch == 0 ? chain.outA : chain.outB, o, tag);
 	}
 };
@@ -125,6 +161,12 @@ public:
 class ModelChallengerGPU : public ModelDefaultGPU {
 public:
 	ModelChallengerGPU() { setChallenger(true); }
+};
+
+// AIS::ModelBase wiring ("-m 1")
+class ModelBaseGPU : public ModelDefaultGPU {
+public:
+	ModelBaseGPU() { setBase(true); }
 };
 
 } // namespace aisamd

@@ -48,6 +48,8 @@ extern "C" {
 #define AISGPU_FMT_CF32 1
 
 /* models (DSP/Model.h:61-72) */
+#define AISGPU_MODEL_BASE 1        /* AIS::ModelBase       (-m 1), DSP/Model.cpp:419-438: FM receiver; the GPU delivers the sign of the
+                                    * filtered discriminator per 48 kHz sample, SimplePLL + decoder (feedback loop) run on the host */
 #define AISGPU_MODEL_DEFAULT 2     /* AIS::ModelDefault    (-m 2), DSP/Model.cpp:520-577 */
 #define AISGPU_MODEL_CHALLENGER 4  /* AIS::ModelChallenger (-m 4), DSP/Model.cpp:601-678: ModelDefault + the FM branch */
 
@@ -64,7 +66,7 @@ typedef struct aisgpu_cfg {
 	                    * (DownsampleKFilter ladders; block_len must then be a multiple of 24576 * rate/288000) (Model.cpp:129-338) */
 	int n_receivers;   /* independent dual-channel receiver instances batched on this GPU */
 	int block_len;     /* IQ samples per receiver per Receive() block; multiple of 512 * bucket_rate/48000 */
-	int model;         /* AISGPU_MODEL_DEFAULT or AISGPU_MODEL_CHALLENGER */
+	int model;         /* AISGPU_MODEL_BASE, AISGPU_MODEL_DEFAULT or AISGPU_MODEL_CHALLENGER */
 	int input_format;  /* AISGPU_FMT_* */
 	int afc_wide;      /* KEY_SETTING_AFC_WIDE (default on, Model.cpp:536-540) */
 	int droop;         /* KEY_SETTING_DROOP    (default on, Model.cpp:223-229) */
@@ -85,7 +87,7 @@ typedef struct aisgpu_out {
 	const float* ppm;        /* [n_windows] tag.ppm */
 	const int* group_window; /* reserved (NULL): window of group g is (5*(first_group+g)+4 - first_sample48)/512 */
 	long long first_sample48;/* stream index (48 kHz) of the first sample of this block */
-	const uint32_t* fm_bits; /* AISGPU_MODEL_CHALLENGER only (else NULL): bit n of word n/32 set <=> the filtered FM discriminator
+	const uint32_t* fm_bits; /* AISGPU_MODEL_CHALLENGER and AISGPU_MODEL_BASE (else NULL; with MODEL_BASE n_groups is 0 and only this is valid): bit n of word n/32 set <=> the filtered FM discriminator
 	                          * sample first_sample48 + n is > 0 (what Deinterleave S_af hands to DEC_af[n % 5], Model.cpp:638-639) */
 } aisgpu_out;
 

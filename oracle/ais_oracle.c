@@ -326,6 +326,7 @@ typedef struct ao_dec {
 	char channel;
 	struct ao_dec* sib[16];
 	int nsib;
+	int* fast_pll; /* ModelBase: DecoderMessage -> SimplePLL::Signal (Model.cpp:434-435, DSP.cpp:46-57) */
 } ao_dec;
 
 static int g_seq_id = 0; /* Message.cpp:28-39: process-global sequence counter */
@@ -351,6 +352,10 @@ static void sink_text(msgsink* s, const char* line, int n) {
 
 static void dec_next(ao_dec* d, int s, int pos) { /* AIS.cpp:33-53 */
 	d->state = s; d->position = pos; d->one_seq_count = 0;
+	if (d->fast_pll) { /* AIS.cpp:39-46: StartTraining / StopTraining */
+		if (s == ST_TRAINING) *d->fast_pll = 1;
+		else if (s == ST_STARTFLAG) *d->fast_pll = 0;
+	}
 	if (s == ST_FOUNDMESSAGE) /* Reset broadcast to the connected sibling decoders: AIS.cpp:47-49,98-108 */
 		for (int i = 0; i < d->nsib; i++) { ao_dec* o = d->sib[i]; o->state = ST_TRAINING; o->position = 0; o->one_seq_count = 0; }
 }
@@ -505,6 +510,8 @@ typedef struct {
 	/* Challenger FM branch: Demod::FM (Demod.cpp:27-37), Filter (Receiver taps), Deinterleave(5) (DSP.h:51-74) */
 	cf fm_prev; float fr_hist[36]; int fm_last; long long fm_idx;
 	ao_dec decf[5];
+	/* ModelBase: FM -> Filter(Receiver) -> SimplePLL -> one Decoder (Model.cpp:419-438) */
+	float pll; int pll_prev, pll_fast; ao_dec decb;
 	fvec tap48, tapcgf, tapfir, ppm_cgf, ppm_fir;
 	bitrec br[5], brf[5];
 } chan_t;
@@ -559,6 +566,24 @@ static void fm_branch(ao_chain* c, chan_t* ch, cf x) { /* Model.cpp:638-639 */
 	ch->fm_last = (ch->fm_last + 1) % 5;
 }
 
+static void base_branch(ao_chain* c, chan_t* ch, cf x) { /* Model.cpp:431-432 */
+	cf p = { x.re * ch->fm_prev.re - x.im * (-ch->fm_prev.im), x.re * (-ch->fm_prev.im) + x.im * ch->fm_prev.re };
+	float v = atan2f(p.im, p.re) / PI_F; /* Demod::FM, Demod.cpp:27-37 */
+	ch->fm_prev = x;
+	float f = fir_r_step(ch->fr_hist, TAPS_RECEIVER, 37, v);
+	if (c->taps) { fv_push(&ch->brf[0].bits, &f, 1); fv_push(&ch->brf[0].lvl, &c->tag.sample_lvl, 1); lv_push1(&ch->brf[0].idx, c->tag.sample_idx); }
+	/* SimplePLL::Receive, DSP.cpp:28-44 */
+	int bit = f > 0;
+	if (bit != ch->pll_prev) ch->pll += (0.5f - ch->pll) * (ch->pll_fast ? 0.6f : 0.05f);
+	ch->pll += 0.2f;
+	if (ch->pll >= 1.0f) {
+		dec_run(&ch->decb, f, &c->tag, &c->sink);
+		if (c->taps) { fv_push(&ch->br[0].bits, &f, 1); fv_push(&ch->br[0].lvl, &c->tag.sample_lvl, 1); lv_push1(&ch->br[0].idx, c->tag.sample_idx); }
+		ch->pll -= (int)ch->pll;
+	}
+	ch->pll_prev = bit;
+}
+
 static void channel_receive(ao_chain* c, chan_t* ch, const cf* x96, int n96) {
 	/* DS2_a -> FCIC5_a (Model.cpp:341-346) */
 	int n = n96 / 2;
@@ -567,6 +592,11 @@ static void channel_receive(ao_chain* c, chan_t* ch, const cf* x96, int n96) {
 	cic5_run(&ch->ds2, x96, n96, t, 1);
 	cic5_run(&ch->fcic, t, n, y, 0);
 	if (c->taps) fv_push(&ch->tap48, (const float*)y, 2LL * n);
+	if (c->model == 1) { /* ModelBase: no CGF, the channel goes straight into the FM receiver */
+		for (int i = 0; i < n; i++) base_branch(c, ch, y[i]);
+		free(t);
+		return;
+	}
 	/* SquareFreqOffsetCorrection::Receive, DSP.cpp:475-489 */
 	for (int i = 0; i < n; i++) {
 		cgf_t* g = &ch->cgf;
@@ -722,6 +752,8 @@ ao_chain* ao_create(int model, int sample_rate, int fmt, int flags) {
 		chan_t* ch = &c->ch[q];
 		ch->cgf.rot.re = 1.0f;
 		ch->cgf.window = 187; ch->cgf.wide = 1; /* Model.cpp:533-540 */
+		ch->decb.channel = "AB"[q]; ch->decb.fast_pll = &ch->pll_fast; /* Model.cpp:434-435 */
+		ch->pll_fast = 1; /* DSP.h:40 */
 		for (int j = 0; j < 5; j++) {
 			ch->dec[j].channel = "AB"[q]; ch->decf[j].channel = "AB"[q];
 			/* Reset mesh: Model.cpp:566-573 (Default), :658-674 (Challenger) */

@@ -77,6 +77,7 @@ struct Harness {
 	Device::Device dev;
 	AIS::ModelDefault* md = nullptr;
 	AIS::ModelChallenger* mc = nullptr;
+	AIS::ModelBase* mb = nullptr;
 	AIS::Model* model = nullptr;
 	TAG tag;
 	Format fmt;
@@ -94,7 +95,7 @@ struct Harness {
 
 extern "C" {
 
-// kind: 2 = ModelDefault, 4 = ModelChallenger.  fmt: 0 = CU8, 1 = CF32.
+// kind: 1 = ModelBase, 2 = ModelDefault, 4 = ModelChallenger.  fmt: 0 = CU8, 1 = CF32.
 // flags: bit 0 record float taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`
 void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 	const int taps = flags & 1;
@@ -102,6 +103,7 @@ void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 		Format f = fmt == 0 ? Format::CU8 : Format::CF32;
 		Harness* h = new Harness(f, sample_rate);
 		if (kind == 4) { h->mc = new AIS::ModelChallenger(); h->model = h->mc; }
+		else if (kind == 1) { h->mb = new AIS::ModelBase(); h->model = h->mb; }
 		else { h->md = new AIS::ModelDefault(); h->model = h->md; }
 		if (flags & 2) h->model->SetKey(AIS::KEY_SETTING_DSK, "ON");
 		if (flags & 4) h->model->SetKey(AIS::KEY_SETTING_PS_EMA, "OFF");
@@ -113,7 +115,11 @@ void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 			for (auto& t : h->tap) t.on = true;
 			*fe->C_a >> h->tap[0];
 			*fe->C_b >> h->tap[1];
-			if (h->md) {
+			if (h->mb) { // sampler output (what the decoder gets) and the filtered discriminator in front of it
+				h->bits[0][0].on = h->bits[1][0].on = h->fmbits[0][0].on = h->fmbits[1][0].on = true;
+				h->mb->sampler_a.out >> h->bits[0][0]; h->mb->sampler_b.out >> h->bits[1][0];
+				h->mb->FR_a.out >> h->fmbits[0][0];    h->mb->FR_b.out >> h->fmbits[1][0];
+			} else if (h->md) {
 				h->md->CGF_a.out >> h->tap[2]; h->md->CGF_b.out >> h->tap[3];
 				h->md->FC_a.out >> h->tap[4];  h->md->FC_b.out >> h->tap[5];
 				for (int j = 0; j < 5; j++) {
@@ -209,7 +215,7 @@ void ref_reset_seq(void) { AIS::Message::ID.store(0); }
 
 void ref_destroy(void* hv) {
 	Harness* h = (Harness*)hv;
-	delete h->md; delete h->mc;
+	delete h->md; delete h->mc; delete h->mb;
 	delete h;
 }
 

@@ -408,3 +408,34 @@ def test_phase_search_boxcar():
     for block, nb, rid in ((131072, 6, 41), (16384, 20, 42), (786432, 2, 43)):
         x = synth.receiver_stream(block * nb, receiver_id=rid, gap_slots=(1, 2))
         _run_gpu_vs_oracle([x, x[::-1].copy()], 1536000, "cf32", block, nb, ps_ema=False)
+
+
+def test_model_base_nmea_end_to_end():
+    """AIS::ModelBase (-m 1, a14): GPU front end + FM discriminator + 37-tap filter, host SimplePLL/decoder loop; the
+    discriminator signs and the NMEA text against the checker."""
+    from ais_catcher_amd import host
+    block, nblocks = 131072, 12
+    x = synth.receiver_stream(block * nblocks, receiver_id=61, gap_slots=(1, 2), type5_every=4)
+    chk = checkers.Ref(model=1, taps=True) if checkers.have_ref() else checkers.Oracle(model=1, taps=True)
+    chk.feed_blocks(x, block)
+    # (1) the device output: sign of the filtered discriminator for every 48 kHz sample
+    g = gpu.AisGpu(block_len=block, model=gpu.MODEL_BASE)
+    L = block // 32
+    for b in range(nblocks):
+        g.submit(0, x[b * block:(b + 1) * block])
+        g.run()
+        g.sync_outputs()
+        for ch in range(2):
+            o = g.fetch(0, ch)
+            assert o["n_groups"] == 0
+            ref = chk.bits(ch, 0, 1)[0][b * L:(b + 1) * L] > 0
+            assert np.array_equal(o["fm_bits"].astype(bool), ref), "block %d ch %d" % (b, ch)
+    g.close()
+    # (2) end to end through the C++ host model
+    host.reset_sequence()
+    m = host.ModelBaseGPU(block_len=block)
+    for b in range(nblocks):
+        m.receive(x[b * block:(b + 1) * block])
+    assert m.nmea() == chk.nmea() and len(chk.nmea()) >= 3
+    a, c = m.msg_meta(), chk.msg_meta()
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])

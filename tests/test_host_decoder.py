@@ -89,3 +89,24 @@ def test_challenger_replay_matches_checker():
     assert m.nmea() == chk.nmea() and len(chk.nmea()) >= 5
     a, c = m.msg_meta(), chk.msg_meta()
     assert np.array_equal(a[1], c[1])
+
+
+def test_model_base_replay_matches_checker():
+    """ModelBase wiring (SimplePLL sampler switched fast/slow by its decoder) fed with the sign of the checker's filtered
+    discriminator == the checker's NMEA: the sampler and the feedback loop are host logic."""
+    block, nblocks = 131072, 12
+    x = synth.receiver_stream(block * nblocks, receiver_id=9, gap_slots=(1, 2), type5_every=4)
+    chk = checkers.Ref(model=1, taps=True) if checkers.have_ref() else checkers.Oracle(model=1, taps=True)
+    chk.feed_blocks(x, block)
+    host.reset_sequence()
+    m = host.ModelBaseGPU(detached=True)
+    L = block // 32
+    W = L // 512
+    fm = [chk.bits(ch, 0, 1)[0] for ch in range(2)]
+    empty5 = np.zeros((5, 0), np.float32)
+    for b in range(nblocks):
+        for ch in range(2):
+            m.replay(ch, (b * L) // 5, b * L, empty5, np.zeros(0, np.float32), np.zeros(W, np.float32), fm=fm[ch][b * L:(b + 1) * L])
+    assert m.nmea() == chk.nmea() and len(chk.nmea()) >= 3
+    a, c = m.msg_meta(), chk.msg_meta()
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])

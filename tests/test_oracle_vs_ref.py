@@ -95,3 +95,29 @@ def test_phase_search_boxcar():
     """`-go PS_EMA off`: Demod::PhaseSearch (Demod.cpp:103-170) instead of PhaseSearchEMA"""
     lines = _compare(2, 1536000, "cf32", 131072, 8, rid=24, ps_ema=False)
     assert len(lines) >= 3
+
+
+def _compare_base(rate, fmt, block, nblocks, rid, **kw):
+    """ModelBase (-m 1): FM discriminator -> 37-tap filter -> SimplePLL (fast/slow switched by the decoder) -> one decoder."""
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=rid, **kw)
+    data = synth.to_cu8(x) if fmt == "cu8" else x
+    o = checkers.Oracle(model=1, rate=rate, fmt=fmt, taps=True)
+    r = checkers.Ref(model=1, rate=rate, fmt=fmt, taps=True)
+    o.feed_blocks(data, block)
+    r.feed_blocks(data, block)
+    for w in (0, 1):
+        assert np.array_equal(o.tap(w).view(np.float32), r.tap(w).view(np.float32))
+    for ch in range(2):
+        fo, fr = o.bits(ch, 0, 1)[0], r.bits(ch, 0, 1)[0]      # filtered discriminator, every 48 kHz sample
+        assert len(fo) == len(fr) > 0 and np.array_equal(fo, fr)
+        so, sr = o.bits(ch, 0, 0), r.bits(ch, 0, 0)            # what the sampler hands to the decoder
+        assert len(so[0]) == len(sr[0]) > 0 and np.array_equal(so[0], sr[0])
+    assert o.nmea() == r.nmea()
+    ol, rl = o.msg_meta(), r.msg_meta()
+    assert np.array_equal(ol[0], rl[0]) and np.array_equal(ol[1], rl[1])
+    return r.nmea()
+
+
+def test_model_base_fm_receiver():
+    assert len(_compare_base(1536000, "cf32", 131072, 12, rid=51, type5_every=4)) >= 3
+    _compare_base(1536000, "cu8", 16384, 40, rid=52)
