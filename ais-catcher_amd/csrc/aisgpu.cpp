@@ -15,6 +15,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "../../include/aisgpu.h"
@@ -131,8 +133,11 @@ struct aisgpu {
 	const void* cur_in = nullptr; long long cur_in_stride = 0;
 	bool submitted = false, have_out = false;
 	SubOut sub[MAXSUB]; int n_sub = 0;
-	struct { bool valid = false; int q = 0, pb = 0; long long g0 = 0, g1 = 0, first48 = 0; } pend; // deferred second half
+	struct { bool valid = false; int q = 0, pb = 0; long long g0 = 0, g1 = 0, first48 = 0; unsigned block = 0, sub = 0; } pend; // deferred second half
 	bool defer = true;
+	// device frame decoder (AISGPU_FLAG_GPU_DECODE)
+	bool gpu_decode = false; DecState* d_dec = nullptr; uint32_t* d_frames = nullptr; unsigned* d_frame_count = nullptr;
+	uint32_t* h_frames = nullptr; unsigned frames_seen = 0; int max_frames = 0; std::vector<aisgpu_frame> frames;
 	bool ps_box = false; PsBoxState* d_box[2] = {}; // Demod::PhaseSearch (boxcar) instead of PhaseSearchEMA
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
@@ -241,6 +246,17 @@ int span_tiles(int tiles_per_block, int n_rx, int threads, int tile96, int reque
 
 int enqueue_downstream_fused(aisgpu_t* h, int q, int pb);
 
+// AIS::Decoder on the device, behind PhaseSearchEMA of the same block (same stream)
+int enqueue_decode(aisgpu_t* h, int pb, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s) {
+	if (!h->gpu_decode) return AISGPU_OK;
+	K7Params k7;
+	k7.bits = h->d_bits[pb]; k7.bits_stride = h->words; k7.lvl = h->d_lvl[pb]; k7.lvl_stride = h->Gcap;
+	k7.state = h->d_dec; k7.frames = h->d_frames; k7.frame_count = h->d_frame_count; k7.max_frames = h->max_frames;
+	k7.first_group = g0; k7.n_groups = n_groups; k7.n_chan = h->n_chan; k7.block = block; k7.sub = sub;
+	HIPCHK(launch_k7(k7, s));
+	return AISGPU_OK;
+}
+
 K2Params make_k2(aisgpu_t* h, int q) {
 	K2Params k2;
 	k2.c48 = h->d_c48[q]; k2.c48_stride = h->c48s; k2.cgf = h->d_cgf; k2.cgf_stride = CGF_HIST + h->L;
@@ -289,6 +305,7 @@ int enqueue_back(aisgpu_t* h) {
 	if (h->ps_box) HIPCHK(launch_k4_box(k4, h->s2));
 	else if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, h->s2));
 	else HIPCHK(launch_k4_sequential(k4, h->s2));
+	{ int rc = enqueue_decode(h, pb, g0, (int)(g1 - g0), h->pend.block, h->pend.sub, h->s2); if (rc) return rc; }
 	HIPCHK(hipEventRecord(h->ev_ema[pb], h->s2));
 	return AISGPU_OK;
 }
@@ -345,6 +362,7 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 		else if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, h->s1));
 		else HIPCHK(launch_k4_sequential(k4, h->s1));
 	}
+	{ int rc = enqueue_decode(h, pb, g0, n_groups, (unsigned)h->block_idx, (unsigned)h->n_sub, h->s1); if (rc) return rc; }
 	HIPCHK(hipEventRecord(h->ev_ema[pb], h->s1));
 
 	if (h->n_sub < MAXSUB) {
@@ -407,6 +425,7 @@ int enqueue_downstream(aisgpu_t* h, int q, int pb) {
 	// ScatterPLL groups completed inside this block (DSP/DSP.h:95-117): group g completes with sample 5g+4
 	const long long g0 = h->n48 / 5, g1 = (h->n48 + h->L) / 5;
 	h->pend.valid = true; h->pend.q = q; h->pend.pb = pb; h->pend.g0 = g0; h->pend.g1 = g1; h->pend.first48 = h->n48;
+	h->pend.block = (unsigned)h->block_idx; h->pend.sub = (unsigned)h->n_sub;
 	if (h->n_sub < MAXSUB) {
 		SubOut& s = h->sub[h->n_sub++];
 		s.pb = pb; s.q = q; s.groups = (int)(g1 - g0); s.first_group = g0; s.first48 = h->n48;
@@ -414,6 +433,51 @@ int enqueue_downstream(aisgpu_t* h, int q, int pb) {
 	h->n48 += h->L;
 	h->block_idx++;
 	if (h->serial || !h->defer) return enqueue_back(h);
+	return AISGPU_OK;
+}
+
+// the frames the device decoders completed since the previous call, in the reference's emission order
+int gather_frames(aisgpu_t* h) {
+	unsigned total = 0;
+	HIPCHK(hipMemcpy(&total, h->d_frame_count, sizeof total, hipMemcpyDeviceToHost));
+	const unsigned fresh = total - h->frames_seen;
+	h->frames.clear();
+	if (fresh > (unsigned)h->max_frames) { h->err = "frame ring overflow: call aisgpu_sync_outputs() more often"; h->frames_seen = total; return AISGPU_ERR_OVERFLOW; }
+	if (fresh == 0) return AISGPU_OK;
+	const unsigned first = h->frames_seen % (unsigned)h->max_frames;
+	const size_t rec = DEC_FRAME_WORDS * sizeof(uint32_t);
+	const unsigned n1 = first + fresh <= (unsigned)h->max_frames ? fresh : (unsigned)h->max_frames - first;
+	HIPCHK(hipMemcpy(h->h_frames, h->d_frames + (size_t)first * DEC_FRAME_WORDS, n1 * rec, hipMemcpyDeviceToHost));
+	if (n1 < fresh) HIPCHK(hipMemcpy(h->h_frames + (size_t)n1 * DEC_FRAME_WORDS, h->d_frames, (fresh - n1) * rec, hipMemcpyDeviceToHost));
+	h->frames_seen = total;
+	h->frames.resize(fresh);
+	for (unsigned i = 0; i < fresh; i++) {
+		const uint32_t* f = h->h_frames + (size_t)i * DEC_FRAME_WORDS;
+		aisgpu_frame& o = h->frames[i];
+		const unsigned dec = f[0];
+		o.rx = (int)(dec / 10); o.ch = (int)(dec / 5 % 2); o.phase = (int)(dec % 5);
+		o.group = (int)f[1]; o.position = (int)f[2];
+		memcpy(&o.level_sum, &f[3], 4);
+		o.start_idx = (long long)((unsigned long long)f[4] | (unsigned long long)f[5] << 32);
+		o.end_idx = (long long)((unsigned long long)f[6] | (unsigned long long)f[7] << 32);
+		o.sub = (int)f[9];
+		memset(o.data, 0, sizeof o.data);
+		memcpy(o.data, &f[10], DEC_DATA_WORDS * 4);
+	}
+	std::vector<aisgpu_frame> sorted(fresh);
+	std::vector<unsigned> idx(fresh);
+	for (unsigned i = 0; i < fresh; i++) idx[i] = i;
+	std::sort(idx.begin(), idx.end(), [&](unsigned a, unsigned b) {
+		const uint32_t* fa = h->h_frames + (size_t)a * DEC_FRAME_WORDS; const uint32_t* fb = h->h_frames + (size_t)b * DEC_FRAME_WORDS;
+		const aisgpu_frame &x = h->frames[a], &y = h->frames[b];
+		if (x.rx != y.rx) return x.rx < y.rx;
+		if (fa[8] != fb[8]) return (int)(fa[8] - fb[8]) < 0;
+		if (x.ch != y.ch) return x.ch < y.ch;
+		if (x.group != y.group) return x.group < y.group;
+		return x.phase < y.phase;
+	});
+	for (unsigned i = 0; i < fresh; i++) sorted[i] = h->frames[idx[i]];
+	h->frames.swap(sorted);
 	return AISGPU_OK;
 }
 
@@ -666,6 +730,15 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			HIPCHK(hipHostMalloc((void**)&h->h_usalpha[i], ((size_t)US_HIST + h->n_pre) * sizeof(float), hipHostMallocDefault));
 		}
 	}
+	h->gpu_decode = (cfg->flags & AISGPU_FLAG_GPU_DECODE) != 0;
+	if (h->gpu_decode) {
+		if (cfg->model != AISGPU_MODEL_DEFAULT) { h->err = "AISGPU_FLAG_GPU_DECODE: ModelDefault only"; return AISGPU_ERR_ARG; }
+		h->max_frames = (int)C * 64; // ring between two aisgpu_sync_outputs(): a slot holds ~2 frames per channel and block
+		HIPCHK(dalloc(&h->d_dec, (size_t)h->n_chains)); // zero = State::TRAINING, lastBit = prev = 0 (Marine/AIS.h:44-56)
+		HIPCHK(dalloc(&h->d_frames, (size_t)h->max_frames * DEC_FRAME_WORDS));
+		HIPCHK(dalloc(&h->d_frame_count, 1));
+		HIPCHK(hipHostMalloc((void**)&h->h_frames, (size_t)h->max_frames * DEC_FRAME_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+	}
 	h->ps_box = (cfg->flags & AISGPU_FLAG_PS_BOXCAR) != 0;
 	if (h->ps_box) for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_box[i], (size_t)h->n_chains));
 	// experimental (AISGPU_FUSED=1): bit-exact, but slower end to end than the materialised path so far
@@ -753,6 +826,8 @@ void aisgpu_destroy(aisgpu_t* h) {
 	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); hipFree(h->d_ckw[i]); }
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
 	hipFree(h->d_box[0]); hipFree(h->d_box[1]);
+	hipFree(h->d_dec); hipFree(h->d_frames); hipFree(h->d_frame_count);
+	if (h->h_frames) hipHostFree(h->h_frames);
 	hipFree(h->d_fmprev[0]); hipFree(h->d_fmprev[1]);
 	hipFree(h->d_cgf); hipFree(h->d_omega); hipFree(h->d_step);
 	hipFree(h->d_rotstate); hipFree(h->d_firtap); hipFree(h->d_ppmtab);
@@ -968,7 +1043,16 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 	}
 	int rc = sync_all(h);
 	if (rc != AISGPU_OK) return rc;
+	if (h->gpu_decode) { rc = gather_frames(h); if (rc != AISGPU_OK) return rc; }
 	h->have_out = true;
+	return AISGPU_OK;
+}
+
+int aisgpu_frames(aisgpu_t* h, const aisgpu_frame** frames, int* count) {
+	if (!h || !frames || !count) return AISGPU_ERR_ARG;
+	if (!h->gpu_decode || !h->have_out) return AISGPU_ERR_STATE;
+	*frames = h->frames.data();
+	*count = (int)h->frames.size();
 	return AISGPU_OK;
 }
 

@@ -112,6 +112,20 @@ struct K4Params {
 	const PsBoxState* box_in; PsBoxState* box_out; long long first_group;
 };
 
+// K7: AIS::Decoder on the device (frame decoder).  One lane per decoder, 12 meshes of 5 decoders per wave.
+constexpr int DEC_DATA_WORDS = 36;  // MAX_AIS_FRAME_LENGTH = 1064 + 16 + 7 bits -> 136 bytes
+constexpr int DEC_FRAME_WORDS = 10 + DEC_DATA_WORDS; // record: decoder, group, position, level bits, start_idx (2), end_idx (2), block, sub, data
+struct DecState { int state, lastBit, prev, position, osc; float level; long long start_idx; uint32_t data[DEC_DATA_WORDS]; };
+struct K7Params {
+	const uint32_t* bits; long long bits_stride; // [n_chan * 5][bits_stride] packed hard decisions
+	const float* lvl; long long lvl_stride;      // [n_chan][lvl_stride]
+	DecState* state;                              // [n_chan * 5], updated in place
+	uint32_t* frames; unsigned* frame_count; int max_frames; // ring of records, monotonic counter
+	long long first_group; int n_groups, n_chan;
+	unsigned block, sub;                          // stamped into the records
+};
+hipError_t launch_k7(const K7Params& p, hipStream_t s);
+
 hipError_t launch_k1(const K1Params& p, int K, bool cu8, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s);
 hipError_t launch_k1u(const K1uParams& p, int n_rx, hipStream_t s);
 hipError_t launch_copy_rows(const float2* src, long long src_stride, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);

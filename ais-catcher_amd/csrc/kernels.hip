@@ -1802,6 +1802,151 @@ __global__ __launch_bounds__(256) void k5_filter(K5Params p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K7: AIS::Decoder (Marine/AIS.h:82-181, Marine/AIS.cpp:33-142) on the device -- NRZI, training / start-flag state machine,
+// bit de-stuffing, CRC-16 residue check, the early-abort heuristics and the Reset mesh between the five decoders of a
+// channel (DSP/Model.cpp:566-573).  One lane per decoder, the five decoders of a channel in adjacent lanes (12 channels per
+// wave), one pass over the block's symbols.  The reference feeds the five decoders of a group one after the other; here
+// they step together, and only when one of them completes a frame with a good CRC is the order restored: the decoders
+// after it are rolled back, reset and stepped again, the ones before it are reset afterwards (a decoder that has just been
+// reset cannot complete a frame, so one repair pass is enough).  Frames leave as records (bits as received, level sum,
+// indices); length validation, the level in dB and the NMEA text stay on the host (Marine/Message.cpp), they are string work.
+// ------------------------------------------------------------------------------------------
+struct DecReg { int state, lastBit, prev, position, osc; float level; long long start_idx; };
+enum { DST_TRAINING = 0, DST_STARTFLAG = 1, DST_DATAFCS = 3 };
+constexpr int DEC_MAX_FRAME = 1064 + 16 + 7;
+
+__device__ __forceinline__ bool dec_cannot_be_valid(const uint32_t* data, int len) { // Marine/AIS.cpp:111-142
+	if (len < 30) return false;
+	const uint32_t w0 = data[0], w1 = data[64];
+	const int t = (int)((w0 & 255u) >> 2);
+	switch (len) {
+	case 30: return t > 28 || t == 0;
+	case 62: return (((w0 >> 8) & 255u) << 22 | ((w0 >> 16) & 255u) << 14 | (w0 >> 24) << 6 | (w1 & 255u) >> 2) > 999999999u;
+	case 96: return t == 10;
+	case 168: return t == 16;
+	case 184: return t == 15 || t == 20 || t == 23;
+	case 192: return t == 1 || t == 2 || t == 3 || t == 4 || t == 7 || t == 9 || t == 11 || t == 18 || t == 22 || t == 24 || t == 25 || t == 27 || t == 28;
+	case 336: return t == 19;
+	case 385: return t == 21;
+	case 448: return t == 5;
+	}
+	return false;
+}
+
+// one symbol; data = this lane's column of the LDS frame buffer (word w at data[64 * w]); returns true when a frame with a
+// good CRC has just been completed (r.position / r.level still hold the frame's values, the caller finishes the transition)
+__device__ __forceinline__ bool dec_step(DecReg& r, int dd, float slvl, long long sidx, uint32_t* data) {
+	const int Bit = !(dd ^ r.prev); // NRZI
+	r.prev = dd;
+	bool found = false;
+	if (r.state == DST_TRAINING) {
+		if (Bit != r.lastBit) r.position++;
+		else if (r.position > 4) { r.start_idx = sidx; r.state = DST_STARTFLAG; r.position = Bit ? 3 : 1; r.osc = 0; }
+		else { r.position = 0; r.osc = 0; }
+	} else if (r.state == DST_STARTFLAG) {
+		if (r.position == 7) {
+			if (Bit == 0) {
+				r.state = DST_DATAFCS; r.position = 0; r.osc = 0; r.level = 0.0f;
+				for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = 0u; // msg.clear()
+			} else { r.state = DST_TRAINING; r.position = 0; r.osc = 0; }
+		} else if (Bit == 1) r.position++;
+		else { r.state = DST_TRAINING; r.position = 0; r.osc = 0; }
+	} else { // DATAFCS
+		if (r.position < DEC_MAX_FRAME) {
+			uint32_t* w = data + 64 * (r.position >> 5);
+			const uint32_t m = 1u << (r.position & 31);
+			*w = Bit ? (*w | m) : (*w & ~m);
+		}
+		r.position++;
+		r.level += slvl; // tag.mode & 1 (Common.h:242)
+		if (Bit == 1) {
+			if (r.osc == 5) { // closing flag (or abort)
+				const int len = r.position - 7;
+				if (len >= 16) { // CRC-16/X.25 residue over the bits as received (AIS.cpp:55-64)
+					uint32_t crc = 0xFFFFu;
+					for (int i = 0; i < len; i++) {
+						const uint32_t b = (data[64 * (i >> 5)] >> (i & 31)) & 1u;
+						crc = ((b ^ crc) & 1u) ? ((crc >> 1) ^ 0x8408u) : (crc >> 1);
+					}
+					found = crc == (uint32_t)(uint16_t)~0x0F47;
+				}
+				if (!found) { r.state = DST_TRAINING; r.position = 0; r.osc = 0; }
+			} else r.osc++;
+		} else {
+			if (r.osc == 5) r.position--; // bit de-stuffing
+			r.osc = 0;
+		}
+		if (!found && r.state == DST_DATAFCS && (r.position == DEC_MAX_FRAME || dec_cannot_be_valid(data, r.position))) {
+			r.state = DST_TRAINING; r.position = 0; r.osc = 0;
+		}
+	}
+	r.lastBit = Bit;
+	return found;
+}
+
+__global__ __launch_bounds__(64) void k7_decode(K7Params p) {
+	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64]; // [word][lane]
+	__shared__ float lv[64 * 33];                   // [lane][32 groups], padded
+	const int lane = threadIdx.x;
+	const int mesh = lane / 5, j = lane - 5 * mesh;  // lanes 60..63 idle
+	const int chan_raw = blockIdx.x * 12 + mesh;
+	const bool live = lane < 60 && chan_raw < p.n_chan;
+	const int chan = live ? chan_raw : 0;
+	const int dec = chan * 5 + (live ? j : 0);
+	uint32_t* data = fdata + lane;
+	DecState* st = p.state + dec;
+	DecReg r;
+	r.state = st->state; r.lastBit = st->lastBit; r.prev = st->prev; r.position = st->position; r.osc = st->osc;
+	r.level = st->level; r.start_idx = st->start_idx;
+	for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = st->data[w];
+	const uint32_t* brow = p.bits + (size_t)dec * p.bits_stride;
+	const float* lrow = p.lvl + (size_t)chan * p.lvl_stride;
+	for (int g0 = 0; g0 < p.n_groups; g0 += 32) {
+		const uint32_t word = brow[g0 >> 5];
+		const int n = p.n_groups - g0 < 32 ? p.n_groups - g0 : 32;
+		for (int e = 0; e < 32; e++) lv[lane * 33 + e] = e < n ? lrow[g0 + e] : 0.0f;
+		for (int e = 0; e < n; e++) {
+			const int g = g0 + e;
+			const int dd = (int)((word >> e) & 1u);
+			const float slvl = lv[lane * 33 + e];
+			const long long sidx = 5 * (p.first_group + g) + j; // tag.sample_idx of this symbol
+			const DecReg before = r;
+			bool found = live && dec_step(r, dd, slvl, sidx, data);
+			const unsigned long long F = __ballot(found);
+			if (F != 0) { // rare: restore the order in which the reference runs the five decoders of a group
+				const unsigned m5 = (unsigned)(F >> (5 * mesh)) & 31u;
+				if (live && m5 != 0) {
+					const int jmin = __builtin_ctz(m5);
+					if (j > jmin) { // would have been reset before its step
+						r = before;
+						r.state = DST_TRAINING; r.position = 0; r.osc = 0;
+						dec_step(r, dd, slvl, sidx, data);
+					} else if (j < jmin) { // reset after its step
+						r.state = DST_TRAINING; r.position = 0; r.osc = 0;
+					} else { // the decoder that found the message
+						const unsigned slot = atomicAdd(p.frame_count, 1u) % (unsigned)p.max_frames;
+						{
+							uint32_t* f = p.frames + (size_t)slot * DEC_FRAME_WORDS;
+							f[0] = (uint32_t)dec; f[1] = (uint32_t)g; f[2] = (uint32_t)r.position; f[3] = __float_as_uint(r.level);
+							f[4] = (uint32_t)(unsigned long long)r.start_idx; f[5] = (uint32_t)((unsigned long long)r.start_idx >> 32);
+							f[6] = (uint32_t)(unsigned long long)sidx; f[7] = (uint32_t)((unsigned long long)sidx >> 32);
+							f[8] = p.block; f[9] = p.sub;
+							for (int w = 0; w < DEC_DATA_WORDS; w++) f[10 + w] = data[64 * w];
+						}
+						r.state = DST_TRAINING; r.position = 0; r.osc = 0; // FOUNDMESSAGE (resets the siblings), then TRAINING
+					}
+				}
+			}
+		}
+	}
+	if (live) {
+		st->state = r.state; st->lastBit = r.lastBit; st->prev = r.prev; st->position = r.position; st->osc = r.osc;
+		st->level = r.level; st->start_idx = r.start_idx;
+		for (int w = 0; w < DEC_DATA_WORDS; w++) st->data[w] = data[64 * w];
+	}
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 template <int K, int P, int D, int NT, bool CU8, bool PRE>
@@ -1956,6 +2101,11 @@ hipError_t launch_k2c(const K2Params& p, int n_chan, hipStream_t s) {
 hipError_t launch_k3(const K3Params& p, int n_chan, hipStream_t s) {
 	if (p.n_groups <= 0) return hipSuccess;
 	hipLaunchKernelGGL(k3_fir_scatter, dim3((p.n_groups + 255) / 256, n_chan), dim3(256), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_k7(const K7Params& p, hipStream_t s) {
+	hipLaunchKernelGGL(k7_decode, dim3((p.n_chan + 11) / 12), dim3(64), 0, s, p);
 	return hipGetLastError();
 }
 

@@ -20,12 +20,13 @@ FLAG_TAPS = 1
 FLAG_SERIAL = 2
 FLAG_DSK = 4
 FLAG_PS_BOXCAR = 8
+FLAG_GPU_DECODE = 16
 
 EXPORTS = (
     "aisgpu_default_cfg", "aisgpu_create", "aisgpu_destroy", "aisgpu_submit", "aisgpu_submit_device",
     "aisgpu_run", "aisgpu_sync_outputs", "aisgpu_sync", "aisgpu_fetch", "aisgpu_tap", "aisgpu_stream",
     "aisgpu_frontend_ms", "aisgpu_timing", "aisgpu_strerror", "aisgpu_last_error", "aisgpu_device_count",
-    "aisgpu_out_count", "aisgpu_fetch_sub", "aisgpu_selftest",
+    "aisgpu_out_count", "aisgpu_fetch_sub", "aisgpu_selftest", "aisgpu_frames",
 )
 
 
@@ -33,6 +34,12 @@ class Cfg(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "sample_rate", "n_receivers", "block_len", "model", "input_format", "afc_wide", "droop",
         "device_id", "flags", "tiles_per_span")]
+
+
+class Frame(ctypes.Structure):
+    _fields_ = [("rx", ctypes.c_int), ("ch", ctypes.c_int), ("phase", ctypes.c_int), ("sub", ctypes.c_int),
+                ("group", ctypes.c_int), ("position", ctypes.c_int), ("level_sum", ctypes.c_float),
+                ("start_idx", ctypes.c_longlong), ("end_idx", ctypes.c_longlong), ("data", ctypes.c_ubyte * 144)]
 
 
 class Out(ctypes.Structure):
@@ -74,6 +81,8 @@ def load():
     lib.aisgpu_fetch.argtypes = [vp, ci, ci, ctypes.POINTER(Out)]
     lib.aisgpu_out_count.argtypes = [vp]
     lib.aisgpu_fetch_sub.argtypes = [vp, ci, ci, ci, ctypes.POINTER(Out)]
+    if hasattr(lib, "aisgpu_frames"):
+        lib.aisgpu_frames.argtypes = [vp, ctypes.POINTER(ctypes.POINTER(Frame)), ctypes.POINTER(ci)]
     lib.aisgpu_tap.argtypes = [vp, ci, ci, vp, cll]
     lib.aisgpu_tap.restype = cll
     lib.aisgpu_stream.argtypes = [vp]
@@ -103,7 +112,7 @@ class AisGpu:
 
     def __init__(self, sample_rate=1536000, n_receivers=1, block_len=786432, input_format=FMT_CF32,
                  afc_wide=True, droop=True, device_id=0, taps=False, tiles_per_span=0, serial=False, model=MODEL_DEFAULT,
-                 dsk=False, ps_ema=True):
+                 dsk=False, ps_ema=True, gpu_decode=False):
         self.lib = load()
         cfg = Cfg()
         self.lib.aisgpu_default_cfg(ctypes.byref(cfg))
@@ -111,7 +120,7 @@ class AisGpu:
         cfg.model = model
         cfg.input_format, cfg.afc_wide, cfg.droop = input_format, int(afc_wide), int(droop)
         cfg.device_id, cfg.tiles_per_span = device_id, tiles_per_span
-        cfg.flags = (FLAG_TAPS if taps else 0) | (FLAG_SERIAL if serial else 0) | (FLAG_DSK if dsk else 0) | (0 if ps_ema else FLAG_PS_BOXCAR)
+        cfg.flags = (FLAG_TAPS if taps else 0) | (FLAG_SERIAL if serial else 0) | (FLAG_DSK if dsk else 0) | (0 if ps_ema else FLAG_PS_BOXCAR) | (FLAG_GPU_DECODE if gpu_decode else 0)
         self.cfg = cfg
         self.h = ctypes.c_void_p()
         rc = self.lib.aisgpu_create(ctypes.byref(cfg), ctypes.byref(self.h))
@@ -169,6 +178,15 @@ class AisGpu:
             fm = ((w[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).reshape(-1).astype(np.uint8)
         return dict(bits=bits, lvl=lvl, ppm=ppm, first_group=o.first_group, first_sample48=o.first_sample48,
                     n_groups=n, n_windows=o.n_windows, fm_bits=fm)
+
+    def frames(self):
+        """AISGPU_FLAG_GPU_DECODE: list of dicts, the frames completed since the previous sync_outputs()."""
+        fp = ctypes.POINTER(Frame)()
+        n = ctypes.c_int()
+        self._chk(self.lib.aisgpu_frames(self.h, ctypes.byref(fp), ctypes.byref(n)), "aisgpu_frames")
+        return [dict(rx=fp[i].rx, ch=fp[i].ch, phase=fp[i].phase, sub=fp[i].sub, group=fp[i].group, position=fp[i].position,
+                     level_sum=fp[i].level_sum, start_idx=fp[i].start_idx, end_idx=fp[i].end_idx, data=bytes(fp[i].data))
+                for i in range(n.value)]
 
     def tap(self, which, rx=0):
         n = self.lib.aisgpu_tap(self.h, which, rx, None, 0)

@@ -43,12 +43,14 @@ class Batch:
     """Shared GPU context for n_receivers ModelDefaultGPU instances (one per receiver thread)."""
 
     def __init__(self, sample_rate=1536000, n_receivers=1, block_len=786432, input_format=_gpu.FMT_CF32, device_id=0,
-                 model=_gpu.MODEL_DEFAULT):
+                 model=_gpu.MODEL_DEFAULT, gpu_decode=False):
         lib = load()
         cfg = _gpu.Cfg()
         _gpu.load().aisgpu_default_cfg(ctypes.byref(cfg))
         cfg.sample_rate, cfg.n_receivers, cfg.block_len = sample_rate, n_receivers, block_len
         cfg.input_format, cfg.device_id, cfg.model = input_format, device_id, model
+        if gpu_decode:
+            cfg.flags |= _gpu.FLAG_GPU_DECODE
         err = ctypes.create_string_buffer(512)
         self.h = lib.aishost_batch_create(ctypes.byref(cfg), err, 512)
         if not self.h:
@@ -63,12 +65,12 @@ class Batch:
 
 class ModelDefaultGPU:
     def __init__(self, sample_rate=1536000, block_len=786432, input_format=_gpu.FMT_CF32, ch1="A", ch2="B",
-                 batch=None, rx=0, detached=False, model=_gpu.MODEL_DEFAULT):
+                 batch=None, rx=0, detached=False, model=_gpu.MODEL_DEFAULT, gpu_decode=False):
         self.lib = load()
         err = ctypes.create_string_buffer(512)
         self.fmt = input_format
         self.h = self.lib.aishost_model_create(batch.h if batch else None, rx, sample_rate, block_len, input_format,
-                                               ch1.encode(), ch2.encode(), 1 if detached else 0, model, err, 512)
+                                               ch1.encode(), ch2.encode(), 1 if detached else 0, model | (0x100 if gpu_decode else 0), err, 512)
         if not self.h:
             raise RuntimeError(err.value.decode())
 

@@ -94,6 +94,16 @@ bool Decoder::processData(int len, TAG& tag) { // AIS.cpp:66-96
 	return true;
 }
 
+bool Decoder::emitFrame(const uint8_t* bits, int pos, FLOAT32 level_sum, long long start, long long end, TAG& tag) {
+	if (pos < 7 || pos > MAX_AIS_FRAME_LENGTH) return false;
+	msg.clear();
+	for (int i = 0; i < pos; i++) msg.setBit(i, (bits[i >> 3] >> (i & 7)) & 1);
+	if (tag.mode & 1) tag.level = level_sum / pos;
+	start_idx = start;
+	end_idx = end;
+	return processData(pos - 7, tag);
+}
+
 bool Decoder::cannotBeValid(int len) const { // early-abort heuristics (AIS.cpp:111-142)
 	const int END = 24;
 	if (len < 6 + END) return false;

@@ -84,6 +84,9 @@ public:
 	void Signal(const DecoderSignals& in) override {
 		if (in == DecoderSignals::Reset) NextState(State::TRAINING, 0);
 	}
+	// A frame whose state machine ran on the GPU (aisgpu_frames): the part of Run()/processData() that follows the closing
+	// flag -- tag.level, CRC (checked again), length, validate, NMEA, Send (Marine/AIS.h:150-160, Marine/AIS.cpp:66-96)
+	bool emitFrame(const uint8_t* bits_as_received, int position, FLOAT32 level_sum, long long start, long long end, TAG& tag);
 	SignalHub<DecoderSignals> DecoderMessage;
 };
 

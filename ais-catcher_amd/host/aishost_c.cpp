@@ -52,8 +52,9 @@ void* aishost_model_create(void* batch, int rx, int sample_rate, int block_len, 
 		m->fmt = input_format == AISGPU_FMT_CU8 ? Format::CU8 : Format::CF32;
 		m->m.setFormat(m->fmt);
 		m->m.setBlockLength(block_len);
-		m->m.setChallenger(model == AISGPU_MODEL_CHALLENGER);
-		m->m.setBase(model == AISGPU_MODEL_BASE);
+		m->m.setChallenger((model & 0xff) == AISGPU_MODEL_CHALLENGER);
+		m->m.setBase((model & 0xff) == AISGPU_MODEL_BASE);
+		m->m.setGpuDecode((model & 0x100) != 0); // bit 8 of `model`: AISGPU_FLAG_GPU_DECODE for a stand-alone receiver
 		if (batch) m->m.useBatch((GpuBatch*)batch, rx);
 		if (!detached) m->m.buildModel(ch1, ch2, sample_rate, false, nullptr);
 		else m->m.wireDecoders(ch1, ch2); // no GPU context

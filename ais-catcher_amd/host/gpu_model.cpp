@@ -86,6 +86,24 @@ void GpuChain::process(const void* data, int len, TAG& tag) {
 	// One downstream block per Receive() call of the chain behind the (optional) resampler; within it Rotate hands
 	// the whole block to channel A before channel B (reference DSP/DSP.cpp:312-313)
 	const int nsub = batch->outCount();
+	if (batch->config().flags & AISGPU_FLAG_GPU_DECODE) { // the device ran the decoders: only completed frames come back
+		const aisgpu_frame* fr = nullptr;
+		int nf = 0;
+		if (batch->frames(&fr, &nf) != AISGPU_OK) { failed = true; return; }
+		for (int i = 0; i < nf; i++) {
+			const aisgpu_frame& f = fr[i];
+			if (f.rx != rx || f.sub >= nsub) continue;
+			aisgpu_out o;
+			if (batch->fetch(f.sub, rx, f.ch, &o) != AISGPU_OK) { failed = true; return; }
+			const long long n_last = 5 * (o.first_group + f.group) + 4; // like replay(): what the tag held when the frame closed
+			const int w = (int)((n_last - o.first_sample48) / 512);
+			if (o.ppm && w >= 0 && w < o.n_windows) tag.ppm = o.ppm[w];
+			if (tag.mode & 1) tag.sample_lvl = o.lvl[f.group];
+			tag.sample_idx = f.end_idx;
+			if (on_frame) on_frame(f, tag);
+		}
+		return;
+	}
 	for (int s = 0; s < nsub; s++) {
 		for (int ch = 0; ch < 2; ch++) {
 			aisgpu_out o;
@@ -112,6 +130,7 @@ void ModelDefaultGPU::buildModel(char CH1, char CH2, int sample_rate, bool /*tim
 		c.afc_wide = CGF_wide;
 		c.droop = droop_compensation;
 		c.model = base ? AISGPU_MODEL_BASE : challenger ? AISGPU_MODEL_CHALLENGER : AISGPU_MODEL_DEFAULT;
+		if (gpu_decode) c.flags |= AISGPU_FLAG_GPU_DECODE;
 		batch = new GpuBatch(c); // throws std::runtime_error on unsupported rate / missing GPU
 		own_batch = true;
 		chain.attach(batch, 0);
@@ -134,6 +153,10 @@ void ModelDefaultGPU::wireDecoders(char CH1, char CH2) {
 		DEC_base_b.DecoderMessage.Connect(sampler_b);
 		return;
 	}
+	chain.setFrameHandler([this](const aisgpu_frame& f, TAG& tag) {
+		AIS::Decoder& d = (f.ch == 0 ? DEC_a : DEC_b)[f.phase];
+		d.emitFrame(f.data, f.position, f.level_sum, f.start_idx, f.end_idx, tag);
+	});
 	for (int i = 0; i < N_SAMPLES_PER_SYMBOL; i++) {
 		DEC_a[i].setOrigin(CH1, station, own_mmsi);
 		DEC_b[i].setOrigin(CH2, station, own_mmsi);

@@ -74,6 +74,7 @@ public:
 	int submitAndWait(int rx, const void* iq, int n_iq);
 	int outCount() { return aisgpu_out_count(ctx); }
 	int fetch(int sub, int rx, int ch, aisgpu_out* out) { return aisgpu_fetch_sub(ctx, sub, rx, ch, out); }
+	int frames(const aisgpu_frame** f, int* n) { return aisgpu_frames(ctx, f, n); }
 	const char* lastError() { return aisgpu_last_error(ctx); }
 };
 
@@ -81,6 +82,8 @@ class GpuChain : public StreamIn<CFLOAT32>, public StreamIn<CU8> {
 	GpuBatch* batch = nullptr;
 	int rx = 0;
 	std::function<void(const std::string&)> on_error;
+	// AISGPU_FLAG_GPU_DECODE: the decoders' state machines ran on the device; a completed frame goes to its decoder's tail
+	std::function<void(const aisgpu_frame&, TAG&)> on_frame;
 	bool failed = false;
 
 	void process(const void* data, int len, TAG& tag);
@@ -95,6 +98,7 @@ public:
 
 	void attach(GpuBatch* b, int receiver) { batch = b; rx = receiver; }
 	void setErrorHandler(std::function<void(const std::string&)> f) { on_error = f; }
+	void setFrameHandler(std::function<void(const aisgpu_frame&, TAG&)> f) { on_frame = f; }
 	void Receive(const CFLOAT32* data, int len, TAG& tag) override { process(data, len, tag); }
 	void Receive(const CU8* data, int len, TAG& tag) override { process(data, len, tag); }
 	// Replay one channel's symbol decisions of a block into the five phase outputs (host logic,
@@ -115,6 +119,7 @@ class ModelDefaultGPU {
 	AIS::Decoder DEC_a[N_SAMPLES_PER_SYMBOL], DEC_b[N_SAMPLES_PER_SYMBOL];
 	AIS::Decoder DEC_af[N_SAMPLES_PER_SYMBOL], DEC_bf[N_SAMPLES_PER_SYMBOL]; // ModelChallenger only
 	bool challenger = false;
+	bool gpu_decode = false; // AIS::Decoder state machines on the device (ModelDefault only)
 	bool base = false; // AIS::ModelBase wiring: outFM -> SimplePLL -> one decoder per channel, decoder -> sampler feedback
 	SimplePLL sampler_a, sampler_b;
 	AIS::Decoder DEC_base_a, DEC_base_b;
@@ -141,6 +146,7 @@ public:
 	void setDroop(bool b) { droop_compensation = b; }
 	void setChallenger(bool b) { challenger = b; } // AIS::ModelChallenger wiring (Model.cpp:601-678) instead of ModelDefault
 	void setBase(bool b) { base = b; }             // AIS::ModelBase wiring (Model.cpp:419-438)
+	void setGpuDecode(bool b) { gpu_decode = b; }  // frames from aisgpu_frames() instead of replaying decisions
 	// same signature as AIS::Model::buildModel (the Device* of the reference is only used for wiring there)
 	void buildModel(char CH1, char CH2, int sample_rate, bool timerOn, void* device);
 	// decoder wiring only, no GPU context (CPU tests of the replay/decoder host logic)

@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--receivers", type=int, default=256)
     ap.add_argument("--preroll", type=int, default=40, help="untimed steps before the warm-up (GPU clock ramp)")
+    ap.add_argument("--gpu-decode", action="store_true", help="also run the AIS::Decoder state machines on the device (frames out)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -123,7 +124,7 @@ def main():
     nb = 2  # distinct resident blocks cycled (2 x 1.6 GB)
     rx_ids = shard.receiver_range(rank, world, R)  # this rank's receivers; no other rank touches them
     data = make_resident_input(torch, R, nb, seed=rx_ids[0] // R)
-    g = gpu.AisGpu(sample_rate=RATE, n_receivers=R, block_len=BLOCK, device_id=local)
+    g = gpu.AisGpu(sample_rate=RATE, n_receivers=R, block_len=BLOCK, device_id=local, gpu_decode=args.gpu_decode)
 
     def step(i):
         g.submit_device(data[i % nb].data_ptr(), BLOCK)
@@ -189,7 +190,7 @@ def main():
         "config": {"workload": "BASELINE configs[3]: %d batched dual-channel receivers per GPU, 1536 kSPS CF32, "
                                "%d IQ samples per receiver per step, resident in HBM, chain up to hard bits/levels/ppm"
                                % (R, BLOCK),
-                   "receivers_per_gpu": R, "block_len": BLOCK, "sample_rate": RATE, "parallelism": "receivers sharded, no collective"},
+                   "gpu_frame_decoder": bool(args.gpu_decode), "receivers_per_gpu": R, "block_len": BLOCK, "sample_rate": RATE, "parallelism": "receivers sharded, no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_bytes_per_launch": traffic_bytes,

@@ -56,6 +56,7 @@ extern "C" {
 #define AISGPU_FLAG_TAPS 1    /* keep intermediate float taps readable via aisgpu_tap() (tests) */
 #define AISGPU_FLAG_SERIAL 2  /* profiling aid: one stream, no overlap between the kernels of consecutive blocks */
 #define AISGPU_FLAG_PS_BOXCAR 8 /* KEY_SETTING_PS_EMA off: Demod::PhaseSearch (boxcar history) instead of PhaseSearchEMA (Model.cpp:550-555) */
+#define AISGPU_FLAG_GPU_DECODE 16 /* run AIS::Decoder (frame decoder + Reset mesh) on the device too: aisgpu_frames() (ModelDefault only) */
 #define AISGPU_FLAG_DSK 4     /* KEY_SETTING_DSK (`-go DSK on`): 576k / 1152k / 2304k use the decimate-by-3 ladder (Model.cpp:130) */
 
 typedef struct aisgpu aisgpu_t;
@@ -116,6 +117,21 @@ int aisgpu_fetch(aisgpu_t* h, int rx, int ch, aisgpu_out* out); /* == aisgpu_fet
  * (each is one Receive() call of everything behind the resampler in the reference).  aisgpu_out_count() tells how
  * many the last aisgpu_run() completed (always 1 for the 2^k rates); fetch them in order with aisgpu_fetch_sub(). */
 int aisgpu_out_count(aisgpu_t* h);
+
+/* AISGPU_FLAG_GPU_DECODE: the frames the ten AIS::Decoder objects of every receiver completed with a good CRC during the
+ * last aisgpu_run() (replaces feeding aisgpu_out's decisions to AIS::Decoder::Receive, Marine/AIS.h:82-181).  What is left
+ * for the caller is AIS::Decoder::processData's tail (Marine/AIS.cpp:66-96): tag.level = level_sum / position (and its dB
+ * conversion), Message::validate, buildNMEA.  Sorted the way the reference emits: by receiver, then downstream block,
+ * channel A before channel B, group, phase.  Valid after aisgpu_sync_outputs() until the next aisgpu_run(). */
+typedef struct aisgpu_frame {
+	int rx, ch, phase, sub;   /* receiver, channel 0/1, decoder DEC_x[phase], downstream block of this run */
+	int group;                /* group (symbol index of the phase chain) inside that block whose bit completed the closing flag */
+	int position;             /* decoder bit position at that moment; the frame incl. its FCS is position - 7 bits long */
+	float level_sum;          /* sum of tag.sample_lvl over the frame's bits */
+	long long start_idx, end_idx; /* tag.sample_idx at the start flag / at the last bit */
+	unsigned char data[144];  /* bits as received (Message::setBit order: bit i -> byte i/8, bit i%8) */
+} aisgpu_frame;
+int aisgpu_frames(aisgpu_t* h, const aisgpu_frame** frames, int* count);
 int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* out);
 
 /* Float taps of the last block (tests only; needs AISGPU_FLAG_TAPS):

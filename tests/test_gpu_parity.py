@@ -439,3 +439,46 @@ def test_model_base_nmea_end_to_end():
     assert m.nmea() == chk.nmea() and len(chk.nmea()) >= 3
     a, c = m.msg_meta(), chk.msg_meta()
     assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+
+
+@pytest.mark.parametrize("block,nblocks,fmt", [(786432, 4, "cf32"), (16384, 96, "cf32"), (131072, 16, "cu8")])
+def test_gpu_frame_decoder_nmea(block, nblocks, fmt):
+    """AISGPU_FLAG_GPU_DECODE: the ten AIS::Decoder state machines (NRZI, flags, de-stuffing, CRC, early aborts, Reset mesh)
+    run on the device; the host only formats the frames that come back.  NMEA text, levels and ppm against the checker,
+    with block sizes that cut frames at every possible place."""
+    from ais_catcher_amd import host
+    x = synth.receiver_stream(block * nblocks, receiver_id=71, type5_every=3, gap_slots=(0, 1))
+    data = synth.to_cu8(x) if fmt == "cu8" else x
+    per = 2 if fmt == "cu8" else 1
+    chk = checkers.Ref(fmt=fmt) if checkers.have_ref() else checkers.Oracle(fmt=fmt)
+    chk.feed_blocks(data, block)
+    host.reset_sequence()
+    m = host.ModelDefaultGPU(block_len=block, input_format=gpu.FMT_CU8 if fmt == "cu8" else gpu.FMT_CF32, gpu_decode=True)
+    for b in range(nblocks):
+        m.receive(data[b * block * per:(b + 1) * block * per])
+    assert len(chk.nmea()) >= 8
+    assert m.nmea() == chk.nmea()
+    a, c = m.msg_meta(), chk.msg_meta()
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+
+
+def test_gpu_frame_decoder_matches_host_decoders_on_a_batch():
+    """8 receivers, noisy weak signals (many false trainings, aborted and CRC-failing frames): device decoders == host decoders."""
+    from ais_catcher_amd import host
+    block, nblocks, R = 131072, 12, 8
+    streams = [synth.receiver_stream(block * nblocks, receiver_id=80 + r, gap_slots=(0, 2), noise_sigma=0.05 + 0.03 * r) for r in range(R)]
+    out = []
+    for dec in (False, True):
+        host.reset_sequence()
+        batch = host.Batch(n_receivers=R, block_len=block, gpu_decode=dec)
+        models = [host.ModelDefaultGPU(block_len=block, batch=batch, rx=r) for r in range(R)]
+        import threading
+        def work(r):
+            for b in range(nblocks):
+                models[r].receive(streams[r][b * block:(b + 1) * block])
+        th = [threading.Thread(target=work, args=(r,)) for r in range(R)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        out.append([sorted(mm.nmea()) for mm in models])
+    assert out[0] == out[1]
+    assert sum(len(o) for o in out[0]) >= 8
