@@ -93,6 +93,7 @@ struct aisgpu {
 	hipEvent_t ev_c48free[NBUF] = {}; // s1: K2c(f) done (c48/fz/rotT[q] consumed) -> s0 may run the front end of f+NBUF
 	hipEvent_t ev_ema[2] = {};        // s2: K4(f) done (sym/lvl[p] consumed)
 	hipEvent_t ev_k3[2] = {};         // front stream: sym/lvl[p] of block f written -> s2 may run K4(f)
+	hipEvent_t ev_k4[2] = {};         // s2: bits[p] of block f written -> s5 may run the frame decoder
 	// device buffers
 	void* d_in = nullptr; void* d_hist = nullptr; void* d_hist2 = nullptr;
 	float2* d_xpre[2] = {};           // pre-decimated stream: [R][xh + n_pre], ping-pong by input block (MODE_PRE uses [0] only)
@@ -305,7 +306,15 @@ int enqueue_back(aisgpu_t* h) {
 	if (h->ps_box) HIPCHK(launch_k4_box(k4, h->s2));
 	else if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, h->s2));
 	else HIPCHK(launch_k4_sequential(k4, h->s2));
-	{ int rc = enqueue_decode(h, pb, g0, (int)(g1 - g0), h->pend.block, h->pend.sub, h->s2); if (rc) return rc; }
+	if (h->gpu_decode) { // the frame decoder is a long latency-bound kernel of a few waves: own stream, so that the next
+		// block's PhaseSearchEMA does not queue behind it; sym/lvl/bits[pb] are free again only when IT is done
+		HIPCHK(hipEventRecord(h->ev_k4[pb], h->s2));
+		HIPCHK(hipStreamWaitEvent(h->s5, h->ev_k4[pb], 0));
+		int rc = enqueue_decode(h, pb, g0, (int)(g1 - g0), h->pend.block, h->pend.sub, h->s5);
+		if (rc) return rc;
+		HIPCHK(hipEventRecord(h->ev_ema[pb], h->s5));
+		return AISGPU_OK;
+	}
 	HIPCHK(hipEventRecord(h->ev_ema[pb], h->s2));
 	return AISGPU_OK;
 }
@@ -677,6 +686,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	}
 	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_ema[i], hipEventDisableTiming));
 	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_k3[i], hipEventDisableTiming));
+	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_k4[i], hipEventDisableTiming));
 	if (const char* e = getenv("AISGPU_DEFER")) h->defer = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_TRACE")) h->trace = atoi(e) != 0;
 
@@ -813,6 +823,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	for (int i = 0; i < 2; i++) {
 		if (h->ev_ema[i]) hipEventDestroy(h->ev_ema[i]);
 		if (h->ev_k3[i]) hipEventDestroy(h->ev_k3[i]);
+		if (h->ev_k4[i]) hipEventDestroy(h->ev_k4[i]);
 		hipFree(h->d_sym[i]); hipFree(h->d_lvl[i]); hipFree(h->d_bits[i]); hipFree(h->d_ema[i]);
 		hipFree(h->d_rot[i]); if (h->h_rot[i]) hipHostFree(h->h_rot[i]); if (h->rot_ev[i]) hipEventDestroy(h->rot_ev[i]);
 		hipFree(h->d_usidx[i]); hipFree(h->d_usalpha[i]); hipFree(h->d_xpre[i]);

@@ -115,7 +115,7 @@ struct K4Params {
 // K7: AIS::Decoder on the device (frame decoder).  One lane per decoder, 12 meshes of 5 decoders per wave.
 constexpr int DEC_DATA_WORDS = 36;  // MAX_AIS_FRAME_LENGTH = 1064 + 16 + 7 bits -> 136 bytes
 constexpr int DEC_FRAME_WORDS = 10 + DEC_DATA_WORDS; // record: decoder, group, position, level bits, start_idx (2), end_idx (2), block, sub, data
-struct DecState { int state, lastBit, prev, position, osc; float level; long long start_idx; uint32_t data[DEC_DATA_WORDS]; };
+struct DecState { int state, lastBit, prev, position, osc; float level; long long start_idx; uint32_t crc[8]; uint32_t data[DEC_DATA_WORDS]; };
 struct K7Params {
 	const uint32_t* bits; long long bits_stride; // [n_chan * 5][bits_stride] packed hard decisions
 	const float* lvl; long long lvl_stride;      // [n_chan][lvl_stride]

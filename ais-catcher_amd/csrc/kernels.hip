@@ -1811,13 +1811,16 @@ __global__ __launch_bounds__(256) void k5_filter(K5Params p) {
 // reset cannot complete a frame, so one repair pass is enough).  Frames leave as records (bits as received, level sum,
 // indices); length validation, the level in dB and the NMEA text stay on the host (Marine/Message.cpp), they are string work.
 // ------------------------------------------------------------------------------------------
-struct DecReg { int state, lastBit, prev, position, osc; float level; long long start_idx; };
+struct DecReg { int state, lastBit, prev, position, osc; float level; long long start_idx; uint32_t crc, cw; int cwi; };
 enum { DST_TRAINING = 0, DST_STARTFLAG = 1, DST_DATAFCS = 3 };
 constexpr int DEC_MAX_FRAME = 1064 + 16 + 7;
 
-__device__ __forceinline__ bool dec_cannot_be_valid(const uint32_t* data, int len) { // Marine/AIS.cpp:111-142
-	if (len < 30) return false;
-	const uint32_t w0 = data[0], w1 = data[64];
+// positions at which Decoder::cannotBeValid (Marine/AIS.cpp:111-142) looks at the message type: 6, 38, 72, 144, 160, 168, 312,
+// 361, 424 bits + 24
+__device__ __forceinline__ bool dec_check_position(int len) {
+	return len == 30 || len == 62 || len == 96 || len == 168 || len == 184 || len == 192 || len == 336 || len == 385 || len == 448;
+}
+__device__ __forceinline__ bool dec_cannot_be_valid(uint32_t w0, uint32_t w1, int len) { // Marine/AIS.cpp:111-142
 	const int t = (int)((w0 & 255u) >> 2);
 	switch (len) {
 	case 30: return t > 28 || t == 0;
@@ -1834,51 +1837,76 @@ __device__ __forceinline__ bool dec_cannot_be_valid(const uint32_t* data, int le
 }
 
 // one symbol; data = this lane's column of the LDS frame buffer (word w at data[64 * w]); returns true when a frame with a
-// good CRC has just been completed (r.position / r.level still hold the frame's values, the caller finishes the transition)
+// good CRC has just been completed (r.position / r.level still hold the frame's values, the caller finishes the transition).
+// A wave's decoders are in all states at once and the wave is alone on its SIMD, so what counts is the length of the
+// dependent chain per symbol:
+//  * TRAINING and STARTFLAG are evaluated with selects, only the DATAFCS work sits in a branch;
+//  * the 32-bit word of the frame that is being filled lives in a register (r.cw) and goes to LDS when the position moves
+//    on to another word;
+//  * the CRC-16/X.25 register (AIS.cpp:55-64) advances with every stored bit -- a de-stuffed bit simply does not advance
+//    it.  The residue check covers the first position-7 bits, so when the closing flag is complete the last seven steps
+//    are undone: the step c' = (c >> 1) ^ ((b ^ c) & 1 ? 0x8408 : 0) is invertible (bit 15 of c' tells whether the
+//    polynomial was applied).  No loop over the frame at that moment, which would stall the other 59 decoders.
 __device__ __forceinline__ bool dec_step(DecReg& r, int dd, float slvl, long long sidx, uint32_t* data) {
 	const int Bit = !(dd ^ r.prev); // NRZI
 	r.prev = dd;
 	bool found = false;
-	if (r.state == DST_TRAINING) {
-		if (Bit != r.lastBit) r.position++;
-		else if (r.position > 4) { r.start_idx = sidx; r.state = DST_STARTFLAG; r.position = Bit ? 3 : 1; r.osc = 0; }
-		else { r.position = 0; r.osc = 0; }
-	} else if (r.state == DST_STARTFLAG) {
-		if (r.position == 7) {
-			if (Bit == 0) {
-				r.state = DST_DATAFCS; r.position = 0; r.osc = 0; r.level = 0.0f;
-				for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = 0u; // msg.clear()
-			} else { r.state = DST_TRAINING; r.position = 0; r.osc = 0; }
-		} else if (Bit == 1) r.position++;
-		else { r.state = DST_TRAINING; r.position = 0; r.osc = 0; }
-	} else { // DATAFCS
-		if (r.position < DEC_MAX_FRAME) {
-			uint32_t* w = data + 64 * (r.position >> 5);
-			const uint32_t m = 1u << (r.position & 31);
-			*w = Bit ? (*w | m) : (*w & ~m);
+	const int st = r.state, pos = r.position;
+	if (st == DST_DATAFCS) {
+		const int wi = pos >> 5;
+		if (wi != r.cwi) { // the position moved on to another word (backwards only after a de-stuffed bit: reload)
+			data[64 * r.cwi] = r.cw;
+			r.cw = wi < r.cwi ? data[64 * wi] : 0u;
+			r.cwi = wi;
 		}
-		r.position++;
+		if (pos < DEC_MAX_FRAME) {
+			const uint32_t m = 1u << (pos & 31);
+			r.cw = Bit ? (r.cw | m) : (r.cw & ~m);
+		}
+		const bool stuffed = Bit == 0 && r.osc == 5;
+		if (!stuffed) r.crc = (((uint32_t)Bit ^ r.crc) & 1u) ? ((r.crc >> 1) ^ 0x8408u) : (r.crc >> 1);
+		int np = stuffed ? pos : pos + 1, nosc = Bit ? r.osc + 1 : 0, nst = DST_DATAFCS;
 		r.level += slvl; // tag.mode & 1 (Common.h:242)
-		if (Bit == 1) {
-			if (r.osc == 5) { // closing flag (or abort)
-				const int len = r.position - 7;
-				if (len >= 16) { // CRC-16/X.25 residue over the bits as received (AIS.cpp:55-64)
-					uint32_t crc = 0xFFFFu;
-					for (int i = 0; i < len; i++) {
-						const uint32_t b = (data[64 * (i >> 5)] >> (i & 31)) & 1u;
-						crc = ((b ^ crc) & 1u) ? ((crc >> 1) ^ 0x8408u) : (crc >> 1);
-					}
-					found = crc == (uint32_t)(uint16_t)~0x0F47;
+		if (Bit == 1 && r.osc == 5) { // six ones: closing flag (or abort)
+			const int len = np - 7;
+			if (len >= 16) {
+				data[64 * r.cwi] = r.cw;
+				const int lo = len >> 5;
+				const unsigned long long two = (unsigned long long)data[64 * lo] | ((unsigned long long)data[64 * (lo + 1 < DEC_DATA_WORDS ? lo + 1 : lo)] << 32);
+				const uint32_t tail = (uint32_t)(two >> (len & 31)) & 127u; // bits len .. len+6, the last seven stored
+				uint32_t c = r.crc;
+#pragma unroll
+				for (int i = 6; i >= 0; i--) { // undo bit len+i
+					const uint32_t x = (c >> 15) & 1u;
+					c = (((c ^ (x ? 0x8408u : 0u)) << 1) | (x ^ ((tail >> i) & 1u))) & 0xFFFFu;
 				}
-				if (!found) { r.state = DST_TRAINING; r.position = 0; r.osc = 0; }
-			} else r.osc++;
-		} else {
-			if (r.osc == 5) r.position--; // bit de-stuffing
-			r.osc = 0;
+				found = c == (uint32_t)(uint16_t)~0x0F47;
+			}
+			if (!found) { nst = DST_TRAINING; np = 0; }
+			nosc = 0;
 		}
-		if (!found && r.state == DST_DATAFCS && (r.position == DEC_MAX_FRAME || dec_cannot_be_valid(data, r.position))) {
-			r.state = DST_TRAINING; r.position = 0; r.osc = 0;
+		if (!found && nst == DST_DATAFCS && (np == DEC_MAX_FRAME || (dec_check_position(np) &&
+		        dec_cannot_be_valid(r.cwi == 0 ? r.cw : data[0], r.cwi == 1 ? r.cw : data[64], np)))) {
+			nst = DST_TRAINING; np = 0; nosc = 0;
 		}
+		r.state = nst; r.position = np; r.osc = nosc; // (when found, position still is the frame's: the caller needs it)
+	} else {
+		// TRAINING: count alternations; two equal bits after more than four of them are the start of a flag
+		const bool alt = Bit != r.lastBit;
+		const bool to_flag = !alt && pos > 4;
+		const int t_state = to_flag ? DST_STARTFLAG : DST_TRAINING;
+		const int t_pos = alt ? pos + 1 : (to_flag ? (Bit ? 3 : 1) : 0);
+		// STARTFLAG: ones up to position 7, then a zero opens the frame
+		const bool open = pos == 7 && Bit == 0;
+		const bool more = pos != 7 && Bit == 1;
+		const int f_state = open ? DST_DATAFCS : (more ? DST_STARTFLAG : DST_TRAINING);
+		const int f_pos = more ? pos + 1 : 0;
+		const bool training = st == DST_TRAINING;
+		r.state = training ? t_state : f_state;
+		r.position = training ? t_pos : f_pos;
+		if (training && to_flag) r.start_idx = sidx;
+		if (training ? !alt : !more) r.osc = 0; // every NextState() call clears one_seq_count (AIS.cpp:33-37)
+		if (!training && open) { r.level = 0.0f; r.crc = 0xFFFFu; r.cw = 0u; r.cwi = 0; } // (msg.clear(): bits at and beyond `position` are never read)
 	}
 	r.lastBit = Bit;
 	return found;
@@ -1899,12 +1927,20 @@ __global__ __launch_bounds__(64) void k7_decode(K7Params p) {
 	r.state = st->state; r.lastBit = st->lastBit; r.prev = st->prev; r.position = st->position; r.osc = st->osc;
 	r.level = st->level; r.start_idx = st->start_idx;
 	for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = st->data[w];
+	r.crc = st->crc[0]; r.cw = st->crc[1]; r.cwi = (int)st->crc[2];
 	const uint32_t* brow = p.bits + (size_t)dec * p.bits_stride;
 	const float* lrow = p.lvl + (size_t)chan * p.lvl_stride;
 	for (int g0 = 0; g0 < p.n_groups; g0 += 32) {
 		const uint32_t word = brow[g0 >> 5];
 		const int n = p.n_groups - g0 < 32 ? p.n_groups - g0 : 32;
-		for (int e = 0; e < 32; e++) lv[lane * 33 + e] = e < n ? lrow[g0 + e] : 0.0f;
+		{ // the row is padded to a multiple of 32 groups: eight unconditional 16-byte loads, issued together
+			const float4* src = reinterpret_cast<const float4*>(lrow + g0);
+			float4 t[8];
+#pragma unroll
+			for (int q = 0; q < 8; q++) t[q] = src[q];
+#pragma unroll
+			for (int q = 0; q < 8; q++) { float* d = &lv[lane * 33 + 4 * q]; d[0] = t[q].x; d[1] = t[q].y; d[2] = t[q].z; d[3] = t[q].w; }
+		}
 		for (int e = 0; e < n; e++) {
 			const int g = g0 + e;
 			const int dd = (int)((word >> e) & 1u);
@@ -1942,7 +1978,9 @@ __global__ __launch_bounds__(64) void k7_decode(K7Params p) {
 	if (live) {
 		st->state = r.state; st->lastBit = r.lastBit; st->prev = r.prev; st->position = r.position; st->osc = r.osc;
 		st->level = r.level; st->start_idx = r.start_idx;
+		data[64 * r.cwi] = r.cw;
 		for (int w = 0; w < DEC_DATA_WORDS; w++) st->data[w] = data[64 * w];
+		st->crc[0] = r.crc; st->crc[1] = r.cw; st->crc[2] = (uint32_t)r.cwi;
 	}
 }
 
