@@ -95,7 +95,7 @@ struct aisgpu {
 	hipEvent_t ev_k3[2] = {};         // front stream: sym/lvl[p] of block f written -> s2 may run K4(f)
 	hipEvent_t ev_k4[2] = {};         // s2: bits[p] of block f written -> s5 may run the frame decoder
 	// device buffers
-	void* d_in = nullptr; void* d_hist = nullptr; void* d_hist2 = nullptr;
+	void* d_in = nullptr; void* d_hist[2] = {}; void* d_hist2[2] = {}; // input tails, double buffered (read by span 0, written for the next block)
 	float2* d_xpre[2] = {};           // pre-decimated stream: [R][xh + n_pre], ping-pong by input block (MODE_PRE uses [0] only)
 	float2* d_rot[2] = {};
 	int* d_usidx[2] = {}; float* d_usalpha[2] = {};
@@ -720,14 +720,16 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	// history of the raw input: the last tile of the previous block (for the first kernel that touches the input)
 	{
 		const size_t first_tile = KP > 0 ? h->ptile_in : (h->tile_in > 0 ? h->tile_in : 64);
-		HIPCHK(dalloc((unsigned char**)&h->d_hist, R * first_tile * h->in_bytes));
-		// zero signal before the stream starts: CU8 zero is the byte 128 (Utilities/Convert.cpp:255-264)
-		if (cfg->input_format == AISGPU_FMT_CU8) HIPCHK(hipMemset(h->d_hist, 0x80, R * first_tile * h->in_bytes));
+		for (int i = 0; i < 2; i++) {
+			HIPCHK(dalloc((unsigned char**)&h->d_hist[i], R * first_tile * h->in_bytes));
+			// zero signal before the stream starts: CU8 zero is the byte 128 (Utilities/Convert.cpp:255-264)
+			if (cfg->input_format == AISGPU_FMT_CU8) HIPCHK(hipMemset(h->d_hist[i], 0x80, R * first_tile * h->in_bytes));
+		}
 	}
 	if (KP > 0 || mode == MODE_DSK) {
 		const int nx = mode == MODE_RESAMPLE || mode == MODE_DSK ? 2 : 1;
 		for (int i = 0; i < nx; i++) HIPCHK(dalloc(&h->d_xpre[i], R * ((size_t)h->xh + h->n_pre)));
-		if (mode == MODE_PRE) HIPCHK(dalloc((unsigned char**)&h->d_hist2, R * h->tile_in * 8));
+		if (mode == MODE_PRE) for (int i = 0; i < 2; i++) HIPCHK(dalloc((unsigned char**)&h->d_hist2[i], R * h->tile_in * 8));
 	}
 	for (int i = 0; i < 2; i++) {
 		HIPCHK(dalloc(&h->d_rot[i], (size_t)ROT_HIST + h->n96));
@@ -831,7 +833,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 		if (h->h_usalpha[i]) hipHostFree(h->h_usalpha[i]);
 	}
 	for (auto& p : h->ev_free) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-	hipFree(h->d_in); hipFree(h->d_hist); hipFree(h->d_hist2);
+	hipFree(h->d_in); hipFree(h->d_hist[0]); hipFree(h->d_hist[1]); hipFree(h->d_hist2[0]); hipFree(h->d_hist2[1]);
 	hipFree(h->d_fm); hipFree(h->d_fmbits[0]); hipFree(h->d_fmbits[1]);
 	if (h->h_fmbits) hipHostFree(h->h_fmbits);
 	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); hipFree(h->d_ckw[i]); }
@@ -923,7 +925,9 @@ int aisgpu_run(aisgpu_t* h) {
 		if (two && h->in_blocks > 0) // history = the last xh samples before this block
 			HIPCHK(launch_copy_rows(h->d_xpre[xb ^ 1] + h->n_pre, xstride, xcur, xstride, h->xh, R, h->stream));
 		K1Params kp{};
-		kp.in = h->cur_in; kp.in_stride = h->cur_in_stride; kp.hist = h->d_hist; kp.rot = nullptr;
+		const int hb = (int)(h->in_blocks & 1);
+		const bool pre_saves = !cu8 && h->KP >= 2 && h->depth == 0; // the register/LDS-DMA kernel saves the tail itself
+		kp.in = h->cur_in; kp.in_stride = h->cur_in_stride; kp.hist = h->d_hist[hb]; kp.hist_out = pre_saves ? h->d_hist[hb ^ 1] : nullptr; kp.rot = nullptr;
 		kp.c48 = nullptr; kp.c48_stride = 0;
 		kp.tiles_per_block = h->ptiles_per_block; kp.tiles_per_span = h->ptiles_per_span;
 		kp.alpha = 0; kp.beta = 1; kp.has_fdc = 0;
@@ -931,8 +935,8 @@ int aisgpu_run(aisgpu_t* h) {
 		int rc = time_begin(); if (rc) return rc;
 		HIPCHK(launch_k1(kp, h->KP, cu8, h->tile96, h->depth, h->k1_threads, h->pspans, R, h->stream));
 		rc = time_end(); if (rc) return rc;
-		HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist,
-		                      h->ptile_in * h->in_bytes, R, h->stream));
+		if (!pre_saves) HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist[hb ^ 1],
+		                                      h->ptile_in * h->in_bytes, R, h->stream));
 	}
 
 	if (h->mode == MODE_DSK) {
@@ -968,7 +972,10 @@ int aisgpu_run(aisgpu_t* h) {
 		const bool from_pre = h->mode == MODE_PRE;
 		k1.in = from_pre ? (const void*)xcur : h->cur_in;
 		k1.in_stride = from_pre ? xstride : h->cur_in_stride;
-		k1.hist = from_pre ? h->d_hist2 : h->d_hist;
+		const int hb = (int)(h->in_blocks & 1);
+		const bool saves = (from_pre || !cu8) && h->K >= 2 && h->depth == 0; // the register/LDS-DMA kernel saves the tail itself
+		k1.hist = from_pre ? h->d_hist2[hb] : h->d_hist[hb];
+		k1.hist_out = !saves ? nullptr : from_pre ? h->d_hist2[hb ^ 1] : h->d_hist[hb ^ 1];
 		k1.rot = h->d_rot[pb];
 		k1.c48 = h->d_c48[q]; k1.c48_stride = h->c48s;
 		k1.tiles_per_block = h->tiles_per_block; k1.tiles_per_span = h->tiles_per_span;
@@ -977,8 +984,9 @@ int aisgpu_run(aisgpu_t* h) {
 		if (!from_pre) { int rc = time_begin(); if (rc) return rc; }
 		{ TraceScope t(h, "front", h->stream); HIPCHK(launch_k1(k1, h->K, from_pre ? false : cu8, h->tile96, h->depth, h->k1_threads, h->spans, R, h->stream)); }
 		if (!from_pre) { int rc = time_end(); if (rc) return rc; }
-		if (from_pre) HIPCHK(launch_k1_tail(xcur, xstride * 8, (long long)h->n_pre * 8, h->d_hist2, h->tile_in * 8, R, h->stream));
-		else HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist,
+		if (saves) {}
+		else if (from_pre) HIPCHK(launch_k1_tail(xcur, xstride * 8, (long long)h->n_pre * 8, h->d_hist2[hb ^ 1], h->tile_in * 8, R, h->stream));
+		else HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist[hb ^ 1],
 		                           h->tile_in * h->in_bytes, R, h->stream));
 		int rc = enqueue_downstream(h, q, pb);
 		if (rc) return rc;

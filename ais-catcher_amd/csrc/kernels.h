@@ -13,6 +13,7 @@ struct K1Params {
 	const void* in;          // [n_rx][in_stride] input samples (float2 or uchar2)
 	long long in_stride;     // samples
 	const void* hist;        // [n_rx][tile] last tile of the previous block
+	void* hist_out;          // != nullptr (k1_dpp, CF32, K >= 2): the wave that reads the block's last tile saves it here for the next block
 	const float2* rot;       // [ROT_HIST + block_len >> K] Rotate phasor per 96 kHz sample (host generated)
 	float2* c48;             // [n_rx][2][c48_stride] 48 kHz front-end output (FCIC5_a/b.out)
 	long long c48_stride;

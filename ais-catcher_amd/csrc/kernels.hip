@@ -607,6 +607,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 				x[2 * e] = c2{ v.x, v.y }; x[2 * e + 1] = c2{ v.z, v.w };
 			}
 			wave_sync(); // the tile is in registers: the next one may land in xt
+			if (p.hist_out && tile == p.tiles_per_block - 1) { // the block's last tile is the next block's warm-up tile
+				float4* ho = reinterpret_cast<float4*>((unsigned char*)p.hist_out + (size_t)rx * TILE_BYTES) + lane * W4;
+#pragma unroll
+				for (int e = 0; e < W4; e++) ho[e] = make_float4(x[2 * e].x, x[2 * e].y, x[2 * e + 1].x, x[2 * e + 1].y);
+			}
 		}
 		// the Rotate phasor travels one tile ahead like the samples: with a global_load_lds in flight the compiler
 		// waits for ALL vector memory operations at the first use of an ordinary load, so the only such use sits
@@ -1269,6 +1274,20 @@ __global__ __launch_bounds__(256) void k2_cgf_apply(K2Params p) {
 	__shared__ float2 tile[64][65];
 	const int t = threadIdx.x;
 	const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+	if (blockIdx.x == gridDim.x - 1) {
+		// the workgroup that overwrites the row's last CGF_HIST samples first carries them (the previous block's tail: FIR-17
+		// history + a partial ScatterPLL group) to the front of the row; nobody else touches either range in this launch
+		const int L = p.n_windows * 512;
+#pragma unroll
+		for (int q = 0; q < 16; q++) {
+			const int c = c0 + (t >> 6) + 4 * q;
+			if (c < p.n_chan) {
+				float2* y = p.cgf + (size_t)c * p.cgf_stride;
+				y[t & 63] = y[L + (t & 63)];
+			}
+		}
+		__syncthreads();
+	}
 	{
 		const int cc = t & 63, nn = t >> 6; // 4 time rows per pass
 #pragma unroll
@@ -1387,7 +1406,7 @@ __device__ __forceinline__ unsigned ps_step(float2 v, float pc, float psn, float
 	return (unsigned)(X >> (rowbase + idx)) & 1u;
 }
 
-constexpr int PS_BATCH = 16; // symbols whose samples are fetched together
+constexpr int PS_BATCH = 8;  // symbols whose samples are fetched together
 
 template <int MODE>
 __device__ __forceinline__ void ps_chain(const float2* __restrict__ x, uint32_t* __restrict__ out, int n, bool writer, float pc,
@@ -2130,8 +2149,7 @@ hipError_t launch_k6(const K6Params& p, hipStream_t s) {
 	return hipGetLastError();
 }
 
-hipError_t launch_k2c(const K2Params& p, int n_chan, hipStream_t s) {
-	hipLaunchKernelGGL(k2_cgf_carry, dim3(n_chan), dim3(64), 0, s, p);
+hipError_t launch_k2c(const K2Params& p, int n_chan, hipStream_t s) { // history carry (inside the last tile's workgroups) + apply
 	hipLaunchKernelGGL(k2_cgf_apply, dim3(p.n_windows * 8, (n_chan + 63) / 64), dim3(256), 0, s, p);
 	return hipGetLastError();
 }
