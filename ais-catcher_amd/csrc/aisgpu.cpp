@@ -117,6 +117,7 @@ struct aisgpu {
 	float2* h_rot[2] = {};
 	int* h_usidx[2] = {}; float* h_usalpha[2] = {};
 	hipEvent_t rot_ev[2] = {};
+	float2* h_rot_dev[2] = {}; bool rot_by_kernel = true; // device view of the pinned table buffers
 	uint32_t* h_bits = nullptr; float* h_lvl = nullptr; float* h_ppm = nullptr; // MAXSUB slots each
 	// stream state
 	long long in_blocks = 0;     // input blocks run so far
@@ -735,6 +736,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(dalloc(&h->d_rot[i], (size_t)ROT_HIST + h->n96));
 		HIPCHK(hipHostMalloc((void**)&h->h_rot[i], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipHostMallocDefault));
 		HIPCHK(hipEventCreateWithFlags(&h->rot_ev[i], hipEventDisableTiming));
+		if (hipHostGetDevicePointer((void**)&h->h_rot_dev[i], h->h_rot[i], 0) != hipSuccess) h->rot_by_kernel = false;
+		if (const char* e = getenv("AISGPU_ROTCOPY")) h->rot_by_kernel = h->rot_by_kernel && atoi(e) == 0;
 		if (mode == MODE_RESAMPLE) {
 			HIPCHK(dalloc(&h->d_usidx[i], (size_t)US_HIST + h->n_pre));
 			HIPCHK(dalloc(&h->d_usalpha[i], (size_t)US_HIST + h->n_pre));
@@ -964,7 +967,10 @@ int aisgpu_run(aisgpu_t* h) {
 		// (only blocks when the host runs more than one block ahead of the device)
 		if (h->block_idx >= 2) HIPCHK(hipEventSynchronize(h->rot_ev[pb]));
 		gen_rot_table(h, h->h_rot[pb]);
-		HIPCHK(hipMemcpyAsync(h->d_rot[pb], h->h_rot[pb], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+		// a small kernel pulls the table out of the pinned host buffer (a copy-engine transfer in the middle of the front
+		// stream costs its set-up latency between two kernels)
+		if (h->rot_by_kernel) HIPCHK(launch_copy_rows(h->h_rot_dev[pb], 0, h->d_rot[pb], 0, ROT_HIST + h->n96, 1, h->stream));
+		else HIPCHK(hipMemcpyAsync(h->d_rot[pb], h->h_rot[pb], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
 		HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
 		// c48/fz/ppm[q] were last read by K2b/K2c of block f-NBUF
 		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[q], 0));
