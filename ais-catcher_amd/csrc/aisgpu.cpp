@@ -143,7 +143,7 @@ struct aisgpu {
 	bool ps_box = false; PsBoxState* d_box[2] = {}; // Demod::PhaseSearch (boxcar) instead of PhaseSearchEMA
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
-	bool fused = false; int GL = 40;
+	bool fused = false; int GL = 40; bool search_on_front = false;
 	float2 *d_ck[NBUF] = {}, *d_ckw[NBUF] = {}, *d_dfhist[2] = {};
 	// per-kernel geometry
 	int tile_in = 0, tiles_per_block = 0, tiles_per_span = 0, spans = 0;         // fused front end (its own input)
@@ -322,10 +322,9 @@ int enqueue_back(aisgpu_t* h) {
 
 // Default path: the phasor recurrence keeps checkpoints only, and one fused kernel derotates, filters and scatters.
 // Nothing behind the FFT touches the front stream, so nothing needs to be deferred:
-//   front stream: front end, FFT            (HBM-bound)
-//   s4: spectral searches                   (latency-bound)
+//   front stream: front end, FFT, spectral searches (HBM-bound + a short latency-bound kernel; four streams are the limit)
 //   s3: phasor recurrence, own CUs          (latency-bound)
-//   s5: derotation + FIR + ScatterPLL       (VALU/latency-bound)
+//   s4: derotation + FIR + ScatterPLL       (VALU/latency-bound)
 //   s1: PhaseSearchEMA                      (VALU-bound; both overlap the next block's front end)
 int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	K2Params k2 = make_k2(h, q);
@@ -336,9 +335,10 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	k2.ck_first = n_rel0 - 20; k2.ck_period = 5 * h->GL; k2.n_ck = S;
 	{ TraceScope t(h, "fft", h->stream); HIPCHK(launch_k2a_fft(k2, h->n_chan, h->stream)); }
 	HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
-	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_front[q], 0));
-	{ TraceScope t(h, "search", h->s4); HIPCHK(launch_k2a_search(k2, h->n_chan, h->s4)); }
-	HIPCHK(hipEventRecord(h->ev_search[q], h->s4));
+	hipStream_t ss = h->search_on_front ? h->stream : h->s4; // with the searches on the front stream four streams are enough
+	HIPCHK(hipStreamWaitEvent(ss, h->ev_front[q], 0));
+	{ TraceScope t(h, "search", ss); HIPCHK(launch_k2a_search(k2, h->n_chan, ss)); }
+	HIPCHK(hipEventRecord(h->ev_search[q], ss));
 	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_search[q], 0));
 	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_c48free[q], 0)); // ck[q] was last read by K6 of block f-NBUF
 	{ TraceScope t(h, "phasor", h->s3); HIPCHK(launch_k2b_ck(k2, h->n_chan, h->s3)); }
@@ -352,11 +352,11 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	memcpy(k6.taps, TAPS_COHERENT, sizeof k6.taps);
 	k6.first_group = g0; k6.n_rel0 = n_rel0; k6.n_groups = n_groups; k6.L = h->L; k6.n_windows = h->W; k6.n_chan = h->n_chan;
 	k6.GL = h->GL; k6.S = S;
-	HIPCHK(hipStreamWaitEvent(h->s5, h->ev_phasor[q], 0));
-	HIPCHK(hipStreamWaitEvent(h->s5, h->ev_ema[pb], 0)); // sym/lvl[pb] were last read by K4 of block f-2
-	{ TraceScope t(h, "derotfir", h->s5); HIPCHK(launch_k6(k6, h->s5)); }
-	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s5));
-	HIPCHK(hipEventRecord(h->ev_k3[pb], h->s5));
+	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_phasor[q], 0));
+	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_ema[pb], 0)); // sym/lvl[pb] were last read by K4 (or the frame decoder) of block f-2
+	{ TraceScope t(h, "derotfir", h->s4); HIPCHK(launch_k6(k6, h->s4)); }
+	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s4));
+	HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4));
 	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_k3[pb], 0));
 
 	K4Params k4;
@@ -372,8 +372,13 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 		else if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, h->s1));
 		else HIPCHK(launch_k4_sequential(k4, h->s1));
 	}
-	{ int rc = enqueue_decode(h, pb, g0, n_groups, (unsigned)h->block_idx, (unsigned)h->n_sub, h->s1); if (rc) return rc; }
-	HIPCHK(hipEventRecord(h->ev_ema[pb], h->s1));
+	if (h->gpu_decode) { // own stream, see enqueue_back()
+		HIPCHK(hipEventRecord(h->ev_k4[pb], h->s1));
+		HIPCHK(hipStreamWaitEvent(h->s5, h->ev_k4[pb], 0));
+		int rc = enqueue_decode(h, pb, g0, n_groups, (unsigned)h->block_idx, (unsigned)h->n_sub, h->s5);
+		if (rc) return rc;
+		HIPCHK(hipEventRecord(h->ev_ema[pb], h->s5));
+	} else HIPCHK(hipEventRecord(h->ev_ema[pb], h->s1));
 
 	if (h->n_sub < MAXSUB) {
 		SubOut& so = h->sub[h->n_sub++];
@@ -667,15 +672,17 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			HIPCHK(hipExtStreamCreateWithCUMask(&h->s1, (uint32_t)words, rest.data()));
 			HIPCHK(hipExtStreamCreateWithCUMask(&h->s3, (uint32_t)words, lat.data()));
 			HIPCHK(hipExtStreamCreateWithCUMask(&h->s4, (uint32_t)words, rest.data()));
-			if (getenv("AISGPU_S5") && atoi(getenv("AISGPU_S5")) == 4) h->s5 = h->s4;       // experiment: share the search stream
-			else if (getenv("AISGPU_S5") && atoi(getenv("AISGPU_S5")) == 1) h->s5 = h->s1;  // experiment: share the PhaseSearchEMA stream
-			else HIPCHK(hipExtStreamCreateWithCUMask(&h->s5, (uint32_t)words, rest.data()));
+			// a fifth stream only for the optional frame decoder: beyond four streams HIP shares hardware queues and kernels
+			// of different streams start waiting for each other (measured: 0.62 -> 0.69 ms per step)
+			if (cfg->flags & AISGPU_FLAG_GPU_DECODE) HIPCHK(hipExtStreamCreateWithCUMask(&h->s5, (uint32_t)words, rest.data()));
+			else h->s5 = h->s4;
 		} else {
 			HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 			HIPCHK(hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking));
 			HIPCHK(hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking));
 			HIPCHK(hipStreamCreateWithFlags(&h->s4, hipStreamNonBlocking));
-			HIPCHK(hipStreamCreateWithFlags(&h->s5, hipStreamNonBlocking));
+			if (cfg->flags & AISGPU_FLAG_GPU_DECODE) HIPCHK(hipStreamCreateWithFlags(&h->s5, hipStreamNonBlocking));
+			else h->s5 = h->s4;
 		}
 		h->s2 = h->s1; // apply + FIR + PhaseSearchEMA of a block run back to back on one stream
 	}
@@ -756,9 +763,12 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	}
 	h->ps_box = (cfg->flags & AISGPU_FLAG_PS_BOXCAR) != 0;
 	if (h->ps_box) for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_box[i], (size_t)h->n_chains));
-	// experimental (AISGPU_FUSED=1): bit-exact, but slower end to end than the materialised path so far
-	h->fused = false;
-	if (const char* e = getenv("AISGPU_FUSED")) h->fused = atoi(e) != 0 && !(cfg->flags & AISGPU_FLAG_TAPS) && !h->challenger;
+	// default: the fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); the materialised path serves
+	// the taps and the FM branch, which need those arrays, and stays selectable (AISGPU_FUSED=0)
+	h->fused = !(cfg->flags & AISGPU_FLAG_TAPS) && !h->challenger && !h->base;
+	if (const char* e = getenv("AISGPU_FUSED")) h->fused = h->fused && atoi(e) != 0;
+	h->search_on_front = h->fused; // keeps the stream count at four
+	if (const char* e = getenv("AISGPU_SEARCH0")) h->search_on_front = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_GL")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0) h->GL = v; }
 	if (h->fused) {
 		const size_t cs = (C + 63) / 64 * 64;
@@ -856,7 +866,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	if (h->s1 && !h->serial) hipStreamDestroy(h->s1);
 	if (h->s3 && !h->serial) hipStreamDestroy(h->s3);
 	if (h->s4 && !h->serial) hipStreamDestroy(h->s4);
-	if (h->s5 && !h->serial && h->s5 != h->s4 && h->s5 != h->s1) hipStreamDestroy(h->s5);
+	if (h->s5 && !h->serial && h->s5 != h->s4) hipStreamDestroy(h->s5);
 	delete h;
 }
 

@@ -482,3 +482,82 @@ def test_gpu_frame_decoder_matches_host_decoders_on_a_batch():
         out.append([sorted(mm.nmea()) for mm in models])
     assert out[0] == out[1]
     assert sum(len(o) for o in out[0]) >= 8
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The default (fused) back end: checkpointed phasor recurrence + derotation/FIR/ScatterPLL in one kernel.  It has no float
+# taps (nothing is materialised), so it is compared on everything it delivers: hard bits, levels, ppm, per block.
+# ---------------------------------------------------------------------------------------------------------------
+def _run_outputs_vs_oracle(streams, rate, fmt, block, nblocks, **kw):
+    R = len(streams)
+    okw = dict(dsk=kw.get("dsk", False), ps_ema=kw.get("ps_ema", True))
+    g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block,
+                   input_format=gpu.FMT_CU8 if fmt == "cu8" else gpu.FMT_CF32, taps=False, **kw)
+    per = 2 if fmt == "cu8" else 1
+    oracles = [checkers.Oracle(model=2, rate=rate, fmt=fmt, taps=True, **okw) for _ in range(R)]
+    for o, x in zip(oracles, streams):
+        o.feed_blocks(x, block)
+    oppm = [[o.tap_ppm(2), o.tap_ppm(3)] for o in oracles]
+    obits = [[[o.bits(ch, j) for j in range(5)] for ch in range(2)] for o in oracles]
+    gd = [[0, 0] for _ in range(R)]
+    wd = [[0, 0] for _ in range(R)]
+    for b in range(nblocks):
+        for r in range(R):
+            g.submit(r, streams[r][b * block * per:(b + 1) * block * per])
+        g.run()
+        g.sync_outputs()
+        for s in range(g.out_count()):
+            for r in range(R):
+                for ch in range(2):
+                    out = g.fetch(r, ch, s)
+                    n, g0, W = out["n_groups"], gd[r][ch], out["n_windows"]
+                    assert out["first_group"] == g0
+                    for j in range(5):
+                        assert np.array_equal(out["bits"][j], obits[r][ch][j][0][g0:g0 + n]), "bits b%d s%d r%d c%d j%d" % (b, s, r, ch, j)
+                    assert _feq(out["lvl"], obits[r][ch][0][1][g0:g0 + n]), "lvl b%d s%d r%d c%d" % (b, s, r, ch)
+                    assert _feq(out["ppm"], oppm[r][ch][wd[r][ch]:wd[r][ch] + W]), "ppm b%d s%d r%d c%d" % (b, s, r, ch)
+                    gd[r][ch] += n
+                    wd[r][ch] += W
+    assert gd[0][0] > 0
+    g.close()
+
+
+@pytest.mark.parametrize("block,nblocks", [(786432, 3), (16384, 30), (65536, 9)])
+def test_fused_backend_1536k(block, nblocks):
+    xs = [synth.receiver_stream(block * nblocks, receiver_id=90 + r, gap_slots=(0, 2)) for r in range(3)]
+    _run_outputs_vs_oracle(xs, 1536000, "cf32", block, nblocks)
+    _run_outputs_vs_oracle([synth.to_cu8(xs[0])], 1536000, "cu8", block, nblocks)
+
+
+@pytest.mark.parametrize("rate,kw", [(192000, {}), (768000, {}), (3072000, {}), (12288000, {}), (6000000, {}), (2400000, {}),
+                                     (288000, {}), (1152000, {"dsk": True})])
+def test_fused_backend_other_ladders(rate, kw):
+    if rate in (288000, 1152000):
+        block = 24576 * (rate // 288000) * 2
+    elif rate in (6000000, 2400000):
+        block = 786432 if rate == 6000000 else 393216
+    else:
+        block = 512 * (rate // 48000) * 8
+    x = synth.receiver_stream(block * 3, sample_rate=rate, receiver_id=95, gap_slots=(1, 2))
+    _run_outputs_vs_oracle([x], rate, "cf32", block, 3, **kw)
+
+
+def test_fused_backend_edge_inputs_and_boxcar():
+    n = 16384 * 5
+    rng = np.random.default_rng(3)
+    zero = np.zeros(n, np.complex64)
+    dc = np.full(n, 0.25 - 0.5j, np.complex64)
+    wild = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    wild[:n // 2] *= np.float32(1e-18)
+    wild[n // 2:] *= np.float32(3e4)
+    _run_outputs_vs_oracle([zero, dc, wild], 1536000, "cf32", 16384, 5)
+    x = synth.receiver_stream(131072 * 4, receiver_id=96)
+    _run_outputs_vs_oracle([x], 1536000, "cf32", 131072, 4, ps_ema=False)
+
+
+def test_materialised_backend_without_taps(monkeypatch):
+    """AISGPU_FUSED=0 keeps the phasor / derotated-sample arrays (the path the taps and the FM branch use) with the deferred
+    second half; same outputs."""
+    monkeypatch.setenv("AISGPU_FUSED", "0")
+    xs = [synth.receiver_stream(65536 * 9, receiver_id=97 + r, gap_slots=(0, 2)) for r in range(2)]
+    _run_outputs_vs_oracle(xs, 1536000, "cf32", 65536, 9)
