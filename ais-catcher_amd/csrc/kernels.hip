@@ -870,8 +870,11 @@ __device__ __forceinline__ void wave_argmax_first(float& v, int& i) {
 //
 // k2_cgf_search: the order-sensitive part -- the float prefix sum and the two first-maximum searches, which the
 // reference evaluates strictly left to right -- one LANE per window, 64 windows per wave, branch-free.
-constexpr int FFT_NW = 8;
-constexpr int MAG_STRIDE = 520; // floats; 8 (mod 64) banks between the windows of a wave
+#ifndef FFT_NW_
+#define FFT_NW_ 8
+#endif
+constexpr int FFT_NW = FFT_NW_;                 // windows per wave: the staging buffer below bounds the occupancy (LDS)
+constexpr int MAG_STRIDE = 512 + 64 / FFT_NW;   // floats; 64/NW (mod 64) banks between the windows of a wave
 
 // twiddle o with its rotated copy (-o.y, o.x): o * c = c.xx * o + c.yy * (-o.y, o.x) = (o.x c.x - o.y c.y, o.x c.y + o.y c.x),
 // the same two products and one addition per component as std::complex's operator* (x - y == x + (-y) exactly)
@@ -975,14 +978,15 @@ __global__ __launch_bounds__(64) void k2_fft_mag(K2Params p) {
 		for (int r = 0; r < 8; r++) mg[(lane + 64 * r + 256) & 511] = hypot_bins(v[r].x, v[r].y);
 	}
 	__syncthreads();
-	// transposed store: 8 bins x 8 windows per instruction, 32 contiguous bytes per bin
-	const int W = W0 + l7;
+	// transposed store: 64/NW bins x NW windows per instruction, 4*NW contiguous bytes per bin
+	const int wl = lane % FFT_NW, qs = lane / FFT_NW;
+	const int W = W0 + wl;
 	if (W < n_win_total) {
 		float* dst = p.magT + (size_t)(W >> 6) * (512 * 64) + (W & 63);
-		const float* mg = mag + l7 * MAG_STRIDE;
+		const float* mg = mag + wl * MAG_STRIDE;
 #pragma unroll 8
-		for (int it = 0; it < 64; it++) {
-			const int q = it * 8 + l8;
+		for (int it = 0; it < 8 * FFT_NW; it++) {
+			const int q = it * (64 / FFT_NW) + qs;
 			dst[(size_t)q * 64] = mg[q];
 		}
 	}
