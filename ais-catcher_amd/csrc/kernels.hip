@@ -1839,104 +1839,90 @@ __global__ __launch_bounds__(256) void k5_filter(K5Params p) {
 // reset cannot complete a frame, so one repair pass is enough).  Frames leave as records (bits as received, level sum,
 // indices); length validation, the level in dB and the NMEA text stay on the host (Marine/Message.cpp), they are string work.
 // ------------------------------------------------------------------------------------------
-struct DecReg { int state, lastBit, prev, position, osc; float level; long long start_idx; uint32_t crc, cw; int cwi; };
+struct DecReg { int state, lastBit, prev, position, osc; float level; long long start_idx; uint32_t crc, cw, tail; int cwi, abort_pos; };
 enum { DST_TRAINING = 0, DST_STARTFLAG = 1, DST_DATAFCS = 3 };
 constexpr int DEC_MAX_FRAME = 1064 + 16 + 7;
 
-// positions at which Decoder::cannotBeValid (Marine/AIS.cpp:111-142) looks at the message type: 6, 38, 72, 144, 160, 168, 312,
-// 361, 424 bits + 24
-__device__ __forceinline__ bool dec_check_position(int len) {
-	return len == 30 || len == 62 || len == 96 || len == 168 || len == 184 || len == 192 || len == 336 || len == 385 || len == 448;
-}
-__device__ __forceinline__ bool dec_cannot_be_valid(uint32_t w0, uint32_t w1, int len) { // Marine/AIS.cpp:111-142
-	const int t = (int)((w0 & 255u) >> 2);
-	switch (len) {
-	case 30: return t > 28 || t == 0;
-	case 62: return (((w0 >> 8) & 255u) << 22 | ((w0 >> 16) & 255u) << 14 | (w0 >> 24) << 6 | (w1 & 255u) >> 2) > 999999999u;
-	case 96: return t == 10;
-	case 168: return t == 16;
-	case 184: return t == 15 || t == 20 || t == 23;
-	case 192: return t == 1 || t == 2 || t == 3 || t == 4 || t == 7 || t == 9 || t == 11 || t == 18 || t == 22 || t == 24 || t == 25 || t == 27 || t == 28;
-	case 336: return t == 19;
-	case 385: return t == 21;
-	case 448: return t == 5;
-	}
-	return false;
+// Decoder::cannotBeValid (Marine/AIS.cpp:111-142) looks at the message type at frame positions 30, 96, 168, 184, 192, 336, 385,
+// 448 (and at the MMSI at 62).  The type is final long before position 30, so the one position at which a frame of this type
+// gets aborted is looked up once, at position 30: 0 = never, 30 = now (type 0 or > 28).
+__device__ __forceinline__ int dec_abort_position(int t) {
+	constexpr uint32_t at192 = (1u << 1) | (1u << 2) | (1u << 3) | (1u << 4) | (1u << 7) | (1u << 9) | (1u << 11) | (1u << 18) | (1u << 22) |
+	                           (1u << 24) | (1u << 25) | (1u << 27) | (1u << 28);
+	if (t > 28 || t == 0) return 30;
+	if ((at192 >> t) & 1u) return 192;
+	if (t == 15 || t == 20 || t == 23) return 184;
+	return t == 10 ? 96 : t == 16 ? 168 : t == 19 ? 336 : t == 21 ? 385 : t == 5 ? 448 : 0;
 }
 
 // one symbol; data = this lane's column of the LDS frame buffer (word w at data[64 * w]); returns true when a frame with a
 // good CRC has just been completed (r.position / r.level still hold the frame's values, the caller finishes the transition).
-// A wave's decoders are in all states at once and the wave is alone on its SIMD, so what counts is the length of the
-// dependent chain per symbol:
-//  * TRAINING and STARTFLAG are evaluated with selects, only the DATAFCS work sits in a branch;
-//  * the 32-bit word of the frame that is being filled lives in a register (r.cw) and goes to LDS when the position moves
-//    on to another word;
-//  * the CRC-16/X.25 register (AIS.cpp:55-64) advances with every stored bit -- a de-stuffed bit simply does not advance
-//    it.  The residue check covers the first position-7 bits, so when the closing flag is complete the last seven steps
-//    are undone: the step c' = (c >> 1) ^ ((b ^ c) & 1 ? 0x8408 : 0) is invertible (bit 15 of c' tells whether the
-//    polynomial was applied).  No loop over the frame at that moment, which would stall the other 59 decoders.
+// A wave's decoders are in all states at once and the wave is alone on its SIMD, so what counts is the number of
+// instructions per symbol; everything is therefore evaluated with selects for all lanes, and only two rare events branch
+// (the type / MMSI look-ups at positions 30 and 62):
+//  * the 32-bit word of the frame that is being filled lives in a register (r.cw) and is written to LDS when the position
+//    moves on to the next word;
+//  * the CRC-16/X.25 register (AIS.cpp:55-64) runs SEVEN BITS BEHIND the stored bits (r.tail holds those seven): the
+//    residue check covers the first position-7 bits, so when the closing flag is complete the register already is the
+//    answer -- no loop over the frame, no undoing.  A de-stuffed bit advances nothing.
 __device__ __forceinline__ bool dec_step(DecReg& r, int dd, float slvl, long long sidx, uint32_t* data) {
-	const int Bit = !(dd ^ r.prev); // NRZI
+	const int Bit = dd == r.prev; // NRZI: !(d ^ prev)
 	r.prev = dd;
-	bool found = false;
-	const int st = r.state, pos = r.position;
-	if (st == DST_DATAFCS) {
-		const int wi = pos >> 5;
-		if (wi != r.cwi) { // the position moved on to another word (backwards only after a de-stuffed bit: reload)
-			data[64 * r.cwi] = r.cw;
-			r.cw = wi < r.cwi ? data[64 * wi] : 0u;
-			r.cwi = wi;
+	const int st = r.state, pos = r.position, osc = r.osc;
+	const bool isD = st == DST_DATAFCS, isT = st == DST_TRAINING;
+	// ---- TRAINING: count alternations; two equal bits after more than four of them are the start of a flag
+	const bool alt = Bit != r.lastBit;
+	const bool to_flag = isT && !alt && pos > 4;
+	// ---- STARTFLAG: ones up to position 7, then a zero opens the frame
+	const bool open = st == DST_STARTFLAG && pos == 7 && Bit == 0;
+	const bool more = st == DST_STARTFLAG && pos != 7 && Bit == 1;
+	const int tf_state = isT ? (to_flag ? DST_STARTFLAG : DST_TRAINING) : (open ? DST_DATAFCS : (more ? DST_STARTFLAG : DST_TRAINING));
+	const int tf_pos = isT ? (alt ? pos + 1 : (to_flag ? (Bit ? 3 : 1) : 0)) : (more ? pos + 1 : 0);
+	const int tf_osc = (isT ? alt : more) ? osc : 0; // every NextState() call clears one_seq_count (AIS.cpp:33-37)
+	// ---- DATAFCS
+	const bool stuffed = Bit == 0 && osc == 5; // bit de-stuffing: the position does not advance, the next bit overwrites this one
+	const bool close = Bit == 1 && osc == 5;   // six ones: closing flag (or abort)
+	const bool adv = isD && !stuffed;
+	const int wi = pos >> 5;
+	const bool next_word = isD && wi != r.cwi;
+	if (next_word) data[64 * r.cwi] = r.cw;
+	uint32_t cw = next_word ? 0u : r.cw;
+	const uint32_t m = 1u << (pos & 31);
+	if (isD && pos < DEC_MAX_FRAME) cw = Bit ? (cw | m) : (cw & ~m);
+	const uint32_t outb = (r.tail >> 6) & 1u; // the bit that leaves the seven-bit window enters the CRC
+	const uint32_t crc_n = ((outb ^ r.crc) & 1u) ? ((r.crc >> 1) ^ 0x8408u) : (r.crc >> 1);
+	const uint32_t crc = (adv && pos >= 7) ? crc_n : r.crc;
+	const uint32_t tail = adv ? (((r.tail << 1) | (uint32_t)Bit) & 127u) : r.tail;
+	const int np = stuffed ? pos : pos + 1;
+	const bool found = isD && close && np - 7 >= 16 && crc == (uint32_t)(uint16_t)~0x0F47;
+	bool abort_frame = np == DEC_MAX_FRAME || (r.abort_pos != 0 && np == r.abort_pos);
+	int abort_pos = r.abort_pos;
+	if (isD && !close && (np == 30 || np == 62)) { // once per frame each
+		if (np == 30) { // type = first byte >> 2; bits 0..29 are all in the first word, which is still in the register
+			abort_pos = dec_abort_position((int)((cw & 255u) >> 2));
+			abort_frame = abort_frame || abort_pos == 30;
+		} else { // MMSI = bits 8..37: first word is in LDS by now, the second one in the register
+			const uint32_t w0 = data[0];
+			abort_frame = abort_frame || (((w0 >> 8) & 255u) << 22 | ((w0 >> 16) & 255u) << 14 | (w0 >> 24) << 6 | (cw & 255u) >> 2) > 999999999u;
 		}
-		if (pos < DEC_MAX_FRAME) {
-			const uint32_t m = 1u << (pos & 31);
-			r.cw = Bit ? (r.cw | m) : (r.cw & ~m);
-		}
-		const bool stuffed = Bit == 0 && r.osc == 5;
-		if (!stuffed) r.crc = (((uint32_t)Bit ^ r.crc) & 1u) ? ((r.crc >> 1) ^ 0x8408u) : (r.crc >> 1);
-		int np = stuffed ? pos : pos + 1, nosc = Bit ? r.osc + 1 : 0, nst = DST_DATAFCS;
-		r.level += slvl; // tag.mode & 1 (Common.h:242)
-		if (Bit == 1 && r.osc == 5) { // six ones: closing flag (or abort)
-			const int len = np - 7;
-			if (len >= 16) {
-				data[64 * r.cwi] = r.cw;
-				const int lo = len >> 5;
-				const unsigned long long two = (unsigned long long)data[64 * lo] | ((unsigned long long)data[64 * (lo + 1 < DEC_DATA_WORDS ? lo + 1 : lo)] << 32);
-				const uint32_t tail = (uint32_t)(two >> (len & 31)) & 127u; // bits len .. len+6, the last seven stored
-				uint32_t c = r.crc;
-#pragma unroll
-				for (int i = 6; i >= 0; i--) { // undo bit len+i
-					const uint32_t x = (c >> 15) & 1u;
-					c = (((c ^ (x ? 0x8408u : 0u)) << 1) | (x ^ ((tail >> i) & 1u))) & 0xFFFFu;
-				}
-				found = c == (uint32_t)(uint16_t)~0x0F47;
-			}
-			if (!found) { nst = DST_TRAINING; np = 0; }
-			nosc = 0;
-		}
-		if (!found && nst == DST_DATAFCS && (np == DEC_MAX_FRAME || (dec_check_position(np) &&
-		        dec_cannot_be_valid(r.cwi == 0 ? r.cw : data[0], r.cwi == 1 ? r.cw : data[64], np)))) {
-			nst = DST_TRAINING; np = 0; nosc = 0;
-		}
-		r.state = nst; r.position = np; r.osc = nosc; // (when found, position still is the frame's: the caller needs it)
-	} else {
-		// TRAINING: count alternations; two equal bits after more than four of them are the start of a flag
-		const bool alt = Bit != r.lastBit;
-		const bool to_flag = !alt && pos > 4;
-		const int t_state = to_flag ? DST_STARTFLAG : DST_TRAINING;
-		const int t_pos = alt ? pos + 1 : (to_flag ? (Bit ? 3 : 1) : 0);
-		// STARTFLAG: ones up to position 7, then a zero opens the frame
-		const bool open = pos == 7 && Bit == 0;
-		const bool more = pos != 7 && Bit == 1;
-		const int f_state = open ? DST_DATAFCS : (more ? DST_STARTFLAG : DST_TRAINING);
-		const int f_pos = more ? pos + 1 : 0;
-		const bool training = st == DST_TRAINING;
-		r.state = training ? t_state : f_state;
-		r.position = training ? t_pos : f_pos;
-		if (training && to_flag) r.start_idx = sidx;
-		if (training ? !alt : !more) r.osc = 0; // every NextState() call clears one_seq_count (AIS.cpp:33-37)
-		if (!training && open) { r.level = 0.0f; r.crc = 0xFFFFu; r.cw = 0u; r.cwi = 0; } // (msg.clear(): bits at and beyond `position` are never read)
 	}
+	const bool leave = (close && !found) || (!close && abort_frame);
+	const int d_state = leave ? DST_TRAINING : DST_DATAFCS;
+	const int d_pos = leave ? 0 : np; // (when found, position still is the frame's: the caller needs it)
+	const int d_osc = (close || leave) ? 0 : (Bit ? osc + 1 : 0);
+	// ---- commit
+	r.state = isD ? d_state : tf_state;
+	r.position = isD ? d_pos : tf_pos;
+	r.osc = isD ? d_osc : tf_osc;
+	r.level = isD ? r.level + slvl : (open ? 0.0f : r.level); // tag.mode & 1 (Common.h:242)
+	if (to_flag) r.start_idx = sidx;
+	r.crc = open ? 0xFFFFu : crc;
+	r.tail = open ? 0u : tail;
+	r.cw = open ? 0u : cw; // (msg.clear(): bits at and beyond `position` are never read)
+	r.cwi = open ? 0 : (isD ? wi : r.cwi);
+	r.abort_pos = open ? 0 : abort_pos;
 	r.lastBit = Bit;
+	if (found) data[64 * r.cwi] = r.cw; // the record is copied out of LDS
 	return found;
 }
 
@@ -1955,7 +1941,7 @@ __global__ __launch_bounds__(64) void k7_decode(K7Params p) {
 	r.state = st->state; r.lastBit = st->lastBit; r.prev = st->prev; r.position = st->position; r.osc = st->osc;
 	r.level = st->level; r.start_idx = st->start_idx;
 	for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = st->data[w];
-	r.crc = st->crc[0]; r.cw = st->crc[1]; r.cwi = (int)st->crc[2];
+	r.crc = st->crc[0]; r.cw = st->crc[1]; r.cwi = (int)st->crc[2]; r.tail = st->crc[3]; r.abort_pos = (int)st->crc[4];
 	const uint32_t* brow = p.bits + (size_t)dec * p.bits_stride;
 	const float* lrow = p.lvl + (size_t)chan * p.lvl_stride;
 	for (int g0 = 0; g0 < p.n_groups; g0 += 32) {
@@ -2008,7 +1994,7 @@ __global__ __launch_bounds__(64) void k7_decode(K7Params p) {
 		st->level = r.level; st->start_idx = r.start_idx;
 		data[64 * r.cwi] = r.cw;
 		for (int w = 0; w < DEC_DATA_WORDS; w++) st->data[w] = data[64 * w];
-		st->crc[0] = r.crc; st->crc[1] = r.cw; st->crc[2] = (uint32_t)r.cwi;
+		st->crc[0] = r.crc; st->crc[1] = r.cw; st->crc[2] = (uint32_t)r.cwi; st->crc[3] = r.tail; st->crc[4] = (uint32_t)r.abort_pos;
 	}
 }
 
