@@ -668,14 +668,24 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			const int words = (n_cu + 31) / 32;
 			std::vector<uint32_t> lat(words, 0u), rest(words, 0u);
 			for (int i = 0; i < n_cu; i++) (i < reserve ? lat : rest)[i / 32] |= 1u << (i % 32);
-			HIPCHK(hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)words, rest.data()));
-			HIPCHK(hipExtStreamCreateWithCUMask(&h->s1, (uint32_t)words, rest.data()));
-			HIPCHK(hipExtStreamCreateWithCUMask(&h->s3, (uint32_t)words, lat.data()));
-			HIPCHK(hipExtStreamCreateWithCUMask(&h->s4, (uint32_t)words, rest.data()));
-			// a fifth stream only for the optional frame decoder: beyond four streams HIP shares hardware queues and kernels
-			// of different streams start waiting for each other (measured: 0.62 -> 0.69 ms per step)
-			if (cfg->flags & AISGPU_FLAG_GPU_DECODE) HIPCHK(hipExtStreamCreateWithCUMask(&h->s5, (uint32_t)words, rest.data()));
-			else h->s5 = h->s4;
+			// (a runtime without CU masks falls back to ordinary streams: same results, the recurrence just shares its SIMDs)
+			bool masked = hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)words, rest.data()) == hipSuccess;
+			masked = masked && hipExtStreamCreateWithCUMask(&h->s1, (uint32_t)words, rest.data()) == hipSuccess;
+			masked = masked && hipExtStreamCreateWithCUMask(&h->s3, (uint32_t)words, lat.data()) == hipSuccess;
+			masked = masked && hipExtStreamCreateWithCUMask(&h->s4, (uint32_t)words, rest.data()) == hipSuccess;
+			if (masked && (cfg->flags & AISGPU_FLAG_GPU_DECODE)) masked = hipExtStreamCreateWithCUMask(&h->s5, (uint32_t)words, rest.data()) == hipSuccess;
+			if (!masked) {
+				(void)hipGetLastError();
+				hipStream_t* all[5] = { &h->stream, &h->s1, &h->s3, &h->s4, &h->s5 };
+				for (auto ps : all) { if (*ps) hipStreamDestroy(*ps); *ps = nullptr; }
+				HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+				HIPCHK(hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking));
+				HIPCHK(hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking));
+				HIPCHK(hipStreamCreateWithFlags(&h->s4, hipStreamNonBlocking));
+				if (cfg->flags & AISGPU_FLAG_GPU_DECODE) HIPCHK(hipStreamCreateWithFlags(&h->s5, hipStreamNonBlocking));
+			}
+			if (!h->s5) h->s5 = h->s4; // a fifth stream only for the optional frame decoder: beyond four streams HIP shares hardware
+			                           // queues and kernels of different streams start waiting for each other (0.62 -> 0.69 ms per step)
 		} else {
 			HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 			HIPCHK(hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking));
