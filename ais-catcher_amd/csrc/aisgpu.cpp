@@ -58,7 +58,7 @@ enum Mode {
 	MODE_DSK,       // rate == 288k * 2^k: k CIC5 stages (or a plain conversion), DownsampleKFilter (/3), Rotate, ...
 };
 
-struct SubOut { int pb, q, groups; long long first_group, first48; };
+struct SubOut { int pb, lv, q, groups; long long first_group, first48; };
 
 } // namespace
 
@@ -91,7 +91,8 @@ struct aisgpu {
 	bool serial = false;
 	hipEvent_t ev_front[NBUF] = {};   // s0: K2a(f) done -> s3 may start K2b(f)
 	hipEvent_t ev_c48free[NBUF] = {}; // s1: K2c(f) done (c48/fz/rotT[q] consumed) -> s0 may run the front end of f+NBUF
-	hipEvent_t ev_ema[2] = {};        // s2: K4(f) done (sym/lvl[p] consumed)
+	hipEvent_t ev_ema[4] = {};        // block f (slot f & 3) completely done: bits[f & 1] and lvl[f & 3] written AND consumed by the frame decoder
+	hipEvent_t ev_sym[2] = {};        // PhaseSearch has read sym[p] of block f
 	hipEvent_t ev_k3[2] = {};         // front stream: sym/lvl[p] of block f written -> s2 may run K4(f)
 	hipEvent_t ev_k4[2] = {};         // s2: bits[p] of block f written -> s5 may run the frame decoder
 	// device buffers
@@ -102,7 +103,7 @@ struct aisgpu {
 	float2 *d_c48[NBUF] = {}, *d_sym[2] = {};
 	float2 *d_rotT[NBUF] = {};
 	float2 *d_cgf = nullptr, *d_omega = nullptr, *d_step = nullptr, *d_rotstate = nullptr, *d_firtap = nullptr;
-	float *d_ppmtab = nullptr, *d_ppm[NBUF] = {}, *d_lvl[2] = {};
+	float *d_ppmtab = nullptr, *d_ppm[NBUF] = {}, *d_lvl[4] = {}; // lvl: ring of 4 (block f & 3): it lives until the block's (deferred) walk and decoder are done
 	int* d_fz[NBUF] = {};
 	float* d_magT[NBUF] = {}; // shifted FFT magnitudes (written by the FFT on the front stream, read by the searches on s3)
 	uint32_t* d_bits[2] = {};
@@ -112,6 +113,9 @@ struct aisgpu {
 	EmaState* d_ema[2] = {}; // state before / after the current downstream block (swapped per block)
 	uint32_t* d_pswords = nullptr; float *d_psma0 = nullptr, *d_psma1 = nullptr; unsigned* d_psfin = nullptr; int* d_psflag = nullptr;
 	int ps_warm = 256; bool ps_parallel = true;
+	struct { bool valid = false; K4Params k4; int pb = 0, lv = 0; long long g0 = 0; unsigned block = 0, sub = 0; hipStream_t s = nullptr; } wpend; // walk not yet run
+	bool walk_ride = true;
+	bool ps_lane = false; int walk_prio = 3; int ps_prio = 0; int ps_cl = 512; uint2* d_pslw[2] = {}; // lane-per-chunk PhaseSearchEMA: chunk length, sign words [n_chains][Gcap]
 	// host (pinned)
 	void* h_in = nullptr;
 	float2* h_rot[2] = {};
@@ -135,7 +139,7 @@ struct aisgpu {
 	const void* cur_in = nullptr; long long cur_in_stride = 0;
 	bool submitted = false, have_out = false;
 	SubOut sub[MAXSUB]; int n_sub = 0;
-	struct { bool valid = false; int q = 0, pb = 0; long long g0 = 0, g1 = 0, first48 = 0; unsigned block = 0, sub = 0; } pend; // deferred second half
+	struct { bool valid = false; int q = 0, pb = 0, lv = 0; long long g0 = 0, g1 = 0, first48 = 0; unsigned block = 0, sub = 0; } pend; // deferred second half
 	bool defer = true;
 	// device frame decoder (AISGPU_FLAG_GPU_DECODE)
 	bool gpu_decode = false; DecState* d_dec = nullptr; uint32_t* d_frames = nullptr; unsigned* d_frame_count = nullptr;
@@ -248,11 +252,75 @@ int span_tiles(int tiles_per_block, int n_rx, int threads, int tile96, int reque
 
 int enqueue_downstream_fused(aisgpu_t* h, int q, int pb);
 
+// what follows PhaseSearch of a block: the optional device frame decoder, and the event that frees sym/lvl/bits[pb]
+int enqueue_decode(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s);
+int finish_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s) {
+	if (h->gpu_decode) { // the frame decoder is a long latency-bound kernel of a few waves: own stream, so that the next
+		// block's PhaseSearchEMA does not queue behind it; sym/lvl/bits[pb] are free again only when IT is done
+		HIPCHK(hipEventRecord(h->ev_k4[pb], s));
+		HIPCHK(hipStreamWaitEvent(h->s5, h->ev_k4[pb], 0));
+		int rc = enqueue_decode(h, pb, lv, g0, n_groups, block, sub, h->s5);
+		if (rc) return rc;
+		HIPCHK(hipEventRecord(h->ev_ema[lv], h->s5));
+	} else HIPCHK(hipEventRecord(h->ev_ema[lv], s));
+	return AISGPU_OK;
+}
+
+// the walk of the previous block that has not ridden along with a next block's sign-word launch (results requested)
+int flush_walk(aisgpu_t* h) {
+	if (!h->wpend.valid) return AISGPU_OK;
+	h->wpend.valid = false;
+	HIPCHK(launch_k4_walk(h->wpend.k4, h->wpend.s));
+	return finish_k4(h, h->wpend.pb, h->wpend.lv, h->wpend.g0, h->wpend.k4.n_groups, h->wpend.block, h->wpend.sub, h->wpend.s);
+}
+
+// PhaseSearchEMA / PhaseSearch of one downstream block (sym/lvl parity pb) on stream s
+int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s) {
+	// bits[pb] was last read by the frame decoder / the copies of block f-2 (slot lv ^ 2): long done, and ordered here
+	HIPCHK(hipStreamWaitEvent(s, h->ev_ema[lv ^ 2], 0));
+	K4Params k4;
+	k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[pb]; k4.bits_stride = h->words;
+	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
+	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag + pb;
+	k4.n_chains = h->n_chains; k4.n_groups = n_groups;
+	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
+	k4.lw = h->d_pslw[pb]; k4.lw_quads = h->Gcap / 4; k4.prio = h->ps_prio; k4.prio_walk = h->walk_prio; k4.ma_stride = (h->n_chains + 63) / 64 * 64;
+	k4.cl = h->ps_cl; k4.n_lchunks = (n_groups + h->ps_cl - 1) / h->ps_cl;
+	k4.box_in = h->d_box[pb]; k4.box_out = h->d_box[pb ^ 1]; k4.first_group = g0;
+	if (!h->ps_box && h->ps_parallel && h->ps_lane && k4.n_lchunks > 1) {
+		// (a) sign words of this block, one lane per (chain, chunk), and their verification; (b) the walk over them: one lane
+		// per chain, ~5000 dependent steps, 40 waves for 256 receivers -- pure latency.  It rides along with the NEXT
+		// block's sign-word launch (extra workgroups of the same grid) instead of occupying the stream on its own; until
+		// then the block is pending (flush_walk() when results are requested).  Order of the state: the fallback of block f
+		// (exact sequential kernel, runs only if the verification failed) reads max_idx as walk(f-1) left it and rewrites
+		// everything before the next block's sign words start; walk(f) then skips the block.
+		const bool ride = h->wpend.valid && h->wpend.s == s && !h->serial && h->walk_ride;
+		if (h->wpend.valid && !ride) { int rc = flush_walk(h); if (rc) return rc; }
+		HIPCHK(launch_k4_lane_words(k4, ride ? &h->wpend.k4 : nullptr, s));
+		HIPCHK(launch_k4_fallback(k4, s)); // after the previous block's walk (same launch as the sign words), before the next block's sign words
+		HIPCHK(hipEventRecord(h->ev_sym[pb], s));
+		if (ride) {
+			h->wpend.valid = false;
+			int rc = finish_k4(h, h->wpend.pb, h->wpend.lv, h->wpend.g0, h->wpend.k4.n_groups, h->wpend.block, h->wpend.sub, s);
+			if (rc) return rc;
+		}
+		h->wpend.valid = true; h->wpend.k4 = k4; h->wpend.pb = pb; h->wpend.lv = lv; h->wpend.g0 = g0; h->wpend.block = block; h->wpend.sub = sub; h->wpend.s = s;
+		if (h->serial || !h->walk_ride) return flush_walk(h);
+		return AISGPU_OK;
+	}
+	{ int rc = flush_walk(h); if (rc) return rc; }
+	if (h->ps_box) HIPCHK(launch_k4_box(k4, s));
+	else if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, s));
+	else HIPCHK(launch_k4_sequential(k4, s));
+	HIPCHK(hipEventRecord(h->ev_sym[pb], s));
+	return finish_k4(h, pb, lv, g0, n_groups, block, sub, s);
+}
+
 // AIS::Decoder on the device, behind PhaseSearchEMA of the same block (same stream)
-int enqueue_decode(aisgpu_t* h, int pb, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s) {
+int enqueue_decode(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s) {
 	if (!h->gpu_decode) return AISGPU_OK;
 	K7Params k7;
-	k7.bits = h->d_bits[pb]; k7.bits_stride = h->words; k7.lvl = h->d_lvl[pb]; k7.lvl_stride = h->Gcap;
+	k7.bits = h->d_bits[pb]; k7.bits_stride = h->words; k7.lvl = h->d_lvl[lv]; k7.lvl_stride = h->Gcap;
 	k7.state = h->d_dec; k7.frames = h->d_frames; k7.frame_count = h->d_frame_count; k7.max_frames = h->max_frames;
 	k7.first_group = g0; k7.n_groups = n_groups; k7.n_chan = h->n_chan; k7.block = block; k7.sub = sub;
 	HIPCHK(launch_k7(k7, s));
@@ -273,18 +341,19 @@ K2Params make_k2(aisgpu_t* h, int q) {
 int enqueue_back(aisgpu_t* h) {
 	if (!h->pend.valid) return AISGPU_OK;
 	h->pend.valid = false;
-	const int q = h->pend.q, pb = h->pend.pb;
+	const int q = h->pend.q, pb = h->pend.pb, lv = h->pend.lv;
 	const long long g0 = h->pend.g0, g1 = h->pend.g1;
 	const K2Params k2 = make_k2(h, q);
 	HIPCHK(hipStreamWaitEvent(h->stream, h->ev_phasor[q], 0));
 	HIPCHK(launch_k2c(k2, h->n_chan, h->stream));
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->stream));
 	K3Params k3;
-	k3.cgf = h->d_cgf; k3.cgf_stride = CGF_HIST + h->L; k3.sym = h->d_sym[pb]; k3.sym_stride = h->Gcap; k3.lvl = h->d_lvl[pb];
+	k3.cgf = h->d_cgf; k3.cgf_stride = CGF_HIST + h->L; k3.sym = h->d_sym[pb]; k3.sym_stride = h->Gcap; k3.lvl = h->d_lvl[lv];
 	k3.fir_tap = h->d_firtap; k3.fir_tap_stride = 8 + h->L;
 	memcpy(k3.taps, TAPS_COHERENT, sizeof k3.taps);
 	k3.first_group = g0; k3.first_sample48 = h->pend.first48; k3.n_groups = (int)(g1 - g0);
-	HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ema[pb], 0)); // sym/lvl[pb] were last read by K4 of block f-2
+	HIPCHK(hipStreamWaitEvent(h->stream, h->ev_sym[pb], 0)); // sym[pb] was last read by PhaseSearch of block f-2,
+	HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ema[lv], 0)); // lvl[lv] by the frame decoder / the copies of block f-4
 	HIPCHK(launch_k3(k3, h->n_chan, h->stream));
 	if (h->challenger) { // FM branch on the same derotated samples (Model.cpp:638-639)
 		K5Params k5;
@@ -296,28 +365,8 @@ int enqueue_back(aisgpu_t* h) {
 	HIPCHK(hipEventRecord(h->ev_k3[pb], h->stream));
 
 	// ---- PhaseSearchEMA chains on s1: VALU-bound, overlaps the HBM-bound front end of the next block
-	K4Params k4;
-	k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[pb]; k4.bits_stride = h->words;
-	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
-	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag;
-	k4.n_chains = h->n_chains; k4.n_groups = (int)(g1 - g0);
-	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
 	HIPCHK(hipStreamWaitEvent(h->s2, h->ev_k3[pb], 0));
-	k4.box_in = h->d_box[pb]; k4.box_out = h->d_box[pb ^ 1]; k4.first_group = g0;
-	if (h->ps_box) HIPCHK(launch_k4_box(k4, h->s2));
-	else if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, h->s2));
-	else HIPCHK(launch_k4_sequential(k4, h->s2));
-	if (h->gpu_decode) { // the frame decoder is a long latency-bound kernel of a few waves: own stream, so that the next
-		// block's PhaseSearchEMA does not queue behind it; sym/lvl/bits[pb] are free again only when IT is done
-		HIPCHK(hipEventRecord(h->ev_k4[pb], h->s2));
-		HIPCHK(hipStreamWaitEvent(h->s5, h->ev_k4[pb], 0));
-		int rc = enqueue_decode(h, pb, g0, (int)(g1 - g0), h->pend.block, h->pend.sub, h->s5);
-		if (rc) return rc;
-		HIPCHK(hipEventRecord(h->ev_ema[pb], h->s5));
-		return AISGPU_OK;
-	}
-	HIPCHK(hipEventRecord(h->ev_ema[pb], h->s2));
-	return AISGPU_OK;
+	return enqueue_k4(h, pb, lv, g0, (int)(g1 - g0), h->pend.block, h->pend.sub, h->s2);
 }
 
 // Default path: the phasor recurrence keeps checkpoints only, and one fused kernel derotates, filters and scatters.
@@ -327,6 +376,7 @@ int enqueue_back(aisgpu_t* h) {
 //   s4: derotation + FIR + ScatterPLL       (VALU/latency-bound)
 //   s1: PhaseSearchEMA                      (VALU-bound; both overlap the next block's front end)
 int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
+	const int lv = (int)(h->block_idx & 3);
 	K2Params k2 = make_k2(h, q);
 	const long long g0 = h->n48 / 5, g1 = (h->n48 + h->L) / 5; // groups completed inside this block (DSP/DSP.h:95-117)
 	const int n_groups = (int)(g1 - g0), n_rel0 = (int)(g0 * 5 - h->n48);
@@ -348,41 +398,27 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	k6.c48 = h->d_c48[q]; k6.c48_stride = h->c48s; k6.ck = h->d_ck[q]; k6.ckw = h->d_ckw[q]; k6.ck_stride = k2.ck_stride;
 	k6.step_table = h->d_step; k6.fz = h->d_fz[q];
 	k6.hist_in = h->d_dfhist[pb ^ 1]; k6.hist_out = h->d_dfhist[pb];
-	k6.sym = h->d_sym[pb]; k6.sym_stride = h->Gcap; k6.lvl = h->d_lvl[pb];
+	k6.sym = h->d_sym[pb]; k6.sym_stride = h->Gcap; k6.lvl = h->d_lvl[lv];
 	memcpy(k6.taps, TAPS_COHERENT, sizeof k6.taps);
 	k6.first_group = g0; k6.n_rel0 = n_rel0; k6.n_groups = n_groups; k6.L = h->L; k6.n_windows = h->W; k6.n_chan = h->n_chan;
 	k6.GL = h->GL; k6.S = S;
 	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_phasor[q], 0));
-	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_ema[pb], 0)); // sym/lvl[pb] were last read by K4 (or the frame decoder) of block f-2
+	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_sym[pb], 0)); // sym[pb] was last read by PhaseSearch of block f-2,
+	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_ema[lv], 0)); // lvl[lv] by the frame decoder / the copies of block f-4
 	{ TraceScope t(h, "derotfir", h->s4); HIPCHK(launch_k6(k6, h->s4)); }
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s4));
 	HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4));
 	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_k3[pb], 0));
 
-	K4Params k4;
-	k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[pb]; k4.bits_stride = h->words;
-	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
-	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag;
-	k4.n_chains = h->n_chains; k4.n_groups = n_groups;
-	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
 	{
 		TraceScope t(h, "psearch", h->s1);
-		k4.box_in = h->d_box[pb]; k4.box_out = h->d_box[pb ^ 1]; k4.first_group = g0;
-		if (h->ps_box) HIPCHK(launch_k4_box(k4, h->s1));
-		else if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, h->s1));
-		else HIPCHK(launch_k4_sequential(k4, h->s1));
-	}
-	if (h->gpu_decode) { // own stream, see enqueue_back()
-		HIPCHK(hipEventRecord(h->ev_k4[pb], h->s1));
-		HIPCHK(hipStreamWaitEvent(h->s5, h->ev_k4[pb], 0));
-		int rc = enqueue_decode(h, pb, g0, n_groups, (unsigned)h->block_idx, (unsigned)h->n_sub, h->s5);
+		int rc = enqueue_k4(h, pb, lv, g0, n_groups, (unsigned)h->block_idx, (unsigned)h->n_sub, h->s1);
 		if (rc) return rc;
-		HIPCHK(hipEventRecord(h->ev_ema[pb], h->s5));
-	} else HIPCHK(hipEventRecord(h->ev_ema[pb], h->s1));
+	}
 
 	if (h->n_sub < MAXSUB) {
 		SubOut& so = h->sub[h->n_sub++];
-		so.pb = pb; so.q = q; so.groups = n_groups; so.first_group = g0; so.first48 = h->n48;
+		so.pb = pb; so.lv = lv; so.q = q; so.groups = n_groups; so.first_group = g0; so.first48 = h->n48;
 	}
 	h->n48 += h->L;
 	h->block_idx++;
@@ -412,7 +448,7 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 	HIPCHK(hipStreamWaitEvent(h->s2, h->ev_k3[pb], 0)); // aisgpu_sync_outputs copies on s2
 	if (h->n_sub < MAXSUB) {
 		SubOut& so = h->sub[h->n_sub++];
-		so.pb = pb; so.q = q; so.groups = 0; so.first_group = h->n48 / 5; so.first48 = h->n48;
+		so.pb = pb; so.lv = 0; so.q = q; so.groups = 0; so.first_group = h->n48 / 5; so.first48 = h->n48;
 	}
 	h->n48 += h->L;
 	h->block_idx++;
@@ -439,11 +475,11 @@ int enqueue_downstream(aisgpu_t* h, int q, int pb) {
 	if (rc) return rc;
 	// ScatterPLL groups completed inside this block (DSP/DSP.h:95-117): group g completes with sample 5g+4
 	const long long g0 = h->n48 / 5, g1 = (h->n48 + h->L) / 5;
-	h->pend.valid = true; h->pend.q = q; h->pend.pb = pb; h->pend.g0 = g0; h->pend.g1 = g1; h->pend.first48 = h->n48;
+	h->pend.valid = true; h->pend.q = q; h->pend.pb = pb; h->pend.lv = (int)(h->block_idx & 3); h->pend.g0 = g0; h->pend.g1 = g1; h->pend.first48 = h->n48;
 	h->pend.block = (unsigned)h->block_idx; h->pend.sub = (unsigned)h->n_sub;
 	if (h->n_sub < MAXSUB) {
 		SubOut& s = h->sub[h->n_sub++];
-		s.pb = pb; s.q = q; s.groups = (int)(g1 - g0); s.first_group = g0; s.first48 = h->n48;
+		s.pb = pb; s.lv = (int)(h->block_idx & 3); s.q = q; s.groups = (int)(g1 - g0); s.first_group = g0; s.first48 = h->n48;
 	}
 	h->n48 += h->L;
 	h->block_idx++;
@@ -498,6 +534,7 @@ int gather_frames(aisgpu_t* h) {
 
 int sync_all(aisgpu_t* h) {
 	{ int rc = enqueue_back(h); if (rc) return rc; }
+	{ int rc = flush_walk(h); if (rc) return rc; }
 	HIPCHK(hipStreamSynchronize(h->stream));
 	HIPCHK(hipStreamSynchronize(h->s1));
 	HIPCHK(hipStreamSynchronize(h->s3));
@@ -702,7 +739,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(hipEventCreateWithFlags(&h->ev_search[i], hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&h->ev_c48free[i], hipEventDisableTiming));
 	}
-	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_ema[i], hipEventDisableTiming));
+	for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_ema[i], hipEventDisableTiming));
+	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_sym[i], hipEventDisableTiming));
 	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_k3[i], hipEventDisableTiming));
 	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_k4[i], hipEventDisableTiming));
 	if (const char* e = getenv("AISGPU_DEFER")) h->defer = atoi(e) != 0;
@@ -795,9 +833,9 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(dalloc(&h->d_ppm[i], C * h->W));
 		HIPCHK(dalloc(&h->d_rotT[i], (size_t)h->L * ((C + 63) / 64 * 64)));
 	}
+	for (int i = 0; i < 4; i++) HIPCHK(dalloc(&h->d_lvl[i], C * h->Gcap));
 	for (int i = 0; i < 2; i++) {
 		HIPCHK(dalloc(&h->d_sym[i], C * 5 * h->Gcap));
-		HIPCHK(dalloc(&h->d_lvl[i], C * h->Gcap));
 		HIPCHK(dalloc(&h->d_bits[i], C * 5 * h->words));
 		HIPCHK(dalloc(&h->d_ema[i], C * 5));
 	}
@@ -816,9 +854,23 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	const int ps_chunks = (h->Gcap + PS_CHUNK - 1) / PS_CHUNK;
 	if (const char* e = getenv("AISGPU_PS_WARM")) { int v = atoi(e); if (v >= 1 && v <= PS_CHUNK) h->ps_warm = (v + 15) / 16 * 16; } // test hook: small values force the exact fallback
 	if (getenv("AISGPU_PS_SEQUENTIAL")) h->ps_parallel = false;
+	// PhaseSearchEMA variant: "row" (default: 16 lanes per chain and chunk, 91 M wave-instructions per bench step, 10240 waves)
+	// or "lane" (one lane per chain and chunk + a sequential integer walk: 33 M wave-instructions, but only 400 long waves that
+	// get a quarter of the issue slots next to the front end -- measured 0.68 against 0.62 ms per step)
+	if (const char* e = getenv("AISGPU_K4")) h->ps_lane = strcmp(e, "lane") == 0;
+	if (const char* e = getenv("AISGPU_PS_PRIO")) h->ps_prio = atoi(e);
+	if (const char* e = getenv("AISGPU_WALK_PRIO")) h->walk_prio = atoi(e);
+	if (const char* e = getenv("AISGPU_WALK_RIDE")) h->walk_ride = atoi(e) != 0;
+	if (const char* e = getenv("AISGPU_PS_CL")) { int v = atoi(e); if (v >= 128 && v <= 8192) h->ps_cl = (v + 31) / 32 * 32; }
+	const size_t lane_chunks = (size_t)(h->Gcap + h->ps_cl - 1) / h->ps_cl, ma_stride = (C * 5 + 63) / 64 * 64;
+	size_t n_ma = C * 5 * ps_chunks * 16;
+	if (h->ps_lane) {
+		for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_pslw[i], 3 * ma_stride * (size_t)h->Gcap / 2)); // uint2 units: 3 planes x Gcap / 4 rows x ma_stride x 16 B
+		if (lane_chunks * 16 * ma_stride > n_ma) n_ma = lane_chunks * 16 * ma_stride;
+	}
 	HIPCHK(dalloc(&h->d_pswords, C * 5 * ps_chunks * (PS_CHUNK / 32) * 16));
-	HIPCHK(dalloc(&h->d_psma0, C * 5 * ps_chunks * 16));
-	HIPCHK(dalloc(&h->d_psma1, C * 5 * ps_chunks * 16));
+	HIPCHK(dalloc(&h->d_psma0, n_ma));
+	HIPCHK(dalloc(&h->d_psma1, n_ma));
 	HIPCHK(dalloc(&h->d_psfin, C * 5 * ps_chunks * 16));
 	HIPCHK(dalloc(&h->d_psflag, 4));
 	if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_firtap, C * (8 + h->L)));
@@ -845,11 +897,12 @@ void aisgpu_destroy(aisgpu_t* h) {
 		if (h->ev_c48free[i]) hipEventDestroy(h->ev_c48free[i]);
 		hipFree(h->d_rotT[i]); hipFree(h->d_c48[i]); hipFree(h->d_fz[i]); hipFree(h->d_ppm[i]);
 	}
+	for (int i = 0; i < 4; i++) { if (h->ev_ema[i]) hipEventDestroy(h->ev_ema[i]); hipFree(h->d_lvl[i]); }
 	for (int i = 0; i < 2; i++) {
-		if (h->ev_ema[i]) hipEventDestroy(h->ev_ema[i]);
+		if (h->ev_sym[i]) hipEventDestroy(h->ev_sym[i]);
 		if (h->ev_k3[i]) hipEventDestroy(h->ev_k3[i]);
 		if (h->ev_k4[i]) hipEventDestroy(h->ev_k4[i]);
-		hipFree(h->d_sym[i]); hipFree(h->d_lvl[i]); hipFree(h->d_bits[i]); hipFree(h->d_ema[i]);
+		hipFree(h->d_sym[i]); hipFree(h->d_bits[i]); hipFree(h->d_ema[i]);
 		hipFree(h->d_rot[i]); if (h->h_rot[i]) hipHostFree(h->h_rot[i]); if (h->rot_ev[i]) hipEventDestroy(h->rot_ev[i]);
 		hipFree(h->d_usidx[i]); hipFree(h->d_usalpha[i]); hipFree(h->d_xpre[i]);
 		if (h->h_usidx[i]) hipHostFree(h->h_usidx[i]);
@@ -867,7 +920,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_fmprev[0]); hipFree(h->d_fmprev[1]);
 	hipFree(h->d_cgf); hipFree(h->d_omega); hipFree(h->d_step);
 	hipFree(h->d_rotstate); hipFree(h->d_firtap); hipFree(h->d_ppmtab);
-	hipFree(h->d_pswords); hipFree(h->d_psma0); hipFree(h->d_psma1); hipFree(h->d_psfin); hipFree(h->d_psflag);
+	hipFree(h->d_pslw[0]); hipFree(h->d_pslw[1]); hipFree(h->d_pswords); hipFree(h->d_psma0); hipFree(h->d_psma1); hipFree(h->d_psfin); hipFree(h->d_psflag);
 	if (h->h_in) hipHostFree(h->h_in);
 	if (h->h_bits) hipHostFree(h->h_bits);
 	if (h->h_lvl) hipHostFree(h->h_lvl);
@@ -1075,12 +1128,15 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 	if (h->in_blocks == 0) return AISGPU_ERR_STATE;
 	const size_t C = h->n_chan;
 	{ int rc = enqueue_back(h); if (rc) return rc; }
+	{ int rc = flush_walk(h); if (rc) return rc; }
 	for (int s = 0; s < h->n_sub; s++) {
 		const SubOut& so = h->sub[s];
-		// s2 is ordered after K4 of that block, which is ordered after everything that produced lvl/ppm
+		// ev_ema[pb]: PhaseSearch (and the frame decoder) of that block are done, wherever their last kernel ran; they are
+		// ordered after everything that produced lvl/ppm
 		if (!h->base) {
+		HIPCHK(hipStreamWaitEvent(h->s2, h->ev_ema[so.lv], 0));
 		HIPCHK(hipMemcpyAsync(h->h_bits + (size_t)s * C * 5 * h->words, h->d_bits[so.pb], C * 5 * h->words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s2));
-		HIPCHK(hipMemcpyAsync(h->h_lvl + (size_t)s * C * h->Gcap, h->d_lvl[so.pb], C * h->Gcap * sizeof(float), hipMemcpyDeviceToHost, h->s2));
+		HIPCHK(hipMemcpyAsync(h->h_lvl + (size_t)s * C * h->Gcap, h->d_lvl[so.lv], C * h->Gcap * sizeof(float), hipMemcpyDeviceToHost, h->s2));
 		HIPCHK(hipMemcpyAsync(h->h_ppm + (size_t)s * C * h->W, h->d_ppm[so.q], C * h->W * sizeof(float), hipMemcpyDeviceToHost, h->s2));
 		}
 		if (h->challenger || h->base)

@@ -109,6 +109,12 @@ struct K4Params {
 	unsigned* fin;     // [16] low 4 bits: final max_idx per start index; bits 4..7: last four decisions of hypothesis k
 	int* flag;         // != 0: a speculative warm-up did not reproduce the sequential EMA -> exact fallback runs
 	int n_chains, n_groups, n_chunks, warm;
+	// lane-per-chunk variant (k4_lane_chunks + k4_walk): sign words per symbol, EMA snapshots laid out [chunk][k][ma_stride]
+	uint2* lw;                               // three planes (up, dn, x) of uint4 [lw_quads][ma_stride]: four consecutive symbols of a chain
+	int prio_walk;
+	int lw_quads, prio;                      // rows per plane (>= ceil(groups / 4)); s_setprio level of k4_lane_chunks
+	long long ma_stride;                     // n_chains rounded up to 64 (also the row length of ma_start / ma_fin in this variant)
+	int cl, n_lchunks;                       // chunk length (multiple of 32), chunks
 	// boxcar variant (k4_phase_search_box)
 	const PsBoxState* box_in; PsBoxState* box_out; long long first_group;
 };
@@ -154,6 +160,10 @@ constexpr int FM_HIST = 36;
 
 hipError_t launch_k5(const K5Params& p, int n_chan, hipStream_t s);
 hipError_t launch_k4(const K4Params& p, hipStream_t s);          // chunk-parallel + assemble + (conditional) exact fallback
+// one lane per (chain, chunk): sign words + verification; the (conditional) exact fallback; the sequential integer walk
+hipError_t launch_k4_lane_words(const K4Params& p, const K4Params* walk_prev, hipStream_t s); // walk_prev: the previous block's walk rides along
+hipError_t launch_k4_fallback(const K4Params& p, hipStream_t s);
+hipError_t launch_k4_walk(const K4Params& p, hipStream_t s);
 hipError_t launch_k4_sequential(const K4Params& p, hipStream_t s); // the plain sequential kernel only
 hipError_t launch_k4_box(const K4Params& p, hipStream_t s);        // Demod::PhaseSearch (boxcar history), sequential
 

@@ -1709,6 +1709,357 @@ __global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K4 lane-per-chunk (default): the row kernels above spend one LANE per hypothesis, i.e. 16 lanes x ~26 VALU
+// instructions per symbol, most of them on getting three neighbouring ma[] values and two predicates across lanes.
+// Here one lane owns one (chain, time chunk) and ALL 16 hypotheses of it in registers -- the pairs (j, 15 - j) that
+// the reference computes from the same two products (Demod.cpp:66-77) are one VGPR pair, so the products, the sums
+// a + b / a - b and the EMA are packed-fp32 instructions -- and nothing is exchanged between lanes at all.
+// What the sequential part of the reference needs from the float state is reduced to sign bits, one word per symbol:
+//     g[k] = ma[k] > ma[k-1]        (sign of ma[k-1] - ma[k])
+//     h[k] = ma[k+1] > ma[k-1]      (sign of ma[k-1] - ma[k+1])
+//     d[k] = t[k] > 0               (sign of 0 - t[k]; +-0 -> 0 like the comparison)
+// (x > y  <=>  signbit(y - x) for finite floats: the subtraction is exact in sign, and equal values give +0.)
+// The first-maximum search over {max_idx - 1, max_idx, max_idx + 1} (Demod.cpp:80-92) is a function of g and h
+// only: with i = max_idx, "ma[i] > ma[i-1]" = g[i]; the third candidate is compared with the better of the two,
+// i.e. with ma[i] when g[i] (that is g[i+1]) and with ma[i-1] otherwise (that is h[i]).  k4_walk then runs the
+// integer recurrence max_idx -> output bit sequentially, one lane per chain (40 waves for 256 receivers; ~8
+// dependent integer instructions per symbol), verifies the speculative EMA warm-ups of the chunks bit for bit
+// (same rule as above: any difference raises p.flag and the exact sequential kernel recomputes the block) and
+// writes the packed decisions and the new state.
+// VALU cost per symbol and chain: 48 (EMA) + 19 + 8 (differences) + 48 (sign collection) = 123 lane-instructions
+// against 416 for the row kernel; the price is 8 bytes of scratch per symbol (written once, read once).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ c2 pk_sum_diff(c2 ab) { // (ab.x + ab.y, ab.x - ab.y); x - y == x + (-y) exactly
+	c2 r;
+	asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(ab));
+	return r;
+}
+__device__ __forceinline__ c2 pk_diff_cross(c2 a, c2 b) { // (a.x - b.x, b.y - a.y)
+	c2 r;
+	asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+__device__ __forceinline__ c2 pk_neg_from_zero(c2 t) { // (0 - t.x, 0 - t.y)
+	c2 r;
+	const c2 z = { 0.0f, 0.0f };
+	asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(z), "v"(t));
+	return r;
+}
+__device__ __forceinline__ unsigned push_sign(unsigned acc, float v) { // (acc << 1) | signbit(v)
+	return __builtin_amdgcn_alignbit(acc, __float_as_uint(v), 31);
+}
+
+struct PsLane { c2 P[8]; }; // P[j] = (ma[j], ma[15 - j])
+
+__device__ __forceinline__ c2 ps_lane_cs(int j) { return c2{ c_ps_phase[j].x, c_ps_phase[j].y }; }
+
+// EMA update of all 16 hypotheses for one symbol; T[j] = (t[j], t[15 - j])
+__device__ __forceinline__ void ps_lane_ema(c2 v, PsLane& st, c2 (&T)[8]) {
+	const float w = 0.85f;
+	const float w1 = 1 - w; // (1 - weight) evaluated in float (Demod.cpp:71)
+	const c2 W = { w, w };
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		const c2 ab = v * ps_lane_cs(j); // a = re * phase[j].real(), b = im * phase[j].imag()
+		T[j] = pk_sum_diff(ab);
+		c2 u; // (1 - weight) * std::abs(t): the |.| source modifier keeps it at one instruction per hypothesis
+		asm("v_mul_f32_e64 %0, %1, |%2|" : "=v"(u.x) : "v"(w1), "v"(T[j].x));
+		asm("v_mul_f32_e64 %0, %1, |%2|" : "=v"(u.y) : "v"(w1), "v"(T[j].y));
+		st.P[j] = W * st.P[j] + u;
+	}
+}
+
+// decisions of one symbol as a word over the hypotheses: bit k = t[k] > 0
+__device__ __forceinline__ unsigned ps_lane_decisions(const c2 (&T)[8]) {
+	float nt[16];
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		const c2 N = pk_neg_from_zero(T[j]);
+		nt[j] = N.x; nt[15 - j] = N.y;
+	}
+	unsigned d = 0;
+#pragma unroll
+	for (int k = 15; k >= 0; k--) d = push_sign(d, nt[k]);
+	return d;
+}
+
+// What k4_walk needs of one symbol, every 16-bit field repeated in both halves of its word (so that a bit-field
+// extract at offset max_idx needs no "& 15"):
+//   up[i]: the search moves to i + 1  <=>  g[i] ? g[i+1] : h[i]   (the third candidate beats the better of the first two)
+//   dn[i]: the search moves to i - 1  <=>  !g[i] && !h[i]         (the first candidate, max_idx - 1, stays the maximum)
+//   x[i] : bit(nDelay) ^ bit(nDelay + 1) of hypothesis i = d(n-3)[i] ^ d(n-4)[i]
+struct PsWords { unsigned up, dn, x; };
+struct PsHist { unsigned d1, d2, d3, d4; }; // decision words of 1..4 symbols ago
+
+__device__ __forceinline__ PsWords ps_lane_words(const PsLane& st, const c2 (&T)[8], PsHist& hs) {
+	const c2(&P)[8] = st.P;
+	float e[16], f[16]; // e[k] = ma[k-1] - ma[k], f[k] = ma[k-1] - ma[k+1]
+#pragma unroll
+	for (int k = 1; k <= 7; k++) {
+		const c2 E = pk_diff_cross(P[k - 1], P[k]); // (ma[k-1] - ma[k], ma[15-k] - ma[16-k])
+		e[k] = E.x; e[16 - k] = E.y;
+	}
+	e[0] = P[0].y - P[0].x; // ma[15] - ma[0]
+	e[8] = P[7].x - P[7].y; // ma[7] - ma[8]
+#pragma unroll
+	for (int k = 1; k <= 6; k++) {
+		const c2 F = pk_diff_cross(P[k - 1], P[k + 1]); // (ma[k-1] - ma[k+1], ma[14-k] - ma[16-k])
+		f[k] = F.x; f[15 - k] = F.y;
+	}
+	f[0] = P[0].y - P[1].x;  // ma[15] - ma[1]
+	f[7] = P[6].x - P[7].y;  // ma[6] - ma[8]
+	f[8] = P[7].x - P[6].y;  // ma[7] - ma[9]
+	f[15] = P[1].y - P[0].x; // ma[14] - ma[0]
+	unsigned g = 0, hh = 0;
+#pragma unroll
+	for (int k = 15; k >= 0; k--) { g = push_sign(g, e[k]); hh = push_sign(hh, f[k]); }
+	const unsigned gd = g | (g << 16), hd = hh | (hh << 16);
+	const unsigned g1 = __builtin_amdgcn_alignbit(gd, gd, 1); // g[i + 1] at bit i
+	PsWords w;
+	w.up = (gd & g1) | (~gd & hd);
+	w.dn = ~(gd | hd);
+	const unsigned x = hs.d3 ^ hs.d4; // nDelay = 3 (Model.cpp:560-561): decisions of 3 and 4 symbols ago
+	w.x = x | (x << 16);
+	hs.d4 = hs.d3; hs.d3 = hs.d2; hs.d2 = hs.d1; hs.d1 = ps_lane_decisions(T);
+	return w;
+}
+
+constexpr int PSL_BATCH = 8;
+
+template <int N>
+__device__ __forceinline__ void ps_lane_load(const float2* x, c2 (&v)[N]) {
+#pragma unroll
+	for (int e = 0; e < N; e += 2) {
+		const float4 t = *reinterpret_cast<const float4*>(x + e);
+		v[e] = c2{ t.x, t.y }; v[e + 1] = c2{ t.z, t.w };
+	}
+}
+
+__device__ __forceinline__ void ps_walk_body(const K4Params& p, int wave);
+
+// grid (chains / 64, chunks [+ 1]): the extra row of workgroups, if any, walks the PREVIOUS block (parameter block w)
+__global__ __launch_bounds__(64) void k4_lane_chunks(K4Params p, K4Params w) {
+	// (the walk's workgroups come FIRST in dispatch order: they are the longest-running ones)
+	const int has_walk = (int)gridDim.y - p.n_lchunks;
+	if (has_walk && blockIdx.y == 0) { ps_walk_body(w, blockIdx.x); return; }
+	const int lane = threadIdx.x;
+	const int chain_raw = blockIdx.x * 64 + lane;
+	const bool live = chain_raw < p.n_chains;
+	const int chain = live ? chain_raw : p.n_chains - 1;
+	const int chunk = (int)blockIdx.y - has_walk;
+	const int g0 = chunk * p.cl;
+	const int g1 = g0 + p.cl < p.n_groups ? g0 + p.cl : p.n_groups;
+	if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
+	else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
+	else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
+	const float2* x = p.sym + (size_t)chain * p.sym_stride;
+	// three planes (up, dn, x), time-major in groups of four symbols: uint4 [plane][g / 4][ma_stride]: this kernel's
+	// stores and k4_walk's loads are whole 1 KiB rows per wave
+	const size_t plane = (size_t)p.lw_quads * p.ma_stride;
+	uint4* lw_up = reinterpret_cast<uint4*>(p.lw) + chain_raw;
+	uint4* lw_dn = lw_up + plane;
+	uint4* lw_x = lw_dn + plane;
+	const size_t mslot = (size_t)chunk * 16 * p.ma_stride + chain_raw; // [chunk][k][chain]
+	const EmaState* s0 = p.state_in + chain;
+
+	PsLane st;
+	PsHist hs;
+	int ws = g0 - p.warm;
+	if (ws <= 0) { // the true state, replayed exactly from the block start (always so for chunk 0)
+		ws = 0;
+#pragma unroll
+		for (int j = 0; j < 8; j++) st.P[j] = c2{ s0->ma[j], s0->ma[15 - j] };
+	} else {
+#pragma unroll
+		for (int j = 0; j < 8; j++) st.P[j] = c2{ 0.0f, 0.0f };
+	}
+	if (g0 == 0) {
+		hs.d1 = hs.d2 = hs.d3 = hs.d4 = 0;
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			const unsigned b = s0->bits[k]; // bit j: decision of j + 1 symbols ago
+			hs.d1 |= (b & 1u) << k; hs.d2 |= ((b >> 1) & 1u) << k; hs.d3 |= ((b >> 2) & 1u) << k; hs.d4 |= ((b >> 3) & 1u) << k;
+		}
+	} else {
+		// warm-up: EMA only (warm and cl are multiples of 8 symbols) ...
+#pragma unroll 1
+		for (int g = ws; g < g0 - PSL_BATCH; g += PSL_BATCH) {
+			c2 v[PSL_BATCH];
+			ps_lane_load(x + g, v);
+#pragma unroll
+			for (int e = 0; e < PSL_BATCH; e++) { c2 T[8]; ps_lane_ema(v[e], st, T); __builtin_amdgcn_sched_barrier(0); }
+		}
+		// ... and the decisions of its last four symbols
+		c2 v[PSL_BATCH];
+		ps_lane_load(x + g0 - PSL_BATCH, v);
+		unsigned dd[4];
+#pragma unroll
+		for (int e = 0; e < PSL_BATCH; e++) {
+			c2 T[8];
+			ps_lane_ema(v[e], st, T);
+			if (e >= PSL_BATCH - 4) dd[e - (PSL_BATCH - 4)] = ps_lane_decisions(T);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		hs.d1 = dd[3]; hs.d2 = dd[2]; hs.d3 = dd[1]; hs.d4 = dd[0];
+	}
+	{ // (unconditional stores: padded columns exist for dead lanes)
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			p.ma_start[mslot + (size_t)j * p.ma_stride] = st.P[j].x;
+			p.ma_start[mslot + (size_t)(15 - j) * p.ma_stride] = st.P[j].y;
+		}
+	}
+	const int n = g1 - g0;
+	const int nb = n - (n % PSL_BATCH);
+	c2 cur[PSL_BATCH];
+	if (nb > 0) ps_lane_load(x + g0, cur);
+#pragma unroll 1
+	for (int q = 0; q < nb; q += PSL_BATCH) {
+		c2 nxt[PSL_BATCH];
+		const int qn = q + PSL_BATCH < nb ? q + PSL_BATCH : q; // next batch in flight while this one is processed
+		ps_lane_load(x + g0 + qn, nxt);
+		PsWords wd[PSL_BATCH];
+#pragma unroll
+		for (int e = 0; e < PSL_BATCH; e++) {
+			c2 T[8];
+			ps_lane_ema(cur[e], st, T);
+			wd[e] = ps_lane_words(st, T, hs);
+			__builtin_amdgcn_sched_barrier(0); // one symbol at a time: interleaving all eight costs 440 registers
+		}
+		// (unconditional: a branch here would let the compiler sink the sign collection of all eight symbols behind it
+		// and keep 400 floats alive)
+#pragma unroll
+		for (int e = 0; e < PSL_BATCH; e += 4) {
+			const size_t row = (size_t)((g0 + q + e) >> 2) * p.ma_stride;
+			lw_up[row] = make_uint4(wd[e].up, wd[e + 1].up, wd[e + 2].up, wd[e + 3].up);
+			lw_dn[row] = make_uint4(wd[e].dn, wd[e + 1].dn, wd[e + 2].dn, wd[e + 3].dn);
+			lw_x[row] = make_uint4(wd[e].x, wd[e + 1].x, wd[e + 2].x, wd[e + 3].x);
+		}
+#pragma unroll
+		for (int e = 0; e < PSL_BATCH; e++) cur[e] = nxt[e];
+	}
+#pragma unroll 1
+	for (int q = nb; q < n; q++) {
+		const float2 t = x[g0 + q];
+		c2 T[8];
+		ps_lane_ema(c2{ t.x, t.y }, st, T);
+		const PsWords wd = ps_lane_words(st, T, hs);
+		const size_t row = (size_t)((g0 + q) >> 2) * p.ma_stride;
+		const int sub = (g0 + q) & 3;
+		reinterpret_cast<unsigned*>(lw_up + row)[sub] = wd.up;
+		reinterpret_cast<unsigned*>(lw_dn + row)[sub] = wd.dn;
+		reinterpret_cast<unsigned*>(lw_x + row)[sub] = wd.x;
+	}
+	{
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			p.ma_fin[mslot + (size_t)j * p.ma_stride] = st.P[j].x;
+			p.ma_fin[mslot + (size_t)(15 - j) * p.ma_stride] = st.P[j].y;
+		}
+	}
+	if (live && g1 == p.n_groups) { // the block's last chunk leaves the float state and the decision history
+		EmaState* sto = p.state_out + chain;
+#pragma unroll
+		for (int j = 0; j < 8; j++) { sto->ma[j] = st.P[j].x; sto->ma[15 - j] = st.P[j].y; }
+#pragma unroll
+		for (int k = 0; k < 16; k++) // only the last four decisions can ever be read again
+			sto->bits[k] = ((hs.d1 >> k) & 1u) | (((hs.d2 >> k) & 1u) << 1) | (((hs.d3 >> k) & 1u) << 2) | (((hs.d4 >> k) & 1u) << 3);
+	}
+}
+
+// k4_walk: the integer recurrence max_idx -> output bit, one lane per chain, strictly sequential over the block.  Per symbol
+// the dependent chain is two bit-field extracts and one three-operand add (max_idx is kept unreduced: the extracts use
+// its low five bits and the words repeat every 16); the output bit costs one more extract and one shift-or.
+#ifndef WALK_B_
+#define WALK_B_ 16
+#endif
+constexpr int WALK_B = WALK_B_; // symbols per register batch (16 or 32)
+
+struct WalkBuf { uint4 up[WALK_B / 4], dn[WALK_B / 4], x[WALK_B / 4]; };
+
+__device__ __forceinline__ void walk_load(WalkBuf& b, const uint4* lw, size_t plane, long long stride, int g, int n) {
+	const int last = (n - 1) >> 2;
+#pragma unroll
+	for (int e = 0; e < WALK_B / 4; e++) {
+		int gq = (g >> 2) + e;
+		gq = gq < last ? gq : last; // wave-uniform clamp: batches past the end re-read the last group and are not used
+		const uint4* src = lw + (size_t)gq * stride;
+		b.up[e] = src[0]; b.dn[e] = src[plane]; b.x[e] = src[2 * plane];
+	}
+}
+
+__device__ __forceinline__ unsigned u4_get(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+template <bool GUARD>
+__device__ __forceinline__ uint32_t walk_batch(const WalkBuf& b, int q, int n, int& idx) {
+	uint32_t part = 0;
+#pragma unroll
+	for (int e = 0; e < WALK_B; e++) {
+		if (!GUARD || q + e < n) { // wave-uniform
+			const unsigned up = u4_get(b.up[e >> 2], e & 3), dn = u4_get(b.dn[e >> 2], e & 3), xx = u4_get(b.x[e >> 2], e & 3);
+			idx = idx + (int)__builtin_amdgcn_ubfe(up, (unsigned)idx, 1u) + __builtin_amdgcn_sbfe((int)dn, (unsigned)idx, 1u);
+			part |= __builtin_amdgcn_ubfe(xx, (unsigned)idx, 1u) << e;
+		}
+	}
+	return part;
+}
+
+// speculative warm-ups: chunk c must have started from exactly the values chunk c-1 ended with; any difference raises
+// p.flag and the exact sequential kernel recomputes the block
+__global__ __launch_bounds__(256) void k4_verify(K4Params p) {
+	const size_t per_chunk = (size_t)16 * p.ma_stride;
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= per_chunk * (size_t)(p.n_lchunks - 1)) return;
+	const int chain = (int)(i % (size_t)p.ma_stride);
+	const bool bad = chain < p.n_chains && __float_as_uint(p.ma_start[per_chunk + i]) != __float_as_uint(p.ma_fin[i]);
+	if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(p.flag, 1);
+}
+
+__device__ __forceinline__ void ps_walk_body(const K4Params& p, int wave) {
+	const int lane = threadIdx.x;
+	const int chain_raw = wave * 64 + lane;
+	const bool live = chain_raw < p.n_chains;
+	const int chain = live ? chain_raw : p.n_chains - 1;
+	const EmaState* st = p.state_in + chain;
+	EmaState* sto = p.state_out + chain;
+	const uint4* lw = reinterpret_cast<const uint4*>(p.lw) + chain_raw;
+	const size_t plane = (size_t)p.lw_quads * p.ma_stride;
+	const int n = p.n_groups;
+	if (*p.flag != 0) return; // the exact sequential kernel has produced this block
+	if (p.prio_walk == 3) __builtin_amdgcn_s_setprio(3);
+	else if (p.prio_walk == 2) __builtin_amdgcn_s_setprio(2);
+	else if (p.prio_walk == 1) __builtin_amdgcn_s_setprio(1);
+	WalkBuf b0, b1;
+	walk_load(b0, lw, plane, p.ma_stride, 0, n);
+	walk_load(b1, lw, plane, p.ma_stride, WALK_B, n);
+	int idx = st->max_idx;
+	uint32_t* out = p.bits + (size_t)chain * p.bits_stride;
+	// (WALK_B == 16: two batches make one output word; WALK_B == 32: one batch does)
+	auto put = [&](int q0, uint32_t v) {
+		if (WALK_B == 32) { if (live) out[q0 >> 5] = v; }
+		else if (live) reinterpret_cast<uint16_t*>(out)[q0 >> 4] = (uint16_t)v;
+	};
+	int q = 0;
+#pragma unroll 1
+	for (; q + 2 * WALK_B <= n; q += 2 * WALK_B) {
+		uint32_t v = walk_batch<false>(b0, q, n, idx);
+		walk_load(b0, lw, plane, p.ma_stride, q + 2 * WALK_B, n);
+		put(q, v);
+		v = walk_batch<false>(b1, q + WALK_B, n, idx);
+		walk_load(b1, lw, plane, p.ma_stride, q + 3 * WALK_B, n);
+		put(q + WALK_B, v);
+	}
+	if (q < n) { const uint32_t v = walk_batch<true>(b0, q, n, idx); put(q, v); }
+	if (q + WALK_B < n) { const uint32_t v = walk_batch<true>(b1, q + WALK_B, n, idx); put(q + WALK_B, v); }
+	if (live) {
+		sto->max_idx = idx & 15;
+		sto->rot = (st->rot + p.n_groups) & 3;
+	}
+}
+
+__global__ __launch_bounds__(64) void k4_walk(K4Params p) { ps_walk_body(p, blockIdx.x); }
+
+// ------------------------------------------------------------------------------------------
 // K5: ModelChallenger's non-coherent branch (DSP/Model.cpp:638-639): Demod::FM (DSP/Demod.cpp:27-37) ->
 // DSP::Filter with Filters::Receiver (37 taps, DSP/DSP.cpp:249-280) -> Deinterleave(5) -> AIS::Decoder.
 // The decoders only look at the sign, so the device hands back one bit per 48 kHz sample.
@@ -2185,6 +2536,25 @@ hipError_t launch_k4(const K4Params& p, hipStream_t s) {
 	hipLaunchKernelGGL(k4_phase_chunks, dim3((p.n_chains + 3) / 4, p.n_chunks), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(k4_assemble, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(k4_phase_search, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p, 1); // exits at once unless flagged
+	return hipGetLastError();
+}
+
+// lane-per-chunk PhaseSearchEMA in three parts, so that the latency-bound walk can run on another stream (CUs of its own):
+// (a) sign words + verification, (b) the exact sequential kernel if the verification failed, (c) the walk (skips when (b) ran)
+hipError_t launch_k4_lane_words(const K4Params& p, const K4Params* walk_prev, hipStream_t s) {
+	hipError_t e = hipMemsetAsync(p.flag, 0, sizeof(int), s);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k4_lane_chunks, dim3((p.n_chains + 63) / 64, p.n_lchunks + (walk_prev ? 1 : 0)), dim3(64), 0, s, p, walk_prev ? *walk_prev : p);
+	const size_t n_cmp = (size_t)16 * p.ma_stride * (p.n_lchunks - 1);
+	if (n_cmp > 0) hipLaunchKernelGGL(k4_verify, dim3((unsigned)((n_cmp + 255) / 256)), dim3(256), 0, s, p);
+	return hipGetLastError();
+}
+hipError_t launch_k4_fallback(const K4Params& p, hipStream_t s) {
+	hipLaunchKernelGGL(k4_phase_search, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p, 1); // exits at once unless flagged
+	return hipGetLastError();
+}
+hipError_t launch_k4_walk(const K4Params& p, hipStream_t s) {
+	hipLaunchKernelGGL(k4_walk, dim3((p.n_chains + 63) / 64), dim3(64), 0, s, p);
 	return hipGetLastError();
 }
 

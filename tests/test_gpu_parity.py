@@ -133,6 +133,24 @@ def test_edge_inputs():
     _run_gpu_vs_oracle([cu], 1536000, "cu8", 16384, 4)
 
 
+def test_edge_inputs_through_the_chunked_phase_search(monkeypatch):
+    """Blocks long enough for the lane-per-chunk PhaseSearchEMA (sign words + integer walk), with chunks shorter than
+    the warm-up: exact zeros (t == +-0 must count as "not > 0"), DC, alternating full scale, 10^22 dynamic range."""
+    monkeypatch.setenv("AISGPU_K4", "lane")
+    monkeypatch.setenv("AISGPU_PS_CL", "128")
+    n = 131072 * 3
+    rng = np.random.default_rng(11)
+    zero = np.zeros(n, np.complex64)
+    dc = np.full(n, 0.25 - 0.5j, np.complex64)
+    alt = (np.where(np.arange(n) % 2 == 0, 1.0, -1.0) * (1 + 1j)).astype(np.complex64)
+    wild = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    wild[:n // 3] *= np.float32(1e-18)
+    wild[n // 3:2 * n // 3] *= np.float32(3e4)
+    half = zero.copy()
+    half[n // 2:] = wild[n // 2:]
+    _run_gpu_vs_oracle([zero, dc, alt, wild, half], 1536000, "cf32", 131072, 3)
+
+
 def test_noise_only_long():
     rng = np.random.default_rng(2)
     x = (0.05 * (rng.standard_normal(786432 * 2) + 1j * rng.standard_normal(786432 * 2))).astype(np.complex64)
@@ -239,11 +257,16 @@ def test_nmea_batched_receivers_on_threads():
     batch.close()
 
 
-@pytest.mark.parametrize("env", [{"AISGPU_PS_WARM": "16"}, {"AISGPU_PS_SEQUENTIAL": "1"}, {"AISGPU_SERIAL": "1"}])
+@pytest.mark.parametrize("env", [{"AISGPU_PS_WARM": "16"}, {"AISGPU_PS_SEQUENTIAL": "1"}, {"AISGPU_SERIAL": "1"},
+                                 {"AISGPU_K4": "lane"}, {"AISGPU_K4": "lane", "AISGPU_PS_WARM": "16"},
+                                 {"AISGPU_K4": "lane", "AISGPU_WALK_RIDE": "0"}, {"AISGPU_K4": "lane", "AISGPU_SERIAL": "1"},
+                                 {"AISGPU_K4": "lane", "AISGPU_PS_CL": "128"}, {"AISGPU_K4": "lane", "AISGPU_PS_CL": "1024"},
+                                 {"AISGPU_K4": "lane", "AISGPU_PS_CL": "4096"}])
 def test_phase_search_fallback_and_variants(env, monkeypatch):
     """The chunk-parallel PhaseSearchEMA verifies its speculative warm-ups; with a 16-symbol warm-up the check
     must fail and the sequential fallback must still deliver bit-exact decisions.  Also: the plain sequential
-    kernel and the single-stream (non-overlapped) schedule."""
+    kernel, the single-stream (non-overlapped) schedule, and the lane-per-chunk variant (sign words + integer walk that
+    rides along with the next block's launch) with several chunk lengths."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     xs = [synth.receiver_stream(786432 * 2, receiver_id=40 + r) for r in range(2)]
@@ -460,6 +483,14 @@ def test_gpu_frame_decoder_nmea(block, nblocks, fmt):
     assert m.nmea() == chk.nmea()
     a, c = m.msg_meta(), chk.msg_meta()
     assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+
+
+def test_gpu_frame_decoder_behind_the_deferred_walk(monkeypatch):
+    """Lane-per-chunk PhaseSearchEMA: the hard bits of block f are complete only after the walk that rides along with block
+    f+1 (or the flush when results are requested); the device decoders and the copies must wait for exactly that."""
+    monkeypatch.setenv("AISGPU_K4", "lane")
+    test_gpu_frame_decoder_nmea(786432, 4, "cf32")
+    test_gpu_frame_decoder_nmea(131072, 16, "cu8")
 
 
 def test_gpu_frame_decoder_matches_host_decoders_on_a_batch():
