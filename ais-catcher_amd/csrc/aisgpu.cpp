@@ -71,6 +71,7 @@ struct aisgpu {
 	int depth = 1;        // tiles prefetched ahead by the front end
 	int k1_threads = 64;  // front-end workgroup size (64: one autonomous wave per workgroup)
 	int in_bytes = 0;     // bytes per input sample
+	int kfmt = 0;         // kernel numbering of the input format
 	int n_pre = 0;        // samples per receiver per input block after the pre-decimation pass
 	int n96 = 0, L = 0, W = 0; // per downstream block: 96 kHz samples, 48 kHz samples per channel, CGF windows
 	int Gcap = 0, words = 0;   // group capacity per block, bit words per chain
@@ -623,7 +624,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		}
 	}
 	if (cfg->model != AISGPU_MODEL_DEFAULT && cfg->model != AISGPU_MODEL_CHALLENGER && cfg->model != AISGPU_MODEL_BASE) return AISGPU_ERR_ARG;
-	if (cfg->input_format != AISGPU_FMT_CU8 && cfg->input_format != AISGPU_FMT_CF32) return AISGPU_ERR_ARG;
+	if (cfg->input_format != AISGPU_FMT_CU8 && cfg->input_format != AISGPU_FMT_CF32 && cfg->input_format != AISGPU_FMT_CS8 &&
+	    cfg->input_format != AISGPU_FMT_CS16) return AISGPU_ERR_ARG;
 	if (cfg->n_receivers < 1 || cfg->n_receivers > 65535) return AISGPU_ERR_ARG;
 	// a downstream block must be a whole number of 512-sample CGF windows
 	const int dec48 = mode == MODE_DSK ? 6 << KP : 2 << k; // input samples per 48 kHz sample (bucket rate)
@@ -649,7 +651,10 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			if (ok) { h->k1_threads = a; h->tile96 = b; h->depth = d; }
 		}
 	}
-	h->in_bytes = cfg->input_format == AISGPU_FMT_CU8 ? 2 : 8;
+	h->in_bytes = cfg->input_format == AISGPU_FMT_CF32 ? 8 : cfg->input_format == AISGPU_FMT_CS16 ? 4 : 2;
+	// kernel numbering of the formats: 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16
+	h->kfmt = cfg->input_format == AISGPU_FMT_CF32 ? 0 : cfg->input_format == AISGPU_FMT_CU8 ? 1 : cfg->input_format == AISGPU_FMT_CS8 ? 2 : 3;
+	if (h->kfmt > 1 && h->depth != 0) { delete h; return AISGPU_ERR_ARG; } // CS8 / CS16: register (DPP) front end only
 	h->n_pre = cfg->block_len >> KP;
 	if (mode == MODE_RESAMPLE) h->n96 = h->n_pre / 4; // one flush of n_pre samples at the bucket rate >> KP (= 384 kHz)
 	else if (mode == MODE_DSK) h->n96 = h->n_pre / 3;
@@ -964,7 +969,7 @@ int aisgpu_run(aisgpu_t* h) {
 	if (!h) return AISGPU_ERR_ARG;
 	if (!h->submitted) return AISGPU_ERR_STATE;
 	HIPCHK(hipSetDevice(h->cfg.device_id));
-	const bool cu8 = h->cfg.input_format == AISGPU_FMT_CU8;
+	const bool cu8 = h->kfmt != 0; // an integer format: converted on the fly by the front end
 	const int R = h->cfg.n_receivers;
 	h->n_sub = 0;
 
@@ -991,7 +996,7 @@ int aisgpu_run(aisgpu_t* h) {
 		xcur = h->d_xpre[xb];
 		xstride = (long long)h->xh + h->n_pre;
 		if (h->in_blocks > 0) HIPCHK(launch_copy_rows(h->d_xpre[xb ^ 1] + h->n_pre, xstride, xcur, xstride, h->xh, R, h->stream));
-		HIPCHK(launch_convert_rows(h->cur_in, h->cur_in_stride, cu8 ? 1 : 0, xcur + h->xh, xstride, h->n_pre, R, h->stream));
+		HIPCHK(launch_convert_rows(h->cur_in, h->cur_in_stride, h->kfmt, xcur + h->xh, xstride, h->n_pre, R, h->stream));
 	}
 	if (h->KP > 0) {
 		const bool two = h->mode == MODE_RESAMPLE || h->mode == MODE_DSK;
@@ -1009,7 +1014,7 @@ int aisgpu_run(aisgpu_t* h) {
 		kp.alpha = 0; kp.beta = 1; kp.has_fdc = 0;
 		kp.pre_out = xcur + h->xh; kp.pre_stride = xstride;
 		int rc = time_begin(); if (rc) return rc;
-		HIPCHK(launch_k1(kp, h->KP, cu8, h->tile96, h->depth, h->k1_threads, h->pspans, R, h->stream));
+		HIPCHK(launch_k1(kp, h->KP, h->kfmt, h->tile96, h->depth, h->k1_threads, h->pspans, R, h->stream));
 		rc = time_end(); if (rc) return rc;
 		if (!pre_saves) HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist[hb ^ 1],
 		                                      h->ptile_in * h->in_bytes, R, h->stream));
@@ -1061,7 +1066,7 @@ int aisgpu_run(aisgpu_t* h) {
 		k1.alpha = h->alpha; k1.beta = h->beta; k1.has_fdc = h->has_fdc;
 		k1.pre_out = nullptr; k1.pre_stride = 0;
 		if (!from_pre) { int rc = time_begin(); if (rc) return rc; }
-		{ TraceScope t(h, "front", h->stream); HIPCHK(launch_k1(k1, h->K, from_pre ? false : cu8, h->tile96, h->depth, h->k1_threads, h->spans, R, h->stream)); }
+		{ TraceScope t(h, "front", h->stream); HIPCHK(launch_k1(k1, h->K, from_pre ? 0 : h->kfmt, h->tile96, h->depth, h->k1_threads, h->spans, R, h->stream)); }
 		if (!from_pre) { int rc = time_end(); if (rc) return rc; }
 		if (saves) {}
 		else if (from_pre) HIPCHK(launch_k1_tail(xcur, xstride * 8, (long long)h->n_pre * 8, h->d_hist2[hb ^ 1], h->tile_in * 8, R, h->stream));

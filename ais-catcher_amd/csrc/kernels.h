@@ -133,13 +133,14 @@ struct K7Params {
 };
 hipError_t launch_k7(const K7Params& p, hipStream_t s);
 
-hipError_t launch_k1(const K1Params& p, int K, bool cu8, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s);
+// fmt (kernel numbering): 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16
+hipError_t launch_k1(const K1Params& p, int K, int fmt, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s);
 hipError_t launch_k1u(const K1uParams& p, int n_rx, hipStream_t s);
 hipError_t launch_copy_rows(const float2* src, long long src_stride, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
 hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long block_bytes, void* hist, int tail_bytes,
                           int n_rx, hipStream_t s);
 hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s);
-hipError_t launch_convert_rows(const void* in, long long in_stride, int cu8, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
+hipError_t launch_convert_rows(const void* in, long long in_stride, int fmt, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
 hipError_t launch_k2a_fft(const K2Params& p, int n_chan, hipStream_t s);
 hipError_t launch_k2a_search(const K2Params& p, int n_chan, hipStream_t s);
 hipError_t launch_selftest_hypot(const float2* in, int n, unsigned* mismatches, hipStream_t s);

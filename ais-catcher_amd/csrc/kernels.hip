@@ -539,11 +539,14 @@ __device__ __forceinline__ void wave_sync() {
 #ifndef K1_WAVES
 #define K1_WAVES 3
 #endif
-template <int K, bool CU8, bool PRE>
+// FMT: input sample format (Utilities/StreamHelpers.cpp:51-133): 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16
+constexpr int fmt_bytes(int fmt) { return fmt == 0 ? 8 : fmt == 3 ? 4 : 2; }
+
+template <int K, int FMT, bool PRE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4))) void k1_dpp(K1Params p) {
 	constexpr int C0 = 1 << K;        // input samples per lane per tile
 	constexpr int TILE_IN = 64 * C0;  // input samples per wave-tile
-	constexpr bool DMA = C0 >= 4 && !CU8; // tiles come straight from HBM into LDS (global_load_lds), no staging registers
+	constexpr bool DMA = C0 >= 4 && FMT == 0; // tiles come straight from HBM into LDS (global_load_lds), no staging registers
 	constexpr int W4 = C0 / 2;            // 16-byte pieces per lane
 	__shared__ __attribute__((aligned(16))) float4 xt[DMA ? 64 * W4 : 1]; // the tile, linear, XOR-swizzled in units of 16 B
 	__shared__ __attribute__((aligned(16))) float2 x5[2][8 + 64];  // rotated up/down with 8 samples of history
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 	int tile_last = tile_first + p.tiles_per_span;
 	if (tile_last >= p.tiles_per_block) tile_last = p.tiles_per_block - 1;
 
-	constexpr int TILE_BYTES = TILE_IN * (CU8 ? 2 : 8);
+	constexpr int TILE_BYTES = TILE_IN * fmt_bytes(FMT);
 	constexpr int LANE_BYTES = TILE_BYTES / 64;                    // 2^K * (2 or 8)
 	constexpr int NV = LANE_BYTES >= 16 ? LANE_BYTES / 16 : 1;      // 16-byte pieces per lane
 	uint4 pre[DMA ? 1 : NV];
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 	auto prefetch = [&](int tile) {
 		const unsigned char* base;
 		if (tile < 0) base = (const unsigned char*)p.hist + (size_t)rx * TILE_BYTES;
-		else base = (const unsigned char*)p.in + ((size_t)rx * p.in_stride + (size_t)tile * TILE_IN) * (CU8 ? 2 : 8);
+		else base = (const unsigned char*)p.in + ((size_t)rx * p.in_stride + (size_t)tile * TILE_IN) * fmt_bytes(FMT);
 		if constexpr (DMA) {
 			const uint4* src = (const uint4*)base + dma_r * W4 + dma_q;
 #pragma unroll
@@ -595,13 +598,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 
 	for (int tile = tile_first; tile <= tile_last; tile++) {
 		c2 x[C0];
-		if constexpr (CU8) { // Utilities/Convert.cpp:255-264: ((int)u - 128) / 128.0f (exact)
+		if constexpr (FMT == 1 || FMT == 2) { // Utilities/Convert.cpp:255-275: ((int)u - 128) / 128.0f, (int8) / 128.0f (exact)
 			const unsigned* w = reinterpret_cast<const unsigned*>(pre);
 #pragma unroll
 			for (int i = 0; i < C0; i++) {
 				const unsigned v = w[i >> 1] >> ((i & 1) * 16);
-				x[i] = c2{ (float)((int)(v & 255u) - 128) * 0.0078125f, (float)((int)((v >> 8) & 255u) - 128) * 0.0078125f };
+				const int re = FMT == 1 ? (int)(v & 255u) - 128 : (int)(signed char)(v & 255u);
+				const int im = FMT == 1 ? (int)((v >> 8) & 255u) - 128 : (int)(signed char)((v >> 8) & 255u);
+				x[i] = c2{ (float)re * 0.0078125f, (float)im * 0.0078125f };
 			}
+		} else if constexpr (FMT == 3) { // Utilities/Convert.cpp:277-286: (int16) / 32768.0f (exact)
+			const unsigned* w = reinterpret_cast<const unsigned*>(pre);
+#pragma unroll
+			for (int i = 0; i < C0; i++)
+				x[i] = c2{ (float)(int)(short)(w[i] & 0xffffu) * 0.000030517578125f, (float)(int)(short)(w[i] >> 16) * 0.000030517578125f };
 		} else if constexpr (C0 < 4) {
 			x[0] = c2{ __uint_as_float(pre[0].x), __uint_as_float(pre[0].y) };
 			x[1] = c2{ __uint_as_float(pre[0].z), __uint_as_float(pre[0].w) };
@@ -812,14 +822,21 @@ __global__ __launch_bounds__(256) void k1k_dsk_frontend(K1kParams p) {
 }
 
 // raw input rows -> complex float rows (Utilities/Convert.cpp:255-264 for CU8), for ladders without a CIC5 pre-pass
-__global__ void k_convert_rows(const unsigned char* in, long long in_stride_bytes, int cu8, float2* dst, long long dst_stride, int n) {
+__global__ void k_convert_rows(const unsigned char* in, long long in_stride_bytes, int fmt, float2* dst, long long dst_stride, int n) {
 	const int rx = blockIdx.y;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		float2 v;
-		if (cu8) {
-			const unsigned char* u = in + (size_t)rx * in_stride_bytes + 2 * (size_t)i;
+		const unsigned char* row = in + (size_t)rx * in_stride_bytes;
+		if (fmt == 1) {
+			const unsigned char* u = row + 2 * (size_t)i;
 			v = make_float2((float)((int)u[0] - 128) * 0.0078125f, (float)((int)u[1] - 128) * 0.0078125f);
-		} else v = reinterpret_cast<const float2*>(in + (size_t)rx * in_stride_bytes)[i];
+		} else if (fmt == 2) {
+			const signed char* u = reinterpret_cast<const signed char*>(row) + 2 * (size_t)i;
+			v = make_float2((float)(int)u[0] * 0.0078125f, (float)(int)u[1] * 0.0078125f);
+		} else if (fmt == 3) {
+			const short* u = reinterpret_cast<const short*>(row) + 2 * (size_t)i;
+			v = make_float2((float)(int)u[0] * 0.000030517578125f, (float)(int)u[1] * 0.000030517578125f);
+		} else v = reinterpret_cast<const float2*>(row)[i];
 		dst[(size_t)rx * dst_stride + i] = v;
 	}
 }
@@ -2389,33 +2406,40 @@ static hipError_t launch_k1_p(const K1Params& p, int K, bool cu8, int spans, int
 	return hipErrorInvalidValue;
 }
 
-template <int K>
-static hipError_t launch_k1_dpp_k(const K1Params& p, bool cu8, int spans, int n_rx, hipStream_t s) {
-	const bool pre = p.pre_out != nullptr;
-	if (cu8) {
-		if (pre) hipLaunchKernelGGL((k1_dpp<K, true, true>), dim3(spans, n_rx), dim3(64), 0, s, p);
-		else hipLaunchKernelGGL((k1_dpp<K, true, false>), dim3(spans, n_rx), dim3(64), 0, s, p);
-	} else {
-		if (pre) hipLaunchKernelGGL((k1_dpp<K, false, true>), dim3(spans, n_rx), dim3(64), 0, s, p);
-		else hipLaunchKernelGGL((k1_dpp<K, false, false>), dim3(spans, n_rx), dim3(64), 0, s, p);
-	}
+template <int K, int FMT>
+static hipError_t launch_k1_dpp_kf(const K1Params& p, int spans, int n_rx, hipStream_t s) {
+	if (p.pre_out != nullptr) hipLaunchKernelGGL((k1_dpp<K, FMT, true>), dim3(spans, n_rx), dim3(64), 0, s, p);
+	else hipLaunchKernelGGL((k1_dpp<K, FMT, false>), dim3(spans, n_rx), dim3(64), 0, s, p);
 	return hipGetLastError();
 }
 
-static hipError_t launch_k1_dpp(const K1Params& p, int K, bool cu8, int spans, int n_rx, hipStream_t s) {
+template <int K>
+static hipError_t launch_k1_dpp_k(const K1Params& p, int fmt, int spans, int n_rx, hipStream_t s) {
+	switch (fmt) {
+	case 0: return launch_k1_dpp_kf<K, 0>(p, spans, n_rx, s);
+	case 1: return launch_k1_dpp_kf<K, 1>(p, spans, n_rx, s);
+	case 2: return launch_k1_dpp_kf<K, 2>(p, spans, n_rx, s);
+	case 3: return launch_k1_dpp_kf<K, 3>(p, spans, n_rx, s);
+	}
+	return hipErrorInvalidValue;
+}
+
+static hipError_t launch_k1_dpp(const K1Params& p, int K, int fmt, int spans, int n_rx, hipStream_t s) {
 	switch (K) {
-	case 4: return launch_k1_dpp_k<4>(p, cu8, spans, n_rx, s);
-	case 3: return launch_k1_dpp_k<3>(p, cu8, spans, n_rx, s);
-	case 2: return launch_k1_dpp_k<2>(p, cu8, spans, n_rx, s);
-	case 1: return launch_k1_dpp_k<1>(p, cu8, spans, n_rx, s);
+	case 4: return launch_k1_dpp_k<4>(p, fmt, spans, n_rx, s);
+	case 3: return launch_k1_dpp_k<3>(p, fmt, spans, n_rx, s);
+	case 2: return launch_k1_dpp_k<2>(p, fmt, spans, n_rx, s);
+	case 1: return launch_k1_dpp_k<1>(p, fmt, spans, n_rx, s);
 	}
 	return hipErrorInvalidValue;
 }
 
 // tile96: samples at the kernel's output rate per tile; depth: tiles prefetched ahead; threads: workgroup size
 // (256, or 64 = one autonomous wave per workgroup)
-hipError_t launch_k1(const K1Params& p, int K, bool cu8, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s) {
-	if (depth == 0) return launch_k1_dpp(p, K, cu8, spans, n_rx, s); // register (DPP) variant: 64 threads, tile96 = 64
+hipError_t launch_k1(const K1Params& p, int K, int fmt, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s) {
+	if (depth == 0) return launch_k1_dpp(p, K, fmt, spans, n_rx, s); // register (DPP) variant: 64 threads, tile96 = 64
+	if (fmt > 1) return hipErrorInvalidValue; // the LDS-staged variants read CF32 and CU8 only
+	const bool cu8 = fmt == 1;
 	switch (threads * 10000 + tile96 * 10 + depth) {
 	case 2562562: return launch_k1_p<256, 2, 256>(p, K, cu8, spans, n_rx, s);
 	case 640641: return launch_k1_p<64, 1, 64>(p, K, cu8, spans, n_rx, s);
@@ -2434,10 +2458,10 @@ hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s) {
 	return hipGetLastError();
 }
 
-hipError_t launch_convert_rows(const void* in, long long in_stride, int cu8, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s) {
+hipError_t launch_convert_rows(const void* in, long long in_stride, int fmt, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s) {
 	int blocks = (n + 255) / 256;
 	if (blocks > 256) blocks = 256;
-	hipLaunchKernelGGL(k_convert_rows, dim3(blocks, n_rx), dim3(256), 0, s, (const unsigned char*)in, in_stride * (cu8 ? 2 : 8), cu8, dst, dst_stride, n);
+	hipLaunchKernelGGL(k_convert_rows, dim3(blocks, n_rx), dim3(256), 0, s, (const unsigned char*)in, in_stride * fmt_bytes(fmt), fmt, dst, dst_stride, n);
 	return hipGetLastError();
 }
 

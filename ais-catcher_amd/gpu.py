@@ -12,7 +12,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AISGPU_LIB") or os.path.join(_HERE, "libaisgpu.so")  # AISGPU_LIB: A/B a kernel build
 
-FMT_CU8, FMT_CF32 = 0, 1
+FMT_CU8, FMT_CF32, FMT_CS8, FMT_CS16 = 0, 1, 2, 3
+_ELEMS = {FMT_CU8: 2, FMT_CS8: 2, FMT_CS16: 2, FMT_CF32: 1}  # numpy elements per IQ sample (uint8 / int8 / int16 pairs, complex64)
 MODEL_BASE = 1
 MODEL_DEFAULT = 2
 MODEL_CHALLENGER = 4
@@ -140,7 +141,7 @@ class AisGpu:
 
     def submit(self, rx, block):
         block = np.ascontiguousarray(block)
-        per = 2 if self.cfg.input_format == FMT_CU8 else 1
+        per = _ELEMS[self.cfg.input_format]
         self._chk(self.lib.aisgpu_submit(self.h, rx, block.ctypes.data, block.size // per), "aisgpu_submit")
 
     def submit_device(self, ptr, rx_stride_samples):

@@ -49,7 +49,7 @@ void* aishost_model_create(void* batch, int rx, int sample_rate, int block_len, 
                            int detached, int model, char* errbuf, int errcap) {
 	Model* m = new Model();
 	try {
-		m->fmt = input_format == AISGPU_FMT_CU8 ? Format::CU8 : Format::CF32;
+		m->fmt = input_format == AISGPU_FMT_CU8 ? Format::CU8 : input_format == AISGPU_FMT_CS8 ? Format::CS8 : input_format == AISGPU_FMT_CS16 ? Format::CS16 : Format::CF32;
 		m->m.setFormat(m->fmt);
 		m->m.setBlockLength(block_len);
 		m->m.setChallenger((model & 0xff) == AISGPU_MODEL_CHALLENGER);

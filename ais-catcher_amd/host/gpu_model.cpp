@@ -126,7 +126,7 @@ void ModelDefaultGPU::buildModel(char CH1, char CH2, int sample_rate, bool /*tim
 		c.sample_rate = sample_rate;
 		c.n_receivers = 1;
 		c.block_len = block_len;
-		c.input_format = format == Format::CU8 ? AISGPU_FMT_CU8 : AISGPU_FMT_CF32;
+		c.input_format = format == Format::CU8 ? AISGPU_FMT_CU8 : format == Format::CS8 ? AISGPU_FMT_CS8 : format == Format::CS16 ? AISGPU_FMT_CS16 : AISGPU_FMT_CF32;
 		c.afc_wide = CGF_wide;
 		c.droop = droop_compensation;
 		c.model = base ? AISGPU_MODEL_BASE : challenger ? AISGPU_MODEL_CHALLENGER : AISGPU_MODEL_DEFAULT;
@@ -194,6 +194,8 @@ void ModelDefaultGPU::wireDecoders(char CH1, char CH2) {
 void ModelDefaultGPU::Receive(const RAW* raw, TAG& tag) {
 	if (raw->format == Format::CU8) chain.Receive((const CU8*)raw->data, raw->size / 2, tag);
 	else if (raw->format == Format::CF32) chain.Receive((const CFLOAT32*)raw->data, raw->size / (int)sizeof(CFLOAT32), tag);
+	else if (raw->format == Format::CS8) chain.Receive((const CS8*)raw->data, raw->size / 2, tag);
+	else if (raw->format == Format::CS16) chain.Receive((const CS16*)raw->data, raw->size / 4, tag);
 }
 
 } // namespace aisamd

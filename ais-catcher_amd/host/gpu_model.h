@@ -78,7 +78,7 @@ public:
 	const char* lastError() { return aisgpu_last_error(ctx); }
 };
 
-class GpuChain : public StreamIn<CFLOAT32>, public StreamIn<CU8> {
+class GpuChain : public StreamIn<CFLOAT32>, public StreamIn<CU8>, public StreamIn<CS8>, public StreamIn<CS16> {
 	GpuBatch* batch = nullptr;
 	int rx = 0;
 	std::function<void(const std::string&)> on_error;
@@ -101,6 +101,9 @@ public:
 	void setFrameHandler(std::function<void(const aisgpu_frame&, TAG&)> f) { on_frame = f; }
 	void Receive(const CFLOAT32* data, int len, TAG& tag) override { process(data, len, tag); }
 	void Receive(const CU8* data, int len, TAG& tag) override { process(data, len, tag); }
+	// the raw integer formats Util::ConvertRAW turns into CFLOAT32 (Utilities/StreamHelpers.cpp:91-106): converted on the device
+	void Receive(const CS8* data, int len, TAG& tag) override { process(data, len, tag); }
+	void Receive(const CS16* data, int len, TAG& tag) override { process(data, len, tag); }
 	// Replay one channel's symbol decisions of a block into the five phase outputs (host logic,
 	// also used stand-alone by the CPU tests).
 	static void replay(Connection<FLOAT32>* out, const aisgpu_out& o, TAG& tag);

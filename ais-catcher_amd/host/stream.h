@@ -13,9 +13,11 @@
 typedef float FLOAT32;
 typedef std::complex<FLOAT32> CFLOAT32;
 typedef std::complex<uint8_t> CU8;
+typedef std::complex<int8_t> CS8;    // Library/Common.h
+typedef std::complex<int16_t> CS16;
 typedef char BIT;
 
-enum class Format { CU8, CF32, UNKNOWN };
+enum class Format { CU8, CF32, CS8, CS16, UNKNOWN };
 
 // side-band struct that travels with every Receive() (Library/Common.h:240-288)
 struct TAG {

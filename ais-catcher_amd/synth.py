@@ -163,6 +163,22 @@ def to_cu8(x):
     return np.clip(np.round(v * 128.0 + 128.0), 0, 255).astype(np.uint8).reshape(-1)
 
 
+def to_cs8(x):
+    """complex64 -> interleaved int8 pairs, round(x*128) clipped (the reference divides by 128: Utilities/Convert.cpp:266-275)."""
+    v = np.empty((len(x), 2), dtype=np.float32)
+    v[:, 0] = x.real
+    v[:, 1] = x.imag
+    return np.clip(np.round(v * 128.0), -128, 127).astype(np.int8).reshape(-1)
+
+
+def to_cs16(x):
+    """complex64 -> interleaved int16 pairs, round(x*32768) clipped (Utilities/Convert.cpp:277-286)."""
+    v = np.empty((len(x), 2), dtype=np.float32)
+    v[:, 0] = x.real
+    v[:, 1] = x.imag
+    return np.clip(np.round(v * 32768.0), -32768, 32767).astype(np.int16).reshape(-1)
+
+
 def expected_nmea(sched):
     """The single-sentence NMEA lines a perfect receiver would print for a schedule."""
     out = []

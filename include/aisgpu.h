@@ -46,6 +46,8 @@ extern "C" {
 /* input formats: the RAW formats the reference's file/RTL devices deliver (Library/Common.h:88-99) */
 #define AISGPU_FMT_CU8 0
 #define AISGPU_FMT_CF32 1
+#define AISGPU_FMT_CS8 2   /* Utilities/Convert.cpp:266-275: (int8) / 128.0f */
+#define AISGPU_FMT_CS16 3  /* Utilities/Convert.cpp:277-286: (int16) / 32768.0f */
 
 /* models (DSP/Model.h:61-72) */
 #define AISGPU_MODEL_BASE 1        /* AIS::ModelBase       (-m 1), DSP/Model.cpp:419-438: FM receiver; the GPU delivers the sign of the

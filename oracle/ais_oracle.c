@@ -692,7 +692,7 @@ static void upsample_run(ao_chain* c, const cf* x, int len) { /* DSP.cpp:192-212
 }
 
 int ao_feed(ao_chain* c, const void* data, int nbytes) {
-	int n = c->fmt == 0 ? nbytes / 2 : nbytes / 8;
+	int n = c->fmt == 1 ? nbytes / 8 : c->fmt == 3 ? nbytes / 4 : nbytes / 2;
 	if (n > c->bcap) {
 		c->b0 = (cf*)realloc(c->b0, sizeof(cf) * (size_t)n);
 		c->b1 = (cf*)realloc(c->b1, sizeof(cf) * (size_t)n);
@@ -702,6 +702,14 @@ int ao_feed(ao_chain* c, const void* data, int nbytes) {
 	if (c->fmt == 0) { /* Utilities/Convert.cpp:255-264 */
 		const uint8_t* u = (const uint8_t*)data;
 		for (int i = 0; i < n; i++) { c->b0[i].re = ((int)u[2 * i] - 128) / 128.0f; c->b0[i].im = ((int)u[2 * i + 1] - 128) / 128.0f; }
+		in = c->b0;
+	} else if (c->fmt == 2) { /* CS8, Utilities/Convert.cpp:266-275 */
+		const int8_t* u = (const int8_t*)data;
+		for (int i = 0; i < n; i++) { c->b0[i].re = u[2 * i] / 128.0f; c->b0[i].im = u[2 * i + 1] / 128.0f; }
+		in = c->b0;
+	} else if (c->fmt == 3) { /* CS16, Utilities/Convert.cpp:277-286 */
+		const int16_t* u = (const int16_t*)data;
+		for (int i = 0; i < n; i++) { c->b0[i].re = u[2 * i] / 32768.0f; c->b0[i].im = u[2 * i + 1] / 32768.0f; }
 		in = c->b0;
 	} else in = (const cf*)data;
 	int m = n;

@@ -95,12 +95,12 @@ struct Harness {
 
 extern "C" {
 
-// kind: 1 = ModelBase, 2 = ModelDefault, 4 = ModelChallenger.  fmt: 0 = CU8, 1 = CF32.
+// kind: 1 = ModelBase, 2 = ModelDefault, 4 = ModelChallenger.  fmt: 0 = CU8, 1 = CF32, 2 = CS8, 3 = CS16.
 // flags: bit 0 record float taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`
 void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 	const int taps = flags & 1;
 	try {
-		Format f = fmt == 0 ? Format::CU8 : Format::CF32;
+		Format f = fmt == 0 ? Format::CU8 : fmt == 2 ? Format::CS8 : fmt == 3 ? Format::CS16 : Format::CF32;
 		Harness* h = new Harness(f, sample_rate);
 		if (kind == 4) { h->mc = new AIS::ModelChallenger(); h->model = h->mc; }
 		else if (kind == 1) { h->mb = new AIS::ModelBase(); h->model = h->mb; }

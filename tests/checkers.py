@@ -53,7 +53,7 @@ class _Chain:
         self._f = f
         self.fmt = fmt
         flags = (1 if taps else 0) | (2 if dsk else 0) | (0 if ps_ema else 4)
-        self.h = f("create")(model, rate, 0 if fmt == "cu8" else 1, flags)
+        self.h = f("create")(model, rate, {"cu8": 0, "cf32": 1, "cs8": 2, "cs16": 3}[fmt], flags)
         if not self.h:
             raise RuntimeError("checker create failed")
 
@@ -63,7 +63,7 @@ class _Chain:
 
     def feed_blocks(self, x, block_len):
         """Feed whole blocks of block_len IQ samples (the tail that does not fill a block is dropped)."""
-        per = 2 if self.fmt == "cu8" else 1
+        per = 1 if self.fmt == "cf32" else 2
         n = (len(x) // per) // block_len
         for b in range(n):
             self.feed(x[b * block_len * per:(b + 1) * block_len * per])

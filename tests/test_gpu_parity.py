@@ -19,6 +19,9 @@ except Exception:  # pragma: no cover
     torch = None
 
 
+_FMT = {"cu8": gpu.FMT_CU8, "cf32": gpu.FMT_CF32, "cs8": gpu.FMT_CS8, "cs16": gpu.FMT_CS16}
+
+
 def _feq(a, b):
     a = np.ascontiguousarray(a)
     b = np.ascontiguousarray(b)
@@ -30,8 +33,8 @@ def _run_gpu_vs_oracle(streams, rate, fmt, block, nblocks, **kw):
     R = len(streams)
     okw = dict(dsk=kw.get("dsk", False), ps_ema=kw.get("ps_ema", True))
     g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block,
-                   input_format=gpu.FMT_CU8 if fmt == "cu8" else gpu.FMT_CF32, taps=True, **kw)
-    per = 2 if fmt == "cu8" else 1
+                   input_format=_FMT[fmt], taps=True, **kw)
+    per = 1 if fmt == "cf32" else 2
     oracles = [checkers.Oracle(model=2, rate=rate, fmt=fmt, taps=True, **okw) for _ in range(R)]
     for o, x in zip(oracles, streams):
         o.feed_blocks(x, block)
@@ -95,6 +98,20 @@ def test_golden_cu8(golden):
 def test_cf32_reference_block_two_receivers():
     xs = [synth.receiver_stream(786432 * 3, receiver_id=r, type5_every=5) for r in (0, 1)]
     _run_gpu_vs_oracle(xs, 1536000, "cf32", 786432, 3)
+
+
+@pytest.mark.parametrize("fmt,rate,block", [("cs8", 1536000, 131072), ("cs16", 1536000, 131072), ("cs16", 768000, 65536),
+                                            ("cs8", 192000, 16384), ("cs16", 3072000, 262144), ("cs8", 6000000, 786432),
+                                            ("cs16", 288000, 49152)])
+def test_signed_integer_formats(fmt, rate, block):
+    """CS8 / CS16 input (Util::ConvertRAW, Utilities/StreamHelpers.cpp:91-106 + Convert.cpp:266-286) converted inside the
+    front end: direct ladders, a pre-decimated one, the resampled one and a decimate-by-3 one."""
+    x = synth.receiver_stream(block * 3, sample_rate=rate, receiver_id=61, gap_slots=(0, 2))
+    data = synth.to_cs8(x) if fmt == "cs8" else synth.to_cs16(x)
+    if rate == 6000000:
+        _run_multi_sub(data, rate, block, 3, fmt=fmt)
+    else:
+        _run_gpu_vs_oracle([data], rate, fmt, block, 3)
 
 
 def test_cu8_equals_cf32_path():
@@ -277,8 +294,8 @@ def _run_multi_sub(x, rate, block, nblocks, fmt="cf32"):
     """Rates whose ladder contains the resampler or a pre-decimation pass: compare every completed downstream
     block (there can be 1 or 2 per input block) with the oracle's stream."""
     g = gpu.AisGpu(sample_rate=rate, n_receivers=1, block_len=block,
-                   input_format=gpu.FMT_CU8 if fmt == "cu8" else gpu.FMT_CF32, taps=True)
-    per = 2 if fmt == "cu8" else 1
+                   input_format=_FMT[fmt], taps=True)
+    per = 1 if fmt == "cf32" else 2
     o = checkers.Oracle(model=2, rate=rate, fmt=fmt, taps=True)
     o.feed_blocks(x, block)
     otap = [o.tap(w) for w in range(6)]
@@ -472,11 +489,11 @@ def test_gpu_frame_decoder_nmea(block, nblocks, fmt):
     from ais_catcher_amd import host
     x = synth.receiver_stream(block * nblocks, receiver_id=71, type5_every=3, gap_slots=(0, 1))
     data = synth.to_cu8(x) if fmt == "cu8" else x
-    per = 2 if fmt == "cu8" else 1
+    per = 1 if fmt == "cf32" else 2
     chk = checkers.Ref(fmt=fmt) if checkers.have_ref() else checkers.Oracle(fmt=fmt)
     chk.feed_blocks(data, block)
     host.reset_sequence()
-    m = host.ModelDefaultGPU(block_len=block, input_format=gpu.FMT_CU8 if fmt == "cu8" else gpu.FMT_CF32, gpu_decode=True)
+    m = host.ModelDefaultGPU(block_len=block, input_format=_FMT[fmt], gpu_decode=True)
     for b in range(nblocks):
         m.receive(data[b * block * per:(b + 1) * block * per])
     assert len(chk.nmea()) >= 8
@@ -523,8 +540,8 @@ def _run_outputs_vs_oracle(streams, rate, fmt, block, nblocks, **kw):
     R = len(streams)
     okw = dict(dsk=kw.get("dsk", False), ps_ema=kw.get("ps_ema", True))
     g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block,
-                   input_format=gpu.FMT_CU8 if fmt == "cu8" else gpu.FMT_CF32, taps=False, **kw)
-    per = 2 if fmt == "cu8" else 1
+                   input_format=_FMT[fmt], taps=False, **kw)
+    per = 1 if fmt == "cf32" else 2
     oracles = [checkers.Oracle(model=2, rate=rate, fmt=fmt, taps=True, **okw) for _ in range(R)]
     for o, x in zip(oracles, streams):
         o.feed_blocks(x, block)

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.skipif(not checkers.have_ref("strict"), reason="oracle/
 
 def _compare(model, rate, fmt, block, nblocks, rid, fm=False, dsk=False, ps_ema=True, **kw):
     x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=rid, **kw)
-    data = synth.to_cu8(x) if fmt == "cu8" else x
+    data = {"cu8": synth.to_cu8, "cs8": synth.to_cs8, "cs16": synth.to_cs16, "cf32": lambda v: v}[fmt](x)
     o = checkers.Oracle(model=model, rate=rate, fmt=fmt, taps=True, dsk=dsk, ps_ema=ps_ema)
     r = checkers.Ref(model=model, rate=rate, fmt=fmt, taps=True, dsk=dsk, ps_ema=ps_ema)
     o.feed_blocks(data, block)
@@ -43,6 +43,12 @@ def test_default_cf32_reference_block():
 
 def test_default_cu8_rtl_block():
     assert len(_compare(2, 1536000, "cu8", 131072, 8, rid=1)) >= 3
+
+
+@pytest.mark.parametrize("fmt", ["cs8", "cs16"])
+def test_default_signed_integer_formats(fmt):
+    """Util::ConvertRAW's CS8 / CS16 branches (Utilities/StreamHelpers.cpp:91-106, Convert.cpp:266-286)"""
+    assert len(_compare(2, 1536000, fmt, 131072, 8, rid=12)) >= 3
 
 
 def test_default_small_blocks():
