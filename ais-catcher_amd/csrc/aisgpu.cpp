@@ -623,7 +623,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			mode = MODE_RESAMPLE; K = 0; KP = k - 2;
 		}
 	}
-	if (cfg->model != AISGPU_MODEL_DEFAULT && cfg->model != AISGPU_MODEL_CHALLENGER && cfg->model != AISGPU_MODEL_BASE) return AISGPU_ERR_ARG;
+	if (cfg->model != AISGPU_MODEL_DEFAULT && cfg->model != AISGPU_MODEL_CHALLENGER && cfg->model != AISGPU_MODEL_BASE &&
+	    cfg->model != AISGPU_MODEL_STANDARD) return AISGPU_ERR_ARG;
 	if (cfg->input_format != AISGPU_FMT_CU8 && cfg->input_format != AISGPU_FMT_CF32 && cfg->input_format != AISGPU_FMT_CS8 &&
 	    cfg->input_format != AISGPU_FMT_CS16) return AISGPU_ERR_ARG;
 	if (cfg->n_receivers < 1 || cfg->n_receivers > 65535) return AISGPU_ERR_ARG;
@@ -640,7 +641,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->cfg = *cfg;
 	h->mode = mode; h->K = K; h->KP = KP;
 	h->challenger = cfg->model == AISGPU_MODEL_CHALLENGER;
-	h->base = cfg->model == AISGPU_MODEL_BASE;
+	h->base = cfg->model == AISGPU_MODEL_BASE || cfg->model == AISGPU_MODEL_STANDARD; // both: FM receiver on the 48 kHz channels
 	// front-end geometry (tuning knobs; the defaults are the measured best): workgroup size, output samples per
 	// tile, prefetch depth.  Compiled combinations: "256,256,2", "64,64,1", "64,64,2".
 	h->k1_threads = 64; h->tile96 = 64; h->depth = 0; // autonomous waves, register/DPP ladder (profiles/r01_k1_geometry_sweep.txt)
@@ -710,12 +711,23 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			const int words = (n_cu + 31) / 32;
 			std::vector<uint32_t> lat(words, 0u), rest(words, 0u);
 			for (int i = 0; i < n_cu; i++) (i < reserve ? lat : rest)[i / 32] |= 1u << (i % 32);
+			// optional spatial split of the rest (AISGPU_FRONT_CUS=N): the front stream on N CUs of its own, the back-end streams on
+			// the others (mask bit i is CU i / 8 of XCD i % 8, so every slice is spread evenly over the XCDs)
+			std::vector<uint32_t> front = rest, back = rest;
+			if (const char* fc = getenv("AISGPU_FRONT_CUS")) {
+				const int nf = atoi(fc);
+				if (nf > 0 && reserve + nf < n_cu) {
+					front.assign(words, 0u); back.assign(words, 0u);
+					for (int i = reserve; i < n_cu; i++) (i < reserve + nf ? front : back)[i / 32] |= 1u << (i % 32);
+					if (getenv("AISGPU_BACK_ALL")) back = rest; // the back end may also use the front end's CUs
+				}
+			}
 			// (a runtime without CU masks falls back to ordinary streams: same results, the recurrence just shares its SIMDs)
-			bool masked = hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)words, rest.data()) == hipSuccess;
-			masked = masked && hipExtStreamCreateWithCUMask(&h->s1, (uint32_t)words, rest.data()) == hipSuccess;
+			bool masked = hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)words, front.data()) == hipSuccess;
+			masked = masked && hipExtStreamCreateWithCUMask(&h->s1, (uint32_t)words, back.data()) == hipSuccess;
 			masked = masked && hipExtStreamCreateWithCUMask(&h->s3, (uint32_t)words, lat.data()) == hipSuccess;
-			masked = masked && hipExtStreamCreateWithCUMask(&h->s4, (uint32_t)words, rest.data()) == hipSuccess;
-			if (masked && (cfg->flags & AISGPU_FLAG_GPU_DECODE)) masked = hipExtStreamCreateWithCUMask(&h->s5, (uint32_t)words, rest.data()) == hipSuccess;
+			masked = masked && hipExtStreamCreateWithCUMask(&h->s4, (uint32_t)words, back.data()) == hipSuccess;
+			if (masked && (cfg->flags & AISGPU_FLAG_GPU_DECODE)) masked = hipExtStreamCreateWithCUMask(&h->s5, (uint32_t)words, back.data()) == hipSuccess;
 			if (!masked) {
 				(void)hipGetLastError();
 				hipStream_t* all[5] = { &h->stream, &h->s1, &h->s3, &h->s4, &h->s5 };

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("AISGPU_LIB") or os.path.join(_HERE, "libaisgpu.so")  
 
 FMT_CU8, FMT_CF32, FMT_CS8, FMT_CS16 = 0, 1, 2, 3
 _ELEMS = {FMT_CU8: 2, FMT_CS8: 2, FMT_CS16: 2, FMT_CF32: 1}  # numpy elements per IQ sample (uint8 / int8 / int16 pairs, complex64)
+MODEL_STANDARD = 0
 MODEL_BASE = 1
 MODEL_DEFAULT = 2
 MODEL_CHALLENGER = 4

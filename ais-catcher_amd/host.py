@@ -130,6 +130,14 @@ class ModelChallengerGPU(ModelDefaultGPU):
         super().__init__(**kw)
 
 
+class ModelStandardGPU(ModelDefaultGPU):
+    """AIS::ModelStandard (-m 0): GPU front end + FM discriminator + filter; Deinterleave(5) and five decoders on the host."""
+
+    def __init__(self, **kw):
+        kw["model"] = _gpu.MODEL_STANDARD
+        super().__init__(**kw)
+
+
 class ModelBaseGPU(ModelDefaultGPU):
     """AIS::ModelBase (-m 1): GPU front end + FM discriminator + filter; SimplePLL and its decoder feedback on the host."""
 

@@ -129,7 +129,7 @@ void ModelDefaultGPU::buildModel(char CH1, char CH2, int sample_rate, bool /*tim
 		c.input_format = format == Format::CU8 ? AISGPU_FMT_CU8 : format == Format::CS8 ? AISGPU_FMT_CS8 : format == Format::CS16 ? AISGPU_FMT_CS16 : AISGPU_FMT_CF32;
 		c.afc_wide = CGF_wide;
 		c.droop = droop_compensation;
-		c.model = base ? AISGPU_MODEL_BASE : challenger ? AISGPU_MODEL_CHALLENGER : AISGPU_MODEL_DEFAULT;
+		c.model = standard ? AISGPU_MODEL_STANDARD : base ? AISGPU_MODEL_BASE : challenger ? AISGPU_MODEL_CHALLENGER : AISGPU_MODEL_DEFAULT;
 		if (gpu_decode) c.flags |= AISGPU_FLAG_GPU_DECODE;
 		batch = new GpuBatch(c); // throws std::runtime_error on unsupported rate / missing GPU
 		own_batch = true;
@@ -151,6 +151,23 @@ void ModelDefaultGPU::wireDecoders(char CH1, char CH2) {
 		DEC_base_b.out.Connect(&fan);
 		DEC_base_a.DecoderMessage.Connect(sampler_a);
 		DEC_base_b.DecoderMessage.Connect(sampler_b);
+		return;
+	}
+	if (standard) { // Model.cpp:484-518
+		S_a.setConnections(N_SAMPLES_PER_SYMBOL);
+		S_b.setConnections(N_SAMPLES_PER_SYMBOL);
+		chain.outFMa >> S_a;
+		chain.outFMb >> S_b;
+		for (int i = 0; i < N_SAMPLES_PER_SYMBOL; i++) {
+			DEC_a[i].setOrigin(CH1, station, own_mmsi);
+			DEC_b[i].setOrigin(CH2, station, own_mmsi);
+			S_a.out[i] >> DEC_a[i];
+			S_b.out[i] >> DEC_b[i];
+			DEC_a[i].out.Connect(&fan);
+			DEC_b[i].out.Connect(&fan);
+			for (int j = 0; j < N_SAMPLES_PER_SYMBOL; j++)
+				if (i != j) { DEC_a[i].DecoderMessage.Connect(DEC_a[j]); DEC_b[i].DecoderMessage.Connect(DEC_b[j]); }
+		}
 		return;
 	}
 	chain.setFrameHandler([this](const aisgpu_frame& f, TAG& tag) {

@@ -32,6 +32,24 @@ constexpr int N_SAMPLES_PER_SYMBOL = 5; // reference DSP/Model.h:37
 
 // DSP::SimplePLL of the reference (DSP/DSP.h:35-50, DSP/DSP.cpp:28-57): the symbol sampler of ModelBase.  Sequential, one
 // float of state, and switched between a fast and a slow loop by the decoder behind it -- host logic by nature.
+// DSP::Deinterleave (DSP/DSP.h:51-74): round-robin over n outputs, one sample per Send, stamps tag.sample_idx
+template <typename T>
+class Deinterleave : public StreamIn<T> {
+	int lastSymbol = 0;
+	long long sample_idx = 0;
+
+public:
+	std::vector<Connection<T>> out;
+	void setConnections(int n) { out.resize(n); }
+	void Receive(const T* data, int len, TAG& tag) override {
+		for (int i = 0; i < len; i++) {
+			tag.sample_idx = sample_idx++;
+			out[lastSymbol].Send(&data[i], 1, tag);
+			lastSymbol = (lastSymbol + 1) % (int)out.size();
+		}
+	}
+};
+
 class SimplePLL : public SimpleStreamInOut<FLOAT32, FLOAT32>, public SignalIn<DecoderSignals> {
 	bool prev = false;
 	float PLL = 0.0f;
@@ -123,6 +141,8 @@ class ModelDefaultGPU {
 	AIS::Decoder DEC_af[N_SAMPLES_PER_SYMBOL], DEC_bf[N_SAMPLES_PER_SYMBOL]; // ModelChallenger only
 	bool challenger = false;
 	bool gpu_decode = false; // AIS::Decoder state machines on the device (ModelDefault only)
+	bool standard = false; // AIS::ModelStandard wiring: outFM -> Deinterleave(5) -> DEC_a/b[5] with their Reset mesh
+	Deinterleave<FLOAT32> S_a, S_b;
 	bool base = false; // AIS::ModelBase wiring: outFM -> SimplePLL -> one decoder per channel, decoder -> sampler feedback
 	SimplePLL sampler_a, sampler_b;
 	AIS::Decoder DEC_base_a, DEC_base_b;
@@ -149,6 +169,7 @@ public:
 	void setDroop(bool b) { droop_compensation = b; }
 	void setChallenger(bool b) { challenger = b; } // AIS::ModelChallenger wiring (Model.cpp:601-678) instead of ModelDefault
 	void setBase(bool b) { base = b; }             // AIS::ModelBase wiring (Model.cpp:419-438)
+	void setStandard(bool b) { standard = b; }     // AIS::ModelStandard wiring (Model.cpp:484-518)
 	void setGpuDecode(bool b) { gpu_decode = b; }  // frames from aisgpu_frames() instead of replaying decisions
 	// same signature as AIS::Model::buildModel (the Device* of the reference is only used for wiring there)
 	void buildModel(char CH1, char CH2, int sample_rate, bool timerOn, void* device);
@@ -160,7 +181,7 @@ public:
 	void Receive(const RAW* raw, TAG& tag);
 	// CPU-only replay entry (host-logic tests): decisions produced elsewhere
 	void replay(int ch, const aisgpu_out& o, TAG& tag) {
-		if (base) GpuChain::replayBase(ch == 0 ? chain.outFMa : chain.outFMb, o, tag);
+		if (base || standard) GpuChain::replayBase(ch == 0 ? chain.outFMa : chain.outFMb, o, tag);
 		else if (challenger) GpuChain::replayChallenger(ch == 0 ? chain.outA : chain.outB, ch == 0 ? chain.outAf : chain.outBf, o, tag);
 		else GpuChain::replay(ch == 0 ? chain.outA : chain.outB, o, tag);
 	}
@@ -170,6 +191,12 @@ public:
 class ModelChallengerGPU : public ModelDefaultGPU {
 public:
 	ModelChallengerGPU() { setChallenger(true); }
+};
+
+// AIS::ModelStandard wiring ("-m 0")
+class ModelStandardGPU : public ModelDefaultGPU {
+public:
+	ModelStandardGPU() { setStandard(true); }
 };
 
 // AIS::ModelBase wiring ("-m 1")

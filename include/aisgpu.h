@@ -50,6 +50,8 @@ extern "C" {
 #define AISGPU_FMT_CS16 3  /* Utilities/Convert.cpp:277-286: (int16) / 32768.0f */
 
 /* models (DSP/Model.h:61-72) */
+#define AISGPU_MODEL_STANDARD 0    /* AIS::ModelStandard   (-m 0), DSP/Model.cpp:484-518: FM receiver with five decoders on the deinterleaved
+                                    * discriminator; the device path and the outputs are those of AISGPU_MODEL_BASE */
 #define AISGPU_MODEL_BASE 1        /* AIS::ModelBase       (-m 1), DSP/Model.cpp:419-438: FM receiver; the GPU delivers the sign of the
                                     * filtered discriminator per 48 kHz sample, SimplePLL + decoder (feedback loop) run on the host */
 #define AISGPU_MODEL_DEFAULT 2     /* AIS::ModelDefault    (-m 2), DSP/Model.cpp:520-577 */

@@ -597,6 +597,11 @@ static void channel_receive(ao_chain* c, chan_t* ch, const cf* x96, int n96) {
 		free(t);
 		return;
 	}
+	if (c->model == 0) { /* ModelStandard (Model.cpp:484-518): FM -> Filter(Receiver) -> Deinterleave(5) -> five decoders */
+		for (int i = 0; i < n; i++) fm_branch(c, ch, y[i]);
+		free(t);
+		return;
+	}
 	/* SquareFreqOffsetCorrection::Receive, DSP.cpp:475-489 */
 	for (int i = 0; i < n; i++) {
 		cgf_t* g = &ch->cgf;
@@ -772,7 +777,7 @@ ao_chain* ao_create(int model, int sample_rate, int fmt, int flags) {
 				}
 				if (i != j) {
 					ch->dec[j].sib[ch->dec[j].nsib++] = &ch->dec[i];
-					if (model == 4) ch->decf[j].sib[ch->decf[j].nsib++] = &ch->decf[i];
+					if (model == 4 || model == 0) ch->decf[j].sib[ch->decf[j].nsib++] = &ch->decf[i]; /* Standard: Model.cpp:505-514 */
 				}
 			}
 		}

@@ -78,6 +78,7 @@ struct Harness {
 	AIS::ModelDefault* md = nullptr;
 	AIS::ModelChallenger* mc = nullptr;
 	AIS::ModelBase* mb = nullptr;
+	AIS::ModelStandard* ms = nullptr;
 	AIS::Model* model = nullptr;
 	TAG tag;
 	Format fmt;
@@ -95,7 +96,7 @@ struct Harness {
 
 extern "C" {
 
-// kind: 1 = ModelBase, 2 = ModelDefault, 4 = ModelChallenger.  fmt: 0 = CU8, 1 = CF32, 2 = CS8, 3 = CS16.
+// kind: 0 = ModelStandard, 1 = ModelBase, 2 = ModelDefault, 4 = ModelChallenger.  fmt: 0 = CU8, 1 = CF32, 2 = CS8, 3 = CS16.
 // flags: bit 0 record float taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`
 void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 	const int taps = flags & 1;
@@ -104,6 +105,7 @@ void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 		Harness* h = new Harness(f, sample_rate);
 		if (kind == 4) { h->mc = new AIS::ModelChallenger(); h->model = h->mc; }
 		else if (kind == 1) { h->mb = new AIS::ModelBase(); h->model = h->mb; }
+		else if (kind == 0) { h->ms = new AIS::ModelStandard(); h->model = h->ms; }
 		else { h->md = new AIS::ModelDefault(); h->model = h->md; }
 		if (flags & 2) h->model->SetKey(AIS::KEY_SETTING_DSK, "ON");
 		if (flags & 4) h->model->SetKey(AIS::KEY_SETTING_PS_EMA, "OFF");
@@ -119,6 +121,12 @@ void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 				h->bits[0][0].on = h->bits[1][0].on = h->fmbits[0][0].on = h->fmbits[1][0].on = true;
 				h->mb->sampler_a.out >> h->bits[0][0]; h->mb->sampler_b.out >> h->bits[1][0];
 				h->mb->FR_a.out >> h->fmbits[0][0];    h->mb->FR_b.out >> h->fmbits[1][0];
+			} else if (h->ms) { // what each of the five decoders of a channel gets (Deinterleave outputs)
+				for (int j = 0; j < 5; j++) {
+					h->fmbits[0][j].on = h->fmbits[1][j].on = true;
+					h->ms->S_a.out[j] >> h->fmbits[0][j];
+					h->ms->S_b.out[j] >> h->fmbits[1][j];
+				}
 			} else if (h->md) {
 				h->md->CGF_a.out >> h->tap[2]; h->md->CGF_b.out >> h->tap[3];
 				h->md->FC_a.out >> h->tap[4];  h->md->FC_b.out >> h->tap[5];
@@ -215,7 +223,7 @@ void ref_reset_seq(void) { AIS::Message::ID.store(0); }
 
 void ref_destroy(void* hv) {
 	Harness* h = (Harness*)hv;
-	delete h->md; delete h->mc; delete h->mb;
+	delete h->md; delete h->mc; delete h->mb; delete h->ms;
 	delete h;
 }
 

@@ -481,6 +481,26 @@ def test_model_base_nmea_end_to_end():
     assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
 
 
+@pytest.mark.parametrize("rate,fmt,block", [(1536000, "cf32", 131072), (1536000, "cu8", 131072), (768000, "cf32", 65536)])
+def test_model_standard_nmea_end_to_end(rate, fmt, block):
+    """AIS::ModelStandard (-m 0): the device path of ModelBase (front end + FM discriminator + 37-tap filter), then on the host
+    Deinterleave(5) and five decoders with their Reset mesh; NMEA text, levels and ppm against the checker."""
+    from ais_catcher_amd import host
+    nblocks = 10
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=31, gap_slots=(1, 2), type5_every=4)
+    data = synth.to_cu8(x) if fmt == "cu8" else x
+    per = 1 if fmt == "cf32" else 2
+    chk = checkers.Ref(model=0, rate=rate, fmt=fmt) if checkers.have_ref() else checkers.Oracle(model=0, rate=rate, fmt=fmt)
+    chk.feed_blocks(data, block)
+    host.reset_sequence()
+    m = host.ModelStandardGPU(sample_rate=rate, block_len=block, input_format=_FMT[fmt])
+    for b in range(nblocks):
+        m.receive(data[b * block * per:(b + 1) * block * per])
+    assert m.nmea() == chk.nmea() and len(chk.nmea()) >= 3
+    a, c = m.msg_meta(), chk.msg_meta()
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+
+
 @pytest.mark.parametrize("block,nblocks,fmt", [(786432, 4, "cf32"), (16384, 96, "cf32"), (131072, 16, "cu8")])
 def test_gpu_frame_decoder_nmea(block, nblocks, fmt):
     """AISGPU_FLAG_GPU_DECODE: the ten AIS::Decoder state machines (NRZI, flags, de-stuffing, CRC, early aborts, Reset mesh)

@@ -127,3 +127,25 @@ def _compare_base(rate, fmt, block, nblocks, rid, **kw):
 def test_model_base_fm_receiver():
     assert len(_compare_base(1536000, "cf32", 131072, 12, rid=51, type5_every=4)) >= 3
     _compare_base(1536000, "cu8", 16384, 40, rid=52)
+
+
+@pytest.mark.parametrize("rate,fmt,block", [(1536000, "cf32", 131072), (1536000, "cu8", 131072), (768000, "cf32", 65536)])
+def test_model_standard(rate, fmt, block):
+    """ModelStandard (-m 0, Model.cpp:484-518): FM discriminator -> 37-tap filter -> Deinterleave(5) -> five decoders with
+    their Reset mesh; what every decoder receives and the NMEA text."""
+    x = synth.receiver_stream(block * 10, sample_rate=rate, receiver_id=31, gap_slots=(1, 2), type5_every=4)
+    data = synth.to_cu8(x) if fmt == "cu8" else x
+    o = checkers.Oracle(model=0, rate=rate, fmt=fmt, taps=True)
+    r = checkers.Ref(model=0, rate=rate, fmt=fmt, taps=True)
+    o.feed_blocks(data, block)
+    r.feed_blocks(data, block)
+    for w in (0, 1):
+        assert np.array_equal(o.tap(w).view(np.float32), r.tap(w).view(np.float32))
+    for ch in range(2):
+        for j in range(5):
+            ob, rb = o.bits(ch, j, 1), r.bits(ch, j, 1)
+            assert len(ob[0]) == len(rb[0]) > 0
+            assert np.array_equal(ob[0], rb[0]) and np.array_equal(ob[2], rb[2])
+    assert o.nmea() == r.nmea() and len(r.nmea()) >= 3
+    ol, rl = o.msg_meta(), r.msg_meta()
+    assert np.array_equal(ol[0], rl[0]) and np.array_equal(ol[1], rl[1])
