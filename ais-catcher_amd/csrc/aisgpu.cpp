@@ -655,7 +655,11 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->in_bytes = cfg->input_format == AISGPU_FMT_CF32 ? 8 : cfg->input_format == AISGPU_FMT_CS16 ? 4 : 2;
 	// kernel numbering of the formats: 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16
 	h->kfmt = cfg->input_format == AISGPU_FMT_CF32 ? 0 : cfg->input_format == AISGPU_FMT_CU8 ? 1 : cfg->input_format == AISGPU_FMT_CS8 ? 2 : 3;
-	if (h->kfmt > 1 && h->depth != 0) { delete h; return AISGPU_ERR_ARG; } // CS8 / CS16: register (DPP) front end only
+	if ((cfg->flags & AISGPU_FLAG_FP_DS) && cfg->sample_rate == 1536000) { // Model.cpp:224-237: only this ladder has a fixed-point twin,
+		if (h->kfmt != 1) { delete h; return AISGPU_ERR_ARG; }              // and only ConvertRAW::outCU8 feeds it
+		h->kfmt = 4;
+	}
+	if (h->kfmt > 1 && h->depth != 0) { delete h; return AISGPU_ERR_ARG; } // CS8 / CS16 / fixed point: register (DPP) front end only
 	h->n_pre = cfg->block_len >> KP;
 	if (mode == MODE_RESAMPLE) h->n96 = h->n_pre / 4; // one flush of n_pre samples at the bucket rate >> KP (= 384 kHz)
 	else if (mode == MODE_DSK) h->n96 = h->n_pre / 3;
@@ -796,7 +800,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		for (int i = 0; i < 2; i++) {
 			HIPCHK(dalloc((unsigned char**)&h->d_hist[i], R * first_tile * h->in_bytes));
 			// zero signal before the stream starts: CU8 zero is the byte 128 (Utilities/Convert.cpp:255-264)
-			if (cfg->input_format == AISGPU_FMT_CU8) HIPCHK(hipMemset(h->d_hist[i], 0x80, R * first_tile * h->in_bytes));
+			// (the fixed-point ladder starts from h0..h4 = 0, DSP.h:397: bytes of zero)
+			if (cfg->input_format == AISGPU_FMT_CU8 && h->kfmt != 4) HIPCHK(hipMemset(h->d_hist[i], 0x80, R * first_tile * h->in_bytes));
 		}
 	}
 	if (KP > 0 || mode == MODE_DSK) {
@@ -1075,7 +1080,7 @@ int aisgpu_run(aisgpu_t* h) {
 		k1.rot = h->d_rot[pb];
 		k1.c48 = h->d_c48[q]; k1.c48_stride = h->c48s;
 		k1.tiles_per_block = h->tiles_per_block; k1.tiles_per_span = h->tiles_per_span;
-		k1.alpha = h->alpha; k1.beta = h->beta; k1.has_fdc = h->has_fdc;
+		k1.alpha = h->alpha; k1.beta = h->beta; k1.has_fdc = h->has_fdc; k1.stream_start = h->in_blocks == 0;
 		k1.pre_out = nullptr; k1.pre_stride = 0;
 		if (!from_pre) { int rc = time_begin(); if (rc) return rc; }
 		{ TraceScope t(h, "front", h->stream); HIPCHK(launch_k1(k1, h->K, from_pre ? 0 : h->kfmt, h->tile96, h->depth, h->k1_threads, h->spans, R, h->stream)); }

@@ -20,6 +20,7 @@ struct K1Params {
 	int tiles_per_block, tiles_per_span;
 	float alpha, beta;       // FilterComplex3Tap
 	int has_fdc;
+	int stream_start;        // != 0: first block of the stream (only the fixed-point ladder needs to know)
 	float2* pre_out;         // != nullptr: pre-decimation pass, write the level after K stages here ([n_rx][pre_stride])
 	long long pre_stride;
 };
@@ -133,7 +134,7 @@ struct K7Params {
 };
 hipError_t launch_k7(const K7Params& p, hipStream_t s);
 
-// fmt (kernel numbering): 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16
+// fmt (kernel numbering): 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16, 4 = CU8 through the fixed-point ladder (K = 4)
 hipError_t launch_k1(const K1Params& p, int K, int fmt, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s);
 hipError_t launch_k1u(const K1uParams& p, int n_rx, hipStream_t s);
 hipError_t launch_copy_rows(const float2* src, long long src_stride, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);

@@ -425,28 +425,42 @@ __device__ __forceinline__ c2 carry_to_next_tile(c2 halo, c2 cur) {
 	p.y = dpp_carry_lane63(halo.y, cur.y);
 	return p;
 }
+// the same two moves for a sample packed into one register (fixed-point ladder: I in bits 0..15, Q in bits 16..31)
+__device__ __forceinline__ unsigned from_prev_lane(unsigned cur, unsigned prev) {
+	return (unsigned)__builtin_amdgcn_update_dpp((int)prev, (int)cur, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ unsigned carry_to_next_tile(unsigned halo, unsigned cur) {
+	return (unsigned)__builtin_amdgcn_update_dpp((int)halo, (int)cur, 0x13C, 0x1, 0x1, false);
+}
 
 // cic5_dec_chunk on native vectors (same pairing, same rounding)
-template <int NOUT>
-__device__ __forceinline__ void cic5_dec_chunk_v(c2 (&v)[2 * NOUT + 4], c2 (&out)[NOUT]) {
+// T = c2: float stage (DSP.cpp:93-117).  T = unsigned: one stage of the fixed-point ladder DS_UINT16::Run (DSP.cpp:499-522):
+// I and Q are 16-bit fields of one word, the five cascaded sums are plain 32-bit additions (no field ever overflows: 8-bit
+// input, gain 32 per stage, SHIFT bits dropped per stage), the stage output is (z >> SHIFT) & mask.  Integer sums do not
+// care about the order, so the same pairing as the float stage is used.
+template <int NOUT, typename T, int SHIFT>
+__device__ __forceinline__ void cic5_dec_chunk_v(T (&v)[2 * NOUT + 4], T (&out)[NOUT]) {
 #pragma unroll
 	for (int lvl = 0; lvl < 4; lvl++) {
 #pragma unroll
 		for (int i = 0; i < 2 * NOUT + 3 - lvl; i++) v[i] = v[i + 1] + v[i];
 	}
 #pragma unroll
-	for (int q = 0; q < NOUT; q++) out[q] = (v[2 * q + 1] + v[2 * q]) * 0.03125f;
+	for (int q = 0; q < NOUT; q++) {
+		if constexpr (sizeof(T) == sizeof(c2)) out[q] = (v[2 * q + 1] + v[2 * q]) * 0.03125f;
+		else out[q] = ((v[2 * q + 1] + v[2 * q]) >> SHIFT) & ((0xFFFFu >> SHIFT) * 0x10001u);
+	}
 }
 
-template <int C> struct HaloState;           // shadow registers of one stage (all zero = silence before the stream)
-template <> struct HaloState<16> { c2 p[5]; };
-template <> struct HaloState<8> { c2 p[5]; };
-template <> struct HaloState<4> { c2 p[4], q; };
-template <> struct HaloState<2> { c2 p1[2], p2[2], p3; };
+template <int C, typename T> struct HaloState;           // shadow registers of one stage (all zero = silence before the stream)
+template <typename T> struct HaloState<16, T> { T p[5]; };
+template <typename T> struct HaloState<8, T> { T p[5]; };
+template <typename T> struct HaloState<4, T> { T p[4], q; };
+template <typename T> struct HaloState<2, T> { T p1[2], p2[2], p3; };
 
 // h[i] = sample (chunk_start - 5 + i) of the stage's input stream
-template <int C>
-__device__ __forceinline__ void get_halo(const c2 (&x)[C], const HaloState<C>& hs, c2 (&h)[5]) {
+template <int C, typename T>
+__device__ __forceinline__ void get_halo(const T (&x)[C], const HaloState<C, T>& hs, T (&h)[5]) {
 	if constexpr (C >= 5) {
 #pragma unroll
 		for (int i = 0; i < 5; i++) h[i] = from_prev_lane(x[C - 5 + i], hs.p[i]);
@@ -463,8 +477,8 @@ __device__ __forceinline__ void get_halo(const c2 (&x)[C], const HaloState<C>& h
 	}
 }
 // after the halo values have been consumed: their registers become the shadows of the next tile
-template <int C>
-__device__ __forceinline__ void put_halo(const c2 (&x)[C], HaloState<C>& hs, const c2 (&h)[5]) {
+template <int C, typename T>
+__device__ __forceinline__ void put_halo(const T (&x)[C], HaloState<C, T>& hs, const T (&h)[5]) {
 	if constexpr (C >= 5) {
 #pragma unroll
 		for (int i = 0; i < 5; i++) hs.p[i] = carry_to_next_tile(h[i], x[C - 5 + i]);
@@ -481,24 +495,37 @@ __device__ __forceinline__ void put_halo(const c2 (&x)[C], HaloState<C>& hs, con
 	}
 }
 
-template <int C>
-__device__ __forceinline__ void reg_stage(const c2 (&x)[C], HaloState<C>& hs, c2 (&out)[C / 2]) {
-	c2 h[5];
-	get_halo<C>(x, hs, h);
-	c2 v[C + 4];
+template <int SHIFT, int C, typename T>
+__device__ __forceinline__ void reg_stage(const T (&x)[C], HaloState<C, T>& hs, T (&out)[C / 2]) {
+	T h[5];
+	get_halo<C, T>(x, hs, h);
+	T v[C + 4];
 #pragma unroll
 	for (int i = 0; i < 5; i++) v[i] = h[i];
 #pragma unroll
 	for (int i = 0; i < C - 1; i++) v[5 + i] = x[i];
-	cic5_dec_chunk_v<C / 2>(v, out);
-	put_halo<C>(x, hs, h);
+	cic5_dec_chunk_v<C / 2, T, SHIFT>(v, out);
+	put_halo<C, T>(x, hs, h);
 }
+template <int C>
+__device__ __forceinline__ void reg_stage(const c2 (&x)[C], HaloState<C, c2>& hs, c2 (&out)[C / 2]) { reg_stage<0, C, c2>(x, hs, out); }
 
 template <int K> struct RegLadder;
-template <> struct RegLadder<4> { HaloState<16> s16; HaloState<8> s8; HaloState<4> s4; HaloState<2> s2; };
-template <> struct RegLadder<3> { HaloState<8> s8; HaloState<4> s4; HaloState<2> s2; };
-template <> struct RegLadder<2> { HaloState<4> s4; HaloState<2> s2; };
-template <> struct RegLadder<1> { HaloState<2> s2; };
+template <> struct RegLadder<4> { HaloState<16, c2> s16; HaloState<8, c2> s8; HaloState<4, c2> s4; HaloState<2, c2> s2; };
+template <> struct RegLadder<3> { HaloState<8, c2> s8; HaloState<4, c2> s4; HaloState<2, c2> s2; };
+template <> struct RegLadder<2> { HaloState<4, c2> s4; HaloState<2, c2> s2; };
+template <> struct RegLadder<1> { HaloState<2, c2> s2; };
+
+// Downsample16_CU8 (DSP.cpp:639-651, `-go FP_DS on` at 1536 kSPS): four DS_UINT16 stages with shifts 3, 4, 5, 0, then
+// uint16 -> int16 by flipping the sign bits and / 32768.0f (DSP.cpp:587-607)
+struct FixLadder { HaloState<16, unsigned> s16; HaloState<8, unsigned> s8; HaloState<4, unsigned> s4; HaloState<2, unsigned> s2; };
+__device__ __forceinline__ c2 run_fix_ladder(const unsigned (&x)[16], FixLadder& st) {
+	unsigned a[8], b[4], c[2], d[1];
+	reg_stage<3, 16, unsigned>(x, st.s16, a); reg_stage<4, 8, unsigned>(a, st.s8, b);
+	reg_stage<5, 4, unsigned>(b, st.s4, c); reg_stage<0, 2, unsigned>(c, st.s2, d);
+	const unsigned z = d[0] ^ 0x80008000u;
+	return c2{ (float)(int)(short)(z & 0xffffu) * 0.000030517578125f, (float)(int)(short)(z >> 16) * 0.000030517578125f };
+}
 
 template <int K>
 __device__ __forceinline__ c2 run_ladder(const c2 (&x)[1 << K], RegLadder<K>& st) {
@@ -539,7 +566,8 @@ __device__ __forceinline__ void wave_sync() {
 #ifndef K1_WAVES
 #define K1_WAVES 3
 #endif
-// FMT: input sample format (Utilities/StreamHelpers.cpp:51-133): 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16
+// FMT: input sample format (Utilities/StreamHelpers.cpp:51-133): 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16;
+// 4 = CU8 through the fixed-point ladder Downsample16_CU8 (K = 4 only)
 constexpr int fmt_bytes(int fmt) { return fmt == 0 ? 8 : fmt == 3 ? 4 : 2; }
 
 template <int K, int FMT, bool PRE>
@@ -558,6 +586,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 
 	if (lane < 8) { x5[0][lane] = x5[1][lane] = x6[0][lane] = x6[1][lane] = make_float2(0.f, 0.f); }
 	RegLadder<K> st = {};
+	FixLadder fst = {};
 	c2 fdc_p1 = { 0.f, 0.f }, fdc_p2 = { 0.f, 0.f };
 
 	const int tile_first = span * p.tiles_per_span - 1; // warm-up tile
@@ -598,7 +627,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 
 	for (int tile = tile_first; tile <= tile_last; tile++) {
 		c2 x[C0];
-		if constexpr (FMT == 1 || FMT == 2) { // Utilities/Convert.cpp:255-275: ((int)u - 128) / 128.0f, (int8) / 128.0f (exact)
+		unsigned xi[FMT == 4 ? C0 : 1];
+		if constexpr (FMT == 4) { // z = I | Q << 16 (DSP.cpp:532-533)
+			const unsigned* w = reinterpret_cast<const unsigned*>(pre);
+#pragma unroll
+			for (int i = 0; i < C0; i++) {
+				const unsigned v = w[i >> 1] >> ((i & 1) * 16);
+				xi[i] = (v & 255u) | ((v & 0xff00u) << 8);
+			}
+		} else if constexpr (FMT == 1 || FMT == 2) { // Utilities/Convert.cpp:255-275: ((int)u - 128) / 128.0f, (int8) / 128.0f (exact)
 			const unsigned* w = reinterpret_cast<const unsigned*>(pre);
 #pragma unroll
 			for (int i = 0; i < C0; i++) {
@@ -636,7 +673,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 		prefetch(tile_n);
 		if (!PRE) rot_next = p.rot[(size_t)ROT_HIST + (long long)tile_n * 64 + lane];
 
-		const c2 x96 = run_ladder<K>(x, st);
+		c2 x96;
+		if constexpr (FMT == 4) {
+			x96 = run_fix_ladder(xi, fst);
+			// before the stream starts the fixed-point stages hold zeros, which is -1.0 after the sign flip, but the float stages
+			// behind them have seen nothing at all: the warm-up tile of the very first block contributes zeros
+			if (p.stream_start && tile < 0) x96 = c2{ 0.0f, 0.0f };
+		}
+		else x96 = run_ladder<K>(x, st);
 		if constexpr (PRE) {
 			if (tile > tile_first) p.pre_out[(size_t)rx * p.pre_stride + (size_t)tile * 64 + lane] = make_float2(x96.x, x96.y);
 		} else {
@@ -2420,6 +2464,13 @@ static hipError_t launch_k1_dpp_k(const K1Params& p, int fmt, int spans, int n_r
 	case 1: return launch_k1_dpp_kf<K, 1>(p, spans, n_rx, s);
 	case 2: return launch_k1_dpp_kf<K, 2>(p, spans, n_rx, s);
 	case 3: return launch_k1_dpp_kf<K, 3>(p, spans, n_rx, s);
+	case 4:
+		if constexpr (K == 4) {
+			if (p.pre_out != nullptr) return hipErrorInvalidValue;
+			hipLaunchKernelGGL((k1_dpp<4, 4, false>), dim3(spans, n_rx), dim3(64), 0, s, p);
+			return hipGetLastError();
+		}
+		break;
 	}
 	return hipErrorInvalidValue;
 }
@@ -2438,7 +2489,7 @@ static hipError_t launch_k1_dpp(const K1Params& p, int K, int fmt, int spans, in
 // (256, or 64 = one autonomous wave per workgroup)
 hipError_t launch_k1(const K1Params& p, int K, int fmt, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s) {
 	if (depth == 0) return launch_k1_dpp(p, K, fmt, spans, n_rx, s); // register (DPP) variant: 64 threads, tile96 = 64
-	if (fmt > 1) return hipErrorInvalidValue; // the LDS-staged variants read CF32 and CU8 only
+	if (fmt > 1) return hipErrorInvalidValue; // the LDS-staged variants read CF32 and CU8 (float ladder) only
 	const bool cu8 = fmt == 1;
 	switch (threads * 10000 + tile96 * 10 + depth) {
 	case 2562562: return launch_k1_p<256, 2, 256>(p, K, cu8, spans, n_rx, s);

@@ -55,7 +55,8 @@ void* aishost_model_create(void* batch, int rx, int sample_rate, int block_len, 
 		m->m.setChallenger((model & 0xff) == AISGPU_MODEL_CHALLENGER);
 		m->m.setBase((model & 0xff) == AISGPU_MODEL_BASE);
 		m->m.setStandard((model & 0xff) == AISGPU_MODEL_STANDARD);
-		m->m.setGpuDecode((model & 0x100) != 0); // bit 8 of `model`: AISGPU_FLAG_GPU_DECODE for a stand-alone receiver
+		m->m.setGpuDecode((model & 0x100) != 0);
+		m->m.setFixedPoint((model & 0x200) != 0); // bit 9: AISGPU_FLAG_FP_DS for a stand-alone receiver // bit 8 of `model`: AISGPU_FLAG_GPU_DECODE for a stand-alone receiver
 		if (batch) m->m.useBatch((GpuBatch*)batch, rx);
 		if (!detached) m->m.buildModel(ch1, ch2, sample_rate, false, nullptr);
 		else m->m.wireDecoders(ch1, ch2); // no GPU context

@@ -131,6 +131,7 @@ void ModelDefaultGPU::buildModel(char CH1, char CH2, int sample_rate, bool /*tim
 		c.droop = droop_compensation;
 		c.model = standard ? AISGPU_MODEL_STANDARD : base ? AISGPU_MODEL_BASE : challenger ? AISGPU_MODEL_CHALLENGER : AISGPU_MODEL_DEFAULT;
 		if (gpu_decode) c.flags |= AISGPU_FLAG_GPU_DECODE;
+		if (fixedpointDS) c.flags |= AISGPU_FLAG_FP_DS;
 		batch = new GpuBatch(c); // throws std::runtime_error on unsupported rate / missing GPU
 		own_batch = true;
 		chain.attach(batch, 0);

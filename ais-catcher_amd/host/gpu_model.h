@@ -151,6 +151,7 @@ class ModelDefaultGPU {
 	int block_len = 786432;
 	Format format = Format::CF32;
 	bool CGF_wide = true, droop_compensation = true;
+	bool fixedpointDS = false; // KEY_SETTING_FP_DS (Model.cpp:362-363)
 
 	struct Fan : public StreamIn<AIS::Message> { // PassThrough<Message> of the reference (Model.h:88)
 		StreamOut<AIS::Message>* o = nullptr;
@@ -167,6 +168,7 @@ public:
 	void setOwnMMSI(int m) { own_mmsi = m; }
 	void setAFCWide(bool b) { CGF_wide = b; }
 	void setDroop(bool b) { droop_compensation = b; }
+	void setFixedPoint(bool b) { fixedpointDS = b; }
 	void setChallenger(bool b) { challenger = b; } // AIS::ModelChallenger wiring (Model.cpp:601-678) instead of ModelDefault
 	void setBase(bool b) { base = b; }             // AIS::ModelBase wiring (Model.cpp:419-438)
 	void setStandard(bool b) { standard = b; }     // AIS::ModelStandard wiring (Model.cpp:484-518)

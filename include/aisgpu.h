@@ -61,6 +61,8 @@ extern "C" {
 #define AISGPU_FLAG_SERIAL 2  /* profiling aid: one stream, no overlap between the kernels of consecutive blocks */
 #define AISGPU_FLAG_PS_BOXCAR 8 /* KEY_SETTING_PS_EMA off: Demod::PhaseSearch (boxcar history) instead of PhaseSearchEMA (Model.cpp:550-555) */
 #define AISGPU_FLAG_GPU_DECODE 16 /* run AIS::Decoder (frame decoder + Reset mesh) on the device too: aisgpu_frames() (ModelDefault only) */
+#define AISGPU_FLAG_FP_DS 32  /* KEY_SETTING_FP_DS (`-go FP_DS on`, `-F`): 1536 kSPS CU8 input goes through the fixed-point ladder
+                               * Downsample16_CU8 (DSP/DSP.cpp:499-651, Model.cpp:231-237); ignored at other rates like in the reference */
 #define AISGPU_FLAG_DSK 4     /* KEY_SETTING_DSK (`-go DSK on`): 576k / 1152k / 2304k use the decimate-by-3 ladder (Model.cpp:130) */
 
 typedef struct aisgpu aisgpu_t;

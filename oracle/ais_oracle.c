@@ -519,6 +519,7 @@ typedef struct {
 struct ao_chain {
 	int model, fmt, rate, taps;
 	int npre, npost, has_us, has_fdc, has_dsk, ps_ema;
+	int fixed; uint32_t fix_h[4][5]; /* `-go FP_DS on` at 1536 kSPS: Downsample16_CU8, h0..h4 of its four DS_UINT16 stages */
 	/* DownsampleKFilter (DSP.cpp:160-189, DSP.h:181-211): BlackmanHarris_28_3, K = 3, output blocks of 8192 */
 	cf* dsk_buf; long long dsk_cap; cf dsk_out[8192]; int dsk_in, dsk_idx_out;
 	float fdc_alpha;
@@ -696,6 +697,38 @@ static void upsample_run(ao_chain* c, const cf* x, int len) { /* DSP.cpp:192-212
 	}
 }
 
+/* One DS_UINT16 stage (DSP.cpp:499-522, macros :85-90): I in bits 0..15, Q in bits 16..31 of one word, five cascaded two-tap
+ * sums, output at the first sample of every pair, (z >> shift) & mask */
+static int ds_uint16_run(uint32_t* h, const uint32_t* in, uint32_t* out, int len, int shift) {
+	uint32_t mask = 0xFFFFu >> shift;
+	mask |= mask << 16;
+	len >>= 1;
+	for (int i = 0; i < len; i++) {
+		uint32_t r[5], z = in[2 * i];
+		for (int k = 0; k < 5; k++) { r[k] = z; z += h[k]; }   /* MA1(0..4) */
+		out[i] = (z >> shift) & mask;
+		z = in[2 * i + 1];
+		for (int k = 0; k < 5; k++) { h[k] = z; z += r[k]; }   /* MA2(0..4) */
+	}
+	return len;
+}
+/* Downsample16_CU8::Receive (DSP.cpp:639-651): shifts 3, 4, 5, then the stage that ends in int16 / 32768.0f (:587-607) */
+static int ds16_cu8(ao_chain* c, const uint8_t* u, int n, cf* out) {
+	uint32_t* buf = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n + 2));
+	for (int i = 0; i < n; i++) buf[i] = (uint32_t)u[2 * i] | ((uint32_t)u[2 * i + 1] << 16);
+	int len = ds_uint16_run(c->fix_h[0], buf, buf, n, 3);
+	len = ds_uint16_run(c->fix_h[1], buf, buf, len, 4);
+	len = ds_uint16_run(c->fix_h[2], buf, buf, len, 5);
+	len = ds_uint16_run(c->fix_h[3], buf, buf, len, 0);
+	for (int i = 0; i < len; i++) {
+		uint32_t z = buf[i] ^ 0x80008000u; /* uint to int in parallel by flipping the sign bits */
+		out[i].re = ((int16_t)(z & 0xFFFFu)) / 32768.0f;
+		out[i].im = ((int16_t)(z >> 16)) / 32768.0f;
+	}
+	free(buf);
+	return len;
+}
+
 int ao_feed(ao_chain* c, const void* data, int nbytes) {
 	int n = c->fmt == 1 ? nbytes / 8 : c->fmt == 3 ? nbytes / 4 : nbytes / 2;
 	if (n > c->bcap) {
@@ -704,6 +737,12 @@ int ao_feed(ao_chain* c, const void* data, int nbytes) {
 		c->bcap = n;
 	}
 	const cf* in;
+	if (c->fixed) { /* Model.cpp:231-237: convert.outCU8 >> DS16_CU8 >> [FDC] >> ROT; any other format produces nothing */
+		if (c->fmt != 0) return 0;
+		int m16 = ds16_cu8(c, (const uint8_t*)data, n, c->b0);
+		frontend_96k(c, c->b0, m16);
+		return 0;
+	}
 	if (c->fmt == 0) { /* Utilities/Convert.cpp:255-264 */
 		const uint8_t* u = (const uint8_t*)data;
 		for (int i = 0; i < n; i++) { c->b0[i].re = ((int)u[2 * i] - 128) / 128.0f; c->b0[i].im = ((int)u[2 * i + 1] - 128) / 128.0f; }
@@ -731,7 +770,7 @@ int ao_feed(ao_chain* c, const void* data, int nbytes) {
 }
 
 ao_chain* ao_create(int model, int sample_rate, int fmt, int flags) {
-	/* flags: bit 0 record taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off` */
+	/* flags: bit 0 record taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`, bit 3 `-go FP_DS on` */
 	static const unsigned buckets_nodsk[] = { 96000, 192000, 288000, 384000, 768000, 1536000, 3072000, 6144000, 12288000 }; /* Model.cpp:129-130 */
 	static const unsigned buckets_dsk[] = { 96000, 192000, 288000, 384000, 576000, 768000, 1152000, 1536000, 2304000, 3072000, 6144000, 12288000 };
 	const int taps = flags & 1, dsk = (flags >> 1) & 1;
@@ -751,6 +790,7 @@ ao_chain* ao_create(int model, int sample_rate, int fmt, int flags) {
 	ao_chain* c = (ao_chain*)calloc(1, sizeof(ao_chain));
 	c->model = model; c->fmt = fmt; c->rate = sample_rate; c->taps = taps;
 	c->ps_ema = !((flags >> 2) & 1);
+	c->fixed = ((flags >> 3) & 1) && sample_rate == 1536000; /* Model.cpp:224: only the 1536k case looks at fixedpointDS */
 	c->has_dsk = is3;
 	c->has_us = !is3 && bucket != (unsigned)sample_rate;
 	c->has_fdc = !is3 && k > 0; /* the decimate-by-3 ladders have no droop compensation (Model.cpp:207-219 etc.) */

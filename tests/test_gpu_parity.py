@@ -31,7 +31,7 @@ def _feq(a, b):
 def _run_gpu_vs_oracle(streams, rate, fmt, block, nblocks, **kw):
     """streams: list of per-receiver arrays.  Compares every block's taps and outputs per receiver."""
     R = len(streams)
-    okw = dict(dsk=kw.get("dsk", False), ps_ema=kw.get("ps_ema", True))
+    okw = dict(dsk=kw.get("dsk", False), ps_ema=kw.get("ps_ema", True), fp_ds=kw.get("fp_ds", False))
     g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block,
                    input_format=_FMT[fmt], taps=True, **kw)
     per = 1 if fmt == "cf32" else 2
@@ -112,6 +112,26 @@ def test_signed_integer_formats(fmt, rate, block):
         _run_multi_sub(data, rate, block, 3, fmt=fmt)
     else:
         _run_gpu_vs_oracle([data], rate, fmt, block, 3)
+
+
+def test_fixed_point_ladder_fp_ds():
+    """`-go FP_DS on` (-F): 1536 kSPS CU8 through Downsample16_CU8, the SWAR fixed-point CIC5 ladder (DSP.cpp:499-651),
+    evaluated with packed 16-bit fields in the front end's registers; taps, hard bits and the NMEA text."""
+    from ais_catcher_amd import host
+    xs = [synth.to_cu8(synth.receiver_stream(131072 * 6, receiver_id=64 + r, gap_slots=(0, 2))) for r in range(2)]
+    _run_gpu_vs_oracle(xs, 1536000, "cu8", 131072, 6, fp_ds=True)
+    _run_gpu_vs_oracle(xs[:1], 1536000, "cu8", 16384, 12, fp_ds=True)
+    edge = np.zeros(2 * 16384 * 4, np.uint8)
+    edge[0::4] = 255
+    edge[1::7] = 1
+    _run_gpu_vs_oracle([edge], 1536000, "cu8", 16384, 4, fp_ds=True)
+    chk = checkers.Ref(fmt="cu8", fp_ds=True) if checkers.have_ref() else checkers.Oracle(fmt="cu8", fp_ds=True)
+    chk.feed_blocks(xs[0], 131072)
+    host.reset_sequence()
+    m = host.ModelDefaultGPU(block_len=131072, input_format=gpu.FMT_CU8, fp_ds=True)
+    for b in range(6):
+        m.receive(xs[0][b * 262144:(b + 1) * 262144])
+    assert m.nmea() == chk.nmea() and len(chk.nmea()) >= 2
 
 
 def test_cu8_equals_cf32_path():
@@ -558,7 +578,7 @@ def test_gpu_frame_decoder_matches_host_decoders_on_a_batch():
 # ---------------------------------------------------------------------------------------------------------------
 def _run_outputs_vs_oracle(streams, rate, fmt, block, nblocks, **kw):
     R = len(streams)
-    okw = dict(dsk=kw.get("dsk", False), ps_ema=kw.get("ps_ema", True))
+    okw = dict(dsk=kw.get("dsk", False), ps_ema=kw.get("ps_ema", True), fp_ds=kw.get("fp_ds", False))
     g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block,
                    input_format=_FMT[fmt], taps=False, **kw)
     per = 1 if fmt == "cf32" else 2

@@ -149,3 +149,22 @@ def test_model_standard(rate, fmt, block):
     assert o.nmea() == r.nmea() and len(r.nmea()) >= 3
     ol, rl = o.msg_meta(), r.msg_meta()
     assert np.array_equal(ol[0], rl[0]) and np.array_equal(ol[1], rl[1])
+
+
+def test_fixed_point_ladder_fp_ds():
+    """`-go FP_DS on`: Downsample16_CU8 (DSP.cpp:499-651) in front of the rotator instead of the four float CIC5 stages"""
+    block = 131072
+    x = synth.to_cu8(synth.receiver_stream(block * 8, receiver_id=33, gap_slots=(0, 2)))
+    o = checkers.Oracle(fmt="cu8", taps=True, fp_ds=True)
+    r = checkers.Ref(fmt="cu8", taps=True, fp_ds=True)
+    plain = checkers.Ref(fmt="cu8", taps=True)
+    for c in (o, r, plain):
+        c.feed_blocks(x, block)
+    for w in range(6):
+        assert np.array_equal(o.tap(w).view(np.float32), r.tap(w).view(np.float32)), "tap %d" % w
+    assert not np.array_equal(r.tap(0).view(np.float32), plain.tap(0).view(np.float32))  # the truncating ladder is a different filter
+    for ch in range(2):
+        for j in range(5):
+            for p, q in zip(o.bits(ch, j), r.bits(ch, j)):
+                assert np.array_equal(p, q)
+    assert o.nmea() == r.nmea() and len(r.nmea()) >= 3
