@@ -109,6 +109,7 @@ struct aisgpu {
 	float* d_magT[NBUF] = {}; // shifted FFT magnitudes (written by the FFT on the front stream, read by the searches on s3)
 	uint32_t* d_bits[2] = {};
 	bool challenger = false;
+	bool v2 = false; float2* h_c48 = nullptr; // ModelEngineV2: front end only, the 48 kHz channels go to the host (MAXSUB slots)
 	bool base = false; float2* d_fmprev[2] = {}; // ModelBase: FM receiver on the 48 kHz channels, no coherent chain
 	float* d_fm = nullptr; uint32_t* d_fmbits[2] = {}; uint32_t* h_fmbits = nullptr; // ModelChallenger FM branch
 	EmaState* d_ema[2] = {}; // state before / after the current downstream block (swapped per block)
@@ -456,7 +457,23 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 	return AISGPU_OK;
 }
 
+// ModelEngineV2 (Model.cpp:440-463): nothing behind the front end runs here; the block's two 48 kHz channels travel to the host
+int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
+	if (h->n_sub < MAXSUB) {
+		const size_t C = h->n_chan;
+		HIPCHK(hipMemcpy2DAsync(h->h_c48 + (size_t)h->n_sub * C * h->L, (size_t)h->L * sizeof(float2), h->d_c48[q], (size_t)h->c48s * sizeof(float2),
+		                        (size_t)h->L * sizeof(float2), C, hipMemcpyDeviceToHost, h->stream));
+		SubOut& so = h->sub[h->n_sub++];
+		so.pb = pb; so.lv = 0; so.q = q; so.groups = 0; so.first_group = h->n48 / 5; so.first48 = h->n48;
+	}
+	HIPCHK(hipEventRecord(h->ev_c48free[q], h->stream));
+	h->n48 += h->L;
+	h->block_idx++;
+	return AISGPU_OK;
+}
+
 int enqueue_downstream(aisgpu_t* h, int q, int pb) {
+	if (h->v2) return enqueue_downstream_v2(h, q, pb);
 	if (h->base) return enqueue_downstream_base(h, q, pb);
 	if (h->fused) return enqueue_downstream_fused(h, q, pb);
 	const K2Params k2 = make_k2(h, q);
@@ -624,7 +641,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		}
 	}
 	if (cfg->model != AISGPU_MODEL_DEFAULT && cfg->model != AISGPU_MODEL_CHALLENGER && cfg->model != AISGPU_MODEL_BASE &&
-	    cfg->model != AISGPU_MODEL_STANDARD) return AISGPU_ERR_ARG;
+	    cfg->model != AISGPU_MODEL_STANDARD && cfg->model != AISGPU_MODEL_V2) return AISGPU_ERR_ARG;
 	if (cfg->input_format != AISGPU_FMT_CU8 && cfg->input_format != AISGPU_FMT_CF32 && cfg->input_format != AISGPU_FMT_CS8 &&
 	    cfg->input_format != AISGPU_FMT_CS16) return AISGPU_ERR_ARG;
 	if (cfg->n_receivers < 1 || cfg->n_receivers > 65535) return AISGPU_ERR_ARG;
@@ -642,6 +659,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->mode = mode; h->K = K; h->KP = KP;
 	h->challenger = cfg->model == AISGPU_MODEL_CHALLENGER;
 	h->base = cfg->model == AISGPU_MODEL_BASE || cfg->model == AISGPU_MODEL_STANDARD; // both: FM receiver on the 48 kHz channels
+	h->v2 = cfg->model == AISGPU_MODEL_V2;
 	// front-end geometry (tuning knobs; the defaults are the measured best): workgroup size, output samples per
 	// tile, prefetch depth.  Compiled combinations: "256,256,2", "64,64,1", "64,64,2".
 	h->k1_threads = 64; h->tile96 = 64; h->depth = 0; // autonomous waves, register/DPP ladder (profiles/r01_k1_geometry_sweep.txt)
@@ -835,7 +853,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	if (h->ps_box) for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_box[i], (size_t)h->n_chains));
 	// default: the fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); the materialised path serves
 	// the taps and the FM branch, which need those arrays, and stays selectable (AISGPU_FUSED=0)
-	h->fused = !(cfg->flags & AISGPU_FLAG_TAPS) && !h->challenger && !h->base;
+	h->fused = !(cfg->flags & AISGPU_FLAG_TAPS) && !h->challenger && !h->base && !h->v2;
 	if (const char* e = getenv("AISGPU_FUSED")) h->fused = h->fused && atoi(e) != 0;
 	h->search_on_front = h->fused; // keeps the stream count at four
 	if (const char* e = getenv("AISGPU_SEARCH0")) h->search_on_front = atoi(e) != 0;
@@ -896,6 +914,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	HIPCHK(dalloc(&h->d_psfin, C * 5 * ps_chunks * 16));
 	HIPCHK(dalloc(&h->d_psflag, 4));
 	if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_firtap, C * (8 + h->L)));
+	if (h->v2) HIPCHK(hipHostMalloc((void**)&h->h_c48, MAXSUB * C * h->L * sizeof(float2), hipHostMallocDefault));
 	HIPCHK(hipHostMalloc((void**)&h->h_bits, MAXSUB * C * 5 * h->words * sizeof(uint32_t), hipHostMallocDefault));
 	HIPCHK(hipHostMalloc((void**)&h->h_lvl, MAXSUB * C * h->Gcap * sizeof(float), hipHostMallocDefault));
 	HIPCHK(hipHostMalloc((void**)&h->h_ppm, MAXSUB * C * h->W * sizeof(float), hipHostMallocDefault));
@@ -934,6 +953,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_in); hipFree(h->d_hist[0]); hipFree(h->d_hist[1]); hipFree(h->d_hist2[0]); hipFree(h->d_hist2[1]);
 	hipFree(h->d_fm); hipFree(h->d_fmbits[0]); hipFree(h->d_fmbits[1]);
 	if (h->h_fmbits) hipHostFree(h->h_fmbits);
+	if (h->h_c48) hipHostFree(h->h_c48);
 	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); hipFree(h->d_ckw[i]); }
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
 	hipFree(h->d_box[0]); hipFree(h->d_box[1]);
@@ -1155,7 +1175,7 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 		const SubOut& so = h->sub[s];
 		// ev_ema[pb]: PhaseSearch (and the frame decoder) of that block are done, wherever their last kernel ran; they are
 		// ordered after everything that produced lvl/ppm
-		if (!h->base) {
+		if (!h->base && !h->v2) {
 		HIPCHK(hipStreamWaitEvent(h->s2, h->ev_ema[so.lv], 0));
 		HIPCHK(hipMemcpyAsync(h->h_bits + (size_t)s * C * 5 * h->words, h->d_bits[so.pb], C * 5 * h->words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s2));
 		HIPCHK(hipMemcpyAsync(h->h_lvl + (size_t)s * C * h->Gcap, h->d_lvl[so.lv], C * h->Gcap * sizeof(float), hipMemcpyDeviceToHost, h->s2));
@@ -1197,6 +1217,7 @@ int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* o) {
 	o->group_window = nullptr;
 	o->first_sample48 = so.first48;
 	o->fm_bits = (h->challenger || h->base) ? h->h_fmbits + (size_t)sub * C * (h->L / 32) + chan * (h->L / 32) : nullptr;
+	o->c48 = h->v2 ? (const float*)(h->h_c48 + ((size_t)sub * C + chan) * h->L) : nullptr;
 	return AISGPU_OK;
 }
 

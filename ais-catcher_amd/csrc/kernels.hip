@@ -7,6 +7,7 @@
 // File:line citations are relative to the reference's Source/ directory.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 
@@ -2450,10 +2451,23 @@ static hipError_t launch_k1_p(const K1Params& p, int K, bool cu8, int spans, int
 	return hipErrorInvalidValue;
 }
 
+// Occupancy cap of the front end: its one-wave workgroups use ~10 KB of LDS and ~120 VGPRs, so four of them fit a SIMD and
+// leave 32 VGPRs -- room for exactly one wave of anything else.  Padding the LDS allocation (unused dynamic shared memory)
+// caps it at 3 (or 2) per SIMD; the kernel itself is as fast with 3 as with 4 (HBM-bound), and the back end gets wave slots.
+static int k1_lds_pad() {
+	static int pad = -1;
+	if (pad < 0) {
+		const char* e = getenv("AISGPU_K1_PER_SIMD");
+		const int per = e ? atoi(e) : 4;
+		pad = per == 3 ? 2700 : per == 2 ? 8400 : per == 1 ? 24000 : 0;
+	}
+	return pad;
+}
+
 template <int K, int FMT>
 static hipError_t launch_k1_dpp_kf(const K1Params& p, int spans, int n_rx, hipStream_t s) {
-	if (p.pre_out != nullptr) hipLaunchKernelGGL((k1_dpp<K, FMT, true>), dim3(spans, n_rx), dim3(64), 0, s, p);
-	else hipLaunchKernelGGL((k1_dpp<K, FMT, false>), dim3(spans, n_rx), dim3(64), 0, s, p);
+	if (p.pre_out != nullptr) hipLaunchKernelGGL((k1_dpp<K, FMT, true>), dim3(spans, n_rx), dim3(64), k1_lds_pad(), s, p);
+	else hipLaunchKernelGGL((k1_dpp<K, FMT, false>), dim3(spans, n_rx), dim3(64), k1_lds_pad(), s, p);
 	return hipGetLastError();
 }
 
@@ -2467,7 +2481,7 @@ static hipError_t launch_k1_dpp_k(const K1Params& p, int fmt, int spans, int n_r
 	case 4:
 		if constexpr (K == 4) {
 			if (p.pre_out != nullptr) return hipErrorInvalidValue;
-			hipLaunchKernelGGL((k1_dpp<4, 4, false>), dim3(spans, n_rx), dim3(64), 0, s, p);
+			hipLaunchKernelGGL((k1_dpp<4, 4, false>), dim3(spans, n_rx), dim3(64), k1_lds_pad(), s, p);
 			return hipGetLastError();
 		}
 		break;

@@ -16,6 +16,7 @@ FMT_CU8, FMT_CF32, FMT_CS8, FMT_CS16 = 0, 1, 2, 3
 _ELEMS = {FMT_CU8: 2, FMT_CS8: 2, FMT_CS16: 2, FMT_CF32: 1}  # numpy elements per IQ sample (uint8 / int8 / int16 pairs, complex64)
 MODEL_STANDARD = 0
 MODEL_BASE = 1
+MODEL_V2 = 11
 MODEL_DEFAULT = 2
 MODEL_CHALLENGER = 4
 FLAG_TAPS = 1
@@ -56,6 +57,7 @@ class Out(ctypes.Structure):
         ("group_window", ctypes.POINTER(ctypes.c_int)),
         ("first_sample48", ctypes.c_longlong),
         ("fm_bits", ctypes.POINTER(ctypes.c_uint32)),
+        ("c48", ctypes.POINTER(ctypes.c_float)),
     ]
 
 
@@ -179,8 +181,11 @@ class AisGpu:
             L = o.n_windows * 512
             w = np.ctypeslib.as_array(o.fm_bits, shape=(L // 32,))
             fm = ((w[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).reshape(-1).astype(np.uint8)
+        c48 = None
+        if o.c48:
+            c48 = np.ctypeslib.as_array(o.c48, shape=(o.n_windows * 1024,)).copy().view(np.complex64)
         return dict(bits=bits, lvl=lvl, ppm=ppm, first_group=o.first_group, first_sample48=o.first_sample48,
-                    n_groups=n, n_windows=o.n_windows, fm_bits=fm)
+                    n_groups=n, n_windows=o.n_windows, fm_bits=fm, c48=c48)
 
     def frames(self):
         """AISGPU_FLAG_GPU_DECODE: list of dicts, the frames completed since the previous sync_outputs()."""

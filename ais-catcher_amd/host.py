@@ -32,6 +32,7 @@ def load():
     lib.aishost_model_destroy.argtypes = [vp]
     lib.aishost_model_receive.argtypes = [vp, vp, ci]
     lib.aishost_model_replay.argtypes = [vp, ci, cll, cll, ci, ctypes.POINTER(vp), vp, ci, vp, vp]
+    lib.aishost_model_feed48.argtypes = [vp, ci, vp, ci]
     lib.aishost_model_msg_count.argtypes = [vp]
     lib.aishost_model_nmea.argtypes = [vp, ctypes.c_char_p, ci]
     lib.aishost_model_msg_meta.argtypes = [vp, vp, vp, ci]
@@ -99,6 +100,11 @@ class ModelDefaultGPU:
         self.lib.aishost_model_replay(self.h, ch, first_group, first_sample48, n, ptrs, lvl.ctypes.data, len(ppm), ppm.ctypes.data,
                                       fmw.ctypes.data if fmw is not None else None)
 
+    def feed48(self, ch, iq):
+        """ModelEngineV2 host logic (detached or not): one block of the 48 kHz channel ch as complex64."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        self.lib.aishost_model_feed48(self.h, ch, iq.ctypes.data, len(iq))
+
     def nmea(self):
         n = self.lib.aishost_model_nmea(self.h, None, 0)
         buf = ctypes.create_string_buffer(n)
@@ -127,6 +133,14 @@ class ModelDefaultGPU:
 class ModelChallengerGPU(ModelDefaultGPU):
     def __init__(self, **kw):
         kw["model"] = _gpu.MODEL_CHALLENGER
+        super().__init__(**kw)
+
+
+class ModelEngineV2GPU(ModelDefaultGPU):
+    """AIS::ModelEngineV2 (-m 11): GPU front end; V2::Engine (whose every block depends on its decoders' state) on the host."""
+
+    def __init__(self, **kw):
+        kw["model"] = _gpu.MODEL_V2
         super().__init__(**kw)
 
 

@@ -122,7 +122,8 @@ bool Decoder::cannotBeValid(int len) const { // early-abort heuristics (AIS.cpp:
 	return false;
 }
 
-void Decoder::Run(FLOAT32 sample, TAG& tag) { // Marine/AIS.h:91-181
+bool Decoder::step(FLOAT32 sample, TAG& tag) { // Marine/AIS.h:91-181
+	bool found = false;
 	const BIT d = sample > 0;
 	const BIT Bit = !(d ^ prev); // NRZI
 	prev = d;
@@ -151,7 +152,8 @@ void Decoder::Run(FLOAT32 sample, TAG& tag) { // Marine/AIS.h:91-181
 			if (one_seq_count == 5) { // six ones: closing flag (or abort)
 				if (tag.mode & 1) tag.level = level / position;
 				end_idx = tag.sample_idx;
-				if (processData(position - 7, tag)) NextState(State::FOUNDMESSAGE, 0);
+				found = processData(position - 7, tag);
+				if (found) NextState(State::FOUNDMESSAGE, 0);
 				NextState(State::TRAINING, 0);
 			} else one_seq_count++;
 		} else {
@@ -163,6 +165,7 @@ void Decoder::Run(FLOAT32 sample, TAG& tag) { // Marine/AIS.h:91-181
 	default: break;
 	}
 	lastBit = Bit;
+	return found;
 }
 
 } // namespace AIS

@@ -74,12 +74,17 @@ class Decoder : public SimpleStreamInOut<FLOAT32, Message>, public SignalIn<Deco
 	bool CRC16(int len) const;
 	bool processData(int len, TAG& tag);
 	bool cannotBeValid(int len) const;
-	void Run(FLOAT32 sample, TAG& tag);
+	bool step(FLOAT32 sample, TAG& tag); // true: this bit completed a frame with a good CRC
 
 public:
+	// Per-bit entry (Marine/AIS.h:88-181): the V2 engine calls it directly.  FOUNDMESSAGE on the completing bit, else the resting state.
+	State Run(FLOAT32 sample, TAG& tag) { return step(sample, tag) ? State::FOUNDMESSAGE : state; }
+	void reset() { NextState(State::TRAINING, 0); }
+	State getState() const { return state; }
+	long long getStartIdx() const { return start_idx; }
 	void setOrigin(char c, int /*station*/, int own) { channel = c; own_mmsi = own; }
 	void Receive(const FLOAT32* data, int len, TAG& tag) override {
-		for (int i = 0; i < len; i++) Run(data[i], tag);
+		for (int i = 0; i < len; i++) step(data[i], tag);
 	}
 	void Signal(const DecoderSignals& in) override {
 		if (in == DecoderSignals::Reset) NextState(State::TRAINING, 0);

@@ -55,6 +55,7 @@ void* aishost_model_create(void* batch, int rx, int sample_rate, int block_len, 
 		m->m.setChallenger((model & 0xff) == AISGPU_MODEL_CHALLENGER);
 		m->m.setBase((model & 0xff) == AISGPU_MODEL_BASE);
 		m->m.setStandard((model & 0xff) == AISGPU_MODEL_STANDARD);
+		m->m.setEngineV2((model & 0xff) == AISGPU_MODEL_V2);
 		m->m.setGpuDecode((model & 0x100) != 0);
 		m->m.setFixedPoint((model & 0x200) != 0); // bit 9: AISGPU_FLAG_FP_DS for a stand-alone receiver // bit 8 of `model`: AISGPU_FLAG_GPU_DECODE for a stand-alone receiver
 		if (batch) m->m.useBatch((GpuBatch*)batch, rx);
@@ -87,6 +88,13 @@ int aishost_model_replay(void* mv, int ch, long long first_group, long long firs
 	for (int j = 0; j < 5; j++) o.bits[j] = bits5[j];
 	o.lvl = lvl; o.n_windows = n_windows; o.ppm = ppm; o.fm_bits = fm_bits;
 	m->m.replay(ch, o, m->tag);
+	return 0;
+}
+
+// ModelEngineV2 host logic without a GPU: one block of a 48 kHz channel (n complex samples), as the device would hand it over
+int aishost_model_feed48(void* mv, int ch, const float* iq, int n) {
+	Model* m = (Model*)mv;
+	(ch == 0 ? m->m.Chain().outC48a : m->m.Chain().outC48b).Send((const CFLOAT32*)iq, n, m->tag);
 	return 0;
 }
 

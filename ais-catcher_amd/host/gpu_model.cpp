@@ -32,9 +32,10 @@ int GpuBatch::submitAndWait(int rx, const void* iq, int n_iq) {
 	return status;
 }
 
-void GpuChain::replay(Connection<FLOAT32>* out, const aisgpu_out& o, TAG& tag) {
+void GpuChain::replay(Connection<FLOAT32>* out, const aisgpu_out& o, TAG& tag, int n0, int n1) {
 	for (int g = 0; g < o.n_groups; g++) {
 		const long long n_last = 5 * (o.first_group + g) + 4; // the sample that completes the group
+		if (n_last - o.first_sample48 < n0 || n_last - o.first_sample48 >= n1) continue;
 		const int w = (int)((n_last - o.first_sample48) / 512);
 		if (o.ppm && w >= 0 && w < o.n_windows) tag.ppm = o.ppm[w];
 		if (tag.mode & 1) tag.sample_lvl = o.lvl[g];
@@ -46,9 +47,9 @@ void GpuChain::replay(Connection<FLOAT32>* out, const aisgpu_out& o, TAG& tag) {
 	}
 }
 
-void GpuChain::replayChallenger(Connection<FLOAT32>* coh, Connection<FLOAT32>* fm, const aisgpu_out& o, TAG& tag) {
+void GpuChain::replayChallenger(Connection<FLOAT32>* coh, Connection<FLOAT32>* fm, const aisgpu_out& o, TAG& tag, int n0, int n1) {
 	const int L = o.n_windows * 512;
-	for (int n = 0; n < L; n++) {
+	for (int n = n0 > 0 ? n0 : 0; n < L && n < n1; n++) {
 		const long long N = o.first_sample48 + n;
 		if (o.ppm) tag.ppm = o.ppm[n >> 9]; // set by the CGF before it hands the window to the throttle (DSP.cpp:484)
 		if (N % 5 == 4) { // ScatterPLL has its five samples (DSP.h:101-113)
@@ -67,9 +68,9 @@ void GpuChain::replayChallenger(Connection<FLOAT32>* coh, Connection<FLOAT32>* f
 	}
 }
 
-void GpuChain::replayBase(Connection<FLOAT32>& fm, const aisgpu_out& o, TAG& tag) {
+void GpuChain::replayBase(Connection<FLOAT32>& fm, const aisgpu_out& o, TAG& tag, int n0, int n1) {
 	const int L = o.n_windows * 512;
-	for (int n = 0; n < L; n++) { // FM, Filter and SimplePLL leave the tag alone (Demod.cpp:27-37, DSP.cpp:249-280, 28-44)
+	for (int n = n0 > 0 ? n0 : 0; n < L && n < n1; n++) { // FM, Filter and SimplePLL leave the tag alone (Demod.cpp:27-37, DSP.cpp:249-280, 28-44)
 		const FLOAT32 f = ((o.fm_bits[n >> 5] >> (n & 31)) & 1u) ? 1.0f : -1.0f;
 		fm.Send(&f, 1, tag);
 	}
@@ -104,13 +105,25 @@ void GpuChain::process(const void* data, int len, TAG& tag) {
 		}
 		return;
 	}
+	// On the decimate-by-3 ladders DownsampleKFilter hands its output on in blocks of 8192 samples (DSP/DSP.h:193), so Rotate --
+	// and with it the A-then-B order -- works on 4096 samples at 48 kHz at a time, however long the input block was.
+	const aisgpu_cfg& cf = batch->config();
+	const bool by3 = cf.sample_rate == 288000 ||
+	                 ((cf.flags & AISGPU_FLAG_DSK) && (cf.sample_rate == 576000 || cf.sample_rate == 1152000 || cf.sample_rate == 2304000));
 	for (int s = 0; s < nsub; s++) {
-		for (int ch = 0; ch < 2; ch++) {
-			aisgpu_out o;
-			if (batch->fetch(s, rx, ch, &o) != AISGPU_OK) { failed = true; return; }
-			if (o.fm_bits && o.n_groups == 0) replayBase(ch == 0 ? outFMa : outFMb, o, tag);
-			else if (o.fm_bits) replayChallenger(ch == 0 ? outA : outB, ch == 0 ? outAf : outBf, o, tag);
-			else replay(ch == 0 ? outA : outB, o, tag);
+		aisgpu_out o[2];
+		for (int ch = 0; ch < 2; ch++)
+			if (batch->fetch(s, rx, ch, &o[ch]) != AISGPU_OK) { failed = true; return; }
+		const int L = o[0].n_windows * 512, step = by3 ? 4096 : L;
+		for (int n0 = 0; n0 < L; n0 += step) {
+			for (int ch = 0; ch < 2; ch++) {
+				const aisgpu_out& c = o[ch];
+				const int n1 = n0 + step < L ? n0 + step : L;
+				if (c.c48) (ch == 0 ? outC48a : outC48b).Send((const CFLOAT32*)c.c48 + n0, n1 - n0, tag);
+				else if (c.fm_bits && c.n_groups == 0) replayBase(ch == 0 ? outFMa : outFMb, c, tag, n0, n1);
+				else if (c.fm_bits) replayChallenger(ch == 0 ? outA : outB, ch == 0 ? outAf : outBf, c, tag, n0, n1);
+				else replay(ch == 0 ? outA : outB, c, tag, n0, n1);
+			}
 		}
 	}
 }
@@ -129,7 +142,7 @@ void ModelDefaultGPU::buildModel(char CH1, char CH2, int sample_rate, bool /*tim
 		c.input_format = format == Format::CU8 ? AISGPU_FMT_CU8 : format == Format::CS8 ? AISGPU_FMT_CS8 : format == Format::CS16 ? AISGPU_FMT_CS16 : AISGPU_FMT_CF32;
 		c.afc_wide = CGF_wide;
 		c.droop = droop_compensation;
-		c.model = standard ? AISGPU_MODEL_STANDARD : base ? AISGPU_MODEL_BASE : challenger ? AISGPU_MODEL_CHALLENGER : AISGPU_MODEL_DEFAULT;
+		c.model = v2 ? AISGPU_MODEL_V2 : standard ? AISGPU_MODEL_STANDARD : base ? AISGPU_MODEL_BASE : challenger ? AISGPU_MODEL_CHALLENGER : AISGPU_MODEL_DEFAULT;
 		if (gpu_decode) c.flags |= AISGPU_FLAG_GPU_DECODE;
 		if (fixedpointDS) c.flags |= AISGPU_FLAG_FP_DS;
 		batch = new GpuBatch(c); // throws std::runtime_error on unsupported rate / missing GPU
@@ -152,6 +165,19 @@ void ModelDefaultGPU::wireDecoders(char CH1, char CH2) {
 		DEC_base_b.out.Connect(&fan);
 		DEC_base_a.DecoderMessage.Connect(sampler_a);
 		DEC_base_b.DecoderMessage.Connect(sampler_b);
+		return;
+	}
+	if (v2) { // Model.cpp:440-463
+		V2_a.setOrigin(CH1, station, own_mmsi);
+		V2_b.setOrigin(CH2, station, own_mmsi);
+		V2_a.setWeights(dd_train, dd_weight);
+		V2_b.setWeights(dd_train, dd_weight);
+		chain.outC48a >> V2_a;
+		chain.outC48b >> V2_b;
+		for (int i = 0; i < V2Engine::N_DECODERS; i++) {
+			V2_a.getDecoder(i).out.Connect(&fan);
+			V2_b.getDecoder(i).out.Connect(&fan);
+		}
 		return;
 	}
 	if (standard) { // Model.cpp:484-518

@@ -25,6 +25,7 @@
 #include "../../include/aisgpu.h"
 #include "ais_frame.h"
 #include "stream.h"
+#include "v2_engine.h"
 
 namespace aisamd {
 
@@ -113,6 +114,8 @@ public:
 	// ModelBase: the filtered FM discriminator of each channel (FR_a / FR_b, DSP/Model.cpp:431-432); only its sign is known
 	// here, and only its sign is looked at downstream (DSP.cpp:30, Marine/AIS.h:96)
 	Connection<FLOAT32> outFMa, outFMb;
+	// ModelEngineV2: the 48 kHz channels themselves (C_a / C_b, DSP/Model.cpp:345-346), one Send per block
+	Connection<CFLOAT32> outC48a, outC48b;
 
 	void attach(GpuBatch* b, int receiver) { batch = b; rx = receiver; }
 	void setErrorHandler(std::function<void(const std::string&)> f) { on_error = f; }
@@ -124,13 +127,14 @@ public:
 	void Receive(const CS16* data, int len, TAG& tag) override { process(data, len, tag); }
 	// Replay one channel's symbol decisions of a block into the five phase outputs (host logic,
 	// also used stand-alone by the CPU tests).
-	static void replay(Connection<FLOAT32>* out, const aisgpu_out& o, TAG& tag);
+	// (n0, n1: only the part of the block whose 48 kHz samples [n0, n1) complete it -- Rotate's sub-blocks on the decimate-by-3 ladders)
+	static void replay(Connection<FLOAT32>* out, const aisgpu_out& o, TAG& tag, int n0 = 0, int n1 = 1 << 30);
 	// ModelChallenger: the reference throttles the CGF output one sample at a time into both branches
 	// (Deinterleave n=1, Model.cpp:630-639), so per 48 kHz sample N: first the coherent branch (which fires its five
 	// decoders when N completes a group), then FM decoder N % 5.
-	static void replayChallenger(Connection<FLOAT32>* coh, Connection<FLOAT32>* fm, const aisgpu_out& o, TAG& tag);
+	static void replayChallenger(Connection<FLOAT32>* coh, Connection<FLOAT32>* fm, const aisgpu_out& o, TAG& tag, int n0 = 0, int n1 = 1 << 30);
 	// ModelBase: every 48 kHz sample of the block, in order, into the sampler
-	static void replayBase(Connection<FLOAT32>& fm, const aisgpu_out& o, TAG& tag);
+	static void replayBase(Connection<FLOAT32>& fm, const aisgpu_out& o, TAG& tag, int n0 = 0, int n1 = 1 << 30);
 };
 
 class ModelDefaultGPU {
@@ -141,6 +145,9 @@ class ModelDefaultGPU {
 	AIS::Decoder DEC_af[N_SAMPLES_PER_SYMBOL], DEC_bf[N_SAMPLES_PER_SYMBOL]; // ModelChallenger only
 	bool challenger = false;
 	bool gpu_decode = false; // AIS::Decoder state machines on the device (ModelDefault only)
+	bool v2 = false; // AIS::ModelEngineV2 wiring: outC48 -> V2Engine (six decoders inside) per channel
+	V2Engine V2_a, V2_b;
+	float dd_train = 0.75f, dd_weight = 0.86f; // DSP/Model.h:272
 	bool standard = false; // AIS::ModelStandard wiring: outFM -> Deinterleave(5) -> DEC_a/b[5] with their Reset mesh
 	Deinterleave<FLOAT32> S_a, S_b;
 	bool base = false; // AIS::ModelBase wiring: outFM -> SimplePLL -> one decoder per channel, decoder -> sampler feedback
@@ -172,6 +179,8 @@ public:
 	void setChallenger(bool b) { challenger = b; } // AIS::ModelChallenger wiring (Model.cpp:601-678) instead of ModelDefault
 	void setBase(bool b) { base = b; }             // AIS::ModelBase wiring (Model.cpp:419-438)
 	void setStandard(bool b) { standard = b; }     // AIS::ModelStandard wiring (Model.cpp:484-518)
+	void setEngineV2(bool b) { v2 = b; }           // AIS::ModelEngineV2 wiring (Model.cpp:440-463)
+	void setV2Weights(float train, float track) { dd_train = train; dd_weight = track; } // KEY_SETTING_DD_TRAIN / DD_WEIGHT
 	void setGpuDecode(bool b) { gpu_decode = b; }  // frames from aisgpu_frames() instead of replaying decisions
 	// same signature as AIS::Model::buildModel (the Device* of the reference is only used for wiring there)
 	void buildModel(char CH1, char CH2, int sample_rate, bool timerOn, void* device);
@@ -193,6 +202,12 @@ public:
 class ModelChallengerGPU : public ModelDefaultGPU {
 public:
 	ModelChallengerGPU() { setChallenger(true); }
+};
+
+// AIS::ModelEngineV2 wiring ("-m 11")
+class ModelEngineV2GPU : public ModelDefaultGPU {
+public:
+	ModelEngineV2GPU() { setEngineV2(true); }
 };
 
 // AIS::ModelStandard wiring ("-m 0")

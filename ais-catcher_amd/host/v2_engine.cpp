@@ -1,0 +1,259 @@
+// ais-catcher_amd/host/v2_engine.cpp -- see v2_engine.h.  Citations: reference DSP/Decoder/V2/V2Engine.cpp unless noted.
+#include "v2_engine.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace aisamd {
+
+namespace {
+
+const float PI_F = 3.14159265358979323846f; // Library/Common.h:318
+const float PROMINENCE_GATE = 5.5f, SLOT_LOCK = 0.64f, LEARN_W = 0.2f; // :29-31
+
+// Filters::Coherent / Filters::Receiver (DSP/Filters.h:24-41)
+const float TAPS17[17] = { 2.06995719e-06f, 3.18610148e-05f, 3.40605309e-04f, 2.52892989e-03f, 1.30411453e-02f, 4.67076746e-02f,
+	                       1.16186141e-01f, 2.00730781e-01f, 2.40861391e-01f, 2.00730781e-01f, 1.16186141e-01f, 4.67076746e-02f,
+	                       1.30411453e-02f, 2.52892989e-03f, 3.40605309e-04f, 3.18610148e-05f, 2.06995719e-06f };
+const float TAPS37[37] = { 0.00119025f, -0.00148464f, -0.00282428f, -0.00200561f, -0.00068852f, 0.00343044f, 0.00902093f, 0.01367867f,
+	                       0.01147965f, 0.0027259f, -0.01766614f, -0.04244429f, -0.0577468f, -0.05245161f, -0.01072754f, 0.0732564f,
+	                       0.17643278f, 0.25582214f, 0.28200453f, 0.25582214f, 0.17643278f, 0.0732564f, -0.01072754f, -0.05245161f,
+	                       -0.0577468f, -0.04244429f, -0.01766614f, 0.0027259f, 0.01147965f, 0.01367867f, 0.00902093f, 0.00343044f,
+	                       -0.00068852f, -0.00200561f, -0.00282428f, -0.00148464f, 0.00119025f };
+
+inline float power(CFLOAT32 z) { return z.real() * z.real() + z.imag() * z.imag(); }
+// the two products and one sum per component of std::complex's operator*
+inline CFLOAT32 mul(CFLOAT32 a, CFLOAT32 b) {
+	return CFLOAT32(a.real() * b.real() - a.imag() * b.imag(), a.real() * b.imag() + a.imag() * b.real());
+}
+inline CFLOAT32 scale(CFLOAT32 a, float t) { return CFLOAT32(a.real() * t, a.imag() * t); }
+
+inline int reverse9(int x) { // FFT::rev(x, 9) (DSP/FFT.h:36-66)
+	int y = 0;
+	for (int i = 0; i < 9; i++) { y = (y << 1) | (x & 1); x >>= 1; }
+	return y;
+}
+
+// octant-reduced polynomial arctangent (:244-263)
+inline float arctan2(float y, float x) {
+	const float ax = fabsf(x), ay = fabsf(y);
+	const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+	if (mx == 0.0f) return 0.0f;
+	const float a = mn / mx, s = a * a;
+	float r = ((-0.0464964749f * s + 0.15931422f) * s - 0.327622764f) * s * a + a;
+	if (ay > ax) r = 1.57079637f - r;
+	if (x < 0.0f) r = 3.14159274f - r;
+	return y < 0.0f ? -r : r;
+}
+
+} // namespace
+
+V2Engine::Tone::Tone() : omega(BLOCK), work(BLOCK) {
+	for (int s = 0; s < BLOCK; s++) { // FFT::calcOmega (DSP/FFT.h:83)
+		const float th = ((float)(-2.0 * (double)PI_F) * (float)s) / (float)BLOCK;
+		omega[s] = CFLOAT32(cosf(th), sinf(th));
+	}
+}
+
+float V2Engine::Tone::estimate(const CFLOAT32* w) { // :56-131
+	const int N = BLOCK, delta = 102, M = 133, ofs = 15;
+	for (int n = 0; n < N; n++) work[reverse9(n)] = mul(w[n], w[n]);
+	// FFT::Plan::fft (DSP/FFT.h:94-129): in-place radix-2 on the bit-reversed input, twiddles from the table
+	for (int m2 = 1, r = N; m2 < N; m2 <<= 1) {
+		r >>= 1;
+		const int m = m2 << 1;
+		for (int j = 0, tw = 0; j < m2; j++, tw += r) {
+			const CFLOAT32 o = omega[tw];
+			for (int k = 0; k < N; k += m) {
+				const CFLOAT32 t = mul(o, work[k + j + m2]);
+				work[k + j + m2] = work[k + j] - t;
+				work[k + j] += t;
+			}
+		}
+	}
+	for (int i = 0; i < N / 2; i++) mag[i] = sqrtf(power(work[i + N / 2])); // fftshift order
+	for (int i = 0; i < N / 2; i++) mag[i + N / 2] = sqrtf(power(work[i]));
+
+	float rolling = 0.0f;
+	for (int j = 0; j < M; j++) rolling += mag[j];
+	float best = rolling + 0.6f * (mag[ofs] + mag[ofs + delta]);
+	int wi = 0;
+	for (int i = 1; i <= N - M; i++) {
+		rolling = rolling - mag[i - 1] + mag[i + M - 1];
+		const float v = rolling + 0.6f * (mag[i + ofs] + mag[i + ofs + delta]);
+		if (v > best) { best = v; wi = i; }
+	}
+	int fz = -1;
+	float peak = 0.0f;
+	for (int i = wi; i < wi + (M - delta); i++) {
+		const float h = mag[i] + mag[i + delta];
+		if (h > peak) { peak = h; fz = i; }
+	}
+	float total = 0.0f;
+	for (int i = 0; i < N; i++) total += mag[i];
+	prominence = total > 0.0f ? peak * (N / 2) / total : 0.0f;
+	if (fz < 0) return 0.0f;
+	float frac = 0.0f;
+	if (fz > 0 && fz + delta + 1 < N) { // parabola through the three pair sums around the peak
+		const float a = mag[fz - 1] + mag[fz - 1 + delta];
+		const float c = mag[fz + 1] + mag[fz + 1 + delta];
+		const float den = a - 2.0f * peak + c;
+		if (den < 0.0f) {
+			frac = 0.5f * (a - c) / den;
+			frac = frac > 0.5f ? 0.5f : (frac < -0.5f ? -0.5f : frac);
+		}
+	}
+	return (N / 2 - (fz + frac + delta / 2.0f)) / 2.0f / N;
+}
+
+void V2Engine::Tone::derotate(float f, const CFLOAT32* src, CFLOAT32* dst, int len) { // :133-146
+	const float ang = f * 2.0f * PI_F;
+	const CFLOAT32 step(cosf(ang), sinf(ang)); // std::polar(1.0f, ang)
+	CFLOAT32 r = rot;
+	for (int i = 0; i < len; i++) {
+		r = mul(r, step);
+		dst[i] = mul(src[i], r);
+	}
+	const float a = hypotf(r.real(), r.imag()); // std::abs
+	rot = CFLOAT32(r.real() / a, r.imag() / a);
+	last_f = f;
+}
+
+void V2Engine::fir17(const CFLOAT32* in, CFLOAT32* out) { // dot17 + FilterFL17::Run (:38-46, :154-167)
+	auto dot = [](const CFLOAT32* a) {
+		CFLOAT32 sum(0.0f, 0.0f);
+		for (int i = 0; i < 8; i++) sum += scale(a[i] + a[16 - i], TAPS17[i]);
+		return sum + scale(a[8], TAPS17[8]);
+	};
+	std::memcpy(carry17 + 16, in, 16 * sizeof(CFLOAT32));
+	for (int i = 0; i < 16; i++) *out++ = dot(carry17 + i);
+	for (int i = 0; i <= BLOCK - 17; i++) *out++ = dot(in + i);
+	std::memcpy(carry17, in + (BLOCK - 16), 16 * sizeof(CFLOAT32));
+}
+
+void V2Engine::fir37(const float* in, float* out) { // dot37 + FilterFL37::Run (:48-54, :175-188)
+	auto dot = [](const float* a) {
+		float sum = 0.0f;
+		for (int i = 0; i < 18; i++) sum += (a[i] + a[36 - i]) * TAPS37[i];
+		return sum + a[18] * TAPS37[18];
+	};
+	std::memcpy(carry37 + 36, in, 36 * sizeof(float));
+	for (int i = 0; i < 36; i++) *out++ = dot(carry37 + i);
+	for (int i = 0; i <= BLOCK - 37; i++) *out++ = dot(in + i);
+	std::memcpy(carry37, in + (BLOCK - 36), 36 * sizeof(float));
+}
+
+int V2Engine::Tracker::run(CFLOAT32 z, bool training) { // Rotate90 + PhaseTracker::Run (:190-226)
+	const float src_re = (rot & 1) ? z.imag() : z.real(), src_im = (rot & 1) ? z.real() : z.imag();
+	z = CFLOAT32(((rot ^ (rot >> 1)) & 1) ? -src_re : src_re, (rot & 2) ? -src_im : src_im);
+	rot = (rot + 1) & 3;
+	const float alpha = training ? weight_train : weight;
+	const float beta = 1.0f - alpha;
+	const float proj = z.real() * s.real() + z.imag() * s.imag();
+	const float d = proj >= 0.0f ? 1.0f : -1.0f;
+	s = scale(s, alpha) + scale(z, beta * d);
+	const int decision = proj > 0.0f ? 1 : 0;
+	const int bit = decision ^ prev_decision; // differential: a 180 degree offset cancels
+	prev_decision = decision;
+	return bit;
+}
+
+bool V2Engine::BitClock::run(float sample, bool training) { // BitPLL::Run (:228-242)
+	const int bit = sample > 0.0f ? 1 : 0;
+	if (bit != last_bit) phase += (0.5f - phase) * (training ? 0.6f : 0.05f);
+	last_bit = bit;
+	phase += 0.2f;
+	if (phase < 1.0f) return false;
+	phase -= (int)phase;
+	return true;
+}
+
+V2Engine::V2Engine() {
+	for (auto& c : carry17) c = CFLOAT32(0.0f, 0.0f);
+	for (auto& c : carry37) c = 0.0f;
+	for (auto& c : raw) c = CFLOAT32(0.0f, 0.0f);
+}
+
+bool V2Engine::laterHalfIsLouder(const CFLOAT32* in) const { // midWins (:281-291): in[0, 256) against in[512, 768)
+	float head = 0.0f, tail = 0.0f;
+	for (int i = 0; i < BLOCK / 2; i++) {
+		head += power(in[i]);
+		tail += power(in[BLOCK + i]);
+	}
+	return tail > head;
+}
+
+void V2Engine::correctFrequency(const CFLOAT32* in, CFLOAT32* out, bool busy) { // Engine::CGF (:293-326)
+	const bool locked = power(slot_ema) >= SLOT_LOCK;
+	const int e = (int)(((slot_phase - sample_idx) % SLOT + SLOT) % SLOT);
+	ppm_prev = ppm;
+	float f;
+	if (locked && e < BLOCK) { // a slot starts inside this block: [0, e) keeps the previous frequency
+		ppm_split = e;
+		tone.derotate(tone.last_f, in, out, e);
+		f = tone.estimate(in + e);
+		tone.derotate(f, in + e, out + e, BLOCK - e);
+	} else {
+		ppm_split = 0;
+		const int offset = (!busy && laterHalfIsLouder(in)) ? BLOCK / 2 : 0;
+		f = tone.estimate(in + offset);
+		if (busy && tone.prominence < PROMINENCE_GATE) f = tone.last_f; // tone gate: hold while a decode is in flight
+		tone.derotate(f, in, out, BLOCK);
+	}
+	ppm = f * 48000.0f / 162.0f;
+}
+
+void V2Engine::learnSlot(const AIS::Decoder& d) { // :328-337
+	const long long a = d.getStartIdx() - PRE;
+	const float th = (float)((a % SLOT + SLOT) % SLOT) * (2.0f * PI_F / SLOT);
+	slot_ema = scale(slot_ema, 1.0f - LEARN_W) + scale(CFLOAT32(cosf(th), sinf(th)), LEARN_W);
+	const float ph = atan2f(slot_ema.imag(), slot_ema.real()) * (SLOT / (2.0f * PI_F));
+	slot_phase = (int)(ph + SLOT + 0.5f) % SLOT;
+}
+
+void V2Engine::resetAll() {
+	for (auto& d : dec) d.reset();
+}
+
+void V2Engine::block(TAG& tag) { // Engine::processBlock (:345-388)
+	slot_ema = scale(slot_ema, 0.9999f); // the slot predictor forgets in ~25 s of silence
+	bool busy = false;
+	for (int j = 0; j < 5; j++) busy |= dec[j].getState() != AIS::State::TRAINING;
+	correctFrequency(raw, derot, busy);
+	fir17(derot, coh);
+	for (int i = 0; i < BLOCK; i++) { // FMDemod::Run (:265-273) on the uncorrected block
+		const CFLOAT32 p = mul(raw[i], std::conj(fm_prev));
+		disc[i] = arctan2(p.imag(), p.real()) / PI_F;
+		fm_prev = raw[i];
+	}
+	fir37(disc, disc_f);
+	tag.ppm = ppm_prev;
+	for (int i = 0; i < BLOCK; i++) {
+		if (i == ppm_split) tag.ppm = ppm;
+		tag.sample_idx = sample_idx++;
+		const int bit = trk[di].run(coh[i], dec[di].getState() == AIS::State::TRAINING);
+		tag.sample_lvl = power(coh[i]);
+		if (dec[di].Run(bit ? 1.0f : -1.0f, tag) == AIS::State::FOUNDMESSAGE) {
+			learnSlot(dec[di]);
+			resetAll();
+		}
+		if (fm_clock.run(disc_f[i], dec[FM_DEC].getState() == AIS::State::TRAINING))
+			if (dec[FM_DEC].Run(disc_f[i], tag) == AIS::State::FOUNDMESSAGE) resetAll();
+		di = di + 1 == 5 ? 0 : di + 1;
+	}
+	std::memmove(raw, raw + BLOCK, BLOCK * sizeof *raw);
+}
+
+void V2Engine::Receive(const CFLOAT32* data, int len, TAG& tag) { // :390-406
+	while (len > 0) {
+		const int n = BLOCK - fill < len ? BLOCK - fill : len;
+		std::memcpy(raw + BLOCK + fill, data, n * sizeof(CFLOAT32));
+		fill += n; data += n; len -= n;
+		if (fill == BLOCK) {
+			block(tag);
+			fill = 0;
+		}
+	}
+}
+
+} // namespace aisamd

@@ -55,6 +55,9 @@ extern "C" {
 #define AISGPU_MODEL_BASE 1        /* AIS::ModelBase       (-m 1), DSP/Model.cpp:419-438: FM receiver; the GPU delivers the sign of the
                                     * filtered discriminator per 48 kHz sample, SimplePLL + decoder (feedback loop) run on the host */
 #define AISGPU_MODEL_DEFAULT 2     /* AIS::ModelDefault    (-m 2), DSP/Model.cpp:520-577 */
+#define AISGPU_MODEL_V2 11         /* AIS::ModelEngineV2  (-m 11), DSP/Model.cpp:440-463: the device runs the front end only and hands over the
+                                    * two 48 kHz channels (aisgpu_out.c48); V2::Engine's per-block decisions depend on the state of its own
+                                    * decoders (DSP/Decoder/V2/V2Engine.cpp:300-341), so it runs behind the boundary, on the host */
 #define AISGPU_MODEL_CHALLENGER 4  /* AIS::ModelChallenger (-m 4), DSP/Model.cpp:601-678: ModelDefault + the FM branch */
 
 #define AISGPU_FLAG_TAPS 1    /* keep intermediate float taps readable via aisgpu_tap() (tests) */
@@ -96,6 +99,8 @@ typedef struct aisgpu_out {
 	long long first_sample48;/* stream index (48 kHz) of the first sample of this block */
 	const uint32_t* fm_bits; /* AISGPU_MODEL_CHALLENGER and AISGPU_MODEL_BASE (else NULL; with MODEL_BASE n_groups is 0 and only this is valid): bit n of word n/32 set <=> the filtered FM discriminator
 	                          * sample first_sample48 + n is > 0 (what Deinterleave S_af hands to DEC_af[n % 5], Model.cpp:638-639) */
+	const float* c48;        /* AISGPU_MODEL_V2 only (else NULL): the channel's 48 kHz front-end output of this block (FCIC5_a/b.out, Model.cpp:345-346),
+	                          * 512 * n_windows complex samples, interleaved re/im; n_groups is 0 */
 } aisgpu_out;
 
 void aisgpu_default_cfg(aisgpu_cfg* cfg);

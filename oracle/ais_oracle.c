@@ -455,7 +455,8 @@ static int dec_process(ao_dec* d, int len, tag_t* tag, msgsink* sink) { /* AIS.c
 	}
 	return 1;
 }
-static void dec_run(ao_dec* d, float sample, tag_t* tag, msgsink* sink) { /* AIS.h:91-181 */
+static int dec_run(ao_dec* d, float sample, tag_t* tag, msgsink* sink) { /* AIS.h:91-181; returns 1 on the bit that completes a frame with a good CRC */
+	int found = 0;
 	int dd = sample > 0;
 	int Bit = !(dd ^ d->prev);
 	d->prev = dd;
@@ -482,7 +483,8 @@ static void dec_run(ao_dec* d, float sample, tag_t* tag, msgsink* sink) { /* AIS
 			if (d->one_seq_count == 5) {
 				if (tag->mode & 1) tag->level = d->level / d->position;
 				d->end_idx = tag->sample_idx;
-				if (dec_process(d, d->position - 7, tag, sink)) dec_next(d, ST_FOUNDMESSAGE, 0);
+				found = dec_process(d, d->position - 7, tag, sink);
+				if (found) dec_next(d, ST_FOUNDMESSAGE, 0);
 				dec_next(d, ST_TRAINING, 0);
 			} else d->one_seq_count++;
 		} else {
@@ -494,7 +496,10 @@ static void dec_run(ao_dec* d, float sample, tag_t* tag, msgsink* sink) { /* AIS
 	default: break;
 	}
 	d->lastBit = Bit;
+	return found;
 }
+
+#include "ais_oracle_v2.inc"
 
 /* ---------------------------------------------------------------- per-channel back end */
 typedef struct { fvec bits, lvl; lvec idx; } bitrec;
@@ -512,6 +517,7 @@ typedef struct {
 	ao_dec decf[5];
 	/* ModelBase: FM -> Filter(Receiver) -> SimplePLL -> one Decoder (Model.cpp:419-438) */
 	float pll; int pll_prev, pll_fast; ao_dec decb;
+	v2_t* v2; /* ModelEngineV2 */
 	fvec tap48, tapcgf, tapfir, ppm_cgf, ppm_fir;
 	bitrec br[5], brf[5];
 } chan_t;
@@ -595,6 +601,11 @@ static void channel_receive(ao_chain* c, chan_t* ch, const cf* x96, int n96) {
 	if (c->taps) fv_push(&ch->tap48, (const float*)y, 2LL * n);
 	if (c->model == 1) { /* ModelBase: no CGF, the channel goes straight into the FM receiver */
 		for (int i = 0; i < n; i++) base_branch(c, ch, y[i]);
+		free(t);
+		return;
+	}
+	if (c->model == 11) { /* ModelEngineV2 (Model.cpp:440-463): the channel goes into V2::Engine */
+		v2_receive(ch->v2, y, n, &c->tag, &c->sink);
 		free(t);
 		return;
 	}
@@ -807,6 +818,7 @@ ao_chain* ao_create(int model, int sample_rate, int fmt, int flags) {
 		ch->cgf.window = 187; ch->cgf.wide = 1; /* Model.cpp:533-540 */
 		ch->decb.channel = "AB"[q]; ch->decb.fast_pll = &ch->pll_fast; /* Model.cpp:434-435 */
 		ch->pll_fast = 1; /* DSP.h:40 */
+		if (model == 11) { ch->v2 = (v2_t*)malloc(sizeof(v2_t)); v2_init(ch->v2, "AB"[q]); }
 		for (int j = 0; j < 5; j++) {
 			ch->dec[j].channel = "AB"[q]; ch->decf[j].channel = "AB"[q];
 			/* Reset mesh: Model.cpp:566-573 (Default), :658-674 (Challenger) */
@@ -831,6 +843,7 @@ void ao_destroy(ao_chain* c) {
 	free(c->dsk_buf);
 	for (int q = 0; q < 2; q++) {
 		chan_t* ch = &c->ch[q];
+		free(ch->v2);
 		fv_free(&ch->tap48); fv_free(&ch->tapcgf); fv_free(&ch->tapfir); fv_free(&ch->ppm_cgf); fv_free(&ch->ppm_fir);
 		for (int j = 0; j < 5; j++) {
 			fv_free(&ch->br[j].bits); fv_free(&ch->br[j].lvl); free(ch->br[j].idx.p);

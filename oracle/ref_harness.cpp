@@ -79,6 +79,7 @@ struct Harness {
 	AIS::ModelChallenger* mc = nullptr;
 	AIS::ModelBase* mb = nullptr;
 	AIS::ModelStandard* ms = nullptr;
+	AIS::ModelEngineV2* mv = nullptr;
 	AIS::Model* model = nullptr;
 	TAG tag;
 	Format fmt;
@@ -96,7 +97,7 @@ struct Harness {
 
 extern "C" {
 
-// kind: 0 = ModelStandard, 1 = ModelBase, 2 = ModelDefault, 4 = ModelChallenger.  fmt: 0 = CU8, 1 = CF32, 2 = CS8, 3 = CS16.
+// kind: 0 = ModelStandard, 1 = ModelBase, 2 = ModelDefault, 4 = ModelChallenger, 11 = ModelEngineV2.  fmt: 0 = CU8, 1 = CF32, 2 = CS8, 3 = CS16.
 // flags: bit 0 record float taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`, bit 3 `-go FP_DS on`
 void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 	const int taps = flags & 1;
@@ -106,6 +107,7 @@ void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 		if (kind == 4) { h->mc = new AIS::ModelChallenger(); h->model = h->mc; }
 		else if (kind == 1) { h->mb = new AIS::ModelBase(); h->model = h->mb; }
 		else if (kind == 0) { h->ms = new AIS::ModelStandard(); h->model = h->ms; }
+		else if (kind == 11) { h->mv = new AIS::ModelEngineV2(); h->model = h->mv; }
 		else { h->md = new AIS::ModelDefault(); h->model = h->md; }
 		if (flags & 2) h->model->SetKey(AIS::KEY_SETTING_DSK, "ON");
 		if (flags & 4) h->model->SetKey(AIS::KEY_SETTING_PS_EMA, "OFF");
@@ -122,6 +124,7 @@ void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 				h->bits[0][0].on = h->bits[1][0].on = h->fmbits[0][0].on = h->fmbits[1][0].on = true;
 				h->mb->sampler_a.out >> h->bits[0][0]; h->mb->sampler_b.out >> h->bits[1][0];
 				h->mb->FR_a.out >> h->fmbits[0][0];    h->mb->FR_b.out >> h->fmbits[1][0];
+			} else if (h->mv) { // (the engine's internals are private arrays; the 48 kHz taps and the messages are compared)
 			} else if (h->ms) { // what each of the five decoders of a channel gets (Deinterleave outputs)
 				for (int j = 0; j < 5; j++) {
 					h->fmbits[0][j].on = h->fmbits[1][j].on = true;
@@ -224,7 +227,7 @@ void ref_reset_seq(void) { AIS::Message::ID.store(0); }
 
 void ref_destroy(void* hv) {
 	Harness* h = (Harness*)hv;
-	delete h->md; delete h->mc; delete h->mb; delete h->ms;
+	delete h->md; delete h->mc; delete h->mb; delete h->ms; delete h->mv;
 	delete h;
 }
 

@@ -501,6 +501,62 @@ def test_model_base_nmea_end_to_end():
     assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
 
 
+@pytest.mark.parametrize("model", [2, 4, 0])
+def test_decimate_by_3_ladder_message_order(model):
+    """288 kSPS: DownsampleKFilter hands Rotate 8192 samples at a time, so the reference alternates between the channels every
+    4096 samples at 48 kHz inside one input block; the host replay must follow, or the messages come out in another order."""
+    from ais_catcher_amd import host
+    rate, block, nblocks = 288000, 49152, 14
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=47, gap_slots=(0, 1), type5_every=4)
+    chk = checkers.Ref(model=model, rate=rate) if checkers.have_ref() else checkers.Oracle(model=model, rate=rate)
+    chk.feed_blocks(x, block)
+    host.reset_sequence()
+    cls = {2: host.ModelDefaultGPU, 4: host.ModelChallengerGPU, 0: host.ModelStandardGPU}[model]
+    m = cls(sample_rate=rate, block_len=block)
+    for b in range(nblocks):
+        m.receive(x[b * block:(b + 1) * block])
+    assert m.nmea() == chk.nmea() and len(chk.nmea()) >= 6
+    assert len(set(l.split(",")[4] for l in chk.nmea())) == 2  # both channels carry messages
+
+
+@pytest.mark.parametrize("rate,fmt,block,nblocks", [(1536000, "cf32", 131072, 24), (1536000, "cu8", 786432, 4), (768000, "cf32", 65536, 24),
+                                                    (6000000, "cf32", 786432, 4), (288000, "cf32", 49152, 12)])
+def test_model_engine_v2_end_to_end(rate, fmt, block, nblocks):
+    """AIS::ModelEngineV2 (-m 11): the device runs the front end and hands over the two 48 kHz channels (bit-exact against the
+    checker's taps); V2::Engine -- whose every 512-sample block depends on the state of its own decoders -- runs on the host."""
+    from ais_catcher_amd import host
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=46, gap_slots=(1, 2), type5_every=4)
+    data = synth.to_cu8(x) if fmt == "cu8" else x
+    per = 1 if fmt == "cf32" else 2
+    chk = checkers.Ref(model=11, rate=rate, fmt=fmt, taps=True) if checkers.have_ref() else checkers.Oracle(model=11, rate=rate, fmt=fmt, taps=True)
+    chk.feed_blocks(data, block)
+    # (1) the device output
+    g = gpu.AisGpu(sample_rate=rate, block_len=block, input_format=_FMT[fmt], model=gpu.MODEL_V2)
+    taps = [chk.tap(0), chk.tap(1)]
+    done = [0, 0]
+    for b in range(nblocks):
+        g.submit(0, data[b * block * per:(b + 1) * block * per])
+        g.run()
+        g.sync_outputs()
+        for sub in range(g.out_count()):
+            for ch in range(2):
+                o = g.fetch(0, ch, sub)
+                n = len(o["c48"])
+                assert o["n_groups"] == 0 and n == 512 * o["n_windows"] and o["first_sample48"] == done[ch]
+                assert _feq(o["c48"], taps[ch][done[ch]:done[ch] + n]), "block %d ch %d" % (b, ch)
+                done[ch] += n
+    g.close()
+    assert done[0] > 0 and done[0] == done[1]
+    # (2) end to end through the C++ host model
+    host.reset_sequence()
+    m = host.ModelEngineV2GPU(sample_rate=rate, block_len=block, input_format=_FMT[fmt])
+    for b in range(nblocks):
+        m.receive(data[b * block * per:(b + 1) * block * per])
+    assert m.nmea() == chk.nmea() and len(chk.nmea()) >= 3
+    a, c = m.msg_meta(), chk.msg_meta()
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+
+
 @pytest.mark.parametrize("rate,fmt,block", [(1536000, "cf32", 131072), (1536000, "cu8", 131072), (768000, "cf32", 65536)])
 def test_model_standard_nmea_end_to_end(rate, fmt, block):
     """AIS::ModelStandard (-m 0): the device path of ModelBase (front end + FM discriminator + 37-tap filter), then on the host

@@ -110,3 +110,22 @@ def test_model_base_replay_matches_checker():
     assert m.nmea() == chk.nmea() and len(chk.nmea()) >= 3
     a, c = m.msg_meta(), chk.msg_meta()
     assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+
+
+@pytest.mark.parametrize("block,nblocks,rid,kw", [(131072, 24, 51, {}), (16384, 96, 52, {"gap_slots": (0, 1)}), (786432, 4, 53, {"type5_every": 3})])
+def test_v2_engine_host_logic_matches_checker(block, nblocks, rid, kw):
+    """ModelEngineV2 (-m 11): the host engine (ais-catcher_amd/host/v2_engine.cpp) fed with the 48 kHz channels a checker
+    recorded, in the block structure the device delivers them (channel A's block, then channel B's)."""
+    x = synth.receiver_stream(block * nblocks, receiver_id=rid, **kw)
+    chk = checkers.Ref(model=11, taps=True) if checkers.have_ref() else checkers.Oracle(model=11, taps=True)
+    chk.feed_blocks(x, block)
+    host.reset_sequence()
+    m = host.ModelEngineV2GPU(block_len=block, detached=True)
+    L = block // 32
+    ta, tb = chk.tap(0), chk.tap(1)
+    for b in range(nblocks):
+        m.feed48(0, ta[b * L:(b + 1) * L])
+        m.feed48(1, tb[b * L:(b + 1) * L])
+    assert m.nmea() == chk.nmea() and len(chk.nmea()) >= 3
+    a, c = m.msg_meta(), chk.msg_meta()
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])

@@ -168,3 +168,23 @@ def test_fixed_point_ladder_fp_ds():
             for p, q in zip(o.bits(ch, j), r.bits(ch, j)):
                 assert np.array_equal(p, q)
     assert o.nmea() == r.nmea() and len(r.nmea()) >= 3
+
+
+@pytest.mark.parametrize("rate,fmt,block,rid,kw", [(1536000, "cf32", 131072, 41, {}), (1536000, "cf32", 16384, 42, {"gap_slots": (0, 1)}),
+                                                  (1536000, "cu8", 786432, 43, {"type5_every": 3}), (768000, "cf32", 65536, 44, {}),
+                                                  (6000000, "cf32", 786432, 45, {})])
+def test_model_engine_v2(rate, fmt, block, rid, kw):
+    """ModelEngineV2 (-m 11, Model.cpp:440-463): oracle/ais_oracle_v2.inc against V2::Engine of the compiled reference --
+    the 48 kHz channels, the NMEA text, the levels and the ppm of every message."""
+    n = max(6, 786432 * 4 // block)
+    x = synth.receiver_stream(block * n, sample_rate=rate, receiver_id=rid, **kw)
+    data = synth.to_cu8(x) if fmt == "cu8" else x
+    o = checkers.Oracle(model=11, rate=rate, fmt=fmt, taps=True)
+    r = checkers.Ref(model=11, rate=rate, fmt=fmt, taps=True)
+    o.feed_blocks(data, block)
+    r.feed_blocks(data, block)
+    for w in (0, 1):
+        assert np.array_equal(o.tap(w).view(np.float32), r.tap(w).view(np.float32))
+    assert o.nmea() == r.nmea() and len(r.nmea()) >= 3
+    ol, rl = o.msg_meta(), r.msg_meta()
+    assert np.array_equal(ol[0], rl[0]) and np.array_equal(ol[1], rl[1])
