@@ -150,6 +150,8 @@ struct aisgpu {
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
 	bool fused = false; int GL = 40; bool search_on_front = false;
+	bool defer_fused = false; // spectral analysis on s4, second half of a block one block later
+	struct { bool valid = false; int q = 0, pb = 0, lv = 0, n_groups = 0, n_rel0 = 0, S = 0; long long g0 = 0; unsigned block = 0, sub = 0; } fpend;
 	float2 *d_ck[NBUF] = {}, *d_ckw[NBUF] = {}, *d_dfhist[2] = {};
 	// per-kernel geometry
 	int tile_in = 0, tiles_per_block = 0, tiles_per_span = 0, spans = 0;         // fused front end (its own input)
@@ -253,6 +255,7 @@ int span_tiles(int tiles_per_block, int n_rx, int threads, int tile96, int reque
 }
 
 int enqueue_downstream_fused(aisgpu_t* h, int q, int pb);
+int enqueue_fused_back(aisgpu_t* h);
 
 // what follows PhaseSearch of a block: the optional device frame decoder, and the event that frees sym/lvl/bits[pb]
 int enqueue_decode(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s);
@@ -377,6 +380,31 @@ int enqueue_back(aisgpu_t* h) {
 //   s3: phasor recurrence, own CUs          (latency-bound)
 //   s4: derotation + FIR + ScatterPLL       (VALU/latency-bound)
 //   s1: PhaseSearchEMA                      (VALU-bound; both overlap the next block's front end)
+// second half of the fused path for one block: derotation + FIR + ScatterPLL (s4), then PhaseSearch (s1)
+int enqueue_fused_back(aisgpu_t* h) {
+	if (!h->fpend.valid) return AISGPU_OK;
+	h->fpend.valid = false;
+	const int q = h->fpend.q, pb = h->fpend.pb, lv = h->fpend.lv, n_groups = h->fpend.n_groups;
+	const long long g0 = h->fpend.g0;
+	K6Params k6;
+	k6.c48 = h->d_c48[q]; k6.c48_stride = h->c48s; k6.ck = h->d_ck[q]; k6.ckw = h->d_ckw[q]; k6.ck_stride = (h->n_chan + 63) / 64 * 64;
+	k6.step_table = h->d_step; k6.fz = h->d_fz[q];
+	k6.hist_in = h->d_dfhist[pb ^ 1]; k6.hist_out = h->d_dfhist[pb];
+	k6.sym = h->d_sym[pb]; k6.sym_stride = h->Gcap; k6.lvl = h->d_lvl[lv];
+	memcpy(k6.taps, TAPS_COHERENT, sizeof k6.taps);
+	k6.first_group = g0; k6.n_rel0 = h->fpend.n_rel0; k6.n_groups = n_groups; k6.L = h->L; k6.n_windows = h->W; k6.n_chan = h->n_chan;
+	k6.GL = h->GL; k6.S = h->fpend.S;
+	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_phasor[q], 0));
+	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_sym[pb], 0)); // sym[pb] was last read by PhaseSearch of block f-2,
+	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_ema[lv], 0)); // lvl[lv] by the frame decoder / the copies of block f-4
+	{ TraceScope t(h, "derotfir", h->s4); HIPCHK(launch_k6(k6, h->s4)); }
+	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s4));
+	HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4));
+	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_k3[pb], 0));
+	TraceScope t(h, "psearch", h->s1);
+	return enqueue_k4(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub, h->s1);
+}
+
 int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	const int lv = (int)(h->block_idx & 3);
 	K2Params k2 = make_k2(h, q);
@@ -385,10 +413,20 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	const int S = (n_groups + h->GL - 1) / h->GL;
 	k2.ck = h->d_ck[q]; k2.ckw = h->d_ckw[q]; k2.ck_stride = k2.rotT_stride;
 	k2.ck_first = n_rel0 - 20; k2.ck_period = 5 * h->GL; k2.n_ck = S;
-	{ TraceScope t(h, "fft", h->stream); HIPCHK(launch_k2a_fft(k2, h->n_chan, h->stream)); }
-	HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
-	hipStream_t ss = h->search_on_front ? h->stream : h->s4; // with the searches on the front stream four streams are enough
-	HIPCHK(hipStreamWaitEvent(ss, h->ev_front[q], 0));
+	// The spectral analysis (FFT + searches) either follows the front end on its stream, or -- AISGPU_DEFER_FUSED -- runs on s4
+	// next to it; s4 then must not sit waiting for this block's phasor recurrence, so the second half of the block (derotation /
+	// FIR, PhaseSearch) is enqueued one block later, behind the next block's analysis (or when results are requested).
+	hipStream_t sa = h->defer_fused ? h->s4 : h->stream;
+	if (h->defer_fused) {
+		HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
+		HIPCHK(hipStreamWaitEvent(h->s4, h->ev_front[q], 0));
+	}
+	{ TraceScope t(h, "fft", sa); HIPCHK(launch_k2a_fft(k2, h->n_chan, sa)); }
+	hipStream_t ss = h->defer_fused ? h->s4 : h->search_on_front ? h->stream : h->s4; // with the searches on the front stream four streams are enough
+	if (!h->defer_fused) {
+		HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
+		HIPCHK(hipStreamWaitEvent(ss, h->ev_front[q], 0));
+	}
 	{ TraceScope t(h, "search", ss); HIPCHK(launch_k2a_search(k2, h->n_chan, ss)); }
 	HIPCHK(hipEventRecord(h->ev_search[q], ss));
 	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_search[q], 0));
@@ -396,34 +434,16 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	{ TraceScope t(h, "phasor", h->s3); HIPCHK(launch_k2b_ck(k2, h->n_chan, h->s3)); }
 	HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
 
-	K6Params k6;
-	k6.c48 = h->d_c48[q]; k6.c48_stride = h->c48s; k6.ck = h->d_ck[q]; k6.ckw = h->d_ckw[q]; k6.ck_stride = k2.ck_stride;
-	k6.step_table = h->d_step; k6.fz = h->d_fz[q];
-	k6.hist_in = h->d_dfhist[pb ^ 1]; k6.hist_out = h->d_dfhist[pb];
-	k6.sym = h->d_sym[pb]; k6.sym_stride = h->Gcap; k6.lvl = h->d_lvl[lv];
-	memcpy(k6.taps, TAPS_COHERENT, sizeof k6.taps);
-	k6.first_group = g0; k6.n_rel0 = n_rel0; k6.n_groups = n_groups; k6.L = h->L; k6.n_windows = h->W; k6.n_chan = h->n_chan;
-	k6.GL = h->GL; k6.S = S;
-	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_phasor[q], 0));
-	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_sym[pb], 0)); // sym[pb] was last read by PhaseSearch of block f-2,
-	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_ema[lv], 0)); // lvl[lv] by the frame decoder / the copies of block f-4
-	{ TraceScope t(h, "derotfir", h->s4); HIPCHK(launch_k6(k6, h->s4)); }
-	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s4));
-	HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4));
-	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_k3[pb], 0));
-
-	{
-		TraceScope t(h, "psearch", h->s1);
-		int rc = enqueue_k4(h, pb, lv, g0, n_groups, (unsigned)h->block_idx, (unsigned)h->n_sub, h->s1);
-		if (rc) return rc;
-	}
-
+	{ int rc = enqueue_fused_back(h); if (rc) return rc; } // the previous block's second half, if it was deferred
+	h->fpend.valid = true; h->fpend.q = q; h->fpend.pb = pb; h->fpend.lv = lv; h->fpend.g0 = g0; h->fpend.n_groups = n_groups;
+	h->fpend.n_rel0 = n_rel0; h->fpend.S = S; h->fpend.block = (unsigned)h->block_idx; h->fpend.sub = (unsigned)h->n_sub;
 	if (h->n_sub < MAXSUB) {
 		SubOut& so = h->sub[h->n_sub++];
 		so.pb = pb; so.lv = lv; so.q = q; so.groups = n_groups; so.first_group = g0; so.first48 = h->n48;
 	}
 	h->n48 += h->L;
 	h->block_idx++;
+	if (h->serial || !h->defer_fused) return enqueue_fused_back(h);
 	return AISGPU_OK;
 }
 
@@ -552,6 +572,7 @@ int gather_frames(aisgpu_t* h) {
 
 int sync_all(aisgpu_t* h) {
 	{ int rc = enqueue_back(h); if (rc) return rc; }
+	{ int rc = enqueue_fused_back(h); if (rc) return rc; }
 	{ int rc = flush_walk(h); if (rc) return rc; }
 	HIPCHK(hipStreamSynchronize(h->stream));
 	HIPCHK(hipStreamSynchronize(h->s1));
@@ -857,6 +878,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	if (const char* e = getenv("AISGPU_FUSED")) h->fused = h->fused && atoi(e) != 0;
 	h->search_on_front = h->fused; // keeps the stream count at four
 	if (const char* e = getenv("AISGPU_SEARCH0")) h->search_on_front = atoi(e) != 0;
+	if (const char* e = getenv("AISGPU_DEFER_FUSED")) h->defer_fused = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_GL")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0) h->GL = v; }
 	if (h->fused) {
 		const size_t cs = (C + 63) / 64 * 64;
@@ -1170,6 +1192,7 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 	if (h->in_blocks == 0) return AISGPU_ERR_STATE;
 	const size_t C = h->n_chan;
 	{ int rc = enqueue_back(h); if (rc) return rc; }
+	{ int rc = enqueue_fused_back(h); if (rc) return rc; }
 	{ int rc = flush_walk(h); if (rc) return rc; }
 	for (int s = 0; s < h->n_sub; s++) {
 		const SubOut& so = h->sub[s];

@@ -95,7 +95,10 @@ struct EmaState { float ma[16]; unsigned bits[16]; int max_idx, rot; int pad[2];
 // shift registers and max_idx
 struct PsBoxState { float mem[12][16]; unsigned bits[16]; int max_idx; int pad[3]; };
 
-constexpr int PS_CHUNK = 1024;   // symbols per time chunk of the chunk-parallel PhaseSearchEMA (multiple of 32)
+#ifndef PS_CHUNK_
+#define PS_CHUNK_ 1024
+#endif
+constexpr int PS_CHUNK = PS_CHUNK_;   // symbols per time chunk of the chunk-parallel PhaseSearchEMA (multiple of 32)
 constexpr int PS_MAXCHUNKS = 16;
 
 struct K4Params {

@@ -1,7 +1,10 @@
 #!/bin/bash
 export TMPDIR=/tmp
-for e in "A=1" "AISGPU_K1_PER_SIMD=3" "AISGPU_K1_PER_SIMD=2" "AISGPU_K1_PER_SIMD=3 AISGPU_K4=lane" "AISGPU_K1_PER_SIMD=2 AISGPU_K4=lane" "AISGPU_K1_PER_SIMD=1"; do echo "$e"; env $e python bench.py --no-cpu-baseline | python -c "
+for r in 1 2; do
+for L in c1024 c1664 c2048 c512; do
+for D in 0 1; do
+echo -n "$L defer=$D: "; AISGPU_DEFER_FUSED=$D AISGPU_LIB=$(realpath tools/ab/lib_$L.so) python bench.py --steps 80 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
 r=d['roofline']
-print(d['ms_per_step'], d['value'], 'k1', r['avg_launch_ms'], 'iso', r['isolated_launch_ms'], 'frac', r['frac'])"; done
+print(d['ms_per_step'], d['value'], 'k1', r['avg_launch_ms'])"; done; done; done
