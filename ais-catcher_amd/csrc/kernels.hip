@@ -1431,11 +1431,12 @@ __constant__ float2 c_ps_phase[8] = { // DSP/Demod.h:29-31
 // neighbour exchange inside a 16-lane row: DPP row rotate (a VALU modifier, no LDS round trip).
 // The rotate direction is probed once per wave (mode 0: row_ror:1 delivers lane k-1; mode 1: lane k+1;
 // mode 2: unexpected -> fall back to ds_bpermute), so correctness never rests on the ISA manual's wording.
+// (mov_dpp: every lane is written, so there is no `old` value to initialise -- one instruction instead of two)
 __device__ __forceinline__ float dpp_ror1(float v) {
-	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, false));
+	return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x121, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float dpp_ror15(float v) {
-	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x12F, 0xF, 0xF, false));
+	return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x12F, 0xF, 0xF, true));
 }
 
 // Per-lane state is just ma[k]; the 8-bit decision shift registers bits[k] of the reference live in
@@ -1448,13 +1449,19 @@ struct PsWave {
 // One symbol for all 16 hypotheses of a row (DSP/Demod.cpp:39-101); v is already multiplied by (1j)^n (K3).
 // Returns the emitted bit (0/1).
 template <int MODE>
-__device__ __forceinline__ unsigned ps_step(float2 v, float pc, float psn, float& ma, PsWave& hs, int& idx, int k, int rowbase) {
+// M: the hypothesis' EMA in BOTH halves of a register pair -- the update is one packed multiply (|t|, ma) * (1 - w, w) and one
+// packed cross add, whose two results are the same sum, so the pair is ready for the next symbol without a move
+__device__ __forceinline__ unsigned ps_step(float2 v, float pc, float psn, c2& M, PsWave& hs, int& idx, int k, int rowbase) {
 	const float w = 0.85f;
 	const float w1 = 1 - w; // (1 - weight) evaluated in float (Demod.cpp:71)
 	const float a = v.x * pc, b = v.y * psn;
 	const float tt = a + b;
 	const unsigned long long dn = __ballot(tt > 0); // bits[k] = (bits[k] << 1) | (t > 0)
-	ma = w * ma + w1 * fabsf(tt);
+	{
+		const c2 u = c2{ fabsf(tt), M.y } * c2{ w1, w };
+		M = u.yx + u.xy; // w * ma + w1 * |t| (Demod.cpp:71), twice
+	}
+	const float ma = M.y;
 	float left, right;
 	if (MODE == 2) {
 		left = __shfl(ma, (k + 15) & 15, 16);
@@ -1469,8 +1476,12 @@ __device__ __forceinline__ unsigned ps_step(float2 v, float pc, float psn, float
 	const bool p1 = right > bestc;     // idx+1 beats the better of the two
 	const unsigned long long B0 = __ballot(p0), B1 = __ballot(p1);
 	const int sh = rowbase + idx;
-	const int q0 = (int)((unsigned)(B0 >> sh) & 1u), q1 = (int)((unsigned)(B1 >> sh) & 1u);
-	idx = (idx + (q1 ? 1 : q0 - 1)) & 15; // prev-1, prev, prev+1 with first-maximum preference
+	// prev-1, prev, prev+1 with first-maximum preference: +1 where the third candidate wins (p1), -1 where neither the second
+	// nor the third does; the two ballot words are combined on the scalar unit, a lane only extracts its bit of each
+	const unsigned long long UP = B1, DN = ~(B0 | B1);
+	const int up = (int)((unsigned)(UP >> sh) & 1u);
+	const int down = __builtin_amdgcn_sbfe((int)(unsigned)(DN >> sh), 0u, 1u); // -1 or 0
+	idx = (idx + up + down) & 15;
 	// nDelay = 3 (Model.cpp:560-561): after the shift-in, bit 3 = decision of 3 symbols ago, bit 4 = 4 symbols ago
 	const unsigned long long X = hs.h3 ^ hs.h4;
 	hs.h4 = hs.h3; hs.h3 = hs.h2; hs.h2 = hs.h1; hs.h1 = dn;
@@ -1481,7 +1492,7 @@ constexpr int PS_BATCH = 8;  // symbols whose samples are fetched together
 
 template <int MODE>
 __device__ __forceinline__ void ps_chain(const float2* __restrict__ x, uint32_t* __restrict__ out, int n, bool writer, float pc,
-                                         float psn, float& ma, PsWave& hs, int& idx, int k, int rowbase) {
+                                         float psn, c2& ma, PsWave& hs, int& idx, int k, int rowbase) {
 	const int nb = n - (n % PS_BATCH);
 	uint32_t word = 0;
 	float2 cur[PS_BATCH];
@@ -1536,7 +1547,7 @@ __global__ __launch_bounds__(64) void k4_phase_search(K4Params p, int conditiona
 
 	const EmaState* st = p.state_in + cidx;
 	EmaState* sto = p.state_out + cidx;
-	float ma = st->ma[k];
+	c2 ma = c2{ st->ma[k], st->ma[k] };
 	const unsigned bits = st->bits[k]; // bit j = decision of j+1 symbols ago
 	PsWave hs;
 	hs.h1 = __ballot((bits & 1u) != 0);
@@ -1552,7 +1563,7 @@ __global__ __launch_bounds__(64) void k4_phase_search(K4Params p, int conditiona
 	else if (all_right) ps_chain<1>(x, out, p.n_groups, writer, pc, psn, ma, hs, idx, k, rowbase);
 	else ps_chain<2>(x, out, p.n_groups, writer, pc, psn, ma, hs, idx, k, rowbase);
 	if (live) {
-		sto->ma[k] = ma;
+		sto->ma[k] = ma.y;
 		// only the last four decisions can ever be read again (bits 3 and 4 after the next shift-in)
 		sto->bits[k] = (unsigned)((hs.h1 >> lane) & 1ull) | ((unsigned)((hs.h2 >> lane) & 1ull) << 1) |
 		               ((unsigned)((hs.h3 >> lane) & 1ull) << 2) | ((unsigned)((hs.h4 >> lane) & 1ull) << 3);
@@ -1637,12 +1648,15 @@ __global__ __launch_bounds__(64) void k4_phase_search_box(K4Params p) {
 //    k4_assemble then walks the chunks sequentially, picking for each the trajectory of the true start.
 // ------------------------------------------------------------------------------------------
 template <int MODE>
-__device__ __forceinline__ void ps_warm_step(float2 v, float pc, float psn, float& ma, PsWave& hs) {
+__device__ __forceinline__ void ps_warm_step(float2 v, float pc, float psn, c2& M, PsWave& hs) {
 	const float w = 0.85f;
 	const float w1 = 1 - w;
 	const float tt = v.x * pc + v.y * psn;
 	const unsigned long long dn = __ballot(tt > 0);
-	ma = w * ma + w1 * fabsf(tt);
+	{
+		const c2 u = c2{ fabsf(tt), M.y } * c2{ w1, w };
+		M = u.yx + u.xy;
+	}
 	hs.h4 = hs.h3; hs.h3 = hs.h2; hs.h2 = hs.h1; hs.h1 = dn;
 }
 
@@ -1656,17 +1670,17 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 	const int g1 = g0 + PS_CHUNK < p.n_groups ? g0 + PS_CHUNK : p.n_groups;
 	const size_t slot = (size_t)chain * p.n_chunks + chunk;
 
-	float ma;
+	c2 ma;
 	PsWave hs;
 	int idx;
 	if (chunk == 0) { // the true state
 		const EmaState* st = p.state_in + chain;
-		ma = st->ma[k];
+		ma = c2{ st->ma[k], st->ma[k] };
 		const unsigned bits = st->bits[k];
 		hs.h1 = __ballot((bits & 1u) != 0); hs.h2 = __ballot((bits & 2u) != 0);
 		hs.h3 = __ballot((bits & 4u) != 0); hs.h4 = __ballot((bits & 8u) != 0);
 	} else {
-		ma = 0.0f;
+		ma = c2{ 0.0f, 0.0f };
 		hs.h1 = hs.h2 = hs.h3 = hs.h4 = 0;
 		const int ws = g0 - p.warm; // >= 0: warm is a multiple of PS_BATCH and <= PS_CHUNK
 #pragma unroll 1
@@ -1677,7 +1691,7 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 #pragma unroll
 			for (int e = 0; e < PS_BATCH; e++) ps_warm_step<MODE>(wv[e], pc, psn, ma, hs);
 		}
-		if (live) p.ma_start[slot * 16 + k] = ma;
+		if (live) p.ma_start[slot * 16 + k] = ma.y;
 	}
 	idx = k; // trajectory that starts at max_idx == k
 
@@ -1716,7 +1730,7 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 	}
 	if ((n & 31) != 0 && live) wout[(n >> 5) * 16] = word;
 	if (live) {
-		p.ma_fin[slot * 16 + k] = ma;
+		p.ma_fin[slot * 16 + k] = ma.y;
 		const unsigned dec = (unsigned)((hs.h1 >> lane) & 1ull) | ((unsigned)((hs.h2 >> lane) & 1ull) << 1) |
 		                     ((unsigned)((hs.h3 >> lane) & 1ull) << 2) | ((unsigned)((hs.h4 >> lane) & 1ull) << 3);
 		p.fin[slot * 16 + k] = (unsigned)idx | (dec << 4);
