@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "kernels.h"
 
@@ -584,6 +585,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 	const int rx = blockIdx.y;
 	const int span = blockIdx.x;
 	__builtin_amdgcn_s_setprio(K1_PRIO);
+#ifdef K1_CAP3
+	// Occupancy cap: ~120 VGPRs and ~10 KB of LDS let FOUR of these one-wave workgroups share a SIMD, and sixteen of them hold
+	// 156 of a CU's 160 KB of LDS -- nothing that needs LDS (the FFT, the staged PhaseSearch) gets on the CU beside them.  The
+	// kernel is as fast with three (HBM-bound); naming v135 as clobbered makes its allocation 136 registers = three per SIMD.
+	asm volatile("" ::: "v135");
+#endif
 
 	if (lane < 8) { x5[0][lane] = x5[1][lane] = x6[0][lane] = x6[1][lane] = make_float2(0.f, 0.f); }
 	RegLadder<K> st = {};
@@ -1660,8 +1667,17 @@ __device__ __forceinline__ void ps_warm_step(float2 v, float pc, float psn, c2& 
 	hs.h4 = hs.h3; hs.h3 = hs.h2; hs.h2 = hs.h1; hs.h1 = dn;
 }
 
+// The 16 lanes of a row consume the same sample, and a wave that waits for its own 8-symbol prefetch is latency-bound as soon
+// as the front end loads the memory system (0.17 ms alone, 0.55 ms next to it).  So the wave stages its input: every lane
+// fetches a different symbol (one load instruction = 16 symbols per chain, whole 128-byte segments), a super-batch of PS_SB
+// symbols per chain goes through a double-buffered LDS tile, and the loads of super-batch n+2 are in flight while n is
+// processed (64 symbols x 20 instructions of cover).  The steps then read their sample as an LDS broadcast.
+constexpr int PS_SB = 64;            // symbols per chain per super-batch
+constexpr int PS_SB_PAD = PS_SB + 4; // row pitch: the four rows' broadcast reads fall into different banks
+
 template <int MODE>
-__device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int chunk, bool live, int k, int rowbase, int lane) {
+__device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int chunk, bool live, int k, int rowbase, int lane,
+                                              float2 (*stage)[4][PS_SB_PAD]) {
 	const int jj = k < 8 ? k : 15 - k;
 	const float pc = c_ps_phase[jj].x;
 	const float psn = k < 8 ? c_ps_phase[jj].y : -c_ps_phase[jj].y;
@@ -1669,65 +1685,86 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 	const int g0 = chunk * PS_CHUNK;
 	const int g1 = g0 + PS_CHUNK < p.n_groups ? g0 + PS_CHUNK : p.n_groups;
 	const size_t slot = (size_t)chain * p.n_chunks + chunk;
+	const int row = rowbase >> 4;
 
 	c2 ma;
 	PsWave hs;
-	int idx;
+	int idx = k; // trajectory that starts at max_idx == k
+	int start = g0;
 	if (chunk == 0) { // the true state
 		const EmaState* st = p.state_in + chain;
 		ma = c2{ st->ma[k], st->ma[k] };
 		const unsigned bits = st->bits[k];
 		hs.h1 = __ballot((bits & 1u) != 0); hs.h2 = __ballot((bits & 2u) != 0);
 		hs.h3 = __ballot((bits & 4u) != 0); hs.h4 = __ballot((bits & 8u) != 0);
-	} else {
+	} else { // speculative: replay the `warm` symbols in front of the chunk from zero (warm: multiple of 8, <= PS_CHUNK)
 		ma = c2{ 0.0f, 0.0f };
 		hs.h1 = hs.h2 = hs.h3 = hs.h4 = 0;
-		const int ws = g0 - p.warm; // >= 0: warm is a multiple of PS_BATCH and <= PS_CHUNK
-#pragma unroll 1
-		for (int g = ws; g < g0; g += PS_BATCH) {
-			float2 wv[PS_BATCH];
-#pragma unroll
-			for (int e = 0; e < PS_BATCH; e++) wv[e] = x[g + e];
-#pragma unroll
-			for (int e = 0; e < PS_BATCH; e++) ps_warm_step<MODE>(wv[e], pc, psn, ma, hs);
-		}
-		if (live) p.ma_start[slot * 16 + k] = ma.y;
+		start = g0 - p.warm;
 	}
-	idx = k; // trajectory that starts at max_idx == k
+	const int last_i = (int)p.sym_stride - 1;
+	float2 r[PS_SB / 16];
+	const auto fetch = [&](int sb) {
+#pragma unroll
+		for (int q = 0; q < PS_SB / 16; q++) {
+			int i = start + sb * PS_SB + q * 16 + k;
+			i = i < last_i ? i : last_i; // (past the chunk's end: any readable sample, it is never used)
+			r[q] = x[i];
+		}
+	};
+	const auto stash = [&](int buf) {
+#pragma unroll
+		for (int q = 0; q < PS_SB / 16; q++) stage[buf][row][q * 16 + k] = r[q];
+	};
+	const int nsb = (g1 - start + PS_SB - 1) / PS_SB;
+	fetch(0);
+	stash(0);
+	if (nsb > 1) fetch(1);
 
 	uint32_t* wout = p.words + slot * (PS_CHUNK / 32) * 16 + k;
 	uint32_t word = 0;
-	const int n = g1 - g0;
-	const int nb = n - (n % PS_BATCH);
-	float2 cur[PS_BATCH];
-	if (nb > 0) {
-#pragma unroll
-		for (int e = 0; e < PS_BATCH; e++) cur[e] = x[g0 + e];
-	}
 #pragma unroll 1
-	for (int q = 0; q < nb; q += PS_BATCH) {
-		float2 nxt[PS_BATCH];
-		const int qn = q + PS_BATCH < nb ? q + PS_BATCH : q;
+	for (int sb = 0; sb < nsb; sb++) {
+		const int buf = sb & 1;
+		wave_sync(); // the tile written by this wave's own stash() is read below (one-wave workgroup: ordering only)
+#pragma unroll 1
+		for (int s8 = 0; s8 < PS_SB; s8 += PS_BATCH) {
+			const int g = start + sb * PS_SB + s8;
+			if (g >= g1) break;
+			float2 v[PS_BATCH];
+			{
+				const float4* src = reinterpret_cast<const float4*>(&stage[buf][row][s8]);
 #pragma unroll
-		for (int e = 0; e < PS_BATCH; e++) nxt[e] = x[g0 + qn + e];
-		uint32_t part = 0;
+				for (int e = 0; e < PS_BATCH; e += 2) { const float4 t = src[e >> 1]; v[e] = make_float2(t.x, t.y); v[e + 1] = make_float2(t.z, t.w); }
+			}
+			if (g < g0) { // warm-up: EMA and decision history only
 #pragma unroll
-		for (int e = 0; e < PS_BATCH; e++) part |= ps_step<MODE>(cur[e], pc, psn, ma, hs, idx, k, rowbase) << e;
-		word |= part << (q & 31);
-		if (((q + PS_BATCH) & 31) == 0) {
-			if (live) wout[(q >> 5) * 16] = word;
-			word = 0;
+				for (int e = 0; e < PS_BATCH; e++) ps_warm_step<MODE>(v[e], pc, psn, ma, hs);
+				if (g + PS_BATCH == g0 && live) p.ma_start[slot * 16 + k] = ma.y;
+			} else {
+				const int q = g - g0;
+				uint32_t part = 0;
+				if (g + PS_BATCH <= g1) {
+#pragma unroll
+					for (int e = 0; e < PS_BATCH; e++) part |= ps_step<MODE>(v[e], pc, psn, ma, hs, idx, k, rowbase) << e;
+				} else {
+#pragma unroll
+					for (int e = 0; e < PS_BATCH; e++)
+						if (g + e < g1) part |= ps_step<MODE>(v[e], pc, psn, ma, hs, idx, k, rowbase) << e; // wave-uniform
+				}
+				word |= part << (q & 31);
+				if (((q + PS_BATCH) & 31) == 0) {
+					if (live) wout[(q >> 5) * 16] = word;
+					word = 0;
+				}
+			}
 		}
-#pragma unroll
-		for (int e = 0; e < PS_BATCH; e++) cur[e] = nxt[e];
-	}
-	for (int q = nb; q < n; q++) {
-		word |= ps_step<MODE>(x[g0 + q], pc, psn, ma, hs, idx, k, rowbase) << (q & 31);
-		if ((q & 31) == 31) {
-			if (live) wout[(q >> 5) * 16] = word;
-			word = 0;
+		if (sb + 1 < nsb) {
+			stash(buf ^ 1);                  // super-batch sb + 1 has been in flight for one super-batch of work
+			if (sb + 2 < nsb) fetch(sb + 2);
 		}
 	}
+	const int n = g1 - g0;
 	if ((n & 31) != 0 && live) wout[(n >> 5) * 16] = word;
 	if (live) {
 		p.ma_fin[slot * 16 + k] = ma.y;
@@ -1738,6 +1775,7 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 }
 
 __global__ __launch_bounds__(64) void k4_phase_chunks(K4Params p) {
+	__shared__ __attribute__((aligned(16))) float2 stage[2][4][PS_SB_PAD];
 	const int lane = threadIdx.x;
 	const int k = lane & 15, row = lane >> 4;
 	const int chunk = blockIdx.y;
@@ -1747,9 +1785,9 @@ __global__ __launch_bounds__(64) void k4_phase_chunks(K4Params p) {
 	const int rowbase = row * 16;
 	const int src = __builtin_amdgcn_update_dpp(0, k, 0x121, 0xF, 0xF, false);
 	const bool all_left = __all(src == ((k + 15) & 15)), all_right = __all(src == ((k + 1) & 15));
-	if (all_left) ps_chunk_body<0>(p, chain, chunk, live, k, rowbase, lane);
-	else if (all_right) ps_chunk_body<1>(p, chain, chunk, live, k, rowbase, lane);
-	else ps_chunk_body<2>(p, chain, chunk, live, k, rowbase, lane);
+	if (all_left) ps_chunk_body<0>(p, chain, chunk, live, k, rowbase, lane, stage);
+	else if (all_right) ps_chunk_body<1>(p, chain, chunk, live, k, rowbase, lane, stage);
+	else ps_chunk_body<2>(p, chain, chunk, live, k, rowbase, lane, stage);
 }
 
 // sequential over the (few) chunks of a chain, 16 lanes per chain: verify the speculative warm-ups, select the
