@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-for e in "A=1" "AISGPU_S4_CUS=128" "AISGPU_S4_CUS=64" "AISGPU_S4_CUS=32" "AISGPU_S4_CUS=16" "A=1"; do
+for e in "A=1" "AISGPU_GL=24" "AISGPU_GL=16" "AISGPU_GL=80" "AISGPU_GL=8" "A=1"; do
 echo -n "$e: "; env $e python bench.py --steps 80 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())

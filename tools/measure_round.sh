@@ -3,6 +3,7 @@
 # same command, serial-mode per-kernel stats, SQ counters and HBM traffic of the front-end kernel.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+mkdir -p gpurun_out
 R=$PWD
 TAG=${1:-r01_v5}
 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
@@ -13,4 +14,6 @@ AISGPU_SERIAL=1 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_serial -o
 python tools/rocprof_summary.py $(find gpurun_out/prof_serial -name "*.db" | head -1) > gpurun_out/${TAG}_serial_kernel_stats.txt
 GRAFT_REPO_ROOT=$R ./tools/pmc_traffic.sh > gpurun_out/pmc_traffic.log 2>&1
 GRAFT_REPO_ROOT=$R ./tools/pmc_k1.sh > gpurun_out/${TAG}_pmc_sq.txt 2>&1
+cp gpurun_out/pmc_traffic.json gpurun_out/${TAG}_pmc_traffic_k1.json 2>/dev/null
+rm -rf gpurun_out/prof_bench gpurun_out/prof_serial gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_sq1 gpurun_out/pmc_sq2
 tail -1 gpurun_out/${TAG}_bench.json | cut -c1-400
