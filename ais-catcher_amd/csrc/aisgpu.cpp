@@ -897,7 +897,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	}
 	for (int i = 0; i < 4; i++) HIPCHK(dalloc(&h->d_lvl[i], C * h->Gcap));
 	for (int i = 0; i < 2; i++) {
-		HIPCHK(dalloc(&h->d_sym[i], C * 5 * h->Gcap));
+		HIPCHK(dalloc(&h->d_sym[i], sym_elems((int)C, h->Gcap))); // SymRow layout (kernels.h): channels padded to 64
 		HIPCHK(dalloc(&h->d_bits[i], C * 5 * h->words));
 		HIPCHK(dalloc(&h->d_ema[i], C * 5));
 	}

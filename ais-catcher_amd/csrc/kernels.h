@@ -71,7 +71,7 @@ struct K6Params {
 	const float2* ckw;                           // ... and at every window start (renormalised)
 	const float2* step_table; const int* fz;     // fz[chain][n_windows]
 	const float2* hist_in; float2* hist_out;     // [n_chan][DF_HIST]
-	float2* sym; long long sym_stride;           // [n_chan][5][sym_stride]
+	float2* sym; long long sym_stride;           // SymRow layout, sym_stride = group capacity (also the row pitch of lvl)
 	float* lvl;                                   // [n_chan][sym_stride]
 	float taps[17];
 	long long first_group;
@@ -87,6 +87,24 @@ struct K3Params {
 	float taps[17];
 	long long first_group, first_sample48;
 	int n_groups;
+};
+
+// Layout of the FIR / ScatterPLL output `sym` (what PhaseSearch consumes): float4 [n_chan / 64][groups / 2][5][64] -- the pair
+// of symbols (g, g + 1) of sampling phase j for 64 adjacent channels.  The derotation / FIR kernel has one LANE per channel,
+// so in this layout each of its stores is 1 KiB contiguous; with one row per (channel, phase) the same stores were 64
+// scattered 16-byte pieces, and it was exactly those scattered writes that cost the front end 0.05 ms per launch
+// (profiles/r01_v7_interference_experiments.txt).  Element (chan, j, g) as a float2 index:
+constexpr int SYM_PAIR = 5 * 64 * 2; // float2 elements from one symbol pair of a row to the next
+__host__ __device__ inline size_t sym_row_base(int chan, int j, long long gcap) {
+	return ((size_t)(chan >> 6) * (size_t)(gcap >> 1) * 5 + (size_t)j) * 128 + (size_t)(chan & 63) * 2;
+}
+__host__ __device__ inline size_t sym_elems(int n_chan, long long gcap) { return (size_t)((n_chan + 63) / 64) * 64 * 5 * (size_t)gcap; }
+// one (channel, phase) row: element g at base[(g >> 1) * SYM_PAIR + (g & 1)]
+struct SymRow {
+	const float2* base;
+	__host__ __device__ SymRow(const float2* sym, int chain /* chan * 5 + j */, long long gcap) : base(sym + sym_row_base(chain / 5, chain % 5, gcap)) {}
+	__host__ __device__ float2 operator[](int g) const { return base[(size_t)(g >> 1) * SYM_PAIR + (g & 1)]; }
+	__host__ __device__ const float4* pair(int g) const { return reinterpret_cast<const float4*>(base + (size_t)(g >> 1) * SYM_PAIR); } // g even
 };
 
 struct EmaState { float ma[16]; unsigned bits[16]; int max_idx, rot; int pad[2]; };

@@ -1316,10 +1316,10 @@ __global__ __launch_bounds__(64) void k3_derot_fir(K6Params p) {
 		if (live) {
 			if (g + 4 <= gb) {
 #pragma unroll
-				for (int j = 0; j < 5; j++) {
-					float4* dst = reinterpret_cast<float4*>(p.sym + ((size_t)chain * 5 + j) * p.sym_stride + g);
+				for (int j = 0; j < 5; j++) { // lane = channel: each store is 64 x 16 B contiguous (SymRow layout, kernels.h)
+					float4* dst = reinterpret_cast<float4*>(p.sym + sym_row_base(chain, j, p.sym_stride) + (size_t)(g >> 1) * SYM_PAIR);
 #pragma unroll
-					for (int q = 0; q < 2; q++) dst[q] = make_float4(out[j][2 * q].x, out[j][2 * q].y, out[j][2 * q + 1].x, out[j][2 * q + 1].y);
+					for (int q = 0; q < 2; q++) dst[q * (SYM_PAIR / 2)] = make_float4(out[j][2 * q].x, out[j][2 * q].y, out[j][2 * q + 1].x, out[j][2 * q + 1].y);
 				}
 				*reinterpret_cast<float4*>(p.lvl + (size_t)chain * p.sym_stride + g) = make_float4(lv[0], lv[1], lv[2], lv[3]);
 			} else {
@@ -1327,7 +1327,7 @@ __global__ __launch_bounds__(64) void k3_derot_fir(K6Params p) {
 				for (int gi = 0; gi < 4; gi++) {
 					if (g + gi < gb) {
 #pragma unroll
-						for (int j = 0; j < 5; j++) p.sym[((size_t)chain * 5 + j) * p.sym_stride + g + gi] = make_float2(out[j][gi].x, out[j][gi].y);
+						for (int j = 0; j < 5; j++) p.sym[sym_row_base(chain, j, p.sym_stride) + (size_t)((g + gi) >> 1) * SYM_PAIR + ((g + gi) & 1)] = make_float2(out[j][gi].x, out[j][gi].y);
 						p.lvl[(size_t)chain * p.sym_stride + g + gi] = lv[gi];
 					}
 				}
@@ -1417,7 +1417,7 @@ __global__ __launch_bounds__(256) void k3_fir_scatter(K3Params p) {
 		float2 sv = (rot & 1) ? make_float2(acc.y, acc.x) : acc; // rot 1: (-y, x)   rot 3: (y, -x)
 		if (rot == 1 || rot == 2) sv.x = -sv.x;
 		if (rot >= 2) sv.y = -sv.y;
-		p.sym[((size_t)chan * 5 + j) * p.sym_stride + g] = sv;
+		p.sym[sym_row_base(chan, j, p.sym_stride) + (size_t)(g >> 1) * SYM_PAIR + (g & 1)] = sv;
 		if (p.fir_tap) p.fir_tap[(size_t)chan * p.fir_tap_stride + (n_rel + j + 4)] = acc;
 	}
 	p.lvl[(size_t)chan * p.sym_stride + g] = __fdiv_rn(level, 5.0f);
@@ -1498,7 +1498,7 @@ __device__ __forceinline__ unsigned ps_step(float2 v, float pc, float psn, c2& M
 constexpr int PS_BATCH = 8;  // symbols whose samples are fetched together
 
 template <int MODE>
-__device__ __forceinline__ void ps_chain(const float2* __restrict__ x, uint32_t* __restrict__ out, int n, bool writer, float pc,
+__device__ __forceinline__ void ps_chain(const SymRow x, uint32_t* __restrict__ out, int n, bool writer, float pc,
                                          float psn, c2& ma, PsWave& hs, int& idx, int k, int rowbase) {
 	const int nb = n - (n % PS_BATCH);
 	uint32_t word = 0;
@@ -1563,7 +1563,7 @@ __global__ __launch_bounds__(64) void k4_phase_search(K4Params p, int conditiona
 	hs.h4 = __ballot((bits & 8u) != 0);
 	int idx = st->max_idx;
 
-	const float2* x = p.sym + (size_t)cidx * p.sym_stride;
+	const SymRow x(p.sym, cidx, p.sym_stride);
 	uint32_t* out = p.bits + (size_t)cidx * p.bits_stride;
 	const bool writer = live && k == 0;
 	if (all_left) ps_chain<0>(x, out, p.n_groups, writer, pc, psn, ma, hs, idx, k, rowbase);
@@ -1604,7 +1604,7 @@ __global__ __launch_bounds__(64) void k4_phase_search_box(K4Params p) {
 	unsigned bits = st->bits[k];
 	int idx = st->max_idx;
 	int last = (int)(p.first_group % 12); // every chain has consumed first_group symbols
-	const float2* x = p.sym + (size_t)cidx * p.sym_stride;
+	const SymRow x(p.sym, cidx, p.sym_stride);
 	uint32_t* out = p.bits + (size_t)cidx * p.bits_stride;
 	uint32_t word = 0;
 	for (int g = 0; g < p.n_groups; g++) {
@@ -1681,7 +1681,7 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 	const int jj = k < 8 ? k : 15 - k;
 	const float pc = c_ps_phase[jj].x;
 	const float psn = k < 8 ? c_ps_phase[jj].y : -c_ps_phase[jj].y;
-	const float2* x = p.sym + (size_t)chain * p.sym_stride;
+	const SymRow x(p.sym, chain, p.sym_stride);
 	const int g0 = chunk * PS_CHUNK;
 	const int g1 = g0 + PS_CHUNK < p.n_groups ? g0 + PS_CHUNK : p.n_groups;
 	const size_t slot = (size_t)chain * p.n_chunks + chunk;
@@ -1779,7 +1779,10 @@ __global__ __launch_bounds__(64) void k4_phase_chunks(K4Params p) {
 	const int lane = threadIdx.x;
 	const int k = lane & 15, row = lane >> 4;
 	const int chunk = blockIdx.y;
-	const int chain_raw = blockIdx.x * 4 + row; // the four rows of a wave work on the same chunk: equal trip counts
+	// the four rows of a wave: the same sampling phase of four ADJACENT channels (their symbol pairs are 64 contiguous bytes in
+	// the SymRow layout) and the same chunk (equal trip counts)
+	const int j = blockIdx.x % 5, chan = (blockIdx.x / 5) * 4 + row;
+	const int chain_raw = chan * 5 + j;
 	const bool live = chain_raw < p.n_chains;
 	const int chain = live ? chain_raw : p.n_chains - 1;
 	const int rowbase = row * 16;
@@ -1941,10 +1944,10 @@ __device__ __forceinline__ PsWords ps_lane_words(const PsLane& st, const c2 (&T)
 constexpr int PSL_BATCH = 8;
 
 template <int N>
-__device__ __forceinline__ void ps_lane_load(const float2* x, c2 (&v)[N]) {
+__device__ __forceinline__ void ps_lane_load(const SymRow& x, int g, c2 (&v)[N]) { // g even
 #pragma unroll
 	for (int e = 0; e < N; e += 2) {
-		const float4 t = *reinterpret_cast<const float4*>(x + e);
+		const float4 t = *x.pair(g + e);
 		v[e] = c2{ t.x, t.y }; v[e + 1] = c2{ t.z, t.w };
 	}
 }
@@ -1966,7 +1969,7 @@ __global__ __launch_bounds__(64) void k4_lane_chunks(K4Params p, K4Params w) {
 	if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
 	else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
 	else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
-	const float2* x = p.sym + (size_t)chain * p.sym_stride;
+	const SymRow x(p.sym, chain, p.sym_stride);
 	// three planes (up, dn, x), time-major in groups of four symbols: uint4 [plane][g / 4][ma_stride]: this kernel's
 	// stores and k4_walk's loads are whole 1 KiB rows per wave
 	const size_t plane = (size_t)p.lw_quads * p.ma_stride;
@@ -1999,13 +2002,13 @@ __global__ __launch_bounds__(64) void k4_lane_chunks(K4Params p, K4Params w) {
 #pragma unroll 1
 		for (int g = ws; g < g0 - PSL_BATCH; g += PSL_BATCH) {
 			c2 v[PSL_BATCH];
-			ps_lane_load(x + g, v);
+			ps_lane_load(x, g, v);
 #pragma unroll
 			for (int e = 0; e < PSL_BATCH; e++) { c2 T[8]; ps_lane_ema(v[e], st, T); __builtin_amdgcn_sched_barrier(0); }
 		}
 		// ... and the decisions of its last four symbols
 		c2 v[PSL_BATCH];
-		ps_lane_load(x + g0 - PSL_BATCH, v);
+		ps_lane_load(x, g0 - PSL_BATCH, v);
 		unsigned dd[4];
 #pragma unroll
 		for (int e = 0; e < PSL_BATCH; e++) {
@@ -2026,12 +2029,12 @@ __global__ __launch_bounds__(64) void k4_lane_chunks(K4Params p, K4Params w) {
 	const int n = g1 - g0;
 	const int nb = n - (n % PSL_BATCH);
 	c2 cur[PSL_BATCH];
-	if (nb > 0) ps_lane_load(x + g0, cur);
+	if (nb > 0) ps_lane_load(x, g0, cur);
 #pragma unroll 1
 	for (int q = 0; q < nb; q += PSL_BATCH) {
 		c2 nxt[PSL_BATCH];
 		const int qn = q + PSL_BATCH < nb ? q + PSL_BATCH : q; // next batch in flight while this one is processed
-		ps_lane_load(x + g0 + qn, nxt);
+		ps_lane_load(x, g0 + qn, nxt);
 		PsWords wd[PSL_BATCH];
 #pragma unroll
 		for (int e = 0; e < PSL_BATCH; e++) {
@@ -2674,7 +2677,7 @@ hipError_t launch_k4(const K4Params& p, hipStream_t s) {
 	if (p.n_groups <= 0) return hipSuccess;
 	hipError_t e = hipMemsetAsync(p.flag, 0, sizeof(int), s);
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(k4_phase_chunks, dim3((p.n_chains + 3) / 4, p.n_chunks), dim3(64), 0, s, p);
+	hipLaunchKernelGGL(k4_phase_chunks, dim3((p.n_chains / 5 + 3) / 4 * 5, p.n_chunks), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(k4_assemble, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(k4_phase_search, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p, 1); // exits at once unless flagged
 	return hipGetLastError();
