@@ -122,7 +122,8 @@ struct aisgpu {
 	void* h_in = nullptr;
 	float2* h_rot[2] = {};
 	int* h_usidx[2] = {}; float* h_usalpha[2] = {};
-	hipEvent_t rot_ev[2] = {};
+	hipEvent_t rot_ev[2] = {}; bool rot_ev_used[2] = {}; bool rot_ahead = false; // (rot_ahead: the next block's table is already on its way)
+	bool rot_stage_ahead = true;
 	float2* h_rot_dev[2] = {}; bool rot_by_kernel = true; // device view of the pinned table buffers
 	uint32_t* h_bits = nullptr; float* h_lvl = nullptr; float* h_ppm = nullptr; // MAXSUB slots each
 	// stream state
@@ -879,6 +880,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->search_on_front = h->fused; // keeps the stream count at four
 	if (const char* e = getenv("AISGPU_SEARCH0")) h->search_on_front = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_DEFER_FUSED")) h->defer_fused = atoi(e) != 0;
+	if (const char* e = getenv("AISGPU_ROT_AHEAD")) h->rot_stage_ahead = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_GL")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0) h->GL = v; }
 	if (h->fused) {
 		const size_t cs = (C + 63) / 64 * 64;
@@ -1088,6 +1090,7 @@ int aisgpu_run(aisgpu_t* h) {
 		gen_rot_table(h, h->h_rot[pb]);
 		HIPCHK(hipMemcpyAsync(h->d_rot[pb], h->h_rot[pb], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
 		HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
+		h->rot_ev_used[pb] = true;
 		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[q], 0));
 		K1kParams kk;
 		kk.xin = xcur; kk.xin_stride = xstride; kk.xin_off = h->xh;
@@ -1102,13 +1105,23 @@ int aisgpu_run(aisgpu_t* h) {
 		const int q = (int)(h->block_idx % NBUF); // ring slot of c48 / fz / ppm / rotT
 		// the pinned phasor buffer `pb` was last used two blocks ago; wait until that upload has been consumed
 		// (only blocks when the host runs more than one block ahead of the device)
-		if (h->block_idx >= 2) HIPCHK(hipEventSynchronize(h->rot_ev[pb]));
-		gen_rot_table(h, h->h_rot[pb]);
-		// a small kernel pulls the table out of the pinned host buffer (a copy-engine transfer in the middle of the front
-		// stream costs its set-up latency between two kernels)
-		if (h->rot_by_kernel) HIPCHK(launch_copy_rows(h->h_rot_dev[pb], 0, h->d_rot[pb], 0, ROT_HIST + h->n96, 1, h->stream));
-		else HIPCHK(hipMemcpyAsync(h->d_rot[pb], h->h_rot[pb], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
-		HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
+		// The Rotate phasor table of this block: staged one block AHEAD on s3 (below), so that neither the 10 us copy nor its launch
+		// gap sits between two kernels of the front stream; only the first block (and the single-stream mode) stages it here.
+		const auto stage_rot = [&](int b, hipStream_t st) -> int {
+			// the pinned buffer `b` was last used two blocks ago; wait until that upload has been consumed (only blocks when the
+			// host runs more than one block ahead of the device)
+			if (h->rot_ev_used[b]) HIPCHK(hipEventSynchronize(h->rot_ev[b]));
+			gen_rot_table(h, h->h_rot[b]);
+			// a small kernel pulls the table out of the pinned host buffer (a copy-engine transfer costs its set-up latency)
+			if (h->rot_by_kernel) HIPCHK(launch_copy_rows(h->h_rot_dev[b], 0, h->d_rot[b], 0, ROT_HIST + h->n96, 1, st));
+			else HIPCHK(hipMemcpyAsync(h->d_rot[b], h->h_rot[b], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, st));
+			HIPCHK(hipEventRecord(h->rot_ev[b], st));
+			h->rot_ev_used[b] = true;
+			return AISGPU_OK;
+		};
+		if (!h->rot_ahead) { int rc = stage_rot(pb, h->stream); if (rc) return rc; }
+		else HIPCHK(hipStreamWaitEvent(h->stream, h->rot_ev[pb], 0));
+		h->rot_ahead = false;
 		// c48/fz/ppm[q] were last read by K2b/K2c of block f-NBUF
 		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[q], 0));
 		K1Params k1{};
@@ -1131,6 +1144,13 @@ int aisgpu_run(aisgpu_t* h) {
 		else if (from_pre) HIPCHK(launch_k1_tail(xcur, xstride * 8, (long long)h->n_pre * 8, h->d_hist2[hb ^ 1], h->tile_in * 8, R, h->stream));
 		else HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist[hb ^ 1],
 		                           h->tile_in * h->in_bytes, R, h->stream));
+		if (!h->serial && h->fused && h->rot_stage_ahead) {
+			// next block's table, on s3 in front of this block's phasor recurrence: d_rot[pb ^ 1] was last read by the front end of
+			// block f-1, which finished before the recurrence of block f-1 that precedes this copy on s3
+			int rc = stage_rot(pb ^ 1, h->s3);
+			if (rc) return rc;
+			h->rot_ahead = true;
+		}
 		int rc = enqueue_downstream(h, q, pb);
 		if (rc) return rc;
 	} else {
