@@ -146,6 +146,7 @@ struct aisgpu {
 	bool defer = true;
 	// device frame decoder (AISGPU_FLAG_GPU_DECODE)
 	bool gpu_decode = false; DecState* d_dec = nullptr; uint32_t* d_frames = nullptr; unsigned* d_frame_count = nullptr;
+	bool k7_event = true; uint32_t *d_k7ev = nullptr, *d_k7cnt = nullptr; uint16_t* d_k7open = nullptr; K7Slot* d_k7slot = nullptr; int* d_k7ovf = nullptr;
 	uint32_t* h_frames = nullptr; unsigned frames_seen = 0; int max_frames = 0; std::vector<aisgpu_frame> frames;
 	bool ps_box = false; PsBoxState* d_box[2] = {}; // Demod::PhaseSearch (boxcar) instead of PhaseSearchEMA
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
@@ -329,7 +330,11 @@ int enqueue_decode(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsi
 	k7.bits = h->d_bits[pb]; k7.bits_stride = h->words; k7.lvl = h->d_lvl[lv]; k7.lvl_stride = h->Gcap;
 	k7.state = h->d_dec; k7.frames = h->d_frames; k7.frame_count = h->d_frame_count; k7.max_frames = h->max_frames;
 	k7.first_group = g0; k7.n_groups = n_groups; k7.n_chan = h->n_chan; k7.block = block; k7.sub = sub;
-	HIPCHK(launch_k7(k7, s));
+	if (h->k7_event) { // event-driven decoders (kernels.h): same DecState between blocks, so the two can even alternate
+		K7eParams q;
+		q.k = k7; q.ev = h->d_k7ev; q.cnt = h->d_k7cnt; q.open_c = h->d_k7open; q.slot = h->d_k7slot; q.overflow = h->d_k7ovf;
+		HIPCHK(launch_k7e(q, s));
+	} else HIPCHK(launch_k7(k7, s));
 	return AISGPU_OK;
 }
 
@@ -530,6 +535,11 @@ int enqueue_downstream(aisgpu_t* h, int q, int pb) {
 int gather_frames(aisgpu_t* h) {
 	unsigned total = 0;
 	HIPCHK(hipMemcpy(&total, h->d_frame_count, sizeof total, hipMemcpyDeviceToHost));
+	if (h->k7_event) {
+		int ovf = 0;
+		HIPCHK(hipMemcpy(&ovf, h->d_k7ovf, sizeof ovf, hipMemcpyDeviceToHost));
+		if (ovf) { h->err = "event-driven frame decoder: more than K7E_OPENCAP frame starts in one block of one decoder (use AISGPU_K7=seq)"; return AISGPU_ERR_OVERFLOW; }
+	}
 	const unsigned fresh = total - h->frames_seen;
 	h->frames.clear();
 	if (fresh > (unsigned)h->max_frames) { h->err = "frame ring overflow: call aisgpu_sync_outputs() more often"; h->frames_seen = total; return AISGPU_ERR_OVERFLOW; }
@@ -868,6 +878,14 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		h->max_frames = (int)C * 64; // ring between two aisgpu_sync_outputs(): a slot holds ~2 frames per channel and block
 		HIPCHK(dalloc(&h->d_dec, (size_t)h->n_chains)); // zero = State::TRAINING, lastBit = prev = 0 (Marine/AIS.h:44-56)
 		HIPCHK(dalloc(&h->d_frames, (size_t)h->max_frames * DEC_FRAME_WORDS));
+		if (const char* e = getenv("AISGPU_K7")) h->k7_event = strcmp(e, "seq") != 0; // "seq": one lane per decoder, symbol by symbol
+		if (h->k7_event) {
+			HIPCHK(dalloc(&h->d_k7ev, (size_t)h->n_chains * K7E_EVCAP));
+			HIPCHK(dalloc(&h->d_k7cnt, (size_t)h->n_chains));
+			HIPCHK(dalloc(&h->d_k7open, (size_t)h->n_chains * K7E_OPENCAP));
+			HIPCHK(dalloc(&h->d_k7slot, (size_t)h->n_chains * K7E_OPENCAP));
+			HIPCHK(dalloc(&h->d_k7ovf, 4));
+		}
 		HIPCHK(dalloc(&h->d_frame_count, 1));
 		HIPCHK(hipHostMalloc((void**)&h->h_frames, (size_t)h->max_frames * DEC_FRAME_WORDS * sizeof(uint32_t), hipHostMallocDefault));
 	}
@@ -982,6 +1000,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
 	hipFree(h->d_box[0]); hipFree(h->d_box[1]);
 	hipFree(h->d_dec); hipFree(h->d_frames); hipFree(h->d_frame_count);
+	hipFree(h->d_k7ev); hipFree(h->d_k7cnt); hipFree(h->d_k7open); hipFree(h->d_k7slot); hipFree(h->d_k7ovf);
 	if (h->h_frames) hipHostFree(h->h_frames);
 	hipFree(h->d_fmprev[0]); hipFree(h->d_fmprev[1]);
 	hipFree(h->d_cgf); hipFree(h->d_omega); hipFree(h->d_step);

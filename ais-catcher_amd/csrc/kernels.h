@@ -155,6 +155,25 @@ struct K7Params {
 };
 hipError_t launch_k7(const K7Params& p, hipStream_t s);
 
+// K7e: the same decoders, event driven.  A decoder in TRAINING can only leave it where two equal NRZI bits follow at least five
+// alternations -- a pure function of the hard bits -- so the places where a frame could start are found bit-parallel (k7e_scan),
+// every possible frame is run from its start to its end by a lane of its own (k7e_sim: O(frame length) dependent steps instead
+// of O(block length)), and one lane per channel then decides, in the reference's time order, which of them really happened
+// (k7e_resolve: a frame is real if its decoder was in TRAINING long enough before it, and it is cut short by the Reset of a
+// sibling that completes a message first).  State between blocks is the same DecState as the sequential kernel's.
+constexpr int K7E_EVCAP = 1024;  // events per decoder and block (candidates are >= 6 symbols apart)
+constexpr int K7E_OPENCAP = 128; // frames run per decoder and block; more raise *overflow (use the sequential kernel for such input)
+struct K7Slot { int end, flags; DecState s; }; // flags: 1 found, 2 still running at the end of the block
+struct K7eParams {
+	K7Params k;
+	uint32_t* ev;        // [n_dec][K7E_EVCAP]  c | kind << 13 | (fail offset) << 15 | slot << 19
+	uint32_t* cnt;       // [n_dec]             events | runs << 16
+	uint16_t* open_c;    // [n_dec][K7E_OPENCAP] first symbol of run k (0xFFFF: the frame carried over from the previous block)
+	K7Slot* slot;        // [n_dec][K7E_OPENCAP]
+	int* overflow;
+};
+hipError_t launch_k7e(const K7eParams& p, hipStream_t s);
+
 // fmt (kernel numbering): 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16, 4 = CU8 through the fixed-point ladder (K = 4)
 hipError_t launch_k1(const K1Params& p, int K, int fmt, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s);
 hipError_t launch_k1u(const K1uParams& p, int n_rx, hipStream_t s);

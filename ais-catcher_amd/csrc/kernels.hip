@@ -2467,6 +2467,283 @@ __global__ __launch_bounds__(64) void k7_decode(K7Params p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K7e: event-driven frame decoders (see kernels.h).  Conventions: symbol g of decoder (chan, j) is bit g of its packed row;
+// Bit[g] = (dd[g] == dd[g-1]) is the NRZI bit, alt[g] = (Bit[g] != Bit[g-1]).  In TRAINING the reference counts consecutive
+// alternations in `position` and leaves for STARTFLAG at the first symbol with alt == 0 and position > 4 (Marine/AIS.h:109-119).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t K7E_CONT = 0xFFFFu;
+enum { K7E_FAIL = 0, K7E_RUN = 1 };
+
+__device__ __forceinline__ int k7e_training_pos(const DecState* st) { // alternations counted so far, only "> 4" ever matters
+	return st->state == DST_TRAINING ? (st->position < 5 ? st->position : 5) : 0;
+}
+
+// one lane per decoder: every candidate of the block, classified
+__global__ __launch_bounds__(64) void k7e_scan(K7eParams q) {
+	const K7Params& p = q.k;
+	__builtin_amdgcn_s_setprio(3); // a handful of latency-bound waves: they need their few issue slots at once
+	const int d = blockIdx.x * 64 + threadIdx.x;
+	if (d >= p.n_chan * 5) return;
+	const DecState* st = p.state + d;
+	const uint32_t* brow = p.bits + (size_t)d * p.bits_stride;
+	uint32_t* ev = q.ev + (size_t)d * K7E_EVCAP;
+	uint16_t* oc = q.open_c + (size_t)d * K7E_OPENCAP;
+	const int n = p.n_groups, nw = (n + 31) >> 5;
+	int nev = 0, nrun = 0;
+	if (st->state != DST_TRAINING) { // a frame (or a start flag) is in flight: it continues at symbol 0
+		ev[nev++] = 0u | (K7E_RUN << 13) | (0u << 19);
+		oc[nrun++] = (uint16_t)K7E_CONT;
+	}
+	// carry-in: dd[-1], Bit[-1] and the alternations counted so far (they are the last `position` symbols)
+	uint32_t prevD = st->prev ? 0x80000000u : 0u, prevB = st->lastBit ? 0x80000000u : 0u;
+	const int p5 = k7e_training_pos(st);
+	uint32_t prevA = p5 ? (0xFFFFFFFFu << (32 - p5)) : 0u;
+	// A candidate that fails in STARTFLAG only matters through the candidates of the same decoder it blocks (those up to five
+	// symbols behind its failing symbol) and through the alternation count at the end of the block; alone in the noise -- the
+	// usual case, one every ~64 symbols -- it has no effect whatever the siblings do, and is not even listed.
+	uint32_t pend = 0; int pend_until = -1; // the last FAIL event, not yet written: listed only if something falls inside its shadow
+	const auto flush_pend = [&](int next_c) {
+		if (pend_until >= 0 && next_c < pend_until) { if (nev < K7E_EVCAP) ev[nev++] = pend; else atomicOr(q.overflow, 2); }
+		pend_until = -1;
+	};
+	constexpr int PF = 8; // words fetched together
+	uint32_t buf[PF + 1];
+#pragma unroll
+	for (int e = 0; e <= PF; e++) buf[e] = e < nw ? brow[e] : 0u;
+	for (int w = 0; w < nw; w++) {
+		const int bi = w % PF;
+		if (bi == 0 && w > 0) {
+#pragma unroll
+			for (int e = 0; e <= PF; e++) buf[e] = w + e < nw ? brow[w + e] : 0u;
+		}
+		uint32_t D = 0, Dn = 0;
+#pragma unroll
+		for (int e = 0; e < PF; e++) if (e == bi) { D = buf[e]; Dn = buf[e + 1]; }
+		const uint32_t B = ~(D ^ ((D << 1) | (prevD >> 31)));
+		const uint32_t A = B ^ ((B << 1) | (prevB >> 31));
+		const int nv = n - 32 * w < 32 ? n - 32 * w : 32; // valid symbols in this word
+		const uint32_t valid = nv < 32 ? ((1u << nv) - 1u) : 0xFFFFFFFFu;
+		const unsigned long long X = ((unsigned long long)A << 32) | prevA;
+		const unsigned long long R = X & (X >> 1) & (X >> 2) & (X >> 3) & (X >> 4);
+		uint32_t cand = ~A & (uint32_t)(R >> 27) & valid; // alt == 0 with the five symbols before it all alternating
+		if (cand) {
+			const uint32_t Bn = ~(Dn ^ ((Dn << 1) | (D >> 31)));
+			const unsigned long long BB = ((unsigned long long)Bn << 32) | B;
+			while (cand) {
+				const int i = __builtin_ctz(cand);
+				cand &= cand - 1;
+				const int c = 32 * w + i;
+				// STARTFLAG (AIS.h:121-141): entered with position 3 (Bit == 1) or 1 (Bit == 0); ones up to position 7, then a zero
+				const int need = ((BB >> i) & 1ull) ? 4 : 6;
+				const unsigned long long seq = BB >> (i + 1);
+				int t = __builtin_ctzll(~seq); // ones that follow the candidate (at most 31 - ... are looked at: need <= 6)
+				t = t < 8 ? t : 8;
+				const int avail = n - (c + 1); // symbols of this block behind the candidate
+				int kind, off = 0;
+				if (t < need) { // a zero where a one was needed, at c + 1 + t
+					if (t < avail) { kind = K7E_FAIL; off = 1 + t; } else kind = K7E_RUN; // (not decided inside this block)
+				} else if (need < avail) { // the symbol at position 7 exists: it must be a zero
+					if (t == need) kind = K7E_RUN; else { kind = K7E_FAIL; off = 1 + need; }
+				} else kind = K7E_RUN;
+				int slot = 0;
+				if (kind == K7E_RUN) {
+					if (nrun < K7E_OPENCAP) { slot = nrun; oc[nrun++] = (uint16_t)c; } else { atomicOr(q.overflow, 1); kind = K7E_FAIL; off = 1; }
+				}
+				const uint32_t e32 = (uint32_t)c | ((uint32_t)kind << 13) | ((uint32_t)off << 15) | ((uint32_t)slot << 19);
+				flush_pend(c);
+				if (kind == K7E_FAIL) { pend = e32; pend_until = c + off + 6; }
+				else if (nev < K7E_EVCAP) ev[nev++] = e32;
+				else atomicOr(q.overflow, 2);
+			}
+		}
+		prevD = D; prevB = B; prevA = A;
+	}
+	flush_pend(pend_until > n ? n : 1 << 30); // (kept if its shadow reaches past the end of the block)
+	q.cnt[d] = (uint32_t)nev | ((uint32_t)nrun << 16);
+}
+
+// one lane per (decoder, run): the reference's state machine from the candidate (or from the carried state) until it is back in
+// TRAINING, has completed a message, or the block ends
+__global__ __launch_bounds__(64) void k7e_sim(K7eParams q) {
+	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64]; // [word][lane]
+	const K7Params& p = q.k;
+	__builtin_amdgcn_s_setprio(3);
+	const int lane = threadIdx.x;
+	const int d = blockIdx.x * 8 + (lane >> 3); // eight lanes per decoder take its runs round robin
+	const int n_dec = p.n_chan * 5;
+	const int dd_ = d < n_dec ? d : 0;
+	const int nrun = d < n_dec ? (int)(q.cnt[dd_] >> 16) : 0;
+	const int chan = dd_ / 5, j = dd_ - 5 * chan;
+	const DecState* st = p.state + dd_;
+	const uint32_t* brow = p.bits + (size_t)dd_ * p.bits_stride;
+	const float* lrow = p.lvl + (size_t)chan * p.lvl_stride;
+	uint32_t* data = fdata + lane;
+	const int n = p.n_groups;
+	const auto dd_at = [&](int g) -> int { return g < 0 ? st->prev : (int)((brow[g >> 5] >> (g & 31)) & 1u); };
+	for (int k = lane & 7; __any(k < nrun); k += 8) {
+		const bool act = k < nrun;
+		const uint32_t c0 = act ? q.open_c[(size_t)dd_ * K7E_OPENCAP + k] : 0u;
+		const bool cont = c0 == K7E_CONT;
+		const int c = cont ? 0 : (int)c0;
+		DecReg r;
+		if (cont) {
+			r.state = st->state; r.lastBit = st->lastBit; r.prev = st->prev; r.position = st->position; r.osc = st->osc;
+			r.level = st->level; r.start_idx = st->start_idx;
+			for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = st->data[w];
+			r.crc = st->crc[0]; r.cw = st->crc[1]; r.cwi = (int)st->crc[2]; r.tail = st->crc[3]; r.abort_pos = (int)st->crc[4];
+		} else {
+			r.state = DST_TRAINING; r.position = 5; r.osc = 0; r.level = 0.0f; r.start_idx = 0;
+			r.prev = dd_at(c - 1);
+			r.lastBit = c - 1 < 0 ? st->lastBit : (dd_at(c - 1) == (c - 2 < 0 ? st->prev : dd_at(c - 2)));
+			for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = 0u;
+			r.crc = 0xFFFFu; r.cw = 0u; r.cwi = 0; r.tail = 0u; r.abort_pos = 0;
+		}
+		bool running = act;
+		int g = c, end = n, flags = 2; // (2: still running when the block ends)
+		while (__any(running)) {
+			// eight symbols per round: their levels and decisions are fetched together (a step that waits for its own loads
+			// is pure memory latency)
+			float lv[8];
+			const int gc = g < n ? g : n - 1;
+			const uint32_t w0 = brow[gc >> 5], w1 = brow[(gc + 7 < n ? gc + 7 : n - 1) >> 5];
+#pragma unroll
+			for (int e = 0; e < 8; e++) lv[e] = lrow[g + e < n ? g + e : n - 1];
+#pragma unroll
+			for (int e = 0; e < 8; e++) {
+				if (running) {
+					if (g >= n) running = false;
+					else {
+						const uint32_t word = (g >> 5) == (gc >> 5) ? w0 : w1;
+						const int dbit = (int)((word >> (g & 31)) & 1u);
+						const bool found = dec_step(r, dbit, lv[e], 5 * (p.first_group + g) + j, data);
+						if (found) { end = g; flags = 1; running = false; }
+						else if (r.state == DST_TRAINING) { end = g; flags = 0; running = false; }
+						g++;
+					}
+				}
+			}
+		}
+		if (act) {
+			K7Slot* sl = q.slot + (size_t)d * K7E_OPENCAP + k;
+			sl->end = end; sl->flags = flags;
+			if (flags != 0) { // a message (position / level / start_idx / data are the frame's) or the state to carry on with
+				DecState* o = &sl->s;
+				o->state = r.state; o->lastBit = r.lastBit; o->prev = r.prev; o->position = r.position; o->osc = r.osc;
+				o->level = r.level; o->start_idx = r.start_idx;
+				if (flags == 2) data[64 * r.cwi] = r.cw;
+				for (int w = 0; w < DEC_DATA_WORDS; w++) o->data[w] = data[64 * w];
+				o->crc[0] = r.crc; o->crc[1] = r.cw; o->crc[2] = (uint32_t)r.cwi; o->crc[3] = r.tail; o->crc[4] = (uint32_t)r.abort_pos;
+			}
+		}
+	}
+}
+
+// One lane per decoder, the five lanes of a channel walk together: which of the runs really happened, in the order in which the
+// reference runs its five decoders (symbol by symbol, phase 0..4 within a group), with the Reset a decoder sends its siblings
+// when it completes a message.  Per round every lane offers the time of its next event (the start of its next candidate, or the
+// end of the run it is in), the channel's earliest one is processed by its owner, and a completed message is broadcast.
+__global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
+	const K7Params& p = q.k;
+	__builtin_amdgcn_s_setprio(3); // a handful of latency-bound waves: they need their few issue slots at once
+	const int lane = threadIdx.x;
+	const int mesh = lane / 5, j = lane - 5 * mesh; // lanes 60..63 idle
+	const int chan_raw = blockIdx.x * 12 + mesh;
+	const bool live = lane < 60 && chan_raw < p.n_chan;
+	const int d = (live ? chan_raw : 0) * 5 + (live ? j : 0);
+	const int base = 5 * mesh;
+	const int n = p.n_groups;
+	constexpr int INF = 1 << 26;
+	DecState* st = p.state + d;
+	const int state0 = st->state, prev0 = st->prev, last0 = st->lastBit, pos0 = k7e_training_pos(st);
+	const uint32_t* evd = q.ev + (size_t)d * K7E_EVCAP;
+	const K7Slot* slots = q.slot + (size_t)d * K7E_OPENCAP;
+	const int nev = live ? (int)(q.cnt[d] & 0xFFFFu) : 0;
+	int ptr = 0, free_at = state0 == DST_TRAINING ? 5 - pos0 : 0, end_ = INF, slot_ = 0;
+	bool busy = false, fnd = false;
+	uint32_t head = ptr < nev ? evd[0] : 0xFFFFFFFFu;
+	for (;;) {
+		const int t = busy ? end_ : (head != 0xFFFFFFFFu ? (int)(head & 0x1FFFu) : INF);
+		const int key = live && t < n ? t * 8 + j : INF * 8; // (equal groups: the lower phase first)
+		int mk = key;
+#pragma unroll
+		for (int o = 1; o < 5; o++) {
+			const int other = __shfl(key, base + (j + o) % 5);
+			mk = other < mk ? other : mk;
+		}
+		if (!__any(mk < INF * 8)) break; // (runs that are still going at the end of the block stay busy)
+		const bool mine = live && key == mk && mk < INF * 8;
+		int bcast = -1; // a completed message: (group << 3) | phase, told to the siblings
+		if (mine) {
+			if (!busy) { // a candidate: real only if the decoder has been counting alternations for five symbols
+				const uint32_t e = head;
+				ptr++;
+				const int c = (int)(e & 0x1FFFu), kind = (int)((e >> 13) & 3u), off = (int)((e >> 15) & 15u), sl = (int)(e >> 19);
+				if (c >= free_at) {
+					busy = true; slot_ = sl;
+					if (kind == K7E_FAIL) { end_ = c + off; fnd = false; }
+					else {
+						const int2 ef = *reinterpret_cast<const int2*>(slots + sl); // (end, flags)
+						fnd = (ef.y & 1) != 0;
+						end_ = (ef.y & 2) ? INF : ef.x;
+					}
+				}
+				head = ptr < nev ? evd[ptr] : 0xFFFFFFFFu;
+			} else {
+				const int e = end_;
+				busy = false;
+				free_at = e + 6; // back in TRAINING with position 0 at symbol e
+				if (fnd) {
+					const K7Slot* s = slots + slot_;
+					const unsigned fs = atomicAdd(p.frame_count, 1u) % (unsigned)p.max_frames;
+					uint32_t* f = p.frames + (size_t)fs * DEC_FRAME_WORDS;
+					const long long sidx = 5 * (p.first_group + e) + j;
+					f[0] = (uint32_t)d; f[1] = (uint32_t)e; f[2] = (uint32_t)s->s.position; f[3] = __float_as_uint(s->s.level);
+					f[4] = (uint32_t)(unsigned long long)s->s.start_idx; f[5] = (uint32_t)((unsigned long long)s->s.start_idx >> 32);
+					f[6] = (uint32_t)(unsigned long long)sidx; f[7] = (uint32_t)((unsigned long long)sidx >> 32);
+					f[8] = p.block; f[9] = p.sub;
+					for (int w = 0; w < DEC_DATA_WORDS; w++) f[10 + w] = s->s.data[w];
+					bcast = (e << 3) | j;
+				}
+			}
+		}
+		// Reset to the siblings (AIS.cpp:47-49): the phases behind the finder are reset BEFORE their step of that group
+		const int owner = base + (mk & 7);
+		const int msg = __shfl(bcast, mk < INF * 8 ? owner : lane);
+		if (live && !mine && msg >= 0) {
+			const int e = msg >> 3, jw = msg & 7;
+			const int fa = e + (j > jw ? 5 : 6);
+			if (busy) { busy = false; free_at = fa; }
+			else if (fa > free_at) free_at = fa;
+		}
+	}
+	if (!live) return;
+	// state for the next block
+	if (busy) { // the run that is still going: its state as k7e_sim left it
+		*st = slots[slot_].s;
+		return;
+	}
+	// TRAINING: lastBit, prev and the alternations counted (those that end at the last symbol, none before the restart)
+	const uint32_t* brow = p.bits + (size_t)d * p.bits_stride;
+	const int nw = (n + 31) >> 5;
+	const uint32_t wl = nw > 0 ? brow[nw - 1] : 0u, wp = nw > 1 ? brow[nw - 2] : 0u; // the last 33+ decisions, fetched once
+	const auto dd_at = [&](int g) -> int {
+		if (g < 0) return prev0;
+		return (int)(((g >> 5) == nw - 1 ? wl : wp) >> (g & 31)) & 1;
+	};
+	const auto bit_at = [&](int g) -> int { return g < 0 ? last0 : (dd_at(g) == dd_at(g - 1)); }; // (g >= -1 only)
+	int run = 0;
+	for (int g = n - 1; run < 5; g--) {
+		if (g < 0) { run += pos0 < 5 - run ? pos0 : 5 - run; break; } // the alternations carried in from the block before
+		if (bit_at(g) == bit_at(g - 1)) break;
+		run++;
+	}
+	int lim = n + 5 - free_at; // symbols since position was last set to zero
+	lim = lim < 0 ? 0 : lim;
+	st->state = DST_TRAINING; st->position = run < lim ? run : lim; st->osc = 0;
+	st->lastBit = n > 0 ? bit_at(n - 1) : last0; st->prev = n > 0 ? dd_at(n - 1) : prev0;
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 template <int K, int P, int D, int NT, bool CU8, bool PRE>
@@ -2652,6 +2929,15 @@ hipError_t launch_k3(const K3Params& p, int n_chan, hipStream_t s) {
 
 hipError_t launch_k7(const K7Params& p, hipStream_t s) {
 	hipLaunchKernelGGL(k7_decode, dim3((p.n_chan + 11) / 12), dim3(64), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_k7e(const K7eParams& q, hipStream_t s) {
+	const int n_dec = q.k.n_chan * 5;
+	if (q.k.n_groups <= 0) return hipSuccess;
+	hipLaunchKernelGGL(k7e_scan, dim3((n_dec + 63) / 64), dim3(64), 0, s, q);
+	hipLaunchKernelGGL(k7e_sim, dim3((n_dec + 7) / 8), dim3(64), 0, s, q);
+	hipLaunchKernelGGL(k7e_resolve, dim3((q.k.n_chan + 11) / 12), dim3(64), 0, s, q);
 	return hipGetLastError();
 }
 
