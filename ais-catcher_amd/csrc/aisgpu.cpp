@@ -146,6 +146,7 @@ struct aisgpu {
 	bool defer = true;
 	// device frame decoder (AISGPU_FLAG_GPU_DECODE)
 	bool gpu_decode = false; DecState* d_dec = nullptr; uint32_t* d_frames = nullptr; unsigned* d_frame_count = nullptr;
+	bool k7_alt = false; // test hook (AISGPU_K7=alt): the two decoder implementations take turns, block by block, on the same DecState
 	bool k7_event = true; uint32_t *d_k7ev = nullptr, *d_k7cnt = nullptr; uint16_t* d_k7open = nullptr; K7Slot* d_k7slot = nullptr; int* d_k7ovf = nullptr;
 	uint32_t* h_frames = nullptr; unsigned frames_seen = 0; int max_frames = 0; std::vector<aisgpu_frame> frames;
 	bool ps_box = false; PsBoxState* d_box[2] = {}; // Demod::PhaseSearch (boxcar) instead of PhaseSearchEMA
@@ -330,7 +331,7 @@ int enqueue_decode(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsi
 	k7.bits = h->d_bits[pb]; k7.bits_stride = h->words; k7.lvl = h->d_lvl[lv]; k7.lvl_stride = h->Gcap;
 	k7.state = h->d_dec; k7.frames = h->d_frames; k7.frame_count = h->d_frame_count; k7.max_frames = h->max_frames;
 	k7.first_group = g0; k7.n_groups = n_groups; k7.n_chan = h->n_chan; k7.block = block; k7.sub = sub;
-	if (h->k7_event) { // event-driven decoders (kernels.h): same DecState between blocks, so the two can even alternate
+	if (h->k7_event && !(h->k7_alt && (block & 1))) { // event-driven decoders (kernels.h): same DecState between blocks, so the two can even alternate
 		K7eParams q;
 		q.k = k7; q.ev = h->d_k7ev; q.cnt = h->d_k7cnt; q.open_c = h->d_k7open; q.slot = h->d_k7slot; q.overflow = h->d_k7ovf;
 		HIPCHK(launch_k7e(q, s));
@@ -878,7 +879,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		h->max_frames = (int)C * 64; // ring between two aisgpu_sync_outputs(): a slot holds ~2 frames per channel and block
 		HIPCHK(dalloc(&h->d_dec, (size_t)h->n_chains)); // zero = State::TRAINING, lastBit = prev = 0 (Marine/AIS.h:44-56)
 		HIPCHK(dalloc(&h->d_frames, (size_t)h->max_frames * DEC_FRAME_WORDS));
-		if (const char* e = getenv("AISGPU_K7")) h->k7_event = strcmp(e, "seq") != 0; // "seq": one lane per decoder, symbol by symbol
+		if (const char* e = getenv("AISGPU_K7")) { h->k7_event = strcmp(e, "seq") != 0; h->k7_alt = strcmp(e, "alt") == 0; } // "seq": one lane per decoder, symbol by symbol
 		if (h->k7_event) {
 			HIPCHK(dalloc(&h->d_k7ev, (size_t)h->n_chains * K7E_EVCAP));
 			HIPCHK(dalloc(&h->d_k7cnt, (size_t)h->n_chains));

@@ -606,6 +606,16 @@ def test_gpu_frame_decoder_behind_the_deferred_walk(monkeypatch):
     test_gpu_frame_decoder_nmea(131072, 16, "cu8")
 
 
+@pytest.mark.parametrize("mode", ["seq", "alt"])
+def test_gpu_frame_decoder_implementations_share_their_state(mode, monkeypatch):
+    """AISGPU_K7=seq: the symbol-by-symbol kernel; alt: event-driven and sequential kernels take turns block by block on the same
+    DecState (training counts, start flags and frames in flight cross the block boundaries in both directions)."""
+    monkeypatch.setenv("AISGPU_K7", mode)
+    test_gpu_frame_decoder_nmea(16384, 96, "cf32")
+    test_gpu_frame_decoder_nmea(131072, 16, "cu8")
+    test_gpu_frame_decoder_nmea(786432, 4, "cf32")
+
+
 def test_gpu_frame_decoder_matches_host_decoders_on_a_batch():
     """8 receivers, noisy weak signals (many false trainings, aborted and CRC-failing frames): device decoders == host decoders."""
     from ais_catcher_amd import host
