@@ -572,6 +572,8 @@ __device__ __forceinline__ void wave_sync() {
 // 4 = CU8 through the fixed-point ladder Downsample16_CU8 (K = 4 only)
 constexpr int fmt_bytes(int fmt) { return fmt == 0 ? 8 : fmt == 3 ? 4 : 2; }
 
+__device__ __forceinline__ void k1_fft_tail(const K1Params& p, int rx, int span, float2* X); // below, with the FFT
+
 template <int K, int FMT, bool PRE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4))) void k1_dpp(K1Params p) {
 	constexpr int C0 = 1 << K;        // input samples per lane per tile
@@ -581,6 +583,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 	__shared__ __attribute__((aligned(16))) float4 xt[DMA ? 64 * W4 : 1]; // the tile, linear, XOR-swizzled in units of 16 B
 	__shared__ __attribute__((aligned(16))) float2 x5[2][8 + 64];  // rotated up/down with 8 samples of history
 	__shared__ __attribute__((aligned(16))) float2 x6[2][8 + 32];  // DS2_a/b output
+	constexpr bool XFFT_IN_XT = DMA && K == 4; // the FFT tail's exchange buffer (4.7 KB) reuses the tile buffer where that is big enough
+	__shared__ __attribute__((aligned(16))) float2 xfft[(PRE || XFFT_IN_XT) ? 1 : 584];
 	const int lane = threadIdx.x;
 	const int rx = blockIdx.y;
 	const int span = blockIdx.x;
@@ -731,6 +735,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 			if (lane < 8) { x5[0][lane] = x5[0][64 + lane]; x5[1][lane] = x5[1][64 + lane]; }
 			else if (lane < 16) { x6[0][lane - 8] = x6[0][32 + lane - 8]; x6[1][lane - 8] = x6[1][32 + lane - 8]; }
 		}
+	}
+	if constexpr (!PRE) {
+		if (p.fft_windows > 0) k1_fft_tail(p, rx, span, XFFT_IN_XT ? reinterpret_cast<float2*>(xt) : xfft);
 	}
 }
 
@@ -947,8 +954,23 @@ constexpr int MAG_STRIDE = 512 + 64 / FFT_NW;   // floats; 64/NW (mod 64) banks 
 
 // twiddle o with its rotated copy (-o.y, o.x): o * c = c.xx * o + c.yy * (-o.y, o.x) = (o.x c.x - o.y c.y, o.x c.y + o.y c.x),
 // the same two products and one addition per component as std::complex's operator* (x - y == x + (-y) exactly)
+// FFT_SLIM (default): only o stays in registers and the rotated copy is rebuilt where it is used (two sign/move operations per
+// twiddle and window): 96 instead of 124 VGPRs, so that a wave of this kernel still fits on a SIMD that already holds a
+// derotation/FIR wave and three PhaseSearch waves (it sits on the front stream: whatever delays it delays the next front end).
+#ifndef FFT_SLIM
+#define FFT_SLIM 1
+#endif
+#if FFT_SLIM
+struct Tw { c2 o; };
+__device__ __forceinline__ Tw make_tw(float2 o) { return Tw{ c2{ o.x, o.y } }; }
+__device__ __forceinline__ c2 cmul_tw(const Tw& w, c2 c) { const c2 r = c2{ -w.o.y, w.o.x }; return c.xx * w.o + c.yy * r; }
+__device__ __forceinline__ void tw_pin(Tw& w) { asm volatile("" : "+v"(w.o)); } // keeps the rotated copy from being hoisted out of the window loop
+#else
 struct Tw { c2 o, r; };
+__device__ __forceinline__ Tw make_tw(float2 o) { return Tw{ c2{ o.x, o.y }, c2{ -o.y, o.x } }; }
 __device__ __forceinline__ c2 cmul_tw(const Tw& w, c2 c) { return c.xx * w.o + c.yy * w.r; }
+__device__ __forceinline__ void tw_pin(Tw&) {}
+#endif
 
 // three radix-2 stages on the 8 points of a lane; tw0: twiddle of the first stage (all 4 butterflies), tw1[b]:
 // second stage for local index bit 0 = b, tw2[c]: third stage for local index bits (1,0) = c
@@ -999,54 +1021,91 @@ __global__ void k_selftest_hypot(const float2* in, int n, unsigned* mismatches) 
 	if (__float_as_uint(a) != __float_as_uint(b)) atomicAdd(mismatches, 1u);
 }
 
+// the lane-dependent twiddles of the three register passes (pass 1's are the same for every lane: scalar loads)
+struct FftTwiddles { Tw a0, a1[2], a2[4], b0, b1[2], b2[4], c0, c1[2], c2_[4]; };
+__device__ __forceinline__ FftTwiddles fft_twiddles(const float2* omega, int lane) {
+	const int l7 = lane & 7;
+	const auto tw = [&](int idx) { return make_tw(omega[idx]); };
+	FftTwiddles t;
+	t.a0 = tw(0); t.a1[0] = tw(0); t.a1[1] = tw(128); t.a2[0] = tw(0); t.a2[1] = tw(64); t.a2[2] = tw(128); t.a2[3] = tw(192);
+	t.b0 = tw(l7 << 5); t.b1[0] = tw(l7 << 4); t.b1[1] = tw((l7 + 8) << 4);
+	t.b2[0] = tw(l7 << 3); t.b2[1] = tw((l7 + 8) << 3); t.b2[2] = tw((l7 + 16) << 3); t.b2[3] = tw((l7 + 24) << 3);
+	t.c0 = tw(lane << 2); t.c1[0] = tw(lane << 1); t.c1[1] = tw((lane + 64) << 1);
+	t.c2_[0] = tw(lane); t.c2_[1] = tw(lane + 64); t.c2_[2] = tw(lane + 128); t.c2_[3] = tw(lane + 192);
+	return t;
+}
+// lane's sample r of a window: bit-reversed storage (DSP.cpp:480): position 8*lane + r <- sample brev6(lane) + 64*brev3(r)
+__device__ __forceinline__ int fft_src_lane(int lane) { return (int)(__brev((unsigned)lane) >> 26); }
+__device__ __forceinline__ int fft_src_step(int r) { return 64 * (((r & 1) << 2) | (r & 2) | (r >> 2)); }
+
+// One 512-point window by one wave: v[r] holds the lane's 8 squared samples on entry, m[r] = |X[lane + 64 r]| on exit.
+// X: 584 float2 of wave-private LDS.  A one-wave workgroup orders its LDS exchanges with wavefront-scope fences (wave_sync);
+// __syncthreads() would also wait for whatever global loads the caller has in flight.
+__device__ __forceinline__ void fft512_mag(c2 (&v)[8], float2* X, FftTwiddles& t, int lane, float (&m)[8]) {
+	const int l7 = lane & 7, l8 = lane >> 3;
+	tw_pin(t.b0); tw_pin(t.b1[0]); tw_pin(t.b1[1]); tw_pin(t.c0); tw_pin(t.c1[0]); tw_pin(t.c1[1]);
+#pragma unroll
+	for (int r = 0; r < 4; r++) { tw_pin(t.b2[r]); tw_pin(t.c2_[r]); }
+	fft_pass(v, t.a0, t.a1, t.a2); // stages 0-2: position 8*lane + r
+#pragma unroll
+	for (int r = 0; r < 8; r++) X[9 * lane + r] = make_float2(v[r].x, v[r].y); // index P + (P >> 3)
+	wave_sync();
+#pragma unroll
+	for (int r = 0; r < 8; r++) { const float2 d = X[l7 + 9 * r + 72 * l8]; v[r] = c2{ d.x, d.y }; }
+	wave_sync();
+	fft_pass(v, t.b0, t.b1, t.b2); // stages 3-5: position l7 + 8*r + 64*l8
+#pragma unroll
+	for (int r = 0; r < 8; r++) X[l7 + 8 * r + 72 * l8] = make_float2(v[r].x, v[r].y); // index P + 8 * (P >> 6)
+	wave_sync();
+#pragma unroll
+	for (int r = 0; r < 8; r++) { const float2 d = X[lane + 72 * r]; v[r] = c2{ d.x, d.y }; }
+	wave_sync();
+	fft_pass(v, t.c0, t.c1, t.c2_); // stages 6-8: bin lane + 64*r
+#pragma unroll
+	for (int r = 0; r < 8; r++) m[r] = hypot_bins(v[r].x, v[r].y);
+}
+__device__ __forceinline__ void fft_square(const float2 (&d)[8], c2 (&v)[8]) {
+#pragma unroll
+	for (int r = 0; r < 8; r++) v[r] = c2{ d[r].x * d[r].x - d[r].y * d[r].y, d[r].x * d[r].y + d[r].y * d[r].x }; // data[i] * data[i]
+}
+
 __global__ __launch_bounds__(64) void k2_fft_mag(K2Params p) {
 	__shared__ __attribute__((aligned(16))) float2 X[584];
 	__shared__ __attribute__((aligned(16))) float mag[FFT_NW * MAG_STRIDE];
 
 	__builtin_amdgcn_s_setprio(1);
-	const int lane = threadIdx.x, l7 = lane & 7, l8 = lane >> 3;
+	const int lane = threadIdx.x;
 	const int W0 = blockIdx.x * FFT_NW, n_win_total = p.n_chan * p.n_windows;
-	const auto tw = [&](int idx) { const float2 o = p.omega[idx]; return Tw{ c2{ o.x, o.y }, c2{ -o.y, o.x } }; };
+	FftTwiddles t = fft_twiddles(p.omega, lane);
+	const int src = fft_src_lane(lane);
 
-	// pass 1 twiddles are the same for every lane (scalar loads); passes 2 and 3 depend on the lane
-	const Tw a0 = tw(0), a1[2] = { tw(0), tw(128) }, a2[4] = { tw(0), tw(64), tw(128), tw(192) };
-	const Tw b0 = tw(l7 << 5), b1[2] = { tw(l7 << 4), tw((l7 + 8) << 4) };
-	const Tw b2[4] = { tw(l7 << 3), tw((l7 + 8) << 3), tw((l7 + 16) << 3), tw((l7 + 24) << 3) };
-	const Tw c0 = tw(lane << 2), c1[2] = { tw(lane << 1), tw((lane + 64) << 1) };
-	const Tw c2_[4] = { tw(lane), tw(lane + 64), tw(lane + 128), tw(lane + 192) };
-	const int src = (int)(__brev((unsigned)lane) >> 26); // bit-reversed storage (DSP.cpp:480): position 8*lane + r <- sample brev6(lane) + 64*brev3(r)
-
+	// the 8 samples of a lane for window W0 + wi; the next window's are requested before this one's butterflies start, so the
+	// wave (there are only one or two per SIMD: LDS) does not sit through a memory round trip per window
+	float2 dn[8];
+	const auto fetch = [&](int wi) {
+		int W = W0 + wi;
+		W = W < n_win_total ? W : n_win_total - 1;
+		const int chan = W / p.n_windows, w = W - chan * p.n_windows;
+		const float2* x = p.c48 + (size_t)chan * p.c48_stride + (size_t)w * 512 + src;
+#pragma unroll
+		for (int r = 0; r < 8; r++) dn[r] = x[fft_src_step(r)];
+	};
+	fetch(0);
 	for (int wi = 0; wi < FFT_NW; wi++) {
 		const int W = W0 + wi;
 		if (W >= n_win_total) break;
-		const int chan = W / p.n_windows, w = W - chan * p.n_windows;
-		const float2* x = p.c48 + (size_t)chan * p.c48_stride + (size_t)w * 512 + src;
 		c2 v[8];
-#pragma unroll
-		for (int r = 0; r < 8; r++) {
-			const float2 d = x[64 * (((r & 1) << 2) | (r & 2) | (r >> 2))];
-			v[r] = c2{ d.x * d.x - d.y * d.y, d.x * d.y + d.y * d.x }; // data[i] * data[i]
-		}
-		fft_pass(v, a0, a1, a2); // stages 0-2: position 8*lane + r
-#pragma unroll
-		for (int r = 0; r < 8; r++) X[9 * lane + r] = make_float2(v[r].x, v[r].y); // index P + (P >> 3)
-		__syncthreads();
-#pragma unroll
-		for (int r = 0; r < 8; r++) { const float2 d = X[l7 + 9 * r + 72 * l8]; v[r] = c2{ d.x, d.y }; }
-		__syncthreads();
-		fft_pass(v, b0, b1, b2); // stages 3-5: position l7 + 8*r + 64*l8
-#pragma unroll
-		for (int r = 0; r < 8; r++) X[l7 + 8 * r + 72 * l8] = make_float2(v[r].x, v[r].y); // index P + 8 * (P >> 6)
-		__syncthreads();
-#pragma unroll
-		for (int r = 0; r < 8; r++) { const float2 d = X[lane + 72 * r]; v[r] = c2{ d.x, d.y }; }
-		__syncthreads();
-		fft_pass(v, c0, c1, c2_); // stages 6-8: bin lane + 64*r
+		fft_square(dn, v);
+		__builtin_amdgcn_sched_barrier(0); // (the scheduler would otherwise sink the requests to the end of the iteration)
+		if (wi + 1 < FFT_NW) fetch(wi + 1);
+		__builtin_amdgcn_sched_barrier(0);
+		float m[8];
+		fft512_mag(v, X, t, lane, m);
 		float* mg = mag + wi * MAG_STRIDE;
 #pragma unroll
-		for (int r = 0; r < 8; r++) mg[(lane + 64 * r + 256) & 511] = hypot_bins(v[r].x, v[r].y);
+		for (int r = 0; r < 8; r++) mg[(lane + 64 * r + 256) & 511] = m[r];
 	}
-	__syncthreads();
+	wave_sync();
 	// transposed store: 64/NW bins x NW windows per instruction, 4*NW contiguous bytes per bin
 	const int wl = lane % FFT_NW, qs = lane / FFT_NW;
 	const int W = W0 + wl;
@@ -1058,6 +1117,66 @@ __global__ __launch_bounds__(64) void k2_fft_mag(K2Params p) {
 			const int q = it * (64 / FFT_NW) + qs;
 			dst[(size_t)q * 64] = mg[q];
 		}
+	}
+}
+
+// The same analysis riding at the end of a front-end wave (k1_dpp): a span of tiles_per_span tiles is tiles_per_span * 32
+// samples of each 48 kHz channel, i.e. p.fft_windows whole windows per channel, all of them written by this very wave a moment
+// ago (they come back from L2).  The spectral analysis then costs no kernel of its own on the front stream -- where it used to
+// take 0.05 ms alone and 0.11-0.20 ms next to the back end of the previous block -- and its arithmetic fills issue slots of a
+// kernel that is waiting for HBM most of the time.  Magnitudes leave window-major (256 contiguous bytes per store);
+// k2_mag_transpose turns them into the window-minor layout of the search kernel.
+__device__ __forceinline__ void k1_fft_tail(const K1Params& p, int rx, int span, float2* X) {
+	const int lane = threadIdx.x;
+	// This wave's own c48 stores must have reached L2 (its L1 never held those lines), and the last tile's LDS-DMA must have
+	// landed before the tile buffer is reused: a workgroup-scope fence is exactly "s_waitcnt vmcnt(0)" -- an agent-scope one
+	// (__threadfence) adds an L2 write-back and an L1 invalidate per span, which cost more than the analysis itself.
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	FftTwiddles t = fft_twiddles(p.omega, lane);
+	const int src = fft_src_lane(lane);
+	const int nw = p.fft_windows, n = 2 * nw;
+	float2 dn[8];
+	const auto fetch = [&](int i) {
+		const int ch = i >= nw ? 1 : 0, w = span * nw + (i - ch * nw);
+		const float2* x = p.c48 + ((size_t)rx * 2 + ch) * p.c48_stride + (size_t)w * 512 + src;
+#pragma unroll
+		for (int r = 0; r < 8; r++) dn[r] = x[fft_src_step(r)];
+	};
+	fetch(0);
+	for (int i = 0; i < n; i++) {
+		c2 v[8];
+		fft_square(dn, v);
+		__builtin_amdgcn_sched_barrier(0);
+		if (i + 1 < n) fetch(i + 1);
+		__builtin_amdgcn_sched_barrier(0);
+		float m[8];
+		fft512_mag(v, X, t, lane, m);
+		const int ch = i >= nw ? 1 : 0, w = span * nw + (i - ch * nw);
+		float* row = p.magW + (((size_t)rx * 2 + ch) * p.n_windows + w) * 512;
+#pragma unroll
+		for (int r = 0; r < 8; r++) row[(lane + 64 * r + 256) & 511] = m[r];
+	}
+}
+
+// window-major magnitudes [W][512] -> window-minor [W / 64][512][64] (what k2_cgf_search's lane-per-window walk reads)
+__global__ __launch_bounds__(256) void k2_mag_transpose(const float* __restrict__ magW, float* __restrict__ magT, int n_win_total) {
+	__shared__ float tile[64][65];
+	const int t = threadIdx.x, W0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+#pragma unroll
+	for (int pass = 0; pass < 4; pass++) {
+		const int wl = pass * 16 + (t >> 4);
+		int W = W0 + wl;
+		W = W < n_win_total ? W : n_win_total - 1;
+		const float4 v = *reinterpret_cast<const float4*>(magW + (size_t)W * 512 + b0 + (t & 15) * 4);
+		float* d = &tile[wl][(t & 15) * 4];
+		d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+	}
+	__syncthreads();
+	float* dst = magT + (size_t)blockIdx.x * (512 * 64) + (size_t)b0 * 64;
+#pragma unroll
+	for (int pass = 0; pass < 16; pass++) {
+		const int bin = pass * 4 + (t >> 6), wl = t & 63;
+		dst[(size_t)bin * 64 + wl] = tile[wl][bin];
 	}
 }
 
@@ -1216,8 +1335,11 @@ __device__ __forceinline__ c2 pk_sub_add(c2 a, c2 b) { // (a.x - b.x, a.y + b.y)
 
 // R0 = first_group & 3: the (1j)^n pre-rotation pattern of the 4 groups of a body is the same for the whole launch
 // (segments and bodies start at multiples of 4 groups)
+#ifndef K6_WAVES
+#define K6_WAVES 2
+#endif
 template <int R0>
-__global__ __launch_bounds__(64) void k3_derot_fir(K6Params p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6_WAVES))) void k3_derot_fir(K6Params p) {
 	const int lane = threadIdx.x, s = blockIdx.x;
 	const int chain_raw = blockIdx.y * 64 + lane;
 	const bool live = chain_raw < p.n_chan;
@@ -1774,7 +1896,10 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 	}
 }
 
-__global__ __launch_bounds__(64) void k4_phase_chunks(K4Params p) {
+#ifndef K4_WAVES
+#define K4_WAVES 8
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K4_WAVES, K4_WAVES))) void k4_phase_chunks(K4Params p) {
 	__shared__ __attribute__((aligned(16))) float2 stage[2][4][PS_SB_PAD];
 	const int lane = threadIdx.x;
 	const int k = lane & 15, row = lane >> 4;
@@ -1805,23 +1930,64 @@ __global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
 	int start = st->max_idx;
 	uint32_t* out = p.bits + (size_t)chain * p.bits_stride;
 	bool bad = false;
-	for (int c = 0; c < p.n_chunks; c++) {
-		const size_t slot = (size_t)chain * p.n_chunks + c;
-		if (c > 0) {
-			const unsigned a = __float_as_uint(p.ma_start[slot * 16 + k]), b = __float_as_uint(p.ma_fin[(slot - 1) * 16 + k]);
-			bad = bad || (a != b);
+	// Next to the front end a dependent global load costs microseconds, so the walk over the chunks must not contain any:
+	// lane k fetches fin[.][k] of AS chunks at once, the start index then hops from chunk to chunk through lane shuffles,
+	// and only after that are the word gathers (whose addresses are all known by then) issued together.
+	constexpr int AS = 8;
+	static_assert(PS_CHUNK % 512 == 0, "k4_assemble: whole words per lane");
+	constexpr int WPL = PS_CHUNK / 32 / 16; // words per lane and chunk
+	const size_t base = (size_t)chain * p.n_chunks;
+	unsigned fin_last = 0, ma_last = 0;
+	for (int c0 = 0; c0 < p.n_chunks; c0 += AS) {
+		unsigned f[AS], ms[AS], mf[AS];
+#pragma unroll
+		for (int e = 0; e < AS; e++) {
+			const int c = c0 + e;
+			const bool on = c < p.n_chunks;
+			const size_t slot = base + (on ? c : p.n_chunks - 1);
+			f[e] = p.fin[slot * 16 + k];
+			mf[e] = __float_as_uint(p.ma_fin[slot * 16 + k]);
+			ms[e] = (on && c > 0) ? __float_as_uint(p.ma_start[slot * 16 + k]) : 0u;
 		}
-		const int g0 = c * PS_CHUNK;
-		const int n = (g0 + PS_CHUNK < p.n_groups ? PS_CHUNK : p.n_groups - g0);
-		const int nw = (n + 31) >> 5;
-		const uint32_t* w = p.words + slot * (PS_CHUNK / 32) * 16 + start;
-		for (int i = k; i < nw; i += 16) out[(g0 >> 5) + i] = w[i * 16];
-		start = (int)(p.fin[slot * 16 + start] & 15u);
+		int st_e[AS];
+#pragma unroll
+		for (int e = 0; e < AS; e++) {
+			const int c = c0 + e;
+			st_e[e] = start;
+			if (c < p.n_chunks) { // wave-uniform
+				if (c > 0) bad = bad || (ms[e] != (e > 0 ? mf[e - 1] : ma_last));
+				start = __shfl((int)f[e], start, 16) & 15;
+				fin_last = f[e];
+			}
+		}
+		uint32_t wv[AS][WPL];
+#pragma unroll
+		for (int e = 0; e < AS; e++) {
+			const int c = c0 + e;
+			if (c >= p.n_chunks) break;
+			const int g0 = c * PS_CHUNK;
+			const int n = (g0 + PS_CHUNK < p.n_groups ? PS_CHUNK : p.n_groups - g0);
+			const int nw = (n + 31) >> 5;
+			const uint32_t* w = p.words + (base + c) * (PS_CHUNK / 32) * 16 + st_e[e];
+#pragma unroll
+			for (int q = 0; q < WPL; q++) { const int i = k + 16 * q; wv[e][q] = i < nw ? w[i * 16] : 0u; }
+		}
+#pragma unroll
+		for (int e = 0; e < AS; e++) {
+			const int c = c0 + e;
+			if (c >= p.n_chunks) break;
+			const int g0 = c * PS_CHUNK;
+			const int n = (g0 + PS_CHUNK < p.n_groups ? PS_CHUNK : p.n_groups - g0);
+			const int nw = (n + 31) >> 5;
+#pragma unroll
+			for (int q = 0; q < WPL; q++) { const int i = k + 16 * q; if (i < nw) out[(g0 >> 5) + i] = wv[e][q]; }
+		}
+		ma_last = mf[AS - 1]; // only read when another batch follows, i.e. when all AS chunks of this one were live
 	}
 	if (bad) atomicOr(p.flag, 1);
-	const size_t last = (size_t)chain * p.n_chunks + (p.n_chunks - 1);
+	const size_t last = base + (p.n_chunks - 1);
 	sto->ma[k] = p.ma_fin[last * 16 + k];
-	sto->bits[k] = p.fin[last * 16 + k] >> 4;
+	sto->bits[k] = fin_last >> 4;
 	if (k == 0) { sto->max_idx = start; sto->rot = (st->rot + p.n_groups) & 3; }
 }
 
@@ -2886,6 +3052,12 @@ hipError_t launch_selftest_hypot(const float2* in, int n, unsigned* mismatches, 
 hipError_t launch_k2a_fft(const K2Params& p, int n_chan, hipStream_t s) {
 	const int n = n_chan * p.n_windows;
 	hipLaunchKernelGGL(k2_fft_mag, dim3((n + FFT_NW - 1) / FFT_NW), dim3(64), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_k2a_transpose(const K2Params& p, int n_chan, hipStream_t s) {
+	const int n = n_chan * p.n_windows;
+	hipLaunchKernelGGL(k2_mag_transpose, dim3((n + 63) / 64, 8), dim3(256), 0, s, p.magW, p.magT, n);
 	return hipGetLastError();
 }
 
