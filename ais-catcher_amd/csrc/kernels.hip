@@ -1128,6 +1128,9 @@ __global__ __launch_bounds__(64) void k2_fft_mag(K2Params p) {
 // k2_mag_transpose turns them into the window-minor layout of the search kernel.
 __device__ __forceinline__ void k1_fft_tail(const K1Params& p, int rx, int span, float2* X) {
 	const int lane = threadIdx.x;
+#ifdef K1_TAIL_PRIO
+	__builtin_amdgcn_s_setprio(K1_TAIL_PRIO);
+#endif
 	// This wave's own c48 stores must have reached L2 (its L1 never held those lines), and the last tile's LDS-DMA must have
 	// landed before the tile buffer is reused: a workgroup-scope fence is exactly "s_waitcnt vmcnt(0)" -- an agent-scope one
 	// (__threadfence) adds an L2 write-back and an L1 invalidate per span, which cost more than the analysis itself.
@@ -1904,6 +1907,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K4_WAVES, K4
 	const int lane = threadIdx.x;
 	const int k = lane & 15, row = lane >> 4;
 	const int chunk = blockIdx.y;
+	if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
+	else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
+	else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
 	// the four rows of a wave: the same sampling phase of four ADJACENT channels (their symbol pairs are 64 contiguous bytes in
 	// the SymRow layout) and the same chunk (equal trip counts)
 	const int j = blockIdx.x % 5, chan = (blockIdx.x / 5) * 4 + row;

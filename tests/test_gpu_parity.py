@@ -709,6 +709,25 @@ def test_fused_backend_edge_inputs_and_boxcar():
     _run_outputs_vs_oracle([x], 1536000, "cf32", 131072, 4, ps_ema=False)
 
 
+@pytest.mark.parametrize("tps,env", [(16, None), (32, None), (48, None), (0, "0"), (24, None)])
+def test_spectral_analysis_at_the_end_of_the_front_end_waves(tps, env, monkeypatch):
+    """The FFT of SquareFreqOffsetCorrection rides in the front-end kernel when a span is a whole number of 512-sample windows
+    (16 tiles): one, two or three windows per channel and span; AISGPU_FFT_K1=0 / spans of 24 tiles use the FFT kernel.
+    ppm (i.e. every window's peak search), hard bits and levels must not change by a bit, on pure and pre-decimated ladders
+    and on integer input."""
+    if env is not None:
+        monkeypatch.setenv("AISGPU_FFT_K1", env)
+    kw = {"tiles_per_span": tps} if tps else {}
+    xs = [synth.receiver_stream(98304 * 4, receiver_id=120 + r, gap_slots=(0, 2)) for r in range(3)]
+    _run_outputs_vs_oracle(xs, 1536000, "cf32", 98304, 4, **kw)       # 96 tiles per block
+    _run_outputs_vs_oracle([synth.to_cu8(xs[1])], 1536000, "cu8", 98304, 4, **kw)
+    if tps in (16, 0):
+        x = synth.receiver_stream(786432 * 2, sample_rate=6144000, receiver_id=123, gap_slots=(1, 2))
+        _run_outputs_vs_oracle([x], 6144000, "cf32", 786432, 2, **kw)  # pre-decimation pass in front: 192 tiles of the second pass
+        x = synth.receiver_stream(24576 * 3, sample_rate=384000, receiver_id=124, gap_slots=(1, 2))
+        _run_outputs_vs_oracle([x], 384000, "cf32", 24576 * 2, 1, **kw)  # two stages only: 96 tiles
+
+
 def test_materialised_backend_without_taps(monkeypatch):
     """AISGPU_FUSED=0 keeps the phasor / derotated-sample arrays (the path the taps and the FM branch use) with the deferred
     second half; same outputs."""
