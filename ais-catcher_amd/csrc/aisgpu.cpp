@@ -544,6 +544,13 @@ int gather_frames(aisgpu_t* h) {
 		HIPCHK(hipMemcpy(&ovf, h->d_k7ovf, sizeof ovf, hipMemcpyDeviceToHost));
 		if (ovf) { h->err = "event-driven frame decoder: more than K7E_OPENCAP frame starts in one block of one decoder (use AISGPU_K7=seq)"; return AISGPU_ERR_OVERFLOW; }
 	}
+	if (h->k7_event && getenv("AISGPU_K7E_STATS")) { // experiment aid: events / runs per decoder in the last block
+		std::vector<uint32_t> cnt((size_t)h->n_chan * 5);
+		HIPCHK(hipMemcpy(cnt.data(), h->d_k7cnt, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		unsigned long long se = 0, sr = 0; unsigned me = 0, mr = 0;
+		for (uint32_t v : cnt) { se += v & 0xFFFFu; sr += v >> 16; me = std::max(me, v & 0xFFFFu); mr = std::max(mr, v >> 16); }
+		fprintf(stderr, "K7E_STATS decoders %zu: events avg %.1f max %u, runs avg %.1f max %u\n", cnt.size(), (double)se / cnt.size(), me, (double)sr / cnt.size(), mr);
+	}
 	const unsigned fresh = total - h->frames_seen;
 	h->frames.clear();
 	if (fresh > (unsigned)h->max_frames) { h->err = "frame ring overflow: call aisgpu_sync_outputs() more often"; h->frames_seen = total; return AISGPU_ERR_OVERFLOW; }

@@ -2644,6 +2644,12 @@ __global__ __launch_bounds__(64) void k7_decode(K7Params p) {
 // alternations in `position` and leaves for STARTFLAG at the first symbol with alt == 0 and position > 4 (Marine/AIS.h:109-119).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t K7E_CONT = 0xFFFFu;
+constexpr int K7E_RW = 32; // events a lane of k7e_resolve stages in LDS at a time
+#ifndef K7E_SIM_LANES_
+#define K7E_SIM_LANES_ 16
+#endif
+constexpr int K7E_SIM_LANES = K7E_SIM_LANES_; // lanes of k7e_sim per decoder
+constexpr int K7E_FOUND = 8;  // completed messages a lane of k7e_resolve notes before it copies them out
 enum { K7E_FAIL = 0, K7E_RUN = 1 };
 
 __device__ __forceinline__ int k7e_training_pos(const DecState* st) { // alternations counted so far, only "> 4" ever matters
@@ -2679,14 +2685,17 @@ __global__ __launch_bounds__(64) void k7e_scan(K7eParams q) {
 		pend_until = -1;
 	};
 	constexpr int PF = 8; // words fetched together
-	uint32_t buf[PF + 1];
+	uint32_t buf[PF + 1], nbuf[PF + 1]; // the batch being scanned and the one behind it, requested a batch ahead
 #pragma unroll
-	for (int e = 0; e <= PF; e++) buf[e] = e < nw ? brow[e] : 0u;
+	for (int e = 0; e <= PF; e++) nbuf[e] = e < nw ? brow[e] : 0u;
 	for (int w = 0; w < nw; w++) {
 		const int bi = w % PF;
-		if (bi == 0 && w > 0) {
+		if (bi == 0) {
 #pragma unroll
-			for (int e = 0; e <= PF; e++) buf[e] = w + e < nw ? brow[w + e] : 0u;
+			for (int e = 0; e <= PF; e++) buf[e] = nbuf[e];
+#pragma unroll
+			for (int e = 0; e <= PF; e++) nbuf[e] = w + PF + e < nw ? brow[w + PF + e] : 0u;
+			__builtin_amdgcn_sched_barrier(0);
 		}
 		uint32_t D = 0, Dn = 0;
 #pragma unroll
@@ -2741,7 +2750,10 @@ __global__ __launch_bounds__(64) void k7e_sim(K7eParams q) {
 	const K7Params& p = q.k;
 	__builtin_amdgcn_s_setprio(3);
 	const int lane = threadIdx.x;
-	const int d = blockIdx.x * 8 + (lane >> 3); // eight lanes per decoder take its runs round robin
+	// K7E_SIM_LANES lanes per decoder take its runs round robin.  A decoder has ~4.5 runs per block on the bench signal (13 at
+	// most), a step costs ~180 instructions of a wave that is alone on its SIMD, and there are fewer waves than SIMDs: with 16
+	// lanes a second round (0.1 ms) practically never happens, and idle lanes cost nothing.
+	const int d = blockIdx.x * (64 / K7E_SIM_LANES) + lane / K7E_SIM_LANES;
 	const int n_dec = p.n_chan * 5;
 	const int dd_ = d < n_dec ? d : 0;
 	const int nrun = d < n_dec ? (int)(q.cnt[dd_] >> 16) : 0;
@@ -2752,7 +2764,7 @@ __global__ __launch_bounds__(64) void k7e_sim(K7eParams q) {
 	uint32_t* data = fdata + lane;
 	const int n = p.n_groups;
 	const auto dd_at = [&](int g) -> int { return g < 0 ? st->prev : (int)((brow[g >> 5] >> (g & 31)) & 1u); };
-	for (int k = lane & 7; __any(k < nrun); k += 8) {
+	for (int k = lane % K7E_SIM_LANES; __any(k < nrun); k += K7E_SIM_LANES) {
 		const bool act = k < nrun;
 		const uint32_t c0 = act ? q.open_c[(size_t)dd_ * K7E_OPENCAP + k] : 0u;
 		const bool cont = c0 == K7E_CONT;
@@ -2772,14 +2784,22 @@ __global__ __launch_bounds__(64) void k7e_sim(K7eParams q) {
 		}
 		bool running = act;
 		int g = c, end = n, flags = 2; // (2: still running when the block ends)
-		while (__any(running)) {
-			// eight symbols per round: their levels and decisions are fetched together (a step that waits for its own loads
-			// is pure memory latency)
-			float lv[8];
-			const int gc = g < n ? g : n - 1;
-			const uint32_t w0 = brow[gc >> 5], w1 = brow[(gc + 7 < n ? gc + 7 : n - 1) >> 5];
+		// eight symbols per round: their levels and decisions are fetched together, and one round AHEAD -- a running lane advances
+		// by exactly eight symbols per round, so the next round's addresses are known, and a round that waits for its own loads
+		// is pure memory latency (~2 us per eight symbols next to the front end)
+		float lv[8], lvn[8];
+		uint32_t w0, w1, w0n, w1n;
+		const auto fetch = [&](int gg, float (&l)[8], uint32_t& a, uint32_t& b) {
+			const int gc = gg < n ? gg : n - 1;
+			a = brow[gc >> 5]; b = brow[(gc + 7 < n ? gc + 7 : n - 1) >> 5];
 #pragma unroll
-			for (int e = 0; e < 8; e++) lv[e] = lrow[g + e < n ? g + e : n - 1];
+			for (int e = 0; e < 8; e++) l[e] = lrow[gg + e < n ? gg + e : n - 1];
+		};
+		fetch(g, lv, w0, w1);
+		while (__any(running)) {
+			const int gc = g < n ? g : n - 1;
+			fetch(g + 8, lvn, w0n, w1n);
+			__builtin_amdgcn_sched_barrier(0); // (keeps the requests in front of the eight steps)
 #pragma unroll
 			for (int e = 0; e < 8; e++) {
 				if (running) {
@@ -2794,6 +2814,9 @@ __global__ __launch_bounds__(64) void k7e_sim(K7eParams q) {
 					}
 				}
 			}
+#pragma unroll
+			for (int e = 0; e < 8; e++) lv[e] = lvn[e];
+			w0 = w0n; w1 = w1n;
 		}
 		if (act) {
 			K7Slot* sl = q.slot + (size_t)d * K7E_OPENCAP + k;
@@ -2832,7 +2855,55 @@ __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 	const int nev = live ? (int)(q.cnt[d] & 0xFFFFu) : 0;
 	int ptr = 0, free_at = state0 == DST_TRAINING ? 5 - pos0 : 0, end_ = INF, slot_ = 0;
 	bool busy = false, fnd = false;
-	uint32_t head = ptr < nev ? evd[0] : 0xFFFFFFFFu;
+	// A round of the walk is a few dozen instructions; an event fetched when it is needed would cost a memory round trip per
+	// event (and a second one for the (end, flags) of its run).  So every lane stages its next K7E_RW events and their run
+	// records in LDS with all loads in flight together, and the walk reads LDS.
+	__shared__ uint32_t s_ev[K7E_RW][64];
+	__shared__ int2 s_ef[K7E_RW][64];
+	int win0 = 0;
+	const auto stage = [&](int from) {
+#pragma unroll
+		for (int h = 0; h < K7E_RW; h += 16) {
+			uint32_t e[16];
+			int2 f[16];
+#pragma unroll
+			for (int i = 0; i < 16; i++) e[i] = from + h + i < nev ? evd[from + h + i] : 0xFFFFFFFFu;
+#pragma unroll
+			for (int i = 0; i < 16; i++) {
+				const bool run = e[i] != 0xFFFFFFFFu && ((e[i] >> 13) & 3u) == K7E_RUN;
+				f[i] = run ? *reinterpret_cast<const int2*>(slots + (e[i] >> 19)) : make_int2(0, 0); // (end, flags)
+			}
+#pragma unroll
+			for (int i = 0; i < 16; i++) { s_ev[h + i][lane] = e[i]; s_ef[h + i][lane] = f[i]; }
+		}
+		win0 = from;
+	};
+	stage(0);
+	uint32_t head = s_ev[0][lane];
+	// A completed message is a record of 46 words behind an atomic counter: copied out inside the walk, every one of them would
+	// stall its whole wave for two memory round trips (the walk was 0.16 ms, nine tenths of it these).  The walk only notes
+	// (symbol, run) and the records leave together at the end: one atomic per lane, all loads in flight at once.  Their order
+	// in the ring is irrelevant (the host sorts by receiver, block, channel, group, phase).
+	__shared__ uint32_t s_found[K7E_FOUND][64];
+	int nfound = 0;
+	const auto emit = [&](int from, int to) {
+		const int cnt = to - from;
+		if (cnt <= 0) return;
+		const unsigned fs0 = atomicAdd(p.frame_count, (unsigned)cnt);
+		for (int i = from; i < to; i++) {
+			const uint32_t v = s_found[i][lane];
+			const int e = (int)(v & 0xFFFFu);
+			const K7Slot* s = slots + (v >> 16);
+			uint32_t* f = p.frames + (size_t)((fs0 + (unsigned)(i - from)) % (unsigned)p.max_frames) * DEC_FRAME_WORDS;
+			const long long sidx = 5 * (p.first_group + e) + j;
+			f[0] = (uint32_t)d; f[1] = (uint32_t)e; f[2] = (uint32_t)s->s.position; f[3] = __float_as_uint(s->s.level);
+			f[4] = (uint32_t)(unsigned long long)s->s.start_idx; f[5] = (uint32_t)((unsigned long long)s->s.start_idx >> 32);
+			f[6] = (uint32_t)(unsigned long long)sidx; f[7] = (uint32_t)((unsigned long long)sidx >> 32);
+			f[8] = p.block; f[9] = p.sub;
+#pragma unroll
+			for (int w = 0; w < DEC_DATA_WORDS; w++) f[10 + w] = s->s.data[w];
+		}
+	};
 	for (;;) {
 		const int t = busy ? end_ : (head != 0xFFFFFFFFu ? (int)(head & 0x1FFFu) : INF);
 		const int key = live && t < n ? t * 8 + j : INF * 8; // (equal groups: the lower phase first)
@@ -2854,26 +2925,20 @@ __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 					busy = true; slot_ = sl;
 					if (kind == K7E_FAIL) { end_ = c + off; fnd = false; }
 					else {
-						const int2 ef = *reinterpret_cast<const int2*>(slots + sl); // (end, flags)
+						const int2 ef = s_ef[ptr - 1 - win0][lane]; // (end, flags) of run sl
 						fnd = (ef.y & 1) != 0;
 						end_ = (ef.y & 2) ? INF : ef.x;
 					}
 				}
-				head = ptr < nev ? evd[ptr] : 0xFFFFFFFFu;
+				if (ptr - win0 == K7E_RW) stage(ptr); // (only this lane's columns are touched)
+				head = s_ev[ptr - win0][lane];
 			} else {
 				const int e = end_;
 				busy = false;
 				free_at = e + 6; // back in TRAINING with position 0 at symbol e
-				if (fnd) {
-					const K7Slot* s = slots + slot_;
-					const unsigned fs = atomicAdd(p.frame_count, 1u) % (unsigned)p.max_frames;
-					uint32_t* f = p.frames + (size_t)fs * DEC_FRAME_WORDS;
-					const long long sidx = 5 * (p.first_group + e) + j;
-					f[0] = (uint32_t)d; f[1] = (uint32_t)e; f[2] = (uint32_t)s->s.position; f[3] = __float_as_uint(s->s.level);
-					f[4] = (uint32_t)(unsigned long long)s->s.start_idx; f[5] = (uint32_t)((unsigned long long)s->s.start_idx >> 32);
-					f[6] = (uint32_t)(unsigned long long)sidx; f[7] = (uint32_t)((unsigned long long)sidx >> 32);
-					f[8] = p.block; f[9] = p.sub;
-					for (int w = 0; w < DEC_DATA_WORDS; w++) f[10 + w] = s->s.data[w];
+				if (fnd) { // noted now, copied out behind the walk (or right away when the note pad is full)
+					if (nfound == K7E_FOUND) { emit(0, nfound); nfound = 0; }
+					s_found[nfound++][lane] = (uint32_t)e | ((uint32_t)slot_ << 16);
 					bcast = (e << 3) | j;
 				}
 			}
@@ -2889,6 +2954,7 @@ __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 		}
 	}
 	if (!live) return;
+	emit(0, nfound);
 	// state for the next block
 	if (busy) { // the run that is still going: its state as k7e_sim left it
 		*st = slots[slot_].s;
@@ -3114,7 +3180,7 @@ hipError_t launch_k7e(const K7eParams& q, hipStream_t s) {
 	const int n_dec = q.k.n_chan * 5;
 	if (q.k.n_groups <= 0) return hipSuccess;
 	hipLaunchKernelGGL(k7e_scan, dim3((n_dec + 63) / 64), dim3(64), 0, s, q);
-	hipLaunchKernelGGL(k7e_sim, dim3((n_dec + 7) / 8), dim3(64), 0, s, q);
+	hipLaunchKernelGGL(k7e_sim, dim3((n_dec * K7E_SIM_LANES + 63) / 64), dim3(64), 0, s, q);
 	hipLaunchKernelGGL(k7e_resolve, dim3((q.k.n_chan + 11) / 12), dim3(64), 0, s, q);
 	return hipGetLastError();
 }
