@@ -107,8 +107,7 @@ struct aisgpu {
 	float *d_ppmtab = nullptr, *d_ppm[NBUF] = {}, *d_lvl[4] = {}; // lvl: ring of 4 (block f & 3): it lives until the block's (deferred) walk and decoder are done
 	int* d_fz[NBUF] = {};
 	float* d_magT[NBUF] = {}; // shifted FFT magnitudes (written by the FFT on the front stream, read by the searches on s3)
-	float* d_magW[NBUF] = {}; // the same window-major, when the FFT rides at the end of the front-end waves (fft_in_k1)
-	bool fft_in_k1 = false;
+	bool fft_in_k1 = false;   // the spectral analysis rides at the end of the front-end waves (k1_fft_tail): fz / ppm come from K1
 	uint32_t* d_bits[2] = {};
 	bool challenger = false;
 	bool v2 = false; float2* h_c48 = nullptr; // ModelEngineV2: front end only, the 48 kHz channels go to the host (MAXSUB slots)
@@ -344,7 +343,7 @@ int enqueue_decode(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsi
 K2Params make_k2(aisgpu_t* h, int q) {
 	K2Params k2;
 	k2.c48 = h->d_c48[q]; k2.c48_stride = h->c48s; k2.cgf = h->d_cgf; k2.cgf_stride = CGF_HIST + h->L;
-	k2.omega = h->d_omega; k2.step_table = h->d_step; k2.ppm_table = h->d_ppmtab; k2.magT = h->d_magT[q]; k2.magW = h->d_magW[q]; k2.fz = h->d_fz[q]; k2.ppm = h->d_ppm[q];
+	k2.omega = h->d_omega; k2.step_table = h->d_step; k2.ppm_table = h->d_ppmtab; k2.magT = h->d_magT[q]; k2.fz = h->d_fz[q]; k2.ppm = h->d_ppm[q];
 	k2.rot_state = h->d_rotstate; k2.n_windows = h->W; k2.wide = h->cfg.afc_wide ? 1 : 0;
 	k2.rotT = h->d_rotT[q]; k2.rotT_stride = (h->n_chan + 63) / 64 * 64; k2.n_chan = h->n_chan;
 	return k2;
@@ -425,20 +424,24 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	// The spectral analysis (FFT + searches) either follows the front end on its stream, or -- AISGPU_DEFER_FUSED -- runs on s4
 	// next to it; s4 then must not sit waiting for this block's phasor recurrence, so the second half of the block (derotation /
 	// FIR, PhaseSearch) is enqueued one block later, behind the next block's analysis (or when results are requested).
-	hipStream_t sa = h->defer_fused ? h->s4 : h->stream;
-	if (h->defer_fused) {
-		HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
-		HIPCHK(hipStreamWaitEvent(h->s4, h->ev_front[q], 0));
+	if (h->fft_in_k1) {
+		// the front-end waves have done the whole analysis (k1_fft_tail): fz / ppm of this block are there when K1 is
+		HIPCHK(hipEventRecord(h->ev_search[q], h->stream));
+	} else {
+		hipStream_t sa = h->defer_fused ? h->s4 : h->stream;
+		if (h->defer_fused) {
+			HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
+			HIPCHK(hipStreamWaitEvent(h->s4, h->ev_front[q], 0));
+		}
+		{ TraceScope t(h, "fft", sa); HIPCHK(launch_k2a_fft(k2, h->n_chan, sa)); }
+		hipStream_t ss = h->defer_fused ? h->s4 : h->search_on_front ? h->stream : h->s4; // with the searches on the front stream four streams are enough
+		if (!h->defer_fused) {
+			HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
+			HIPCHK(hipStreamWaitEvent(ss, h->ev_front[q], 0));
+		}
+		{ TraceScope t(h, "search", ss); HIPCHK(launch_k2a_search(k2, h->n_chan, ss)); }
+		HIPCHK(hipEventRecord(h->ev_search[q], ss));
 	}
-	if (h->fft_in_k1) { TraceScope t(h, "fft", sa); HIPCHK(launch_k2a_transpose(k2, h->n_chan, sa)); } // the front end left the magnitudes window-major
-	else { TraceScope t(h, "fft", sa); HIPCHK(launch_k2a_fft(k2, h->n_chan, sa)); }
-	hipStream_t ss = h->defer_fused ? h->s4 : h->search_on_front ? h->stream : h->s4; // with the searches on the front stream four streams are enough
-	if (!h->defer_fused) {
-		HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
-		HIPCHK(hipStreamWaitEvent(ss, h->ev_front[q], 0));
-	}
-	{ TraceScope t(h, "search", ss); HIPCHK(launch_k2a_search(k2, h->n_chan, ss)); }
-	HIPCHK(hipEventRecord(h->ev_search[q], ss));
 	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_search[q], 0));
 	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_c48free[q], 0)); // ck[q] was last read by K6 of block f-NBUF
 	{ TraceScope t(h, "phasor", h->s3); HIPCHK(launch_k2b_ck(k2, h->n_chan, h->s3)); }
@@ -937,7 +940,6 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	}
 	for (int i = 0; i < NBUF; i++) {
 		HIPCHK(dalloc(&h->d_magT[i], (C * h->W + 63) / 64 * (size_t)(512 * 64)));
-		if (h->fft_in_k1) HIPCHK(dalloc(&h->d_magW[i], (C * h->W + 63) / 64 * (size_t)(512 * 64)));
 		HIPCHK(dalloc(&h->d_c48[i], C * h->c48s + 64)); // + over-read slack of the fused FIR kernel's last segment
 		HIPCHK(dalloc(&h->d_fz[i], C * h->W));
 		HIPCHK(dalloc(&h->d_ppm[i], C * h->W));
@@ -1024,7 +1026,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_fm); hipFree(h->d_fmbits[0]); hipFree(h->d_fmbits[1]);
 	if (h->h_fmbits) hipHostFree(h->h_fmbits);
 	if (h->h_c48) hipHostFree(h->h_c48);
-	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_magW[i]); hipFree(h->d_ck[i]); hipFree(h->d_ckw[i]); }
+	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); hipFree(h->d_ckw[i]); }
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
 	hipFree(h->d_box[0]); hipFree(h->d_box[1]);
 	hipFree(h->d_dec); hipFree(h->d_frames); hipFree(h->d_frame_count);
@@ -1184,7 +1186,10 @@ int aisgpu_run(aisgpu_t* h) {
 		k1.tiles_per_block = h->tiles_per_block; k1.tiles_per_span = h->tiles_per_span;
 		k1.alpha = h->alpha; k1.beta = h->beta; k1.has_fdc = h->has_fdc; k1.stream_start = h->in_blocks == 0;
 		k1.pre_out = nullptr; k1.pre_stride = 0;
-		if (h->fft_in_k1) { k1.fft_windows = h->tiles_per_span / 16; k1.n_windows = h->W; k1.omega = h->d_omega; k1.magW = h->d_magW[q]; }
+		if (h->fft_in_k1) {
+			k1.fft_windows = h->tiles_per_span / 16; k1.n_windows = h->W; k1.wide = h->cfg.afc_wide ? 1 : 0;
+			k1.omega = h->d_omega; k1.ppm_table = h->d_ppmtab; k1.fz = h->d_fz[q]; k1.ppm = h->d_ppm[q];
+		}
 		if (!from_pre) { int rc = time_begin(); if (rc) return rc; }
 		{ TraceScope t(h, "front", h->stream); HIPCHK(launch_k1(k1, h->K, from_pre ? 0 : h->kfmt, h->tile96, h->depth, h->k1_threads, h->spans, R, h->stream)); }
 		if (!from_pre) { int rc = time_end(); if (rc) return rc; }

@@ -24,9 +24,11 @@ struct K1Params {
 	float2* pre_out;         // != nullptr: pre-decimation pass, write the level after K stages here ([n_rx][pre_stride])
 	long long pre_stride;
 	// spectral analysis at the end of every span (k1_dpp only): fft_windows = tiles_per_span / 16 windows per channel, 0 = off
-	int fft_windows, n_windows;
+	int fft_windows, n_windows, wide;
 	const float2* omega;     // [512] FFT twiddles
-	float* magW;             // [n_rx * 2 * n_windows][512] shifted FFT magnitudes, window-major
+	const float* ppm_table;  // [FZ_COUNT]
+	int* fz;                 // [n_rx * 2][n_windows]
+	float* ppm;              // [n_rx * 2][n_windows]
 };
 
 constexpr int US_HIST = 96;  // resampler table entries carried in front of each flush block (halo of K1u: 84)
@@ -56,7 +58,6 @@ struct K2Params {
 	const float2* step_table; // [FZ_COUNT] rot_step per fz
 	const float* ppm_table;   // [FZ_COUNT]
 	float* magT;              // [ceil(n_chan * n_windows / 64)][512][64] shifted FFT magnitudes, window-minor
-	const float* magW;        // the same window-major (written by the front end's FFT tail, k2_mag_transpose turns it into magT)
 	int* fz;                  // [n_chan][n_windows]
 	float* ppm;               // [n_chan][n_windows]
 	float2* rot_state;        // [n_chan]
@@ -188,7 +189,6 @@ hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long b
 hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s);
 hipError_t launch_convert_rows(const void* in, long long in_stride, int fmt, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
 hipError_t launch_k2a_fft(const K2Params& p, int n_chan, hipStream_t s);
-hipError_t launch_k2a_transpose(const K2Params& p, int n_chan, hipStream_t s);
 hipError_t launch_k2a_search(const K2Params& p, int n_chan, hipStream_t s);
 hipError_t launch_selftest_hypot(const float2* in, int n, unsigned* mismatches, hipStream_t s);
 hipError_t launch_k2b(const K2Params& p, int n_chan, hipStream_t s); // phasor recurrence

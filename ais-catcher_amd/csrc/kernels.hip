@@ -568,6 +568,11 @@ __device__ __forceinline__ void wave_sync() {
 #ifndef K1_WAVES
 #define K1_WAVES 3
 #endif
+// three front-end workgroups per SIMD by register allocation (see the kernel): the default since the spectral analysis rides in
+// this kernel, 1-2 % per step (profiles/r01_v10_experiments.txt); -DK1_NOCAP / -DK1_CAP2 for the experiments
+#if !defined(K1_CAP3) && !defined(K1_CAP2) && !defined(K1_NOCAP)
+#define K1_CAP3 1
+#endif
 // FMT: input sample format (Utilities/StreamHelpers.cpp:51-133): 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16;
 // 4 = CU8 through the fixed-point ladder Downsample16_CU8 (K = 4 only)
 constexpr int fmt_bytes(int fmt) { return fmt == 0 ? 8 : fmt == 3 ? 4 : 2; }
@@ -583,8 +588,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 	__shared__ __attribute__((aligned(16))) float4 xt[DMA ? 64 * W4 : 1]; // the tile, linear, XOR-swizzled in units of 16 B
 	__shared__ __attribute__((aligned(16))) float2 x5[2][8 + 64];  // rotated up/down with 8 samples of history
 	__shared__ __attribute__((aligned(16))) float2 x6[2][8 + 32];  // DS2_a/b output
-	constexpr bool XFFT_IN_XT = DMA && K == 4; // the FFT tail's exchange buffer (4.7 KB) reuses the tile buffer where that is big enough
-	__shared__ __attribute__((aligned(16))) float2 xfft[(PRE || XFFT_IN_XT) ? 1 : 584];
+	constexpr bool XFFT_IN_XT = DMA && K == 4; // the FFT tail's exchange / search buffer (8 KB) reuses the tile buffer where that is big enough
+	__shared__ __attribute__((aligned(16))) float2 xfft[(PRE || XFFT_IN_XT) ? 1 : 1024];
 	const int lane = threadIdx.x;
 	const int rx = blockIdx.y;
 	const int span = blockIdx.x;
@@ -594,6 +599,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 	// 156 of a CU's 160 KB of LDS -- nothing that needs LDS (the FFT, the staged PhaseSearch) gets on the CU beside them.  The
 	// kernel is as fast with three (HBM-bound); naming v135 as clobbered makes its allocation 136 registers = three per SIMD.
 	asm volatile("" ::: "v135");
+#endif
+#ifdef K1_CAP2
+	// two per SIMD (176 registers each): 160 registers and half of the LDS stay free for PhaseSearch / derotation waves
+	asm volatile("" ::: "v175");
 #endif
 
 	if (lane < 8) { x5[0][lane] = x5[1][lane] = x6[0][lane] = x6[1][lane] = make_float2(0.f, 0.f); }
@@ -1120,12 +1129,90 @@ __global__ __launch_bounds__(64) void k2_fft_mag(K2Params p) {
 	}
 }
 
-// The same analysis riding at the end of a front-end wave (k1_dpp): a span of tiles_per_span tiles is tiles_per_span * 32
-// samples of each 48 kHz channel, i.e. p.fft_windows whole windows per channel, all of them written by this very wave a moment
-// ago (they come back from L2).  The spectral analysis then costs no kernel of its own on the front stream -- where it used to
-// take 0.05 ms alone and 0.11-0.20 ms next to the back end of the previous block -- and its arithmetic fills issue slots of a
-// kernel that is waiting for HBM most of the time.  Magnitudes leave window-major (256 contiguous bytes per store);
-// k2_mag_transpose turns them into the window-minor layout of the search kernel.
+// SquareFreqOffsetCorrection::correctFrequency (DSP.cpp:426-456) by ONE WAVE for the windows whose magnitudes it holds in
+// registers (NWIN of them side by side: their dependent chains interleave).  m[w][r] = |X[lane + 64 r]| of window w.
+//  * shifted index q = (bin + 256) % 512 lives at lane q % 64 of register q / 64;
+//  * cumsum[q] = cumsum[q - 1] + mag[q] is evaluated in exactly that order: a chain of 511 dependent additions per window, one
+//    per step of a wave-wide shift (every lane adds its left neighbour's running value; after step k the lanes up to k are
+//    final and stay so).  63 steps per register, 8 registers, the last lane's value carried into the next register;
+//  * the 379 candidates of the wide search and the 36 of the second search are then independent: cumsum and magnitudes go
+//    through LDS once (S: 1024 floats per window), every lane evaluates its candidates with the reference's expression, and
+//    "first maximum under a strict >" is a wave reduction (larger value wins, ties go to the lower index; NaN never wins,
+//    like `v > best`).
+// Returns fz (DSP.cpp:449-456: N/2 - (i + delta/2), -1 without a positive peak) in every lane.
+template <int NWIN>
+__device__ __forceinline__ void spectral_search(const float (&m)[NWIN][8], float* S, int lane, int wide, int (&fz)[NWIN]) {
+	float M[NWIN][8], C[NWIN][8];
+#pragma unroll
+	for (int w = 0; w < NWIN; w++)
+#pragma unroll
+		for (int q8 = 0; q8 < 8; q8++) M[w][q8] = m[w][(q8 + 4) & 7];
+	float carry[NWIN];
+#pragma unroll
+	for (int q8 = 0; q8 < 8; q8++) {
+		float c[NWIN], mz[NWIN];
+#pragma unroll
+		for (int w = 0; w < NWIN; w++) {
+			mz[w] = lane == 0 ? 0.0f : M[w][q8];                    // lane 0 holds its final value from the start
+			c[w] = q8 == 0 ? 0.0f : carry[w] + M[w][q8];            // cumsum[0] = 0; cumsum[64 k] = cumsum[64 k - 1] + mag[64 k]
+		}
+#pragma unroll 3
+		for (int it = 0; it < 63; it++) {
+#pragma unroll
+			for (int w = 0; w < NWIN; w++) c[w] = dpp_wave_shr1(c[w], c[w]) + mz[w];
+		}
+#pragma unroll
+		for (int w = 0; w < NWIN; w++) {
+			C[w][q8] = c[w];
+			carry[w] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c[w]), 63));
+		}
+	}
+	wave_sync(); // the FFT's last exchange has been read
+#pragma unroll
+	for (int w = 0; w < NWIN; w++)
+#pragma unroll
+		for (int q8 = 0; q8 < 8; q8++) { S[1024 * w + lane + 64 * q8] = C[w][q8]; S[1024 * w + 512 + lane + 64 * q8] = M[w][q8]; }
+	wave_sync();
+	constexpr int BIG = 0x7fffffff;
+#pragma unroll
+	for (int w = 0; w < NWIN; w++) {
+		const float* Cs = S + 1024 * w;
+		const float* Ms = Cs + 512;
+		int wi = 0;
+		if (wide) { // v(i) = cumsum[i + M] - cumsum[i] + 0.6f * (mag[i + ofs] + mag[i + ofs + delta]), i = 0 .. 378 (DSP.cpp:426-447)
+			float best = -1.0f;
+			int bi = BIG;
+#pragma unroll
+			for (int t = 0; t < 6; t++) {
+				const int i = lane + 64 * t;
+				if (i <= 512 - 134) {
+					const float v = Cs[i + 133] - C[w][t] + 0.6f * (Ms[i + 15] + Ms[i + 117]);
+					if (v > best) { best = v; bi = i; }
+				}
+			}
+			wave_argmax_first(best, bi);
+			if (!(best > -1.0f)) bi = 0;
+			wi = bi + 66 - 256; // wi + M/2 - N/2
+		}
+		// second search (DSP.cpp:449-456): i in [wi + 187, wi + 223), first maximum above 0
+		float h = 0.0f;
+		int hidx = BIG;
+		if (lane < 36) {
+			const int i = wi + 187 + lane;
+			const float v = Ms[(i + 512) & 511] + Ms[(i + 102 + 512) & 511];
+			if (v > 0.0f) { h = v; hidx = i; }
+		}
+		wave_argmax_first(h, hidx);
+		fz[w] = (h > 0.0f) ? (205 - hidx) : -1;
+	}
+}
+
+// The whole spectral analysis riding at the end of a front-end wave (k1_dpp): a span of 16 tiles is 512 samples of each 48 kHz
+// channel, i.e. one window of SquareFreqOffsetCorrection per channel (p.fft_windows of them for longer spans), all written by
+// this very wave a moment ago.  FFT, magnitudes, prefix sum and both peak searches happen in the wave's registers and LDS; what
+// leaves is fz and ppm of the window -- 8 bytes instead of 2 KB of magnitudes -- so neither the FFT kernel (0.05 ms alone,
+// 0.16-0.20 ms on the front stream next to the previous block's back end), nor a search kernel, nor 0.2 GB of magnitude
+// traffic per step remain, and the arithmetic fills issue slots of a kernel that waits for HBM most of the time.
 __device__ __forceinline__ void k1_fft_tail(const K1Params& p, int rx, int span, float2* X) {
 	const int lane = threadIdx.x;
 #ifdef K1_TAIL_PRIO
@@ -1137,49 +1224,32 @@ __device__ __forceinline__ void k1_fft_tail(const K1Params& p, int rx, int span,
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	FftTwiddles t = fft_twiddles(p.omega, lane);
 	const int src = fft_src_lane(lane);
-	const int nw = p.fft_windows, n = 2 * nw;
-	float2 dn[8];
-	const auto fetch = [&](int i) {
-		const int ch = i >= nw ? 1 : 0, w = span * nw + (i - ch * nw);
-		const float2* x = p.c48 + ((size_t)rx * 2 + ch) * p.c48_stride + (size_t)w * 512 + src;
+	const int nw = p.fft_windows;
+	float* S = reinterpret_cast<float*>(X); // 2 x 1024 floats for the searches; the FFT's exchange buffer (584 float2) is the front of it
+	for (int i = 0; i < nw; i++) {
+		const int w = span * nw + i;
+		float2 d[2][8];
 #pragma unroll
-		for (int r = 0; r < 8; r++) dn[r] = x[fft_src_step(r)];
-	};
-	fetch(0);
-	for (int i = 0; i < n; i++) {
-		c2 v[8];
-		fft_square(dn, v);
-		__builtin_amdgcn_sched_barrier(0);
-		if (i + 1 < n) fetch(i + 1);
-		__builtin_amdgcn_sched_barrier(0);
-		float m[8];
-		fft512_mag(v, X, t, lane, m);
-		const int ch = i >= nw ? 1 : 0, w = span * nw + (i - ch * nw);
-		float* row = p.magW + (((size_t)rx * 2 + ch) * p.n_windows + w) * 512;
+		for (int ch = 0; ch < 2; ch++) {
+			const float2* x = p.c48 + ((size_t)rx * 2 + ch) * p.c48_stride + (size_t)w * 512 + src;
 #pragma unroll
-		for (int r = 0; r < 8; r++) row[(lane + 64 * r + 256) & 511] = m[r];
-	}
-}
-
-// window-major magnitudes [W][512] -> window-minor [W / 64][512][64] (what k2_cgf_search's lane-per-window walk reads)
-__global__ __launch_bounds__(256) void k2_mag_transpose(const float* __restrict__ magW, float* __restrict__ magT, int n_win_total) {
-	__shared__ float tile[64][65];
-	const int t = threadIdx.x, W0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+			for (int r = 0; r < 8; r++) d[ch][r] = x[fft_src_step(r)];
+		}
+		float m[2][8];
 #pragma unroll
-	for (int pass = 0; pass < 4; pass++) {
-		const int wl = pass * 16 + (t >> 4);
-		int W = W0 + wl;
-		W = W < n_win_total ? W : n_win_total - 1;
-		const float4 v = *reinterpret_cast<const float4*>(magW + (size_t)W * 512 + b0 + (t & 15) * 4);
-		float* d = &tile[wl][(t & 15) * 4];
-		d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-	}
-	__syncthreads();
-	float* dst = magT + (size_t)blockIdx.x * (512 * 64) + (size_t)b0 * 64;
-#pragma unroll
-	for (int pass = 0; pass < 16; pass++) {
-		const int bin = pass * 4 + (t >> 6), wl = t & 63;
-		dst[(size_t)bin * 64 + wl] = tile[wl][bin];
+		for (int ch = 0; ch < 2; ch++) {
+			c2 v[8];
+			fft_square(d[ch], v);
+			fft512_mag(v, X, t, lane, m[ch]);
+		}
+		int fz[2];
+		spectral_search<2>(m, S, lane, p.wide, fz);
+		if (lane < 2) {
+			const int f = lane == 0 ? fz[0] : fz[1];
+			const size_t W = ((size_t)rx * 2 + lane) * p.n_windows + w;
+			p.fz[W] = f;
+			p.ppm[W] = p.ppm_table[f + 205];
+		}
 	}
 }
 
@@ -3124,12 +3194,6 @@ hipError_t launch_selftest_hypot(const float2* in, int n, unsigned* mismatches, 
 hipError_t launch_k2a_fft(const K2Params& p, int n_chan, hipStream_t s) {
 	const int n = n_chan * p.n_windows;
 	hipLaunchKernelGGL(k2_fft_mag, dim3((n + FFT_NW - 1) / FFT_NW), dim3(64), 0, s, p);
-	return hipGetLastError();
-}
-
-hipError_t launch_k2a_transpose(const K2Params& p, int n_chan, hipStream_t s) {
-	const int n = n_chan * p.n_windows;
-	hipLaunchKernelGGL(k2_mag_transpose, dim3((n + 63) / 64, 8), dim3(256), 0, s, p.magW, p.magT, n);
 	return hipGetLastError();
 }
 
