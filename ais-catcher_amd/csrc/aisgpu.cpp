@@ -99,6 +99,8 @@ struct aisgpu {
 	// device buffers
 	void* d_in = nullptr; void* d_hist[2] = {}; void* d_hist2[2] = {}; // input tails, double buffered (read by span 0, written for the next block)
 	float2* d_xpre[2] = {};           // pre-decimated stream: [R][xh + n_pre], ping-pong by input block (MODE_PRE uses [0] only)
+	float2* d_xmid = nullptr;         // [R][block_len >> KPa]: between the two passes of a pre-decimation of more than four stages
+	int KPa = 0;                      // != 0: the pre-decimation runs as KPa stages, then four (rates above 6144k that are resampled: 8 / 10 MSPS)
 	float2* d_rot[2] = {};
 	int* d_usidx[2] = {}; float* d_usalpha[2] = {};
 	float2 *d_c48[NBUF] = {}, *d_sym[2] = {};
@@ -682,7 +684,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			if (k <= 4) { mode = MODE_DIRECT; K = k; KP = 0; }
 			else { mode = MODE_PRE; K = 4; KP = k - 4; }
 		} else {
-			if (k < 3 || k > 6) return AISGPU_ERR_ARG; // the resampler sits two CIC5 stages in front of 96 kHz
+			if (k < 3) return AISGPU_ERR_ARG; // the resampler sits two CIC5 stages in front of 96 kHz
 			mode = MODE_RESAMPLE; K = 0; KP = k - 2;
 		}
 	}
@@ -747,8 +749,9 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		h->tiles_per_span = span_tiles(h->tiles_per_block, cfg->n_receivers, h->k1_threads, h->tile96, cfg->tiles_per_span);
 		h->spans = (h->tiles_per_block + h->tiles_per_span - 1) / h->tiles_per_span;
 	}
+	if (KP > 4) h->KPa = KP - 4; // (only the resampled 12288k bucket: five stages in front of the resampler, Model.cpp:166-172)
 	if (KP > 0) {
-		h->ptile_in = h->tile96 << KP;
+		h->ptile_in = h->tile96 << (h->KPa ? h->KPa : KP);
 		if (cfg->block_len % h->ptile_in) { delete h; return AISGPU_ERR_ARG; }
 		h->ptiles_per_block = cfg->block_len / h->ptile_in;
 		h->ptiles_per_span = span_tiles(h->ptiles_per_block, cfg->n_receivers, h->k1_threads, h->tile96, cfg->tiles_per_span);
@@ -872,6 +875,11 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		const int nx = mode == MODE_RESAMPLE || mode == MODE_DSK ? 2 : 1;
 		for (int i = 0; i < nx; i++) HIPCHK(dalloc(&h->d_xpre[i], R * ((size_t)h->xh + h->n_pre)));
 		if (mode == MODE_PRE) for (int i = 0; i < 2; i++) HIPCHK(dalloc((unsigned char**)&h->d_hist2[i], R * h->tile_in * 8));
+		if (h->KPa) { // second pre-decimation pass: four stages on the CF32 stream of the first
+			if ((cfg->block_len >> h->KPa) % (h->tile96 << 4)) return AISGPU_ERR_ARG;
+			HIPCHK(dalloc(&h->d_xmid, R * (size_t)(cfg->block_len >> h->KPa)));
+			for (int i = 0; i < 2; i++) HIPCHK(dalloc((unsigned char**)&h->d_hist2[i], R * (size_t)(h->tile96 << 4) * 8));
+		}
 	}
 	for (int i = 0; i < 2; i++) {
 		HIPCHK(dalloc(&h->d_rot[i], (size_t)ROT_HIST + h->n96));
@@ -1022,6 +1030,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 		if (h->h_usalpha[i]) hipHostFree(h->h_usalpha[i]);
 	}
 	for (auto& p : h->ev_free) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+	hipFree(h->d_xmid);
 	hipFree(h->d_in); hipFree(h->d_hist[0]); hipFree(h->d_hist[1]); hipFree(h->d_hist2[0]); hipFree(h->d_hist2[1]);
 	hipFree(h->d_fm); hipFree(h->d_fmbits[0]); hipFree(h->d_fmbits[1]);
 	if (h->h_fmbits) hipHostFree(h->h_fmbits);
@@ -1117,15 +1126,30 @@ int aisgpu_run(aisgpu_t* h) {
 			HIPCHK(launch_copy_rows(h->d_xpre[xb ^ 1] + h->n_pre, xstride, xcur, xstride, h->xh, R, h->stream));
 		K1Params kp{};
 		const int hb = (int)(h->in_blocks & 1);
-		const bool pre_saves = !cu8 && h->KP >= 2 && h->depth == 0; // the register/LDS-DMA kernel saves the tail itself
+		const int KP1 = h->KPa ? h->KPa : h->KP; // stages of the (first) pass over the raw input
+		const long long n_mid = (long long)h->cfg.block_len >> KP1;
+		const bool pre_saves = !cu8 && KP1 >= 2 && h->depth == 0; // the register/LDS-DMA kernel saves the tail itself
 		kp.in = h->cur_in; kp.in_stride = h->cur_in_stride; kp.hist = h->d_hist[hb]; kp.hist_out = pre_saves ? h->d_hist[hb ^ 1] : nullptr; kp.rot = nullptr;
 		kp.c48 = nullptr; kp.c48_stride = 0;
 		kp.tiles_per_block = h->ptiles_per_block; kp.tiles_per_span = h->ptiles_per_span;
 		kp.alpha = 0; kp.beta = 1; kp.has_fdc = 0;
-		kp.pre_out = xcur + h->xh; kp.pre_stride = xstride;
+		kp.pre_out = h->KPa ? h->d_xmid : xcur + h->xh; kp.pre_stride = h->KPa ? n_mid : xstride;
 		int rc = time_begin(); if (rc) return rc;
-		HIPCHK(launch_k1(kp, h->KP, h->kfmt, h->tile96, h->depth, h->k1_threads, h->pspans, R, h->stream));
+		HIPCHK(launch_k1(kp, KP1, h->kfmt, h->tile96, h->depth, h->k1_threads, h->pspans, R, h->stream));
 		rc = time_end(); if (rc) return rc;
+		if (h->KPa) { // four more stages on the CF32 stream of the first pass (its own tail tile: d_hist2)
+			K1Params kb{};
+			const int tile_b = h->tile96 << 4;
+			const bool b_saves = h->depth == 0;
+			kb.in = h->d_xmid; kb.in_stride = n_mid; kb.hist = h->d_hist2[hb]; kb.hist_out = b_saves ? h->d_hist2[hb ^ 1] : nullptr; kb.rot = nullptr;
+			kb.c48 = nullptr; kb.c48_stride = 0;
+			kb.tiles_per_block = (int)(n_mid / tile_b);
+			kb.tiles_per_span = span_tiles(kb.tiles_per_block, (int)R, h->k1_threads, h->tile96, h->cfg.tiles_per_span);
+			kb.alpha = 0; kb.beta = 1; kb.has_fdc = 0;
+			kb.pre_out = xcur + h->xh; kb.pre_stride = xstride;
+			HIPCHK(launch_k1(kb, 4, 0, h->tile96, h->depth, h->k1_threads, (kb.tiles_per_block + kb.tiles_per_span - 1) / kb.tiles_per_span, R, h->stream));
+			if (!b_saves) HIPCHK(launch_k1_tail(h->d_xmid, n_mid * 8, n_mid * 8, h->d_hist2[hb ^ 1], tile_b * 8, R, h->stream));
+		}
 		if (!pre_saves) HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist[hb ^ 1],
 		                                      h->ptile_in * h->in_bytes, R, h->stream));
 	}

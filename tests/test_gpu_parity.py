@@ -376,6 +376,17 @@ def test_other_resampled_rates(rate):
     _run_multi_sub(x, rate, block, 4)
 
 
+@pytest.mark.parametrize("rate,fmt", [(10000000, "cf32"), (8000000, "cf32"), (10000000, "cu8")])
+def test_resampled_rates_above_6144k(rate, fmt):
+    """10 MSPS (Airspy R2) / 8 MSPS: bucket 12288k, FIVE CIC5 stages in front of the resampler (Model.cpp:166-172) -- two
+    pre-decimation passes (1 + 4 stages) -- then Upsample -> DS2_2 -> DS2_1 -> FDC(-2.0)."""
+    block = 512 * 256 * 6
+    x = synth.receiver_stream(block * 4, sample_rate=rate, receiver_id=53, gap_slots=(1, 2))
+    if fmt == "cu8":
+        x = synth.to_cu8(x)
+    _run_multi_sub(x, rate, block, 4, fmt=fmt)
+
+
 def test_challenger_fm_branch_bits_and_nmea():
     """AIS::ModelChallenger at 1536 kSPS: FM-branch decisions (atan2f discriminator -> 37-tap FIR -> sign) and the
     end-to-end NMEA of the 20-decoder wiring == the checker (Model.cpp:601-678)."""

@@ -70,6 +70,13 @@ def test_default_6msps_upsampled():
     assert len(lines) >= 1
 
 
+@pytest.mark.parametrize("rate", [10000000, 8000000])
+def test_default_rates_above_6144k_upsampled(rate):
+    # 10 MSPS (Airspy R2) / 8 MSPS -> 12.288M bucket: DS2_7 .. DS2_3, Upsample, DS2_2, DS2_1, FDC(-2.0) (Model.cpp:166-172)
+    lines = _compare(2, rate, "cf32", 512 * 256 * 6, 4, rid=6, gap_slots=(1, 2))
+    assert len(lines) >= 1
+
+
 def test_strict_and_shipped_builds_decode_the_same():
     if not checkers.have_ref("fast"):
         pytest.skip("fast build missing")
