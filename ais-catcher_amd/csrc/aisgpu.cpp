@@ -684,7 +684,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			if (k <= 4) { mode = MODE_DIRECT; K = k; KP = 0; }
 			else { mode = MODE_PRE; K = 4; KP = k - 4; }
 		} else {
-			if (k < 3) return AISGPU_ERR_ARG; // the resampler sits two CIC5 stages in front of 96 kHz
+			if (k < 2) return AISGPU_ERR_ARG; // the resampler sits two CIC5 stages in front of 96 kHz (k == 2: on the input itself)
 			mode = MODE_RESAMPLE; K = 0; KP = k - 2;
 		}
 	}
@@ -756,8 +756,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		h->ptiles_per_block = cfg->block_len / h->ptile_in;
 		h->ptiles_per_span = span_tiles(h->ptiles_per_block, cfg->n_receivers, h->k1_threads, h->tile96, cfg->tiles_per_span);
 		h->pspans = (h->ptiles_per_block + h->ptiles_per_span - 1) / h->ptiles_per_span;
-		h->xh = mode == MODE_RESAMPLE ? h->n_pre + XPAD : 0;
 	}
+	if (mode == MODE_RESAMPLE) h->xh = h->n_pre + XPAD;
 	if (mode == MODE_DSK) h->xh = DSK_HIST;
 	*out = h; // from here on the caller destroys it on failure
 
@@ -871,7 +871,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			if (cfg->input_format == AISGPU_FMT_CU8 && h->kfmt != 4) HIPCHK(hipMemset(h->d_hist[i], 0x80, R * first_tile * h->in_bytes));
 		}
 	}
-	if (KP > 0 || mode == MODE_DSK) {
+	if (KP > 0 || mode == MODE_DSK || mode == MODE_RESAMPLE) {
 		const int nx = mode == MODE_RESAMPLE || mode == MODE_DSK ? 2 : 1;
 		for (int i = 0; i < nx; i++) HIPCHK(dalloc(&h->d_xpre[i], R * ((size_t)h->xh + h->n_pre)));
 		if (mode == MODE_PRE) for (int i = 0; i < 2; i++) HIPCHK(dalloc((unsigned char**)&h->d_hist2[i], R * h->tile_in * 8));
@@ -1110,7 +1110,8 @@ int aisgpu_run(aisgpu_t* h) {
 	// ---- pre-decimation pass (MODE_PRE / MODE_RESAMPLE): KP CIC5 stages at the input rate -> d_xpre
 	float2* xcur = nullptr;
 	long long xstride = 0;
-	if (h->KP == 0 && h->mode == MODE_DSK) { // 288 kHz input: no CIC5 stage in front of DownsampleKFilter, only the conversion
+	if (h->KP == 0 && (h->mode == MODE_DSK || h->mode == MODE_RESAMPLE)) { // 288 kHz input: no CIC5 stage in front of DownsampleKFilter, only the
+		// conversion; likewise rates resampled into the 384k bucket: Upsample works on the converted input itself (Model.cpp:295-301)
 		const int xb = (int)(h->in_blocks & 1);
 		xcur = h->d_xpre[xb];
 		xstride = (long long)h->xh + h->n_pre;

@@ -1948,7 +1948,9 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 						if (g + e < g1) part |= ps_step<MODE>(v[e], pc, psn, ma, hs, idx, k, rowbase) << e; // wave-uniform
 				}
 				word |= part << (q & 31);
-				if (((q + PS_BATCH) & 31) == 0) {
+				// (a last, partial batch never completes a word -- the write behind the loop is the one that stores it;
+				// flushed here as well it was overwritten by an empty word whenever n % 32 was 25 .. 31)
+				if (((q + PS_BATCH) & 31) == 0 && g + PS_BATCH <= g1) {
 					if (live) wout[(q >> 5) * 16] = word;
 					word = 0;
 				}

@@ -376,6 +376,18 @@ def test_other_resampled_rates(rate):
     _run_multi_sub(x, rate, block, 4)
 
 
+@pytest.mark.parametrize("rate,fmt", [(300000, "cf32"), (350000, "cf32"), (300000, "cu8"), (300000, "cs16")])
+def test_resampled_rates_into_the_384k_bucket(rate, fmt):
+    """288k < rate < 384k: the resampler works on the converted input itself (no CIC5 stage in front, Model.cpp:295-301)."""
+    block = 4096 * 24
+    x = synth.receiver_stream(block * 5, sample_rate=rate, receiver_id=54, gap_slots=(1, 2))
+    if fmt == "cu8":
+        x = synth.to_cu8(x)
+    elif fmt == "cs16":
+        x = synth.to_cs16(x)
+    _run_multi_sub(x, rate, block, 5, fmt=fmt)
+
+
 @pytest.mark.parametrize("rate,fmt", [(10000000, "cf32"), (8000000, "cf32"), (10000000, "cu8")])
 def test_resampled_rates_above_6144k(rate, fmt):
     """10 MSPS (Airspy R2) / 8 MSPS: bucket 12288k, FIVE CIC5 stages in front of the resampler (Model.cpp:166-172) -- two
@@ -737,6 +749,17 @@ def test_spectral_analysis_at_the_end_of_the_front_end_waves(tps, env, monkeypat
         _run_outputs_vs_oracle([x], 6144000, "cf32", 786432, 2, **kw)  # pre-decimation pass in front: 192 tiles of the second pass
         x = synth.receiver_stream(24576 * 3, sample_rate=384000, receiver_id=124, gap_slots=(1, 2))
         _run_outputs_vs_oracle([x], 384000, "cf32", 24576 * 2, 1, **kw)  # two stages only: 96 tiles
+
+
+@pytest.mark.parametrize("windows", [14, 19, 24, 39])
+def test_phase_search_chunk_whose_last_word_ends_in_a_partial_batch(windows):
+    """Group counts whose last chunk has 25 .. 31 symbols in its last word (409, 410, 921, 922 ...): the chunk kernel's last,
+    partial batch of 8 ends on a word boundary.  (Such a word used to be flushed inside the loop and then overwritten by an
+    empty one; found with the 300 kSPS ladder, whose blocks of 12288 samples at 48 kHz have 2457 groups.)"""
+    block = 32 * 512 * windows
+    xs = [synth.receiver_stream(block * 3, receiver_id=130 + r, gap_slots=(0, 1)) for r in range(2)]
+    _run_outputs_vs_oracle(xs, 1536000, "cf32", block, 3)
+    _run_gpu_vs_oracle(xs[:1], 1536000, "cf32", block, 2)  # materialised back end (taps)
 
 
 def test_materialised_backend_without_taps(monkeypatch):

@@ -70,6 +70,13 @@ def test_default_6msps_upsampled():
     assert len(lines) >= 1
 
 
+@pytest.mark.parametrize("rate", [300000, 350000])
+def test_default_rates_upsampled_into_the_384k_bucket(rate):
+    # 288k < rate < 384k: Upsample on the converted input itself, then DS2_2, DS2_1, FDC(-1.1) (Model.cpp:295-301)
+    lines = _compare(2, rate, "cf32", 4096 * 24, 5, rid=7, gap_slots=(1, 2))
+    assert len(lines) >= 1
+
+
 @pytest.mark.parametrize("rate", [10000000, 8000000])
 def test_default_rates_above_6144k_upsampled(rate):
     # 10 MSPS (Airspy R2) / 8 MSPS -> 12.288M bucket: DS2_7 .. DS2_3, Upsample, DS2_2, DS2_1, FDC(-2.0) (Model.cpp:166-172)
