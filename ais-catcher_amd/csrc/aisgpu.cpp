@@ -100,6 +100,7 @@ struct aisgpu {
 	void* d_in = nullptr; void* d_hist[2] = {}; void* d_hist2[2] = {}; // input tails, double buffered (read by span 0, written for the next block)
 	float2* d_xpre[2] = {};           // pre-decimated stream: [R][xh + n_pre], ping-pong by input block (MODE_PRE uses [0] only)
 	float2* d_xmid = nullptr;         // [R][block_len >> KPa]: between the two passes of a pre-decimation of more than four stages
+	bool us_dsk = false;              // Upsample in front of DownsampleKFilter (rates below a decimate-by-3 bucket): resampler flow, K1k front end
 	int KPa = 0;                      // != 0: the pre-decimation runs as KPa stages, then four (rates above 6144k that are resampled: 8 / 10 MSPS)
 	float2* d_rot[2] = {};
 	int* d_usidx[2] = {}; float* d_usalpha[2] = {};
@@ -675,9 +676,10 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	for (int i = 0; i < n3; i++) if (buckets3[i] >= cfg->sample_rate && (k < 0 || buckets3[i] < buckets[k])) { k3 = i; break; }
 	if (cfg->sample_rate < 96000 || (k < 1 && k3 < 0)) return AISGPU_ERR_ARG;
 	Mode mode; int K, KP;
+	const bool by3 = k3 >= 0;
 	if (k3 >= 0) { // a decimate-by-3 bucket is the smallest one >= rate
-		if (buckets3[k3] != cfg->sample_rate) return AISGPU_ERR_ARG; // Upsample in front of DownsampleKFilter: not built
-		mode = MODE_DSK; K = 0; KP = k3; k = 0;
+		// below the bucket: convert >> DS2.. >> US >> DSK (Model.cpp:213-219 etc.): the resampler flow with the decimate-by-3 front end
+		mode = buckets3[k3] != cfg->sample_rate ? MODE_RESAMPLE : MODE_DSK; K = 0; KP = k3; k = 0;
 	} else {
 		const bool interpolated = buckets[k] != cfg->sample_rate;
 		if (!interpolated) {
@@ -694,11 +696,11 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	    cfg->input_format != AISGPU_FMT_CS16) return AISGPU_ERR_ARG;
 	if (cfg->n_receivers < 1 || cfg->n_receivers > 65535) return AISGPU_ERR_ARG;
 	// a downstream block must be a whole number of 512-sample CGF windows
-	const int dec48 = mode == MODE_DSK ? 6 << KP : 2 << k; // input samples per 48 kHz sample (bucket rate)
+	const int dec48 = by3 ? 6 << KP : 2 << k; // input samples per 48 kHz sample (bucket rate)
 	if (cfg->block_len < 512 * dec48 || cfg->block_len % (512 * dec48) != 0) return AISGPU_ERR_ARG;
 	// DownsampleKFilter hands its output on in blocks of 8192 samples (DSP.h:193), whatever the input block was: only
 	// input blocks that are a whole number of them reproduce the reference's call pattern (its file block does)
-	if (mode == MODE_DSK && cfg->block_len % ((3 * 8192) << KP) != 0) return AISGPU_ERR_ARG;
+	if (by3 && cfg->block_len % ((3 * 8192) << KP) != 0) return AISGPU_ERR_ARG;
 	if (aisgpu_device_count() <= cfg->device_id || cfg->device_id < 0) return AISGPU_ERR_NODEV;
 
 	aisgpu_t* h = new (std::nothrow) aisgpu();
@@ -727,8 +729,9 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	}
 	if (h->kfmt > 1 && h->depth != 0) { delete h; return AISGPU_ERR_ARG; } // CS8 / CS16 / fixed point: register (DPP) front end only
 	h->n_pre = cfg->block_len >> KP;
-	if (mode == MODE_RESAMPLE) h->n96 = h->n_pre / 4; // one flush of n_pre samples at the bucket rate >> KP (= 384 kHz)
-	else if (mode == MODE_DSK) h->n96 = h->n_pre / 3;
+	h->us_dsk = by3 && mode == MODE_RESAMPLE;
+	if (by3) h->n96 = h->n_pre / 3;
+	else if (mode == MODE_RESAMPLE) h->n96 = h->n_pre / 4; // one flush of n_pre samples at the bucket rate >> KP (= 384 kHz)
 	else h->n96 = h->n_pre >> K;
 	h->L = h->n96 / 2;
 	h->W = h->L / 512;
@@ -737,11 +740,11 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->words = h->Gcap / 32;
 	h->n_chan = cfg->n_receivers * 2;
 	h->n_chains = h->n_chan * 5;
-	h->has_fdc = cfg->droop && mode != MODE_DSK ? 1 : 0; // no droop filter on the decimate-by-3 ladders (Model.cpp:207-219)
+	h->has_fdc = cfg->droop && !by3 ? 1 : 0; // no droop filter on the decimate-by-3 ladders (Model.cpp:207-219)
 	h->alpha = alphas[k];
 	h->beta = 1 - 2 * h->alpha; // DSP/DSP.h:296, evaluated in float
-	h->us_increment = (float)cfg->sample_rate / (float)buckets[k]; // DSP/DSP.h:172-176
-	h->rot_period = mode == MODE_DSK ? 8192 : 0; // Rotate is called once per DownsampleKFilter output block
+	h->us_increment = (float)cfg->sample_rate / (float)(by3 ? buckets3[k3] : buckets[k]); // DSP/DSP.h:172-176
+	h->rot_period = by3 ? 8192 : 0; // Rotate is called once per DownsampleKFilter output block
 	if (K > 0) {
 		h->tile_in = h->tile96 << K;
 		if (h->n_pre % h->tile_in) { delete h; return AISGPU_ERR_ARG; }
@@ -1169,6 +1172,7 @@ int aisgpu_run(aisgpu_t* h) {
 		K1kParams kk;
 		kk.xin = xcur; kk.xin_stride = xstride; kk.xin_off = h->xh;
 		kk.rot = h->d_rot[pb]; kk.c48 = h->d_c48[q]; kk.c48_stride = h->c48s; kk.L = h->L;
+		kk.us_idx = nullptr; kk.us_alpha = nullptr;
 		memcpy(kk.taps, TAPS_BH_28_3, sizeof kk.taps);
 		HIPCHK(launch_k1k(kk, R, h->stream));
 		int rc = enqueue_downstream(h, q, pb);
@@ -1260,12 +1264,21 @@ int aisgpu_run(aisgpu_t* h) {
 					HIPCHK(hipMemcpyAsync(h->d_usalpha[pb], ta, ((size_t)US_HIST + len) * sizeof(float), hipMemcpyHostToDevice, h->stream));
 					HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
 					HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[q], 0));
+					if (h->us_dsk) { // US >> DSK >> ROT: the flush is a whole number of the filter's 8192-sample output blocks
+						K1kParams kk;
+						kk.xin = xcur; kk.xin_stride = xstride; kk.xin_off = h->xh;
+						kk.rot = h->d_rot[pb]; kk.c48 = h->d_c48[q]; kk.c48_stride = h->c48s; kk.L = h->L;
+						kk.us_idx = h->d_usidx[pb]; kk.us_alpha = h->d_usalpha[pb];
+						memcpy(kk.taps, TAPS_BH_28_3, sizeof kk.taps);
+						HIPCHK(launch_k1k(kk, R, h->stream));
+					} else {
 					K1uParams ku;
 					ku.xin = xcur; ku.xin_stride = xstride; ku.xin_off = h->xh;
 					ku.us_idx = h->d_usidx[pb]; ku.us_alpha = h->d_usalpha[pb]; ku.rot = h->d_rot[pb];
 					ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
 					ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->has_fdc; ku.L = h->L;
 					HIPCHK(launch_k1u(ku, R, h->stream));
+					}
 					int rc = enqueue_downstream(h, q, pb);
 					if (rc) return rc;
 				}

@@ -47,6 +47,7 @@ struct K1kParams { // decimate-by-3 front end (DownsampleKFilter ladders: 288k *
 	const float2* rot;      // [ROT_HIST + n96]
 	float2* c48; long long c48_stride;
 	float taps[26];         // Filters::BlackmanHarris_28_3
+	const int* us_idx; const float* us_alpha; // != nullptr: [US_HIST + len] Upsample in front of the filter (see K1uParams), xin is ITS input
 	int L;                  // 48 kHz samples per channel per block
 };
 constexpr int DSK_HIST = 128; // samples of the 288 kHz stream kept in front of a block

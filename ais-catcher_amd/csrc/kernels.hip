@@ -855,6 +855,16 @@ __global__ __launch_bounds__(256) void k1k_dsk_frontend(K1kParams p) {
 	const int m0 = blockIdx.x * M;
 	const float2* x = p.xin + (size_t)rx * p.xin_stride + p.xin_off;
 	const int n_lo = 6 * m0 - 70;
+	if (p.us_idx) { // Upsample in front of the filter (rates below a decimate-by-3 bucket): sample n of the flush is interpolated
+		for (int q = t; q < 6 * M + 70; q += 256) { // from the input stream like in K1u (DSP.cpp:199: products rounded separately)
+			const int n = n_lo + q;
+			const int i = p.us_idx[US_HIST + n];
+			const float al = p.us_alpha[US_HIST + n];
+			const float2 a = x[i - 1], b = x[i];
+			const float w0 = 1 - al;
+			X[q] = make_float2(w0 * a.x + al * b.x, w0 * a.y + al * b.y);
+		}
+	} else
 	for (int q = t; q < 6 * M + 70; q += 256) X[q] = x[n_lo + q];
 	__syncthreads();
 	for (int q = t; q < 2 * M + 15; q += 256) { // i = 2 m0 - 15 + q

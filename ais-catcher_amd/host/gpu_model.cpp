@@ -108,8 +108,15 @@ void GpuChain::process(const void* data, int len, TAG& tag) {
 	// On the decimate-by-3 ladders DownsampleKFilter hands its output on in blocks of 8192 samples (DSP/DSP.h:193), so Rotate --
 	// and with it the A-then-B order -- works on 4096 samples at 48 kHz at a time, however long the input block was.
 	const aisgpu_cfg& cf = batch->config();
-	const bool by3 = cf.sample_rate == 288000 ||
-	                 ((cf.flags & AISGPU_FLAG_DSK) && (cf.sample_rate == 576000 || cf.sample_rate == 1152000 || cf.sample_rate == 2304000));
+	bool by3 = false; // the smallest bucket >= rate is a decimate-by-3 one (Model.cpp:129-145), exact or resampled into
+	{
+		static const int b2[8] = { 96000, 192000, 384000, 768000, 1536000, 3072000, 6144000, 12288000 };
+		static const int b3[4] = { 288000, 576000, 1152000, 2304000 };
+		int best = 0;
+		for (int i = 0; i < 8 && !best; i++) if (b2[i] >= cf.sample_rate) best = b2[i];
+		const int n3 = (cf.flags & AISGPU_FLAG_DSK) ? 4 : 1;
+		for (int i = 0; i < n3; i++) if (b3[i] >= cf.sample_rate && (!best || b3[i] < best)) { by3 = true; break; }
+	}
 	for (int s = 0; s < nsub; s++) {
 		aisgpu_out o[2];
 		for (int ch = 0; ch < 2; ch++)

@@ -701,7 +701,10 @@ static void upsample_run(ao_chain* c, const cf* x, int len) { /* DSP.cpp:192-212
 			cf o = { w0 * u->a.re + u->alpha * b.re, w0 * u->a.im + u->alpha * b.im };
 			u->out[u->idx_out++] = o;
 			u->alpha += u->increment;
-			if (u->idx_out == len || u->idx_out == u->cap) { post_us(c, u->out, u->idx_out); u->idx_out = 0; }
+			if (u->idx_out == len || u->idx_out == u->cap) { /* US >> DS2_2 .., or US >> DSK on the decimate-by-3 ladders (Model.cpp:213-219 etc.) */
+				if (c->has_dsk) dsk_run(c, u->out, u->idx_out); else post_us(c, u->out, u->idx_out);
+				u->idx_out = 0;
+			}
 		} while (u->alpha < 1.0f);
 		u->alpha -= 1.0f;
 		u->a = b;
@@ -774,8 +777,8 @@ int ao_feed(ao_chain* c, const void* data, int nbytes) {
 		in = o; m /= 2;
 		o = (o == c->b1) ? c->b0 : c->b1;
 	}
-	if (c->has_dsk) dsk_run(c, in, m);
-	else if (c->has_us) upsample_run(c, in, m);
+	if (c->has_us) upsample_run(c, in, m);
+	else if (c->has_dsk) dsk_run(c, in, m);
 	else post_us(c, in, m);
 	return 0;
 }
@@ -795,18 +798,17 @@ ao_chain* ao_create(int model, int sample_rate, int fmt, int flags) {
 	int k = 0, is3 = 0; /* bucket = 96000 * 2^k or 288000 * 2^k */
 	if (bucket % 288000 == 0) { is3 = 1; while ((288000u << k) != bucket) k++; }
 	else while ((96000u << k) != bucket) k++;
-	/* interpolation into a decimate-by-3 bucket (US >> DSK) is outside this oracle */
-	if (is3 && bucket != (unsigned)sample_rate) return NULL;
 	static const float alphas[] = { 0.0f, -0.8f, -1.1f, -1.2f, -1.2f, -1.5f, -2.0f, -2.0f }; /* Model.cpp:157-338 */
 	ao_chain* c = (ao_chain*)calloc(1, sizeof(ao_chain));
 	c->model = model; c->fmt = fmt; c->rate = sample_rate; c->taps = taps;
 	c->ps_ema = !((flags >> 2) & 1);
 	c->fixed = ((flags >> 3) & 1) && sample_rate == 1536000; /* Model.cpp:224: only the 1536k case looks at fixedpointDS */
 	c->has_dsk = is3;
-	c->has_us = !is3 && bucket != (unsigned)sample_rate;
+	c->has_us = bucket != (unsigned)sample_rate;
 	c->has_fdc = !is3 && k > 0; /* the decimate-by-3 ladders have no droop compensation (Model.cpp:207-219 etc.) */
 	c->fdc_alpha = is3 ? 0.0f : alphas[k];
-	if (c->has_us) { c->npost = k >= 2 ? 2 : k; c->npre = k - c->npost; }
+	if (is3) { c->npre = k; c->npost = 0; } /* convert >> DS2_k .. DS2_1 >> [US] >> DSK */
+	else if (c->has_us) { c->npost = k >= 2 ? 2 : k; c->npre = k - c->npost; }
 	else { c->npre = k; c->npost = 0; }
 	c->us.increment = (float)sample_rate / (float)bucket;
 	c->rot.re = 1.0f; c->rot.im = 0.0f;

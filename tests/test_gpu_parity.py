@@ -310,13 +310,13 @@ def test_phase_search_fallback_and_variants(env, monkeypatch):
     _run_gpu_vs_oracle(xs, 1536000, "cf32", 786432, 2)
 
 
-def _run_multi_sub(x, rate, block, nblocks, fmt="cf32"):
+def _run_multi_sub(x, rate, block, nblocks, fmt="cf32", dsk=False):
     """Rates whose ladder contains the resampler or a pre-decimation pass: compare every completed downstream
     block (there can be 1 or 2 per input block) with the oracle's stream."""
     g = gpu.AisGpu(sample_rate=rate, n_receivers=1, block_len=block,
-                   input_format=_FMT[fmt], taps=True)
+                   input_format=_FMT[fmt], taps=True, dsk=dsk)
     per = 1 if fmt == "cf32" else 2
-    o = checkers.Oracle(model=2, rate=rate, fmt=fmt, taps=True)
+    o = checkers.Oracle(model=2, rate=rate, fmt=fmt, taps=True, dsk=dsk)
     o.feed_blocks(x, block)
     otap = [o.tap(w) for w in range(6)]
     oppm = [o.tap_ppm(2), o.tap_ppm(3)]
@@ -483,6 +483,34 @@ def test_decimate_by_3_ladders(rate, dsk):
     x = synth.receiver_stream(block * 3, sample_rate=rate, receiver_id=31, gap_slots=(1, 2))
     _run_gpu_vs_oracle([x], rate, "cf32", block, 3, dsk=dsk)
     _run_gpu_vs_oracle([synth.to_cu8(x)], rate, "cu8", block, 3, dsk=dsk)
+
+
+@pytest.mark.parametrize("rate,dsk,k,fmt", [(250000, False, 0, "cf32"), (240000, False, 0, "cu8"), (500000, True, 1, "cf32"),
+                                            (1000000, True, 2, "cf32"), (2000000, True, 3, "cu8")])
+def test_rates_resampled_into_a_decimate_by_3_bucket(rate, dsk, k, fmt):
+    """Upsample in front of DownsampleKFilter (Model.cpp:213-219 etc.): 250k / 240k -> 288k; with `-go DSK on` 500k -> 576k,
+    1 MSPS -> 1152k, 2 MSPS -> 2304k (the reference then prefers these to the next 2^k bucket)."""
+    block = (24576 << k) * 2
+    x = synth.receiver_stream(block * 5, sample_rate=rate, receiver_id=55, gap_slots=(1, 2))
+    if fmt == "cu8":
+        x = synth.to_cu8(x)
+    _run_multi_sub(x, rate, block, 5, fmt=fmt, dsk=dsk)
+
+
+def test_resampled_decimate_by_3_ladder_message_order():
+    """250 kSPS end to end through the host model: Rotate still works on the filter's 8192-sample blocks, so the channels
+    alternate every 4096 samples at 48 kHz inside a downstream block."""
+    from ais_catcher_amd import host
+    rate, block, nblocks = 250000, 49152, 16
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=48, gap_slots=(0, 1), type5_every=4)
+    chk = checkers.Ref(model=2, rate=rate) if checkers.have_ref() else checkers.Oracle(model=2, rate=rate)
+    chk.feed_blocks(x, block)
+    host.reset_sequence()
+    m = host.ModelDefaultGPU(sample_rate=rate, block_len=block)
+    for b in range(nblocks):
+        m.receive(x[b * block:(b + 1) * block])
+    assert m.nmea() == chk.nmea() and len(chk.nmea()) >= 6
+    assert len(set(l.split(",")[4] for l in chk.nmea())) == 2
 
 
 def test_phase_search_boxcar():
@@ -760,6 +788,20 @@ def test_phase_search_chunk_whose_last_word_ends_in_a_partial_batch(windows):
     xs = [synth.receiver_stream(block * 3, receiver_id=130 + r, gap_slots=(0, 1)) for r in range(2)]
     _run_outputs_vs_oracle(xs, 1536000, "cf32", block, 3)
     _run_gpu_vs_oracle(xs[:1], 1536000, "cf32", block, 2)  # materialised back end (taps)
+
+
+@pytest.mark.parametrize("fmt", ["cf32", "cu8"])
+def test_block_length_sweep(fmt):
+    """Every block length of 1 .. 48 windows of 512 samples at 48 kHz (the reference accepts any multiple of 16384 input
+    samples at 1536 kSPS): chunk tails, segment tails, span counts and ring phases all change with it; hard bits, levels and
+    ppm must not."""
+    for windows in range(1, 49):
+        block = 32 * 512 * windows
+        nblocks = 3 if windows < 24 else 2
+        x = synth.receiver_stream(block * nblocks, receiver_id=200 + windows, gap_slots=(0, 1))
+        if fmt == "cu8":
+            x = synth.to_cu8(x)
+        _run_outputs_vs_oracle([x], 1536000, fmt, block, nblocks)
 
 
 def test_materialised_backend_without_taps(monkeypatch):

@@ -70,6 +70,16 @@ def test_default_6msps_upsampled():
     assert len(lines) >= 1
 
 
+@pytest.mark.parametrize("rate,dsk,block", [(250000, False, 24576 * 3), (240000, False, 24576 * 2), (500000, True, 49152 * 2),
+                                            (1000000, True, 98304 * 2), (2000000, True, 196608), (250000, False, 20000)])
+def test_rates_upsampled_into_a_decimate_by_3_bucket(rate, dsk, block):
+    # convert >> DS2.. >> US >> DSK >> ROT (Model.cpp:213-219, 254-259, 284-289, 311-313): 250k / 240k -> 288k; with `-go DSK on`
+    # 500k -> 576k, 1 MSPS -> 1152k, 2 MSPS -> 2304k (instead of the next 2^k bucket); also an input block that is not a
+    # whole number of the filter's 8192-sample output blocks
+    lines = _compare(2, rate, "cf32", block, 6, rid=8, dsk=dsk, gap_slots=(1, 2))
+    assert len(lines) >= 1
+
+
 @pytest.mark.parametrize("rate", [300000, 350000])
 def test_default_rates_upsampled_into_the_384k_bucket(rate):
     # 288k < rate < 384k: Upsample on the converted input itself, then DS2_2, DS2_1, FDC(-1.1) (Model.cpp:295-301)
