@@ -55,6 +55,7 @@ enum Mode {
 	MODE_DIRECT,    // rate == 96k * 2^k, k <= 4: one fused front-end kernel
 	MODE_PRE,       // rate == 96k * 2^k, k = 5..7: (k-4) CIC5 stages in a pre-decimation pass, then the fused kernel
 	MODE_RESAMPLE,  // rate between two buckets: (k-2) CIC5 stages, Upsample to the bucket, DS2_2, DS2_1, ...
+	MODE_96K,       // rate == 96k: no decimation in front of Rotate at all (Model.cpp:332-334)
 	MODE_DSK,       // rate == 288k * 2^k: k CIC5 stages (or a plain conversion), DownsampleKFilter (/3), Rotate, ...
 };
 
@@ -100,6 +101,7 @@ struct aisgpu {
 	void* d_in = nullptr; void* d_hist[2] = {}; void* d_hist2[2] = {}; // input tails, double buffered (read by span 0, written for the next block)
 	float2* d_xpre[2] = {};           // pre-decimated stream: [R][xh + n_pre], ping-pong by input block (MODE_PRE uses [0] only)
 	float2* d_xmid = nullptr;         // [R][block_len >> KPa]: between the two passes of a pre-decimation of more than four stages
+	int npost = 2;                    // CIC5 stages behind the resampler (K1u): 2, 1 (192k bucket), 0 (96 kSPS input: no resampler either)
 	bool us_dsk = false;              // Upsample in front of DownsampleKFilter (rates below a decimate-by-3 bucket): resampler flow, K1k front end
 	int KPa = 0;                      // != 0: the pre-decimation runs as KPa stages, then four (rates above 6144k that are resampled: 8 / 10 MSPS)
 	float2* d_rot[2] = {};
@@ -674,7 +676,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	int k = -1, k3 = -1;
 	for (int i = 0; i < 8; i++) if (buckets[i] >= cfg->sample_rate) { k = i; break; }
 	for (int i = 0; i < n3; i++) if (buckets3[i] >= cfg->sample_rate && (k < 0 || buckets3[i] < buckets[k])) { k3 = i; break; }
-	if (cfg->sample_rate < 96000 || (k < 1 && k3 < 0)) return AISGPU_ERR_ARG;
+	if (cfg->sample_rate < 96000 || (k < 0 && k3 < 0)) return AISGPU_ERR_ARG;
 	Mode mode; int K, KP;
 	const bool by3 = k3 >= 0;
 	if (k3 >= 0) { // a decimate-by-3 bucket is the smallest one >= rate
@@ -683,11 +685,12 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	} else {
 		const bool interpolated = buckets[k] != cfg->sample_rate;
 		if (!interpolated) {
-			if (k <= 4) { mode = MODE_DIRECT; K = k; KP = 0; }
+			if (k == 0) { mode = MODE_96K; K = 0; KP = 0; }
+			else if (k <= 4) { mode = MODE_DIRECT; K = k; KP = 0; }
 			else { mode = MODE_PRE; K = 4; KP = k - 4; }
 		} else {
-			if (k < 2) return AISGPU_ERR_ARG; // the resampler sits two CIC5 stages in front of 96 kHz (k == 2: on the input itself)
-			mode = MODE_RESAMPLE; K = 0; KP = k - 2;
+			// the resampler sits two CIC5 stages in front of 96 kHz (k == 2: on the input itself; k == 1, the 192k bucket: one stage)
+			mode = MODE_RESAMPLE; K = 0; KP = k >= 2 ? k - 2 : 0;
 		}
 	}
 	if (cfg->model != AISGPU_MODEL_DEFAULT && cfg->model != AISGPU_MODEL_CHALLENGER && cfg->model != AISGPU_MODEL_BASE &&
@@ -731,7 +734,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->n_pre = cfg->block_len >> KP;
 	h->us_dsk = by3 && mode == MODE_RESAMPLE;
 	if (by3) h->n96 = h->n_pre / 3;
-	else if (mode == MODE_RESAMPLE) h->n96 = h->n_pre / 4; // one flush of n_pre samples at the bucket rate >> KP (= 384 kHz)
+	else if (mode == MODE_RESAMPLE) { h->npost = k >= 2 ? 2 : 1; h->n96 = h->n_pre >> h->npost; } // one flush of n_pre samples at the bucket rate >> KP (384 kHz, or 192 kHz)
+	else if (mode == MODE_96K) { h->npost = 0; h->n96 = h->n_pre; }
 	else h->n96 = h->n_pre >> K;
 	h->L = h->n96 / 2;
 	h->W = h->L / 512;
@@ -740,7 +744,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->words = h->Gcap / 32;
 	h->n_chan = cfg->n_receivers * 2;
 	h->n_chains = h->n_chan * 5;
-	h->has_fdc = cfg->droop && !by3 ? 1 : 0; // no droop filter on the decimate-by-3 ladders (Model.cpp:207-219)
+	h->has_fdc = cfg->droop && !by3 && k > 0 ? 1 : 0; // no droop filter on the decimate-by-3 ladders (Model.cpp:207-219) nor at 96 kSPS
 	h->alpha = alphas[k];
 	h->beta = 1 - 2 * h->alpha; // DSP/DSP.h:296, evaluated in float
 	h->us_increment = (float)cfg->sample_rate / (float)(by3 ? buckets3[k3] : buckets[k]); // DSP/DSP.h:172-176
@@ -761,7 +765,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		h->pspans = (h->ptiles_per_block + h->ptiles_per_span - 1) / h->ptiles_per_span;
 	}
 	if (mode == MODE_RESAMPLE) h->xh = h->n_pre + XPAD;
-	if (mode == MODE_DSK) h->xh = DSK_HIST;
+	if (mode == MODE_DSK || mode == MODE_96K) h->xh = DSK_HIST;
 	*out = h; // from here on the caller destroys it on failure
 
 	HIPCHK(hipSetDevice(cfg->device_id));
@@ -874,8 +878,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			if (cfg->input_format == AISGPU_FMT_CU8 && h->kfmt != 4) HIPCHK(hipMemset(h->d_hist[i], 0x80, R * first_tile * h->in_bytes));
 		}
 	}
-	if (KP > 0 || mode == MODE_DSK || mode == MODE_RESAMPLE) {
-		const int nx = mode == MODE_RESAMPLE || mode == MODE_DSK ? 2 : 1;
+	if (KP > 0 || mode == MODE_DSK || mode == MODE_RESAMPLE || mode == MODE_96K) {
+		const int nx = mode == MODE_RESAMPLE || mode == MODE_DSK || mode == MODE_96K ? 2 : 1;
 		for (int i = 0; i < nx; i++) HIPCHK(dalloc(&h->d_xpre[i], R * ((size_t)h->xh + h->n_pre)));
 		if (mode == MODE_PRE) for (int i = 0; i < 2; i++) HIPCHK(dalloc((unsigned char**)&h->d_hist2[i], R * h->tile_in * 8));
 		if (h->KPa) { // second pre-decimation pass: four stages on the CF32 stream of the first
@@ -1113,7 +1117,7 @@ int aisgpu_run(aisgpu_t* h) {
 	// ---- pre-decimation pass (MODE_PRE / MODE_RESAMPLE): KP CIC5 stages at the input rate -> d_xpre
 	float2* xcur = nullptr;
 	long long xstride = 0;
-	if (h->KP == 0 && (h->mode == MODE_DSK || h->mode == MODE_RESAMPLE)) { // 288 kHz input: no CIC5 stage in front of DownsampleKFilter, only the
+	if (h->KP == 0 && (h->mode == MODE_DSK || h->mode == MODE_RESAMPLE || h->mode == MODE_96K)) { // 288 kHz input: no CIC5 stage in front of DownsampleKFilter, only the
 		// conversion; likewise rates resampled into the 384k bucket: Upsample works on the converted input itself (Model.cpp:295-301)
 		const int xb = (int)(h->in_blocks & 1);
 		xcur = h->d_xpre[xb];
@@ -1158,7 +1162,25 @@ int aisgpu_run(aisgpu_t* h) {
 		                                      h->ptile_in * h->in_bytes, R, h->stream));
 	}
 
-	if (h->mode == MODE_DSK) {
+	if (h->mode == MODE_96K) {
+		// ---- 96 kSPS: the converted input goes straight into Rotate; one downstream block per input block
+		const int pb = (int)(h->block_idx & 1);
+		const int q = (int)(h->block_idx % NBUF);
+		if (h->block_idx >= 2) HIPCHK(hipEventSynchronize(h->rot_ev[pb]));
+		gen_rot_table(h, h->h_rot[pb]);
+		HIPCHK(hipMemcpyAsync(h->d_rot[pb], h->h_rot[pb], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
+		h->rot_ev_used[pb] = true;
+		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[q], 0));
+		K1uParams ku;
+		ku.xin = xcur; ku.xin_stride = xstride; ku.xin_off = h->xh;
+		ku.us_idx = nullptr; ku.us_alpha = nullptr; ku.rot = h->d_rot[pb];
+		ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
+		ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = 0; ku.L = h->L;
+		HIPCHK(launch_k1u(ku, 0, R, h->stream));
+		int rc = enqueue_downstream(h, q, pb);
+		if (rc) return rc;
+	} else if (h->mode == MODE_DSK) {
 		// ---- decimate-by-3 ladder: one downstream block per input block (block_len is a whole number of the
 		// filter's 8192-sample output blocks, so the reference hands everything on within the same call)
 		const int pb = (int)(h->block_idx & 1);
@@ -1277,7 +1299,7 @@ int aisgpu_run(aisgpu_t* h) {
 					ku.us_idx = h->d_usidx[pb]; ku.us_alpha = h->d_usalpha[pb]; ku.rot = h->d_rot[pb];
 					ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
 					ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->has_fdc; ku.L = h->L;
-					HIPCHK(launch_k1u(ku, R, h->stream));
+					HIPCHK(launch_k1u(ku, h->npost, R, h->stream));
 					}
 					int rc = enqueue_downstream(h, q, pb);
 					if (rc) return rc;

@@ -770,9 +770,13 @@ __device__ __forceinline__ float2 cic5_at(const float2* a, int pos2j) { // decim
 	return o[0];
 }
 
+// NPOST: CIC5 stages between the resampler and the 96 kHz point -- 2 (buckets 384k ... 12288k), 1 (rates resampled into the 192k
+// bucket: US >> DS2_1, Model.cpp:323-329), 0 (96 kSPS input, no resampler at all: convert >> ROT, Model.cpp:332-334; xin is the
+// converted input itself)
+template <int NPOST>
 __global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
-	__shared__ float2 U[8 * K1U_M + 88];   // u(n),  n  in [8 m0 - 83, 8 m0 + 8 M)
-	__shared__ float2 S1[4 * K1U_M + 40];  // 192 kHz-equivalent level, j in [4 m0 - 39, 4 m0 + 4 M)
+	__shared__ float2 U[NPOST == 2 ? 8 * K1U_M + 88 : 1];   // u(n),  n  in [8 m0 - 83, 8 m0 + 8 M)
+	__shared__ float2 S1[NPOST >= 1 ? 4 * K1U_M + 40 : 1];  // 192 kHz-equivalent level, j in [4 m0 - 39, 4 m0 + 4 M)
 	__shared__ float2 S2[2 * K1U_M + 18];  // 96 kHz level,           i in [2 m0 - 17, 2 m0 + 2 M)
 	__shared__ float2 RU[2][2 * K1U_M + 16]; // rotated up/down,        i in [2 m0 - 15, 2 m0 + 2 M)
 	__shared__ float2 DD[2][K1U_M + 6];    // DS2_a/b output,         j in [m0 - 5, m0 + M)
@@ -780,26 +784,33 @@ __global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
 	const int rx = blockIdx.y;
 	const int m0 = blockIdx.x * K1U_M;
 	const float2* x = p.xin + (size_t)rx * p.xin_stride + p.xin_off; // x[i]: i relative to the current block start
-	{
+	const auto resampled = [&](int n) { // output n of Upsample: (1 - alpha) * a + alpha * b, products rounded separately (DSP.cpp:199)
+		const int i = p.us_idx[US_HIST + n];
+		const float al = p.us_alpha[US_HIST + n];
+		const float2 a = x[i - 1], b = x[i];
+		const float w0 = 1 - al;
+		return make_float2(w0 * a.x + al * b.x, w0 * a.y + al * b.y);
+	};
+	if constexpr (NPOST == 2) {
 		const int n_lo = 8 * m0 - 83;
-		for (int q = t; q < 8 * K1U_M + 83; q += 256) {
-			const int n = n_lo + q;
-			const int i = p.us_idx[US_HIST + n];
-			const float al = p.us_alpha[US_HIST + n];
-			const float2 a = x[i - 1], b = x[i];
-			const float w0 = 1 - al; // (1 - alpha) * a + alpha * b, products rounded separately (DSP.cpp:199)
-			U[q] = make_float2(w0 * a.x + al * b.x, w0 * a.y + al * b.y);
+		for (int q = t; q < 8 * K1U_M + 83; q += 256) U[q] = resampled(n_lo + q);
+		__syncthreads();
+		for (int q = t; q < 4 * K1U_M + 39; q += 256) { // j = 4 m0 - 39 + q needs u(2j-5..2j): U index 2j - n_lo
+			const int j = 4 * m0 - 39 + q;
+			S1[q] = cic5_at(U, 2 * j - (8 * m0 - 83));
 		}
+		__syncthreads();
+	} else if constexpr (NPOST == 1) {
+		for (int q = t; q < 4 * K1U_M + 39; q += 256) S1[q] = resampled(4 * m0 - 39 + q);
+		__syncthreads();
 	}
-	__syncthreads();
-	for (int q = t; q < 4 * K1U_M + 39; q += 256) { // j = 4 m0 - 39 + q needs u(2j-5..2j): U index 2j - n_lo
-		const int j = 4 * m0 - 39 + q;
-		S1[q] = cic5_at(U, 2 * j - (8 * m0 - 83));
-	}
-	__syncthreads();
-	for (int q = t; q < 2 * K1U_M + 17; q += 256) { // i = 2 m0 - 17 + q needs s1(2i-5..2i)
-		const int i = 2 * m0 - 17 + q;
-		S2[q] = cic5_at(S1, 2 * i - (4 * m0 - 39));
+	if constexpr (NPOST >= 1) {
+		for (int q = t; q < 2 * K1U_M + 17; q += 256) { // i = 2 m0 - 17 + q needs s1(2i-5..2i)
+			const int i = 2 * m0 - 17 + q;
+			S2[q] = cic5_at(S1, 2 * i - (4 * m0 - 39));
+		}
+	} else {
+		for (int q = t; q < 2 * K1U_M + 17; q += 256) S2[q] = x[2 * m0 - 17 + q];
 	}
 	__syncthreads();
 	for (int q = t; q < 2 * K1U_M + 15; q += 256) { // i = 2 m0 - 15 + q: FDC (DSP.cpp:283-293) + Rotate (DSP.cpp:296-316)
@@ -3165,8 +3176,11 @@ hipError_t launch_k1(const K1Params& p, int K, int fmt, int tile96, int depth, i
 	return hipErrorInvalidValue;
 }
 
-hipError_t launch_k1u(const K1uParams& p, int n_rx, hipStream_t s) {
-	hipLaunchKernelGGL(k1u_resample_frontend, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
+hipError_t launch_k1u(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
+	if (npost == 2) hipLaunchKernelGGL(k1u_resample_frontend<2>, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
+	else if (npost == 1) hipLaunchKernelGGL(k1u_resample_frontend<1>, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
+	else if (npost == 0) hipLaunchKernelGGL(k1u_resample_frontend<0>, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
+	else return hipErrorInvalidValue;
 	return hipGetLastError();
 }
 

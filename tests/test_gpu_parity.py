@@ -376,6 +376,17 @@ def test_other_resampled_rates(rate):
     _run_multi_sub(x, rate, block, 4)
 
 
+@pytest.mark.parametrize("rate,block,fmt", [(96000, 1024 * 48, "cf32"), (96000, 1024 * 24, "cu8"), (150000, 2048 * 30, "cf32"),
+                                            (120000, 2048 * 24, "cs8"), (96000, 1024, "cf32")])
+def test_lowest_rates(rate, block, fmt):
+    """96 kSPS (no decimation in front of Rotate, Model.cpp:332-334) and rates resampled into the 192k bucket (one CIC5 stage
+    behind the resampler, Model.cpp:323-329)."""
+    nblocks = 6 if block > 1024 else 200
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=56, gap_slots=(1, 2))
+    x = {"cu8": synth.to_cu8, "cs8": synth.to_cs8, "cf32": lambda v: v}[fmt](x)
+    _run_multi_sub(x, rate, block, nblocks, fmt=fmt)
+
+
 @pytest.mark.parametrize("rate,fmt", [(300000, "cf32"), (350000, "cf32"), (300000, "cu8"), (300000, "cs16")])
 def test_resampled_rates_into_the_384k_bucket(rate, fmt):
     """288k < rate < 384k: the resampler works on the converted input itself (no CIC5 stage in front, Model.cpp:295-301)."""

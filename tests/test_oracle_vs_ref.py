@@ -80,6 +80,13 @@ def test_rates_upsampled_into_a_decimate_by_3_bucket(rate, dsk, block):
     assert len(lines) >= 1
 
 
+@pytest.mark.parametrize("rate,block", [(96000, 1024 * 48), (150000, 2048 * 30), (120000, 2048 * 24), (96000, 1024 * 7)])
+def test_lowest_rates(rate, block):
+    # 96 kSPS: convert >> ROT (Model.cpp:332-334); 96k < rate < 192k: US >> DS2_1 >> FDC(-0.8) >> ROT (Model.cpp:323-329)
+    lines = _compare(2, rate, "cf32", block, 8, rid=9, gap_slots=(1, 2))
+    assert len(lines) >= 1
+
+
 @pytest.mark.parametrize("rate", [300000, 350000])
 def test_default_rates_upsampled_into_the_384k_bucket(rate):
     # 288k < rate < 384k: Upsample on the converted input itself, then DS2_2, DS2_1, FDC(-1.1) (Model.cpp:295-301)
