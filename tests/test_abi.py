@@ -36,7 +36,7 @@ def test_create_rejects_bad_config_without_gpu_work():
     cfg = gpu.Cfg()
     lib.aisgpu_default_cfg(ctypes.byref(cfg))
     h = ctypes.c_void_p()
-    for bad_rate in (50000, 250000, 13000000):  # below 96k; resampled ladder without two CIC5 stages behind it; above 12288k
+    for bad_rate in (50000, 95999, 13000000):  # below 96k (Model.cpp:109-110); above 12288k
         cfg.sample_rate = bad_rate
         assert lib.aisgpu_create(ctypes.byref(cfg), ctypes.byref(h)) == 1 and not h
     cfg.sample_rate = 1536000
@@ -64,5 +64,8 @@ def test_create_ladder_selection_for_decimate_by_3_rates():
     assert rc(288000, 3072 * 5) == 1                          # not a whole number of the filter's 8192-sample output blocks
     assert rc(2304000, 24576 * 8 * 2, gpu.FLAG_DSK) in (0, 2)
     assert rc(2304000, 512 * 64 * 6) in (0, 2)                # without the option 2304k is resampled up to 3072k
-    assert rc(500000, 786432, gpu.FLAG_DSK) == 1              # would need Upsample in front of DownsampleKFilter
-    assert rc(500000, 786432) in (0, 2)                       # resampled up to 768k
+    assert rc(500000, 24576 * 2 * 4, gpu.FLAG_DSK) in (0, 2)  # Upsample in front of DownsampleKFilter: 500k -> 576k
+    assert rc(500000, 614400, gpu.FLAG_DSK) == 1              # ... whose flushes must be whole 8192-sample output blocks
+    assert rc(500000, 786432) in (0, 2)                       # without the option: resampled up to 768k
+    assert rc(250000, 24576 * 3) in (0, 2)                    # 250k -> 288k (no option needed)
+    assert rc(96000, 1024 * 16) in (0, 2) and rc(150000, 2048 * 16) in (0, 2) and rc(10000000, 131072 * 6) in (0, 2)
