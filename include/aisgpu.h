@@ -71,9 +71,11 @@ extern "C" {
 typedef struct aisgpu aisgpu_t;
 
 typedef struct aisgpu_cfg {
-	int sample_rate;   /* 96000*2^k for k = 1..7 (192k .. 12288k); any rate in (384k, 6144k) that the reference resamples up
-	                    * to the next 2^k bucket, e.g. 6000000; 288000, and with AISGPU_FLAG_DSK 576000 / 1152000 / 2304000
-	                    * (DownsampleKFilter ladders; block_len must then be a multiple of 24576 * rate/288000) (Model.cpp:129-338) */
+	int sample_rate;   /* any rate from 96000 to 12288000 (ModelFrontend::buildModel, Model.cpp:109-338): the buckets 96000*2^k
+	                    * (k = 0..7), 288000 and -- with AISGPU_FLAG_DSK -- 576000 / 1152000 / 2304000 (DownsampleKFilter ladders),
+	                    * and every rate in between, which the reference resamples (Upsample) into the smallest bucket above it,
+	                    * e.g. 250000, 2400000, 6000000, 10000000.  On a DownsampleKFilter bucket block_len must be a multiple of
+	                    * 24576 * bucket/288000 (whole 8192-sample output blocks of the filter) */
 	int n_receivers;   /* independent dual-channel receiver instances batched on this GPU */
 	int block_len;     /* IQ samples per receiver per Receive() block; multiple of 512 * bucket_rate/48000 */
 	int model;         /* AISGPU_MODEL_BASE, AISGPU_MODEL_DEFAULT or AISGPU_MODEL_CHALLENGER */
