@@ -195,7 +195,10 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_bytes_per_launch": traffic_bytes,
                      "algorithmic_bytes_per_launch": samples_per_step * ALGO_BYTES_PER_SAMPLE,
-                     "kernel": "k1_dpp (front end: CIC5 ladder + FDC + Rotate + DS2 + FCIC5)", "avg_launch_ms": round(k1_ms, 4), "launches": k1_n,
+                     "kernel": "k1_dpp (front end: CIC5 ladder + FDC + Rotate + DS2 + FCIC5 + the spectral analysis of every window: "
+                               "FFT-512, prefix sum, peak searches)", "avg_launch_ms": round(k1_ms, 4), "launches": k1_n,
+                     # the same algorithmic bytes over the whole step (all kernels of the chain, wall clock / steps)
+                     "whole_chain_frac": round(samples_per_step * ALGO_BYTES_PER_SAMPLE / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                      "isolated_launch_ms": round(iso_ms, 4),
                      "isolated_frac": round(samples_per_step * ALGO_BYTES_PER_SAMPLE / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if iso_ms > 0 else None},
     }
