@@ -1177,10 +1177,23 @@ __device__ __forceinline__ void spectral_search(const float (&m)[NWIN][8], float
 			mz[w] = lane == 0 ? 0.0f : M[w][q8];                    // lane 0 holds its final value from the start
 			c[w] = q8 == 0 ? 0.0f : carry[w] + M[w][q8];            // cumsum[0] = 0; cumsum[64 k] = cumsum[64 k - 1] + mag[64 k]
 		}
+		if constexpr (NWIN == 2) {
+			// one fused instruction per step and chain: c = shift(c) + mz, lane 0 (no source lane, bound_ctrl off) keeps its value.
+			// A DPP read of a register needs two wait states behind the VALU write of it: the other chain's step and one s_nop.
+			asm volatile("s_nop 1");
 #pragma unroll 3
-		for (int it = 0; it < 63; it++) {
+			for (int it = 0; it < 63; it++)
+				asm volatile("v_add_f32_dpp %0, %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+				             "v_add_f32_dpp %1, %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+				             "s_nop 0"
+				             : "+v"(c[0]), "+v"(c[1]) : "v"(mz[0]), "v"(mz[1]));
+			asm volatile("s_nop 1");
+		} else {
+#pragma unroll 3
+			for (int it = 0; it < 63; it++) {
 #pragma unroll
-			for (int w = 0; w < NWIN; w++) c[w] = dpp_wave_shr1(c[w], c[w]) + mz[w];
+				for (int w = 0; w < NWIN; w++) c[w] = dpp_wave_shr1(c[w], c[w]) + mz[w];
+			}
 		}
 #pragma unroll
 		for (int w = 0; w < NWIN; w++) {
