@@ -660,6 +660,49 @@ def test_gpu_frame_decoder_nmea(block, nblocks, fmt):
     assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
 
 
+@pytest.mark.parametrize("mode", ["event", "seq"])
+def test_gpu_frame_decoder_block_length_sweep(mode, monkeypatch):
+    """The device decoders over block lengths of 1 .. 47 windows (odd group counts, partial last words of the packed hard bits,
+    frames cut at every place): NMEA text and levels == the checker, for the event-driven kernels and the sequential one."""
+    from ais_catcher_amd import host
+    if mode == "seq":
+        monkeypatch.setenv("AISGPU_K7", "seq")
+    for windows in (1, 2, 3, 5, 7, 11, 14, 19, 24, 29, 39, 47):
+        block = 32 * 512 * windows
+        nblocks = max(3, 786432 // block)
+        x = synth.receiver_stream(block * nblocks, receiver_id=300 + windows, type5_every=3, gap_slots=(0, 1))
+        chk = checkers.Ref() if checkers.have_ref() else checkers.Oracle()
+        chk.feed_blocks(x, block)
+        host.reset_sequence()
+        m = host.ModelDefaultGPU(block_len=block, gpu_decode=True)
+        for b in range(nblocks):
+            m.receive(x[b * block:(b + 1) * block])
+        assert m.nmea() == chk.nmea(), "windows %d" % windows
+        a, c = m.msg_meta(), chk.msg_meta()
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]), "windows %d" % windows
+        m.close()
+
+
+@pytest.mark.parametrize("model", [4, 1, 0])
+def test_other_models_block_length_sweep(model):
+    """ModelChallenger (PhaseSearch + FM branch, 20 decoders), ModelBase (SimplePLL with decoder feedback) and ModelStandard end
+    to end over a handful of block lengths."""
+    from ais_catcher_amd import host
+    cls = {4: host.ModelChallengerGPU, 1: host.ModelBaseGPU, 0: host.ModelStandardGPU}[model]
+    for windows in (2, 5, 14, 19, 24, 39):
+        block = 32 * 512 * windows
+        nblocks = max(3, 524288 // block)
+        x = synth.receiver_stream(block * nblocks, receiver_id=400 + windows, gap_slots=(0, 1), type5_every=4)
+        chk = checkers.Ref(model=model) if checkers.have_ref() else checkers.Oracle(model=model)
+        chk.feed_blocks(x, block)
+        host.reset_sequence()
+        m = cls(block_len=block)
+        for b in range(nblocks):
+            m.receive(x[b * block:(b + 1) * block])
+        assert m.nmea() == chk.nmea(), "model %d windows %d" % (model, windows)
+        m.close()
+
+
 def test_gpu_frame_decoder_behind_the_deferred_walk(monkeypatch):
     """Lane-per-chunk PhaseSearchEMA: the hard bits of block f are complete only after the walk that rides along with block
     f+1 (or the flush when results are requested); the device decoders and the copies must wait for exactly that."""
