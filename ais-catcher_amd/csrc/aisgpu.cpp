@@ -388,8 +388,9 @@ int enqueue_back(aisgpu_t* h) {
 }
 
 // Default path: the phasor recurrence keeps checkpoints only, and one fused kernel derotates, filters and scatters.
-// Nothing behind the FFT touches the front stream, so nothing needs to be deferred:
-//   front stream: front end, FFT, spectral searches (HBM-bound + a short latency-bound kernel; four streams are the limit)
+// Nothing behind the spectral analysis touches the front stream, so nothing needs to be deferred:
+//   front stream: front end with the spectral analysis inside its waves (k1_fft_tail); only where a span is not a whole number
+//                 of windows the FFT and search kernels follow it here (four streams are the limit)
 //   s3: phasor recurrence, own CUs          (latency-bound)
 //   s4: derotation + FIR + ScatterPLL       (VALU/latency-bound)
 //   s1: PhaseSearchEMA                      (VALU-bound; both overlap the next block's front end)
@@ -426,7 +427,7 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	const int S = (n_groups + h->GL - 1) / h->GL;
 	k2.ck = h->d_ck[q]; k2.ckw = h->d_ckw[q]; k2.ck_stride = k2.rotT_stride;
 	k2.ck_first = n_rel0 - 20; k2.ck_period = 5 * h->GL; k2.n_ck = S;
-	// The spectral analysis (FFT + searches) either follows the front end on its stream, or -- AISGPU_DEFER_FUSED -- runs on s4
+	// Without the analysis in the front-end waves, FFT + searches either follow the front end on its stream, or -- AISGPU_DEFER_FUSED -- run on s4
 	// next to it; s4 then must not sit waiting for this block's phasor recurrence, so the second half of the block (derotation /
 	// FIR, PhaseSearch) is enqueued one block later, behind the next block's analysis (or when results are requested).
 	if (h->fft_in_k1) {
