@@ -101,6 +101,7 @@ struct aisgpu {
 	void* d_in = nullptr; void* d_hist[2] = {}; void* d_hist2[2] = {}; // input tails, double buffered (read by span 0, written for the next block)
 	float2* d_xpre[2] = {};           // pre-decimated stream: [R][xh + n_pre], ping-pong by input block (MODE_PRE uses [0] only)
 	float2* d_xmid = nullptr;         // [R][block_len >> KPa]: between the two passes of a pre-decimation of more than four stages
+	bool mode_x = false;              // channel mode X: single-channel front end K1x (npost stages down to 48 kHz), channel B silent
 	int npost = 2;                    // CIC5 stages behind the resampler (K1u): 2, 1 (192k bucket), 0 (96 kSPS input: no resampler either)
 	bool us_dsk = false;              // Upsample in front of DownsampleKFilter (rates below a decimate-by-3 bucket): resampler flow, K1k front end
 	int KPa = 0;                      // != 0: the pre-decimation runs as KPa stages, then four (rates above 6144k that are resampled: 8 / 10 MSPS)
@@ -677,9 +678,25 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	int k = -1, k3 = -1;
 	for (int i = 0; i < 8; i++) if (buckets[i] >= cfg->sample_rate) { k = i; break; }
 	for (int i = 0; i < n3; i++) if (buckets3[i] >= cfg->sample_rate && (k < 0 || buckets3[i] < buckets[k])) { k3 = i; break; }
+	// channel mode X (Model.cpp:35-107): one channel at 48k / 96k / 192k, or resampled into the next of these; 12k .. 192k
+	const bool mode_x = (cfg->flags & AISGPU_FLAG_MODE_X) != 0;
+	int kx = -1;
+	if (mode_x) {
+		static const int bx[3] = { 48000, 96000, 192000 };
+		// (the reference takes 12k .. 192k; below 24k the resampler would complete more than two downstream blocks per input
+		// block, which the double-buffered outputs do not hold -- and 9600 Bd GMSK needs more than that anyway)
+		if (cfg->sample_rate < 24000 || cfg->sample_rate > 192000) return AISGPU_ERR_ARG;
+		if (cfg->model != AISGPU_MODEL_DEFAULT || (cfg->flags & (AISGPU_FLAG_FP_DS | AISGPU_FLAG_DSK))) return AISGPU_ERR_ARG;
+		for (int i = 0; i < 3; i++) if (bx[i] >= cfg->sample_rate) { kx = i; break; }
+		k = kx; k3 = -1;
+	} else
 	if (cfg->sample_rate < 96000 || (k < 0 && k3 < 0)) return AISGPU_ERR_ARG;
 	Mode mode; int K, KP;
 	const bool by3 = k3 >= 0;
+	if (mode_x) { // the flows of the 96k input (exact bucket) / of the resampler (in between), with the single-channel front end K1x
+		static const int bx[3] = { 48000, 96000, 192000 };
+		mode = bx[kx] != cfg->sample_rate ? MODE_RESAMPLE : MODE_96K; K = 0; KP = 0;
+	} else
 	if (k3 >= 0) { // a decimate-by-3 bucket is the smallest one >= rate
 		// below the bucket: convert >> DS2.. >> US >> DSK (Model.cpp:213-219 etc.): the resampler flow with the decimate-by-3 front end
 		mode = buckets3[k3] != cfg->sample_rate ? MODE_RESAMPLE : MODE_DSK; K = 0; KP = k3; k = 0;
@@ -700,7 +717,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	    cfg->input_format != AISGPU_FMT_CS16) return AISGPU_ERR_ARG;
 	if (cfg->n_receivers < 1 || cfg->n_receivers > 65535) return AISGPU_ERR_ARG;
 	// a downstream block must be a whole number of 512-sample CGF windows
-	const int dec48 = by3 ? 6 << KP : 2 << k; // input samples per 48 kHz sample (bucket rate)
+	const int dec48 = mode_x ? 1 << kx : by3 ? 6 << KP : 2 << k; // input samples per 48 kHz sample (bucket rate)
 	if (cfg->block_len < 512 * dec48 || cfg->block_len % (512 * dec48) != 0) return AISGPU_ERR_ARG;
 	// DownsampleKFilter hands its output on in blocks of 8192 samples (DSP.h:193), whatever the input block was: only
 	// input blocks that are a whole number of them reproduce the reference's call pattern (its file block does)
@@ -737,6 +754,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	if (by3) h->n96 = h->n_pre / 3;
 	else if (mode == MODE_RESAMPLE) { h->npost = k >= 2 ? 2 : 1; h->n96 = h->n_pre >> h->npost; } // one flush of n_pre samples at the bucket rate >> KP (384 kHz, or 192 kHz)
 	else if (mode == MODE_96K) { h->npost = 0; h->n96 = h->n_pre; }
+	h->mode_x = mode_x;
+	if (mode_x) { h->npost = kx; h->n96 = 2 * (h->n_pre >> kx); } // (no Rotate, no 96 kHz point: n96 only sizes the unused phasor table; L = n96 / 2)
 	else h->n96 = h->n_pre >> K;
 	h->L = h->n96 / 2;
 	h->W = h->L / 512;
@@ -746,9 +765,9 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->n_chan = cfg->n_receivers * 2;
 	h->n_chains = h->n_chan * 5;
 	h->has_fdc = cfg->droop && !by3 && k > 0 ? 1 : 0; // no droop filter on the decimate-by-3 ladders (Model.cpp:207-219) nor at 96 kSPS
-	h->alpha = alphas[k];
+	h->alpha = mode_x ? (kx == 2 ? -1.1f : -0.8f) : alphas[k]; // Model.cpp:64,76
 	h->beta = 1 - 2 * h->alpha; // DSP/DSP.h:296, evaluated in float
-	h->us_increment = (float)cfg->sample_rate / (float)(by3 ? buckets3[k3] : buckets[k]); // DSP/DSP.h:172-176
+	h->us_increment = (float)cfg->sample_rate / (float)(mode_x ? 48000 << kx : by3 ? buckets3[k3] : buckets[k]); // DSP/DSP.h:172-176
 	h->rot_period = by3 ? 8192 : 0; // Rotate is called once per DownsampleKFilter output block
 	if (K > 0) {
 		h->tile_in = h->tile96 << K;
@@ -1177,8 +1196,9 @@ int aisgpu_run(aisgpu_t* h) {
 		ku.xin = xcur; ku.xin_stride = xstride; ku.xin_off = h->xh;
 		ku.us_idx = nullptr; ku.us_alpha = nullptr; ku.rot = h->d_rot[pb];
 		ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
-		ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = 0; ku.L = h->L;
-		HIPCHK(launch_k1u(ku, 0, R, h->stream));
+		ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->mode_x ? h->has_fdc : 0; ku.L = h->L;
+		if (h->mode_x) HIPCHK(launch_k1x(ku, h->npost, R, h->stream));
+		else HIPCHK(launch_k1u(ku, 0, R, h->stream));
 		int rc = enqueue_downstream(h, q, pb);
 		if (rc) return rc;
 	} else if (h->mode == MODE_DSK) {
@@ -1300,7 +1320,8 @@ int aisgpu_run(aisgpu_t* h) {
 					ku.us_idx = h->d_usidx[pb]; ku.us_alpha = h->d_usalpha[pb]; ku.rot = h->d_rot[pb];
 					ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
 					ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->has_fdc; ku.L = h->L;
-					HIPCHK(launch_k1u(ku, h->npost, R, h->stream));
+					if (h->mode_x) HIPCHK(launch_k1x(ku, h->npost, R, h->stream));
+					else HIPCHK(launch_k1u(ku, h->npost, R, h->stream));
 					}
 					int rc = enqueue_downstream(h, q, pb);
 					if (rc) return rc;

@@ -187,6 +187,7 @@ hipError_t launch_k1u(const K1uParams& p, int npost, int n_rx, hipStream_t s); /
 hipError_t launch_copy_rows(const float2* src, long long src_stride, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
 hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long block_bytes, void* hist, int tail_bytes,
                           int n_rx, hipStream_t s);
+hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s); // channel mode X: npost CIC5 stages down to 48 kHz, us_idx == nullptr: no resampler
 hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s);
 hipError_t launch_convert_rows(const void* in, long long in_stride, int fmt, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
 hipError_t launch_k2a_fft(const K2Params& p, int n_chan, hipStream_t s);

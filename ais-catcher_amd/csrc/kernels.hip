@@ -855,6 +855,68 @@ __global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K1x: channel mode X (`-c X`, Model.cpp:35-107): ONE channel, already centred, at 48 / 96 / 192 kSPS (or resampled into the
+// next of these): convert >> [US] >> [DS2_2] >> [DS2_1] >> [FDC] >> FCIC5_a.  Same tile scheme as K1u (a workgroup produces
+// K1U_M outputs at 48 kHz and recomputes the short halos of every stage); only channel A's row of c48 is written, channel
+// B's stays silent (zero), so everything behind the front end runs unchanged.
+// ------------------------------------------------------------------------------------------
+template <int NPOST>
+__global__ __launch_bounds__(256) void k1x_single_channel(K1uParams p) {
+	constexpr int M = K1U_M;
+	__shared__ float2 U[NPOST == 2 ? 4 * M + 44 : 1];  // 192 kHz level, n in [4 m0 - 43, 4 m0 + 4 M)
+	__shared__ float2 S1[NPOST >= 1 ? 2 * M + 20 : 1]; // 96 kHz level,  j in [2 m0 - 19, 2 m0 + 2 M)
+	__shared__ float2 T[M + 8];                        // 48 kHz level,  m in [m0 - 7, m0 + M)
+	__shared__ float2 F[M + 6];                        // behind the droop filter, m in [m0 - 5, m0 + M)
+	const int t = threadIdx.x;
+	const int rx = blockIdx.y;
+	const int m0 = blockIdx.x * M;
+	const float2* x = p.xin + (size_t)rx * p.xin_stride + p.xin_off;
+	const auto level0 = [&](int n) -> float2 { // sample n of the stream the first CIC5 stage (or the 48 kHz point) sees
+		if (!p.us_idx) return x[n];
+		const int i = p.us_idx[US_HIST + n];
+		const float al = p.us_alpha[US_HIST + n];
+		const float2 a = x[i - 1], b = x[i];
+		const float w0 = 1 - al; // DSP.cpp:199, products rounded separately
+		return make_float2(w0 * a.x + al * b.x, w0 * a.y + al * b.y);
+	};
+	if constexpr (NPOST == 2) {
+		for (int q = t; q < 4 * M + 43; q += 256) U[q] = level0(4 * m0 - 43 + q);
+		__syncthreads();
+		for (int q = t; q < 2 * M + 19; q += 256) S1[q] = cic5_at(U, 2 * (2 * m0 - 19 + q) - (4 * m0 - 43));
+		__syncthreads();
+	} else if constexpr (NPOST == 1) {
+		for (int q = t; q < 2 * M + 19; q += 256) S1[q] = level0(2 * m0 - 19 + q);
+		__syncthreads();
+	}
+	for (int q = t; q < M + 7; q += 256) {
+		if constexpr (NPOST >= 1) T[q] = cic5_at(S1, 2 * (m0 - 7 + q) - (2 * m0 - 19));
+		else T[q] = level0(m0 - 7 + q);
+	}
+	__syncthreads();
+	for (int q = t; q < M + 5; q += 256) { // FDC (DSP.cpp:283-293): alpha * (h1 + x) + h2 * beta
+		const float2 xm2 = T[q], xm1 = T[q + 1], xv = T[q + 2];
+		float2 y = xv;
+		if (p.has_fdc) {
+			const float2 s2 = cadd(xm2, xv);
+			y = make_float2(p.alpha * s2.x + xm1.x * p.beta, p.alpha * s2.y + xm1.y * p.beta);
+		}
+		F[q] = y;
+	}
+	__syncthreads();
+	if (t < M) { // FilterCIC5 (DSP.cpp:132-157)
+		float2 v[6];
+#pragma unroll
+		for (int e = 0; e < 6; e++) v[e] = F[t + e]; // f(m-5 .. m)
+#pragma unroll
+		for (int lvl = 0; lvl < 5; lvl++) {
+#pragma unroll
+			for (int i = 0; i < 5 - lvl; i++) v[i] = cadd(v[i + 1], v[i]);
+		}
+		p.c48[((size_t)rx * 2) * p.c48_stride + m0 + t] = make_float2(v[0].x * 0.03125f, v[0].y * 0.03125f);
+	}
+}
+
+// ------------------------------------------------------------------------------------------
 // K1k: the tail of a decimate-by-3 ladder (rates 288k * 2^k, Model.cpp:207-219,248-259,278-289,308-313):
 // DownsampleKFilter (26-tap Blackman-Harris FIR, keep every 3rd output, DSP.cpp:160-189, DSP.h:195-201) ->
 // Rotate -> DS2_a/b -> FilterCIC5 (no droop filter on these ladders).  With block lengths that are a multiple
@@ -3199,6 +3261,14 @@ hipError_t launch_k1u(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
 	if (npost == 2) hipLaunchKernelGGL(k1u_resample_frontend<2>, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
 	else if (npost == 1) hipLaunchKernelGGL(k1u_resample_frontend<1>, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
 	else if (npost == 0) hipLaunchKernelGGL(k1u_resample_frontend<0>, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
+	else return hipErrorInvalidValue;
+	return hipGetLastError();
+}
+
+hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
+	if (npost == 2) hipLaunchKernelGGL(k1x_single_channel<2>, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
+	else if (npost == 1) hipLaunchKernelGGL(k1x_single_channel<1>, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
+	else if (npost == 0) hipLaunchKernelGGL(k1x_single_channel<0>, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
 	else return hipErrorInvalidValue;
 	return hipGetLastError();
 }

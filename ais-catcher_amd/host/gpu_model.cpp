@@ -109,7 +109,7 @@ void GpuChain::process(const void* data, int len, TAG& tag) {
 	// and with it the A-then-B order -- works on 4096 samples at 48 kHz at a time, however long the input block was.
 	const aisgpu_cfg& cf = batch->config();
 	bool by3 = false; // the smallest bucket >= rate is a decimate-by-3 one (Model.cpp:129-145), exact or resampled into
-	{
+	if (!(cf.flags & AISGPU_FLAG_MODE_X)) {
 		static const int b2[8] = { 96000, 192000, 384000, 768000, 1536000, 3072000, 6144000, 12288000 };
 		static const int b3[4] = { 288000, 576000, 1152000, 2304000 };
 		int best = 0;
@@ -152,6 +152,7 @@ void ModelDefaultGPU::buildModel(char CH1, char CH2, int sample_rate, bool /*tim
 		c.model = v2 ? AISGPU_MODEL_V2 : standard ? AISGPU_MODEL_STANDARD : base ? AISGPU_MODEL_BASE : challenger ? AISGPU_MODEL_CHALLENGER : AISGPU_MODEL_DEFAULT;
 		if (gpu_decode) c.flags |= AISGPU_FLAG_GPU_DECODE;
 		if (fixedpointDS) c.flags |= AISGPU_FLAG_FP_DS;
+		if (mode_x) c.flags |= AISGPU_FLAG_MODE_X;
 		batch = new GpuBatch(c); // throws std::runtime_error on unsupported rate / missing GPU
 		own_batch = true;
 		chain.attach(batch, 0);

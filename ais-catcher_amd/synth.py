@@ -119,7 +119,7 @@ def _fftconv_same(x, g):
 
 def receiver_stream(n_samples, sample_rate=1536000, receiver_id=0, payloads=PAYLOADS,
                     noise_sigma=0.01, gap_slots=(2, 4), type5_every=0, seed_base=12345,
-                    return_schedule=False):
+                    return_schedule=False, single_channel=False):
     """One receiver's complex64 stream of n_samples with slot-aligned bursts on both channels.
 
     RNG: numpy.default_rng(seed_base + receiver_id). Returns complex64 [n_samples]
@@ -141,7 +141,7 @@ def receiver_stream(n_samples, sample_rate=1536000, receiver_id=0, payloads=PAYL
         if start + len(b) > n_samples:
             break
         ch = int(rng.integers(0, 2))              # 0 = A (-25 kHz), 1 = B (+25 kHz)
-        fc = (-25000.0 if ch == 0 else 25000.0) + rng.uniform(-300.0, 300.0)
+        fc = (0.0 if single_channel else (-25000.0 if ch == 0 else 25000.0)) + rng.uniform(-300.0, 300.0)  # channel mode X: one channel at 0 Hz
         amp = rng.uniform(0.15, 0.5)
         ph0 = rng.uniform(0.0, 2.0 * np.pi)
         t = np.arange(len(b), dtype=np.float64)

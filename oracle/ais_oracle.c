@@ -524,7 +524,7 @@ typedef struct {
 
 struct ao_chain {
 	int model, fmt, rate, taps;
-	int npre, npost, has_us, has_fdc, has_dsk, ps_ema;
+	int npre, npost, has_us, has_fdc, has_dsk, ps_ema, mode_x;
 	int fixed; uint32_t fix_h[4][5]; /* `-go FP_DS on` at 1536 kSPS: Downsample16_CU8, h0..h4 of its four DS_UINT16 stages */
 	/* DownsampleKFilter (DSP.cpp:160-189, DSP.h:181-211): BlackmanHarris_28_3, K = 3, output blocks of 8192 */
 	cf* dsk_buf; long long dsk_cap; cf dsk_out[8192]; int dsk_in, dsk_idx_out;
@@ -591,13 +591,22 @@ static void base_branch(ao_chain* c, chan_t* ch, cf x) { /* Model.cpp:431-432 */
 	ch->pll_prev = bit;
 }
 
+static void channel_48k(ao_chain* c, chan_t* ch, const cf* x48, int n);
+
 static void channel_receive(ao_chain* c, chan_t* ch, const cf* x96, int n96) {
 	/* DS2_a -> FCIC5_a (Model.cpp:341-346) */
 	int n = n96 / 2;
-	cf* t = (cf*)malloc(sizeof(cf) * (size_t)(n + 2) * 2);
-	cf* y = t + n + 2;
+	cf* t = (cf*)malloc(sizeof(cf) * (size_t)(n + 2));
 	cic5_run(&ch->ds2, x96, n96, t, 1);
-	cic5_run(&ch->fcic, t, n, y, 0);
+	channel_48k(c, ch, t, n);
+	free(t);
+}
+
+/* FCIC5 and everything behind it; mode X feeds it directly (Model.cpp:35-107: ... >> FCIC5_a) */
+static void channel_48k(ao_chain* c, chan_t* ch, const cf* x48, int n) {
+	cf* t = (cf*)malloc(sizeof(cf) * (size_t)(n + 2));
+	cf* y = t;
+	cic5_run(&ch->fcic, x48, n, y, 0);
 	if (c->taps) fv_push(&ch->tap48, (const float*)y, 2LL * n);
 	if (c->model == 1) { /* ModelBase: no CGF, the channel goes straight into the FM receiver */
 		for (int i = 0; i < n; i++) base_branch(c, ch, y[i]);
@@ -659,7 +668,14 @@ static void post_us(ao_chain* c, const cf* x, int n) { /* DS2_2 -> DS2_1 (or few
 		if (bufs[1]) free(bufs[1]);
 		bufs[1] = o; in = o; m /= 2;
 	}
-	frontend_96k(c, in, m);
+	if (c->mode_x) { /* Model.cpp:35-107: [US] >> [DS2_2] >> [DS2_1] >> [FDC] >> FCIC5_a, one channel */
+		if (c->has_fdc && m > 0) {
+			cf* f = (cf*)malloc(sizeof(cf) * (size_t)m);
+			fdc_run(&c->fdc, c->fdc_alpha, in, m, f);
+			channel_48k(c, &c->ch[0], f, m);
+			free(f);
+		} else if (m > 0) channel_48k(c, &c->ch[0], in, m);
+	} else frontend_96k(c, in, m);
 	if (bufs[1]) free(bufs[1]);
 }
 
@@ -787,16 +803,19 @@ ao_chain* ao_create(int model, int sample_rate, int fmt, int flags) {
 	/* flags: bit 0 record taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`, bit 3 `-go FP_DS on` */
 	static const unsigned buckets_nodsk[] = { 96000, 192000, 288000, 384000, 768000, 1536000, 3072000, 6144000, 12288000 }; /* Model.cpp:129-130 */
 	static const unsigned buckets_dsk[] = { 96000, 192000, 288000, 384000, 576000, 768000, 1152000, 1536000, 2304000, 3072000, 6144000, 12288000 };
-	const int taps = flags & 1, dsk = (flags >> 1) & 1;
-	const unsigned* buckets = dsk ? buckets_dsk : buckets_nodsk;
-	const int nb = dsk ? 12 : 9;
+	/* ... bit 4 channel mode X (`-c X`: one channel, 12k .. 192k, Model.cpp:35-107) */
+	static const unsigned buckets_x[] = { 48000, 96000, 192000 };
+	const int taps = flags & 1, dsk = (flags >> 1) & 1, mode_x = (flags >> 4) & 1;
+	const unsigned* buckets = mode_x ? buckets_x : dsk ? buckets_dsk : buckets_nodsk;
+	const int nb = mode_x ? 3 : dsk ? 12 : 9;
 	tables_init();
 	int bi = -1;
 	for (int i = 0; i < nb; i++) if (buckets[i] >= (unsigned)sample_rate) { bi = i; break; }
-	if (bi < 0 || sample_rate < 96000) return NULL;
+	if (bi < 0 || sample_rate < (mode_x ? 12000 : 96000)) return NULL;
 	const unsigned bucket = buckets[bi];
-	int k = 0, is3 = 0; /* bucket = 96000 * 2^k or 288000 * 2^k */
-	if (bucket % 288000 == 0) { is3 = 1; while ((288000u << k) != bucket) k++; }
+	int k = 0, is3 = 0; /* bucket = 96000 * 2^k or 288000 * 2^k (mode X: 48000 * 2^k) */
+	if (mode_x) while ((48000u << k) != bucket) k++;
+	else if (bucket % 288000 == 0) { is3 = 1; while ((288000u << k) != bucket) k++; }
 	else while ((96000u << k) != bucket) k++;
 	static const float alphas[] = { 0.0f, -0.8f, -1.1f, -1.2f, -1.2f, -1.5f, -2.0f, -2.0f }; /* Model.cpp:157-338 */
 	ao_chain* c = (ao_chain*)calloc(1, sizeof(ao_chain));
@@ -805,9 +824,12 @@ ao_chain* ao_create(int model, int sample_rate, int fmt, int flags) {
 	c->fixed = ((flags >> 3) & 1) && sample_rate == 1536000; /* Model.cpp:224: only the 1536k case looks at fixedpointDS */
 	c->has_dsk = is3;
 	c->has_us = bucket != (unsigned)sample_rate;
+	c->mode_x = mode_x;
 	c->has_fdc = !is3 && k > 0; /* the decimate-by-3 ladders have no droop compensation (Model.cpp:207-219 etc.) */
 	c->fdc_alpha = is3 ? 0.0f : alphas[k];
-	if (is3) { c->npre = k; c->npost = 0; } /* convert >> DS2_k .. DS2_1 >> [US] >> DSK */
+	if (mode_x) c->fdc_alpha = k == 2 ? -1.1f : -0.8f; /* Model.cpp:64,76 */
+	if (mode_x) { c->npre = 0; c->npost = k; } /* convert >> [US] >> DS2_2 >> DS2_1 */
+	else if (is3) { c->npre = k; c->npost = 0; } /* convert >> DS2_k .. DS2_1 >> [US] >> DSK */
 	else if (c->has_us) { c->npost = k >= 2 ? 2 : k; c->npre = k - c->npost; }
 	else { c->npre = k; c->npost = 0; }
 	c->us.increment = (float)sample_rate / (float)bucket;
@@ -818,11 +840,11 @@ ao_chain* ao_create(int model, int sample_rate, int fmt, int flags) {
 		chan_t* ch = &c->ch[q];
 		ch->cgf.rot.re = 1.0f;
 		ch->cgf.window = 187; ch->cgf.wide = 1; /* Model.cpp:533-540 */
-		ch->decb.channel = "AB"[q]; ch->decb.fast_pll = &ch->pll_fast; /* Model.cpp:434-435 */
+		ch->decb.channel = mode_x ? 'X' : "AB"[q]; ch->decb.fast_pll = &ch->pll_fast; /* Model.cpp:434-435 */
 		ch->pll_fast = 1; /* DSP.h:40 */
 		if (model == 11) { ch->v2 = (v2_t*)malloc(sizeof(v2_t)); v2_init(ch->v2, "AB"[q]); }
 		for (int j = 0; j < 5; j++) {
-			ch->dec[j].channel = "AB"[q]; ch->decf[j].channel = "AB"[q];
+			ch->dec[j].channel = mode_x ? 'X' : "AB"[q]; ch->decf[j].channel = mode_x ? 'X' : "AB"[q];
 			/* Reset mesh: Model.cpp:566-573 (Default), :658-674 (Challenger) */
 			for (int i = 0; i < 5; i++) {
 				if (model == 4) {

@@ -33,7 +33,7 @@ def have_ref(kind="strict"):
 class _Chain:
     """One receiver instance behind either checker library."""
 
-    def __init__(self, lib, prefix, model, rate, fmt, taps, dsk=False, ps_ema=True, fp_ds=False):
+    def __init__(self, lib, prefix, model, rate, fmt, taps, dsk=False, ps_ema=True, fp_ds=False, mode_x=False):
         self.lib, self.p = lib, prefix
         f = lambda name: getattr(lib, prefix + name)
         f("create").restype = ctypes.c_void_p
@@ -52,7 +52,7 @@ class _Chain:
         f("destroy").argtypes = [ctypes.c_void_p]
         self._f = f
         self.fmt = fmt
-        flags = (1 if taps else 0) | (2 if dsk else 0) | (0 if ps_ema else 4) | (8 if fp_ds else 0)
+        flags = (1 if taps else 0) | (2 if dsk else 0) | (0 if ps_ema else 4) | (8 if fp_ds else 0) | (16 if mode_x else 0)
         self.h = f("create")(model, rate, {"cu8": 0, "cf32": 1, "cs8": 2, "cs16": 3}[fmt], flags)
         if not self.h:
             raise RuntimeError("checker create failed")
@@ -123,19 +123,19 @@ def _lib(path):
     return _libs[path]
 
 
-def Oracle(model=2, rate=1536000, fmt="cf32", taps=False, dsk=False, ps_ema=True, fp_ds=False):
+def Oracle(model=2, rate=1536000, fmt="cf32", taps=False, dsk=False, ps_ema=True, fp_ds=False, mode_x=False):
     path = os.path.join(ORACLE_DIR, "libaisoracle.so")
     if not os.path.exists(path):
         build_oracle()
     lib = _lib(path)
     lib.ao_reset_seq()
-    return _Chain(lib, "ao_", model, rate, fmt, taps, dsk, ps_ema, fp_ds)
+    return _Chain(lib, "ao_", model, rate, fmt, taps, dsk, ps_ema, fp_ds, mode_x)
 
 
-def Ref(model=2, rate=1536000, fmt="cf32", taps=False, kind="strict", dsk=False, ps_ema=True, fp_ds=False):
+def Ref(model=2, rate=1536000, fmt="cf32", taps=False, kind="strict", dsk=False, ps_ema=True, fp_ds=False, mode_x=False):
     lib = _lib(os.path.join(ORACLE_DIR, "_ref", "libaisref_%s.so" % kind))
     lib.ref_reset_seq()
-    return _Chain(lib, "ref_", model, rate, fmt, taps, dsk, ps_ema, fp_ds)
+    return _Chain(lib, "ref_", model, rate, fmt, taps, dsk, ps_ema, fp_ds, mode_x)
 
 
 def oracle_lib():

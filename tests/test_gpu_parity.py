@@ -376,6 +376,54 @@ def test_other_resampled_rates(rate):
     _run_multi_sub(x, rate, block, 4)
 
 
+@pytest.mark.parametrize("rate,block,fmt", [(48000, 512 * 40, "cf32"), (96000, 1024 * 40, "cf32"), (192000, 2048 * 40, "cu8"),
+                                            (40000, 512 * 40, "cf32"), (150000, 2048 * 30, "cs16"), (25000, 512 * 16, "cf32")])
+def test_channel_mode_x(rate, block, fmt):
+    """`-c X` (Model.cpp:35-107): one already centred channel at 48 / 96 / 192 kSPS or resampled into the next of these; the
+    single-channel front end K1x feeds channel A, channel B stays silent.  48 kHz tap, hard bits, levels, ppm per downstream
+    block, then NMEA (channel letter X) through the host model."""
+    from ais_catcher_amd import host
+    nblocks = 8
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=77, gap_slots=(1, 2), single_channel=True)
+    data = {"cu8": synth.to_cu8, "cs16": synth.to_cs16, "cf32": lambda v: v}[fmt](x)
+    per = 1 if fmt == "cf32" else 2
+    o = checkers.Oracle(model=2, rate=rate, fmt=fmt, taps=True, mode_x=True)
+    o.feed_blocks(data, block)
+    g = gpu.AisGpu(sample_rate=rate, n_receivers=1, block_len=block, input_format=_FMT[fmt], taps=True, mode_x=True)
+    otap, oppm = o.tap(0), o.tap_ppm(2)
+    obits = [o.bits(0, j) for j in range(5)]
+    n48 = gd = 0
+    for b in range(nblocks):
+        g.submit(0, data[b * block * per:(b + 1) * block * per])
+        g.run()
+        g.sync_outputs()
+        ns = g.out_count()
+        for s_ in range(ns):
+            out = g.fetch(0, 0, s_)
+            L, n = out["n_windows"] * 512, out["n_groups"]
+            assert out["first_sample48"] == n48
+            for j in range(5):
+                assert np.array_equal(out["bits"][j], obits[j][0][gd:gd + n]), "bits blk %d sub %d j %d" % (b, s_, j)
+            assert _feq(out["lvl"], obits[0][1][gd:gd + n]) and _feq(out["ppm"], oppm[n48 // 512:(n48 + L) // 512])
+            if s_ == ns - 1:
+                assert _feq(g.tap(0), otap[n48:n48 + L])
+            silent = g.fetch(0, 1, s_)
+            assert not np.any(silent["lvl"])  # channel B: nothing
+            n48 += L
+            gd += n
+    g.close()
+    if rate >= 40000:  # (below that the synthetic bursts are under-sampled for the decoders; the chain is still compared above)
+        chk = checkers.Ref(model=2, rate=rate, fmt=fmt, mode_x=True) if checkers.have_ref() else o
+        if chk is not o:
+            chk.feed_blocks(data, block)
+        host.reset_sequence()
+        m = host.ModelDefaultGPU(sample_rate=rate, block_len=block, input_format=_FMT[fmt], ch1="X", ch2="X", mode_x=True)
+        for b in range(nblocks):
+            m.receive(data[b * block * per:(b + 1) * block * per])
+        assert m.nmea() == chk.nmea() and len(chk.nmea()) >= 10
+        m.close()
+
+
 @pytest.mark.parametrize("rate,block,fmt", [(96000, 1024 * 48, "cf32"), (96000, 1024 * 24, "cu8"), (150000, 2048 * 30, "cf32"),
                                             (120000, 2048 * 24, "cs8"), (96000, 1024, "cf32")])
 def test_lowest_rates(rate, block, fmt):

@@ -80,6 +80,26 @@ def test_rates_upsampled_into_a_decimate_by_3_bucket(rate, dsk, block):
     assert len(lines) >= 1
 
 
+@pytest.mark.parametrize("rate,block", [(48000, 512 * 40), (96000, 1024 * 40), (192000, 2048 * 40), (40000, 512 * 40), (150000, 2048 * 30),
+                                        (12000, 512 * 8), (48000, 3000)])
+def test_channel_mode_x(rate, block):
+    """`-c X` (Receiver.cpp:87-98, Model.cpp:35-107): one channel, already centred, 12k .. 192k -- convert >> [US] >> [DS2_2] >>
+    [DS2_1] >> [FDC] >> FCIC5_a; the messages carry channel 'X'."""
+    x = synth.receiver_stream(block * 8, sample_rate=rate, receiver_id=77, gap_slots=(1, 2), single_channel=True)
+    o = checkers.Oracle(model=2, rate=rate, taps=True, mode_x=True)
+    r = checkers.Ref(model=2, rate=rate, taps=True, mode_x=True)
+    o.feed_blocks(x, block)
+    r.feed_blocks(x, block)
+    for w in (0, 2, 4):
+        assert len(o.tap(w)) == len(r.tap(w)) > 0 and np.array_equal(o.tap(w).view(np.float32), r.tap(w).view(np.float32))
+    for j in range(5):
+        for a, b in zip(o.bits(0, j), r.bits(0, j)):
+            assert np.array_equal(a, b)
+    assert o.nmea() == r.nmea()
+    if rate >= 40000:
+        assert len(r.nmea()) >= 5 and all(l.split(",")[4] == "X" for l in r.nmea())
+
+
 @pytest.mark.parametrize("rate,block", [(96000, 1024 * 48), (150000, 2048 * 30), (120000, 2048 * 24), (96000, 1024 * 7)])
 def test_lowest_rates(rate, block):
     # 96 kSPS: convert >> ROT (Model.cpp:332-334); 96k < rate < 192k: US >> DS2_1 >> FDC(-0.8) >> ROT (Model.cpp:323-329)
