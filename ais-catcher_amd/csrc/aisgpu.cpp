@@ -754,9 +754,9 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	if (by3) h->n96 = h->n_pre / 3;
 	else if (mode == MODE_RESAMPLE) { h->npost = k >= 2 ? 2 : 1; h->n96 = h->n_pre >> h->npost; } // one flush of n_pre samples at the bucket rate >> KP (384 kHz, or 192 kHz)
 	else if (mode == MODE_96K) { h->npost = 0; h->n96 = h->n_pre; }
+	else h->n96 = h->n_pre >> K;
 	h->mode_x = mode_x;
 	if (mode_x) { h->npost = kx; h->n96 = 2 * (h->n_pre >> kx); } // (no Rotate, no 96 kHz point: n96 only sizes the unused phasor table; L = n96 / 2)
-	else h->n96 = h->n_pre >> K;
 	h->L = h->n96 / 2;
 	h->W = h->L / 512;
 	h->Gcap = ((h->L + 4) / 5 + 1 + 31) / 32 * 32;
