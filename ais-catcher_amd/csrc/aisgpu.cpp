@@ -928,6 +928,9 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(dalloc(&h->d_dec, (size_t)h->n_chains)); // zero = State::TRAINING, lastBit = prev = 0 (Marine/AIS.h:44-56)
 		HIPCHK(dalloc(&h->d_frames, (size_t)h->max_frames * DEC_FRAME_WORDS));
 		if (const char* e = getenv("AISGPU_K7")) { h->k7_event = strcmp(e, "seq") != 0; h->k7_alt = strcmp(e, "alt") == 0; } // "seq": one lane per decoder, symbol by symbol
+		// the event words hold a symbol index in 13 bits: blocks of more than 8191 groups (e.g. the reference's CU8 file block of
+		// 3,145,728 samples at 1536 kSPS) go through the sequential decoder kernel
+		if ((h->L + 4) / 5 + 1 > 8191) h->k7_event = false;
 		if (h->k7_event) {
 			HIPCHK(dalloc(&h->d_k7ev, (size_t)h->n_chains * K7E_EVCAP));
 			HIPCHK(dalloc(&h->d_k7cnt, (size_t)h->n_chains));

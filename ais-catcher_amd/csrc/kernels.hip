@@ -2818,7 +2818,10 @@ __global__ __launch_bounds__(64) void k7_decode(K7Params p) {
 // alternations in `position` and leaves for STARTFLAG at the first symbol with alt == 0 and position > 4 (Marine/AIS.h:109-119).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t K7E_CONT = 0xFFFFu;
-constexpr int K7E_RW = 32; // events a lane of k7e_resolve stages in LDS at a time
+#ifndef K7E_RW_
+#define K7E_RW_ 32
+#endif
+constexpr int K7E_RW = K7E_RW_; // events a lane of k7e_resolve stages in LDS at a time (a multiple of 16; -DK7E_RW_=16 exercises the re-staging)
 #ifndef K7E_SIM_LANES_
 #define K7E_SIM_LANES_ 16
 #endif
