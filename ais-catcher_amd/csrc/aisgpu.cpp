@@ -119,6 +119,7 @@ struct aisgpu {
 	bool v2 = false; float2* h_c48 = nullptr; // ModelEngineV2: front end only, the 48 kHz channels go to the host (MAXSUB slots)
 	bool base = false; float2* d_fmprev[2] = {}; // ModelBase: FM receiver on the 48 kHz channels, no coherent chain
 	float* d_fm = nullptr; uint32_t* d_fmbits[2] = {}; uint32_t* h_fmbits = nullptr; // ModelChallenger FM branch
+	float* d_fmfir = nullptr; // [n_chan][L] Filter(Receiver) output of the last downstream block (AISGPU_FLAG_TAPS)
 	EmaState* d_ema[2] = {}; // state before / after the current downstream block (swapped per block)
 	uint32_t* d_pswords = nullptr; float *d_psma0 = nullptr, *d_psma1 = nullptr; unsigned* d_psfin = nullptr; int* d_psflag = nullptr;
 	int ps_warm = 256; bool ps_parallel = true;
@@ -185,6 +186,17 @@ int fail(aisgpu_t* h, int code, const char* what, hipError_t e) {
 	return code;
 }
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(h, AISGPU_ERR_HIP, #call, e_); } while (0)
+
+// HIP's current device is a per-thread setting and the entry points are called from the receivers' own threads
+// (GpuBatch::submitAndWait): every entry point that touches HIP selects the context's device and restores the caller's.
+struct DevGuard {
+	int prev = -1;
+	explicit DevGuard(const aisgpu_t* h) {
+		if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+		if (prev != h->cfg.device_id) (void)hipSetDevice(h->cfg.device_id); else prev = -1;
+	}
+	~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 template <typename T>
 hipError_t dalloc(T** p, size_t n) {
@@ -378,6 +390,7 @@ int enqueue_back(aisgpu_t* h) {
 		K5Params k5;
 		k5.x = h->d_cgf; k5.x_stride = CGF_HIST + h->L; k5.x_off = CGF_HIST; k5.prev_in = nullptr; k5.prev_out = nullptr; k5.fm = h->d_fm; k5.fm_stride = FM_HIST + h->L;
 		k5.fmbits = h->d_fmbits[pb]; k5.fmbits_stride = h->L / 32; k5.L = h->L;
+		k5.fir_out = h->d_fmfir; k5.fir_stride = h->L;
 		memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
 		HIPCHK(launch_k5(k5, h->n_chan, h->stream));
 	}
@@ -483,6 +496,7 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 	k5.x = h->d_c48[q]; k5.x_stride = h->c48s; k5.x_off = 0; k5.prev_in = h->d_fmprev[pb]; k5.prev_out = h->d_fmprev[pb ^ 1];
 	k5.fm = h->d_fm; k5.fm_stride = FM_HIST + h->L;
 	k5.fmbits = h->d_fmbits[pb]; k5.fmbits_stride = h->L / 32; k5.L = h->L;
+	k5.fir_out = h->d_fmfir; k5.fir_stride = h->L;
 	memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
 	HIPCHK(launch_k5(k5, h->n_chan, h->stream));
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->stream));
@@ -552,7 +566,12 @@ int gather_frames(aisgpu_t* h) {
 	if (h->k7_event) {
 		int ovf = 0;
 		HIPCHK(hipMemcpy(&ovf, h->d_k7ovf, sizeof ovf, hipMemcpyDeviceToHost));
-		if (ovf) { h->err = "event-driven frame decoder: more than K7E_OPENCAP frame starts in one block of one decoder (use AISGPU_K7=seq)"; return AISGPU_ERR_OVERFLOW; }
+		if (ovf) { // not sticky: this call's frames are lost, the next block starts from the DecState the kernels left
+			HIPCHK(hipMemset(h->d_k7ovf, 0, sizeof(int)));
+			h->frames_seen = total; h->frames.clear();
+			h->err = "event-driven frame decoder: more than K7E_OPENCAP frame starts in one block of one decoder (use AISGPU_K7=seq)";
+			return AISGPU_ERR_OVERFLOW;
+		}
 	}
 	if (h->k7_event && getenv("AISGPU_K7E_STATS")) { // experiment aid: events / runs per decoder in the last block
 		std::vector<uint32_t> cnt((size_t)h->n_chan * 5);
@@ -995,6 +1014,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(dalloc(&h->d_fm, C * (FM_HIST + h->L)));
 		for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmbits[i], C * (h->L / 32)));
 		HIPCHK(hipHostMalloc((void**)&h->h_fmbits, MAXSUB * C * (h->L / 32) * sizeof(uint32_t), hipHostMallocDefault));
+		if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_fmfir, C * (size_t)h->L));
 	}
 	HIPCHK(dalloc(&h->d_rotstate, C));
 	{
@@ -1034,6 +1054,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 
 void aisgpu_destroy(aisgpu_t* h) {
 	if (!h) return;
+	DevGuard dg(h);
 	h->pend.valid = false;
 	if (h->stream) hipStreamSynchronize(h->stream);
 	if (h->s1) hipStreamSynchronize(h->s1);
@@ -1062,7 +1083,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	for (auto& p : h->ev_free) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
 	hipFree(h->d_xmid);
 	hipFree(h->d_in); hipFree(h->d_hist[0]); hipFree(h->d_hist[1]); hipFree(h->d_hist2[0]); hipFree(h->d_hist2[1]);
-	hipFree(h->d_fm); hipFree(h->d_fmbits[0]); hipFree(h->d_fmbits[1]);
+	hipFree(h->d_fm); hipFree(h->d_fmfir); hipFree(h->d_fmbits[0]); hipFree(h->d_fmbits[1]);
 	if (h->h_fmbits) hipHostFree(h->h_fmbits);
 	if (h->h_c48) hipHostFree(h->h_c48);
 	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); hipFree(h->d_ckw[i]); }
@@ -1089,6 +1110,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 
 int aisgpu_submit(aisgpu_t* h, int rx, const void* iq, int n_iq) {
 	if (!h || !iq || rx < 0 || rx >= h->cfg.n_receivers || n_iq != h->cfg.block_len) return AISGPU_ERR_ARG;
+	DevGuard dg(h);
 	const size_t row = (size_t)h->cfg.block_len * h->in_bytes;
 	if (!h->d_in) {
 		HIPCHK(hipMalloc(&h->d_in, row * h->cfg.n_receivers));
@@ -1117,7 +1139,7 @@ int aisgpu_submit_device(aisgpu_t* h, const void* iq_dev, long long rx_stride_sa
 int aisgpu_run(aisgpu_t* h) {
 	if (!h) return AISGPU_ERR_ARG;
 	if (!h->submitted) return AISGPU_ERR_STATE;
-	HIPCHK(hipSetDevice(h->cfg.device_id));
+	DevGuard dg(h);
 	const bool cu8 = h->kfmt != 0; // an integer format: converted on the fly by the front end
 	const int R = h->cfg.n_receivers;
 	h->n_sub = 0;
@@ -1342,12 +1364,14 @@ int aisgpu_run(aisgpu_t* h) {
 
 int aisgpu_sync(aisgpu_t* h) {
 	if (!h) return AISGPU_ERR_ARG;
+	DevGuard dg(h);
 	return sync_all(h);
 }
 
 int aisgpu_sync_outputs(aisgpu_t* h) {
 	if (!h) return AISGPU_ERR_ARG;
 	if (h->in_blocks == 0) return AISGPU_ERR_STATE;
+	DevGuard dg(h);
 	const size_t C = h->n_chan;
 	{ int rc = enqueue_back(h); if (rc) return rc; }
 	{ int rc = enqueue_fused_back(h); if (rc) return rc; }
@@ -1405,11 +1429,22 @@ int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* o) {
 int aisgpu_fetch(aisgpu_t* h, int rx, int ch, aisgpu_out* o) { return aisgpu_fetch_sub(h, 0, rx, ch, o); }
 
 long long aisgpu_tap(aisgpu_t* h, int which, int rx, float* dst, long long cap) {
-	if (!h || which < 0 || which > 5 || rx < 0 || rx >= h->cfg.n_receivers) return -AISGPU_ERR_ARG;
+	if (!h || which < 0 || which > 9 || rx < 0 || rx >= h->cfg.n_receivers) return -AISGPU_ERR_ARG;
 	if (!(h->cfg.flags & AISGPU_FLAG_TAPS)) return -AISGPU_ERR_STATE;
 	if (h->block_idx == 0 || h->n_sub == 0) return -AISGPU_ERR_STATE;
+	DevGuard dg(h);
 	const size_t chan = (size_t)rx * 2 + (which & 1);
 	const SubOut& so = h->sub[h->n_sub - 1]; // taps show the last downstream block
+	if (which >= 6) { // real-valued taps of the FM receivers (ModelChallenger FM branch, ModelBase, ModelStandard)
+		if (!h->d_fm || !h->d_fmfir) return -AISGPU_ERR_STATE;
+		const float* fsrc = which < 8 ? h->d_fm + chan * (FM_HIST + h->L) + FM_HIST : h->d_fmfir + chan * (size_t)h->L;
+		if (sync_all(h) != AISGPU_OK) return -AISGPU_ERR_HIP;
+		if (dst) {
+			const long long c = h->L < cap ? h->L : cap;
+			if (hipMemcpy(dst, fsrc, (size_t)c * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -AISGPU_ERR_HIP;
+		}
+		return h->L;
+	}
 	const float2* src;
 	long long n = h->L;
 	if (which < 2) src = h->d_c48[so.q] + chan * h->c48s;
@@ -1433,6 +1468,7 @@ void* aisgpu_stream(aisgpu_t* h) { return h ? (void*)h->stream : nullptr; }
 
 void aisgpu_timing(aisgpu_t* h, int enable) {
 	if (!h) return;
+	DevGuard dg(h);
 	sync_all(h);
 	h->timing = enable != 0;
 	h->k1_ms = 0;
@@ -1441,6 +1477,7 @@ void aisgpu_timing(aisgpu_t* h, int enable) {
 
 float aisgpu_frontend_ms(aisgpu_t* h, int* launches) {
 	if (!h) return 0;
+	DevGuard dg(h);
 	sync_all(h);
 	if (launches) *launches = h->k1_launches;
 	return h->k1_launches ? (float)(h->k1_ms / h->k1_launches) : 0.0f;

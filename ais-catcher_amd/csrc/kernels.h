@@ -205,6 +205,7 @@ struct K5Params { // ModelChallenger FM branch (Model.cpp:638-639): Demod::FM ->
 	uint32_t* fmbits; long long fmbits_stride; // [n_chan][L/32] bit n: filtered discriminator > 0
 	float taps[37];
 	int L;
+	float* fir_out; long long fir_stride;     // optional [n_chan][fir_stride]: the filter output itself (AISGPU_FLAG_TAPS)
 };
 constexpr int FM_HIST = 36;
 

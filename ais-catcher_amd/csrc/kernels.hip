@@ -2635,6 +2635,7 @@ __global__ __launch_bounds__(256) void k5_filter(K5Params p) {
 	float acc = 0.0f;
 #pragma unroll
 	for (int i = 0; i < 37; i++) acc += p.taps[i] * f[i]; // x += taps[i] * *data++ (DSP.h:257-263)
+	if (p.fir_out) p.fir_out[(size_t)chan * p.fir_stride + n] = acc;
 	const unsigned long long b = __ballot(acc > 0);
 	if ((threadIdx.x & 63) == 0) {
 		uint32_t* o = p.fmbits + (size_t)chan * p.fmbits_stride + (n >> 5);

@@ -205,6 +205,15 @@ class AisGpu:
         self.lib.aisgpu_tap(self.h, which, rx, out.ctypes.data, n)
         return out
 
+    def tapf(self, which, rx=0):
+        """Real-valued taps 6..9 of the FM receivers (Demod::FM output, Filter(Receiver) output), last downstream block."""
+        n = self.lib.aisgpu_tap(self.h, which, rx, None, 0)
+        if n < 0:
+            raise AisGpuError("aisgpu_tap failed (%d)" % n)
+        out = np.zeros(n, np.float32)
+        self.lib.aisgpu_tap(self.h, which, rx, out.ctypes.data, n)
+        return out
+
     def timing(self, enable=True):
         self.lib.aisgpu_timing(self.h, int(enable))
 

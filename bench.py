@@ -6,16 +6,28 @@ Workload (BASELINE.json configs[3] / configs[4]): 256 batched dual-channel recei
 synthetic GMSK bursts + AWGN, inputs resident in HBM before the timed region.  One process per GPU;
 receivers are independent, so N GPUs run N x 256 receivers with no collective (weak scaling).
 
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) this script starts the N ranks itself (one
+process per GPU, LOCAL_RANK = device); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+it is one of the ranks.  The ranks only meet in a timing barrier and the max-over-ranks of the elapsed time
+(torch.distributed, gloo: there is no RCCL traffic on this path -- SURVEY.md 8(e)).
+
 Prints ONE JSON line (rank 0): metric/value/unit..., plus
-  roofline     -- front-end kernel (the HBM-bound kernel): algorithmic bytes per launch
-                  (8.30 B/IQ sample) / its average launch time measured with HIP events
-                  on the library's own stream
-  cpu_baseline -- the reference's own sources compiled with its shipped flags (oracle/_ref), timed on
-                  this host's cores on a bounded sample of the same workload (rank 0, N=1 only)
+  roofline       -- front-end kernel (the HBM-bound kernel): algorithmic bytes per launch
+                    (8.30 B/IQ sample) / its average launch time measured with HIP events
+                    on the library's own stream over the timed region
+  cpu_baseline   -- the reference's own sources compiled with its shipped flags (oracle/_ref), timed on
+                    this host's cores on a bounded sample of the same workload (rank 0, N=1 only)
+  parity_checked -- receivers whose hard bits / levels / ppm of the LAST TIMED block were compared bit for
+                    bit with the oracle fed the same block sequence (SURVEY.md 8(d) "parity gates in the
+                    same run"); a mismatch makes the run fail (exit status 3)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -32,31 +44,33 @@ RATE = 1536000
 BLOCK = 786432
 
 
-def make_resident_input(torch, n_rx, n_blocks, seed, unique=8):
-    """[n_blocks][n_rx][BLOCK] complex64 on the GPU: `unique` CPU-synthesised burst streams, shared by
-    receiver groups with a per-receiver slot shift, plus independent AWGN per receiver (torch RNG)."""
-    import _pkg
-    _pkg.load()
-    from ais_catcher_amd import synth
-    slot = 40960
-    base = []
-    for u in range(unique):
-        x = synth.receiver_stream(BLOCK * n_blocks, receiver_id=seed * 1000 + u, noise_sigma=0.0)
-        base.append(torch.from_numpy(x.view(np.float32).reshape(n_blocks, BLOCK, 2)))
-    base = torch.stack(base).cuda()                      # [unique][n_blocks][BLOCK][2]
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(12345 + seed)
-    out = torch.empty((n_blocks, n_rx, BLOCK, 2), dtype=torch.float32, device="cuda")
-    for r in range(n_rx):
-        b = torch.roll(base[r % unique], shifts=(r // unique) * slot, dims=1)
-        out[:, r] = b
-    out.add_(torch.randn(out.shape, generator=gen, device="cuda", dtype=torch.float32), alpha=0.01)
-    torch.cuda.synchronize()
-    return out
+def host_description():
+    """nproc / lscpu of the machine the CPU baseline runs on (SURVEY.md 8(d) asks for it in the report)."""
+    info = {"nproc": os.cpu_count()}
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {}
+        for line in txt.splitlines():
+            if ":" in line:
+                k, v = line.split(":", 1)
+                kv[k.strip()] = v.strip()
+        info["model"] = kv.get("Model name")
+        sockets, cps, tpc = kv.get("Socket(s)"), kv.get("Core(s) per socket"), kv.get("Thread(s) per core")
+        if sockets and cps:
+            info["physical_cores"] = int(sockets) * int(cps)
+        if tpc:
+            info["threads_per_core"] = int(tpc)
+    except Exception:
+        pass
+    try:
+        info["usable_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    return info
 
 
 def cpu_baseline(seconds=12.0):
-    """Reference chain (shipped flags -O3 -ffast-math) on the host cores, one ModelDefault per thread."""
+    """Reference chain (shipped flags -O3 -ffast-math) on ALL the cores this process may use, one ModelDefault per thread."""
     import checkers
     import _pkg
     _pkg.load()
@@ -65,7 +79,8 @@ def cpu_baseline(seconds=12.0):
         kind, mk = "reference", (lambda: checkers.Ref(model=2, rate=RATE, fmt="cf32", kind="fast"))
     else:
         kind, mk = "port", (lambda: checkers.Oracle(model=2, rate=RATE, fmt="cf32"))
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    host = host_description()
+    cores = max(1, host.get("usable_cpus") or host.get("nproc") or 1)
     nblk = 4
     x = synth.receiver_stream(BLOCK * nblk, receiver_id=4242)
     blocks = [np.ascontiguousarray(x[i * BLOCK:(i + 1) * BLOCK]) for i in range(nblk)]
@@ -77,7 +92,7 @@ def cpu_baseline(seconds=12.0):
         c = chains[i]
         k = 0
         while time.perf_counter() < t_end:
-            c.feed(blocks[k % nblk])
+            c.feed(blocks[k % nblk])   # ctypes releases the GIL: the threads run the compiled chain concurrently
             k += 1
         counts[i] = k
 
@@ -90,8 +105,77 @@ def cpu_baseline(seconds=12.0):
     dt = time.perf_counter() - t0
     total = sum(counts) * BLOCK
     return {"value": round(total / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": kind,
-            "sample": "%d blocks of %d CF32 IQ samples over %d threads in %.1f s (4 distinct blocks cycled, "
-                      "one ModelDefault instance per thread, in-memory)" % (sum(counts), BLOCK, cores, dt)}
+            "per_thread": round(total / dt / 1e6 / cores, 2), "host": host,
+            "sample": "%d blocks of %d CF32 IQ samples over %d threads (= every CPU this process may run on) in %.1f s "
+                      "(4 distinct blocks cycled, one ModelDefault instance per thread, in-memory)" % (sum(counts), BLOCK, cores, dt)}
+
+
+def parity_check(g, data, sequence, receivers):
+    """Outputs of the LAST block of `sequence` (what the context `g` holds after sync_outputs) against the oracle fed the same
+    sequence of resident blocks, for the given receivers.  Returns (receivers checked, list of mismatch descriptions)."""
+    import checkers
+    from concurrent.futures import ThreadPoolExecutor
+    nb = data.shape[0]
+    L = BLOCK // 32
+    g0_last = (len(sequence) - 1) * L // 5
+    n_last = len(sequence) * L // 5 - g0_last
+    W = L // 512
+
+    def one(r):
+        blocks = [data[b, r].cpu().numpy().reshape(-1).view(np.complex64) for b in range(nb)]
+        o = checkers.Oracle(model=2, rate=RATE, fmt="cf32", taps=True)
+        o.set_taps(False)
+        for i, b in enumerate(sequence):
+            if i == len(sequence) - 1:   # only the last block's outputs are compared (and recorded)
+                o.set_taps(True)
+            o.feed(blocks[b])
+        bad = []
+        for ch in range(2):
+            out = g.fetch(r, ch)
+            if out["n_groups"] != n_last or out["first_group"] != g0_last:
+                bad.append("rx %d ch %d: group bookkeeping" % (r, ch))
+                continue
+            ol = None
+            for j in range(5):
+                ob, ol_, _ = o.bits(ch, j)
+                ol = ol_
+                if len(ob) != n_last or not np.array_equal(out["bits"][j], ob):
+                    bad.append("rx %d ch %d phase %d: hard bits" % (r, ch, j))
+            if not np.array_equal(out["lvl"].view(np.uint32), ol.view(np.uint32)):
+                bad.append("rx %d ch %d: levels" % (r, ch))
+            oppm = o.tap_ppm(2 + ch)
+            if len(oppm) != W or not np.array_equal(out["ppm"].view(np.uint32), oppm.view(np.uint32)):
+                bad.append("rx %d ch %d: ppm" % (r, ch))
+        o.close()
+        return bad
+
+    with ThreadPoolExecutor(max_workers=min(len(receivers), os.cpu_count() or 1)) as ex:
+        res = list(ex.map(one, receivers))
+    return len(receivers), [m for bad in res for m in bad]
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) and relay rank 0's line."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].communicate()[0].decode()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
@@ -104,60 +188,114 @@ def main():
     ap.add_argument("--gpu-decode", action="store_true", help="also run the AIS::Decoder state machines on the device (frames out)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--parity-receivers", type=int, default=16, help="receivers compared with the oracle after the timed region (0 = off)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise the rank launch / sharding / barrier / report path only (CPU tests)")
     args = ap.parse_args()
 
-    import torch
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE); they must agree" % (args.gpus, world))
+
+    import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")   # timing barrier + max over ranks only: no data-path collective, no RCCL
 
     import _pkg
     _pkg.load()
-    from ais_catcher_amd import gpu, shard
+    from ais_catcher_amd import shard, workload
 
     R = args.receivers
     nb = 2  # distinct resident blocks cycled (2 x 1.6 GB)
     rx_ids = shard.receiver_range(rank, world, R)  # this rank's receivers; no other rank touches them
-    data = make_resident_input(torch, R, nb, seed=rx_ids[0] // R)
-    g = gpu.AisGpu(sample_rate=RATE, n_receivers=R, block_len=BLOCK, device_id=local, gpu_decode=args.gpu_decode)
+    samples_per_step = R * BLOCK
 
-    def step(i):
-        g.submit_device(data[i % nb].data_ptr(), BLOCK)
+    def barrier():
+        if not args.dry_run:
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        if not args.dry_run:
+            torch.cuda.synchronize()
+
+    if args.dry_run:
+        barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.001 * args.steps)
+        barrier()
+        dt = shard.max_over_ranks(time.perf_counter() - t0, dist)
+        owned = [None] * world
+        if dist is not None:
+            dist.all_gather_object(owned, [rx_ids[0], rx_ids[-1]])
+        else:
+            owned = [[rx_ids[0], rx_ids[-1]]]
+        if rank == 0:
+            print(json.dumps({"metric": "IQ Msamples/s (CFLOAT32) through ModelDefault chain", "dry_run": True,
+                              "value": round(shard.aggregate_msamples(samples_per_step, world, args.steps, dt), 1), "unit": "Msamples/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
+                              "receiver_ranges": owned}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+
+    from ais_catcher_amd import gpu
+    torch.cuda.set_device(local)
+    data = workload.resident_batch(torch, R, nb, seed=rx_ids[0] // R)
+    g = gpu.AisGpu(sample_rate=RATE, n_receivers=R, block_len=BLOCK, device_id=local, gpu_decode=args.gpu_decode)
+    sequence = workload.block_sequence(args.preroll, args.warmup, args.steps, nb)
+    it = iter(sequence)
+
+    def step():
+        g.submit_device(data[next(it)].data_ptr(), BLOCK)
         g.run()
 
     # Clock ramp: after the idle time of the set-up the GPU runs its first ~8 ms of load at a low clock and then pauses
     # for ~6 ms while it switches up (tools/host_times.py: run() call 5 of a cold context blocks for 7.5 ms).  A few
     # dozen untimed steps in front of the W warm-up steps keep that one-off transient out of the K timed steps.
-    for i in range(args.preroll):
-        step(i)
+    for _ in range(args.preroll):
+        step()
     g.sync()
-    for i in range(args.warmup):
-        step(i)
+    for _ in range(args.warmup):
+        step()
     g.sync()
     g.timing(not os.environ.get("BENCH_NO_K1_EVENTS"))
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    t_enq = time.perf_counter() - t0   # host time to enqueue all steps (no device sync inside)
+    for _ in range(args.steps):
+        step()
+    t_enq = time.perf_counter() - t0   # host time to enqueue all steps (includes the library's back-pressure: it lets the host run two blocks ahead)
     g.sync()
     barrier()
     dt = time.perf_counter() - t0
-    dt = shard.max_over_ranks(dt, dist, device="cuda")
+    dt = shard.max_over_ranks(dt, dist)
 
     k1_ms, k1_n = g.frontend_ms()
+
+    # ---- parity gate on the run that was just timed: the last block's outputs of a spread of receivers against the oracle
+    n_checked, mismatches = 0, []
+    if args.parity_receivers > 0:
+        g.sync_outputs()
+        n = min(args.parity_receivers, R)
+        receivers = sorted(set(int(round(i * (R - 1) / max(n - 1, 1))) for i in range(n)))
+        n_checked, mismatches = parity_check(g, data, sequence, receivers)
+
+    # ---- host cost of one aisgpu_run() with the device idle (no back-pressure): what the calling thread pays per block
+    host_ms = []
+    for i in range(12):
+        g.submit_device(data[i % nb].data_ptr(), BLOCK)
+        t1 = time.perf_counter()
+        g.run()
+        host_ms.append((time.perf_counter() - t1) * 1e3)
+        g.sync()
+    host_ms = sorted(host_ms[2:])
     g.close()
     # the same kernel measured without the other streams' kernels competing for the chip (untimed extra steps)
     gs = gpu.AisGpu(sample_rate=RATE, n_receivers=R, block_len=BLOCK, device_id=local, serial=True)
@@ -171,29 +309,44 @@ def main():
         gs.run()
     iso_ms, _ = gs.frontend_ms()
     gs.close()
-    samples_per_step = R * BLOCK
     value = shard.aggregate_msamples(samples_per_step, world, args.steps, dt)
     achieved = samples_per_step * ALGO_BYTES_PER_SAMPLE / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
-    # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (FETCH_SIZE/WRITE_SIZE, collected separately
-    # by tools/pmc_traffic.sh on this workload and committed under profiles/); expressed like `achieved` (GB/s)
-    traffic = traffic_bytes = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_k1.json")
-    if os.path.exists(tpath) and R == 256 and k1_ms > 0:
-        traffic_bytes = json.load(open(tpath))["hbm_bytes_per_launch"]
+    # HBM-side bytes per launch of the same kernel come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs:
+    # tools/pmc_traffic.sh).  `traffic` is filled only from a measurement of THIS session (BENCH_TRAFFIC_JSON = the file that
+    # script just wrote on this box); otherwise it is null and `traffic_reference` names the committed profile.
+    traffic = traffic_bytes = traffic_src = None
+    tpath = os.environ.get("BENCH_TRAFFIC_JSON")
+    if tpath and os.path.exists(tpath) and R == 256 and k1_ms > 0:
+        tj = json.load(open(tpath))
+        traffic_bytes = tj["hbm_bytes_per_launch"]
         traffic = round(traffic_bytes / (k1_ms * 1e-3) / 1e9, 1)
+        traffic_src = {"file": os.path.basename(tpath), "host": tj.get("host"), "commit": tj.get("commit")}
+    ref_profile = None
+    for cand in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        if cand.startswith("r02_") and cand.endswith("pmc_traffic_k1.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                ref_profile = {"file": "profiles/" + cand, "hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch"),
+                               "host": tj.get("host"), "commit": tj.get("commit"), "note": "separate rocprofv3 --pmc session, not this run"}
+            except Exception:
+                pass
+            break
     res = {
         "metric": "IQ Msamples/s (CFLOAT32) through ModelDefault chain", "value": round(value, 1),
         "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
+        "host_cost_ms_per_step": round(float(np.median(host_ms)), 4),
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "parity_checked": n_checked, "parity": ("bit-exact vs oracle (hard bits, levels, ppm of the last timed block)" if n_checked and not mismatches
+                                                else "off" if not n_checked else "MISMATCH: " + "; ".join(mismatches[:8])),
         "config": {"workload": "BASELINE configs[3]: %d batched dual-channel receivers per GPU, 1536 kSPS CF32, "
                                "%d IQ samples per receiver per step, resident in HBM, chain up to hard bits/levels/ppm"
                                % (R, BLOCK),
                    "gpu_frame_decoder": bool(args.gpu_decode), "receivers_per_gpu": R, "block_len": BLOCK, "sample_rate": RATE, "parallelism": "receivers sharded, no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "traffic_bytes_per_launch": traffic_bytes,
+                     "traffic_bytes_per_launch": traffic_bytes, "traffic_source": traffic_src, "traffic_reference": ref_profile,
                      "algorithmic_bytes_per_launch": samples_per_step * ALGO_BYTES_PER_SAMPLE,
                      "kernel": "k1_dpp (front end: CIC5 ladder + FDC + Rotate + DS2 + FCIC5 + the spectral analysis of every window: "
                                "FFT-512, prefix sum, peak searches)", "avg_launch_ms": round(k1_ms, 4), "launches": k1_n,
@@ -202,6 +355,17 @@ def main():
                      "isolated_launch_ms": round(iso_ms, 4),
                      "isolated_frac": round(samples_per_step * ALGO_BYTES_PER_SAMPLE / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if iso_ms > 0 else None},
     }
+    bad = len(mismatches)
+    if dist is not None:  # a mismatch on any rank fails the job
+        t = torch.tensor([bad], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        bad_all = int(t.item())
+        c = torch.tensor([n_checked], dtype=torch.int64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        res["parity_checked"] = int(c.item())
+        if bad_all and not bad:
+            res["parity"] = "MISMATCH on another rank"
+        bad = bad_all
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
@@ -209,7 +373,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 3 if bad else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -134,8 +134,8 @@ int aisgpu_fetch(aisgpu_t* h, int rx, int ch, aisgpu_out* out); /* == aisgpu_fet
  * many the last aisgpu_run() completed (always 1 for the 2^k rates); fetch them in order with aisgpu_fetch_sub(). */
 int aisgpu_out_count(aisgpu_t* h);
 
-/* AISGPU_FLAG_GPU_DECODE: the frames the ten AIS::Decoder objects of every receiver completed with a good CRC during the
- * last aisgpu_run() (replaces feeding aisgpu_out's decisions to AIS::Decoder::Receive, Marine/AIS.h:82-181).  What is left
+/* AISGPU_FLAG_GPU_DECODE: the frames the ten AIS::Decoder objects of every receiver completed with a good CRC since the
+ * previous aisgpu_sync_outputs() -- i.e. during the last aisgpu_run() when every run is followed by one (replaces feeding aisgpu_out's decisions to AIS::Decoder::Receive, Marine/AIS.h:82-181).  What is left
  * for the caller is AIS::Decoder::processData's tail (Marine/AIS.cpp:66-96): tag.level = level_sum / position (and its dB
  * conversion), Message::validate, buildNMEA.  Sorted the way the reference emits: by receiver, then downstream block,
  * channel A before channel B, group, phase.  Valid after aisgpu_sync_outputs() until the next aisgpu_run(). */
@@ -152,7 +152,10 @@ int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* out);
 
 /* Float taps of the last block (tests only; needs AISGPU_FLAG_TAPS):
  *   which 0/1: 48 kHz front-end output A/B (== FCIC5_a/b.out), 2/3: CGF output, 4/5: FIR-17 output.
- * Copies up to cap complex samples (interleaved re,im) to dst; returns the number available or <0. */
+ * Copies up to cap complex samples (interleaved re,im) to dst; returns the number available or <0.
+ *   which 6/7: Demod::FM output A/B (FM_a/b.out, DSP/Demod.cpp:27-37), 8/9: Filter(Receiver, 37 taps) output A/B (FR_a/b.out,
+ *   DSP/Model.cpp:431-432,638-639) of the FM receivers (AISGPU_MODEL_CHALLENGER / _BASE / _STANDARD): REAL samples, one float
+ *   per 48 kHz sample; cap and the return value count floats. */
 long long aisgpu_tap(aisgpu_t* h, int which, int rx, float* dst, long long cap);
 
 /* raw HIP stream / timing hooks for the benchmark */

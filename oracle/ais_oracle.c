@@ -519,6 +519,7 @@ typedef struct {
 	float pll; int pll_prev, pll_fast; ao_dec decb;
 	v2_t* v2; /* ModelEngineV2 */
 	fvec tap48, tapcgf, tapfir, ppm_cgf, ppm_fir;
+	fvec tapfm, tapfr; /* real taps: Demod::FM output, Filter(Receiver) output, every 48 kHz sample in order */
 	bitrec br[5], brf[5];
 } chan_t;
 
@@ -566,6 +567,7 @@ static void fm_branch(ao_chain* c, chan_t* ch, cf x) { /* Model.cpp:638-639 */
 	float v = atan2f(p.im, p.re) / PI_F;
 	ch->fm_prev = x;
 	float f = fir_r_step(ch->fr_hist, TAPS_RECEIVER, 37, v);
+	if (c->taps) { fv_push(&ch->tapfm, &v, 1); fv_push(&ch->tapfr, &f, 1); }
 	c->tag.sample_idx = ch->fm_idx++;
 	int j = ch->fm_last;
 	dec_run(&ch->decf[j], f, &c->tag, &c->sink);
@@ -578,6 +580,7 @@ static void base_branch(ao_chain* c, chan_t* ch, cf x) { /* Model.cpp:431-432 */
 	float v = atan2f(p.im, p.re) / PI_F; /* Demod::FM, Demod.cpp:27-37 */
 	ch->fm_prev = x;
 	float f = fir_r_step(ch->fr_hist, TAPS_RECEIVER, 37, v);
+	if (c->taps) { fv_push(&ch->tapfm, &v, 1); fv_push(&ch->tapfr, &f, 1); }
 	if (c->taps) { fv_push(&ch->brf[0].bits, &f, 1); fv_push(&ch->brf[0].lvl, &c->tag.sample_lvl, 1); lv_push1(&ch->brf[0].idx, c->tag.sample_idx); }
 	/* SimplePLL::Receive, DSP.cpp:28-44 */
 	int bit = f > 0;
@@ -868,7 +871,7 @@ void ao_destroy(ao_chain* c) {
 	for (int q = 0; q < 2; q++) {
 		chan_t* ch = &c->ch[q];
 		free(ch->v2);
-		fv_free(&ch->tap48); fv_free(&ch->tapcgf); fv_free(&ch->tapfir); fv_free(&ch->ppm_cgf); fv_free(&ch->ppm_fir);
+		fv_free(&ch->tap48); fv_free(&ch->tapcgf); fv_free(&ch->tapfir); fv_free(&ch->ppm_cgf); fv_free(&ch->ppm_fir); fv_free(&ch->tapfm); fv_free(&ch->tapfr);
 		for (int j = 0; j < 5; j++) {
 			fv_free(&ch->br[j].bits); fv_free(&ch->br[j].lvl); free(ch->br[j].idx.p);
 			fv_free(&ch->brf[j].bits); fv_free(&ch->brf[j].lvl); free(ch->brf[j].idx.p);
@@ -897,6 +900,15 @@ long long ao_tap(ao_chain* c, int which, float* dst, long long cap) {
 	chan_t* ch = &c->ch[which & 1];
 	const fvec* v = which < 2 ? &ch->tap48 : which < 4 ? &ch->tapcgf : &ch->tapfir;
 	return copy_out(v, dst, cap, 2);
+}
+/* recording of taps / decisions on or off from now on (created with taps: a long stream can be fed with only its end recorded) */
+void ao_set_taps(ao_chain* c, int on) { c->taps = on ? 1 : 0; }
+/* real-valued taps of the FM receivers (ModelChallenger FM branch, ModelBase, ModelStandard): 6/7 = Demod::FM output A/B
+ * (Demod.cpp:27-37), 8/9 = Filter(Receiver) output A/B (DSP.cpp:249-280), one float per 48 kHz sample */
+long long ao_tapf(ao_chain* c, int which, float* dst, long long cap) {
+	if (which < 6 || which > 9) return 0;
+	chan_t* ch = &c->ch[which & 1];
+	return copy_out(which < 8 ? &ch->tapfm : &ch->tapfr, dst, cap, 1);
 }
 long long ao_tap_ppm(ao_chain* c, int which, float* dst, long long cap) {
 	chan_t* ch = &c->ch[which & 1];

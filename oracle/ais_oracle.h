@@ -35,6 +35,10 @@ int ao_msg_meta(ao_chain*, float* level, float* ppm, int cap);
 /* taps: 0/1 = 48 kHz front-end output A/B, 2/3 = CGF out, 4/5 = FIR-17 out (complex, interleaved) */
 long long ao_tap(ao_chain*, int which, float* dst, long long cap);
 long long ao_tap_ppm(ao_chain*, int which, float* dst, long long cap);
+/* switch the recording of taps / decisions on or off from the next ao_feed() on (the chain must have been created with taps) */
+void ao_set_taps(ao_chain*, int on);
+/* real taps of the FM receivers: 6/7 = Demod::FM output A/B, 8/9 = Filter(Receiver, 37 taps) output A/B, one float per 48 kHz sample */
+long long ao_tapf(ao_chain*, int which, float* dst, long long cap);
 long long ao_bits(ao_chain*, int ch, int j, int fm, float* bits, float* lvl, long long* idx, long long cap);
 void ao_reset_seq(void);
 

@@ -48,7 +48,7 @@ struct BitRec : public StreamIn<FLOAT32> {
 	std::vector<float> bits;
 	std::vector<float> lvl;
 	std::vector<long long> idx;
-	bool on = false;
+	bool on = false, connected = false;
 	void Receive(const FLOAT32* d, int len, TAG& tag) {
 		if (!on) return;
 		for (int i = 0; i < len; i++) {
@@ -86,9 +86,11 @@ struct Harness {
 	MsgSink sink;
 	// taps: 0/1 = 48k front-end output A/B (FCIC5_a/b.out), 2/3 = CGF out, 4/5 = FIR-17 out
 	Rec<CFLOAT32> tap[6];
+	Rec<FLOAT32> ftap[4]; // 6/7 = Demod::FM output A/B, 8/9 = Filter(Receiver) output A/B (the FM receivers)
 	BitRec bits[2][5];   // after PhaseSearchEMA, per channel/phase
 	BitRec fmbits[2][5]; // challenger FM branch (input of DEC_af/bf)
 	double seconds = 0;
+	bool taps_connected = false, ftap_connected = false;
 
 	Harness(Format f, int rate) : dev(f, rate, Type::RAWFILE, "stub"), fmt(f) {}
 };
@@ -121,6 +123,11 @@ void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 			for (auto& t : h->tap) t.on = true;
 			*fe->C_a >> h->tap[0];
 			*fe->C_b >> h->tap[1];
+			h->taps_connected = true;
+			if (h->mb || h->ms || h->mc) { h->ftap_connected = true; for (auto& t : h->ftap) t.on = true; }
+			if (h->mb) { h->mb->FM_a.out >> h->ftap[0]; h->mb->FM_b.out >> h->ftap[1]; h->mb->FR_a.out >> h->ftap[2]; h->mb->FR_b.out >> h->ftap[3]; }
+			if (h->ms) { h->ms->FM_a.out >> h->ftap[0]; h->ms->FM_b.out >> h->ftap[1]; h->ms->FR_a.out >> h->ftap[2]; h->ms->FR_b.out >> h->ftap[3]; }
+			if (h->mc) { h->mc->FM_af.out >> h->ftap[0]; h->mc->FM_bf.out >> h->ftap[1]; h->mc->FR_af.out >> h->ftap[2]; h->mc->FR_bf.out >> h->ftap[3]; }
 			if (h->mb) { // sampler output (what the decoder gets) and the filtered discriminator in front of it
 				h->bits[0][0].on = h->bits[1][0].on = h->fmbits[0][0].on = h->fmbits[1][0].on = true;
 				h->mb->sampler_a.out >> h->bits[0][0]; h->mb->sampler_b.out >> h->bits[1][0];
@@ -153,6 +160,7 @@ void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 				}
 			}
 		}
+		for (int c = 0; c < 2; c++) for (int j = 0; j < 5; j++) { h->bits[c][j].connected = h->bits[c][j].on; h->fmbits[c][j].connected = h->fmbits[c][j].on; }
 		return h;
 	} catch (const std::exception& e) {
 		fprintf(stderr, "ref_create: %s\n", e.what());
@@ -199,6 +207,25 @@ long long ref_tap(void* hv, int which, float* dst, long long cap) {
 	auto& b = h->tap[which].buf;
 	long long n = (long long)b.size();
 	if (dst) memcpy(dst, b.data(), sizeof(CFLOAT32) * (size_t)(n < cap ? n : cap));
+	return n;
+}
+
+// recorders on / off from now on (only those connected at creation, i.e. created with the taps flag)
+void ref_set_taps(void* hv, int on) {
+	Harness* h = (Harness*)hv;
+	if (!h->taps_connected) return;
+	for (auto& t : h->tap) t.on = on;
+	for (auto& t : h->ftap) t.on = on && h->ftap_connected;
+	for (int c = 0; c < 2; c++) for (int j = 0; j < 5; j++) { h->bits[c][j].on = on && h->bits[c][j].connected; h->fmbits[c][j].on = on && h->fmbits[c][j].connected; }
+}
+
+// real taps of the FM receivers: 6/7 = Demod::FM output A/B, 8/9 = Filter(Receiver) output A/B
+long long ref_tapf(void* hv, int which, float* dst, long long cap) {
+	Harness* h = (Harness*)hv;
+	if (which < 6 || which > 9) return 0;
+	auto& b = h->ftap[which - 6].buf;
+	long long n = (long long)b.size();
+	if (dst) memcpy(dst, b.data(), sizeof(float) * (size_t)(n < cap ? n : cap));
 	return n;
 }
 

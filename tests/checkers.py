@@ -46,9 +46,13 @@ class _Chain:
         f("tap").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong]
         f("tap_ppm").restype = ctypes.c_longlong
         f("tap_ppm").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong]
+        f("tapf").restype = ctypes.c_longlong
+        f("tapf").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong]
         f("bits").restype = ctypes.c_longlong
         f("bits").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong]
+        f("set_taps").argtypes = [ctypes.c_void_p, ctypes.c_int]
+        f("set_taps").restype = None
         f("destroy").argtypes = [ctypes.c_void_p]
         self._f = f
         self.fmt = fmt
@@ -87,6 +91,17 @@ class _Chain:
         out = np.zeros(n, np.complex64)
         self._f("tap")(self.h, which, out.ctypes.data, n)
         return out
+
+    def tapf(self, which):
+        """Real taps of the FM receivers: 6/7 = Demod::FM output A/B, 8/9 = Filter(Receiver) output A/B."""
+        n = self._f("tapf")(self.h, which, None, 0)
+        out = np.zeros(n, np.float32)
+        self._f("tapf")(self.h, which, out.ctypes.data, n)
+        return out
+
+    def set_taps(self, on):
+        """Recording of taps / decisions on or off from the next feed() on (chain created with taps=True)."""
+        self._f("set_taps")(self.h, 1 if on else 0)
 
     def tap_ppm(self, which):
         n = self._f("tap_ppm")(self.h, which, None, 0)

@@ -912,3 +912,134 @@ def test_materialised_backend_without_taps(monkeypatch):
     monkeypatch.setenv("AISGPU_FUSED", "0")
     xs = [synth.receiver_stream(65536 * 9, receiver_id=97 + r, gap_slots=(0, 2)) for r in range(2)]
     _run_outputs_vs_oracle(xs, 1536000, "cf32", 65536, 9)
+
+
+@pytest.mark.parametrize("model,rate,fmt,block", [(1, 1536000, "cf32", 131072), (0, 768000, "cu8", 65536), (4, 1536000, "cf32", 131072),
+                                                  (4, 1536000, "cf32", 786432), (1, 288000, "cf32", 49152)])
+def test_fm_receiver_float_taps(model, rate, fmt, block):
+    """a11 / a12 as FLOATS (north star: intermediate samples within 1e-5 rel; here 0 ulp): the device's Demod::FM output (atan2f
+    restated, taps 6/7) and its Filter(Receiver) output (37 taps, taps 8/9) of every 48 kHz sample against FM_a/b.out and
+    FR_a/b.out of the compiled reference (Model.cpp:431-432, 500-503, 638-639) -- ModelBase, ModelStandard, ModelChallenger."""
+    nblocks = 4
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=150 + model, gap_slots=(1, 2))
+    data = synth.to_cu8(x) if fmt == "cu8" else x
+    per = 1 if fmt == "cf32" else 2
+    chk = (checkers.Ref if checkers.have_ref() else checkers.Oracle)(model=model, rate=rate, fmt=fmt, taps=True)
+    chk.feed_blocks(data, block)
+    want = {w: chk.tapf(w) for w in (6, 7, 8, 9)}
+    g = gpu.AisGpu(sample_rate=rate, block_len=block, input_format=_FMT[fmt], model={1: gpu.MODEL_BASE, 0: gpu.MODEL_STANDARD, 4: gpu.MODEL_CHALLENGER}[model], taps=True)
+    L = block // (rate // 48000)
+    for b in range(nblocks):
+        g.submit(0, data[b * block * per:(b + 1) * block * per])
+        g.run()
+        g.sync_outputs()
+        for w in (6, 7, 8, 9):
+            got = g.tapf(w)
+            assert len(got) == L
+            assert np.array_equal(got.view(np.uint32), want[w][b * L:(b + 1) * L].view(np.uint32)), "tap %d block %d" % (w, b)
+    assert np.any(want[8] != 0)
+    g.close()
+
+
+def _oracle_outputs(x, block, rate=1536000):
+    """Oracle outputs of one CF32 stream fed in blocks: hard bits [2][5][G], levels [2][G], ppm [2][W]."""
+    o = checkers.Oracle(model=2, rate=rate, fmt="cf32", taps=True)
+    o.feed_blocks(x, block)
+    bits = [[o.bits(ch, j)[0] for j in range(5)] for ch in range(2)]
+    lvl = [o.bits(ch, 0)[1] for ch in range(2)]
+    ppm = [o.tap_ppm(2), o.tap_ppm(3)]
+    o.close()
+    return bits, lvl, ppm
+
+
+@pytest.mark.parametrize("R,unique", [(256, 32), (40, 8)])
+def test_benchmarked_path_distinct_receivers_vs_oracle(R, unique):
+    """The configuration bench.py measures -- BASELINE configs[3]: R batched receivers x 786,432 CF32 samples resident in HBM,
+    DEFAULT path (taps off: fused derotation/FIR back end, spectral analysis at the end of the front-end waves, chunk-parallel
+    PhaseSearch), R DISTINCT streams (ais-catcher_amd/workload.py, the generator bench.py uses) -- two blocks, EVERY receiver's
+    hard bits, levels and ppm bit-exact against the oracle.  40 receivers: a channel count that is not a multiple of 64."""
+    import concurrent.futures
+    from ais_catcher_amd import workload
+    block, nblocks = workload.BLOCK, 2
+    data = workload.resident_batch(torch, R, nblocks, seed=7, unique=unique)
+    g = gpu.AisGpu(n_receivers=R, block_len=block)  # taps=False: the default (fused) path
+    with concurrent.futures.ThreadPoolExecutor(max_workers=16) as ex:
+        futs = [ex.submit(_oracle_outputs, workload.host_stream(data, r, list(range(nblocks))), block) for r in range(R)]
+        gd = wd = 0
+        got = []
+        for b in range(nblocks):
+            g.submit_device(data[b].data_ptr(), block)
+            g.run()
+            g.sync_outputs()
+            got.append([[g.fetch(r, ch) for ch in range(2)] for r in range(R)])
+        want = [f.result() for f in futs]
+    distinct = set()
+    for b in range(nblocks):
+        n, W = got[b][0][0]["n_groups"], got[b][0][0]["n_windows"]
+        for r in range(R):
+            bits, lvl, ppm = want[r]
+            for ch in range(2):
+                out = got[b][r][ch]
+                assert out["n_groups"] == n and out["first_group"] == gd
+                for j in range(5):
+                    assert np.array_equal(out["bits"][j], bits[ch][j][gd:gd + n]), "bits blk %d rx %d ch %d phase %d" % (b, r, ch, j)
+                assert _feq(out["lvl"], lvl[ch][gd:gd + n]), "lvl blk %d rx %d ch %d" % (b, r, ch)
+                assert _feq(out["ppm"], ppm[ch][wd:wd + W]), "ppm blk %d rx %d ch %d" % (b, r, ch)
+            distinct.add(got[b][r][0]["lvl"][:64].tobytes())
+        gd += n
+        wd += W
+    assert len(distinct) == R * nblocks  # the receivers really carried different signals
+    g.close()
+
+
+def test_benchmarked_path_with_device_frame_decoders_vs_oracle():
+    """40 distinct receivers (80 channels: the second 64-channel row block is partial) on the default path WITH the frame decoders
+    on the device: hard bits / levels / ppm against the oracle and every receiver's NMEA text (frames from aisgpu_frames()
+    through the host tail) against the oracle's, in order."""
+    import threading
+    from ais_catcher_amd import host, workload
+    R, block, nblocks = 40, 131072, 6
+    data = workload.resident_batch(torch, R, nblocks, seed=11, unique=8, block=block)
+    streams = [workload.host_stream(data, r, list(range(nblocks))) for r in range(R)]
+    want_nmea = []
+    for x in streams:
+        c = checkers.Oracle()
+        c.feed_blocks(x, block)
+        want_nmea.append(c.nmea())
+    # (1) decisions with the decoders running beside them
+    g = gpu.AisGpu(n_receivers=R, block_len=block, gpu_decode=True)
+    want = [_oracle_outputs(x, block) for x in streams]
+    gd = wd = 0
+    nframes = 0
+    for b in range(nblocks):
+        g.submit_device(data[b].data_ptr(), block)
+        g.run()
+        g.sync_outputs()
+        nframes += len(g.frames())
+        for r in range(R):
+            for ch in range(2):
+                out = g.fetch(r, ch)
+                n, W = out["n_groups"], out["n_windows"]
+                for j in range(5):
+                    assert np.array_equal(out["bits"][j], want[r][0][ch][j][gd:gd + n]), "bits blk %d rx %d ch %d phase %d" % (b, r, ch, j)
+                assert _feq(out["lvl"], want[r][1][ch][gd:gd + n]) and _feq(out["ppm"], want[r][2][ch][wd:wd + W])
+        gd += n
+        wd += W
+    g.close()
+    assert nframes >= sum(len(w) for w in want_nmea) // 2
+    # (2) end to end: frames -> host tail -> NMEA, one thread per receiver like the reference's device threads
+    host.reset_sequence()
+    batch = host.Batch(n_receivers=R, block_len=block, gpu_decode=True)
+    models = [host.ModelDefaultGPU(block_len=block, batch=batch, rx=r) for r in range(R)]
+
+    def work(r):
+        for b in range(nblocks):
+            models[r].receive(streams[r][b * block:(b + 1) * block])
+    th = [threading.Thread(target=work, args=(r,)) for r in range(R)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for r in range(R):
+        assert sorted(models[r].nmea()) == sorted(want_nmea[r]), "rx %d" % r
+        models[r].close()
+    batch.close()
+    assert sum(len(w) for w in want_nmea) >= R

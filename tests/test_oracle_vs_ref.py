@@ -239,3 +239,20 @@ def test_model_engine_v2(rate, fmt, block, rid, kw):
     assert o.nmea() == r.nmea() and len(r.nmea()) >= 3
     ol, rl = o.msg_meta(), r.msg_meta()
     assert np.array_equal(ol[0], rl[0]) and np.array_equal(ol[1], rl[1])
+
+
+@pytest.mark.parametrize("model,rate,fmt,block", [(1, 1536000, "cf32", 131072), (0, 768000, "cu8", 65536), (4, 1536000, "cf32", 131072),
+                                                  (4, 6000000, "cf32", 786432)])
+def test_fm_receiver_float_taps(model, rate, fmt, block):
+    """Demod::FM output (taps 6/7) and Filter(Receiver) output (taps 8/9) of the FM receivers -- ModelBase, ModelStandard and
+    the FM branch of ModelChallenger (Model.cpp:431-432, 500-503, 638-639): the restatement's floats == the reference's."""
+    x = synth.receiver_stream(block * 5, sample_rate=rate, receiver_id=140 + model, gap_slots=(1, 2))
+    data = synth.to_cu8(x) if fmt == "cu8" else x
+    o = checkers.Oracle(model=model, rate=rate, fmt=fmt, taps=True)
+    r = checkers.Ref(model=model, rate=rate, fmt=fmt, taps=True)
+    o.feed_blocks(data, block)
+    r.feed_blocks(data, block)
+    for w in (6, 7, 8, 9):
+        a, b = o.tapf(w), r.tapf(w)
+        assert len(a) == len(b) > 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32)), "tap %d" % w
+    assert np.any(o.tapf(6) != 0)
