@@ -31,6 +31,11 @@ def load():
     lib.aishost_model_create.argtypes = [vp, ci, ci, ci, ci, ctypes.c_char, ctypes.c_char, ci, ci, ctypes.c_char_p, ci]
     lib.aishost_model_destroy.argtypes = [vp]
     lib.aishost_model_receive.argtypes = [vp, vp, ci]
+    lib.aishost_model_leave.argtypes = [vp]
+    lib.aishost_model_leave.restype = None
+    lib.aishost_batch_set_timeout.argtypes = [vp, ci]
+    lib.aishost_batch_set_timeout.restype = None
+    lib.aishost_batch_active.argtypes = [vp]
     lib.aishost_model_replay.argtypes = [vp, ci, cll, cll, ci, ctypes.POINTER(vp), vp, ci, vp, vp]
     lib.aishost_model_feed48.argtypes = [vp, ci, vp, ci]
     lib.aishost_model_msg_count.argtypes = [vp]
@@ -58,6 +63,13 @@ class Batch:
             raise RuntimeError(err.value.decode())
         self.cfg = cfg
 
+    def set_timeout(self, ms):
+        """A receiver that has not delivered `ms` after the first one of a block is evicted (<= 0: wait for ever)."""
+        load().aishost_batch_set_timeout(self.h, ms)
+
+    def active(self):
+        return load().aishost_batch_active(self.h)
+
     def close(self):
         if self.h:
             load().aishost_batch_destroy(self.h)
@@ -76,8 +88,13 @@ class ModelDefaultGPU:
             raise RuntimeError(err.value.decode())
 
     def receive(self, block):
+        """One device block; returns the AISGPU_* status (0 = ok; e.g. 4 once the batch has evicted this receiver)."""
         block = np.ascontiguousarray(block)
-        self.lib.aishost_model_receive(self.h, block.ctypes.data, block.nbytes)
+        return self.lib.aishost_model_receive(self.h, block.ctypes.data, block.nbytes)
+
+    def leave(self):
+        """End of this receiver's input: the batch it shares stops waiting for it."""
+        self.lib.aishost_model_leave(self.h)
 
     def replay(self, ch, first_group, first_sample48, bits5, lvl, ppm, fm=None):
         """bits5: [5][n_groups] array of +-1 (or 0/1) decisions; packed here like the GPU packs them.

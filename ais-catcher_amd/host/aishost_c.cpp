@@ -76,9 +76,12 @@ void aishost_model_destroy(void* mv) { delete (Model*)mv; }
 int aishost_model_receive(void* mv, const void* data, int nbytes) {
 	Model* m = (Model*)mv;
 	RAW r = { m->fmt, (void*)data, nbytes };
-	m->m.Receive(&r, m->tag);
-	return 0;
+	return m->m.Receive(&r, m->tag); // AISGPU_* status of the block
 }
+// end of this receiver's input: a shared batch stops waiting for it
+void aishost_model_leave(void* mv) { ((Model*)mv)->m.Chain().detach(); }
+void aishost_batch_set_timeout(void* b, int ms) { ((GpuBatch*)b)->setTimeout(ms); }
+int aishost_batch_active(void* b) { return ((GpuBatch*)b)->activeReceivers(); }
 
 int aishost_model_replay(void* mv, int ch, long long first_group, long long first_sample48, int n_groups,
                          const uint32_t* const* bits5, const float* lvl, int n_windows, const float* ppm, const uint32_t* fm_bits) {

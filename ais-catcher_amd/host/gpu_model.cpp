@@ -1,6 +1,10 @@
 // ais-catcher_amd/host/gpu_model.cpp -- see gpu_model.h
 #include "gpu_model.h"
 
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+
 namespace aisamd {
 
 GpuBatch::GpuBatch(const aisgpu_cfg& c) : cfg(c) {
@@ -10,26 +14,61 @@ GpuBatch::GpuBatch(const aisgpu_cfg& c) : cfg(c) {
 		if (ctx) { msg += std::string(": ") + aisgpu_last_error(ctx); aisgpu_destroy(ctx); ctx = nullptr; }
 		throw std::runtime_error(msg);
 	}
+	active = cfg.n_receivers;
+	present.assign(cfg.n_receivers, 0);
+	gone.assign(cfg.n_receivers, 0);
+	if (const char* e = getenv("AISGPU_BATCH_TIMEOUT_MS")) timeout_ms = atoi(e);
 }
 
 GpuBatch::~GpuBatch() { aisgpu_destroy(ctx); }
 
+void GpuBatch::launch() {
+	// run the whole batch for this block, copy the outputs back, release everyone (rows of receivers that are gone keep
+	// whatever their staging rows held: receivers are closed systems, nobody reads those outputs)
+	int st = aisgpu_run(ctx);
+	if (st == AISGPU_OK) st = aisgpu_sync_outputs(ctx);
+	gen_status[generation & 1] = st;
+	arrived = 0;
+	std::fill(present.begin(), present.end(), 0);
+	generation++;
+	cv.notify_all();
+}
+
 int GpuBatch::submitAndWait(int rx, const void* iq, int n_iq) {
 	std::unique_lock<std::mutex> lock(mtx);
-	int rc = aisgpu_submit(ctx, rx, iq, n_iq);
-	if (rc != AISGPU_OK) { status = rc; }
-	const long long my_gen = generation;
-	if (++arrived == cfg.n_receivers) {
-		// last receiver of this block: run the whole batch, copy the outputs back, release everyone
-		if (status == AISGPU_OK) status = aisgpu_run(ctx);
-		if (status == AISGPU_OK) status = aisgpu_sync_outputs(ctx);
-		arrived = 0;
-		generation++;
-		cv.notify_all();
-	} else {
-		cv.wait(lock, [&] { return generation != my_gen; });
+	if (rx < 0 || rx >= cfg.n_receivers) return AISGPU_ERR_ARG;
+	if (gone[rx]) return AISGPU_ERR_STATE;
+	const int rc = aisgpu_submit(ctx, rx, iq, n_iq);
+	if (rc != AISGPU_OK) { // this receiver's problem only (wrong block length ...): it leaves, the others go on
+		gone[rx] = 1;
+		active--;
+		if (arrived > 0 && arrived == active) launch();
+		return rc;
 	}
-	return status;
+	const long long my_gen = generation;
+	present[rx] = 1;
+	if (++arrived == active) {
+		launch(); // last receiver of this block
+	} else {
+		const auto done = [&] { return generation != my_gen; };
+		if (timeout_ms <= 0) cv.wait(lock, done);
+		else if (!cv.wait_for(lock, std::chrono::milliseconds(timeout_ms), done)) {
+			// some receiver stopped delivering: evict everyone who has not handed in this block and run with the rest
+			for (int r = 0; r < cfg.n_receivers; r++)
+				if (!gone[r] && !present[r]) { gone[r] = 1; active--; }
+			if (generation == my_gen) launch();
+		}
+	}
+	return gen_status[my_gen & 1];
+}
+
+void GpuBatch::leave(int rx) {
+	std::unique_lock<std::mutex> lock(mtx);
+	if (rx < 0 || rx >= cfg.n_receivers || gone[rx]) return;
+	gone[rx] = 1;
+	active--;
+	if (present[rx]) { present[rx] = 0; arrived--; }
+	if (arrived > 0 && arrived == active) launch();
 }
 
 void GpuChain::replay(Connection<FLOAT32>* out, const aisgpu_out& o, TAG& tag, int n0, int n1) {
@@ -77,8 +116,10 @@ void GpuChain::replayBase(Connection<FLOAT32>& fm, const aisgpu_out& o, TAG& tag
 }
 
 void GpuChain::process(const void* data, int len, TAG& tag) {
-	if (failed || !batch) return;
+	if (!batch) { last_status = AISGPU_ERR_STATE; return; }
+	if (failed) return; // (last_status keeps the code of the failure)
 	int rc = batch->submitAndWait(rx, data, len);
+	last_status = rc;
 	if (rc != AISGPU_OK) {
 		failed = true;
 		if (on_error) on_error(std::string("GpuChain: ") + aisgpu_strerror(rc) + ": " + batch->lastError());
@@ -90,12 +131,12 @@ void GpuChain::process(const void* data, int len, TAG& tag) {
 	if (batch->config().flags & AISGPU_FLAG_GPU_DECODE) { // the device ran the decoders: only completed frames come back
 		const aisgpu_frame* fr = nullptr;
 		int nf = 0;
-		if (batch->frames(&fr, &nf) != AISGPU_OK) { failed = true; return; }
+		if ((rc = batch->frames(&fr, &nf)) != AISGPU_OK) { failed = true; last_status = rc; return; }
 		for (int i = 0; i < nf; i++) {
 			const aisgpu_frame& f = fr[i];
 			if (f.rx != rx || f.sub >= nsub) continue;
 			aisgpu_out o;
-			if (batch->fetch(f.sub, rx, f.ch, &o) != AISGPU_OK) { failed = true; return; }
+			if ((rc = batch->fetch(f.sub, rx, f.ch, &o)) != AISGPU_OK) { failed = true; last_status = rc; return; }
 			const long long n_last = 5 * (o.first_group + f.group) + 4; // like replay(): what the tag held when the frame closed
 			const int w = (int)((n_last - o.first_sample48) / 512);
 			if (o.ppm && w >= 0 && w < o.n_windows) tag.ppm = o.ppm[w];
@@ -120,7 +161,7 @@ void GpuChain::process(const void* data, int len, TAG& tag) {
 	for (int s = 0; s < nsub; s++) {
 		aisgpu_out o[2];
 		for (int ch = 0; ch < 2; ch++)
-			if (batch->fetch(s, rx, ch, &o[ch]) != AISGPU_OK) { failed = true; return; }
+			if ((rc = batch->fetch(s, rx, ch, &o[ch])) != AISGPU_OK) { failed = true; last_status = rc; return; }
 		const int L = o[0].n_windows * 512, step = by3 ? 4096 : L;
 		for (int n0 = 0; n0 < L; n0 += step) {
 			for (int ch = 0; ch < 2; ch++) {
@@ -137,6 +178,7 @@ void GpuChain::process(const void* data, int len, TAG& tag) {
 
 ModelDefaultGPU::~ModelDefaultGPU() {
 	if (own_batch) delete batch;
+	else chain.detach(); // a shared batch stops waiting for this receiver
 }
 
 void ModelDefaultGPU::buildModel(char CH1, char CH2, int sample_rate, bool /*timerOn*/, void* /*device*/) {
@@ -243,11 +285,13 @@ void ModelDefaultGPU::wireDecoders(char CH1, char CH2) {
 	}
 }
 
-void ModelDefaultGPU::Receive(const RAW* raw, TAG& tag) {
+int ModelDefaultGPU::Receive(const RAW* raw, TAG& tag) {
 	if (raw->format == Format::CU8) chain.Receive((const CU8*)raw->data, raw->size / 2, tag);
 	else if (raw->format == Format::CF32) chain.Receive((const CFLOAT32*)raw->data, raw->size / (int)sizeof(CFLOAT32), tag);
 	else if (raw->format == Format::CS8) chain.Receive((const CS8*)raw->data, raw->size / 2, tag);
 	else if (raw->format == Format::CS16) chain.Receive((const CS16*)raw->data, raw->size / 4, tag);
+	else return AISGPU_ERR_ARG;
+	return chain.status();
 }
 
 } // namespace aisamd

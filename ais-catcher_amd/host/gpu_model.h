@@ -21,6 +21,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "../../include/aisgpu.h"
 #include "ais_frame.h"
@@ -80,17 +81,28 @@ class GpuBatch {
 	aisgpu_cfg cfg;
 	std::mutex mtx;
 	std::condition_variable cv;
-	int arrived = 0;
+	int arrived = 0;             // receivers that have handed in their block of the current generation
+	int active = 0;              // receivers still taking part (n_receivers minus those that left or were evicted)
+	std::vector<char> present;   // [rx] handed in its block of the current generation
+	std::vector<char> gone;      // [rx] left (end of its stream, failure) or evicted (stopped delivering): never waited for again
 	long long generation = 0;
-	int status = AISGPU_OK;
+	int gen_status[2] = { AISGPU_OK, AISGPU_OK }; // status of generation g in slot g & 1 (a failed run does not poison later ones)
+	int timeout_ms = 10000;      // a receiver that has not delivered this long after the first one of a generation is evicted
+	void launch();               // run the batch for the current generation and release the waiting threads (mtx held)
 
 public:
 	explicit GpuBatch(const aisgpu_cfg& c);
 	~GpuBatch();
 	GpuBatch(const GpuBatch&) = delete;
 	const aisgpu_cfg& config() const { return cfg; }
-	// Copies the receiver's block in; returns once the whole batch has been processed for this block.
+	// Copies the receiver's block in; returns once the whole batch has been processed for this block.  AISGPU_ERR_STATE for a
+	// receiver that was evicted (it did not deliver within the timeout while the others waited -- the reference marks such a
+	// device lost, Device/Device.h:60-61) or has left.  Errors of one receiver's submit concern only that receiver.
 	int submitAndWait(int rx, const void* iq, int n_iq);
+	// The receiver will not deliver any more (end of its input, or it failed): the others stop waiting for it.
+	void leave(int rx);
+	void setTimeout(int ms) { std::lock_guard<std::mutex> l(mtx); timeout_ms = ms; } // <= 0: wait for ever
+	int activeReceivers() { std::lock_guard<std::mutex> l(mtx); return active; }
 	int outCount() { return aisgpu_out_count(ctx); }
 	int fetch(int sub, int rx, int ch, aisgpu_out* out) { return aisgpu_fetch_sub(ctx, sub, rx, ch, out); }
 	int frames(const aisgpu_frame** f, int* n) { return aisgpu_frames(ctx, f, n); }
@@ -104,6 +116,7 @@ class GpuChain : public StreamIn<CFLOAT32>, public StreamIn<CU8>, public StreamI
 	// AISGPU_FLAG_GPU_DECODE: the decoders' state machines ran on the device; a completed frame goes to its decoder's tail
 	std::function<void(const aisgpu_frame&, TAG&)> on_frame;
 	bool failed = false;
+	int last_status = AISGPU_OK;
 
 	void process(const void* data, int len, TAG& tag);
 
@@ -118,6 +131,8 @@ public:
 	Connection<CFLOAT32> outC48a, outC48b;
 
 	void attach(GpuBatch* b, int receiver) { batch = b; rx = receiver; }
+	void detach() { if (batch) batch->leave(rx); batch = nullptr; } // end of this receiver's stream: the batch stops waiting for it
+	int status() const { return last_status; }                      // AISGPU_* status of the last Receive()
 	void setErrorHandler(std::function<void(const std::string&)> f) { on_error = f; }
 	void setFrameHandler(std::function<void(const aisgpu_frame&, TAG&)> f) { on_frame = f; }
 	void Receive(const CFLOAT32* data, int len, TAG& tag) override { process(data, len, tag); }
@@ -191,7 +206,9 @@ public:
 	StreamOut<AIS::Message>& Output() { return output; }
 	GpuChain& Chain() { return chain; }
 	// entry used by the C API: the RAW block as the device thread delivers it (Device/FileRAW.cpp:135)
-	void Receive(const RAW* raw, TAG& tag);
+	// (returns the AISGPU_* status of the block: the reference's Receive() is void and reports through Error()/StopRequest(),
+	// Device/FileRAW.cpp:111-115 -- here the caller gets the code, the error handler the text)
+	int Receive(const RAW* raw, TAG& tag);
 	// CPU-only replay entry (host-logic tests): decisions produced elsewhere
 	void replay(int ch, const aisgpu_out& o, TAG& tag) {
 		if (base || standard) GpuChain::replayBase(ch == 0 ? chain.outFMa : chain.outFMb, o, tag);

@@ -1,0 +1,243 @@
+/*
+ * Source/DSP/GPU/ModelGPU.cpp -- see ModelGPU.h.  Reference-side binding of libaisgpu.so; test infrastructure of the
+ * MI355X repository (compiled by oracle/Makefile against the unmodified reference), not part of its product libraries.
+ */
+#include <stdexcept>
+
+#include "ModelGPU.h"
+
+namespace AIS
+{
+	// ---- GpuChain
+
+	void GpuChain::open(const RAW *raw)
+	{
+		int bytes = 0;
+		switch (raw->format)
+		{
+		case Format::CU8: cfg.input_format = AISGPU_FMT_CU8; bytes = 2; break;
+		case Format::CS8: cfg.input_format = AISGPU_FMT_CS8; bytes = 2; break;
+		case Format::CS16: cfg.input_format = AISGPU_FMT_CS16; bytes = 4; break;
+		case Format::CF32: cfg.input_format = AISGPU_FMT_CF32; bytes = 8; break;
+		default:
+			throw std::runtime_error("GPU model: input format not supported (CU8, CS8, CS16, CF32)");
+		}
+		cfg.block_len = raw->size / bytes; // the device hands over blocks of one size (Device/FileRAW.h:43, Device/RTLSDR.h:57)
+		// Model.cpp:224-237: the fixed-point ladder only exists at 1536 kSPS and is fed from ConvertRAW::outCU8
+		if ((cfg.flags & AISGPU_FLAG_FP_DS) && (cfg.sample_rate != 1536000 || raw->format != Format::CU8)) cfg.flags &= ~AISGPU_FLAG_FP_DS;
+		int rc = aisgpu_create(&cfg, &ctx);
+		if (rc != AISGPU_OK)
+		{
+			std::string msg = std::string("GPU model: ") + aisgpu_strerror(rc);
+			if (ctx)
+			{
+				msg += std::string(": ") + aisgpu_last_error(ctx);
+				aisgpu_destroy(ctx);
+				ctx = nullptr;
+			}
+			throw std::runtime_error(msg);
+		}
+	}
+
+	void GpuChain::replay(Connection<FLOAT32> *out, const aisgpu_out &o, TAG &tag, int n0, int n1)
+	{
+		for (int g = 0; g < o.n_groups; g++)
+		{
+			const long long rel = 5 * (o.first_group + g) + 4 - o.first_sample48; // the sample that completes the group
+			if (rel < n0 || rel >= n1) continue;
+			const int w = (int)(rel / 512);
+			if (o.ppm && w >= 0 && w < o.n_windows) tag.ppm = o.ppm[w];
+			if (tag.mode & 1) tag.sample_lvl = o.lvl[g];
+			for (int j = 0; j < N_SAMPLES_PER_SYMBOL; j++)
+			{
+				tag.sample_idx = 5 * (o.first_group + g) + j;
+				FLOAT32 b = ((o.bits[j][g >> 5] >> (g & 31)) & 1u) ? 1.0f : -1.0f;
+				out[j].Send((const FLOAT32 *)&b, 1, tag);
+			}
+		}
+	}
+
+	// the reference throttles the CGF output one sample at a time into both branches (Deinterleave n = 1, Model.cpp:630-639):
+	// per 48 kHz sample N first the coherent branch (its five decoders fire when N completes a group), then FM decoder N % 5
+	void GpuChain::replayChallenger(Connection<FLOAT32> *coh, Connection<FLOAT32> *fm, const aisgpu_out &o, TAG &tag, int n0, int n1)
+	{
+		const int L = o.n_windows * 512;
+		for (int n = n0; n < L && n < n1; n++)
+		{
+			const long long N = o.first_sample48 + n;
+			if (o.ppm) tag.ppm = o.ppm[n >> 9];
+			if (N % 5 == 4)
+			{
+				const long long g = N / 5;
+				const int gi = (int)(g - o.first_group);
+				if (tag.mode & 1) tag.sample_lvl = o.lvl[gi];
+				for (int j = 0; j < N_SAMPLES_PER_SYMBOL; j++)
+				{
+					tag.sample_idx = 5 * g + j;
+					FLOAT32 b = ((o.bits[j][gi >> 5] >> (gi & 31)) & 1u) ? 1.0f : -1.0f;
+					coh[j].Send((const FLOAT32 *)&b, 1, tag);
+				}
+			}
+			tag.sample_idx = N;
+			FLOAT32 f = ((o.fm_bits[n >> 5] >> (n & 31)) & 1u) ? 1.0f : -1.0f;
+			fm[(int)(N % 5)].Send((const FLOAT32 *)&f, 1, tag);
+		}
+	}
+
+	void GpuChain::Receive(const RAW *raw, int len, TAG &tag)
+	{
+		if (failed || len != 1) return;
+		if (!ctx) open(raw); // throws like the reference's models do at set-up (Model.cpp:109-110)
+
+		const int bytes = cfg.input_format == AISGPU_FMT_CF32 ? 8 : cfg.input_format == AISGPU_FMT_CS16 ? 4 : 2;
+		int rc = aisgpu_submit(ctx, 0, raw->data, raw->size / bytes); // copies: the block is only borrowed (Device/FileRAW.cpp:131-136)
+		if (rc == AISGPU_OK) rc = aisgpu_run(ctx);
+		if (rc == AISGPU_OK) rc = aisgpu_sync_outputs(ctx);
+		if (rc != AISGPU_OK)
+		{
+			failed = true; // the reference logs and stops (Device/FileRAW.cpp:111-115)
+			Error() << "GPU model: " << aisgpu_strerror(rc) << ": " << aisgpu_last_error(ctx);
+			StopRequest();
+			return;
+		}
+		// on the decimate-by-3 ladders Rotate works on DownsampleKFilter's 8192-sample blocks (DSP/DSP.h:193): A then B every
+		// 4096 samples at 48 kHz; everywhere else channel A's whole block comes first
+		static const int b2[8] = {96000, 192000, 384000, 768000, 1536000, 3072000, 6144000, 12288000};
+		static const int b3[4] = {288000, 576000, 1152000, 2304000};
+		int best = 0;
+		bool by3 = false;
+		for (int i = 0; i < 8 && !best; i++) if (b2[i] >= cfg.sample_rate) best = b2[i];
+		for (int i = 0; i < ((cfg.flags & AISGPU_FLAG_DSK) ? 4 : 1); i++)
+			if (b3[i] >= cfg.sample_rate && (!best || b3[i] < best)) { by3 = true; break; }
+
+		const int nsub = aisgpu_out_count(ctx); // downstream blocks this input block completed (1, or 1..2 behind the resampler)
+		for (int s = 0; s < nsub; s++)
+		{
+			aisgpu_out o[2];
+			for (int ch = 0; ch < 2; ch++)
+				if (aisgpu_fetch_sub(ctx, s, 0, ch, &o[ch]) != AISGPU_OK) { failed = true; return; }
+			const int L = o[0].n_windows * 512, step = by3 ? 4096 : L;
+			for (int n0 = 0; n0 < L; n0 += step)
+				for (int ch = 0; ch < 2; ch++)
+				{
+					const int n1 = n0 + step < L ? n0 + step : L;
+					if (o[ch].fm_bits) replayChallenger(ch == 0 ? outA : outB, ch == 0 ? outAf : outBf, o[ch], tag, n0, n1);
+					else replay(ch == 0 ? outA : outB, o[ch], tag, n0, n1);
+				}
+		}
+	}
+
+	// ---- ModelDefaultGPU
+
+	void ModelDefaultGPU::buildFrontend(int sample_rate, bool timerOn, Device::Device *dev, int model)
+	{
+		device = dev;
+		if (mode != Mode::AB && mode != Mode::CD) throw std::runtime_error("GPU model: channel modes AB / CD only");
+		if (sample_rate < 96000 || sample_rate > 12288000)
+			throw std::runtime_error("Model: sample rate must be between 96K and 12288K (inclusive)."); // Model.cpp:109-110
+
+		Connection<RAW> &physical = timerOn ? (*device >> timer).out : device->out; // Model.cpp:33
+		physical >> chain;
+
+		aisgpu_cfg &c = chain.config();
+		c.sample_rate = sample_rate;
+		c.n_receivers = 1;
+		c.model = model;
+		c.afc_wide = CGF_wide;
+		c.droop = droop_compensation;
+		c.flags = (PS_EMA ? 0 : AISGPU_FLAG_PS_BOXCAR) | (fixedpointDS ? AISGPU_FLAG_FP_DS : 0) | (allowDSK ? AISGPU_FLAG_DSK : 0);
+	}
+
+	void ModelDefaultGPU::buildModel(char CH1, char CH2, int sample_rate, bool timerOn, Device::Device *dev)
+	{
+		buildFrontend(sample_rate, timerOn, dev, AISGPU_MODEL_DEFAULT);
+
+		for (int i = 0; i < N_SAMPLES_PER_SYMBOL; i++) // the decoder wiring of ModelDefault::buildModel (Model.cpp:545-574)
+		{
+			DEC_a[i].setOrigin(CH1, station, own_mmsi);
+			DEC_b[i].setOrigin(CH2, station, own_mmsi);
+
+			chain.outA[i] >> DEC_a[i] >> output;
+			chain.outB[i] >> DEC_b[i] >> output;
+
+			for (int j = 0; j < N_SAMPLES_PER_SYMBOL; j++)
+				if (i != j)
+				{
+					DEC_a[i].DecoderMessage.Connect(DEC_a[j]);
+					DEC_b[i].DecoderMessage.Connect(DEC_b[j]);
+				}
+		}
+	}
+
+	Setting &ModelDefaultGPU::SetKey(AIS::Keys key, const std::string &arg)
+	{
+		switch (key)
+		{
+		case AIS::KEY_SETTING_PS_EMA: // Model.cpp:579-594
+			PS_EMA = Util::Parse::Switch(arg);
+			break;
+		case AIS::KEY_SETTING_AFC_WIDE:
+			CGF_wide = Util::Parse::Switch(arg);
+			break;
+		case AIS::KEY_SETTING_FP_DS: // Model.cpp:358-402
+			fixedpointDS = Util::Parse::Switch(arg);
+			break;
+		case AIS::KEY_SETTING_DSK:
+			allowDSK = Util::Parse::Switch(arg);
+			break;
+		case AIS::KEY_SETTING_DROOP:
+			droop_compensation = Util::Parse::Switch(arg);
+			break;
+		case AIS::KEY_SETTING_SOXR:
+		case AIS::KEY_SETTING_SRC:
+		case AIS::KEY_SETTING_MA:
+			if (Util::Parse::Switch(arg)) throw std::runtime_error(getName() + ": the soxr / samplerate / moving-average downsamplers are CPU-only");
+			break;
+		default:
+			Model::SetKey(key, arg);
+			break;
+		}
+		return *this;
+	}
+
+	std::string ModelDefaultGPU::Get()
+	{
+		return "ps_ema " + Util::Convert::toString(PS_EMA) + " afc_wide " + Util::Convert::toString(CGF_wide) + " droop " + Util::Convert::toString(droop_compensation) +
+			   " fp_ds " + Util::Convert::toString(fixedpointDS) + " dsk " + Util::Convert::toString(allowDSK) + " " + Model::Get();
+	}
+
+	// ---- ModelChallengerGPU
+
+	void ModelChallengerGPU::buildModel(char CH1, char CH2, int sample_rate, bool timerOn, Device::Device *dev)
+	{
+		buildFrontend(sample_rate, timerOn, dev, AISGPU_MODEL_CHALLENGER);
+
+		for (int i = 0; i < N_SAMPLES_PER_SYMBOL; i++) // Model.cpp:641-674
+		{
+			DEC_a[i].setOrigin(CH1, station, own_mmsi);
+			DEC_b[i].setOrigin(CH2, station, own_mmsi);
+			DEC_af[i].setOrigin(CH1, station, own_mmsi);
+			DEC_bf[i].setOrigin(CH2, station, own_mmsi);
+
+			chain.outA[i] >> DEC_a[i] >> output;
+			chain.outB[i] >> DEC_b[i] >> output;
+			chain.outAf[i] >> DEC_af[i] >> output;
+			chain.outBf[i] >> DEC_bf[i] >> output;
+
+			for (int j = 0; j < N_SAMPLES_PER_SYMBOL; j++)
+			{
+				DEC_af[i].DecoderMessage.Connect(DEC_a[j]);
+				DEC_a[i].DecoderMessage.Connect(DEC_af[j]);
+				DEC_bf[i].DecoderMessage.Connect(DEC_b[j]);
+				DEC_b[i].DecoderMessage.Connect(DEC_bf[j]);
+				if (i != j)
+				{
+					DEC_a[i].DecoderMessage.Connect(DEC_a[j]);
+					DEC_b[i].DecoderMessage.Connect(DEC_b[j]);
+					DEC_af[i].DecoderMessage.Connect(DEC_af[j]);
+					DEC_bf[i].DecoderMessage.Connect(DEC_bf[j]);
+				}
+			}
+		}
+	}
+}

@@ -24,6 +24,9 @@
 
 #include "Model.h"
 #include "Device.h"
+#ifdef HASMI355X
+#include "ModelGPU.h" // the reference-side binding of libaisgpu.so (integration/reference/Source/DSP/GPU): engines 12 / 14
+#endif
 
 // normally provided by Application/Main.cpp:38-49 (which we do not link)
 std::atomic<bool> stop;
@@ -80,6 +83,7 @@ struct Harness {
 	AIS::ModelBase* mb = nullptr;
 	AIS::ModelStandard* ms = nullptr;
 	AIS::ModelEngineV2* mv = nullptr;
+	AIS::Model* mgpu = nullptr; // AIS::ModelDefaultGPU / ModelChallengerGPU (refgpu build only)
 	AIS::Model* model = nullptr;
 	TAG tag;
 	Format fmt;
@@ -99,7 +103,7 @@ struct Harness {
 
 extern "C" {
 
-// kind: 0 = ModelStandard, 1 = ModelBase, 2 = ModelDefault, 4 = ModelChallenger, 11 = ModelEngineV2.  fmt: 0 = CU8, 1 = CF32, 2 = CS8, 3 = CS16.
+// kind: 0 = ModelStandard, 1 = ModelBase, 2 = ModelDefault, 4 = ModelChallenger, 11 = ModelEngineV2; libaisrefgpu.so only: 12 = ModelDefaultGPU, 14 = ModelChallengerGPU.  fmt: 0 = CU8, 1 = CF32, 2 = CS8, 3 = CS16.
 // flags: bit 0 record float taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`, bit 3 `-go FP_DS on`, bit 4 channel mode X (`-c X`)
 void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 	const int taps = flags & 1;
@@ -110,6 +114,11 @@ void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 		else if (kind == 1) { h->mb = new AIS::ModelBase(); h->model = h->mb; }
 		else if (kind == 0) { h->ms = new AIS::ModelStandard(); h->model = h->ms; }
 		else if (kind == 11) { h->mv = new AIS::ModelEngineV2(); h->model = h->mv; }
+#ifdef HASMI355X
+		// what Receiver::addModel (Application/Receiver.cpp:155-195) would do for the new engine numbers
+		else if (kind == 12) { h->mgpu = new AIS::ModelDefaultGPU(); h->model = h->mgpu; }
+		else if (kind == 14) { h->mgpu = new AIS::ModelChallengerGPU(); h->model = h->mgpu; }
+#endif
 		else { h->md = new AIS::ModelDefault(); h->model = h->md; }
 		if (flags & 2) h->model->SetKey(AIS::KEY_SETTING_DSK, "ON");
 		if (flags & 4) h->model->SetKey(AIS::KEY_SETTING_PS_EMA, "OFF");
@@ -118,7 +127,7 @@ void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 		else h->model->buildModel('A', 'B', sample_rate, false, &h->dev);
 		h->model->Output() >> h->sink;
 		h->dev.setTag(h->tag);
-		if (taps) {
+		if (taps && !h->mgpu) {
 			AIS::ModelFrontend* fe = static_cast<AIS::ModelFrontend*>(h->model);
 			for (auto& t : h->tap) t.on = true;
 			*fe->C_a >> h->tap[0];
@@ -173,7 +182,12 @@ int ref_feed(void* hv, const void* data, int nbytes) {
 	Harness* h = (Harness*)hv;
 	RAW r = { h->fmt, (void*)data, nbytes };
 	auto t0 = std::chrono::high_resolution_clock::now();
-	h->dev.out.Send(&r, 1, h->tag);
+	try {
+		h->dev.out.Send(&r, 1, h->tag);
+	} catch (const std::exception& e) { // set-up errors of a model surface at its first block (the reference catches them in CommandLine::run)
+		fprintf(stderr, "ref_feed: %s\n", e.what());
+		return -1;
+	}
 	auto t1 = std::chrono::high_resolution_clock::now();
 	h->seconds += std::chrono::duration<double>(t1 - t0).count();
 	return 0;
@@ -255,7 +269,7 @@ void ref_reset_seq(void) { AIS::Message::ID.store(0); }
 
 void ref_destroy(void* hv) {
 	Harness* h = (Harness*)hv;
-	delete h->md; delete h->mc; delete h->mb; delete h->ms; delete h->mv;
+	delete h->md; delete h->mc; delete h->mb; delete h->ms; delete h->mv; delete h->mgpu;
 	delete h;
 }
 

@@ -63,7 +63,7 @@ class _Chain:
 
     def feed(self, block):
         block = np.ascontiguousarray(block)
-        self._f("feed")(self.h, block.ctypes.data, block.nbytes)
+        return self._f("feed")(self.h, block.ctypes.data, block.nbytes)
 
     def feed_blocks(self, x, block_len):
         """Feed whole blocks of block_len IQ samples (the tail that does not fill a block is dropped)."""
@@ -151,6 +151,19 @@ def Ref(model=2, rate=1536000, fmt="cf32", taps=False, kind="strict", dsk=False,
     lib = _lib(os.path.join(ORACLE_DIR, "_ref", "libaisref_%s.so" % kind))
     lib.ref_reset_seq()
     return _Chain(lib, "ref_", model, rate, fmt, taps, dsk, ps_ema, fp_ds, mode_x)
+
+
+def have_refgpu():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libaisrefgpu.so"))
+
+
+def RefGpu(model=12, rate=1536000, fmt="cf32", dsk=False, ps_ema=True, fp_ds=False):
+    """oracle/_ref/libaisrefgpu.so: the reference's unmodified sources PLUS the reference-side binding of libaisgpu.so
+    (integration/reference/Source/DSP/GPU/ModelGPU.cpp, an AIS::Model subclass compiled against the reference's real headers).
+    model 2 / 4 = the reference's own ModelDefault / ModelChallenger, 12 / 14 = the same engines with the DSP on the GPU."""
+    lib = _lib(os.path.join(ORACLE_DIR, "_ref", "libaisrefgpu.so"))
+    lib.ref_reset_seq()
+    return _Chain(lib, "ref_", model, rate, fmt, False, dsk, ps_ema, fp_ds, False)
 
 
 def oracle_lib():

@@ -72,3 +72,23 @@ def test_create_ladder_selection_for_decimate_by_3_rates():
     # channel mode X: 12k .. 192k, one channel (Model.cpp:37-38)
     assert rc(48000, 512 * 8, gpu.FLAG_MODE_X) in (0, 2) and rc(40000, 512 * 8, gpu.FLAG_MODE_X) in (0, 2) and rc(192000, 2048 * 8, gpu.FLAG_MODE_X) in (0, 2)
     assert rc(23999, 512 * 8, gpu.FLAG_MODE_X) == 1 and rc(200000, 4096 * 8, gpu.FLAG_MODE_X) == 1 and rc(48000, 512 * 8) == 1
+
+
+def test_reference_binding_links_and_fails_loudly_without_a_gpu():
+    """oracle/_ref/libaisrefgpu.so = the reference's unmodified objects + integration/reference/Source/DSP/GPU/ModelGPU.cpp (an
+    AIS::Model subclass written against the reference's real headers) + libaisgpu.so.  Without a GPU the engine builds (wiring
+    only) and its first block reports AISGPU_ERR_NODEV as a std::runtime_error -- there is no CPU fallback behind it."""
+    import numpy as np
+    import pytest
+    import checkers
+    if not checkers.have_refgpu():
+        pytest.skip("libaisrefgpu.so not built")
+    import ctypes
+    from ais_catcher_amd import gpu
+    if gpu.load().aisgpu_device_count() > 0:
+        pytest.skip("a GPU is present: covered by the -m gpu tests")
+    m = checkers.RefGpu(model=12)
+    assert m.feed(np.zeros(16384, np.complex64)) == -1
+    assert m.nmea() == []
+    cpu = checkers.RefGpu(model=2)   # the reference's own engine from the same binary still runs
+    assert cpu.feed(np.zeros(16384, np.complex64)) == 0

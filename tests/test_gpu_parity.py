@@ -1043,3 +1043,69 @@ def test_benchmarked_path_with_device_frame_decoders_vs_oracle():
         models[r].close()
     batch.close()
     assert sum(len(w) for w in want_nmea) >= R
+
+
+def test_batch_survives_receivers_that_end_early_or_stall():
+    """GpuBatch (host/gpu_model.*): a receiver whose input ends calls leave() and the others stop waiting for it; one that just
+    stops delivering is evicted after the timeout (the reference marks such a device lost, Device/Device.h:60-61) and gets
+    AISGPU_ERR_STATE when it comes back; the remaining receivers' NMEA is untouched by either."""
+    import threading
+    import time
+    from ais_catcher_amd import host
+    R, block, nblocks = 4, 131072, 6
+    xs = [synth.receiver_stream(block * nblocks, receiver_id=170 + r, gap_slots=(1, 2)) for r in range(R)]
+    want = []
+    for x in xs:
+        c = checkers.Oracle()
+        c.feed_blocks(x, block)
+        want.append(c.nmea())
+    batch = host.Batch(n_receivers=R, block_len=block)
+    batch.set_timeout(1500)
+    models = [host.ModelDefaultGPU(block_len=block, batch=batch, rx=r) for r in range(R)]
+    status = [[] for _ in range(R)]
+
+    def run(r):
+        for b in range(nblocks):
+            if r == 1 and b == 2:      # end of input after two blocks
+                models[r].leave()
+                return
+            if r == 3 and b == 3:      # stalls (longer than the timeout), then comes back
+                time.sleep(4.0)
+            status[r].append(models[r].receive(xs[r][b * block:(b + 1) * block]))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(R)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert status[0] == [0] * nblocks and status[2] == [0] * nblocks
+    assert status[1] == [0, 0]
+    assert status[3][:3] == [0, 0, 0] and status[3][3] == 4 and batch.active() == 2
+    for r in (0, 2):
+        assert models[r].nmea() == want[r] and len(want[r]) >= 2
+    # what the receivers that dropped out had decoded until then is a prefix of their reference output
+    assert models[1].nmea() == want[1][:len(models[1].nmea())]
+    for m in models:
+        m.close()
+    batch.close()
+
+
+@pytest.mark.skipif(not checkers.have_refgpu(), reason="oracle/_ref/libaisrefgpu.so not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("gpu_model,cpu_model,rate,fmt,block,nblocks,kw", [
+    (12, 2, 1536000, "cf32", 786432, 4, {}), (12, 2, 1536000, "cu8", 131072, 12, {}), (12, 2, 1536000, "cu8", 131072, 8, {"fp_ds": True}),
+    (12, 2, 1536000, "cf32", 131072, 8, {"ps_ema": False}), (12, 2, 288000, "cf32", 49152, 12, {}), (12, 2, 6000000, "cs16", 786432, 4, {}),
+    (14, 4, 1536000, "cf32", 131072, 10, {}), (14, 4, 6000000, "cf32", 786432, 5, {})])
+def test_reference_binding_compiled_against_the_real_reference(gpu_model, cpu_model, rate, fmt, block, nblocks, kw):
+    """Row 8(b), for real: integration/reference/Source/DSP/GPU/ModelGPU.cpp -- an AIS::Model subclass (DSP/Model.h:76-126) that
+    takes the device's RAW blocks through the reference's own Connection<RAW> (Library/Stream.h), calls the C ABI, and feeds the
+    reference's own AIS::Decoder objects with their Reset mesh -- is compiled against the reference's headers and linked with its
+    unmodified objects (oracle/Makefile: refgpu).  Engine 12 / 14 (GPU) must print what engine 2 / 4 (the reference's CPU chain)
+    prints from the same binary, including the settings that arrive through SetKey (Model.cpp:358-402, 579-594)."""
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=180 + gpu_model, gap_slots=(1, 2), type5_every=4)
+    data = {"cu8": synth.to_cu8, "cs16": synth.to_cs16, "cf32": lambda v: v}[fmt](x)
+    out = []
+    for model in (cpu_model, gpu_model):
+        m = checkers.RefGpu(model=model, rate=rate, fmt=fmt, **kw)
+        m.feed_blocks(data, block)
+        out.append((m.nmea(), m.msg_meta()))
+        m.close()
+    assert out[0][0] == out[1][0] and len(out[0][0]) >= 3
+    assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])  # tag.level, tag.ppm per message
