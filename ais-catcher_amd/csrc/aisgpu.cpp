@@ -16,6 +16,9 @@
 #include <new>
 #include <string>
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -60,6 +63,19 @@ enum Mode {
 };
 
 struct SubOut { int pb, lv, q, groups; long long first_group, first48; };
+
+// Rotate phasor tables of the direct / pre-decimated ladders come from a worker thread that runs ahead of the caller: the table
+// of a block is a 49,152-step DEPENDENT float recurrence (0.15-0.2 ms on a host core), data independent, so it has no business
+// on the thread that enqueues the kernels.  Ring of NR pinned tables; table k lives in slot k % NR until its upload has been
+// consumed (the slot's event).  The caller takes the tables strictly in order.
+struct RotWorker {
+	static constexpr int NR = 4;
+	std::thread th; std::mutex m; std::condition_variable cv;
+	float2* tab[NR] = {}; float2* tab_dev[NR] = {}; hipEvent_t ev[NR] = {};
+	long long produced = 0; // tables 0 .. produced-1 are complete
+	long long launched = 0; // tables 0 .. launched-1 have been handed to the device (their slot's event is recorded)
+	bool stop = false, started = false;
+};
 
 } // namespace
 
@@ -131,6 +147,7 @@ struct aisgpu {
 	float2* h_rot[2] = {};
 	int* h_usidx[2] = {}; float* h_usalpha[2] = {};
 	hipEvent_t rot_ev[2] = {}; bool rot_ev_used[2] = {}; bool rot_ahead = false; // (rot_ahead: the next block's table is already on its way)
+	RotWorker rw; int rot_slot[2] = {}; bool rot_worker = true; // AISGPU_ROT_WORKER=0: tables generated on the calling thread
 	bool rot_stage_ahead = true;
 	float2* h_rot_dev[2] = {}; bool rot_by_kernel = true; // device view of the pinned table buffers
 	uint32_t* h_bits = nullptr; float* h_lvl = nullptr; float* h_ppm = nullptr; // MAXSUB slots each
@@ -225,6 +242,60 @@ void gen_rot_table(aisgpu_t* h, float2* tab) {
 	}
 	h->rot = r;
 	for (int i = 0; i < ROT_HIST; i++) h->rot_tail[i] = t[h->n96 - ROT_HIST + i];
+}
+
+void rot_worker_main(aisgpu_t* h) {
+	RotWorker& w = h->rw;
+	(void)hipSetDevice(h->cfg.device_id);
+	for (long long k = 0;; k++) {
+		const int slot = (int)(k % RotWorker::NR);
+		{
+			std::unique_lock<std::mutex> l(w.m);
+			w.cv.wait(l, [&] { return w.stop || k < RotWorker::NR || w.launched > k - RotWorker::NR; });
+			if (w.stop) return;
+		}
+		if (k >= RotWorker::NR) (void)hipEventSynchronize(w.ev[slot]); // the upload of table k - NR has been consumed
+		gen_rot_table(h, w.tab[slot]); // (h->rot / rot_tail belong to this thread from now on)
+		{ std::lock_guard<std::mutex> l(w.m); w.produced = k + 1; }
+		w.cv.notify_all();
+	}
+}
+
+// next table (strictly in order) -> d_rot[b] on stream st
+int stage_rot_from_worker(aisgpu_t* h, int b, hipStream_t st) {
+	RotWorker& w = h->rw;
+	if (!w.started) {
+		for (int i = 0; i < RotWorker::NR; i++) {
+			HIPCHK(hipHostMalloc((void**)&w.tab[i], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipHostMallocDefault));
+			HIPCHK(hipEventCreateWithFlags(&w.ev[i], hipEventDisableTiming));
+			if (hipHostGetDevicePointer((void**)&w.tab_dev[i], w.tab[i], 0) != hipSuccess) h->rot_by_kernel = false;
+		}
+		w.started = true;
+		w.th = std::thread(rot_worker_main, h);
+	}
+	const long long k = w.launched; // only this thread writes it
+	{
+		std::unique_lock<std::mutex> l(w.m);
+		w.cv.wait(l, [&] { return w.produced > k; });
+	}
+	const int slot = (int)(k % RotWorker::NR);
+	if (h->rot_by_kernel) HIPCHK(launch_copy_rows(w.tab_dev[slot], 0, h->d_rot[b], 0, ROT_HIST + h->n96, 1, st));
+	else HIPCHK(hipMemcpyAsync(h->d_rot[b], w.tab[slot], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, st));
+	HIPCHK(hipEventRecord(w.ev[slot], st));
+	h->rot_slot[b] = slot;
+	{ std::lock_guard<std::mutex> l(w.m); w.launched = k + 1; }
+	w.cv.notify_all();
+	return AISGPU_OK;
+}
+
+void rot_worker_stop(aisgpu_t* h) {
+	RotWorker& w = h->rw;
+	if (!w.started) return;
+	{ std::lock_guard<std::mutex> l(w.m); w.stop = true; }
+	w.cv.notify_all();
+	if (w.th.joinable()) w.th.join();
+	for (int i = 0; i < RotWorker::NR; i++) { if (w.tab[i]) hipHostFree(w.tab[i]); if (w.ev[i]) hipEventDestroy(w.ev[i]); }
+	w.started = false;
 }
 
 void drain_events(aisgpu_t* h) {
@@ -970,6 +1041,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	if (const char* e = getenv("AISGPU_SEARCH0")) h->search_on_front = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_DEFER_FUSED")) h->defer_fused = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_ROT_AHEAD")) h->rot_stage_ahead = atoi(e) != 0;
+	if (const char* e = getenv("AISGPU_ROT_WORKER")) h->rot_worker = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_GL")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0) h->GL = v; }
 	// The spectral analysis rides at the end of the front-end waves (k1_fft_tail) when every span is a whole number of 512-sample
 	// windows of the 48 kHz channels (16 tiles each) and whole spans make up the block; the automatic span length is rounded up
@@ -1055,6 +1127,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 void aisgpu_destroy(aisgpu_t* h) {
 	if (!h) return;
 	DevGuard dg(h);
+	rot_worker_stop(h);
 	h->pend.valid = false;
 	if (h->stream) hipStreamSynchronize(h->stream);
 	if (h->s1) hipStreamSynchronize(h->s1);
@@ -1254,6 +1327,7 @@ int aisgpu_run(aisgpu_t* h) {
 		// The Rotate phasor table of this block: staged one block AHEAD on s3 (below), so that neither the 10 us copy nor its launch
 		// gap sits between two kernels of the front stream; only the first block (and the single-stream mode) stages it here.
 		const auto stage_rot = [&](int b, hipStream_t st) -> int {
+			if (h->rot_worker) return stage_rot_from_worker(h, b, st); // table generated ahead by the worker thread
 			// the pinned buffer `b` was last used two blocks ago; wait until that upload has been consumed (only blocks when the
 			// host runs more than one block ahead of the device)
 			if (h->rot_ev_used[b]) HIPCHK(hipEventSynchronize(h->rot_ev[b]));
@@ -1266,7 +1340,7 @@ int aisgpu_run(aisgpu_t* h) {
 			return AISGPU_OK;
 		};
 		if (!h->rot_ahead) { int rc = stage_rot(pb, h->stream); if (rc) return rc; }
-		else HIPCHK(hipStreamWaitEvent(h->stream, h->rot_ev[pb], 0));
+		else HIPCHK(hipStreamWaitEvent(h->stream, h->rot_worker ? h->rw.ev[h->rot_slot[pb]] : h->rot_ev[pb], 0));
 		h->rot_ahead = false;
 		// c48/fz/ppm[q] were last read by K2b/K2c of block f-NBUF
 		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[q], 0));

@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  AISGPU_SERIAL=1 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_$c -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  AISGPU_SERIAL=1 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_$c -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --parity-receivers 0 > /dev/null 2>&1
 done
 python - <<PY
 import sqlite3, json
@@ -15,7 +15,13 @@ def per_launch(db, counter):
     return r[0] / r[1]
 f = per_launch("$R/gpurun_out/pmc_FETCH_SIZE/p_results.db", "FETCH_SIZE")
 w = per_launch("$R/gpurun_out/pmc_WRITE_SIZE/p_results.db", "WRITE_SIZE")
+import socket, subprocess
+def sh(cmd):
+    try: return subprocess.run(cmd, shell=True, capture_output=True, text=True, timeout=20).stdout.strip()
+    except Exception: return None
 out = {"kernel": "k1_dpp", "fetch_size_kib_raw": f, "write_size_kib": w,
+       "host": socket.gethostname(), "commit": open("$R/gpurun_out/.commit").read().strip() if __import__("os").path.exists("$R/gpurun_out/.commit") else None,
+       "gpu": sh("rocm-smi --showuniqueid 2>/dev/null | grep -i 'unique id' | head -1"),
        "hbm_bytes_per_launch": f * 1024 * 2 + w * 1024,
        "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 for 16 B/lane coalesced reads); separate --pmc passes"}
 json.dump(out, open("$R/gpurun_out/pmc_traffic.json", "w"), indent=1)
