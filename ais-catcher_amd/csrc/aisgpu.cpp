@@ -175,12 +175,15 @@ struct aisgpu {
 	bool k7_event = true; uint32_t *d_k7ev = nullptr, *d_k7cnt = nullptr; uint16_t* d_k7open = nullptr; K7Slot* d_k7slot = nullptr; int* d_k7ovf = nullptr;
 	uint32_t* h_frames = nullptr; unsigned frames_seen = 0; int max_frames = 0; std::vector<aisgpu_frame> frames;
 	bool ps_box = false; PsBoxState* d_box[2] = {}; // Demod::PhaseSearch (boxcar) instead of PhaseSearchEMA
+	bool elide_waits = true; // AISGPU_ELIDE_WAITS=0: always enqueue the barrier packet
+	int ablate = 0; // experiment aid (AISGPU_ABLATE, results are then wrong): bit 0 skip PhaseSearch, 1 skip derotation/FIR, 2 skip the phasor recurrence, 3 skip the front end
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
 	bool fused = false; int GL = 40; bool search_on_front = false;
 	bool defer_fused = false; // spectral analysis on s4, second half of a block one block later
 	struct { bool valid = false; int q = 0, pb = 0, lv = 0, n_groups = 0, n_rel0 = 0, S = 0; long long g0 = 0; unsigned block = 0, sub = 0; } fpend;
 	float2 *d_ck[NBUF] = {}, *d_ckw[NBUF] = {}, *d_dfhist[2] = {};
+	bool k46 = false; float2* d_ck8[NBUF] = {}; int* d_qflag = nullptr; int n_quads = 0; // FIR + PhaseSearch in one kernel (no FIR outputs in HBM)
 	// per-kernel geometry
 	int tile_in = 0, tiles_per_block = 0, tiles_per_span = 0, spans = 0;         // fused front end (its own input)
 	int ptile_in = 0, ptiles_per_block = 0, ptiles_per_span = 0, pspans = 0;     // pre-decimation pass
@@ -214,6 +217,12 @@ struct DevGuard {
 	}
 	~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
+
+// Cross-stream dependency.  A wait on an event that has already completed is elided on the host (hipEventQuery): a barrier
+// packet costs the command processor microseconds even when its signal is long satisfied, and the front stream had two of
+// them between consecutive front-end launches.
+hipError_t wait_event(aisgpu_t* h, hipStream_t s, hipEvent_t ev);
+#define WAITEV(stream_, ev_) HIPCHK(wait_event(h, (stream_), (ev_)))
 
 template <typename T>
 hipError_t dalloc(T** p, size_t n) {
@@ -298,6 +307,12 @@ void rot_worker_stop(aisgpu_t* h) {
 	w.started = false;
 }
 
+hipError_t wait_event(aisgpu_t* h, hipStream_t s, hipEvent_t ev) {
+	if (h->elide_waits && hipEventQuery(ev) == hipSuccess) return hipSuccess;
+	(void)hipGetLastError(); // (hipErrorNotReady is not an error)
+	return hipStreamWaitEvent(s, ev, 0);
+}
+
 void drain_events(aisgpu_t* h) {
 	for (auto& p : h->ev_busy) {
 		float ms = 0;
@@ -356,7 +371,7 @@ int finish_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned 
 	if (h->gpu_decode) { // the frame decoder is a long latency-bound kernel of a few waves: own stream, so that the next
 		// block's PhaseSearchEMA does not queue behind it; sym/lvl/bits[pb] are free again only when IT is done
 		HIPCHK(hipEventRecord(h->ev_k4[pb], s));
-		HIPCHK(hipStreamWaitEvent(h->s5, h->ev_k4[pb], 0));
+		WAITEV(h->s5, h->ev_k4[pb]);
 		int rc = enqueue_decode(h, pb, lv, g0, n_groups, block, sub, h->s5);
 		if (rc) return rc;
 		HIPCHK(hipEventRecord(h->ev_ema[lv], h->s5));
@@ -375,7 +390,7 @@ int flush_walk(aisgpu_t* h) {
 // PhaseSearchEMA / PhaseSearch of one downstream block (sym/lvl parity pb) on stream s
 int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s) {
 	// bits[pb] was last read by the frame decoder / the copies of block f-2 (slot lv ^ 2): long done, and ordered here
-	HIPCHK(hipStreamWaitEvent(s, h->ev_ema[lv ^ 2], 0));
+	WAITEV(s, h->ev_ema[lv ^ 2]);
 	K4Params k4;
 	k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[pb]; k4.bits_stride = h->words;
 	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
@@ -408,7 +423,7 @@ int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned
 	}
 	{ int rc = flush_walk(h); if (rc) return rc; }
 	if (h->ps_box) HIPCHK(launch_k4_box(k4, s));
-	else if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, s));
+	else if (h->ps_parallel && k4.n_chunks > 1) { if (!(h->ablate & 1)) HIPCHK(launch_k4(k4, s)); }
 	else HIPCHK(launch_k4_sequential(k4, s));
 	HIPCHK(hipEventRecord(h->ev_sym[pb], s));
 	return finish_k4(h, pb, lv, g0, n_groups, block, sub, s);
@@ -446,7 +461,7 @@ int enqueue_back(aisgpu_t* h) {
 	const int q = h->pend.q, pb = h->pend.pb, lv = h->pend.lv;
 	const long long g0 = h->pend.g0, g1 = h->pend.g1;
 	const K2Params k2 = make_k2(h, q);
-	HIPCHK(hipStreamWaitEvent(h->stream, h->ev_phasor[q], 0));
+	WAITEV(h->stream, h->ev_phasor[q]);
 	HIPCHK(launch_k2c(k2, h->n_chan, h->stream));
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->stream));
 	K3Params k3;
@@ -454,8 +469,8 @@ int enqueue_back(aisgpu_t* h) {
 	k3.fir_tap = h->d_firtap; k3.fir_tap_stride = 8 + h->L;
 	memcpy(k3.taps, TAPS_COHERENT, sizeof k3.taps);
 	k3.first_group = g0; k3.first_sample48 = h->pend.first48; k3.n_groups = (int)(g1 - g0);
-	HIPCHK(hipStreamWaitEvent(h->stream, h->ev_sym[pb], 0)); // sym[pb] was last read by PhaseSearch of block f-2,
-	HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ema[lv], 0)); // lvl[lv] by the frame decoder / the copies of block f-4
+	WAITEV(h->stream, h->ev_sym[pb]); // sym[pb] was last read by PhaseSearch of block f-2,
+	WAITEV(h->stream, h->ev_ema[lv]); // lvl[lv] by the frame decoder / the copies of block f-4
 	HIPCHK(launch_k3(k3, h->n_chan, h->stream));
 	if (h->challenger) { // FM branch on the same derotated samples (Model.cpp:638-639)
 		K5Params k5;
@@ -468,7 +483,7 @@ int enqueue_back(aisgpu_t* h) {
 	HIPCHK(hipEventRecord(h->ev_k3[pb], h->stream));
 
 	// ---- PhaseSearchEMA chains on s1: VALU-bound, overlaps the HBM-bound front end of the next block
-	HIPCHK(hipStreamWaitEvent(h->s2, h->ev_k3[pb], 0));
+	WAITEV(h->s2, h->ev_k3[pb]);
 	return enqueue_k4(h, pb, lv, g0, (int)(g1 - g0), h->pend.block, h->pend.sub, h->s2);
 }
 
@@ -480,11 +495,14 @@ int enqueue_back(aisgpu_t* h) {
 //   s4: derotation + FIR + ScatterPLL       (VALU/latency-bound)
 //   s1: PhaseSearchEMA                      (VALU-bound; both overlap the next block's front end)
 // second half of the fused path for one block: derotation + FIR + ScatterPLL (s4), then PhaseSearch (s1)
+int enqueue_k46(aisgpu_t* h, int q, int pb, int lv, long long g0, int n_groups, int n_rel0, unsigned block, unsigned sub);
+
 int enqueue_fused_back(aisgpu_t* h) {
 	if (!h->fpend.valid) return AISGPU_OK;
 	h->fpend.valid = false;
 	const int q = h->fpend.q, pb = h->fpend.pb, lv = h->fpend.lv, n_groups = h->fpend.n_groups;
 	const long long g0 = h->fpend.g0;
+	if (h->k46) return enqueue_k46(h, q, pb, lv, g0, n_groups, h->fpend.n_rel0, h->fpend.block, h->fpend.sub);
 	K6Params k6;
 	k6.c48 = h->d_c48[q]; k6.c48_stride = h->c48s; k6.ck = h->d_ck[q]; k6.ckw = h->d_ckw[q]; k6.ck_stride = (h->n_chan + 63) / 64 * 64;
 	k6.step_table = h->d_step; k6.fz = h->d_fz[q];
@@ -493,15 +511,43 @@ int enqueue_fused_back(aisgpu_t* h) {
 	memcpy(k6.taps, TAPS_COHERENT, sizeof k6.taps);
 	k6.first_group = g0; k6.n_rel0 = h->fpend.n_rel0; k6.n_groups = n_groups; k6.L = h->L; k6.n_windows = h->W; k6.n_chan = h->n_chan;
 	k6.GL = h->GL; k6.S = h->fpend.S;
-	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_phasor[q], 0));
-	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_sym[pb], 0)); // sym[pb] was last read by PhaseSearch of block f-2,
-	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_ema[lv], 0)); // lvl[lv] by the frame decoder / the copies of block f-4
-	{ TraceScope t(h, "derotfir", h->s4); HIPCHK(launch_k6(k6, h->s4)); }
+	WAITEV(h->s4, h->ev_phasor[q]);
+	WAITEV(h->s4, h->ev_sym[pb]); // sym[pb] was last read by PhaseSearch of block f-2,
+	WAITEV(h->s4, h->ev_ema[lv]); // lvl[lv] by the frame decoder / the copies of block f-4
+	if (!(h->ablate & 2)) { TraceScope t(h, "derotfir", h->s4); HIPCHK(launch_k6(k6, h->s4)); }
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s4));
 	HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4));
-	HIPCHK(hipStreamWaitEvent(h->s1, h->ev_k3[pb], 0));
+	WAITEV(h->s1, h->ev_k3[pb]);
 	TraceScope t(h, "psearch", h->s1);
 	return enqueue_k4(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub, h->s1);
+}
+
+// derotation + FIR + ScatterPLL + PhaseSearchEMA of one downstream block as one kernel on s1 (no FIR outputs in HBM)
+int enqueue_k46(aisgpu_t* h, int q, int pb, int lv, long long g0, int n_groups, int n_rel0, unsigned block, unsigned sub) {
+	hipStream_t s = h->s1;
+	K46Params k{};
+	K4Params& k4 = k.k4;
+	k4.sym = nullptr; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[pb]; k4.bits_stride = h->words;
+	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
+	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag + pb;
+	k4.qflag = h->d_qflag + (size_t)pb * h->n_quads;
+	k4.n_chains = h->n_chains; k4.n_groups = n_groups;
+	k4.n_chunks = (n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm; k4.prio = h->ps_prio;
+	k4.first_group = g0;
+	k.c48 = h->d_c48[q]; k.c48_stride = h->c48s; k.ck8 = h->d_ck8[q]; k.ck_stride = (h->n_chan + 63) / 64 * 64;
+	k.step_table = h->d_step; k.fz = h->d_fz[q];
+	k.hist_in = h->d_dfhist[pb ^ 1]; k.hist_out = h->d_dfhist[pb];
+	k.lvl = h->d_lvl[lv]; k.lvl_stride = h->Gcap;
+	memcpy(k.taps, TAPS_COHERENT, sizeof k.taps);
+	k.first_group = g0; k.n_rel0 = n_rel0; k.L = h->L; k.n_windows = h->W; k.n_chan = h->n_chan; k.sequential = 0;
+	WAITEV(s, h->ev_phasor[q]);
+	WAITEV(s, h->ev_ema[lv]);     // lvl[lv] was last read by the frame decoder / the copies of block f-4,
+	WAITEV(s, h->ev_ema[lv ^ 2]); // bits[pb] by those of block f-2
+	{ int rc = flush_walk(h); if (rc) return rc; }
+	if (!(h->ablate & 1)) { TraceScope t(h, "firsearch", s); HIPCHK(launch_k46(k, s)); }
+	HIPCHK(hipEventRecord(h->ev_c48free[q], s));
+	HIPCHK(hipEventRecord(h->ev_sym[pb], s));
+	return finish_k4(h, pb, lv, g0, n_groups, block, sub, s);
 }
 
 int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
@@ -522,20 +568,20 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 		hipStream_t sa = h->defer_fused ? h->s4 : h->stream;
 		if (h->defer_fused) {
 			HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
-			HIPCHK(hipStreamWaitEvent(h->s4, h->ev_front[q], 0));
+			WAITEV(h->s4, h->ev_front[q]);
 		}
 		{ TraceScope t(h, "fft", sa); HIPCHK(launch_k2a_fft(k2, h->n_chan, sa)); }
 		hipStream_t ss = h->defer_fused ? h->s4 : h->search_on_front ? h->stream : h->s4; // with the searches on the front stream four streams are enough
 		if (!h->defer_fused) {
 			HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
-			HIPCHK(hipStreamWaitEvent(ss, h->ev_front[q], 0));
+			WAITEV(ss, h->ev_front[q]);
 		}
 		{ TraceScope t(h, "search", ss); HIPCHK(launch_k2a_search(k2, h->n_chan, ss)); }
 		HIPCHK(hipEventRecord(h->ev_search[q], ss));
 	}
-	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_search[q], 0));
-	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_c48free[q], 0)); // ck[q] was last read by K6 of block f-NBUF
-	{ TraceScope t(h, "phasor", h->s3); HIPCHK(launch_k2b_ck(k2, h->n_chan, h->s3)); }
+	WAITEV(h->s3, h->ev_search[q]);
+	WAITEV(h->s3, h->ev_c48free[q]); // ck[q] was last read by K6 of block f-NBUF
+	if (!(h->ablate & 4)) { TraceScope t(h, "phasor", h->s3); if (h->k46) HIPCHK(launch_k2b_ck8(k2, h->d_ck8[q], h->n_chan, h->s3)); else HIPCHK(launch_k2b_ck(k2, h->n_chan, h->s3)); }
 	HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
 
 	{ int rc = enqueue_fused_back(h); if (rc) return rc; } // the previous block's second half, if it was deferred
@@ -572,7 +618,7 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 	HIPCHK(launch_k5(k5, h->n_chan, h->stream));
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->stream));
 	HIPCHK(hipEventRecord(h->ev_k3[pb], h->stream));
-	HIPCHK(hipStreamWaitEvent(h->s2, h->ev_k3[pb], 0)); // aisgpu_sync_outputs copies on s2
+	WAITEV(h->s2, h->ev_k3[pb]); // aisgpu_sync_outputs copies on s2
 	if (h->n_sub < MAXSUB) {
 		SubOut& so = h->sub[h->n_sub++];
 		so.pb = pb; so.lv = 0; so.q = q; so.groups = 0; so.first_group = h->n48 / 5; so.first48 = h->n48;
@@ -606,11 +652,11 @@ int enqueue_downstream(aisgpu_t* h, int q, int pb) {
 	HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
 	// ---- s4: the sequential spectral searches, then on s3 the sequential CGF phasor recurrence (needs fz of this
 	// block; rotT[q] was last read by apply(f-NBUF))
-	HIPCHK(hipStreamWaitEvent(h->s4, h->ev_front[q], 0));
+	WAITEV(h->s4, h->ev_front[q]);
 	HIPCHK(launch_k2a_search(k2, h->n_chan, h->s4));
 	HIPCHK(hipEventRecord(h->ev_search[q], h->s4));
-	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_search[q], 0));
-	HIPCHK(hipStreamWaitEvent(h->s3, h->ev_c48free[q], 0));
+	WAITEV(h->s3, h->ev_search[q]);
+	WAITEV(h->s3, h->ev_c48free[q]);
 	HIPCHK(launch_k2b(k2, h->n_chan, h->s3));
 	HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
 
@@ -950,6 +996,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_k4[i], hipEventDisableTiming));
 	if (const char* e = getenv("AISGPU_DEFER")) h->defer = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_TRACE")) h->trace = atoi(e) != 0;
+	if (const char* e = getenv("AISGPU_ABLATE")) h->ablate = atoi(e);
+	if (const char* e = getenv("AISGPU_ELIDE_WAITS")) h->elide_waits = atoi(e) != 0;
 
 	// ---- constant tables (host libm, like the reference on this machine)
 	{
@@ -1059,8 +1107,19 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			h->spans = h->tiles_per_block / t;
 		} else h->fft_in_k1 = false;
 	}
+	// derotation + FIR + PhaseSearchEMA as ONE kernel (the FIR outputs stay in LDS): the default of the fused back end for the
+	// chunk-parallel row search; AISGPU_K46=0 keeps the two-kernel form (which the boxcar / lane / sequential variants use)
+	h->k46 = h->fused && !h->ps_box;
+	if (const char* e = getenv("AISGPU_K46")) h->k46 = h->k46 && atoi(e) != 0;
+	if (const char* e = getenv("AISGPU_K4")) if (strcmp(e, "lane") == 0) h->k46 = false;
+	if (getenv("AISGPU_PS_SEQUENTIAL")) h->k46 = false;
 	if (h->fused) {
 		const size_t cs = (C + 63) / 64 * 64;
+		if (h->k46) {
+			h->n_quads = (int)((C + 3) / 4);
+			for (int i = 0; i < NBUF; i++) HIPCHK(dalloc(&h->d_ck8[i], (size_t)(h->L / 8) * cs));
+			HIPCHK(dalloc(&h->d_qflag, 2 * (size_t)h->n_quads));
+		}
 		for (int i = 0; i < NBUF; i++) {
 			HIPCHK(dalloc(&h->d_ck[i], (size_t)(h->Gcap / h->GL + 2) * cs));
 			HIPCHK(dalloc(&h->d_ckw[i], (size_t)h->W * cs));
@@ -1159,7 +1218,8 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_fm); hipFree(h->d_fmfir); hipFree(h->d_fmbits[0]); hipFree(h->d_fmbits[1]);
 	if (h->h_fmbits) hipHostFree(h->h_fmbits);
 	if (h->h_c48) hipHostFree(h->h_c48);
-	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); hipFree(h->d_ckw[i]); }
+	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); hipFree(h->d_ckw[i]); hipFree(h->d_ck8[i]); }
+	hipFree(h->d_qflag);
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
 	hipFree(h->d_box[0]); hipFree(h->d_box[1]);
 	hipFree(h->d_dec); hipFree(h->d_frames); hipFree(h->d_frame_count);
@@ -1289,7 +1349,7 @@ int aisgpu_run(aisgpu_t* h) {
 		HIPCHK(hipMemcpyAsync(h->d_rot[pb], h->h_rot[pb], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
 		HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
 		h->rot_ev_used[pb] = true;
-		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[q], 0));
+		WAITEV(h->stream, h->ev_c48free[q]);
 		K1uParams ku;
 		ku.xin = xcur; ku.xin_stride = xstride; ku.xin_off = h->xh;
 		ku.us_idx = nullptr; ku.us_alpha = nullptr; ku.rot = h->d_rot[pb];
@@ -1309,7 +1369,7 @@ int aisgpu_run(aisgpu_t* h) {
 		HIPCHK(hipMemcpyAsync(h->d_rot[pb], h->h_rot[pb], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
 		HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
 		h->rot_ev_used[pb] = true;
-		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[q], 0));
+		WAITEV(h->stream, h->ev_c48free[q]);
 		K1kParams kk;
 		kk.xin = xcur; kk.xin_stride = xstride; kk.xin_off = h->xh;
 		kk.rot = h->d_rot[pb]; kk.c48 = h->d_c48[q]; kk.c48_stride = h->c48s; kk.L = h->L;
@@ -1340,10 +1400,10 @@ int aisgpu_run(aisgpu_t* h) {
 			return AISGPU_OK;
 		};
 		if (!h->rot_ahead) { int rc = stage_rot(pb, h->stream); if (rc) return rc; }
-		else HIPCHK(hipStreamWaitEvent(h->stream, h->rot_worker ? h->rw.ev[h->rot_slot[pb]] : h->rot_ev[pb], 0));
+		else WAITEV(h->stream, h->rot_worker ? h->rw.ev[h->rot_slot[pb]] : h->rot_ev[pb]);
 		h->rot_ahead = false;
 		// c48/fz/ppm[q] were last read by K2b/K2c of block f-NBUF
-		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[q], 0));
+		WAITEV(h->stream, h->ev_c48free[q]);
 		K1Params k1{};
 		const bool from_pre = h->mode == MODE_PRE;
 		k1.in = from_pre ? (const void*)xcur : h->cur_in;
@@ -1362,7 +1422,7 @@ int aisgpu_run(aisgpu_t* h) {
 			k1.omega = h->d_omega; k1.ppm_table = h->d_ppmtab; k1.fz = h->d_fz[q]; k1.ppm = h->d_ppm[q];
 		}
 		if (!from_pre) { int rc = time_begin(); if (rc) return rc; }
-		{ TraceScope t(h, "front", h->stream); HIPCHK(launch_k1(k1, h->K, from_pre ? 0 : h->kfmt, h->tile96, h->depth, h->k1_threads, h->spans, R, h->stream)); }
+		if (!(h->ablate & 8)) { TraceScope t(h, "front", h->stream); HIPCHK(launch_k1(k1, h->K, from_pre ? 0 : h->kfmt, h->tile96, h->depth, h->k1_threads, h->spans, R, h->stream)); }
 		if (!from_pre) { int rc = time_end(); if (rc) return rc; }
 		if (saves) {}
 		else if (from_pre) HIPCHK(launch_k1_tail(xcur, xstride * 8, (long long)h->n_pre * 8, h->d_hist2[hb ^ 1], h->tile_in * 8, R, h->stream));
@@ -1405,7 +1465,7 @@ int aisgpu_run(aisgpu_t* h) {
 					HIPCHK(hipMemcpyAsync(h->d_usidx[pb], ti, ((size_t)US_HIST + len) * sizeof(int), hipMemcpyHostToDevice, h->stream));
 					HIPCHK(hipMemcpyAsync(h->d_usalpha[pb], ta, ((size_t)US_HIST + len) * sizeof(float), hipMemcpyHostToDevice, h->stream));
 					HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
-					HIPCHK(hipStreamWaitEvent(h->stream, h->ev_c48free[q], 0));
+					WAITEV(h->stream, h->ev_c48free[q]);
 					if (h->us_dsk) { // US >> DSK >> ROT: the flush is a whole number of the filter's 8192-sample output blocks
 						K1kParams kk;
 						kk.xin = xcur; kk.xin_stride = xstride; kk.xin_off = h->xh;
@@ -1455,7 +1515,7 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 		// ev_ema[pb]: PhaseSearch (and the frame decoder) of that block are done, wherever their last kernel ran; they are
 		// ordered after everything that produced lvl/ppm
 		if (!h->base && !h->v2) {
-		HIPCHK(hipStreamWaitEvent(h->s2, h->ev_ema[so.lv], 0));
+		WAITEV(h->s2, h->ev_ema[so.lv]);
 		HIPCHK(hipMemcpyAsync(h->h_bits + (size_t)s * C * 5 * h->words, h->d_bits[so.pb], C * 5 * h->words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s2));
 		HIPCHK(hipMemcpyAsync(h->h_lvl + (size_t)s * C * h->Gcap, h->d_lvl[so.lv], C * h->Gcap * sizeof(float), hipMemcpyDeviceToHost, h->s2));
 		HIPCHK(hipMemcpyAsync(h->h_ppm + (size_t)s * C * h->W, h->d_ppm[so.q], C * h->W * sizeof(float), hipMemcpyDeviceToHost, h->s2));

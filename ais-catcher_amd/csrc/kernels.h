@@ -146,7 +146,29 @@ struct K4Params {
 	int cl, n_lchunks;                       // chunk length (multiple of 32), chunks
 	// boxcar variant (k4_phase_search_box)
 	const PsBoxState* box_in; PsBoxState* box_out; long long first_group;
+	int* qflag = nullptr;                    // != nullptr (fused FIR + PhaseSearch kernel): one flag per channel quad instead of *flag
 };
+
+// K46: derotation + FilterComplex(Coherent) + ScatterPLL + PhaseSearchEMA in ONE kernel (k46_fir_phase_chunks): the FIR outputs
+// ("sym", 8 bytes per symbol and chain) never exist in HBM.  A workgroup = 5 waves = the five sampling phases of 4 adjacent
+// channels for one time chunk; per super-batch of 64 symbols it derotates the 352 samples it needs into LDS (shared by the
+// five waves), every wave filters its own phase out of them, and the PhaseSearch steps read their symbols from LDS as before.
+constexpr int K46_NB8 = 44;           // 8-sample blocks derotated per super-batch and channel (16 + 5 * 64 samples, 8-aligned, + tail)
+constexpr int K46_YPITCH = 8 * K46_NB8 + 2; // row pitch of the derotated-sample tile (float2): rows start in different banks
+struct K46Params {
+	K4Params k4;                                  // state, scratch of the chunk-parallel search, bits, chunk geometry
+	const float2* c48; long long c48_stride;
+	const float2* ck8; long long ck_stride;       // [L / 8][ck_stride]: CGF phasor BEFORE sample 8 t (renormalised at window starts)
+	const float2* step_table; const int* fz;      // fz[chan][n_windows]
+	const float2* hist_in; float2* hist_out;      // [n_chan][DF_HIST] last derotated samples of the previous / of this block
+	float* lvl; long long lvl_stride;             // [n_chan][lvl_stride]
+	float taps[17];
+	long long first_group;
+	int n_rel0, L, n_windows, n_chan;
+	int sequential;                               // exact fallback: one chunk = the whole block, runs only where k4.qflag[quad] is set
+};
+hipError_t launch_k46(const K46Params& p, hipStream_t s);
+hipError_t launch_k2b_ck8(const K2Params& p, float2* ck8, int n_chan, hipStream_t s); // phasor recurrence, state kept every 8 samples
 
 // K7: AIS::Decoder on the device (frame decoder).  One lane per decoder, 12 meshes of 5 decoders per wave.
 constexpr int DEC_DATA_WORDS = 36;  // MAX_AIS_FRAME_LENGTH = 1064 + 16 + 7 bits -> 136 bytes

@@ -563,6 +563,10 @@ __device__ __forceinline__ void wave_sync() {
 #ifndef K1_PRIO
 #define K1_PRIO 2
 #endif
+// cache policy of the input stream (aux operand of global_load_lds: 0 default, 2 = nt: read once, do not keep)
+#ifndef K1_LOAD_AUX
+#define K1_LOAD_AUX 0
+#endif
 // Register budget: three front-end waves per SIMD must leave room for one PhaseSearchEMA wave (96 VGPRs) in the
 // 512-entry file, or the two kernels evict each other instead of overlapping (HBM-bound next to VALU-bound).
 #ifndef K1_WAVES
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 #pragma unroll
 			for (int e = 0; e < NV; e++)
 				if (e >= WARM_SKIP_E || !warm)
-				__builtin_amdgcn_global_load_lds((const void*)(src + e * 64), (__attribute__((address_space(3))) void*)(xt + e * 64), 16, 0, 0);
+				__builtin_amdgcn_global_load_lds((const void*)(src + e * 64), (__attribute__((address_space(3))) void*)(xt + e * 64), 16, 0, K1_LOAD_AUX);
 		} else if constexpr (LANE_BYTES >= 16) {
 			const uint4* src = (const uint4*)base;
 #pragma unroll
@@ -2076,7 +2080,13 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 #ifndef K4_WAVES
 #define K4_WAVES 8
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K4_WAVES, K4_WAVES))) void k4_phase_chunks(K4Params p) {
+// Register budget: a SIMD that holds three front-end waves (3 x 136 VGPRs) has 104 registers left; what the PhaseSearch waves
+// are allowed decides how many of them fit into that gap (64: one, 48: two, 32: three) -- i.e. whether they run beside the
+// front end or only in the holes it leaves.
+#ifndef K4_NUM_VGPR
+#define K4_NUM_VGPR 64
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K4_WAVES, K4_WAVES))) __attribute__((amdgpu_num_vgpr(K4_NUM_VGPR))) void k4_phase_chunks(K4Params p) {
 	__shared__ __attribute__((aligned(16))) float2 stage[2][4][PS_SB_PAD];
 	const int lane = threadIdx.x;
 	const int k = lane & 15, row = lane >> 4;
@@ -2164,11 +2174,269 @@ __global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
 		}
 		ma_last = mf[AS - 1]; // only read when another batch follows, i.e. when all AS chunks of this one were live
 	}
-	if (bad) atomicOr(p.flag, 1);
+	if (bad) { if (p.qflag) atomicOr(p.qflag + chain / 20, 1); else atomicOr(p.flag, 1); }
 	const size_t last = base + (p.n_chunks - 1);
 	sto->ma[k] = p.ma_fin[last * 16 + k];
 	sto->bits[k] = fin_last >> 4;
 	if (k == 0) { sto->max_idx = start; sto->rot = (st->rot + p.n_groups) & 3; }
+}
+
+// ------------------------------------------------------------------------------------------
+// K46: derotation (DSP.cpp:457-466) + FilterComplex(Filters::Coherent) (DSP.cpp:215-246) + ScatterPLL (DSP.h:95-117) +
+// PhaseSearchEMA (Demod.cpp:39-101) in one kernel.  The pipeline is bound by HBM traffic (profiles/r02_expA.txt: every kernel
+// costs ~0.2 us per MB it moves, whatever it computes), and the FIR outputs were its largest intermediate: 126 MB written by
+// the derotation/FIR kernel, 244 MB read back by PhaseSearch, 146 MB of 48 kHz samples read to produce them.  Here they only
+// ever exist in LDS.
+//   workgroup = 5 waves = the five sampling phases of 4 adjacent channels x one time chunk of the chunk-parallel search
+//   per super-batch of 64 symbols (= 320 samples of each channel, + 16 of FIR history, 8-aligned: K46_NB8 blocks of 8):
+//     A  176 threads: one 8-sample block each -- phasor state before the block from the recurrence kernel (ck8), 8 sequential
+//        complex products, 8 derotated samples -> ytile (shared by the five waves); blocks in front of the stream block come
+//        from the previous block's tail (hist_in, already derotated), the block's last 24 go to hist_out
+//     B  wave j, lane (channel row, k): the FIR outputs of phase j for symbols k, k + 16, k + 32, k + 48 of the super-batch,
+//        17 taps left to right from 0 like the reference; |out|^2 -> normtile; (1j)^n pre-rotation; -> the wave's stage rows
+//     C  256 threads: ScatterPLL level of (channel, symbol) = ((((n0 + n1) + n2) + n3) + n4) / 5 over the five waves' norms
+//     D  every wave: the 64 PhaseSearch steps of its four chains (ps_step / ps_warm_step, as k4_phase_chunks)
+//   The loads of super-batch n + 1 are issued between B and D, so they are in flight during the steps.
+// Arithmetic per sample / symbol is exactly that of k2_cgf_phasor_ck + k3_derot_fir + k4_phase_chunks.
+// sequential != 0: the exact fallback -- one chunk = the whole block from the true state, decisions and state written
+// directly; runs only for channel quads whose flag k4_assemble raised (a speculative EMA warm-up that did not reproduce the
+// sequential values), so one receiver with an extreme level step costs one workgroup, not the batch.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ void k46_body(const K46Params& p, float2 (*ytile)[K46_YPITCH], float2 (*stage)[4][PS_SB_PAD], float (*normtile)[4][PS_SB]) {
+	const K4Params& q4 = p.k4;
+	const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+	const int k = lane & 15, row = lane >> 4, rowbase = row * 16;
+	const int quad = blockIdx.x;
+	const bool seq = p.sequential != 0;
+	const int chunk = seq ? 0 : blockIdx.y;
+	const int chan_raw = quad * 4 + row;
+	const bool live = chan_raw < p.n_chan;
+	const int chan = live ? chan_raw : p.n_chan - 1;
+	const int j = wv;                 // sampling phase of this wave
+	const int chain = chan * 5 + j;
+	const int jj = k < 8 ? k : 15 - k;
+	const float pc = c_ps_phase[jj].x;
+	const float psn = k < 8 ? c_ps_phase[jj].y : -c_ps_phase[jj].y;
+	const int g0 = seq ? 0 : chunk * PS_CHUNK;
+	const int g1 = seq ? q4.n_groups : (g0 + PS_CHUNK < q4.n_groups ? g0 + PS_CHUNK : q4.n_groups);
+	const size_t slot = (size_t)chain * q4.n_chunks + chunk;
+
+	c2 ma;
+	PsWave hs;
+	int idx = k; // trajectory that starts at max_idx == k
+	int start = g0;
+	const EmaState* st_in = q4.state_in + chain;
+	const int start_idx0 = st_in->max_idx;
+	if (chunk == 0) { // the true state
+		ma = c2{ st_in->ma[k], st_in->ma[k] };
+		const unsigned bits = st_in->bits[k];
+		hs.h1 = __ballot((bits & 1u) != 0); hs.h2 = __ballot((bits & 2u) != 0);
+		hs.h3 = __ballot((bits & 4u) != 0); hs.h4 = __ballot((bits & 8u) != 0);
+	} else { // speculative: replay the `warm` symbols in front of the chunk from zero
+		ma = c2{ 0.0f, 0.0f };
+		hs.h1 = hs.h2 = hs.h3 = hs.h4 = 0;
+		start = g0 - q4.warm;
+	}
+	const int nsb = (g1 - start + PS_SB - 1) / PS_SB;
+	const bool last_chunk = seq || chunk == q4.n_chunks - 1;
+
+	// ---- phase A item of this thread: (channel a_r of the quad, 8-sample block a_t of the super-batch's range)
+	const int a_r = tid & 3, a_t = tid >> 2;
+	const bool a_on = tid < 4 * K46_NB8;
+	const bool a_live = quad * 4 + a_r < p.n_chan;
+	const int a_chan = a_live ? quad * 4 + a_r : p.n_chan - 1;
+	float4 d[4];
+	float2 ckv = make_float2(1.0f, 0.0f), stp = make_float2(1.0f, 0.0f);
+	int a_n8 = 0; // block-relative index of the first sample of the item's block in the super-batch being fetched
+	const auto range_base8 = [&](int sb) { return (p.n_rel0 + 5 * (start + sb * PS_SB) - 16) >> 3; }; // floor: the range can start in the previous block
+	const auto fetch = [&](int sb) {
+		if (!a_on) return;
+		const int t = range_base8(sb) + a_t;
+		a_n8 = 8 * t;
+		if (t < 0) { // the previous block's tail, already derotated
+			const float4* hsrc = reinterpret_cast<const float4*>(p.hist_in + (size_t)a_chan * DF_HIST + (DF_HIST + a_n8));
+#pragma unroll
+			for (int e = 0; e < 4; e++) d[e] = hsrc[e];
+		} else if (a_n8 < p.L) {
+			const float4* src = reinterpret_cast<const float4*>(p.c48 + (size_t)a_chan * p.c48_stride + a_n8);
+#pragma unroll
+			for (int e = 0; e < 4; e++) d[e] = src[e];
+			ckv = p.ck8[(size_t)t * p.ck_stride + a_chan];
+			stp = p.step_table[p.fz[(size_t)a_chan * p.n_windows + (a_n8 >> 9)] + 205];
+		}
+	};
+	const auto derotate_store = [&](int sb) {
+		if (!a_on) return;
+		c2 y[8];
+		if (a_n8 < 0 || a_n8 >= p.L) {
+#pragma unroll
+			for (int e = 0; e < 4; e++) { y[2 * e] = c2{ d[e].x, d[e].y }; y[2 * e + 1] = c2{ d[e].z, d[e].w }; }
+		} else {
+			c2 rot = { ckv.x, ckv.y };
+			const c2 st = { stp.x, stp.y }, st_sw = { -stp.y, stp.x };
+#pragma unroll
+			for (int e = 0; e < 8; e++) {
+				const float dx = (e & 1) ? d[e >> 1].z : d[e >> 1].x, dy = (e & 1) ? d[e >> 1].w : d[e >> 1].y;
+				rot = rot.xx * st + rot.yy * st_sw;             // rot *= rot_step (DSP.cpp:462)
+				y[e] = pk_sub_add(rot * dx, rot.yx * dy);       // output[i] *= rot (DSP.cpp:463)
+			}
+			if (last_chunk && sb == nsb - 1 && a_live && a_n8 >= p.L - DF_HIST) { // the next block's history
+				float4* hdst = reinterpret_cast<float4*>(p.hist_out + (size_t)a_chan * DF_HIST + (a_n8 - (p.L - DF_HIST)));
+#pragma unroll
+				for (int e = 0; e < 4; e++) hdst[e] = make_float4(y[2 * e].x, y[2 * e].y, y[2 * e + 1].x, y[2 * e + 1].y);
+			}
+		}
+		float4* dst = reinterpret_cast<float4*>(&ytile[a_r][8 * a_t]);
+#pragma unroll
+		for (int e = 0; e < 4; e++) dst[e] = make_float4(y[2 * e].x, y[2 * e].y, y[2 * e + 1].x, y[2 * e + 1].y);
+	};
+
+	uint32_t* wout = q4.words + slot * (PS_CHUNK / 32) * 16 + k;
+	uint32_t* bout = q4.bits + (size_t)chain * q4.bits_stride;
+	const bool seq_writer = seq && live && k == start_idx0;
+	uint32_t word = 0;
+	fetch(0);
+#pragma unroll 1
+	for (int sb = 0; sb < nsb; sb++) {
+		const int S0 = start + sb * PS_SB;
+		const int base8 = range_base8(sb);
+		derotate_store(sb);                                  // A
+		__syncthreads();
+		const bool proper = S0 + PS_SB > g0;                 // the super-batch holds symbols of the chunk itself (not only warm-up)
+		{                                                    // B
+			const float2* yrow = &ytile[row][0];
+#pragma unroll
+			for (int i = 0; i < PS_SB / 16; i++) {
+				const int si = k + 16 * i, sidx = S0 + si;
+				const float2* yp = yrow + (p.n_rel0 + 5 * sidx + j - 16 - 8 * base8);
+				c2 acc = { 0.0f, 0.0f };
+#pragma unroll
+				for (int m = 0; m < 17; m++) { const float2 v = yp[m]; acc = acc + c2{ v.x, v.y } * p.taps[m]; } // DSP.h:224-230
+				if (proper) normtile[wv][row][si] = acc.x * acc.x + acc.y * acc.y; // std::norm
+				// PhaseSearchEMA multiplies symbol n of a chain by (1j)^(n & 3) with swaps / negations (Demod.cpp:44-61)
+				const int rsel = (int)((p.first_group + sidx) & 3);
+				c2 sv = (rsel & 1) ? acc.yx : acc;
+				if (rsel == 1 || rsel == 2) sv.x = -sv.x;
+				if (rsel >= 2) sv.y = -sv.y;
+				stage[wv][row][si] = make_float2(sv.x, sv.y);
+			}
+		}
+		if (sb + 1 < nsb) fetch(sb + 1);                     // in flight during the steps
+		__syncthreads();
+		if (proper && tid < 4 * PS_SB) {                     // C: ScatterPLL level (DSP.h:101-106)
+			const int r = tid >> 6, si = tid & 63, sidx = S0 + si;
+			if (sidx >= g0 && sidx < g1 && quad * 4 + r < p.n_chan) {
+				float level = 0.0f;
+#pragma unroll
+				for (int ph = 0; ph < 5; ph++) level = level + normtile[ph][r][si];
+				p.lvl[(size_t)(quad * 4 + r) * p.lvl_stride + sidx] = __fdiv_rn(level, 5.0f);
+			}
+		}
+#pragma unroll 1
+		for (int s8 = 0; s8 < PS_SB; s8 += PS_BATCH) {       // D
+			const int g = S0 + s8;
+			if (g >= g1) break;
+			float2 v[PS_BATCH];
+			{
+				const float4* src = reinterpret_cast<const float4*>(&stage[wv][row][s8]);
+#pragma unroll
+				for (int e = 0; e < PS_BATCH; e += 2) { const float4 t = src[e >> 1]; v[e] = make_float2(t.x, t.y); v[e + 1] = make_float2(t.z, t.w); }
+			}
+			if (g < g0) { // warm-up: EMA and decision history only
+#pragma unroll
+				for (int e = 0; e < PS_BATCH; e++) ps_warm_step<MODE>(v[e], pc, psn, ma, hs);
+				if (g + PS_BATCH == g0 && live) q4.ma_start[slot * 16 + k] = ma.y;
+			} else {
+				const int q = g - g0;
+				uint32_t part = 0;
+				if (g + PS_BATCH <= g1) {
+#pragma unroll
+					for (int e = 0; e < PS_BATCH; e++) part |= ps_step<MODE>(v[e], pc, psn, ma, hs, idx, k, rowbase) << e;
+				} else {
+#pragma unroll
+					for (int e = 0; e < PS_BATCH; e++)
+						if (g + e < g1) part |= ps_step<MODE>(v[e], pc, psn, ma, hs, idx, k, rowbase) << e; // wave-uniform
+				}
+				word |= part << (q & 31);
+				if (((q + PS_BATCH) & 31) == 0 && g + PS_BATCH <= g1) {
+					if (seq) { if (seq_writer) bout[q >> 5] = word; }
+					else if (live) wout[(q >> 5) * 16] = word;
+					word = 0;
+				}
+			}
+		}
+		// (the next iteration's derotate_store overwrites ytile: every wave has passed the second barrier, i.e. finished B)
+	}
+	const int n = g1 - g0;
+	if ((n & 31) != 0) {
+		if (seq) { if (seq_writer) bout[n >> 5] = word; }
+		else if (live) wout[(n >> 5) * 16] = word;
+	}
+	if (live) {
+		const unsigned dec = (unsigned)((hs.h1 >> lane) & 1ull) | ((unsigned)((hs.h2 >> lane) & 1ull) << 1) |
+		                     ((unsigned)((hs.h3 >> lane) & 1ull) << 2) | ((unsigned)((hs.h4 >> lane) & 1ull) << 3);
+		if (seq) {
+			EmaState* sto = q4.state_out + chain;
+			sto->ma[k] = ma.y;
+			sto->bits[k] = dec;
+			if (k == start_idx0) { sto->max_idx = idx; sto->rot = (st_in->rot + q4.n_groups) & 3; }
+		} else {
+			q4.ma_fin[slot * 16 + k] = ma.y;
+			q4.fin[slot * 16 + k] = (unsigned)idx | (dec << 4);
+		}
+	}
+}
+
+__global__ __launch_bounds__(320) void k46_fir_phase_chunks(K46Params p) {
+	__shared__ __attribute__((aligned(16))) float2 ytile[4][K46_YPITCH];
+	__shared__ __attribute__((aligned(16))) float2 stage[5][4][PS_SB_PAD];
+	__shared__ float normtile[5][4][PS_SB];
+	if (p.sequential) { // exact fallback, only where the verification of a speculative warm-up failed
+		if (p.k4.qflag[blockIdx.x] == 0) return; // (workgroup-uniform, in front of every barrier)
+	}
+	if (p.k4.prio == 1) __builtin_amdgcn_s_setprio(1);
+	else if (p.k4.prio == 2) __builtin_amdgcn_s_setprio(2);
+	else if (p.k4.prio == 3) __builtin_amdgcn_s_setprio(3);
+	const int k = threadIdx.x & 15;
+	const int src = __builtin_amdgcn_update_dpp(0, k, 0x121, 0xF, 0xF, false);
+	const bool all_left = __all(src == ((k + 15) & 15)), all_right = __all(src == ((k + 1) & 15));
+	// (the probe's outcome is a property of the hardware: the same in all five waves, so the barriers inside stay aligned)
+	if (all_left) k46_body<0>(p, ytile, stage, normtile);
+	else if (all_right) k46_body<1>(p, ytile, stage, normtile);
+	else k46_body<2>(p, ytile, stage, normtile);
+	if (p.sequential) {
+		__syncthreads();
+		if (threadIdx.x == 0) p.k4.qflag[blockIdx.x] = 0; // consumed
+	}
+}
+
+// the CGF phasor recurrence (as k2_cgf_phasor_ck) keeping its state in front of every 8th sample: what K46's derotation starts from
+__global__ __launch_bounds__(64) void k2_cgf_phasor_ck8(K2Params p, float2* ck8) {
+	const int lane = threadIdx.x;
+	const int chan_raw = blockIdx.x * 64 + lane;
+	const bool live = chan_raw < p.n_chan;
+	const int chan = live ? chan_raw : p.n_chan - 1;
+	__builtin_amdgcn_s_setprio(3);
+	const float2 r0 = p.rot_state[chan];
+	v2f cur = { r0.x, r0.y };
+	float2* o = ck8 + (size_t)blockIdx.x * 64 + lane; // padded columns exist for dead lanes
+	for (int w = 0; w < p.n_windows; w++) {
+		const int fz = p.fz[(size_t)chan * p.n_windows + w];
+		const float2 stp = p.step_table[fz + 205];
+		const v2f st = { stp.x, stp.y }, st_sw = { -stp.y, stp.x };
+#pragma unroll 2
+		for (int b = 0; b < 64; b++) {
+			*o = make_float2(cur.x, cur.y);
+			o += p.ck_stride;
+#pragma unroll
+			for (int e = 0; e < 8; e++) cur = cur.xx * st + cur.yy * st_sw; // rot *= rot_step
+		}
+		const float a = hypot_ref(cur.x, cur.y); // rot /= std::abs(rot), once per window (DSP.cpp:465)
+		cur.x = __fdiv_rn(cur.x, a);
+		cur.y = __fdiv_rn(cur.y, a);
+	}
+	if (live) p.rot_state[chan] = make_float2(cur.x, cur.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3393,6 +3661,20 @@ hipError_t launch_k4(const K4Params& p, hipStream_t s) {
 	hipLaunchKernelGGL(k4_phase_chunks, dim3((p.n_chains / 5 + 3) / 4 * 5, p.n_chunks), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(k4_assemble, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(k4_phase_search, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p, 1); // exits at once unless flagged
+	return hipGetLastError();
+}
+
+hipError_t launch_k46(const K46Params& p, hipStream_t s) {
+	const int n_quads = (p.n_chan + 3) / 4;
+	hipLaunchKernelGGL(k46_fir_phase_chunks, dim3(n_quads, p.k4.n_chunks), dim3(320), 0, s, p);
+	hipLaunchKernelGGL(k4_assemble, dim3((p.k4.n_chains + 3) / 4), dim3(64), 0, s, p.k4);
+	K46Params f = p;
+	f.sequential = 1;
+	hipLaunchKernelGGL(k46_fir_phase_chunks, dim3(n_quads, 1), dim3(320), 0, s, f); // exits at once unless flagged
+	return hipGetLastError();
+}
+hipError_t launch_k2b_ck8(const K2Params& p, float2* ck8, int n_chan, hipStream_t s) {
+	hipLaunchKernelGGL(k2_cgf_phasor_ck8, dim3((n_chan + 63) / 64), dim3(64), 0, s, p, ck8);
 	return hipGetLastError();
 }
 

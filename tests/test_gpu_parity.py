@@ -1109,3 +1109,33 @@ def test_reference_binding_compiled_against_the_real_reference(gpu_model, cpu_mo
         m.close()
     assert out[0][0] == out[1][0] and len(out[0][0]) >= 3
     assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])  # tag.level, tag.ppm per message
+
+
+@pytest.mark.parametrize("env", [{"AISGPU_PS_WARM": "16"}, {"AISGPU_PS_WARM": "64"}, {"AISGPU_K46": "0"}, {"AISGPU_K46": "0", "AISGPU_PS_WARM": "16"},
+                                 {"AISGPU_SERIAL": "1"}, {"AISGPU_PS_SEQUENTIAL": "1"}, {"AISGPU_K4": "lane"}])
+def test_fused_fir_phase_search_kernel_and_its_exact_fallback(env, monkeypatch):
+    """The default back end derotates, filters and searches in ONE kernel (k46_fir_phase_chunks: the FIR outputs never leave LDS).
+    With a 16- or 64-symbol warm-up the speculative EMA start of every chunk is wrong, the verification flags every channel
+    quad, and the kernel's sequential mode must recompute them exactly; AISGPU_K46=0 is the two-kernel form (derotation / FIR
+    into HBM, then PhaseSearch), also with its own fallback; plus the single-stream schedule and the other search variants.
+    5 receivers: 10 channels = two full quads and one half-empty quad."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    xs = [synth.receiver_stream(786432 * 2, receiver_id=210 + r, gap_slots=(0, 2)) for r in range(5)]
+    _run_outputs_vs_oracle(xs, 1536000, "cf32", 786432, 2)
+    _run_outputs_vs_oracle(xs[:2], 1536000, "cf32", 98304, 5)   # 614 / 615 groups per block: one chunk, group phase rotating
+
+
+def test_extreme_receiver_only_costs_its_own_quad():
+    """A level step of many decades in ONE receiver defeats the speculative warm-up of its chains (the EMA needs more than 256
+    symbols to forget): only that receiver's channel quad goes through the sequential fallback; everybody's outputs stay exact."""
+    block, nblocks, R = 786432, 2, 6
+    xs = [synth.receiver_stream(block * nblocks, receiver_id=220 + r, gap_slots=(0, 2)) for r in range(R)]
+    rng = np.random.default_rng(5)
+    wild = (rng.standard_normal(block * nblocks) + 1j * rng.standard_normal(block * nblocks)).astype(np.complex64)
+    wild[:block // 2] *= np.float32(3e4)
+    wild[block // 2:block] *= np.float32(1e-18)
+    wild[block:block + block // 3] *= np.float32(1e3)
+    wild[block + block // 3:] *= np.float32(1e-12)
+    xs[3] = wild
+    _run_outputs_vs_oracle(xs, 1536000, "cf32", block, nblocks)
