@@ -183,6 +183,8 @@ struct aisgpu {
 	bool defer_fused = false; // spectral analysis on s4, second half of a block one block later
 	struct { bool valid = false; int q = 0, pb = 0, lv = 0, n_groups = 0, n_rel0 = 0, S = 0; long long g0 = 0; unsigned block = 0, sub = 0; } fpend;
 	float2 *d_ck[NBUF] = {}, *d_ckw[NBUF] = {}, *d_dfhist[2] = {};
+	int ps_streams = 1; // row sets per wave of the chunk-parallel PhaseSearch kernel (AISGPU_K4_STREAMS=2: k4_phase_chunks2, measured 0.53 against 0.50 ms per step)
+	int* d_qflag4 = nullptr; // [2][n_chains / 4] fallback flags of the row PhaseSearch kernels
 	bool k46 = false; float2* d_ck8[NBUF] = {}; int* d_qflag = nullptr; int n_quads = 0; // FIR + PhaseSearch in one kernel (no FIR outputs in HBM)
 	// per-kernel geometry
 	int tile_in = 0, tiles_per_block = 0, tiles_per_span = 0, spans = 0;         // fused front end (its own input)
@@ -400,6 +402,8 @@ int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned
 	k4.lw = h->d_pslw[pb]; k4.lw_quads = h->Gcap / 4; k4.prio = h->ps_prio; k4.prio_walk = h->walk_prio; k4.ma_stride = (h->n_chains + 63) / 64 * 64;
 	k4.cl = h->ps_cl; k4.n_lchunks = (n_groups + h->ps_cl - 1) / h->ps_cl;
 	k4.box_in = h->d_box[pb]; k4.box_out = h->d_box[pb ^ 1]; k4.first_group = g0;
+	k4.streams = h->ps_streams;
+	if (h->d_qflag4 && !h->ps_lane) { k4.qflag = h->d_qflag4 + (size_t)pb * ((h->n_chains + 3) / 4); k4.qflag_div = 4; } // per-workgroup fallback flags
 	if (!h->ps_box && h->ps_parallel && h->ps_lane && k4.n_lchunks > 1) {
 		// (a) sign words of this block, one lane per (chain, chunk), and their verification; (b) the walk over them: one lane
 		// per chain, ~5000 dependent steps, 40 waves for 256 receivers -- pure latency.  It rides along with the NEXT
@@ -530,7 +534,7 @@ int enqueue_k46(aisgpu_t* h, int q, int pb, int lv, long long g0, int n_groups, 
 	k4.sym = nullptr; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[pb]; k4.bits_stride = h->words;
 	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
 	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag + pb;
-	k4.qflag = h->d_qflag + (size_t)pb * h->n_quads;
+	k4.qflag = h->d_qflag + (size_t)pb * h->n_quads; k4.qflag_div = 20;
 	k4.n_chains = h->n_chains; k4.n_groups = n_groups;
 	k4.n_chunks = (n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm; k4.prio = h->ps_prio;
 	k4.first_group = g0;
@@ -1109,8 +1113,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	}
 	// derotation + FIR + PhaseSearchEMA as ONE kernel (the FIR outputs stay in LDS): the default of the fused back end for the
 	// chunk-parallel row search; AISGPU_K46=0 keeps the two-kernel form (which the boxcar / lane / sequential variants use)
-	h->k46 = h->fused && !h->ps_box;
-	if (const char* e = getenv("AISGPU_K46")) h->k46 = h->k46 && atoi(e) != 0;
+	h->k46 = false; // (measured 0.71 against 0.51 ms per step: its 112 registers find no room next to the front end's waves -- DESIGN.md)
+	if (const char* e = getenv("AISGPU_K46")) h->k46 = h->fused && !h->ps_box && atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_K4")) if (strcmp(e, "lane") == 0) h->k46 = false;
 	if (getenv("AISGPU_PS_SEQUENTIAL")) h->k46 = false;
 	if (h->fused) {
@@ -1160,6 +1164,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	// get a quarter of the issue slots next to the front end -- measured 0.68 against 0.62 ms per step)
 	if (const char* e = getenv("AISGPU_K4")) h->ps_lane = strcmp(e, "lane") == 0;
 	if (const char* e = getenv("AISGPU_PS_PRIO")) h->ps_prio = atoi(e);
+	if (const char* e = getenv("AISGPU_K4_STREAMS")) h->ps_streams = atoi(e) == 2 ? 2 : 1;
 	if (const char* e = getenv("AISGPU_WALK_PRIO")) h->walk_prio = atoi(e);
 	if (const char* e = getenv("AISGPU_WALK_RIDE")) h->walk_ride = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_PS_CL")) { int v = atoi(e); if (v >= 128 && v <= 8192) h->ps_cl = (v + 31) / 32 * 32; }
@@ -1174,6 +1179,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	HIPCHK(dalloc(&h->d_psma1, n_ma));
 	HIPCHK(dalloc(&h->d_psfin, C * 5 * ps_chunks * 16));
 	HIPCHK(dalloc(&h->d_psflag, 4));
+	if (!getenv("AISGPU_PS_GLOBAL_FLAG")) HIPCHK(dalloc(&h->d_qflag4, 2 * (size_t)((C * 5 + 3) / 4)));
 	if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_firtap, C * (8 + h->L)));
 	if (h->v2) HIPCHK(hipHostMalloc((void**)&h->h_c48, MAXSUB * C * h->L * sizeof(float2), hipHostMallocDefault));
 	HIPCHK(hipHostMalloc((void**)&h->h_bits, MAXSUB * C * 5 * h->words * sizeof(uint32_t), hipHostMallocDefault));
@@ -1219,7 +1225,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	if (h->h_fmbits) hipHostFree(h->h_fmbits);
 	if (h->h_c48) hipHostFree(h->h_c48);
 	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); hipFree(h->d_ckw[i]); hipFree(h->d_ck8[i]); }
-	hipFree(h->d_qflag);
+	hipFree(h->d_qflag); hipFree(h->d_qflag4);
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
 	hipFree(h->d_box[0]); hipFree(h->d_box[1]);
 	hipFree(h->d_dec); hipFree(h->d_frames); hipFree(h->d_frame_count);

@@ -138,6 +138,7 @@ struct K4Params {
 	unsigned* fin;     // [16] low 4 bits: final max_idx per start index; bits 4..7: last four decisions of hypothesis k
 	int* flag;         // != 0: a speculative warm-up did not reproduce the sequential EMA -> exact fallback runs
 	int n_chains, n_groups, n_chunks, warm;
+	int streams = 1;   // 2: k4_phase_chunks2 (two channel quads per wave)
 	// lane-per-chunk variant (k4_lane_chunks + k4_walk): sign words per symbol, EMA snapshots laid out [chunk][k][ma_stride]
 	uint2* lw;                               // three planes (up, dn, x) of uint4 [lw_quads][ma_stride]: four consecutive symbols of a chain
 	int prio_walk;
@@ -146,7 +147,8 @@ struct K4Params {
 	int cl, n_lchunks;                       // chunk length (multiple of 32), chunks
 	// boxcar variant (k4_phase_search_box)
 	const PsBoxState* box_in; PsBoxState* box_out; long long first_group;
-	int* qflag = nullptr;                    // != nullptr (fused FIR + PhaseSearch kernel): one flag per channel quad instead of *flag
+	int* qflag = nullptr;                    // != nullptr: one flag per qflag_div chains instead of the batch-global *flag, so that the
+	int qflag_div = 4;                       // exact fallback re-runs only those (4: the chains of one k4_phase_search workgroup; 20: one channel quad of K46)
 };
 
 // K46: derotation + FilterComplex(Coherent) + ScatterPLL + PhaseSearchEMA in ONE kernel (k46_fir_phase_chunks): the FIR outputs

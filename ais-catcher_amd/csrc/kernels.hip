@@ -18,6 +18,10 @@ namespace aisk {
 // small helpers
 // ------------------------------------------------------------------------------------------
 typedef float c2 __attribute__((ext_vector_type(2))); // complex sample as a native 2-vector (one VGPR pair)
+typedef float c4 __attribute__((ext_vector_type(4)));
+// streamed once: loads / stores with the non-temporal hint (the builtins want native vector types)
+__device__ __forceinline__ float2 nt_load(const float2* p) { const c2 v = __builtin_nontemporal_load(reinterpret_cast<const c2*>(p)); return make_float2(v.x, v.y); }
+__device__ __forceinline__ void nt_store(float4 v, float4* p) { __builtin_nontemporal_store(c4{ v.x, v.y, v.z, v.w }, reinterpret_cast<c4*>(p)); }
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -563,9 +567,11 @@ __device__ __forceinline__ void wave_sync() {
 #ifndef K1_PRIO
 #define K1_PRIO 2
 #endif
-// cache policy of the input stream (aux operand of global_load_lds: 0 default, 2 = nt: read once, do not keep)
+// cache policy of the input stream (aux operand of global_load_lds: 0 default, 2 = nt: read once, do not keep).  nt: the kernel
+// alone 3 % faster, the step 0-3 % depending on the box (profiles/r02_expF.txt, r02_expG.txt); the SAME hint on the
+// intermediates (FIR outputs, 48 kHz channels) costs 5-10 %: their consumers do find them in L2 / Infinity Cache
 #ifndef K1_LOAD_AUX
-#define K1_LOAD_AUX 0
+#define K1_LOAD_AUX 2
 #endif
 // Register budget: three front-end waves per SIMD must leave room for one PhaseSearchEMA wave (96 VGPRs) in the
 // 512-entry file, or the two kernels evict each other instead of overlapping (HBM-bound next to VALU-bound).
@@ -1609,7 +1615,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6
 			float2 d[20];
 			const float2* xb = p.c48 + n;
 #pragma unroll
+#ifdef K6_NT
+			for (int m = 0; m < 20; m++) d[m] = nt_load(&(xb + m)[xoff]);
+#else
 			for (int m = 0; m < 20; m++) d[m] = (xb + m)[xoff];
+#endif
 			body([&](int m) { return derotate(d[m]); });
 		} else {
 			body([&](int m) { return next_sample(n + m); });
@@ -1620,7 +1630,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6
 				for (int j = 0; j < 5; j++) { // lane = channel: each store is 64 x 16 B contiguous (SymRow layout, kernels.h)
 					float4* dst = reinterpret_cast<float4*>(p.sym + sym_row_base(chain, j, p.sym_stride) + (size_t)(g >> 1) * SYM_PAIR);
 #pragma unroll
+#ifdef K6_NT
+					for (int q = 0; q < 2; q++) nt_store(make_float4(out[j][2 * q].x, out[j][2 * q].y, out[j][2 * q + 1].x, out[j][2 * q + 1].y), &dst[q * (SYM_PAIR / 2)]);
+#else
 					for (int q = 0; q < 2; q++) dst[q * (SYM_PAIR / 2)] = make_float4(out[j][2 * q].x, out[j][2 * q].y, out[j][2 * q + 1].x, out[j][2 * q + 1].y);
+#endif
 				}
 				*reinterpret_cast<float4*>(p.lvl + (size_t)chain * p.sym_stride + g) = make_float4(lv[0], lv[1], lv[2], lv[3]);
 			} else {
@@ -1796,7 +1810,10 @@ __device__ __forceinline__ unsigned ps_step(float2 v, float pc, float psn, c2& M
 	return (unsigned)(X >> (rowbase + idx)) & 1u;
 }
 
-constexpr int PS_BATCH = 8;  // symbols whose samples are fetched together
+#ifndef PS_BATCH_
+#define PS_BATCH_ 8
+#endif
+constexpr int PS_BATCH = PS_BATCH_;  // symbols whose samples are fetched together (8; 4 with a tighter register budget)
 
 template <int MODE>
 __device__ __forceinline__ void ps_chain(const SymRow x, uint32_t* __restrict__ out, int n, bool writer, float pc,
@@ -1838,7 +1855,12 @@ __device__ __forceinline__ void ps_chain(const SymRow x, uint32_t* __restrict__ 
 // Sequential reference kernel: one pass over the whole block per chain.  Used as the exact fallback of the
 // chunk-parallel path (runs only when p.flag is set) and on its own for small batches.
 __global__ __launch_bounds__(64) void k4_phase_search(K4Params p, int conditional) {
-	if (conditional && *p.flag == 0) return;
+	if (conditional) { // exact fallback: only where k4_assemble found a speculative warm-up that did not reproduce the sequential EMA
+		if (p.qflag) { // per workgroup (its four chains): one receiver with an extreme level step does not cost the whole batch
+			if (p.qflag[blockIdx.x] == 0) return; // (one wave: the branch has consumed every lane's load before the store below)
+			if (threadIdx.x == 0) p.qflag[blockIdx.x] = 0;
+		} else if (*p.flag == 0) return;
+	}
 	const int lane = threadIdx.x;
 	const int k = lane & 15, row = lane >> 4;
 	const int chain = blockIdx.x * 4 + row; // (rx*2 + ch) * 5 + j
@@ -2010,7 +2032,11 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 		for (int q = 0; q < PS_SB / 16; q++) {
 			int i = start + sb * PS_SB + q * 16 + k;
 			i = i < last_i ? i : last_i; // (past the chunk's end: any readable sample, it is never used)
+#ifdef K4_NT
+			r[q] = nt_load(&x.base[(size_t)(i >> 1) * SYM_PAIR + (i & 1)]); // read once
+#else
 			r[q] = x[i];
+#endif
 		}
 	};
 	const auto stash = [&](int buf) {
@@ -2108,6 +2134,169 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K4_WAVES, K4
 	else ps_chunk_body<2>(p, chain, chunk, live, k, rowbase, lane, stage);
 }
 
+// ------------------------------------------------------------------------------------------
+// k4_phase_chunks2: the same chunk kernel with TWO independent row sets per wave -- the quads of channels 8q .. 8q+3 and
+// 8q+4 .. 8q+7, same sampling phase, same chunk -- whose steps are interleaved instruction by instruction.
+//  * a SIMD that holds three front-end waves has 104 registers left: room for ONE PhaseSearch wave of 64 (or of 96) registers,
+//    and a lone wave of dependent steps (ballot -> scalar -> shift -> add chains) leaves most issue slots unused; two
+//    independent streams in that one wave fill them (same residency, twice the work per resident wave);
+//  * the FIR outputs of 8 adjacent channels are one whole 128-byte line of the SymRow layout: with one quad per wave every
+//    line was fetched twice, half used each time (244 MB read for 126 MB of data, profiles/r02_v1_pmc_traffic_all_kernels.txt).
+// State, scratch layout and results are exactly k4_phase_chunks' (k4_assemble and the fallback do not know the difference).
+// ------------------------------------------------------------------------------------------
+constexpr int PS_BATCH2 = 4; // symbols per inner batch of the two-stream kernel (two streams' samples in registers at once)
+template <int MODE>
+__device__ __forceinline__ void ps_chunk_body2(const K4Params& p, const int (&chain)[2], const bool (&live)[2], int chunk, int k, int rowbase, int lane,
+                                               float2 (*stage)[2][4][PS_SB_PAD]) {
+	const int jj = k < 8 ? k : 15 - k;
+	const float pc = c_ps_phase[jj].x;
+	const float psn = k < 8 ? c_ps_phase[jj].y : -c_ps_phase[jj].y;
+	const SymRow x[2] = { SymRow(p.sym, chain[0], p.sym_stride), SymRow(p.sym, chain[1], p.sym_stride) };
+	const int g0 = chunk * PS_CHUNK;
+	const int g1 = g0 + PS_CHUNK < p.n_groups ? g0 + PS_CHUNK : p.n_groups;
+	const size_t slot[2] = { (size_t)chain[0] * p.n_chunks + chunk, (size_t)chain[1] * p.n_chunks + chunk };
+	const int row = rowbase >> 4;
+
+	c2 ma[2];
+	PsWave hs[2];
+	int idx[2] = { k, k }; // trajectories that start at max_idx == k
+	int start = g0;
+#pragma unroll
+	for (int s = 0; s < 2; s++) {
+		if (chunk == 0) { // the true state
+			const EmaState* st = p.state_in + chain[s];
+			ma[s] = c2{ st->ma[k], st->ma[k] };
+			const unsigned bits = st->bits[k];
+			hs[s].h1 = __ballot((bits & 1u) != 0); hs[s].h2 = __ballot((bits & 2u) != 0);
+			hs[s].h3 = __ballot((bits & 4u) != 0); hs[s].h4 = __ballot((bits & 8u) != 0);
+		} else { // speculative: replay the `warm` symbols in front of the chunk from zero
+			ma[s] = c2{ 0.0f, 0.0f };
+			hs[s].h1 = hs[s].h2 = hs[s].h3 = hs[s].h4 = 0;
+		}
+	}
+	if (chunk != 0) start = g0 - p.warm;
+	const int last_i = (int)p.sym_stride - 1;
+	float2 r[2][PS_SB / 16];
+	const auto fetch = [&](int sb) {
+#pragma unroll
+		for (int q = 0; q < PS_SB / 16; q++) {
+			int i = start + sb * PS_SB + q * 16 + k;
+			i = i < last_i ? i : last_i; // (past the chunk's end: any readable sample, it is never used)
+			r[0][q] = x[0][i]; // the two quads' symbols are the two halves of one 128-byte line
+			r[1][q] = x[1][i];
+		}
+	};
+	const auto stash = [&](int buf) {
+#pragma unroll
+		for (int s = 0; s < 2; s++)
+#pragma unroll
+			for (int q = 0; q < PS_SB / 16; q++) stage[s][buf][row][q * 16 + k] = r[s][q];
+	};
+	const int nsb = (g1 - start + PS_SB - 1) / PS_SB;
+	fetch(0);
+	stash(0);
+	if (nsb > 1) fetch(1);
+
+	uint32_t* wout[2] = { p.words + slot[0] * (PS_CHUNK / 32) * 16 + k, p.words + slot[1] * (PS_CHUNK / 32) * 16 + k };
+	uint32_t word[2] = { 0, 0 };
+#pragma unroll 1
+	for (int sb = 0; sb < nsb; sb++) {
+		const int buf = sb & 1;
+		wave_sync(); // the tiles written by this wave's own stash() are read below (one-wave workgroup: ordering only)
+#pragma unroll 1
+		for (int s8 = 0; s8 < PS_SB; s8 += PS_BATCH2) {
+			const int g = start + sb * PS_SB + s8;
+			if (g >= g1) break;
+			float2 v[2][PS_BATCH2];
+#pragma unroll
+			for (int s = 0; s < 2; s++) {
+				const float4* src = reinterpret_cast<const float4*>(&stage[s][buf][row][s8]);
+#pragma unroll
+				for (int e = 0; e < PS_BATCH2; e += 2) { const float4 t = src[e >> 1]; v[s][e] = make_float2(t.x, t.y); v[s][e + 1] = make_float2(t.z, t.w); }
+			}
+			if (g < g0) { // warm-up: EMA and decision history only
+#pragma unroll
+				for (int e = 0; e < PS_BATCH2; e++) {
+					ps_warm_step<MODE>(v[0][e], pc, psn, ma[0], hs[0]);
+					ps_warm_step<MODE>(v[1][e], pc, psn, ma[1], hs[1]);
+				}
+				if (g + PS_BATCH2 == g0) {
+					if (live[0]) p.ma_start[slot[0] * 16 + k] = ma[0].y;
+					if (live[1]) p.ma_start[slot[1] * 16 + k] = ma[1].y;
+				}
+			} else {
+				const int q = g - g0;
+				uint32_t part[2] = { 0, 0 };
+				if (g + PS_BATCH2 <= g1) {
+#pragma unroll
+					for (int e = 0; e < PS_BATCH2; e++) {
+						part[0] |= ps_step<MODE>(v[0][e], pc, psn, ma[0], hs[0], idx[0], k, rowbase) << e;
+						part[1] |= ps_step<MODE>(v[1][e], pc, psn, ma[1], hs[1], idx[1], k, rowbase) << e;
+					}
+				} else {
+#pragma unroll
+					for (int e = 0; e < PS_BATCH2; e++)
+						if (g + e < g1) { // wave-uniform
+							part[0] |= ps_step<MODE>(v[0][e], pc, psn, ma[0], hs[0], idx[0], k, rowbase) << e;
+							part[1] |= ps_step<MODE>(v[1][e], pc, psn, ma[1], hs[1], idx[1], k, rowbase) << e;
+						}
+				}
+				word[0] |= part[0] << (q & 31);
+				word[1] |= part[1] << (q & 31);
+				if (((q + PS_BATCH2) & 31) == 0 && g + PS_BATCH2 <= g1) {
+					if (live[0]) wout[0][(q >> 5) * 16] = word[0];
+					if (live[1]) wout[1][(q >> 5) * 16] = word[1];
+					word[0] = word[1] = 0;
+				}
+			}
+		}
+		if (sb + 1 < nsb) {
+			stash(buf ^ 1);                  // super-batch sb + 1 has been in flight for one super-batch of work
+			if (sb + 2 < nsb) fetch(sb + 2);
+		}
+	}
+	const int n = g1 - g0;
+#pragma unroll
+	for (int s = 0; s < 2; s++) {
+		if ((n & 31) != 0 && live[s]) wout[s][(n >> 5) * 16] = word[s];
+		if (live[s]) {
+			p.ma_fin[slot[s] * 16 + k] = ma[s].y;
+			const unsigned dec = (unsigned)((hs[s].h1 >> lane) & 1ull) | ((unsigned)((hs[s].h2 >> lane) & 1ull) << 1) |
+			                     ((unsigned)((hs[s].h3 >> lane) & 1ull) << 2) | ((unsigned)((hs[s].h4 >> lane) & 1ull) << 3);
+			p.fin[slot[s] * 16 + k] = (unsigned)idx[s] | (dec << 4);
+		}
+	}
+}
+
+#ifndef K4X2_WAVES
+#define K4X2_WAVES 4 // 97 registers, allocated 104: exactly what three front-end waves (3 x 136) leave of a SIMD's 512
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K4X2_WAVES, K4X2_WAVES))) void k4_phase_chunks2(K4Params p) {
+	__shared__ __attribute__((aligned(16))) float2 stage[2][2][4][PS_SB_PAD];
+	const int lane = threadIdx.x;
+	const int k = lane & 15, row = lane >> 4;
+	const int chunk = blockIdx.y;
+	if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
+	else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
+	else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
+	// the wave's two row sets: the same sampling phase of channels 8q .. 8q+3 and 8q+4 .. 8q+7 (one 128-byte line per symbol pair)
+	const int j = blockIdx.x % 5, chan0 = (blockIdx.x / 5) * 8 + row;
+	const int n_chan = p.n_chains / 5;
+	int chain[2]; bool live[2];
+#pragma unroll
+	for (int s = 0; s < 2; s++) {
+		const int c = chan0 + 4 * s;
+		live[s] = c < n_chan;
+		chain[s] = (live[s] ? c : n_chan - 1) * 5 + j;
+	}
+	const int rowbase = row * 16;
+	const int src = __builtin_amdgcn_update_dpp(0, k, 0x121, 0xF, 0xF, false);
+	const bool all_left = __all(src == ((k + 15) & 15)), all_right = __all(src == ((k + 1) & 15));
+	if (all_left) ps_chunk_body2<0>(p, chain, live, chunk, k, rowbase, lane, stage);
+	else if (all_right) ps_chunk_body2<1>(p, chain, live, chunk, k, rowbase, lane, stage);
+	else ps_chunk_body2<2>(p, chain, live, chunk, k, rowbase, lane, stage);
+}
+
 // sequential over the (few) chunks of a chain, 16 lanes per chain: verify the speculative warm-ups, select the
 // trajectory of the true start index per chunk, emit the packed decisions and the new state
 __global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
@@ -2174,7 +2363,7 @@ __global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
 		}
 		ma_last = mf[AS - 1]; // only read when another batch follows, i.e. when all AS chunks of this one were live
 	}
-	if (bad) { if (p.qflag) atomicOr(p.qflag + chain / 20, 1); else atomicOr(p.flag, 1); }
+	if (bad) { if (p.qflag) atomicOr(p.qflag + chain / p.qflag_div, 1); else atomicOr(p.flag, 1); }
 	const size_t last = base + (p.n_chunks - 1);
 	sto->ma[k] = p.ma_fin[last * 16 + k];
 	sto->bits[k] = fin_last >> 4;
@@ -3656,9 +3845,12 @@ hipError_t launch_k4_sequential(const K4Params& p, hipStream_t s) {
 
 hipError_t launch_k4(const K4Params& p, hipStream_t s) {
 	if (p.n_groups <= 0) return hipSuccess;
-	hipError_t e = hipMemsetAsync(p.flag, 0, sizeof(int), s);
-	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(k4_phase_chunks, dim3((p.n_chains / 5 + 3) / 4 * 5, p.n_chunks), dim3(64), 0, s, p);
+	if (!p.qflag) { // (the per-workgroup flags are cleared by the fallback kernel itself)
+		hipError_t e = hipMemsetAsync(p.flag, 0, sizeof(int), s);
+		if (e != hipSuccess) return e;
+	}
+	if (p.streams == 2) hipLaunchKernelGGL(k4_phase_chunks2, dim3((p.n_chains / 5 + 7) / 8 * 5, p.n_chunks), dim3(64), 0, s, p);
+	else hipLaunchKernelGGL(k4_phase_chunks, dim3((p.n_chains / 5 + 3) / 4 * 5, p.n_chunks), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(k4_assemble, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(k4_phase_search, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p, 1); // exits at once unless flagged
 	return hipGetLastError();

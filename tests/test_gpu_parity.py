@@ -1111,10 +1111,11 @@ def test_reference_binding_compiled_against_the_real_reference(gpu_model, cpu_mo
     assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])  # tag.level, tag.ppm per message
 
 
-@pytest.mark.parametrize("env", [{"AISGPU_PS_WARM": "16"}, {"AISGPU_PS_WARM": "64"}, {"AISGPU_K46": "0"}, {"AISGPU_K46": "0", "AISGPU_PS_WARM": "16"},
-                                 {"AISGPU_SERIAL": "1"}, {"AISGPU_PS_SEQUENTIAL": "1"}, {"AISGPU_K4": "lane"}])
+@pytest.mark.parametrize("env", [{"AISGPU_K46": "1"}, {"AISGPU_K46": "1", "AISGPU_PS_WARM": "16"}, {"AISGPU_K46": "1", "AISGPU_PS_WARM": "64"}, {"AISGPU_K46": "0"},
+                                 {"AISGPU_K46": "0", "AISGPU_PS_WARM": "16"}, {"AISGPU_K46": "1", "AISGPU_SERIAL": "1"}, {"AISGPU_SERIAL": "1"},
+                                 {"AISGPU_PS_SEQUENTIAL": "1"}, {"AISGPU_K4": "lane"}])
 def test_fused_fir_phase_search_kernel_and_its_exact_fallback(env, monkeypatch):
-    """The default back end derotates, filters and searches in ONE kernel (k46_fir_phase_chunks: the FIR outputs never leave LDS).
+    """AISGPU_K46=1: the back end derotates, filters and searches in ONE kernel (k46_fir_phase_chunks: the FIR outputs never leave LDS).
     With a 16- or 64-symbol warm-up the speculative EMA start of every chunk is wrong, the verification flags every channel
     quad, and the kernel's sequential mode must recompute them exactly; AISGPU_K46=0 is the two-kernel form (derotation / FIR
     into HBM, then PhaseSearch), also with its own fallback; plus the single-stream schedule and the other search variants.
