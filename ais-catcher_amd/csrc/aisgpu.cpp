@@ -170,6 +170,7 @@ struct aisgpu {
 	struct { bool valid = false; int q = 0, pb = 0, lv = 0; long long g0 = 0, g1 = 0, first48 = 0; unsigned block = 0, sub = 0; } pend; // deferred second half
 	bool defer = true;
 	// device frame decoder (AISGPU_FLAG_GPU_DECODE)
+	int dec_kind = 0; uint32_t* d_fmrows[2] = {}; float* d_last_lvl[2] = {}; int fmrow_words = 0; // device decoders of ModelStandard (1) / ModelChallenger (2) / ModelBase (3)
 	bool gpu_decode = false; DecState* d_dec = nullptr; uint32_t* d_frames = nullptr; unsigned* d_frame_count = nullptr;
 	bool k7_alt = false; // test hook (AISGPU_K7=alt): the two decoder implementations take turns, block by block, on the same DecState
 	bool k7_event = true; uint32_t *d_k7ev = nullptr, *d_k7cnt = nullptr; uint16_t* d_k7open = nullptr; K7Slot* d_k7slot = nullptr; int* d_k7ovf = nullptr;
@@ -434,12 +435,27 @@ int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned
 }
 
 // AIS::Decoder on the device, behind PhaseSearchEMA of the same block (same stream)
-int enqueue_decode(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s) {
-	if (!h->gpu_decode) return AISGPU_OK;
+K7Params make_k7(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub) {
 	K7Params k7;
 	k7.bits = h->d_bits[pb]; k7.bits_stride = h->words; k7.lvl = h->d_lvl[lv]; k7.lvl_stride = h->Gcap;
 	k7.state = h->d_dec; k7.frames = h->d_frames; k7.frame_count = h->d_frame_count; k7.max_frames = h->max_frames;
 	k7.first_group = g0; k7.n_groups = n_groups; k7.n_chan = h->n_chan; k7.block = block; k7.sub = sub;
+	k7.kind = h->dec_kind;
+	if (h->dec_kind != 0) { // ModelStandard / ModelChallenger / ModelBase wirings
+		k7.fm_cur = h->d_fmbits[pb]; k7.fm_prev = h->d_fmbits[pb ^ 1]; k7.fm_stride = h->L / 32;
+		k7.fmrows = h->d_fmrows[pb]; k7.fmrows_stride = h->fmrow_words; k7.last_lvl_in = h->d_last_lvl[pb ^ 1]; k7.last_lvl = h->d_last_lvl[pb];
+		k7.n_rel0 = (int)(g0 * 5 - (long long)block * h->L); k7.L = h->L; // (every downstream block has L samples: block * L is its first one)
+	}
+	return k7;
+}
+
+int enqueue_decode(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s) {
+	if (!h->gpu_decode) return AISGPU_OK;
+	const K7Params k7 = make_k7(h, pb, lv, g0, n_groups, block, sub);
+	if (h->dec_kind != 0) { // (the FM bits were regrouped on the stream that produced them, see launch_k7_pack)
+		HIPCHK(launch_k7_mesh(k7, s));
+		return AISGPU_OK;
+	}
 	if (h->k7_event && !(h->k7_alt && (block & 1))) { // event-driven decoders (kernels.h): same DecState between blocks, so the two can even alternate
 		K7eParams q;
 		q.k = k7; q.ev = h->d_k7ev; q.cnt = h->d_k7cnt; q.open_c = h->d_k7open; q.slot = h->d_k7slot; q.overflow = h->d_k7ovf;
@@ -483,6 +499,10 @@ int enqueue_back(aisgpu_t* h) {
 		k5.fir_out = h->d_fmfir; k5.fir_stride = h->L;
 		memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
 		HIPCHK(launch_k5(k5, h->n_chan, h->stream));
+		if (h->gpu_decode) { // device decoders: the FM bits regrouped per decoder, here, where this and the previous block's bits are in order
+			WAITEV(h->stream, h->ev_ema[lv ^ 2]); // fmrows[pb] was last read by the decoders of block f-2
+			HIPCHK(launch_k7_pack(make_k7(h, pb, lv, g0, (int)(g1 - g0), h->pend.block, h->pend.sub), h->stream));
+		}
 	}
 	HIPCHK(hipEventRecord(h->ev_k3[pb], h->stream));
 
@@ -621,6 +641,12 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 	memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
 	HIPCHK(launch_k5(k5, h->n_chan, h->stream));
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->stream));
+	if (h->gpu_decode) { // SimplePLL + decoder (ModelBase) / Deinterleave + five decoders (ModelStandard) on the device, behind the filter
+		const long long g0 = h->n48 / 5, g1 = (h->n48 + h->L) / 5;
+		const K7Params k7 = make_k7(h, pb, 0, g0, (int)(g1 - g0), (unsigned)h->block_idx, (unsigned)h->n_sub);
+		if (h->dec_kind == 1) HIPCHK(launch_k7_pack(k7, h->stream));
+		HIPCHK(launch_k7_mesh(k7, h->stream));
+	}
 	HIPCHK(hipEventRecord(h->ev_k3[pb], h->stream));
 	WAITEV(h->s2, h->ev_k3[pb]); // aisgpu_sync_outputs copies on s2
 	if (h->n_sub < MAXSUB) {
@@ -716,7 +742,11 @@ int gather_frames(aisgpu_t* h) {
 		const uint32_t* f = h->h_frames + (size_t)i * DEC_FRAME_WORDS;
 		aisgpu_frame& o = h->frames[i];
 		const unsigned dec = f[0];
-		o.rx = (int)(dec / 10); o.ch = (int)(dec / 5 % 2); o.phase = (int)(dec % 5);
+		if (h->dec_kind == 2) { // ModelChallenger: dec = channel * 10 + position in the reference's order (FM0..FM3, coherent 0..4, FM4)
+			const unsigned ord = dec % 10;
+			o.rx = (int)(dec / 20); o.ch = (int)(dec / 10 % 2); o.phase = ord < 4 ? 5 + (int)ord : ord == 9 ? 9 : (int)ord - 4; // 5..9: the FM decoders
+		} else if (h->dec_kind == 3) { o.rx = (int)(dec / 2); o.ch = (int)(dec % 2); o.phase = 0; } // ModelBase: one decoder per channel
+		else { o.rx = (int)(dec / 10); o.ch = (int)(dec / 5 % 2); o.phase = (int)(dec % 5); }
 		o.group = (int)f[1]; o.position = (int)f[2];
 		memcpy(&o.level_sum, &f[3], 4);
 		o.start_idx = (long long)((unsigned long long)f[4] | (unsigned long long)f[5] << 32);
@@ -728,13 +758,25 @@ int gather_frames(aisgpu_t* h) {
 	std::vector<aisgpu_frame> sorted(fresh);
 	std::vector<unsigned> idx(fresh);
 	for (unsigned i = 0; i < fresh; i++) idx[i] = i;
+	// On the decimate-by-3 ladders Rotate hands over DownsampleKFilter's 8192-sample blocks: the reference alternates between the
+	// channels every 4096 samples at 48 kHz (and GpuChain::process replays in that order); elsewhere channel A's whole block
+	// comes first.  slice = the 4096-sample piece of its downstream block in which the frame closed.
+	const auto slice_of = [&](const aisgpu_frame& x) -> long long {
+		if (h->rot_period <= 0 || x.sub < 0 || x.sub >= h->n_sub) return 0;
+		const SubOut& so = h->sub[x.sub];
+		const long long n_rel = h->dec_kind == 3 ? x.group : 5 * (so.first_group + x.group) + (h->dec_kind == 1 ? x.phase : 4) - so.first48;
+		return n_rel / 4096;
+	};
 	std::sort(idx.begin(), idx.end(), [&](unsigned a, unsigned b) {
 		const uint32_t* fa = h->h_frames + (size_t)a * DEC_FRAME_WORDS; const uint32_t* fb = h->h_frames + (size_t)b * DEC_FRAME_WORDS;
 		const aisgpu_frame &x = h->frames[a], &y = h->frames[b];
 		if (x.rx != y.rx) return x.rx < y.rx;
 		if (fa[8] != fb[8]) return (int)(fa[8] - fb[8]) < 0;
+		const long long sx = slice_of(x), sy = slice_of(y);
+		if (sx != sy) return sx < sy;
 		if (x.ch != y.ch) return x.ch < y.ch;
 		if (x.group != y.group) return x.group < y.group;
+		if (h->dec_kind == 2) return fa[0] % 10 < fb[0] % 10; // the reference's order inside a group
 		return x.phase < y.phase;
 	});
 	for (unsigned i = 0; i < fresh; i++) sorted[i] = h->frames[idx[i]];
@@ -1065,11 +1107,21 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	}
 	h->gpu_decode = (cfg->flags & AISGPU_FLAG_GPU_DECODE) != 0;
 	if (h->gpu_decode) {
-		if (cfg->model != AISGPU_MODEL_DEFAULT) { h->err = "AISGPU_FLAG_GPU_DECODE: ModelDefault only"; return AISGPU_ERR_ARG; }
+		if (cfg->model == AISGPU_MODEL_V2) { h->err = "AISGPU_FLAG_GPU_DECODE: not for ModelEngineV2 (its decoders steer the engine block by block)"; return AISGPU_ERR_ARG; }
+		h->dec_kind = cfg->model == AISGPU_MODEL_STANDARD ? 1 : cfg->model == AISGPU_MODEL_CHALLENGER ? 2 : cfg->model == AISGPU_MODEL_BASE ? 3 : 0;
 		h->max_frames = (int)C * 64; // ring between two aisgpu_sync_outputs(): a slot holds ~2 frames per channel and block
-		HIPCHK(dalloc(&h->d_dec, (size_t)h->n_chains)); // zero = State::TRAINING, lastBit = prev = 0 (Marine/AIS.h:44-56)
+		HIPCHK(dalloc(&h->d_dec, (size_t)C * 10)); // zero = State::TRAINING, lastBit = prev = 0 (Marine/AIS.h:44-56); up to ten decoders per channel
+		if (h->dec_kind == 1 || h->dec_kind == 2) {
+			h->fmrow_words = h->Gcap / 32;
+			for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmrows[i], C * 5 * (size_t)h->fmrow_words));
+			for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_last_lvl[i], C));
+		}
+		if (h->dec_kind != 0) h->k7_event = false; // the event-driven form exists for ModelDefault's wiring only
+		// (on the decimate-by-3 ladders Rotate alternates between the channels every 4096 samples, and with it the level the FM
+		// decoders of ModelChallenger inherit through the shared TAG: that variant of the mesh kernel does not exist)
+		if (h->dec_kind == 2 && by3) { h->err = "AISGPU_FLAG_GPU_DECODE with ModelChallenger: not on the decimate-by-3 ladders"; return AISGPU_ERR_ARG; }
 		HIPCHK(dalloc(&h->d_frames, (size_t)h->max_frames * DEC_FRAME_WORDS));
-		if (const char* e = getenv("AISGPU_K7")) { h->k7_event = strcmp(e, "seq") != 0; h->k7_alt = strcmp(e, "alt") == 0; } // "seq": one lane per decoder, symbol by symbol
+		if (const char* e = getenv("AISGPU_K7")) if (h->dec_kind == 0) { h->k7_event = strcmp(e, "seq") != 0; h->k7_alt = strcmp(e, "alt") == 0; } // "seq": one lane per decoder, symbol by symbol
 		// the event words hold a symbol index in 13 bits: blocks of more than 8191 groups (e.g. the reference's CU8 file block of
 		// 3,145,728 samples at 1536 kSPS) go through the sequential decoder kernel
 		if ((h->L + 4) / 5 + 1 > 8191) h->k7_event = false;
@@ -1228,7 +1280,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_qflag); hipFree(h->d_qflag4);
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
 	hipFree(h->d_box[0]); hipFree(h->d_box[1]);
-	hipFree(h->d_dec); hipFree(h->d_frames); hipFree(h->d_frame_count);
+	hipFree(h->d_dec); hipFree(h->d_frames); hipFree(h->d_frame_count); hipFree(h->d_fmrows[0]); hipFree(h->d_fmrows[1]); hipFree(h->d_last_lvl[0]); hipFree(h->d_last_lvl[1]);
 	hipFree(h->d_k7ev); hipFree(h->d_k7cnt); hipFree(h->d_k7open); hipFree(h->d_k7slot); hipFree(h->d_k7ovf);
 	if (h->h_frames) hipHostFree(h->h_frames);
 	hipFree(h->d_fmprev[0]); hipFree(h->d_fmprev[1]);

@@ -183,8 +183,18 @@ struct K7Params {
 	uint32_t* frames; unsigned* frame_count; int max_frames; // ring of records, monotonic counter
 	long long first_group; int n_groups, n_chan;
 	unsigned block, sub;                          // stamped into the records
+	// the other engines' decoder wirings (k7_decode_mesh / k7_base); kind: 0 ModelDefault (5 coherent decoders per channel),
+	// 1 ModelStandard (5 decoders on the deinterleaved FM discriminator, Model.cpp:505-514), 2 ModelChallenger (10 per channel:
+	// coherent + FM, Model.cpp:641-674), 3 ModelBase (SimplePLL + one decoder with its feedback, Model.cpp:428-435)
+	int kind = 0;
+	const uint32_t* fm_cur = nullptr; const uint32_t* fm_prev = nullptr; long long fm_stride = 0; // [n_chan][L / 32] sign of the filtered discriminator, this / previous block
+	uint32_t* fmrows = nullptr; long long fmrows_stride = 0; // [n_chan * 5][words] scratch: the FM bits regrouped per decoder (sample 5 g + j -> row j, bit g)
+	const float* last_lvl_in = nullptr; float* last_lvl = nullptr; // [n_chan] ScatterPLL level of the last group of the previous / of this block (what tag.sample_lvl still holds)
+	int n_rel0 = 0, L = 0;                        // first_group * 5 - first_sample48; 48 kHz samples per block
 };
 hipError_t launch_k7(const K7Params& p, hipStream_t s);
+hipError_t launch_k7_pack(const K7Params& p, hipStream_t s); // kind 1 / 2: regroup the FM bits per decoder (on the stream that produced them)
+hipError_t launch_k7_mesh(const K7Params& p, hipStream_t s); // kind 1 / 2 / 3: the decoders
 
 // K7e: the same decoders, event driven.  A decoder in TRAINING can only leave it where two equal NRZI bits follow at least five
 // alternations -- a pure function of the hard bits -- so the places where a frame could start are found bit-parallel (k7e_scan),

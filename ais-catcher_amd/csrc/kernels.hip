@@ -3271,6 +3271,180 @@ __global__ __launch_bounds__(64) void k7_decode(K7Params p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K7 for the other engines (sequential kernels; the event-driven form exists for ModelDefault only).
+//  * k7_pack_fm: the FM receivers hand every 48 kHz sample n to decoder n % 5 (Deinterleave, DSP.h:51-74): regroup the sign bits
+//    of the filtered discriminator per decoder (row j, bit g = sample 5 g + j), for the groups completed inside this block
+//    (the first one may have started in the previous block: those bits come from the previous block's row).
+//  * k7_decode_mesh<1>: ModelStandard -- five decoders with their Reset mesh on those rows (tag.sample_lvl is never set in
+//    this engine: level 0; tag.sample_idx = n).
+//  * k7_decode_mesh<2>: ModelChallenger -- ten decoders per channel.  Per group the reference runs FM0..FM3 (samples 5g..5g+3),
+//    then, with sample 5g+4, the five coherent decoders and FM4 (Model.cpp:630-639); any of the ten that completes
+//    a message resets the other nine (Model.cpp:658-674).  The ten step together in that order's lanes and the order is
+//    restored by the same roll-back as in k7_decode.  tag.sample_lvl is written by ScatterPLL when a group completes, so
+//    FM0..FM3 still see the previous group's level.
+//  * k7_base: ModelBase -- DSP::SimplePLL (DSP.cpp:28-44) in front of ONE decoder per channel, sequential over the 48 kHz
+//    samples; the sampler's fast / slow loop follows the decoder's StartTraining / StopTraining signals (DSP.cpp:46-57,
+//    AIS.cpp:41-46), which amounts to "the decoder is in TRAINING".  tag.sample_idx / sample_lvl are never set in this engine.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k7_pack_fm(K7Params p) {
+	const int dec = blockIdx.y, chan = dec / 5, j = dec - 5 * chan;
+	const int w = blockIdx.x * 256 + threadIdx.x;
+	if (w >= (int)p.fmrows_stride) return;
+	const uint32_t* cur = p.fm_cur + (size_t)chan * p.fm_stride;
+	const uint32_t* prev = p.fm_prev + (size_t)chan * p.fm_stride;
+	uint32_t word = 0;
+	for (int e = 0; e < 32; e++) {
+		const int g = 32 * w + e;
+		if (g >= p.n_groups) break;
+		const int n = p.n_rel0 + 5 * g + j; // block-relative sample
+		const uint32_t b = n >= 0 ? (cur[n >> 5] >> (n & 31)) & 1u : (prev[(p.L + n) >> 5] >> ((p.L + n) & 31)) & 1u;
+		word |= b << e;
+	}
+	p.fmrows[(size_t)dec * p.fmrows_stride + w] = word;
+}
+
+template <int KIND> // 1: ModelStandard (mesh of 5 on the FM rows), 2: ModelChallenger (mesh of 10)
+__global__ __launch_bounds__(64) void k7_decode_mesh(K7Params p) {
+	constexpr int MESH = KIND == 2 ? 10 : 5, PER_WAVE = 60 / MESH;
+	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64]; // [word][lane]
+	__shared__ float lv[64 * 33];
+	const int lane = threadIdx.x;
+	const int mesh = lane / MESH, o = lane - MESH * mesh; // o: position in the reference's order within a group
+	const int chan_raw = blockIdx.x * PER_WAVE + mesh;
+	const bool live = lane < 60 && chan_raw < p.n_chan;
+	const int chan = live ? chan_raw : 0;
+	// ModelChallenger: o = 0..3 FM0..FM3, 4..8 the coherent decoders 0..4, 9 FM4
+	const bool is_fm = KIND == 1 || o < 4 || o == 9;
+	const int j = KIND == 1 ? o : (o < 4 ? o : o == 9 ? 4 : o - 4);
+	const int dec = chan * MESH + (live ? o : 0);
+	uint32_t* data = fdata + lane;
+	DecState* st = p.state + dec;
+	DecReg r;
+	r.state = st->state; r.lastBit = st->lastBit; r.prev = st->prev; r.position = st->position; r.osc = st->osc;
+	r.level = st->level; r.start_idx = st->start_idx;
+	for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = st->data[w];
+	r.crc = st->crc[0]; r.cw = st->crc[1]; r.cwi = (int)st->crc[2]; r.tail = st->crc[3]; r.abort_pos = (int)st->crc[4];
+	const uint32_t* brow = is_fm ? p.fmrows + (size_t)(chan * 5 + j) * p.fmrows_stride : p.bits + (size_t)(chan * 5 + j) * p.bits_stride;
+	const float* lrow = KIND == 2 ? p.lvl + (size_t)chan * p.lvl_stride : nullptr;
+	// tag.sample_lvl as FM0..FM3 of a group see it: what the previous group's ScatterPLL left.  The TAG is ONE object per device,
+	// shared by both channels, and Rotate hands channel A its whole block before channel B (DSP.cpp:312-313): the first FM
+	// samples of channel A's block still see channel B's last level of the PREVIOUS block, those of channel B's block see
+	// channel A's last level of THIS block; samples of a group that began in the previous block saw their own channel's.
+	float lvl_prev = 0.0f, lvl_other = 0.0f;
+	if (KIND == 2) {
+		lvl_prev = p.last_lvl_in[chan];
+		lvl_other = (chan & 1) ? (p.n_groups > 0 ? p.lvl[(size_t)(chan ^ 1) * p.lvl_stride + p.n_groups - 1] : p.last_lvl_in[chan ^ 1]) : p.last_lvl_in[chan ^ 1];
+	}
+	const unsigned mesh_mask = (1u << MESH) - 1u;
+	for (int g0 = 0; g0 < p.n_groups; g0 += 32) {
+		const uint32_t word = brow[g0 >> 5];
+		const int n = p.n_groups - g0 < 32 ? p.n_groups - g0 : 32;
+		if (KIND == 2) {
+			const float4* src = reinterpret_cast<const float4*>(lrow + g0);
+			float4 t[8];
+#pragma unroll
+			for (int q = 0; q < 8; q++) t[q] = src[q];
+#pragma unroll
+			for (int q = 0; q < 8; q++) { float* d = &lv[lane * 33 + 4 * q]; d[0] = t[q].x; d[1] = t[q].y; d[2] = t[q].z; d[3] = t[q].w; }
+		}
+		for (int e = 0; e < n; e++) {
+			const int g = g0 + e;
+			const int dd = (int)((word >> e) & 1u);
+			const float lv_g = KIND == 2 ? lv[lane * 33 + e] : 0.0f;
+			float slvl = 0.0f;
+			if (KIND == 2) {
+				slvl = (is_fm && o < 4) ? lvl_prev : lv_g;
+				if (g == 0 && is_fm && o < 4 && p.n_rel0 + j >= 0) slvl = lvl_other; // the block's first samples: the other channel ran last
+			}
+			lvl_prev = lv_g;
+			const long long sidx = 5 * (p.first_group + g) + j; // coherent: ScatterPLL's sample_idx; FM: the sample number (Deinterleave)
+			const DecReg before = r;
+			bool found = live && dec_step(r, dd, slvl, sidx, data);
+			const unsigned long long F = __ballot(found);
+			if (F != 0) { // rare: restore the order in which the reference runs the decoders of a group
+				const unsigned mm = (unsigned)(F >> (MESH * mesh)) & mesh_mask;
+				if (live && mm != 0) {
+					const int omin = __builtin_ctz(mm);
+					if (o > omin) { // would have been reset before its step
+						r = before;
+						r.state = DST_TRAINING; r.position = 0; r.osc = 0;
+						dec_step(r, dd, slvl, sidx, data);
+					} else if (o < omin) { // reset after its step
+						r.state = DST_TRAINING; r.position = 0; r.osc = 0;
+					} else { // the decoder that found the message
+						const unsigned slot = atomicAdd(p.frame_count, 1u) % (unsigned)p.max_frames;
+						uint32_t* f = p.frames + (size_t)slot * DEC_FRAME_WORDS;
+						f[0] = (uint32_t)dec; f[1] = (uint32_t)g; f[2] = (uint32_t)r.position; f[3] = __float_as_uint(r.level);
+						f[4] = (uint32_t)(unsigned long long)r.start_idx; f[5] = (uint32_t)((unsigned long long)r.start_idx >> 32);
+						f[6] = (uint32_t)(unsigned long long)sidx; f[7] = (uint32_t)((unsigned long long)sidx >> 32);
+						f[8] = p.block; f[9] = p.sub;
+						for (int w = 0; w < DEC_DATA_WORDS; w++) f[10 + w] = data[64 * w];
+						r.state = DST_TRAINING; r.position = 0; r.osc = 0;
+					}
+				}
+			}
+		}
+	}
+	if (live) {
+		st->state = r.state; st->lastBit = r.lastBit; st->prev = r.prev; st->position = r.position; st->osc = r.osc;
+		st->level = r.level; st->start_idx = r.start_idx;
+		data[64 * r.cwi] = r.cw;
+		for (int w = 0; w < DEC_DATA_WORDS; w++) st->data[w] = data[64 * w];
+		st->crc[0] = r.crc; st->crc[1] = r.cw; st->crc[2] = (uint32_t)r.cwi; st->crc[3] = r.tail; st->crc[4] = (uint32_t)r.abort_pos;
+		if (KIND == 2 && o == 0) p.last_lvl[chan] = lvl_prev; // (a block without a complete group hands on what it was given)
+	}
+}
+
+__global__ __launch_bounds__(64) void k7_base(K7Params p) {
+	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64]; // [word][lane]
+	const int lane = threadIdx.x;
+	const int chan_raw = blockIdx.x * 64 + lane;
+	const bool live = chan_raw < p.n_chan;
+	const int chan = live ? chan_raw : 0;
+	uint32_t* data = fdata + lane;
+	DecState* st = p.state + chan;
+	DecReg r;
+	r.state = st->state; r.lastBit = st->lastBit; r.prev = st->prev; r.position = st->position; r.osc = st->osc;
+	r.level = st->level; r.start_idx = st->start_idx;
+	for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = st->data[w];
+	r.crc = st->crc[0]; r.cw = st->crc[1]; r.cwi = (int)st->crc[2]; r.tail = st->crc[3]; r.abort_pos = (int)st->crc[4];
+	float pll = __uint_as_float(st->crc[5]); // SimplePLL::PLL
+	int pprev = (int)st->crc[6];              // SimplePLL::prev
+	const uint32_t* brow = p.fm_cur + (size_t)chan * p.fm_stride;
+	for (int n0 = 0; n0 < p.L; n0 += 32) {
+		const uint32_t word = brow[n0 >> 5];
+		for (int e = 0; e < 32; e++) {
+			const int bit = (int)((word >> e) & 1u);       // data[i] > 0
+			const bool fast = r.state == DST_TRAINING;     // FastPLL (StartTraining / StopTraining, AIS.cpp:41-46)
+			if (bit != pprev) pll += (0.5f - pll) * (fast ? 0.6f : 0.05f);
+			pll += 0.2f;
+			const bool emit = pll >= 1.0f;
+			if (emit) pll -= (float)(int)pll;
+			pprev = bit;
+			bool found = false;
+			if (live && emit) found = dec_step(r, bit, 0.0f, 0ll, data); // tag.sample_lvl / sample_idx are never set in this engine
+			if (found) {
+				const unsigned slot = atomicAdd(p.frame_count, 1u) % (unsigned)p.max_frames;
+				uint32_t* f = p.frames + (size_t)slot * DEC_FRAME_WORDS;
+				f[0] = (uint32_t)chan; f[1] = (uint32_t)(n0 + e); f[2] = (uint32_t)r.position; f[3] = __float_as_uint(r.level);
+				f[4] = 0; f[5] = 0; f[6] = 0; f[7] = 0;
+				f[8] = p.block; f[9] = p.sub;
+				for (int w = 0; w < DEC_DATA_WORDS; w++) f[10 + w] = data[64 * w];
+				r.state = DST_TRAINING; r.position = 0; r.osc = 0;
+			}
+		}
+	}
+	if (live) {
+		st->state = r.state; st->lastBit = r.lastBit; st->prev = r.prev; st->position = r.position; st->osc = r.osc;
+		st->level = r.level; st->start_idx = r.start_idx;
+		data[64 * r.cwi] = r.cw;
+		for (int w = 0; w < DEC_DATA_WORDS; w++) st->data[w] = data[64 * w];
+		st->crc[0] = r.crc; st->crc[1] = r.cw; st->crc[2] = (uint32_t)r.cwi; st->crc[3] = r.tail; st->crc[4] = (uint32_t)r.abort_pos;
+		st->crc[5] = __float_as_uint(pll); st->crc[6] = (uint32_t)pprev;
+	}
+}
+
+// ------------------------------------------------------------------------------------------
 // K7e: event-driven frame decoders (see kernels.h).  Conventions: symbol g of decoder (chan, j) is bit g of its packed row;
 // Bit[g] = (dd[g] == dd[g-1]) is the NRZI bit, alt[g] = (Bit[g] != Bit[g-1]).  In TRAINING the reference counts consecutive
 // alternations in `position` and leaves for STARTFLAG at the first symbol with alt == 0 and position > 4 (Marine/AIS.h:109-119).
@@ -3813,6 +3987,20 @@ hipError_t launch_k3(const K3Params& p, int n_chan, hipStream_t s) {
 
 hipError_t launch_k7(const K7Params& p, hipStream_t s) {
 	hipLaunchKernelGGL(k7_decode, dim3((p.n_chan + 11) / 12), dim3(64), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_k7_pack(const K7Params& p, hipStream_t s) {
+	if (p.n_groups > 0) hipLaunchKernelGGL(k7_pack_fm, dim3(((unsigned)p.fmrows_stride + 255) / 256, p.n_chan * 5), dim3(256), 0, s, p);
+	return hipGetLastError();
+}
+hipError_t launch_k7_mesh(const K7Params& p, hipStream_t s) {
+	if (p.kind == 3) {
+		hipLaunchKernelGGL(k7_base, dim3((p.n_chan + 63) / 64), dim3(64), 0, s, p);
+		return hipGetLastError();
+	}
+	if (p.kind == 1) hipLaunchKernelGGL(k7_decode_mesh<1>, dim3((p.n_chan + 11) / 12), dim3(64), 0, s, p);
+	else hipLaunchKernelGGL(k7_decode_mesh<2>, dim3((p.n_chan + 5) / 6), dim3(64), 0, s, p);
 	return hipGetLastError();
 }
 

@@ -137,10 +137,14 @@ void GpuChain::process(const void* data, int len, TAG& tag) {
 			if (f.rx != rx || f.sub >= nsub) continue;
 			aisgpu_out o;
 			if ((rc = batch->fetch(f.sub, rx, f.ch, &o)) != AISGPU_OK) { failed = true; last_status = rc; return; }
-			const long long n_last = 5 * (o.first_group + f.group) + 4; // like replay(): what the tag held when the frame closed
-			const int w = (int)((n_last - o.first_sample48) / 512);
-			if (o.ppm && w >= 0 && w < o.n_windows) tag.ppm = o.ppm[w];
-			if (tag.mode & 1) tag.sample_lvl = o.lvl[f.group];
+			if (o.n_groups > 0) { // (the FM receivers -- ModelBase / ModelStandard -- never touch tag.ppm / tag.sample_lvl)
+				// what the tag held when the frame closed: a coherent decoder runs when its group completes (sample 5g+4, like replay()),
+				// an FM decoder of ModelChallenger with its own sample (end_idx)
+				const long long n_last = f.phase >= 5 ? f.end_idx : 5 * (o.first_group + f.group) + 4;
+				const int w = (int)((n_last - o.first_sample48) / 512);
+				if (o.ppm && w >= 0 && w < o.n_windows) tag.ppm = o.ppm[w];
+				if (tag.mode & 1) tag.sample_lvl = o.lvl[f.group];
+			}
 			tag.sample_idx = f.end_idx;
 			if (on_frame) on_frame(f, tag);
 		}
@@ -206,6 +210,15 @@ void ModelDefaultGPU::buildModel(char CH1, char CH2, int sample_rate, bool /*tim
 
 void ModelDefaultGPU::wireDecoders(char CH1, char CH2) {
 	fan.o = &output;
+	// AISGPU_FLAG_GPU_DECODE: the state machines ran on the device, a completed frame goes to the tail of ITS decoder
+	// (phase 0..4: DEC_x[phase] -- DEC_base_x for ModelBase --, 5..9: the FM decoders DEC_xf[phase - 5] of ModelChallenger)
+	chain.setFrameHandler([this](const aisgpu_frame& f, TAG& tag) {
+		AIS::Decoder* d;
+		if (base) d = f.ch == 0 ? &DEC_base_a : &DEC_base_b;
+		else if (f.phase >= 5) d = &(f.ch == 0 ? DEC_af : DEC_bf)[f.phase - 5];
+		else d = &(f.ch == 0 ? DEC_a : DEC_b)[f.phase];
+		d->emitFrame(f.data, f.position, f.level_sum, f.start_idx, f.end_idx, tag);
+	});
 	if (base) { // Model.cpp:428-435
 		DEC_base_a.setOrigin(CH1, station, own_mmsi);
 		DEC_base_b.setOrigin(CH2, station, own_mmsi);
@@ -247,10 +260,6 @@ void ModelDefaultGPU::wireDecoders(char CH1, char CH2) {
 		}
 		return;
 	}
-	chain.setFrameHandler([this](const aisgpu_frame& f, TAG& tag) {
-		AIS::Decoder& d = (f.ch == 0 ? DEC_a : DEC_b)[f.phase];
-		d.emitFrame(f.data, f.position, f.level_sum, f.start_idx, f.end_idx, tag);
-	});
 	for (int i = 0; i < N_SAMPLES_PER_SYMBOL; i++) {
 		DEC_a[i].setOrigin(CH1, station, own_mmsi);
 		DEC_b[i].setOrigin(CH2, station, own_mmsi);

@@ -63,7 +63,9 @@ extern "C" {
 #define AISGPU_FLAG_TAPS 1    /* keep intermediate float taps readable via aisgpu_tap() (tests) */
 #define AISGPU_FLAG_SERIAL 2  /* profiling aid: one stream, no overlap between the kernels of consecutive blocks */
 #define AISGPU_FLAG_PS_BOXCAR 8 /* KEY_SETTING_PS_EMA off: Demod::PhaseSearch (boxcar history) instead of PhaseSearchEMA (Model.cpp:550-555) */
-#define AISGPU_FLAG_GPU_DECODE 16 /* run AIS::Decoder (frame decoder + Reset mesh) on the device too: aisgpu_frames() (ModelDefault only) */
+#define AISGPU_FLAG_GPU_DECODE 16 /* run the AIS::Decoder objects (frame decoder + Reset mesh) on the device too: aisgpu_frames().  ModelDefault (five per
+                                   * channel), ModelStandard (five on the deinterleaved discriminator), ModelChallenger (ten: coherent + FM, Model.cpp:641-674)
+                                   * and ModelBase (DSP::SimplePLL + one decoder with its feedback loop, DSP.cpp:28-57, Model.cpp:428-435); not ModelEngineV2 */
 #define AISGPU_FLAG_FP_DS 32  /* KEY_SETTING_FP_DS (`-go FP_DS on`, `-F`): 1536 kSPS CU8 input goes through the fixed-point ladder
                                * Downsample16_CU8 (DSP/DSP.cpp:499-651, Model.cpp:231-237); ignored at other rates like in the reference */
 #define AISGPU_FLAG_MODE_X 64 /* channel mode X (`-c X`, Receiver.cpp:87-98, Model.cpp:35-107): ONE channel, already centred, sample_rate
@@ -140,8 +142,8 @@ int aisgpu_out_count(aisgpu_t* h);
  * conversion), Message::validate, buildNMEA.  Sorted the way the reference emits: by receiver, then downstream block,
  * channel A before channel B, group, phase.  Valid after aisgpu_sync_outputs() until the next aisgpu_run(). */
 typedef struct aisgpu_frame {
-	int rx, ch, phase, sub;   /* receiver, channel 0/1, decoder DEC_x[phase], downstream block of this run */
-	int group;                /* group (symbol index of the phase chain) inside that block whose bit completed the closing flag */
+	int rx, ch, phase, sub;   /* receiver, channel 0/1, decoder DEC_x[phase] (5..9: ModelChallenger's FM decoders DEC_xf[phase - 5]), downstream block of this run */
+	int group;                /* group (symbol index of the phase chain) inside that block whose bit completed the closing flag (ModelBase: the 48 kHz sample) */
 	int position;             /* decoder bit position at that moment; the frame incl. its FCS is position - 7 bits long */
 	float level_sum;          /* sum of tag.sample_lvl over the frame's bits */
 	long long start_idx, end_idx; /* tag.sample_idx at the start flag / at the last bit */

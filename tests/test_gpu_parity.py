@@ -1140,3 +1140,58 @@ def test_extreme_receiver_only_costs_its_own_quad():
     wild[block + block // 3:] *= np.float32(1e-12)
     xs[3] = wild
     _run_outputs_vs_oracle(xs, 1536000, "cf32", block, nblocks)
+
+
+@pytest.mark.parametrize("model,rate,fmt,block,nblocks", [(4, 1536000, "cf32", 131072, 12), (4, 1536000, "cu8", 786432, 3), (4, 6000000, "cf32", 786432, 5),
+                                                         (0, 1536000, "cf32", 131072, 12), (0, 768000, "cu8", 65536, 20), (0, 288000, "cf32", 49152, 12), (2, 288000, "cf32", 49152, 12), (2, 1536000, "cf32", 131072, 8),
+                                                         (1, 1536000, "cf32", 131072, 12), (1, 1536000, "cu8", 16384, 60), (1, 2400000, "cf32", 393216, 6)])
+def test_device_decoders_of_the_other_engines(model, rate, fmt, block, nblocks):
+    """AISGPU_FLAG_GPU_DECODE beyond ModelDefault: the decoder state machines of ModelChallenger (ten per channel: FM0..FM3,
+    the five coherent ones, FM4 per group, any of them resetting the other nine -- Model.cpp:630-674), of ModelStandard (five on
+    the deinterleaved discriminator, Model.cpp:505-514) and of ModelBase (DSP::SimplePLL in front of one decoder whose
+    StartTraining / StopTraining signals switch the sampler's loop, DSP.cpp:28-57) run on the device; the host only finishes the
+    frames (validate, NMEA).  NMEA text and the per-message tag.level / tag.ppm against the compiled reference, in order."""
+    from ais_catcher_amd import host
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=230 + model, gap_slots=(0, 2), type5_every=4)
+    data = synth.to_cu8(x) if fmt == "cu8" else x
+    per = 1 if fmt == "cf32" else 2
+    chk = (checkers.Ref if checkers.have_ref() else checkers.Oracle)(model=model, rate=rate, fmt=fmt)
+    chk.feed_blocks(data, block)
+    host.reset_sequence()
+    cls = {4: host.ModelChallengerGPU, 0: host.ModelStandardGPU, 1: host.ModelBaseGPU, 2: host.ModelDefaultGPU}[model]
+    m = cls(sample_rate=rate, block_len=block, input_format=_FMT[fmt], gpu_decode=True)
+    for b in range(nblocks):
+        assert m.receive(data[b * block * per:(b + 1) * block * per]) == 0
+    assert len(chk.nmea()) >= 3
+    assert m.nmea() == chk.nmea()
+    a, c = m.msg_meta(), chk.msg_meta()
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+    m.close()
+
+
+def test_device_decoders_of_the_other_engines_on_a_noisy_batch():
+    """Six receivers with weak, noisy signals (false trainings, aborted frames, CRC failures) through ModelChallenger's
+    twenty-decoder mesh and ModelBase's sampler loop on the device against the host decoders fed with the same decisions."""
+    import threading
+    from ais_catcher_amd import host
+    block, nblocks, R = 131072, 10, 6
+    streams = [synth.receiver_stream(block * nblocks, receiver_id=240 + r, gap_slots=(0, 2), noise_sigma=0.04 + 0.03 * r) for r in range(R)]
+    for model, cls in ((gpu.MODEL_CHALLENGER, host.ModelChallengerGPU), (gpu.MODEL_BASE, host.ModelBaseGPU), (gpu.MODEL_STANDARD, host.ModelStandardGPU)):
+        out = []
+        for dec in (False, True):
+            host.reset_sequence()
+            batch = host.Batch(n_receivers=R, block_len=block, model=model, gpu_decode=dec)
+            models = [cls(block_len=block, batch=batch, rx=r) for r in range(R)]
+
+            def work(r):
+                for b in range(nblocks):
+                    models[r].receive(streams[r][b * block:(b + 1) * block])
+            th = [threading.Thread(target=work, args=(r,)) for r in range(R)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            out.append([mm.nmea() for mm in models])
+            for mm in models:
+                mm.close()
+            batch.close()
+        assert out[0] == out[1], "model %d" % model
+        assert sum(len(o) for o in out[0]) >= R
