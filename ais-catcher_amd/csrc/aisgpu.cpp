@@ -133,6 +133,7 @@ struct aisgpu {
 	uint32_t* d_bits[2] = {};
 	bool challenger = false;
 	bool v2 = false; float2* h_c48 = nullptr; // ModelEngineV2: front end only, the 48 kHz channels go to the host (MAXSUB slots)
+	bool v2_assist = true; float2* d_v2hist = nullptr; float *d_v2f = nullptr, *d_v2prom = nullptr, *d_v2en = nullptr, *h_v2f = nullptr, *h_v2prom = nullptr, *h_v2en = nullptr; // decoder-independent part of V2::Engine on the device
 	bool base = false; float2* d_fmprev[2] = {}; // ModelBase: FM receiver on the 48 kHz channels, no coherent chain
 	float* d_fm = nullptr; uint32_t* d_fmbits[2] = {}; uint32_t* h_fmbits = nullptr; // ModelChallenger FM branch
 	float* d_fmfir = nullptr; // [n_chan][L] Filter(Receiver) output of the last downstream block (AISGPU_FLAG_TAPS)
@@ -664,6 +665,21 @@ int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
 		const size_t C = h->n_chan;
 		HIPCHK(hipMemcpy2DAsync(h->h_c48 + (size_t)h->n_sub * C * h->L, (size_t)h->L * sizeof(float2), h->d_c48[q], (size_t)h->c48s * sizeof(float2),
 		                        (size_t)h->L * sizeof(float2), C, hipMemcpyDeviceToHost, h->stream));
+		if (h->v2_assist) { // FreqOffset::Estimate of every offset-0 / offset-256 window, midWins' energies, the FM branch up to its sign
+			KV2Params k{};
+			k.c48 = h->d_c48[q]; k.c48_stride = h->c48s; k.hist = h->d_v2hist; k.omega = h->d_omega;
+			k.est_f = h->d_v2f; k.est_prom = h->d_v2prom; k.energy = h->d_v2en;
+			k.disc = h->d_fm; k.fmprev = h->d_fmprev[0]; k.fmbits = h->d_fmbits[pb]; k.fmbits_stride = h->L / 32;
+			k.fir_out = h->d_fmfir; k.fir_stride = h->L;
+			memcpy(k.taps, TAPS_RECEIVER, sizeof k.taps);
+			k.n_windows = h->W; k.L = h->L; k.n_chan = h->n_chan;
+			HIPCHK(launch_kv2(k, h->stream));
+			const size_t s_ = (size_t)h->n_sub;
+			HIPCHK(hipMemcpyAsync(h->h_v2f + s_ * C * 2 * h->W, h->d_v2f, C * 2 * h->W * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipMemcpyAsync(h->h_v2prom + s_ * C * 2 * h->W, h->d_v2prom, C * 2 * h->W * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipMemcpyAsync(h->h_v2en + s_ * C * (h->W + 1), h->d_v2en, C * (h->W + 1) * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipMemcpyAsync(h->h_fmbits + s_ * C * (h->L / 32), h->d_fmbits[pb], C * (h->L / 32) * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+		}
 		SubOut& so = h->sub[h->n_sub++];
 		so.pb = pb; so.lv = 0; so.q = q; so.groups = 0; so.first_group = h->n48 / 5; so.first48 = h->n48;
 	}
@@ -1233,7 +1249,24 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	HIPCHK(dalloc(&h->d_psflag, 4));
 	if (!getenv("AISGPU_PS_GLOBAL_FLAG")) HIPCHK(dalloc(&h->d_qflag4, 2 * (size_t)((C * 5 + 3) / 4)));
 	if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_firtap, C * (8 + h->L)));
-	if (h->v2) HIPCHK(hipHostMalloc((void**)&h->h_c48, MAXSUB * C * h->L * sizeof(float2), hipHostMallocDefault));
+	if (h->v2) {
+		HIPCHK(hipHostMalloc((void**)&h->h_c48, MAXSUB * C * h->L * sizeof(float2), hipHostMallocDefault));
+		if (const char* e = getenv("AISGPU_V2_ASSIST")) h->v2_assist = atoi(e) != 0; // 0: the front end only, everything else on the host
+		if (h->v2_assist) {
+			HIPCHK(dalloc(&h->d_v2hist, C * V2_HIST));
+			HIPCHK(dalloc(&h->d_v2f, C * 2 * h->W)); HIPCHK(dalloc(&h->d_v2prom, C * 2 * h->W)); HIPCHK(dalloc(&h->d_v2en, C * (h->W + 1)));
+			HIPCHK(hipHostMalloc((void**)&h->h_v2f, MAXSUB * C * 2 * h->W * sizeof(float), hipHostMallocDefault));
+			HIPCHK(hipHostMalloc((void**)&h->h_v2prom, MAXSUB * C * 2 * h->W * sizeof(float), hipHostMallocDefault));
+			HIPCHK(hipHostMalloc((void**)&h->h_v2en, MAXSUB * C * (h->W + 1) * sizeof(float), hipHostMallocDefault));
+			HIPCHK(dalloc(&h->d_fm, C * (FM_HIST + h->L)));
+			for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmbits[i], C * (h->L / 32)));
+			HIPCHK(hipHostMalloc((void**)&h->h_fmbits, MAXSUB * C * (h->L / 32) * sizeof(uint32_t), hipHostMallocDefault));
+			if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_fmfir, C * (size_t)h->L));
+			// FMDemod::prev: the engine decodes an all-zero block first (its look-back before the stream, V2Engine.cpp:275-279), which
+			// leaves prev = 0 -- not the 1 + 0j of the constructor (V2Engine.h:84) -- in front of the first real sample
+			HIPCHK(dalloc(&h->d_fmprev[0], C));
+		}
+	}
 	HIPCHK(hipHostMalloc((void**)&h->h_bits, MAXSUB * C * 5 * h->words * sizeof(uint32_t), hipHostMallocDefault));
 	HIPCHK(hipHostMalloc((void**)&h->h_lvl, MAXSUB * C * h->Gcap * sizeof(float), hipHostMallocDefault));
 	HIPCHK(hipHostMalloc((void**)&h->h_ppm, MAXSUB * C * h->W * sizeof(float), hipHostMallocDefault));
@@ -1276,6 +1309,8 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_fm); hipFree(h->d_fmfir); hipFree(h->d_fmbits[0]); hipFree(h->d_fmbits[1]);
 	if (h->h_fmbits) hipHostFree(h->h_fmbits);
 	if (h->h_c48) hipHostFree(h->h_c48);
+	hipFree(h->d_v2hist); hipFree(h->d_v2f); hipFree(h->d_v2prom); hipFree(h->d_v2en);
+	if (h->h_v2f) hipHostFree(h->h_v2f); if (h->h_v2prom) hipHostFree(h->h_v2prom); if (h->h_v2en) hipHostFree(h->h_v2en);
 	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); hipFree(h->d_ckw[i]); hipFree(h->d_ck8[i]); }
 	hipFree(h->d_qflag); hipFree(h->d_qflag4);
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
@@ -1613,8 +1648,12 @@ int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* o) {
 	o->ppm = h->h_ppm + (size_t)sub * C * h->W + chan * h->W;
 	o->group_window = nullptr;
 	o->first_sample48 = so.first48;
-	o->fm_bits = (h->challenger || h->base) ? h->h_fmbits + (size_t)sub * C * (h->L / 32) + chan * (h->L / 32) : nullptr;
+	o->fm_bits = (h->challenger || h->base || (h->v2 && h->v2_assist)) ? h->h_fmbits + (size_t)sub * C * (h->L / 32) + chan * (h->L / 32) : nullptr;
 	o->c48 = h->v2 ? (const float*)(h->h_c48 + ((size_t)sub * C + chan) * h->L) : nullptr;
+	const bool va = h->v2 && h->v2_assist;
+	o->v2_f = va ? h->h_v2f + ((size_t)sub * C + chan) * 2 * h->W : nullptr;
+	o->v2_prom = va ? h->h_v2prom + ((size_t)sub * C + chan) * 2 * h->W : nullptr;
+	o->v2_energy = va ? h->h_v2en + ((size_t)sub * C + chan) * (h->W + 1) : nullptr;
 	return AISGPU_OK;
 }
 

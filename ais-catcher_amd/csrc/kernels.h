@@ -244,6 +244,30 @@ struct K5Params { // ModelChallenger FM branch (Model.cpp:638-639): Demod::FM ->
 constexpr int FM_HIST = 36;
 
 hipError_t launch_k5(const K5Params& p, int n_chan, hipStream_t s);
+
+// ModelEngineV2 (-m 11): what V2::Engine computes from the 48 kHz channel ALONE -- i.e. everything that does not depend on the
+// state of its decoders -- for all 512-sample blocks of a batch at once (DSP/Decoder/V2/V2Engine.cpp):
+//   * FreqOffset::Estimate (:56-131) of every window that Engine::CGF can ask for without a learned slot phase: the windows
+//     at offset 0 and 256 of every block (:312-314), i.e. every 256 samples; f and prominence per window
+//   * the two half-block energies midWins compares (:281-291)
+//   * FMDemod::Run with atan2_fast (:244-273) and FilterFL37 (:175-188): the sign of the filtered discriminator per sample
+// The host engine keeps what closes over its decoders every 512 samples: tone gate, derotation (std::polar of an interpolated
+// frequency: libm), FilterFL17, PhaseTracker, BitPLL, the decoders, the slot-phase learner (:293-388).
+constexpr int V2_HIST = 512; // samples of the previous block kept in front of the current one (one engine block of look-back)
+struct KV2Params {
+	const float2* c48; long long c48_stride;   // this block's 48 kHz channels
+	float2* hist;                               // [n_chan][V2_HIST] last samples of the previous block (zeros before the stream); updated at the end
+	const float2* omega;                        // FFT twiddles
+	float* est_f; float* est_prom;              // [n_chan][2 * n_windows]: window w starts at sample -512 + 256 w of this block
+	float* energy;                              // [n_chan][n_windows + 1]: sum of |x|^2 over [-512 + 512 i, +256)
+	float* disc;                                // [n_chan][FM_HIST + L] discriminator (FM_HIST leading history), as K5
+	float2* fmprev;                             // [n_chan] FMDemod::prev (0 in front of the first sample: the engine's all-zero look-back block has passed)
+	uint32_t* fmbits; long long fmbits_stride;  // [n_chan][L / 32]
+	float* fir_out; long long fir_stride;       // optional (taps): the FilterFL37 output itself
+	float taps[37];
+	int n_windows, L, n_chan;
+};
+hipError_t launch_kv2(const KV2Params& p, hipStream_t s);
 hipError_t launch_k4(const K4Params& p, hipStream_t s);          // chunk-parallel + assemble + (conditional) exact fallback
 // one lane per (chain, chunk): sign words + verification; the (conditional) exact fallback; the sequential integer walk
 hipError_t launch_k4_lane_words(const K4Params& p, const K4Params* walk_prev, hipStream_t s); // walk_prev: the previous block's walk rides along

@@ -3102,6 +3102,167 @@ __global__ __launch_bounds__(256) void k5_filter(K5Params p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// KV2: the decoder-independent part of V2::Engine (ModelEngineV2, DSP/Decoder/V2/V2Engine.cpp), see kernels.h.
+// ------------------------------------------------------------------------------------------
+// sample n of the stream relative to this block's first sample; n in [-V2_HIST, L)
+__device__ __forceinline__ float2 v2_sample(const KV2Params& p, int chan, int n) {
+	return n < 0 ? p.hist[(size_t)chan * V2_HIST + (V2_HIST + n)] : p.c48[(size_t)chan * p.c48_stride + n];
+}
+
+// FreqOffset::Estimate (:56-131) for FFT_NW windows per wave: the FFT of the squared window with the reference's butterflies
+// (fft512 passes as in k2_fft_mag), magnitudes sqrtf(re^2 + im^2) in float (norm2, :33-36) in fftshift order, then one lane
+// per window runs the reference's loops in their order: the rolling 133-bin sum (two dependent operations per step), the peak
+// pair 102 bins apart, the total, the prominence and the parabola through the three pair sums.
+__global__ __launch_bounds__(64) void kv2_estimate(KV2Params p) {
+	__shared__ __attribute__((aligned(16))) float2 X[584];
+	__shared__ __attribute__((aligned(16))) float mag[FFT_NW * MAG_STRIDE];
+	const int lane = threadIdx.x;
+	const int nw = 2 * p.n_windows;
+	const int W0 = blockIdx.x * FFT_NW, n_win_total = p.n_chan * nw;
+	FftTwiddles t = fft_twiddles(p.omega, lane);
+	const int src = fft_src_lane(lane);
+	for (int wi = 0; wi < FFT_NW; wi++) {
+		const int W = W0 + wi;
+		if (W >= n_win_total) break;
+		const int chan = W / nw, w = W - chan * nw;
+		const int s0 = -V2_HIST + 256 * w;
+		float2 dn[8];
+#pragma unroll
+		for (int r = 0; r < 8; r++) dn[r] = v2_sample(p, chan, s0 + src + fft_src_step(r));
+		c2 v[8];
+		fft_square(dn, v); // window[n] * window[n] into the bit-reversed position (:63-64)
+		const int l7 = lane & 7, l8 = lane >> 3;
+		fft_pass(v, t.a0, t.a1, t.a2);
+#pragma unroll
+		for (int r = 0; r < 8; r++) X[9 * lane + r] = make_float2(v[r].x, v[r].y);
+		wave_sync();
+#pragma unroll
+		for (int r = 0; r < 8; r++) { const float2 d = X[l7 + 9 * r + 72 * l8]; v[r] = c2{ d.x, d.y }; }
+		wave_sync();
+		fft_pass(v, t.b0, t.b1, t.b2);
+#pragma unroll
+		for (int r = 0; r < 8; r++) X[l7 + 8 * r + 72 * l8] = make_float2(v[r].x, v[r].y);
+		wave_sync();
+#pragma unroll
+		for (int r = 0; r < 8; r++) { const float2 d = X[lane + 72 * r]; v[r] = c2{ d.x, d.y }; }
+		wave_sync();
+		fft_pass(v, t.c0, t.c1, t.c2_); // bin lane + 64 r
+		float* mg = mag + wi * MAG_STRIDE;
+#pragma unroll
+		// sqrtf(norm2(x)) (:69-72): the float square root through the correctly rounded double one (53 >= 2 * 24 + 2 bits: exact)
+		for (int r = 0; r < 8; r++) mg[(lane + 64 * r + 256) & 511] = (float)__dsqrt_rn((double)(v[r].x * v[r].x + v[r].y * v[r].y));
+	}
+	wave_sync();
+	const int W = W0 + lane;
+	if (lane < FFT_NW && W < n_win_total) {
+		const float* m = mag + lane * MAG_STRIDE;
+		constexpr int N = 512, delta = 102, M = 133, ofs = 15;
+		float rolling = 0.0f;
+		for (int jx = 0; jx < M; jx++) rolling += m[jx];
+		float best = rolling + 0.6f * (m[ofs] + m[ofs + delta]);
+		int wi_ = 0;
+		for (int i = 1; i <= N - M; i++) {
+			rolling = rolling - m[i - 1] + m[i + M - 1];
+			const float v = rolling + 0.6f * (m[i + ofs] + m[i + ofs + delta]);
+			if (v > best) { best = v; wi_ = i; }
+		}
+		int fz = -1;
+		float peak = 0.0f;
+		for (int i = wi_; i < wi_ + (M - delta); i++) {
+			const float h = m[i] + m[i + delta];
+			if (h > peak) { peak = h; fz = i; }
+		}
+		float total = 0.0f;
+		for (int i = 0; i < N; i++) total += m[i];
+		const float prom = total > 0.0f ? __fdiv_rn(peak * (float)(N / 2), total) : 0.0f;
+		float f = 0.0f;
+		if (fz >= 0) {
+			float frac = 0.0f;
+			if (fz > 0 && fz + delta + 1 < N) {
+				const float a = m[fz - 1] + m[fz - 1 + delta];
+				const float c = m[fz + 1] + m[fz + 1 + delta];
+				const float den = a - 2.0f * peak + c;
+				if (den < 0.0f) {
+					frac = __fdiv_rn(0.5f * (a - c), den);
+					frac = frac > 0.5f ? 0.5f : (frac < -0.5f ? -0.5f : frac);
+				}
+			}
+			f = __fdiv_rn(__fdiv_rn((float)(N / 2) - ((float)fz + frac + 51.0f), 2.0f), (float)N);
+		}
+		p.est_f[W] = f;
+		p.est_prom[W] = prom;
+	}
+}
+
+// half-block energies (midWins, :281-291): one lane per (channel, block start -512 + 512 i), 256 terms in order
+__global__ __launch_bounds__(64) void kv2_energy(KV2Params p) {
+	const int id = blockIdx.x * 64 + threadIdx.x;
+	const int per = p.n_windows + 1;
+	if (id >= p.n_chan * per) return;
+	const int chan = id / per, i = id - chan * per;
+	const int s0 = -V2_HIST + 512 * i;
+	float e = 0.0f;
+	for (int n = 0; n < 256; n++) {
+		const float2 z = v2_sample(p, chan, s0 + n);
+		e += z.x * z.x + z.y * z.y;
+	}
+	p.energy[id] = e;
+}
+
+// octant-reduced polynomial arctangent (:244-263), operation by operation
+__device__ __forceinline__ float atan2_fast_ref(float y, float x) {
+	const float ax = fabsf(x), ay = fabsf(y);
+	const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+	if (mx == 0.0f) return 0.0f;
+	const float a = __fdiv_rn(mn, mx), s = a * a;
+	float r = ((-0.0464964749f * s + 0.15931422f) * s - 0.327622764f) * s * a + a;
+	if (ay > ax) r = 1.57079637f - r;
+	if (x < 0.0f) r = 3.14159274f - r;
+	return y < 0.0f ? -r : r;
+}
+
+__global__ __launch_bounds__(256) void kv2_fm(KV2Params p) { // FMDemod::Run (:265-273)
+	const int chan = blockIdx.y;
+	const int n = blockIdx.x * 256 + threadIdx.x;
+	if (n >= p.L) return;
+	const float2* y = p.c48 + (size_t)chan * p.c48_stride + n;
+	const float2 d = y[0];
+	const float2 pv = n == 0 ? p.fmprev[chan] : y[-1];
+	const float npi = -pv.y; // input[i] * std::conj(prev)
+	const float re = d.x * pv.x - d.y * npi;
+	const float im = d.x * npi + d.y * pv.x;
+	p.disc[(size_t)chan * (FM_HIST + p.L) + FM_HIST + n] = __fdiv_rn(atan2_fast_ref(im, re), 3.14159265358979323846f);
+}
+
+// FilterFL37 (:48-54, :175-188): out[n] = sum_{i<18} (a[i] + a[36 - i]) * taps[i] + a[18] * taps[18] over a = disc[n-36 .. n]
+__global__ __launch_bounds__(256) void kv2_filter(KV2Params p) {
+	const int chan = blockIdx.y;
+	const int n = blockIdx.x * 256 + threadIdx.x; // L is a multiple of 512
+	const float* a = p.disc + (size_t)chan * (FM_HIST + p.L) + n; // a[i] = disc[n - 36 + i]
+	float sum = 0.0f;
+#pragma unroll
+	for (int i = 0; i < 18; i++) sum += (a[i] + a[36 - i]) * p.taps[i];
+	sum = sum + a[18] * p.taps[18];
+	if (p.fir_out) p.fir_out[(size_t)chan * p.fir_stride + n] = sum;
+	const unsigned long long b = __ballot(sum > 0.0f);
+	if ((threadIdx.x & 63) == 0) {
+		uint32_t* o = p.fmbits + (size_t)chan * p.fmbits_stride + (n >> 5);
+		o[0] = (uint32_t)b;
+		o[1] = (uint32_t)(b >> 32);
+	}
+}
+
+// after everything above has read them: the block's tail becomes the next block's look-back
+__global__ __launch_bounds__(64) void kv2_carry(KV2Params p) {
+	const int chan = blockIdx.x;
+	float* dsc = p.disc + (size_t)chan * (FM_HIST + p.L);
+	if (threadIdx.x < FM_HIST) dsc[threadIdx.x] = dsc[p.L + threadIdx.x];
+	const float2* x = p.c48 + (size_t)chan * p.c48_stride + (p.L - V2_HIST);
+	for (int i = threadIdx.x; i < V2_HIST; i += 64) p.hist[(size_t)chan * V2_HIST + i] = x[i];
+	if (threadIdx.x == 0) p.fmprev[chan] = p.c48[(size_t)chan * p.c48_stride + p.L - 1];
+}
+
+// ------------------------------------------------------------------------------------------
 // K7: AIS::Decoder (Marine/AIS.h:82-181, Marine/AIS.cpp:33-142) on the device -- NRZI, training / start-flag state machine,
 // bit de-stuffing, CRC-16 residue check, the early-abort heuristics and the Reset mesh between the five decoders of a
 // channel (DSP/Model.cpp:566-573).  One lane per decoder, the five decoders of a channel in adjacent lanes (12 channels per
@@ -3987,6 +4148,16 @@ hipError_t launch_k3(const K3Params& p, int n_chan, hipStream_t s) {
 
 hipError_t launch_k7(const K7Params& p, hipStream_t s) {
 	hipLaunchKernelGGL(k7_decode, dim3((p.n_chan + 11) / 12), dim3(64), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_kv2(const KV2Params& p, hipStream_t s) {
+	const int n_est = p.n_chan * 2 * p.n_windows;
+	hipLaunchKernelGGL(kv2_estimate, dim3((n_est + FFT_NW - 1) / FFT_NW), dim3(64), 0, s, p);
+	hipLaunchKernelGGL(kv2_energy, dim3((p.n_chan * (p.n_windows + 1) + 63) / 64), dim3(64), 0, s, p);
+	hipLaunchKernelGGL(kv2_fm, dim3(p.L / 256, p.n_chan), dim3(256), 0, s, p);
+	hipLaunchKernelGGL(kv2_filter, dim3(p.L / 256, p.n_chan), dim3(256), 0, s, p);
+	hipLaunchKernelGGL(kv2_carry, dim3(p.n_chan), dim3(64), 0, s, p);
 	return hipGetLastError();
 }
 

@@ -59,6 +59,9 @@ class Out(ctypes.Structure):
         ("first_sample48", ctypes.c_longlong),
         ("fm_bits", ctypes.POINTER(ctypes.c_uint32)),
         ("c48", ctypes.POINTER(ctypes.c_float)),
+        ("v2_f", ctypes.POINTER(ctypes.c_float)),
+        ("v2_prom", ctypes.POINTER(ctypes.c_float)),
+        ("v2_energy", ctypes.POINTER(ctypes.c_float)),
     ]
 
 
@@ -185,8 +188,13 @@ class AisGpu:
         c48 = None
         if o.c48:
             c48 = np.ctypeslib.as_array(o.c48, shape=(o.n_windows * 1024,)).copy().view(np.complex64)
+        v2 = None
+        if o.v2_f:
+            W = o.n_windows
+            v2 = dict(f=np.ctypeslib.as_array(o.v2_f, shape=(2 * W,)).copy(), prom=np.ctypeslib.as_array(o.v2_prom, shape=(2 * W,)).copy(),
+                      energy=np.ctypeslib.as_array(o.v2_energy, shape=(W + 1,)).copy())
         return dict(bits=bits, lvl=lvl, ppm=ppm, first_group=o.first_group, first_sample48=o.first_sample48,
-                    n_groups=n, n_windows=o.n_windows, fm_bits=fm, c48=c48)
+                    n_groups=n, n_windows=o.n_windows, fm_bits=fm, c48=c48, v2=v2)
 
     def frames(self):
         """AISGPU_FLAG_GPU_DECODE: list of dicts, the frames completed since the previous sync_outputs()."""

@@ -171,7 +171,11 @@ void GpuChain::process(const void* data, int len, TAG& tag) {
 			for (int ch = 0; ch < 2; ch++) {
 				const aisgpu_out& c = o[ch];
 				const int n1 = n0 + step < L ? n0 + step : L;
-				if (c.c48) (ch == 0 ? outC48a : outC48b).Send((const CFLOAT32*)c.c48 + n0, n1 - n0, tag);
+				if (c.c48) {
+					if (on_c48) on_c48(ch, c, n0);
+					(ch == 0 ? outC48a : outC48b).Send((const CFLOAT32*)c.c48 + n0, n1 - n0, tag);
+					if (on_c48_done && n1 == L) on_c48_done(ch, L);
+				}
 				else if (c.fm_bits && c.n_groups == 0) replayBase(ch == 0 ? outFMa : outFMb, c, tag, n0, n1);
 				else if (c.fm_bits) replayChallenger(ch == 0 ? outA : outB, ch == 0 ? outAf : outBf, c, tag, n0, n1);
 				else replay(ch == 0 ? outA : outB, c, tag, n0, n1);
@@ -237,6 +241,11 @@ void ModelDefaultGPU::wireDecoders(char CH1, char CH2) {
 		V2_b.setWeights(dd_train, dd_weight);
 		chain.outC48a >> V2_a;
 		chain.outC48b >> V2_b;
+		// what the device computed ahead for the engine blocks of this data (estimates, energies, discriminator signs)
+		chain.on_c48 = [this](int ch, const aisgpu_out& o, int n0) {
+			(ch == 0 ? V2_a : V2_b).setAssist(o.v2_f, o.v2_prom, o.v2_energy, o.v2_f ? o.fm_bits : nullptr, n0 / V2Engine::BLOCK);
+		};
+		chain.on_c48_done = [this](int ch, int L) { (ch == 0 ? V2_a : V2_b).finishAssist(L); };
 		for (int i = 0; i < V2Engine::N_DECODERS; i++) {
 			V2_a.getDecoder(i).out.Connect(&fan);
 			V2_b.getDecoder(i).out.Connect(&fan);

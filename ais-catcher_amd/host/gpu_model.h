@@ -135,6 +135,9 @@ public:
 	int status() const { return last_status; }                      // AISGPU_* status of the last Receive()
 	void setErrorHandler(std::function<void(const std::string&)> f) { on_error = f; }
 	void setFrameHandler(std::function<void(const aisgpu_frame&, TAG&)> f) { on_frame = f; }
+	// ModelEngineV2: called before / after the 48 kHz samples of a device block go out on outC48x (device assist of the engines)
+	std::function<void(int ch, const aisgpu_out&, int first_sample)> on_c48;
+	std::function<void(int ch, int L)> on_c48_done;
 	void Receive(const CFLOAT32* data, int len, TAG& tag) override { process(data, len, tag); }
 	void Receive(const CU8* data, int len, TAG& tag) override { process(data, len, tag); }
 	// the raw integer formats Util::ConvertRAW turns into CFLOAT32 (Utilities/StreamHelpers.cpp:91-106): converted on the device

@@ -195,8 +195,13 @@ void V2Engine::correctFrequency(const CFLOAT32* in, CFLOAT32* out, bool busy) { 
 		tone.derotate(f, in + e, out + e, BLOCK - e);
 	} else {
 		ppm_split = 0;
-		const int offset = (!busy && laterHalfIsLouder(in)) ? BLOCK / 2 : 0;
-		f = tone.estimate(in + offset);
+		// (with device assist the two candidate windows' estimates and the two energies are there already: aisgpu_out.v2_*)
+		const bool louder = as_en ? as_en[as_i + 1] > as_en[as_i] : laterHalfIsLouder(in);
+		const int offset = (!busy && louder) ? BLOCK / 2 : 0;
+		if (as_f) {
+			f = as_f[2 * as_i + (offset ? 1 : 0)];
+			tone.prominence = as_prom[2 * as_i + (offset ? 1 : 0)];
+		} else f = tone.estimate(in + offset);
 		if (busy && tone.prominence < PROMINENCE_GATE) f = tone.last_f; // tone gate: hold while a decode is in flight
 		tone.derotate(f, in, out, BLOCK);
 	}
@@ -221,12 +226,20 @@ void V2Engine::block(TAG& tag) { // Engine::processBlock (:345-388)
 	for (int j = 0; j < 5; j++) busy |= dec[j].getState() != AIS::State::TRAINING;
 	correctFrequency(raw, derot, busy);
 	fir17(derot, coh);
-	for (int i = 0; i < BLOCK; i++) { // FMDemod::Run (:265-273) on the uncorrected block
-		const CFLOAT32 p = mul(raw[i], std::conj(fm_prev));
-		disc[i] = arctan2(p.imag(), p.real()) / PI_F;
-		fm_prev = raw[i];
+	if (as_fm) { // the device ran FMDemod + FilterFL37; only the sign is looked at below (BitPLL, NRZI)
+		for (int i = 0; i < BLOCK; i++) {
+			const int n = BLOCK * (as_i - 1) + i; // the decoded block is the one BEFORE the look-ahead block as_i
+			const uint32_t w = n >= 0 ? as_fm[n >> 5] : fm_tail[i >> 5];
+			disc_f[i] = ((w >> (n & 31)) & 1u) ? 1.0f : -1.0f;
+		}
+	} else {
+		for (int i = 0; i < BLOCK; i++) { // FMDemod::Run (:265-273) on the uncorrected block
+			const CFLOAT32 p = mul(raw[i], std::conj(fm_prev));
+			disc[i] = arctan2(p.imag(), p.real()) / PI_F;
+			fm_prev = raw[i];
+		}
+		fir37(disc, disc_f);
 	}
-	fir37(disc, disc_f);
 	tag.ppm = ppm_prev;
 	for (int i = 0; i < BLOCK; i++) {
 		if (i == ppm_split) tag.ppm = ppm;
@@ -242,6 +255,7 @@ void V2Engine::block(TAG& tag) { // Engine::processBlock (:345-388)
 		di = di + 1 == 5 ? 0 : di + 1;
 	}
 	std::memmove(raw, raw + BLOCK, BLOCK * sizeof *raw);
+	as_i++;
 }
 
 void V2Engine::Receive(const CFLOAT32* data, int len, TAG& tag) { // :390-406

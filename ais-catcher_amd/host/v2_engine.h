@@ -66,6 +66,13 @@ private:
 	long long sample_idx = 0;
 	float ppm = 0.0f, ppm_prev = 0.0f;
 
+	// ---- what the device has already computed for the engine blocks of the data that is being received (aisgpu_out.v2_*):
+	// the frequency estimates of the offset-0 / offset-256 windows, midWins' energies and the sign of the filtered discriminator
+	const float *as_f = nullptr, *as_prom = nullptr, *as_en = nullptr;
+	const uint32_t* as_fm = nullptr;
+	int as_i = 0;              // engine block (within the device's block) that the next block() call decodes the look-back of
+	uint32_t fm_tail[BLOCK / 32] = {}; // discriminator signs of the previous device block's last 512 samples
+
 	bool laterHalfIsLouder(const CFLOAT32* in) const;
 	void correctFrequency(const CFLOAT32* in, CFLOAT32* out, bool busy);
 	void learnSlot(const AIS::Decoder& d);
@@ -81,6 +88,16 @@ public:
 		for (auto& d : dec) d.setOrigin(channel, station, own_mmsi);
 	}
 	AIS::Decoder& getDecoder(int i) { return dec[i]; }
+	// Device assist for the NEXT Receive() call: the arrays of aisgpu_out (v2_f, v2_prom, v2_energy, fm_bits) of the device block the
+	// data belongs to and the index of the data's first 512-sample engine block inside it.  nullptr switches back to host-only.
+	void setAssist(const float* f, const float* prom, const float* energy, const uint32_t* fm_bits, int first_engine_block) {
+		as_f = f; as_prom = prom; as_en = energy; as_fm = fm_bits; as_i = first_engine_block;
+	}
+	// after the last Receive() of a device block of L samples: keep the discriminator signs of its last 512 samples
+	void finishAssist(int L) {
+		if (as_fm) for (int w = 0; w < BLOCK / 32; w++) fm_tail[w] = as_fm[(L - BLOCK) / 32 + w];
+		as_f = as_prom = as_en = nullptr; as_fm = nullptr;
+	}
 	void Receive(const CFLOAT32* data, int len, TAG& tag) override;
 };
 

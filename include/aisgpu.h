@@ -108,6 +108,17 @@ typedef struct aisgpu_out {
 	                          * sample first_sample48 + n is > 0 (what Deinterleave S_af hands to DEC_af[n % 5], Model.cpp:638-639) */
 	const float* c48;        /* AISGPU_MODEL_V2 only (else NULL): the channel's 48 kHz front-end output of this block (FCIC5_a/b.out, Model.cpp:345-346),
 	                          * 512 * n_windows complex samples, interleaved re/im; n_groups is 0 */
+	/* AISGPU_MODEL_V2 only (else NULL): what V2::Engine computes from the channel alone, for every 512-sample engine block of
+	 * this block at once (DSP/Decoder/V2/V2Engine.cpp).  Engine block i (i = 0 .. n_windows-1) is the one the engine decodes
+	 * when block-relative samples [512 i, 512 i + 512) arrive as its look-ahead, i.e. samples [512 i - 512, 512 i):
+	 *   v2_f[2 i], v2_prom[2 i]          FreqOffset::Estimate (:56-131) of the window at offset 0 of that engine block (f, prominence)
+	 *   v2_f[2 i + 1], v2_prom[2 i + 1]  ... at offset 256 (Engine::CGF's "mid" window, :312-314)
+	 *   v2_energy[i], v2_energy[i + 1]   midWins' head / tail sums (:281-291)
+	 *   fm_bits (above)                  bit n: FilterFL37(FMDemod(x))[n] > 0 for block-relative sample n (:244-273, :175-188)
+	 * The windows an engine asks for once it has learned a slot phase (:300-309) are not among them: it computes those itself. */
+	const float* v2_f;
+	const float* v2_prom;
+	const float* v2_energy;  /* n_windows + 1 values */
 } aisgpu_out;
 
 void aisgpu_default_cfg(aisgpu_cfg* cfg);

@@ -24,6 +24,7 @@
 
 #include "Model.h"
 #include "Device.h"
+#include "Filters.h"
 #ifdef HASMI355X
 #include "ModelGPU.h" // the reference-side binding of libaisgpu.so (integration/reference/Source/DSP/GPU): engines 12 / 14
 #endif
@@ -262,6 +263,27 @@ long long ref_bits(void* hv, int ch, int j, int fm, float* bits, float* lvl, lon
 	if (lvl) memcpy(lvl, r.lvl.data(), sizeof(float) * (size_t)c);
 	if (idx) memcpy(idx, r.idx.data(), sizeof(long long) * (size_t)c);
 	return n;
+}
+
+// ---- V2::Engine's decoder-independent stages as stand-alone functions (the structs are public, V2Engine.h:32-101)
+// FreqOffset::Estimate of one 512-sample window (complex, interleaved): f and the prominence it leaves behind
+void ref_v2_estimate(const float* window, float* f, float* prom) {
+	V2::FreqOffset fo;
+	*f = fo.Estimate((const CFLOAT32*)window);
+	*prom = fo.prominence;
+}
+// FMDemod + FilterFL37 over n (multiple of 512) samples of a stream that starts behind the engine's all-zero look-back block
+void ref_v2_fm(const float* x, int n, float* disc, float* filt) {
+	V2::FMDemod fm;
+	V2::FilterFL37 fl(Filters::Receiver.data());
+	std::vector<CFLOAT32> zero(V2::BLOCK_SIZE, CFLOAT32(0.0f, 0.0f));
+	std::vector<float> d(V2::BLOCK_SIZE), o(V2::BLOCK_SIZE);
+	fm.Run(zero.data(), d.data());
+	fl.Run(d.data(), o.data());
+	for (int b = 0; b + V2::BLOCK_SIZE <= n; b += V2::BLOCK_SIZE) {
+		fm.Run((const CFLOAT32*)x + b, disc + b);
+		fl.Run(disc + b, filt + b);
+	}
 }
 
 // Message::ID is the process-global multi-sentence sequence counter (Marine/Message.cpp:28-39)

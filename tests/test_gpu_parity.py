@@ -1195,3 +1195,64 @@ def test_device_decoders_of_the_other_engines_on_a_noisy_batch():
             batch.close()
         assert out[0] == out[1], "model %d" % model
         assert sum(len(o) for o in out[0]) >= R
+
+
+@pytest.mark.skipif(not checkers.have_ref(), reason="needs the compiled reference (V2::FreqOffset / FMDemod / FilterFL37 called directly)")
+@pytest.mark.parametrize("rate,fmt,block", [(1536000, "cf32", 131072), (1536000, "cu8", 786432), (288000, "cf32", 49152)])
+def test_engine_v2_device_stages_against_the_reference_structs(rate, fmt, block):
+    """f2: what V2::Engine computes from the 48 kHz channel alone runs on the device for every engine block of a batch --
+    FreqOffset::Estimate (f and prominence) of the offset-0 / offset-256 windows, midWins' half-block energies, FMDemod with
+    atan2_fast + FilterFL37.  Compared as FLOATS, bit for bit, with the reference's own structs (V2Engine.h:32-101) run on the
+    device's 48 kHz samples (themselves bit-exact with the reference, test_model_engine_v2_end_to_end)."""
+    import ctypes
+    lib = ctypes.CDLL(checkers.os.path.join(checkers.ORACLE_DIR, "_ref", "libaisref_strict.so"))
+    lib.ref_v2_estimate.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    lib.ref_v2_estimate.restype = None
+    lib.ref_v2_fm.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.ref_v2_fm.restype = None
+    nblocks = 4
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=250, gap_slots=(0, 2))
+    data = synth.to_cu8(x) if fmt == "cu8" else x
+    per = 1 if fmt == "cf32" else 2
+    g = gpu.AisGpu(sample_rate=rate, block_len=block, input_format=_FMT[fmt], model=gpu.MODEL_V2, taps=True)
+    L = block // (rate // 48000)
+    W = L // 512
+    stream = [np.zeros(512, np.complex64), np.zeros(512, np.complex64)]   # the engine's look-back in front of the stream
+    filt_all = [[], []]
+    for b in range(nblocks):
+        g.submit(0, data[b * block * per:(b + 1) * block * per])
+        g.run()
+        g.sync_outputs()
+        for ch in range(2):
+            o = g.fetch(0, ch)
+            prev_tail = stream[ch][-512:]
+            cur = o["c48"]
+            ext = np.concatenate([prev_tail, cur])            # sample -512 .. L-1 of this block
+            v2 = o["v2"]
+            for w in range(2 * W):
+                win = np.ascontiguousarray(ext[256 * w:256 * w + 512])
+                f, prom = ctypes.c_float(), ctypes.c_float()
+                lib.ref_v2_estimate(win.ctypes.data, ctypes.byref(f), ctypes.byref(prom))
+                assert np.float32(f.value).view(np.uint32) == v2["f"][w:w + 1].view(np.uint32)[0], "f blk %d ch %d window %d" % (b, ch, w)
+                assert np.float32(prom.value).view(np.uint32) == v2["prom"][w:w + 1].view(np.uint32)[0], "prominence blk %d ch %d window %d" % (b, ch, w)
+            for i in range(W + 1):
+                e = np.float32(0.0)
+                seg = ext[512 * i:512 * i + 256]
+                for z in seg:  # midWins sums in order
+                    e = np.float32(e + np.float32(np.float32(z.real * z.real) + np.float32(z.imag * z.imag)))
+                assert e.view(np.uint32) == v2["energy"][i:i + 1].view(np.uint32)[0], "energy blk %d ch %d %d" % (b, ch, i)
+            stream[ch] = np.concatenate([stream[ch], cur])
+            filt_all[ch].append((g.tapf(6 + ch), g.tapf(8 + ch), o["fm_bits"]))
+    g.close()
+    for ch in range(2):
+        xs = np.ascontiguousarray(stream[ch][512:])
+        n = len(xs)
+        disc, filt = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        lib.ref_v2_fm(xs.ctypes.data, n, disc.ctypes.data, filt.ctypes.data)
+        got_d = np.concatenate([t[0] for t in filt_all[ch]])
+        got_f = np.concatenate([t[1] for t in filt_all[ch]])
+        got_b = np.concatenate([t[2] for t in filt_all[ch]])
+        assert np.array_equal(got_d.view(np.uint32), disc.view(np.uint32)), "FMDemod ch %d" % ch
+        assert np.array_equal(got_f.view(np.uint32), filt.view(np.uint32)), "FilterFL37 ch %d" % ch
+        assert np.array_equal(got_b.astype(bool), filt > 0)
+        assert np.any(filt != 0)
