@@ -114,7 +114,10 @@ struct aisgpu {
 	hipEvent_t ev_k3[2] = {};         // front stream: sym/lvl[p] of block f written -> s2 may run K4(f)
 	hipEvent_t ev_k4[2] = {};         // s2: bits[p] of block f written -> s5 may run the frame decoder
 	// device buffers
-	void* d_in = nullptr; void* d_hist[2] = {}; void* d_hist2[2] = {}; // input tails, double buffered (read by span 0, written for the next block)
+	void* d_in[2] = {}; void* d_hist[2] = {}; void* d_hist2[2] = {}; // input tails, double buffered (read by span 0, written for the next block)
+	// staging of host blocks (aisgpu_submit), double buffered by input block: block f+1 is copied in (pinned buffer, then H2D on a
+	// copy stream of its own) while block f is still being computed
+	hipStream_t sc = nullptr; hipEvent_t ev_h2d[2] = {}, ev_in_free[2] = {}; bool in_used[2] = {}; std::mutex submit_mtx; bool staged = false;
 	float2* d_xpre[2] = {};           // pre-decimated stream: [R][xh + n_pre], ping-pong by input block (MODE_PRE uses [0] only)
 	float2* d_xmid = nullptr;         // [R][block_len >> KPa]: between the two passes of a pre-decimation of more than four stages
 	bool mode_x = false;              // channel mode X: single-channel front end K1x (npost stages down to 48 kHz), channel B silent
@@ -144,7 +147,7 @@ struct aisgpu {
 	bool walk_ride = true;
 	bool ps_lane = false; int walk_prio = 3; int ps_prio = 0; int ps_cl = 512; uint2* d_pslw[2] = {}; // lane-per-chunk PhaseSearchEMA: chunk length, sign words [n_chains][Gcap]
 	// host (pinned)
-	void* h_in = nullptr;
+	void* h_in[2] = {};
 	float2* h_rot[2] = {};
 	int* h_usidx[2] = {}; float* h_usalpha[2] = {};
 	hipEvent_t rot_ev[2] = {}; bool rot_ev_used[2] = {}; bool rot_ahead = false; // (rot_ahead: the next block's table is already on its way)
@@ -168,6 +171,7 @@ struct aisgpu {
 	const void* cur_in = nullptr; long long cur_in_stride = 0;
 	bool submitted = false, have_out = false;
 	SubOut sub[MAXSUB]; int n_sub = 0;
+	SubOut osub[MAXSUB]; int n_osub = 0; // the downstream blocks whose outputs the last aisgpu_sync_outputs() brought to the host (what fetch serves)
 	struct { bool valid = false; int q = 0, pb = 0, lv = 0; long long g0 = 0, g1 = 0, first48 = 0; unsigned block = 0, sub = 0; } pend; // deferred second half
 	bool defer = true;
 	// device frame decoder (AISGPU_FLAG_GPU_DECODE)
@@ -778,8 +782,8 @@ int gather_frames(aisgpu_t* h) {
 	// channels every 4096 samples at 48 kHz (and GpuChain::process replays in that order); elsewhere channel A's whole block
 	// comes first.  slice = the 4096-sample piece of its downstream block in which the frame closed.
 	const auto slice_of = [&](const aisgpu_frame& x) -> long long {
-		if (h->rot_period <= 0 || x.sub < 0 || x.sub >= h->n_sub) return 0;
-		const SubOut& so = h->sub[x.sub];
+		if (h->rot_period <= 0 || x.sub < 0 || x.sub >= h->n_osub) return 0;
+		const SubOut& so = h->osub[x.sub];
 		const long long n_rel = h->dec_kind == 3 ? x.group : 5 * (so.first_group + x.group) + (h->dec_kind == 1 ? x.phase : 4) - so.first48;
 		return n_rel / 4096;
 	};
@@ -1305,7 +1309,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	}
 	for (auto& p : h->ev_free) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
 	hipFree(h->d_xmid);
-	hipFree(h->d_in); hipFree(h->d_hist[0]); hipFree(h->d_hist[1]); hipFree(h->d_hist2[0]); hipFree(h->d_hist2[1]);
+	hipFree(h->d_in[0]); hipFree(h->d_in[1]); hipFree(h->d_hist[0]); hipFree(h->d_hist[1]); hipFree(h->d_hist2[0]); hipFree(h->d_hist2[1]);
 	hipFree(h->d_fm); hipFree(h->d_fmfir); hipFree(h->d_fmbits[0]); hipFree(h->d_fmbits[1]);
 	if (h->h_fmbits) hipHostFree(h->h_fmbits);
 	if (h->h_c48) hipHostFree(h->h_c48);
@@ -1322,7 +1326,8 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_cgf); hipFree(h->d_omega); hipFree(h->d_step);
 	hipFree(h->d_rotstate); hipFree(h->d_firtap); hipFree(h->d_ppmtab);
 	hipFree(h->d_pslw[0]); hipFree(h->d_pslw[1]); hipFree(h->d_pswords); hipFree(h->d_psma0); hipFree(h->d_psma1); hipFree(h->d_psfin); hipFree(h->d_psflag);
-	if (h->h_in) hipHostFree(h->h_in);
+	for (int i = 0; i < 2; i++) { if (h->h_in[i]) hipHostFree(h->h_in[i]); if (h->ev_h2d[i]) hipEventDestroy(h->ev_h2d[i]); if (h->ev_in_free[i]) hipEventDestroy(h->ev_in_free[i]); }
+	if (h->sc) { hipStreamSynchronize(h->sc); hipStreamDestroy(h->sc); }
 	if (h->h_bits) hipHostFree(h->h_bits);
 	if (h->h_lvl) hipHostFree(h->h_lvl);
 	if (h->h_ppm) hipHostFree(h->h_ppm);
@@ -1338,18 +1343,30 @@ int aisgpu_submit(aisgpu_t* h, int rx, const void* iq, int n_iq) {
 	if (!h || !iq || rx < 0 || rx >= h->cfg.n_receivers || n_iq != h->cfg.block_len) return AISGPU_ERR_ARG;
 	DevGuard dg(h);
 	const size_t row = (size_t)h->cfg.block_len * h->in_bytes;
-	if (!h->d_in) {
-		HIPCHK(hipMalloc(&h->d_in, row * h->cfg.n_receivers));
-		HIPCHK(hipHostMalloc(&h->h_in, row * h->cfg.n_receivers, hipHostMallocDefault));
+	int p;
+	{ // bookkeeping under a lock (receiver threads submit concurrently); the copy itself is done outside it
+		std::lock_guard<std::mutex> l(h->submit_mtx);
+		p = (int)(h->in_blocks & 1);
+		if (!h->sc) {
+			HIPCHK(hipStreamCreateWithFlags(&h->sc, hipStreamNonBlocking));
+			for (int i = 0; i < 2; i++) {
+				HIPCHK(hipMalloc(&h->d_in[i], row * h->cfg.n_receivers));
+				HIPCHK(hipHostMalloc(&h->h_in[i], row * h->cfg.n_receivers, hipHostMallocDefault));
+				HIPCHK(hipEventCreateWithFlags(&h->ev_h2d[i], hipEventDisableTiming));
+				HIPCHK(hipEventCreateWithFlags(&h->ev_in_free[i], hipEventDisableTiming));
+			}
+		}
+		if (!h->submitted) { // first row of a new block: this staging pair was last used two blocks ago
+			if (h->in_used[p]) HIPCHK(hipEventSynchronize(h->ev_in_free[p]));
+			h->cur_in = h->d_in[p];
+			h->cur_in_stride = h->cfg.block_len;
+			h->submitted = true;
+			h->staged = true;
+		}
 	}
-	// the caller's buffer is only borrowed for this call (Device/FileRAW.cpp:131-136): copy to pinned staging.
-	// The staging buffer of the previous block has been consumed once the front-end stream is idle.
-	if (!h->submitted && h->in_blocks > 0) HIPCHK(hipStreamSynchronize(h->stream));
-	memcpy((char*)h->h_in + row * rx, iq, row);
-	HIPCHK(hipMemcpyAsync((char*)h->d_in + row * rx, (char*)h->h_in + row * rx, row, hipMemcpyHostToDevice, h->stream));
-	h->cur_in = h->d_in;
-	h->cur_in_stride = h->cfg.block_len;
-	h->submitted = true;
+	// the caller's buffer is only borrowed for this call (Device/FileRAW.cpp:131-136): copy to pinned staging, then to the device
+	memcpy((char*)h->h_in[p] + row * rx, iq, row);
+	HIPCHK(hipMemcpyAsync((char*)h->d_in[p] + row * rx, (char*)h->h_in[p] + row * rx, row, hipMemcpyHostToDevice, h->sc));
 	return AISGPU_OK;
 }
 
@@ -1359,6 +1376,7 @@ int aisgpu_submit_device(aisgpu_t* h, const void* iq_dev, long long rx_stride_sa
 	h->cur_in = iq_dev;
 	h->cur_in_stride = rx_stride_samples;
 	h->submitted = true;
+	h->staged = false;
 	return AISGPU_OK;
 }
 
@@ -1369,6 +1387,11 @@ int aisgpu_run(aisgpu_t* h) {
 	const bool cu8 = h->kfmt != 0; // an integer format: converted on the fly by the front end
 	const int R = h->cfg.n_receivers;
 	h->n_sub = 0;
+	const int in_p = (int)(h->in_blocks & 1);
+	if (h->staged) { // the rows' host -> device copies run on the copy stream: the front stream waits for them
+		HIPCHK(hipEventRecord(h->ev_h2d[in_p], h->sc));
+		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_h2d[in_p], 0));
+	}
 
 	EvPair ev{};
 	auto time_begin = [&]() -> int {
@@ -1583,9 +1606,12 @@ int aisgpu_run(aisgpu_t* h) {
 		}
 		h->us_in += len;
 	}
+	if (h->staged) { // everything that reads the staged input (front end, tail copies, conversions) is on the front stream, in front of this
+		HIPCHK(hipEventRecord(h->ev_in_free[in_p], h->stream));
+		h->in_used[in_p] = true;
+	}
 	h->in_blocks++;
 	h->submitted = false;
-	h->have_out = false;
 	return AISGPU_OK;
 }
 
@@ -1618,6 +1644,8 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 	}
 	int rc = sync_all(h);
 	if (rc != AISGPU_OK) return rc;
+	h->n_osub = h->n_sub;
+	for (int i = 0; i < h->n_sub; i++) h->osub[i] = h->sub[i];
 	if (h->gpu_decode) { rc = gather_frames(h); if (rc != AISGPU_OK) return rc; }
 	h->have_out = true;
 	return AISGPU_OK;
@@ -1631,15 +1659,15 @@ int aisgpu_frames(aisgpu_t* h, const aisgpu_frame** frames, int* count) {
 	return AISGPU_OK;
 }
 
-int aisgpu_out_count(aisgpu_t* h) { return h ? h->n_sub : 0; }
+int aisgpu_out_count(aisgpu_t* h) { return h ? h->n_osub : 0; }
 
 int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* o) {
 	if (!h || !o || rx < 0 || rx >= h->cfg.n_receivers || ch < 0 || ch > 1) return AISGPU_ERR_ARG;
 	if (!h->have_out) return AISGPU_ERR_STATE;
-	if (sub < 0 || sub >= h->n_sub) return AISGPU_ERR_ARG;
+	if (sub < 0 || sub >= h->n_osub) return AISGPU_ERR_ARG;
 	const size_t C = h->n_chan;
 	const size_t chan = (size_t)rx * 2 + ch;
-	const SubOut& so = h->sub[sub];
+	const SubOut& so = h->osub[sub];
 	o->n_groups = so.groups;
 	o->first_group = so.first_group;
 	for (int j = 0; j < 5; j++) o->bits[j] = h->h_bits + (size_t)sub * C * 5 * h->words + (chan * 5 + j) * h->words;

@@ -36,6 +36,10 @@ def load():
     lib.aishost_batch_set_timeout.argtypes = [vp, ci]
     lib.aishost_batch_set_timeout.restype = None
     lib.aishost_batch_active.argtypes = [vp]
+    lib.aishost_batch_set_pipelined.argtypes = [vp, ci]
+    lib.aishost_batch_set_pipelined.restype = None
+    lib.aishost_model_flush.argtypes = [vp]
+    lib.aishost_model_flush.restype = None
     lib.aishost_model_replay.argtypes = [vp, ci, cll, cll, ci, ctypes.POINTER(vp), vp, ci, vp, vp]
     lib.aishost_model_feed48.argtypes = [vp, ci, vp, ci]
     lib.aishost_model_msg_count.argtypes = [vp]
@@ -70,6 +74,10 @@ class Batch:
     def active(self):
         return load().aishost_batch_active(self.h)
 
+    def set_pipelined(self, on=True):
+        """Hand-off one block deep: receive() of block f returns once f has been started on the device, having decoded block f-1."""
+        load().aishost_batch_set_pipelined(self.h, int(on))
+
     def close(self):
         if self.h:
             load().aishost_batch_destroy(self.h)
@@ -91,6 +99,10 @@ class ModelDefaultGPU:
         """One device block; returns the AISGPU_* status (0 = ok; e.g. 4 once the batch has evicted this receiver)."""
         block = np.ascontiguousarray(block)
         return self.lib.aishost_model_receive(self.h, block.ctypes.data, block.nbytes)
+
+    def flush(self):
+        """After the last block of a pipelined batch: collect and decode the last block's outputs."""
+        self.lib.aishost_model_flush(self.h)
 
     def leave(self):
         """End of this receiver's input: the batch it shares stops waiting for it."""

@@ -81,6 +81,9 @@ int aishost_model_receive(void* mv, const void* data, int nbytes) {
 // end of this receiver's input: a shared batch stops waiting for it
 void aishost_model_leave(void* mv) { ((Model*)mv)->m.Chain().detach(); }
 void aishost_batch_set_timeout(void* b, int ms) { ((GpuBatch*)b)->setTimeout(ms); }
+void aishost_batch_set_pipelined(void* b, int on) { ((GpuBatch*)b)->setPipelined(on != 0); }
+// after the last block of a pipelined batch: collect (and decode) the last block's outputs
+void aishost_model_flush(void* mv) { Model* m = (Model*)mv; m->m.Flush(m->tag); }
 int aishost_batch_active(void* b) { return ((GpuBatch*)b)->activeReceivers(); }
 
 int aishost_model_replay(void* mv, int ch, long long first_group, long long first_sample48, int n_groups,

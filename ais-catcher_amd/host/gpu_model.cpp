@@ -25,20 +25,33 @@ GpuBatch::~GpuBatch() { aisgpu_destroy(ctx); }
 void GpuBatch::launch() {
 	// run the whole batch for this block, copy the outputs back, release everyone (rows of receivers that are gone keep
 	// whatever their staging rows held: receivers are closed systems, nobody reads those outputs)
-	int st = aisgpu_run(ctx);
-	if (st == AISGPU_OK) st = aisgpu_sync_outputs(ctx);
+	int st = AISGPU_OK;
+	if (pipelined) { // the previous block's outputs first (the device has had the receivers' whole replay time to finish it), then start this one
+		if (generation > 0) st = aisgpu_sync_outputs(ctx);
+		if (st == AISGPU_OK && fed > 0) st = aisgpu_run(ctx);
+	} else {
+		st = aisgpu_run(ctx);
+		if (st == AISGPU_OK) st = aisgpu_sync_outputs(ctx);
+	}
 	gen_status[generation & 1] = st;
 	arrived = 0;
+	fed = 0;
 	std::fill(present.begin(), present.end(), 0);
 	generation++;
 	cv.notify_all();
 }
 
 int GpuBatch::submitAndWait(int rx, const void* iq, int n_iq) {
-	std::unique_lock<std::mutex> lock(mtx);
 	if (rx < 0 || rx >= cfg.n_receivers) return AISGPU_ERR_ARG;
-	if (gone[rx]) return AISGPU_ERR_STATE;
-	const int rc = aisgpu_submit(ctx, rx, iq, n_iq);
+	{
+		std::lock_guard<std::mutex> lock(mtx);
+		if (gone[rx]) return AISGPU_ERR_STATE;
+	}
+	// the copy into the pinned staging row happens OUTSIDE the batch lock: the receivers' threads copy their rows concurrently
+	// (aisgpu_submit is thread safe for different rx)
+	const int rc = iq ? aisgpu_submit(ctx, rx, iq, n_iq) : AISGPU_OK; // iq == nullptr: drain request of a pipelined batch
+	std::unique_lock<std::mutex> lock(mtx);
+	if (gone[rx]) return AISGPU_ERR_STATE; // (evicted meanwhile)
 	if (rc != AISGPU_OK) { // this receiver's problem only (wrong block length ...): it leaves, the others go on
 		gone[rx] = 1;
 		active--;
@@ -47,6 +60,7 @@ int GpuBatch::submitAndWait(int rx, const void* iq, int n_iq) {
 	}
 	const long long my_gen = generation;
 	present[rx] = 1;
+	if (iq) fed++;
 	if (++arrived == active) {
 		launch(); // last receiver of this block
 	} else {
@@ -127,7 +141,8 @@ void GpuChain::process(const void* data, int len, TAG& tag) {
 	}
 	// One downstream block per Receive() call of the chain behind the (optional) resampler; within it Rotate hands
 	// the whole block to channel A before channel B (reference DSP/DSP.cpp:312-313)
-	const int nsub = batch->outCount();
+	const int nsub = batch->outCount(); // (a pipelined batch serves the PREVIOUS block's outputs here: none after the first call)
+	if (nsub == 0) return;
 	if (batch->config().flags & AISGPU_FLAG_GPU_DECODE) { // the device ran the decoders: only completed frames come back
 		const aisgpu_frame* fr = nullptr;
 		int nf = 0;

@@ -88,6 +88,8 @@ class GpuBatch {
 	long long generation = 0;
 	int gen_status[2] = { AISGPU_OK, AISGPU_OK }; // status of generation g in slot g & 1 (a failed run does not poison later ones)
 	int timeout_ms = 10000;      // a receiver that has not delivered this long after the first one of a generation is evicted
+	bool pipelined = false;      // launch = collect the PREVIOUS block's outputs, then start this one: the host consumes block f-1 while the device runs f
+	int fed = 0;                 // receivers that handed in data (not a drain request) in the current generation
 	void launch();               // run the batch for the current generation and release the waiting threads (mtx held)
 
 public:
@@ -102,6 +104,12 @@ public:
 	// The receiver will not deliver any more (end of its input, or it failed): the others stop waiting for it.
 	void leave(int rx);
 	void setTimeout(int ms) { std::lock_guard<std::mutex> l(mtx); timeout_ms = ms; } // <= 0: wait for ever
+	// Pipelined hand-off: submitAndWait() of block f returns as soon as block f has been STARTED, with the outputs of block f-1 ready
+	// (aisgpu_fetch serves them until the next launch); the receivers' replay / decoding of f-1 and the copying-in of f+1 then overlap
+	// the device's work on f.  Messages come out one block later; after the last block every receiver calls submitAndWait(rx, nullptr, 0)
+	// once to collect the last outputs.  Set before the first block.
+	void setPipelined(bool b) { std::lock_guard<std::mutex> l(mtx); pipelined = b; }
+	bool isPipelined() const { return pipelined; }
 	int activeReceivers() { std::lock_guard<std::mutex> l(mtx); return active; }
 	int outCount() { return aisgpu_out_count(ctx); }
 	int fetch(int sub, int rx, int ch, aisgpu_out* out) { return aisgpu_fetch_sub(ctx, sub, rx, ch, out); }
@@ -132,6 +140,7 @@ public:
 
 	void attach(GpuBatch* b, int receiver) { batch = b; rx = receiver; }
 	void detach() { if (batch) batch->leave(rx); batch = nullptr; } // end of this receiver's stream: the batch stops waiting for it
+	void flush(TAG& tag) { if (batch && batch->isPipelined()) process(nullptr, 0, tag); } // pipelined batch: collect the last block's outputs
 	int status() const { return last_status; }                      // AISGPU_* status of the last Receive()
 	void setErrorHandler(std::function<void(const std::string&)> f) { on_error = f; }
 	void setFrameHandler(std::function<void(const aisgpu_frame&, TAG&)> f) { on_frame = f; }
@@ -212,6 +221,7 @@ public:
 	// (returns the AISGPU_* status of the block: the reference's Receive() is void and reports through Error()/StopRequest(),
 	// Device/FileRAW.cpp:111-115 -- here the caller gets the code, the error handler the text)
 	int Receive(const RAW* raw, TAG& tag);
+	void Flush(TAG& tag) { chain.flush(tag); } // after the last block of a pipelined batch
 	// CPU-only replay entry (host-logic tests): decisions produced elsewhere
 	void replay(int ch, const aisgpu_out& o, TAG& tag) {
 		if (base || standard) GpuChain::replayBase(ch == 0 ? chain.outFMa : chain.outFMb, o, tag);

@@ -94,7 +94,8 @@ typedef struct aisgpu_cfg {
 
 /* per (receiver, channel) result of one block: what ScatterPLL/PhaseSearchEMA hand to the
  * five AIS::Decoder objects (DSP/DSP.h:95-117, Demod.cpp:96-99), in host memory owned by the
- * context and valid until the next aisgpu_run(). */
+ * context and valid until the next aisgpu_sync_outputs() -- so a caller may hand in and start the NEXT block
+ * (aisgpu_submit x R, aisgpu_run) while it still consumes these (pipelined hand-off, GpuBatch::setPipelined). */
 typedef struct aisgpu_out {
 	int n_groups;            /* complete 5-sample groups emitted in this block */
 	long long first_group;   /* stream index of the first group; tag.sample_idx of phase j = 5*(first_group+g)+j */
@@ -127,7 +128,9 @@ void aisgpu_destroy(aisgpu_t* h);
 
 /* Copy one receiver's block from host memory (borrowed for the call only, like the reference's
  * Receive(const T*, int, TAG&), Library/Stream.h:36-45) into the staging buffer.  n_iq must equal
- * block_len.  Data is CU8 pairs or CFLOAT32 per cfg.input_format. */
+ * block_len.  Data is CU8 pairs or CFLOAT32 per cfg.input_format.  Thread safe for different rx (receiver threads copy
+ * their rows concurrently); the staging buffers are double buffered, so the rows of block f+1 may be submitted while
+ * block f is still running. */
 int aisgpu_submit(aisgpu_t* h, int rx, const void* iq, int n_iq);
 
 /* Zero-copy alternative: the whole batch is already resident in device memory as
@@ -136,7 +139,7 @@ int aisgpu_submit_device(aisgpu_t* h, const void* iq_dev, long long rx_stride_sa
 
 /* Enqueue the whole chain for the submitted block on the context's stream (asynchronous). */
 int aisgpu_run(aisgpu_t* h);
-/* Enqueue the device->host copy of the block's outputs and wait for the stream. */
+/* Enqueue the device->host copy of the outputs of the last aisgpu_run() and wait for them. */
 int aisgpu_sync_outputs(aisgpu_t* h);
 /* Wait for the stream without copying outputs (throughput runs). */
 int aisgpu_sync(aisgpu_t* h);

@@ -1256,3 +1256,40 @@ def test_engine_v2_device_stages_against_the_reference_structs(rate, fmt, block)
         assert np.array_equal(got_f.view(np.uint32), filt.view(np.uint32)), "FilterFL37 ch %d" % ch
         assert np.array_equal(got_b.astype(bool), filt > 0)
         assert np.any(filt != 0)
+
+
+def test_pipelined_batch_hand_off():
+    """GpuBatch::setPipelined: receive() of block f returns once f has been started on the device, with block f-1 decoded; the
+    receivers copy block f+1 in (double-buffered pinned staging, H2D on a copy stream) and decode f-1 while the device runs f.
+    Same NMEA as the checker once the last block has been flushed -- also with the frame decoders on the device."""
+    import threading
+    from ais_catcher_amd import host
+    R, block, nblocks = 5, 131072, 7
+    xs = [synth.receiver_stream(block * nblocks, receiver_id=260 + r, gap_slots=(0, 2)) for r in range(R)]
+    want = []
+    for x in xs:
+        c = checkers.Oracle()
+        c.feed_blocks(x, block)
+        want.append(c.nmea())
+    for dec in (False, True):
+        host.reset_sequence()
+        batch = host.Batch(n_receivers=R, block_len=block, gpu_decode=dec)
+        batch.set_pipelined(True)
+        models = [host.ModelDefaultGPU(block_len=block, batch=batch, rx=r) for r in range(R)]
+        seen_after_first = [None] * R
+
+        def run(r):
+            for b in range(nblocks):
+                assert models[r].receive(xs[r][b * block:(b + 1) * block]) == 0
+                if b == 0:
+                    seen_after_first[r] = len(models[r].nmea())
+            models[r].flush()
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(R)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert seen_after_first == [0] * R   # one block deep: nothing is decoded in the first call
+        for r in range(R):
+            assert models[r].nmea() == want[r] and len(want[r]) >= 2, "rx %d dec %s" % (r, dec)
+            models[r].close()
+        batch.close()
