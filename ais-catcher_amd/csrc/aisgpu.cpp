@@ -432,7 +432,7 @@ int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned
 		return AISGPU_OK;
 	}
 	{ int rc = flush_walk(h); if (rc) return rc; }
-	if (h->ps_box) HIPCHK(launch_k4_box(k4, s));
+	if (h->ps_box) { if (!h->ps_parallel) k4.streams = 0; else k4.box_out = h->d_box[pb ^ 1]; HIPCHK(launch_k4_box(k4, s)); } // (streams == 0: the sequential row kernel)
 	else if (h->ps_parallel && k4.n_chunks > 1) { if (!(h->ablate & 1)) HIPCHK(launch_k4(k4, s)); }
 	else HIPCHK(launch_k4_sequential(k4, s));
 	HIPCHK(hipEventRecord(h->ev_sym[pb], s));

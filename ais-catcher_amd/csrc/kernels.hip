@@ -1966,6 +1966,104 @@ __global__ __launch_bounds__(64) void k4_phase_search_box(K4Params p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K4' chunk-parallel (round 2): Demod::PhaseSearch's float state is the |t| of the last 12 symbols (slot = symbol count % 12) and
+// the 8-bit decision registers -- a chunk that replays the 16 symbols in front of it has EXACTLY the sequential state, no
+// speculation and nothing to verify.  Only max_idx is carried through time, and it is tracked for all 16 possible starts like
+// in k4_phase_chunks (lane k: the trajectory that starts at k); k4_assemble selects.  Scratch layout as k4_phase_chunks
+// (words, fin; ma_start / ma_fin are written as zeros so that the verification in k4_assemble is vacuous).
+// ------------------------------------------------------------------------------------------
+constexpr int BOX_WARM = 16;
+__global__ __launch_bounds__(64) void k4_box_chunks(K4Params p) {
+	__shared__ float mem[64][13]; // [lane][slot], padded
+	const int lane = threadIdx.x;
+	const int k = lane & 15, row = lane >> 4;
+	const int chunk = blockIdx.y;
+	const int j = blockIdx.x % 5, chan = (blockIdx.x / 5) * 4 + row;
+	const int chain_raw = chan * 5 + j;
+	const bool live = chain_raw < p.n_chains;
+	const int chain = live ? chain_raw : p.n_chains - 1;
+	const int jj = k < 8 ? k : 15 - k;
+	const float pc = c_ps_phase[jj].x;
+	const float psn = k < 8 ? c_ps_phase[jj].y : -c_ps_phase[jj].y;
+	const int g0 = chunk * PS_CHUNK;
+	const int g1 = g0 + PS_CHUNK < p.n_groups ? g0 + PS_CHUNK : p.n_groups;
+	const size_t slot = (size_t)chain * p.n_chunks + chunk;
+	const PsBoxState* st = p.box_in + chain;
+	unsigned bits = 0;
+	int start = g0;
+	if (chunk == 0) {
+#pragma unroll
+		for (int l = 0; l < 12; l++) mem[lane][l] = st->mem[l][k];
+		bits = st->bits[k];
+	} else {
+#pragma unroll
+		for (int l = 0; l < 12; l++) mem[lane][l] = 0.0f; // every slot is rewritten during the warm-up
+		start = g0 - BOX_WARM;
+	}
+	int idx = k; // the trajectory that starts at max_idx == k
+	int last = (int)((p.first_group + start) % 12); // every chain has consumed first_group + start symbols
+	const SymRow x(p.sym, chain, p.sym_stride);
+	uint32_t* wout = p.words + slot * (PS_CHUNK / 32) * 16 + k;
+	uint32_t word = 0;
+	const int last_i = (int)p.sym_stride - 1;
+	float2 cur[PS_BATCH];
+#pragma unroll
+	for (int e = 0; e < PS_BATCH; e++) { const int i = start + e; cur[e] = x[i < last_i ? i : last_i]; }
+#pragma unroll 1
+	for (int gb = start; gb < g1; gb += PS_BATCH) {
+		float2 nxt[PS_BATCH];
+#pragma unroll
+		for (int e = 0; e < PS_BATCH; e++) { const int i = gb + PS_BATCH + e; nxt[e] = x[i < last_i ? i : last_i]; }
+#pragma unroll
+		for (int e = 0; e < PS_BATCH; e++) {
+			const int g = gb + e;
+			if (g < g1) { // wave-uniform
+				const float2 v = cur[e]; // already multiplied by (1j)^n
+				const float tt = v.x * pc + v.y * psn;
+				bits = (bits << 1) | (tt > 0 ? 1u : 0u);
+				mem[lane][last] = fabsf(tt);
+				last = last == 11 ? 0 : last + 1;
+				if (g >= g0) {
+					float avg = mem[lane][0];
+#pragma unroll
+					for (int l = 1; l < 12; l++) avg += mem[lane][l];
+					float max_val = 0.0f;
+					int res = k;
+#pragma unroll
+					for (int d = -2; d <= 2; d++) {
+						const float a = __shfl(avg, (k + d + 16) & 15, 16);
+						if (a > max_val) { max_val = a; res = (k + d + 16) & 15; }
+					}
+					idx = __shfl(res, idx, 16);
+					const unsigned b = (unsigned)__shfl((int)bits, idx, 16);
+					const int q = g - g0;
+					word |= (((b >> 4) ^ (b >> 3)) & 1u) << (q & 31);
+					if ((q & 31) == 31) {
+						if (live) wout[(q >> 5) * 16] = word;
+						word = 0;
+					}
+				}
+			}
+		}
+#pragma unroll
+		for (int e = 0; e < PS_BATCH; e++) cur[e] = nxt[e];
+	}
+	const int n = g1 - g0;
+	if ((n & 31) != 0 && live) wout[(n >> 5) * 16] = word;
+	if (live) {
+		p.ma_fin[slot * 16 + k] = 0.0f;
+		if (chunk > 0) p.ma_start[slot * 16 + k] = 0.0f;
+		p.fin[slot * 16 + k] = (unsigned)idx | ((bits & 0xffu) << 4);
+		if (chunk == p.n_chunks - 1) { // the block's final float state (max_idx: k4_assemble)
+			PsBoxState* sto = p.box_out + chain;
+#pragma unroll
+			for (int l = 0; l < 12; l++) sto->mem[l][k] = mem[lane][l];
+			sto->bits[k] = bits & 0xffu;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------
 // K4 chunk-parallel: the block's symbols are cut into chunks of PS_CHUNK; one 16-lane row per (chain, chunk).
 //  * ma[k] is a contraction (x0.85 per symbol), so a chunk starts from ma = 0 and first replays the `warm`
 //    symbols in front of it; after that the float state is (with overwhelming probability) bit-identical to
@@ -2306,7 +2404,7 @@ __global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
 	if (chain >= p.n_chains) return;
 	const EmaState* st = p.state_in + chain;
 	EmaState* sto = p.state_out + chain;
-	int start = st->max_idx;
+	int start = p.box_out ? p.box_in[chain].max_idx : st->max_idx; // (boxcar variant: its own state block)
 	uint32_t* out = p.bits + (size_t)chain * p.bits_stride;
 	bool bad = false;
 	// Next to the front end a dependent global load costs microseconds, so the walk over the chunks must not contain any:
@@ -2368,6 +2466,7 @@ __global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
 	sto->ma[k] = p.ma_fin[last * 16 + k];
 	sto->bits[k] = fin_last >> 4;
 	if (k == 0) { sto->max_idx = start; sto->rot = (st->rot + p.n_groups) & 3; }
+	if (p.box_out && k == 0) p.box_out[chain].max_idx = start; // boxcar variant: its own state block
 }
 
 // ------------------------------------------------------------------------------------------
@@ -4192,6 +4291,13 @@ hipError_t launch_k5(const K5Params& p, int n_chan, hipStream_t s) {
 }
 
 hipError_t launch_k4_box(const K4Params& p, hipStream_t s) {
+	if (p.n_chunks > 1 && p.streams != 0) { // chunk-parallel: exact by construction (16 symbols of look-back), k4_assemble picks the trajectories
+		K4Params q = p;
+		q.qflag = nullptr;
+		hipLaunchKernelGGL(k4_box_chunks, dim3((p.n_chains / 5 + 3) / 4 * 5, p.n_chunks), dim3(64), 0, s, q);
+		hipLaunchKernelGGL(k4_assemble, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, q);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL(k4_phase_search_box, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p);
 	return hipGetLastError();
 }

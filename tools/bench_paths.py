@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Throughput of the paths that are NOT on the bench line: other ladders, formats, engines and options,
+inputs resident in HBM (noise + bursts of one synthetic receiver replicated), chain up to its device outputs.
+usage: tools/bench_paths.py [R]   -> one line per configuration: IQ MS/s, ms per step
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import _pkg  # noqa: E402
+
+_pkg.load()
+from ais_catcher_amd import gpu, synth  # noqa: E402
+
+
+def run(name, R, rate, block, fmt="cf32", steps=30, **kw):
+    x = synth.receiver_stream(block * 2, sample_rate=rate, receiver_id=7, single_channel=kw.get("mode_x", False))
+    if fmt == "cf32":
+        host = x.view(np.float32).reshape(2, block, 2)
+        code = gpu.FMT_CF32
+    elif fmt == "cu8":
+        host = synth.to_cu8(x).reshape(2, block, 2)
+        code = gpu.FMT_CU8
+    else:
+        host = synth.to_cs16(x).reshape(2, block, 2)
+        code = gpu.FMT_CS16
+    dev = torch.from_numpy(np.ascontiguousarray(host)).cuda()
+    data = dev.unsqueeze(1).expand(2, R, block, 2).contiguous()   # [2 blocks][R][block][2]
+    torch.cuda.synchronize()
+    g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block, input_format=code, **kw)
+    for i in range(30):  # warm-up incl. the clock ramp after the idle set-up time
+        g.submit_device(data[i & 1].data_ptr(), block)
+        g.run()
+    g.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        g.submit_device(data[i & 1].data_ptr(), block)
+        g.run()
+    g.sync()
+    dt = time.perf_counter() - t0
+    g.close()
+    del data, dev
+    print("%-64s %9.0f MS/s   %7.3f ms per step of %d x %d samples" % (name, R * block * steps / dt / 1e6, dt / steps * 1e3, R, block), flush=True)
+
+
+if __name__ == "__main__":
+    R = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    B = 786432
+    run("ModelDefault 1536k CF32 (the bench line)", R, 1536000, B)
+    run("ModelDefault 1536k CF32, frame decoders on the device (K7e)", R, 1536000, B, gpu_decode=True)
+    run("ModelDefault 1536k CF32, PS_EMA off (boxcar PhaseSearch, sequential rows)", R, 1536000, B, ps_ema=False)
+    run("ModelDefault 1536k CU8", R, 1536000, B, fmt="cu8")
+    run("ModelDefault 1536k CU8, FP_DS (fixed-point ladder)", R, 1536000, B, fmt="cu8", fp_ds=True)
+    run("ModelDefault 1536k CS16", R, 1536000, B, fmt="cs16")
+    run("ModelDefault 768k CF32 (three CIC5 stages)", R, 768000, B // 2)
+    run("ModelDefault 3072k CF32 (pre-decimation pass)", R // 2, 3072000, B)
+    run("ModelDefault 6 MSPS CF32 (pre-decimation + resampler K1u)", R // 4, 6000000, B)
+    run("ModelDefault 288k CF32 (decimate-by-3 front end K1k)", R, 288000, 49152 * 4)
+    run("ModelDefault 2400k CF32 (resampled into 3072k)", R // 2, 2400000, B // 2)
+    run("ModelDefault mode X 96k CF32 (single channel K1x)", R, 96000, 1024 * 48, mode_x=True)
+    run("ModelChallenger 1536k CF32 (materialised back end + FM branch)", R, 1536000, B, model=gpu.MODEL_CHALLENGER)
+    run("ModelChallenger 1536k CF32, twenty decoders on the device", R, 1536000, B, model=gpu.MODEL_CHALLENGER, gpu_decode=True)
+    run("ModelChallenger 6 MSPS CF32 (BASELINE configs[2])", R // 4, 6000000, B, model=gpu.MODEL_CHALLENGER)
+    run("ModelBase 1536k CF32 (front end + FM receiver, signs out)", R, 1536000, B, model=gpu.MODEL_BASE)
+    run("ModelBase 1536k CF32, SimplePLL + decoder on the device", R, 1536000, B, model=gpu.MODEL_BASE, gpu_decode=True)
+    run("ModelStandard 1536k CF32, five decoders on the device", R, 1536000, B, model=gpu.MODEL_STANDARD, gpu_decode=True)
+    run("ModelEngineV2 1536k CF32 (front end + estimates / energies / FM branch, c48 to the host)", R, 1536000, B, model=gpu.MODEL_V2)
