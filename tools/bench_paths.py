@@ -52,7 +52,7 @@ if __name__ == "__main__":
     B = 786432
     run("ModelDefault 1536k CF32 (the bench line)", R, 1536000, B)
     run("ModelDefault 1536k CF32, frame decoders on the device (K7e)", R, 1536000, B, gpu_decode=True)
-    run("ModelDefault 1536k CF32, PS_EMA off (boxcar PhaseSearch, sequential rows)", R, 1536000, B, ps_ema=False)
+    run("ModelDefault 1536k CF32, PS_EMA off (boxcar PhaseSearch, chunk-parallel)", R, 1536000, B, ps_ema=False)
     run("ModelDefault 1536k CU8", R, 1536000, B, fmt="cu8")
     run("ModelDefault 1536k CU8, FP_DS (fixed-point ladder)", R, 1536000, B, fmt="cu8", fp_ds=True)
     run("ModelDefault 1536k CS16", R, 1536000, B, fmt="cs16")
