@@ -1024,8 +1024,21 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			}
 			// (a runtime without CU masks falls back to ordinary streams: same results, the recurrence just shares its SIMDs)
 			bool masked = hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)words, front.data()) == hipSuccess;
+			// experiment knob AISGPU_STREAM_PRIO="<front>,<ps>,<fir>": plain streams with HIP queue priorities (-1 high, 0 normal, 1 low)
+			// instead of the CU-masked ones for the front end / PhaseSearch / derotation-FIR streams
+			// Default (round 2, profiles/r02_expI.txt .. r02_expK.txt): the front stream as a plain stream of the LOWEST queue priority
+			// (the workgroup dispatcher then prefers the back end's workgroups whenever a slot frees up; 2-3 % per step), the others
+			// CU-masked as before.  99 = keep the CU-masked stream.
+			int pf = 99, pp = 99, pk = 99;
+			{ int least = 0, greatest = 0; if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) pf = least; }
+			if (const char* pe = getenv("AISGPU_STREAM_PRIO")) sscanf(pe, "%d:%d:%d", &pf, &pp, &pk);
+			if (pf != 99) { hipStreamDestroy(h->stream); h->stream = nullptr; masked = masked && hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, pf) == hipSuccess; }
+			if (pp != 99) masked = masked && hipStreamCreateWithPriority(&h->s1, hipStreamNonBlocking, pp) == hipSuccess;
+			else
 			masked = masked && hipExtStreamCreateWithCUMask(&h->s1, (uint32_t)words, back.data()) == hipSuccess;
 			masked = masked && hipExtStreamCreateWithCUMask(&h->s3, (uint32_t)words, lat.data()) == hipSuccess;
+			if (pk != 99) masked = masked && hipStreamCreateWithPriority(&h->s4, hipStreamNonBlocking, pk) == hipSuccess;
+			else
 			masked = masked && hipExtStreamCreateWithCUMask(&h->s4, (uint32_t)words, back.data()) == hipSuccess;
 			if (masked && (cfg->flags & AISGPU_FLAG_GPU_DECODE)) masked = hipExtStreamCreateWithCUMask(&h->s5, (uint32_t)words, back.data()) == hipSuccess;
 			if (!masked) {
@@ -1175,7 +1188,9 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	if (h->fft_in_k1) {
 		int t = h->tiles_per_span;
 		if (cfg->tiles_per_span <= 0 && !getenv("AISGPU_TPS")) {
-			t = 16; // one window per channel and span: the most workgroups, the best balance at the end of the launch (measured: 16 < 32 < 48)
+			// two windows per channel and span where the block allows it: one warm-up tile per 32 instead of per 16 tiles (3 % less
+			// front-end work); round 1 measured 16 < 32 < 48, round 2 with the non-temporal input stream 32 < 16 < 48 (r02_expJ.txt)
+			t = (h->tiles_per_block % 32 == 0 && h->tiles_per_block >= 64) ? 32 : 16;
 			while (t <= h->tiles_per_block && h->tiles_per_block % t) t += 16;
 		}
 		if (t >= 16 && t <= h->tiles_per_block && t % 16 == 0 && h->tiles_per_block % t == 0) {
