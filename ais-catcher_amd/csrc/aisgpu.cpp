@@ -171,6 +171,10 @@ struct aisgpu {
 	const void* cur_in = nullptr; long long cur_in_stride = 0;
 	bool submitted = false, have_out = false;
 	SubOut sub[MAXSUB]; int n_sub = 0;
+	// Resamplers that complete more than two downstream blocks per input block (channel mode X below 24 kSPS: up to four) would
+	// overwrite the two-deep device output rings before aisgpu_sync_outputs() copies them: there every downstream block's outputs
+	// are copied to its host slot as soon as they exist (two sets of host slots, by input block)
+	bool eager_out = false; int out_set = 0, oset = 0;
 	SubOut osub[MAXSUB]; int n_osub = 0; // the downstream blocks whose outputs the last aisgpu_sync_outputs() brought to the host (what fetch serves)
 	struct { bool valid = false; int q = 0, pb = 0, lv = 0; long long g0 = 0, g1 = 0, first48 = 0; unsigned block = 0, sub = 0; } pend; // deferred second half
 	bool defer = true;
@@ -375,6 +379,17 @@ int enqueue_fused_back(aisgpu_t* h);
 
 // what follows PhaseSearch of a block: the optional device frame decoder, and the event that frees sym/lvl/bits[pb]
 int enqueue_decode(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s);
+// eager_out: this downstream block's outputs to their host slot, on the stream that has just produced the last of them
+int copy_out_eager(aisgpu_t* h, int pb, int lv, unsigned block, unsigned sub, hipStream_t s) {
+	if (!h->eager_out || sub >= (unsigned)MAXSUB) return AISGPU_OK;
+	const size_t C = h->n_chan, slot = (size_t)h->out_set * MAXSUB + sub;
+	const int q = (int)(block % NBUF);
+	HIPCHK(hipMemcpyAsync(h->h_bits + slot * C * 5 * h->words, h->d_bits[pb], C * 5 * h->words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	HIPCHK(hipMemcpyAsync(h->h_lvl + slot * C * h->Gcap, h->d_lvl[lv], C * h->Gcap * sizeof(float), hipMemcpyDeviceToHost, s));
+	HIPCHK(hipMemcpyAsync(h->h_ppm + slot * C * h->W, h->d_ppm[q], C * h->W * sizeof(float), hipMemcpyDeviceToHost, s));
+	return AISGPU_OK;
+}
+
 int finish_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s) {
 	if (h->gpu_decode) { // the frame decoder is a long latency-bound kernel of a few waves: own stream, so that the next
 		// block's PhaseSearchEMA does not queue behind it; sym/lvl/bits[pb] are free again only when IT is done
@@ -382,8 +397,14 @@ int finish_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned 
 		WAITEV(h->s5, h->ev_k4[pb]);
 		int rc = enqueue_decode(h, pb, lv, g0, n_groups, block, sub, h->s5);
 		if (rc) return rc;
+		rc = copy_out_eager(h, pb, lv, block, sub, h->s5);
+		if (rc) return rc;
 		HIPCHK(hipEventRecord(h->ev_ema[lv], h->s5));
-	} else HIPCHK(hipEventRecord(h->ev_ema[lv], s));
+	} else {
+		int rc = copy_out_eager(h, pb, lv, block, sub, s);
+		if (rc) return rc;
+		HIPCHK(hipEventRecord(h->ev_ema[lv], s));
+	}
 	return AISGPU_OK;
 }
 
@@ -885,9 +906,9 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	int kx = -1;
 	if (mode_x) {
 		static const int bx[3] = { 48000, 96000, 192000 };
-		// (the reference takes 12k .. 192k; below 24k the resampler would complete more than two downstream blocks per input
-		// block, which the double-buffered outputs do not hold -- and 9600 Bd GMSK needs more than that anyway)
-		if (cfg->sample_rate < 24000 || cfg->sample_rate > 192000) return AISGPU_ERR_ARG;
+		// (12k .. 192k like the reference; below 24k the resampler completes up to four downstream blocks per input block:
+		// eager_out)
+		if (cfg->sample_rate < 12000 || cfg->sample_rate > 192000) return AISGPU_ERR_ARG; // Model.cpp:37-38
 		if (cfg->model != AISGPU_MODEL_DEFAULT || (cfg->flags & (AISGPU_FLAG_FP_DS | AISGPU_FLAG_DSK))) return AISGPU_ERR_ARG;
 		for (int i = 0; i < 3; i++) if (bx[i] >= cfg->sample_rate) { kx = i; break; }
 		k = kx; k3 = -1;
@@ -958,6 +979,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	else if (mode == MODE_96K) { h->npost = 0; h->n96 = h->n_pre; }
 	else h->n96 = h->n_pre >> K;
 	h->mode_x = mode_x;
+	h->eager_out = mode_x && cfg->sample_rate < 24000;
 	if (mode_x) { h->npost = kx; h->n96 = 2 * (h->n_pre >> kx); } // (no Rotate, no 96 kHz point: n96 only sizes the unused phasor table; L = n96 / 2)
 	h->L = h->n96 / 2;
 	h->W = h->L / 512;
@@ -1286,9 +1308,10 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			HIPCHK(dalloc(&h->d_fmprev[0], C));
 		}
 	}
-	HIPCHK(hipHostMalloc((void**)&h->h_bits, MAXSUB * C * 5 * h->words * sizeof(uint32_t), hipHostMallocDefault));
-	HIPCHK(hipHostMalloc((void**)&h->h_lvl, MAXSUB * C * h->Gcap * sizeof(float), hipHostMallocDefault));
-	HIPCHK(hipHostMalloc((void**)&h->h_ppm, MAXSUB * C * h->W * sizeof(float), hipHostMallocDefault));
+	const size_t osets = h->eager_out ? 2 : 1;
+	HIPCHK(hipHostMalloc((void**)&h->h_bits, osets * MAXSUB * C * 5 * h->words * sizeof(uint32_t), hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void**)&h->h_lvl, osets * MAXSUB * C * h->Gcap * sizeof(float), hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void**)&h->h_ppm, osets * MAXSUB * C * h->W * sizeof(float), hipHostMallocDefault));
 	HIPCHK(hipDeviceSynchronize());
 	return AISGPU_OK;
 }
@@ -1403,6 +1426,7 @@ int aisgpu_run(aisgpu_t* h) {
 	const int R = h->cfg.n_receivers;
 	h->n_sub = 0;
 	const int in_p = (int)(h->in_blocks & 1);
+	h->out_set = h->eager_out ? in_p : 0;
 	if (h->staged) { // the rows' host -> device copies run on the copy stream: the front stream waits for them
 		HIPCHK(hipEventRecord(h->ev_h2d[in_p], h->sc));
 		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_h2d[in_p], 0));
@@ -1597,6 +1621,7 @@ int aisgpu_run(aisgpu_t* h) {
 					HIPCHK(hipMemcpyAsync(h->d_usalpha[pb], ta, ((size_t)US_HIST + len) * sizeof(float), hipMemcpyHostToDevice, h->stream));
 					HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
 					WAITEV(h->stream, h->ev_c48free[q]);
+					if (h->eager_out) WAITEV(h->stream, h->ev_ema[(h->block_idx + 1) & 3]); // ppm[q] of block f-3 has been copied out
 					if (h->us_dsk) { // US >> DSK >> ROT: the flush is a whole number of the filter's 8192-sample output blocks
 						K1kParams kk;
 						kk.xin = xcur; kk.xin_stride = xstride; kk.xin_off = h->xh;
@@ -1648,7 +1673,7 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 		const SubOut& so = h->sub[s];
 		// ev_ema[pb]: PhaseSearch (and the frame decoder) of that block are done, wherever their last kernel ran; they are
 		// ordered after everything that produced lvl/ppm
-		if (!h->base && !h->v2) {
+		if (!h->base && !h->v2 && !h->eager_out) {
 		WAITEV(h->s2, h->ev_ema[so.lv]);
 		HIPCHK(hipMemcpyAsync(h->h_bits + (size_t)s * C * 5 * h->words, h->d_bits[so.pb], C * 5 * h->words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s2));
 		HIPCHK(hipMemcpyAsync(h->h_lvl + (size_t)s * C * h->Gcap, h->d_lvl[so.lv], C * h->Gcap * sizeof(float), hipMemcpyDeviceToHost, h->s2));
@@ -1660,6 +1685,7 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 	int rc = sync_all(h);
 	if (rc != AISGPU_OK) return rc;
 	h->n_osub = h->n_sub;
+	h->oset = h->out_set;
 	for (int i = 0; i < h->n_sub; i++) h->osub[i] = h->sub[i];
 	if (h->gpu_decode) { rc = gather_frames(h); if (rc != AISGPU_OK) return rc; }
 	h->have_out = true;
@@ -1685,10 +1711,11 @@ int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* o) {
 	const SubOut& so = h->osub[sub];
 	o->n_groups = so.groups;
 	o->first_group = so.first_group;
-	for (int j = 0; j < 5; j++) o->bits[j] = h->h_bits + (size_t)sub * C * 5 * h->words + (chan * 5 + j) * h->words;
-	o->lvl = h->h_lvl + (size_t)sub * C * h->Gcap + chan * h->Gcap;
+	const size_t oslot = (size_t)h->oset * MAXSUB + sub; // (eager_out: the set of host slots the synced run wrote)
+	for (int j = 0; j < 5; j++) o->bits[j] = h->h_bits + oslot * C * 5 * h->words + (chan * 5 + j) * h->words;
+	o->lvl = h->h_lvl + oslot * C * h->Gcap + chan * h->Gcap;
 	o->n_windows = h->W;
-	o->ppm = h->h_ppm + (size_t)sub * C * h->W + chan * h->W;
+	o->ppm = h->h_ppm + oslot * C * h->W + chan * h->W;
 	o->group_window = nullptr;
 	o->first_sample48 = so.first48;
 	o->fm_bits = (h->challenger || h->base || (h->v2 && h->v2_assist)) ? h->h_fmbits + (size_t)sub * C * (h->L / 32) + chan * (h->L / 32) : nullptr;

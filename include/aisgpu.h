@@ -69,8 +69,8 @@ extern "C" {
 #define AISGPU_FLAG_FP_DS 32  /* KEY_SETTING_FP_DS (`-go FP_DS on`, `-F`): 1536 kSPS CU8 input goes through the fixed-point ladder
                                * Downsample16_CU8 (DSP/DSP.cpp:499-651, Model.cpp:231-237); ignored at other rates like in the reference */
 #define AISGPU_FLAG_MODE_X 64 /* channel mode X (`-c X`, Receiver.cpp:87-98, Model.cpp:35-107): ONE channel, already centred, sample_rate
-                              * 24000 .. 192000 (buckets 48k / 96k / 192k, resampled in between; the reference also takes 12k .. 24k);
-                              * channel A carries it, channel B stays silent */
+                              * 12000 .. 192000 like the reference (buckets 48k / 96k / 192k, resampled in between; below 24000 one input
+                              * block completes up to four downstream blocks, aisgpu_out_count()); channel A carries it, channel B stays silent */
 #define AISGPU_FLAG_DSK 4     /* KEY_SETTING_DSK (`-go DSK on`): 576k / 1152k / 2304k use the decimate-by-3 ladder (Model.cpp:130) */
 
 typedef struct aisgpu aisgpu_t;

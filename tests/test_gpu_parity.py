@@ -377,10 +377,11 @@ def test_other_resampled_rates(rate):
 
 
 @pytest.mark.parametrize("rate,block,fmt", [(48000, 512 * 40, "cf32"), (96000, 1024 * 40, "cf32"), (192000, 2048 * 40, "cu8"),
-                                            (40000, 512 * 40, "cf32"), (150000, 2048 * 30, "cs16"), (25000, 512 * 16, "cf32")])
+                                            (40000, 512 * 40, "cf32"), (150000, 2048 * 30, "cs16"), (25000, 512 * 16, "cf32"), (12000, 512 * 8, "cf32"), (16000, 512 * 12, "cu8"), (20000, 512 * 16, "cf32")])
 def test_channel_mode_x(rate, block, fmt):
     """`-c X` (Model.cpp:35-107): one already centred channel at 48 / 96 / 192 kSPS or resampled into the next of these; the
-    single-channel front end K1x feeds channel A, channel B stays silent.  48 kHz tap, hard bits, levels, ppm per downstream
+    single-channel front end K1x feeds channel A, channel B stays silent (below 24 kSPS one input block completes up to four
+    downstream blocks: their outputs are copied out as they complete).  48 kHz tap, hard bits, levels, ppm per downstream
     block, then NMEA (channel letter X) through the host model."""
     from ais_catcher_amd import host
     nblocks = 8
