@@ -1687,8 +1687,8 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 	h->n_osub = h->n_sub;
 	h->oset = h->out_set;
 	for (int i = 0; i < h->n_sub; i++) h->osub[i] = h->sub[i];
+	h->have_out = true; // (the decisions are there even if the frame ring below has overflowed)
 	if (h->gpu_decode) { rc = gather_frames(h); if (rc != AISGPU_OK) return rc; }
-	h->have_out = true;
 	return AISGPU_OK;
 }
 

@@ -96,22 +96,26 @@ struct K3Params {
 	int n_groups;
 };
 
-// Layout of the FIR / ScatterPLL output `sym` (what PhaseSearch consumes): float4 [n_chan / 64][groups / 2][5][64] -- the pair
-// of symbols (g, g + 1) of sampling phase j for 64 adjacent channels.  The derotation / FIR kernel has one LANE per channel,
-// so in this layout each of its stores is 1 KiB contiguous; with one row per (channel, phase) the same stores were 64
-// scattered 16-byte pieces, and it was exactly those scattered writes that cost the front end 0.05 ms per launch
-// (profiles/r01_v7_interference_experiments.txt).  Element (chan, j, g) as a float2 index:
-constexpr int SYM_PAIR = 5 * 64 * 2; // float2 elements from one symbol pair of a row to the next
+// Layout of the FIR / ScatterPLL output `sym` (what PhaseSearch consumes), in float2 elements:
+//   [n_chan / 64][groups / 4][phase 5][quad 16][pair 2][channel of the quad 4][symbol of the pair 2]
+// i.e. per (64 channels, 4 groups, phase) a 2 KiB slab in which the two symbol pairs of the four ADJACENT channels of a quad
+// are 128 contiguous bytes.  Both sides see whole lines: the derotation / FIR kernel has one lane per channel and writes a
+// body's two pairs with two 16-byte stores per lane, which fill the quads' lines back to back (64-byte runs per instruction,
+// never the scattered 16-byte pieces that cost the front end 0.05 ms per launch in round 1); a PhaseSearch wave = one phase
+// of one quad, and each of its fetches covers whole 128-byte lines (round 1's [groups / 2][5][64 channels] made it fetch
+// every line twice, half used: 244 MB read for 126 MB of data).
+constexpr int SYM_SLAB = 5 * 256; // float2 elements from group g to group g + 4 of a row
 __host__ __device__ inline size_t sym_row_base(int chan, int j, long long gcap) {
-	return ((size_t)(chan >> 6) * (size_t)(gcap >> 1) * 5 + (size_t)j) * 128 + (size_t)(chan & 63) * 2;
+	return ((size_t)(chan >> 6) * (size_t)(gcap >> 2) * 5 + (size_t)j) * 256 + (size_t)((chan & 63) >> 2) * 16 + (size_t)(chan & 3) * 2;
 }
+__host__ __device__ inline size_t sym_offset(int g) { return (size_t)(g >> 2) * SYM_SLAB + (size_t)((g >> 1) & 1) * 8 + (size_t)(g & 1); }
 __host__ __device__ inline size_t sym_elems(int n_chan, long long gcap) { return (size_t)((n_chan + 63) / 64) * 64 * 5 * (size_t)gcap; }
-// one (channel, phase) row: element g at base[(g >> 1) * SYM_PAIR + (g & 1)]
+// one (channel, phase) row: element g at base[sym_offset(g)]
 struct SymRow {
 	const float2* base;
 	__host__ __device__ SymRow(const float2* sym, int chain /* chan * 5 + j */, long long gcap) : base(sym + sym_row_base(chain / 5, chain % 5, gcap)) {}
-	__host__ __device__ float2 operator[](int g) const { return base[(size_t)(g >> 1) * SYM_PAIR + (g & 1)]; }
-	__host__ __device__ const float4* pair(int g) const { return reinterpret_cast<const float4*>(base + (size_t)(g >> 1) * SYM_PAIR); } // g even
+	__host__ __device__ float2 operator[](int g) const { return base[sym_offset(g)]; }
+	__host__ __device__ const float4* pair(int g) const { return reinterpret_cast<const float4*>(base + sym_offset(g)); } // g even
 };
 
 struct EmaState { float ma[16]; unsigned bits[16]; int max_idx, rot; int pad[2]; };

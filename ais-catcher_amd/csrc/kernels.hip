@@ -1627,13 +1627,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6
 		if (live) {
 			if (g + 4 <= gb) {
 #pragma unroll
-				for (int j = 0; j < 5; j++) { // lane = channel: each store is 64 x 16 B contiguous (SymRow layout, kernels.h)
-					float4* dst = reinterpret_cast<float4*>(p.sym + sym_row_base(chain, j, p.sym_stride) + (size_t)(g >> 1) * SYM_PAIR);
+				for (int j = 0; j < 5; j++) { // lane = channel: the body's two pairs fill the quads' 128-byte lines (SymRow layout, kernels.h)
+					float4* dst = reinterpret_cast<float4*>(p.sym + sym_row_base(chain, j, p.sym_stride) + sym_offset(g));
 #pragma unroll
 #ifdef K6_NT
-					for (int q = 0; q < 2; q++) nt_store(make_float4(out[j][2 * q].x, out[j][2 * q].y, out[j][2 * q + 1].x, out[j][2 * q + 1].y), &dst[q * (SYM_PAIR / 2)]);
+					for (int q = 0; q < 2; q++) nt_store(make_float4(out[j][2 * q].x, out[j][2 * q].y, out[j][2 * q + 1].x, out[j][2 * q + 1].y), &dst[q * 4]);
 #else
-					for (int q = 0; q < 2; q++) dst[q * (SYM_PAIR / 2)] = make_float4(out[j][2 * q].x, out[j][2 * q].y, out[j][2 * q + 1].x, out[j][2 * q + 1].y);
+					for (int q = 0; q < 2; q++) dst[q * 4] = make_float4(out[j][2 * q].x, out[j][2 * q].y, out[j][2 * q + 1].x, out[j][2 * q + 1].y); // pair 1: 64 bytes behind pair 0
 #endif
 				}
 				*reinterpret_cast<float4*>(p.lvl + (size_t)chain * p.sym_stride + g) = make_float4(lv[0], lv[1], lv[2], lv[3]);
@@ -1642,7 +1642,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6
 				for (int gi = 0; gi < 4; gi++) {
 					if (g + gi < gb) {
 #pragma unroll
-						for (int j = 0; j < 5; j++) p.sym[sym_row_base(chain, j, p.sym_stride) + (size_t)((g + gi) >> 1) * SYM_PAIR + ((g + gi) & 1)] = make_float2(out[j][gi].x, out[j][gi].y);
+						for (int j = 0; j < 5; j++) p.sym[sym_row_base(chain, j, p.sym_stride) + sym_offset(g + gi)] = make_float2(out[j][gi].x, out[j][gi].y);
 						p.lvl[(size_t)chain * p.sym_stride + g + gi] = lv[gi];
 					}
 				}
@@ -1732,7 +1732,7 @@ __global__ __launch_bounds__(256) void k3_fir_scatter(K3Params p) {
 		float2 sv = (rot & 1) ? make_float2(acc.y, acc.x) : acc; // rot 1: (-y, x)   rot 3: (y, -x)
 		if (rot == 1 || rot == 2) sv.x = -sv.x;
 		if (rot >= 2) sv.y = -sv.y;
-		p.sym[sym_row_base(chan, j, p.sym_stride) + (size_t)(g >> 1) * SYM_PAIR + (g & 1)] = sv;
+		p.sym[sym_row_base(chan, j, p.sym_stride) + sym_offset(g)] = sv;
 		if (p.fir_tap) p.fir_tap[(size_t)chan * p.fir_tap_stride + (n_rel + j + 4)] = acc;
 	}
 	p.lvl[(size_t)chan * p.sym_stride + g] = __fdiv_rn(level, 5.0f);
@@ -2130,8 +2130,10 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 		for (int q = 0; q < PS_SB / 16; q++) {
 			int i = start + sb * PS_SB + q * 16 + k;
 			i = i < last_i ? i : last_i; // (past the chunk's end: any readable sample, it is never used)
-#ifdef K4_NT
-			r[q] = nt_load(&x.base[(size_t)(i >> 1) * SYM_PAIR + (i & 1)]); // read once
+#ifdef K4_EXP_NO_LOADS // experiment (results wrong): the kernel's arithmetic without its global loads
+			r[q] = make_float2(0.25f + (float)(i & 7), 0.5f - (float)(i & 3));
+#elif defined(K4_NT)
+			r[q] = nt_load(&x.base[sym_offset(i)]); // read once
 #else
 			r[q] = x[i];
 #endif
@@ -2162,6 +2164,12 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 #pragma unroll
 				for (int e = 0; e < PS_BATCH; e += 2) { const float4 t = src[e >> 1]; v[e] = make_float2(t.x, t.y); v[e + 1] = make_float2(t.z, t.w); }
 			}
+#ifdef K4_EXP_NO_COMPUTE // experiment (results wrong): the kernel's memory traffic and staging without its arithmetic
+			{ float acc_ = 0.0f;
+#pragma unroll
+			  for (int e = 0; e < PS_BATCH; e++) acc_ += v[e].x;
+			  ma.x = acc_; word ^= __float_as_uint(acc_) & 1u; continue; }
+#endif
 			if (g < g0) { // warm-up: EMA and decision history only
 #pragma unroll
 				for (int e = 0; e < PS_BATCH; e++) ps_warm_step<MODE>(v[e], pc, psn, ma, hs);
@@ -3397,11 +3405,14 @@ __device__ __forceinline__ int dec_abort_position(int t) {
 //  * the CRC-16/X.25 register (AIS.cpp:55-64) runs SEVEN BITS BEHIND the stored bits (r.tail holds those seven): the
 //    residue check covers the first position-7 bits, so when the closing flag is complete the register already is the
 //    answer -- no loop over the frame, no undoing.  A de-stuffed bit advances nothing.
+// DATA_ONLY: the caller guarantees r.state == DST_DATAFCS (k7e_sim: a run leaves TRAINING / STARTFLAG after a few symbols and ends
+// when it leaves DATAFCS) -- the TRAINING / STARTFLAG half of the step folds away
+template <bool DATA_ONLY = false>
 __device__ __forceinline__ bool dec_step(DecReg& r, int dd, float slvl, long long sidx, uint32_t* data) {
 	const int Bit = dd == r.prev; // NRZI: !(d ^ prev)
 	r.prev = dd;
-	const int st = r.state, pos = r.position, osc = r.osc;
-	const bool isD = st == DST_DATAFCS, isT = st == DST_TRAINING;
+	const int st = DATA_ONLY ? (int)DST_DATAFCS : r.state, pos = r.position, osc = r.osc;
+	const bool isD = DATA_ONLY || st == DST_DATAFCS, isT = !DATA_ONLY && st == DST_TRAINING;
 	// ---- TRAINING: count alternations; two equal bits after more than four of them are the start of a flag
 	const bool alt = Bit != r.lastBit;
 	const bool to_flag = isT && !alt && pos > 4;
@@ -3853,11 +3864,11 @@ __global__ __launch_bounds__(64) void k7e_sim(K7eParams q) {
 		}
 		bool running = act;
 		int g = c, end = n, flags = 2; // (2: still running when the block ends)
-		// eight symbols per round: their levels and decisions are fetched together, and one round AHEAD -- a running lane advances
-		// by exactly eight symbols per round, so the next round's addresses are known, and a round that waits for its own loads
-		// is pure memory latency (~2 us per eight symbols next to the front end)
-		float lv[8], lvn[8];
-		uint32_t w0, w1, w0n, w1n;
+		// eight symbols per round: their levels and decisions are fetched together, and TWO rounds ahead -- a running lane advances
+		// by exactly eight symbols per round, so the addresses are known, and a round that waits for its own loads is pure memory
+		// latency (~2 us per eight symbols next to the front end, against ~1.5 us of steps)
+		float lv[8], lvn[8], lvm[8];
+		uint32_t w0, w1, w0n, w1n, w0m, w1m;
 		const auto fetch = [&](int gg, float (&l)[8], uint32_t& a, uint32_t& b) {
 			const int gc = gg < n ? gg : n - 1;
 			a = brow[gc >> 5]; b = brow[(gc + 7 < n ? gc + 7 : n - 1) >> 5];
@@ -3865,27 +3876,34 @@ __global__ __launch_bounds__(64) void k7e_sim(K7eParams q) {
 			for (int e = 0; e < 8; e++) l[e] = lrow[gg + e < n ? gg + e : n - 1];
 		};
 		fetch(g, lv, w0, w1);
+		fetch(g + 8, lvn, w0n, w1n);
 		while (__any(running)) {
 			const int gc = g < n ? g : n - 1;
-			fetch(g + 8, lvn, w0n, w1n);
+			fetch(g + 16, lvm, w0m, w1m);
 			__builtin_amdgcn_sched_barrier(0); // (keeps the requests in front of the eight steps)
+			// once every running lane is inside a frame (a few symbols after its start) the step is the DATAFCS-only one
+			const bool all_data = __all(!running || r.state == DST_DATAFCS);
+			const auto round = [&](auto step) {
 #pragma unroll
-			for (int e = 0; e < 8; e++) {
-				if (running) {
-					if (g >= n) running = false;
-					else {
-						const uint32_t word = (g >> 5) == (gc >> 5) ? w0 : w1;
-						const int dbit = (int)((word >> (g & 31)) & 1u);
-						const bool found = dec_step(r, dbit, lv[e], 5 * (p.first_group + g) + j, data);
-						if (found) { end = g; flags = 1; running = false; }
-						else if (r.state == DST_TRAINING) { end = g; flags = 0; running = false; }
-						g++;
+				for (int e = 0; e < 8; e++) {
+					if (running) {
+						if (g >= n) running = false;
+						else {
+							const uint32_t word = (g >> 5) == (gc >> 5) ? w0 : w1;
+							const int dbit = (int)((word >> (g & 31)) & 1u);
+							const bool found = step(dbit, lv[e], 5 * (p.first_group + g) + j);
+							if (found) { end = g; flags = 1; running = false; }
+							else if (r.state == DST_TRAINING) { end = g; flags = 0; running = false; }
+							g++;
+						}
 					}
 				}
-			}
+			};
+			if (all_data) round([&](int dbit, float l, long long sidx) { return dec_step<true>(r, dbit, l, sidx, data); });
+			else round([&](int dbit, float l, long long sidx) { return dec_step<false>(r, dbit, l, sidx, data); });
 #pragma unroll
-			for (int e = 0; e < 8; e++) lv[e] = lvn[e];
-			w0 = w0n; w1 = w1n;
+			for (int e = 0; e < 8; e++) { lv[e] = lvn[e]; lvn[e] = lvm[e]; }
+			w0 = w0n; w1 = w1n; w0n = w0m; w1n = w1m;
 		}
 		if (act) {
 			K7Slot* sl = q.slot + (size_t)d * K7E_OPENCAP + k;

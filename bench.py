@@ -285,7 +285,13 @@ def main():
     # ---- parity gate on the run that was just timed: the last block's outputs of a spread of receivers against the oracle
     n_checked, mismatches = 0, []
     if args.parity_receivers > 0:
-        g.sync_outputs()
+        try:
+            g.sync_outputs()
+        except gpu.AisGpuError as e:
+            # --gpu-decode: a throughput run never collects its frames, so their ring has wrapped (AISGPU_ERR_OVERFLOW); the
+            # decisions that are compared below have been copied all the same
+            if not (args.gpu_decode and "(5)" in str(e)):
+                raise
         n = min(args.parity_receivers, R)
         receivers = sorted(set(int(round(i * (R - 1) / max(n - 1, 1))) for i in range(n)))
         n_checked, mismatches = parity_check(g, data, sequence, receivers)
