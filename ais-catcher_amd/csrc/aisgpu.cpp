@@ -49,7 +49,10 @@ const float TAPS_BH_28_3[26] = { // DSP/Filters.h:45-53 (Filters::BlackmanHarris
 
 struct EvPair { hipEvent_t a, b; };
 struct TraceRec { const char* name; long long block; hipEvent_t a, b; }; // AISGPU_TRACE=1: kernel timeline from HIP events
-constexpr int NBUF = 3;    // ring depth of the buffers that cross from the front-end stream to the others
+#ifndef AISGPU_NBUF
+#define AISGPU_NBUF 3
+#endif
+constexpr int NBUF = AISGPU_NBUF;    // ring depth of the buffers that cross from the front-end stream to the others
 constexpr int MAXSUB = 4;  // downstream blocks ("flushes" of the resampler) that one input block can complete
 constexpr int XPAD = 128;  // extra history of the pre-decimated stream in front of one full block (resampler halo)
 
@@ -1621,7 +1624,7 @@ int aisgpu_run(aisgpu_t* h) {
 					HIPCHK(hipMemcpyAsync(h->d_usalpha[pb], ta, ((size_t)US_HIST + len) * sizeof(float), hipMemcpyHostToDevice, h->stream));
 					HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
 					WAITEV(h->stream, h->ev_c48free[q]);
-					if (h->eager_out) WAITEV(h->stream, h->ev_ema[(h->block_idx + 1) & 3]); // ppm[q] of block f-3 has been copied out
+					if (h->eager_out) WAITEV(h->stream, h->ev_ema[(h->block_idx + 4 - NBUF % 4) & 3]); // ppm[q] of block f-NBUF has been copied out
 					if (h->us_dsk) { // US >> DSK >> ROT: the flush is a whole number of the filter's 8192-sample output blocks
 						K1kParams kk;
 						kk.xin = xcur; kk.xin_stride = xstride; kk.xin_off = h->xh;

@@ -1,0 +1,274 @@
+// ais-catcher_amd/csrc/dec_core.h -- the frame decoder's arithmetic (AIS::Decoder, reference Marine/AIS.h:82-181, Marine/AIS.cpp:33-142)
+// as code that compiles for the device (kernels.hip) AND for the host: tests/dec_core_fuzz.cpp runs the word-parallel frame
+// evaluator below against the symbol-by-symbol step on millions of random streams without a GPU.  Nothing here is shipped as a
+// CPU path: the host build exists for that test only.
+#pragma once
+#include <stdint.h>
+#if defined(__HIPCC__)
+#define DEC_HD __device__ __forceinline__
+#else
+#define DEC_HD static inline
+#endif
+
+constexpr int DEC_LANES = 64; // a decoder's frame buffer is one column of a [word][64 lanes] tile: word w at data[64 * w]
+
+struct DecReg { int state, lastBit, prev, position, osc; float level; long long start_idx; uint32_t crc, cw, tail; int cwi, abort_pos; };
+enum { DST_TRAINING = 0, DST_STARTFLAG = 1, DST_DATAFCS = 3 };
+constexpr int DEC_MAX_FRAME = 1064 + 16 + 7;
+
+// Decoder::cannotBeValid (Marine/AIS.cpp:111-142) looks at the message type at frame positions 30, 96, 168, 184, 192, 336, 385,
+// 448 (and at the MMSI at 62).  The type is final long before position 30, so the one position at which a frame of this type
+// gets aborted is looked up once, at position 30: 0 = never, 30 = now (type 0 or > 28).
+DEC_HD int dec_abort_position(int t) {
+	constexpr uint32_t at192 = (1u << 1) | (1u << 2) | (1u << 3) | (1u << 4) | (1u << 7) | (1u << 9) | (1u << 11) | (1u << 18) | (1u << 22) |
+	                           (1u << 24) | (1u << 25) | (1u << 27) | (1u << 28);
+	if (t > 28 || t == 0) return 30;
+	if ((at192 >> t) & 1u) return 192;
+	if (t == 15 || t == 20 || t == 23) return 184;
+	return t == 10 ? 96 : t == 16 ? 168 : t == 19 ? 336 : t == 21 ? 385 : t == 5 ? 448 : 0;
+}
+
+// one symbol; data = this lane's column of the LDS frame buffer (word w at data[64 * w]); returns true when a frame with a
+// good CRC has just been completed (r.position / r.level still hold the frame's values, the caller finishes the transition).
+// A wave's decoders are in all states at once and the wave is alone on its SIMD, so what counts is the number of
+// instructions per symbol; everything is therefore evaluated with selects for all lanes, and only two rare events branch
+// (the type / MMSI look-ups at positions 30 and 62):
+//  * the 32-bit word of the frame that is being filled lives in a register (r.cw) and is written to LDS when the position
+//    moves on to the next word;
+//  * the CRC-16/X.25 register (AIS.cpp:55-64) runs SEVEN BITS BEHIND the stored bits (r.tail holds those seven): the
+//    residue check covers the first position-7 bits, so when the closing flag is complete the register already is the
+//    answer -- no loop over the frame, no undoing.  A de-stuffed bit advances nothing.
+// DATA_ONLY: the caller guarantees r.state == DST_DATAFCS (k7e_sim: a run leaves TRAINING / STARTFLAG after a few symbols and ends
+// when it leaves DATAFCS) -- the TRAINING / STARTFLAG half of the step folds away
+template <bool DATA_ONLY = false>
+DEC_HD bool dec_step(DecReg& r, int dd, float slvl, long long sidx, uint32_t* data) {
+	const int Bit = dd == r.prev; // NRZI: !(d ^ prev)
+	r.prev = dd;
+	const int st = DATA_ONLY ? (int)DST_DATAFCS : r.state, pos = r.position, osc = r.osc;
+	const bool isD = DATA_ONLY || st == DST_DATAFCS, isT = !DATA_ONLY && st == DST_TRAINING;
+	// ---- TRAINING: count alternations; two equal bits after more than four of them are the start of a flag
+	const bool alt = Bit != r.lastBit;
+	const bool to_flag = isT && !alt && pos > 4;
+	// ---- STARTFLAG: ones up to position 7, then a zero opens the frame
+	const bool open = st == DST_STARTFLAG && pos == 7 && Bit == 0;
+	const bool more = st == DST_STARTFLAG && pos != 7 && Bit == 1;
+	const int tf_state = isT ? (to_flag ? DST_STARTFLAG : DST_TRAINING) : (open ? DST_DATAFCS : (more ? DST_STARTFLAG : DST_TRAINING));
+	const int tf_pos = isT ? (alt ? pos + 1 : (to_flag ? (Bit ? 3 : 1) : 0)) : (more ? pos + 1 : 0);
+	const int tf_osc = (isT ? alt : more) ? osc : 0; // every NextState() call clears one_seq_count (AIS.cpp:33-37)
+	// ---- DATAFCS
+	const bool stuffed = Bit == 0 && osc == 5; // bit de-stuffing: the position does not advance, the next bit overwrites this one
+	const bool close = Bit == 1 && osc == 5;   // six ones: closing flag (or abort)
+	const bool adv = isD && !stuffed;
+	const int wi = pos >> 5;
+	const bool next_word = isD && wi != r.cwi;
+	if (next_word) data[64 * r.cwi] = r.cw;
+	uint32_t cw = next_word ? 0u : r.cw;
+	const uint32_t m = 1u << (pos & 31);
+	if (isD && pos < DEC_MAX_FRAME) cw = Bit ? (cw | m) : (cw & ~m);
+	const uint32_t outb = (r.tail >> 6) & 1u; // the bit that leaves the seven-bit window enters the CRC
+	const uint32_t crc_n = ((outb ^ r.crc) & 1u) ? ((r.crc >> 1) ^ 0x8408u) : (r.crc >> 1);
+	const uint32_t crc = (adv && pos >= 7) ? crc_n : r.crc;
+	const uint32_t tail = adv ? (((r.tail << 1) | (uint32_t)Bit) & 127u) : r.tail;
+	const int np = stuffed ? pos : pos + 1;
+	const bool found = isD && close && np - 7 >= 16 && crc == (uint32_t)(uint16_t)~0x0F47;
+	bool abort_frame = np == DEC_MAX_FRAME || (r.abort_pos != 0 && np == r.abort_pos);
+	int abort_pos = r.abort_pos;
+	if (isD && !close && (np == 30 || np == 62)) { // once per frame each
+		if (np == 30) { // type = first byte >> 2; bits 0..29 are all in the first word, which is still in the register
+			abort_pos = dec_abort_position((int)((cw & 255u) >> 2));
+			abort_frame = abort_frame || abort_pos == 30;
+		} else { // MMSI = bits 8..37: first word is in LDS by now, the second one in the register
+			const uint32_t w0 = data[0];
+			abort_frame = abort_frame || (((w0 >> 8) & 255u) << 22 | ((w0 >> 16) & 255u) << 14 | (w0 >> 24) << 6 | (cw & 255u) >> 2) > 999999999u;
+		}
+	}
+	const bool leave = (close && !found) || (!close && abort_frame);
+	const int d_state = leave ? DST_TRAINING : DST_DATAFCS;
+	const int d_pos = leave ? 0 : np; // (when found, position still is the frame's: the caller needs it)
+	const int d_osc = (close || leave) ? 0 : (Bit ? osc + 1 : 0);
+	// ---- commit
+	r.state = isD ? d_state : tf_state;
+	r.position = isD ? d_pos : tf_pos;
+	r.osc = isD ? d_osc : tf_osc;
+	r.level = isD ? r.level + slvl : (open ? 0.0f : r.level); // tag.mode & 1 (Common.h:242)
+	if (to_flag) r.start_idx = sidx;
+	r.crc = open ? 0xFFFFu : crc;
+	r.tail = open ? 0u : tail;
+	r.cw = open ? 0u : cw; // (msg.clear(): bits at and beyond `position` are never read)
+	r.cwi = open ? 0 : (isD ? wi : r.cwi);
+	r.abort_pos = open ? 0 : abort_pos;
+	r.lastBit = Bit;
+	if (found) data[64 * r.cwi] = r.cw; // the record is copied out of LDS
+	return found;
+}
+
+// ------------------------------------------------------------------------------------------
+// A frame in DATAFCS, 32 symbols at a time.
+//
+// Inside a frame the step above is a function of very little: the position advances with every symbol that is not a stuffed zero
+// (a zero behind exactly five ones), the frame closes at the first run of six ones, and it is abandoned where the position
+// reaches 30 (message type impossible), 62 (MMSI impossible), the type's own limit, or the maximum length.  The evaluator works
+// on words of NRZI bits: run detection, the stuffed-bit mask and the close position are shifts and ANDs, the de-stuffed bits are
+// appended to the frame buffer word-wise, the few thresholds are looked up with a rank-select, and the CRC register -- which the
+// step keeps seven bits behind the stored bits -- is computed from the frame buffer (byte-wise, table in `tab`) only when a
+// closing flag needs it or the block ends.  The level sum (tag.sample_lvl of every DATAFCS symbol, added in symbol order like
+// the step does) is likewise only formed for a completed message or a frame that continues in the next block.
+// Everything it leaves behind -- (end, flags) and, for flags 1 / 2, the DecReg and the frame buffer -- is what stepping
+// dec_step() symbol by symbol would have left (tests/dec_core_fuzz.cpp checks exactly that).
+// ------------------------------------------------------------------------------------------
+DEC_HD void dec_crc_table_entry(int i, uint16_t* tab) { // tab[i]: eight steps of the bit-serial register (AIS.cpp:55-64) from i
+	uint32_t c = (uint32_t)i;
+	for (int k = 0; k < 8; k++) c = (c & 1u) ? ((c >> 1) ^ 0x8408u) : (c >> 1);
+	tab[i] = (uint16_t)c;
+}
+
+// CRC register after the frame's first `count` bits (bit p = bit p & 31 of word p >> 5)
+DEC_HD uint32_t dec_crc_bits(const uint32_t* data, int count, const uint16_t* tab) {
+	uint32_t crc = 0xFFFFu;
+	const int nbytes = count >> 3;
+	for (int k = 0; k < nbytes; k += 4) {
+		const uint32_t w = data[DEC_LANES * (k >> 2)];
+		const int m = nbytes - k < 4 ? nbytes - k : 4;
+		for (int b = 0; b < m; b++) crc = (crc >> 8) ^ tab[(crc ^ (w >> (8 * b))) & 255u];
+	}
+	for (int p = nbytes * 8; p < count; p++) {
+		const uint32_t bit = (data[DEC_LANES * (p >> 5)] >> (p & 31)) & 1u;
+		crc = ((bit ^ crc) & 1u) ? ((crc >> 1) ^ 0x8408u) : (crc >> 1);
+	}
+	return crc;
+}
+
+DEC_HD int dec_select_bit(uint32_t m, int k) { // index of the k-th (1-based) set bit of m (k <= popcount)
+	for (int i = 1; i < k; i++) m &= m - 1;
+	return __builtin_ctz(m);
+}
+
+// r: a decoder in DATAFCS in front of symbol g (r.prev = decision g-1); brow: the packed decisions of the block (nw words, n
+// symbols); lrow: the levels.  Returns flags -- 0: back in TRAINING at symbol `end`; 1: message completed at `end`;
+// 2: the block ended (`end` = n) -- and for 1 / 2 the state and the frame buffer.
+DEC_HD int dec_run_frame(DecReg& r, uint32_t* data, const uint32_t* brow, const float* lrow, int g, int n, const uint16_t* tab, int& end) {
+	const int g_first = g;
+	int pos = r.position, osc = r.osc, abort_pos = r.abort_pos;
+	uint32_t dprev = (uint32_t)r.prev;
+	// the word that is being filled: the step flushes it when the position has moved on to the next word
+	int wi = pos >> 5;
+	uint32_t cw = r.cw;
+	if (wi != r.cwi) { data[DEC_LANES * r.cwi] = cw; cw = 0u; }
+	const int nw = (n + 31) >> 5;
+	int flags = 2, last_stuffed = 0;
+	uint32_t lastB = (uint32_t)r.lastBit;
+	end = n;
+	// a window is 32 symbols from g on: two adjacent words of the row, and the window after it needs the next one -- requested two
+	// windows ahead, a wave that is alone on its SIMD has nothing else to cover a memory round trip with
+	const int sh = g & 31;
+	const auto word_at = [&](int i) { return brow[i < nw ? i : nw - 1]; };
+	uint32_t wa = g < n ? word_at(g >> 5) : 0u, wb = g < n ? word_at((g >> 5) + 1) : 0u, wc = g < n ? word_at((g >> 5) + 2) : 0u;
+	while (g < n) {
+		const int nv = n - g < 32 ? n - g : 32;
+		const uint32_t wd = word_at((g >> 5) + 3);
+		const uint32_t D = sh ? ((wa >> sh) | (wb << (32 - sh))) : wa;
+		wa = wb; wb = wc; wc = wd;
+		const uint32_t B = ~(D ^ ((D << 1) | dprev)); // NRZI
+		const uint32_t valid = nv < 32 ? ((1u << nv) - 1u) : 0xFFFFFFFFu;
+		// ones in front of the window: the `osc` counted so far
+		const unsigned long long X = ((unsigned long long)B << 5) | (unsigned long long)(((1u << osc) - 1u) << (5 - osc));
+		const unsigned long long R5 = X & (X >> 1) & (X >> 2) & (X >> 3) & (X >> 4); // bit i: the five symbols before symbol i are ones
+		const uint32_t five = (uint32_t)R5;
+		const uint32_t C = five & B & valid; // sixth one: closing flag
+		const int e = C ? __builtin_ctz(C) : 32;
+		const int lim = C ? e + 1 : nv; // symbols of this window that are stepped at all
+		const uint32_t lm = lim < 32 ? ((1u << lim) - 1u) : 0xFFFFFFFFu;
+		const uint32_t S = five & ~B & lm;  // stuffed zeros
+		const uint32_t K = lm & ~S;         // symbols that advance the position
+		const int a = __builtin_popcount(K);
+		// de-stuff (from the top, so that the lower indices stay valid) and append at `pos`
+		uint32_t v = B & lm;
+		for (uint32_t sm = S; sm;) {
+			const int s = 31 - __builtin_clz(sm);
+			sm &= ~(1u << s);
+			const uint32_t low = v & ((1u << s) - 1u);
+			v = low | (s < 31 ? ((v >> (s + 1)) << s) : 0u);
+		}
+		{
+			const int o = pos & 31;
+			const unsigned long long t = (unsigned long long)v << o;
+			cw |= (uint32_t)t;
+			if (o + a >= 32) { data[DEC_LANES * wi] = cw; cw = (uint32_t)(t >> 32); wi++; }
+		}
+		// thresholds the position passes in this window, in order; the closing symbol itself is exempt (AIS.cpp:`!close && abort`)
+		int abort_at = -1;
+		const int np1 = pos + a; // position behind the window
+		if (pos < 30 && np1 >= 30) {
+			const int sy = dec_select_bit(K, 30 - pos);
+			if (!(C && sy == e)) {
+				const uint32_t w0 = wi == 0 ? cw : data[0];
+				abort_pos = dec_abort_position((int)((w0 & 255u) >> 2));
+				if (abort_pos == 30) abort_at = sy;
+			}
+		}
+		if (abort_at < 0 && pos < 62 && np1 >= 62) {
+			const int sy = dec_select_bit(K, 62 - pos);
+			if (!(C && sy == e)) {
+				const uint32_t w0 = data[0], w1 = wi == 1 ? cw : data[DEC_LANES];
+				if ((((w0 >> 8) & 255u) << 22 | ((w0 >> 16) & 255u) << 14 | (w0 >> 24) << 6 | (w1 & 255u) >> 2) > 999999999u) abort_at = sy;
+			}
+		}
+		if (abort_at < 0 && abort_pos > 30 && pos < abort_pos && np1 >= abort_pos) {
+			const int sy = dec_select_bit(K, abort_pos - pos);
+			if (!(C && sy == e)) abort_at = sy;
+		}
+		if (abort_at < 0 && pos < DEC_MAX_FRAME && np1 >= DEC_MAX_FRAME) {
+			const int sy = dec_select_bit(K, DEC_MAX_FRAME - pos);
+			if (!(C && sy == e)) abort_at = sy;
+		}
+		if (abort_at >= 0) { end = g + abort_at; return 0; }
+		pos = np1;
+		dprev = (D >> (nv - 1)) & 1u; // (a closed window ends the run: dprev / lastB are then set below)
+		if (C) {
+			end = g + e;
+			data[DEC_LANES * wi] = cw;
+			if (pos - 7 < 16 || dec_crc_bits(data, pos - 7, tab) != (uint32_t)(uint16_t)~0x0F47) return 0;
+			flags = 1;
+			dprev = (D >> e) & 1u; lastB = 1u; osc = 0; last_stuffed = 0;
+			break;
+		}
+		lastB = (B >> (nv - 1)) & 1u;
+		last_stuffed = (int)((S >> (nv - 1)) & 1u);
+		{ // ones at the end of the window
+			const uint32_t top = ~(B << (32 - nv)); // (nv >= 1)
+			const int t = top ? __builtin_clz(top) : 32;
+			osc = t >= nv ? osc + nv : t;
+		}
+		g += nv;
+	}
+	if (flags == 2 && g == g_first) return 2; // (nothing stepped: the state is the one that came in)
+	// ---- the state the step would have left
+	// (cwi, cw): the word of the position at which the last symbol was stored -- `pos` itself for a stuffed zero, pos - 1 otherwise.
+	// Where the position has just crossed into a word that no symbol has touched, the step still holds the full one.
+	const int last_pos = last_stuffed ? pos : pos - 1;
+	const int cwi = last_pos >> 5;
+	if (cwi != wi) cw = data[DEC_LANES * cwi];
+	else data[DEC_LANES * wi] = cw;
+	const int last_sym = flags == 1 ? end : n - 1;
+	float level = r.level;
+	{ // (in symbol order, like the step; eight loads in flight)
+		int i = g_first;
+		for (; i + 8 <= last_sym + 1; i += 8) {
+			float l[8];
+			for (int e = 0; e < 8; e++) l[e] = lrow[i + e];
+			for (int e = 0; e < 8; e++) level = level + l[e];
+		}
+		for (; i <= last_sym; i++) level = level + lrow[i];
+	}
+	r.level = level;
+	r.state = DST_DATAFCS; r.position = pos; r.osc = osc; r.prev = (int)dprev; r.lastBit = (int)lastB;
+	r.cw = cw; r.cwi = cwi; r.abort_pos = abort_pos;
+	r.crc = dec_crc_bits(data, pos >= 7 ? pos - 7 : 0, tab);
+	uint32_t tail = 0;
+	for (int k = 0; k < 7; k++) {
+		const int p = pos - 1 - k;
+		if (p >= 0) tail |= ((data[DEC_LANES * (p >> 5)] >> (p & 31)) & 1u) << k;
+	}
+	r.tail = tail;
+	return flags;
+}

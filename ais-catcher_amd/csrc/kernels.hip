@@ -3379,95 +3379,7 @@ __global__ __launch_bounds__(64) void kv2_carry(KV2Params p) {
 // reset cannot complete a frame, so one repair pass is enough).  Frames leave as records (bits as received, level sum,
 // indices); length validation, the level in dB and the NMEA text stay on the host (Marine/Message.cpp), they are string work.
 // ------------------------------------------------------------------------------------------
-struct DecReg { int state, lastBit, prev, position, osc; float level; long long start_idx; uint32_t crc, cw, tail; int cwi, abort_pos; };
-enum { DST_TRAINING = 0, DST_STARTFLAG = 1, DST_DATAFCS = 3 };
-constexpr int DEC_MAX_FRAME = 1064 + 16 + 7;
-
-// Decoder::cannotBeValid (Marine/AIS.cpp:111-142) looks at the message type at frame positions 30, 96, 168, 184, 192, 336, 385,
-// 448 (and at the MMSI at 62).  The type is final long before position 30, so the one position at which a frame of this type
-// gets aborted is looked up once, at position 30: 0 = never, 30 = now (type 0 or > 28).
-__device__ __forceinline__ int dec_abort_position(int t) {
-	constexpr uint32_t at192 = (1u << 1) | (1u << 2) | (1u << 3) | (1u << 4) | (1u << 7) | (1u << 9) | (1u << 11) | (1u << 18) | (1u << 22) |
-	                           (1u << 24) | (1u << 25) | (1u << 27) | (1u << 28);
-	if (t > 28 || t == 0) return 30;
-	if ((at192 >> t) & 1u) return 192;
-	if (t == 15 || t == 20 || t == 23) return 184;
-	return t == 10 ? 96 : t == 16 ? 168 : t == 19 ? 336 : t == 21 ? 385 : t == 5 ? 448 : 0;
-}
-
-// one symbol; data = this lane's column of the LDS frame buffer (word w at data[64 * w]); returns true when a frame with a
-// good CRC has just been completed (r.position / r.level still hold the frame's values, the caller finishes the transition).
-// A wave's decoders are in all states at once and the wave is alone on its SIMD, so what counts is the number of
-// instructions per symbol; everything is therefore evaluated with selects for all lanes, and only two rare events branch
-// (the type / MMSI look-ups at positions 30 and 62):
-//  * the 32-bit word of the frame that is being filled lives in a register (r.cw) and is written to LDS when the position
-//    moves on to the next word;
-//  * the CRC-16/X.25 register (AIS.cpp:55-64) runs SEVEN BITS BEHIND the stored bits (r.tail holds those seven): the
-//    residue check covers the first position-7 bits, so when the closing flag is complete the register already is the
-//    answer -- no loop over the frame, no undoing.  A de-stuffed bit advances nothing.
-// DATA_ONLY: the caller guarantees r.state == DST_DATAFCS (k7e_sim: a run leaves TRAINING / STARTFLAG after a few symbols and ends
-// when it leaves DATAFCS) -- the TRAINING / STARTFLAG half of the step folds away
-template <bool DATA_ONLY = false>
-__device__ __forceinline__ bool dec_step(DecReg& r, int dd, float slvl, long long sidx, uint32_t* data) {
-	const int Bit = dd == r.prev; // NRZI: !(d ^ prev)
-	r.prev = dd;
-	const int st = DATA_ONLY ? (int)DST_DATAFCS : r.state, pos = r.position, osc = r.osc;
-	const bool isD = DATA_ONLY || st == DST_DATAFCS, isT = !DATA_ONLY && st == DST_TRAINING;
-	// ---- TRAINING: count alternations; two equal bits after more than four of them are the start of a flag
-	const bool alt = Bit != r.lastBit;
-	const bool to_flag = isT && !alt && pos > 4;
-	// ---- STARTFLAG: ones up to position 7, then a zero opens the frame
-	const bool open = st == DST_STARTFLAG && pos == 7 && Bit == 0;
-	const bool more = st == DST_STARTFLAG && pos != 7 && Bit == 1;
-	const int tf_state = isT ? (to_flag ? DST_STARTFLAG : DST_TRAINING) : (open ? DST_DATAFCS : (more ? DST_STARTFLAG : DST_TRAINING));
-	const int tf_pos = isT ? (alt ? pos + 1 : (to_flag ? (Bit ? 3 : 1) : 0)) : (more ? pos + 1 : 0);
-	const int tf_osc = (isT ? alt : more) ? osc : 0; // every NextState() call clears one_seq_count (AIS.cpp:33-37)
-	// ---- DATAFCS
-	const bool stuffed = Bit == 0 && osc == 5; // bit de-stuffing: the position does not advance, the next bit overwrites this one
-	const bool close = Bit == 1 && osc == 5;   // six ones: closing flag (or abort)
-	const bool adv = isD && !stuffed;
-	const int wi = pos >> 5;
-	const bool next_word = isD && wi != r.cwi;
-	if (next_word) data[64 * r.cwi] = r.cw;
-	uint32_t cw = next_word ? 0u : r.cw;
-	const uint32_t m = 1u << (pos & 31);
-	if (isD && pos < DEC_MAX_FRAME) cw = Bit ? (cw | m) : (cw & ~m);
-	const uint32_t outb = (r.tail >> 6) & 1u; // the bit that leaves the seven-bit window enters the CRC
-	const uint32_t crc_n = ((outb ^ r.crc) & 1u) ? ((r.crc >> 1) ^ 0x8408u) : (r.crc >> 1);
-	const uint32_t crc = (adv && pos >= 7) ? crc_n : r.crc;
-	const uint32_t tail = adv ? (((r.tail << 1) | (uint32_t)Bit) & 127u) : r.tail;
-	const int np = stuffed ? pos : pos + 1;
-	const bool found = isD && close && np - 7 >= 16 && crc == (uint32_t)(uint16_t)~0x0F47;
-	bool abort_frame = np == DEC_MAX_FRAME || (r.abort_pos != 0 && np == r.abort_pos);
-	int abort_pos = r.abort_pos;
-	if (isD && !close && (np == 30 || np == 62)) { // once per frame each
-		if (np == 30) { // type = first byte >> 2; bits 0..29 are all in the first word, which is still in the register
-			abort_pos = dec_abort_position((int)((cw & 255u) >> 2));
-			abort_frame = abort_frame || abort_pos == 30;
-		} else { // MMSI = bits 8..37: first word is in LDS by now, the second one in the register
-			const uint32_t w0 = data[0];
-			abort_frame = abort_frame || (((w0 >> 8) & 255u) << 22 | ((w0 >> 16) & 255u) << 14 | (w0 >> 24) << 6 | (cw & 255u) >> 2) > 999999999u;
-		}
-	}
-	const bool leave = (close && !found) || (!close && abort_frame);
-	const int d_state = leave ? DST_TRAINING : DST_DATAFCS;
-	const int d_pos = leave ? 0 : np; // (when found, position still is the frame's: the caller needs it)
-	const int d_osc = (close || leave) ? 0 : (Bit ? osc + 1 : 0);
-	// ---- commit
-	r.state = isD ? d_state : tf_state;
-	r.position = isD ? d_pos : tf_pos;
-	r.osc = isD ? d_osc : tf_osc;
-	r.level = isD ? r.level + slvl : (open ? 0.0f : r.level); // tag.mode & 1 (Common.h:242)
-	if (to_flag) r.start_idx = sidx;
-	r.crc = open ? 0xFFFFu : crc;
-	r.tail = open ? 0u : tail;
-	r.cw = open ? 0u : cw; // (msg.clear(): bits at and beyond `position` are never read)
-	r.cwi = open ? 0 : (isD ? wi : r.cwi);
-	r.abort_pos = open ? 0 : abort_pos;
-	r.lastBit = Bit;
-	if (found) data[64 * r.cwi] = r.cw; // the record is copied out of LDS
-	return found;
-}
+#include "dec_core.h"
 
 __global__ __launch_bounds__(64) void k7_decode(K7Params p) {
 	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64]; // [word][lane]
@@ -3824,15 +3736,19 @@ __global__ __launch_bounds__(64) void k7e_scan(K7eParams q) {
 }
 
 // one lane per (decoder, run): the reference's state machine from the candidate (or from the carried state) until it is back in
-// TRAINING, has completed a message, or the block ends
+// TRAINING, has completed a message, or the block ends.  Up to the frame's first symbol (the rest of the start flag: nine
+// symbols at most) that is the step itself; inside the frame it is dec_run_frame (dec_core.h), which works on words of 32
+// symbols -- a frame of 250 symbols is eight rounds of ~100 instructions instead of 250 steps of ~180.
 __global__ __launch_bounds__(64) void k7e_sim(K7eParams q) {
 	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64]; // [word][lane]
+	__shared__ uint16_t s_crc[256];
 	const K7Params& p = q.k;
 	__builtin_amdgcn_s_setprio(3);
 	const int lane = threadIdx.x;
+	for (int i = lane; i < 256; i += 64) dec_crc_table_entry(i, s_crc);
+	__syncthreads();
 	// K7E_SIM_LANES lanes per decoder take its runs round robin.  A decoder has ~4.5 runs per block on the bench signal (13 at
-	// most), a step costs ~180 instructions of a wave that is alone on its SIMD, and there are fewer waves than SIMDs: with 16
-	// lanes a second round (0.1 ms) practically never happens, and idle lanes cost nothing.
+	// most) and there are fewer waves than SIMDs: with 16 lanes a second round practically never happens, and idle lanes cost nothing.
 	const int d = blockIdx.x * (64 / K7E_SIM_LANES) + lane / K7E_SIM_LANES;
 	const int n_dec = p.n_chan * 5;
 	const int dd_ = d < n_dec ? d : 0;
@@ -3842,7 +3758,7 @@ __global__ __launch_bounds__(64) void k7e_sim(K7eParams q) {
 	const uint32_t* brow = p.bits + (size_t)dd_ * p.bits_stride;
 	const float* lrow = p.lvl + (size_t)chan * p.lvl_stride;
 	uint32_t* data = fdata + lane;
-	const int n = p.n_groups;
+	const int n = p.n_groups, nw = (n + 31) >> 5;
 	const auto dd_at = [&](int g) -> int { return g < 0 ? st->prev : (int)((brow[g >> 5] >> (g & 31)) & 1u); };
 	for (int k = lane % K7E_SIM_LANES; __any(k < nrun); k += K7E_SIM_LANES) {
 		const bool act = k < nrun;
@@ -3859,52 +3775,26 @@ __global__ __launch_bounds__(64) void k7e_sim(K7eParams q) {
 			r.state = DST_TRAINING; r.position = 5; r.osc = 0; r.level = 0.0f; r.start_idx = 0;
 			r.prev = dd_at(c - 1);
 			r.lastBit = c - 1 < 0 ? st->lastBit : (dd_at(c - 1) == (c - 2 < 0 ? st->prev : dd_at(c - 2)));
-			for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = 0u;
 			r.crc = 0xFFFFu; r.cw = 0u; r.cwi = 0; r.tail = 0u; r.abort_pos = 0;
 		}
 		bool running = act;
 		int g = c, end = n, flags = 2; // (2: still running when the block ends)
-		// eight symbols per round: their levels and decisions are fetched together, and TWO rounds ahead -- a running lane advances
-		// by exactly eight symbols per round, so the addresses are known, and a round that waits for its own loads is pure memory
-		// latency (~2 us per eight symbols next to the front end, against ~1.5 us of steps)
-		float lv[8], lvn[8], lvm[8];
-		uint32_t w0, w1, w0n, w1n, w0m, w1m;
-		const auto fetch = [&](int gg, float (&l)[8], uint32_t& a, uint32_t& b) {
-			const int gc = gg < n ? gg : n - 1;
-			a = brow[gc >> 5]; b = brow[(gc + 7 < n ? gc + 7 : n - 1) >> 5];
-#pragma unroll
-			for (int e = 0; e < 8; e++) l[e] = lrow[gg + e < n ? gg + e : n - 1];
-		};
-		fetch(g, lv, w0, w1);
-		fetch(g + 8, lvn, w0n, w1n);
-		while (__any(running)) {
-			const int gc = g < n ? g : n - 1;
-			fetch(g + 16, lvm, w0m, w1m);
-			__builtin_amdgcn_sched_barrier(0); // (keeps the requests in front of the eight steps)
-			// once every running lane is inside a frame (a few symbols after its start) the step is the DATAFCS-only one
-			const bool all_data = __all(!running || r.state == DST_DATAFCS);
-			const auto round = [&](auto step) {
-#pragma unroll
-				for (int e = 0; e < 8; e++) {
-					if (running) {
-						if (g >= n) running = false;
-						else {
-							const uint32_t word = (g >> 5) == (gc >> 5) ? w0 : w1;
-							const int dbit = (int)((word >> (g & 31)) & 1u);
-							const bool found = step(dbit, lv[e], 5 * (p.first_group + g) + j);
-							if (found) { end = g; flags = 1; running = false; }
-							else if (r.state == DST_TRAINING) { end = g; flags = 0; running = false; }
-							g++;
-						}
-					}
+		// ---- the rest of the start flag, symbol by symbol (its decisions are in two adjacent words)
+		const int i0 = c >> 5;
+		const uint32_t w0 = brow[i0 < nw ? i0 : nw - 1], w1 = brow[i0 + 1 < nw ? i0 + 1 : nw - 1];
+		while (__any(running && r.state != DST_DATAFCS)) {
+			if (running && r.state != DST_DATAFCS) {
+				if (g >= n) running = false;
+				else {
+					const uint32_t word = (g >> 5) == i0 ? w0 : w1;
+					dec_step<false>(r, (int)((word >> (g & 31)) & 1u), 0.0f, 5 * (p.first_group + g) + j, data);
+					if (r.state == DST_TRAINING) { end = g; flags = 0; running = false; }
+					g++;
 				}
-			};
-			if (all_data) round([&](int dbit, float l, long long sidx) { return dec_step<true>(r, dbit, l, sidx, data); });
-			else round([&](int dbit, float l, long long sidx) { return dec_step<false>(r, dbit, l, sidx, data); });
-#pragma unroll
-			for (int e = 0; e < 8; e++) { lv[e] = lvn[e]; lvn[e] = lvm[e]; }
-			w0 = w0n; w1 = w1n; w0n = w0m; w1n = w1m;
+			}
 		}
+		// ---- the frame
+		if (running) flags = dec_run_frame(r, data, brow, lrow, g, n, s_crc, end);
 		if (act) {
 			K7Slot* sl = q.slot + (size_t)d * K7E_OPENCAP + k;
 			sl->end = end; sl->flags = flags;
@@ -3913,7 +3803,8 @@ __global__ __launch_bounds__(64) void k7e_sim(K7eParams q) {
 				o->state = r.state; o->lastBit = r.lastBit; o->prev = r.prev; o->position = r.position; o->osc = r.osc;
 				o->level = r.level; o->start_idx = r.start_idx;
 				if (flags == 2) data[64 * r.cwi] = r.cw;
-				for (int w = 0; w < DEC_DATA_WORDS; w++) o->data[w] = data[64 * w];
+				const int used = flags == 1 ? (r.position + 31) >> 5 : r.cwi + 1; // (words behind them are never read)
+				for (int w = 0; w < DEC_DATA_WORDS; w++) o->data[w] = w < used ? data[64 * w] : 0u;
 				o->crc[0] = r.crc; o->crc[1] = r.cw; o->crc[2] = (uint32_t)r.cwi; o->crc[3] = r.tail; o->crc[4] = (uint32_t)r.abort_pos;
 			}
 		}

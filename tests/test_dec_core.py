@@ -1,0 +1,29 @@
+"""The word-parallel frame evaluator of the device decoders (ais-catcher_amd/csrc/dec_core.h: dec_run_frame, what k7e_sim runs
+inside a frame) against the symbol-by-symbol step of the same header, on random streams cut into random blocks -- the device
+header built for the host (tests/dec_core_fuzz.cpp).  The step's own semantics (reference Marine/AIS.h:82-181, Marine/AIS.cpp:33-142)
+are pinned by the GPU parity tests against the reference's decoders; this test needs no GPU."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def fuzz_binary(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("dec_core") / "dec_core_fuzz")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "ais-catcher_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "dec_core_fuzz.cpp"), "-o", out], check=True)
+    return out
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_frame_evaluator_equals_the_step(fuzz_binary, seed):
+    r = subprocess.run([fuzz_binary, "250000", str(seed)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all equal" in r.stdout
+    # the generator reaches what it is meant to reach: completed messages, abandoned frames, frames that cross blocks
+    runs, messages, other, crossings = (int(v) for v in re.findall(r"\d+", r.stdout)[:4])
+    assert runs == 250000 and messages > 10000 and other > 100000 and crossings > 50000, r.stdout
