@@ -127,7 +127,7 @@ struct aisgpu {
 	int npost = 2;                    // CIC5 stages behind the resampler (K1u): 2, 1 (192k bucket), 0 (96 kSPS input: no resampler either)
 	bool us_dsk = false;              // Upsample in front of DownsampleKFilter (rates below a decimate-by-3 bucket): resampler flow, K1k front end
 	int KPa = 0;                      // != 0: the pre-decimation runs as KPa stages, then four (rates above 6144k that are resampled: 8 / 10 MSPS)
-	float2* d_rot[2] = {};
+	float2* d_rot[4] = {}; // Rotate phasor tables: ring of 4 on the main path (block f & 3, staged two blocks ahead), [f & 1] on the others
 	int* d_usidx[2] = {}; float* d_usalpha[2] = {};
 	float2 *d_c48[NBUF] = {}, *d_sym[2] = {};
 	float2 *d_rotT[NBUF] = {};
@@ -136,7 +136,7 @@ struct aisgpu {
 	int* d_fz[NBUF] = {};
 	float* d_magT[NBUF] = {}; // shifted FFT magnitudes (written by the FFT on the front stream, read by the searches on s3)
 	bool fft_in_k1 = false;   // the spectral analysis rides at the end of the front-end waves (k1_fft_tail): fz / ppm come from K1
-	uint32_t* d_bits[2] = {};
+	uint32_t* d_bits[4] = {}; // ring of 4 (block f & 3), like lvl: the frame decoder of block f-2 may still be reading while PhaseSearch of block f writes
 	bool challenger = false;
 	bool v2 = false; float2* h_c48 = nullptr; // ModelEngineV2: front end only, the 48 kHz channels go to the host (MAXSUB slots)
 	bool v2_assist = true; float2* d_v2hist = nullptr; float *d_v2f = nullptr, *d_v2prom = nullptr, *d_v2en = nullptr, *h_v2f = nullptr, *h_v2prom = nullptr, *h_v2en = nullptr; // decoder-independent part of V2::Engine on the device
@@ -147,16 +147,18 @@ struct aisgpu {
 	uint32_t* d_pswords = nullptr; float *d_psma0 = nullptr, *d_psma1 = nullptr; unsigned* d_psfin = nullptr; int* d_psflag = nullptr;
 	int ps_warm = 256; bool ps_parallel = true;
 	struct { bool valid = false; K4Params k4; int pb = 0, lv = 0; long long g0 = 0; unsigned block = 0, sub = 0; hipStream_t s = nullptr; } wpend; // walk not yet run
+	struct { bool valid = false; int pb = 0, lv = 0, n_groups = 0; long long g0 = 0; unsigned block = 0, sub = 0; } dpend; // frame decoders not yet enqueued (dec_defer)
+	bool dec_defer = false; // the frame decoders of block f are enqueued behind the derotation / FIR kernel of block f+1 (they share its stream)
 	bool walk_ride = true;
 	bool ps_lane = false; int walk_prio = 3; int ps_prio = 0; int ps_cl = 512; uint2* d_pslw[2] = {}; // lane-per-chunk PhaseSearchEMA: chunk length, sign words [n_chains][Gcap]
 	// host (pinned)
 	void* h_in[2] = {};
-	float2* h_rot[2] = {};
+	float2* h_rot[4] = {};
 	int* h_usidx[2] = {}; float* h_usalpha[2] = {};
-	hipEvent_t rot_ev[2] = {}; bool rot_ev_used[2] = {}; bool rot_ahead = false; // (rot_ahead: the next block's table is already on its way)
-	RotWorker rw; int rot_slot[2] = {}; bool rot_worker = true; // AISGPU_ROT_WORKER=0: tables generated on the calling thread
+	hipEvent_t rot_ev[4] = {}; bool rot_ev_used[4] = {}; long long rot_next = 0; int rot_lead = 2; // rot_next: first block whose table has not been staged yet
+	RotWorker rw; int rot_slot[4] = {}; bool rot_worker = true; // AISGPU_ROT_WORKER=0: tables generated on the calling thread
 	bool rot_stage_ahead = true;
-	float2* h_rot_dev[2] = {}; bool rot_by_kernel = true; // device view of the pinned table buffers
+	float2* h_rot_dev[4] = {}; bool rot_by_kernel = true; // device view of the pinned table buffers
 	uint32_t* h_bits = nullptr; float* h_lvl = nullptr; float* h_ppm = nullptr; // MAXSUB slots each
 	// stream state
 	long long in_blocks = 0;     // input blocks run so far
@@ -387,13 +389,34 @@ int copy_out_eager(aisgpu_t* h, int pb, int lv, unsigned block, unsigned sub, hi
 	if (!h->eager_out || sub >= (unsigned)MAXSUB) return AISGPU_OK;
 	const size_t C = h->n_chan, slot = (size_t)h->out_set * MAXSUB + sub;
 	const int q = (int)(block % NBUF);
-	HIPCHK(hipMemcpyAsync(h->h_bits + slot * C * 5 * h->words, h->d_bits[pb], C * 5 * h->words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	HIPCHK(hipMemcpyAsync(h->h_bits + slot * C * 5 * h->words, h->d_bits[lv], C * 5 * h->words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 	HIPCHK(hipMemcpyAsync(h->h_lvl + slot * C * h->Gcap, h->d_lvl[lv], C * h->Gcap * sizeof(float), hipMemcpyDeviceToHost, s));
 	HIPCHK(hipMemcpyAsync(h->h_ppm + slot * C * h->W, h->d_ppm[q], C * h->W * sizeof(float), hipMemcpyDeviceToHost, s));
 	return AISGPU_OK;
 }
 
+// the frame decoders of the block whose PhaseSearch has been enqueued (dec_defer: one block later, see aisgpu_create)
+int flush_decode(aisgpu_t* h) {
+	if (!h->dpend.valid) return AISGPU_OK;
+	h->dpend.valid = false;
+	const int pb = h->dpend.pb, lv = h->dpend.lv;
+	WAITEV(h->s5, h->ev_k4[pb]);
+	int rc = enqueue_decode(h, pb, lv, h->dpend.g0, h->dpend.n_groups, h->dpend.block, h->dpend.sub, h->s5);
+	if (rc) return rc;
+	rc = copy_out_eager(h, pb, lv, h->dpend.block, h->dpend.sub, h->s5);
+	if (rc) return rc;
+	HIPCHK(hipEventRecord(h->ev_ema[lv], h->s5));
+	return AISGPU_OK;
+}
+
 int finish_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s) {
+	if (h->gpu_decode && h->dec_defer) {
+		{ int rc = flush_decode(h); if (rc) return rc; }
+		HIPCHK(hipEventRecord(h->ev_k4[pb], s));
+		h->dpend.valid = true; h->dpend.pb = pb; h->dpend.lv = lv; h->dpend.g0 = g0; h->dpend.n_groups = n_groups; h->dpend.block = block; h->dpend.sub = sub;
+		if (h->serial) return flush_decode(h);
+		return AISGPU_OK;
+	}
 	if (h->gpu_decode) { // the frame decoder is a long latency-bound kernel of a few waves: own stream, so that the next
 		// block's PhaseSearchEMA does not queue behind it; sym/lvl/bits[pb] are free again only when IT is done
 		HIPCHK(hipEventRecord(h->ev_k4[pb], s));
@@ -421,10 +444,12 @@ int flush_walk(aisgpu_t* h) {
 
 // PhaseSearchEMA / PhaseSearch of one downstream block (sym/lvl parity pb) on stream s
 int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s) {
-	// bits[pb] was last read by the frame decoder / the copies of block f-2 (slot lv ^ 2): long done, and ordered here
-	WAITEV(s, h->ev_ema[lv ^ 2]);
+	// bits[lv] was last read by the frame decoder / the copies of block f-4: long done, and ordered here.  (A ring of two made
+	// PhaseSearch(f) wait for the frame decoders of block f-2, which start behind PhaseSearch(f-2): a loop of two steps that
+	// had to hold a PhaseSearch and a decoder pass one after the other -- 0.62 ms per step with the decoders on the device.)
+	WAITEV(s, h->ev_ema[lv]);
 	K4Params k4;
-	k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[pb]; k4.bits_stride = h->words;
+	k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[lv]; k4.bits_stride = h->words;
 	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
 	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag + pb;
 	k4.n_chains = h->n_chains; k4.n_groups = n_groups;
@@ -466,7 +491,7 @@ int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned
 // AIS::Decoder on the device, behind PhaseSearchEMA of the same block (same stream)
 K7Params make_k7(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub) {
 	K7Params k7;
-	k7.bits = h->d_bits[pb]; k7.bits_stride = h->words; k7.lvl = h->d_lvl[lv]; k7.lvl_stride = h->Gcap;
+	k7.bits = h->d_bits[lv]; k7.bits_stride = h->words; k7.lvl = h->d_lvl[lv]; k7.lvl_stride = h->Gcap;
 	k7.state = h->d_dec; k7.frames = h->d_frames; k7.frame_count = h->d_frame_count; k7.max_frames = h->max_frames;
 	k7.first_group = g0; k7.n_groups = n_groups; k7.n_chan = h->n_chan; k7.block = block; k7.sub = sub;
 	k7.kind = h->dec_kind;
@@ -570,6 +595,7 @@ int enqueue_fused_back(aisgpu_t* h) {
 	if (!(h->ablate & 2)) { TraceScope t(h, "derotfir", h->s4); HIPCHK(launch_k6(k6, h->s4)); }
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s4));
 	HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4));
+	{ int rc = flush_decode(h); if (rc) return rc; } // (dec_defer) the previous block's frame decoders, behind this block's derotation / FIR kernel
 	WAITEV(h->s1, h->ev_k3[pb]);
 	TraceScope t(h, "psearch", h->s1);
 	return enqueue_k4(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub, h->s1);
@@ -580,7 +606,7 @@ int enqueue_k46(aisgpu_t* h, int q, int pb, int lv, long long g0, int n_groups, 
 	hipStream_t s = h->s1;
 	K46Params k{};
 	K4Params& k4 = k.k4;
-	k4.sym = nullptr; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[pb]; k4.bits_stride = h->words;
+	k4.sym = nullptr; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[lv]; k4.bits_stride = h->words;
 	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
 	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag + pb;
 	k4.qflag = h->d_qflag + (size_t)pb * h->n_quads; k4.qflag_div = 20;
@@ -594,8 +620,7 @@ int enqueue_k46(aisgpu_t* h, int q, int pb, int lv, long long g0, int n_groups, 
 	memcpy(k.taps, TAPS_COHERENT, sizeof k.taps);
 	k.first_group = g0; k.n_rel0 = n_rel0; k.L = h->L; k.n_windows = h->W; k.n_chan = h->n_chan; k.sequential = 0;
 	WAITEV(s, h->ev_phasor[q]);
-	WAITEV(s, h->ev_ema[lv]);     // lvl[lv] was last read by the frame decoder / the copies of block f-4,
-	WAITEV(s, h->ev_ema[lv ^ 2]); // bits[pb] by those of block f-2
+	WAITEV(s, h->ev_ema[lv]);     // lvl[lv] and bits[lv] were last read by the frame decoder / the copies of block f-4
 	{ int rc = flush_walk(h); if (rc) return rc; }
 	if (!(h->ablate & 1)) { TraceScope t(h, "firsearch", s); HIPCHK(launch_k46(k, s)); }
 	HIPCHK(hipEventRecord(h->ev_c48free[q], s));
@@ -832,6 +857,7 @@ int sync_all(aisgpu_t* h) {
 	{ int rc = enqueue_back(h); if (rc) return rc; }
 	{ int rc = enqueue_fused_back(h); if (rc) return rc; }
 	{ int rc = flush_walk(h); if (rc) return rc; }
+	{ int rc = flush_decode(h); if (rc) return rc; }
 	HIPCHK(hipStreamSynchronize(h->stream));
 	HIPCHK(hipStreamSynchronize(h->s1));
 	HIPCHK(hipStreamSynchronize(h->s3));
@@ -1065,7 +1091,22 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			if (pk != 99) masked = masked && hipStreamCreateWithPriority(&h->s4, hipStreamNonBlocking, pk) == hipSuccess;
 			else
 			masked = masked && hipExtStreamCreateWithCUMask(&h->s4, (uint32_t)words, back.data()) == hipSuccess;
-			if (masked && (cfg->flags & AISGPU_FLAG_GPU_DECODE)) masked = hipExtStreamCreateWithCUMask(&h->s5, (uint32_t)words, back.data()) == hipSuccess;
+			// Where the frame decoders run (AISGPU_DEC_STREAM).  The chip dispatches from four compute queues at a time: a fifth active
+			// stream shares a pipe with one of the others and their kernels take turns (0.59 - 0.62 ms per step with ModelDefault's
+			// event-driven decoders on a stream of their own, whatever those kernels cost -- even with all three skipped).  So by
+			// default they share the derotation / FIR stream (4), a block late (dec_defer): 0.52 ms.  5 = own stream (the sequential
+			// decoder kernels of the other engines, which run for a whole step), 1 = PhaseSearch's stream.
+			const char* ds = getenv("AISGPU_DEC_STREAM");
+			const bool default_kind = cfg->model != AISGPU_MODEL_STANDARD && cfg->model != AISGPU_MODEL_CHALLENGER && cfg->model != AISGPU_MODEL_BASE;
+			const int dsel = ds ? atoi(ds) : (default_kind ? 4 : 5);
+			if (dsel == 4 || dsel == 1) h->s5 = nullptr;
+			else if (masked && (cfg->flags & AISGPU_FLAG_GPU_DECODE)) {
+				// the event-driven frame decoders are three latency-bound kernels of a few dozen waves (k7e_scan 40, k7e_resolve 43):
+				// AISGPU_DEC_MASK=1 puts them on the reserved CUs, next to the phasor recurrence, instead of among the front end's waves
+				const char* dm = getenv("AISGPU_DEC_MASK");
+				const bool on_lat = dm && atoi(dm) == 1;
+				masked = hipExtStreamCreateWithCUMask(&h->s5, (uint32_t)words, (on_lat ? lat : back).data()) == hipSuccess;
+			}
 			if (!masked) {
 				(void)hipGetLastError();
 				hipStream_t* all[5] = { &h->stream, &h->s1, &h->s3, &h->s4, &h->s5 };
@@ -1076,7 +1117,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 				HIPCHK(hipStreamCreateWithFlags(&h->s4, hipStreamNonBlocking));
 				if (cfg->flags & AISGPU_FLAG_GPU_DECODE) HIPCHK(hipStreamCreateWithFlags(&h->s5, hipStreamNonBlocking));
 			}
-			if (!h->s5) h->s5 = h->s4; // a fifth stream only for the optional frame decoder: beyond four streams HIP shares hardware
+			if (!h->s5) h->s5 = dsel == 1 ? h->s1 : h->s4; // a fifth stream only for the optional frame decoder: beyond four streams HIP shares hardware
 			                           // queues and kernels of different streams start waiting for each other (0.62 -> 0.69 ms per step)
 		} else {
 			HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -1087,6 +1128,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			else h->s5 = h->s4;
 		}
 		h->s2 = h->s1; // apply + FIR + PhaseSearchEMA of a block run back to back on one stream
+		h->dec_defer = h->s5 == h->s4 && h->s4 != h->stream;
+		if (const char* e = getenv("AISGPU_DEC_DEFER")) h->dec_defer = atoi(e) != 0;
 	}
 	for (int i = 0; i < NBUF; i++) {
 		HIPCHK(hipEventCreateWithFlags(&h->ev_front[i], hipEventDisableTiming));
@@ -1150,12 +1193,14 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			for (int i = 0; i < 2; i++) HIPCHK(dalloc((unsigned char**)&h->d_hist2[i], R * (size_t)(h->tile96 << 4) * 8));
 		}
 	}
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < 4; i++) {
 		HIPCHK(dalloc(&h->d_rot[i], (size_t)ROT_HIST + h->n96));
 		HIPCHK(hipHostMalloc((void**)&h->h_rot[i], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipHostMallocDefault));
 		HIPCHK(hipEventCreateWithFlags(&h->rot_ev[i], hipEventDisableTiming));
 		if (hipHostGetDevicePointer((void**)&h->h_rot_dev[i], h->h_rot[i], 0) != hipSuccess) h->rot_by_kernel = false;
 		if (const char* e = getenv("AISGPU_ROTCOPY")) h->rot_by_kernel = h->rot_by_kernel && atoi(e) == 0;
+	}
+	for (int i = 0; i < 2; i++) {
 		if (mode == MODE_RESAMPLE) {
 			HIPCHK(dalloc(&h->d_usidx[i], (size_t)US_HIST + h->n_pre));
 			HIPCHK(dalloc(&h->d_usalpha[i], (size_t)US_HIST + h->n_pre));
@@ -1175,6 +1220,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_last_lvl[i], C));
 		}
 		if (h->dec_kind != 0) h->k7_event = false; // the event-driven form exists for ModelDefault's wiring only
+		if (h->dec_kind != 0) h->dec_defer = false; // (the FM decoders read the previous block's discriminator bits, a ring of two)
 		// (on the decimate-by-3 ladders Rotate alternates between the channels every 4096 samples, and with it the level the FM
 		// decoders of ModelChallenger inherit through the shared TAG: that variant of the mesh kernel does not exist)
 		if (h->dec_kind == 2 && by3) { h->err = "AISGPU_FLAG_GPU_DECODE with ModelChallenger: not on the decimate-by-3 ladders"; return AISGPU_ERR_ARG; }
@@ -1203,6 +1249,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	if (const char* e = getenv("AISGPU_SEARCH0")) h->search_on_front = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_DEFER_FUSED")) h->defer_fused = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_ROT_AHEAD")) h->rot_stage_ahead = atoi(e) != 0;
+	if (const char* e = getenv("AISGPU_ROT_LEAD")) { const int v = atoi(e); if (v >= 1 && v <= 2) h->rot_lead = v; }
 	if (const char* e = getenv("AISGPU_ROT_WORKER")) h->rot_worker = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_GL")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0) h->GL = v; }
 	// The spectral analysis rides at the end of the front-end waves (k1_fft_tail) when every span is a whole number of 512-sample
@@ -1249,10 +1296,9 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(dalloc(&h->d_ppm[i], C * h->W));
 		HIPCHK(dalloc(&h->d_rotT[i], (size_t)h->L * ((C + 63) / 64 * 64)));
 	}
-	for (int i = 0; i < 4; i++) HIPCHK(dalloc(&h->d_lvl[i], C * h->Gcap));
+	for (int i = 0; i < 4; i++) { HIPCHK(dalloc(&h->d_lvl[i], C * h->Gcap)); HIPCHK(dalloc(&h->d_bits[i], C * 5 * h->words)); }
 	for (int i = 0; i < 2; i++) {
 		HIPCHK(dalloc(&h->d_sym[i], sym_elems((int)C, h->Gcap))); // SymRow layout (kernels.h): channels padded to 64
-		HIPCHK(dalloc(&h->d_bits[i], C * 5 * h->words));
 		HIPCHK(dalloc(&h->d_ema[i], C * 5));
 	}
 	HIPCHK(dalloc(&h->d_cgf, C * (CGF_HIST + h->L)));
@@ -1337,13 +1383,13 @@ void aisgpu_destroy(aisgpu_t* h) {
 		if (h->ev_c48free[i]) hipEventDestroy(h->ev_c48free[i]);
 		hipFree(h->d_rotT[i]); hipFree(h->d_c48[i]); hipFree(h->d_fz[i]); hipFree(h->d_ppm[i]);
 	}
-	for (int i = 0; i < 4; i++) { if (h->ev_ema[i]) hipEventDestroy(h->ev_ema[i]); hipFree(h->d_lvl[i]); }
+	for (int i = 0; i < 4; i++) { if (h->ev_ema[i]) hipEventDestroy(h->ev_ema[i]); hipFree(h->d_lvl[i]); hipFree(h->d_bits[i]);
+		hipFree(h->d_rot[i]); if (h->h_rot[i]) hipHostFree(h->h_rot[i]); if (h->rot_ev[i]) hipEventDestroy(h->rot_ev[i]); }
 	for (int i = 0; i < 2; i++) {
 		if (h->ev_sym[i]) hipEventDestroy(h->ev_sym[i]);
 		if (h->ev_k3[i]) hipEventDestroy(h->ev_k3[i]);
 		if (h->ev_k4[i]) hipEventDestroy(h->ev_k4[i]);
-		hipFree(h->d_sym[i]); hipFree(h->d_bits[i]); hipFree(h->d_ema[i]);
-		hipFree(h->d_rot[i]); if (h->h_rot[i]) hipHostFree(h->h_rot[i]); if (h->rot_ev[i]) hipEventDestroy(h->rot_ev[i]);
+		hipFree(h->d_sym[i]); hipFree(h->d_ema[i]);
 		hipFree(h->d_usidx[i]); hipFree(h->d_usalpha[i]); hipFree(h->d_xpre[i]);
 		if (h->h_usidx[i]) hipHostFree(h->h_usidx[i]);
 		if (h->h_usalpha[i]) hipHostFree(h->h_usalpha[i]);
@@ -1376,7 +1422,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	if (h->s1 && !h->serial) hipStreamDestroy(h->s1);
 	if (h->s3 && !h->serial) hipStreamDestroy(h->s3);
 	if (h->s4 && !h->serial) hipStreamDestroy(h->s4);
-	if (h->s5 && !h->serial && h->s5 != h->s4) hipStreamDestroy(h->s5);
+	if (h->s5 && !h->serial && h->s5 != h->s4 && h->s5 != h->s1) hipStreamDestroy(h->s5);
 	delete h;
 }
 
@@ -1557,9 +1603,9 @@ int aisgpu_run(aisgpu_t* h) {
 			h->rot_ev_used[b] = true;
 			return AISGPU_OK;
 		};
-		if (!h->rot_ahead) { int rc = stage_rot(pb, h->stream); if (rc) return rc; }
-		else WAITEV(h->stream, h->rot_worker ? h->rw.ev[h->rot_slot[pb]] : h->rot_ev[pb]);
-		h->rot_ahead = false;
+		const int rb = (int)(h->block_idx & 3); // ring slot of this block's table
+		if (h->rot_next <= h->block_idx) { int rc = stage_rot(rb, h->stream); if (rc) return rc; h->rot_next = h->block_idx + 1; }
+		else WAITEV(h->stream, h->rot_worker ? h->rw.ev[h->rot_slot[rb]] : h->rot_ev[rb]);
 		// c48/fz/ppm[q] were last read by K2b/K2c of block f-NBUF
 		WAITEV(h->stream, h->ev_c48free[q]);
 		K1Params k1{};
@@ -1570,7 +1616,7 @@ int aisgpu_run(aisgpu_t* h) {
 		const bool saves = (from_pre || !cu8) && h->K >= 2 && h->depth == 0; // the register/LDS-DMA kernel saves the tail itself
 		k1.hist = from_pre ? h->d_hist2[hb] : h->d_hist[hb];
 		k1.hist_out = !saves ? nullptr : from_pre ? h->d_hist2[hb ^ 1] : h->d_hist[hb ^ 1];
-		k1.rot = h->d_rot[pb];
+		k1.rot = h->d_rot[rb];
 		k1.c48 = h->d_c48[q]; k1.c48_stride = h->c48s;
 		k1.tiles_per_block = h->tiles_per_block; k1.tiles_per_span = h->tiles_per_span;
 		k1.alpha = h->alpha; k1.beta = h->beta; k1.has_fdc = h->has_fdc; k1.stream_start = h->in_blocks == 0;
@@ -1587,11 +1633,15 @@ int aisgpu_run(aisgpu_t* h) {
 		else HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist[hb ^ 1],
 		                           h->tile_in * h->in_bytes, R, h->stream));
 		if (!h->serial && h->fused && h->rot_stage_ahead) {
-			// next block's table, on s3 in front of this block's phasor recurrence: d_rot[pb ^ 1] was last read by the front end of
-			// block f-1, which finished before the recurrence of block f-1 that precedes this copy on s3
-			int rc = stage_rot(pb ^ 1, h->s3);
-			if (rc) return rc;
-			h->rot_ahead = true;
+			// The tables of the next blocks, on s3 in front of this block's phasor recurrence -- TWO blocks ahead (AISGPU_ROT_LEAD): on s3
+			// the copy runs when the recurrence of block f-1 is through, and with a lead of one the front end of block f+1 had to
+			// wait for exactly that -- a loop front end(f-1) -> recurrence(f-1) -> table(f+1) -> front end(f+1) that held the step at
+			// (front end + recurrence + copy) / 2 = 0.47 ms.  d_rot[(f+2) & 3] was last read by the front end of block f-2.
+			while (h->rot_next <= h->block_idx + h->rot_lead) {
+				int rc = stage_rot((int)(h->rot_next & 3), h->s3);
+				if (rc) return rc;
+				h->rot_next++;
+			}
 		}
 		int rc = enqueue_downstream(h, q, pb);
 		if (rc) return rc;
@@ -1672,13 +1722,14 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 	{ int rc = enqueue_back(h); if (rc) return rc; }
 	{ int rc = enqueue_fused_back(h); if (rc) return rc; }
 	{ int rc = flush_walk(h); if (rc) return rc; }
+	{ int rc = flush_decode(h); if (rc) return rc; }
 	for (int s = 0; s < h->n_sub; s++) {
 		const SubOut& so = h->sub[s];
 		// ev_ema[pb]: PhaseSearch (and the frame decoder) of that block are done, wherever their last kernel ran; they are
 		// ordered after everything that produced lvl/ppm
 		if (!h->base && !h->v2 && !h->eager_out) {
 		WAITEV(h->s2, h->ev_ema[so.lv]);
-		HIPCHK(hipMemcpyAsync(h->h_bits + (size_t)s * C * 5 * h->words, h->d_bits[so.pb], C * 5 * h->words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s2));
+		HIPCHK(hipMemcpyAsync(h->h_bits + (size_t)s * C * 5 * h->words, h->d_bits[so.lv], C * 5 * h->words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s2));
 		HIPCHK(hipMemcpyAsync(h->h_lvl + (size_t)s * C * h->Gcap, h->d_lvl[so.lv], C * h->Gcap * sizeof(float), hipMemcpyDeviceToHost, h->s2));
 		HIPCHK(hipMemcpyAsync(h->h_ppm + (size_t)s * C * h->W, h->d_ppm[so.q], C * h->W * sizeof(float), hipMemcpyDeviceToHost, h->s2));
 		}

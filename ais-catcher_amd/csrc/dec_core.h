@@ -272,3 +272,84 @@ DEC_HD int dec_run_frame(DecReg& r, uint32_t* data, const uint32_t* brow, const 
 	r.tail = tail;
 	return flags;
 }
+
+// ------------------------------------------------------------------------------------------
+// k7e_scan: where could a frame start?  A decoder in TRAINING leaves it at the first symbol with alt == 0 after more than four
+// alternations (Marine/AIS.h:109-119) -- a pattern of seven decisions.  Every such candidate is classified from the bits behind
+// it: the start flag fails (K7E_FAIL, at symbol c + off) or a frame opens / the block ends first (K7E_RUN).
+//   event word: c | kind << 13 | off << 15 | slot << 19
+// A FAIL candidate only matters through the candidates of the same decoder that it blocks (those up to five symbols behind its
+// failing symbol) and through the alternation count at the end of the block; alone in the noise -- the usual case, one every
+// ~64 symbols -- it has no effect whatever the siblings do, and is not listed.
+// The row is scanned in segments of words, one lane each (dec_scan_words); a segment's last FAIL stays pending until the next
+// candidate behind the segment is known.  dec_scan_row is the same scan as one loop (the first implementation; the host test
+// compares the two, the device runs the segments).
+// ------------------------------------------------------------------------------------------
+enum { K7E_FAIL = 0, K7E_RUN = 1 };
+constexpr int DEC_SCAN_MAXW = 16; // words per segment at most (16 segments: rows of up to 8192 symbols)
+constexpr int DEC_SCAN_INF = 1 << 30;
+struct ScanSeg { int nev, nrun, first_c; uint32_t pend; int pend_until; };
+
+// one candidate: (kind, off) from the NRZI bits behind it; BB: bits of this word (low half) and of the next one
+DEC_HD uint32_t dec_scan_classify(unsigned long long BB, int i, int c, int n) {
+	// STARTFLAG (AIS.h:121-141): entered with position 3 (Bit == 1) or 1 (Bit == 0); ones up to position 7, then a zero
+	const int need = ((BB >> i) & 1ull) ? 4 : 6;
+	const unsigned long long seq = BB >> (i + 1);
+	int t = __builtin_ctzll(~seq); // ones that follow the candidate (need <= 6 of them are looked at)
+	t = t < 8 ? t : 8;
+	const int avail = n - (c + 1); // symbols of this block behind the candidate
+	int kind, off = 0;
+	if (t < need) { // a zero where a one was needed, at c + 1 + t
+		if (t < avail) { kind = K7E_FAIL; off = 1 + t; } else kind = K7E_RUN; // (not decided inside this block)
+	} else if (need < avail) { // the symbol at position 7 exists: it must be a zero
+		if (t == need) kind = K7E_RUN; else { kind = K7E_FAIL; off = 1 + need; }
+	} else kind = K7E_RUN;
+	return (uint32_t)c | ((uint32_t)kind << 13) | ((uint32_t)off << 15);
+}
+
+// W[i] = word w_begin + i of the row for i <= cnt (0 behind the row's last word); prevD / prevB / prevA: the word in front of the
+// segment (decisions, NRZI bits, alternations -- of the latter two only the top bits matter).  emit(e32) for every event that is
+// listed for sure, in order, RUN events numbered from 0 in bits 19..
+template <class Emit>
+DEC_HD void dec_scan_words(const uint32_t (&W)[DEC_SCAN_MAXW + 1], int cnt, int w_begin, int n, uint32_t prevD, uint32_t prevB, uint32_t prevA,
+                           ScanSeg& sg, Emit emit) {
+	sg.nev = 0; sg.nrun = 0; sg.first_c = DEC_SCAN_INF; sg.pend = 0u; sg.pend_until = -1;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+	for (int k = 0; k < DEC_SCAN_MAXW; k++) {
+		if (k < cnt) {
+			const int w = w_begin + k;
+			const uint32_t D = W[k], Dn = W[k + 1];
+			const uint32_t B = ~(D ^ ((D << 1) | (prevD >> 31)));
+			const uint32_t A = B ^ ((B << 1) | (prevB >> 31));
+			const int nv = n - 32 * w < 32 ? n - 32 * w : 32; // valid symbols in this word
+			const uint32_t valid = nv < 32 ? ((1u << nv) - 1u) : 0xFFFFFFFFu;
+			const unsigned long long X = ((unsigned long long)A << 32) | prevA;
+			const unsigned long long R = X & (X >> 1) & (X >> 2) & (X >> 3) & (X >> 4);
+			uint32_t cand = ~A & (uint32_t)(R >> 27) & valid; // alt == 0 with the five symbols before it all alternating
+			if (cand) {
+				const uint32_t Bn = ~(Dn ^ ((Dn << 1) | (D >> 31)));
+				const unsigned long long BB = ((unsigned long long)Bn << 32) | B;
+				while (cand) {
+					const int i = __builtin_ctz(cand);
+					cand &= cand - 1;
+					const int c = 32 * w + i;
+					uint32_t e32 = dec_scan_classify(BB, i, c, n);
+					if (sg.first_c == DEC_SCAN_INF) sg.first_c = c;
+					if (sg.pend_until >= 0 && c < sg.pend_until) { emit(sg.pend); sg.nev++; }
+					sg.pend_until = -1;
+					if (((e32 >> 13) & 3u) == K7E_FAIL) { sg.pend = e32; sg.pend_until = c + (int)((e32 >> 15) & 15u) + 6; }
+					else { e32 |= (uint32_t)sg.nrun << 19; sg.nrun++; emit(e32); sg.nev++; }
+				}
+			}
+			prevD = D; prevB = B; prevA = A;
+		}
+	}
+}
+
+// carries of a segment that starts at word w_begin > 0, from the word in front of it (their low bits are not exact, and never used)
+DEC_HD void dec_scan_carry(uint32_t Dp, uint32_t& prevD, uint32_t& prevB, uint32_t& prevA) {
+	const uint32_t Bp = ~(Dp ^ (Dp << 1));
+	prevD = Dp; prevB = Bp; prevA = Bp ^ (Bp << 1);
+}

@@ -1477,9 +1477,16 @@ __global__ __launch_bounds__(64) void k2_cgf_phasor_ck(K2Params p) {
 	ck[0] = r0;
 	int s = 1, next_ck = p.ck_first + p.ck_period, n = 0;
 	float2* const ckw = p.ckw + (size_t)blockIdx.x * 64 + lane;
+	// A window's step is two dependent loads (the window's frequency bin, then the table entry): fetched where they are needed they
+	// were two memory round trips in front of every window's 512 steps -- 48 times a few microseconds next to the front end, a
+	// third of the kernel.  The bin is requested two windows ahead and the table entry one window ahead.
+	const int* fzrow = p.fz + (size_t)chan * p.n_windows;
+	int fz_next = fzrow[p.n_windows > 1 ? 1 : 0];
+	float2 stp_next = p.step_table[fzrow[0] + 205];
 	for (int w = 0; w < p.n_windows; w++) {
-		const int fz = p.fz[(size_t)chan * p.n_windows + w];
-		const float2 stp = p.step_table[fz + 205];
+		const float2 stp = stp_next;
+		stp_next = p.step_table[fz_next + 205];
+		fz_next = fzrow[w + 2 < p.n_windows ? w + 2 : p.n_windows - 1];
 		const v2f st = { stp.x, stp.y }, st_sw = { -stp.y, stp.x };
 		const int wend = (w + 1) * 512;
 		ckw[(size_t)w * p.ck_stride] = make_float2(cur.x, cur.y); // state at the window start (after the renormalisation)
@@ -3642,97 +3649,79 @@ constexpr int K7E_RW = K7E_RW_; // events a lane of k7e_resolve stages in LDS at
 #endif
 constexpr int K7E_SIM_LANES = K7E_SIM_LANES_; // lanes of k7e_sim per decoder
 constexpr int K7E_FOUND = 8;  // completed messages a lane of k7e_resolve notes before it copies them out
-enum { K7E_FAIL = 0, K7E_RUN = 1 };
 
 __device__ __forceinline__ int k7e_training_pos(const DecState* st) { // alternations counted so far, only "> 4" ever matters
 	return st->state == DST_TRAINING ? (st->position < 5 ? st->position : 5) : 0;
 }
 
-// one lane per decoder: every candidate of the block, classified
+// Sixteen lanes per decoder, each a segment of the row's words: every candidate of the block, classified (dec_core.h).  One lane
+// per decoder walked 154 words one after the other -- 0.12 ms alone and 0.17 - 0.22 ms next to the front end, a third of the
+// decoder pass; a segment is ten words, whose loads are all in flight at once.  The lanes of a decoder then agree on what a
+// segment cannot know alone -- whether its last failed candidate blocks the first candidate behind the segment, and where its
+// events and runs go in the decoder's lists -- with a suffix minimum and two prefix sums over the 16-lane row.
+constexpr int K7E_SCAN_CAP = DEC_SCAN_MAXW * 32 / 6 + 3; // events of one segment (candidates are >= 6 symbols apart)
 __global__ __launch_bounds__(64) void k7e_scan(K7eParams q) {
+	__shared__ uint32_t s_list[K7E_SCAN_CAP][64];
 	const K7Params& p = q.k;
-	__builtin_amdgcn_s_setprio(3); // a handful of latency-bound waves: they need their few issue slots at once
-	const int d = blockIdx.x * 64 + threadIdx.x;
-	if (d >= p.n_chan * 5) return;
+	__builtin_amdgcn_s_setprio(3); // latency-bound waves: they need their few issue slots at once
+	const int lane = threadIdx.x, seg = lane & 15;
+	const int n_dec = p.n_chan * 5;
+	const int d_raw = blockIdx.x * 4 + (lane >> 4);
+	const bool live = d_raw < n_dec;
+	const int d = live ? d_raw : 0;
 	const DecState* st = p.state + d;
 	const uint32_t* brow = p.bits + (size_t)d * p.bits_stride;
 	uint32_t* ev = q.ev + (size_t)d * K7E_EVCAP;
 	uint16_t* oc = q.open_c + (size_t)d * K7E_OPENCAP;
-	const int n = p.n_groups, nw = (n + 31) >> 5;
-	int nev = 0, nrun = 0;
-	if (st->state != DST_TRAINING) { // a frame (or a start flag) is in flight: it continues at symbol 0
-		ev[nev++] = 0u | (K7E_RUN << 13) | (0u << 19);
-		oc[nrun++] = (uint16_t)K7E_CONT;
+	const int n = p.n_groups, nw = (n + 31) >> 5, wps = (nw + 15) >> 4;
+	const int w_begin = seg * wps;
+	const int cnt = w_begin >= nw ? 0 : (nw - w_begin < wps ? nw - w_begin : wps);
+	uint32_t W[DEC_SCAN_MAXW + 1];
+#pragma unroll
+	for (int k = 0; k <= DEC_SCAN_MAXW; k++) W[k] = k <= cnt && w_begin + k < nw ? brow[w_begin + k] : 0u;
+	const int state0 = st->state;
+	uint32_t prevD, prevB, prevA;
+	if (w_begin == 0) { // carry-in: dd[-1], Bit[-1] and the alternations counted so far (they are the last `position` symbols)
+		prevD = st->prev ? 0x80000000u : 0u; prevB = st->lastBit ? 0x80000000u : 0u;
+		const int p5 = k7e_training_pos(st);
+		prevA = p5 ? (0xFFFFFFFFu << (32 - p5)) : 0u;
+	} else dec_scan_carry(cnt > 0 ? brow[w_begin - 1] : 0u, prevD, prevB, prevA);
+	ScanSeg sg;
+	dec_scan_words(W, cnt, w_begin, n, prevD, prevB, prevA, sg, [&](uint32_t e) { s_list[sg.nev][lane] = e; });
+	// ---- the lanes of the decoder
+	int m = sg.first_c; // first candidate at or behind this segment
+#pragma unroll
+	for (int o = 1; o < 16; o <<= 1) { const int t = __shfl_down(m, o, 16); if (seg + o < 16) m = t < m ? t : m; }
+	int nf = __shfl_down(m, 1, 16); // ... behind it
+	if (seg == 15) nf = DEC_SCAN_INF;
+	const bool trailing = sg.pend_until >= 0 && (nf != DEC_SCAN_INF ? nf < sg.pend_until : sg.pend_until > n);
+	const int mine_ev = sg.nev + (trailing ? 1 : 0);
+	int sum_ev = mine_ev, sum_run = sg.nrun; // inclusive prefix sums over the row
+#pragma unroll
+	for (int o = 1; o < 16; o <<= 1) {
+		const int te = __shfl_up(sum_ev, o, 16), tr = __shfl_up(sum_run, o, 16);
+		if (seg >= o) { sum_ev += te; sum_run += tr; }
 	}
-	// carry-in: dd[-1], Bit[-1] and the alternations counted so far (they are the last `position` symbols)
-	uint32_t prevD = st->prev ? 0x80000000u : 0u, prevB = st->lastBit ? 0x80000000u : 0u;
-	const int p5 = k7e_training_pos(st);
-	uint32_t prevA = p5 ? (0xFFFFFFFFu << (32 - p5)) : 0u;
-	// A candidate that fails in STARTFLAG only matters through the candidates of the same decoder it blocks (those up to five
-	// symbols behind its failing symbol) and through the alternation count at the end of the block; alone in the noise -- the
-	// usual case, one every ~64 symbols -- it has no effect whatever the siblings do, and is not even listed.
-	uint32_t pend = 0; int pend_until = -1; // the last FAIL event, not yet written: listed only if something falls inside its shadow
-	const auto flush_pend = [&](int next_c) {
-		if (pend_until >= 0 && next_c < pend_until) { if (nev < K7E_EVCAP) ev[nev++] = pend; else atomicOr(q.overflow, 2); }
-		pend_until = -1;
-	};
-	constexpr int PF = 8; // words fetched together
-	uint32_t buf[PF + 1], nbuf[PF + 1]; // the batch being scanned and the one behind it, requested a batch ahead
-#pragma unroll
-	for (int e = 0; e <= PF; e++) nbuf[e] = e < nw ? brow[e] : 0u;
-	for (int w = 0; w < nw; w++) {
-		const int bi = w % PF;
-		if (bi == 0) {
-#pragma unroll
-			for (int e = 0; e <= PF; e++) buf[e] = nbuf[e];
-#pragma unroll
-			for (int e = 0; e <= PF; e++) nbuf[e] = w + PF + e < nw ? brow[w + PF + e] : 0u;
-			__builtin_amdgcn_sched_barrier(0);
+	const int base = state0 != DST_TRAINING ? 1 : 0; // a frame (or a start flag) is in flight: it continues at symbol 0
+	const int ev_off = base + sum_ev - mine_ev, run_off = base + sum_run - sg.nrun;
+	if (!live) return;
+	int over = 0;
+	if (seg == 0 && base) { ev[0] = 0u | (K7E_RUN << 13) | (0u << 19); oc[0] = (uint16_t)K7E_CONT; }
+	for (int i = 0; i < sg.nev; i++) {
+		uint32_t e = s_list[i][lane];
+		if (((e >> 13) & 3u) == K7E_RUN) {
+			const int slot = (int)(e >> 19) + run_off;
+			if (slot >= K7E_OPENCAP) { over |= 1; e = (e & 0x1FFFu) | (K7E_FAIL << 13) | (1u << 15); }
+			else { oc[slot] = (uint16_t)(e & 0x1FFFu); e = (e & 0x7FFFFu) | ((uint32_t)slot << 19); }
 		}
-		uint32_t D = 0, Dn = 0;
-#pragma unroll
-		for (int e = 0; e < PF; e++) if (e == bi) { D = buf[e]; Dn = buf[e + 1]; }
-		const uint32_t B = ~(D ^ ((D << 1) | (prevD >> 31)));
-		const uint32_t A = B ^ ((B << 1) | (prevB >> 31));
-		const int nv = n - 32 * w < 32 ? n - 32 * w : 32; // valid symbols in this word
-		const uint32_t valid = nv < 32 ? ((1u << nv) - 1u) : 0xFFFFFFFFu;
-		const unsigned long long X = ((unsigned long long)A << 32) | prevA;
-		const unsigned long long R = X & (X >> 1) & (X >> 2) & (X >> 3) & (X >> 4);
-		uint32_t cand = ~A & (uint32_t)(R >> 27) & valid; // alt == 0 with the five symbols before it all alternating
-		if (cand) {
-			const uint32_t Bn = ~(Dn ^ ((Dn << 1) | (D >> 31)));
-			const unsigned long long BB = ((unsigned long long)Bn << 32) | B;
-			while (cand) {
-				const int i = __builtin_ctz(cand);
-				cand &= cand - 1;
-				const int c = 32 * w + i;
-				// STARTFLAG (AIS.h:121-141): entered with position 3 (Bit == 1) or 1 (Bit == 0); ones up to position 7, then a zero
-				const int need = ((BB >> i) & 1ull) ? 4 : 6;
-				const unsigned long long seq = BB >> (i + 1);
-				int t = __builtin_ctzll(~seq); // ones that follow the candidate (at most 31 - ... are looked at: need <= 6)
-				t = t < 8 ? t : 8;
-				const int avail = n - (c + 1); // symbols of this block behind the candidate
-				int kind, off = 0;
-				if (t < need) { // a zero where a one was needed, at c + 1 + t
-					if (t < avail) { kind = K7E_FAIL; off = 1 + t; } else kind = K7E_RUN; // (not decided inside this block)
-				} else if (need < avail) { // the symbol at position 7 exists: it must be a zero
-					if (t == need) kind = K7E_RUN; else { kind = K7E_FAIL; off = 1 + need; }
-				} else kind = K7E_RUN;
-				int slot = 0;
-				if (kind == K7E_RUN) {
-					if (nrun < K7E_OPENCAP) { slot = nrun; oc[nrun++] = (uint16_t)c; } else { atomicOr(q.overflow, 1); kind = K7E_FAIL; off = 1; }
-				}
-				const uint32_t e32 = (uint32_t)c | ((uint32_t)kind << 13) | ((uint32_t)off << 15) | ((uint32_t)slot << 19);
-				flush_pend(c);
-				if (kind == K7E_FAIL) { pend = e32; pend_until = c + off + 6; }
-				else if (nev < K7E_EVCAP) ev[nev++] = e32;
-				else atomicOr(q.overflow, 2);
-			}
-		}
-		prevD = D; prevB = B; prevA = A;
+		if (ev_off + i < K7E_EVCAP) ev[ev_off + i] = e; else over |= 2;
 	}
-	flush_pend(pend_until > n ? n : 1 << 30); // (kept if its shadow reaches past the end of the block)
-	q.cnt[d] = (uint32_t)nev | ((uint32_t)nrun << 16);
+	if (trailing) { if (ev_off + sg.nev < K7E_EVCAP) ev[ev_off + sg.nev] = sg.pend; else over |= 2; }
+	if (over) atomicOr(q.overflow, over);
+	if (seg == 15) {
+		const int tot_ev = base + sum_ev, tot_run = base + sum_run;
+		q.cnt[d] = (uint32_t)(tot_ev < K7E_EVCAP ? tot_ev : K7E_EVCAP) | ((uint32_t)(tot_run < K7E_OPENCAP ? tot_run : K7E_OPENCAP) << 16);
+	}
 }
 
 // one lane per (decoder, run): the reference's state machine from the candidate (or from the carried state) until it is back in
@@ -3811,19 +3800,27 @@ __global__ __launch_bounds__(64) void k7e_sim(K7eParams q) {
 	}
 }
 
-// One lane per decoder, the five lanes of a channel walk together: which of the runs really happened, in the order in which the
+// One lane per decoder, the five lanes of a channel (of the eight it owns in the wave) walk together: which of the runs really happened, in the order in which the
 // reference runs its five decoders (symbol by symbol, phase 0..4 within a group), with the Reset a decoder sends its siblings
 // when it completes a message.  Per round every lane offers the time of its next event (the start of its next candidate, or the
 // end of the run it is in), the channel's earliest one is processed by its owner, and a completed message is broadcast.
+// minimum / maximum over the eight lanes of a channel: two quad permutes and a half-row mirror (DPP, no LDS round trip -- the walk
+// is a chain of dependent rounds, and next to the front end every ds_bpermute of a round waited in the LDS queue)
+__device__ __forceinline__ int grp8_min(int v) {
+	int t = __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); v = t < v ? t : v;  // quad_perm [1,0,3,2]
+	t = __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true); v = t < v ? t : v;      // quad_perm [2,3,0,1]
+	t = __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true); return t < v ? t : v;  // row_half_mirror
+}
+__device__ __forceinline__ int grp8_max(int v) { return -grp8_min(-v); }
+
 __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 	const K7Params& p = q.k;
 	__builtin_amdgcn_s_setprio(3); // a handful of latency-bound waves: they need their few issue slots at once
 	const int lane = threadIdx.x;
-	const int mesh = lane / 5, j = lane - 5 * mesh; // lanes 60..63 idle
-	const int chan_raw = blockIdx.x * 12 + mesh;
-	const bool live = lane < 60 && chan_raw < p.n_chan;
+	const int mesh = lane >> 3, j = lane & 7; // eight lanes per channel, five of them decoders
+	const int chan_raw = blockIdx.x * 8 + mesh;
+	const bool live = j < 5 && chan_raw < p.n_chan;
 	const int d = (live ? chan_raw : 0) * 5 + (live ? j : 0);
-	const int base = 5 * mesh;
 	const int n = p.n_groups;
 	constexpr int INF = 1 << 26;
 	DecState* st = p.state + d;
@@ -3885,12 +3882,7 @@ __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 	for (;;) {
 		const int t = busy ? end_ : (head != 0xFFFFFFFFu ? (int)(head & 0x1FFFu) : INF);
 		const int key = live && t < n ? t * 8 + j : INF * 8; // (equal groups: the lower phase first)
-		int mk = key;
-#pragma unroll
-		for (int o = 1; o < 5; o++) {
-			const int other = __shfl(key, base + (j + o) % 5);
-			mk = other < mk ? other : mk;
-		}
+		const int mk = grp8_min(key);
 		if (!__any(mk < INF * 8)) break; // (runs that are still going at the end of the block stay busy)
 		const bool mine = live && key == mk && mk < INF * 8;
 		int bcast = -1; // a completed message: (group << 3) | phase, told to the siblings
@@ -3922,8 +3914,7 @@ __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 			}
 		}
 		// Reset to the siblings (AIS.cpp:47-49): the phases behind the finder are reset BEFORE their step of that group
-		const int owner = base + (mk & 7);
-		const int msg = __shfl(bcast, mk < INF * 8 ? owner : lane);
+		const int msg = grp8_max(bcast); // (only the owner of the round can have one)
 		if (live && !mine && msg >= 0) {
 			const int e = msg >> 3, jw = msg & 7;
 			const int fa = e + (j > jw ? 5 : 6);
@@ -4186,9 +4177,10 @@ hipError_t launch_k7_mesh(const K7Params& p, hipStream_t s) {
 hipError_t launch_k7e(const K7eParams& q, hipStream_t s) {
 	const int n_dec = q.k.n_chan * 5;
 	if (q.k.n_groups <= 0) return hipSuccess;
-	hipLaunchKernelGGL(k7e_scan, dim3((n_dec + 63) / 64), dim3(64), 0, s, q);
-	hipLaunchKernelGGL(k7e_sim, dim3((n_dec * K7E_SIM_LANES + 63) / 64), dim3(64), 0, s, q);
-	hipLaunchKernelGGL(k7e_resolve, dim3((q.k.n_chan + 11) / 12), dim3(64), 0, s, q);
+	static const int skip = getenv("AISGPU_K7E_SKIP") ? atoi(getenv("AISGPU_K7E_SKIP")) : 0; // experiments only (1 scan, 2 sim, 4 resolve: results wrong)
+	if (!(skip & 1)) hipLaunchKernelGGL(k7e_scan, dim3((n_dec + 3) / 4), dim3(64), 0, s, q);
+	if (!(skip & 2)) hipLaunchKernelGGL(k7e_sim, dim3((n_dec * K7E_SIM_LANES + 63) / 64), dim3(64), 0, s, q);
+	if (!(skip & 4)) hipLaunchKernelGGL(k7e_resolve, dim3((q.k.n_chan + 7) / 8), dim3(64), 0, s, q);
 	return hipGetLastError();
 }
 

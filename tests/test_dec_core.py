@@ -27,3 +27,20 @@ def test_frame_evaluator_equals_the_step(fuzz_binary, seed):
     # the generator reaches what it is meant to reach: completed messages, abandoned frames, frames that cross blocks
     runs, messages, other, crossings = (int(v) for v in re.findall(r"\d+", r.stdout)[:4])
     assert runs == 250000 and messages > 10000 and other > 100000 and crossings > 50000, r.stdout
+
+
+@pytest.fixture(scope="module")
+def scan_binary(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("dec_scan") / "dec_scan_fuzz")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "ais-catcher_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "dec_scan_fuzz.cpp"), "-o", out], check=True)
+    return out
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_segmented_candidate_scan_equals_the_row_scan(scan_binary, seed):
+    """k7e_scan's sixteen segments per row (dec_scan_words + the combination of the lanes) against the scan as one loop."""
+    r = subprocess.run([scan_binary, "40000", str(seed)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows, events, failures, runs, over = (int(v) for v in re.findall(r"\d+", r.stdout)[:5])
+    assert "all equal" in r.stdout and rows == 40000 and failures > 100000 and runs > 100000 and over > 100, r.stdout

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Rotate tables staged one or two blocks ahead (the copy sits behind the previous block's phasor recurrence on its stream)
+cd "$(dirname "$0")/.."
+run() { env $1 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --parity-receivers 4 $2 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); r = d['roofline']; print('%-40s ms/step %.4f  k1 ovl %.4f %s' % ('$1 $2', d['ms_per_step'], r['avg_launch_ms'], d['parity'][:9]))"; }
+for i in 1 2 3; do
+run AISGPU_ROT_LEAD=1 ""
+run AISGPU_ROT_LEAD=2 ""
+run AISGPU_ROT_LEAD=1 --gpu-decode
+run AISGPU_ROT_LEAD=2 --gpu-decode
+done
