@@ -109,6 +109,8 @@ struct aisgpu {
 	hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, s3 = nullptr, s4 = nullptr, s5 = nullptr;
 	hipEvent_t ev_phasor[NBUF] = {};  // s3: phasor(f) done -> s1 may apply it
 	hipEvent_t ev_search[NBUF] = {};  // s4: fz(f) known -> s3 may run the phasor recurrence
+	hipEvent_t k1_done[NBUF] = {};    // the event bound to the front-end launch of block f (ext_launch), or nullptr: ev_search is recorded behind it
+	bool ext_launch = true;           // AISGPU_EXT_LAUNCH=0: events as packets of their own behind / in front of the launch
 	bool serial = false;
 	hipEvent_t ev_front[NBUF] = {};   // s0: K2a(f) done -> s3 may start K2b(f)
 	hipEvent_t ev_c48free[NBUF] = {}; // s1: K2c(f) done (c48/fz/rotT[q] consumed) -> s0 may run the front end of f+NBUF
@@ -641,8 +643,9 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	// FIR, PhaseSearch) is enqueued one block later, behind the next block's analysis (or when results are requested).
 	if (h->fft_in_k1) {
 		// the front-end waves have done the whole analysis (k1_fft_tail): fz / ppm of this block are there when K1 is
-		HIPCHK(hipEventRecord(h->ev_search[q], h->stream));
+		if (!h->k1_done[q]) { HIPCHK(hipEventRecord(h->ev_search[q], h->stream)); h->k1_done[q] = h->ev_search[q]; }
 	} else {
+		h->k1_done[q] = nullptr;
 		hipStream_t sa = h->defer_fused ? h->s4 : h->stream;
 		if (h->defer_fused) {
 			HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
@@ -657,7 +660,7 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 		{ TraceScope t(h, "search", ss); HIPCHK(launch_k2a_search(k2, h->n_chan, ss)); }
 		HIPCHK(hipEventRecord(h->ev_search[q], ss));
 	}
-	WAITEV(h->s3, h->ev_search[q]);
+	WAITEV(h->s3, h->k1_done[q] ? h->k1_done[q] : h->ev_search[q]);
 	WAITEV(h->s3, h->ev_c48free[q]); // ck[q] was last read by K6 of block f-NBUF
 	if (!(h->ablate & 4)) { TraceScope t(h, "phasor", h->s3); if (h->k46) HIPCHK(launch_k2b_ck8(k2, h->d_ck8[q], h->n_chan, h->s3)); else HIPCHK(launch_k2b_ck(k2, h->n_chan, h->s3)); }
 	HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
@@ -1134,7 +1137,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	for (int i = 0; i < NBUF; i++) {
 		HIPCHK(hipEventCreateWithFlags(&h->ev_front[i], hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&h->ev_phasor[i], hipEventDisableTiming));
-		HIPCHK(hipEventCreateWithFlags(&h->ev_search[i], hipEventDisableTiming));
+		HIPCHK(hipEventCreate(&h->ev_search[i])); // (may be bound to a launch as its stop event)
 		HIPCHK(hipEventCreateWithFlags(&h->ev_c48free[i], hipEventDisableTiming));
 	}
 	for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_ema[i], hipEventDisableTiming));
@@ -1249,6 +1252,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	if (const char* e = getenv("AISGPU_SEARCH0")) h->search_on_front = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_DEFER_FUSED")) h->defer_fused = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_ROT_AHEAD")) h->rot_stage_ahead = atoi(e) != 0;
+	if (const char* e = getenv("AISGPU_EXT_LAUNCH")) h->ext_launch = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_ROT_LEAD")) { const int v = atoi(e); if (v >= 1 && v <= 2) h->rot_lead = v; }
 	if (const char* e = getenv("AISGPU_ROT_WORKER")) h->rot_worker = atoi(e) != 0;
 	if (const char* e = getenv("AISGPU_GL")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0) h->GL = v; }
@@ -1625,9 +1629,25 @@ int aisgpu_run(aisgpu_t* h) {
 			k1.fft_windows = h->tiles_per_span / 16; k1.n_windows = h->W; k1.wide = h->cfg.afc_wide ? 1 : 0;
 			k1.omega = h->d_omega; k1.ppm_table = h->d_ppmtab; k1.fz = h->d_fz[q]; k1.ppm = h->d_ppm[q];
 		}
+		// the launch's events ride on its dispatch packet where they can: "front end of block f done" (what s3 waits for) and,
+		// while the launch is being timed, its two time stamps
+		const bool bound = h->ext_launch && !from_pre && h->fft_in_k1 && h->fused && h->depth == 0 && !h->serial && !(h->ablate & 8) && !h->trace;
+		h->k1_done[q] = nullptr;
+		if (bound) {
+			hipEvent_t e0 = nullptr, e1 = h->ev_search[q];
+			if (h->timing) {
+				if (h->ev_free.empty()) { HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b)); }
+				else { ev = h->ev_free.back(); h->ev_free.pop_back(); }
+				e0 = ev.a; e1 = ev.b;
+				h->ev_busy.push_back(ev);
+			}
+			HIPCHK(launch_k1(k1, h->K, h->kfmt, h->tile96, h->depth, h->k1_threads, h->spans, R, h->stream, e0, e1));
+			h->k1_done[q] = e1;
+		} else {
 		if (!from_pre) { int rc = time_begin(); if (rc) return rc; }
 		if (!(h->ablate & 8)) { TraceScope t(h, "front", h->stream); HIPCHK(launch_k1(k1, h->K, from_pre ? 0 : h->kfmt, h->tile96, h->depth, h->k1_threads, h->spans, R, h->stream)); }
 		if (!from_pre) { int rc = time_end(); if (rc) return rc; }
+		}
 		if (saves) {}
 		else if (from_pre) HIPCHK(launch_k1_tail(xcur, xstride * 8, (long long)h->n_pre * 8, h->d_hist2[hb ^ 1], h->tile_in * 8, R, h->stream));
 		else HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist[hb ^ 1],

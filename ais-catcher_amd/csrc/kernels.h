@@ -220,7 +220,9 @@ struct K7eParams {
 hipError_t launch_k7e(const K7eParams& p, hipStream_t s);
 
 // fmt (kernel numbering): 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16, 4 = CU8 through the fixed-point ladder (K = 4)
-hipError_t launch_k1(const K1Params& p, int K, int fmt, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s);
+// ev_start / ev_stop (register variant, depth 0): events bound to the dispatch itself (no barrier packets): time stamps, and "this launch is done" for other streams
+hipError_t launch_k1(const K1Params& p, int K, int fmt, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s, hipEvent_t ev_start = nullptr,
+                     hipEvent_t ev_stop = nullptr);
 hipError_t launch_k1u(const K1uParams& p, int npost, int n_rx, hipStream_t s); // npost: CIC5 stages behind the resampler (2, 1; 0 = 96 kSPS input, no resampler)
 hipError_t launch_copy_rows(const float2* src, long long src_stride, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
 hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long block_bytes, void* hist, int tail_bytes,
