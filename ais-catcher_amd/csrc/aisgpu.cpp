@@ -453,7 +453,7 @@ int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned
 	K4Params k4;
 	k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[lv]; k4.bits_stride = h->words;
 	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
-	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag + pb;
+	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag + pb; k4.fb_count = h->d_psflag + 2;
 	k4.n_chains = h->n_chains; k4.n_groups = n_groups;
 	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
 	k4.lw = h->d_pslw[pb]; k4.lw_quads = h->Gcap / 4; k4.prio = h->ps_prio; k4.prio_walk = h->walk_prio; k4.ma_stride = (h->n_chains + 63) / 64 * 64;
@@ -610,7 +610,7 @@ int enqueue_k46(aisgpu_t* h, int q, int pb, int lv, long long g0, int n_groups, 
 	K4Params& k4 = k.k4;
 	k4.sym = nullptr; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[lv]; k4.bits_stride = h->words;
 	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
-	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag + pb;
+	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag + pb; k4.fb_count = h->d_psflag + 2;
 	k4.qflag = h->d_qflag + (size_t)pb * h->n_quads; k4.qflag_div = 20;
 	k4.n_chains = h->n_chains; k4.n_groups = n_groups;
 	k4.n_chunks = (n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm; k4.prio = h->ps_prio;
@@ -1763,6 +1763,15 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 	for (int i = 0; i < h->n_sub; i++) h->osub[i] = h->sub[i];
 	h->have_out = true; // (the decisions are there even if the frame ring below has overflowed)
 	if (h->gpu_decode) { rc = gather_frames(h); if (rc != AISGPU_OK) return rc; }
+	return AISGPU_OK;
+}
+
+int aisgpu_ps_fallbacks(aisgpu_t* h, long long* count) {
+	if (!h || !count) return AISGPU_ERR_ARG;
+	DevGuard dg(h);
+	int v = 0;
+	if (h->d_psflag) HIPCHK(hipMemcpy(&v, h->d_psflag + 2, sizeof v, hipMemcpyDeviceToHost));
+	*count = v;
 	return AISGPU_OK;
 }
 

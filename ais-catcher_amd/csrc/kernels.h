@@ -153,6 +153,7 @@ struct K4Params {
 	const PsBoxState* box_in; PsBoxState* box_out; long long first_group;
 	int* qflag = nullptr;                    // != nullptr: one flag per qflag_div chains instead of the batch-global *flag, so that the
 	int qflag_div = 4;                       // exact fallback re-runs only those (4: the chains of one k4_phase_search workgroup; 20: one channel quad of K46)
+	int* fb_count = nullptr;                 // statistics: workgroups of the exact fallback that really ran (aisgpu_ps_fallbacks)
 };
 
 // K46: derotation + FilterComplex(Coherent) + ScatterPLL + PhaseSearchEMA in ONE kernel (k46_fir_phase_chunks): the FIR outputs

@@ -1868,6 +1868,7 @@ __global__ __launch_bounds__(64) void k4_phase_search(K4Params p, int conditiona
 			if (p.qflag[blockIdx.x] == 0) return; // (one wave: the branch has consumed every lane's load before the store below)
 			if (threadIdx.x == 0) p.qflag[blockIdx.x] = 0;
 		} else if (*p.flag == 0) return;
+		if (threadIdx.x == 0 && p.fb_count) atomicAdd(p.fb_count, 1);
 	}
 	const int lane = threadIdx.x;
 	const int k = lane & 15, row = lane >> 4;

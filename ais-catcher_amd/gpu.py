@@ -31,7 +31,7 @@ EXPORTS = (
     "aisgpu_default_cfg", "aisgpu_create", "aisgpu_destroy", "aisgpu_submit", "aisgpu_submit_device",
     "aisgpu_run", "aisgpu_sync_outputs", "aisgpu_sync", "aisgpu_fetch", "aisgpu_tap", "aisgpu_stream",
     "aisgpu_frontend_ms", "aisgpu_timing", "aisgpu_strerror", "aisgpu_last_error", "aisgpu_device_count",
-    "aisgpu_out_count", "aisgpu_fetch_sub", "aisgpu_selftest", "aisgpu_frames",
+    "aisgpu_out_count", "aisgpu_fetch_sub", "aisgpu_selftest", "aisgpu_frames", "aisgpu_ps_fallbacks",
 )
 
 
@@ -90,6 +90,7 @@ def load():
     lib.aisgpu_fetch.argtypes = [vp, ci, ci, ctypes.POINTER(Out)]
     lib.aisgpu_out_count.argtypes = [vp]
     lib.aisgpu_fetch_sub.argtypes = [vp, ci, ci, ci, ctypes.POINTER(Out)]
+    lib.aisgpu_ps_fallbacks.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
     if hasattr(lib, "aisgpu_frames"):
         lib.aisgpu_frames.argtypes = [vp, ctypes.POINTER(ctypes.POINTER(Frame)), ctypes.POINTER(ci)]
     lib.aisgpu_tap.argtypes = [vp, ci, ci, vp, cll]
@@ -204,6 +205,12 @@ class AisGpu:
         return [dict(rx=fp[i].rx, ch=fp[i].ch, phase=fp[i].phase, sub=fp[i].sub, group=fp[i].group, position=fp[i].position,
                      level_sum=fp[i].level_sum, start_idx=fp[i].start_idx, end_idx=fp[i].end_idx, data=bytes(fp[i].data))
                 for i in range(n.value)]
+
+    def ps_fallbacks(self):
+        """Workgroups (four chains each) of the chunk-parallel PhaseSearchEMA that went through the exact sequential kernel so far."""
+        n = ctypes.c_longlong()
+        self._chk(self.lib.aisgpu_ps_fallbacks(self.h, ctypes.byref(n)), "aisgpu_ps_fallbacks")
+        return n.value
 
     def tap(self, which, rx=0):
         n = self.lib.aisgpu_tap(self.h, which, rx, None, 0)

@@ -164,6 +164,12 @@ typedef struct aisgpu_frame {
 	unsigned char data[144];  /* bits as received (Message::setBit order: bit i -> byte i/8, bit i%8) */
 } aisgpu_frame;
 int aisgpu_frames(aisgpu_t* h, const aisgpu_frame** frames, int* count);
+
+/* Statistics of the chunk-parallel PhaseSearchEMA (reference DSP/Demod.cpp:39-101): the number of workgroups (four chains each) whose
+ * speculative warm-up did not reproduce the sequential EMA bit for bit and that therefore went through the exact sequential kernel,
+ * summed over the blocks completed so far (call it behind aisgpu_sync_outputs()).  Results are bit-exact either way; the count says
+ * how often the slow path ran (an extreme level step of a receiver; AISGPU_PS_WARM sets the warm-up length, default 256 symbols). */
+int aisgpu_ps_fallbacks(aisgpu_t* h, long long* count);
 int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* out);
 
 /* Float taps of the last block (tests only; needs AISGPU_FLAG_TAPS):

@@ -310,6 +310,42 @@ def test_phase_search_fallback_and_variants(env, monkeypatch):
     _run_gpu_vs_oracle(xs, 1536000, "cf32", 786432, 2)
 
 
+@pytest.mark.parametrize("warm, expect_fallbacks", [(None, False), ("16", True)])
+def test_phase_search_fallback_counter(warm, expect_fallbacks, monkeypatch):
+    """aisgpu_ps_fallbacks(): with the default warm-up of 256 symbols no workgroup of a burst-carrying batch needs the exact
+    sequential kernel (a warm-up of 192 already costs one per block of 640, 160 a dozen per hundred -- profiles/r02_expZ.txt);
+    a 16-symbol warm-up sends practically all of them through it.  The decisions are the oracle's either way."""
+    if warm:
+        monkeypatch.setenv("AISGPU_PS_WARM", warm)
+    R, block, nb = 8, 786432, 3
+    xs = [synth.receiver_stream(block * nb, receiver_id=70 + r) for r in range(R)]
+    g = gpu.AisGpu(sample_rate=1536000, n_receivers=R, block_len=block)
+    os_ = []
+    for r in range(R):
+        o = checkers.Oracle(model=2, rate=1536000, fmt="cf32", taps=True)
+        o.feed_blocks(xs[r], block)
+        os_.append(o)
+    got = [[[] for _ in range(2)] for _ in range(R)]
+    for b in range(nb):
+        for r in range(R):
+            g.submit(r, xs[r][b * block:(b + 1) * block])
+        g.run()
+        g.sync_outputs()
+        for r in range(R):
+            for ch in range(2):
+                got[r][ch].append(g.fetch(r, ch)["bits"])
+    n = g.ps_fallbacks()
+    g.close()
+    for r in range(R):
+        for ch in range(2):
+            have = np.concatenate(got[r][ch], axis=1)
+            for j in range(5):
+                want = os_[r].bits(ch, j)[0]
+                n_cmp = min(len(want), have.shape[1])
+                assert n_cmp > 14000 and np.array_equal(have[j, :n_cmp], want[:n_cmp])
+    assert (n > 0) if expect_fallbacks else (n == 0), n
+
+
 def _run_multi_sub(x, rate, block, nblocks, fmt="cf32", dsk=False):
     """Rates whose ladder contains the resampler or a pre-decimation pass: compare every completed downstream
     block (there can be 1 or 2 per input block) with the oracle's stream."""
