@@ -86,6 +86,7 @@ struct aisgpu {
 	aisgpu_cfg cfg;
 	Mode mode = MODE_DIRECT;
 	int K = 0;            // CIC5 stages executed by the fused front-end kernel (MODE_DIRECT / MODE_PRE)
+	int ma_m = 0;         // > 0: `-go MA on`, input samples per 96 kHz sample (the flow of MODE_96K behind launch_ma_rows)
 	int KP = 0;           // CIC5 stages of the pre-decimation pass
 	int tile96 = 64;      // output samples per front-end tile
 	int depth = 1;        // tiles prefetched ahead by the front end
@@ -947,7 +948,6 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	} else
 	if (cfg->sample_rate < 96000 || (k < 0 && k3 < 0)) return AISGPU_ERR_ARG;
 	Mode mode; int K, KP;
-	const bool by3 = k3 >= 0;
 	if (mode_x) { // the flows of the 96k input (exact bucket) / of the resampler (in between), with the single-channel front end K1x
 		static const int bx[3] = { 48000, 96000, 192000 };
 		mode = bx[kx] != cfg->sample_rate ? MODE_RESAMPLE : MODE_96K; K = 0; KP = 0;
@@ -966,13 +966,25 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			mode = MODE_RESAMPLE; K = 0; KP = k >= 2 ? k - 2 : 0;
 		}
 	}
+	// `-go MA on` (Model.cpp:111-126): the moving-average branch comes before the ladders and before FP_DS / DSK are looked at:
+	// convert >> DS_MA >> ROT, i.e. the flow of a 96 kSPS input behind an integrate-and-dump pass, Rotate called once per
+	// 8192-sample output block of the downsampler (DSP.cpp:60-82)
+	int ma_m = 0;
+	if ((cfg->flags & AISGPU_FLAG_MA_DS) != 0) {
+		if (mode_x) return AISGPU_ERR_ARG;
+		if (cfg->sample_rate < 192000 || cfg->sample_rate > 12288000 || cfg->sample_rate % 96000 != 0) return AISGPU_ERR_ARG;
+		ma_m = cfg->sample_rate / 96000;
+		if (cfg->block_len % ma_m != 0 || (cfg->block_len / ma_m) % 8192 != 0) return AISGPU_ERR_ARG;
+		mode = MODE_96K; K = 0; KP = 0; k = 0; k3 = -1;
+	}
+	const bool by3 = k3 >= 0 && ma_m == 0;
 	if (cfg->model != AISGPU_MODEL_DEFAULT && cfg->model != AISGPU_MODEL_CHALLENGER && cfg->model != AISGPU_MODEL_BASE &&
 	    cfg->model != AISGPU_MODEL_STANDARD && cfg->model != AISGPU_MODEL_V2) return AISGPU_ERR_ARG;
 	if (cfg->input_format != AISGPU_FMT_CU8 && cfg->input_format != AISGPU_FMT_CF32 && cfg->input_format != AISGPU_FMT_CS8 &&
 	    cfg->input_format != AISGPU_FMT_CS16) return AISGPU_ERR_ARG;
 	if (cfg->n_receivers < 1 || cfg->n_receivers > 65535) return AISGPU_ERR_ARG;
 	// a downstream block must be a whole number of 512-sample CGF windows
-	const int dec48 = mode_x ? 1 << kx : by3 ? 6 << KP : 2 << k; // input samples per 48 kHz sample (bucket rate)
+	const int dec48 = ma_m ? 2 * ma_m : mode_x ? 1 << kx : by3 ? 6 << KP : 2 << k; // input samples per 48 kHz sample (bucket rate)
 	if (cfg->block_len < 512 * dec48 || cfg->block_len % (512 * dec48) != 0) return AISGPU_ERR_ARG;
 	// DownsampleKFilter hands its output on in blocks of 8192 samples (DSP.h:193), whatever the input block was: only
 	// input blocks that are a whole number of them reproduce the reference's call pattern (its file block does)
@@ -999,12 +1011,13 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->in_bytes = cfg->input_format == AISGPU_FMT_CF32 ? 8 : cfg->input_format == AISGPU_FMT_CS16 ? 4 : 2;
 	// kernel numbering of the formats: 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16
 	h->kfmt = cfg->input_format == AISGPU_FMT_CF32 ? 0 : cfg->input_format == AISGPU_FMT_CU8 ? 1 : cfg->input_format == AISGPU_FMT_CS8 ? 2 : 3;
-	if ((cfg->flags & AISGPU_FLAG_FP_DS) && cfg->sample_rate == 1536000) { // Model.cpp:224-237: only this ladder has a fixed-point twin,
+	if ((cfg->flags & AISGPU_FLAG_FP_DS) && cfg->sample_rate == 1536000 && !ma_m) { // Model.cpp:224-237: only this ladder has a fixed-point twin,
 		if (h->kfmt != 1) { delete h; return AISGPU_ERR_ARG; }              // and only ConvertRAW::outCU8 feeds it
 		h->kfmt = 4;
 	}
 	if (h->kfmt > 1 && h->depth != 0) { delete h; return AISGPU_ERR_ARG; } // CS8 / CS16 / fixed point: register (DPP) front end only
-	h->n_pre = cfg->block_len >> KP;
+	h->n_pre = ma_m ? cfg->block_len / ma_m : cfg->block_len >> KP;
+	h->ma_m = ma_m;
 	h->us_dsk = by3 && mode == MODE_RESAMPLE;
 	if (by3) h->n96 = h->n_pre / 3;
 	else if (mode == MODE_RESAMPLE) { h->npost = k >= 2 ? 2 : 1; h->n96 = h->n_pre >> h->npost; } // one flush of n_pre samples at the bucket rate >> KP (384 kHz, or 192 kHz)
@@ -1024,7 +1037,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->alpha = mode_x ? (kx == 2 ? -1.1f : -0.8f) : alphas[k]; // Model.cpp:64,76
 	h->beta = 1 - 2 * h->alpha; // DSP/DSP.h:296, evaluated in float
 	h->us_increment = (float)cfg->sample_rate / (float)(mode_x ? 48000 << kx : by3 ? buckets3[k3] : buckets[k]); // DSP/DSP.h:172-176
-	h->rot_period = by3 ? 8192 : 0; // Rotate is called once per DownsampleKFilter output block
+	h->rot_period = by3 || ma_m ? 8192 : 0; // Rotate is called once per DownsampleKFilter / DownsampleMovingAverage output block
 	if (K > 0) {
 		h->tile_in = h->tile96 << K;
 		if (h->n_pre % h->tile_in) { delete h; return AISGPU_ERR_ARG; }
@@ -1226,7 +1239,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		if (h->dec_kind != 0) h->dec_defer = false; // (the FM decoders read the previous block's discriminator bits, a ring of two)
 		// (on the decimate-by-3 ladders Rotate alternates between the channels every 4096 samples, and with it the level the FM
 		// decoders of ModelChallenger inherit through the shared TAG: that variant of the mesh kernel does not exist)
-		if (h->dec_kind == 2 && by3) { h->err = "AISGPU_FLAG_GPU_DECODE with ModelChallenger: not on the decimate-by-3 ladders"; return AISGPU_ERR_ARG; }
+		if (h->dec_kind == 2 && (by3 || ma_m)) { h->err = "AISGPU_FLAG_GPU_DECODE with ModelChallenger: not on the decimate-by-3 ladders / behind the moving-average downsampler"; return AISGPU_ERR_ARG; }
 		HIPCHK(dalloc(&h->d_frames, (size_t)h->max_frames * DEC_FRAME_WORDS));
 		if (const char* e = getenv("AISGPU_K7")) if (h->dec_kind == 0) { h->k7_event = strcmp(e, "seq") != 0; h->k7_alt = strcmp(e, "alt") == 0; } // "seq": one lane per decoder, symbol by symbol
 		// the event words hold a symbol index in 13 bits: blocks of more than 8191 groups (e.g. the reference's CU8 file block of
@@ -1509,7 +1522,8 @@ int aisgpu_run(aisgpu_t* h) {
 		xcur = h->d_xpre[xb];
 		xstride = (long long)h->xh + h->n_pre;
 		if (h->in_blocks > 0) HIPCHK(launch_copy_rows(h->d_xpre[xb ^ 1] + h->n_pre, xstride, xcur, xstride, h->xh, R, h->stream));
-		HIPCHK(launch_convert_rows(h->cur_in, h->cur_in_stride, h->kfmt, xcur + h->xh, xstride, h->n_pre, R, h->stream));
+		if (h->ma_m) HIPCHK(launch_ma_rows(h->cur_in, h->cur_in_stride, h->kfmt, h->ma_m, xcur + h->xh, xstride, h->n_pre, R, h->stream));
+		else HIPCHK(launch_convert_rows(h->cur_in, h->cur_in_stride, h->kfmt, xcur + h->xh, xstride, h->n_pre, R, h->stream));
 	}
 	if (h->KP > 0) {
 		const bool two = h->mode == MODE_RESAMPLE || h->mode == MODE_DSK;

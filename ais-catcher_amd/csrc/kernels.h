@@ -231,6 +231,8 @@ hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long b
 hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s); // channel mode X: npost CIC5 stages down to 48 kHz, us_idx == nullptr: no resampler
 hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s);
 hipError_t launch_convert_rows(const void* in, long long in_stride, int fmt, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
+// DownsampleMovingAverage (DSP.cpp:60-82) at an integer ratio m: dst[i] = (((0 + x[m i]) + x[m i + 1]) + ...) / m, n outputs per row
+hipError_t launch_ma_rows(const void* in, long long in_stride, int fmt, int m, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
 hipError_t launch_k2a_fft(const K2Params& p, int n_chan, hipStream_t s);
 hipError_t launch_k2a_search(const K2Params& p, int n_chan, hipStream_t s);
 hipError_t launch_selftest_hypot(const float2* in, int n, unsigned* mismatches, hipStream_t s);

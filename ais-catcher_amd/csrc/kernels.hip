@@ -1009,6 +1009,37 @@ __global__ void k_convert_rows(const unsigned char* in, long long in_stride_byte
 	}
 }
 
+// DownsampleMovingAverage (DSP/DSP.cpp:60-82, `-go MA on`) at an integer ratio m = sample_rate / 96000: every output is the sum of
+// its own m inputs, accumulated from zero in input order (D += data[i]), divided by (float) m -- complex / real, two true
+// divisions.  Outputs are independent of each other, so one thread per output; a thread's m inputs are contiguous (m * 8 bytes of
+// CF32: whole cache lines from 1536 kSPS on).
+__global__ void k_ma_rows(const unsigned char* in, long long in_stride_bytes, int fmt, int m, float2* dst, long long dst_stride, int n) {
+	const int rx = blockIdx.y;
+	const unsigned char* row = in + (size_t)rx * in_stride_bytes;
+	const float fm = (float)m;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		float dr = 0.0f, di = 0.0f;
+		const size_t i0 = (size_t)i * (size_t)m;
+		if (fmt == 0) {
+			const float2* x = reinterpret_cast<const float2*>(row) + i0;
+			if ((m & 1) == 0) { // 16-byte loads
+				const float4* x4 = reinterpret_cast<const float4*>(x);
+				for (int j = 0; j < m / 2; j++) { const float4 v = x4[j]; dr += v.x; di += v.y; dr += v.z; di += v.w; }
+			} else for (int j = 0; j < m; j++) { const float2 v = x[j]; dr += v.x; di += v.y; }
+		} else if (fmt == 1) { // Utilities/Convert.cpp:255-264
+			const unsigned char* u = row + 2 * i0;
+			for (int j = 0; j < m; j++) { dr += (float)((int)u[2 * j] - 128) * 0.0078125f; di += (float)((int)u[2 * j + 1] - 128) * 0.0078125f; }
+		} else if (fmt == 2) {
+			const signed char* u = reinterpret_cast<const signed char*>(row) + 2 * i0;
+			for (int j = 0; j < m; j++) { dr += (float)(int)u[2 * j] * 0.0078125f; di += (float)(int)u[2 * j + 1] * 0.0078125f; }
+		} else {
+			const short* u = reinterpret_cast<const short*>(row) + 2 * i0;
+			for (int j = 0; j < m; j++) { dr += (float)(int)u[2 * j] * 0.000030517578125f; di += (float)(int)u[2 * j + 1] * 0.000030517578125f; }
+		}
+		dst[(size_t)rx * dst_stride + i] = make_float2(__fdiv_rn(dr, fm), __fdiv_rn(di, fm));
+	}
+}
+
 // copy rows of float2 (history carry of the pre-decimated stream)
 __global__ void k_copy_rows(const float2* src, long long src_stride, float2* dst, long long dst_stride, int n) {
 	const int rx = blockIdx.y;
@@ -4092,6 +4123,13 @@ hipError_t launch_convert_rows(const void* in, long long in_stride, int fmt, flo
 	int blocks = (n + 255) / 256;
 	if (blocks > 256) blocks = 256;
 	hipLaunchKernelGGL(k_convert_rows, dim3(blocks, n_rx), dim3(256), 0, s, (const unsigned char*)in, in_stride * fmt_bytes(fmt), fmt, dst, dst_stride, n);
+	return hipGetLastError();
+}
+
+hipError_t launch_ma_rows(const void* in, long long in_stride, int fmt, int m, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s) {
+	int blocks = (n + 255) / 256;
+	if (blocks > 256) blocks = 256;
+	hipLaunchKernelGGL(k_ma_rows, dim3(blocks, n_rx), dim3(256), 0, s, (const unsigned char*)in, in_stride * fmt_bytes(fmt), fmt, m, dst, dst_stride, n);
 	return hipGetLastError();
 }
 

@@ -26,6 +26,7 @@ FLAG_FP_DS = 32
 FLAG_PS_BOXCAR = 8
 FLAG_GPU_DECODE = 16
 FLAG_MODE_X = 64
+FLAG_MA_DS = 128
 
 EXPORTS = (
     "aisgpu_default_cfg", "aisgpu_create", "aisgpu_destroy", "aisgpu_submit", "aisgpu_submit_device",
@@ -122,7 +123,7 @@ class AisGpu:
 
     def __init__(self, sample_rate=1536000, n_receivers=1, block_len=786432, input_format=FMT_CF32,
                  afc_wide=True, droop=True, device_id=0, taps=False, tiles_per_span=0, serial=False, model=MODEL_DEFAULT,
-                 dsk=False, ps_ema=True, gpu_decode=False, fp_ds=False, mode_x=False):
+                 dsk=False, ps_ema=True, gpu_decode=False, fp_ds=False, mode_x=False, ma=False):
         self.lib = load()
         cfg = Cfg()
         self.lib.aisgpu_default_cfg(ctypes.byref(cfg))
@@ -130,7 +131,7 @@ class AisGpu:
         cfg.model = model
         cfg.input_format, cfg.afc_wide, cfg.droop = input_format, int(afc_wide), int(droop)
         cfg.device_id, cfg.tiles_per_span = device_id, tiles_per_span
-        cfg.flags = (FLAG_TAPS if taps else 0) | (FLAG_SERIAL if serial else 0) | (FLAG_DSK if dsk else 0) | (0 if ps_ema else FLAG_PS_BOXCAR) | (FLAG_GPU_DECODE if gpu_decode else 0) | (FLAG_FP_DS if fp_ds else 0) | (FLAG_MODE_X if mode_x else 0)
+        cfg.flags = (FLAG_TAPS if taps else 0) | (FLAG_SERIAL if serial else 0) | (FLAG_DSK if dsk else 0) | (0 if ps_ema else FLAG_PS_BOXCAR) | (FLAG_GPU_DECODE if gpu_decode else 0) | (FLAG_FP_DS if fp_ds else 0) | (FLAG_MODE_X if mode_x else 0) | (FLAG_MA_DS if ma else 0)
         self.cfg = cfg
         self.h = ctypes.c_void_p()
         rc = self.lib.aisgpu_create(ctypes.byref(cfg), ctypes.byref(self.h))

@@ -86,12 +86,12 @@ class Batch:
 
 class ModelDefaultGPU:
     def __init__(self, sample_rate=1536000, block_len=786432, input_format=_gpu.FMT_CF32, ch1="A", ch2="B",
-                 batch=None, rx=0, detached=False, model=_gpu.MODEL_DEFAULT, gpu_decode=False, fp_ds=False, mode_x=False):
+                 batch=None, rx=0, detached=False, model=_gpu.MODEL_DEFAULT, gpu_decode=False, fp_ds=False, mode_x=False, ma=False):
         self.lib = load()
         err = ctypes.create_string_buffer(512)
         self.fmt = input_format
         self.h = self.lib.aishost_model_create(batch.h if batch else None, rx, sample_rate, block_len, input_format,
-                                               ch1.encode(), ch2.encode(), 1 if detached else 0, model | (0x100 if gpu_decode else 0) | (0x200 if fp_ds else 0) | (0x400 if mode_x else 0), err, 512)
+                                               ch1.encode(), ch2.encode(), 1 if detached else 0, model | (0x100 if gpu_decode else 0) | (0x200 if fp_ds else 0) | (0x400 if mode_x else 0) | (0x800 if ma else 0), err, 512)
         if not self.h:
             raise RuntimeError(err.value.decode())
 

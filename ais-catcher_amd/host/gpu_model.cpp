@@ -176,6 +176,7 @@ void GpuChain::process(const void* data, int len, TAG& tag) {
 		for (int i = 0; i < 8 && !best; i++) if (b2[i] >= cf.sample_rate) best = b2[i];
 		const int n3 = (cf.flags & AISGPU_FLAG_DSK) ? 4 : 1;
 		for (int i = 0; i < n3; i++) if (b3[i] >= cf.sample_rate && (!best || b3[i] < best)) { by3 = true; break; }
+		if (cf.flags & AISGPU_FLAG_MA_DS) by3 = true; // DownsampleMovingAverage hands on blocks of 8192 samples too (DSP.h:128)
 	}
 	for (int s = 0; s < nsub; s++) {
 		aisgpu_out o[2];
@@ -217,6 +218,7 @@ void ModelDefaultGPU::buildModel(char CH1, char CH2, int sample_rate, bool /*tim
 		c.model = v2 ? AISGPU_MODEL_V2 : standard ? AISGPU_MODEL_STANDARD : base ? AISGPU_MODEL_BASE : challenger ? AISGPU_MODEL_CHALLENGER : AISGPU_MODEL_DEFAULT;
 		if (gpu_decode) c.flags |= AISGPU_FLAG_GPU_DECODE;
 		if (fixedpointDS) c.flags |= AISGPU_FLAG_FP_DS;
+		if (MA_DS) c.flags |= AISGPU_FLAG_MA_DS;
 		if (mode_x) c.flags |= AISGPU_FLAG_MODE_X;
 		batch = new GpuBatch(c); // throws std::runtime_error on unsupported rate / missing GPU
 		own_batch = true;

@@ -186,6 +186,7 @@ class ModelDefaultGPU {
 	Format format = Format::CF32;
 	bool CGF_wide = true, droop_compensation = true;
 	bool fixedpointDS = false; // KEY_SETTING_FP_DS (Model.cpp:362-363)
+	bool MA_DS = false;        // KEY_SETTING_MA (Model.cpp:376-380): DownsampleMovingAverage instead of the CIC5 ladder
 	bool mode_x = false;       // channel mode X (Model.cpp:35-107)
 
 	struct Fan : public StreamIn<AIS::Message> { // PassThrough<Message> of the reference (Model.h:88)
@@ -203,7 +204,8 @@ public:
 	void setOwnMMSI(int m) { own_mmsi = m; }
 	void setAFCWide(bool b) { CGF_wide = b; }
 	void setDroop(bool b) { droop_compensation = b; }
-	void setFixedPoint(bool b) { fixedpointDS = b; }
+	void setFixedPoint(bool b) { fixedpointDS = b; if (b) MA_DS = false; }
+	void setMovingAverage(bool b) { MA_DS = b; }
 	void setModeX(bool b) { mode_x = b; }          // AIS::Model::setMode(Mode::X) (DSP/Model.h:104, Receiver.cpp:87-98): one channel, 12k .. 192k
 	void setChallenger(bool b) { challenger = b; } // AIS::ModelChallenger wiring (Model.cpp:601-678) instead of ModelDefault
 	void setBase(bool b) { base = b; }             // AIS::ModelBase wiring (Model.cpp:419-438)

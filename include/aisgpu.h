@@ -72,6 +72,11 @@ extern "C" {
                               * 12000 .. 192000 like the reference (buckets 48k / 96k / 192k, resampled in between; below 24000 one input
                               * block completes up to four downstream blocks, aisgpu_out_count()); channel A carries it, channel B stays silent */
 #define AISGPU_FLAG_DSK 4     /* KEY_SETTING_DSK (`-go DSK on`): 576k / 1152k / 2304k use the decimate-by-3 ladder (Model.cpp:130) */
+#define AISGPU_FLAG_MA_DS 128 /* KEY_SETTING_MA (`-go MA on`, Model.cpp:122-126): convert >> DownsampleMovingAverage >> Rotate instead of the CIC5 ladder
+                               * -- integrate-and-dump to 96 kHz (DSP.cpp:60-82), handed on in blocks of 8192 samples.  Here for sample rates
+                               * that are a multiple of 96000 (192k .. 12288k: 2 .. 128 samples per output) and input blocks that are a whole
+                               * number of its output blocks (block_len * 96000 / sample_rate a multiple of 8192, as the reference's file blocks
+                               * are); like the reference, the option overrides FP_DS and DSK.  Not with channel mode X. */
 
 typedef struct aisgpu aisgpu_t;
 

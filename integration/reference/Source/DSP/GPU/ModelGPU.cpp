@@ -109,6 +109,7 @@ namespace AIS
 		for (int i = 0; i < 8 && !best; i++) if (b2[i] >= cfg.sample_rate) best = b2[i];
 		for (int i = 0; i < ((cfg.flags & AISGPU_FLAG_DSK) ? 4 : 1); i++)
 			if (b3[i] >= cfg.sample_rate && (!best || b3[i] < best)) { by3 = true; break; }
+		if (cfg.flags & AISGPU_FLAG_MA_DS) by3 = true; // DownsampleMovingAverage hands on blocks of 8192 samples too (DSP/DSP.h:128)
 
 		const int nsub = aisgpu_out_count(ctx); // downstream blocks this input block completed (1, or 1..2 behind the resampler)
 		for (int s = 0; s < nsub; s++)
@@ -145,7 +146,7 @@ namespace AIS
 		c.model = model;
 		c.afc_wide = CGF_wide;
 		c.droop = droop_compensation;
-		c.flags = (PS_EMA ? 0 : AISGPU_FLAG_PS_BOXCAR) | (fixedpointDS ? AISGPU_FLAG_FP_DS : 0) | (allowDSK ? AISGPU_FLAG_DSK : 0);
+		c.flags = (PS_EMA ? 0 : AISGPU_FLAG_PS_BOXCAR) | (fixedpointDS ? AISGPU_FLAG_FP_DS : 0) | (allowDSK ? AISGPU_FLAG_DSK : 0) | (MA_DS ? AISGPU_FLAG_MA_DS : 0);
 	}
 
 	void ModelDefaultGPU::buildModel(char CH1, char CH2, int sample_rate, bool timerOn, Device::Device *dev)
@@ -181,6 +182,10 @@ namespace AIS
 			break;
 		case AIS::KEY_SETTING_FP_DS: // Model.cpp:358-402
 			fixedpointDS = Util::Parse::Switch(arg);
+			MA_DS = false;
+			break;
+		case AIS::KEY_SETTING_MA: // (sample rates that are a multiple of 96 kHz, blocks that are whole output blocks: aisgpu.h)
+			MA_DS = Util::Parse::Switch(arg);
 			break;
 		case AIS::KEY_SETTING_DSK:
 			allowDSK = Util::Parse::Switch(arg);
@@ -190,8 +195,8 @@ namespace AIS
 			break;
 		case AIS::KEY_SETTING_SOXR:
 		case AIS::KEY_SETTING_SRC:
-		case AIS::KEY_SETTING_MA:
-			if (Util::Parse::Switch(arg)) throw std::runtime_error(getName() + ": the soxr / samplerate / moving-average downsamplers are CPU-only");
+			if (Util::Parse::Switch(arg)) throw std::runtime_error(getName() + ": the soxr / samplerate downsamplers are CPU-only (external libraries)");
+			MA_DS = false;
 			break;
 		default:
 			Model::SetKey(key, arg);
@@ -203,7 +208,7 @@ namespace AIS
 	std::string ModelDefaultGPU::Get()
 	{
 		return "ps_ema " + Util::Convert::toString(PS_EMA) + " afc_wide " + Util::Convert::toString(CGF_wide) + " droop " + Util::Convert::toString(droop_compensation) +
-			   " fp_ds " + Util::Convert::toString(fixedpointDS) + " dsk " + Util::Convert::toString(allowDSK) + " " + Model::Get();
+			   " fp_ds " + Util::Convert::toString(fixedpointDS) + " dsk " + Util::Convert::toString(allowDSK) + (MA_DS ? " MA ON " : " ") + Model::Get();
 	}
 
 	// ---- ModelChallengerGPU

@@ -52,7 +52,7 @@ namespace AIS
 		GpuChain chain;
 		AIS::Decoder DEC_a[N_SAMPLES_PER_SYMBOL], DEC_b[N_SAMPLES_PER_SYMBOL];
 
-		bool PS_EMA = true, CGF_wide = true, droop_compensation = true, fixedpointDS = false, allowDSK = false;
+		bool PS_EMA = true, CGF_wide = true, droop_compensation = true, fixedpointDS = false, allowDSK = false, MA_DS = false;
 
 		void buildFrontend(int sample_rate, bool timerOn, Device::Device *dev, int model);
 

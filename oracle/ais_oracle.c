@@ -529,6 +529,7 @@ struct ao_chain {
 	int fixed; uint32_t fix_h[4][5]; /* `-go FP_DS on` at 1536 kSPS: Downsample16_CU8, h0..h4 of its four DS_UINT16 stages */
 	/* DownsampleKFilter (DSP.cpp:160-189, DSP.h:181-211): BlackmanHarris_28_3, K = 3, output blocks of 8192 */
 	cf* dsk_buf; long long dsk_cap; cf dsk_out[8192]; int dsk_in, dsk_idx_out;
+	int ma; cf ma_D; int ma_df, ma_idx_out, ma_idx_in; /* `-go MA on`: DownsampleMovingAverage (DSP.cpp:60-82); its 8192-sample output block is dsk_out */
 	float fdc_alpha;
 	cic5_t pre[8], post[2];
 	ups_t us;
@@ -762,6 +763,21 @@ static int ds16_cu8(ao_chain* c, const uint8_t* u, int n, cf* out) {
 	return len;
 }
 
+static void ma_run(ao_chain* c, const cf* data, int len) { /* DSP.cpp:60-82: integrate and dump to 96 kHz, blocks of 8192 */
+	for (int i = 0; i < len; i++) {
+		c->ma_D.re += data[i].re; c->ma_D.im += data[i].im; /* D += data[i] */
+		c->ma_df++;
+		c->ma_idx_out += 96000; /* out_rate (Model.cpp:124) */
+		if (c->ma_idx_out >= c->rate) {
+			c->ma_idx_out %= c->rate;
+			const float df = (float)c->ma_df; /* D / (FLOAT32)df: complex / real = two divisions */
+			c->dsk_out[c->ma_idx_in].re = c->ma_D.re / df; c->dsk_out[c->ma_idx_in].im = c->ma_D.im / df;
+			c->ma_D.re = 0.0f; c->ma_D.im = 0.0f; c->ma_df = 0;
+			if (++c->ma_idx_in == 8192) { frontend_96k(c, c->dsk_out, 8192); c->ma_idx_in = 0; }
+		}
+	}
+}
+
 int ao_feed(ao_chain* c, const void* data, int nbytes) {
 	int n = c->fmt == 1 ? nbytes / 8 : c->fmt == 3 ? nbytes / 4 : nbytes / 2;
 	if (n > c->bcap) {
@@ -789,6 +805,7 @@ int ao_feed(ao_chain* c, const void* data, int nbytes) {
 		for (int i = 0; i < n; i++) { c->b0[i].re = u[2 * i] / 32768.0f; c->b0[i].im = u[2 * i + 1] / 32768.0f; }
 		in = c->b0;
 	} else in = (const cf*)data;
+	if (c->ma) { ma_run(c, in, n); return 0; } /* Model.cpp:122-126: physical >> convert >> DS_MA >> ROT */
 	int m = n;
 	cf* o = c->b1;
 	for (int s = 0; s < c->npre; s++) {
@@ -803,7 +820,7 @@ int ao_feed(ao_chain* c, const void* data, int nbytes) {
 }
 
 ao_chain* ao_create(int model, int sample_rate, int fmt, int flags) {
-	/* flags: bit 0 record taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`, bit 3 `-go FP_DS on` */
+	/* flags: bit 0 record taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`, bit 3 `-go FP_DS on`, bit 5 `-go MA on` (bit 4 below) */
 	static const unsigned buckets_nodsk[] = { 96000, 192000, 288000, 384000, 768000, 1536000, 3072000, 6144000, 12288000 }; /* Model.cpp:129-130 */
 	static const unsigned buckets_dsk[] = { 96000, 192000, 288000, 384000, 576000, 768000, 1152000, 1536000, 2304000, 3072000, 6144000, 12288000 };
 	/* ... bit 4 channel mode X (`-c X`: one channel, 12k .. 192k, Model.cpp:35-107) */
@@ -835,6 +852,9 @@ ao_chain* ao_create(int model, int sample_rate, int fmt, int flags) {
 	else if (is3) { c->npre = k; c->npost = 0; } /* convert >> DS2_k .. DS2_1 >> [US] >> DSK */
 	else if (c->has_us) { c->npost = k >= 2 ? 2 : k; c->npre = k - c->npost; }
 	else { c->npre = k; c->npost = 0; }
+	if (((flags >> 5) & 1) && !mode_x) { /* Model.cpp:111-126: the MA branch comes before the ladders (and before FP_DS is looked at) */
+		c->ma = 1; c->fixed = 0; c->has_dsk = 0; c->has_us = 0; c->has_fdc = 0; c->npre = 0; c->npost = 0;
+	}
 	c->us.increment = (float)sample_rate / (float)bucket;
 	c->rot.re = 1.0f; c->rot.im = 0.0f;
 	ao_rotate_mult((float*)&c->mult);

@@ -105,7 +105,7 @@ struct Harness {
 extern "C" {
 
 // kind: 0 = ModelStandard, 1 = ModelBase, 2 = ModelDefault, 4 = ModelChallenger, 11 = ModelEngineV2; libaisrefgpu.so only: 12 = ModelDefaultGPU, 14 = ModelChallengerGPU.  fmt: 0 = CU8, 1 = CF32, 2 = CS8, 3 = CS16.
-// flags: bit 0 record float taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`, bit 3 `-go FP_DS on`, bit 4 channel mode X (`-c X`)
+// flags: bit 0 record float taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`, bit 3 `-go FP_DS on`, bit 4 channel mode X (`-c X`), bit 5 `-go MA on`
 void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 	const int taps = flags & 1;
 	try {
@@ -124,6 +124,7 @@ void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 		if (flags & 2) h->model->SetKey(AIS::KEY_SETTING_DSK, "ON");
 		if (flags & 4) h->model->SetKey(AIS::KEY_SETTING_PS_EMA, "OFF");
 		if (flags & 8) h->model->SetKey(AIS::KEY_SETTING_FP_DS, "ON");
+		if (flags & 32) h->model->SetKey(AIS::KEY_SETTING_MA, "ON");
 		if (flags & 16) { h->model->setMode(AIS::Mode::X); h->model->buildModel('X', 'X', sample_rate, false, &h->dev); } // Receiver.cpp:87-98,220
 		else h->model->buildModel('A', 'B', sample_rate, false, &h->dev);
 		h->model->Output() >> h->sink;

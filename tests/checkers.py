@@ -33,7 +33,7 @@ def have_ref(kind="strict"):
 class _Chain:
     """One receiver instance behind either checker library."""
 
-    def __init__(self, lib, prefix, model, rate, fmt, taps, dsk=False, ps_ema=True, fp_ds=False, mode_x=False):
+    def __init__(self, lib, prefix, model, rate, fmt, taps, dsk=False, ps_ema=True, fp_ds=False, mode_x=False, ma=False):
         self.lib, self.p = lib, prefix
         f = lambda name: getattr(lib, prefix + name)
         f("create").restype = ctypes.c_void_p
@@ -56,7 +56,7 @@ class _Chain:
         f("destroy").argtypes = [ctypes.c_void_p]
         self._f = f
         self.fmt = fmt
-        flags = (1 if taps else 0) | (2 if dsk else 0) | (0 if ps_ema else 4) | (8 if fp_ds else 0) | (16 if mode_x else 0)
+        flags = (1 if taps else 0) | (2 if dsk else 0) | (0 if ps_ema else 4) | (8 if fp_ds else 0) | (16 if mode_x else 0) | (32 if ma else 0)
         self.h = f("create")(model, rate, {"cu8": 0, "cf32": 1, "cs8": 2, "cs16": 3}[fmt], flags)
         if not self.h:
             raise RuntimeError("checker create failed")
@@ -138,32 +138,32 @@ def _lib(path):
     return _libs[path]
 
 
-def Oracle(model=2, rate=1536000, fmt="cf32", taps=False, dsk=False, ps_ema=True, fp_ds=False, mode_x=False):
+def Oracle(model=2, rate=1536000, fmt="cf32", taps=False, dsk=False, ps_ema=True, fp_ds=False, mode_x=False, ma=False):
     path = os.path.join(ORACLE_DIR, "libaisoracle.so")
     if not os.path.exists(path):
         build_oracle()
     lib = _lib(path)
     lib.ao_reset_seq()
-    return _Chain(lib, "ao_", model, rate, fmt, taps, dsk, ps_ema, fp_ds, mode_x)
+    return _Chain(lib, "ao_", model, rate, fmt, taps, dsk, ps_ema, fp_ds, mode_x, ma)
 
 
-def Ref(model=2, rate=1536000, fmt="cf32", taps=False, kind="strict", dsk=False, ps_ema=True, fp_ds=False, mode_x=False):
+def Ref(model=2, rate=1536000, fmt="cf32", taps=False, kind="strict", dsk=False, ps_ema=True, fp_ds=False, mode_x=False, ma=False):
     lib = _lib(os.path.join(ORACLE_DIR, "_ref", "libaisref_%s.so" % kind))
     lib.ref_reset_seq()
-    return _Chain(lib, "ref_", model, rate, fmt, taps, dsk, ps_ema, fp_ds, mode_x)
+    return _Chain(lib, "ref_", model, rate, fmt, taps, dsk, ps_ema, fp_ds, mode_x, ma)
 
 
 def have_refgpu():
     return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libaisrefgpu.so"))
 
 
-def RefGpu(model=12, rate=1536000, fmt="cf32", dsk=False, ps_ema=True, fp_ds=False):
+def RefGpu(model=12, rate=1536000, fmt="cf32", dsk=False, ps_ema=True, fp_ds=False, ma=False):
     """oracle/_ref/libaisrefgpu.so: the reference's unmodified sources PLUS the reference-side binding of libaisgpu.so
     (integration/reference/Source/DSP/GPU/ModelGPU.cpp, an AIS::Model subclass compiled against the reference's real headers).
     model 2 / 4 = the reference's own ModelDefault / ModelChallenger, 12 / 14 = the same engines with the DSP on the GPU."""
     lib = _lib(os.path.join(ORACLE_DIR, "_ref", "libaisrefgpu.so"))
     lib.ref_reset_seq()
-    return _Chain(lib, "ref_", model, rate, fmt, False, dsk, ps_ema, fp_ds, False)
+    return _Chain(lib, "ref_", model, rate, fmt, False, dsk, ps_ema, fp_ds, False, ma)
 
 
 def oracle_lib():

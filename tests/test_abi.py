@@ -72,6 +72,10 @@ def test_create_ladder_selection_for_decimate_by_3_rates():
     # channel mode X: 12k .. 192k, one channel (Model.cpp:37-38)
     assert rc(48000, 512 * 8, gpu.FLAG_MODE_X) in (0, 2) and rc(40000, 512 * 8, gpu.FLAG_MODE_X) in (0, 2) and rc(192000, 2048 * 8, gpu.FLAG_MODE_X) in (0, 2)
     assert rc(12000, 512 * 8, gpu.FLAG_MODE_X) in (0, 2) and rc(11999, 512 * 8, gpu.FLAG_MODE_X) == 1 and rc(200000, 4096 * 8, gpu.FLAG_MODE_X) == 1 and rc(48000, 512 * 8) == 1
+    # `-go MA on` (Model.cpp:122-126): multiples of 96 kHz, input blocks that are whole 8192-sample output blocks of the downsampler
+    assert rc(1536000, 131072, gpu.FLAG_MA_DS) in (0, 2) and rc(2400000, 204800, gpu.FLAG_MA_DS) in (0, 2) and rc(192000, 16384 * 3, gpu.FLAG_MA_DS) in (0, 2)
+    assert rc(1536000, 65536, gpu.FLAG_MA_DS) == 1 and rc(1000000, 131072, gpu.FLAG_MA_DS) == 1 and rc(96000, 8192, gpu.FLAG_MA_DS) == 1
+    assert rc(48000, 8192, gpu.FLAG_MA_DS | gpu.FLAG_MODE_X) == 1
 
 
 def test_reference_binding_links_and_fails_loudly_without_a_gpu():

@@ -31,7 +31,7 @@ def _feq(a, b):
 def _run_gpu_vs_oracle(streams, rate, fmt, block, nblocks, **kw):
     """streams: list of per-receiver arrays.  Compares every block's taps and outputs per receiver."""
     R = len(streams)
-    okw = dict(dsk=kw.get("dsk", False), ps_ema=kw.get("ps_ema", True), fp_ds=kw.get("fp_ds", False))
+    okw = dict(dsk=kw.get("dsk", False), ps_ema=kw.get("ps_ema", True), fp_ds=kw.get("fp_ds", False), ma=kw.get("ma", False))
     g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block,
                    input_format=_FMT[fmt], taps=True, **kw)
     per = 1 if fmt == "cf32" else 2
@@ -581,6 +581,47 @@ def test_decimate_by_3_ladders(rate, dsk):
     _run_gpu_vs_oracle([synth.to_cu8(x)], rate, "cu8", block, 3, dsk=dsk)
 
 
+@pytest.mark.parametrize("rate, fmt, block, nblocks", [(1536000, "cf32", 131072, 8), (1536000, "cu8", 131072 * 3, 3), (768000, "cs16", 65536, 8),
+                                                       (2304000, "cf32", 196608, 6), (2400000, "cu8", 204800, 6), (192000, "cs8", 16384 * 2, 6)])
+def test_moving_average_downsampler(rate, fmt, block, nblocks):
+    """`-go MA on` (Model.cpp:122-126, DSP.cpp:60-82): integrate-and-dump to 96 kHz in front of Rotate (which then works on the
+    downsampler's 8192-sample blocks); every tap, bit, level and ppm against the oracle (== the compiled reference with the key
+    set, tests/test_oracle_vs_ref.py::test_moving_average_downsampler)."""
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=63, gap_slots=(1, 2))
+    data = {"cu8": synth.to_cu8, "cs8": synth.to_cs8, "cs16": synth.to_cs16, "cf32": lambda v: v}[fmt](x)
+    _run_gpu_vs_oracle([data], rate, fmt, block, nblocks, ma=True)
+
+
+@pytest.mark.parametrize("model", [2, 4])
+def test_moving_average_downsampler_messages(model):
+    """... and the NMEA lines in the reference's order (channel A / B alternate every 4096 samples at 48 kHz, as on the
+    decimate-by-3 ladders), through the host mirror and -- where the reference is compiled -- through the reference-side binding
+    with SetKey(KEY_SETTING_MA, "ON")."""
+    from ais_catcher_amd import host
+    rate, block, nblocks = 1536000, 786432, 4
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=64, gap_slots=(0, 1), type5_every=4)
+    chk = checkers.Ref(model=model, rate=rate, ma=True) if checkers.have_ref() else checkers.Oracle(model=model, rate=rate, ma=True)
+    chk.feed_blocks(x, block)
+    want = chk.nmea()
+    assert len(want) >= 6 and len(set(l.split(",")[4] for l in want)) == 2
+    host.reset_sequence()
+    cls = {2: host.ModelDefaultGPU, 4: host.ModelChallengerGPU}[model]
+    m = cls(sample_rate=rate, block_len=block, ma=True)
+    for b in range(nblocks):
+        m.receive(x[b * block:(b + 1) * block])
+    assert m.nmea() == want
+    if model == 2:  # ... and with the frame decoders on the device (frames sorted into the same 4096-sample slices)
+        host.reset_sequence()
+        md = cls(sample_rate=rate, block_len=block, ma=True, gpu_decode=True)
+        for b in range(nblocks):
+            md.receive(x[b * block:(b + 1) * block])
+        assert md.nmea() == want
+    if checkers.have_refgpu():
+        r = checkers.RefGpu(model=12 if model == 2 else 14, rate=rate, ma=True)
+        r.feed_blocks(x, block)
+        assert r.nmea() == want
+
+
 @pytest.mark.parametrize("rate,dsk,k,fmt", [(250000, False, 0, "cf32"), (240000, False, 0, "cu8"), (500000, True, 1, "cf32"),
                                             (1000000, True, 2, "cf32"), (2000000, True, 3, "cu8")])
 def test_rates_resampled_into_a_decimate_by_3_bucket(rate, dsk, k, fmt):
@@ -834,7 +875,7 @@ def test_gpu_frame_decoder_matches_host_decoders_on_a_batch():
 # ---------------------------------------------------------------------------------------------------------------
 def _run_outputs_vs_oracle(streams, rate, fmt, block, nblocks, **kw):
     R = len(streams)
-    okw = dict(dsk=kw.get("dsk", False), ps_ema=kw.get("ps_ema", True), fp_ds=kw.get("fp_ds", False))
+    okw = dict(dsk=kw.get("dsk", False), ps_ema=kw.get("ps_ema", True), fp_ds=kw.get("fp_ds", False), ma=kw.get("ma", False))
     g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block,
                    input_format=_FMT[fmt], taps=False, **kw)
     per = 1 if fmt == "cf32" else 2

@@ -10,11 +10,11 @@ from ais_catcher_amd import synth
 pytestmark = pytest.mark.skipif(not checkers.have_ref("strict"), reason="oracle/_ref not built")
 
 
-def _compare(model, rate, fmt, block, nblocks, rid, fm=False, dsk=False, ps_ema=True, **kw):
+def _compare(model, rate, fmt, block, nblocks, rid, fm=False, dsk=False, ps_ema=True, ma=False, **kw):
     x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=rid, **kw)
     data = {"cu8": synth.to_cu8, "cs8": synth.to_cs8, "cs16": synth.to_cs16, "cf32": lambda v: v}[fmt](x)
-    o = checkers.Oracle(model=model, rate=rate, fmt=fmt, taps=True, dsk=dsk, ps_ema=ps_ema)
-    r = checkers.Ref(model=model, rate=rate, fmt=fmt, taps=True, dsk=dsk, ps_ema=ps_ema)
+    o = checkers.Oracle(model=model, rate=rate, fmt=fmt, taps=True, dsk=dsk, ps_ema=ps_ema, ma=ma)
+    r = checkers.Ref(model=model, rate=rate, fmt=fmt, taps=True, dsk=dsk, ps_ema=ps_ema, ma=ma)
     o.feed_blocks(data, block)
     r.feed_blocks(data, block)
     for w in range(6):
@@ -146,6 +146,16 @@ def test_decimate_by_3_ladders_with_dsk(rate):
 def test_dsk_input_blocks_not_aligned_to_its_output_blocks():
     """input blocks that are not a multiple of 3 * 8192 samples: the phase carry (idx_in) and the partial output block"""
     _compare(2, 288000, "cf32", 40000, 12, rid=23, gap_slots=(1, 1))
+
+
+@pytest.mark.parametrize("model, rate, fmt, block", [(2, 1536000, "cf32", 131072), (2, 1536000, "cu8", 100000), (2, 768000, "cs16", 65536),
+                                                    (2, 2304000, "cf32", 196608), (4, 1536000, "cf32", 131072), (2, 250000, "cf32", 50000),
+                                                    (2, 2400000, "cu8", 204800)])
+def test_moving_average_downsampler(model, rate, fmt, block):
+    """`-go MA on` (Model.cpp:122-126, DSP.cpp:60-82): integrate-and-dump to 96 kHz in blocks of 8192, then Rotate; integer and
+    fractional ratios, input blocks that are not aligned to its output blocks."""
+    lines = _compare(model, rate, fmt, block, 12 if block < 150000 else 8, rid=61, ma=True, fm=model == 4, gap_slots=(1, 2))
+    assert len(lines) >= 2
 
 
 def test_phase_search_boxcar():
