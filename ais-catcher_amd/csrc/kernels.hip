@@ -1807,21 +1807,27 @@ struct PsWave {
 	unsigned long long h1, h2, h3, h4; // decisions of 1..4 symbols ago, one bit per lane
 };
 
+// M.y: the hypothesis' EMA (M.x is unused).  The step is issue-bound next to the front end, and a packed f32
+// instruction takes two issue slots on gfx950: the EMA update as one packed multiply and one packed cross add (plus the v_and for
+// |t|, which packed operands cannot take as a modifier) was five slots, the three scalar instructions below are three.
+__device__ __forceinline__ float ps_ema(float ma, float tt) { // w * ma + (1 - w) * |t|, each product and the sum rounded (Demod.cpp:71)
+	const float w = 0.85f;
+	const float w1 = 1 - w; // (1 - weight) evaluated in float
+	float p_t, p_m, r;
+	asm("v_mul_f32 %0, |%1|, %2" : "=v"(p_t) : "v"(tt), "s"(w1));
+	asm("v_mul_f32 %0, %1, %2" : "=v"(p_m) : "v"(ma), "s"(w));
+	asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(p_m), "v"(p_t));
+	return r;
+}
+
 // One symbol for all 16 hypotheses of a row (DSP/Demod.cpp:39-101); v is already multiplied by (1j)^n (K3).
 // Returns the emitted bit (0/1).
 template <int MODE>
-// M: the hypothesis' EMA in BOTH halves of a register pair -- the update is one packed multiply (|t|, ma) * (1 - w, w) and one
-// packed cross add, whose two results are the same sum, so the pair is ready for the next symbol without a move
 __device__ __forceinline__ unsigned ps_step(float2 v, float pc, float psn, c2& M, PsWave& hs, int& idx, int k, int rowbase) {
-	const float w = 0.85f;
-	const float w1 = 1 - w; // (1 - weight) evaluated in float (Demod.cpp:71)
 	const float a = v.x * pc, b = v.y * psn;
 	const float tt = a + b;
 	const unsigned long long dn = __ballot(tt > 0); // bits[k] = (bits[k] << 1) | (t > 0)
-	{
-		const c2 u = c2{ fabsf(tt), M.y } * c2{ w1, w };
-		M = u.yx + u.xy; // w * ma + w1 * |t| (Demod.cpp:71), twice
-	}
+	M.y = ps_ema(M.y, tt);
 	const float ma = M.y;
 	float left, right;
 	if (MODE == 2) {
@@ -1836,17 +1842,19 @@ __device__ __forceinline__ unsigned ps_step(float2 v, float pc, float psn, c2& M
 	const float bestc = p0 ? ma : left;
 	const bool p1 = right > bestc;     // idx+1 beats the better of the two
 	const unsigned long long B0 = __ballot(p0), B1 = __ballot(p1);
-	const int sh = rowbase + idx;
+	const int sh = rowbase | (idx & 15); // (rowbase is a multiple of 16)
 	// prev-1, prev, prev+1 with first-maximum preference: +1 where the third candidate wins (p1), -1 where neither the second
 	// nor the third does; the two ballot words are combined on the scalar unit, a lane only extracts its bit of each
 	const unsigned long long UP = B1, DN = ~(B0 | B1);
 	const int up = (int)((unsigned)(UP >> sh) & 1u);
-	const int down = __builtin_amdgcn_sbfe((int)(unsigned)(DN >> sh), 0u, 1u); // -1 or 0
-	idx = (idx + up + down) & 15;
+	int down, moved; // (pinned: the compiler turns the sign-extending extract into and + sub and the three-operand add into two)
+	asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(down) : "v"((unsigned)(DN >> sh))); // -1 or 0
+	asm("v_add3_u32 %0, %1, %2, %3" : "=v"(moved) : "v"(idx), "v"(up), "v"(down));
+	idx = moved; // (only its low four bits count: masked where it is used -- one v_and_or with the row base per step -- and where it is stored)
 	// nDelay = 3 (Model.cpp:560-561): after the shift-in, bit 3 = decision of 3 symbols ago, bit 4 = 4 symbols ago
 	const unsigned long long X = hs.h3 ^ hs.h4;
 	hs.h4 = hs.h3; hs.h3 = hs.h2; hs.h2 = hs.h1; hs.h1 = dn;
-	return (unsigned)(X >> (rowbase + idx)) & 1u;
+	return (unsigned)(X >> (rowbase | (idx & 15))) & 1u;
 }
 
 #ifndef PS_BATCH_
@@ -1937,7 +1945,7 @@ __global__ __launch_bounds__(64) void k4_phase_search(K4Params p, int conditiona
 		// only the last four decisions can ever be read again (bits 3 and 4 after the next shift-in)
 		sto->bits[k] = (unsigned)((hs.h1 >> lane) & 1ull) | ((unsigned)((hs.h2 >> lane) & 1ull) << 1) |
 		               ((unsigned)((hs.h3 >> lane) & 1ull) << 2) | ((unsigned)((hs.h4 >> lane) & 1ull) << 3);
-		if (k == 0) { sto->max_idx = idx; sto->rot = (st->rot + p.n_groups) & 3; }
+		if (k == 0) { sto->max_idx = idx & 15; sto->rot = (st->rot + p.n_groups) & 3; }
 	}
 }
 
@@ -2000,7 +2008,7 @@ __global__ __launch_bounds__(64) void k4_phase_search_box(K4Params p) {
 #pragma unroll
 		for (int l = 0; l < 12; l++) sto->mem[l][k] = mem[lane][l];
 		sto->bits[k] = bits & 0xffu;
-		if (k == 0) sto->max_idx = idx;
+		if (k == 0) sto->max_idx = idx & 15;
 	}
 	(void)rowbase;
 }
@@ -2093,7 +2101,7 @@ __global__ __launch_bounds__(64) void k4_box_chunks(K4Params p) {
 	if (live) {
 		p.ma_fin[slot * 16 + k] = 0.0f;
 		if (chunk > 0) p.ma_start[slot * 16 + k] = 0.0f;
-		p.fin[slot * 16 + k] = (unsigned)idx | ((bits & 0xffu) << 4);
+		p.fin[slot * 16 + k] = (unsigned)(idx & 15) | ((bits & 0xffu) << 4);
 		if (chunk == p.n_chunks - 1) { // the block's final float state (max_idx: k4_assemble)
 			PsBoxState* sto = p.box_out + chain;
 #pragma unroll
@@ -2117,14 +2125,9 @@ __global__ __launch_bounds__(64) void k4_box_chunks(K4Params p) {
 // ------------------------------------------------------------------------------------------
 template <int MODE>
 __device__ __forceinline__ void ps_warm_step(float2 v, float pc, float psn, c2& M, PsWave& hs) {
-	const float w = 0.85f;
-	const float w1 = 1 - w;
 	const float tt = v.x * pc + v.y * psn;
 	const unsigned long long dn = __ballot(tt > 0);
-	{
-		const c2 u = c2{ fabsf(tt), M.y } * c2{ w1, w };
-		M = u.yx + u.xy;
-	}
+	M.y = ps_ema(M.y, tt);
 	hs.h4 = hs.h3; hs.h3 = hs.h2; hs.h2 = hs.h1; hs.h1 = dn;
 }
 
@@ -2245,7 +2248,7 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 		p.ma_fin[slot * 16 + k] = ma.y;
 		const unsigned dec = (unsigned)((hs.h1 >> lane) & 1ull) | ((unsigned)((hs.h2 >> lane) & 1ull) << 1) |
 		                     ((unsigned)((hs.h3 >> lane) & 1ull) << 2) | ((unsigned)((hs.h4 >> lane) & 1ull) << 3);
-		p.fin[slot * 16 + k] = (unsigned)idx | (dec << 4);
+		p.fin[slot * 16 + k] = (unsigned)(idx & 15) | (dec << 4);
 	}
 }
 
@@ -2409,7 +2412,7 @@ __device__ __forceinline__ void ps_chunk_body2(const K4Params& p, const int (&ch
 			p.ma_fin[slot[s] * 16 + k] = ma[s].y;
 			const unsigned dec = (unsigned)((hs[s].h1 >> lane) & 1ull) | ((unsigned)((hs[s].h2 >> lane) & 1ull) << 1) |
 			                     ((unsigned)((hs[s].h3 >> lane) & 1ull) << 2) | ((unsigned)((hs[s].h4 >> lane) & 1ull) << 3);
-			p.fin[slot[s] * 16 + k] = (unsigned)idx[s] | (dec << 4);
+			p.fin[slot[s] * 16 + k] = (unsigned)(idx[s] & 15) | (dec << 4);
 		}
 	}
 }
@@ -2716,10 +2719,10 @@ __device__ __forceinline__ void k46_body(const K46Params& p, float2 (*ytile)[K46
 			EmaState* sto = q4.state_out + chain;
 			sto->ma[k] = ma.y;
 			sto->bits[k] = dec;
-			if (k == start_idx0) { sto->max_idx = idx; sto->rot = (st_in->rot + q4.n_groups) & 3; }
+			if (k == start_idx0) { sto->max_idx = idx & 15; sto->rot = (st_in->rot + q4.n_groups) & 3; }
 		} else {
 			q4.ma_fin[slot * 16 + k] = ma.y;
-			q4.fin[slot * 16 + k] = (unsigned)idx | (dec << 4);
+			q4.fin[slot * 16 + k] = (unsigned)(idx & 15) | (dec << 4);
 		}
 	}
 }
