@@ -701,9 +701,25 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->stream));
 	if (h->gpu_decode) { // SimplePLL + decoder (ModelBase) / Deinterleave + five decoders (ModelStandard) on the device, behind the filter
 		const long long g0 = h->n48 / 5, g1 = (h->n48 + h->L) / 5;
-		const K7Params k7 = make_k7(h, pb, 0, g0, (int)(g1 - g0), (unsigned)h->block_idx, (unsigned)h->n_sub);
-		if (h->dec_kind == 1) HIPCHK(launch_k7_pack(k7, h->stream));
-		HIPCHK(launch_k7_mesh(k7, h->stream));
+		K7Params k7 = make_k7(h, pb, 0, g0, (int)(g1 - g0), (unsigned)h->block_idx, (unsigned)h->n_sub);
+		if (h->dec_kind == 1 && h->k7_event && !h->serial && !(h->k7_alt && (h->block_idx & 1))) {
+			// ModelStandard's five decoders per channel are ModelDefault's mesh on other bits: the event-driven kernels take the FM
+			// rows as their decision rows (no level: tag.sample_lvl is never set in this engine), on PhaseSearch's otherwise idle
+			// stream, next to the next block's front end (the sequential mesh kernel held the front stream for 2.5 ms per step)
+			WAITEV(h->stream, h->ev_k4[pb]); // fmrows[pb] was last read by the decoders of block f-2
+			HIPCHK(launch_k7_pack(k7, h->stream));
+			HIPCHK(hipEventRecord(h->ev_sym[pb], h->stream));
+			WAITEV(h->s1, h->ev_sym[pb]);
+			k7.bits = h->d_fmrows[pb]; k7.bits_stride = h->fmrow_words; k7.lvl = nullptr; k7.kind = 0;
+			K7eParams q;
+			q.k = k7; q.ev = h->d_k7ev; q.cnt = h->d_k7cnt; q.open_c = h->d_k7open; q.slot = h->d_k7slot; q.overflow = h->d_k7ovf;
+			HIPCHK(launch_k7e(q, h->s1));
+			HIPCHK(hipEventRecord(h->ev_k4[pb], h->s1));
+		} else {
+			if (h->dec_kind == 1 && h->k7_alt) WAITEV(h->stream, h->ev_k4[pb ^ 1]); // (test hook: the previous block's decoders ran on s1)
+			if (h->dec_kind == 1) HIPCHK(launch_k7_pack(k7, h->stream));
+			HIPCHK(launch_k7_mesh(k7, h->stream));
+		}
 	}
 	HIPCHK(hipEventRecord(h->ev_k3[pb], h->stream));
 	WAITEV(h->s2, h->ev_k3[pb]); // aisgpu_sync_outputs copies on s2
@@ -1235,13 +1251,13 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmrows[i], C * 5 * (size_t)h->fmrow_words));
 			for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_last_lvl[i], C));
 		}
-		if (h->dec_kind != 0) h->k7_event = false; // the event-driven form exists for ModelDefault's wiring only
+		if (h->dec_kind > 1) h->k7_event = false; // the event-driven form: ModelDefault's wiring and ModelStandard's (the same mesh of five on the FM rows)
 		if (h->dec_kind != 0) h->dec_defer = false; // (the FM decoders read the previous block's discriminator bits, a ring of two)
 		// (on the decimate-by-3 ladders Rotate alternates between the channels every 4096 samples, and with it the level the FM
 		// decoders of ModelChallenger inherit through the shared TAG: that variant of the mesh kernel does not exist)
 		if (h->dec_kind == 2 && (by3 || ma_m)) { h->err = "AISGPU_FLAG_GPU_DECODE with ModelChallenger: not on the decimate-by-3 ladders / behind the moving-average downsampler"; return AISGPU_ERR_ARG; }
 		HIPCHK(dalloc(&h->d_frames, (size_t)h->max_frames * DEC_FRAME_WORDS));
-		if (const char* e = getenv("AISGPU_K7")) if (h->dec_kind == 0) { h->k7_event = strcmp(e, "seq") != 0; h->k7_alt = strcmp(e, "alt") == 0; } // "seq": one lane per decoder, symbol by symbol
+		if (const char* e = getenv("AISGPU_K7")) if (h->dec_kind <= 1) { h->k7_event = strcmp(e, "seq") != 0; h->k7_alt = strcmp(e, "alt") == 0; } // "seq": one lane per decoder, symbol by symbol
 		// the event words hold a symbol index in 13 bits: blocks of more than 8191 groups (e.g. the reference's CU8 file block of
 		// 3,145,728 samples at 1536 kSPS) go through the sequential decoder kernel
 		if ((h->L + 4) / 5 + 1 > 8191) h->k7_event = false;

@@ -251,7 +251,7 @@ DEC_HD int dec_run_frame(DecReg& r, uint32_t* data, const uint32_t* brow, const 
 	else data[DEC_LANES * wi] = cw;
 	const int last_sym = flags == 1 ? end : n - 1;
 	float level = r.level;
-	{ // (in symbol order, like the step; eight loads in flight)
+	if (lrow) { // (in symbol order, like the step; eight loads in flight.  No level row: tag.sample_lvl is never set in that engine, the sum stays 0)
 		int i = g_first;
 		for (; i + 8 <= last_sym + 1; i += 8) {
 			float l[8];

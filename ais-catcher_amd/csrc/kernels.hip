@@ -3781,7 +3781,7 @@ __global__ __launch_bounds__(64) void k7e_sim(K7eParams q) {
 	const int chan = dd_ / 5, j = dd_ - 5 * chan;
 	const DecState* st = p.state + dd_;
 	const uint32_t* brow = p.bits + (size_t)dd_ * p.bits_stride;
-	const float* lrow = p.lvl + (size_t)chan * p.lvl_stride;
+	const float* lrow = p.lvl ? p.lvl + (size_t)chan * p.lvl_stride : nullptr; // (ModelStandard: no ScatterPLL, no level)
 	uint32_t* data = fdata + lane;
 	const int n = p.n_groups, nw = (n + 31) >> 5;
 	const auto dd_at = [&](int g) -> int { return g < 0 ? st->prev : (int)((brow[g >> 5] >> (g & 31)) & 1u); };
