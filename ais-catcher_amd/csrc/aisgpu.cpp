@@ -509,7 +509,7 @@ K7Params make_k7(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsign
 int enqueue_decode(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s) {
 	if (!h->gpu_decode) return AISGPU_OK;
 	const K7Params k7 = make_k7(h, pb, lv, g0, n_groups, block, sub);
-	if (h->dec_kind != 0) { // (the FM bits were regrouped on the stream that produced them, see launch_k7_pack)
+	if (h->dec_kind != 0 && !(h->dec_kind == 2 && h->k7_event && !(h->k7_alt && (block & 1)))) { // (the FM bits were regrouped on the stream that produced them, see launch_k7_pack)
 		HIPCHK(launch_k7_mesh(k7, s));
 		return AISGPU_OK;
 	}
@@ -774,6 +774,7 @@ int enqueue_downstream(aisgpu_t* h, int q, int pb) {
 	WAITEV(h->s4, h->ev_front[q]);
 	HIPCHK(launch_k2a_search(k2, h->n_chan, h->s4));
 	HIPCHK(hipEventRecord(h->ev_search[q], h->s4));
+	{ int rc = flush_decode(h); if (rc) return rc; } // (dec_defer) the frame decoders of the block before the previous one, behind this block's searches
 	WAITEV(h->s3, h->ev_search[q]);
 	WAITEV(h->s3, h->ev_c48free[q]);
 	HIPCHK(launch_k2b(k2, h->n_chan, h->s3));
@@ -1129,7 +1130,10 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			// default they share the derotation / FIR stream (4), a block late (dec_defer): 0.52 ms.  5 = own stream (the sequential
 			// decoder kernels of the other engines, which run for a whole step), 1 = PhaseSearch's stream.
 			const char* ds = getenv("AISGPU_DEC_STREAM");
-			const bool default_kind = cfg->model != AISGPU_MODEL_STANDARD && cfg->model != AISGPU_MODEL_CHALLENGER && cfg->model != AISGPU_MODEL_BASE;
+			// (ModelChallenger's mesh of ten likewise, when its event-driven form will run: blocks of at most 8191 groups, no AISGPU_K7=seq)
+			const bool evt = !(getenv("AISGPU_K7") && strcmp(getenv("AISGPU_K7"), "seq") == 0) && (h->L + 4) / 5 + 1 <= 8191;
+			const bool default_kind = (cfg->model != AISGPU_MODEL_STANDARD && cfg->model != AISGPU_MODEL_CHALLENGER && cfg->model != AISGPU_MODEL_BASE) ||
+			                          (cfg->model == AISGPU_MODEL_CHALLENGER && evt);
 			const int dsel = ds ? atoi(ds) : (default_kind ? 4 : 5);
 			if (dsel == 4 || dsel == 1) h->s5 = nullptr;
 			else if (masked && (cfg->flags & AISGPU_FLAG_GPU_DECODE)) {
@@ -1251,21 +1255,22 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmrows[i], C * 5 * (size_t)h->fmrow_words));
 			for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_last_lvl[i], C));
 		}
-		if (h->dec_kind > 1) h->k7_event = false; // the event-driven form: ModelDefault's wiring and ModelStandard's (the same mesh of five on the FM rows)
-		if (h->dec_kind != 0) h->dec_defer = false; // (the FM decoders read the previous block's discriminator bits, a ring of two)
+		if (h->dec_kind > 2) h->k7_event = false; // the event-driven form: ModelDefault's wiring, ModelStandard's (the same mesh of five on the FM rows), ModelChallenger's mesh of ten
+		if (h->dec_kind == 1 || h->dec_kind == 3) h->dec_defer = false; // (ModelStandard / ModelBase: their decoders are enqueued by the FM receiver's own flow)
 		// (on the decimate-by-3 ladders Rotate alternates between the channels every 4096 samples, and with it the level the FM
 		// decoders of ModelChallenger inherit through the shared TAG: that variant of the mesh kernel does not exist)
 		if (h->dec_kind == 2 && (by3 || ma_m)) { h->err = "AISGPU_FLAG_GPU_DECODE with ModelChallenger: not on the decimate-by-3 ladders / behind the moving-average downsampler"; return AISGPU_ERR_ARG; }
 		HIPCHK(dalloc(&h->d_frames, (size_t)h->max_frames * DEC_FRAME_WORDS));
-		if (const char* e = getenv("AISGPU_K7")) if (h->dec_kind <= 1) { h->k7_event = strcmp(e, "seq") != 0; h->k7_alt = strcmp(e, "alt") == 0; } // "seq": one lane per decoder, symbol by symbol
+		if (const char* e = getenv("AISGPU_K7")) if (h->dec_kind <= 2) { h->k7_event = strcmp(e, "seq") != 0; h->k7_alt = strcmp(e, "alt") == 0; } // "seq": one lane per decoder, symbol by symbol
 		// the event words hold a symbol index in 13 bits: blocks of more than 8191 groups (e.g. the reference's CU8 file block of
 		// 3,145,728 samples at 1536 kSPS) go through the sequential decoder kernel
 		if ((h->L + 4) / 5 + 1 > 8191) h->k7_event = false;
 		if (h->k7_event) {
-			HIPCHK(dalloc(&h->d_k7ev, (size_t)h->n_chains * K7E_EVCAP));
-			HIPCHK(dalloc(&h->d_k7cnt, (size_t)h->n_chains));
-			HIPCHK(dalloc(&h->d_k7open, (size_t)h->n_chains * K7E_OPENCAP));
-			HIPCHK(dalloc(&h->d_k7slot, (size_t)h->n_chains * K7E_OPENCAP));
+			const size_t n_dec = (size_t)h->n_chains * (h->dec_kind == 2 ? 2 : 1); // (ModelChallenger: ten decoders per channel)
+			HIPCHK(dalloc(&h->d_k7ev, n_dec * K7E_EVCAP));
+			HIPCHK(dalloc(&h->d_k7cnt, n_dec));
+			HIPCHK(dalloc(&h->d_k7open, n_dec * K7E_OPENCAP));
+			HIPCHK(dalloc(&h->d_k7slot, n_dec * K7E_OPENCAP));
 			HIPCHK(dalloc(&h->d_k7ovf, 4));
 		}
 		HIPCHK(dalloc(&h->d_frame_count, 1));

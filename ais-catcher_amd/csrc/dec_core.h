@@ -146,7 +146,10 @@ DEC_HD int dec_select_bit(uint32_t m, int k) { // index of the k-th (1-based) se
 // r: a decoder in DATAFCS in front of symbol g (r.prev = decision g-1); brow: the packed decisions of the block (nw words, n
 // symbols); lrow: the levels.  Returns flags -- 0: back in TRAINING at symbol `end`; 1: message completed at `end`;
 // 2: the block ended (`end` = n) -- and for 1 / 2 the state and the frame buffer.
-DEC_HD int dec_run_frame(DecReg& r, uint32_t* data, const uint32_t* brow, const float* lrow, int g, int n, const uint16_t* tab, int& end) {
+// lvl_shift / lvl_first: ModelChallenger's FM0..FM3 see tag.sample_lvl as the PREVIOUS group's ScatterPLL left it (symbol i adds
+// lrow[i - 1]; symbol 0 what the block before -- or the other channel -- left: lvl_first).
+DEC_HD int dec_run_frame(DecReg& r, uint32_t* data, const uint32_t* brow, const float* lrow, int g, int n, const uint16_t* tab, int& end,
+                         int lvl_shift = 0, float lvl_first = 0.0f) {
 	const int g_first = g;
 	int pos = r.position, osc = r.osc, abort_pos = r.abort_pos;
 	uint32_t dprev = (uint32_t)r.prev;
@@ -253,6 +256,10 @@ DEC_HD int dec_run_frame(DecReg& r, uint32_t* data, const uint32_t* brow, const 
 	float level = r.level;
 	if (lrow) { // (in symbol order, like the step; eight loads in flight.  No level row: tag.sample_lvl is never set in that engine, the sum stays 0)
 		int i = g_first;
+		if (lvl_shift) {
+			if (i == 0 && i <= last_sym) { level = level + lvl_first; i = 1; }
+			lrow -= 1;
+		}
 		for (; i + 8 <= last_sym + 1; i += 8) {
 			float l[8];
 			for (int e = 0; e < 8; e++) l[e] = lrow[i + e];

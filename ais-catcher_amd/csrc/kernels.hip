@@ -3690,6 +3690,27 @@ __device__ __forceinline__ int k7e_training_pos(const DecState* st) { // alterna
 	return st->state == DST_TRAINING ? (st->position < 5 ? st->position : 5) : 0;
 }
 
+// The decoders a K7e launch serves: five per channel on the coherent rows (ModelDefault; ModelStandard with the FM rows handed in as
+// `bits`), or -- kind 2, ModelChallenger -- ten per channel in the reference's order within a group (o = 0..3: FM0..FM3, 4..8: the
+// coherent decoders 0..4, 9: FM4; Model.cpp:630-639), decoder d = chan * 10 + o, the FM ones on the regrouped discriminator rows.
+struct K7eDec { const uint32_t* row; int chan, j, o; bool lvl_shift; };
+__device__ __forceinline__ int k7e_mesh(const K7Params& p) { return p.kind == 2 ? 10 : 5; }
+__device__ __forceinline__ K7eDec k7e_decoder(const K7Params& p, int d) {
+	K7eDec r;
+	if (p.kind == 2) {
+		r.chan = d / 10; r.o = d - 10 * r.chan;
+		const bool is_fm = r.o < 4 || r.o == 9;
+		r.j = r.o < 4 ? r.o : r.o == 9 ? 4 : r.o - 4;
+		r.row = is_fm ? p.fmrows + (size_t)(r.chan * 5 + r.j) * p.fmrows_stride : p.bits + (size_t)(r.chan * 5 + r.j) * p.bits_stride;
+		r.lvl_shift = r.o < 4; // FM0..FM3 run before the group's ScatterPLL output: they see the previous group's level
+	} else {
+		r.chan = d / 5; r.j = d - 5 * r.chan; r.o = r.j;
+		r.row = p.bits + (size_t)d * p.bits_stride;
+		r.lvl_shift = false;
+	}
+	return r;
+}
+
 // Sixteen lanes per decoder, each a segment of the row's words: every candidate of the block, classified (dec_core.h).  One lane
 // per decoder walked 154 words one after the other -- 0.12 ms alone and 0.17 - 0.22 ms next to the front end, a third of the
 // decoder pass; a segment is ten words, whose loads are all in flight at once.  The lanes of a decoder then agree on what a
@@ -3701,12 +3722,12 @@ __global__ __launch_bounds__(64) void k7e_scan(K7eParams q) {
 	const K7Params& p = q.k;
 	__builtin_amdgcn_s_setprio(3); // latency-bound waves: they need their few issue slots at once
 	const int lane = threadIdx.x, seg = lane & 15;
-	const int n_dec = p.n_chan * 5;
+	const int n_dec = p.n_chan * k7e_mesh(p);
 	const int d_raw = blockIdx.x * 4 + (lane >> 4);
 	const bool live = d_raw < n_dec;
 	const int d = live ? d_raw : 0;
 	const DecState* st = p.state + d;
-	const uint32_t* brow = p.bits + (size_t)d * p.bits_stride;
+	const uint32_t* brow = k7e_decoder(p, d).row;
 	uint32_t* ev = q.ev + (size_t)d * K7E_EVCAP;
 	uint16_t* oc = q.open_c + (size_t)d * K7E_OPENCAP;
 	const int n = p.n_groups, nw = (n + 31) >> 5, wps = (nw + 15) >> 4;
@@ -3775,13 +3796,23 @@ __global__ __launch_bounds__(64) void k7e_sim(K7eParams q) {
 	// K7E_SIM_LANES lanes per decoder take its runs round robin.  A decoder has ~4.5 runs per block on the bench signal (13 at
 	// most) and there are fewer waves than SIMDs: with 16 lanes a second round practically never happens, and idle lanes cost nothing.
 	const int d = blockIdx.x * (64 / K7E_SIM_LANES) + lane / K7E_SIM_LANES;
-	const int n_dec = p.n_chan * 5;
+	const int n_dec = p.n_chan * k7e_mesh(p);
 	const int dd_ = d < n_dec ? d : 0;
 	const int nrun = d < n_dec ? (int)(q.cnt[dd_] >> 16) : 0;
-	const int chan = dd_ / 5, j = dd_ - 5 * chan;
+	const K7eDec dc = k7e_decoder(p, dd_);
+	const int chan = dc.chan, j = dc.j;
 	const DecState* st = p.state + dd_;
-	const uint32_t* brow = p.bits + (size_t)dd_ * p.bits_stride;
+	const uint32_t* brow = dc.row;
 	const float* lrow = p.lvl ? p.lvl + (size_t)chan * p.lvl_stride : nullptr; // (ModelStandard: no ScatterPLL, no level)
+	// ModelChallenger's FM0..FM3: the level of symbol 0 is what tag.sample_lvl held when the block began -- this channel's last
+	// group of the block before, or, for samples of this block, what the OTHER channel left (one TAG per device, Rotate hands
+	// channel A its whole block before channel B: k7_decode_mesh<2>)
+	float lvl_first = 0.0f;
+	if (dc.lvl_shift) {
+		lvl_first = p.last_lvl_in[chan];
+		if (p.n_rel0 + j >= 0)
+			lvl_first = (chan & 1) ? (p.n_groups > 0 ? p.lvl[(size_t)(chan ^ 1) * p.lvl_stride + p.n_groups - 1] : p.last_lvl_in[chan ^ 1]) : p.last_lvl_in[chan ^ 1];
+	}
 	uint32_t* data = fdata + lane;
 	const int n = p.n_groups, nw = (n + 31) >> 5;
 	const auto dd_at = [&](int g) -> int { return g < 0 ? st->prev : (int)((brow[g >> 5] >> (g & 31)) & 1u); };
@@ -3819,7 +3850,7 @@ __global__ __launch_bounds__(64) void k7e_sim(K7eParams q) {
 			}
 		}
 		// ---- the frame
-		if (running) flags = dec_run_frame(r, data, brow, lrow, g, n, s_crc, end);
+		if (running) flags = dec_run_frame(r, data, brow, lrow, g, n, s_crc, end, dc.lvl_shift ? 1 : 0, lvl_first);
 		if (act) {
 			K7Slot* sl = q.slot + (size_t)d * K7E_OPENCAP + k;
 			sl->end = end; sl->flags = flags;
@@ -3847,16 +3878,28 @@ __device__ __forceinline__ int grp8_min(int v) {
 	t = __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true); v = t < v ? t : v;      // quad_perm [2,3,0,1]
 	t = __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true); return t < v ? t : v;  // row_half_mirror
 }
-__device__ __forceinline__ int grp8_max(int v) { return -grp8_min(-v); }
+// (sixteen lanes: one more step, the mirror of the whole row)
+template <int GROUP>
+__device__ __forceinline__ int grp_min(int v) {
+	v = grp8_min(v);
+	if (GROUP == 16) { const int t = __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true); v = t < v ? t : v; } // row_mirror
+	return v;
+}
+template <int GROUP>
+__device__ __forceinline__ int grp_max(int v) { return -grp_min<GROUP>(-v); }
 
+// MESH decoders per channel in GROUP lanes (5 in 8: ModelDefault / ModelStandard; 10 in 16: ModelChallenger, lane o = the decoder's
+// place in the reference's order within a group)
+template <int MESH, int GROUP>
 __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 	const K7Params& p = q.k;
 	__builtin_amdgcn_s_setprio(3); // a handful of latency-bound waves: they need their few issue slots at once
 	const int lane = threadIdx.x;
-	const int mesh = lane >> 3, j = lane & 7; // eight lanes per channel, five of them decoders
-	const int chan_raw = blockIdx.x * 8 + mesh;
-	const bool live = j < 5 && chan_raw < p.n_chan;
-	const int d = (live ? chan_raw : 0) * 5 + (live ? j : 0);
+	const int mesh = lane / GROUP, j = lane % GROUP; // j: the decoder's place in the order of a group (its phase, for the meshes of five)
+	const int chan_raw = blockIdx.x * (64 / GROUP) + mesh;
+	const bool live = j < MESH && chan_raw < p.n_chan;
+	const int d = (live ? chan_raw : 0) * MESH + (live ? j : 0);
+	const K7eDec dc = k7e_decoder(p, d);
 	const int n = p.n_groups;
 	constexpr int INF = 1 << 26;
 	DecState* st = p.state + d;
@@ -3906,7 +3949,7 @@ __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 			const int e = (int)(v & 0xFFFFu);
 			const K7Slot* s = slots + (v >> 16);
 			uint32_t* f = p.frames + (size_t)((fs0 + (unsigned)(i - from)) % (unsigned)p.max_frames) * DEC_FRAME_WORDS;
-			const long long sidx = 5 * (p.first_group + e) + j;
+			const long long sidx = 5 * (p.first_group + e) + dc.j;
 			f[0] = (uint32_t)d; f[1] = (uint32_t)e; f[2] = (uint32_t)s->s.position; f[3] = __float_as_uint(s->s.level);
 			f[4] = (uint32_t)(unsigned long long)s->s.start_idx; f[5] = (uint32_t)((unsigned long long)s->s.start_idx >> 32);
 			f[6] = (uint32_t)(unsigned long long)sidx; f[7] = (uint32_t)((unsigned long long)sidx >> 32);
@@ -3917,11 +3960,11 @@ __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 	};
 	for (;;) {
 		const int t = busy ? end_ : (head != 0xFFFFFFFFu ? (int)(head & 0x1FFFu) : INF);
-		const int key = live && t < n ? t * 8 + j : INF * 8; // (equal groups: the lower phase first)
-		const int mk = grp8_min(key);
-		if (!__any(mk < INF * 8)) break; // (runs that are still going at the end of the block stay busy)
-		const bool mine = live && key == mk && mk < INF * 8;
-		int bcast = -1; // a completed message: (group << 3) | phase, told to the siblings
+		const int key = live && t < n ? t * 16 + j : INF * 16; // (equal groups: the reference's order within a group)
+		const int mk = grp_min<GROUP>(key);
+		if (!__any(mk < INF * 16)) break; // (runs that are still going at the end of the block stay busy)
+		const bool mine = live && key == mk && mk < INF * 16;
+		int bcast = -1; // a completed message: (group << 4) | place in the order, told to the siblings
 		if (mine) {
 			if (!busy) { // a candidate: real only if the decoder has been counting alternations for five symbols
 				const uint32_t e = head;
@@ -3945,14 +3988,14 @@ __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 				if (fnd) { // noted now, copied out behind the walk (or right away when the note pad is full)
 					if (nfound == K7E_FOUND) { emit(0, nfound); nfound = 0; }
 					s_found[nfound++][lane] = (uint32_t)e | ((uint32_t)slot_ << 16);
-					bcast = (e << 3) | j;
+					bcast = (e << 4) | j;
 				}
 			}
 		}
 		// Reset to the siblings (AIS.cpp:47-49): the phases behind the finder are reset BEFORE their step of that group
-		const int msg = grp8_max(bcast); // (only the owner of the round can have one)
+		const int msg = grp_max<GROUP>(bcast); // (only the owner of the round can have one)
 		if (live && !mine && msg >= 0) {
-			const int e = msg >> 3, jw = msg & 7;
+			const int e = msg >> 4, jw = msg & 15;
 			const int fa = e + (j > jw ? 5 : 6);
 			if (busy) { busy = false; free_at = fa; }
 			else if (fa > free_at) free_at = fa;
@@ -3960,13 +4003,15 @@ __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 	}
 	if (!live) return;
 	emit(0, nfound);
+	// (ModelChallenger) tag.sample_lvl as the block leaves it for this channel's FM decoders of the next one
+	if (MESH == 10 && j == 0) p.last_lvl[dc.chan] = n > 0 ? p.lvl[(size_t)dc.chan * p.lvl_stride + n - 1] : p.last_lvl_in[dc.chan];
 	// state for the next block
 	if (busy) { // the run that is still going: its state as k7e_sim left it
 		*st = slots[slot_].s;
 		return;
 	}
 	// TRAINING: lastBit, prev and the alternations counted (those that end at the last symbol, none before the restart)
-	const uint32_t* brow = p.bits + (size_t)d * p.bits_stride;
+	const uint32_t* brow = dc.row;
 	const int nw = (n + 31) >> 5;
 	const uint32_t wl = nw > 0 ? brow[nw - 1] : 0u, wp = nw > 1 ? brow[nw - 2] : 0u; // the last 33+ decisions, fetched once
 	const auto dd_at = [&](int g) -> int {
@@ -4231,12 +4276,15 @@ hipError_t launch_k7_mesh(const K7Params& p, hipStream_t s) {
 }
 
 hipError_t launch_k7e(const K7eParams& q, hipStream_t s) {
-	const int n_dec = q.k.n_chan * 5;
+	const int n_dec = q.k.n_chan * (q.k.kind == 2 ? 10 : 5);
 	if (q.k.n_groups <= 0) return hipSuccess;
 	static const int skip = getenv("AISGPU_K7E_SKIP") ? atoi(getenv("AISGPU_K7E_SKIP")) : 0; // experiments only (1 scan, 2 sim, 4 resolve: results wrong)
 	if (!(skip & 1)) hipLaunchKernelGGL(k7e_scan, dim3((n_dec + 3) / 4), dim3(64), 0, s, q);
 	if (!(skip & 2)) hipLaunchKernelGGL(k7e_sim, dim3((n_dec * K7E_SIM_LANES + 63) / 64), dim3(64), 0, s, q);
-	if (!(skip & 4)) hipLaunchKernelGGL(k7e_resolve, dim3((q.k.n_chan + 7) / 8), dim3(64), 0, s, q);
+	if (!(skip & 4)) {
+		if (q.k.kind == 2) hipLaunchKernelGGL((k7e_resolve<10, 16>), dim3((q.k.n_chan + 3) / 4), dim3(64), 0, s, q);
+		else hipLaunchKernelGGL((k7e_resolve<5, 8>), dim3((q.k.n_chan + 7) / 8), dim3(64), 0, s, q);
+	}
 	return hipGetLastError();
 }
 

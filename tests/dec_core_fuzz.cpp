@@ -28,7 +28,7 @@ static void fresh(Dec& d, int prev, int lastBit) {
 	d.r.crc = 0xFFFFu; d.r.cw = 0u; d.r.cwi = 0; d.r.tail = 0u; d.r.abort_pos = 0;
 }
 
-struct Block { std::vector<uint32_t> bits; std::vector<float> lvl; int n; long long first_group; };
+struct Block { std::vector<uint32_t> bits; std::vector<float> lvl; int n; long long first_group; int shift; float first; };
 
 // the run as k7e_sim used to make it: one dec_step per symbol
 static int run_steps(Dec& d, const Block& b, int c, int& end) {
@@ -36,7 +36,8 @@ static int run_steps(Dec& d, const Block& b, int c, int& end) {
 	end = b.n;
 	while (g < b.n) {
 		const int dbit = (int)((b.bits[g >> 5] >> (g & 31)) & 1u);
-		const bool found = dec_step<false>(d.r, dbit, b.lvl[g], 5 * (b.first_group + g) + 2, d.data());
+		const float slvl = b.shift ? (g == 0 ? b.first : b.lvl[g - 1]) : b.lvl[g]; // (ModelChallenger's FM0..FM3: the previous group's level)
+		const bool found = dec_step<false>(d.r, dbit, slvl, 5 * (b.first_group + g) + 2, d.data());
 		if (found) { end = g; flags = 1; break; }
 		if (d.r.state == DST_TRAINING) { end = g; flags = 0; break; }
 		g++;
@@ -56,7 +57,7 @@ static int run_words(Dec& d, const Block& b, int c, int& end) {
 		g++;
 	}
 	if (d.r.state != DST_DATAFCS) { d.data()[DEC_LANES * d.r.cwi] = d.r.cw; return 2; }
-	const int flags = dec_run_frame(d.r, d.data(), b.bits.data(), b.lvl.data(), g, b.n, g_tab, end);
+	const int flags = dec_run_frame(d.r, d.data(), b.bits.data(), b.lvl.data(), g, b.n, g_tab, end, b.shift, b.first);
 	if (flags == 2) d.data()[DEC_LANES * d.r.cwi] = d.r.cw;
 	return flags;
 }
@@ -161,6 +162,7 @@ int main(int argc, char** argv) {
 		long long first_group = rnd(0, 1 << 20);
 		n_runs++;
 		int nblocks = 0;
+		const int shifted = rnd(0, 2) == 0;
 		while (at < total) {
 			// the block starts at stream symbol s0 <= at (the run's first block: the candidate is somewhere inside it)
 			const int lead = cont ? 0 : rnd(0, at < 70 ? at : 70);
@@ -169,6 +171,7 @@ int main(int argc, char** argv) {
 			const int n = lead + bl < total - s0 ? lead + bl : total - s0;
 			Block blk;
 			blk.n = n; blk.first_group = first_group;
+			blk.shift = shifted; blk.first = (float)rnd(0, 1 << 16) / 256.0f;
 			blk.bits.assign((n + 31) / 32 + 1, 0u);
 			blk.lvl.assign(lvl.begin() + s0, lvl.begin() + s0 + n);
 			for (int i = 0; i < n; i++) blk.bits[i >> 5] |= (uint32_t)dd[s0 + i] << (i & 31);

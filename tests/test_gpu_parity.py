@@ -1247,12 +1247,14 @@ def test_device_decoders_of_the_other_engines(model, rate, fmt, block, nblocks):
     m.close()
 
 
-def test_model_standard_sequential_decoder_kernel(monkeypatch):
-    """ModelStandard's decoders run event-driven by default (ModelDefault's kernels on the FM rows); AISGPU_K7=seq keeps the
-    sequential mesh kernel reachable, and alternating blocks between the two (AISGPU_K7=alt) shares their state."""
+@pytest.mark.parametrize("model", [0, 4])
+def test_sequential_decoder_kernels_of_the_other_engines(model, monkeypatch):
+    """ModelStandard's and ModelChallenger's decoders run event-driven by default (ModelDefault's kernels on the FM rows / the mesh
+    of ten in the reference's order within a group); AISGPU_K7=seq keeps the sequential mesh kernels reachable, and alternating
+    blocks between the two implementations (AISGPU_K7=alt) shares their state."""
     for mode in ("seq", "alt"):
         monkeypatch.setenv("AISGPU_K7", mode)
-        test_device_decoders_of_the_other_engines(0, 1536000, "cf32", 131072, 12)
+        test_device_decoders_of_the_other_engines(model, 1536000, "cf32", 131072, 12)
 
 
 def test_device_decoders_of_the_other_engines_on_a_noisy_batch():
