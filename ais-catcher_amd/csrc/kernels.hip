@@ -3497,7 +3497,8 @@ __global__ __launch_bounds__(64) void k7_decode(K7Params p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K7 for the other engines (sequential kernels; the event-driven form exists for ModelDefault only).
+// K7 for the other engines, sequential forms (ModelStandard and ModelChallenger run event-driven by default -- K7e below, kinds 1 / 2 --
+// and come here with AISGPU_K7=seq or blocks of more than 8191 groups; ModelBase always).
 //  * k7_pack_fm: the FM receivers hand every 48 kHz sample n to decoder n % 5 (Deinterleave, DSP.h:51-74): regroup the sign bits
 //    of the filtered discriminator per decoder (row j, bit g = sample 5 g + j), for the groups completed inside this block
 //    (the first one may have started in the previous block: those bits come from the previous block's row).
