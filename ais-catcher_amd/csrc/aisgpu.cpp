@@ -190,6 +190,7 @@ struct aisgpu {
 	int dec_kind = 0; uint32_t* d_fmrows[2] = {}; float* d_last_lvl[2] = {}; int fmrow_words = 0; // device decoders of ModelStandard (1) / ModelChallenger (2) / ModelBase (3)
 	bool gpu_decode = false; DecState* d_dec = nullptr; uint32_t* d_frames = nullptr; unsigned* d_frame_count = nullptr;
 	bool k7_alt = false; // test hook (AISGPU_K7=alt): the two decoder implementations take turns, block by block, on the same DecState
+	long long k7e_pass = 0; // passes of the event-driven decoder kernels so far (parity: which overflow flag a pass uses)
 	bool k7_event = true; uint32_t *d_k7ev = nullptr, *d_k7cnt = nullptr; uint16_t* d_k7open = nullptr; K7Slot* d_k7slot = nullptr; int* d_k7ovf = nullptr;
 	uint32_t* h_frames = nullptr; unsigned frames_seen = 0; int max_frames = 0; std::vector<aisgpu_frame> frames;
 	bool ps_box = false; PsBoxState* d_box[2] = {}; // Demod::PhaseSearch (boxcar) instead of PhaseSearchEMA
@@ -506,6 +507,20 @@ K7Params make_k7(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsign
 	return k7;
 }
 
+// the event-driven decoder kernels, and behind them the sequential kernel of the same wiring as their exact fallback (it runs only
+// for a block in which some decoder has more candidates / frame starts than the lists hold: the event-driven kernels then touch
+// nothing).  kq: the parameters as the event-driven kernels see them; kseq: as the sequential kernel does (ModelStandard differs).
+int launch_decoders_event(aisgpu_t* h, const K7Params& kq, K7Params kseq, hipStream_t s) {
+	const int par = (int)(h->k7e_pass++ & 1);
+	K7eParams q;
+	q.k = kq; q.ev = h->d_k7ev; q.cnt = h->d_k7cnt; q.open_c = h->d_k7open; q.slot = h->d_k7slot;
+	q.overflow = h->d_k7ovf + par; q.overflow_clear = h->d_k7ovf + (par ^ 1);
+	HIPCHK(launch_k7e(q, s));
+	kseq.cond = q.overflow; kseq.cond_count = h->d_k7ovf + 2;
+	if (kseq.kind == 0) HIPCHK(launch_k7(kseq, s)); else HIPCHK(launch_k7_mesh(kseq, s));
+	return AISGPU_OK;
+}
+
 int enqueue_decode(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s) {
 	if (!h->gpu_decode) return AISGPU_OK;
 	const K7Params k7 = make_k7(h, pb, lv, g0, n_groups, block, sub);
@@ -514,10 +529,9 @@ int enqueue_decode(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsi
 		return AISGPU_OK;
 	}
 	if (h->k7_event && !(h->k7_alt && (block & 1))) { // event-driven decoders (kernels.h): same DecState between blocks, so the two can even alternate
-		K7eParams q;
-		q.k = k7; q.ev = h->d_k7ev; q.cnt = h->d_k7cnt; q.open_c = h->d_k7open; q.slot = h->d_k7slot; q.overflow = h->d_k7ovf;
-		HIPCHK(launch_k7e(q, s));
-	} else HIPCHK(launch_k7(k7, s));
+		return launch_decoders_event(h, k7, k7, s);
+	} else if (h->dec_kind == 2) HIPCHK(launch_k7_mesh(k7, s));
+	else HIPCHK(launch_k7(k7, s));
 	return AISGPU_OK;
 }
 
@@ -710,10 +724,9 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 			HIPCHK(launch_k7_pack(k7, h->stream));
 			HIPCHK(hipEventRecord(h->ev_sym[pb], h->stream));
 			WAITEV(h->s1, h->ev_sym[pb]);
-			k7.bits = h->d_fmrows[pb]; k7.bits_stride = h->fmrow_words; k7.lvl = nullptr; k7.kind = 0;
-			K7eParams q;
-			q.k = k7; q.ev = h->d_k7ev; q.cnt = h->d_k7cnt; q.open_c = h->d_k7open; q.slot = h->d_k7slot; q.overflow = h->d_k7ovf;
-			HIPCHK(launch_k7e(q, h->s1));
+			K7Params kq = k7;
+			kq.bits = h->d_fmrows[pb]; kq.bits_stride = h->fmrow_words; kq.lvl = nullptr; kq.kind = 0;
+			{ int rc = launch_decoders_event(h, kq, k7, h->s1); if (rc) return rc; }
 			HIPCHK(hipEventRecord(h->ev_k4[pb], h->s1));
 		} else {
 			if (h->dec_kind == 1 && h->k7_alt) WAITEV(h->stream, h->ev_k4[pb ^ 1]); // (test hook: the previous block's decoders ran on s1)
@@ -800,16 +813,6 @@ int enqueue_downstream(aisgpu_t* h, int q, int pb) {
 int gather_frames(aisgpu_t* h) {
 	unsigned total = 0;
 	HIPCHK(hipMemcpy(&total, h->d_frame_count, sizeof total, hipMemcpyDeviceToHost));
-	if (h->k7_event) {
-		int ovf = 0;
-		HIPCHK(hipMemcpy(&ovf, h->d_k7ovf, sizeof ovf, hipMemcpyDeviceToHost));
-		if (ovf) { // not sticky: this call's frames are lost, the next block starts from the DecState the kernels left
-			HIPCHK(hipMemset(h->d_k7ovf, 0, sizeof(int)));
-			h->frames_seen = total; h->frames.clear();
-			h->err = "event-driven frame decoder: more than K7E_OPENCAP frame starts in one block of one decoder (use AISGPU_K7=seq)";
-			return AISGPU_ERR_OVERFLOW;
-		}
-	}
 	if (h->k7_event && getenv("AISGPU_K7E_STATS")) { // experiment aid: events / runs per decoder in the last block
 		std::vector<uint32_t> cnt((size_t)h->n_chan * 5);
 		HIPCHK(hipMemcpy(cnt.data(), h->d_k7cnt, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1798,6 +1801,15 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 	for (int i = 0; i < h->n_sub; i++) h->osub[i] = h->sub[i];
 	h->have_out = true; // (the decisions are there even if the frame ring below has overflowed)
 	if (h->gpu_decode) { rc = gather_frames(h); if (rc != AISGPU_OK) return rc; }
+	return AISGPU_OK;
+}
+
+int aisgpu_decoder_fallbacks(aisgpu_t* h, long long* count) {
+	if (!h || !count) return AISGPU_ERR_ARG;
+	DevGuard dg(h);
+	int v = 0;
+	if (h->d_k7ovf) HIPCHK(hipMemcpy(&v, h->d_k7ovf + 2, sizeof v, hipMemcpyDeviceToHost));
+	*count = v;
 	return AISGPU_OK;
 }
 

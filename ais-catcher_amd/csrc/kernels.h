@@ -196,6 +196,8 @@ struct K7Params {
 	uint32_t* fmrows = nullptr; long long fmrows_stride = 0; // [n_chan * 5][words] scratch: the FM bits regrouped per decoder (sample 5 g + j -> row j, bit g)
 	const float* last_lvl_in = nullptr; float* last_lvl = nullptr; // [n_chan] ScatterPLL level of the last group of the previous / of this block (what tag.sample_lvl still holds)
 	int n_rel0 = 0, L = 0;                        // first_group * 5 - first_sample48; 48 kHz samples per block
+	// sequential kernels as the exact fallback of the event-driven ones: run only where *cond != 0, count the passes that ran in *cond_count
+	const int* cond = nullptr; int* cond_count = nullptr;
 };
 hipError_t launch_k7(const K7Params& p, hipStream_t s);
 hipError_t launch_k7_pack(const K7Params& p, hipStream_t s); // kind 1 / 2: regroup the FM bits per decoder (on the stream that produced them)
@@ -208,7 +210,7 @@ hipError_t launch_k7_mesh(const K7Params& p, hipStream_t s); // kind 1 / 2 / 3: 
 // (k7e_resolve: a frame is real if its decoder was in TRAINING long enough before it, and it is cut short by the Reset of a
 // sibling that completes a message first).  State between blocks is the same DecState as the sequential kernel's.
 constexpr int K7E_EVCAP = 1024;  // events per decoder and block (candidates are >= 6 symbols apart)
-constexpr int K7E_OPENCAP = 128; // frames run per decoder and block; more raise *overflow (use the sequential kernel for such input)
+constexpr int K7E_OPENCAP = 128; // frames run per decoder and block; a block with more raises *overflow and is decoded by the sequential kernel
 struct K7Slot { int end, flags; DecState s; }; // flags: 1 found, 2 still running at the end of the block
 struct K7eParams {
 	K7Params k;
@@ -216,7 +218,9 @@ struct K7eParams {
 	uint32_t* cnt;       // [n_dec]             events | runs << 16
 	uint16_t* open_c;    // [n_dec][K7E_OPENCAP] first symbol of run k (0xFFFF: the frame carried over from the previous block)
 	K7Slot* slot;        // [n_dec][K7E_OPENCAP]
-	int* overflow;
+	int* overflow;       // != 0 behind k7e_scan: a decoder has more candidates / frame starts in this block than the lists hold -- k7e_sim and
+	                     // k7e_resolve then leave everything as it is and the sequential kernel (K7Params::cond) decodes the block
+	int* overflow_clear; // the flag of the pass before (cleared by this pass's scan: everything that looked at it has run)
 };
 hipError_t launch_k7e(const K7eParams& p, hipStream_t s);
 

@@ -3428,6 +3428,10 @@ __global__ __launch_bounds__(64) void k7_decode(K7Params p) {
 	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64]; // [word][lane]
 	__shared__ float lv[64 * 33];                   // [lane][32 groups], padded
 	const int lane = threadIdx.x;
+	if (p.cond) { // exact fallback of the event-driven kernels: only for a block whose candidate lists overflowed
+		if (*p.cond == 0) return;
+		if (blockIdx.x == 0 && lane == 0 && p.cond_count) atomicAdd(p.cond_count, 1);
+	}
 	const int mesh = lane / 5, j = lane - 5 * mesh;  // lanes 60..63 idle
 	const int chan_raw = blockIdx.x * 12 + mesh;
 	const bool live = lane < 60 && chan_raw < p.n_chan;
@@ -3536,6 +3540,10 @@ __global__ __launch_bounds__(64) void k7_decode_mesh(K7Params p) {
 	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64]; // [word][lane]
 	__shared__ float lv[64 * 33];
 	const int lane = threadIdx.x;
+	if (p.cond) { // exact fallback of the event-driven kernels (see k7_decode)
+		if (*p.cond == 0) return;
+		if (blockIdx.x == 0 && lane == 0 && p.cond_count) atomicAdd(p.cond_count, 1);
+	}
 	const int mesh = lane / MESH, o = lane - MESH * mesh; // o: position in the reference's order within a group
 	const int chan_raw = blockIdx.x * PER_WAVE + mesh;
 	const bool live = lane < 60 && chan_raw < p.n_chan;
@@ -3723,6 +3731,7 @@ __global__ __launch_bounds__(64) void k7e_scan(K7eParams q) {
 	const K7Params& p = q.k;
 	__builtin_amdgcn_s_setprio(3); // latency-bound waves: they need their few issue slots at once
 	const int lane = threadIdx.x, seg = lane & 15;
+	if (blockIdx.x == 0 && lane == 0 && q.overflow_clear) *q.overflow_clear = 0;
 	const int n_dec = p.n_chan * k7e_mesh(p);
 	const int d_raw = blockIdx.x * 4 + (lane >> 4);
 	const bool live = d_raw < n_dec;
@@ -3790,6 +3799,7 @@ __global__ __launch_bounds__(64) void k7e_sim(K7eParams q) {
 	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64]; // [word][lane]
 	__shared__ uint16_t s_crc[256];
 	const K7Params& p = q.k;
+	if (*q.overflow != 0) return; // (uniform: the sequential kernel decodes this block)
 	__builtin_amdgcn_s_setprio(3);
 	const int lane = threadIdx.x;
 	for (int i = lane; i < 256; i += 64) dec_crc_table_entry(i, s_crc);
@@ -3894,6 +3904,7 @@ __device__ __forceinline__ int grp_max(int v) { return -grp_min<GROUP>(-v); }
 template <int MESH, int GROUP>
 __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 	const K7Params& p = q.k;
+	if (*q.overflow != 0) return; // (uniform: nothing has been touched, the sequential kernel decodes this block from the same state)
 	__builtin_amdgcn_s_setprio(3); // a handful of latency-bound waves: they need their few issue slots at once
 	const int lane = threadIdx.x;
 	const int mesh = lane / GROUP, j = lane % GROUP; // j: the decoder's place in the order of a group (its phase, for the meshes of five)

@@ -32,7 +32,7 @@ EXPORTS = (
     "aisgpu_default_cfg", "aisgpu_create", "aisgpu_destroy", "aisgpu_submit", "aisgpu_submit_device",
     "aisgpu_run", "aisgpu_sync_outputs", "aisgpu_sync", "aisgpu_fetch", "aisgpu_tap", "aisgpu_stream",
     "aisgpu_frontend_ms", "aisgpu_timing", "aisgpu_strerror", "aisgpu_last_error", "aisgpu_device_count",
-    "aisgpu_out_count", "aisgpu_fetch_sub", "aisgpu_selftest", "aisgpu_frames", "aisgpu_ps_fallbacks",
+    "aisgpu_out_count", "aisgpu_fetch_sub", "aisgpu_selftest", "aisgpu_frames", "aisgpu_ps_fallbacks", "aisgpu_decoder_fallbacks",
 )
 
 
@@ -92,6 +92,7 @@ def load():
     lib.aisgpu_out_count.argtypes = [vp]
     lib.aisgpu_fetch_sub.argtypes = [vp, ci, ci, ci, ctypes.POINTER(Out)]
     lib.aisgpu_ps_fallbacks.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
+    lib.aisgpu_decoder_fallbacks.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
     if hasattr(lib, "aisgpu_frames"):
         lib.aisgpu_frames.argtypes = [vp, ctypes.POINTER(ctypes.POINTER(Frame)), ctypes.POINTER(ci)]
     lib.aisgpu_tap.argtypes = [vp, ci, ci, vp, cll]
@@ -211,6 +212,12 @@ class AisGpu:
         """Workgroups (four chains each) of the chunk-parallel PhaseSearchEMA that went through the exact sequential kernel so far."""
         n = ctypes.c_longlong()
         self._chk(self.lib.aisgpu_ps_fallbacks(self.h, ctypes.byref(n)), "aisgpu_ps_fallbacks")
+        return n.value
+
+    def decoder_fallbacks(self):
+        """Blocks whose frame decoders went through the sequential kernel (candidate lists of the event-driven kernels full)."""
+        n = ctypes.c_longlong()
+        self._chk(self.lib.aisgpu_decoder_fallbacks(self.h, ctypes.byref(n)), "aisgpu_decoder_fallbacks")
         return n.value
 
     def tap(self, which, rx=0):

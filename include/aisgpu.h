@@ -175,6 +175,12 @@ int aisgpu_frames(aisgpu_t* h, const aisgpu_frame** frames, int* count);
  * summed over the blocks completed so far (call it behind aisgpu_sync_outputs()).  Results are bit-exact either way; the count says
  * how often the slow path ran (an extreme level step of a receiver; AISGPU_PS_WARM sets the warm-up length, default 256 symbols). */
 int aisgpu_ps_fallbacks(aisgpu_t* h, long long* count);
+
+/* AISGPU_FLAG_GPU_DECODE, event-driven decoder kernels (ModelDefault / ModelStandard / ModelChallenger): the number of blocks that went
+ * through the sequential decoder kernel instead, because some decoder had more candidate frame starts in the block than the
+ * kernels' lists hold (128 frames / 1024 candidates per decoder and block: a carrier that repeats preamble + start flag every
+ * few dozen symbols).  The frames are the same either way; the sequential kernel is ~10x slower. */
+int aisgpu_decoder_fallbacks(aisgpu_t* h, long long* count);
 int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* out);
 
 /* Float taps of the last block (tests only; needs AISGPU_FLAG_TAPS):

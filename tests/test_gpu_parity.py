@@ -1247,6 +1247,42 @@ def test_device_decoders_of_the_other_engines(model, rate, fmt, block, nblocks):
     m.close()
 
 
+def test_frame_decoder_candidate_lists_overflow_falls_back(monkeypatch):
+    """A carrier that repeats preamble + start flag every 20 symbols gives every decoder ~245 frame starts per block -- more than
+    the event-driven kernels' lists hold (128).  Such a block goes through the sequential kernel on the device (conditional
+    launch, same state in, same state out): the frames are those of AISGPU_K7=seq, nothing fails, and the blocks around it run
+    event-driven again."""
+    block, nb, sps = 786432, 4, 160
+    n = block * nb
+    pattern = np.array([0, 1] * 4 + [0, 1, 1, 1, 1, 1, 1, 0] + [1, 0, 1, 1], np.uint8)
+    lvl = synth.nrzi(np.tile(pattern, n // sps // len(pattern) + 2))
+    rect = lvl[np.minimum(np.arange(n) // sps, len(lvl) - 1)]
+    phase = np.cumsum(synth._fftconv_same(rect, synth._gauss(sps))) * (np.pi / 2.0) / sps
+    carrier = 0.3 * np.exp(1j * (phase - 2.0 * np.pi * 25000.0 / 1536000 * np.arange(n)))
+    carrier[:block] = 0.0                      # block 0: ordinary traffic only (event-driven), blocks 1 .. 2: the carrier on channel A
+    carrier[3 * block:] = 0.0                  # block 3: ordinary again
+    x = (carrier + synth.receiver_stream(n, receiver_id=78, gap_slots=(0, 1)).astype(np.complex128)).astype(np.complex64)
+
+    def run():
+        g = gpu.AisGpu(sample_rate=1536000, n_receivers=1, block_len=block, gpu_decode=True)
+        out = []
+        for b in range(nb):
+            g.submit(0, x[b * block:(b + 1) * block])
+            g.run()
+            g.sync_outputs()
+            out.append(sorted((f["ch"], f["group"], f["phase"], f["position"], f["level_sum"], f["start_idx"], f["end_idx"], f["data"]) for f in g.frames()))
+        nfb = g.decoder_fallbacks()
+        g.close()
+        return out, nfb
+
+    got, nfb = run()
+    monkeypatch.setenv("AISGPU_K7", "seq")
+    want, nseq = run()
+    assert nfb == 2 and nseq == 0               # exactly the two carrier blocks
+    assert got == want
+    assert len(want[0]) >= 1 and len(want[3]) >= 1  # ordinary messages before and behind
+
+
 @pytest.mark.parametrize("model", [0, 4])
 def test_sequential_decoder_kernels_of_the_other_engines(model, monkeypatch):
     """ModelStandard's and ModelChallenger's decoders run event-driven by default (ModelDefault's kernels on the FM rows / the mesh
