@@ -44,3 +44,22 @@ def test_segmented_candidate_scan_equals_the_row_scan(scan_binary, seed):
     assert r.returncode == 0, r.stdout + r.stderr
     rows, events, failures, runs, over = (int(v) for v in re.findall(r"\d+", r.stdout)[:5])
     assert "all equal" in r.stdout and rows == 40000 and failures > 100000 and runs > 100000 and over > 100, r.stdout
+
+
+@pytest.fixture(scope="module")
+def mesh_binary(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("dec_mesh") / "dec_mesh_fuzz")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "ais-catcher_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "dec_mesh_fuzz.cpp"), "-o", out], check=True)
+    return out
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_event_driven_decoders_equal_the_stepped_mesh(mesh_binary, seed):
+    """The whole method of the device frame decoders -- candidate scan, one run per possible frame, the walk that decides in the
+    reference's order which runs happened and what a sibling's Reset cuts short -- against five / ten decoders stepped symbol by
+    symbol with their Reset mesh, over multi-block streams with decision errors (tests/dec_mesh_fuzz.cpp)."""
+    r = subprocess.run([mesh_binary, "5000", str(seed)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    streams, blocks, messages, carried = (int(v) for v in re.findall(r"\d+", r.stdout)[:4])
+    assert "all equal" in r.stdout and streams == 5000 and blocks > 10000 and messages > 5000 and carried > 20000, r.stdout
