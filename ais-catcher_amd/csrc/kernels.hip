@@ -590,6 +590,12 @@ constexpr int fmt_bytes(int fmt) { return fmt == 0 ? 8 : fmt == 3 ? 4 : 2; }
 
 __device__ __forceinline__ void k1_fft_tail(const K1Params& p, int rx, int span, float2* X); // below, with the FFT
 
+template <int E> struct K1Const { static constexpr int value = E; };
+template <int E, int N, class F>
+__device__ __forceinline__ void k1_static_for(F&& f) {
+	if constexpr (E < N) { f(K1Const<E>{}); k1_static_for<E + 1, N>(f); }
+}
+
 template <int K, int FMT, bool PRE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4))) void k1_dpp(K1Params p) {
 	constexpr int C0 = 1 << K;        // input samples per lane per tile
@@ -644,10 +650,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 		if constexpr (DMA) {
 			const uint4* src = (const uint4*)base + dma_r * W4 + dma_q;
 			const bool warm = WARM_SKIP_E > 0 && tile == tile_first; // wave-uniform
+#ifdef K1_DMA_IMM // the instruction's immediate offset moves the global AND the LDS address: pieces e and e + 1 are 1 KiB apart in both
+			k1_static_for<0, NV>([&](auto ec) {
+				constexpr int e = decltype(ec)::value, PER = 4; // 4 KiB of immediate range
+				if (e >= WARM_SKIP_E || !warm)
+					__builtin_amdgcn_global_load_lds((const void*)(src + (e / PER) * PER * 64), (__attribute__((address_space(3))) void*)(xt + (e / PER) * PER * 64), 16,
+					                                 (e % PER) * 1024, K1_LOAD_AUX);
+			});
+#else
 #pragma unroll
 			for (int e = 0; e < NV; e++)
 				if (e >= WARM_SKIP_E || !warm)
-				__builtin_amdgcn_global_load_lds((const void*)(src + e * 64), (__attribute__((address_space(3))) void*)(xt + e * 64), 16, 0, K1_LOAD_AUX);
+					__builtin_amdgcn_global_load_lds((const void*)(src + e * 64), (__attribute__((address_space(3))) void*)(xt + e * 64), 16, 0, K1_LOAD_AUX);
+#endif
 		} else if constexpr (LANE_BYTES >= 16) {
 			const uint4* src = (const uint4*)base;
 #pragma unroll
