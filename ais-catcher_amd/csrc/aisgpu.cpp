@@ -50,9 +50,9 @@ const float TAPS_BH_28_3[26] = { // DSP/Filters.h:45-53 (Filters::BlackmanHarris
 struct EvPair { hipEvent_t a, b; };
 struct TraceRec { const char* name; long long block; hipEvent_t a, b; }; // AISGPU_TRACE=1: kernel timeline from HIP events
 #ifndef AISGPU_NBUF
-#define AISGPU_NBUF 3
+#define AISGPU_NBUF 4
 #endif
-constexpr int NBUF = AISGPU_NBUF;    // ring depth of the buffers that cross from the front-end stream to the others
+constexpr int NBUF = AISGPU_NBUF;    // ring depth of the buffers that cross from the front-end stream to the others (4 against 3: -1.5 % per step, profiles/r03_expA.txt)
 constexpr int MAXSUB = 4;  // downstream blocks ("flushes" of the resampler) that one input block can complete
 constexpr int XPAD = 128;  // extra history of the pre-decimated stream in front of one full block (resampler halo)
 

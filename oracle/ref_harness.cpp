@@ -21,6 +21,8 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <thread>
+#include <sched.h>
 
 #include "Model.h"
 #include "Device.h"
@@ -285,6 +287,52 @@ void ref_v2_fm(const float* x, int n, float* disc, float* filt) {
 		fm.Run((const CFLOAT32*)x + b, disc + b);
 		fl.Run(disc + b, filt + b);
 	}
+}
+
+void ref_destroy(void* hv);
+// CPU baseline (bench.py): `nthreads` independent receivers, one per thread, each thread pinned to cpus[i] (if
+// given), its model built and its input blocks copied INSIDE the thread (first touch on the thread's own NUMA node), all started
+// together, each feeding its blocks round robin until the deadline.  counts[i] = blocks thread i completed.  Returns the
+// wall-clock seconds from the common start to the last thread's end.
+double ref_bench_threads(int kind, int sample_rate, int fmt, const void* blocks, int nblk, int block_bytes, int nthreads, const int* cpus,
+                         double seconds, long long* counts) {
+	std::atomic<int> ready(0);
+	std::atomic<bool> go(false);
+	std::vector<std::thread> th;
+	std::vector<double> t_end(nthreads, 0.0);
+	const auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double t_start = 0;
+	for (int i = 0; i < nthreads; i++) {
+		counts[i] = 0;
+		th.emplace_back([&, i] {
+			if (cpus && cpus[i] >= 0) {
+				cpu_set_t set; CPU_ZERO(&set); CPU_SET(cpus[i], &set);
+				sched_setaffinity(0, sizeof set, &set);
+			}
+			void* h = ref_create(kind, sample_rate, fmt, 0);
+			std::vector<char> local((size_t)nblk * block_bytes);
+			memcpy(local.data(), blocks, local.size());
+			if (h) ref_feed(h, local.data(), block_bytes); // warm-up: page in, size every block's output vector
+			ready++;
+			while (!go.load()) std::this_thread::yield();
+			const double deadline = t_start + seconds;
+			long long k = 0;
+			while (h && clk() < deadline) {
+				ref_feed(h, local.data() + (size_t)(k % nblk) * block_bytes, block_bytes);
+				k++;
+			}
+			t_end[i] = clk();
+			counts[i] = k;
+			if (h) ref_destroy(h);
+		});
+	}
+	while (ready.load() < nthreads) std::this_thread::yield();
+	t_start = clk();
+	go = true;
+	for (auto& t : th) t.join();
+	double last = t_start;
+	for (double e : t_end) if (e > last) last = e;
+	return last - t_start;
 }
 
 // Message::ID is the process-global multi-sentence sequence counter (Marine/Message.cpp:28-39)
