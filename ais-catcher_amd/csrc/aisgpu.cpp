@@ -16,6 +16,8 @@
 #include <new>
 #include <string>
 #include <algorithm>
+#include <cctype>
+#include <map>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -46,6 +48,28 @@ const float TAPS_BH_28_3[26] = { // DSP/Filters.h:45-53 (Filters::BlackmanHarris
 	-1.43685846e-02f, -4.45615933e-02f, -3.44883647e-02f, 5.53474269e-02f, 2.01827915e-01f, 3.16534610e-01f, 3.16534610e-01f,
 	2.01827915e-01f, 5.53474269e-02f, -3.44883647e-02f, -4.45615933e-02f, -1.43685846e-02f, 9.04975801e-03f, 1.09494413e-02f,
 	3.12793899e-03f, -1.64972455e-03f, -1.54206250e-03f, -2.90015252e-04f, 6.32542387e-05f };
+
+// Test hooks (aisgpu_set_option, include/aisgpu.h): process-wide key/value pairs read by aisgpu_create().  The release library
+// reads NO environment variable; a -DAISGPU_EXPERIMENTS build also looks for AISGPU_<KEY> there.
+std::mutex g_opt_mtx;
+std::map<std::string, std::string> g_opt;
+std::string opt_str(const char* key) {
+	{
+		std::lock_guard<std::mutex> l(g_opt_mtx);
+		auto it = g_opt.find(key);
+		if (it != g_opt.end()) return it->second;
+	}
+#ifdef AISGPU_EXPERIMENTS
+	std::string env = "AISGPU_";
+	for (const char* c = key; *c; c++) env += (char)toupper((unsigned char)*c);
+	if (const char* e = getenv(env.c_str())) return e;
+#endif
+	return std::string();
+}
+int opt_int(const char* key, int dflt) {
+	const std::string v = opt_str(key);
+	return v.empty() ? dflt : atoi(v.c_str());
+}
 
 struct EvPair { hipEvent_t a, b; };
 struct TraceRec { const char* name; long long block; hipEvent_t a, b; }; // AISGPU_TRACE=1: kernel timeline from HIP events
@@ -89,8 +113,6 @@ struct aisgpu {
 	int ma_m = 0;         // > 0: `-go MA on`, input samples per 96 kHz sample (the flow of MODE_96K behind launch_ma_rows)
 	int KP = 0;           // CIC5 stages of the pre-decimation pass
 	int tile96 = 64;      // output samples per front-end tile
-	int depth = 1;        // tiles prefetched ahead by the front end
-	int k1_threads = 64;  // front-end workgroup size (64: one autonomous wave per workgroup)
 	int in_bytes = 0;     // bytes per input sample
 	int kfmt = 0;         // kernel numbering of the input format
 	int n_pre = 0;        // samples per receiver per input block after the pre-decimation pass
@@ -110,8 +132,7 @@ struct aisgpu {
 	hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, s3 = nullptr, s4 = nullptr, s5 = nullptr;
 	hipEvent_t ev_phasor[NBUF] = {};  // s3: phasor(f) done -> s1 may apply it
 	hipEvent_t ev_search[NBUF] = {};  // s4: fz(f) known -> s3 may run the phasor recurrence
-	hipEvent_t k1_done[NBUF] = {};    // the event bound to the front-end launch of block f (ext_launch), or nullptr: ev_search is recorded behind it
-	bool ext_launch = true;           // AISGPU_EXT_LAUNCH=0: events as packets of their own behind / in front of the launch
+	hipEvent_t k1_done[NBUF] = {};    // the event bound to the front-end launch of block f (hipExtLaunchKernelGGL), or nullptr: ev_search is recorded behind it
 	bool serial = false;
 	hipEvent_t ev_front[NBUF] = {};   // s0: K2a(f) done -> s3 may start K2b(f)
 	hipEvent_t ev_c48free[NBUF] = {}; // s1: K2c(f) done (c48/fz/rotT[q] consumed) -> s0 may run the front end of f+NBUF
@@ -149,18 +170,14 @@ struct aisgpu {
 	EmaState* d_ema[2] = {}; // state before / after the current downstream block (swapped per block)
 	uint32_t* d_pswords = nullptr; float *d_psma0 = nullptr, *d_psma1 = nullptr; unsigned* d_psfin = nullptr; int* d_psflag = nullptr;
 	int ps_warm = 256; bool ps_parallel = true;
-	struct { bool valid = false; K4Params k4; int pb = 0, lv = 0; long long g0 = 0; unsigned block = 0, sub = 0; hipStream_t s = nullptr; } wpend; // walk not yet run
 	struct { bool valid = false; int pb = 0, lv = 0, n_groups = 0; long long g0 = 0; unsigned block = 0, sub = 0; } dpend; // frame decoders not yet enqueued (dec_defer)
 	bool dec_defer = false; // the frame decoders of block f are enqueued behind the derotation / FIR kernel of block f+1 (they share its stream)
-	bool walk_ride = true;
-	bool ps_lane = false; int walk_prio = 3; int ps_prio = 0; int ps_cl = 512; uint2* d_pslw[2] = {}; // lane-per-chunk PhaseSearchEMA: chunk length, sign words [n_chains][Gcap]
 	// host (pinned)
 	void* h_in[2] = {};
 	float2* h_rot[4] = {};
 	int* h_usidx[2] = {}; float* h_usalpha[2] = {};
-	hipEvent_t rot_ev[4] = {}; bool rot_ev_used[4] = {}; long long rot_next = 0; int rot_lead = 2; // rot_next: first block whose table has not been staged yet
-	RotWorker rw; int rot_slot[4] = {}; bool rot_worker = true; // AISGPU_ROT_WORKER=0: tables generated on the calling thread
-	bool rot_stage_ahead = true;
+	hipEvent_t rot_ev[4] = {}; bool rot_ev_used[4] = {}; long long rot_next = 0; // first block whose table has not been staged yet
+	RotWorker rw; int rot_slot[4] = {};
 	float2* h_rot_dev[4] = {}; bool rot_by_kernel = true; // device view of the pinned table buffers
 	uint32_t* h_bits = nullptr; float* h_lvl = nullptr; float* h_ppm = nullptr; // MAXSUB slots each
 	// stream state
@@ -194,17 +211,12 @@ struct aisgpu {
 	bool k7_event = true; uint32_t *d_k7ev = nullptr, *d_k7cnt = nullptr; uint16_t* d_k7open = nullptr; K7Slot* d_k7slot = nullptr; int* d_k7ovf = nullptr;
 	uint32_t* h_frames = nullptr; unsigned frames_seen = 0; int max_frames = 0; std::vector<aisgpu_frame> frames;
 	bool ps_box = false; PsBoxState* d_box[2] = {}; // Demod::PhaseSearch (boxcar) instead of PhaseSearchEMA
-	bool elide_waits = true; // AISGPU_ELIDE_WAITS=0: always enqueue the barrier packet
-	int ablate = 0; // experiment aid (AISGPU_ABLATE, results are then wrong): bit 0 skip PhaseSearch, 1 skip derotation/FIR, 2 skip the phasor recurrence, 3 skip the front end
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
-	bool fused = false; int GL = 40; bool search_on_front = false;
-	bool defer_fused = false; // spectral analysis on s4, second half of a block one block later
+	bool fused = false; int GL = 40; // groups per segment of the derotation / FIR kernel
 	struct { bool valid = false; int q = 0, pb = 0, lv = 0, n_groups = 0, n_rel0 = 0, S = 0; long long g0 = 0; unsigned block = 0, sub = 0; } fpend;
 	float2 *d_ck[NBUF] = {}, *d_ckw[NBUF] = {}, *d_dfhist[2] = {};
-	int ps_streams = 1; // row sets per wave of the chunk-parallel PhaseSearch kernel (AISGPU_K4_STREAMS=2: k4_phase_chunks2, measured 0.53 against 0.50 ms per step)
 	int* d_qflag4 = nullptr; // [2][n_chains / 4] fallback flags of the row PhaseSearch kernels
-	bool k46 = false; float2* d_ck8[NBUF] = {}; int* d_qflag = nullptr; int n_quads = 0; // FIR + PhaseSearch in one kernel (no FIR outputs in HBM)
 	// per-kernel geometry
 	int tile_in = 0, tiles_per_block = 0, tiles_per_span = 0, spans = 0;         // fused front end (its own input)
 	int ptile_in = 0, ptiles_per_block = 0, ptiles_per_span = 0, pspans = 0;     // pre-decimation pass
@@ -329,7 +341,7 @@ void rot_worker_stop(aisgpu_t* h) {
 }
 
 hipError_t wait_event(aisgpu_t* h, hipStream_t s, hipEvent_t ev) {
-	if (h->elide_waits && hipEventQuery(ev) == hipSuccess) return hipSuccess;
+	if (hipEventQuery(ev) == hipSuccess) return hipSuccess;
 	(void)hipGetLastError(); // (hipErrorNotReady is not an error)
 	return hipStreamWaitEvent(s, ev, 0);
 }
@@ -371,12 +383,11 @@ void trace_dump(aisgpu_t* h) {
 	h->trace_recs.clear();
 }
 
-int span_tiles(int tiles_per_block, int n_rx, int threads, int tile96, int requested) {
+int span_tiles(int tiles_per_block, int n_rx, int requested) {
 	int tps = requested;
-	if (const char* e = getenv("AISGPU_TPS")) tps = atoi(e); // tuning knob
 	if (tps <= 0) {
 		tps = tiles_per_block;
-		const long long want = threads == 64 ? 8192 : (tile96 >= 256 ? 1024 : 2048); // workgroups: a few per CU per residency slot
+		const long long want = 8192; // workgroups: a few per CU per residency slot
 		while (tps > 8 && (long long)n_rx * ((tiles_per_block + tps - 1) / tps) < want) tps = (tps + 1) / 2;
 	}
 	if (tps > tiles_per_block) tps = tiles_per_block;
@@ -438,14 +449,6 @@ int finish_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned 
 	return AISGPU_OK;
 }
 
-// the walk of the previous block that has not ridden along with a next block's sign-word launch (results requested)
-int flush_walk(aisgpu_t* h) {
-	if (!h->wpend.valid) return AISGPU_OK;
-	h->wpend.valid = false;
-	HIPCHK(launch_k4_walk(h->wpend.k4, h->wpend.s));
-	return finish_k4(h, h->wpend.pb, h->wpend.lv, h->wpend.g0, h->wpend.k4.n_groups, h->wpend.block, h->wpend.sub, h->wpend.s);
-}
-
 // PhaseSearchEMA / PhaseSearch of one downstream block (sym/lvl parity pb) on stream s
 int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s) {
 	// bits[lv] was last read by the frame decoder / the copies of block f-4: long done, and ordered here.  (A ring of two made
@@ -458,35 +461,10 @@ int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned
 	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag + pb; k4.fb_count = h->d_psflag + 2;
 	k4.n_chains = h->n_chains; k4.n_groups = n_groups;
 	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
-	k4.lw = h->d_pslw[pb]; k4.lw_quads = h->Gcap / 4; k4.prio = h->ps_prio; k4.prio_walk = h->walk_prio; k4.ma_stride = (h->n_chains + 63) / 64 * 64;
-	k4.cl = h->ps_cl; k4.n_lchunks = (n_groups + h->ps_cl - 1) / h->ps_cl;
 	k4.box_in = h->d_box[pb]; k4.box_out = h->d_box[pb ^ 1]; k4.first_group = g0;
-	k4.streams = h->ps_streams;
-	if (h->d_qflag4 && !h->ps_lane) { k4.qflag = h->d_qflag4 + (size_t)pb * ((h->n_chains + 3) / 4); k4.qflag_div = 4; } // per-workgroup fallback flags
-	if (!h->ps_box && h->ps_parallel && h->ps_lane && k4.n_lchunks > 1) {
-		// (a) sign words of this block, one lane per (chain, chunk), and their verification; (b) the walk over them: one lane
-		// per chain, ~5000 dependent steps, 40 waves for 256 receivers -- pure latency.  It rides along with the NEXT
-		// block's sign-word launch (extra workgroups of the same grid) instead of occupying the stream on its own; until
-		// then the block is pending (flush_walk() when results are requested).  Order of the state: the fallback of block f
-		// (exact sequential kernel, runs only if the verification failed) reads max_idx as walk(f-1) left it and rewrites
-		// everything before the next block's sign words start; walk(f) then skips the block.
-		const bool ride = h->wpend.valid && h->wpend.s == s && !h->serial && h->walk_ride;
-		if (h->wpend.valid && !ride) { int rc = flush_walk(h); if (rc) return rc; }
-		HIPCHK(launch_k4_lane_words(k4, ride ? &h->wpend.k4 : nullptr, s));
-		HIPCHK(launch_k4_fallback(k4, s)); // after the previous block's walk (same launch as the sign words), before the next block's sign words
-		HIPCHK(hipEventRecord(h->ev_sym[pb], s));
-		if (ride) {
-			h->wpend.valid = false;
-			int rc = finish_k4(h, h->wpend.pb, h->wpend.lv, h->wpend.g0, h->wpend.k4.n_groups, h->wpend.block, h->wpend.sub, s);
-			if (rc) return rc;
-		}
-		h->wpend.valid = true; h->wpend.k4 = k4; h->wpend.pb = pb; h->wpend.lv = lv; h->wpend.g0 = g0; h->wpend.block = block; h->wpend.sub = sub; h->wpend.s = s;
-		if (h->serial || !h->walk_ride) return flush_walk(h);
-		return AISGPU_OK;
-	}
-	{ int rc = flush_walk(h); if (rc) return rc; }
-	if (h->ps_box) { if (!h->ps_parallel) k4.streams = 0; else k4.box_out = h->d_box[pb ^ 1]; HIPCHK(launch_k4_box(k4, s)); } // (streams == 0: the sequential row kernel)
-	else if (h->ps_parallel && k4.n_chunks > 1) { if (!(h->ablate & 1)) HIPCHK(launch_k4(k4, s)); }
+	if (h->d_qflag4) { k4.qflag = h->d_qflag4 + (size_t)pb * ((h->n_chains + 3) / 4); k4.qflag_div = 4; } // per-workgroup fallback flags
+	if (h->ps_box) { k4.chunked = h->ps_parallel ? 1 : 0; HIPCHK(launch_k4_box(k4, s)); }
+	else if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, s));
 	else HIPCHK(launch_k4_sequential(k4, s));
 	HIPCHK(hipEventRecord(h->ev_sym[pb], s));
 	return finish_k4(h, pb, lv, g0, n_groups, block, sub, s);
@@ -511,6 +489,7 @@ K7Params make_k7(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsign
 // for a block in which some decoder has more candidates / frame starts than the lists hold: the event-driven kernels then touch
 // nothing).  kq: the parameters as the event-driven kernels see them; kseq: as the sequential kernel does (ModelStandard differs).
 int launch_decoders_event(aisgpu_t* h, const K7Params& kq, K7Params kseq, hipStream_t s) {
+	if (kq.n_groups <= 0) return AISGPU_OK; // (nothing is launched: the pass parity -- which overflow flag a pass uses / clears -- must not advance)
 	const int par = (int)(h->k7e_pass++ & 1);
 	K7eParams q;
 	q.k = kq; q.ev = h->d_k7ev; q.cnt = h->d_k7cnt; q.open_c = h->d_k7open; q.slot = h->d_k7slot;
@@ -590,14 +569,11 @@ int enqueue_back(aisgpu_t* h) {
 //   s4: derotation + FIR + ScatterPLL       (VALU/latency-bound)
 //   s1: PhaseSearchEMA                      (VALU-bound; both overlap the next block's front end)
 // second half of the fused path for one block: derotation + FIR + ScatterPLL (s4), then PhaseSearch (s1)
-int enqueue_k46(aisgpu_t* h, int q, int pb, int lv, long long g0, int n_groups, int n_rel0, unsigned block, unsigned sub);
-
 int enqueue_fused_back(aisgpu_t* h) {
 	if (!h->fpend.valid) return AISGPU_OK;
 	h->fpend.valid = false;
 	const int q = h->fpend.q, pb = h->fpend.pb, lv = h->fpend.lv, n_groups = h->fpend.n_groups;
 	const long long g0 = h->fpend.g0;
-	if (h->k46) return enqueue_k46(h, q, pb, lv, g0, n_groups, h->fpend.n_rel0, h->fpend.block, h->fpend.sub);
 	K6Params k6;
 	k6.c48 = h->d_c48[q]; k6.c48_stride = h->c48s; k6.ck = h->d_ck[q]; k6.ckw = h->d_ckw[q]; k6.ck_stride = (h->n_chan + 63) / 64 * 64;
 	k6.step_table = h->d_step; k6.fz = h->d_fz[q];
@@ -609,40 +585,13 @@ int enqueue_fused_back(aisgpu_t* h) {
 	WAITEV(h->s4, h->ev_phasor[q]);
 	WAITEV(h->s4, h->ev_sym[pb]); // sym[pb] was last read by PhaseSearch of block f-2,
 	WAITEV(h->s4, h->ev_ema[lv]); // lvl[lv] by the frame decoder / the copies of block f-4
-	if (!(h->ablate & 2)) { TraceScope t(h, "derotfir", h->s4); HIPCHK(launch_k6(k6, h->s4)); }
+	{ TraceScope t(h, "derotfir", h->s4); HIPCHK(launch_k6(k6, h->s4)); }
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s4));
 	HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4));
 	{ int rc = flush_decode(h); if (rc) return rc; } // (dec_defer) the previous block's frame decoders, behind this block's derotation / FIR kernel
 	WAITEV(h->s1, h->ev_k3[pb]);
 	TraceScope t(h, "psearch", h->s1);
 	return enqueue_k4(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub, h->s1);
-}
-
-// derotation + FIR + ScatterPLL + PhaseSearchEMA of one downstream block as one kernel on s1 (no FIR outputs in HBM)
-int enqueue_k46(aisgpu_t* h, int q, int pb, int lv, long long g0, int n_groups, int n_rel0, unsigned block, unsigned sub) {
-	hipStream_t s = h->s1;
-	K46Params k{};
-	K4Params& k4 = k.k4;
-	k4.sym = nullptr; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[lv]; k4.bits_stride = h->words;
-	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
-	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag + pb; k4.fb_count = h->d_psflag + 2;
-	k4.qflag = h->d_qflag + (size_t)pb * h->n_quads; k4.qflag_div = 20;
-	k4.n_chains = h->n_chains; k4.n_groups = n_groups;
-	k4.n_chunks = (n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm; k4.prio = h->ps_prio;
-	k4.first_group = g0;
-	k.c48 = h->d_c48[q]; k.c48_stride = h->c48s; k.ck8 = h->d_ck8[q]; k.ck_stride = (h->n_chan + 63) / 64 * 64;
-	k.step_table = h->d_step; k.fz = h->d_fz[q];
-	k.hist_in = h->d_dfhist[pb ^ 1]; k.hist_out = h->d_dfhist[pb];
-	k.lvl = h->d_lvl[lv]; k.lvl_stride = h->Gcap;
-	memcpy(k.taps, TAPS_COHERENT, sizeof k.taps);
-	k.first_group = g0; k.n_rel0 = n_rel0; k.L = h->L; k.n_windows = h->W; k.n_chan = h->n_chan; k.sequential = 0;
-	WAITEV(s, h->ev_phasor[q]);
-	WAITEV(s, h->ev_ema[lv]);     // lvl[lv] and bits[lv] were last read by the frame decoder / the copies of block f-4
-	{ int rc = flush_walk(h); if (rc) return rc; }
-	if (!(h->ablate & 1)) { TraceScope t(h, "firsearch", s); HIPCHK(launch_k46(k, s)); }
-	HIPCHK(hipEventRecord(h->ev_c48free[q], s));
-	HIPCHK(hipEventRecord(h->ev_sym[pb], s));
-	return finish_k4(h, pb, lv, g0, n_groups, block, sub, s);
 }
 
 int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
@@ -653,34 +602,20 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	const int S = (n_groups + h->GL - 1) / h->GL;
 	k2.ck = h->d_ck[q]; k2.ckw = h->d_ckw[q]; k2.ck_stride = k2.rotT_stride;
 	k2.ck_first = n_rel0 - 20; k2.ck_period = 5 * h->GL; k2.n_ck = S;
-	// Without the analysis in the front-end waves, FFT + searches either follow the front end on its stream, or -- AISGPU_DEFER_FUSED -- run on s4
-	// next to it; s4 then must not sit waiting for this block's phasor recurrence, so the second half of the block (derotation /
-	// FIR, PhaseSearch) is enqueued one block later, behind the next block's analysis (or when results are requested).
 	if (h->fft_in_k1) {
 		// the front-end waves have done the whole analysis (k1_fft_tail): fz / ppm of this block are there when K1 is
 		if (!h->k1_done[q]) { HIPCHK(hipEventRecord(h->ev_search[q], h->stream)); h->k1_done[q] = h->ev_search[q]; }
-	} else {
+	} else { // FFT + searches follow the front end on its stream (four busy streams are the limit)
 		h->k1_done[q] = nullptr;
-		hipStream_t sa = h->defer_fused ? h->s4 : h->stream;
-		if (h->defer_fused) {
-			HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
-			WAITEV(h->s4, h->ev_front[q]);
-		}
-		{ TraceScope t(h, "fft", sa); HIPCHK(launch_k2a_fft(k2, h->n_chan, sa)); }
-		hipStream_t ss = h->defer_fused ? h->s4 : h->search_on_front ? h->stream : h->s4; // with the searches on the front stream four streams are enough
-		if (!h->defer_fused) {
-			HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
-			WAITEV(ss, h->ev_front[q]);
-		}
-		{ TraceScope t(h, "search", ss); HIPCHK(launch_k2a_search(k2, h->n_chan, ss)); }
-		HIPCHK(hipEventRecord(h->ev_search[q], ss));
+		{ TraceScope t(h, "fft", h->stream); HIPCHK(launch_k2a_fft(k2, h->n_chan, h->stream)); }
+		{ TraceScope t(h, "search", h->stream); HIPCHK(launch_k2a_search(k2, h->n_chan, h->stream)); }
+		HIPCHK(hipEventRecord(h->ev_search[q], h->stream));
 	}
 	WAITEV(h->s3, h->k1_done[q] ? h->k1_done[q] : h->ev_search[q]);
 	WAITEV(h->s3, h->ev_c48free[q]); // ck[q] was last read by K6 of block f-NBUF
-	if (!(h->ablate & 4)) { TraceScope t(h, "phasor", h->s3); if (h->k46) HIPCHK(launch_k2b_ck8(k2, h->d_ck8[q], h->n_chan, h->s3)); else HIPCHK(launch_k2b_ck(k2, h->n_chan, h->s3)); }
+	{ TraceScope t(h, "phasor", h->s3); HIPCHK(launch_k2b_ck(k2, h->n_chan, h->s3)); }
 	HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
 
-	{ int rc = enqueue_fused_back(h); if (rc) return rc; } // the previous block's second half, if it was deferred
 	h->fpend.valid = true; h->fpend.q = q; h->fpend.pb = pb; h->fpend.lv = lv; h->fpend.g0 = g0; h->fpend.n_groups = n_groups;
 	h->fpend.n_rel0 = n_rel0; h->fpend.S = S; h->fpend.block = (unsigned)h->block_idx; h->fpend.sub = (unsigned)h->n_sub;
 	if (h->n_sub < MAXSUB) {
@@ -689,8 +624,7 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	}
 	h->n48 += h->L;
 	h->block_idx++;
-	if (h->serial || !h->defer_fused) return enqueue_fused_back(h);
-	return AISGPU_OK;
+	return enqueue_fused_back(h);
 }
 
 // Path with the phasor and derotated-sample arrays materialised (taps, Challenger FM branch): everything behind the
@@ -813,13 +747,15 @@ int enqueue_downstream(aisgpu_t* h, int q, int pb) {
 int gather_frames(aisgpu_t* h) {
 	unsigned total = 0;
 	HIPCHK(hipMemcpy(&total, h->d_frame_count, sizeof total, hipMemcpyDeviceToHost));
-	if (h->k7_event && getenv("AISGPU_K7E_STATS")) { // experiment aid: events / runs per decoder in the last block
+#ifdef AISGPU_EXPERIMENTS
+	if (h->k7_event && opt_int("k7e_stats", 0)) { // experiment aid: events / runs per decoder in the last block
 		std::vector<uint32_t> cnt((size_t)h->n_chan * 5);
 		HIPCHK(hipMemcpy(cnt.data(), h->d_k7cnt, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
 		unsigned long long se = 0, sr = 0; unsigned me = 0, mr = 0;
 		for (uint32_t v : cnt) { se += v & 0xFFFFu; sr += v >> 16; me = std::max(me, v & 0xFFFFu); mr = std::max(mr, v >> 16); }
 		fprintf(stderr, "K7E_STATS decoders %zu: events avg %.1f max %u, runs avg %.1f max %u\n", cnt.size(), (double)se / cnt.size(), me, (double)sr / cnt.size(), mr);
 	}
+#endif
 	const unsigned fresh = total - h->frames_seen;
 	h->frames.clear();
 	if (fresh > (unsigned)h->max_frames) { h->err = "frame ring overflow: call aisgpu_sync_outputs() more often"; h->frames_seen = total; return AISGPU_ERR_OVERFLOW; }
@@ -880,7 +816,6 @@ int gather_frames(aisgpu_t* h) {
 int sync_all(aisgpu_t* h) {
 	{ int rc = enqueue_back(h); if (rc) return rc; }
 	{ int rc = enqueue_fused_back(h); if (rc) return rc; }
-	{ int rc = flush_walk(h); if (rc) return rc; }
 	{ int rc = flush_decode(h); if (rc) return rc; }
 	HIPCHK(hipStreamSynchronize(h->stream));
 	HIPCHK(hipStreamSynchronize(h->s1));
@@ -908,6 +843,17 @@ const char* aisgpu_strerror(int code) {
 	return "unknown error";
 }
 const char* aisgpu_last_error(aisgpu_t* h) { return h ? h->err.c_str() : ""; }
+
+int aisgpu_set_option(const char* key, const char* value) {
+	if (!key || !*key) return AISGPU_ERR_ARG;
+	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "fused", "fft_in_k1", "trace", "k7e_stats" };
+	bool ok = false;
+	for (const char* k : known) ok = ok || strcmp(k, key) == 0;
+	if (!ok) return AISGPU_ERR_ARG;
+	std::lock_guard<std::mutex> l(g_opt_mtx);
+	if (value && *value) g_opt[key] = value; else g_opt.erase(key);
+	return AISGPU_OK;
+}
 
 int aisgpu_device_count(void) {
 	int n = 0;
@@ -1018,16 +964,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->challenger = cfg->model == AISGPU_MODEL_CHALLENGER;
 	h->base = cfg->model == AISGPU_MODEL_BASE || cfg->model == AISGPU_MODEL_STANDARD; // both: FM receiver on the 48 kHz channels
 	h->v2 = cfg->model == AISGPU_MODEL_V2;
-	// front-end geometry (tuning knobs; the defaults are the measured best): workgroup size, output samples per
-	// tile, prefetch depth.  Compiled combinations: "256,256,2", "64,64,1", "64,64,2".
-	h->k1_threads = 64; h->tile96 = 64; h->depth = 0; // autonomous waves, register/DPP ladder (profiles/r01_k1_geometry_sweep.txt)
-	if (const char* e = getenv("AISGPU_K1")) { // "threads,tile96,depth"
-		int a = 0, b = 0, d = 0;
-		if (sscanf(e, "%d,%d,%d", &a, &b, &d) == 3) {
-			const bool ok = (a == 256 && b == 256 && d == 2) || (a == 64 && b == 64 && (d == 0 || d == 1 || d == 2)); // d == 0: register (DPP) ladder
-			if (ok) { h->k1_threads = a; h->tile96 = b; h->depth = d; }
-		}
-	}
+	h->tile96 = 64; // one autonomous wave per workgroup, register/DPP ladder: 64 samples at the kernel's output rate per tile
 	h->in_bytes = cfg->input_format == AISGPU_FMT_CF32 ? 8 : cfg->input_format == AISGPU_FMT_CS16 ? 4 : 2;
 	// kernel numbering of the formats: 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16
 	h->kfmt = cfg->input_format == AISGPU_FMT_CF32 ? 0 : cfg->input_format == AISGPU_FMT_CU8 ? 1 : cfg->input_format == AISGPU_FMT_CS8 ? 2 : 3;
@@ -1035,7 +972,6 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		if (h->kfmt != 1) { delete h; return AISGPU_ERR_ARG; }              // and only ConvertRAW::outCU8 feeds it
 		h->kfmt = 4;
 	}
-	if (h->kfmt > 1 && h->depth != 0) { delete h; return AISGPU_ERR_ARG; } // CS8 / CS16 / fixed point: register (DPP) front end only
 	h->n_pre = ma_m ? cfg->block_len / ma_m : cfg->block_len >> KP;
 	h->ma_m = ma_m;
 	h->us_dsk = by3 && mode == MODE_RESAMPLE;
@@ -1062,7 +998,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		h->tile_in = h->tile96 << K;
 		if (h->n_pre % h->tile_in) { delete h; return AISGPU_ERR_ARG; }
 		h->tiles_per_block = h->n_pre / h->tile_in;
-		h->tiles_per_span = span_tiles(h->tiles_per_block, cfg->n_receivers, h->k1_threads, h->tile96, cfg->tiles_per_span);
+		h->tiles_per_span = span_tiles(h->tiles_per_block, cfg->n_receivers, cfg->tiles_per_span);
 		h->spans = (h->tiles_per_block + h->tiles_per_span - 1) / h->tiles_per_span;
 	}
 	if (KP > 4) h->KPa = KP - 4; // (only the resampled 12288k bucket: five stages in front of the resampler, Model.cpp:166-172)
@@ -1070,7 +1006,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		h->ptile_in = h->tile96 << (h->KPa ? h->KPa : KP);
 		if (cfg->block_len % h->ptile_in) { delete h; return AISGPU_ERR_ARG; }
 		h->ptiles_per_block = cfg->block_len / h->ptile_in;
-		h->ptiles_per_span = span_tiles(h->ptiles_per_block, cfg->n_receivers, h->k1_threads, h->tile96, cfg->tiles_per_span);
+		h->ptiles_per_span = span_tiles(h->ptiles_per_block, cfg->n_receivers, cfg->tiles_per_span);
 		h->pspans = (h->ptiles_per_block + h->ptiles_per_span - 1) / h->ptiles_per_span;
 	}
 	if (mode == MODE_RESAMPLE) h->xh = h->n_pre + XPAD;
@@ -1078,97 +1014,59 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	*out = h; // from here on the caller destroys it on failure
 
 	HIPCHK(hipSetDevice(cfg->device_id));
-	if ((cfg->flags & AISGPU_FLAG_SERIAL) || getenv("AISGPU_SERIAL")) { // profiling aid: no cross-block overlap, every kernel runs alone
+	const std::string k7_opt = opt_str("k7"); // test hook: "seq" = the symbol-by-symbol decoder kernels, "alt" = both implementations take turns
+	if ((cfg->flags & AISGPU_FLAG_SERIAL) || opt_int("serial", 0)) { // profiling aid: no cross-block overlap, every kernel runs alone
 		HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 		h->s1 = h->s2 = h->s3 = h->s4 = h->s5 = h->stream;
 		h->serial = true;
 	} else {
-		// HIP maps streams onto a small number of hardware queues (4 by default, one is the application's
-		// null stream): two of our streams sharing a queue would serialise.  So: three streams.
+		// The chip dispatches from four compute queues at a time, so the pipeline has exactly four busy streams:
+		// front end, phasor recurrence, derotation / FIR, PhaseSearch.
 		//
 		// The CGF phasor recurrence (s3) is a handful of latency-bound waves and the longest dependency chain of the
 		// pipeline; sharing a SIMD with throughput kernels more than doubles its run time (every foreign VALU
 		// instruction delays its next dependent one).  It therefore gets CUs of its own: CU-mask bits 0..7 are one
-		// CU in each of the 8 XCDs (tools/microbench_cumask.hip), 3% of the chip; the other streams use the rest.
+		// CU in each of the 8 XCDs (tools/microbench_cumask.hip), 3% of the chip; the back-end streams use the rest.
+		// The front stream is a plain stream of the LOWEST queue priority: the workgroup dispatcher then prefers the back end's
+		// workgroups whenever a slot frees up (2-3 % per step, profiles/r02_expI.txt .. r02_expK.txt).
 		int n_cu = 0;
 		HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device_id));
-		const char* e = getenv("AISGPU_CUMASK");
-		const int reserve = e ? atoi(e) : 8;
-		if (reserve > 0 && reserve < n_cu && n_cu >= 64) {
+		const int reserve = 8;
+		// Where the frame decoders run.  A fifth active stream shares a pipe with one of the others and their kernels take turns
+		// (0.59 - 0.62 ms per step with ModelDefault's event-driven decoders on a stream of their own, whatever those kernels cost).
+		// So the event-driven decoders share the derotation / FIR stream, a block late (dec_defer): 0.52 ms.  Only the sequential
+		// decoder kernels of the other engines, which run for a whole step, get a stream of their own.
+		const bool evt = k7_opt != "seq" && (h->L + 4) / 5 + 1 <= 8191; // (ModelChallenger's mesh of ten: event-driven for blocks of at most 8191 groups)
+		const bool dec_on_fir_stream = (cfg->model != AISGPU_MODEL_STANDARD && cfg->model != AISGPU_MODEL_CHALLENGER && cfg->model != AISGPU_MODEL_BASE) ||
+		                               (cfg->model == AISGPU_MODEL_CHALLENGER && evt);
+		const bool own_dec_stream = (cfg->flags & AISGPU_FLAG_GPU_DECODE) && !dec_on_fir_stream;
+		bool masked = false;
+		if (n_cu >= 64) {
 			const int words = (n_cu + 31) / 32;
 			std::vector<uint32_t> lat(words, 0u), rest(words, 0u);
 			for (int i = 0; i < n_cu; i++) (i < reserve ? lat : rest)[i / 32] |= 1u << (i % 32);
-			// optional spatial split of the rest (AISGPU_FRONT_CUS=N): the front stream on N CUs of its own, the back-end streams on
-			// the others (mask bit i is CU i / 8 of XCD i % 8, so every slice is spread evenly over the XCDs)
-			std::vector<uint32_t> front = rest, back = rest;
-			if (const char* fc = getenv("AISGPU_FRONT_CUS")) {
-				const int nf = atoi(fc);
-				if (nf > 0 && reserve + nf < n_cu) {
-					front.assign(words, 0u); back.assign(words, 0u);
-					for (int i = reserve; i < n_cu; i++) (i < reserve + nf ? front : back)[i / 32] |= 1u << (i % 32);
-					if (getenv("AISGPU_BACK_ALL")) back = rest; // the back end may also use the front end's CUs
-				}
-			}
+			int least = 0, greatest = 0;
+			const bool prio = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
 			// (a runtime without CU masks falls back to ordinary streams: same results, the recurrence just shares its SIMDs)
-			bool masked = hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)words, front.data()) == hipSuccess;
-			// experiment knob AISGPU_STREAM_PRIO="<front>,<ps>,<fir>": plain streams with HIP queue priorities (-1 high, 0 normal, 1 low)
-			// instead of the CU-masked ones for the front end / PhaseSearch / derotation-FIR streams
-			// Default (round 2, profiles/r02_expI.txt .. r02_expK.txt): the front stream as a plain stream of the LOWEST queue priority
-			// (the workgroup dispatcher then prefers the back end's workgroups whenever a slot frees up; 2-3 % per step), the others
-			// CU-masked as before.  99 = keep the CU-masked stream.
-			int pf = 99, pp = 99, pk = 99;
-			{ int least = 0, greatest = 0; if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) pf = least; }
-			if (const char* pe = getenv("AISGPU_STREAM_PRIO")) sscanf(pe, "%d:%d:%d", &pf, &pp, &pk);
-			if (pf != 99) { hipStreamDestroy(h->stream); h->stream = nullptr; masked = masked && hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, pf) == hipSuccess; }
-			if (pp != 99) masked = masked && hipStreamCreateWithPriority(&h->s1, hipStreamNonBlocking, pp) == hipSuccess;
-			else
-			masked = masked && hipExtStreamCreateWithCUMask(&h->s1, (uint32_t)words, back.data()) == hipSuccess;
+			masked = (prio ? hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, least) : hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)words, rest.data())) == hipSuccess;
+			masked = masked && hipExtStreamCreateWithCUMask(&h->s1, (uint32_t)words, rest.data()) == hipSuccess;
 			masked = masked && hipExtStreamCreateWithCUMask(&h->s3, (uint32_t)words, lat.data()) == hipSuccess;
-			if (pk != 99) masked = masked && hipStreamCreateWithPriority(&h->s4, hipStreamNonBlocking, pk) == hipSuccess;
-			else
-			masked = masked && hipExtStreamCreateWithCUMask(&h->s4, (uint32_t)words, back.data()) == hipSuccess;
-			// Where the frame decoders run (AISGPU_DEC_STREAM).  The chip dispatches from four compute queues at a time: a fifth active
-			// stream shares a pipe with one of the others and their kernels take turns (0.59 - 0.62 ms per step with ModelDefault's
-			// event-driven decoders on a stream of their own, whatever those kernels cost -- even with all three skipped).  So by
-			// default they share the derotation / FIR stream (4), a block late (dec_defer): 0.52 ms.  5 = own stream (the sequential
-			// decoder kernels of the other engines, which run for a whole step), 1 = PhaseSearch's stream.
-			const char* ds = getenv("AISGPU_DEC_STREAM");
-			// (ModelChallenger's mesh of ten likewise, when its event-driven form will run: blocks of at most 8191 groups, no AISGPU_K7=seq)
-			const bool evt = !(getenv("AISGPU_K7") && strcmp(getenv("AISGPU_K7"), "seq") == 0) && (h->L + 4) / 5 + 1 <= 8191;
-			const bool default_kind = (cfg->model != AISGPU_MODEL_STANDARD && cfg->model != AISGPU_MODEL_CHALLENGER && cfg->model != AISGPU_MODEL_BASE) ||
-			                          (cfg->model == AISGPU_MODEL_CHALLENGER && evt);
-			const int dsel = ds ? atoi(ds) : (default_kind ? 4 : 5);
-			if (dsel == 4 || dsel == 1) h->s5 = nullptr;
-			else if (masked && (cfg->flags & AISGPU_FLAG_GPU_DECODE)) {
-				// the event-driven frame decoders are three latency-bound kernels of a few dozen waves (k7e_scan 40, k7e_resolve 43):
-				// AISGPU_DEC_MASK=1 puts them on the reserved CUs, next to the phasor recurrence, instead of among the front end's waves
-				const char* dm = getenv("AISGPU_DEC_MASK");
-				const bool on_lat = dm && atoi(dm) == 1;
-				masked = hipExtStreamCreateWithCUMask(&h->s5, (uint32_t)words, (on_lat ? lat : back).data()) == hipSuccess;
-			}
-			if (!masked) {
-				(void)hipGetLastError();
-				hipStream_t* all[5] = { &h->stream, &h->s1, &h->s3, &h->s4, &h->s5 };
-				for (auto ps : all) { if (*ps) hipStreamDestroy(*ps); *ps = nullptr; }
-				HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-				HIPCHK(hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking));
-				HIPCHK(hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking));
-				HIPCHK(hipStreamCreateWithFlags(&h->s4, hipStreamNonBlocking));
-				if (cfg->flags & AISGPU_FLAG_GPU_DECODE) HIPCHK(hipStreamCreateWithFlags(&h->s5, hipStreamNonBlocking));
-			}
-			if (!h->s5) h->s5 = dsel == 1 ? h->s1 : h->s4; // a fifth stream only for the optional frame decoder: beyond four streams HIP shares hardware
-			                           // queues and kernels of different streams start waiting for each other (0.62 -> 0.69 ms per step)
-		} else {
+			masked = masked && hipExtStreamCreateWithCUMask(&h->s4, (uint32_t)words, rest.data()) == hipSuccess;
+			if (own_dec_stream) masked = masked && hipExtStreamCreateWithCUMask(&h->s5, (uint32_t)words, rest.data()) == hipSuccess;
+		}
+		if (!masked) {
+			(void)hipGetLastError();
+			hipStream_t* all[5] = { &h->stream, &h->s1, &h->s3, &h->s4, &h->s5 };
+			for (auto ps : all) { if (*ps) hipStreamDestroy(*ps); *ps = nullptr; }
 			HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 			HIPCHK(hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking));
 			HIPCHK(hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking));
 			HIPCHK(hipStreamCreateWithFlags(&h->s4, hipStreamNonBlocking));
-			if (cfg->flags & AISGPU_FLAG_GPU_DECODE) HIPCHK(hipStreamCreateWithFlags(&h->s5, hipStreamNonBlocking));
-			else h->s5 = h->s4;
+			if (own_dec_stream) HIPCHK(hipStreamCreateWithFlags(&h->s5, hipStreamNonBlocking));
 		}
+		if (!h->s5) h->s5 = h->s4;
 		h->s2 = h->s1; // apply + FIR + PhaseSearchEMA of a block run back to back on one stream
 		h->dec_defer = h->s5 == h->s4 && h->s4 != h->stream;
-		if (const char* e = getenv("AISGPU_DEC_DEFER")) h->dec_defer = atoi(e) != 0;
 	}
 	for (int i = 0; i < NBUF; i++) {
 		HIPCHK(hipEventCreateWithFlags(&h->ev_front[i], hipEventDisableTiming));
@@ -1180,10 +1078,9 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_sym[i], hipEventDisableTiming));
 	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_k3[i], hipEventDisableTiming));
 	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_k4[i], hipEventDisableTiming));
-	if (const char* e = getenv("AISGPU_DEFER")) h->defer = atoi(e) != 0;
-	if (const char* e = getenv("AISGPU_TRACE")) h->trace = atoi(e) != 0;
-	if (const char* e = getenv("AISGPU_ABLATE")) h->ablate = atoi(e);
-	if (const char* e = getenv("AISGPU_ELIDE_WAITS")) h->elide_waits = atoi(e) != 0;
+#ifdef AISGPU_EXPERIMENTS
+	h->trace = opt_int("trace", 0) != 0; // kernel timeline from HIP events on stderr
+#endif
 
 	// ---- constant tables (host libm, like the reference on this machine)
 	{
@@ -1237,7 +1134,6 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(hipHostMalloc((void**)&h->h_rot[i], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipHostMallocDefault));
 		HIPCHK(hipEventCreateWithFlags(&h->rot_ev[i], hipEventDisableTiming));
 		if (hipHostGetDevicePointer((void**)&h->h_rot_dev[i], h->h_rot[i], 0) != hipSuccess) h->rot_by_kernel = false;
-		if (const char* e = getenv("AISGPU_ROTCOPY")) h->rot_by_kernel = h->rot_by_kernel && atoi(e) == 0;
 	}
 	for (int i = 0; i < 2; i++) {
 		if (mode == MODE_RESAMPLE) {
@@ -1264,7 +1160,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		// decoders of ModelChallenger inherit through the shared TAG: that variant of the mesh kernel does not exist)
 		if (h->dec_kind == 2 && (by3 || ma_m)) { h->err = "AISGPU_FLAG_GPU_DECODE with ModelChallenger: not on the decimate-by-3 ladders / behind the moving-average downsampler"; return AISGPU_ERR_ARG; }
 		HIPCHK(dalloc(&h->d_frames, (size_t)h->max_frames * DEC_FRAME_WORDS));
-		if (const char* e = getenv("AISGPU_K7")) if (h->dec_kind <= 2) { h->k7_event = strcmp(e, "seq") != 0; h->k7_alt = strcmp(e, "alt") == 0; } // "seq": one lane per decoder, symbol by symbol
+		if (!k7_opt.empty() && h->dec_kind <= 2) { h->k7_event = k7_opt != "seq"; h->k7_alt = k7_opt == "alt"; } // "seq": one lane per decoder, symbol by symbol
 		// the event words hold a symbol index in 13 bits: blocks of more than 8191 groups (e.g. the reference's CU8 file block of
 		// 3,145,728 samples at 1536 kSPS) go through the sequential decoder kernel
 		if ((h->L + 4) / 5 + 1 > 8191) h->k7_event = false;
@@ -1282,25 +1178,15 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->ps_box = (cfg->flags & AISGPU_FLAG_PS_BOXCAR) != 0;
 	if (h->ps_box) for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_box[i], (size_t)h->n_chains));
 	// default: the fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); the materialised path serves
-	// the taps and the FM branch, which need those arrays, and stays selectable (AISGPU_FUSED=0)
-	h->fused = !(cfg->flags & AISGPU_FLAG_TAPS) && !h->challenger && !h->base && !h->v2;
-	if (const char* e = getenv("AISGPU_FUSED")) h->fused = h->fused && atoi(e) != 0;
-	h->search_on_front = h->fused; // keeps the stream count at four
-	if (const char* e = getenv("AISGPU_SEARCH0")) h->search_on_front = atoi(e) != 0;
-	if (const char* e = getenv("AISGPU_DEFER_FUSED")) h->defer_fused = atoi(e) != 0;
-	if (const char* e = getenv("AISGPU_ROT_AHEAD")) h->rot_stage_ahead = atoi(e) != 0;
-	if (const char* e = getenv("AISGPU_EXT_LAUNCH")) h->ext_launch = atoi(e) != 0;
-	if (const char* e = getenv("AISGPU_ROT_LEAD")) { const int v = atoi(e); if (v >= 1 && v <= 2) h->rot_lead = v; }
-	if (const char* e = getenv("AISGPU_ROT_WORKER")) h->rot_worker = atoi(e) != 0;
-	if (const char* e = getenv("AISGPU_GL")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0) h->GL = v; }
+	// the taps and the FM branch, which need those arrays, and stays selectable (option "fused" = 0: test hook)
+	h->fused = !(cfg->flags & AISGPU_FLAG_TAPS) && !h->challenger && !h->base && !h->v2 && opt_int("fused", 1) != 0;
 	// The spectral analysis rides at the end of the front-end waves (k1_fft_tail) when every span is a whole number of 512-sample
 	// windows of the 48 kHz channels (16 tiles each) and whole spans make up the block; the automatic span length is rounded up
-	// to such a value, an explicit one (cfg / AISGPU_TPS) is taken as it is.
-	h->fft_in_k1 = h->fused && h->depth == 0 && (mode == MODE_DIRECT || mode == MODE_PRE);
-	if (const char* e = getenv("AISGPU_FFT_K1")) h->fft_in_k1 = h->fft_in_k1 && atoi(e) != 0;
+	// to such a value, an explicit one (cfg.tiles_per_span) is taken as it is.  Option "fft_in_k1" = 0 (test hook): the FFT / search kernels.
+	h->fft_in_k1 = h->fused && (mode == MODE_DIRECT || mode == MODE_PRE) && opt_int("fft_in_k1", 1) != 0;
 	if (h->fft_in_k1) {
 		int t = h->tiles_per_span;
-		if (cfg->tiles_per_span <= 0 && !getenv("AISGPU_TPS")) {
+		if (cfg->tiles_per_span <= 0) {
 			// two windows per channel and span where the block allows it: one warm-up tile per 32 instead of per 16 tiles (3 % less
 			// front-end work); round 1 measured 16 < 32 < 48, round 2 with the non-temporal input stream 32 < 16 < 48 (r02_expJ.txt)
 			t = (h->tiles_per_block % 32 == 0 && h->tiles_per_block >= 64) ? 32 : 16;
@@ -1311,19 +1197,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			h->spans = h->tiles_per_block / t;
 		} else h->fft_in_k1 = false;
 	}
-	// derotation + FIR + PhaseSearchEMA as ONE kernel (the FIR outputs stay in LDS): the default of the fused back end for the
-	// chunk-parallel row search; AISGPU_K46=0 keeps the two-kernel form (which the boxcar / lane / sequential variants use)
-	h->k46 = false; // (measured 0.71 against 0.51 ms per step: its 112 registers find no room next to the front end's waves -- DESIGN.md)
-	if (const char* e = getenv("AISGPU_K46")) h->k46 = h->fused && !h->ps_box && atoi(e) != 0;
-	if (const char* e = getenv("AISGPU_K4")) if (strcmp(e, "lane") == 0) h->k46 = false;
-	if (getenv("AISGPU_PS_SEQUENTIAL")) h->k46 = false;
 	if (h->fused) {
 		const size_t cs = (C + 63) / 64 * 64;
-		if (h->k46) {
-			h->n_quads = (int)((C + 3) / 4);
-			for (int i = 0; i < NBUF; i++) HIPCHK(dalloc(&h->d_ck8[i], (size_t)(h->L / 8) * cs));
-			HIPCHK(dalloc(&h->d_qflag, 2 * (size_t)h->n_quads));
-		}
 		for (int i = 0; i < NBUF; i++) {
 			HIPCHK(dalloc(&h->d_ck[i], (size_t)(h->Gcap / h->GL + 2) * cs));
 			HIPCHK(dalloc(&h->d_ckw[i], (size_t)h->W * cs));
@@ -1356,33 +1231,18 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(hipMemcpy(h->d_rotstate, ones.data(), C * sizeof(float2), hipMemcpyHostToDevice));
 	}
 	const int ps_chunks = (h->Gcap + PS_CHUNK - 1) / PS_CHUNK;
-	if (const char* e = getenv("AISGPU_PS_WARM")) { int v = atoi(e); if (v >= 1 && v <= PS_CHUNK) h->ps_warm = (v + 15) / 16 * 16; } // test hook: small values force the exact fallback
-	if (getenv("AISGPU_PS_SEQUENTIAL")) h->ps_parallel = false;
-	// PhaseSearchEMA variant: "row" (default: 16 lanes per chain and chunk, 91 M wave-instructions per bench step, 10240 waves)
-	// or "lane" (one lane per chain and chunk + a sequential integer walk: 33 M wave-instructions, but only 400 long waves that
-	// get a quarter of the issue slots next to the front end -- measured 0.68 against 0.62 ms per step)
-	if (const char* e = getenv("AISGPU_K4")) h->ps_lane = strcmp(e, "lane") == 0;
-	if (const char* e = getenv("AISGPU_PS_PRIO")) h->ps_prio = atoi(e);
-	if (const char* e = getenv("AISGPU_K4_STREAMS")) h->ps_streams = atoi(e) == 2 ? 2 : 1;
-	if (const char* e = getenv("AISGPU_WALK_PRIO")) h->walk_prio = atoi(e);
-	if (const char* e = getenv("AISGPU_WALK_RIDE")) h->walk_ride = atoi(e) != 0;
-	if (const char* e = getenv("AISGPU_PS_CL")) { int v = atoi(e); if (v >= 128 && v <= 8192) h->ps_cl = (v + 31) / 32 * 32; }
-	const size_t lane_chunks = (size_t)(h->Gcap + h->ps_cl - 1) / h->ps_cl, ma_stride = (C * 5 + 63) / 64 * 64;
-	size_t n_ma = C * 5 * ps_chunks * 16;
-	if (h->ps_lane) {
-		for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_pslw[i], 3 * ma_stride * (size_t)h->Gcap / 2)); // uint2 units: 3 planes x Gcap / 4 rows x ma_stride x 16 B
-		if (lane_chunks * 16 * ma_stride > n_ma) n_ma = lane_chunks * 16 * ma_stride;
-	}
+	{ const int v = opt_int("ps_warm", 0); if (v >= 1 && v <= PS_CHUNK) h->ps_warm = (v + 15) / 16 * 16; } // test hook: small values force the exact fallback
+	if (opt_int("ps_sequential", 0)) h->ps_parallel = false; // test hook: the plain sequential row kernel
+	const size_t n_ma = C * 5 * ps_chunks * 16;
 	HIPCHK(dalloc(&h->d_pswords, C * 5 * ps_chunks * (PS_CHUNK / 32) * 16));
 	HIPCHK(dalloc(&h->d_psma0, n_ma));
 	HIPCHK(dalloc(&h->d_psma1, n_ma));
 	HIPCHK(dalloc(&h->d_psfin, C * 5 * ps_chunks * 16));
 	HIPCHK(dalloc(&h->d_psflag, 4));
-	if (!getenv("AISGPU_PS_GLOBAL_FLAG")) HIPCHK(dalloc(&h->d_qflag4, 2 * (size_t)((C * 5 + 3) / 4)));
+	HIPCHK(dalloc(&h->d_qflag4, 2 * (size_t)((C * 5 + 3) / 4)));
 	if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_firtap, C * (8 + h->L)));
 	if (h->v2) {
 		HIPCHK(hipHostMalloc((void**)&h->h_c48, MAXSUB * C * h->L * sizeof(float2), hipHostMallocDefault));
-		if (const char* e = getenv("AISGPU_V2_ASSIST")) h->v2_assist = atoi(e) != 0; // 0: the front end only, everything else on the host
 		if (h->v2_assist) {
 			HIPCHK(dalloc(&h->d_v2hist, C * V2_HIST));
 			HIPCHK(dalloc(&h->d_v2f, C * 2 * h->W)); HIPCHK(dalloc(&h->d_v2prom, C * 2 * h->W)); HIPCHK(dalloc(&h->d_v2en, C * (h->W + 1)));
@@ -1443,8 +1303,8 @@ void aisgpu_destroy(aisgpu_t* h) {
 	if (h->h_c48) hipHostFree(h->h_c48);
 	hipFree(h->d_v2hist); hipFree(h->d_v2f); hipFree(h->d_v2prom); hipFree(h->d_v2en);
 	if (h->h_v2f) hipHostFree(h->h_v2f); if (h->h_v2prom) hipHostFree(h->h_v2prom); if (h->h_v2en) hipHostFree(h->h_v2en);
-	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); hipFree(h->d_ckw[i]); hipFree(h->d_ck8[i]); }
-	hipFree(h->d_qflag); hipFree(h->d_qflag4);
+	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); hipFree(h->d_ckw[i]); }
+	hipFree(h->d_qflag4);
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
 	hipFree(h->d_box[0]); hipFree(h->d_box[1]);
 	hipFree(h->d_dec); hipFree(h->d_frames); hipFree(h->d_frame_count); hipFree(h->d_fmrows[0]); hipFree(h->d_fmrows[1]); hipFree(h->d_last_lvl[0]); hipFree(h->d_last_lvl[1]);
@@ -1453,7 +1313,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_fmprev[0]); hipFree(h->d_fmprev[1]);
 	hipFree(h->d_cgf); hipFree(h->d_omega); hipFree(h->d_step);
 	hipFree(h->d_rotstate); hipFree(h->d_firtap); hipFree(h->d_ppmtab);
-	hipFree(h->d_pslw[0]); hipFree(h->d_pslw[1]); hipFree(h->d_pswords); hipFree(h->d_psma0); hipFree(h->d_psma1); hipFree(h->d_psfin); hipFree(h->d_psflag);
+	hipFree(h->d_pswords); hipFree(h->d_psma0); hipFree(h->d_psma1); hipFree(h->d_psfin); hipFree(h->d_psflag);
 	for (int i = 0; i < 2; i++) { if (h->h_in[i]) hipHostFree(h->h_in[i]); if (h->ev_h2d[i]) hipEventDestroy(h->ev_h2d[i]); if (h->ev_in_free[i]) hipEventDestroy(h->ev_in_free[i]); }
 	if (h->sc) { hipStreamSynchronize(h->sc); hipStreamDestroy(h->sc); }
 	if (h->h_bits) hipHostFree(h->h_bits);
@@ -1560,26 +1420,26 @@ int aisgpu_run(aisgpu_t* h) {
 		const int hb = (int)(h->in_blocks & 1);
 		const int KP1 = h->KPa ? h->KPa : h->KP; // stages of the (first) pass over the raw input
 		const long long n_mid = (long long)h->cfg.block_len >> KP1;
-		const bool pre_saves = !cu8 && KP1 >= 2 && h->depth == 0; // the register/LDS-DMA kernel saves the tail itself
+		const bool pre_saves = !cu8 && KP1 >= 2; // the LDS-DMA form of the kernel saves the tail itself
 		kp.in = h->cur_in; kp.in_stride = h->cur_in_stride; kp.hist = h->d_hist[hb]; kp.hist_out = pre_saves ? h->d_hist[hb ^ 1] : nullptr; kp.rot = nullptr;
 		kp.c48 = nullptr; kp.c48_stride = 0;
 		kp.tiles_per_block = h->ptiles_per_block; kp.tiles_per_span = h->ptiles_per_span;
 		kp.alpha = 0; kp.beta = 1; kp.has_fdc = 0;
 		kp.pre_out = h->KPa ? h->d_xmid : xcur + h->xh; kp.pre_stride = h->KPa ? n_mid : xstride;
 		int rc = time_begin(); if (rc) return rc;
-		HIPCHK(launch_k1(kp, KP1, h->kfmt, h->tile96, h->depth, h->k1_threads, h->pspans, R, h->stream));
+		HIPCHK(launch_k1(kp, KP1, h->kfmt, h->pspans, R, h->stream));
 		rc = time_end(); if (rc) return rc;
 		if (h->KPa) { // four more stages on the CF32 stream of the first pass (its own tail tile: d_hist2)
 			K1Params kb{};
 			const int tile_b = h->tile96 << 4;
-			const bool b_saves = h->depth == 0;
+			const bool b_saves = true;
 			kb.in = h->d_xmid; kb.in_stride = n_mid; kb.hist = h->d_hist2[hb]; kb.hist_out = b_saves ? h->d_hist2[hb ^ 1] : nullptr; kb.rot = nullptr;
 			kb.c48 = nullptr; kb.c48_stride = 0;
 			kb.tiles_per_block = (int)(n_mid / tile_b);
-			kb.tiles_per_span = span_tiles(kb.tiles_per_block, (int)R, h->k1_threads, h->tile96, h->cfg.tiles_per_span);
+			kb.tiles_per_span = span_tiles(kb.tiles_per_block, (int)R, h->cfg.tiles_per_span);
 			kb.alpha = 0; kb.beta = 1; kb.has_fdc = 0;
 			kb.pre_out = xcur + h->xh; kb.pre_stride = xstride;
-			HIPCHK(launch_k1(kb, 4, 0, h->tile96, h->depth, h->k1_threads, (kb.tiles_per_block + kb.tiles_per_span - 1) / kb.tiles_per_span, R, h->stream));
+			HIPCHK(launch_k1(kb, 4, 0, (kb.tiles_per_block + kb.tiles_per_span - 1) / kb.tiles_per_span, R, h->stream));
 			if (!b_saves) HIPCHK(launch_k1_tail(h->d_xmid, n_mid * 8, n_mid * 8, h->d_hist2[hb ^ 1], tile_b * 8, R, h->stream));
 		}
 		if (!pre_saves) HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist[hb ^ 1],
@@ -1632,22 +1492,10 @@ int aisgpu_run(aisgpu_t* h) {
 		// (only blocks when the host runs more than one block ahead of the device)
 		// The Rotate phasor table of this block: staged one block AHEAD on s3 (below), so that neither the 10 us copy nor its launch
 		// gap sits between two kernels of the front stream; only the first block (and the single-stream mode) stages it here.
-		const auto stage_rot = [&](int b, hipStream_t st) -> int {
-			if (h->rot_worker) return stage_rot_from_worker(h, b, st); // table generated ahead by the worker thread
-			// the pinned buffer `b` was last used two blocks ago; wait until that upload has been consumed (only blocks when the
-			// host runs more than one block ahead of the device)
-			if (h->rot_ev_used[b]) HIPCHK(hipEventSynchronize(h->rot_ev[b]));
-			gen_rot_table(h, h->h_rot[b]);
-			// a small kernel pulls the table out of the pinned host buffer (a copy-engine transfer costs its set-up latency)
-			if (h->rot_by_kernel) HIPCHK(launch_copy_rows(h->h_rot_dev[b], 0, h->d_rot[b], 0, ROT_HIST + h->n96, 1, st));
-			else HIPCHK(hipMemcpyAsync(h->d_rot[b], h->h_rot[b], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, st));
-			HIPCHK(hipEventRecord(h->rot_ev[b], st));
-			h->rot_ev_used[b] = true;
-			return AISGPU_OK;
-		};
+		const auto stage_rot = [&](int b, hipStream_t st) -> int { return stage_rot_from_worker(h, b, st); }; // table generated ahead by the worker thread
 		const int rb = (int)(h->block_idx & 3); // ring slot of this block's table
 		if (h->rot_next <= h->block_idx) { int rc = stage_rot(rb, h->stream); if (rc) return rc; h->rot_next = h->block_idx + 1; }
-		else WAITEV(h->stream, h->rot_worker ? h->rw.ev[h->rot_slot[rb]] : h->rot_ev[rb]);
+		else WAITEV(h->stream, h->rw.ev[h->rot_slot[rb]]);
 		// c48/fz/ppm[q] were last read by K2b/K2c of block f-NBUF
 		WAITEV(h->stream, h->ev_c48free[q]);
 		K1Params k1{};
@@ -1655,7 +1503,7 @@ int aisgpu_run(aisgpu_t* h) {
 		k1.in = from_pre ? (const void*)xcur : h->cur_in;
 		k1.in_stride = from_pre ? xstride : h->cur_in_stride;
 		const int hb = (int)(h->in_blocks & 1);
-		const bool saves = (from_pre || !cu8) && h->K >= 2 && h->depth == 0; // the register/LDS-DMA kernel saves the tail itself
+		const bool saves = (from_pre || !cu8) && h->K >= 2; // the LDS-DMA form of the kernel saves the tail itself
 		k1.hist = from_pre ? h->d_hist2[hb] : h->d_hist[hb];
 		k1.hist_out = !saves ? nullptr : from_pre ? h->d_hist2[hb ^ 1] : h->d_hist[hb ^ 1];
 		k1.rot = h->d_rot[rb];
@@ -1669,7 +1517,7 @@ int aisgpu_run(aisgpu_t* h) {
 		}
 		// the launch's events ride on its dispatch packet where they can: "front end of block f done" (what s3 waits for) and,
 		// while the launch is being timed, its two time stamps
-		const bool bound = h->ext_launch && !from_pre && h->fft_in_k1 && h->fused && h->depth == 0 && !h->serial && !(h->ablate & 8) && !h->trace;
+		const bool bound = !from_pre && h->fft_in_k1 && h->fused && !h->serial && !h->trace;
 		h->k1_done[q] = nullptr;
 		if (bound) {
 			hipEvent_t e0 = nullptr, e1 = h->ev_search[q];
@@ -1679,23 +1527,23 @@ int aisgpu_run(aisgpu_t* h) {
 				e0 = ev.a; e1 = ev.b;
 				h->ev_busy.push_back(ev);
 			}
-			HIPCHK(launch_k1(k1, h->K, h->kfmt, h->tile96, h->depth, h->k1_threads, h->spans, R, h->stream, e0, e1));
+			HIPCHK(launch_k1(k1, h->K, h->kfmt, h->spans, R, h->stream, e0, e1));
 			h->k1_done[q] = e1;
 		} else {
 		if (!from_pre) { int rc = time_begin(); if (rc) return rc; }
-		if (!(h->ablate & 8)) { TraceScope t(h, "front", h->stream); HIPCHK(launch_k1(k1, h->K, from_pre ? 0 : h->kfmt, h->tile96, h->depth, h->k1_threads, h->spans, R, h->stream)); }
+		{ TraceScope t(h, "front", h->stream); HIPCHK(launch_k1(k1, h->K, from_pre ? 0 : h->kfmt, h->spans, R, h->stream)); }
 		if (!from_pre) { int rc = time_end(); if (rc) return rc; }
 		}
 		if (saves) {}
 		else if (from_pre) HIPCHK(launch_k1_tail(xcur, xstride * 8, (long long)h->n_pre * 8, h->d_hist2[hb ^ 1], h->tile_in * 8, R, h->stream));
 		else HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist[hb ^ 1],
 		                           h->tile_in * h->in_bytes, R, h->stream));
-		if (!h->serial && h->fused && h->rot_stage_ahead) {
-			// The tables of the next blocks, on s3 in front of this block's phasor recurrence -- TWO blocks ahead (AISGPU_ROT_LEAD): on s3
+		if (!h->serial && h->fused) {
+			// The tables of the next blocks, on s3 in front of this block's phasor recurrence -- TWO blocks ahead: on s3
 			// the copy runs when the recurrence of block f-1 is through, and with a lead of one the front end of block f+1 had to
 			// wait for exactly that -- a loop front end(f-1) -> recurrence(f-1) -> table(f+1) -> front end(f+1) that held the step at
 			// (front end + recurrence + copy) / 2 = 0.47 ms.  d_rot[(f+2) & 3] was last read by the front end of block f-2.
-			while (h->rot_next <= h->block_idx + h->rot_lead) {
+			while (h->rot_next <= h->block_idx + 2) {
 				int rc = stage_rot((int)(h->rot_next & 3), h->s3);
 				if (rc) return rc;
 				h->rot_next++;
@@ -1761,8 +1609,11 @@ int aisgpu_run(aisgpu_t* h) {
 		HIPCHK(hipEventRecord(h->ev_in_free[in_p], h->stream));
 		h->in_used[in_p] = true;
 	}
-	h->in_blocks++;
-	h->submitted = false;
+	{ // (a receiver evicted by its batch may still be inside aisgpu_submit: its bookkeeping reads these under the same lock)
+		std::lock_guard<std::mutex> l(h->submit_mtx);
+		h->in_blocks++;
+		h->submitted = false;
+	}
 	return AISGPU_OK;
 }
 
@@ -1779,7 +1630,6 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 	const size_t C = h->n_chan;
 	{ int rc = enqueue_back(h); if (rc) return rc; }
 	{ int rc = enqueue_fused_back(h); if (rc) return rc; }
-	{ int rc = flush_walk(h); if (rc) return rc; }
 	{ int rc = flush_decode(h); if (rc) return rc; }
 	for (int s = 0; s < h->n_sub; s++) {
 		const SubOut& so = h->sub[s];

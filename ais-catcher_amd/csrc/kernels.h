@@ -142,40 +142,13 @@ struct K4Params {
 	unsigned* fin;     // [16] low 4 bits: final max_idx per start index; bits 4..7: last four decisions of hypothesis k
 	int* flag;         // != 0: a speculative warm-up did not reproduce the sequential EMA -> exact fallback runs
 	int n_chains, n_groups, n_chunks, warm;
-	int streams = 1;   // 2: k4_phase_chunks2 (two channel quads per wave)
-	// lane-per-chunk variant (k4_lane_chunks + k4_walk): sign words per symbol, EMA snapshots laid out [chunk][k][ma_stride]
-	uint2* lw;                               // three planes (up, dn, x) of uint4 [lw_quads][ma_stride]: four consecutive symbols of a chain
-	int prio_walk;
-	int lw_quads, prio;                      // rows per plane (>= ceil(groups / 4)); s_setprio level of k4_lane_chunks
-	long long ma_stride;                     // n_chains rounded up to 64 (also the row length of ma_start / ma_fin in this variant)
-	int cl, n_lchunks;                       // chunk length (multiple of 32), chunks
+	int chunked = 1;   // boxcar variant: 0 = the sequential row kernel (one-chunk blocks), 1 = k4_box_chunks
 	// boxcar variant (k4_phase_search_box)
 	const PsBoxState* box_in; PsBoxState* box_out; long long first_group;
 	int* qflag = nullptr;                    // != nullptr: one flag per qflag_div chains instead of the batch-global *flag, so that the
-	int qflag_div = 4;                       // exact fallback re-runs only those (4: the chains of one k4_phase_search workgroup; 20: one channel quad of K46)
+	int qflag_div = 4;                       // exact fallback re-runs only those (4: the chains of one k4_phase_search workgroup)
 	int* fb_count = nullptr;                 // statistics: workgroups of the exact fallback that really ran (aisgpu_ps_fallbacks)
 };
-
-// K46: derotation + FilterComplex(Coherent) + ScatterPLL + PhaseSearchEMA in ONE kernel (k46_fir_phase_chunks): the FIR outputs
-// ("sym", 8 bytes per symbol and chain) never exist in HBM.  A workgroup = 5 waves = the five sampling phases of 4 adjacent
-// channels for one time chunk; per super-batch of 64 symbols it derotates the 352 samples it needs into LDS (shared by the
-// five waves), every wave filters its own phase out of them, and the PhaseSearch steps read their symbols from LDS as before.
-constexpr int K46_NB8 = 44;           // 8-sample blocks derotated per super-batch and channel (16 + 5 * 64 samples, 8-aligned, + tail)
-constexpr int K46_YPITCH = 8 * K46_NB8 + 2; // row pitch of the derotated-sample tile (float2): rows start in different banks
-struct K46Params {
-	K4Params k4;                                  // state, scratch of the chunk-parallel search, bits, chunk geometry
-	const float2* c48; long long c48_stride;
-	const float2* ck8; long long ck_stride;       // [L / 8][ck_stride]: CGF phasor BEFORE sample 8 t (renormalised at window starts)
-	const float2* step_table; const int* fz;      // fz[chan][n_windows]
-	const float2* hist_in; float2* hist_out;      // [n_chan][DF_HIST] last derotated samples of the previous / of this block
-	float* lvl; long long lvl_stride;             // [n_chan][lvl_stride]
-	float taps[17];
-	long long first_group;
-	int n_rel0, L, n_windows, n_chan;
-	int sequential;                               // exact fallback: one chunk = the whole block, runs only where k4.qflag[quad] is set
-};
-hipError_t launch_k46(const K46Params& p, hipStream_t s);
-hipError_t launch_k2b_ck8(const K2Params& p, float2* ck8, int n_chan, hipStream_t s); // phasor recurrence, state kept every 8 samples
 
 // K7: AIS::Decoder on the device (frame decoder).  One lane per decoder, 12 meshes of 5 decoders per wave.
 constexpr int DEC_DATA_WORDS = 36;  // MAX_AIS_FRAME_LENGTH = 1064 + 16 + 7 bits -> 136 bytes
@@ -225,9 +198,8 @@ struct K7eParams {
 hipError_t launch_k7e(const K7eParams& p, hipStream_t s);
 
 // fmt (kernel numbering): 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16, 4 = CU8 through the fixed-point ladder (K = 4)
-// ev_start / ev_stop (register variant, depth 0): events bound to the dispatch itself (no barrier packets): time stamps, and "this launch is done" for other streams
-hipError_t launch_k1(const K1Params& p, int K, int fmt, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s, hipEvent_t ev_start = nullptr,
-                     hipEvent_t ev_stop = nullptr);
+// ev_start / ev_stop: events bound to the dispatch itself (no barrier packets): time stamps, and "this launch is done" for other streams
+hipError_t launch_k1(const K1Params& p, int K, int fmt, int spans, int n_rx, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t launch_k1u(const K1uParams& p, int npost, int n_rx, hipStream_t s); // npost: CIC5 stages behind the resampler (2, 1; 0 = 96 kSPS input, no resampler)
 hipError_t launch_copy_rows(const float2* src, long long src_stride, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
 hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long block_bytes, void* hist, int tail_bytes,
@@ -282,10 +254,6 @@ struct KV2Params {
 };
 hipError_t launch_kv2(const KV2Params& p, hipStream_t s);
 hipError_t launch_k4(const K4Params& p, hipStream_t s);          // chunk-parallel + assemble + (conditional) exact fallback
-// one lane per (chain, chunk): sign words + verification; the (conditional) exact fallback; the sequential integer walk
-hipError_t launch_k4_lane_words(const K4Params& p, const K4Params* walk_prev, hipStream_t s); // walk_prev: the previous block's walk rides along
-hipError_t launch_k4_fallback(const K4Params& p, hipStream_t s);
-hipError_t launch_k4_walk(const K4Params& p, hipStream_t s);
 hipError_t launch_k4_sequential(const K4Params& p, hipStream_t s); // the plain sequential kernel only
 hipError_t launch_k4_box(const K4Params& p, hipStream_t s);        // Demod::PhaseSearch (boxcar history), sequential
 

@@ -54,60 +54,6 @@ __device__ __forceinline__ void cic5_dec_chunk(float2 (&v)[2 * NOUT + 4], float2
 	}
 }
 
-// ------------------------------------------------------------------------------------------
-// K1: front end.  RAW -> [CU8 convert] -> K x Downsample2CIC5 -> FDC -> Rotate -> 2 x (DS2 + FilterCIC5)
-//
-// One workgroup (256 threads) streams a span of consecutive tiles of one receiver.  A tile is P
-// samples at 96 kHz (= P << K input samples); every stage keeps the few samples of history it
-// needs in LDS between tiles, so nothing is recomputed inside a span.  A span starts with one
-// warm-up tile whose outputs are discarded: every stage is feed-forward with a dependency cone of
-// < 348 input samples plus 8 samples of carried history per stage (< 1024 inputs in
-// total), so after one tile all carried histories are exact.
-// Global loads are fully coalesced 16 B / lane and are issued one tile ahead into registers
-// (async-stage split), so HBM latency overlaps the LDS ladder of the current tile.
-//
-// LDS "levels": level s holds the n_s = TILE_IN >> s samples that enter CIC stage s+1.
-//   * chunked levels (n_s / 256 = C in {16, 8, 4} samples per thread): thread t owns row t of C samples;
-//     rows are padded by one 16-byte slot (row strides 144 / 80 / 48 B) so the per-thread 16-byte LDS
-//     reads of a lane group cover all banks; the last 8 samples of the previous tile live in a
-//     separate 8-entry history array (row -1).
-//   * small levels (n_s <= 512): contiguous, 8 leading history slots, thread t produces output t.
-// ------------------------------------------------------------------------------------------
-constexpr int R16 = 18, R8 = 10, R4 = 6; // padded row lengths (float2) for chunk sizes 16, 8, 4
-
-// NT = threads per workgroup.  NT = 64 makes every WAVE an autonomous stream processor: all levels are
-// wave-private, __syncthreads() degenerates to a wait for the wave's own LDS operations, and nothing ever
-// waits for another wave.
-template <int K, int P, int NT>
-struct K1Cfg {
-	static constexpr int TILE_IN = P << K;
-	static constexpr int CE = TILE_IN / NT; // samples per thread of the entry level
-	static_assert(TILE_IN % NT == 0 || TILE_IN < NT, "tile");
-	static constexpr bool has16 = CE >= 16, has8 = CE >= 8, has4 = CE >= 4;
-	static_assert(CE <= 16, "tile too large for the LDS layout");
-	static constexpr int nbig = (has16 ? 1 : 0) + (has8 ? 1 : 0) + (has4 ? 1 : 0);
-	static constexpr int first_small = nbig; // first level stored contiguously
-	static constexpr int n(int s) { return TILE_IN >> s; }
-	// offsets in float2 units
-	static constexpr int off16 = 0;
-	static constexpr int size16 = has16 ? NT * R16 : 0;
-	static constexpr int off8 = off16 + size16;
-	static constexpr int size8 = has8 ? NT * R8 : 0;
-	static constexpr int size4 = (has4 && !has16) ? NT * R4 : 0; // aliases the dead 16-level otherwise
-	static constexpr int off4 = has16 ? off16 : off8 + size8;
-	static constexpr int off_small0 = off8 + size8 + size4;
-	static constexpr int small_off(int s) { // levels first_small .. K (level K = 96 kHz)
-		int o = off_small0;
-		for (int q = first_small; q < s; q++) o += 8 + n(q);
-		return o;
-	}
-	static constexpr int off_x5 = small_off(K + 1);           // 2 x (8 + P): rotated up / down
-	static constexpr int off_x6 = off_x5 + 2 * (8 + P);       // 2 x (8 + P/2): FilterCIC5 input
-	static constexpr int off_h = off_x6 + 2 * (8 + P / 2);    // 3 x 8: histories of the chunked levels
-	static constexpr int total = off_h + 24;
-	static constexpr int bytes = total * 8;
-};
-
 // LDS is addressed in 16-byte units (float4 = two complex samples) wherever a thread moves more than one
 // sample, so that every such access is a single ds_read_b128 / ds_write_b128 (the padded row strides are
 // only conflict free for the 128-bit lane grouping).
@@ -145,256 +91,6 @@ __device__ __forceinline__ float2 cic5_small(const float4* lvl4, int t) {
 	float2 o[1];
 	cic5_dec_chunk<1>(v, o);
 	return o[0];
-}
-
-// D = prefetch depth in tiles: D * TILE bytes per workgroup are in flight, which is what covers the HBM
-// latency (measured: with one tile in flight the kernel is latency bound at ~50 % of peak).
-// PRE = true: stop after the K CIC5 stages and write that level to p.pre_out (the pre-decimation pass of the
-// ladders that are deeper than four stages or contain the fractional resampler, Model.cpp:157-221).
-template <int K, int P, int D, int NT, bool CU8, bool PRE>
-__global__ __launch_bounds__(NT) void k1_frontend(K1Params p) {
-	using C = K1Cfg<K, P, NT>;
-	static_assert(K >= 1 && K <= 4, "ladder depth");
-	// Other kernels of the pipeline run concurrently on other streams; the bandwidth-bound front end gets a
-	// higher issue priority than the throughput kernels behind it (only the tiny phasor kernel is higher).
-	__builtin_amdgcn_s_setprio(2);
-	extern __shared__ __attribute__((aligned(16))) float4 smem4[];
-	float2* const sm = reinterpret_cast<float2*>(smem4);
-	float4* const l16 = smem4 + C::off16 / 2; // rows of R16/2 = 9 float4
-	float4* const l8 = smem4 + C::off8 / 2;   // rows of R8/2 = 5 float4
-	float4* const l4 = smem4 + C::off4 / 2;   // rows of R4/2 = 3 float4
-	float4* const h16 = smem4 + C::off_h / 2; // 4 float4 = last 8 samples
-	float4* const h8 = h16 + 4;
-	float4* const h4 = h16 + 8;
-	constexpr int W16 = R16 / 2, W8 = R8 / 2, W4 = R4 / 2;
-
-	const int t = threadIdx.x;
-	const int rx = blockIdx.y;
-	const int span = blockIdx.x;
-	constexpr int TILE_IN = C::TILE_IN;
-
-	// zero all carried histories (true zero state at stream start; the warm-up tile overwrites them otherwise)
-	if (t < 8) {
-		sm[C::off_h + t] = sm[C::off_h + 8 + t] = sm[C::off_h + 16 + t] = make_float2(0.f, 0.f);
-#pragma unroll
-		for (int s = C::first_small; s <= K; s++) sm[C::small_off(s) + t] = make_float2(0.f, 0.f);
-		sm[C::off_x5 + t] = sm[C::off_x5 + 8 + P + t] = make_float2(0.f, 0.f);
-		sm[C::off_x6 + t] = sm[C::off_x6 + 8 + P / 2 + t] = make_float2(0.f, 0.f);
-	}
-
-	const int tile_first = span * p.tiles_per_span - 1; // warm-up tile
-	int tile_last = tile_first + p.tiles_per_span;        // inclusive
-	if (tile_last >= p.tiles_per_block) tile_last = p.tiles_per_block - 1;
-
-	// ---- register prefetch: 16 bytes per thread per slot, coalesced; D tiles deep
-	constexpr int TILE_BYTES = TILE_IN * (CU8 ? 2 : 8);
-	constexpr int NV = TILE_BYTES >= NT * 16 ? TILE_BYTES / (NT * 16) : 1;
-	constexpr bool PARTIAL = TILE_BYTES < NT * 16; // not every thread has a 16-byte piece
-	uint4 pre[D][NV];
-	auto prefetch = [&](uint4 (&r)[NV], int tile) {
-		// tile -1 lives in the history buffer (last TILE_IN samples of the previous block)
-		const unsigned char* base;
-		if (tile < 0) base = (const unsigned char*)p.hist + (size_t)rx * TILE_BYTES;
-		else base = (const unsigned char*)p.in + ((size_t)rx * p.in_stride + (size_t)tile * TILE_IN) * (CU8 ? 2 : 8);
-		const uint4* src = (const uint4*)base;
-#pragma unroll
-		for (int e = 0; e < NV; e++) {
-			if (PARTIAL) r[e] = (t * 16 < TILE_BYTES) ? src[t] : make_uint4(0, 0, 0, 0);
-			else r[e] = src[e * NT + t];
-		}
-	};
-	auto store_sample_pair = [&](int s, float4 v) { // s: even sample index inside the tile -> entry level
-		if (C::CE == 16) l16[(s >> 4) * W16 + ((s & 15) >> 1)] = v;
-		else if (C::CE == 8) l8[(s >> 3) * W8 + ((s & 7) >> 1)] = v;
-		else if (C::CE == 4) l4[(s >> 2) * W4 + ((s & 3) >> 1)] = v;
-		else smem4[C::small_off(0) / 2 + 4 + (s >> 1)] = v;
-	};
-	auto stage_in = [&](uint4 (&r)[NV]) {
-		if (!CU8) {
-#pragma unroll
-			for (int e = 0; e < NV; e++) {
-				const int s = (e * NT + t) * 2;
-				if (PARTIAL && s >= TILE_IN) continue;
-				store_sample_pair(s, make_float4(__uint_as_float(r[e].x), __uint_as_float(r[e].y), __uint_as_float(r[e].z), __uint_as_float(r[e].w)));
-			}
-		} else {
-#pragma unroll
-			for (int e = 0; e < NV; e++) {
-				const int s = (e * NT + t) * 8; // 16 bytes = 8 CU8 samples
-				if (PARTIAL && s >= TILE_IN) continue;
-				const unsigned w[4] = { r[e].x, r[e].y, r[e].z, r[e].w };
-#pragma unroll
-				for (int q = 0; q < 4; q++) { // Utilities/Convert.cpp:255-264: ((int)u - 128) / 128.0f (exact)
-					float4 v;
-					v.x = (float)((int)(w[q] & 255u) - 128) * 0.0078125f;
-					v.y = (float)((int)((w[q] >> 8) & 255u) - 128) * 0.0078125f;
-					v.z = (float)((int)((w[q] >> 16) & 255u) - 128) * 0.0078125f;
-					v.w = (float)((int)(w[q] >> 24) - 128) * 0.0078125f;
-					store_sample_pair(s + 2 * q, v);
-				}
-			}
-		}
-	};
-
-	auto process_tile = [&](int tile, uint4 (&regs)[NV]) {
-		__syncthreads(); // previous tile fully consumed (aliased level, x6 reads, tail copies)
-		stage_in(regs);
-		__syncthreads();
-		// The Rotate phasor of this tile is fetched BEFORE the prefetch is issued: vector-memory loads retire
-		// in order, so a load issued after the prefetch would force `s_waitcnt vmcnt(0)` at its use in the
-		// middle of the ladder and drain the prefetch there (that was 65 % of the kernel's wave time).
-		// (unconditional for the same reason: no control flow between the loads and their waits)
-		float2 rotv = make_float2(1.0f, 0.0f);
-		if (!PRE) rotv = p.rot[(size_t)ROT_HIST + (long long)tile * P + (t & (P - 1))]; // ROT_HIST leading entries: previous block's tail
-		// unconditional (clamped past the end of the span) so that the number of loads in flight is static and
-		// the compiler can wait for the phasor alone (`vmcnt(NV)`) instead of draining everything
-		prefetch(regs, tile + D <= tile_last ? tile + D : tile_last);
-
-		// ---- chunk 16 -> 8: thread owns x[16t..16t+15], needs x[16t-5..16t+14], makes 8 outputs
-		if (C::has16) {
-			float2 v[20];
-			const float4* own = l16 + t * W16;
-			const float4* halo = (t == 0) ? h16 + 1 : l16 + (t - 1) * W16 + 5; // samples 16t-6 .. 16t-1
-			float4 hv[3], ov[8];
-			lds4_batch<3>(halo, hv);
-			lds4_batch<8>(own, ov);
-			v[0] = hi(hv[0]);
-			v[1] = lo(hv[1]); v[2] = hi(hv[1]);
-			v[3] = lo(hv[2]); v[4] = hi(hv[2]);
-#pragma unroll
-			for (int e = 0; e < 7; e++) { v[5 + 2 * e] = lo(ov[e]); v[6 + 2 * e] = hi(ov[e]); }
-			v[19] = lo(ov[7]);
-			float2 o[8];
-			cic5_dec_chunk<8>(v, o);
-			float4* dst = l8 + t * W8;
-#pragma unroll
-			for (int e = 0; e < 4; e++) dst[e] = pack(o[2 * e], o[2 * e + 1]);
-			__syncthreads();
-			if (t == NT - 1) { // tail for the next tile (this level's body is dead from here on)
-#pragma unroll
-				for (int e = 0; e < 4; e++) h16[e] = ov[4 + e];
-			}
-		}
-		// ---- chunk 8 -> 4: thread owns x[8t..8t+7], needs x[8t-5..8t+6], makes 4 outputs
-		if (C::has8) {
-			float2 v[12];
-			const float4* own = l8 + t * W8;
-			const float4* halo = (t == 0) ? h8 + 1 : l8 + (t - 1) * W8 + 1; // samples 8t-6 .. 8t-1
-			float4 hv[3], ov[4];
-			lds4_batch<3>(halo, hv);
-			lds4_batch<4>(own, ov);
-			v[0] = hi(hv[0]);
-			v[1] = lo(hv[1]); v[2] = hi(hv[1]);
-			v[3] = lo(hv[2]); v[4] = hi(hv[2]);
-#pragma unroll
-			for (int e = 0; e < 3; e++) { v[5 + 2 * e] = lo(ov[e]); v[6 + 2 * e] = hi(ov[e]); }
-			v[11] = lo(ov[3]);
-			float2 o[4];
-			cic5_dec_chunk<4>(v, o);
-			float4* dst = l4 + t * W4;
-			dst[0] = pack(o[0], o[1]);
-			dst[1] = pack(o[2], o[3]);
-			__syncthreads();
-			if (t == NT - 1) {
-#pragma unroll
-				for (int e = 0; e < 4; e++) h8[e] = ov[e];
-			}
-		}
-		// ---- chunk 4 -> contiguous: thread owns x[4t..4t+3], needs x[4t-5..4t+2], makes 2 outputs
-		if (C::has4) {
-			float2 v[8];
-			const float4* a = (t >= 2) ? l4 + (t - 2) * W4 + 1 : h4 + 1 + 2 * t; // samples 4t-6, 4t-5
-			const float4* b = (t >= 1) ? l4 + (t - 1) * W4 : h4 + 2;             // samples 4t-4 .. 4t-1
-			const float4* own = l4 + t * W4;
-			const float4 av = lds4(a), b0 = lds4(b), b1 = lds4(b + 1), o0 = lds4(own), o1 = lds4(own + 1);
-			v[0] = hi(av);
-			v[1] = lo(b0); v[2] = hi(b0);
-			v[3] = lo(b1); v[4] = hi(b1);
-			v[5] = lo(o0); v[6] = hi(o0);
-			v[7] = lo(o1);
-			float2 o[2];
-			cic5_dec_chunk<2>(v, o);
-			smem4[C::small_off(C::first_small) / 2 + 4 + t] = pack(o[0], o[1]);
-			__syncthreads();
-			if (t == NT - 1) { h4[0] = b0; h4[1] = b1; h4[2] = o0; h4[3] = o1; } // last 8 samples of this level
-		}
-		// ---- remaining stages on contiguous levels: thread t < n/2 makes output t from in[2t-5..2t]
-#pragma unroll
-		for (int s = C::first_small; s < K; s++) {
-			if (t < C::n(s + 1)) sm[C::small_off(s + 1) + 8 + t] = cic5_small(smem4 + C::small_off(s) / 2, t);
-			__syncthreads();
-		}
-		float2* const x4 = sm + C::small_off(K);
-		float2* const x5 = sm + C::off_x5;
-		float2* const x6 = sm + C::off_x6;
-		if (PRE) {
-			if (t < P && tile > tile_first) p.pre_out[(size_t)rx * p.pre_stride + (size_t)tile * P + t] = x4[8 + t];
-			__syncthreads();
-		}
-		// ---- FDC (DSP.cpp:283-293) + Rotate (DSP.cpp:296-316) at 96 kHz
-		if (!PRE && t < P) {
-			const float2 xm2 = x4[8 + t - 2], xm1 = x4[8 + t - 1], x = x4[8 + t];
-			float2 y = x;
-			if (p.has_fdc) {
-				// alpha * (h1 + x) + h2 * beta, evaluated componentwise: add, mul, mul, add
-				const float2 s2 = cadd(xm2, x);
-				y = make_float2(p.alpha * s2.x + xm1.x * p.beta, p.alpha * s2.y + xm1.y * p.beta);
-			}
-			const float2 rot = rotv;
-			const float RR = y.x * rot.x, II = y.y * rot.y, RI = y.x * rot.y, IR = y.y * rot.x;
-			x5[8 + t] = make_float2(RR - II, IR + RI);         // up   -> channel A
-			x5[8 + P + 8 + t] = make_float2(RR + II, IR - RI); // down -> channel B
-		}
-		__syncthreads();
-		// ---- DS2_a / DS2_b (96k -> 48k): first half of the active threads channel A, second half channel B
-		if (!PRE && t < P) {
-			const int ch = t / (P / 2), j = t % (P / 2);
-			x6[ch * (8 + P / 2) + 8 + j] = cic5_small(smem4 + (C::off_x5 + ch * (8 + P)) / 2, j);
-		}
-		__syncthreads();
-		// ---- FilterCIC5 (DSP.cpp:132-157): same binomial filter, no decimation -> 48 kHz output
-		if (!PRE && t < P) {
-			const int ch = t / (P / 2), j = t % (P / 2);
-			const float2* src = x6 + ch * (8 + P / 2) + 8 + j - 5;
-			float2 v[6];
-#pragma unroll
-			for (int e = 0; e < 6; e++) v[e] = src[e];
-#pragma unroll
-			for (int lvl = 0; lvl < 5; lvl++) {
-#pragma unroll
-				for (int i = 0; i < 5 - lvl; i++) v[i] = cadd(v[i + 1], v[i]);
-			}
-			if (tile > tile_first) {
-				float2* dst = p.c48 + ((size_t)rx * 2 + ch) * p.c48_stride + (size_t)tile * (P / 2) + j;
-				*dst = make_float2(v[0].x * 0.03125f, v[0].y * 0.03125f);
-			}
-		}
-		__syncthreads();
-		// ---- carry the tails of the contiguous levels to their leading history slots
-		{
-			constexpr int NSMALL = K - C::first_small + 1;
-			const int grp = t >> 3, e = t & 7;
-			if (grp < NSMALL) {
-				const int s = C::first_small + grp;
-				int off = C::off_small0;
-				for (int q = C::first_small; q < s; q++) off += 8 + (C::TILE_IN >> q);
-				const int cnt = C::TILE_IN >> s;
-				sm[off + e] = sm[off + cnt + e];
-			} else if (grp == NSMALL) x5[e] = x5[P + e];
-			else if (grp == NSMALL + 1) x5[8 + P + e] = x5[8 + P + P + e];
-			else if (grp == NSMALL + 2) x6[e] = x6[P / 2 + e];
-			else if (grp == NSMALL + 3) x6[8 + P / 2 + e] = x6[8 + P / 2 + P / 2 + e];
-		}
-	};
-
-#pragma unroll
-	for (int d = 0; d < D; d++)
-		if (tile_first + d <= tile_last) prefetch(pre[d], tile_first + d);
-	for (int tile = tile_first; tile <= tile_last; tile += D) {
-#pragma unroll
-		for (int d = 0; d < D; d++)
-			if (tile + d <= tile_last) process_tile(tile + d, pre[d]);
-	}
 }
 
 // ------------------------------------------------------------------------------------------
@@ -579,11 +275,6 @@ __device__ __forceinline__ void wave_sync() {
 #ifndef K1_WAVES
 #define K1_WAVES 3
 #endif
-// three front-end workgroups per SIMD by register allocation (see the kernel): the default since the spectral analysis rides in
-// this kernel, 1-2 % per step (profiles/r01_v10_experiments.txt); -DK1_NOCAP / -DK1_CAP2 for the experiments
-#if !defined(K1_CAP3) && !defined(K1_CAP2) && !defined(K1_NOCAP)
-#define K1_CAP3 1
-#endif
 // FMT: input sample format (Utilities/StreamHelpers.cpp:51-133): 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16;
 // 4 = CU8 through the fixed-point ladder Downsample16_CU8 (K = 4 only)
 constexpr int fmt_bytes(int fmt) { return fmt == 0 ? 8 : fmt == 3 ? 4 : 2; }
@@ -611,16 +302,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 	const int rx = blockIdx.y;
 	const int span = blockIdx.x;
 	__builtin_amdgcn_s_setprio(K1_PRIO);
-#ifdef K1_CAP3
 	// Occupancy cap: ~120 VGPRs and ~10 KB of LDS let FOUR of these one-wave workgroups share a SIMD, and sixteen of them hold
 	// 156 of a CU's 160 KB of LDS -- nothing that needs LDS (the FFT, the staged PhaseSearch) gets on the CU beside them.  The
 	// kernel is as fast with three (HBM-bound); naming v135 as clobbered makes its allocation 136 registers = three per SIMD.
 	asm volatile("" ::: "v135");
-#endif
-#ifdef K1_CAP2
-	// two per SIMD (176 registers each): 160 registers and half of the LDS stay free for PhaseSearch / derotation waves
-	asm volatile("" ::: "v175");
-#endif
 
 	if (lane < 8) { x5[0][lane] = x5[1][lane] = x6[0][lane] = x6[1][lane] = make_float2(0.f, 0.f); }
 	RegLadder<K> st = {};
@@ -650,19 +335,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 		if constexpr (DMA) {
 			const uint4* src = (const uint4*)base + dma_r * W4 + dma_q;
 			const bool warm = WARM_SKIP_E > 0 && tile == tile_first; // wave-uniform
-#ifdef K1_DMA_IMM // the instruction's immediate offset moves the global AND the LDS address: pieces e and e + 1 are 1 KiB apart in both
-			k1_static_for<0, NV>([&](auto ec) {
-				constexpr int e = decltype(ec)::value, PER = 4; // 4 KiB of immediate range
-				if (e >= WARM_SKIP_E || !warm)
-					__builtin_amdgcn_global_load_lds((const void*)(src + (e / PER) * PER * 64), (__attribute__((address_space(3))) void*)(xt + (e / PER) * PER * 64), 16,
-					                                 (e % PER) * 1024, K1_LOAD_AUX);
-			});
-#else
 #pragma unroll
 			for (int e = 0; e < NV; e++)
 				if (e >= WARM_SKIP_E || !warm)
 					__builtin_amdgcn_global_load_lds((const void*)(src + e * 64), (__attribute__((address_space(3))) void*)(xt + e * 64), 16, 0, K1_LOAD_AUX);
-#endif
 		} else if constexpr (LANE_BYTES >= 16) {
 			const uint4* src = (const uint4*)base;
 #pragma unroll
@@ -1112,20 +788,10 @@ constexpr int MAG_STRIDE = 512 + 64 / FFT_NW;   // floats; 64/NW (mod 64) banks 
 // FFT_SLIM (default): only o stays in registers and the rotated copy is rebuilt where it is used (two sign/move operations per
 // twiddle and window): 96 instead of 124 VGPRs, so that a wave of this kernel still fits on a SIMD that already holds a
 // derotation/FIR wave and three PhaseSearch waves (it sits on the front stream: whatever delays it delays the next front end).
-#ifndef FFT_SLIM
-#define FFT_SLIM 1
-#endif
-#if FFT_SLIM
 struct Tw { c2 o; };
 __device__ __forceinline__ Tw make_tw(float2 o) { return Tw{ c2{ o.x, o.y } }; }
 __device__ __forceinline__ c2 cmul_tw(const Tw& w, c2 c) { const c2 r = c2{ -w.o.y, w.o.x }; return c.xx * w.o + c.yy * r; }
 __device__ __forceinline__ void tw_pin(Tw& w) { asm volatile("" : "+v"(w.o)); } // keeps the rotated copy from being hoisted out of the window loop
-#else
-struct Tw { c2 o, r; };
-__device__ __forceinline__ Tw make_tw(float2 o) { return Tw{ c2{ o.x, o.y }, c2{ -o.y, o.x } }; }
-__device__ __forceinline__ c2 cmul_tw(const Tw& w, c2 c) { return c.xx * w.o + c.yy * w.r; }
-__device__ __forceinline__ void tw_pin(Tw&) {}
-#endif
 
 // three radix-2 stages on the 8 points of a lane; tw0: twiddle of the first stage (all 4 butterflies), tw1[b]:
 // second stage for local index bit 0 = b, tw2[c]: third stage for local index bits (1,0) = c
@@ -1374,9 +1040,6 @@ __device__ __forceinline__ void spectral_search(const float (&m)[NWIN][8], float
 // traffic per step remain, and the arithmetic fills issue slots of a kernel that waits for HBM most of the time.
 __device__ __forceinline__ void k1_fft_tail(const K1Params& p, int rx, int span, float2* X) {
 	const int lane = threadIdx.x;
-#ifdef K1_TAIL_PRIO
-	__builtin_amdgcn_s_setprio(K1_TAIL_PRIO);
-#endif
 	// This wave's own c48 stores must have reached L2 (its L1 never held those lines), and the last tile's LDS-DMA must have
 	// landed before the tile buffer is reused: a workgroup-scope fence is exactly "s_waitcnt vmcnt(0)" -- an agent-scope one
 	// (__threadfence) adds an L2 write-back and an L1 invalidate per span, which cost more than the analysis itself.
@@ -1669,11 +1332,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6
 			float2 d[20];
 			const float2* xb = p.c48 + n;
 #pragma unroll
-#ifdef K6_NT
-			for (int m = 0; m < 20; m++) d[m] = nt_load(&(xb + m)[xoff]);
-#else
 			for (int m = 0; m < 20; m++) d[m] = (xb + m)[xoff];
-#endif
 			body([&](int m) { return derotate(d[m]); });
 		} else {
 			body([&](int m) { return next_sample(n + m); });
@@ -1684,11 +1343,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6
 				for (int j = 0; j < 5; j++) { // lane = channel: the body's two pairs fill the quads' 128-byte lines (SymRow layout, kernels.h)
 					float4* dst = reinterpret_cast<float4*>(p.sym + sym_row_base(chain, j, p.sym_stride) + sym_offset(g));
 #pragma unroll
-#ifdef K6_NT
-					for (int q = 0; q < 2; q++) nt_store(make_float4(out[j][2 * q].x, out[j][2 * q].y, out[j][2 * q + 1].x, out[j][2 * q + 1].y), &dst[q * 4]);
-#else
 					for (int q = 0; q < 2; q++) dst[q * 4] = make_float4(out[j][2 * q].x, out[j][2 * q].y, out[j][2 * q + 1].x, out[j][2 * q + 1].y); // pair 1: 64 bytes behind pair 0
-#endif
 				}
 				*reinterpret_cast<float4*>(p.lvl + (size_t)chain * p.sym_stride + g) = make_float4(lv[0], lv[1], lv[2], lv[3]);
 			} else {
@@ -2188,13 +1843,7 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 		for (int q = 0; q < PS_SB / 16; q++) {
 			int i = start + sb * PS_SB + q * 16 + k;
 			i = i < last_i ? i : last_i; // (past the chunk's end: any readable sample, it is never used)
-#ifdef K4_EXP_NO_LOADS // experiment (results wrong): the kernel's arithmetic without its global loads
-			r[q] = make_float2(0.25f + (float)(i & 7), 0.5f - (float)(i & 3));
-#elif defined(K4_NT)
-			r[q] = nt_load(&x.base[sym_offset(i)]); // read once
-#else
 			r[q] = x[i];
-#endif
 		}
 	};
 	const auto stash = [&](int buf) {
@@ -2222,12 +1871,6 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 #pragma unroll
 				for (int e = 0; e < PS_BATCH; e += 2) { const float4 t = src[e >> 1]; v[e] = make_float2(t.x, t.y); v[e + 1] = make_float2(t.z, t.w); }
 			}
-#ifdef K4_EXP_NO_COMPUTE // experiment (results wrong): the kernel's memory traffic and staging without its arithmetic
-			{ float acc_ = 0.0f;
-#pragma unroll
-			  for (int e = 0; e < PS_BATCH; e++) acc_ += v[e].x;
-			  ma.x = acc_; word ^= __float_as_uint(acc_) & 1u; continue; }
-#endif
 			if (g < g0) { // warm-up: EMA and decision history only
 #pragma unroll
 				for (int e = 0; e < PS_BATCH; e++) ps_warm_step<MODE>(v[e], pc, psn, ma, hs);
@@ -2281,9 +1924,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K4_WAVES, K4
 	const int lane = threadIdx.x;
 	const int k = lane & 15, row = lane >> 4;
 	const int chunk = blockIdx.y;
-	if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
-	else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
-	else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
 	// the four rows of a wave: the same sampling phase of four ADJACENT channels (their symbol pairs are 64 contiguous bytes in
 	// the SymRow layout) and the same chunk (equal trip counts)
 	const int j = blockIdx.x % 5, chan = (blockIdx.x / 5) * 4 + row;
@@ -2296,169 +1936,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K4_WAVES, K4
 	if (all_left) ps_chunk_body<0>(p, chain, chunk, live, k, rowbase, lane, stage);
 	else if (all_right) ps_chunk_body<1>(p, chain, chunk, live, k, rowbase, lane, stage);
 	else ps_chunk_body<2>(p, chain, chunk, live, k, rowbase, lane, stage);
-}
-
-// ------------------------------------------------------------------------------------------
-// k4_phase_chunks2: the same chunk kernel with TWO independent row sets per wave -- the quads of channels 8q .. 8q+3 and
-// 8q+4 .. 8q+7, same sampling phase, same chunk -- whose steps are interleaved instruction by instruction.
-//  * a SIMD that holds three front-end waves has 104 registers left: room for ONE PhaseSearch wave of 64 (or of 96) registers,
-//    and a lone wave of dependent steps (ballot -> scalar -> shift -> add chains) leaves most issue slots unused; two
-//    independent streams in that one wave fill them (same residency, twice the work per resident wave);
-//  * the FIR outputs of 8 adjacent channels are one whole 128-byte line of the SymRow layout: with one quad per wave every
-//    line was fetched twice, half used each time (244 MB read for 126 MB of data, profiles/r02_v1_pmc_traffic_all_kernels.txt).
-// State, scratch layout and results are exactly k4_phase_chunks' (k4_assemble and the fallback do not know the difference).
-// ------------------------------------------------------------------------------------------
-constexpr int PS_BATCH2 = 4; // symbols per inner batch of the two-stream kernel (two streams' samples in registers at once)
-template <int MODE>
-__device__ __forceinline__ void ps_chunk_body2(const K4Params& p, const int (&chain)[2], const bool (&live)[2], int chunk, int k, int rowbase, int lane,
-                                               float2 (*stage)[2][4][PS_SB_PAD]) {
-	const int jj = k < 8 ? k : 15 - k;
-	const float pc = c_ps_phase[jj].x;
-	const float psn = k < 8 ? c_ps_phase[jj].y : -c_ps_phase[jj].y;
-	const SymRow x[2] = { SymRow(p.sym, chain[0], p.sym_stride), SymRow(p.sym, chain[1], p.sym_stride) };
-	const int g0 = chunk * PS_CHUNK;
-	const int g1 = g0 + PS_CHUNK < p.n_groups ? g0 + PS_CHUNK : p.n_groups;
-	const size_t slot[2] = { (size_t)chain[0] * p.n_chunks + chunk, (size_t)chain[1] * p.n_chunks + chunk };
-	const int row = rowbase >> 4;
-
-	c2 ma[2];
-	PsWave hs[2];
-	int idx[2] = { k, k }; // trajectories that start at max_idx == k
-	int start = g0;
-#pragma unroll
-	for (int s = 0; s < 2; s++) {
-		if (chunk == 0) { // the true state
-			const EmaState* st = p.state_in + chain[s];
-			ma[s] = c2{ st->ma[k], st->ma[k] };
-			const unsigned bits = st->bits[k];
-			hs[s].h1 = __ballot((bits & 1u) != 0); hs[s].h2 = __ballot((bits & 2u) != 0);
-			hs[s].h3 = __ballot((bits & 4u) != 0); hs[s].h4 = __ballot((bits & 8u) != 0);
-		} else { // speculative: replay the `warm` symbols in front of the chunk from zero
-			ma[s] = c2{ 0.0f, 0.0f };
-			hs[s].h1 = hs[s].h2 = hs[s].h3 = hs[s].h4 = 0;
-		}
-	}
-	if (chunk != 0) start = g0 - p.warm;
-	const int last_i = (int)p.sym_stride - 1;
-	float2 r[2][PS_SB / 16];
-	const auto fetch = [&](int sb) {
-#pragma unroll
-		for (int q = 0; q < PS_SB / 16; q++) {
-			int i = start + sb * PS_SB + q * 16 + k;
-			i = i < last_i ? i : last_i; // (past the chunk's end: any readable sample, it is never used)
-			r[0][q] = x[0][i]; // the two quads' symbols are the two halves of one 128-byte line
-			r[1][q] = x[1][i];
-		}
-	};
-	const auto stash = [&](int buf) {
-#pragma unroll
-		for (int s = 0; s < 2; s++)
-#pragma unroll
-			for (int q = 0; q < PS_SB / 16; q++) stage[s][buf][row][q * 16 + k] = r[s][q];
-	};
-	const int nsb = (g1 - start + PS_SB - 1) / PS_SB;
-	fetch(0);
-	stash(0);
-	if (nsb > 1) fetch(1);
-
-	uint32_t* wout[2] = { p.words + slot[0] * (PS_CHUNK / 32) * 16 + k, p.words + slot[1] * (PS_CHUNK / 32) * 16 + k };
-	uint32_t word[2] = { 0, 0 };
-#pragma unroll 1
-	for (int sb = 0; sb < nsb; sb++) {
-		const int buf = sb & 1;
-		wave_sync(); // the tiles written by this wave's own stash() are read below (one-wave workgroup: ordering only)
-#pragma unroll 1
-		for (int s8 = 0; s8 < PS_SB; s8 += PS_BATCH2) {
-			const int g = start + sb * PS_SB + s8;
-			if (g >= g1) break;
-			float2 v[2][PS_BATCH2];
-#pragma unroll
-			for (int s = 0; s < 2; s++) {
-				const float4* src = reinterpret_cast<const float4*>(&stage[s][buf][row][s8]);
-#pragma unroll
-				for (int e = 0; e < PS_BATCH2; e += 2) { const float4 t = src[e >> 1]; v[s][e] = make_float2(t.x, t.y); v[s][e + 1] = make_float2(t.z, t.w); }
-			}
-			if (g < g0) { // warm-up: EMA and decision history only
-#pragma unroll
-				for (int e = 0; e < PS_BATCH2; e++) {
-					ps_warm_step<MODE>(v[0][e], pc, psn, ma[0], hs[0]);
-					ps_warm_step<MODE>(v[1][e], pc, psn, ma[1], hs[1]);
-				}
-				if (g + PS_BATCH2 == g0) {
-					if (live[0]) p.ma_start[slot[0] * 16 + k] = ma[0].y;
-					if (live[1]) p.ma_start[slot[1] * 16 + k] = ma[1].y;
-				}
-			} else {
-				const int q = g - g0;
-				uint32_t part[2] = { 0, 0 };
-				if (g + PS_BATCH2 <= g1) {
-#pragma unroll
-					for (int e = 0; e < PS_BATCH2; e++) {
-						part[0] |= ps_step<MODE>(v[0][e], pc, psn, ma[0], hs[0], idx[0], k, rowbase) << e;
-						part[1] |= ps_step<MODE>(v[1][e], pc, psn, ma[1], hs[1], idx[1], k, rowbase) << e;
-					}
-				} else {
-#pragma unroll
-					for (int e = 0; e < PS_BATCH2; e++)
-						if (g + e < g1) { // wave-uniform
-							part[0] |= ps_step<MODE>(v[0][e], pc, psn, ma[0], hs[0], idx[0], k, rowbase) << e;
-							part[1] |= ps_step<MODE>(v[1][e], pc, psn, ma[1], hs[1], idx[1], k, rowbase) << e;
-						}
-				}
-				word[0] |= part[0] << (q & 31);
-				word[1] |= part[1] << (q & 31);
-				if (((q + PS_BATCH2) & 31) == 0 && g + PS_BATCH2 <= g1) {
-					if (live[0]) wout[0][(q >> 5) * 16] = word[0];
-					if (live[1]) wout[1][(q >> 5) * 16] = word[1];
-					word[0] = word[1] = 0;
-				}
-			}
-		}
-		if (sb + 1 < nsb) {
-			stash(buf ^ 1);                  // super-batch sb + 1 has been in flight for one super-batch of work
-			if (sb + 2 < nsb) fetch(sb + 2);
-		}
-	}
-	const int n = g1 - g0;
-#pragma unroll
-	for (int s = 0; s < 2; s++) {
-		if ((n & 31) != 0 && live[s]) wout[s][(n >> 5) * 16] = word[s];
-		if (live[s]) {
-			p.ma_fin[slot[s] * 16 + k] = ma[s].y;
-			const unsigned dec = (unsigned)((hs[s].h1 >> lane) & 1ull) | ((unsigned)((hs[s].h2 >> lane) & 1ull) << 1) |
-			                     ((unsigned)((hs[s].h3 >> lane) & 1ull) << 2) | ((unsigned)((hs[s].h4 >> lane) & 1ull) << 3);
-			p.fin[slot[s] * 16 + k] = (unsigned)(idx[s] & 15) | (dec << 4);
-		}
-	}
-}
-
-#ifndef K4X2_WAVES
-#define K4X2_WAVES 4 // 97 registers, allocated 104: exactly what three front-end waves (3 x 136) leave of a SIMD's 512
-#endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K4X2_WAVES, K4X2_WAVES))) void k4_phase_chunks2(K4Params p) {
-	__shared__ __attribute__((aligned(16))) float2 stage[2][2][4][PS_SB_PAD];
-	const int lane = threadIdx.x;
-	const int k = lane & 15, row = lane >> 4;
-	const int chunk = blockIdx.y;
-	if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
-	else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
-	else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
-	// the wave's two row sets: the same sampling phase of channels 8q .. 8q+3 and 8q+4 .. 8q+7 (one 128-byte line per symbol pair)
-	const int j = blockIdx.x % 5, chan0 = (blockIdx.x / 5) * 8 + row;
-	const int n_chan = p.n_chains / 5;
-	int chain[2]; bool live[2];
-#pragma unroll
-	for (int s = 0; s < 2; s++) {
-		const int c = chan0 + 4 * s;
-		live[s] = c < n_chan;
-		chain[s] = (live[s] ? c : n_chan - 1) * 5 + j;
-	}
-	const int rowbase = row * 16;
-	const int src = __builtin_amdgcn_update_dpp(0, k, 0x121, 0xF, 0xF, false);
-	const bool all_left = __all(src == ((k + 15) & 15)), all_right = __all(src == ((k + 1) & 15));
-	if (all_left) ps_chunk_body2<0>(p, chain, live, chunk, k, rowbase, lane, stage);
-	else if (all_right) ps_chunk_body2<1>(p, chain, live, chunk, k, rowbase, lane, stage);
-	else ps_chunk_body2<2>(p, chain, live, chunk, k, rowbase, lane, stage);
 }
 
 // sequential over the (few) chunks of a chain, 16 lanes per chain: verify the speculative warm-ups, select the
@@ -2534,615 +2011,6 @@ __global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
 	if (k == 0) { sto->max_idx = start; sto->rot = (st->rot + p.n_groups) & 3; }
 	if (p.box_out && k == 0) p.box_out[chain].max_idx = start; // boxcar variant: its own state block
 }
-
-// ------------------------------------------------------------------------------------------
-// K46: derotation (DSP.cpp:457-466) + FilterComplex(Filters::Coherent) (DSP.cpp:215-246) + ScatterPLL (DSP.h:95-117) +
-// PhaseSearchEMA (Demod.cpp:39-101) in one kernel.  The pipeline is bound by HBM traffic (profiles/r02_expA.txt: every kernel
-// costs ~0.2 us per MB it moves, whatever it computes), and the FIR outputs were its largest intermediate: 126 MB written by
-// the derotation/FIR kernel, 244 MB read back by PhaseSearch, 146 MB of 48 kHz samples read to produce them.  Here they only
-// ever exist in LDS.
-//   workgroup = 5 waves = the five sampling phases of 4 adjacent channels x one time chunk of the chunk-parallel search
-//   per super-batch of 64 symbols (= 320 samples of each channel, + 16 of FIR history, 8-aligned: K46_NB8 blocks of 8):
-//     A  176 threads: one 8-sample block each -- phasor state before the block from the recurrence kernel (ck8), 8 sequential
-//        complex products, 8 derotated samples -> ytile (shared by the five waves); blocks in front of the stream block come
-//        from the previous block's tail (hist_in, already derotated), the block's last 24 go to hist_out
-//     B  wave j, lane (channel row, k): the FIR outputs of phase j for symbols k, k + 16, k + 32, k + 48 of the super-batch,
-//        17 taps left to right from 0 like the reference; |out|^2 -> normtile; (1j)^n pre-rotation; -> the wave's stage rows
-//     C  256 threads: ScatterPLL level of (channel, symbol) = ((((n0 + n1) + n2) + n3) + n4) / 5 over the five waves' norms
-//     D  every wave: the 64 PhaseSearch steps of its four chains (ps_step / ps_warm_step, as k4_phase_chunks)
-//   The loads of super-batch n + 1 are issued between B and D, so they are in flight during the steps.
-// Arithmetic per sample / symbol is exactly that of k2_cgf_phasor_ck + k3_derot_fir + k4_phase_chunks.
-// sequential != 0: the exact fallback -- one chunk = the whole block from the true state, decisions and state written
-// directly; runs only for channel quads whose flag k4_assemble raised (a speculative EMA warm-up that did not reproduce the
-// sequential values), so one receiver with an extreme level step costs one workgroup, not the batch.
-// ------------------------------------------------------------------------------------------
-template <int MODE>
-__device__ __forceinline__ void k46_body(const K46Params& p, float2 (*ytile)[K46_YPITCH], float2 (*stage)[4][PS_SB_PAD], float (*normtile)[4][PS_SB]) {
-	const K4Params& q4 = p.k4;
-	const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-	const int k = lane & 15, row = lane >> 4, rowbase = row * 16;
-	const int quad = blockIdx.x;
-	const bool seq = p.sequential != 0;
-	const int chunk = seq ? 0 : blockIdx.y;
-	const int chan_raw = quad * 4 + row;
-	const bool live = chan_raw < p.n_chan;
-	const int chan = live ? chan_raw : p.n_chan - 1;
-	const int j = wv;                 // sampling phase of this wave
-	const int chain = chan * 5 + j;
-	const int jj = k < 8 ? k : 15 - k;
-	const float pc = c_ps_phase[jj].x;
-	const float psn = k < 8 ? c_ps_phase[jj].y : -c_ps_phase[jj].y;
-	const int g0 = seq ? 0 : chunk * PS_CHUNK;
-	const int g1 = seq ? q4.n_groups : (g0 + PS_CHUNK < q4.n_groups ? g0 + PS_CHUNK : q4.n_groups);
-	const size_t slot = (size_t)chain * q4.n_chunks + chunk;
-
-	c2 ma;
-	PsWave hs;
-	int idx = k; // trajectory that starts at max_idx == k
-	int start = g0;
-	const EmaState* st_in = q4.state_in + chain;
-	const int start_idx0 = st_in->max_idx;
-	if (chunk == 0) { // the true state
-		ma = c2{ st_in->ma[k], st_in->ma[k] };
-		const unsigned bits = st_in->bits[k];
-		hs.h1 = __ballot((bits & 1u) != 0); hs.h2 = __ballot((bits & 2u) != 0);
-		hs.h3 = __ballot((bits & 4u) != 0); hs.h4 = __ballot((bits & 8u) != 0);
-	} else { // speculative: replay the `warm` symbols in front of the chunk from zero
-		ma = c2{ 0.0f, 0.0f };
-		hs.h1 = hs.h2 = hs.h3 = hs.h4 = 0;
-		start = g0 - q4.warm;
-	}
-	const int nsb = (g1 - start + PS_SB - 1) / PS_SB;
-	const bool last_chunk = seq || chunk == q4.n_chunks - 1;
-
-	// ---- phase A item of this thread: (channel a_r of the quad, 8-sample block a_t of the super-batch's range)
-	const int a_r = tid & 3, a_t = tid >> 2;
-	const bool a_on = tid < 4 * K46_NB8;
-	const bool a_live = quad * 4 + a_r < p.n_chan;
-	const int a_chan = a_live ? quad * 4 + a_r : p.n_chan - 1;
-	float4 d[4];
-	float2 ckv = make_float2(1.0f, 0.0f), stp = make_float2(1.0f, 0.0f);
-	int a_n8 = 0; // block-relative index of the first sample of the item's block in the super-batch being fetched
-	const auto range_base8 = [&](int sb) { return (p.n_rel0 + 5 * (start + sb * PS_SB) - 16) >> 3; }; // floor: the range can start in the previous block
-	const auto fetch = [&](int sb) {
-		if (!a_on) return;
-		const int t = range_base8(sb) + a_t;
-		a_n8 = 8 * t;
-		if (t < 0) { // the previous block's tail, already derotated
-			const float4* hsrc = reinterpret_cast<const float4*>(p.hist_in + (size_t)a_chan * DF_HIST + (DF_HIST + a_n8));
-#pragma unroll
-			for (int e = 0; e < 4; e++) d[e] = hsrc[e];
-		} else if (a_n8 < p.L) {
-			const float4* src = reinterpret_cast<const float4*>(p.c48 + (size_t)a_chan * p.c48_stride + a_n8);
-#pragma unroll
-			for (int e = 0; e < 4; e++) d[e] = src[e];
-			ckv = p.ck8[(size_t)t * p.ck_stride + a_chan];
-			stp = p.step_table[p.fz[(size_t)a_chan * p.n_windows + (a_n8 >> 9)] + 205];
-		}
-	};
-	const auto derotate_store = [&](int sb) {
-		if (!a_on) return;
-		c2 y[8];
-		if (a_n8 < 0 || a_n8 >= p.L) {
-#pragma unroll
-			for (int e = 0; e < 4; e++) { y[2 * e] = c2{ d[e].x, d[e].y }; y[2 * e + 1] = c2{ d[e].z, d[e].w }; }
-		} else {
-			c2 rot = { ckv.x, ckv.y };
-			const c2 st = { stp.x, stp.y }, st_sw = { -stp.y, stp.x };
-#pragma unroll
-			for (int e = 0; e < 8; e++) {
-				const float dx = (e & 1) ? d[e >> 1].z : d[e >> 1].x, dy = (e & 1) ? d[e >> 1].w : d[e >> 1].y;
-				rot = rot.xx * st + rot.yy * st_sw;             // rot *= rot_step (DSP.cpp:462)
-				y[e] = pk_sub_add(rot * dx, rot.yx * dy);       // output[i] *= rot (DSP.cpp:463)
-			}
-			if (last_chunk && sb == nsb - 1 && a_live && a_n8 >= p.L - DF_HIST) { // the next block's history
-				float4* hdst = reinterpret_cast<float4*>(p.hist_out + (size_t)a_chan * DF_HIST + (a_n8 - (p.L - DF_HIST)));
-#pragma unroll
-				for (int e = 0; e < 4; e++) hdst[e] = make_float4(y[2 * e].x, y[2 * e].y, y[2 * e + 1].x, y[2 * e + 1].y);
-			}
-		}
-		float4* dst = reinterpret_cast<float4*>(&ytile[a_r][8 * a_t]);
-#pragma unroll
-		for (int e = 0; e < 4; e++) dst[e] = make_float4(y[2 * e].x, y[2 * e].y, y[2 * e + 1].x, y[2 * e + 1].y);
-	};
-
-	uint32_t* wout = q4.words + slot * (PS_CHUNK / 32) * 16 + k;
-	uint32_t* bout = q4.bits + (size_t)chain * q4.bits_stride;
-	const bool seq_writer = seq && live && k == start_idx0;
-	uint32_t word = 0;
-	fetch(0);
-#pragma unroll 1
-	for (int sb = 0; sb < nsb; sb++) {
-		const int S0 = start + sb * PS_SB;
-		const int base8 = range_base8(sb);
-		derotate_store(sb);                                  // A
-		__syncthreads();
-		const bool proper = S0 + PS_SB > g0;                 // the super-batch holds symbols of the chunk itself (not only warm-up)
-		{                                                    // B
-			const float2* yrow = &ytile[row][0];
-#pragma unroll
-			for (int i = 0; i < PS_SB / 16; i++) {
-				const int si = k + 16 * i, sidx = S0 + si;
-				const float2* yp = yrow + (p.n_rel0 + 5 * sidx + j - 16 - 8 * base8);
-				c2 acc = { 0.0f, 0.0f };
-#pragma unroll
-				for (int m = 0; m < 17; m++) { const float2 v = yp[m]; acc = acc + c2{ v.x, v.y } * p.taps[m]; } // DSP.h:224-230
-				if (proper) normtile[wv][row][si] = acc.x * acc.x + acc.y * acc.y; // std::norm
-				// PhaseSearchEMA multiplies symbol n of a chain by (1j)^(n & 3) with swaps / negations (Demod.cpp:44-61)
-				const int rsel = (int)((p.first_group + sidx) & 3);
-				c2 sv = (rsel & 1) ? acc.yx : acc;
-				if (rsel == 1 || rsel == 2) sv.x = -sv.x;
-				if (rsel >= 2) sv.y = -sv.y;
-				stage[wv][row][si] = make_float2(sv.x, sv.y);
-			}
-		}
-		if (sb + 1 < nsb) fetch(sb + 1);                     // in flight during the steps
-		__syncthreads();
-		if (proper && tid < 4 * PS_SB) {                     // C: ScatterPLL level (DSP.h:101-106)
-			const int r = tid >> 6, si = tid & 63, sidx = S0 + si;
-			if (sidx >= g0 && sidx < g1 && quad * 4 + r < p.n_chan) {
-				float level = 0.0f;
-#pragma unroll
-				for (int ph = 0; ph < 5; ph++) level = level + normtile[ph][r][si];
-				p.lvl[(size_t)(quad * 4 + r) * p.lvl_stride + sidx] = __fdiv_rn(level, 5.0f);
-			}
-		}
-#pragma unroll 1
-		for (int s8 = 0; s8 < PS_SB; s8 += PS_BATCH) {       // D
-			const int g = S0 + s8;
-			if (g >= g1) break;
-			float2 v[PS_BATCH];
-			{
-				const float4* src = reinterpret_cast<const float4*>(&stage[wv][row][s8]);
-#pragma unroll
-				for (int e = 0; e < PS_BATCH; e += 2) { const float4 t = src[e >> 1]; v[e] = make_float2(t.x, t.y); v[e + 1] = make_float2(t.z, t.w); }
-			}
-			if (g < g0) { // warm-up: EMA and decision history only
-#pragma unroll
-				for (int e = 0; e < PS_BATCH; e++) ps_warm_step<MODE>(v[e], pc, psn, ma, hs);
-				if (g + PS_BATCH == g0 && live) q4.ma_start[slot * 16 + k] = ma.y;
-			} else {
-				const int q = g - g0;
-				uint32_t part = 0;
-				if (g + PS_BATCH <= g1) {
-#pragma unroll
-					for (int e = 0; e < PS_BATCH; e++) part |= ps_step<MODE>(v[e], pc, psn, ma, hs, idx, k, rowbase) << e;
-				} else {
-#pragma unroll
-					for (int e = 0; e < PS_BATCH; e++)
-						if (g + e < g1) part |= ps_step<MODE>(v[e], pc, psn, ma, hs, idx, k, rowbase) << e; // wave-uniform
-				}
-				word |= part << (q & 31);
-				if (((q + PS_BATCH) & 31) == 0 && g + PS_BATCH <= g1) {
-					if (seq) { if (seq_writer) bout[q >> 5] = word; }
-					else if (live) wout[(q >> 5) * 16] = word;
-					word = 0;
-				}
-			}
-		}
-		// (the next iteration's derotate_store overwrites ytile: every wave has passed the second barrier, i.e. finished B)
-	}
-	const int n = g1 - g0;
-	if ((n & 31) != 0) {
-		if (seq) { if (seq_writer) bout[n >> 5] = word; }
-		else if (live) wout[(n >> 5) * 16] = word;
-	}
-	if (live) {
-		const unsigned dec = (unsigned)((hs.h1 >> lane) & 1ull) | ((unsigned)((hs.h2 >> lane) & 1ull) << 1) |
-		                     ((unsigned)((hs.h3 >> lane) & 1ull) << 2) | ((unsigned)((hs.h4 >> lane) & 1ull) << 3);
-		if (seq) {
-			EmaState* sto = q4.state_out + chain;
-			sto->ma[k] = ma.y;
-			sto->bits[k] = dec;
-			if (k == start_idx0) { sto->max_idx = idx & 15; sto->rot = (st_in->rot + q4.n_groups) & 3; }
-		} else {
-			q4.ma_fin[slot * 16 + k] = ma.y;
-			q4.fin[slot * 16 + k] = (unsigned)(idx & 15) | (dec << 4);
-		}
-	}
-}
-
-__global__ __launch_bounds__(320) void k46_fir_phase_chunks(K46Params p) {
-	__shared__ __attribute__((aligned(16))) float2 ytile[4][K46_YPITCH];
-	__shared__ __attribute__((aligned(16))) float2 stage[5][4][PS_SB_PAD];
-	__shared__ float normtile[5][4][PS_SB];
-	if (p.sequential) { // exact fallback, only where the verification of a speculative warm-up failed
-		if (p.k4.qflag[blockIdx.x] == 0) return; // (workgroup-uniform, in front of every barrier)
-	}
-	if (p.k4.prio == 1) __builtin_amdgcn_s_setprio(1);
-	else if (p.k4.prio == 2) __builtin_amdgcn_s_setprio(2);
-	else if (p.k4.prio == 3) __builtin_amdgcn_s_setprio(3);
-	const int k = threadIdx.x & 15;
-	const int src = __builtin_amdgcn_update_dpp(0, k, 0x121, 0xF, 0xF, false);
-	const bool all_left = __all(src == ((k + 15) & 15)), all_right = __all(src == ((k + 1) & 15));
-	// (the probe's outcome is a property of the hardware: the same in all five waves, so the barriers inside stay aligned)
-	if (all_left) k46_body<0>(p, ytile, stage, normtile);
-	else if (all_right) k46_body<1>(p, ytile, stage, normtile);
-	else k46_body<2>(p, ytile, stage, normtile);
-	if (p.sequential) {
-		__syncthreads();
-		if (threadIdx.x == 0) p.k4.qflag[blockIdx.x] = 0; // consumed
-	}
-}
-
-// the CGF phasor recurrence (as k2_cgf_phasor_ck) keeping its state in front of every 8th sample: what K46's derotation starts from
-__global__ __launch_bounds__(64) void k2_cgf_phasor_ck8(K2Params p, float2* ck8) {
-	const int lane = threadIdx.x;
-	const int chan_raw = blockIdx.x * 64 + lane;
-	const bool live = chan_raw < p.n_chan;
-	const int chan = live ? chan_raw : p.n_chan - 1;
-	__builtin_amdgcn_s_setprio(3);
-	const float2 r0 = p.rot_state[chan];
-	v2f cur = { r0.x, r0.y };
-	float2* o = ck8 + (size_t)blockIdx.x * 64 + lane; // padded columns exist for dead lanes
-	for (int w = 0; w < p.n_windows; w++) {
-		const int fz = p.fz[(size_t)chan * p.n_windows + w];
-		const float2 stp = p.step_table[fz + 205];
-		const v2f st = { stp.x, stp.y }, st_sw = { -stp.y, stp.x };
-#pragma unroll 2
-		for (int b = 0; b < 64; b++) {
-			*o = make_float2(cur.x, cur.y);
-			o += p.ck_stride;
-#pragma unroll
-			for (int e = 0; e < 8; e++) cur = cur.xx * st + cur.yy * st_sw; // rot *= rot_step
-		}
-		const float a = hypot_ref(cur.x, cur.y); // rot /= std::abs(rot), once per window (DSP.cpp:465)
-		cur.x = __fdiv_rn(cur.x, a);
-		cur.y = __fdiv_rn(cur.y, a);
-	}
-	if (live) p.rot_state[chan] = make_float2(cur.x, cur.y);
-}
-
-// ------------------------------------------------------------------------------------------
-// K4 lane-per-chunk (default): the row kernels above spend one LANE per hypothesis, i.e. 16 lanes x ~26 VALU
-// instructions per symbol, most of them on getting three neighbouring ma[] values and two predicates across lanes.
-// Here one lane owns one (chain, time chunk) and ALL 16 hypotheses of it in registers -- the pairs (j, 15 - j) that
-// the reference computes from the same two products (Demod.cpp:66-77) are one VGPR pair, so the products, the sums
-// a + b / a - b and the EMA are packed-fp32 instructions -- and nothing is exchanged between lanes at all.
-// What the sequential part of the reference needs from the float state is reduced to sign bits, one word per symbol:
-//     g[k] = ma[k] > ma[k-1]        (sign of ma[k-1] - ma[k])
-//     h[k] = ma[k+1] > ma[k-1]      (sign of ma[k-1] - ma[k+1])
-//     d[k] = t[k] > 0               (sign of 0 - t[k]; +-0 -> 0 like the comparison)
-// (x > y  <=>  signbit(y - x) for finite floats: the subtraction is exact in sign, and equal values give +0.)
-// The first-maximum search over {max_idx - 1, max_idx, max_idx + 1} (Demod.cpp:80-92) is a function of g and h
-// only: with i = max_idx, "ma[i] > ma[i-1]" = g[i]; the third candidate is compared with the better of the two,
-// i.e. with ma[i] when g[i] (that is g[i+1]) and with ma[i-1] otherwise (that is h[i]).  k4_walk then runs the
-// integer recurrence max_idx -> output bit sequentially, one lane per chain (40 waves for 256 receivers; ~8
-// dependent integer instructions per symbol), verifies the speculative EMA warm-ups of the chunks bit for bit
-// (same rule as above: any difference raises p.flag and the exact sequential kernel recomputes the block) and
-// writes the packed decisions and the new state.
-// VALU cost per symbol and chain: 48 (EMA) + 19 + 8 (differences) + 48 (sign collection) = 123 lane-instructions
-// against 416 for the row kernel; the price is 8 bytes of scratch per symbol (written once, read once).
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ c2 pk_sum_diff(c2 ab) { // (ab.x + ab.y, ab.x - ab.y); x - y == x + (-y) exactly
-	c2 r;
-	asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(ab));
-	return r;
-}
-__device__ __forceinline__ c2 pk_diff_cross(c2 a, c2 b) { // (a.x - b.x, b.y - a.y)
-	c2 r;
-	asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
-	return r;
-}
-__device__ __forceinline__ c2 pk_neg_from_zero(c2 t) { // (0 - t.x, 0 - t.y)
-	c2 r;
-	const c2 z = { 0.0f, 0.0f };
-	asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(z), "v"(t));
-	return r;
-}
-__device__ __forceinline__ unsigned push_sign(unsigned acc, float v) { // (acc << 1) | signbit(v)
-	return __builtin_amdgcn_alignbit(acc, __float_as_uint(v), 31);
-}
-
-struct PsLane { c2 P[8]; }; // P[j] = (ma[j], ma[15 - j])
-
-__device__ __forceinline__ c2 ps_lane_cs(int j) { return c2{ c_ps_phase[j].x, c_ps_phase[j].y }; }
-
-// EMA update of all 16 hypotheses for one symbol; T[j] = (t[j], t[15 - j])
-__device__ __forceinline__ void ps_lane_ema(c2 v, PsLane& st, c2 (&T)[8]) {
-	const float w = 0.85f;
-	const float w1 = 1 - w; // (1 - weight) evaluated in float (Demod.cpp:71)
-	const c2 W = { w, w };
-#pragma unroll
-	for (int j = 0; j < 8; j++) {
-		const c2 ab = v * ps_lane_cs(j); // a = re * phase[j].real(), b = im * phase[j].imag()
-		T[j] = pk_sum_diff(ab);
-		c2 u; // (1 - weight) * std::abs(t): the |.| source modifier keeps it at one instruction per hypothesis
-		asm("v_mul_f32_e64 %0, %1, |%2|" : "=v"(u.x) : "v"(w1), "v"(T[j].x));
-		asm("v_mul_f32_e64 %0, %1, |%2|" : "=v"(u.y) : "v"(w1), "v"(T[j].y));
-		st.P[j] = W * st.P[j] + u;
-	}
-}
-
-// decisions of one symbol as a word over the hypotheses: bit k = t[k] > 0
-__device__ __forceinline__ unsigned ps_lane_decisions(const c2 (&T)[8]) {
-	float nt[16];
-#pragma unroll
-	for (int j = 0; j < 8; j++) {
-		const c2 N = pk_neg_from_zero(T[j]);
-		nt[j] = N.x; nt[15 - j] = N.y;
-	}
-	unsigned d = 0;
-#pragma unroll
-	for (int k = 15; k >= 0; k--) d = push_sign(d, nt[k]);
-	return d;
-}
-
-// What k4_walk needs of one symbol, every 16-bit field repeated in both halves of its word (so that a bit-field
-// extract at offset max_idx needs no "& 15"):
-//   up[i]: the search moves to i + 1  <=>  g[i] ? g[i+1] : h[i]   (the third candidate beats the better of the first two)
-//   dn[i]: the search moves to i - 1  <=>  !g[i] && !h[i]         (the first candidate, max_idx - 1, stays the maximum)
-//   x[i] : bit(nDelay) ^ bit(nDelay + 1) of hypothesis i = d(n-3)[i] ^ d(n-4)[i]
-struct PsWords { unsigned up, dn, x; };
-struct PsHist { unsigned d1, d2, d3, d4; }; // decision words of 1..4 symbols ago
-
-__device__ __forceinline__ PsWords ps_lane_words(const PsLane& st, const c2 (&T)[8], PsHist& hs) {
-	const c2(&P)[8] = st.P;
-	float e[16], f[16]; // e[k] = ma[k-1] - ma[k], f[k] = ma[k-1] - ma[k+1]
-#pragma unroll
-	for (int k = 1; k <= 7; k++) {
-		const c2 E = pk_diff_cross(P[k - 1], P[k]); // (ma[k-1] - ma[k], ma[15-k] - ma[16-k])
-		e[k] = E.x; e[16 - k] = E.y;
-	}
-	e[0] = P[0].y - P[0].x; // ma[15] - ma[0]
-	e[8] = P[7].x - P[7].y; // ma[7] - ma[8]
-#pragma unroll
-	for (int k = 1; k <= 6; k++) {
-		const c2 F = pk_diff_cross(P[k - 1], P[k + 1]); // (ma[k-1] - ma[k+1], ma[14-k] - ma[16-k])
-		f[k] = F.x; f[15 - k] = F.y;
-	}
-	f[0] = P[0].y - P[1].x;  // ma[15] - ma[1]
-	f[7] = P[6].x - P[7].y;  // ma[6] - ma[8]
-	f[8] = P[7].x - P[6].y;  // ma[7] - ma[9]
-	f[15] = P[1].y - P[0].x; // ma[14] - ma[0]
-	unsigned g = 0, hh = 0;
-#pragma unroll
-	for (int k = 15; k >= 0; k--) { g = push_sign(g, e[k]); hh = push_sign(hh, f[k]); }
-	const unsigned gd = g | (g << 16), hd = hh | (hh << 16);
-	const unsigned g1 = __builtin_amdgcn_alignbit(gd, gd, 1); // g[i + 1] at bit i
-	PsWords w;
-	w.up = (gd & g1) | (~gd & hd);
-	w.dn = ~(gd | hd);
-	const unsigned x = hs.d3 ^ hs.d4; // nDelay = 3 (Model.cpp:560-561): decisions of 3 and 4 symbols ago
-	w.x = x | (x << 16);
-	hs.d4 = hs.d3; hs.d3 = hs.d2; hs.d2 = hs.d1; hs.d1 = ps_lane_decisions(T);
-	return w;
-}
-
-constexpr int PSL_BATCH = 8;
-
-template <int N>
-__device__ __forceinline__ void ps_lane_load(const SymRow& x, int g, c2 (&v)[N]) { // g even
-#pragma unroll
-	for (int e = 0; e < N; e += 2) {
-		const float4 t = *x.pair(g + e);
-		v[e] = c2{ t.x, t.y }; v[e + 1] = c2{ t.z, t.w };
-	}
-}
-
-__device__ __forceinline__ void ps_walk_body(const K4Params& p, int wave);
-
-// grid (chains / 64, chunks [+ 1]): the extra row of workgroups, if any, walks the PREVIOUS block (parameter block w)
-__global__ __launch_bounds__(64) void k4_lane_chunks(K4Params p, K4Params w) {
-	// (the walk's workgroups come FIRST in dispatch order: they are the longest-running ones)
-	const int has_walk = (int)gridDim.y - p.n_lchunks;
-	if (has_walk && blockIdx.y == 0) { ps_walk_body(w, blockIdx.x); return; }
-	const int lane = threadIdx.x;
-	const int chain_raw = blockIdx.x * 64 + lane;
-	const bool live = chain_raw < p.n_chains;
-	const int chain = live ? chain_raw : p.n_chains - 1;
-	const int chunk = (int)blockIdx.y - has_walk;
-	const int g0 = chunk * p.cl;
-	const int g1 = g0 + p.cl < p.n_groups ? g0 + p.cl : p.n_groups;
-	if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
-	else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
-	else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
-	const SymRow x(p.sym, chain, p.sym_stride);
-	// three planes (up, dn, x), time-major in groups of four symbols: uint4 [plane][g / 4][ma_stride]: this kernel's
-	// stores and k4_walk's loads are whole 1 KiB rows per wave
-	const size_t plane = (size_t)p.lw_quads * p.ma_stride;
-	uint4* lw_up = reinterpret_cast<uint4*>(p.lw) + chain_raw;
-	uint4* lw_dn = lw_up + plane;
-	uint4* lw_x = lw_dn + plane;
-	const size_t mslot = (size_t)chunk * 16 * p.ma_stride + chain_raw; // [chunk][k][chain]
-	const EmaState* s0 = p.state_in + chain;
-
-	PsLane st;
-	PsHist hs;
-	int ws = g0 - p.warm;
-	if (ws <= 0) { // the true state, replayed exactly from the block start (always so for chunk 0)
-		ws = 0;
-#pragma unroll
-		for (int j = 0; j < 8; j++) st.P[j] = c2{ s0->ma[j], s0->ma[15 - j] };
-	} else {
-#pragma unroll
-		for (int j = 0; j < 8; j++) st.P[j] = c2{ 0.0f, 0.0f };
-	}
-	if (g0 == 0) {
-		hs.d1 = hs.d2 = hs.d3 = hs.d4 = 0;
-#pragma unroll
-		for (int k = 0; k < 16; k++) {
-			const unsigned b = s0->bits[k]; // bit j: decision of j + 1 symbols ago
-			hs.d1 |= (b & 1u) << k; hs.d2 |= ((b >> 1) & 1u) << k; hs.d3 |= ((b >> 2) & 1u) << k; hs.d4 |= ((b >> 3) & 1u) << k;
-		}
-	} else {
-		// warm-up: EMA only (warm and cl are multiples of 8 symbols) ...
-#pragma unroll 1
-		for (int g = ws; g < g0 - PSL_BATCH; g += PSL_BATCH) {
-			c2 v[PSL_BATCH];
-			ps_lane_load(x, g, v);
-#pragma unroll
-			for (int e = 0; e < PSL_BATCH; e++) { c2 T[8]; ps_lane_ema(v[e], st, T); __builtin_amdgcn_sched_barrier(0); }
-		}
-		// ... and the decisions of its last four symbols
-		c2 v[PSL_BATCH];
-		ps_lane_load(x, g0 - PSL_BATCH, v);
-		unsigned dd[4];
-#pragma unroll
-		for (int e = 0; e < PSL_BATCH; e++) {
-			c2 T[8];
-			ps_lane_ema(v[e], st, T);
-			if (e >= PSL_BATCH - 4) dd[e - (PSL_BATCH - 4)] = ps_lane_decisions(T);
-			__builtin_amdgcn_sched_barrier(0);
-		}
-		hs.d1 = dd[3]; hs.d2 = dd[2]; hs.d3 = dd[1]; hs.d4 = dd[0];
-	}
-	{ // (unconditional stores: padded columns exist for dead lanes)
-#pragma unroll
-		for (int j = 0; j < 8; j++) {
-			p.ma_start[mslot + (size_t)j * p.ma_stride] = st.P[j].x;
-			p.ma_start[mslot + (size_t)(15 - j) * p.ma_stride] = st.P[j].y;
-		}
-	}
-	const int n = g1 - g0;
-	const int nb = n - (n % PSL_BATCH);
-	c2 cur[PSL_BATCH];
-	if (nb > 0) ps_lane_load(x, g0, cur);
-#pragma unroll 1
-	for (int q = 0; q < nb; q += PSL_BATCH) {
-		c2 nxt[PSL_BATCH];
-		const int qn = q + PSL_BATCH < nb ? q + PSL_BATCH : q; // next batch in flight while this one is processed
-		ps_lane_load(x, g0 + qn, nxt);
-		PsWords wd[PSL_BATCH];
-#pragma unroll
-		for (int e = 0; e < PSL_BATCH; e++) {
-			c2 T[8];
-			ps_lane_ema(cur[e], st, T);
-			wd[e] = ps_lane_words(st, T, hs);
-			__builtin_amdgcn_sched_barrier(0); // one symbol at a time: interleaving all eight costs 440 registers
-		}
-		// (unconditional: a branch here would let the compiler sink the sign collection of all eight symbols behind it
-		// and keep 400 floats alive)
-#pragma unroll
-		for (int e = 0; e < PSL_BATCH; e += 4) {
-			const size_t row = (size_t)((g0 + q + e) >> 2) * p.ma_stride;
-			lw_up[row] = make_uint4(wd[e].up, wd[e + 1].up, wd[e + 2].up, wd[e + 3].up);
-			lw_dn[row] = make_uint4(wd[e].dn, wd[e + 1].dn, wd[e + 2].dn, wd[e + 3].dn);
-			lw_x[row] = make_uint4(wd[e].x, wd[e + 1].x, wd[e + 2].x, wd[e + 3].x);
-		}
-#pragma unroll
-		for (int e = 0; e < PSL_BATCH; e++) cur[e] = nxt[e];
-	}
-#pragma unroll 1
-	for (int q = nb; q < n; q++) {
-		const float2 t = x[g0 + q];
-		c2 T[8];
-		ps_lane_ema(c2{ t.x, t.y }, st, T);
-		const PsWords wd = ps_lane_words(st, T, hs);
-		const size_t row = (size_t)((g0 + q) >> 2) * p.ma_stride;
-		const int sub = (g0 + q) & 3;
-		reinterpret_cast<unsigned*>(lw_up + row)[sub] = wd.up;
-		reinterpret_cast<unsigned*>(lw_dn + row)[sub] = wd.dn;
-		reinterpret_cast<unsigned*>(lw_x + row)[sub] = wd.x;
-	}
-	{
-#pragma unroll
-		for (int j = 0; j < 8; j++) {
-			p.ma_fin[mslot + (size_t)j * p.ma_stride] = st.P[j].x;
-			p.ma_fin[mslot + (size_t)(15 - j) * p.ma_stride] = st.P[j].y;
-		}
-	}
-	if (live && g1 == p.n_groups) { // the block's last chunk leaves the float state and the decision history
-		EmaState* sto = p.state_out + chain;
-#pragma unroll
-		for (int j = 0; j < 8; j++) { sto->ma[j] = st.P[j].x; sto->ma[15 - j] = st.P[j].y; }
-#pragma unroll
-		for (int k = 0; k < 16; k++) // only the last four decisions can ever be read again
-			sto->bits[k] = ((hs.d1 >> k) & 1u) | (((hs.d2 >> k) & 1u) << 1) | (((hs.d3 >> k) & 1u) << 2) | (((hs.d4 >> k) & 1u) << 3);
-	}
-}
-
-// k4_walk: the integer recurrence max_idx -> output bit, one lane per chain, strictly sequential over the block.  Per symbol
-// the dependent chain is two bit-field extracts and one three-operand add (max_idx is kept unreduced: the extracts use
-// its low five bits and the words repeat every 16); the output bit costs one more extract and one shift-or.
-#ifndef WALK_B_
-#define WALK_B_ 16
-#endif
-constexpr int WALK_B = WALK_B_; // symbols per register batch (16 or 32)
-
-struct WalkBuf { uint4 up[WALK_B / 4], dn[WALK_B / 4], x[WALK_B / 4]; };
-
-__device__ __forceinline__ void walk_load(WalkBuf& b, const uint4* lw, size_t plane, long long stride, int g, int n) {
-	const int last = (n - 1) >> 2;
-#pragma unroll
-	for (int e = 0; e < WALK_B / 4; e++) {
-		int gq = (g >> 2) + e;
-		gq = gq < last ? gq : last; // wave-uniform clamp: batches past the end re-read the last group and are not used
-		const uint4* src = lw + (size_t)gq * stride;
-		b.up[e] = src[0]; b.dn[e] = src[plane]; b.x[e] = src[2 * plane];
-	}
-}
-
-__device__ __forceinline__ unsigned u4_get(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
-
-template <bool GUARD>
-__device__ __forceinline__ uint32_t walk_batch(const WalkBuf& b, int q, int n, int& idx) {
-	uint32_t part = 0;
-#pragma unroll
-	for (int e = 0; e < WALK_B; e++) {
-		if (!GUARD || q + e < n) { // wave-uniform
-			const unsigned up = u4_get(b.up[e >> 2], e & 3), dn = u4_get(b.dn[e >> 2], e & 3), xx = u4_get(b.x[e >> 2], e & 3);
-			idx = idx + (int)__builtin_amdgcn_ubfe(up, (unsigned)idx, 1u) + __builtin_amdgcn_sbfe((int)dn, (unsigned)idx, 1u);
-			part |= __builtin_amdgcn_ubfe(xx, (unsigned)idx, 1u) << e;
-		}
-	}
-	return part;
-}
-
-// speculative warm-ups: chunk c must have started from exactly the values chunk c-1 ended with; any difference raises
-// p.flag and the exact sequential kernel recomputes the block
-__global__ __launch_bounds__(256) void k4_verify(K4Params p) {
-	const size_t per_chunk = (size_t)16 * p.ma_stride;
-	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-	if (i >= per_chunk * (size_t)(p.n_lchunks - 1)) return;
-	const int chain = (int)(i % (size_t)p.ma_stride);
-	const bool bad = chain < p.n_chains && __float_as_uint(p.ma_start[per_chunk + i]) != __float_as_uint(p.ma_fin[i]);
-	if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(p.flag, 1);
-}
-
-__device__ __forceinline__ void ps_walk_body(const K4Params& p, int wave) {
-	const int lane = threadIdx.x;
-	const int chain_raw = wave * 64 + lane;
-	const bool live = chain_raw < p.n_chains;
-	const int chain = live ? chain_raw : p.n_chains - 1;
-	const EmaState* st = p.state_in + chain;
-	EmaState* sto = p.state_out + chain;
-	const uint4* lw = reinterpret_cast<const uint4*>(p.lw) + chain_raw;
-	const size_t plane = (size_t)p.lw_quads * p.ma_stride;
-	const int n = p.n_groups;
-	if (*p.flag != 0) return; // the exact sequential kernel has produced this block
-	if (p.prio_walk == 3) __builtin_amdgcn_s_setprio(3);
-	else if (p.prio_walk == 2) __builtin_amdgcn_s_setprio(2);
-	else if (p.prio_walk == 1) __builtin_amdgcn_s_setprio(1);
-	WalkBuf b0, b1;
-	walk_load(b0, lw, plane, p.ma_stride, 0, n);
-	walk_load(b1, lw, plane, p.ma_stride, WALK_B, n);
-	int idx = st->max_idx;
-	uint32_t* out = p.bits + (size_t)chain * p.bits_stride;
-	// (WALK_B == 16: two batches make one output word; WALK_B == 32: one batch does)
-	auto put = [&](int q0, uint32_t v) {
-		if (WALK_B == 32) { if (live) out[q0 >> 5] = v; }
-		else if (live) reinterpret_cast<uint16_t*>(out)[q0 >> 4] = (uint16_t)v;
-	};
-	int q = 0;
-#pragma unroll 1
-	for (; q + 2 * WALK_B <= n; q += 2 * WALK_B) {
-		uint32_t v = walk_batch<false>(b0, q, n, idx);
-		walk_load(b0, lw, plane, p.ma_stride, q + 2 * WALK_B, n);
-		put(q, v);
-		v = walk_batch<false>(b1, q + WALK_B, n, idx);
-		walk_load(b1, lw, plane, p.ma_stride, q + 3 * WALK_B, n);
-		put(q + WALK_B, v);
-	}
-	if (q < n) { const uint32_t v = walk_batch<true>(b0, q, n, idx); put(q, v); }
-	if (q + WALK_B < n) { const uint32_t v = walk_batch<true>(b1, q + WALK_B, n, idx); put(q + WALK_B, v); }
-	if (live) {
-		sto->max_idx = idx & 15;
-		sto->rot = (st->rot + p.n_groups) & 3;
-	}
-}
-
-__global__ __launch_bounds__(64) void k4_walk(K4Params p) { ps_walk_body(p, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------
 // K5: ModelChallenger's non-coherent branch (DSP/Model.cpp:638-639): Demod::FM (DSP/Demod.cpp:27-37) ->
@@ -4061,64 +2929,14 @@ __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-template <int K, int P, int D, int NT, bool CU8, bool PRE>
-static hipError_t launch_k1_t(const K1Params& p, int spans, int n_rx, hipStream_t s) {
-	static bool attr_set = false;
-	constexpr int bytes = K1Cfg<K, P, NT>::bytes;
-	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute((const void*)k1_frontend<K, P, D, NT, CU8, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-		if (e != hipSuccess) return e;
-		attr_set = true;
-	}
-	hipLaunchKernelGGL((k1_frontend<K, P, D, NT, CU8, PRE>), dim3(spans, n_rx), dim3(NT), bytes, s, p);
-	return hipGetLastError();
-}
-
-template <int P, int D, int NT>
-static hipError_t launch_k1_p(const K1Params& p, int K, bool cu8, int spans, int n_rx, hipStream_t s) {
-	const bool pre = p.pre_out != nullptr;
-	switch (K * 4 + (cu8 ? 2 : 0) + (pre ? 1 : 0)) {
-	case 16: return launch_k1_t<4, P, D, NT, false, false>(p, spans, n_rx, s);
-	case 17: return launch_k1_t<4, P, D, NT, false, true>(p, spans, n_rx, s);
-	case 18: return launch_k1_t<4, P, D, NT, true, false>(p, spans, n_rx, s);
-	case 19: return launch_k1_t<4, P, D, NT, true, true>(p, spans, n_rx, s);
-	case 12: return launch_k1_t<3, P, D, NT, false, false>(p, spans, n_rx, s);
-	case 13: return launch_k1_t<3, P, D, NT, false, true>(p, spans, n_rx, s);
-	case 14: return launch_k1_t<3, P, D, NT, true, false>(p, spans, n_rx, s);
-	case 15: return launch_k1_t<3, P, D, NT, true, true>(p, spans, n_rx, s);
-	case 8: return launch_k1_t<2, P, D, NT, false, false>(p, spans, n_rx, s);
-	case 9: return launch_k1_t<2, P, D, NT, false, true>(p, spans, n_rx, s);
-	case 10: return launch_k1_t<2, P, D, NT, true, false>(p, spans, n_rx, s);
-	case 11: return launch_k1_t<2, P, D, NT, true, true>(p, spans, n_rx, s);
-	case 4: return launch_k1_t<1, P, D, NT, false, false>(p, spans, n_rx, s);
-	case 5: return launch_k1_t<1, P, D, NT, false, true>(p, spans, n_rx, s);
-	case 6: return launch_k1_t<1, P, D, NT, true, false>(p, spans, n_rx, s);
-	case 7: return launch_k1_t<1, P, D, NT, true, true>(p, spans, n_rx, s);
-	}
-	return hipErrorInvalidValue;
-}
-
-// Occupancy cap of the front end: its one-wave workgroups use ~10 KB of LDS and ~120 VGPRs, so four of them fit a SIMD and
-// leave 32 VGPRs -- room for exactly one wave of anything else.  Padding the LDS allocation (unused dynamic shared memory)
-// caps it at 3 (or 2) per SIMD; the kernel itself is as fast with 3 as with 4 (HBM-bound), and the back end gets wave slots.
-static int k1_lds_pad() {
-	static int pad = -1;
-	if (pad < 0) {
-		const char* e = getenv("AISGPU_K1_PER_SIMD");
-		const int per = e ? atoi(e) : 4;
-		pad = per == 3 ? 2700 : per == 2 ? 8400 : per == 1 ? 24000 : 0;
-	}
-	return pad;
-}
-
 // The events of a front-end launch ride on the dispatch packet itself (hipExtLaunchKernelGGL binds them to the kernel command):
 // "the front end of block f is done" -- what the phasor recurrence's stream waits for -- and the two time stamps of the roofline
 // measurement then cost no barrier packets between two launches of the front stream (0.03 ms per step of 0.48).
 struct K1Events { hipEvent_t start = nullptr, stop = nullptr; };
 #define K1_LAUNCH(kernel_, ev_, grid_, s_, p_) \
 	do { \
-		if ((ev_).start || (ev_).stop) hipExtLaunchKernelGGL(kernel_, grid_, dim3(64), k1_lds_pad(), s_, (ev_).start, (ev_).stop, 0, p_); \
-		else hipLaunchKernelGGL(kernel_, grid_, dim3(64), k1_lds_pad(), s_, p_); \
+		if ((ev_).start || (ev_).stop) hipExtLaunchKernelGGL(kernel_, grid_, dim3(64), 0, s_, (ev_).start, (ev_).stop, 0, p_); \
+		else hipLaunchKernelGGL(kernel_, grid_, dim3(64), 0, s_, p_); \
 	} while (0)
 
 template <int K, int FMT>
@@ -4156,21 +2974,9 @@ static hipError_t launch_k1_dpp(const K1Params& p, int K, int fmt, int spans, in
 	return hipErrorInvalidValue;
 }
 
-// tile96: samples at the kernel's output rate per tile; depth: tiles prefetched ahead; threads: workgroup size
-// (256, or 64 = one autonomous wave per workgroup)
-hipError_t launch_k1(const K1Params& p, int K, int fmt, int tile96, int depth, int threads, int spans, int n_rx, hipStream_t s, hipEvent_t ev_start,
-                     hipEvent_t ev_stop) {
+hipError_t launch_k1(const K1Params& p, int K, int fmt, int spans, int n_rx, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
 	K1Events ev; ev.start = ev_start; ev.stop = ev_stop;
-	if (depth == 0) return launch_k1_dpp(p, K, fmt, spans, n_rx, s, ev); // register (DPP) variant: 64 threads, tile96 = 64
-	if (ev_start || ev_stop) return hipErrorInvalidValue; // (bound events: the register variant only)
-	if (fmt > 1) return hipErrorInvalidValue; // the LDS-staged variants read CF32 and CU8 (float ladder) only
-	const bool cu8 = fmt == 1;
-	switch (threads * 10000 + tile96 * 10 + depth) {
-	case 2562562: return launch_k1_p<256, 2, 256>(p, K, cu8, spans, n_rx, s);
-	case 640641: return launch_k1_p<64, 1, 64>(p, K, cu8, spans, n_rx, s);
-	case 640642: return launch_k1_p<64, 2, 64>(p, K, cu8, spans, n_rx, s);
-	}
-	return hipErrorInvalidValue;
+	return launch_k1_dpp(p, K, fmt, spans, n_rx, s, ev);
 }
 
 hipError_t launch_k1u(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
@@ -4305,13 +3111,10 @@ hipError_t launch_k7_mesh(const K7Params& p, hipStream_t s) {
 hipError_t launch_k7e(const K7eParams& q, hipStream_t s) {
 	const int n_dec = q.k.n_chan * (q.k.kind == 2 ? 10 : 5);
 	if (q.k.n_groups <= 0) return hipSuccess;
-	static const int skip = getenv("AISGPU_K7E_SKIP") ? atoi(getenv("AISGPU_K7E_SKIP")) : 0; // experiments only (1 scan, 2 sim, 4 resolve: results wrong)
-	if (!(skip & 1)) hipLaunchKernelGGL(k7e_scan, dim3((n_dec + 3) / 4), dim3(64), 0, s, q);
-	if (!(skip & 2)) hipLaunchKernelGGL(k7e_sim, dim3((n_dec * K7E_SIM_LANES + 63) / 64), dim3(64), 0, s, q);
-	if (!(skip & 4)) {
-		if (q.k.kind == 2) hipLaunchKernelGGL((k7e_resolve<10, 16>), dim3((q.k.n_chan + 3) / 4), dim3(64), 0, s, q);
-		else hipLaunchKernelGGL((k7e_resolve<5, 8>), dim3((q.k.n_chan + 7) / 8), dim3(64), 0, s, q);
-	}
+	hipLaunchKernelGGL(k7e_scan, dim3((n_dec + 3) / 4), dim3(64), 0, s, q);
+	hipLaunchKernelGGL(k7e_sim, dim3((n_dec * K7E_SIM_LANES + 63) / 64), dim3(64), 0, s, q);
+	if (q.k.kind == 2) hipLaunchKernelGGL((k7e_resolve<10, 16>), dim3((q.k.n_chan + 3) / 4), dim3(64), 0, s, q);
+	else hipLaunchKernelGGL((k7e_resolve<5, 8>), dim3((q.k.n_chan + 7) / 8), dim3(64), 0, s, q);
 	return hipGetLastError();
 }
 
@@ -4323,7 +3126,7 @@ hipError_t launch_k5(const K5Params& p, int n_chan, hipStream_t s) {
 }
 
 hipError_t launch_k4_box(const K4Params& p, hipStream_t s) {
-	if (p.n_chunks > 1 && p.streams != 0) { // chunk-parallel: exact by construction (16 symbols of look-back), k4_assemble picks the trajectories
+	if (p.n_chunks > 1 && p.chunked) { // chunk-parallel: exact by construction (16 symbols of look-back), k4_assemble picks the trajectories
 		K4Params q = p;
 		q.qflag = nullptr;
 		hipLaunchKernelGGL(k4_box_chunks, dim3((p.n_chains / 5 + 3) / 4 * 5, p.n_chunks), dim3(64), 0, s, q);
@@ -4346,43 +3149,9 @@ hipError_t launch_k4(const K4Params& p, hipStream_t s) {
 		hipError_t e = hipMemsetAsync(p.flag, 0, sizeof(int), s);
 		if (e != hipSuccess) return e;
 	}
-	if (p.streams == 2) hipLaunchKernelGGL(k4_phase_chunks2, dim3((p.n_chains / 5 + 7) / 8 * 5, p.n_chunks), dim3(64), 0, s, p);
-	else hipLaunchKernelGGL(k4_phase_chunks, dim3((p.n_chains / 5 + 3) / 4 * 5, p.n_chunks), dim3(64), 0, s, p);
+	hipLaunchKernelGGL(k4_phase_chunks, dim3((p.n_chains / 5 + 3) / 4 * 5, p.n_chunks), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(k4_assemble, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(k4_phase_search, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p, 1); // exits at once unless flagged
-	return hipGetLastError();
-}
-
-hipError_t launch_k46(const K46Params& p, hipStream_t s) {
-	const int n_quads = (p.n_chan + 3) / 4;
-	hipLaunchKernelGGL(k46_fir_phase_chunks, dim3(n_quads, p.k4.n_chunks), dim3(320), 0, s, p);
-	hipLaunchKernelGGL(k4_assemble, dim3((p.k4.n_chains + 3) / 4), dim3(64), 0, s, p.k4);
-	K46Params f = p;
-	f.sequential = 1;
-	hipLaunchKernelGGL(k46_fir_phase_chunks, dim3(n_quads, 1), dim3(320), 0, s, f); // exits at once unless flagged
-	return hipGetLastError();
-}
-hipError_t launch_k2b_ck8(const K2Params& p, float2* ck8, int n_chan, hipStream_t s) {
-	hipLaunchKernelGGL(k2_cgf_phasor_ck8, dim3((n_chan + 63) / 64), dim3(64), 0, s, p, ck8);
-	return hipGetLastError();
-}
-
-// lane-per-chunk PhaseSearchEMA in three parts, so that the latency-bound walk can run on another stream (CUs of its own):
-// (a) sign words + verification, (b) the exact sequential kernel if the verification failed, (c) the walk (skips when (b) ran)
-hipError_t launch_k4_lane_words(const K4Params& p, const K4Params* walk_prev, hipStream_t s) {
-	hipError_t e = hipMemsetAsync(p.flag, 0, sizeof(int), s);
-	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(k4_lane_chunks, dim3((p.n_chains + 63) / 64, p.n_lchunks + (walk_prev ? 1 : 0)), dim3(64), 0, s, p, walk_prev ? *walk_prev : p);
-	const size_t n_cmp = (size_t)16 * p.ma_stride * (p.n_lchunks - 1);
-	if (n_cmp > 0) hipLaunchKernelGGL(k4_verify, dim3((unsigned)((n_cmp + 255) / 256)), dim3(256), 0, s, p);
-	return hipGetLastError();
-}
-hipError_t launch_k4_fallback(const K4Params& p, hipStream_t s) {
-	hipLaunchKernelGGL(k4_phase_search, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p, 1); // exits at once unless flagged
-	return hipGetLastError();
-}
-hipError_t launch_k4_walk(const K4Params& p, hipStream_t s) {
-	hipLaunchKernelGGL(k4_walk, dim3((p.n_chains + 63) / 64), dim3(64), 0, s, p);
 	return hipGetLastError();
 }
 

@@ -33,6 +33,7 @@ EXPORTS = (
     "aisgpu_run", "aisgpu_sync_outputs", "aisgpu_sync", "aisgpu_fetch", "aisgpu_tap", "aisgpu_stream",
     "aisgpu_frontend_ms", "aisgpu_timing", "aisgpu_strerror", "aisgpu_last_error", "aisgpu_device_count",
     "aisgpu_out_count", "aisgpu_fetch_sub", "aisgpu_selftest", "aisgpu_frames", "aisgpu_ps_fallbacks", "aisgpu_decoder_fallbacks",
+    "aisgpu_set_option",
 )
 
 
@@ -108,11 +109,28 @@ def load():
     lib.aisgpu_last_error.argtypes = [vp]
     lib.aisgpu_last_error.restype = ctypes.c_char_p
     lib.aisgpu_device_count.restype = ci
+    if hasattr(lib, "aisgpu_set_option"):
+        lib.aisgpu_set_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
     if hasattr(lib, "aisgpu_selftest"):  # absent from older builds used in A/B runs (AISGPU_LIB)
         lib.aisgpu_selftest.argtypes = [ci, ci, vp, cll]
         lib.aisgpu_selftest.restype = cll
     _lib = lib
     return lib
+
+
+# Test hooks of the library (include/aisgpu.h: aisgpu_set_option).  The shipped .so reads no environment variable; for the
+# tests' convenience THIS wrapper forwards AISGPU_<KEY> from the environment to the option of the same name before a context
+# is created (monkeypatch.setenv("AISGPU_PS_WARM", "16") in a test selects the exact-fallback path).
+OPTION_KEYS = ("serial", "ps_warm", "ps_sequential", "k7", "fused", "fft_in_k1")
+
+
+def apply_env_options(lib=None):
+    lib = lib or load()
+    if not hasattr(lib, "aisgpu_set_option"):
+        return
+    for key in OPTION_KEYS:
+        v = os.environ.get("AISGPU_" + key.upper())
+        lib.aisgpu_set_option(key.encode(), v.encode() if v else None)
 
 
 class AisGpuError(RuntimeError):
@@ -126,6 +144,7 @@ class AisGpu:
                  afc_wide=True, droop=True, device_id=0, taps=False, tiles_per_span=0, serial=False, model=MODEL_DEFAULT,
                  dsk=False, ps_ema=True, gpu_decode=False, fp_ds=False, mode_x=False, ma=False):
         self.lib = load()
+        apply_env_options(self.lib)
         cfg = Cfg()
         self.lib.aisgpu_default_cfg(ctypes.byref(cfg))
         cfg.sample_rate, cfg.n_receivers, cfg.block_len = sample_rate, n_receivers, block_len

@@ -62,6 +62,7 @@ class Batch:
         if gpu_decode:
             cfg.flags |= _gpu.FLAG_GPU_DECODE
         err = ctypes.create_string_buffer(512)
+        _gpu.apply_env_options()  # (test hooks: AISGPU_<KEY> of the environment -> aisgpu_set_option; the library itself reads none)
         self.h = lib.aishost_batch_create(ctypes.byref(cfg), err, 512)
         if not self.h:
             raise RuntimeError(err.value.decode())
@@ -90,6 +91,7 @@ class ModelDefaultGPU:
         self.lib = load()
         err = ctypes.create_string_buffer(512)
         self.fmt = input_format
+        _gpu.apply_env_options()
         self.h = self.lib.aishost_model_create(batch.h if batch else None, rx, sample_rate, block_len, input_format,
                                                ch1.encode(), ch2.encode(), 1 if detached else 0, model | (0x100 if gpu_decode else 0) | (0x200 if fp_ds else 0) | (0x400 if mode_x else 0) | (0x800 if ma else 0), err, 512)
         if not self.h:

@@ -58,8 +58,9 @@ void* aishost_model_create(void* batch, int rx, int sample_rate, int block_len, 
 		m->m.setEngineV2((model & 0xff) == AISGPU_MODEL_V2);
 		m->m.setGpuDecode((model & 0x100) != 0);
 		m->m.setModeX((model & 0x400) != 0);      // bit 10: channel mode X
+		// (bit 8 of `model`: AISGPU_FLAG_GPU_DECODE for a stand-alone receiver)  FP_DS first: like the reference's SetKey, it clears MA
+		m->m.setFixedPoint((model & 0x200) != 0);    // bit 9: AISGPU_FLAG_FP_DS
 		m->m.setMovingAverage((model & 0x800) != 0); // bit 11: AISGPU_FLAG_MA_DS (`-go MA on`)
-		m->m.setFixedPoint((model & 0x200) != 0); // bit 9: AISGPU_FLAG_FP_DS for a stand-alone receiver // bit 8 of `model`: AISGPU_FLAG_GPU_DECODE for a stand-alone receiver
 		if (batch) m->m.useBatch((GpuBatch*)batch, rx);
 		if (!detached) m->m.buildModel(ch1, ch2, sample_rate, false, nullptr);
 		else m->m.wireDecoders(ch1, ch2); // no GPU context

@@ -17,7 +17,6 @@ GpuBatch::GpuBatch(const aisgpu_cfg& c) : cfg(c) {
 	active = cfg.n_receivers;
 	present.assign(cfg.n_receivers, 0);
 	gone.assign(cfg.n_receivers, 0);
-	if (const char* e = getenv("AISGPU_BATCH_TIMEOUT_MS")) timeout_ms = atoi(e);
 }
 
 GpuBatch::~GpuBatch() { aisgpu_destroy(ctx); }

@@ -204,7 +204,7 @@ public:
 	void setOwnMMSI(int m) { own_mmsi = m; }
 	void setAFCWide(bool b) { CGF_wide = b; }
 	void setDroop(bool b) { droop_compensation = b; }
-	void setFixedPoint(bool b) { fixedpointDS = b; if (b) MA_DS = false; }
+	void setFixedPoint(bool b) { fixedpointDS = b; MA_DS = false; } // KEY_SETTING_FP_DS clears MA_DS whatever its argument (Model.cpp:362-365)
 	void setMovingAverage(bool b) { MA_DS = b; }
 	void setModeX(bool b) { mode_x = b; }          // AIS::Model::setMode(Mode::X) (DSP/Model.h:104, Receiver.cpp:87-98): one channel, 12k .. 192k
 	void setChallenger(bool b) { challenger = b; } // AIS::ModelChallenger wiring (Model.cpp:601-678) instead of ModelDefault

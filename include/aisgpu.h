@@ -88,7 +88,7 @@ typedef struct aisgpu_cfg {
 	                    * 24576 * bucket/288000 (whole 8192-sample output blocks of the filter) */
 	int n_receivers;   /* independent dual-channel receiver instances batched on this GPU */
 	int block_len;     /* IQ samples per receiver per Receive() block; multiple of 512 * bucket_rate/48000 */
-	int model;         /* AISGPU_MODEL_BASE, AISGPU_MODEL_DEFAULT or AISGPU_MODEL_CHALLENGER */
+	int model;         /* AISGPU_MODEL_STANDARD, _BASE, _DEFAULT, _CHALLENGER or _V2 */
 	int input_format;  /* AISGPU_FMT_* */
 	int afc_wide;      /* KEY_SETTING_AFC_WIDE (default on, Model.cpp:536-540) */
 	int droop;         /* KEY_SETTING_DROOP    (default on, Model.cpp:223-229) */
@@ -159,7 +159,8 @@ int aisgpu_out_count(aisgpu_t* h);
  * previous aisgpu_sync_outputs() -- i.e. during the last aisgpu_run() when every run is followed by one (replaces feeding aisgpu_out's decisions to AIS::Decoder::Receive, Marine/AIS.h:82-181).  What is left
  * for the caller is AIS::Decoder::processData's tail (Marine/AIS.cpp:66-96): tag.level = level_sum / position (and its dB
  * conversion), Message::validate, buildNMEA.  Sorted the way the reference emits: by receiver, then downstream block,
- * channel A before channel B, group, phase.  Valid after aisgpu_sync_outputs() until the next aisgpu_run(). */
+ * channel A before channel B, group, phase.  Valid after aisgpu_sync_outputs() until the next aisgpu_sync_outputs() (the array is
+ * host memory of the context that only that call rewrites: a pipelined caller reads it while the next aisgpu_run() is in flight). */
 typedef struct aisgpu_frame {
 	int rx, ch, phase, sub;   /* receiver, channel 0/1, decoder DEC_x[phase] (5..9: ModelChallenger's FM decoders DEC_xf[phase - 5]), downstream block of this run */
 	int group;                /* group (symbol index of the phase chain) inside that block whose bit completed the closing flag (ModelBase: the 48 kHz sample) */
@@ -173,7 +174,7 @@ int aisgpu_frames(aisgpu_t* h, const aisgpu_frame** frames, int* count);
 /* Statistics of the chunk-parallel PhaseSearchEMA (reference DSP/Demod.cpp:39-101): the number of workgroups (four chains each) whose
  * speculative warm-up did not reproduce the sequential EMA bit for bit and that therefore went through the exact sequential kernel,
  * summed over the blocks completed so far (call it behind aisgpu_sync_outputs()).  Results are bit-exact either way; the count says
- * how often the slow path ran (an extreme level step of a receiver; AISGPU_PS_WARM sets the warm-up length, default 256 symbols). */
+ * how often the slow path ran (an extreme level step of a receiver; option "ps_warm" sets the warm-up length, default 256 symbols). */
 int aisgpu_ps_fallbacks(aisgpu_t* h, long long* count);
 
 /* AISGPU_FLAG_GPU_DECODE, event-driven decoder kernels (ModelDefault / ModelStandard / ModelChallenger): the number of blocks that went
@@ -197,6 +198,18 @@ void* aisgpu_stream(aisgpu_t* h);
  * measured with HIP events on the context's stream; *launches receives the count */
 float aisgpu_frontend_ms(aisgpu_t* h, int* launches);
 void aisgpu_timing(aisgpu_t* h, int enable);
+
+/* Test hooks: process-wide options read by aisgpu_create() (value NULL or "" removes one).  None of them changes a result; they
+ * select an alternative -- equally exact -- code path so that the tests can reach it.  The release library reads no environment
+ * variable (a -DAISGPU_EXPERIMENTS build also accepts AISGPU_<KEY>).  Keys:
+ *   "serial"        1: like AISGPU_FLAG_SERIAL
+ *   "ps_warm"       warm-up length of the speculative PhaseSearchEMA chunks in symbols (small values force the exact fallback)
+ *   "ps_sequential" 1: the sequential PhaseSearch row kernels only
+ *   "k7"            "seq": symbol-by-symbol device decoders; "alt": event-driven and sequential kernels alternate block by block
+ *   "fused"         0: the materialised back end (phasor / derotated-sample arrays in HBM: what AISGPU_FLAG_TAPS uses)
+ *   "fft_in_k1"     0: the spectral analysis as FFT + search kernels instead of inside the front-end waves
+ * Returns AISGPU_ERR_ARG for an unknown key. */
+int aisgpu_set_option(const char* key, const char* value);
 
 const char* aisgpu_strerror(int code);
 const char* aisgpu_last_error(aisgpu_t* h);

@@ -170,11 +170,9 @@ def test_edge_inputs():
     _run_gpu_vs_oracle([cu], 1536000, "cu8", 16384, 4)
 
 
-def test_edge_inputs_through_the_chunked_phase_search(monkeypatch):
-    """Blocks long enough for the lane-per-chunk PhaseSearchEMA (sign words + integer walk), with chunks shorter than
-    the warm-up: exact zeros (t == +-0 must count as "not > 0"), DC, alternating full scale, 10^22 dynamic range."""
-    monkeypatch.setenv("AISGPU_K4", "lane")
-    monkeypatch.setenv("AISGPU_PS_CL", "128")
+def test_edge_inputs_through_the_chunked_phase_search():
+    """Blocks long enough for the chunk-parallel PhaseSearchEMA (several chunks per block, speculative warm-ups that are verified):
+    exact zeros (t == +-0 must count as "not > 0"), DC, alternating full scale, 10^22 dynamic range."""
     n = 131072 * 3
     rng = np.random.default_rng(11)
     zero = np.zeros(n, np.complex64)
@@ -294,16 +292,13 @@ def test_nmea_batched_receivers_on_threads():
     batch.close()
 
 
-@pytest.mark.parametrize("env", [{"AISGPU_PS_WARM": "16"}, {"AISGPU_PS_SEQUENTIAL": "1"}, {"AISGPU_SERIAL": "1"},
-                                 {"AISGPU_K4": "lane"}, {"AISGPU_K4": "lane", "AISGPU_PS_WARM": "16"},
-                                 {"AISGPU_K4": "lane", "AISGPU_WALK_RIDE": "0"}, {"AISGPU_K4": "lane", "AISGPU_SERIAL": "1"},
-                                 {"AISGPU_K4": "lane", "AISGPU_PS_CL": "128"}, {"AISGPU_K4": "lane", "AISGPU_PS_CL": "1024"},
-                                 {"AISGPU_K4": "lane", "AISGPU_PS_CL": "4096"}])
+@pytest.mark.parametrize("env", [{"AISGPU_PS_WARM": "16"}, {"AISGPU_PS_WARM": "64"}, {"AISGPU_PS_SEQUENTIAL": "1"}, {"AISGPU_SERIAL": "1"},
+                                 {"AISGPU_SERIAL": "1", "AISGPU_PS_WARM": "16"}])
 def test_phase_search_fallback_and_variants(env, monkeypatch):
     """The chunk-parallel PhaseSearchEMA verifies its speculative warm-ups; with a 16-symbol warm-up the check
     must fail and the sequential fallback must still deliver bit-exact decisions.  Also: the plain sequential
-    kernel, the single-stream (non-overlapped) schedule, and the lane-per-chunk variant (sign words + integer walk that
-    rides along with the next block's launch) with several chunk lengths."""
+    kernel and the single-stream (non-overlapped) schedule.  (AISGPU_<KEY>: test hooks, forwarded by the Python wrapper to
+    aisgpu_set_option -- the library reads no environment variable.)"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     xs = [synth.receiver_stream(786432 * 2, receiver_id=40 + r) for r in range(2)]
@@ -829,14 +824,6 @@ def test_other_models_block_length_sweep(model):
         m.close()
 
 
-def test_gpu_frame_decoder_behind_the_deferred_walk(monkeypatch):
-    """Lane-per-chunk PhaseSearchEMA: the hard bits of block f are complete only after the walk that rides along with block
-    f+1 (or the flush when results are requested); the device decoders and the copies must wait for exactly that."""
-    monkeypatch.setenv("AISGPU_K4", "lane")
-    test_gpu_frame_decoder_nmea(786432, 4, "cf32")
-    test_gpu_frame_decoder_nmea(131072, 16, "cu8")
-
-
 @pytest.mark.parametrize("mode", ["seq", "alt"])
 def test_gpu_frame_decoder_implementations_share_their_state(mode, monkeypatch):
     """AISGPU_K7=seq: the symbol-by-symbol kernel; alt: event-driven and sequential kernels take turns block by block on the same
@@ -1189,15 +1176,12 @@ def test_reference_binding_compiled_against_the_real_reference(gpu_model, cpu_mo
     assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])  # tag.level, tag.ppm per message
 
 
-@pytest.mark.parametrize("env", [{"AISGPU_K46": "1"}, {"AISGPU_K46": "1", "AISGPU_PS_WARM": "16"}, {"AISGPU_K46": "1", "AISGPU_PS_WARM": "64"}, {"AISGPU_K46": "0"},
-                                 {"AISGPU_K46": "0", "AISGPU_PS_WARM": "16"}, {"AISGPU_K46": "1", "AISGPU_SERIAL": "1"}, {"AISGPU_SERIAL": "1"},
-                                 {"AISGPU_PS_SEQUENTIAL": "1"}, {"AISGPU_K4": "lane"}])
-def test_fused_fir_phase_search_kernel_and_its_exact_fallback(env, monkeypatch):
-    """AISGPU_K46=1: the back end derotates, filters and searches in ONE kernel (k46_fir_phase_chunks: the FIR outputs never leave LDS).
-    With a 16- or 64-symbol warm-up the speculative EMA start of every chunk is wrong, the verification flags every channel
-    quad, and the kernel's sequential mode must recompute them exactly; AISGPU_K46=0 is the two-kernel form (derotation / FIR
-    into HBM, then PhaseSearch), also with its own fallback; plus the single-stream schedule and the other search variants.
-    5 receivers: 10 channels = two full quads and one half-empty quad."""
+@pytest.mark.parametrize("env", [{}, {"AISGPU_PS_WARM": "16"}, {"AISGPU_PS_WARM": "64"}, {"AISGPU_SERIAL": "1"}, {"AISGPU_PS_SEQUENTIAL": "1"}])
+def test_fused_back_end_and_its_exact_fallback(env, monkeypatch):
+    """The default back end (derotation / FIR kernel, then the chunk-parallel PhaseSearch) on 5 receivers = 10 channels (two full
+    quads of the PhaseSearch workgroups and one half-empty one).  With a 16- or 64-symbol warm-up the speculative EMA start of every
+    chunk is wrong, the verification flags every workgroup, and the sequential kernel must recompute them exactly; plus the
+    single-stream schedule and the sequential search."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     xs = [synth.receiver_stream(786432 * 2, receiver_id=210 + r, gap_slots=(0, 2)) for r in range(5)]

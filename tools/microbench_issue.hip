@@ -2,7 +2,9 @@
 // behind the per-kernel "issue ms" column of profiles/r03_issue_model.txt (SQ_INSTS_VALU x class share x cost).
 //   hipcc --offload-arch=gfx950 -O3 tools/microbench_issue.hip -o /tmp/mb_issue && /tmp/mb_issue
 // Every kernel is a loop of 32 independent instructions of one class (8 registers x 4), W one-wave workgroups per SIMD
-// (W = 1, 2, 4: a single wave's issue rate against the SIMD's).  The clock comes from a loop of `s_nop 15` (16 cycles each).
+// (W = 1, 2, 4: a single wave's issue rate against the SIMD's).  The clock comes from a loop of `s_nop 15`: 16 wait states of one
+// 4-cycle issue slot each = 64 cycles (with 16 cycles the plain f32 rate would come out at 0.6 cycles per wave64 instruction, i.e.
+// 100 lanes per clock on a 32-lane SIMD; the device's reported clockRate is printed next to it).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
@@ -79,10 +81,10 @@ int main() {
 	float* d; hipMalloc(&d, 1 << 20);
 	hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
 	const int simds = prop.multiProcessorCount * 4, iters = 20000;
-	// clock: one wave per SIMD, 32 x s_nop 15 per iteration = 512 cycles (+ loop overhead, ~1 %)
+	// clock: one wave per SIMD, 32 x s_nop 15 per iteration = 2048 cycles (+ loop overhead, ~1 %)
 	const float tn = time_kernel(k_nop16, simds, iters, d);
-	const double ghz = (double)iters * 32 * 16 / (tn * 1e-3) / 1e9;
-	printf("%d CUs; clock from the s_nop loop: %.3f GHz (%.3f ms)\n", prop.multiProcessorCount, ghz, tn);
+	const double ghz = (double)iters * 32 * 64 / (tn * 1e-3) / 1e9;
+	printf("%d CUs; clock from the s_nop loop: %.3f GHz (%.3f ms); hipDeviceProp clockRate %.3f GHz\n", prop.multiProcessorCount, ghz, tn, prop.clockRate * 1e-6);
 	const Entry es[] = { { "v_add_f32", k_add }, { "v_mul_f32", k_mul }, { "v_and_b32", k_and }, { "v_pk_add_f32", k_pk_add }, { "v_pk_mul_f32", k_pk_mul },
 		{ "v_mov_b32_dpp wave_shr:1", k_mov_dpp }, { "v_add_f32_dpp wave_shr:1", k_add_dpp }, { "v_mov_b32_dpp quad_perm", k_mov_dpp_quad },
 		{ "v_bfe_i32", k_bfe }, { "v_add3_u32", k_add3 }, { "v_cndmask_b32 (vcc)", k_cndmask }, { "v_cmp_gt_f32 -> vcc", k_cmp_vcc },
