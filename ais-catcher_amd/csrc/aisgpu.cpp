@@ -683,7 +683,8 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
 	if (h->n_sub < MAXSUB) {
 		const size_t C = h->n_chan;
-		HIPCHK(hipMemcpy2DAsync(h->h_c48 + (size_t)h->n_sub * C * h->L, (size_t)h->L * sizeof(float2), h->d_c48[q], (size_t)h->c48s * sizeof(float2),
+		const size_t s_ = (size_t)h->out_set * MAXSUB + h->n_sub; // host slot: two sets, by input block
+		HIPCHK(hipMemcpy2DAsync(h->h_c48 + s_ * C * h->L, (size_t)h->L * sizeof(float2), h->d_c48[q], (size_t)h->c48s * sizeof(float2),
 		                        (size_t)h->L * sizeof(float2), C, hipMemcpyDeviceToHost, h->stream));
 		if (h->v2_assist) { // FreqOffset::Estimate of every offset-0 / offset-256 window, midWins' energies, the FM branch up to its sign
 			KV2Params k{};
@@ -694,7 +695,6 @@ int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
 			memcpy(k.taps, TAPS_RECEIVER, sizeof k.taps);
 			k.n_windows = h->W; k.L = h->L; k.n_chan = h->n_chan;
 			HIPCHK(launch_kv2(k, h->stream));
-			const size_t s_ = (size_t)h->n_sub;
 			HIPCHK(hipMemcpyAsync(h->h_v2f + s_ * C * 2 * h->W, h->d_v2f, C * 2 * h->W * sizeof(float), hipMemcpyDeviceToHost, h->stream));
 			HIPCHK(hipMemcpyAsync(h->h_v2prom + s_ * C * 2 * h->W, h->d_v2prom, C * 2 * h->W * sizeof(float), hipMemcpyDeviceToHost, h->stream));
 			HIPCHK(hipMemcpyAsync(h->h_v2en + s_ * C * (h->W + 1), h->d_v2en, C * (h->W + 1) * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1242,16 +1242,16 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	HIPCHK(dalloc(&h->d_qflag4, 2 * (size_t)((C * 5 + 3) / 4)));
 	if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_firtap, C * (8 + h->L)));
 	if (h->v2) {
-		HIPCHK(hipHostMalloc((void**)&h->h_c48, MAXSUB * C * h->L * sizeof(float2), hipHostMallocDefault));
+		HIPCHK(hipHostMalloc((void**)&h->h_c48, 2 * MAXSUB * C * h->L * sizeof(float2), hipHostMallocDefault)); // (two sets of slots: see out_set)
 		if (h->v2_assist) {
 			HIPCHK(dalloc(&h->d_v2hist, C * V2_HIST));
 			HIPCHK(dalloc(&h->d_v2f, C * 2 * h->W)); HIPCHK(dalloc(&h->d_v2prom, C * 2 * h->W)); HIPCHK(dalloc(&h->d_v2en, C * (h->W + 1)));
-			HIPCHK(hipHostMalloc((void**)&h->h_v2f, MAXSUB * C * 2 * h->W * sizeof(float), hipHostMallocDefault));
-			HIPCHK(hipHostMalloc((void**)&h->h_v2prom, MAXSUB * C * 2 * h->W * sizeof(float), hipHostMallocDefault));
-			HIPCHK(hipHostMalloc((void**)&h->h_v2en, MAXSUB * C * (h->W + 1) * sizeof(float), hipHostMallocDefault));
+			HIPCHK(hipHostMalloc((void**)&h->h_v2f, 2 * MAXSUB * C * 2 * h->W * sizeof(float), hipHostMallocDefault));
+			HIPCHK(hipHostMalloc((void**)&h->h_v2prom, 2 * MAXSUB * C * 2 * h->W * sizeof(float), hipHostMallocDefault));
+			HIPCHK(hipHostMalloc((void**)&h->h_v2en, 2 * MAXSUB * C * (h->W + 1) * sizeof(float), hipHostMallocDefault));
 			HIPCHK(dalloc(&h->d_fm, C * (FM_HIST + h->L)));
 			for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmbits[i], C * (h->L / 32)));
-			HIPCHK(hipHostMalloc((void**)&h->h_fmbits, MAXSUB * C * (h->L / 32) * sizeof(uint32_t), hipHostMallocDefault));
+			HIPCHK(hipHostMalloc((void**)&h->h_fmbits, 2 * MAXSUB * C * (h->L / 32) * sizeof(uint32_t), hipHostMallocDefault));
 			if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_fmfir, C * (size_t)h->L));
 			// FMDemod::prev: the engine decodes an all-zero block first (its look-back before the stream, V2Engine.cpp:275-279), which
 			// leaves prev = 0 -- not the 1 + 0j of the constructor (V2Engine.h:84) -- in front of the first real sample
@@ -1376,7 +1376,7 @@ int aisgpu_run(aisgpu_t* h) {
 	const int R = h->cfg.n_receivers;
 	h->n_sub = 0;
 	const int in_p = (int)(h->in_blocks & 1);
-	h->out_set = h->eager_out ? in_p : 0;
+	h->out_set = (h->eager_out || h->v2) ? in_p : 0; // (both copy outputs to the host inside aisgpu_run(): a pipelined caller is still reading the previous block's)
 	if (h->staged) { // the rows' host -> device copies run on the copy stream: the front stream waits for them
 		HIPCHK(hipEventRecord(h->ev_h2d[in_p], h->sc));
 		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_h2d[in_p], 0));
@@ -1698,12 +1698,13 @@ int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* o) {
 	o->ppm = h->h_ppm + oslot * C * h->W + chan * h->W;
 	o->group_window = nullptr;
 	o->first_sample48 = so.first48;
-	o->fm_bits = (h->challenger || h->base || (h->v2 && h->v2_assist)) ? h->h_fmbits + (size_t)sub * C * (h->L / 32) + chan * (h->L / 32) : nullptr;
-	o->c48 = h->v2 ? (const float*)(h->h_c48 + ((size_t)sub * C + chan) * h->L) : nullptr;
+	const size_t vslot = h->v2 ? oslot : (size_t)sub; // (ModelEngineV2's outputs are copied inside aisgpu_run(): two sets of slots)
+	o->fm_bits = (h->challenger || h->base || (h->v2 && h->v2_assist)) ? h->h_fmbits + vslot * C * (h->L / 32) + chan * (h->L / 32) : nullptr;
+	o->c48 = h->v2 ? (const float*)(h->h_c48 + (vslot * C + chan) * h->L) : nullptr;
 	const bool va = h->v2 && h->v2_assist;
-	o->v2_f = va ? h->h_v2f + ((size_t)sub * C + chan) * 2 * h->W : nullptr;
-	o->v2_prom = va ? h->h_v2prom + ((size_t)sub * C + chan) * 2 * h->W : nullptr;
-	o->v2_energy = va ? h->h_v2en + ((size_t)sub * C + chan) * (h->W + 1) : nullptr;
+	o->v2_f = va ? h->h_v2f + (vslot * C + chan) * 2 * h->W : nullptr;
+	o->v2_prom = va ? h->h_v2prom + (vslot * C + chan) * 2 * h->W : nullptr;
+	o->v2_energy = va ? h->h_v2en + (vslot * C + chan) * (h->W + 1) : nullptr;
 	return AISGPU_OK;
 }
 
