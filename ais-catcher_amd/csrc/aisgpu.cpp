@@ -213,7 +213,10 @@ struct aisgpu {
 	bool ps_box = false; PsBoxState* d_box[2] = {}; // Demod::PhaseSearch (boxcar) instead of PhaseSearchEMA
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
-	bool fused = false; int GL = 40; // groups per segment of the derotation / FIR kernel
+#ifndef AISGPU_GL
+#define AISGPU_GL 40
+#endif
+	bool fused = false; int GL = AISGPU_GL; // groups per segment of the derotation / FIR kernel (multiple of 8)
 	struct { bool valid = false; int q = 0, pb = 0, lv = 0, n_groups = 0, n_rel0 = 0, S = 0; long long g0 = 0; unsigned block = 0, sub = 0; } fpend;
 	float2 *d_ck[NBUF] = {}, *d_ckw[NBUF] = {}, *d_dfhist[2] = {};
 	int* d_qflag4 = nullptr; // [2][n_chains / 4] fallback flags of the row PhaseSearch kernels

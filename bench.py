@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- IQ Msamples/s through the ModelDefault demodulation chain on MI355X.
 
-Workload (BASELINE.json configs[3] / configs[4]): 256 batched dual-channel receivers per GPU,
+Default workload (BASELINE.json configs[3] / configs[4], `--config 4`): 256 batched dual-channel receivers per GPU,
 1536 kSPS CFLOAT32, one reference Receive() block (786,432 IQ samples) per receiver per step,
 synthetic GMSK bursts + AWGN, inputs resident in HBM before the timed region.  One process per GPU;
 receivers are independent, so N GPUs run N x 256 receivers with no collective (weak scaling).
+`--config 2` = configs[1] (ONE receiver: the latency case), `--config 3` = configs[2] (6 MSPS AirSpy-rate input, deeper CIC5
+ladder + fractional resampler, ModelChallenger: 8.14 algorithmic B/sample) -- timed and parity-gated the same way.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4]
 
 With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) this script starts the N ranks itself (one
 process per GPU, LOCAL_RANK = device); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
@@ -42,6 +44,20 @@ ALGO_BYTES_PER_SAMPLE = 8.30   # 8 B read + 0.25 B hard bits + 0
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 RATE = 1536000
 BLOCK = 786432
+
+# BASELINE.json configs, numbered as SURVEY.md does (config 1 = the CPU-only plumbing case, config 5 = config 4 on 8 GPUs)
+CONFIGS = {
+    2: {"key": "configs[1]", "rate": 1536000, "model": 2, "model_name": "ModelDefault", "receivers": 1, "bytes": 8.30,
+        "kernel": "k1_dpp (front end incl. the spectral analysis)",
+        "what": "ONE dual-channel receiver, 1536 kSPS CF32: latency of a block through the chain (the batch of one is launch / recurrence bound)"},
+    3: {"key": "configs[2]", "rate": 6000000, "model": 4, "model_name": "ModelChallenger", "receivers": 256, "bytes": 8.14,
+        "kernel": "k1_dpp<4, CF32, PRE> (the four CIC5 stages at the input rate: the pass that reads the input stream)",
+        "what": "%d batched dual-channel receivers per GPU, 6 MSPS CF32 (AirSpy rate): 4 x CIC5 -> Upsample 125/128 -> 2 x CIC5 -> ... -> "
+                "coherent chain + FM branch (ModelChallenger)"},
+    4: {"key": "configs[3]", "rate": 1536000, "model": 2, "model_name": "ModelDefault", "receivers": 256, "bytes": 8.30,
+        "kernel": "k1_dpp (front end: CIC5 ladder + FDC + Rotate + DS2 + FCIC5 + the spectral analysis of every window: FFT-512, prefix sum, peak searches)",
+        "what": "%d batched dual-channel receivers per GPU, 1536 kSPS CF32"},
+}
 
 
 def host_description():
@@ -145,7 +161,7 @@ def cgroup_throttled_usec():
     return None
 
 
-def cpu_baseline(seconds=16.0):
+def cpu_baseline(seconds=16.0, model=2, rate=RATE):
     """Reference chain (shipped flags -O3 -ffast-math), one independent ModelDefault per thread.  The timing loop lives in the
     checker library (oracle/ref_harness.cpp: ref_bench_threads): every thread is pinned to a physical core of its own (spread
     over the NUMA nodes), builds its model and copies its input blocks itself (first touch on its own node), and all threads
@@ -165,9 +181,9 @@ def cpu_baseline(seconds=16.0):
     host["numa_nodes"] = len(set(n for _, _, _, n in topo))
     host["cgroup_cpu_limit_cores"] = cgroup_cpu_limit()
     nblk = 4
-    x = synth.receiver_stream(BLOCK * nblk, receiver_id=4242)
+    x = synth.receiver_stream(BLOCK * nblk, sample_rate=rate, receiver_id=4242)
     if not checkers.have_ref("fast"):
-        return cpu_baseline_port(seconds, x, nblk, host, phys)
+        return cpu_baseline_port(seconds, x, nblk, host, phys, model, rate)
     lib = ctypes.CDLL(os.path.join(checkers.ORACLE_DIR, "_ref", "libaisref_fast.so"))
     lib.ref_bench_threads.restype = ctypes.c_double
     lib.ref_bench_threads.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]
@@ -177,7 +193,7 @@ def cpu_baseline(seconds=16.0):
         cpus = np.array(pick_cpus(topo, n), np.int32)
         n = len(cpus)
         counts = np.zeros(n, np.int64)
-        dt = lib.ref_bench_threads(2, RATE, 1, buf.ctypes.data, nblk, BLOCK * 8, n, cpus.ctypes.data, secs, counts.ctypes.data)
+        dt = lib.ref_bench_threads(model, rate, 1, buf.ctypes.data, nblk, BLOCK * 8, n, cpus.ctypes.data, secs, counts.ctypes.data)
         return n, float(counts.sum()) * BLOCK / dt / 1e6, dt, int(counts.sum())
 
     thr0 = cgroup_throttled_usec()
@@ -196,15 +212,18 @@ def cpu_baseline(seconds=16.0):
             "cgroup_throttled_s": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e6, 2), "host": host,
             "sample": "%d blocks of %d CF32 IQ samples over %d pinned threads (one per physical core, spread over %d NUMA nodes; the thread "
                       "count with the highest aggregate of the scan) in %.1f s; %d distinct blocks cycled, one ModelDefault instance per "
-                      "thread built and fed inside its thread, in-memory" % (blocks, BLOCK, n, host["numa_nodes"], dt, nblk)}
+                      "thread built and fed inside its thread, in-memory" % (blocks, BLOCK, n, host["numa_nodes"], dt, nblk),
+            "model": model, "sample_rate": rate,
+            "note": "the container's cgroup CPU limit (host.cgroup_cpu_limit_cores), not the host's core count, bounds the aggregate; "
+                    "per_thread x physical cores would be an extrapolation, not a measurement"}
 
 
-def cpu_baseline_port(seconds, x, nblk, host, phys):
+def cpu_baseline_port(seconds, x, nblk, host, phys, model=2, rate=RATE):
     """Fallback where the compiled reference is not there: the oracle's C restatement, one chain per Python thread (ctypes releases the GIL)."""
     import checkers
     cores = max(1, phys)
     blocks = [np.ascontiguousarray(x[i * BLOCK:(i + 1) * BLOCK]) for i in range(nblk)]
-    chains = [checkers.Oracle(model=2, rate=RATE, fmt="cf32") for _ in range(cores)]
+    chains = [checkers.Oracle(model=model, rate=rate, fmt="cf32") for _ in range(cores)]
     counts = [0] * cores
     t_end = time.perf_counter() + seconds
 
@@ -228,20 +247,20 @@ def cpu_baseline_port(seconds, x, nblk, host, phys):
             "sample": "%d blocks of %d CF32 IQ samples over %d threads in %.1f s (oracle restatement)" % (sum(counts), BLOCK, cores, dt)}
 
 
-def parity_check(g, data, sequence, receivers):
+def parity_check(g, data, sequence, receivers, rate=RATE, model=2):
     """Outputs of the LAST block of `sequence` (what the context `g` holds after sync_outputs) against the oracle fed the same
-    sequence of resident blocks, for the given receivers.  Returns (receivers checked, list of mismatch descriptions)."""
+    sequence of resident blocks, for the given receivers: hard bits of all five sampling phases, levels, ppm -- and for
+    ModelChallenger the sign of every filtered FM-discriminator sample (what its five FM decoders per channel see).  A resampled
+    rate completes one or two downstream blocks per input block: all of them are compared, in order.
+    Returns (receivers checked, list of mismatch descriptions)."""
     import checkers
     from concurrent.futures import ThreadPoolExecutor
     nb = data.shape[0]
-    L = BLOCK // 32
-    g0_last = (len(sequence) - 1) * L // 5
-    n_last = len(sequence) * L // 5 - g0_last
-    W = L // 512
+    n_sub = g.out_count()
 
     def one(r):
         blocks = [data[b, r].cpu().numpy().reshape(-1).view(np.complex64) for b in range(nb)]
-        o = checkers.Oracle(model=2, rate=RATE, fmt="cf32", taps=True)
+        o = checkers.Oracle(model=model, rate=rate, fmt="cf32", taps=True)
         o.set_taps(False)
         for i, b in enumerate(sequence):
             if i == len(sequence) - 1:   # only the last block's outputs are compared (and recorded)
@@ -249,21 +268,35 @@ def parity_check(g, data, sequence, receivers):
             o.feed(blocks[b])
         bad = []
         for ch in range(2):
-            out = g.fetch(r, ch)
-            if out["n_groups"] != n_last or out["first_group"] != g0_last:
-                bad.append("rx %d ch %d: group bookkeeping" % (r, ch))
-                continue
+            outs = [g.fetch(r, ch, s) for s in range(n_sub)]
+            for a, b2 in zip(outs, outs[1:]):
+                if b2["first_group"] != a["first_group"] + a["n_groups"] or b2["first_sample48"] != a["first_sample48"] + 512 * a["n_windows"]:
+                    bad.append("rx %d ch %d: downstream blocks not contiguous" % (r, ch))
+            n_tot = sum(t["n_groups"] for t in outs)
             ol = None
             for j in range(5):
-                ob, ol_, _ = o.bits(ch, j)
+                ob, ol_, oi = o.bits(ch, j)
                 ol = ol_
-                if len(ob) != n_last or not np.array_equal(out["bits"][j], ob):
+                got = np.concatenate([t["bits"][j] for t in outs])
+                if len(ob) != n_tot or not np.array_equal(got, ob):
                     bad.append("rx %d ch %d phase %d: hard bits" % (r, ch, j))
-            if not np.array_equal(out["lvl"].view(np.uint32), ol.view(np.uint32)):
+                elif n_tot and int(oi[0]) != 5 * outs[0]["first_group"] + j:
+                    bad.append("rx %d ch %d phase %d: group bookkeeping" % (r, ch, j))
+            if not np.array_equal(np.concatenate([t["lvl"] for t in outs]).view(np.uint32), ol.view(np.uint32)):
                 bad.append("rx %d ch %d: levels" % (r, ch))
             oppm = o.tap_ppm(2 + ch)
-            if len(oppm) != W or not np.array_equal(out["ppm"].view(np.uint32), oppm.view(np.uint32)):
+            gppm = np.concatenate([t["ppm"] for t in outs])
+            if len(oppm) != len(gppm) or not np.array_equal(gppm.view(np.uint32), oppm.view(np.uint32)):
                 bad.append("rx %d ch %d: ppm" % (r, ch))
+            if model == 4:   # FM branch: Demod::FM -> Filter(Receiver) -> Deinterleave(5): decoder j gets stream samples n = j (mod 5)
+                fm = np.concatenate([t["fm_bits"] for t in outs])
+                n0 = outs[0]["first_sample48"]
+                idx = np.arange(n0, n0 + len(fm))
+                for j in range(5):
+                    of, _, _ = o.bits(ch, j, fm=1)
+                    sel = fm[idx % 5 == j]
+                    if len(of) != len(sel) or not np.array_equal(sel != 0, of > 0):
+                        bad.append("rx %d ch %d FM decoder %d: discriminator signs" % (r, ch, j))
         o.close()
         return bad
 
@@ -278,6 +311,35 @@ def free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def pin_to_gpu_numa_node(local_rank):
+    """Bind this rank to the CPUs of its GPU's NUMA node; returns the node or None when the topology is not
+    exposed (/sys/class/drm/card*/device/numa_node: the render nodes in PCI order are the HIP devices in the usual order)."""
+    try:
+        import glob
+        cards = []
+        for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            try:
+                if open(os.path.join(d, "vendor")).read().strip() == "0x1002":   # AMD
+                    cards.append((os.path.realpath(d), int(open(os.path.join(d, "numa_node")).read())))
+            except Exception:
+                pass
+        cards.sort()
+        if local_rank >= len(cards) or cards[local_rank][1] < 0:
+            return None
+        node = cards[local_rank][1]
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return node
+    except Exception:
+        pass
+    return None
 
 
 def spawn_ranks(n):
@@ -301,12 +363,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--receivers", type=int, default=256)
+    ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS), help="BASELINE.json config (SURVEY numbering): 4 = configs[3], the "
+                    "metric's own (256 receivers x 1536 kSPS); 2 = configs[1] (one receiver, latency); 3 = configs[2] (6 MSPS, ModelChallenger)")
+    ap.add_argument("--receivers", type=int, default=0, help="receivers per GPU (0 = the config's own: 256, or 1 for --config 2)")
     ap.add_argument("--preroll", type=int, default=40, help="untimed steps before the warm-up (GPU clock ramp)")
     ap.add_argument("--gpu-decode", action="store_true", help="also run the AIS::Decoder state machines on the device (frames out)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--parity-receivers", type=int, default=16, help="receivers compared with the oracle after the timed region (0 = off)")
+    ap.add_argument("--tiles-per-span", type=int, default=0, help="front-end time tiling (0 = the library's choice); experiments")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise the rank launch / sharding / barrier / report path only (CPU tests)")
     args = ap.parse_args()
 
@@ -329,7 +394,9 @@ def main():
     _pkg.load()
     from ais_catcher_amd import shard, workload
 
-    R = args.receivers
+    C = CONFIGS[args.config]
+    R = args.receivers if args.receivers > 0 else C["receivers"]
+    rate, model, algo_bytes = C["rate"], C["model"], C["bytes"]
     nb = 2  # distinct resident blocks cycled (2 x 1.6 GB)
     rx_ids = shard.receiver_range(rank, world, R)  # this rank's receivers; no other rank touches them
     samples_per_step = R * BLOCK
@@ -365,8 +432,9 @@ def main():
 
     from ais_catcher_amd import gpu
     torch.cuda.set_device(local)
-    data = workload.resident_batch(torch, R, nb, seed=rx_ids[0] // R)
-    g = gpu.AisGpu(sample_rate=RATE, n_receivers=R, block_len=BLOCK, device_id=local, gpu_decode=args.gpu_decode)
+    numa = pin_to_gpu_numa_node(local) if world > 1 else None   # one process per GPU on the GPU's NUMA node
+    data = workload.resident_batch(torch, R, nb, seed=rx_ids[0] // R, unique=min(8, R), sample_rate=rate)
+    g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=BLOCK, device_id=local, gpu_decode=args.gpu_decode, model=model, tiles_per_span=args.tiles_per_span)
     sequence = workload.block_sequence(args.preroll, args.warmup, args.steps, nb)
     it = iter(sequence)
 
@@ -392,8 +460,8 @@ def main():
     t_enq = time.perf_counter() - t0   # host time to enqueue all steps (includes the library's back-pressure: it lets the host run two blocks ahead)
     g.sync()
     barrier()
-    dt = time.perf_counter() - t0
-    dt = shard.max_over_ranks(dt, dist)
+    dt_local = time.perf_counter() - t0
+    dt = shard.max_over_ranks(dt_local, dist)
 
     k1_ms, k1_n = g.frontend_ms()
 
@@ -409,7 +477,7 @@ def main():
                 raise
         n = min(args.parity_receivers, R)
         receivers = sorted(set(int(round(i * (R - 1) / max(n - 1, 1))) for i in range(n)))
-        n_checked, mismatches = parity_check(g, data, sequence, receivers)
+        n_checked, mismatches = parity_check(g, data, sequence, receivers, rate=rate, model=model)
 
     # ---- host cost of one aisgpu_run() with the device idle (no back-pressure): what the calling thread pays per block
     host_ms = []
@@ -422,7 +490,7 @@ def main():
     host_ms = sorted(host_ms[2:])
     g.close()
     # the same kernel measured without the other streams' kernels competing for the chip (untimed extra steps)
-    gs = gpu.AisGpu(sample_rate=RATE, n_receivers=R, block_len=BLOCK, device_id=local, serial=True)
+    gs = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=BLOCK, device_id=local, serial=True, model=model)
     for i in range(2):
         gs.submit_device(data[i % nb].data_ptr(), BLOCK)
         gs.run()
@@ -434,20 +502,20 @@ def main():
     iso_ms, _ = gs.frontend_ms()
     gs.close()
     value = shard.aggregate_msamples(samples_per_step, world, args.steps, dt)
-    achieved = samples_per_step * ALGO_BYTES_PER_SAMPLE / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+    achieved = samples_per_step * algo_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
     # HBM-side bytes per launch of the same kernel come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs:
     # tools/pmc_traffic.sh).  `traffic` is filled only from a measurement of THIS session (BENCH_TRAFFIC_JSON = the file that
     # script just wrote on this box); otherwise it is null and `traffic_reference` names the committed profile.
     traffic = traffic_bytes = traffic_src = None
     tpath = os.environ.get("BENCH_TRAFFIC_JSON")
-    if tpath and os.path.exists(tpath) and R == 256 and k1_ms > 0:
+    if tpath and os.path.exists(tpath) and R == 256 and args.config == 4 and k1_ms > 0:
         tj = json.load(open(tpath))
         traffic_bytes = tj["hbm_bytes_per_launch"]
         traffic = round(traffic_bytes / (k1_ms * 1e-3) / 1e9, 1)
         traffic_src = {"file": os.path.basename(tpath), "host": tj.get("host"), "commit": tj.get("commit")}
     ref_profile = None
     for cand in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-        if cand.startswith("r02_") and cand.endswith("pmc_traffic_k1.json"):
+        if args.config == 4 and cand.startswith("r0") and cand.endswith("pmc_traffic_k1.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 ref_profile = {"file": "profiles/" + cand, "hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch"),
@@ -456,7 +524,7 @@ def main():
                 pass
             break
     res = {
-        "metric": "IQ Msamples/s (CFLOAT32) through ModelDefault chain", "value": round(value, 1),
+        "metric": "IQ Msamples/s (CFLOAT32) through %s chain" % C["model_name"], "value": round(value, 1),
         "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
         "host_cost_ms_per_step": round(float(np.median(host_ms)), 4),
@@ -464,21 +532,23 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "parity_checked": n_checked, "parity": ("bit-exact vs oracle (hard bits, levels, ppm of the last timed block)" if n_checked and not mismatches
                                                 else "off" if not n_checked else "MISMATCH: " + "; ".join(mismatches[:8])),
-        "config": {"workload": "BASELINE configs[3]: %d batched dual-channel receivers per GPU, 1536 kSPS CF32, "
-                               "%d IQ samples per receiver per step, resident in HBM, chain up to hard bits/levels/ppm"
-                               % (R, BLOCK),
-                   "gpu_frame_decoder": bool(args.gpu_decode), "receivers_per_gpu": R, "block_len": BLOCK, "sample_rate": RATE, "parallelism": "receivers sharded, no collective"},
+        "config": {"workload": "BASELINE %s: %s, %d IQ samples per receiver per step, resident in HBM, chain up to hard bits/levels/ppm%s"
+                               % (C["key"], (C["what"] % R) if "%d" in C["what"] else C["what"], BLOCK, " + FM-branch signs" if model == 4 else ""),
+                   "baseline_config": C["key"], "model": C["model_name"], "algorithmic_bytes_per_sample": algo_bytes,
+                   "gpu_frame_decoder": bool(args.gpu_decode), "receivers_per_gpu": R, "block_len": BLOCK, "sample_rate": rate, "parallelism": "receivers sharded, no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_bytes_per_launch": traffic_bytes, "traffic_source": traffic_src, "traffic_reference": ref_profile,
-                     "algorithmic_bytes_per_launch": samples_per_step * ALGO_BYTES_PER_SAMPLE,
-                     "kernel": "k1_dpp (front end: CIC5 ladder + FDC + Rotate + DS2 + FCIC5 + the spectral analysis of every window: "
-                               "FFT-512, prefix sum, peak searches)", "avg_launch_ms": round(k1_ms, 4), "launches": k1_n,
+                     "algorithmic_bytes_per_launch": samples_per_step * algo_bytes,
+                     "kernel": C["kernel"], "avg_launch_ms": round(k1_ms, 4), "launches": k1_n,
                      # the same algorithmic bytes over the whole step (all kernels of the chain, wall clock / steps)
-                     "whole_chain_frac": round(samples_per_step * ALGO_BYTES_PER_SAMPLE / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                     "whole_chain_frac": round(samples_per_step * algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                      "isolated_launch_ms": round(iso_ms, 4),
-                     "isolated_frac": round(samples_per_step * ALGO_BYTES_PER_SAMPLE / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if iso_ms > 0 else None},
+                     "isolated_frac": round(samples_per_step * algo_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if iso_ms > 0 else None},
     }
+    if args.config == 2:   # the single-receiver case: what a block costs end to end on the device, and against real time
+        res["latency_ms_per_block"] = res["ms_per_step"]
+        res["realtime_factor"] = round(BLOCK / rate / (dt / args.steps), 1)
     bad = len(mismatches)
     if dist is not None:  # a mismatch on any rank fails the job
         t = torch.tensor([bad], dtype=torch.int64)
@@ -490,9 +560,18 @@ def main():
         if bad_all and not bad:
             res["parity"] = "MISMATCH on another rank"
         bad = bad_all
+    if dist is not None:
+        # every rank's own front-end launch time and wall clock (the line's roofline is rank 0's): min / max over the ranks
+        per = [None] * world
+        dist.all_gather_object(per, {"rank": rank, "k1_ms": round(k1_ms, 4), "ms_per_step": round(dt_local / args.steps * 1e3, 4), "numa_node": numa})
+        res["per_rank"] = per
+        res["roofline"]["avg_launch_ms_min_max_over_ranks"] = [min(p_["k1_ms"] for p_ in per), max(p_["k1_ms"] for p_ in per)]
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, model=model, rate=rate)
+        elif world > 1:
+            res["cpu_baseline"] = "skipped (N>1: measured on rank 0 of the N=1 run only)"
+            res["roofline"]["traffic_note"] = "PMC traffic is a single-GPU measurement (N=1 run)"
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
