@@ -1261,7 +1261,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			HIPCHK(dalloc(&h->d_fmprev[0], C));
 		}
 	}
-	const size_t osets = h->eager_out ? 2 : 1;
+	const size_t osets = (h->eager_out || h->v2) ? 2 : 1; // (two sets of host slots where outputs are copied inside aisgpu_run(): see out_set)
 	HIPCHK(hipHostMalloc((void**)&h->h_bits, osets * MAXSUB * C * 5 * h->words * sizeof(uint32_t), hipHostMallocDefault));
 	HIPCHK(hipHostMalloc((void**)&h->h_lvl, osets * MAXSUB * C * h->Gcap * sizeof(float), hipHostMallocDefault));
 	HIPCHK(hipHostMalloc((void**)&h->h_ppm, osets * MAXSUB * C * h->W * sizeof(float), hipHostMallocDefault));

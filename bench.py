@@ -247,56 +247,66 @@ def cpu_baseline_port(seconds, x, nblk, host, phys, model=2, rate=RATE):
             "sample": "%d blocks of %d CF32 IQ samples over %d threads in %.1f s (oracle restatement)" % (sum(counts), BLOCK, cores, dt)}
 
 
-def parity_check(g, data, sequence, receivers, rate=RATE, model=2):
+def parity_check(g, data, sequence, receivers, rate=RATE, model=2, fmt="cf32", blocks_of=None, **okw):
     """Outputs of the LAST block of `sequence` (what the context `g` holds after sync_outputs) against the oracle fed the same
-    sequence of resident blocks, for the given receivers: hard bits of all five sampling phases, levels, ppm -- and for
-    ModelChallenger the sign of every filtered FM-discriminator sample (what its five FM decoders per channel see).  A resampled
+    sequence of resident blocks, for the given receivers: hard bits of all five sampling phases, levels, ppm -- for
+    ModelChallenger also the sign of every filtered FM-discriminator sample (what its five FM decoders per channel see), for
+    ModelBase / ModelStandard those signs alone (their whole device output), for ModelEngineV2 the 48 kHz channels.  A resampled
     rate completes one or two downstream blocks per input block: all of them are compared, in order.
-    Returns (receivers checked, list of mismatch descriptions)."""
+    data: resident tensor [n_blocks][n_rx]... (CF32), or blocks_of(r) -> list of host arrays, one per resident block (any format).
+    okw: options of the oracle chain (dsk, ps_ema, fp_ds, mode_x, ma).  Returns (receivers checked, list of mismatch descriptions)."""
     import checkers
     from concurrent.futures import ThreadPoolExecutor
-    nb = data.shape[0]
     n_sub = g.out_count()
 
     def one(r):
-        blocks = [data[b, r].cpu().numpy().reshape(-1).view(np.complex64) for b in range(nb)]
-        o = checkers.Oracle(model=model, rate=rate, fmt="cf32", taps=True)
+        if blocks_of is not None:
+            blocks = blocks_of(r)
+        else:
+            blocks = [data[b, r].cpu().numpy().reshape(-1).view(np.complex64) for b in range(data.shape[0])]
+        o = checkers.Oracle(model=model, rate=rate, fmt=fmt, taps=True, **okw)
         o.set_taps(False)
         for i, b in enumerate(sequence):
             if i == len(sequence) - 1:   # only the last block's outputs are compared (and recorded)
                 o.set_taps(True)
             o.feed(blocks[b])
         bad = []
-        for ch in range(2):
+        for ch in range(1 if okw.get("mode_x") else 2):   # (channel mode X: one channel, the device's channel B stays silent)
             outs = [g.fetch(r, ch, s) for s in range(n_sub)]
             for a, b2 in zip(outs, outs[1:]):
                 if b2["first_group"] != a["first_group"] + a["n_groups"] or b2["first_sample48"] != a["first_sample48"] + 512 * a["n_windows"]:
                     bad.append("rx %d ch %d: downstream blocks not contiguous" % (r, ch))
-            n_tot = sum(t["n_groups"] for t in outs)
-            ol = None
-            for j in range(5):
-                ob, ol_, oi = o.bits(ch, j)
-                ol = ol_
-                got = np.concatenate([t["bits"][j] for t in outs])
-                if len(ob) != n_tot or not np.array_equal(got, ob):
-                    bad.append("rx %d ch %d phase %d: hard bits" % (r, ch, j))
-                elif n_tot and int(oi[0]) != 5 * outs[0]["first_group"] + j:
-                    bad.append("rx %d ch %d phase %d: group bookkeeping" % (r, ch, j))
-            if not np.array_equal(np.concatenate([t["lvl"] for t in outs]).view(np.uint32), ol.view(np.uint32)):
-                bad.append("rx %d ch %d: levels" % (r, ch))
-            oppm = o.tap_ppm(2 + ch)
-            gppm = np.concatenate([t["ppm"] for t in outs])
-            if len(oppm) != len(gppm) or not np.array_equal(gppm.view(np.uint32), oppm.view(np.uint32)):
-                bad.append("rx %d ch %d: ppm" % (r, ch))
-            if model == 4:   # FM branch: Demod::FM -> Filter(Receiver) -> Deinterleave(5): decoder j gets stream samples n = j (mod 5)
+            if model in (2, 4):
+                n_tot = sum(t["n_groups"] for t in outs)
+                ol = None
+                for j in range(5):
+                    ob, ol_, oi = o.bits(ch, j)
+                    ol = ol_
+                    got = np.concatenate([t["bits"][j] for t in outs])
+                    if len(ob) != n_tot or not np.array_equal(got, ob):
+                        bad.append("rx %d ch %d phase %d: hard bits" % (r, ch, j))
+                    elif n_tot and int(oi[0]) != 5 * outs[0]["first_group"] + j:
+                        bad.append("rx %d ch %d phase %d: group bookkeeping" % (r, ch, j))
+                if not np.array_equal(np.concatenate([t["lvl"] for t in outs]).view(np.uint32), ol.view(np.uint32)):
+                    bad.append("rx %d ch %d: levels" % (r, ch))
+                oppm = o.tap_ppm(2 + ch)
+                gppm = np.concatenate([t["ppm"] for t in outs])
+                if len(oppm) != len(gppm) or not np.array_equal(gppm.view(np.uint32), oppm.view(np.uint32)):
+                    bad.append("rx %d ch %d: ppm" % (r, ch))
+            if model in (4, 0, 1):   # FM receivers: Demod::FM -> Filter(Receiver); with Deinterleave(5) decoder j gets stream samples n = j (mod 5)
                 fm = np.concatenate([t["fm_bits"] for t in outs])
                 n0 = outs[0]["first_sample48"]
                 idx = np.arange(n0, n0 + len(fm))
-                for j in range(5):
+                for j in range(1 if model == 1 else 5):
                     of, _, _ = o.bits(ch, j, fm=1)
-                    sel = fm[idx % 5 == j]
+                    sel = fm if model == 1 else fm[idx % 5 == j]   # ModelBase: the sampler sees every sample
                     if len(of) != len(sel) or not np.array_equal(sel != 0, of > 0):
-                        bad.append("rx %d ch %d FM decoder %d: discriminator signs" % (r, ch, j))
+                        bad.append("rx %d ch %d FM stream %d: discriminator signs" % (r, ch, j))
+            if model == 11:
+                want = o.tap(ch)
+                got = np.concatenate([t["c48"] for t in outs])
+                if len(want) != len(got) or not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+                    bad.append("rx %d ch %d: 48 kHz channel" % (r, ch))
         o.close()
         return bad
 

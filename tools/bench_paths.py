@@ -15,24 +15,39 @@ import _pkg  # noqa: E402
 
 _pkg.load()
 from ais_catcher_amd import gpu, synth  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench  # noqa: E402  (the parity gate of the bench line, shared)
+
+
+GATE = {"checked": 0, "failed": []}
 
 
 def run(name, R, rate, block, fmt="cf32", steps=30, **kw):
+    """One path: 30 untimed + `steps` timed steps over two resident blocks (one synthetic receiver replicated R times), then the
+    SAME parity gate as bench.py on the run that was just timed: the last block's outputs of the first and the last receiver
+    against the oracle fed the same block sequence, bit for bit (hard bits, levels, ppm, FM signs, 48 kHz channels -- whatever
+    the engine hands out)."""
+    model = kw.get("model", gpu.MODEL_DEFAULT)
     x = synth.receiver_stream(block * 2, sample_rate=rate, receiver_id=7, single_channel=kw.get("mode_x", False))
     if fmt == "cf32":
+        hostx = x
         host = x.view(np.float32).reshape(2, block, 2)
         code = gpu.FMT_CF32
     elif fmt == "cu8":
-        host = synth.to_cu8(x).reshape(2, block, 2)
+        hostx = synth.to_cu8(x)
+        host = hostx.reshape(2, block, 2)
         code = gpu.FMT_CU8
     else:
-        host = synth.to_cs16(x).reshape(2, block, 2)
+        hostx = synth.to_cs16(x)
+        host = hostx.reshape(2, block, 2)
         code = gpu.FMT_CS16
+    per = len(hostx) // 2
     dev = torch.from_numpy(np.ascontiguousarray(host)).cuda()
     data = dev.unsqueeze(1).expand(2, R, block, 2).contiguous()   # [2 blocks][R][block][2]
     torch.cuda.synchronize()
     g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block, input_format=code, **kw)
-    for i in range(30):  # warm-up incl. the clock ramp after the idle set-up time
+    warm = 30
+    for i in range(warm):  # warm-up incl. the clock ramp after the idle set-up time
         g.submit_device(data[i & 1].data_ptr(), block)
         g.run()
     g.sync()
@@ -42,9 +57,24 @@ def run(name, R, rate, block, fmt="cf32", steps=30, **kw):
         g.run()
     g.sync()
     dt = time.perf_counter() - t0
+    verdict = "parity off"
+    if not os.environ.get("BENCH_PATHS_NO_GATE"):
+        try:
+            g.sync_outputs()
+        except gpu.AisGpuError as e:  # (device decoders: a throughput run never collects its frames, the decisions are copied all the same)
+            if not (kw.get("gpu_decode") and "(5)" in str(e)):
+                raise
+        seq = [i & 1 for i in range(warm)] + [i & 1 for i in range(steps)]
+        okw = {k: kw[k] for k in ("ps_ema", "fp_ds", "mode_x", "dsk", "ma") if k in kw}
+        blocks = [hostx[:per], hostx[per:]]
+        n, bad = bench.parity_check(g, None, seq, sorted({0, R - 1}), rate=rate, model=model, fmt=fmt, blocks_of=lambda r: blocks, **okw)
+        GATE["checked"] += n
+        verdict = "parity: %d receivers bit-exact" % n if not bad else "PARITY MISMATCH: " + "; ".join(bad[:4])
+        if bad:
+            GATE["failed"].append(name)
     g.close()
     del data, dev
-    print("%-64s %9.0f MS/s   %7.3f ms per step of %d x %d samples" % (name, R * block * steps / dt / 1e6, dt / steps * 1e3, R, block), flush=True)
+    print("%-64s %9.0f MS/s   %7.3f ms per step of %d x %d samples   %s" % (name, R * block * steps / dt / 1e6, dt / steps * 1e3, R, block, verdict), flush=True)
 
 
 if __name__ == "__main__":
@@ -58,14 +88,16 @@ if __name__ == "__main__":
     run("ModelDefault 1536k CS16", R, 1536000, B, fmt="cs16")
     run("ModelDefault 768k CF32 (three CIC5 stages)", R, 768000, B // 2)
     run("ModelDefault 3072k CF32 (pre-decimation pass)", R // 2, 3072000, B)
-    run("ModelDefault 6 MSPS CF32 (pre-decimation + resampler K1u)", R // 4, 6000000, B)
+    run("ModelDefault 6 MSPS CF32 (pre-decimation + resampler K1u)", R, 6000000, B)
     run("ModelDefault 288k CF32 (decimate-by-3 front end K1k)", R, 288000, 49152 * 4)
     run("ModelDefault 2400k CF32 (resampled into 3072k)", R // 2, 2400000, B // 2)
     run("ModelDefault mode X 96k CF32 (single channel K1x)", R, 96000, 1024 * 48, mode_x=True)
     run("ModelChallenger 1536k CF32 (materialised back end + FM branch)", R, 1536000, B, model=gpu.MODEL_CHALLENGER)
     run("ModelChallenger 1536k CF32, twenty decoders on the device", R, 1536000, B, model=gpu.MODEL_CHALLENGER, gpu_decode=True)
-    run("ModelChallenger 6 MSPS CF32 (BASELINE configs[2])", R // 4, 6000000, B, model=gpu.MODEL_CHALLENGER)
+    run("ModelChallenger 6 MSPS CF32 (BASELINE configs[2])", R, 6000000, B, model=gpu.MODEL_CHALLENGER)
     run("ModelBase 1536k CF32 (front end + FM receiver, signs out)", R, 1536000, B, model=gpu.MODEL_BASE)
     run("ModelBase 1536k CF32, SimplePLL + decoder on the device", R, 1536000, B, model=gpu.MODEL_BASE, gpu_decode=True)
     run("ModelStandard 1536k CF32, five decoders on the device", R, 1536000, B, model=gpu.MODEL_STANDARD, gpu_decode=True)
     run("ModelEngineV2 1536k CF32 (front end + estimates / energies / FM branch, c48 to the host)", R, 1536000, B, model=gpu.MODEL_V2)
+    print("parity gate: %d receiver outputs compared, %d paths failed %s" % (GATE["checked"], len(GATE["failed"]), GATE["failed"]))
+    sys.exit(3 if GATE["failed"] else 0)
