@@ -210,6 +210,7 @@ struct aisgpu {
 	long long k7e_pass = 0; // passes of the event-driven decoder kernels so far (parity: which overflow flag a pass uses)
 	bool k7_event = true; uint32_t *d_k7ev = nullptr, *d_k7cnt = nullptr; uint16_t* d_k7open = nullptr; K7Slot* d_k7slot = nullptr; int* d_k7ovf = nullptr;
 	uint32_t* h_frames = nullptr; unsigned frames_seen = 0; int max_frames = 0; std::vector<aisgpu_frame> frames;
+	K7bParams k7b{}; bool base_chunked = false; // ModelBase's sampler + decoder loop, chunk-parallel (k7b_*)
 	bool ps_box = false; PsBoxState* d_box[2] = {}; // Demod::PhaseSearch (boxcar) instead of PhaseSearchEMA
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
@@ -648,6 +649,7 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 	k5.fmbits = h->d_fmbits[pb]; k5.fmbits_stride = h->L / 32; k5.L = h->L;
 	k5.fir_out = h->d_fmfir; k5.fir_stride = h->L;
 	memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
+	if (h->gpu_decode && h->base_chunked) WAITEV(h->stream, h->ev_k4[pb]); // fmbits[pb] was last read by the decoders of block f-2 (on s1)
 	HIPCHK(launch_k5(k5, h->n_chan, h->stream));
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->stream));
 	if (h->gpu_decode) { // SimplePLL + decoder (ModelBase) / Deinterleave + five decoders (ModelStandard) on the device, behind the filter
@@ -665,8 +667,16 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 			kq.bits = h->d_fmrows[pb]; kq.bits_stride = h->fmrow_words; kq.lvl = nullptr; kq.kind = 0;
 			{ int rc = launch_decoders_event(h, kq, k7, h->s1); if (rc) return rc; }
 			HIPCHK(hipEventRecord(h->ev_k4[pb], h->s1));
+		} else if (h->dec_kind == 3 && h->base_chunked && !(h->k7_alt && (h->block_idx & 1))) {
+			// ModelBase: the chunk-parallel sampler + decoder kernels on PhaseSearch's otherwise idle stream, next to the next block's
+			// front end (k7_base alone held the front stream for 5 ms per step of 256 receivers)
+			HIPCHK(hipEventRecord(h->ev_sym[pb], h->stream));
+			WAITEV(h->s1, h->ev_sym[pb]);
+			h->k7b.k = k7;
+			HIPCHK(launch_k7b(h->k7b, h->s1));
+			HIPCHK(hipEventRecord(h->ev_k4[pb], h->s1));
 		} else {
-			if (h->dec_kind == 1 && h->k7_alt) WAITEV(h->stream, h->ev_k4[pb ^ 1]); // (test hook: the previous block's decoders ran on s1)
+			if ((h->dec_kind == 1 || h->dec_kind == 3) && h->k7_alt) WAITEV(h->stream, h->ev_k4[pb ^ 1]); // (test hook: the previous block's decoders ran on s1)
 			if (h->dec_kind == 1) HIPCHK(launch_k7_pack(k7, h->stream));
 			HIPCHK(launch_k7_mesh(k7, h->stream));
 		}
@@ -1152,6 +1162,18 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		h->dec_kind = cfg->model == AISGPU_MODEL_STANDARD ? 1 : cfg->model == AISGPU_MODEL_CHALLENGER ? 2 : cfg->model == AISGPU_MODEL_BASE ? 3 : 0;
 		h->max_frames = (int)C * 64; // ring between two aisgpu_sync_outputs(): a slot holds ~2 frames per channel and block
 		HIPCHK(dalloc(&h->d_dec, (size_t)C * 10)); // zero = State::TRAINING, lastBit = prev = 0 (Marine/AIS.h:44-56); up to ten decoders per channel
+		if (cfg->model == AISGPU_MODEL_BASE && k7_opt != "seq") { // chunk-parallel sampler + decoder loop (kernels.h: K7b); "seq": k7_base alone
+			K7bParams& b = h->k7b;
+			b.n_chunks = (h->L + K7B_CH - 1) / K7B_CH;
+			b.n_chan_pad = (int)((C + 63) / 64 * 64);
+			const size_t slots = (size_t)b.n_chunks * b.n_chan_pad;
+			HIPCHK(dalloc(&b.ckpt, slots * (K7B_CH / 32)));
+			HIPCHK(dalloc(&b.end, slots)); HIPCHK(dalloc(&b.task_end, slots));
+			HIPCHK(dalloc(&b.frames, slots * (1 + K7B_FCAP * K7B_FREC))); HIPCHK(dalloc(&b.task_frames, slots * (1 + K7B_FCAP * K7B_FREC)));
+			HIPCHK(dalloc(&b.task_merge, slots));
+			HIPCHK(dalloc(&b.fallback, (size_t)b.n_chan_pad + 1)); b.fallback_count = b.fallback + b.n_chan_pad;
+			h->base_chunked = true;
+		}
 		if (h->dec_kind == 1 || h->dec_kind == 2) {
 			h->fmrow_words = h->Gcap / 32;
 			for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmrows[i], C * 5 * (size_t)h->fmrow_words));
@@ -1163,7 +1185,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		// decoders of ModelChallenger inherit through the shared TAG: that variant of the mesh kernel does not exist)
 		if (h->dec_kind == 2 && (by3 || ma_m)) { h->err = "AISGPU_FLAG_GPU_DECODE with ModelChallenger: not on the decimate-by-3 ladders / behind the moving-average downsampler"; return AISGPU_ERR_ARG; }
 		HIPCHK(dalloc(&h->d_frames, (size_t)h->max_frames * DEC_FRAME_WORDS));
-		if (!k7_opt.empty() && h->dec_kind <= 2) { h->k7_event = k7_opt != "seq"; h->k7_alt = k7_opt == "alt"; } // "seq": one lane per decoder, symbol by symbol
+		if (!k7_opt.empty()) { h->k7_event = h->dec_kind <= 2 && k7_opt != "seq"; h->k7_alt = k7_opt == "alt"; } // "seq": one lane per decoder, symbol by symbol
 		// the event words hold a symbol index in 13 bits: blocks of more than 8191 groups (e.g. the reference's CU8 file block of
 		// 3,145,728 samples at 1536 kSPS) go through the sequential decoder kernel
 		if ((h->L + 4) / 5 + 1 > 8191) h->k7_event = false;
@@ -1310,6 +1332,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_qflag4);
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
 	hipFree(h->d_box[0]); hipFree(h->d_box[1]);
+	hipFree(h->k7b.ckpt); hipFree(h->k7b.end); hipFree(h->k7b.task_end); hipFree(h->k7b.frames); hipFree(h->k7b.task_frames); hipFree(h->k7b.task_merge); hipFree(h->k7b.fallback);
 	hipFree(h->d_dec); hipFree(h->d_frames); hipFree(h->d_frame_count); hipFree(h->d_fmrows[0]); hipFree(h->d_fmrows[1]); hipFree(h->d_last_lvl[0]); hipFree(h->d_last_lvl[1]);
 	hipFree(h->d_k7ev); hipFree(h->d_k7cnt); hipFree(h->d_k7open); hipFree(h->d_k7slot); hipFree(h->d_k7ovf);
 	if (h->h_frames) hipHostFree(h->h_frames);

@@ -170,8 +170,42 @@ struct K7Params {
 	const float* last_lvl_in = nullptr; float* last_lvl = nullptr; // [n_chan] ScatterPLL level of the last group of the previous / of this block (what tag.sample_lvl still holds)
 	int n_rel0 = 0, L = 0;                        // first_group * 5 - first_sample48; 48 kHz samples per block
 	// sequential kernels as the exact fallback of the event-driven ones: run only where *cond != 0, count the passes that ran in *cond_count
-	const int* cond = nullptr; int* cond_count = nullptr;
+	int* cond = nullptr; int* cond_count = nullptr; // (k7_base: cond = one flag per channel, cleared by the kernel)
 };
+// K7b: ModelBase's sampler + decoder loop (DSP::SimplePLL with the decoder's StartTraining / StopTraining feedback, DSP/DSP.cpp:28-57,
+// Model.cpp:428-435), chunk-parallel and exact.  The loop gain of the sampler follows the decoder's state sample by sample, so the
+// coupled system is sequential -- but it FORGETS: in fast mode (decoder in TRAINING) every sign change contracts the PLL phase by
+// 0.4, and a decoder in TRAINING is a function of its last few symbols.  So:
+//   k7b_spec      one lane per (channel, chunk of K7B_CH samples): chunk 0 runs from the carried state (exact); every other chunk
+//                 starts K7B_WARM samples early from a fresh state and records its trajectory: the sampler / decoder state in front of
+//                 every 32nd sample (12 bytes), the frames it completes, and its full state at the chunk's end;
+//   k7b_task      one lane per chunk boundary whose speculative state is NOT bit-identical with the previous chunk's end state (a frame
+//                 in flight, a silent stretch): the exact loop from that end state on, until its state equals a recorded one of the
+//                 speculative trajectory it runs alongside (both decoders in TRAINING: from there on the two are the same for ever) --
+//                 or until the block ends;
+//   k7b_assemble  one lane per channel walks the boundaries in order, decides which trajectory is the true one where, copies its
+//                 frames to the ring and the final state to DecState.
+// A frame list that overflows (more than K7B_FCAP frames in a chunk / task) flags the channel; k7_base then decodes it from the
+// untouched carried state (K7Params::cond = per-channel flags).  Same DecState between blocks as k7_base: the two can alternate.
+constexpr int K7B_CH = 512;     // samples per chunk (multiple of 32): 48 chunks per channel in a 786,432-sample block at 1536 kSPS
+constexpr int K7B_WARM = 256;   // samples of warm-up in front of a speculative chunk (<= K7B_CH, multiple of 32): ~50 sign changes of 0.4 each
+constexpr int K7B_FCAP = 4;     // frames recorded per chunk / per task
+constexpr int K7B_FREC = 2 + DEC_DATA_WORDS; // sample index, position, data
+struct K7bCkpt { uint32_t pll, position, flags; }; // flags: pprev | state << 1 | lastBit << 3 | prev << 4 | osc << 5
+struct K7bParams {
+	K7Params k;
+	int n_chunks;
+	K7bCkpt* ckpt;        // [n_chunks][K7B_CH / 32][n_chan_pad]: state in front of sample 32 i of the chunk
+	DecState* end;        // [n_chunks][n_chan_pad] full state at the end of the chunk's trajectory
+	uint32_t* frames;     // [n_chunks][n_chan_pad][1 + K7B_FCAP * K7B_FREC] count, records
+	int* task_merge;      // [n_chunks][n_chan_pad] per boundary c >= 1: -1 no task (states matched), else the sample at which the task merged (L: never)
+	DecState* task_end;   // [n_chunks][n_chan_pad] state of a task that ran to the end of the block
+	uint32_t* task_frames;// like frames
+	int* fallback;        // [n_chan_pad] != 0: a frame list overflowed, k7_base decodes the channel's block
+	int* fallback_count;  // statistics
+	int n_chan_pad;
+};
+hipError_t launch_k7b(const K7bParams& p, hipStream_t s);
 hipError_t launch_k7(const K7Params& p, hipStream_t s);
 hipError_t launch_k7_pack(const K7Params& p, hipStream_t s); // kind 1 / 2: regroup the FM bits per decoder (on the stream that produced them)
 hipError_t launch_k7_mesh(const K7Params& p, hipStream_t s); // kind 1 / 2 / 3: the decoders

@@ -2517,7 +2517,13 @@ __global__ __launch_bounds__(64) void k7_base(K7Params p) {
 	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64]; // [word][lane]
 	const int lane = threadIdx.x;
 	const int chan_raw = blockIdx.x * 64 + lane;
-	const bool live = chan_raw < p.n_chan;
+	bool live = chan_raw < p.n_chan;
+	if (p.cond) { // exact fallback of the chunk-parallel kernels (k7b_*): only the channels they flagged, from the untouched carried state
+		const bool mine = live && p.cond[chan_raw] != 0;
+		if (!__any(mine)) return;
+		if (mine) { p.cond[chan_raw] = 0; atomicAdd(p.cond_count, 1); }
+		live = mine;
+	}
 	const int chan = live ? chan_raw : 0;
 	uint32_t* data = fdata + lane;
 	DecState* st = p.state + chan;
@@ -2560,6 +2566,205 @@ __global__ __launch_bounds__(64) void k7_base(K7Params p) {
 		st->crc[0] = r.crc; st->crc[1] = r.cw; st->crc[2] = (uint32_t)r.cwi; st->crc[3] = r.tail; st->crc[4] = (uint32_t)r.abort_pos;
 		st->crc[5] = __float_as_uint(pll); st->crc[6] = (uint32_t)pprev;
 	}
+}
+
+// ------------------------------------------------------------------------------------------
+// K7b: ModelBase's SimplePLL + decoder loop, chunk-parallel (see kernels.h)
+// ------------------------------------------------------------------------------------------
+struct BaseReg { DecReg r; float pll; int pprev; };
+
+__device__ __forceinline__ void base_load(BaseReg& b, const DecState* st, uint32_t* data) {
+	DecReg& r = b.r;
+	r.state = st->state; r.lastBit = st->lastBit; r.prev = st->prev; r.position = st->position; r.osc = st->osc;
+	r.level = st->level; r.start_idx = st->start_idx;
+	for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = st->data[w];
+	r.crc = st->crc[0]; r.cw = st->crc[1]; r.cwi = (int)st->crc[2]; r.tail = st->crc[3]; r.abort_pos = (int)st->crc[4];
+	b.pll = __uint_as_float(st->crc[5]); b.pprev = (int)st->crc[6];
+}
+__device__ __forceinline__ void base_store(const BaseReg& b, DecState* st, uint32_t* data) {
+	const DecReg& r = b.r;
+	st->state = r.state; st->lastBit = r.lastBit; st->prev = r.prev; st->position = r.position; st->osc = r.osc;
+	st->level = r.level; st->start_idx = r.start_idx;
+	data[64 * r.cwi] = r.cw;
+	for (int w = 0; w < DEC_DATA_WORDS; w++) st->data[w] = data[64 * w];
+	st->crc[0] = r.crc; st->crc[1] = r.cw; st->crc[2] = (uint32_t)r.cwi; st->crc[3] = r.tail; st->crc[4] = (uint32_t)r.abort_pos;
+	st->crc[5] = __float_as_uint(b.pll); st->crc[6] = (uint32_t)b.pprev; st->crc[7] = 0;
+}
+__device__ __forceinline__ void base_fresh(BaseReg& b, int pprev, uint32_t* data) {
+	DecReg& r = b.r;
+	r.state = DST_TRAINING; r.lastBit = 0; r.prev = 0; r.position = 0; r.osc = 0; r.level = 0.0f; r.start_idx = 0;
+	r.crc = 0; r.cw = 0; r.cwi = 0; r.tail = 0; r.abort_pos = 0;
+	for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = 0;
+	b.pll = 0.0f; b.pprev = pprev;
+}
+__device__ __forceinline__ K7bCkpt base_ckpt(const BaseReg& b) {
+	K7bCkpt c;
+	c.pll = __float_as_uint(b.pll); c.position = (uint32_t)b.r.position;
+	c.flags = (uint32_t)b.pprev | (uint32_t)b.r.state << 1 | (uint32_t)b.r.lastBit << 3 | (uint32_t)b.r.prev << 4 | (uint32_t)b.r.osc << 5;
+	return c;
+}
+// the two trajectories are the same from here on: identical sampler state, identical decoder state, the decoder in TRAINING (where
+// the rest of its registers -- CRC, frame buffer, abort position -- is dead: all of it is initialised again when a frame opens)
+__device__ __forceinline__ bool base_same(const K7bCkpt& a, const K7bCkpt& b) {
+	return a.pll == b.pll && a.position == b.position && a.flags == b.flags && ((a.flags >> 1) & 3u) == (uint32_t)DST_TRAINING;
+}
+__device__ __forceinline__ int base_bit(const uint32_t* brow, int n) { return (int)((brow[n >> 5] >> (n & 31)) & 1u); }
+// one sample of SimplePLL::Receive (DSP.cpp:28-44); true when the sampler hands this sample to the decoder
+__device__ __forceinline__ bool base_pll_step(BaseReg& b, int bit) {
+	const bool fast = b.r.state == DST_TRAINING; // FastPLL (StartTraining / StopTraining, AIS.cpp:41-46)
+	if (bit != b.pprev) b.pll += (0.5f - b.pll) * (fast ? 0.6f : 0.05f);
+	b.pll += 0.2f;
+	const bool emit = b.pll >= 1.0f;
+	if (emit) b.pll -= (float)(int)b.pll;
+	b.pprev = bit;
+	return emit;
+}
+__device__ __forceinline__ void base_record(BaseReg& b, int n, uint32_t* list, uint32_t* data, bool& overflow) {
+	const uint32_t cnt = list[0];
+	if (cnt < (uint32_t)K7B_FCAP) {
+		uint32_t* f = list + 1 + cnt * K7B_FREC;
+		f[0] = (uint32_t)n; f[1] = (uint32_t)b.r.position;
+		for (int w = 0; w < DEC_DATA_WORDS; w++) f[2 + w] = data[64 * w];
+		list[0] = cnt + 1;
+	} else overflow = true;
+}
+// The lanes of a wave are independent sample streams, so they need not sit at the same sample: every lane advances ITS stream up to
+// its next emission (the sampler emits every fifth sample, give or take; ~10 instructions per sample) and then all lanes run the
+// decoder step together -- once per symbol instead of once per sample of whichever lane happens to emit (the step is ~150
+// instructions of selects, and with one sample per iteration some lane emits in every iteration).
+// AT(n): called in front of every sample with n % 32 == 0 (checkpoint store / compare); returns false to stop the lane there.
+template <class AT, class FOUND>
+__device__ __forceinline__ void base_run(BaseReg& b, const uint32_t* brow, int n, int n_end, bool active, uint32_t* data, AT&& at, FOUND&& on_found) {
+	uint32_t word = active && n < n_end ? brow[n >> 5] : 0u;
+	while (__any(active && n < n_end)) {
+		bool emit = false;
+		int bit = 0;
+		while (active && n < n_end && !emit) {
+			if ((n & 31) == 0) {
+				word = brow[n >> 5];
+				if (!at(n)) { active = false; break; }
+			}
+			bit = (int)((word >> (n & 31)) & 1u);
+			emit = base_pll_step(b, bit);
+			n++;
+		}
+		bool found = false;
+		if (emit) found = dec_step(b.r, bit, 0.0f, 0ll, data); // (tag.sample_lvl / sample_idx are never set in this engine)
+		if (found) {
+			on_found(n - 1);
+			b.r.state = DST_TRAINING; b.r.position = 0; b.r.osc = 0;
+		}
+	}
+}
+
+__global__ __launch_bounds__(64) void k7b_spec(K7bParams q) {
+	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64];
+	const K7Params& p = q.k;
+	const int lane = threadIdx.x, c = blockIdx.y;
+	const int chan_raw = blockIdx.x * 64 + lane;
+	const bool live = chan_raw < p.n_chan;
+	const int chan = live ? chan_raw : 0;
+	uint32_t* data = fdata + lane;
+	const size_t slot = (size_t)c * q.n_chan_pad + chan_raw;
+	const uint32_t* brow = p.fm_cur + (size_t)chan * p.fm_stride;
+	const int n0 = c * K7B_CH, n1 = n0 + K7B_CH < p.L ? n0 + K7B_CH : p.L;
+	BaseReg b;
+	int start = n0;
+	if (c == 0) base_load(b, p.state + chan, data);
+	else {
+		start = n0 - K7B_WARM; // (>= 0: K7B_WARM <= K7B_CH)
+		base_fresh(b, start > 0 ? base_bit(brow, start - 1) : 0, data);
+	}
+	uint32_t* list = q.frames + slot * (1 + K7B_FCAP * K7B_FREC);
+	if (live) list[0] = 0;
+	bool overflow = false;
+	K7bCkpt* ck = q.ckpt + (size_t)c * (K7B_CH / 32) * q.n_chan_pad + chan_raw;
+	base_run(b, brow, start, n1, live, data,
+	         [&](int n) { if (n >= n0) ck[(size_t)((n - n0) >> 5) * q.n_chan_pad] = base_ckpt(b); return true; },
+	         [&](int n) { if (n >= n0) base_record(b, n, list, data, overflow); }); // (what the warm-up "completes" is not a frame)
+	if (live) {
+		base_store(b, q.end + slot, data);
+		if (overflow) q.fallback[chan_raw] = 1;
+	}
+}
+
+__global__ __launch_bounds__(64) void k7b_task(K7bParams q) {
+	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64];
+	const K7Params& p = q.k;
+	const int lane = threadIdx.x, c = blockIdx.y + 1;
+	const int chan_raw = blockIdx.x * 64 + lane;
+	const bool live = chan_raw < p.n_chan;
+	const int chan = live ? chan_raw : 0;
+	uint32_t* data = fdata + lane;
+	const size_t slot = (size_t)c * q.n_chan_pad + chan_raw;
+	const uint32_t* brow = p.fm_cur + (size_t)chan * p.fm_stride;
+	BaseReg b;
+	base_load(b, q.end + (size_t)(c - 1) * q.n_chan_pad + chan, data);
+	const K7bCkpt* ck = q.ckpt + chan_raw;
+	const auto ckpt_at = [&](int n) { return ck[((size_t)(n / K7B_CH) * (K7B_CH / 32) + (size_t)((n % K7B_CH) >> 5)) * q.n_chan_pad]; };
+	const int n0 = c * K7B_CH;
+	const bool run = live && !base_same(base_ckpt(b), ckpt_at(n0));
+	int merge = run ? p.L : -1;
+	uint32_t* list = q.task_frames + slot * (1 + K7B_FCAP * K7B_FREC);
+	if (live) list[0] = 0;
+	bool overflow = false;
+	// the recorded state one checkpoint ahead travels in registers (a dependent global load per 32 samples would set the pace)
+	K7bCkpt next = ckpt_at(n0 + 32 < p.L ? n0 + 32 : n0);
+	base_run(b, brow, n0, p.L, run, data,
+	         [&](int n) {
+		         if (n == n0) return true;
+		         const K7bCkpt cur = next;
+		         next = ckpt_at(n + 32 < p.L ? n + 32 : n);
+		         if (base_same(base_ckpt(b), cur)) { merge = n; return false; }
+		         return true;
+	         },
+	         [&](int n) { base_record(b, n, list, data, overflow); });
+	if (live) {
+		q.task_merge[slot] = merge;
+		if (merge == p.L) base_store(b, q.task_end + slot, data); // ran to the end of the block: this is the channel's state
+		if (overflow) q.fallback[chan_raw] = 1;
+	}
+}
+
+__global__ __launch_bounds__(64) void k7b_assemble(K7bParams q) {
+	const K7Params& p = q.k;
+	const int chan = blockIdx.x * 64 + threadIdx.x;
+	if (chan >= p.n_chan) return;
+	if (q.fallback[chan]) return; // k7_base decodes this channel's block from the untouched carried state
+	const size_t per = 1 + K7B_FCAP * K7B_FREC;
+	const auto emit = [&](const uint32_t* list, int from) { // the list's frames that completed at sample >= from
+		const uint32_t cnt = list[0];
+		for (uint32_t i = 0; i < cnt; i++) {
+			const uint32_t* r = list + 1 + i * K7B_FREC;
+			if ((int)r[0] < from) continue;
+			const unsigned slot = atomicAdd(p.frame_count, 1u) % (unsigned)p.max_frames;
+			uint32_t* f = p.frames + (size_t)slot * DEC_FRAME_WORDS;
+			f[0] = (uint32_t)chan; f[1] = r[0]; f[2] = r[1]; f[3] = 0; // (level sum: tag.sample_lvl is never set in this engine)
+			f[4] = 0; f[5] = 0; f[6] = 0; f[7] = 0;
+			f[8] = p.block; f[9] = p.sub;
+			for (int w = 0; w < DEC_DATA_WORDS; w++) f[10 + w] = r[2 + w];
+		}
+	};
+	// chunk 0's trajectory is exact from sample 0; `from` = the sample from which the current chunk's recorded trajectory is the true one
+	emit(q.frames + (size_t)chan * per, 0);
+	const DecState* final_state = q.end + (size_t)(q.n_chunks - 1) * q.n_chan_pad + chan;
+	// the walk is a chain of dependent decisions: the merge positions come to LDS first (all loads in flight at once)
+	constexpr int MAXC = 160;
+	__shared__ int merges[MAXC][64];
+	const bool staged = q.n_chunks <= MAXC;
+	if (staged) for (int i = 1; i < q.n_chunks; i++) merges[i][threadIdx.x] = q.task_merge[(size_t)i * q.n_chan_pad + chan];
+	int c = 1;
+	while (c < q.n_chunks) {
+		const size_t slot = (size_t)c * q.n_chan_pad + chan;
+		const int merge = staged ? merges[c][threadIdx.x] : q.task_merge[slot];
+		if (merge < 0) { emit(q.frames + slot * per, 0); c++; continue; } // the speculative state WAS the true one
+		emit(q.task_frames + slot * per, 0); // the exact loop from the previous chunk's (true) end state up to the merge
+		if (merge >= p.L) { final_state = q.task_end + slot; break; }
+		const int cm = merge / K7B_CH; // the chunk whose recorded trajectory the task joined (the boundaries in between lie inside the task)
+		emit(q.frames + ((size_t)cm * q.n_chan_pad + chan) * per, merge);
+		c = cm + 1;
+	}
+	p.state[chan] = *final_state;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3105,6 +3310,17 @@ hipError_t launch_k7_mesh(const K7Params& p, hipStream_t s) {
 	}
 	if (p.kind == 1) hipLaunchKernelGGL(k7_decode_mesh<1>, dim3((p.n_chan + 11) / 12), dim3(64), 0, s, p);
 	else hipLaunchKernelGGL(k7_decode_mesh<2>, dim3((p.n_chan + 5) / 6), dim3(64), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_k7b(const K7bParams& q, hipStream_t s) {
+	const int gx = (q.k.n_chan + 63) / 64;
+	hipLaunchKernelGGL(k7b_spec, dim3(gx, q.n_chunks), dim3(64), 0, s, q);
+	if (q.n_chunks > 1) hipLaunchKernelGGL(k7b_task, dim3(gx, q.n_chunks - 1), dim3(64), 0, s, q);
+	hipLaunchKernelGGL(k7b_assemble, dim3(gx), dim3(64), 0, s, q);
+	K7Params fb = q.k; // exact fallback: exits at once unless a channel is flagged
+	fb.cond = q.fallback; fb.cond_count = q.fallback_count;
+	hipLaunchKernelGGL(k7_base, dim3(gx), dim3(64), 0, s, fb);
 	return hipGetLastError();
 }
 

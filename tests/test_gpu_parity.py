@@ -1404,3 +1404,64 @@ def test_pipelined_batch_hand_off(model):
             assert models[r].nmea() == want[r] and len(want[r]) >= 2, "rx %d dec %s" % (r, dec)
             models[r].close()
         batch.close()
+
+
+@pytest.mark.parametrize("mode", [None, "seq", "alt"])
+@pytest.mark.parametrize("case", ["busy", "quiet", "short_blocks", "batch"])
+def test_model_base_chunk_parallel_sampler_and_decoder(case, mode, monkeypatch):
+    """ModelBase with AISGPU_FLAG_GPU_DECODE: DSP::SimplePLL (whose loop gain follows the decoder's StartTraining / StopTraining,
+    DSP.cpp:28-57, Model.cpp:428-435) and its decoder as the chunk-parallel kernels k7b_spec / k7b_task / k7b_assemble: speculative
+    chunks from a fresh state, the exact loop wherever a chunk boundary's speculative state is not the previous chunk's end state
+    (frames in flight: back-to-back bursts keep a task running across several chunks; silence: nothing to converge on), merged
+    where the states meet again.  NMEA text and per-message level / ppm against the compiled reference; `seq` = k7_base alone,
+    `alt` = the two implementations take turns block by block on the same DecState."""
+    from ais_catcher_amd import host
+    if mode:
+        monkeypatch.setenv("AISGPU_K7", mode)
+    R = 1
+    if case == "busy":      # bursts in consecutive slots: hardly any boundary sees a decoder in TRAINING
+        block, nblocks, kw = 786432, 3, dict(gap_slots=(0, 0), type5_every=3)
+    elif case == "quiet":   # long gaps, and a stretch of exact silence (no sign changes: the speculative phase cannot converge)
+        block, nblocks, kw = 786432, 3, dict(gap_slots=(6, 9))
+    elif case == "short_blocks":  # 512 / 4096 samples at 48 kHz per block: a single (partial) chunk, then two chunks
+        block, nblocks, kw = 16384, 48, dict(gap_slots=(0, 2))
+    else:
+        R, block, nblocks, kw = 5, 393216, 4, dict(gap_slots=(0, 3))  # (no multi-sentence messages: their sequence digit is process-global)
+    xs = [synth.receiver_stream(block * nblocks, receiver_id=300 + r, **kw) for r in range(R)]
+    if case == "quiet":
+        xs[0][block // 3: block // 3 + 200000] = 0
+    if case == "short_blocks":
+        xs.append(synth.receiver_stream(131072 * 6, receiver_id=311, gap_slots=(0, 1)))
+    want, got = [], []
+    for i, x in enumerate(xs):
+        blk = 131072 if (case == "short_blocks" and i == len(xs) - 1) else block
+        chk = (checkers.Ref if checkers.have_ref() else checkers.Oracle)(model=1, rate=1536000, fmt="cf32")
+        chk.feed_blocks(x, blk)
+        want.append((chk.nmea(), chk.msg_meta()))
+    if R > 1:
+        import threading
+        host.reset_sequence()
+        batch = host.Batch(n_receivers=R, block_len=block, gpu_decode=True, model=gpu.MODEL_BASE)
+        models = [host.ModelBaseGPU(block_len=block, batch=batch, rx=r, gpu_decode=True) for r in range(R)]
+
+        def work(r):
+            for b in range(nblocks):
+                assert models[r].receive(xs[r][b * block:(b + 1) * block]) == 0
+        th = [threading.Thread(target=work, args=(r,)) for r in range(R)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        for r in range(R):
+            assert sorted(models[r].nmea()) == sorted(want[r][0]) and len(want[r][0]) >= 2, "rx %d" % r
+            models[r].close()
+        batch.close()
+        return
+    for i, x in enumerate(xs):
+        blk = 131072 if (case == "short_blocks" and i == len(xs) - 1) else block
+        host.reset_sequence()
+        m = host.ModelBaseGPU(block_len=blk, gpu_decode=True)
+        for b in range(len(x) // blk):
+            assert m.receive(x[b * blk:(b + 1) * blk]) == 0
+        assert m.nmea() == want[i][0] and len(want[i][0]) >= 2, "stream %d" % i
+        a, c = m.msg_meta(), want[i][1]
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+        m.close()
