@@ -8,35 +8,94 @@
 
 namespace AIS
 {
+	// ---- GpuPool
+
+	GpuPool &GpuPool::instance()
+	{
+		static GpuPool pool;
+		return pool;
+	}
+
+	static bool same_group(const aisgpu_cfg &a, const aisgpu_cfg &b)
+	{
+		return a.sample_rate == b.sample_rate && a.model == b.model && a.afc_wide == b.afc_wide && a.droop == b.droop && a.flags == b.flags &&
+			   a.device_id == b.device_id;
+	}
+
+	GpuPool::Group *GpuPool::reserve(const aisgpu_cfg &c, int &rx)
+	{
+		std::lock_guard<std::mutex> l(mtx);
+		aisgpu_cfg want = c;
+		if (gpu_decode) want.flags |= AISGPU_FLAG_GPU_DECODE;
+		for (Group *g : groups)
+			if (!g->batch && same_group(g->cfg, want)) // (a group whose context exists is closed: later receivers form the next one)
+			{
+				rx = g->reserved++;
+				g->users++;
+				return g;
+			}
+		Group *g = new Group();
+		g->cfg = want;
+		rx = g->reserved++;
+		g->users++;
+		groups.push_back(g);
+		return g;
+	}
+
+	aisamd::GpuBatch *GpuPool::open(Group *g, int block_len, int input_format)
+	{
+		std::lock_guard<std::mutex> l(mtx);
+		if (!g->batch)
+		{
+			g->cfg.n_receivers = g->reserved;
+			g->cfg.block_len = block_len;
+			g->cfg.input_format = input_format;
+			// Model.cpp:224-237: the fixed-point ladder only exists at 1536 kSPS and is fed from ConvertRAW::outCU8
+			if ((g->cfg.flags & AISGPU_FLAG_FP_DS) && (g->cfg.sample_rate != 1536000 || input_format != AISGPU_FMT_CU8)) g->cfg.flags &= ~AISGPU_FLAG_FP_DS;
+			g->batch = new aisamd::GpuBatch(g->cfg); // throws std::runtime_error (unsupported rate / block length, no GPU) like the reference's models at set-up
+			g->batch->setTimeout(timeout_ms);
+			g->batch->setPipelined(pipelined);
+		}
+		else if (g->cfg.block_len != block_len || g->cfg.input_format != input_format)
+			throw std::runtime_error("GPU model: the receivers of one batch must deliver blocks of one size and format");
+		return g->batch;
+	}
+
+	void GpuPool::release(Group *g, int rx)
+	{
+		std::lock_guard<std::mutex> l(mtx);
+		if (g->batch) g->batch->leave(rx);
+		if (--g->users == 0)
+		{
+			delete g->batch;
+			for (size_t i = 0; i < groups.size(); i++)
+				if (groups[i] == g)
+				{
+					groups.erase(groups.begin() + i);
+					break;
+				}
+			delete g;
+		}
+	}
+
+	// ---- the tail of AIS::Decoder::Run for a frame the GPU decoders completed (see ModelGPU.h)
+
+	void GpuEmitFrame(Decoder &d, const aisgpu_frame &f, TAG &tag)
+	{
+		d.msg.clear();
+		for (int i = 0; i < f.position; i++)
+			d.msg.setBit(i, (f.data[i >> 3] >> (i & 7)) & 1);
+		if (tag.mode & 1) tag.level = f.level_sum / f.position; // Marine/AIS.h:152-153
+		d.start_idx = f.start_idx;
+		d.end_idx = f.end_idx;
+		d.processData(f.position - 7, tag); // CRC (again), dB, validate, buildNMEA, Send (Marine/AIS.cpp:66-96)
+	}
+
 	// ---- GpuChain
 
-	void GpuChain::open(const RAW *raw)
+	GpuChain::~GpuChain()
 	{
-		int bytes = 0;
-		switch (raw->format)
-		{
-		case Format::CU8: cfg.input_format = AISGPU_FMT_CU8; bytes = 2; break;
-		case Format::CS8: cfg.input_format = AISGPU_FMT_CS8; bytes = 2; break;
-		case Format::CS16: cfg.input_format = AISGPU_FMT_CS16; bytes = 4; break;
-		case Format::CF32: cfg.input_format = AISGPU_FMT_CF32; bytes = 8; break;
-		default:
-			throw std::runtime_error("GPU model: input format not supported (CU8, CS8, CS16, CF32)");
-		}
-		cfg.block_len = raw->size / bytes; // the device hands over blocks of one size (Device/FileRAW.h:43, Device/RTLSDR.h:57)
-		// Model.cpp:224-237: the fixed-point ladder only exists at 1536 kSPS and is fed from ConvertRAW::outCU8
-		if ((cfg.flags & AISGPU_FLAG_FP_DS) && (cfg.sample_rate != 1536000 || raw->format != Format::CU8)) cfg.flags &= ~AISGPU_FLAG_FP_DS;
-		int rc = aisgpu_create(&cfg, &ctx);
-		if (rc != AISGPU_OK)
-		{
-			std::string msg = std::string("GPU model: ") + aisgpu_strerror(rc);
-			if (ctx)
-			{
-				msg += std::string(": ") + aisgpu_last_error(ctx);
-				aisgpu_destroy(ctx);
-				ctx = nullptr;
-			}
-			throw std::runtime_error(msg);
-		}
+		if (group) GpuPool::instance().release(group, rx);
 	}
 
 	void GpuChain::replay(Connection<FLOAT32> *out, const aisgpu_out &o, TAG &tag, int n0, int n1)
@@ -84,20 +143,80 @@ namespace AIS
 		}
 	}
 
+	// ModelBase / ModelStandard: every 48 kHz sample of the block, in order (Demod::FM, Filter and SimplePLL leave the tag alone)
+	void GpuChain::replayFM(Connection<FLOAT32> &fm, const aisgpu_out &o, TAG &tag, int n0, int n1)
+	{
+		const int L = o.n_windows * 512;
+		for (int n = n0; n < L && n < n1; n++)
+		{
+			FLOAT32 f = ((o.fm_bits[n >> 5] >> (n & 31)) & 1u) ? 1.0f : -1.0f;
+			fm.Send((const FLOAT32 *)&f, 1, tag);
+		}
+	}
+
 	void GpuChain::Receive(const RAW *raw, int len, TAG &tag)
 	{
-		if (failed || len != 1) return;
-		if (!ctx) open(raw); // throws like the reference's models do at set-up (Model.cpp:109-110)
+		if (failed || len != 1 || !group) return;
+		int fmt = 0, bytes = 0;
+		switch (raw->format)
+		{
+		case Format::CU8: fmt = AISGPU_FMT_CU8; bytes = 2; break;
+		case Format::CS8: fmt = AISGPU_FMT_CS8; bytes = 2; break;
+		case Format::CS16: fmt = AISGPU_FMT_CS16; bytes = 4; break;
+		case Format::CF32: fmt = AISGPU_FMT_CF32; bytes = 8; break;
+		default:
+			throw std::runtime_error("GPU model: input format not supported (CU8, CS8, CS16, CF32)");
+		}
+		// the device hands over blocks of one size (Device/FileRAW.h:43, Device/RTLSDR.h:57); the first block of the group creates its
+		// context (throws like the reference's models do at set-up, Model.cpp:109-110)
+		if (!batch) batch = GpuPool::instance().open(group, raw->size / bytes, fmt);
 
-		const int bytes = cfg.input_format == AISGPU_FMT_CF32 ? 8 : cfg.input_format == AISGPU_FMT_CS16 ? 4 : 2;
-		int rc = aisgpu_submit(ctx, 0, raw->data, raw->size / bytes); // copies: the block is only borrowed (Device/FileRAW.cpp:131-136)
-		if (rc == AISGPU_OK) rc = aisgpu_run(ctx);
-		if (rc == AISGPU_OK) rc = aisgpu_sync_outputs(ctx);
+		// copies the block (it is only borrowed, Device/FileRAW.cpp:131-136), meets the other receivers of the batch, returns when the
+		// whole batch has been through the GPU
+		const int rc = batch->submitAndWait(rx, raw->data, raw->size / bytes);
 		if (rc != AISGPU_OK)
 		{
 			failed = true; // the reference logs and stops (Device/FileRAW.cpp:111-115)
-			Error() << "GPU model: " << aisgpu_strerror(rc) << ": " << aisgpu_last_error(ctx);
+			Error() << "GPU model: " << aisgpu_strerror(rc) << ": " << batch->lastError();
 			StopRequest();
+			return;
+		}
+		deliver(tag);
+	}
+
+	void GpuChain::Flush(TAG &tag)
+	{
+		if (failed || !batch || !batch->isPipelined()) return;
+		if (batch->submitAndWait(rx, nullptr, 0) == AISGPU_OK) deliver(tag);
+	}
+
+	void GpuChain::deliver(TAG &tag)
+	{
+		const aisgpu_cfg &cfg = batch->config();
+		const int nsub = batch->outCount(); // downstream blocks this input block completed (1, or 1..2 behind the resampler; 0: the first call of a pipelined batch)
+		if (nsub == 0) return;
+		if (cfg.flags & AISGPU_FLAG_GPU_DECODE)
+		{ // the decoders' state machines ran on the device: only completed frames come back, each to the tail of ITS decoder
+			const aisgpu_frame *fr = nullptr;
+			int nf = 0;
+			if (batch->frames(&fr, &nf) != AISGPU_OK) { failed = true; return; }
+			for (int i = 0; i < nf; i++)
+			{
+				const aisgpu_frame &f = fr[i];
+				if (f.rx != rx || f.sub >= nsub) continue;
+				aisgpu_out o;
+				if (batch->fetch(f.sub, rx, f.ch, &o) != AISGPU_OK) { failed = true; return; }
+				if (o.n_groups > 0)
+				{ // what the tag held when the frame closed (the FM receivers never touch tag.ppm / tag.sample_lvl)
+					const long long n_last = f.phase >= 5 ? f.end_idx : 5 * (o.first_group + f.group) + 4;
+					const int w = (int)((n_last - o.first_sample48) / 512);
+					if (o.ppm && w >= 0 && w < o.n_windows) tag.ppm = o.ppm[w];
+					if (tag.mode & 1) tag.sample_lvl = o.lvl[f.group];
+				}
+				tag.sample_idx = f.end_idx;
+				Decoder *d = (f.phase >= 0 && f.phase < 2 * N_SAMPLES_PER_SYMBOL) ? dec[f.ch & 1][f.phase] : nullptr;
+				if (d) GpuEmitFrame(*d, f, tag);
+			}
 			return;
 		}
 		// on the decimate-by-3 ladders Rotate works on DownsampleKFilter's 8192-sample blocks (DSP/DSP.h:193): A then B every
@@ -111,18 +230,18 @@ namespace AIS
 			if (b3[i] >= cfg.sample_rate && (!best || b3[i] < best)) { by3 = true; break; }
 		if (cfg.flags & AISGPU_FLAG_MA_DS) by3 = true; // DownsampleMovingAverage hands on blocks of 8192 samples too (DSP/DSP.h:128)
 
-		const int nsub = aisgpu_out_count(ctx); // downstream blocks this input block completed (1, or 1..2 behind the resampler)
 		for (int s = 0; s < nsub; s++)
 		{
 			aisgpu_out o[2];
 			for (int ch = 0; ch < 2; ch++)
-				if (aisgpu_fetch_sub(ctx, s, 0, ch, &o[ch]) != AISGPU_OK) { failed = true; return; }
+				if (batch->fetch(s, rx, ch, &o[ch]) != AISGPU_OK) { failed = true; return; }
 			const int L = o[0].n_windows * 512, step = by3 ? 4096 : L;
 			for (int n0 = 0; n0 < L; n0 += step)
 				for (int ch = 0; ch < 2; ch++)
 				{
 					const int n1 = n0 + step < L ? n0 + step : L;
-					if (o[ch].fm_bits) replayChallenger(ch == 0 ? outA : outB, ch == 0 ? outAf : outBf, o[ch], tag, n0, n1);
+					if (o[ch].fm_bits && o[ch].n_groups == 0) replayFM(ch == 0 ? outFMa : outFMb, o[ch], tag, n0, n1);
+					else if (o[ch].fm_bits) replayChallenger(ch == 0 ? outA : outB, ch == 0 ? outAf : outBf, o[ch], tag, n0, n1);
 					else replay(ch == 0 ? outA : outB, o[ch], tag, n0, n1);
 				}
 		}
@@ -140,13 +259,14 @@ namespace AIS
 		Connection<RAW> &physical = timerOn ? (*device >> timer).out : device->out; // Model.cpp:33
 		physical >> chain;
 
-		aisgpu_cfg &c = chain.config();
+		aisgpu_cfg c;
+		aisgpu_default_cfg(&c);
 		c.sample_rate = sample_rate;
-		c.n_receivers = 1;
 		c.model = model;
 		c.afc_wide = CGF_wide;
 		c.droop = droop_compensation;
 		c.flags = (PS_EMA ? 0 : AISGPU_FLAG_PS_BOXCAR) | (fixedpointDS ? AISGPU_FLAG_FP_DS : 0) | (allowDSK ? AISGPU_FLAG_DSK : 0) | (MA_DS ? AISGPU_FLAG_MA_DS : 0);
+		chain.join(c); // this receiver's row in the batch of all receivers built with the same configuration
 	}
 
 	void ModelDefaultGPU::buildModel(char CH1, char CH2, int sample_rate, bool timerOn, Device::Device *dev)
@@ -160,6 +280,8 @@ namespace AIS
 
 			chain.outA[i] >> DEC_a[i] >> output;
 			chain.outB[i] >> DEC_b[i] >> output;
+			chain.dec[0][i] = &DEC_a[i];
+			chain.dec[1][i] = &DEC_b[i];
 
 			for (int j = 0; j < N_SAMPLES_PER_SYMBOL; j++)
 				if (i != j)
@@ -228,6 +350,10 @@ namespace AIS
 			chain.outB[i] >> DEC_b[i] >> output;
 			chain.outAf[i] >> DEC_af[i] >> output;
 			chain.outBf[i] >> DEC_bf[i] >> output;
+			chain.dec[0][i] = &DEC_a[i];
+			chain.dec[1][i] = &DEC_b[i];
+			chain.dec[0][N_SAMPLES_PER_SYMBOL + i] = &DEC_af[i]; // (frames of the device decoders: phase 5..9 = the FM decoders)
+			chain.dec[1][N_SAMPLES_PER_SYMBOL + i] = &DEC_bf[i];
 
 			for (int j = 0; j < N_SAMPLES_PER_SYMBOL; j++)
 			{
@@ -244,5 +370,53 @@ namespace AIS
 				}
 			}
 		}
+	}
+
+	// ---- ModelStandardGPU (Model.cpp:484-518)
+
+	void ModelStandardGPU::buildModel(char CH1, char CH2, int sample_rate, bool timerOn, Device::Device *dev)
+	{
+		buildFrontend(sample_rate, timerOn, dev, AISGPU_MODEL_STANDARD);
+
+		S_a.setConnections(N_SAMPLES_PER_SYMBOL);
+		S_b.setConnections(N_SAMPLES_PER_SYMBOL);
+		chain.outFMa >> S_a;
+		chain.outFMb >> S_b;
+
+		for (int i = 0; i < N_SAMPLES_PER_SYMBOL; i++)
+		{
+			DEC_a[i].setOrigin(CH1, station, own_mmsi);
+			DEC_b[i].setOrigin(CH2, station, own_mmsi);
+
+			S_a.out[i] >> DEC_a[i] >> output;
+			S_b.out[i] >> DEC_b[i] >> output;
+			chain.dec[0][i] = &DEC_a[i];
+			chain.dec[1][i] = &DEC_b[i];
+
+			for (int j = 0; j < N_SAMPLES_PER_SYMBOL; j++)
+				if (i != j)
+				{
+					DEC_a[i].DecoderMessage.Connect(DEC_a[j]);
+					DEC_b[i].DecoderMessage.Connect(DEC_b[j]);
+				}
+		}
+	}
+
+	// ---- ModelBaseGPU (Model.cpp:419-438): the reference's own SimplePLL with the decoder's training signals fed back into it
+
+	void ModelBaseGPU::buildModel(char CH1, char CH2, int sample_rate, bool timerOn, Device::Device *dev)
+	{
+		buildFrontend(sample_rate, timerOn, dev, AISGPU_MODEL_BASE);
+
+		DEC_a[0].setOrigin(CH1, station, own_mmsi);
+		DEC_b[0].setOrigin(CH2, station, own_mmsi);
+
+		chain.outFMa >> sampler_a >> DEC_a[0] >> output;
+		chain.outFMb >> sampler_b >> DEC_b[0] >> output;
+		chain.dec[0][0] = &DEC_a[0];
+		chain.dec[1][0] = &DEC_b[0];
+
+		DEC_a[0].DecoderMessage.Connect(sampler_a);
+		DEC_b[0].DecoderMessage.Connect(sampler_b);
 	}
 }

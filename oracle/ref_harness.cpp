@@ -86,7 +86,11 @@ struct Harness {
 	AIS::ModelBase* mb = nullptr;
 	AIS::ModelStandard* ms = nullptr;
 	AIS::ModelEngineV2* mv = nullptr;
-	AIS::Model* mgpu = nullptr; // AIS::ModelDefaultGPU / ModelChallengerGPU (refgpu build only)
+#ifdef HASMI355X
+	AIS::ModelDefaultGPU* mgpu = nullptr; // the GPU engines (refgpu build only)
+#else
+	AIS::Model* mgpu = nullptr;
+#endif
 	AIS::Model* model = nullptr;
 	TAG tag;
 	Format fmt;
@@ -106,8 +110,11 @@ struct Harness {
 
 extern "C" {
 
-// kind: 0 = ModelStandard, 1 = ModelBase, 2 = ModelDefault, 4 = ModelChallenger, 11 = ModelEngineV2; libaisrefgpu.so only: 12 = ModelDefaultGPU, 14 = ModelChallengerGPU.  fmt: 0 = CU8, 1 = CF32, 2 = CS8, 3 = CS16.
-// flags: bit 0 record float taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`, bit 3 `-go FP_DS on`, bit 4 channel mode X (`-c X`), bit 5 `-go MA on`
+// kind: 0 = ModelStandard, 1 = ModelBase, 2 = ModelDefault, 4 = ModelChallenger, 11 = ModelEngineV2; libaisrefgpu.so only: 12 = ModelDefaultGPU,
+// 14 = ModelChallengerGPU, 20 = ModelStandardGPU, 21 = ModelBaseGPU.  fmt: 0 = CU8, 1 = CF32, 2 = CS8, 3 = CS16.
+// flags: bit 0 record float taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`, bit 3 `-go FP_DS on`, bit 4 channel mode X (`-c X`), bit 5 `-go MA on`;
+// GPU engines: bit 6 the AIS::Decoder state machines on the device (GpuPool::setGpuDecode), bit 7 pipelined hand-off (GpuPool::setPipelined).
+// GPU engines created with the same configuration before their first block share ONE GPU context (GpuPool): feed them from one thread each.
 void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 	const int taps = flags & 1;
 	try {
@@ -119,8 +126,13 @@ void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 		else if (kind == 11) { h->mv = new AIS::ModelEngineV2(); h->model = h->mv; }
 #ifdef HASMI355X
 		// what Receiver::addModel (Application/Receiver.cpp:155-195) would do for the new engine numbers
-		else if (kind == 12) { h->mgpu = new AIS::ModelDefaultGPU(); h->model = h->mgpu; }
-		else if (kind == 14) { h->mgpu = new AIS::ModelChallengerGPU(); h->model = h->mgpu; }
+		else if (kind == 12 || kind == 14 || kind == 20 || kind == 21) {
+			AIS::GpuPool::instance().setGpuDecode((flags & 64) != 0);
+			AIS::GpuPool::instance().setPipelined((flags & 128) != 0);
+			h->mgpu = kind == 12 ? new AIS::ModelDefaultGPU() : kind == 14 ? (AIS::ModelDefaultGPU*)new AIS::ModelChallengerGPU()
+			        : kind == 20 ? (AIS::ModelDefaultGPU*)new AIS::ModelStandardGPU() : (AIS::ModelDefaultGPU*)new AIS::ModelBaseGPU();
+			h->model = h->mgpu;
+		}
 #endif
 		else { h->md = new AIS::ModelDefault(); h->model = h->md; }
 		if (flags & 2) h->model->SetKey(AIS::KEY_SETTING_DSK, "ON");
@@ -195,6 +207,16 @@ int ref_feed(void* hv, const void* data, int nbytes) {
 	auto t1 = std::chrono::high_resolution_clock::now();
 	h->seconds += std::chrono::duration<double>(t1 - t0).count();
 	return 0;
+}
+
+// pipelined GPU batches: collect the last block's outputs (what the patched Receiver does when its device has delivered its last block)
+void ref_flush(void* hv) {
+#ifdef HASMI355X
+	Harness* h = (Harness*)hv;
+	if (h->mgpu) h->mgpu->Flush(h->tag);
+#else
+	(void)hv;
+#endif
 }
 
 double ref_seconds(void* hv) { return ((Harness*)hv)->seconds; }

@@ -33,7 +33,7 @@ def have_ref(kind="strict"):
 class _Chain:
     """One receiver instance behind either checker library."""
 
-    def __init__(self, lib, prefix, model, rate, fmt, taps, dsk=False, ps_ema=True, fp_ds=False, mode_x=False, ma=False):
+    def __init__(self, lib, prefix, model, rate, fmt, taps, dsk=False, ps_ema=True, fp_ds=False, mode_x=False, ma=False, extra_flags=0):
         self.lib, self.p = lib, prefix
         f = lambda name: getattr(lib, prefix + name)
         f("create").restype = ctypes.c_void_p
@@ -56,7 +56,7 @@ class _Chain:
         f("destroy").argtypes = [ctypes.c_void_p]
         self._f = f
         self.fmt = fmt
-        flags = (1 if taps else 0) | (2 if dsk else 0) | (0 if ps_ema else 4) | (8 if fp_ds else 0) | (16 if mode_x else 0) | (32 if ma else 0)
+        flags = (1 if taps else 0) | (2 if dsk else 0) | (0 if ps_ema else 4) | (8 if fp_ds else 0) | (16 if mode_x else 0) | (32 if ma else 0) | extra_flags
         self.h = f("create")(model, rate, {"cu8": 0, "cf32": 1, "cs8": 2, "cs16": 3}[fmt], flags)
         if not self.h:
             raise RuntimeError("checker create failed")
@@ -157,13 +157,19 @@ def have_refgpu():
     return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libaisrefgpu.so"))
 
 
-def RefGpu(model=12, rate=1536000, fmt="cf32", dsk=False, ps_ema=True, fp_ds=False, ma=False):
+def RefGpu(model=12, rate=1536000, fmt="cf32", dsk=False, ps_ema=True, fp_ds=False, ma=False, gpu_decode=False, pipelined=False):
     """oracle/_ref/libaisrefgpu.so: the reference's unmodified sources PLUS the reference-side binding of libaisgpu.so
     (integration/reference/Source/DSP/GPU/ModelGPU.cpp, an AIS::Model subclass compiled against the reference's real headers).
-    model 2 / 4 = the reference's own ModelDefault / ModelChallenger, 12 / 14 = the same engines with the DSP on the GPU."""
+    model 2 / 4 / 0 / 1 = the reference's own ModelDefault / ModelChallenger / ModelStandard / ModelBase, 12 / 14 / 20 / 21 = the same
+    engines with the DSP on the GPU.  GPU engines created with the same configuration before their first block share one GPU context
+    (feed them from one thread each); gpu_decode: decoder state machines on the device; pipelined: call flush() after the last block."""
     lib = _lib(os.path.join(ORACLE_DIR, "_ref", "libaisrefgpu.so"))
     lib.ref_reset_seq()
-    return _Chain(lib, "ref_", model, rate, fmt, False, dsk, ps_ema, fp_ds, False, ma)
+    c = _Chain(lib, "ref_", model, rate, fmt, False, dsk, ps_ema, fp_ds, False, ma, extra_flags=(64 if gpu_decode else 0) | (128 if pipelined else 0))
+    lib.ref_flush.argtypes = [ctypes.c_void_p]
+    lib.ref_flush.restype = None
+    c.flush = lambda: lib.ref_flush(c.h)
+    return c
 
 
 def oracle_lib():

@@ -1157,7 +1157,8 @@ def test_batch_survives_receivers_that_end_early_or_stall():
 @pytest.mark.parametrize("gpu_model,cpu_model,rate,fmt,block,nblocks,kw", [
     (12, 2, 1536000, "cf32", 786432, 4, {}), (12, 2, 1536000, "cu8", 131072, 12, {}), (12, 2, 1536000, "cu8", 131072, 8, {"fp_ds": True}),
     (12, 2, 1536000, "cf32", 131072, 8, {"ps_ema": False}), (12, 2, 288000, "cf32", 49152, 12, {}), (12, 2, 6000000, "cs16", 786432, 4, {}),
-    (14, 4, 1536000, "cf32", 131072, 10, {}), (14, 4, 6000000, "cf32", 786432, 5, {})])
+    (14, 4, 1536000, "cf32", 131072, 10, {}), (14, 4, 6000000, "cf32", 786432, 5, {}),
+    (20, 0, 1536000, "cf32", 131072, 10, {}), (21, 1, 1536000, "cf32", 131072, 10, {}), (21, 1, 768000, "cu8", 65536, 16, {})])
 def test_reference_binding_compiled_against_the_real_reference(gpu_model, cpu_model, rate, fmt, block, nblocks, kw):
     """Row 8(b), for real: integration/reference/Source/DSP/GPU/ModelGPU.cpp -- an AIS::Model subclass (DSP/Model.h:76-126) that
     takes the device's RAW blocks through the reference's own Connection<RAW> (Library/Stream.h), calls the C ABI, and feeds the
@@ -1465,3 +1466,41 @@ def test_model_base_chunk_parallel_sampler_and_decoder(case, mode, monkeypatch):
         a, c = m.msg_meta(), want[i][1]
         assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
         m.close()
+
+
+@pytest.mark.skipif(not checkers.have_refgpu(), reason="oracle/_ref/libaisrefgpu.so not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("gpu_model,cpu_model,opts", [(12, 2, {}), (12, 2, {"gpu_decode": True}), (12, 2, {"pipelined": True}),
+                                                      (12, 2, {"gpu_decode": True, "pipelined": True}), (14, 4, {}), (14, 4, {"gpu_decode": True}),
+                                                      (20, 0, {}), (20, 0, {"gpu_decode": True}), (21, 1, {}), (21, 1, {"gpu_decode": True})])
+def test_eight_reference_receivers_share_one_gpu_context(gpu_model, cpu_model, opts):
+    """The batched hand-off compiled against the REAL reference (integration/reference/Source/DSP/GPU/ModelGPU.cpp + GpuBatch):
+    eight AIS::Model instances of one libaisrefgpu.so process -- the reference's own Device, TAG, AIS::Decoder, SimplePLL,
+    Deinterleave, Message objects -- register with the process-wide GpuPool, their eight device threads meet once per block in ONE
+    aisgpu context (n_receivers = 8), and every receiver prints, in order, exactly what the reference's CPU engine prints for its
+    stream.  Also with the decoder state machines on the device (frames finished by GpuEmitFrame = the tail of AIS::Decoder::Run)
+    and with the pipelined hand-off (messages one block late, Flush() after the last block)."""
+    import threading
+    R, block, nblocks = 8, 131072, 8
+    xs = [synth.receiver_stream(block * nblocks, receiver_id=500 + r, gap_slots=(0, 2)) for r in range(R)]
+    want = []
+    for x in xs:
+        c = checkers.RefGpu(model=cpu_model)
+        c.feed_blocks(x, block)
+        want.append((c.nmea(), c.msg_meta()))
+        c.close()
+    models = [checkers.RefGpu(model=gpu_model, **opts) for _ in range(R)]   # all built before the first block: one group, one context
+
+    def run(r):
+        for b in range(nblocks):
+            assert models[r].feed(xs[r][b * block:(b + 1) * block]) == 0
+        if opts.get("pipelined"):
+            models[r].flush()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(R)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for r in range(R):
+        assert models[r].nmea() == want[r][0] and len(want[r][0]) >= 2, "rx %d" % r
+        a, c = models[r].msg_meta(), want[r][1]
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]), "rx %d: tag.level / tag.ppm per message" % r
+        models[r].close()
