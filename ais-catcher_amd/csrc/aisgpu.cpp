@@ -78,7 +78,6 @@ struct TraceRec { const char* name; long long block; hipEvent_t a, b; }; // AISG
 #endif
 constexpr int NBUF = AISGPU_NBUF;    // ring depth of the buffers that cross from the front-end stream to the others (4 against 3: -1.5 % per step, profiles/r03_expA.txt)
 constexpr int MAXSUB = 4;  // downstream blocks ("flushes" of the resampler) that one input block can complete
-constexpr int XPAD = 128;  // extra history of the pre-decimated stream in front of one full block (resampler halo)
 
 // How the samples get from the input rate to the two 48 kHz channels (ModelFrontend::buildModel, Model.cpp:129-346)
 enum Mode {
@@ -130,6 +129,11 @@ struct aisgpu {
 	//   s1 (= s2): K2c -> K3 -> K4 (+ D2H of the outputs) (apply phasors, FIR/ScatterPLL, PhaseSearchEMA)
 	// Buffers that cross a stream boundary are ring buffered by downstream-block index.
 	hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, s3 = nullptr, s4 = nullptr, s5 = nullptr;
+	// ds: the stream of everything BEHIND the 48 kHz front-end output on the resampled ladders (FFT, searches, apply, FIR, FM branch).
+	// Normally the front stream itself; on a resampled ladder with a pre-decimation pass (6 MSPS: BASELINE configs[2]) it is s4, so
+	// that the HBM-bound passes over the NEXT input block (pre-decimation, resampler front end) overlap the dozen small
+	// latency-bound kernels behind this one.
+	hipStream_t ds = nullptr; hipEvent_t ev_pre[NBUF] = {}; // ev_pre[q]: the resampler front end of downstream block q is done (front stream -> ds)
 	hipEvent_t ev_phasor[NBUF] = {};  // s3: phasor(f) done -> s1 may apply it
 	hipEvent_t ev_search[NBUF] = {};  // s4: fz(f) known -> s3 may run the phasor recurrence
 	hipEvent_t k1_done[NBUF] = {};    // the event bound to the front-end launch of block f (hipExtLaunchKernelGGL), or nullptr: ev_search is recorded behind it
@@ -145,7 +149,9 @@ struct aisgpu {
 	// staging of host blocks (aisgpu_submit), double buffered by input block: block f+1 is copied in (pinned buffer, then H2D on a
 	// copy stream of its own) while block f is still being computed
 	hipStream_t sc = nullptr; hipEvent_t ev_h2d[2] = {}, ev_in_free[2] = {}; bool in_used[2] = {}; std::mutex submit_mtx; bool staged = false;
-	float2* d_xpre[2] = {};           // pre-decimated stream: [R][xh + n_pre], ping-pong by input block (MODE_PRE uses [0] only)
+	float2* d_xpre[4] = {};           // pre-decimated stream: [R][xh + n_pre], ping-pong by input block (MODE_PRE uses [0] only); resampled ladders: ring of
+	                                  // four [R][n_pre]: a flush may reach a whole input block back (no history copy: K1uParams::xprev / xprev2), and the
+	                                  // pass over block f+1 must not wait for the resampler kernels of block f
 	float2* d_xmid = nullptr;         // [R][block_len >> KPa]: between the two passes of a pre-decimation of more than four stages
 	bool mode_x = false;              // channel mode X: single-channel front end K1x (npost stages down to 48 kHz), channel B silent
 	int npost = 2;                    // CIC5 stages behind the resampler (K1u): 2, 1 (192k bucket), 0 (96 kSPS input: no resampler either)
@@ -535,30 +541,30 @@ int enqueue_back(aisgpu_t* h) {
 	const int q = h->pend.q, pb = h->pend.pb, lv = h->pend.lv;
 	const long long g0 = h->pend.g0, g1 = h->pend.g1;
 	const K2Params k2 = make_k2(h, q);
-	WAITEV(h->stream, h->ev_phasor[q]);
-	HIPCHK(launch_k2c(k2, h->n_chan, h->stream));
-	HIPCHK(hipEventRecord(h->ev_c48free[q], h->stream));
+	WAITEV(h->ds, h->ev_phasor[q]);
+	HIPCHK(launch_k2c(k2, h->n_chan, h->ds));
+	HIPCHK(hipEventRecord(h->ev_c48free[q], h->ds));
 	K3Params k3;
 	k3.cgf = h->d_cgf; k3.cgf_stride = CGF_HIST + h->L; k3.sym = h->d_sym[pb]; k3.sym_stride = h->Gcap; k3.lvl = h->d_lvl[lv];
 	k3.fir_tap = h->d_firtap; k3.fir_tap_stride = 8 + h->L;
 	memcpy(k3.taps, TAPS_COHERENT, sizeof k3.taps);
 	k3.first_group = g0; k3.first_sample48 = h->pend.first48; k3.n_groups = (int)(g1 - g0);
-	WAITEV(h->stream, h->ev_sym[pb]); // sym[pb] was last read by PhaseSearch of block f-2,
-	WAITEV(h->stream, h->ev_ema[lv]); // lvl[lv] by the frame decoder / the copies of block f-4
-	HIPCHK(launch_k3(k3, h->n_chan, h->stream));
+	WAITEV(h->ds, h->ev_sym[pb]); // sym[pb] was last read by PhaseSearch of block f-2,
+	WAITEV(h->ds, h->ev_ema[lv]); // lvl[lv] by the frame decoder / the copies of block f-4
+	HIPCHK(launch_k3(k3, h->n_chan, h->ds));
 	if (h->challenger) { // FM branch on the same derotated samples (Model.cpp:638-639)
 		K5Params k5;
 		k5.x = h->d_cgf; k5.x_stride = CGF_HIST + h->L; k5.x_off = CGF_HIST; k5.prev_in = nullptr; k5.prev_out = nullptr; k5.fm = h->d_fm; k5.fm_stride = FM_HIST + h->L;
 		k5.fmbits = h->d_fmbits[pb]; k5.fmbits_stride = h->L / 32; k5.L = h->L;
 		k5.fir_out = h->d_fmfir; k5.fir_stride = h->L;
 		memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
-		HIPCHK(launch_k5(k5, h->n_chan, h->stream));
+		HIPCHK(launch_k5(k5, h->n_chan, h->ds));
 		if (h->gpu_decode) { // device decoders: the FM bits regrouped per decoder, here, where this and the previous block's bits are in order
-			WAITEV(h->stream, h->ev_ema[lv ^ 2]); // fmrows[pb] was last read by the decoders of block f-2
-			HIPCHK(launch_k7_pack(make_k7(h, pb, lv, g0, (int)(g1 - g0), h->pend.block, h->pend.sub), h->stream));
+			WAITEV(h->ds, h->ev_ema[lv ^ 2]); // fmrows[pb] was last read by the decoders of block f-2
+			HIPCHK(launch_k7_pack(make_k7(h, pb, lv, g0, (int)(g1 - g0), h->pend.block, h->pend.sub), h->ds));
 		}
 	}
-	HIPCHK(hipEventRecord(h->ev_k3[pb], h->stream));
+	HIPCHK(hipEventRecord(h->ev_k3[pb], h->ds));
 
 	// ---- PhaseSearchEMA chains on s1: VALU-bound, overlaps the HBM-bound front end of the next block
 	WAITEV(h->s2, h->ev_k3[pb]);
@@ -611,9 +617,9 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 		if (!h->k1_done[q]) { HIPCHK(hipEventRecord(h->ev_search[q], h->stream)); h->k1_done[q] = h->ev_search[q]; }
 	} else { // FFT + searches follow the front end on its stream (four busy streams are the limit)
 		h->k1_done[q] = nullptr;
-		{ TraceScope t(h, "fft", h->stream); HIPCHK(launch_k2a_fft(k2, h->n_chan, h->stream)); }
-		{ TraceScope t(h, "search", h->stream); HIPCHK(launch_k2a_search(k2, h->n_chan, h->stream)); }
-		HIPCHK(hipEventRecord(h->ev_search[q], h->stream));
+		{ TraceScope t(h, "fft", h->ds); HIPCHK(launch_k2a_fft(k2, h->n_chan, h->ds)); }
+		{ TraceScope t(h, "search", h->ds); HIPCHK(launch_k2a_search(k2, h->n_chan, h->ds)); }
+		HIPCHK(hipEventRecord(h->ev_search[q], h->ds));
 	}
 	WAITEV(h->s3, h->k1_done[q] ? h->k1_done[q] : h->ev_search[q]);
 	WAITEV(h->s3, h->ev_c48free[q]); // ck[q] was last read by K6 of block f-NBUF
@@ -649,9 +655,9 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 	k5.fmbits = h->d_fmbits[pb]; k5.fmbits_stride = h->L / 32; k5.L = h->L;
 	k5.fir_out = h->d_fmfir; k5.fir_stride = h->L;
 	memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
-	if (h->gpu_decode && h->base_chunked) WAITEV(h->stream, h->ev_k4[pb]); // fmbits[pb] was last read by the decoders of block f-2 (on s1)
-	HIPCHK(launch_k5(k5, h->n_chan, h->stream));
-	HIPCHK(hipEventRecord(h->ev_c48free[q], h->stream));
+	if (h->gpu_decode && h->base_chunked) WAITEV(h->ds, h->ev_k4[pb]); // fmbits[pb] was last read by the decoders of block f-2 (on s1)
+	HIPCHK(launch_k5(k5, h->n_chan, h->ds));
+	HIPCHK(hipEventRecord(h->ev_c48free[q], h->ds));
 	if (h->gpu_decode) { // SimplePLL + decoder (ModelBase) / Deinterleave + five decoders (ModelStandard) on the device, behind the filter
 		const long long g0 = h->n48 / 5, g1 = (h->n48 + h->L) / 5;
 		K7Params k7 = make_k7(h, pb, 0, g0, (int)(g1 - g0), (unsigned)h->block_idx, (unsigned)h->n_sub);
@@ -659,9 +665,9 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 			// ModelStandard's five decoders per channel are ModelDefault's mesh on other bits: the event-driven kernels take the FM
 			// rows as their decision rows (no level: tag.sample_lvl is never set in this engine), on PhaseSearch's otherwise idle
 			// stream, next to the next block's front end (the sequential mesh kernel held the front stream for 2.5 ms per step)
-			WAITEV(h->stream, h->ev_k4[pb]); // fmrows[pb] was last read by the decoders of block f-2
-			HIPCHK(launch_k7_pack(k7, h->stream));
-			HIPCHK(hipEventRecord(h->ev_sym[pb], h->stream));
+			WAITEV(h->ds, h->ev_k4[pb]); // fmrows[pb] was last read by the decoders of block f-2
+			HIPCHK(launch_k7_pack(k7, h->ds));
+			HIPCHK(hipEventRecord(h->ev_sym[pb], h->ds));
 			WAITEV(h->s1, h->ev_sym[pb]);
 			K7Params kq = k7;
 			kq.bits = h->d_fmrows[pb]; kq.bits_stride = h->fmrow_words; kq.lvl = nullptr; kq.kind = 0;
@@ -670,18 +676,18 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 		} else if (h->dec_kind == 3 && h->base_chunked && !(h->k7_alt && (h->block_idx & 1))) {
 			// ModelBase: the chunk-parallel sampler + decoder kernels on PhaseSearch's otherwise idle stream, next to the next block's
 			// front end (k7_base alone held the front stream for 5 ms per step of 256 receivers)
-			HIPCHK(hipEventRecord(h->ev_sym[pb], h->stream));
+			HIPCHK(hipEventRecord(h->ev_sym[pb], h->ds));
 			WAITEV(h->s1, h->ev_sym[pb]);
 			h->k7b.k = k7;
 			HIPCHK(launch_k7b(h->k7b, h->s1));
 			HIPCHK(hipEventRecord(h->ev_k4[pb], h->s1));
 		} else {
-			if ((h->dec_kind == 1 || h->dec_kind == 3) && h->k7_alt) WAITEV(h->stream, h->ev_k4[pb ^ 1]); // (test hook: the previous block's decoders ran on s1)
-			if (h->dec_kind == 1) HIPCHK(launch_k7_pack(k7, h->stream));
-			HIPCHK(launch_k7_mesh(k7, h->stream));
+			if ((h->dec_kind == 1 || h->dec_kind == 3) && h->k7_alt) WAITEV(h->ds, h->ev_k4[pb ^ 1]); // (test hook: the previous block's decoders ran on s1)
+			if (h->dec_kind == 1) HIPCHK(launch_k7_pack(k7, h->ds));
+			HIPCHK(launch_k7_mesh(k7, h->ds));
 		}
 	}
-	HIPCHK(hipEventRecord(h->ev_k3[pb], h->stream));
+	HIPCHK(hipEventRecord(h->ev_k3[pb], h->ds));
 	WAITEV(h->s2, h->ev_k3[pb]); // aisgpu_sync_outputs copies on s2
 	if (h->n_sub < MAXSUB) {
 		SubOut& so = h->sub[h->n_sub++];
@@ -698,7 +704,7 @@ int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
 		const size_t C = h->n_chan;
 		const size_t s_ = (size_t)h->out_set * MAXSUB + h->n_sub; // host slot: two sets, by input block
 		HIPCHK(hipMemcpy2DAsync(h->h_c48 + s_ * C * h->L, (size_t)h->L * sizeof(float2), h->d_c48[q], (size_t)h->c48s * sizeof(float2),
-		                        (size_t)h->L * sizeof(float2), C, hipMemcpyDeviceToHost, h->stream));
+		                        (size_t)h->L * sizeof(float2), C, hipMemcpyDeviceToHost, h->ds));
 		if (h->v2_assist) { // FreqOffset::Estimate of every offset-0 / offset-256 window, midWins' energies, the FM branch up to its sign
 			KV2Params k{};
 			k.c48 = h->d_c48[q]; k.c48_stride = h->c48s; k.hist = h->d_v2hist; k.omega = h->d_omega;
@@ -707,16 +713,16 @@ int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
 			k.fir_out = h->d_fmfir; k.fir_stride = h->L;
 			memcpy(k.taps, TAPS_RECEIVER, sizeof k.taps);
 			k.n_windows = h->W; k.L = h->L; k.n_chan = h->n_chan;
-			HIPCHK(launch_kv2(k, h->stream));
-			HIPCHK(hipMemcpyAsync(h->h_v2f + s_ * C * 2 * h->W, h->d_v2f, C * 2 * h->W * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-			HIPCHK(hipMemcpyAsync(h->h_v2prom + s_ * C * 2 * h->W, h->d_v2prom, C * 2 * h->W * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-			HIPCHK(hipMemcpyAsync(h->h_v2en + s_ * C * (h->W + 1), h->d_v2en, C * (h->W + 1) * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-			HIPCHK(hipMemcpyAsync(h->h_fmbits + s_ * C * (h->L / 32), h->d_fmbits[pb], C * (h->L / 32) * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(launch_kv2(k, h->ds));
+			HIPCHK(hipMemcpyAsync(h->h_v2f + s_ * C * 2 * h->W, h->d_v2f, C * 2 * h->W * sizeof(float), hipMemcpyDeviceToHost, h->ds));
+			HIPCHK(hipMemcpyAsync(h->h_v2prom + s_ * C * 2 * h->W, h->d_v2prom, C * 2 * h->W * sizeof(float), hipMemcpyDeviceToHost, h->ds));
+			HIPCHK(hipMemcpyAsync(h->h_v2en + s_ * C * (h->W + 1), h->d_v2en, C * (h->W + 1) * sizeof(float), hipMemcpyDeviceToHost, h->ds));
+			HIPCHK(hipMemcpyAsync(h->h_fmbits + s_ * C * (h->L / 32), h->d_fmbits[pb], C * (h->L / 32) * sizeof(uint32_t), hipMemcpyDeviceToHost, h->ds));
 		}
 		SubOut& so = h->sub[h->n_sub++];
 		so.pb = pb; so.lv = 0; so.q = q; so.groups = 0; so.first_group = h->n48 / 5; so.first48 = h->n48;
 	}
-	HIPCHK(hipEventRecord(h->ev_c48free[q], h->stream));
+	HIPCHK(hipEventRecord(h->ev_c48free[q], h->ds));
 	h->n48 += h->L;
 	h->block_idx++;
 	return AISGPU_OK;
@@ -727,8 +733,8 @@ int enqueue_downstream(aisgpu_t* h, int q, int pb) {
 	if (h->base) return enqueue_downstream_base(h, q, pb);
 	if (h->fused) return enqueue_downstream_fused(h, q, pb);
 	const K2Params k2 = make_k2(h, q);
-	HIPCHK(launch_k2a_fft(k2, h->n_chan, h->stream));
-	HIPCHK(hipEventRecord(h->ev_front[q], h->stream));
+	HIPCHK(launch_k2a_fft(k2, h->n_chan, h->ds));
+	HIPCHK(hipEventRecord(h->ev_front[q], h->ds));
 	// ---- s4: the sequential spectral searches, then on s3 the sequential CGF phasor recurrence (needs fz of this
 	// block; rotT[q] was last read by apply(f-NBUF))
 	WAITEV(h->s4, h->ev_front[q]);
@@ -1022,7 +1028,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		h->ptiles_per_span = span_tiles(h->ptiles_per_block, cfg->n_receivers, cfg->tiles_per_span);
 		h->pspans = (h->ptiles_per_block + h->ptiles_per_span - 1) / h->ptiles_per_span;
 	}
-	if (mode == MODE_RESAMPLE) h->xh = h->n_pre + XPAD;
+	if (mode == MODE_RESAMPLE) h->xh = 0; // (ring of three input blocks instead of a copied history)
 	if (mode == MODE_DSK || mode == MODE_96K) h->xh = DSK_HIST;
 	*out = h; // from here on the caller destroys it on failure
 
@@ -1081,6 +1087,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		h->s2 = h->s1; // apply + FIR + PhaseSearchEMA of a block run back to back on one stream
 		h->dec_defer = h->s5 == h->s4 && h->s4 != h->stream;
 	}
+	h->ds = (!h->serial && h->mode == MODE_RESAMPLE && h->KP > 0) ? h->s4 : h->stream;
+	for (int i = 0; i < NBUF; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_pre[i], hipEventDisableTiming));
 	for (int i = 0; i < NBUF; i++) {
 		HIPCHK(hipEventCreateWithFlags(&h->ev_front[i], hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&h->ev_phasor[i], hipEventDisableTiming));
@@ -1133,7 +1141,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		}
 	}
 	if (KP > 0 || mode == MODE_DSK || mode == MODE_RESAMPLE || mode == MODE_96K) {
-		const int nx = mode == MODE_RESAMPLE || mode == MODE_DSK || mode == MODE_96K ? 2 : 1;
+		const int nx = mode == MODE_RESAMPLE ? 4 : (mode == MODE_DSK || mode == MODE_96K) ? 2 : 1;
 		for (int i = 0; i < nx; i++) HIPCHK(dalloc(&h->d_xpre[i], R * ((size_t)h->xh + h->n_pre)));
 		if (mode == MODE_PRE) for (int i = 0; i < 2; i++) HIPCHK(dalloc((unsigned char**)&h->d_hist2[i], R * h->tile_in * 8));
 		if (h->KPa) { // second pre-decimation pass: four stages on the CF32 stream of the first
@@ -1316,7 +1324,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 		if (h->ev_k3[i]) hipEventDestroy(h->ev_k3[i]);
 		if (h->ev_k4[i]) hipEventDestroy(h->ev_k4[i]);
 		hipFree(h->d_sym[i]); hipFree(h->d_ema[i]);
-		hipFree(h->d_usidx[i]); hipFree(h->d_usalpha[i]); hipFree(h->d_xpre[i]);
+		hipFree(h->d_usidx[i]); hipFree(h->d_usalpha[i]); hipFree(h->d_xpre[i]); hipFree(h->d_xpre[i + 2]);
 		if (h->h_usidx[i]) hipHostFree(h->h_usidx[i]);
 		if (h->h_usalpha[i]) hipHostFree(h->h_usalpha[i]);
 	}
@@ -1345,6 +1353,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	if (h->h_bits) hipHostFree(h->h_bits);
 	if (h->h_lvl) hipHostFree(h->h_lvl);
 	if (h->h_ppm) hipHostFree(h->h_ppm);
+	for (int i = 0; i < NBUF; i++) if (h->ev_pre[i]) hipEventDestroy(h->ev_pre[i]);
 	if (h->stream) hipStreamDestroy(h->stream);
 	if (h->s1 && !h->serial) hipStreamDestroy(h->s1);
 	if (h->s3 && !h->serial) hipStreamDestroy(h->s3);
@@ -1428,16 +1437,17 @@ int aisgpu_run(aisgpu_t* h) {
 	long long xstride = 0;
 	if (h->KP == 0 && (h->mode == MODE_DSK || h->mode == MODE_RESAMPLE || h->mode == MODE_96K)) { // 288 kHz input: no CIC5 stage in front of DownsampleKFilter, only the
 		// conversion; likewise rates resampled into the 384k bucket: Upsample works on the converted input itself (Model.cpp:295-301)
-		const int xb = (int)(h->in_blocks & 1);
+		const bool ring = h->mode == MODE_RESAMPLE;
+		const int xb = ring ? (int)(h->in_blocks & 3) : (int)(h->in_blocks & 1);
 		xcur = h->d_xpre[xb];
 		xstride = (long long)h->xh + h->n_pre;
-		if (h->in_blocks > 0) HIPCHK(launch_copy_rows(h->d_xpre[xb ^ 1] + h->n_pre, xstride, xcur, xstride, h->xh, R, h->stream));
+		if (!ring && h->in_blocks > 0) HIPCHK(launch_copy_rows(h->d_xpre[xb ^ 1] + h->n_pre, xstride, xcur, xstride, h->xh, R, h->stream));
 		if (h->ma_m) HIPCHK(launch_ma_rows(h->cur_in, h->cur_in_stride, h->kfmt, h->ma_m, xcur + h->xh, xstride, h->n_pre, R, h->stream));
 		else HIPCHK(launch_convert_rows(h->cur_in, h->cur_in_stride, h->kfmt, xcur + h->xh, xstride, h->n_pre, R, h->stream));
 	}
 	if (h->KP > 0) {
-		const bool two = h->mode == MODE_RESAMPLE || h->mode == MODE_DSK;
-		const int xb = two ? (int)(h->in_blocks & 1) : 0;
+		const bool ring = h->mode == MODE_RESAMPLE, two = h->mode == MODE_DSK;
+		const int xb = ring ? (int)(h->in_blocks & 3) : two ? (int)(h->in_blocks & 1) : 0;
 		xcur = h->d_xpre[xb];
 		xstride = (long long)h->xh + h->n_pre;
 		if (two && h->in_blocks > 0) // history = the last xh samples before this block
@@ -1610,6 +1620,7 @@ int aisgpu_run(aisgpu_t* h) {
 					if (h->us_dsk) { // US >> DSK >> ROT: the flush is a whole number of the filter's 8192-sample output blocks
 						K1kParams kk;
 						kk.xin = xcur; kk.xin_stride = xstride; kk.xin_off = h->xh;
+						kk.xprev = h->d_xpre[(h->in_blocks + 3) & 3]; kk.xprev2 = h->d_xpre[(h->in_blocks + 2) & 3]; kk.n_in = h->n_pre;
 						kk.rot = h->d_rot[pb]; kk.c48 = h->d_c48[q]; kk.c48_stride = h->c48s; kk.L = h->L;
 						kk.us_idx = h->d_usidx[pb]; kk.us_alpha = h->d_usalpha[pb];
 						memcpy(kk.taps, TAPS_BH_28_3, sizeof kk.taps);
@@ -1617,11 +1628,16 @@ int aisgpu_run(aisgpu_t* h) {
 					} else {
 					K1uParams ku;
 					ku.xin = xcur; ku.xin_stride = xstride; ku.xin_off = h->xh;
+					ku.xprev = h->d_xpre[(h->in_blocks + 3) & 3]; ku.xprev2 = h->d_xpre[(h->in_blocks + 2) & 3]; ku.n_in = h->n_pre;
 					ku.us_idx = h->d_usidx[pb]; ku.us_alpha = h->d_usalpha[pb]; ku.rot = h->d_rot[pb];
 					ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
 					ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->has_fdc; ku.L = h->L;
 					if (h->mode_x) HIPCHK(launch_k1x(ku, h->npost, R, h->stream));
 					else HIPCHK(launch_k1u(ku, h->npost, R, h->stream));
+					}
+					if (h->ds != h->stream) { // the 48 kHz channels of this flush exist: everything behind them runs on ds, next to the next input block's pass
+						HIPCHK(hipEventRecord(h->ev_pre[q], h->stream));
+						WAITEV(h->ds, h->ev_pre[q]);
 					}
 					int rc = enqueue_downstream(h, q, pb);
 					if (rc) return rc;

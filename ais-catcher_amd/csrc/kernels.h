@@ -40,6 +40,27 @@ struct K1uParams {
 	float2* c48; long long c48_stride;
 	float alpha, beta; int has_fdc;
 	int L;                  // 48 kHz samples per channel per flush block (len / 8)
+	// resampled ladders: the input blocks live in a ring of three buffers instead of one buffer with a copied history (a flush may
+	// begin a whole input block back): sample i < 0 is xprev[n_in + i], i < -n_in is xprev2[2 n_in + i] (rows of xin_stride, no offset)
+	const float2* xprev = nullptr; const float2* xprev2 = nullptr; int n_in = 0;
+};
+// sample i of the pre-decimated stream relative to the current input block's start (see K1uParams::xprev)
+struct XRow {
+	const float2 *cur, *prev, *prev2; int n;
+	__host__ __device__ float2 operator[](int i) const { return (i >= 0 || !prev) ? cur[i] : (i >= -n ? prev[n + i] : prev2[2 * n + i]); }
+};
+// the same for a workgroup that only touches samples [lo, hi]: nearly always they lie in ONE of the three buffers, and the access is a
+// plain pointer again (workgroup-uniform choice); only a span that straddles a block boundary goes through the three-way select
+struct XSpan {
+	XRow row; const float2* base; bool mixed;
+	__host__ __device__ XSpan(const XRow& r, int lo, int hi) : row(r) {
+		mixed = false;
+		if (lo >= 0 || !r.prev) base = r.cur;
+		else if (hi < 0 && lo >= -r.n) base = r.prev + r.n;
+		else if (hi < -r.n) base = r.prev2 + 2 * r.n;
+		else { base = r.cur; mixed = true; }
+	}
+	__host__ __device__ float2 operator[](int i) const { return mixed ? row[i] : base[i]; }
 };
 
 struct K1kParams { // decimate-by-3 front end (DownsampleKFilter ladders: 288k * 2^k)
@@ -49,6 +70,7 @@ struct K1kParams { // decimate-by-3 front end (DownsampleKFilter ladders: 288k *
 	float taps[26];         // Filters::BlackmanHarris_28_3
 	const int* us_idx; const float* us_alpha; // != nullptr: [US_HIST + len] Upsample in front of the filter (see K1uParams), xin is ITS input
 	int L;                  // 48 kHz samples per channel per block
+	const float2* xprev = nullptr; const float2* xprev2 = nullptr; int n_in = 0; // ring of three input blocks (see K1uParams)
 };
 constexpr int DSK_HIST = 128; // samples of the 288 kHz stream kept in front of a block
 

@@ -491,7 +491,11 @@ __global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
 	const int t = threadIdx.x;
 	const int rx = blockIdx.y;
 	const int m0 = blockIdx.x * K1U_M;
-	const float2* x = p.xin + (size_t)rx * p.xin_stride + p.xin_off; // x[i]: i relative to the current block start
+	const size_t xrow = (size_t)rx * p.xin_stride + p.xin_off;
+	const XRow xr{ p.xin + xrow, p.xprev ? p.xprev + xrow : nullptr, p.xprev2 ? p.xprev2 + xrow : nullptr, p.n_in }; // xr[i]: i relative to the current block start
+	// the input samples this workgroup's outputs interpolate between (us_idx is non-decreasing)
+	const int nn_lo = NPOST == 2 ? 8 * m0 - 83 : NPOST == 1 ? 4 * m0 - 39 : 0, nn_hi = NPOST == 2 ? 8 * m0 + 8 * K1U_M - 1 : NPOST == 1 ? 4 * m0 + 4 * K1U_M - 1 : 0;
+	const XSpan x = NPOST == 0 ? XSpan(xr, 2 * m0 - 17, 2 * m0 + 2 * K1U_M) : XSpan(xr, p.us_idx[US_HIST + nn_lo] - 1, p.us_idx[US_HIST + nn_hi]);
 	const auto resampled = [&](int n) { // output n of Upsample: (1 - alpha) * a + alpha * b, products rounded separately (DSP.cpp:199)
 		const int i = p.us_idx[US_HIST + n];
 		const float al = p.us_alpha[US_HIST + n];
@@ -572,7 +576,8 @@ __global__ __launch_bounds__(256) void k1x_single_channel(K1uParams p) {
 	const int t = threadIdx.x;
 	const int rx = blockIdx.y;
 	const int m0 = blockIdx.x * M;
-	const float2* x = p.xin + (size_t)rx * p.xin_stride + p.xin_off;
+	const size_t xrow = (size_t)rx * p.xin_stride + p.xin_off;
+	const XRow x{ p.xin + xrow, p.xprev ? p.xprev + xrow : nullptr, p.xprev2 ? p.xprev2 + xrow : nullptr, p.n_in };
 	const auto level0 = [&](int n) -> float2 { // sample n of the stream the first CIC5 stage (or the 48 kHz point) sees
 		if (!p.us_idx) return x[n];
 		const int i = p.us_idx[US_HIST + n];
@@ -634,9 +639,11 @@ __global__ __launch_bounds__(256) void k1k_dsk_frontend(K1kParams p) {
 	const int t = threadIdx.x;
 	const int rx = blockIdx.y;
 	const int m0 = blockIdx.x * M;
-	const float2* x = p.xin + (size_t)rx * p.xin_stride + p.xin_off;
+	const size_t xrow = (size_t)rx * p.xin_stride + p.xin_off;
+	const XRow xr{ p.xin + xrow, p.xprev ? p.xprev + xrow : nullptr, p.xprev2 ? p.xprev2 + xrow : nullptr, p.n_in };
 	const int n_lo = 6 * m0 - 70;
 	if (p.us_idx) { // Upsample in front of the filter (rates below a decimate-by-3 bucket): sample n of the flush is interpolated
+		const XSpan x(xr, p.us_idx[US_HIST + n_lo] - 1, p.us_idx[US_HIST + n_lo + 6 * M + 69]);
 		for (int q = t; q < 6 * M + 70; q += 256) { // from the input stream like in K1u (DSP.cpp:199: products rounded separately)
 			const int n = n_lo + q;
 			const int i = p.us_idx[US_HIST + n];
@@ -646,7 +653,7 @@ __global__ __launch_bounds__(256) void k1k_dsk_frontend(K1kParams p) {
 			X[q] = make_float2(w0 * a.x + al * b.x, w0 * a.y + al * b.y);
 		}
 	} else
-	for (int q = t; q < 6 * M + 70; q += 256) X[q] = x[n_lo + q];
+	for (int q = t; q < 6 * M + 70; q += 256) X[q] = xr[n_lo + q];
 	__syncthreads();
 	for (int q = t; q < 2 * M + 15; q += 256) { // i = 2 m0 - 15 + q
 		const int i = 2 * m0 - 15 + q;
@@ -1076,6 +1083,7 @@ __device__ __forceinline__ void k1_fft_tail(const K1Params& p, int rx, int span,
 }
 
 __global__ __launch_bounds__(64) void k2_cgf_search(K2Params p) {
+	__builtin_amdgcn_s_setprio(3); // a few latency-bound waves (one lane per window) next to the HBM-bound passes: 0.26 -> 0.05 ms at 6 MSPS
 	const int lane = threadIdx.x;
 	const int W = blockIdx.x * 64 + lane, n_win_total = p.n_chan * p.n_windows;
 	const float* mrow = p.magT + (size_t)blockIdx.x * (512 * 64); // wave-uniform: mrow[64 * q + lane] = |X[(q + 256) % 512]| of this lane's window
