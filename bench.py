@@ -315,6 +315,44 @@ def parity_check(g, data, sequence, receivers, rate=RATE, model=2, fmt="cf32", b
     return len(receivers), [m for bad in res for m in bad]
 
 
+def pmc_traffic_pass(config, receivers):
+    """HBM-side bytes per launch of the front-end kernel from the PMC counters, measured in THIS session: two separate rocprofv3
+    --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only, as MI355X_MICROARCH.md prescribes) over a short serial-mode run of
+    this script.  FETCH_SIZE is doubled (gfx950 reports half of the bytes of wide coalesced reads); both counters are in KiB.
+    Returns a dict or None (no rocprofv3 on PATH, or a pass failed)."""
+    import shutil
+    import sqlite3
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            env = dict(os.environ, AISGPU_SERIAL="1", TMPDIR="/tmp")
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--config", str(config), "--receivers", str(receivers), "--steps", "3", "--warmup", "1", "--preroll", "2",
+                   "--no-cpu-baseline", "--parity-receivers", "0", "--no-pmc"]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            db = None
+            for root, _, files in os.walk(out):
+                for f in files:
+                    if f.endswith(".db"):
+                        db = os.path.join(root, f)
+            c = sqlite3.connect(db)
+            r = c.execute("select sum(value), count(distinct dispatch_id) from counters_collection where kernel_name like '%k1_dpp%' and counter_name=?",
+                          (counter,)).fetchone()
+            vals[counter] = r[0] / r[1]
+        return {"fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"],
+                "hbm_bytes_per_launch": vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024, "host": socket.gethostname(),
+                "note": "this session: separate rocprofv3 --pmc passes (serial mode, 3 launches each); FETCH_SIZE doubled per MI355X_MICROARCH.md"}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -381,6 +419,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--parity-receivers", type=int, default=16, help="receivers compared with the oracle after the timed region (0 = off)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the two short rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--tiles-per-span", type=int, default=0, help="front-end time tiling (0 = the library's choice); experiments")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise the rank launch / sharding / barrier / report path only (CPU tests)")
     args = ap.parse_args()
@@ -523,6 +562,12 @@ def main():
         traffic_bytes = tj["hbm_bytes_per_launch"]
         traffic = round(traffic_bytes / (k1_ms * 1e-3) / 1e9, 1)
         traffic_src = {"file": os.path.basename(tpath), "host": tj.get("host"), "commit": tj.get("commit")}
+    elif world == 1 and rank == 0 and not args.no_pmc and k1_ms > 0 and not args.gpu_decode:
+        tj = pmc_traffic_pass(args.config, R)   # (after the timed region and the contexts of this process are closed)
+        if tj:
+            traffic_bytes = tj["hbm_bytes_per_launch"]
+            traffic = round(traffic_bytes / (k1_ms * 1e-3) / 1e9, 1)
+            traffic_src = tj
     ref_profile = None
     for cand in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         if args.config == 4 and cand.startswith("r0") and cand.endswith("pmc_traffic_k1.json"):
@@ -548,6 +593,7 @@ def main():
                    "gpu_frame_decoder": bool(args.gpu_decode), "receivers_per_gpu": R, "block_len": BLOCK, "sample_rate": rate, "parallelism": "receivers sharded, no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_over_algorithmic": round(traffic_bytes / (samples_per_step * algo_bytes), 3) if traffic_bytes else None,
                      "traffic_bytes_per_launch": traffic_bytes, "traffic_source": traffic_src, "traffic_reference": ref_profile,
                      "algorithmic_bytes_per_launch": samples_per_step * algo_bytes,
                      "kernel": C["kernel"], "avg_launch_ms": round(k1_ms, 4), "launches": k1_n,

@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  AISGPU_SERIAL=1 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_$c -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --parity-receivers 0 > /dev/null 2>&1
+  AISGPU_SERIAL=1 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_$c -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --parity-receivers 0 > /dev/null 2>&1
 done
 python - <<PY
 import sqlite3, json
