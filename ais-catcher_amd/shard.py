@@ -1,8 +1,8 @@
 """Multi-GPU sharding of independent receivers: no data-path collective.
 
 Receivers are closed systems, so rank r of W simply owns a contiguous range of receiver ids; the only
-communication is the benchmark's barrier and the max-over-ranks of the elapsed time (torch.distributed,
-backend nccl = RCCL on the GPUs, gloo in the CPU tests).
+communication is the benchmark's barrier and the max-over-ranks of the elapsed time (torch.distributed on
+gloo, on the GPU box as in the CPU tests: there is no RCCL traffic on this path).
 """
 
 

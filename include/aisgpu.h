@@ -53,11 +53,13 @@ extern "C" {
 #define AISGPU_MODEL_STANDARD 0    /* AIS::ModelStandard   (-m 0), DSP/Model.cpp:484-518: FM receiver with five decoders on the deinterleaved
                                     * discriminator; the device path and the outputs are those of AISGPU_MODEL_BASE */
 #define AISGPU_MODEL_BASE 1        /* AIS::ModelBase       (-m 1), DSP/Model.cpp:419-438: FM receiver; the GPU delivers the sign of the
-                                    * filtered discriminator per 48 kHz sample, SimplePLL + decoder (feedback loop) run on the host */
+                                    * filtered discriminator per 48 kHz sample; SimplePLL + decoder (feedback loop) run on the host, or -- with
+                                    * AISGPU_FLAG_GPU_DECODE -- chunk-parallel on the device (aisgpu_frames) */
 #define AISGPU_MODEL_DEFAULT 2     /* AIS::ModelDefault    (-m 2), DSP/Model.cpp:520-577 */
-#define AISGPU_MODEL_V2 11         /* AIS::ModelEngineV2  (-m 11), DSP/Model.cpp:440-463: the device runs the front end only and hands over the
-                                    * two 48 kHz channels (aisgpu_out.c48); V2::Engine's per-block decisions depend on the state of its own
-                                    * decoders (DSP/Decoder/V2/V2Engine.cpp:300-341), so it runs behind the boundary, on the host */
+#define AISGPU_MODEL_V2 11         /* AIS::ModelEngineV2  (-m 11), DSP/Model.cpp:440-463: the device runs the front end and what V2::Engine computes from
+                                    * the channel alone (frequency estimates, energies, FM branch: aisgpu_out.v2_*, fm_bits) and hands over the two 48 kHz
+                                    * channels (aisgpu_out.c48); the engine's coherent branch closes over the state of its own decoders every sample
+                                    * (DSP/Decoder/V2/V2Engine.cpp:300-388), so it runs behind the boundary, on the host */
 #define AISGPU_MODEL_CHALLENGER 4  /* AIS::ModelChallenger (-m 4), DSP/Model.cpp:601-678: ModelDefault + the FM branch */
 
 #define AISGPU_FLAG_TAPS 1    /* keep intermediate float taps readable via aisgpu_tap() (tests) */
