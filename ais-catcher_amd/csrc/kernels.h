@@ -209,7 +209,10 @@ struct K7Params {
 //                 frames to the ring and the final state to DecState.
 // A frame list that overflows (more than K7B_FCAP frames in a chunk / task) flags the channel; k7_base then decodes it from the
 // untouched carried state (K7Params::cond = per-channel flags).  Same DecState between blocks as k7_base: the two can alternate.
-constexpr int K7B_CH = 512;     // samples per chunk (multiple of 32): 48 chunks per channel in a 786,432-sample block at 1536 kSPS
+#ifndef K7B_CH_
+#define K7B_CH_ 512
+#endif
+constexpr int K7B_CH = K7B_CH_; // samples per chunk (multiple of 32): 48 chunks per channel in a 786,432-sample block at 1536 kSPS
 constexpr int K7B_WARM = 256;   // samples of warm-up in front of a speculative chunk (<= K7B_CH, multiple of 32): ~50 sign changes of 0.4 each
 constexpr int K7B_FCAP = 4;     // frames recorded per chunk / per task
 constexpr int K7B_FREC = 2 + DEC_DATA_WORDS; // sample index, position, data

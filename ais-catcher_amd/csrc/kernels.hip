@@ -2711,68 +2711,163 @@ __global__ __launch_bounds__(64) void k7b_task(K7bParams q) {
 	const K7bCkpt* ck = q.ckpt + chan_raw;
 	const auto ckpt_at = [&](int n) { return ck[((size_t)(n / K7B_CH) * (K7B_CH / 32) + (size_t)((n % K7B_CH) >> 5)) * q.n_chan_pad]; };
 	const int n0 = c * K7B_CH;
+	// (Tasks whose start state is not the true one -- the end of a trajectory that never became true -- are wasted work, but they run
+	// beside the useful ones; restricting the launch to boundaries whose predecessor is known to be true, in passes, was measured: the
+	// longest USEFUL task sets the time either way, profiles/r03_k7b_*.)
 	const bool run = live && !base_same(base_ckpt(b), ckpt_at(n0));
 	int merge = run ? p.L : -1;
+	const bool decided = live;
 	uint32_t* list = q.task_frames + slot * (1 + K7B_FCAP * K7B_FREC);
 	if (live) list[0] = 0;
 	bool overflow = false;
-	// the recorded state one checkpoint ahead travels in registers (a dependent global load per 32 samples would set the pace)
-	K7bCkpt next = ckpt_at(n0 + 32 < p.L ? n0 + 32 : n0);
-	base_run(b, brow, n0, p.L, run, data,
-	         [&](int n) {
-		         if (n == n0) return true;
-		         const K7bCkpt cur = next;
-		         next = ckpt_at(n + 32 < p.L ? n + 32 : n);
-		         if (base_same(base_ckpt(b), cur)) { merge = n; return false; }
-		         return true;
-	         },
-	         [&](int n) { base_record(b, n, list, data, overflow); });
-	if (live) {
+	// A task spends most of its samples INSIDE a frame, where the sampler's gain is fixed (slow) whatever the decoder does until the
+	// frame ends.  So while a lane's decoder is in DATAFCS the lane runs the sampler alone for up to 32 symbols, collects their
+	// decisions in a word and lets the word-parallel frame evaluator (dec_run_frame, the one k7e_sim uses; fuzzed against dec_step on
+	// the host) swallow them at once -- ~90 instead of ~225 instructions per symbol.  Only a word in which the frame ENDS (closing
+	// flag, abort) is not accepted: the lane goes back to the state in front of that word and walks it symbol by symbol, so that the
+	// sampler's gain switches at exactly the sample the reference switches it.  No checkpoint can match inside a frame (both
+	// decoders must be in TRAINING), so none is compared there.
+	__shared__ uint16_t s_crc[256];
+	__shared__ uint32_t s_sym[64];
+	for (int i = lane; i < 256; i += 64) dec_crc_table_entry(i, s_crc);
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+	__builtin_amdgcn_s_barrier();
+	int n = n0;
+	bool active = run, finish = false;
+	uint32_t word = active ? brow[n >> 5] : 0u;
+	K7bCkpt next = ckpt_at(n0 + 32 < p.L ? n0 + 32 : n0); // the recorded state one checkpoint ahead travels in registers
+	int next_n = n0 + 32;
+	while (__any(active && n < p.L)) {
+		const bool live_lane = active && n < p.L;
+		if (live_lane && b.r.state == DST_DATAFCS && !finish) { // ---- inside a frame: the sampler alone, one word of symbols
+			const BaseReg snap = b;
+			const int n_s = n;
+			const uint32_t w_s = word;
+			uint32_t bits = 0;
+			int ns = 0;
+			while (ns < 32 && n < p.L) {
+				if ((n & 31) == 0) word = brow[n >> 5];
+				const int bit = (int)((word >> (n & 31)) & 1u);
+				const bool emit = base_pll_step(b, bit);
+				n++;
+				if (emit) { bits |= (uint32_t)bit << ns; ns++; }
+			}
+			s_sym[lane] = bits;
+			int end = 0;
+			const int flags = dec_run_frame(b.r, data, s_sym + lane, nullptr, 0, ns, s_crc, end);
+			if (flags != 2) { b = snap; n = n_s; word = w_s; finish = true; } // the frame ends in this word: symbol by symbol
+		} else if (live_lane) { // ---- one symbol: the samples up to the next emission, then the decoder step
+			bool emit = false;
+			int bit = 0;
+			while (active && n < p.L && !emit) {
+				if ((n & 31) == 0) {
+					word = brow[n >> 5];
+					if (n > n0) {
+						const K7bCkpt cur = next_n == n ? next : ckpt_at(n);
+						next_n = n + 32;
+						next = ckpt_at(next_n < p.L ? next_n : n);
+						if (base_same(base_ckpt(b), cur)) { merge = n; active = false; break; }
+					}
+				}
+				bit = (int)((word >> (n & 31)) & 1u);
+				emit = base_pll_step(b, bit);
+				n++;
+			}
+			if (emit && dec_step(b.r, bit, 0.0f, 0ll, data)) { // (tag.sample_lvl / sample_idx are never set in this engine)
+				base_record(b, n - 1, list, data, overflow);
+				b.r.state = DST_TRAINING; b.r.position = 0; b.r.osc = 0;
+			}
+			if (b.r.state != DST_DATAFCS) finish = false;
+		}
+	}
+	if (decided) {
 		q.task_merge[slot] = merge;
-		if (merge == p.L) base_store(b, q.task_end + slot, data); // ran to the end of the block: this is the channel's state
+		if (run && merge == p.L) base_store(b, q.task_end + slot, data); // ran to the end of the block: this is the channel's state
 		if (overflow) q.fallback[chan_raw] = 1;
 	}
 }
 
 __global__ __launch_bounds__(64) void k7b_assemble(K7bParams q) {
 	const K7Params& p = q.k;
-	const int chan = blockIdx.x * 64 + threadIdx.x;
-	if (chan >= p.n_chan) return;
-	if (q.fallback[chan]) return; // k7_base decodes this channel's block from the untouched carried state
+	const int lane = threadIdx.x;
+	const int chan_raw = blockIdx.x * 64 + lane;
+	const bool live = chan_raw < p.n_chan;
+	const int chan = live ? chan_raw : 0;
 	const size_t per = 1 + K7B_FCAP * K7B_FREC;
-	const auto emit = [&](const uint32_t* list, int from) { // the list's frames that completed at sample >= from
-		const uint32_t cnt = list[0];
+	// The walk is a chain of dependent decisions, and nearly every list is empty: merge positions and list lengths come to LDS
+	// first, eight boundaries' loads in flight at once (one dependent global load per boundary made this kernel 0.1 ms).
+	constexpr int MAXC = 96;
+	__shared__ int merges[MAXC][64];
+	__shared__ unsigned short counts[MAXC][64]; // frames of the chunk's list | frames of the boundary's task list << 8
+	const bool staged = q.n_chunks <= MAXC;
+	if (staged)
+		for (int i0 = 0; i0 < q.n_chunks; i0 += 8) {
+			int m[8]; uint32_t a[8], t[8];
+#pragma unroll
+			for (int e = 0; e < 8; e++) {
+				const int i = i0 + e < q.n_chunks ? i0 + e : q.n_chunks - 1;
+				const size_t sl = (size_t)i * q.n_chan_pad + chan;
+				m[e] = q.task_merge[sl]; a[e] = q.frames[sl * per]; t[e] = q.task_frames[sl * per];
+			}
+#pragma unroll
+			for (int e = 0; e < 8; e++)
+				if (i0 + e < q.n_chunks) {
+					merges[i0 + e][lane] = i0 + e ? m[e] : -1;
+					counts[i0 + e][lane] = (unsigned short)(a[e] | (i0 + e ? t[e] << 8 : 0u));
+				}
+		}
+	const auto merge_of = [&](int c) { return staged ? merges[c][lane] : q.task_merge[(size_t)c * q.n_chan_pad + chan]; };
+	const auto n_spec = [&](int c) { return staged ? (uint32_t)(counts[c][lane] & 255u) : q.frames[((size_t)c * q.n_chan_pad + chan) * per]; };
+	const auto n_task = [&](int c) { return staged ? (uint32_t)(counts[c][lane] >> 8) : q.task_frames[((size_t)c * q.n_chan_pad + chan) * per]; };
+	// one walk over the boundaries; visit(list, count, from): the list's frames that completed at sample >= from are the channel's.
+	// Returns the final state's source, or nullptr where a boundary needed a task that no pass ran.
+	const auto walk = [&](auto&& visit) -> const DecState* {
+		visit(q.frames + (size_t)chan * per, n_spec(0), 0); // chunk 0's trajectory is exact from sample 0
+		const DecState* fin = q.end + (size_t)(q.n_chunks - 1) * q.n_chan_pad + chan;
+		int c = 1;
+		while (c < q.n_chunks) {
+			const size_t slot = (size_t)c * q.n_chan_pad + chan;
+			const int merge = merge_of(c);
+			if (merge == -2) return nullptr;
+			if (merge < 0) { visit(q.frames + slot * per, n_spec(c), 0); c++; continue; } // the speculative state WAS the true one
+			visit(q.task_frames + slot * per, n_task(c), 0); // the exact loop from the previous chunk's (true) end state up to the merge
+			if (merge >= p.L) return q.task_end + slot;
+			const int cm = merge / K7B_CH; // the chunk whose recorded trajectory the task joined (the boundaries in between lie inside the task)
+			visit(q.frames + ((size_t)cm * q.n_chan_pad + chan) * per, n_spec(cm), merge);
+			c = cm + 1;
+		}
+		return fin;
+	};
+	// pass 1: is the chain complete, and how many frames does the channel emit?  (One atomic per wave instead of one per frame:
+	// two thousand atomics on one counter were most of this kernel's time.)
+	unsigned mine = 0;
+	const DecState* fin = nullptr;
+	const bool skip = !live || q.fallback[chan] != 0; // (flagged by a frame list that overflowed: k7_base decodes the block from the untouched state)
+	if (!skip) {
+		fin = walk([&](const uint32_t* list, uint32_t cnt, int from) {
+			for (uint32_t i = 0; i < cnt; i++) mine += (int)list[1 + i * K7B_FREC] >= from ? 1u : 0u;
+		});
+		if (!fin) { q.fallback[chan] = 1; mine = 0; } // a chain of more tasks than passes
+	}
+	unsigned incl = mine;
+	for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+	unsigned base = 0;
+	if (lane == 63 && incl) base = atomicAdd(p.frame_count, incl);
+	base = __shfl(base, 63);
+	if (skip || !fin) return;
+	unsigned at = base + incl - mine;
+	walk([&](const uint32_t* list, uint32_t cnt, int from) {
 		for (uint32_t i = 0; i < cnt; i++) {
 			const uint32_t* r = list + 1 + i * K7B_FREC;
 			if ((int)r[0] < from) continue;
-			const unsigned slot = atomicAdd(p.frame_count, 1u) % (unsigned)p.max_frames;
-			uint32_t* f = p.frames + (size_t)slot * DEC_FRAME_WORDS;
+			uint32_t* f = p.frames + (size_t)(at++ % (unsigned)p.max_frames) * DEC_FRAME_WORDS;
 			f[0] = (uint32_t)chan; f[1] = r[0]; f[2] = r[1]; f[3] = 0; // (level sum: tag.sample_lvl is never set in this engine)
 			f[4] = 0; f[5] = 0; f[6] = 0; f[7] = 0;
 			f[8] = p.block; f[9] = p.sub;
 			for (int w = 0; w < DEC_DATA_WORDS; w++) f[10 + w] = r[2 + w];
 		}
-	};
-	// chunk 0's trajectory is exact from sample 0; `from` = the sample from which the current chunk's recorded trajectory is the true one
-	emit(q.frames + (size_t)chan * per, 0);
-	const DecState* final_state = q.end + (size_t)(q.n_chunks - 1) * q.n_chan_pad + chan;
-	// the walk is a chain of dependent decisions: the merge positions come to LDS first (all loads in flight at once)
-	constexpr int MAXC = 160;
-	__shared__ int merges[MAXC][64];
-	const bool staged = q.n_chunks <= MAXC;
-	if (staged) for (int i = 1; i < q.n_chunks; i++) merges[i][threadIdx.x] = q.task_merge[(size_t)i * q.n_chan_pad + chan];
-	int c = 1;
-	while (c < q.n_chunks) {
-		const size_t slot = (size_t)c * q.n_chan_pad + chan;
-		const int merge = staged ? merges[c][threadIdx.x] : q.task_merge[slot];
-		if (merge < 0) { emit(q.frames + slot * per, 0); c++; continue; } // the speculative state WAS the true one
-		emit(q.task_frames + slot * per, 0); // the exact loop from the previous chunk's (true) end state up to the merge
-		if (merge >= p.L) { final_state = q.task_end + slot; break; }
-		const int cm = merge / K7B_CH; // the chunk whose recorded trajectory the task joined (the boundaries in between lie inside the task)
-		emit(q.frames + ((size_t)cm * q.n_chan_pad + chan) * per, merge);
-		c = cm + 1;
-	}
-	p.state[chan] = *final_state;
+	});
+	p.state[chan] = *fin;
 }
 
 // ------------------------------------------------------------------------------------------
