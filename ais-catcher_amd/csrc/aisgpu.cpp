@@ -216,7 +216,9 @@ struct aisgpu {
 	long long k7e_pass = 0; // passes of the event-driven decoder kernels so far (parity: which overflow flag a pass uses)
 	bool k7_event = true; uint32_t *d_k7ev = nullptr, *d_k7cnt = nullptr; uint16_t* d_k7open = nullptr; K7Slot* d_k7slot = nullptr; int* d_k7ovf = nullptr;
 	uint32_t* h_frames = nullptr; unsigned frames_seen = 0; int max_frames = 0; std::vector<aisgpu_frame> frames;
-	K7bParams k7b{}; bool base_chunked = false; // ModelBase's sampler + decoder loop, chunk-parallel (k7b_*)
+	// ModelBase's sampler + decoder loop, chunk-parallel (k7b_*).  Two sets of the speculative pass's scratch, by block parity: the pass
+	// of block f+1 (s4) runs beside the boundary tasks of block f (s1); ev_spec[p]: the pass of the block with parity p is done.
+	K7bParams k7b[2] = {}; bool base_chunked = false; hipEvent_t ev_spec[2] = {};
 	bool ps_box = false; PsBoxState* d_box[2] = {}; // Demod::PhaseSearch (boxcar) instead of PhaseSearchEMA
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
@@ -655,7 +657,14 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 	k5.fmbits = h->d_fmbits[pb]; k5.fmbits_stride = h->L / 32; k5.L = h->L;
 	k5.fir_out = h->d_fmfir; k5.fir_stride = h->L;
 	memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
-	if (h->gpu_decode && h->base_chunked) WAITEV(h->ds, h->ev_k4[pb]); // fmbits[pb] was last read by the decoders of block f-2 (on s1)
+	if (h->ds != h->stream) { // the FM receiver on a stream of its own: behind this block's front end, beside the next one's
+		HIPCHK(hipEventRecord(h->ev_pre[q], h->stream));
+		WAITEV(h->ds, h->ev_pre[q]);
+	}
+	if (h->gpu_decode && h->base_chunked) {
+		WAITEV(h->ds, h->ev_k4[pb]);       // fmbits[pb] was last read by the boundary tasks of block f-2 (on s1)
+		WAITEV(h->ds, h->ev_spec[pb ^ 1]); // and by the speculative pass of block f-1 (its first chunk's warm-up, on s4)
+	}
 	HIPCHK(launch_k5(k5, h->n_chan, h->ds));
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->ds));
 	if (h->gpu_decode) { // SimplePLL + decoder (ModelBase) / Deinterleave + five decoders (ModelStandard) on the device, behind the filter
@@ -676,10 +685,17 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 		} else if (h->dec_kind == 3 && h->base_chunked && !(h->k7_alt && (h->block_idx & 1))) {
 			// ModelBase: the chunk-parallel sampler + decoder kernels on PhaseSearch's otherwise idle stream, next to the next block's
 			// front end (k7_base alone held the front stream for 5 ms per step of 256 receivers)
+			// The speculative pass reads nothing but the FM rows: on s4 (idle in this engine), beside the tasks of the block before.
+			// Its scratch set was last read by the tasks of block f-2: this block's FM receiver has waited for them (above).
+			K7bParams& kb = h->k7b[pb];
+			kb.k = k7;
 			HIPCHK(hipEventRecord(h->ev_sym[pb], h->ds));
-			WAITEV(h->s1, h->ev_sym[pb]);
-			h->k7b.k = k7;
-			HIPCHK(launch_k7b(h->k7b, h->s1));
+			WAITEV(h->s4, h->ev_sym[pb]);
+			HIPCHK(launch_k7b_spec(kb, h->s4));
+			HIPCHK(hipEventRecord(h->ev_spec[pb], h->s4));
+			WAITEV(h->s1, h->ev_spec[pb]);
+			WAITEV(h->s1, h->ev_sym[pb]); // (and behind whatever ran on the FM receiver's stream before: k7_base of an alternating test run)
+			HIPCHK(launch_k7b_finish(kb, h->s1));
 			HIPCHK(hipEventRecord(h->ev_k4[pb], h->s1));
 		} else {
 			if ((h->dec_kind == 1 || h->dec_kind == 3) && h->k7_alt) WAITEV(h->ds, h->ev_k4[pb ^ 1]); // (test hook: the previous block's decoders ran on s1)
@@ -774,6 +790,25 @@ int gather_frames(aisgpu_t* h) {
 		for (uint32_t v : cnt) { se += v & 0xFFFFu; sr += v >> 16; me = std::max(me, v & 0xFFFFu); mr = std::max(mr, v >> 16); }
 		fprintf(stderr, "K7E_STATS decoders %zu: events avg %.1f max %u, runs avg %.1f max %u\n", cnt.size(), (double)se / cnt.size(), me, (double)sr / cnt.size(), mr);
 	}
+	if (h->base_chunked && opt_int("k7b_stats", 0)) { // experiment aid: the boundary tasks of the last block
+		const K7bParams& b = h->k7b[(h->block_idx + 1) & 1]; // (the last block's parity)
+		std::vector<int> m((size_t)b.n_chunks * b.n_chan_pad);
+		HIPCHK(hipMemcpy(m.data(), b.task_merge, m.size() * sizeof(int), hipMemcpyDeviceToHost));
+		std::vector<int> fb(b.n_chan_pad);
+		HIPCHK(hipMemcpy(fb.data(), b.fallback, fb.size() * sizeof(int), hipMemcpyDeviceToHost));
+		long long n = 0, sum = 0; int mx = 0, hist[8] = {0};
+		for (int c = 0; c < b.n_chunks; c++)
+			for (int ch = 0; ch < h->n_chan; ch++) {
+				const int v = m[(size_t)c * b.n_chan_pad + ch];
+				if (v < 0) continue;
+				const int len = v - c * K7B_CH;
+				n++; sum += len; mx = std::max(mx, len);
+				hist[len < 128 ? 0 : len < 256 ? 1 : len < 512 ? 2 : len < 1024 ? 3 : len < 2048 ? 4 : len < 4096 ? 5 : len < 8192 ? 6 : 7]++;
+			}
+		int nfb = 0; for (int ch = 0; ch < h->n_chan; ch++) nfb += fb[ch] != 0;
+		fprintf(stderr, "K7B_STATS boundaries %d: tasks %lld (avg %.0f samples, max %d), <128 %d <256 %d <512 %d <1k %d <2k %d <4k %d <8k %d more %d; fallback channels %d\n",
+		        b.n_chunks * h->n_chan, n, n ? (double)sum / n : 0.0, mx, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], nfb);
+	}
 #endif
 	const unsigned fresh = total - h->frames_seen;
 	h->frames.clear();
@@ -865,7 +900,7 @@ const char* aisgpu_last_error(aisgpu_t* h) { return h ? h->err.c_str() : ""; }
 
 int aisgpu_set_option(const char* key, const char* value) {
 	if (!key || !*key) return AISGPU_ERR_ARG;
-	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "fused", "fft_in_k1", "trace", "k7e_stats" };
+	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "fused", "fft_in_k1", "trace", "k7e_stats", "k7b_stats" };
 	bool ok = false;
 	for (const char* k : known) ok = ok || strcmp(k, key) == 0;
 	if (!ok) return AISGPU_ERR_ARG;
@@ -1170,17 +1205,28 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		h->dec_kind = cfg->model == AISGPU_MODEL_STANDARD ? 1 : cfg->model == AISGPU_MODEL_CHALLENGER ? 2 : cfg->model == AISGPU_MODEL_BASE ? 3 : 0;
 		h->max_frames = (int)C * 64; // ring between two aisgpu_sync_outputs(): a slot holds ~2 frames per channel and block
 		HIPCHK(dalloc(&h->d_dec, (size_t)C * 10)); // zero = State::TRAINING, lastBit = prev = 0 (Marine/AIS.h:44-56); up to ten decoders per channel
-		if (cfg->model == AISGPU_MODEL_BASE && k7_opt != "seq") { // chunk-parallel sampler + decoder loop (kernels.h: K7b); "seq": k7_base alone
-			K7bParams& b = h->k7b;
-			b.n_chunks = (h->L + K7B_CH - 1) / K7B_CH;
-			b.n_chan_pad = (int)((C + 63) / 64 * 64);
-			const size_t slots = (size_t)b.n_chunks * b.n_chan_pad;
-			HIPCHK(dalloc(&b.ckpt, slots * (K7B_CH / 32)));
-			HIPCHK(dalloc(&b.end, slots)); HIPCHK(dalloc(&b.task_end, slots));
-			HIPCHK(dalloc(&b.frames, slots * (1 + K7B_FCAP * K7B_FREC))); HIPCHK(dalloc(&b.task_frames, slots * (1 + K7B_FCAP * K7B_FREC)));
-			HIPCHK(dalloc(&b.task_merge, slots));
-			HIPCHK(dalloc(&b.fallback, (size_t)b.n_chan_pad + 1)); b.fallback_count = b.fallback + b.n_chan_pad;
+		// chunk-parallel sampler + decoder loop (kernels.h: K7b); "seq" / blocks of unusual length: k7_base alone
+		if (cfg->model == AISGPU_MODEL_BASE && k7_opt != "seq" && (h->L + K7B_CH - 1) / K7B_CH <= K7B_MAXC && h->L < 65534 && h->L % 32 == 0 && h->L >= K7B_WARM) {
+			for (int i = 0; i < 2; i++) {
+				K7bParams& b = h->k7b[i];
+				b.n_chunks = (h->L + K7B_CH - 1) / K7B_CH;
+				b.n_chan_pad = (int)((C + 63) / 64 * 64);
+				const size_t slots = (size_t)b.n_chunks * b.n_chan_pad;
+				HIPCHK(dalloc(&b.ckpt, slots * (K7B_CH / 32)));
+				HIPCHK(dalloc(&b.end, slots));
+				HIPCHK(dalloc(&b.frames, slots * (1 + K7B_FCAP * K7B_FREC)));
+				HIPCHK(dalloc(&b.fallback, (size_t)b.n_chan_pad + 1)); b.fallback_count = b.fallback + b.n_chan_pad;
+				if (i == 0) { // (the tasks' own scratch: one block at a time)
+					HIPCHK(dalloc(&b.task_end, slots));
+					HIPCHK(dalloc(&b.task_frames, slots * (1 + K7B_FCAP * K7B_FREC)));
+					HIPCHK(dalloc(&b.task_merge, slots));
+					HIPCHK(dalloc(&b.take_spec, slots)); HIPCHK(dalloc(&b.take_task, slots));
+				} else { b.task_end = h->k7b[0].task_end; b.task_frames = h->k7b[0].task_frames; b.task_merge = h->k7b[0].task_merge; b.take_spec = h->k7b[0].take_spec; b.take_task = h->k7b[0].take_task; }
+				HIPCHK(hipEventCreateWithFlags(&h->ev_spec[i], hipEventDisableTiming));
+			}
 			h->base_chunked = true;
+			// (The FM receiver stays on the front stream: it and the front end are both bound by memory, side by side -- ds = s4 -- they
+			// only take from each other: 0.59 against 0.54 ms per step.)
 		}
 		if (h->dec_kind == 1 || h->dec_kind == 2) {
 			h->fmrow_words = h->Gcap / 32;
@@ -1340,7 +1386,11 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_qflag4);
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
 	hipFree(h->d_box[0]); hipFree(h->d_box[1]);
-	hipFree(h->k7b.ckpt); hipFree(h->k7b.end); hipFree(h->k7b.task_end); hipFree(h->k7b.frames); hipFree(h->k7b.task_frames); hipFree(h->k7b.task_merge); hipFree(h->k7b.fallback);
+	for (int i = 0; i < 2; i++) {
+		hipFree(h->k7b[i].ckpt); hipFree(h->k7b[i].end); hipFree(h->k7b[i].frames); hipFree(h->k7b[i].fallback);
+		if (h->ev_spec[i]) hipEventDestroy(h->ev_spec[i]);
+	}
+	hipFree(h->k7b[0].task_end); hipFree(h->k7b[0].task_frames); hipFree(h->k7b[0].task_merge); hipFree(h->k7b[0].take_spec); hipFree(h->k7b[0].take_task);
 	hipFree(h->d_dec); hipFree(h->d_frames); hipFree(h->d_frame_count); hipFree(h->d_fmrows[0]); hipFree(h->d_fmrows[1]); hipFree(h->d_last_lvl[0]); hipFree(h->d_last_lvl[1]);
 	hipFree(h->d_k7ev); hipFree(h->d_k7cnt); hipFree(h->d_k7open); hipFree(h->d_k7slot); hipFree(h->d_k7ovf);
 	if (h->h_frames) hipHostFree(h->h_frames);

@@ -148,6 +148,20 @@ DEC_HD int dec_select_bit(uint32_t m, int k) { // index of the k-th (1-based) se
 // 2: the block ended (`end` = n) -- and for 1 / 2 the state and the frame buffer.
 // lvl_shift / lvl_first: ModelChallenger's FM0..FM3 see tag.sample_lvl as the PREVIOUS group's ScatterPLL left it (symbol i adds
 // lrow[i - 1]; symbol 0 what the block before -- or the other channel -- left: lvl_first).
+// LAZY: r.crc and r.tail are NOT brought up to date for flags 2 (a caller that feeds the frame word by word would pay a pass over
+// the whole frame buffer per word); dec_fix_crc_tail() forms them when the symbol-by-symbol step is about to need them.
+DEC_HD void dec_fix_crc_tail(DecReg& r, uint32_t* data, const uint16_t* tab) {
+	data[DEC_LANES * r.cwi] = r.cw; // (the word that is being filled lives in the register)
+	const int pos = r.position;
+	r.crc = dec_crc_bits(data, pos >= 7 ? pos - 7 : 0, tab);
+	uint32_t tail = 0;
+	for (int k = 0; k < 7; k++) {
+		const int p = pos - 1 - k;
+		if (p >= 0) tail |= ((data[DEC_LANES * (p >> 5)] >> (p & 31)) & 1u) << k;
+	}
+	r.tail = tail;
+}
+template <bool LAZY = false>
 DEC_HD int dec_run_frame(DecReg& r, uint32_t* data, const uint32_t* brow, const float* lrow, int g, int n, const uint16_t* tab, int& end,
                          int lvl_shift = 0, float lvl_first = 0.0f) {
 	const int g_first = g;
@@ -270,6 +284,7 @@ DEC_HD int dec_run_frame(DecReg& r, uint32_t* data, const uint32_t* brow, const 
 	r.level = level;
 	r.state = DST_DATAFCS; r.position = pos; r.osc = osc; r.prev = (int)dprev; r.lastBit = (int)lastB;
 	r.cw = cw; r.cwi = cwi; r.abort_pos = abort_pos;
+	if (LAZY && flags == 2) return flags;
 	r.crc = dec_crc_bits(data, pos >= 7 ? pos - 7 : 0, tab);
 	uint32_t tail = 0;
 	for (int k = 0; k < 7; k++) {

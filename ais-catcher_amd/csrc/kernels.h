@@ -213,8 +213,12 @@ struct K7Params {
 #define K7B_CH_ 512
 #endif
 constexpr int K7B_CH = K7B_CH_; // samples per chunk (multiple of 32): 48 chunks per channel in a 786,432-sample block at 1536 kSPS
-constexpr int K7B_WARM = 256;   // samples of warm-up in front of a speculative chunk (<= K7B_CH, multiple of 32): ~50 sign changes of 0.4 each
+#ifndef K7B_WARM_
+#define K7B_WARM_ 256
+#endif
+constexpr int K7B_WARM = K7B_WARM_;   // samples of warm-up in front of a speculative chunk (<= K7B_CH, multiple of 32): ~50 sign changes of 0.4 each
 constexpr int K7B_FCAP = 4;     // frames recorded per chunk / per task
+constexpr int K7B_MAXC = 96;    // chunks per block at most (and L < 65534: 16-bit merge positions in k7b_assemble's notes); beyond: k7_base alone
 constexpr int K7B_FREC = 2 + DEC_DATA_WORDS; // sample index, position, data
 struct K7bCkpt { uint32_t pll, position, flags; }; // flags: pprev | state << 1 | lastBit << 3 | prev << 4 | osc << 5
 struct K7bParams {
@@ -226,11 +230,17 @@ struct K7bParams {
 	int* task_merge;      // [n_chunks][n_chan_pad] per boundary c >= 1: -1 no task (states matched), else the sample at which the task merged (L: never)
 	DecState* task_end;   // [n_chunks][n_chan_pad] state of a task that ran to the end of the block
 	uint32_t* task_frames;// like frames
+	uint32_t* take_spec;  // [n_chunks][n_chan_pad] k7b_assemble's notes: the chunk's list is the channel's from sample (v >> 16) on, at offset (v & 0xFFFF) of its frames; ~0: not
+	uint32_t* take_task;  // likewise for the boundary's task list (offset; ~0: not)
 	int* fallback;        // [n_chan_pad] != 0: a frame list overflowed, k7_base decodes the channel's block
 	int* fallback_count;  // statistics
 	int n_chan_pad;
 };
-hipError_t launch_k7b(const K7bParams& p, hipStream_t s);
+// k7b_spec needs the block's FM rows only (and scratch of its own: the caller alternates two sets), so it may run beside the previous
+// block's launch_k7b_finish(); that one (k7b_task, k7b_assemble, the conditional k7_base) is what carries the channels' state from
+// block to block and runs in block order.
+hipError_t launch_k7b_spec(const K7bParams& p, hipStream_t s);
+hipError_t launch_k7b_finish(const K7bParams& p, hipStream_t s);
 hipError_t launch_k7(const K7Params& p, hipStream_t s);
 hipError_t launch_k7_pack(const K7Params& p, hipStream_t s); // kind 1 / 2: regroup the FM bits per decoder (on the stream that produced them)
 hipError_t launch_k7_mesh(const K7Params& p, hipStream_t s); // kind 1 / 2 / 3: the decoders

@@ -2617,15 +2617,40 @@ __device__ __forceinline__ bool base_same(const K7bCkpt& a, const K7bCkpt& b) {
 	return a.pll == b.pll && a.position == b.position && a.flags == b.flags && ((a.flags >> 1) & 3u) == (uint32_t)DST_TRAINING;
 }
 __device__ __forceinline__ int base_bit(const uint32_t* brow, int n) { return (int)((brow[n >> 5] >> (n & 31)) & 1u); }
-// one sample of SimplePLL::Receive (DSP.cpp:28-44); true when the sampler hands this sample to the decoder
+// one sample of SimplePLL::Receive (DSP.cpp:28-44); true when the sampler hands this sample to the decoder.
+// The loop is one chain of dependent operations in a wave that has nothing else to issue, so it is written for the length of that
+// chain, without a branch: a correction with gain +0 leaves pll as it is (x * 0 = +-0, pll + +-0 = pll); pll stays in [0, 1.2) (a
+// correction moves it towards 0.5), so the (int)pll that an emission subtracts is 1 and pll - 1 is exact: v_fract_f32 is the wrap.
+// (k7_base keeps the reference's own form; the parity tests compare the two.)
 __device__ __forceinline__ bool base_pll_step(BaseReg& b, int bit) {
-	const bool fast = b.r.state == DST_TRAINING; // FastPLL (StartTraining / StopTraining, AIS.cpp:41-46)
-	if (bit != b.pprev) b.pll += (0.5f - b.pll) * (fast ? 0.6f : 0.05f);
-	b.pll += 0.2f;
-	const bool emit = b.pll >= 1.0f;
-	if (emit) b.pll -= (float)(int)b.pll;
+	const uint32_t gain = b.r.state == DST_TRAINING ? __builtin_bit_cast(uint32_t, 0.6f) : __builtin_bit_cast(uint32_t, 0.05f); // FastPLL (StartTraining / StopTraining, AIS.cpp:41-46)
+	const uint32_t g = bit != b.pprev ? gain : 0u;
+	float pll = b.pll + (0.5f - b.pll) * __uint_as_float(g);
+	pll = pll + 0.2f;
+	b.pll = __builtin_amdgcn_fractf(pll);
 	b.pprev = bit;
-	return emit;
+	return pll >= 1.0f;
+}
+// The sampler inside a frame (slow gain) over one whole word of 32 samples, n % 32 == 0 in front of it; the decisions it hands to the
+// decoder are appended to `bits` from bit ns on.
+__device__ __forceinline__ void base_slow_word(float& pll_io, int& pprev, uint32_t w, uint32_t& bits, int& ns) {
+	const uint32_t T = w ^ ((w << 1) | (uint32_t)pprev); // sign changes
+	float pll = pll_io;
+	uint32_t E = 0; // sample i emitted: bit 31 - i
+#pragma unroll
+	for (int i = 0; i < 32; i++) {
+		const uint32_t g = (uint32_t)((int32_t)(T << (31 - i)) >> 31) & __builtin_bit_cast(uint32_t, 0.05f);
+		pll = pll + (0.5f - pll) * __uint_as_float(g);
+		pll = pll + 0.2f;
+		E = E + E + (pll >= 1.0f ? 1u : 0u);
+		pll = __builtin_amdgcn_fractf(pll);
+	}
+	pll_io = pll;
+	pprev = (int)(w >> 31);
+	for (E = __builtin_bitreverse32(E); E; E &= E - 1u) {
+		bits |= ((w >> __builtin_ctz(E)) & 1u) << ns;
+		ns++;
+	}
 }
 __device__ __forceinline__ void base_record(BaseReg& b, int n, uint32_t* list, uint32_t* data, bool& overflow) {
 	const uint32_t cnt = list[0];
@@ -2636,37 +2661,12 @@ __device__ __forceinline__ void base_record(BaseReg& b, int n, uint32_t* list, u
 		list[0] = cnt + 1;
 	} else overflow = true;
 }
-// The lanes of a wave are independent sample streams, so they need not sit at the same sample: every lane advances ITS stream up to
-// its next emission (the sampler emits every fifth sample, give or take; ~10 instructions per sample) and then all lanes run the
-// decoder step together -- once per symbol instead of once per sample of whichever lane happens to emit (the step is ~150
-// instructions of selects, and with one sample per iteration some lane emits in every iteration).
-// AT(n): called in front of every sample with n % 32 == 0 (checkpoint store / compare); returns false to stop the lane there.
-template <class AT, class FOUND>
-__device__ __forceinline__ void base_run(BaseReg& b, const uint32_t* brow, int n, int n_end, bool active, uint32_t* data, AT&& at, FOUND&& on_found) {
-	uint32_t word = active && n < n_end ? brow[n >> 5] : 0u;
-	while (__any(active && n < n_end)) {
-		bool emit = false;
-		int bit = 0;
-		while (active && n < n_end && !emit) {
-			if ((n & 31) == 0) {
-				word = brow[n >> 5];
-				if (!at(n)) { active = false; break; }
-			}
-			bit = (int)((word >> (n & 31)) & 1u);
-			emit = base_pll_step(b, bit);
-			n++;
-		}
-		bool found = false;
-		if (emit) found = dec_step(b.r, bit, 0.0f, 0ll, data); // (tag.sample_lvl / sample_idx are never set in this engine)
-		if (found) {
-			on_found(n - 1);
-			b.r.state = DST_TRAINING; b.r.position = 0; b.r.osc = 0;
-		}
-	}
-}
-
 __global__ __launch_bounds__(64) void k7b_spec(K7bParams q) {
+#ifndef K7B_NOPRIO
+	__builtin_amdgcn_s_setprio(3); // a long dependent chain in few waves, beside front-end waves that fill every SIMD: issue first
+#endif
 	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64];
+	__shared__ uint32_t rowbits[(K7B_CH + K7B_WARM) / 32 * 64]; // the lanes' bit rows for this chunk (+ warm-up), word i of lane l at [64 i + l]
 	const K7Params& p = q.k;
 	const int lane = threadIdx.x, c = blockIdx.y;
 	const int chan_raw = blockIdx.x * 64 + lane;
@@ -2676,96 +2676,175 @@ __global__ __launch_bounds__(64) void k7b_spec(K7bParams q) {
 	const size_t slot = (size_t)c * q.n_chan_pad + chan_raw;
 	const uint32_t* brow = p.fm_cur + (size_t)chan * p.fm_stride;
 	const int n0 = c * K7B_CH, n1 = n0 + K7B_CH < p.L ? n0 + K7B_CH : p.L;
+	// Every chunk is speculative, the block's first one too (its warm-up: the tail of the previous block's row): this kernel then
+	// depends on nothing the previous block's decoders leave behind, and runs beside them.
+	const uint32_t* prow = p.fm_prev + (size_t)chan * p.fm_stride + p.fm_stride; // word -i of this row = word L / 32 - i of the previous block's
 	BaseReg b;
-	int start = n0;
-	if (c == 0) base_load(b, p.state + chan, data);
-	else {
-		start = n0 - K7B_WARM; // (>= 0: K7B_WARM <= K7B_CH)
-		base_fresh(b, start > 0 ? base_bit(brow, start - 1) : 0, data);
-	}
+	const int start = n0 - K7B_WARM;
+	base_fresh(b, start > 0 ? base_bit(brow, start - 1) : (int)((prow[(start - 1) >> 5] >> ((start - 1) & 31)) & 1u), data);
 	uint32_t* list = q.frames + slot * (1 + K7B_FCAP * K7B_FREC);
 	if (live) list[0] = 0;
 	bool overflow = false;
 	K7bCkpt* ck = q.ckpt + (size_t)c * (K7B_CH / 32) * q.n_chan_pad + chan_raw;
-	base_run(b, brow, start, n1, live, data,
-	         [&](int n) { if (n >= n0) ck[(size_t)((n - n0) >> 5) * q.n_chan_pad] = base_ckpt(b); return true; },
-	         [&](int n) { if (n >= n0) base_record(b, n, list, data, overflow); }); // (what the warm-up "completes" is not a frame)
+	const int w0 = start >> 5, nwd = (n1 - start + 31) >> 5;
+#pragma unroll 8
+	for (int i = 0; i < nwd; i++) rowbits[64 * i + lane] = w0 + i >= 0 ? brow[w0 + i] : prow[w0 + i];
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // (one-wave workgroup: every lane reads its own column, ordering only)
+	// The lanes of a wave are independent sample streams.  They walk the chunk in step word by word (32 samples: the word fetch and the
+	// checkpoint store are then uniform, once per word -- with every lane at a sample of its own some lane crossed a word boundary in
+	// nearly every iteration, and the whole wave waited for its LDS read), and inside a word every lane advances to ITS next emission
+	// (the sampler emits every fifth sample, give or take) before all lanes run the decoder step together: once per symbol instead of
+	// once per sample of whichever lane happens to emit (the step is ~150 instructions of selects).
+	uint32_t ahead = rowbits[lane];
+	for (int nb = start, wi = 0; nb < n1; nb += 32, wi++) {
+		const uint32_t word = ahead;
+		ahead = rowbits[64 * (wi + 1 < nwd ? wi + 1 : wi) + lane];
+		if (nb >= n0) ck[(size_t)((nb - n0) >> 5) * q.n_chan_pad] = base_ckpt(b); // (channel rows are padded: idle lanes write their own slot)
+		int i = 0;
+		while (__any(i < 32)) {
+			bool emit = false;
+			int bit = 0;
+			while (i < 32 && !emit) {
+				bit = (int)((word >> i) & 1u);
+				emit = base_pll_step(b, bit);
+				i++;
+			}
+			if (emit && dec_step(b.r, bit, 0.0f, 0ll, data)) { // (tag.sample_lvl / sample_idx are never set in this engine)
+				if (nb >= n0 && live) base_record(b, nb + i - 1, list, data, overflow); // (what the warm-up "completes" is not a frame)
+				b.r.state = DST_TRAINING; b.r.position = 0; b.r.osc = 0;
+			}
+		}
+	}
 	if (live) {
 		base_store(b, q.end + slot, data);
 		if (overflow) q.fallback[chan_raw] = 1;
 	}
 }
 
+// Only K7B_TL lanes of a task wave carry a channel: the tasks of a wave are unrelated loops (a frame here, a closing flag there), every
+// one of them costs the whole wave its instructions, and a 64-channel wave had three to eight of them back to back.  With few channels
+// per wave most waves find no task and leave at once, and the ones that stay run little more than their own.
+// A task is one long dependent chain in a wave that has nothing else to do, so nothing in the loop waits for memory: the bit row
+// travels two words ahead in registers, the checkpoint to compare with one ahead.  (Windows of row and checkpoints staged in LDS by
+// the whole wave were measured as well: no faster -- what is left is the chain of dependent instructions itself, ~6 clocks each.)
+constexpr int K7B_TL = 8;
 __global__ __launch_bounds__(64) void k7b_task(K7bParams q) {
+	__builtin_amdgcn_s_setprio(3);
 	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64];
+	__shared__ uint16_t s_crc[256];
+	__shared__ uint32_t s_sym[64];
 	const K7Params& p = q.k;
-	const int lane = threadIdx.x, c = blockIdx.y + 1;
-	const int chan_raw = blockIdx.x * 64 + lane;
-	const bool live = chan_raw < p.n_chan;
-	const int chan = live ? chan_raw : 0;
+	const int lane = threadIdx.x, c = blockIdx.y;
+#ifdef K7B_DEBUG
+	const long long dbg_w0 = wall_clock64(); long long dbg_w1 = 0, dbg_w2 = 0; int dbg_a = 0, dbg_c = 0;
+#endif
+	const int chan0 = blockIdx.x * K7B_TL;
+	const bool live = lane < K7B_TL && chan0 + lane < p.n_chan;
+	const int chan = live ? chan0 + lane : 0; // (idle lanes read channel 0's rows and write nothing)
 	uint32_t* data = fdata + lane;
-	const size_t slot = (size_t)c * q.n_chan_pad + chan_raw;
-	const uint32_t* brow = p.fm_cur + (size_t)chan * p.fm_stride;
+	const size_t slot = (size_t)c * q.n_chan_pad + chan;
 	BaseReg b;
-	base_load(b, q.end + (size_t)(c - 1) * q.n_chan_pad + chan, data);
-	const K7bCkpt* ck = q.ckpt + chan_raw;
-	const auto ckpt_at = [&](int n) { return ck[((size_t)(n / K7B_CH) * (K7B_CH / 32) + (size_t)((n % K7B_CH) >> 5)) * q.n_chan_pad]; };
+	base_load(b, c ? q.end + (size_t)(c - 1) * q.n_chan_pad + chan : p.state + chan, data); // boundary 0: the state the previous block left
+	const auto ckpt_of = [&](int ch, int w) { // the recorded state in front of sample 32 w of channel ch
+		const int n = w << 5;
+		return q.ckpt[((size_t)(n / K7B_CH) * (K7B_CH / 32) + (size_t)((n % K7B_CH) >> 5)) * q.n_chan_pad + ch];
+	};
 	const int n0 = c * K7B_CH;
 	// (Tasks whose start state is not the true one -- the end of a trajectory that never became true -- are wasted work, but they run
 	// beside the useful ones; restricting the launch to boundaries whose predecessor is known to be true, in passes, was measured: the
-	// longest USEFUL task sets the time either way, profiles/r03_k7b_*.)
-	const bool run = live && !base_same(base_ckpt(b), ckpt_at(n0));
+	// longest USEFUL task sets the time either way.)
+	const bool run = live && !base_same(base_ckpt(b), ckpt_of(chan, n0 >> 5));
 	int merge = run ? p.L : -1;
-	const bool decided = live;
 	uint32_t* list = q.task_frames + slot * (1 + K7B_FCAP * K7B_FREC);
-	if (live) list[0] = 0;
+	if (live) {
+		list[0] = 0;
+		if (!run) q.task_merge[slot] = -1;
+	}
+#ifdef K7B_DEBUG
+	dbg_w1 = wall_clock64();
+	if (!__any(run) && blockIdx.x == 0 && lane == 0) printf("K7B idle wave: boundary %d start %lld decided after %lld\n", c, dbg_w0, dbg_w1 - dbg_w0);
+#endif
+	if (!__any(run)) return;
+	for (int i = lane; i < 256; i += 64) dec_crc_table_entry(i, s_crc);
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // (one-wave workgroup: ordering only)
+	const int nw_row = (p.L + 31) >> 5;
+	const uint32_t* brow = p.fm_cur + (size_t)chan * p.fm_stride;
+	const auto row_word = [&](int w) { return brow[w < nw_row ? w : nw_row - 1]; };
 	bool overflow = false;
 	// A task spends most of its samples INSIDE a frame, where the sampler's gain is fixed (slow) whatever the decoder does until the
 	// frame ends.  So while a lane's decoder is in DATAFCS the lane runs the sampler alone for up to 32 symbols, collects their
 	// decisions in a word and lets the word-parallel frame evaluator (dec_run_frame, the one k7e_sim uses; fuzzed against dec_step on
-	// the host) swallow them at once -- ~90 instead of ~225 instructions per symbol.  Only a word in which the frame ENDS (closing
-	// flag, abort) is not accepted: the lane goes back to the state in front of that word and walks it symbol by symbol, so that the
-	// sampler's gain switches at exactly the sample the reference switches it.  No checkpoint can match inside a frame (both
-	// decoders must be in TRAINING), so none is compared there.
-	__shared__ uint16_t s_crc[256];
-	__shared__ uint32_t s_sym[64];
-	for (int i = lane; i < 256; i += 64) dec_crc_table_entry(i, s_crc);
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-	__builtin_amdgcn_s_barrier();
+	// the host) swallow them at once.  Only a word in which the frame ENDS (closing flag, abort) is not accepted: the lane goes back
+	// to the state in front of that word and walks it symbol by symbol, so that the sampler's gain switches at exactly the sample the
+	// reference switches it.  No checkpoint can match inside a frame (both decoders must be in TRAINING), so none is compared there.
 	int n = n0;
 	bool active = run, finish = false;
-	uint32_t word = active ? brow[n >> 5] : 0u;
-	K7bCkpt next = ckpt_at(n0 + 32 < p.L ? n0 + 32 : n0); // the recorded state one checkpoint ahead travels in registers
-	int next_n = n0 + 32;
-	while (__any(active && n < p.L)) {
-		const bool live_lane = active && n < p.L;
+	// w1 / w2: the words behind `word` (in front of a sample with n % 32 == 0: the words AT n)
+	uint32_t word = 0u, w1 = active ? row_word(n >> 5) : 0u, w2 = active ? row_word((n >> 5) + 1) : 0u;
+	K7bCkpt next = ckpt_of(chan, (n0 >> 5) + 1 < nw_row ? (n0 >> 5) + 1 : n0 >> 5); // the recorded state one checkpoint ahead
+	int next_w = (n0 >> 5) + 1;
+	bool stale = false; // r.crc / r.tail behind (dec_run_frame<LAZY>)
+#ifdef K7B_CAP
+	const int dbg_end = n0 + K7B_CAP < p.L ? n0 + K7B_CAP : p.L; // timing experiment only (wrong results): no task longer than K7B_CAP samples
+#define K7B_END dbg_end
+#else
+#define K7B_END p.L
+#endif
+	while (__any(active && n < K7B_END)) {
+		const bool live_lane = active && n < K7B_END;
 		if (live_lane && b.r.state == DST_DATAFCS && !finish) { // ---- inside a frame: the sampler alone, one word of symbols
+#ifdef K7B_DEBUG
+			dbg_a++;
+#endif
 			const BaseReg snap = b;
 			const int n_s = n;
-			const uint32_t w_s = word;
+			const uint32_t w_s = word, w1_s = w1, w2_s = w2;
 			uint32_t bits = 0;
 			int ns = 0;
-			while (ns < 32 && n < p.L) {
-				if ((n & 31) == 0) word = brow[n >> 5];
+			// up to the next word boundary sample by sample (at most 7 decisions), then whole words (at most 22 / 30 decisions in 3 / 4:
+			// the phase advances by 0.225 per sample at most)
+			int whole = (n & 31) ? 3 : 4;
+			while ((n & 31) != 0 && n < p.L) {
 				const int bit = (int)((word >> (n & 31)) & 1u);
 				const bool emit = base_pll_step(b, bit);
 				n++;
 				if (emit) { bits |= (uint32_t)bit << ns; ns++; }
 			}
-			s_sym[lane] = bits;
-			int end = 0;
-			const int flags = dec_run_frame(b.r, data, s_sym + lane, nullptr, 0, ns, s_crc, end);
-			if (flags != 2) { b = snap; n = n_s; word = w_s; finish = true; } // the frame ends in this word: symbol by symbol
+			for (; whole > 0 && n + 32 <= p.L; whole--) {
+				word = w1; w1 = w2; w2 = row_word((n >> 5) + 2);
+				base_slow_word(b.pll, b.pprev, word, bits, ns);
+				n += 32;
+			}
+			if (n + 32 > p.L) // (a block whose length is not a multiple of 32: the last samples one by one)
+				while (ns < 32 && n < p.L) {
+					if ((n & 31) == 0) { word = w1; w1 = w2; w2 = row_word((n >> 5) + 2); }
+					const int bit = (int)((word >> (n & 31)) & 1u);
+					const bool emit = base_pll_step(b, bit);
+					n++;
+					if (emit) { bits |= (uint32_t)bit << ns; ns++; }
+				}
+			if (ns > 0) {
+				s_sym[lane] = bits;
+				int end = 0;
+				const int flags = dec_run_frame<true>(b.r, data, s_sym + lane, nullptr, 0, ns, s_crc, end);
+				stale = true;
+				if (flags != 2) { // the frame ends in this word: symbol by symbol, from the state in front of it
+					b = snap; n = n_s; word = w_s; w1 = w1_s; w2 = w2_s; finish = true;
+					dec_fix_crc_tail(b.r, data, s_crc);
+					stale = false;
+				}
+			}
 		} else if (live_lane) { // ---- one symbol: the samples up to the next emission, then the decoder step
 			bool emit = false;
 			int bit = 0;
 			while (active && n < p.L && !emit) {
 				if ((n & 31) == 0) {
-					word = brow[n >> 5];
+					word = w1; w1 = w2; w2 = row_word((n >> 5) + 2);
 					if (n > n0) {
-						const K7bCkpt cur = next_n == n ? next : ckpt_at(n);
-						next_n = n + 32;
-						next = ckpt_at(next_n < p.L ? next_n : n);
+						const int w = n >> 5;
+						const K7bCkpt cur = next_w == w ? next : ckpt_of(chan, w);
+						next_w = w + 1;
+						next = ckpt_of(chan, next_w < nw_row ? next_w : w);
 						if (base_same(base_ckpt(b), cur)) { merge = n; active = false; break; }
 					}
 				}
@@ -2773,6 +2852,9 @@ __global__ __launch_bounds__(64) void k7b_task(K7bParams q) {
 				emit = base_pll_step(b, bit);
 				n++;
 			}
+#ifdef K7B_DEBUG
+			dbg_c++;
+#endif
 			if (emit && dec_step(b.r, bit, 0.0f, 0ll, data)) { // (tag.sample_lvl / sample_idx are never set in this engine)
 				base_record(b, n - 1, list, data, overflow);
 				b.r.state = DST_TRAINING; b.r.position = 0; b.r.osc = 0;
@@ -2780,84 +2862,90 @@ __global__ __launch_bounds__(64) void k7b_task(K7bParams q) {
 			if (b.r.state != DST_DATAFCS) finish = false;
 		}
 	}
-	if (decided) {
+#ifdef K7B_DEBUG
+	dbg_w2 = wall_clock64();
+	if (run && (merge - n0 > 2048 || (chan & 63) == 5))
+		printf("K7B task: chan %d boundary %d length %d words %d symbols %d: start %lld, decided after %lld, done after %lld (10 ns)\n", chan, c, merge - n0, dbg_a, dbg_c, dbg_w0, dbg_w1 - dbg_w0, dbg_w2 - dbg_w0);
+#endif
+	if (run) {
 		q.task_merge[slot] = merge;
-		if (run && merge == p.L) base_store(b, q.task_end + slot, data); // ran to the end of the block: this is the channel's state
-		if (overflow) q.fallback[chan_raw] = 1;
+		if (merge == p.L) { // ran to the end of the block: this is the channel's state
+			if (stale && b.r.state == DST_DATAFCS) dec_fix_crc_tail(b.r, data, s_crc); // (the block ends inside a frame)
+			base_store(b, q.task_end + slot, data);
+		}
+		if (overflow) q.fallback[chan] = 1;
 	}
 }
 
-__global__ __launch_bounds__(64) void k7b_assemble(K7bParams q) {
+// One workgroup per 64 channels, K7B_AW waves.  The decision which trajectory is the channel's is a chain over the boundaries (wave
+// 0, one lane per channel); copying the frames out is not -- a lane that did it alone went from list to list with two dependent
+// memory round trips each (0.28 ms of this kernel with 256 distinct receivers) -- so the walk only notes per list "yours from sample
+// s on, at offset o of your frames", and the waves share the lists out.  The walk is a scan over the boundaries in order, eight
+// boundaries' merge positions and list lengths in registers at a time (no LDS tile: beside the front end, whose workgroups hold all of
+// a CU's LDS, a workgroup that asks for 30 KB waited for most of the front end's launch).
+constexpr int K7B_AW = 8;
+constexpr uint32_t K7B_NOT = 0xFFFFFFFFu;
+__global__ __launch_bounds__(64 * K7B_AW) void k7b_assemble(K7bParams q) {
+	__builtin_amdgcn_s_setprio(3);
 	const K7Params& p = q.k;
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int chan_raw = blockIdx.x * 64 + lane;
 	const bool live = chan_raw < p.n_chan;
 	const int chan = live ? chan_raw : 0;
 	const size_t per = 1 + K7B_FCAP * K7B_FREC;
-	// The walk is a chain of dependent decisions, and nearly every list is empty: merge positions and list lengths come to LDS
-	// first, eight boundaries' loads in flight at once (one dependent global load per boundary made this kernel 0.1 ms).
-	constexpr int MAXC = 96;
-	__shared__ int merges[MAXC][64];
-	__shared__ unsigned short counts[MAXC][64]; // frames of the chunk's list | frames of the boundary's task list << 8
-	const bool staged = q.n_chunks <= MAXC;
-	if (staged)
-		for (int i0 = 0; i0 < q.n_chunks; i0 += 8) {
+	__shared__ uint32_t out_base[64];
+	if (wave == 0) {
+		unsigned mine = 0;
+		const DecState* fin = nullptr;
+		const bool go = live && q.fallback[chan] == 0; // (flagged by a frame list that overflowed: k7_base decodes the block from the untouched state)
+		constexpr int NEVER = 0x7FFFFFFF;
+		int next_c = go ? 0 : NEVER; // the next boundary to decide (the ones before it lie inside a task)
+		int pend_c = -1, pend_from = 0; // the chunk whose recorded trajectory the last task joined, and where
+		if (go) fin = q.end + (size_t)(q.n_chunks - 1) * q.n_chan_pad + chan;
+		for (int c0 = 0; c0 < q.n_chunks; c0 += 8) {
 			int m[8]; uint32_t a[8], t[8];
 #pragma unroll
 			for (int e = 0; e < 8; e++) {
-				const int i = i0 + e < q.n_chunks ? i0 + e : q.n_chunks - 1;
+				const int i = c0 + e < q.n_chunks ? c0 + e : q.n_chunks - 1;
 				const size_t sl = (size_t)i * q.n_chan_pad + chan;
 				m[e] = q.task_merge[sl]; a[e] = q.frames[sl * per]; t[e] = q.task_frames[sl * per];
 			}
 #pragma unroll
-			for (int e = 0; e < 8; e++)
-				if (i0 + e < q.n_chunks) {
-					merges[i0 + e][lane] = i0 + e ? m[e] : -1;
-					counts[i0 + e][lane] = (unsigned short)(a[e] | (i0 + e ? t[e] << 8 : 0u));
+			for (int e = 0; e < 8; e++) {
+				const int c = c0 + e;
+				if (c < q.n_chunks) {
+					const size_t sl = (size_t)c * q.n_chan_pad + chan_raw;
+					uint32_t rs = K7B_NOT, rt = K7B_NOT;
+					if (c == next_c) {
+						if (m[e] < 0) { rs = mine; mine += a[e]; next_c = c + 1; } // the speculative state WAS the true one
+						else {
+							rt = mine; mine += t[e]; // the exact loop from the previous chunk's (true) end state up to the merge
+							if (m[e] >= p.L) { fin = q.task_end + (size_t)c * q.n_chan_pad + chan; next_c = NEVER; }
+							else { pend_c = m[e] / K7B_CH; pend_from = m[e]; next_c = pend_c + 1; }
+						}
+					}
+					if (c == pend_c) { // the trajectory the task joined (possibly inside this very chunk): only what it completed from there on
+						unsigned k = 0;
+						const uint32_t* list = q.frames + ((size_t)c * q.n_chan_pad + chan) * per;
+						for (unsigned i = 0; i < a[e]; i++) k += (int)list[1 + i * K7B_FREC] >= pend_from ? 1u : 0u;
+						rs = (uint32_t)pend_from << 16 | mine;
+						mine += k;
+						pend_c = -1;
+					}
+					q.take_spec[sl] = rs; q.take_task[sl] = rt;
 				}
+			}
 		}
-	const auto merge_of = [&](int c) { return staged ? merges[c][lane] : q.task_merge[(size_t)c * q.n_chan_pad + chan]; };
-	const auto n_spec = [&](int c) { return staged ? (uint32_t)(counts[c][lane] & 255u) : q.frames[((size_t)c * q.n_chan_pad + chan) * per]; };
-	const auto n_task = [&](int c) { return staged ? (uint32_t)(counts[c][lane] >> 8) : q.task_frames[((size_t)c * q.n_chan_pad + chan) * per]; };
-	// one walk over the boundaries; visit(list, count, from): the list's frames that completed at sample >= from are the channel's.
-	// Returns the final state's source, or nullptr where a boundary needed a task that no pass ran.
-	const auto walk = [&](auto&& visit) -> const DecState* {
-		visit(q.frames + (size_t)chan * per, n_spec(0), 0); // chunk 0's trajectory is exact from sample 0
-		const DecState* fin = q.end + (size_t)(q.n_chunks - 1) * q.n_chan_pad + chan;
-		int c = 1;
-		while (c < q.n_chunks) {
-			const size_t slot = (size_t)c * q.n_chan_pad + chan;
-			const int merge = merge_of(c);
-			if (merge == -2) return nullptr;
-			if (merge < 0) { visit(q.frames + slot * per, n_spec(c), 0); c++; continue; } // the speculative state WAS the true one
-			visit(q.task_frames + slot * per, n_task(c), 0); // the exact loop from the previous chunk's (true) end state up to the merge
-			if (merge >= p.L) return q.task_end + slot;
-			const int cm = merge / K7B_CH; // the chunk whose recorded trajectory the task joined (the boundaries in between lie inside the task)
-			visit(q.frames + ((size_t)cm * q.n_chan_pad + chan) * per, n_spec(cm), merge);
-			c = cm + 1;
-		}
-		return fin;
-	};
-	// pass 1: is the chain complete, and how many frames does the channel emit?  (One atomic per wave instead of one per frame:
-	// two thousand atomics on one counter were most of this kernel's time.)
-	unsigned mine = 0;
-	const DecState* fin = nullptr;
-	const bool skip = !live || q.fallback[chan] != 0; // (flagged by a frame list that overflowed: k7_base decodes the block from the untouched state)
-	if (!skip) {
-		fin = walk([&](const uint32_t* list, uint32_t cnt, int from) {
-			for (uint32_t i = 0; i < cnt; i++) mine += (int)list[1 + i * K7B_FREC] >= from ? 1u : 0u;
-		});
-		if (!fin) { q.fallback[chan] = 1; mine = 0; } // a chain of more tasks than passes
+		unsigned incl = mine;
+		for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+		unsigned base = 0;
+		if (lane == 63 && incl) base = atomicAdd(p.frame_count, incl);
+		out_base[lane] = __shfl(base, 63) + incl - mine;
+		if (fin) p.state[chan] = *fin;
 	}
-	unsigned incl = mine;
-	for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-	unsigned base = 0;
-	if (lane == 63 && incl) base = atomicAdd(p.frame_count, incl);
-	base = __shfl(base, 63);
-	if (skip || !fin) return;
-	unsigned at = base + incl - mine;
-	walk([&](const uint32_t* list, uint32_t cnt, int from) {
-		for (uint32_t i = 0; i < cnt; i++) {
+	__syncthreads(); // (wave 0's notes are in memory: the barrier waits for its stores)
+	const auto emit = [&](const uint32_t* list, unsigned cnt, int from, unsigned at) {
+		for (unsigned i = 0; i < cnt; i++) {
 			const uint32_t* r = list + 1 + i * K7B_FREC;
 			if ((int)r[0] < from) continue;
 			uint32_t* f = p.frames + (size_t)(at++ % (unsigned)p.max_frames) * DEC_FRAME_WORDS;
@@ -2866,8 +2954,15 @@ __global__ __launch_bounds__(64) void k7b_assemble(K7bParams q) {
 			f[8] = p.block; f[9] = p.sub;
 			for (int w = 0; w < DEC_DATA_WORDS; w++) f[10 + w] = r[2 + w];
 		}
-	});
-	p.state[chan] = *fin;
+	};
+	for (int c = wave; c < q.n_chunks; c += K7B_AW) {
+		const size_t sl = (size_t)c * q.n_chan_pad + chan_raw;
+		const uint32_t ts = __builtin_nontemporal_load(q.take_spec + sl), tt = __builtin_nontemporal_load(q.take_task + sl);
+		const size_t ls = ((size_t)c * q.n_chan_pad + chan) * per;
+		const uint32_t cs = q.frames[ls], ct = q.task_frames[ls];
+		if (ts != K7B_NOT && cs) emit(q.frames + ls, cs, (int)(ts >> 16), out_base[lane] + (ts & 0xFFFFu));
+		if (tt != K7B_NOT && ct) emit(q.task_frames + ls, ct, 0, out_base[lane] + tt);
+	}
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3416,11 +3511,15 @@ hipError_t launch_k7_mesh(const K7Params& p, hipStream_t s) {
 	return hipGetLastError();
 }
 
-hipError_t launch_k7b(const K7bParams& q, hipStream_t s) {
+hipError_t launch_k7b_spec(const K7bParams& q, hipStream_t s) {
+	hipLaunchKernelGGL(k7b_spec, dim3((q.k.n_chan + 63) / 64, q.n_chunks), dim3(64), 0, s, q);
+	return hipGetLastError();
+}
+
+hipError_t launch_k7b_finish(const K7bParams& q, hipStream_t s) {
 	const int gx = (q.k.n_chan + 63) / 64;
-	hipLaunchKernelGGL(k7b_spec, dim3(gx, q.n_chunks), dim3(64), 0, s, q);
-	if (q.n_chunks > 1) hipLaunchKernelGGL(k7b_task, dim3(gx, q.n_chunks - 1), dim3(64), 0, s, q);
-	hipLaunchKernelGGL(k7b_assemble, dim3(gx), dim3(64), 0, s, q);
+	hipLaunchKernelGGL(k7b_task, dim3((q.k.n_chan + K7B_TL - 1) / K7B_TL, q.n_chunks), dim3(64), 0, s, q);
+	hipLaunchKernelGGL(k7b_assemble, dim3(gx), dim3(64 * K7B_AW), 0, s, q);
 	K7Params fb = q.k; // exact fallback: exits at once unless a channel is flagged
 	fb.cond = q.fallback; fb.cond_count = q.fallback_count;
 	hipLaunchKernelGGL(k7_base, dim3(gx), dim3(64), 0, s, fb);

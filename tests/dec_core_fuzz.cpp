@@ -20,6 +20,7 @@ struct Dec {
 };
 
 static uint16_t g_tab[256];
+static bool g_lazy = false; // third argument "lazy": the evaluator as K7b's boundary tasks call it (CRC register / tail formed on demand)
 
 static void fresh(Dec& d, int prev, int lastBit) {
 	memset(&d, 0, sizeof d);
@@ -57,7 +58,8 @@ static int run_words(Dec& d, const Block& b, int c, int& end) {
 		g++;
 	}
 	if (d.r.state != DST_DATAFCS) { d.data()[DEC_LANES * d.r.cwi] = d.r.cw; return 2; }
-	const int flags = dec_run_frame(d.r, d.data(), b.bits.data(), b.lvl.data(), g, b.n, g_tab, end, b.shift, b.first);
+	const int flags = g_lazy ? dec_run_frame<true>(d.r, d.data(), b.bits.data(), b.lvl.data(), g, b.n, g_tab, end, b.shift, b.first)
+	                         : dec_run_frame<false>(d.r, d.data(), b.bits.data(), b.lvl.data(), g, b.n, g_tab, end, b.shift, b.first);
 	if (flags == 2) d.data()[DEC_LANES * d.r.cwi] = d.r.cw;
 	return flags;
 }
@@ -83,6 +85,7 @@ static uint16_t crc16(const std::vector<int>& bits) {
 int main(int argc, char** argv) {
 	const long trials = argc > 1 ? atol(argv[1]) : 200000;
 	const unsigned seed = argc > 2 ? (unsigned)atol(argv[2]) : 1u;
+	g_lazy = argc > 3 && !strcmp(argv[3], "lazy");
 	for (int i = 0; i < 256; i++) dec_crc_table_entry(i, g_tab);
 	std::mt19937 rng(seed);
 	const auto rnd = [&](int lo, int hi) { return lo + (int)(rng() % (unsigned)(hi - lo + 1)); };
@@ -180,7 +183,9 @@ int main(int argc, char** argv) {
 			const int fa = run_steps(a, blk, lead, ea);
 			const int fb = run_words(b, blk, lead, eb);
 			const char* what = "";
-			if (fa != fb || ea != eb || (fa != 0 && !same_state(a, b, fa, &what))) {
+			Dec bc = b; // (lazy: the stale registers stay in b -- the next block's call must not depend on them)
+			if (g_lazy && fb == 2) dec_fix_crc_tail(bc.r, bc.data(), g_tab);
+			if (fa != fb || ea != eb || (fa != 0 && !same_state(a, bc, fa, &what))) {
 				printf("MISMATCH trial %ld seed %u block %d (mode %d, lead %d, n %d): flags %d / %d, end %d / %d, %s (position %d / %d)\n", t, seed,
 				       nblocks, mode, lead, n, fa, fb, ea, eb, what, a.r.position, b.r.position);
 				return 1;

@@ -29,6 +29,14 @@ def test_frame_evaluator_equals_the_step(fuzz_binary, seed):
     assert runs == 250000 and messages > 10000 and other > 100000 and crossings > 50000, r.stdout
 
 
+def test_lazy_frame_evaluator_equals_the_step(fuzz_binary):
+    """The evaluator as K7b's boundary tasks call it: CRC register and seven-bit tail not kept up to date from word to word
+    (dec_run_frame<LAZY>), formed by dec_fix_crc_tail() when the symbol-by-symbol step takes over."""
+    r = subprocess.run([fuzz_binary, "250000", "5", "lazy"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all equal" in r.stdout
+
+
 @pytest.fixture(scope="module")
 def scan_binary(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("dec_scan") / "dec_scan_fuzz")

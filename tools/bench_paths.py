@@ -14,7 +14,7 @@ import torch  # noqa: E402
 import _pkg  # noqa: E402
 
 _pkg.load()
-from ais_catcher_amd import gpu, synth  # noqa: E402
+from ais_catcher_amd import gpu, synth, workload  # noqa: E402
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench  # noqa: E402  (the parity gate of the bench line, shared)
 
@@ -23,11 +23,16 @@ GATE = {"checked": 0, "failed": []}
 
 
 def run(name, R, rate, block, fmt="cf32", steps=30, **kw):
-    """One path: 30 untimed + `steps` timed steps over two resident blocks (one synthetic receiver replicated R times), then the
+    """One path: 30 untimed + `steps` timed steps over two resident blocks (one synthetic receiver replicated R times; with
+    BENCH_PATHS_DISTINCT=1 and CF32 input the bench line's batch of R DISTINCT receivers, workload.resident_batch), then the
     SAME parity gate as bench.py on the run that was just timed: the last block's outputs of the first and the last receiver
     against the oracle fed the same block sequence, bit for bit (hard bits, levels, ppm, FM signs, 48 kHz channels -- whatever
     the engine hands out)."""
     model = kw.get("model", gpu.MODEL_DEFAULT)
+    only = os.environ.get("BENCH_PATHS_ONLY")
+    if only and only not in name:
+        return
+    distinct = bool(os.environ.get("BENCH_PATHS_DISTINCT")) and fmt == "cf32" and not kw.get("mode_x")
     x = synth.receiver_stream(block * 2, sample_rate=rate, receiver_id=7, single_channel=kw.get("mode_x", False))
     if fmt == "cf32":
         hostx = x
@@ -44,6 +49,10 @@ def run(name, R, rate, block, fmt="cf32", steps=30, **kw):
     per = len(hostx) // 2
     dev = torch.from_numpy(np.ascontiguousarray(host)).cuda()
     data = dev.unsqueeze(1).expand(2, R, block, 2).contiguous()   # [2 blocks][R][block][2]
+    if distinct:
+        del data
+        data = workload.resident_batch(torch, R, 2, block=block, sample_rate=rate)
+        name += " [distinct receivers]"
     torch.cuda.synchronize()
     g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block, input_format=code, **kw)
     warm = 30
@@ -67,7 +76,10 @@ def run(name, R, rate, block, fmt="cf32", steps=30, **kw):
         seq = [i & 1 for i in range(warm)] + [i & 1 for i in range(steps)]
         okw = {k: kw[k] for k in ("ps_ema", "fp_ds", "mode_x", "dsk", "ma") if k in kw}
         blocks = [hostx[:per], hostx[per:]]
-        n, bad = bench.parity_check(g, None, seq, sorted({0, R - 1}), rate=rate, model=model, fmt=fmt, blocks_of=lambda r: blocks, **okw)
+        blocks_of = lambda r: blocks
+        if distinct:
+            blocks_of = lambda r: [np.ascontiguousarray(data[b, r].cpu().numpy()).view(np.complex64).reshape(-1) for b in range(2)]
+        n, bad = bench.parity_check(g, None, seq, sorted({0, R - 1}), rate=rate, model=model, fmt=fmt, blocks_of=blocks_of, **okw)
         GATE["checked"] += n
         verdict = "parity: %d receivers bit-exact" % n if not bad else "PARITY MISMATCH: " + "; ".join(bad[:4])
         if bad:
