@@ -1216,17 +1216,19 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 				HIPCHK(dalloc(&b.end, slots));
 				HIPCHK(dalloc(&b.frames, slots * (1 + K7B_FCAP * K7B_FREC)));
 				HIPCHK(dalloc(&b.fallback, (size_t)b.n_chan_pad + 1)); b.fallback_count = b.fallback + b.n_chan_pad;
+				HIPCHK(dalloc(&b.sum_spec, (size_t)b.n_chan_pad * K7B_MAXC));
 				if (i == 0) { // (the tasks' own scratch: one block at a time)
 					HIPCHK(dalloc(&b.task_end, slots));
 					HIPCHK(dalloc(&b.task_frames, slots * (1 + K7B_FCAP * K7B_FREC)));
 					HIPCHK(dalloc(&b.task_merge, slots));
 					HIPCHK(dalloc(&b.take_spec, slots)); HIPCHK(dalloc(&b.take_task, slots));
-				} else { b.task_end = h->k7b[0].task_end; b.task_frames = h->k7b[0].task_frames; b.task_merge = h->k7b[0].task_merge; b.take_spec = h->k7b[0].take_spec; b.take_task = h->k7b[0].take_task; }
+					HIPCHK(dalloc(&b.sum_task, (size_t)b.n_chan_pad * K7B_MAXC));
+					HIPCHK(dalloc(&b.out_base, (size_t)b.n_chan_pad)); HIPCHK(dalloc(&b.fin_sel, (size_t)b.n_chan_pad));
+				} else { b.task_end = h->k7b[0].task_end; b.task_frames = h->k7b[0].task_frames; b.task_merge = h->k7b[0].task_merge; b.take_spec = h->k7b[0].take_spec; b.take_task = h->k7b[0].take_task; b.sum_task = h->k7b[0].sum_task; b.out_base = h->k7b[0].out_base; b.fin_sel = h->k7b[0].fin_sel; }
 				HIPCHK(hipEventCreateWithFlags(&h->ev_spec[i], hipEventDisableTiming));
 			}
 			h->base_chunked = true;
-			// (The FM receiver stays on the front stream: it and the front end are both bound by memory, side by side -- ds = s4 -- they
-			// only take from each other: 0.59 against 0.54 ms per step.)
+			// (The FM receiver stays on the front stream; on s4 in front of the speculative pass -- ds = s4 -- the step is the same.)
 		}
 		if (h->dec_kind == 1 || h->dec_kind == 2) {
 			h->fmrow_words = h->Gcap / 32;
@@ -1387,10 +1389,10 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
 	hipFree(h->d_box[0]); hipFree(h->d_box[1]);
 	for (int i = 0; i < 2; i++) {
-		hipFree(h->k7b[i].ckpt); hipFree(h->k7b[i].end); hipFree(h->k7b[i].frames); hipFree(h->k7b[i].fallback);
+		hipFree(h->k7b[i].ckpt); hipFree(h->k7b[i].end); hipFree(h->k7b[i].frames); hipFree(h->k7b[i].fallback); hipFree(h->k7b[i].sum_spec);
 		if (h->ev_spec[i]) hipEventDestroy(h->ev_spec[i]);
 	}
-	hipFree(h->k7b[0].task_end); hipFree(h->k7b[0].task_frames); hipFree(h->k7b[0].task_merge); hipFree(h->k7b[0].take_spec); hipFree(h->k7b[0].take_task);
+	hipFree(h->k7b[0].task_end); hipFree(h->k7b[0].task_frames); hipFree(h->k7b[0].task_merge); hipFree(h->k7b[0].take_spec); hipFree(h->k7b[0].take_task); hipFree(h->k7b[0].sum_task); hipFree(h->k7b[0].out_base); hipFree(h->k7b[0].fin_sel);
 	hipFree(h->d_dec); hipFree(h->d_frames); hipFree(h->d_frame_count); hipFree(h->d_fmrows[0]); hipFree(h->d_fmrows[1]); hipFree(h->d_last_lvl[0]); hipFree(h->d_last_lvl[1]);
 	hipFree(h->d_k7ev); hipFree(h->d_k7cnt); hipFree(h->d_k7open); hipFree(h->d_k7slot); hipFree(h->d_k7ovf);
 	if (h->h_frames) hipHostFree(h->h_frames);

@@ -198,15 +198,19 @@ struct K7Params {
 // Model.cpp:428-435), chunk-parallel and exact.  The loop gain of the sampler follows the decoder's state sample by sample, so the
 // coupled system is sequential -- but it FORGETS: in fast mode (decoder in TRAINING) every sign change contracts the PLL phase by
 // 0.4, and a decoder in TRAINING is a function of its last few symbols.  So:
-//   k7b_spec      one lane per (channel, chunk of K7B_CH samples): chunk 0 runs from the carried state (exact); every other chunk
-//                 starts K7B_WARM samples early from a fresh state and records its trajectory: the sampler / decoder state in front of
-//                 every 32nd sample (12 bytes), the frames it completes, and its full state at the chunk's end;
-//   k7b_task      one lane per chunk boundary whose speculative state is NOT bit-identical with the previous chunk's end state (a frame
-//                 in flight, a silent stretch): the exact loop from that end state on, until its state equals a recorded one of the
-//                 speculative trajectory it runs alongside (both decoders in TRAINING: from there on the two are the same for ever) --
-//                 or until the block ends;
-//   k7b_assemble  one lane per channel walks the boundaries in order, decides which trajectory is the true one where, copies its
-//                 frames to the ring and the final state to DecState.
+//   k7b_spec      one lane per (channel, chunk of K7B_CH samples): every chunk starts K7B_WARM samples early from a fresh state (the
+//                 block's first chunk on the tail of the previous block's row) and records its trajectory: the sampler / decoder state
+//                 in front of every 32nd sample (12 bytes), the frames it completes, and its full state at the chunk's end.  Needs
+//                 nothing but the FM rows: runs on its own stream beside the previous block's tasks (two sets of scratch);
+//   k7b_task      one lane per chunk boundary whose speculative state is NOT bit-identical with the true one -- the previous chunk's
+//                 end state, for boundary 0 the state the previous block left (a frame in flight, a silent stretch): the exact loop
+//                 from that state on, until its state equals a recorded one of the speculative trajectory it runs alongside (both
+//                 decoders in TRAINING: from there on the two are the same for ever) -- or until the block ends.  Word by word: inside a
+//                 frame the sampler alone over four words and the word-parallel frame evaluator; in TRAINING the sampler alone over
+//                 a word and the five-instruction TRAINING step; symbol by symbol only where the decoder changes state;
+//   k7b_walk      one lane per channel scans the boundaries in order, decides which trajectory is the true one where, notes per frame
+//                 list whether (and from which sample on) it is the channel's;
+//   k7b_emit      one lane per list copies the noted frames to the ring, and the channel's final state to DecState.
 // A frame list that overflows (more than K7B_FCAP frames in a chunk / task) flags the channel; k7_base then decodes it from the
 // untouched carried state (K7Params::cond = per-channel flags).  Same DecState between blocks as k7_base: the two can alternate.
 #ifndef K7B_CH_
@@ -218,7 +222,7 @@ constexpr int K7B_CH = K7B_CH_; // samples per chunk (multiple of 32): 48 chunks
 #endif
 constexpr int K7B_WARM = K7B_WARM_;   // samples of warm-up in front of a speculative chunk (<= K7B_CH, multiple of 32): ~50 sign changes of 0.4 each
 constexpr int K7B_FCAP = 4;     // frames recorded per chunk / per task
-constexpr int K7B_MAXC = 96;    // chunks per block at most (and L < 65534: 16-bit merge positions in k7b_assemble's notes); beyond: k7_base alone
+constexpr int K7B_MAXC = 96;    // chunks per block at most (and L < 65534: 16-bit merge positions in k7b_walk's notes); beyond: k7_base alone
 constexpr int K7B_FREC = 2 + DEC_DATA_WORDS; // sample index, position, data
 struct K7bCkpt { uint32_t pll, position, flags; }; // flags: pprev | state << 1 | lastBit << 3 | prev << 4 | osc << 5
 struct K7bParams {
@@ -230,14 +234,18 @@ struct K7bParams {
 	int* task_merge;      // [n_chunks][n_chan_pad] per boundary c >= 1: -1 no task (states matched), else the sample at which the task merged (L: never)
 	DecState* task_end;   // [n_chunks][n_chan_pad] state of a task that ran to the end of the block
 	uint32_t* task_frames;// like frames
-	uint32_t* take_spec;  // [n_chunks][n_chan_pad] k7b_assemble's notes: the chunk's list is the channel's from sample (v >> 16) on, at offset (v & 0xFFFF) of its frames; ~0: not
+	uint8_t* sum_spec;    // [n_chan_pad][K7B_MAXC] frames in the chunk's list (rows per channel: k7b_walk fetches a channel's boundaries with wide loads)
+	uint32_t* sum_task;   // [n_chan_pad][K7B_MAXC] per boundary: task_merge + 1 (0: no task) | frames in the task's list << 16
+	uint32_t* take_spec;  // [n_chunks][n_chan_pad] k7b_walk's notes: the chunk's list (of (v >> 12) & 15 frames) is the channel's from sample v >> 16 on, at offset v & 0xFFF of its frames; ~0: not
 	uint32_t* take_task;  // likewise for the boundary's task list (offset; ~0: not)
+	uint32_t* out_base;   // [n_chan_pad] k7b_walk -> k7b_emit: the ring position of the channel's first frame of this block
+	uint32_t* fin_sel;    // [n_chan_pad] k7b_walk -> k7b_emit: where the channel's state after this block is (see k7b_walk)
 	int* fallback;        // [n_chan_pad] != 0: a frame list overflowed, k7_base decodes the channel's block
 	int* fallback_count;  // statistics
 	int n_chan_pad;
 };
 // k7b_spec needs the block's FM rows only (and scratch of its own: the caller alternates two sets), so it may run beside the previous
-// block's launch_k7b_finish(); that one (k7b_task, k7b_assemble, the conditional k7_base) is what carries the channels' state from
+// block's launch_k7b_finish(); that one (k7b_task, k7b_walk, k7b_emit, the conditional k7_base) is what carries the channels' state from
 // block to block and runs in block order.
 hipError_t launch_k7b_spec(const K7bParams& p, hipStream_t s);
 hipError_t launch_k7b_finish(const K7bParams& p, hipStream_t s);

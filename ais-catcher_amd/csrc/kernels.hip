@@ -2631,15 +2631,16 @@ __device__ __forceinline__ bool base_pll_step(BaseReg& b, int bit) {
 	b.pprev = bit;
 	return pll >= 1.0f;
 }
-// The sampler inside a frame (slow gain) over one whole word of 32 samples, n % 32 == 0 in front of it; the decisions it hands to the
-// decoder are appended to `bits` from bit ns on.
-__device__ __forceinline__ void base_slow_word(float& pll_io, int& pprev, uint32_t w, uint32_t& bits, int& ns) {
+// The sampler with a FIXED gain over one whole word of 32 samples, n % 32 == 0 in front of it; the decisions it hands to the decoder
+// are appended to `bits` from bit ns on (at most 8 per word with the slow gain, 16 with the fast one).
+template <bool FAST>
+__device__ __forceinline__ void base_gain_word(float& pll_io, int& pprev, uint32_t w, uint32_t& bits, int& ns) {
 	const uint32_t T = w ^ ((w << 1) | (uint32_t)pprev); // sign changes
 	float pll = pll_io;
 	uint32_t E = 0; // sample i emitted: bit 31 - i
 #pragma unroll
 	for (int i = 0; i < 32; i++) {
-		const uint32_t g = (uint32_t)((int32_t)(T << (31 - i)) >> 31) & __builtin_bit_cast(uint32_t, 0.05f);
+		const uint32_t g = (uint32_t)((int32_t)(T << (31 - i)) >> 31) & __builtin_bit_cast(uint32_t, FAST ? 0.6f : 0.05f);
 		pll = pll + (0.5f - pll) * __uint_as_float(g);
 		pll = pll + 0.2f;
 		E = E + E + (pll >= 1.0f ? 1u : 0u);
@@ -2652,13 +2653,13 @@ __device__ __forceinline__ void base_slow_word(float& pll_io, int& pprev, uint32
 		ns++;
 	}
 }
-__device__ __forceinline__ void base_record(BaseReg& b, int n, uint32_t* list, uint32_t* data, bool& overflow) {
-	const uint32_t cnt = list[0];
+// (the list's length travels in a register: a counter in memory is a round trip per frame)
+__device__ __forceinline__ void base_record(BaseReg& b, int n, uint32_t* list, uint32_t& cnt, uint32_t* data, bool& overflow) {
 	if (cnt < (uint32_t)K7B_FCAP) {
 		uint32_t* f = list + 1 + cnt * K7B_FREC;
 		f[0] = (uint32_t)n; f[1] = (uint32_t)b.r.position;
 		for (int w = 0; w < DEC_DATA_WORDS; w++) f[2 + w] = data[64 * w];
-		list[0] = cnt + 1;
+		cnt++;
 	} else overflow = true;
 }
 __global__ __launch_bounds__(64) void k7b_spec(K7bParams q) {
@@ -2683,7 +2684,7 @@ __global__ __launch_bounds__(64) void k7b_spec(K7bParams q) {
 	const int start = n0 - K7B_WARM;
 	base_fresh(b, start > 0 ? base_bit(brow, start - 1) : (int)((prow[(start - 1) >> 5] >> ((start - 1) & 31)) & 1u), data);
 	uint32_t* list = q.frames + slot * (1 + K7B_FCAP * K7B_FREC);
-	if (live) list[0] = 0;
+	uint32_t n_rec = 0;
 	bool overflow = false;
 	K7bCkpt* ck = q.ckpt + (size_t)c * (K7B_CH / 32) * q.n_chan_pad + chan_raw;
 	const int w0 = start >> 5, nwd = (n1 - start + 31) >> 5;
@@ -2710,13 +2711,14 @@ __global__ __launch_bounds__(64) void k7b_spec(K7bParams q) {
 				i++;
 			}
 			if (emit && dec_step(b.r, bit, 0.0f, 0ll, data)) { // (tag.sample_lvl / sample_idx are never set in this engine)
-				if (nb >= n0 && live) base_record(b, nb + i - 1, list, data, overflow); // (what the warm-up "completes" is not a frame)
+				if (nb >= n0 && live) base_record(b, nb + i - 1, list, n_rec, data, overflow); // (what the warm-up "completes" is not a frame)
 				b.r.state = DST_TRAINING; b.r.position = 0; b.r.osc = 0;
 			}
 		}
 	}
 	if (live) {
 		base_store(b, q.end + slot, data);
+		q.sum_spec[(size_t)chan * K7B_MAXC + c] = (uint8_t)n_rec;
 		if (overflow) q.fallback[chan_raw] = 1;
 	}
 }
@@ -2735,9 +2737,6 @@ __global__ __launch_bounds__(64) void k7b_task(K7bParams q) {
 	__shared__ uint32_t s_sym[64];
 	const K7Params& p = q.k;
 	const int lane = threadIdx.x, c = blockIdx.y;
-#ifdef K7B_DEBUG
-	const long long dbg_w0 = wall_clock64(); long long dbg_w1 = 0, dbg_w2 = 0; int dbg_a = 0, dbg_c = 0;
-#endif
 	const int chan0 = blockIdx.x * K7B_TL;
 	const bool live = lane < K7B_TL && chan0 + lane < p.n_chan;
 	const int chan = live ? chan0 + lane : 0; // (idle lanes read channel 0's rows and write nothing)
@@ -2750,125 +2749,128 @@ __global__ __launch_bounds__(64) void k7b_task(K7bParams q) {
 		return q.ckpt[((size_t)(n / K7B_CH) * (K7B_CH / 32) + (size_t)((n % K7B_CH) >> 5)) * q.n_chan_pad + ch];
 	};
 	const int n0 = c * K7B_CH;
+	// what a task needs first -- two words of the bit row, the next checkpoint -- is asked for together with the state (one round trip)
+	const int nw_row = (p.L + 31) >> 5;
+	const uint32_t* brow = p.fm_cur + (size_t)chan * p.fm_stride;
+	const auto row_word = [&](int w) { return brow[w < nw_row ? w : nw_row - 1]; };
+	uint32_t w1 = row_word(n0 >> 5), w2 = row_word((n0 >> 5) + 1);
+	K7bCkpt next = ckpt_of(chan, (n0 >> 5) + 1 < nw_row ? (n0 >> 5) + 1 : n0 >> 5); // the recorded state one checkpoint ahead
 	// (Tasks whose start state is not the true one -- the end of a trajectory that never became true -- are wasted work, but they run
 	// beside the useful ones; restricting the launch to boundaries whose predecessor is known to be true, in passes, was measured: the
 	// longest USEFUL task sets the time either way.)
 	const bool run = live && !base_same(base_ckpt(b), ckpt_of(chan, n0 >> 5));
 	int merge = run ? p.L : -1;
 	uint32_t* list = q.task_frames + slot * (1 + K7B_FCAP * K7B_FREC);
-	if (live) {
-		list[0] = 0;
-		if (!run) q.task_merge[slot] = -1;
-	}
-#ifdef K7B_DEBUG
-	dbg_w1 = wall_clock64();
-	if (!__any(run) && blockIdx.x == 0 && lane == 0) printf("K7B idle wave: boundary %d start %lld decided after %lld\n", c, dbg_w0, dbg_w1 - dbg_w0);
-#endif
+	uint32_t n_rec = 0;
+	if (live && !run) { q.task_merge[slot] = -1; q.sum_task[(size_t)chan * K7B_MAXC + c] = 0u; }
 	if (!__any(run)) return;
 	for (int i = lane; i < 256; i += 64) dec_crc_table_entry(i, s_crc);
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // (one-wave workgroup: ordering only)
-	const int nw_row = (p.L + 31) >> 5;
-	const uint32_t* brow = p.fm_cur + (size_t)chan * p.fm_stride;
-	const auto row_word = [&](int w) { return brow[w < nw_row ? w : nw_row - 1]; };
 	bool overflow = false;
-	// A task spends most of its samples INSIDE a frame, where the sampler's gain is fixed (slow) whatever the decoder does until the
-	// frame ends.  So while a lane's decoder is in DATAFCS the lane runs the sampler alone for up to 32 symbols, collects their
-	// decisions in a word and lets the word-parallel frame evaluator (dec_run_frame, the one k7e_sim uses; fuzzed against dec_step on
-	// the host) swallow them at once.  Only a word in which the frame ENDS (closing flag, abort) is not accepted: the lane goes back
-	// to the state in front of that word and walks it symbol by symbol, so that the sampler's gain switches at exactly the sample the
-	// reference switches it.  No checkpoint can match inside a frame (both decoders must be in TRAINING), so none is compared there.
-	int n = n0;
-	bool active = run, finish = false;
-	// w1 / w2: the words behind `word` (in front of a sample with n % 32 == 0: the words AT n)
-	uint32_t word = 0u, w1 = active ? row_word(n >> 5) : 0u, w2 = active ? row_word((n >> 5) + 1) : 0u;
-	K7bCkpt next = ckpt_of(chan, (n0 >> 5) + 1 < nw_row ? (n0 >> 5) + 1 : n0 >> 5); // the recorded state one checkpoint ahead
+	// The task walks its channel word by word (32 samples).  In front of every word: the word itself (travelling two ahead), the
+	// comparison with the recorded state (the merge), and the choice of how to walk the word --
+	//  A  the decoder is inside a frame (DATAFCS): the sampler's gain is slow whatever the decoder does until the frame ends, so the
+	//     sampler runs alone over up to four words (branch-free, base_gain_word), and the word-parallel frame evaluator (dec_run_frame,
+	//     the one k7e_sim uses; fuzzed against dec_step on the host) swallows the <= 30 decisions at once.  Only a stretch in which the
+	//     frame ENDS (closing flag, abort) is not accepted: the lane goes back to the state in front of it, lets the evaluator take
+	//     the decisions before the end (sampler sample by sample, it has to stop at that very emission) and walks the rest in C, so
+	//     that the gain switches at exactly the sample the reference switches it.
+	//  F  the decoder is in TRAINING: the gain is fast as long as it stays there.  The sampler runs alone over the word, the decoder's
+	//     TRAINING step (count alternations: five instructions) over its decisions; if one of them starts a flag, the word is walked
+	//     again in C.
+	//  C  symbol by symbol: the samples up to the next emission (or the end of the word), then the decoder step.
+	// No checkpoint can match inside a frame (both decoders must be in TRAINING).
+	int n = n0, bn = -1; // bn: the word boundary whose work (fetch, comparison) is done
+	bool active = run, finish = false, cword = false;
+	uint32_t word = 0u; // the word of sample n (w1 / w2: the two behind it; in front of a boundary that has not been worked: the words AT n)
 	int next_w = (n0 >> 5) + 1;
 	bool stale = false; // r.crc / r.tail behind (dec_run_frame<LAZY>)
-#ifdef K7B_CAP
-	const int dbg_end = n0 + K7B_CAP < p.L ? n0 + K7B_CAP : p.L; // timing experiment only (wrong results): no task longer than K7B_CAP samples
-#define K7B_END dbg_end
-#else
-#define K7B_END p.L
-#endif
-	while (__any(active && n < K7B_END)) {
-		const bool live_lane = active && n < K7B_END;
-		if (live_lane && b.r.state == DST_DATAFCS && !finish) { // ---- inside a frame: the sampler alone, one word of symbols
-#ifdef K7B_DEBUG
-			dbg_a++;
-#endif
+	const int n_end = p.L;
+	while (__any(active && n < n_end)) {
+		if (active && n < n_end && (n & 31) == 0 && n != bn) { // ---- a word boundary
+			bn = n;
+			word = w1; w1 = w2; w2 = row_word((n >> 5) + 2);
+			if (n > n0) {
+				const int w = n >> 5;
+				const K7bCkpt cur = next_w == w ? next : ckpt_of(chan, w);
+				next_w = w + 1;
+				next = ckpt_of(chan, next_w < nw_row ? next_w : w);
+				if (base_same(base_ckpt(b), cur)) { merge = n; active = false; }
+			}
+		}
+		const bool go = active && n < n_end;
+		const bool whole = go && (n & 31) == 0 && n + 32 <= n_end;
+		if (whole && b.r.state == DST_DATAFCS && !finish) { // ---- A
 			const BaseReg snap = b;
 			const int n_s = n;
 			const uint32_t w_s = word, w1_s = w1, w2_s = w2;
 			uint32_t bits = 0;
 			int ns = 0;
-			// up to the next word boundary sample by sample (at most 7 decisions), then whole words (at most 22 / 30 decisions in 3 / 4:
-			// the phase advances by 0.225 per sample at most)
-			int whole = (n & 31) ? 3 : 4;
-			while ((n & 31) != 0 && n < p.L) {
-				const int bit = (int)((word >> (n & 31)) & 1u);
-				const bool emit = base_pll_step(b, bit);
-				n++;
-				if (emit) { bits |= (uint32_t)bit << ns; ns++; }
-			}
-			for (; whole > 0 && n + 32 <= p.L; whole--) {
+			base_gain_word<false>(b.pll, b.pprev, word, bits, ns);
+			n += 32;
+			for (int k = 1; k < 4 && n + 32 <= n_end; k++) { // (at most 30 decisions in four words: the phase advances by 0.225 per sample at most)
 				word = w1; w1 = w2; w2 = row_word((n >> 5) + 2);
-				base_slow_word(b.pll, b.pprev, word, bits, ns);
+				base_gain_word<false>(b.pll, b.pprev, word, bits, ns);
 				n += 32;
 			}
-			if (n + 32 > p.L) // (a block whose length is not a multiple of 32: the last samples one by one)
-				while (ns < 32 && n < p.L) {
-					if ((n & 31) == 0) { word = w1; w1 = w2; w2 = row_word((n >> 5) + 2); }
+			s_sym[lane] = bits;
+			int end = 0;
+			const int flags = dec_run_frame<true>(b.r, data, s_sym + lane, nullptr, 0, ns, s_crc, end);
+			stale = true;
+			if (flags != 2) { // the frame ends at decision `end` of this stretch
+				b = snap; n = n_s; word = w_s; w1 = w1_s; w2 = w2_s; finish = true;
+				bits = 0;
+				for (int left = end; left > 0;) { // the decisions in front of it (the frame goes on behind every one of them: slow gain)
+					if ((n & 31) == 0 && n != bn) { bn = n; word = w1; w1 = w2; w2 = row_word((n >> 5) + 2); next_w = -1; }
 					const int bit = (int)((word >> (n & 31)) & 1u);
 					const bool emit = base_pll_step(b, bit);
 					n++;
-					if (emit) { bits |= (uint32_t)bit << ns; ns++; }
+					if (emit) { bits |= (uint32_t)bit << (end - left); left--; }
 				}
-			if (ns > 0) {
 				s_sym[lane] = bits;
-				int end = 0;
-				const int flags = dec_run_frame<true>(b.r, data, s_sym + lane, nullptr, 0, ns, s_crc, end);
-				stale = true;
-				if (flags != 2) { // the frame ends in this word: symbol by symbol, from the state in front of it
-					b = snap; n = n_s; word = w_s; w1 = w1_s; w2 = w2_s; finish = true;
-					dec_fix_crc_tail(b.r, data, s_crc);
-					stale = false;
-				}
+				int e2 = 0;
+				if (end == 0) dec_fix_crc_tail(b.r, data, s_crc);
+				else if (dec_run_frame<false>(b.r, data, s_sym + lane, nullptr, 0, end, s_crc, e2) != 2) overflow = true; // (cannot happen: the same decisions; k7_base would decode the block)
+				stale = false;
 			}
-		} else if (live_lane) { // ---- one symbol: the samples up to the next emission, then the decoder step
+		} else if (whole && b.r.state == DST_TRAINING && !cword) { // ---- F
+			const float pll_s = b.pll;
+			const int pprev_s = b.pprev, last_s = b.r.lastBit, prev_s = b.r.prev, pos_s = b.r.position, osc_s = b.r.osc;
+			uint32_t bits = 0;
+			int ns = 0;
+			base_gain_word<true>(b.pll, b.pprev, word, bits, ns);
+			bool ok = true;
+			for (int k = 0; k < ns; k++) { // AIS::Decoder in TRAINING (Marine/AIS.h:109-119; dec_step's isT half)
+				const int dd = (int)((bits >> k) & 1u);
+				const int Bit = dd == b.r.prev;
+				b.r.prev = dd;
+				const bool alt = Bit != b.r.lastBit;
+				ok = ok && (alt || b.r.position <= 4); // (else: two equal bits after more than four alternations start a flag)
+				b.r.position = alt ? b.r.position + 1 : 0;
+				b.r.osc = alt ? b.r.osc : 0;
+				b.r.lastBit = Bit;
+			}
+			if (ok) n += 32;
+			else { b.pll = pll_s; b.pprev = pprev_s; b.r.lastBit = last_s; b.r.prev = prev_s; b.r.position = pos_s; b.r.osc = osc_s; cword = true; }
+		} else if (go) { // ---- C
 			bool emit = false;
 			int bit = 0;
-			while (active && n < p.L && !emit) {
-				if ((n & 31) == 0) {
-					word = w1; w1 = w2; w2 = row_word((n >> 5) + 2);
-					if (n > n0) {
-						const int w = n >> 5;
-						const K7bCkpt cur = next_w == w ? next : ckpt_of(chan, w);
-						next_w = w + 1;
-						next = ckpt_of(chan, next_w < nw_row ? next_w : w);
-						if (base_same(base_ckpt(b), cur)) { merge = n; active = false; break; }
-					}
-				}
+			do {
 				bit = (int)((word >> (n & 31)) & 1u);
 				emit = base_pll_step(b, bit);
 				n++;
-			}
-#ifdef K7B_DEBUG
-			dbg_c++;
-#endif
+			} while (!emit && (n & 31) != 0 && n < n_end);
 			if (emit && dec_step(b.r, bit, 0.0f, 0ll, data)) { // (tag.sample_lvl / sample_idx are never set in this engine)
-				base_record(b, n - 1, list, data, overflow);
+				base_record(b, n - 1, list, n_rec, data, overflow);
 				b.r.state = DST_TRAINING; b.r.position = 0; b.r.osc = 0;
 			}
 			if (b.r.state != DST_DATAFCS) finish = false;
+			if ((n & 31) == 0) cword = false;
 		}
 	}
-#ifdef K7B_DEBUG
-	dbg_w2 = wall_clock64();
-	if (run && (merge - n0 > 2048 || (chan & 63) == 5))
-		printf("K7B task: chan %d boundary %d length %d words %d symbols %d: start %lld, decided after %lld, done after %lld (10 ns)\n", chan, c, merge - n0, dbg_a, dbg_c, dbg_w0, dbg_w1 - dbg_w0, dbg_w2 - dbg_w0);
-#endif
 	if (run) {
 		q.task_merge[slot] = merge;
+		q.sum_task[(size_t)chan * K7B_MAXC + c] = (uint32_t)(merge + 1) | n_rec << 16;
 		if (merge == p.L) { // ran to the end of the block: this is the channel's state
 			if (stale && b.r.state == DST_DATAFCS) dec_fix_crc_tail(b.r, data, s_crc); // (the block ends inside a frame)
 			base_store(b, q.task_end + slot, data);
@@ -2877,58 +2879,71 @@ __global__ __launch_bounds__(64) void k7b_task(K7bParams q) {
 	}
 }
 
-// One workgroup per 64 channels, K7B_AW waves.  The decision which trajectory is the channel's is a chain over the boundaries (wave
-// 0, one lane per channel); copying the frames out is not -- a lane that did it alone went from list to list with two dependent
-// memory round trips each (0.28 ms of this kernel with 256 distinct receivers) -- so the walk only notes per list "yours from sample
-// s on, at offset o of your frames", and the waves share the lists out.  The walk is a scan over the boundaries in order, eight
-// boundaries' merge positions and list lengths in registers at a time (no LDS tile: beside the front end, whose workgroups hold all of
-// a CU's LDS, a workgroup that asks for 30 KB waited for most of the front end's launch).
-constexpr int K7B_AW = 8;
+// k7b_walk / k7b_emit.  The decision which trajectory is the channel's is a chain over the boundaries (k7b_walk: one lane per
+// channel); copying the frames out is not -- a lane that did it alone went from list to list with two dependent memory round trips
+// each (0.28 ms with 256 distinct receivers) -- so the walk only notes per list "yours from sample s on, at offset o of your
+// frames", and k7b_emit copies the lists out, one lane per list.  Two kernels of one-wave workgroups, not one of
+// eight-wave workgroups with a barrier: beside the front end and the next block's speculative pass a CU rarely has eight wave slots
+// with the registers free at once, and the workgroup waited for most of the front end's launch (0.2 ms against 0.04 alone).
+// The kernel runs beside the next block's front end, which keeps the memory system full: a round trip takes microseconds, and what
+// the kernel costs is the NUMBER of dependent round trips.  So the pass and the tasks leave a summary per (channel, boundary) --
+// merge position, list lengths -- in rows per CHANNEL, a lane fetches 48 boundaries of its channel with 15 wide loads in flight at
+// once, and the walk is a fully unrolled scan over registers.  (No LDS tile either: the front end's workgroups hold all of a CU's
+// LDS, and a workgroup that asked for 30 KB waited for most of the front end's launch.)
+constexpr int K7B_SCAN = 48; // boundaries per batch of the scan (K7B_MAXC = 2 batches)
 constexpr uint32_t K7B_NOT = 0xFFFFFFFFu;
-__global__ __launch_bounds__(64 * K7B_AW) void k7b_assemble(K7bParams q) {
+__global__ __launch_bounds__(64) void k7b_walk(K7bParams q) {
 	__builtin_amdgcn_s_setprio(3);
 	const K7Params& p = q.k;
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int lane = threadIdx.x;
 	const int chan_raw = blockIdx.x * 64 + lane;
 	const bool live = chan_raw < p.n_chan;
 	const int chan = live ? chan_raw : 0;
 	const size_t per = 1 + K7B_FCAP * K7B_FREC;
-	__shared__ uint32_t out_base[64];
-	if (wave == 0) {
+	{
 		unsigned mine = 0;
 		const DecState* fin = nullptr;
-		const bool go = live && q.fallback[chan] == 0; // (flagged by a frame list that overflowed: k7_base decodes the block from the untouched state)
+		uint4 tw[K7B_SCAN / 4], sw[K7B_SCAN / 16];
+		const auto fetch = [&](int c0) {
+			const uint4* trow = reinterpret_cast<const uint4*>(q.sum_task + (size_t)chan * K7B_MAXC + c0);
+			const uint4* srow = reinterpret_cast<const uint4*>(q.sum_spec + (size_t)chan * K7B_MAXC + c0);
+#pragma unroll
+			for (int e = 0; e < K7B_SCAN / 4; e++) tw[e] = trow[e];
+#pragma unroll
+			for (int e = 0; e < K7B_SCAN / 16; e++) sw[e] = srow[e];
+		};
+		fetch(0); // (in flight together with the flag below: one round trip, not two)
+		const bool go = live && __builtin_nontemporal_load(q.fallback + chan) == 0; // (flagged by a frame list that overflowed: k7_base decodes the block from the untouched state)
 		constexpr int NEVER = 0x7FFFFFFF;
 		int next_c = go ? 0 : NEVER; // the next boundary to decide (the ones before it lie inside a task)
 		int pend_c = -1, pend_from = 0; // the chunk whose recorded trajectory the last task joined, and where
 		if (go) fin = q.end + (size_t)(q.n_chunks - 1) * q.n_chan_pad + chan;
-		for (int c0 = 0; c0 < q.n_chunks; c0 += 8) {
-			int m[8]; uint32_t a[8], t[8];
+		static_assert(K7B_MAXC % K7B_SCAN == 0 && K7B_SCAN % 16 == 0, "k7b_walk: whole 16-byte loads per batch");
+		for (int c0 = 0; c0 < q.n_chunks; c0 += K7B_SCAN) {
+			if (c0) fetch(c0);
 #pragma unroll
-			for (int e = 0; e < 8; e++) {
-				const int i = c0 + e < q.n_chunks ? c0 + e : q.n_chunks - 1;
-				const size_t sl = (size_t)i * q.n_chan_pad + chan;
-				m[e] = q.task_merge[sl]; a[e] = q.frames[sl * per]; t[e] = q.task_frames[sl * per];
-			}
-#pragma unroll
-			for (int e = 0; e < 8; e++) {
+			for (int e = 0; e < K7B_SCAN; e++) {
 				const int c = c0 + e;
 				if (c < q.n_chunks) {
+					const uint32_t t4 = e % 4 == 0 ? tw[e / 4].x : e % 4 == 1 ? tw[e / 4].y : e % 4 == 2 ? tw[e / 4].z : tw[e / 4].w;
+					const uint32_t s4 = (e / 4) % 4 == 0 ? sw[e / 16].x : (e / 4) % 4 == 1 ? sw[e / 16].y : (e / 4) % 4 == 2 ? sw[e / 16].z : sw[e / 16].w;
+					const int m = (int)(t4 & 0xFFFFu) - 1;             // -1: the speculative state was the true one
+					const uint32_t t = t4 >> 16, a = (s4 >> (8 * (e % 4))) & 255u; // frames in the task's / the chunk's list
 					const size_t sl = (size_t)c * q.n_chan_pad + chan_raw;
 					uint32_t rs = K7B_NOT, rt = K7B_NOT;
 					if (c == next_c) {
-						if (m[e] < 0) { rs = mine; mine += a[e]; next_c = c + 1; } // the speculative state WAS the true one
+						if (m < 0) { rs = a << 12 | mine; mine += a; next_c = c + 1; }
 						else {
-							rt = mine; mine += t[e]; // the exact loop from the previous chunk's (true) end state up to the merge
-							if (m[e] >= p.L) { fin = q.task_end + (size_t)c * q.n_chan_pad + chan; next_c = NEVER; }
-							else { pend_c = m[e] / K7B_CH; pend_from = m[e]; next_c = pend_c + 1; }
+							rt = t << 12 | mine; mine += t; // the exact loop from the previous chunk's (true) end state up to the merge
+							if (m >= p.L) { fin = q.task_end + (size_t)c * q.n_chan_pad + chan; next_c = NEVER; }
+							else { pend_c = m / K7B_CH; pend_from = m; next_c = pend_c + 1; }
 						}
 					}
 					if (c == pend_c) { // the trajectory the task joined (possibly inside this very chunk): only what it completed from there on
 						unsigned k = 0;
 						const uint32_t* list = q.frames + ((size_t)c * q.n_chan_pad + chan) * per;
-						for (unsigned i = 0; i < a[e]; i++) k += (int)list[1 + i * K7B_FREC] >= pend_from ? 1u : 0u;
-						rs = (uint32_t)pend_from << 16 | mine;
+						for (unsigned i = 0; i < a; i++) k += (int)list[1 + i * K7B_FREC] >= pend_from ? 1u : 0u; // (rare: a dependent read)
+						rs = (uint32_t)pend_from << 16 | a << 12 | mine;
 						mine += k;
 						pend_c = -1;
 					}
@@ -2940,13 +2955,46 @@ __global__ __launch_bounds__(64 * K7B_AW) void k7b_assemble(K7bParams q) {
 		for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d); if (lane >= d) incl += o; }
 		unsigned base = 0;
 		if (lane == 63 && incl) base = atomicAdd(p.frame_count, incl);
-		out_base[lane] = __shfl(base, 63) + incl - mine;
-		if (fin) p.state[chan] = *fin;
+		q.out_base[chan_raw] = __shfl(base, 63) + incl - mine;
+		// where the channel's state after this block is to be found (k7b_emit copies it): 0 = nowhere (k7_base will decode the block),
+		// 1 = the last chunk's trajectory, 2 + c = the task of boundary c
+		q.fin_sel[chan_raw] = !fin ? 0u : fin == q.end + (size_t)(q.n_chunks - 1) * q.n_chan_pad + chan ? 1u : 2u + (uint32_t)(fin - (q.task_end + chan)) / (uint32_t)q.n_chan_pad;
 	}
-	__syncthreads(); // (wave 0's notes are in memory: the barrier waits for its stores)
-	const auto emit = [&](const uint32_t* list, unsigned cnt, int from, unsigned at) {
+}
+
+// one lane per (chunk, channel): the chunk's list and its boundary's task list.  Beside the front end a memory round trip is ~10 us
+// (tens of MB in flight), so the first record of either list is fetched together with the notes, before it is known whether the
+// list is the channel's: one round trip in the common case.
+__global__ __launch_bounds__(64) void k7b_emit(K7bParams q) {
+	__builtin_amdgcn_s_setprio(3);
+	const K7Params& p = q.k;
+	const int lane = threadIdx.x, c = blockIdx.y;
+	const int chan_raw = blockIdx.x * 64 + lane;
+	const bool live = chan_raw < p.n_chan;
+	const int chan = live ? chan_raw : 0;
+	const size_t per = 1 + K7B_FCAP * K7B_FREC;
+	const size_t sl = (size_t)c * q.n_chan_pad + chan_raw;
+	const uint32_t* lists[2] = { q.frames + ((size_t)c * q.n_chan_pad + chan) * per, q.task_frames + ((size_t)c * q.n_chan_pad + chan) * per };
+	const unsigned my_base = q.out_base[chan_raw];
+	const uint32_t notes[2] = { q.take_spec[sl], q.take_task[sl] };
+	const uint32_t sel = c == q.n_chunks - 1 ? q.fin_sel[chan_raw] : 0u;
+	uint32_t first[2][K7B_FREC];
+#pragma unroll
+	for (int l = 0; l < 2; l++)
+#pragma unroll
+		for (int w = 0; w < K7B_FREC; w++) first[l][w] = lists[l][1 + w];
+	// note: first sample << 16 | frames in the list << 12 | offset among the channel's frames (< 4096: K7B_MAXC * 2 * K7B_FCAP)
+#pragma unroll
+	for (int l = 0; l < 2; l++) {
+		const uint32_t note = notes[l];
+		if (note == K7B_NOT || !live) continue;
+		const unsigned cnt = (note >> 12) & 15u;
+		const int from = l == 0 ? (int)(note >> 16) : 0;
+		unsigned at = my_base + (note & 0xFFFu);
 		for (unsigned i = 0; i < cnt; i++) {
-			const uint32_t* r = list + 1 + i * K7B_FREC;
+			uint32_t r[K7B_FREC];
+			if (i == 0) { for (int w = 0; w < K7B_FREC; w++) r[w] = first[l][w]; }
+			else { for (int w = 0; w < K7B_FREC; w++) r[w] = lists[l][1 + i * K7B_FREC + w]; }
 			if ((int)r[0] < from) continue;
 			uint32_t* f = p.frames + (size_t)(at++ % (unsigned)p.max_frames) * DEC_FRAME_WORDS;
 			f[0] = (uint32_t)chan; f[1] = r[0]; f[2] = r[1]; f[3] = 0; // (level sum: tag.sample_lvl is never set in this engine)
@@ -2954,15 +3002,8 @@ __global__ __launch_bounds__(64 * K7B_AW) void k7b_assemble(K7bParams q) {
 			f[8] = p.block; f[9] = p.sub;
 			for (int w = 0; w < DEC_DATA_WORDS; w++) f[10 + w] = r[2 + w];
 		}
-	};
-	for (int c = wave; c < q.n_chunks; c += K7B_AW) {
-		const size_t sl = (size_t)c * q.n_chan_pad + chan_raw;
-		const uint32_t ts = __builtin_nontemporal_load(q.take_spec + sl), tt = __builtin_nontemporal_load(q.take_task + sl);
-		const size_t ls = ((size_t)c * q.n_chan_pad + chan) * per;
-		const uint32_t cs = q.frames[ls], ct = q.task_frames[ls];
-		if (ts != K7B_NOT && cs) emit(q.frames + ls, cs, (int)(ts >> 16), out_base[lane] + (ts & 0xFFFFu));
-		if (tt != K7B_NOT && ct) emit(q.task_frames + ls, ct, 0, out_base[lane] + tt);
 	}
+	if (sel != 0u && live) p.state[chan] = sel == 1u ? q.end[(size_t)(q.n_chunks - 1) * q.n_chan_pad + chan] : q.task_end[(size_t)(sel - 2u) * q.n_chan_pad + chan];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3519,7 +3560,8 @@ hipError_t launch_k7b_spec(const K7bParams& q, hipStream_t s) {
 hipError_t launch_k7b_finish(const K7bParams& q, hipStream_t s) {
 	const int gx = (q.k.n_chan + 63) / 64;
 	hipLaunchKernelGGL(k7b_task, dim3((q.k.n_chan + K7B_TL - 1) / K7B_TL, q.n_chunks), dim3(64), 0, s, q);
-	hipLaunchKernelGGL(k7b_assemble, dim3(gx), dim3(64 * K7B_AW), 0, s, q);
+	hipLaunchKernelGGL(k7b_walk, dim3(gx), dim3(64), 0, s, q);
+	hipLaunchKernelGGL(k7b_emit, dim3(gx, q.n_chunks), dim3(64), 0, s, q);
 	K7Params fb = q.k; // exact fallback: exits at once unless a channel is flagged
 	fb.cond = q.fallback; fb.cond_count = q.fallback_count;
 	hipLaunchKernelGGL(k7_base, dim3(gx), dim3(64), 0, s, fb);

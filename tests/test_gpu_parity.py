@@ -1408,13 +1408,15 @@ def test_pipelined_batch_hand_off(model):
 
 
 @pytest.mark.parametrize("mode", [None, "seq", "alt"])
-@pytest.mark.parametrize("case", ["busy", "quiet", "short_blocks", "batch"])
+@pytest.mark.parametrize("case", ["busy", "quiet", "short_blocks", "long_frames", "batch"])
 def test_model_base_chunk_parallel_sampler_and_decoder(case, mode, monkeypatch):
     """ModelBase with AISGPU_FLAG_GPU_DECODE: DSP::SimplePLL (whose loop gain follows the decoder's StartTraining / StopTraining,
-    DSP.cpp:28-57, Model.cpp:428-435) and its decoder as the chunk-parallel kernels k7b_spec / k7b_task / k7b_assemble: speculative
-    chunks from a fresh state, the exact loop wherever a chunk boundary's speculative state is not the previous chunk's end state
-    (frames in flight: back-to-back bursts keep a task running across several chunks; silence: nothing to converge on), merged
-    where the states meet again.  NMEA text and per-message level / ppm against the compiled reference; `seq` = k7_base alone,
+    DSP.cpp:28-57, Model.cpp:428-435) and its decoder as the chunk-parallel kernels k7b_spec / k7b_task / k7b_walk / k7b_emit: speculative
+    chunks from a fresh state (the block's first one warmed up on the previous block's tail), the exact loop wherever a chunk
+    boundary's speculative state is not the previous chunk's end state (frames in flight: back-to-back bursts keep a task running
+    across several chunks; silence: nothing to converge on; `long_frames`: 1,000-bit binary messages that lose their closing flag
+    keep the decoder in DATAFCS -- and the task in its word-parallel frame mode -- for a thousand symbols, across block
+    boundaries), merged where the states meet again.  NMEA text and per-message level / ppm against the compiled reference; `seq` = k7_base alone,
     `alt` = the two implementations take turns block by block on the same DecState."""
     from ais_catcher_amd import host
     if mode:
@@ -1426,11 +1428,25 @@ def test_model_base_chunk_parallel_sampler_and_decoder(case, mode, monkeypatch):
         block, nblocks, kw = 786432, 3, dict(gap_slots=(6, 9))
     elif case == "short_blocks":  # 512 / 4096 samples at 48 kHz per block: a single (partial) chunk, then two chunks
         block, nblocks, kw = 16384, 48, dict(gap_slots=(0, 2))
+    elif case == "long_frames":
+        block, nblocks, kw = 786432, 3, dict(gap_slots=(2, 5))
     else:
         R, block, nblocks, kw = 5, 393216, 4, dict(gap_slots=(0, 3))  # (no multi-sentence messages: their sequence digit is process-global)
     xs = [synth.receiver_stream(block * nblocks, receiver_id=300 + r, **kw) for r in range(R)]
     if case == "quiet":
         xs[0][block // 3: block // 3 + 200000] = 0
+    if case == "long_frames":  # type 8 (never abandoned for its type, Marine/AIS.cpp:111-142), 168 characters, the last fifth of the burst missing
+        long_msg = "8" + ("0123456789:;<=>?@ABCDEFGHIJKLMNOPQRSTUVW`abcdefghijklmnopqrstuvw" * 3)[:167]
+        burst = synth.gmsk_burst(long_msg, 1536000)
+        rng = np.random.default_rng(77)
+        for k in range(9):
+            at = int(rng.integers(0, len(xs[0]) - len(burst)))
+            if k == 0:
+                at = block - len(burst) // 2   # one of them across the first block boundary
+            cut = burst[: int(len(burst) * rng.uniform(0.55, 0.95))]
+            t = np.arange(len(cut))
+            fc = (25000.0 if k & 1 else -25000.0) + rng.uniform(-200.0, 200.0)
+            xs[0][at:at + len(cut)] += (0.6 * cut * np.exp(1j * (2.0 * np.pi * fc / 1536000.0 * t + rng.uniform(0, 6.28)))).astype(np.complex64)
     if case == "short_blocks":
         xs.append(synth.receiver_stream(131072 * 6, receiver_id=311, gap_slots=(0, 1)))
     want, got = [], []
