@@ -171,7 +171,7 @@ struct aisgpu {
 	bool v2 = false; float2* h_c48 = nullptr; // ModelEngineV2: front end only, the 48 kHz channels go to the host (MAXSUB slots)
 	bool v2_assist = true; float2* d_v2hist = nullptr; float *d_v2f = nullptr, *d_v2prom = nullptr, *d_v2en = nullptr, *h_v2f = nullptr, *h_v2prom = nullptr, *h_v2en = nullptr; // decoder-independent part of V2::Engine on the device
 	bool base = false; float2* d_fmprev[2] = {}; // ModelBase: FM receiver on the 48 kHz channels, no coherent chain
-	float* d_fm = nullptr; uint32_t* d_fmbits[2] = {}; uint32_t* h_fmbits = nullptr; // ModelChallenger FM branch
+	float* d_fm = nullptr; float* d_fmhist[2] = {}; uint32_t* d_fmbits[2] = {}; uint32_t* h_fmbits = nullptr; // ModelChallenger FM branch
 	float* d_fmfir = nullptr; // [n_chan][L] Filter(Receiver) output of the last downstream block (AISGPU_FLAG_TAPS)
 	EmaState* d_ema[2] = {}; // state before / after the current downstream block (swapped per block)
 	uint32_t* d_pswords = nullptr; float *d_psma0 = nullptr, *d_psma1 = nullptr; unsigned* d_psfin = nullptr; int* d_psflag = nullptr;
@@ -557,6 +557,7 @@ int enqueue_back(aisgpu_t* h) {
 	if (h->challenger) { // FM branch on the same derotated samples (Model.cpp:638-639)
 		K5Params k5;
 		k5.x = h->d_cgf; k5.x_stride = CGF_HIST + h->L; k5.x_off = CGF_HIST; k5.prev_in = nullptr; k5.prev_out = nullptr; k5.fm = h->d_fm; k5.fm_stride = FM_HIST + h->L;
+		k5.hist_in = h->d_fmhist[pb]; k5.hist_out = h->d_fmhist[pb ^ 1];
 		k5.fmbits = h->d_fmbits[pb]; k5.fmbits_stride = h->L / 32; k5.L = h->L;
 		k5.fir_out = h->d_fmfir; k5.fir_stride = h->L;
 		memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
@@ -654,6 +655,7 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 	K5Params k5;
 	k5.x = h->d_c48[q]; k5.x_stride = h->c48s; k5.x_off = 0; k5.prev_in = h->d_fmprev[pb]; k5.prev_out = h->d_fmprev[pb ^ 1];
 	k5.fm = h->d_fm; k5.fm_stride = FM_HIST + h->L;
+	k5.hist_in = h->d_fmhist[pb]; k5.hist_out = h->d_fmhist[pb ^ 1];
 	k5.fmbits = h->d_fmbits[pb]; k5.fmbits_stride = h->L / 32; k5.L = h->L;
 	k5.fir_out = h->d_fmfir; k5.fir_stride = h->L;
 	memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
@@ -1301,7 +1303,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	HIPCHK(dalloc(&h->d_cgf, C * (CGF_HIST + h->L)));
 	if (h->base) for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmprev[i], C)); // Demod::FM::prev = 0 (Demod.h)
 	if (h->challenger || h->base) {
-		HIPCHK(dalloc(&h->d_fm, C * (FM_HIST + h->L)));
+		if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_fm, C * (FM_HIST + h->L))); // (the discriminator output is a tap only)
+		for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmhist[i], C * FM_HIST)); // zero: DSP::Filter starts on zeros
 		for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmbits[i], C * (h->L / 32)));
 		HIPCHK(hipHostMalloc((void**)&h->h_fmbits, MAXSUB * C * (h->L / 32) * sizeof(uint32_t), hipHostMallocDefault));
 		if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_fmfir, C * (size_t)h->L));
@@ -1379,7 +1382,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	for (auto& p : h->ev_free) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
 	hipFree(h->d_xmid);
 	hipFree(h->d_in[0]); hipFree(h->d_in[1]); hipFree(h->d_hist[0]); hipFree(h->d_hist[1]); hipFree(h->d_hist2[0]); hipFree(h->d_hist2[1]);
-	hipFree(h->d_fm); hipFree(h->d_fmfir); hipFree(h->d_fmbits[0]); hipFree(h->d_fmbits[1]);
+	hipFree(h->d_fm); hipFree(h->d_fmhist[0]); hipFree(h->d_fmhist[1]); hipFree(h->d_fmfir); hipFree(h->d_fmbits[0]); hipFree(h->d_fmbits[1]);
 	if (h->h_fmbits) hipHostFree(h->h_fmbits);
 	if (h->h_c48) hipHostFree(h->h_c48);
 	hipFree(h->d_v2hist); hipFree(h->d_v2f); hipFree(h->d_v2prom); hipFree(h->d_v2en);

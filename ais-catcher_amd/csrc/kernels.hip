@@ -2105,37 +2105,39 @@ __device__ __forceinline__ float atan2f_ref(float y, float x) {
 	}
 }
 
-// history carry of the discriminator output (same stream, before k5_fm overwrites the row)
-__global__ __launch_bounds__(64) void k5_carry(K5Params p) {
-	float* f = p.fm + (size_t)blockIdx.x * p.fm_stride;
-	if (threadIdx.x < FM_HIST) f[threadIdx.x] = f[p.L + threadIdx.x];
-}
-
-__global__ __launch_bounds__(256) void k5_fm(K5Params p) {
-	const int chan = blockIdx.y;
-	const int n = blockIdx.x * 256 + threadIdx.x;
-	if (n >= p.L) return;
-	const float2* y = p.x + (size_t)chan * p.x_stride + p.x_off + n;
-	const float2 d = y[0];
-	const float2 pv = (n == 0 && p.prev_in) ? p.prev_in[chan] : y[-1];
-	if (n == p.L - 1 && p.prev_out) p.prev_out[chan] = d;
-	// data[i] * std::conj(prev): (xr*pr - xi*(-pi), xr*(-pi) + xi*pr)
-	const float npi = -pv.y;
-	const float re = d.x * pv.x - d.y * npi;
-	const float im = d.x * npi + d.y * pv.x;
-	p.fm[(size_t)chan * p.fm_stride + FM_HIST + n] = __fdiv_rn(atan2f_ref(im, re), 3.14159265358979323846f);
-}
-
-__global__ __launch_bounds__(256) void k5_filter(K5Params p) {
-	const int chan = blockIdx.y;
-	const int n = blockIdx.x * 256 + threadIdx.x; // L is a multiple of 512
-	const float* f = p.fm + (size_t)chan * p.fm_stride + n; // f[i] = fm[n - 36 + i]
+// The FM receiver as ONE kernel: Demod::FM (Demod.cpp:27-37) into LDS, DSP::Filter with the 37 Receiver taps (DSP.cpp:249-280) out
+// of LDS, the sign into the bit row.  A workgroup makes 256 outputs and needs the discriminator at 36 samples in front of them: the
+// first tile of a block takes those from the previous block's last tile (hist_in / hist_out, two buffers by block parity -- first
+// and last tile of one launch run side by side), every other tile computes them again (14 % more atan2, and the discriminator
+// output -- 50 MB per block written and read 37 times through the caches -- never leaves the chip; it is stored only as a tap).
+__global__ __launch_bounds__(256) void k5_fm_filter(K5Params p) {
+	__shared__ float s_fm[256 + FM_HIST];
+	const int chan = blockIdx.y, t = threadIdx.x;
+	const int t0 = blockIdx.x * 256; // L is a multiple of 256
+	const float2* y = p.x + (size_t)chan * p.x_stride + p.x_off;
+	const auto disc = [&](int n) { // sample n >= 0 of the block
+		const float2 d = y[n];
+		const float2 pv = (n == 0 && p.prev_in) ? p.prev_in[chan] : y[n - 1];
+		if (n == p.L - 1 && p.prev_out) p.prev_out[chan] = d;
+		// data[i] * std::conj(prev): (xr*pr - xi*(-pi), xr*(-pi) + xi*pr)
+		const float npi = -pv.y;
+		const float re = d.x * pv.x - d.y * npi;
+		const float im = d.x * npi + d.y * pv.x;
+		return __fdiv_rn(atan2f_ref(im, re), 3.14159265358979323846f);
+	};
+	const float f = disc(t0 + t);
+	s_fm[FM_HIST + t] = f;
+	if (p.fm) p.fm[(size_t)chan * p.fm_stride + FM_HIST + t0 + t] = f;
+	if (t < FM_HIST) s_fm[t] = t0 == 0 ? p.hist_in[(size_t)chan * FM_HIST + t] : disc(t0 - FM_HIST + t);
+	if (t0 + 256 == p.L && t >= 256 - FM_HIST) p.hist_out[(size_t)chan * FM_HIST + (t - (256 - FM_HIST))] = f;
+	__syncthreads();
 	float acc = 0.0f;
 #pragma unroll
-	for (int i = 0; i < 37; i++) acc += p.taps[i] * f[i]; // x += taps[i] * *data++ (DSP.h:257-263)
+	for (int i = 0; i < 37; i++) acc += p.taps[i] * s_fm[t + i]; // x += taps[i] * *data++ (DSP.h:257-263)
+	const int n = t0 + t;
 	if (p.fir_out) p.fir_out[(size_t)chan * p.fir_stride + n] = acc;
 	const unsigned long long b = __ballot(acc > 0);
-	if ((threadIdx.x & 63) == 0) {
+	if ((t & 63) == 0) {
 		uint32_t* o = p.fmbits + (size_t)chan * p.fmbits_stride + (n >> 5);
 		o[0] = (uint32_t)b;
 		o[1] = (uint32_t)(b >> 32);
@@ -2663,9 +2665,7 @@ __device__ __forceinline__ void base_record(BaseReg& b, int n, uint32_t* list, u
 	} else overflow = true;
 }
 __global__ __launch_bounds__(64) void k7b_spec(K7bParams q) {
-#ifndef K7B_NOPRIO
 	__builtin_amdgcn_s_setprio(3); // a long dependent chain in few waves, beside front-end waves that fill every SIMD: issue first
-#endif
 	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64];
 	__shared__ uint32_t rowbits[(K7B_CH + K7B_WARM) / 32 * 64]; // the lanes' bit rows for this chunk (+ warm-up), word i of lane l at [64 i + l]
 	const K7Params& p = q.k;
@@ -3579,9 +3579,7 @@ hipError_t launch_k7e(const K7eParams& q, hipStream_t s) {
 }
 
 hipError_t launch_k5(const K5Params& p, int n_chan, hipStream_t s) {
-	hipLaunchKernelGGL(k5_carry, dim3(n_chan), dim3(64), 0, s, p);
-	hipLaunchKernelGGL(k5_fm, dim3(p.L / 256, n_chan), dim3(256), 0, s, p);
-	hipLaunchKernelGGL(k5_filter, dim3(p.L / 256, n_chan), dim3(256), 0, s, p);
+	hipLaunchKernelGGL(k5_fm_filter, dim3(p.L / 256, n_chan), dim3(256), 0, s, p);
 	return hipGetLastError();
 }
 
