@@ -598,8 +598,24 @@ int enqueue_fused_back(aisgpu_t* h) {
 	WAITEV(h->s4, h->ev_phasor[q]);
 	WAITEV(h->s4, h->ev_sym[pb]); // sym[pb] was last read by PhaseSearch of block f-2,
 	WAITEV(h->s4, h->ev_ema[lv]); // lvl[lv] by the frame decoder / the copies of block f-4
+	if (h->challenger) { k6.cgf = h->d_cgf + CGF_HIST; k6.cgf_stride = CGF_HIST + h->L; }
 	{ TraceScope t(h, "derotfir", h->s4); HIPCHK(launch_k6(k6, h->s4)); }
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s4));
+	if (h->challenger) { // FM branch on the derotated samples the kernel above stored on its way (Model.cpp:638-639)
+		K5Params k5;
+		k5.x = h->d_cgf; k5.x_stride = CGF_HIST + h->L; k5.x_off = CGF_HIST;
+		k5.prev_in = h->d_fmprev[pb]; k5.prev_out = h->d_fmprev[pb ^ 1]; // (the rows carry no history here: the sample before the block)
+		k5.fm = nullptr; k5.fm_stride = 0;
+		k5.hist_in = h->d_fmhist[pb]; k5.hist_out = h->d_fmhist[pb ^ 1];
+		k5.fmbits = h->d_fmbits[pb]; k5.fmbits_stride = h->L / 32; k5.L = h->L;
+		k5.fir_out = nullptr; k5.fir_stride = 0;
+		memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
+		HIPCHK(launch_k5(k5, h->n_chan, h->s4));
+		if (h->gpu_decode) { // device decoders: the FM bits regrouped per decoder, here, where this and the previous block's bits are in order
+			WAITEV(h->s4, h->ev_ema[lv ^ 2]); // fmrows[pb] was last read by the decoders of block f-2
+			HIPCHK(launch_k7_pack(make_k7(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub), h->s4));
+		}
+	}
 	HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4));
 	{ int rc = flush_decode(h); if (rc) return rc; } // (dec_defer) the previous block's frame decoders, behind this block's derotation / FIR kernel
 	WAITEV(h->s1, h->ev_k3[pb]);
@@ -1260,9 +1276,12 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	}
 	h->ps_box = (cfg->flags & AISGPU_FLAG_PS_BOXCAR) != 0;
 	if (h->ps_box) for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_box[i], (size_t)h->n_chains));
-	// default: the fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); the materialised path serves
-	// the taps and the FM branch, which need those arrays, and stays selectable (option "fused" = 0: test hook)
-	h->fused = !(cfg->flags & AISGPU_FLAG_TAPS) && !h->challenger && !h->base && !h->v2 && opt_int("fused", 1) != 0;
+	// default: the fused derotation + FIR path (no phasor array in HBM, and no derotated-sample array either -- except for
+	// ModelChallenger, whose FM branch demodulates those samples: there the fused kernel stores them on its way); the materialised
+	// path serves the taps, which need those arrays, and stays selectable (option "fused" = 0: test hook)
+	// (ModelChallenger on the resampled ladders keeps the materialised path: there the FFT / search kernels, the fused kernel and the
+	// FM receiver would queue on one stream -- 0.70 against 0.53 ms per step at 6 MSPS, BASELINE configs[2])
+	h->fused = !(cfg->flags & AISGPU_FLAG_TAPS) && !h->base && !h->v2 && !(h->challenger && mode != MODE_DIRECT && mode != MODE_PRE) && opt_int("fused", 1) != 0;
 	// The spectral analysis rides at the end of the front-end waves (k1_fft_tail) when every span is a whole number of 512-sample
 	// windows of the 48 kHz channels (16 tiles each) and whole spans make up the block; the automatic span length is rounded up
 	// to such a value, an explicit one (cfg.tiles_per_span) is taken as it is.  Option "fft_in_k1" = 0 (test hook): the FFT / search kernels.
@@ -1301,7 +1320,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(dalloc(&h->d_ema[i], C * 5));
 	}
 	HIPCHK(dalloc(&h->d_cgf, C * (CGF_HIST + h->L)));
-	if (h->base) for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmprev[i], C)); // Demod::FM::prev = 0 (Demod.h)
+	if (h->base || (h->challenger && h->fused)) for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmprev[i], C)); // Demod::FM::prev = 0 (Demod.h)
 	if (h->challenger || h->base) {
 		if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_fm, C * (FM_HIST + h->L))); // (the discriminator output is a tap only)
 		for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmhist[i], C * FM_HIST)); // zero: DSP::Filter starts on zeros

@@ -102,6 +102,7 @@ struct K6Params {
 	const float2* hist_in; float2* hist_out;     // [n_chan][DF_HIST]
 	float2* sym; long long sym_stride;           // SymRow layout, sym_stride = group capacity (also the row pitch of lvl)
 	float* lvl;                                   // [n_chan][sym_stride]
+	float2* cgf = nullptr; long long cgf_stride = 0; // optional: sample n of the derotated stream at cgf[chan * cgf_stride + n] (ModelChallenger's FM branch)
 	float taps[17];
 	long long first_group;
 	int n_rel0;                                   // first_group * 5 - first_sample48, in [-4, 0]

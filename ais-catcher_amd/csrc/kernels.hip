@@ -1248,7 +1248,9 @@ __device__ __forceinline__ c2 pk_sub_add(c2 a, c2 b) { // (a.x - b.x, a.y + b.y)
 #ifndef K6_WAVES
 #define K6_WAVES 2
 #endif
-template <int R0>
+// CGF: the derotated samples are stored as well (ModelChallenger: its FM branch demodulates them, Model.cpp:638-639) -- every sample
+// once, by the segment whose FIR outputs begin with it.
+template <int R0, bool CGF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6_WAVES))) void k3_derot_fir(K6Params p) {
 	const int lane = threadIdx.x, s = blockIdx.x;
 	const int chain_raw = blockIdx.y * 64 + lane;
@@ -1262,6 +1264,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6
 	// wave-uniform base pointers + a 32-bit per-lane element offset (SGPR base / VGPR offset addressing)
 	const unsigned xoff = (unsigned)chain * (unsigned)p.c48_stride, hoff = (unsigned)chain * DF_HIST;
 	const unsigned ckoff = (unsigned)(blockIdx.y * 64 + lane);
+	const unsigned cgoff = CGF ? (unsigned)chain * (unsigned)p.cgf_stride : 0u;
 	const float2* hin = p.hist_in + DF_HIST;              // hin[n][hoff], n in [-DF_HIST, 0)
 	float2* hout = p.hist_out - (p.L - DF_HIST);          // hout[n][hoff], n in [L - DF_HIST, L)
 	const int* fzrow = p.fz + (size_t)chain * p.n_windows;
@@ -1290,6 +1293,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6
 		}
 		const c2 y = derotate((p.c48 + nn)[xoff]);
 		if (last && nn >= p.L - DF_HIST && nn < p.L && live) (hout + nn)[hoff] = make_float2(y.x, y.y);
+		if (CGF && nn >= a && nn < e && live) (p.cgf + nn)[cgoff] = make_float2(y.x, y.y);
 		return y;
 	};
 	c2 y[20];
@@ -1341,7 +1345,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6
 			const float2* xb = p.c48 + n;
 #pragma unroll
 			for (int m = 0; m < 20; m++) d[m] = (xb + m)[xoff];
-			body([&](int m) { return derotate(d[m]); });
+			body([&](int m) {
+				const c2 v = derotate(d[m]);
+				if (CGF && n + m < e && live) (p.cgf + n + m)[cgoff] = make_float2(v.x, v.y);
+				return v;
+			});
 		} else {
 			body([&](int m) { return next_sample(n + m); });
 		}
@@ -3503,11 +3511,18 @@ hipError_t launch_k2b_ck(const K2Params& p, int n_chan, hipStream_t s) {
 
 hipError_t launch_k6(const K6Params& p, hipStream_t s) {
 	const dim3 grid(p.S, (p.n_chan + 63) / 64);
-	switch ((int)(p.first_group & 3)) {
-	case 0: hipLaunchKernelGGL(k3_derot_fir<0>, grid, dim3(64), 0, s, p); break;
-	case 1: hipLaunchKernelGGL(k3_derot_fir<1>, grid, dim3(64), 0, s, p); break;
-	case 2: hipLaunchKernelGGL(k3_derot_fir<2>, grid, dim3(64), 0, s, p); break;
-	default: hipLaunchKernelGGL(k3_derot_fir<3>, grid, dim3(64), 0, s, p); break;
+	const int r0 = (int)(p.first_group & 3);
+	if (p.cgf) switch (r0) {
+		case 0: hipLaunchKernelGGL((k3_derot_fir<0, true>), grid, dim3(64), 0, s, p); break;
+		case 1: hipLaunchKernelGGL((k3_derot_fir<1, true>), grid, dim3(64), 0, s, p); break;
+		case 2: hipLaunchKernelGGL((k3_derot_fir<2, true>), grid, dim3(64), 0, s, p); break;
+		default: hipLaunchKernelGGL((k3_derot_fir<3, true>), grid, dim3(64), 0, s, p); break;
+	}
+	else switch (r0) {
+		case 0: hipLaunchKernelGGL((k3_derot_fir<0, false>), grid, dim3(64), 0, s, p); break;
+		case 1: hipLaunchKernelGGL((k3_derot_fir<1, false>), grid, dim3(64), 0, s, p); break;
+		case 2: hipLaunchKernelGGL((k3_derot_fir<2, false>), grid, dim3(64), 0, s, p); break;
+		default: hipLaunchKernelGGL((k3_derot_fir<3, false>), grid, dim3(64), 0, s, p); break;
 	}
 	return hipGetLastError();
 }
