@@ -1408,7 +1408,7 @@ def test_pipelined_batch_hand_off(model):
 
 
 @pytest.mark.parametrize("mode", [None, "seq", "alt"])
-@pytest.mark.parametrize("case", ["busy", "quiet", "short_blocks", "long_frames", "batch"])
+@pytest.mark.parametrize("case", ["busy", "quiet", "short_blocks", "huge_blocks", "long_frames", "batch"])
 def test_model_base_chunk_parallel_sampler_and_decoder(case, mode, monkeypatch):
     """ModelBase with AISGPU_FLAG_GPU_DECODE: DSP::SimplePLL (whose loop gain follows the decoder's StartTraining / StopTraining,
     DSP.cpp:28-57, Model.cpp:428-435) and its decoder as the chunk-parallel kernels k7b_spec / k7b_task / k7b_walk / k7b_emit: speculative
@@ -1428,6 +1428,8 @@ def test_model_base_chunk_parallel_sampler_and_decoder(case, mode, monkeypatch):
         block, nblocks, kw = 786432, 3, dict(gap_slots=(6, 9))
     elif case == "short_blocks":  # 512 / 4096 samples at 48 kHz per block: a single (partial) chunk, then two chunks
         block, nblocks, kw = 16384, 48, dict(gap_slots=(0, 2))
+    elif case == "huge_blocks":   # 65,536 samples at 48 kHz per block: more chunks than the walk's notes hold -- the library falls back to k7_base alone
+        block, nblocks, kw = 2097152, 2, dict(gap_slots=(1, 3))
     elif case == "long_frames":
         block, nblocks, kw = 786432, 3, dict(gap_slots=(2, 5))
     else:
