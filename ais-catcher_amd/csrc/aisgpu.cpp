@@ -506,7 +506,12 @@ int launch_decoders_event(aisgpu_t* h, const K7Params& kq, K7Params kseq, hipStr
 	K7eParams q;
 	q.k = kq; q.ev = h->d_k7ev; q.cnt = h->d_k7cnt; q.open_c = h->d_k7open; q.slot = h->d_k7slot;
 	q.overflow = h->d_k7ovf + par; q.overflow_clear = h->d_k7ovf + (par ^ 1);
-	HIPCHK(launch_k7e(q, s));
+	HIPCHK(launch_k7e_runs(q, s));
+	// (The walk -- a few dozen latency-bound waves -- runs 5-8 times slower beside the front end than alone.  On the phasor recurrence's
+	// stream, whose CUs the back end does not use, the kernel itself took 0.08 instead of 0.22-0.30 ms, but it then sits behind the
+	// next block's recurrence and the decoders' stream waits for it: 0.65 against 0.54 ms per step.  A stream of its own is a fifth
+	// one: see aisgpu_create.)
+	HIPCHK(launch_k7e_resolve(q, s));
 	kseq.cond = q.overflow; kseq.cond_count = h->d_k7ovf + 2;
 	if (kseq.kind == 0) HIPCHK(launch_k7(kseq, s)); else HIPCHK(launch_k7_mesh(kseq, s));
 	return AISGPU_OK;

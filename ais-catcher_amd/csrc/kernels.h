@@ -273,7 +273,8 @@ struct K7eParams {
 	                     // k7e_resolve then leave everything as it is and the sequential kernel (K7Params::cond) decodes the block
 	int* overflow_clear; // the flag of the pass before (cleared by this pass's scan: everything that looked at it has run)
 };
-hipError_t launch_k7e(const K7eParams& p, hipStream_t s);
+hipError_t launch_k7e_runs(const K7eParams& p, hipStream_t s);
+hipError_t launch_k7e_resolve(const K7eParams& p, hipStream_t s);
 
 // fmt (kernel numbering): 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16, 4 = CU8 through the fixed-point ladder (K = 4)
 // ev_start / ev_stop: events bound to the dispatch itself (no barrier packets): time stamps, and "this launch is done" for other streams

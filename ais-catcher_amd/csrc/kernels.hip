@@ -3239,7 +3239,6 @@ __device__ __forceinline__ int grp_max(int v) { return -grp_min<GROUP>(-v); }
 template <int MESH, int GROUP>
 __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 	const K7Params& p = q.k;
-	if (*q.overflow != 0) return; // (uniform: nothing has been touched, the sequential kernel decodes this block from the same state)
 	__builtin_amdgcn_s_setprio(3); // a handful of latency-bound waves: they need their few issue slots at once
 	const int lane = threadIdx.x;
 	const int mesh = lane / GROUP, j = lane % GROUP; // j: the decoder's place in the order of a group (its phase, for the meshes of five)
@@ -3250,37 +3249,41 @@ __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 	const int n = p.n_groups;
 	constexpr int INF = 1 << 26;
 	DecState* st = p.state + d;
-	const int state0 = st->state, prev0 = st->prev, last0 = st->lastBit, pos0 = k7e_training_pos(st);
 	const uint32_t* evd = q.ev + (size_t)d * K7E_EVCAP;
 	const K7Slot* slots = q.slot + (size_t)d * K7E_OPENCAP;
-	const int nev = live ? (int)(q.cnt[d] & 0xFFFFu) : 0;
-	int ptr = 0, free_at = state0 == DST_TRAINING ? 5 - pos0 : 0, end_ = INF, slot_ = 0;
-	bool busy = false, fnd = false;
-	// A round of the walk is a few dozen instructions; an event fetched when it is needed would cost a memory round trip per
-	// event (and a second one for the (end, flags) of its run).  So every lane stages its next K7E_RW events and their run
-	// records in LDS with all loads in flight together, and the walk reads LDS.
+	// The kernel is a few waves that run beside the next block's front end, where a memory round trip is 10-30 us: what it costs is the
+	// NUMBER of dependent round trips (0.33 ms of them per block when every piece was fetched where it was needed).  So everything the
+	// walk can need first is asked for at once, before any of it is looked at: the overflow flag, the carried state, the lists'
+	// lengths, the first K7E_RW events, and the (end, flags) of the first K7E_RW runs -- run k of a decoder sits in slot k, so its
+	// head does not wait for the event that names it.
 	__shared__ uint32_t s_ev[K7E_RW][64];
-	__shared__ int2 s_ef[K7E_RW][64];
-	int win0 = 0;
-	const auto stage = [&](int from) {
+	__shared__ int2 s_ef[K7E_RW][64]; // (end, flags) of run sw0 + i
+	int win0 = 0, sw0 = 0, nev = 0;
+	const auto stage = [&](int from, int run0, bool first) {
 #pragma unroll
 		for (int h = 0; h < K7E_RW; h += 16) {
 			uint32_t e[16];
 			int2 f[16];
 #pragma unroll
-			for (int i = 0; i < 16; i++) e[i] = from + h + i < nev ? evd[from + h + i] : 0xFFFFFFFFu;
+			for (int i = 0; i < 16; i++) e[i] = (first || from + h + i < nev) ? evd[from + h + i < K7E_EVCAP ? from + h + i : K7E_EVCAP - 1] : 0xFFFFFFFFu;
 #pragma unroll
-			for (int i = 0; i < 16; i++) {
-				const bool run = e[i] != 0xFFFFFFFFu && ((e[i] >> 13) & 3u) == K7E_RUN;
-				f[i] = run ? *reinterpret_cast<const int2*>(slots + (e[i] >> 19)) : make_int2(0, 0); // (end, flags)
-			}
+			for (int i = 0; i < 16; i++) f[i] = *reinterpret_cast<const int2*>(slots + (run0 + h + i < K7E_OPENCAP ? run0 + h + i : K7E_OPENCAP - 1));
 #pragma unroll
 			for (int i = 0; i < 16; i++) { s_ev[h + i][lane] = e[i]; s_ef[h + i][lane] = f[i]; }
 		}
-		win0 = from;
+		win0 = from; sw0 = run0;
 	};
-	stage(0);
-	uint32_t head = s_ev[0][lane];
+	const int ovf = *q.overflow;
+	const int state0 = st->state, prev0 = st->prev, last0 = st->lastBit, position0 = st->position;
+	const uint32_t cnt0 = q.cnt[d];
+	stage(0, 0, true);
+	if (ovf != 0) return; // (uniform: nothing has been touched, the sequential kernel decodes this block from the same state)
+	const int pos0 = state0 == DST_TRAINING ? (position0 < 5 ? position0 : 5) : 0; // (k7e_training_pos)
+	nev = live ? (int)(cnt0 & 0xFFFFu) : 0;
+	int ptr = 0, free_at = state0 == DST_TRAINING ? 5 - pos0 : 0, end_ = INF, slot_ = 0, next_run = 0;
+	bool busy = false, fnd = false;
+	const auto ev_at = [&](int i) { return i < nev ? s_ev[i - win0][lane] : 0xFFFFFFFFu; }; // (the first window was fetched before nev was known)
+	uint32_t head = ev_at(0);
 	// A completed message is a record of 46 words behind an atomic counter: copied out inside the walk, every one of them would
 	// stall its whole wave for two memory round trips (the walk was 0.16 ms, nine tenths of it these).  The walk only notes
 	// (symbol, run) and the records leave together at the end: one atomic per lane, all loads in flight at once.  Their order
@@ -3317,17 +3320,18 @@ __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 				const uint32_t e = head;
 				ptr++;
 				const int c = (int)(e & 0x1FFFu), kind = (int)((e >> 13) & 3u), off = (int)((e >> 15) & 15u), sl = (int)(e >> 19);
+				if (kind == K7E_RUN) next_run = sl + 1;
 				if (c >= free_at) {
 					busy = true; slot_ = sl;
 					if (kind == K7E_FAIL) { end_ = c + off; fnd = false; }
 					else {
-						const int2 ef = s_ef[ptr - 1 - win0][lane]; // (end, flags) of run sl
+						const int2 ef = sl >= sw0 && sl < sw0 + K7E_RW ? s_ef[sl - sw0][lane] : *reinterpret_cast<const int2*>(slots + sl); // (end, flags) of run sl
 						fnd = (ef.y & 1) != 0;
 						end_ = (ef.y & 2) ? INF : ef.x;
 					}
 				}
-				if (ptr - win0 == K7E_RW) stage(ptr); // (only this lane's columns are touched)
-				head = s_ev[ptr - win0][lane];
+				if (ptr - win0 == K7E_RW && ptr < nev) stage(ptr, next_run, false); // (only this lane's columns are touched; the runs behind the last one seen)
+				head = ev_at(ptr);
 			} else {
 				const int e = end_;
 				busy = false;
@@ -3348,19 +3352,51 @@ __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 			else if (fa > free_at) free_at = fa;
 		}
 	}
+	// ---- the completed messages leave together: the wave's notes in one list, one lane per message (46 words, all loads in flight at
+	// once), one atomic for the wave -- and what the state for the next block needs is asked for in the same round trip
+	const uint32_t* brow = dc.row;
+	const int nw = (n + 31) >> 5;
+	const uint32_t wl = nw > 0 ? brow[nw - 1] : 0u, wp = nw > 1 ? brow[nw - 2] : 0u; // the last 33+ decisions
+	DecState carried;
+	if (live && busy) carried = slots[slot_].s; // the run that is still going: its state as k7e_sim left it
+	__shared__ uint32_t s_note[K7E_FOUND * 64][2];
+	{
+		int incl = nfound;
+		for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+		const int total = __shfl(incl, 63), first = incl - nfound;
+		for (int i = 0; i < nfound; i++) { s_note[first + i][0] = s_found[i][lane]; s_note[first + i][1] = (uint32_t)d; }
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // (one-wave workgroup: ordering only)
+		unsigned fs0 = 0;
+		for (int b0 = 0; b0 < total; b0 += 64) {
+			const bool has = b0 + lane < total;
+			const uint32_t v = has ? s_note[b0 + lane][0] : 0u;
+			const int dn = has ? (int)s_note[b0 + lane][1] : d;
+			const int e = (int)(v & 0xFFFFu);
+			const K7Slot* sl = q.slot + (size_t)dn * K7E_OPENCAP + (v >> 16);
+			uint32_t rec[4 + DEC_DATA_WORDS];
+			rec[0] = (uint32_t)sl->s.position; rec[1] = __float_as_uint(sl->s.level);
+			rec[2] = (uint32_t)(unsigned long long)sl->s.start_idx; rec[3] = (uint32_t)((unsigned long long)sl->s.start_idx >> 32);
+#pragma unroll
+			for (int w = 0; w < DEC_DATA_WORDS; w++) rec[4 + w] = sl->s.data[w];
+			if (b0 == 0) { if (lane == 0) fs0 = atomicAdd(p.frame_count, (unsigned)total); fs0 = __shfl(fs0, 0); }
+			if (has) {
+				uint32_t* f = p.frames + (size_t)((fs0 + (unsigned)(b0 + lane)) % (unsigned)p.max_frames) * DEC_FRAME_WORDS;
+				const long long sidx = 5 * (p.first_group + e) + k7e_decoder(p, dn).j;
+				f[0] = (uint32_t)dn; f[1] = (uint32_t)e; f[2] = rec[0]; f[3] = rec[1];
+				f[4] = rec[2]; f[5] = rec[3];
+				f[6] = (uint32_t)(unsigned long long)sidx; f[7] = (uint32_t)((unsigned long long)sidx >> 32);
+				f[8] = p.block; f[9] = p.sub;
+#pragma unroll
+				for (int w = 0; w < DEC_DATA_WORDS; w++) f[10 + w] = rec[4 + w];
+			}
+		}
+	}
 	if (!live) return;
-	emit(0, nfound);
 	// (ModelChallenger) tag.sample_lvl as the block leaves it for this channel's FM decoders of the next one
 	if (MESH == 10 && j == 0) p.last_lvl[dc.chan] = n > 0 ? p.lvl[(size_t)dc.chan * p.lvl_stride + n - 1] : p.last_lvl_in[dc.chan];
 	// state for the next block
-	if (busy) { // the run that is still going: its state as k7e_sim left it
-		*st = slots[slot_].s;
-		return;
-	}
+	if (busy) { *st = carried; return; }
 	// TRAINING: lastBit, prev and the alternations counted (those that end at the last symbol, none before the restart)
-	const uint32_t* brow = dc.row;
-	const int nw = (n + 31) >> 5;
-	const uint32_t wl = nw > 0 ? brow[nw - 1] : 0u, wp = nw > 1 ? brow[nw - 2] : 0u; // the last 33+ decisions, fetched once
 	const auto dd_at = [&](int g) -> int {
 		if (g < 0) return prev0;
 		return (int)(((g >> 5) == nw - 1 ? wl : wp) >> (g & 31)) & 1;
@@ -3583,11 +3619,16 @@ hipError_t launch_k7b_finish(const K7bParams& q, hipStream_t s) {
 	return hipGetLastError();
 }
 
-hipError_t launch_k7e(const K7eParams& q, hipStream_t s) {
+hipError_t launch_k7e_runs(const K7eParams& q, hipStream_t s) { // candidate scan + one run per possible frame: wide kernels
 	const int n_dec = q.k.n_chan * (q.k.kind == 2 ? 10 : 5);
 	if (q.k.n_groups <= 0) return hipSuccess;
 	hipLaunchKernelGGL(k7e_scan, dim3((n_dec + 3) / 4), dim3(64), 0, s, q);
 	hipLaunchKernelGGL(k7e_sim, dim3((n_dec * K7E_SIM_LANES + 63) / 64), dim3(64), 0, s, q);
+	return hipGetLastError();
+}
+
+hipError_t launch_k7e_resolve(const K7eParams& q, hipStream_t s) { // the walk: a few dozen latency-bound waves
+	if (q.k.n_groups <= 0) return hipSuccess;
 	if (q.k.kind == 2) hipLaunchKernelGGL((k7e_resolve<10, 16>), dim3((q.k.n_chan + 3) / 4), dim3(64), 0, s, q);
 	else hipLaunchKernelGGL((k7e_resolve<5, 8>), dim3((q.k.n_chan + 7) / 8), dim3(64), 0, s, q);
 	return hipGetLastError();
