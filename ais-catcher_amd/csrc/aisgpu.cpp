@@ -923,7 +923,7 @@ const char* aisgpu_last_error(aisgpu_t* h) { return h ? h->err.c_str() : ""; }
 
 int aisgpu_set_option(const char* key, const char* value) {
 	if (!key || !*key) return AISGPU_ERR_ARG;
-	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "fused", "fft_in_k1", "trace", "k7e_stats", "k7b_stats" };
+	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "trace", "k7e_stats", "k7b_stats" };
 	bool ok = false;
 	for (const char* k : known) ok = ok || strcmp(k, key) == 0;
 	if (!ok) return AISGPU_ERR_ARG;
@@ -1234,6 +1234,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 				K7bParams& b = h->k7b[i];
 				b.n_chunks = (h->L + K7B_CH - 1) / K7B_CH;
 				b.n_chan_pad = (int)((C + 63) / 64 * 64);
+				{ const int v = opt_int("k7b_fcap", 0); if (v >= 1 && v <= K7B_FCAP) b.fcap = v; } // test hook: small values force the exact fallback (k7_base)
 				const size_t slots = (size_t)b.n_chunks * b.n_chan_pad;
 				HIPCHK(dalloc(&b.ckpt, slots * (K7B_CH / 32)));
 				HIPCHK(dalloc(&b.end, slots));
@@ -1780,7 +1781,13 @@ int aisgpu_decoder_fallbacks(aisgpu_t* h, long long* count) {
 	DevGuard dg(h);
 	int v = 0;
 	if (h->d_k7ovf) HIPCHK(hipMemcpy(&v, h->d_k7ovf + 2, sizeof v, hipMemcpyDeviceToHost));
-	*count = v;
+	long long total = v;
+	if (h->base_chunked) // ModelBase: channel-blocks whose frame lists overflowed and went through k7_base (both scratch sets)
+		for (int i = 0; i < 2; i++) {
+			HIPCHK(hipMemcpy(&v, h->k7b[i].fallback_count, sizeof v, hipMemcpyDeviceToHost));
+			total += v;
+		}
+	*count = total;
 	return AISGPU_OK;
 }
 

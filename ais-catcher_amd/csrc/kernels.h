@@ -244,6 +244,7 @@ struct K7bParams {
 	int* fallback;        // [n_chan_pad] != 0: a frame list overflowed, k7_base decodes the channel's block
 	int* fallback_count;  // statistics
 	int n_chan_pad;
+	int fcap = K7B_FCAP;  // frames a list takes (<= K7B_FCAP; a smaller value is a test hook: it forces the fallback)
 };
 // k7b_spec needs the block's FM rows only (and scratch of its own: the caller alternates two sets), so it may run beside the previous
 // block's launch_k7b_finish(); that one (k7b_task, k7b_walk, k7b_emit, the conditional k7_base) is what carries the channels' state from

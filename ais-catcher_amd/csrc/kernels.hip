@@ -2664,8 +2664,8 @@ __device__ __forceinline__ void base_gain_word(float& pll_io, int& pprev, uint32
 	}
 }
 // (the list's length travels in a register: a counter in memory is a round trip per frame)
-__device__ __forceinline__ void base_record(BaseReg& b, int n, uint32_t* list, uint32_t& cnt, uint32_t* data, bool& overflow) {
-	if (cnt < (uint32_t)K7B_FCAP) {
+__device__ __forceinline__ void base_record(BaseReg& b, int n, uint32_t* list, uint32_t& cnt, uint32_t cap, uint32_t* data, bool& overflow) {
+	if (cnt < cap) {
 		uint32_t* f = list + 1 + cnt * K7B_FREC;
 		f[0] = (uint32_t)n; f[1] = (uint32_t)b.r.position;
 		for (int w = 0; w < DEC_DATA_WORDS; w++) f[2 + w] = data[64 * w];
@@ -2719,7 +2719,7 @@ __global__ __launch_bounds__(64) void k7b_spec(K7bParams q) {
 				i++;
 			}
 			if (emit && dec_step(b.r, bit, 0.0f, 0ll, data)) { // (tag.sample_lvl / sample_idx are never set in this engine)
-				if (nb >= n0 && live) base_record(b, nb + i - 1, list, n_rec, data, overflow); // (what the warm-up "completes" is not a frame)
+				if (nb >= n0 && live) base_record(b, nb + i - 1, list, n_rec, (uint32_t)q.fcap, data, overflow); // (what the warm-up "completes" is not a frame)
 				b.r.state = DST_TRAINING; b.r.position = 0; b.r.osc = 0;
 			}
 		}
@@ -2869,7 +2869,7 @@ __global__ __launch_bounds__(64) void k7b_task(K7bParams q) {
 				n++;
 			} while (!emit && (n & 31) != 0 && n < n_end);
 			if (emit && dec_step(b.r, bit, 0.0f, 0ll, data)) { // (tag.sample_lvl / sample_idx are never set in this engine)
-				base_record(b, n - 1, list, n_rec, data, overflow);
+				base_record(b, n - 1, list, n_rec, (uint32_t)q.fcap, data, overflow);
 				b.r.state = DST_TRAINING; b.r.position = 0; b.r.osc = 0;
 			}
 			if (b.r.state != DST_DATAFCS) finish = false;

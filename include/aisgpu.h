@@ -182,7 +182,9 @@ int aisgpu_ps_fallbacks(aisgpu_t* h, long long* count);
 /* AISGPU_FLAG_GPU_DECODE, event-driven decoder kernels (ModelDefault / ModelStandard / ModelChallenger): the number of blocks that went
  * through the sequential decoder kernel instead, because some decoder had more candidate frame starts in the block than the
  * kernels' lists hold (128 frames / 1024 candidates per decoder and block: a carrier that repeats preamble + start flag every
- * few dozen symbols).  The frames are the same either way; the sequential kernel is ~10x slower. */
+ * few dozen symbols).  The frames are the same either way; the sequential kernel is ~10x slower.
+ * ModelBase (chunk-parallel sampler + decoder kernels): the number of (channel, block) pairs that went through the sequential kernel
+ * because a chunk or a boundary task completed more than four frames. */
 int aisgpu_decoder_fallbacks(aisgpu_t* h, long long* count);
 int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* out);
 
@@ -208,6 +210,7 @@ void aisgpu_timing(aisgpu_t* h, int enable);
  *   "ps_warm"       warm-up length of the speculative PhaseSearchEMA chunks in symbols (small values force the exact fallback)
  *   "ps_sequential" 1: the sequential PhaseSearch row kernels only
  *   "k7"            "seq": symbol-by-symbol device decoders; "alt": event-driven and sequential kernels alternate block by block
+ *   "k7b_fcap"      1 .. 4: frames a list of ModelBase's chunk-parallel decoder kernels takes (small values force the exact fallback, k7_base)
  *   "fused"         0: the materialised back end (phasor / derotated-sample arrays in HBM: what AISGPU_FLAG_TAPS uses)
  *   "fft_in_k1"     0: the spectral analysis as FFT + search kernels instead of inside the front-end waves
  * Returns AISGPU_ERR_ARG for an unknown key. */

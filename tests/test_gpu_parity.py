@@ -1486,6 +1486,35 @@ def test_model_base_chunk_parallel_sampler_and_decoder(case, mode, monkeypatch):
         m.close()
 
 
+def test_model_base_frame_list_overflow_falls_back(monkeypatch):
+    """A chunk or a boundary task of the chunk-parallel ModelBase kernels that completes more frames than its list takes flags the
+    channel, and k7_base decodes that channel's block from the untouched carried state.  With the list capacity set to ONE frame
+    (test hook k7b_fcap) back-to-back bursts overflow the lists of boundary tasks in many blocks: the NMEA stays the reference's, the
+    fallback counter says that the path ran, and the channels that did not overflow went through the chunk-parallel kernels."""
+    from ais_catcher_amd import host
+    block, nblocks = 786432, 3
+    x = synth.receiver_stream(block * nblocks, receiver_id=431, gap_slots=(0, 0), type5_every=4)
+    chk = (checkers.Ref if checkers.have_ref() else checkers.Oracle)(model=1, rate=1536000, fmt="cf32")
+    chk.feed_blocks(x, block)
+    want = chk.nmea()
+    monkeypatch.setenv("AISGPU_K7B_FCAP", "1")
+    host.reset_sequence()
+    m = host.ModelBaseGPU(block_len=block, gpu_decode=True)
+    for b in range(nblocks):
+        assert m.receive(x[b * block:(b + 1) * block]) == 0
+    assert m.nmea() == want and len(want) >= 10
+    m.close()
+    gpu.apply_env_options()
+    g = gpu.AisGpu(sample_rate=1536000, n_receivers=1, block_len=block, model=gpu.MODEL_BASE, gpu_decode=True)
+    for b in range(nblocks):
+        g.submit(0, x[b * block:(b + 1) * block])
+        g.run()
+        g.sync_outputs()
+    n_fb = g.decoder_fallbacks()
+    g.close()
+    assert 1 <= n_fb <= 2 * nblocks, n_fb   # (channel, block) pairs that took the fallback: some, and at most all
+
+
 @pytest.mark.skipif(not checkers.have_refgpu(), reason="oracle/_ref/libaisrefgpu.so not built (needs /root/reference at build time)")
 @pytest.mark.parametrize("gpu_model,cpu_model,opts", [(12, 2, {}), (12, 2, {"gpu_decode": True}), (12, 2, {"pipelined": True}),
                                                       (12, 2, {"gpu_decode": True, "pipelined": True}), (14, 4, {}), (14, 4, {"gpu_decode": True}),
