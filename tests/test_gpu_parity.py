@@ -1486,6 +1486,63 @@ def test_model_base_chunk_parallel_sampler_and_decoder(case, mode, monkeypatch):
         m.close()
 
 
+def test_model_base_many_distinct_receivers_chunk_parallel_equals_sequential(monkeypatch):
+    """The chunk-parallel ModelBase kernels on a batch whose lanes all do something different: 40 receivers with their own burst
+    schedules, gaps, truncated bursts and noise (80 channels: one full wave of the speculative pass and a partial one, ten task
+    waves per boundary), four blocks.  Every frame of every receiver -- channel, sample, length, bits -- must be the one the
+    sequential kernel (k7 = seq: one lane per channel, symbol by symbol) produces from the same state sequence, and the NMEA of four
+    of the receivers the reference's."""
+    from ais_catcher_amd import host
+    block, nblocks, R = 393216, 4, 40
+    rng = np.random.default_rng(2024)
+    xs = []
+    for r in range(R):
+        x = synth.receiver_stream(block * nblocks, receiver_id=900 + r, gap_slots=(int(rng.integers(0, 3)), int(rng.integers(3, 7))), type5_every=int(rng.integers(0, 5)))
+        for _ in range(int(rng.integers(0, 4))):   # a few bursts lose their tail (no closing flag: long stays in DATAFCS)
+            at = int(rng.integers(0, len(x) - 60000))
+            x[at:at + int(rng.integers(2000, 40000))] *= np.float32(0.02)
+        xs.append(x)
+
+    def run():
+        gpu.apply_env_options()
+        g = gpu.AisGpu(sample_rate=1536000, n_receivers=R, block_len=block, model=gpu.MODEL_BASE, gpu_decode=True)
+        out = []
+        for b in range(nblocks):
+            for r in range(R):
+                g.submit(r, xs[r][b * block:(b + 1) * block])
+            g.run()
+            g.sync_outputs()
+            out.append(sorted((f["rx"], f["ch"], f["group"], f["position"], used_bits(f)) for f in g.frames()))
+        nfb = g.decoder_fallbacks()
+        g.close()
+        return out, nfb
+
+    def used_bits(f):  # the frame's first `position` bits (what the buffer holds behind them is never read, Marine/AIS.h:150-163)
+        n = f["position"]
+        d = bytearray(f["data"][:(n + 7) // 8])
+        if n % 8:
+            d[-1] &= (1 << (n % 8)) - 1
+        return bytes(d)
+
+    got, nfb = run()
+    monkeypatch.setenv("AISGPU_K7", "seq")
+    want, _ = run()
+    monkeypatch.delenv("AISGPU_K7")
+    for b in range(nblocks):
+        assert got[b] == want[b], "block %d: %d / %d frames, first difference %s" % (
+            b, len(got[b]), len(want[b]), next(((x[:4], y[:4]) for x, y in zip(got[b], want[b]) if x != y), None))
+    assert sum(len(b) for b in want) >= 8 * R and nfb == 0
+    for r in (0, 13, 27, 39):
+        chk = (checkers.Ref if checkers.have_ref() else checkers.Oracle)(model=1, rate=1536000, fmt="cf32")
+        chk.feed_blocks(xs[r], block)
+        host.reset_sequence()
+        m = host.ModelBaseGPU(block_len=block, gpu_decode=True)
+        for b in range(nblocks):
+            assert m.receive(xs[r][b * block:(b + 1) * block]) == 0
+        assert m.nmea() == chk.nmea(), "rx %d" % r
+        m.close()
+
+
 def test_model_base_frame_list_overflow_falls_back(monkeypatch):
     """A chunk or a boundary task of the chunk-parallel ModelBase kernels that completes more frames than its list takes flags the
     channel, and k7_base decodes that channel's block from the untouched carried state.  With the list capacity set to ONE frame
