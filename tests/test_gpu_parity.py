@@ -1486,6 +1486,48 @@ def test_model_base_chunk_parallel_sampler_and_decoder(case, mode, monkeypatch):
         m.close()
 
 
+@pytest.mark.parametrize("model", ["default", "standard", "challenger"])
+def test_event_driven_decoders_on_many_distinct_receivers_equal_sequential(model, monkeypatch):
+    """The event-driven decoder kernels (candidate scan, one run per possible frame, the walk; the walk copies a wave's completed
+    messages out one lane per message) on a batch whose decoders all do something different: 24 receivers with their own burst
+    schedules and noise, three blocks.  Every frame -- decoder, group, length, bits, level sum, start / end index -- must be the
+    one the sequential kernels (k7 = seq) produce."""
+    block, nblocks, R = 393216, 3, 24
+    mdl = {"default": gpu.MODEL_DEFAULT, "standard": gpu.MODEL_STANDARD, "challenger": gpu.MODEL_CHALLENGER}[model]
+    rng = np.random.default_rng(77)
+    xs = [synth.receiver_stream(block * nblocks, receiver_id=700 + r, gap_slots=(int(rng.integers(0, 3)), int(rng.integers(3, 6))),
+                                type5_every=int(rng.integers(0, 5))) for r in range(R)]
+
+    def used_bits(f):
+        n = f["position"]
+        d = bytearray(f["data"][:(n + 7) // 8])
+        if n % 8:
+            d[-1] &= (1 << (n % 8)) - 1
+        return bytes(d)
+
+    def run():
+        gpu.apply_env_options()
+        g = gpu.AisGpu(sample_rate=1536000, n_receivers=R, block_len=block, model=mdl, gpu_decode=True)
+        out = []
+        for b in range(nblocks):
+            for r in range(R):
+                g.submit(r, xs[r][b * block:(b + 1) * block])
+            g.run()
+            g.sync_outputs()
+            out.append(sorted((f["rx"], f["ch"], f["phase"], f["group"], f["position"], f["level_sum"], f["start_idx"], f["end_idx"], used_bits(f)) for f in g.frames()))
+        nfb = g.decoder_fallbacks()
+        g.close()
+        return out, nfb
+
+    got, nfb = run()
+    monkeypatch.setenv("AISGPU_K7", "seq")
+    want, _ = run()
+    monkeypatch.delenv("AISGPU_K7")
+    for b in range(nblocks):
+        assert got[b] == want[b], "block %d: %d / %d frames" % (b, len(got[b]), len(want[b]))
+    assert sum(len(b) for b in want) >= 5 * R and nfb == 0
+
+
 def test_model_base_many_distinct_receivers_chunk_parallel_equals_sequential(monkeypatch):
     """The chunk-parallel ModelBase kernels on a batch whose lanes all do something different: 40 receivers with their own burst
     schedules, gaps, truncated bursts and noise (80 channels: one full wave of the speculative pass and a partial one, ten task
