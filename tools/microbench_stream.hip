@@ -35,6 +35,31 @@ __global__ __launch_bounds__(NT) void spanwalk(const float4* __restrict__ in, fl
 	if (acc == 12345.678f) out[0] = acc;
 }
 
+// (c) the front end's own pattern: one-wave workgroups, an 8 KB tile per step fetched straight into LDS (global_load_lds, 16 B per
+// lane), read back from LDS, and WR 16-byte stores per lane and tile (the 48 kHz output is 1/16 of the input: WR = 1 every second tile)
+template <int WR>
+__global__ __launch_bounds__(64) void ldsdma_walk(const float4* __restrict__ in, float4* __restrict__ wout, float* out, int tiles_per_span, size_t span_stride4) {
+	__shared__ float4 tile[512];
+	const float4* src = in + (size_t)blockIdx.x * span_stride4;
+	float4* dst = wout + (size_t)blockIdx.x * (span_stride4 / 16);
+	const int lane = threadIdx.x;
+	float acc = 0;
+	for (int e = 0; e < 8; e++)
+		__builtin_amdgcn_global_load_lds((const void*)(src + e * 64 + lane), (__attribute__((address_space(3))) void*)(tile + e * 64), 16, 0, 2);
+	for (int t = 0; t < tiles_per_span; t++) {
+		__builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
+		float4 cur[8];
+		for (int e = 0; e < 8; e++) cur[e] = tile[e * 64 + lane];
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+		const int tn = t + 1 < tiles_per_span ? t + 1 : t;
+		for (int e = 0; e < 8; e++)
+			__builtin_amdgcn_global_load_lds((const void*)(src + (size_t)tn * 512 + e * 64 + lane), (__attribute__((address_space(3))) void*)(tile + e * 64), 16, 0, 2);
+		for (int e = 0; e < 8; e++) acc += cur[e].x + cur[e].y + cur[e].z + cur[e].w;
+		if (WR && (t & 1)) dst[(size_t)(t >> 1) * 64 + lane] = make_float4(acc, cur[1].x, cur[2].y, cur[3].z);
+	}
+	if (acc == 12345.678f) out[0] = acc;
+}
+
 template <typename F>
 static void timeit(const char* name, F launch, double bytes) {
 	hipEvent_t a, b;
@@ -78,6 +103,12 @@ int main() {
 		auto k2 = spanwalk<64, 8, 0>;
 		timeit("spanwalk 8192 WG x64, 8KB tile, no LDS", [&] { hipLaunchKernelGGL(k2, dim3(8192), dim3(64), 0, 0, d, o, 24, (size_t)24 * 512); }, (double)bytes);
 		timeit("spanwalk 32768 WG x64, 8KB tile, no LDS", [&] { hipLaunchKernelGGL(k2, dim3(32768), dim3(64), 0, 0, d, o, 6, (size_t)6 * 512); }, (double)bytes);
+	}
+	{
+		float4* w; hipMalloc(&w, bytes / 16 + (1 << 20));
+		timeit("LDS-DMA walk 8192 WG x64, 8KB tile, read only", [&] { hipLaunchKernelGGL(ldsdma_walk<0>, dim3(8192), dim3(64), 0, 0, d, w, o, 24, (size_t)24 * 512); }, (double)bytes);
+		timeit("LDS-DMA walk 8192 WG x64, 8KB tile, + 1/16 written", [&] { hipLaunchKernelGGL(ldsdma_walk<1>, dim3(8192), dim3(64), 0, 0, d, w, o, 24, (size_t)24 * 512); }, (double)bytes * (1.0 + 1.0 / 16));
+		timeit("LDS-DMA walk 6144 WG x64 (32 tiles), + 1/16 written", [&] { hipLaunchKernelGGL(ldsdma_walk<1>, dim3(6144), dim3(64), 0, 0, d, w, o, 32, (size_t)32 * 512); }, (double)bytes * (1.0 + 1.0 / 16));
 	}
 	return 0;
 }
