@@ -41,7 +41,7 @@ template <int WR>
 __global__ __launch_bounds__(64) void ldsdma_walk(const float4* __restrict__ in, float4* __restrict__ wout, float* out, int tiles_per_span, size_t span_stride4) {
 	__shared__ float4 tile[512];
 	const float4* src = in + (size_t)blockIdx.x * span_stride4;
-	float4* dst = wout + (size_t)blockIdx.x * (span_stride4 / 16);
+	float4* dst = wout + (size_t)blockIdx.x * (span_stride4 / (WR == 5 ? 8 : 16));
 	const int lane = threadIdx.x;
 	float acc = 0;
 	for (int e = 0; e < 8; e++)
@@ -55,9 +55,25 @@ __global__ __launch_bounds__(64) void ldsdma_walk(const float4* __restrict__ in,
 		for (int e = 0; e < 8; e++)
 			__builtin_amdgcn_global_load_lds((const void*)(src + (size_t)tn * 512 + e * 64 + lane), (__attribute__((address_space(3))) void*)(tile + e * 64), 16, 0, 2);
 		for (int e = 0; e < 8; e++) acc += cur[e].x + cur[e].y + cur[e].z + cur[e].w;
-		if (WR && (t & 1)) dst[(size_t)(t >> 1) * 64 + lane] = make_float4(acc, cur[1].x, cur[2].y, cur[3].z);
+		const float4 v = make_float4(acc, cur[1].x, cur[2].y, cur[3].z);
+		if (WR == 1 && (t & 1)) dst[(size_t)(t >> 1) * 64 + lane] = v;                              // 1 KB per wave every second tile
+		if (WR == 2 && (t & 1)) { typedef float v4f __attribute__((ext_vector_type(4))); v4f nv = { v.x, v.y, v.z, v.w }; __builtin_nontemporal_store(nv, reinterpret_cast<v4f*>(dst + (size_t)(t >> 1) * 64 + lane)); } // the same, non-temporal
+		if (WR == 3 && (t & 7) == 7) {                                                              // 4 KB per wave every eighth tile
+			for (int e = 0; e < 4; e++) dst[(size_t)(t >> 3) * 256 + e * 64 + lane] = v;
+		}
+		if (WR == 5) dst[(size_t)t * 64 + lane] = v;                                                // 1 KB per wave every tile: 1/8 written
+		if (WR == 4 && (t & 1)) { // 16 B per lane, but lanes 1 KB apart (64 B per line touched: partial lines)
+			dst[(size_t)lane * 64 + (t >> 1)] = v;
+		}
 	}
 	if (acc == 12345.678f) out[0] = acc;
+}
+
+// (d) writes alone: every wave stores NT x 1 KB, contiguous per workgroup
+__global__ __launch_bounds__(64) void write_only(float4* __restrict__ w, int per_wg) {
+	float4* dst = w + (size_t)blockIdx.x * per_wg * 64;
+	const float4 v = make_float4(1.f, 2.f, 3.f, (float)blockIdx.x);
+	for (int t = 0; t < per_wg; t++) dst[(size_t)t * 64 + threadIdx.x] = v;
 }
 
 template <typename F>
@@ -109,6 +125,15 @@ int main() {
 		timeit("LDS-DMA walk 8192 WG x64, 8KB tile, read only", [&] { hipLaunchKernelGGL(ldsdma_walk<0>, dim3(8192), dim3(64), 0, 0, d, w, o, 24, (size_t)24 * 512); }, (double)bytes);
 		timeit("LDS-DMA walk 8192 WG x64, 8KB tile, + 1/16 written", [&] { hipLaunchKernelGGL(ldsdma_walk<1>, dim3(8192), dim3(64), 0, 0, d, w, o, 24, (size_t)24 * 512); }, (double)bytes * (1.0 + 1.0 / 16));
 		timeit("LDS-DMA walk 6144 WG x64 (32 tiles), + 1/16 written", [&] { hipLaunchKernelGGL(ldsdma_walk<1>, dim3(6144), dim3(64), 0, 0, d, w, o, 32, (size_t)32 * 512); }, (double)bytes * (1.0 + 1.0 / 16));
+		{
+			float4* w2; hipMalloc(&w2, bytes / 8 + (1 << 20));
+			timeit("  ... 1/8 written (1 KB per wave every tile)", [&] { hipLaunchKernelGGL(ldsdma_walk<5>, dim3(8192), dim3(64), 0, 0, d, w2, o, 24, (size_t)24 * 512); }, (double)bytes * (1.0 + 1.0 / 8));
+			timeit("writes alone, 0.2 GB (8192 WG x 24 KB)", [&] { hipLaunchKernelGGL(write_only, dim3(8192), dim3(64), 0, 0, w2, 24); }, (double)8192 * 24 * 1024);
+			timeit("writes alone, 1.61 GB (8192 WG x 192 KB)", [&] { hipLaunchKernelGGL(write_only, dim3(8192), dim3(64), 0, 0, d, 192); }, (double)8192 * 192 * 1024);
+		}
+		timeit("  ... non-temporal stores", [&] { hipLaunchKernelGGL(ldsdma_walk<2>, dim3(8192), dim3(64), 0, 0, d, w, o, 24, (size_t)24 * 512); }, (double)bytes * (1.0 + 1.0 / 16));
+		timeit("  ... 4 KB per wave every eighth tile", [&] { hipLaunchKernelGGL(ldsdma_walk<3>, dim3(8192), dim3(64), 0, 0, d, w, o, 24, (size_t)24 * 512); }, (double)bytes * (1.0 + 1.0 / 16));
+		timeit("  ... 16 B per lane, lanes 1 KB apart", [&] { hipLaunchKernelGGL(ldsdma_walk<4>, dim3(8192), dim3(64), 0, 0, d, w, o, 24, (size_t)24 * 512); }, (double)bytes * (1.0 + 1.0 / 16));
 	}
 	return 0;
 }
