@@ -175,13 +175,6 @@ struct aisgpu {
 	float* d_fmfir = nullptr; // [n_chan][L] Filter(Receiver) output of the last downstream block (AISGPU_FLAG_TAPS)
 	EmaState* d_ema[2] = {}; // state before / after the current downstream block (swapped per block)
 	uint32_t* d_pswords = nullptr; float *d_psma0 = nullptr, *d_psma1 = nullptr; unsigned* d_psfin = nullptr; int* d_psflag = nullptr;
-	uint32_t* d_psmasks[4] = {}; long long mask_stride = 0; // PhaseSearchEMA tables (kernels.h: PS_MASK_DWORDS per chain and 32 symbols), ring by block & 3 like bits / lvl: a block's walk may be up to three blocks behind its tables
-	// The walk over a block's tables (k4_walk) is not enqueued with them: it rides along with the phasor recurrence of the block
-	// after next (its reserved CUs, its stream) -- or, where the caller wants results / the schedule is serial, runs as a kernel of
-	// its own.  What follows the walk (frame decoders, copies, "bits / lvl of this block are free again") is enqueued behind it.
-	struct WalkPend { K4Params k4; int pb, lv; long long g0; int n_groups; unsigned block, sub; hipStream_t s; };
-	WalkPend wq[4]; int wq_n = 0;
-	hipEvent_t ev_tab[4] = {}, ev_walked[4] = {}; // by block & 3: tables complete (PhaseSearch stream) / walked (s3)
 	int ps_warm = 256; bool ps_parallel = true;
 	struct { bool valid = false; int pb = 0, lv = 0, n_groups = 0; long long g0 = 0; unsigned block = 0, sub = 0; } dpend; // frame decoders not yet enqueued (dec_defer)
 	bool dec_defer = false; // the frame decoders of block f are enqueued behind the derotation / FIR kernel of block f+1 (they share its stream)
@@ -468,35 +461,6 @@ int finish_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned 
 	return AISGPU_OK;
 }
 
-// what follows the walk of a block's tables: it was enqueued on s3 (riding with a phasor recurrence, or as a kernel of its own)
-int finish_walk(aisgpu_t* h, const aisgpu::WalkPend& w) {
-	HIPCHK(hipEventRecord(h->ev_walked[w.block & 3], h->s3));
-	WAITEV(w.s, h->ev_walked[w.block & 3]);
-	return finish_k4(h, w.pb, w.lv, w.g0, w.n_groups, w.block, w.sub, w.s);
-}
-// the oldest pending walk, if the phasor recurrence about to be launched on s3 may take it along: only a block whose tables are
-// surely complete by then (two blocks back) -- the recurrence must never wait for the PhaseSearch stream
-bool take_walk(aisgpu_t* h, aisgpu::WalkPend* w) {
-	if (h->wq_n < 2) return false;
-	*w = h->wq[0];
-	for (int i = 1; i < h->wq_n; i++) h->wq[i - 1] = h->wq[i];
-	h->wq_n--;
-	return true;
-}
-// every pending walk as a kernel of its own, oldest first (the caller wants results; serial schedule)
-int flush_walks(aisgpu_t* h) {
-	while (h->wq_n > 0) {
-		const aisgpu::WalkPend w = h->wq[0];
-		for (int i = 1; i < h->wq_n; i++) h->wq[i - 1] = h->wq[i];
-		h->wq_n--;
-		WAITEV(h->s3, h->ev_tab[w.block & 3]);
-		{ TraceScope t(h, "walk", h->s3); HIPCHK(launch_k4_walk(w.k4, h->s3)); }
-		int rc = finish_walk(h, w);
-		if (rc) return rc;
-	}
-	return AISGPU_OK;
-}
-
 // PhaseSearchEMA / PhaseSearch of one downstream block (sym/lvl parity pb) on stream s
 int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s) {
 	// bits[lv] was last read by the frame decoder / the copies of block f-4: long done, and ordered here.  (A ring of two made
@@ -509,22 +473,10 @@ int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned
 	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag + pb; k4.fb_count = h->d_psflag + 2;
 	k4.n_chains = h->n_chains; k4.n_groups = n_groups;
 	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
-	k4.masks = h->d_psmasks[lv]; k4.mask_stride = h->mask_stride;
 	k4.box_in = h->d_box[pb]; k4.box_out = h->d_box[pb ^ 1]; k4.first_group = g0;
 	if (h->d_qflag4) { k4.qflag = h->d_qflag4 + (size_t)pb * ((h->n_chains + 3) / 4); k4.qflag_div = 4; } // per-workgroup fallback flags
-	if (!h->ps_box && h->ps_parallel && k4.n_chunks > 1 && n_groups > 0) {
-		// tables + verification here; the walk -- and with it everything that needs the bits -- later (WalkPend)
-		if (h->wq_n == 4) { int rc = flush_walks(h); if (rc) return rc; }
-		HIPCHK(launch_k4(k4, s));
-		HIPCHK(hipEventRecord(h->ev_sym[pb], s));
-		HIPCHK(hipEventRecord(h->ev_tab[block & 3], s));
-		aisgpu::WalkPend& w = h->wq[h->wq_n++];
-		w.k4 = k4; w.pb = pb; w.lv = lv; w.g0 = g0; w.n_groups = n_groups; w.block = block; w.sub = sub; w.s = s;
-		if (h->serial || h->s3 == s) return flush_walks(h);
-		return AISGPU_OK;
-	}
-	{ int rc = flush_walks(h); if (rc) return rc; } // (a block that takes the sequential kernels reads max_idx: every earlier walk first)
 	if (h->ps_box) { k4.chunked = h->ps_parallel ? 1 : 0; HIPCHK(launch_k4_box(k4, s)); }
+	else if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, s));
 	else HIPCHK(launch_k4_sequential(k4, s));
 	HIPCHK(hipEventRecord(h->ev_sym[pb], s));
 	return finish_k4(h, pb, lv, g0, n_groups, block, sub, s);
@@ -695,14 +647,8 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	}
 	WAITEV(h->s3, h->k1_done[q] ? h->k1_done[q] : h->ev_search[q]);
 	WAITEV(h->s3, h->ev_c48free[q]); // ck[q] was last read by K6 of block f-NBUF
-	{
-		aisgpu::WalkPend w;
-		const bool ride = take_walk(h, &w);
-		if (ride) WAITEV(h->s3, h->ev_tab[w.block & 3]);
-		{ TraceScope t(h, "phasor", h->s3); HIPCHK(launch_k2b_ck(k2, h->n_chan, h->s3, ride ? &w.k4 : nullptr)); }
-		HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
-		if (ride) { int rc = finish_walk(h, w); if (rc) return rc; }
-	}
+	{ TraceScope t(h, "phasor", h->s3); HIPCHK(launch_k2b_ck(k2, h->n_chan, h->s3)); }
+	HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
 
 	h->fpend.valid = true; h->fpend.q = q; h->fpend.pb = pb; h->fpend.lv = lv; h->fpend.g0 = g0; h->fpend.n_groups = n_groups;
 	h->fpend.n_rel0 = n_rel0; h->fpend.S = S; h->fpend.block = (unsigned)h->block_idx; h->fpend.sub = (unsigned)h->n_sub;
@@ -836,14 +782,8 @@ int enqueue_downstream(aisgpu_t* h, int q, int pb) {
 	{ int rc = flush_decode(h); if (rc) return rc; } // (dec_defer) the frame decoders of the block before the previous one, behind this block's searches
 	WAITEV(h->s3, h->ev_search[q]);
 	WAITEV(h->s3, h->ev_c48free[q]);
-	{
-		aisgpu::WalkPend w;
-		const bool ride = take_walk(h, &w);
-		if (ride) WAITEV(h->s3, h->ev_tab[w.block & 3]);
-		HIPCHK(launch_k2b(k2, h->n_chan, h->s3, ride ? &w.k4 : nullptr));
-		HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
-		if (ride) { int rc = finish_walk(h, w); if (rc) return rc; }
-	}
+	HIPCHK(launch_k2b(k2, h->n_chan, h->s3));
+	HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
 
 	int rc = enqueue_back(h); // the previous block's second half
 	if (rc) return rc;
@@ -953,7 +893,6 @@ int gather_frames(aisgpu_t* h) {
 int sync_all(aisgpu_t* h) {
 	{ int rc = enqueue_back(h); if (rc) return rc; }
 	{ int rc = enqueue_fused_back(h); if (rc) return rc; }
-	{ int rc = flush_walks(h); if (rc) return rc; }
 	{ int rc = flush_decode(h); if (rc) return rc; }
 	HIPCHK(hipStreamSynchronize(h->stream));
 	HIPCHK(hipStreamSynchronize(h->s1));
@@ -1218,7 +1157,6 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(hipEventCreateWithFlags(&h->ev_c48free[i], hipEventDisableTiming));
 	}
 	for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_ema[i], hipEventDisableTiming));
-	for (int i = 0; i < 4; i++) { HIPCHK(hipEventCreateWithFlags(&h->ev_tab[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_walked[i], hipEventDisableTiming)); }
 	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_sym[i], hipEventDisableTiming));
 	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_k3[i], hipEventDisableTiming));
 	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_k4[i], hipEventDisableTiming));
@@ -1408,11 +1346,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	{ const int v = opt_int("ps_warm", 0); if (v >= 1 && v <= PS_CHUNK) h->ps_warm = (v + 15) / 16 * 16; } // test hook: small values force the exact fallback
 	if (opt_int("ps_sequential", 0)) h->ps_parallel = false; // test hook: the plain sequential row kernel
 	const size_t n_ma = C * 5 * ps_chunks * 16;
-	if (h->ps_box) HIPCHK(dalloc(&h->d_pswords, C * 5 * ps_chunks * (PS_CHUNK / 32) * 16));
-	else {
-		h->mask_stride = (long long)(h->Gcap / 32) * PS_MASK_DWORDS;
-		for (int i = 0; i < 4; i++) HIPCHK(dalloc(&h->d_psmasks[i], C * 5 * (size_t)h->mask_stride));
-	}
+	HIPCHK(dalloc(&h->d_pswords, C * 5 * ps_chunks * (PS_CHUNK / 32) * 16));
 	HIPCHK(dalloc(&h->d_psma0, n_ma));
 	HIPCHK(dalloc(&h->d_psma1, n_ma));
 	HIPCHK(dalloc(&h->d_psfin, C * 5 * ps_chunks * 16));
@@ -1462,7 +1396,6 @@ void aisgpu_destroy(aisgpu_t* h) {
 		if (h->ev_c48free[i]) hipEventDestroy(h->ev_c48free[i]);
 		hipFree(h->d_rotT[i]); hipFree(h->d_c48[i]); hipFree(h->d_fz[i]); hipFree(h->d_ppm[i]);
 	}
-	for (int i = 0; i < 4; i++) { if (h->ev_tab[i]) hipEventDestroy(h->ev_tab[i]); if (h->ev_walked[i]) hipEventDestroy(h->ev_walked[i]); }
 	for (int i = 0; i < 4; i++) { if (h->ev_ema[i]) hipEventDestroy(h->ev_ema[i]); hipFree(h->d_lvl[i]); hipFree(h->d_bits[i]);
 		hipFree(h->d_rot[i]); if (h->h_rot[i]) hipHostFree(h->h_rot[i]); if (h->rot_ev[i]) hipEventDestroy(h->rot_ev[i]); }
 	for (int i = 0; i < 2; i++) {
@@ -1497,7 +1430,6 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_fmprev[0]); hipFree(h->d_fmprev[1]);
 	hipFree(h->d_cgf); hipFree(h->d_omega); hipFree(h->d_step);
 	hipFree(h->d_rotstate); hipFree(h->d_firtap); hipFree(h->d_ppmtab);
-	for (int i = 0; i < 4; i++) hipFree(h->d_psmasks[i]);
 	hipFree(h->d_pswords); hipFree(h->d_psma0); hipFree(h->d_psma1); hipFree(h->d_psfin); hipFree(h->d_psflag);
 	for (int i = 0; i < 2; i++) { if (h->h_in[i]) hipHostFree(h->h_in[i]); if (h->ev_h2d[i]) hipEventDestroy(h->ev_h2d[i]); if (h->ev_in_free[i]) hipEventDestroy(h->ev_in_free[i]); }
 	if (h->sc) { hipStreamSynchronize(h->sc); hipStreamDestroy(h->sc); }
@@ -1823,7 +1755,6 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 	const size_t C = h->n_chan;
 	{ int rc = enqueue_back(h); if (rc) return rc; }
 	{ int rc = enqueue_fused_back(h); if (rc) return rc; }
-	{ int rc = flush_walks(h); if (rc) return rc; }
 	{ int rc = flush_decode(h); if (rc) return rc; }
 	for (int s = 0; s < h->n_sub; s++) {
 		const SubOut& so = h->sub[s];

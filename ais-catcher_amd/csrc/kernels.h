@@ -152,13 +152,6 @@ struct PsBoxState { float mem[12][16]; unsigned bits[16]; int max_idx; int pad[3
 #endif
 constexpr int PS_CHUNK = PS_CHUNK_;   // symbols per time chunk of the chunk-parallel PhaseSearchEMA (multiple of 32)
 constexpr int PS_MAXCHUNKS = 16;
-// PhaseSearchEMA as two passes (round 4).  The chunk kernel keeps only what needs the float pipeline -- the 16 EMAs, the 16 decisions,
-// and per hypothesis the two comparisons that say where max_idx would move FROM there -- and leaves them as three bit tables per
-// symbol: UP (move to idx + 1), DN (move to idx - 1), X (the emitted bit if max_idx ends up here).  The walk itself -- one integer
-// trajectory per chain from the TRUE max_idx, six instructions per symbol -- is k4_walk: one lane per chain, off the critical stream.
-// Layout per (chain, group of 32 symbols): [table 3][word 16]; word k of a table holds hypothesis h of symbol 31 - k at bit h and
-// of symbol 15 - k at bit 16 + h (what a 16-lane transposition of the lanes' newest-at-bit-0 history words produces).
-constexpr int PS_MASK_DWORDS = 48;
 
 struct K4Params {
 	const float2* sym; long long sym_stride; // chain c row = c * sym_stride
@@ -166,12 +159,10 @@ struct K4Params {
 	const EmaState* state_in;                // state before this block
 	EmaState* state_out;                     // state after this block
 	// chunk-parallel scratch, all indexed [chain][chunk][...]
-	uint32_t* words;   // (boxcar variant) [PS_CHUNK/32][16] output words per possible start index
+	uint32_t* words;   // [PS_CHUNK/32][16] output words per possible start index
 	float* ma_start;   // [16] EMA after the warm-up (speculative), chunk > 0
 	float* ma_fin;     // [16] EMA at the end of the chunk
-	unsigned* fin;     // [16] EMA variant: the last four decisions of hypothesis k; boxcar variant: low 4 bits final max_idx per start index, bits 4..7 the decisions
-	// EMA variant: what the walk needs, per (chain, 32 symbols): three 16 x 16-bit tables, symbol-major (see PS_MASK_* below)
-	uint32_t* masks = nullptr; long long mask_stride = 0; // dwords per chain (PS_MASK_DWORDS per group of 32 symbols)
+	unsigned* fin;     // [16] low 4 bits: final max_idx per start index; bits 4..7: last four decisions of hypothesis k
 	int* flag;         // != 0: a speculative warm-up did not reproduce the sequential EMA -> exact fallback runs
 	int n_chains, n_groups, n_chunks, warm;
 	int chunked = 1;   // boxcar variant: 0 = the sequential row kernel (one-chunk blocks), 1 = k4_box_chunks
@@ -301,11 +292,10 @@ hipError_t launch_ma_rows(const void* in, long long in_stride, int fmt, int m, f
 hipError_t launch_k2a_fft(const K2Params& p, int n_chan, hipStream_t s);
 hipError_t launch_k2a_search(const K2Params& p, int n_chan, hipStream_t s);
 hipError_t launch_selftest_hypot(const float2* in, int n, unsigned* mismatches, hipStream_t s);
-// walk != nullptr: the PhaseSearch walk of an earlier block (its tables are complete) rides along as extra workgroups
-hipError_t launch_k2b(const K2Params& p, int n_chan, hipStream_t s, const K4Params* walk = nullptr); // phasor recurrence
+hipError_t launch_k2b(const K2Params& p, int n_chan, hipStream_t s); // phasor recurrence
 hipError_t launch_k2c(const K2Params& p, int n_chan, hipStream_t s); // history carry + apply
 hipError_t launch_k3(const K3Params& p, int n_chan, hipStream_t s);
-hipError_t launch_k2b_ck(const K2Params& p, int n_chan, hipStream_t s, const K4Params* walk = nullptr); // phasor recurrence, checkpoints only
+hipError_t launch_k2b_ck(const K2Params& p, int n_chan, hipStream_t s); // phasor recurrence, checkpoints only
 hipError_t launch_k6(const K6Params& p, hipStream_t s);
 struct K5Params { // ModelChallenger FM branch (Model.cpp:638-639): Demod::FM -> Filter(Receiver, 37 taps) -> sign
 	const float2* x; long long x_stride; long long x_off; // input rows: sample n of the block at x[chan * x_stride + x_off + n]
@@ -344,8 +334,7 @@ struct KV2Params {
 	int n_windows, L, n_chan;
 };
 hipError_t launch_kv2(const KV2Params& p, hipStream_t s);
-hipError_t launch_k4(const K4Params& p, hipStream_t s);          // chunk-parallel tables + verification (with the conditional exact recomputation)
-hipError_t launch_k4_walk(const K4Params& p, hipStream_t s);     // the max_idx walk over the tables of one block: bits + max_idx
+hipError_t launch_k4(const K4Params& p, hipStream_t s);          // chunk-parallel + assemble + (conditional) exact fallback
 hipError_t launch_k4_sequential(const K4Params& p, hipStream_t s); // the plain sequential kernel only
 hipError_t launch_k4_box(const K4Params& p, hipStream_t s);        // Demod::PhaseSearch (boxcar history), sequential
 

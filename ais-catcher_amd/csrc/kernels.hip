@@ -1147,13 +1147,7 @@ __global__ __launch_bounds__(64) void k2_cgf_search(K2Params p) {
 // ------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// The PhaseSearch walk of an EARLIER block rides along with the recurrence (workgroups behind the recurrence's own): both are a
-// handful of waves that are one long dependent chain, and on the recurrence's reserved CUs neither waits for anybody's issue slots
-// or LDS queue -- and the walk is off the PhaseSearch stream, which is the pipeline's critical one (k4_walk: the same as a kernel).
-__device__ __forceinline__ void psm_walk_rider(const K4Params& w, int wg);
-
-__global__ __launch_bounds__(64) void k2_cgf_phasor(K2Params p, K4Params w) {
-	if ((int)blockIdx.x >= (p.n_chan + 63) / 64) { psm_walk_rider(w, (int)blockIdx.x - (p.n_chan + 63) / 64); return; }
+__global__ __launch_bounds__(64) void k2_cgf_phasor(K2Params p) {
 	const int lane = threadIdx.x;
 	const int chan_raw = blockIdx.x * 64 + lane;
 	const bool live = chan_raw < p.n_chan;
@@ -1189,8 +1183,7 @@ __global__ __launch_bounds__(64) void k2_cgf_phasor(K2Params p, K4Params w) {
 // The same recurrence without the per-sample stores: only its state at the start of every time segment of the
 // fused derotation/FIR kernel is kept (K6 recomputes the 200-odd steps of a segment, 64 chains per wave, all
 // segments in parallel).  3 packed VALU ops per step and nothing else.
-__global__ __launch_bounds__(64) void k2_cgf_phasor_ck(K2Params p, K4Params w) {
-	if ((int)blockIdx.x >= (p.n_chan + 63) / 64) { psm_walk_rider(w, (int)blockIdx.x - (p.n_chan + 63) / 64); return; }
+__global__ __launch_bounds__(64) void k2_cgf_phasor_ck(K2Params p) {
 	const int lane = threadIdx.x;
 	const int chan_raw = blockIdx.x * 64 + lane;
 	const bool live = chan_raw < p.n_chan;
@@ -1805,146 +1798,67 @@ __global__ __launch_bounds__(64) void k4_box_chunks(K4Params p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K4 chunk-parallel, in two passes (round 4; DSP/Demod.cpp:39-101).
-// The block's symbols are cut into chunks of PS_CHUNK; one 16-lane row per (chain, chunk), lane k = hypothesis k.
+// K4 chunk-parallel: the block's symbols are cut into chunks of PS_CHUNK; one 16-lane row per (chain, chunk).
 //  * ma[k] is a contraction (x0.85 per symbol), so a chunk starts from ma = 0 and first replays the `warm`
 //    symbols in front of it; after that the float state is (with overwhelming probability) bit-identical to
-//    the sequential one.  That is VERIFIED: k4_verify compares the post-warm-up values with the previous
-//    chunk's final values bit for bit; where they differ -- or an EMA is not finite -- the same workgroup recomputes its
-//    four chains' block sequentially from the true state with the reference's own comparisons.  Always bit-exact.
+//    the sequential one.  That is VERIFIED: k4_assemble compares the post-warm-up values with the previous
+//    chunk's final values bit for bit and raises p.flag on any difference, in which case the sequential
+//    kernel above recomputes the block exactly.  Results are therefore always bit-exact.
 //  * the decisions (t > 0) do not depend on state at all.
-//  * max_idx is not contractive and is not guessed: the chunk kernel does not follow it at all (rounds 1-3 had lane k follow the
-//    trajectory that starts at k: 9 of the 21 instructions per symbol).  A lane only records, per symbol, what max_idx would do
-//    FROM its hypothesis -- up (the right neighbour beats both), down (neither it nor the right one beats the left one) -- and the
-//    bit the chain emits if max_idx ends there; sign bits of float differences shifted into history words, no compare, no ballot,
-//    no scalar work.  Every 32 symbols the row transposes its three history words (16 lanes x 32 bits -> per symbol 16 bits, four
-//    DPP butterfly stages) and stores them; k4_walk follows the one true trajectory per chain through these tables later.
+//  * max_idx is not contractive, so it is not guessed: lane k of the row tracks the trajectory that STARTS at
+//    max_idx = k (same instructions as one trajectory, the row's 16 lanes just stop being redundant);
+//    k4_assemble then walks the chunks sequentially, picking for each the trajectory of the true start.
 // ------------------------------------------------------------------------------------------
-constexpr int PS_SB = 64;            // symbols per chain per super-batch (staged through LDS: the 16 lanes of a row consume the same sample)
+template <int MODE>
+__device__ __forceinline__ void ps_warm_step(float2 v, float pc, float psn, c2& M, PsWave& hs) {
+	const float tt = v.x * pc + v.y * psn;
+	const unsigned long long dn = __ballot(tt > 0);
+	M.y = ps_ema(M.y, tt);
+	hs.h4 = hs.h3; hs.h3 = hs.h2; hs.h2 = hs.h1; hs.h1 = dn;
+}
+
+// The 16 lanes of a row consume the same sample, and a wave that waits for its own 8-symbol prefetch is latency-bound as soon
+// as the front end loads the memory system (0.17 ms alone, 0.55 ms next to it).  So the wave stages its input: every lane
+// fetches a different symbol (one load instruction = 16 symbols per chain, whole 128-byte segments), a super-batch of PS_SB
+// symbols per chain goes through a double-buffered LDS tile, and the loads of super-batch n+2 are in flight while n is
+// processed (64 symbols x 20 instructions of cover).  The steps then read their sample as an LDS broadcast.
+constexpr int PS_SB = 64;            // symbols per chain per super-batch
 constexpr int PS_SB_PAD = PS_SB + 4; // row pitch: the four rows' broadcast reads fall into different banks
 
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_perm(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true); }
-
-// 16 lanes x (2 x 16 bits): out[lane l] bit 16 u + b = in[lane b] bit 16 u + l (both halves of the word at once).  Butterfly: at
-// distance d a lane keeps the bit positions that agree with its own bit d and takes the others from lane l ^ d, moved by d
-// (a 32-bit rotate never carries a wanted bit across the halves).  amt / keep: per-lane constants of the four stages.
-struct RowT { unsigned amt[4], keep[4]; };
-__device__ __forceinline__ RowT rowt_init(int k) {
-	RowT t;
-	const unsigned B[4] = { 0xFF00FF00u, 0xF0F0F0F0u, 0xCCCCCCCCu, 0xAAAAAAAAu };
-#pragma unroll
-	for (int i = 0; i < 4; i++) {
-		const int d = 8 >> i;
-		t.amt[i] = (k & d) ? (unsigned)d : (unsigned)(32 - d);
-		t.keep[i] = (k & d) ? B[i] : ~B[i];
-	}
-	return t;
-}
-__device__ __forceinline__ unsigned rowt_stage(unsigned x, unsigned y, unsigned amt, unsigned keep) {
-	const unsigned sh = __builtin_amdgcn_alignbit(y, y, amt); // rotate right
-	return (x & keep) | (sh & ~keep);                         // v_bfi_b32
-}
-__device__ __forceinline__ unsigned row_transpose(unsigned x, const RowT& t) {
-	x = rowt_stage(x, dpp_perm<0x128>(x), t.amt[0], t.keep[0]);                  // lane ^ 8: row_ror:8
-	x = rowt_stage(x, dpp_perm<0x1B>(dpp_perm<0x141>(x)), t.amt[1], t.keep[1]);  // lane ^ 4: row_half_mirror (^ 7), then quad_perm:[3,2,1,0] (^ 3)
-	x = rowt_stage(x, dpp_perm<0x4E>(x), t.amt[2], t.keep[2]);                   // lane ^ 2: quad_perm:[2,3,0,1]
-	x = rowt_stage(x, dpp_perm<0xB1>(x), t.amt[3], t.keep[3]);                   // lane ^ 1: quad_perm:[1,0,3,2]
-	return x;
-}
-
-// per-lane state of a row's pass over its symbols
-struct PsLane {
-	float ma;            // the hypothesis' EMA
-	unsigned dn, dnp;    // decisions, newest at bit 0 (dn keeps shifting; dnp: its value at the last group boundary)
-	unsigned p0, p1;     // "ma[k] > ma[k-1]" and "ma[k+1] > max(ma[k], ma[k-1])" per symbol, newest at bit 0
-};
-
-// EXACT = false: the predicates are sign bits of float differences (x - y < 0 <=> x < y for finite operands: subnormals are kept,
-// -ffp-contract=off) shifted into the history words with v_alignbit -- twelve VALU instructions per symbol, none of them a compare.
-// An EMA that is not finite at a chunk's end sends the workgroup through the EXACT = true form, which uses the reference's own
-// comparisons (Demod.cpp:66-90), NaN semantics included.  MODE: which way row_ror turns (probed per wave): 0 = row_ror:1 delivers
-// lane k - 1.  The neighbour arithmetic takes its DPP operand inside the instruction (v_sub_f32_dpp, v_max_f32_dpp): the compiler
-// does not fold the permute into fsub / fmax (and canonicalises fmaxf's operands), so the step is written out; a DPP instruction
-// needs two wait states behind the VALU write of any register it reads (the hazard recogniser cannot see into the block: s_nop).
-#define PSM_NEIGHBOURS(L_, R_) \
-	"v_sub_f32 %[t0], 0, %[tt]\n\t"                /* sign(0 - t) <=> t > 0 (0 - (+-0) = +0) */ \
-	"v_mul_f32 %[t1], |%[tt]|, %[w1]\n\t"          /* w * ma + (1 - w) * |t|, each product and the sum rounded (Demod.cpp:71) */ \
-	"v_mul_f32 %[ma], %[ma], %[w]\n\t" \
-	"v_add_f32 %[ma], %[ma], %[t1]\n\t" \
-	"v_alignbit_b32 %[dn], %[dn], %[t0], 31\n\t" \
-	"s_nop 0\n\t" \
-	"v_sub_f32_dpp %[t0], %[ma], %[ma] row_ror:" L_ " row_mask:0xf bank_mask:0xf\n\t"    /* left - ma: < 0 <=> ma > left */ \
-	"v_max_f32_dpp %[t1], %[ma], %[ma] row_ror:" L_ " row_mask:0xf bank_mask:0xf\n\t"    /* == (ma > left ? ma : left): finite, both >= +0 */ \
-	"v_alignbit_b32 %[p0], %[p0], %[t0], 31\n\t" \
-	"s_nop 0\n\t" \
-	"v_subrev_f32_dpp %[t0], %[ma], %[t1] row_ror:" R_ " row_mask:0xf bank_mask:0xf\n\t" /* that - right: < 0 <=> right beats both */ \
-	"v_alignbit_b32 %[p1], %[p1], %[t0], 31"
-template <int MODE, bool EXACT>
-__device__ __forceinline__ void psm_step(float2 v, float pc, float psn, PsLane& s, int k) {
-	const float tt = v.x * pc + v.y * psn;
-	if (EXACT) {
-		s.dn = (s.dn << 1) | (tt > 0 ? 1u : 0u);
-		s.ma = ps_ema(s.ma, tt);
-		const float ma = s.ma;
-		float left, right;
-		if (MODE == 2) { left = __shfl(ma, (k + 15) & 15, 16); right = __shfl(ma, (k + 1) & 15, 16); }
-		else { const float r1 = dpp_ror1(ma), r15 = dpp_ror15(ma); left = MODE == 0 ? r1 : r15; right = MODE == 0 ? r15 : r1; }
-		const bool p0 = ma > left;
-		const float bestc = p0 ? ma : left;
-		const bool p1 = right > bestc;
-		s.p0 = (s.p0 << 1) | (p0 ? 1u : 0u);
-		s.p1 = (s.p1 << 1) | (p1 ? 1u : 0u);
-	} else {
-		const float w = 0.85f;
-		const float w1 = 1 - w; // (1 - weight) evaluated in float
-		float t0, t1;
-		if (MODE == 0) asm(PSM_NEIGHBOURS("1", "15") : [ma] "+v"(s.ma), [dn] "+v"(s.dn), [p0] "+v"(s.p0), [p1] "+v"(s.p1), [t0] "=&v"(t0), [t1] "=&v"(t1) : [tt] "v"(tt), [w] "s"(w), [w1] "s"(w1));
-		else asm(PSM_NEIGHBOURS("15", "1") : [ma] "+v"(s.ma), [dn] "+v"(s.dn), [p0] "+v"(s.p0), [p1] "+v"(s.p1), [t0] "=&v"(t0), [t1] "=&v"(t1) : [tt] "v"(tt), [w] "s"(w), [w1] "s"(w1));
-	}
-}
-template <bool EXACT>
-__device__ __forceinline__ void psm_warm_step(float2 v, float pc, float psn, PsLane& s) { // EMA and decision history only
-	const float tt = v.x * pc + v.y * psn;
-	if (EXACT) s.dn = (s.dn << 1) | (tt > 0 ? 1u : 0u);
-	else s.dn = __builtin_amdgcn_alignbit(s.dn, __float_as_uint(0.0f - tt), 31);
-	s.ma = ps_ema(s.ma, tt);
-}
-
-// the tables of the last `r` symbols (r = 32: a whole group) to mask group `wg` of the row's chain
-__device__ __forceinline__ void psm_flush(const K4Params& p, int chain, int wg, bool live, int k, PsLane& s, int r) {
-	int kk = k;
-	asm volatile("" : "+v"(kk)); // (the eight stage constants are rebuilt here, once per 32 symbols, instead of living in registers through the steps)
-	const RowT rt = rowt_init(kk);
-	// X of symbol i = decision(i - 3) ^ decision(i - 4) (nDelay = 3, Model.cpp:560-561): bit t of the history <-> bits t + 3, t + 4
-	const unsigned hi = r == 32 ? s.dnp : (s.dnp >> (32 - r));
-	unsigned x = __builtin_amdgcn_alignbit(hi, s.dn, 3) ^ __builtin_amdgcn_alignbit(hi, s.dn, 4);
-	unsigned up = s.p1, dn = ~(s.p0 | s.p1);
-	if (r != 32) { x <<= 32 - r; up <<= 32 - r; dn <<= 32 - r; } // a partial last group: its first symbol still at bit 31
-	up = row_transpose(up, rt); dn = row_transpose(dn, rt); x = row_transpose(x, rt);
-	if (live) {
-		uint32_t* dst = p.masks + (size_t)chain * p.mask_stride + (size_t)wg * PS_MASK_DWORDS + k;
-		dst[0] = up; dst[16] = dn; dst[32] = x;
-	}
-	s.dnp = s.dn;
-}
-
-// One row's pass over the symbols [g0, g1) of its chain, `warm` symbols of EMA / decision warm-up in front (0: s holds the true state).
-template <int MODE, bool EXACT>
-__device__ __forceinline__ void psm_run(const K4Params& p, int chain, bool live, int g0, int g1, int warm, PsLane& s, float* ma_warm,
-                                        int k, int row, float2 (*stage)[4][PS_SB_PAD]) {
+template <int MODE>
+__device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int chunk, bool live, int k, int rowbase, int lane,
+                                              float2 (*stage)[4][PS_SB_PAD]) {
 	const int jj = k < 8 ? k : 15 - k;
 	const float pc = c_ps_phase[jj].x;
-	const float psn = k < 8 ? c_ps_phase[jj].y : -c_ps_phase[jj].y; // a - b == a + (im * -s) exactly
+	const float psn = k < 8 ? c_ps_phase[jj].y : -c_ps_phase[jj].y;
 	const SymRow x(p.sym, chain, p.sym_stride);
-	const int start = g0 - warm;
+	const int g0 = chunk * PS_CHUNK;
+	const int g1 = g0 + PS_CHUNK < p.n_groups ? g0 + PS_CHUNK : p.n_groups;
+	const size_t slot = (size_t)chain * p.n_chunks + chunk;
+	const int row = rowbase >> 4;
+
+	c2 ma;
+	PsWave hs;
+	int idx = k; // trajectory that starts at max_idx == k
+	int start = g0;
+	if (chunk == 0) { // the true state
+		const EmaState* st = p.state_in + chain;
+		ma = c2{ st->ma[k], st->ma[k] };
+		const unsigned bits = st->bits[k];
+		hs.h1 = __ballot((bits & 1u) != 0); hs.h2 = __ballot((bits & 2u) != 0);
+		hs.h3 = __ballot((bits & 4u) != 0); hs.h4 = __ballot((bits & 8u) != 0);
+	} else { // speculative: replay the `warm` symbols in front of the chunk from zero (warm: multiple of 8, <= PS_CHUNK)
+		ma = c2{ 0.0f, 0.0f };
+		hs.h1 = hs.h2 = hs.h3 = hs.h4 = 0;
+		start = g0 - p.warm;
+	}
 	const int last_i = (int)p.sym_stride - 1;
 	float2 r[PS_SB / 16];
-	const auto fetch = [&](int sb) { // every lane a different symbol: one load instruction = 16 symbols per chain, whole 128-byte segments
+	const auto fetch = [&](int sb) {
 #pragma unroll
 		for (int q = 0; q < PS_SB / 16; q++) {
 			int i = start + sb * PS_SB + q * 16 + k;
-			i = i < last_i ? i : last_i; // (past the end: any readable sample, it is never used)
+			i = i < last_i ? i : last_i; // (past the chunk's end: any readable sample, it is never used)
 			r[q] = x[i];
 		}
 	};
@@ -1956,7 +1870,9 @@ __device__ __forceinline__ void psm_run(const K4Params& p, int chain, bool live,
 	fetch(0);
 	stash(0);
 	if (nsb > 1) fetch(1);
-	if (warm == 0) s.dnp = s.dn;
+
+	uint32_t* wout = p.words + slot * (PS_CHUNK / 32) * 16 + k;
+	uint32_t word = 0;
 #pragma unroll 1
 	for (int sb = 0; sb < nsb; sb++) {
 		const int buf = sb & 1;
@@ -1971,18 +1887,28 @@ __device__ __forceinline__ void psm_run(const K4Params& p, int chain, bool live,
 #pragma unroll
 				for (int e = 0; e < PS_BATCH; e += 2) { const float4 t = src[e >> 1]; v[e] = make_float2(t.x, t.y); v[e + 1] = make_float2(t.z, t.w); }
 			}
-			if (g < g0) { // warm-up (a multiple of PS_BATCH symbols)
+			if (g < g0) { // warm-up: EMA and decision history only
 #pragma unroll
-				for (int e = 0; e < PS_BATCH; e++) psm_warm_step<EXACT>(v[e], pc, psn, s);
-				if (g + PS_BATCH == g0) { *ma_warm = s.ma; s.dnp = s.dn; }
-			} else if (g + PS_BATCH <= g1) {
-#pragma unroll
-				for (int e = 0; e < PS_BATCH; e++) psm_step<MODE, EXACT>(v[e], pc, psn, s, k);
-				if (((g - g0 + PS_BATCH) & 31) == 0) psm_flush(p, chain, (g - g0) >> 5, live, k, s, 32);
+				for (int e = 0; e < PS_BATCH; e++) ps_warm_step<MODE>(v[e], pc, psn, ma, hs);
+				if (g + PS_BATCH == g0 && live) p.ma_start[slot * 16 + k] = ma.y;
 			} else {
+				const int q = g - g0;
+				uint32_t part = 0;
+				if (g + PS_BATCH <= g1) {
 #pragma unroll
-				for (int e = 0; e < PS_BATCH; e++)
-					if (g + e < g1) psm_step<MODE, EXACT>(v[e], pc, psn, s, k); // wave-uniform
+					for (int e = 0; e < PS_BATCH; e++) part |= ps_step<MODE>(v[e], pc, psn, ma, hs, idx, k, rowbase) << e;
+				} else {
+#pragma unroll
+					for (int e = 0; e < PS_BATCH; e++)
+						if (g + e < g1) part |= ps_step<MODE>(v[e], pc, psn, ma, hs, idx, k, rowbase) << e; // wave-uniform
+				}
+				word |= part << (q & 31);
+				// (a last, partial batch never completes a word -- the write behind the loop is the one that stores it;
+				// flushed here as well it was overwritten by an empty word whenever n % 32 was 25 .. 31)
+				if (((q + PS_BATCH) & 31) == 0 && g + PS_BATCH <= g1) {
+					if (live) wout[(q >> 5) * 16] = word;
+					word = 0;
+				}
 			}
 		}
 		if (sb + 1 < nsb) {
@@ -1991,13 +1917,13 @@ __device__ __forceinline__ void psm_run(const K4Params& p, int chain, bool live,
 		}
 	}
 	const int n = g1 - g0;
-	if ((n & 31) != 0) psm_flush(p, chain, n >> 5, live, k, s, n & 31);
-}
-
-__device__ __forceinline__ void psm_load_state(const EmaState* st, int k, PsLane& s) {
-	s.ma = st->ma[k];
-	s.dn = st->bits[k]; // bit j = decision of j + 1 symbols ago
-	s.dnp = s.dn; s.p0 = s.p1 = 0;
+	if ((n & 31) != 0 && live) wout[(n >> 5) * 16] = word;
+	if (live) {
+		p.ma_fin[slot * 16 + k] = ma.y;
+		const unsigned dec = (unsigned)((hs.h1 >> lane) & 1ull) | ((unsigned)((hs.h2 >> lane) & 1ull) << 1) |
+		                     ((unsigned)((hs.h3 >> lane) & 1ull) << 2) | ((unsigned)((hs.h4 >> lane) & 1ull) << 3);
+		p.fin[slot * 16 + k] = (unsigned)(idx & 15) | (dec << 4);
+	}
 }
 
 #ifndef K4_WAVES
@@ -2009,185 +1935,26 @@ __device__ __forceinline__ void psm_load_state(const EmaState* st, int k, PsLane
 #ifndef K4_NUM_VGPR
 #define K4_NUM_VGPR 64
 #endif
-// the four rows of a wave: the same sampling phase of four ADJACENT channels (their symbol pairs are 64 contiguous bytes in the
-// SymRow layout) -- workgroup bx of the chunk grid and of k4_verify
-__device__ __forceinline__ int psm_chain(const K4Params& p, int bx, int row, bool& live) {
-	const int j = bx % 5, chan = (bx / 5) * 4 + row;
-	const int chain_raw = chan * 5 + j;
-	live = chain_raw < p.n_chains;
-	return live ? chain_raw : p.n_chains - 1;
-}
-__device__ __forceinline__ int psm_mode(int k) { // which way row_ror:1 turns: 0 = it delivers lane k - 1, 1 = lane k + 1, 2 = neither (shuffles)
-	const int src = __builtin_amdgcn_update_dpp(0, k, 0x121, 0xF, 0xF, false);
-	return __all(src == ((k + 15) & 15)) ? 0 : __all(src == ((k + 1) & 15)) ? 1 : 2;
-}
-
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K4_WAVES, K4_WAVES))) __attribute__((amdgpu_num_vgpr(K4_NUM_VGPR))) void k4_phase_chunks(K4Params p) {
 	__shared__ __attribute__((aligned(16))) float2 stage[2][4][PS_SB_PAD];
 	const int lane = threadIdx.x;
 	const int k = lane & 15, row = lane >> 4;
 	const int chunk = blockIdx.y;
-	bool live;
-	const int chain = psm_chain(p, blockIdx.x, row, live);
-	const int g0 = chunk * PS_CHUNK;
-	const int g1 = g0 + PS_CHUNK < p.n_groups ? g0 + PS_CHUNK : p.n_groups;
-	const size_t slot = (size_t)chain * p.n_chunks + chunk;
-	PsLane s;
-	int warm = 0;
-	if (chunk == 0) psm_load_state(p.state_in + chain, k, s); // the true state
-	else { s.ma = 0.0f; s.dn = s.dnp = s.p0 = s.p1 = 0; warm = p.warm; } // speculative: replay the `warm` symbols in front of the chunk from zero
-	float ma_warm = 0.0f;
-	K4Params q = p; // (group index inside the chunk -> inside the block)
-	q.masks = p.masks + (size_t)(g0 >> 5) * PS_MASK_DWORDS;
-	const int mode = psm_mode(k);
-	if (mode == 0) psm_run<0, false>(q, chain, live, g0, g1, warm, s, &ma_warm, k, row, stage);
-	else if (mode == 1) psm_run<1, false>(q, chain, live, g0, g1, warm, s, &ma_warm, k, row, stage);
-	else s.ma = __uint_as_float(0x7FC00000u); // (a permute that turns neither way: k4_verify recomputes the chains with shuffles)
-	if (live) {
-		if (chunk > 0) p.ma_start[slot * 16 + k] = ma_warm;
-		p.ma_fin[slot * 16 + k] = s.ma;
-		p.fin[slot * 16 + k] = s.dn & 15u;
-	}
-}
-
-// One wave per chunk-grid workgroup (its four chains): verify the speculative warm-ups -- every chunk's EMAs after the warm-up
-// against the previous chunk's final ones, bit for bit, and every final EMA finite -- and write the state after the block (EMAs,
-// last four decisions; max_idx is the walk's).  Where the check fails the wave recomputes its four chains' block sequentially
-// from the true state, with the reference's comparisons, tables and state.
-__global__ __launch_bounds__(64) void k4_verify(K4Params p) {
-	__shared__ __attribute__((aligned(16))) float2 stage[2][4][PS_SB_PAD];
-	const int lane = threadIdx.x;
-	const int k = lane & 15, row = lane >> 4;
-	bool live;
-	const int chain = psm_chain(p, blockIdx.x, row, live);
-	const size_t base = (size_t)chain * p.n_chunks;
-	bool bad = false;
-	unsigned prev = 0;
-	for (int c = 0; c < p.n_chunks; c++) { // (a handful: all loads independent)
-		const unsigned mf = __float_as_uint(p.ma_fin[(base + c) * 16 + k]);
-		if (c > 0) bad = bad || __float_as_uint(p.ma_start[(base + c) * 16 + k]) != prev;
-		bad = bad || (mf & 0x7F800000u) == 0x7F800000u;
-		prev = mf;
-	}
-	const EmaState* st = p.state_in + chain;
-	EmaState* sto = p.state_out + chain;
-	if (__any(bad && live)) {
-		if (lane == 0 && p.fb_count) atomicAdd(p.fb_count, 1);
-		PsLane s;
-		psm_load_state(st, k, s);
-		float dummy;
-		const int mode = psm_mode(k);
-		if (mode == 0) psm_run<0, true>(p, chain, live, 0, p.n_groups, 0, s, &dummy, k, row, stage);
-		else if (mode == 1) psm_run<1, true>(p, chain, live, 0, p.n_groups, 0, s, &dummy, k, row, stage);
-		else psm_run<2, true>(p, chain, live, 0, p.n_groups, 0, s, &dummy, k, row, stage);
-		if (live) { sto->ma[k] = s.ma; sto->bits[k] = s.dn & 15u; }
-	} else if (live) {
-		sto->ma[k] = __uint_as_float(prev);
-		sto->bits[k] = p.fin[(base + p.n_chunks - 1) * 16 + k];
-	}
-	if (live && k == 0) sto->rot = (st->rot + p.n_groups) & 3;
-}
-
-// The walk (Demod.cpp:77-98): one lane per chain follows max_idx through the block's tables from the chain's true max_idx and
-// packs the emitted bits.  Six instructions per symbol, three of them a dependent chain; 48 table words per 32 symbols, the next
-// group's in flight while this one is walked.
-typedef unsigned u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned psm_word(const u4 (&m)[12], int i) { // word i of [table 3][16] (i: a constant after unrolling)
-	return m[i >> 2][i & 3];
-}
-__device__ __forceinline__ void psm_walk_group(const u4 (&m)[12], int n, int& idx, uint32_t& word) {
-	word = 0;
-#pragma unroll
-	for (int s = 0; s < 32; s++) {
-		if (s < n) { // (n: wave-uniform)
-			const int t = 31 - s, kk = t & 15, half = (t >> 4) * 16;
-			const unsigned o = ((unsigned)idx & 15u) | (unsigned)half;
-			const int up = (int)__builtin_amdgcn_ubfe(psm_word(m, kk), o, 1);
-			const int dn = __builtin_amdgcn_sbfe((int)psm_word(m, 16 + kk), o, 1); // -1 or 0
-			idx = idx + up + dn;
-			const unsigned o2 = ((unsigned)idx & 15u) | (unsigned)half;
-			word |= __builtin_amdgcn_ubfe(psm_word(m, 32 + kk), o2, 1) << s;
-		}
-	}
-}
-// A chain's tables of one group are 192 contiguous bytes and the chains of a wave are tens of KB apart: fetched by their own lanes,
-// every load instruction touches 64 different lines (and the walk is bound by the texture addresser of its few CUs: 0.43 ms on the
-// recurrence's eight).  So the wave fetches cooperatively -- twelve lanes per chain, 16 bytes each: an instruction covers five
-// chains' whole blocks -- and hands the words to their lanes through LDS (row pitch 13 x 16 bytes: conflict-free 128-bit reads).
-constexpr int PSW_PITCH = 13; // u4 per chain in the exchange buffer
-#ifndef PSW_DEPTH_
-#define PSW_DEPTH_ 4
-#endif
-constexpr int PSW_DEPTH = PSW_DEPTH_; // groups of tables in flight per wave
-__device__ __forceinline__ void psm_walk(const K4Params& p, int chain0, u4* xbuf) {
-	const int lane = threadIdx.x;
-	const int chain_raw = chain0 + lane;
+	// the four rows of a wave: the same sampling phase of four ADJACENT channels (their symbol pairs are 64 contiguous bytes in
+	// the SymRow layout) and the same chunk (equal trip counts)
+	const int j = blockIdx.x % 5, chan = (blockIdx.x / 5) * 4 + row;
+	const int chain_raw = chan * 5 + j;
 	const bool live = chain_raw < p.n_chains;
 	const int chain = live ? chain_raw : p.n_chains - 1;
-	const EmaState* st = p.state_in + chain;
-	EmaState* sto = p.state_out + chain;
-	int idx = st->max_idx;
-	uint32_t* out = p.bits + (size_t)chain * p.bits_stride;
-	const int ng = (p.n_groups + 31) >> 5;
-	// piece i of the cooperative fetch: flat = 64 i + lane -> chain flat / 12 of the wave, part flat % 12
-	const u4* src[12];
-	int dst[12];
-#pragma unroll
-	for (int i = 0; i < 12; i++) {
-		const int flat = 64 * i + lane, c = flat / 12, part = flat - 12 * c;
-		int cc = chain0 + c;
-		cc = cc < p.n_chains ? cc : p.n_chains - 1;
-		src[i] = reinterpret_cast<const u4*>(p.masks + (size_t)cc * p.mask_stride) + part;
-		dst[i] = c * PSW_PITCH + part;
-	}
-	// Beside the front end a load takes microseconds and a group is walked in 0.8.  Two sets of PSW_DEPTH groups (registers, in the
-	// cooperative layout): while one set is walked the other one's loads -- all issued at the start of the round -- are in flight,
-	// and the only wait is the compiler's own "all loads" at the head of a round, PSW_DEPTH groups of work after they were issued.
-	u4 ring[2][PSW_DEPTH][12], cur[12];
-	const int nr = (ng + PSW_DEPTH - 1) / PSW_DEPTH; // rounds
-	const auto fetch = [&](u4 (&set)[PSW_DEPTH][12], int round) {
-#pragma unroll
-		for (int d = 0; d < PSW_DEPTH; d++) {
-			int g = round * PSW_DEPTH + d;
-			g = g < ng ? g : ng - 1; // (behind the block's end: clamped, never walked)
-#pragma unroll
-			for (int i = 0; i < 12; i++) set[d][i] = src[i][(size_t)g * 12];
-		}
-	};
-	const auto walk = [&](u4 (&set)[PSW_DEPTH][12], int round) {
-#pragma unroll
-		for (int d = 0; d < PSW_DEPTH; d++) {
-			const int g = round * PSW_DEPTH + d;
-#pragma unroll
-			for (int i = 0; i < 12; i++) xbuf[dst[i]] = set[d][i];
-			wave_sync();
-#pragma unroll
-			for (int i = 0; i < 12; i++) cur[i] = xbuf[lane * PSW_PITCH + i];
-			wave_sync();
-			const int n = p.n_groups - 32 * g;
-			uint32_t word;
-			if (n >= 32) psm_walk_group(cur, 32, idx, word);
-			else psm_walk_group(cur, n, idx, word);
-			if (live && g < ng) out[g] = word;
-		}
-	};
-	fetch(ring[0], 0);
-	for (int r = 0; r < nr; r += 2) { // (a round behind the last one is fetched clamped and walks nothing)
-		fetch(ring[1], r + 1);
-		walk(ring[0], r);
-		fetch(ring[0], r + 2);
-		walk(ring[1], r + 1);
-	}
-	if (live) sto->max_idx = idx & 15;
+	const int rowbase = row * 16;
+	const int src = __builtin_amdgcn_update_dpp(0, k, 0x121, 0xF, 0xF, false);
+	const bool all_left = __all(src == ((k + 15) & 15)), all_right = __all(src == ((k + 1) & 15));
+	if (all_left) ps_chunk_body<0>(p, chain, chunk, live, k, rowbase, lane, stage);
+	else if (all_right) ps_chunk_body<1>(p, chain, chunk, live, k, rowbase, lane, stage);
+	else ps_chunk_body<2>(p, chain, chunk, live, k, rowbase, lane, stage);
 }
-__device__ __forceinline__ void psm_walk_rider(const K4Params& w, int wg) {
-	__shared__ u4 xbuf[64 * PSW_PITCH];
-	__builtin_amdgcn_s_setprio(2); // a long dependent chain: issue early (the recurrence itself, 3, first)
-	psm_walk(w, wg * 64, xbuf);
-}
-__global__ __launch_bounds__(64) void k4_walk(K4Params p) { psm_walk_rider(p, (int)blockIdx.x); }
 
-// (boxcar variant only) sequential over the (few) chunks of a chain, 16 lanes per chain: select the
+// sequential over the (few) chunks of a chain, 16 lanes per chain: verify the speculative warm-ups, select the
 // trajectory of the true start index per chunk, emit the packed decisions and the new state
 __global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
 	const int lane = threadIdx.x;
@@ -3768,16 +3535,13 @@ hipError_t launch_k2a_search(const K2Params& p, int n_chan, hipStream_t s) {
 	return hipGetLastError();
 }
 
-static K4Params no_walk() { K4Params w; memset(&w, 0, sizeof w); return w; }
-static int walk_wgs(const K4Params* walk) { return walk && walk->n_groups > 0 ? (walk->n_chains + 63) / 64 : 0; }
-
-hipError_t launch_k2b(const K2Params& p, int n_chan, hipStream_t s, const K4Params* walk) {
-	hipLaunchKernelGGL(k2_cgf_phasor, dim3((n_chan + 63) / 64 + walk_wgs(walk)), dim3(64), 0, s, p, walk_wgs(walk) ? *walk : no_walk());
+hipError_t launch_k2b(const K2Params& p, int n_chan, hipStream_t s) {
+	hipLaunchKernelGGL(k2_cgf_phasor, dim3((n_chan + 63) / 64), dim3(64), 0, s, p);
 	return hipGetLastError();
 }
 
-hipError_t launch_k2b_ck(const K2Params& p, int n_chan, hipStream_t s, const K4Params* walk) {
-	hipLaunchKernelGGL(k2_cgf_phasor_ck, dim3((n_chan + 63) / 64 + walk_wgs(walk)), dim3(64), 0, s, p, walk_wgs(walk) ? *walk : no_walk());
+hipError_t launch_k2b_ck(const K2Params& p, int n_chan, hipStream_t s) {
+	hipLaunchKernelGGL(k2_cgf_phasor_ck, dim3((n_chan + 63) / 64), dim3(64), 0, s, p);
 	return hipGetLastError();
 }
 
@@ -3895,15 +3659,13 @@ hipError_t launch_k4_sequential(const K4Params& p, hipStream_t s) {
 
 hipError_t launch_k4(const K4Params& p, hipStream_t s) {
 	if (p.n_groups <= 0) return hipSuccess;
-	const int gx = (p.n_chains / 5 + 3) / 4 * 5;
-	hipLaunchKernelGGL(k4_phase_chunks, dim3(gx, p.n_chunks), dim3(64), 0, s, p);
-	hipLaunchKernelGGL(k4_verify, dim3(gx), dim3(64), 0, s, p); // + the exact recomputation where a warm-up did not reproduce the sequential EMA
-	return hipGetLastError();
-}
-
-hipError_t launch_k4_walk(const K4Params& p, hipStream_t s) {
-	if (p.n_groups <= 0) return hipSuccess;
-	hipLaunchKernelGGL(k4_walk, dim3((p.n_chains + 63) / 64), dim3(64), 0, s, p);
+	if (!p.qflag) { // (the per-workgroup flags are cleared by the fallback kernel itself)
+		hipError_t e = hipMemsetAsync(p.flag, 0, sizeof(int), s);
+		if (e != hipSuccess) return e;
+	}
+	hipLaunchKernelGGL(k4_phase_chunks, dim3((p.n_chains / 5 + 3) / 4 * 5, p.n_chunks), dim3(64), 0, s, p);
+	hipLaunchKernelGGL(k4_assemble, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p);
+	hipLaunchKernelGGL(k4_phase_search, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p, 1); // exits at once unless flagged
 	return hipGetLastError();
 }
 
