@@ -301,7 +301,7 @@ struct K5Params { // ModelChallenger FM branch (Model.cpp:638-639): Demod::FM ->
 	const float2* x; long long x_stride; long long x_off; // input rows: sample n of the block at x[chan * x_stride + x_off + n]
 	const float2* prev_in; float2* prev_out;   // optional [n_chan]: the sample before the block when the rows carry no history (ModelBase)
 	float* fm; long long fm_stride;          // optional (AISGPU_FLAG_TAPS) [n_chan][FM_HIST + L]: the discriminator output at [FM_HIST + n]
-	const float* hist_in; float* hist_out;   // [n_chan][FM_HIST] the discriminator's last FM_HIST outputs of the previous block / of this one
+	const float* hist_in = nullptr; float* hist_out = nullptr; // [n_chan][FM_HIST] the discriminator's last FM_HIST outputs of the previous block / of this one (both required: launch_k5 refuses a null)
 	uint32_t* fmbits; long long fmbits_stride; // [n_chan][L/32] bit n: filtered discriminator > 0
 	float taps[37];
 	int L;

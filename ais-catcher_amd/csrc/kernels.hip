@@ -3635,6 +3635,7 @@ hipError_t launch_k7e_resolve(const K7eParams& q, hipStream_t s) { // the walk: 
 }
 
 hipError_t launch_k5(const K5Params& p, int n_chan, hipStream_t s) {
+	if (!p.hist_in || !p.hist_out) return hipErrorInvalidValue; // the first / last tile of a row dereference them
 	hipLaunchKernelGGL(k5_fm_filter, dim3(p.L / 256, n_chan), dim3(256), 0, s, p);
 	return hipGetLastError();
 }

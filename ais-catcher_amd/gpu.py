@@ -124,13 +124,30 @@ def load():
 OPTION_KEYS = ("serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1")
 
 
+_forwarded = set()
+
+
 def apply_env_options(lib=None):
+    """Forward AISGPU_<KEY> from the environment to aisgpu_set_option(key).  Only keys that are (or, at the previous call, were) in
+    the environment are touched, so an option the application set itself through aisgpu_set_option() survives.  The options are
+    process-wide and sampled by aisgpu_create().  An AISGPU_* variable that names no option is an error of the caller's (a renamed
+    knob must fail loudly, not select the default path silently)."""
     lib = lib or load()
     if not hasattr(lib, "aisgpu_set_option"):
         return
+    known = {"AISGPU_" + k.upper() for k in OPTION_KEYS} | {"AISGPU_LIB", "AISGPU_TRACE", "AISGPU_K7E_STATS", "AISGPU_K7B_STATS"}
+    unknown = sorted(v for v in os.environ if v.startswith("AISGPU_") and v not in known)
+    if unknown:
+        import warnings
+        warnings.warn("environment variables that name no aisgpu option: %s (options: %s)" % (", ".join(unknown), ", ".join(OPTION_KEYS)))
     for key in OPTION_KEYS:
         v = os.environ.get("AISGPU_" + key.upper())
-        lib.aisgpu_set_option(key.encode(), v.encode() if v else None)
+        if v:
+            lib.aisgpu_set_option(key.encode(), v.encode())
+            _forwarded.add(key)
+        elif key in _forwarded:   # set by this wrapper earlier and gone from the environment since: back to the default
+            lib.aisgpu_set_option(key.encode(), None)
+            _forwarded.discard(key)
 
 
 class AisGpuError(RuntimeError):

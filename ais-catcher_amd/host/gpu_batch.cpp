@@ -18,6 +18,7 @@ GpuBatch::GpuBatch(const aisgpu_cfg& c) : cfg(c) {
 	active = cfg.n_receivers;
 	present.assign(cfg.n_receivers, 0);
 	gone.assign(cfg.n_receivers, 0);
+	frame_snap = std::make_shared<const std::vector<aisgpu_frame>>();
 }
 
 GpuBatch::~GpuBatch() { aisgpu_destroy(ctx); }
@@ -32,6 +33,12 @@ void GpuBatch::launch() {
 	} else {
 		st = aisgpu_run(ctx);
 		if (st == AISGPU_OK) st = aisgpu_sync_outputs(ctx);
+	}
+	if (cfg.flags & AISGPU_FLAG_GPU_DECODE) { // this generation's frames, for as long as any receiver still reads them
+		const aisgpu_frame* fr = nullptr;
+		int nf = 0;
+		if (st == AISGPU_OK && aisgpu_out_count(ctx) > 0) st = aisgpu_frames(ctx, &fr, &nf);
+		frame_snap = std::make_shared<const std::vector<aisgpu_frame>>(fr, fr + (st == AISGPU_OK ? nf : 0));
 	}
 	gen_status[generation & 1] = st;
 	arrived = 0;

@@ -8,6 +8,7 @@
 // (integration/reference/Source/DSP/GPU/ModelGPU.cpp).  Depends on the C ABI and the standard library only.
 #pragma once
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -29,6 +30,10 @@ class GpuBatch {
 	int timeout_ms = 10000;      // a receiver that has not delivered this long after the first one of a generation is evicted
 	bool pipelined = false;      // launch = collect the PREVIOUS block's outputs, then start this one: the host consumes block f-1 while the device runs f
 	int fed = 0;                 // receivers that handed in data (not a drain request) in the current generation
+	// AISGPU_FLAG_GPU_DECODE: the frames of the generation whose outputs are being served, copied out of the context at launch().  A
+	// receiver reads them through its own reference: one that the timeout evicted while it was still delivering keeps a valid (old)
+	// list instead of the context's array, which the next aisgpu_sync_outputs() clears and refills under it.
+	std::shared_ptr<const std::vector<aisgpu_frame>> frame_snap;
 	void launch();               // run the batch for the current generation and release the waiting threads (mtx held)
 
 public:
@@ -52,7 +57,7 @@ public:
 	int activeReceivers() { std::lock_guard<std::mutex> l(mtx); return active; }
 	int outCount() { return aisgpu_out_count(ctx); }
 	int fetch(int sub, int rx, int ch, aisgpu_out* out) { return aisgpu_fetch_sub(ctx, sub, rx, ch, out); }
-	int frames(const aisgpu_frame** f, int* n) { return aisgpu_frames(ctx, f, n); }
+	std::shared_ptr<const std::vector<aisgpu_frame>> frames() { std::lock_guard<std::mutex> l(mtx); return frame_snap; } // never null
 	const char* lastError() { return aisgpu_last_error(ctx); }
 };
 

@@ -66,11 +66,9 @@ void GpuChain::process(const void* data, int len, TAG& tag) {
 	const int nsub = batch->outCount(); // (a pipelined batch serves the PREVIOUS block's outputs here: none after the first call)
 	if (nsub == 0) return;
 	if (batch->config().flags & AISGPU_FLAG_GPU_DECODE) { // the device ran the decoders: only completed frames come back
-		const aisgpu_frame* fr = nullptr;
-		int nf = 0;
-		if ((rc = batch->frames(&fr, &nf)) != AISGPU_OK) { failed = true; last_status = rc; return; }
-		for (int i = 0; i < nf; i++) {
-			const aisgpu_frame& f = fr[i];
+		const auto frames = batch->frames(); // (this generation's list, valid for as long as this reference lives)
+		for (size_t i = 0; i < frames->size(); i++) {
+			const aisgpu_frame& f = (*frames)[i];
 			if (f.rx != rx || f.sub >= nsub) continue;
 			aisgpu_out o;
 			if ((rc = batch->fetch(f.sub, rx, f.ch, &o)) != AISGPU_OK) { failed = true; last_status = rc; return; }

@@ -199,19 +199,25 @@ def cpu_baseline(seconds=16.0, model=2, rate=RATE):
     thr0 = cgroup_throttled_usec()
     _, single, _, _ = run(1, 1.5)
     limit = host["cgroup_cpu_limit_cores"]
-    cand = sorted(set(max(1, c) for c in [phys // 8, phys // 4, phys // 2, phys] + ([int(limit), int(limit * 2)] if limit else []) if c <= len(topo)))
-    scan = {}
+    # thread counts up to what the container may actually run: above the cgroup quota every further thread only adds throttling
+    # (one oversubscribed point is kept in the scan to show it, but is never the reported figure)
+    cap = min(len(topo), int(limit)) if limit and limit >= 1 else len(topo)
+    cand = sorted(set(max(1, c) for c in [phys // 8, phys // 4, phys // 2, phys, cap // 2, cap] if c <= cap))
+    scan, over = {}, {}
     for n in cand:
         nn, v, _, _ = run(n, 1.0)
         scan[nn] = round(v, 1)
+    if cap < len(topo):
+        nn, v, _, _ = run(min(len(topo), 2 * cap), 1.0)
+        over[nn] = round(v, 1)
     best = max(scan, key=lambda k: scan[k])
     n, value, dt, blocks = run(best, max(4.0, seconds - 1.5 - 1.0 * len(cand)))
     thr1 = cgroup_throttled_usec()
     return {"value": round(value, 2), "unit": "Msamples/s", "cores": n, "kind": "reference",
-            "per_thread": round(value / n, 2), "single_thread": round(single, 2), "thread_scan": scan,
+            "per_thread": round(value / n, 2), "single_thread": round(single, 2), "thread_scan": scan, "thread_scan_over_quota": over,
             "cgroup_throttled_s": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e6, 2), "host": host,
             "sample": "%d blocks of %d CF32 IQ samples over %d pinned threads (one per physical core, spread over %d NUMA nodes; the thread "
-                      "count with the highest aggregate of the scan) in %.1f s; %d distinct blocks cycled, one ModelDefault instance per "
+                      "count <= the cgroup quota with the highest aggregate of the scan) in %.1f s; %d distinct blocks cycled, one ModelDefault instance per "
                       "thread built and fed inside its thread, in-memory" % (blocks, BLOCK, n, host["numa_nodes"], dt, nblk),
             "model": model, "sample_rate": rate,
             "note": "the container's cgroup CPU limit (host.cgroup_cpu_limit_cores), not the host's core count, bounds the aggregate; "
@@ -326,7 +332,7 @@ def pmc_traffic_pass(config, receivers):
     if not shutil.which("rocprofv3"):
         return None
     tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
-    vals = {}
+    vals, per_kernel = {}, {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
@@ -344,8 +350,19 @@ def pmc_traffic_pass(config, receivers):
             r = c.execute("select sum(value), count(distinct dispatch_id) from counters_collection where kernel_name like '%k1_dpp%' and counter_name=?",
                           (counter,)).fetchone()
             vals[counter] = r[0] / r[1]
+            # the whole step: every kernel of the library (one launch of each per step; the derotation / FIR kernel's four template
+            # instances take turns), summed and divided by the number of steps = launches of the front-end kernel
+            per_kernel[counter] = {}
+            for name, v in c.execute("select kernel_name, sum(value) from counters_collection where kernel_name like '%aisk::%' and counter_name=? "
+                                     "group by kernel_name", (counter,)).fetchall():
+                short = name.split("aisk::")[1].split("(")[0].split("<")[0]
+                per_kernel[counter][short] = per_kernel[counter].get(short, 0.0) + v / r[1]
+        step = {k: per_kernel["FETCH_SIZE"].get(k, 0.0) * 1024 * 2 + per_kernel["WRITE_SIZE"].get(k, 0.0) * 1024
+                for k in set(per_kernel["FETCH_SIZE"]) | set(per_kernel["WRITE_SIZE"])}
         return {"fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"],
                 "hbm_bytes_per_launch": vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024, "host": socket.gethostname(),
+                "step_bytes": sum(step.values()), "step_bytes_by_kernel": {k: round(v) for k, v in sorted(step.items(), key=lambda kv: -kv[1])},
+                "step_read_bytes": sum(per_kernel["FETCH_SIZE"].values()) * 1024 * 2, "step_written_bytes": sum(per_kernel["WRITE_SIZE"].values()) * 1024,
                 "note": "this session: separate rocprofv3 --pmc passes (serial mode, 3 launches each); FETCH_SIZE doubled per MI355X_MICROARCH.md"}
     except Exception:
         return None
@@ -555,7 +572,7 @@ def main():
     # HBM-side bytes per launch of the same kernel come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs:
     # tools/pmc_traffic.sh).  `traffic` is filled only from a measurement of THIS session (BENCH_TRAFFIC_JSON = the file that
     # script just wrote on this box); otherwise it is null and `traffic_reference` names the committed profile.
-    traffic = traffic_bytes = traffic_src = None
+    traffic = traffic_bytes = traffic_src = step_bytes = None
     tpath = os.environ.get("BENCH_TRAFFIC_JSON")
     if tpath and os.path.exists(tpath) and R == 256 and args.config == 4 and k1_ms > 0:
         tj = json.load(open(tpath))
@@ -568,6 +585,7 @@ def main():
             traffic_bytes = tj["hbm_bytes_per_launch"]
             traffic = round(traffic_bytes / (k1_ms * 1e-3) / 1e9, 1)
             traffic_src = tj
+            step_bytes = tj.get("step_bytes")
     ref_profile = None
     for cand in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         if args.config == 4 and cand.startswith("r0") and cand.endswith("pmc_traffic_k1.json"):
@@ -595,6 +613,9 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_over_algorithmic": round(traffic_bytes / (samples_per_step * algo_bytes), 3) if traffic_bytes else None,
                      "traffic_bytes_per_launch": traffic_bytes, "traffic_source": traffic_src, "traffic_reference": ref_profile,
+                     # all kernels of a step (front end, phasor recurrence, derotation / FIR, PhaseSearch, assemble), same PMC passes
+                     "step_traffic_bytes": step_bytes,
+                     "step_traffic_over_algorithmic": round(step_bytes / (samples_per_step * algo_bytes), 3) if step_bytes else None,
                      "algorithmic_bytes_per_launch": samples_per_step * algo_bytes,
                      "kernel": C["kernel"], "avg_launch_ms": round(k1_ms, 4), "launches": k1_n,
                      # the same algorithmic bytes over the whole step (all kernels of the chain, wall clock / steps)

@@ -63,8 +63,15 @@ namespace AIS
 
 	void GpuPool::release(Group *g, int rx)
 	{
+		// leave() may run a whole block (aisgpu_run + aisgpu_sync_outputs): not under the pool's lock, which every other receiver's
+		// reserve() / open() / release() takes.  The batch pointer cannot go away meanwhile: this receiver still counts in users.
+		aisamd::GpuBatch *b;
+		{
+			std::lock_guard<std::mutex> l(mtx);
+			b = g->batch;
+		}
+		if (b) b->leave(rx);
 		std::lock_guard<std::mutex> l(mtx);
-		if (g->batch) g->batch->leave(rx);
 		if (--g->users == 0)
 		{
 			delete g->batch;
@@ -197,12 +204,10 @@ namespace AIS
 		if (nsub == 0) return;
 		if (cfg.flags & AISGPU_FLAG_GPU_DECODE)
 		{ // the decoders' state machines ran on the device: only completed frames come back, each to the tail of ITS decoder
-			const aisgpu_frame *fr = nullptr;
-			int nf = 0;
-			if (batch->frames(&fr, &nf) != AISGPU_OK) { failed = true; return; }
-			for (int i = 0; i < nf; i++)
+			const auto frames = batch->frames(); // (this generation's list, valid for as long as this reference lives)
+			for (size_t i = 0; i < frames->size(); i++)
 			{
-				const aisgpu_frame &f = fr[i];
+				const aisgpu_frame &f = (*frames)[i];
 				if (f.rx != rx || f.sub >= nsub) continue;
 				aisgpu_out o;
 				if (batch->fetch(f.sub, rx, f.ch, &o) != AISGPU_OK) { failed = true; return; }

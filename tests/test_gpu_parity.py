@@ -930,11 +930,12 @@ def test_fused_backend_edge_inputs_and_boxcar():
 @pytest.mark.parametrize("tps,env", [(16, None), (32, None), (48, None), (0, "0"), (24, None)])
 def test_spectral_analysis_at_the_end_of_the_front_end_waves(tps, env, monkeypatch):
     """The FFT of SquareFreqOffsetCorrection rides in the front-end kernel when a span is a whole number of 512-sample windows
-    (16 tiles): one, two or three windows per channel and span; AISGPU_FFT_K1=0 / spans of 24 tiles use the FFT kernel.
+    (16 tiles): one, two or three windows per channel and span; AISGPU_FFT_IN_K1=0 (option fft_in_k1) / spans of 24 tiles use
+    the FFT and search kernels.
     ppm (i.e. every window's peak search), hard bits and levels must not change by a bit, on pure and pre-decimated ladders
     and on integer input."""
     if env is not None:
-        monkeypatch.setenv("AISGPU_FFT_K1", env)
+        monkeypatch.setenv("AISGPU_FFT_IN_K1", env)
     kw = {"tiles_per_span": tps} if tps else {}
     xs = [synth.receiver_stream(98304 * 4, receiver_id=120 + r, gap_slots=(0, 2)) for r in range(3)]
     _run_outputs_vs_oracle(xs, 1536000, "cf32", 98304, 4, **kw)       # 96 tiles per block

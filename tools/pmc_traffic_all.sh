@@ -17,12 +17,13 @@ def per_launch(db, counter):
 f = per_launch("/tmp/pmc_all_FETCH_SIZE/p_results.db", "FETCH_SIZE")
 w = per_launch("/tmp/pmc_all_WRITE_SIZE/p_results.db", "WRITE_SIZE")
 print("%-58s %8s %14s %14s" % ("kernel", "launches", "read MB (x2)", "written MB"))
+steps = max(v[1] for k, v in f.items() if "k1_dpp" in k)   # one launch of the front end per step
 tr = tw = 0.0
 for k in sorted(f, key=lambda k: -(f[k][0] * 2 + w.get(k, (0, 0))[0])):
     rd, wr = f[k][0] * 2 * 1024 / 1e6, w.get(k, (0, 0))[0] * 1024 / 1e6
     print("%-58s %8d %14.1f %14.1f" % (k.split("aisk::")[1].split("(")[0][:58], f[k][1], rd, wr))
-    if "k3_derot_fir" in k and "<0>" not in k:
-        continue  # the four instantiations alternate: count one launch per step
-    tr += rd; tw += wr
-print("per step (one launch of each kernel): read %.1f MB, written %.1f MB" % (tr, tw))
+    # per step: a kernel's total over the run divided by the number of steps (the template instances of the derotation / FIR
+    # kernel take turns: each has fewer launches than there are steps, together one per step)
+    tr += rd * f[k][1] / steps; tw += wr * w.get(k, (0, f[k][1]))[1] / steps
+print("per step (every kernel's bytes over the run / %d steps): read %.1f MB, written %.1f MB, together %.1f MB" % (steps, tr, tw, tr + tw))
 PY
