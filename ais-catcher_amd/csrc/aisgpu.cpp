@@ -222,12 +222,9 @@ struct aisgpu {
 	bool ps_box = false; PsBoxState* d_box[2] = {}; // Demod::PhaseSearch (boxcar) instead of PhaseSearchEMA
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
-#ifndef AISGPU_GL
-#define AISGPU_GL 40
-#endif
-	bool fused = false; int GL = AISGPU_GL; // groups per segment of the derotation / FIR kernel (multiple of 8)
+	bool fused = false; // derotation + FIR + ScatterPLL as one kernel behind the checkpointed phasor recurrence (the default)
 	struct { bool valid = false; int q = 0, pb = 0, lv = 0, n_groups = 0, n_rel0 = 0, S = 0; long long g0 = 0; unsigned block = 0, sub = 0; } fpend;
-	float2 *d_ck[NBUF] = {}, *d_ckw[NBUF] = {}, *d_dfhist[2] = {};
+	float2 *d_ck[NBUF] = {}, *d_dfhist[2] = {};
 	int* d_qflag4 = nullptr; // [2][n_chains / 4] fallback flags of the row PhaseSearch kernels
 	// per-kernel geometry
 	int tile_in = 0, tiles_per_block = 0, tiles_per_span = 0, spans = 0;         // fused front end (its own input)
@@ -593,17 +590,22 @@ int enqueue_fused_back(aisgpu_t* h) {
 	const int q = h->fpend.q, pb = h->fpend.pb, lv = h->fpend.lv, n_groups = h->fpend.n_groups;
 	const long long g0 = h->fpend.g0;
 	K6Params k6;
-	k6.c48 = h->d_c48[q]; k6.c48_stride = h->c48s; k6.ck = h->d_ck[q]; k6.ckw = h->d_ckw[q]; k6.ck_stride = (h->n_chan + 63) / 64 * 64;
+	k6.c48 = h->d_c48[q]; k6.c48_stride = h->c48s; k6.ck = h->d_ck[q]; k6.ck_stride = (h->n_chan + 63) / 64 * 64;
 	k6.step_table = h->d_step; k6.fz = h->d_fz[q];
 	k6.hist_in = h->d_dfhist[pb ^ 1]; k6.hist_out = h->d_dfhist[pb];
 	k6.sym = h->d_sym[pb]; k6.sym_stride = h->Gcap; k6.lvl = h->d_lvl[lv];
 	memcpy(k6.taps, TAPS_COHERENT, sizeof k6.taps);
 	k6.first_group = g0; k6.n_rel0 = h->fpend.n_rel0; k6.n_groups = n_groups; k6.L = h->L; k6.n_windows = h->W; k6.n_chan = h->n_chan;
-	k6.GL = h->GL; k6.S = h->fpend.S;
 	WAITEV(h->s4, h->ev_phasor[q]);
 	WAITEV(h->s4, h->ev_sym[pb]); // sym[pb] was last read by PhaseSearch of block f-2,
 	WAITEV(h->s4, h->ev_ema[lv]); // lvl[lv] by the frame decoder / the copies of block f-4
 	if (h->challenger) { k6.cgf = h->d_cgf + CGF_HIST; k6.cgf_stride = CGF_HIST + h->L; }
+	{
+		K2Params k2r = make_k2(h, q);
+		k2r.ck = h->d_ck[q]; k2r.ck_stride = k6.ck_stride;
+		TraceScope t(h, "refine", h->s4);
+		HIPCHK(launch_k2b_refine(k2r, h->n_chan, h->s4));
+	}
 	{ TraceScope t(h, "derotfir", h->s4); HIPCHK(launch_k6(k6, h->s4)); }
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s4));
 	if (h->challenger) { // FM branch on the derotated samples the kernel above stored on its way (Model.cpp:638-639)
@@ -633,9 +635,7 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	K2Params k2 = make_k2(h, q);
 	const long long g0 = h->n48 / 5, g1 = (h->n48 + h->L) / 5; // groups completed inside this block (DSP/DSP.h:95-117)
 	const int n_groups = (int)(g1 - g0), n_rel0 = (int)(g0 * 5 - h->n48);
-	const int S = (n_groups + h->GL - 1) / h->GL;
-	k2.ck = h->d_ck[q]; k2.ckw = h->d_ckw[q]; k2.ck_stride = k2.rotT_stride;
-	k2.ck_first = n_rel0 - 20; k2.ck_period = 5 * h->GL; k2.n_ck = S;
+	k2.ck = h->d_ck[q]; k2.ck_stride = k2.rotT_stride;
 	if (h->fft_in_k1) {
 		// the front-end waves have done the whole analysis (k1_fft_tail): fz / ppm of this block are there when K1 is
 		if (!h->k1_done[q]) { HIPCHK(hipEventRecord(h->ev_search[q], h->stream)); h->k1_done[q] = h->ev_search[q]; }
@@ -651,7 +651,7 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
 
 	h->fpend.valid = true; h->fpend.q = q; h->fpend.pb = pb; h->fpend.lv = lv; h->fpend.g0 = g0; h->fpend.n_groups = n_groups;
-	h->fpend.n_rel0 = n_rel0; h->fpend.S = S; h->fpend.block = (unsigned)h->block_idx; h->fpend.sub = (unsigned)h->n_sub;
+	h->fpend.n_rel0 = n_rel0; h->fpend.block = (unsigned)h->block_idx; h->fpend.sub = (unsigned)h->n_sub;
 	if (h->n_sub < MAXSUB) {
 		SubOut& so = h->sub[h->n_sub++];
 		so.pb = pb; so.lv = lv; so.q = q; so.groups = n_groups; so.first_group = g0; so.first48 = h->n48;
@@ -1309,11 +1309,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		} else h->fft_in_k1 = false;
 	}
 	if (h->fused) {
-		const size_t cs = (C + 63) / 64 * 64;
-		for (int i = 0; i < NBUF; i++) {
-			HIPCHK(dalloc(&h->d_ck[i], (size_t)(h->Gcap / h->GL + 2) * cs));
-			HIPCHK(dalloc(&h->d_ckw[i], (size_t)h->W * cs));
-		}
+		for (int i = 0; i < NBUF; i++) HIPCHK(dalloc(&h->d_ck[i], (C + 63) / 64 * 64 * (size_t)h->W * CK_SLOTS)); // phasor checkpoints per (window, slot, chain)
 		for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_dfhist[i], C * DF_HIST)); // zero = silence before the stream
 	}
 	for (int i = 0; i < NBUF; i++) {
@@ -1415,7 +1411,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	if (h->h_c48) hipHostFree(h->h_c48);
 	hipFree(h->d_v2hist); hipFree(h->d_v2f); hipFree(h->d_v2prom); hipFree(h->d_v2en);
 	if (h->h_v2f) hipHostFree(h->h_v2f); if (h->h_v2prom) hipHostFree(h->h_v2prom); if (h->h_v2en) hipHostFree(h->h_v2en);
-	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); hipFree(h->d_ckw[i]); }
+	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); }
 	hipFree(h->d_qflag4);
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
 	hipFree(h->d_box[0]); hipFree(h->d_box[1]);

@@ -86,18 +86,19 @@ struct K2Params {
 	float2* rot_state;        // [n_chan]
 	float2* rotT; long long rotT_stride; // [L][rotT_stride] derotation phasor per sample, time-major
 	int n_windows, wide, n_chan;
-	// checkpointed recurrence (k2_cgf_phasor_ck): state BEFORE sample ck_first + s * ck_period for s = 1..n_ck-1, block start for s = 0
-	float2* ck; long long ck_stride; // [n_ck][ck_stride]
-	float2* ckw;                     // [n_windows][ck_stride] state at every window start
-	int ck_first, ck_period, n_ck;
+	// checkpointed recurrence (k2_cgf_phasor_ck): per (chain, window) CK_SLOTS entries, entry i = the state BEFORE sample
+	// 512 w + CK_SEG i of the block (i = 0: the window's start, after the renormalisation), CK_USED of them written
+	float2* ck; long long ck_stride; // [n_windows][CK_SLOTS][ck_stride]: time-major, chains padded to 64
 };
 
-// Fused derotation + FilterComplex(Coherent) + ScatterPLL (k3_derot_fir): one wave = 64 chains x one time segment
+// Fused derotation + FilterComplex(Coherent) + ScatterPLL (k6_window_fir): one wave = one chain x one 512-sample window, lanes over
+// time.  The recurrence kernel leaves its state every CK_SEG samples of every window, so lane i restarts it for its own nine
+// samples: the derotated window goes through LDS, the lanes then own one ScatterPLL group each.
 constexpr int DF_HIST = 24; // derotated samples carried from block to block (17-tap history + a partial group)
+constexpr int CK_SEG = 9, CK_USED = 57, CK_SLOTS = 64; // 56 segments of nine samples and one of eight per window
 struct K6Params {
 	const float2* c48; long long c48_stride;
-	const float2* ck; long long ck_stride;       // phasor checkpoints, segment-major
-	const float2* ckw;                           // ... and at every window start (renormalised)
+	const float2* ck; long long ck_stride;       // phasor checkpoints [n_windows][CK_SLOTS][ck_stride]
 	const float2* step_table; const int* fz;     // fz[chain][n_windows]
 	const float2* hist_in; float2* hist_out;     // [n_chan][DF_HIST]
 	float2* sym; long long sym_stride;           // SymRow layout, sym_stride = group capacity (also the row pitch of lvl)
@@ -106,7 +107,7 @@ struct K6Params {
 	float taps[17];
 	long long first_group;
 	int n_rel0;                                   // first_group * 5 - first_sample48, in [-4, 0]
-	int n_groups, L, n_windows, n_chan, GL, S;    // GL groups per segment (multiple of 8), S segments
+	int n_groups, L, n_windows, n_chan;
 };
 
 struct K3Params {
@@ -119,26 +120,19 @@ struct K3Params {
 	int n_groups;
 };
 
-// Layout of the FIR / ScatterPLL output `sym` (what PhaseSearch consumes), in float2 elements:
-//   [n_chan / 64][groups / 4][phase 5][quad 16][pair 2][channel of the quad 4][symbol of the pair 2]
-// i.e. per (64 channels, 4 groups, phase) a 2 KiB slab in which the two symbol pairs of the four ADJACENT channels of a quad
-// are 128 contiguous bytes.  Both sides see whole lines: the derotation / FIR kernel has one lane per channel and writes a
-// body's two pairs with two 16-byte stores per lane, which fill the quads' lines back to back (64-byte runs per instruction,
-// never the scattered 16-byte pieces that cost the front end 0.05 ms per launch in round 1); a PhaseSearch wave = one phase
-// of one quad, and each of its fetches covers whole 128-byte lines (round 1's [groups / 2][5][64 channels] made it fetch
-// every line twice, half used: 244 MB read for 126 MB of data).
-constexpr int SYM_SLAB = 5 * 256; // float2 elements from group g to group g + 4 of a row
-__host__ __device__ inline size_t sym_row_base(int chan, int j, long long gcap) {
-	return ((size_t)(chan >> 6) * (size_t)(gcap >> 2) * 5 + (size_t)j) * 256 + (size_t)((chan & 63) >> 2) * 16 + (size_t)(chan & 3) * 2;
-}
-__host__ __device__ inline size_t sym_offset(int g) { return (size_t)(g >> 2) * SYM_SLAB + (size_t)((g >> 1) & 1) * 8 + (size_t)(g & 1); }
-__host__ __device__ inline size_t sym_elems(int n_chan, long long gcap) { return (size_t)((n_chan + 63) / 64) * 64 * 5 * (size_t)gcap; }
-// one (channel, phase) row: element g at base[sym_offset(g)]
+// Layout of the FIR / ScatterPLL output `sym` (what PhaseSearch consumes): one row of `gcap` float2 per (channel, sampling phase),
+// group g at element g.  Both sides see whole lines: the derotation / FIR kernel has its lanes over the groups of ONE channel's
+// window (64 lanes x 8 bytes = 512 contiguous bytes per phase and store), a PhaseSearch row fetches 16 consecutive symbols of its
+// chain (128 bytes) per lane group.  (Rounds 1-3 had one lane per CHANNEL in the producer and a layout interleaved over 64
+// channels for it.)
+__host__ __device__ inline size_t sym_row_base(int chan, int j, long long gcap) { return ((size_t)chan * 5 + (size_t)j) * (size_t)gcap; }
+__host__ __device__ inline size_t sym_offset(int g) { return (size_t)g; }
+__host__ __device__ inline size_t sym_elems(int n_chan, long long gcap) { return (size_t)n_chan * 5 * (size_t)gcap; }
+// one (channel, phase) row: element g at base[g]
 struct SymRow {
 	const float2* base;
-	__host__ __device__ SymRow(const float2* sym, int chain /* chan * 5 + j */, long long gcap) : base(sym + sym_row_base(chain / 5, chain % 5, gcap)) {}
-	__host__ __device__ float2 operator[](int g) const { return base[sym_offset(g)]; }
-	__host__ __device__ const float4* pair(int g) const { return reinterpret_cast<const float4*>(base + sym_offset(g)); } // g even
+	__host__ __device__ SymRow(const float2* sym, int chain /* chan * 5 + j */, long long gcap) : base(sym + (size_t)chain * (size_t)gcap) {}
+	__host__ __device__ float2 operator[](int g) const { return base[g]; }
 };
 
 struct EmaState { float ma[16]; unsigned bits[16]; int max_idx, rot; int pad[2]; };
@@ -295,7 +289,8 @@ hipError_t launch_selftest_hypot(const float2* in, int n, unsigned* mismatches, 
 hipError_t launch_k2b(const K2Params& p, int n_chan, hipStream_t s); // phasor recurrence
 hipError_t launch_k2c(const K2Params& p, int n_chan, hipStream_t s); // history carry + apply
 hipError_t launch_k3(const K3Params& p, int n_chan, hipStream_t s);
-hipError_t launch_k2b_ck(const K2Params& p, int n_chan, hipStream_t s); // phasor recurrence, checkpoints only
+hipError_t launch_k2b_ck(const K2Params& p, int n_chan, hipStream_t s); // phasor recurrence, the state at every window start only
+hipError_t launch_k2b_refine(const K2Params& p, int n_chan, hipStream_t s); // ... and from there the checkpoints inside the windows (in front of launch_k6, any stream)
 hipError_t launch_k6(const K6Params& p, hipStream_t s);
 struct K5Params { // ModelChallenger FM branch (Model.cpp:638-639): Demod::FM -> Filter(Receiver, 37 taps) -> sign
 	const float2* x; long long x_stride; long long x_off; // input rows: sample n of the block at x[chan * x_stride + x_off + n]

@@ -1180,9 +1180,11 @@ __global__ __launch_bounds__(64) void k2_cgf_phasor(K2Params p) {
 	if (live) p.rot_state[chan] = make_float2(cur.x, cur.y);
 }
 
-// The same recurrence without the per-sample stores: only its state at the start of every time segment of the
-// fused derotation/FIR kernel is kept (K6 recomputes the 200-odd steps of a segment, 64 chains per wave, all
-// segments in parallel).  3 packed VALU ops per step and nothing else.
+// The same recurrence without the per-sample stores: only its state at the start of every window is kept (after the
+// renormalisation).  3 packed VALU ops per step and nothing else -- in particular no store per few steps: beside the front end a
+// store is acknowledged after ~20 us, a wave may have 63 memory operations outstanding, and 57 checkpoints per 4.8 us window
+// stalled the recurrence at that limit (0.32 -> 0.45 ms beside the front end, the pipeline's longest chain).  The checkpoints
+// inside the windows are k2_cgf_refine's.
 __global__ __launch_bounds__(64) void k2_cgf_phasor_ck(K2Params p) {
 	const int lane = threadIdx.x;
 	const int chan_raw = blockIdx.x * 64 + lane;
@@ -1191,10 +1193,7 @@ __global__ __launch_bounds__(64) void k2_cgf_phasor_ck(K2Params p) {
 	__builtin_amdgcn_s_setprio(3);
 	const float2 r0 = p.rot_state[chan];
 	v2f cur = { r0.x, r0.y };
-	float2* const ck = p.ck + (size_t)blockIdx.x * 64 + lane; // padded columns exist for dead lanes
-	ck[0] = r0;
-	int s = 1, next_ck = p.ck_first + p.ck_period, n = 0;
-	float2* const ckw = p.ckw + (size_t)blockIdx.x * 64 + lane;
+	float2* const ckw = p.ck + (size_t)blockIdx.x * 64 + lane; // slot 0 of every window; padded columns exist for dead lanes
 	// A window's step is two dependent loads (the window's frequency bin, then the table entry): fetched where they are needed they
 	// were two memory round trips in front of every window's 512 steps -- 48 times a few microseconds next to the front end, a
 	// third of the kernel.  The bin is requested two windows ahead and the table entry one window ahead.
@@ -1206,20 +1205,9 @@ __global__ __launch_bounds__(64) void k2_cgf_phasor_ck(K2Params p) {
 		stp_next = p.step_table[fz_next + 205];
 		fz_next = fzrow[w + 2 < p.n_windows ? w + 2 : p.n_windows - 1];
 		const v2f st = { stp.x, stp.y }, st_sw = { -stp.y, stp.x };
-		const int wend = (w + 1) * 512;
-		ckw[(size_t)w * p.ck_stride] = make_float2(cur.x, cur.y); // state at the window start (after the renormalisation)
-		while (n < wend) {
-			if (s < p.n_ck && next_ck == n) { // wave-uniform
-				ck[(size_t)s * p.ck_stride] = make_float2(cur.x, cur.y);
-				s++;
-				next_ck += p.ck_period;
-			}
-			const int stop = (s < p.n_ck && next_ck < wend) ? next_ck : wend;
-			const int run = stop - n;
+		ckw[(size_t)w * CK_SLOTS * p.ck_stride] = make_float2(cur.x, cur.y); // state at the window start (after the renormalisation)
 #pragma unroll 8
-			for (int k = 0; k < run; k++) cur = cur.xx * st + cur.yy * st_sw; // rot *= rot_step
-			n = stop;
-		}
+		for (int k = 0; k < 512; k++) cur = cur.xx * st + cur.yy * st_sw; // rot *= rot_step
 		const float a = hypot_ref(cur.x, cur.y); // rot /= std::abs(rot), once per window (DSP.cpp:465)
 		cur.x = __fdiv_rn(cur.x, a);
 		cur.y = __fdiv_rn(cur.y, a);
@@ -1227,15 +1215,39 @@ __global__ __launch_bounds__(64) void k2_cgf_phasor_ck(K2Params p) {
 	if (live) p.rot_state[chan] = make_float2(cur.x, cur.y);
 }
 
+// The recurrence once more inside every window, all windows in parallel (one lane per (chain, window), 64 chains of one window
+// per wave): from the window's start state, its state in front of every CK_SEG-th sample -- what lane i of k6_window_fir restarts
+// from.  Time-major: a store is 512 contiguous bytes.  384 short waves; the stores of a wave are fewer than it may have outstanding.
+__global__ __launch_bounds__(64) void k2_cgf_refine(K2Params p) {
+	const int lane = threadIdx.x, w = blockIdx.y;
+	const int chan_raw = blockIdx.x * 64 + lane;
+	const int chan = chan_raw < p.n_chan ? chan_raw : p.n_chan - 1;
+	float2* o = p.ck + (size_t)w * CK_SLOTS * p.ck_stride + (size_t)blockIdx.x * 64 + lane;
+	const float2 r0 = o[0];
+	const float2 stp = p.step_table[p.fz[(size_t)chan * p.n_windows + w] + 205];
+	v2f cur = { r0.x, r0.y };
+	const v2f st = { stp.x, stp.y }, st_sw = { -stp.y, stp.x };
+#pragma unroll 8
+	for (int i = 1; i < CK_USED; i++) {
+#pragma unroll
+		for (int k = 0; k < CK_SEG; k++) cur = cur.xx * st + cur.yy * st_sw; // rot *= rot_step
+		o[(size_t)i * p.ck_stride] = make_float2(cur.x, cur.y);
+	}
+}
+
 // ------------------------------------------------------------------------------------------
 // K6: output[i] *= rot (DSP.cpp:457-466) + FilterComplex(Filters::Coherent) + ScatterPLL (DSP.cpp:215-246,
 // DSP.h:95-117) in one pass, without the phasor array and without the derotated-sample array in HBM.
-// One wave = 64 chains (one per lane) x one time segment of GL ScatterPLL groups: it restarts the recurrence
-// from the segment's checkpoint, 20 samples early (FIR history), and walks the segment sample by sample --
-// everything that depends on time (window boundaries, renormalisation, group phase, the (1j)^n pre-rotation of
-// PhaseSearchEMA) is wave-uniform.  Each lane reads its own chain's row sequentially (whole cache lines per
-// lane) and keeps the last 20 derotated samples in registers; the outputs of 4 groups are written together
-// (32 contiguous bytes per lane and symbol phase).  Arithmetic per sample is exactly K2b/K2c/K3's.
+// One wave = ONE chain x one 512-sample window, lanes over time (round 4; rounds 1-3 had one lane per chain walking a segment
+// with 20 samples of history in registers: 178 VGPRs, which never fitted beside three front-end waves and displaced one).
+//  * lane i < 60 owns nine consecutive samples: it restarts the recurrence from the checkpoint in front of them (lanes 0..2: the
+//    last three segments of the previous window, the FIR's history; in the block's first window the previous block's carried
+//    samples instead), derotates them and leaves them in LDS -- every sample's arithmetic is exactly K2b/K2c's;
+//  * a lane then owns one ScatterPLL group (two rounds: a window completes 102 or 103 groups): 21 derotated samples out of LDS,
+//    the five 17-tap sums each left to right from 0 (DSP.h:224-230), the level, the (1j)^n pre-rotation of PhaseSearchEMA; the
+//    groups of a window are consecutive elements of the channel's five rows: 512 contiguous bytes per store.
+// The groups of window w are those whose LAST sample lies in it.  Workgroup ids put a channel's windows on one XCD, one behind the
+// other (the rows' lines that two windows share meet in that L2).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ c2 pk_sub_add(c2 a, c2 b) { // (a.x - b.x, a.y + b.y) in one packed add (x - y == x + (-y) exactly)
 	c2 r;
@@ -1243,136 +1255,78 @@ __device__ __forceinline__ c2 pk_sub_add(c2 a, c2 b) { // (a.x - b.x, a.y + b.y)
 	return r;
 }
 
-// R0 = first_group & 3: the (1j)^n pre-rotation pattern of the 4 groups of a body is the same for the whole launch
-// (segments and bodies start at multiples of 4 groups)
+constexpr int K6_HALO = 3 * CK_SEG - 1; // derotated samples in front of the window: segments 54..56 of the previous one (26; 20 are needed)
 #ifndef K6_WAVES
-#define K6_WAVES 2
+#define K6_WAVES 8
 #endif
-// CGF: the derotated samples are stored as well (ModelChallenger: its FM branch demodulates them, Model.cpp:638-639) -- every sample
-// once, by the segment whose FIR outputs begin with it.
-template <int R0, bool CGF>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6_WAVES))) void k3_derot_fir(K6Params p) {
-	const int lane = threadIdx.x, s = blockIdx.x;
-	const int chain_raw = blockIdx.y * 64 + lane;
-	const bool live = chain_raw < p.n_chan;
-	const int chain = live ? chain_raw : p.n_chan - 1;
-	const int ga = s * p.GL;
-	const int gb = ga + p.GL < p.n_groups ? ga + p.GL : p.n_groups;
-	const bool last = s == p.S - 1;
-	const int a = p.n_rel0 + 5 * ga;                 // first sample that has a FIR output here
-	const int e = last ? p.L : p.n_rel0 + 5 * gb;    // one past the last sample to derotate
-	// wave-uniform base pointers + a 32-bit per-lane element offset (SGPR base / VGPR offset addressing)
-	const unsigned xoff = (unsigned)chain * (unsigned)p.c48_stride, hoff = (unsigned)chain * DF_HIST;
-	const unsigned ckoff = (unsigned)(blockIdx.y * 64 + lane);
-	const unsigned cgoff = CGF ? (unsigned)chain * (unsigned)p.cgf_stride : 0u;
-	const float2* hin = p.hist_in + DF_HIST;              // hin[n][hoff], n in [-DF_HIST, 0)
-	float2* hout = p.hist_out - (p.L - DF_HIST);          // hout[n][hoff], n in [L - DF_HIST, L)
-	const int* fzrow = p.fz + (size_t)chain * p.n_windows;
-	const float2 r0 = (p.ck + (size_t)s * p.ck_stride)[ckoff];
-	c2 rot = { r0.x, r0.y }, st = { 0.f, 0.f }, st_sw = { 0.f, 0.f };
-	const auto load_step = [&](int w) {
-		const float2 stp = p.step_table[fzrow[w] + 205];
-		st = c2{ stp.x, stp.y }; st_sw = c2{ -stp.y, stp.x };
-	};
-	int n = a - 20;
-	load_step((n > 0 ? n : 0) >> 9);
-	// derotated sample n (wave-uniform n); advances the recurrence.  The once-per-window renormalisation
-	// rot /= |rot| is not redone here: the recurrence kernel left the renormalised state of every window start.
-	// PLAIN: the caller guarantees 0 <= n, no window start and no block-tail store (straight-line code, so the
-	// loads of a whole body can be issued together)
-	const auto derotate = [&](float2 d) -> c2 {
-		rot = rot.xx * st + rot.yy * st_sw; // rot *= rot_step
-		return pk_sub_add(rot * d.x, rot.yx * d.y); // data * rot = (d.x r.x - d.y r.y, d.x r.y + d.y r.x)
-	};
-	const auto next_sample = [&](int nn) -> c2 {
-		if (nn < 0) { const float2 d = (hin + nn)[hoff]; return c2{ d.x, d.y }; } // the previous block's tail
-		if ((nn & 511) == 0 && nn < p.L) {
-			load_step(nn >> 9);
-			const float2 r = (p.ckw + (size_t)(nn >> 9) * p.ck_stride)[ckoff];
-			rot = c2{ r.x, r.y };
-		}
-		const c2 y = derotate((p.c48 + nn)[xoff]);
-		if (last && nn >= p.L - DF_HIST && nn < p.L && live) (hout + nn)[hoff] = make_float2(y.x, y.y);
-		if (CGF && nn >= a && nn < e && live) (p.cgf + nn)[cgoff] = make_float2(y.x, y.y);
-		return y;
-	};
-	c2 y[20];
+// CGF: the derotated samples are stored as well (ModelChallenger: its FM branch demodulates them, Model.cpp:638-639)
+template <bool CGF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6_WAVES))) void k6_window_fir(K6Params p) {
+	__shared__ __attribute__((aligned(16))) float2 ybuf[K6_HALO + 512 + 6];
+	const int lane = threadIdx.x;
+	const int W = p.n_windows;
+	// id = (((chain / 64) W + w) 8 + chain % 8) 8 + (chain / 8) % 8: the XCD (id % 8) depends on the chain alone, a chain's windows are
+	// 64 ids apart, and the eight chains that share a 64-byte run of the time-major checkpoints are neighbours on one XCD
+	const int t = blockIdx.x >> 6, w = t % W, chain = (t / W) * 64 + (blockIdx.x & 7) * 8 + ((blockIdx.x >> 3) & 7);
+	if (chain >= p.n_chan) return;
+	const float2* xrow = p.c48 + (size_t)chain * p.c48_stride;
+	// ---- derotation: lane -> segment (lanes 0..2: the previous window's last three)
+	{
+		const int seg = lane - 3;
+		const int ws = seg >= 0 ? w : w - 1, si = seg >= 0 ? seg : CK_USED + seg;
+		if (lane < CK_USED + 3 && ws >= 0) {
+			const int n0 = ws * 512 + si * CK_SEG;
+			const float2 r0 = p.ck[((size_t)ws * CK_SLOTS + si) * p.ck_stride + chain];
+			const float2 stp = p.step_table[p.fz[(size_t)chain * W + ws] + 205];
+			float2 d[CK_SEG];
 #pragma unroll
-	for (int m = 0; m < 20; m++) y[m] = next_sample(n + m);
-	n += 20;
-	for (int g = ga; n < e; g += 4, n += 20) {
-		c2 out[5][4];
-		float lv[4];
-		// FIR + ScatterPLL of the 4 groups whose 20 derotated samples are produced by `sample(m)`
-		const auto body = [&](auto sample) {
+			for (int m = 0; m < CK_SEG; m++) d[m] = xrow[n0 + m]; // (segment 56: the ninth is the next window's first sample, unused)
+			c2 rot = { r0.x, r0.y };
+			const c2 st = { stp.x, stp.y }, st_sw = { -stp.y, stp.x };
+			float2* y = ybuf + K6_HALO + (n0 - w * 512);
 #pragma unroll
-			for (int gi = 0; gi < 4; gi++) {
-				c2 yn[5]; // the group's own samples; y[] keeps the 20 before them until the group is done
-#pragma unroll
-				for (int j = 0; j < 5; j++) yn[j] = sample(gi * 5 + j);
-				// the five 17-tap sums of the group advance together, tap by tap (each one left to right from 0, DSP.h:224-230)
-				c2 acc[5];
-#pragma unroll
-				for (int j = 0; j < 5; j++) acc[j] = c2{ 0.0f, 0.0f };
-#pragma unroll
-				for (int i = 0; i < 17; i++) {
-#pragma unroll
-					for (int j = 0; j < 5; j++) {
-						const int k = j - 16 + i; // sample index relative to the group's first sample
-						acc[j] = acc[j] + (k >= 0 ? yn[k < 5 ? k : 0] : y[(gi * 5 + k + 20) % 20]) * p.taps[i];
-					}
-				}
-#pragma unroll
-				for (int j = 0; j < 5; j++) y[gi * 5 + j] = yn[j];
-				float level = 0.0f;
-				// PhaseSearchEMA multiplies symbol n of a chain by (1j)^(n & 3) with swaps/negations (Demod.cpp:44-61);
-				// every chain has consumed exactly first_group + g symbols, so that exact rotation is applied here
-				const int rsel = (R0 + gi) & 3; // compile-time after unrolling
-#pragma unroll
-				for (int j = 0; j < 5; j++) {
-					level = level + (acc[j].x * acc[j].x + acc[j].y * acc[j].y); // std::norm
-					c2 sv = (rsel & 1) ? acc[j].yx : acc[j]; // rot 1: (-y, x)   rot 3: (y, -x)
-					if (rsel == 1 || rsel == 2) sv.x = -sv.x;
-					if (rsel >= 2) sv.y = -sv.y;
-					out[j][gi] = sv;
-				}
-				lv[gi] = __fdiv_rn(level, 5.0f);
-			}
-		};
-		const bool plain = n >= 0 && (n & 511) != 0 && (n & 511) + 20 <= 512 && !(last && n + 20 > p.L - DF_HIST);
-		if (plain) {
-			float2 d[20];
-			const float2* xb = p.c48 + n;
-#pragma unroll
-			for (int m = 0; m < 20; m++) d[m] = (xb + m)[xoff];
-			body([&](int m) {
-				const c2 v = derotate(d[m]);
-				if (CGF && n + m < e && live) (p.cgf + n + m)[cgoff] = make_float2(v.x, v.y);
-				return v;
-			});
-		} else {
-			body([&](int m) { return next_sample(n + m); });
-		}
-		if (live) {
-			if (g + 4 <= gb) {
-#pragma unroll
-				for (int j = 0; j < 5; j++) { // lane = channel: the body's two pairs fill the quads' 128-byte lines (SymRow layout, kernels.h)
-					float4* dst = reinterpret_cast<float4*>(p.sym + sym_row_base(chain, j, p.sym_stride) + sym_offset(g));
-#pragma unroll
-					for (int q = 0; q < 2; q++) dst[q * 4] = make_float4(out[j][2 * q].x, out[j][2 * q].y, out[j][2 * q + 1].x, out[j][2 * q + 1].y); // pair 1: 64 bytes behind pair 0
-				}
-				*reinterpret_cast<float4*>(p.lvl + (size_t)chain * p.sym_stride + g) = make_float4(lv[0], lv[1], lv[2], lv[3]);
-			} else {
-#pragma unroll
-				for (int gi = 0; gi < 4; gi++) {
-					if (g + gi < gb) {
-#pragma unroll
-						for (int j = 0; j < 5; j++) p.sym[sym_row_base(chain, j, p.sym_stride) + sym_offset(g + gi)] = make_float2(out[j][gi].x, out[j][gi].y);
-						p.lvl[(size_t)chain * p.sym_stride + g + gi] = lv[gi];
-					}
-				}
+			for (int m = 0; m < CK_SEG; m++) {
+				rot = rot.xx * st + rot.yy * st_sw;                       // rot *= rot_step
+				const c2 v = pk_sub_add(rot * d[m].x, rot.yx * d[m].y);   // data * rot = (d.x r.x - d.y r.y, d.x r.y + d.y r.x)
+				if (m < CK_SEG - 1 || si < CK_USED - 1) y[m] = make_float2(v.x, v.y);
 			}
 		}
+		if (w == 0 && lane < DF_HIST) ybuf[K6_HALO - DF_HIST + lane] = p.hist_in[(size_t)chain * DF_HIST + lane]; // the previous block's tail
+	}
+	__syncthreads(); // (one wave: ordering)
+	if (CGF) {
+		float2* out = p.cgf + (size_t)chain * p.cgf_stride + (size_t)w * 512;
+#pragma unroll
+		for (int q = 0; q < 8; q++) out[q * 64 + lane] = ybuf[K6_HALO + q * 64 + lane];
+	}
+	if (w == W - 1 && lane < DF_HIST) p.hist_out[(size_t)chain * DF_HIST + lane] = ybuf[K6_HALO + 512 - DF_HIST + lane];
+	// ---- FIR + ScatterPLL: block-local group gl covers samples n_rel0 + 5 gl .. + 4
+	const int g_lo = (w * 512 - p.n_rel0) / 5;                                              // ceil((512 w - 4 - n_rel0) / 5), numerator + 4 >= 0
+	const int g_end = w == W - 1 ? p.n_groups : min(p.n_groups, ((w + 1) * 512 - p.n_rel0) / 5);
+	const int r0sel = (int)(p.first_group & 3);
+	for (int gl = g_lo + lane; gl < g_end; gl += 64) {
+		const int a = p.n_rel0 + 5 * gl - w * 512; // the group's first sample relative to the window: -4 .. 507
+		const float2* wsrc = ybuf + K6_HALO + a - 16;
+		c2 win[21];
+#pragma unroll
+		for (int i = 0; i < 21; i++) { const float2 v = wsrc[i]; win[i] = c2{ v.x, v.y }; }
+		// PhaseSearchEMA multiplies symbol n of a chain by (1j)^(n & 3) with swaps/negations (Demod.cpp:44-61); every chain has
+		// consumed exactly first_group + gl symbols, so that exact rotation is applied here: rot 1: (-y, x)  rot 2: (-x, -y)  rot 3: (y, -x)
+		const int rsel = (r0sel + gl) & 3;
+		const unsigned nx = (rsel == 1 || rsel == 2) ? 0x80000000u : 0u, ny = rsel >= 2 ? 0x80000000u : 0u;
+		const bool swap = (rsel & 1) != 0;
+		float level = 0.0f;
+		float2* srow = p.sym + sym_row_base(chain, 0, p.sym_stride) + gl;
+#pragma unroll
+		for (int j = 0; j < 5; j++) {
+			c2 acc = { 0.0f, 0.0f };
+#pragma unroll
+			for (int i = 0; i < 17; i++) acc = acc + win[j + i] * p.taps[i];
+			level = level + (acc.x * acc.x + acc.y * acc.y); // std::norm
+			const float sx = swap ? acc.y : acc.x, sy = swap ? acc.x : acc.y;
+			srow[(size_t)j * p.sym_stride] = make_float2(__uint_as_float(__float_as_uint(sx) ^ nx), __uint_as_float(__float_as_uint(sy) ^ ny));
+		}
+		p.lvl[(size_t)chain * p.sym_stride + gl] = __fdiv_rn(level, 5.0f);
 	}
 }
 
@@ -3545,21 +3499,15 @@ hipError_t launch_k2b_ck(const K2Params& p, int n_chan, hipStream_t s) {
 	return hipGetLastError();
 }
 
+hipError_t launch_k2b_refine(const K2Params& p, int n_chan, hipStream_t s) {
+	hipLaunchKernelGGL(k2_cgf_refine, dim3((n_chan + 63) / 64, p.n_windows), dim3(64), 0, s, p);
+	return hipGetLastError();
+}
+
 hipError_t launch_k6(const K6Params& p, hipStream_t s) {
-	const dim3 grid(p.S, (p.n_chan + 63) / 64);
-	const int r0 = (int)(p.first_group & 3);
-	if (p.cgf) switch (r0) {
-		case 0: hipLaunchKernelGGL((k3_derot_fir<0, true>), grid, dim3(64), 0, s, p); break;
-		case 1: hipLaunchKernelGGL((k3_derot_fir<1, true>), grid, dim3(64), 0, s, p); break;
-		case 2: hipLaunchKernelGGL((k3_derot_fir<2, true>), grid, dim3(64), 0, s, p); break;
-		default: hipLaunchKernelGGL((k3_derot_fir<3, true>), grid, dim3(64), 0, s, p); break;
-	}
-	else switch (r0) {
-		case 0: hipLaunchKernelGGL((k3_derot_fir<0, false>), grid, dim3(64), 0, s, p); break;
-		case 1: hipLaunchKernelGGL((k3_derot_fir<1, false>), grid, dim3(64), 0, s, p); break;
-		case 2: hipLaunchKernelGGL((k3_derot_fir<2, false>), grid, dim3(64), 0, s, p); break;
-		default: hipLaunchKernelGGL((k3_derot_fir<3, false>), grid, dim3(64), 0, s, p); break;
-	}
+	const dim3 grid((unsigned)((p.n_chan + 63) / 64 * 64 * p.n_windows));
+	if (p.cgf) hipLaunchKernelGGL(k6_window_fir<true>, grid, dim3(64), 0, s, p);
+	else hipLaunchKernelGGL(k6_window_fir<false>, grid, dim3(64), 0, s, p);
 	return hipGetLastError();
 }
 
