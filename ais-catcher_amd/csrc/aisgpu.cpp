@@ -225,7 +225,6 @@ struct aisgpu {
 	bool fused = false; // derotation + FIR + ScatterPLL as one kernel behind the checkpointed phasor recurrence (the default)
 	struct { bool valid = false; int q = 0, pb = 0, lv = 0, n_groups = 0, n_rel0 = 0, S = 0; long long g0 = 0; unsigned block = 0, sub = 0; } fpend;
 	float2 *d_ck[NBUF] = {}, *d_dfhist[2] = {};
-	int* d_qflag4 = nullptr; // [2][n_chains / 4] fallback flags of the row PhaseSearch kernels
 	// per-kernel geometry
 	int tile_in = 0, tiles_per_block = 0, tiles_per_span = 0, spans = 0;         // fused front end (its own input)
 	int ptile_in = 0, ptiles_per_block = 0, ptiles_per_span = 0, pspans = 0;     // pre-decimation pass
@@ -467,11 +466,10 @@ int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned
 	K4Params k4;
 	k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[lv]; k4.bits_stride = h->words;
 	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
-	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.flag = h->d_psflag + pb; k4.fb_count = h->d_psflag + 2;
+	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.fb_count = h->d_psflag + 2;
 	k4.n_chains = h->n_chains; k4.n_groups = n_groups;
 	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
 	k4.box_in = h->d_box[pb]; k4.box_out = h->d_box[pb ^ 1]; k4.first_group = g0;
-	if (h->d_qflag4) { k4.qflag = h->d_qflag4 + (size_t)pb * ((h->n_chains + 3) / 4); k4.qflag_div = 4; } // per-workgroup fallback flags
 	if (h->ps_box) { k4.chunked = h->ps_parallel ? 1 : 0; HIPCHK(launch_k4_box(k4, s)); }
 	else if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, s));
 	else HIPCHK(launch_k4_sequential(k4, s));
@@ -1347,7 +1345,6 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	HIPCHK(dalloc(&h->d_psma1, n_ma));
 	HIPCHK(dalloc(&h->d_psfin, C * 5 * ps_chunks * 16));
 	HIPCHK(dalloc(&h->d_psflag, 4));
-	HIPCHK(dalloc(&h->d_qflag4, 2 * (size_t)((C * 5 + 3) / 4)));
 	if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_firtap, C * (8 + h->L)));
 	if (h->v2) {
 		HIPCHK(hipHostMalloc((void**)&h->h_c48, 2 * MAXSUB * C * h->L * sizeof(float2), hipHostMallocDefault)); // (two sets of slots: see out_set)
@@ -1412,7 +1409,6 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_v2hist); hipFree(h->d_v2f); hipFree(h->d_v2prom); hipFree(h->d_v2en);
 	if (h->h_v2f) hipHostFree(h->h_v2f); if (h->h_v2prom) hipHostFree(h->h_v2prom); if (h->h_v2en) hipHostFree(h->h_v2en);
 	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); }
-	hipFree(h->d_qflag4);
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);
 	hipFree(h->d_box[0]); hipFree(h->d_box[1]);
 	for (int i = 0; i < 2; i++) {

@@ -157,13 +157,10 @@ struct K4Params {
 	float* ma_start;   // [16] EMA after the warm-up (speculative), chunk > 0
 	float* ma_fin;     // [16] EMA at the end of the chunk
 	unsigned* fin;     // [16] low 4 bits: final max_idx per start index; bits 4..7: last four decisions of hypothesis k
-	int* flag;         // != 0: a speculative warm-up did not reproduce the sequential EMA -> exact fallback runs
 	int n_chains, n_groups, n_chunks, warm;
 	int chunked = 1;   // boxcar variant: 0 = the sequential row kernel (one-chunk blocks), 1 = k4_box_chunks
 	// boxcar variant (k4_phase_search_box)
 	const PsBoxState* box_in; PsBoxState* box_out; long long first_group;
-	int* qflag = nullptr;                    // != nullptr: one flag per qflag_div chains instead of the batch-global *flag, so that the
-	int qflag_div = 4;                       // exact fallback re-runs only those (4: the chains of one k4_phase_search workgroup)
 	int* fb_count = nullptr;                 // statistics: workgroups of the exact fallback that really ran (aisgpu_ps_fallbacks)
 };
 
@@ -329,7 +326,7 @@ struct KV2Params {
 	int n_windows, L, n_chan;
 };
 hipError_t launch_kv2(const KV2Params& p, hipStream_t s);
-hipError_t launch_k4(const K4Params& p, hipStream_t s);          // chunk-parallel + assemble + (conditional) exact fallback
+hipError_t launch_k4(const K4Params& p, hipStream_t s);          // chunk-parallel + assemble (with the exact sequential search where a speculative warm-up failed)
 hipError_t launch_k4_sequential(const K4Params& p, hipStream_t s); // the plain sequential kernel only
 hipError_t launch_k4_box(const K4Params& p, hipStream_t s);        // Demod::PhaseSearch (boxcar history), sequential
 

@@ -1539,19 +1539,12 @@ __device__ __forceinline__ void ps_chain(const SymRow x, uint32_t* __restrict__ 
 	if ((n & 31) != 0 && writer) out[n >> 5] = word;
 }
 
-// Sequential reference kernel: one pass over the whole block per chain.  Used as the exact fallback of the
-// chunk-parallel path (runs only when p.flag is set) and on its own for small batches.
-__global__ __launch_bounds__(64) void k4_phase_search(K4Params p, int conditional) {
-	if (conditional) { // exact fallback: only where k4_assemble found a speculative warm-up that did not reproduce the sequential EMA
-		if (p.qflag) { // per workgroup (its four chains): one receiver with an extreme level step does not cost the whole batch
-			if (p.qflag[blockIdx.x] == 0) return; // (one wave: the branch has consumed every lane's load before the store below)
-			if (threadIdx.x == 0) p.qflag[blockIdx.x] = 0;
-		} else if (*p.flag == 0) return;
-		if (threadIdx.x == 0 && p.fb_count) atomicAdd(p.fb_count, 1);
-	}
+// Sequential reference search: one pass over the whole block for the four chains of workgroup bx.  On its own (k4_phase_search)
+// for small batches / one-chunk blocks, and as the exact fallback of the chunk-parallel path inside k4_assemble.
+__device__ __forceinline__ void ps_search_quad(const K4Params& p, int bx) {
 	const int lane = threadIdx.x;
 	const int k = lane & 15, row = lane >> 4;
-	const int chain = blockIdx.x * 4 + row; // (rx*2 + ch) * 5 + j
+	const int chain = bx * 4 + row; // (rx*2 + ch) * 5 + j
 	const bool live = chain < p.n_chains;
 	const int cidx = live ? chain : p.n_chains - 1;
 	const int rowbase = row * 16;
@@ -1588,6 +1581,7 @@ __global__ __launch_bounds__(64) void k4_phase_search(K4Params p, int conditiona
 		if (k == 0) { sto->max_idx = idx & 15; sto->rot = (st->rot + p.n_groups) & 3; }
 	}
 }
+__global__ __launch_bounds__(64) void k4_phase_search(K4Params p) { ps_search_quad(p, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------
 // K4': Demod::PhaseSearch (Demod.cpp:103-170), the boxcar variant behind `-go PS_EMA off` (nHistory = 12, nDelay = 3,
@@ -1756,8 +1750,8 @@ __global__ __launch_bounds__(64) void k4_box_chunks(K4Params p) {
 //  * ma[k] is a contraction (x0.85 per symbol), so a chunk starts from ma = 0 and first replays the `warm`
 //    symbols in front of it; after that the float state is (with overwhelming probability) bit-identical to
 //    the sequential one.  That is VERIFIED: k4_assemble compares the post-warm-up values with the previous
-//    chunk's final values bit for bit and raises p.flag on any difference, in which case the sequential
-//    kernel above recomputes the block exactly.  Results are therefore always bit-exact.
+//    chunk's final values bit for bit; on any difference in its four chains the assembling wave runs the sequential
+//    search above over the block, from the true state.  Results are therefore always bit-exact.
 //  * the decisions (t > 0) do not depend on state at all.
 //  * max_idx is not contractive, so it is not guessed: lane k of the row tracks the trajectory that STARTS at
 //    max_idx = k (same instructions as one trajectory, the row's 16 lanes just stop being redundant);
@@ -1974,12 +1968,19 @@ __global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
 		}
 		ma_last = mf[AS - 1]; // only read when another batch follows, i.e. when all AS chunks of this one were live
 	}
-	if (bad) { if (p.qflag) atomicOr(p.qflag + chain / p.qflag_div, 1); else atomicOr(p.flag, 1); }
 	const size_t last = base + (p.n_chunks - 1);
 	sto->ma[k] = p.ma_fin[last * 16 + k];
 	sto->bits[k] = fin_last >> 4;
 	if (k == 0) { sto->max_idx = start; sto->rot = (st->rot + p.n_groups) & 3; }
 	if (p.box_out && k == 0) p.box_out[chain].max_idx = start; // boxcar variant: its own state block
+	// A speculative warm-up that did not reproduce the sequential EMA anywhere in the wave's four chains: the wave itself recomputes
+	// them sequentially from the true state, here and now (the same wave would have been the one to do it in a kernel of its own --
+	// which cost a launch boundary on the PhaseSearch stream, the pipeline's critical one, for every block).  (Rows of chains that
+	// do not exist have left above: ballots and DPP row operations of the search only ever look inside a row.)
+	if (__any(bad)) {
+		if (__builtin_amdgcn_readfirstlane(lane) == lane && p.fb_count) atomicAdd(p.fb_count, 1);
+		ps_search_quad(p, blockIdx.x);
+	}
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3591,7 +3592,6 @@ hipError_t launch_k5(const K5Params& p, int n_chan, hipStream_t s) {
 hipError_t launch_k4_box(const K4Params& p, hipStream_t s) {
 	if (p.n_chunks > 1 && p.chunked) { // chunk-parallel: exact by construction (16 symbols of look-back), k4_assemble picks the trajectories
 		K4Params q = p;
-		q.qflag = nullptr;
 		hipLaunchKernelGGL(k4_box_chunks, dim3((p.n_chains / 5 + 3) / 4 * 5, p.n_chunks), dim3(64), 0, s, q);
 		hipLaunchKernelGGL(k4_assemble, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, q);
 		return hipGetLastError();
@@ -3602,19 +3602,14 @@ hipError_t launch_k4_box(const K4Params& p, hipStream_t s) {
 
 hipError_t launch_k4_sequential(const K4Params& p, hipStream_t s) {
 	if (p.n_groups <= 0) return hipSuccess;
-	hipLaunchKernelGGL(k4_phase_search, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p, 0);
+	hipLaunchKernelGGL(k4_phase_search, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p);
 	return hipGetLastError();
 }
 
 hipError_t launch_k4(const K4Params& p, hipStream_t s) {
 	if (p.n_groups <= 0) return hipSuccess;
-	if (!p.qflag) { // (the per-workgroup flags are cleared by the fallback kernel itself)
-		hipError_t e = hipMemsetAsync(p.flag, 0, sizeof(int), s);
-		if (e != hipSuccess) return e;
-	}
 	hipLaunchKernelGGL(k4_phase_chunks, dim3((p.n_chains / 5 + 3) / 4 * 5, p.n_chunks), dim3(64), 0, s, p);
-	hipLaunchKernelGGL(k4_assemble, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p);
-	hipLaunchKernelGGL(k4_phase_search, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p, 1); // exits at once unless flagged
+	hipLaunchKernelGGL(k4_assemble, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p); // + the exact sequential search where a warm-up failed
 	return hipGetLastError();
 }
 
