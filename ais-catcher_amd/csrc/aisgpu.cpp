@@ -1286,9 +1286,9 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	// default: the fused derotation + FIR path (no phasor array in HBM, and no derotated-sample array either -- except for
 	// ModelChallenger, whose FM branch demodulates those samples: there the fused kernel stores them on its way); the materialised
 	// path serves the taps, which need those arrays, and stays selectable (option "fused" = 0: test hook)
-	// (ModelChallenger on the resampled ladders keeps the materialised path: there the FFT / search kernels, the fused kernel and the
-	// FM receiver would queue on one stream -- 0.70 against 0.53 ms per step at 6 MSPS, BASELINE configs[2])
-	h->fused = !(cfg->flags & AISGPU_FLAG_TAPS) && !h->base && !h->v2 && !(h->challenger && mode != MODE_DIRECT && mode != MODE_PRE) && opt_int("fused", 1) != 0;
+	// (round 4: also ModelChallenger on the resampled ladders -- BASELINE configs[2], 6 MSPS: with the lanes-over-time derotation / FIR
+	// kernel 0.558 -> 0.538 ms per step; with round 3's lane-per-chain kernel it had been 0.70 against 0.53)
+	h->fused = !(cfg->flags & AISGPU_FLAG_TAPS) && !h->base && !h->v2 && opt_int("fused", 1) != 0;
 	// The spectral analysis rides at the end of the front-end waves (k1_fft_tail) when every span is a whole number of 512-sample
 	// windows of the 48 kHz channels (16 tiles each) and whole spans make up the block; the automatic span length is rounded up
 	// to such a value, an explicit one (cfg.tiles_per_span) is taken as it is.  Option "fft_in_k1" = 0 (test hook): the FFT / search kernels.
