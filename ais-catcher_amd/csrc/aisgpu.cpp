@@ -103,6 +103,18 @@ struct RotWorker {
 	bool stop = false, started = false;
 };
 
+// The same for the resampled ladders (round 4): the tables of a flush -- (input index, alpha) per Upsample output and the Rotate
+// phasors -- are 100,000 dependent float steps per input block, data independent: a worker thread builds them ahead, the caller
+// only launches the kernels that copy them.  Flush k lives in slot k % USR; run r (input block r) completes nflush[r % NRUN] flushes.
+struct UsWorker {
+	static constexpr int NRUN = 8;
+	std::thread th; std::mutex m; std::condition_variable cv;
+	int nflush[NRUN] = {};
+	long long produced_runs = 0, taken_runs = 0;    // runs whose tables are complete / whose copies the caller has enqueued
+	long long produced_flush = 0, copied_flush = 0; // flushes built / handed to the device (their slot's copy event is recorded)
+	bool stop = false, started = false;
+};
+
 } // namespace
 
 struct aisgpu {
@@ -158,7 +170,9 @@ struct aisgpu {
 	bool us_dsk = false;              // Upsample in front of DownsampleKFilter (rates below a decimate-by-3 bucket): resampler flow, K1k front end
 	int KPa = 0;                      // != 0: the pre-decimation runs as KPa stages, then four (rates above 6144k that are resampled: 8 / 10 MSPS)
 	float2* d_rot[4] = {}; // Rotate phasor tables: ring of 4 on the main path (block f & 3, staged two blocks ahead), [f & 1] on the others
-	int* d_usidx[2] = {}; float* d_usalpha[2] = {};
+	static const int USR = 8; // resampler tables: ring of eight flushes (generated and copied one input block ahead)
+	int* d_usidx[USR] = {}; float* d_usalpha[USR] = {}; float2* d_usrot[USR] = {}; float2* h_usrot[USR] = {};
+	float2 *us_dev_idx[USR] = {}, *us_dev_alpha[USR] = {}, *us_dev_rot[USR] = {}; bool us_by_kernel = true; // device views of the pinned table buffers
 	float2 *d_c48[NBUF] = {}, *d_sym[2] = {};
 	float2 *d_rotT[NBUF] = {};
 	float2 *d_cgf = nullptr, *d_omega = nullptr, *d_step = nullptr, *d_rotstate = nullptr, *d_firtap = nullptr;
@@ -181,7 +195,11 @@ struct aisgpu {
 	// host (pinned)
 	void* h_in[2] = {};
 	float2* h_rot[4] = {};
-	int* h_usidx[2] = {}; float* h_usalpha[2] = {};
+	int* h_usidx[USR] = {}; float* h_usalpha[USR] = {};
+	// resampled ladders: tables of flush b (slot b & 3) copied (us_copy_ev, table stream) / consumed by its resampler front end (us_used_ev);
+	// pre-decimated input block g (slot g & 3) written (ev_xin, front stream) / read for the last time by the flushes of run g (ev_xread)
+	hipEvent_t us_copy_ev[USR] = {}, us_used_ev[USR] = {}, ev_xin[4] = {}, ev_xread[4] = {}; bool us_slot_used[USR] = {};
+	UsWorker uw; long long run_flush = 0, run_idx = 0; int next_nflush = 0; // (run_flush: flushes whose resampler front end has been launched)
 	hipEvent_t rot_ev[4] = {}; bool rot_ev_used[4] = {}; long long rot_next = 0; // first block whose table has not been staged yet
 	RotWorker rw; int rot_slot[4] = {};
 	float2* h_rot_dev[4] = {}; bool rot_by_kernel = true; // device view of the pinned table buffers
@@ -902,6 +920,105 @@ int sync_all(aisgpu_t* h) {
 	return AISGPU_OK;
 }
 
+// Resampled ladders, host part (worker thread): replay Upsample::Receive over one input block's n_pre inputs (DSP.cpp:192-212);
+// every time `len` outputs are complete the reference flushes them downstream as one Receive() call -> one downstream block here.
+// The tables of such a flush -- (input index, alpha) per output, the Rotate phasors -- depend on the stream position alone.
+void us_worker_main(aisgpu_t* h) {
+	UsWorker& w = h->uw;
+	(void)hipSetDevice(h->cfg.device_id);
+	const int len = h->n_pre;
+	for (long long run = 0;; run++) {
+		{
+			std::unique_lock<std::mutex> l(w.m);
+			w.cv.wait(l, [&] { return w.stop || run < w.taken_runs + 3; }); // at most three input blocks ahead of the caller
+			if (w.stop) return;
+		}
+		const long long in0 = h->us_in;
+		int n_flush = 0;
+		for (int i = 0; i < len; i++) {
+			do {
+				h->us_pend_idx.push_back(in0 + i);
+				h->us_pend_alpha.push_back(h->us_alpha);
+				h->us_alpha += h->us_increment;
+				if ((int)h->us_pend_idx.size() == len) {
+					const long long k = w.produced_flush;
+					const int slot = (int)(k % aisgpu::USR);
+					if (k >= aisgpu::USR) { // the pinned buffers of slot k % USR were last read by the copy kernels of flush k - USR
+						{
+							std::unique_lock<std::mutex> l(w.m);
+							w.cv.wait(l, [&] { return w.stop || w.copied_flush > k - aisgpu::USR; });
+							if (w.stop) return;
+						}
+						(void)hipEventSynchronize(h->us_copy_ev[slot]);
+					}
+					gen_rot_table(h, h->h_usrot[slot]);
+					int* ti = h->h_usidx[slot]; float* ta = h->h_usalpha[slot];
+					for (int e = 0; e < US_HIST; e++) { // halo: the tail of the previous flush, re-based to this block
+						const long long a = h->us_tail_idx[e];
+						ti[e] = a < 0 ? -1 : (int)(a - in0);
+						ta[e] = h->us_tail_alpha[e];
+					}
+					for (int e = 0; e < len; e++) { ti[US_HIST + e] = (int)(h->us_pend_idx[e] - in0); ta[US_HIST + e] = h->us_pend_alpha[e]; }
+					for (int e = 0; e < US_HIST; e++) { h->us_tail_idx[e] = h->us_pend_idx[len - US_HIST + e]; h->us_tail_alpha[e] = h->us_pend_alpha[len - US_HIST + e]; }
+					h->us_pend_idx.clear(); h->us_pend_alpha.clear();
+					{ std::lock_guard<std::mutex> l(w.m); w.produced_flush = k + 1; }
+					n_flush++;
+				}
+			} while (h->us_alpha < 1.0f);
+			h->us_alpha -= 1.0f;
+		}
+		h->us_in += len;
+		{ std::lock_guard<std::mutex> l(w.m); w.nflush[run % UsWorker::NRUN] = n_flush; w.produced_runs = run + 1; }
+		w.cv.notify_all();
+	}
+}
+
+void us_worker_stop(aisgpu_t* h) {
+	UsWorker& w = h->uw;
+	if (!w.started) return;
+	{ std::lock_guard<std::mutex> l(w.m); w.stop = true; }
+	w.cv.notify_all();
+	if (w.th.joinable()) w.th.join();
+	w.started = false;
+}
+
+// The caller's part: the copies of run `run`'s tables to the device (table stream cs), one input block ahead of the pass over the
+// raw input -- by copy kernels that read the pinned buffers through their device view: hipMemcpyAsync from pinned memory behind
+// pending kernels costs the calling thread and the stream 0.2 ms per flush here.  Returns the run's number of flushes.
+int stage_resample_run(aisgpu_t* h, long long run, int* n_flush_out) {
+	UsWorker& w = h->uw;
+	if (!w.started) { w.started = true; w.th = std::thread(us_worker_main, h); }
+	hipStream_t cs = h->serial ? h->stream : h->s3;
+	const int len = h->n_pre;
+	int n_flush = 0;
+	{
+		std::unique_lock<std::mutex> l(w.m);
+		w.cv.wait(l, [&] { return w.produced_runs > run; });
+		n_flush = w.nflush[run % UsWorker::NRUN];
+	}
+	for (int i = 0; i < n_flush; i++) {
+		const long long k = w.copied_flush; // (only this thread writes it)
+		const int slot = (int)(k % aisgpu::USR);
+		if (h->us_slot_used[slot]) WAITEV(cs, h->us_used_ev[slot]); // the device tables of the slot: read by the front end of flush k - USR
+		if (h->us_by_kernel) {
+			HIPCHK(launch_copy_rows(h->us_dev_rot[slot], 0, h->d_usrot[slot], 0, ROT_HIST + h->n96, 1, cs));
+			HIPCHK(launch_copy_rows(h->us_dev_idx[slot], 0, reinterpret_cast<float2*>(h->d_usidx[slot]), 0, (US_HIST + len) / 2, 1, cs));
+			HIPCHK(launch_copy_rows(h->us_dev_alpha[slot], 0, reinterpret_cast<float2*>(h->d_usalpha[slot]), 0, (US_HIST + len) / 2, 1, cs));
+		} else {
+			HIPCHK(hipMemcpyAsync(h->d_usrot[slot], h->h_usrot[slot], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, cs));
+			HIPCHK(hipMemcpyAsync(h->d_usidx[slot], h->h_usidx[slot], ((size_t)US_HIST + len) * sizeof(int), hipMemcpyHostToDevice, cs));
+			HIPCHK(hipMemcpyAsync(h->d_usalpha[slot], h->h_usalpha[slot], ((size_t)US_HIST + len) * sizeof(float), hipMemcpyHostToDevice, cs));
+		}
+		HIPCHK(hipEventRecord(h->us_copy_ev[slot], cs));
+		{ std::lock_guard<std::mutex> l(w.m); w.copied_flush = k + 1; }
+		w.cv.notify_all();
+	}
+	{ std::lock_guard<std::mutex> l(w.m); w.taken_runs = run + 1; }
+	w.cv.notify_all();
+	*n_flush_out = n_flush;
+	return AISGPU_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -1126,7 +1243,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			int least = 0, greatest = 0;
 			const bool prio = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
 			// (a runtime without CU masks falls back to ordinary streams: same results, the recurrence just shares its SIMDs)
-			masked = (prio ? hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, least) : hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)words, rest.data())) == hipSuccess;
+						masked = (prio ? hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, least) : hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)words, rest.data())) == hipSuccess;
 			masked = masked && hipExtStreamCreateWithCUMask(&h->s1, (uint32_t)words, rest.data()) == hipSuccess;
 			masked = masked && hipExtStreamCreateWithCUMask(&h->s3, (uint32_t)words, lat.data()) == hipSuccess;
 			masked = masked && hipExtStreamCreateWithCUMask(&h->s4, (uint32_t)words, rest.data()) == hipSuccess;
@@ -1215,12 +1332,18 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(hipEventCreateWithFlags(&h->rot_ev[i], hipEventDisableTiming));
 		if (hipHostGetDevicePointer((void**)&h->h_rot_dev[i], h->h_rot[i], 0) != hipSuccess) h->rot_by_kernel = false;
 	}
-	for (int i = 0; i < 2; i++) {
-		if (mode == MODE_RESAMPLE) {
+	if (mode == MODE_RESAMPLE) {
+		for (int i = 0; i < 4; i++) { HIPCHK(hipEventCreateWithFlags(&h->ev_xin[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_xread[i], hipEventDisableTiming)); }
+		for (int i = 0; i < aisgpu::USR; i++) {
+			HIPCHK(hipEventCreateWithFlags(&h->us_copy_ev[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->us_used_ev[i], hipEventDisableTiming));
 			HIPCHK(dalloc(&h->d_usidx[i], (size_t)US_HIST + h->n_pre));
 			HIPCHK(dalloc(&h->d_usalpha[i], (size_t)US_HIST + h->n_pre));
+			HIPCHK(dalloc(&h->d_usrot[i], (size_t)ROT_HIST + h->n96));
 			HIPCHK(hipHostMalloc((void**)&h->h_usidx[i], ((size_t)US_HIST + h->n_pre) * sizeof(int), hipHostMallocDefault));
 			HIPCHK(hipHostMalloc((void**)&h->h_usalpha[i], ((size_t)US_HIST + h->n_pre) * sizeof(float), hipHostMallocDefault));
+			HIPCHK(hipHostMalloc((void**)&h->h_usrot[i], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipHostMallocDefault));
+			if (hipHostGetDevicePointer((void**)&h->us_dev_idx[i], h->h_usidx[i], 0) != hipSuccess || hipHostGetDevicePointer((void**)&h->us_dev_alpha[i], h->h_usalpha[i], 0) != hipSuccess ||
+			    hipHostGetDevicePointer((void**)&h->us_dev_rot[i], h->h_usrot[i], 0) != hipSuccess || ((US_HIST + h->n_pre) & 1)) h->us_by_kernel = false;
 		}
 	}
 	h->gpu_decode = (cfg->flags & AISGPU_FLAG_GPU_DECODE) != 0;
@@ -1375,6 +1498,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	if (!h) return;
 	DevGuard dg(h);
 	rot_worker_stop(h);
+	us_worker_stop(h);
 	h->pend.valid = false;
 	if (h->stream) hipStreamSynchronize(h->stream);
 	if (h->s1) hipStreamSynchronize(h->s1);
@@ -1396,10 +1520,17 @@ void aisgpu_destroy(aisgpu_t* h) {
 		if (h->ev_k3[i]) hipEventDestroy(h->ev_k3[i]);
 		if (h->ev_k4[i]) hipEventDestroy(h->ev_k4[i]);
 		hipFree(h->d_sym[i]); hipFree(h->d_ema[i]);
-		hipFree(h->d_usidx[i]); hipFree(h->d_usalpha[i]); hipFree(h->d_xpre[i]); hipFree(h->d_xpre[i + 2]);
+		hipFree(h->d_xpre[i]); hipFree(h->d_xpre[i + 2]);
+	}
+	for (int i = 0; i < aisgpu::USR; i++) {
+		hipFree(h->d_usidx[i]); hipFree(h->d_usalpha[i]); hipFree(h->d_usrot[i]);
 		if (h->h_usidx[i]) hipHostFree(h->h_usidx[i]);
 		if (h->h_usalpha[i]) hipHostFree(h->h_usalpha[i]);
+		if (h->h_usrot[i]) hipHostFree(h->h_usrot[i]);
+		if (h->us_copy_ev[i]) hipEventDestroy(h->us_copy_ev[i]);
+		if (h->us_used_ev[i]) hipEventDestroy(h->us_used_ev[i]);
 	}
+	for (int i = 0; i < 4; i++) { if (h->ev_xin[i]) hipEventDestroy(h->ev_xin[i]); if (h->ev_xread[i]) hipEventDestroy(h->ev_xread[i]); }
 	for (auto& p : h->ev_free) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
 	hipFree(h->d_xmid);
 	hipFree(h->d_in[0]); hipFree(h->d_in[1]); hipFree(h->d_hist[0]); hipFree(h->d_hist[1]); hipFree(h->d_hist2[0]); hipFree(h->d_hist2[1]);
@@ -1506,6 +1637,18 @@ int aisgpu_run(aisgpu_t* h) {
 		h->ev_busy.push_back(ev);
 		return AISGPU_OK;
 	};
+
+	// ---- resampled ladders: the tables of the flushes this input block completes were staged during the previous call; stage the
+	// NEXT block's now (they depend on the stream position alone: us_worker_main / stage_resample_run)
+	int n_flush = 0;
+	if (h->mode == MODE_RESAMPLE) {
+		if (h->run_idx == 0) { int rc = stage_resample_run(h, 0, &h->next_nflush); if (rc) return rc; }
+		n_flush = h->next_nflush;
+		{ int rc = stage_resample_run(h, h->run_idx + 1, &h->next_nflush); if (rc) return rc; }
+		h->run_idx++;
+		// the pass below overwrites the pre-decimated block of four runs ago: the flushes of the run before last were its last readers
+		WAITEV(h->stream, h->ev_xread[(h->in_blocks + 2) & 3]);
+	}
 
 	// ---- pre-decimation pass (MODE_PRE / MODE_RESAMPLE): KP CIC5 stages at the input rate -> d_xpre
 	float2* xcur = nullptr;
@@ -1663,64 +1806,51 @@ int aisgpu_run(aisgpu_t* h) {
 		int rc = enqueue_downstream(h, q, pb);
 		if (rc) return rc;
 	} else {
-		// ---- replay Upsample::Receive over this block's n_pre inputs (DSP.cpp:192-212); every time `len` outputs
-		// are complete the reference flushes them downstream as one Receive() call -> one downstream block here
-		const long long in0 = h->us_in;
+		// ---- resampled ladders, device part: the flushes this block completes (tables: see the top).  The resampler front end stays on
+		// the front stream, behind the pass over the raw input: next to the NEXT block's pass (on the downstream stream) it takes
+		// 0.27-0.39 ms instead of 0.09 -- both want the CUs' LDS and the same memory system -- and the downstream stream becomes the
+		// pipeline's longest (0.60 ms per step); everything behind the 48 kHz channels runs on `ds`.
+		HIPCHK(hipEventRecord(h->ev_xin[h->in_blocks & 3], h->stream)); // the pre-decimated block is there
+		hipStream_t st = h->stream;
 		const int len = h->n_pre;
-		for (int i = 0; i < len; i++) {
-			do {
-				h->us_pend_idx.push_back(in0 + i);
-				h->us_pend_alpha.push_back(h->us_alpha);
-				h->us_alpha += h->us_increment;
-				if ((int)h->us_pend_idx.size() == len) {
-					const int pb = (int)(h->block_idx & 1);
-					const int q = (int)(h->block_idx % NBUF);
-					if (h->block_idx >= 2) HIPCHK(hipEventSynchronize(h->rot_ev[pb]));
-					gen_rot_table(h, h->h_rot[pb]);
-					int* ti = h->h_usidx[pb]; float* ta = h->h_usalpha[pb];
-					for (int e = 0; e < US_HIST; e++) { // halo: the tail of the previous flush, re-based to this block
-						const long long a = h->us_tail_idx[e];
-						ti[e] = a < 0 ? -1 : (int)(a - in0);
-						ta[e] = h->us_tail_alpha[e];
-					}
-					for (int e = 0; e < len; e++) { ti[US_HIST + e] = (int)(h->us_pend_idx[e] - in0); ta[US_HIST + e] = h->us_pend_alpha[e]; }
-					for (int e = 0; e < US_HIST; e++) { h->us_tail_idx[e] = h->us_pend_idx[len - US_HIST + e]; h->us_tail_alpha[e] = h->us_pend_alpha[len - US_HIST + e]; }
-					h->us_pend_idx.clear(); h->us_pend_alpha.clear();
-					HIPCHK(hipMemcpyAsync(h->d_rot[pb], h->h_rot[pb], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
-					HIPCHK(hipMemcpyAsync(h->d_usidx[pb], ti, ((size_t)US_HIST + len) * sizeof(int), hipMemcpyHostToDevice, h->stream));
-					HIPCHK(hipMemcpyAsync(h->d_usalpha[pb], ta, ((size_t)US_HIST + len) * sizeof(float), hipMemcpyHostToDevice, h->stream));
-					HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
-					WAITEV(h->stream, h->ev_c48free[q]);
-					if (h->eager_out) WAITEV(h->stream, h->ev_ema[(h->block_idx + 4 - NBUF % 4) & 3]); // ppm[q] of block f-NBUF has been copied out
-					if (h->us_dsk) { // US >> DSK >> ROT: the flush is a whole number of the filter's 8192-sample output blocks
-						K1kParams kk;
-						kk.xin = xcur; kk.xin_stride = xstride; kk.xin_off = h->xh;
-						kk.xprev = h->d_xpre[(h->in_blocks + 3) & 3]; kk.xprev2 = h->d_xpre[(h->in_blocks + 2) & 3]; kk.n_in = h->n_pre;
-						kk.rot = h->d_rot[pb]; kk.c48 = h->d_c48[q]; kk.c48_stride = h->c48s; kk.L = h->L;
-						kk.us_idx = h->d_usidx[pb]; kk.us_alpha = h->d_usalpha[pb];
-						memcpy(kk.taps, TAPS_BH_28_3, sizeof kk.taps);
-						HIPCHK(launch_k1k(kk, R, h->stream));
-					} else {
-					K1uParams ku;
-					ku.xin = xcur; ku.xin_stride = xstride; ku.xin_off = h->xh;
-					ku.xprev = h->d_xpre[(h->in_blocks + 3) & 3]; ku.xprev2 = h->d_xpre[(h->in_blocks + 2) & 3]; ku.n_in = h->n_pre;
-					ku.us_idx = h->d_usidx[pb]; ku.us_alpha = h->d_usalpha[pb]; ku.rot = h->d_rot[pb];
-					ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
-					ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->has_fdc; ku.L = h->L;
-					if (h->mode_x) HIPCHK(launch_k1x(ku, h->npost, R, h->stream));
-					else HIPCHK(launch_k1u(ku, h->npost, R, h->stream));
-					}
-					if (h->ds != h->stream) { // the 48 kHz channels of this flush exist: everything behind them runs on ds, next to the next input block's pass
-						HIPCHK(hipEventRecord(h->ev_pre[q], h->stream));
-						WAITEV(h->ds, h->ev_pre[q]);
-					}
-					int rc = enqueue_downstream(h, q, pb);
-					if (rc) return rc;
-				}
-			} while (h->us_alpha < 1.0f);
-			h->us_alpha -= 1.0f;
+		(void)len;
+		for (int fi = 0; fi < n_flush; fi++) {
+			const int pb = (int)(h->block_idx & 1);
+			const int q = (int)(h->block_idx % NBUF);
+			const int slot = (int)(h->run_flush++ % aisgpu::USR);
+			WAITEV(st, h->ev_xin[h->in_blocks & 3]);
+			WAITEV(st, h->us_copy_ev[slot]);
+			WAITEV(st, h->ev_c48free[q]);
+			if (h->eager_out) WAITEV(st, h->ev_ema[(h->block_idx + 4 - NBUF % 4) & 3]); // ppm[q] of block f-NBUF has been copied out
+			if (h->us_dsk) { // US >> DSK >> ROT: the flush is a whole number of the filter's 8192-sample output blocks
+				K1kParams kk;
+				kk.xin = xcur; kk.xin_stride = xstride; kk.xin_off = h->xh;
+				kk.xprev = h->d_xpre[(h->in_blocks + 3) & 3]; kk.xprev2 = h->d_xpre[(h->in_blocks + 2) & 3]; kk.n_in = h->n_pre;
+				kk.rot = h->d_usrot[slot]; kk.c48 = h->d_c48[q]; kk.c48_stride = h->c48s; kk.L = h->L;
+				kk.us_idx = h->d_usidx[slot]; kk.us_alpha = h->d_usalpha[slot];
+				memcpy(kk.taps, TAPS_BH_28_3, sizeof kk.taps);
+				HIPCHK(launch_k1k(kk, R, st));
+			} else {
+				K1uParams ku;
+				ku.xin = xcur; ku.xin_stride = xstride; ku.xin_off = h->xh;
+				ku.xprev = h->d_xpre[(h->in_blocks + 3) & 3]; ku.xprev2 = h->d_xpre[(h->in_blocks + 2) & 3]; ku.n_in = h->n_pre;
+				ku.us_idx = h->d_usidx[slot]; ku.us_alpha = h->d_usalpha[slot]; ku.rot = h->d_usrot[slot];
+				ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
+				ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->has_fdc; ku.L = h->L;
+				if (h->mode_x) HIPCHK(launch_k1x(ku, h->npost, R, st));
+				else HIPCHK(launch_k1u(ku, h->npost, R, st));
+			}
+			HIPCHK(hipEventRecord(h->us_used_ev[slot], st));
+			HIPCHK(hipEventRecord(h->ev_xread[h->in_blocks & 3], st)); // (the run's last flush leaves the event that counts)
+			h->us_slot_used[slot] = true;
+			if (h->ds != st) { // the 48 kHz channels of this flush exist: everything behind them runs on ds, next to the next input block's pass
+				HIPCHK(hipEventRecord(h->ev_pre[q], st));
+				WAITEV(h->ds, h->ev_pre[q]);
+			}
+			int rc = enqueue_downstream(h, q, pb); // (advances block_idx)
+			if (rc) return rc;
 		}
-		h->us_in += len;
+		if (n_flush == 0) HIPCHK(hipEventRecord(h->ev_xread[h->in_blocks & 3], st)); // (behind the earlier runs' flushes on st)
 	}
 	if (h->staged) { // everything that reads the staged input (front end, tail copies, conversions) is on the front stream, in front of this
 		HIPCHK(hipEventRecord(h->ev_in_free[in_p], h->stream));

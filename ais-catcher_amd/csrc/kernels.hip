@@ -3376,15 +3376,24 @@ __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 // "the front end of block f is done" -- what the phasor recurrence's stream waits for -- and the two time stamps of the roofline
 // measurement then cost no barrier packets between two launches of the front stream (0.03 ms per step of 0.48).
 struct K1Events { hipEvent_t start = nullptr, stop = nullptr; };
-#define K1_LAUNCH(kernel_, ev_, grid_, s_, p_) \
+#define K1_LAUNCH(kernel_, ev_, grid_, s_, p_) K1_LAUNCH_LDS(kernel_, ev_, grid_, s_, p_, 0)
+#define K1_LAUNCH_LDS(kernel_, ev_, grid_, s_, p_, lds_) \
 	do { \
-		if ((ev_).start || (ev_).stop) hipExtLaunchKernelGGL(kernel_, grid_, dim3(64), 0, s_, (ev_).start, (ev_).stop, 0, p_); \
-		else hipLaunchKernelGGL(kernel_, grid_, dim3(64), 0, s_, p_); \
+		if ((ev_).start || (ev_).stop) hipExtLaunchKernelGGL(kernel_, grid_, dim3(64), lds_, s_, (ev_).start, (ev_).stop, 0, p_); \
+		else hipLaunchKernelGGL(kernel_, grid_, dim3(64), lds_, s_, p_); \
 	} while (0)
+// The pre-decimation pass needs few registers, so the hardware would take sixteen of its one-wave workgroups per CU -- all of the
+// CU's LDS.  The resampler front end of the previous block (256 threads, 6.6 KB of LDS per workgroup), which runs beside it on the
+// downstream stream, then only gets LDS as fast as workgroups of the pass retire (0.39 instead of 0.09 ms, BASELINE configs[2]).
+// Unused dynamic LDS brings the pass to ten workgroups per CU: 60 KB stay free for the kernels behind the 48 kHz channels, which all
+// run beside the next block's pass (12 per CU, like the main front end: 2 % slower per step; 8: no better).
+#ifndef K1_PRE_EXTRA_LDS
+#define K1_PRE_EXTRA_LDS 6400
+#endif
 
 template <int K, int FMT>
 static hipError_t launch_k1_dpp_kf(const K1Params& p, int spans, int n_rx, hipStream_t s, const K1Events& ev) {
-	if (p.pre_out != nullptr) K1_LAUNCH((k1_dpp<K, FMT, true>), ev, dim3(spans, n_rx), s, p);
+	if (p.pre_out != nullptr) K1_LAUNCH_LDS((k1_dpp<K, FMT, true>), ev, dim3(spans, n_rx), s, p, K1_PRE_EXTRA_LDS);
 	else K1_LAUNCH((k1_dpp<K, FMT, false>), ev, dim3(spans, n_rx), s, p);
 	return hipGetLastError();
 }
