@@ -183,6 +183,7 @@ struct aisgpu {
 	uint32_t* d_bits[4] = {}; // ring of 4 (block f & 3), like lvl: the frame decoder of block f-2 may still be reading while PhaseSearch of block f writes
 	bool challenger = false;
 	bool v2 = false; float2* h_c48 = nullptr; // ModelEngineV2: front end only, the 48 kHz channels go to the host (MAXSUB slots)
+	V2ChanState* d_v2st = nullptr; float2* d_slotcs = nullptr; int* d_v2locked = nullptr; // AISGPU_FLAG_GPU_DECODE with ModelEngineV2: the engine itself on the device (kv2_engine)
 	bool v2_assist = true; float2* d_v2hist = nullptr; float *d_v2f = nullptr, *d_v2prom = nullptr, *d_v2en = nullptr, *h_v2f = nullptr, *h_v2prom = nullptr, *h_v2en = nullptr; // decoder-independent part of V2::Engine on the device
 	bool base = false; float2* d_fmprev[2] = {}; // ModelBase: FM receiver on the 48 kHz channels, no coherent chain
 	float* d_fm = nullptr; float* d_fmhist[2] = {}; uint32_t* d_fmbits[2] = {}; uint32_t* h_fmbits = nullptr; // ModelChallenger FM branch
@@ -758,8 +759,10 @@ int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
 	if (h->n_sub < MAXSUB) {
 		const size_t C = h->n_chan;
 		const size_t s_ = (size_t)h->out_set * MAXSUB + h->n_sub; // host slot: two sets, by input block
-		HIPCHK(hipMemcpy2DAsync(h->h_c48 + s_ * C * h->L, (size_t)h->L * sizeof(float2), h->d_c48[q], (size_t)h->c48s * sizeof(float2),
-		                        (size_t)h->L * sizeof(float2), C, hipMemcpyDeviceToHost, h->ds));
+		const bool on_device = h->gpu_decode; // the whole engine on the device: frames out, the channels never cross PCIe
+		if (!on_device)
+			HIPCHK(hipMemcpy2DAsync(h->h_c48 + s_ * C * h->L, (size_t)h->L * sizeof(float2), h->d_c48[q], (size_t)h->c48s * sizeof(float2),
+			                        (size_t)h->L * sizeof(float2), C, hipMemcpyDeviceToHost, h->ds));
 		if (h->v2_assist) { // FreqOffset::Estimate of every offset-0 / offset-256 window, midWins' energies, the FM branch up to its sign
 			KV2Params k{};
 			k.c48 = h->d_c48[q]; k.c48_stride = h->c48s; k.hist = h->d_v2hist; k.omega = h->d_omega;
@@ -768,11 +771,21 @@ int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
 			k.fir_out = h->d_fmfir; k.fir_stride = h->L;
 			memcpy(k.taps, TAPS_RECEIVER, sizeof k.taps);
 			k.n_windows = h->W; k.L = h->L; k.n_chan = h->n_chan;
-			HIPCHK(launch_kv2(k, h->ds));
-			HIPCHK(hipMemcpyAsync(h->h_v2f + s_ * C * 2 * h->W, h->d_v2f, C * 2 * h->W * sizeof(float), hipMemcpyDeviceToHost, h->ds));
-			HIPCHK(hipMemcpyAsync(h->h_v2prom + s_ * C * 2 * h->W, h->d_v2prom, C * 2 * h->W * sizeof(float), hipMemcpyDeviceToHost, h->ds));
-			HIPCHK(hipMemcpyAsync(h->h_v2en + s_ * C * (h->W + 1), h->d_v2en, C * (h->W + 1) * sizeof(float), hipMemcpyDeviceToHost, h->ds));
-			HIPCHK(hipMemcpyAsync(h->h_fmbits + s_ * C * (h->L / 32), h->d_fmbits[pb], C * (h->L / 32) * sizeof(uint32_t), hipMemcpyDeviceToHost, h->ds));
+			if (on_device) {
+				KV2EParams e{};
+				e.k = k; e.fm_prev = h->d_fmbits[pb ^ 1]; e.st = h->d_v2st; e.dec = h->d_dec; e.slot_cs = h->d_slotcs;
+				e.w_train = 0.75f; e.w_track = 0.86f; // PhaseTracker's defaults (V2Engine.h:70-71)
+				e.frames = h->d_frames; e.frame_count = h->d_frame_count; e.max_frames = h->max_frames;
+				e.block = (unsigned)h->block_idx; e.sub = (unsigned)h->n_sub; e.locked_estimates = h->d_v2locked;
+				memcpy(e.taps17, TAPS_COHERENT, sizeof e.taps17);
+				HIPCHK(launch_kv2(k, h->ds, &e));
+			} else {
+				HIPCHK(launch_kv2(k, h->ds));
+				HIPCHK(hipMemcpyAsync(h->h_v2f + s_ * C * 2 * h->W, h->d_v2f, C * 2 * h->W * sizeof(float), hipMemcpyDeviceToHost, h->ds));
+				HIPCHK(hipMemcpyAsync(h->h_v2prom + s_ * C * 2 * h->W, h->d_v2prom, C * 2 * h->W * sizeof(float), hipMemcpyDeviceToHost, h->ds));
+				HIPCHK(hipMemcpyAsync(h->h_v2en + s_ * C * (h->W + 1), h->d_v2en, C * (h->W + 1) * sizeof(float), hipMemcpyDeviceToHost, h->ds));
+				HIPCHK(hipMemcpyAsync(h->h_fmbits + s_ * C * (h->L / 32), h->d_fmbits[pb], C * (h->L / 32) * sizeof(uint32_t), hipMemcpyDeviceToHost, h->ds));
+			}
 		}
 		SubOut& so = h->sub[h->n_sub++];
 		so.pb = pb; so.lv = 0; so.q = q; so.groups = 0; so.first_group = h->n48 / 5; so.first48 = h->n48;
@@ -868,6 +881,7 @@ int gather_frames(aisgpu_t* h) {
 			const unsigned ord = dec % 10;
 			o.rx = (int)(dec / 20); o.ch = (int)(dec / 10 % 2); o.phase = ord < 4 ? 5 + (int)ord : ord == 9 ? 9 : (int)ord - 4; // 5..9: the FM decoders
 		} else if (h->dec_kind == 3) { o.rx = (int)(dec / 2); o.ch = (int)(dec % 2); o.phase = 0; } // ModelBase: one decoder per channel
+		else if (h->dec_kind == 4) { o.rx = (int)(dec / 12); o.ch = (int)(dec / 6 % 2); o.phase = (int)(dec % 6); } // ModelEngineV2: 0..4 behind the trackers, 5 the FM decoder
 		else { o.rx = (int)(dec / 10); o.ch = (int)(dec / 5 % 2); o.phase = (int)(dec % 5); }
 		o.group = (int)f[1]; o.position = (int)f[2];
 		memcpy(&o.level_sum, &f[3], 4);
@@ -897,6 +911,7 @@ int gather_frames(aisgpu_t* h) {
 		const long long sx = slice_of(x), sy = slice_of(y);
 		if (sx != sy) return sx < sy;
 		if (x.ch != y.ch) return x.ch < y.ch;
+		if (h->dec_kind == 4) { if (x.end_idx != y.end_idx) return x.end_idx < y.end_idx; return x.phase < y.phase; } // (group carries tag.ppm there)
 		if (x.group != y.group) return x.group < y.group;
 		if (h->dec_kind == 2) return fa[0] % 10 < fb[0] % 10; // the reference's order inside a group
 		return x.phase < y.phase;
@@ -1348,8 +1363,20 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	}
 	h->gpu_decode = (cfg->flags & AISGPU_FLAG_GPU_DECODE) != 0;
 	if (h->gpu_decode) {
-		if (cfg->model == AISGPU_MODEL_V2) { h->err = "AISGPU_FLAG_GPU_DECODE: not for ModelEngineV2 (its decoders steer the engine block by block)"; return AISGPU_ERR_ARG; }
-		h->dec_kind = cfg->model == AISGPU_MODEL_STANDARD ? 1 : cfg->model == AISGPU_MODEL_CHALLENGER ? 2 : cfg->model == AISGPU_MODEL_BASE ? 3 : 0;
+		// ModelEngineV2 (4): six decoders per channel inside the engine kernel (kv2_engine): tone gate, derotation, trackers, decoders
+		h->dec_kind = cfg->model == AISGPU_MODEL_STANDARD ? 1 : cfg->model == AISGPU_MODEL_CHALLENGER ? 2 : cfg->model == AISGPU_MODEL_BASE ? 3 : cfg->model == AISGPU_MODEL_V2 ? 4 : 0;
+		if (h->dec_kind == 4) {
+			std::vector<V2ChanState> init(C);
+			memset(init.data(), 0, C * sizeof(V2ChanState));
+			for (size_t i = 0; i < C; i++) init[i].rot = make_float2(1.0f, 0.0f); // FreqOffset::rot (V2Engine.h:34)
+			HIPCHK(dalloc(&h->d_v2st, C));
+			HIPCHK(hipMemcpy(h->d_v2st, init.data(), C * sizeof(V2ChanState), hipMemcpyHostToDevice));
+			std::vector<float2> cs(1280); // learnSlotPhase (V2Engine.cpp:331-333): th = (float)m * (2 pi / SLOT), the host's cosf / sinf
+			for (int m = 0; m < 1280; m++) { const float th = (float)m * (2.0f * PI_F / 1280); cs[m] = make_float2(cosf(th), sinf(th)); }
+			HIPCHK(dalloc(&h->d_slotcs, 1280));
+			HIPCHK(hipMemcpy(h->d_slotcs, cs.data(), 1280 * sizeof(float2), hipMemcpyHostToDevice));
+			HIPCHK(dalloc(&h->d_v2locked, 1));
+		}
 		h->max_frames = (int)C * 64; // ring between two aisgpu_sync_outputs(): a slot holds ~2 frames per channel and block
 		HIPCHK(dalloc(&h->d_dec, (size_t)C * 10)); // zero = State::TRAINING, lastBit = prev = 0 (Marine/AIS.h:44-56); up to ten decoders per channel
 		// chunk-parallel sampler + decoder loop (kernels.h: K7b); "seq" / blocks of unusual length: k7_base alone
@@ -1383,6 +1410,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmrows[i], C * 5 * (size_t)h->fmrow_words));
 			for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_last_lvl[i], C));
 		}
+		if (h->dec_kind == 4) h->dec_defer = false; // (ModelEngineV2: the decoders run inside the engine kernel)
 		if (h->dec_kind > 2) h->k7_event = false; // the event-driven form: ModelDefault's wiring, ModelStandard's (the same mesh of five on the FM rows), ModelChallenger's mesh of ten
 		if (h->dec_kind == 1 || h->dec_kind == 3) h->dec_defer = false; // (ModelStandard / ModelBase: their decoders are enqueued by the FM receiver's own flow)
 		// (on the decimate-by-3 ladders Rotate alternates between the channels every 4096 samples, and with it the level the FM
@@ -1537,7 +1565,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_fm); hipFree(h->d_fmhist[0]); hipFree(h->d_fmhist[1]); hipFree(h->d_fmfir); hipFree(h->d_fmbits[0]); hipFree(h->d_fmbits[1]);
 	if (h->h_fmbits) hipHostFree(h->h_fmbits);
 	if (h->h_c48) hipHostFree(h->h_c48);
-	hipFree(h->d_v2hist); hipFree(h->d_v2f); hipFree(h->d_v2prom); hipFree(h->d_v2en);
+	hipFree(h->d_v2hist); hipFree(h->d_v2f); hipFree(h->d_v2prom); hipFree(h->d_v2en); hipFree(h->d_v2st); hipFree(h->d_slotcs); hipFree(h->d_v2locked);
 	if (h->h_v2f) hipHostFree(h->h_v2f); if (h->h_v2prom) hipHostFree(h->h_v2prom); if (h->h_v2en) hipHostFree(h->h_v2en);
 	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); }
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);

@@ -325,7 +325,33 @@ struct KV2Params {
 	float taps[37];
 	int n_windows, L, n_chan;
 };
-hipError_t launch_kv2(const KV2Params& p, hipStream_t s);
+// ModelEngineV2 with AISGPU_FLAG_GPU_DECODE (round 4): the engine's coherent branch on the device as well -- per channel strictly
+// sequential over its 512-sample blocks, like the reference (V2Engine.cpp:293-388): the tone gate / slot lock decide the frequency
+// from the decoders' states, Derotate is an accumulated phasor, the five PhaseTrackers take their loop weight from their decoder's
+// state sample by sample, the six decoders reset each other.  kv2_engine: one wave = V2E_NCH channels x 6 lanes (five tracker +
+// decoder lanes and the FM decoder behind its BitPLL), the groups of five samples in step, the reference's order inside a group
+// restored only where a message completes.  Exact but for ONE function: std::polar of the estimated frequency is the device's
+// sincosf, not the host libm's; frames out like the other engines' device decoders.
+constexpr int V2E_NCH = 10;
+struct V2Tracker { unsigned rot; float2 s; int prev_decision; };
+struct V2ChanState { // zero-initialised but for rot = (1, 0)
+	float2 rot; float last_f; float ppm, ppm_prev; float2 slot_ema; int slot_phase, di; long long sample_idx;
+	float pll_phase; int pll_last;
+	V2Tracker trk[5];
+	float2 carry17[16];
+};
+struct KV2EParams {
+	KV2Params k;               // this block's channels, the previous block's tail, estimates, energies, this block's discriminator signs
+	const uint32_t* fm_prev;   // [n_chan][L / 32] the previous block's discriminator signs
+	V2ChanState* st;           // [n_chan]
+	DecState* dec;             // [n_chan * 6]
+	const float2* slot_cs;     // [1280] (cosf, sinf)(k * (2 pi / 1280)) from the host's libm (learnSlotPhase, :328-337)
+	float w_train, w_track;
+	uint32_t* frames; unsigned* frame_count; int max_frames; unsigned block, sub;
+	int* locked_estimates;     // statistics: Estimate() calls at a learned slot phase (the windows the assist kernels cannot know)
+	float taps17[17];
+};
+hipError_t launch_kv2(const KV2Params& p, hipStream_t s, const KV2EParams* engine = nullptr); // engine: kv2_engine runs before the look-back is overwritten
 hipError_t launch_k4(const K4Params& p, hipStream_t s);          // chunk-parallel + assemble (with the exact sequential search where a speculative warm-up failed)
 hipError_t launch_k4_sequential(const K4Params& p, hipStream_t s); // the plain sequential kernel only
 hipError_t launch_k4_box(const K4Params& p, hipStream_t s);        // Demod::PhaseSearch (boxcar history), sequential

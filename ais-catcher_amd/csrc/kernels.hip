@@ -2119,6 +2119,72 @@ __device__ __forceinline__ float2 v2_sample(const KV2Params& p, int chan, int n)
 // (fft512 passes as in k2_fft_mag), magnitudes sqrtf(re^2 + im^2) in float (norm2, :33-36) in fftshift order, then one lane
 // per window runs the reference's loops in their order: the rolling 133-bin sum (two dependent operations per step), the peak
 // pair 102 bins apart, the total, the prominence and the parabola through the three pair sums.
+// the wave-wide part: magnitudes of the window that starts at sample s0 of the channel, fftshift order, into mg[512]
+__device__ __forceinline__ void v2_fft_mag_window(const KV2Params& p, int chan, int s0, float2* X, float* mg, FftTwiddles& t, int lane) {
+	const int src = fft_src_lane(lane);
+	float2 dn[8];
+#pragma unroll
+	for (int r = 0; r < 8; r++) dn[r] = v2_sample(p, chan, s0 + src + fft_src_step(r));
+	c2 v[8];
+	fft_square(dn, v); // window[n] * window[n] into the bit-reversed position (:63-64)
+	const int l7 = lane & 7, l8 = lane >> 3;
+	fft_pass(v, t.a0, t.a1, t.a2);
+#pragma unroll
+	for (int r = 0; r < 8; r++) X[9 * lane + r] = make_float2(v[r].x, v[r].y);
+	wave_sync();
+#pragma unroll
+	for (int r = 0; r < 8; r++) { const float2 d = X[l7 + 9 * r + 72 * l8]; v[r] = c2{ d.x, d.y }; }
+	wave_sync();
+	fft_pass(v, t.b0, t.b1, t.b2);
+#pragma unroll
+	for (int r = 0; r < 8; r++) X[l7 + 8 * r + 72 * l8] = make_float2(v[r].x, v[r].y);
+	wave_sync();
+#pragma unroll
+	for (int r = 0; r < 8; r++) { const float2 d = X[lane + 72 * r]; v[r] = c2{ d.x, d.y }; }
+	wave_sync();
+	fft_pass(v, t.c0, t.c1, t.c2_); // bin lane + 64 r
+#pragma unroll
+	// sqrtf(norm2(x)) (:69-72): the float square root through the correctly rounded double one (53 >= 2 * 24 + 2 bits: exact)
+	for (int r = 0; r < 8; r++) mg[(lane + 64 * r + 256) & 511] = (float)__dsqrt_rn((double)(v[r].x * v[r].x + v[r].y * v[r].y));
+}
+// the sequential part (:74-131), one lane: the reference's loops in their order
+__device__ __forceinline__ void v2_search(const float* m, float& f_out, float& prom_out) {
+	constexpr int N = 512, delta = 102, M = 133, ofs = 15;
+	float rolling = 0.0f;
+	for (int jx = 0; jx < M; jx++) rolling += m[jx];
+	float best = rolling + 0.6f * (m[ofs] + m[ofs + delta]);
+	int wi_ = 0;
+	for (int i = 1; i <= N - M; i++) {
+		rolling = rolling - m[i - 1] + m[i + M - 1];
+		const float v = rolling + 0.6f * (m[i + ofs] + m[i + ofs + delta]);
+		if (v > best) { best = v; wi_ = i; }
+	}
+	int fz = -1;
+	float peak = 0.0f;
+	for (int i = wi_; i < wi_ + (M - delta); i++) {
+		const float h = m[i] + m[i + delta];
+		if (h > peak) { peak = h; fz = i; }
+	}
+	float total = 0.0f;
+	for (int i = 0; i < N; i++) total += m[i];
+	prom_out = total > 0.0f ? __fdiv_rn(peak * (float)(N / 2), total) : 0.0f;
+	float f = 0.0f;
+	if (fz >= 0) {
+		float frac = 0.0f;
+		if (fz > 0 && fz + delta + 1 < N) {
+			const float a = m[fz - 1] + m[fz - 1 + delta];
+			const float c = m[fz + 1] + m[fz + 1 + delta];
+			const float den = a - 2.0f * peak + c;
+			if (den < 0.0f) {
+				frac = __fdiv_rn(0.5f * (a - c), den);
+				frac = frac > 0.5f ? 0.5f : (frac < -0.5f ? -0.5f : frac);
+			}
+		}
+		f = __fdiv_rn(__fdiv_rn((float)(N / 2) - ((float)fz + frac + 51.0f), 2.0f), (float)N);
+	}
+	f_out = f;
+}
+
 __global__ __launch_bounds__(64) void kv2_estimate(KV2Params p) {
 	__shared__ __attribute__((aligned(16))) float2 X[584];
 	__shared__ __attribute__((aligned(16))) float mag[FFT_NW * MAG_STRIDE];
@@ -2126,75 +2192,17 @@ __global__ __launch_bounds__(64) void kv2_estimate(KV2Params p) {
 	const int nw = 2 * p.n_windows;
 	const int W0 = blockIdx.x * FFT_NW, n_win_total = p.n_chan * nw;
 	FftTwiddles t = fft_twiddles(p.omega, lane);
-	const int src = fft_src_lane(lane);
 	for (int wi = 0; wi < FFT_NW; wi++) {
 		const int W = W0 + wi;
 		if (W >= n_win_total) break;
 		const int chan = W / nw, w = W - chan * nw;
-		const int s0 = -V2_HIST + 256 * w;
-		float2 dn[8];
-#pragma unroll
-		for (int r = 0; r < 8; r++) dn[r] = v2_sample(p, chan, s0 + src + fft_src_step(r));
-		c2 v[8];
-		fft_square(dn, v); // window[n] * window[n] into the bit-reversed position (:63-64)
-		const int l7 = lane & 7, l8 = lane >> 3;
-		fft_pass(v, t.a0, t.a1, t.a2);
-#pragma unroll
-		for (int r = 0; r < 8; r++) X[9 * lane + r] = make_float2(v[r].x, v[r].y);
-		wave_sync();
-#pragma unroll
-		for (int r = 0; r < 8; r++) { const float2 d = X[l7 + 9 * r + 72 * l8]; v[r] = c2{ d.x, d.y }; }
-		wave_sync();
-		fft_pass(v, t.b0, t.b1, t.b2);
-#pragma unroll
-		for (int r = 0; r < 8; r++) X[l7 + 8 * r + 72 * l8] = make_float2(v[r].x, v[r].y);
-		wave_sync();
-#pragma unroll
-		for (int r = 0; r < 8; r++) { const float2 d = X[lane + 72 * r]; v[r] = c2{ d.x, d.y }; }
-		wave_sync();
-		fft_pass(v, t.c0, t.c1, t.c2_); // bin lane + 64 r
-		float* mg = mag + wi * MAG_STRIDE;
-#pragma unroll
-		// sqrtf(norm2(x)) (:69-72): the float square root through the correctly rounded double one (53 >= 2 * 24 + 2 bits: exact)
-		for (int r = 0; r < 8; r++) mg[(lane + 64 * r + 256) & 511] = (float)__dsqrt_rn((double)(v[r].x * v[r].x + v[r].y * v[r].y));
+		v2_fft_mag_window(p, chan, -V2_HIST + 256 * w, X, mag + wi * MAG_STRIDE, t, lane);
 	}
 	wave_sync();
 	const int W = W0 + lane;
 	if (lane < FFT_NW && W < n_win_total) {
-		const float* m = mag + lane * MAG_STRIDE;
-		constexpr int N = 512, delta = 102, M = 133, ofs = 15;
-		float rolling = 0.0f;
-		for (int jx = 0; jx < M; jx++) rolling += m[jx];
-		float best = rolling + 0.6f * (m[ofs] + m[ofs + delta]);
-		int wi_ = 0;
-		for (int i = 1; i <= N - M; i++) {
-			rolling = rolling - m[i - 1] + m[i + M - 1];
-			const float v = rolling + 0.6f * (m[i + ofs] + m[i + ofs + delta]);
-			if (v > best) { best = v; wi_ = i; }
-		}
-		int fz = -1;
-		float peak = 0.0f;
-		for (int i = wi_; i < wi_ + (M - delta); i++) {
-			const float h = m[i] + m[i + delta];
-			if (h > peak) { peak = h; fz = i; }
-		}
-		float total = 0.0f;
-		for (int i = 0; i < N; i++) total += m[i];
-		const float prom = total > 0.0f ? __fdiv_rn(peak * (float)(N / 2), total) : 0.0f;
-		float f = 0.0f;
-		if (fz >= 0) {
-			float frac = 0.0f;
-			if (fz > 0 && fz + delta + 1 < N) {
-				const float a = m[fz - 1] + m[fz - 1 + delta];
-				const float c = m[fz + 1] + m[fz + 1 + delta];
-				const float den = a - 2.0f * peak + c;
-				if (den < 0.0f) {
-					frac = __fdiv_rn(0.5f * (a - c), den);
-					frac = frac > 0.5f ? 0.5f : (frac < -0.5f ? -0.5f : frac);
-				}
-			}
-			f = __fdiv_rn(__fdiv_rn((float)(N / 2) - ((float)fz + frac + 51.0f), 2.0f), (float)N);
-		}
+		float f, prom;
+		v2_search(mag + lane * MAG_STRIDE, f, prom);
 		p.est_f[W] = f;
 		p.est_prom[W] = prom;
 	}
@@ -2353,6 +2361,262 @@ __global__ __launch_bounds__(64) void k7_decode(K7Params p) {
 		data[64 * r.cwi] = r.cw;
 		for (int w = 0; w < DEC_DATA_WORDS; w++) st->data[w] = data[64 * w];
 		st->crc[0] = r.crc; st->crc[1] = r.cw; st->crc[2] = (uint32_t)r.cwi; st->crc[3] = r.tail; st->crc[4] = (uint32_t)r.abort_pos;
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// KV2E: V2::Engine's coherent branch with its decoders on the device (kernels.h: KV2EParams).  Per channel everything below
+// happens in the reference's order; what is parallel is the channels (V2E_NCH per wave) and, inside a channel, the six
+// decoders of a group of five samples -- until one of them completes a message: then the group is redone sample by sample.
+// ------------------------------------------------------------------------------------------
+struct V2Lane { DecReg r; V2Tracker t; float pll_phase; int pll_last; };
+
+__device__ __forceinline__ c2 v2_dot17(const float2* a, const float* taps) { // dot17 (:38-45)
+	c2 sum = { 0.0f, 0.0f };
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		const float2 u = a[i], v = a[16 - i];
+		const c2 w = c2{ u.x + v.x, u.y + v.y };
+		sum = sum + w * taps[i];
+	}
+	const float2 m = a[8];
+	return sum + c2{ m.x, m.y } * taps[8];
+}
+__device__ __forceinline__ int v2_track(V2Tracker& t, c2 z, bool training, float w_train, float w_track) { // PhaseTracker::Run (:190-223)
+	const unsigned rot = t.rot;
+	const float sre = (rot & 1) ? z.y : z.x, sim = (rot & 1) ? z.x : z.y;
+	const float zr = ((rot ^ (rot >> 1)) & 1) ? -sre : sre, zi = (rot & 2) ? -sim : sim;
+	t.rot = (rot + 1) & 3;
+	const float alpha = training ? w_train : w_track;
+	const float beta = 1.0f - alpha;
+	const float proj = zr * t.s.x + zi * t.s.y;
+	const float d = proj >= 0.0f ? 1.0f : -1.0f;
+	const float bd = beta * d;
+	t.s = make_float2(alpha * t.s.x + bd * zr, alpha * t.s.y + bd * zi);
+	const int decision = proj > 0.0f ? 1 : 0;
+	const int bit = decision ^ t.prev_decision;
+	t.prev_decision = decision;
+	return bit;
+}
+__device__ __forceinline__ bool v2_pll(float& phase, int& last_bit, int bit, bool training) { // BitPLL::Run (:225-242)
+	if (bit != last_bit) phase += (0.5f - phase) * (training ? 0.6f : 0.05f);
+	last_bit = bit;
+	phase += 0.2f;
+	if (phase < 1.0f) return false;
+	phase -= (float)(int)phase;
+	return true;
+}
+__device__ __forceinline__ void v2_reset(DecReg& r) { r.state = DST_TRAINING; r.position = 0; r.osc = 0; }
+
+__global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
+	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64]; // [word][lane]
+	__shared__ __attribute__((aligned(16))) float2 dero[V2E_NCH][16 + 512 + 2];
+	__shared__ __attribute__((aligned(16))) float2 X[584];
+	__shared__ __attribute__((aligned(16))) float mag[512 + 8];
+	const KV2Params& p = q.k;
+	const int lane = threadIdx.x;
+	const int mesh = lane / 6, j = lane - 6 * mesh; // lanes 60..63 idle
+	const int chan_raw = blockIdx.x * V2E_NCH + mesh;
+	const bool live = lane < 6 * V2E_NCH && chan_raw < p.n_chan;
+	const int chan = live ? chan_raw : p.n_chan - 1;
+	const int lead = mesh * 6;                        // the channel's first lane: it owns the engine's scalar state
+	const bool leader = live && j == 0;
+	const int dec = chan * 6 + j;
+	uint32_t* data = fdata + lane;
+	V2ChanState* cs = q.st + chan;
+	V2Lane L;
+	{
+		const DecState* st = q.dec + dec;
+		DecReg& r = L.r;
+		r.state = st->state; r.lastBit = st->lastBit; r.prev = st->prev; r.position = st->position; r.osc = st->osc;
+		r.level = st->level; r.start_idx = st->start_idx;
+		for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = st->data[w];
+		r.crc = st->crc[0]; r.cw = st->crc[1]; r.cwi = (int)st->crc[2]; r.tail = st->crc[3]; r.abort_pos = (int)st->crc[4];
+		L.t = cs->trk[j < 5 ? j : 0];
+		L.pll_phase = cs->pll_phase; L.pll_last = cs->pll_last;
+	}
+	float2 rot = cs->rot, slot_ema = cs->slot_ema;
+	float last_f = cs->last_f, ppm = cs->ppm, ppm_prev = cs->ppm_prev;
+	int slot_phase = cs->slot_phase, di = cs->di;
+	long long sample_idx = cs->sample_idx;
+	if (live) for (int i = j; i < 16; i += 6) dero[mesh][i] = cs->carry17[i];
+	FftTwiddles tw = fft_twiddles(p.omega, lane);
+	const uint32_t* fm_cur = p.fmbits + (size_t)chan * p.fmbits_stride;
+	const uint32_t* fm_old = q.fm_prev + (size_t)chan * p.fmbits_stride;
+	const auto fm_sign = [&](int n) -> int { // sign of the filtered discriminator at sample n of this device block (n < 0: the previous block)
+		const int m = n < 0 ? n + p.L : n;
+		const uint32_t w = (n < 0 ? fm_old : fm_cur)[m >> 5];
+		return (int)((w >> (m & 31)) & 1u);
+	};
+	const auto emit = [&](const DecReg& r, long long sidx, float tag_ppm) {
+		const unsigned slot = atomicAdd(q.frame_count, 1u) % (unsigned)q.max_frames;
+		uint32_t* f = q.frames + (size_t)slot * DEC_FRAME_WORDS;
+		f[0] = (uint32_t)dec; f[1] = __float_as_uint(tag_ppm); f[2] = (uint32_t)r.position; f[3] = __float_as_uint(r.level);
+		f[4] = (uint32_t)(unsigned long long)r.start_idx; f[5] = (uint32_t)((unsigned long long)r.start_idx >> 32);
+		f[6] = (uint32_t)(unsigned long long)sidx; f[7] = (uint32_t)((unsigned long long)sidx >> 32);
+		f[8] = q.block; f[9] = q.sub;
+		for (int w = 0; w < DEC_DATA_WORDS; w++) f[10 + w] = data[64 * w];
+	};
+	const auto learn_slot = [&](long long start_idx) { // learnSlotPhase (:328-337), the leader's registers
+		const long long a = start_idx - 155;
+		const int m = (int)((a % 1280 + 1280) % 1280);
+		const float2 csv = q.slot_cs[m];
+		slot_ema = make_float2((1.0f - 0.2f) * slot_ema.x + 0.2f * csv.x, (1.0f - 0.2f) * slot_ema.y + 0.2f * csv.y);
+		const float ph = atan2f_ref(slot_ema.y, slot_ema.x) * (1280.0f / (2.0f * 3.14159265358979323846f));
+		slot_phase = (int)(ph + 1280.0f + 0.5f) % 1280;
+	};
+	const auto derotate = [&](float f, int from, int to) { // FreqOffset::Derotate (:133-146) over samples [from, to) of the block that starts at n0
+		float sn, cn;
+		sincosf(f * 2.0f * 3.14159265358979323846f, &sn, &cn); // std::polar(1.0f, f * 2 pi): the device's sincosf (see kernels.h)
+		const c2 st = { cn, sn }, st_sw = { -sn, cn };
+		c2 r = { rot.x, rot.y };
+		float2* d = &dero[mesh][16]; // (the block's raw samples, staged by the whole wave: derotated in place)
+		for (int k = from; k < to; k++) {
+			const float2 x = d[k];
+			r = r.xx * st + r.yy * st_sw; // r *= rot_step
+			d[k] = make_float2(x.x * r.x - x.y * r.y, x.x * r.y + x.y * r.x); // src * r
+		}
+		const float a = hypot_ref(r.x, r.y);
+		rot = make_float2(__fdiv_rn(r.x, a), __fdiv_rn(r.y, a));
+		last_f = f;
+	};
+
+	for (int blk = 0; blk < p.n_windows; blk++) {
+		const int n0 = -V2_HIST + 512 * blk; // the decoded block; [n0 + 512, n0 + 1024) is the look-ahead
+		// the block's 512 samples of every channel of the wave into LDS (coalesced, all lanes): the leader derotates them in place --
+		// fetched by the leader inside its serial loop they were sixty-four memory round trips per block
+		for (int m = 0; m < V2E_NCH; m++) {
+			const int cm = blockIdx.x * V2E_NCH + m;
+			if (cm >= p.n_chan) break;
+#pragma unroll
+			for (int i = 0; i < 8; i++) dero[m][16 + i * 64 + lane] = v2_sample(p, cm, n0 + i * 64 + lane);
+		}
+		wave_sync();
+		// ---- Engine::processBlock (:345-352): slot predictor decay, busy, CGF
+		const unsigned long long B = __ballot(live && j < 5 && L.r.state != DST_TRAINING);
+		const bool busy = ((B >> lead) & 31ull) != 0;
+		int split = 0;
+		float f = 0.0f;
+		bool need_est = false;
+		int e_slot = 0;
+		if (leader) {
+			slot_ema = make_float2(slot_ema.x * 0.9999f, slot_ema.y * 0.9999f);
+			const bool locked = slot_ema.x * slot_ema.x + slot_ema.y * slot_ema.y >= 0.64f;
+			e_slot = (int)((((long long)slot_phase - sample_idx) % 1280 + 1280) % 1280);
+			ppm_prev = ppm;
+			if (locked && e_slot < 512) { need_est = true; split = e_slot; }
+			else {
+				const float* en = p.energy + (size_t)chan * (p.n_windows + 1);
+				const bool louder = en[blk + 1] > en[blk];
+				const int w = 2 * blk + ((!busy && louder) ? 1 : 0);
+				f = p.est_f[(size_t)chan * 2 * p.n_windows + w];
+				const float prom = p.est_prom[(size_t)chan * 2 * p.n_windows + w];
+				if (busy && prom < 5.5f) f = last_f; // tone gate: hold while a decode is in flight
+			}
+		}
+		// a slot starts inside this block: [0, e) keeps the previous frequency, Estimate() works on the 512 samples from e on -- a window
+		// the assist kernels did not compute.  The whole wave does its FFT, channel by channel; its leader the sequential search.
+		unsigned long long NE = __ballot(need_est);
+		if (NE != 0 && leader && need_est) derotate(last_f, 0, split); // (also for e == 0: the renormalisation happens)
+		while (NE != 0) {
+			const int ll = __builtin_ctzll(NE);
+			NE &= NE - 1;
+			const int ch2 = __shfl(chan, ll), e2 = __shfl(split, ll);
+			v2_fft_mag_window(p, ch2, n0 + e2, X, mag, tw, lane);
+			wave_sync();
+			if (lane == ll) { float prom; v2_search(mag, f, prom); if (q.locked_estimates) atomicAdd(q.locked_estimates, 1); }
+			wave_sync();
+		}
+		if (leader) {
+			derotate(f, split, 512);
+			ppm = __fdiv_rn(f * 48000.0f, 162.0f);
+		}
+		wave_sync();
+		const float b_ppm = __shfl(ppm, lead), b_ppm_prev = __shfl(ppm_prev, lead);
+		const int b_split = __shfl(split, lead);
+		// ---- the 512 samples: tracker di handles sample i (di runs on across blocks), the FM decoder sees every sample through its PLL
+		const int off = j < 5 ? (j - di + 5) % 5 : 0; // this tracker's sample inside a group of five
+		for (int g5 = 0; g5 < 512; g5 += 5) {
+			const V2Lane before = L;
+			const int ng = 512 - g5 < 5 ? 512 - g5 : 5;
+			// the FM decoder's lane: its PLL over the group's samples up to the first one on which it fires -- that symbol goes through
+			// the decoder together with the trackers' -- and, behind the decoder step (the PLL's gain follows the decoder's state), the rest
+			int my_k = -1, s_next = ng;
+			if (j == 5) {
+				const bool training = L.r.state == DST_TRAINING;
+				for (int s5 = 0; s5 < ng; s5++)
+					if (v2_pll(L.pll_phase, L.pll_last, fm_sign(n0 + g5 + s5), training)) { my_k = g5 + s5; s_next = s5 + 1; break; }
+			} else if (off < ng) my_k = g5 + off;
+			const bool have = live && my_k >= 0;
+			const int kk = have ? my_k : 0;
+			const c2 z = v2_dot17(&dero[mesh][kk], q.taps17); // FilterFL17 (:154-167): output kk from carry + block samples kk .. kk + 16
+			const int bit = j < 5 ? v2_track(L.t, z, L.r.state == DST_TRAINING, q.w_train, q.w_track) : fm_sign(n0 + kk);
+			if (!have && j < 5) L.t = before.t;
+			const float slvl = z.x * z.x + z.y * z.y;
+			const long long sidx = sample_idx + kk;
+			bool found = have && dec_step(L.r, bit, slvl, sidx, data);
+			bool again = false;
+			if (j == 5) {
+				const bool training = L.r.state == DST_TRAINING;
+				for (int s5 = s_next; s5 < ng; s5++) again = v2_pll(L.pll_phase, L.pll_last, fm_sign(n0 + g5 + s5), training) || again;
+			}
+			// anything that breaks the lockstep -- a completed message (it resets the other five at ITS sample), or an FM decoder that
+			// clocks two symbols inside one group -- sends the channel through the reference's own order, sample by sample
+			const unsigned long long F = __ballot(found || (again && live));
+			if (((F >> lead) & 63ull) != 0 && live) {
+				L = before;
+				// (the frame buffers: a lane that is rolled back may have written a word of its column: dec_step rewrites what it needs)
+				for (int s5 = 0; s5 < ng; s5++) {
+					const int k5 = g5 + s5;
+					const float tag_ppm = k5 >= b_split ? b_ppm : b_ppm_prev;
+					const long long si = sample_idx + k5;
+					const c2 zz = v2_dot17(&dero[mesh][k5], q.taps17);
+					const float lv = zz.x * zz.x + zz.y * zz.y;
+					bool fnd = false;
+					if (j < 5 && off == s5) {
+						const int b2 = v2_track(L.t, zz, L.r.state == DST_TRAINING, q.w_train, q.w_track);
+						fnd = dec_step(L.r, b2, lv, si, data);
+						if (fnd) emit(L.r, si, tag_ppm);
+					}
+					unsigned long long FF = __ballot(fnd);
+					unsigned hit = (unsigned)((FF >> lead) & 63ull);
+					if (hit) { // learnSlotPhase(dec[di]) + resetDecoders()
+						const long long sidx0 = __shfl(L.r.start_idx, lead + __builtin_ctz(hit));
+						if (j == 0) learn_slot(sidx0);
+						v2_reset(L.r);
+					}
+					fnd = false;
+					if (j == 5 && v2_pll(L.pll_phase, L.pll_last, fm_sign(n0 + k5), L.r.state == DST_TRAINING)) {
+						fnd = dec_step(L.r, fm_sign(n0 + k5), lv, si, data);
+						if (fnd) emit(L.r, si, tag_ppm);
+					}
+					FF = __ballot(fnd);
+					hit = (unsigned)((FF >> lead) & 63ull);
+					if (hit) v2_reset(L.r);
+				}
+			}
+		}
+		sample_idx += 512;
+		di = (di + 512) % 5;
+		wave_sync();
+		if (live) for (int i = j; i < 16; i += 6) dero[mesh][i] = dero[mesh][512 + i]; // FilterFL17's carry
+		wave_sync();
+	}
+	if (live) {
+		DecState* st = q.dec + dec;
+		const DecReg& r = L.r;
+		st->state = r.state; st->lastBit = r.lastBit; st->prev = r.prev; st->position = r.position; st->osc = r.osc;
+		st->level = r.level; st->start_idx = r.start_idx;
+		data[64 * r.cwi] = r.cw;
+		for (int w = 0; w < DEC_DATA_WORDS; w++) st->data[w] = data[64 * w];
+		st->crc[0] = r.crc; st->crc[1] = r.cw; st->crc[2] = (uint32_t)r.cwi; st->crc[3] = r.tail; st->crc[4] = (uint32_t)r.abort_pos;
+		if (j < 5) cs->trk[j] = L.t;
+		if (j == 5) { cs->pll_phase = L.pll_phase; cs->pll_last = L.pll_last; }
+		if (j == 0) {
+			cs->rot = rot; cs->last_f = last_f; cs->ppm = ppm; cs->ppm_prev = ppm_prev; cs->slot_ema = slot_ema; cs->slot_phase = slot_phase;
+			cs->di = di; cs->sample_idx = sample_idx;
+		}
+		for (int i = j; i < 16; i += 6) cs->carry17[i] = dero[mesh][i];
 	}
 }
 
@@ -3537,12 +3801,13 @@ hipError_t launch_k7(const K7Params& p, hipStream_t s) {
 	return hipGetLastError();
 }
 
-hipError_t launch_kv2(const KV2Params& p, hipStream_t s) {
+hipError_t launch_kv2(const KV2Params& p, hipStream_t s, const KV2EParams* engine) {
 	const int n_est = p.n_chan * 2 * p.n_windows;
 	hipLaunchKernelGGL(kv2_estimate, dim3((n_est + FFT_NW - 1) / FFT_NW), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(kv2_energy, dim3((p.n_chan * (p.n_windows + 1) + 63) / 64), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(kv2_fm, dim3(p.L / 256, p.n_chan), dim3(256), 0, s, p);
 	hipLaunchKernelGGL(kv2_filter, dim3(p.L / 256, p.n_chan), dim3(256), 0, s, p);
+	if (engine) hipLaunchKernelGGL(kv2_engine, dim3((p.n_chan + V2E_NCH - 1) / V2E_NCH), dim3(64), 0, s, *engine); // (reads the look-back: before the carry)
 	hipLaunchKernelGGL(kv2_carry, dim3(p.n_chan), dim3(64), 0, s, p);
 	return hipGetLastError();
 }

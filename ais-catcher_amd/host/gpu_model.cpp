@@ -1,5 +1,6 @@
 // ais-catcher_amd/host/gpu_model.cpp -- see gpu_model.h
 #include "gpu_model.h"
+#include <cstring>
 
 #include <algorithm>
 #include <chrono>
@@ -155,7 +156,10 @@ void ModelDefaultGPU::wireDecoders(char CH1, char CH2) {
 	// (phase 0..4: DEC_x[phase] -- DEC_base_x for ModelBase --, 5..9: the FM decoders DEC_xf[phase - 5] of ModelChallenger)
 	chain.setFrameHandler([this](const aisgpu_frame& f, TAG& tag) {
 		AIS::Decoder* d;
-		if (base) d = f.ch == 0 ? &DEC_base_a : &DEC_base_b;
+		if (v2) { // the engine ran on the device (kv2_engine): decoder 0..4 behind the trackers, 5 the FM decoder; group = the bits of tag.ppm
+			d = &(f.ch == 0 ? V2_a : V2_b).getDecoder(f.phase < V2Engine::N_DECODERS ? f.phase : 0);
+			memcpy(&tag.ppm, &f.group, sizeof(float));
+		} else if (base) d = f.ch == 0 ? &DEC_base_a : &DEC_base_b;
 		else if (f.phase >= 5) d = &(f.ch == 0 ? DEC_af : DEC_bf)[f.phase - 5];
 		else d = &(f.ch == 0 ? DEC_a : DEC_b)[f.phase];
 		d->emitFrame(f.data, f.position, f.level_sum, f.start_idx, f.end_idx, tag);

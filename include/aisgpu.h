@@ -67,7 +67,12 @@ extern "C" {
 #define AISGPU_FLAG_PS_BOXCAR 8 /* KEY_SETTING_PS_EMA off: Demod::PhaseSearch (boxcar history) instead of PhaseSearchEMA (Model.cpp:550-555) */
 #define AISGPU_FLAG_GPU_DECODE 16 /* run the AIS::Decoder objects (frame decoder + Reset mesh) on the device too: aisgpu_frames().  ModelDefault (five per
                                    * channel), ModelStandard (five on the deinterleaved discriminator), ModelChallenger (ten: coherent + FM, Model.cpp:641-674)
-                                   * and ModelBase (DSP::SimplePLL + one decoder with its feedback loop, DSP.cpp:28-57, Model.cpp:428-435); not ModelEngineV2 */
+                                   * and ModelBase (DSP::SimplePLL + one decoder with its feedback loop, DSP.cpp:28-57, Model.cpp:428-435).
+                                   * ModelEngineV2 (round 4): the whole V2::Engine per channel -- tone gate / slot lock, Derotate, FilterFL17, five
+                                   * PhaseTrackers, BitPLL, six decoders, slot-phase learner (V2Engine.cpp:293-388) -- runs on the device, strictly in the
+                                   * reference's order per channel; the 48 kHz channels are NOT copied to the host (aisgpu_out.c48 stays empty), frames come
+                                   * back.  One deviation from bit-exactness: std::polar of the estimated frequency is the device's sincosf (NMEA text and
+                                   * tag.ppm equal the reference's on the tested streams, the per-message level within 1e-5) */
 #define AISGPU_FLAG_FP_DS 32  /* KEY_SETTING_FP_DS (`-go FP_DS on`, `-F`): 1536 kSPS CU8 input goes through the fixed-point ladder
                                * Downsample16_CU8 (DSP/DSP.cpp:499-651, Model.cpp:231-237); ignored at other rates like in the reference */
 #define AISGPU_FLAG_MODE_X 64 /* channel mode X (`-c X`, Receiver.cpp:87-98, Model.cpp:35-107): ONE channel, already centred, sample_rate
@@ -164,8 +169,10 @@ int aisgpu_out_count(aisgpu_t* h);
  * channel A before channel B, group, phase.  Valid after aisgpu_sync_outputs() until the next aisgpu_sync_outputs() (the array is
  * host memory of the context that only that call rewrites: a pipelined caller reads it while the next aisgpu_run() is in flight). */
 typedef struct aisgpu_frame {
-	int rx, ch, phase, sub;   /* receiver, channel 0/1, decoder DEC_x[phase] (5..9: ModelChallenger's FM decoders DEC_xf[phase - 5]), downstream block of this run */
-	int group;                /* group (symbol index of the phase chain) inside that block whose bit completed the closing flag (ModelBase: the 48 kHz sample) */
+	int rx, ch, phase, sub;   /* receiver, channel 0/1, decoder DEC_x[phase] (5..9: ModelChallenger's FM decoders DEC_xf[phase - 5]; ModelEngineV2: 0..4 the
+	                           * decoders behind the phase trackers, 5 the FM decoder), downstream block of this run */
+	int group;                /* group (symbol index of the phase chain) inside that block whose bit completed the closing flag (ModelBase: the 48 kHz sample;
+	                           * ModelEngineV2: the bits of tag.ppm at that moment, a float -- the engine switches frequencies inside its blocks) */
 	int position;             /* decoder bit position at that moment; the frame incl. its FCS is position - 7 bits long */
 	float level_sum;          /* sum of tag.sample_lvl over the frame's bits */
 	long long start_idx, end_idx; /* tag.sample_idx at the start flag / at the last bit */

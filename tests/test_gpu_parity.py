@@ -740,6 +740,32 @@ def test_model_engine_v2_end_to_end(rate, fmt, block, nblocks):
     assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
 
 
+@pytest.mark.parametrize("rate,fmt,block,nblocks", [(1536000, "cf32", 131072, 24), (1536000, "cu8", 786432, 4), (768000, "cf32", 65536, 24), (6000000, "cf32", 786432, 4)])
+def test_model_engine_v2_on_the_device(rate, fmt, block, nblocks):
+    """AISGPU_FLAG_GPU_DECODE with ModelEngineV2 (round 4): the engine's coherent branch runs on the device too
+    (kv2_engine: tone gate / slot lock from the decoders' states, Derotate, FilterFL17, five PhaseTrackers, six decoders with
+    their reset, the slot-phase learner) -- the 48 kHz channels never leave the device, completed frames come back.  Everything
+    is the reference's arithmetic in the reference's order except std::polar of the estimated frequency (the device's sincosf
+    instead of the host libm's): the NMEA text and tag.ppm must equal the compiled reference's, the per-message level -- a sum
+    of |derotated, filtered sample|^2 -- within the north star's 1e-5."""
+    from ais_catcher_amd import host
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=46, gap_slots=(1, 2), type5_every=4)
+    data = synth.to_cu8(x) if fmt == "cu8" else x
+    per = 1 if fmt == "cf32" else 2
+    chk = checkers.Ref(model=11, rate=rate, fmt=fmt) if checkers.have_ref() else checkers.Oracle(model=11, rate=rate, fmt=fmt)
+    chk.feed_blocks(data, block)
+    host.reset_sequence()
+    m = host.ModelEngineV2GPU(sample_rate=rate, block_len=block, input_format=_FMT[fmt], gpu_decode=True)
+    for b in range(nblocks):
+        assert m.receive(data[b * block * per:(b + 1) * block * per]) == 0
+    assert len(chk.nmea()) >= 3
+    assert m.nmea() == chk.nmea()
+    a, c = m.msg_meta(), chk.msg_meta()
+    assert np.array_equal(a[1], c[1]), "tag.ppm"
+    assert np.allclose(a[0], c[0], rtol=1e-5, atol=0), "tag.level"
+    m.close()
+
+
 @pytest.mark.parametrize("rate,fmt,block", [(1536000, "cf32", 131072), (1536000, "cu8", 131072), (768000, "cf32", 65536)])
 def test_model_standard_nmea_end_to_end(rate, fmt, block):
     """AIS::ModelStandard (-m 0): the device path of ModelBase (front end + FM discriminator + 37-tap filter), then on the host
