@@ -1940,6 +1940,10 @@ int aisgpu_decoder_fallbacks(aisgpu_t* h, long long* count) {
 			HIPCHK(hipMemcpy(&v, h->k7b[i].fallback_count, sizeof v, hipMemcpyDeviceToHost));
 			total += v;
 		}
+	if (h->d_v2locked) { // ModelEngineV2 on the device: FreqOffset::Estimate() calls at a learned slot phase (windows the assist kernels cannot know)
+		HIPCHK(hipMemcpy(&v, h->d_v2locked, sizeof v, hipMemcpyDeviceToHost));
+		total += v;
+	}
 	*count = total;
 	return AISGPU_OK;
 }

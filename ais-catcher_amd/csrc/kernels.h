@@ -330,8 +330,8 @@ struct KV2Params {
 // from the decoders' states, Derotate is an accumulated phasor, the five PhaseTrackers take their loop weight from their decoder's
 // state sample by sample, the six decoders reset each other.  kv2_engine: one wave = V2E_NCH channels x 6 lanes (five tracker +
 // decoder lanes and the FM decoder behind its BitPLL), the groups of five samples in step, the reference's order inside a group
-// restored only where a message completes.  Exact but for ONE function: std::polar of the estimated frequency is the device's
-// sincosf, not the host libm's; frames out like the other engines' device decoders.
+// restored only where a message completes.  std::polar of the estimated frequency: glibc's sinf / cosf restated (sin_or_cos_ref);
+// frames out like the other engines' device decoders.
 constexpr int V2E_NCH = 10;
 struct V2Tracker { unsigned rot; float2 s; int prev_decision; };
 struct V2ChanState { // zero-initialised but for rot = (1, 0)

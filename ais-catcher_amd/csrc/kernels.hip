@@ -2369,6 +2369,40 @@ __global__ __launch_bounds__(64) void k7_decode(K7Params p) {
 // happens in the reference's order; what is parallel is the channels (V2E_NCH per wave) and, inside a channel, the six
 // decoders of a group of five samples -- until one of them completes a message: then the group is redone sample by sample.
 // ------------------------------------------------------------------------------------------
+// sinf / cosf of glibc 2.35 (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h) for |y| < 120, operation by operation, in the
+// variant glibc's ifunc selects on CPUs with FMA (every a * b + c fused): double-precision polynomials on the argument reduced by
+// multiples of pi / 2, the result rounded to float once.  Coefficients: __sincosf_table of the image's libm.so.6.  The CPU test
+// tests/test_sincosf.py checks the same restatement against the host libm on 2 x 10^7 inputs.
+__device__ __forceinline__ float sincosf_poly_ref(double x, double x2, bool neg, int n) {
+	const double sg = neg ? -1.0 : 1.0; // the second table entry: the cosine coefficients negated
+	if ((n & 1) == 0) {
+		const double x3 = x * x2;
+		const double s1 = __fma_rn(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+		const double x7 = x3 * x2;
+		const double s = __fma_rn(x3, -0x1.555545995a603p-3, x);
+		return (float)__fma_rn(x7, s1, s);
+	}
+	const double x4 = x2 * x2;
+	const double c2 = __fma_rn(x2, sg * 0x1.99343027bf8c3p-16, sg * -0x1.6c087e89a359dp-10);
+	const double c1 = __fma_rn(x2, sg * -0x1.ffffffd0c621cp-2, sg * 0x1p0);
+	const double x6 = x4 * x2;
+	const double c = __fma_rn(x4, sg * 0x1.55553e1068f19p-5, c1);
+	return (float)__fma_rn(x6, c2, c);
+}
+__device__ __forceinline__ float sin_or_cos_ref(float y, int iscos) {
+	const auto abstop12 = [](float v) { return (__float_as_uint(v) >> 20) & 0x7ffu; };
+	double x = (double)y;
+	if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+		if (abstop12(y) < abstop12(0x1p-12f)) return iscos ? 1.0f : y;
+		return sincosf_poly_ref(x, x * x, false, iscos);
+	}
+	const double r = x * 0x1.45F306DC9C883p+23;
+	const int n = ((int)r + 0x800000) >> 24;
+	x = __fma_rn(-(double)n, 0x1.921FB54442D18p0, x);
+	const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+	return sincosf_poly_ref(x * sgn, x * x, (n & 2) != 0, n ^ iscos);
+}
+
 struct V2Lane { DecReg r; V2Tracker t; float pll_phase; int pll_last; };
 
 __device__ __forceinline__ c2 v2_dot17(const float2* a, const float* taps) { // dot17 (:38-45)
@@ -2466,8 +2500,8 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 		slot_phase = (int)(ph + 1280.0f + 0.5f) % 1280;
 	};
 	const auto derotate = [&](float f, int from, int to) { // FreqOffset::Derotate (:133-146) over samples [from, to) of the block that starts at n0
-		float sn, cn;
-		sincosf(f * 2.0f * 3.14159265358979323846f, &sn, &cn); // std::polar(1.0f, f * 2 pi): the device's sincosf (see kernels.h)
+		const float th = f * 2.0f * 3.14159265358979323846f; // std::polar(1.0f, f * 2.0f * PI): (rho * cos(theta), rho * sin(theta))
+		const float sn = 1.0f * sin_or_cos_ref(th, 0), cn = 1.0f * sin_or_cos_ref(th, 1);
 		const c2 st = { cn, sn }, st_sw = { -sn, cn };
 		c2 r = { rot.x, rot.y };
 		float2* d = &dero[mesh][16]; // (the block's raw samples, staged by the whole wave: derotated in place)

@@ -71,8 +71,7 @@ extern "C" {
                                    * ModelEngineV2 (round 4): the whole V2::Engine per channel -- tone gate / slot lock, Derotate, FilterFL17, five
                                    * PhaseTrackers, BitPLL, six decoders, slot-phase learner (V2Engine.cpp:293-388) -- runs on the device, strictly in the
                                    * reference's order per channel; the 48 kHz channels are NOT copied to the host (aisgpu_out.c48 stays empty), frames come
-                                   * back.  One deviation from bit-exactness: std::polar of the estimated frequency is the device's sincosf (NMEA text and
-                                   * tag.ppm equal the reference's on the tested streams, the per-message level within 1e-5) */
+                                   * back (NMEA text, tag.ppm and tag.level equal the reference's bit for bit; std::polar = glibc's sinf / cosf restated) */
 #define AISGPU_FLAG_FP_DS 32  /* KEY_SETTING_FP_DS (`-go FP_DS on`, `-F`): 1536 kSPS CU8 input goes through the fixed-point ladder
                                * Downsample16_CU8 (DSP/DSP.cpp:499-651, Model.cpp:231-237); ignored at other rates like in the reference */
 #define AISGPU_FLAG_MODE_X 64 /* channel mode X (`-c X`, Receiver.cpp:87-98, Model.cpp:35-107): ONE channel, already centred, sample_rate
@@ -192,6 +191,8 @@ int aisgpu_ps_fallbacks(aisgpu_t* h, long long* count);
  * few dozen symbols).  The frames are the same either way; the sequential kernel is ~10x slower.
  * ModelBase (chunk-parallel sampler + decoder kernels): the number of (channel, block) pairs that went through the sequential kernel
  * because a chunk or a boundary task completed more than four frames. */
+/* (ModelEngineV2 with AISGPU_FLAG_GPU_DECODE: the number of FreqOffset::Estimate() calls the engine kernel made at a learned slot phase --
+ * windows at an arbitrary offset, which the assist kernels cannot compute ahead: the kernel's slow path, exact like the rest.) */
 int aisgpu_decoder_fallbacks(aisgpu_t* h, long long* count);
 int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* out);
 
