@@ -42,6 +42,8 @@ def load():
     lib.aishost_model_flush.restype = None
     lib.aishost_model_replay.argtypes = [vp, ci, cll, cll, ci, ctypes.POINTER(vp), vp, ci, vp, vp]
     lib.aishost_model_feed48.argtypes = [vp, ci, vp, ci]
+    if hasattr(lib, "aishost_model_frame"):
+        lib.aishost_model_frame.argtypes = [vp, vp]
     lib.aishost_model_msg_count.argtypes = [vp]
     lib.aishost_model_nmea.argtypes = [vp, ctypes.c_char_p, ci]
     lib.aishost_model_msg_meta.argtypes = [vp, vp, vp, ci]
@@ -130,6 +132,14 @@ class ModelDefaultGPU:
             fmw = np.ascontiguousarray((fb << np.arange(32, dtype=np.uint32)[None, :]).sum(axis=1, dtype=np.uint64).astype(np.uint32))
         self.lib.aishost_model_replay(self.h, ch, first_group, first_sample48, n, ptrs, lvl.ctypes.data, len(ppm), ppm.ctypes.data,
                                       fmw.ctypes.data if fmw is not None else None)
+
+    def frame(self, f):
+        """One frame of the device decoders (a dict of gpu.AisGpu.frames()) to the tail of its decoder (validation, NMEA text)."""
+        fr = _gpu.Frame()
+        for k in ("rx", "ch", "phase", "sub", "group", "position", "level_sum", "start_idx", "end_idx"):
+            setattr(fr, k, f[k])
+        ctypes.memmove(fr.data, f["data"], min(len(f["data"]), 144))
+        self.lib.aishost_model_frame(self.h, ctypes.byref(fr))
 
     def feed48(self, ch, iq):
         """ModelEngineV2 host logic (detached or not): one block of the 48 kHz channel ch as complex64."""

@@ -101,6 +101,16 @@ int aishost_model_replay(void* mv, int ch, long long first_group, long long firs
 }
 
 // ModelEngineV2 host logic without a GPU: one block of a 48 kHz channel (n complex samples), as the device would hand it over
+// one frame of the device decoders (aisgpu_frame) to the tail of its decoder: validation, NMEA text.  For callers that hold the
+// frames themselves (bench.py's gate of the timed --gpu-decode run, on a detached model); tag.ppm / tag.level are the caller's.
+int aishost_model_frame(void* mv, const aisgpu_frame* f) {
+	Model* m = (Model*)mv;
+	if (!f) return AISGPU_ERR_ARG;
+	m->tag.sample_idx = f->end_idx;
+	m->m.Chain().emitFrame(*f, m->tag);
+	return 0;
+}
+
 int aishost_model_feed48(void* mv, int ch, const float* iq, int n) {
 	Model* m = (Model*)mv;
 	(ch == 0 ? m->m.Chain().outC48a : m->m.Chain().outC48b).Send((const CFLOAT32*)iq, n, m->tag);

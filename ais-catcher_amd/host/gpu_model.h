@@ -104,6 +104,7 @@ public:
 	int status() const { return last_status; }                      // AISGPU_* status of the last Receive()
 	void setErrorHandler(std::function<void(const std::string&)> f) { on_error = f; }
 	void setFrameHandler(std::function<void(const aisgpu_frame&, TAG&)> f) { on_frame = f; }
+	void emitFrame(const aisgpu_frame& f, TAG& tag) { if (on_frame) on_frame(f, tag); } // a device frame to the tail of ITS decoder (what process() does for every frame of a block)
 	// ModelEngineV2: called before / after the 48 kHz samples of a device block go out on outC48x (device assist of the engines)
 	std::function<void(int ch, const aisgpu_out&, int first_sample)> on_c48;
 	std::function<void(int ch, int L)> on_c48_done;

@@ -253,7 +253,7 @@ def cpu_baseline_port(seconds, x, nblk, host, phys, model=2, rate=RATE):
             "sample": "%d blocks of %d CF32 IQ samples over %d threads in %.1f s (oracle restatement)" % (sum(counts), BLOCK, cores, dt)}
 
 
-def parity_check(g, data, sequence, receivers, rate=RATE, model=2, fmt="cf32", blocks_of=None, **okw):
+def parity_check(g, data, sequence, receivers, rate=RATE, model=2, fmt="cf32", blocks_of=None, frames=None, **okw):
     """Outputs of the LAST block of `sequence` (what the context `g` holds after sync_outputs) against the oracle fed the same
     sequence of resident blocks, for the given receivers: hard bits of all five sampling phases, levels, ppm -- for
     ModelChallenger also the sign of every filtered FM-discriminator sample (what its five FM decoders per channel see), for
@@ -272,11 +272,26 @@ def parity_check(g, data, sequence, receivers, rate=RATE, model=2, fmt="cf32", b
             blocks = [data[b, r].cpu().numpy().reshape(-1).view(np.complex64) for b in range(data.shape[0])]
         o = checkers.Oracle(model=model, rate=rate, fmt=fmt, taps=True, **okw)
         o.set_taps(False)
+        n_lines = 0
         for i, b in enumerate(sequence):
             if i == len(sequence) - 1:   # only the last block's outputs are compared (and recorded)
                 o.set_taps(True)
+                n_lines = len(o.nmea()) if frames is not None else 0
             o.feed(blocks[b])
         bad = []
+        if frames is not None:   # --gpu-decode: the frames the device decoders completed in the last block, through the host tail
+            # (validation, NMEA text), against the messages the oracle's decoders printed for that block -- in order; the multi-part
+            # sentence id is a per-process counter: compared without it (and without the checksum over it)
+            from ais_catcher_amd import host
+            strip = lambda ls: [",".join(f for i, f in enumerate(l.split("*")[0].split(",")) if i != 3) for l in ls]
+            hm = {2: host.ModelDefaultGPU, 4: host.ModelChallengerGPU, 0: host.ModelStandardGPU, 1: host.ModelBaseGPU, 11: host.ModelEngineV2GPU}[model](
+                sample_rate=rate, detached=True, gpu_decode=True)
+            for f in frames:
+                if f["rx"] == r:
+                    hm.frame(f)
+            if strip(hm.nmea()) != strip(o.nmea()[n_lines:]):
+                bad.append("rx %d: NMEA of the device decoders' frames (%d lines, the oracle printed %d)" % (r, len(hm.nmea()), len(o.nmea()) - n_lines))
+            hm.close()
         for ch in range(1 if okw.get("mode_x") else 2):   # (channel mode X: one channel, the device's channel B stays silent)
             outs = [g.fetch(r, ch, s) for s in range(n_sub)]
             for a, b2 in zip(outs, outs[1:]):
@@ -308,7 +323,7 @@ def parity_check(g, data, sequence, receivers, rate=RATE, model=2, fmt="cf32", b
                     sel = fm if model == 1 else fm[idx % 5 == j]   # ModelBase: the sampler sees every sample
                     if len(of) != len(sel) or not np.array_equal(sel != 0, of > 0):
                         bad.append("rx %d ch %d FM stream %d: discriminator signs" % (r, ch, j))
-            if model == 11:
+            if model == 11 and frames is None:   # (the whole engine on the device: no 48 kHz channels come back, the frames above are the output)
                 want = o.tap(ch)
                 got = np.concatenate([t["c48"] for t in outs])
                 if len(want) != len(got) or not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
@@ -533,17 +548,28 @@ def main():
 
     # ---- parity gate on the run that was just timed: the last block's outputs of a spread of receivers against the oracle
     n_checked, mismatches = 0, []
+    frames_checked = None
     if args.parity_receivers > 0:
+        frames = None
         try:
             g.sync_outputs()
         except gpu.AisGpuError as e:
             # --gpu-decode: a throughput run never collects its frames, so their ring has wrapped (AISGPU_ERR_OVERFLOW); the
-            # decisions that are compared below have been copied all the same
+            # decisions have been copied all the same
             if not (args.gpu_decode and "(5)" in str(e)):
                 raise
+        if args.gpu_decode:
+            # ... so the gate looks at ONE MORE block, untimed, behind the timed ones: same decoders, same state, and this block's
+            # frames alone are in the ring (decisions and frames of that block are compared)
+            sequence = sequence + [(sequence[-1] + 1) % nb]
+            g.submit_device(data[sequence[-1]].data_ptr(), BLOCK)
+            g.run()
+            g.sync_outputs()
+            frames = g.frames()
+            frames_checked = len(frames)
         n = min(args.parity_receivers, R)
         receivers = sorted(set(int(round(i * (R - 1) / max(n - 1, 1))) for i in range(n)))
-        n_checked, mismatches = parity_check(g, data, sequence, receivers, rate=rate, model=model)
+        n_checked, mismatches = parity_check(g, data, sequence, receivers, rate=rate, model=model, frames=frames)
 
     # ---- host cost of one aisgpu_run() with the device idle (no back-pressure): what the calling thread pays per block
     host_ms = []
@@ -603,8 +629,9 @@ def main():
         "host_cost_ms_per_step": round(float(np.median(host_ms)), 4),
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "parity_checked": n_checked, "parity": ("bit-exact vs oracle (hard bits, levels, ppm of the last timed block)" if n_checked and not mismatches
+        "parity_checked": n_checked, "parity": (("bit-exact vs oracle (hard bits, levels, ppm and the NMEA text of the device decoders' frames, block behind the last timed one)" if frames_checked is not None else "bit-exact vs oracle (hard bits, levels, ppm of the last timed block)") if n_checked and not mismatches
                                                 else "off" if not n_checked else "MISMATCH: " + "; ".join(mismatches[:8])),
+        "frames_checked": frames_checked,
         "config": {"workload": "BASELINE %s: %s, %d IQ samples per receiver per step, resident in HBM, chain up to hard bits/levels/ppm%s"
                                % (C["key"], (C["what"] % R) if "%d" in C["what"] else C["what"], BLOCK, " + FM-branch signs" if model == 4 else ""),
                    "baseline_config": C["key"], "model": C["model_name"], "algorithmic_bytes_per_sample": algo_bytes,

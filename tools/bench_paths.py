@@ -67,23 +67,28 @@ def run(name, R, rate, block, fmt="cf32", steps=30, **kw):
     g.sync()
     dt = time.perf_counter() - t0
     verdict = "parity off"
-    if model == gpu.MODEL_V2 and kw.get("gpu_decode"):
-        verdict = "frames only (the NMEA gate of this path: tests/test_gpu_parity.py::test_model_engine_v2_on_the_device)"
-    elif not os.environ.get("BENCH_PATHS_NO_GATE"):
+    if not os.environ.get("BENCH_PATHS_NO_GATE"):
         try:
             g.sync_outputs()
         except gpu.AisGpuError as e:  # (device decoders: a throughput run never collects its frames, the decisions are copied all the same)
             if not (kw.get("gpu_decode") and "(5)" in str(e)):
                 raise
         seq = [i & 1 for i in range(warm)] + [i & 1 for i in range(steps)]
+        frames = None
+        if kw.get("gpu_decode"):  # one more block behind the timed ones: its frames alone are in the ring (bench.py does the same)
+            seq.append(steps & 1)
+            g.submit_device(data[steps & 1].data_ptr(), block)
+            g.run()
+            g.sync_outputs()
+            frames = g.frames()
         okw = {k: kw[k] for k in ("ps_ema", "fp_ds", "mode_x", "dsk", "ma") if k in kw}
         blocks = [hostx[:per], hostx[per:]]
         blocks_of = lambda r: blocks
         if distinct:
             blocks_of = lambda r: [np.ascontiguousarray(data[b, r].cpu().numpy()).view(np.complex64).reshape(-1) for b in range(2)]
-        n, bad = bench.parity_check(g, None, seq, sorted({0, R - 1}), rate=rate, model=model, fmt=fmt, blocks_of=blocks_of, **okw)
+        n, bad = bench.parity_check(g, None, seq, sorted({0, R - 1}), rate=rate, model=model, fmt=fmt, blocks_of=blocks_of, frames=frames, **okw)
         GATE["checked"] += n
-        verdict = "parity: %d receivers bit-exact" % n if not bad else "PARITY MISMATCH: " + "; ".join(bad[:4])
+        verdict = ("parity: %d receivers bit-exact%s" % (n, " incl. the NMEA text of %d device frames" % len(frames) if frames is not None else "")) if not bad else "PARITY MISMATCH: " + "; ".join(bad[:4])
         if bad:
             GATE["failed"].append(name)
     g.close()
