@@ -2447,6 +2447,7 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 	__shared__ __attribute__((aligned(16))) float2 dero[V2E_NCH][16 + 512 + 2];
 	__shared__ __attribute__((aligned(16))) float2 X[584];
 	__shared__ __attribute__((aligned(16))) float mag[512 + 8];
+	__shared__ uint32_t fmw[V2E_NCH][16];
 	const KV2Params& p = q.k;
 	const int lane = threadIdx.x;
 	const int mesh = lane / 6, j = lane - 6 * mesh; // lanes 60..63 idle
@@ -2477,11 +2478,9 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 	FftTwiddles tw = fft_twiddles(p.omega, lane);
 	const uint32_t* fm_cur = p.fmbits + (size_t)chan * p.fmbits_stride;
 	const uint32_t* fm_old = q.fm_prev + (size_t)chan * p.fmbits_stride;
-	const auto fm_sign = [&](int n) -> int { // sign of the filtered discriminator at sample n of this device block (n < 0: the previous block)
-		const int m = n < 0 ? n + p.L : n;
-		const uint32_t w = (n < 0 ? fm_old : fm_cur)[m >> 5];
-		return (int)((w >> (m & 31)) & 1u);
-	};
+	// sign of the filtered discriminator at sample k of the engine block that is being decoded: the block's sixteen words are staged in
+	// LDS at the top of the block (fetched where the PLL needs them they were a memory round trip per sample of a serial loop)
+	const auto fm_sign = [&](int k) -> int { return (int)((fmw[mesh][k >> 5] >> (k & 31)) & 1u); };
 	const auto emit = [&](const DecReg& r, long long sidx, float tag_ppm) {
 		const unsigned slot = atomicAdd(q.frame_count, 1u) % (unsigned)q.max_frames;
 		uint32_t* f = q.frames + (size_t)slot * DEC_FRAME_WORDS;
@@ -2524,6 +2523,10 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 			if (cm >= p.n_chan) break;
 #pragma unroll
 			for (int i = 0; i < 8; i++) dero[m][16 + i * 64 + lane] = v2_sample(p, cm, n0 + i * 64 + lane);
+		}
+		if (live) for (int i = j; i < 16; i += 6) { // (n0 is a multiple of 512: whole words; block 0 decodes the previous device block's tail)
+			const int m0 = n0 < 0 ? n0 + p.L : n0;
+			fmw[mesh][i] = (n0 < 0 ? fm_old : fm_cur)[(m0 >> 5) + i];
 		}
 		wave_sync();
 		// ---- Engine::processBlock (:345-352): slot predictor decay, busy, CGF
@@ -2579,12 +2582,12 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 			if (j == 5) {
 				const bool training = L.r.state == DST_TRAINING;
 				for (int s5 = 0; s5 < ng; s5++)
-					if (v2_pll(L.pll_phase, L.pll_last, fm_sign(n0 + g5 + s5), training)) { my_k = g5 + s5; s_next = s5 + 1; break; }
+					if (v2_pll(L.pll_phase, L.pll_last, fm_sign(g5 + s5), training)) { my_k = g5 + s5; s_next = s5 + 1; break; }
 			} else if (off < ng) my_k = g5 + off;
 			const bool have = live && my_k >= 0;
 			const int kk = have ? my_k : 0;
 			const c2 z = v2_dot17(&dero[mesh][kk], q.taps17); // FilterFL17 (:154-167): output kk from carry + block samples kk .. kk + 16
-			const int bit = j < 5 ? v2_track(L.t, z, L.r.state == DST_TRAINING, q.w_train, q.w_track) : fm_sign(n0 + kk);
+			const int bit = j < 5 ? v2_track(L.t, z, L.r.state == DST_TRAINING, q.w_train, q.w_track) : fm_sign(kk);
 			if (!have && j < 5) L.t = before.t;
 			const float slvl = z.x * z.x + z.y * z.y;
 			const long long sidx = sample_idx + kk;
@@ -2592,7 +2595,7 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 			bool again = false;
 			if (j == 5) {
 				const bool training = L.r.state == DST_TRAINING;
-				for (int s5 = s_next; s5 < ng; s5++) again = v2_pll(L.pll_phase, L.pll_last, fm_sign(n0 + g5 + s5), training) || again;
+				for (int s5 = s_next; s5 < ng; s5++) again = v2_pll(L.pll_phase, L.pll_last, fm_sign(g5 + s5), training) || again;
 			}
 			// anything that breaks the lockstep -- a completed message (it resets the other five at ITS sample), or an FM decoder that
 			// clocks two symbols inside one group -- sends the channel through the reference's own order, sample by sample
@@ -2620,8 +2623,8 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 						v2_reset(L.r);
 					}
 					fnd = false;
-					if (j == 5 && v2_pll(L.pll_phase, L.pll_last, fm_sign(n0 + k5), L.r.state == DST_TRAINING)) {
-						fnd = dec_step(L.r, fm_sign(n0 + k5), lv, si, data);
+					if (j == 5 && v2_pll(L.pll_phase, L.pll_last, fm_sign(k5), L.r.state == DST_TRAINING)) {
+						fnd = dec_step(L.r, fm_sign(k5), lv, si, data);
 						if (fnd) emit(L.r, si, tag_ppm);
 					}
 					FF = __ballot(fnd);
