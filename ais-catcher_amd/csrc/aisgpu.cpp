@@ -178,6 +178,7 @@ struct aisgpu {
 	float2 *d_cgf = nullptr, *d_omega = nullptr, *d_step = nullptr, *d_rotstate = nullptr, *d_firtap = nullptr;
 	float *d_ppmtab = nullptr, *d_ppm[NBUF] = {}, *d_lvl[4] = {}; // lvl: ring of 4 (block f & 3): it lives until the block's (deferred) walk and decoder are done
 	int* d_fz[NBUF] = {};
+	int phasor_simds = 1024;  // SIMDs the phasor recurrence's stream may use (the reserved CUs'): picks the form of the kernel
 	float* d_magT[NBUF] = {}; // shifted FFT magnitudes (written by the FFT on the front stream, read by the searches on s3)
 	bool fft_in_k1 = false;   // the spectral analysis rides at the end of the front-end waves (k1_fft_tail): fz / ppm come from K1
 	uint32_t* d_bits[4] = {}; // ring of 4 (block f & 3), like lvl: the frame decoder of block f-2 may still be reading while PhaseSearch of block f writes
@@ -664,7 +665,7 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	}
 	WAITEV(h->s3, h->k1_done[q] ? h->k1_done[q] : h->ev_search[q]);
 	WAITEV(h->s3, h->ev_c48free[q]); // ck[q] was last read by K6 of block f-NBUF
-	{ TraceScope t(h, "phasor", h->s3); HIPCHK(launch_k2b_ck(k2, h->n_chan, h->s3)); }
+	{ TraceScope t(h, "phasor", h->s3); HIPCHK(launch_k2b_ck(k2, h->n_chan, h->s3, h->phasor_simds)); }
 	HIPCHK(hipEventRecord(h->ev_phasor[q], h->s3));
 
 	h->fpend.valid = true; h->fpend.q = q; h->fpend.pb = pb; h->fpend.lv = lv; h->fpend.g0 = g0; h->fpend.n_groups = n_groups;
@@ -1274,6 +1275,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			HIPCHK(hipStreamCreateWithFlags(&h->s4, hipStreamNonBlocking));
 			if (own_dec_stream) HIPCHK(hipStreamCreateWithFlags(&h->s5, hipStreamNonBlocking));
 		}
+		h->phasor_simds = (masked ? reserve : n_cu) * 4;
 		if (!h->s5) h->s5 = h->s4;
 		h->s2 = h->s1; // apply + FIR + PhaseSearchEMA of a block run back to back on one stream
 		h->dec_defer = h->s5 == h->s4 && h->s4 != h->stream;

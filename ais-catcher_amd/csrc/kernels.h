@@ -286,7 +286,7 @@ hipError_t launch_selftest_hypot(const float2* in, int n, unsigned* mismatches, 
 hipError_t launch_k2b(const K2Params& p, int n_chan, hipStream_t s); // phasor recurrence
 hipError_t launch_k2c(const K2Params& p, int n_chan, hipStream_t s); // history carry + apply
 hipError_t launch_k3(const K3Params& p, int n_chan, hipStream_t s);
-hipError_t launch_k2b_ck(const K2Params& p, int n_chan, hipStream_t s); // phasor recurrence, the state at every window start only
+hipError_t launch_k2b_ck(const K2Params& p, int n_chan, hipStream_t s, int simds); // phasor recurrence, the state at every window start only (simds: how many SIMDs the stream may use)
 hipError_t launch_k2b_refine(const K2Params& p, int n_chan, hipStream_t s); // ... and from there the checkpoints inside the windows (in front of launch_k6, any stream)
 hipError_t launch_k6(const K6Params& p, hipStream_t s);
 struct K5Params { // ModelChallenger FM branch (Model.cpp:638-639): Demod::FM -> Filter(Receiver, 37 taps) -> sign

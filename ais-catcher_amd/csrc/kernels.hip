@@ -1215,6 +1215,44 @@ __global__ __launch_bounds__(64) void k2_cgf_phasor_ck(K2Params p) {
 	if (live) p.rot_state[chan] = make_float2(cur.x, cur.y);
 }
 
+// The same once more with a chain on a PAIR of lanes (even lane: real part, odd lane: imaginary part; 32 chains per wave).
+// The packed form above takes 24 cycles per step -- three packed operations of a dependent chain, 8 cycles each; here a step
+// is own * c, partner * (-/+ s) with the partner's value through the DPP operand, and their sum: three plain operations, 4 cycles
+// each.  Every product and sum is the one of the packed form (x c + y (-s); y c + x s = x s + y c), so the states are the same bits.
+// Twice the waves: the launcher takes this form while every wave still has a SIMD of the reserved CUs to itself.  Measured alone,
+// 512 chains x 48 windows: 183 us against 247 (18 against 24 cycles per step: the DPP operand wants two wait states behind the
+// sum that wrote it, one of them an s_nop); with (own c, own s') as ONE packed product and the sum taking the partner's half through
+// DPP: 267 us -- a packed operation is 8 cycles to its dependant (profiles/r04_expC_phasor_pairs.txt).
+__global__ __launch_bounds__(64) void k2_cgf_phasor_ck_pairs(K2Params p) {
+	const int lane = threadIdx.x, comp = lane & 1;
+	const int chan_raw = blockIdx.x * 32 + (lane >> 1);
+	const bool live = chan_raw < p.n_chan;
+	const int chan = live ? chan_raw : p.n_chan - 1;
+	__builtin_amdgcn_s_setprio(3);
+	float own = reinterpret_cast<const float*>(p.rot_state)[(size_t)chan * 2 + comp];
+	float* const ckw = reinterpret_cast<float*>(p.ck + (size_t)blockIdx.x * 32) + lane; // (padded columns exist for dead lanes)
+	const int* fzrow = p.fz + (size_t)chan * p.n_windows;
+	int fz_next = fzrow[p.n_windows > 1 ? 1 : 0];
+	float2 stp_next = p.step_table[fzrow[0] + 205];
+	for (int w = 0; w < p.n_windows; w++) {
+		const float2 stp = stp_next;
+		stp_next = p.step_table[fz_next + 205];
+		fz_next = fzrow[w + 2 < p.n_windows ? w + 2 : p.n_windows - 1];
+		const float c = stp.x, s = comp ? stp.y : -stp.y;
+		ckw[(size_t)w * CK_SLOTS * p.ck_stride * 2] = own; // state at the window start (after the renormalisation)
+#pragma unroll 16
+		for (int k = 0; k < 512; k++) {
+			const float u = own * c;
+			const float partner = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own), 0xB1, 0xf, 0xf, true)); // quad_perm [1,0,3,2]
+			own = u + partner * s; // rot *= rot_step
+		}
+		const float partner = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own), 0xB1, 0xf, 0xf, true));
+		const float a = comp ? hypot_ref(partner, own) : hypot_ref(own, partner); // rot /= std::abs(rot), once per window (DSP.cpp:465)
+		own = __fdiv_rn(own, a);
+	}
+	if (live) reinterpret_cast<float*>(p.rot_state)[(size_t)chan * 2 + comp] = own;
+}
+
 // The recurrence once more inside every window, all windows in parallel (one lane per (chain, window), 64 chains of one window
 // per wave): from the window's start state, its state in front of every CK_SEG-th sample -- what lane i of k6_window_fir restarts
 // from.  Time-major: a store is 512 contiguous bytes.  384 short waves; the stores of a wave are fewer than it may have outstanding.
@@ -3805,7 +3843,11 @@ hipError_t launch_k2b(const K2Params& p, int n_chan, hipStream_t s) {
 	return hipGetLastError();
 }
 
-hipError_t launch_k2b_ck(const K2Params& p, int n_chan, hipStream_t s) {
+hipError_t launch_k2b_ck(const K2Params& p, int n_chan, hipStream_t s, int simds) {
+	if ((n_chan + 31) / 32 <= simds) { // one wave per SIMD at most: the latency-bound form with a chain per lane pair
+		hipLaunchKernelGGL(k2_cgf_phasor_ck_pairs, dim3((n_chan + 31) / 32), dim3(64), 0, s, p);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL(k2_cgf_phasor_ck, dim3((n_chan + 63) / 64), dim3(64), 0, s, p);
 	return hipGetLastError();
 }
