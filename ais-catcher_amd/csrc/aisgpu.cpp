@@ -76,6 +76,7 @@ struct TraceRec { const char* name; long long block; hipEvent_t a, b; }; // AISG
 #ifndef AISGPU_NBUF
 #define AISGPU_NBUF 4
 #endif
+constexpr int XR = 6;  // resampled ladders: ring of pre-decimated input blocks (see d_xpre)
 constexpr int NBUF = AISGPU_NBUF;    // ring depth of the buffers that cross from the front-end stream to the others (4 against 3: -1.5 % per step, profiles/r03_expA.txt)
 constexpr int MAXSUB = 4;  // downstream blocks ("flushes" of the resampler) that one input block can complete
 
@@ -161,8 +162,8 @@ struct aisgpu {
 	// staging of host blocks (aisgpu_submit), double buffered by input block: block f+1 is copied in (pinned buffer, then H2D on a
 	// copy stream of its own) while block f is still being computed
 	hipStream_t sc = nullptr; hipEvent_t ev_h2d[2] = {}, ev_in_free[2] = {}; bool in_used[2] = {}; std::mutex submit_mtx; bool staged = false;
-	float2* d_xpre[4] = {};           // pre-decimated stream: [R][xh + n_pre], ping-pong by input block (MODE_PRE uses [0] only); resampled ladders: ring of
-	                                  // four [R][n_pre]: a flush may reach a whole input block back (no history copy: K1uParams::xprev / xprev2), and the
+	float2* d_xpre[XR] = {};           // pre-decimated stream: [R][xh + n_pre], ping-pong by input block (MODE_PRE uses [0] only); resampled ladders: ring of
+	                                  // XR [R][n_pre]: a flush may reach a whole input block back (no history copy: K1uParams::xprev / xprev2), and the
 	                                  // pass over block f+1 must not wait for the resampler kernels of block f
 	float2* d_xmid = nullptr;         // [R][block_len >> KPa]: between the two passes of a pre-decimation of more than four stages
 	bool mode_x = false;              // channel mode X: single-channel front end K1x (npost stages down to 48 kHz), channel B silent
@@ -199,8 +200,8 @@ struct aisgpu {
 	float2* h_rot[4] = {};
 	int* h_usidx[USR] = {}; float* h_usalpha[USR] = {};
 	// resampled ladders: tables of flush b (slot b & 3) copied (us_copy_ev, table stream) / consumed by its resampler front end (us_used_ev);
-	// pre-decimated input block g (slot g & 3) written (ev_xin, front stream) / read for the last time by the flushes of run g (ev_xread)
-	hipEvent_t us_copy_ev[USR] = {}, us_used_ev[USR] = {}, ev_xin[4] = {}, ev_xread[4] = {}; bool us_slot_used[USR] = {};
+	// pre-decimated input block g (slot g % XR) written (ev_xin, front stream) / read for the last time by the flushes of run g (ev_xread)
+	hipEvent_t us_copy_ev[USR] = {}, us_used_ev[USR] = {}, ev_xin[XR] = {}, ev_xread[XR] = {}; bool us_slot_used[USR] = {};
 	UsWorker uw; long long run_flush = 0, run_idx = 0; int next_nflush = 0; // (run_flush: flushes whose resampler front end has been launched)
 	hipEvent_t rot_ev[4] = {}; bool rot_ev_used[4] = {}; long long rot_next = 0; // first block whose table has not been staged yet
 	RotWorker rw; int rot_slot[4] = {};
@@ -217,7 +218,7 @@ struct aisgpu {
 	// resampler replay (DSP.cpp:192-212): alpha carried, outputs waiting for a full flush
 	float us_alpha = 0.0f;
 	long long us_in = 0;          // inputs consumed so far (pre-decimated samples)
-	std::vector<long long> us_pend_idx; std::vector<float> us_pend_alpha;
+	std::vector<int> us_pend_idx; std::vector<float> us_pend_alpha; int us_pend_n = 0; // (the table thread's)
 	std::vector<long long> us_tail_idx; std::vector<float> us_tail_alpha; // last US_HIST entries of the previous flush
 	const void* cur_in = nullptr; long long cur_in_stride = 0;
 	bool submitted = false, have_out = false;
@@ -242,6 +243,8 @@ struct aisgpu {
 	bool ps_box = false; PsBoxState* d_box[2] = {}; // Demod::PhaseSearch (boxcar) instead of PhaseSearchEMA
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
+	bool us_on_ds = false; // resampled ladders: the resampler front end on the downstream stream, the second half of a flush one flush late (option "us_on_ds")
+	bool fm_on_s1 = false, fm_ev_used = false; hipEvent_t ev_fm = nullptr; // ModelChallenger's FM branch in front of PhaseSearch on s1 (option "fm_on_s1"; default: the resampled ladders)
 	bool fused = false; // derotation + FIR + ScatterPLL as one kernel behind the checkpointed phasor recurrence (the default)
 	struct { bool valid = false; int q = 0, pb = 0, lv = 0, n_groups = 0, n_rel0 = 0, S = 0; long long g0 = 0; unsigned block = 0, sub = 0; } fpend;
 	float2 *d_ck[NBUF] = {}, *d_dfhist[2] = {};
@@ -300,14 +303,17 @@ void gen_rot_table(aisgpu_t* h, float2* tab) {
 	const float2 m = h->mult;
 	float2* t = tab + ROT_HIST;
 	const int period = h->rot_period > 0 ? h->rot_period : h->n96; // samples per Rotate::Receive call
-	for (int i = 0; i < h->n96; i++) {
+	// (a countdown, not (i + 1) % period: the division was two thirds of this loop, and the loop half of the resampled ladders'
+	// table thread -- 0.19 of its 0.40 ms per input block, which at 6 MSPS was the step)
+	for (int i = 0, left = period; i < h->n96; i++) {
 		t[i] = r;
 		float re = r.x * m.x - r.y * m.y;
 		float im = r.x * m.y + r.y * m.x;
 		r.x = re; r.y = im;
-		if ((i + 1) % period == 0) { // rot /= std::abs(rot) at the end of every call (DSP.cpp:315)
+		if (--left == 0) { // rot /= std::abs(rot) at the end of every call (DSP.cpp:315)
 			float a = hypotf(r.x, r.y);
 			r.x /= a; r.y /= a;
+			left = period;
 		}
 	}
 	h->rot = r;
@@ -618,6 +624,7 @@ int enqueue_fused_back(aisgpu_t* h) {
 	WAITEV(h->s4, h->ev_sym[pb]); // sym[pb] was last read by PhaseSearch of block f-2,
 	WAITEV(h->s4, h->ev_ema[lv]); // lvl[lv] by the frame decoder / the copies of block f-4
 	if (h->challenger) { k6.cgf = h->d_cgf + CGF_HIST; k6.cgf_stride = CGF_HIST + h->L; }
+	if (h->challenger && h->fm_on_s1 && h->fm_ev_used) WAITEV(h->s4, h->ev_fm); // the derotated samples of the previous block: read by its FM branch, on s1
 	{
 		K2Params k2r = make_k2(h, q);
 		k2r.ck = h->d_ck[q]; k2r.ck_stride = k6.ck_stride;
@@ -626,6 +633,11 @@ int enqueue_fused_back(aisgpu_t* h) {
 	}
 	{ TraceScope t(h, "derotfir", h->s4); HIPCHK(launch_k6(k6, h->s4)); }
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s4));
+	// Where the FM branch runs: behind the derotation / FIR kernel on s4, or (fm_on_s1) in front of PhaseSearch on s1.  On the resampled
+	// ladders s4 also carries the spectral analysis and, with the recurrence on s3 in the middle of its chain, is the stream that sets
+	// the step (BASELINE configs[2]); s1 has the time.
+	hipStream_t fs = h->fm_on_s1 ? h->s1 : h->s4;
+	if (h->challenger && h->fm_on_s1) { HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4)); WAITEV(h->s1, h->ev_k3[pb]); }
 	if (h->challenger) { // FM branch on the derotated samples the kernel above stored on its way (Model.cpp:638-639)
 		K5Params k5;
 		k5.x = h->d_cgf; k5.x_stride = CGF_HIST + h->L; k5.x_off = CGF_HIST;
@@ -635,13 +647,14 @@ int enqueue_fused_back(aisgpu_t* h) {
 		k5.fmbits = h->d_fmbits[pb]; k5.fmbits_stride = h->L / 32; k5.L = h->L;
 		k5.fir_out = nullptr; k5.fir_stride = 0;
 		memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
-		HIPCHK(launch_k5(k5, h->n_chan, h->s4));
+		HIPCHK(launch_k5(k5, h->n_chan, fs));
 		if (h->gpu_decode) { // device decoders: the FM bits regrouped per decoder, here, where this and the previous block's bits are in order
-			WAITEV(h->s4, h->ev_ema[lv ^ 2]); // fmrows[pb] was last read by the decoders of block f-2
-			HIPCHK(launch_k7_pack(make_k7(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub), h->s4));
+			WAITEV(fs, h->ev_ema[lv ^ 2]); // fmrows[pb] was last read by the decoders of block f-2
+			HIPCHK(launch_k7_pack(make_k7(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub), fs));
 		}
+		if (h->fm_on_s1) { HIPCHK(hipEventRecord(h->ev_fm, h->s1)); h->fm_ev_used = true; }
 	}
-	HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4));
+	if (!(h->challenger && h->fm_on_s1)) HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4));
 	{ int rc = flush_decode(h); if (rc) return rc; } // (dec_defer) the previous block's frame decoders, behind this block's derotation / FIR kernel
 	WAITEV(h->s1, h->ev_k3[pb]);
 	TraceScope t(h, "psearch", h->s1);
@@ -659,8 +672,7 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 		if (!h->k1_done[q]) { HIPCHK(hipEventRecord(h->ev_search[q], h->stream)); h->k1_done[q] = h->ev_search[q]; }
 	} else { // FFT + searches follow the front end on its stream (four busy streams are the limit)
 		h->k1_done[q] = nullptr;
-		{ TraceScope t(h, "fft", h->ds); HIPCHK(launch_k2a_fft(k2, h->n_chan, h->ds)); }
-		{ TraceScope t(h, "search", h->ds); HIPCHK(launch_k2a_search(k2, h->n_chan, h->ds)); }
+		{ TraceScope t(h, "fft+search", h->ds); HIPCHK(launch_k2a_fft_search(k2, h->n_chan, h->ds)); }
 		HIPCHK(hipEventRecord(h->ev_search[q], h->ds));
 	}
 	WAITEV(h->s3, h->k1_done[q] ? h->k1_done[q] : h->ev_search[q]);
@@ -676,6 +688,7 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	}
 	h->n48 += h->L;
 	h->block_idx++;
+	if (h->us_on_ds) return AISGPU_OK; // (the second half follows the NEXT flush's resampler front end, or the caller's sync)
 	return enqueue_fused_back(h);
 }
 
@@ -951,12 +964,20 @@ void us_worker_main(aisgpu_t* h) {
 		}
 		const long long in0 = h->us_in;
 		int n_flush = 0;
+		// The outputs of the flush being filled: input index relative to THIS run's first input (entries of the previous run: negative)
+		// and alpha, in plain arrays -- the loop is the float recurrence alpha += increment (DSP.cpp:192-212) and little else.
+		if ((int)h->us_pend_idx.size() != len) { h->us_pend_idx.assign(len, 0); h->us_pend_alpha.assign(len, 0.0f); h->us_pend_n = 0; }
+		int* const pi = h->us_pend_idx.data();
+		float* const pa = h->us_pend_alpha.data();
+		int n = h->us_pend_n;
+		for (int e = 0; e < n; e++) pi[e] -= len;
+		float alpha = h->us_alpha;
+		const float inc = h->us_increment;
 		for (int i = 0; i < len; i++) {
 			do {
-				h->us_pend_idx.push_back(in0 + i);
-				h->us_pend_alpha.push_back(h->us_alpha);
-				h->us_alpha += h->us_increment;
-				if ((int)h->us_pend_idx.size() == len) {
+				pi[n] = i; pa[n] = alpha; n++;
+				alpha += inc;
+				if (n == len) {
 					const long long k = w.produced_flush;
 					const int slot = (int)(k % aisgpu::USR);
 					if (k >= aisgpu::USR) { // the pinned buffers of slot k % USR were last read by the copy kernels of flush k - USR
@@ -974,15 +995,18 @@ void us_worker_main(aisgpu_t* h) {
 						ti[e] = a < 0 ? -1 : (int)(a - in0);
 						ta[e] = h->us_tail_alpha[e];
 					}
-					for (int e = 0; e < len; e++) { ti[US_HIST + e] = (int)(h->us_pend_idx[e] - in0); ta[US_HIST + e] = h->us_pend_alpha[e]; }
-					for (int e = 0; e < US_HIST; e++) { h->us_tail_idx[e] = h->us_pend_idx[len - US_HIST + e]; h->us_tail_alpha[e] = h->us_pend_alpha[len - US_HIST + e]; }
-					h->us_pend_idx.clear(); h->us_pend_alpha.clear();
+					memcpy(ti + US_HIST, pi, (size_t)len * sizeof(int));
+					memcpy(ta + US_HIST, pa, (size_t)len * sizeof(float));
+					for (int e = 0; e < US_HIST; e++) { h->us_tail_idx[e] = in0 + pi[len - US_HIST + e]; h->us_tail_alpha[e] = pa[len - US_HIST + e]; }
+					n = 0;
 					{ std::lock_guard<std::mutex> l(w.m); w.produced_flush = k + 1; }
 					n_flush++;
 				}
-			} while (h->us_alpha < 1.0f);
-			h->us_alpha -= 1.0f;
+			} while (alpha < 1.0f);
+			alpha -= 1.0f;
 		}
+		h->us_alpha = alpha;
+		h->us_pend_n = n;
 		h->us_in += len;
 		{ std::lock_guard<std::mutex> l(w.m); w.nflush[run % UsWorker::NRUN] = n_flush; w.produced_runs = run + 1; }
 		w.cv.notify_all();
@@ -1054,7 +1078,7 @@ const char* aisgpu_last_error(aisgpu_t* h) { return h ? h->err.c_str() : ""; }
 
 int aisgpu_set_option(const char* key, const char* value) {
 	if (!key || !*key) return AISGPU_ERR_ARG;
-	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "trace", "k7e_stats", "k7b_stats" };
+	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "fm_on_s1", "us_on_ds", "front_low_prio", "trace", "k7e_stats", "k7b_stats" };
 	bool ok = false;
 	for (const char* k : known) ok = ok || strcmp(k, key) == 0;
 	if (!ok) return AISGPU_ERR_ARG;
@@ -1257,7 +1281,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			std::vector<uint32_t> lat(words, 0u), rest(words, 0u);
 			for (int i = 0; i < n_cu; i++) (i < reserve ? lat : rest)[i / 32] |= 1u << (i % 32);
 			int least = 0, greatest = 0;
-			const bool prio = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
+			const bool prio = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest && opt_int("front_low_prio", 1) != 0;
 			// (a runtime without CU masks falls back to ordinary streams: same results, the recurrence just shares its SIMDs)
 						masked = (prio ? hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, least) : hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)words, rest.data())) == hipSuccess;
 			masked = masked && hipExtStreamCreateWithCUMask(&h->s1, (uint32_t)words, rest.data()) == hipSuccess;
@@ -1282,6 +1306,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	}
 	h->ds = (!h->serial && h->mode == MODE_RESAMPLE && h->KP > 0) ? h->s4 : h->stream;
 	for (int i = 0; i < NBUF; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_pre[i], hipEventDisableTiming));
+	HIPCHK(hipEventCreateWithFlags(&h->ev_fm, hipEventDisableTiming));
+	h->fm_on_s1 = !h->serial && opt_int("fm_on_s1", h->mode == MODE_RESAMPLE ? 1 : 0) != 0;
 	for (int i = 0; i < NBUF; i++) {
 		HIPCHK(hipEventCreateWithFlags(&h->ev_front[i], hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&h->ev_phasor[i], hipEventDisableTiming));
@@ -1334,7 +1360,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		}
 	}
 	if (KP > 0 || mode == MODE_DSK || mode == MODE_RESAMPLE || mode == MODE_96K) {
-		const int nx = mode == MODE_RESAMPLE ? 4 : (mode == MODE_DSK || mode == MODE_96K) ? 2 : 1;
+		const int nx = mode == MODE_RESAMPLE ? XR : (mode == MODE_DSK || mode == MODE_96K) ? 2 : 1;
 		for (int i = 0; i < nx; i++) HIPCHK(dalloc(&h->d_xpre[i], R * ((size_t)h->xh + h->n_pre)));
 		if (mode == MODE_PRE) for (int i = 0; i < 2; i++) HIPCHK(dalloc((unsigned char**)&h->d_hist2[i], R * h->tile_in * 8));
 		if (h->KPa) { // second pre-decimation pass: four stages on the CF32 stream of the first
@@ -1350,7 +1376,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		if (hipHostGetDevicePointer((void**)&h->h_rot_dev[i], h->h_rot[i], 0) != hipSuccess) h->rot_by_kernel = false;
 	}
 	if (mode == MODE_RESAMPLE) {
-		for (int i = 0; i < 4; i++) { HIPCHK(hipEventCreateWithFlags(&h->ev_xin[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_xread[i], hipEventDisableTiming)); }
+		for (int i = 0; i < XR; i++) { HIPCHK(hipEventCreateWithFlags(&h->ev_xin[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_xread[i], hipEventDisableTiming)); }
 		for (int i = 0; i < aisgpu::USR; i++) {
 			HIPCHK(hipEventCreateWithFlags(&h->us_copy_ev[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->us_used_ev[i], hipEventDisableTiming));
 			HIPCHK(dalloc(&h->d_usidx[i], (size_t)US_HIST + h->n_pre));
@@ -1442,6 +1468,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	// (round 4: also ModelChallenger on the resampled ladders -- BASELINE configs[2], 6 MSPS: with the lanes-over-time derotation / FIR
 	// kernel 0.558 -> 0.538 ms per step; with round 3's lane-per-chain kernel it had been 0.70 against 0.53)
 	h->fused = !(cfg->flags & AISGPU_FLAG_TAPS) && !h->base && !h->v2 && opt_int("fused", 1) != 0;
+	h->us_on_ds = !h->serial && h->fused && h->mode == MODE_RESAMPLE && h->ds != h->stream && opt_int("us_on_ds", 1) != 0;
 	// The spectral analysis rides at the end of the front-end waves (k1_fft_tail) when every span is a whole number of 512-sample
 	// windows of the 48 kHz channels (16 tiles each) and whole spans make up the block; the automatic span length is rounded up
 	// to such a value, an explicit one (cfg.tiles_per_span) is taken as it is.  Option "fft_in_k1" = 0 (test hook): the FFT / search kernels.
@@ -1538,6 +1565,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	drain_events(h);
 	for (int i = 0; i < NBUF; i++) {
 		if (h->ev_front[i]) hipEventDestroy(h->ev_front[i]);
+		if (i == 0 && h->ev_fm) hipEventDestroy(h->ev_fm);
 		if (h->ev_phasor[i]) hipEventDestroy(h->ev_phasor[i]);
 		if (h->ev_search[i]) hipEventDestroy(h->ev_search[i]);
 		if (h->ev_c48free[i]) hipEventDestroy(h->ev_c48free[i]);
@@ -1550,7 +1578,6 @@ void aisgpu_destroy(aisgpu_t* h) {
 		if (h->ev_k3[i]) hipEventDestroy(h->ev_k3[i]);
 		if (h->ev_k4[i]) hipEventDestroy(h->ev_k4[i]);
 		hipFree(h->d_sym[i]); hipFree(h->d_ema[i]);
-		hipFree(h->d_xpre[i]); hipFree(h->d_xpre[i + 2]);
 	}
 	for (int i = 0; i < aisgpu::USR; i++) {
 		hipFree(h->d_usidx[i]); hipFree(h->d_usalpha[i]); hipFree(h->d_usrot[i]);
@@ -1560,7 +1587,8 @@ void aisgpu_destroy(aisgpu_t* h) {
 		if (h->us_copy_ev[i]) hipEventDestroy(h->us_copy_ev[i]);
 		if (h->us_used_ev[i]) hipEventDestroy(h->us_used_ev[i]);
 	}
-	for (int i = 0; i < 4; i++) { if (h->ev_xin[i]) hipEventDestroy(h->ev_xin[i]); if (h->ev_xread[i]) hipEventDestroy(h->ev_xread[i]); }
+	for (int i = 0; i < XR; i++) hipFree(h->d_xpre[i]);
+	for (int i = 0; i < XR; i++) { if (h->ev_xin[i]) hipEventDestroy(h->ev_xin[i]); if (h->ev_xread[i]) hipEventDestroy(h->ev_xread[i]); }
 	for (auto& p : h->ev_free) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
 	hipFree(h->d_xmid);
 	hipFree(h->d_in[0]); hipFree(h->d_in[1]); hipFree(h->d_hist[0]); hipFree(h->d_hist[1]); hipFree(h->d_hist2[0]); hipFree(h->d_hist2[1]);
@@ -1677,7 +1705,9 @@ int aisgpu_run(aisgpu_t* h) {
 		{ int rc = stage_resample_run(h, h->run_idx + 1, &h->next_nflush); if (rc) return rc; }
 		h->run_idx++;
 		// the pass below overwrites the pre-decimated block of four runs ago: the flushes of the run before last were its last readers
-		WAITEV(h->stream, h->ev_xread[(h->in_blocks + 2) & 3]);
+		// (a ring of XR = 6 since the resampler front end runs beside the NEXT pass and ends after it: with four, pass g + 2 waited for
+		// the front end of run g -- 0.05 .. 0.2 ms of every step on the front stream)
+		WAITEV(h->stream, h->ev_xread[(h->in_blocks + XR - 2) % XR]);
 	}
 
 	// ---- pre-decimation pass (MODE_PRE / MODE_RESAMPLE): KP CIC5 stages at the input rate -> d_xpre
@@ -1686,7 +1716,7 @@ int aisgpu_run(aisgpu_t* h) {
 	if (h->KP == 0 && (h->mode == MODE_DSK || h->mode == MODE_RESAMPLE || h->mode == MODE_96K)) { // 288 kHz input: no CIC5 stage in front of DownsampleKFilter, only the
 		// conversion; likewise rates resampled into the 384k bucket: Upsample works on the converted input itself (Model.cpp:295-301)
 		const bool ring = h->mode == MODE_RESAMPLE;
-		const int xb = ring ? (int)(h->in_blocks & 3) : (int)(h->in_blocks & 1);
+		const int xb = ring ? (int)(h->in_blocks % XR) : (int)(h->in_blocks & 1);
 		xcur = h->d_xpre[xb];
 		xstride = (long long)h->xh + h->n_pre;
 		if (!ring && h->in_blocks > 0) HIPCHK(launch_copy_rows(h->d_xpre[xb ^ 1] + h->n_pre, xstride, xcur, xstride, h->xh, R, h->stream));
@@ -1695,7 +1725,7 @@ int aisgpu_run(aisgpu_t* h) {
 	}
 	if (h->KP > 0) {
 		const bool ring = h->mode == MODE_RESAMPLE, two = h->mode == MODE_DSK;
-		const int xb = ring ? (int)(h->in_blocks & 3) : two ? (int)(h->in_blocks & 1) : 0;
+		const int xb = ring ? (int)(h->in_blocks % XR) : two ? (int)(h->in_blocks & 1) : 0;
 		xcur = h->d_xpre[xb];
 		xstride = (long long)h->xh + h->n_pre;
 		if (two && h->in_blocks > 0) // history = the last xh samples before this block
@@ -1840,22 +1870,26 @@ int aisgpu_run(aisgpu_t* h) {
 		// the front stream, behind the pass over the raw input: next to the NEXT block's pass (on the downstream stream) it takes
 		// 0.27-0.39 ms instead of 0.09 -- both want the CUs' LDS and the same memory system -- and the downstream stream becomes the
 		// pipeline's longest (0.60 ms per step); everything behind the 48 kHz channels runs on `ds`.
-		HIPCHK(hipEventRecord(h->ev_xin[h->in_blocks & 3], h->stream)); // the pre-decimated block is there
-		hipStream_t st = h->stream;
+		HIPCHK(hipEventRecord(h->ev_xin[h->in_blocks % XR], h->stream)); // the pre-decimated block is there
+		// Round 4, late: with us_on_ds the resampler front end is the FIRST thing on the downstream stream when the pass over the input
+		// ends -- that stream is idle then (the previous block's derotation / FIR kernel is deferred behind it: enqueue_fused_back
+		// below), its queue outranks the front stream's, so the resampler takes the CUs at the boundary between two passes instead
+		// of getting them one by one from a pass already resident -- and the front stream is the passes back to back.
+		hipStream_t st = h->us_on_ds ? h->ds : h->stream;
 		const int len = h->n_pre;
 		(void)len;
 		for (int fi = 0; fi < n_flush; fi++) {
 			const int pb = (int)(h->block_idx & 1);
 			const int q = (int)(h->block_idx % NBUF);
 			const int slot = (int)(h->run_flush++ % aisgpu::USR);
-			WAITEV(st, h->ev_xin[h->in_blocks & 3]);
+			WAITEV(st, h->ev_xin[h->in_blocks % XR]);
 			WAITEV(st, h->us_copy_ev[slot]);
 			WAITEV(st, h->ev_c48free[q]);
 			if (h->eager_out) WAITEV(st, h->ev_ema[(h->block_idx + 4 - NBUF % 4) & 3]); // ppm[q] of block f-NBUF has been copied out
 			if (h->us_dsk) { // US >> DSK >> ROT: the flush is a whole number of the filter's 8192-sample output blocks
 				K1kParams kk;
 				kk.xin = xcur; kk.xin_stride = xstride; kk.xin_off = h->xh;
-				kk.xprev = h->d_xpre[(h->in_blocks + 3) & 3]; kk.xprev2 = h->d_xpre[(h->in_blocks + 2) & 3]; kk.n_in = h->n_pre;
+				kk.xprev = h->d_xpre[(h->in_blocks + XR - 1) % XR]; kk.xprev2 = h->d_xpre[(h->in_blocks + XR - 2) % XR]; kk.n_in = h->n_pre;
 				kk.rot = h->d_usrot[slot]; kk.c48 = h->d_c48[q]; kk.c48_stride = h->c48s; kk.L = h->L;
 				kk.us_idx = h->d_usidx[slot]; kk.us_alpha = h->d_usalpha[slot];
 				memcpy(kk.taps, TAPS_BH_28_3, sizeof kk.taps);
@@ -1863,7 +1897,7 @@ int aisgpu_run(aisgpu_t* h) {
 			} else {
 				K1uParams ku;
 				ku.xin = xcur; ku.xin_stride = xstride; ku.xin_off = h->xh;
-				ku.xprev = h->d_xpre[(h->in_blocks + 3) & 3]; ku.xprev2 = h->d_xpre[(h->in_blocks + 2) & 3]; ku.n_in = h->n_pre;
+				ku.xprev = h->d_xpre[(h->in_blocks + XR - 1) % XR]; ku.xprev2 = h->d_xpre[(h->in_blocks + XR - 2) % XR]; ku.n_in = h->n_pre;
 				ku.us_idx = h->d_usidx[slot]; ku.us_alpha = h->d_usalpha[slot]; ku.rot = h->d_usrot[slot];
 				ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
 				ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->has_fdc; ku.L = h->L;
@@ -1871,16 +1905,17 @@ int aisgpu_run(aisgpu_t* h) {
 				else HIPCHK(launch_k1u(ku, h->npost, R, st));
 			}
 			HIPCHK(hipEventRecord(h->us_used_ev[slot], st));
-			HIPCHK(hipEventRecord(h->ev_xread[h->in_blocks & 3], st)); // (the run's last flush leaves the event that counts)
+			HIPCHK(hipEventRecord(h->ev_xread[h->in_blocks % XR], st)); // (the run's last flush leaves the event that counts)
 			h->us_slot_used[slot] = true;
 			if (h->ds != st) { // the 48 kHz channels of this flush exist: everything behind them runs on ds, next to the next input block's pass
 				HIPCHK(hipEventRecord(h->ev_pre[q], st));
 				WAITEV(h->ds, h->ev_pre[q]);
 			}
+			if (h->us_on_ds) { int rc = enqueue_fused_back(h); if (rc) return rc; } // the previous flush's second half: behind this flush's resampler on ds
 			int rc = enqueue_downstream(h, q, pb); // (advances block_idx)
 			if (rc) return rc;
 		}
-		if (n_flush == 0) HIPCHK(hipEventRecord(h->ev_xread[h->in_blocks & 3], st)); // (behind the earlier runs' flushes on st)
+		if (n_flush == 0) HIPCHK(hipEventRecord(h->ev_xread[h->in_blocks % XR], st)); // (behind the earlier runs' flushes on st)
 	}
 	if (h->staged) { // everything that reads the staged input (front end, tail copies, conversions) is on the front stream, in front of this
 		HIPCHK(hipEventRecord(h->ev_in_free[in_p], h->stream));

@@ -282,6 +282,7 @@ hipError_t launch_convert_rows(const void* in, long long in_stride, int fmt, flo
 hipError_t launch_ma_rows(const void* in, long long in_stride, int fmt, int m, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
 hipError_t launch_k2a_fft(const K2Params& p, int n_chan, hipStream_t s);
 hipError_t launch_k2a_search(const K2Params& p, int n_chan, hipStream_t s);
+hipError_t launch_k2a_fft_search(const K2Params& p, int n_chan, hipStream_t s); // both in one kernel, no magnitudes in HBM (n_chan even: the two channels of a receiver)
 hipError_t launch_selftest_hypot(const float2* in, int n, unsigned* mismatches, hipStream_t s);
 hipError_t launch_k2b(const K2Params& p, int n_chan, hipStream_t s); // phasor recurrence
 hipError_t launch_k2c(const K2Params& p, int n_chan, hipStream_t s); // history carry + apply

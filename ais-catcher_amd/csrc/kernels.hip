@@ -467,7 +467,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 // 32 output samples per channel and recomputes the short halos of every stage (no carried state).  This stream
 // carries 1/16 of the input rate, so the kernel is a footnote in the time budget.
 // ------------------------------------------------------------------------------------------
-constexpr int K1U_M = 32;  // 48 kHz outputs per channel per workgroup
+constexpr int K1U_M = 128; // 48 kHz outputs per channel per workgroup (every block is a whole number of 512-sample windows, aisgpu.cpp)
+// Round 4: 128, was 32.  With 32 a workgroup's stages had 64 .. 339 items for its 256 threads and six barriers for them -- 85 us per
+// block on the 6 MSPS ladder's front stream, a fifth of the step; the halos are 83 samples per 8 M inputs either way.
 
 __device__ __forceinline__ float2 cic5_at(const float2* a, int pos2j) { // decimating CIC5 output from a[pos2j-5 .. pos2j]
 	float2 v[6];
@@ -481,51 +483,87 @@ __device__ __forceinline__ float2 cic5_at(const float2* a, int pos2j) { // decim
 // NPOST: CIC5 stages between the resampler and the 96 kHz point -- 2 (buckets 384k ... 12288k), 1 (rates resampled into the 192k
 // bucket: US >> DS2_1, Model.cpp:323-329), 0 (96 kSPS input, no resampler at all: convert >> ROT, Model.cpp:332-334; xin is the
 // converted input itself)
-template <int NPOST>
+template <int NPOST, int M>
 __global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
-	__shared__ float2 U[NPOST == 2 ? 8 * K1U_M + 88 : 1];   // u(n),  n  in [8 m0 - 83, 8 m0 + 8 M)
-	__shared__ float2 S1[NPOST >= 1 ? 4 * K1U_M + 40 : 1];  // 192 kHz-equivalent level, j in [4 m0 - 39, 4 m0 + 4 M)
-	__shared__ float2 S2[2 * K1U_M + 18];  // 96 kHz level,           i in [2 m0 - 17, 2 m0 + 2 M)
-	__shared__ float2 RU[2][2 * K1U_M + 16]; // rotated up/down,        i in [2 m0 - 15, 2 m0 + 2 M)
-	__shared__ float2 DD[2][K1U_M + 6];    // DS2_a/b output,         j in [m0 - 5, m0 + M)
+	// One pool, so that the staged input span (XS) can lie over the buffers of the later stages:
+	constexpr int UN = NPOST == 2 ? 8 * M + 88 : 0;   // u(n),  n  in [8 m0 - 83, 8 m0 + 8 M)
+	constexpr int S1N = NPOST >= 1 ? 4 * M + 40 : 0;  // 192 kHz-equivalent level, j in [4 m0 - 39, 4 m0 + 4 M)
+	constexpr int S2N = 2 * M + 18;                   // 96 kHz level,           i in [2 m0 - 17, 2 m0 + 2 M)
+	constexpr int RUN = 2 * M + 16;                   // rotated up / down,      i in [2 m0 - 15, 2 m0 + 2 M)   (two rows)
+	constexpr int DDN = M + 6;                        // DS2_a/b output,         j in [m0 - 5, m0 + M)          (two rows)
+	constexpr bool DD_IN_U = NPOST == 2;              // (u is dead long before: 19.9 KB, eight workgroups per CU instead of seven)
+	__shared__ float2 pool[UN + S1N + S2N + 2 * RUN + (DD_IN_U ? 0 : 2 * DDN)];
+	float2* const U = pool; float2* const S1 = pool + UN; float2* const S2 = S1 + S1N; float2* const RU = S2 + S2N; float2* const DD = DD_IN_U ? U : RU + 2 * RUN;
 	const int t = threadIdx.x;
 	const int rx = blockIdx.y;
-	const int m0 = blockIdx.x * K1U_M;
+	const int m0 = blockIdx.x * M;
 	const size_t xrow = (size_t)rx * p.xin_stride + p.xin_off;
 	const XRow xr{ p.xin + xrow, p.xprev ? p.xprev + xrow : nullptr, p.xprev2 ? p.xprev2 + xrow : nullptr, p.n_in }; // xr[i]: i relative to the current block start
-	// the input samples this workgroup's outputs interpolate between (us_idx is non-decreasing)
-	const int nn_lo = NPOST == 2 ? 8 * m0 - 83 : NPOST == 1 ? 4 * m0 - 39 : 0, nn_hi = NPOST == 2 ? 8 * m0 + 8 * K1U_M - 1 : NPOST == 1 ? 4 * m0 + 4 * K1U_M - 1 : 0;
-	const XSpan x = NPOST == 0 ? XSpan(xr, 2 * m0 - 17, 2 * m0 + 2 * K1U_M) : XSpan(xr, p.us_idx[US_HIST + nn_lo] - 1, p.us_idx[US_HIST + nn_hi]);
-	const auto resampled = [&](int n) { // output n of Upsample: (1 - alpha) * a + alpha * b, products rounded separately (DSP.cpp:199)
-		const int i = p.us_idx[US_HIST + n];
-		const float al = p.us_alpha[US_HIST + n];
-		const float2 a = x[i - 1], b = x[i];
-		const float w0 = 1 - al;
-		return make_float2(w0 * a.x + al * b.x, w0 * a.y + al * b.y);
-	};
-	if constexpr (NPOST == 2) {
-		const int n_lo = 8 * m0 - 83;
-		for (int q = t; q < 8 * K1U_M + 83; q += 256) U[q] = resampled(n_lo + q);
+	if constexpr (NPOST >= 1) {
+		// Upsample (DSP.cpp:192-212): output n = (1 - alpha) * x[b - 1] + alpha * x[b], products rounded separately (DSP.cpp:199), (b, alpha) from
+		// the tables.  Round 4: the table entries of ALL of a thread's outputs are requested at once, the input span they point into
+		// (us_idx is non-decreasing; an upsampler's span is no longer than its outputs) is staged in LDS with coalesced loads, and the
+		// interpolation reads LDS -- two memory round trips per workgroup, not two per 256 outputs (b, then x[b]): the kernel is
+		// latency-bound, 0.10 ms of the 6 MSPS ladder's 0.47 ms step when it meets the pass over the next input block.
+		constexpr int NU = NPOST == 2 ? 8 * M + 83 : 4 * M + 39;          // resampled samples this workgroup needs
+		constexpr int NQ = (NU + 255) / 256;
+		constexpr int XS_CAP = (NPOST == 2 ? S1N : 0) + S2N + 2 * RUN; // the span lies over the later stages' buffers
+		float2* const XS = NPOST == 2 ? S1 : S2;
+		float2* const dst = NPOST == 2 ? U : S1;
+		const int n_lo = NPOST == 2 ? 8 * m0 - 83 : 4 * m0 - 39;
+		int ib[NQ]; float al[NQ];
+#pragma unroll
+		for (int k = 0; k < NQ; k++) {
+			const int q = t + 256 * k;
+			ib[k] = q < NU ? p.us_idx[US_HIST + n_lo + q] : 0;
+			al[k] = q < NU ? p.us_alpha[US_HIST + n_lo + q] : 0.0f;
+		}
+		const int lo = p.us_idx[US_HIST + n_lo] - 1, hi = p.us_idx[US_HIST + n_lo + NU - 1];
+		if (hi - lo + 1 <= XS_CAP) {
+			const XSpan x(xr, lo, hi);
+			for (int q = t; q <= hi - lo; q += 256) XS[q] = x[lo + q];
+			__syncthreads();
+#pragma unroll
+			for (int k = 0; k < NQ; k++) {
+				const int q = t + 256 * k;
+				if (q < NU) { // (dst and XS do not overlap)
+					const float2 a = XS[ib[k] - 1 - lo], b = XS[ib[k] - lo];
+					const float w0 = 1 - al[k];
+					dst[q] = make_float2(w0 * a.x + al[k] * b.x, w0 * a.y + al[k] * b.y);
+				}
+			}
+		} else { // (not an upsampler's table: straight from global memory)
+			const XSpan x(xr, lo, hi);
+#pragma unroll
+			for (int k = 0; k < NQ; k++) {
+				const int q = t + 256 * k;
+				if (q < NU) {
+					const float2 a = x[ib[k] - 1], b = x[ib[k]];
+					const float w0 = 1 - al[k];
+					dst[q] = make_float2(w0 * a.x + al[k] * b.x, w0 * a.y + al[k] * b.y);
+				}
+			}
+		}
 		__syncthreads();
-		for (int q = t; q < 4 * K1U_M + 39; q += 256) { // j = 4 m0 - 39 + q needs u(2j-5..2j): U index 2j - n_lo
+	}
+	if constexpr (NPOST == 2) {
+		for (int q = t; q < 4 * M + 39; q += 256) { // j = 4 m0 - 39 + q needs u(2j-5..2j): U index 2j - n_lo
 			const int j = 4 * m0 - 39 + q;
 			S1[q] = cic5_at(U, 2 * j - (8 * m0 - 83));
 		}
 		__syncthreads();
-	} else if constexpr (NPOST == 1) {
-		for (int q = t; q < 4 * K1U_M + 39; q += 256) S1[q] = resampled(4 * m0 - 39 + q);
-		__syncthreads();
 	}
 	if constexpr (NPOST >= 1) {
-		for (int q = t; q < 2 * K1U_M + 17; q += 256) { // i = 2 m0 - 17 + q needs s1(2i-5..2i)
+		for (int q = t; q < 2 * M + 17; q += 256) { // i = 2 m0 - 17 + q needs s1(2i-5..2i)
 			const int i = 2 * m0 - 17 + q;
 			S2[q] = cic5_at(S1, 2 * i - (4 * m0 - 39));
 		}
 	} else {
-		for (int q = t; q < 2 * K1U_M + 17; q += 256) S2[q] = x[2 * m0 - 17 + q];
+		const XSpan x(xr, 2 * m0 - 17, 2 * m0 + 2 * M);
+		for (int q = t; q < 2 * M + 17; q += 256) S2[q] = x[2 * m0 - 17 + q];
 	}
 	__syncthreads();
-	for (int q = t; q < 2 * K1U_M + 15; q += 256) { // i = 2 m0 - 15 + q: FDC (DSP.cpp:283-293) + Rotate (DSP.cpp:296-316)
+	for (int q = t; q < 2 * M + 15; q += 256) { // i = 2 m0 - 15 + q: FDC (DSP.cpp:283-293) + Rotate (DSP.cpp:296-316)
 		const int i = 2 * m0 - 15 + q;
 		const int si = i - (2 * m0 - 17);
 		const float2 xm2 = S2[si - 2], xm1 = S2[si - 1], xv = S2[si];
@@ -536,21 +574,21 @@ __global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
 		}
 		const float2 rot = p.rot[ROT_HIST + i];
 		const float RR = y.x * rot.x, II = y.y * rot.y, RI = y.x * rot.y, IR = y.y * rot.x;
-		RU[0][q] = make_float2(RR - II, IR + RI);
-		RU[1][q] = make_float2(RR + II, IR - RI);
+		RU[q] = make_float2(RR - II, IR + RI);
+		RU[RUN + q] = make_float2(RR + II, IR - RI);
 	}
 	__syncthreads();
-	for (int q = t; q < 2 * (K1U_M + 5); q += 256) { // DS2_a / DS2_b: j = m0 - 5 + jj needs up(2j-5..2j)
-		const int ch = q / (K1U_M + 5), jj = q % (K1U_M + 5);
+	for (int q = t; q < 2 * (M + 5); q += 256) { // DS2_a / DS2_b: j = m0 - 5 + jj needs up(2j-5..2j)
+		const int ch = q / (M + 5), jj = q % (M + 5);
 		const int j = m0 - 5 + jj;
-		DD[ch][jj] = cic5_at(RU[ch], 2 * j - (2 * m0 - 15));
+		DD[ch * DDN + jj] = cic5_at(RU + ch * RUN, 2 * j - (2 * m0 - 15));
 	}
 	__syncthreads();
-	if (t < 2 * K1U_M) { // FilterCIC5 (DSP.cpp:132-157)
-		const int ch = t / K1U_M, mm = t % K1U_M;
+	if (t < 2 * M) { // FilterCIC5 (DSP.cpp:132-157)
+		const int ch = t / M, mm = t % M;
 		float2 v[6];
 #pragma unroll
-		for (int e = 0; e < 6; e++) v[e] = DD[ch][mm + e]; // d(m-5 .. m)
+		for (int e = 0; e < 6; e++) v[e] = DD[ch * DDN + mm + e]; // d(m-5 .. m)
 #pragma unroll
 		for (int lvl = 0; lvl < 5; lvl++) {
 #pragma unroll
@@ -566,9 +604,8 @@ __global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
 // K1U_M outputs at 48 kHz and recomputes the short halos of every stage); only channel A's row of c48 is written, channel
 // B's stays silent (zero), so everything behind the front end runs unchanged.
 // ------------------------------------------------------------------------------------------
-template <int NPOST>
+template <int NPOST, int M>
 __global__ __launch_bounds__(256) void k1x_single_channel(K1uParams p) {
-	constexpr int M = K1U_M;
 	__shared__ float2 U[NPOST == 2 ? 4 * M + 44 : 1];  // 192 kHz level, n in [4 m0 - 43, 4 m0 + 4 M)
 	__shared__ float2 S1[NPOST >= 1 ? 2 * M + 20 : 1]; // 96 kHz level,  j in [2 m0 - 19, 2 m0 + 2 M)
 	__shared__ float2 T[M + 8];                        // 48 kHz level,  m in [m0 - 7, m0 + M)
@@ -631,8 +668,8 @@ __global__ __launch_bounds__(256) void k1x_single_channel(K1uParams p) {
 // sum_t taps[t] * x[3 i + t - 25] (accumulated left to right from 0).  Same tile scheme as K1u: a workgroup
 // produces 32 outputs per channel and recomputes the short halos of every stage.
 // ------------------------------------------------------------------------------------------
+template <int M>
 __global__ __launch_bounds__(256) void k1k_dsk_frontend(K1kParams p) {
-	constexpr int M = K1U_M;
 	__shared__ float2 X[6 * M + 72];       // x(n), n in [6 m0 - 70, 6 m0 + 6 M)
 	__shared__ float2 RU[2][2 * M + 16];   // rotated up/down, i in [2 m0 - 15, 2 m0 + 2 M)
 	__shared__ float2 DD[2][M + 6];        // DS2_a/b output,  j in [m0 - 5, m0 + M)
@@ -1080,6 +1117,15 @@ __device__ __forceinline__ void k1_fft_tail(const K1Params& p, int rx, int span,
 			p.ppm[W] = p.ppm_table[f + 205];
 		}
 	}
+}
+
+// The same analysis as a kernel of its own, one wave per (receiver, window), for the front ends that do not end in k1_dpp (the resampled
+// and decimate-by-3 ladders, mode X): it replaces k2_fft_mag + k2_cgf_search there -- 21 KB of LDS and 88 VGPRs per wave, 2 KB of
+// magnitudes per window out and in again -- which beside the 6 MSPS ladder's pass over the input took 0.23 + 0.06 ms instead of
+// 0.02 + 0.03 alone and were the longest link of that path's back-end chain (profiles/r04_config3_timeline.txt).
+__global__ __launch_bounds__(64) void k2_fft_search_win(K1Params p) {
+	__shared__ __attribute__((aligned(16))) float2 X[1024];
+	k1_fft_tail(p, blockIdx.y, blockIdx.x, X); // (p.fft_windows = 1: "span" = window)
 }
 
 __global__ __launch_bounds__(64) void k2_cgf_search(K2Params p) {
@@ -3770,24 +3816,27 @@ hipError_t launch_k1(const K1Params& p, int K, int fmt, int spans, int n_rx, hip
 	return launch_k1_dpp(p, K, fmt, spans, n_rx, s, ev);
 }
 
+#define K1U_LAUNCH(kernel_, ...) hipLaunchKernelGGL((kernel_<__VA_ARGS__ K1U_M>), dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p)
+#define K1U_COMMA ,
+
 hipError_t launch_k1u(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
-	if (npost == 2) hipLaunchKernelGGL(k1u_resample_frontend<2>, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
-	else if (npost == 1) hipLaunchKernelGGL(k1u_resample_frontend<1>, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
-	else if (npost == 0) hipLaunchKernelGGL(k1u_resample_frontend<0>, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
+	if (npost == 2) K1U_LAUNCH(k1u_resample_frontend, 2 K1U_COMMA);
+	else if (npost == 1) K1U_LAUNCH(k1u_resample_frontend, 1 K1U_COMMA);
+	else if (npost == 0) K1U_LAUNCH(k1u_resample_frontend, 0 K1U_COMMA);
 	else return hipErrorInvalidValue;
 	return hipGetLastError();
 }
 
 hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
-	if (npost == 2) hipLaunchKernelGGL(k1x_single_channel<2>, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
-	else if (npost == 1) hipLaunchKernelGGL(k1x_single_channel<1>, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
-	else if (npost == 0) hipLaunchKernelGGL(k1x_single_channel<0>, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
+	if (npost == 2) K1U_LAUNCH(k1x_single_channel, 2 K1U_COMMA);
+	else if (npost == 1) K1U_LAUNCH(k1x_single_channel, 1 K1U_COMMA);
+	else if (npost == 0) K1U_LAUNCH(k1x_single_channel, 0 K1U_COMMA);
 	else return hipErrorInvalidValue;
 	return hipGetLastError();
 }
 
 hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s) {
-	hipLaunchKernelGGL(k1k_dsk_frontend, dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p);
+	K1U_LAUNCH(k1k_dsk_frontend, );
 	return hipGetLastError();
 }
 
@@ -3829,6 +3878,14 @@ hipError_t launch_selftest_hypot(const float2* in, int n, unsigned* mismatches, 
 hipError_t launch_k2a_fft(const K2Params& p, int n_chan, hipStream_t s) {
 	const int n = n_chan * p.n_windows;
 	hipLaunchKernelGGL(k2_fft_mag, dim3((n + FFT_NW - 1) / FFT_NW), dim3(64), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_k2a_fft_search(const K2Params& p, int n_chan, hipStream_t s) { // fz / ppm of every window straight from c48 (both channels of a receiver per wave)
+	K1Params k{};
+	k.c48 = const_cast<float2*>(p.c48); k.c48_stride = p.c48_stride; k.omega = p.omega; k.ppm_table = p.ppm_table; k.fz = p.fz; k.ppm = p.ppm;
+	k.fft_windows = 1; k.n_windows = p.n_windows; k.wide = p.wide;
+	hipLaunchKernelGGL(k2_fft_search_win, dim3(p.n_windows, n_chan / 2), dim3(64), 0, s, k);
 	return hipGetLastError();
 }
 

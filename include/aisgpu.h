@@ -221,6 +221,8 @@ void aisgpu_timing(aisgpu_t* h, int enable);
  *   "k7b_fcap"      1 .. 4: frames a list of ModelBase's chunk-parallel decoder kernels takes (small values force the exact fallback, k7_base)
  *   "fused"         0: the materialised back end (phasor / derotated-sample arrays in HBM: what AISGPU_FLAG_TAPS uses)
  *   "fft_in_k1"     0: the spectral analysis as FFT + search kernels instead of inside the front-end waves
+ *   "fm_on_s1"      0 / 1: ModelChallenger's FM branch behind the derotation / FIR kernel, or in front of PhaseSearch on its stream
+ *   "us_on_ds"      0: resampled ladders: the resampler front end on the front stream behind the pass over the input (default: downstream stream)
  * Returns AISGPU_ERR_ARG for an unknown key. */
 int aisgpu_set_option(const char* key, const char* value);
 
