@@ -165,6 +165,7 @@ struct aisgpu {
 	float2* d_xpre[XR] = {};           // pre-decimated stream: [R][xh + n_pre], ping-pong by input block (MODE_PRE uses [0] only); resampled ladders: ring of
 	                                  // XR [R][n_pre]: a flush may reach a whole input block back (no history copy: K1uParams::xprev / xprev2), and the
 	                                  // pass over block f+1 must not wait for the resampler kernels of block f
+	bool x_direct = false; float2* d_xhist[2] = {}; // CF32 input of the ladders without a pass at the input rate read in place: the kept tails [R][xh]
 	float2* d_xmid = nullptr;         // [R][block_len >> KPa]: between the two passes of a pre-decimation of more than four stages
 	bool mode_x = false;              // channel mode X: single-channel front end K1x (npost stages down to 48 kHz), channel B silent
 	int npost = 2;                    // CIC5 stages behind the resampler (K1u): 2, 1 (192k bucket), 0 (96 kSPS input: no resampler either)
@@ -1078,7 +1079,7 @@ const char* aisgpu_last_error(aisgpu_t* h) { return h ? h->err.c_str() : ""; }
 
 int aisgpu_set_option(const char* key, const char* value) {
 	if (!key || !*key) return AISGPU_ERR_ARG;
-	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "fm_on_s1", "us_on_ds", "front_low_prio", "trace", "k7e_stats", "k7b_stats" };
+	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "fm_on_s1", "us_on_ds", "front_low_prio", "x_direct", "trace", "k7e_stats", "k7b_stats" };
 	bool ok = false;
 	for (const char* k : known) ok = ok || strcmp(k, key) == 0;
 	if (!ok) return AISGPU_ERR_ARG;
@@ -1360,7 +1361,9 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		}
 	}
 	if (KP > 0 || mode == MODE_DSK || mode == MODE_RESAMPLE || mode == MODE_96K) {
-		const int nx = mode == MODE_RESAMPLE ? XR : (mode == MODE_DSK || mode == MODE_96K) ? 2 : 1;
+		h->x_direct = KP == 0 && (mode == MODE_DSK || mode == MODE_96K) && h->kfmt == 0 && !h->ma_m && h->xh <= h->n_pre && opt_int("x_direct", 1) != 0;
+		if (h->x_direct) for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_xhist[i], R * (size_t)h->xh)); // zero = silence before the stream
+		const int nx = h->x_direct ? 0 : mode == MODE_RESAMPLE ? XR : (mode == MODE_DSK || mode == MODE_96K) ? 2 : 1;
 		for (int i = 0; i < nx; i++) HIPCHK(dalloc(&h->d_xpre[i], R * ((size_t)h->xh + h->n_pre)));
 		if (mode == MODE_PRE) for (int i = 0; i < 2; i++) HIPCHK(dalloc((unsigned char**)&h->d_hist2[i], R * h->tile_in * 8));
 		if (h->KPa) { // second pre-decimation pass: four stages on the CF32 stream of the first
@@ -1588,6 +1591,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 		if (h->us_used_ev[i]) hipEventDestroy(h->us_used_ev[i]);
 	}
 	for (int i = 0; i < XR; i++) hipFree(h->d_xpre[i]);
+	hipFree(h->d_xhist[0]); hipFree(h->d_xhist[1]);
 	for (int i = 0; i < XR; i++) { if (h->ev_xin[i]) hipEventDestroy(h->ev_xin[i]); if (h->ev_xread[i]) hipEventDestroy(h->ev_xread[i]); }
 	for (auto& p : h->ev_free) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
 	hipFree(h->d_xmid);
@@ -1719,9 +1723,14 @@ int aisgpu_run(aisgpu_t* h) {
 		const int xb = ring ? (int)(h->in_blocks % XR) : (int)(h->in_blocks & 1);
 		xcur = h->d_xpre[xb];
 		xstride = (long long)h->xh + h->n_pre;
+		if (h->x_direct) {
+			// CF32 rows are read where the caller put them (round 4: the converted copy was 0.5 of the 2.2 ms the front stream of the
+			// 288 kSPS ladder took per 1.6 GB of input); what the next block needs of this one is its tail: d_xhist, by block parity
+		} else {
 		if (!ring && h->in_blocks > 0) HIPCHK(launch_copy_rows(h->d_xpre[xb ^ 1] + h->n_pre, xstride, xcur, xstride, h->xh, R, h->stream));
 		if (h->ma_m) HIPCHK(launch_ma_rows(h->cur_in, h->cur_in_stride, h->kfmt, h->ma_m, xcur + h->xh, xstride, h->n_pre, R, h->stream));
 		else HIPCHK(launch_convert_rows(h->cur_in, h->cur_in_stride, h->kfmt, xcur + h->xh, xstride, h->n_pre, R, h->stream));
+		}
 	}
 	if (h->KP > 0) {
 		const bool ring = h->mode == MODE_RESAMPLE, two = h->mode == MODE_DSK;
@@ -1772,11 +1781,13 @@ int aisgpu_run(aisgpu_t* h) {
 		WAITEV(h->stream, h->ev_c48free[q]);
 		K1uParams ku;
 		ku.xin = xcur; ku.xin_stride = xstride; ku.xin_off = h->xh;
+		if (h->x_direct) { ku.xin = static_cast<const float2*>(h->cur_in); ku.xin_stride = h->cur_in_stride; ku.xin_off = 0; ku.xhist = h->d_xhist[h->in_blocks & 1]; ku.xhist_len = h->xh; }
 		ku.us_idx = nullptr; ku.us_alpha = nullptr; ku.rot = h->d_rot[pb];
 		ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
 		ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->mode_x ? h->has_fdc : 0; ku.L = h->L;
 		if (h->mode_x) HIPCHK(launch_k1x(ku, h->npost, R, h->stream));
 		else HIPCHK(launch_k1u(ku, 0, R, h->stream));
+		if (h->x_direct) HIPCHK(launch_copy_rows(ku.xin + h->n_pre - h->xh, ku.xin_stride, h->d_xhist[(h->in_blocks & 1) ^ 1], h->xh, h->xh, R, h->stream));
 		int rc = enqueue_downstream(h, q, pb);
 		if (rc) return rc;
 	} else if (h->mode == MODE_DSK) {
@@ -1792,10 +1803,12 @@ int aisgpu_run(aisgpu_t* h) {
 		WAITEV(h->stream, h->ev_c48free[q]);
 		K1kParams kk;
 		kk.xin = xcur; kk.xin_stride = xstride; kk.xin_off = h->xh;
+		if (h->x_direct) { kk.xin = static_cast<const float2*>(h->cur_in); kk.xin_stride = h->cur_in_stride; kk.xin_off = 0; kk.xhist = h->d_xhist[h->in_blocks & 1]; kk.xhist_len = h->xh; }
 		kk.rot = h->d_rot[pb]; kk.c48 = h->d_c48[q]; kk.c48_stride = h->c48s; kk.L = h->L;
 		kk.us_idx = nullptr; kk.us_alpha = nullptr;
 		memcpy(kk.taps, TAPS_BH_28_3, sizeof kk.taps);
 		HIPCHK(launch_k1k(kk, R, h->stream));
+		if (h->x_direct) HIPCHK(launch_copy_rows(kk.xin + h->n_pre - h->xh, kk.xin_stride, h->d_xhist[(h->in_blocks & 1) ^ 1], h->xh, h->xh, R, h->stream));
 		int rc = enqueue_downstream(h, q, pb);
 		if (rc) return rc;
 	} else if (h->mode != MODE_RESAMPLE) {

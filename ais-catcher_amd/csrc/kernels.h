@@ -43,12 +43,22 @@ struct K1uParams {
 	// resampled ladders: the input blocks live in a ring of three buffers instead of one buffer with a copied history (a flush may
 	// begin a whole input block back): sample i < 0 is xprev[n_in + i], i < -n_in is xprev2[2 n_in + i] (rows of xin_stride, no offset)
 	const float2* xprev = nullptr; const float2* xprev2 = nullptr; int n_in = 0;
+	// CF32 input read where the caller put it (no converted copy): xin = the caller's rows (xin_off = 0), and the samples in front of the
+	// block come from xhist[rx * xhist_len + xhist_len + i], i in [-xhist_len, 0) -- the previous block's tail, kept by the library
+	const float2* xhist = nullptr; int xhist_len = 0;
 };
 // sample i of the pre-decimated stream relative to the current input block's start (see K1uParams::xprev)
 struct XRow {
 	const float2 *cur, *prev, *prev2; int n;
 	__host__ __device__ float2 operator[](int i) const { return (i >= 0 || !prev) ? cur[i] : (i >= -n ? prev[n + i] : prev2[2 * n + i]); }
 };
+// the row of receiver rx for either arrangement of the samples in front of the block
+template <class P>
+__host__ __device__ inline XRow make_xrow(const P& p, int rx) {
+	const size_t xrow = (size_t)rx * p.xin_stride + p.xin_off;
+	if (p.xhist) return XRow{ p.xin + xrow, p.xhist + (size_t)rx * p.xhist_len, nullptr, p.xhist_len };
+	return XRow{ p.xin + xrow, p.xprev ? p.xprev + xrow : nullptr, p.xprev2 ? p.xprev2 + xrow : nullptr, p.n_in };
+}
 // the same for a workgroup that only touches samples [lo, hi]: nearly always they lie in ONE of the three buffers, and the access is a
 // plain pointer again (workgroup-uniform choice); only a span that straddles a block boundary goes through the three-way select
 struct XSpan {
@@ -71,6 +81,7 @@ struct K1kParams { // decimate-by-3 front end (DownsampleKFilter ladders: 288k *
 	const int* us_idx; const float* us_alpha; // != nullptr: [US_HIST + len] Upsample in front of the filter (see K1uParams), xin is ITS input
 	int L;                  // 48 kHz samples per channel per block
 	const float2* xprev = nullptr; const float2* xprev2 = nullptr; int n_in = 0; // ring of three input blocks (see K1uParams)
+	const float2* xhist = nullptr; int xhist_len = 0; // CF32 input in place + kept tail (see K1uParams)
 };
 constexpr int DSK_HIST = 128; // samples of the 288 kHz stream kept in front of a block
 

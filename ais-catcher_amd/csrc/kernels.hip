@@ -467,6 +467,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 // 32 output samples per channel and recomputes the short halos of every stage (no carried state).  This stream
 // carries 1/16 of the input rate, so the kernel is a footnote in the time budget.
 // ------------------------------------------------------------------------------------------
+constexpr int K1U_T = 320; // threads per workgroup of these front ends: their stages have 2 M + 15 .. 2 M + 19 = 271 .. 275 items at M = 128 -- with 256 threads a
+                           // second round for the last 15 .. 19 of them, in the FIR stage of the decimate-by-3 ladder (26 taps) half of the kernel
 constexpr int K1U_M = 128; // 48 kHz outputs per channel per workgroup (every block is a whole number of 512-sample windows, aisgpu.cpp)
 // Round 4: 128, was 32.  With 32 a workgroup's stages had 64 .. 339 items for its 256 threads and six barriers for them -- 85 us per
 // block on the 6 MSPS ladder's front stream, a fifth of the step; the halos are 83 samples per 8 M inputs either way.
@@ -484,7 +486,7 @@ __device__ __forceinline__ float2 cic5_at(const float2* a, int pos2j) { // decim
 // bucket: US >> DS2_1, Model.cpp:323-329), 0 (96 kSPS input, no resampler at all: convert >> ROT, Model.cpp:332-334; xin is the
 // converted input itself)
 template <int NPOST, int M>
-__global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
+__global__ __launch_bounds__(K1U_T) void k1u_resample_frontend(K1uParams p) {
 	// One pool, so that the staged input span (XS) can lie over the buffers of the later stages:
 	constexpr int UN = NPOST == 2 ? 8 * M + 88 : 0;   // u(n),  n  in [8 m0 - 83, 8 m0 + 8 M)
 	constexpr int S1N = NPOST >= 1 ? 4 * M + 40 : 0;  // 192 kHz-equivalent level, j in [4 m0 - 39, 4 m0 + 4 M)
@@ -497,8 +499,7 @@ __global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
 	const int t = threadIdx.x;
 	const int rx = blockIdx.y;
 	const int m0 = blockIdx.x * M;
-	const size_t xrow = (size_t)rx * p.xin_stride + p.xin_off;
-	const XRow xr{ p.xin + xrow, p.xprev ? p.xprev + xrow : nullptr, p.xprev2 ? p.xprev2 + xrow : nullptr, p.n_in }; // xr[i]: i relative to the current block start
+	const XRow xr = make_xrow(p, rx); // xr[i]: i relative to the current block start
 	if constexpr (NPOST >= 1) {
 		// Upsample (DSP.cpp:192-212): output n = (1 - alpha) * x[b - 1] + alpha * x[b], products rounded separately (DSP.cpp:199), (b, alpha) from
 		// the tables.  Round 4: the table entries of ALL of a thread's outputs are requested at once, the input span they point into
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
 		// interpolation reads LDS -- two memory round trips per workgroup, not two per 256 outputs (b, then x[b]): the kernel is
 		// latency-bound, 0.10 ms of the 6 MSPS ladder's 0.47 ms step when it meets the pass over the next input block.
 		constexpr int NU = NPOST == 2 ? 8 * M + 83 : 4 * M + 39;          // resampled samples this workgroup needs
-		constexpr int NQ = (NU + 255) / 256;
+		constexpr int NQ = (NU + K1U_T - 1) / K1U_T;
 		constexpr int XS_CAP = (NPOST == 2 ? S1N : 0) + S2N + 2 * RUN; // the span lies over the later stages' buffers
 		float2* const XS = NPOST == 2 ? S1 : S2;
 		float2* const dst = NPOST == 2 ? U : S1;
@@ -514,18 +515,18 @@ __global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
 		int ib[NQ]; float al[NQ];
 #pragma unroll
 		for (int k = 0; k < NQ; k++) {
-			const int q = t + 256 * k;
+			const int q = t + K1U_T * k;
 			ib[k] = q < NU ? p.us_idx[US_HIST + n_lo + q] : 0;
 			al[k] = q < NU ? p.us_alpha[US_HIST + n_lo + q] : 0.0f;
 		}
 		const int lo = p.us_idx[US_HIST + n_lo] - 1, hi = p.us_idx[US_HIST + n_lo + NU - 1];
 		if (hi - lo + 1 <= XS_CAP) {
 			const XSpan x(xr, lo, hi);
-			for (int q = t; q <= hi - lo; q += 256) XS[q] = x[lo + q];
+			for (int q = t; q <= hi - lo; q += K1U_T) XS[q] = x[lo + q];
 			__syncthreads();
 #pragma unroll
 			for (int k = 0; k < NQ; k++) {
-				const int q = t + 256 * k;
+				const int q = t + K1U_T * k;
 				if (q < NU) { // (dst and XS do not overlap)
 					const float2 a = XS[ib[k] - 1 - lo], b = XS[ib[k] - lo];
 					const float w0 = 1 - al[k];
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
 			const XSpan x(xr, lo, hi);
 #pragma unroll
 			for (int k = 0; k < NQ; k++) {
-				const int q = t + 256 * k;
+				const int q = t + K1U_T * k;
 				if (q < NU) {
 					const float2 a = x[ib[k] - 1], b = x[ib[k]];
 					const float w0 = 1 - al[k];
@@ -547,23 +548,23 @@ __global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
 		__syncthreads();
 	}
 	if constexpr (NPOST == 2) {
-		for (int q = t; q < 4 * M + 39; q += 256) { // j = 4 m0 - 39 + q needs u(2j-5..2j): U index 2j - n_lo
+		for (int q = t; q < 4 * M + 39; q += K1U_T) { // j = 4 m0 - 39 + q needs u(2j-5..2j): U index 2j - n_lo
 			const int j = 4 * m0 - 39 + q;
 			S1[q] = cic5_at(U, 2 * j - (8 * m0 - 83));
 		}
 		__syncthreads();
 	}
 	if constexpr (NPOST >= 1) {
-		for (int q = t; q < 2 * M + 17; q += 256) { // i = 2 m0 - 17 + q needs s1(2i-5..2i)
+		for (int q = t; q < 2 * M + 17; q += K1U_T) { // i = 2 m0 - 17 + q needs s1(2i-5..2i)
 			const int i = 2 * m0 - 17 + q;
 			S2[q] = cic5_at(S1, 2 * i - (4 * m0 - 39));
 		}
 	} else {
 		const XSpan x(xr, 2 * m0 - 17, 2 * m0 + 2 * M);
-		for (int q = t; q < 2 * M + 17; q += 256) S2[q] = x[2 * m0 - 17 + q];
+		for (int q = t; q < 2 * M + 17; q += K1U_T) S2[q] = x[2 * m0 - 17 + q];
 	}
 	__syncthreads();
-	for (int q = t; q < 2 * M + 15; q += 256) { // i = 2 m0 - 15 + q: FDC (DSP.cpp:283-293) + Rotate (DSP.cpp:296-316)
+	for (int q = t; q < 2 * M + 15; q += K1U_T) { // i = 2 m0 - 15 + q: FDC (DSP.cpp:283-293) + Rotate (DSP.cpp:296-316)
 		const int i = 2 * m0 - 15 + q;
 		const int si = i - (2 * m0 - 17);
 		const float2 xm2 = S2[si - 2], xm1 = S2[si - 1], xv = S2[si];
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
 		RU[RUN + q] = make_float2(RR + II, IR - RI);
 	}
 	__syncthreads();
-	for (int q = t; q < 2 * (M + 5); q += 256) { // DS2_a / DS2_b: j = m0 - 5 + jj needs up(2j-5..2j)
+	for (int q = t; q < 2 * (M + 5); q += K1U_T) { // DS2_a / DS2_b: j = m0 - 5 + jj needs up(2j-5..2j)
 		const int ch = q / (M + 5), jj = q % (M + 5);
 		const int j = m0 - 5 + jj;
 		DD[ch * DDN + jj] = cic5_at(RU + ch * RUN, 2 * j - (2 * m0 - 15));
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(256) void k1u_resample_frontend(K1uParams p) {
 // B's stays silent (zero), so everything behind the front end runs unchanged.
 // ------------------------------------------------------------------------------------------
 template <int NPOST, int M>
-__global__ __launch_bounds__(256) void k1x_single_channel(K1uParams p) {
+__global__ __launch_bounds__(K1U_T) void k1x_single_channel(K1uParams p) {
 	__shared__ float2 U[NPOST == 2 ? 4 * M + 44 : 1];  // 192 kHz level, n in [4 m0 - 43, 4 m0 + 4 M)
 	__shared__ float2 S1[NPOST >= 1 ? 2 * M + 20 : 1]; // 96 kHz level,  j in [2 m0 - 19, 2 m0 + 2 M)
 	__shared__ float2 T[M + 8];                        // 48 kHz level,  m in [m0 - 7, m0 + M)
@@ -613,8 +614,7 @@ __global__ __launch_bounds__(256) void k1x_single_channel(K1uParams p) {
 	const int t = threadIdx.x;
 	const int rx = blockIdx.y;
 	const int m0 = blockIdx.x * M;
-	const size_t xrow = (size_t)rx * p.xin_stride + p.xin_off;
-	const XRow x{ p.xin + xrow, p.xprev ? p.xprev + xrow : nullptr, p.xprev2 ? p.xprev2 + xrow : nullptr, p.n_in };
+	const XRow x = make_xrow(p, rx);
 	const auto level0 = [&](int n) -> float2 { // sample n of the stream the first CIC5 stage (or the 48 kHz point) sees
 		if (!p.us_idx) return x[n];
 		const int i = p.us_idx[US_HIST + n];
@@ -624,20 +624,20 @@ __global__ __launch_bounds__(256) void k1x_single_channel(K1uParams p) {
 		return make_float2(w0 * a.x + al * b.x, w0 * a.y + al * b.y);
 	};
 	if constexpr (NPOST == 2) {
-		for (int q = t; q < 4 * M + 43; q += 256) U[q] = level0(4 * m0 - 43 + q);
+		for (int q = t; q < 4 * M + 43; q += K1U_T) U[q] = level0(4 * m0 - 43 + q);
 		__syncthreads();
-		for (int q = t; q < 2 * M + 19; q += 256) S1[q] = cic5_at(U, 2 * (2 * m0 - 19 + q) - (4 * m0 - 43));
+		for (int q = t; q < 2 * M + 19; q += K1U_T) S1[q] = cic5_at(U, 2 * (2 * m0 - 19 + q) - (4 * m0 - 43));
 		__syncthreads();
 	} else if constexpr (NPOST == 1) {
-		for (int q = t; q < 2 * M + 19; q += 256) S1[q] = level0(2 * m0 - 19 + q);
+		for (int q = t; q < 2 * M + 19; q += K1U_T) S1[q] = level0(2 * m0 - 19 + q);
 		__syncthreads();
 	}
-	for (int q = t; q < M + 7; q += 256) {
+	for (int q = t; q < M + 7; q += K1U_T) {
 		if constexpr (NPOST >= 1) T[q] = cic5_at(S1, 2 * (m0 - 7 + q) - (2 * m0 - 19));
 		else T[q] = level0(m0 - 7 + q);
 	}
 	__syncthreads();
-	for (int q = t; q < M + 5; q += 256) { // FDC (DSP.cpp:283-293): alpha * (h1 + x) + h2 * beta
+	for (int q = t; q < M + 5; q += K1U_T) { // FDC (DSP.cpp:283-293): alpha * (h1 + x) + h2 * beta
 		const float2 xm2 = T[q], xm1 = T[q + 1], xv = T[q + 2];
 		float2 y = xv;
 		if (p.has_fdc) {
@@ -669,19 +669,18 @@ __global__ __launch_bounds__(256) void k1x_single_channel(K1uParams p) {
 // produces 32 outputs per channel and recomputes the short halos of every stage.
 // ------------------------------------------------------------------------------------------
 template <int M>
-__global__ __launch_bounds__(256) void k1k_dsk_frontend(K1kParams p) {
+__global__ __launch_bounds__(K1U_T) void k1k_dsk_frontend(K1kParams p) {
 	__shared__ float2 X[6 * M + 72];       // x(n), n in [6 m0 - 70, 6 m0 + 6 M)
 	__shared__ float2 RU[2][2 * M + 16];   // rotated up/down, i in [2 m0 - 15, 2 m0 + 2 M)
 	__shared__ float2 DD[2][M + 6];        // DS2_a/b output,  j in [m0 - 5, m0 + M)
 	const int t = threadIdx.x;
 	const int rx = blockIdx.y;
 	const int m0 = blockIdx.x * M;
-	const size_t xrow = (size_t)rx * p.xin_stride + p.xin_off;
-	const XRow xr{ p.xin + xrow, p.xprev ? p.xprev + xrow : nullptr, p.xprev2 ? p.xprev2 + xrow : nullptr, p.n_in };
+	const XRow xr = make_xrow(p, rx);
 	const int n_lo = 6 * m0 - 70;
 	if (p.us_idx) { // Upsample in front of the filter (rates below a decimate-by-3 bucket): sample n of the flush is interpolated
 		const XSpan x(xr, p.us_idx[US_HIST + n_lo] - 1, p.us_idx[US_HIST + n_lo + 6 * M + 69]);
-		for (int q = t; q < 6 * M + 70; q += 256) { // from the input stream like in K1u (DSP.cpp:199: products rounded separately)
+		for (int q = t; q < 6 * M + 70; q += K1U_T) { // from the input stream like in K1u (DSP.cpp:199: products rounded separately)
 			const int n = n_lo + q;
 			const int i = p.us_idx[US_HIST + n];
 			const float al = p.us_alpha[US_HIST + n];
@@ -690,9 +689,9 @@ __global__ __launch_bounds__(256) void k1k_dsk_frontend(K1kParams p) {
 			X[q] = make_float2(w0 * a.x + al * b.x, w0 * a.y + al * b.y);
 		}
 	} else
-	for (int q = t; q < 6 * M + 70; q += 256) X[q] = xr[n_lo + q];
+	for (int q = t; q < 6 * M + 70; q += K1U_T) X[q] = xr[n_lo + q];
 	__syncthreads();
-	for (int q = t; q < 2 * M + 15; q += 256) { // i = 2 m0 - 15 + q
+	for (int q = t; q < 2 * M + 15; q += K1U_T) { // i = 2 m0 - 15 + q
 		const int i = 2 * m0 - 15 + q;
 		const float2* d = X + (3 * i - 25 - n_lo);
 		float2 acc = make_float2(0.0f, 0.0f);
@@ -704,7 +703,7 @@ __global__ __launch_bounds__(256) void k1k_dsk_frontend(K1kParams p) {
 		RU[1][q] = make_float2(RR + II, IR - RI);
 	}
 	__syncthreads();
-	for (int q = t; q < 2 * (M + 5); q += 256) { // DS2_a / DS2_b: j = m0 - 5 + jj needs up(2j-5..2j)
+	for (int q = t; q < 2 * (M + 5); q += K1U_T) { // DS2_a / DS2_b: j = m0 - 5 + jj needs up(2j-5..2j)
 		const int ch = q / (M + 5), jj = q % (M + 5);
 		const int j = m0 - 5 + jj;
 		DD[ch][jj] = cic5_at(RU[ch], 2 * j - (2 * m0 - 15));
@@ -3816,7 +3815,7 @@ hipError_t launch_k1(const K1Params& p, int K, int fmt, int spans, int n_rx, hip
 	return launch_k1_dpp(p, K, fmt, spans, n_rx, s, ev);
 }
 
-#define K1U_LAUNCH(kernel_, ...) hipLaunchKernelGGL((kernel_<__VA_ARGS__ K1U_M>), dim3(p.L / K1U_M, n_rx), dim3(256), 0, s, p)
+#define K1U_LAUNCH(kernel_, ...) hipLaunchKernelGGL((kernel_<__VA_ARGS__ K1U_M>), dim3(p.L / K1U_M, n_rx), dim3(K1U_T), 0, s, p)
 #define K1U_COMMA ,
 
 hipError_t launch_k1u(const K1uParams& p, int npost, int n_rx, hipStream_t s) {

@@ -1,10 +1,10 @@
 #!/bin/bash
 # rocprofv3 kernel stats of one configuration of the library: tools/prof_path.sh OUTNAME "<python kwargs of gpu.AisGpu>" [steps] [R]
 # e.g. tools/prof_path.sh base_dec "model=gpu.MODEL_BASE, gpu_decode=True"     (RATE=6000000 in the environment: another sample rate;
-# DISTINCT=1: the bench's batch of distinct receivers instead of 256 copies of one stream; LIB=path: another build of libaisgpu.so)
+# BLOCK=196608: another block length; DISTINCT=1: the bench's batch of distinct receivers instead of 256 copies of one stream; LIB=path: another build of libaisgpu.so)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-R=$PWD; OUT=$1; KW=$2; STEPS=${3:-12}; NRX=${4:-256}; RATE=${RATE:-1536000}; DISTINCT=${DISTINCT:-0}
+R=$PWD; OUT=$1; KW=$2; STEPS=${3:-12}; NRX=${4:-256}; RATE=${RATE:-1536000}; DISTINCT=${DISTINCT:-0}; BLOCK=${BLOCK:-786432}
 rm -rf /tmp/prof_$OUT
 cat > /tmp/prof_$OUT.py <<PY
 import sys
@@ -12,7 +12,7 @@ sys.path.insert(0, "$R")
 import numpy as np, torch, _pkg
 _pkg.load()
 from ais_catcher_amd import gpu, synth, workload
-B = 786432
+B = $BLOCK
 if $DISTINCT:
     data = workload.resident_batch(torch, $NRX, 2, sample_rate=$RATE)
 else:
