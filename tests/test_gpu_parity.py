@@ -538,6 +538,54 @@ def test_config3_6msps_challenger_nmea():
     m.close()
 
 
+@pytest.mark.parametrize("env", [{"AISGPU_US_ON_DS": "0"}, {"AISGPU_FM_ON_S1": "0"}, {"AISGPU_US_ON_DS": "0", "AISGPU_FM_ON_S1": "0"},
+                                 {"AISGPU_FRONT_LOW_PRIO": "0"}, {"AISGPU_SERIAL": "1"}])
+def test_config3_stream_placements(env, monkeypatch):
+    """The 6 MSPS ladder's kernels can sit on the streams in several ways (resampler front end behind the pass over the input or on
+    the downstream stream with the previous flush's second half deferred behind it; FM branch behind the derotation / FIR kernel or in
+    front of PhaseSearch; front stream of lower or equal queue priority; everything on one stream): the messages are the checker's in
+    every one, also across the drain at the end of the stream (the deferred second half)."""
+    from ais_catcher_amd import host
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    block, nblocks = 786432, 5
+    x = synth.receiver_stream(block * nblocks, sample_rate=6000000, receiver_id=62, type5_every=5)
+    chk = checkers.Ref(model=4, rate=6000000) if checkers.have_ref() else checkers.Oracle(model=4, rate=6000000)
+    chk.feed_blocks(x, block)
+    host.reset_sequence()
+    m = host.ModelChallengerGPU(sample_rate=6000000, block_len=block)
+    for b in range(nblocks):
+        m.receive(x[b * block:(b + 1) * block])
+    assert len(chk.nmea()) >= 4
+    assert m.nmea() == chk.nmea()
+    m.close()
+
+
+def test_challenger_fm_branch_on_the_phase_search_stream(monkeypatch):
+    """ModelChallenger at 1536 kSPS with the FM branch in front of PhaseSearch on its stream (the resampled ladders' default)."""
+    from ais_catcher_amd import host
+    monkeypatch.setenv("AISGPU_FM_ON_S1", "1")
+    block, nblocks = 131072, 8
+    x = synth.receiver_stream(block * nblocks, receiver_id=63, gap_slots=(1, 2), type5_every=4)
+    chk = checkers.Ref(model=4) if checkers.have_ref() else checkers.Oracle(model=4)
+    chk.feed_blocks(x, block)
+    host.reset_sequence()
+    m = host.ModelChallengerGPU(block_len=block)
+    for b in range(nblocks):
+        m.receive(x[b * block:(b + 1) * block])
+    assert m.nmea() == chk.nmea() and len(chk.nmea()) >= 4
+    m.close()
+
+
+@pytest.mark.parametrize("rate,block", [(288000, 49152), (96000, 1024 * 24)])
+def test_cf32_input_through_the_converted_copy(rate, block, monkeypatch):
+    """The ladders without a pass at the input rate read CF32 rows in place and keep each block's tail (x_direct); option x_direct = 0
+    sends CF32 through the converted copy the integer formats use.  Same outputs, bit for bit, over several blocks (the kept tail)."""
+    monkeypatch.setenv("AISGPU_X_DIRECT", "0")
+    x = synth.receiver_stream(block * 6, sample_rate=rate, receiver_id=64)
+    _run_outputs_vs_oracle([x], rate, "cf32", block, 6)
+
+
 def test_fft_bin_magnitude_matches_hypot_restatement():
     """The FFT-bin magnitude routine (double sqrt without the denormal rescaling) against the glibc-equivalent
     hypotf restatement on 16M inputs: random bit patterns over the exponent range IQ data can reach, IQ-like
