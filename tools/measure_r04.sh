@@ -9,6 +9,7 @@ python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err   
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_steps20.json 2>/dev/null   # the driver's command shape
 python bench.py --config 2 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > gpurun_out/${TAG}_bench_config2.json 2>/dev/null
 python bench.py --config 3 --steps 20 --warmup 5 --cpu-seconds 10 > gpurun_out/${TAG}_bench_config3.json 2>/dev/null
+python bench.py --config 3 --no-cpu-baseline --no-pmc > gpurun_out/${TAG}_bench_config3_steps100.json 2>/dev/null   # configs[2] at the default 100 steps
 python bench.py --gpu-decode --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_gpu_decode.json 2>/dev/null
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o res -- python $R/bench.py --no-cpu-baseline --no-pmc > $R/gpurun_out/prof_bench.log 2>&1)
 DB=$(find gpurun_out/prof_bench -name "*.db" | head -1)
