@@ -744,6 +744,8 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 			// Its scratch set was last read by the tasks of block f-2: this block's FM receiver has waited for them (above).
 			K7bParams& kb = h->k7b[pb];
 			kb.k = k7;
+			// (with the FM receiver on s4 too -- base_fm_on_ds -- the pass queues behind it there; on s1, in front of its block's tasks, it
+			// costs 256 distinct receivers 0.15 ms per step: measured, not kept)
 			HIPCHK(hipEventRecord(h->ev_sym[pb], h->ds));
 			WAITEV(h->s4, h->ev_sym[pb]);
 			HIPCHK(launch_k7b_spec(kb, h->s4));
@@ -1079,7 +1081,7 @@ const char* aisgpu_last_error(aisgpu_t* h) { return h ? h->err.c_str() : ""; }
 
 int aisgpu_set_option(const char* key, const char* value) {
 	if (!key || !*key) return AISGPU_ERR_ARG;
-	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "fm_on_s1", "us_on_ds", "front_low_prio", "x_direct", "trace", "k7e_stats", "k7b_stats" };
+	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "fm_on_s1", "us_on_ds", "front_low_prio", "x_direct", "base_fm_on_ds", "trace", "k7e_stats", "k7b_stats" };
 	bool ok = false;
 	for (const char* k : known) ok = ok || strcmp(k, key) == 0;
 	if (!ok) return AISGPU_ERR_ARG;
@@ -1305,7 +1307,9 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		h->s2 = h->s1; // apply + FIR + PhaseSearchEMA of a block run back to back on one stream
 		h->dec_defer = h->s5 == h->s4 && h->s4 != h->stream;
 	}
-	h->ds = (!h->serial && h->mode == MODE_RESAMPLE && h->KP > 0) ? h->s4 : h->stream;
+	// ModelBase / ModelStandard (round 4, late): the FM receiver leaves the front stream as well -- front end 0.34 + FM receiver 0.10 ms
+	// one behind the other WERE these engines' step (0.467 ms; with the decoders on the device 0.497), whatever the decoders cost
+	h->ds = (!h->serial && ((h->mode == MODE_RESAMPLE && h->KP > 0) || (h->base && opt_int("base_fm_on_ds", 1) != 0))) ? h->s4 : h->stream;
 	for (int i = 0; i < NBUF; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_pre[i], hipEventDisableTiming));
 	HIPCHK(hipEventCreateWithFlags(&h->ev_fm, hipEventDisableTiming));
 	h->fm_on_s1 = !h->serial && opt_int("fm_on_s1", h->mode == MODE_RESAMPLE ? 1 : 0) != 0;
