@@ -192,7 +192,7 @@ struct aisgpu {
 	float* d_fm = nullptr; float* d_fmhist[2] = {}; uint32_t* d_fmbits[2] = {}; uint32_t* h_fmbits = nullptr; // ModelChallenger FM branch
 	float* d_fmfir = nullptr; // [n_chan][L] Filter(Receiver) output of the last downstream block (AISGPU_FLAG_TAPS)
 	EmaState* d_ema[2] = {}; // state before / after the current downstream block (swapped per block)
-	uint32_t* d_pswords = nullptr; uint32_t* d_pscwords = nullptr; float *d_psma0 = nullptr, *d_psma1 = nullptr; unsigned* d_psfin = nullptr; int* d_psflag = nullptr;
+	uint32_t* d_pswords = nullptr; float *d_psma0 = nullptr, *d_psma1 = nullptr; unsigned* d_psfin = nullptr; int* d_psflag = nullptr;
 	int ps_warm = 256; bool ps_parallel = true;
 	struct { bool valid = false; int pb = 0, lv = 0, n_groups = 0; long long g0 = 0; unsigned block = 0, sub = 0; } dpend; // frame decoders not yet enqueued (dec_defer)
 	bool dec_defer = false; // the frame decoders of block f are enqueued behind the derotation / FIR kernel of block f+1 (they share its stream)
@@ -493,7 +493,7 @@ int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned
 	K4Params k4;
 	k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[lv]; k4.bits_stride = h->words;
 	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
-	k4.words = h->d_pswords; k4.cwords = h->d_pscwords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.fb_count = h->d_psflag + 2;
+	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.fb_count = h->d_psflag + 2;
 	k4.n_chains = h->n_chains; k4.n_groups = n_groups;
 	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
 	k4.box_in = h->d_box[pb]; k4.box_out = h->d_box[pb ^ 1]; k4.first_group = g0;
@@ -1528,7 +1528,6 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	if (opt_int("ps_sequential", 0)) h->ps_parallel = false; // test hook: the plain sequential row kernel
 	const size_t n_ma = C * 5 * ps_chunks * 16;
 	HIPCHK(dalloc(&h->d_pswords, C * 5 * ps_chunks * (PS_CHUNK / 32) * 16));
-	HIPCHK(dalloc(&h->d_pscwords, C * 5 * ps_chunks * (PS_CHUNK / 32)));
 	HIPCHK(dalloc(&h->d_psma0, n_ma));
 	HIPCHK(dalloc(&h->d_psma1, n_ma));
 	HIPCHK(dalloc(&h->d_psfin, C * 5 * ps_chunks * 16));
@@ -1620,7 +1619,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_fmprev[0]); hipFree(h->d_fmprev[1]);
 	hipFree(h->d_cgf); hipFree(h->d_omega); hipFree(h->d_step);
 	hipFree(h->d_rotstate); hipFree(h->d_firtap); hipFree(h->d_ppmtab);
-	hipFree(h->d_pswords); hipFree(h->d_pscwords); hipFree(h->d_psma0); hipFree(h->d_psma1); hipFree(h->d_psfin); hipFree(h->d_psflag);
+	hipFree(h->d_pswords); hipFree(h->d_psma0); hipFree(h->d_psma1); hipFree(h->d_psfin); hipFree(h->d_psflag);
 	for (int i = 0; i < 2; i++) { if (h->h_in[i]) hipHostFree(h->h_in[i]); if (h->ev_h2d[i]) hipEventDestroy(h->ev_h2d[i]); if (h->ev_in_free[i]) hipEventDestroy(h->ev_in_free[i]); }
 	if (h->sc) { hipStreamSynchronize(h->sc); hipStreamDestroy(h->sc); }
 	if (h->h_bits) hipHostFree(h->h_bits);

@@ -164,8 +164,7 @@ struct K4Params {
 	const EmaState* state_in;                // state before this block
 	EmaState* state_out;                     // state after this block
 	// chunk-parallel scratch, all indexed [chain][chunk][...]
-	uint32_t* words;   // [PS_CHUNK/32][16] output words per possible start index, up to the word from which all sixteen agree
-	uint32_t* cwords;  // [PS_CHUNK/32] the words from there on (fin bits 16..21: that word's index; 63: none)
+	uint32_t* words;   // [PS_CHUNK/32][16] output words per possible start index
 	float* ma_start;   // [16] EMA after the warm-up (speculative), chunk > 0
 	float* ma_fin;     // [16] EMA at the end of the chunk
 	unsigned* fin;     // [16] low 4 bits: final max_idx per start index; bits 4..7: last four decisions of hypothesis k

@@ -1818,7 +1818,7 @@ __global__ __launch_bounds__(64) void k4_box_chunks(K4Params p) {
 	if (live) {
 		p.ma_fin[slot * 16 + k] = 0.0f;
 		if (chunk > 0) p.ma_start[slot * 16 + k] = 0.0f;
-		p.fin[slot * 16 + k] = (unsigned)(idx & 15) | ((bits & 0xffu) << 4) | (63u << 16); // (no common words: every trajectory's words are kept)
+		p.fin[slot * 16 + k] = (unsigned)(idx & 15) | ((bits & 0xffu) << 4);
 		if (chunk == p.n_chunks - 1) { // the block's final float state (max_idx: k4_assemble)
 			PsBoxState* sto = p.box_out + chain;
 #pragma unroll
@@ -1902,21 +1902,7 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 	stash(0);
 	if (nsb > 1) fetch(1);
 
-	const unsigned woff = (unsigned)slot * (PS_CHUNK / 32) * 16 + k; // (element offsets: the addresses are formed at the stores, once per 32 symbols -- the kernel lives on 64 registers)
-	// The sixteen trajectories of a row differ in max_idx alone and coalesce within a few symbols: from the first word boundary at
-	// which all sixteen hold the same index their words are the same for good.  Up to there every trajectory's words are kept
-	// ([word][16], as before), behind it ONE word per 32 symbols (cwords: 128 contiguous bytes per chunk) -- 0.2 KB instead of 2 KB
-	// per (chain, chunk), 26 MB of writes per step that the assembling kernel read back (writes cost this chain three times what
-	// reads do).  fin carries the first common word's index.
-	int first_common = PS_CHUNK / 32 + 1; // (> any word index: not yet)
-	const auto flush = [&](int wi, uint32_t w) {
-		if (wi < first_common) {
-			if (live) p.words[woff + wi * 16] = w;
-			const int i0 = __builtin_amdgcn_update_dpp(0, idx, 0x150, 0xF, 0xF, false); // row_share:0 -- the row's first trajectory
-			const unsigned long long same = __ballot(idx == i0);
-			if (((same >> rowbase) & 0xFFFFull) == 0xFFFFull) first_common = wi + 1;
-		} else if (k == 0 && live) p.cwords[(woff >> 4) + wi] = w;
-	};
+	uint32_t* wout = p.words + slot * (PS_CHUNK / 32) * 16 + k;
 	uint32_t word = 0;
 #pragma unroll 1
 	for (int sb = 0; sb < nsb; sb++) {
@@ -1951,7 +1937,7 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 				// (a last, partial batch never completes a word -- the write behind the loop is the one that stores it;
 				// flushed here as well it was overwritten by an empty word whenever n % 32 was 25 .. 31)
 				if (((q + PS_BATCH) & 31) == 0 && g + PS_BATCH <= g1) {
-					flush(q >> 5, word);
+					if (live) wout[(q >> 5) * 16] = word;
 					word = 0;
 				}
 			}
@@ -1962,12 +1948,12 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 		}
 	}
 	const int n = g1 - g0;
-	if ((n & 31) != 0) flush(n >> 5, word);
+	if ((n & 31) != 0 && live) wout[(n >> 5) * 16] = word;
 	if (live) {
 		p.ma_fin[slot * 16 + k] = ma.y;
 		const unsigned dec = (unsigned)((hs.h1 >> lane) & 1ull) | ((unsigned)((hs.h2 >> lane) & 1ull) << 1) |
 		                     ((unsigned)((hs.h3 >> lane) & 1ull) << 2) | ((unsigned)((hs.h4 >> lane) & 1ull) << 3);
-		p.fin[slot * 16 + k] = (unsigned)(idx & 15) | (dec << 4) | ((unsigned)first_common << 16);
+		p.fin[slot * 16 + k] = (unsigned)(idx & 15) | (dec << 4);
 	}
 }
 
@@ -2050,10 +2036,8 @@ __global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
 			const int n = (g0 + PS_CHUNK < p.n_groups ? PS_CHUNK : p.n_groups - g0);
 			const int nw = (n + 31) >> 5;
 			const uint32_t* w = p.words + (base + c) * (PS_CHUNK / 32) * 16 + st_e[e];
-			const uint32_t* cw = p.cwords + (base + c) * (PS_CHUNK / 32);
-			const int fc = (int)((f[e] >> 16) & 63u); // first word that all sixteen trajectories share (the same in every lane)
 #pragma unroll
-			for (int q = 0; q < WPL; q++) { const int i = k + 16 * q; wv[e][q] = i < nw ? (i < fc ? w[i * 16] : cw[i]) : 0u; }
+			for (int q = 0; q < WPL; q++) { const int i = k + 16 * q; wv[e][q] = i < nw ? w[i * 16] : 0u; }
 		}
 #pragma unroll
 		for (int e = 0; e < AS; e++) {
@@ -2069,7 +2053,7 @@ __global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
 	}
 	const size_t last = base + (p.n_chunks - 1);
 	sto->ma[k] = p.ma_fin[last * 16 + k];
-	sto->bits[k] = (fin_last >> 4) & 0xffu;
+	sto->bits[k] = fin_last >> 4;
 	if (k == 0) { sto->max_idx = start; sto->rot = (st->rot + p.n_groups) & 3; }
 	if (p.box_out && k == 0) p.box_out[chain].max_idx = start; // boxcar variant: its own state block
 	// A speculative warm-up that did not reproduce the sequential EMA anywhere in the wave's four chains: the wave itself recomputes
