@@ -1753,6 +1753,7 @@ int aisgpu_run(aisgpu_t* h) {
 		kp.tiles_per_block = h->ptiles_per_block; kp.tiles_per_span = h->ptiles_per_span;
 		kp.alpha = 0; kp.beta = 1; kp.has_fdc = 0;
 		kp.pre_out = h->KPa ? h->d_xmid : xcur + h->xh; kp.pre_stride = h->KPa ? n_mid : xstride;
+		if (h->mode == MODE_RESAMPLE && h->challenger) kp.pre_extra_lds = 10240; // eight workgroups of the pass per CU instead of ten (kernels.hip, launch_k1_dpp_kf)
 		int rc = time_begin(); if (rc) return rc;
 		HIPCHK(launch_k1(kp, KP1, h->kfmt, h->pspans, R, h->stream));
 		rc = time_end(); if (rc) return rc;

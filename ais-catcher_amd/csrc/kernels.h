@@ -23,6 +23,7 @@ struct K1Params {
 	int stream_start;        // != 0: first block of the stream (only the fixed-point ladder needs to know)
 	float2* pre_out;         // != nullptr: pre-decimation pass, write the level after K stages here ([n_rx][pre_stride])
 	long long pre_stride;
+	int pre_extra_lds = 0;   // pre-decimation pass: unused dynamic LDS per workgroup that caps its workgroups per CU (0: the default, ten)
 	// spectral analysis at the end of every span (k1_dpp only): fft_windows = tiles_per_span / 16 windows per channel, 0 = off
 	int fft_windows, n_windows, wide;
 	const float2* omega;     // [512] FFT twiddles

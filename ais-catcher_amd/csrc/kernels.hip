@@ -3770,14 +3770,16 @@ struct K1Events { hipEvent_t start = nullptr, stop = nullptr; };
 // CU's LDS.  The resampler front end of the previous block (256 threads, 6.6 KB of LDS per workgroup), which runs beside it on the
 // downstream stream, then only gets LDS as fast as workgroups of the pass retire (0.39 instead of 0.09 ms, BASELINE configs[2]).
 // Unused dynamic LDS brings the pass to ten workgroups per CU: 60 KB stay free for the kernels behind the 48 kHz channels, which all
-// run beside the next block's pass (12 per CU, like the main front end: 2 % slower per step; 8: no better).
+// run beside the next block's pass (12 per CU, like the main front end: 2 % slower per step; 8: no better).  Late in round 4, with the
+// resampler front end on the downstream stream: ModelChallenger's 6 MSPS ladder (BASELINE configs[2]), whose back end is the largest,
+// gains 1.5 - 3 % with eight per CU (K1Params::pre_extra_lds = 10240), the other ladders lose 0 - 10 % with eight or seven.
 #ifndef K1_PRE_EXTRA_LDS
 #define K1_PRE_EXTRA_LDS 6400
 #endif
 
 template <int K, int FMT>
 static hipError_t launch_k1_dpp_kf(const K1Params& p, int spans, int n_rx, hipStream_t s, const K1Events& ev) {
-	if (p.pre_out != nullptr) K1_LAUNCH_LDS((k1_dpp<K, FMT, true>), ev, dim3(spans, n_rx), s, p, K1_PRE_EXTRA_LDS);
+	if (p.pre_out != nullptr) K1_LAUNCH_LDS((k1_dpp<K, FMT, true>), ev, dim3(spans, n_rx), s, p, (p.pre_extra_lds > 0 ? p.pre_extra_lds : K1_PRE_EXTRA_LDS));
 	else K1_LAUNCH((k1_dpp<K, FMT, false>), ev, dim3(spans, n_rx), s, p);
 	return hipGetLastError();
 }
