@@ -245,6 +245,7 @@ struct aisgpu {
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
 	bool us_on_ds = false; // resampled ladders: the resampler front end on the downstream stream, the second half of a flush one flush late (option "us_on_ds")
+	bool fm_in_k6 = false; // ModelChallenger, fused back end: Demod::FM + Filter(Receiver) inside k6_window_fir (option "fm_in_k6", default on)
 	bool fm_on_s1 = false, fm_ev_used = false; hipEvent_t ev_fm = nullptr; // ModelChallenger's FM branch in front of PhaseSearch on s1 (option "fm_on_s1"; default: the resampled ladders)
 	bool fused = false; // derotation + FIR + ScatterPLL as one kernel behind the checkpointed phasor recurrence (the default)
 	struct { bool valid = false; int q = 0, pb = 0, lv = 0, n_groups = 0, n_rel0 = 0, S = 0; long long g0 = 0; unsigned block = 0, sub = 0; } fpend;
@@ -624,7 +625,12 @@ int enqueue_fused_back(aisgpu_t* h) {
 	WAITEV(h->s4, h->ev_phasor[q]);
 	WAITEV(h->s4, h->ev_sym[pb]); // sym[pb] was last read by PhaseSearch of block f-2,
 	WAITEV(h->s4, h->ev_ema[lv]); // lvl[lv] by the frame decoder / the copies of block f-4
-	if (h->challenger) { k6.cgf = h->d_cgf + CGF_HIST; k6.cgf_stride = CGF_HIST + h->L; }
+	if (h->challenger && h->fm_in_k6) { // the FM branch inside the derotation / FIR kernel: bits out, no derotated samples in HBM
+		k6.fmbits = h->d_fmbits[pb]; k6.fmbits_stride = h->L / 32;
+		memcpy(k6.fm_taps, TAPS_RECEIVER, sizeof k6.fm_taps);
+	} else if (h->challenger) { k6.cgf = h->d_cgf + CGF_HIST; k6.cgf_stride = CGF_HIST + h->L; }
+	// (the previous block's FM branch / regrouping kernel on s1 reads what this launch overwrites: the derotated samples, or -- with the
+	// FM branch inside the kernel -- the FM bits of the block before, which the regrouping of the previous block reads as its "previous")
 	if (h->challenger && h->fm_on_s1 && h->fm_ev_used) WAITEV(h->s4, h->ev_fm); // the derotated samples of the previous block: read by its FM branch, on s1
 	{
 		K2Params k2r = make_k2(h, q);
@@ -639,6 +645,13 @@ int enqueue_fused_back(aisgpu_t* h) {
 	// the step (BASELINE configs[2]); s1 has the time.
 	hipStream_t fs = h->fm_on_s1 ? h->s1 : h->s4;
 	if (h->challenger && h->fm_on_s1) { HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4)); WAITEV(h->s1, h->ev_k3[pb]); }
+	if (h->challenger && h->fm_in_k6) {
+		if (h->gpu_decode) { // device decoders: the FM bits regrouped per decoder, where this and the previous block's bits are in order
+			WAITEV(fs, h->ev_ema[lv ^ 2]); // fmrows[pb] was last read by the decoders of block f-2
+			HIPCHK(launch_k7_pack(make_k7(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub), fs));
+			if (h->fm_on_s1) { HIPCHK(hipEventRecord(h->ev_fm, h->s1)); h->fm_ev_used = true; }
+		}
+	} else
 	if (h->challenger) { // FM branch on the derotated samples the kernel above stored on its way (Model.cpp:638-639)
 		K5Params k5;
 		k5.x = h->d_cgf; k5.x_stride = CGF_HIST + h->L; k5.x_off = CGF_HIST;
@@ -1081,7 +1094,7 @@ const char* aisgpu_last_error(aisgpu_t* h) { return h ? h->err.c_str() : ""; }
 
 int aisgpu_set_option(const char* key, const char* value) {
 	if (!key || !*key) return AISGPU_ERR_ARG;
-	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "fm_on_s1", "us_on_ds", "front_low_prio", "x_direct", "base_fm_on_ds", "trace", "k7e_stats", "k7b_stats" };
+	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "fm_on_s1", "fm_in_k6", "pre_extra_lds", "us_on_ds", "front_low_prio", "x_direct", "base_fm_on_ds", "trace", "k7e_stats", "k7b_stats" };
 	bool ok = false;
 	for (const char* k : known) ok = ok || strcmp(k, key) == 0;
 	if (!ok) return AISGPU_ERR_ARG;
@@ -1475,6 +1488,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	// (round 4: also ModelChallenger on the resampled ladders -- BASELINE configs[2], 6 MSPS: with the lanes-over-time derotation / FIR
 	// kernel 0.558 -> 0.538 ms per step; with round 3's lane-per-chain kernel it had been 0.70 against 0.53)
 	h->fused = !(cfg->flags & AISGPU_FLAG_TAPS) && !h->base && !h->v2 && opt_int("fused", 1) != 0;
+	h->fm_in_k6 = h->challenger && h->fused && opt_int("fm_in_k6", 1) != 0;
 	h->us_on_ds = !h->serial && h->fused && h->mode == MODE_RESAMPLE && h->ds != h->stream && opt_int("us_on_ds", 1) != 0;
 	// The spectral analysis rides at the end of the front-end waves (k1_fft_tail) when every span is a whole number of 512-sample
 	// windows of the 48 kHz channels (16 tiles each) and whole spans make up the block; the automatic span length is rounded up
@@ -1753,7 +1767,7 @@ int aisgpu_run(aisgpu_t* h) {
 		kp.tiles_per_block = h->ptiles_per_block; kp.tiles_per_span = h->ptiles_per_span;
 		kp.alpha = 0; kp.beta = 1; kp.has_fdc = 0;
 		kp.pre_out = h->KPa ? h->d_xmid : xcur + h->xh; kp.pre_stride = h->KPa ? n_mid : xstride;
-		if (h->mode == MODE_RESAMPLE && h->challenger) kp.pre_extra_lds = 10240; // eight workgroups of the pass per CU instead of ten (kernels.hip, launch_k1_dpp_kf)
+		kp.pre_extra_lds = opt_int("pre_extra_lds", 0); // (test hook: workgroups of the pass per CU through its unused dynamic LDS; 0 = the default, ten) // eight workgroups of the pass per CU instead of ten (kernels.hip, launch_k1_dpp_kf)
 		int rc = time_begin(); if (rc) return rc;
 		HIPCHK(launch_k1(kp, KP1, h->kfmt, h->pspans, R, h->stream));
 		rc = time_end(); if (rc) return rc;

@@ -106,7 +106,8 @@ struct K2Params {
 // Fused derotation + FilterComplex(Coherent) + ScatterPLL (k6_window_fir): one wave = one chain x one 512-sample window, lanes over
 // time.  The recurrence kernel leaves its state every CK_SEG samples of every window, so lane i restarts it for its own nine
 // samples: the derotated window goes through LDS, the lanes then own one ScatterPLL group each.
-constexpr int DF_HIST = 24; // derotated samples carried from block to block (17-tap history + a partial group)
+constexpr int FM_HIST = 36; // discriminator values in front of a block / window that the 37-tap Receiver filter reaches back to
+constexpr int DF_HIST = 40; // derotated samples carried from block to block (17-tap history + a partial group: 20; the FM branch inside k6_window_fir: 37)
 constexpr int CK_SEG = 9, CK_USED = 57, CK_SLOTS = 64; // 56 segments of nine samples and one of eight per window
 struct K6Params {
 	const float2* c48; long long c48_stride;
@@ -115,7 +116,8 @@ struct K6Params {
 	const float2* hist_in; float2* hist_out;     // [n_chan][DF_HIST]
 	float2* sym; long long sym_stride;           // SymRow layout, sym_stride = group capacity (also the row pitch of lvl)
 	float* lvl;                                   // [n_chan][sym_stride]
-	float2* cgf = nullptr; long long cgf_stride = 0; // optional: sample n of the derotated stream at cgf[chan * cgf_stride + n] (ModelChallenger's FM branch)
+	float2* cgf = nullptr; long long cgf_stride = 0; // optional: sample n of the derotated stream at cgf[chan * cgf_stride + n] (ModelChallenger's FM branch as kernels of its own)
+	uint32_t* fmbits = nullptr; long long fmbits_stride = 0; float fm_taps[37] = {}; // optional: ModelChallenger's FM branch inside the kernel -- sign of the filtered discriminator, [n_chan][L / 32]
 	float taps[17];
 	long long first_group;
 	int n_rel0;                                   // first_group * 5 - first_sample48, in [-4, 0]
@@ -312,7 +314,6 @@ struct K5Params { // ModelChallenger FM branch (Model.cpp:638-639): Demod::FM ->
 	int L;
 	float* fir_out; long long fir_stride;     // optional [n_chan][fir_stride]: the filter output itself (AISGPU_FLAG_TAPS)
 };
-constexpr int FM_HIST = 36;
 
 hipError_t launch_k5(const K5Params& p, int n_chan, hipStream_t s);
 

@@ -1338,14 +1338,24 @@ __device__ __forceinline__ c2 pk_sub_add(c2 a, c2 b) { // (a.x - b.x, a.y + b.y)
 	return r;
 }
 
-constexpr int K6_HALO = 3 * CK_SEG - 1; // derotated samples in front of the window: segments 54..56 of the previous one (26; 20 are needed)
+constexpr int K6_HL = 5;                    // segments of the previous window derotated again as the window's halo
+constexpr int K6_HALO = K6_HL * CK_SEG - 1; // = 44 samples: segments 52..56 (the FIR needs 20; the FM branch 37: 36 of the Receiver filter + Demod::FM's prev)
+static_assert(DF_HIST <= K6_HALO && DF_HIST >= FM_HIST + 1, "k6_window_fir: the carried tail is the first window's halo");
 #ifndef K6_WAVES
 #define K6_WAVES 8
 #endif
-// CGF: the derotated samples are stored as well (ModelChallenger: its FM branch demodulates them, Model.cpp:638-639)
-template <bool CGF>
+__device__ __forceinline__ float atan2f_ref(float y, float x);
+// CGF: the derotated samples are stored as well (ModelChallenger with the FM branch as kernels of its own: k5_fm_filter demodulates them,
+// Model.cpp:638-639).  FM (round 4, late): ModelChallenger's FM branch inside this kernel -- Demod::FM (Demod.cpp:27-37) and
+// Filter(Receiver) (DSP.h:257-263) on the derotated window while it sits in LDS, the signs out as bits: the derotated samples never
+// reach HBM (100 MB out, 100 MB in per step of 256 receivers) and k5_fm_filter's launch is gone.  Every value is k5_fm_filter's: the
+// discriminator of sample n from samples n and n - 1, the 37-tap sum left to right; the 36 discriminator values in front of the window
+// are computed again from the halo (in a block's first window: from the carried tail, whose first samples are zero before the stream
+// starts -- atan2f(+0, +0) / pi = 0, the filter's zero history).
+template <bool CGF, bool FM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6_WAVES))) void k6_window_fir(K6Params p) {
 	__shared__ __attribute__((aligned(16))) float2 ybuf[K6_HALO + 512 + 6];
+	__shared__ float s_fm[FM ? FM_HIST + 512 : 1];
 	const int lane = threadIdx.x;
 	const int W = p.n_windows;
 	// id = (((chain / 64) W + w) 8 + chain % 8) 8 + (chain / 8) % 8: the XCD (id % 8) depends on the chain alone, a chain's windows are
@@ -1355,9 +1365,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6
 	const float2* xrow = p.c48 + (size_t)chain * p.c48_stride;
 	// ---- derotation: lane -> segment (lanes 0..2: the previous window's last three)
 	{
-		const int seg = lane - 3;
+		const int seg = lane - K6_HL;
 		const int ws = seg >= 0 ? w : w - 1, si = seg >= 0 ? seg : CK_USED + seg;
-		if (lane < CK_USED + 3 && ws >= 0) {
+		if (lane < CK_USED + K6_HL && ws >= 0) {
 			const int n0 = ws * 512 + si * CK_SEG;
 			const float2 r0 = p.ck[((size_t)ws * CK_SLOTS + si) * p.ck_stride + chain];
 			const float2 stp = p.step_table[p.fz[(size_t)chain * W + ws] + 205];
@@ -1383,6 +1393,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6
 		for (int q = 0; q < 8; q++) out[q * 64 + lane] = ybuf[K6_HALO + q * 64 + lane];
 	}
 	if (w == W - 1 && lane < DF_HIST) p.hist_out[(size_t)chain * DF_HIST + lane] = ybuf[K6_HALO + 512 - DF_HIST + lane];
+	if constexpr (FM) {
+		// discriminator value i = sample (i - FM_HIST) of the window: data[i] * std::conj(prev) -> atan2f / pi, as in k5_fm_filter
+		for (int i = lane; i < FM_HIST + 512; i += 64) {
+			const float2 d = ybuf[K6_HALO - FM_HIST + i], pv = ybuf[K6_HALO - FM_HIST + i - 1];
+			const float npi = -pv.y;
+			const float re = d.x * pv.x - d.y * npi;
+			const float im = d.x * npi + d.y * pv.x;
+			s_fm[i] = __fdiv_rn(atan2f_ref(im, re), 3.14159265358979323846f);
+		}
+		__syncthreads(); // (one wave: ordering)
+		uint32_t* o = p.fmbits + (size_t)chain * p.fmbits_stride + w * 16;
+#pragma unroll 1
+		for (int q = 0; q < 8; q++) {
+			float acc = 0.0f;
+#pragma unroll
+			for (int i = 0; i < 37; i++) acc += p.fm_taps[i] * s_fm[q * 64 + lane + i]; // x += taps[i] * *data++ (DSP.h:257-263)
+			const unsigned long long b = __ballot(acc > 0);
+			if (lane == 0) { o[2 * q] = (uint32_t)b; o[2 * q + 1] = (uint32_t)(b >> 32); }
+		}
+	}
 	// ---- FIR + ScatterPLL: block-local group gl covers samples n_rel0 + 5 gl .. + 4
 	const int g_lo = (w * 512 - p.n_rel0) / 5;                                              // ceil((512 w - 4 - n_rel0) / 5), numerator + 4 >= 0
 	const int g_end = w == W - 1 ? p.n_groups : min(p.n_groups, ((w + 1) * 512 - p.n_rel0) / 5);
@@ -3772,7 +3802,8 @@ struct K1Events { hipEvent_t start = nullptr, stop = nullptr; };
 // Unused dynamic LDS brings the pass to ten workgroups per CU: 60 KB stay free for the kernels behind the 48 kHz channels, which all
 // run beside the next block's pass (12 per CU, like the main front end: 2 % slower per step; 8: no better).  Late in round 4, with the
 // resampler front end on the downstream stream: ModelChallenger's 6 MSPS ladder (BASELINE configs[2]), whose back end is the largest,
-// gains 1.5 - 3 % with eight per CU (K1Params::pre_extra_lds = 10240), the other ladders lose 0 - 10 % with eight or seven.
+// gained 1.5 - 3 % with eight per CU (K1Params::pre_extra_lds = 10240) while its FM branch was a kernel of its own; with that branch
+// inside k6_window_fir eight, ten and seven are within 1 % of each other; the other ladders lose 0 - 10 % with eight or seven.  Ten.
 #ifndef K1_PRE_EXTRA_LDS
 #define K1_PRE_EXTRA_LDS 6400
 #endif
@@ -3917,8 +3948,9 @@ hipError_t launch_k2b_refine(const K2Params& p, int n_chan, hipStream_t s) {
 
 hipError_t launch_k6(const K6Params& p, hipStream_t s) {
 	const dim3 grid((unsigned)((p.n_chan + 63) / 64 * 64 * p.n_windows));
-	if (p.cgf) hipLaunchKernelGGL(k6_window_fir<true>, grid, dim3(64), 0, s, p);
-	else hipLaunchKernelGGL(k6_window_fir<false>, grid, dim3(64), 0, s, p);
+	if (p.fmbits) hipLaunchKernelGGL((k6_window_fir<false, true>), grid, dim3(64), 0, s, p);
+	else if (p.cgf) hipLaunchKernelGGL((k6_window_fir<true, false>), grid, dim3(64), 0, s, p);
+	else hipLaunchKernelGGL((k6_window_fir<false, false>), grid, dim3(64), 0, s, p);
 	return hipGetLastError();
 }
 

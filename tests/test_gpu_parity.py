@@ -561,6 +561,41 @@ def test_config3_stream_placements(env, monkeypatch):
     m.close()
 
 
+@pytest.mark.parametrize("env", [{"AISGPU_FM_IN_K6": "0"}, {"AISGPU_FM_IN_K6": "0", "AISGPU_FM_ON_S1": "1"}, {"AISGPU_FM_IN_K6": "1", "AISGPU_FM_ON_S1": "1"}])
+def test_challenger_fm_branch_placements(env, monkeypatch):
+    """ModelChallenger's FM branch inside the derotation / FIR kernel (the default) or as kernels of its own on the stored derotated
+    samples, on either stream: the FM decisions of every sample and the NMEA of the twenty decoders (host and device) are the checker's,
+    over eight blocks (the carried tail of 40 derotated samples / the discriminator history of the separate kernels)."""
+    from ais_catcher_amd import host
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    block, nblocks = 131072, 8
+    x = synth.receiver_stream(block * nblocks, receiver_id=65, gap_slots=(1, 2), type5_every=4)
+    chk = checkers.Ref(model=4, taps=True) if checkers.have_ref() else checkers.Oracle(model=4, taps=True)
+    chk.feed_blocks(x, block)
+    L = block // 32
+    g = gpu.AisGpu(n_receivers=1, block_len=block, model=gpu.MODEL_CHALLENGER)
+    for b in range(nblocks):
+        g.submit(0, x[b * block:(b + 1) * block])
+        g.run()
+        g.sync_outputs()
+        for ch in range(2):
+            out = g.fetch(0, ch)
+            for j in range(5):
+                f = chk.bits(ch, j, 1)[0]
+                N = np.arange(b * L, (b + 1) * L)
+                sel = N[N % 5 == j]
+                assert np.array_equal(out["fm_bits"][sel - b * L], (f[sel // 5] > 0).astype(np.uint8)), "fm blk %d ch %d j %d" % (b, ch, j)
+    g.close()
+    for dec in (False, True):
+        host.reset_sequence()
+        m = host.ModelChallengerGPU(block_len=block, gpu_decode=dec) if dec else host.ModelChallengerGPU(block_len=block)
+        for b in range(nblocks):
+            m.receive(x[b * block:(b + 1) * block])
+        assert m.nmea() == chk.nmea() and len(chk.nmea()) >= 4
+        m.close()
+
+
 def test_challenger_fm_branch_on_the_phase_search_stream(monkeypatch):
     """ModelChallenger at 1536 kSPS with the FM branch in front of PhaseSearch on its stream (the resampled ladders' default)."""
     from ais_catcher_amd import host

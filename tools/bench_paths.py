@@ -113,7 +113,7 @@ if __name__ == "__main__":
     run("ModelDefault 288k CF32 (decimate-by-3 front end K1k)", R * 4, 288000, 49152 * 4)
     run("ModelDefault 2400k CF32 (resampled into 3072k)", R // 2, 2400000, B // 2)
     run("ModelDefault mode X 96k CF32 (single channel K1x)", R * 16, 96000, 1024 * 48, mode_x=True)
-    run("ModelChallenger 1536k CF32 (fused back end storing the derotated samples + FM receiver)", R, 1536000, B, model=gpu.MODEL_CHALLENGER)
+    run("ModelChallenger 1536k CF32 (fused back end, FM branch inside the derotation / FIR kernel)", R, 1536000, B, model=gpu.MODEL_CHALLENGER)
     run("ModelChallenger 1536k CF32, twenty decoders on the device", R, 1536000, B, model=gpu.MODEL_CHALLENGER, gpu_decode=True)
     run("ModelChallenger 6 MSPS CF32 (BASELINE configs[2])", R, 6000000, B, model=gpu.MODEL_CHALLENGER)
     run("ModelBase 1536k CF32 (front end + FM receiver, signs out)", R, 1536000, B, model=gpu.MODEL_BASE)
