@@ -222,6 +222,7 @@ void aisgpu_timing(aisgpu_t* h, int enable);
  *   "fused"         0: the materialised back end (phasor / derotated-sample arrays in HBM: what AISGPU_FLAG_TAPS uses)
  *   "fft_in_k1"     0: the spectral analysis as FFT + search kernels instead of inside the front-end waves
  *   "fm_in_k6"      0: ModelChallenger's FM branch as kernels of its own on the stored derotated samples (default: inside the derotation / FIR kernel)
+ *   "pre_extra_lds" bytes of unused dynamic LDS per workgroup of the pre-decimation pass (caps its workgroups per CU; 0: the default)
  *   "fm_on_s1"      0 / 1: ModelChallenger's FM branch behind the derotation / FIR kernel, or in front of PhaseSearch on its stream
  *   "base_fm_on_ds" 0: ModelBase / ModelStandard: the FM receiver on the front stream behind the front end (default: the downstream stream)
  *   "x_direct"      0: 288 kSPS-family / 96 kSPS ladders: CF32 input through a converted copy like the other formats (default: read in place)
