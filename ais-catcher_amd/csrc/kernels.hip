@@ -1353,7 +1353,7 @@ __device__ __forceinline__ float atan2f_ref(float y, float x);
 // are computed again from the halo (in a block's first window: from the carried tail, whose first samples are zero before the stream
 // starts -- atan2f(+0, +0) / pi = 0, the filter's zero history).
 template <bool CGF, bool FM>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6_WAVES))) void k6_window_fir(K6Params p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FM ? 6 : K6_WAVES, FM ? 6 : K6_WAVES))) void k6_window_fir(K6Params p) { // (the FM form needs 73 registers: six waves per SIMD)
 	__shared__ __attribute__((aligned(16))) float2 ybuf[K6_HALO + 512 + 6];
 	__shared__ float s_fm[FM ? FM_HIST + 512 : 1];
 	const int lane = threadIdx.x;
