@@ -612,6 +612,15 @@ def test_challenger_fm_branch_on_the_phase_search_stream(monkeypatch):
     m.close()
 
 
+@pytest.mark.parametrize("rate,block,nblocks", [(6000000, 786432, 14), (2400000, 393216, 14), (250000, 49152, 20)])
+def test_resampled_ladders_over_many_blocks(rate, block, nblocks):
+    """The resampled ladders keep rings -- six pre-decimated input blocks, eight sets of resampler tables, two sets of everything behind
+    the 48 kHz channels, the second half of a flush deferred behind the next flush's resampler front end: a run long enough for every
+    ring to wrap more than once; hard bits, levels and ppm of every downstream block against the oracle."""
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=66, gap_slots=(0, 2))
+    _run_outputs_vs_oracle([x], rate, "cf32", block, nblocks)
+
+
 @pytest.mark.parametrize("rate,block", [(288000, 49152), (96000, 1024 * 24)])
 def test_cf32_input_through_the_converted_copy(rate, block, monkeypatch):
     """The ladders without a pass at the input rate read CF32 rows in place and keep each block's tail (x_direct); option x_direct = 0
