@@ -245,7 +245,6 @@ struct aisgpu {
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
 	bool us_on_ds = false; // resampled ladders: the resampler front end on the downstream stream, the second half of a flush one flush late (option "us_on_ds")
-	bool fm_in_k6 = false; // ModelChallenger, fused back end: Demod::FM + Filter(Receiver) inside k6_window_fir (option "fm_in_k6", default on)
 	bool fm_on_s1 = false, fm_ev_used = false; hipEvent_t ev_fm = nullptr; // ModelChallenger's FM branch in front of PhaseSearch on s1 (option "fm_on_s1"; default: the resampled ladders)
 	bool fused = false; // derotation + FIR + ScatterPLL as one kernel behind the checkpointed phasor recurrence (the default)
 	struct { bool valid = false; int q = 0, pb = 0, lv = 0, n_groups = 0, n_rel0 = 0, S = 0; long long g0 = 0; unsigned block = 0, sub = 0; } fpend;
@@ -625,13 +624,12 @@ int enqueue_fused_back(aisgpu_t* h) {
 	WAITEV(h->s4, h->ev_phasor[q]);
 	WAITEV(h->s4, h->ev_sym[pb]); // sym[pb] was last read by PhaseSearch of block f-2,
 	WAITEV(h->s4, h->ev_ema[lv]); // lvl[lv] by the frame decoder / the copies of block f-4
-	if (h->challenger && h->fm_in_k6) { // the FM branch inside the derotation / FIR kernel: bits out, no derotated samples in HBM
+	if (h->challenger) { // ModelChallenger: the FM branch inside the derotation / FIR kernel (Demod::FM + Filter(Receiver)): bits out, no derotated samples in HBM
 		k6.fmbits = h->d_fmbits[pb]; k6.fmbits_stride = h->L / 32;
 		memcpy(k6.fm_taps, TAPS_RECEIVER, sizeof k6.fm_taps);
-	} else if (h->challenger) { k6.cgf = h->d_cgf + CGF_HIST; k6.cgf_stride = CGF_HIST + h->L; }
-	// (the previous block's FM branch / regrouping kernel on s1 reads what this launch overwrites: the derotated samples, or -- with the
-	// FM branch inside the kernel -- the FM bits of the block before, which the regrouping of the previous block reads as its "previous")
-	if (h->challenger && h->fm_on_s1 && h->fm_ev_used) WAITEV(h->s4, h->ev_fm); // the derotated samples of the previous block: read by its FM branch, on s1
+	}
+	// (the previous block's regrouping kernel on s1 reads what this launch overwrites: the FM bits of the block before, its "previous")
+	if (h->challenger && h->fm_on_s1 && h->fm_ev_used) WAITEV(h->s4, h->ev_fm);
 	{
 		K2Params k2r = make_k2(h, q);
 		k2r.ck = h->d_ck[q]; k2r.ck_stride = k6.ck_stride;
@@ -640,32 +638,14 @@ int enqueue_fused_back(aisgpu_t* h) {
 	}
 	{ TraceScope t(h, "derotfir", h->s4); HIPCHK(launch_k6(k6, h->s4)); }
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s4));
-	// Where the FM branch runs: behind the derotation / FIR kernel on s4, or (fm_on_s1) in front of PhaseSearch on s1.  On the resampled
-	// ladders s4 also carries the spectral analysis and, with the recurrence on s3 in the middle of its chain, is the stream that sets
-	// the step (BASELINE configs[2]); s1 has the time.
+	// Where the device decoders' regrouping of the FM bits runs: behind the derotation / FIR kernel on s4, or (fm_on_s1) in front of
+	// PhaseSearch on s1.  On the resampled ladders s4 also carries the spectral analysis and, with the recurrence on s3 in the middle of
+	// its chain, is the stream that sets the step (BASELINE configs[2]); s1 has the time.
 	hipStream_t fs = h->fm_on_s1 ? h->s1 : h->s4;
 	if (h->challenger && h->fm_on_s1) { HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4)); WAITEV(h->s1, h->ev_k3[pb]); }
-	if (h->challenger && h->fm_in_k6) {
-		if (h->gpu_decode) { // device decoders: the FM bits regrouped per decoder, where this and the previous block's bits are in order
-			WAITEV(fs, h->ev_ema[lv ^ 2]); // fmrows[pb] was last read by the decoders of block f-2
-			HIPCHK(launch_k7_pack(make_k7(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub), fs));
-			if (h->fm_on_s1) { HIPCHK(hipEventRecord(h->ev_fm, h->s1)); h->fm_ev_used = true; }
-		}
-	} else
-	if (h->challenger) { // FM branch on the derotated samples the kernel above stored on its way (Model.cpp:638-639)
-		K5Params k5;
-		k5.x = h->d_cgf; k5.x_stride = CGF_HIST + h->L; k5.x_off = CGF_HIST;
-		k5.prev_in = h->d_fmprev[pb]; k5.prev_out = h->d_fmprev[pb ^ 1]; // (the rows carry no history here: the sample before the block)
-		k5.fm = nullptr; k5.fm_stride = 0;
-		k5.hist_in = h->d_fmhist[pb]; k5.hist_out = h->d_fmhist[pb ^ 1];
-		k5.fmbits = h->d_fmbits[pb]; k5.fmbits_stride = h->L / 32; k5.L = h->L;
-		k5.fir_out = nullptr; k5.fir_stride = 0;
-		memcpy(k5.taps, TAPS_RECEIVER, sizeof k5.taps);
-		HIPCHK(launch_k5(k5, h->n_chan, fs));
-		if (h->gpu_decode) { // device decoders: the FM bits regrouped per decoder, here, where this and the previous block's bits are in order
-			WAITEV(fs, h->ev_ema[lv ^ 2]); // fmrows[pb] was last read by the decoders of block f-2
-			HIPCHK(launch_k7_pack(make_k7(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub), fs));
-		}
+	if (h->challenger && h->gpu_decode) { // device decoders: the FM bits regrouped per decoder, where this and the previous block's bits are in order
+		WAITEV(fs, h->ev_ema[lv ^ 2]); // fmrows[pb] was last read by the decoders of block f-2
+		HIPCHK(launch_k7_pack(make_k7(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub), fs));
 		if (h->fm_on_s1) { HIPCHK(hipEventRecord(h->ev_fm, h->s1)); h->fm_ev_used = true; }
 	}
 	if (!(h->challenger && h->fm_on_s1)) HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4));
@@ -1052,6 +1032,11 @@ int stage_resample_run(aisgpu_t* h, long long run, int* n_flush_out) {
 		w.cv.wait(l, [&] { return w.produced_runs > run; });
 		n_flush = w.nflush[run % UsWorker::NRUN];
 	}
+	// The table ring (USR slots, staged one run ahead) and the output slots (MAXSUB per input block) are sized for at most MAXSUB
+	// flushes per run -- every ratio aisgpu_create() accepts stays below (increment >= 1/4): refuse anything else instead of reusing
+	// a slot whose tables are still unread.
+	static_assert(aisgpu::USR >= 2 * MAXSUB, "resampler table ring: two runs of MAXSUB flushes each");
+	if (n_flush > MAXSUB) { h->err = "resampler: more downstream blocks per input block than the table ring holds"; return AISGPU_ERR_STATE; }
 	for (int i = 0; i < n_flush; i++) {
 		const long long k = w.copied_flush; // (only this thread writes it)
 		const int slot = (int)(k % aisgpu::USR);
@@ -1094,7 +1079,7 @@ const char* aisgpu_last_error(aisgpu_t* h) { return h ? h->err.c_str() : ""; }
 
 int aisgpu_set_option(const char* key, const char* value) {
 	if (!key || !*key) return AISGPU_ERR_ARG;
-	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "fm_on_s1", "fm_in_k6", "pre_extra_lds", "us_on_ds", "front_low_prio", "x_direct", "base_fm_on_ds", "trace", "k7e_stats", "k7b_stats" };
+	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "trace", "k7e_stats", "k7b_stats" };
 	bool ok = false;
 	for (const char* k : known) ok = ok || strcmp(k, key) == 0;
 	if (!ok) return AISGPU_ERR_ARG;
@@ -1297,7 +1282,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			std::vector<uint32_t> lat(words, 0u), rest(words, 0u);
 			for (int i = 0; i < n_cu; i++) (i < reserve ? lat : rest)[i / 32] |= 1u << (i % 32);
 			int least = 0, greatest = 0;
-			const bool prio = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest && opt_int("front_low_prio", 1) != 0;
+			const bool prio = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest; // (the front stream at the lowest queue priority: the dispatcher prefers the back end's workgroups whenever a slot frees up)
 			// (a runtime without CU masks falls back to ordinary streams: same results, the recurrence just shares its SIMDs)
 						masked = (prio ? hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, least) : hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)words, rest.data())) == hipSuccess;
 			masked = masked && hipExtStreamCreateWithCUMask(&h->s1, (uint32_t)words, rest.data()) == hipSuccess;
@@ -1322,10 +1307,10 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	}
 	// ModelBase / ModelStandard (round 4, late): the FM receiver leaves the front stream as well -- front end 0.34 + FM receiver 0.10 ms
 	// one behind the other WERE these engines' step (0.467 ms; with the decoders on the device 0.497), whatever the decoders cost
-	h->ds = (!h->serial && ((h->mode == MODE_RESAMPLE && h->KP > 0) || (h->base && opt_int("base_fm_on_ds", 1) != 0))) ? h->s4 : h->stream;
+	h->ds = (!h->serial && ((h->mode == MODE_RESAMPLE && h->KP > 0) || h->base)) ? h->s4 : h->stream;
 	for (int i = 0; i < NBUF; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_pre[i], hipEventDisableTiming));
 	HIPCHK(hipEventCreateWithFlags(&h->ev_fm, hipEventDisableTiming));
-	h->fm_on_s1 = !h->serial && opt_int("fm_on_s1", h->mode == MODE_RESAMPLE ? 1 : 0) != 0;
+	h->fm_on_s1 = !h->serial && h->mode == MODE_RESAMPLE; // ModelChallenger's FM bits regrouped in front of PhaseSearch on ITS stream where s4 carries the analysis too (resampled ladders)
 	for (int i = 0; i < NBUF; i++) {
 		HIPCHK(hipEventCreateWithFlags(&h->ev_front[i], hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&h->ev_phasor[i], hipEventDisableTiming));
@@ -1378,7 +1363,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		}
 	}
 	if (KP > 0 || mode == MODE_DSK || mode == MODE_RESAMPLE || mode == MODE_96K) {
-		h->x_direct = KP == 0 && (mode == MODE_DSK || mode == MODE_96K) && h->kfmt == 0 && !h->ma_m && h->xh <= h->n_pre && opt_int("x_direct", 1) != 0;
+		h->x_direct = KP == 0 && (mode == MODE_DSK || mode == MODE_96K) && h->kfmt == 0 && !h->ma_m && h->xh <= h->n_pre;
 		if (h->x_direct) for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_xhist[i], R * (size_t)h->xh)); // zero = silence before the stream
 		const int nx = h->x_direct ? 0 : mode == MODE_RESAMPLE ? XR : (mode == MODE_DSK || mode == MODE_96K) ? 2 : 1;
 		for (int i = 0; i < nx; i++) HIPCHK(dalloc(&h->d_xpre[i], R * ((size_t)h->xh + h->n_pre)));
@@ -1414,6 +1399,11 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		// ModelEngineV2 (4): six decoders per channel inside the engine kernel (kv2_engine): tone gate, derotation, trackers, decoders
 		h->dec_kind = cfg->model == AISGPU_MODEL_STANDARD ? 1 : cfg->model == AISGPU_MODEL_CHALLENGER ? 2 : cfg->model == AISGPU_MODEL_BASE ? 3 : cfg->model == AISGPU_MODEL_V2 ? 4 : 0;
 		if (h->dec_kind == 4) {
+			// std::polar in V2::FreqOffset::Derotate is the HOST's sinf / cosf in the reference; the device restates glibc 2.35's FMA variant.
+			// Where the host's libm computes anything else (another libm, a CPU without FMA) the engine on the device would silently differ
+			// from the reference on this host in the last bit of a phasor: refuse instead (the host-engine path has no such dependency).
+			static const bool libm_ok = sincos_restatement_matches_host_libm(); // (3.6 M arguments, once per process)
+			if (!libm_ok) { h->err = "AISGPU_FLAG_GPU_DECODE with ModelEngineV2: the host's sinf / cosf differ from the device's restatement (glibc 2.35, FMA variant); run the engine on the host (without the flag)"; return AISGPU_ERR_ARG; }
 			std::vector<V2ChanState> init(C);
 			memset(init.data(), 0, C * sizeof(V2ChanState));
 			for (size_t i = 0; i < C; i++) init[i].rot = make_float2(1.0f, 0.0f); // FreqOffset::rot (V2Engine.h:34)
@@ -1488,8 +1478,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	// (round 4: also ModelChallenger on the resampled ladders -- BASELINE configs[2], 6 MSPS: with the lanes-over-time derotation / FIR
 	// kernel 0.558 -> 0.538 ms per step; with round 3's lane-per-chain kernel it had been 0.70 against 0.53)
 	h->fused = !(cfg->flags & AISGPU_FLAG_TAPS) && !h->base && !h->v2 && opt_int("fused", 1) != 0;
-	h->fm_in_k6 = h->challenger && h->fused && opt_int("fm_in_k6", 1) != 0;
-	h->us_on_ds = !h->serial && h->fused && h->mode == MODE_RESAMPLE && h->ds != h->stream && opt_int("us_on_ds", 1) != 0;
+	h->us_on_ds = !h->serial && h->fused && h->mode == MODE_RESAMPLE && h->ds != h->stream;
 	// The spectral analysis rides at the end of the front-end waves (k1_fft_tail) when every span is a whole number of 512-sample
 	// windows of the 48 kHz channels (16 tiles each) and whole spans make up the block; the automatic span length is rounded up
 	// to such a value, an explicit one (cfg.tiles_per_span) is taken as it is.  Option "fft_in_k1" = 0 (test hook): the FFT / search kernels.
@@ -1511,20 +1500,22 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		for (int i = 0; i < NBUF; i++) HIPCHK(dalloc(&h->d_ck[i], (C + 63) / 64 * 64 * (size_t)h->W * CK_SLOTS)); // phasor checkpoints per (window, slot, chain)
 		for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_dfhist[i], C * DF_HIST)); // zero = silence before the stream
 	}
+	// the FFT magnitudes and the per-sample phasors exist only on the materialised path (taps, option fused = 0): 0.6 GB per 256 receivers
+	const bool materialised = !h->fused && !h->base && !h->v2;
 	for (int i = 0; i < NBUF; i++) {
-		HIPCHK(dalloc(&h->d_magT[i], (C * h->W + 63) / 64 * (size_t)(512 * 64)));
+		if (materialised) HIPCHK(dalloc(&h->d_magT[i], (C * h->W + 63) / 64 * (size_t)(512 * 64)));
 		HIPCHK(dalloc(&h->d_c48[i], C * h->c48s + 64)); // + over-read slack of the fused FIR kernel's last segment
 		HIPCHK(dalloc(&h->d_fz[i], C * h->W));
 		HIPCHK(dalloc(&h->d_ppm[i], C * h->W));
-		HIPCHK(dalloc(&h->d_rotT[i], (size_t)h->L * ((C + 63) / 64 * 64)));
+		if (materialised) HIPCHK(dalloc(&h->d_rotT[i], (size_t)h->L * ((C + 63) / 64 * 64)));
 	}
 	for (int i = 0; i < 4; i++) { HIPCHK(dalloc(&h->d_lvl[i], C * h->Gcap)); HIPCHK(dalloc(&h->d_bits[i], C * 5 * h->words)); }
 	for (int i = 0; i < 2; i++) {
 		HIPCHK(dalloc(&h->d_sym[i], sym_elems((int)C, h->Gcap))); // SymRow layout (kernels.h): channels padded to 64
 		HIPCHK(dalloc(&h->d_ema[i], C * 5));
 	}
-	HIPCHK(dalloc(&h->d_cgf, C * (CGF_HIST + h->L)));
-	if (h->base || (h->challenger && h->fused)) for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmprev[i], C)); // Demod::FM::prev = 0 (Demod.h)
+	if (!h->fused) HIPCHK(dalloc(&h->d_cgf, C * (CGF_HIST + h->L))); // (the materialised path only: the fused back end keeps the derotated samples on chip)
+	if (h->base) for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmprev[i], C)); // Demod::FM::prev = 0 (Demod.h)
 	if (h->challenger || h->base) {
 		if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_fm, C * (FM_HIST + h->L))); // (the discriminator output is a tap only)
 		for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmhist[i], C * FM_HIST)); // zero: DSP::Filter starts on zeros
@@ -1548,16 +1539,21 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	HIPCHK(dalloc(&h->d_psflag, 4));
 	if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_firtap, C * (8 + h->L)));
 	if (h->v2) {
-		HIPCHK(hipHostMalloc((void**)&h->h_c48, 2 * MAXSUB * C * h->L * sizeof(float2), hipHostMallocDefault)); // (two sets of slots: see out_set)
+		// With the engine on the device (AISGPU_FLAG_GPU_DECODE) nothing but frames goes to the host: no pinned slots for the channels,
+		// the estimates, the energies or the discriminator signs (several GB at 2,048 receivers), and aisgpu_fetch_sub() returns NULL for them.
+		const bool v2_host = !h->gpu_decode;
+		if (v2_host) HIPCHK(hipHostMalloc((void**)&h->h_c48, 2 * MAXSUB * C * h->L * sizeof(float2), hipHostMallocDefault)); // (two sets of slots: see out_set)
 		if (h->v2_assist) {
 			HIPCHK(dalloc(&h->d_v2hist, C * V2_HIST));
 			HIPCHK(dalloc(&h->d_v2f, C * 2 * h->W)); HIPCHK(dalloc(&h->d_v2prom, C * 2 * h->W)); HIPCHK(dalloc(&h->d_v2en, C * (h->W + 1)));
-			HIPCHK(hipHostMalloc((void**)&h->h_v2f, 2 * MAXSUB * C * 2 * h->W * sizeof(float), hipHostMallocDefault));
-			HIPCHK(hipHostMalloc((void**)&h->h_v2prom, 2 * MAXSUB * C * 2 * h->W * sizeof(float), hipHostMallocDefault));
-			HIPCHK(hipHostMalloc((void**)&h->h_v2en, 2 * MAXSUB * C * (h->W + 1) * sizeof(float), hipHostMallocDefault));
+			if (v2_host) {
+				HIPCHK(hipHostMalloc((void**)&h->h_v2f, 2 * MAXSUB * C * 2 * h->W * sizeof(float), hipHostMallocDefault));
+				HIPCHK(hipHostMalloc((void**)&h->h_v2prom, 2 * MAXSUB * C * 2 * h->W * sizeof(float), hipHostMallocDefault));
+				HIPCHK(hipHostMalloc((void**)&h->h_v2en, 2 * MAXSUB * C * (h->W + 1) * sizeof(float), hipHostMallocDefault));
+			}
 			HIPCHK(dalloc(&h->d_fm, C * (FM_HIST + h->L)));
 			for (int i = 0; i < 2; i++) HIPCHK(dalloc(&h->d_fmbits[i], C * (h->L / 32)));
-			HIPCHK(hipHostMalloc((void**)&h->h_fmbits, 2 * MAXSUB * C * (h->L / 32) * sizeof(uint32_t), hipHostMallocDefault));
+			if (v2_host) HIPCHK(hipHostMalloc((void**)&h->h_fmbits, 2 * MAXSUB * C * (h->L / 32) * sizeof(uint32_t), hipHostMallocDefault));
 			if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_fmfir, C * (size_t)h->L));
 			// FMDemod::prev: the engine decodes an all-zero block first (its look-back before the stream, V2Engine.cpp:275-279), which
 			// leaves prev = 0 -- not the 1 + 0j of the constructor (V2Engine.h:84) -- in front of the first real sample
@@ -1767,7 +1763,6 @@ int aisgpu_run(aisgpu_t* h) {
 		kp.tiles_per_block = h->ptiles_per_block; kp.tiles_per_span = h->ptiles_per_span;
 		kp.alpha = 0; kp.beta = 1; kp.has_fdc = 0;
 		kp.pre_out = h->KPa ? h->d_xmid : xcur + h->xh; kp.pre_stride = h->KPa ? n_mid : xstride;
-		kp.pre_extra_lds = opt_int("pre_extra_lds", 0); // (test hook: workgroups of the pass per CU through its unused dynamic LDS; 0 = the default, ten) // eight workgroups of the pass per CU instead of ten (kernels.hip, launch_k1_dpp_kf)
 		int rc = time_begin(); if (rc) return rc;
 		HIPCHK(launch_k1(kp, KP1, h->kfmt, h->pspans, R, h->stream));
 		rc = time_end(); if (rc) return rc;
@@ -2053,9 +2048,10 @@ int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* o) {
 	o->group_window = nullptr;
 	o->first_sample48 = so.first48;
 	const size_t vslot = h->v2 ? oslot : (size_t)sub; // (ModelEngineV2's outputs are copied inside aisgpu_run(): two sets of slots)
-	o->fm_bits = (h->challenger || h->base || (h->v2 && h->v2_assist)) ? h->h_fmbits + vslot * C * (h->L / 32) + chan * (h->L / 32) : nullptr;
-	o->c48 = h->v2 ? (const float*)(h->h_c48 + (vslot * C + chan) * h->L) : nullptr;
-	const bool va = h->v2 && h->v2_assist;
+	// (ModelEngineV2 with the engine on the device: none of these was copied -- or allocated -- on the host side)
+	o->fm_bits = ((h->challenger || h->base || (h->v2 && h->v2_assist)) && h->h_fmbits) ? h->h_fmbits + vslot * C * (h->L / 32) + chan * (h->L / 32) : nullptr;
+	o->c48 = (h->v2 && h->h_c48) ? (const float*)(h->h_c48 + (vslot * C + chan) * h->L) : nullptr;
+	const bool va = h->v2 && h->v2_assist && h->h_v2f;
 	o->v2_f = va ? h->h_v2f + (vslot * C + chan) * 2 * h->W : nullptr;
 	o->v2_prom = va ? h->h_v2prom + (vslot * C + chan) * 2 * h->W : nullptr;
 	o->v2_energy = va ? h->h_v2en + (vslot * C + chan) * (h->W + 1) : nullptr;

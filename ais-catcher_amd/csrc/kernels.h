@@ -23,7 +23,6 @@ struct K1Params {
 	int stream_start;        // != 0: first block of the stream (only the fixed-point ladder needs to know)
 	float2* pre_out;         // != nullptr: pre-decimation pass, write the level after K stages here ([n_rx][pre_stride])
 	long long pre_stride;
-	int pre_extra_lds = 0;   // pre-decimation pass: unused dynamic LDS per workgroup that caps its workgroups per CU (0: the default, ten)
 	// spectral analysis at the end of every span (k1_dpp only): fft_windows = tiles_per_span / 16 windows per channel, 0 = off
 	int fft_windows, n_windows, wide;
 	const float2* omega;     // [512] FFT twiddles
@@ -116,7 +115,6 @@ struct K6Params {
 	const float2* hist_in; float2* hist_out;     // [n_chan][DF_HIST]
 	float2* sym; long long sym_stride;           // SymRow layout, sym_stride = group capacity (also the row pitch of lvl)
 	float* lvl;                                   // [n_chan][sym_stride]
-	float2* cgf = nullptr; long long cgf_stride = 0; // optional: sample n of the derotated stream at cgf[chan * cgf_stride + n] (ModelChallenger's FM branch as kernels of its own)
 	uint32_t* fmbits = nullptr; long long fmbits_stride = 0; float fm_taps[37] = {}; // optional: ModelChallenger's FM branch inside the kernel -- sign of the filtered discriminator, [n_chan][L / 32]
 	float taps[17];
 	long long first_group;
@@ -365,6 +363,7 @@ struct KV2EParams {
 	int* locked_estimates;     // statistics: Estimate() calls at a learned slot phase (the windows the assist kernels cannot know)
 	float taps17[17];
 };
+bool sincos_restatement_matches_host_libm(); // kv2_engine's sinf / cosf (glibc 2.35, FMA variant) on the host against the host's own libm
 hipError_t launch_kv2(const KV2Params& p, hipStream_t s, const KV2EParams* engine = nullptr); // engine: kv2_engine runs before the look-back is overwritten
 hipError_t launch_k4(const K4Params& p, hipStream_t s);          // chunk-parallel + assemble (with the exact sequential search where a speculative warm-up failed)
 hipError_t launch_k4_sequential(const K4Params& p, hipStream_t s); // the plain sequential kernel only

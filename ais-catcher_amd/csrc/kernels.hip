@@ -1345,14 +1345,13 @@ static_assert(DF_HIST <= K6_HALO && DF_HIST >= FM_HIST + 1, "k6_window_fir: the 
 #define K6_WAVES 8
 #endif
 __device__ __forceinline__ float atan2f_ref(float y, float x);
-// CGF: the derotated samples are stored as well (ModelChallenger with the FM branch as kernels of its own: k5_fm_filter demodulates them,
-// Model.cpp:638-639).  FM (round 4, late): ModelChallenger's FM branch inside this kernel -- Demod::FM (Demod.cpp:27-37) and
+// FM (round 4, late): ModelChallenger's FM branch (Model.cpp:638-639) inside this kernel -- Demod::FM (Demod.cpp:27-37) and
 // Filter(Receiver) (DSP.h:257-263) on the derotated window while it sits in LDS, the signs out as bits: the derotated samples never
 // reach HBM (100 MB out, 100 MB in per step of 256 receivers) and k5_fm_filter's launch is gone.  Every value is k5_fm_filter's: the
 // discriminator of sample n from samples n and n - 1, the 37-tap sum left to right; the 36 discriminator values in front of the window
 // are computed again from the halo (in a block's first window: from the carried tail, whose first samples are zero before the stream
 // starts -- atan2f(+0, +0) / pi = 0, the filter's zero history).
-template <bool CGF, bool FM>
+template <bool FM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FM ? 6 : K6_WAVES, FM ? 6 : K6_WAVES))) void k6_window_fir(K6Params p) { // (the FM form needs 73 registers: six waves per SIMD)
 	__shared__ __attribute__((aligned(16))) float2 ybuf[K6_HALO + 512 + 6];
 	__shared__ float s_fm[FM ? FM_HIST + 512 : 1];
@@ -1387,11 +1386,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FM ? 6 : K6_
 		if (w == 0 && lane < DF_HIST) ybuf[K6_HALO - DF_HIST + lane] = p.hist_in[(size_t)chain * DF_HIST + lane]; // the previous block's tail
 	}
 	__syncthreads(); // (one wave: ordering)
-	if (CGF) {
-		float2* out = p.cgf + (size_t)chain * p.cgf_stride + (size_t)w * 512;
-#pragma unroll
-		for (int q = 0; q < 8; q++) out[q * 64 + lane] = ybuf[K6_HALO + q * 64 + lane];
-	}
 	if (w == W - 1 && lane < DF_HIST) p.hist_out[(size_t)chain * DF_HIST + lane] = ybuf[K6_HALO + 512 - DF_HIST + lane];
 	if constexpr (FM) {
 		// discriminator value i = sample (i - FM_HIST) of the window: data[i] * std::conj(prev) -> atan2f / pi, as in k5_fm_filter
@@ -2486,24 +2480,32 @@ __global__ __launch_bounds__(64) void k7_decode(K7Params p) {
 // variant glibc's ifunc selects on CPUs with FMA (every a * b + c fused): double-precision polynomials on the argument reduced by
 // multiples of pi / 2, the result rounded to float once.  Coefficients: __sincosf_table of the image's libm.so.6.  The CPU test
 // tests/test_sincosf.py checks the same restatement against the host libm on 2 x 10^7 inputs.
-__device__ __forceinline__ float sincosf_poly_ref(double x, double x2, bool neg, int n) {
+// (host + device: aisgpu_create() runs the same code on the host against the host's own sinf / cosf before it accepts the engine
+// on the device -- a host whose libm is not this one would otherwise diverge from the reference silently)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define V2_FMA(a, b, c) __fma_rn((a), (b), (c))
+#else
+#define V2_FMA(a, b, c) fma((a), (b), (c))
+#endif
+__host__ __device__ __forceinline__ unsigned v2_float_bits(float v) { unsigned u; memcpy(&u, &v, 4); return u; }
+__host__ __device__ __forceinline__ float sincosf_poly_ref(double x, double x2, bool neg, int n) {
 	const double sg = neg ? -1.0 : 1.0; // the second table entry: the cosine coefficients negated
 	if ((n & 1) == 0) {
 		const double x3 = x * x2;
-		const double s1 = __fma_rn(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+		const double s1 = V2_FMA(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
 		const double x7 = x3 * x2;
-		const double s = __fma_rn(x3, -0x1.555545995a603p-3, x);
-		return (float)__fma_rn(x7, s1, s);
+		const double s = V2_FMA(x3, -0x1.555545995a603p-3, x);
+		return (float)V2_FMA(x7, s1, s);
 	}
 	const double x4 = x2 * x2;
-	const double c2 = __fma_rn(x2, sg * 0x1.99343027bf8c3p-16, sg * -0x1.6c087e89a359dp-10);
-	const double c1 = __fma_rn(x2, sg * -0x1.ffffffd0c621cp-2, sg * 0x1p0);
+	const double c2 = V2_FMA(x2, sg * 0x1.99343027bf8c3p-16, sg * -0x1.6c087e89a359dp-10);
+	const double c1 = V2_FMA(x2, sg * -0x1.ffffffd0c621cp-2, sg * 0x1p0);
 	const double x6 = x4 * x2;
-	const double c = __fma_rn(x4, sg * 0x1.55553e1068f19p-5, c1);
-	return (float)__fma_rn(x6, c2, c);
+	const double c = V2_FMA(x4, sg * 0x1.55553e1068f19p-5, c1);
+	return (float)V2_FMA(x6, c2, c);
 }
-__device__ __forceinline__ float sin_or_cos_ref(float y, int iscos) {
-	const auto abstop12 = [](float v) { return (__float_as_uint(v) >> 20) & 0x7ffu; };
+__host__ __device__ __forceinline__ float sin_or_cos_ref(float y, int iscos) {
+	const auto abstop12 = [](float v) { return (v2_float_bits(v) >> 20) & 0x7ffu; };
 	double x = (double)y;
 	if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
 		if (abstop12(y) < abstop12(0x1p-12f)) return iscos ? 1.0f : y;
@@ -2511,9 +2513,20 @@ __device__ __forceinline__ float sin_or_cos_ref(float y, int iscos) {
 	}
 	const double r = x * 0x1.45F306DC9C883p+23;
 	const int n = ((int)r + 0x800000) >> 24;
-	x = __fma_rn(-(double)n, 0x1.921FB54442D18p0, x);
+	x = V2_FMA(-(double)n, 0x1.921FB54442D18p0, x);
 	const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
 	return sincosf_poly_ref(x * sgn, x * x, (n & 2) != 0, n ^ iscos);
+}
+// The restatement above against the host's libm on the arguments FreqOffset::Derotate can form (|f| <= 0.25 cycles per sample:
+// |theta| <= pi / 2) and beyond: every float of a 2^-20 grid over [-1.7, 1.7] and a sweep of small magnitudes; true = identical bits.
+bool sincos_restatement_matches_host_libm() {
+	for (int i = -1782580; i <= 1782580; i++) {
+		const float y = (float)i * 0x1p-20f;
+		if (v2_float_bits(sin_or_cos_ref(y, 0)) != v2_float_bits(sinf(y)) || v2_float_bits(sin_or_cos_ref(y, 1)) != v2_float_bits(cosf(y))) return false;
+	}
+	for (float y = 1.0f; y > 1e-30f; y *= 0.9990234375f)
+		if (v2_float_bits(sin_or_cos_ref(y, 0)) != v2_float_bits(sinf(y)) || v2_float_bits(sin_or_cos_ref(-y, 1)) != v2_float_bits(cosf(-y))) return false;
+	return true;
 }
 
 struct V2Lane { DecReg r; V2Tracker t; float pll_phase; int pll_last; };
@@ -2563,7 +2576,7 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 	__shared__ uint32_t fmw[V2E_NCH][16];
 	const KV2Params& p = q.k;
 	const int lane = threadIdx.x;
-	const int mesh = lane / 6, j = lane - 6 * mesh; // lanes 60..63 idle
+	const int mesh = lane < 6 * V2E_NCH ? lane / 6 : V2E_NCH - 1, j = lane - 6 * mesh; // lanes 60..63 idle (j = 6 .. 9, never live; their LDS reads stay inside the last channel's rows)
 	const int chan_raw = blockIdx.x * V2E_NCH + mesh;
 	const bool live = lane < 6 * V2E_NCH && chan_raw < p.n_chan;
 	const int chan = live ? chan_raw : p.n_chan - 1;
@@ -3726,8 +3739,9 @@ __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 	const uint32_t* brow = dc.row;
 	const int nw = (n + 31) >> 5;
 	const uint32_t wl = nw > 0 ? brow[nw - 1] : 0u, wp = nw > 1 ? brow[nw - 2] : 0u; // the last 33+ decisions
-	DecState carried;
-	if (live && busy) carried = slots[slot_].s; // the run that is still going: its state as k7e_sim left it
+	// the run that is still going: its state as k7e_sim left it becomes the decoder's state for the next block -- copied here, with the
+	// wave's other requests in flight, not held across the copy-out below (as a local it lived in 216 bytes of scratch per lane)
+	if (live && busy) *st = slots[slot_].s;
 	__shared__ uint32_t s_note[K7E_FOUND * 64][2];
 	{
 		int incl = nfound;
@@ -3764,7 +3778,7 @@ __global__ __launch_bounds__(64) void k7e_resolve(K7eParams q) {
 	// (ModelChallenger) tag.sample_lvl as the block leaves it for this channel's FM decoders of the next one
 	if (MESH == 10 && j == 0) p.last_lvl[dc.chan] = n > 0 ? p.lvl[(size_t)dc.chan * p.lvl_stride + n - 1] : p.last_lvl_in[dc.chan];
 	// state for the next block
-	if (busy) { *st = carried; return; }
+	if (busy) return;
 	// TRAINING: lastBit, prev and the alternations counted (those that end at the last symbol, none before the restart)
 	const auto dd_at = [&](int g) -> int {
 		if (g < 0) return prev0;
@@ -3802,15 +3816,15 @@ struct K1Events { hipEvent_t start = nullptr, stop = nullptr; };
 // Unused dynamic LDS brings the pass to ten workgroups per CU: 60 KB stay free for the kernels behind the 48 kHz channels, which all
 // run beside the next block's pass (12 per CU, like the main front end: 2 % slower per step; 8: no better).  Late in round 4, with the
 // resampler front end on the downstream stream: ModelChallenger's 6 MSPS ladder (BASELINE configs[2]), whose back end is the largest,
-// gained 1.5 - 3 % with eight per CU (K1Params::pre_extra_lds = 10240) while its FM branch was a kernel of its own; with that branch
-// inside k6_window_fir eight, ten and seven are within 1 % of each other; the other ladders lose 0 - 10 % with eight or seven.  Ten.
+// gained 1.5 - 3 % with eight per CU while its FM branch was a kernel of its own; with that branch inside k6_window_fir eight, ten
+// and seven are within 1 % of each other; the other ladders lose 0 - 10 % with eight or seven.  Ten.
 #ifndef K1_PRE_EXTRA_LDS
 #define K1_PRE_EXTRA_LDS 6400
 #endif
 
 template <int K, int FMT>
 static hipError_t launch_k1_dpp_kf(const K1Params& p, int spans, int n_rx, hipStream_t s, const K1Events& ev) {
-	if (p.pre_out != nullptr) K1_LAUNCH_LDS((k1_dpp<K, FMT, true>), ev, dim3(spans, n_rx), s, p, (p.pre_extra_lds > 0 ? p.pre_extra_lds : K1_PRE_EXTRA_LDS));
+	if (p.pre_out != nullptr) K1_LAUNCH_LDS((k1_dpp<K, FMT, true>), ev, dim3(spans, n_rx), s, p, K1_PRE_EXTRA_LDS);
 	else K1_LAUNCH((k1_dpp<K, FMT, false>), ev, dim3(spans, n_rx), s, p);
 	return hipGetLastError();
 }
@@ -3948,9 +3962,8 @@ hipError_t launch_k2b_refine(const K2Params& p, int n_chan, hipStream_t s) {
 
 hipError_t launch_k6(const K6Params& p, hipStream_t s) {
 	const dim3 grid((unsigned)((p.n_chan + 63) / 64 * 64 * p.n_windows));
-	if (p.fmbits) hipLaunchKernelGGL((k6_window_fir<false, true>), grid, dim3(64), 0, s, p);
-	else if (p.cgf) hipLaunchKernelGGL((k6_window_fir<true, false>), grid, dim3(64), 0, s, p);
-	else hipLaunchKernelGGL((k6_window_fir<false, false>), grid, dim3(64), 0, s, p);
+	if (p.fmbits) hipLaunchKernelGGL((k6_window_fir<true>), grid, dim3(64), 0, s, p);
+	else hipLaunchKernelGGL((k6_window_fir<false>), grid, dim3(64), 0, s, p);
 	return hipGetLastError();
 }
 

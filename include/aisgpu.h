@@ -70,8 +70,11 @@ extern "C" {
                                    * and ModelBase (DSP::SimplePLL + one decoder with its feedback loop, DSP.cpp:28-57, Model.cpp:428-435).
                                    * ModelEngineV2 (round 4): the whole V2::Engine per channel -- tone gate / slot lock, Derotate, FilterFL17, five
                                    * PhaseTrackers, BitPLL, six decoders, slot-phase learner (V2Engine.cpp:293-388) -- runs on the device, strictly in the
-                                   * reference's order per channel; the 48 kHz channels are NOT copied to the host (aisgpu_out.c48 stays empty), frames come
-                                   * back (NMEA text, tag.ppm and tag.level equal the reference's bit for bit; std::polar = glibc's sinf / cosf restated) */
+                                   * reference's order per channel; nothing but frames goes to the host: aisgpu_out.c48, v2_f, v2_prom, v2_energy and fm_bits are
+                                   * NULL (no pinned host slots are allocated for them), frames come back (NMEA text, tag.ppm and tag.level equal the
+                                   * reference's bit for bit; std::polar = glibc 2.35's sinf / cosf restated in the FMA variant its ifunc selects on x86-64
+                                   * hosts with FMA: aisgpu_create() checks the restatement against the host's own sinf / cosf and refuses the flag for
+                                   * this model with AISGPU_ERR_ARG where they differ -- see INTEGRATION.md) */
 #define AISGPU_FLAG_FP_DS 32  /* KEY_SETTING_FP_DS (`-go FP_DS on`, `-F`): 1536 kSPS CU8 input goes through the fixed-point ladder
                                * Downsample16_CU8 (DSP/DSP.cpp:499-651, Model.cpp:231-237); ignored at other rates like in the reference */
 #define AISGPU_FLAG_MODE_X 64 /* channel mode X (`-c X`, Receiver.cpp:87-98, Model.cpp:35-107): ONE channel, already centred, sample_rate
@@ -118,9 +121,9 @@ typedef struct aisgpu_out {
 	long long first_sample48;/* stream index (48 kHz) of the first sample of this block */
 	const uint32_t* fm_bits; /* AISGPU_MODEL_CHALLENGER and AISGPU_MODEL_BASE (else NULL; with MODEL_BASE n_groups is 0 and only this is valid): bit n of word n/32 set <=> the filtered FM discriminator
 	                          * sample first_sample48 + n is > 0 (what Deinterleave S_af hands to DEC_af[n % 5], Model.cpp:638-639) */
-	const float* c48;        /* AISGPU_MODEL_V2 only (else NULL): the channel's 48 kHz front-end output of this block (FCIC5_a/b.out, Model.cpp:345-346),
+	const float* c48;        /* AISGPU_MODEL_V2 without AISGPU_FLAG_GPU_DECODE only (else NULL): the channel's 48 kHz front-end output of this block (FCIC5_a/b.out, Model.cpp:345-346),
 	                          * 512 * n_windows complex samples, interleaved re/im; n_groups is 0 */
-	/* AISGPU_MODEL_V2 only (else NULL): what V2::Engine computes from the channel alone, for every 512-sample engine block of
+	/* AISGPU_MODEL_V2 without AISGPU_FLAG_GPU_DECODE only (else NULL, and fm_bits too): what V2::Engine computes from the channel alone, for every 512-sample engine block of
 	 * this block at once (DSP/Decoder/V2/V2Engine.cpp).  Engine block i (i = 0 .. n_windows-1) is the one the engine decodes
 	 * when block-relative samples [512 i, 512 i + 512) arrive as its look-ahead, i.e. samples [512 i - 512, 512 i):
 	 *   v2_f[2 i], v2_prom[2 i]          FreqOffset::Estimate (:56-131) of the window at offset 0 of that engine block (f, prominence)
@@ -221,13 +224,6 @@ void aisgpu_timing(aisgpu_t* h, int enable);
  *   "k7b_fcap"      1 .. 4: frames a list of ModelBase's chunk-parallel decoder kernels takes (small values force the exact fallback, k7_base)
  *   "fused"         0: the materialised back end (phasor / derotated-sample arrays in HBM: what AISGPU_FLAG_TAPS uses)
  *   "fft_in_k1"     0: the spectral analysis as FFT + search kernels instead of inside the front-end waves
- *   "fm_in_k6"      0: ModelChallenger's FM branch as kernels of its own on the stored derotated samples (default: inside the derotation / FIR kernel)
- *   "pre_extra_lds" bytes of unused dynamic LDS per workgroup of the pre-decimation pass (caps its workgroups per CU; 0: the default)
- *   "fm_on_s1"      0 / 1: ModelChallenger's FM branch behind the derotation / FIR kernel, or in front of PhaseSearch on its stream
- *   "base_fm_on_ds" 0: ModelBase / ModelStandard: the FM receiver on the front stream behind the front end (default: the downstream stream)
- *   "x_direct"      0: 288 kSPS-family / 96 kSPS ladders: CF32 input through a converted copy like the other formats (default: read in place)
- *   "front_low_prio" 0: the front stream at the same queue priority as the others
- *   "us_on_ds"      0: resampled ladders: the resampler front end on the front stream behind the pass over the input (default: downstream stream)
  * Returns AISGPU_ERR_ARG for an unknown key. */
 int aisgpu_set_option(const char* key, const char* value);
 
