@@ -188,6 +188,7 @@ struct aisgpu {
 	bool v2 = false; float2* h_c48 = nullptr; // ModelEngineV2: front end only, the 48 kHz channels go to the host (MAXSUB slots)
 	V2ChanState* d_v2st = nullptr; float2* d_slotcs = nullptr; int* d_v2locked = nullptr; // AISGPU_FLAG_GPU_DECODE with ModelEngineV2: the engine itself on the device (kv2_engine)
 	bool v2_assist = true; float2* d_v2hist = nullptr; float *d_v2f = nullptr, *d_v2prom = nullptr, *d_v2en = nullptr, *h_v2f = nullptr, *h_v2prom = nullptr, *h_v2en = nullptr; // decoder-independent part of V2::Engine on the device
+	bool k46 = false; // default path: derotation + FIR + PhaseSearch in one kernel (k46_window_search; test hook "k46" = 0: k6_window_fir + k4_phase_chunks)
 	bool base = false; float2* d_fmprev[2] = {}; // ModelBase: FM receiver on the 48 kHz channels, no coherent chain
 	float* d_fm = nullptr; float* d_fmhist[2] = {}; uint32_t* d_fmbits[2] = {}; uint32_t* h_fmbits = nullptr; // ModelChallenger FM branch
 	float* d_fmfir = nullptr; // [n_chan][L] Filter(Receiver) output of the last downstream block (AISGPU_FLAG_TAPS)
@@ -621,6 +622,36 @@ int enqueue_fused_back(aisgpu_t* h) {
 	k6.sym = h->d_sym[pb]; k6.sym_stride = h->Gcap; k6.lvl = h->d_lvl[lv];
 	memcpy(k6.taps, TAPS_COHERENT, sizeof k6.taps);
 	k6.first_group = g0; k6.n_rel0 = h->fpend.n_rel0; k6.n_groups = n_groups; k6.L = h->L; k6.n_windows = h->W; k6.n_chan = h->n_chan;
+	const int n_chunks = (n_groups + PS_CHUNK - 1) / PS_CHUNK;
+	if (h->k46 && n_chunks > 1) {
+		// Round 5: derotation + FIR + ScatterPLL + PhaseSearch as ONE kernel on the PhaseSearch stream (k46_window_search): the FIR outputs
+		// stay in LDS, `sym` is neither written nor read (the exact fallback inside k46_assemble materialises its rows when it has to).
+		hipStream_t s = h->s1;
+		WAITEV(s, h->ev_phasor[q]);
+		WAITEV(s, h->ev_sym[pb]); // (sym[pb]: the fallback's rows; last read by the fallback of block f-2, same stream)
+		WAITEV(s, h->ev_ema[lv]); // lvl[lv] / bits[lv]: the frame decoder / the copies of block f-4
+		{
+			K2Params k2r = make_k2(h, q);
+			k2r.ck = h->d_ck[q]; k2r.ck_stride = k6.ck_stride;
+			TraceScope t(h, "refine", s);
+			HIPCHK(launch_k2b_refine(k2r, h->n_chan, s));
+		}
+		K46Params kq;
+		kq.f = k6;
+		K4Params& k4 = kq.s;
+		k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[lv]; k4.bits_stride = h->words;
+		k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
+		k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.fb_count = h->d_psflag + 2;
+		k4.n_chains = h->n_chains; k4.n_groups = n_groups; k4.n_chunks = n_chunks; k4.warm = h->ps_warm;
+		k4.box_in = nullptr; k4.box_out = nullptr; k4.first_group = g0;
+		kq.trips_pad = 0;
+		{ TraceScope t(h, "fir+psearch", s); HIPCHK(launch_k46(kq, s)); }
+		HIPCHK(hipEventRecord(h->ev_c48free[q], s));
+		HIPCHK(hipEventRecord(h->ev_k3[pb], s));
+		HIPCHK(hipEventRecord(h->ev_sym[pb], s));
+		{ int rc = flush_decode(h); if (rc) return rc; } // (dec_defer) the previous block's frame decoders on their stream
+		return finish_k4(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub, s);
+	}
 	WAITEV(h->s4, h->ev_phasor[q]);
 	WAITEV(h->s4, h->ev_sym[pb]); // sym[pb] was last read by PhaseSearch of block f-2,
 	WAITEV(h->s4, h->ev_ema[lv]); // lvl[lv] by the frame decoder / the copies of block f-4
@@ -1079,7 +1110,7 @@ const char* aisgpu_last_error(aisgpu_t* h) { return h ? h->err.c_str() : ""; }
 
 int aisgpu_set_option(const char* key, const char* value) {
 	if (!key || !*key) return AISGPU_ERR_ARG;
-	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "trace", "k7e_stats", "k7b_stats" };
+	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "k46", "trace", "k7e_stats", "k7b_stats" };
 	bool ok = false;
 	for (const char* k : known) ok = ok || strcmp(k, key) == 0;
 	if (!ok) return AISGPU_ERR_ARG;
@@ -1478,6 +1509,8 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	// (round 4: also ModelChallenger on the resampled ladders -- BASELINE configs[2], 6 MSPS: with the lanes-over-time derotation / FIR
 	// kernel 0.558 -> 0.538 ms per step; with round 3's lane-per-chain kernel it had been 0.70 against 0.53)
 	h->fused = !(cfg->flags & AISGPU_FLAG_TAPS) && !h->base && !h->v2 && opt_int("fused", 1) != 0;
+	// Measured (profiles/r05_expA_k46.txt): bit-exact, 240 MB less traffic per step, and 5 % SLOWER per step -- so it is off unless asked for
+	h->k46 = h->fused && !h->challenger && !(cfg->flags & AISGPU_FLAG_PS_BOXCAR) && opt_int("k46", 0) != 0 && opt_int("ps_sequential", 0) == 0;
 	h->us_on_ds = !h->serial && h->fused && h->mode == MODE_RESAMPLE && h->ds != h->stream;
 	// The spectral analysis rides at the end of the front-end waves (k1_fft_tail) when every span is a whole number of 512-sample
 	// windows of the 48 kHz channels (16 tiles each) and whole spans make up the block; the automatic span length is rounded up

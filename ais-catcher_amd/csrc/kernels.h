@@ -365,6 +365,10 @@ struct KV2EParams {
 };
 bool sincos_restatement_matches_host_libm(); // kv2_engine's sinf / cosf (glibc 2.35, FMA variant) on the host against the host's own libm
 hipError_t launch_kv2(const KV2Params& p, hipStream_t s, const KV2EParams* engine = nullptr); // engine: kv2_engine runs before the look-back is overwritten
+// Derotation + FIR + ScatterPLL + PhaseSearchEMA in one workgroup (k46_window_search, kernels.hip): K6Params without `sym` traffic
+// (f.sym = the block parity's global rows: only the exact fallback inside k46_assemble writes and reads them), K4Params as for launch_k4
+struct K46Params { K6Params f; K4Params s; int trips_pad; };
+hipError_t launch_k46(K46Params q, hipStream_t st);
 hipError_t launch_k4(const K4Params& p, hipStream_t s);          // chunk-parallel + assemble (with the exact sequential search where a speculative warm-up failed)
 hipError_t launch_k4_sequential(const K4Params& p, hipStream_t s); // the plain sequential kernel only
 hipError_t launch_k4_box(const K4Params& p, hipStream_t s);        // Demod::PhaseSearch (boxcar history), sequential

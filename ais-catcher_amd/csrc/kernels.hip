@@ -1351,16 +1351,13 @@ __device__ __forceinline__ float atan2f_ref(float y, float x);
 // discriminator of sample n from samples n and n - 1, the 37-tap sum left to right; the 36 discriminator values in front of the window
 // are computed again from the halo (in a block's first window: from the carried tail, whose first samples are zero before the stream
 // starts -- atan2f(+0, +0) / pi = 0, the filter's zero history).
+constexpr int K6_YBUF = K6_HALO + 512 + 6; // derotated samples of a window in LDS: halo + window + the over-read of the last group's window
+// one (channel, window) by one wave (a one-wave workgroup, or one whose other waves do not share ybuf / s_fm: the barriers below
+// are then ordering only)
 template <bool FM>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FM ? 6 : K6_WAVES, FM ? 6 : K6_WAVES))) void k6_window_fir(K6Params p) { // (the FM form needs 73 registers: six waves per SIMD)
-	__shared__ __attribute__((aligned(16))) float2 ybuf[K6_HALO + 512 + 6];
-	__shared__ float s_fm[FM ? FM_HIST + 512 : 1];
-	const int lane = threadIdx.x;
+__device__ __forceinline__ void k6_window_body(const K6Params& p, int chain, int w, float2* ybuf, float* s_fm) {
+	const int lane = threadIdx.x & 63;
 	const int W = p.n_windows;
-	// id = (((chain / 64) W + w) 8 + chain % 8) 8 + (chain / 8) % 8: the XCD (id % 8) depends on the chain alone, a chain's windows are
-	// 64 ids apart, and the eight chains that share a 64-byte run of the time-major checkpoints are neighbours on one XCD
-	const int t = blockIdx.x >> 6, w = t % W, chain = (t / W) * 64 + (blockIdx.x & 7) * 8 + ((blockIdx.x >> 3) & 7);
-	if (chain >= p.n_chan) return;
 	const float2* xrow = p.c48 + (size_t)chain * p.c48_stride;
 	// ---- derotation: lane -> segment (lanes 0..2: the previous window's last three)
 	{
@@ -1386,7 +1383,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FM ? 6 : K6_
 		if (w == 0 && lane < DF_HIST) ybuf[K6_HALO - DF_HIST + lane] = p.hist_in[(size_t)chain * DF_HIST + lane]; // the previous block's tail
 	}
 	__syncthreads(); // (one wave: ordering)
-	if (w == W - 1 && lane < DF_HIST) p.hist_out[(size_t)chain * DF_HIST + lane] = ybuf[K6_HALO + 512 - DF_HIST + lane];
+	if (w == W - 1 && lane < DF_HIST && p.hist_out) p.hist_out[(size_t)chain * DF_HIST + lane] = ybuf[K6_HALO + 512 - DF_HIST + lane];
 	if constexpr (FM) {
 		// discriminator value i = sample (i - FM_HIST) of the window: data[i] * std::conj(prev) -> atan2f / pi, as in k5_fm_filter
 		for (int i = lane; i < FM_HIST + 512; i += 64) {
@@ -1435,6 +1432,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FM ? 6 : K6_
 		}
 		p.lvl[(size_t)chain * p.sym_stride + gl] = __fdiv_rn(level, 5.0f);
 	}
+}
+
+template <bool FM>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FM ? 6 : K6_WAVES, FM ? 6 : K6_WAVES))) void k6_window_fir(K6Params p) { // (the FM form needs 73 registers: six waves per SIMD)
+	__shared__ __attribute__((aligned(16))) float2 ybuf[K6_YBUF];
+	__shared__ float s_fm[FM ? FM_HIST + 512 : 1];
+	// id = (((chain / 64) W + w) 8 + chain % 8) 8 + (chain / 8) % 8: the XCD (id % 8) depends on the chain alone, a chain's windows are
+	// 64 ids apart, and the eight chains that share a 64-byte run of the time-major checkpoints are neighbours on one XCD
+	const int W = p.n_windows;
+	const int t = blockIdx.x >> 6, w = t % W, chain = (t / W) * 64 + (blockIdx.x & 7) * 8 + ((blockIdx.x >> 3) & 7);
+	if (chain >= p.n_chan) return;
+	k6_window_body<FM>(p, chain, w, ybuf, s_fm);
 }
 
 // carry the tail of the previous block's derotated samples (FIR-17 history + partial ScatterPLL group) to the
@@ -2011,11 +2020,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K4_WAVES, K4
 
 // sequential over the (few) chunks of a chain, 16 lanes per chain: verify the speculative warm-ups, select the
 // trajectory of the true start index per chunk, emit the packed decisions and the new state
-__global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
-	const int lane = threadIdx.x;
-	const int k = lane & 15, row = lane >> 4;
-	const int chain = blockIdx.x * 4 + row;
-	if (chain >= p.n_chains) return;
+__device__ __forceinline__ bool ps_assemble_rows(const K4Params& p, int chain, int k) { // returns: a speculative warm-up of this row failed
 	const EmaState* st = p.state_in + chain;
 	EmaState* sto = p.state_out + chain;
 	int start = p.box_out ? p.box_in[chain].max_idx : st->max_idx; // (boxcar variant: its own state block)
@@ -2080,12 +2085,338 @@ __global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
 	sto->bits[k] = fin_last >> 4;
 	if (k == 0) { sto->max_idx = start; sto->rot = (st->rot + p.n_groups) & 3; }
 	if (p.box_out && k == 0) p.box_out[chain].max_idx = start; // boxcar variant: its own state block
+	return bad;
+}
+
+__global__ __launch_bounds__(64) void k4_assemble(K4Params p) {
+	const int lane = threadIdx.x;
+	const int k = lane & 15, row = lane >> 4;
+	const int chain = blockIdx.x * 4 + row;
+	if (chain >= p.n_chains) return;
+	const bool bad = ps_assemble_rows(p, chain, k);
 	// A speculative warm-up that did not reproduce the sequential EMA anywhere in the wave's four chains: the wave itself recomputes
 	// them sequentially from the true state, here and now (the same wave would have been the one to do it in a kernel of its own --
 	// which cost a launch boundary on the PhaseSearch stream, the pipeline's critical one, for every block).  (Rows of chains that
 	// do not exist have left above: ballots and DPP row operations of the search only ever look inside a row.)
 	if (__any(bad)) {
 		if (__builtin_amdgcn_readfirstlane(lane) == lane && p.fb_count) atomicAdd(p.fb_count, 1);
+		ps_search_quad(p, blockIdx.x);
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// K46 (round 5): derotation + FilterComplex(17) + ScatterPLL + PhaseSearchEMA in ONE workgroup -- the FIR outputs (`sym`, as large
+// as the 48 kHz channels: 105 MB written and 123 MB read back per step of 256 receivers) never leave the chip, and k6_window_fir's
+// launch is gone from the default path.  Reference: DSP.cpp:457-466, :215-246, DSP.h:95-117, Demod.cpp:39-101 -- every value is the
+// one k6_window_fir / k4_phase_chunks compute, in the same order.
+//  * workgroup = four waves = sixteen PhaseSearch rows: the five sampling phases of THREE adjacent channels (row R -> channel R / 5,
+//    phase R % 5; the sixteenth row idles), one chunk of PS_CHUNK symbols with its speculative warm-up in front, like k4_phase_chunks
+//    (round 2's k46 had five waves of 105 registers: they found no room beside three front-end waves per SIMD; four waves of <= 104
+//    registers sit in the registers and the 40 KB of LDS the front end cannot use);
+//  * the chunk is walked window by window (512 samples of each channel = 102 or 103 symbols of each phase).  Per window, wave c < 3
+//    is k6_window_fir for channel c: lanes over time restart the phasor recurrence from the checkpoints (k2_cgf_refine), derotate
+//    into the wave's own LDS window, then own one ScatterPLL group each; the five FIR outputs of a group go to an LDS row per
+//    (channel, phase) instead of `sym`.  All four waves then run PhaseSearch over the window's symbols, samples as LDS broadcasts;
+//  * software pipeline: the rows are double buffered, so ONE barrier per window; wave c computes window w + 1 in front of its
+//    PhaseSearch pass over window w, and the global loads of window w + 2 (nine samples and one checkpoint per lane) are in flight
+//    during that pass -- beside the front end a load takes 10-20 us, a pass about as long;
+//  * a chunk's warm-up (256 symbols) recomputes 2.5 windows of FIR: +25 % of the FIR arithmetic (a tenth of PhaseSearch's).
+// The groups of window w are those whose LAST sample lies in it (as in k6_window_fir); `lvl` of a group is written by the chunk that
+// owns the group.  k46_assemble = k4_assemble; its exact fallback (a speculative warm-up that failed, never seen with 256 symbols
+// of warm-up) first materialises `sym` for its channels with k6_window_fir's body, then runs the sequential search as before.
+// ------------------------------------------------------------------------------------------
+constexpr int K46_CH = 3;                               // channels per workgroup
+constexpr int K46_HL = 3;                               // halo segments (26 samples: the FIR reaches 20 back)
+constexpr int K46_HALO = K46_HL * CK_SEG - 1;
+constexpr int K46_WIN = K46_HALO + 512 + 2;             // a wave's LDS window: halo, window, the unused ninth sample of the last segment
+constexpr int K46_YBUF = K46_WIN + 64;                  // + the lanes' checkpoints (x parts, then y parts: two 256-byte runs)
+constexpr int K46_ROW = 110;                            // LDS row of a (channel, phase): 103 symbols + 7 of alignment slack; 110 x 8 B puts the four rows of a wave into different banks
+static_assert(K46_HALO >= 20 && K46_HALO <= DF_HIST, "k46: halo");
+constexpr int K46_RAW4 = (K46_HALO + 512) / 2;          // 16-byte pieces of a window's raw samples (halo + window)
+static_assert((K46_HALO & 1) == 0 && (K46_WIN & 1) == 0, "k46: the halo begins on a 16-byte boundary of the channel's row");
+// LDS-DMA by hand: lane l's 16 (4) bytes at g land at LDS byte address lds_base + 16 l (4 l); lds_base wave-uniform.  Inline assembly
+// on purpose: the compiler does not know these operations, so it puts no vmcnt wait in front of LDS reads that cannot alias them
+// (with the builtin every ds_read of the PhaseSearch pass waited for vmcnt(0) -- i.e. also for the pass's own stores, which are
+// acknowledged after 10-20 us beside the front end).  The reader waits itself: k46_wait_vm().  (m0 is not used by anything else here.)
+__device__ __forceinline__ void k46_dma16(const void* g, unsigned lds_base) {
+	asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void k46_dma4(const void* g, unsigned lds_base) {
+	asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(lds_base) : "memory");
+}
+// wait until at most n (wave-uniform) of the wave's vector memory operations are outstanding: everything older than its n youngest
+// -- the stores of the PhaseSearch pass in between -- has completed (loads and stores of a wave retire in order on gfx9)
+__device__ __forceinline__ void k46_wait_vm(int n) {
+	switch (n) {
+	case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+	case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+	case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+	case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+	case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+	case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+	default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break; // (more stores in between: a stronger wait than needed)
+	}
+}
+// workgroup barrier for LDS data only: __syncthreads() also waits for vmcnt(0) -- the prefetch in flight and the pass's stores
+__device__ __forceinline__ void k46_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int MODE>
+__device__ __forceinline__ void k46_body(const K46Params& q, int trip, int chunk, float2 (*ybufs)[K46_YBUF], float2 (*symL)[K46_CH][5][K46_ROW]) {
+	const K6Params& p = q.f;
+	const K4Params& s = q.s;
+	const int lane = threadIdx.x & 63;
+	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int W = p.n_windows;
+	// ---- PhaseSearch rows
+	const int k = lane & 15, row = lane >> 4, rowbase = row * 16;
+	const int R = wv * 4 + row;
+	const int c_ps = R < 15 ? R / 5 : K46_CH - 1, j_ps = R < 15 ? R % 5 : 4;
+	const int chan_ps = trip * K46_CH + c_ps;
+	const bool live = R < 15 && chan_ps < p.n_chan;
+	const int chain = live ? chan_ps * 5 + j_ps : s.n_chains - 1;
+	const int jj = k < 8 ? k : 15 - k;
+	const float pc = c_ps_phase[jj].x;
+	const float psn = k < 8 ? c_ps_phase[jj].y : -c_ps_phase[jj].y;
+	float pc_l, psn_l; // (the same two behind the wait in front of the window loop)
+	const int g0 = chunk * PS_CHUNK;
+	const int g1 = g0 + PS_CHUNK < s.n_groups ? g0 + PS_CHUNK : s.n_groups;
+	const size_t slot = (size_t)chain * s.n_chunks + chunk;
+	c2 ma;
+	PsWave hs;
+	int idx = k;
+	int start = g0;
+	if (chunk == 0) {
+		const EmaState* st = s.state_in + chain;
+		ma = c2{ st->ma[k], st->ma[k] };
+		const unsigned bits = st->bits[k];
+		hs.h1 = __ballot((bits & 1u) != 0); hs.h2 = __ballot((bits & 2u) != 0);
+		hs.h3 = __ballot((bits & 4u) != 0); hs.h4 = __ballot((bits & 8u) != 0);
+	} else {
+		ma = c2{ 0.0f, 0.0f };
+		hs.h1 = hs.h2 = hs.h3 = hs.h4 = 0;
+		start = g0 - s.warm;
+	}
+	uint32_t* wout = s.words + slot * (PS_CHUNK / 32) * 16 + k;
+	uint32_t word = 0;
+	const int wave_stores = __any(live) ? 1 : 0; // a store under `live` is an instruction of this wave iff one of its rows exists
+	int n_st = 0; // vector memory operations (stores) this wave has issued since its last fir_load()
+	// ---- windows of the chunk (group gl: samples n_rel0 + 5 gl .. + 4 of the block; it belongs to the window of its last sample)
+	const int w_first = (p.n_rel0 + 5 * start + 4) >> 9, w_last = (p.n_rel0 + 5 * (g1 - 1) + 4) >> 9;
+	const auto g_lo_of = [&](int w) { return (w * 512 - p.n_rel0) / 5; };
+	const auto g_end_of = [&](int w) { return w >= W - 1 ? p.n_groups : min(p.n_groups, ((w + 1) * 512 - p.n_rel0) / 5); };
+	// rows in LDS start at a group index that is a multiple of 8 away from `start`: PhaseSearch's batches of 8 then are aligned reads
+	const auto base_of = [&](int w) { const int gl = g_lo_of(w); return gl - ((gl - start) & 7); };
+	// ---- the derotation / FIR wave of channel wv (waves 0 .. 2)
+	const int chan_f = trip * K46_CH + (wv < K46_CH ? wv : 0);
+	const bool fir_wave = wv < K46_CH && chan_f < p.n_chan;
+	const int chf = chan_f < p.n_chan ? chan_f : p.n_chan - 1;
+	float2* ybuf = ybufs[wv < K46_CH ? wv : 0];
+	const float2* xrow = p.c48 + (size_t)chf * p.c48_stride;
+	// the windows' phasor steps: lane i keeps the step of window w_first - 1 + i (one dependent pair of loads per chunk, not per window)
+	float2 stp_l;
+	{
+		int wi = w_first - 1 + lane;
+		wi = wi < 0 ? 0 : (wi > W - 1 ? W - 1 : wi);
+		stp_l = p.step_table[p.fz[(size_t)chf * W + wi] + 205];
+	}
+	const int seg = lane - K46_HL;
+	const int si = seg >= 0 ? seg : CK_USED + seg;
+	// the window's raw samples (with the halo in front) and the lanes' checkpoints travel from HBM straight into the wave's LDS window
+	// (no staging registers: nine samples per lane held across a PhaseSearch pass were twenty registers the pass does not have).
+	// Issued one PhaseSearch pass ahead of fir_compute(), which waits for them with k46_wait_vm().
+	const unsigned ybuf_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) float2*)ybuf);
+	const auto fir_load = [&](int w) {
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the window's last reads have returned before anything lands in it)
+		const int ws = seg >= 0 ? w : w - 1;
+		if (lane < CK_USED + K46_HL && ws >= 0) {
+			const float* ckp = reinterpret_cast<const float*>(p.ck + ((size_t)ws * CK_SLOTS + si) * p.ck_stride + chf);
+			k46_dma4(ckp, ybuf_lds + K46_WIN * 8);
+			k46_dma4(ckp + 1, ybuf_lds + K46_WIN * 8 + 256);
+		}
+		const float2* src = xrow + (w * 512 - K46_HALO) + 2 * lane;
+#pragma unroll
+		for (int e = 0; e < (K46_RAW4 + 63) / 64; e++) {
+			const int piece = e * 64 + lane;
+			if (piece < K46_RAW4 && (w > 0 || piece >= K46_HALO / 2)) // (the block's first window: its halo is the carried tail)
+				k46_dma16(src + e * 128, ybuf_lds + e * 1024);
+		}
+	};
+	const auto fir_compute = [&](int w, int younger, int buf) { // younger: vector memory operations of this wave since fir_load(w)
+		k46_wait_vm(younger);
+		const int ws = seg >= 0 ? w : w - 1;
+		const int iw = w - (w_first - 1);
+		const auto lane_value = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+		const float sx_c = lane_value(stp_l.x, iw), sy_c = lane_value(stp_l.y, iw), sx_p = lane_value(stp_l.x, iw - 1), sy_p = lane_value(stp_l.y, iw - 1);
+		if (lane < CK_USED + K46_HL && ws >= 0) {
+			const int n0 = ws * 512 + si * CK_SEG;
+			const float stx = seg >= 0 ? sx_c : sx_p, sty = seg >= 0 ? sy_c : sy_p;
+			const float* ckl = reinterpret_cast<const float*>(ybuf + K46_WIN);
+			c2 rot = { ckl[lane], ckl[64 + lane] };
+			const c2 st = { stx, sty }, st_sw = { -sty, stx };
+			float2* y = ybuf + K46_HALO + (n0 - w * 512); // in place: every sample belongs to exactly one lane
+			float2 d[CK_SEG];
+#pragma unroll
+			for (int m = 0; m < CK_SEG; m++) d[m] = y[m]; // (segment 56: the ninth is beyond the window, unused)
+#pragma unroll
+			for (int m = 0; m < CK_SEG; m++) {
+				rot = rot.xx * st + rot.yy * st_sw;                       // rot *= rot_step
+				const c2 v = pk_sub_add(rot * d[m].x, rot.yx * d[m].y);   // data * rot
+				if (m < CK_SEG - 1 || si < CK_USED - 1) y[m] = make_float2(v.x, v.y);
+			}
+		}
+		if (w == 0 && lane < K46_HALO) ybuf[lane] = p.hist_in[(size_t)chf * DF_HIST + (DF_HIST - K46_HALO) + lane]; // the previous block's tail
+		wave_sync();
+		if (w == W - 1 && lane < DF_HIST) p.hist_out[(size_t)chf * DF_HIST + lane] = ybuf[K46_HALO + 512 - DF_HIST + lane];
+		const int g_lo = g_lo_of(w), g_end = g_end_of(w), base = base_of(w);
+		const int r0sel = (int)(p.first_group & 3);
+		for (int gl = g_lo + lane; gl < g_end; gl += 64) {
+			const int a = p.n_rel0 + 5 * gl - w * 512; // the group's first sample relative to the window: -4 .. 507
+			const float2* wsrc = ybuf + K46_HALO + a - 16;
+			// the five 17-tap sums of the group advance together over its 21 samples -- each still x += taps[i] * d[i] from i = 0 upwards
+			// (DSP.h:224-230) -- so a sample is dead once its five products are formed: ten accumulator registers instead of a 42-register window
+			c2 acc[5] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+#pragma unroll
+			for (int i = 0; i < 21; i++) {
+				const float2 v = wsrc[i];
+				const c2 x = c2{ v.x, v.y };
+#pragma unroll
+				for (int j = 0; j < 5; j++)
+					if (i - j >= 0 && i - j < 17) acc[j] = acc[j] + x * p.taps[i - j];
+			}
+			const int rsel = (r0sel + gl) & 3; // the (1j)^n of PhaseSearchEMA (Demod.cpp:44-61), as in k6_window_fir
+			const unsigned nx = (rsel == 1 || rsel == 2) ? 0x80000000u : 0u, ny = rsel >= 2 ? 0x80000000u : 0u;
+			const bool swap = (rsel & 1) != 0;
+			float level = 0.0f;
+#pragma unroll
+			for (int j = 0; j < 5; j++) {
+				level = level + (acc[j].x * acc[j].x + acc[j].y * acc[j].y); // std::norm
+				const float sx = swap ? acc[j].y : acc[j].x, sy = swap ? acc[j].x : acc[j].y;
+				symL[buf][wv][j][gl - base] = make_float2(__uint_as_float(__float_as_uint(sx) ^ nx), __uint_as_float(__float_as_uint(sy) ^ ny));
+			}
+			if (gl >= g0 && gl < g1) p.lvl[(size_t)chf * p.sym_stride + gl] = __fdiv_rn(level, 5.0f); // (a warm-up group is the previous chunk's)
+		}
+		wave_sync(); // (the next window's derotation overwrites ybuf: LDS operations of a wave execute in order)
+	};
+	// ---- PhaseSearch over the symbols of window w that belong to this chunk (or its warm-up)
+	const auto ps_window = [&](int w, int buf) {
+		const int gl_lo = g_lo_of(w), gl_end = g_end_of(w), base = base_of(w);
+		const int a = gl_lo > start ? gl_lo : start, b = gl_end < g1 ? gl_end : g1;
+		const float2* srow = &symL[buf][c_ps][j_ps][0];
+#pragma unroll 1
+		for (int gb = a - ((a - start) & 7); gb < b; gb += 8) {
+			float2 v[8];
+			{
+				const float4* src = reinterpret_cast<const float4*>(srow + (gb - base));
+#pragma unroll
+				for (int e = 0; e < 8; e += 2) { const float4 t = src[e >> 1]; v[e] = make_float2(t.x, t.y); v[e + 1] = make_float2(t.z, t.w); }
+			}
+			const bool full = gb >= a && gb + 8 <= b;
+			const int gend = gb + 8 < b ? gb + 8 : b;
+			if (gb < g0) { // warm-up: EMA and decision history only (a batch never straddles g0: warm and PS_CHUNK are multiples of 8)
+				if (full) {
+#pragma unroll
+					for (int e = 0; e < 8; e++) ps_warm_step<MODE>(v[e], pc_l, psn_l, ma, hs);
+				} else {
+#pragma unroll
+					for (int e = 0; e < 8; e++) if (gb + e >= a && gb + e < b) ps_warm_step<MODE>(v[e], pc_l, psn_l, ma, hs); // wave-uniform
+				}
+				if (gend == g0) { if (live) s.ma_start[slot * 16 + k] = ma.y; n_st += wave_stores; }
+			} else {
+				const int qb = gb - g0;
+				if (full) {
+					uint32_t part = 0;
+#pragma unroll
+					for (int e = 0; e < 8; e++) part |= ps_step<MODE>(v[e], pc_l, psn_l, ma, hs, idx, k, rowbase) << e;
+					word |= part << (qb & 31);
+					if (((qb + 8) & 31) == 0) { if (live) wout[(qb >> 5) * 16] = word; word = 0; n_st += wave_stores; }
+				} else {
+#pragma unroll
+					for (int e = 0; e < 8; e++) {
+						if (gb + e >= a && gb + e < b) { // wave-uniform
+							word |= ps_step<MODE>(v[e], pc_l, psn_l, ma, hs, idx, k, rowbase) << ((qb + e) & 31);
+							if (((qb + e) & 31) == 31) { if (live) wout[(qb >> 5) * 16] = word; word = 0; n_st += wave_stores; }
+						}
+					}
+				}
+			}
+		}
+	};
+	// Everything fetched with ordinary loads so far is made final HERE: a value whose load the compiler still counts as pending when the
+	// window loop begins would get its vmcnt(0) wait inside the loop -- where it waits for the PhaseSearch pass's stores.
+	asm volatile("s_waitcnt vmcnt(0)" : "+v"(stp_l.x), "+v"(stp_l.y), "+v"(ma), "+v"(idx) :: "memory");
+	{ float pc_ = pc, psn_ = psn; asm volatile("" : "+v"(pc_), "+v"(psn_)); pc_l = pc_; psn_l = psn_; }
+	if (fir_wave) {
+		fir_load(w_first);
+		fir_compute(w_first, 0, w_first & 1);
+		if (w_first + 1 <= w_last) fir_load(w_first + 1);
+	}
+	k46_barrier();
+#pragma unroll 1
+	for (int w = w_first; w <= w_last; w++) {
+		if (fir_wave && w + 1 <= w_last) {
+			fir_compute(w + 1, n_st, (w + 1) & 1);   // its loads were issued a whole PhaseSearch pass ago
+			if (w + 2 <= w_last) fir_load(w + 2);    // in flight during the pass below
+		}
+		n_st = 0;
+		ps_window(w, w & 1);
+		k46_barrier(); // rows [w & 1] are free for window w + 2, rows [(w + 1) & 1] complete
+	}
+	const int n = g1 - g0;
+	if ((n & 31) != 0 && live) wout[(n >> 5) * 16] = word;
+	if (live) {
+		s.ma_fin[slot * 16 + k] = ma.y;
+		const unsigned dec = (unsigned)((hs.h1 >> lane) & 1ull) | ((unsigned)((hs.h2 >> lane) & 1ull) << 1) |
+		                     ((unsigned)((hs.h3 >> lane) & 1ull) << 2) | ((unsigned)((hs.h4 >> lane) & 1ull) << 3);
+		s.fin[slot * 16 + k] = (unsigned)(idx & 15) | (dec << 4);
+	}
+}
+
+#ifndef K46_WAVES
+#define K46_WAVES 5 // occupancy target of five waves per SIMD = at most 96 registers: three front-end waves of 136 leave 104
+#endif
+// (The LDS is dynamic: with a static 40 KB the compiler sees "four workgroups per CU" and budgets 128 registers whatever it is asked
+// for; what the kernel has to fit into is the gap beside the front end, which the compiler cannot know.)
+// (and the two sides of the LDS are different objects: the waits the compiler puts in front of reads of the DMA's target must not land in
+// front of PhaseSearch's reads of the rows)
+constexpr size_t K46_LDS = sizeof(float2) * ((size_t)2 * K46_CH * 5 * K46_ROW);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K46_WAVES, K46_WAVES))) void k46_window_search(K46Params q) {
+	__shared__ __attribute__((aligned(16))) float2 ybufs[K46_CH][K46_YBUF];
+	static_assert(sizeof(float2) * K46_CH * K46_YBUF + K46_LDS <= 40960, "k46: the LDS twelve front-end workgroups leave on a CU");
+	extern __shared__ __attribute__((aligned(16))) float2 k46_rows[];
+	float2 (*symL)[K46_CH][5][K46_ROW] = reinterpret_cast<float2 (*)[K46_CH][5][K46_ROW]>(k46_rows);
+	// workgroup id -> (channel triple, chunk): id % 8 is the XCD; an XCD takes a contiguous eighth of the triples, neighbours in
+	// time one behind the other -- the 128-byte lines of the time-major checkpoints (sixteen chains each) stay in ONE L2
+	const int per = q.trips_pad >> 3;
+	const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+	const int trip = xcd * per + sq % per, chunk = sq / per;
+	if (trip * K46_CH >= q.f.n_chan) return; // (the whole workgroup: no barrier has been reached)
+	const int lane = threadIdx.x & 63, k = lane & 15;
+	const int src = __builtin_amdgcn_update_dpp(0, k, 0x121, 0xF, 0xF, false);
+	const bool all_left = __all(src == ((k + 15) & 15)), all_right = __all(src == ((k + 1) & 15));
+	if (all_left) k46_body<0>(q, trip, chunk, ybufs, symL);
+	else if (all_right) k46_body<1>(q, trip, chunk, ybufs, symL);
+	else k46_body<2>(q, trip, chunk, ybufs, symL);
+}
+
+// k4_assemble for the fused workgroups: there is no `sym` in HBM, so the exact fallback first produces the rows of its (at most two)
+// channels with k6_window_fir's body, window by window -- into the global `sym` of this block parity, which nothing else touches in
+// this mode (two waves that share a channel write the same values) -- and then runs the sequential search over them.
+__global__ __launch_bounds__(64) void k46_assemble(K46Params q) {
+	__shared__ __attribute__((aligned(16))) float2 ybuf[K6_YBUF];
+	const K4Params& p = q.s;
+	const int lane = threadIdx.x;
+	const int k = lane & 15, row = lane >> 4;
+	const int chain = blockIdx.x * 4 + row;
+	// (rows of chains that do not exist stay: the fallback's derotation / FIR body needs all 64 lanes of the wave)
+	const bool bad = chain < p.n_chains && ps_assemble_rows(p, chain, k);
+	if (__any(bad)) {
+		if (lane == 0 && p.fb_count) atomicAdd(p.fb_count, 1);
+		const int c_lo = (blockIdx.x * 4) / 5, c_hi = min((int)blockIdx.x * 4 + 3, p.n_chains - 1) / 5;
+		K6Params f = q.f;
+		f.hist_out = nullptr; // (the fused workgroups have written the carried tail)
+		for (int c = c_lo; c <= c_hi; c++)
+			for (int w = 0; w < f.n_windows; w++) { k6_window_body<false>(f, c, w, ybuf, nullptr); __syncthreads(); } // (one wave: ordering)
+		__threadfence();
 		ps_search_quad(p, blockIdx.x);
 	}
 }
@@ -4059,6 +4390,15 @@ hipError_t launch_k4_box(const K4Params& p, hipStream_t s) {
 hipError_t launch_k4_sequential(const K4Params& p, hipStream_t s) {
 	if (p.n_groups <= 0) return hipSuccess;
 	hipLaunchKernelGGL(k4_phase_search, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_k46(K46Params q, hipStream_t st) {
+	if (q.s.n_groups <= 0) return hipSuccess;
+	const int trips = (q.f.n_chan + K46_CH - 1) / K46_CH;
+	q.trips_pad = (trips + 7) / 8 * 8;
+	hipLaunchKernelGGL(k46_window_search, dim3((unsigned)q.trips_pad * (unsigned)q.s.n_chunks), dim3(256), K46_LDS, st, q);
+	hipLaunchKernelGGL(k46_assemble, dim3((q.s.n_chains + 3) / 4), dim3(64), 0, st, q); // + the exact fallback where a warm-up failed
 	return hipGetLastError();
 }
 

@@ -1034,6 +1034,23 @@ def test_fused_backend_1536k(block, nblocks):
     _run_outputs_vs_oracle([synth.to_cu8(xs[0])], 1536000, "cu8", block, nblocks)
 
 
+@pytest.mark.parametrize("env", [{"AISGPU_K46": "1"}, {"AISGPU_K46": "1", "AISGPU_PS_WARM": "16"}, {}, {"AISGPU_PS_WARM": "16"}, {"AISGPU_K46": "1", "AISGPU_SERIAL": "1"}])
+@pytest.mark.parametrize("R,block,nblocks", [(1, 786432, 6), (5, 786432, 3), (2, 491520, 4)])
+def test_fir_and_phase_search_in_one_workgroup(env, R, block, nblocks, monkeypatch):
+    """Round 5's fused back end (option k46 = 1; measured slower than the two kernels, so not the default -- profiles/r05_expA_k46.txt):
+    derotation + FIR + ScatterPLL + PhaseSearchEMA in one workgroup (k46_window_search: four waves = the five sampling phases of
+    three adjacent channels, the FIR outputs only in LDS).  Channel counts that leave the last
+    workgroup with one or two channels (2, 10 and 4 channels), blocks whose first group begins in the previous block (24,576 samples
+    = 4,915.2 groups per block: every alignment within five blocks), a block of exactly three chunks (15,360 samples = 3,072 groups);
+    with a 16-symbol warm-up every speculative chunk fails its check and the assembling wave materialises the rows of its
+    channels and searches sequentially; without the option the two-kernel default runs on the same inputs.
+    Hard bits, levels and ppm of every block against the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    xs = [synth.receiver_stream(block * nblocks, receiver_id=330 + r, gap_slots=(0, 2)) for r in range(R)]
+    _run_outputs_vs_oracle(xs, 1536000, "cf32", block, nblocks)
+
+
 @pytest.mark.parametrize("rate,kw", [(192000, {}), (768000, {}), (3072000, {}), (12288000, {}), (6000000, {}), (2400000, {}),
                                      (288000, {}), (1152000, {"dsk": True})])
 def test_fused_backend_other_ladders(rate, kw):
