@@ -40,12 +40,14 @@ DEC_HD int dec_abort_position(int t) {
 //    answer -- no loop over the frame, no undoing.  A de-stuffed bit advances nothing.
 // DATA_ONLY: the caller guarantees r.state == DST_DATAFCS (k7e_sim: a run leaves TRAINING / STARTFLAG after a few symbols and ends
 // when it leaves DATAFCS) -- the TRAINING / STARTFLAG half of the step folds away
-template <bool DATA_ONLY = false>
+// NO_DATA: the caller guarantees r.state != DST_DATAFCS (kv2_engine while none of a channel's decoders is inside a frame): the DATAFCS
+// half folds away; the step may OPEN a frame (STARTFLAG -> DATAFCS), it can never complete one
+template <bool DATA_ONLY = false, bool NO_DATA = false>
 DEC_HD bool dec_step(DecReg& r, int dd, float slvl, long long sidx, uint32_t* data) {
 	const int Bit = dd == r.prev; // NRZI: !(d ^ prev)
 	r.prev = dd;
 	const int st = DATA_ONLY ? (int)DST_DATAFCS : r.state, pos = r.position, osc = r.osc;
-	const bool isD = DATA_ONLY || st == DST_DATAFCS, isT = !DATA_ONLY && st == DST_TRAINING;
+	const bool isD = !NO_DATA && (DATA_ONLY || st == DST_DATAFCS), isT = !DATA_ONLY && st == DST_TRAINING;
 	// ---- TRAINING: count alternations; two equal bits after more than four of them are the start of a flag
 	const bool alt = Bit != r.lastBit;
 	const bool to_flag = isT && !alt && pos > 4;

@@ -340,11 +340,10 @@ struct KV2Params {
 // ModelEngineV2 with AISGPU_FLAG_GPU_DECODE (round 4): the engine's coherent branch on the device as well -- per channel strictly
 // sequential over its 512-sample blocks, like the reference (V2Engine.cpp:293-388): the tone gate / slot lock decide the frequency
 // from the decoders' states, Derotate is an accumulated phasor, the five PhaseTrackers take their loop weight from their decoder's
-// state sample by sample, the six decoders reset each other.  kv2_engine: one wave = V2E_NCH channels x 6 lanes (five tracker +
-// decoder lanes and the FM decoder behind its BitPLL), the groups of five samples in step, the reference's order inside a group
-// restored only where a message completes.  std::polar of the estimated frequency: glibc's sinf / cosf restated (sin_or_cos_ref);
-// frames out like the other engines' device decoders.
-constexpr int V2E_NCH = 10;
+// state sample by sample, the six decoders reset each other.  kv2_engine: one wave per channel (round 5) -- Derotate and FilterFL17
+// block-wise with lanes over time, then six lanes (five tracker + decoder lanes and the FM decoder behind its BitPLL) walk the groups
+// of five samples in step, the reference's order inside a group restored only where a message completes.  std::polar of the estimated
+// frequency: glibc's sinf / cosf restated (sin_or_cos_ref); frames out like the other engines' device decoders.
 struct V2Tracker { unsigned rot; float2 s; int prev_decision; };
 struct V2ChanState { // zero-initialised but for rot = (1, 0)
 	float2 rot; float last_f; float ppm, ppm_prev; float2 slot_ema; int slot_phase, di; long long sample_idx;

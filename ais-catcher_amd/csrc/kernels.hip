@@ -2804,8 +2804,8 @@ __global__ __launch_bounds__(64) void k7_decode(K7Params p) {
 
 // ------------------------------------------------------------------------------------------
 // KV2E: V2::Engine's coherent branch with its decoders on the device (kernels.h: KV2EParams).  Per channel everything below
-// happens in the reference's order; what is parallel is the channels (V2E_NCH per wave) and, inside a channel, the six
-// decoders of a group of five samples -- until one of them completes a message: then the group is redone sample by sample.
+// happens in the reference's order; what is parallel is the channels (one per wave) and, inside a channel, the block-wise stages and
+// the six decoders of a group of five samples -- until one of them completes a message: then the group is redone sample by sample.
 // ------------------------------------------------------------------------------------------
 // sinf / cosf of glibc 2.35 (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h) for |y| < 120, operation by operation, in the
 // variant glibc's ifunc selects on CPUs with FMA (every a * b + c fused): double-precision polynomials on the argument reduced by
@@ -2898,22 +2898,61 @@ __device__ __forceinline__ bool v2_pll(float& phase, int& last_bit, int bit, boo
 	return true;
 }
 __device__ __forceinline__ void v2_reset(DecReg& r) { r.state = DST_TRAINING; r.position = 0; r.osc = 0; }
+// dec_step() for a decoder that is NOT inside a frame (TRAINING or STARTFLAG; Marine/AIS.h:91-181 with state != DATAFCS), as arithmetic
+// on 0 / 1 integers -- no branch, no memory: the step may open a frame (STARTFLAG -> DATAFCS), it can never complete one.  `on` = 0
+// leaves the decoder as it is.  Field by field what dec_step<false, true> computes (tests: the engine's parity tests; dec_core.h).
+__device__ __forceinline__ void v2_dec_idle(DecReg& r, int dd, long long sidx, int on) {
+	const int Bit = dd == r.prev;
+	const int pos = r.position, st = r.state;
+	const int isT = st == DST_TRAINING, isS = st == DST_STARTFLAG;
+	const int alt = Bit != r.lastBit;
+	const int to_flag = isT & (alt ^ 1) & (pos > 4);
+	const int at7 = pos == 7;
+	const int open = isS & at7 & (Bit ^ 1);
+	const int more = isS & (at7 ^ 1) & Bit;
+	const int n_state = to_flag | more ? (int)DST_STARTFLAG : (open ? (int)DST_DATAFCS : (int)DST_TRAINING);
+	const int grow = (isT & alt) | more;                       // position + 1
+	const int n_pos = grow ? pos + 1 : (to_flag ? 1 + 2 * Bit : 0);
+	const int n_osc = grow ? r.osc : 0;                        // every NextState() call clears one_seq_count (AIS.cpp:33-37)
+	const int keep = (on ^ 1);
+	r.prev = on ? dd : r.prev;
+	r.state = on ? n_state : st;
+	r.position = on ? n_pos : pos;
+	r.osc = on ? n_osc : r.osc;
+	const int op = open & on;
+	r.level = op ? 0.0f : r.level;
+	r.start_idx = (to_flag & on) ? sidx : r.start_idx;
+	r.crc = op ? 0xFFFFu : r.crc;
+	r.tail = op ? 0u : r.tail;
+	r.cw = op ? 0u : r.cw;
+	r.cwi = op ? 0 : r.cwi;
+	r.abort_pos = op ? 0 : r.abort_pos;
+	r.lastBit = on ? Bit : r.lastBit;
+	(void)keep;
+}
 
+// Round 5: ONE channel per wave (round 4 had ten channels x six lanes in a wave: 52 waves on a chip of 1,024 SIMDs, every wave as slow
+// as its slowest channel and every roll-back of one channel paid by ten).  What the reference computes block-wise is block-wise here,
+// with lanes over time, and only the decoders' loop is serial:
+//  * Derotate (:133-146): the phasor is rounded at every step, so every lane runs the recurrence and keeps the state in front of its
+//    own eight samples (512 steps of three packed operations -- the chain a single lane needed anyway), then derotates those eight;
+//  * FilterFL17 (:154-167, Engine::processBlock's filter17.Run(freq_corrected, coh_filtered), :351): all 512 outputs once per block
+//    into LDS, eight per lane -- the group loop and its roll-back read them instead of filtering per decoder and sample;
+//  * the group loop: five tracker lanes + the FM decoder's lane as before; while none of the six decoders is inside a frame
+//    (DATAFCS) -- four fifths of the time on the bench signal -- the decoder step is its TRAINING / STARTFLAG half only.
+// The channel's scalar state (phasor, slot predictor, sample index ...) lives in every lane, identically: no leader, no broadcasts.
 __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64]; // [word][lane]
-	__shared__ __attribute__((aligned(16))) float2 dero[V2E_NCH][16 + 512 + 2];
-	__shared__ __attribute__((aligned(16))) float2 X[584];
+	__shared__ __attribute__((aligned(16))) float2 dero[16 + 512 + 2]; // FilterFL17's carry, then the block: raw, derotated in place
+	__shared__ __attribute__((aligned(16))) float2 X[584];              // Estimate()'s exchange space; afterwards the block's 512 FilterFL17 outputs
 	__shared__ __attribute__((aligned(16))) float mag[512 + 8];
-	__shared__ uint32_t fmw[V2E_NCH][16];
+	__shared__ uint32_t fmw[16];
+	float2* const zb = X;
 	const KV2Params& p = q.k;
-	const int lane = threadIdx.x;
-	const int mesh = lane < 6 * V2E_NCH ? lane / 6 : V2E_NCH - 1, j = lane - 6 * mesh; // lanes 60..63 idle (j = 6 .. 9, never live; their LDS reads stay inside the last channel's rows)
-	const int chan_raw = blockIdx.x * V2E_NCH + mesh;
-	const bool live = lane < 6 * V2E_NCH && chan_raw < p.n_chan;
-	const int chan = live ? chan_raw : p.n_chan - 1;
-	const int lead = mesh * 6;                        // the channel's first lane: it owns the engine's scalar state
-	const bool leader = live && j == 0;
-	const int dec = chan * 6 + j;
+	const int lane = threadIdx.x, j = lane;
+	const int chan = blockIdx.x;
+	const bool dl = lane < 6; // the six decoder lanes: 0..4 behind the trackers, 5 the FM decoder behind its BitPLL
+	const int dec = chan * 6 + (dl ? j : 0);
 	uint32_t* data = fdata + lane;
 	V2ChanState* cs = q.st + chan;
 	V2Lane L;
@@ -2931,13 +2970,12 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 	float last_f = cs->last_f, ppm = cs->ppm, ppm_prev = cs->ppm_prev;
 	int slot_phase = cs->slot_phase, di = cs->di;
 	long long sample_idx = cs->sample_idx;
-	if (live) for (int i = j; i < 16; i += 6) dero[mesh][i] = cs->carry17[i];
+	if (lane < 16) dero[lane] = cs->carry17[lane];
 	FftTwiddles tw = fft_twiddles(p.omega, lane);
 	const uint32_t* fm_cur = p.fmbits + (size_t)chan * p.fmbits_stride;
 	const uint32_t* fm_old = q.fm_prev + (size_t)chan * p.fmbits_stride;
-	// sign of the filtered discriminator at sample k of the engine block that is being decoded: the block's sixteen words are staged in
-	// LDS at the top of the block (fetched where the PLL needs them they were a memory round trip per sample of a serial loop)
-	const auto fm_sign = [&](int k) -> int { return (int)((fmw[mesh][k >> 5] >> (k & 31)) & 1u); };
+	// sign of the filtered discriminator at sample k of the engine block that is being decoded (the block's sixteen words: LDS)
+	const auto fm_sign = [&](int k) -> int { return (int)((fmw[k >> 5] >> (k & 31)) & 1u); };
 	const auto emit = [&](const DecReg& r, long long sidx, float tag_ppm) {
 		const unsigned slot = atomicAdd(q.frame_count, 1u) % (unsigned)q.max_frames;
 		uint32_t* f = q.frames + (size_t)slot * DEC_FRAME_WORDS;
@@ -2947,7 +2985,7 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 		f[8] = q.block; f[9] = q.sub;
 		for (int w = 0; w < DEC_DATA_WORDS; w++) f[10 + w] = data[64 * w];
 	};
-	const auto learn_slot = [&](long long start_idx) { // learnSlotPhase (:328-337), the leader's registers
+	const auto learn_slot = [&](long long start_idx) { // learnSlotPhase (:328-337), every lane alike
 		const long long a = start_idx - 155;
 		const int m = (int)((a % 1280 + 1280) % 1280);
 		const float2 csv = q.slot_cs[m];
@@ -2955,16 +2993,31 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 		const float ph = atan2f_ref(slot_ema.y, slot_ema.x) * (1280.0f / (2.0f * 3.14159265358979323846f));
 		slot_phase = (int)(ph + 1280.0f + 0.5f) % 1280;
 	};
-	const auto derotate = [&](float f, int from, int to) { // FreqOffset::Derotate (:133-146) over samples [from, to) of the block that starts at n0
+	// FreqOffset::Derotate (:133-146) over samples [from, to) of the staged block: lane l owns samples from + 8 l .. + 7
+	const auto derotate = [&](float f, int from, int to) {
 		const float th = f * 2.0f * 3.14159265358979323846f; // std::polar(1.0f, f * 2.0f * PI): (rho * cos(theta), rho * sin(theta))
 		const float sn = 1.0f * sin_or_cos_ref(th, 0), cn = 1.0f * sin_or_cos_ref(th, 1);
 		const c2 st = { cn, sn }, st_sw = { -sn, cn };
-		c2 r = { rot.x, rot.y };
-		float2* d = &dero[mesh][16]; // (the block's raw samples, staged by the whole wave: derotated in place)
-		for (int k = from; k < to; k++) {
-			const float2 x = d[k];
-			r = r.xx * st + r.yy * st_sw; // r *= rot_step
-			d[k] = make_float2(x.x * r.x - x.y * r.y, x.x * r.y + x.y * r.x); // src * r
+		c2 r = { rot.x, rot.y }, mine = r;
+		const int n = to - from;
+		for (int c = 0; c * 8 < n; c++) { // the state in front of sample from + 8 c: lane c's
+			if (c == lane) mine = r;
+			const int m = n - c * 8 < 8 ? n - c * 8 : 8;
+			if (m == 8) {
+#pragma unroll
+				for (int i = 0; i < 8; i++) r = r.xx * st + r.yy * st_sw; // r *= rot_step
+			} else {
+				for (int i = 0; i < m; i++) r = r.xx * st + r.yy * st_sw;
+			}
+		}
+		float2* d = &dero[16 + from + 8 * lane];
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+			if (8 * lane + i < n) {
+				const float2 x = d[i];
+				mine = mine.xx * st + mine.yy * st_sw;
+				d[i] = make_float2(x.x * mine.x - x.y * mine.y, x.x * mine.y + x.y * mine.x); // src * r
+			}
 		}
 		const float a = hypot_ref(r.x, r.y);
 		rot = make_float2(__fdiv_rn(r.x, a), __fdiv_rn(r.y, a));
@@ -2973,98 +3026,114 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 
 	for (int blk = 0; blk < p.n_windows; blk++) {
 		const int n0 = -V2_HIST + 512 * blk; // the decoded block; [n0 + 512, n0 + 1024) is the look-ahead
-		// the block's 512 samples of every channel of the wave into LDS (coalesced, all lanes): the leader derotates them in place --
-		// fetched by the leader inside its serial loop they were sixty-four memory round trips per block
-		for (int m = 0; m < V2E_NCH; m++) {
-			const int cm = blockIdx.x * V2E_NCH + m;
-			if (cm >= p.n_chan) break;
 #pragma unroll
-			for (int i = 0; i < 8; i++) dero[m][16 + i * 64 + lane] = v2_sample(p, cm, n0 + i * 64 + lane);
-		}
-		if (live) for (int i = j; i < 16; i += 6) { // (n0 is a multiple of 512: whole words; block 0 decodes the previous device block's tail)
+		for (int i = 0; i < 8; i++) dero[16 + i * 64 + lane] = v2_sample(p, chan, n0 + i * 64 + lane);
+		if (lane < 16) { // (n0 is a multiple of 512: whole words; block 0 decodes the previous device block's tail)
 			const int m0 = n0 < 0 ? n0 + p.L : n0;
-			fmw[mesh][i] = (n0 < 0 ? fm_old : fm_cur)[(m0 >> 5) + i];
+			fmw[lane] = (n0 < 0 ? fm_old : fm_cur)[(m0 >> 5) + lane];
 		}
 		wave_sync();
 		// ---- Engine::processBlock (:345-352): slot predictor decay, busy, CGF
-		const unsigned long long B = __ballot(live && j < 5 && L.r.state != DST_TRAINING);
-		const bool busy = ((B >> lead) & 31ull) != 0;
+		const bool busy = __ballot(dl && j < 5 && L.r.state != DST_TRAINING) != 0;
+		slot_ema = make_float2(slot_ema.x * 0.9999f, slot_ema.y * 0.9999f);
+		const bool locked = slot_ema.x * slot_ema.x + slot_ema.y * slot_ema.y >= 0.64f;
+		const int e_slot = (int)((((long long)slot_phase - sample_idx) % 1280 + 1280) % 1280);
+		ppm_prev = ppm;
 		int split = 0;
 		float f = 0.0f;
-		bool need_est = false;
-		int e_slot = 0;
-		if (leader) {
-			slot_ema = make_float2(slot_ema.x * 0.9999f, slot_ema.y * 0.9999f);
-			const bool locked = slot_ema.x * slot_ema.x + slot_ema.y * slot_ema.y >= 0.64f;
-			e_slot = (int)((((long long)slot_phase - sample_idx) % 1280 + 1280) % 1280);
-			ppm_prev = ppm;
-			if (locked && e_slot < 512) { need_est = true; split = e_slot; }
-			else {
-				const float* en = p.energy + (size_t)chan * (p.n_windows + 1);
-				const bool louder = en[blk + 1] > en[blk];
-				const int w = 2 * blk + ((!busy && louder) ? 1 : 0);
-				f = p.est_f[(size_t)chan * 2 * p.n_windows + w];
-				const float prom = p.est_prom[(size_t)chan * 2 * p.n_windows + w];
-				if (busy && prom < 5.5f) f = last_f; // tone gate: hold while a decode is in flight
-			}
-		}
-		// a slot starts inside this block: [0, e) keeps the previous frequency, Estimate() works on the 512 samples from e on -- a window
-		// the assist kernels did not compute.  The whole wave does its FFT, channel by channel; its leader the sequential search.
-		unsigned long long NE = __ballot(need_est);
-		if (NE != 0 && leader && need_est) derotate(last_f, 0, split); // (also for e == 0: the renormalisation happens)
-		while (NE != 0) {
-			const int ll = __builtin_ctzll(NE);
-			NE &= NE - 1;
-			const int ch2 = __shfl(chan, ll), e2 = __shfl(split, ll);
-			v2_fft_mag_window(p, ch2, n0 + e2, X, mag, tw, lane);
+		if (locked && e_slot < 512) {
+			// a slot starts inside this block: [0, e) keeps the previous frequency, Estimate() works on the 512 samples from e on -- a window
+			// the assist kernels did not compute: FFT by the wave, the sequential search by one lane
+			split = e_slot;
+			derotate(last_f, 0, split); // (also for e == 0: the renormalisation happens)
+			v2_fft_mag_window(p, chan, n0 + split, X, mag, tw, lane);
 			wave_sync();
-			if (lane == ll) { float prom; v2_search(mag, f, prom); if (q.locked_estimates) atomicAdd(q.locked_estimates, 1); }
+			if (lane == 0) { float prom; v2_search(mag, f, prom); if (q.locked_estimates) atomicAdd(q.locked_estimates, 1); }
+			f = __shfl(f, 0);
 			wave_sync();
+		} else {
+			const float* en = p.energy + (size_t)chan * (p.n_windows + 1);
+			const bool louder = en[blk + 1] > en[blk];
+			const int w = 2 * blk + ((!busy && louder) ? 1 : 0);
+			f = p.est_f[(size_t)chan * 2 * p.n_windows + w];
+			const float prom = p.est_prom[(size_t)chan * 2 * p.n_windows + w];
+			if (busy && prom < 5.5f) f = last_f; // tone gate: hold while a decode is in flight
 		}
-		if (leader) {
-			derotate(f, split, 512);
-			ppm = __fdiv_rn(f * 48000.0f, 162.0f);
+		derotate(f, split, 512);
+		ppm = __fdiv_rn(f * 48000.0f, 162.0f);
+		wave_sync();
+		// ---- FilterFL17 (:154-167) of the whole block: output k from carry + block samples k .. k + 16
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+			const c2 z = v2_dot17(&dero[i * 64 + lane], q.taps17);
+			zb[i * 64 + lane] = make_float2(z.x, z.y);
 		}
 		wave_sync();
-		const float b_ppm = __shfl(ppm, lead), b_ppm_prev = __shfl(ppm_prev, lead);
-		const int b_split = __shfl(split, lead);
 		// ---- the 512 samples: tracker di handles sample i (di runs on across blocks), the FM decoder sees every sample through its PLL
 		const int off = j < 5 ? (j - di + 5) % 5 : 0; // this tracker's sample inside a group of five
-		for (int g5 = 0; g5 < 512; g5 += 5) {
+		// (a generic lambda: the 102 whole groups of a block are one straight-line body, the two samples behind them another instance)
+		const auto group = [&](const int g5, auto whole_group) {
+			constexpr bool WHOLE = decltype(whole_group)::value != 0;
 			const V2Lane before = L;
-			const int ng = 512 - g5 < 5 ? 512 - g5 : 5;
-			// the FM decoder's lane: its PLL over the group's samples up to the first one on which it fires -- that symbol goes through
-			// the decoder together with the trackers' -- and, behind the decoder step (the PLL's gain follows the decoder's state), the rest
-			int my_k = -1, s_next = ng;
-			if (j == 5) {
-				const bool training = L.r.state == DST_TRAINING;
-				for (int s5 = 0; s5 < ng; s5++)
-					if (v2_pll(L.pll_phase, L.pll_last, fm_sign(g5 + s5), training)) { my_k = g5 + s5; s_next = s5 + 1; break; }
-			} else if (off < ng) my_k = g5 + off;
-			const bool have = live && my_k >= 0;
+			const int ng = WHOLE ? 5 : 512 - g5;
+			// The FM decoder's lane: its BitPLL (:225-242) over the group's samples.  The symbol of the first sample on which it fires goes
+			// through the decoder together with the trackers'; the samples behind that one see the PLL gain of the decoder's state AFTER
+			// that step in the reference.  Here all five run first, straight-line, with the gain of the state before the group: exact
+			// unless the step flips TRAINING <-> not-TRAINING AND a later sample of the group has a sign change (the only place the gain
+			// enters) -- then, as for a second symbol inside one group, the group is redone sample by sample below.
+			const unsigned fm5 = (unsigned)(((((unsigned long long)fmw[(g5 >> 5) + 1 < 16 ? (g5 >> 5) + 1 : 15]) << 32) | fmw[g5 >> 5]) >> (g5 & 31));
+			const bool tr0 = L.r.state == DST_TRAINING;
+			int k_pll = -1;
+			bool again = false, chg_after = false;
+			{
+				float ph = L.pll_phase;
+				int lastb = L.pll_last;
+				const float gain = tr0 ? 0.6f : 0.05f;
+#pragma unroll
+				for (int s5 = 0; s5 < 5; s5++) {
+					if (s5 < ng) { // (wave-uniform: only a block's last group is short)
+						const int b = (int)((fm5 >> s5) & 1u);
+						const bool chg = b != lastb;
+						const float ph_c = ph + (0.5f - ph) * gain;
+						ph = chg ? ph_c : ph;
+						lastb = b;
+						ph += 0.2f;
+						const bool fire = !(ph < 1.0f);
+						const float ph_w = ph - (float)(int)ph;
+						ph = fire ? ph_w : ph;
+						chg_after = chg_after || (chg && k_pll >= 0);
+						again = again || (fire && k_pll >= 0);
+						k_pll = (fire && k_pll < 0) ? g5 + s5 : k_pll;
+					}
+				}
+				if (j == 5) { L.pll_phase = ph; L.pll_last = lastb; }
+			}
+			const int my_k = j == 5 ? k_pll : ((j < 5 && off < ng) ? g5 + off : -1);
+			const bool have = dl && my_k >= 0;
 			const int kk = have ? my_k : 0;
-			const c2 z = v2_dot17(&dero[mesh][kk], q.taps17); // FilterFL17 (:154-167): output kk from carry + block samples kk .. kk + 16
-			const int bit = j < 5 ? v2_track(L.t, z, L.r.state == DST_TRAINING, q.w_train, q.w_track) : fm_sign(kk);
+			const float2 zf = zb[kk];
+			const c2 z = { zf.x, zf.y };
+			const int bit = j < 5 ? v2_track(L.t, z, tr0, q.w_train, q.w_track) : (int)((fm5 >> (kk - g5)) & 1u);
 			if (!have && j < 5) L.t = before.t;
 			const float slvl = z.x * z.x + z.y * z.y;
 			const long long sidx = sample_idx + kk;
-			bool found = have && dec_step(L.r, bit, slvl, sidx, data);
-			bool again = false;
-			if (j == 5) {
-				const bool training = L.r.state == DST_TRAINING;
-				for (int s5 = s_next; s5 < ng; s5++) again = v2_pll(L.pll_phase, L.pll_last, fm_sign(g5 + s5), training) || again;
-			}
+			// no decoder of the channel inside a frame: the step's TRAINING / STARTFLAG half is the whole step (it cannot complete a message)
+			const bool in_frame = __ballot(dl && L.r.state == DST_DATAFCS) != 0;
+			bool found = false;
+			if (in_frame) { if (have) found = dec_step(L.r, bit, slvl, sidx, data); }
+			else v2_dec_idle(L.r, bit, sidx, have ? 1 : 0); // (every lane, no branch)
+			again = j == 5 && (again || (chg_after && (L.r.state == DST_TRAINING) != tr0));
 			// anything that breaks the lockstep -- a completed message (it resets the other five at ITS sample), or an FM decoder that
 			// clocks two symbols inside one group -- sends the channel through the reference's own order, sample by sample
-			const unsigned long long F = __ballot(found || (again && live));
-			if (((F >> lead) & 63ull) != 0 && live) {
+			if (__ballot(found || (again && dl)) != 0) {
 				L = before;
 				// (the frame buffers: a lane that is rolled back may have written a word of its column: dec_step rewrites what it needs)
 				for (int s5 = 0; s5 < ng; s5++) {
 					const int k5 = g5 + s5;
-					const float tag_ppm = k5 >= b_split ? b_ppm : b_ppm_prev;
+					const float tag_ppm = k5 >= split ? ppm : ppm_prev;
 					const long long si = sample_idx + k5;
-					const c2 zz = v2_dot17(&dero[mesh][k5], q.taps17);
+					const float2 zq = zb[k5];
+					const c2 zz = { zq.x, zq.y };
 					const float lv = zz.x * zz.x + zz.y * zz.y;
 					bool fnd = false;
 					if (j < 5 && off == s5) {
@@ -3073,10 +3142,9 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 						if (fnd) emit(L.r, si, tag_ppm);
 					}
 					unsigned long long FF = __ballot(fnd);
-					unsigned hit = (unsigned)((FF >> lead) & 63ull);
-					if (hit) { // learnSlotPhase(dec[di]) + resetDecoders()
-						const long long sidx0 = __shfl(L.r.start_idx, lead + __builtin_ctz(hit));
-						if (j == 0) learn_slot(sidx0);
+					if (FF != 0) { // learnSlotPhase(dec[di]) + resetDecoders()
+						const long long sidx0 = __shfl(L.r.start_idx, __builtin_ctzll(FF));
+						learn_slot(sidx0);
 						v2_reset(L.r);
 					}
 					fnd = false;
@@ -3085,18 +3153,22 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 						if (fnd) emit(L.r, si, tag_ppm);
 					}
 					FF = __ballot(fnd);
-					hit = (unsigned)((FF >> lead) & 63ull);
-					if (hit) v2_reset(L.r);
+					if (FF != 0) v2_reset(L.r);
 				}
 			}
+		};
+		{
+#pragma unroll 1
+			for (int g5 = 0; g5 + 5 <= 512; g5 += 5) group(g5, K1Const<1>{});
+			group(510, K1Const<0>{}); // 512 = 102 x 5 + 2
 		}
 		sample_idx += 512;
 		di = (di + 512) % 5;
 		wave_sync();
-		if (live) for (int i = j; i < 16; i += 6) dero[mesh][i] = dero[mesh][512 + i]; // FilterFL17's carry
+		if (lane < 16) dero[lane] = dero[512 + lane]; // FilterFL17's carry
 		wave_sync();
 	}
-	if (live) {
+	if (dl) {
 		DecState* st = q.dec + dec;
 		const DecReg& r = L.r;
 		st->state = r.state; st->lastBit = r.lastBit; st->prev = r.prev; st->position = r.position; st->osc = r.osc;
@@ -3106,12 +3178,12 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 		st->crc[0] = r.crc; st->crc[1] = r.cw; st->crc[2] = (uint32_t)r.cwi; st->crc[3] = r.tail; st->crc[4] = (uint32_t)r.abort_pos;
 		if (j < 5) cs->trk[j] = L.t;
 		if (j == 5) { cs->pll_phase = L.pll_phase; cs->pll_last = L.pll_last; }
-		if (j == 0) {
-			cs->rot = rot; cs->last_f = last_f; cs->ppm = ppm; cs->ppm_prev = ppm_prev; cs->slot_ema = slot_ema; cs->slot_phase = slot_phase;
-			cs->di = di; cs->sample_idx = sample_idx;
-		}
-		for (int i = j; i < 16; i += 6) cs->carry17[i] = dero[mesh][i];
 	}
+	if (lane == 0) {
+		cs->rot = rot; cs->last_f = last_f; cs->ppm = ppm; cs->ppm_prev = ppm_prev; cs->slot_ema = slot_ema; cs->slot_phase = slot_phase;
+		cs->di = di; cs->sample_idx = sample_idx;
+	}
+	if (lane < 16) cs->carry17[lane] = dero[lane];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -4320,7 +4392,7 @@ hipError_t launch_kv2(const KV2Params& p, hipStream_t s, const KV2EParams* engin
 	hipLaunchKernelGGL(kv2_energy, dim3((p.n_chan * (p.n_windows + 1) + 63) / 64), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(kv2_fm, dim3(p.L / 256, p.n_chan), dim3(256), 0, s, p);
 	hipLaunchKernelGGL(kv2_filter, dim3(p.L / 256, p.n_chan), dim3(256), 0, s, p);
-	if (engine) hipLaunchKernelGGL(kv2_engine, dim3((p.n_chan + V2E_NCH - 1) / V2E_NCH), dim3(64), 0, s, *engine); // (reads the look-back: before the carry)
+	if (engine) hipLaunchKernelGGL(kv2_engine, dim3(p.n_chan), dim3(64), 0, s, *engine); // one wave per channel (reads the look-back: before the carry)
 	hipLaunchKernelGGL(kv2_carry, dim3(p.n_chan), dim3(64), 0, s, p);
 	return hipGetLastError();
 }

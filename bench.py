@@ -24,6 +24,8 @@ Prints ONE JSON line (rank 0): metric/value/unit..., plus
   parity_checked -- receivers whose hard bits / levels / ppm of the LAST TIMED block were compared bit for
                     bit with the oracle fed the same block sequence (SURVEY.md 8(d) "parity gates in the
                     same run"); a mismatch makes the run fail (exit status 3)
+  other_configs  -- (default workload, N=1) BASELINE configs[1] and configs[2] timed and parity-gated by this same script
+                    behind the main timed region (20 steps each, own processes): value, ms_per_step, whole_chain_frac
 """
 import argparse
 import json
@@ -353,7 +355,7 @@ def pmc_traffic_pass(config, receivers):
             out = os.path.join(tmp, counter)
             env = dict(os.environ, AISGPU_SERIAL="1", TMPDIR="/tmp")
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
-                   "--config", str(config), "--receivers", str(receivers), "--steps", "3", "--warmup", "1", "--preroll", "2",
+                   "--config", str(config), "--receivers", str(receivers), "--steps", "3", "--warmup", "1", "--preroll", "2", "--no-other-configs",
                    "--no-cpu-baseline", "--parity-receivers", "0", "--no-pmc"]
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             db = None
@@ -383,6 +385,34 @@ def pmc_traffic_pass(config, receivers):
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def other_configs(steps=20, warmup=5):
+    """BASELINE configs[1] (one receiver) and configs[2] (6 MSPS, ModelChallenger, 256 receivers) behind the default workload's timed
+    region and gate: the same code path (this script with --config 2 / 3, the driver's 20-step shape, parity gate on), each in a
+    process of its own so that nothing of the main run is resident beside it.  One short record per config in the line."""
+    out = []
+    for cfg in (2, 3):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--steps", str(steps), "--warmup", str(warmup),
+               "--no-cpu-baseline", "--no-pmc", "--no-other-configs"]
+        rec = {"baseline_config": CONFIGS[cfg]["key"], "steps": steps, "warmup": warmup}
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, text=True)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            d = json.loads(line[-1])
+            r = d["roofline"]
+            rec.update({"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "whole_chain_frac": r["whole_chain_frac"],
+                        "kernel_frac": r["frac"], "kernel_avg_launch_ms": r["avg_launch_ms"], "receivers": d["config"]["receivers_per_gpu"],
+                        "model": d["config"]["model"], "sample_rate": d["config"]["sample_rate"],
+                        "algorithmic_bytes_per_sample": d["config"]["algorithmic_bytes_per_sample"],
+                        "parity_checked": d["parity_checked"], "parity": d["parity"], "exit_status": p.returncode})
+            for k in ("latency_ms_per_block", "realtime_factor"):
+                if k in d:
+                    rec[k] = d[k]
+        except Exception as e:  # the main line must not depend on it
+            rec["error"] = "%s: %s" % (type(e).__name__, e)
+        out.append(rec)
+    return out
 
 
 def free_port():
@@ -454,6 +484,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two short rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--tiles-per-span", type=int, default=0, help="front-end time tiling (0 = the library's choice); experiments")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise the rank launch / sharding / barrier / report path only (CPU tests)")
+    ap.add_argument("--no-other-configs", action="store_true", help="do not time BASELINE configs[1] / configs[2] behind the default workload (other_configs in the line)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -671,6 +702,8 @@ def main():
         res["per_rank"] = per
         res["roofline"]["avg_launch_ms_min_max_over_ranks"] = [min(p_["k1_ms"] for p_ in per), max(p_["k1_ms"] for p_ in per)]
     if rank == 0:
+        if world == 1 and args.config == 4 and not args.no_other_configs and not args.no_pmc and not args.gpu_decode:  # (--no-pmc = the quick form of the tools' A/B loops)
+            res["other_configs"] = other_configs()
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, model=model, rate=rate)
         elif world > 1:

@@ -1,0 +1,13 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "engine_v2 or engine" > gpurun_out/r05_t6_v2tests.log 2>&1; tail -4 gpurun_out/r05_t6_v2tests.log
+KW="model=gpu.MODEL_V2, gpu_decode=True"
+LINES_OUT=6 DISTINCT=1 tools/prof_path.sh v2_b "$KW" 4 256 | grep -E "kv2_engine|kernel " > gpurun_out/r05_t6_v2.txt
+DISTINCT=1 PMC="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES" tools/prof_path.sh v2_pmc "$KW" 2 256 > /dev/null 2>&1
+python - <<'PY' >> gpurun_out/r05_t6_v2.txt 2>&1
+import sqlite3, glob
+db = glob.glob('/tmp/prof_v2_pmc/**/*.db', recursive=True)[0]
+c = sqlite3.connect(db)
+for r in c.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection where kernel_name like '%kv2_engine%' group by kernel_name, counter_name"):
+    print(r[0][:40], r[1], r[2] / r[3])
+PY
+cat gpurun_out/r05_t6_v2.txt
