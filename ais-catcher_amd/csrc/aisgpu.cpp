@@ -193,14 +193,7 @@ struct aisgpu {
 	float* d_fm = nullptr; float* d_fmhist[2] = {}; uint32_t* d_fmbits[2] = {}; uint32_t* h_fmbits = nullptr; // ModelChallenger FM branch
 	float* d_fmfir = nullptr; // [n_chan][L] Filter(Receiver) output of the last downstream block (AISGPU_FLAG_TAPS)
 	EmaState* d_ema[2] = {}; // state before / after the current downstream block (swapped per block)
-	uint32_t* d_pswords[2] = {}; float *d_psma0[2] = {}, *d_psma1[2] = {}; unsigned* d_psfin[2] = {}; int* d_psflag = nullptr; // chunk-parallel PhaseSearch scratch (two sets: ps_split)
-	// ps_split (round 5): k4_assemble leaves the PhaseSearch stream.  Chunk 0 of a block warms up on the previous block's last PS_TAIL symbols
-	// (d_pstail, a ring of three written by k6_window_fir) like every other chunk, so the chunk kernel of block f + 1 needs nothing that
-	// k4_assemble(f) writes: the PhaseSearch stream is the chunk kernels back to back, and assemble(f) follows the derotation / FIR kernel
-	// of block f + 1 on ITS stream (test hook "ps_split" = 0: chunks + assemble one behind the other on the PhaseSearch stream)
-	bool ps_split = false; float2* d_pstail[3] = {}; bool tail_cur_ok = false, tail_prev_ok = false; unsigned k4_count = 0;
-	hipEvent_t ev_k4c[2] = {}, ev_asm[2] = {}; bool asm_used[2] = {};
-	struct { bool valid = false; K4Params k4; int pb = 0, lv = 0, sc = 0, n_groups = 0; long long g0 = 0; unsigned block = 0, sub = 0; } apend;
+	uint32_t* d_pswords = nullptr; float *d_psma0 = nullptr, *d_psma1 = nullptr; unsigned* d_psfin = nullptr; int* d_psflag = nullptr;
 	int ps_warm = 256; bool ps_parallel = true;
 	struct { bool valid = false; int pb = 0, lv = 0, n_groups = 0; long long g0 = 0; unsigned block = 0, sub = 0; } dpend; // frame decoders not yet enqueued (dec_defer)
 	bool dec_defer = false; // the frame decoders of block f are enqueued behind the derotation / FIR kernel of block f+1 (they share its stream)
@@ -492,53 +485,22 @@ int finish_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned 
 	return AISGPU_OK;
 }
 
-// ps_split: k4_assemble of the block whose chunk kernel was enqueued last, on the derotation / FIR stream (behind that kernel of the NEXT
-// block, or the caller's sync); with it everything that follows a block's PhaseSearch (finish_k4)
-int flush_assemble(aisgpu_t* h) {
-	if (!h->apend.valid) return AISGPU_OK;
-	h->apend.valid = false;
-	const int pb = h->apend.pb, lv = h->apend.lv, sc = h->apend.sc;
-	hipStream_t s = h->s4;
-	WAITEV(s, h->ev_k4c[sc]);
-	if (h->asm_used[sc ^ 1]) WAITEV(s, h->ev_asm[sc ^ 1]); // the state chain: the previous block's assemble / sequential search, wherever it ran
-	WAITEV(s, h->ev_ema[lv]); // bits[lv] was last read by the frame decoder / the copies of block f-4
-	{ TraceScope t(h, "assemble", s); HIPCHK(launch_k4_assemble(h->apend.k4, s)); }
-	HIPCHK(hipEventRecord(h->ev_asm[sc], s)); h->asm_used[sc] = true;
-	HIPCHK(hipEventRecord(h->ev_sym[pb], s)); // (the exact fallback inside k4_assemble reads sym[pb] too)
-	return finish_k4(h, pb, lv, h->apend.g0, h->apend.n_groups, h->apend.block, h->apend.sub, s);
-}
-
-// PhaseSearchEMA / PhaseSearch of one downstream block (sym/lvl parity pb) on stream s; split: the caller is the fused back end (ps_split)
-int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s, bool split = false) {
-	K4Params k4;
-	const int sc = (int)(h->k4_count++ & 1);
-	k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[lv]; k4.bits_stride = h->words;
-	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
-	k4.words = h->d_pswords[sc]; k4.ma_start = h->d_psma0[sc]; k4.ma_fin = h->d_psma1[sc]; k4.fin = h->d_psfin[sc]; k4.fb_count = h->d_psflag + 2;
-	k4.n_chains = h->n_chains; k4.n_groups = n_groups;
-	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
-	k4.box_in = h->d_box[pb]; k4.box_out = h->d_box[pb ^ 1]; k4.first_group = g0;
-	if (h->asm_used[sc]) WAITEV(s, h->ev_asm[sc]); // the scratch set: read by k4_assemble of the block before the previous one
-	if (split && h->ps_split && !h->ps_box && h->ps_parallel && k4.n_chunks > 1 && !h->serial) {
-		if (h->tail_prev_ok && h->ps_warm <= PS_TAIL) k4.tail_in = h->d_pstail[(block + 2) % 3]; // the previous block's tail (else: chunk 0 from the true state, which needs assemble(f - 1): same stream order below)
-		if (!k4.tail_in) { int rc = flush_assemble(h); if (rc) return rc; WAITEV(s, h->ev_asm[sc ^ 1]); }
-		HIPCHK(launch_k4_chunks(k4, s));
-		HIPCHK(hipEventRecord(h->ev_k4c[sc], s));
-		{ int rc = flush_assemble(h); if (rc) return rc; } // (normally done already behind this block's derotation / FIR kernel)
-		h->apend.valid = true; h->apend.k4 = k4; h->apend.pb = pb; h->apend.lv = lv; h->apend.sc = sc; h->apend.n_groups = n_groups;
-		h->apend.g0 = g0; h->apend.block = block; h->apend.sub = sub;
-		return AISGPU_OK;
-	}
-	{ int rc = flush_assemble(h); if (rc) return rc; } // (a block that takes the unsplit form behind split ones: their assemble first)
-	if (h->asm_used[sc ^ 1]) WAITEV(s, h->ev_asm[sc ^ 1]); // state_in: written by the previous block's k4_assemble, wherever it ran
+// PhaseSearchEMA / PhaseSearch of one downstream block (sym/lvl parity pb) on stream s
+int enqueue_k4(aisgpu_t* h, int pb, int lv, long long g0, int n_groups, unsigned block, unsigned sub, hipStream_t s) {
 	// bits[lv] was last read by the frame decoder / the copies of block f-4: long done, and ordered here.  (A ring of two made
 	// PhaseSearch(f) wait for the frame decoders of block f-2, which start behind PhaseSearch(f-2): a loop of two steps that
 	// had to hold a PhaseSearch and a decoder pass one after the other -- 0.62 ms per step with the decoders on the device.)
 	WAITEV(s, h->ev_ema[lv]);
+	K4Params k4;
+	k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[lv]; k4.bits_stride = h->words;
+	k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
+	k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.fb_count = h->d_psflag + 2;
+	k4.n_chains = h->n_chains; k4.n_groups = n_groups;
+	k4.n_chunks = (k4.n_groups + PS_CHUNK - 1) / PS_CHUNK; k4.warm = h->ps_warm;
+	k4.box_in = h->d_box[pb]; k4.box_out = h->d_box[pb ^ 1]; k4.first_group = g0;
 	if (h->ps_box) { k4.chunked = h->ps_parallel ? 1 : 0; HIPCHK(launch_k4_box(k4, s)); }
 	else if (h->ps_parallel && k4.n_chunks > 1) HIPCHK(launch_k4(k4, s));
 	else HIPCHK(launch_k4_sequential(k4, s));
-	HIPCHK(hipEventRecord(h->ev_asm[sc], s)); h->asm_used[sc] = true; // (the state of this block is final: what a later split block's chain waits for)
 	HIPCHK(hipEventRecord(h->ev_sym[pb], s));
 	return finish_k4(h, pb, lv, g0, n_groups, block, sub, s);
 }
@@ -679,7 +641,7 @@ int enqueue_fused_back(aisgpu_t* h) {
 		K4Params& k4 = kq.s;
 		k4.sym = h->d_sym[pb]; k4.sym_stride = h->Gcap; k4.bits = h->d_bits[lv]; k4.bits_stride = h->words;
 		k4.state_in = h->d_ema[pb]; k4.state_out = h->d_ema[pb ^ 1];
-		k4.words = h->d_pswords[0]; k4.ma_start = h->d_psma0[0]; k4.ma_fin = h->d_psma1[0]; k4.fin = h->d_psfin[0]; k4.fb_count = h->d_psflag + 2;
+		k4.words = h->d_pswords; k4.ma_start = h->d_psma0; k4.ma_fin = h->d_psma1; k4.fin = h->d_psfin; k4.fb_count = h->d_psflag + 2;
 		k4.n_chains = h->n_chains; k4.n_groups = n_groups; k4.n_chunks = n_chunks; k4.warm = h->ps_warm;
 		k4.box_in = nullptr; k4.box_out = nullptr; k4.first_group = g0;
 		kq.trips_pad = 0;
@@ -690,7 +652,6 @@ int enqueue_fused_back(aisgpu_t* h) {
 		{ int rc = flush_decode(h); if (rc) return rc; } // (dec_defer) the previous block's frame decoders on their stream
 		return finish_k4(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub, s);
 	}
-	if (h->ps_split && !h->challenger && n_groups >= PS_TAIL) k6.tail_out = h->d_pstail[h->fpend.block % 3]; // (read by the next block's chunk 0; its previous content by PhaseSearch of block f-2: ev_sym below)
 	WAITEV(h->s4, h->ev_phasor[q]);
 	WAITEV(h->s4, h->ev_sym[pb]); // sym[pb] was last read by PhaseSearch of block f-2,
 	WAITEV(h->s4, h->ev_ema[lv]); // lvl[lv] by the frame decoder / the copies of block f-4
@@ -708,9 +669,6 @@ int enqueue_fused_back(aisgpu_t* h) {
 	}
 	{ TraceScope t(h, "derotfir", h->s4); HIPCHK(launch_k6(k6, h->s4)); }
 	HIPCHK(hipEventRecord(h->ev_c48free[q], h->s4));
-	h->tail_prev_ok = h->tail_cur_ok; h->tail_cur_ok = k6.tail_out != nullptr;
-	if (!h->challenger) HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4)); // (what this block's PhaseSearch waits for: in front of the previous block's assemble)
-	{ int rc = flush_assemble(h); if (rc) return rc; } // ps_split: k4_assemble of the PREVIOUS block here, off the PhaseSearch stream
 	// Where the device decoders' regrouping of the FM bits runs: behind the derotation / FIR kernel on s4, or (fm_on_s1) in front of
 	// PhaseSearch on s1.  On the resampled ladders s4 also carries the spectral analysis and, with the recurrence on s3 in the middle of
 	// its chain, is the stream that sets the step (BASELINE configs[2]); s1 has the time.
@@ -721,11 +679,11 @@ int enqueue_fused_back(aisgpu_t* h) {
 		HIPCHK(launch_k7_pack(make_k7(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub), fs));
 		if (h->fm_on_s1) { HIPCHK(hipEventRecord(h->ev_fm, h->s1)); h->fm_ev_used = true; }
 	}
-	if (h->challenger && !h->fm_on_s1) HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4));
+	if (!(h->challenger && h->fm_on_s1)) HIPCHK(hipEventRecord(h->ev_k3[pb], h->s4));
 	{ int rc = flush_decode(h); if (rc) return rc; } // (dec_defer) the previous block's frame decoders, behind this block's derotation / FIR kernel
 	WAITEV(h->s1, h->ev_k3[pb]);
 	TraceScope t(h, "psearch", h->s1);
-	return enqueue_k4(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub, h->s1, !h->challenger);
+	return enqueue_k4(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub, h->s1);
 }
 
 int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
@@ -1007,7 +965,6 @@ int gather_frames(aisgpu_t* h) {
 int sync_all(aisgpu_t* h) {
 	{ int rc = enqueue_back(h); if (rc) return rc; }
 	{ int rc = enqueue_fused_back(h); if (rc) return rc; }
-	{ int rc = flush_assemble(h); if (rc) return rc; }
 	{ int rc = flush_decode(h); if (rc) return rc; }
 	HIPCHK(hipStreamSynchronize(h->stream));
 	HIPCHK(hipStreamSynchronize(h->s1));
@@ -1153,7 +1110,7 @@ const char* aisgpu_last_error(aisgpu_t* h) { return h ? h->err.c_str() : ""; }
 
 int aisgpu_set_option(const char* key, const char* value) {
 	if (!key || !*key) return AISGPU_ERR_ARG;
-	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "k46", "ps_split", "trace", "k7e_stats", "k7b_stats" };
+	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "k46", "trace", "k7e_stats", "k7b_stats" };
 	bool ok = false;
 	for (const char* k : known) ok = ok || strcmp(k, key) == 0;
 	if (!ok) return AISGPU_ERR_ARG;
@@ -1608,16 +1565,10 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	{ const int v = opt_int("ps_warm", 0); if (v >= 1 && v <= PS_CHUNK) h->ps_warm = (v + 15) / 16 * 16; } // test hook: small values force the exact fallback
 	if (opt_int("ps_sequential", 0)) h->ps_parallel = false; // test hook: the plain sequential row kernel
 	const size_t n_ma = C * 5 * ps_chunks * 16;
-	h->ps_split = h->fused && !h->challenger && !h->serial && h->s4 != h->s1 && opt_int("ps_split", 1) != 0;
-	for (int i = 0; i < 2; i++) {
-		HIPCHK(dalloc(&h->d_pswords[i], C * 5 * ps_chunks * (PS_CHUNK / 32) * 16));
-		HIPCHK(dalloc(&h->d_psma0[i], n_ma));
-		HIPCHK(dalloc(&h->d_psma1[i], n_ma));
-		HIPCHK(dalloc(&h->d_psfin[i], C * 5 * ps_chunks * 16));
-		HIPCHK(hipEventCreateWithFlags(&h->ev_k4c[i], hipEventDisableTiming));
-		HIPCHK(hipEventCreateWithFlags(&h->ev_asm[i], hipEventDisableTiming));
-	}
-	if (h->ps_split) for (int i = 0; i < 3; i++) HIPCHK(dalloc(&h->d_pstail[i], C * 5 * (size_t)PS_TAIL));
+	HIPCHK(dalloc(&h->d_pswords, C * 5 * ps_chunks * (PS_CHUNK / 32) * 16));
+	HIPCHK(dalloc(&h->d_psma0, n_ma));
+	HIPCHK(dalloc(&h->d_psma1, n_ma));
+	HIPCHK(dalloc(&h->d_psfin, C * 5 * ps_chunks * 16));
 	HIPCHK(dalloc(&h->d_psflag, 4));
 	if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_firtap, C * (8 + h->L)));
 	if (h->v2) {
@@ -1711,13 +1662,7 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_fmprev[0]); hipFree(h->d_fmprev[1]);
 	hipFree(h->d_cgf); hipFree(h->d_omega); hipFree(h->d_step);
 	hipFree(h->d_rotstate); hipFree(h->d_firtap); hipFree(h->d_ppmtab);
-	for (int i = 0; i < 2; i++) {
-		hipFree(h->d_pswords[i]); hipFree(h->d_psma0[i]); hipFree(h->d_psma1[i]); hipFree(h->d_psfin[i]);
-		if (h->ev_k4c[i]) hipEventDestroy(h->ev_k4c[i]);
-		if (h->ev_asm[i]) hipEventDestroy(h->ev_asm[i]);
-	}
-	for (int i = 0; i < 3; i++) hipFree(h->d_pstail[i]);
-	hipFree(h->d_psflag);
+	hipFree(h->d_pswords); hipFree(h->d_psma0); hipFree(h->d_psma1); hipFree(h->d_psfin); hipFree(h->d_psflag);
 	for (int i = 0; i < 2; i++) { if (h->h_in[i]) hipHostFree(h->h_in[i]); if (h->ev_h2d[i]) hipEventDestroy(h->ev_h2d[i]); if (h->ev_in_free[i]) hipEventDestroy(h->ev_in_free[i]); }
 	if (h->sc) { hipStreamSynchronize(h->sc); hipStreamDestroy(h->sc); }
 	if (h->h_bits) hipHostFree(h->h_bits);
@@ -2057,7 +2002,6 @@ int aisgpu_sync_outputs(aisgpu_t* h) {
 	const size_t C = h->n_chan;
 	{ int rc = enqueue_back(h); if (rc) return rc; }
 	{ int rc = enqueue_fused_back(h); if (rc) return rc; }
-	{ int rc = flush_assemble(h); if (rc) return rc; }
 	{ int rc = flush_decode(h); if (rc) return rc; }
 	for (int s = 0; s < h->n_sub; s++) {
 		const SubOut& so = h->sub[s];

@@ -115,7 +115,6 @@ struct K6Params {
 	const float2* hist_in; float2* hist_out;     // [n_chan][DF_HIST]
 	float2* sym; long long sym_stride;           // SymRow layout, sym_stride = group capacity (also the row pitch of lvl)
 	float* lvl;                                   // [n_chan][sym_stride]
-	float2* tail_out = nullptr;                   // optional [n_chan * 5][PS_TAIL]: the last PS_TAIL FIR outputs of every (channel, phase) row once more -- the next block's PhaseSearch warms its first chunk up on them
 	uint32_t* fmbits = nullptr; long long fmbits_stride = 0; float fm_taps[37] = {}; // optional: ModelChallenger's FM branch inside the kernel -- sign of the filtered discriminator, [n_chan][L / 32]
 	float taps[17];
 	long long first_group;
@@ -149,7 +148,6 @@ struct SymRow {
 };
 
 struct EmaState { float ma[16]; unsigned bits[16]; int max_idx, rot; int pad[2]; };
-constexpr int PS_TAIL = 256; // symbols of a row kept for the next block's first chunk (>= the warm-up length)
 
 // Demod::PhaseSearch (boxcar, `-go PS_EMA off`): per chain the |t| ring of the 16 hypotheses (slot-major), the decision
 // shift registers and max_idx
@@ -176,10 +174,6 @@ struct K4Params {
 	// boxcar variant (k4_phase_search_box)
 	const PsBoxState* box_in; PsBoxState* box_out; long long first_group;
 	int* fb_count = nullptr;                 // statistics: workgroups of the exact fallback that really ran (aisgpu_ps_fallbacks)
-	// != nullptr: chunk 0 is speculative like the others -- it warms up on the previous block's last `warm` symbols ([n_chains][PS_TAIL],
-	// symbol -i in front of the block at [PS_TAIL - i]) instead of starting from state_in, and k4_assemble checks it against state_in.  The
-	// chunk kernel then needs nothing the previous block's k4_assemble writes: the two can run side by side (aisgpu.cpp: ps_split)
-	const float2* tail_in = nullptr;
 };
 
 // K7: AIS::Decoder on the device (frame decoder).  One lane per decoder, 12 meshes of 5 decoders per wave.
@@ -375,8 +369,6 @@ hipError_t launch_kv2(const KV2Params& p, hipStream_t s, const KV2EParams* engin
 struct K46Params { K6Params f; K4Params s; int trips_pad; };
 hipError_t launch_k46(K46Params q, hipStream_t st);
 hipError_t launch_k4(const K4Params& p, hipStream_t s);          // chunk-parallel + assemble (with the exact sequential search where a speculative warm-up failed)
-hipError_t launch_k4_chunks(const K4Params& p, hipStream_t s);   // ... the two halves on their own
-hipError_t launch_k4_assemble(const K4Params& p, hipStream_t s);
 hipError_t launch_k4_sequential(const K4Params& p, hipStream_t s); // the plain sequential kernel only
 hipError_t launch_k4_box(const K4Params& p, hipStream_t s);        // Demod::PhaseSearch (boxcar history), sequential
 

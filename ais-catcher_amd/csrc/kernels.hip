@@ -1428,9 +1428,7 @@ __device__ __forceinline__ void k6_window_body(const K6Params& p, int chain, int
 			for (int i = 0; i < 17; i++) acc = acc + win[j + i] * p.taps[i];
 			level = level + (acc.x * acc.x + acc.y * acc.y); // std::norm
 			const float sx = swap ? acc.y : acc.x, sy = swap ? acc.x : acc.y;
-			const float2 out = make_float2(__uint_as_float(__float_as_uint(sx) ^ nx), __uint_as_float(__float_as_uint(sy) ^ ny));
-			srow[(size_t)j * p.sym_stride] = out;
-			if (p.tail_out && gl >= p.n_groups - PS_TAIL) p.tail_out[((size_t)chain * 5 + j) * PS_TAIL + (gl - (p.n_groups - PS_TAIL))] = out;
+			srow[(size_t)j * p.sym_stride] = make_float2(__uint_as_float(__float_as_uint(sx) ^ nx), __uint_as_float(__float_as_uint(sy) ^ ny));
 		}
 		p.lvl[(size_t)chain * p.sym_stride + gl] = __fdiv_rn(level, 5.0f);
 	}
@@ -1907,8 +1905,7 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 	PsWave hs;
 	int idx = k; // trajectory that starts at max_idx == k
 	int start = g0;
-	const bool spec0 = p.tail_in != nullptr; // chunk 0 speculative too: warmed up on the previous block's tail
-	if (chunk == 0 && !spec0) { // the true state
+	if (chunk == 0) { // the true state
 		const EmaState* st = p.state_in + chain;
 		ma = c2{ st->ma[k], st->ma[k] };
 		const unsigned bits = st->bits[k];
@@ -1920,14 +1917,13 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 		start = g0 - p.warm;
 	}
 	const int last_i = (int)p.sym_stride - 1;
-	const float2* tail = spec0 ? p.tail_in + (size_t)chain * PS_TAIL + PS_TAIL : nullptr; // symbol -i in front of the block at tail[-i]
 	float2 r[PS_SB / 16];
 	const auto fetch = [&](int sb) {
 #pragma unroll
 		for (int q = 0; q < PS_SB / 16; q++) {
 			int i = start + sb * PS_SB + q * 16 + k;
 			i = i < last_i ? i : last_i; // (past the chunk's end: any readable sample, it is never used)
-			r[q] = i < 0 ? tail[i] : x[i]; // (i < 0: chunk 0's warm-up only)
+			r[q] = x[i];
 		}
 	};
 	const auto stash = [&](int buf) {
@@ -2047,7 +2043,7 @@ __device__ __forceinline__ bool ps_assemble_rows(const K4Params& p, int chain, i
 			const size_t slot = base + (on ? c : p.n_chunks - 1);
 			f[e] = p.fin[slot * 16 + k];
 			mf[e] = __float_as_uint(p.ma_fin[slot * 16 + k]);
-			ms[e] = (on && (c > 0 || p.tail_in)) ? __float_as_uint(p.ma_start[slot * 16 + k]) : 0u;
+			ms[e] = (on && c > 0) ? __float_as_uint(p.ma_start[slot * 16 + k]) : 0u;
 		}
 		int st_e[AS];
 #pragma unroll
@@ -2056,7 +2052,6 @@ __device__ __forceinline__ bool ps_assemble_rows(const K4Params& p, int chain, i
 			st_e[e] = start;
 			if (c < p.n_chunks) { // wave-uniform
 				if (c > 0) bad = bad || (ms[e] != (e > 0 ? mf[e - 1] : ma_last));
-				else if (p.tail_in) bad = bad || (ms[e] != __float_as_uint(st->ma[k])); // chunk 0 warmed up on the previous block's tail
 				start = __shfl((int)f[e], start, 16) & 15;
 				fin_last = f[e];
 			}
@@ -4479,19 +4474,11 @@ hipError_t launch_k46(K46Params q, hipStream_t st) {
 	return hipGetLastError();
 }
 
-hipError_t launch_k4_chunks(const K4Params& p, hipStream_t s) {
+hipError_t launch_k4(const K4Params& p, hipStream_t s) {
 	if (p.n_groups <= 0) return hipSuccess;
 	hipLaunchKernelGGL(k4_phase_chunks, dim3((p.n_chains / 5 + 3) / 4 * 5, p.n_chunks), dim3(64), 0, s, p);
-	return hipGetLastError();
-}
-hipError_t launch_k4_assemble(const K4Params& p, hipStream_t s) {
-	if (p.n_groups <= 0) return hipSuccess;
 	hipLaunchKernelGGL(k4_assemble, dim3((p.n_chains + 3) / 4), dim3(64), 0, s, p); // + the exact sequential search where a warm-up failed
 	return hipGetLastError();
-}
-hipError_t launch_k4(const K4Params& p, hipStream_t s) {
-	const hipError_t e = launch_k4_chunks(p, s);
-	return e != hipSuccess ? e : launch_k4_assemble(p, s);
 }
 
 } // namespace aisk

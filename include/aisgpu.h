@@ -224,8 +224,6 @@ void aisgpu_timing(aisgpu_t* h, int enable);
  *   "k7b_fcap"      1 .. 4: frames a list of ModelBase's chunk-parallel decoder kernels takes (small values force the exact fallback, k7_base)
  *   "fused"         0: the materialised back end (phasor / derotated-sample arrays in HBM: what AISGPU_FLAG_TAPS uses)
  *   "fft_in_k1"     0: the spectral analysis as FFT + search kernels instead of inside the front-end waves
- *   "ps_split"      0: k4_assemble behind its chunk kernel on the PhaseSearch stream, chunk 0 of a block from the carried state (default: chunk 0
- *                   speculative like the others, on the previous block's last 256 symbols, and k4_assemble on the derotation / FIR stream)
  *   "k46"           1: derotation / FIR and PhaseSearchEMA in one workgroup that keeps the FIR outputs in LDS (k46_window_search, round 5:
  *                   exact, 0.24 GB less traffic per step, measured 5 % slower) instead of k6_window_fir + k4_phase_chunks
  * Returns AISGPU_ERR_ARG for an unknown key. */

@@ -1034,8 +1034,7 @@ def test_fused_backend_1536k(block, nblocks):
     _run_outputs_vs_oracle([synth.to_cu8(xs[0])], 1536000, "cu8", block, nblocks)
 
 
-@pytest.mark.parametrize("env", [{"AISGPU_K46": "1"}, {"AISGPU_K46": "1", "AISGPU_PS_WARM": "16"}, {}, {"AISGPU_PS_WARM": "16"}, {"AISGPU_K46": "1", "AISGPU_SERIAL": "1"},
-                                 {"AISGPU_PS_SPLIT": "0"}, {"AISGPU_PS_SPLIT": "0", "AISGPU_PS_WARM": "16"}, {"AISGPU_PS_WARM": "64"}])
+@pytest.mark.parametrize("env", [{"AISGPU_K46": "1"}, {"AISGPU_K46": "1", "AISGPU_PS_WARM": "16"}, {}, {"AISGPU_PS_WARM": "16"}, {"AISGPU_K46": "1", "AISGPU_SERIAL": "1"}])
 @pytest.mark.parametrize("R,block,nblocks", [(1, 786432, 6), (5, 786432, 3), (2, 491520, 4)])
 def test_fir_and_phase_search_in_one_workgroup(env, R, block, nblocks, monkeypatch):
     """Round 5's fused back end (option k46 = 1; measured slower than the two kernels, so not the default -- profiles/r05_expA_k46.txt):
@@ -1044,9 +1043,7 @@ def test_fir_and_phase_search_in_one_workgroup(env, R, block, nblocks, monkeypat
     workgroup with one or two channels (2, 10 and 4 channels), blocks whose first group begins in the previous block (24,576 samples
     = 4,915.2 groups per block: every alignment within five blocks), a block of exactly three chunks (15,360 samples = 3,072 groups);
     with a 16-symbol warm-up every speculative chunk fails its check and the assembling wave materialises the rows of its
-    channels and searches sequentially; without the option the two-kernel default runs on the same inputs -- by default with k4_assemble
-    off the PhaseSearch stream (ps_split: chunk 0 of a block warms up on the previous block's last 256 symbols and is verified against
-    the carried state like every other chunk; a short warm-up fails that check as well), with ps_split = 0 one behind the other.
+    channels and searches sequentially; without the option the two-kernel default runs on the same inputs.
     Hard bits, levels and ppm of every block against the oracle."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
