@@ -1755,9 +1755,12 @@ int aisgpu_run(aisgpu_t* h) {
 		n_flush = h->next_nflush;
 		{ int rc = stage_resample_run(h, h->run_idx + 1, &h->next_nflush); if (rc) return rc; }
 		h->run_idx++;
-		// the pass below overwrites the pre-decimated block of four runs ago: the flushes of the run before last were its last readers
-		// (a ring of XR = 6 since the resampler front end runs beside the NEXT pass and ends after it: with four, pass g + 2 waited for
-		// the front end of run g -- 0.05 .. 0.2 ms of every step on the front stream)
+		// The pass of run g overwrites ring slot g % XR = the pre-decimated block of run g - XR, whose last reader is the resampler front
+		// end of run g - XR + 2 (as xprev2).  The pass nevertheless waits for the flushes of run g - 2 -- more than the ring of six needs,
+		// and deliberately: with the minimal wait (run g - 4; measured in round 5, A/B on one box) the passes run up to four blocks
+		// ahead of everything behind them, the steady state is the same (0.464-0.466 against 0.463-0.475 ms per step at 6 MSPS: what
+		// separates two passes is the resampler front end's 12,288 workgroups taking the CUs first at every boundary, not this wait) and
+		// a 20-step region drains a longer backlog (0.490-0.498 against 0.479-0.483 ms).
 		WAITEV(h->stream, h->ev_xread[(h->in_blocks + XR - 2) % XR]);
 	}
 
