@@ -25,8 +25,8 @@ GATE = {"checked": 0, "failed": []}
 def run(name, R, rate, block, fmt="cf32", steps=30, **kw):
     """One path: 30 untimed + `steps` timed steps over two resident blocks (one synthetic receiver replicated R times; with
     BENCH_PATHS_DISTINCT=1 and CF32 input the bench line's batch of R DISTINCT receivers, workload.resident_batch), then the
-    SAME parity gate as bench.py on the run that was just timed: the last block's outputs of the first and the last receiver
-    against the oracle fed the same block sequence, bit for bit (hard bits, levels, ppm, FM signs, 48 kHz channels -- whatever
+    SAME parity gate as bench.py on the run that was just timed: the last block's outputs of the first and the last receiver (eight receivers
+    spread over the batch when they are distinct) against the oracle fed the same block sequence, bit for bit (hard bits, levels, ppm, FM signs, 48 kHz channels -- whatever
     the engine hands out)."""
     model = kw.get("model", gpu.MODEL_DEFAULT)
     only = os.environ.get("BENCH_PATHS_ONLY")
@@ -86,7 +86,9 @@ def run(name, R, rate, block, fmt="cf32", steps=30, **kw):
         blocks_of = lambda r: blocks
         if distinct:
             blocks_of = lambda r: [np.ascontiguousarray(data[b, r].cpu().numpy()).view(np.complex64).reshape(-1) for b in range(2)]
-        n, bad = bench.parity_check(g, None, seq, sorted({0, R - 1}), rate=rate, model=model, fmt=fmt, blocks_of=blocks_of, frames=frames, **okw)
+        # replicated receivers are all the same stream: the first and the last say everything; distinct ones: eight spread over the batch
+        gated = sorted({0, R - 1}) if not distinct else sorted(set(int(round(i * (R - 1) / 7.0)) for i in range(8)))
+        n, bad = bench.parity_check(g, None, seq, gated, rate=rate, model=model, fmt=fmt, blocks_of=blocks_of, frames=frames, **okw)
         GATE["checked"] += n
         verdict = ("parity: %d receivers bit-exact%s" % (n, " incl. the NMEA text of %d device frames" % len(frames) if frames is not None else "")) if not bad else "PARITY MISMATCH: " + "; ".join(bad[:4])
         if bad:
