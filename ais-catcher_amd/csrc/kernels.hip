@@ -987,9 +987,8 @@ __global__ __launch_bounds__(64) void k2_fft_mag(K2Params p) {
 // SquareFreqOffsetCorrection::correctFrequency (DSP.cpp:426-456) by ONE WAVE for the windows whose magnitudes it holds in
 // registers (NWIN of them side by side: their dependent chains interleave).  m[w][r] = |X[lane + 64 r]| of window w.
 //  * shifted index q = (bin + 256) % 512 lives at lane q % 64 of register q / 64;
-//  * cumsum[q] = cumsum[q - 1] + mag[q] is evaluated in exactly that order: a chain of 511 dependent additions per window, one
-//    per step of a wave-wide shift (every lane adds its left neighbour's running value; after step k the lanes up to k are
-//    final and stay so).  63 steps per register, 8 registers, the last lane's value carried into the next register;
+//  * cumsum[q] = cumsum[q - 1] + mag[q] is evaluated in exactly that order: a chain of 511 dependent additions per window, by one
+//    lane per window through LDS (round 5; a wave-wide DPP shift-add chain before);
 //  * the 379 candidates of the wide search and the 36 of the second search are then independent: cumsum and magnitudes go
 //    through LDS once (S: 1024 floats per window), every lane evaluates its candidates with the reference's expression, and
 //    "first maximum under a strict >" is a wave reduction (larger value wins, ties go to the lower index; NaN never wins,
@@ -997,49 +996,33 @@ __global__ __launch_bounds__(64) void k2_fft_mag(K2Params p) {
 // Returns fz (DSP.cpp:449-456: N/2 - (i + delta/2), -1 without a positive peak) in every lane.
 template <int NWIN>
 __device__ __forceinline__ void spectral_search(const float (&m)[NWIN][8], float* S, int lane, int wide, int (&fz)[NWIN]) {
-	float M[NWIN][8], C[NWIN][8];
-#pragma unroll
-	for (int w = 0; w < NWIN; w++)
-#pragma unroll
-		for (int q8 = 0; q8 < 8; q8++) M[w][q8] = m[w][(q8 + 4) & 7];
-	float carry[NWIN];
-#pragma unroll
-	for (int q8 = 0; q8 < 8; q8++) {
-		float c[NWIN], mz[NWIN];
-#pragma unroll
-		for (int w = 0; w < NWIN; w++) {
-			mz[w] = lane == 0 ? 0.0f : M[w][q8];                    // lane 0 holds its final value from the start
-			c[w] = q8 == 0 ? 0.0f : carry[w] + M[w][q8];            // cumsum[0] = 0; cumsum[64 k] = cumsum[64 k - 1] + mag[64 k]
-		}
-		if constexpr (NWIN == 2) {
-			// one fused instruction per step and chain: c = shift(c) + mz, lane 0 (no source lane, bound_ctrl off) keeps its value.
-			// A DPP read of a register needs two wait states behind the VALU write of it: the other chain's step and one s_nop.
-			asm volatile("s_nop 1");
-#pragma unroll 3
-			for (int it = 0; it < 63; it++)
-				asm volatile("v_add_f32_dpp %0, %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-				             "v_add_f32_dpp %1, %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-				             "s_nop 0"
-				             : "+v"(c[0]), "+v"(c[1]) : "v"(mz[0]), "v"(mz[1]));
-			asm volatile("s_nop 1");
-		} else {
-#pragma unroll 3
-			for (int it = 0; it < 63; it++) {
-#pragma unroll
-				for (int w = 0; w < NWIN; w++) c[w] = dpp_wave_shr1(c[w], c[w]) + mz[w];
-			}
-		}
-#pragma unroll
-		for (int w = 0; w < NWIN; w++) {
-			C[w][q8] = c[w];
-			carry[w] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c[w]), 63));
-		}
-	}
 	wave_sync(); // the FFT's last exchange has been read
 #pragma unroll
 	for (int w = 0; w < NWIN; w++)
 #pragma unroll
-		for (int q8 = 0; q8 < 8; q8++) { S[1024 * w + lane + 64 * q8] = C[w][q8]; S[1024 * w + 512 + lane + 64 * q8] = M[w][q8]; }
+		for (int q8 = 0; q8 < 8; q8++) S[1024 * w + 512 + lane + 64 * q8] = m[w][(q8 + 4) & 7]; // shifted magnitudes: index q at lane q % 64 of register q / 64
+	wave_sync();
+	// The prefix sum, one LANE per window: cumsum[0] = 0, cumsum[q] = cumsum[q - 1] + mag[q] in exactly that order -- 511 dependent
+	// additions whoever does them.  Rounds 1-4 ran the chain as a wave-wide DPP shift-add (one instruction advances it by one element,
+	// 63 steps per register, two windows interleaved): 3 issue slots per element and window pair, 12 M VALU instructions per launch, an
+	// eighth of the front end's -- and the front end shares its SIMDs' issue slots with PhaseSearch.  A lane that walks its
+	// window through LDS needs 1.5 per element for ALL windows of the wave together (128-bit reads and writes, four additions each).
+	if (lane < NWIN) {
+		float4* Cs4 = reinterpret_cast<float4*>(S + 1024 * lane);
+		const float4* Ms4 = reinterpret_cast<const float4*>(S + 1024 * lane + 512);
+		float c = 0.0f;
+#pragma unroll 4
+		for (int q4 = 0; q4 < 128; q4++) {
+			const float4 v = Ms4[q4];
+			float4 o;
+			o.x = q4 == 0 ? 0.0f : c + v.x; // cumsum[0] = 0 (DSP.cpp:431)
+			o.y = o.x + v.y;
+			o.z = o.y + v.z;
+			o.w = o.z + v.w;
+			c = o.w;
+			Cs4[q4] = o;
+		}
+	}
 	wave_sync();
 	constexpr int BIG = 0x7fffffff;
 #pragma unroll
@@ -1054,7 +1037,7 @@ __device__ __forceinline__ void spectral_search(const float (&m)[NWIN][8], float
 			for (int t = 0; t < 6; t++) {
 				const int i = lane + 64 * t;
 				if (i <= 512 - 134) {
-					const float v = Cs[i + 133] - C[w][t] + 0.6f * (Ms[i + 15] + Ms[i + 117]);
+					const float v = Cs[i + 133] - Cs[i] + 0.6f * (Ms[i + 15] + Ms[i + 117]);
 					if (v > best) { best = v; bi = i; }
 				}
 			}
