@@ -40,14 +40,12 @@ DEC_HD int dec_abort_position(int t) {
 //    answer -- no loop over the frame, no undoing.  A de-stuffed bit advances nothing.
 // DATA_ONLY: the caller guarantees r.state == DST_DATAFCS (k7e_sim: a run leaves TRAINING / STARTFLAG after a few symbols and ends
 // when it leaves DATAFCS) -- the TRAINING / STARTFLAG half of the step folds away
-// NO_DATA: the caller guarantees r.state != DST_DATAFCS (kv2_engine while none of a channel's decoders is inside a frame): the DATAFCS
-// half folds away; the step may OPEN a frame (STARTFLAG -> DATAFCS), it can never complete one
-template <bool DATA_ONLY = false, bool NO_DATA = false>
+template <bool DATA_ONLY = false>
 DEC_HD bool dec_step(DecReg& r, int dd, float slvl, long long sidx, uint32_t* data) {
 	const int Bit = dd == r.prev; // NRZI: !(d ^ prev)
 	r.prev = dd;
 	const int st = DATA_ONLY ? (int)DST_DATAFCS : r.state, pos = r.position, osc = r.osc;
-	const bool isD = !NO_DATA && (DATA_ONLY || st == DST_DATAFCS), isT = !DATA_ONLY && st == DST_TRAINING;
+	const bool isD = DATA_ONLY || st == DST_DATAFCS, isT = !DATA_ONLY && st == DST_TRAINING;
 	// ---- TRAINING: count alternations; two equal bits after more than four of them are the start of a flag
 	const bool alt = Bit != r.lastBit;
 	const bool to_flag = isT && !alt && pos > 4;
@@ -102,6 +100,37 @@ DEC_HD bool dec_step(DecReg& r, int dd, float slvl, long long sidx, uint32_t* da
 	r.lastBit = Bit;
 	if (found) data[64 * r.cwi] = r.cw; // the record is copied out of LDS
 	return found;
+}
+
+// dec_step() for a decoder that is NOT inside a frame (TRAINING or STARTFLAG; Marine/AIS.h:91-181 with state != DATAFCS), as arithmetic
+// on 0 / 1 integers -- no branch, no memory: the step may open a frame (STARTFLAG -> DATAFCS), it can never complete one.  `on` = 0
+// leaves the decoder as it is.  Field by field what dec_step computes for such a decoder (tests/dec_core_fuzz.cpp `idle` checks it against dec_step on random states; the engine's parity tests).
+DEC_HD void dec_step_idle(DecReg& r, int dd, long long sidx, int on) {
+	const int Bit = dd == r.prev;
+	const int pos = r.position, st = r.state;
+	const int isT = st == DST_TRAINING, isS = st == DST_STARTFLAG;
+	const int alt = Bit != r.lastBit;
+	const int to_flag = isT & (alt ^ 1) & (pos > 4);
+	const int at7 = pos == 7;
+	const int open = isS & at7 & (Bit ^ 1);
+	const int more = isS & (at7 ^ 1) & Bit;
+	const int n_state = to_flag | more ? (int)DST_STARTFLAG : (open ? (int)DST_DATAFCS : (int)DST_TRAINING);
+	const int grow = (isT & alt) | more;                       // position + 1
+	const int n_pos = grow ? pos + 1 : (to_flag ? 1 + 2 * Bit : 0);
+	const int n_osc = grow ? r.osc : 0;                        // every NextState() call clears one_seq_count (AIS.cpp:33-37)
+	r.prev = on ? dd : r.prev;
+	r.state = on ? n_state : st;
+	r.position = on ? n_pos : pos;
+	r.osc = on ? n_osc : r.osc;
+	const int op = open & on;
+	r.level = op ? 0.0f : r.level;
+	r.start_idx = (to_flag & on) ? sidx : r.start_idx;
+	r.crc = op ? 0xFFFFu : r.crc;
+	r.tail = op ? 0u : r.tail;
+	r.cw = op ? 0u : r.cw;
+	r.cwi = op ? 0 : r.cwi;
+	r.abort_pos = op ? 0 : r.abort_pos;
+	r.lastBit = on ? Bit : r.lastBit;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -2881,38 +2881,6 @@ __device__ __forceinline__ bool v2_pll(float& phase, int& last_bit, int bit, boo
 	return true;
 }
 __device__ __forceinline__ void v2_reset(DecReg& r) { r.state = DST_TRAINING; r.position = 0; r.osc = 0; }
-// dec_step() for a decoder that is NOT inside a frame (TRAINING or STARTFLAG; Marine/AIS.h:91-181 with state != DATAFCS), as arithmetic
-// on 0 / 1 integers -- no branch, no memory: the step may open a frame (STARTFLAG -> DATAFCS), it can never complete one.  `on` = 0
-// leaves the decoder as it is.  Field by field what dec_step<false, true> computes (tests: the engine's parity tests; dec_core.h).
-__device__ __forceinline__ void v2_dec_idle(DecReg& r, int dd, long long sidx, int on) {
-	const int Bit = dd == r.prev;
-	const int pos = r.position, st = r.state;
-	const int isT = st == DST_TRAINING, isS = st == DST_STARTFLAG;
-	const int alt = Bit != r.lastBit;
-	const int to_flag = isT & (alt ^ 1) & (pos > 4);
-	const int at7 = pos == 7;
-	const int open = isS & at7 & (Bit ^ 1);
-	const int more = isS & (at7 ^ 1) & Bit;
-	const int n_state = to_flag | more ? (int)DST_STARTFLAG : (open ? (int)DST_DATAFCS : (int)DST_TRAINING);
-	const int grow = (isT & alt) | more;                       // position + 1
-	const int n_pos = grow ? pos + 1 : (to_flag ? 1 + 2 * Bit : 0);
-	const int n_osc = grow ? r.osc : 0;                        // every NextState() call clears one_seq_count (AIS.cpp:33-37)
-	const int keep = (on ^ 1);
-	r.prev = on ? dd : r.prev;
-	r.state = on ? n_state : st;
-	r.position = on ? n_pos : pos;
-	r.osc = on ? n_osc : r.osc;
-	const int op = open & on;
-	r.level = op ? 0.0f : r.level;
-	r.start_idx = (to_flag & on) ? sidx : r.start_idx;
-	r.crc = op ? 0xFFFFu : r.crc;
-	r.tail = op ? 0u : r.tail;
-	r.cw = op ? 0u : r.cw;
-	r.cwi = op ? 0 : r.cwi;
-	r.abort_pos = op ? 0 : r.abort_pos;
-	r.lastBit = on ? Bit : r.lastBit;
-	(void)keep;
-}
 
 // Round 5: ONE channel per wave (round 4 had ten channels x six lanes in a wave: 52 waves on a chip of 1,024 SIMDs, every wave as slow
 // as its slowest channel and every roll-back of one channel paid by ten).  What the reference computes block-wise is block-wise here,
@@ -3104,7 +3072,7 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 			const bool in_frame = __ballot(dl && L.r.state == DST_DATAFCS) != 0;
 			bool found = false;
 			if (in_frame) { if (have) found = dec_step(L.r, bit, slvl, sidx, data); }
-			else v2_dec_idle(L.r, bit, sidx, have ? 1 : 0); // (every lane, no branch)
+			else dec_step_idle(L.r, bit, sidx, have ? 1 : 0); // (every lane, no branch)
 			again = j == 5 && (again || (chg_after && (L.r.state == DST_TRAINING) != tr0));
 			// anything that breaks the lockstep -- a completed message (it resets the other five at ITS sample), or an FM decoder that
 			// clocks two symbols inside one group -- sends the channel through the reference's own order, sample by sample

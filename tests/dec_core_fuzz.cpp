@@ -89,6 +89,38 @@ int main(int argc, char** argv) {
 	for (int i = 0; i < 256; i++) dec_crc_table_entry(i, g_tab);
 	std::mt19937 rng(seed);
 	const auto rnd = [&](int lo, int hi) { return lo + (int)(rng() % (unsigned)(hi - lo + 1)); };
+	if (argc > 3 && !strcmp(argv[3], "idle")) {
+		// dec_step_idle (kv2_engine's branch-free step for a decoder that is not inside a frame) against dec_step, field by field: random
+		// TRAINING / STARTFLAG states incl. the ones where a flag starts, continues, opens a frame or falls back, random stale frame
+		// registers (a step that opens a frame must clear them exactly like dec_step), and `on` = 0 (nothing may change)
+		long opened = 0, flagged = 0;
+		for (long t = 0; t < trials; t++) {
+			Dec a;
+			a.r.state = rnd(0, 1) ? (int)DST_TRAINING : (int)DST_STARTFLAG;
+			a.r.lastBit = rnd(0, 1); a.r.prev = rnd(0, 1);
+			a.r.position = a.r.state == DST_STARTFLAG ? rnd(0, 9) : rnd(0, 12);
+			a.r.osc = rnd(0, 7); a.r.level = (float)rnd(0, 1000) * 0.125f; a.r.start_idx = rnd(0, 1 << 30);
+			a.r.crc = (uint32_t)rnd(0, 0xFFFF); a.r.cw = (uint32_t)rng(); a.r.tail = (uint32_t)rnd(0, 127); a.r.cwi = rnd(0, 35); a.r.abort_pos = rnd(0, 448);
+			Dec b = a;
+			const int dd = rnd(0, 1), on = rnd(0, 7) != 0;
+			const long long sidx = rnd(0, 1 << 30);
+			const float slvl = (float)rnd(0, 100);
+			Dec ref = a;
+			bool found = false;
+			if (on) found = dec_step<false>(ref.r, dd, slvl, sidx, ref.data());
+			dec_step_idle(b.r, dd, sidx, on);
+			const DecReg &x = ref.r, &y = b.r;
+			if (found || x.state != y.state || x.lastBit != y.lastBit || x.prev != y.prev || x.position != y.position || x.osc != y.osc || x.level != y.level ||
+			    x.start_idx != y.start_idx || x.crc != y.crc || x.cw != y.cw || x.tail != y.tail || x.cwi != y.cwi || x.abort_pos != y.abort_pos) {
+				printf("MISMATCH at trial %ld (state %d pos %d dd %d on %d)\n", t, a.r.state, a.r.position, dd, on);
+				return 1;
+			}
+			opened += on && y.state == DST_DATAFCS;
+			flagged += on && a.r.state == DST_TRAINING && y.state == DST_STARTFLAG;
+		}
+		printf("idle steps %ld, frames opened %ld, flags started %ld: all equal\n", trials, opened, flagged);
+		return 0;
+	}
 	long n_found = 0, n_cont = 0, n_abort = 0, n_runs = 0;
 	for (long t = 0; t < trials; t++) {
 		// ---- a stream of NRZI bits

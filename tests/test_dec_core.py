@@ -37,6 +37,15 @@ def test_lazy_frame_evaluator_equals_the_step(fuzz_binary):
     assert "all equal" in r.stdout
 
 
+def test_idle_decoder_step_equals_the_step(fuzz_binary):
+    """dec_step_idle -- the branch-free TRAINING / STARTFLAG step kv2_engine takes while no decoder of a channel is inside a frame --
+    against dec_step on random states, field by field (incl. the frame registers a step that opens a frame clears)."""
+    r = subprocess.run([fuzz_binary, "2000000", "7", "idle"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    steps, opened, flagged = (int(v) for v in re.findall(r"\d+", r.stdout)[:3])
+    assert "all equal" in r.stdout and steps == 2000000 and opened > 10000 and flagged > 10000, r.stdout
+
+
 @pytest.fixture(scope="module")
 def scan_binary(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("dec_scan") / "dec_scan_fuzz")
