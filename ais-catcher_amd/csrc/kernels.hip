@@ -1394,9 +1394,18 @@ __device__ __forceinline__ void k6_window_body(const K6Params& p, int chain, int
 	for (int gl = g_lo + lane; gl < g_end; gl += 64) {
 		const int a = p.n_rel0 + 5 * gl - w * 512; // the group's first sample relative to the window: -4 .. 507
 		const float2* wsrc = ybuf + K6_HALO + a - 16;
-		c2 win[21];
+		// the five 17-tap sums of the group advance together over its 21 samples -- each still x += taps[i] * d[i] from i = 0 upwards
+		// (DSP.h:224-230) -- so a sample is dead once its five products are formed: ten accumulator registers instead of a 42-register
+		// window (round 5: the kernel then fits beside a PhaseSearch wave in the registers three front-end waves leave on a SIMD)
+		c2 accs[5] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
 #pragma unroll
-		for (int i = 0; i < 21; i++) { const float2 v = wsrc[i]; win[i] = c2{ v.x, v.y }; }
+		for (int i = 0; i < 21; i++) {
+			const float2 v = wsrc[i];
+			const c2 x = c2{ v.x, v.y };
+#pragma unroll
+			for (int j = 0; j < 5; j++)
+				if (i - j >= 0 && i - j < 17) accs[j] = accs[j] + x * p.taps[i - j];
+		}
 		// PhaseSearchEMA multiplies symbol n of a chain by (1j)^(n & 3) with swaps/negations (Demod.cpp:44-61); every chain has
 		// consumed exactly first_group + gl symbols, so that exact rotation is applied here: rot 1: (-y, x)  rot 2: (-x, -y)  rot 3: (y, -x)
 		const int rsel = (r0sel + gl) & 3;
@@ -1406,9 +1415,7 @@ __device__ __forceinline__ void k6_window_body(const K6Params& p, int chain, int
 		float2* srow = p.sym + sym_row_base(chain, 0, p.sym_stride) + gl;
 #pragma unroll
 		for (int j = 0; j < 5; j++) {
-			c2 acc = { 0.0f, 0.0f };
-#pragma unroll
-			for (int i = 0; i < 17; i++) acc = acc + win[j + i] * p.taps[i];
+			const c2 acc = accs[j];
 			level = level + (acc.x * acc.x + acc.y * acc.y); // std::norm
 			const float sx = swap ? acc.y : acc.x, sy = swap ? acc.x : acc.y;
 			srow[(size_t)j * p.sym_stride] = make_float2(__uint_as_float(__float_as_uint(sx) ^ nx), __uint_as_float(__float_as_uint(sy) ^ ny));
@@ -1418,7 +1425,7 @@ __device__ __forceinline__ void k6_window_body(const K6Params& p, int chain, int
 }
 
 template <bool FM>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FM ? 6 : K6_WAVES, FM ? 6 : K6_WAVES))) void k6_window_fir(K6Params p) { // (the FM form needs 73 registers: six waves per SIMD)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FM ? 6 : K6_WAVES, FM ? 6 : K6_WAVES))) void k6_window_fir(K6Params p) { // (38 / 39 registers since round 5; the FM form's scalar registers allow six waves per SIMD)
 	__shared__ __attribute__((aligned(16))) float2 ybuf[K6_YBUF];
 	__shared__ float s_fm[FM ? FM_HIST + 512 : 1];
 	// id = (((chain / 64) W + w) 8 + chain % 8) 8 + (chain / 8) % 8: the XCD (id % 8) depends on the chain alone, a chain's windows are
