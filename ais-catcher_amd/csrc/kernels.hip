@@ -500,6 +500,10 @@ __global__ __launch_bounds__(K1U_T) void k1u_resample_frontend(K1uParams p) {
 	const int rx = blockIdx.y;
 	const int m0 = blockIdx.x * M;
 	const XRow xr = make_xrow(p, rx); // xr[i]: i relative to the current block start
+	// (the Rotate phasor of this thread's 96 kHz sample is requested here, with the table entries: fetched where it is used it was a
+	// third dependent memory round trip of a latency-bound workgroup)
+	static_assert(2 * M + 15 <= K1U_T, "k1u: one Rotate item per thread");
+	const float2 rot_mine = t < 2 * M + 15 ? p.rot[ROT_HIST + 2 * m0 - 15 + t] : make_float2(0.0f, 0.0f);
 	if constexpr (NPOST >= 1) {
 		// Upsample (DSP.cpp:192-212): output n = (1 - alpha) * x[b - 1] + alpha * x[b], products rounded separately (DSP.cpp:199), (b, alpha) from
 		// the tables.  Round 4: the table entries of ALL of a thread's outputs are requested at once, the input span they point into
@@ -573,7 +577,7 @@ __global__ __launch_bounds__(K1U_T) void k1u_resample_frontend(K1uParams p) {
 			const float2 s2 = cadd(xm2, xv);
 			y = make_float2(p.alpha * s2.x + xm1.x * p.beta, p.alpha * s2.y + xm1.y * p.beta);
 		}
-		const float2 rot = p.rot[ROT_HIST + i];
+		const float2 rot = rot_mine; // (= p.rot[ROT_HIST + i]: q == t, one item per thread)
 		const float RR = y.x * rot.x, II = y.y * rot.y, RI = y.x * rot.y, IR = y.y * rot.x;
 		RU[q] = make_float2(RR - II, IR + RI);
 		RU[RUN + q] = make_float2(RR + II, IR - RI);
