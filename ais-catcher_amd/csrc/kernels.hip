@@ -1988,12 +1988,15 @@ __device__ __forceinline__ void ps_chunk_body(const K4Params& p, int chain, int 
 #define K4_WAVES 8
 #endif
 // Register budget: a SIMD that holds three front-end waves (3 x 136 VGPRs) has 104 registers left; what the PhaseSearch waves
-// are allowed decides how many of them fit into that gap (64: one, 48: two, 32: three) -- i.e. whether they run beside the
-// front end or only in the holes it leaves.
+// are allowed decides how many of them fit into that gap (64: one, 48: two, 32: three).  (The attribute counts architectural VGPRs and
+// LLVM doubles it on targets with the unified register file -- a request above the waves-per-eu limit is silently dropped, which is
+// why rounds 2-4 never saw 48 honoured: hence the / 2.)  Measured in round 5 (profiles/r05_expH_k4_two_waves.txt): with 48 registers and
+// PS_BATCH_ = 4 the loop has no scratch traffic and two of these waves share a SIMD with the front end's three -- and the step does
+// not move (+-0.3 % against the same batch size with 56 registers): it is not PhaseSearch's residency that the step waits for.
 #ifndef K4_NUM_VGPR
 #define K4_NUM_VGPR 64
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K4_WAVES, K4_WAVES))) __attribute__((amdgpu_num_vgpr(K4_NUM_VGPR))) void k4_phase_chunks(K4Params p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K4_WAVES, K4_WAVES))) __attribute__((amdgpu_num_vgpr(K4_NUM_VGPR / 2))) void k4_phase_chunks(K4Params p) {
 	__shared__ __attribute__((aligned(16))) float2 stage[2][4][PS_SB_PAD];
 	const int lane = threadIdx.x;
 	const int k = lane & 15, row = lane >> 4;
