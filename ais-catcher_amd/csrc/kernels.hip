@@ -1764,9 +1764,169 @@ __global__ __launch_bounds__(64) void k4_phase_search_box(K4Params p) {
 // in k4_phase_chunks (lane k: the trajectory that starts at k); k4_assemble selects.  Scratch layout as k4_phase_chunks
 // (words, fin; ma_start / ma_fin are written as zeros so that the verification in k4_assemble is vacuous).
 // ------------------------------------------------------------------------------------------
+// Round 5 (late): the ring in REGISTERS.  The first form kept memory[k][slot] in LDS behind a running slot index -- 13 LDS operations
+// and five ds_bpermute per symbol, 0.6 ms per step beside the front end.  Now a chunk starts where slot 0 is written (its warm-up is
+// 16 .. 27 symbols instead of 16: any look-back of at least 12 gives the exact state), the loop walks twelve symbols per turn and
+// every one of them writes ITS register of r[12]; the sum is the same twelve additions in slot order.  The four neighbours of the
+// candidate search are DPP row rotations (direction probed per wave, ds_bpermute as the fallback, like the EMA search), the decisions
+// live in ballots (PsWave), the samples come through the EMA kernel's LDS staging (one load = 16 symbols of a chain).  Only the
+// block's first chunk, whose ring comes from the previous block with the slot counter wherever it stands, first walks up to eleven
+// symbols with a run-time slot.
 constexpr int BOX_WARM = 16;
-__global__ __launch_bounds__(64) void k4_box_chunks(K4Params p) {
-	__shared__ float mem[64][13]; // [lane][slot], padded
+constexpr int BOX_SB = 48;             // symbols per chain per super-batch: four turns of twelve
+constexpr int BOX_SB_PAD = BOX_SB + 4; // row pitch (as PS_SB_PAD)
+#ifndef BOX_NUM_VGPR
+#define BOX_NUM_VGPR 96
+#endif
+template <int MODE, int D> // the value of lane k + D of the row (D = -2 .. 2)
+__device__ __forceinline__ float box_neighbour(float v, int k) {
+	if constexpr (D == 0) return v;
+	else if constexpr (MODE == 2) return __shfl(v, (k + D + 16) & 15, 16);
+	else { // MODE 0: row_ror:n delivers lane k - n, MODE 1: lane k + n
+		constexpr int n = MODE == 0 ? (16 - D) & 15 : (16 + D) & 15;
+		return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x120 + n, 0xF, 0xF, true));
+	}
+}
+template <int MODE>
+__device__ __forceinline__ void box_chunk_body(const K4Params& p, int chain, int chunk, bool live, int k, int rowbase, int lane,
+                                               float2 (*stage)[4][BOX_SB_PAD]) {
+	const int jj = k < 8 ? k : 15 - k;
+	const float pc = c_ps_phase[jj].x;
+	const float psn = k < 8 ? c_ps_phase[jj].y : -c_ps_phase[jj].y;
+	const int g0 = chunk * PS_CHUNK;
+	const int g1 = g0 + PS_CHUNK < p.n_groups ? g0 + PS_CHUNK : p.n_groups;
+	const size_t slot = (size_t)chain * p.n_chunks + chunk;
+	const int row = rowbase >> 4;
+	const SymRow x(p.sym, chain, p.sym_stride);
+	uint32_t* wout = p.words + slot * (PS_CHUNK / 32) * 16 + k;
+	uint32_t word = 0;
+	float r[12]; // memory[k][slot]: t itself, |t| where it is summed (a source modifier)
+	PsWave hs;
+	int idx = k; // the trajectory that starts at max_idx == k
+	// what follows the ring write of a symbol: average in slot order, the five-candidate first-maximum search for "previous max_idx
+	// == this lane", the hop of the trajectory, the delayed decision of the hypothesis it lands on
+	const auto search = [&]() -> unsigned { // (the ring holds this symbol's t, the ballots the decisions in front of it)
+		float avg = fabsf(r[0]);
+#pragma unroll
+		for (int l = 1; l < 12; l++) avg += fabsf(r[l]);
+		float max_val = 0.0f;
+		int res = k;
+		k1_static_for<0, 5>([&](auto e) {
+			constexpr int d = decltype(e)::value - 2;
+			const float a = box_neighbour<MODE, d>(avg, k);
+			if (a > max_val) { max_val = a; res = (k + d + 16) & 15; }
+		});
+		idx = __shfl(res, idx, 16);
+		const unsigned long long X = hs.h3 ^ hs.h4; // bit(nDelay) XOR bit(nDelay + 1) after this symbol's shift-in
+		return (unsigned)(X >> (rowbase | idx)) & 1u;
+	};
+	const auto finish = [&](float tt, int g) { // one symbol, wherever it stands (warm-up, the turns at a chunk's ends, the first chunk's peel)
+		const unsigned long long dn = __ballot(tt > 0);
+		if (g >= g0) { // wave-uniform
+			const int q = g - g0;
+			word |= search() << (q & 31);
+			if ((q & 31) == 31) {
+				if (live) wout[(q >> 5) * 16] = word;
+				word = 0;
+			}
+		}
+		hs.h4 = hs.h3; hs.h3 = hs.h2; hs.h2 = hs.h1; hs.h1 = dn;
+	};
+	int start;
+	if (chunk == 0) { // the true state; the slot counter stands at first_group % 12
+		const PsBoxState* st = p.box_in + chain;
+#pragma unroll
+		for (int l = 0; l < 12; l++) r[l] = st->mem[l][k];
+		const unsigned bits = st->bits[k];
+		hs.h1 = __ballot((bits & 1u) != 0); hs.h2 = __ballot((bits & 2u) != 0);
+		hs.h3 = __ballot((bits & 4u) != 0); hs.h4 = __ballot((bits & 8u) != 0);
+		const int s0 = (int)(p.first_group % 12);
+		const int peel = (12 - s0) % 12 < g1 ? (12 - s0) % 12 : g1;
+		float2 v[11];
+#pragma unroll
+		for (int e = 0; e < 11; e++) v[e] = x[e < peel ? e : 0];
+#pragma unroll 1
+		for (int e = 0; e < peel; e++) {
+			float2 ve = v[0];
+#pragma unroll
+			for (int i = 1; i < 11; i++) ve = e == i ? v[i] : ve;
+			const float tt = ve.x * pc + ve.y * psn;
+			const int sl = s0 + e;
+#pragma unroll
+			for (int l = 0; l < 12; l++) r[l] = l == sl ? tt : r[l];
+			finish(tt, e);
+		}
+		start = peel;
+	} else { // every slot is rewritten during the warm-up
+#pragma unroll
+		for (int l = 0; l < 12; l++) r[l] = 0.0f;
+		hs.h1 = hs.h2 = hs.h3 = hs.h4 = 0;
+		start = g0 - BOX_WARM;
+		start -= (int)((p.first_group + start) % 12);
+	}
+	const int last_i = (int)p.sym_stride - 1;
+	float2 pre[BOX_SB / 16];
+	const auto fetch = [&](int sb) {
+#pragma unroll
+		for (int q = 0; q < BOX_SB / 16; q++) {
+			int i = start + sb * BOX_SB + q * 16 + k;
+			i = i < last_i ? i : last_i;
+			pre[q] = x[i];
+		}
+	};
+	const auto stash = [&](int buf) {
+#pragma unroll
+		for (int q = 0; q < BOX_SB / 16; q++) stage[buf][row][q * 16 + k] = pre[q];
+	};
+	const int nsb = (g1 - start + BOX_SB - 1) / BOX_SB;
+	if (nsb > 0) { fetch(0); stash(0); }
+	if (nsb > 1) fetch(1);
+#pragma unroll 1
+	for (int sb = 0; sb < nsb; sb++) {
+		const int buf = sb & 1;
+		wave_sync();
+#pragma unroll 1
+		for (int s12 = 0; s12 < BOX_SB; s12 += 12) {
+			const int g = start + sb * BOX_SB + s12;
+			if (g >= g1) break;
+			float2 v[12];
+			{
+				const float4* src = reinterpret_cast<const float4*>(&stage[buf][row][s12]);
+#pragma unroll
+				for (int e = 0; e < 12; e += 2) { const float4 t = src[e >> 1]; v[e] = make_float2(t.x, t.y); v[e + 1] = make_float2(t.z, t.w); }
+			}
+			if (g + 12 <= g1) {
+#pragma unroll
+				for (int e = 0; e < 12; e++) { const float tt = v[e].x * pc + v[e].y * psn; r[e] = tt; finish(tt, g + e); }
+			} else {
+#pragma unroll
+				for (int e = 0; e < 12; e++)
+					if (g + e < g1) { const float tt = v[e].x * pc + v[e].y * psn; r[e] = tt; finish(tt, g + e); } // wave-uniform
+			}
+		}
+		if (sb + 1 < nsb) {
+			stash(buf ^ 1);
+			if (sb + 2 < nsb) fetch(sb + 2);
+		}
+	}
+	const int n = g1 - g0;
+	if ((n & 31) != 0 && live) wout[(n >> 5) * 16] = word;
+	if (live) {
+		const unsigned dec = (unsigned)((hs.h1 >> lane) & 1ull) | ((unsigned)((hs.h2 >> lane) & 1ull) << 1) |
+		                     ((unsigned)((hs.h3 >> lane) & 1ull) << 2) | ((unsigned)((hs.h4 >> lane) & 1ull) << 3);
+		p.ma_fin[slot * 16 + k] = 0.0f;
+		if (chunk > 0) p.ma_start[slot * 16 + k] = 0.0f;
+		p.fin[slot * 16 + k] = (unsigned)(idx & 15) | (dec << 4); // (only the last four decisions can ever be read again)
+		if (chunk == p.n_chunks - 1) { // the block's final float state (max_idx: k4_assemble)
+			PsBoxState* sto = p.box_out + chain;
+#pragma unroll
+			for (int l = 0; l < 12; l++) sto->mem[l][k] = fabsf(r[l]);
+			sto->bits[k] = dec;
+		}
+	}
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(BOX_NUM_VGPR / 2))) void k4_box_chunks(K4Params p) { // (beside three front-end waves a SIMD has 104 registers left)
+	__shared__ __attribute__((aligned(16))) float2 stage[2][4][BOX_SB_PAD];
 	const int lane = threadIdx.x;
 	const int k = lane & 15, row = lane >> 4;
 	const int chunk = blockIdx.y;
@@ -1774,85 +1934,14 @@ __global__ __launch_bounds__(64) void k4_box_chunks(K4Params p) {
 	const int chain_raw = chan * 5 + j;
 	const bool live = chain_raw < p.n_chains;
 	const int chain = live ? chain_raw : p.n_chains - 1;
-	const int jj = k < 8 ? k : 15 - k;
-	const float pc = c_ps_phase[jj].x;
-	const float psn = k < 8 ? c_ps_phase[jj].y : -c_ps_phase[jj].y;
-	const int g0 = chunk * PS_CHUNK;
-	const int g1 = g0 + PS_CHUNK < p.n_groups ? g0 + PS_CHUNK : p.n_groups;
-	const size_t slot = (size_t)chain * p.n_chunks + chunk;
-	const PsBoxState* st = p.box_in + chain;
-	unsigned bits = 0;
-	int start = g0;
-	if (chunk == 0) {
-#pragma unroll
-		for (int l = 0; l < 12; l++) mem[lane][l] = st->mem[l][k];
-		bits = st->bits[k];
-	} else {
-#pragma unroll
-		for (int l = 0; l < 12; l++) mem[lane][l] = 0.0f; // every slot is rewritten during the warm-up
-		start = g0 - BOX_WARM;
-	}
-	int idx = k; // the trajectory that starts at max_idx == k
-	int last = (int)((p.first_group + start) % 12); // every chain has consumed first_group + start symbols
-	const SymRow x(p.sym, chain, p.sym_stride);
-	uint32_t* wout = p.words + slot * (PS_CHUNK / 32) * 16 + k;
-	uint32_t word = 0;
-	const int last_i = (int)p.sym_stride - 1;
-	float2 cur[PS_BATCH];
-#pragma unroll
-	for (int e = 0; e < PS_BATCH; e++) { const int i = start + e; cur[e] = x[i < last_i ? i : last_i]; }
-#pragma unroll 1
-	for (int gb = start; gb < g1; gb += PS_BATCH) {
-		float2 nxt[PS_BATCH];
-#pragma unroll
-		for (int e = 0; e < PS_BATCH; e++) { const int i = gb + PS_BATCH + e; nxt[e] = x[i < last_i ? i : last_i]; }
-#pragma unroll
-		for (int e = 0; e < PS_BATCH; e++) {
-			const int g = gb + e;
-			if (g < g1) { // wave-uniform
-				const float2 v = cur[e]; // already multiplied by (1j)^n
-				const float tt = v.x * pc + v.y * psn;
-				bits = (bits << 1) | (tt > 0 ? 1u : 0u);
-				mem[lane][last] = fabsf(tt);
-				last = last == 11 ? 0 : last + 1;
-				if (g >= g0) {
-					float avg = mem[lane][0];
-#pragma unroll
-					for (int l = 1; l < 12; l++) avg += mem[lane][l];
-					float max_val = 0.0f;
-					int res = k;
-#pragma unroll
-					for (int d = -2; d <= 2; d++) {
-						const float a = __shfl(avg, (k + d + 16) & 15, 16);
-						if (a > max_val) { max_val = a; res = (k + d + 16) & 15; }
-					}
-					idx = __shfl(res, idx, 16);
-					const unsigned b = (unsigned)__shfl((int)bits, idx, 16);
-					const int q = g - g0;
-					word |= (((b >> 4) ^ (b >> 3)) & 1u) << (q & 31);
-					if ((q & 31) == 31) {
-						if (live) wout[(q >> 5) * 16] = word;
-						word = 0;
-					}
-				}
-			}
-		}
-#pragma unroll
-		for (int e = 0; e < PS_BATCH; e++) cur[e] = nxt[e];
-	}
-	const int n = g1 - g0;
-	if ((n & 31) != 0 && live) wout[(n >> 5) * 16] = word;
-	if (live) {
-		p.ma_fin[slot * 16 + k] = 0.0f;
-		if (chunk > 0) p.ma_start[slot * 16 + k] = 0.0f;
-		p.fin[slot * 16 + k] = (unsigned)(idx & 15) | ((bits & 0xffu) << 4);
-		if (chunk == p.n_chunks - 1) { // the block's final float state (max_idx: k4_assemble)
-			PsBoxState* sto = p.box_out + chain;
-#pragma unroll
-			for (int l = 0; l < 12; l++) sto->mem[l][k] = mem[lane][l];
-			sto->bits[k] = bits & 0xffu;
-		}
-	}
+	const int rowbase = row * 16;
+	const int s1 = __builtin_amdgcn_update_dpp(0, k, 0x121, 0xF, 0xF, false), s2 = __builtin_amdgcn_update_dpp(0, k, 0x122, 0xF, 0xF, false);
+	const int s14 = __builtin_amdgcn_update_dpp(0, k, 0x12E, 0xF, 0xF, false), s15 = __builtin_amdgcn_update_dpp(0, k, 0x12F, 0xF, 0xF, false);
+	const bool all_left = __all(s1 == ((k + 15) & 15) && s2 == ((k + 14) & 15) && s14 == ((k + 2) & 15) && s15 == ((k + 1) & 15));
+	const bool all_right = __all(s1 == ((k + 1) & 15) && s2 == ((k + 2) & 15) && s14 == ((k + 14) & 15) && s15 == ((k + 15) & 15));
+	if (all_left) box_chunk_body<0>(p, chain, chunk, live, k, rowbase, lane, stage);
+	else if (all_right) box_chunk_body<1>(p, chain, chunk, live, k, rowbase, lane, stage);
+	else box_chunk_body<2>(p, chain, chunk, live, k, rowbase, lane, stage);
 }
 
 // ------------------------------------------------------------------------------------------

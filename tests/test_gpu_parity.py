@@ -709,7 +709,7 @@ def test_resampled_decimate_by_3_ladder_message_order():
 def test_phase_search_boxcar():
     """`-go PS_EMA off` (a9'): Demod::PhaseSearch with its 12-symbol boxcar instead of PhaseSearchEMA; three block sizes so
     that the ring slot and the decision history cross block boundaries at different phases."""
-    for block, nb, rid in ((131072, 6, 41), (16384, 20, 42), (786432, 2, 43)):
+    for block, nb, rid in ((131072, 6, 41), (16384, 20, 42), (786432, 2, 43), (393216, 5, 44)): # (the last two: chunk-parallel, ring slot 0 / 7 and 0 / 9 / 6 / 3 / 0 at the block starts)
         x = synth.receiver_stream(block * nb, receiver_id=rid, gap_slots=(1, 2))
         _run_gpu_vs_oracle([x, x[::-1].copy()], 1536000, "cf32", block, nb, ps_ema=False)
 
