@@ -76,14 +76,17 @@ struct TraceRec { const char* name; long long block; hipEvent_t a, b; }; // AISG
 #ifndef AISGPU_NBUF
 #define AISGPU_NBUF 4
 #endif
+#ifndef K_DIRECT_MAX
+#define K_DIRECT_MAX 5
+#endif
 constexpr int XR = 6;  // resampled ladders: ring of pre-decimated input blocks (see d_xpre)
 constexpr int NBUF = AISGPU_NBUF;    // ring depth of the buffers that cross from the front-end stream to the others (4 against 3: -1.5 % per step, profiles/r03_expA.txt)
 constexpr int MAXSUB = 4;  // downstream blocks ("flushes" of the resampler) that one input block can complete
 
 // How the samples get from the input rate to the two 48 kHz channels (ModelFrontend::buildModel, Model.cpp:129-346)
 enum Mode {
-	MODE_DIRECT,    // rate == 96k * 2^k, k <= 4: one fused front-end kernel
-	MODE_PRE,       // rate == 96k * 2^k, k = 5..7: (k-4) CIC5 stages in a pre-decimation pass, then the fused kernel
+	MODE_DIRECT,    // rate == 96k * 2^k, k <= 5: one fused front-end kernel
+	MODE_PRE,       // rate == 96k * 2^k, k = 6, 7: (k-4) CIC5 stages in a pre-decimation pass, then the fused kernel
 	MODE_RESAMPLE,  // rate between two buckets: (k-2) CIC5 stages, Upsample to the bucket, DS2_2, DS2_1, ...
 	MODE_96K,       // rate == 96k: no decimation in front of Rotate at all (Model.cpp:332-334)
 	MODE_DSK,       // rate == 288k * 2^k: k CIC5 stages (or a plain conversion), DownsampleKFilter (/3), Rotate, ...
@@ -1189,7 +1192,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		const bool interpolated = buckets[k] != cfg->sample_rate;
 		if (!interpolated) {
 			if (k == 0) { mode = MODE_96K; K = 0; KP = 0; }
-			else if (k <= 4) { mode = MODE_DIRECT; K = k; KP = 0; }
+			else if (k <= K_DIRECT_MAX) { mode = MODE_DIRECT; K = k; KP = 0; } // (3072 kSPS: five stages in the front-end waves since round 5 -- one pass over the input instead of 1 + 1/2 + 1/2)
 			else { mode = MODE_PRE; K = 4; KP = k - 4; }
 		} else {
 			// the resampler sits two CIC5 stages in front of 96 kHz (k == 2: on the input itself; k == 1, the 192k bucket: one stage)

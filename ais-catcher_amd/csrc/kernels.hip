@@ -156,6 +156,7 @@ __device__ __forceinline__ void cic5_dec_chunk_v(T (&v)[2 * NOUT + 4], T (&out)[
 }
 
 template <int C, typename T> struct HaloState;           // shadow registers of one stage (all zero = silence before the stream)
+template <typename T> struct HaloState<32, T> { T p[5]; };
 template <typename T> struct HaloState<16, T> { T p[5]; };
 template <typename T> struct HaloState<8, T> { T p[5]; };
 template <typename T> struct HaloState<4, T> { T p[4], q; };
@@ -214,6 +215,7 @@ template <int C>
 __device__ __forceinline__ void reg_stage(const c2 (&x)[C], HaloState<C, c2>& hs, c2 (&out)[C / 2]) { reg_stage<0, C, c2>(x, hs, out); }
 
 template <int K> struct RegLadder;
+template <> struct RegLadder<5> { HaloState<32, c2> s32; HaloState<16, c2> s16; HaloState<8, c2> s8; HaloState<4, c2> s4; HaloState<2, c2> s2; };
 template <> struct RegLadder<4> { HaloState<16, c2> s16; HaloState<8, c2> s8; HaloState<4, c2> s4; HaloState<2, c2> s2; };
 template <> struct RegLadder<3> { HaloState<8, c2> s8; HaloState<4, c2> s4; HaloState<2, c2> s2; };
 template <> struct RegLadder<2> { HaloState<4, c2> s4; HaloState<2, c2> s2; };
@@ -232,7 +234,11 @@ __device__ __forceinline__ c2 run_fix_ladder(const unsigned (&x)[16], FixLadder&
 
 template <int K>
 __device__ __forceinline__ c2 run_ladder(const c2 (&x)[1 << K], RegLadder<K>& st) {
-	if constexpr (K == 4) {
+	if constexpr (K == 5) { // 3072 kSPS in one pass (round 5, late): 32 samples per lane
+		c2 z[16], a[8], b[4], c[2], d[1];
+		reg_stage<32>(x, st.s32, z); reg_stage<16>(z, st.s16, a); reg_stage<8>(a, st.s8, b); reg_stage<4>(b, st.s4, c); reg_stage<2>(c, st.s2, d);
+		return d[0];
+	} else if constexpr (K == 4) {
 		c2 a[8], b[4], c[2], d[1];
 		reg_stage<16>(x, st.s16, a); reg_stage<8>(a, st.s8, b); reg_stage<4>(b, st.s4, c); reg_stage<2>(c, st.s2, d);
 		return d[0];
@@ -288,7 +294,7 @@ __device__ __forceinline__ void k1_static_for(F&& f) {
 }
 
 template <int K, int FMT, bool PRE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4))) void k1_dpp(K1Params p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 5 ? 2 : K1_WAVES, 4))) void k1_dpp(K1Params p) { // (K = 5: 32 samples per lane, two waves per SIMD with 16 KB tiles)
 	constexpr int C0 = 1 << K;        // input samples per lane per tile
 	constexpr int TILE_IN = 64 * C0;  // input samples per wave-tile
 	constexpr bool DMA = C0 >= 4 && FMT == 0; // tiles come straight from HBM into LDS (global_load_lds), no staging registers
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 	__shared__ __attribute__((aligned(16))) float4 xt[DMA ? 64 * W4 : 1]; // the tile, linear, XOR-swizzled in units of 16 B
 	__shared__ __attribute__((aligned(16))) float2 x5[2][8 + 64];  // rotated up/down with 8 samples of history
 	__shared__ __attribute__((aligned(16))) float2 x6[2][8 + 32];  // DS2_a/b output
-	constexpr bool XFFT_IN_XT = DMA && K == 4; // the FFT tail's exchange / search buffer (8 KB) reuses the tile buffer where that is big enough
+	constexpr bool XFFT_IN_XT = DMA && K >= 4; // the FFT tail's exchange / search buffer (8 KB) reuses the tile buffer where that is big enough
 	__shared__ __attribute__((aligned(16))) float2 xfft[(PRE || XFFT_IN_XT) ? 1 : 1024];
 	const int lane = threadIdx.x;
 	const int rx = blockIdx.y;
@@ -327,18 +333,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES, 4)
 	// The warm-up tile only has to fill the filters: nothing a later tile puts out depends on more than the last 603 input samples
 	// (dependency cone of the whole ladder), so of its 64 lane rows only the last 64 - WARM_SKIP_ROWS are fetched; the first rows
 	// keep whatever the tile buffer held -- the values computed from them are finite-window sums that never reach a stored output.
-	constexpr int WARM_SKIP_E = (DMA && C0 == 16) ? 3 : 0; // 3 of the 8 load instructions = rows 0 .. 23 = 384 of 1024 samples
+	constexpr int WARM_SKIP_E = (DMA && C0 == 16) ? 3 : (DMA && C0 == 32) ? 6 : 0; // 3 of the 8 load instructions = rows 0 .. 23 = 384 of 1024 samples (K = 5: the cone is 2 x 603 + 5 samples; 6 of 16 instructions = rows 0 .. 23 = 768 of 2048)
 	auto prefetch = [&](int tile) {
 		const unsigned char* base;
 		if (tile < 0) base = (const unsigned char*)p.hist + (size_t)rx * TILE_BYTES;
 		else base = (const unsigned char*)p.in + ((size_t)rx * p.in_stride + (size_t)tile * TILE_IN) * fmt_bytes(FMT);
 		if constexpr (DMA) {
-			const uint4* src = (const uint4*)base + dma_r * W4 + dma_q;
 			const bool warm = WARM_SKIP_E > 0 && tile == tile_first; // wave-uniform
+			if constexpr (W4 <= 8) { // an instruction covers a multiple of W4 rows: the row's swizzle term is the same for every e
+				const uint4* src = (const uint4*)base + dma_r * W4 + dma_q;
 #pragma unroll
-			for (int e = 0; e < NV; e++)
-				if (e >= WARM_SKIP_E || !warm)
-					__builtin_amdgcn_global_load_lds((const void*)(src + e * 64), (__attribute__((address_space(3))) void*)(xt + e * 64), 16, 0, K1_LOAD_AUX);
+				for (int e = 0; e < NV; e++)
+					if (e >= WARM_SKIP_E || !warm)
+						__builtin_amdgcn_global_load_lds((const void*)(src + e * 64), (__attribute__((address_space(3))) void*)(xt + e * 64), 16, 0, K1_LOAD_AUX);
+			} else { // W4 = 16 (K = 5): four rows per instruction, row = 4 e + dma_r, so its swizzle term is dma_r ^ 4 (e % 4) (disjoint bits)
+				const uint4* src = (const uint4*)base + dma_r * W4;
+#pragma unroll
+				for (int e = 0; e < NV; e++)
+					if (e >= WARM_SKIP_E || !warm)
+						__builtin_amdgcn_global_load_lds((const void*)(src + e * 64 + (dma_q ^ ((64 / W4 * e) % W4))), (__attribute__((address_space(3))) void*)(xt + e * 64), 16, 0, K1_LOAD_AUX);
+			}
 		} else if constexpr (LANE_BYTES >= 16) {
 			const uint4* src = (const uint4*)base;
 #pragma unroll
@@ -4281,8 +4295,10 @@ struct K1Events { hipEvent_t start = nullptr, stop = nullptr; };
 
 template <int K, int FMT>
 static hipError_t launch_k1_dpp_kf(const K1Params& p, int spans, int n_rx, hipStream_t s, const K1Events& ev) {
-	if (p.pre_out != nullptr) K1_LAUNCH_LDS((k1_dpp<K, FMT, true>), ev, dim3(spans, n_rx), s, p, K1_PRE_EXTRA_LDS);
-	else K1_LAUNCH((k1_dpp<K, FMT, false>), ev, dim3(spans, n_rx), s, p);
+	if constexpr (K < 5) { // (no pre-decimation pass has five stages: that form is not instantiated)
+		if (p.pre_out != nullptr) { K1_LAUNCH_LDS((k1_dpp<K, FMT, true>), ev, dim3(spans, n_rx), s, p, K1_PRE_EXTRA_LDS); return hipGetLastError(); }
+	}
+	K1_LAUNCH((k1_dpp<K, FMT, false>), ev, dim3(spans, n_rx), s, p);
 	return hipGetLastError();
 }
 
@@ -4306,6 +4322,7 @@ static hipError_t launch_k1_dpp_k(const K1Params& p, int fmt, int spans, int n_r
 
 static hipError_t launch_k1_dpp(const K1Params& p, int K, int fmt, int spans, int n_rx, hipStream_t s, const K1Events& ev) {
 	switch (K) {
+	case 5: return p.pre_out != nullptr ? hipErrorInvalidValue : launch_k1_dpp_k<5>(p, fmt, spans, n_rx, s, ev); // (no pre-decimation pass has five stages)
 	case 4: return launch_k1_dpp_k<4>(p, fmt, spans, n_rx, s, ev);
 	case 3: return launch_k1_dpp_k<3>(p, fmt, spans, n_rx, s, ev);
 	case 2: return launch_k1_dpp_k<2>(p, fmt, spans, n_rx, s, ev);

@@ -108,12 +108,14 @@ if __name__ == "__main__":
     run("ModelDefault 1536k CU8, FP_DS (fixed-point ladder)", R, 1536000, B, fmt="cu8", fp_ds=True)
     run("ModelDefault 1536k CS16", R, 1536000, B, fmt="cs16")
     run("ModelDefault 768k CF32 (three CIC5 stages)", R, 768000, B // 2)
-    run("ModelDefault 3072k CF32 (pre-decimation pass)", R // 2, 3072000, B)
+    run("ModelDefault 3072k CF32 (five CIC5 stages in the front-end waves)", R, 3072000, B)
+    run("ModelDefault 3072k CU8", R, 3072000, B, fmt="cu8")
+    run("ModelDefault 6144k CF32 (pre-decimation pass of two stages)", R // 2, 6144000, B * 2)
     run("ModelDefault 6 MSPS CF32 (pre-decimation + resampler K1u)", R, 6000000, B)
     # (the low-rate ladders with as many receivers as make a step of the bench line's size, 1.6 GB of input: 256 receivers are a
     # 0.4 / 0.1 GB step there, which the latency of the kernel chain bounds, not any kernel)
     run("ModelDefault 288k CF32 (decimate-by-3 front end K1k)", R * 4, 288000, 49152 * 4)
-    run("ModelDefault 2400k CF32 (resampled into 3072k)", R // 2, 2400000, B // 2)
+    run("ModelDefault 2400k CF32 (resampled into 3072k)", R, 2400000, B)
     run("ModelDefault mode X 96k CF32 (single channel K1x)", R * 16, 96000, 1024 * 48, mode_x=True)
     run("ModelChallenger 1536k CF32 (fused back end, FM branch inside the derotation / FIR kernel)", R, 1536000, B, model=gpu.MODEL_CHALLENGER)
     run("ModelChallenger 1536k CF32, twenty decoders on the device", R, 1536000, B, model=gpu.MODEL_CHALLENGER, gpu_decode=True)
