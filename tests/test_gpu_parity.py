@@ -1090,6 +1090,10 @@ def test_spectral_analysis_at_the_end_of_the_front_end_waves(tps, env, monkeypat
     xs = [synth.receiver_stream(98304 * 4, receiver_id=120 + r, gap_slots=(0, 2)) for r in range(3)]
     _run_outputs_vs_oracle(xs, 1536000, "cf32", 98304, 4, **kw)       # 96 tiles per block
     _run_outputs_vs_oracle([synth.to_cu8(xs[1])], 1536000, "cu8", 98304, 4, **kw)
+    # 3072 kSPS: five stages in the front-end waves (tiles of 2,048 samples, 16 KB by LDS-DMA for CF32), the same tail behind them
+    x5 = synth.receiver_stream(196608 * 3, sample_rate=3072000, receiver_id=125, gap_slots=(0, 2))
+    _run_outputs_vs_oracle([x5, x5[::-1].copy()], 3072000, "cf32", 196608, 3, **kw)  # 96 tiles per block
+    _run_outputs_vs_oracle([synth.to_cs16(x5)], 3072000, "cs16", 196608, 3, **kw)
     if tps in (16, 0):
         x = synth.receiver_stream(786432 * 2, sample_rate=6144000, receiver_id=123, gap_slots=(1, 2))
         _run_outputs_vs_oracle([x], 6144000, "cf32", 786432, 2, **kw)  # pre-decimation pass in front: 192 tiles of the second pass
@@ -1358,7 +1362,8 @@ def test_extreme_receiver_only_costs_its_own_quad():
 
 @pytest.mark.parametrize("model,rate,fmt,block,nblocks", [(4, 1536000, "cf32", 131072, 12), (4, 1536000, "cu8", 786432, 3), (4, 6000000, "cf32", 786432, 5),
                                                          (0, 1536000, "cf32", 131072, 12), (0, 768000, "cu8", 65536, 20), (0, 288000, "cf32", 49152, 12), (2, 288000, "cf32", 49152, 12), (2, 1536000, "cf32", 131072, 8),
-                                                         (1, 1536000, "cf32", 131072, 12), (1, 1536000, "cu8", 16384, 60), (1, 2400000, "cf32", 393216, 6)])
+                                                         (1, 1536000, "cf32", 131072, 12), (1, 1536000, "cu8", 16384, 60), (1, 2400000, "cf32", 393216, 6),
+                                                         (4, 3072000, "cf32", 262144, 9), (0, 3072000, "cu8", 262144, 9), (1, 3072000, "cf32", 786432, 3), (2, 3072000, "cf32", 262144, 9)]) # (3072 kSPS: five stages in the front-end waves)
 def test_device_decoders_of_the_other_engines(model, rate, fmt, block, nblocks):
     """AISGPU_FLAG_GPU_DECODE beyond ModelDefault: the decoder state machines of ModelChallenger (ten per channel: FM0..FM3,
     the five coherent ones, FM4 per group, any of them resetting the other nine -- Model.cpp:630-674), of ModelStandard (five on
