@@ -76,8 +76,11 @@ struct TraceRec { const char* name; long long block; hipEvent_t a, b; }; // AISG
 #ifndef AISGPU_NBUF
 #define AISGPU_NBUF 4
 #endif
+#ifndef KP_PASS_MAX
+#define KP_PASS_MAX 5
+#endif
 #ifndef K_DIRECT_MAX
-#define K_DIRECT_MAX 5
+#define K_DIRECT_MAX 6
 #endif
 constexpr int XR = 6;  // resampled ladders: ring of pre-decimated input blocks (see d_xpre)
 constexpr int NBUF = AISGPU_NBUF;    // ring depth of the buffers that cross from the front-end stream to the others (4 against 3: -1.5 % per step, profiles/r03_expA.txt)
@@ -85,8 +88,8 @@ constexpr int MAXSUB = 4;  // downstream blocks ("flushes" of the resampler) tha
 
 // How the samples get from the input rate to the two 48 kHz channels (ModelFrontend::buildModel, Model.cpp:129-346)
 enum Mode {
-	MODE_DIRECT,    // rate == 96k * 2^k, k <= 5: one fused front-end kernel
-	MODE_PRE,       // rate == 96k * 2^k, k = 6, 7: (k-4) CIC5 stages in a pre-decimation pass, then the fused kernel
+	MODE_DIRECT,    // rate == 96k * 2^k, k <= 6: one fused front-end kernel
+	MODE_PRE,       // rate == 96k * 2^k, k = 7 (12288 kSPS): three CIC5 stages in a pre-decimation pass, then the fused kernel with four
 	MODE_RESAMPLE,  // rate between two buckets: (k-2) CIC5 stages, Upsample to the bucket, DS2_2, DS2_1, ...
 	MODE_96K,       // rate == 96k: no decimation in front of Rotate at all (Model.cpp:332-334)
 	MODE_DSK,       // rate == 288k * 2^k: k CIC5 stages (or a plain conversion), DownsampleKFilter (/3), Rotate, ...
@@ -1192,7 +1195,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		const bool interpolated = buckets[k] != cfg->sample_rate;
 		if (!interpolated) {
 			if (k == 0) { mode = MODE_96K; K = 0; KP = 0; }
-			else if (k <= K_DIRECT_MAX) { mode = MODE_DIRECT; K = k; KP = 0; } // (3072 kSPS: five stages in the front-end waves since round 5 -- one pass over the input instead of 1 + 1/2 + 1/2)
+			else if (k <= K_DIRECT_MAX) { mode = MODE_DIRECT; K = k; KP = 0; } // (3072 / 6144 kSPS: five / six stages in the front-end waves since round 5 -- one pass over the input instead of 1 + 1/2 + 1/2 / 1 + 1/4 + 1/4)
 			else { mode = MODE_PRE; K = 4; KP = k - 4; }
 		} else {
 			// the resampler sits two CIC5 stages in front of 96 kHz (k == 2: on the input itself; k == 1, the 192k bucket: one stage)
@@ -1268,7 +1271,9 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		h->tiles_per_span = span_tiles(h->tiles_per_block, cfg->n_receivers, cfg->tiles_per_span);
 		h->spans = (h->tiles_per_block + h->tiles_per_span - 1) / h->tiles_per_span;
 	}
-	if (KP > 4) h->KPa = KP - 4; // (only the resampled 12288k bucket: five stages in front of the resampler, Model.cpp:166-172)
+	// (only the resampled 12288k bucket -- 8 / 10 MSPS -- has five stages in front of the resampler, Model.cpp:166-172: one pass of five stages since round 5;
+	// -DKP_PASS_MAX=4 brings back the two passes of rounds 3-4, one stage + four on an intermediate stream of half the input's size)
+	if (KP > KP_PASS_MAX) h->KPa = KP - 4;
 	if (KP > 0) {
 		h->ptile_in = h->tile96 << (h->KPa ? h->KPa : KP);
 		if (cfg->block_len % h->ptile_in) { delete h; return AISGPU_ERR_ARG; }

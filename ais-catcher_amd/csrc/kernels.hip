@@ -156,6 +156,7 @@ __device__ __forceinline__ void cic5_dec_chunk_v(T (&v)[2 * NOUT + 4], T (&out)[
 }
 
 template <int C, typename T> struct HaloState;           // shadow registers of one stage (all zero = silence before the stream)
+template <typename T> struct HaloState<64, T> { T p[5]; };
 template <typename T> struct HaloState<32, T> { T p[5]; };
 template <typename T> struct HaloState<16, T> { T p[5]; };
 template <typename T> struct HaloState<8, T> { T p[5]; };
@@ -215,6 +216,7 @@ template <int C>
 __device__ __forceinline__ void reg_stage(const c2 (&x)[C], HaloState<C, c2>& hs, c2 (&out)[C / 2]) { reg_stage<0, C, c2>(x, hs, out); }
 
 template <int K> struct RegLadder;
+template <> struct RegLadder<6> { HaloState<64, c2> s64; HaloState<32, c2> s32; HaloState<16, c2> s16; HaloState<8, c2> s8; HaloState<4, c2> s4; HaloState<2, c2> s2; };
 template <> struct RegLadder<5> { HaloState<32, c2> s32; HaloState<16, c2> s16; HaloState<8, c2> s8; HaloState<4, c2> s4; HaloState<2, c2> s2; };
 template <> struct RegLadder<4> { HaloState<16, c2> s16; HaloState<8, c2> s8; HaloState<4, c2> s4; HaloState<2, c2> s2; };
 template <> struct RegLadder<3> { HaloState<8, c2> s8; HaloState<4, c2> s4; HaloState<2, c2> s2; };
@@ -234,7 +236,11 @@ __device__ __forceinline__ c2 run_fix_ladder(const unsigned (&x)[16], FixLadder&
 
 template <int K>
 __device__ __forceinline__ c2 run_ladder(const c2 (&x)[1 << K], RegLadder<K>& st) {
-	if constexpr (K == 5) { // 3072 kSPS in one pass (round 5, late): 32 samples per lane
+	if constexpr (K == 6) { // 6144 kSPS in one pass: 64 samples per lane, one wave per SIMD
+		c2 y[32], z[16], a[8], b[4], c[2], d[1];
+		reg_stage<64>(x, st.s64, y); reg_stage<32>(y, st.s32, z); reg_stage<16>(z, st.s16, a); reg_stage<8>(a, st.s8, b); reg_stage<4>(b, st.s4, c); reg_stage<2>(c, st.s2, d);
+		return d[0];
+	} else if constexpr (K == 5) { // 3072 kSPS in one pass (round 5, late): 32 samples per lane
 		c2 z[16], a[8], b[4], c[2], d[1];
 		reg_stage<32>(x, st.s32, z); reg_stage<16>(z, st.s16, a); reg_stage<8>(a, st.s8, b); reg_stage<4>(b, st.s4, c); reg_stage<2>(c, st.s2, d);
 		return d[0];
@@ -294,7 +300,7 @@ __device__ __forceinline__ void k1_static_for(F&& f) {
 }
 
 template <int K, int FMT, bool PRE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 5 ? 2 : K1_WAVES, 4))) void k1_dpp(K1Params p) { // (K = 5: 32 samples per lane, two waves per SIMD with 16 KB tiles)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 6 ? 1 : K == 5 ? 2 : K1_WAVES, 4))) void k1_dpp(K1Params p) { // (K = 5: 32 samples per lane, two waves per SIMD with 16 KB tiles; K = 6: 64, one wave with 32 KB tiles)
 	constexpr int C0 = 1 << K;        // input samples per lane per tile
 	constexpr int TILE_IN = 64 * C0;  // input samples per wave-tile
 	constexpr bool DMA = C0 >= 4 && FMT == 0; // tiles come straight from HBM into LDS (global_load_lds), no staging registers
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 5 ? 2 :
 	// The warm-up tile only has to fill the filters: nothing a later tile puts out depends on more than the last 603 input samples
 	// (dependency cone of the whole ladder), so of its 64 lane rows only the last 64 - WARM_SKIP_ROWS are fetched; the first rows
 	// keep whatever the tile buffer held -- the values computed from them are finite-window sums that never reach a stored output.
-	constexpr int WARM_SKIP_E = (DMA && C0 == 16) ? 3 : (DMA && C0 == 32) ? 6 : 0; // 3 of the 8 load instructions = rows 0 .. 23 = 384 of 1024 samples (K = 5: the cone is 2 x 603 + 5 samples; 6 of 16 instructions = rows 0 .. 23 = 768 of 2048)
+	constexpr int WARM_SKIP_E = (DMA && C0 == 16) ? 3 : (DMA && C0 == 32) ? 6 : (DMA && C0 == 64) ? 12 : 0; // 3 of the 8 load instructions = rows 0 .. 23 = 384 of 1024 samples (K = 5: the cone is 2 x 603 + 5 samples; 6 of 16 instructions = rows 0 .. 23 = 768 of 2048; K = 6: 2,427 samples; 12 of 32 = rows 0 .. 23 = 1,536 of 4,096)
 	auto prefetch = [&](int tile) {
 		const unsigned char* base;
 		if (tile < 0) base = (const unsigned char*)p.hist + (size_t)rx * TILE_BYTES;
@@ -4295,8 +4301,8 @@ struct K1Events { hipEvent_t start = nullptr, stop = nullptr; };
 
 template <int K, int FMT>
 static hipError_t launch_k1_dpp_kf(const K1Params& p, int spans, int n_rx, hipStream_t s, const K1Events& ev) {
-	if constexpr (K < 5) { // (no pre-decimation pass has five stages: that form is not instantiated)
-		if (p.pre_out != nullptr) { K1_LAUNCH_LDS((k1_dpp<K, FMT, true>), ev, dim3(spans, n_rx), s, p, K1_PRE_EXTRA_LDS); return hipGetLastError(); }
+	if constexpr (K < 6) { // (no pre-decimation pass has six stages: that form is not instantiated; five: 8 / 10 MSPS, two waves per SIMD already)
+		if (p.pre_out != nullptr) { K1_LAUNCH_LDS((k1_dpp<K, FMT, true>), ev, dim3(spans, n_rx), s, p, K < 5 ? K1_PRE_EXTRA_LDS : 0); return hipGetLastError(); }
 	}
 	K1_LAUNCH((k1_dpp<K, FMT, false>), ev, dim3(spans, n_rx), s, p);
 	return hipGetLastError();
@@ -4322,7 +4328,8 @@ static hipError_t launch_k1_dpp_k(const K1Params& p, int fmt, int spans, int n_r
 
 static hipError_t launch_k1_dpp(const K1Params& p, int K, int fmt, int spans, int n_rx, hipStream_t s, const K1Events& ev) {
 	switch (K) {
-	case 5: return p.pre_out != nullptr ? hipErrorInvalidValue : launch_k1_dpp_k<5>(p, fmt, spans, n_rx, s, ev); // (no pre-decimation pass has five stages)
+	case 6: return p.pre_out != nullptr ? hipErrorInvalidValue : launch_k1_dpp_k<6>(p, fmt, spans, n_rx, s, ev);
+	case 5: return launch_k1_dpp_k<5>(p, fmt, spans, n_rx, s, ev);
 	case 4: return launch_k1_dpp_k<4>(p, fmt, spans, n_rx, s, ev);
 	case 3: return launch_k1_dpp_k<3>(p, fmt, spans, n_rx, s, ev);
 	case 2: return launch_k1_dpp_k<2>(p, fmt, spans, n_rx, s, ev);

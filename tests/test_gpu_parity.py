@@ -482,7 +482,7 @@ def test_resampled_rates_into_the_384k_bucket(rate, fmt):
 @pytest.mark.parametrize("rate,fmt", [(10000000, "cf32"), (8000000, "cf32"), (10000000, "cu8")])
 def test_resampled_rates_above_6144k(rate, fmt):
     """10 MSPS (Airspy R2) / 8 MSPS: bucket 12288k, FIVE CIC5 stages in front of the resampler (Model.cpp:166-172) -- two
-    pre-decimation passes (1 + 4 stages) -- then Upsample -> DS2_2 -> DS2_1 -> FDC(-2.0)."""
+    pre-decimation passes (1 + 4 stages) in rounds 3-4, ONE pass of five stages (k1_dpp<5, FMT, PRE>) since round 5 -- then Upsample -> DS2_2 -> DS2_1 -> FDC(-2.0)."""
     block = 512 * 256 * 6
     x = synth.receiver_stream(block * 4, sample_rate=rate, receiver_id=53, gap_slots=(1, 2))
     if fmt == "cu8":

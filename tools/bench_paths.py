@@ -110,7 +110,10 @@ if __name__ == "__main__":
     run("ModelDefault 768k CF32 (three CIC5 stages)", R, 768000, B // 2)
     run("ModelDefault 3072k CF32 (five CIC5 stages in the front-end waves)", R, 3072000, B)
     run("ModelDefault 3072k CU8", R, 3072000, B, fmt="cu8")
-    run("ModelDefault 6144k CF32 (pre-decimation pass of two stages)", R // 2, 6144000, B * 2)
+    run("ModelDefault 6144k CF32 (six CIC5 stages in the front-end waves)", R // 2, 6144000, B * 2)
+    run("ModelDefault 12288k CF32 (pre-decimation pass of three stages)", R // 2, 12288000, B * 2)
+    run("ModelDefault 10 MSPS CF32 (Airspy R2: pre-decimation pass of five stages + resampler K1u)", R // 2, 10000000, B * 2)
+    run("ModelDefault 10 MSPS CU8", R // 2, 10000000, B * 2, fmt="cu8")
     run("ModelDefault 6 MSPS CF32 (pre-decimation + resampler K1u)", R, 6000000, B)
     # (the low-rate ladders with as many receivers as make a step of the bench line's size, 1.6 GB of input: 256 receivers are a
     # 0.4 / 0.1 GB step there, which the latency of the kernel chain bounds, not any kernel)
