@@ -46,6 +46,7 @@ struct K1uParams {
 	// CF32 input read where the caller put it (no converted copy): xin = the caller's rows (xin_off = 0), and the samples in front of the
 	// block come from xhist[rx * xhist_len + xhist_len + i], i in [-xhist_len, 0) -- the previous block's tail, kept by the library
 	const float2* xhist = nullptr; int xhist_len = 0;
+	int spw = 1;            // spans (of K1U_M outputs per channel) a workgroup of the resampler front end walks (set by launch_k1u)
 };
 // sample i of the pre-decimated stream relative to the current input block's start (see K1uParams::xprev)
 struct XRow {

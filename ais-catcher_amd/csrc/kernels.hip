@@ -489,6 +489,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 6 ? 1 :
 // ------------------------------------------------------------------------------------------
 constexpr int K1U_T = 320; // threads per workgroup of these front ends: their stages have 2 M + 15 .. 2 M + 19 = 271 .. 275 items at M = 128 -- with 256 threads a
                            // second round for the last 15 .. 19 of them, in the FIR stage of the decimate-by-3 ladder (26 taps) half of the kernel
+#ifndef K1U_MIN_WGS
+#define K1U_MIN_WGS (4 * 1536)
+#endif
+#ifndef K1U_SPW
+#define K1U_SPW 8
+#endif
 constexpr int K1U_M = 128; // 48 kHz outputs per channel per workgroup (every block is a whole number of 512-sample windows, aisgpu.cpp)
 // Round 4: 128, was 32.  With 32 a workgroup's stages had 64 .. 339 items for its 256 threads and six barriers for them -- 85 us per
 // block on the 6 MSPS ladder's front stream, a fifth of the step; the halos are 83 samples per 8 M inputs either way.
@@ -505,6 +511,14 @@ __device__ __forceinline__ float2 cic5_at(const float2* a, int pos2j) { // decim
 // NPOST: CIC5 stages between the resampler and the 96 kHz point -- 2 (buckets 384k ... 12288k), 1 (rates resampled into the 192k
 // bucket: US >> DS2_1, Model.cpp:323-329), 0 (96 kSPS input, no resampler at all: convert >> ROT, Model.cpp:332-334; xin is the
 // converted input itself)
+// LDS-only barrier of a multi-wave workgroup: __syncthreads() also waits for every outstanding global load (s_waitcnt vmcnt(0)), which would
+// drain the next span's prefetch at the first barrier of this span's stages
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Round 5 (late): a workgroup walks p.spw CONSECUTIVE spans of its receiver, and what a span needs from memory -- table entries, Rotate
+// phasor, the staged input span -- is requested one span ahead into registers (the span's bounds two ahead: the input loads depend on
+// them).  Alone the kernel was two dependent round trips and six barriers per 128 outputs, 2 x its instruction floor (60 us per flush of
+// the 6 MSPS ladder, 111 us at 2.4 MSPS); the barriers between the stages wait for LDS only, so the prefetch stays in flight.
 template <int NPOST, int M>
 __global__ __launch_bounds__(K1U_T) void k1u_resample_frontend(K1uParams p) {
 	// One pool, so that the staged input span (XS) can lie over the buffers of the later stages:
@@ -518,108 +532,150 @@ __global__ __launch_bounds__(K1U_T) void k1u_resample_frontend(K1uParams p) {
 	float2* const U = pool; float2* const S1 = pool + UN; float2* const S2 = S1 + S1N; float2* const RU = S2 + S2N; float2* const DD = DD_IN_U ? U : RU + 2 * RUN;
 	const int t = threadIdx.x;
 	const int rx = blockIdx.y;
-	const int m0 = blockIdx.x * M;
 	const XRow xr = make_xrow(p, rx); // xr[i]: i relative to the current block start
-	// (the Rotate phasor of this thread's 96 kHz sample is requested here, with the table entries: fetched where it is used it was a
-	// third dependent memory round trip of a latency-bound workgroup)
 	static_assert(2 * M + 15 <= K1U_T, "k1u: one Rotate item per thread");
-	const float2 rot_mine = t < 2 * M + 15 ? p.rot[ROT_HIST + 2 * m0 - 15 + t] : make_float2(0.0f, 0.0f);
-	if constexpr (NPOST >= 1) {
-		// Upsample (DSP.cpp:192-212): output n = (1 - alpha) * x[b - 1] + alpha * x[b], products rounded separately (DSP.cpp:199), (b, alpha) from
-		// the tables.  Round 4: the table entries of ALL of a thread's outputs are requested at once, the input span they point into
-		// (us_idx is non-decreasing; an upsampler's span is no longer than its outputs) is staged in LDS with coalesced loads, and the
-		// interpolation reads LDS -- two memory round trips per workgroup, not two per 256 outputs (b, then x[b]): the kernel is
-		// latency-bound, 0.10 ms of the 6 MSPS ladder's 0.47 ms step when it meets the pass over the next input block.
-		constexpr int NU = NPOST == 2 ? 8 * M + 83 : 4 * M + 39;          // resampled samples this workgroup needs
-		constexpr int NQ = (NU + K1U_T - 1) / K1U_T;
-		constexpr int XS_CAP = (NPOST == 2 ? S1N : 0) + S2N + 2 * RUN; // the span lies over the later stages' buffers
-		float2* const XS = NPOST == 2 ? S1 : S2;
-		float2* const dst = NPOST == 2 ? U : S1;
-		const int n_lo = NPOST == 2 ? 8 * m0 - 83 : 4 * m0 - 39;
-		int ib[NQ]; float al[NQ];
-#pragma unroll
-		for (int k = 0; k < NQ; k++) {
-			const int q = t + K1U_T * k;
-			ib[k] = q < NU ? p.us_idx[US_HIST + n_lo + q] : 0;
-			al[k] = q < NU ? p.us_alpha[US_HIST + n_lo + q] : 0.0f;
-		}
-		const int lo = p.us_idx[US_HIST + n_lo] - 1, hi = p.us_idx[US_HIST + n_lo + NU - 1];
-		if (hi - lo + 1 <= XS_CAP) {
-			const XSpan x(xr, lo, hi);
-			for (int q = t; q <= hi - lo; q += K1U_T) XS[q] = x[lo + q];
-			__syncthreads();
+	// Upsample (DSP.cpp:192-212): output n = (1 - alpha) * x[b - 1] + alpha * x[b], products rounded separately (DSP.cpp:199), (b, alpha) from
+	// the tables: the entries of ALL of a thread's outputs, and the input span they point into (us_idx is non-decreasing; an upsampler's
+	// span is no longer than its outputs), staged in LDS with coalesced loads; the interpolation reads LDS.
+	constexpr int NU = NPOST == 2 ? 8 * M + 83 : NPOST == 1 ? 4 * M + 39 : 1; // resampled samples a span needs
+	constexpr int NQ = (NU + K1U_T - 1) / K1U_T;
+	constexpr int XS_CAP = NPOST == 0 ? 2 * M + 17 : (NPOST == 2 ? S1N : 0) + S2N + 2 * RUN; // the staged span lies over the later stages' buffers
+	constexpr int NXS = (XS_CAP + K1U_T - 1) / K1U_T;
+	float2* const XS = NPOST == 2 ? S1 : S2;
+	struct Pre { float2 rot; int ib[NQ]; float al[NQ]; int lo, hi; float2 xs[NXS]; };
+	const auto n_lo_of = [&](int m0) { return NPOST == 2 ? 8 * m0 - 83 : NPOST == 1 ? 4 * m0 - 39 : 2 * m0 - 17; };
+	const auto bounds = [&](int m0, int& lo, int& hi) { // the input samples a span touches (NPOST = 0: the span itself)
+		if constexpr (NPOST >= 1) { lo = p.us_idx[US_HIST + n_lo_of(m0)] - 1; hi = p.us_idx[US_HIST + n_lo_of(m0) + NU - 1]; }
+		else { lo = 2 * m0 - 17; hi = 2 * m0 + 2 * M - 1; }
+	};
+	const auto fetch = [&](int m0, int lo, int hi, Pre& q) {
+		q.rot = t < 2 * M + 15 ? p.rot[ROT_HIST + 2 * m0 - 15 + t] : make_float2(0.0f, 0.0f);
+		if constexpr (NPOST >= 1) {
 #pragma unroll
 			for (int k = 0; k < NQ; k++) {
-				const int q = t + K1U_T * k;
-				if (q < NU) { // (dst and XS do not overlap)
-					const float2 a = XS[ib[k] - 1 - lo], b = XS[ib[k] - lo];
-					const float w0 = 1 - al[k];
-					dst[q] = make_float2(w0 * a.x + al[k] * b.x, w0 * a.y + al[k] * b.y);
-				}
+				const int i = t + K1U_T * k;
+				q.ib[k] = i < NU ? p.us_idx[US_HIST + n_lo_of(m0) + i] : 0;
+				q.al[k] = i < NU ? p.us_alpha[US_HIST + n_lo_of(m0) + i] : 0.0f;
 			}
-		} else { // (not an upsampler's table: straight from global memory)
+		}
+		q.lo = lo; q.hi = hi;
+		if (hi - lo + 1 <= XS_CAP) { // (workgroup-uniform)
 			const XSpan x(xr, lo, hi);
 #pragma unroll
-			for (int k = 0; k < NQ; k++) {
-				const int q = t + K1U_T * k;
-				if (q < NU) {
-					const float2 a = x[ib[k] - 1], b = x[ib[k]];
-					const float w0 = 1 - al[k];
-					dst[q] = make_float2(w0 * a.x + al[k] * b.x, w0 * a.y + al[k] * b.y);
-				}
+			for (int k = 0; k < NXS; k++) {
+				const int i = t + K1U_T * k;
+				q.xs[k] = i <= hi - lo ? x[lo + i] : make_float2(0.0f, 0.0f);
 			}
 		}
-		__syncthreads();
+	};
+	const int span0 = blockIdx.x * p.spw;
+	int lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0;
+	Pre cur;
+	{
+		int lo0, hi0;
+		bounds(span0 * M, lo0, hi0);
+		if (p.spw > 1) bounds((span0 + 1) * M, lo1, hi1);
+		fetch(span0 * M, lo0, hi0, cur);
 	}
-	if constexpr (NPOST == 2) {
-		for (int q = t; q < 4 * M + 39; q += K1U_T) { // j = 4 m0 - 39 + q needs u(2j-5..2j): U index 2j - n_lo
-			const int j = 4 * m0 - 39 + q;
-			S1[q] = cic5_at(U, 2 * j - (8 * m0 - 83));
-		}
-		__syncthreads();
-	}
-	if constexpr (NPOST >= 1) {
-		for (int q = t; q < 2 * M + 17; q += K1U_T) { // i = 2 m0 - 17 + q needs s1(2i-5..2i)
-			const int i = 2 * m0 - 17 + q;
-			S2[q] = cic5_at(S1, 2 * i - (4 * m0 - 39));
-		}
-	} else {
-		const XSpan x(xr, 2 * m0 - 17, 2 * m0 + 2 * M);
-		for (int q = t; q < 2 * M + 17; q += K1U_T) S2[q] = x[2 * m0 - 17 + q];
-	}
-	__syncthreads();
-	for (int q = t; q < 2 * M + 15; q += K1U_T) { // i = 2 m0 - 15 + q: FDC (DSP.cpp:283-293) + Rotate (DSP.cpp:296-316)
-		const int i = 2 * m0 - 15 + q;
-		const int si = i - (2 * m0 - 17);
-		const float2 xm2 = S2[si - 2], xm1 = S2[si - 1], xv = S2[si];
-		float2 y = xv;
-		if (p.has_fdc) {
-			const float2 s2 = cadd(xm2, xv);
-			y = make_float2(p.alpha * s2.x + xm1.x * p.beta, p.alpha * s2.y + xm1.y * p.beta);
-		}
-		const float2 rot = rot_mine; // (= p.rot[ROT_HIST + i]: q == t, one item per thread)
-		const float RR = y.x * rot.x, II = y.y * rot.y, RI = y.x * rot.y, IR = y.y * rot.x;
-		RU[q] = make_float2(RR - II, IR + RI);
-		RU[RUN + q] = make_float2(RR + II, IR - RI);
-	}
-	__syncthreads();
-	for (int q = t; q < 2 * (M + 5); q += K1U_T) { // DS2_a / DS2_b: j = m0 - 5 + jj needs up(2j-5..2j)
-		const int ch = q / (M + 5), jj = q % (M + 5);
-		const int j = m0 - 5 + jj;
-		DD[ch * DDN + jj] = cic5_at(RU + ch * RUN, 2 * j - (2 * m0 - 15));
-	}
-	__syncthreads();
-	if (t < 2 * M) { // FilterCIC5 (DSP.cpp:132-157)
-		const int ch = t / M, mm = t % M;
-		float2 v[6];
+#pragma unroll 1
+	for (int sp = 0; sp < p.spw; sp++) {
+		const int m0 = (span0 + sp) * M;
+		Pre nxt = cur;
+		if constexpr (NPOST >= 1) {
+			float2* const dst = NPOST == 2 ? U : S1;
+			const int lo = cur.lo, hi = cur.hi;
+			if (hi - lo + 1 <= XS_CAP) {
 #pragma unroll
-		for (int e = 0; e < 6; e++) v[e] = DD[ch * DDN + mm + e]; // d(m-5 .. m)
+				for (int k = 0; k < NXS; k++) {
+					const int i = t + K1U_T * k;
+					if (i <= hi - lo) XS[i] = cur.xs[k];
+				}
+				// this span's registers are consumed (ib / al / rot stay): the next span's loads go out now and land during the stages below
+				if (sp + 1 < p.spw) fetch(m0 + M, lo1, hi1, nxt);
+				if (sp + 2 < p.spw) bounds(m0 + 2 * M, lo2, hi2);
+				lds_barrier();
 #pragma unroll
-		for (int lvl = 0; lvl < 5; lvl++) {
+				for (int k = 0; k < NQ; k++) {
+					const int i = t + K1U_T * k;
+					if (i < NU) { // (dst and XS do not overlap)
+						const float2 a = XS[cur.ib[k] - 1 - lo], b = XS[cur.ib[k] - lo];
+						const float w0 = 1 - cur.al[k];
+						dst[i] = make_float2(w0 * a.x + cur.al[k] * b.x, w0 * a.y + cur.al[k] * b.y);
+					}
+				}
+			} else { // (not an upsampler's table: straight from global memory)
+				const XSpan x(xr, lo, hi);
 #pragma unroll
-			for (int i = 0; i < 5 - lvl; i++) v[i] = cadd(v[i + 1], v[i]);
+				for (int k = 0; k < NQ; k++) {
+					const int i = t + K1U_T * k;
+					if (i < NU) {
+						const float2 a = x[cur.ib[k] - 1], b = x[cur.ib[k]];
+						const float w0 = 1 - cur.al[k];
+						dst[i] = make_float2(w0 * a.x + cur.al[k] * b.x, w0 * a.y + cur.al[k] * b.y);
+					}
+				}
+				if (sp + 1 < p.spw) fetch(m0 + M, lo1, hi1, nxt);
+				if (sp + 2 < p.spw) bounds(m0 + 2 * M, lo2, hi2);
+			}
+			lds_barrier();
 		}
-		p.c48[((size_t)rx * 2 + ch) * p.c48_stride + m0 + mm] = make_float2(v[0].x * 0.03125f, v[0].y * 0.03125f);
+		if constexpr (NPOST == 2) {
+			for (int q = t; q < 4 * M + 39; q += K1U_T) { // j = 4 m0 - 39 + q needs u(2j-5..2j): U index 2j - n_lo
+				const int j = 4 * m0 - 39 + q;
+				S1[q] = cic5_at(U, 2 * j - (8 * m0 - 83));
+			}
+			lds_barrier();
+		}
+		if constexpr (NPOST >= 1) {
+			for (int q = t; q < 2 * M + 17; q += K1U_T) { // i = 2 m0 - 17 + q needs s1(2i-5..2i)
+				const int i = 2 * m0 - 17 + q;
+				S2[q] = cic5_at(S1, 2 * i - (4 * m0 - 39));
+			}
+		} else {
+#pragma unroll
+			for (int k = 0; k < NXS; k++) {
+				const int i = t + K1U_T * k;
+				if (i < 2 * M + 17) S2[i] = cur.xs[k];
+			}
+			if (sp + 1 < p.spw) fetch(m0 + M, lo1, hi1, nxt);
+			if (sp + 2 < p.spw) bounds(m0 + 2 * M, lo2, hi2);
+		}
+		lds_barrier();
+		for (int q = t; q < 2 * M + 15; q += K1U_T) { // i = 2 m0 - 15 + q: FDC (DSP.cpp:283-293) + Rotate (DSP.cpp:296-316)
+			const int i = 2 * m0 - 15 + q;
+			const int si = i - (2 * m0 - 17);
+			const float2 xm2 = S2[si - 2], xm1 = S2[si - 1], xv = S2[si];
+			float2 y = xv;
+			if (p.has_fdc) {
+				const float2 s2 = cadd(xm2, xv);
+				y = make_float2(p.alpha * s2.x + xm1.x * p.beta, p.alpha * s2.y + xm1.y * p.beta);
+			}
+			const float2 rot = cur.rot; // (= p.rot[ROT_HIST + i]: q == t, one item per thread)
+			const float RR = y.x * rot.x, II = y.y * rot.y, RI = y.x * rot.y, IR = y.y * rot.x;
+			RU[q] = make_float2(RR - II, IR + RI);
+			RU[RUN + q] = make_float2(RR + II, IR - RI);
+		}
+		lds_barrier();
+		for (int q = t; q < 2 * (M + 5); q += K1U_T) { // DS2_a / DS2_b: j = m0 - 5 + jj needs up(2j-5..2j)
+			const int ch = q / (M + 5), jj = q % (M + 5);
+			const int j = m0 - 5 + jj;
+			DD[ch * DDN + jj] = cic5_at(RU + ch * RUN, 2 * j - (2 * m0 - 15));
+		}
+		lds_barrier();
+		if (t < 2 * M) { // FilterCIC5 (DSP.cpp:132-157)
+			const int ch = t / M, mm = t % M;
+			float2 v[6];
+#pragma unroll
+			for (int e = 0; e < 6; e++) v[e] = DD[ch * DDN + mm + e]; // d(m-5 .. m)
+#pragma unroll
+			for (int lvl = 0; lvl < 5; lvl++) {
+#pragma unroll
+				for (int i = 0; i < 5 - lvl; i++) v[i] = cadd(v[i + 1], v[i]);
+			}
+			p.c48[((size_t)rx * 2 + ch) * p.c48_stride + m0 + mm] = make_float2(v[0].x * 0.03125f, v[0].y * 0.03125f);
+		}
+		lds_barrier(); // (the next span's staging overwrites the pool)
+		cur = nxt; lo1 = lo2; hi1 = hi2;
 	}
 }
 
@@ -4344,12 +4400,18 @@ hipError_t launch_k1(const K1Params& p, int K, int fmt, int spans, int n_rx, hip
 }
 
 #define K1U_LAUNCH(kernel_, ...) hipLaunchKernelGGL((kernel_<__VA_ARGS__ K1U_M>), dim3(p.L / K1U_M, n_rx), dim3(K1U_T), 0, s, p)
+#define K1U_LAUNCH_SPW(kernel_, q_, ...) hipLaunchKernelGGL((kernel_<__VA_ARGS__ K1U_M>), dim3(p.L / K1U_M / (q_).spw, n_rx), dim3(K1U_T), 0, s, q_)
 #define K1U_COMMA ,
 
 hipError_t launch_k1u(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
-	if (npost == 2) K1U_LAUNCH(k1u_resample_frontend, 2 K1U_COMMA);
-	else if (npost == 1) K1U_LAUNCH(k1u_resample_frontend, 1 K1U_COMMA);
-	else if (npost == 0) K1U_LAUNCH(k1u_resample_frontend, 0 K1U_COMMA);
+	// spans per workgroup: as many as leave the chip four rounds of workgroups (every flush is a whole number of 512-sample windows = 4 spans)
+	K1uParams q = p;
+	const int spans = p.L / K1U_M;
+	q.spw = K1U_SPW;
+	while (q.spw > 1 && (spans % q.spw != 0 || (long long)(spans / q.spw) * n_rx < K1U_MIN_WGS)) q.spw >>= 1;
+	if (npost == 2) K1U_LAUNCH_SPW(k1u_resample_frontend, q, 2 K1U_COMMA);
+	else if (npost == 1) K1U_LAUNCH_SPW(k1u_resample_frontend, q, 1 K1U_COMMA);
+	else if (npost == 0) K1U_LAUNCH_SPW(k1u_resample_frontend, q, 0 K1U_COMMA);
 	else return hipErrorInvalidValue;
 	return hipGetLastError();
 }
