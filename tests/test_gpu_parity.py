@@ -398,6 +398,18 @@ def test_deep_pure_ladders(rate):
     _run_multi_sub(synth.to_cu8(x), rate, block, 3, fmt="cu8")
 
 
+@pytest.mark.parametrize("rate", [3072000, 6144000])
+def test_deep_ladders_in_one_pass_smallest_blocks(rate):
+    """Five / six CIC5 stages in the front-end waves (k1_dpp<5>, <6>: tiles of 2,048 / 4,096 samples) with blocks of ONE 512-sample
+    window (16 tiles: every span is a single window, the warm-up tile of every block is the previous block's last tile) and of three
+    windows, three receivers of which one is silence and one is reversed; CF32 (LDS-DMA tiles) and CS16 (register path)."""
+    for windows, nb in ((1, 14), (3, 5)):
+        block = 512 * (rate // 48000) * windows
+        x = synth.receiver_stream(block * nb, sample_rate=rate, receiver_id=54 + windows, gap_slots=(0, 1))
+        _run_outputs_vs_oracle([x, np.zeros_like(x), x[::-1].copy()], rate, "cf32", block, nb)
+        _run_outputs_vs_oracle([synth.to_cs16(x)], rate, "cs16", block, nb)
+
+
 @pytest.mark.parametrize("rate", [2000000, 1000000, 2400000])
 def test_other_resampled_rates(rate):
     """Rates whose resampler increment is NOT exactly representable: the host replays the float accumulation."""
