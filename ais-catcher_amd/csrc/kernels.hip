@@ -483,12 +483,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 6 ? 1 :
 // Upsample (linear fractional resampler, DSP/DSP.cpp:192-212) -> DS2_2 -> DS2_1 -> FDC -> Rotate -> DS2_a/b ->
 // FilterCIC5, on the pre-decimated stream written by the PRE pass.  The resampler's (input index, alpha) sequence
 // is data independent and comes as a host-generated table (the float accumulation `alpha += increment` is
-// replayed exactly there), so every output is a pure function of nearby inputs: a workgroup computes a tile of
-// 32 output samples per channel and recomputes the short halos of every stage (no carried state).  This stream
-// carries 1/16 of the input rate, so the kernel is a footnote in the time budget.
+// replayed exactly there), so every output is a pure function of nearby inputs: a span of K1U_M = 128 output samples
+// per channel is computed from scratch, with the short halos of every stage recomputed (no carried state), and a
+// workgroup walks a few consecutive spans with the next one's loads in flight (round 5).  The stream carries 1/16 of
+// the input rate; the kernel is 48 us per flush of the 6 MSPS ladder when alone, a tenth of that step.
 // ------------------------------------------------------------------------------------------
 constexpr int K1U_T = 320; // threads per workgroup of these front ends: their stages have 2 M + 15 .. 2 M + 19 = 271 .. 275 items at M = 128 -- with 256 threads a
                            // second round for the last 15 .. 19 of them, in the FIR stage of the decimate-by-3 ladder (26 taps) half of the kernel
+// spans a workgroup of k1u_resample_frontend walks: at most K1U_SPW, as few as leave K1U_MIN_WGS workgroups (four rounds of a chip that holds
+// 1,536 of them; longer walks measured no better, profiles/r05_expL_resampler_span_walk.txt)
 #ifndef K1U_MIN_WGS
 #define K1U_MIN_WGS (4 * 1536)
 #endif
