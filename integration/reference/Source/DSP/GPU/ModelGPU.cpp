@@ -2,6 +2,7 @@
  * Source/DSP/GPU/ModelGPU.cpp -- see ModelGPU.h.  Reference-side binding of libaisgpu.so; test infrastructure of the
  * MI355X repository (compiled by oracle/Makefile against the unmodified reference), not part of its product libraries.
  */
+#include <algorithm>
 #include <stdexcept>
 
 #include "ModelGPU.h"
@@ -161,9 +162,31 @@ namespace AIS
 		}
 	}
 
+	// One block of the context's size through the batch: copies it (it is only borrowed, Device/FileRAW.cpp:131-136), meets the other
+	// receivers of the batch, returns when the whole batch has been through the GPU, then replays this receiver's outputs.
+	bool GpuChain::runBlock(const void *iq, TAG &tag)
+	{
+		const int rc = batch->submitAndWait(rx, iq, block_bytes / sample_bytes);
+		if (rc != AISGPU_OK)
+		{
+			failed = true; // the reference logs and stops (Device/FileRAW.cpp:111-115)
+			Error() << "GPU model: " << aisgpu_strerror(rc) << ": " << batch->lastError();
+			StopRequest();
+			return false;
+		}
+		deliver(tag);
+		return !failed;
+	}
+
+	// A device does not promise one block size per call.  RAWFile hands over `nblocks * fifo.BlockSize()` bytes with nblocks = 1 or 2
+	// depending on how far its reader thread got (Device/FileRAW.cpp:120-136, Library/FIFO.h:99-109); the SDR devices send whatever
+	// their FIFO holds.  The GPU context works on blocks of ONE size, so the chain re-blocks: whole blocks go straight from the
+	// caller's buffer, a remainder waits in `carry` for the next call.  What comes out equals the reference's own chain driven with
+	// calls of that block size (the one thing a call boundary changes in the arithmetic is where Rotate renormalises its phasor,
+	// DSP/DSP.cpp:315 -- in the reference itself that depends on the reader thread's timing).
 	void GpuChain::Receive(const RAW *raw, int len, TAG &tag)
 	{
-		if (failed || len != 1 || !group) return;
+		if (failed || len != 1 || !group || raw->size <= 0) return;
 		int fmt = 0, bytes = 0;
 		switch (raw->format)
 		{
@@ -174,21 +197,40 @@ namespace AIS
 		default:
 			throw std::runtime_error("GPU model: input format not supported (CU8, CS8, CS16, CF32)");
 		}
-		// the device hands over blocks of one size (Device/FileRAW.h:43, Device/RTLSDR.h:57); the first block of the group creates its
-		// context (throws like the reference's models do at set-up, Model.cpp:109-110)
-		if (!batch) batch = GpuPool::instance().open(group, raw->size / bytes, fmt);
-
-		// copies the block (it is only borrowed, Device/FileRAW.cpp:131-136), meets the other receivers of the batch, returns when the
-		// whole batch has been through the GPU
-		const int rc = batch->submitAndWait(rx, raw->data, raw->size / bytes);
-		if (rc != AISGPU_OK)
+		if (!batch)
 		{
-			failed = true; // the reference logs and stops (Device/FileRAW.cpp:111-115)
-			Error() << "GPU model: " << aisgpu_strerror(rc) << ": " << batch->lastError();
-			StopRequest();
-			return;
+			// The block of the group's context: what `GpuPool::setBlockBytes` asked for; else the file reader's FIFO block when the
+			// device is one and this call is a whole number of them (Device/FileRAW.h:43: 24 * 16 * 16384 bytes, whether this first
+			// call carries one or two); else the size of this first call (the SDR devices' callbacks, Device/RTLSDR.h:57).  The
+			// first block of the group creates the context (throws like the reference's models do at set-up, Model.cpp:109-110).
+			static const int RAWFILE_FIFO_BLOCK = 24 * 16 * 16384;
+			block_bytes = GpuPool::instance().blockBytes();
+			if (block_bytes <= 0) block_bytes = (device_type == Type::RAWFILE && raw->size % RAWFILE_FIFO_BLOCK == 0) ? RAWFILE_FIFO_BLOCK : raw->size;
+			if (block_bytes % bytes) throw std::runtime_error("GPU model: block size is not a whole number of samples");
+			sample_bytes = bytes;
+			format = fmt;
+			batch = GpuPool::instance().open(group, block_bytes / bytes, fmt);
+			carry.reserve(block_bytes);
 		}
-		deliver(tag);
+		else if (fmt != format)
+			throw std::runtime_error("GPU model: the input format changed between blocks");
+
+		const char *p = (const char *)raw->data;
+		size_t left = (size_t)raw->size;
+		if (!carry.empty())
+		{ // complete the block a previous call began
+			const size_t take = std::min(left, (size_t)block_bytes - carry.size());
+			carry.insert(carry.end(), p, p + take);
+			p += take;
+			left -= take;
+			if (carry.size() < (size_t)block_bytes) return;
+			const bool ok = runBlock(carry.data(), tag);
+			carry.clear();
+			if (!ok) return;
+		}
+		for (; left >= (size_t)block_bytes; p += block_bytes, left -= block_bytes)
+			if (!runBlock(p, tag)) return;
+		carry.insert(carry.end(), p, p + left);
 	}
 
 	void GpuChain::Flush(TAG &tag)
@@ -257,6 +299,7 @@ namespace AIS
 	void ModelDefaultGPU::buildFrontend(int sample_rate, bool timerOn, Device::Device *dev, int model)
 	{
 		device = dev;
+		chain.device_type = dev ? dev->getDriver() : Type::NONE;
 		if (mode != Mode::AB && mode != Mode::CD) throw std::runtime_error("GPU model: channel modes AB / CD only");
 		if (sample_rate < 96000 || sample_rate > 12288000)
 			throw std::runtime_error("Model: sample rate must be between 96K and 12288K (inclusive)."); // Model.cpp:109-110

@@ -53,7 +53,7 @@ namespace AIS
 		std::mutex mtx;
 		std::vector<Group *> groups;
 		bool pipelined = false, gpu_decode = false;
-		int timeout_ms = 10000;
+		int timeout_ms = 10000, block_bytes = 0;
 
 	public:
 		static GpuPool &instance();
@@ -71,6 +71,9 @@ namespace AIS
 		void setGpuDecode(bool b) { std::lock_guard<std::mutex> l(mtx); gpu_decode = b; }
 		void setTimeout(int ms) { std::lock_guard<std::mutex> l(mtx); timeout_ms = ms; }
 		bool gpuDecode() { std::lock_guard<std::mutex> l(mtx); return gpu_decode; }
+		// bytes per GPU block (`-go GPU_BLOCK n` of the patched Receiver); 0 = by the device (GpuChain::Receive)
+		void setBlockBytes(int n) { std::lock_guard<std::mutex> l(mtx); block_bytes = n; }
+		int blockBytes() { std::lock_guard<std::mutex> l(mtx); return block_bytes; }
 	};
 
 	// The tail of AIS::Decoder::Run for a frame whose bits the GPU decoders collected (Marine/AIS.h:150-163: tag.level, end_idx,
@@ -79,8 +82,9 @@ namespace AIS
 	// compiles this one translation unit with -fno-access-control instead, so that the reference stays unmodified.
 	void GpuEmitFrame(Decoder &d, const aisgpu_frame &f, TAG &tag);
 
-	// StreamIn<RAW> in place of Util::ConvertRAW and everything behind it: the device block goes to the GPU as it is (CU8, CS8,
-	// CS16 and CF32 are converted inside the front-end kernel); the symbol decisions come back and are replayed into the
+	// StreamIn<RAW> in place of Util::ConvertRAW and everything behind it: the device's bytes go to the GPU as they are (CU8, CS8,
+	// CS16 and CF32 are converted inside the front-end kernel), cut into blocks of the context's size whatever the size of the
+	// device's calls (RAWFile hands over one OR two FIFO blocks per call, Device/FileRAW.cpp:120-136); the symbol decisions come back and are replayed into the
 	// decoders in the reference's order (channel A's whole block first, DSP/DSP.cpp:312-313; per group the phases 0..4 with
 	// tag.sample_idx / tag.sample_lvl / tag.ppm as ScatterPLL and the CGF set them, DSP/DSP.h:95-117, DSP/DSP.cpp:484).
 	class GpuChain : public StreamIn<RAW>
@@ -89,7 +93,12 @@ namespace AIS
 		aisamd::GpuBatch *batch = nullptr;
 		int rx = 0;
 		bool failed = false;
+		// re-blocking (Receive): the context's block in bytes, bytes per IQ sample, the AISGPU_FMT_* of the stream, and the part of
+		// the next block that earlier calls left behind
+		int block_bytes = 0, sample_bytes = 0, format = 0;
+		std::vector<char> carry;
 
+		bool runBlock(const void *iq, TAG &tag);
 		void deliver(TAG &tag);
 		void replay(Connection<FLOAT32> *out, const aisgpu_out &o, TAG &tag, int n0, int n1);
 		void replayChallenger(Connection<FLOAT32> *coh, Connection<FLOAT32> *fm, const aisgpu_out &o, TAG &tag, int n0, int n1);
@@ -101,6 +110,7 @@ namespace AIS
 		Connection<FLOAT32> outFMa, outFMb;											  // ModelBase / ModelStandard: FR_a / FR_b .out (Model.cpp:431-432, 495-496), sign only
 		// AISGPU_FLAG_GPU_DECODE: decoder of (channel, phase) -- phase 5..9: ModelChallenger's FM decoders -- set by the model
 		Decoder *dec[2][2 * N_SAMPLES_PER_SYMBOL] = {};
+		Type device_type = Type::NONE; // the device's driver (Device::getDriver), set by the model: picks the block size for the file reader
 
 		virtual ~GpuChain();
 		void join(const aisgpu_cfg &c) { group = GpuPool::instance().reserve(c, rx); }

@@ -26,6 +26,7 @@
 
 #include "Model.h"
 #include "Device.h"
+#include "FileRAW.h" // the reference's own file reader (Device/FileRAW.cpp: reader thread + FIFO + run thread), for ref_create_file()
 #include "Filters.h"
 #ifdef HASMI355X
 #include "ModelGPU.h" // the reference-side binding of libaisgpu.so (integration/reference/Source/DSP/GPU): engines 12 / 14
@@ -79,8 +80,16 @@ struct MsgSink : public StreamIn<AIS::Message> {
 	}
 };
 
+struct CallCounter : public StreamIn<RAW> { // what the device's calls looked like
+	int calls = 0, max_size = 0;
+	void Receive(const RAW* r, int len, TAG&) { calls++; if (r->size > max_size) max_size = r->size; }
+};
+
 struct Harness {
-	Device::Device dev;
+	CallCounter cc;
+	Device::Device stub;
+	Device::RAWFile* file = nullptr; // ref_create_file(): the model hangs on the reference's real RAWFile instead of the stub
+	Device::Device& dev;
 	AIS::ModelDefault* md = nullptr;
 	AIS::ModelChallenger* mc = nullptr;
 	AIS::ModelBase* mb = nullptr;
@@ -103,7 +112,7 @@ struct Harness {
 	double seconds = 0;
 	bool taps_connected = false, ftap_connected = false;
 
-	Harness(Format f, int rate) : dev(f, rate, Type::RAWFILE, "stub"), fmt(f) {}
+	Harness(Format f, int rate, Device::RAWFile* rf = nullptr) : stub(f, rate, Type::RAWFILE, "stub"), file(rf), dev(rf ? *(Device::Device*)rf : stub), fmt(f) {}
 };
 
 } // namespace
@@ -115,11 +124,25 @@ extern "C" {
 // flags: bit 0 record float taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`, bit 3 `-go FP_DS on`, bit 4 channel mode X (`-c X`), bit 5 `-go MA on`;
 // GPU engines: bit 6 the AIS::Decoder state machines on the device (GpuPool::setGpuDecode), bit 7 pipelined hand-off (GpuPool::setPipelined).
 // GPU engines created with the same configuration before their first block share ONE GPU context (GpuPool): feed them from one thread each.
-void* ref_create(int kind, int sample_rate, int fmt, int flags) {
+void* ref_create_file(int kind, int sample_rate, int fmt, int flags, const char* filename);
+void* ref_create(int kind, int sample_rate, int fmt, int flags) { return ref_create_file(kind, sample_rate, fmt, flags, nullptr); }
+
+// filename != NULL: the model is built on the reference's own Device::RAWFile (what `-r <fmt> <file> -s <rate>` sets up,
+// Application/Receiver.cpp + Device/FileRAW.cpp:230-251) instead of the stub device; ref_play_file() then runs the file through it
+// with the reference's reader thread, FIFO and run thread -- including the 1-or-2-block hand-offs of FIFO::Front(-1)
+// (Library/FIFO.h:99-109).  flags bit 8: `-go AFC_WIDE off`, bit 9: `-go DROOP off`.
+void* ref_create_file(int kind, int sample_rate, int fmt, int flags, const char* filename) {
 	const int taps = flags & 1;
 	try {
 		Format f = fmt == 0 ? Format::CU8 : fmt == 2 ? Format::CS8 : fmt == 3 ? Format::CS16 : Format::CF32;
-		Harness* h = new Harness(f, sample_rate);
+		Device::RAWFile* rf = nullptr;
+		if (filename) {
+			rf = new Device::RAWFile();
+			rf->SetKey(AIS::KEY_SETTING_FILE, filename);
+			rf->setFormat(f);
+			rf->setSampleRate(sample_rate);
+		}
+		Harness* h = new Harness(f, sample_rate, rf);
 		if (kind == 4) { h->mc = new AIS::ModelChallenger(); h->model = h->mc; }
 		else if (kind == 1) { h->mb = new AIS::ModelBase(); h->model = h->mb; }
 		else if (kind == 0) { h->ms = new AIS::ModelStandard(); h->model = h->ms; }
@@ -139,10 +162,13 @@ void* ref_create(int kind, int sample_rate, int fmt, int flags) {
 		if (flags & 4) h->model->SetKey(AIS::KEY_SETTING_PS_EMA, "OFF");
 		if (flags & 8) h->model->SetKey(AIS::KEY_SETTING_FP_DS, "ON");
 		if (flags & 32) h->model->SetKey(AIS::KEY_SETTING_MA, "ON");
+		if (flags & 256) h->model->SetKey(AIS::KEY_SETTING_AFC_WIDE, "OFF");
+		if (flags & 512) h->model->SetKey(AIS::KEY_SETTING_DROOP, "OFF");
 		if (flags & 16) { h->model->setMode(AIS::Mode::X); h->model->buildModel('X', 'X', sample_rate, false, &h->dev); } // Receiver.cpp:87-98,220
 		else h->model->buildModel('A', 'B', sample_rate, false, &h->dev);
 		h->model->Output() >> h->sink;
 		h->dev.setTag(h->tag);
+		if (h->file) h->file->out.Connect(&h->cc);
 		if (taps && !h->mgpu) {
 			AIS::ModelFrontend* fe = static_cast<AIS::ModelFrontend*>(h->model);
 			for (auto& t : h->tap) t.on = true;
@@ -207,6 +233,43 @@ int ref_feed(void* hv, const void* data, int nbytes) {
 	auto t1 = std::chrono::high_resolution_clock::now();
 	h->seconds += std::chrono::duration<double>(t1 - t0).count();
 	return 0;
+}
+
+// Runs the whole file through the model on the reference's own threads (Device/FileRAW.cpp:199-206); returns when the run thread
+// has seen the end of the input (RAWFile::isStreaming() turns false, :139-140), -1 after timeout_s, -2 if the chain stopped the process.
+// calls / max_blocks (may be NULL): the number of Receive() calls the device made and the largest number of FIFO blocks in one.
+int ref_play_file(void* hv, double timeout_s, int* calls, int* max_blocks) {
+	Harness* h = (Harness*)hv;
+	if (!h->file) return -3;
+	CallCounter& cc = h->cc;
+	stop = false;
+	int rc = 0;
+	try {
+		h->file->Play();
+		const auto t0 = std::chrono::steady_clock::now();
+		while (h->file->isStreaming() && !stop) {
+			std::this_thread::sleep_for(std::chrono::milliseconds(2));
+			if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) { rc = -1; break; }
+		}
+		if (stop) rc = -2;
+		h->file->Stop();
+		h->file->Close();
+	} catch (const std::exception& e) {
+		fprintf(stderr, "ref_play_file: %s\n", e.what());
+		rc = -4;
+	}
+	if (calls) *calls = cc.calls;
+	if (max_blocks) *max_blocks = cc.max_size / (24 * 16 * 16384);
+	return rc;
+}
+
+// bytes per GPU block for the GPU engines built from now on (0: by the device) -- what `-go GPU_BLOCK n` of the patched Receiver sets
+void ref_gpu_block_bytes(int n) {
+#ifdef HASMI355X
+	AIS::GpuPool::instance().setBlockBytes(n);
+#else
+	(void)n;
+#endif
 }
 
 // pipelined GPU batches: collect the last block's outputs (what the patched Receiver does when its device has delivered its last block)
@@ -363,7 +426,9 @@ void ref_reset_seq(void) { AIS::Message::ID.store(0); }
 void ref_destroy(void* hv) {
 	Harness* h = (Harness*)hv;
 	delete h->md; delete h->mc; delete h->mb; delete h->ms; delete h->mv; delete h->mgpu;
+	Device::RAWFile* rf = h->file;
 	delete h;
+	delete rf;
 }
 
 } // extern "C"

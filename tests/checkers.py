@@ -33,7 +33,8 @@ def have_ref(kind="strict"):
 class _Chain:
     """One receiver instance behind either checker library."""
 
-    def __init__(self, lib, prefix, model, rate, fmt, taps, dsk=False, ps_ema=True, fp_ds=False, mode_x=False, ma=False, extra_flags=0):
+    def __init__(self, lib, prefix, model, rate, fmt, taps, dsk=False, ps_ema=True, fp_ds=False, mode_x=False, ma=False, extra_flags=0,
+                 afc_wide=True, droop=True, filename=None):
         self.lib, self.p = lib, prefix
         f = lambda name: getattr(lib, prefix + name)
         f("create").restype = ctypes.c_void_p
@@ -56,14 +57,29 @@ class _Chain:
         f("destroy").argtypes = [ctypes.c_void_p]
         self._f = f
         self.fmt = fmt
-        flags = (1 if taps else 0) | (2 if dsk else 0) | (0 if ps_ema else 4) | (8 if fp_ds else 0) | (16 if mode_x else 0) | (32 if ma else 0) | extra_flags
-        self.h = f("create")(model, rate, {"cu8": 0, "cf32": 1, "cs8": 2, "cs16": 3}[fmt], flags)
+        flags = ((1 if taps else 0) | (2 if dsk else 0) | (0 if ps_ema else 4) | (8 if fp_ds else 0) | (16 if mode_x else 0) | (32 if ma else 0)
+                 | (0 if afc_wide else 256) | (0 if droop else 512) | extra_flags)  # bits 8 / 9: `-go AFC_WIDE off` / `-go DROOP off`
+        fmt_id = {"cu8": 0, "cf32": 1, "cs8": 2, "cs16": 3}[fmt]
+        if filename is not None:  # Ref / RefGpu only: the model on the reference's own Device::RAWFile (play_file() runs it)
+            f("create_file").restype = ctypes.c_void_p
+            f("create_file").argtypes = [ctypes.c_int] * 4 + [ctypes.c_char_p]
+            f("play_file").argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+            self.h = f("create_file")(model, rate, fmt_id, flags, os.fsencode(filename))
+        else:
+            self.h = f("create")(model, rate, fmt_id, flags)
         if not self.h:
             raise RuntimeError("checker create failed")
 
     def feed(self, block):
         block = np.ascontiguousarray(block)
         return self._f("feed")(self.h, block.ctypes.data, block.nbytes)
+
+    def play_file(self, timeout_s=120.0):
+        """Runs the whole file through the model on the reference's own reader / run threads (Device/FileRAW.cpp); returns
+        (status, number of Receive() calls the device made, largest number of FIFO blocks in one call)."""
+        calls, maxb = ctypes.c_int(0), ctypes.c_int(0)
+        rc = self._f("play_file")(self.h, timeout_s, ctypes.byref(calls), ctypes.byref(maxb))
+        return rc, calls.value, maxb.value
 
     def feed_blocks(self, x, block_len):
         """Feed whole blocks of block_len IQ samples (the tail that does not fill a block is dropped)."""
@@ -138,26 +154,36 @@ def _lib(path):
     return _libs[path]
 
 
-def Oracle(model=2, rate=1536000, fmt="cf32", taps=False, dsk=False, ps_ema=True, fp_ds=False, mode_x=False, ma=False):
+def Oracle(model=2, rate=1536000, fmt="cf32", taps=False, dsk=False, ps_ema=True, fp_ds=False, mode_x=False, ma=False, afc_wide=True, droop=True):
     path = os.path.join(ORACLE_DIR, "libaisoracle.so")
     if not os.path.exists(path):
         build_oracle()
     lib = _lib(path)
     lib.ao_reset_seq()
-    return _Chain(lib, "ao_", model, rate, fmt, taps, dsk, ps_ema, fp_ds, mode_x, ma)
+    return _Chain(lib, "ao_", model, rate, fmt, taps, dsk, ps_ema, fp_ds, mode_x, ma, afc_wide=afc_wide, droop=droop)
 
 
-def Ref(model=2, rate=1536000, fmt="cf32", taps=False, kind="strict", dsk=False, ps_ema=True, fp_ds=False, mode_x=False, ma=False):
+def Ref(model=2, rate=1536000, fmt="cf32", taps=False, kind="strict", dsk=False, ps_ema=True, fp_ds=False, mode_x=False, ma=False, afc_wide=True, droop=True,
+        filename=None):
     lib = _lib(os.path.join(ORACLE_DIR, "_ref", "libaisref_%s.so" % kind))
     lib.ref_reset_seq()
-    return _Chain(lib, "ref_", model, rate, fmt, taps, dsk, ps_ema, fp_ds, mode_x, ma)
+    return _Chain(lib, "ref_", model, rate, fmt, taps, dsk, ps_ema, fp_ds, mode_x, ma, afc_wide=afc_wide, droop=droop, filename=filename)
 
 
 def have_refgpu():
     return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libaisrefgpu.so"))
 
 
-def RefGpu(model=12, rate=1536000, fmt="cf32", dsk=False, ps_ema=True, fp_ds=False, ma=False, gpu_decode=False, pipelined=False):
+def refgpu_block_bytes(n):
+    """Bytes per GPU block for the GPU engines built from now on (GpuPool::setBlockBytes); 0 = by the device."""
+    lib = _lib(os.path.join(ORACLE_DIR, "_ref", "libaisrefgpu.so"))
+    lib.ref_gpu_block_bytes.argtypes = [ctypes.c_int]
+    lib.ref_gpu_block_bytes.restype = None
+    lib.ref_gpu_block_bytes(n)
+
+
+def RefGpu(model=12, rate=1536000, fmt="cf32", dsk=False, ps_ema=True, fp_ds=False, ma=False, gpu_decode=False, pipelined=False, afc_wide=True, droop=True,
+           filename=None):
     """oracle/_ref/libaisrefgpu.so: the reference's unmodified sources PLUS the reference-side binding of libaisgpu.so
     (integration/reference/Source/DSP/GPU/ModelGPU.cpp, an AIS::Model subclass compiled against the reference's real headers).
     model 2 / 4 / 0 / 1 = the reference's own ModelDefault / ModelChallenger / ModelStandard / ModelBase, 12 / 14 / 20 / 21 = the same
@@ -165,7 +191,8 @@ def RefGpu(model=12, rate=1536000, fmt="cf32", dsk=False, ps_ema=True, fp_ds=Fal
     (feed them from one thread each); gpu_decode: decoder state machines on the device; pipelined: call flush() after the last block."""
     lib = _lib(os.path.join(ORACLE_DIR, "_ref", "libaisrefgpu.so"))
     lib.ref_reset_seq()
-    c = _Chain(lib, "ref_", model, rate, fmt, False, dsk, ps_ema, fp_ds, False, ma, extra_flags=(64 if gpu_decode else 0) | (128 if pipelined else 0))
+    c = _Chain(lib, "ref_", model, rate, fmt, False, dsk, ps_ema, fp_ds, False, ma, extra_flags=(64 if gpu_decode else 0) | (128 if pipelined else 0),
+               afc_wide=afc_wide, droop=droop, filename=filename)
     lib.ref_flush.argtypes = [ctypes.c_void_p]
     lib.ref_flush.restype = None
     c.flush = lambda: lib.ref_flush(c.h)

@@ -1344,6 +1344,116 @@ def test_reference_binding_compiled_against_the_real_reference(gpu_model, cpu_mo
     assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])  # tag.level, tag.ppm per message
 
 
+def _by_channel(lines):
+    """NMEA lines per channel letter, in order (the A / B interleave of the reference depends on how many FIFO blocks a call carried)."""
+    out = {}
+    for ln in lines:
+        out.setdefault(ln.split(",")[4], []).append(ln)
+    return out
+
+
+_FIFO_BLOCK = 24 * 16 * 16384  # Device/FileRAW.h:43
+
+
+@pytest.mark.skipif(not checkers.have_refgpu(), reason="oracle/_ref/libaisrefgpu.so not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("gpu_model,cpu_model,fmt,runs", [(12, 2, "cu8", 20), (12, 2, "cf32", 6), (14, 4, "cu8", 4)])
+def test_binding_behind_the_reference_file_reader(tmp_path, gpu_model, cpu_model, fmt, runs):
+    """BASELINE configs[0] / configs[1]'s input path, for real: `-r <file> -s 1536000` = the reference's own Device::RAWFile
+    (Device/FileRAW.cpp linked unmodified: reader thread -> FIFO -> run thread), whose run thread hands over ONE OR TWO FIFO blocks
+    per Receive() depending on how far the reader got (FileRAW.cpp:120-136, Library/FIFO.h:99-109).  The GPU engine re-blocks
+    inside GpuChain::Receive; it must print, per channel and in order, what the reference's CPU engine prints from the same file
+    through the same reader -- every time, with the reader thread racing (the file ends in a partial block the reader pads)."""
+    per = {"cu8": 2, "cf32": 8}[fmt]
+    block = _FIFO_BLOCK // per
+    x = synth.receiver_stream(block * 4 + block // 3, receiver_id=300 + gpu_model, gap_slots=(1, 2))  # (no two-sentence messages: their sequence digit follows the process-wide A / B order, Message.cpp:28-39)
+    fn = str(tmp_path / ("in." + fmt))
+    (synth.to_cu8(x) if fmt == "cu8" else x).tofile(fn)
+    m = checkers.RefGpu(model=cpu_model, fmt=fmt, filename=fn)
+    rc, calls, _ = m.play_file()
+    want = _by_channel(m.nmea())
+    m.close()
+    assert rc == 0 and sum(len(v) for v in want.values()) >= 20
+    seen = set()
+    for i in range(runs):
+        g = checkers.RefGpu(model=gpu_model, fmt=fmt, filename=fn)
+        rc, calls, maxb = g.play_file()
+        got = _by_channel(g.nmea())
+        g.close()
+        seen.add((calls, maxb))
+        assert rc == 0, "run %d: the chain stopped (calls %d, largest hand-off %d blocks)" % (i, calls, maxb)
+        assert got == want, "run %d (calls %d, largest hand-off %d blocks)" % (i, calls, maxb)
+    print("hand-off patterns seen (calls, max blocks per call):", sorted(seen))
+
+
+@pytest.mark.skipif(not checkers.have_refgpu(), reason="oracle/_ref/libaisrefgpu.so not built (needs /root/reference at build time)")
+def test_binding_reblocks_whatever_the_device_sends():
+    """Deterministic side of the same contract, on the stub device: two FIFO blocks in one call, then one, then two (what
+    FIFO::Front(-1) produces), must equal single-block calls; and with an explicit GPU block (GpuPool::setBlockBytes) calls of
+    arbitrary sizes -- smaller than a block, not a multiple of it, larger than two -- are cut into that block, the remainder carried."""
+    block = _FIFO_BLOCK // 8
+    x = synth.receiver_stream(block * 5, receiver_id=311, gap_slots=(1, 2))
+    c = checkers.RefGpu(model=2, fmt="cf32")
+    c.feed_blocks(x, block)
+    want = c.nmea()
+    c.close()
+    g = checkers.RefGpu(model=12, fmt="cf32")
+    for a, b in ((0, 2), (2, 3), (3, 5)):
+        assert g.feed(x[a * block:b * block]) == 0
+    assert g.nmea() == want and len(want) >= 20
+    g.close()
+
+    small = 131072
+    y = synth.receiver_stream(small * 12, receiver_id=312, gap_slots=(1, 2))
+    c = checkers.RefGpu(model=2, fmt="cf32")
+    c.feed_blocks(y, small)
+    want = c.nmea()
+    c.close()
+    checkers.refgpu_block_bytes(small * 8)
+    try:
+        g = checkers.RefGpu(model=12, fmt="cf32")
+        pos = 0
+        for n in (1000, small - 1000, 3 * small + 17, 5, small // 2, 2 * small, 10 ** 9):
+            n = min(n, len(y) - pos)
+            assert g.feed(y[pos:pos + n]) == 0
+            pos += n
+        assert pos == len(y)
+        assert g.nmea() == want and len(want) >= 8
+        g.close()
+    finally:
+        checkers.refgpu_block_bytes(0)
+
+
+@pytest.mark.skipif(not checkers.have_refgpu(), reason="oracle/_ref/libaisrefgpu.so not built (needs /root/reference at build time)")
+def test_three_file_readers_share_one_gpu_context(tmp_path):
+    """Three receivers of one process, each behind its own RAWFile (six reference threads racing), one GPU context: the receivers
+    meet once per GPU block although their devices' calls carry different numbers of blocks."""
+    import threading
+    block = _FIFO_BLOCK // 2
+    fns, want = [], []
+    for r in range(3):
+        x = synth.receiver_stream(block * 3 + 12345, receiver_id=320 + r, gap_slots=(1, 2))
+        fns.append(str(tmp_path / ("rx%d.cu8" % r)))
+        synth.to_cu8(x).tofile(fns[-1])
+        c = checkers.RefGpu(model=2, fmt="cu8")
+        cu8 = np.fromfile(fns[-1], np.uint8)
+        c.feed_blocks(np.concatenate([cu8, np.zeros(4 * block * 2 - len(cu8), np.uint8)]), block)  # (the reader pads the tail with zero BYTES, FileRAW.cpp:103-104)
+        want.append(_by_channel(c.nmea()))
+        c.close()
+    for rep in range(3):
+        gs = [checkers.RefGpu(model=12, fmt="cu8", filename=fn) for fn in fns]  # same configuration: one group, one context
+        res = [None] * 3
+        ths = [threading.Thread(target=lambda i=i: res.__setitem__(i, gs[i].play_file())) for i in range(3)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        for i in range(3):
+            assert res[i][0] == 0, res
+            assert _by_channel(gs[i].nmea()) == want[i], "receiver %d, hand-offs %r" % (i, res)
+        for g in gs:
+            g.close()
+
+
 @pytest.mark.parametrize("env", [{}, {"AISGPU_PS_WARM": "16"}, {"AISGPU_PS_WARM": "64"}, {"AISGPU_SERIAL": "1"}, {"AISGPU_PS_SEQUENTIAL": "1"}])
 def test_fused_back_end_and_its_exact_fallback(env, monkeypatch):
     """The default back end (derotation / FIR kernel, then the chunk-parallel PhaseSearch) on 5 receivers = 10 channels (two full
