@@ -820,7 +820,8 @@ int ao_feed(ao_chain* c, const void* data, int nbytes) {
 }
 
 ao_chain* ao_create(int model, int sample_rate, int fmt, int flags) {
-	/* flags: bit 0 record taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`, bit 3 `-go FP_DS on`, bit 5 `-go MA on` (bit 4 below) */
+	/* flags: bit 0 record taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`, bit 3 `-go FP_DS on`, bit 5 `-go MA on` (bit 4 below),
+	 * bit 8 `-go AFC_WIDE off` (Model.cpp:536-540,586-588), bit 9 `-go DROOP off` (Model.cpp:384-386: every ladder without FDC) */
 	static const unsigned buckets_nodsk[] = { 96000, 192000, 288000, 384000, 768000, 1536000, 3072000, 6144000, 12288000 }; /* Model.cpp:129-130 */
 	static const unsigned buckets_dsk[] = { 96000, 192000, 288000, 384000, 576000, 768000, 1152000, 1536000, 2304000, 3072000, 6144000, 12288000 };
 	/* ... bit 4 channel mode X (`-c X`: one channel, 12k .. 192k, Model.cpp:35-107) */
@@ -845,7 +846,7 @@ ao_chain* ao_create(int model, int sample_rate, int fmt, int flags) {
 	c->has_dsk = is3;
 	c->has_us = bucket != (unsigned)sample_rate;
 	c->mode_x = mode_x;
-	c->has_fdc = !is3 && k > 0; /* the decimate-by-3 ladders have no droop compensation (Model.cpp:207-219 etc.) */
+	c->has_fdc = !is3 && k > 0 && !((flags >> 9) & 1); /* the decimate-by-3 ladders have no droop compensation (Model.cpp:207-219 etc.); `DROOP off`: nobody has */
 	c->fdc_alpha = is3 ? 0.0f : alphas[k];
 	if (mode_x) c->fdc_alpha = k == 2 ? -1.1f : -0.8f; /* Model.cpp:64,76 */
 	if (mode_x) { c->npre = 0; c->npost = k; } /* convert >> [US] >> DS2_2 >> DS2_1 */
@@ -862,7 +863,7 @@ ao_chain* ao_create(int model, int sample_rate, int fmt, int flags) {
 	for (int q = 0; q < 2; q++) {
 		chan_t* ch = &c->ch[q];
 		ch->cgf.rot.re = 1.0f;
-		ch->cgf.window = 187; ch->cgf.wide = 1; /* Model.cpp:533-540 */
+		ch->cgf.window = 187; ch->cgf.wide = !((flags >> 8) & 1); /* Model.cpp:533-540 */
 		ch->decb.channel = mode_x ? 'X' : "AB"[q]; ch->decb.fast_pll = &ch->pll_fast; /* Model.cpp:434-435 */
 		ch->pll_fast = 1; /* DSP.h:40 */
 		if (model == 11) { ch->v2 = (v2_t*)malloc(sizeof(v2_t)); v2_init(ch->v2, "AB"[q]); }

@@ -23,7 +23,7 @@ typedef struct ao_chain ao_chain;
 /* model: 11 = ModelEngineV2 (V2::Engine behind the front end, oracle/ais_oracle_v2.inc), 0 = ModelStandard (FM receiver, five decoders on the deinterleaved discriminator), 1 = ModelBase (FM receiver, SimplePLL with decoder feedback), 2 = ModelDefault, 4 = ModelChallenger.  fmt: 0 = CU8, 1 = CF32, 2 = CS8, 3 = CS16.
  * flags: bit 0 record taps, bit 1 `-go DSK on` (decimate-by-3 ladders for 576k/1152k/2304k), bit 2 `-go PS_EMA off`
  * (PhaseSearch with a boxcar history instead of PhaseSearchEMA), bit 3 `-go FP_DS on` (fixed-point ladder Downsample16_CU8 at
- * 1536 kSPS, CU8 input). */
+ * 1536 kSPS, CU8 input), bit 4 channel mode X, bit 5 `-go MA on`, bit 8 `-go AFC_WIDE off`, bit 9 `-go DROOP off`. */
 ao_chain* ao_create(int model, int sample_rate, int fmt, int flags);
 void ao_destroy(ao_chain*);
 /* one call == one reference Receive() block (call boundaries are part of the numerical contract:

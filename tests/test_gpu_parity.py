@@ -31,7 +31,8 @@ def _feq(a, b):
 def _run_gpu_vs_oracle(streams, rate, fmt, block, nblocks, **kw):
     """streams: list of per-receiver arrays.  Compares every block's taps and outputs per receiver."""
     R = len(streams)
-    okw = dict(dsk=kw.get("dsk", False), ps_ema=kw.get("ps_ema", True), fp_ds=kw.get("fp_ds", False), ma=kw.get("ma", False))
+    okw = dict(dsk=kw.get("dsk", False), ps_ema=kw.get("ps_ema", True), fp_ds=kw.get("fp_ds", False), ma=kw.get("ma", False),
+               afc_wide=kw.get("afc_wide", True), droop=kw.get("droop", True))
     g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block,
                    input_format=_FMT[fmt], taps=True, **kw)
     per = 1 if fmt == "cf32" else 2
@@ -1007,7 +1008,8 @@ def test_gpu_frame_decoder_matches_host_decoders_on_a_batch():
 # ---------------------------------------------------------------------------------------------------------------
 def _run_outputs_vs_oracle(streams, rate, fmt, block, nblocks, **kw):
     R = len(streams)
-    okw = dict(dsk=kw.get("dsk", False), ps_ema=kw.get("ps_ema", True), fp_ds=kw.get("fp_ds", False), ma=kw.get("ma", False))
+    okw = dict(dsk=kw.get("dsk", False), ps_ema=kw.get("ps_ema", True), fp_ds=kw.get("fp_ds", False), ma=kw.get("ma", False),
+               afc_wide=kw.get("afc_wide", True), droop=kw.get("droop", True))
     g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block,
                    input_format=_FMT[fmt], taps=False, **kw)
     per = 1 if fmt == "cf32" else 2
@@ -1342,6 +1344,53 @@ def test_reference_binding_compiled_against_the_real_reference(gpu_model, cpu_mo
         m.close()
     assert out[0][0] == out[1][0] and len(out[0][0]) >= 3
     assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])  # tag.level, tag.ppm per message
+
+
+@pytest.mark.parametrize("rate,fmt,block,nblocks,afc_wide,droop,extra", [
+    (1536000, "cf32", 131072, 6, False, True, {}), (1536000, "cf32", 131072, 6, True, False, {}), (1536000, "cu8", 786432, 2, False, False, {}),
+    (768000, "cf32", 65536, 8, False, False, {}), (3072000, "cf32", 262144, 5, False, False, {}), (1536000, "cu8", 131072, 6, True, False, {"fp_ds": True}),
+    (192000, "cf32", 16384, 12, False, False, {})])
+def test_afc_wide_off_and_droop_off_taps(rate, fmt, block, nblocks, afc_wide, droop, extra):
+    """`-go AFC_WIDE off` / `-go DROOP off` (aisgpu_cfg.afc_wide / .droop; Model.cpp:536-540, 384-386, 162-327) on the materialised
+    path: all float taps (48 kHz front end, CGF, FIR), hard bits, levels and ppm bit-exact against the oracle -- which is pinned to
+    the compiled reference with the same two keys in tests/test_oracle_vs_ref.py::test_afc_wide_off_and_droop_off."""
+    xs = [synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=330 + r, gap_slots=(0, 2)) for r in range(2)]
+    if fmt == "cu8":
+        xs = [synth.to_cu8(x) for x in xs]
+    _run_gpu_vs_oracle(xs, rate, fmt, block, nblocks, afc_wide=afc_wide, droop=droop, **extra)
+
+
+@pytest.mark.parametrize("rate,fmt,block,nblocks,afc_wide,droop,extra", [
+    (1536000, "cf32", 786432, 3, False, True, {}), (1536000, "cf32", 786432, 3, True, False, {}), (1536000, "cf32", 131072, 6, False, False, {}),
+    (768000, "cf32", 393216, 3, False, False, {}), (6000000, "cf32", 786432, 5, False, False, {}), (6000000, "cf32", 786432, 5, False, True, {}),
+    (6144000, "cf32", 786432, 3, True, False, {}), (2400000, "cf32", 393216, 5, False, False, {}), (288000, "cf32", 49152, 8, False, False, {}),
+    (1536000, "cf32", 786432, 2, False, False, {"ps_ema": False})])
+def test_afc_wide_off_and_droop_off_default_path(rate, fmt, block, nblocks, afc_wide, droop, extra):
+    """The same two keys on the path bench.py measures (spectral analysis inside the front-end waves, fused derotation / FIR,
+    chunk-parallel PhaseSearch), on the direct, the resampled (6 MSPS, 2.4 MSPS), the six-stage and the decimate-by-3 ladders."""
+    xs = [synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=340 + r, gap_slots=(0, 2)) for r in range(3)]
+    _run_outputs_vs_oracle(xs, rate, fmt, block, nblocks, afc_wide=afc_wide, droop=droop, **extra)
+
+
+@pytest.mark.skipif(not checkers.have_refgpu(), reason="oracle/_ref/libaisrefgpu.so not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("gpu_model,cpu_model,rate,fmt,block,nblocks,kw", [
+    (12, 2, 1536000, "cf32", 786432, 3, {"afc_wide": False}), (12, 2, 1536000, "cu8", 131072, 10, {"droop": False}),
+    (12, 2, 6000000, "cf32", 786432, 4, {"afc_wide": False, "droop": False}), (14, 4, 1536000, "cf32", 131072, 10, {"afc_wide": False, "droop": False}),
+    (12, 2, 768000, "cf32", 65536, 12, {"afc_wide": False, "droop": False})])
+def test_reference_binding_afc_wide_and_droop_keys(gpu_model, cpu_model, rate, fmt, block, nblocks, kw):
+    """The two keys arriving the reference's way -- Model::SetKey(KEY_SETTING_AFC_WIDE / KEY_SETTING_DROOP, "OFF") on the
+    AIS::Model subclass of the binding (ModelGPU.cpp: SetKey -> aisgpu_cfg.afc_wide / .droop) -- against the reference's own
+    engine given the same keys, from the same binary: NMEA text, tag.level and tag.ppm per message."""
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=350 + gpu_model, gap_slots=(1, 2))
+    data = synth.to_cu8(x) if fmt == "cu8" else x
+    out = []
+    for model in (cpu_model, gpu_model):
+        m = checkers.RefGpu(model=model, rate=rate, fmt=fmt, **kw)
+        m.feed_blocks(data, block)
+        out.append((m.nmea(), m.msg_meta()))
+        m.close()
+    assert out[0][0] == out[1][0] and len(out[0][0]) >= 3
+    assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])
 
 
 def _by_channel(lines):
