@@ -251,8 +251,8 @@ struct aisgpu {
 	bool ps_box = false; PsBoxState* d_box[2] = {}; // Demod::PhaseSearch (boxcar) instead of PhaseSearchEMA
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
-	bool us_on_ds = false; // resampled ladders: the resampler front end on the downstream stream, the second half of a flush one flush late (option "us_on_ds")
-	bool fm_on_s1 = false, fm_ev_used = false; hipEvent_t ev_fm = nullptr; // ModelChallenger's FM branch in front of PhaseSearch on s1 (option "fm_on_s1"; default: the resampled ladders)
+	bool us_on_ds = false; // resampled ladders: the resampler front end on the downstream stream, the second half of a flush one flush late (fixed by the mode at create, not an option)
+	bool fm_on_s1 = false, fm_ev_used = false; hipEvent_t ev_fm = nullptr; // where the device decoders' regrouping of ModelChallenger's FM bits (k7_pack) runs: in front of PhaseSearch on s1 on the resampled ladders, else behind K6 on s4 (fixed by the mode; ev_fm only exists with challenger + gpu_decode + a resampled ladder)
 	bool fused = false; // derotation + FIR + ScatterPLL as one kernel behind the checkpointed phasor recurrence (the default)
 	struct { bool valid = false; int q = 0, pb = 0, lv = 0, n_groups = 0, n_rel0 = 0, S = 0; long long g0 = 0; unsigned block = 0, sub = 0; } fpend;
 	float2 *d_ck[NBUF] = {}, *d_dfhist[2] = {};
@@ -774,7 +774,7 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 			// Its scratch set was last read by the tasks of block f-2: this block's FM receiver has waited for them (above).
 			K7bParams& kb = h->k7b[pb];
 			kb.k = k7;
-			// (with the FM receiver on s4 too -- base_fm_on_ds -- the pass queues behind it there; on s1, in front of its block's tasks, it
+			// (with the FM receiver on s4 too -- measured in round 4, not kept -- the pass queues behind it there; on s1, in front of its block's tasks, it
 			// costs 256 distinct receivers 0.15 ms per step: measured, not kept)
 			HIPCHK(hipEventRecord(h->ev_sym[pb], h->ds));
 			WAITEV(h->s4, h->ev_sym[pb]);

@@ -56,10 +56,13 @@ extern "C" {
                                     * filtered discriminator per 48 kHz sample; SimplePLL + decoder (feedback loop) run on the host, or -- with
                                     * AISGPU_FLAG_GPU_DECODE -- chunk-parallel on the device (aisgpu_frames) */
 #define AISGPU_MODEL_DEFAULT 2     /* AIS::ModelDefault    (-m 2), DSP/Model.cpp:520-577 */
-#define AISGPU_MODEL_V2 11         /* AIS::ModelEngineV2  (-m 11), DSP/Model.cpp:440-463: the device runs the front end and what V2::Engine computes from
-                                    * the channel alone (frequency estimates, energies, FM branch: aisgpu_out.v2_*, fm_bits) and hands over the two 48 kHz
-                                    * channels (aisgpu_out.c48); the engine's coherent branch closes over the state of its own decoders every sample
-                                    * (DSP/Decoder/V2/V2Engine.cpp:300-388), so it runs behind the boundary, on the host */
+#define AISGPU_MODEL_V2 11         /* AIS::ModelEngineV2  (-m 11), DSP/Model.cpp:440-463.  Two forms:
+                                    * - with AISGPU_FLAG_GPU_DECODE the whole V2::Engine of every channel runs ON THE DEVICE (kv2_engine: DSP/Decoder/V2/
+                                    *   V2Engine.cpp:293-388 in the reference's order per channel) and only frames come back (aisgpu_frames);
+                                    * - without it the device runs the front end and what the engine computes from the channel alone (frequency estimates,
+                                    *   energies, FM branch: aisgpu_out.v2_*, fm_bits) and hands over the two 48 kHz channels (aisgpu_out.c48) to an engine
+                                    *   on the host (ais-catcher_amd/host/v2_engine.*), whose coherent branch closes over the state of its own decoders
+                                    *   every sample (V2Engine.cpp:300-388). */
 #define AISGPU_MODEL_CHALLENGER 4  /* AIS::ModelChallenger (-m 4), DSP/Model.cpp:601-678: ModelDefault + the FM branch */
 
 #define AISGPU_FLAG_TAPS 1    /* keep intermediate float taps readable via aisgpu_tap() (tests) */
@@ -142,7 +145,12 @@ void aisgpu_destroy(aisgpu_t* h);
 
 /* Copy one receiver's block from host memory (borrowed for the call only, like the reference's
  * Receive(const T*, int, TAG&), Library/Stream.h:36-45) into the staging buffer.  n_iq must equal
- * block_len.  Data is CU8 pairs or CFLOAT32 per cfg.input_format.  Thread safe for different rx (receiver threads copy
+ * block_len (AISGPU_ERR_ARG otherwise): the context works on blocks of ONE size, because a block is one Receive() call of the
+ * reference's chain and call boundaries are part of the arithmetic (Rotate renormalises once per call, DSP/DSP.cpp:315).  A caller
+ * whose device hands over other sizes -- the reference's RAWFile sends one OR two FIFO blocks per call, Device/FileRAW.cpp:120-136
+ * -- cuts them into block_len pieces and calls submit / run once per piece; the reference-side binding does exactly that
+ * (GpuChain::Receive, integration/reference/Source/DSP/GPU/ModelGPU.cpp, tested behind the reference's real file reader).
+ * Data is CU8 / CS8 pairs, CS16 pairs or CFLOAT32 per cfg.input_format.  Thread safe for different rx (receiver threads copy
  * their rows concurrently); the staging buffers are double buffered, so the rows of block f+1 may be submitted while
  * block f is still running. */
 int aisgpu_submit(aisgpu_t* h, int rx, const void* iq, int n_iq);
@@ -159,9 +167,10 @@ int aisgpu_sync_outputs(aisgpu_t* h);
 int aisgpu_sync(aisgpu_t* h);
 int aisgpu_fetch(aisgpu_t* h, int rx, int ch, aisgpu_out* out); /* == aisgpu_fetch_sub(h, 0, ...) */
 /* Sample rates between two 2^k buckets go through the reference's fractional resampler (DSP/DSP.cpp:192-212), which
- * hands fixed-size blocks downstream whenever one is full: one input block then completes 1 or 2 downstream blocks
- * (each is one Receive() call of everything behind the resampler in the reference).  aisgpu_out_count() tells how
- * many the last aisgpu_run() completed (always 1 for the 2^k rates); fetch them in order with aisgpu_fetch_sub(). */
+ * hands fixed-size blocks downstream whenever one is full: one input block then completes 1 to 4 downstream blocks
+ * (each is one Receive() call of everything behind the resampler in the reference; 1 or 2 at the dual-channel rates, up to 4 in
+ * channel mode X below 24 kSPS).  aisgpu_out_count() tells how many the last aisgpu_run() completed (always 1 for the 2^k
+ * rates); fetch them in order with aisgpu_fetch_sub(). */
 int aisgpu_out_count(aisgpu_t* h);
 
 /* AISGPU_FLAG_GPU_DECODE: the frames the ten AIS::Decoder objects of every receiver completed with a good CRC since the
