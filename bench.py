@@ -390,7 +390,9 @@ def pmc_traffic_pass(config, receivers):
 def other_configs(steps=20, warmup=5):
     """BASELINE configs[1] (one receiver) and configs[2] (6 MSPS, ModelChallenger, 256 receivers) behind the default workload's timed
     region and gate: the same code path (this script with --config 2 / 3, the driver's 20-step shape, parity gate on), each in a
-    process of its own so that nothing of the main run is resident beside it.  One short record per config in the line."""
+    process of its own so that nothing of the main run is resident beside it.  One short record per config in the line.  A parity
+    MISMATCH in one of them fails the whole run (main() returns 3, like a mismatch of the default workload); a child that times out or
+    dies leaves an "error" / a non-zero "exit_status" in its record and the main line stands (its numbers do not depend on them)."""
     out = []
     for cfg in (2, 3):
         cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--steps", str(steps), "--warmup", str(warmup),
@@ -526,17 +528,20 @@ def main():
         t0 = time.perf_counter()
         time.sleep(0.001 * args.steps)
         barrier()
-        dt = shard.max_over_ranks(time.perf_counter() - t0, dist)
+        dt_local = time.perf_counter() - t0
+        dt = shard.max_over_ranks(dt_local, dist)
+        mine = [rx_ids[0], rx_ids[-1], round(dt_local / args.steps * 1e3, 4)]
         owned = [None] * world
         if dist is not None:
-            dist.all_gather_object(owned, [rx_ids[0], rx_ids[-1]])
+            dist.all_gather_object(owned, mine)
         else:
-            owned = [[rx_ids[0], rx_ids[-1]]]
+            owned = [mine]
         if rank == 0:
             print(json.dumps({"metric": "IQ Msamples/s (CFLOAT32) through ModelDefault chain", "dry_run": True,
                               "value": round(shard.aggregate_msamples(samples_per_step, world, args.steps, dt), 1), "unit": "Msamples/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
-                              "receiver_ranges": owned}), flush=True)
+                              "receiver_ranges": [o[:2] for o in owned],
+                              "per_rank": [{"rank": i, "ms_per_step": o[2]} for i, o in enumerate(owned)]}), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -704,6 +709,9 @@ def main():
     if rank == 0:
         if world == 1 and args.config == 4 and not args.no_other_configs and not args.no_pmc and not args.gpu_decode:  # (--no-pmc = the quick form of the tools' A/B loops)
             res["other_configs"] = other_configs()
+            if any(str(o.get("parity", "")).startswith("MISMATCH") or o.get("exit_status") == 3 for o in res["other_configs"]):
+                bad = max(bad, 1)   # parity of configs[1] / configs[2] is part of this run's gate
+                res["parity"] = res["parity"] + "; MISMATCH in other_configs"
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, model=model, rate=rate)
         elif world > 1:

@@ -68,6 +68,21 @@ def test_bench_under_the_drivers_launcher():
     assert len(out) == 1 and out[0]["n_gpus"] == 2 and out[0]["receiver_ranges"] == [[0, 255], [256, 511]]
 
 
+def test_eight_ranks_under_the_drivers_launcher():
+    """The shape of the driver's 8-GPU run (BASELINE configs[4]: 2048 receivers, 256 per GPU): eight ranks, the ranges
+    [0, 255] ... [1792, 2047], one per_rank record each, one line from rank 0 -- so that the first real 8-GPU run cannot fail on plumbing."""
+    port = _free_port()
+    rc, out, err = _bench(["--gpus", "8", "--steps", "20", "--warmup", "5", "--dry-run"],
+                          launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                                    "--master-port", str(port)])
+    assert rc == 0, err
+    assert len(out) == 1 and out[0]["n_gpus"] == 8 and out[0]["steps"] == 20 and out[0]["warmup"] == 5 and out[0]["scaling"] == "weak"
+    assert out[0]["receiver_ranges"] == [[256 * r, 256 * r + 255] for r in range(8)]
+    assert [p["rank"] for p in out[0]["per_rank"]] == list(range(8)) and all(p["ms_per_step"] > 0 for p in out[0]["per_rank"])
+    # weak scaling: the value is the whole job's (eight times one rank's samples over the slowest rank's time)
+    assert out[0]["value"] == pytest.approx(8 * 256 * 786432 * 20 / (max(p["ms_per_step"] for p in out[0]["per_rank"]) * 20 * 1e-3) / 1e6, rel=0.05)
+
+
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():
     rc, out, err = _bench(["--gpus", "4", "--dry-run"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert rc != 0 and not out and "must agree" in err
