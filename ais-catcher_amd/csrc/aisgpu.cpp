@@ -251,6 +251,7 @@ struct aisgpu {
 	bool ps_box = false; PsBoxState* d_box[2] = {}; // Demod::PhaseSearch (boxcar) instead of PhaseSearchEMA
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
+	int k1u_spw = 0; // test hook "k1u_spw": forces the resampler front end's span walk (launch_k1u)
 	bool us_on_ds = false; // resampled ladders: the resampler front end on the downstream stream, the second half of a flush one flush late (fixed by the mode at create, not an option)
 	bool fm_on_s1 = false, fm_ev_used = false; hipEvent_t ev_fm = nullptr; // where the device decoders' regrouping of ModelChallenger's FM bits (k7_pack) runs: in front of PhaseSearch on s1 on the resampled ladders, else behind K6 on s4 (fixed by the mode; ev_fm only exists with challenger + gpu_decode + a resampled ladder)
 	bool fused = false; // derotation + FIR + ScatterPLL as one kernel behind the checkpointed phasor recurrence (the default)
@@ -1116,7 +1117,7 @@ const char* aisgpu_last_error(aisgpu_t* h) { return h ? h->err.c_str() : ""; }
 
 int aisgpu_set_option(const char* key, const char* value) {
 	if (!key || !*key) return AISGPU_ERR_ARG;
-	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "k46", "trace", "k7e_stats", "k7b_stats" };
+	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "k46", "k1u_spw", "trace", "k7e_stats", "k7b_stats" };
 	bool ok = false;
 	for (const char* k : known) ok = ok || strcmp(k, key) == 0;
 	if (!ok) return AISGPU_ERR_ARG;
@@ -1571,6 +1572,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	}
 	const int ps_chunks = (h->Gcap + PS_CHUNK - 1) / PS_CHUNK;
 	{ const int v = opt_int("ps_warm", 0); if (v >= 1 && v <= PS_CHUNK) h->ps_warm = (v + 15) / 16 * 16; } // test hook: small values force the exact fallback
+	{ const int v = opt_int("k1u_spw", 0); if (v == 2 || v == 4 || v == 8) h->k1u_spw = v; }
 	if (opt_int("ps_sequential", 0)) h->ps_parallel = false; // test hook: the plain sequential row kernel
 	const size_t n_ma = C * 5 * ps_chunks * 16;
 	HIPCHK(dalloc(&h->d_pswords, C * 5 * ps_chunks * (PS_CHUNK / 32) * 16));
@@ -1844,7 +1846,7 @@ int aisgpu_run(aisgpu_t* h) {
 		ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
 		ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->mode_x ? h->has_fdc : 0; ku.L = h->L;
 		if (h->mode_x) HIPCHK(launch_k1x(ku, h->npost, R, h->stream));
-		else HIPCHK(launch_k1u(ku, 0, R, h->stream));
+		else { ku.spw_force = h->k1u_spw; HIPCHK(launch_k1u(ku, 0, R, h->stream)); }
 		if (h->x_direct) HIPCHK(launch_copy_rows(ku.xin + h->n_pre - h->xh, ku.xin_stride, h->d_xhist[(h->in_blocks & 1) ^ 1], h->xh, h->xh, R, h->stream));
 		int rc = enqueue_downstream(h, q, pb);
 		if (rc) return rc;
@@ -1973,7 +1975,7 @@ int aisgpu_run(aisgpu_t* h) {
 				ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
 				ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->has_fdc; ku.L = h->L;
 				if (h->mode_x) HIPCHK(launch_k1x(ku, h->npost, R, st));
-				else HIPCHK(launch_k1u(ku, h->npost, R, st));
+				else { ku.spw_force = h->k1u_spw; HIPCHK(launch_k1u(ku, h->npost, R, st)); }
 			}
 			HIPCHK(hipEventRecord(h->us_used_ev[slot], st));
 			HIPCHK(hipEventRecord(h->ev_xread[h->in_blocks % XR], st)); // (the run's last flush leaves the event that counts)

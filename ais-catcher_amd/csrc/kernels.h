@@ -47,6 +47,7 @@ struct K1uParams {
 	// block come from xhist[rx * xhist_len + xhist_len + i], i in [-xhist_len, 0) -- the previous block's tail, kept by the library
 	const float2* xhist = nullptr; int xhist_len = 0;
 	int spw = 1;            // spans (of K1U_M outputs per channel) a workgroup of the resampler front end walks (set by launch_k1u)
+	int spw_force = 0;      // test hook "k1u_spw" (2 / 4 / 8): the span walk of that length whatever the number of workgroups it leaves
 };
 // sample i of the pre-decimated stream relative to the current input block's start (see K1uParams::xprev)
 struct XRow {

@@ -4411,7 +4411,8 @@ hipError_t launch_k1u(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
 	K1uParams q = p;
 	const int spans = p.L / K1U_M;
 	q.spw = K1U_SPW;
-	while (q.spw > 1 && (spans % q.spw != 0 || (long long)(spans / q.spw) * n_rx < K1U_MIN_WGS)) q.spw >>= 1;
+	if (p.spw_force > 1) { q.spw = p.spw_force < K1U_SPW ? p.spw_force : K1U_SPW; while (q.spw > 1 && spans % q.spw != 0) q.spw >>= 1; } // (tests: few receivers, long walks)
+	else while (q.spw > 1 && (spans % q.spw != 0 || (long long)(spans / q.spw) * n_rx < K1U_MIN_WGS)) q.spw >>= 1;
 	if (npost == 2) K1U_LAUNCH_SPW(k1u_resample_frontend, q, 2 K1U_COMMA);
 	else if (npost == 1) K1U_LAUNCH_SPW(k1u_resample_frontend, q, 1 K1U_COMMA);
 	else if (npost == 0) K1U_LAUNCH_SPW(k1u_resample_frontend, q, 0 K1U_COMMA);

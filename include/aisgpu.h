@@ -235,6 +235,8 @@ void aisgpu_timing(aisgpu_t* h, int enable);
  *   "fft_in_k1"     0: the spectral analysis as FFT + search kernels instead of inside the front-end waves
  *   "k46"           1: derotation / FIR and PhaseSearchEMA in one workgroup that keeps the FIR outputs in LDS (k46_window_search, round 5:
  *                   exact, 0.24 GB less traffic per step, measured 5 % slower) instead of k6_window_fir + k4_phase_chunks
+ *   "k1u_spw"       2 / 4 / 8: the resampler front end (k1u_resample_frontend) walks that many consecutive spans per workgroup whatever the
+ *                   batch size (by default only batches of ~200 receivers and more get walks longer than one span)
  * Returns AISGPU_ERR_ARG for an unknown key. */
 int aisgpu_set_option(const char* key, const char* value);
 

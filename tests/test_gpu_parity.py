@@ -612,6 +612,19 @@ def test_resampled_ladders_over_many_blocks(rate, block, nblocks):
     _run_outputs_vs_oracle([x], rate, "cf32", block, nblocks)
 
 
+@pytest.mark.parametrize("spw", [2, 4, 8])
+@pytest.mark.parametrize("rate,block,nblocks", [(6000000, 786432, 6), (2400000, 393216, 6), (10000000, 786432, 5), (1000000, 512 * 32 * 3, 8),
+                                                (150000, 512 * 4 * 6, 8), (6000000, 512 * 128 * 3, 8)])
+def test_resampler_front_end_span_walk(spw, rate, block, nblocks, monkeypatch):
+    """k1u_resample_frontend walking 2 / 4 / 8 consecutive spans per workgroup (register prefetch one span ahead, LDS-only barriers,
+    the next span's samples staged over the later stages' buffers).  launch_k1u only chooses such walks for batches of ~200 receivers
+    and more; the test hook "k1u_spw" forces them for three receivers -- also on flushes whose span count is not a multiple of the
+    walk (blocks of three 512-sample windows = 12 spans: the walk falls back to 4), with two and with one stage behind the resampler."""
+    monkeypatch.setenv("AISGPU_K1U_SPW", str(spw))
+    xs = [synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=360 + r, gap_slots=(0, 2)) for r in range(3)]
+    _run_outputs_vs_oracle(xs, rate, "cf32", block, nblocks)
+
+
 def test_fft_bin_magnitude_matches_hypot_restatement():
     """The FFT-bin magnitude routine (double sqrt without the denormal rescaling) against the glibc-equivalent
     hypotf restatement on 16M inputs: random bit patterns over the exponent range IQ data can reach, IQ-like
