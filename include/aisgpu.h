@@ -77,7 +77,10 @@ extern "C" {
                                    * NULL (no pinned host slots are allocated for them), frames come back (NMEA text, tag.ppm and tag.level equal the
                                    * reference's bit for bit; std::polar = glibc 2.35's sinf / cosf restated in the FMA variant its ifunc selects on x86-64
                                    * hosts with FMA: aisgpu_create() checks the restatement against the host's own sinf / cosf and refuses the flag for
-                                   * this model with AISGPU_ERR_ARG where they differ -- see INTEGRATION.md) */
+                                   * this model with AISGPU_ERR_ARG where they differ -- see INTEGRATION.md.  That check is a SAMPLE: every float of a
+                                   * 2^-20 grid over [-1.7, 1.7] plus a geometric sweep towards 0, 3.6 M of the ~10^9 floats FreqOffset::Derotate's argument
+                                   * can take (Estimate interpolates between bins, V2Engine.cpp:113-128, so the set is not finite in practice).  It
+                                   * recognises a libm whose algorithm or FMA variant differs; it cannot prove equality on every argument) */
 #define AISGPU_FLAG_FP_DS 32  /* KEY_SETTING_FP_DS (`-go FP_DS on`, `-F`): 1536 kSPS CU8 input goes through the fixed-point ladder
                                * Downsample16_CU8 (DSP/DSP.cpp:499-651, Model.cpp:231-237); ignored at other rates like in the reference */
 #define AISGPU_FLAG_MODE_X 64 /* channel mode X (`-c X`, Receiver.cpp:87-98, Model.cpp:35-107): ONE channel, already centred, sample_rate
