@@ -210,7 +210,9 @@ __device__ __forceinline__ void reg_stage(const T (&x)[C], HaloState<C, T>& hs, 
 #pragma unroll
 	for (int i = 0; i < C - 1; i++) v[5 + i] = x[i];
 	cic5_dec_chunk_v<C / 2, T, SHIFT>(v, out);
+#ifndef ABL_NO_PUT // (ablation builds only: wrong results, measures what the carry moves cost)
 	put_halo<C, T>(x, hs, h);
+#endif
 }
 template <int C>
 __device__ __forceinline__ void reg_stage(const c2 (&x)[C], HaloState<C, c2>& hs, c2 (&out)[C / 2]) { reg_stage<0, C, c2>(x, hs, out); }
@@ -881,14 +883,35 @@ __global__ void k1_tail(const unsigned char* in, long long in_stride_bytes, long
 // |X| via the glibc-equivalent hypot, the *sequential* float prefix sum (one lane, 511 adds: a
 // parallel scan would round differently), then the two first-maximum searches as wave reductions.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_argmax_first(float& v, int& i) {
-	// larger value wins; ties -> lower index (the reference scans upward with a strict '>')
-#pragma unroll
-	for (int off = 32; off >= 1; off >>= 1) {
-		float ov = __shfl_xor(v, off);
-		int oi = __shfl_xor(i, off);
-		if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-	}
+// Wave-wide "first maximum": the lane values v >= 0 (sums of magnitudes; a lane without a candidate holds `none`, which is below every
+// candidate) with their indices i; afterwards every lane holds the largest v and, among the lanes that had it, the smallest i -- what
+// the reference's upward scan with a strict '>' finds.  For non-negative floats the IEEE order is the order of the bit patterns, so the
+// maximum is an unsigned integer maximum, taken in six DPP steps (two inside the quads, half-row and row mirror, then the row
+// broadcasts 15 and 31 that gfx9 has: the result arrives in lane 63) plus a v_readlane; the index is a second reduction (minimum
+// over the lanes that hold the maximum).  Rounds 1-5 did this with ds_bpermute butterflies: 12 LDS round trips and ~120 instructions
+// with branches per reduction, a third of the spectral analysis' instructions (profiles/r06_expB_fft_tail_argmax.txt).
+// Precondition: no lane holds NaN or a negative value other than `none` (the callers' `v > best` never lets a NaN in).
+template <bool IS_MIN>
+__device__ __forceinline__ unsigned wave_reduce_u32(unsigned k) {
+	const auto op = [](unsigned a, unsigned b) { return IS_MIN ? (a < b ? a : b) : (a > b ? a : b); };
+	k = op(k, (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+	k = op(k, (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+	k = op(k, (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, 0x141, 0xF, 0xF, false)); // row_half_mirror
+	k = op(k, (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, 0x140, 0xF, 0xF, false)); // row_mirror: every lane has its row's result
+	k = op(k, (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, 0x142, 0xA, 0xF, false)); // row_bcast:15 into rows 1 and 3
+	k = op(k, (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, 0x143, 0xC, 0xF, false)); // row_bcast:31 into rows 2 and 3
+	return (unsigned)__builtin_amdgcn_readlane((int)k, 63);
+}
+__device__ __forceinline__ void wave_argmax_first(float& v, int& i, float none) {
+#ifdef ABL_NO_ARGMAX
+	return;
+#endif
+	// key 0: no candidate; a candidate's key is its bit pattern + 1 (so that a candidate of +0.0 still beats "none")
+	const unsigned key = v > none ? __float_as_uint(v) + 1u : 0u;
+	const unsigned m = wave_reduce_u32<false>(key);
+	const unsigned first = wave_reduce_u32<true>(key == m ? (unsigned)i : 0x7fffffffu);
+	v = m ? __uint_as_float(m - 1u) : none;
+	i = (int)first;
 }
 
 // K2a is two kernels.
@@ -1124,7 +1147,7 @@ __device__ __forceinline__ void spectral_search(const float (&m)[NWIN][8], float
 					if (v > best) { best = v; bi = i; }
 				}
 			}
-			wave_argmax_first(best, bi);
+			wave_argmax_first(best, bi, -1.0f);
 			if (!(best > -1.0f)) bi = 0;
 			wi = bi + 66 - 256; // wi + M/2 - N/2
 		}
@@ -1136,7 +1159,7 @@ __device__ __forceinline__ void spectral_search(const float (&m)[NWIN][8], float
 			const float v = Ms[(i + 512) & 511] + Ms[(i + 102 + 512) & 511];
 			if (v > 0.0f) { h = v; hidx = i; }
 		}
-		wave_argmax_first(h, hidx);
+		wave_argmax_first(h, hidx, 0.0f);
 		fz[w] = (h > 0.0f) ? (205 - hidx) : -1;
 	}
 }
@@ -1667,6 +1690,9 @@ __device__ __forceinline__ unsigned ps_step(float2 v, float pc, float psn, c2& M
 		left = MODE == 0 ? r1 : r15;
 		right = MODE == 0 ? r15 : r1;
 	}
+#ifdef ABL_NO_WALK // (ablation builds only: wrong results)
+	{ const unsigned long long X0 = hs.h3 ^ hs.h4; hs.h4 = hs.h3; hs.h3 = hs.h2; hs.h2 = hs.h1; hs.h1 = dn; (void)left; (void)right; return (unsigned)X0 & 1u; }
+#endif
 	const bool p0 = ma > left;         // centre beats idx-1
 	const float bestc = p0 ? ma : left;
 	const bool p1 = right > bestc;     // idx+1 beats the better of the two

@@ -1,11 +1,11 @@
 #!/bin/bash
-# A/B builds x environment settings on one GPU box: tools/abenv.sh rounds "lib.so[,VAR=v,...]" ...
+# A/B builds x environment settings on one GPU box: tools/abenv.sh rounds "lib.so[,VAR=v,...]" ...   (STEPS=, PARITY=, ABARGS="--config 3" in the environment)
 cd "$(dirname "$0")/.."
 N=$1; shift
 for i in $(seq $N); do
   for SPEC in "$@"; do
     L=${SPEC%%,*}; E=""; [ "$SPEC" != "$L" ] && E=$(echo "${SPEC#*,}" | tr ',' ' ')
-    env $E AISGPU_LIB=$(realpath $L) python bench.py --steps 40 --warmup 5 --no-cpu-baseline --parity-receivers 4 2>/dev/null | python -c "
+    env $E AISGPU_LIB=$(realpath $L) python bench.py --steps ${STEPS:-40} --warmup 5 --no-cpu-baseline --no-pmc --no-other-configs --parity-receivers ${PARITY:-4} $ABARGS 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
