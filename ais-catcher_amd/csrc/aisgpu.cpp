@@ -252,6 +252,11 @@ struct aisgpu {
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
 	int k1u_spw = 0; // test hook "k1u_spw": forces the resampler front end's span walk (launch_k1u)
+	// Round 6: the tail of a resampled ladder with two stages behind Upsample (every bucket from 384k up: 6 MSPS, 2.4 MSPS, 10 MSPS ...)
+	// as one-wave workgroups of the front-end kernel itself -- k1_dpp<2, 5, false>: Upsample outputs computed where the other formats
+	// convert, DS2_2 / DS2_1 in registers, and with the fused back end the spectral analysis at the end of its waves -- instead of
+	// k1u_resample_frontend (320-thread workgroups, six barriers per 128 outputs) + k2_fft_search_win.  Test hook "us_k1" = 0: the old pair.
+	bool us_k1 = false, us_fft_in_k1 = false; int us_tiles_per_block = 0, us_tiles_per_span = 0;
 	bool us_on_ds = false; // resampled ladders: the resampler front end on the downstream stream, the second half of a flush one flush late (fixed by the mode at create, not an option)
 	bool fm_on_s1 = false, fm_ev_used = false; hipEvent_t ev_fm = nullptr; // where the device decoders' regrouping of ModelChallenger's FM bits (k7_pack) runs: in front of PhaseSearch on s1 on the resampled ladders, else behind K6 on s4 (fixed by the mode; ev_fm only exists with challenger + gpu_decode + a resampled ladder)
 	bool fused = false; // derotation + FIR + ScatterPLL as one kernel behind the checkpointed phasor recurrence (the default)
@@ -699,7 +704,9 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	const long long g0 = h->n48 / 5, g1 = (h->n48 + h->L) / 5; // groups completed inside this block (DSP/DSP.h:95-117)
 	const int n_groups = (int)(g1 - g0), n_rel0 = (int)(g0 * 5 - h->n48);
 	k2.ck = h->d_ck[q]; k2.ck_stride = k2.rotT_stride;
-	if (h->fft_in_k1) {
+	if (h->us_fft_in_k1) {
+		// (resampled ladder: the caller has recorded k1_done[q] on the stream its front-end waves ran on)
+	} else if (h->fft_in_k1) {
 		// the front-end waves have done the whole analysis (k1_fft_tail): fz / ppm of this block are there when K1 is
 		if (!h->k1_done[q]) { HIPCHK(hipEventRecord(h->ev_search[q], h->stream)); h->k1_done[q] = h->ev_search[q]; }
 	} else { // FFT + searches follow the front end on its stream (four busy streams are the limit)
@@ -1117,7 +1124,7 @@ const char* aisgpu_last_error(aisgpu_t* h) { return h ? h->err.c_str() : ""; }
 
 int aisgpu_set_option(const char* key, const char* value) {
 	if (!key || !*key) return AISGPU_ERR_ARG;
-	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "k46", "k1u_spw", "trace", "k7e_stats", "k7b_stats" };
+	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "k46", "k1u_spw", "us_k1", "trace", "k7e_stats", "k7b_stats" };
 	bool ok = false;
 	for (const char* k : known) ok = ok || strcmp(k, key) == 0;
 	if (!ok) return AISGPU_ERR_ARG;
@@ -1537,6 +1544,14 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 			h->tiles_per_span = t;
 			h->spans = h->tiles_per_block / t;
 		} else h->fft_in_k1 = false;
+	}
+	h->us_k1 = mode == MODE_RESAMPLE && h->npost == 2 && !h->mode_x && !h->us_dsk && h->n_pre % (16 * 256) == 0 && opt_int("us_k1", 1) != 0;
+	if (h->us_k1) { // tiles of 256 Upsample outputs (64 samples at 96 kHz); spans of whole 512-sample windows (16 tiles), two where the flush allows it
+		h->us_tiles_per_block = h->n_pre / 256;
+		int t = (h->us_tiles_per_block % 32 == 0 && h->us_tiles_per_block >= 64) ? 32 : 16;
+		if (cfg->tiles_per_span >= 16 && cfg->tiles_per_span % 16 == 0 && h->us_tiles_per_block % cfg->tiles_per_span == 0) t = cfg->tiles_per_span;
+		h->us_tiles_per_span = t;
+		h->us_fft_in_k1 = h->fused && opt_int("fft_in_k1", 1) != 0;
 	}
 	if (h->fused) {
 		for (int i = 0; i < NBUF; i++) HIPCHK(dalloc(&h->d_ck[i], (C + 63) / 64 * 64 * (size_t)h->W * CK_SLOTS)); // phasor checkpoints per (window, slot, chain)
@@ -1975,6 +1990,22 @@ int aisgpu_run(aisgpu_t* h) {
 				ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
 				ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->has_fdc; ku.L = h->L;
 				if (h->mode_x) HIPCHK(launch_k1x(ku, h->npost, R, st));
+				else if (h->us_k1) { // the same stages as one-wave workgroups of the front-end kernel (see us_k1)
+					K1Params k1{};
+					k1.in = nullptr; k1.in_stride = 0; k1.hist = nullptr; k1.hist_out = nullptr;
+					k1.us_idx = ku.us_idx; k1.us_alpha = ku.us_alpha;
+					k1.xin = ku.xin; k1.xin_stride = ku.xin_stride; k1.xin_off = ku.xin_off; k1.xprev = ku.xprev; k1.xprev2 = ku.xprev2; k1.n_in = ku.n_in;
+					k1.rot = ku.rot; k1.c48 = ku.c48; k1.c48_stride = ku.c48_stride;
+					k1.tiles_per_block = h->us_tiles_per_block; k1.tiles_per_span = h->us_tiles_per_span;
+					k1.alpha = h->alpha; k1.beta = h->beta; k1.has_fdc = h->has_fdc; k1.stream_start = 0;
+					k1.pre_out = nullptr; k1.pre_stride = 0;
+					if (h->us_fft_in_k1) {
+						k1.fft_windows = h->us_tiles_per_span / 16; k1.n_windows = h->W; k1.wide = h->cfg.afc_wide ? 1 : 0;
+						k1.omega = h->d_omega; k1.ppm_table = h->d_ppmtab; k1.fz = h->d_fz[q]; k1.ppm = h->d_ppm[q];
+					}
+					{ TraceScope t(h, "usfront", st); HIPCHK(launch_k1(k1, 2, 5, h->us_tiles_per_block / h->us_tiles_per_span, R, st)); }
+					if (h->us_fft_in_k1) { HIPCHK(hipEventRecord(h->ev_search[q], st)); h->k1_done[q] = h->ev_search[q]; } // fz / ppm of the flush are there when these waves are
+				}
 				else { ku.spw_force = h->k1u_spw; HIPCHK(launch_k1u(ku, h->npost, R, st)); }
 			}
 			HIPCHK(hipEventRecord(h->us_used_ev[slot], st));

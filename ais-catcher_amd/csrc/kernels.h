@@ -29,6 +29,14 @@ struct K1Params {
 	const float* ppm_table;  // [FZ_COUNT]
 	int* fz;                 // [n_rx * 2][n_windows]
 	float* ppm;              // [n_rx * 2][n_windows]
+	// FMT 5 (round 6: the tail of a resampled ladder in the front-end waves, k1_dpp<2, 5, false>): the block is one flush of Upsample
+	// (DSP.cpp:192-212) and its samples are not read but COMPUTED where the other formats convert -- input sample n of the block is
+	// Upsample output n of the flush, (1 - alpha) * x[b - 1] + alpha * x[b], (b, alpha) from the tables of K1uParams ([US_HIST + len]),
+	// x the pre-decimated stream with its ring of earlier blocks (the fields of K1uParams: make_xrow)
+	const int* us_idx = nullptr; const float* us_alpha = nullptr;
+	const float2* xin = nullptr; long long xin_stride = 0; long long xin_off = 0;
+	const float2* xprev = nullptr; const float2* xprev2 = nullptr; int n_in = 0;
+	const float2* xhist = nullptr; int xhist_len = 0;
 };
 
 constexpr int US_HIST = 96;  // resampler table entries carried in front of each flush block (halo of K1u: 84)

@@ -291,7 +291,7 @@ __device__ __forceinline__ void wave_sync() {
 #endif
 // FMT: input sample format (Utilities/StreamHelpers.cpp:51-133): 0 = CF32, 1 = CU8, 2 = CS8, 3 = CS16;
 // 4 = CU8 through the fixed-point ladder Downsample16_CU8 (K = 4 only)
-constexpr int fmt_bytes(int fmt) { return fmt == 0 ? 8 : fmt == 3 ? 4 : 2; }
+constexpr int fmt_bytes(int fmt) { return fmt == 0 || fmt == 5 ? 8 : fmt == 3 ? 4 : 2; } // (5: Upsample outputs computed in the wave, see K1Params::us_idx)
 
 __device__ __forceinline__ void k1_fft_tail(const K1Params& p, int rx, int span, float2* X); // below, with the FFT
 
@@ -315,10 +315,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 6 ? 1 :
 	const int lane = threadIdx.x;
 	const int rx = blockIdx.y;
 	const int span = blockIdx.x;
-	__builtin_amdgcn_s_setprio(K1_PRIO);
+#ifndef K1US_PRIO
+#define K1US_PRIO K1_PRIO
+#endif
+	__builtin_amdgcn_s_setprio(FMT == 5 ? K1US_PRIO : K1_PRIO);
 	// Occupancy cap: ~120 VGPRs and ~10 KB of LDS let FOUR of these one-wave workgroups share a SIMD, and sixteen of them hold
 	// 156 of a CU's 160 KB of LDS -- nothing that needs LDS (the FFT, the staged PhaseSearch) gets on the CU beside them.  The
 	// kernel is as fast with three (HBM-bound); naming v135 as clobbered makes its allocation 136 registers = three per SIMD.
+#ifdef K1US_NO_CLOBBER
+	if constexpr (FMT != 5)
+#endif
 	asm volatile("" ::: "v135");
 
 	if (lane < 8) { x5[0][lane] = x5[1][lane] = x6[0][lane] = x6[1][lane] = make_float2(0.f, 0.f); }
@@ -372,7 +378,52 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 6 ? 1 :
 			pre[0] = make_uint4(((const unsigned*)base)[lane], 0, 0, 0);
 		}
 	};
-	prefetch(tile_first);
+	// FMT 5: the tile's samples are Upsample outputs n = 4 C0' ... computed from the pre-decimated stream.  Two loads deep: the table
+	// entries (input index b, alpha) of a lane's C0 outputs travel two tiles ahead, the input samples they point at one tile ahead.
+	// Output n of the flush lives at table index US_HIST + n; the warm-up tile of span 0 reaches back to n = -64 C0, the tables to
+	// n = -US_HIST, which covers the dependency cone of everything behind (83 + 8 samples, like k1u_resample_frontend's halo): the lanes
+	// in front of that produce zeros that never reach a stored output.
+	static_assert(FMT != 5 || (K == 2 && !PRE), "k1_dpp: the resampled form is the two-stage tail of the ladder");
+	struct UsTab { int ib[FMT == 5 ? C0 : 1]; float al[FMT == 5 ? C0 : 1]; };
+	struct UsXs { float2 a[FMT == 5 ? C0 : 1], b[FMT == 5 ? C0 : 1]; float al[FMT == 5 ? C0 : 1]; bool dead; };
+	UsTab us_tab = {};
+	UsXs us_xs = {};
+	XRow us_row = {};
+	if constexpr (FMT == 5) us_row = make_xrow(p, rx);
+	const auto us_tab_fetch = [&](int tile, UsTab& t) {
+		if constexpr (FMT == 5) {
+			int n0 = tile * TILE_IN + lane * C0;
+			n0 = n0 < -US_HIST ? -US_HIST : n0;
+			const int4 ib = *reinterpret_cast<const int4*>(p.us_idx + US_HIST + n0);
+			const float4 al = *reinterpret_cast<const float4*>(p.us_alpha + US_HIST + n0);
+			t.ib[0] = ib.x; t.ib[1] = ib.y; t.ib[2] = ib.z; t.ib[3] = ib.w;
+			t.al[0] = al.x; t.al[1] = al.y; t.al[2] = al.z; t.al[3] = al.w;
+		}
+	};
+	const auto us_xs_fetch = [&](int tile, const UsTab& t, UsXs& q) {
+		if constexpr (FMT == 5) {
+			q.dead = tile * TILE_IN + lane * C0 < -US_HIST;
+			// the input samples of a whole tile nearly always lie in ONE of the ring's blocks: a wave-uniform base then (us_idx is non-decreasing)
+			const int lo = __builtin_amdgcn_readfirstlane(t.ib[0]) - 1, hi = __builtin_amdgcn_readlane(t.ib[C0 - 1], 63);
+			const XSpan x(us_row, lo, hi);
+			if (!x.mixed) { // (wave-uniform)
+#pragma unroll
+				for (int i = 0; i < C0; i++) { q.a[i] = x.base[t.ib[i] - 1]; q.b[i] = x.base[t.ib[i]]; }
+			} else {
+#pragma unroll
+				for (int i = 0; i < C0; i++) { q.a[i] = us_row[t.ib[i] - 1]; q.b[i] = us_row[t.ib[i]]; }
+			}
+#pragma unroll
+			for (int i = 0; i < C0; i++) q.al[i] = t.al[i];
+		}
+	};
+	if constexpr (FMT == 5) {
+		static_assert(FMT != 5 || C0 == 4, "k1_dpp: one int4 / float4 of table entries per lane");
+		UsTab t0 = {};
+		us_tab_fetch(tile_first, t0);
+		us_xs_fetch(tile_first, t0, us_xs);
+		us_tab_fetch(tile_first + 1 <= tile_last ? tile_first + 1 : tile_last, us_tab);
+	} else prefetch(tile_first);
 	float2 rot_next = make_float2(1.0f, 0.0f);
 	if (!PRE) rot_next = p.rot[(size_t)ROT_HIST + (long long)tile_first * 64 + lane];
 
@@ -394,6 +445,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 6 ? 1 :
 				const int re = FMT == 1 ? (int)(v & 255u) - 128 : (int)(signed char)(v & 255u);
 				const int im = FMT == 1 ? (int)((v >> 8) & 255u) - 128 : (int)(signed char)((v >> 8) & 255u);
 				x[i] = c2{ (float)re * 0.0078125f, (float)im * 0.0078125f };
+			}
+		} else if constexpr (FMT == 5) { // Upsample (DSP.cpp:192-212): (1 - alpha) * a + alpha * b, products and sum rounded separately (as k1u_resample_frontend)
+#pragma unroll
+			for (int i = 0; i < C0; i++) {
+				const float al = us_xs.al[i], w0 = 1 - al;
+				const float2 a = us_xs.a[i], b = us_xs.b[i];
+				x[i] = us_xs.dead ? c2{ 0.0f, 0.0f } : c2{ w0 * a.x + al * b.x, w0 * a.y + al * b.y };
 			}
 		} else if constexpr (FMT == 3) { // Utilities/Convert.cpp:277-286: (int16) / 32768.0f (exact)
 			const unsigned* w = reinterpret_cast<const unsigned*>(pre);
@@ -421,7 +479,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 6 ? 1 :
 		// at the top of the loop, where the tile itself is awaited anyway
 		const float2 rotv = rot_next;
 		const int tile_n = tile + 1 <= tile_last ? tile + 1 : tile_last;
-		prefetch(tile_n);
+		if constexpr (FMT == 5) {
+			us_xs_fetch(tile_n, us_tab, us_xs); // (x[] above holds this tile: its registers are free)
+			us_tab_fetch(tile + 2 <= tile_last ? tile + 2 : tile_last, us_tab);
+		} else prefetch(tile_n);
 		if (!PRE) rot_next = p.rot[(size_t)ROT_HIST + (long long)tile_n * 64 + lane];
 
 		c2 x96;
@@ -4404,6 +4465,13 @@ static hipError_t launch_k1_dpp_k(const K1Params& p, int fmt, int spans, int n_r
 		if constexpr (K == 4) {
 			if (p.pre_out != nullptr) return hipErrorInvalidValue;
 			K1_LAUNCH((k1_dpp<4, 4, false>), ev, dim3(spans, n_rx), s, p);
+			return hipGetLastError();
+		}
+		break;
+	case 5: // the tail of a resampled ladder: Upsample outputs computed in the wave (K1Params::us_idx)
+		if constexpr (K == 2) {
+			if (p.pre_out != nullptr || !p.us_idx || !p.us_alpha || !p.xin) return hipErrorInvalidValue;
+			K1_LAUNCH((k1_dpp<2, 5, false>), ev, dim3(spans, n_rx), s, p);
 			return hipGetLastError();
 		}
 		break;

@@ -240,6 +240,8 @@ void aisgpu_timing(aisgpu_t* h, int enable);
  *                   exact, 0.24 GB less traffic per step, measured 5 % slower) instead of k6_window_fir + k4_phase_chunks
  *   "k1u_spw"       2 / 4 / 8: the resampler front end (k1u_resample_frontend) walks that many consecutive spans per workgroup whatever the
  *                   batch size (by default only batches of ~200 receivers and more get walks longer than one span)
+ *   "us_k1"         0: the tail of the resampled ladders (buckets from 384k up) as k1u_resample_frontend + the FFT / search kernel, the form
+ *                   of rounds 3-5, instead of one-wave workgroups of the front-end kernel (k1_dpp<2, 5, false>, round 6)
  * Returns AISGPU_ERR_ARG for an unknown key. */
 int aisgpu_set_option(const char* key, const char* value);
 

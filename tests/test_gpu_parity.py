@@ -621,8 +621,25 @@ def test_resampler_front_end_span_walk(spw, rate, block, nblocks, monkeypatch):
     and more; the test hook "k1u_spw" forces them for three receivers -- also on flushes whose span count is not a multiple of the
     walk (blocks of three 512-sample windows = 12 spans: the walk falls back to 4), with two and with one stage behind the resampler."""
     monkeypatch.setenv("AISGPU_K1U_SPW", str(spw))
+    monkeypatch.setenv("AISGPU_US_K1", "0")  # (round 6: by default the ladders with two stages behind the resampler end in k1_dpp<2, 5, false> instead)
     xs = [synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=360 + r, gap_slots=(0, 2)) for r in range(3)]
     _run_outputs_vs_oracle(xs, rate, "cf32", block, nblocks)
+
+
+@pytest.mark.parametrize("us_k1", ["1", "0"])
+@pytest.mark.parametrize("rate,block,nblocks,fmt", [(6000000, 786432, 6, "cf32"), (2400000, 393216, 6, "cu8"), (10000000, 786432, 5, "cf32"), (1000000, 512 * 32 * 3, 8, "cs16"),
+                                                    (5000000, 512 * 128, 14, "cf32"), (700000, 512 * 16 * 5, 9, "cf32")])
+def test_resampled_ladder_tail_in_the_front_end_waves(us_k1, rate, block, nblocks, fmt, monkeypatch):
+    """Round 6: Upsample -> DS2_2 -> DS2_1 -> FDC -> Rotate -> DS2_a/b -> FilterCIC5 (Model.cpp:163-189, DSP.cpp:192-212) as one-wave
+    workgroups of the front-end kernel -- k1_dpp<2, 5, false>: a lane computes its four Upsample outputs from the pre-decimated
+    stream (tables two tiles ahead, samples one tile ahead), the two stages run in registers, the spectral analysis rides at the end
+    of the waves -- against the oracle, and the same configurations through the form of rounds 3-5 (k1u_resample_frontend +
+    k2_fft_search_win, test hook us_k1 = 0).  Flushes that straddle input blocks (every one at these ratios), one-window flushes
+    (5 MSPS with 65,536-sample blocks: 16 tiles, one span), the first flush's halo in front of the stream, integer input formats."""
+    monkeypatch.setenv("AISGPU_US_K1", us_k1)
+    conv = {"cu8": synth.to_cu8, "cs16": synth.to_cs16, "cf32": lambda v: v}[fmt]
+    xs = [conv(synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=370 + r, gap_slots=(0, 2))) for r in range(3)]
+    _run_outputs_vs_oracle(xs, rate, fmt, block, nblocks)
 
 
 def test_fft_bin_magnitude_matches_hypot_restatement():
