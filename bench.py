@@ -59,6 +59,12 @@ CONFIGS = {
     4: {"key": "configs[3]", "rate": 1536000, "model": 2, "model_name": "ModelDefault", "receivers": 256, "bytes": 8.30,
         "kernel": "k1_dpp (front end: CIC5 ladder + FDC + Rotate + DS2 + FCIC5 + the spectral analysis of every window: FFT-512, prefix sum, peak searches)",
         "what": "%d batched dual-channel receivers per GPU, 1536 kSPS CF32"},
+    # not a BASELINE config: configs[3]'s batch with the input as CU8 (what BASELINE configs[0] reads and RTL-SDRs deliver), converted
+    # inside the front-end kernel (Utilities/Convert.cpp:255-264).  2.30 algorithmic B/sample: the same arithmetic on 3.6 x fewer bytes,
+    # so its step time is the chain's compute / latency floor -- reported in other_configs of the default run
+    5: {"key": "configs[3] with CU8 input", "rate": 1536000, "model": 2, "model_name": "ModelDefault", "receivers": 256, "bytes": 2.30, "format": "cu8",
+        "kernel": "k1_dpp<4, CU8, false> (the same front end, CU8 -> CF32 in its lanes)",
+        "what": "%d batched dual-channel receivers per GPU, 1536 kSPS CU8 (the synthetic CF32 batch as round(x * 128 + 128) bytes)"},
 }
 
 
@@ -388,13 +394,14 @@ def pmc_traffic_pass(config, receivers):
 
 
 def other_configs(steps=20, warmup=5):
-    """BASELINE configs[1] (one receiver) and configs[2] (6 MSPS, ModelChallenger, 256 receivers) behind the default workload's timed
+    """BASELINE configs[1] (one receiver), configs[2] (6 MSPS, ModelChallenger, 256 receivers) and the default batch with CU8 input
+    (2.30 algorithmic B/sample: the chain's compute floor, its whole_chain_frac priced at those bytes) behind the default workload's timed
     region and gate: the same code path (this script with --config 2 / 3, the driver's 20-step shape, parity gate on), each in a
     process of its own so that nothing of the main run is resident beside it.  One short record per config in the line.  A parity
     MISMATCH in one of them fails the whole run (main() returns 3, like a mismatch of the default workload); a child that times out or
     dies leaves an "error" / a non-zero "exit_status" in its record and the main line stands (its numbers do not depend on them)."""
     out = []
-    for cfg in (2, 3):
+    for cfg in (2, 3, 5):
         cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--steps", str(steps), "--warmup", str(warmup),
                "--no-cpu-baseline", "--no-pmc", "--no-other-configs"]
         rec = {"baseline_config": CONFIGS[cfg]["key"], "steps": steps, "warmup": warmup}
@@ -551,7 +558,15 @@ def main():
     torch.cuda.set_device(local)
     numa = pin_to_gpu_numa_node(local) if world > 1 else None   # one process per GPU on the GPU's NUMA node
     data = workload.resident_batch(torch, R, nb, seed=rx_ids[0] // R, unique=min(8, R), sample_rate=rate)
-    g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=BLOCK, device_id=local, gpu_decode=args.gpu_decode, model=model, tiles_per_span=args.tiles_per_span)
+    fmt = C.get("format", "cf32")
+    blocks_of = None
+    if fmt == "cu8":   # Util::Convert's input: unsigned bytes, I then Q (the reference's file format `-r cu8`)
+        data = torch.clamp(torch.round(data * 128.0 + 128.0), 0, 255).to(torch.uint8)
+        torch.cuda.synchronize()
+        blocks_of = lambda r: [data[b, r].cpu().numpy().reshape(-1) for b in range(nb)]
+    in_fmt = {"cf32": gpu.FMT_CF32, "cu8": gpu.FMT_CU8}[fmt]
+    g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=BLOCK, device_id=local, gpu_decode=args.gpu_decode, model=model, tiles_per_span=args.tiles_per_span,
+                   input_format=in_fmt)
     sequence = workload.block_sequence(args.preroll, args.warmup, args.steps, nb)
     it = iter(sequence)
 
@@ -605,7 +620,7 @@ def main():
             frames_checked = len(frames)
         n = min(args.parity_receivers, R)
         receivers = sorted(set(int(round(i * (R - 1) / max(n - 1, 1))) for i in range(n)))
-        n_checked, mismatches = parity_check(g, data, sequence, receivers, rate=rate, model=model, frames=frames)
+        n_checked, mismatches = parity_check(g, data, sequence, receivers, rate=rate, model=model, frames=frames, fmt=fmt, blocks_of=blocks_of)
 
     # ---- host cost of one aisgpu_run() with the device idle (no back-pressure): what the calling thread pays per block
     host_ms = []
@@ -618,7 +633,7 @@ def main():
     host_ms = sorted(host_ms[2:])
     g.close()
     # the same kernel measured without the other streams' kernels competing for the chip (untimed extra steps)
-    gs = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=BLOCK, device_id=local, serial=True, model=model)
+    gs = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=BLOCK, device_id=local, serial=True, model=model, input_format=in_fmt)
     for i in range(2):
         gs.submit_device(data[i % nb].data_ptr(), BLOCK)
         gs.run()
@@ -659,7 +674,7 @@ def main():
                 pass
             break
     res = {
-        "metric": "IQ Msamples/s (CFLOAT32) through %s chain" % C["model_name"], "value": round(value, 1),
+        "metric": "IQ Msamples/s (%s) through %s chain" % ("CFLOAT32" if fmt == "cf32" else fmt.upper(), C["model_name"]), "value": round(value, 1),
         "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
         "host_cost_ms_per_step": round(float(np.median(host_ms)), 4),
