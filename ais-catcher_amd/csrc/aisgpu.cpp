@@ -1941,12 +1941,20 @@ int aisgpu_run(aisgpu_t* h) {
 		else HIPCHK(launch_k1_tail(h->cur_in, h->cur_in_stride * h->in_bytes, (long long)h->cfg.block_len * h->in_bytes, h->d_hist[hb ^ 1],
 		                           h->tile_in * h->in_bytes, R, h->stream));
 		if (!h->serial && h->fused) {
-			// The tables of the next blocks, on s3 in front of this block's phasor recurrence -- TWO blocks ahead: on s3
-			// the copy runs when the recurrence of block f-1 is through, and with a lead of one the front end of block f+1 had to
-			// wait for exactly that -- a loop front end(f-1) -> recurrence(f-1) -> table(f+1) -> front end(f+1) that held the step at
-			// (front end + recurrence + copy) / 2 = 0.47 ms.  d_rot[(f+2) & 3] was last read by the front end of block f-2.
+			// The tables of the next blocks -- TWO blocks ahead, on s4 (refine + derotation / FIR) since round 6.  Rounds 2-5 had the copy on
+			// s3 in front of this block's phasor recurrence: with a lead of one the front end of block f+1 had to wait for the recurrence of
+			// block f-1 to be through -- a loop front end(f-1) -> recurrence(f-1) -> table(f+1) -> front end(f+1) that held the step at
+			// (front end + recurrence + copy) / 2 = 0.47 ms -- hence the lead of two; but s3 is also where a LONE receiver's step is
+			// decided: its recurrences run back to back there (0.181 ms each, a chain across blocks that nothing shortens), and the
+			// 20-25 us copy kernel between two of them (it reads pinned host memory) was a tenth of BASELINE configs[1]'s 0.219 ms per
+			// block: 0.195-0.203 with the copy on s4, whose kernels of block f-1 also run behind that block's recurrence, so the slot
+			// d_rot[(f+2) & 3] -- last read by the front end of block f-2 -- is free as before.  256 receivers: unchanged (+-0.3 %).
 			while (h->rot_next <= h->block_idx + 2) {
-				int rc = stage_rot((int)(h->rot_next & 3), h->s3);
+				if (h->rot_next >= 4) { // (explicitly, for the stream plans in which s4 carries nothing of block f-1: option k46)
+					const int qr = (int)((h->rot_next - 4) % NBUF);
+					WAITEV(h->s4, h->k1_done[qr] ? h->k1_done[qr] : h->ev_search[qr]);
+				}
+				int rc = stage_rot((int)(h->rot_next & 3), h->s4);
 				if (rc) return rc;
 				h->rot_next++;
 			}

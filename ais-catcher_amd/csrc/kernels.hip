@@ -513,14 +513,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 6 ? 1 :
 			wave_sync();
 			// ---- DS2_a / DS2_b: lanes 0..31 channel A, lanes 32..63 channel B
 			const int ch = lane >> 5, j = lane & 31;
+#ifdef ABL_NO_LDS_TAIL // (ablation builds only: wrong results -- the same arithmetic on registers, no LDS round trip to wait for)
+			{
+				float2 vv[6] = { make_float2(RR, II), make_float2(RI, IR), make_float2(II, RR), make_float2(IR, RI), make_float2(RR, RI), make_float2(II, IR) };
+				float2 oo[1];
+				cic5_dec_chunk<1>(vv, oo);
+				x6[ch][8 + j] = oo[0];
+			}
+#else
 			x6[ch][8 + j] = cic5_small(reinterpret_cast<const float4*>(&x5[ch][0]), j);
+#endif
 			wave_sync();
 			// ---- FilterCIC5 (DSP.cpp:132-157)
 			{
 				const float2* src = &x6[ch][8 + j - 5];
 				float2 v[6];
+#ifdef ABL_NO_LDS_TAIL
+				for (int e = 0; e < 6; e++) v[e] = make_float2(RR * (float)e, II);
+				(void)src;
+#else
 #pragma unroll
 				for (int e = 0; e < 6; e++) v[e] = src[e];
+#endif
 #pragma unroll
 				for (int lvl = 0; lvl < 5; lvl++) {
 #pragma unroll
