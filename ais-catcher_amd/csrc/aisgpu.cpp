@@ -173,7 +173,8 @@ struct aisgpu {
 	                                  // pass over block f+1 must not wait for the resampler kernels of block f
 	bool x_direct = false; float2* d_xhist[2] = {}; // CF32 input of the ladders without a pass at the input rate read in place: the kept tails [R][xh]
 	float2* d_xmid = nullptr;         // [R][block_len >> KPa]: between the two passes of a pre-decimation of more than four stages
-	bool mode_x = false;              // channel mode X: single-channel front end K1x (npost stages down to 48 kHz), channel B silent
+	bool mode_x = false;              // channel mode X: single-channel front end K1x (npost stages down to 48 kHz); receivers packed (chain = receiver), no channel B
+	std::vector<float> h_silent, h_silent_ppm; // what aisgpu_fetch hands out for "channel B" in that mode
 	int npost = 2;                    // CIC5 stages behind the resampler (K1u): 2, 1 (192k bucket), 0 (96 kSPS input: no resampler either)
 	bool us_dsk = false;              // Upsample in front of DownsampleKFilter (rates below a decimate-by-3 bucket): resampler flow, K1k front end
 	int KPa = 0;                      // != 0: the pre-decimation runs as KPa stages, then four (rates above 6144k that are resampled: 8 / 10 MSPS)
@@ -937,6 +938,7 @@ int gather_frames(aisgpu_t* h) {
 			o.rx = (int)(dec / 20); o.ch = (int)(dec / 10 % 2); o.phase = ord < 4 ? 5 + (int)ord : ord == 9 ? 9 : (int)ord - 4; // 5..9: the FM decoders
 		} else if (h->dec_kind == 3) { o.rx = (int)(dec / 2); o.ch = (int)(dec % 2); o.phase = 0; } // ModelBase: one decoder per channel
 		else if (h->dec_kind == 4) { o.rx = (int)(dec / 12); o.ch = (int)(dec / 6 % 2); o.phase = (int)(dec % 6); } // ModelEngineV2: 0..4 behind the trackers, 5 the FM decoder
+		else if (h->mode_x) { o.rx = (int)(dec / 5); o.ch = 0; o.phase = (int)(dec % 5); } // (receivers packed: chain = receiver)
 		else { o.rx = (int)(dec / 10); o.ch = (int)(dec / 5 % 2); o.phase = (int)(dec % 5); }
 		o.group = (int)f[1]; o.position = (int)f[2];
 		memcpy(&o.level_sum, &f[3], 4);
@@ -1265,7 +1267,11 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	h->Gcap = ((h->L + 4) / 5 + 1 + 31) / 32 * 32;
 	h->c48s = (long long)h->L + 32;
 	h->words = h->Gcap / 32;
-	h->n_chan = cfg->n_receivers * 2;
+	// Channel mode X (round 6): ONE channel per receiver, so the receivers are PACKED -- chain r is receiver r, and everything behind
+	// the 48 kHz channels runs over R chains instead of 2 R of which every second one is silence (half of that path's time in rounds
+	// 3-5).  The kernels that take the two channels of "a receiver" together (spectral analysis) see pairs of receivers; an odd batch
+	// gets one silent row at the end.
+	h->n_chan = mode_x ? (cfg->n_receivers + 1) / 2 * 2 : cfg->n_receivers * 2;
 	h->n_chains = h->n_chan * 5;
 	h->has_fdc = cfg->droop && !by3 && k > 0 ? 1 : 0; // no droop filter on the decimate-by-3 ladders (Model.cpp:207-219) nor at 96 kSPS
 	h->alpha = mode_x ? (kx == 2 ? -1.1f : -0.8f) : alphas[k]; // Model.cpp:64,76
@@ -1397,6 +1403,10 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		HIPCHK(hipMemcpy(h->d_omega, omega.data(), 512 * sizeof(float2), hipMemcpyHostToDevice));
 		HIPCHK(hipMemcpy(h->d_step, step.data(), FZ_COUNT * sizeof(float2), hipMemcpyHostToDevice));
 		HIPCHK(hipMemcpy(h->d_ppmtab, ppm.data(), FZ_COUNT * sizeof(float), hipMemcpyHostToDevice));
+		if (mode_x) { // "channel B" of aisgpu_fetch: zero decisions / levels, the ppm of a window without a peak (fz = -1, DSP.cpp:449-456, 484)
+			h->h_silent.assign((size_t)h->Gcap + 64, 0.0f);
+			h->h_silent_ppm.assign((size_t)h->W + 1, ppm[-1 - FZ_MIN]);
+		}
 	}
 	const size_t R = cfg->n_receivers, C = h->n_chan;
 	// history of the raw input: the last tile of the previous block (for the first kernel that touches the input)
@@ -1860,7 +1870,7 @@ int aisgpu_run(aisgpu_t* h) {
 		ku.us_idx = nullptr; ku.us_alpha = nullptr; ku.rot = h->d_rot[pb];
 		ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
 		ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->mode_x ? h->has_fdc : 0; ku.L = h->L;
-		if (h->mode_x) HIPCHK(launch_k1x(ku, h->npost, R, h->stream));
+		if (h->mode_x) { ku.c48_rows_per_rx = 1; HIPCHK(launch_k1x(ku, h->npost, R, h->stream)); }
 		else { ku.spw_force = h->k1u_spw; HIPCHK(launch_k1u(ku, 0, R, h->stream)); }
 		if (h->x_direct) HIPCHK(launch_copy_rows(ku.xin + h->n_pre - h->xh, ku.xin_stride, h->d_xhist[(h->in_blocks & 1) ^ 1], h->xh, h->xh, R, h->stream));
 		int rc = enqueue_downstream(h, q, pb);
@@ -1997,7 +2007,7 @@ int aisgpu_run(aisgpu_t* h) {
 				ku.us_idx = h->d_usidx[slot]; ku.us_alpha = h->d_usalpha[slot]; ku.rot = h->d_usrot[slot];
 				ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
 				ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->has_fdc; ku.L = h->L;
-				if (h->mode_x) HIPCHK(launch_k1x(ku, h->npost, R, st));
+				if (h->mode_x) { ku.c48_rows_per_rx = 1; HIPCHK(launch_k1x(ku, h->npost, R, st)); }
 				else if (h->us_k1) { // the same stages as one-wave workgroups of the front-end kernel (see us_k1)
 					K1Params k1{};
 					k1.in = nullptr; k1.in_stride = 0; k1.hist = nullptr; k1.hist_out = nullptr;
@@ -2121,10 +2131,20 @@ int aisgpu_fetch_sub(aisgpu_t* h, int sub, int rx, int ch, aisgpu_out* o) {
 	if (!h->have_out) return AISGPU_ERR_STATE;
 	if (sub < 0 || sub >= h->n_osub) return AISGPU_ERR_ARG;
 	const size_t C = h->n_chan;
-	const size_t chan = (size_t)rx * 2 + ch;
+	const size_t chan = h->mode_x ? (size_t)rx : (size_t)rx * 2 + ch;
 	const SubOut& so = h->osub[sub];
 	o->n_groups = so.groups;
 	o->first_group = so.first_group;
+	if (h->mode_x && ch == 1) { // channel mode X has no second channel: what a chain fed with silence puts out (decisions 0, level 0, the ppm of "no peak")
+		for (int j = 0; j < 5; j++) o->bits[j] = reinterpret_cast<const uint32_t*>(h->h_silent.data());
+		o->lvl = h->h_silent.data();
+		o->n_windows = h->W;
+		o->ppm = h->h_silent_ppm.data();
+		o->group_window = nullptr;
+		o->first_sample48 = so.first48;
+		o->fm_bits = nullptr; o->c48 = nullptr; o->v2_f = o->v2_prom = o->v2_energy = nullptr;
+		return AISGPU_OK;
+	}
 	const size_t oslot = (size_t)h->oset * MAXSUB + sub; // (eager_out: the set of host slots the synced run wrote)
 	for (int j = 0; j < 5; j++) o->bits[j] = h->h_bits + oslot * C * 5 * h->words + (chan * 5 + j) * h->words;
 	o->lvl = h->h_lvl + oslot * C * h->Gcap + chan * h->Gcap;
@@ -2150,7 +2170,8 @@ long long aisgpu_tap(aisgpu_t* h, int which, int rx, float* dst, long long cap) 
 	if (!(h->cfg.flags & AISGPU_FLAG_TAPS)) return -AISGPU_ERR_STATE;
 	if (h->block_idx == 0 || h->n_sub == 0) return -AISGPU_ERR_STATE;
 	DevGuard dg(h);
-	const size_t chan = (size_t)rx * 2 + (which & 1);
+	if (h->mode_x && (which & 1)) return -AISGPU_ERR_ARG; // (channel mode X: one channel)
+	const size_t chan = h->mode_x ? (size_t)rx : (size_t)rx * 2 + (which & 1);
 	const SubOut& so = h->sub[h->n_sub - 1]; // taps show the last downstream block
 	if (which >= 6) { // real-valued taps of the FM receivers (ModelChallenger FM branch, ModelBase, ModelStandard)
 		if (!h->d_fm || !h->d_fmfir) return -AISGPU_ERR_STATE;

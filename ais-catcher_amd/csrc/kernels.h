@@ -54,6 +54,7 @@ struct K1uParams {
 	// CF32 input read where the caller put it (no converted copy): xin = the caller's rows (xin_off = 0), and the samples in front of the
 	// block come from xhist[rx * xhist_len + xhist_len + i], i in [-xhist_len, 0) -- the previous block's tail, kept by the library
 	const float2* xhist = nullptr; int xhist_len = 0;
+	int c48_rows_per_rx = 2; // k1x_single_channel: rows of c48 per receiver -- 2: the receiver's channel A of a dual-channel layout; 1 (round 6): receivers packed, row = receiver
 	int spw = 1;            // spans (of K1U_M outputs per channel) a workgroup of the resampler front end walks (set by launch_k1u)
 	int spw_force = 0;      // test hook "k1u_spw" (2 / 4 / 8): the span walk of that length whatever the number of workgroups it leaves
 };

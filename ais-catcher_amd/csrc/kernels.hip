@@ -816,7 +816,7 @@ __global__ __launch_bounds__(K1U_T) void k1x_single_channel(K1uParams p) {
 #pragma unroll
 			for (int i = 0; i < 5 - lvl; i++) v[i] = cadd(v[i + 1], v[i]);
 		}
-		p.c48[((size_t)rx * 2) * p.c48_stride + m0 + t] = make_float2(v[0].x * 0.03125f, v[0].y * 0.03125f);
+		p.c48[((size_t)rx * p.c48_rows_per_rx) * p.c48_stride + m0 + t] = make_float2(v[0].x * 0.03125f, v[0].y * 0.03125f);
 	}
 }
 

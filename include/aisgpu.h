@@ -85,7 +85,9 @@ extern "C" {
                                * Downsample16_CU8 (DSP/DSP.cpp:499-651, Model.cpp:231-237); ignored at other rates like in the reference */
 #define AISGPU_FLAG_MODE_X 64 /* channel mode X (`-c X`, Receiver.cpp:87-98, Model.cpp:35-107): ONE channel, already centred, sample_rate
                               * 12000 .. 192000 like the reference (buckets 48k / 96k / 192k, resampled in between; below 24000 one input
-                              * block completes up to four downstream blocks, aisgpu_out_count()); channel A carries it, channel B stays silent */
+                              * block completes up to four downstream blocks, aisgpu_out_count()).  The receiver's channel is channel 0 of aisgpu_fetch();
+                              * channel 1 does not exist (round 6: the receivers of a batch are packed, one chain per receiver) -- aisgpu_fetch(rx, 1)
+                              * hands out what a chain fed with silence puts out (no decision set, level 0), frames carry ch = 0 */
 #define AISGPU_FLAG_DSK 4     /* KEY_SETTING_DSK (`-go DSK on`): 576k / 1152k / 2304k use the decimate-by-3 ladder (Model.cpp:130) */
 #define AISGPU_FLAG_MA_DS 128 /* KEY_SETTING_MA (`-go MA on`, Model.cpp:122-126): convert >> DownsampleMovingAverage >> Rotate instead of the CIC5 ladder
                                * -- integrate-and-dump to 96 kHz (DSP.cpp:60-82), handed on in blocks of 8192 samples.  Here for sample rates

@@ -469,6 +469,54 @@ def test_channel_mode_x(rate, block, fmt):
         m.close()
 
 
+@pytest.mark.parametrize("rate,block,nblocks,R,gpu_decode", [(96000, 1024 * 48, 4, 3, False), (192000, 2048 * 24, 5, 5, False), (40000, 512 * 40, 6, 3, False),
+                                                           (16000, 512 * 12, 8, 2, False), (96000, 1024 * 48, 4, 3, True), (150000, 2048 * 30, 5, 4, True)])
+def test_channel_mode_x_receivers_packed(rate, block, nblocks, R, gpu_decode):
+    """Round 6: in channel mode X the receivers of a batch are packed -- chain r of everything behind the 48 kHz channels IS receiver r,
+    instead of every receiver dragging a silent channel B through the back end.  Distinct receivers (odd counts: one silent row pads
+    the batch for the kernels that take channels in pairs), the fused default path, every downstream block (up to four per input block
+    below 24 kSPS): hard bits, levels, ppm per receiver against the oracle; aisgpu_fetch(rx, 1) hands out silence; with the frame
+    decoders on the device the frames carry the right receiver and print the oracle's NMEA (channel letter X)."""
+    from ais_catcher_amd import host
+    xs = [synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=380 + r, gap_slots=(1, 2), single_channel=True) for r in range(R)]
+    oracles = []
+    for x in xs:
+        o = checkers.Oracle(model=2, rate=rate, fmt="cf32", taps=True, mode_x=True)
+        o.feed_blocks(x, block)
+        oracles.append(o)
+    g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block, mode_x=True, gpu_decode=gpu_decode)
+    hms = [host.ModelDefaultGPU(sample_rate=rate, detached=True, gpu_decode=True, ch1="X", ch2="X", mode_x=True) for _ in range(R)] if gpu_decode else []
+    gd, wd = [0] * R, [0] * R
+    for b in range(nblocks):
+        for r in range(R):
+            g.submit(r, xs[r][b * block:(b + 1) * block])
+        g.run()
+        g.sync_outputs()
+        for s_ in range(g.out_count()):
+            for r in range(R):
+                out, o = g.fetch(r, 0, s_), oracles[r]
+                n, W = out["n_groups"], out["n_windows"]
+                assert out["first_group"] == gd[r]
+                for j in range(5):
+                    assert np.array_equal(out["bits"][j], o.bits(0, j)[0][gd[r]:gd[r] + n]), "bits b%d s%d r%d j%d" % (b, s_, r, j)
+                assert _feq(out["lvl"], o.bits(0, 0)[1][gd[r]:gd[r] + n]) and _feq(out["ppm"], o.tap_ppm(2)[wd[r]:wd[r] + W])
+                silent = g.fetch(r, 1, s_)
+                assert silent["n_groups"] == n and not np.any(silent["lvl"]) and not any(np.any(silent["bits"][j] > 0) for j in range(5))
+                gd[r] += n
+                wd[r] += W
+        if gpu_decode:
+            for f in g.frames():
+                assert 0 <= f["rx"] < R and f["ch"] == 0
+                hms[f["rx"]].frame(f)
+    g.close()
+    assert gd[0] > 0
+    if gpu_decode:
+        strip = lambda ls: [",".join(f for i, f in enumerate(l.split("*")[0].split(",")) if i != 3) for l in ls]
+        for r in range(R):
+            assert strip(hms[r].nmea()) == strip(oracles[r].nmea()) and len(oracles[r].nmea()) >= 3, "receiver %d" % r
+            hms[r].close()
+
+
 @pytest.mark.parametrize("rate,block,fmt", [(96000, 1024 * 48, "cf32"), (96000, 1024 * 24, "cu8"), (150000, 2048 * 30, "cf32"),
                                             (120000, 2048 * 24, "cs8"), (96000, 1024, "cf32")])
 def test_lowest_rates(rate, block, fmt):
