@@ -1293,6 +1293,10 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		if (cfg->block_len % h->ptile_in) { delete h; return AISGPU_ERR_ARG; }
 		h->ptiles_per_block = cfg->block_len / h->ptile_in;
 		h->ptiles_per_span = span_tiles(h->ptiles_per_block, cfg->n_receivers, cfg->tiles_per_span);
+		// Round 6: where the heuristic lands on 24 tiles (the bench batch: 768 tiles x 256 receivers) 32 are better -- one warm-up tile per
+		// 32 instead of per 24, 6,144 waves instead of 8,192: BASELINE configs[2] 0.405-0.436 -> 0.395-0.396 ms per step, 48 and 96 lose
+		// 10 % and 30 % (profiles/r06_expD_pass_span_length.txt); the main front end has used 32 since round 1.
+		if (cfg->tiles_per_span <= 0 && h->ptiles_per_span >= 17 && h->ptiles_per_span < 32 && h->ptiles_per_block % 32 == 0) h->ptiles_per_span = 32;
 		h->pspans = (h->ptiles_per_block + h->ptiles_per_span - 1) / h->ptiles_per_span;
 	}
 	if (mode == MODE_RESAMPLE) h->xh = 0; // (ring of three input blocks instead of a copied history)
