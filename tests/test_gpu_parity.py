@@ -1483,7 +1483,7 @@ _FIFO_BLOCK = 24 * 16 * 16384  # Device/FileRAW.h:43
 
 
 @pytest.mark.skipif(not checkers.have_refgpu(), reason="oracle/_ref/libaisrefgpu.so not built (needs /root/reference at build time)")
-@pytest.mark.parametrize("gpu_model,cpu_model,fmt,runs", [(12, 2, "cu8", 20), (12, 2, "cf32", 6), (14, 4, "cu8", 4)])
+@pytest.mark.parametrize("gpu_model,cpu_model,fmt,runs", [(12, 2, "cu8", 20), (12, 2, "cf32", 6), (14, 4, "cu8", 4), (20, 0, "cu8", 3), (21, 1, "cf32", 3)])
 def test_binding_behind_the_reference_file_reader(tmp_path, gpu_model, cpu_model, fmt, runs):
     """BASELINE configs[0] / configs[1]'s input path, for real: `-r <file> -s 1536000` = the reference's own Device::RAWFile
     (Device/FileRAW.cpp linked unmodified: reader thread -> FIFO -> run thread), whose run thread hands over ONE OR TWO FIFO blocks
