@@ -3,6 +3,7 @@
  * MI355X repository (compiled by oracle/Makefile against the unmodified reference), not part of its product libraries.
  */
 #include <algorithm>
+#include <cstring>
 #include <stdexcept>
 
 #include "ModelGPU.h"
@@ -261,6 +262,7 @@ namespace AIS
 					if (tag.mode & 1) tag.sample_lvl = o.lvl[f.group];
 				}
 				tag.sample_idx = f.end_idx;
+				if (cfg.model == AISGPU_MODEL_V2) memcpy(&tag.ppm, &f.group, sizeof(float)); // (the engine switches frequencies inside its blocks: the frame carries the bits of tag.ppm, aisgpu.h)
 				Decoder *d = (f.phase >= 0 && f.phase < 2 * N_SAMPLES_PER_SYMBOL) ? dec[f.ch & 1][f.phase] : nullptr;
 				if (d) GpuEmitFrame(*d, f, tag);
 			}
@@ -287,7 +289,8 @@ namespace AIS
 				for (int ch = 0; ch < 2; ch++)
 				{
 					const int n1 = n0 + step < L ? n0 + step : L;
-					if (o[ch].fm_bits && o[ch].n_groups == 0) replayFM(ch == 0 ? outFMa : outFMb, o[ch], tag, n0, n1);
+					if (o[ch].c48) (ch == 0 ? outC48a : outC48b).Send((const CFLOAT32 *)o[ch].c48 + n0, n1 - n0, tag); // ModelEngineV2, engine on the host: the channel itself
+					else if (o[ch].fm_bits && o[ch].n_groups == 0) replayFM(ch == 0 ? outFMa : outFMb, o[ch], tag, n0, n1);
 					else if (o[ch].fm_bits) replayChallenger(ch == 0 ? outA : outB, ch == 0 ? outAf : outBf, o[ch], tag, n0, n1);
 					else replay(ch == 0 ? outA : outB, o[ch], tag, n0, n1);
 				}
@@ -418,6 +421,57 @@ namespace AIS
 				}
 			}
 		}
+	}
+
+	// ---- ModelEngineV2GPU (Model.cpp:440-482)
+
+	void ModelEngineV2GPU::buildModel(char CH1, char CH2, int sample_rate, bool timerOn, Device::Device *dev)
+	{
+		if (GpuPool::instance().gpuDecode() && (dd_train != 0.75f || dd_weight != 0.86f))
+			throw std::runtime_error(getName() + ": the engine on the device has the default DD_TRAIN / DD_WEIGHT only");
+		buildFrontend(sample_rate, timerOn, dev, AISGPU_MODEL_V2);
+
+		V2_a.setOrigin(CH1, station, own_mmsi);
+		V2_b.setOrigin(CH2, station, own_mmsi);
+		V2_a.setWeights(dd_train, dd_weight);
+		V2_b.setWeights(dd_train, dd_weight);
+
+		chain.outC48a >> V2_a; // *C_a >> V2_a (Model.cpp:452-453)
+		chain.outC48b >> V2_b;
+
+		for (int i = 0; i < V2::Engine::N_DECODERS; i++)
+		{
+			V2_a.getDecoder(i) >> output;
+			V2_b.getDecoder(i) >> output;
+			chain.dec[0][i] = &V2_a.getDecoder(i);
+			chain.dec[1][i] = &V2_b.getDecoder(i);
+		}
+	}
+
+	Setting &ModelEngineV2GPU::SetKey(AIS::Keys key, const std::string &arg)
+	{
+		switch (key)
+		{
+		case AIS::KEY_SETTING_DD_TRAIN: // Model.cpp:465-482
+			dd_train = Util::Parse::Float(arg, 0.0, 1.0);
+			break;
+		case AIS::KEY_SETTING_DD_WEIGHT:
+			dd_weight = Util::Parse::Float(arg, 0.0, 1.0);
+			break;
+		case AIS::KEY_SETTING_PS_EMA: // (keys of ModelDefault, not of ModelFrontend: the reference's engine does not know them either)
+		case AIS::KEY_SETTING_AFC_WIDE:
+			Model::SetKey(key, arg);
+			break;
+		default:
+			ModelDefaultGPU::SetKey(key, arg);
+			break;
+		}
+		return *this;
+	}
+
+	std::string ModelEngineV2GPU::Get()
+	{
+		return "dd_train " + Util::Convert::toString(dd_train) + " dd_weight " + Util::Convert::toString(dd_weight) + " " + ModelDefaultGPU::Get();
 	}
 
 	// ---- ModelStandardGPU (Model.cpp:484-518)

@@ -1,6 +1,6 @@
 /*
  * Source/DSP/GPU/ModelGPU.h -- the file a maintainer adds to the REFERENCE tree (jvde-github/AIS-catcher v0.70) to run the
- * hot path of AIS::ModelDefault / ModelChallenger / ModelStandard / ModelBase on an MI355X through the C ABI of libaisgpu.so
+ * hot path of AIS::ModelDefault / ModelChallenger / ModelStandard / ModelBase / ModelEngineV2 on an MI355X through the C ABI of libaisgpu.so
  * (include/aisgpu.h).
  *
  * It is written against the reference's own headers -- Stream.h (StreamIn / Connection, Library/Stream.h:36-167), Model.h
@@ -32,6 +32,7 @@
 #include "Model.h"
 #include "AIS.h"
 #include "DSP.h"
+#include "V2Engine.h"
 #include "aisgpu.h"
 #include "gpu_batch.h"
 
@@ -108,7 +109,9 @@ namespace AIS
 		Connection<FLOAT32> outA[N_SAMPLES_PER_SYMBOL], outB[N_SAMPLES_PER_SYMBOL];	  // what CD_EMA_a/b[i].out carry (Model.cpp:563-564)
 		Connection<FLOAT32> outAf[N_SAMPLES_PER_SYMBOL], outBf[N_SAMPLES_PER_SYMBOL]; // ModelChallenger: S_af / S_bf .out[i] (Model.cpp:638-639), sign only
 		Connection<FLOAT32> outFMa, outFMb;											  // ModelBase / ModelStandard: FR_a / FR_b .out (Model.cpp:431-432, 495-496), sign only
-		// AISGPU_FLAG_GPU_DECODE: decoder of (channel, phase) -- phase 5..9: ModelChallenger's FM decoders -- set by the model
+		Connection<CFLOAT32> outC48a, outC48b;										  // ModelEngineV2 with the engine on the host: FCIC5_a / FCIC5_b .out, the 48 kHz channels (Model.cpp:345-346, 452-453)
+		// AISGPU_FLAG_GPU_DECODE: decoder of (channel, phase) -- phase 5..9: ModelChallenger's FM decoders; ModelEngineV2: 0..4 behind the
+		// trackers, 5 the FM decoder -- set by the model
 		Decoder *dec[2][2 * N_SAMPLES_PER_SYMBOL] = {};
 		Type device_type = Type::NONE; // the device's driver (Device::getDriver), set by the model: picks the block size for the file reader
 
@@ -146,6 +149,23 @@ namespace AIS
 	public:
 		ModelChallengerGPU() { setName("AIS engine v1 high (MI355X)"); }
 		void buildModel(char, char, int, bool, Device::Device *);
+	};
+
+	// AIS::ModelEngineV2 (Model.cpp:440-463, "-m 31" here).  Two forms: by default the GPU runs the front end and hands
+	// the two 48 kHz channels to the reference's own V2::Engine objects (chain.outC48a >> V2_a, exactly where *C_a >> V2_a sits in the
+	// reference); with GpuPool::setGpuDecode(true) the whole engine runs on the device (kv2_engine) and only completed frames come back,
+	// each to the tail of ITS decoder of the reference's engine object (V2_x.getDecoder(phase)).  The device engine has PhaseTracker's
+	// default weights (V2Engine.h:70-71): other DD_TRAIN / DD_WEIGHT values are refused in that form.
+	class ModelEngineV2GPU : public ModelDefaultGPU
+	{
+		V2::Engine V2_a, V2_b;
+		float dd_train = 0.75f, dd_weight = 0.86f; // DSP/Model.h:272
+
+	public:
+		ModelEngineV2GPU() { setName("AIS engine v2 base (MI355X)"); }
+		void buildModel(char, char, int, bool, Device::Device *);
+		Setting &SetKey(AIS::Keys key, const std::string &arg);
+		std::string Get();
 	};
 
 	// AIS::ModelStandard (Model.cpp:484-518): front end + FM receiver on the GPU, the reference's Deinterleave(5) + five decoders here

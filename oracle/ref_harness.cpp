@@ -120,7 +120,7 @@ struct Harness {
 extern "C" {
 
 // kind: 0 = ModelStandard, 1 = ModelBase, 2 = ModelDefault, 4 = ModelChallenger, 11 = ModelEngineV2; libaisrefgpu.so only: 12 = ModelDefaultGPU,
-// 14 = ModelChallengerGPU, 20 = ModelStandardGPU, 21 = ModelBaseGPU.  fmt: 0 = CU8, 1 = CF32, 2 = CS8, 3 = CS16.
+// 14 = ModelChallengerGPU, 20 = ModelStandardGPU, 21 = ModelBaseGPU, 31 = ModelEngineV2GPU.  fmt: 0 = CU8, 1 = CF32, 2 = CS8, 3 = CS16.
 // flags: bit 0 record float taps, bit 1 `-go DSK on`, bit 2 `-go PS_EMA off`, bit 3 `-go FP_DS on`, bit 4 channel mode X (`-c X`), bit 5 `-go MA on`;
 // GPU engines: bit 6 the AIS::Decoder state machines on the device (GpuPool::setGpuDecode), bit 7 pipelined hand-off (GpuPool::setPipelined).
 // GPU engines created with the same configuration before their first block share ONE GPU context (GpuPool): feed them from one thread each.
@@ -149,11 +149,12 @@ void* ref_create_file(int kind, int sample_rate, int fmt, int flags, const char*
 		else if (kind == 11) { h->mv = new AIS::ModelEngineV2(); h->model = h->mv; }
 #ifdef HASMI355X
 		// what Receiver::addModel (Application/Receiver.cpp:155-195) would do for the new engine numbers
-		else if (kind == 12 || kind == 14 || kind == 20 || kind == 21) {
+		else if (kind == 12 || kind == 14 || kind == 20 || kind == 21 || kind == 31) {
 			AIS::GpuPool::instance().setGpuDecode((flags & 64) != 0);
 			AIS::GpuPool::instance().setPipelined((flags & 128) != 0);
 			h->mgpu = kind == 12 ? new AIS::ModelDefaultGPU() : kind == 14 ? (AIS::ModelDefaultGPU*)new AIS::ModelChallengerGPU()
-			        : kind == 20 ? (AIS::ModelDefaultGPU*)new AIS::ModelStandardGPU() : (AIS::ModelDefaultGPU*)new AIS::ModelBaseGPU();
+			        : kind == 20 ? (AIS::ModelDefaultGPU*)new AIS::ModelStandardGPU() : kind == 31 ? (AIS::ModelDefaultGPU*)new AIS::ModelEngineV2GPU()
+			        : (AIS::ModelDefaultGPU*)new AIS::ModelBaseGPU();
 			h->model = h->mgpu;
 		}
 #endif

@@ -1471,6 +1471,26 @@ def test_reference_binding_afc_wide_and_droop_keys(gpu_model, cpu_model, rate, f
     assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])
 
 
+@pytest.mark.skipif(not checkers.have_refgpu(), reason="oracle/_ref/libaisrefgpu.so not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("rate,fmt,block,nblocks,gpu_decode", [(1536000, "cf32", 786432, 4, False), (1536000, "cu8", 131072, 16, False), (6000000, "cf32", 786432, 4, False),
+                                                               (1536000, "cf32", 786432, 4, True), (1536000, "cu8", 131072, 16, True), (288000, "cf32", 49152, 12, False)])
+def test_reference_binding_engine_v2(rate, fmt, block, nblocks, gpu_decode):
+    """Round 6: AIS::ModelEngineV2 in the reference-side binding (ModelEngineV2GPU, engine 31): by default the GPU front end feeds the
+    reference's OWN V2::Engine objects the 48 kHz channels (chain.outC48a >> V2_a: DSP/Model.cpp:452-453); with the decoders on the
+    device the whole engine runs there (kv2_engine) and the frames go to the tail of the reference's decoder objects.  Either way
+    engine 31 must print what the reference's engine 11 prints from the same binary: NMEA text, tag.level, tag.ppm per message."""
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=390, gap_slots=(1, 2), type5_every=4)
+    data = synth.to_cu8(x) if fmt == "cu8" else x
+    out = []
+    for model, kw in ((11, {}), (31, {"gpu_decode": gpu_decode})):
+        m = checkers.RefGpu(model=model, rate=rate, fmt=fmt, **kw)
+        m.feed_blocks(data, block)
+        out.append((m.nmea(), m.msg_meta()))
+        m.close()
+    assert out[0][0] == out[1][0] and len(out[0][0]) >= 3
+    assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])
+
+
 def _by_channel(lines):
     """NMEA lines per channel letter, in order (the A / B interleave of the reference depends on how many FIFO blocks a call carried)."""
     out = {}
@@ -1483,7 +1503,7 @@ _FIFO_BLOCK = 24 * 16 * 16384  # Device/FileRAW.h:43
 
 
 @pytest.mark.skipif(not checkers.have_refgpu(), reason="oracle/_ref/libaisrefgpu.so not built (needs /root/reference at build time)")
-@pytest.mark.parametrize("gpu_model,cpu_model,fmt,runs", [(12, 2, "cu8", 20), (12, 2, "cf32", 6), (14, 4, "cu8", 4), (20, 0, "cu8", 3), (21, 1, "cf32", 3)])
+@pytest.mark.parametrize("gpu_model,cpu_model,fmt,runs", [(12, 2, "cu8", 20), (12, 2, "cf32", 6), (14, 4, "cu8", 4), (20, 0, "cu8", 3), (21, 1, "cf32", 3), (31, 11, "cu8", 3)])
 def test_binding_behind_the_reference_file_reader(tmp_path, gpu_model, cpu_model, fmt, runs):
     """BASELINE configs[0] / configs[1]'s input path, for real: `-r <file> -s 1536000` = the reference's own Device::RAWFile
     (Device/FileRAW.cpp linked unmodified: reader thread -> FIFO -> run thread), whose run thread hands over ONE OR TWO FIFO blocks
