@@ -279,14 +279,15 @@ namespace AIS
 			if (b3[i] >= cfg.sample_rate && (!best || b3[i] < best)) { by3 = true; break; }
 		if (cfg.flags & AISGPU_FLAG_MA_DS) by3 = true; // DownsampleMovingAverage hands on blocks of 8192 samples too (DSP/DSP.h:128)
 
+		const int nch = (cfg.flags & AISGPU_FLAG_MODE_X) ? 1 : 2; // (channel mode X: FCIC5_b never sends anything in the reference either, Model.cpp:101-104)
 		for (int s = 0; s < nsub; s++)
 		{
 			aisgpu_out o[2];
-			for (int ch = 0; ch < 2; ch++)
+			for (int ch = 0; ch < nch; ch++)
 				if (batch->fetch(s, rx, ch, &o[ch]) != AISGPU_OK) { failed = true; return; }
 			const int L = o[0].n_windows * 512, step = by3 ? 4096 : L;
 			for (int n0 = 0; n0 < L; n0 += step)
-				for (int ch = 0; ch < 2; ch++)
+				for (int ch = 0; ch < nch; ch++)
 				{
 					const int n1 = n0 + step < L ? n0 + step : L;
 					if (o[ch].c48) (ch == 0 ? outC48a : outC48b).Send((const CFLOAT32 *)o[ch].c48 + n0, n1 - n0, tag); // ModelEngineV2, engine on the host: the channel itself
@@ -303,9 +304,18 @@ namespace AIS
 	{
 		device = dev;
 		chain.device_type = dev ? dev->getDriver() : Type::NONE;
-		if (mode != Mode::AB && mode != Mode::CD) throw std::runtime_error("GPU model: channel modes AB / CD only");
-		if (sample_rate < 96000 || sample_rate > 12288000)
-			throw std::runtime_error("Model: sample rate must be between 96K and 12288K (inclusive)."); // Model.cpp:109-110
+		if (mode == Mode::X)
+		{ // one channel, already centred (Model.cpp:35-107): the single-channel front end, ModelDefault's chain behind it
+			if (model != AISGPU_MODEL_DEFAULT) throw std::runtime_error("GPU model: channel mode X with the ModelDefault engine only");
+			if (sample_rate < 12000 || sample_rate > 192000)
+				throw std::runtime_error("Model: sample rate must be between 12k and 192k (inclusive)."); // Model.cpp:38-39
+		}
+		else
+		{
+			if (mode != Mode::AB && mode != Mode::CD) throw std::runtime_error("GPU model: channel modes AB / CD / X only");
+			if (sample_rate < 96000 || sample_rate > 12288000)
+				throw std::runtime_error("Model: sample rate must be between 96K and 12288K (inclusive)."); // Model.cpp:109-110
+		}
 
 		Connection<RAW> &physical = timerOn ? (*device >> timer).out : device->out; // Model.cpp:33
 		physical >> chain;
@@ -317,6 +327,7 @@ namespace AIS
 		c.afc_wide = CGF_wide;
 		c.droop = droop_compensation;
 		c.flags = (PS_EMA ? 0 : AISGPU_FLAG_PS_BOXCAR) | (fixedpointDS ? AISGPU_FLAG_FP_DS : 0) | (allowDSK ? AISGPU_FLAG_DSK : 0) | (MA_DS ? AISGPU_FLAG_MA_DS : 0);
+		if (mode == Mode::X) c.flags = (c.flags & AISGPU_FLAG_PS_BOXCAR) | AISGPU_FLAG_MODE_X; // (the single-channel ladders know neither FP_DS nor DSK nor MA, Model.cpp:35-107)
 		chain.join(c); // this receiver's row in the batch of all receivers built with the same configuration
 	}
 

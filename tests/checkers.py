@@ -183,7 +183,7 @@ def refgpu_block_bytes(n):
 
 
 def RefGpu(model=12, rate=1536000, fmt="cf32", dsk=False, ps_ema=True, fp_ds=False, ma=False, gpu_decode=False, pipelined=False, afc_wide=True, droop=True,
-           filename=None):
+           filename=None, mode_x=False):
     """oracle/_ref/libaisrefgpu.so: the reference's unmodified sources PLUS the reference-side binding of libaisgpu.so
     (integration/reference/Source/DSP/GPU/ModelGPU.cpp, an AIS::Model subclass compiled against the reference's real headers).
     model 2 / 4 / 0 / 1 = the reference's own ModelDefault / ModelChallenger / ModelStandard / ModelBase, 12 / 14 / 20 / 21 = the same
@@ -191,7 +191,7 @@ def RefGpu(model=12, rate=1536000, fmt="cf32", dsk=False, ps_ema=True, fp_ds=Fal
     (feed them from one thread each); gpu_decode: decoder state machines on the device; pipelined: call flush() after the last block."""
     lib = _lib(os.path.join(ORACLE_DIR, "_ref", "libaisrefgpu.so"))
     lib.ref_reset_seq()
-    c = _Chain(lib, "ref_", model, rate, fmt, False, dsk, ps_ema, fp_ds, False, ma, extra_flags=(64 if gpu_decode else 0) | (128 if pipelined else 0),
+    c = _Chain(lib, "ref_", model, rate, fmt, False, dsk, ps_ema, fp_ds, mode_x, ma, extra_flags=(64 if gpu_decode else 0) | (128 if pipelined else 0),
                afc_wide=afc_wide, droop=droop, filename=filename)
     lib.ref_flush.argtypes = [ctypes.c_void_p]
     lib.ref_flush.restype = None

@@ -1491,6 +1491,24 @@ def test_reference_binding_engine_v2(rate, fmt, block, nblocks, gpu_decode):
     assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])
 
 
+@pytest.mark.skipif(not checkers.have_refgpu(), reason="oracle/_ref/libaisrefgpu.so not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("rate,fmt,block,nblocks,gpu_decode", [(96000, "cf32", 1024 * 48, 8, False), (192000, "cu8", 2048 * 24, 8, False), (150000, "cs16", 2048 * 30, 8, False),
+                                                               (48000, "cf32", 512 * 40, 8, False), (96000, "cf32", 1024 * 48, 8, True)])
+def test_reference_binding_channel_mode_x(rate, fmt, block, nblocks, gpu_decode):
+    """Round 6: `-c X` through the reference-side binding -- AIS::Model::setMode(Mode::X) + buildModel('X', 'X', ...) as Receiver.cpp:87-98,
+    220 does -- engine 12 against the reference's engine 2 in the same mode from the same binary (one channel, NMEA with channel letter X)."""
+    x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=395, gap_slots=(1, 2), single_channel=True)
+    data = {"cu8": synth.to_cu8, "cs16": synth.to_cs16, "cf32": lambda v: v}[fmt](x)
+    out = []
+    for model, kw in ((2, {}), (12, {"gpu_decode": gpu_decode})):
+        m = checkers.RefGpu(model=model, rate=rate, fmt=fmt, mode_x=True, **kw)
+        m.feed_blocks(data, block)
+        out.append((m.nmea(), m.msg_meta()))
+        m.close()
+    assert out[0][0] == out[1][0] and len(out[0][0]) >= 5
+    assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])
+
+
 def _by_channel(lines):
     """NMEA lines per channel letter, in order (the A / B interleave of the reference depends on how many FIFO blocks a call carried)."""
     out = {}
