@@ -203,19 +203,157 @@ __device__ __forceinline__ void put_halo(const T (&x)[C], HaloState<C, T>& hs, c
 template <int SHIFT, int C, typename T>
 __device__ __forceinline__ void reg_stage(const T (&x)[C], HaloState<C, T>& hs, T (&out)[C / 2]) {
 	T h[5];
+#ifdef ABL_NO_HALO // (ablation builds only: wrong results -- no halo exchange at all)
+#pragma unroll
+	for (int i = 0; i < 5; i++) h[i] = x[i % C];
+#else
 	get_halo<C, T>(x, hs, h);
+#endif
 	T v[C + 4];
 #pragma unroll
 	for (int i = 0; i < 5; i++) v[i] = h[i];
 #pragma unroll
 	for (int i = 0; i < C - 1; i++) v[5 + i] = x[i];
 	cic5_dec_chunk_v<C / 2, T, SHIFT>(v, out);
-#ifndef ABL_NO_PUT // (ablation builds only: wrong results, measures what the carry moves cost)
+#if !defined(ABL_NO_PUT) && !defined(ABL_NO_HALO) // (ablation builds only: wrong results, measures what the carry moves cost)
 	put_halo<C, T>(x, hs, h);
 #endif
 }
 template <int C>
 __device__ __forceinline__ void reg_stage(const c2 (&x)[C], HaloState<C, c2>& hs, c2 (&out)[C / 2]) { reg_stage<0, C, c2>(x, hs, out); }
+
+// ------------------------------------------------------------------------------------------
+// Round 6: the halo exchange as ONE neighbour value per Pascal level ("level carry") instead of five input samples per stage.
+// s_k[n] = s_{k-1}[n] + s_{k-1}[n-1]: for the first sample of a lane's chunk the second operand is the LAST element of the previous
+// lane's level k-1 -- the neighbour has computed it anyway -- so the lane needs one value per level (five per stage: x[C-1], L1[C-1] ..
+// L4[C-1]) and adds it with the shift fused into the addition (v_add_f32_dpp wave_shr:1), instead of fetching five raw samples (ten DPP
+// moves) and re-adding the neighbour's triangle over them (4 C + 6 + C/2 additions per stage then, 4 C + C/2 now: the floor of this
+// pairing).  Every sum is the same pair of operands as before (float addition commutes), so the results are the same bits.
+// Lane 0's neighbour is lane 63 of the PREVIOUS tile: lane 63 leaves its five level tails of every stage in 40 bytes of LDS per
+// stage (a one-lane write), every lane reads them back at the next tile (a broadcast read; only lane 0's copy matters) and forms
+// `own + carry` with a packed addition, which the fused DPP additions then overwrite in lanes 1..63 -- no carry moves through the
+// DPP network (rounds 1-5: ten per stage and tile).  Tile loop of the four-stage ladder: 224 packed + 88 DPP -> 200 + 48 instructions.
+// Used by the integer input formats only (see k1_dpp: LC).
+// (`s_nop 1` in front of the DPP pair: a VGPR written by the preceding VALU instruction may not be read through DPP for two wait
+// states, and the compiler's hazard recogniser does not look into inline assembly.)
+// ------------------------------------------------------------------------------------------
+#ifndef K1_LEVEL_CARRY
+#define K1_LEVEL_CARRY 1
+#endif
+__device__ __forceinline__ void wave_sync();
+__device__ __forceinline__ c2 nb_add(c2 own, c2 tail, c2 carry) { // lanes 1..63: tail[lane - 1] + own; lane 0: carry + own
+	const c2 r = own + carry;
+	float rx = r.x, ry = r.y;
+	asm("s_nop 1\n\tv_add_f32_dpp %0, %2, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %3, %5 wave_shr:1 row_mask:0xf bank_mask:0xf"
+	    : "+v"(rx), "+v"(ry) : "v"(tail.x), "v"(tail.y), "v"(own.x), "v"(own.y));
+	return c2{ rx, ry };
+}
+__device__ __forceinline__ unsigned nb_add(unsigned own, unsigned tail, unsigned carry) {
+	unsigned r = own + carry;
+	asm("s_nop 1\n\tv_add_u32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(tail), "v"(own));
+	return r;
+}
+template <int C, typename T>
+__device__ __forceinline__ void level_lc(const T (&in)[C], T carry, T (&out)[C]) {
+	out[0] = nb_add(in[0], in[C - 1], carry);
+#pragma unroll
+	for (int i = 1; i < C; i++) out[i] = in[i] + in[i - 1];
+}
+// one decimating CIC5 stage: x = the lane's C consecutive inputs, carry[k] = lane 63's tail of level k of the previous tile (valid in
+// lane 0), tails[k] = this lane's (k = 0: the last input, k = 1..4: the last element of level k); out = C / 2 outputs
+template <int SHIFT, int C, typename T>
+__device__ __forceinline__ void reg_stage_lc(const T (&x)[C], const T (&carry)[5], T (&tails)[5], T (&out)[C / 2]) {
+	T a[C], b[C], c[C], d[C];
+	level_lc<C, T>(x, carry[0], a);
+	level_lc<C, T>(a, carry[1], b);
+	level_lc<C, T>(b, carry[2], c);
+	level_lc<C, T>(c, carry[3], d);
+	tails[0] = x[C - 1]; tails[1] = a[C - 1]; tails[2] = b[C - 1]; tails[3] = c[C - 1]; tails[4] = d[C - 1];
+	T e[C / 2];
+	e[0] = nb_add(d[0], d[C - 1], carry[4]);
+#pragma unroll
+	for (int q = 1; q < C / 2; q++) e[q] = d[2 * q] + d[2 * q - 1];
+#pragma unroll
+	for (int q = 0; q < C / 2; q++) {
+		if constexpr (sizeof(T) == sizeof(c2)) out[q] = e[q] * 0.03125f;
+		else out[q] = (e[q] >> SHIFT) & ((0xFFFFu >> SHIFT) * 0x10001u);
+	}
+}
+// The carry traffic of a whole ladder in two batches: every lane reads the 5 K slots at the top of the tile (one round trip for all
+// stages: a read per stage in front of its stage cost the wave four LDS latencies per tile and was slower than the moves it saved),
+// lane 63 writes its tails behind the last stage, and ONE wavefront-scope fence follows.
+// Lane 63 writes, every lane reads at the next tile: without that fence this is a data race to the compiler, which then forwards a
+// lane's OWN (never executed) store and keeps the carries of lanes 0..62 in registers for ever -- seen with the pre-decimation
+// passes, whose loop has no other fence.  Wavefront scope: ordering only, the LDS unit executes a wave's instructions in order.
+template <int NS, typename T, typename LT>
+__device__ __forceinline__ void lc_load(const LT* lc, T (&carry)[NS][5]) {
+#pragma unroll
+	for (int s = 0; s < NS; s++)
+#pragma unroll
+		for (int k = 0; k < 5; k++) {
+			if constexpr (sizeof(T) == sizeof(c2)) { const float2 v = lc[5 * s + k]; carry[s][k] = c2{ v.x, v.y }; }
+			else carry[s][k] = lc[5 * s + k];
+		}
+}
+template <int NS, typename T, typename LT>
+__device__ __forceinline__ void lc_store(LT* lc, const T (&tails)[NS][5], int lane) {
+	if (lane == 63) {
+#pragma unroll
+		for (int s = 0; s < NS; s++)
+#pragma unroll
+			for (int k = 0; k < 5; k++) {
+				if constexpr (sizeof(T) == sizeof(c2)) lc[5 * s + k] = make_float2(tails[s][k].x, tails[s][k].y);
+				else lc[5 * s + k] = tails[s][k];
+			}
+	}
+	wave_sync();
+}
+template <int K>
+__device__ __forceinline__ c2 run_ladder_lc(const c2 (&x)[1 << K], float2* lc, int lane) {
+	c2 cr[K][5], tl[K][5];
+	lc_load<K, c2>(lc, cr);
+	c2 r;
+	if constexpr (K == 6) {
+		c2 y[32], z[16], a[8], b[4], c[2], d[1];
+		reg_stage_lc<0, 64>(x, cr[0], tl[0], y); reg_stage_lc<0, 32>(y, cr[1], tl[1], z); reg_stage_lc<0, 16>(z, cr[2], tl[2], a);
+		reg_stage_lc<0, 8>(a, cr[3], tl[3], b); reg_stage_lc<0, 4>(b, cr[4], tl[4], c); reg_stage_lc<0, 2>(c, cr[5], tl[5], d);
+		r = d[0];
+	} else if constexpr (K == 5) {
+		c2 z[16], a[8], b[4], c[2], d[1];
+		reg_stage_lc<0, 32>(x, cr[0], tl[0], z); reg_stage_lc<0, 16>(z, cr[1], tl[1], a); reg_stage_lc<0, 8>(a, cr[2], tl[2], b);
+		reg_stage_lc<0, 4>(b, cr[3], tl[3], c); reg_stage_lc<0, 2>(c, cr[4], tl[4], d);
+		r = d[0];
+	} else if constexpr (K == 4) {
+		c2 a[8], b[4], c[2], d[1];
+		reg_stage_lc<0, 16>(x, cr[0], tl[0], a); reg_stage_lc<0, 8>(a, cr[1], tl[1], b); reg_stage_lc<0, 4>(b, cr[2], tl[2], c); reg_stage_lc<0, 2>(c, cr[3], tl[3], d);
+		r = d[0];
+	} else if constexpr (K == 3) {
+		c2 b[4], c[2], d[1];
+		reg_stage_lc<0, 8>(x, cr[0], tl[0], b); reg_stage_lc<0, 4>(b, cr[1], tl[1], c); reg_stage_lc<0, 2>(c, cr[2], tl[2], d);
+		r = d[0];
+	} else if constexpr (K == 2) {
+		c2 c[2], d[1];
+		reg_stage_lc<0, 4>(x, cr[0], tl[0], c); reg_stage_lc<0, 2>(c, cr[1], tl[1], d);
+		r = d[0];
+	} else {
+		c2 d[1];
+		reg_stage_lc<0, 2>(x, cr[0], tl[0], d);
+		r = d[0];
+	}
+	lc_store<K, c2>(lc, tl, lane);
+	return r;
+}
+// Downsample16_CU8 (see run_fix_ladder) with the level carry: packed 16-bit fields, integer additions
+__device__ __forceinline__ c2 run_fix_ladder_lc(const unsigned (&x)[16], unsigned* lc, int lane) {
+	unsigned cr[4][5], tl[4][5];
+	lc_load<4, unsigned>(lc, cr);
+	unsigned a[8], b[4], c[2], d[1];
+	reg_stage_lc<3, 16, unsigned>(x, cr[0], tl[0], a); reg_stage_lc<4, 8, unsigned>(a, cr[1], tl[1], b);
+	reg_stage_lc<5, 4, unsigned>(b, cr[2], tl[2], c); reg_stage_lc<0, 2, unsigned>(c, cr[3], tl[3], d);
+	lc_store<4, unsigned>(lc, tl, lane);
+	const unsigned z = d[0] ^ 0x80008000u;
+	return c2{ (float)(int)(short)(z & 0xffffu) * 0.000030517578125f, (float)(int)(short)(z >> 16) * 0.000030517578125f };
+}
 
 template <int K> struct RegLadder;
 template <> struct RegLadder<6> { HaloState<64, c2> s64; HaloState<32, c2> s32; HaloState<16, c2> s16; HaloState<8, c2> s8; HaloState<4, c2> s4; HaloState<2, c2> s2; };
@@ -312,6 +450,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 6 ? 1 :
 	__shared__ __attribute__((aligned(16))) float2 x6[2][8 + 32];  // DS2_a/b output
 	constexpr bool XFFT_IN_XT = DMA && K >= 4; // the FFT tail's exchange / search buffer (8 KB) reuses the tile buffer where that is big enough
 	__shared__ __attribute__((aligned(16))) float2 xfft[(PRE || XFFT_IN_XT) ? 1 : 1024];
+	// Level carry (run_ladder_lc) where the kernel is bound by its instructions -- the integer input formats, which are converted in
+	// the lanes and read a quarter or half of the bytes: -3 % per step with CU8 input, +2 % GS/s with FP_DS.  The CF32 forms keep the
+	// five-sample halos: they are paced by their tile stream, and what the level carry saves in instructions (346 -> 283 per tile)
+	// it costs them in latency per tile (an LDS round trip for the carries, wait states in front of the fused DPP additions):
+	// +0.4 ... 0.9 % per step, front end alone +3 % (profiles/r06_expF_level_carry.txt).
+	constexpr bool LC = K1_LEVEL_CARRY != 0 && FMT >= 1 && FMT <= 4;
+	__shared__ __attribute__((aligned(16))) float2 lc_f[LC ? 5 * K + 2 : 1]; // level carries: lane 63's five tails per stage
+	__shared__ unsigned lc_u[LC && FMT == 4 ? 20 : 1];
 	const int lane = threadIdx.x;
 	const int rx = blockIdx.y;
 	const int span = blockIdx.x;
@@ -328,6 +474,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 6 ? 1 :
 	asm volatile("" ::: "v135");
 
 	if (lane < 8) { x5[0][lane] = x5[1][lane] = x6[0][lane] = x6[1][lane] = make_float2(0.f, 0.f); }
+	if (LC) { // silence before the span's warm-up tile, as the zeroed shadow registers were
+		if (lane < 5 * K) lc_f[lane] = make_float2(0.f, 0.f);
+		if (FMT == 4 && lane < 20) lc_u[lane] = 0u;
+	}
 	RegLadder<K> st = {};
 	FixLadder fst = {};
 	c2 fdc_p1 = { 0.f, 0.f }, fdc_p2 = { 0.f, 0.f };
@@ -487,11 +637,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 6 ? 1 :
 
 		c2 x96;
 		if constexpr (FMT == 4) {
-			x96 = run_fix_ladder(xi, fst);
+			if constexpr (LC) x96 = run_fix_ladder_lc(xi, lc_u, lane);
+			else x96 = run_fix_ladder(xi, fst);
 			// before the stream starts the fixed-point stages hold zeros, which is -1.0 after the sign flip, but the float stages
 			// behind them have seen nothing at all: the warm-up tile of the very first block contributes zeros
 			if (p.stream_start && tile < 0) x96 = c2{ 0.0f, 0.0f };
 		}
+		else if constexpr (LC) x96 = run_ladder_lc<K>(x, lc_f, lane);
 		else x96 = run_ladder<K>(x, st);
 		if constexpr (PRE) {
 			if (tile > tile_first) p.pre_out[(size_t)rx * p.pre_stride + (size_t)tile * 64 + lane] = make_float2(x96.x, x96.y);
