@@ -194,6 +194,7 @@ struct aisgpu {
 	bool challenger = false;
 	bool v2 = false; float2* h_c48 = nullptr; // ModelEngineV2: front end only, the 48 kHz channels go to the host (MAXSUB slots)
 	V2ChanState* d_v2st = nullptr; float2* d_slotcs = nullptr; int* d_v2locked = nullptr; // AISGPU_FLAG_GPU_DECODE with ModelEngineV2: the engine itself on the device (kv2_engine)
+	int v2_roles = 1; // kv2_engine: trackers and FM decoder on two waves (test hook "v2_roles" = 0: the one-wave form of round 5)
 	bool v2_assist = true; float2* d_v2hist = nullptr; float *d_v2f = nullptr, *d_v2prom = nullptr, *d_v2en = nullptr, *h_v2f = nullptr, *h_v2prom = nullptr, *h_v2en = nullptr; // decoder-independent part of V2::Engine on the device
 	bool k46 = false; // default path: derotation + FIR + PhaseSearch in one kernel (k46_window_search; test hook "k46" = 0: k6_window_fir + k4_phase_chunks)
 	bool base = false; float2* d_fmprev[2] = {}; // ModelBase: FM receiver on the 48 kHz channels, no coherent chain
@@ -832,7 +833,7 @@ int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
 				e.k = k; e.fm_prev = h->d_fmbits[pb ^ 1]; e.st = h->d_v2st; e.dec = h->d_dec; e.slot_cs = h->d_slotcs;
 				e.w_train = 0.75f; e.w_track = 0.86f; // PhaseTracker's defaults (V2Engine.h:70-71)
 				e.frames = h->d_frames; e.frame_count = h->d_frame_count; e.max_frames = h->max_frames;
-				e.block = (unsigned)h->block_idx; e.sub = (unsigned)h->n_sub; e.locked_estimates = h->d_v2locked;
+				e.block = (unsigned)h->block_idx; e.sub = (unsigned)h->n_sub; e.locked_estimates = h->d_v2locked; e.roles = h->v2_roles;
 				memcpy(e.taps17, TAPS_COHERENT, sizeof e.taps17);
 				HIPCHK(launch_kv2(k, h->ds, &e));
 			} else {
@@ -1126,7 +1127,7 @@ const char* aisgpu_last_error(aisgpu_t* h) { return h ? h->err.c_str() : ""; }
 
 int aisgpu_set_option(const char* key, const char* value) {
 	if (!key || !*key) return AISGPU_ERR_ARG;
-	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "k46", "k1u_spw", "us_k1", "trace", "k7e_stats", "k7b_stats" };
+	static const char* const known[] = { "serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "k46", "k1u_spw", "us_k1", "v2_roles", "trace", "k7e_stats", "k7b_stats" };
 	bool ok = false;
 	for (const char* k : known) ok = ok || strcmp(k, key) == 0;
 	if (!ok) return AISGPU_ERR_ARG;
@@ -1611,6 +1612,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	HIPCHK(dalloc(&h->d_psflag, 4));
 	if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_firtap, C * (8 + h->L)));
 	if (h->v2) {
+		h->v2_roles = opt_int("v2_roles", 1) != 0;
 		// With the engine on the device (AISGPU_FLAG_GPU_DECODE) nothing but frames goes to the host: no pinned slots for the channels,
 		// the estimates, the energies or the discriminator signs (several GB at 2,048 receivers), and aisgpu_fetch_sub() returns NULL for them.
 		const bool v2_host = !h->gpu_decode;
@@ -1641,6 +1643,9 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 }
 
 void aisgpu_destroy(aisgpu_t* h) {
+#ifdef V2_PROF
+	if (h && h->v2) { hipDeviceSynchronize(); aisk::v2_prof_dump(); }
+#endif
 	if (!h) return;
 	DevGuard dg(h);
 	rot_worker_stop(h);

@@ -169,6 +169,71 @@ DEC_HD uint32_t dec_crc_bits(const uint32_t* data, int count, const uint16_t* ta
 	return crc;
 }
 
+// ------------------------------------------------------------------------------------------
+// The lean pair (round 6, kv2_engine's two-wave form): the same decoder with fewer instructions per symbol.  A decoder that uses them
+// uses them for every symbol: r.crc and r.tail are NOT maintained (the CRC of a frame is formed from its buffer when a closing flag asks
+// for it, byte-wise through `tab`), r.osc is 0 outside DATAFCS (what dec_step leaves there anyway).
+//  * dec_lean_idle: a decoder in TRAINING / STARTFLAG; returns 1 when the step opened a frame (the frame registers are cleared).
+//  * dec_lean_data: a decoder in DATAFCS; returns true when a frame with a good CRC has just been completed (as dec_step: position and
+//    level still the frame's).  Everything that is rare -- closing flag, the look-ups at positions 30 / 62, the type's own limit, the
+//    maximum length -- sits behind one branch.
+// tests/dec_core_fuzz.cpp `lean` steps both forms side by side over random streams.
+// ------------------------------------------------------------------------------------------
+DEC_HD int dec_lean_idle(DecReg& r, int dd, long long sidx) {
+	const int Bit = dd == r.prev;
+	const int pos = r.position;
+	const bool isT = r.state == DST_TRAINING;
+	const bool alt = Bit != r.lastBit;
+	const bool at7 = pos == 7;
+	const bool to_flag = isT && !alt && pos > 4;
+	const bool open = !isT && at7 && !Bit;
+	const bool more = !isT && !at7 && Bit;
+	const bool grow = (isT && alt) || more;
+	r.prev = dd;
+	r.lastBit = Bit;
+	r.state = (to_flag || more) ? (int)DST_STARTFLAG : (open ? (int)DST_DATAFCS : (int)DST_TRAINING);
+	r.position = grow ? pos + 1 : (to_flag ? 1 + 2 * Bit : 0);
+	r.start_idx = to_flag ? sidx : r.start_idx;
+	if (open) { r.level = 0.0f; r.cw = 0u; r.cwi = 0; r.abort_pos = 0; r.osc = 0; }
+	return open ? 1 : 0;
+}
+
+DEC_HD bool dec_lean_data(DecReg& r, int dd, float slvl, uint32_t* data, const uint16_t* tab) {
+	const int Bit = dd == r.prev;
+	r.prev = dd;
+	r.lastBit = Bit;
+	const int pos = r.position, osc = r.osc;
+	const bool six = osc == 5;
+	const bool close = six && Bit;
+	const int np = (six && !Bit) ? pos : pos + 1; // a stuffed zero does not advance: the next bit overwrites it
+	const int wi = pos >> 5;
+	if (wi != r.cwi) { data[DEC_LANES * r.cwi] = r.cw; r.cw = 0u; r.cwi = wi; }
+	const uint32_t sh = (uint32_t)pos & 31u;
+	if (pos < DEC_MAX_FRAME) r.cw = (r.cw & ~(1u << sh)) | ((uint32_t)Bit << sh);
+	r.level = r.level + slvl;
+	r.position = np;
+	r.osc = Bit ? osc + 1 : 0;
+	if (!(close || np == 30 || np == 62 || np == DEC_MAX_FRAME || np == r.abort_pos)) return false;
+	// ---- the rare rest of the step
+	if (close) {
+		data[DEC_LANES * r.cwi] = r.cw;
+		r.osc = 0;
+		if (np - 7 >= 16 && dec_crc_bits(data, np - 7, tab) == (uint32_t)(uint16_t)~0x0F47) return true; // (state, position, level: the frame's)
+		r.state = DST_TRAINING; r.position = 0;
+		return false;
+	}
+	bool abort_frame = np == DEC_MAX_FRAME || (r.abort_pos != 0 && np == r.abort_pos);
+	if (np == 30) { // type = first byte >> 2; bits 0..29 are all in the first word, which is still in the register
+		r.abort_pos = dec_abort_position((int)((r.cw & 255u) >> 2));
+		abort_frame = abort_frame || r.abort_pos == 30;
+	} else if (np == 62) { // MMSI = bits 8..37: first word is in the buffer by now, the second one in the register
+		const uint32_t w0 = data[0];
+		abort_frame = abort_frame || (((w0 >> 8) & 255u) << 22 | ((w0 >> 16) & 255u) << 14 | (w0 >> 24) << 6 | (r.cw & 255u) >> 2) > 999999999u;
+	}
+	if (abort_frame) { r.state = DST_TRAINING; r.position = 0; r.osc = 0; }
+	return false;
+}
+
 DEC_HD int dec_select_bit(uint32_t m, int k) { // index of the k-th (1-based) set bit of m (k <= popcount)
 	for (int i = 1; i < k; i++) m &= m - 1;
 	return __builtin_ctz(m);

@@ -371,8 +371,12 @@ struct KV2EParams {
 	float w_train, w_track;
 	uint32_t* frames; unsigned* frame_count; int max_frames; unsigned block, sub;
 	int* locked_estimates;     // statistics: Estimate() calls at a learned slot phase (the windows the assist kernels cannot know)
+	int roles;                 // 1: trackers and FM decoder on two waves of a workgroup (round 6); 0: one wave, six lanes in step (test hook "v2_roles")
 	float taps17[17];
 };
+#ifdef V2_PROF
+void v2_prof_dump(); // experiment build: cycles of kv2_engine's phases on stderr
+#endif
 bool sincos_restatement_matches_host_libm(); // kv2_engine's sinf / cosf (glibc 2.35, FMA variant) on the host against the host's own libm
 hipError_t launch_kv2(const KV2Params& p, hipStream_t s, const KV2EParams* engine = nullptr); // engine: kv2_engine runs before the look-back is overwritten
 // Derotation + FIR + ScatterPLL + PhaseSearchEMA in one workgroup (k46_window_search, kernels.hip): K6Params without `sym` traffic

@@ -121,7 +121,7 @@ def load():
 # Test hooks of the library (include/aisgpu.h: aisgpu_set_option).  The shipped .so reads no environment variable; for the
 # tests' convenience THIS wrapper forwards AISGPU_<KEY> from the environment to the option of the same name before a context
 # is created (monkeypatch.setenv("AISGPU_PS_WARM", "16") in a test selects the exact-fallback path).
-OPTION_KEYS = ("serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "k46", "k1u_spw", "us_k1")
+OPTION_KEYS = ("serial", "ps_warm", "ps_sequential", "k7", "k7b_fcap", "fused", "fft_in_k1", "k46", "k1u_spw", "us_k1", "v2_roles")
 
 
 _forwarded = set()

@@ -89,6 +89,73 @@ int main(int argc, char** argv) {
 	for (int i = 0; i < 256; i++) dec_crc_table_entry(i, g_tab);
 	std::mt19937 rng(seed);
 	const auto rnd = [&](int lo, int hi) { return lo + (int)(rng() % (unsigned)(hi - lo + 1)); };
+	if (argc > 3 && !strcmp(argv[3], "lean")) {
+		// dec_lean_idle / dec_lean_data (kv2_engine's two-wave form) against dec_step, symbol by symbol over long streams of noise, preambles,
+		// flags and stuffed payloads with good and broken CRCs; after a completed message both decoders are reset like V2's resetDecoders().
+		// Every field the lean pair maintains must agree after every symbol, the frame buffers wherever a message completes.
+		long steps = 0, n_msg = 0, n_open = 0, n_abort_ = 0;
+		for (long t = 0; t < trials; t++) {
+			std::vector<int> nrzi;
+			const int segs = rnd(1, 6);
+			for (int sg = 0; sg < segs; sg++) {
+				if (rnd(0, 2) == 0) {
+					const int pone = rnd(0, 3) == 0 ? 80 : rnd(30, 60);
+					for (int i = rnd(1, 400); i > 0; i--) nrzi.push_back(rnd(0, 99) < pone);
+					continue;
+				}
+				for (int i = 0, pre = rnd(4, 30); i < pre; i++) nrzi.push_back(i & 1);
+				const int flag[8] = { 0, 1, 1, 1, 1, 1, 1, 0 };
+				for (int b : flag) nrzi.push_back(b);
+				int L;
+				switch (rnd(0, 6)) {
+				case 6: L = rnd(0, 3); break;
+				case 0: L = 168; break;
+				case 1: L = 8 * rnd(1, 132); break;
+				case 2: L = rnd(1, 1100); break;
+				case 3: L = 424; break;
+				case 4: L = rnd(1040, 1090); break;
+				default: L = 8 * rnd(2, 60); break;
+				}
+				std::vector<int> pay(L);
+				const int pone = rnd(0, 3) == 0 ? 80 : 50;
+				for (int& b : pay) b = rnd(0, 99) < pone;
+				if (rnd(0, 3) && L >= 8) { const int type = rnd(1, 27); for (int k = 0; k < 6; k++) pay[2 + k] = (type >> k) & 1; }
+				if (rnd(0, 2) && L >= 40) for (int k = 34; k < 40; k++) pay[k] = 0;
+				const uint16_t fcs = crc16(pay);
+				for (int k = 0; k < 16; k++) pay.push_back((fcs >> k) & 1);
+				if (rnd(0, 4) == 0) pay[rnd(0, (int)pay.size() - 1)] ^= 1;
+				if (rnd(0, 30) == 0) pay.pop_back();
+				int ones = 0;
+				for (int b : pay) { nrzi.push_back(b); ones = b ? ones + 1 : 0; if (ones == 5) { nrzi.push_back(0); ones = 0; } }
+				if (rnd(0, 9)) for (int b : flag) nrzi.push_back(b);
+			}
+			Dec a, b;
+			fresh(a, rnd(0, 1), rnd(0, 1));
+			a.r.position = rnd(0, 6);
+			b = a;
+			int p = a.r.prev;
+			for (size_t i = 0; i < nrzi.size(); i++) {
+				const int dd = nrzi[i] ? p : !p; p = dd;
+				const float slvl = (float)rnd(0, 1 << 20) / 4096.0f;
+				const long long sidx = 7 * (long long)i + 3;
+				const int st_before = a.r.state;
+				const bool fa = dec_step<false>(a.r, dd, slvl, sidx, a.data());
+				bool fb = false;
+				if (b.r.state == DST_DATAFCS) fb = dec_lean_data(b.r, dd, slvl, b.data(), g_tab);
+				else n_open += dec_lean_idle(b.r, dd, sidx);
+				steps++;
+				const DecReg &x = a.r, &y = b.r;
+				bool bad = fa != fb || x.state != y.state || x.lastBit != y.lastBit || x.prev != y.prev || x.position != y.position || x.osc != y.osc || x.start_idx != y.start_idx;
+				if (x.state == DST_DATAFCS) bad = bad || memcmp(&x.level, &y.level, 4) || x.cw != y.cw || x.cwi != y.cwi || x.abort_pos != y.abort_pos;
+				if (fa && !bad) for (int w = 0; w < (x.position + 31) / 32; w++) bad = bad || a.data()[DEC_LANES * w] != b.data()[DEC_LANES * w];
+				if (bad) { printf("MISMATCH lean trial %ld symbol %zu (state %d -> %d / %d, position %d / %d, found %d / %d)\n", t, i, st_before, x.state, y.state, x.position, y.position, (int)fa, (int)fb); return 1; }
+				n_abort_ += st_before == DST_DATAFCS && !fa && x.state == DST_TRAINING;
+				if (fa) { n_msg++; a.r.state = b.r.state = DST_TRAINING; a.r.position = b.r.position = 0; a.r.osc = b.r.osc = 0; }
+			}
+		}
+		printf("lean steps %ld, frames opened %ld, messages %ld, frames abandoned %ld: all equal\n", steps, n_open, n_msg, n_abort_);
+		return 0;
+	}
 	if (argc > 3 && !strcmp(argv[3], "idle")) {
 		// dec_step_idle (kv2_engine's branch-free step for a decoder that is not inside a frame) against dec_step, field by field: random
 		// TRAINING / STARTFLAG states incl. the ones where a flag starts, continues, opens a frame or falls back, random stale frame

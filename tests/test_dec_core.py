@@ -46,6 +46,15 @@ def test_idle_decoder_step_equals_the_step(fuzz_binary):
     assert "all equal" in r.stdout and steps == 2000000 and opened > 10000 and flagged > 10000, r.stdout
 
 
+def test_lean_decoder_pair_equals_the_step(fuzz_binary):
+    """dec_lean_idle / dec_lean_data -- the decoder of kv2_engine's two-wave form (round 6: no CRC register kept per symbol, the rare
+    events of a frame behind one branch) -- against dec_step, symbol by symbol over streams of noise, preambles, flags and stuffed payloads."""
+    r = subprocess.run([fuzz_binary, "20000", "11", "lean"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    steps, opened, messages, abandoned = (int(v) for v in re.findall(r"\d+", r.stdout)[:4])
+    assert "all equal" in r.stdout and steps > 5000000 and opened > 20000 and messages > 5000 and abandoned > 10000, r.stdout
+
+
 @pytest.fixture(scope="module")
 def scan_binary(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("dec_scan") / "dec_scan_fuzz")

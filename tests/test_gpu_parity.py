@@ -892,15 +892,19 @@ def test_model_engine_v2_end_to_end(rate, fmt, block, nblocks):
     assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
 
 
+@pytest.mark.parametrize("roles", ["1", "0"])
 @pytest.mark.parametrize("rate,fmt,block,nblocks", [(1536000, "cf32", 131072, 24), (1536000, "cu8", 786432, 4), (768000, "cf32", 65536, 24), (6000000, "cf32", 786432, 4)])
-def test_model_engine_v2_on_the_device(rate, fmt, block, nblocks):
+def test_model_engine_v2_on_the_device(rate, fmt, block, nblocks, roles, monkeypatch):
     """AISGPU_FLAG_GPU_DECODE with ModelEngineV2 (round 4): the engine's coherent branch runs on the device too
     (kv2_engine: tone gate / slot lock from the decoders' states, Derotate, FilterFL17, five PhaseTrackers, six decoders with
     their reset, the slot-phase learner) -- the 48 kHz channels never leave the device, completed frames come back.  Everything
     is the reference's arithmetic in the reference's order, std::polar of the estimated frequency included (glibc's sinf / cosf
     restated, tests/test_sincosf.py): NMEA text, tag.ppm and the per-message level -- a sum of |derotated, filtered sample|^2
-    over the frame -- must equal the compiled reference's bit for bit."""
+    over the frame -- must equal the compiled reference's bit for bit.
+    roles = 1 (round 6, the default): the trackers and the FM decoder on two waves of a workgroup, speculating that no message completes,
+    with the exact order restored where one does; roles = 0: round 5's one-wave form (test hook v2_roles)."""
     from ais_catcher_amd import host
+    monkeypatch.setenv("AISGPU_V2_ROLES", roles)
     x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=46, gap_slots=(1, 2), type5_every=4)
     data = synth.to_cu8(x) if fmt == "cu8" else x
     per = 1 if fmt == "cf32" else 2
@@ -918,13 +922,15 @@ def test_model_engine_v2_on_the_device(rate, fmt, block, nblocks):
     m.close()
 
 
-def test_model_engine_v2_on_the_device_batch_of_distinct_receivers():
+@pytest.mark.parametrize("roles", ["1", "0"])
+def test_model_engine_v2_on_the_device_batch_of_distinct_receivers(roles, monkeypatch):
     """Seven distinct receivers = fourteen channels: one full wave of the engine kernel (ten channels) and a partial one, one host
     thread per receiver on a shared batch; every receiver's NMEA text, levels and ppm against the compiled reference, in order.
     The streams put their bursts on the SOTDMA slot grid, so the engines learn the slot phase and take the kernel's slow path
     (Estimate() at an arbitrary offset inside the block) as well: counted."""
     import threading
     from ais_catcher_amd import host
+    monkeypatch.setenv("AISGPU_V2_ROLES", roles)
     R, block, nblocks = 7, 131072, 30
     xs = [synth.receiver_stream(block * nblocks, receiver_id=400 + r, gap_slots=(0, 1), type5_every=5) for r in range(R)]
     want = []
