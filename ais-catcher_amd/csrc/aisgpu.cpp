@@ -1612,7 +1612,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	HIPCHK(dalloc(&h->d_psflag, 4));
 	if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_firtap, C * (8 + h->L)));
 	if (h->v2) {
-		h->v2_roles = opt_int("v2_roles", 1) != 0;
+		h->v2_roles = opt_int("v2_roles", 1);
 		// With the engine on the device (AISGPU_FLAG_GPU_DECODE) nothing but frames goes to the host: no pinned slots for the channels,
 		// the estimates, the energies or the discriminator signs (several GB at 2,048 receivers), and aisgpu_fetch_sub() returns NULL for them.
 		const bool v2_host = !h->gpu_decode;
