@@ -196,6 +196,10 @@ struct aisgpu {
 	V2ChanState* d_v2st = nullptr; float2* d_slotcs = nullptr; int* d_v2locked = nullptr; // AISGPU_FLAG_GPU_DECODE with ModelEngineV2: the engine itself on the device (kv2_engine)
 	int v2_roles = 1; // kv2_engine: trackers and FM decoder on two waves (test hook "v2_roles" = 0: the one-wave form of round 5)
 	bool v2_assist = true; float2* d_v2hist = nullptr; float *d_v2f = nullptr, *d_v2prom = nullptr, *d_v2en = nullptr, *h_v2f = nullptr, *h_v2prom = nullptr, *h_v2en = nullptr; // decoder-independent part of V2::Engine on the device
+	// the engine on the device (round 6): on a stream of its own, beside the next block's front end and assist kernels -- what it reads of
+	// the assist kernels' outputs exists twice (by block parity): look-back, estimates, energies, the previous block's last discriminator signs
+	float2* d_v2hist2 = nullptr; float *d_v2f2 = nullptr, *d_v2prom2 = nullptr, *d_v2en2 = nullptr; uint32_t* d_v2fmtail[2] = { nullptr, nullptr };
+	hipEvent_t ev_v2assist = nullptr, ev_v2engine[2] = { nullptr, nullptr }; int v2_par = 0; hipStream_t v2_stream = nullptr;
 	bool k46 = false; // default path: derotation + FIR + PhaseSearch in one kernel (k46_window_search; test hook "k46" = 0: k6_window_fir + k4_phase_chunks)
 	bool base = false; float2* d_fmprev[2] = {}; // ModelBase: FM receiver on the 48 kHz channels, no coherent chain
 	float* d_fm = nullptr; float* d_fmhist[2] = {}; uint32_t* d_fmbits[2] = {}; uint32_t* h_fmbits = nullptr; // ModelChallenger FM branch
@@ -822,20 +826,34 @@ int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
 			                        (size_t)h->L * sizeof(float2), C, hipMemcpyDeviceToHost, h->ds));
 		if (h->v2_assist) { // FreqOffset::Estimate of every offset-0 / offset-256 window, midWins' energies, the FM branch up to its sign
 			KV2Params k{};
-			k.c48 = h->d_c48[q]; k.c48_stride = h->c48s; k.hist = h->d_v2hist; k.omega = h->d_omega;
+			k.c48 = h->d_c48[q]; k.c48_stride = h->c48s; k.hist = h->d_v2hist; k.hist_out = h->d_v2hist; k.fmtail_out = nullptr; k.omega = h->d_omega;
 			k.est_f = h->d_v2f; k.est_prom = h->d_v2prom; k.energy = h->d_v2en;
 			k.disc = h->d_fm; k.fmprev = h->d_fmprev[0]; k.fmbits = h->d_fmbits[pb]; k.fmbits_stride = h->L / 32;
 			k.fir_out = h->d_fmfir; k.fir_stride = h->L;
 			memcpy(k.taps, TAPS_RECEIVER, sizeof k.taps);
 			k.n_windows = h->W; k.L = h->L; k.n_chan = h->n_chan;
 			if (on_device) {
+				const int par = h->v2_par; // this block reads pair member `par`; its tail goes to the other one
+				h->v2_par ^= 1;
+				k.hist = par ? h->d_v2hist2 : h->d_v2hist; k.hist_out = par ? h->d_v2hist : h->d_v2hist2;
+				k.est_f = par ? h->d_v2f2 : h->d_v2f; k.est_prom = par ? h->d_v2prom2 : h->d_v2prom; k.energy = par ? h->d_v2en2 : h->d_v2en;
+				k.fmtail_out = h->d_v2fmtail[par ^ 1];
 				KV2EParams e{};
-				e.k = k; e.fm_prev = h->d_fmbits[pb ^ 1]; e.st = h->d_v2st; e.dec = h->d_dec; e.slot_cs = h->d_slotcs;
+				e.k = k; e.fm_prev = h->d_v2fmtail[par]; e.st = h->d_v2st; e.dec = h->d_dec; e.slot_cs = h->d_slotcs;
 				e.w_train = 0.75f; e.w_track = 0.86f; // PhaseTracker's defaults (V2Engine.h:70-71)
 				e.frames = h->d_frames; e.frame_count = h->d_frame_count; e.max_frames = h->max_frames;
 				e.block = (unsigned)h->block_idx; e.sub = (unsigned)h->n_sub; e.locked_estimates = h->d_v2locked; e.roles = h->v2_roles;
 				memcpy(e.taps17, TAPS_COHERENT, sizeof e.taps17);
-				HIPCHK(launch_kv2(k, h->ds, &e));
+				// ds: assist kernels of this block; engine stream: the engine behind them; ds again: the carry, which overwrites what the
+				// engine of the PREVIOUS block read (the other pair member, fmbits[pb ^ 1] is next) -- so it waits for that engine, not this one
+				HIPCHK(launch_kv2_assist(k, h->ds));
+				HIPCHK(hipEventRecord(h->ev_v2assist, h->ds));
+				WAITEV(h->v2_stream, h->ev_v2assist);
+				HIPCHK(launch_kv2_engine(e, h->v2_stream));
+				HIPCHK(hipEventRecord(h->ev_v2engine[par], h->v2_stream));
+				WAITEV(h->ds, h->ev_v2engine[par ^ 1]);
+				HIPCHK(launch_kv2_carry(k, h->ds));
+				HIPCHK(hipEventRecord(h->ev_c48free[q], h->v2_stream)); // (the engine is the block's last reader of its 48 kHz channels)
 			} else {
 				HIPCHK(launch_kv2(k, h->ds));
 				HIPCHK(hipMemcpyAsync(h->h_v2f + s_ * C * 2 * h->W, h->d_v2f, C * 2 * h->W * sizeof(float), hipMemcpyDeviceToHost, h->ds));
@@ -847,7 +865,7 @@ int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
 		SubOut& so = h->sub[h->n_sub++];
 		so.pb = pb; so.lv = 0; so.q = q; so.groups = 0; so.first_group = h->n48 / 5; so.first48 = h->n48;
 	}
-	HIPCHK(hipEventRecord(h->ev_c48free[q], h->ds));
+	if (!(h->gpu_decode && h->v2_assist)) HIPCHK(hipEventRecord(h->ev_c48free[q], h->ds));
 	h->n48 += h->L;
 	h->block_idx++;
 	return AISGPU_OK;
@@ -1620,6 +1638,17 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 		if (h->v2_assist) {
 			HIPCHK(dalloc(&h->d_v2hist, C * V2_HIST));
 			HIPCHK(dalloc(&h->d_v2f, C * 2 * h->W)); HIPCHK(dalloc(&h->d_v2prom, C * 2 * h->W)); HIPCHK(dalloc(&h->d_v2en, C * (h->W + 1)));
+			if (!v2_host) {
+				HIPCHK(dalloc(&h->d_v2hist2, C * V2_HIST));
+				HIPCHK(dalloc(&h->d_v2f2, C * 2 * h->W)); HIPCHK(dalloc(&h->d_v2prom2, C * 2 * h->W)); HIPCHK(dalloc(&h->d_v2en2, C * (h->W + 1)));
+				for (int i = 0; i < 2; i++) { HIPCHK(dalloc(&h->d_v2fmtail[i], C * 16)); HIPCHK(hipEventCreateWithFlags(&h->ev_v2engine[i], hipEventDisableTiming)); }
+				HIPCHK(hipEventCreateWithFlags(&h->ev_v2assist, hipEventDisableTiming));
+				// (measured, round 6: the engine on s1 beside the next block's front end and assist kernels takes 4.1 ms instead of 2.6 -- its
+				// workgroups need 50 KB of LDS each and wait for CUs the throughput kernels fill, and every shared SIMD delays its dependent
+				// chains -- so the step got slower, 4.1 against 3.1 ms.  The engine stays behind its assist kernels on their stream; the
+				// pairs of buffers stay, they cost nothing.)
+				h->v2_stream = h->ds;
+			}
 			if (v2_host) {
 				HIPCHK(hipHostMalloc((void**)&h->h_v2f, 2 * MAXSUB * C * 2 * h->W * sizeof(float), hipHostMallocDefault));
 				HIPCHK(hipHostMalloc((void**)&h->h_v2prom, 2 * MAXSUB * C * 2 * h->W * sizeof(float), hipHostMallocDefault));
@@ -1691,6 +1720,9 @@ void aisgpu_destroy(aisgpu_t* h) {
 	if (h->h_fmbits) hipHostFree(h->h_fmbits);
 	if (h->h_c48) hipHostFree(h->h_c48);
 	hipFree(h->d_v2hist); hipFree(h->d_v2f); hipFree(h->d_v2prom); hipFree(h->d_v2en); hipFree(h->d_v2st); hipFree(h->d_slotcs); hipFree(h->d_v2locked);
+	hipFree(h->d_v2hist2); hipFree(h->d_v2f2); hipFree(h->d_v2prom2); hipFree(h->d_v2en2); hipFree(h->d_v2fmtail[0]); hipFree(h->d_v2fmtail[1]);
+	if (h->ev_v2assist) hipEventDestroy(h->ev_v2assist);
+	for (int i = 0; i < 2; i++) if (h->ev_v2engine[i]) hipEventDestroy(h->ev_v2engine[i]);
 	if (h->h_v2f) hipHostFree(h->h_v2f); if (h->h_v2prom) hipHostFree(h->h_v2prom); if (h->h_v2en) hipHostFree(h->h_v2en);
 	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); }
 	hipFree(h->d_dfhist[0]); hipFree(h->d_dfhist[1]);

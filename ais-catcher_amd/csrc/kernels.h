@@ -337,7 +337,10 @@ hipError_t launch_k5(const K5Params& p, int n_chan, hipStream_t s);
 constexpr int V2_HIST = 512; // samples of the previous block kept in front of the current one (one engine block of look-back)
 struct KV2Params {
 	const float2* c48; long long c48_stride;   // this block's 48 kHz channels
-	float2* hist;                               // [n_chan][V2_HIST] last samples of the previous block (zeros before the stream); updated at the end
+	float2* hist;                               // [n_chan][V2_HIST] last samples of the previous block (zeros before the stream)
+	float2* hist_out;                           // where kv2_carry leaves this block's tail (the same buffer, or the other one of a pair: the engine of
+	                                            // this block may still be reading `hist` on its own stream while the next block's assist kernels start)
+	uint32_t* fmtail_out;                       // optional [n_chan][16]: the last 512 discriminator signs of this block, for the engine of the next one
 	const float2* omega;                        // FFT twiddles
 	float* est_f; float* est_prom;              // [n_chan][2 * n_windows]: window w starts at sample -512 + 256 w of this block
 	float* energy;                              // [n_chan][n_windows + 1]: sum of |x|^2 over [-512 + 512 i, +256)
@@ -364,7 +367,7 @@ struct V2ChanState { // zero-initialised but for rot = (1, 0)
 };
 struct KV2EParams {
 	KV2Params k;               // this block's channels, the previous block's tail, estimates, energies, this block's discriminator signs
-	const uint32_t* fm_prev;   // [n_chan][L / 32] the previous block's discriminator signs
+	const uint32_t* fm_prev;   // [n_chan][16] the previous block's last 512 discriminator signs (kv2_carry's fmtail_out)
 	V2ChanState* st;           // [n_chan]
 	DecState* dec;             // [n_chan * 6]
 	const float2* slot_cs;     // [1280] (cosf, sinf)(k * (2 pi / 1280)) from the host's libm (learnSlotPhase, :328-337)
@@ -379,6 +382,10 @@ void v2_prof_dump(); // experiment build: cycles of kv2_engine's phases on stder
 #endif
 bool sincos_restatement_matches_host_libm(); // kv2_engine's sinf / cosf (glibc 2.35, FMA variant) on the host against the host's own libm
 hipError_t launch_kv2(const KV2Params& p, hipStream_t s, const KV2EParams* engine = nullptr); // engine: kv2_engine runs before the look-back is overwritten
+// the same in three parts (round 6: the engine on a stream of its own, beside the next block's front end and assist kernels)
+hipError_t launch_kv2_assist(const KV2Params& p, hipStream_t s);
+hipError_t launch_kv2_engine(const KV2EParams& e, hipStream_t s);
+hipError_t launch_kv2_carry(const KV2Params& p, hipStream_t s);
 // Derotation + FIR + ScatterPLL + PhaseSearchEMA in one workgroup (k46_window_search, kernels.hip): K6Params without `sym` traffic
 // (f.sym = the block parity's global rows: only the exact fallback inside k46_assemble writes and reads them), K4Params as for launch_k4
 struct K46Params { K6Params f; K4Params s; int trips_pad; };

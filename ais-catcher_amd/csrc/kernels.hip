@@ -3128,8 +3128,9 @@ __global__ __launch_bounds__(64) void kv2_carry(KV2Params p) {
 	float* dsc = p.disc + (size_t)chan * (FM_HIST + p.L);
 	if (threadIdx.x < FM_HIST) dsc[threadIdx.x] = dsc[p.L + threadIdx.x];
 	const float2* x = p.c48 + (size_t)chan * p.c48_stride + (p.L - V2_HIST);
-	for (int i = threadIdx.x; i < V2_HIST; i += 64) p.hist[(size_t)chan * V2_HIST + i] = x[i];
+	for (int i = threadIdx.x; i < V2_HIST; i += 64) p.hist_out[(size_t)chan * V2_HIST + i] = x[i];
 	if (threadIdx.x == 0) p.fmprev[chan] = p.c48[(size_t)chan * p.c48_stride + p.L - 1];
+	if (p.fmtail_out && threadIdx.x < 16) p.fmtail_out[(size_t)chan * 16 + threadIdx.x] = p.fmbits[(size_t)chan * p.fmbits_stride + (p.L - 512) / 32 + threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3423,7 +3424,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void kv2_engine_t(KV2EParams q) {
 	if (SPLIT) for (int i = threadIdx.x; i < 256; i += 128) dec_crc_table_entry(i, crctab); // (first read behind block 0's barrier)
 	FftTwiddles tw = fft_twiddles(p.omega, lane);
 	const uint32_t* fm_cur = p.fmbits + (size_t)chan * p.fmbits_stride;
-	const uint32_t* fm_old = q.fm_prev + (size_t)chan * p.fmbits_stride;
+	const uint32_t* fm_old = q.fm_prev + (size_t)chan * 16 - (size_t)(p.L - 512) / 32; // (indexed like fm_cur: word (L - 512) / 32 + l is its word l)
 	// sign of the filtered discriminator at sample k of the engine block that is being decoded (the block's sixteen words: LDS)
 	const auto fm_sign = [&](int k) -> int { return (int)((fmw[k >> 5] >> (k & 31)) & 1u); };
 	const auto emit = [&](const DecReg& r, long long sidx, float tag_ppm) {
@@ -3958,6 +3959,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 	__shared__ float2 sh_slot_ema;   // the slot predictor after a learnSlotPhase (wave 0 -> wave 2)
 	__shared__ int sh_slot_phase;
 	const KV2Params& p = q.k;
+	__builtin_amdgcn_s_setprio(3); // (every wave here is one long dependent chain: it must issue the moment it can, the throughput kernels beside it fill the gaps)
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	const int lane = threadIdx.x & 63, j = lane;
 	const int chan = blockIdx.x;
@@ -3987,7 +3989,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 	for (int i = threadIdx.x; i < 256; i += 192) dec_crc_table_entry(i, crctab); // (first read behind the first barrier)
 	FftTwiddles tw = fft_twiddles(p.omega, lane);
 	const uint32_t* fm_cur = p.fmbits + (size_t)chan * p.fmbits_stride;
-	const uint32_t* fm_old = q.fm_prev + (size_t)chan * p.fmbits_stride;
+	const uint32_t* fm_old = q.fm_prev + (size_t)chan * 16 - (size_t)(p.L - 512) / 32; // (indexed like fm_cur: word (L - 512) / 32 + l is its word l)
 	const auto emit = [&](const DecReg& r, long long sidx, float tag_ppm) {
 		const unsigned slot = atomicAdd(q.frame_count, 1u) % (unsigned)q.max_frames;
 		uint32_t* f = q.frames + (size_t)slot * DEC_FRAME_WORDS;
@@ -5779,19 +5781,29 @@ hipError_t launch_k7(const K7Params& p, hipStream_t s) {
 	return hipGetLastError();
 }
 
-hipError_t launch_kv2(const KV2Params& p, hipStream_t s, const KV2EParams* engine) {
+hipError_t launch_kv2_assist(const KV2Params& p, hipStream_t s) {
 	const int n_est = p.n_chan * 2 * p.n_windows;
 	hipLaunchKernelGGL(kv2_estimate, dim3((n_est + FFT_NW - 1) / FFT_NW), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(kv2_energy, dim3((p.n_chan * (p.n_windows + 1) + 63) / 64), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(kv2_fm, dim3(p.L / 256, p.n_chan), dim3(256), 0, s, p);
 	hipLaunchKernelGGL(kv2_filter, dim3(p.L / 256, p.n_chan), dim3(256), 0, s, p);
-	if (engine) { // one workgroup per channel (reads the look-back: before the carry)
-		if (engine->roles == 2) hipLaunchKernelGGL(kv2_engine_t<true>, dim3(p.n_chan), dim3(128), 0, s, *engine);
-		else if (engine->roles) hipLaunchKernelGGL(kv2_engine_roles, dim3(p.n_chan), dim3(192), 0, s, *engine);
-		else hipLaunchKernelGGL(kv2_engine_t<false>, dim3(p.n_chan), dim3(64), 0, s, *engine);
-	}
+	return hipGetLastError();
+}
+hipError_t launch_kv2_engine(const KV2EParams& e, hipStream_t s) { // one workgroup per channel (reads the look-back `hist`)
+	if (e.roles == 2) hipLaunchKernelGGL(kv2_engine_t<true>, dim3(e.k.n_chan), dim3(128), 0, s, e);
+	else if (e.roles) hipLaunchKernelGGL(kv2_engine_roles, dim3(e.k.n_chan), dim3(192), 0, s, e);
+	else hipLaunchKernelGGL(kv2_engine_t<false>, dim3(e.k.n_chan), dim3(64), 0, s, e);
+	return hipGetLastError();
+}
+hipError_t launch_kv2_carry(const KV2Params& p, hipStream_t s) {
 	hipLaunchKernelGGL(kv2_carry, dim3(p.n_chan), dim3(64), 0, s, p);
 	return hipGetLastError();
+}
+hipError_t launch_kv2(const KV2Params& p, hipStream_t s, const KV2EParams* engine) {
+	hipError_t e = launch_kv2_assist(p, s);
+	if (e == hipSuccess && engine) e = launch_kv2_engine(*engine, s);
+	if (e == hipSuccess) e = launch_kv2_carry(p, s);
+	return e;
 }
 
 hipError_t launch_k7_pack(const K7Params& p, hipStream_t s) {
