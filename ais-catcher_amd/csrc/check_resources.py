@@ -18,7 +18,7 @@ BUDGET = [
     ("k6_window_fir", 64, 0),
     ("k2_cgf_phasor_ck_pairs", 128, 0),
     ("k1u_resample_frontend", 128, 0),
-    ("kv2_engine", 256, 0),
+    ("kv2_engine", 256, 0),           # (kv2_engine: one wave per channel; kv2_engine_roles: three)
 ]
 
 

@@ -3280,24 +3280,10 @@ bool sincos_restatement_matches_host_libm() {
 }
 
 struct V2Lane { DecReg r; V2Tracker t; float pll_phase; int pll_last; };
-#ifdef V2_PROF // experiment build: cycles of the engine's phases, summed over the waves (tools/build_variant.sh v2prof -DV2_PROF)
+#ifdef V2_PROF // experiment build: cycles of the engine's phases, summed over the waves and launches (tools/build_variant.sh v2prof -DV2_PROF)
 __device__ unsigned long long v2_prof[16];
 #define V2P_T0() const unsigned long long v2p_t0 = __builtin_readcyclecounter()
 #define V2P_ADD(slot) do { if (lane == 0) atomicAdd(&v2_prof[slot], __builtin_readcyclecounter() - v2p_t0); } while (0)
-#ifdef V2_PROF_GRP // cycles per path of the FM wave's turn (s_memtime tied to the values it must wait for)
-#define V2P_G0() unsigned long long v2p_g0; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(v2p_g0) : "v"(rare) : "memory")
-#define V2P_GACC(i) do { unsigned long long t1_; asm volatile("s_nop 0\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1_) : "v"(ph), "v"(last), "v"(L.r.state), "v"(L.r.position), "s"(kret) : "memory"); v2p_acc[i] += t1_ - v2p_g0; v2p_n[i]++; } while (0)
-#define V2P_GFLUSH() do { if (lane == 0) for (int i = 0; i < 3; i++) { atomicAdd(&v2_prof[10 + i], v2p_acc[i]); atomicAdd(&v2_prof[13 + i], (unsigned long long)v2p_n[i]); } } while (0)
-#else
-#define V2P_G0() do {} while (0)
-#define V2P_GACC(i) do {} while (0)
-#define V2P_GFLUSH() do {} while (0)
-#endif
-#ifdef V2_PROF_CNT
-#define V2P_CNT(slot) do { if (lane == 0) atomicAdd(&v2_prof[slot], 1ull); } while (0)
-#else
-#define V2P_CNT(slot) do {} while (0)
-#endif
 void v2_prof_dump() {
 	unsigned long long h[16];
 	if (hipMemcpyFromSymbol(h, HIP_SYMBOL(v2_prof), sizeof h) != hipSuccess) return;
@@ -3308,10 +3294,6 @@ void v2_prof_dump() {
 #else
 #define V2P_T0() do {} while (0)
 #define V2P_ADD(slot) do {} while (0)
-#define V2P_G0() do {} while (0)
-#define V2P_GACC(i) do {} while (0)
-#define V2P_GFLUSH() do {} while (0)
-#define V2P_CNT(slot) do {} while (0)
 #endif
 
 __device__ __forceinline__ c2 v2_dot17(const float2* a, const float* taps) { // dot17 (:38-45)
@@ -3374,36 +3356,19 @@ __device__ __forceinline__ void v2_reset(DecReg& r) { r.state = DST_TRAINING; r.
 //  * the group loop: five tracker lanes + the FM decoder's lane as before; while none of the six decoders is inside a frame
 //    (DATAFCS) -- four fifths of the time on the bench signal -- the decoder step is its TRAINING / STARTFLAG half only.
 // The channel's scalar state (phasor, slot predictor, sample index ...) lives in every lane, identically: no leader, no broadcasts.
-// Round 6 (SPLIT): the engine's two halves -- the five PhaseTrackers with their decoders, and the FM decoder behind its BitPLL -- are
-// coupled only through resetDecoders() at a completed message (:374-385), a rare event.  They run on the two waves of a workgroup,
-// each as its own loop over the block (wave 0: front end, then five lanes with one tracker + decoder each, a group of five samples per
-// turn; wave 1: one lane, sample by sample, the PLL's bits and flags in scalar registers), speculating that nobody completes a message.
-// A wave that does complete one stops there; the waves exchange the positions at the end of the block, and where there is one, both
-// restore the state they had at the last agreed position, run up to the earliest completion k* exactly, handle sample k* in the
-// reference's order (the tracker's decoder first: message out, learnSlotPhase, all six reset; then the FM decoder), and speculate on
-// from k* + 1.  Completed messages leave the kernel only from that exact pass.
-template <bool SPLIT>
-__global__ __launch_bounds__(SPLIT ? 128 : 64) void kv2_engine_t(KV2EParams q) {
+__global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64]; // [word][lane]
-	__shared__ uint32_t fsnap[SPLIT ? DEC_DATA_WORDS * 64 : 1]; // SPLIT: the frame buffers at the last agreed position
 	__shared__ __attribute__((aligned(16))) float2 dero[16 + 512 + 2]; // FilterFL17's carry, then the block: raw, derotated in place
 	__shared__ __attribute__((aligned(16))) float2 X[584];              // Estimate()'s exchange space; afterwards the block's 512 FilterFL17 outputs
 	__shared__ __attribute__((aligned(16))) float mag[512 + 8];
 	__shared__ uint32_t fmw[16];
-	__shared__ __attribute__((aligned(8))) uint32_t fmw2[SPLIT ? 18 : 2];
-	__shared__ uint16_t crctab[SPLIT ? 256 : 2]; // SPLIT: byte-wise CRC steps (the lean decoder forms a frame's CRC from its buffer at the closing flag)
-	__shared__ int kx[2][2];      // SPLIT: first completed message of each wave, by exchange parity
-	__shared__ float sh_ppm[2];   // SPLIT: ppm, ppm_prev and the split of the block for the FM decoder's tag
-	__shared__ int sh_split;
 	float2* const zb = X;
 	const KV2Params& p = q.k;
-	const int wave = SPLIT ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-	const int lane = threadIdx.x & 63, j = lane;
+	const int lane = threadIdx.x, j = lane;
 	const int chan = blockIdx.x;
-	const bool fm_wave = SPLIT && wave == 1; // this wave is the FM decoder behind its BitPLL (its lane 0)
-	const bool dl = SPLIT ? (fm_wave ? lane == 0 : lane < 5) : lane < 6; // the decoder lanes: 0..4 behind the trackers, 5 the FM decoder behind its BitPLL
-	const int dec = chan * 6 + (fm_wave ? 5 : (dl ? j : 0));
-	uint32_t* data = fdata + (fm_wave ? (lane == 0 ? 5 : 63) : lane);
+	const bool dl = lane < 6; // the six decoder lanes: 0..4 behind the trackers, 5 the FM decoder behind its BitPLL
+	const int dec = chan * 6 + (dl ? j : 0);
+	uint32_t* data = fdata + lane;
 	V2ChanState* cs = q.st + chan;
 	V2Lane L;
 	{
@@ -3411,7 +3376,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void kv2_engine_t(KV2EParams q) {
 		DecReg& r = L.r;
 		r.state = st->state; r.lastBit = st->lastBit; r.prev = st->prev; r.position = st->position; r.osc = st->osc;
 		r.level = st->level; r.start_idx = st->start_idx;
-		if (!SPLIT || dl) for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = st->data[w];
+		for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = st->data[w];
 		r.crc = st->crc[0]; r.cw = st->crc[1]; r.cwi = (int)st->crc[2]; r.tail = st->crc[3]; r.abort_pos = (int)st->crc[4];
 		L.t = cs->trk[j < 5 ? j : 0];
 		L.pll_phase = cs->pll_phase; L.pll_last = cs->pll_last;
@@ -3420,11 +3385,10 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void kv2_engine_t(KV2EParams q) {
 	float last_f = cs->last_f, ppm = cs->ppm, ppm_prev = cs->ppm_prev;
 	int slot_phase = cs->slot_phase, di = cs->di;
 	long long sample_idx = cs->sample_idx;
-	if (lane < 16 && !fm_wave) dero[lane] = cs->carry17[lane];
-	if (SPLIT) for (int i = threadIdx.x; i < 256; i += 128) dec_crc_table_entry(i, crctab); // (first read behind block 0's barrier)
+	if (lane < 16) dero[lane] = cs->carry17[lane];
 	FftTwiddles tw = fft_twiddles(p.omega, lane);
 	const uint32_t* fm_cur = p.fmbits + (size_t)chan * p.fmbits_stride;
-	const uint32_t* fm_old = q.fm_prev + (size_t)chan * 16 - (size_t)(p.L - 512) / 32; // (indexed like fm_cur: word (L - 512) / 32 + l is its word l)
+	const uint32_t* fm_old = q.fm_prev + (size_t)chan * 16 - (size_t)(p.L - 512) / 32; // (indexed like fm_cur: word (L - 512) / 32 + l is word l of the previous block's last sixteen)
 	// sign of the filtered discriminator at sample k of the engine block that is being decoded (the block's sixteen words: LDS)
 	const auto fm_sign = [&](int k) -> int { return (int)((fmw[k >> 5] >> (k & 31)) & 1u); };
 	const auto emit = [&](const DecReg& r, long long sidx, float tag_ppm) {
@@ -3477,17 +3441,9 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void kv2_engine_t(KV2EParams q) {
 
 	for (int blk = 0; blk < p.n_windows; blk++) {
 		const int n0 = -V2_HIST + 512 * blk; // the decoded block; [n0 + 512, n0 + 1024) is the look-ahead
-		int split = 0;
-		uint32_t fmv = 0u; // SPLIT, FM wave: lane l < 16 holds word l of the block's discriminator signs
-		if (fm_wave) {
-			const int m0 = n0 < 0 ? n0 + p.L : n0;
-			if (lane < 16) fmv = (n0 < 0 ? fm_old : fm_cur)[(m0 >> 5) + lane];
-			if (lane < 18) fmw2[lane] = lane < 16 ? fmv : 0u; // (the hot loop reads its five signs from here, vector side; two words of padding)
-		} else {
-		V2P_T0();
 #pragma unroll
 		for (int i = 0; i < 8; i++) dero[16 + i * 64 + lane] = v2_sample(p, chan, n0 + i * 64 + lane);
-		if (!SPLIT && lane < 16) { // (n0 is a multiple of 512: whole words; block 0 decodes the previous device block's tail)
+		if (lane < 16) { // (n0 is a multiple of 512: whole words; block 0 decodes the previous device block's tail)
 			const int m0 = n0 < 0 ? n0 + p.L : n0;
 			fmw[lane] = (n0 < 0 ? fm_old : fm_cur)[(m0 >> 5) + lane];
 		}
@@ -3498,6 +3454,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void kv2_engine_t(KV2EParams q) {
 		const bool locked = slot_ema.x * slot_ema.x + slot_ema.y * slot_ema.y >= 0.64f;
 		const int e_slot = (int)((((long long)slot_phase - sample_idx) % 1280 + 1280) % 1280);
 		ppm_prev = ppm;
+		int split = 0;
 		float f = 0.0f;
 		if (locked && e_slot < 512) {
 			// a slot starts inside this block: [0, e) keeps the previous frequency, Estimate() works on the 512 samples from e on -- a window
@@ -3521,387 +3478,105 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void kv2_engine_t(KV2EParams q) {
 		ppm = __fdiv_rn(f * 48000.0f, 162.0f);
 		wave_sync();
 		// ---- FilterFL17 (:154-167) of the whole block: output k from carry + block samples k .. k + 16
-		// (SPLIT: tracker (di + k) % 5 takes sample k as its k / 5-th of the block: the sample is stored turned by that tracker's Rotate90,
-		// :175-188 -- swaps and sign changes, |z|^2 keeps its bits)
-		const int rots = SPLIT ? (__builtin_amdgcn_readlane((int)L.t.rot, 0) | (__builtin_amdgcn_readlane((int)L.t.rot, 1) << 2) | (__builtin_amdgcn_readlane((int)L.t.rot, 2) << 4) |
-		                          (__builtin_amdgcn_readlane((int)L.t.rot, 3) << 6) | (__builtin_amdgcn_readlane((int)L.t.rot, 4) << 8)) : 0;
 #pragma unroll
 		for (int i = 0; i < 8; i++) {
 			const c2 z = v2_dot17(&dero[i * 64 + lane], q.taps17);
-			if constexpr (SPLIT) {
-				const int k = i * 64 + lane;
-				const unsigned rot = (unsigned)((rots >> (2 * ((di + k) % 5))) + k / 5) & 3u;
-				const float sre = (rot & 1u) ? z.y : z.x, sim = (rot & 1u) ? z.x : z.y;
-				zb[k] = make_float2(((rot ^ (rot >> 1)) & 1u) ? -sre : sre, (rot & 2u) ? -sim : sim);
-			} else zb[i * 64 + lane] = make_float2(z.x, z.y);
+			zb[i * 64 + lane] = make_float2(z.x, z.y);
 		}
-		if (SPLIT && lane == 0) { sh_ppm[0] = ppm; sh_ppm[1] = ppm_prev; sh_split = split; }
 		wave_sync();
-		V2P_ADD(0);
-		}
-		if constexpr (!SPLIT) {
-			// ---- the 512 samples: tracker di handles sample i (di runs on across blocks), the FM decoder sees every sample through its PLL
-			const int off = j < 5 ? (j - di + 5) % 5 : 0; // this tracker's sample inside a group of five
-			// (a generic lambda: the 102 whole groups of a block are one straight-line body, the two samples behind them another instance)
-			const auto group = [&](const int g5, auto whole_group) {
-				constexpr bool WHOLE = decltype(whole_group)::value != 0;
-				const V2Lane before = L;
-				const int ng = WHOLE ? 5 : 512 - g5;
-				// The FM decoder's lane: its BitPLL (:225-242) over the group's samples.  The symbol of the first sample on which it fires goes
-				// through the decoder together with the trackers'; the samples behind that one see the PLL gain of the decoder's state AFTER
-				// that step in the reference.  Here all five run first, straight-line, with the gain of the state before the group: exact
-				// unless the step flips TRAINING <-> not-TRAINING AND a later sample of the group has a sign change (the only place the gain
-				// enters) -- then, as for a second symbol inside one group, the group is redone sample by sample below.
-				const unsigned fm5 = (unsigned)(((((unsigned long long)fmw[(g5 >> 5) + 1 < 16 ? (g5 >> 5) + 1 : 15]) << 32) | fmw[g5 >> 5]) >> (g5 & 31));
-				const bool tr0 = L.r.state == DST_TRAINING;
-				int k_pll = -1;
-				bool again = false, chg_after = false;
-				{
-					float ph = L.pll_phase;
-					int lastb = L.pll_last;
-					const float gain = tr0 ? 0.6f : 0.05f;
-	#pragma unroll
-					for (int s5 = 0; s5 < 5; s5++) {
-						if (s5 < ng) { // (wave-uniform: only a block's last group is short)
-							const int b = (int)((fm5 >> s5) & 1u);
-							const bool chg = b != lastb;
-							const float ph_c = ph + (0.5f - ph) * gain;
-							ph = chg ? ph_c : ph;
-							lastb = b;
-							ph += 0.2f;
-							const bool fire = !(ph < 1.0f);
-							const float ph_w = ph - (float)(int)ph;
-							ph = fire ? ph_w : ph;
-							chg_after = chg_after || (chg && k_pll >= 0);
-							again = again || (fire && k_pll >= 0);
-							k_pll = (fire && k_pll < 0) ? g5 + s5 : k_pll;
-						}
-					}
-					if (j == 5) { L.pll_phase = ph; L.pll_last = lastb; }
-				}
-				const int my_k = j == 5 ? k_pll : ((j < 5 && off < ng) ? g5 + off : -1);
-				const bool have = dl && my_k >= 0;
-				const int kk = have ? my_k : 0;
-				const float2 zf = zb[kk];
-				const c2 z = { zf.x, zf.y };
-				const int bit = j < 5 ? v2_track(L.t, z, tr0, q.w_train, q.w_track) : (int)((fm5 >> (kk - g5)) & 1u);
-				if (!have && j < 5) L.t = before.t;
-				const float slvl = z.x * z.x + z.y * z.y;
-				const long long sidx = sample_idx + kk;
-				// no decoder of the channel inside a frame: the step's TRAINING / STARTFLAG half is the whole step (it cannot complete a message)
-				const bool in_frame = __ballot(dl && L.r.state == DST_DATAFCS) != 0;
-				bool found = false;
-				if (in_frame) { if (have) found = dec_step(L.r, bit, slvl, sidx, data); }
-				else dec_step_idle(L.r, bit, sidx, have ? 1 : 0); // (every lane, no branch)
-				again = j == 5 && (again || (chg_after && (L.r.state == DST_TRAINING) != tr0));
-				// anything that breaks the lockstep -- a completed message (it resets the other five at ITS sample), or an FM decoder that
-				// clocks two symbols inside one group -- sends the channel through the reference's own order, sample by sample
-				if (__ballot(found || (again && dl)) != 0) {
-					L = before;
-					// (the frame buffers: a lane that is rolled back may have written a word of its column: dec_step rewrites what it needs)
-					for (int s5 = 0; s5 < ng; s5++) {
-						const int k5 = g5 + s5;
-						const float tag_ppm = k5 >= split ? ppm : ppm_prev;
-						const long long si = sample_idx + k5;
-						const float2 zq = zb[k5];
-						const c2 zz = { zq.x, zq.y };
-						const float lv = zz.x * zz.x + zz.y * zz.y;
-						bool fnd = false;
-						if (j < 5 && off == s5) {
-							const int b2 = v2_track(L.t, zz, L.r.state == DST_TRAINING, q.w_train, q.w_track);
-							fnd = dec_step(L.r, b2, lv, si, data);
-							if (fnd) emit(L.r, si, tag_ppm);
-						}
-						unsigned long long FF = __ballot(fnd);
-						if (FF != 0) { // learnSlotPhase(dec[di]) + resetDecoders()
-							const long long sidx0 = __shfl(L.r.start_idx, __builtin_ctzll(FF));
-							learn_slot(sidx0);
-							v2_reset(L.r);
-						}
-						fnd = false;
-						if (j == 5 && v2_pll(L.pll_phase, L.pll_last, fm_sign(k5), L.r.state == DST_TRAINING)) {
-							fnd = dec_step(L.r, fm_sign(k5), lv, si, data);
-							if (fnd) emit(L.r, si, tag_ppm);
-						}
-						FF = __ballot(fnd);
-						if (FF != 0) v2_reset(L.r);
-					}
-				}
-			};
+		// ---- the 512 samples: tracker di handles sample i (di runs on across blocks), the FM decoder sees every sample through its PLL
+		const int off = j < 5 ? (j - di + 5) % 5 : 0; // this tracker's sample inside a group of five
+		// (a generic lambda: the 102 whole groups of a block are one straight-line body, the two samples behind them another instance)
+		const auto group = [&](const int g5, auto whole_group) {
+			constexpr bool WHOLE = decltype(whole_group)::value != 0;
+			const V2Lane before = L;
+			const int ng = WHOLE ? 5 : 512 - g5;
+			// The FM decoder's lane: its BitPLL (:225-242) over the group's samples.  The symbol of the first sample on which it fires goes
+			// through the decoder together with the trackers'; the samples behind that one see the PLL gain of the decoder's state AFTER
+			// that step in the reference.  Here all five run first, straight-line, with the gain of the state before the group: exact
+			// unless the step flips TRAINING <-> not-TRAINING AND a later sample of the group has a sign change (the only place the gain
+			// enters) -- then, as for a second symbol inside one group, the group is redone sample by sample below.
+			const unsigned fm5 = (unsigned)(((((unsigned long long)fmw[(g5 >> 5) + 1 < 16 ? (g5 >> 5) + 1 : 15]) << 32) | fmw[g5 >> 5]) >> (g5 & 31));
+			const bool tr0 = L.r.state == DST_TRAINING;
+			int k_pll = -1;
+			bool again = false, chg_after = false;
 			{
-	#pragma unroll 1
-				for (int g5 = 0; g5 + 5 <= 512; g5 += 5) group(g5, K1Const<1>{});
-				group(510, K1Const<0>{}); // 512 = 102 x 5 + 2
-			}
-		} else {
-			{ V2P_T0(); __syncthreads(); V2P_ADD(1 + wave); } // the block's FilterFL17 outputs, ppm and split are there
-			const int off = (j - di + 5) % 5; // tracker wave: this lane's sample inside a group of five
-			const float ppm_b = sh_ppm[0], ppm_prev_b = sh_ppm[1];
-			const int split_b = sh_split;
-			// ---- tracker wave: samples [from, to) of the block, a group of five per turn, every lane its own sample of the group; stops
-			// behind the first group in which a decoder completed a message and returns that sample (512: none).  The decoder is the lean
-			// pair of dec_core.h; whole groups need no lane predicate and ask for their samples a turn ahead.
-			const auto first_of = [&](const unsigned long long F, const int g5) -> int { // the earliest sample of the group among the lanes of F
-				for (int o = 0; o < 4; o++) if ((F >> ((o + di) % 5)) & 1ull) return g5 + o;
-				return g5 + 4;
-			};
-			const auto coh_group = [&](const int g5, const int from, const int to, bool& fnd) -> int { // any group; -1: no message completed
-				const int my_k = g5 + off;
-				bool found = false;
-				if (dl && my_k >= from && my_k < to) {
-					const float2 zf = zb[my_k];
-					const int bit = v2_track_pre(L.t, zf.x, zf.y, L.r.state == DST_TRAINING, q.w_train, q.w_track);
-					if (L.r.state == DST_DATAFCS) found = dec_lean_data(L.r, bit, zf.x * zf.x + zf.y * zf.y, data, crctab);
-					else dec_lean_idle(L.r, bit, sample_idx + my_k);
-				}
-				const unsigned long long F = __ballot(found);
-				if (F == 0) return -1;
-				fnd = found;
-				return first_of(F, g5);
-			};
-			const auto coh_run = [&](const int from, const int to, bool& fnd) -> int {
-				fnd = false;
-				int g5 = from - from % 5;
-				if (g5 < from) {
-					const int kf = coh_group(g5, from, to, fnd);
-					if (kf >= 0) return kf;
-					g5 += 5;
-				}
-				if (g5 + 5 <= to) {
-					float2 zf = zb[dl ? g5 + off : 0];
-#pragma unroll 1
-					for (; g5 + 5 <= to; g5 += 5) {
-						const float2 zfn = zb[dl ? g5 + 5 + off : 0]; // (the next group's sample: the wave has nothing else to cover LDS latency with)
-						const int bit = v2_track_pre(L.t, zf.x, zf.y, L.r.state == DST_TRAINING, q.w_train, q.w_track);
-#ifdef V2_ABLW0
-						if (false) {
-#else
-						if (__ballot(dl && L.r.state == DST_DATAFCS) != 0) {
-#endif
-							bool found = false;
-							if (dl) {
-								if (L.r.state == DST_DATAFCS) found = dec_lean_data(L.r, bit, zf.x * zf.x + zf.y * zf.y, data, crctab);
-								else dec_lean_idle(L.r, bit, sample_idx + (g5 + off));
-							}
-							const unsigned long long F = __ballot(found);
-							if (F != 0) { fnd = found; return first_of(F, g5); }
-						} else dec_lean_idle(L.r, bit, sample_idx + (g5 + off)); // (every lane, no branch: lanes that are no decoder never reach a frame buffer)
-						zf = zfn;
-					}
-				}
-				if (g5 < to) {
-					const int kf = coh_group(g5, from, to, fnd);
-					if (kf >= 0) return kf;
-				}
-				return 512;
-			};
-			// ---- FM wave: BitPLL (:225-242) + decoder, one lane works (every decision is the wave's: scalar registers hold the discriminator's
-			// signs, the PLL's last bit and the decoder's TRAINING flag).  fm_exact: sample by sample in the reference's order.
-			const auto fm_exact = [&](const int from, const int to, float& ph, int& last_io, bool& fnd) -> int {
-				// (vector-side arithmetic like fm_run's turn; the only branch per sample is "the PLL fired")
-				int last = last_io;
-				asm volatile("" : "+v"(ph), "+v"(last));
-				uint32_t gainb = L.r.state == DST_TRAINING ? 0x3F19999Au : 0x3D4CCCCDu; // 0.6f : 0.05f
-				uint32_t wv = fmw2[from >> 5];
-				int kret = 512;
-#pragma unroll 1
-				for (int k = from; k < to; k++) {
-					if ((k & 31) == 0) wv = fmw2[k >> 5];
-					const int b = (int)((wv >> (k & 31)) & 1u);
-					const float gs = __uint_as_float(gainb & (uint32_t)(-(b ^ last)));
-					last = b;
-					ph = ph + (0.5f - ph) * gs;
-					ph = ph + 0.2f;
-					const float fl = __builtin_floorf(ph); // (1 <= phase < 1.2 where it fires: phase - (int)phase)
-					ph = ph - fl;
-					if (__ballot(fl != 0.0f) != 0) {
-						bool found = false;
-						if (__builtin_amdgcn_readfirstlane(L.r.state) == DST_DATAFCS) {
-							const float2 zq = zb[k];
-							found = dec_lean_data(L.r, b, zq.x * zq.x + zq.y * zq.y, data, crctab);
-						} else dec_lean_idle(L.r, b, sample_idx + k);
-						gainb = L.r.state == DST_TRAINING ? 0x3F19999Au : 0x3D4CCCCDu;
-						if (__builtin_amdgcn_readfirstlane((int)found) != 0) { fnd = found; kret = k; break; }
-					}
-				}
-				last_io = __builtin_amdgcn_readfirstlane(last);
-				return kret;
-			};
-			// fm_run: five samples per turn, straight-line, with the PLL gain of the decoder's state in front of the five (the gain only enters
-			// at a sign change); the decoder steps at the sample on which the PLL fires.  Exact when the PLL fires exactly once within the five
-			// and the step does not flip TRAINING <-> not-TRAINING in front of a later sign change of the five; everything else (3-8 % of the
-			// turns) goes through fm_exact.  A wave that is alone on its SIMD pays ~5 cycles per plain vector instruction, ~9 per compare or
-			// scalar instruction and 20-30 per hand-over between the two units (tools/microbench_issue.hip, W = 1): the turn is therefore
-			// written as integer / float arithmetic on vector registers -- masks instead of selects, floor() instead of a compare against 1,
-			// the fired positions summed as powers of two -- with ONE branch for all rare cases.
-			const auto fm_run = [&](const int from, const int to, bool& fnd) -> int {
-				fnd = false;
 				float ph = L.pll_phase;
-				int last = L.pll_last;
-				asm volatile("" : "+v"(ph), "+v"(last)); // (loaded through scalar registers: keep what follows on the vector side)
-				int k = from, kret = 512;
-				const auto window = [&](const int kk) -> unsigned long long { // the signs from sample kk & ~31 on (64 of them)
-					const uint32_t* w = fmw2 + (kk >> 5);
-					return ((unsigned long long)w[1] << 32) | w[0];
-				};
-				unsigned long long win = window(k);
-#ifdef V2_PROF_GRP
-				unsigned long long v2p_acc[3] = { 0, 0, 0 }; unsigned v2p_n[3] = { 0, 0, 0 };
-#endif
-#pragma unroll 1
-				for (; k + 5 <= to && kret == 512; k += 5) { // (one way in, one way round: the rare cases rejoin the turn's end)
-					const uint32_t b5 = (uint32_t)(win >> (k & 31)) & 31u;
-					win = window(k + 5 < 512 ? k + 5 : k); // (a turn ahead)
-					const uint32_t c5 = (b5 ^ ((b5 << 1) | (uint32_t)last)) & 31u; // sign changes
-					const int st0 = L.r.state;
-					const int m0 = st0 < 1 ? st0 : 1; // 0: TRAINING
-					const uint32_t gainb = st0 == DST_TRAINING ? 0x3F19999Au : 0x3D4CCCCDu; // 0.6f : 0.05f
-					float pq = ph, ff = 0.0f;
+				int lastb = L.pll_last;
+				const float gain = tr0 ? 0.6f : 0.05f;
 #pragma unroll
-					for (int s5 = 0; s5 < 5; s5++) {
-						const float gs = __uint_as_float(gainb & (uint32_t)__builtin_amdgcn_sbfe((int)c5, s5, 1)); // the gain at a sign change, 0.0f otherwise
-						pq = pq + (0.5f - pq) * gs;             // (x + 0 * y == x: no select)
-						pq = pq + 0.2f;
-						const float fl = __builtin_floorf(pq);  // 1.0f where it fires (1 <= phase < 1.2), else 0.0f
-						pq = pq - fl;                           // phase - (int)phase, exact
-						ff = __builtin_fmaf(fl, (float)(1 << s5), ff);
-					}
-					const uint32_t fires = (uint32_t)ff;
-					const int s1 = __builtin_ffs((int)fires) - 1; // first sample that fires (-1: none)
-					const int b1 = (int)((b5 >> (s1 & 31)) & 1u);
-					// ---- the decoder's step for a decoder in TRAINING / STARTFLAG, as arithmetic on 0 / 1 (dec_lean_idle)
-					const int pos = L.r.position;
-					const int Bit = (b1 ^ L.r.prev) ^ 1;
-					const int alt = Bit ^ L.r.lastBit;
-					const int gt4 = (int)((uint32_t)(4 - pos) >> 31);        // position > 4
-					const int at7 = (int)((uint32_t)((pos ^ 7) - 1) >> 31);  // position == 7
-					const int isT = m0 ^ 1;
-					const int to_flag = isT & (alt ^ 1) & gt4;
-					const int open = m0 & at7 & (Bit ^ 1);
-					const int more = m0 & (at7 ^ 1) & Bit;
-					const int grow = (isT & alt) | more;
-					const int n_pos = (grow ? pos + 1 : 0) + (to_flag ? 1 + 2 * Bit : 0);
-					const int n_state = (to_flag | more);   // (an opened frame is one of the rare cases below)
-					// ---- rare: no or several fires, a frame (entered, or being decoded), a flipped TRAINING flag in front of a later sign change
-					const uint32_t others = fires & (fires - 1u);
-					const uint32_t later = c5 >> ((s1 + 1) & 31);
-					const uint32_t rare = others | (uint32_t)(s1 >> 31) | (uint32_t)(st0 >> 1) | (uint32_t)open | ((uint32_t)(n_state ^ m0) & (later < 1u ? later : 1u));
-#ifdef V2_ABL
-					if (V2_ABL == 0 && __ballot(rare != 0u) != 0) {
-#else
-					if (__ballot(rare != 0u) != 0) { // (every lane alike)
-#endif
-						bool done = false;
-						V2P_G0();
-#ifdef V2_ABL
-						if (V2_ABL == 4) done = __builtin_amdgcn_readfirstlane(st0) == DST_DATAFCS; // (timing only: no in-frame path)
-						else if (V2_ABL == 3 && __builtin_amdgcn_readfirstlane(st0) != DST_DATAFCS) done = true; // (timing only: no exact path)
-						else
-#endif
-						if (__builtin_amdgcn_readfirstlane(st0) == DST_DATAFCS && __builtin_amdgcn_readfirstlane((int)(others | (uint32_t)(s1 >> 31))) == 0) {
-							// inside a frame, one fire: the gain is 0.05 whatever happens unless the frame ends here in front of a later sign change
-							const DecReg r0 = L.r;
-							const float2 zq = zb[k + s1];
-							const bool found = dec_lean_data(L.r, b1, zq.x * zq.x + zq.y * zq.y, data, crctab);
-							if (__builtin_amdgcn_readfirstlane((int)found) != 0) { fnd = found; kret = k + s1; done = true; } // (exact up to and including this step)
-							else if (__builtin_amdgcn_readfirstlane(L.r.state) == DST_DATAFCS || __builtin_amdgcn_readfirstlane((int)later) == 0) { ph = pq; last = (int)(b5 >> 4); done = true; }
-							else L.r = r0;
-							if (done) V2P_GACC(1);
-						}
-						if (!done) { // the reference's order, sample by sample (a frame buffer word dec_lean_data may have written is rewritten by it)
-							int last_s = __builtin_amdgcn_readfirstlane(last);
-							kret = fm_exact(k, k + 5, ph, last_s, fnd);
-							last = last_s;
-							asm volatile("" : "+v"(ph), "+v"(last));
-							V2P_GACC(2);
-						}
-					} else {
-#if !defined(V2_ABL) || V2_ABL < 2
-						const long long sidx = sample_idx + (k + s1);
-						L.r.start_idx = to_flag ? sidx : L.r.start_idx;
-						L.r.state = n_state; L.r.position = n_pos; L.r.lastBit = Bit; L.r.prev = b1;
-#endif
-						ph = pq; last = (int)(b5 >> 4);
+				for (int s5 = 0; s5 < 5; s5++) {
+					if (s5 < ng) { // (wave-uniform: only a block's last group is short)
+						const int b = (int)((fm5 >> s5) & 1u);
+						const bool chg = b != lastb;
+						const float ph_c = ph + (0.5f - ph) * gain;
+						ph = chg ? ph_c : ph;
+						lastb = b;
+						ph += 0.2f;
+						const bool fire = !(ph < 1.0f);
+						const float ph_w = ph - (float)(int)ph;
+						ph = fire ? ph_w : ph;
+						chg_after = chg_after || (chg && k_pll >= 0);
+						again = again || (fire && k_pll >= 0);
+						k_pll = (fire && k_pll < 0) ? g5 + s5 : k_pll;
 					}
 				}
-				V2P_GFLUSH();
-				if (kret != 512) k = to; // (stopped at a completed message)
-				int last_s = __builtin_amdgcn_readfirstlane(last);
-				if (kret == 512 && k < to) kret = fm_exact(k, to, ph, last_s, fnd);
-				L.pll_phase = ph; L.pll_last = last_s;
-				return kret;
-			};
-			uint32_t* const snapc = fsnap + (data - fdata);
-			V2Lane S = L;
-			bool snap_cols = false;
-			const auto snapshot = [&]() {
-				S = L;
-				snap_cols = __ballot(dl && L.r.state == DST_DATAFCS) != 0; // (a decoder that is not inside a frame has nothing in its buffer)
-				if (snap_cols && dl) for (int w = 0; w < DEC_DATA_WORDS; w++) snapc[64 * w] = data[64 * w];
-			};
-			const auto restore = [&]() {
-				L = S;
-				if (snap_cols && dl) for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = snapc[64 * w];
-			};
-			snapshot();
-			// the reference's order for samples [from, to), group by group / sample by sample (only behind a completed message)
-			const auto coh_slow = [&](const int from, const int to, bool& fnd) -> int {
-				fnd = false;
-#pragma unroll 1
-				for (int g5 = from - from % 5; g5 < to; g5 += 5) {
-					const int kf = coh_group(g5, from, to, fnd);
-					if (kf >= 0) return kf;
-				}
-				return 512;
-			};
-			const auto fm_slow = [&](const int from, const int to, bool& fnd) -> int {
-				fnd = false;
-				float ph = L.pll_phase;
-				int last = __builtin_amdgcn_readfirstlane(L.pll_last);
-				const int kf = fm_exact(from, to, ph, last, fnd);
-				L.pll_phase = ph; L.pll_last = last;
-				return kf;
-			};
-			int P = 0, xi = 0;
-#pragma unroll 1
-			for (;;) {
-				bool fnd = false;
-				int k;
-				{ V2P_T0(); k = fm_wave ? fm_run(P, 512, fnd) : coh_run(P, 512, fnd); V2P_ADD(3 + wave); }
-				// the speculative pass is through (or stopped at a completed message): who was first?
-				if (lane == 0) kx[xi & 1][wave] = k;
-				{ V2P_T0(); __syncthreads(); V2P_ADD(7 + wave); }
-				const int kc = __builtin_amdgcn_readfirstlane(kx[xi & 1][0]), kf = __builtin_amdgcn_readfirstlane(kx[xi & 1][1]);
-				xi++;
-				if (kc == 512 && kf == 512) break;
-				V2P_T0();
-				const bool coh_wins = kc <= kf; // (the same sample: the tracker's decoder runs first and resets the FM decoder in front of its step, :374-385)
-				const int kstar = coh_wins ? kc : kf;
-				restore();
-				const float tag_ppm = kstar >= split_b ? ppm_b : ppm_prev_b;
-				if (fm_wave) {
-					fm_slow(P, kstar, fnd); // exact up to k*: now sample k* itself
-					if (coh_wins) v2_reset(L.r);
-					fm_slow(kstar, kstar + 1, fnd);
-					if (!coh_wins) { if (lane == 0) emit(L.r, sample_idx + kstar, tag_ppm); v2_reset(L.r); }
-				} else {
-					coh_slow(P, kstar, fnd);
-					coh_slow(kstar, kstar + 1, fnd);
-					if (coh_wins) {
-						const unsigned long long FF = __ballot(fnd) | (1ull << 63); // (the lane that handled k*)
-						if (fnd) emit(L.r, sample_idx + kstar, tag_ppm);
+				if (j == 5) { L.pll_phase = ph; L.pll_last = lastb; }
+			}
+			const int my_k = j == 5 ? k_pll : ((j < 5 && off < ng) ? g5 + off : -1);
+			const bool have = dl && my_k >= 0;
+			const int kk = have ? my_k : 0;
+			const float2 zf = zb[kk];
+			const c2 z = { zf.x, zf.y };
+			const int bit = j < 5 ? v2_track(L.t, z, tr0, q.w_train, q.w_track) : (int)((fm5 >> (kk - g5)) & 1u);
+			if (!have && j < 5) L.t = before.t;
+			const float slvl = z.x * z.x + z.y * z.y;
+			const long long sidx = sample_idx + kk;
+			// no decoder of the channel inside a frame: the step's TRAINING / STARTFLAG half is the whole step (it cannot complete a message)
+			const bool in_frame = __ballot(dl && L.r.state == DST_DATAFCS) != 0;
+			bool found = false;
+			if (in_frame) { if (have) found = dec_step(L.r, bit, slvl, sidx, data); }
+			else dec_step_idle(L.r, bit, sidx, have ? 1 : 0); // (every lane, no branch)
+			again = j == 5 && (again || (chg_after && (L.r.state == DST_TRAINING) != tr0));
+			// anything that breaks the lockstep -- a completed message (it resets the other five at ITS sample), or an FM decoder that
+			// clocks two symbols inside one group -- sends the channel through the reference's own order, sample by sample
+			if (__ballot(found || (again && dl)) != 0) {
+				L = before;
+				// (the frame buffers: a lane that is rolled back may have written a word of its column: dec_step rewrites what it needs)
+				for (int s5 = 0; s5 < ng; s5++) {
+					const int k5 = g5 + s5;
+					const float tag_ppm = k5 >= split ? ppm : ppm_prev;
+					const long long si = sample_idx + k5;
+					const float2 zq = zb[k5];
+					const c2 zz = { zq.x, zq.y };
+					const float lv = zz.x * zz.x + zz.y * zz.y;
+					bool fnd = false;
+					if (j < 5 && off == s5) {
+						const int b2 = v2_track(L.t, zz, L.r.state == DST_TRAINING, q.w_train, q.w_track);
+						fnd = dec_step(L.r, b2, lv, si, data);
+						if (fnd) emit(L.r, si, tag_ppm);
+					}
+					unsigned long long FF = __ballot(fnd);
+					if (FF != 0) { // learnSlotPhase(dec[di]) + resetDecoders()
 						const long long sidx0 = __shfl(L.r.start_idx, __builtin_ctzll(FF));
 						learn_slot(sidx0);
+						v2_reset(L.r);
 					}
-					v2_reset(L.r);
+					fnd = false;
+					if (j == 5 && v2_pll(L.pll_phase, L.pll_last, fm_sign(k5), L.r.state == DST_TRAINING)) {
+						fnd = dec_step(L.r, fm_sign(k5), lv, si, data);
+						if (fnd) emit(L.r, si, tag_ppm);
+					}
+					FF = __ballot(fnd);
+					if (FF != 0) v2_reset(L.r);
 				}
-				P = kstar + 1;
-				snapshot();
-				V2P_ADD(5 + wave);
 			}
+		};
+		{
+#pragma unroll 1
+			for (int g5 = 0; g5 + 5 <= 512; g5 += 5) group(g5, K1Const<1>{});
+			group(510, K1Const<0>{}); // 512 = 102 x 5 + 2
 		}
-		if (fm_wave) { sample_idx += 512; continue; }
-		if (SPLIT && j < 5) L.t.rot = (L.t.rot + (unsigned)((512 - (j - di + 5) % 5 + 4) / 5)) & 3u; // Rotate90 calls of this tracker in the block
 		sample_idx += 512;
 		di = (di + 512) % 5;
 		wave_sync();
@@ -3916,10 +3591,9 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void kv2_engine_t(KV2EParams q) {
 		data[64 * r.cwi] = r.cw;
 		for (int w = 0; w < DEC_DATA_WORDS; w++) st->data[w] = data[64 * w];
 		st->crc[0] = r.crc; st->crc[1] = r.cw; st->crc[2] = (uint32_t)r.cwi; st->crc[3] = r.tail; st->crc[4] = (uint32_t)r.abort_pos;
-		if (j < 5 && !fm_wave) cs->trk[j] = L.t;
-		if (SPLIT ? fm_wave : j == 5) { cs->pll_phase = L.pll_phase; cs->pll_last = L.pll_last; }
+		if (j < 5) cs->trk[j] = L.t;
+		if (j == 5) { cs->pll_phase = L.pll_phase; cs->pll_last = L.pll_last; }
 	}
-	if (fm_wave) return;
 	if (lane == 0) {
 		cs->rot = rot; cs->last_f = last_f; cs->ppm = ppm; cs->ppm_prev = ppm_prev; cs->slot_ema = slot_ema; cs->slot_phase = slot_phase;
 		cs->di = di; cs->sample_idx = sample_idx;
@@ -3939,8 +3613,11 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void kv2_engine_t(KV2EParams q) {
 //    which only a completed message moves: the wave prepares the block for both answers where they differ (two frequencies ->
 //    two derotated, filtered, pre-rotated blocks in LDS), and the right one is picked when the decoders arrive.  A message completed by
 //    a tracker's decoder in between (learnSlotPhase) voids the preparation: the block is prepared again, in the open.
-// Waves 0 and 1 speculate that nobody completes a message inside a block and restore the reference's order where one does (see
-// kv2_engine_t<true>, the two-wave form this kernel grew out of).  Everything is the reference's arithmetic in the reference's order.
+// Waves 0 and 1 speculate that nobody completes a message inside a block: a wave that does complete one stops there, the waves exchange
+// the positions at the end of the block, and where there is one, both restore the state they had at the last agreed position, run up to
+// the earliest completion k* exactly, handle sample k* in the reference's order (the tracker's decoder first: message out,
+// learnSlotPhase, all six reset; then the FM decoder), and speculate on from k* + 1.  Completed messages leave the kernel only from
+// that exact pass.  Everything is the reference's arithmetic in the reference's order.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64]; // [word][column]: columns 0..4 the trackers' decoders, 5 the FM decoder
@@ -4188,9 +3865,6 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 	for (int blk = 0; blk < p.n_windows; blk++) {
 		const int n0 = -V2_HIST + 512 * blk;
 		const float2* const zb = zbuf[cur];
-#ifdef V2_PROF
-		const unsigned long long v2p_blk0 = __builtin_readcyclecounter();
-#endif
 		int learned = 0; // wave 0: a tracker's decoder completed a message in this block (the slot predictor moved)
 		{
 			if (fm_wave) {
@@ -4201,258 +3875,258 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 			const int off = (j - di + 5) % 5; // tracker wave: this lane's sample inside a group of five
 			const float ppm_b = sh_ppm[cur], ppm_prev_b = sh_ppm_prev[cur];
 			const int split_b = sh_split[cur];
-		// ---- tracker wave: samples [from, to) of the block, a group of five per turn, every lane its own sample of the group; stops
-		// behind the first group in which a decoder completed a message and returns that sample (512: none).  The decoder is the lean
-		// pair of dec_core.h; whole groups need no lane predicate and ask for their samples a turn ahead.
-		const auto first_of = [&](const unsigned long long F, const int g5) -> int { // the earliest sample of the group among the lanes of F
-			for (int o = 0; o < 4; o++) if ((F >> ((o + di) % 5)) & 1ull) return g5 + o;
-			return g5 + 4;
-		};
-		const auto coh_group = [&](const int g5, const int from, const int to, bool& fnd) -> int { // any group; -1: no message completed
-			const int my_k = g5 + off;
-			bool found = false;
-			if (dl && my_k >= from && my_k < to) {
-				const float2 zf = zb[my_k];
-				const int bit = v2_track_pre(L.t, zf.x, zf.y, L.r.state == DST_TRAINING, q.w_train, q.w_track);
-				if (L.r.state == DST_DATAFCS) found = dec_lean_data(L.r, bit, zf.x * zf.x + zf.y * zf.y, data, crctab);
-				else dec_lean_idle(L.r, bit, sample_idx + my_k);
-			}
-			const unsigned long long F = __ballot(found);
-			if (F == 0) return -1;
-			fnd = found;
-			return first_of(F, g5);
-		};
-		// dec_lean_idle as arithmetic on 0 / 1: m = 0 in TRAINING, 1 in STARTFLAG; the step's new state (0 / 1; `open`: it opened a frame instead)
-		struct IdleStep { int state, pos, Bit, to_flag, open; };
-		const auto idle_arith = [&](const int m, const int pos, const int lastBit, const int prev, const int b) -> IdleStep {
-			const int Bit = (b ^ prev) ^ 1;
-			const int alt = Bit ^ lastBit;
-			const int gt4 = (int)((uint32_t)(4 - pos) >> 31);        // position > 4
-			const int at7 = (int)((uint32_t)((pos ^ 7) - 1) >> 31);  // position == 7
-			const int isT = m ^ 1;
-			const int to_flag = isT & (alt ^ 1) & gt4;
-			const int open = m & at7 & (Bit ^ 1);
-			const int more = m & (at7 ^ 1) & Bit;
-			const int grow = (isT & alt) | more;
-			return IdleStep{ to_flag | more, (grow ? pos + 1 : 0) + (to_flag ? 1 + 2 * Bit : 0), Bit, to_flag, open };
-		};
-		const auto next_event_of = [&](const DecReg& r) -> int { // the next position at which a frame's step is not its common case
-			return r.position < 30 ? 30 : r.position < 62 ? 62 : (r.abort_pos > r.position ? r.abort_pos : DEC_MAX_FRAME);
-		};
-		// whole groups: both decoder steps -- TRAINING / STARTFLAG (idle_arith) and DATAFCS (dec_lean_data's common case) -- as arithmetic on
-		// vector registers, chosen per lane; a lane whose symbol is one of the rare ones (a frame opens; closing flag, look-ups at positions
-		// 30 / 62, the type's own limit, the maximum length) takes the lean pair's own code for that symbol
-		const auto coh_run = [&](const int from, const int to, bool& fnd) -> int {
-			fnd = false;
-			int g5 = from - from % 5;
-			if (g5 < from) {
-				const int kf = coh_group(g5, from, to, fnd);
-				if (kf >= 0) return kf;
-				g5 += 5;
-			}
-			if (g5 + 5 <= to) {
-				float2 zf = zb[dl ? g5 + off : 0];
-				int next_ev = next_event_of(L.r);
+			// ---- tracker wave: samples [from, to) of the block, a group of five per turn, every lane its own sample of the group; stops
+			// behind the first group in which a decoder completed a message and returns that sample (512: none).  The decoder is the lean
+			// pair of dec_core.h; whole groups need no lane predicate and ask for their samples a turn ahead.
+			const auto first_of = [&](const unsigned long long F, const int g5) -> int { // the earliest sample of the group among the lanes of F
+				for (int o = 0; o < 4; o++) if ((F >> ((o + di) % 5)) & 1ull) return g5 + o;
+				return g5 + 4;
+			};
+			const auto coh_group = [&](const int g5, const int from, const int to, bool& fnd) -> int { // any group; -1: no message completed
+				const int my_k = g5 + off;
+				bool found = false;
+				if (dl && my_k >= from && my_k < to) {
+					const float2 zf = zb[my_k];
+					const int bit = v2_track_pre(L.t, zf.x, zf.y, L.r.state == DST_TRAINING, q.w_train, q.w_track);
+					if (L.r.state == DST_DATAFCS) found = dec_lean_data(L.r, bit, zf.x * zf.x + zf.y * zf.y, data, crctab);
+					else dec_lean_idle(L.r, bit, sample_idx + my_k);
+				}
+				const unsigned long long F = __ballot(found);
+				if (F == 0) return -1;
+				fnd = found;
+				return first_of(F, g5);
+			};
+			// dec_lean_idle as arithmetic on 0 / 1: m = 0 in TRAINING, 1 in STARTFLAG; the step's new state (0 / 1; `open`: it opened a frame instead)
+			struct IdleStep { int state, pos, Bit, to_flag, open; };
+			const auto idle_arith = [&](const int m, const int pos, const int lastBit, const int prev, const int b) -> IdleStep {
+				const int Bit = (b ^ prev) ^ 1;
+				const int alt = Bit ^ lastBit;
+				const int gt4 = (int)((uint32_t)(4 - pos) >> 31);        // position > 4
+				const int at7 = (int)((uint32_t)((pos ^ 7) - 1) >> 31);  // position == 7
+				const int isT = m ^ 1;
+				const int to_flag = isT & (alt ^ 1) & gt4;
+				const int open = m & at7 & (Bit ^ 1);
+				const int more = m & (at7 ^ 1) & Bit;
+				const int grow = (isT & alt) | more;
+				return IdleStep{ to_flag | more, (grow ? pos + 1 : 0) + (to_flag ? 1 + 2 * Bit : 0), Bit, to_flag, open };
+			};
+			const auto next_event_of = [&](const DecReg& r) -> int { // the next position at which a frame's step is not its common case
+				return r.position < 30 ? 30 : r.position < 62 ? 62 : (r.abort_pos > r.position ? r.abort_pos : DEC_MAX_FRAME);
+			};
+			// whole groups: both decoder steps -- TRAINING / STARTFLAG (idle_arith) and DATAFCS (dec_lean_data's common case) -- as arithmetic on
+			// vector registers, chosen per lane; a lane whose symbol is one of the rare ones (a frame opens; closing flag, look-ups at positions
+			// 30 / 62, the type's own limit, the maximum length) takes the lean pair's own code for that symbol
+			const auto coh_run = [&](const int from, const int to, bool& fnd) -> int {
+				fnd = false;
+				int g5 = from - from % 5;
+				if (g5 < from) {
+					const int kf = coh_group(g5, from, to, fnd);
+					if (kf >= 0) return kf;
+					g5 += 5;
+				}
+				if (g5 + 5 <= to) {
+					float2 zf = zb[dl ? g5 + off : 0];
+					int next_ev = next_event_of(L.r);
 #pragma unroll 1
-				for (; g5 + 5 <= to; g5 += 5) {
-					const float2 zfn = zb[dl ? g5 + 5 + off : 0]; // (the next group's sample: the wave has nothing else to cover LDS latency with)
+					for (; g5 + 5 <= to; g5 += 5) {
+						const float2 zfn = zb[dl ? g5 + 5 + off : 0]; // (the next group's sample: the wave has nothing else to cover LDS latency with)
+						const int st0 = L.r.state;
+						const int bit = v2_track_pre(L.t, zf.x, zf.y, st0 == DST_TRAINING, q.w_train, q.w_track);
+						const int m0 = st0 < 1 ? st0 : 1, isD = st0 >> 1;
+						const int pos = L.r.position;
+						const IdleStep o = idle_arith(m0, pos, L.r.lastBit, L.r.prev, bit);
+						const long long sidx = sample_idx + (g5 + off);
+						if (__ballot(dl && (isD | o.open) != 0) == 0) { // nobody inside a frame, nobody opens one (every lane, no branch)
+							L.r.start_idx = o.to_flag ? sidx : L.r.start_idx;
+							L.r.state = o.state; L.r.position = o.pos; L.r.lastBit = o.Bit; L.r.prev = bit;
+						} else {
+							const int osc = L.r.osc;
+							const int six = (int)((uint32_t)((osc ^ 5) - 1) >> 31); // five ones so far
+							const int close = six & o.Bit, stuffed = six & (o.Bit ^ 1);
+							const int np = pos + 1 - stuffed;
+							const int nw = (pos >> 5) - L.r.cwi; // 1: the position has moved on to the next word
+							const uint32_t sh = (uint32_t)pos & 31u;
+							const uint32_t cw = ((L.r.cw & (uint32_t)(nw - 1)) & ~(1u << sh)) | ((uint32_t)o.Bit << sh);
+							const int ev = (int)((uint32_t)((np ^ next_ev) - 1) >> 31); // position == next_ev
+							const bool D = isD != 0;
+							const bool special = dl && (D ? (close | ev) != 0 : o.open != 0);
+							const bool fr = D && !special && dl, id = !D && !special;
+							if (fr) data[DEC_LANES * L.r.cwi] = L.r.cw; // (the word that is being filled, complete when the position moves on)
+							const float slvl = zf.x * zf.x + zf.y * zf.y;
+							bool found = false;
+							if (__ballot(special) != 0) {
+								if (special) {
+									if (D) found = dec_lean_data(L.r, bit, slvl, data, crctab);
+									else dec_lean_idle(L.r, bit, sidx);
+									next_ev = next_event_of(L.r);
+								}
+							}
+							L.r.level = fr ? L.r.level + slvl : L.r.level;
+							L.r.cw = fr ? cw : L.r.cw; L.r.cwi = fr ? L.r.cwi + nw : L.r.cwi; L.r.osc = fr ? ((osc + 1) & (0 - o.Bit)) : L.r.osc;
+							L.r.start_idx = (id && o.to_flag) ? sidx : L.r.start_idx;
+							L.r.state = id ? o.state : L.r.state; L.r.position = fr ? np : (id ? o.pos : L.r.position);
+							L.r.lastBit = special ? L.r.lastBit : o.Bit; L.r.prev = special ? L.r.prev : bit;
+							const unsigned long long F = __ballot(found);
+							if (F != 0) { fnd = found; return first_of(F, g5); }
+						}
+						zf = zfn;
+					}
+				}
+				if (g5 < to) {
+					const int kf = coh_group(g5, from, to, fnd);
+					if (kf >= 0) return kf;
+				}
+				return 512;
+			};
+			// ---- FM wave: BitPLL (:225-242) + decoder, one lane works (every decision is the wave's: scalar registers hold the discriminator's
+			// signs, the PLL's last bit and the decoder's TRAINING flag).  fm_exact: sample by sample in the reference's order.
+			const auto fm_exact = [&](const int from, const int to, float& ph, int& last_io, bool& fnd) -> int {
+				// (vector-side arithmetic like fm_run's turn; the only branch per sample is "the PLL fired")
+				int last = last_io;
+				asm volatile("" : "+v"(ph), "+v"(last));
+				uint32_t gainb = L.r.state == DST_TRAINING ? 0x3F19999Au : 0x3D4CCCCDu; // 0.6f : 0.05f
+				uint32_t wv = fmw2[from >> 5];
+				int kret = 512;
+#pragma unroll 1
+				for (int k = from; k < to; k++) {
+					if ((k & 31) == 0) wv = fmw2[k >> 5];
+					const int b = (int)((wv >> (k & 31)) & 1u);
+					const float gs = __uint_as_float(gainb & (uint32_t)(-(b ^ last)));
+					last = b;
+					ph = ph + (0.5f - ph) * gs;
+					ph = ph + 0.2f;
+					const float fl = __builtin_floorf(ph); // (1 <= phase < 1.2 where it fires: phase - (int)phase)
+					ph = ph - fl;
+					if (__ballot(fl != 0.0f) != 0) {
+						bool found = false;
+						if (__builtin_amdgcn_readfirstlane(L.r.state) == DST_DATAFCS) {
+							const float2 zq = zb[k];
+							found = dec_lean_data(L.r, b, zq.x * zq.x + zq.y * zq.y, data, crctab);
+						} else dec_lean_idle(L.r, b, sample_idx + k);
+						gainb = L.r.state == DST_TRAINING ? 0x3F19999Au : 0x3D4CCCCDu;
+						if (__builtin_amdgcn_readfirstlane((int)found) != 0) { fnd = found; kret = k; break; }
+					}
+				}
+				last_io = __builtin_amdgcn_readfirstlane(last);
+				return kret;
+			};
+			// fm_run: five samples per turn, straight-line, with the PLL gain of the decoder's state in front of the five (the gain only enters
+			// at a sign change); the decoder steps at the sample on which the PLL fires.  Exact when the PLL fires exactly once within the five
+			// and the step does not flip TRAINING <-> not-TRAINING in front of a later sign change of the five; everything else (3-8 % of the
+			// turns) goes through fm_exact.  A wave that is alone on its SIMD pays ~5 cycles per plain vector instruction, ~9 per compare or
+			// scalar instruction and 20-30 per hand-over between the two units (tools/microbench_issue.hip, W = 1): the turn is therefore
+			// written as integer / float arithmetic on vector registers -- masks instead of selects, floor() instead of a compare against 1,
+			// the fired positions summed as powers of two -- with ONE branch for all rare cases.
+			const auto fm_run = [&](const int from, const int to, bool& fnd) -> int {
+				fnd = false;
+				float ph = L.pll_phase;
+				int last = L.pll_last;
+				asm volatile("" : "+v"(ph), "+v"(last)); // (loaded through scalar registers: keep what follows on the vector side)
+				int k = from, kret = 512;
+				const auto window = [&](const int kk) -> unsigned long long { // the signs from sample kk & ~31 on (64 of them)
+					const uint32_t* w = fmw2 + (kk >> 5);
+					return ((unsigned long long)w[1] << 32) | w[0];
+				};
+				unsigned long long win = window(k);
+				// inside a frame the turn's decoder step is dec_lean_data's common case as arithmetic; the frame's rare symbols -- closing flag, the
+				// look-ups at positions 30 / 62, the type's own limit, the maximum length: the next of them is `next_ev` -- go through fm_exact
+				bool inframe = __builtin_amdgcn_readfirstlane(L.r.state) == DST_DATAFCS; // (scalar: changes only in the rare branch)
+				const auto next_event = [&]() -> int {
+					const int ps = L.r.position, ap = L.r.abort_pos;
+					return ps < 30 ? 30 : ps < 62 ? 62 : (ap > ps ? ap : DEC_MAX_FRAME);
+				};
+				int next_ev = next_event();
+#pragma unroll 1
+				for (; k + 5 <= to && kret == 512; k += 5) { // (one way in, one way round: the rare cases rejoin the turn's end)
+					const uint32_t b5 = (uint32_t)(win >> (k & 31)) & 31u;
+					win = window(k + 5 < 512 ? k + 5 : k); // (a turn ahead)
+					const uint32_t c5 = (b5 ^ ((b5 << 1) | (uint32_t)last)) & 31u; // sign changes
 					const int st0 = L.r.state;
-					const int bit = v2_track_pre(L.t, zf.x, zf.y, st0 == DST_TRAINING, q.w_train, q.w_track);
-					const int m0 = st0 < 1 ? st0 : 1, isD = st0 >> 1;
+					const int m0 = st0 < 1 ? st0 : 1; // 0: TRAINING
+					const uint32_t gainb = st0 == DST_TRAINING ? 0x3F19999Au : 0x3D4CCCCDu; // 0.6f : 0.05f
+					float pq = ph, ff = 0.0f;
+#pragma unroll
+					for (int s5 = 0; s5 < 5; s5++) {
+						const float gs = __uint_as_float(gainb & (uint32_t)__builtin_amdgcn_sbfe((int)c5, s5, 1)); // the gain at a sign change, 0.0f otherwise
+						pq = pq + (0.5f - pq) * gs;             // (x + 0 * y == x: no select)
+						pq = pq + 0.2f;
+						const float fl = __builtin_floorf(pq);  // 1.0f where it fires (1 <= phase < 1.2), else 0.0f
+						pq = __builtin_amdgcn_fractf(pq);       // phase - (int)phase: x - floor(x), exact on [0, 2) (off the chain: floor() only feeds the fired positions)
+						ff = __builtin_fmaf(fl, (float)(1 << s5), ff);
+					}
+					const uint32_t fires = (uint32_t)ff;
+					const int s1 = __builtin_ffs((int)fires) - 1; // first sample that fires (-1: none)
+					const int b1 = (int)((b5 >> (s1 & 31)) & 1u);
+					const uint32_t not_one = (fires & (fires - 1u)) | (uint32_t)(s1 >> 31); // no fire, or several
 					const int pos = L.r.position;
-					const IdleStep o = idle_arith(m0, pos, L.r.lastBit, L.r.prev, bit);
-					const long long sidx = sample_idx + (g5 + off);
-					if (__ballot(dl && (isD | o.open) != 0) == 0) { // nobody inside a frame, nobody opens one (every lane, no branch)
-						L.r.start_idx = o.to_flag ? sidx : L.r.start_idx;
-						L.r.state = o.state; L.r.position = o.pos; L.r.lastBit = o.Bit; L.r.prev = bit;
-					} else {
+					const int Bit = (b1 ^ L.r.prev) ^ 1;
+					bool rare;
+					if (inframe) {
+						// ---- dec_lean_data's common case: store the bit, count ones, skip a stuffed zero, add the level
 						const int osc = L.r.osc;
 						const int six = (int)((uint32_t)((osc ^ 5) - 1) >> 31); // five ones so far
-						const int close = six & o.Bit, stuffed = six & (o.Bit ^ 1);
+						const int close = six & Bit, stuffed = six & (Bit ^ 1);
 						const int np = pos + 1 - stuffed;
 						const int nw = (pos >> 5) - L.r.cwi; // 1: the position has moved on to the next word
+						data[DEC_LANES * L.r.cwi] = L.r.cw;  // (every turn: the word that is being filled, complete when the position moves on)
 						const uint32_t sh = (uint32_t)pos & 31u;
-						const uint32_t cw = ((L.r.cw & (uint32_t)(nw - 1)) & ~(1u << sh)) | ((uint32_t)o.Bit << sh);
-						const int ev = (int)((uint32_t)((np ^ next_ev) - 1) >> 31); // position == next_ev
-						const bool D = isD != 0;
-						const bool special = dl && (D ? (close | ev) != 0 : o.open != 0);
-						const bool fr = D && !special && dl, id = !D && !special;
-						if (fr) data[DEC_LANES * L.r.cwi] = L.r.cw; // (the word that is being filled, complete when the position moves on)
-						const float slvl = zf.x * zf.x + zf.y * zf.y;
-						bool found = false;
-						if (__ballot(special) != 0) {
-							if (special) {
-								if (D) found = dec_lean_data(L.r, bit, slvl, data, crctab);
-								else dec_lean_idle(L.r, bit, sidx);
-								next_ev = next_event_of(L.r);
-							}
+						const uint32_t cw = ((L.r.cw & (uint32_t)(nw - 1)) & ~(1u << sh)) | ((uint32_t)Bit << sh);
+						const float2 zq = zb[(k + s1) & 511];
+						const uint32_t ev = (uint32_t)((np ^ next_ev) - 1) >> 31; // position == next_ev
+						rare = __ballot((not_one | (uint32_t)close | ev) != 0u) != 0;
+						if (!rare) {
+							L.r.level = L.r.level + (zq.x * zq.x + zq.y * zq.y);
+							L.r.cw = cw; L.r.cwi = L.r.cwi + nw; L.r.position = np; L.r.osc = (osc + 1) & (0 - Bit);
+							L.r.lastBit = Bit; L.r.prev = b1;
+							ph = pq; last = (int)(b5 >> 4);
 						}
-						L.r.level = fr ? L.r.level + slvl : L.r.level;
-						L.r.cw = fr ? cw : L.r.cw; L.r.cwi = fr ? L.r.cwi + nw : L.r.cwi; L.r.osc = fr ? ((osc + 1) & (0 - o.Bit)) : L.r.osc;
-						L.r.start_idx = (id && o.to_flag) ? sidx : L.r.start_idx;
-						L.r.state = id ? o.state : L.r.state; L.r.position = fr ? np : (id ? o.pos : L.r.position);
-						L.r.lastBit = special ? L.r.lastBit : o.Bit; L.r.prev = special ? L.r.prev : bit;
-						const unsigned long long F = __ballot(found);
-						if (F != 0) { fnd = found; return first_of(F, g5); }
-					}
-					zf = zfn;
-				}
-			}
-			if (g5 < to) {
-				const int kf = coh_group(g5, from, to, fnd);
-				if (kf >= 0) return kf;
-			}
-			return 512;
-		};
-		// ---- FM wave: BitPLL (:225-242) + decoder, one lane works (every decision is the wave's: scalar registers hold the discriminator's
-		// signs, the PLL's last bit and the decoder's TRAINING flag).  fm_exact: sample by sample in the reference's order.
-		const auto fm_exact = [&](const int from, const int to, float& ph, int& last_io, bool& fnd) -> int {
-			// (vector-side arithmetic like fm_run's turn; the only branch per sample is "the PLL fired")
-			int last = last_io;
-			asm volatile("" : "+v"(ph), "+v"(last));
-			uint32_t gainb = L.r.state == DST_TRAINING ? 0x3F19999Au : 0x3D4CCCCDu; // 0.6f : 0.05f
-			uint32_t wv = fmw2[from >> 5];
-			int kret = 512;
-#pragma unroll 1
-			for (int k = from; k < to; k++) {
-				if ((k & 31) == 0) wv = fmw2[k >> 5];
-				const int b = (int)((wv >> (k & 31)) & 1u);
-				const float gs = __uint_as_float(gainb & (uint32_t)(-(b ^ last)));
-				last = b;
-				ph = ph + (0.5f - ph) * gs;
-				ph = ph + 0.2f;
-				const float fl = __builtin_floorf(ph); // (1 <= phase < 1.2 where it fires: phase - (int)phase)
-				ph = ph - fl;
-				if (__ballot(fl != 0.0f) != 0) {
-					bool found = false;
-					if (__builtin_amdgcn_readfirstlane(L.r.state) == DST_DATAFCS) {
-						const float2 zq = zb[k];
-						found = dec_lean_data(L.r, b, zq.x * zq.x + zq.y * zq.y, data, crctab);
-					} else dec_lean_idle(L.r, b, sample_idx + k);
-					gainb = L.r.state == DST_TRAINING ? 0x3F19999Au : 0x3D4CCCCDu;
-					if (__builtin_amdgcn_readfirstlane((int)found) != 0) { fnd = found; kret = k; break; }
-				}
-			}
-			last_io = __builtin_amdgcn_readfirstlane(last);
-			return kret;
-		};
-		// fm_run: five samples per turn, straight-line, with the PLL gain of the decoder's state in front of the five (the gain only enters
-		// at a sign change); the decoder steps at the sample on which the PLL fires.  Exact when the PLL fires exactly once within the five
-		// and the step does not flip TRAINING <-> not-TRAINING in front of a later sign change of the five; everything else (3-8 % of the
-		// turns) goes through fm_exact.  A wave that is alone on its SIMD pays ~5 cycles per plain vector instruction, ~9 per compare or
-		// scalar instruction and 20-30 per hand-over between the two units (tools/microbench_issue.hip, W = 1): the turn is therefore
-		// written as integer / float arithmetic on vector registers -- masks instead of selects, floor() instead of a compare against 1,
-		// the fired positions summed as powers of two -- with ONE branch for all rare cases.
-		const auto fm_run = [&](const int from, const int to, bool& fnd) -> int {
-			fnd = false;
-			float ph = L.pll_phase;
-			int last = L.pll_last;
-			asm volatile("" : "+v"(ph), "+v"(last)); // (loaded through scalar registers: keep what follows on the vector side)
-			int k = from, kret = 512;
-			const auto window = [&](const int kk) -> unsigned long long { // the signs from sample kk & ~31 on (64 of them)
-				const uint32_t* w = fmw2 + (kk >> 5);
-				return ((unsigned long long)w[1] << 32) | w[0];
-			};
-			unsigned long long win = window(k);
-			// inside a frame the turn's decoder step is dec_lean_data's common case as arithmetic; the frame's rare symbols -- closing flag, the
-			// look-ups at positions 30 / 62, the type's own limit, the maximum length: the next of them is `next_ev` -- go through fm_exact
-			bool inframe = __builtin_amdgcn_readfirstlane(L.r.state) == DST_DATAFCS; // (scalar: changes only in the rare branch)
-			const auto next_event = [&]() -> int {
-				const int ps = L.r.position, ap = L.r.abort_pos;
-				return ps < 30 ? 30 : ps < 62 ? 62 : (ap > ps ? ap : DEC_MAX_FRAME);
-			};
-			int next_ev = next_event();
-#pragma unroll 1
-			for (; k + 5 <= to && kret == 512; k += 5) { // (one way in, one way round: the rare cases rejoin the turn's end)
-				const uint32_t b5 = (uint32_t)(win >> (k & 31)) & 31u;
-				win = window(k + 5 < 512 ? k + 5 : k); // (a turn ahead)
-				const uint32_t c5 = (b5 ^ ((b5 << 1) | (uint32_t)last)) & 31u; // sign changes
-				const int st0 = L.r.state;
-				const int m0 = st0 < 1 ? st0 : 1; // 0: TRAINING
-				const uint32_t gainb = st0 == DST_TRAINING ? 0x3F19999Au : 0x3D4CCCCDu; // 0.6f : 0.05f
-				float pq = ph, ff = 0.0f;
-#pragma unroll
-				for (int s5 = 0; s5 < 5; s5++) {
-					const float gs = __uint_as_float(gainb & (uint32_t)__builtin_amdgcn_sbfe((int)c5, s5, 1)); // the gain at a sign change, 0.0f otherwise
-					pq = pq + (0.5f - pq) * gs;             // (x + 0 * y == x: no select)
-					pq = pq + 0.2f;
-					const float fl = __builtin_floorf(pq);  // 1.0f where it fires (1 <= phase < 1.2), else 0.0f
-					pq = __builtin_amdgcn_fractf(pq);       // phase - (int)phase: x - floor(x), exact on [0, 2) (off the chain: floor() only feeds the fired positions)
-					ff = __builtin_fmaf(fl, (float)(1 << s5), ff);
-				}
-				const uint32_t fires = (uint32_t)ff;
-				const int s1 = __builtin_ffs((int)fires) - 1; // first sample that fires (-1: none)
-				const int b1 = (int)((b5 >> (s1 & 31)) & 1u);
-				const uint32_t not_one = (fires & (fires - 1u)) | (uint32_t)(s1 >> 31); // no fire, or several
-				const int pos = L.r.position;
-				const int Bit = (b1 ^ L.r.prev) ^ 1;
-				bool rare;
-				if (inframe) {
-					// ---- dec_lean_data's common case: store the bit, count ones, skip a stuffed zero, add the level
-					const int osc = L.r.osc;
-					const int six = (int)((uint32_t)((osc ^ 5) - 1) >> 31); // five ones so far
-					const int close = six & Bit, stuffed = six & (Bit ^ 1);
-					const int np = pos + 1 - stuffed;
-					const int nw = (pos >> 5) - L.r.cwi; // 1: the position has moved on to the next word
-					data[DEC_LANES * L.r.cwi] = L.r.cw;  // (every turn: the word that is being filled, complete when the position moves on)
-					const uint32_t sh = (uint32_t)pos & 31u;
-					const uint32_t cw = ((L.r.cw & (uint32_t)(nw - 1)) & ~(1u << sh)) | ((uint32_t)Bit << sh);
-					const float2 zq = zb[(k + s1) & 511];
-					const uint32_t ev = (uint32_t)((np ^ next_ev) - 1) >> 31; // position == next_ev
-					rare = __ballot((not_one | (uint32_t)close | ev) != 0u) != 0;
-					if (!rare) {
-						L.r.level = L.r.level + (zq.x * zq.x + zq.y * zq.y);
-						L.r.cw = cw; L.r.cwi = L.r.cwi + nw; L.r.position = np; L.r.osc = (osc + 1) & (0 - Bit);
-						L.r.lastBit = Bit; L.r.prev = b1;
-						ph = pq; last = (int)(b5 >> 4);
-					}
-				} else {
-					// ---- the decoder's step for a decoder in TRAINING / STARTFLAG, as arithmetic on 0 / 1 (dec_lean_idle)
-					const IdleStep o1 = idle_arith(m0, pos, L.r.lastBit, L.r.prev, b1);
-					// rare: no or several fires, a frame opens, a flipped TRAINING flag in front of a later sign change
-					const uint32_t later = c5 >> ((s1 + 1) & 31);
-					const uint32_t bad1 = (uint32_t)o1.open | ((uint32_t)(o1.state ^ m0) & (later < 1u ? later : 1u));
-					rare = __ballot((not_one | bad1) != 0u) != 0;
-					if (!rare) {
-						const long long sidx = sample_idx + (k + s1);
-						L.r.start_idx = o1.to_flag ? sidx : L.r.start_idx;
-						L.r.state = o1.state; L.r.position = o1.pos; L.r.lastBit = o1.Bit; L.r.prev = b1;
-						ph = pq; last = (int)(b5 >> 4);
 					} else {
-						// the two frequent rare turns stay arithmetic: no fire (nothing to decode), or two fires with both steps clean
-						const uint32_t f_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)fires);
-						const uint32_t rest = f_s & (f_s - 1u);
-						if (f_s == 0u) { ph = pq; last = (int)(b5 >> 4); rare = false; }
-						else if (rest != 0u && (rest & (rest - 1u)) == 0u && __builtin_amdgcn_readfirstlane((int)bad1) == 0) {
-							const int s2 = __builtin_ctz(rest);
-							const int b2 = (int)((b5 >> s2) & 1u);
-							const IdleStep o2 = idle_arith(o1.state, o1.pos, o1.Bit, b1, b2);
-							const uint32_t later2 = c5 >> (s2 + 1);
-							const uint32_t bad2 = (uint32_t)o2.open | ((uint32_t)(o2.state ^ o1.state) & (later2 < 1u ? later2 : 1u));
-							if (__builtin_amdgcn_readfirstlane((int)bad2) == 0) {
-								const long long sidx1 = sample_idx + (k + s1), sidx2 = sample_idx + (k + s2);
-								L.r.start_idx = o2.to_flag ? sidx2 : (o1.to_flag ? sidx1 : L.r.start_idx);
-								L.r.state = o2.state; L.r.position = o2.pos; L.r.lastBit = o2.Bit; L.r.prev = b2;
-								ph = pq; last = (int)(b5 >> 4); rare = false;
+						// ---- the decoder's step for a decoder in TRAINING / STARTFLAG, as arithmetic on 0 / 1 (dec_lean_idle)
+						const IdleStep o1 = idle_arith(m0, pos, L.r.lastBit, L.r.prev, b1);
+						// rare: no or several fires, a frame opens, a flipped TRAINING flag in front of a later sign change
+						const uint32_t later = c5 >> ((s1 + 1) & 31);
+						const uint32_t bad1 = (uint32_t)o1.open | ((uint32_t)(o1.state ^ m0) & (later < 1u ? later : 1u));
+						rare = __ballot((not_one | bad1) != 0u) != 0;
+						if (!rare) {
+							const long long sidx = sample_idx + (k + s1);
+							L.r.start_idx = o1.to_flag ? sidx : L.r.start_idx;
+							L.r.state = o1.state; L.r.position = o1.pos; L.r.lastBit = o1.Bit; L.r.prev = b1;
+							ph = pq; last = (int)(b5 >> 4);
+						} else {
+							// the two frequent rare turns stay arithmetic: no fire (nothing to decode), or two fires with both steps clean
+							const uint32_t f_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)fires);
+							const uint32_t rest = f_s & (f_s - 1u);
+							if (f_s == 0u) { ph = pq; last = (int)(b5 >> 4); rare = false; }
+							else if (rest != 0u && (rest & (rest - 1u)) == 0u && __builtin_amdgcn_readfirstlane((int)bad1) == 0) {
+								const int s2 = __builtin_ctz(rest);
+								const int b2 = (int)((b5 >> s2) & 1u);
+								const IdleStep o2 = idle_arith(o1.state, o1.pos, o1.Bit, b1, b2);
+								const uint32_t later2 = c5 >> (s2 + 1);
+								const uint32_t bad2 = (uint32_t)o2.open | ((uint32_t)(o2.state ^ o1.state) & (later2 < 1u ? later2 : 1u));
+								if (__builtin_amdgcn_readfirstlane((int)bad2) == 0) {
+									const long long sidx1 = sample_idx + (k + s1), sidx2 = sample_idx + (k + s2);
+									L.r.start_idx = o2.to_flag ? sidx2 : (o1.to_flag ? sidx1 : L.r.start_idx);
+									L.r.state = o2.state; L.r.position = o2.pos; L.r.lastBit = o2.Bit; L.r.prev = b2;
+									ph = pq; last = (int)(b5 >> 4); rare = false;
+								}
 							}
 						}
 					}
+					if (rare) { // the reference's order, sample by sample (a frame buffer word the turn may have written is rewritten by it)
+						int last_s = __builtin_amdgcn_readfirstlane(last);
+						kret = fm_exact(k, k + 5, ph, last_s, fnd);
+						last = last_s;
+						asm volatile("" : "+v"(ph), "+v"(last));
+						inframe = __builtin_amdgcn_readfirstlane(L.r.state) == DST_DATAFCS;
+						next_ev = next_event();
+					}
 				}
-				if (rare) { // the reference's order, sample by sample (a frame buffer word the turn may have written is rewritten by it)
-					int last_s = __builtin_amdgcn_readfirstlane(last);
-					kret = fm_exact(k, k + 5, ph, last_s, fnd);
-					last = last_s;
-					asm volatile("" : "+v"(ph), "+v"(last));
-					inframe = __builtin_amdgcn_readfirstlane(L.r.state) == DST_DATAFCS;
-					next_ev = next_event();
-				}
-			}
-			if (kret != 512) k = to; // (stopped at a completed message)
-			int last_s = __builtin_amdgcn_readfirstlane(last);
-			if (kret == 512 && k < to) kret = fm_exact(k, to, ph, last_s, fnd);
-			L.pll_phase = ph; L.pll_last = last_s;
-			return kret;
-		};
+				if (kret != 512) k = to; // (stopped at a completed message)
+				int last_s = __builtin_amdgcn_readfirstlane(last);
+				if (kret == 512 && k < to) kret = fm_exact(k, to, ph, last_s, fnd);
+				L.pll_phase = ph; L.pll_last = last_s;
+				return kret;
+			};
 			uint32_t* const snapc = fsnap + (data - fdata);
 			V2Lane S = L;
 			bool snap_cols = false;
@@ -4485,22 +4159,11 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 				return kf;
 			};
 			int P = 0;
-#ifdef V2_PROF
-			if (lane == 0) atomicAdd(&v2_prof[5 + wave], __builtin_readcyclecounter() - v2p_blk0);
-#endif
 #pragma unroll 1
 			for (;;) {
 				bool fnd = false;
 				int k;
-#if defined(V2_ABLR) && V2_ABLR == 1
-				{ V2P_T0(); k = fm_wave ? 512 : coh_run(P, 512, fnd); V2P_ADD(3 + wave); }
-#elif defined(V2_ABLR) && V2_ABLR == 2
-				{ V2P_T0(); k = fm_wave ? fm_run(P, 512, fnd) : 512; V2P_ADD(3 + wave); }
-#elif defined(V2_ABLR) && V2_ABLR == 3
-				{ V2P_T0(); k = 512; V2P_ADD(3 + wave); }
-#else
 				{ V2P_T0(); k = fm_wave ? fm_run(P, 512, fnd) : coh_run(P, 512, fnd); V2P_ADD(3 + wave); }
-#endif
 				// the speculative pass is through (or stopped at a completed message): who was first?
 				if (wave == 0) {
 					const int busy = __ballot(dl && L.r.state != DST_TRAINING) != 0 ? 1 : 0; // (as the next block will find the decoders, if nobody completed a message)
@@ -5790,9 +5453,8 @@ hipError_t launch_kv2_assist(const KV2Params& p, hipStream_t s) {
 	return hipGetLastError();
 }
 hipError_t launch_kv2_engine(const KV2EParams& e, hipStream_t s) { // one workgroup per channel (reads the look-back `hist`)
-	if (e.roles == 2) hipLaunchKernelGGL(kv2_engine_t<true>, dim3(e.k.n_chan), dim3(128), 0, s, e);
-	else if (e.roles) hipLaunchKernelGGL(kv2_engine_roles, dim3(e.k.n_chan), dim3(192), 0, s, e);
-	else hipLaunchKernelGGL(kv2_engine_t<false>, dim3(e.k.n_chan), dim3(64), 0, s, e);
+	if (e.roles) hipLaunchKernelGGL(kv2_engine_roles, dim3(e.k.n_chan), dim3(192), 0, s, e);
+	else hipLaunchKernelGGL(kv2_engine, dim3(e.k.n_chan), dim3(64), 0, s, e);
 	return hipGetLastError();
 }
 hipError_t launch_kv2_carry(const KV2Params& p, hipStream_t s) {
