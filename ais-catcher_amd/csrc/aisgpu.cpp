@@ -1630,7 +1630,10 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	HIPCHK(dalloc(&h->d_psflag, 4));
 	if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_firtap, C * (8 + h->L)));
 	if (h->v2) {
-		h->v2_roles = opt_int("v2_roles", 1);
+		// kv2_engine_roles (three waves per channel, 50 KB of LDS each) while a launch's workgroups are resident in at most two rounds;
+		// bigger batches fill the chip with round 5's one-wave kernel (measured, distinct receivers: 64 rx 22 / 9 GS/s, 256 66 / 32,
+		// 512 68 / 53, 1,024 69 / 90; profiles/r06_expG_v2_engine.txt).  Test hook "v2_roles" = 0 / 1 forces one of them.
+		h->v2_roles = opt_int("v2_roles", h->n_chan <= 1024 ? 1 : 0);
 		// With the engine on the device (AISGPU_FLAG_GPU_DECODE) nothing but frames goes to the host: no pinned slots for the channels,
 		// the estimates, the energies or the discriminator signs (several GB at 2,048 receivers), and aisgpu_fetch_sub() returns NULL for them.
 		const bool v2_host = !h->gpu_decode;
