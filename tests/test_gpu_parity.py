@@ -970,6 +970,35 @@ def test_model_engine_v2_on_the_device_batch_of_distinct_receivers(roles, monkey
     g.close()
 
 
+def test_model_engine_v2_three_waves_equal_one_wave_on_a_batch(monkeypatch):
+    """Round 6: kv2_engine_roles (trackers / FM decoder / the next block's front end for both values of busy on three waves, every
+    block speculating that nobody completes a message) against round 5's one-wave kernel -- which the tests above pin to the compiled
+    reference -- on 48 distinct noisy receivers of the bench's workload over eighteen blocks of 15 engine blocks each: every frame record
+    (decoder, position, level sum, start / end index, bits), 96 channels' worth, must be identical, and so must the number of
+    Estimate() calls at a learned slot phase (the preparation of a block is voided and redone wherever a tracker's decoder completes
+    a message, and at the learned slot phase only one answer exists)."""
+    import torch
+    from ais_catcher_amd import workload
+    R, block, nblocks = 48, 245760, 3  # (a whole number of SOTDMA slots per block: the engines learn the slot phase over the passes)
+    data = workload.resident_batch(torch, R, nblocks, seed=3, block=block)
+    out = []
+    for roles in ("1", "0"):
+        monkeypatch.setenv("AISGPU_V2_ROLES", roles)
+        g = gpu.AisGpu(n_receivers=R, block_len=block, model=gpu.MODEL_V2, gpu_decode=True)
+        frames = []
+        for b in range(6 * nblocks):
+            g.submit_device(data[b % nblocks].data_ptr(), block)
+            g.run()
+            g.sync_outputs()
+            frames += g.frames()
+        # (the record carries the whole frame buffer; bits at and beyond `position` are whatever earlier frames left there)
+        bits = lambda f: (f["data"][:f["position"] // 8], f["data"][f["position"] // 8] & ((1 << (f["position"] % 8)) - 1))
+        out.append((sorted((f["rx"], f["ch"], f["end_idx"], f["phase"], f["start_idx"], f["position"], f["level_sum"]) + bits(f) for f in frames), g.decoder_fallbacks()))
+        g.close()
+    assert len(out[0][0]) >= 200 and out[0][0] == out[1][0]
+    assert out[0][1] == out[1][1] and out[0][1] > 0
+
+
 @pytest.mark.parametrize("rate,fmt,block", [(1536000, "cf32", 131072), (1536000, "cu8", 131072), (768000, "cf32", 65536)])
 def test_model_standard_nmea_end_to_end(rate, fmt, block):
     """AIS::ModelStandard (-m 0): the device path of ModelBase (front end + FM discriminator + 37-tap filter), then on the host
