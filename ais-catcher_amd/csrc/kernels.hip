@@ -3636,11 +3636,19 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 	__shared__ float2 sh_slot_ema;   // the slot predictor after a learnSlotPhase (wave 0 -> wave 2)
 	__shared__ int sh_slot_phase;
 	const KV2Params& p = q.k;
+#ifdef V2_PROF
+	const unsigned long long v2p_k0 = __builtin_readcyclecounter();
+#endif
 	__builtin_amdgcn_s_setprio(3); // (every wave here is one long dependent chain: it must issue the moment it can, the throughput kernels beside it fill the gaps)
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	const int lane = threadIdx.x & 63, j = lane;
 	const int chan = blockIdx.x;
-	const bool fm_wave = wave == 1, fe_wave = wave == 2;
+#ifndef V2_FM_WAVE
+#define V2_FM_WAVE 2
+#endif
+	// (which wave takes which role: with two workgroups per CU and the waves dealt round-robin to the four SIMDs -- 0 1 2 | 3 0 1 -- the
+	// order trackers, front end, FM decoder puts every decoder wave beside at most the light front-end wave of the other workgroup)
+	const bool fm_wave = wave == V2_FM_WAVE, fe_wave = wave == 3 - V2_FM_WAVE;
 	const bool dl = wave == 0 ? lane < 5 : (fm_wave && lane == 0); // the decoder lanes
 	const int dec = chan * 6 + (fm_wave ? 5 : (dl ? j : 0));
 	uint32_t* data = fdata + (wave == 0 ? lane : (dl ? 5 : 63));
@@ -4028,6 +4036,9 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 					return ((unsigned long long)w[1] << 32) | w[0];
 				};
 				unsigned long long win = window(k);
+#ifdef V2_PROF_FM
+				unsigned long long tq0; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tq0) : "v"(ph), "v"(last) : "memory");
+#endif
 				// inside a frame the turn's decoder step is dec_lean_data's common case as arithmetic; the frame's rare symbols -- closing flag, the
 				// look-ups at positions 30 / 62, the type's own limit, the maximum length: the next of them is `next_ev` -- go through fm_exact
 				bool inframe = __builtin_amdgcn_readfirstlane(L.r.state) == DST_DATAFCS; // (scalar: changes only in the rare branch)
@@ -4121,6 +4132,10 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 						next_ev = next_event();
 					}
 				}
+#ifdef V2_PROF_FM
+				unsigned long long tq1; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tq1) : "v"(ph), "v"(last), "v"(L.r.state), "v"(L.r.position), "s"(kret) : "memory");
+				if (lane == 0) { atomicAdd(&v2_prof[10], tq1 - tq0); atomicAdd(&v2_prof[11], (unsigned long long)((k - from) / 5)); }
+#endif
 				if (kret != 512) k = to; // (stopped at a completed message)
 				int last_s = __builtin_amdgcn_readfirstlane(last);
 				if (kret == 512 && k < to) kret = fm_exact(k, to, ph, last_s, fnd);
@@ -4158,32 +4173,38 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 				L.pll_phase = ph; L.pll_last = last;
 				return kf;
 			};
-			int P = 0;
+			// One call site of the hot loops: the speculative pass over [P, 512), and -- behind a completed message -- the exact prefix [P, k*)
+			// again (no message can complete in it), before sample k* itself goes through the symbol-by-symbol code.
+			int P = 0, to = 512, kstar = 512;
+			bool prefix = false, coh_wins = false;
 #pragma unroll 1
 			for (;;) {
 				bool fnd = false;
 				int k;
-				{ V2P_T0(); k = fm_wave ? fm_run(P, 512, fnd) : coh_run(P, 512, fnd); V2P_ADD(3 + wave); }
-				// the speculative pass is through (or stopped at a completed message): who was first?
-				if (wave == 0) {
-					const int busy = __ballot(dl && L.r.state != DST_TRAINING) != 0 ? 1 : 0; // (as the next block will find the decoders, if nobody completed a message)
-					if (lane == 0) { kx[xi & 1][0] = k; kx[xi & 1][2] = busy; kx[xi & 1][3] = learned; }
-				} else if (lane == 0) kx[xi & 1][1] = k;
-				{ V2P_T0(); __syncthreads(); V2P_ADD(7 + wave); }
-				const int kc = __builtin_amdgcn_readfirstlane(kx[xi & 1][0]), kf = __builtin_amdgcn_readfirstlane(kx[xi & 1][1]);
-				xi++;
-				if (kc == 512 && kf == 512) break;
-				const bool coh_wins = kc <= kf; // (the same sample: the tracker's decoder runs first and resets the FM decoder in front of its step, :374-385)
-				const int kstar = coh_wins ? kc : kf;
-				restore();
+				{ V2P_T0(); k = fm_wave ? fm_run(P, to, fnd) : coh_run(P, to, fnd); V2P_ADD(3 + (fm_wave ? 1 : 0)); }
+				if (!prefix) {
+					// the speculative pass is through (or stopped at a completed message): who was first?
+					if (wave == 0) {
+						const int busy = __ballot(dl && L.r.state != DST_TRAINING) != 0 ? 1 : 0; // (as the next block will find the decoders, if nobody completed a message)
+						if (lane == 0) { kx[xi & 1][0] = k; kx[xi & 1][2] = busy; kx[xi & 1][3] = learned; }
+					} else if (lane == 0) kx[xi & 1][1] = k;
+					{ V2P_T0(); __syncthreads(); V2P_ADD(7 + (fm_wave ? 1 : 0)); }
+					const int kc = __builtin_amdgcn_readfirstlane(kx[xi & 1][0]), kf = __builtin_amdgcn_readfirstlane(kx[xi & 1][1]);
+					xi++;
+					if (kc == 512 && kf == 512) break;
+					coh_wins = kc <= kf; // (the same sample: the tracker's decoder runs first and resets the FM decoder in front of its step, :374-385)
+					kstar = coh_wins ? kc : kf;
+					restore();
+					to = kstar; prefix = true;
+					continue;
+				}
+				// exact up to k*: now sample k* itself
 				const float tag_ppm = kstar >= split_b ? ppm_b : ppm_prev_b;
 				if (fm_wave) {
-					fm_slow(P, kstar, fnd); // exact up to k*: now sample k* itself
 					if (coh_wins) v2_reset(L.r);
 					fm_slow(kstar, kstar + 1, fnd);
 					if (!coh_wins) { if (lane == 0) emit(L.r, sample_idx + kstar, tag_ppm); v2_reset(L.r); }
 				} else {
-					coh_slow(P, kstar, fnd);
 					coh_slow(kstar, kstar + 1, fnd);
 					if (coh_wins) {
 						const unsigned long long FF = __ballot(fnd) | (1ull << 63); // (the lane that handled k*)
@@ -4194,7 +4215,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 					}
 					v2_reset(L.r);
 				}
-				P = kstar + 1;
+				P = kstar + 1; to = 512; prefix = false;
 				snapshot();
 			}
 			if (wave == 0 && j < 5) L.t.rot = (L.t.rot + (unsigned)((512 - (j - di + 5) % 5 + 4) / 5)) & 3u; // Rotate90 calls of this tracker in the block
@@ -4208,6 +4229,9 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 		else { __syncthreads(); cur = (cur + 1) % 3; } // (wave 2 prepares the block again, in the open)
 	}
 	}
+#ifdef V2_PROF
+	if (lane == 0 && fm_wave) { const unsigned long long d_ = __builtin_readcyclecounter() - v2p_k0; atomicMax(&v2_prof[12], d_); atomicAdd(&v2_prof[13], d_); atomicAdd(&v2_prof[14], 1ull); atomicMin(&v2_prof[15], ~d_); }
+#endif
 	if (dl) {
 		DecState* st = q.dec + dec;
 		const DecReg& r = L.r;
