@@ -3282,6 +3282,7 @@ bool sincos_restatement_matches_host_libm() {
 struct V2Lane { DecReg r; V2Tracker t; float pll_phase; int pll_last; };
 #ifdef V2_PROF // experiment build: cycles of the engine's phases, summed over the waves and launches (tools/build_variant.sh v2prof -DV2_PROF)
 __device__ unsigned long long v2_prof[16];
+__device__ unsigned long long v2_prof_wg[1024][4]; // per workgroup (last launch wins): tracker wave's run, FM wave's run, FM wave's resident time, messages
 #define V2P_T0() const unsigned long long v2p_t0 = __builtin_readcyclecounter()
 #define V2P_ADD(slot) do { if (lane == 0) atomicAdd(&v2_prof[slot], __builtin_readcyclecounter() - v2p_t0); } while (0)
 void v2_prof_dump() {
@@ -3290,6 +3291,9 @@ void v2_prof_dump() {
 	fprintf(stderr, "v2_prof:");
 	for (int i = 0; i < 16; i++) fprintf(stderr, " %llu", h[i]);
 	fprintf(stderr, "\n");
+	static unsigned long long w[1024][4];
+	if (hipMemcpyFromSymbol(w, HIP_SYMBOL(v2_prof_wg), sizeof w) != hipSuccess) return;
+	for (int i = 0; i < 1024; i++) if (w[i][2]) fprintf(stderr, "v2_wg %d %llu %llu %llu %llu\n", i, w[i][0], w[i][1], w[i][2], w[i][3]);
 }
 #else
 #define V2P_T0() do {} while (0)
@@ -3638,6 +3642,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 	const KV2Params& p = q.k;
 #ifdef V2_PROF
 	const unsigned long long v2p_k0 = __builtin_readcyclecounter();
+	if (threadIdx.x < 2 && blockIdx.x < 1024) v2_prof_wg[blockIdx.x][threadIdx.x] = 0;
 #endif
 	__builtin_amdgcn_s_setprio(3); // (every wave here is one long dependent chain: it must issue the moment it can, the throughput kernels beside it fill the gaps)
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -4031,14 +4036,10 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 				int last = L.pll_last;
 				asm volatile("" : "+v"(ph), "+v"(last)); // (loaded through scalar registers: keep what follows on the vector side)
 				int k = from, kret = 512;
-				const auto window = [&](const int kk) -> unsigned long long { // the signs from sample kk & ~31 on (64 of them)
-					const uint32_t* w = fmw2 + (kk >> 5);
-					return ((unsigned long long)w[1] << 32) | w[0];
-				};
-				unsigned long long win = window(k);
-#ifdef V2_PROF_FM
-				unsigned long long tq0; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tq0) : "v"(ph), "v"(last) : "memory");
-#endif
+				// the discriminator's signs from sample k on, in scalar registers: five leave per turn, a word of 32 arrives when half are gone
+				const auto sword = [&](const int w) -> unsigned long long { return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)fmw2[w < 17 ? w : 17]); };
+				unsigned long long win = (sword(k >> 5) | (sword((k >> 5) + 1) << 32)) >> (k & 31);
+				int have = 64 - (k & 31), nextw = (k >> 5) + 2;
 				// inside a frame the turn's decoder step is dec_lean_data's common case as arithmetic; the frame's rare symbols -- closing flag, the
 				// look-ups at positions 30 / 62, the type's own limit, the maximum length: the next of them is `next_ev` -- go through fm_exact
 				bool inframe = __builtin_amdgcn_readfirstlane(L.r.state) == DST_DATAFCS; // (scalar: changes only in the rare branch)
@@ -4049,8 +4050,9 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 				int next_ev = next_event();
 #pragma unroll 1
 				for (; k + 5 <= to && kret == 512; k += 5) { // (one way in, one way round: the rare cases rejoin the turn's end)
-					const uint32_t b5 = (uint32_t)(win >> (k & 31)) & 31u;
-					win = window(k + 5 < 512 ? k + 5 : k); // (a turn ahead)
+					const uint32_t b5 = (uint32_t)win & 31u;
+					win >>= 5; have -= 5;
+					if (have <= 32) { win |= sword(nextw) << have; have += 32; nextw++; }
 					const uint32_t c5 = (b5 ^ ((b5 << 1) | (uint32_t)last)) & 31u; // sign changes
 					const int st0 = L.r.state;
 					const int m0 = st0 < 1 ? st0 : 1; // 0: TRAINING
@@ -4063,12 +4065,13 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 						pq = pq + 0.2f;
 						const float fl = __builtin_floorf(pq);  // 1.0f where it fires (1 <= phase < 1.2), else 0.0f
 						pq = __builtin_amdgcn_fractf(pq);       // phase - (int)phase: x - floor(x), exact on [0, 2) (off the chain: floor() only feeds the fired positions)
-						ff = __builtin_fmaf(fl, (float)(1 << s5), ff);
+						ff = s5 == 0 ? fl : __builtin_fmaf(fl, (float)(1 << s5), ff);
 					}
 					const uint32_t fires = (uint32_t)ff;
-					const int s1 = __builtin_ffs((int)fires) - 1; // first sample that fires (-1: none)
-					const int b1 = (int)((b5 >> (s1 & 31)) & 1u);
-					const uint32_t not_one = (fires & (fires - 1u)) | (uint32_t)(s1 >> 31); // no fire, or several
+					int s1; // first sample that fires (-1: none)
+					asm("v_ffbl_b32 %0, %1" : "=v"(s1) : "v"(fires));
+					const int b1 = (int)__builtin_amdgcn_ubfe(b5, (uint32_t)s1, 1u); // (offset 31 of a five-bit field where nothing fired: 0)
+					const uint32_t not_one = (uint32_t)__builtin_popcount(fires) ^ 1u; // no fire, or several
 					const int pos = L.r.position;
 					const int Bit = (b1 ^ L.r.prev) ^ 1;
 					bool rare;
@@ -4132,10 +4135,6 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 						next_ev = next_event();
 					}
 				}
-#ifdef V2_PROF_FM
-				unsigned long long tq1; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tq1) : "v"(ph), "v"(last), "v"(L.r.state), "v"(L.r.position), "s"(kret) : "memory");
-				if (lane == 0) { atomicAdd(&v2_prof[10], tq1 - tq0); atomicAdd(&v2_prof[11], (unsigned long long)((k - from) / 5)); }
-#endif
 				if (kret != 512) k = to; // (stopped at a completed message)
 				int last_s = __builtin_amdgcn_readfirstlane(last);
 				if (kret == 512 && k < to) kret = fm_exact(k, to, ph, last_s, fnd);
@@ -4181,7 +4180,12 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 			for (;;) {
 				bool fnd = false;
 				int k;
-				{ V2P_T0(); k = fm_wave ? fm_run(P, to, fnd) : coh_run(P, to, fnd); V2P_ADD(3 + (fm_wave ? 1 : 0)); }
+#ifdef V2_PROF
+				{ const unsigned long long t0_ = __builtin_readcyclecounter(); k = fm_wave ? fm_run(P, to, fnd) : coh_run(P, to, fnd); const unsigned long long d_ = __builtin_readcyclecounter() - t0_;
+				  if (lane == 0) { atomicAdd(&v2_prof[3 + (fm_wave ? 1 : 0)], d_); if (chan < 1024) v2_prof_wg[chan][fm_wave ? 1 : 0] += d_; } }
+#else
+				k = fm_wave ? fm_run(P, to, fnd) : coh_run(P, to, fnd);
+#endif
 				if (!prefix) {
 					// the speculative pass is through (or stopped at a completed message): who was first?
 					if (wave == 0) {
@@ -4212,6 +4216,9 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 						const long long sidx0 = __shfl(L.r.start_idx, __builtin_ctzll(FF));
 						learn_slot(sidx0);
 						learned = 1;
+#ifdef V2_PROF
+						if (lane == 0 && chan < 1024) v2_prof_wg[chan][3]++;
+#endif
 					}
 					v2_reset(L.r);
 				}
@@ -4230,6 +4237,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 	}
 	}
 #ifdef V2_PROF
+	if (lane == 0 && fm_wave && chan < 1024) v2_prof_wg[chan][2] = __builtin_readcyclecounter() - v2p_k0;
 	if (lane == 0 && fm_wave) { const unsigned long long d_ = __builtin_readcyclecounter() - v2p_k0; atomicMax(&v2_prof[12], d_); atomicAdd(&v2_prof[13], d_); atomicAdd(&v2_prof[14], 1ull); atomicMin(&v2_prof[15], ~d_); }
 #endif
 	if (dl) {
