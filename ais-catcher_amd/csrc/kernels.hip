@@ -3637,8 +3637,9 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 	__shared__ float sh_ppm[3], sh_ppm_prev[3]; // per zbuf slot: what the decoders' tags need
 	__shared__ int sh_split[3];
 	__shared__ int sh_nc[2];         // by block parity: candidates wave 2 prepared for the next block
-	__shared__ float2 sh_slot_ema;   // the slot predictor after a learnSlotPhase (wave 0 -> wave 2)
-	__shared__ int sh_slot_phase;
+	__shared__ float2 sh_slot_ema[2]; // by block parity: the slot predictor after a learnSlotPhase (wave 0 -> the others)
+	__shared__ int sh_slot_phase[2];
+	int blk_now = 0;                 // (wave 0 / 1: the block being decoded)
 	const KV2Params& p = q.k;
 #ifdef V2_PROF
 	const unsigned long long v2p_k0 = __builtin_readcyclecounter();
@@ -3696,7 +3697,17 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 		slot_ema = make_float2((1.0f - 0.2f) * slot_ema.x + 0.2f * csv.x, (1.0f - 0.2f) * slot_ema.y + 0.2f * csv.y);
 		const float ph = atan2f_ref(slot_ema.y, slot_ema.x) * (1280.0f / (2.0f * 3.14159265358979323846f));
 		slot_phase = (int)(ph + 1280.0f + 0.5f) % 1280;
-		if (lane == 0) { sh_slot_ema = slot_ema; sh_slot_phase = slot_phase; }
+		if (lane == 0) { sh_slot_ema[blk_now & 1] = slot_ema; sh_slot_phase[blk_now & 1] = slot_phase; }
+	};
+	// A tracker's decoder completed a message in block b (learnSlotPhase moved the slot predictor): is what wave 2 prepared for block b + 1
+	// still that block?  CGF consults the predictor only to ask "locked, and does a slot start inside the block" (:297-311); where the
+	// answer was no when the block was prepared and is no now, the preparation stands (it depends on busy alone).  Every wave asks alike.
+	const auto still_valid = [&](const int b, const long long sidx_next, const int spec_locked) -> bool {
+		const float2 se_new = sh_slot_ema[b & 1];
+		const float2 se = make_float2(se_new.x * 0.9999f, se_new.y * 0.9999f);
+		const bool locked = se.x * se.x + se.y * se.y >= 0.64f;
+		const int e_slot = (int)((((long long)sh_slot_phase[b & 1] - sidx_next) % 1280 + 1280) % 1280);
+		return !(locked && e_slot < 512) && !spec_locked;
 	};
 	// ---- wave 2 ----------------------------------------------------------------------------
 	// FreqOffset::Derotate (:133-146) over samples [from, to) of the staged block into a candidate's buffer: lane l owns samples from + 8 l .. + 7
@@ -3837,7 +3848,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 				blk++;
 				redo = false;
 			} else {
-				if (lane == 0) sh_nc[blk & 1] = nc;
+				if (lane == 0) sh_nc[blk & 1] = nc | (cand_locked << 2);
 				int busy = 0, lrn = 0;
 #pragma unroll 1
 				for (;;) { // the others' exchanges of block blk
@@ -3847,10 +3858,13 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 					xi++;
 					if (kc == 512 && kf == 512) break;
 				}
-				if (lrn) { // the slot predictor moved: the block is prepared again, in the open
-					slot_ema = sh_slot_ema; slot_phase = sh_slot_phase;
-					mode = busy ? 1 : 0; s0 = s1 = (cur + 1) % 3; redo = true;
-					continue;
+				if (lrn) { // the slot predictor moved
+					slot_ema = sh_slot_ema[blk & 1]; slot_phase = sh_slot_phase[blk & 1];
+					if (!still_valid(blk, sample_idx, cand_locked)) { // the block is prepared again, in the open
+						mode = busy ? 1 : 0; s0 = s1 = (cur + 1) % 3; redo = true;
+						continue;
+					}
+					cand_se = make_float2(slot_ema.x * 0.9999f, slot_ema.y * 0.9999f); // (what front() would have decayed)
 				}
 				const int sel = (nc == 2 && busy) ? 1 : 0;
 				adopt(sel);
@@ -3878,6 +3892,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 	for (int blk = 0; blk < p.n_windows; blk++) {
 		const int n0 = -V2_HIST + 512 * blk;
 		const float2* const zb = zbuf[cur];
+		blk_now = blk;
 		int learned = 0; // wave 0: a tracker's decoder completed a message in this block (the slot predictor moved)
 		{
 			if (fm_wave) {
@@ -4232,7 +4247,8 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 		}
 		// ---- which block is next?  (the last exchange of the block carries busy and learned)
 		const int busy = __builtin_amdgcn_readfirstlane(kx[(xi - 1) & 1][2]), lrn = __builtin_amdgcn_readfirstlane(kx[(xi - 1) & 1][3]);
-		if (lrn == 0) cur = (cur + 1 + ((__builtin_amdgcn_readfirstlane(sh_nc[blk & 1]) == 2 && busy) ? 1 : 0)) % 3;
+		const int ncl = __builtin_amdgcn_readfirstlane(sh_nc[blk & 1]);
+		if (lrn == 0 || still_valid(blk, sample_idx, ncl >> 2)) cur = (cur + 1 + (((ncl & 3) == 2 && busy) ? 1 : 0)) % 3;
 		else { __syncthreads(); cur = (cur + 1) % 3; } // (wave 2 prepares the block again, in the open)
 	}
 	}
