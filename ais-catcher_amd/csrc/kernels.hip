@@ -3700,14 +3700,15 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 		if (lane == 0) { sh_slot_ema[blk_now & 1] = slot_ema; sh_slot_phase[blk_now & 1] = slot_phase; }
 	};
 	// A tracker's decoder completed a message in block b (learnSlotPhase moved the slot predictor): is what wave 2 prepared for block b + 1
-	// still that block?  CGF consults the predictor only to ask "locked, and does a slot start inside the block" (:297-311); where the
-	// answer was no when the block was prepared and is no now, the preparation stands (it depends on busy alone).  Every wave asks alike.
-	const auto still_valid = [&](const int b, const long long sidx_next, const int spec_locked) -> bool {
+	// still that block?  CGF consults the predictor for one thing: "locked, and a slot starts inside the block, at sample e" (:297-311).  Where
+	// the answer is what it was when the block was prepared (no such slot then and now, or the same e), the preparation stands.  Every
+	// wave asks alike; e_spec: the preparation's e, -1 without one.
+	const auto still_valid = [&](const int b, const long long sidx_next, const int e_spec) -> bool {
 		const float2 se_new = sh_slot_ema[b & 1];
 		const float2 se = make_float2(se_new.x * 0.9999f, se_new.y * 0.9999f);
 		const bool locked = se.x * se.x + se.y * se.y >= 0.64f;
 		const int e_slot = (int)((((long long)sh_slot_phase[b & 1] - sidx_next) % 1280 + 1280) % 1280);
-		return !(locked && e_slot < 512) && !spec_locked;
+		return ((locked && e_slot < 512) ? e_slot : -1) == e_spec;
 	};
 	// ---- wave 2 ----------------------------------------------------------------------------
 	// FreqOffset::Derotate (:133-146) over samples [from, to) of the staged block into a candidate's buffer: lane l owns samples from + 8 l .. + 7
@@ -3754,7 +3755,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 	};
 	float cand_f0 = 0.0f, cand_f1 = 0.0f, cand_ppm0 = 0.0f, cand_ppm1 = 0.0f; // (scalars, not arrays: no scratch)
 	float2 cand_rot0 = rot, cand_rot1 = rot, cand_se = slot_ema;
-	int cand_locked = 0;
+	int cand_locked = 0, cand_e = -1; // the prepared block went through the learned-slot path, with the slot at sample cand_e
 	// Engine::processBlock (:345-352) up to coh_filtered for block blk, from wave 2's state (rot, last_f, slot_ema / slot_phase as of the end
 	// of the block before, sample_idx / di / rots of block blk).  mode 0 / 1: busy is known; 2: prepare both answers where they differ.
 	// Candidate c goes to dero2[c] and zbuf[slot_c]; returns the number of candidates.
@@ -3772,6 +3773,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 		// a window the assist kernels did not compute: FFT by the wave, the sequential search by one lane; busy does not enter.  Otherwise
 		// the frequency is the estimate of the window midWins picks (!busy, :312-314) or the tone gate's choice (busy): two candidates
 		// where they differ.  The derotations are jobs of one loop (one copy of the code, sinf / cosf included).
+		cand_e = cand_locked ? e_slot : -1;
 		if (cand_locked) split = e_slot;
 		else {
 			const float* en = p.energy + (size_t)chan * (p.n_windows + 1);
@@ -3848,7 +3850,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 				blk++;
 				redo = false;
 			} else {
-				if (lane == 0) sh_nc[blk & 1] = nc | (cand_locked << 2);
+				if (lane == 0) sh_nc[blk & 1] = nc | ((cand_e + 1) << 2);
 				int busy = 0, lrn = 0;
 #pragma unroll 1
 				for (;;) { // the others' exchanges of block blk
@@ -3860,7 +3862,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 				}
 				if (lrn) { // the slot predictor moved
 					slot_ema = sh_slot_ema[blk & 1]; slot_phase = sh_slot_phase[blk & 1];
-					if (!still_valid(blk, sample_idx, cand_locked)) { // the block is prepared again, in the open
+					if (!still_valid(blk, sample_idx, cand_e)) { // the block is prepared again, in the open
 						mode = busy ? 1 : 0; s0 = s1 = (cur + 1) % 3; redo = true;
 						continue;
 					}
@@ -4248,7 +4250,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 		// ---- which block is next?  (the last exchange of the block carries busy and learned)
 		const int busy = __builtin_amdgcn_readfirstlane(kx[(xi - 1) & 1][2]), lrn = __builtin_amdgcn_readfirstlane(kx[(xi - 1) & 1][3]);
 		const int ncl = __builtin_amdgcn_readfirstlane(sh_nc[blk & 1]);
-		if (lrn == 0 || still_valid(blk, sample_idx, ncl >> 2)) cur = (cur + 1 + (((ncl & 3) == 2 && busy) ? 1 : 0)) % 3;
+		if (lrn == 0 || still_valid(blk, sample_idx, (ncl >> 2) - 1)) cur = (cur + 1 + (((ncl & 3) == 2 && busy) ? 1 : 0)) % 3;
 		else { __syncthreads(); cur = (cur + 1) % 3; } // (wave 2 prepares the block again, in the open)
 	}
 	}
