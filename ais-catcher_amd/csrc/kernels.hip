@@ -3980,23 +3980,28 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 							const int ev = (int)((uint32_t)((np ^ next_ev) - 1) >> 31); // position == next_ev
 							const bool D = isD != 0;
 							const bool special = dl && (D ? (close | ev) != 0 : o.open != 0);
-							const bool fr = D && !special && dl, id = !D && !special;
-							if (fr) data[DEC_LANES * L.r.cwi] = L.r.cw; // (the word that is being filled, complete when the position moves on)
+							if (D && dl) data[DEC_LANES * L.r.cwi] = L.r.cw; // (the word that is being filled, complete when the position moves on)
 							const float slvl = zf.x * zf.x + zf.y * zf.y;
+							// both steps are committed for every lane -- the frame registers of a decoder outside a frame are don't-cares (a
+							// frame that opens clears them) -- and a lane whose symbol is one of the rare ones redoes it from the state it had
+							const DecReg r_pre = L.r;
+							L.r.level = L.r.level + slvl;
+							L.r.cw = cw; L.r.cwi = L.r.cwi + nw; L.r.osc = (osc + 1) & (0 - o.Bit);
+							L.r.start_idx = o.to_flag ? sidx : L.r.start_idx; // (never inside a frame: m0 = 1 there)
+							L.r.state = D ? (int)DST_DATAFCS : o.state; L.r.position = D ? np : o.pos;
+							L.r.lastBit = o.Bit; L.r.prev = bit;
+							unsigned long long F = 0; // lanes whose decoder completed a message
 							bool found = false;
 							if (__ballot(special) != 0) {
 								if (special) {
-									if (D) found = dec_lean_data(L.r, bit, slvl, data, crctab);
-									else dec_lean_idle(L.r, bit, sidx);
+									DecReg r1 = r_pre;
+									if (D) found = dec_lean_data(r1, bit, slvl, data, crctab);
+									else dec_lean_idle(r1, bit, sidx);
+									L.r = r1;
 									next_ev = next_event_of(L.r);
 								}
+								F = __ballot(found);
 							}
-							L.r.level = fr ? L.r.level + slvl : L.r.level;
-							L.r.cw = fr ? cw : L.r.cw; L.r.cwi = fr ? L.r.cwi + nw : L.r.cwi; L.r.osc = fr ? ((osc + 1) & (0 - o.Bit)) : L.r.osc;
-							L.r.start_idx = (id && o.to_flag) ? sidx : L.r.start_idx;
-							L.r.state = id ? o.state : L.r.state; L.r.position = fr ? np : (id ? o.pos : L.r.position);
-							L.r.lastBit = special ? L.r.lastBit : o.Bit; L.r.prev = special ? L.r.prev : bit;
-							const unsigned long long F = __ballot(found);
 							if (F != 0) { fnd = found; return first_of(F, g5); }
 						}
 						zf = zfn;
@@ -4263,7 +4268,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 		const DecReg& r = L.r;
 		st->state = r.state; st->lastBit = r.lastBit; st->prev = r.prev; st->position = r.position; st->osc = r.osc;
 		st->level = r.level; st->start_idx = r.start_idx;
-		data[64 * r.cwi] = r.cw;
+		if (r.state == DST_DATAFCS) data[64 * r.cwi] = r.cw; // (outside a frame the frame registers are don't-cares: cwi may point anywhere)
 		for (int w = 0; w < DEC_DATA_WORDS; w++) st->data[w] = data[64 * w];
 		st->crc[0] = r.crc; st->crc[1] = r.cw; st->crc[2] = (uint32_t)r.cwi; st->crc[3] = r.tail; st->crc[4] = (uint32_t)r.abort_pos;
 		if (wave == 0) cs->trk[j] = L.t;
