@@ -893,7 +893,8 @@ def test_model_engine_v2_end_to_end(rate, fmt, block, nblocks):
 
 
 @pytest.mark.parametrize("roles", ["1", "0"])
-@pytest.mark.parametrize("rate,fmt,block,nblocks", [(1536000, "cf32", 131072, 24), (1536000, "cu8", 786432, 4), (768000, "cf32", 65536, 24), (6000000, "cf32", 786432, 4)])
+@pytest.mark.parametrize("rate,fmt,block,nblocks", [(1536000, "cf32", 131072, 24), (1536000, "cu8", 786432, 4), (768000, "cf32", 65536, 24), (6000000, "cf32", 786432, 4),
+                                                    (1536000, "cf32", 16384, 192), (1536000, "cf32", 49152, 64)])  # (one and three engine blocks per call)
 def test_model_engine_v2_on_the_device(rate, fmt, block, nblocks, roles, monkeypatch):
     """AISGPU_FLAG_GPU_DECODE with ModelEngineV2 (round 4): the engine's coherent branch runs on the device too
     (kv2_engine: tone gate / slot lock from the decoders' states, Derotate, FilterFL17, five PhaseTrackers, six decoders with
