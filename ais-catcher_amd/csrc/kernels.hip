@@ -959,16 +959,16 @@ __global__ __launch_bounds__(K1U_T) void k1x_single_channel(K1uParams p) {
 		F[q] = y;
 	}
 	__syncthreads();
-	if (t < M) { // FilterCIC5 (DSP.cpp:132-157)
+	for (int q = t; q < M; q += K1U_T) { // FilterCIC5 (DSP.cpp:132-157)
 		float2 v[6];
 #pragma unroll
-		for (int e = 0; e < 6; e++) v[e] = F[t + e]; // f(m-5 .. m)
+		for (int e = 0; e < 6; e++) v[e] = F[q + e]; // f(m-5 .. m)
 #pragma unroll
 		for (int lvl = 0; lvl < 5; lvl++) {
 #pragma unroll
 			for (int i = 0; i < 5 - lvl; i++) v[i] = cadd(v[i + 1], v[i]);
 		}
-		p.c48[((size_t)rx * p.c48_rows_per_rx) * p.c48_stride + m0 + t] = make_float2(v[0].x * 0.03125f, v[0].y * 0.03125f);
+		p.c48[((size_t)rx * p.c48_rows_per_rx) * p.c48_stride + m0 + q] = make_float2(v[0].x * 0.03125f, v[0].y * 0.03125f);
 	}
 }
 
@@ -5389,10 +5389,14 @@ hipError_t launch_k1u(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
 	return hipGetLastError();
 }
 
+#ifndef K1X_M
+#define K1X_M 512 // 48 kHz outputs per workgroup of the mode-X front end: a whole window (K1U_M = 128 made 786 k workgroups of a 4,096-receiver step)
+#endif
 hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
-	if (npost == 2) K1U_LAUNCH(k1x_single_channel, 2 K1U_COMMA);
-	else if (npost == 1) K1U_LAUNCH(k1x_single_channel, 1 K1U_COMMA);
-	else if (npost == 0) K1U_LAUNCH(k1x_single_channel, 0 K1U_COMMA);
+	const dim3 grid(p.L / K1X_M, n_rx);
+	if (npost == 2) hipLaunchKernelGGL((k1x_single_channel<2, K1X_M>), grid, dim3(K1U_T), 0, s, p);
+	else if (npost == 1) hipLaunchKernelGGL((k1x_single_channel<1, K1X_M>), grid, dim3(K1U_T), 0, s, p);
+	else if (npost == 0) hipLaunchKernelGGL((k1x_single_channel<0, K1X_M>), grid, dim3(K1U_T), 0, s, p);
 	else return hipErrorInvalidValue;
 	return hipGetLastError();
 }
