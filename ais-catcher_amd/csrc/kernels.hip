@@ -1021,8 +1021,8 @@ __global__ __launch_bounds__(K1U_T) void k1k_dsk_frontend(K1kParams p) {
 		DD[ch][jj] = cic5_at(RU[ch], 2 * j - (2 * m0 - 15));
 	}
 	__syncthreads();
-	if (t < 2 * M) { // FilterCIC5 (DSP.cpp:132-157)
-		const int ch = t / M, mm = t % M;
+	for (int q = t; q < 2 * M; q += K1U_T) { // FilterCIC5 (DSP.cpp:132-157)
+		const int ch = q / M, mm = q % M;
 		float2 v[6];
 #pragma unroll
 		for (int e = 0; e < 6; e++) v[e] = DD[ch][mm + e]; // d(m-5 .. m)
@@ -3392,7 +3392,7 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 	if (lane < 16) dero[lane] = cs->carry17[lane];
 	FftTwiddles tw = fft_twiddles(p.omega, lane);
 	const uint32_t* fm_cur = p.fmbits + (size_t)chan * p.fmbits_stride;
-	const uint32_t* fm_old = q.fm_prev + (size_t)chan * 16 - (size_t)(p.L - 512) / 32; // (indexed like fm_cur: word (L - 512) / 32 + l is word l of the previous block's last sixteen)
+	const uint32_t* fm_old = q.fm_prev + (size_t)chan * 16; // the previous block's last sixteen words (kv2_carry's fmtail_out)
 	// sign of the filtered discriminator at sample k of the engine block that is being decoded (the block's sixteen words: LDS)
 	const auto fm_sign = [&](int k) -> int { return (int)((fmw[k >> 5] >> (k & 31)) & 1u); };
 	const auto emit = [&](const DecReg& r, long long sidx, float tag_ppm) {
@@ -3449,7 +3449,7 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 		for (int i = 0; i < 8; i++) dero[16 + i * 64 + lane] = v2_sample(p, chan, n0 + i * 64 + lane);
 		if (lane < 16) { // (n0 is a multiple of 512: whole words; block 0 decodes the previous device block's tail)
 			const int m0 = n0 < 0 ? n0 + p.L : n0;
-			fmw[lane] = (n0 < 0 ? fm_old : fm_cur)[(m0 >> 5) + lane];
+			fmw[lane] = n0 < 0 ? fm_old[lane] : fm_cur[(m0 >> 5) + lane];
 		}
 		wave_sync();
 		// ---- Engine::processBlock (:345-352): slot predictor decay, busy, CGF
@@ -3680,7 +3680,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 	for (int i = threadIdx.x; i < 256; i += 192) dec_crc_table_entry(i, crctab); // (first read behind the first barrier)
 	FftTwiddles tw = fft_twiddles(p.omega, lane);
 	const uint32_t* fm_cur = p.fmbits + (size_t)chan * p.fmbits_stride;
-	const uint32_t* fm_old = q.fm_prev + (size_t)chan * 16 - (size_t)(p.L - 512) / 32; // (indexed like fm_cur: word (L - 512) / 32 + l is its word l)
+	const uint32_t* fm_old = q.fm_prev + (size_t)chan * 16; // the previous block's last sixteen words (kv2_carry's fmtail_out)
 	const auto emit = [&](const DecReg& r, long long sidx, float tag_ppm) {
 		const unsigned slot = atomicAdd(q.frame_count, 1u) % (unsigned)q.max_frames;
 		uint32_t* f = q.frames + (size_t)slot * DEC_FRAME_WORDS;
@@ -3899,7 +3899,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 		{
 			if (fm_wave) {
 				const int m0 = n0 < 0 ? n0 + p.L : n0; // (n0 is a multiple of 512: whole words; block 0 decodes the previous device block's tail)
-				if (lane < 18) fmw2[lane] = lane < 16 ? (n0 < 0 ? fm_old : fm_cur)[(m0 >> 5) + lane] : 0u; // (two words of padding)
+				if (lane < 18) fmw2[lane] = lane < 16 ? (n0 < 0 ? fm_old[lane] : fm_cur[(m0 >> 5) + lane]) : 0u; // (two words of padding)
 				wave_sync();
 			} else slot_ema = make_float2(slot_ema.x * 0.9999f, slot_ema.y * 0.9999f); // slot predictor decay (:345)
 			const int off = (j - di + 5) % 5; // tracker wave: this lane's sample inside a group of five
@@ -5401,8 +5401,11 @@ hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
 	return hipGetLastError();
 }
 
+#ifndef K1K_M
+#define K1K_M 128 // 48 kHz outputs per channel per workgroup of the decimate-by-3 front end
+#endif
 hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s) {
-	K1U_LAUNCH(k1k_dsk_frontend, );
+	hipLaunchKernelGGL((k1k_dsk_frontend<K1K_M>), dim3(p.L / K1K_M, n_rx), dim3(K1U_T), 0, s, p);
 	return hipGetLastError();
 }
 
