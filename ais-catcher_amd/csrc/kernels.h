@@ -354,7 +354,8 @@ struct KV2Params {
 // ModelEngineV2 with AISGPU_FLAG_GPU_DECODE (round 4): the engine's coherent branch on the device as well -- per channel strictly
 // sequential over its 512-sample blocks, like the reference (V2Engine.cpp:293-388): the tone gate / slot lock decide the frequency
 // from the decoders' states, Derotate is an accumulated phasor, the five PhaseTrackers take their loop weight from their decoder's
-// state sample by sample, the six decoders reset each other.  kv2_engine: one wave per channel (round 5) -- Derotate and FilterFL17
+// state sample by sample, the six decoders reset each other.  kv2_engine_roles (round 6, see kernels.hip): three waves per channel.
+// kv2_engine: one wave per channel (round 5) -- Derotate and FilterFL17
 // block-wise with lanes over time, then six lanes (five tracker + decoder lanes and the FM decoder behind its BitPLL) walk the groups
 // of five samples in step, the reference's order inside a group restored only where a message completes.  std::polar of the estimated
 // frequency: glibc's sinf / cosf restated (sin_or_cos_ref); frames out like the other engines' device decoders.
@@ -374,7 +375,8 @@ struct KV2EParams {
 	float w_train, w_track;
 	uint32_t* frames; unsigned* frame_count; int max_frames; unsigned block, sub;
 	int* locked_estimates;     // statistics: Estimate() calls at a learned slot phase (the windows the assist kernels cannot know)
-	int roles;                 // 1: trackers and FM decoder on two waves of a workgroup (round 6); 0: one wave, six lanes in step (test hook "v2_roles")
+	int roles;                 // 1: kv2_engine_roles -- trackers, FM decoder and the next block's front end on three waves of a workgroup (round 6);
+	                           // 0: kv2_engine -- one wave, six lanes in step (round 5; batches of more than 1,024 channels, test hook "v2_roles")
 	float taps17[17];
 };
 #ifdef V2_PROF

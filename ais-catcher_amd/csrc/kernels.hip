@@ -3328,7 +3328,7 @@ __device__ __forceinline__ int v2_track(V2Tracker& t, c2 z, bool training, float
 	return bit;
 }
 // PhaseTracker::Run (:190-223) behind its Rotate90 (:175-188): (zr, zi) is the sample already turned by the tracker's `rot` (kv2_engine's
-// two-wave form turns the block's FilterFL17 outputs where it computes them, lanes over time; t.rot is advanced once per block)
+// three-wave form turns the block's FilterFL17 outputs where it computes them, lanes over time; t.rot is advanced once per block)
 __device__ __forceinline__ int v2_track_pre(V2Tracker& t, float zr, float zi, bool training, float w_train, float w_track) {
 	const float alpha = training ? w_train : w_track;
 	const float beta = 1.0f - alpha;
@@ -4046,12 +4046,14 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 				return kret;
 			};
 			// fm_run: five samples per turn, straight-line, with the PLL gain of the decoder's state in front of the five (the gain only enters
-			// at a sign change); the decoder steps at the sample on which the PLL fires.  Exact when the PLL fires exactly once within the five
-			// and the step does not flip TRAINING <-> not-TRAINING in front of a later sign change of the five; everything else (3-8 % of the
-			// turns) goes through fm_exact.  A wave that is alone on its SIMD pays ~5 cycles per plain vector instruction, ~9 per compare or
-			// scalar instruction and 20-30 per hand-over between the two units (tools/microbench_issue.hip, W = 1): the turn is therefore
-			// written as integer / float arithmetic on vector registers -- masks instead of selects, floor() instead of a compare against 1,
-			// the fired positions summed as powers of two -- with ONE branch for all rare cases.
+			// at a sign change); the decoder steps at the sample on which the PLL fires -- outside a frame as arithmetic on 0 / 1 (idle_arith),
+			// inside one as dec_lean_data's common case.  Exact when the PLL fires exactly once within the five and the step does not flip
+			// TRAINING <-> not-TRAINING in front of a later sign change of the five.  Of the rest (8 % of the turns) the two frequent kinds stay
+			// arithmetic -- no fire (3.9 %: nothing to decode), two fires with both steps clean (3.6 %) --, the others (a frame opens, a rare
+			// symbol inside a frame, a flipped flag in front of a sign change: < 1 %) go through fm_exact.  A wave that is alone on its SIMD
+			// pays 6-9 cycles per instruction of any kind and ~30 more per branch on a vector condition (tools/microbench_lonewave.hip): the
+			// turn is therefore written as integer / float arithmetic on vector registers -- masks instead of selects, floor() / fract()
+			// instead of a compare against 1, the fired positions summed as powers of two -- with ONE branch for all rare cases.
 			const auto fm_run = [&](const int from, const int to, bool& fnd) -> int {
 				fnd = false;
 				float ph = L.pll_phase;
