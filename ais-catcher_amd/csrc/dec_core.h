@@ -172,7 +172,9 @@ DEC_HD uint32_t dec_crc_bits(const uint32_t* data, int count, const uint16_t* ta
 // ------------------------------------------------------------------------------------------
 // The lean pair (round 6, kv2_engine's two-wave form): the same decoder with fewer instructions per symbol.  A decoder that uses them
 // uses them for every symbol: r.crc and r.tail are NOT maintained (the CRC of a frame is formed from its buffer when a closing flag asks
-// for it, byte-wise through `tab`), r.osc is 0 outside DATAFCS (what dec_step leaves there anyway).
+// for it, byte-wise through `tab`), and outside DATAFCS the frame registers (osc, cw, cwi, level, abort_pos) are DON'T-CARES: dec_lean_idle
+// never reads them and clears them where it opens a frame (kv2_engine_roles' tracker wave relies on that: it commits the in-frame
+// arithmetic for every lane).  Whoever stores a decoder must not use cwi as an index unless the decoder is inside a frame.
 //  * dec_lean_idle: a decoder in TRAINING / STARTFLAG; returns 1 when the step opened a frame (the frame registers are cleared).
 //  * dec_lean_data: a decoder in DATAFCS; returns true when a frame with a good CRC has just been completed (as dec_step: position and
 //    level still the frame's).  Everything that is rare -- closing flag, the look-ups at positions 30 / 62, the type's own limit, the
