@@ -145,12 +145,15 @@ int main(int argc, char** argv) {
 				else n_open += dec_lean_idle(b.r, dd, sidx);
 				steps++;
 				const DecReg &x = a.r, &y = b.r;
-				bool bad = fa != fb || x.state != y.state || x.lastBit != y.lastBit || x.prev != y.prev || x.position != y.position || x.osc != y.osc || x.start_idx != y.start_idx;
-				if (x.state == DST_DATAFCS) bad = bad || memcmp(&x.level, &y.level, 4) || x.cw != y.cw || x.cwi != y.cwi || x.abort_pos != y.abort_pos;
+				bool bad = fa != fb || x.state != y.state || x.lastBit != y.lastBit || x.prev != y.prev || x.position != y.position || x.start_idx != y.start_idx;
+				if (x.state == DST_DATAFCS) bad = bad || memcmp(&x.level, &y.level, 4) || x.cw != y.cw || x.cwi != y.cwi || x.abort_pos != y.abort_pos || x.osc != y.osc;
+				else if (!fa) { // outside a frame the lean pair's frame registers are don't-cares (kv2_engine_roles leaves arithmetic garbage there): scribble
+					b.r.osc = rnd(0, 7); b.r.cw = (uint32_t)rng(); b.r.cwi = rnd(0, 1 << 20); b.r.level = (float)rnd(-1000, 1000); b.r.abort_pos = rnd(0, 2000);
+				}
 				if (fa && !bad) for (int w = 0; w < (x.position + 31) / 32; w++) bad = bad || a.data()[DEC_LANES * w] != b.data()[DEC_LANES * w];
 				if (bad) { printf("MISMATCH lean trial %ld symbol %zu (state %d -> %d / %d, position %d / %d, found %d / %d)\n", t, i, st_before, x.state, y.state, x.position, y.position, (int)fa, (int)fb); return 1; }
 				n_abort_ += st_before == DST_DATAFCS && !fa && x.state == DST_TRAINING;
-				if (fa) { n_msg++; a.r.state = b.r.state = DST_TRAINING; a.r.position = b.r.position = 0; a.r.osc = b.r.osc = 0; }
+				if (fa) { n_msg++; a.r.state = b.r.state = DST_TRAINING; a.r.position = b.r.position = 0; a.r.osc = 0; b.r.osc = rnd(0, 7); }
 			}
 		}
 		printf("lean steps %ld, frames opened %ld, messages %ld, frames abandoned %ld: all equal\n", steps, n_open, n_msg, n_abort_);
