@@ -1797,6 +1797,9 @@ int aisgpu_submit_device(aisgpu_t* h, const void* iq_dev, long long rx_stride_sa
 	return AISGPU_OK;
 }
 
+#ifndef ROT_COPY_ON_S3_WITH_DECODERS
+#define ROT_COPY_ON_S3_WITH_DECODERS 1
+#endif
 int aisgpu_run(aisgpu_t* h) {
 	if (!h) return AISGPU_ERR_ARG;
 	if (!h->submitted) return AISGPU_ERR_STATE;
@@ -2003,12 +2006,15 @@ int aisgpu_run(aisgpu_t* h) {
 			// 20-25 us copy kernel between two of them (it reads pinned host memory) was a tenth of BASELINE configs[1]'s 0.219 ms per
 			// block: 0.195-0.203 with the copy on s4, whose kernels of block f-1 also run behind that block's recurrence, so the slot
 			// d_rot[(f+2) & 3] -- last read by the front end of block f-2 -- is free as before.  256 receivers: unchanged (+-0.3 %).
+			// With the frame decoders on the device, one block late on s4 (dec_defer), the copy stays where rounds 2-5 had it: s4 is that
+			// plan's longest stream (measured: bench.py --gpu-decode 20 steps, 375 GS/s with the copy on s4, see profiles/r06_expH).
+			const bool rot_on_s3 = ROT_COPY_ON_S3_WITH_DECODERS && h->gpu_decode && h->dec_defer;
 			while (h->rot_next <= h->block_idx + 2) {
-				if (h->rot_next >= 4) { // (explicitly, for the stream plans in which s4 carries nothing of block f-1: option k46)
+				if (!rot_on_s3 && h->rot_next >= 4) { // (explicitly, for the stream plans in which s4 carries nothing of block f-1: option k46)
 					const int qr = (int)((h->rot_next - 4) % NBUF);
 					WAITEV(h->s4, h->k1_done[qr] ? h->k1_done[qr] : h->ev_search[qr]);
 				}
-				int rc = stage_rot((int)(h->rot_next & 3), h->s4);
+				int rc = stage_rot((int)(h->rot_next & 3), rot_on_s3 ? h->s3 : h->s4);
 				if (rc) return rc;
 				h->rot_next++;
 			}
