@@ -3979,7 +3979,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 							const uint32_t cw = ((L.r.cw & (uint32_t)(nw - 1)) & ~(1u << sh)) | ((uint32_t)o.Bit << sh);
 							const int ev = (int)((uint32_t)((np ^ next_ev) - 1) >> 31); // position == next_ev
 							const bool D = isD != 0;
-							const bool special = dl && (D ? (close | ev) != 0 : o.open != 0);
+							const bool special = dl && ((isD & (close | ev)) | ((isD ^ 1) & o.open)) != 0; // (0 / 1 arithmetic: no lane-dependent branches)
 							if (D && dl) data[DEC_LANES * L.r.cwi] = L.r.cw; // (the word that is being filled, complete when the position moves on)
 							const float slvl = zf.x * zf.x + zf.y * zf.y;
 							// both steps are committed for every lane -- the frame registers of a decoder outside a frame are don't-cares (a
