@@ -154,16 +154,17 @@ DEC_HD void dec_crc_table_entry(int i, uint16_t* tab) { // tab[i]: eight steps o
 }
 
 // CRC register after the frame's first `count` bits (bit p = bit p & 31 of word p >> 5)
+template <int STRIDE = DEC_LANES> // (columns of the frame-buffer tile: kv2_engine_roles keeps eight)
 DEC_HD uint32_t dec_crc_bits(const uint32_t* data, int count, const uint16_t* tab) {
 	uint32_t crc = 0xFFFFu;
 	const int nbytes = count >> 3;
 	for (int k = 0; k < nbytes; k += 4) {
-		const uint32_t w = data[DEC_LANES * (k >> 2)];
+		const uint32_t w = data[STRIDE * (k >> 2)];
 		const int m = nbytes - k < 4 ? nbytes - k : 4;
 		for (int b = 0; b < m; b++) crc = (crc >> 8) ^ tab[(crc ^ (w >> (8 * b))) & 255u];
 	}
 	for (int p = nbytes * 8; p < count; p++) {
-		const uint32_t bit = (data[DEC_LANES * (p >> 5)] >> (p & 31)) & 1u;
+		const uint32_t bit = (data[STRIDE * (p >> 5)] >> (p & 31)) & 1u;
 		crc = ((bit ^ crc) & 1u) ? ((crc >> 1) ^ 0x8408u) : (crc >> 1);
 	}
 	return crc;
@@ -200,6 +201,7 @@ DEC_HD int dec_lean_idle(DecReg& r, int dd, long long sidx) {
 	return open ? 1 : 0;
 }
 
+template <int STRIDE = DEC_LANES>
 DEC_HD bool dec_lean_data(DecReg& r, int dd, float slvl, uint32_t* data, const uint16_t* tab) {
 	const int Bit = dd == r.prev;
 	r.prev = dd;
@@ -209,7 +211,7 @@ DEC_HD bool dec_lean_data(DecReg& r, int dd, float slvl, uint32_t* data, const u
 	const bool close = six && Bit;
 	const int np = (six && !Bit) ? pos : pos + 1; // a stuffed zero does not advance: the next bit overwrites it
 	const int wi = pos >> 5;
-	if (wi != r.cwi) { data[DEC_LANES * r.cwi] = r.cw; r.cw = 0u; r.cwi = wi; }
+	if (wi != r.cwi) { data[STRIDE * r.cwi] = r.cw; r.cw = 0u; r.cwi = wi; }
 	const uint32_t sh = (uint32_t)pos & 31u;
 	if (pos < DEC_MAX_FRAME) r.cw = (r.cw & ~(1u << sh)) | ((uint32_t)Bit << sh);
 	r.level = r.level + slvl;
@@ -218,9 +220,9 @@ DEC_HD bool dec_lean_data(DecReg& r, int dd, float slvl, uint32_t* data, const u
 	if (!(close || np == 30 || np == 62 || np == DEC_MAX_FRAME || np == r.abort_pos)) return false;
 	// ---- the rare rest of the step
 	if (close) {
-		data[DEC_LANES * r.cwi] = r.cw;
+		data[STRIDE * r.cwi] = r.cw;
 		r.osc = 0;
-		if (np - 7 >= 16 && dec_crc_bits(data, np - 7, tab) == (uint32_t)(uint16_t)~0x0F47) return true; // (state, position, level: the frame's)
+		if (np - 7 >= 16 && dec_crc_bits<STRIDE>(data, np - 7, tab) == (uint32_t)(uint16_t)~0x0F47) return true; // (state, position, level: the frame's)
 		r.state = DST_TRAINING; r.position = 0;
 		return false;
 	}

@@ -3624,8 +3624,9 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 // that exact pass.  Everything is the reference's arithmetic in the reference's order.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
-	__shared__ uint32_t fdata[DEC_DATA_WORDS * 64]; // [word][column]: columns 0..4 the trackers' decoders, 5 the FM decoder
-	__shared__ uint32_t fsnap[DEC_DATA_WORDS * 64]; // the frame buffers at the last agreed position
+	constexpr int FS = 8; // columns of the frame-buffer tiles: 0..4 the trackers' decoders, 5 the FM decoder, 6 / 7 where lanes that are no decoder may scribble
+	__shared__ uint32_t fdata[DEC_DATA_WORDS * FS]; // [word][column]
+	__shared__ uint32_t fsnap[DEC_DATA_WORDS * FS]; // the frame buffers at the last agreed position
 	__shared__ __attribute__((aligned(16))) float2 raw[512];                 // wave 2: the block as it came
 	__shared__ __attribute__((aligned(16))) float2 dero2[2][16 + 512 + 2];   // FilterFL17's carry, then the derotated block, per candidate
 	__shared__ __attribute__((aligned(16))) float2 zbuf[3][512 + 8];         // the block's FilterFL17 outputs: being decoded / two candidates for the next block
@@ -3657,7 +3658,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 	const bool fm_wave = wave == V2_FM_WAVE, fe_wave = wave == 3 - V2_FM_WAVE;
 	const bool dl = wave == 0 ? lane < 5 : (fm_wave && lane == 0); // the decoder lanes
 	const int dec = chan * 6 + (fm_wave ? 5 : (dl ? j : 0));
-	uint32_t* data = fdata + (wave == 0 ? lane : (dl ? 5 : 63));
+	uint32_t* data = fdata + (wave == 0 ? (lane < 5 ? lane : 7) : (dl ? 5 : 6));
 	V2ChanState* cs = q.st + chan;
 	V2Lane L;
 	{
@@ -3665,7 +3666,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 		DecReg& r = L.r;
 		r.state = st->state; r.lastBit = st->lastBit; r.prev = st->prev; r.position = st->position; r.osc = st->osc;
 		r.level = st->level; r.start_idx = st->start_idx;
-		if (dl) for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = st->data[w];
+		if (dl) for (int w = 0; w < DEC_DATA_WORDS; w++) data[FS * w] = st->data[w];
 		r.crc = st->crc[0]; r.cw = st->crc[1]; r.cwi = (int)st->crc[2]; r.tail = st->crc[3]; r.abort_pos = (int)st->crc[4];
 		L.t = cs->trk[j < 5 ? j : 0];
 		L.pll_phase = cs->pll_phase; L.pll_last = cs->pll_last;
@@ -3688,7 +3689,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 		f[4] = (uint32_t)(unsigned long long)r.start_idx; f[5] = (uint32_t)((unsigned long long)r.start_idx >> 32);
 		f[6] = (uint32_t)(unsigned long long)sidx; f[7] = (uint32_t)((unsigned long long)sidx >> 32);
 		f[8] = q.block; f[9] = q.sub;
-		for (int w = 0; w < DEC_DATA_WORDS; w++) f[10 + w] = data[64 * w];
+		for (int w = 0; w < DEC_DATA_WORDS; w++) f[10 + w] = data[FS * w];
 	};
 	const auto learn_slot = [&](long long start_idx) { // learnSlotPhase (:328-337), every lane of wave 0 alike
 		const long long a = start_idx - 155;
@@ -3918,7 +3919,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 				if (dl && my_k >= from && my_k < to) {
 					const float2 zf = zb[my_k];
 					const int bit = v2_track_pre(L.t, zf.x, zf.y, L.r.state == DST_TRAINING, q.w_train, q.w_track);
-					if (L.r.state == DST_DATAFCS) found = dec_lean_data(L.r, bit, zf.x * zf.x + zf.y * zf.y, data, crctab);
+					if (L.r.state == DST_DATAFCS) found = dec_lean_data<FS>(L.r, bit, zf.x * zf.x + zf.y * zf.y, data, crctab);
 					else dec_lean_idle(L.r, bit, sample_idx + my_k);
 				}
 				const unsigned long long F = __ballot(found);
@@ -3980,7 +3981,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 							const int ev = (int)((uint32_t)((np ^ next_ev) - 1) >> 31); // position == next_ev
 							const bool D = isD != 0;
 							const bool special = dl && ((isD & (close | ev)) | ((isD ^ 1) & o.open)) != 0; // (0 / 1 arithmetic: no lane-dependent branches)
-							if (D && dl) data[DEC_LANES * L.r.cwi] = L.r.cw; // (the word that is being filled, complete when the position moves on)
+							if (D && dl) data[FS * L.r.cwi] = L.r.cw; // (the word that is being filled, complete when the position moves on)
 							const float slvl = zf.x * zf.x + zf.y * zf.y;
 							// both steps are committed for every lane -- the frame registers of a decoder outside a frame are don't-cares (a
 							// frame that opens clears them) -- and a lane whose symbol is one of the rare ones redoes it from the state it had
@@ -3995,7 +3996,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 							if (__ballot(special) != 0) {
 								if (special) {
 									DecReg r1 = r_pre;
-									if (D) found = dec_lean_data(r1, bit, slvl, data, crctab);
+									if (D) found = dec_lean_data<FS>(r1, bit, slvl, data, crctab);
 									else dec_lean_idle(r1, bit, sidx);
 									L.r = r1;
 									next_ev = next_event_of(L.r);
@@ -4036,7 +4037,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 						bool found = false;
 						if (__builtin_amdgcn_readfirstlane(L.r.state) == DST_DATAFCS) {
 							const float2 zq = zb[k];
-							found = dec_lean_data(L.r, b, zq.x * zq.x + zq.y * zq.y, data, crctab);
+							found = dec_lean_data<FS>(L.r, b, zq.x * zq.x + zq.y * zq.y, data, crctab);
 						} else dec_lean_idle(L.r, b, sample_idx + k);
 						gainb = L.r.state == DST_TRAINING ? 0x3F19999Au : 0x3D4CCCCDu;
 						if (__builtin_amdgcn_readfirstlane((int)found) != 0) { fnd = found; kret = k; break; }
@@ -4106,7 +4107,7 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 						const int close = six & Bit, stuffed = six & (Bit ^ 1);
 						const int np = pos + 1 - stuffed;
 						const int nw = (pos >> 5) - L.r.cwi; // 1: the position has moved on to the next word
-						data[DEC_LANES * L.r.cwi] = L.r.cw;  // (every turn: the word that is being filled, complete when the position moves on)
+						data[FS * L.r.cwi] = L.r.cw;  // (every turn: the word that is being filled, complete when the position moves on)
 						const uint32_t sh = (uint32_t)pos & 31u;
 						const uint32_t cw = ((L.r.cw & (uint32_t)(nw - 1)) & ~(1u << sh)) | ((uint32_t)Bit << sh);
 						const float2 zq = zb[(k + s1) & 511];
@@ -4171,11 +4172,11 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 			const auto snapshot = [&]() {
 				S = L;
 				snap_cols = __ballot(dl && L.r.state == DST_DATAFCS) != 0; // (a decoder that is not inside a frame has nothing in its buffer)
-				if (snap_cols && dl) for (int w = 0; w < DEC_DATA_WORDS; w++) snapc[64 * w] = data[64 * w];
+				if (snap_cols && dl) for (int w = 0; w < DEC_DATA_WORDS; w++) snapc[FS * w] = data[FS * w];
 			};
 			const auto restore = [&]() {
 				L = S;
-				if (snap_cols && dl) for (int w = 0; w < DEC_DATA_WORDS; w++) data[64 * w] = snapc[64 * w];
+				if (snap_cols && dl) for (int w = 0; w < DEC_DATA_WORDS; w++) data[FS * w] = snapc[FS * w];
 			};
 			snapshot();
 			// the reference's order for samples [from, to), group by group / sample by sample (only behind a completed message)
@@ -4270,8 +4271,8 @@ __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
 		const DecReg& r = L.r;
 		st->state = r.state; st->lastBit = r.lastBit; st->prev = r.prev; st->position = r.position; st->osc = r.osc;
 		st->level = r.level; st->start_idx = r.start_idx;
-		if (r.state == DST_DATAFCS) data[64 * r.cwi] = r.cw; // (outside a frame the frame registers are don't-cares: cwi may point anywhere)
-		for (int w = 0; w < DEC_DATA_WORDS; w++) st->data[w] = data[64 * w];
+		if (r.state == DST_DATAFCS) data[FS * r.cwi] = r.cw; // (outside a frame the frame registers are don't-cares: cwi may point anywhere)
+		for (int w = 0; w < DEC_DATA_WORDS; w++) st->data[w] = data[FS * w];
 		st->crc[0] = r.crc; st->crc[1] = r.cw; st->crc[2] = (uint32_t)r.cwi; st->crc[3] = r.tail; st->crc[4] = (uint32_t)r.abort_pos;
 		if (wave == 0) cs->trk[j] = L.t;
 		if (fm_wave) { cs->pll_phase = L.pll_phase; cs->pll_last = L.pll_last; }
