@@ -1630,10 +1630,11 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 	HIPCHK(dalloc(&h->d_psflag, 4));
 	if (cfg->flags & AISGPU_FLAG_TAPS) HIPCHK(dalloc(&h->d_firtap, C * (8 + h->L)));
 	if (h->v2) {
-		// kv2_engine_roles (three waves per channel, 50 KB of LDS each) while a launch's workgroups are resident in at most two rounds;
-		// bigger batches fill the chip with round 5's one-wave kernel (measured, distinct receivers: 64 rx 22 / 9 GS/s, 256 66 / 32,
-		// 512 68 / 53, 1,024 69 / 90; profiles/r06_expG_v2_engine.txt).  Test hook "v2_roles" = 0 / 1 forces one of them.
-		h->v2_roles = opt_int("v2_roles", h->n_chan <= 1024 ? 1 : 0);
+		// kv2_engine_roles: three waves per channel.  Up to 512 channels every wave has a SIMD of its own and the kernel runs as it compiles
+		// (217 registers, two waves per SIMD: 1); bigger batches run the instance compiled for 168 registers (three waves per SIMD, four
+		// workgroups of 35 KB of LDS per CU: 2) -- 256 distinct receivers 75.1 / 73.6 GS/s, 512: 77.2 / 80.6, 1,024: 76.5 / 96.2 (round 5's
+		// one-wave kernel: 32 / 53 / 90; profiles/r06_expG_v2_engine.txt).  Test hook "v2_roles" = 0 / 1 / 2 forces one of the three.
+		h->v2_roles = opt_int("v2_roles", h->n_chan <= 512 ? 1 : 2);
 		// With the engine on the device (AISGPU_FLAG_GPU_DECODE) nothing but frames goes to the host: no pinned slots for the channels,
 		// the estimates, the energies or the discriminator signs (several GB at 2,048 receivers), and aisgpu_fetch_sub() returns NULL for them.
 		const bool v2_host = !h->gpu_decode;

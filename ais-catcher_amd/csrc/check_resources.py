@@ -18,7 +18,9 @@ BUDGET = [
     ("k6_window_fir", 64, 0),
     ("k2_cgf_phasor_ck_pairs", 128, 0),
     ("k1u_resample_frontend", 128, 0),
-    ("kv2_engine", 256, 0),           # (kv2_engine: one wave per channel; kv2_engine_roles: three)
+    ("kv2_engine_rolesE", 256, 0),       # three waves per channel, as it compiles (two waves per SIMD)
+    ("kv2_engine_roles_dense", 168, 128), # the same under 168 registers (three waves per SIMD; measured with its 112 bytes of scratch)
+    ("kv2_engineE", 256, 0),           # (kv2_engine: one wave per channel; kv2_engine_roles: three)
 ]
 
 

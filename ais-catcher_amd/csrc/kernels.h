@@ -376,7 +376,8 @@ struct KV2EParams {
 	uint32_t* frames; unsigned* frame_count; int max_frames; unsigned block, sub;
 	int* locked_estimates;     // statistics: Estimate() calls at a learned slot phase (the windows the assist kernels cannot know)
 	int roles;                 // 1: kv2_engine_roles -- trackers, FM decoder and the next block's front end on three waves of a workgroup (round 6);
-	                           // 0: kv2_engine -- one wave, six lanes in step (round 5; batches of more than 1,024 channels, test hook "v2_roles")
+	                           // 2: the same kernel compiled for 168 registers (three waves per SIMD: batches of more than 512 channels);
+	                           // 0: kv2_engine -- one wave, six lanes in step (round 5; test hook "v2_roles")
 	float taps17[17];
 };
 #ifdef V2_PROF

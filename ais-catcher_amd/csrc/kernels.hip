@@ -3623,666 +3623,13 @@ __global__ __launch_bounds__(64) void kv2_engine(KV2EParams q) {
 // learnSlotPhase, all six reset; then the FM decoder), and speculate on from k* + 1.  Completed messages leave the kernel only from
 // that exact pass.  Everything is the reference's arithmetic in the reference's order.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q) {
-	constexpr int FS = 8; // columns of the frame-buffer tiles: 0..4 the trackers' decoders, 5 the FM decoder, 6 / 7 where lanes that are no decoder may scribble
-	__shared__ uint32_t fdata[DEC_DATA_WORDS * FS]; // [word][column]
-	__shared__ uint32_t fsnap[DEC_DATA_WORDS * FS]; // the frame buffers at the last agreed position
-	__shared__ __attribute__((aligned(16))) float2 raw[512];                 // wave 2: the block as it came
-	__shared__ __attribute__((aligned(16))) float2 dero2[2][16 + 512 + 2];   // FilterFL17's carry, then the derotated block, per candidate
-	__shared__ __attribute__((aligned(16))) float2 zbuf[3][512 + 8];         // the block's FilterFL17 outputs: being decoded / two candidates for the next block
-	__shared__ __attribute__((aligned(16))) float2 X[584];                   // Estimate()'s exchange space (a slot starts inside the block)
-	__shared__ __attribute__((aligned(16))) float mag[512 + 8];
-	__shared__ __attribute__((aligned(8))) uint32_t fmw2[18];
-	__shared__ uint16_t crctab[256];
-	__shared__ int kx[2][4];         // by exchange parity: first completed message of wave 0 / wave 1, busy, "a tracker's decoder completed one in this block"
-	__shared__ float sh_ppm[3], sh_ppm_prev[3]; // per zbuf slot: what the decoders' tags need
-	__shared__ int sh_split[3];
-	__shared__ int sh_nc[2];         // by block parity: candidates wave 2 prepared for the next block
-	__shared__ float2 sh_slot_ema[2]; // by block parity: the slot predictor after a learnSlotPhase (wave 0 -> the others)
-	__shared__ int sh_slot_phase[2];
-	int blk_now = 0;                 // (wave 0 / 1: the block being decoded)
-	const KV2Params& p = q.k;
-#ifdef V2_PROF
-	const unsigned long long v2p_k0 = __builtin_readcyclecounter();
-	if (threadIdx.x < 2 && blockIdx.x < 1024) v2_prof_wg[blockIdx.x][threadIdx.x] = 0;
-#endif
-	__builtin_amdgcn_s_setprio(3); // (every wave here is one long dependent chain: it must issue the moment it can, the throughput kernels beside it fill the gaps)
-	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const int lane = threadIdx.x & 63, j = lane;
-	const int chan = blockIdx.x;
-#ifndef V2_FM_WAVE
-#define V2_FM_WAVE 2
-#endif
-	// (which wave takes which role: with two workgroups per CU and the waves dealt round-robin to the four SIMDs -- 0 1 2 | 3 0 1 -- the
-	// order trackers, front end, FM decoder puts every decoder wave beside at most the light front-end wave of the other workgroup)
-	const bool fm_wave = wave == V2_FM_WAVE, fe_wave = wave == 3 - V2_FM_WAVE;
-	const bool dl = wave == 0 ? lane < 5 : (fm_wave && lane == 0); // the decoder lanes
-	const int dec = chan * 6 + (fm_wave ? 5 : (dl ? j : 0));
-	uint32_t* data = fdata + (wave == 0 ? (lane < 5 ? lane : 7) : (dl ? 5 : 6));
-	V2ChanState* cs = q.st + chan;
-	V2Lane L;
-	{
-		const DecState* st = q.dec + dec;
-		DecReg& r = L.r;
-		r.state = st->state; r.lastBit = st->lastBit; r.prev = st->prev; r.position = st->position; r.osc = st->osc;
-		r.level = st->level; r.start_idx = st->start_idx;
-		if (dl) for (int w = 0; w < DEC_DATA_WORDS; w++) data[FS * w] = st->data[w];
-		r.crc = st->crc[0]; r.cw = st->crc[1]; r.cwi = (int)st->crc[2]; r.tail = st->crc[3]; r.abort_pos = (int)st->crc[4];
-		L.t = cs->trk[j < 5 ? j : 0];
-		L.pll_phase = cs->pll_phase; L.pll_last = cs->pll_last;
-	}
-	float2 rot = cs->rot, slot_ema = cs->slot_ema; // (rot, last_f, ppm, ppm_prev: wave 2's; slot_ema / slot_phase: wave 0's, wave 2 follows them)
-	float last_f = cs->last_f, ppm = cs->ppm, ppm_prev = cs->ppm_prev;
-	int slot_phase = cs->slot_phase, di = cs->di;
-	long long sample_idx = cs->sample_idx;
-	// wave 2's view of the five trackers' Rotate90 counters at the start of a block (two bits each)
-	int rots = (int)(cs->trk[0].rot & 3u) | (int)(cs->trk[1].rot & 3u) << 2 | (int)(cs->trk[2].rot & 3u) << 4 | (int)(cs->trk[3].rot & 3u) << 6 | (int)(cs->trk[4].rot & 3u) << 8;
-	if (fe_wave && lane < 16) { dero2[0][lane] = cs->carry17[lane]; dero2[1][lane] = cs->carry17[lane]; }
-	for (int i = threadIdx.x; i < 256; i += 192) dec_crc_table_entry(i, crctab); // (first read behind the first barrier)
-	FftTwiddles tw = fft_twiddles(p.omega, lane);
-	const uint32_t* fm_cur = p.fmbits + (size_t)chan * p.fmbits_stride;
-	const uint32_t* fm_old = q.fm_prev + (size_t)chan * 16; // the previous block's last sixteen words (kv2_carry's fmtail_out)
-	const auto emit = [&](const DecReg& r, long long sidx, float tag_ppm) {
-		const unsigned slot = atomicAdd(q.frame_count, 1u) % (unsigned)q.max_frames;
-		uint32_t* f = q.frames + (size_t)slot * DEC_FRAME_WORDS;
-		f[0] = (uint32_t)dec; f[1] = __float_as_uint(tag_ppm); f[2] = (uint32_t)r.position; f[3] = __float_as_uint(r.level);
-		f[4] = (uint32_t)(unsigned long long)r.start_idx; f[5] = (uint32_t)((unsigned long long)r.start_idx >> 32);
-		f[6] = (uint32_t)(unsigned long long)sidx; f[7] = (uint32_t)((unsigned long long)sidx >> 32);
-		f[8] = q.block; f[9] = q.sub;
-		for (int w = 0; w < DEC_DATA_WORDS; w++) f[10 + w] = data[FS * w];
-	};
-	const auto learn_slot = [&](long long start_idx) { // learnSlotPhase (:328-337), every lane of wave 0 alike
-		const long long a = start_idx - 155;
-		const int m = (int)((a % 1280 + 1280) % 1280);
-		const float2 csv = q.slot_cs[m];
-		slot_ema = make_float2((1.0f - 0.2f) * slot_ema.x + 0.2f * csv.x, (1.0f - 0.2f) * slot_ema.y + 0.2f * csv.y);
-		const float ph = atan2f_ref(slot_ema.y, slot_ema.x) * (1280.0f / (2.0f * 3.14159265358979323846f));
-		slot_phase = (int)(ph + 1280.0f + 0.5f) % 1280;
-		if (lane == 0) { sh_slot_ema[blk_now & 1] = slot_ema; sh_slot_phase[blk_now & 1] = slot_phase; }
-	};
-	// A tracker's decoder completed a message in block b (learnSlotPhase moved the slot predictor): is what wave 2 prepared for block b + 1
-	// still that block?  CGF consults the predictor for one thing: "locked, and a slot starts inside the block, at sample e" (:297-311).  Where
-	// the answer is what it was when the block was prepared (no such slot then and now, or the same e), the preparation stands.  Every
-	// wave asks alike; e_spec: the preparation's e, -1 without one.
-	const auto still_valid = [&](const int b, const long long sidx_next, const int e_spec) -> bool {
-		const float2 se_new = sh_slot_ema[b & 1];
-		const float2 se = make_float2(se_new.x * 0.9999f, se_new.y * 0.9999f);
-		const bool locked = se.x * se.x + se.y * se.y >= 0.64f;
-		const int e_slot = (int)((((long long)sh_slot_phase[b & 1] - sidx_next) % 1280 + 1280) % 1280);
-		return ((locked && e_slot < 512) ? e_slot : -1) == e_spec;
-	};
-	// ---- wave 2 ----------------------------------------------------------------------------
-	// FreqOffset::Derotate (:133-146) over samples [from, to) of the staged block into a candidate's buffer: lane l owns samples from + 8 l .. + 7
-	const auto derotate = [&](const float f, const int from, const int to, float2& rt, float2* dst) {
-		const float th = f * 2.0f * 3.14159265358979323846f; // std::polar(1.0f, f * 2.0f * PI): (rho * cos(theta), rho * sin(theta))
-		const float sn = 1.0f * sin_or_cos_ref(th, 0), cn = 1.0f * sin_or_cos_ref(th, 1);
-		const c2 st = { cn, sn }, st_sw = { -sn, cn };
-		c2 r = { rt.x, rt.y }, mine = r;
-		const int n = to - from;
-		for (int c = 0; c * 8 < n; c++) { // the state in front of sample from + 8 c: lane c's
-			if (c == lane) mine = r;
-			const int m = n - c * 8 < 8 ? n - c * 8 : 8;
-			if (m == 8) {
-#pragma unroll
-				for (int i = 0; i < 8; i++) r = r.xx * st + r.yy * st_sw; // r *= rot_step
-			} else {
-				for (int i = 0; i < m; i++) r = r.xx * st + r.yy * st_sw;
-			}
-		}
-		const float2* sp = &raw[from + 8 * lane];
-		float2* d = &dst[16 + from + 8 * lane];
-#pragma unroll
-		for (int i = 0; i < 8; i++) {
-			if (8 * lane + i < n) {
-				const float2 x = sp[i];
-				mine = mine.xx * st + mine.yy * st_sw;
-				d[i] = make_float2(x.x * mine.x - x.y * mine.y, x.x * mine.y + x.y * mine.x); // src * r
-			}
-		}
-		const float a = hypot_ref(r.x, r.y);
-		rt = make_float2(__fdiv_rn(r.x, a), __fdiv_rn(r.y, a));
-	};
-	// FilterFL17 (:154-167) of a candidate: output k from carry + block samples k .. k + 16, stored turned by the Rotate90 (:175-188) of the
-	// tracker that will take it (tracker (di + k) % 5, as its k / 5-th sample of the block): swaps and sign changes, |z|^2 keeps its bits
-	const auto filter17 = [&](const float2* de, float2* zo) {
-#pragma unroll
-		for (int i = 0; i < 8; i++) {
-			const c2 z = v2_dot17(&de[i * 64 + lane], q.taps17);
-			const int k = i * 64 + lane;
-			const unsigned rq = (unsigned)((rots >> (2 * ((di + k) % 5))) + k / 5) & 3u;
-			const float sre = (rq & 1u) ? z.y : z.x, sim = (rq & 1u) ? z.x : z.y;
-			zo[k] = make_float2(((rq ^ (rq >> 1)) & 1u) ? -sre : sre, (rq & 2u) ? -sim : sim);
-		}
-	};
-	float cand_f0 = 0.0f, cand_f1 = 0.0f, cand_ppm0 = 0.0f, cand_ppm1 = 0.0f; // (scalars, not arrays: no scratch)
-	float2 cand_rot0 = rot, cand_rot1 = rot, cand_se = slot_ema;
-	int cand_locked = 0, cand_e = -1; // the prepared block went through the learned-slot path, with the slot at sample cand_e
-	// Engine::processBlock (:345-352) up to coh_filtered for block blk, from wave 2's state (rot, last_f, slot_ema / slot_phase as of the end
-	// of the block before, sample_idx / di / rots of block blk).  mode 0 / 1: busy is known; 2: prepare both answers where they differ.
-	// Candidate c goes to dero2[c] and zbuf[slot_c]; returns the number of candidates.
-	const auto front = [&](const int blk, const int mode, const int slot0, const int slot1) -> int {
-		const int n0 = -V2_HIST + 512 * blk; // the decoded block; [n0 + 512, n0 + 1024) is the look-ahead
-#pragma unroll
-		for (int i = 0; i < 8; i++) raw[i * 64 + lane] = v2_sample(p, chan, n0 + i * 64 + lane);
-		wave_sync();
-		cand_se = make_float2(slot_ema.x * 0.9999f, slot_ema.y * 0.9999f); // slot predictor decay
-		const bool locked = cand_se.x * cand_se.x + cand_se.y * cand_se.y >= 0.64f;
-		const int e_slot = (int)((((long long)slot_phase - sample_idx) % 1280 + 1280) % 1280);
-		int nc = 1, split = 0;
-		cand_locked = locked && e_slot < 512 ? 1 : 0;
-		// a slot starts inside this block (cand_locked): [0, e) keeps the previous frequency, Estimate() works on the 512 samples from e on --
-		// a window the assist kernels did not compute: FFT by the wave, the sequential search by one lane; busy does not enter.  Otherwise
-		// the frequency is the estimate of the window midWins picks (!busy, :312-314) or the tone gate's choice (busy): two candidates
-		// where they differ.  The derotations are jobs of one loop (one copy of the code, sinf / cosf included).
-		cand_e = cand_locked ? e_slot : -1;
-		if (cand_locked) split = e_slot;
-		else {
-			const float* en = p.energy + (size_t)chan * (p.n_windows + 1);
-			const bool louder = en[blk + 1] > en[blk];
-			const float* ef = p.est_f + (size_t)chan * 2 * p.n_windows + 2 * blk;
-			const float f_idle = ef[louder ? 1 : 0];
-			const float f_busy = p.est_prom[(size_t)chan * 2 * p.n_windows + 2 * blk] < 5.5f ? last_f : ef[0]; // tone gate: hold while a decode is in flight
-			cand_f0 = mode == 1 ? f_busy : f_idle;
-			if (mode == 2 && __float_as_uint(f_busy) != __float_as_uint(f_idle)) { cand_f1 = f_busy; nc = 2; }
-		}
-		{
-			float2 rt = rot;
-#pragma unroll 1
-			for (int job = 0; job < 2; job++) {
-				float f; int from, to, c;
-				if (cand_locked) {
-					if (job == 0) { f = last_f; from = 0; to = split; c = 0; } // (also for e == 0: the renormalisation happens)
-					else {
-						v2_fft_mag_window(p, chan, n0 + split, X, mag, tw, lane);
-						wave_sync();
-						float fs = 0.0f;
-						if (lane == 0) { float prom; v2_search(mag, fs, prom); }
-						f = __shfl(fs, 0);
-						wave_sync();
-						cand_f0 = f; from = split; to = 512; c = 0;
-					}
-				} else {
-					if (job == 1 && nc == 1) break;
-					f = job ? cand_f1 : cand_f0; from = 0; to = 512; c = job; rt = rot;
-				}
-				derotate(f, from, to, rt, dero2[c]);
-				if (c == 0) cand_rot0 = rt; else cand_rot1 = rt;
-			}
-		}
-		wave_sync();
-		filter17(dero2[0], zbuf[slot0]);
-		cand_ppm0 = __fdiv_rn(cand_f0 * 48000.0f, 162.0f);
-		if (lane == 0) { sh_ppm[slot0] = cand_ppm0; sh_ppm_prev[slot0] = ppm; sh_split[slot0] = split; }
-		if (nc == 2) {
-			filter17(dero2[1], zbuf[slot1]);
-			cand_ppm1 = __fdiv_rn(cand_f1 * 48000.0f, 162.0f);
-			if (lane == 0) { sh_ppm[slot1] = cand_ppm1; sh_ppm_prev[slot1] = ppm; sh_split[slot1] = split; }
-		}
-		wave_sync();
-		return nc;
-	};
-	// the decoders arrived at the block: candidate sel is the block
-	const auto adopt = [&](const int sel) {
-		rot = sel ? cand_rot1 : cand_rot0; last_f = sel ? cand_f1 : cand_f0; ppm_prev = ppm; ppm = sel ? cand_ppm1 : cand_ppm0; slot_ema = cand_se;
-		if (cand_locked && lane == 0 && q.locked_estimates) atomicAdd(q.locked_estimates, 1);
-		if (lane < 16) { const float2 cy = dero2[sel][512 + lane]; dero2[0][lane] = cy; dero2[1][lane] = cy; } // FilterFL17's carry
-		wave_sync();
-	};
-
-	// ---- block 0 in the open: busy from the trackers' decoders as they came
-	if (wave == 0) {
-		const int busy0 = __ballot(dl && L.r.state != DST_TRAINING) != 0 ? 1 : 0;
-		if (lane == 0) kx[1][2] = busy0;
-	}
-	__syncthreads();
-	int cur = 0, xi = 0;
-	if (fe_wave) {
-		// ---- wave 2: block 0 in the open, then always the NEXT block for both answers while the others decode; one call site of front()
-		// (its code -- sinf / cosf, the FFT, the search -- exists once: the kernel must fit the instruction cache it shares)
-		int blk = -1, mode = kx[1][2] ? 1 : 0, s0 = 0, s1 = 0; // blk: the block the others are decoding (-1: none yet)
-		bool redo = false;
-#pragma unroll 1
-		for (;;) {
-			const int nc = front(blk + 1, mode, s0, s1);
-			if (blk < 0 || redo) { // prepared in the open: the others wait
-				adopt(0);
-				__syncthreads();
-				cur = blk < 0 ? 0 : (cur + 1) % 3;
-				blk++;
-				redo = false;
-			} else {
-				if (lane == 0) sh_nc[blk & 1] = nc | ((cand_e + 1) << 2);
-				int busy = 0, lrn = 0;
-#pragma unroll 1
-				for (;;) { // the others' exchanges of block blk
-					__syncthreads();
-					const int kc = __builtin_amdgcn_readfirstlane(kx[xi & 1][0]), kf = __builtin_amdgcn_readfirstlane(kx[xi & 1][1]);
-					busy = __builtin_amdgcn_readfirstlane(kx[xi & 1][2]); lrn = __builtin_amdgcn_readfirstlane(kx[xi & 1][3]);
-					xi++;
-					if (kc == 512 && kf == 512) break;
-				}
-				if (lrn) { // the slot predictor moved
-					slot_ema = sh_slot_ema[blk & 1]; slot_phase = sh_slot_phase[blk & 1];
-					if (!still_valid(blk, sample_idx, cand_e)) { // the block is prepared again, in the open
-						mode = busy ? 1 : 0; s0 = s1 = (cur + 1) % 3; redo = true;
-						continue;
-					}
-					cand_se = make_float2(slot_ema.x * 0.9999f, slot_ema.y * 0.9999f); // (what front() would have decayed)
-				}
-				const int sel = (nc == 2 && busy) ? 1 : 0;
-				adopt(sel);
-				cur = (cur + 1 + sel) % 3;
-				blk++;
-			}
-			// the others decode block blk now
-			if (blk + 1 >= p.n_windows) { // nothing left to prepare: wait for the last block's exchanges
-#pragma unroll 1
-				for (;;) {
-					__syncthreads();
-					const int kc = __builtin_amdgcn_readfirstlane(kx[xi & 1][0]), kf = __builtin_amdgcn_readfirstlane(kx[xi & 1][1]);
-					xi++;
-					if (kc == 512 && kf == 512) break;
-				}
-				break;
-			}
-			sample_idx += 512; // (this wave's clock: the block it prepares)
-			{ int r2 = 0; for (int t = 0; t < 5; t++) r2 |= ((((rots >> (2 * t)) & 3) + (512 - (t - di + 5) % 5 + 4) / 5) & 3) << (2 * t); rots = r2; }
-			di = (di + 512) % 5;
-			mode = 2; s0 = (cur + 1) % 3; s1 = (cur + 2) % 3;
-		}
-	} else {
-	__syncthreads(); // (block 0 is there)
-	for (int blk = 0; blk < p.n_windows; blk++) {
-		const int n0 = -V2_HIST + 512 * blk;
-		const float2* const zb = zbuf[cur];
-		blk_now = blk;
-		int learned = 0; // wave 0: a tracker's decoder completed a message in this block (the slot predictor moved)
-		{
-			if (fm_wave) {
-				const int m0 = n0 < 0 ? n0 + p.L : n0; // (n0 is a multiple of 512: whole words; block 0 decodes the previous device block's tail)
-				if (lane < 18) fmw2[lane] = lane < 16 ? (n0 < 0 ? fm_old[lane] : fm_cur[(m0 >> 5) + lane]) : 0u; // (two words of padding)
-				wave_sync();
-			} else slot_ema = make_float2(slot_ema.x * 0.9999f, slot_ema.y * 0.9999f); // slot predictor decay (:345)
-			const int off = (j - di + 5) % 5; // tracker wave: this lane's sample inside a group of five
-			const float ppm_b = sh_ppm[cur], ppm_prev_b = sh_ppm_prev[cur];
-			const int split_b = sh_split[cur];
-			// ---- tracker wave: samples [from, to) of the block, a group of five per turn, every lane its own sample of the group; stops
-			// behind the first group in which a decoder completed a message and returns that sample (512: none).  The decoder is the lean
-			// pair of dec_core.h; whole groups need no lane predicate and ask for their samples a turn ahead.
-			const auto first_of = [&](const unsigned long long F, const int g5) -> int { // the earliest sample of the group among the lanes of F
-				for (int o = 0; o < 4; o++) if ((F >> ((o + di) % 5)) & 1ull) return g5 + o;
-				return g5 + 4;
-			};
-			const auto coh_group = [&](const int g5, const int from, const int to, bool& fnd) -> int { // any group; -1: no message completed
-				const int my_k = g5 + off;
-				bool found = false;
-				if (dl && my_k >= from && my_k < to) {
-					const float2 zf = zb[my_k];
-					const int bit = v2_track_pre(L.t, zf.x, zf.y, L.r.state == DST_TRAINING, q.w_train, q.w_track);
-					if (L.r.state == DST_DATAFCS) found = dec_lean_data<FS>(L.r, bit, zf.x * zf.x + zf.y * zf.y, data, crctab);
-					else dec_lean_idle(L.r, bit, sample_idx + my_k);
-				}
-				const unsigned long long F = __ballot(found);
-				if (F == 0) return -1;
-				fnd = found;
-				return first_of(F, g5);
-			};
-			// dec_lean_idle as arithmetic on 0 / 1: m = 0 in TRAINING, 1 in STARTFLAG; the step's new state (0 / 1; `open`: it opened a frame instead)
-			struct IdleStep { int state, pos, Bit, to_flag, open; };
-			const auto idle_arith = [&](const int m, const int pos, const int lastBit, const int prev, const int b) -> IdleStep {
-				const int Bit = (b ^ prev) ^ 1;
-				const int alt = Bit ^ lastBit;
-				const int gt4 = (int)((uint32_t)(4 - pos) >> 31);        // position > 4
-				const int at7 = (int)((uint32_t)((pos ^ 7) - 1) >> 31);  // position == 7
-				const int isT = m ^ 1;
-				const int to_flag = isT & (alt ^ 1) & gt4;
-				const int open = m & at7 & (Bit ^ 1);
-				const int more = m & (at7 ^ 1) & Bit;
-				const int grow = (isT & alt) | more;
-				return IdleStep{ to_flag | more, (grow ? pos + 1 : 0) + (to_flag ? 1 + 2 * Bit : 0), Bit, to_flag, open };
-			};
-			const auto next_event_of = [&](const DecReg& r) -> int { // the next position at which a frame's step is not its common case
-				return r.position < 30 ? 30 : r.position < 62 ? 62 : (r.abort_pos > r.position ? r.abort_pos : DEC_MAX_FRAME);
-			};
-			// whole groups: both decoder steps -- TRAINING / STARTFLAG (idle_arith) and DATAFCS (dec_lean_data's common case) -- as arithmetic on
-			// vector registers, chosen per lane; a lane whose symbol is one of the rare ones (a frame opens; closing flag, look-ups at positions
-			// 30 / 62, the type's own limit, the maximum length) takes the lean pair's own code for that symbol
-			const auto coh_run = [&](const int from, const int to, bool& fnd) -> int {
-				fnd = false;
-				int g5 = from - from % 5;
-				if (g5 < from) {
-					const int kf = coh_group(g5, from, to, fnd);
-					if (kf >= 0) return kf;
-					g5 += 5;
-				}
-				if (g5 + 5 <= to) {
-					float2 zf = zb[dl ? g5 + off : 0];
-					int next_ev = next_event_of(L.r);
-#pragma unroll 1
-					for (; g5 + 5 <= to; g5 += 5) {
-						const float2 zfn = zb[dl ? g5 + 5 + off : 0]; // (the next group's sample: the wave has nothing else to cover LDS latency with)
-						const int st0 = L.r.state;
-						const int bit = v2_track_pre(L.t, zf.x, zf.y, st0 == DST_TRAINING, q.w_train, q.w_track);
-						const int m0 = st0 < 1 ? st0 : 1, isD = st0 >> 1;
-						const int pos = L.r.position;
-						const IdleStep o = idle_arith(m0, pos, L.r.lastBit, L.r.prev, bit);
-						const long long sidx = sample_idx + (g5 + off);
-						if (__ballot(dl && (isD | o.open) != 0) == 0) { // nobody inside a frame, nobody opens one (every lane, no branch)
-							L.r.start_idx = o.to_flag ? sidx : L.r.start_idx;
-							L.r.state = o.state; L.r.position = o.pos; L.r.lastBit = o.Bit; L.r.prev = bit;
-						} else {
-							const int osc = L.r.osc;
-							const int six = (int)((uint32_t)((osc ^ 5) - 1) >> 31); // five ones so far
-							const int close = six & o.Bit, stuffed = six & (o.Bit ^ 1);
-							const int np = pos + 1 - stuffed;
-							const int nw = (pos >> 5) - L.r.cwi; // 1: the position has moved on to the next word
-							const uint32_t sh = (uint32_t)pos & 31u;
-							const uint32_t cw = ((L.r.cw & (uint32_t)(nw - 1)) & ~(1u << sh)) | ((uint32_t)o.Bit << sh);
-							const int ev = (int)((uint32_t)((np ^ next_ev) - 1) >> 31); // position == next_ev
-							const bool D = isD != 0;
-							const bool special = dl && ((isD & (close | ev)) | ((isD ^ 1) & o.open)) != 0; // (0 / 1 arithmetic: no lane-dependent branches)
-							if (D && dl) data[FS * L.r.cwi] = L.r.cw; // (the word that is being filled, complete when the position moves on)
-							const float slvl = zf.x * zf.x + zf.y * zf.y;
-							// both steps are committed for every lane -- the frame registers of a decoder outside a frame are don't-cares (a
-							// frame that opens clears them) -- and a lane whose symbol is one of the rare ones redoes it from the state it had
-							const DecReg r_pre = L.r;
-							L.r.level = L.r.level + slvl;
-							L.r.cw = cw; L.r.cwi = L.r.cwi + nw; L.r.osc = (osc + 1) & (0 - o.Bit);
-							L.r.start_idx = o.to_flag ? sidx : L.r.start_idx; // (never inside a frame: m0 = 1 there)
-							L.r.state = D ? (int)DST_DATAFCS : o.state; L.r.position = D ? np : o.pos;
-							L.r.lastBit = o.Bit; L.r.prev = bit;
-							unsigned long long F = 0; // lanes whose decoder completed a message
-							bool found = false;
-							if (__ballot(special) != 0) {
-								if (special) {
-									DecReg r1 = r_pre;
-									if (D) found = dec_lean_data<FS>(r1, bit, slvl, data, crctab);
-									else dec_lean_idle(r1, bit, sidx);
-									L.r = r1;
-									next_ev = next_event_of(L.r);
-								}
-								F = __ballot(found);
-							}
-							if (F != 0) { fnd = found; return first_of(F, g5); }
-						}
-						zf = zfn;
-					}
-				}
-				if (g5 < to) {
-					const int kf = coh_group(g5, from, to, fnd);
-					if (kf >= 0) return kf;
-				}
-				return 512;
-			};
-			// ---- FM wave: BitPLL (:225-242) + decoder, one lane works (every decision is the wave's: scalar registers hold the discriminator's
-			// signs, the PLL's last bit and the decoder's TRAINING flag).  fm_exact: sample by sample in the reference's order.
-			const auto fm_exact = [&](const int from, const int to, float& ph, int& last_io, bool& fnd) -> int {
-				// (vector-side arithmetic like fm_run's turn; the only branch per sample is "the PLL fired")
-				int last = last_io;
-				asm volatile("" : "+v"(ph), "+v"(last));
-				uint32_t gainb = L.r.state == DST_TRAINING ? 0x3F19999Au : 0x3D4CCCCDu; // 0.6f : 0.05f
-				uint32_t wv = fmw2[from >> 5];
-				int kret = 512;
-#pragma unroll 1
-				for (int k = from; k < to; k++) {
-					if ((k & 31) == 0) wv = fmw2[k >> 5];
-					const int b = (int)((wv >> (k & 31)) & 1u);
-					const float gs = __uint_as_float(gainb & (uint32_t)(-(b ^ last)));
-					last = b;
-					ph = ph + (0.5f - ph) * gs;
-					ph = ph + 0.2f;
-					const float fl = __builtin_floorf(ph); // (1 <= phase < 1.2 where it fires: phase - (int)phase)
-					ph = ph - fl;
-					if (__ballot(fl != 0.0f) != 0) {
-						bool found = false;
-						if (__builtin_amdgcn_readfirstlane(L.r.state) == DST_DATAFCS) {
-							const float2 zq = zb[k];
-							found = dec_lean_data<FS>(L.r, b, zq.x * zq.x + zq.y * zq.y, data, crctab);
-						} else dec_lean_idle(L.r, b, sample_idx + k);
-						gainb = L.r.state == DST_TRAINING ? 0x3F19999Au : 0x3D4CCCCDu;
-						if (__builtin_amdgcn_readfirstlane((int)found) != 0) { fnd = found; kret = k; break; }
-					}
-				}
-				last_io = __builtin_amdgcn_readfirstlane(last);
-				return kret;
-			};
-			// fm_run: five samples per turn, straight-line, with the PLL gain of the decoder's state in front of the five (the gain only enters
-			// at a sign change); the decoder steps at the sample on which the PLL fires -- outside a frame as arithmetic on 0 / 1 (idle_arith),
-			// inside one as dec_lean_data's common case.  Exact when the PLL fires exactly once within the five and the step does not flip
-			// TRAINING <-> not-TRAINING in front of a later sign change of the five.  Of the rest (8 % of the turns) the two frequent kinds stay
-			// arithmetic -- no fire (3.9 %: nothing to decode), two fires with both steps clean (3.6 %) --, the others (a frame opens, a rare
-			// symbol inside a frame, a flipped flag in front of a sign change: < 1 %) go through fm_exact.  A wave that is alone on its SIMD
-			// pays 6-9 cycles per instruction of any kind and ~30 more per branch on a vector condition (tools/microbench_lonewave.hip): the
-			// turn is therefore written as integer / float arithmetic on vector registers -- masks instead of selects, floor() / fract()
-			// instead of a compare against 1, the fired positions summed as powers of two -- with ONE branch for all rare cases.
-			const auto fm_run = [&](const int from, const int to, bool& fnd) -> int {
-				fnd = false;
-				float ph = L.pll_phase;
-				int last = L.pll_last;
-				asm volatile("" : "+v"(ph), "+v"(last)); // (loaded through scalar registers: keep what follows on the vector side)
-				int k = from, kret = 512;
-				// the discriminator's signs from sample k on, in scalar registers: five leave per turn, a word of 32 arrives when half are gone
-				const auto sword = [&](const int w) -> unsigned long long { return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)fmw2[w < 17 ? w : 17]); };
-				unsigned long long win = (sword(k >> 5) | (sword((k >> 5) + 1) << 32)) >> (k & 31);
-				int have = 64 - (k & 31), nextw = (k >> 5) + 2;
-				// inside a frame the turn's decoder step is dec_lean_data's common case as arithmetic; the frame's rare symbols -- closing flag, the
-				// look-ups at positions 30 / 62, the type's own limit, the maximum length: the next of them is `next_ev` -- go through fm_exact
-				bool inframe = __builtin_amdgcn_readfirstlane(L.r.state) == DST_DATAFCS; // (scalar: changes only in the rare branch)
-				const auto next_event = [&]() -> int {
-					const int ps = L.r.position, ap = L.r.abort_pos;
-					return ps < 30 ? 30 : ps < 62 ? 62 : (ap > ps ? ap : DEC_MAX_FRAME);
-				};
-				int next_ev = next_event();
-#pragma unroll 1
-				for (; k + 5 <= to && kret == 512; k += 5) { // (one way in, one way round: the rare cases rejoin the turn's end)
-					const uint32_t b5 = (uint32_t)win & 31u;
-					win >>= 5; have -= 5;
-					if (have <= 32) { win |= sword(nextw) << have; have += 32; nextw++; }
-					const uint32_t c5 = (b5 ^ ((b5 << 1) | (uint32_t)last)) & 31u; // sign changes
-					const int st0 = L.r.state;
-					const int m0 = st0 < 1 ? st0 : 1; // 0: TRAINING
-					const uint32_t gainb = st0 == DST_TRAINING ? 0x3F19999Au : 0x3D4CCCCDu; // 0.6f : 0.05f
-					float pq = ph, ff = 0.0f;
-#pragma unroll
-					for (int s5 = 0; s5 < 5; s5++) {
-						const float gs = __uint_as_float(gainb & (uint32_t)__builtin_amdgcn_sbfe((int)c5, s5, 1)); // the gain at a sign change, 0.0f otherwise
-						pq = pq + (0.5f - pq) * gs;             // (x + 0 * y == x: no select)
-						pq = pq + 0.2f;
-						const float fl = __builtin_floorf(pq);  // 1.0f where it fires (1 <= phase < 1.2), else 0.0f
-						pq = __builtin_amdgcn_fractf(pq);       // phase - (int)phase: x - floor(x), exact on [0, 2) (off the chain: floor() only feeds the fired positions)
-						ff = s5 == 0 ? fl : __builtin_fmaf(fl, (float)(1 << s5), ff);
-					}
-					const uint32_t fires = (uint32_t)ff;
-					int s1; // first sample that fires (-1: none)
-					asm("v_ffbl_b32 %0, %1" : "=v"(s1) : "v"(fires));
-					const int b1 = (int)__builtin_amdgcn_ubfe(b5, (uint32_t)s1, 1u); // (offset 31 of a five-bit field where nothing fired: 0)
-					const uint32_t not_one = (uint32_t)__builtin_popcount(fires) ^ 1u; // no fire, or several
-					const int pos = L.r.position;
-					const int Bit = (b1 ^ L.r.prev) ^ 1;
-					bool rare;
-					if (inframe) {
-						// ---- dec_lean_data's common case: store the bit, count ones, skip a stuffed zero, add the level
-						const int osc = L.r.osc;
-						const int six = (int)((uint32_t)((osc ^ 5) - 1) >> 31); // five ones so far
-						const int close = six & Bit, stuffed = six & (Bit ^ 1);
-						const int np = pos + 1 - stuffed;
-						const int nw = (pos >> 5) - L.r.cwi; // 1: the position has moved on to the next word
-						data[FS * L.r.cwi] = L.r.cw;  // (every turn: the word that is being filled, complete when the position moves on)
-						const uint32_t sh = (uint32_t)pos & 31u;
-						const uint32_t cw = ((L.r.cw & (uint32_t)(nw - 1)) & ~(1u << sh)) | ((uint32_t)Bit << sh);
-						const float2 zq = zb[(k + s1) & 511];
-						const uint32_t ev = (uint32_t)((np ^ next_ev) - 1) >> 31; // position == next_ev
-						rare = __ballot((not_one | (uint32_t)close | ev) != 0u) != 0;
-						if (!rare) {
-							L.r.level = L.r.level + (zq.x * zq.x + zq.y * zq.y);
-							L.r.cw = cw; L.r.cwi = L.r.cwi + nw; L.r.position = np; L.r.osc = (osc + 1) & (0 - Bit);
-							L.r.lastBit = Bit; L.r.prev = b1;
-							ph = pq; last = (int)(b5 >> 4);
-						}
-					} else {
-						// ---- the decoder's step for a decoder in TRAINING / STARTFLAG, as arithmetic on 0 / 1 (dec_lean_idle)
-						const IdleStep o1 = idle_arith(m0, pos, L.r.lastBit, L.r.prev, b1);
-						// rare: no or several fires, a frame opens, a flipped TRAINING flag in front of a later sign change
-						const uint32_t later = c5 >> ((s1 + 1) & 31);
-						const uint32_t bad1 = (uint32_t)o1.open | ((uint32_t)(o1.state ^ m0) & (later < 1u ? later : 1u));
-						rare = __ballot((not_one | bad1) != 0u) != 0;
-						if (!rare) {
-							const long long sidx = sample_idx + (k + s1);
-							L.r.start_idx = o1.to_flag ? sidx : L.r.start_idx;
-							L.r.state = o1.state; L.r.position = o1.pos; L.r.lastBit = o1.Bit; L.r.prev = b1;
-							ph = pq; last = (int)(b5 >> 4);
-						} else {
-							// the two frequent rare turns stay arithmetic: no fire (nothing to decode), or two fires with both steps clean
-							const uint32_t f_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)fires);
-							const uint32_t rest = f_s & (f_s - 1u);
-							if (f_s == 0u) { ph = pq; last = (int)(b5 >> 4); rare = false; }
-							else if (rest != 0u && (rest & (rest - 1u)) == 0u && __builtin_amdgcn_readfirstlane((int)bad1) == 0) {
-								const int s2 = __builtin_ctz(rest);
-								const int b2 = (int)((b5 >> s2) & 1u);
-								const IdleStep o2 = idle_arith(o1.state, o1.pos, o1.Bit, b1, b2);
-								const uint32_t later2 = c5 >> (s2 + 1);
-								const uint32_t bad2 = (uint32_t)o2.open | ((uint32_t)(o2.state ^ o1.state) & (later2 < 1u ? later2 : 1u));
-								if (__builtin_amdgcn_readfirstlane((int)bad2) == 0) {
-									const long long sidx1 = sample_idx + (k + s1), sidx2 = sample_idx + (k + s2);
-									L.r.start_idx = o2.to_flag ? sidx2 : (o1.to_flag ? sidx1 : L.r.start_idx);
-									L.r.state = o2.state; L.r.position = o2.pos; L.r.lastBit = o2.Bit; L.r.prev = b2;
-									ph = pq; last = (int)(b5 >> 4); rare = false;
-								}
-							}
-						}
-					}
-					if (rare) { // the reference's order, sample by sample (a frame buffer word the turn may have written is rewritten by it)
-						int last_s = __builtin_amdgcn_readfirstlane(last);
-						kret = fm_exact(k, k + 5, ph, last_s, fnd);
-						last = last_s;
-						asm volatile("" : "+v"(ph), "+v"(last));
-						inframe = __builtin_amdgcn_readfirstlane(L.r.state) == DST_DATAFCS;
-						next_ev = next_event();
-					}
-				}
-				if (kret != 512) k = to; // (stopped at a completed message)
-				int last_s = __builtin_amdgcn_readfirstlane(last);
-				if (kret == 512 && k < to) kret = fm_exact(k, to, ph, last_s, fnd);
-				L.pll_phase = ph; L.pll_last = last_s;
-				return kret;
-			};
-			uint32_t* const snapc = fsnap + (data - fdata);
-			V2Lane S = L;
-			bool snap_cols = false;
-			const auto snapshot = [&]() {
-				S = L;
-				snap_cols = __ballot(dl && L.r.state == DST_DATAFCS) != 0; // (a decoder that is not inside a frame has nothing in its buffer)
-				if (snap_cols && dl) for (int w = 0; w < DEC_DATA_WORDS; w++) snapc[FS * w] = data[FS * w];
-			};
-			const auto restore = [&]() {
-				L = S;
-				if (snap_cols && dl) for (int w = 0; w < DEC_DATA_WORDS; w++) data[FS * w] = snapc[FS * w];
-			};
-			snapshot();
-			// the reference's order for samples [from, to), group by group / sample by sample (only behind a completed message)
-			const auto coh_slow = [&](const int from, const int to, bool& fnd) -> int {
-				fnd = false;
-#pragma unroll 1
-				for (int g5 = from - from % 5; g5 < to; g5 += 5) {
-					const int kf = coh_group(g5, from, to, fnd);
-					if (kf >= 0) return kf;
-				}
-				return 512;
-			};
-			const auto fm_slow = [&](const int from, const int to, bool& fnd) -> int {
-				fnd = false;
-				float ph = L.pll_phase;
-				int last = __builtin_amdgcn_readfirstlane(L.pll_last);
-				const int kf = fm_exact(from, to, ph, last, fnd);
-				L.pll_phase = ph; L.pll_last = last;
-				return kf;
-			};
-			// One call site of the hot loops: the speculative pass over [P, 512), and -- behind a completed message -- the exact prefix [P, k*)
-			// again (no message can complete in it), before sample k* itself goes through the symbol-by-symbol code.
-			int P = 0, to = 512, kstar = 512;
-			bool prefix = false, coh_wins = false;
-#pragma unroll 1
-			for (;;) {
-				bool fnd = false;
-				int k;
-#ifdef V2_PROF
-				{ const unsigned long long t0_ = __builtin_readcyclecounter(); k = fm_wave ? fm_run(P, to, fnd) : coh_run(P, to, fnd); const unsigned long long d_ = __builtin_readcyclecounter() - t0_;
-				  if (lane == 0) { atomicAdd(&v2_prof[3 + (fm_wave ? 1 : 0)], d_); if (chan < 1024) v2_prof_wg[chan][fm_wave ? 1 : 0] += d_; } }
-#else
-				k = fm_wave ? fm_run(P, to, fnd) : coh_run(P, to, fnd);
-#endif
-				if (!prefix) {
-					// the speculative pass is through (or stopped at a completed message): who was first?
-					if (wave == 0) {
-						const int busy = __ballot(dl && L.r.state != DST_TRAINING) != 0 ? 1 : 0; // (as the next block will find the decoders, if nobody completed a message)
-						if (lane == 0) { kx[xi & 1][0] = k; kx[xi & 1][2] = busy; kx[xi & 1][3] = learned; }
-					} else if (lane == 0) kx[xi & 1][1] = k;
-					{ V2P_T0(); __syncthreads(); V2P_ADD(7 + (fm_wave ? 1 : 0)); }
-					const int kc = __builtin_amdgcn_readfirstlane(kx[xi & 1][0]), kf = __builtin_amdgcn_readfirstlane(kx[xi & 1][1]);
-					xi++;
-					if (kc == 512 && kf == 512) break;
-					coh_wins = kc <= kf; // (the same sample: the tracker's decoder runs first and resets the FM decoder in front of its step, :374-385)
-					kstar = coh_wins ? kc : kf;
-					restore();
-					to = kstar; prefix = true;
-					continue;
-				}
-				// exact up to k*: now sample k* itself
-				const float tag_ppm = kstar >= split_b ? ppm_b : ppm_prev_b;
-				if (fm_wave) {
-					if (coh_wins) v2_reset(L.r);
-					fm_slow(kstar, kstar + 1, fnd);
-					if (!coh_wins) { if (lane == 0) emit(L.r, sample_idx + kstar, tag_ppm); v2_reset(L.r); }
-				} else {
-					coh_slow(kstar, kstar + 1, fnd);
-					if (coh_wins) {
-						const unsigned long long FF = __ballot(fnd) | (1ull << 63); // (the lane that handled k*)
-						if (fnd) emit(L.r, sample_idx + kstar, tag_ppm);
-						const long long sidx0 = __shfl(L.r.start_idx, __builtin_ctzll(FF));
-						learn_slot(sidx0);
-						learned = 1;
-#ifdef V2_PROF
-						if (lane == 0 && chan < 1024) v2_prof_wg[chan][3]++;
-#endif
-					}
-					v2_reset(L.r);
-				}
-				P = kstar + 1; to = 512; prefix = false;
-				snapshot();
-			}
-			if (wave == 0 && j < 5) L.t.rot = (L.t.rot + (unsigned)((512 - (j - di + 5) % 5 + 4) / 5)) & 3u; // Rotate90 calls of this tracker in the block
-			sample_idx += 512;
-			di = (di + 512) % 5;
-			if (blk + 1 >= p.n_windows) break;
-		}
-		// ---- which block is next?  (the last exchange of the block carries busy and learned)
-		const int busy = __builtin_amdgcn_readfirstlane(kx[(xi - 1) & 1][2]), lrn = __builtin_amdgcn_readfirstlane(kx[(xi - 1) & 1][3]);
-		const int ncl = __builtin_amdgcn_readfirstlane(sh_nc[blk & 1]);
-		if (lrn == 0 || still_valid(blk, sample_idx, (ncl >> 2) - 1)) cur = (cur + 1 + (((ncl & 3) == 2 && busy) ? 1 : 0)) % 3;
-		else { __syncthreads(); cur = (cur + 1) % 3; } // (wave 2 prepares the block again, in the open)
-	}
-	}
-#ifdef V2_PROF
-	if (lane == 0 && fm_wave && chan < 1024) v2_prof_wg[chan][2] = __builtin_readcyclecounter() - v2p_k0;
-	if (lane == 0 && fm_wave) { const unsigned long long d_ = __builtin_readcyclecounter() - v2p_k0; atomicMax(&v2_prof[12], d_); atomicAdd(&v2_prof[13], d_); atomicAdd(&v2_prof[14], 1ull); atomicMin(&v2_prof[15], ~d_); }
-#endif
-	if (dl) {
-		DecState* st = q.dec + dec;
-		const DecReg& r = L.r;
-		st->state = r.state; st->lastBit = r.lastBit; st->prev = r.prev; st->position = r.position; st->osc = r.osc;
-		st->level = r.level; st->start_idx = r.start_idx;
-		if (r.state == DST_DATAFCS) data[FS * r.cwi] = r.cw; // (outside a frame the frame registers are don't-cares: cwi may point anywhere)
-		for (int w = 0; w < DEC_DATA_WORDS; w++) st->data[w] = data[FS * w];
-		st->crc[0] = r.crc; st->crc[1] = r.cw; st->crc[2] = (uint32_t)r.cwi; st->crc[3] = r.tail; st->crc[4] = (uint32_t)r.abort_pos;
-		if (wave == 0) cs->trk[j] = L.t;
-		if (fm_wave) { cs->pll_phase = L.pll_phase; cs->pll_last = L.pll_last; }
-	}
-	if (wave == 0 && lane == 0) { cs->slot_ema = slot_ema; cs->slot_phase = slot_phase; cs->di = di; cs->sample_idx = sample_idx; }
-	if (fe_wave) {
-		if (lane == 0) { cs->rot = rot; cs->last_f = last_f; cs->ppm = ppm; cs->ppm_prev = ppm_prev; }
-		if (lane < 16) cs->carry17[lane] = dero2[0][lane];
-	}
-}
+#define V2R_KERNEL_HEAD __global__ __launch_bounds__(192) void kv2_engine_roles(KV2EParams q)
+#include "kv2_roles.inc"
+#undef V2R_KERNEL_HEAD
+// (amdgpu_num_vgpr takes half of the budget on this compiler: see check_resources.py)
+#define V2R_KERNEL_HEAD __global__ __launch_bounds__(192) __attribute__((amdgpu_num_vgpr(168 / 2))) void kv2_engine_roles_dense(KV2EParams q)
+#include "kv2_roles.inc"
+#undef V2R_KERNEL_HEAD
 
 // ------------------------------------------------------------------------------------------
 // K7 for the other engines, sequential forms (ModelStandard and ModelChallenger run event-driven by default -- K7e below, kinds 1 / 2 --
@@ -5518,7 +4865,8 @@ hipError_t launch_kv2_assist(const KV2Params& p, hipStream_t s) {
 	return hipGetLastError();
 }
 hipError_t launch_kv2_engine(const KV2EParams& e, hipStream_t s) { // one workgroup per channel (reads the look-back `hist`)
-	if (e.roles) hipLaunchKernelGGL(kv2_engine_roles, dim3(e.k.n_chan), dim3(192), 0, s, e);
+	if (e.roles == 2) hipLaunchKernelGGL(kv2_engine_roles_dense, dim3(e.k.n_chan), dim3(192), 0, s, e);
+	else if (e.roles) hipLaunchKernelGGL(kv2_engine_roles, dim3(e.k.n_chan), dim3(192), 0, s, e);
 	else hipLaunchKernelGGL(kv2_engine, dim3(e.k.n_chan), dim3(64), 0, s, e);
 	return hipGetLastError();
 }

@@ -58,7 +58,7 @@ extern "C" {
 #define AISGPU_MODEL_DEFAULT 2     /* AIS::ModelDefault    (-m 2), DSP/Model.cpp:520-577 */
 #define AISGPU_MODEL_V2 11         /* AIS::ModelEngineV2  (-m 11), DSP/Model.cpp:440-463.  Two forms:
                                     * - with AISGPU_FLAG_GPU_DECODE the whole V2::Engine of every channel runs ON THE DEVICE (kv2_engine_roles, three waves
-                                    *   per channel, for batches of up to 1,024 channels; kv2_engine, one wave per channel, beyond: DSP/Decoder/V2/
+                                    *   per channel; kv2_engine, one wave per channel, is round 5's form and a test hook: DSP/Decoder/V2/
                                     *   V2Engine.cpp:293-388, results in the reference's order per channel) and only frames come back (aisgpu_frames);
                                     * - without it the device runs the front end and what the engine computes from the channel alone (frequency estimates,
                                     *   energies, FM branch: aisgpu_out.v2_*, fm_bits) and hands over the two 48 kHz channels (aisgpu_out.c48) to an engine
@@ -245,8 +245,8 @@ void aisgpu_timing(aisgpu_t* h, int enable);
  *                   batch size (by default only batches of ~200 receivers and more get walks longer than one span)
  *   "us_k1"         0: the tail of the resampled ladders (buckets from 384k up) as k1u_resample_frontend + the FFT / search kernel, the form
  *                   of rounds 3-5, instead of one-wave workgroups of the front-end kernel (k1_dpp<2, 5, false>, round 6)
- *   "v2_roles"      0 / 1: ModelEngineV2 on the device as kv2_engine (one wave per channel, round 5) / kv2_engine_roles (three waves per
- *                   channel, round 6) whatever the batch size (by default the three-wave kernel up to 1,024 channels)
+ *   "v2_roles"      0 / 1 / 2: ModelEngineV2 on the device as kv2_engine (one wave per channel, round 5) / kv2_engine_roles (three waves per
+ *                   channel, round 6) / the same compiled for three waves per SIMD, whatever the batch size (default: 1 up to 512 channels, else 2)
  * Returns AISGPU_ERR_ARG for an unknown key. */
 int aisgpu_set_option(const char* key, const char* value);
 

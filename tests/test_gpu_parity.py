@@ -892,7 +892,7 @@ def test_model_engine_v2_end_to_end(rate, fmt, block, nblocks):
     assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
 
 
-@pytest.mark.parametrize("roles", ["1", "0"])
+@pytest.mark.parametrize("roles", ["1", "2", "0"])
 @pytest.mark.parametrize("rate,fmt,block,nblocks", [(1536000, "cf32", 131072, 24), (1536000, "cu8", 786432, 4), (768000, "cf32", 65536, 24), (6000000, "cf32", 786432, 4),
                                                     (1536000, "cf32", 16384, 192), (1536000, "cf32", 49152, 64)])  # (one and three engine blocks per call)
 def test_model_engine_v2_on_the_device(rate, fmt, block, nblocks, roles, monkeypatch):
@@ -902,8 +902,9 @@ def test_model_engine_v2_on_the_device(rate, fmt, block, nblocks, roles, monkeyp
     is the reference's arithmetic in the reference's order, std::polar of the estimated frequency included (glibc's sinf / cosf
     restated, tests/test_sincosf.py): NMEA text, tag.ppm and the per-message level -- a sum of |derotated, filtered sample|^2
     over the frame -- must equal the compiled reference's bit for bit.
-    roles = 1 (round 6, the default): the trackers and the FM decoder on two waves of a workgroup, speculating that no message completes,
-    with the exact order restored where one does; roles = 0: round 5's one-wave form (test hook v2_roles)."""
+    roles = 1 (round 6, the default up to 512 channels): trackers, FM decoder and the next block's front end on three waves of a workgroup,
+    speculating that no message completes, with the exact order restored where one does; 2: the same kernel compiled for three waves per
+    SIMD (bigger batches); 0: round 5's one-wave form (test hook v2_roles)."""
     from ais_catcher_amd import host
     monkeypatch.setenv("AISGPU_V2_ROLES", roles)
     x = synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=46, gap_slots=(1, 2), type5_every=4)
@@ -983,7 +984,7 @@ def test_model_engine_v2_three_waves_equal_one_wave_on_a_batch(monkeypatch):
     R, block, nblocks = 48, 245760, 3  # (a whole number of SOTDMA slots per block: the engines learn the slot phase over the passes)
     data = workload.resident_batch(torch, R, nblocks, seed=3, block=block)
     out = []
-    for roles in ("1", "0"):
+    for roles in ("1", "2", "0"):
         monkeypatch.setenv("AISGPU_V2_ROLES", roles)
         g = gpu.AisGpu(n_receivers=R, block_len=block, model=gpu.MODEL_V2, gpu_decode=True)
         frames = []
@@ -996,8 +997,8 @@ def test_model_engine_v2_three_waves_equal_one_wave_on_a_batch(monkeypatch):
         bits = lambda f: (f["data"][:f["position"] // 8], f["data"][f["position"] // 8] & ((1 << (f["position"] % 8)) - 1))
         out.append((sorted((f["rx"], f["ch"], f["end_idx"], f["phase"], f["start_idx"], f["position"], f["level_sum"]) + bits(f) for f in frames), g.decoder_fallbacks()))
         g.close()
-    assert len(out[0][0]) >= 200 and out[0][0] == out[1][0]
-    assert out[0][1] == out[1][1] and out[0][1] > 0
+    assert len(out[0][0]) >= 200 and out[0][0] == out[2][0] and out[1][0] == out[2][0]
+    assert out[0][1] == out[2][1] and out[1][1] == out[2][1] and out[0][1] > 0
 
 
 @pytest.mark.parametrize("rate,fmt,block", [(1536000, "cf32", 131072), (1536000, "cu8", 131072), (768000, "cf32", 65536)])
