@@ -199,7 +199,7 @@ struct aisgpu {
 	// the engine on the device (round 6): on a stream of its own, beside the next block's front end and assist kernels -- what it reads of
 	// the assist kernels' outputs exists twice (by block parity): look-back, estimates, energies, the previous block's last discriminator signs
 	float2* d_v2hist2 = nullptr; float *d_v2f2 = nullptr, *d_v2prom2 = nullptr, *d_v2en2 = nullptr; uint32_t* d_v2fmtail[2] = { nullptr, nullptr };
-	hipEvent_t ev_v2assist = nullptr, ev_v2engine[2] = { nullptr, nullptr }; int v2_par = 0; hipStream_t v2_stream = nullptr;
+	hipEvent_t ev_v2assist = nullptr, ev_v2engine[2] = { nullptr, nullptr }, ev_v2front = nullptr, ev_v2fm = nullptr; int v2_par = 0; hipStream_t v2_stream = nullptr;
 	bool k46 = false; // default path: derotation + FIR + PhaseSearch in one kernel (k46_window_search; test hook "k46" = 0: k6_window_fir + k4_phase_chunks)
 	bool base = false; float2* d_fmprev[2] = {}; // ModelBase: FM receiver on the 48 kHz channels, no coherent chain
 	float* d_fm = nullptr; float* d_fmhist[2] = {}; uint32_t* d_fmbits[2] = {}; uint32_t* h_fmbits = nullptr; // ModelChallenger FM branch
@@ -816,6 +816,9 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 }
 
 // ModelEngineV2 (Model.cpp:440-463): nothing behind the front end runs here; the block's two 48 kHz channels travel to the host
+#ifndef V2_FM_BESIDE
+#define V2_FM_BESIDE 1
+#endif
 int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
 	if (h->n_sub < MAXSUB) {
 		const size_t C = h->n_chan;
@@ -846,7 +849,15 @@ int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
 				memcpy(e.taps17, TAPS_COHERENT, sizeof e.taps17);
 				// ds: assist kernels of this block; engine stream: the engine behind them; ds again: the carry, which overwrites what the
 				// engine of the PREVIOUS block read (the other pair member, fmbits[pb ^ 1] is next) -- so it waits for that engine, not this one
-				HIPCHK(launch_kv2_assist(k, h->ds));
+				if (V2_FM_BESIDE && !h->serial && h->s4 != h->ds) {
+					// the FM branch (discriminator + 37-tap filter) beside the estimates: two short kernel pairs that do not fill the chip
+					HIPCHK(hipEventRecord(h->ev_v2front, h->ds)); // (the front end of this block, and the previous block's carry, are through)
+					WAITEV(h->s4, h->ev_v2front);
+					HIPCHK(launch_kv2_assist(k, h->s4, 2));
+					HIPCHK(hipEventRecord(h->ev_v2fm, h->s4));
+					HIPCHK(launch_kv2_assist(k, h->ds, 1));
+					WAITEV(h->ds, h->ev_v2fm);
+				} else HIPCHK(launch_kv2_assist(k, h->ds));
 				HIPCHK(hipEventRecord(h->ev_v2assist, h->ds));
 				WAITEV(h->v2_stream, h->ev_v2assist);
 				HIPCHK(launch_kv2_engine(e, h->v2_stream));
@@ -1647,6 +1658,7 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 				HIPCHK(dalloc(&h->d_v2f2, C * 2 * h->W)); HIPCHK(dalloc(&h->d_v2prom2, C * 2 * h->W)); HIPCHK(dalloc(&h->d_v2en2, C * (h->W + 1)));
 				for (int i = 0; i < 2; i++) { HIPCHK(dalloc(&h->d_v2fmtail[i], C * 16)); HIPCHK(hipEventCreateWithFlags(&h->ev_v2engine[i], hipEventDisableTiming)); }
 				HIPCHK(hipEventCreateWithFlags(&h->ev_v2assist, hipEventDisableTiming));
+				HIPCHK(hipEventCreateWithFlags(&h->ev_v2front, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_v2fm, hipEventDisableTiming));
 				// (measured, round 6: the engine on s1 beside the next block's front end and assist kernels takes 4.1 ms instead of 2.6 -- its
 				// workgroups need 50 KB of LDS each and wait for CUs the throughput kernels fill, and every shared SIMD delays its dependent
 				// chains -- so the step got slower, 4.1 against 3.1 ms.  The engine stays behind its assist kernels on their stream; the
@@ -1726,6 +1738,8 @@ void aisgpu_destroy(aisgpu_t* h) {
 	hipFree(h->d_v2hist); hipFree(h->d_v2f); hipFree(h->d_v2prom); hipFree(h->d_v2en); hipFree(h->d_v2st); hipFree(h->d_slotcs); hipFree(h->d_v2locked);
 	hipFree(h->d_v2hist2); hipFree(h->d_v2f2); hipFree(h->d_v2prom2); hipFree(h->d_v2en2); hipFree(h->d_v2fmtail[0]); hipFree(h->d_v2fmtail[1]);
 	if (h->ev_v2assist) hipEventDestroy(h->ev_v2assist);
+	if (h->ev_v2front) hipEventDestroy(h->ev_v2front);
+	if (h->ev_v2fm) hipEventDestroy(h->ev_v2fm);
 	for (int i = 0; i < 2; i++) if (h->ev_v2engine[i]) hipEventDestroy(h->ev_v2engine[i]);
 	if (h->h_v2f) hipHostFree(h->h_v2f); if (h->h_v2prom) hipHostFree(h->h_v2prom); if (h->h_v2en) hipHostFree(h->h_v2en);
 	for (int i = 0; i < NBUF; i++) { hipFree(h->d_magT[i]); hipFree(h->d_ck[i]); }

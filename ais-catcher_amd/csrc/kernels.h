@@ -386,7 +386,7 @@ void v2_prof_dump(); // experiment build: cycles of kv2_engine's phases on stder
 bool sincos_restatement_matches_host_libm(); // kv2_engine's sinf / cosf (glibc 2.35, FMA variant) on the host against the host's own libm
 hipError_t launch_kv2(const KV2Params& p, hipStream_t s, const KV2EParams* engine = nullptr); // engine: kv2_engine runs before the look-back is overwritten
 // the same in three parts (round 6: the engine on a stream of its own, beside the next block's front end and assist kernels)
-hipError_t launch_kv2_assist(const KV2Params& p, hipStream_t s);
+hipError_t launch_kv2_assist(const KV2Params& p, hipStream_t s, int part = 3); // part 1: estimates + energies, 2: the FM branch
 hipError_t launch_kv2_engine(const KV2EParams& e, hipStream_t s);
 hipError_t launch_kv2_carry(const KV2Params& p, hipStream_t s);
 // Derotation + FIR + ScatterPLL + PhaseSearchEMA in one workgroup (k46_window_search, kernels.hip): K6Params without `sym` traffic

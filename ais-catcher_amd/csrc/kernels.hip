@@ -4856,12 +4856,16 @@ hipError_t launch_k7(const K7Params& p, hipStream_t s) {
 	return hipGetLastError();
 }
 
-hipError_t launch_kv2_assist(const KV2Params& p, hipStream_t s) {
-	const int n_est = p.n_chan * 2 * p.n_windows;
-	hipLaunchKernelGGL(kv2_estimate, dim3((n_est + FFT_NW - 1) / FFT_NW), dim3(64), 0, s, p);
-	hipLaunchKernelGGL(kv2_energy, dim3((p.n_chan * (p.n_windows + 1) + 63) / 64), dim3(64), 0, s, p);
-	hipLaunchKernelGGL(kv2_fm, dim3(p.L / 256, p.n_chan), dim3(256), 0, s, p);
-	hipLaunchKernelGGL(kv2_filter, dim3(p.L / 256, p.n_chan), dim3(256), 0, s, p);
+hipError_t launch_kv2_assist(const KV2Params& p, hipStream_t s, int part) { // part 1: estimates + energies; 2: the FM branch; 3: both
+	if (part & 1) {
+		const int n_est = p.n_chan * 2 * p.n_windows;
+		hipLaunchKernelGGL(kv2_estimate, dim3((n_est + FFT_NW - 1) / FFT_NW), dim3(64), 0, s, p);
+		hipLaunchKernelGGL(kv2_energy, dim3((p.n_chan * (p.n_windows + 1) + 63) / 64), dim3(64), 0, s, p);
+	}
+	if (part & 2) {
+		hipLaunchKernelGGL(kv2_fm, dim3(p.L / 256, p.n_chan), dim3(256), 0, s, p);
+		hipLaunchKernelGGL(kv2_filter, dim3(p.L / 256, p.n_chan), dim3(256), 0, s, p);
+	}
 	return hipGetLastError();
 }
 hipError_t launch_kv2_engine(const KV2EParams& e, hipStream_t s) { // one workgroup per channel (reads the look-back `hist`)
@@ -4875,7 +4879,7 @@ hipError_t launch_kv2_carry(const KV2Params& p, hipStream_t s) {
 	return hipGetLastError();
 }
 hipError_t launch_kv2(const KV2Params& p, hipStream_t s, const KV2EParams* engine) {
-	hipError_t e = launch_kv2_assist(p, s);
+	hipError_t e = launch_kv2_assist(p, s, 3);
 	if (e == hipSuccess && engine) e = launch_kv2_engine(*engine, s);
 	if (e == hipSuccess) e = launch_kv2_carry(p, s);
 	return e;
