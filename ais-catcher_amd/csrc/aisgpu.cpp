@@ -819,6 +819,9 @@ int enqueue_downstream_base(aisgpu_t* h, int q, int pb) {
 #ifndef V2_FM_BESIDE
 #define V2_FM_BESIDE 1
 #endif
+#ifndef V2_ENGINE_OWN_STREAM
+#define V2_ENGINE_OWN_STREAM 0
+#endif
 int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
 	if (h->n_sub < MAXSUB) {
 		const size_t C = h->n_chan;
@@ -849,6 +852,7 @@ int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
 				memcpy(e.taps17, TAPS_COHERENT, sizeof e.taps17);
 				// ds: assist kernels of this block; engine stream: the engine behind them; ds again: the carry, which overwrites what the
 				// engine of the PREVIOUS block read (the other pair member, fmbits[pb ^ 1] is next) -- so it waits for that engine, not this one
+				if (h->v2_stream != h->ds) WAITEV(h->ds, h->ev_v2engine[par ^ 1]); // (only this block's FRONT END ran beside the previous block's engine)
 				if (V2_FM_BESIDE && !h->serial && h->s4 != h->ds) {
 					// the FM branch (discriminator + 37-tap filter) beside the estimates: two short kernel pairs that do not fill the chip
 					HIPCHK(hipEventRecord(h->ev_v2front, h->ds)); // (the front end of this block, and the previous block's carry, are through)
@@ -1661,9 +1665,10 @@ int aisgpu_create(const aisgpu_cfg* cfg, aisgpu_t** out) {
 				HIPCHK(hipEventCreateWithFlags(&h->ev_v2front, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_v2fm, hipEventDisableTiming));
 				// (measured, round 6: the engine on s1 beside the next block's front end and assist kernels takes 4.1 ms instead of 2.6 -- its
 				// workgroups need 50 KB of LDS each and wait for CUs the throughput kernels fill, and every shared SIMD delays its dependent
-				// chains -- so the step got slower, 4.1 against 3.1 ms.  The engine stays behind its assist kernels on their stream; the
-				// pairs of buffers stay, they cost nothing.)
-				h->v2_stream = h->ds;
+				// chains -- so the step got slower, 4.1 against 3.1 ms.  With only the next block's FRONT END beside it (V2_ENGINE_OWN_STREAM = 1,
+				// the assist kernels held back until the engine is through): 3.9 against 2.58 ms.  The engine stays behind its assist kernels
+				// on their stream; the pairs of buffers stay, they cost nothing.)
+				h->v2_stream = (V2_ENGINE_OWN_STREAM && !h->serial) ? h->s1 : h->ds;
 			}
 			if (v2_host) {
 				HIPCHK(hipHostMalloc((void**)&h->h_v2f, 2 * MAXSUB * C * 2 * h->W * sizeof(float), hipHostMallocDefault));
