@@ -27,7 +27,7 @@ GRAFT_REPO_ROOT=$R ./tools/pmc_traffic_all.sh --parity-receivers 0 --no-pmc --no
 python tools/bench_paths.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_paths.txt
 BENCH_PATHS_DISTINCT=1 BENCH_PATHS_ONLY="on the device" python tools/bench_paths.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_paths_distinct_receivers.txt
 DISTINCT=1 LINES_OUT=12 tools/prof_path.sh ${TAG}_v2_engine "model=gpu.MODEL_V2, gpu_decode=True" 8 > /dev/null 2>&1; mv gpurun_out/prof_${TAG}_v2_engine.txt gpurun_out/${TAG}_v2_engine_kernel_stats.txt   # ModelEngineV2's engine on the device: its kernels alone
-for r in 64 512 1024; do BENCH_PATHS_DISTINCT=1 BENCH_PATHS_ONLY="whole engine" python tools/bench_paths.py $r 2>&1 | grep "MS/s"; done > gpurun_out/${TAG}_v2_engine_batch_sizes.txt
+for r in 64 384 512 1024; do BENCH_PATHS_DISTINCT=1 BENCH_PATHS_ONLY="whole engine" python tools/bench_paths.py $r 2>&1 | grep "MS/s"; done > gpurun_out/${TAG}_v2_engine_batch_sizes.txt
 python __graft_entry__.py smoke 2>&1 | grep -v amdgpu.ids | tail -2 > gpurun_out/${TAG}_smoke.txt
 rm -rf gpurun_out/prof_bench gpurun_out/prof_serial gpurun_out/prof_${TAG}_*.log
 tail -1 gpurun_out/${TAG}_bench_steps20.json | cut -c1-600; tail -1 gpurun_out/${TAG}_bench.json | cut -c1-300
