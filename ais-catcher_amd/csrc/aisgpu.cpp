@@ -834,7 +834,7 @@ int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
 			KV2Params k{};
 			k.c48 = h->d_c48[q]; k.c48_stride = h->c48s; k.hist = h->d_v2hist; k.hist_out = h->d_v2hist; k.fmtail_out = nullptr; k.omega = h->d_omega;
 			k.est_f = h->d_v2f; k.est_prom = h->d_v2prom; k.energy = h->d_v2en;
-			k.disc = h->d_fm; k.fmprev = h->d_fmprev[0]; k.fmbits = h->d_fmbits[pb]; k.fmbits_stride = h->L / 32;
+			k.disc = h->d_fm; k.disc_full = (h->cfg.flags & AISGPU_FLAG_TAPS) != 0; k.fmprev = h->d_fmprev[0]; k.fmbits = h->d_fmbits[pb]; k.fmbits_stride = h->L / 32;
 			k.fir_out = h->d_fmfir; k.fir_stride = h->L;
 			memcpy(k.taps, TAPS_RECEIVER, sizeof k.taps);
 			k.n_windows = h->W; k.L = h->L; k.n_chan = h->n_chan;
@@ -853,21 +853,35 @@ int enqueue_downstream_v2(aisgpu_t* h, int q, int pb) {
 				// ds: assist kernels of this block; engine stream: the engine behind them; ds again: the carry, which overwrites what the
 				// engine of the PREVIOUS block read (the other pair member, fmbits[pb ^ 1] is next) -- so it waits for that engine, not this one
 				if (h->v2_stream != h->ds) WAITEV(h->ds, h->ev_v2engine[par ^ 1]); // (only this block's FRONT END ran beside the previous block's engine)
+				bool carried = false;
 				if (V2_FM_BESIDE && !h->serial && h->s4 != h->ds) {
-					// the FM branch (discriminator + 37-tap filter) beside the estimates: two short kernel pairs that do not fill the chip
-					HIPCHK(hipEventRecord(h->ev_v2front, h->ds)); // (the front end of this block, and the previous block's carry, are through)
+					// the FM branch (discriminator + 37-tap filter in one kernel, the half-block energies as its first workgroups) beside the
+					// estimates: two kernels that do not fill the chip.  The carry follows the FM branch on s4 (round 6, late): everything it
+					// reads is there by then, what it writes -- the OTHER members of the look-back pairs, the FM branch's own carries -- is next
+					// read by the assist kernels and the engine of block f+1, and the engine of block f-1, the last reader of those members, was
+					// through before this block's front end began (the step is one chain).  So the 5 us kernel and its two launch gaps leave the
+					// chain; the next front end waits for it through its table's event, recorded on s4 behind it (aisgpu_run).
+					HIPCHK(hipEventRecord(h->ev_v2front, h->ds)); // (the front end of this block is through)
 					WAITEV(h->s4, h->ev_v2front);
-					HIPCHK(launch_kv2_assist(k, h->s4, 2));
+					HIPCHK(launch_kv2_assist(k, h->s4, 2 | 4));
 					HIPCHK(hipEventRecord(h->ev_v2fm, h->s4));
+					if (h->v2_stream == h->ds) {
+						HIPCHK(launch_kv2_carry(k, h->s4));
+						carried = true;
+					}
 					HIPCHK(launch_kv2_assist(k, h->ds, 1));
 					WAITEV(h->ds, h->ev_v2fm);
-				} else HIPCHK(launch_kv2_assist(k, h->ds));
+				} else HIPCHK(launch_kv2_assist(k, h->ds, 7));
 				HIPCHK(hipEventRecord(h->ev_v2assist, h->ds));
 				WAITEV(h->v2_stream, h->ev_v2assist);
 				HIPCHK(launch_kv2_engine(e, h->v2_stream));
 				HIPCHK(hipEventRecord(h->ev_v2engine[par], h->v2_stream));
-				WAITEV(h->ds, h->ev_v2engine[par ^ 1]);
-				HIPCHK(launch_kv2_carry(k, h->ds));
+				if (!carried) { // (carried: the next front end waits for its table's event, recorded on s4 behind the carry -- aisgpu_run)
+					// ds: the carry, which overwrites what the engine of the PREVIOUS block read (the other pair member, fmbits[pb ^ 1] is next)
+					// -- so it waits for that engine, not this one
+					WAITEV(h->ds, h->ev_v2engine[par ^ 1]);
+					HIPCHK(launch_kv2_carry(k, h->ds));
+				}
 				HIPCHK(hipEventRecord(h->ev_c48free[q], h->v2_stream)); // (the engine is the block's last reader of its 48 kHz channels)
 			} else {
 				HIPCHK(launch_kv2(k, h->ds));
@@ -1975,8 +1989,8 @@ int aisgpu_run(aisgpu_t* h) {
 		const int rb = (int)(h->block_idx & 3); // ring slot of this block's table
 		if (h->rot_next <= h->block_idx) { int rc = stage_rot(rb, h->stream); if (rc) return rc; h->rot_next = h->block_idx + 1; }
 		else WAITEV(h->stream, h->rw.ev[h->rot_slot[rb]]);
-		// c48/fz/ppm[q] were last read by K2b/K2c of block f-NBUF
-		WAITEV(h->stream, h->ev_c48free[q]);
+		// c48/fz/ppm[q] were last read by K2b/K2c of block f-NBUF (ModelEngineV2 on the device: by the engine, on this very stream -- no wait to enqueue)
+		if (!(h->v2 && h->gpu_decode && h->v2_assist && h->v2_stream == h->stream)) WAITEV(h->stream, h->ev_c48free[q]);
 		K1Params k1{};
 		const bool from_pre = h->mode == MODE_PRE;
 		k1.in = from_pre ? (const void*)xcur : h->cur_in;
@@ -2041,6 +2055,18 @@ int aisgpu_run(aisgpu_t* h) {
 		}
 		int rc = enqueue_downstream(h, q, pb);
 		if (rc) return rc;
+		if (!h->serial && V2_FM_BESIDE && h->v2 && h->gpu_decode && h->v2_assist && h->s4 != h->ds && h->v2_stream == h->ds) {
+			// ModelEngineV2 with its engine on the device: the step is ONE chain (front end -> assist kernels -> engine), so the 10 us table
+			// copy and its launch gap in front of every front end were 0.7 % of it.  The next block's table goes to s4 instead, BEHIND this
+			// block's FM branch and carry there: the next front end waits for the table's event anyway, which now also says that the carry
+			// is through (it writes the look-back the next block's assist kernels read) -- one wait in front of the front end, not two.
+			// Slot (f+1) & 3 was last read by the front end of block f-3.
+			while (h->rot_next <= h->block_idx) { // (block_idx counts this block already)
+				int rc2 = stage_rot((int)(h->rot_next & 3), h->s4);
+				if (rc2) return rc2;
+				h->rot_next++;
+			}
+		}
 	} else {
 		// ---- resampled ladders, device part: the flushes this block completes (tables: see the top).  The resampler front end stays on
 		// the front stream, behind the pass over the raw input: next to the NEXT block's pass (on the downstream stream) it takes

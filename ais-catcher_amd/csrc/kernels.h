@@ -344,12 +344,14 @@ struct KV2Params {
 	const float2* omega;                        // FFT twiddles
 	float* est_f; float* est_prom;              // [n_chan][2 * n_windows]: window w starts at sample -512 + 256 w of this block
 	float* energy;                              // [n_chan][n_windows + 1]: sum of |x|^2 over [-512 + 512 i, +256)
-	float* disc;                                // [n_chan][FM_HIST + L] discriminator (FM_HIST leading history), as K5
+	float* disc;                                // [n_chan][FM_HIST + L] discriminator (FM_HIST leading history), as K5: [0, FM_HIST) and the block's last FM_HIST values ...
+	bool disc_full;                             // ... all of them (AISGPU_FLAG_TAPS: the discriminator output is a tap only)
 	float2* fmprev;                             // [n_chan] FMDemod::prev (0 in front of the first sample: the engine's all-zero look-back block has passed)
 	uint32_t* fmbits; long long fmbits_stride;  // [n_chan][L / 32]
 	float* fir_out; long long fir_stride;       // optional (taps): the FilterFL37 output itself
 	float taps[37];
 	int n_windows, L, n_chan;
+	int energy_rows;                            // kv2_fm_filter: its first rows of workgroups compute the energies (set by launch_kv2_assist)
 };
 // ModelEngineV2 with AISGPU_FLAG_GPU_DECODE (round 4): the engine's coherent branch on the device as well -- per channel strictly
 // sequential over its 512-sample blocks, like the reference (V2Engine.cpp:293-388): the tone gate / slot lock decide the frequency
@@ -386,7 +388,7 @@ void v2_prof_dump(); // experiment build: cycles of kv2_engine's phases on stder
 bool sincos_restatement_matches_host_libm(); // kv2_engine's sinf / cosf (glibc 2.35, FMA variant) on the host against the host's own libm
 hipError_t launch_kv2(const KV2Params& p, hipStream_t s, const KV2EParams* engine = nullptr); // engine: kv2_engine runs before the look-back is overwritten
 // the same in three parts (round 6: the engine on a stream of its own, beside the next block's front end and assist kernels)
-hipError_t launch_kv2_assist(const KV2Params& p, hipStream_t s, int part = 3); // part 1: estimates + energies, 2: the FM branch
+hipError_t launch_kv2_assist(const KV2Params& p, hipStream_t s, int part = 7); // part 1: estimates, 2: the FM branch, 4: energies
 hipError_t launch_kv2_engine(const KV2EParams& e, hipStream_t s);
 hipError_t launch_kv2_carry(const KV2Params& p, hipStream_t s);
 // Derotation + FIR + ScatterPLL + PhaseSearchEMA in one workgroup (k46_window_search, kernels.hip): K6Params without `sym` traffic

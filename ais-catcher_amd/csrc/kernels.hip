@@ -2971,10 +2971,73 @@ __device__ __forceinline__ float2 v2_sample(const KV2Params& p, int chan, int n)
 	return n < 0 ? p.hist[(size_t)chan * V2_HIST + (V2_HIST + n)] : p.c48[(size_t)chan * p.c48_stride + n];
 }
 
-// FreqOffset::Estimate (:56-131) for FFT_NW windows per wave: the FFT of the squared window with the reference's butterflies
-// (fft512 passes as in k2_fft_mag), magnitudes sqrtf(re^2 + im^2) in float (norm2, :33-36) in fftshift order, then one lane
-// per window runs the reference's loops in their order: the rolling 133-bin sum (two dependent operations per step), the peak
-// pair 102 bins apart, the total, the prominence and the parabola through the three pair sums.
+// FreqOffset::Estimate (:56-131) for V2E_NW windows per wave: the FFT of the squared window with the reference's butterflies
+// (fft512 passes as in k2_fft_mag), magnitudes sqrtf(re^2 + im^2) in float (norm2, :33-36) in fftshift order into LDS, then the
+// reference's loops (:74-131) in their order -- what is a dependent chain by lanes that do nothing else, what is not by the whole wave
+// (round 6, late; one lane per window ran all of it before: 166 us per 256 receivers, most of it that lane's ~15 instructions and LDS
+// round trips per candidate):
+//  * the rolling 133-bin sum (rolling - m[i-1] + m[i+132]: two dependent operations per step) by lanes 0-7, one per window, which
+//    leave every step's value in a small ring; `total` (the sum of all 512 bins from the left) starts with the same 133 additions
+//    and goes on with exactly the bins the rolling sum takes in (m[133] ... m[511]), so lanes 8-15 run it in the same instructions
+//    (they subtract 0.0f, which changes nothing: the sums are >= +0 or NaN);
+//  * the 380 candidates rolling + 0.6 (m[i+15] + m[i+117]) and "first maximum under a strict >" by all lanes in chunks of 64 steps:
+//    eight lanes per window, each over its candidates in rising order, then the larger value wins among them and on equal values
+//    the lower index; a NaN candidate never wins, and a NaN at candidate 0 keeps index 0, as `v > best` has it;
+//  * the peak pair 102 bins apart, the prominence and the parabola through the three pair sums by one lane per window.
+constexpr int V2E_NW = 8;                    // windows per wave (eight lanes per window in the candidate search)
+constexpr int V2E_MS = 512 + 64 / V2E_NW;    // floats per window of magnitudes: 8 banks between the windows of a wave
+constexpr int V2E_CH = 64, V2E_RP = V2E_CH + 8; // steps per chunk of the rolling sum, row pitch of its ring
+// the wave-wide part: magnitudes of the window whose squared samples sit in v[] (bit-reversed positions, as fft_square leaves them),
+// fftshift order, into mg[512]
+__device__ __forceinline__ void v2_fft_mag_sq(c2 (&v)[8], float2* X, float* mg, FftTwiddles& t, int lane) {
+	const int l7 = lane & 7, l8 = lane >> 3;
+	fft_pass(v, t.a0, t.a1, t.a2);
+#pragma unroll
+	for (int r = 0; r < 8; r++) X[9 * lane + r] = make_float2(v[r].x, v[r].y);
+	wave_sync();
+#pragma unroll
+	for (int r = 0; r < 8; r++) { const float2 d = X[l7 + 9 * r + 72 * l8]; v[r] = c2{ d.x, d.y }; }
+	wave_sync();
+	fft_pass(v, t.b0, t.b1, t.b2);
+#pragma unroll
+	for (int r = 0; r < 8; r++) X[l7 + 8 * r + 72 * l8] = make_float2(v[r].x, v[r].y);
+	wave_sync();
+#pragma unroll
+	for (int r = 0; r < 8; r++) { const float2 d = X[lane + 72 * r]; v[r] = c2{ d.x, d.y }; }
+	wave_sync();
+	fft_pass(v, t.c0, t.c1, t.c2_); // bin lane + 64 r
+#pragma unroll
+	// sqrtf(norm2(x)) (:69-72): the float square root through the correctly rounded double one (53 >= 2 * 24 + 2 bits: exact)
+	for (int r = 0; r < 8; r++) mg[(lane + 64 * r + 256) & 511] = (float)__dsqrt_rn((double)(v[r].x * v[r].x + v[r].y * v[r].y));
+}
+// behind the candidate search (:89-131), one lane per window: wi_ = the winning candidate, total = the sum of the 512 bins
+__device__ __forceinline__ void v2_search_tail(const float* m, int wi_, float total, float& f_out, float& prom_out) {
+	constexpr int N = 512, delta = 102, M = 133;
+	int fz = -1;
+	float peak = 0.0f;
+	for (int i = wi_; i < wi_ + (M - delta); i++) {
+		const float h = m[i] + m[i + delta];
+		if (h > peak) { peak = h; fz = i; }
+	}
+	prom_out = total > 0.0f ? __fdiv_rn(peak * (float)(N / 2), total) : 0.0f;
+	float f = 0.0f;
+	if (fz >= 0) {
+		float frac = 0.0f;
+		if (fz > 0 && fz + delta + 1 < N) {
+			const float a = m[fz - 1] + m[fz - 1 + delta];
+			const float c = m[fz + 1] + m[fz + 1 + delta];
+			const float den = a - 2.0f * peak + c;
+			if (den < 0.0f) {
+				frac = __fdiv_rn(0.5f * (a - c), den);
+				frac = frac > 0.5f ? 0.5f : (frac < -0.5f ? -0.5f : frac);
+			}
+		}
+		f = __fdiv_rn(__fdiv_rn((float)(N / 2) - ((float)fz + frac + 51.0f), 2.0f), (float)N);
+	}
+	f_out = f;
+}
+
+// The same estimate by one lane for ONE window (the engine's slot-locked estimates inside kv2_engine / kv2_engine_roles: rare):
 // the wave-wide part: magnitudes of the window that starts at sample s0 of the channel, fftshift order, into mg[512]
 __device__ __forceinline__ void v2_fft_mag_window(const KV2Params& p, int chan, int s0, float2* X, float* mg, FftTwiddles& t, int lane) {
 	const int src = fft_src_lane(lane);
@@ -3043,22 +3106,94 @@ __device__ __forceinline__ void v2_search(const float* m, float& f_out, float& p
 
 __global__ __launch_bounds__(64) void kv2_estimate(KV2Params p) {
 	__shared__ __attribute__((aligned(16))) float2 X[584];
-	__shared__ __attribute__((aligned(16))) float mag[FFT_NW * MAG_STRIDE];
+	__shared__ __attribute__((aligned(16))) float mag[V2E_NW * V2E_MS];
+	static_assert(2 * V2E_NW * V2E_RP <= 2 * 584, "kv2_estimate: the ring of rolling sums (and as many rows of scratch) lives in the FFT's exchange buffer");
 	const int lane = threadIdx.x;
 	const int nw = 2 * p.n_windows;
-	const int W0 = blockIdx.x * FFT_NW, n_win_total = p.n_chan * nw;
+	const int W0 = blockIdx.x * V2E_NW, n_win_total = p.n_chan * nw;
 	FftTwiddles t = fft_twiddles(p.omega, lane);
-	for (int wi = 0; wi < FFT_NW; wi++) {
-		const int W = W0 + wi;
-		if (W >= n_win_total) break;
+	const int src = fft_src_lane(lane);
+	// the 8 samples of a lane for window W0 + wi; the next window's are requested before this one's butterflies start (as k2_fft_mag)
+	float2 dn[8];
+	const auto fetch = [&](int wi) {
+		int W = W0 + wi;
+		W = W < n_win_total ? W : n_win_total - 1;
 		const int chan = W / nw, w = W - chan * nw;
-		v2_fft_mag_window(p, chan, -V2_HIST + 256 * w, X, mag + wi * MAG_STRIDE, t, lane);
+		const int s0 = -V2_HIST + 256 * w + src;
+#pragma unroll
+		for (int r = 0; r < 8; r++) dn[r] = v2_sample(p, chan, s0 + fft_src_step(r));
+	};
+	fetch(0);
+	for (int wi = 0; wi < V2E_NW; wi++) {
+		if (W0 + wi >= n_win_total) break;
+		c2 v[8];
+		fft_square(dn, v); // window[n] * window[n] into the bit-reversed position (:63-64)
+		__builtin_amdgcn_sched_barrier(0);
+		if (wi + 1 < V2E_NW) fetch(wi + 1);
+		__builtin_amdgcn_sched_barrier(0);
+		v2_fft_mag_sq(v, X, mag + wi * V2E_MS, t, lane);
 	}
 	wave_sync();
-	const int W = W0 + lane;
-	if (lane < FFT_NW && W < n_win_total) {
+
+	constexpr int N = 512, delta = 102, M = 133, ofs = 15, NC = N - M + 1; // 380 candidates
+	float* rl = reinterpret_cast<float*>(X); // [2 * V2E_NW][V2E_RP]: the chunk's rolling sums in rows 0-7 (the FFTs are through with X)
+	const int cw = lane & 7;
+	const bool chain = lane < 16, is_total = lane >= 8; // lanes 0-7: rolling sum of window cw, lanes 8-15: its `total`
+	const float* mc = mag + cw * V2E_MS;
+	const int ew = lane >> 3, es = lane & 7;            // candidate search: window ew, candidates es + 8 k of a chunk
+	const float* me = mag + ew * V2E_MS;
+	float r = 0.0f;
+	if (chain) {
+#pragma unroll 19
+		for (int jx = 0; jx < M; jx++) r += mc[jx];
+	}
+	float best = -1.0f; // (every candidate is >= +0 or NaN)
+	int bi = 0;
+	bool nan0 = false;
+#pragma unroll 1
+	for (int c0 = 0; c0 < NC; c0 += V2E_CH) {
+		if (chain) {
+#pragma unroll 1
+			for (int s0 = 0; s0 < V2E_CH; s0 += 16) {
+				float a[16], b[16];
+#pragma unroll
+				for (int e = 0; e < 16; e++) {
+					const int i = c0 + s0 + e;
+					const bool on = i >= 1 && i < NC; // (step 0 is the initial sum itself; zeros leave r as it is)
+					const float av = mc[i >= 1 ? i - 1 : 0], bv = mc[i + M - 1]; // (i + 132 <= 515 < V2E_MS)
+					a[e] = (on && !is_total) ? av : 0.0f;
+					b[e] = on ? bv : 0.0f;
+				}
+#pragma unroll
+				for (int e = 0; e < 16; e++) {
+					r = (r - a[e]) + b[e];
+					rl[lane * V2E_RP + s0 + e] = r; // (rows 8-15: the `total` lanes' running values, which nobody reads -- no branch in the chain)
+				}
+			}
+		}
+		wave_sync();
+#pragma unroll
+		for (int k = 0; k < V2E_CH / 8; k++) {
+			const int s = es + 8 * k, i = c0 + s;
+			const float v = rl[ew * V2E_RP + s] + 0.6f * (me[i + ofs] + me[i + ofs + delta]); // (i + 117 <= 500)
+			if (i == 0) nan0 = v != v;
+			if (i < NC && v > best) { best = v; bi = i; }
+		}
+		wave_sync();
+	}
+	// among the eight lanes of a window: the larger value, on equal values the lower index
+#pragma unroll
+	for (int d = 1; d < 8; d <<= 1) {
+		const float ob = __shfl_xor(best, d);
+		const int oi = __shfl_xor(bi, d);
+		if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+	}
+	if (__shfl((int)nan0, lane & ~7)) bi = 0;
+	const float total = __shfl(r, 8 + ew);
+	const int W = W0 + ew;
+	if (es == 0 && W < n_win_total) {
 		float f, prom;
-		v2_search(mag + lane * MAG_STRIDE, f, prom);
+		v2_search_tail(me, bi, total, f, prom);
 		p.est_f[W] = f;
 		p.est_prom[W] = prom;
 	}
@@ -3091,47 +3226,76 @@ __device__ __forceinline__ float atan2_fast_ref(float y, float x) {
 	return y < 0.0f ? -r : r;
 }
 
-__global__ __launch_bounds__(256) void kv2_fm(KV2Params p) { // FMDemod::Run (:265-273)
-	const int chan = blockIdx.y;
-	const int n = blockIdx.x * 256 + threadIdx.x;
-	if (n >= p.L) return;
-	const float2* y = p.c48 + (size_t)chan * p.c48_stride + n;
-	const float2 d = y[0];
-	const float2 pv = n == 0 ? p.fmprev[chan] : y[-1];
-	const float npi = -pv.y; // input[i] * std::conj(prev)
-	const float re = d.x * pv.x - d.y * npi;
-	const float im = d.x * npi + d.y * pv.x;
-	p.disc[(size_t)chan * (FM_HIST + p.L) + FM_HIST + n] = __fdiv_rn(atan2_fast_ref(im, re), 3.14159265358979323846f);
-}
-
-// FilterFL37 (:48-54, :175-188): out[n] = sum_{i<18} (a[i] + a[36 - i]) * taps[i] + a[18] * taps[18] over a = disc[n-36 .. n]
-__global__ __launch_bounds__(256) void kv2_filter(KV2Params p) {
-	const int chan = blockIdx.y;
-	const int n = blockIdx.x * 256 + threadIdx.x; // L is a multiple of 512
-	const float* a = p.disc + (size_t)chan * (FM_HIST + p.L) + n; // a[i] = disc[n - 36 + i]
+// FMDemod::Run (:265-273) + FilterFL37 (:48-54, :175-188) as ONE kernel (round 6, the form of k5_fm_filter; kv2_fm + kv2_filter before:
+// 67 + 95 us per 256 receivers, the discriminator -- 50 MB per block -- written and read 19 times per output through the caches).  A workgroup
+// makes 256 outputs: out[n] = sum_{i<18} (a[i] + a[36 - i]) * taps[i] + a[18] * taps[18] over a = disc[n-36 .. n], the discriminator in LDS.  The 36
+// values in front of a workgroup's outputs: the first workgroup of a block takes them from the previous block's tail (disc[0 .. 36), put there by
+// kv2_carry), every other one computes them again (14 % more arctangents).  (Four outputs per lane and tiles of 1,024 -- 3.5 % more arctangents, a
+// lane's 40 values in ten 128-bit LDS reads -- take 48 instead of 56 us alone and 139 instead of 130 us beside the estimates, which is where
+// the kernel runs: measured, not kept.)  Only the block's last 36 discriminator values are stored (for
+// kv2_carry), all of them where the taps are asked for (disc_full).
+__global__ __launch_bounds__(256) void kv2_fm_filter(KV2Params p) {
+	__shared__ float s_fm[256 + FM_HIST];
+	const int t = threadIdx.x;
+	const int t0 = blockIdx.x * 256; // L is a multiple of 512
+	if ((int)blockIdx.y < p.energy_rows) { // the launch's FIRST rows of workgroups (so that these long lanes start first): the half-block energies, kv2_energy's lanes
+		const int id = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 256 + t;
+		const int per = p.n_windows + 1;
+		if (id < p.n_chan * per) {
+			const int ch = id / per, i = id - ch * per;
+			const int s0 = -V2_HIST + 512 * i;
+			float e = 0.0f;
+			for (int n = 0; n < 256; n++) {
+				const float2 z = v2_sample(p, ch, s0 + n);
+				e += z.x * z.x + z.y * z.y;
+			}
+			p.energy[id] = e;
+		}
+		return;
+	}
+	const int chan = (int)blockIdx.y - p.energy_rows;
+	const float2* y = p.c48 + (size_t)chan * p.c48_stride;
+	float* dsc = p.disc + (size_t)chan * (FM_HIST + p.L);
+	const auto disc = [&](int n) { // sample n >= 0 of the block
+		const float2 d = y[n];
+		const float2 pv = n == 0 ? p.fmprev[chan] : y[n - 1];
+		const float npi = -pv.y; // input[i] * std::conj(prev)
+		const float re = d.x * pv.x - d.y * npi;
+		const float im = d.x * npi + d.y * pv.x;
+		return __fdiv_rn(atan2_fast_ref(im, re), 3.14159265358979323846f);
+	};
+	const float f = disc(t0 + t);
+	s_fm[FM_HIST + t] = f;
+	if (p.disc_full || (t0 + 256 == p.L && t >= 256 - FM_HIST)) dsc[FM_HIST + t0 + t] = f;
+	if (t < FM_HIST) s_fm[t] = t0 == 0 ? dsc[t] : disc(t0 - FM_HIST + t);
+	__syncthreads();
+	const float* a = s_fm + t; // a[i] = disc[n - 36 + i]
 	float sum = 0.0f;
 #pragma unroll
 	for (int i = 0; i < 18; i++) sum += (a[i] + a[36 - i]) * p.taps[i];
 	sum = sum + a[18] * p.taps[18];
+	const int n = t0 + t;
 	if (p.fir_out) p.fir_out[(size_t)chan * p.fir_stride + n] = sum;
 	const unsigned long long b = __ballot(sum > 0.0f);
-	if ((threadIdx.x & 63) == 0) {
+	if ((t & 63) == 0) {
 		uint32_t* o = p.fmbits + (size_t)chan * p.fmbits_stride + (n >> 5);
 		o[0] = (uint32_t)b;
 		o[1] = (uint32_t)(b >> 32);
 	}
 }
 
-// after everything above has read them: the block's tail becomes the next block's look-back
-__global__ __launch_bounds__(64) void kv2_carry(KV2Params p) {
-	const int chan = blockIdx.x;
+// after everything above has read them: the block's tail becomes the next block's look-back -- one channel by the 64 lanes of a wave.
+// (Round 6, late: done by the engine's own workgroups instead, at their start or at the end of wave 2's loop, it cost the engine kernel
+// 110 us of its 2,066 -- measured on one box, A/B -- so it stays a kernel, and leaves the step's chain by its stream: aisgpu.cpp.)
+__device__ __forceinline__ void v2_carry_chan(const KV2Params& p, int chan, int lane) {
 	float* dsc = p.disc + (size_t)chan * (FM_HIST + p.L);
-	if (threadIdx.x < FM_HIST) dsc[threadIdx.x] = dsc[p.L + threadIdx.x];
+	if (lane < FM_HIST) dsc[lane] = dsc[p.L + lane];
 	const float2* x = p.c48 + (size_t)chan * p.c48_stride + (p.L - V2_HIST);
-	for (int i = threadIdx.x; i < V2_HIST; i += 64) p.hist_out[(size_t)chan * V2_HIST + i] = x[i];
-	if (threadIdx.x == 0) p.fmprev[chan] = p.c48[(size_t)chan * p.c48_stride + p.L - 1];
-	if (p.fmtail_out && threadIdx.x < 16) p.fmtail_out[(size_t)chan * 16 + threadIdx.x] = p.fmbits[(size_t)chan * p.fmbits_stride + (p.L - 512) / 32 + threadIdx.x];
+	for (int i = lane; i < V2_HIST; i += 64) p.hist_out[(size_t)chan * V2_HIST + i] = x[i];
+	if (lane == 0) p.fmprev[chan] = p.c48[(size_t)chan * p.c48_stride + p.L - 1];
+	if (p.fmtail_out && lane < 16) p.fmtail_out[(size_t)chan * 16 + lane] = p.fmbits[(size_t)chan * p.fmbits_stride + (p.L - 512) / 32 + lane];
 }
+__global__ __launch_bounds__(64) void kv2_carry(KV2Params p) { v2_carry_chan(p, blockIdx.x, threadIdx.x); }
 
 // ------------------------------------------------------------------------------------------
 // K7: AIS::Decoder (Marine/AIS.h:82-181, Marine/AIS.cpp:33-142) on the device -- NRZI, training / start-flag state machine,
@@ -4856,16 +5020,18 @@ hipError_t launch_k7(const K7Params& p, hipStream_t s) {
 	return hipGetLastError();
 }
 
-hipError_t launch_kv2_assist(const KV2Params& p, hipStream_t s, int part) { // part 1: estimates + energies; 2: the FM branch; 3: both
+hipError_t launch_kv2_assist(const KV2Params& p, hipStream_t s, int part) { // part 1: estimates; 2: the FM branch; 4: energies; 7: all
 	if (part & 1) {
 		const int n_est = p.n_chan * 2 * p.n_windows;
-		hipLaunchKernelGGL(kv2_estimate, dim3((n_est + FFT_NW - 1) / FFT_NW), dim3(64), 0, s, p);
-		hipLaunchKernelGGL(kv2_energy, dim3((p.n_chan * (p.n_windows + 1) + 63) / 64), dim3(64), 0, s, p);
+		hipLaunchKernelGGL(kv2_estimate, dim3((n_est + V2E_NW - 1) / V2E_NW), dim3(64), 0, s, p);
 	}
+	// (the energies ride in the FM branch's launch as its first rows of workgroups where both are asked for: a 15 us kernel less on the step's chain)
 	if (part & 2) {
-		hipLaunchKernelGGL(kv2_fm, dim3(p.L / 256, p.n_chan), dim3(256), 0, s, p);
-		hipLaunchKernelGGL(kv2_filter, dim3(p.L / 256, p.n_chan), dim3(256), 0, s, p);
-	}
+		KV2Params pe = p;
+		const int per_row = (p.L / 256) * 256;
+		pe.energy_rows = (part & 4) ? (p.n_chan * (p.n_windows + 1) + per_row - 1) / per_row : 0;
+		hipLaunchKernelGGL(kv2_fm_filter, dim3(p.L / 256, p.n_chan + pe.energy_rows), dim3(256), 0, s, pe);
+	} else if (part & 4) hipLaunchKernelGGL(kv2_energy, dim3((p.n_chan * (p.n_windows + 1) + 63) / 64), dim3(64), 0, s, p);
 	return hipGetLastError();
 }
 hipError_t launch_kv2_engine(const KV2EParams& e, hipStream_t s) { // one workgroup per channel (reads the look-back `hist`)
@@ -4879,7 +5045,7 @@ hipError_t launch_kv2_carry(const KV2Params& p, hipStream_t s) {
 	return hipGetLastError();
 }
 hipError_t launch_kv2(const KV2Params& p, hipStream_t s, const KV2EParams* engine) {
-	hipError_t e = launch_kv2_assist(p, s, 3);
+	hipError_t e = launch_kv2_assist(p, s, 7);
 	if (e == hipSuccess && engine) e = launch_kv2_engine(*engine, s);
 	if (e == hipSuccess) e = launch_kv2_carry(p, s);
 	return e;
