@@ -1939,11 +1939,13 @@ int aisgpu_run(aisgpu_t* h) {
 		// ---- 96 kSPS: the converted input goes straight into Rotate; one downstream block per input block
 		const int pb = (int)(h->block_idx & 1);
 		const int q = (int)(h->block_idx % NBUF);
-		if (h->block_idx >= 2) HIPCHK(hipEventSynchronize(h->rot_ev[pb]));
-		gen_rot_table(h, h->h_rot[pb]);
-		HIPCHK(hipMemcpyAsync(h->d_rot[pb], h->h_rot[pb], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
-		HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
-		h->rot_ev_used[pb] = true;
+		if (!h->mode_x) { // (channel mode X has no Rotate: no table to make and to copy in front of every block)
+			if (h->block_idx >= 2) HIPCHK(hipEventSynchronize(h->rot_ev[pb]));
+			gen_rot_table(h, h->h_rot[pb]);
+			HIPCHK(hipMemcpyAsync(h->d_rot[pb], h->h_rot[pb], ((size_t)ROT_HIST + h->n96) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+			HIPCHK(hipEventRecord(h->rot_ev[pb], h->stream));
+			h->rot_ev_used[pb] = true;
+		}
 		WAITEV(h->stream, h->ev_c48free[q]);
 		K1uParams ku;
 		ku.xin = xcur; ku.xin_stride = xstride; ku.xin_off = h->xh;
@@ -1951,7 +1953,7 @@ int aisgpu_run(aisgpu_t* h) {
 		ku.us_idx = nullptr; ku.us_alpha = nullptr; ku.rot = h->d_rot[pb];
 		ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
 		ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->mode_x ? h->has_fdc : 0; ku.L = h->L;
-		if (h->mode_x) { ku.c48_rows_per_rx = 1; HIPCHK(launch_k1x(ku, h->npost, R, h->stream)); }
+		if (h->mode_x) { ku.c48_rows_per_rx = 1; ku.spw_force = h->k1u_spw; HIPCHK(launch_k1x(ku, h->npost, R, h->stream)); } // (test hook k1u_spw != 0: the workgroup form of K1x at 96 kSPS)
 		else { ku.spw_force = h->k1u_spw; HIPCHK(launch_k1u(ku, 0, R, h->stream)); }
 		if (h->x_direct) HIPCHK(launch_copy_rows(ku.xin + h->n_pre - h->xh, ku.xin_stride, h->d_xhist[(h->in_blocks & 1) ^ 1], h->xh, h->xh, R, h->stream));
 		int rc = enqueue_downstream(h, q, pb);

@@ -972,6 +972,95 @@ __global__ __launch_bounds__(K1U_T) void k1x_single_channel(K1uParams p) {
 	}
 }
 
+// K1x at 96 kSPS without a resampler (NPOST = 1, us_idx == nullptr: `-c X` at the rate mode X is usually fed with), register / DPP
+// form (round 6, late) -- k1x_single_channel<1, 512> is five waves x four barriers per 512 outputs, ~4 wave-instructions per output
+// (0.66 ms per 4,096 receivers x 49,152 samples alone, issue-bound like everything behind it, so the step was the sum of its kernels).
+// Here one wave walks a span of tiles of 1,024 input samples like k1_dpp: lane l owns 16 consecutive samples, Downsample2CIC5 is
+// reg_stage<16> (eight 48 kHz samples per lane), the droop filter takes the two samples in front of them and FilterCIC5 the five in
+// front of its eight from the neighbouring lane through DPP wave shifts (lane 0: lane 63's values of the previous tile, shadow
+// registers); a tile comes straight from memory into the wave's LDS buffer (global_load_lds, swizzled as in k1_dpp), the next one is
+// requested as soon as this one is in registers.  A span starts one tile early to fill the filters:
+// nothing put out depends on more than the 19 input samples in front of it (FCIC5 5 + FDC 2 at 48 kHz, CIC5 5 at 96 kHz), so only
+// the last 128 samples of that tile are fetched (one load instruction; in front of the block: the library's look-back of DSK_HIST samples).  Same sums in the same pairs as
+// k1x_single_channel (cic5_dec_chunk; the shared pyramid of FilterCIC5 forms exactly the pair sums of the six-sample one): same bits.
+__global__ __launch_bounds__(64) void k1x_wave(K1uParams p, int tiles_per_span) {
+	__shared__ __attribute__((aligned(16))) float4 xt[512]; // the tile, XOR-swizzled in units of 16 B as in k1_dpp (global_load_lds)
+	const int lane = threadIdx.x, rx = blockIdx.y, span = blockIdx.x;
+	const int tiles = p.L / 512;
+	const int tile_first = span * tiles_per_span - 1; // warm-up tile
+	int tile_last = tile_first + tiles_per_span;
+	if (tile_last >= tiles) tile_last = tiles - 1;
+	const XRow xr = make_xrow(p, rx);
+	float2* out = p.c48 + ((size_t)rx * p.c48_rows_per_rx) * p.c48_stride;
+	HaloState<16, c2> s16 = {};
+	HaloState<8, c2> sf = {};
+	c2 th0 = { 0.f, 0.f }, th1 = { 0.f, 0.f };
+	// slot 64 e + lane of the tile buffer <- piece dma_q of row 8 e + lane / 8 (k1_dpp's DMA path with W4 = 8: conflict-free 128-bit reads)
+	const int dma_off = (lane / 8) * 8 + ((lane % 8) ^ ((lane / 8) % 8));
+	const auto prefetch = [&](int tile) {
+		if (tile == tile_first) { // (wave-uniform) the last 128 samples of the warm-up tile = one load instruction; in front of the block: the look-back
+			static_assert(DSK_HIST == 128, "k1x_wave: the look-back in front of a block is the warm-up tile's last load instruction");
+			const float2* b128 = tile >= 0 ? xr.cur + (size_t)tile * 1024 + 896 : (xr.prev ? xr.prev + (xr.n - 128) : xr.cur - 128);
+			__builtin_amdgcn_global_load_lds((const void*)(reinterpret_cast<const uint4*>(b128) + dma_off), (__attribute__((address_space(3))) void*)(xt + 7 * 64), 16, 0, K1_LOAD_AUX);
+		} else {
+			const uint4* src = reinterpret_cast<const uint4*>(xr.cur + (size_t)tile * 1024) + dma_off;
+#pragma unroll
+			for (int e = 0; e < 8; e++)
+				__builtin_amdgcn_global_load_lds((const void*)(src + e * 64), (__attribute__((address_space(3))) void*)(xt + e * 64), 16, 0, K1_LOAD_AUX);
+		}
+	};
+	prefetch(tile_first);
+	for (int tile = tile_first; tile <= tile_last; tile++) {
+		c2 x[16];
+#pragma unroll
+		for (int e = 0; e < 8; e++) { // every component is used, so these stay 128-bit loads
+			const float4 v = xt[lane * 8 + (e ^ (lane % 8))];
+			x[2 * e] = c2{ v.x, v.y }; x[2 * e + 1] = c2{ v.z, v.w };
+		}
+		wave_sync(); // the tile is in registers: the next one may land in xt
+		if (tile < tile_last) prefetch(tile + 1);
+		c2 t8[8];
+		reg_stage<16>(x, s16, t8); // DS2_1: Downsample2CIC5 (DSP.cpp:93-117)
+		c2 f8[8];
+		if (p.has_fdc) { // FDC (DSP.cpp:283-293): alpha * (h1 + x) + h2 * beta
+			const c2 tm2 = from_prev_lane(t8[6], th0), tm1 = from_prev_lane(t8[7], th1);
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const c2 xm2 = j >= 2 ? t8[j - 2] : (j == 0 ? tm2 : tm1), xm1 = j >= 1 ? t8[j - 1] : tm1;
+				const c2 s2 = xm2 + t8[j];
+				f8[j] = s2 * p.alpha + xm1 * p.beta;
+			}
+			th0 = carry_to_next_tile(tm2, t8[6]);
+			th1 = carry_to_next_tile(tm1, t8[7]);
+		} else {
+#pragma unroll
+			for (int j = 0; j < 8; j++) f8[j] = t8[j];
+		}
+		// FilterCIC5 (DSP.cpp:132-157): out(m) from f(m-5 .. m), five levels of pair sums, * 1/32
+		c2 h[5];
+		get_halo<8, c2>(f8, sf, h);
+		c2 g[13];
+#pragma unroll
+		for (int i = 0; i < 5; i++) g[i] = h[i];
+#pragma unroll
+		for (int i = 0; i < 8; i++) g[5 + i] = f8[i];
+#pragma unroll
+		for (int lvl = 0; lvl < 5; lvl++) {
+#pragma unroll
+			for (int i = 0; i < 12 - lvl; i++) g[i] = g[i + 1] + g[i];
+		}
+		put_halo<8, c2>(f8, sf, h);
+		if (tile > tile_first) {
+			float4* dst = reinterpret_cast<float4*>(out + (size_t)tile * 512 + lane * 8);
+#pragma unroll
+			for (int e = 0; e < 4; e++) {
+				const c2 a = g[2 * e] * 0.03125f, b = g[2 * e + 1] * 0.03125f;
+				dst[e] = make_float4(a.x, a.y, b.x, b.y);
+			}
+		}
+	}
+}
+
 // ------------------------------------------------------------------------------------------
 // K1k: the tail of a decimate-by-3 ladder (rates 288k * 2^k, Model.cpp:207-219,248-259,278-289,308-313):
 // DownsampleKFilter (26-tap Blackman-Harris FIR, keep every 3rd output, DSP.cpp:160-189, DSP.h:195-201) ->
@@ -4906,7 +4995,17 @@ hipError_t launch_k1u(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
 #ifndef K1X_M
 #define K1X_M 512 // 48 kHz outputs per workgroup of the mode-X front end: a whole window (K1U_M = 128 made 786 k workgroups of a 4,096-receiver step)
 #endif
+#ifndef K1X_WAVE
+#define K1X_WAVE 1
+#endif
 hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
+	if (K1X_WAVE && npost == 1 && !p.us_idx && p.L % 512 == 0 && !p.spw_force) { // the register / DPP form (test hook "k1u_spw" != 0: the workgroup form)
+		const int tiles = p.L / 512;
+		int tps = 16; // tiles per span: ~4,096 waves or more where the batch has them
+		while (tps > 1 && (long long)((tiles + tps - 1) / tps) * n_rx < 4096) tps >>= 1;
+		hipLaunchKernelGGL(k1x_wave, dim3((tiles + tps - 1) / tps, n_rx), dim3(64), 0, s, p, tps);
+		return hipGetLastError();
+	}
 	const dim3 grid(p.L / K1X_M, n_rx);
 	if (npost == 2) hipLaunchKernelGGL((k1x_single_channel<2, K1X_M>), grid, dim3(K1U_T), 0, s, p);
 	else if (npost == 1) hipLaunchKernelGGL((k1x_single_channel<1, K1X_M>), grid, dim3(K1U_T), 0, s, p);
