@@ -257,7 +257,7 @@ struct aisgpu {
 	bool ps_box = false; PsBoxState* d_box[2] = {}; // Demod::PhaseSearch (boxcar) instead of PhaseSearchEMA
 	bool trace = false; std::vector<TraceRec> trace_recs; hipEvent_t trace_origin = nullptr;
 	// fused derotation + FIR path (no phasor / derotated-sample arrays in HBM); off when taps or the FM branch need them
-	int k1u_spw = 0; // test hook "k1u_spw": forces the resampler front end's span walk (launch_k1u)
+	int k1u_spw = 0; // test hook "k1u_spw": forces the resampler front end's span walk (launch_k1u); channel mode X at 96 kSPS: 2 = k1x_single_channel, 4 / 8 = k1x_wave's span length
 	// Round 6: the tail of a resampled ladder with two stages behind Upsample (every bucket from 384k up: 6 MSPS, 2.4 MSPS, 10 MSPS ...)
 	// as one-wave workgroups of the front-end kernel itself -- k1_dpp<2, 5, false>: Upsample outputs computed where the other formats
 	// convert, DS2_2 / DS2_1 in registers, and with the fused back end the spectral analysis at the end of its waves -- instead of
@@ -1953,7 +1953,7 @@ int aisgpu_run(aisgpu_t* h) {
 		ku.us_idx = nullptr; ku.us_alpha = nullptr; ku.rot = h->d_rot[pb];
 		ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
 		ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->mode_x ? h->has_fdc : 0; ku.L = h->L;
-		if (h->mode_x) { ku.c48_rows_per_rx = 1; ku.spw_force = h->k1u_spw; HIPCHK(launch_k1x(ku, h->npost, R, h->stream)); } // (test hook k1u_spw != 0: the workgroup form of K1x at 96 kSPS)
+		if (h->mode_x) { ku.c48_rows_per_rx = 1; ku.spw_force = h->k1u_spw; HIPCHK(launch_k1x(ku, h->npost, R, h->stream)); } // (test hook k1u_spw = 2: the workgroup form of K1x at 96 kSPS, 4 / 8: k1x_wave with spans of that many tiles)
 		else { ku.spw_force = h->k1u_spw; HIPCHK(launch_k1u(ku, 0, R, h->stream)); }
 		if (h->x_direct) HIPCHK(launch_copy_rows(ku.xin + h->n_pre - h->xh, ku.xin_stride, h->d_xhist[(h->in_blocks & 1) ^ 1], h->xh, h->xh, R, h->stream));
 		int rc = enqueue_downstream(h, q, pb);

@@ -4999,10 +4999,11 @@ hipError_t launch_k1u(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
 #define K1X_WAVE 1
 #endif
 hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
-	if (K1X_WAVE && npost == 1 && !p.us_idx && p.L % 512 == 0 && !p.spw_force) { // the register / DPP form (test hook "k1u_spw" != 0: the workgroup form)
+	if (K1X_WAVE && npost == 1 && !p.us_idx && p.L % 512 == 0 && p.spw_force != 2) { // the register / DPP form (test hook "k1u_spw" = 2: the workgroup form)
 		const int tiles = p.L / 512;
-		int tps = 16; // tiles per span: ~4,096 waves or more where the batch has them
+		int tps = 16; // tiles per span: ~4,096 waves or more where the batch has them (test hook "k1u_spw" = 4 / 8: spans of that many tiles)
 		while (tps > 1 && (long long)((tiles + tps - 1) / tps) * n_rx < 4096) tps >>= 1;
+		if (p.spw_force > 2) tps = p.spw_force;
 		hipLaunchKernelGGL(k1x_wave, dim3((tiles + tps - 1) / tps, n_rx), dim3(64), 0, s, p, tps);
 		return hipGetLastError();
 	}

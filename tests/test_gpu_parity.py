@@ -517,6 +517,45 @@ def test_channel_mode_x_receivers_packed(rate, block, nblocks, R, gpu_decode):
             hms[r].close()
 
 
+@pytest.mark.parametrize("hook,block,fmt,R", [(0, 1024 * 48, "cf32", 3), (4, 1024 * 48, "cf32", 3), (8, 1024 * 44, "cf32", 2), (2, 1024 * 48, "cf32", 2),
+                                             (0, 1024 * 24, "cu8", 2), (8, 1024 * 24, "cs16", 3), (4, 1024 * 1, "cf32", 2)])
+def test_channel_mode_x_96k_wave_front_end(hook, block, fmt, R, monkeypatch):
+    """Round 6, late: at 96 kSPS the mode-X front end is k1x_wave -- one wave per span of 1,024-sample tiles, Downsample2CIC5 / droop /
+    FilterCIC5 in registers with DPP halos, a warm-up tile of which only the last 128 samples are read (in front of a block: the library's
+    look-back).  Small batches get one-tile spans; the test hook k1u_spw forces spans of 4 / 8 tiles (tile-to-tile shadow registers,
+    a last span that is shorter: 44 and 48 tiles per block; a block of ONE tile), 2 forces the workgroup form it replaced.  CF32 read in
+    place and CU8 / CS16 through the converted copy; 48 kHz samples are compared through hard bits, levels and ppm of every block."""
+    if hook:
+        monkeypatch.setenv("AISGPU_K1U_SPW", str(hook))
+    rate, nblocks = 96000, 5
+    per = 1 if fmt == "cf32" else 2
+    conv = {"cu8": synth.to_cu8, "cs16": synth.to_cs16, "cf32": lambda v: v}[fmt]
+    xs = [conv(synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=610 + r, gap_slots=(1, 2), single_channel=True)) for r in range(R)]
+    oracles = []
+    for x in xs:
+        o = checkers.Oracle(model=2, rate=rate, fmt=fmt, taps=True, mode_x=True)
+        o.feed_blocks(x, block)
+        oracles.append(o)
+    g = gpu.AisGpu(sample_rate=rate, n_receivers=R, block_len=block, input_format=_FMT[fmt], mode_x=True)
+    gd, wd = [0] * R, [0] * R
+    for b in range(nblocks):
+        for r in range(R):
+            g.submit(r, xs[r][b * block * per:(b + 1) * block * per])
+        g.run()
+        g.sync_outputs()
+        for s_ in range(g.out_count()):
+            for r in range(R):
+                out, o = g.fetch(r, 0, s_), oracles[r]
+                n, W = out["n_groups"], out["n_windows"]
+                for j in range(5):
+                    assert np.array_equal(out["bits"][j], o.bits(0, j)[0][gd[r]:gd[r] + n]), "bits b%d s%d r%d j%d" % (b, s_, r, j)
+                assert _feq(out["lvl"], o.bits(0, 0)[1][gd[r]:gd[r] + n]) and _feq(out["ppm"], o.tap_ppm(2)[wd[r]:wd[r] + W])
+                gd[r] += n
+                wd[r] += W
+    g.close()
+    assert gd[0] > 0
+
+
 @pytest.mark.parametrize("rate,block,fmt", [(96000, 1024 * 48, "cf32"), (96000, 1024 * 24, "cu8"), (150000, 2048 * 30, "cf32"),
                                             (120000, 2048 * 24, "cs8"), (96000, 1024, "cf32")])
 def test_lowest_rates(rate, block, fmt):
