@@ -715,7 +715,9 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	} else if (h->fft_in_k1) {
 		// the front-end waves have done the whole analysis (k1_fft_tail): fz / ppm of this block are there when K1 is
 		if (!h->k1_done[q]) { HIPCHK(hipEventRecord(h->ev_search[q], h->stream)); h->k1_done[q] = h->ev_search[q]; }
-	} else { // FFT + searches follow the front end on its stream (four busy streams are the limit)
+	} else { // FFT + searches follow the front end on its stream (four busy streams are the limit; on s4 in front of this block's refine +
+		// derotation / FIR kernels -- tried when the front ends of these ladders became one-wave workgroups, round 6 -- s4 idles through
+		// every recurrence: 288 kSPS 1.60 -> 1.83 ms per step, mode X 2.16 -> 2.46: profiles/r06_expK)
 		h->k1_done[q] = nullptr;
 		{ TraceScope t(h, "fft+search", h->ds); HIPCHK(launch_k2a_fft_search(k2, h->n_chan, h->ds)); }
 		HIPCHK(hipEventRecord(h->ev_search[q], h->ds));
@@ -1975,7 +1977,7 @@ int aisgpu_run(aisgpu_t* h) {
 		kk.rot = h->d_rot[pb]; kk.c48 = h->d_c48[q]; kk.c48_stride = h->c48s; kk.L = h->L;
 		kk.us_idx = nullptr; kk.us_alpha = nullptr;
 		memcpy(kk.taps, TAPS_BH_28_3, sizeof kk.taps);
-		HIPCHK(launch_k1k(kk, R, h->stream));
+		HIPCHK(launch_k1k(kk, R, h->stream, h->k1u_spw));
 		if (h->x_direct) HIPCHK(launch_copy_rows(kk.xin + h->n_pre - h->xh, kk.xin_stride, h->d_xhist[(h->in_blocks & 1) ^ 1], h->xh, h->xh, R, h->stream));
 		int rc = enqueue_downstream(h, q, pb);
 		if (rc) return rc;

@@ -299,7 +299,7 @@ hipError_t launch_copy_rows(const float2* src, long long src_stride, float2* dst
 hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long block_bytes, void* hist, int tail_bytes,
                           int n_rx, hipStream_t s);
 hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s); // channel mode X: npost CIC5 stages down to 48 kHz, us_idx == nullptr: no resampler
-hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s);
+hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s, int hook = 0);
 hipError_t launch_convert_rows(const void* in, long long in_stride, int fmt, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
 // DownsampleMovingAverage (DSP.cpp:60-82) at an integer ratio m: dst[i] = (((0 + x[m i]) + x[m i + 1]) + ...) / m, n outputs per row
 hipError_t launch_ma_rows(const void* in, long long in_stride, int fmt, int m, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);

@@ -1124,6 +1124,110 @@ __global__ __launch_bounds__(K1U_T) void k1k_dsk_frontend(K1kParams p) {
 	}
 }
 
+// K1k without a resampler in front (the 288k * 2^k ladders themselves), register / DPP form (round 6, late; the form of k1x_wave).
+// k1k_dsk_frontend<128> is five waves x four barriers per 128 outputs per channel: 0.73 ms per 1,024 receivers x 196,608 samples alone,
+// issue-bound like everything behind it.  Here one wave walks a span of tiles of 1,536 input samples (512 at 96 kHz, 256 per channel
+// at 48 kHz); a tile comes straight from memory into the wave's LDS buffer (global_load_lds, 1 KB contiguous per instruction), with
+// the previous tile's last 32 samples kept in front of it.  Lane l owns the 96 kHz samples i = 8 l .. 8 l + 7: DownsampleKFilter
+// (DSP.cpp:160-189) is sum_k taps[k] * x[3 i - 25 + k], accumulated from the left, over a window of 48 samples the lane reads from LDS
+// in 24 128-bit pieces (the pieces are XOR-swizzled by their 256-byte row -- through the global addresses of the DMA -- so that the
+// sixteen lanes a read serves hit sixteen different bank groups: a lane's window starts every 192 bytes); Rotate (DSP.cpp:296-316) from
+// the table (requested a tile ahead); DS2_a / DS2_b as reg_stage<8>, FilterCIC5 on the lane's four 48 kHz samples per channel with the
+// five in front of them from the two neighbouring lanes (get_halo<4>).  A span starts a tile early: nothing put out depends on more than
+// 70 input samples in front of it, so of that tile only the last 128 samples are fetched (one load instruction; in front of the block:
+// the library's look-back of DSK_HIST samples).  Same products and sums in the same order as k1k_dsk_frontend: same bits.
+__device__ __forceinline__ int k1kw_slot(int pf) { return (pf & ~15) | ((pf & 15) ^ ((pf >> 4) & 3)); } // logical 16-byte piece (32 look-back samples = 16 pieces in front) -> LDS slot
+__global__ __launch_bounds__(64) void k1k_wave(K1kParams p, int tiles_per_span) {
+	__shared__ __attribute__((aligned(16))) float4 xt[16 + 768];
+	const int lane = threadIdx.x, rx = blockIdx.y, span = blockIdx.x;
+	const int tiles = p.L / 256;
+	const int tile_first = span * tiles_per_span - 1; // warm-up tile
+	int tile_last = tile_first + tiles_per_span;
+	if (tile_last >= tiles) tile_last = tiles - 1;
+	const XRow xr = make_xrow(p, rx);
+	float2* outa = p.c48 + ((size_t)rx * 2) * p.c48_stride;
+	float2* outb = outa + p.c48_stride;
+	HaloState<8, c2> sup = {}, sdn = {};
+	HaloState<4, c2> sfa = {}, sfb = {};
+	// DMA: slot 16 + 64 e + lane <- piece g of the tile with k1kw_slot(16 + g) == that slot (the swizzle term does not depend on e)
+	const int dma_g = (lane & ~15) + ((lane & 15) ^ ((1 + (lane >> 4)) & 3));
+	float4 rot_next[4];
+	const auto prefetch = [&](int tile) {
+		if (tile == tile_first) { // (wave-uniform) only the tile's last 128 samples = its last load instruction
+			static_assert(DSK_HIST == 128, "k1k_wave: the look-back in front of a block is the warm-up tile's last load instruction");
+			const float2* b128 = tile >= 0 ? xr.cur + (size_t)tile * 1536 + 1408 : (xr.prev ? xr.prev + (xr.n - 128) : xr.cur - 128);
+			__builtin_amdgcn_global_load_lds((const void*)(reinterpret_cast<const uint4*>(b128) + dma_g), (__attribute__((address_space(3))) void*)(xt + 16 + 11 * 64), 16, 0, K1_LOAD_AUX);
+		} else {
+			const uint4* src = reinterpret_cast<const uint4*>(xr.cur + (size_t)tile * 1536) + dma_g;
+#pragma unroll
+			for (int e = 0; e < 12; e++)
+				__builtin_amdgcn_global_load_lds((const void*)(src + e * 64), (__attribute__((address_space(3))) void*)(xt + 16 + e * 64), 16, 0, K1_LOAD_AUX);
+		}
+		int i0 = tile * 512 + lane * 8; // the lane's eight Rotate phasors (in front of the table's look-back: lanes whose outputs nobody keeps)
+		i0 = i0 < -ROT_HIST ? -ROT_HIST : i0;
+		const float4* r4 = reinterpret_cast<const float4*>(p.rot + ROT_HIST + i0);
+#pragma unroll
+		for (int e = 0; e < 4; e++) rot_next[e] = r4[e];
+	};
+	prefetch(tile_first);
+	for (int tile = tile_first; tile <= tile_last; tile++) {
+		// the lane's window: samples 24 l - 26 .. 24 l + 21 of the tile = pieces 12 l + 3 .. 12 l + 26 (look-back included)
+		c2 w[48];
+#pragma unroll
+		for (int k = 0; k < 24; k++) {
+			const float4 v = xt[k1kw_slot(12 * lane + 3 + k)];
+			w[2 * k] = c2{ v.x, v.y }; w[2 * k + 1] = c2{ v.z, v.w };
+		}
+		float4 rot[4];
+#pragma unroll
+		for (int e = 0; e < 4; e++) rot[e] = rot_next[e];
+		wave_sync();
+		if (lane < 16) xt[lane] = xt[768 + lane]; // the tile's last 32 samples become the look-back (rows 0 and 48: no swizzle term)
+		wave_sync(); // the window is in registers, the look-back is in place: the next tile may land
+		if (tile < tile_last) prefetch(tile + 1);
+		c2 up[8], dn[8];
+#pragma unroll
+		for (int o = 0; o < 8; o++) {
+			c2 acc = { 0.0f, 0.0f };
+#pragma unroll
+			for (int k = 0; k < 26; k++) acc = acc + w[3 * o + 1 + k] * p.taps[k]; // x[3 i - 25 + k] (DSP.cpp:160-189, DSP.h:195-201)
+			const float rx_ = (o & 1) ? rot[o >> 1].z : rot[o >> 1].x, ry_ = (o & 1) ? rot[o >> 1].w : rot[o >> 1].y;
+			const float RR = acc.x * rx_, II = acc.y * ry_, RI = acc.x * ry_, IR = acc.y * rx_; // DSP.cpp:296-316
+			up[o] = c2{ RR - II, IR + RI };
+			dn[o] = c2{ RR + II, IR - RI };
+		}
+		c2 a4[4], b4[4];
+		reg_stage<8>(up, sup, a4); // DS2_a / DS2_b: Downsample2CIC5
+		reg_stage<8>(dn, sdn, b4);
+		// FilterCIC5 (DSP.cpp:132-157): out(m) from d(m-5 .. m), five levels of pair sums, * 1/32
+		const auto fcic5 = [&](const c2 (&d4)[4], HaloState<4, c2>& st, float2* dst) {
+			c2 h[5];
+			get_halo<4, c2>(d4, st, h);
+			c2 g[9];
+#pragma unroll
+			for (int i = 0; i < 5; i++) g[i] = h[i];
+#pragma unroll
+			for (int i = 0; i < 4; i++) g[5 + i] = d4[i];
+#pragma unroll
+			for (int lvl = 0; lvl < 5; lvl++) {
+#pragma unroll
+				for (int i = 0; i < 8 - lvl; i++) g[i] = g[i + 1] + g[i];
+			}
+			put_halo<4, c2>(d4, st, h);
+			if (tile > tile_first) {
+				float4* o4 = reinterpret_cast<float4*>(dst + (size_t)tile * 256 + lane * 4);
+#pragma unroll
+				for (int e = 0; e < 2; e++) {
+					const c2 x0 = g[2 * e] * 0.03125f, x1 = g[2 * e + 1] * 0.03125f;
+					o4[e] = make_float4(x0.x, x0.y, x1.x, x1.y);
+				}
+			}
+		};
+		fcic5(a4, sfa, outa);
+		fcic5(b4, sfb, outb);
+	}
+}
+
 // raw input rows -> complex float rows (Utilities/Convert.cpp:255-264 for CU8), for ladders without a CIC5 pre-pass
 __global__ void k_convert_rows(const unsigned char* in, long long in_stride_bytes, int fmt, float2* dst, long long dst_stride, int n) {
 	const int rx = blockIdx.y;
@@ -5018,7 +5122,18 @@ hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
 #ifndef K1K_M
 #define K1K_M 128 // 48 kHz outputs per channel per workgroup of the decimate-by-3 front end
 #endif
-hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s) {
+#ifndef K1K_WAVE
+#define K1K_WAVE 1
+#endif
+hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s, int hook) { // hook (test hook "k1u_spw"): 2 = the workgroup form, 4 / 8 = k1k_wave with spans of that many tiles
+	if (K1K_WAVE && !p.us_idx && p.L % 256 == 0 && hook != 2) {
+		const int tiles = p.L / 256;
+		int tps = 16; // tiles per span: ~4,096 waves or more where the batch has them
+		while (tps > 1 && (long long)((tiles + tps - 1) / tps) * n_rx < 4096) tps >>= 1;
+		if (hook > 2) tps = hook;
+		hipLaunchKernelGGL(k1k_wave, dim3((tiles + tps - 1) / tps, n_rx), dim3(64), 0, s, p, tps);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL((k1k_dsk_frontend<K1K_M>), dim3(p.L / K1K_M, n_rx), dim3(K1U_T), 0, s, p);
 	return hipGetLastError();
 }

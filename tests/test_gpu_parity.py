@@ -767,6 +767,23 @@ def test_decimate_by_3_ladders(rate, dsk):
     _run_gpu_vs_oracle([synth.to_cu8(x)], rate, "cu8", block, 3, dsk=dsk)
 
 
+@pytest.mark.parametrize("hook,rate,dsk,fmt,blk", [(4, 288000, False, "cf32", 24576 * 2), (8, 288000, False, "cs16", 24576 * 2), (8, 288000, False, "cf32", 24576 * 3),
+                                                  (4, 1152000, True, "cf32", 24576 * 8), (2, 288000, False, "cf32", 24576 * 2), (4, 288000, False, "cu8", 24576)])
+def test_decimate_by_3_wave_front_end(hook, rate, dsk, fmt, blk, monkeypatch):
+    """Round 6, late: the decimate-by-3 tail without a resampler in front is k1k_wave -- one wave per span of 1,536-sample tiles, the
+    26-tap DownsampleKFilter from a 48-sample window per lane out of LDS (swizzled by the DMA), Rotate, DS2_a / DS2_b and FilterCIC5 in
+    registers with DPP halos (FilterCIC5's reach two lanes back), a warm-up tile of which only the last 128 samples are read.  Small
+    batches get one-tile spans; the test hook k1u_spw forces spans of 4 / 8 tiles (tile-to-tile look-back in LDS and shadow registers;
+    a block is a multiple of 16 tiles), 2 forces the workgroup form it replaced.  Two distinct receivers, every tap (the 48 kHz
+    channels themselves), bits, levels, ppm; CF32 read in place, CS16 / CU8 through the converted copy, 1152 kSPS behind its
+    pre-decimation pass."""
+    monkeypatch.setenv("AISGPU_K1U_SPW", str(hook))
+    nb = 4
+    conv = {"cu8": synth.to_cu8, "cs16": synth.to_cs16, "cf32": lambda v: v}[fmt]
+    xs = [conv(synth.receiver_stream(blk * nb, sample_rate=rate, receiver_id=640 + r, gap_slots=(1, 2))) for r in range(2)]
+    _run_gpu_vs_oracle(xs, rate, fmt, blk, nb, dsk=dsk)
+
+
 @pytest.mark.parametrize("rate, fmt, block, nblocks", [(1536000, "cf32", 131072, 8), (1536000, "cu8", 131072 * 3, 3), (768000, "cs16", 65536, 8),
                                                        (2304000, "cf32", 196608, 6), (2400000, "cu8", 204800, 6), (192000, "cs8", 16384 * 2, 6)])
 def test_moving_average_downsampler(rate, fmt, block, nblocks):
