@@ -190,6 +190,7 @@ struct aisgpu {
 	int phasor_simds = 1024;  // SIMDs the phasor recurrence's stream may use (the reserved CUs'): picks the form of the kernel
 	float* d_magT[NBUF] = {}; // shifted FFT magnitudes (written by the FFT on the front stream, read by the searches on s3)
 	bool fft_in_k1 = false;   // the spectral analysis rides at the end of the front-end waves (k1_fft_tail): fz / ppm come from K1
+	bool front_fft = false;   // ... of this block's front-end waves of k1x_wave / k1k_wave (set per block by aisgpu_run, read by enqueue_downstream_fused)
 	uint32_t* d_bits[4] = {}; // ring of 4 (block f & 3), like lvl: the frame decoder of block f-2 may still be reading while PhaseSearch of block f writes
 	bool challenger = false;
 	bool v2 = false; float2* h_c48 = nullptr; // ModelEngineV2: front end only, the 48 kHz channels go to the host (MAXSUB slots)
@@ -704,6 +705,9 @@ int enqueue_fused_back(aisgpu_t* h) {
 	return enqueue_k4(h, pb, lv, g0, n_groups, h->fpend.block, h->fpend.sub, h->s1);
 }
 
+#ifndef FRONT_FFT_IN_WAVES
+#define FRONT_FFT_IN_WAVES 1
+#endif
 int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	const int lv = (int)(h->block_idx & 3);
 	K2Params k2 = make_k2(h, q);
@@ -712,8 +716,9 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	k2.ck = h->d_ck[q]; k2.ck_stride = k2.rotT_stride;
 	if (h->us_fft_in_k1) {
 		// (resampled ladder: the caller has recorded k1_done[q] on the stream its front-end waves ran on)
-	} else if (h->fft_in_k1) {
-		// the front-end waves have done the whole analysis (k1_fft_tail): fz / ppm of this block are there when K1 is
+	} else if (h->fft_in_k1 || h->front_fft) {
+		// the front-end waves have done the whole analysis (k1_fft_tail; k1x_wave / k1k_wave: wave_fft_tail): fz / ppm of this block are there when K1 is
+		if (h->front_fft) h->k1_done[q] = nullptr;
 		if (!h->k1_done[q]) { HIPCHK(hipEventRecord(h->ev_search[q], h->stream)); h->k1_done[q] = h->ev_search[q]; }
 	} else { // FFT + searches follow the front end on its stream (four busy streams are the limit; on s4 in front of this block's refine +
 		// derotation / FIR kernels -- tried when the front ends of these ladders became one-wave workgroups, round 6 -- s4 idles through
@@ -1955,7 +1960,13 @@ int aisgpu_run(aisgpu_t* h) {
 		ku.us_idx = nullptr; ku.us_alpha = nullptr; ku.rot = h->d_rot[pb];
 		ku.c48 = h->d_c48[q]; ku.c48_stride = h->c48s;
 		ku.alpha = h->alpha; ku.beta = h->beta; ku.has_fdc = h->mode_x ? h->has_fdc : 0; ku.L = h->L;
-		if (h->mode_x) { ku.c48_rows_per_rx = 1; ku.spw_force = h->k1u_spw; HIPCHK(launch_k1x(ku, h->npost, R, h->stream)); } // (test hook k1u_spw = 2: the workgroup form of K1x at 96 kSPS, 4 / 8: k1x_wave with spans of that many tiles)
+		if (h->mode_x) {
+			ku.c48_rows_per_rx = 1; ku.spw_force = h->k1u_spw;
+			// the analysis at the end of the front-end waves (k1x_wave): a block of an even number of windows, the fused back end
+			h->front_fft = h->fused && k1x_wave_form(ku, h->npost) && h->W % 2 == 0 && FRONT_FFT_IN_WAVES;
+			if (h->front_fft) { ku.omega = h->d_omega; ku.ppm_table = h->d_ppmtab; ku.fz = h->d_fz[q]; ku.ppm = h->d_ppm[q]; ku.n_windows = h->W; ku.wide = h->cfg.afc_wide ? 1 : 0; }
+			HIPCHK(launch_k1x(ku, h->npost, R, h->stream));
+		} // (test hook k1u_spw = 2: the workgroup form of K1x at 96 kSPS, 4 / 8: k1x_wave with spans of that many tiles)
 		else { ku.spw_force = h->k1u_spw; HIPCHK(launch_k1u(ku, 0, R, h->stream)); }
 		if (h->x_direct) HIPCHK(launch_copy_rows(ku.xin + h->n_pre - h->xh, ku.xin_stride, h->d_xhist[(h->in_blocks & 1) ^ 1], h->xh, h->xh, R, h->stream));
 		int rc = enqueue_downstream(h, q, pb);
@@ -1977,6 +1988,8 @@ int aisgpu_run(aisgpu_t* h) {
 		kk.rot = h->d_rot[pb]; kk.c48 = h->d_c48[q]; kk.c48_stride = h->c48s; kk.L = h->L;
 		kk.us_idx = nullptr; kk.us_alpha = nullptr;
 		memcpy(kk.taps, TAPS_BH_28_3, sizeof kk.taps);
+		h->front_fft = h->fused && k1k_wave_form(kk, h->k1u_spw) && FRONT_FFT_IN_WAVES; // the analysis at the end of the front-end waves (k1k_wave)
+		if (h->front_fft) { kk.omega = h->d_omega; kk.ppm_table = h->d_ppmtab; kk.fz = h->d_fz[q]; kk.ppm = h->d_ppm[q]; kk.n_windows = h->W; kk.wide = h->cfg.afc_wide ? 1 : 0; }
 		HIPCHK(launch_k1k(kk, R, h->stream, h->k1u_spw));
 		if (h->x_direct) HIPCHK(launch_copy_rows(kk.xin + h->n_pre - h->xh, kk.xin_stride, h->d_xhist[(h->in_blocks & 1) ^ 1], h->xh, h->xh, R, h->stream));
 		int rc = enqueue_downstream(h, q, pb);

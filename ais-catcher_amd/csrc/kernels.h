@@ -56,7 +56,9 @@ struct K1uParams {
 	const float2* xhist = nullptr; int xhist_len = 0;
 	int c48_rows_per_rx = 2; // k1x_single_channel: rows of c48 per receiver -- 2: the receiver's channel A of a dual-channel layout; 1 (round 6): receivers packed, row = receiver
 	int spw = 1;            // spans (of K1U_M outputs per channel) a workgroup of the resampler front end walks (set by launch_k1u)
-	int spw_force = 0;      // test hook "k1u_spw" (2 / 4 / 8): the span walk of that length whatever the number of workgroups it leaves
+	int spw_force = 0;      // test hook "k1u_spw" (2 / 4 / 8): the span walk of that length whatever the number of workgroups it leaves	// the spectral analysis at the end of the waves of the one-wave front ends (k1x_wave / k1k_wave, round 6): fz != nullptr -- every wave
+	// finishes its span with SquareFreqOffsetCorrection's FFT + searches of the windows it has written (as k1_dpp's k1_fft_tail)
+	const float2* omega = nullptr; const float* ppm_table = nullptr; int* fz = nullptr; float* ppm = nullptr; int n_windows = 0, wide = 0;
 };
 // sample i of the pre-decimated stream relative to the current input block's start (see K1uParams::xprev)
 struct XRow {
@@ -92,7 +94,9 @@ struct K1kParams { // decimate-by-3 front end (DownsampleKFilter ladders: 288k *
 	const int* us_idx; const float* us_alpha; // != nullptr: [US_HIST + len] Upsample in front of the filter (see K1uParams), xin is ITS input
 	int L;                  // 48 kHz samples per channel per block
 	const float2* xprev = nullptr; const float2* xprev2 = nullptr; int n_in = 0; // ring of three input blocks (see K1uParams)
-	const float2* xhist = nullptr; int xhist_len = 0; // CF32 input in place + kept tail (see K1uParams)
+	const float2* xhist = nullptr; int xhist_len = 0; // CF32 input in place + kept tail (see K1uParams)	// the spectral analysis at the end of the waves of the one-wave front ends (k1x_wave / k1k_wave, round 6): fz != nullptr -- every wave
+	// finishes its span with SquareFreqOffsetCorrection's FFT + searches of the windows it has written (as k1_dpp's k1_fft_tail)
+	const float2* omega = nullptr; const float* ppm_table = nullptr; int* fz = nullptr; float* ppm = nullptr; int n_windows = 0, wide = 0;
 };
 constexpr int DSK_HIST = 128; // samples of the 288 kHz stream kept in front of a block
 
@@ -300,6 +304,8 @@ hipError_t launch_k1_tail(const void* in, long long in_stride_bytes, long long b
                           int n_rx, hipStream_t s);
 hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s); // channel mode X: npost CIC5 stages down to 48 kHz, us_idx == nullptr: no resampler
 hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s, int hook = 0);
+bool k1k_wave_form(const K1kParams& p, int hook); // launch_k1k takes the one-wave form (k1k_wave), which can carry the spectral analysis (K1kParams::fz)
+bool k1x_wave_form(const K1uParams& p, int npost); // the same for launch_k1x / k1x_wave
 hipError_t launch_convert_rows(const void* in, long long in_stride, int fmt, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
 // DownsampleMovingAverage (DSP.cpp:60-82) at an integer ratio m: dst[i] = (((0 + x[m i]) + x[m i + 1]) + ...) / m, n outputs per row
 hipError_t launch_ma_rows(const void* in, long long in_stride, int fmt, int m, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);

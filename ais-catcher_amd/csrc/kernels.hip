@@ -432,6 +432,7 @@ __device__ __forceinline__ void wave_sync() {
 constexpr int fmt_bytes(int fmt) { return fmt == 0 || fmt == 5 ? 8 : fmt == 3 ? 4 : 2; } // (5: Upsample outputs computed in the wave, see K1Params::us_idx)
 
 __device__ __forceinline__ void k1_fft_tail(const K1Params& p, int rx, int span, float2* X); // below, with the FFT
+template <class P> __device__ __forceinline__ void wave_fft_tail(const P& q, size_t row, bool two_rows, int w0, int nw, float2* X); // (the same for k1x_wave / k1k_wave)
 
 template <int E> struct K1Const { static constexpr int value = E; };
 template <int E, int N, class F>
@@ -1059,6 +1060,8 @@ __global__ __launch_bounds__(64) void k1x_wave(K1uParams p, int tiles_per_span) 
 			}
 		}
 	}
+	// a tile is a window of this row: the span's windows in pairs (launch_k1x: spans of an even number of tiles where p.fz is set)
+	if (p.fz) wave_fft_tail(p, (size_t)rx * p.c48_rows_per_rx, false, tile_first + 1, tile_last - tile_first, reinterpret_cast<float2*>(xt));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1226,6 +1229,8 @@ __global__ __launch_bounds__(64) void k1k_wave(K1kParams p, int tiles_per_span) 
 		fcic5(a4, sfa, outa);
 		fcic5(b4, sfb, outb);
 	}
+	// two tiles are a window of each channel: the span's windows, both channels side by side (launch_k1k: spans of an even number of tiles)
+	if (p.fz) wave_fft_tail(p, (size_t)rx * 2, true, (tile_first + 1) / 2, (tile_last - tile_first) / 2, reinterpret_cast<float2*>(xt));
 }
 
 // raw input rows -> complex float rows (Utilities/Convert.cpp:255-264 for CU8), for ladders without a CIC5 pre-pass
@@ -1590,6 +1595,33 @@ __device__ __forceinline__ void spectral_search(const float (&m)[NWIN][8], float
 // leaves is fz and ppm of the window -- 8 bytes instead of 2 KB of magnitudes -- so neither the FFT kernel (0.05 ms alone,
 // 0.16-0.20 ms on the front stream next to the previous block's back end), nor a search kernel, nor 0.2 GB of magnitude
 // traffic per step remain, and the arithmetic fills issue slots of a kernel that waits for HBM most of the time.
+// the analysis of two windows side by side (their dependent chains interleave): window wa of c48 row ra and window wb of row rb
+__device__ __forceinline__ void k1_fft_pair(const K1Params& p, size_t ra, int wa, size_t rb, int wb, float2* X, FftTwiddles& t, int lane) {
+	const int src = fft_src_lane(lane);
+	float* S = reinterpret_cast<float*>(X); // 2 x 1024 floats for the searches; the FFT's exchange buffer (584 float2) is the front of it
+	float2 d[2][8];
+#pragma unroll
+	for (int ch = 0; ch < 2; ch++) {
+		const float2* x = p.c48 + (ch ? rb : ra) * p.c48_stride + (size_t)(ch ? wb : wa) * 512 + src;
+#pragma unroll
+		for (int r = 0; r < 8; r++) d[ch][r] = x[fft_src_step(r)];
+	}
+	float m[2][8];
+#pragma unroll
+	for (int ch = 0; ch < 2; ch++) {
+		c2 v[8];
+		fft_square(d[ch], v);
+		fft512_mag(v, X, t, lane, m[ch]);
+	}
+	int fz[2];
+	spectral_search<2>(m, S, lane, p.wide, fz);
+	if (lane < 2) {
+		const int f = lane == 0 ? fz[0] : fz[1];
+		const size_t W = (lane == 0 ? ra : rb) * p.n_windows + (lane == 0 ? wa : wb);
+		p.fz[W] = f;
+		p.ppm[W] = p.ppm_table[f + 205];
+	}
+}
 __device__ __forceinline__ void k1_fft_tail(const K1Params& p, int rx, int span, float2* X) {
 	const int lane = threadIdx.x;
 	// This wave's own c48 stores must have reached L2 (its L1 never held those lines), and the last tile's LDS-DMA must have
@@ -1597,34 +1629,23 @@ __device__ __forceinline__ void k1_fft_tail(const K1Params& p, int rx, int span,
 	// (__threadfence) adds an L2 write-back and an L1 invalidate per span, which cost more than the analysis itself.
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	FftTwiddles t = fft_twiddles(p.omega, lane);
-	const int src = fft_src_lane(lane);
 	const int nw = p.fft_windows;
-	float* S = reinterpret_cast<float*>(X); // 2 x 1024 floats for the searches; the FFT's exchange buffer (584 float2) is the front of it
 	for (int i = 0; i < nw; i++) {
 		const int w = span * nw + i;
-		float2 d[2][8];
-#pragma unroll
-		for (int ch = 0; ch < 2; ch++) {
-			const float2* x = p.c48 + ((size_t)rx * 2 + ch) * p.c48_stride + (size_t)w * 512 + src;
-#pragma unroll
-			for (int r = 0; r < 8; r++) d[ch][r] = x[fft_src_step(r)];
-		}
-		float m[2][8];
-#pragma unroll
-		for (int ch = 0; ch < 2; ch++) {
-			c2 v[8];
-			fft_square(d[ch], v);
-			fft512_mag(v, X, t, lane, m[ch]);
-		}
-		int fz[2];
-		spectral_search<2>(m, S, lane, p.wide, fz);
-		if (lane < 2) {
-			const int f = lane == 0 ? fz[0] : fz[1];
-			const size_t W = ((size_t)rx * 2 + lane) * p.n_windows + w;
-			p.fz[W] = f;
-			p.ppm[W] = p.ppm_table[f + 205];
-		}
+		k1_fft_pair(p, (size_t)rx * 2, w, (size_t)rx * 2 + 1, w, X, t, lane);
 	}
+}
+// the spectral analysis at the end of the waves of k1x_wave / k1k_wave (round 6, late): the windows [w0, w0 + nw) this wave has just written,
+// of ONE c48 row in pairs of consecutive windows (mode X: nw even), or of the rows row, row + 1 window by window (two channels)
+template <class P>
+__device__ __forceinline__ void wave_fft_tail(const P& q, size_t row, bool two_rows, int w0, int nw, float2* X) {
+	const int lane = threadIdx.x;
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // (see k1_fft_tail)
+	K1Params p{};
+	p.c48 = q.c48; p.c48_stride = q.c48_stride; p.omega = q.omega; p.ppm_table = q.ppm_table; p.fz = q.fz; p.ppm = q.ppm; p.n_windows = q.n_windows; p.wide = q.wide;
+	FftTwiddles t = fft_twiddles(p.omega, lane);
+	if (two_rows) { for (int i = 0; i < nw; i++) k1_fft_pair(p, row, w0 + i, row + 1, w0 + i, X, t, lane); }
+	else { for (int i = 0; i < nw; i += 2) k1_fft_pair(p, row, w0 + i, row, w0 + i + 1, X, t, lane); }
 }
 
 // The same analysis as a kernel of its own, one wave per (receiver, window), for the front ends that do not end in k1_dpp (the resampled
@@ -5102,15 +5123,19 @@ hipError_t launch_k1u(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
 #ifndef K1X_WAVE
 #define K1X_WAVE 1
 #endif
+bool k1x_wave_form(const K1uParams& p, int npost) { return K1X_WAVE && npost == 1 && !p.us_idx && p.L % 512 == 0 && p.spw_force != 2; }
 hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
-	if (K1X_WAVE && npost == 1 && !p.us_idx && p.L % 512 == 0 && p.spw_force != 2) { // the register / DPP form (test hook "k1u_spw" = 2: the workgroup form)
+	if (k1x_wave_form(p, npost)) { // the register / DPP form (test hook "k1u_spw" = 2: the workgroup form)
 		const int tiles = p.L / 512;
 		int tps = 16; // tiles per span: ~4,096 waves or more where the batch has them (test hook "k1u_spw" = 4 / 8: spans of that many tiles)
-		while (tps > 1 && (long long)((tiles + tps - 1) / tps) * n_rx < 4096) tps >>= 1;
+		const int tps_min = p.fz ? 2 : 1; // (the analysis in the waves takes this row's windows = tiles in pairs)
+		while (tps > tps_min && (long long)((tiles + tps - 1) / tps) * n_rx < 4096) tps >>= 1;
 		if (p.spw_force > 2) tps = p.spw_force;
+		if (p.fz && (tiles % 2 != 0)) return hipErrorInvalidValue; // (the caller sets fz only where a block is an even number of windows)
 		hipLaunchKernelGGL(k1x_wave, dim3((tiles + tps - 1) / tps, n_rx), dim3(64), 0, s, p, tps);
 		return hipGetLastError();
 	}
+	if (p.fz) return hipErrorInvalidValue; // (the analysis in the waves exists in the wave form only: the caller asks k1x_wave_form first)
 	const dim3 grid(p.L / K1X_M, n_rx);
 	if (npost == 2) hipLaunchKernelGGL((k1x_single_channel<2, K1X_M>), grid, dim3(K1U_T), 0, s, p);
 	else if (npost == 1) hipLaunchKernelGGL((k1x_single_channel<1, K1X_M>), grid, dim3(K1U_T), 0, s, p);
@@ -5125,15 +5150,18 @@ hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
 #ifndef K1K_WAVE
 #define K1K_WAVE 1
 #endif
+bool k1k_wave_form(const K1kParams& p, int hook) { return K1K_WAVE && !p.us_idx && p.L % 256 == 0 && hook != 2; }
 hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s, int hook) { // hook (test hook "k1u_spw"): 2 = the workgroup form, 4 / 8 = k1k_wave with spans of that many tiles
-	if (K1K_WAVE && !p.us_idx && p.L % 256 == 0 && hook != 2) {
+	if (k1k_wave_form(p, hook)) {
 		const int tiles = p.L / 256;
 		int tps = 16; // tiles per span: ~4,096 waves or more where the batch has them
-		while (tps > 1 && (long long)((tiles + tps - 1) / tps) * n_rx < 4096) tps >>= 1;
+		const int tps_min = p.fz ? 2 : 1; // (the analysis in the waves: two tiles are a window)
+		while (tps > tps_min && (long long)((tiles + tps - 1) / tps) * n_rx < 4096) tps >>= 1;
 		if (hook > 2) tps = hook;
 		hipLaunchKernelGGL(k1k_wave, dim3((tiles + tps - 1) / tps, n_rx), dim3(64), 0, s, p, tps);
 		return hipGetLastError();
 	}
+	if (p.fz) return hipErrorInvalidValue; // (see launch_k1x)
 	hipLaunchKernelGGL((k1k_dsk_frontend<K1K_M>), dim3(p.L / K1K_M, n_rx), dim3(K1U_T), 0, s, p);
 	return hipGetLastError();
 }

@@ -524,7 +524,9 @@ def test_channel_mode_x_96k_wave_front_end(hook, block, fmt, R, monkeypatch):
     FilterCIC5 in registers with DPP halos, a warm-up tile of which only the last 128 samples are read (in front of a block: the library's
     look-back).  Small batches get one-tile spans; the test hook k1u_spw forces spans of 4 / 8 tiles (tile-to-tile shadow registers,
     a last span that is shorter: 44 and 48 tiles per block; a block of ONE tile), 2 forces the workgroup form it replaced.  CF32 read in
-    place and CU8 / CS16 through the converted copy; 48 kHz samples are compared through hard bits, levels and ppm of every block."""
+    place and CU8 / CS16 through the converted copy; 48 kHz samples are compared through hard bits, levels and ppm of every block.
+    Where a block is an even number of windows the waves also finish their span with the spectral analysis (wave_fft_tail, the row's
+    windows in pairs) instead of k2_fft_search_win behind the front end: ppm of every window."""
     if hook:
         monkeypatch.setenv("AISGPU_K1U_SPW", str(hook))
     rate, nblocks = 96000, 5
@@ -776,12 +778,15 @@ def test_decimate_by_3_wave_front_end(hook, rate, dsk, fmt, blk, monkeypatch):
     batches get one-tile spans; the test hook k1u_spw forces spans of 4 / 8 tiles (tile-to-tile look-back in LDS and shadow registers;
     a block is a multiple of 16 tiles), 2 forces the workgroup form it replaced.  Two distinct receivers, every tap (the 48 kHz
     channels themselves), bits, levels, ppm; CF32 read in place, CS16 / CU8 through the converted copy, 1152 kSPS behind its
-    pre-decimation pass."""
+    pre-decimation pass.  Taps path (the front end alone) and default path (the spectral analysis at the end of the same waves)."""
     monkeypatch.setenv("AISGPU_K1U_SPW", str(hook))
     nb = 4
     conv = {"cu8": synth.to_cu8, "cs16": synth.to_cs16, "cf32": lambda v: v}[fmt]
     xs = [conv(synth.receiver_stream(blk * nb, sample_rate=rate, receiver_id=640 + r, gap_slots=(1, 2))) for r in range(2)]
     _run_gpu_vs_oracle(xs, rate, fmt, blk, nb, dsk=dsk)
+    # the default path: the waves also finish their span with the spectral analysis of the windows they have written (wave_fft_tail)
+    # instead of k2_fft_search_win behind the front end -- ppm of every window, bits, levels
+    _run_outputs_vs_oracle(xs, rate, fmt, blk, nb, dsk=dsk)
 
 
 @pytest.mark.parametrize("rate, fmt, block, nblocks", [(1536000, "cf32", 131072, 8), (1536000, "cu8", 131072 * 3, 3), (768000, "cs16", 65536, 8),
