@@ -1967,7 +1967,12 @@ int aisgpu_run(aisgpu_t* h) {
 			if (h->front_fft) { ku.omega = h->d_omega; ku.ppm_table = h->d_ppmtab; ku.fz = h->d_fz[q]; ku.ppm = h->d_ppm[q]; ku.n_windows = h->W; ku.wide = h->cfg.afc_wide ? 1 : 0; }
 			HIPCHK(launch_k1x(ku, h->npost, R, h->stream));
 		} // (test hook k1u_spw = 2: the workgroup form of K1x at 96 kSPS, 4 / 8: k1x_wave with spans of that many tiles)
-		else { ku.spw_force = h->k1u_spw; HIPCHK(launch_k1u(ku, 0, R, h->stream)); }
+		else {
+			ku.spw_force = h->k1u_spw;
+			h->front_fft = h->fused && k1u96_wave_form(ku, 0) && FRONT_FFT_IN_WAVES; // the analysis at the end of the front-end waves (k1k_wave<false>)
+			if (h->front_fft) { ku.omega = h->d_omega; ku.ppm_table = h->d_ppmtab; ku.fz = h->d_fz[q]; ku.ppm = h->d_ppm[q]; ku.n_windows = h->W; ku.wide = h->cfg.afc_wide ? 1 : 0; }
+			HIPCHK(launch_k1u(ku, 0, R, h->stream));
+		}
 		if (h->x_direct) HIPCHK(launch_copy_rows(ku.xin + h->n_pre - h->xh, ku.xin_stride, h->d_xhist[(h->in_blocks & 1) ^ 1], h->xh, h->xh, R, h->stream));
 		int rc = enqueue_downstream(h, q, pb);
 		if (rc) return rc;

@@ -306,6 +306,7 @@ hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s); /
 hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s, int hook = 0);
 bool k1k_wave_form(const K1kParams& p, int hook); // launch_k1k takes the one-wave form (k1k_wave), which can carry the spectral analysis (K1kParams::fz)
 bool k1x_wave_form(const K1uParams& p, int npost); // the same for launch_k1x / k1x_wave
+bool k1u96_wave_form(const K1uParams& p, int npost); // ... and for launch_k1u at 96 kSPS (npost = 0, no resampler): k1k_wave<false>
 hipError_t launch_convert_rows(const void* in, long long in_stride, int fmt, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);
 // DownsampleMovingAverage (DSP.cpp:60-82) at an integer ratio m: dst[i] = (((0 + x[m i]) + x[m i + 1]) + ...) / m, n outputs per row
 hipError_t launch_ma_rows(const void* in, long long in_stride, int fmt, int m, float2* dst, long long dst_stride, int n, int n_rx, hipStream_t s);

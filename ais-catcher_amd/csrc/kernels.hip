@@ -1140,8 +1140,15 @@ __global__ __launch_bounds__(K1U_T) void k1k_dsk_frontend(K1kParams p) {
 // 70 input samples in front of it, so of that tile only the last 128 samples are fetched (one load instruction; in front of the block:
 // the library's look-back of DSK_HIST samples).  Same products and sums in the same order as k1k_dsk_frontend: same bits.
 __device__ __forceinline__ int k1kw_slot(int pf) { return (pf & ~15) | ((pf & 15) ^ ((pf >> 4) & 3)); } // logical 16-byte piece (32 look-back samples = 16 pieces in front) -> LDS slot
-__global__ __launch_bounds__(64) void k1k_wave(K1kParams p, int tiles_per_span) {
-	__shared__ __attribute__((aligned(16))) float4 xt[16 + 768];
+// FIR = false (P = K1uParams; round 6, last): the same waves for dual-channel 96 kSPS input, the ladder's last bucket (convert >> ROT >> DS2_a/b >>
+// FCIC5, Model.cpp:332-334; k1u_resample_frontend<0> before: 4.96 ms per step of 4,096 receivers x 49,152 samples) -- a tile is 512 samples,
+// a lane's eight 96 kHz samples come straight out of the tile (pieces swizzled by (row / 4) % 4: a lane's 64 bytes start every 64 bytes).
+template <bool FIR, class P>
+__global__ __launch_bounds__(64) void k1k_wave(P p, int tiles_per_span) {
+	constexpr int TS = FIR ? 1536 : 512;  // input samples per tile (512 at 96 kHz)
+	constexpr int NE = TS / 128;          // load instructions per tile (128 samples each)
+	constexpr int LB = FIR ? 16 : 0;      // pieces of look-back in front of the tile
+	__shared__ __attribute__((aligned(16))) float4 xt[LB + TS / 2 < 512 ? 512 : LB + TS / 2]; // (at least the 8 KB the spectral analysis at the end of the span works in)
 	const int lane = threadIdx.x, rx = blockIdx.y, span = blockIdx.x;
 	const int tiles = p.L / 256;
 	const int tile_first = span * tiles_per_span - 1; // warm-up tile
@@ -1152,19 +1159,19 @@ __global__ __launch_bounds__(64) void k1k_wave(K1kParams p, int tiles_per_span) 
 	float2* outb = outa + p.c48_stride;
 	HaloState<8, c2> sup = {}, sdn = {};
 	HaloState<4, c2> sfa = {}, sfb = {};
-	// DMA: slot 16 + 64 e + lane <- piece g of the tile with k1kw_slot(16 + g) == that slot (the swizzle term does not depend on e)
-	const int dma_g = (lane & ~15) + ((lane & 15) ^ ((1 + (lane >> 4)) & 3));
+	// DMA: slot LB + 64 e + lane <- the piece g of the tile that belongs there (the swizzle term does not depend on e)
+	const int dma_g = FIR ? (lane & ~15) + ((lane & 15) ^ ((1 + (lane >> 4)) & 3)) : (lane & ~3) + ((lane & 3) ^ ((lane >> 4) & 3));
 	float4 rot_next[4];
 	const auto prefetch = [&](int tile) {
 		if (tile == tile_first) { // (wave-uniform) only the tile's last 128 samples = its last load instruction
 			static_assert(DSK_HIST == 128, "k1k_wave: the look-back in front of a block is the warm-up tile's last load instruction");
-			const float2* b128 = tile >= 0 ? xr.cur + (size_t)tile * 1536 + 1408 : (xr.prev ? xr.prev + (xr.n - 128) : xr.cur - 128);
-			__builtin_amdgcn_global_load_lds((const void*)(reinterpret_cast<const uint4*>(b128) + dma_g), (__attribute__((address_space(3))) void*)(xt + 16 + 11 * 64), 16, 0, K1_LOAD_AUX);
+			const float2* b128 = tile >= 0 ? xr.cur + (size_t)tile * TS + (TS - 128) : (xr.prev ? xr.prev + (xr.n - 128) : xr.cur - 128);
+			__builtin_amdgcn_global_load_lds((const void*)(reinterpret_cast<const uint4*>(b128) + dma_g), (__attribute__((address_space(3))) void*)(xt + LB + (NE - 1) * 64), 16, 0, K1_LOAD_AUX);
 		} else {
-			const uint4* src = reinterpret_cast<const uint4*>(xr.cur + (size_t)tile * 1536) + dma_g;
+			const uint4* src = reinterpret_cast<const uint4*>(xr.cur + (size_t)tile * TS) + dma_g;
 #pragma unroll
-			for (int e = 0; e < 12; e++)
-				__builtin_amdgcn_global_load_lds((const void*)(src + e * 64), (__attribute__((address_space(3))) void*)(xt + 16 + e * 64), 16, 0, K1_LOAD_AUX);
+			for (int e = 0; e < NE; e++)
+				__builtin_amdgcn_global_load_lds((const void*)(src + e * 64), (__attribute__((address_space(3))) void*)(xt + LB + e * 64), 16, 0, K1_LOAD_AUX);
 		}
 		int i0 = tile * 512 + lane * 8; // the lane's eight Rotate phasors (in front of the table's look-back: lanes whose outputs nobody keeps)
 		i0 = i0 < -ROT_HIST ? -ROT_HIST : i0;
@@ -1174,26 +1181,37 @@ __global__ __launch_bounds__(64) void k1k_wave(K1kParams p, int tiles_per_span) 
 	};
 	prefetch(tile_first);
 	for (int tile = tile_first; tile <= tile_last; tile++) {
-		// the lane's window: samples 24 l - 26 .. 24 l + 21 of the tile = pieces 12 l + 3 .. 12 l + 26 (look-back included)
-		c2 w[48];
+		c2 w[FIR ? 48 : 8];
+		if constexpr (FIR) { // the lane's window: samples 24 l - 26 .. 24 l + 21 of the tile = pieces 12 l + 3 .. 12 l + 26 (look-back included)
 #pragma unroll
-		for (int k = 0; k < 24; k++) {
-			const float4 v = xt[k1kw_slot(12 * lane + 3 + k)];
-			w[2 * k] = c2{ v.x, v.y }; w[2 * k + 1] = c2{ v.z, v.w };
+			for (int k = 0; k < 24; k++) {
+				const float4 v = xt[k1kw_slot(12 * lane + 3 + k)];
+				w[2 * k] = c2{ v.x, v.y }; w[2 * k + 1] = c2{ v.z, v.w };
+			}
+		} else { // the lane's eight samples
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const float4 v = xt[4 * lane + (k ^ ((lane >> 2) & 3))];
+				w[2 * k] = c2{ v.x, v.y }; w[2 * k + 1] = c2{ v.z, v.w };
+			}
 		}
 		float4 rot[4];
 #pragma unroll
 		for (int e = 0; e < 4; e++) rot[e] = rot_next[e];
 		wave_sync();
-		if (lane < 16) xt[lane] = xt[768 + lane]; // the tile's last 32 samples become the look-back (rows 0 and 48: no swizzle term)
-		wave_sync(); // the window is in registers, the look-back is in place: the next tile may land
+		if constexpr (FIR) {
+			if (lane < 16) xt[lane] = xt[768 + lane]; // the tile's last 32 samples become the look-back (rows 0 and 48: no swizzle term)
+			wave_sync(); // the window is in registers, the look-back is in place: the next tile may land
+		}
 		if (tile < tile_last) prefetch(tile + 1);
 		c2 up[8], dn[8];
 #pragma unroll
 		for (int o = 0; o < 8; o++) {
 			c2 acc = { 0.0f, 0.0f };
+			if constexpr (FIR) {
 #pragma unroll
-			for (int k = 0; k < 26; k++) acc = acc + w[3 * o + 1 + k] * p.taps[k]; // x[3 i - 25 + k] (DSP.cpp:160-189, DSP.h:195-201)
+				for (int k = 0; k < 26; k++) acc = acc + w[3 * o + 1 + k] * p.taps[k]; // x[3 i - 25 + k] (DSP.cpp:160-189, DSP.h:195-201)
+			} else acc = w[o];
 			const float rx_ = (o & 1) ? rot[o >> 1].z : rot[o >> 1].x, ry_ = (o & 1) ? rot[o >> 1].w : rot[o >> 1].y;
 			const float RR = acc.x * rx_, II = acc.y * ry_, RI = acc.x * ry_, IR = acc.y * rx_; // DSP.cpp:296-316
 			up[o] = c2{ RR - II, IR + RI };
@@ -5103,7 +5121,21 @@ hipError_t launch_k1(const K1Params& p, int K, int fmt, int spans, int n_rx, hip
 #define K1U_LAUNCH_SPW(kernel_, q_, ...) hipLaunchKernelGGL((kernel_<__VA_ARGS__ K1U_M>), dim3(p.L / K1U_M / (q_).spw, n_rx), dim3(K1U_T), 0, s, q_)
 #define K1U_COMMA ,
 
+#ifndef K1K_WAVE
+#define K1K_WAVE 1
+#endif
+bool k1u96_wave_form(const K1uParams& p, int npost) { return K1K_WAVE && npost == 0 && !p.us_idx && p.L % 256 == 0 && p.spw_force != 2; }
 hipError_t launch_k1u(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
+	if (k1u96_wave_form(p, npost)) { // dual-channel 96 kSPS input: k1k_wave without the filter (test hook "k1u_spw" = 2: the workgroup form, 4 / 8: spans of that many tiles)
+		const int tiles = p.L / 256;
+		int tps = 16;
+		const int tps_min = p.fz ? 2 : 1;
+		while (tps > tps_min && (long long)((tiles + tps - 1) / tps) * n_rx < 4096) tps >>= 1;
+		if (p.spw_force > 2) tps = p.spw_force;
+		hipLaunchKernelGGL((k1k_wave<false, K1uParams>), dim3((tiles + tps - 1) / tps, n_rx), dim3(64), 0, s, p, tps);
+		return hipGetLastError();
+	}
+	if (p.fz) return hipErrorInvalidValue; // (the analysis in the waves exists in the wave form only)
 	// spans per workgroup: as many as leave the chip four rounds of workgroups (every flush is a whole number of 512-sample windows = 4 spans)
 	K1uParams q = p;
 	const int spans = p.L / K1U_M;
@@ -5147,9 +5179,6 @@ hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
 #ifndef K1K_M
 #define K1K_M 128 // 48 kHz outputs per channel per workgroup of the decimate-by-3 front end
 #endif
-#ifndef K1K_WAVE
-#define K1K_WAVE 1
-#endif
 bool k1k_wave_form(const K1kParams& p, int hook) { return K1K_WAVE && !p.us_idx && p.L % 256 == 0 && hook != 2; }
 hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s, int hook) { // hook (test hook "k1u_spw"): 2 = the workgroup form, 4 / 8 = k1k_wave with spans of that many tiles
 	if (k1k_wave_form(p, hook)) {
@@ -5158,7 +5187,7 @@ hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s, int hook) { /
 		const int tps_min = p.fz ? 2 : 1; // (the analysis in the waves: two tiles are a window)
 		while (tps > tps_min && (long long)((tiles + tps - 1) / tps) * n_rx < 4096) tps >>= 1;
 		if (hook > 2) tps = hook;
-		hipLaunchKernelGGL(k1k_wave, dim3((tiles + tps - 1) / tps, n_rx), dim3(64), 0, s, p, tps);
+		hipLaunchKernelGGL((k1k_wave<true, K1kParams>), dim3((tiles + tps - 1) / tps, n_rx), dim3(64), 0, s, p, tps);
 		return hipGetLastError();
 	}
 	if (p.fz) return hipErrorInvalidValue; // (see launch_k1x)

@@ -789,6 +789,21 @@ def test_decimate_by_3_wave_front_end(hook, rate, dsk, fmt, blk, monkeypatch):
     _run_outputs_vs_oracle(xs, rate, fmt, blk, nb, dsk=dsk)
 
 
+@pytest.mark.parametrize("hook,fmt,blk", [(0, "cf32", 1024 * 16), (4, "cf32", 1024 * 24), (8, "cs16", 1024 * 16), (2, "cf32", 1024 * 16), (4, "cu8", 1024)])
+def test_dual_channel_96k_wave_front_end(hook, fmt, blk, monkeypatch):
+    """96 kSPS dual-channel input, the ladder's last bucket (convert >> ROT >> DS2_a/b >> FCIC5, Model.cpp:332-334): k1k_wave without the
+    filter (round 6, last) -- 512-sample tiles, a lane's eight samples straight out of the swizzled tile.  Span lengths by the hook k1u_spw
+    (0: by batch size; 4 / 8; 2: k1u_resample_frontend<0>, the workgroup form), a one-window block, CF32 in place and CS16 / CU8 through
+    the converted copy; taps path (the 48 kHz channels themselves) and default path (spectral analysis at the end of the waves)."""
+    if hook:
+        monkeypatch.setenv("AISGPU_K1U_SPW", str(hook))
+    rate, nb = 96000, 5
+    conv = {"cu8": synth.to_cu8, "cs16": synth.to_cs16, "cf32": lambda v: v}[fmt]
+    xs = [conv(synth.receiver_stream(blk * nb, sample_rate=rate, receiver_id=660 + r, gap_slots=(1, 2))) for r in range(2)]
+    _run_gpu_vs_oracle(xs, rate, fmt, blk, nb)
+    _run_outputs_vs_oracle(xs, rate, fmt, blk, nb)
+
+
 @pytest.mark.parametrize("rate, fmt, block, nblocks", [(1536000, "cf32", 131072, 8), (1536000, "cu8", 131072 * 3, 3), (768000, "cs16", 65536, 8),
                                                        (2304000, "cf32", 196608, 6), (2400000, "cu8", 204800, 6), (192000, "cs8", 16384 * 2, 6)])
 def test_moving_average_downsampler(rate, fmt, block, nblocks):

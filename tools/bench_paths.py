@@ -118,7 +118,9 @@ if __name__ == "__main__":
     # (the low-rate ladders with as many receivers as make a step of the bench line's size, 1.6 GB of input: 256 receivers are a
     # 0.4 / 0.1 GB step there, which the latency of the kernel chain bounds, not any kernel)
     run("ModelDefault 288k CF32 (decimate-by-3 front end K1k)", R * 4, 288000, 49152 * 4)
+    run("ModelDefault 250k CF32 (resampled into 288k: Upsample in front of DownsampleKFilter)", R * 4, 250000, 49152 * 4)
     run("ModelDefault 2400k CF32 (resampled into 3072k)", R, 2400000, B)
+    run("ModelDefault 96k CF32 (dual channel, the ladder's last bucket)", R * 16, 96000, 1024 * 48)
     run("ModelDefault mode X 96k CF32 (single channel K1x)", R * 16, 96000, 1024 * 48, mode_x=True)
     run("ModelChallenger 1536k CF32 (fused back end, FM branch inside the derotation / FIR kernel)", R, 1536000, B, model=gpu.MODEL_CHALLENGER)
     run("ModelChallenger 1536k CF32, twenty decoders on the device", R, 1536000, B, model=gpu.MODEL_CHALLENGER, gpu_decode=True)
