@@ -1061,6 +1061,7 @@ __global__ __launch_bounds__(64) void k1x_wave(K1uParams p, int tiles_per_span) 
 		}
 	}
 	// a tile is a window of this row: the span's windows in pairs (launch_k1x: spans of an even number of tiles where p.fz is set)
+	static_assert(sizeof(xt) >= 1024 * sizeof(float2), "k1x_wave: the spectral analysis works in 8 KB of the tile buffer");
 	if (p.fz) wave_fft_tail(p, (size_t)rx * p.c48_rows_per_rx, false, tile_first + 1, tile_last - tile_first, reinterpret_cast<float2*>(xt));
 }
 
@@ -1248,6 +1249,7 @@ __global__ __launch_bounds__(64) void k1k_wave(P p, int tiles_per_span) {
 		fcic5(b4, sfb, outb);
 	}
 	// two tiles are a window of each channel: the span's windows, both channels side by side (launch_k1k: spans of an even number of tiles)
+	static_assert(sizeof(xt) >= 1024 * sizeof(float2), "k1k_wave: the spectral analysis works in 8 KB of the tile buffer");
 	if (p.fz) wave_fft_tail(p, (size_t)rx * 2, true, (tile_first + 1) / 2, (tile_last - tile_first) / 2, reinterpret_cast<float2*>(xt));
 }
 
