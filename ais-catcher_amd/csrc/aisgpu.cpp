@@ -191,6 +191,7 @@ struct aisgpu {
 	float* d_magT[NBUF] = {}; // shifted FFT magnitudes (written by the FFT on the front stream, read by the searches on s3)
 	bool fft_in_k1 = false;   // the spectral analysis rides at the end of the front-end waves (k1_fft_tail): fz / ppm come from K1
 	bool front_fft = false;   // ... of this block's front-end waves of k1x_wave / k1k_wave (set per block by aisgpu_run, read by enqueue_downstream_fused)
+	bool front_fft_us = false; // ... the same on a resampled decimate-by-3 ladder: the caller has recorded k1_done[q] on the stream those waves ran on
 	uint32_t* d_bits[4] = {}; // ring of 4 (block f & 3), like lvl: the frame decoder of block f-2 may still be reading while PhaseSearch of block f writes
 	bool challenger = false;
 	bool v2 = false; float2* h_c48 = nullptr; // ModelEngineV2: front end only, the 48 kHz channels go to the host (MAXSUB slots)
@@ -714,7 +715,7 @@ int enqueue_downstream_fused(aisgpu_t* h, int q, int pb) {
 	const long long g0 = h->n48 / 5, g1 = (h->n48 + h->L) / 5; // groups completed inside this block (DSP/DSP.h:95-117)
 	const int n_groups = (int)(g1 - g0), n_rel0 = (int)(g0 * 5 - h->n48);
 	k2.ck = h->d_ck[q]; k2.ck_stride = k2.rotT_stride;
-	if (h->us_fft_in_k1) {
+	if (h->us_fft_in_k1 || h->front_fft_us) {
 		// (resampled ladder: the caller has recorded k1_done[q] on the stream its front-end waves ran on)
 	} else if (h->fft_in_k1 || h->front_fft) {
 		// the front-end waves have done the whole analysis (k1_fft_tail; k1x_wave / k1k_wave: wave_fft_tail): fz / ppm of this block are there when K1 is
@@ -2117,7 +2118,11 @@ int aisgpu_run(aisgpu_t* h) {
 				kk.rot = h->d_usrot[slot]; kk.c48 = h->d_c48[q]; kk.c48_stride = h->c48s; kk.L = h->L;
 				kk.us_idx = h->d_usidx[slot]; kk.us_alpha = h->d_usalpha[slot];
 				memcpy(kk.taps, TAPS_BH_28_3, sizeof kk.taps);
-				HIPCHK(launch_k1k(kk, R, st));
+				// (round 6, last: the one-wave front end with Upsample in its lanes, and the spectral analysis at the end of its waves)
+				h->front_fft_us = h->fused && k1k_wave_form(kk, h->k1u_spw) && FRONT_FFT_IN_WAVES;
+				if (h->front_fft_us) { kk.omega = h->d_omega; kk.ppm_table = h->d_ppmtab; kk.fz = h->d_fz[q]; kk.ppm = h->d_ppm[q]; kk.n_windows = h->W; kk.wide = h->cfg.afc_wide ? 1 : 0; }
+				HIPCHK(launch_k1k(kk, R, st, h->k1u_spw));
+				if (h->front_fft_us) { HIPCHK(hipEventRecord(h->ev_search[q], st)); h->k1_done[q] = h->ev_search[q]; } // fz / ppm of the flush are there when these waves are
 			} else {
 				K1uParams ku;
 				ku.xin = xcur; ku.xin_stride = xstride; ku.xin_off = h->xh;

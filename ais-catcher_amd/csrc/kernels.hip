@@ -1144,12 +1144,21 @@ __device__ __forceinline__ int k1kw_slot(int pf) { return (pf & ~15) | ((pf & 15
 // FIR = false (P = K1uParams; round 6, last): the same waves for dual-channel 96 kSPS input, the ladder's last bucket (convert >> ROT >> DS2_a/b >>
 // FCIC5, Model.cpp:332-334; k1u_resample_frontend<0> before: 4.96 ms per step of 4,096 receivers x 49,152 samples) -- a tile is 512 samples,
 // a lane's eight 96 kHz samples come straight out of the tile (pieces swizzled by (row / 4) % 4: a lane's 64 bytes start every 64 bytes).
-template <bool FIR, class P>
+// US = true (FIR only; round 6, last): Upsample (DSP.cpp:192-212) in front of the filter -- the rates resampled into a decimate-by-3 bucket
+// (250 kSPS -> 288k, ...).  A tile's 1,536 samples are not fetched but formed: the input samples they interpolate between are one
+// contiguous span of the pre-decimated stream (us_idx is non-decreasing, the ratio at most 1), which goes into a second LDS buffer by
+// global_load_lds (every 16-byte piece from the block of the ring of three it lies in); lane l then forms the samples 64 j + l of the tile
+// from its table entries (coalesced) and the span (products and sum rounded separately, as k1k_dsk_frontend forms them) and puts them
+// where the DMA would have.  Simple form: span, tables and arithmetic of a tile one after the other (the other wave of the SIMD overlaps).
+template <bool FIR, class P, bool US = false>
 __global__ __launch_bounds__(64) void k1k_wave(P p, int tiles_per_span) {
+	static_assert(!US || FIR, "k1k_wave: Upsample sits in front of the filter");
 	constexpr int TS = FIR ? 1536 : 512;  // input samples per tile (512 at 96 kHz)
 	constexpr int NE = TS / 128;          // load instructions per tile (128 samples each)
 	constexpr int LB = FIR ? 16 : 0;      // pieces of look-back in front of the tile
 	__shared__ __attribute__((aligned(16))) float4 xt[LB + TS / 2 < 512 ? 512 : LB + TS / 2]; // (at least the 8 KB the spectral analysis at the end of the span works in)
+	constexpr int XSP = US ? TS / 2 + 64 : 1; // pieces of the input span of a tile (at most TS + 2 samples, from an even sample on, in whole load instructions)
+	__shared__ __attribute__((aligned(16))) float4 xs[XSP];
 	const int lane = threadIdx.x, rx = blockIdx.y, span = blockIdx.x;
 	const int tiles = p.L / 256;
 	const int tile_first = span * tiles_per_span - 1; // warm-up tile
@@ -1163,8 +1172,62 @@ __global__ __launch_bounds__(64) void k1k_wave(P p, int tiles_per_span) {
 	// DMA: slot LB + 64 e + lane <- the piece g of the tile that belongs there (the swizzle term does not depend on e)
 	const int dma_g = FIR ? (lane & ~15) + ((lane & 15) ^ ((1 + (lane >> 4)) & 3)) : (lane & ~3) + ((lane & 3) ^ ((lane >> 4) & 3));
 	float4 rot_next[4];
+	// US: the input span of a tile's samples [first, TS) (first = TS - 128 for the warm-up tile) requested into xs -- a tile ahead, during
+	// the previous tile's filter, which works from registers; returns the span's first sample
+	const auto span_issue = [&](int tile) -> int {
+		int base = 0;
+		if constexpr (US) {
+			const int first = tile == tile_first ? TS - 128 : 0;
+			const int n0 = tile * TS + first, n1 = tile * TS + TS - 1; // outputs of the flush; in front of the tables' look-back: zeros (nothing kept depends on them)
+			const int na = n0 < -US_HIST ? -US_HIST : n0;
+			const int lo = __builtin_amdgcn_readfirstlane(p.us_idx[US_HIST + na]) - 1, hi = __builtin_amdgcn_readfirstlane(p.us_idx[US_HIST + n1]);
+			base = lo & ~1;
+			const int npieces = ((hi - base) >> 1) + 1; // <= TS / 2 + 2
+#pragma unroll 1
+			for (int e = 0; e * 64 < npieces; e++) {
+				const int pi = e * 64 + lane;
+				const int i = base + 2 * (pi < npieces ? pi : npieces - 1); // (the last piece again: a load instruction writes all 64 slots)
+				const float2* src = (i >= 0 || !xr.prev) ? xr.cur + i : (i >= -xr.n ? xr.prev + (xr.n + i) : xr.prev2 + (2 * xr.n + i));
+				__builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(xs + e * 64), 16, 0, 0);
+			}
+		}
+		return base;
+	};
+	// ... and the tile formed from it in LDS, where the DMA of the unresampled ladders would have put it
+	int span_base = 0;
+	const auto form_tile = [&](int tile) {
+		if constexpr (US) {
+			const int first = tile == tile_first ? TS - 128 : 0;
+			const int base = span_base;
+			int ib[TS / 64]; float al[TS / 64];
+#pragma unroll
+			for (int j = 0; j < TS / 64; j++) {
+				const int n = tile * TS + 64 * j + lane;
+				const bool on = 64 * j >= first && n >= -US_HIST; // (64 j >= first: wave-uniform)
+				ib[j] = on ? p.us_idx[US_HIST + n] : base + 1;
+				al[j] = on ? p.us_alpha[US_HIST + n] : 0.0f;
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // (s_waitcnt vmcnt(0): the span has landed)
+			wave_sync();
+			const float2* xss = reinterpret_cast<const float2*>(xs);
+			float2* xtw = reinterpret_cast<float2*>(xt);
+#pragma unroll
+			for (int j = 0; j < TS / 64; j++) {
+				if (64 * j < first) continue; // (wave-uniform)
+				const int nl = 64 * j + lane, n = tile * TS + nl;
+				const float2 a = xss[ib[j] - 1 - base], b = xss[ib[j] - base];
+				const float w0 = 1 - al[j]; // DSP.cpp:199, products rounded separately
+				float2 v = make_float2(w0 * a.x + al[j] * b.x, w0 * a.y + al[j] * b.y);
+				if (n < -US_HIST) v = make_float2(0.0f, 0.0f);
+				xtw[2 * k1kw_slot((nl + 32) >> 1) + (nl & 1)] = v;
+			}
+			wave_sync();
+		}
+	};
 	const auto prefetch = [&](int tile) {
-		if (tile == tile_first) { // (wave-uniform) only the tile's last 128 samples = its last load instruction
+		if constexpr (US) {
+			span_base = span_issue(tile);
+		} else if (tile == tile_first) { // (wave-uniform) only the tile's last 128 samples = its last load instruction
 			static_assert(DSK_HIST == 128, "k1k_wave: the look-back in front of a block is the warm-up tile's last load instruction");
 			const float2* b128 = tile >= 0 ? xr.cur + (size_t)tile * TS + (TS - 128) : (xr.prev ? xr.prev + (xr.n - 128) : xr.cur - 128);
 			__builtin_amdgcn_global_load_lds((const void*)(reinterpret_cast<const uint4*>(b128) + dma_g), (__attribute__((address_space(3))) void*)(xt + LB + (NE - 1) * 64), 16, 0, K1_LOAD_AUX);
@@ -1182,6 +1245,7 @@ __global__ __launch_bounds__(64) void k1k_wave(P p, int tiles_per_span) {
 	};
 	prefetch(tile_first);
 	for (int tile = tile_first; tile <= tile_last; tile++) {
+		form_tile(tile);
 		c2 w[FIR ? 48 : 8];
 		if constexpr (FIR) { // the lane's window: samples 24 l - 26 .. 24 l + 21 of the tile = pieces 12 l + 3 .. 12 l + 26 (look-back included)
 #pragma unroll
@@ -5181,7 +5245,10 @@ hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
 #ifndef K1K_M
 #define K1K_M 128 // 48 kHz outputs per channel per workgroup of the decimate-by-3 front end
 #endif
-bool k1k_wave_form(const K1kParams& p, int hook) { return K1K_WAVE && !p.us_idx && p.L % 256 == 0 && hook != 2; }
+#ifndef K1K_WAVE_US
+#define K1K_WAVE_US 1
+#endif
+bool k1k_wave_form(const K1kParams& p, int hook) { return K1K_WAVE && (!p.us_idx || K1K_WAVE_US) && p.L % 256 == 0 && hook != 2; }
 hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s, int hook) { // hook (test hook "k1u_spw"): 2 = the workgroup form, 4 / 8 = k1k_wave with spans of that many tiles
 	if (k1k_wave_form(p, hook)) {
 		const int tiles = p.L / 256;
@@ -5189,7 +5256,8 @@ hipError_t launch_k1k(const K1kParams& p, int n_rx, hipStream_t s, int hook) { /
 		const int tps_min = p.fz ? 2 : 1; // (the analysis in the waves: two tiles are a window)
 		while (tps > tps_min && (long long)((tiles + tps - 1) / tps) * n_rx < 4096) tps >>= 1;
 		if (hook > 2) tps = hook;
-		hipLaunchKernelGGL((k1k_wave<true, K1kParams>), dim3((tiles + tps - 1) / tps, n_rx), dim3(64), 0, s, p, tps);
+		if (p.us_idx) hipLaunchKernelGGL((k1k_wave<true, K1kParams, true>), dim3((tiles + tps - 1) / tps, n_rx), dim3(64), 0, s, p, tps); // Upsample in the lanes
+		else hipLaunchKernelGGL((k1k_wave<true, K1kParams>), dim3((tiles + tps - 1) / tps, n_rx), dim3(64), 0, s, p, tps);
 		return hipGetLastError();
 	}
 	if (p.fz) return hipErrorInvalidValue; // (see launch_k1x)

@@ -857,6 +857,21 @@ def test_rates_resampled_into_a_decimate_by_3_bucket(rate, dsk, k, fmt):
     _run_multi_sub(x, rate, block, 5, fmt=fmt, dsk=dsk)
 
 
+@pytest.mark.parametrize("hook,rate,dsk,k,fmt", [(4, 250000, False, 0, "cf32"), (8, 240000, False, 0, "cu8"), (2, 250000, False, 0, "cf32"), (4, 1000000, True, 2, "cf32")])
+def test_resampled_decimate_by_3_wave_front_end(hook, rate, dsk, k, fmt, monkeypatch):
+    """Round 6, last: with Upsample in front of DownsampleKFilter the one-wave front end forms its tiles itself (k1k_wave<true, ., true>): the
+    input span of a tile by global_load_lds out of the ring of three input blocks, the interpolation in the lanes from the host's (index,
+    alpha) tables.  Span lengths by the hook k1u_spw (4 / 8; 2: k1k_dsk_frontend, the workgroup form), flushes that begin in the previous
+    input block, CU8 through the converted ring; taps path (48 kHz channels) and default path (spectral analysis at the end of the waves)."""
+    monkeypatch.setenv("AISGPU_K1U_SPW", str(hook))
+    block = (24576 << k) * 2
+    x = synth.receiver_stream(block * 5, sample_rate=rate, receiver_id=57, gap_slots=(1, 2))
+    if fmt == "cu8":
+        x = synth.to_cu8(x)
+    _run_multi_sub(x, rate, block, 5, fmt=fmt, dsk=dsk)
+    _run_outputs_vs_oracle([x], rate, fmt, block, 5, dsk=dsk)
+
+
 def test_resampled_decimate_by_3_ladder_message_order():
     """250 kSPS end to end through the host model: Rotate still works on the filter's 8192-sample blocks, so the channels
     alternate every 4096 samples at 48 kHz inside a downstream block."""
