@@ -21,7 +21,7 @@ BUDGET = [
     ("kv2_engine_rolesE", 256, 0),       # three waves per channel, as it compiles (two waves per SIMD)
     ("kv2_engine_roles_dense", 168, 128), # the same under 168 registers (three waves per SIMD; measured with its 112 bytes of scratch)
     ("kv2_engineE", 256, 0),           # (kv2_engine: one wave per channel; kv2_engine_roles: three)
-    ("k1x_wave", 128, 0),              # one-wave front ends of round 6 (mode X at 96 kSPS / the decimate-by-3 tail / dual-channel 96 kSPS): four resp. two waves per SIMD, no scratch
+    ("k1x_wave", 168, 0),              # one-wave front ends of round 6 (mode X at 96 kSPS / the decimate-by-3 tail / dual-channel 96 kSPS): four resp. two waves per SIMD, no scratch
     ("k1k_wave", 256, 0),
     ("kv2_estimate", 128, 0),
 ]

@@ -984,8 +984,16 @@ __global__ __launch_bounds__(K1U_T) void k1x_single_channel(K1uParams p) {
 // nothing put out depends on more than the 19 input samples in front of it (FCIC5 5 + FDC 2 at 48 kHz, CIC5 5 at 96 kHz), so only
 // the last 128 samples of that tile are fetched (one load instruction; in front of the block: the library's look-back of DSK_HIST samples).  Same sums in the same pairs as
 // k1x_single_channel (cic5_dec_chunk; the shared pyramid of FilterCIC5 forms exactly the pair sums of the six-sample one): same bits.
+// NPOST = 0 / 2 (round 6, last): the same waves at 48 kSPS (no CIC5 stage: a tile is 512 samples, a lane's eight samples are its 48 kHz
+// samples) and at 192 kSPS (two stages, DS2_2 >> DS2_1: a tile is 2,048 samples, 32 per lane); the pieces of a lane's row are swizzled
+// by (row / 4) % 4, row % 8 and row % 16 (4, 8, 16 pieces per row: a row starts every 64, 128, 256 bytes).
+template <int NPOST>
 __global__ __launch_bounds__(64) void k1x_wave(K1uParams p, int tiles_per_span) {
-	__shared__ __attribute__((aligned(16))) float4 xt[512]; // the tile, XOR-swizzled in units of 16 B as in k1_dpp (global_load_lds)
+	constexpr int C0 = 8 << NPOST;       // input samples per lane and tile
+	constexpr int TS = 64 * C0;          // input samples per tile (512 at 48 kHz: one window of the row)
+	constexpr int W4 = C0 / 2;           // 16-byte pieces per lane row
+	constexpr int NE = TS / 128;         // load instructions per tile (128 samples each)
+	__shared__ __attribute__((aligned(16))) float4 xt[TS / 2 < 512 ? 512 : TS / 2]; // the tile, XOR-swizzled in units of 16 B (global_load_lds); at least the 8 KB of the analysis
 	const int lane = threadIdx.x, rx = blockIdx.y, span = blockIdx.x;
 	const int tiles = p.L / 512;
 	const int tile_first = span * tiles_per_span - 1; // warm-up tile
@@ -993,35 +1001,50 @@ __global__ __launch_bounds__(64) void k1x_wave(K1uParams p, int tiles_per_span) 
 	if (tile_last >= tiles) tile_last = tiles - 1;
 	const XRow xr = make_xrow(p, rx);
 	float2* out = p.c48 + ((size_t)rx * p.c48_rows_per_rx) * p.c48_stride;
+	HaloState<32, c2> s32 = {};
 	HaloState<16, c2> s16 = {};
 	HaloState<8, c2> sf = {};
 	c2 th0 = { 0.f, 0.f }, th1 = { 0.f, 0.f };
-	// slot 64 e + lane of the tile buffer <- piece dma_q of row 8 e + lane / 8 (k1_dpp's DMA path with W4 = 8: conflict-free 128-bit reads)
-	const int dma_off = (lane / 8) * 8 + ((lane % 8) ^ ((lane / 8) % 8));
+	// physical slot of piece q of row r: r W4 + (q ^ swz(r)), swz(r) = (r / 4) % 4 (W4 = 4), r % W4 (W4 = 8, 16): the lanes a 128-bit read serves
+	// together hit different bank groups.  The DMA writes slot 64 e + lane, so that lane fetches the piece that belongs there.
+	const auto swz = [](int r) { return W4 == 4 ? (r >> 2) & 3 : r & (W4 - 1); };
+	const auto dma_piece = [&](int e) { // global piece (16 B) of the tile for slot 64 e + lane
+		const int sl = 64 * e + lane, r = sl / W4, qs = sl % W4;
+		return r * W4 + (qs ^ swz(r));
+	};
 	const auto prefetch = [&](int tile) {
 		if (tile == tile_first) { // (wave-uniform) the last 128 samples of the warm-up tile = one load instruction; in front of the block: the look-back
 			static_assert(DSK_HIST == 128, "k1x_wave: the look-back in front of a block is the warm-up tile's last load instruction");
-			const float2* b128 = tile >= 0 ? xr.cur + (size_t)tile * 1024 + 896 : (xr.prev ? xr.prev + (xr.n - 128) : xr.cur - 128);
-			__builtin_amdgcn_global_load_lds((const void*)(reinterpret_cast<const uint4*>(b128) + dma_off), (__attribute__((address_space(3))) void*)(xt + 7 * 64), 16, 0, K1_LOAD_AUX);
+			const float2* b128 = tile >= 0 ? xr.cur + (size_t)tile * TS + (TS - 128) : (xr.prev ? xr.prev + (xr.n - 128) : xr.cur - 128);
+			__builtin_amdgcn_global_load_lds((const void*)(reinterpret_cast<const uint4*>(b128) + (dma_piece(NE - 1) - 64 * (NE - 1))),
+			                                 (__attribute__((address_space(3))) void*)(xt + (NE - 1) * 64), 16, 0, K1_LOAD_AUX);
 		} else {
-			const uint4* src = reinterpret_cast<const uint4*>(xr.cur + (size_t)tile * 1024) + dma_off;
+			const uint4* src = reinterpret_cast<const uint4*>(xr.cur + (size_t)tile * TS);
 #pragma unroll
-			for (int e = 0; e < 8; e++)
-				__builtin_amdgcn_global_load_lds((const void*)(src + e * 64), (__attribute__((address_space(3))) void*)(xt + e * 64), 16, 0, K1_LOAD_AUX);
+			for (int e = 0; e < NE; e++)
+				__builtin_amdgcn_global_load_lds((const void*)(src + dma_piece(e)), (__attribute__((address_space(3))) void*)(xt + e * 64), 16, 0, K1_LOAD_AUX);
 		}
 	};
 	prefetch(tile_first);
 	for (int tile = tile_first; tile <= tile_last; tile++) {
-		c2 x[16];
+		c2 x[C0];
 #pragma unroll
-		for (int e = 0; e < 8; e++) { // every component is used, so these stay 128-bit loads
-			const float4 v = xt[lane * 8 + (e ^ (lane % 8))];
+		for (int e = 0; e < W4; e++) { // every component is used, so these stay 128-bit loads
+			const float4 v = xt[lane * W4 + (e ^ swz(lane))];
 			x[2 * e] = c2{ v.x, v.y }; x[2 * e + 1] = c2{ v.z, v.w };
 		}
 		wave_sync(); // the tile is in registers: the next one may land in xt
 		if (tile < tile_last) prefetch(tile + 1);
 		c2 t8[8];
-		reg_stage<16>(x, s16, t8); // DS2_1: Downsample2CIC5 (DSP.cpp:93-117)
+		if constexpr (NPOST == 2) { // DS2_2 >> DS2_1: Downsample2CIC5 twice (DSP.cpp:93-117)
+			c2 y16[16];
+			reg_stage<32>(x, s32, y16);
+			reg_stage<16>(y16, s16, t8);
+		} else if constexpr (NPOST == 1) reg_stage<16>(x, s16, t8); // DS2_1
+		else {
+#pragma unroll
+			for (int j = 0; j < 8; j++) t8[j] = x[j];
+		}
 		c2 f8[8];
 		if (p.has_fdc) { // FDC (DSP.cpp:283-293): alpha * (h1 + x) + h2 * beta
 			const c2 tm2 = from_prev_lane(t8[6], th0), tm1 = from_prev_lane(t8[7], th1);
@@ -5221,7 +5244,7 @@ hipError_t launch_k1u(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
 #ifndef K1X_WAVE
 #define K1X_WAVE 1
 #endif
-bool k1x_wave_form(const K1uParams& p, int npost) { return K1X_WAVE && npost == 1 && !p.us_idx && p.L % 512 == 0 && p.spw_force != 2; }
+bool k1x_wave_form(const K1uParams& p, int npost) { return K1X_WAVE && npost >= 0 && npost <= 2 && !p.us_idx && p.L % 512 == 0 && p.spw_force != 2; }
 hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
 	if (k1x_wave_form(p, npost)) { // the register / DPP form (test hook "k1u_spw" = 2: the workgroup form)
 		const int tiles = p.L / 512;
@@ -5230,7 +5253,10 @@ hipError_t launch_k1x(const K1uParams& p, int npost, int n_rx, hipStream_t s) {
 		while (tps > tps_min && (long long)((tiles + tps - 1) / tps) * n_rx < 4096) tps >>= 1;
 		if (p.spw_force > 2) tps = p.spw_force;
 		if (p.fz && (tiles % 2 != 0)) return hipErrorInvalidValue; // (the caller sets fz only where a block is an even number of windows)
-		hipLaunchKernelGGL(k1x_wave, dim3((tiles + tps - 1) / tps, n_rx), dim3(64), 0, s, p, tps);
+		const dim3 gw((tiles + tps - 1) / tps, n_rx);
+		if (npost == 2) hipLaunchKernelGGL(k1x_wave<2>, gw, dim3(64), 0, s, p, tps);
+		else if (npost == 1) hipLaunchKernelGGL(k1x_wave<1>, gw, dim3(64), 0, s, p, tps);
+		else hipLaunchKernelGGL(k1x_wave<0>, gw, dim3(64), 0, s, p, tps);
 		return hipGetLastError();
 	}
 	if (p.fz) return hipErrorInvalidValue; // (the analysis in the waves exists in the wave form only: the caller asks k1x_wave_form first)

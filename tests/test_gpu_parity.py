@@ -517,9 +517,11 @@ def test_channel_mode_x_receivers_packed(rate, block, nblocks, R, gpu_decode):
             hms[r].close()
 
 
-@pytest.mark.parametrize("hook,block,fmt,R", [(0, 1024 * 48, "cf32", 3), (4, 1024 * 48, "cf32", 3), (8, 1024 * 44, "cf32", 2), (2, 1024 * 48, "cf32", 2),
-                                             (0, 1024 * 24, "cu8", 2), (8, 1024 * 24, "cs16", 3), (4, 1024 * 1, "cf32", 2)])
-def test_channel_mode_x_96k_wave_front_end(hook, block, fmt, R, monkeypatch):
+@pytest.mark.parametrize("hook,block,fmt,R,rate", [(0, 1024 * 48, "cf32", 3, 96000), (4, 1024 * 48, "cf32", 3, 96000), (8, 1024 * 44, "cf32", 2, 96000), (2, 1024 * 48, "cf32", 2, 96000),
+                                                  (0, 1024 * 24, "cu8", 2, 96000), (8, 1024 * 24, "cs16", 3, 96000), (4, 1024 * 1, "cf32", 2, 96000),
+                                                  (4, 512 * 48, "cf32", 3, 48000), (0, 512 * 40, "cs16", 2, 48000), (2, 512 * 48, "cf32", 2, 48000),
+                                                  (8, 2048 * 24, "cf32", 2, 192000), (0, 2048 * 16, "cu8", 3, 192000), (4, 2048 * 2, "cf32", 2, 192000)])
+def test_channel_mode_x_wave_front_end(hook, block, fmt, R, rate, monkeypatch):
     """Round 6, late: at 96 kSPS the mode-X front end is k1x_wave -- one wave per span of 1,024-sample tiles, Downsample2CIC5 / droop /
     FilterCIC5 in registers with DPP halos, a warm-up tile of which only the last 128 samples are read (in front of a block: the library's
     look-back).  Small batches get one-tile spans; the test hook k1u_spw forces spans of 4 / 8 tiles (tile-to-tile shadow registers,
@@ -529,7 +531,7 @@ def test_channel_mode_x_96k_wave_front_end(hook, block, fmt, R, monkeypatch):
     windows in pairs) instead of k2_fft_search_win behind the front end: ppm of every window."""
     if hook:
         monkeypatch.setenv("AISGPU_K1U_SPW", str(hook))
-    rate, nblocks = 96000, 5
+    nblocks = 5  # (rate 48000 / 192000 -- round 6, last: the same waves without a CIC5 stage / with two)
     per = 1 if fmt == "cf32" else 2
     conv = {"cu8": synth.to_cu8, "cs16": synth.to_cs16, "cf32": lambda v: v}[fmt]
     xs = [conv(synth.receiver_stream(block * nblocks, sample_rate=rate, receiver_id=610 + r, gap_slots=(1, 2), single_channel=True)) for r in range(R)]

@@ -122,6 +122,8 @@ if __name__ == "__main__":
     run("ModelDefault 2400k CF32 (resampled into 3072k)", R, 2400000, B)
     run("ModelDefault 96k CF32 (dual channel, the ladder's last bucket)", R * 16, 96000, 1024 * 48)
     run("ModelDefault mode X 96k CF32 (single channel K1x)", R * 16, 96000, 1024 * 48, mode_x=True)
+    run("ModelDefault mode X 48k CF32", R * 32, 48000, 512 * 48, mode_x=True)
+    run("ModelDefault mode X 192k CF32", R * 8, 192000, 2048 * 48, mode_x=True)
     run("ModelChallenger 1536k CF32 (fused back end, FM branch inside the derotation / FIR kernel)", R, 1536000, B, model=gpu.MODEL_CHALLENGER)
     run("ModelChallenger 1536k CF32, twenty decoders on the device", R, 1536000, B, model=gpu.MODEL_CHALLENGER, gpu_decode=True)
     run("ModelChallenger 6 MSPS CF32 (BASELINE configs[2])", R, 6000000, B, model=gpu.MODEL_CHALLENGER)
