@@ -5,6 +5,6 @@ N=$1; ONLY=$2; shift 2
 for i in $(seq $N); do
   for SPEC in "$@"; do
     E=""; [ "$SPEC" != "-" ] && E=$(echo "$SPEC" | tr ',' ' ')
-    env $E BENCH_PATHS_ONLY="$ONLY" timeout 300 python tools/bench_paths.py 2>/dev/null | grep "MS/s" | sed "s/^/[$SPEC] /" | cut -c1-190
+    env $E BENCH_PATHS_ONLY="$ONLY" timeout 300 python tools/bench_paths.py 2>/dev/null | grep "MS/s" | sed "s#^#[$SPEC] #" | cut -c1-190
   done
 done
