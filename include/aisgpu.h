@@ -243,7 +243,7 @@ void aisgpu_timing(aisgpu_t* h, int enable);
  *                   exact, 0.24 GB less traffic per step, measured 5 % slower) instead of k6_window_fir + k4_phase_chunks
  *   "k1u_spw"       2 / 4 / 8: the resampler front end (k1u_resample_frontend) walks that many consecutive spans per workgroup whatever the
  *                   batch size (by default only batches of ~200 receivers and more get walks longer than one span).  On the ladders whose
- *                   front end is a one-wave kernel since round 6 (the decimate-by-3 tail k1k_wave, channel mode X at 96 kSPS k1x_wave):
+ *                   front end is a one-wave kernel since round 6 (the decimate-by-3 tail k1k_wave -- also behind Upsample and, without the filter, for dual-channel 96 kSPS --, channel mode X at 48 / 96 / 192 kSPS k1x_wave):
  *                   4 / 8 = spans of that many tiles whatever the batch size, 2 = the workgroup form of rounds 2-5 + the FFT / search kernel
  *   "us_k1"         0: the tail of the resampled ladders (buckets from 384k up) as k1u_resample_frontend + the FFT / search kernel, the form
  *                   of rounds 3-5, instead of one-wave workgroups of the front-end kernel (k1_dpp<2, 5, false>, round 6)
